@@ -1,0 +1,262 @@
+"""Capture golden vectors from the REFERENCE's own code (run by hand; needs /root/reference).
+
+    NUM_MELS=40 python tests/golden/make_golden.py
+
+Imports castorini/howl from /root/reference under the shims in ``_reference_shims.py`` and records
+inputs + outputs of the hot path as small ``.npz`` fixtures next to this file.  The fixtures are data
+(inputs and expected outputs); no reference source travels.  ``tests/test_oracle_golden.py`` pins
+``oracle/`` against them; the ``-m gpu`` tests pin the HIP path against them as well.
+
+Inputs: the six 16 kHz GSC clips the reference's tests hold
+(``test/test_data/datasets/google-speech-commands/{cat,dog}/*.wav``, decoded int16/32768 like
+soundfile does) plus closed-form synthetic clips.  Model weights are closed-form (no RNG, nothing to
+commit): ``oracle.models.res8_init`` / ``lstm_init``.
+"""
+import os
+import random
+import sys
+import wave
+from pathlib import Path
+
+import numpy as np
+import torch
+
+os.environ.setdefault("NUM_MELS", "40")
+HERE = Path(__file__).resolve().parent
+sys.path.insert(0, str(HERE))
+sys.path.insert(0, str(HERE.parent.parent))
+import _reference_shims  # noqa: E402
+
+_reference_shims.install()
+
+from howl.context import InferenceContext  # noqa: E402
+from howl.data.transform.operator import ZmuvTransform  # noqa: E402
+from howl.data.transform.transform import (SpecAugmentTransform, StandardAudioTransform,  # noqa: E402
+                                           create_vtlp_fb_matrix)
+from howl.model import RegisteredModel  # noqa: E402
+from howl.model.inference import FrameInferenceEngine, InferenceEngine  # noqa: E402
+from howl.settings import SETTINGS  # noqa: E402
+from howl.utils.audio_utils import stride  # noqa: E402
+
+from oracle import models as om  # noqa: E402  (closed-form weights only)
+
+torch.manual_seed(0)
+GSC = Path(_reference_shims.REFERENCE) / "test/test_data/datasets/google-speech-commands"
+WAVS = ["cat/0ab3b47d_nohash_0.wav", "cat/0ab3b47d_nohash_1.wav", "cat/0ac15fe9_nohash_0.wav",
+        "dog/0a7c2a8d_nohash_0.wav", "dog/0ab3b47d_nohash_0.wav", "dog/0ac15fe9_nohash_0.wav"]
+
+
+def read_wav(path):
+    with wave.open(str(path), "rb") as w:
+        assert w.getframerate() == 16000 and w.getnchannels() == 1 and w.getsampwidth() == 2
+        return np.frombuffer(w.readframes(w.getnframes()), dtype="<i2").astype(np.float32) / 32768.0
+
+
+def batchify_like_reference(clips):
+    """operator.py:77-86: sort by length descending, zero-pad right to the longest."""
+    clips = sorted(clips, key=lambda c: -len(c))
+    lengths = torch.tensor([len(c) for c in clips])
+    audio = torch.zeros(len(clips), max(len(c) for c in clips))
+    for i, c in enumerate(clips):
+        audio[i, : len(c)] = torch.from_numpy(c)
+    return audio, lengths
+
+
+def synthetic_clips(L):
+    n = np.arange(L, dtype=np.float64)
+    out = []
+    lcg = 12345
+    noise = np.empty(L)
+    for i in range(L):
+        lcg = (1103515245 * lcg + 12345) % (1 << 31)
+        noise[i] = lcg / float(1 << 30) - 1.0
+    out.append((0.3 * np.sin(2 * np.pi * 440.0 * n / 16000 + 0.5) + 0.05 * noise).astype(np.float32))
+    out.append(np.zeros(L, np.float32))
+    out.append(np.where((n // 40) % 2 == 0, 1.0, -1.0).astype(np.float32))
+    imp0 = np.zeros(L, np.float32); imp0[0] = 1.0
+    impl = np.zeros(L, np.float32); impl[L - 1] = 1.0
+    out += [imp0, impl]
+    return np.stack(out)
+
+
+def save(name, **arrays):
+    arrays = {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in arrays.items()}
+    np.savez_compressed(HERE / f"{name}.npz", **arrays)
+    print(f"{name}.npz: " + ", ".join(f"{k}{list(v.shape)}" for k, v in arrays.items()))
+
+
+def main():
+    clips = [read_wav(GSC / w) for w in WAVS]
+    audio, lengths = batchify_like_reference(clips)
+    std = StandardAudioTransform().eval()
+
+    # ---- G1: filterbanks -------------------------------------------------------------------------
+    alphas = [0.9, 0.95, 1.0, 1.05, 1.0999]
+    fbs = {"fb_standard": create_vtlp_fb_matrix(257, 0.0, 8000.0, 40, 16000, 1.0, training=False)}
+    for a in alphas:
+        fbs[f"fb_vtlp_{a}"] = create_vtlp_fb_matrix(257, 0.0, 8000.0, 40, 16000, a, training=True)
+    save("g1_filterbanks", alphas=np.array(alphas), **fbs)
+
+    # ---- G2/G3: frontend ---------------------------------------------------------------------------
+    feats = std(audio)
+    mels = std(audio, mels_only=True)
+    lens_in = torch.tensor([512, 711, 712, 8000, 12971, 16000])
+    std.train()
+    random.seed(11)
+    assert random.random() < 0.75
+    alpha = random.random() * 0.2 + 0.9
+    random.seed(11)
+    feats_vtlp = std(audio)
+    std.eval()
+    save("g2_frontend_gsc", audio=audio, lengths=lengths, feats=feats, mels=mels,
+         lens_in=lens_in, lens_out=std.compute_lengths(lens_in), vtlp_alpha=alpha, mels_vtlp=feats_vtlp[:, 0])
+    syn = {}
+    for L in (8000, 16000, 13527):
+        x = torch.from_numpy(synthetic_clips(L))
+        syn[f"audio_{L}"] = x
+        syn[f"mels_{L}"] = std(x, mels_only=True)
+    save("g2_frontend_synth", **syn)
+
+    # ---- G4: ZMUV ----------------------------------------------------------------------------------
+    zmuv = ZmuvTransform()
+    for c in clips:
+        zmuv.update(std(torch.from_numpy(c)[None]))
+    normed = zmuv(feats)
+    save("g4_zmuv", total=zmuv.total, mean=zmuv.mean, mean2=zmuv.mean2, std=zmuv.std, normed_ch0=normed[:, 0])
+
+    # ---- G5: res8 ----------------------------------------------------------------------------------
+    x = normed
+    for C in (4, 12, 30):
+        model = RegisteredModel.find_registered_class("res8")(C)
+        model.load_state_dict(om.res8_init(C))
+        model.eval()
+        with torch.no_grad():
+            eval_logits = model(x, None)
+        labels = torch.arange(x.size(0)) % C
+        out = dict(labels=labels, eval_logits=eval_logits)
+        model.train()
+        params = list(model.parameters())
+        opt = torch.optim.AdamW(params, 0.01, weight_decay=1e-5)
+        crit = torch.nn.CrossEntropyLoss()
+        for step in range(3):
+            scores = model(x, None)
+            opt.zero_grad(); model.zero_grad()
+            loss = crit(scores, labels)
+            loss.backward()
+            if step == 0:
+                out["train_logits"] = scores.detach().clone()
+                out["loss0"] = loss.detach().clone()
+                for n, p in model.named_parameters():
+                    out["grad0." + n] = p.grad.detach().clone()
+                for i in (1, 6):
+                    out[f"bn{i}.running_mean.1"] = getattr(model, f"bn{i}").running_mean.clone()
+                    out[f"bn{i}.running_var.1"] = getattr(model, f"bn{i}").running_var.clone()
+            opt.step()
+            out[f"loss{step}"] = loss.detach().clone()
+        for n, t in model.state_dict().items():
+            out["sd3." + n] = t.clone()
+        model.eval()
+        with torch.no_grad():
+            out["eval_logits_after3"] = model(x, None)
+        save(f"g5_res8_c{C}", **out)
+
+    # 0.5 s geometry (T=41) eval + one train step, C=4 (BASELINE config 2 shape)
+    x05 = zmuv(std(audio[:, 2000:10000]))
+    model = RegisteredModel.find_registered_class("res8")(4)
+    model.load_state_dict(om.res8_init(4))
+    model.eval()
+    with torch.no_grad():
+        ev = model(x05, None)
+    model.train()
+    sc = model(x05, None)
+    loss = torch.nn.functional.cross_entropy(sc, torch.arange(6) % 4)
+    loss.backward()
+    save("g5_res8_c4_half", audio=audio[:, 2000:10000], eval_logits=ev, train_logits=sc, loss0=loss,
+         **{"grad0.conv0.weight": model.conv0.weight.grad, "grad0.conv1.weight": model.conv1.weight.grad,
+            "grad0.conv6.weight": model.conv6.weight.grad, "grad0.output.weight": model.output.weight.grad})
+
+    # ---- G6: lstm / seq-lstm -------------------------------------------------------------------------
+    flen = std.compute_lengths(lengths)
+    for name in ("lstm", "seq-lstm"):
+        model = RegisteredModel.find_registered_class(name)(5)
+        model.load_state_dict(om.lstm_init(5))
+        model.eval()
+        with torch.no_grad():
+            logits = model(x, flen)
+        out = dict(frame_lengths=flen, logits=logits)
+        model.train()
+        sc = model(x, flen)
+        if name == "lstm":
+            loss = torch.nn.functional.cross_entropy(sc, torch.arange(6) % 5)
+        else:
+            lp = torch.nn.functional.log_softmax(sc, -1)
+            targets = torch.tensor([[0, 1, 2]] * 6)
+            loss = torch.nn.CTCLoss(4)(lp, targets, flen, torch.tensor([3] * 6))
+        loss.backward()
+        out["loss0"] = loss.detach()
+        for n, p in model.named_parameters():
+            out["grad0." + n] = p.grad.detach().clone()
+        # streaming carry over two consecutive calls (rnn.py:62,67-68)
+        model.eval().streaming()
+        with torch.no_grad():
+            a = model(x[:1, :, :, :40], None) if name == "seq-lstm" else model(x[:1, :, :, :40], torch.tensor([40]))
+            b = model(x[:1, :, :, 40:], None) if name == "seq-lstm" else model(x[:1, :, :, 40:], torch.tensor([41]))
+        out["stream_a"], out["stream_b"] = a, b
+        save("g6_" + name.replace("-", "_"), **out)
+
+    # ---- G7: SpecAugment with recorded draws -------------------------------------------------------
+    class Recorder(random.Random):
+        def __init__(self, seed):
+            super().__init__(seed)
+            self.log = []
+
+        def randrange(self, *a):
+            v = super().randrange(*a)
+            self.log.append(v)
+            return v
+
+    sa = SpecAugmentTransform().train()
+    rec = Recorder(5)
+    sa.rand = rec
+    xin = x.clone()
+    # force both augments (prob gates draw from the same RNG via .random())
+    for p in sa.augment_params:
+        p.prob = 1.1
+    for p in sa.augment_params:
+        p.current_value_idx = 2
+    sa.augment_params[1].domain = [10, 50, 60, 125, 150]  # T=81 > t so the mask is not skipped
+    xout = sa(xin)
+    B = x.size(0)
+    save("g7_specaug", x=x, out=xout, f=np.array(rec.log[0:2 * B:2]), f0=np.array(rec.log[1:2 * B:2]),
+         t=np.array(rec.log[2 * B::2]), t0=np.array(rec.log[2 * B + 1::2]))
+
+    # ---- G8: engines -------------------------------------------------------------------------------
+    SETTINGS.inference_engine.inference_sequence = [0, 1, 2]
+    ctx = InferenceContext(["hey", "fire", "fox"], token_type="word")
+    model = RegisteredModel.find_registered_class("res8")(ctx.num_labels)
+    model.load_state_dict(om.res8_init(ctx.num_labels))
+    model.eval().streaming()
+    engine = FrameInferenceEngine(500, 63, model, zmuv, ctx)
+    clip = torch.from_numpy(np.concatenate(clips[:3]))
+    present = engine.infer(clip)
+    hist = np.array(engine.label_history, dtype=np.float64)
+    probs = np.stack([p for _, p in engine.pred_history]) if engine.pred_history else np.zeros((0, 4))
+    n_windows = sum(1 for _ in stride(clip, 500, 63, 16000))
+    save("g8_frame_engine", clip=clip, present=np.array(present), label_history=hist, last_probs=probs,
+         n_windows=np.array(n_windows), num_labels=np.array(ctx.num_labels),
+         negative_label=np.array(ctx.negative_label), blank_label=np.array(ctx.blank_label))
+
+    ctx_b = InferenceContext(["hey", "fire", "fox"], token_type="word", use_blank=True)
+    smodel = RegisteredModel.find_registered_class("seq-lstm")(ctx_b.num_labels)
+    smodel.load_state_dict(om.lstm_init(ctx_b.num_labels))
+    smodel.eval().streaming()
+    SETTINGS.inference_engine.smoothing_window_ms = 0
+    eng = InferenceEngine(smodel, zmuv, ctx_b)
+    present = eng.infer(torch.from_numpy(clips[0]))
+    save("g8_seq_engine", clip=clips[0], present=np.array(present),
+         label_history=np.array(eng.label_history, dtype=np.float64), num_labels=np.array(ctx_b.num_labels),
+         blank_label=np.array(ctx_b.blank_label))
+
+
+if __name__ == "__main__":
+    main()
