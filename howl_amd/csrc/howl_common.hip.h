@@ -1,0 +1,50 @@
+// Shared device/host helpers for the gfx950 kernels behind include/howl_hip.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define HOWL_OK 0
+#define HOWL_E_ARG (-1)       // bad argument (shape / null pointer / unsupported size)
+#define HOWL_E_LAUNCH (-2)    // hipGetLastError() after a launch reported a failure
+#define HOWL_E_WORKSPACE (-3) // caller-provided workspace too small
+
+void howl_set_error(const char* fmt, ...);
+int howl_num_cus();
+
+#define HOWL_REQUIRE(cond, ...)                 \
+    do {                                        \
+        if (!(cond)) {                          \
+            howl_set_error(__VA_ARGS__);        \
+            return HOWL_E_ARG;                  \
+        }                                       \
+    } while (0)
+
+#define HOWL_CHECK_LAUNCH(name)                                                     \
+    do {                                                                            \
+        hipError_t e_ = hipGetLastError();                                          \
+        if (e_ != hipSuccess) {                                                     \
+            howl_set_error("%s: launch failed: %s", name, hipGetErrorString(e_));   \
+            return HOWL_E_LAUNCH;                                                   \
+        }                                                                           \
+    } while (0)
+
+// Lanes of ONE wavefront exchange data through LDS without a workgroup barrier: a wave's DS operations
+// are issued in order, so a wave-scope release/acquire pair (which lowers to s_waitcnt lgkmcnt(0) only)
+// plus the compiler-level wave barrier is sufficient on gfx950.
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    return v;
+}

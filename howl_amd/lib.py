@@ -1,0 +1,69 @@
+"""ctypes binding of the C ABI declared in ``include/howl_hip.h``.
+
+``SIGNATURES`` is the single table of entry points (name -> argtypes); ``tests/test_cabi.py`` checks it against the
+header and against the symbols the built library exports.  ``get()`` loads the in-tree ``libhowl_hip.so`` and fails
+loudly when it is absent -- there is no fallback path.
+"""
+import ctypes
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_long, c_size_t, c_void_p
+from pathlib import Path
+
+LIB_PATH = Path(__file__).resolve().parent / "libhowl_hip.so"
+MAX_MELS = 48
+FB_COLS = 48
+FB_PACKED_FLOATS = 260 * FB_COLS
+
+P = c_void_p  # device pointer
+STREAM = c_void_p
+
+
+class HowlMelPoints(ctypes.Structure):
+    _fields_ = [("f", c_float * (MAX_MELS + 2))]
+
+
+SIGNATURES = {
+    "howl_version": [POINTER(c_int), POINTER(c_int)],
+    "howl_fb_pack": [P, c_int, P, STREAM],
+    "howl_fb_from_points": [POINTER(HowlMelPoints), c_int, c_float, P, STREAM],
+    "howl_logmel_fwd": [P, c_int, c_int, c_long, P, c_int, c_float, P, P, c_int, STREAM],
+    "howl_deltas_fwd": [P, c_int, c_int, c_int, P, P, STREAM],
+    "howl_zmuv_update": [P, c_size_t, P, P, P, P, STREAM],
+    "howl_zmuv_pair": [P, P, P, STREAM],
+    "howl_specaug_mask": [P, c_int, c_int, c_int, c_int, P, P, P, P, STREAM],
+}
+
+
+class HowlHipError(RuntimeError):
+    pass
+
+
+class Library:
+    def __init__(self, path):
+        path = Path(path)
+        if not path.exists():
+            raise HowlHipError(
+                f"{path} not found: the HIP extension is not built. Run `python __graft_entry__.py` "
+                "(build()) first; howl_amd has no CPU fallback.")
+        self.path = path
+        self.cdll = ctypes.CDLL(str(path))
+        self.cdll.howl_last_error.restype = c_char_p
+        self.cdll.howl_last_error.argtypes = []
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(self.cdll, name)  # AttributeError if the library lacks a declared symbol
+            fn.restype = c_int
+            fn.argtypes = argtypes
+
+    def call(self, name, *args):
+        rc = getattr(self.cdll, name)(*args)
+        if rc != 0:
+            raise HowlHipError(f"{name} failed ({rc}): {self.cdll.howl_last_error().decode()}")
+
+
+_LIB = None
+
+
+def get() -> Library:
+    global _LIB
+    if _LIB is None:
+        _LIB = Library(LIB_PATH)
+    return _LIB

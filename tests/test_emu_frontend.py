@@ -1,0 +1,114 @@
+"""Frontend kernels run UNMODIFIED on the hipemu CPU emulator (tiny shapes) against the oracle and the goldens.
+Catches indexing / layout / sync mistakes before a GPU run; the GPU parity tests are in test_gpu_*.py."""
+import numpy as np
+import pytest
+import torch
+
+from emu_util import emu_lib, ptr
+from howl_amd.lib import FB_PACKED_FLOATS, HowlMelPoints
+from oracle import frontend as fe
+
+
+@pytest.fixture(scope="module")
+def lib():
+    return emu_lib()
+
+
+def pack_fb(lib, fb):
+    fbp = np.zeros(FB_PACKED_FLOATS, np.float32)
+    fb = np.ascontiguousarray(fb, np.float32)
+    lib.call("howl_fb_pack", ptr(fb), fb.shape[1], ptr(fbp), None)
+    return fbp
+
+
+def logmel(lib, audio, fbp, M=40, zmuv=None, layout=0):
+    B, L = audio.shape
+    T = 1 + L // 200
+    out = np.full((B, M, T) if layout == 0 else (B, T, M), np.nan, np.float32)
+    lib.call("howl_logmel_fwd", ptr(audio), B, L, L, ptr(fbp), M, 1e-7, ptr(zmuv), ptr(out), layout, None)
+    return out
+
+
+def test_fb_pack_and_points(lib):
+    fb = fe.mel_fb(40).numpy()
+    fbp = pack_fb(lib, fb).reshape(260, 48)
+    assert np.array_equal(fbp[:257, :40], fb) and not fbp[257:].any() and not fbp[:, 40:].any()
+    # corner points -> triangles on the "device", standard and VTLP-warped (alpha > 1 quirk included)
+    import math
+    for alpha in (None, 0.93, 1.0999):
+        m_pts = torch.linspace(0.0, 2595.0 * math.log10(1.0 + 8000.0 / 700.0), 42)
+        f_pts = 700.0 * (10 ** (m_pts / 2595.0) - 1.0)
+        if alpha is not None:
+            thr = 4800 * min(alpha, 1) / alpha
+            f_pts[f_pts <= thr] *= alpha
+            f = f_pts[f_pts > thr]
+            f_pts[f_pts > thr] = 8000 - ((8000 - 4800 * min(alpha, 1)) / (8000 - thr)) * (8000 - f)
+        pts = HowlMelPoints()
+        for i, v in enumerate(f_pts.tolist()):
+            pts.f[i] = v
+        out = np.zeros(FB_PACKED_FLOATS, np.float32)
+        lib.call("howl_fb_from_points", pts, 40, 8000.0, ptr(out), None)
+        ref = fe.mel_fb(40, alpha=alpha).numpy()
+        np.testing.assert_allclose(out.reshape(260, 48)[:257, :40], ref, rtol=0, atol=2e-7)
+
+
+def test_logmel_matches_oracle_and_golden(lib, golden):
+    g = golden("g2_frontend_synth")
+    fbp = pack_fb(lib, fe.mel_fb(40).numpy())
+    for L in (8000, 13527):
+        audio = np.ascontiguousarray(g[f"audio_{L}"][[0, 2, 4]])  # tone+noise, square wave, impulse at L-1
+        out = logmel(lib, audio, fbp)
+        ref = g[f"mels_{L}"][[0, 2, 4]]
+        # log of a power spectrum: compare where mel power is not at the eps floor, abs elsewhere
+        np.testing.assert_allclose(out, ref, rtol=0, atol=2e-3)
+        strong = ref > -8
+        assert np.abs(out - ref)[strong].max() < 2e-4
+        out_t = logmel(lib, audio, fbp, layout=1)
+        assert np.array_equal(out_t, out.transpose(0, 2, 1))
+
+
+def test_logmel_zmuv_and_ragged_tail(lib):
+    rng = np.random.default_rng(0)
+    audio = (0.1 * rng.standard_normal((3, 1000))).astype(np.float32)   # T = 6 -> 18 frames, chunk of 16 + 2
+    fbp = pack_fb(lib, fe.mel_fb(40).numpy())
+    zm = np.array([-3.0, 2.5], np.float32)
+    out = logmel(lib, audio, fbp, zmuv=zm)
+    ref = (fe.standard_audio_transform(torch.from_numpy(audio), fe.mel_fb(40), mels_only=True).numpy() + 3.0) / 2.5
+    np.testing.assert_allclose(out, ref, rtol=0, atol=1e-4)
+
+
+def test_deltas(lib):
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal((2, 40, 9)).astype(np.float32)
+    out = np.zeros((2, 3, 40, 9), np.float32)
+    lib.call("howl_deltas_fwd", ptr(x), 2, 40, 9, None, ptr(out), None)
+    ref = fe.standard_audio_transform(torch.from_numpy(x), None, deltas_only=True).numpy()
+    np.testing.assert_allclose(out, ref, rtol=0, atol=1e-6)
+    x1 = rng.standard_normal((1, 40, 3)).astype(np.float32)   # T < win_length: replicate padding dominates
+    out1 = np.zeros((1, 3, 40, 3), np.float32)
+    lib.call("howl_deltas_fwd", ptr(x1), 1, 40, 3, None, ptr(out1), None)
+    np.testing.assert_allclose(out1, fe.standard_audio_transform(torch.from_numpy(x1), None, deltas_only=True).numpy(),
+                               rtol=0, atol=1e-6)
+
+
+def test_zmuv_update_and_specaug(lib, golden):
+    rng = np.random.default_rng(2)
+    total, mean, mean2 = (np.zeros(1, np.float32) for _ in range(3))
+    scratch = np.zeros(2, np.float64)
+    z = fe.Zmuv()
+    for n in (1000, 77, 5000):
+        x = rng.standard_normal(n).astype(np.float32) * 3 - 7
+        lib.call("howl_zmuv_update", ptr(x), n, ptr(total), ptr(mean), ptr(mean2), ptr(scratch), None)
+        z.update(torch.from_numpy(x))
+    assert total[0] == z.total.item()
+    np.testing.assert_allclose(mean, z.mean.numpy(), rtol=1e-6)
+    np.testing.assert_allclose(mean2, z.mean2.numpy(), rtol=1e-6)
+    pair = np.zeros(2, np.float32)
+    lib.call("howl_zmuv_pair", ptr(mean), ptr(mean2), ptr(pair), None)
+    np.testing.assert_allclose(pair, [z.mean.item(), z.std.item()], rtol=1e-5)
+
+    g = golden("g7_specaug")
+    x = np.ascontiguousarray(g["x"])
+    f0, f, t0, t = (np.ascontiguousarray(g[k], np.int32) for k in ("f0", "f", "t0", "t"))  # keep alive
+    lib.call("howl_specaug_mask", ptr(x), 6, 3, 40, 81, ptr(f0), ptr(f), ptr(t0), ptr(t), None)
+    assert np.array_equal(x, g["out"])
