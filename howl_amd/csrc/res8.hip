@@ -1,0 +1,936 @@
+// res8 classifier forward + backward for gfx950 (MI355X).
+//
+// Replaces the ATen op chain of howl/model/cnn.py:113-145 (Res8: conv0 -> ReLU -> AvgPool(3,4) ->
+// 6 x [conv3x3 45->45, ReLU, (+residual on even i), BatchNorm2d(affine=False)] -> mean -> Linear) and its
+// autograd backward (convolution_backward, threshold_backward, native_batch_norm_backward,
+// avg_pool2d_backward), as driven by training/run/pretrain_gsc.py:126-133 and training/run/train.py:288-302.
+//
+// Layouts (HBM, fp32): activations s_i are (B, 45, H, 10) exactly like the reference's NCHW tensors
+// (H = T/3, P = H*10 positions); weights keep the reference's (45,45,3,3) / (45,1,3,3) / (C,45) shapes so
+// state_dicts are interchangeable (howl/workspace.py:31-67).
+//
+// conv3x3 45->45 (12 of the 13 GFLOP-heavy launches per step: 6 forward, 6 dgrad) is an implicit GEMM on
+// v_mfma_f32_16x16x4_f32 (exact fp32 FMA chains, 157 TFLOP/s peak):
+//     D[position 16][cout 16] += A[position][k] * B[k][cout],   k = (cin block of 4, tap)
+//   * one workgroup = 12 wavefronts = 3 cout tiles x 4 position groups; each wave keeps its 108 weight
+//     fragments (48 padded cin x 9 taps / 4 per MFMA) in VGPRs for the whole launch -- weights never touch LDS;
+//   * one utterance's whole (48, H+1, 12) zero-haloed input map lives in LDS (64.7 KB at H=27), double
+//     buffered; the next utterance is prefetched into registers while the current one is multiplied, and the
+//     previous layer's BatchNorm is applied on the way into LDS ((s - mean) * rstd), so normalised activations
+//     are never materialised in HBM;
+//   * epilogue fuses ReLU, the residual add, the store, and the per-channel sum / sum-of-squares that the next
+//     BatchNorm needs (per-workgroup partials, reduced deterministically by a tiny finalize kernel).
+// wgrad is the transposed GEMM (M = cout, N = tap x cin, K = positions) with the 45x405 accumulators resident
+// in registers across all utterances of a workgroup, written once as per-workgroup partials.
+#include "howl_common.hip.h"
+#include "../../include/howl_hip.h"
+
+namespace {
+
+struct HowlPtrs6 {
+    float* p[6];
+};
+
+constexpr int NMAP = 45;         // res8 feature maps (cnn.py:110)
+constexpr int CP = 48;           // channels padded to 3 MFMA tiles
+constexpr int PW = 10;           // pooled width = 40 mels / 4
+constexpr int WP = 12;           // LDS row pitch: 10 + left/right halo
+constexpr int CONV_THREADS = 768;
+constexpr int KSTEPS = 108;      // 12 cin blocks x 9 taps
+constexpr int PREF = 8;          // float2 prefetch slots per thread: 768*8*2 >= 45*270
+constexpr int MAX_H = 27;
+constexpr float BN_EPS = 1e-5f;
+constexpr float BN_MOMENTUM = 0.1f;
+
+__host__ __device__ inline int chan_stride(int H) {
+    // (H+1) rows of 12 (top halo + data; the bottom halo is the next channel's top halo), padded so that
+    // CS = 17 (mod 32): position-major reads (forward/dgrad) and channel-major reads (wgrad) both spread over banks
+    int cs = (H + 1) * WP;
+    int pad = (17 - (cs % 32) + 32) % 32;
+    return cs + pad;
+}
+__host__ __device__ inline int tile_floats(int H) { return CP * chan_stride(H) + 32; }
+
+// ---------------------------------------------------------------------------------------------------------
+// weight packing: (45,45,3,3) -> per-wave MFMA B fragments  wp[nt][kstep][lane]
+//   forward : B[k][n] = w[cout = 16nt + n][cin = 4*c0 + k][tap]
+//   dgrad   : B[k][n] = w[cout = 4*c0 + k][cin = 16nt + n][8 - tap]   (transposed, spatially flipped)
+// ---------------------------------------------------------------------------------------------------------
+__global__ void pack_weights_kernel(HowlPtrs6 w, float* __restrict__ wp_fwd, float* __restrict__ wp_bwd) {
+    const int layer = blockIdx.y;
+    const int mode = blockIdx.z;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= 3 * KSTEPS * 64) return;
+    const int lane = idx & 63;
+    const int ks = (idx >> 6) % KSTEPS;
+    const int nt = idx / (64 * KSTEPS);
+    const int c0 = ks / 9, tap = ks - 9 * c0;
+    const int kk = 4 * c0 + (lane >> 4);
+    const int n = 16 * nt + (lane & 15);
+    float v = 0.0f;
+    if (kk < NMAP && n < NMAP) {
+        const float* wl = w.p[layer];
+        v = (mode == 0) ? wl[(n * NMAP + kk) * 9 + tap] : wl[(kk * NMAP + n) * 9 + (8 - tap)];
+    }
+    float* dst = (mode == 0 ? wp_fwd : wp_bwd) + (size_t)layer * (3 * KSTEPS * 64);
+    dst[idx] = v;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// shared pieces of the MFMA kernels
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void zero_lds(float* p, int n, int tid, int nthreads) {
+    for (int i = tid; i < n; i += nthreads) p[i] = 0.0f;
+}
+
+// Per-thread staging slots: slot j moves the float2 at element pair e2 = tid + j*768 of an utterance's
+// (45, P) map to its place in the zero-haloed LDS tile.  The destination (and channel, for the BatchNorm
+// parameters) depends only on the thread, so it is packed once: bits 0..19 LDS float offset, 20..25 channel.
+__device__ __forceinline__ void stage_slots(int (&pk)[PREF], int P, int CS, int n2, int tid) {
+#pragma unroll
+    for (int j = 0; j < PREF; ++j) {
+        const int e2 = tid + j * CONV_THREADS;
+        const int e = 2 * e2;
+        const int c = e / P;
+        const int p = e - c * P;
+        const int h = p / PW;
+        const int w = p - h * PW;
+        pk[j] = (e2 < n2) ? ((c * CS + (h + 1) * WP + (w + 1)) | (c << 20)) : -1;
+    }
+}
+
+// registers -> LDS tile, applying x = (v - mean[c]) * rstd[c] (identity when !affine)
+__device__ __forceinline__ void stage_tile(const float2 (&pre)[PREF], const int (&pk)[PREF], float* tile,
+                                           const float* lmean, const float* lrstd, bool affine) {
+#pragma unroll
+    for (int j = 0; j < PREF; ++j) {
+        if (pk[j] >= 0) {
+            const int c = pk[j] >> 20;
+            float v0 = pre[j].x, v1 = pre[j].y;
+            if (affine) {
+                const float m = lmean[c], r = lrstd[c];
+                v0 = (v0 - m) * r;
+                v1 = (v1 - m) * r;
+            }
+            float* d = tile + (pk[j] & 0xFFFFF);
+            d[0] = v0;
+            d[1] = v1;
+        }
+    }
+}
+
+__device__ __forceinline__ void prefetch_tile(float2 (&pre)[PREF], const float* src, int n2, int tid) {
+#pragma unroll
+    for (int j = 0; j < PREF; ++j) {
+        const int e2 = tid + j * CONV_THREADS;
+        pre[j] = (e2 < n2) ? reinterpret_cast<const float2*>(src)[e2] : make_float2(0.0f, 0.0f);
+    }
+}
+
+// MODE 0: forward   out = relu(conv(x)) [+ res]; stats = (sum, sumsq) of out per cout
+// MODE 1: dgrad     out = conv(x);               stats = (sum out, sum out * xhat) per cout, xhat from s_prev
+template <int MODE>
+__global__ __launch_bounds__(CONV_THREADS) void conv3x3_mfma_kernel(
+    const float* __restrict__ in,         // (B,45,P) input activations (s_{i-1}) or dz_i
+    const float* __restrict__ in_stats,   // {mean[48], rstd[48]} applied on load, or nullptr
+    const float* __restrict__ wp,         // packed weights [3][108][64]
+    const float* __restrict__ res,        // fwd: residual (B,45,P) or nullptr
+    float* __restrict__ y_out,            // fwd: relu output before the residual add (B,45,P) or nullptr
+    float* __restrict__ out,              // (B,45,P)
+    const float* __restrict__ xs,         // dgrad: s_{i-1} for xhat, or nullptr (no stats)
+    const float* __restrict__ xs_stats,   // dgrad: {mean, rstd} of layer i-1
+    float* __restrict__ part,             // [gridDim.x][2][48] partial statistics, or nullptr
+    int B, int H) {
+    HIP_DYNAMIC_SHARED(float, lds)
+    const int P = H * PW;
+    const int CS = chan_stride(H);
+    const int TF = tile_floats(H);
+    float* tile0 = lds;
+    float* tile1 = lds + TF;
+    float* lmean = lds + 2 * TF;
+    float* lrstd = lmean + CP;
+    float* red = lrstd + CP;  // [12][2][16]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int nt = wave % 3;
+    const int mg = wave / 3;
+    const int n2 = NMAP * P / 2;
+    const int ntiles = (P + 15) / 16;
+    const bool affine = in_stats != nullptr;
+
+    float wreg[KSTEPS];
+    {
+        const float* wsrc = wp + (size_t)nt * KSTEPS * 64 + lane;
+#pragma unroll
+        for (int k = 0; k < KSTEPS; ++k) wreg[k] = wsrc[k * 64];
+    }
+    zero_lds(lds, 2 * TF, tid, CONV_THREADS);
+    if (tid < CP) {
+        lmean[tid] = affine ? in_stats[tid] : 0.0f;
+        lrstd[tid] = affine ? in_stats[CP + tid] : 1.0f;
+    }
+    const int cout = 16 * nt + (lane & 15);
+    const bool cvalid = cout < NMAP;
+    float xmean = 0.0f, xrstd = 1.0f;
+    if (MODE == 1 && xs != nullptr && cvalid) {
+        xmean = xs_stats[cout];
+        xrstd = xs_stats[CP + cout];
+    }
+    float st0 = 0.0f, st1 = 0.0f;
+
+    float2 pre[PREF];
+    int pk[PREF];
+    stage_slots(pk, P, CS, n2, tid);
+    int b = blockIdx.x;
+    if (b < B) prefetch_tile(pre, in + (size_t)b * NMAP * P, n2, tid);
+    __syncthreads();  // zero fill + stats visible before the first stage
+
+    int it = 0;
+    for (; b < B; b += gridDim.x, ++it) {
+        float* tile = (it & 1) ? tile1 : tile0;
+        stage_tile(pre, pk, tile, lmean, lrstd, affine);
+        __syncthreads();
+        const int bn = b + gridDim.x;
+        if (bn < B) prefetch_tile(pre, in + (size_t)bn * NMAP * P, n2, tid);
+
+        const size_t ubase = (size_t)b * NMAP * P;
+        for (int j = mg; j < ntiles; j += 4) {
+            int m0 = 16 * j + (lane & 15);
+            m0 = m0 < P ? m0 : P - 1;
+            const int h0 = m0 / PW;
+            const float* a0 = tile + (lane >> 4) * CS + h0 * WP + (m0 - h0 * PW);
+            f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int c0 = 0; c0 < 12; ++c0) {
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    const int off = (tap / 3) * WP + (tap % 3);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[off], wreg[c0 * 9 + tap], acc, 0, 0, 0);
+                }
+                a0 += 4 * CS;
+                __builtin_amdgcn_sched_barrier(0);  // keep the A-fragment loads of one cin block from piling up
+            }
+            // epilogue: lane holds cout = 16nt + (lane&15), positions 16j + 4*(lane>>4) + {0,1,2,3}
+            const int mbase = 16 * j + 4 * (lane >> 4);
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const int m = mbase + 2 * hh;
+                if (cvalid && m < P) {
+                    const size_t o = ubase + (size_t)cout * P + m;
+                    float v0 = acc[2 * hh], v1 = acc[2 * hh + 1];
+                    if (MODE == 0) {
+                        v0 = fmaxf(v0, 0.0f);
+                        v1 = fmaxf(v1, 0.0f);
+                        if (y_out != nullptr) *reinterpret_cast<float2*>(y_out + o) = make_float2(v0, v1);
+                        if (res != nullptr) {
+                            const float2 r = *reinterpret_cast<const float2*>(res + o);
+                            v0 += r.x;
+                            v1 += r.y;
+                        }
+                        st0 += v0 + v1;
+                        st1 += v0 * v0 + v1 * v1;
+                    } else if (xs != nullptr) {
+                        const float2 sv = *reinterpret_cast<const float2*>(xs + o);
+                        st0 += v0 + v1;
+                        st1 += v0 * ((sv.x - xmean) * xrstd) + v1 * ((sv.y - xmean) * xrstd);
+                    }
+                    *reinterpret_cast<float2*>(out + o) = make_float2(v0, v1);
+                }
+            }
+        }
+    }
+
+    if (part != nullptr) {
+        // lanes l, l^16, l^32, l^48 hold the same cout: fold them, then fold the 4 position groups via LDS
+        st0 += __shfl_xor(st0, 16);
+        st0 += __shfl_xor(st0, 32);
+        st1 += __shfl_xor(st1, 16);
+        st1 += __shfl_xor(st1, 32);
+        __syncthreads();
+        if (lane < 16) {
+            red[(wave * 2 + 0) * 16 + lane] = st0;
+            red[(wave * 2 + 1) * 16 + lane] = st1;
+        }
+        __syncthreads();
+        if (tid < 2 * CP) {
+            const int which = tid / CP, c = tid - which * CP;
+            const int t3 = c >> 4, cl = c & 15;
+            float s = 0.0f;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) s += red[((g * 3 + t3) * 2 + which) * 16 + cl];
+            part[((size_t)blockIdx.x * 2 + which) * CP + c] = s;
+        }
+    }
+}
+
+// wgrad: dW[cout][cin][tap] += sum_{b,p} dz[b,cout,p] * x[b,cin,p + tap shift],  x = (s_prev - mean) * rstd
+__global__ __launch_bounds__(CONV_THREADS) void wgrad_mfma_kernel(
+    const float* __restrict__ dz, const float* __restrict__ s_prev, const float* __restrict__ in_stats,
+    float* __restrict__ part /* [gridDim.x][48][432] */, int B, int H) {
+    HIP_DYNAMIC_SHARED(float, lds)
+    const int P = H * PW;
+    const int CS = chan_stride(H);
+    const int TF = tile_floats(H);
+    float* tz = lds;
+    float* tx = lds + TF;
+    float* lmean = lds + 2 * TF;
+    float* lrstd = lmean + CP;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int n2 = NMAP * P / 2;
+    const bool affine = in_stats != nullptr;
+    const int ksteps = (P + 3) / 4;
+
+    zero_lds(lds, 2 * TF, tid, CONV_THREADS);
+    if (tid < CP) {
+        lmean[tid] = affine ? in_stats[tid] : 0.0f;
+        lrstd[tid] = affine ? in_stats[CP + tid] : 1.0f;
+    }
+    // this wave's N tiles (tap, cin tile): q = wave, wave+12, wave+24 (< 27); all 3 cout tiles each
+    f32x4 acc[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int mt = 0; mt < 3; ++mt) acc[i][mt] = {0.0f, 0.0f, 0.0f, 0.0f};
+    int boff[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int q = wave + 12 * i;
+        const int tap = (q < 27) ? q / 3 : 0, ct = (q < 27) ? q % 3 : 0;
+        boff[i] = (16 * ct + (lane & 15)) * CS + (tap / 3) * WP + (tap % 3);  // cin row + tap shift (halo origin)
+    }
+    const bool has3 = wave + 24 < 27;
+    const int aoff = (lane & 15) * CS + WP + 1;  // cout row, interior origin
+
+    float2 pz[PREF], px[PREF];
+    int pk[PREF];
+    stage_slots(pk, P, CS, n2, tid);
+    int b = blockIdx.x;
+    if (b < B) {
+        prefetch_tile(pz, dz + (size_t)b * NMAP * P, n2, tid);
+        prefetch_tile(px, s_prev + (size_t)b * NMAP * P, n2, tid);
+    }
+    __syncthreads();
+    for (; b < B; b += gridDim.x) {
+        stage_tile(pz, pk, tz, lmean, lrstd, false);
+        stage_tile(px, pk, tx, lmean, lrstd, affine);
+        __syncthreads();
+        const int bn = b + gridDim.x;
+        if (bn < B) {
+            prefetch_tile(pz, dz + (size_t)bn * NMAP * P, n2, tid);
+            prefetch_tile(px, s_prev + (size_t)bn * NMAP * P, n2, tid);
+        }
+        // K loop over positions, 4 per MFMA: this lane feeds position p = 4*kk + (lane >> 4)
+        int p = lane >> 4;
+        int h = 0, w = p;  // p < 4 < PW
+        for (int kk = 0; kk < ksteps; ++kk) {
+            const int pos = h * WP + w;  // positions >= P land in the zero bottom halo row
+            const float az0 = tz[aoff + pos];
+            const float az1 = tz[aoff + 16 * CS + pos];
+            const float az2 = tz[aoff + 32 * CS + pos];
+            const float bx0 = tx[boff[0] + pos];
+            const float bx1 = tx[boff[1] + pos];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(az0, bx0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(az1, bx0, acc[0][1], 0, 0, 0);
+            acc[0][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(az2, bx0, acc[0][2], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(az0, bx1, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(az1, bx1, acc[1][1], 0, 0, 0);
+            acc[1][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(az2, bx1, acc[1][2], 0, 0, 0);
+            if (has3) {
+                const float bx2 = tx[boff[2] + pos];
+                acc[2][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(az0, bx2, acc[2][0], 0, 0, 0);
+                acc[2][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(az1, bx2, acc[2][1], 0, 0, 0);
+                acc[2][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(az2, bx2, acc[2][2], 0, 0, 0);
+            }
+            w += 4;
+            if (w >= PW) {
+                w -= PW;
+                h += 1;
+            }
+        }
+        __syncthreads();  // single-buffered tiles: everyone done before the next stage overwrites them
+    }
+    // D[row = cout = 16mt + 4*(lane>>4) + r][col = n = lane&15 -> cin = 16ct + col] for N tile q = (tap, ct)
+    float* dst = part + (size_t)blockIdx.x * CP * 432;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int q = wave + 12 * i;
+        if (q < 27) {
+            const int tap = q / 3, ct = q % 3;
+#pragma unroll
+            for (int mt = 0; mt < 3; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int co = 16 * mt + 4 * (lane >> 4) + r;
+                    dst[co * 432 + tap * CP + 16 * ct + (lane & 15)] = acc[i][mt][r];
+                }
+        }
+    }
+}
+
+// sum the per-workgroup partials (fixed order -> deterministic) into dW (45,45,3,3), scaled
+__global__ void wgrad_reduce_kernel(const float* __restrict__ part, int nparts, float* __restrict__ dw) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= NMAP * NMAP * 9) return;
+    const int tap = idx % 9;
+    const int ci = (idx / 9) % NMAP;
+    const int co = idx / (9 * NMAP);
+    const float* src = part + co * 432 + tap * CP + ci;
+    float s = 0.0f;
+    for (int g = 0; g < nparts; ++g) s += src[(size_t)g * CP * 432];
+    dw[idx] = s;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// BatchNorm statistics
+// ---------------------------------------------------------------------------------------------------------
+// forward, training: partials -> batch mean / rstd (biased var), running-stat update (cnn.py:142 semantics of
+// nn.BatchNorm2d(affine=False): momentum 0.1, unbiased variance into running_var, num_batches_tracked += 1)
+__global__ void bn_finalize_kernel(const float* __restrict__ part, int nparts, double count, float* __restrict__ stats,
+                                   float* running_mean, float* running_var, long long* num_batches) {
+    const int c = threadIdx.x;
+    if (c >= CP) return;
+    double s = 0.0, q = 0.0;
+    for (int g = 0; g < nparts; ++g) {
+        s += (double)part[((size_t)g * 2 + 0) * CP + c];
+        q += (double)part[((size_t)g * 2 + 1) * CP + c];
+    }
+    const double mean = s / count;
+    double var = q / count - mean * mean;
+    var = var < 0.0 ? 0.0 : var;
+    stats[c] = (c < NMAP) ? (float)mean : 0.0f;
+    stats[CP + c] = (c < NMAP) ? (float)(1.0 / sqrt(var + (double)BN_EPS)) : 0.0f;
+    if (c < NMAP && running_mean != nullptr) {
+        const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+        running_mean[c] = (1.0f - BN_MOMENTUM) * running_mean[c] + BN_MOMENTUM * (float)mean;
+        running_var[c] = (1.0f - BN_MOMENTUM) * running_var[c] + BN_MOMENTUM * (float)unbiased;
+    }
+    if (c == 0 && num_batches != nullptr) num_batches[0] += 1;
+}
+
+// eval mode: stats from the running buffers
+__global__ void bn_eval_stats_kernel(HowlPtrs6 rmean, HowlPtrs6 rvar, float* __restrict__ stats) {
+    const int layer = blockIdx.x, c = threadIdx.x;
+    if (c >= CP) return;
+    float* st = stats + (size_t)layer * 2 * CP;
+    st[c] = (c < NMAP) ? rmean.p[layer][c] : 0.0f;
+    st[CP + c] = (c < NMAP) ? 1.0f / sqrtf(rvar.p[layer][c] + BN_EPS) : 0.0f;
+}
+
+// backward: partials of (sum dx, sum dx*xhat) -> means m1, m2
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int nparts, double count, float* __restrict__ m12) {
+    const int c = threadIdx.x;
+    if (c >= CP) return;
+    double s = 0.0, q = 0.0;
+    for (int g = 0; g < nparts; ++g) {
+        s += (double)part[((size_t)g * 2 + 0) * CP + c];
+        q += (double)part[((size_t)g * 2 + 1) * CP + c];
+    }
+    m12[c] = (float)(s / count);
+    m12[CP + c] = (float)(q / count);
+}
+
+// backward elementwise: BatchNorm backward (batch statistics) + skip gradient + ReLU mask
+//   ds = rstd * (dx - m1 - xhat * m2) [+ dskip];  dz = ds * (msrc > 0)
+__global__ __launch_bounds__(256) void bn_relu_bwd_kernel(
+    const float* __restrict__ dx,      // (B,45,P) or nullptr -> broadcast of dpool
+    const float* __restrict__ dpool,   // (B,48) used when dx == nullptr, scaled by 1/P
+    const float* __restrict__ s, const float* __restrict__ stats, const float* __restrict__ m12,
+    const float* __restrict__ dskip,   // nullable
+    const float* __restrict__ msrc,    // ReLU output whose sign gives the mask
+    float* __restrict__ ds_out,        // nullable
+    float* __restrict__ dz_out, int B, int P) {
+    const size_t n2 = (size_t)B * NMAP * P / 2;
+    const float invP = 1.0f / (float)P;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t e = 2 * i;
+        const int bc = (int)(e / P);
+        const int b = bc / NMAP, c = bc - b * NMAP;
+        float2 g;
+        if (dx != nullptr) {
+            g = reinterpret_cast<const float2*>(dx)[i];
+        } else {
+            const float v = dpool[b * CP + c] * invP;
+            g = make_float2(v, v);
+        }
+        const float2 sv = reinterpret_cast<const float2*>(s)[i];
+        const float mean = stats[c], rstd = stats[CP + c], m1 = m12[c], m2 = m12[CP + c];
+        float d0 = rstd * (g.x - m1 - ((sv.x - mean) * rstd) * m2);
+        float d1 = rstd * (g.y - m1 - ((sv.y - mean) * rstd) * m2);
+        if (dskip != nullptr) {
+            const float2 k = reinterpret_cast<const float2*>(dskip)[i];
+            d0 += k.x;
+            d1 += k.y;
+        }
+        if (ds_out != nullptr) reinterpret_cast<float2*>(ds_out)[i] = make_float2(d0, d1);
+        const float2 mv = reinterpret_cast<const float2*>(msrc)[i];
+        reinterpret_cast<float2*>(dz_out)[i] = make_float2(mv.x > 0.0f ? d0 : 0.0f, mv.y > 0.0f ? d1 : 0.0f);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// conv0 (1 -> 45, 3x3, pad 1) + ReLU + AvgPool(3,4), forward and weight gradient.  VALU: 2.6 MFLOP/utterance.
+// One wave owns a group of 5 output channels (9 waves), lanes stride over the pooled positions.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int C0_THREADS = 576;
+constexpr int C0_GROUP = 5;
+
+__device__ __forceinline__ void load_feat_tile(float* tin, const float* feat, long sb, long st, long sm, int b, int T,
+                                               int M, int tid, int nthreads) {
+    // tin[(T+2)][M+2], zero halo
+    const int pitch = M + 2;
+    for (int i = tid; i < (T + 2) * pitch; i += nthreads) {
+        const int t = i / pitch - 1, m = i % pitch - 1;
+        tin[i] = (t >= 0 && t < T && m >= 0 && m < M) ? feat[b * sb + t * st + m * sm] : 0.0f;
+    }
+}
+
+__global__ __launch_bounds__(C0_THREADS) void conv0_fwd_kernel(const float* __restrict__ feat, long sb, long st, long sm,
+                                                               const float* __restrict__ w0, float* __restrict__ s0,
+                                                               int B, int T, int M, int H) {
+    HIP_DYNAMIC_SHARED(float, lds)
+    float* tin = lds;                       // (T+2) x (M+2)
+    float* lw = lds + (T + 2) * (M + 2);    // 405 weights
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int pitch = M + 2;
+    const int P = H * PW;
+    for (int i = tid; i < NMAP * 9; i += C0_THREADS) lw[i] = w0[i];
+    for (int b = blockIdx.x; b < B; b += gridDim.x) {
+        __syncthreads();
+        load_feat_tile(tin, feat, sb, st, sm, b, T, M, tid, C0_THREADS);
+        __syncthreads();
+        for (int p = lane; p < P; p += 64) {
+            const int ph = p / PW, pw = p - ph * PW;
+            float patch[5][6];
+#pragma unroll
+            for (int i = 0; i < 5; ++i)
+#pragma unroll
+                for (int j = 0; j < 6; ++j) patch[i][j] = tin[(3 * ph + i) * pitch + 4 * pw + j];
+#pragma unroll
+            for (int cc = 0; cc < C0_GROUP; ++cc) {
+                const int c = wave * C0_GROUP + cc;
+                float wk[9];
+#pragma unroll
+                for (int k = 0; k < 9; ++k) wk[k] = lw[c * 9 + k];
+                float sum = 0.0f;
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float z = 0.0f;
+#pragma unroll
+                        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                            for (int kw = 0; kw < 3; ++kw) z = fmaf(patch[i + kh][j + kw], wk[kh * 3 + kw], z);
+                        sum += fmaxf(z, 0.0f);
+                    }
+                s0[((size_t)b * NMAP + c) * P + p] = sum * (1.0f / 12.0f);
+            }
+        }
+    }
+}
+
+// dW0[c][tap] = sum_{b, pooled pos, 3x4 window} (dy0/12) * [z > 0] * in[...],  dy0 = ga + gb (dx0 from layer 1 + skip)
+__global__ __launch_bounds__(C0_THREADS) void conv0_wgrad_kernel(const float* __restrict__ feat, long sb, long st, long sm,
+                                                                 const float* __restrict__ w0, const float* __restrict__ ga,
+                                                                 const float* __restrict__ gb, float* __restrict__ part,
+                                                                 int B, int T, int M, int H) {
+    HIP_DYNAMIC_SHARED(float, lds)
+    float* tin = lds;
+    float* lw = lds + (T + 2) * (M + 2);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int pitch = M + 2;
+    const int P = H * PW;
+    for (int i = tid; i < NMAP * 9; i += C0_THREADS) lw[i] = w0[i];
+    float gw[C0_GROUP][9];
+#pragma unroll
+    for (int cc = 0; cc < C0_GROUP; ++cc)
+#pragma unroll
+        for (int k = 0; k < 9; ++k) gw[cc][k] = 0.0f;
+    for (int b = blockIdx.x; b < B; b += gridDim.x) {
+        __syncthreads();
+        load_feat_tile(tin, feat, sb, st, sm, b, T, M, tid, C0_THREADS);
+        __syncthreads();
+        for (int p = lane; p < P; p += 64) {
+            const int ph = p / PW, pw = p - ph * PW;
+            float patch[5][6];
+#pragma unroll
+            for (int i = 0; i < 5; ++i)
+#pragma unroll
+                for (int j = 0; j < 6; ++j) patch[i][j] = tin[(3 * ph + i) * pitch + 4 * pw + j];
+#pragma unroll
+            for (int cc = 0; cc < C0_GROUP; ++cc) {
+                const int c = wave * C0_GROUP + cc;
+                const size_t o = ((size_t)b * NMAP + c) * P + p;
+                const float g = (ga[o] + (gb != nullptr ? gb[o] : 0.0f)) * (1.0f / 12.0f);
+                float wk[9];
+#pragma unroll
+                for (int k = 0; k < 9; ++k) wk[k] = lw[c * 9 + k];
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float z = 0.0f;
+#pragma unroll
+                        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                            for (int kw = 0; kw < 3; ++kw) z = fmaf(patch[i + kh][j + kw], wk[kh * 3 + kw], z);
+                        const float gz = z > 0.0f ? g : 0.0f;
+#pragma unroll
+                        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                            for (int kw = 0; kw < 3; ++kw)
+                                gw[cc][kh * 3 + kw] = fmaf(gz, patch[i + kh][j + kw], gw[cc][kh * 3 + kw]);
+                    }
+            }
+        }
+    }
+#pragma unroll
+    for (int cc = 0; cc < C0_GROUP; ++cc)
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const float v = wave_sum(gw[cc][k]);
+            if (lane == 0) part[(size_t)blockIdx.x * NMAP * 9 + (wave * C0_GROUP + cc) * 9 + k] = v;
+        }
+}
+
+__global__ void reduce_parts_kernel(const float* __restrict__ part, int nparts, int n, float* __restrict__ out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    float s = 0.0f;
+    for (int g = 0; g < nparts; ++g) s += part[(size_t)g * n + idx];
+    out[idx] = s;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// head: BN6 -> spatial mean -> Linear(45, C)   (cnn.py:143-145), and its backward
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__ s6, const float* __restrict__ stats,
+                                                       const float* __restrict__ wout, const float* __restrict__ bout,
+                                                       float* __restrict__ pooled, float* __restrict__ logits, int B,
+                                                       int P, int C) {
+    __shared__ float lp[CP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int b = blockIdx.x; b < B; b += gridDim.x) {
+        __syncthreads();
+        for (int c = wave; c < CP; c += 4) {
+            float v = 0.0f;
+            if (c < NMAP) {
+                const float* src = s6 + ((size_t)b * NMAP + c) * P;
+                float acc = 0.0f;
+                for (int p = lane; p < P; p += 64) acc += src[p];
+                acc = wave_sum(acc);
+                v = (acc / (float)P - stats[c]) * stats[CP + c];
+            }
+            if (lane == 0) {
+                lp[c] = v;
+                pooled[(size_t)b * CP + c] = v;
+            }
+        }
+        __syncthreads();
+        for (int k = tid; k < C; k += 256) {
+            float acc = bout[k];
+            for (int c = 0; c < NMAP; ++c) acc = fmaf(wout[k * NMAP + c], lp[c], acc);
+            logits[(size_t)b * C + k] = acc;
+        }
+    }
+}
+
+// dpool[b][c] = sum_k dlogits[b][k] W[k][c]
+__global__ void head_bwd_pool_kernel(const float* __restrict__ dlogits, const float* __restrict__ wout,
+                                     float* __restrict__ dpool, int B, int C) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * CP) return;
+    const int b = idx / CP, c = idx - b * CP;
+    float acc = 0.0f;
+    if (c < NMAP)
+        for (int k = 0; k < C; ++k) acc = fmaf(dlogits[(size_t)b * C + k], wout[k * NMAP + c], acc);
+    dpool[idx] = acc;
+}
+
+// one workgroup per output row k (dW_out[k][:], db[k]); the last row block (k == C) produces the BN6 backward
+// means m1[c] = sum_b dpool / N, m2[c] = sum_b dpool*pooled / N  (dx6 is dpool/P broadcast over positions)
+__global__ __launch_bounds__(64) void head_bwd_param_kernel(const float* __restrict__ dlogits,
+                                                            const float* __restrict__ pooled,
+                                                            const float* __restrict__ dpool, float* __restrict__ dwout,
+                                                            float* __restrict__ dbout, float* __restrict__ m12, int B,
+                                                            int C, int P) {
+    const int k = blockIdx.x, c = threadIdx.x;
+    if (k < C) {
+        float acc = 0.0f, accb = 0.0f;
+        for (int b = 0; b < B; ++b) {
+            const float d = dlogits[(size_t)b * C + k];
+            accb += d;
+            if (c < NMAP) acc = fmaf(d, pooled[(size_t)b * CP + c], acc);
+        }
+        if (c < NMAP) dwout[k * NMAP + c] = acc;
+        if (c == 0) dbout[k] = accb;
+    } else if (c < CP) {
+        double s = 0.0, q = 0.0;
+        for (int b = 0; b < B; ++b) {
+            const double d = (double)dpool[(size_t)b * CP + c];
+            s += d;
+            q += d * (double)pooled[(size_t)b * CP + c];
+        }
+        const double n = (double)B * (double)P;
+        m12[c] = (float)(s / n);
+        m12[CP + c] = (float)(q / n);
+    }
+}
+
+// mean cross-entropy and its gradient (pretrain_gsc.py:95,131; train.py:251,293): one workgroup
+__global__ __launch_bounds__(256) void xent_kernel(const float* __restrict__ logits, const long long* __restrict__ labels,
+                                                   int B, int C, float* __restrict__ loss, float* __restrict__ dlogits) {
+    __shared__ double red[4];
+    double acc = 0.0;
+    const float invB = 1.0f / (float)B;
+    for (int b = threadIdx.x; b < B; b += 256) {
+        const float* row = logits + (size_t)b * C;
+        float mx = row[0];
+        for (int k = 1; k < C; ++k) mx = fmaxf(mx, row[k]);
+        float se = 0.0f;
+        for (int k = 0; k < C; ++k) se += expf(row[k] - mx);
+        const float lse = mx + logf(se);
+        const int y = (int)labels[b];
+        acc += (double)(lse - row[y]);
+        if (dlogits != nullptr)
+            for (int k = 0; k < C; ++k)
+                dlogits[(size_t)b * C + k] = (expf(row[k] - lse) - (k == y ? 1.0f : 0.0f)) * invB;
+    }
+    acc = wave_sum_d(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) loss[0] = (float)((red[0] + red[1] + red[2] + red[3]) / (double)B);
+}
+
+// fused flat AdamW (torch.optim.AdamW defaults; pretrain_gsc.py:93,133)
+__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                             float* __restrict__ v, size_t n, float lr, float b1, float b2, float eps, float wd,
+                             float bc1, float bc2_sqrt, float gscale) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float gi = g[i] * gscale;
+        float pi = p[i] * (1.0f - lr * wd);
+        const float mi = m[i] + (gi - m[i]) * (1.0f - b1);
+        const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        pi -= (lr / bc1) * (mi / denom);
+        p[i] = pi;
+        m[i] = mi;
+        v[i] = vi;
+    }
+}
+
+size_t conv_lds_bytes(int H) { return (size_t)(2 * tile_floats(H) + 2 * CP + 12 * 2 * 16) * sizeof(float); }
+size_t conv0_lds_bytes(int T, int M) { return (size_t)((T + 2) * (M + 2) + NMAP * 9) * sizeof(float); }
+
+struct Ws {
+    float* wp_fwd;   // [6][3][108][64]
+    float* wp_bwd;
+    float* part;     // statistics partials [G][2][48]
+    float* stats;    // eval-mode stats [6][2][48]
+    float* m12;      // [2][48]
+    float* dpool;    // [B][48]
+    float* bufa;     // (B,45,P) x4: dx ping-pong, dz, ds ping-pong
+    float* bufb;
+    float* dz;
+    float* dsa;
+    float* dsb;
+    float* wpart;    // [G][48][432]
+    float* c0part;   // [G][405]
+};
+
+size_t ws_layout(Ws* w, char* base, int B, int H, int G) {
+    size_t off = 0;
+    auto take = [&](size_t floats) {
+        float* p = base ? reinterpret_cast<float*>(base + off) : nullptr;
+        off += ((floats * sizeof(float) + 255) / 256) * 256;
+        return p;
+    };
+    const size_t act = (size_t)B * NMAP * H * PW;
+    Ws t;
+    t.wp_fwd = take((size_t)6 * 3 * KSTEPS * 64);
+    t.wp_bwd = take((size_t)6 * 3 * KSTEPS * 64);
+    t.part = take((size_t)G * 2 * CP);
+    t.stats = take((size_t)6 * 2 * CP);
+    t.m12 = take(2 * CP);
+    t.dpool = take((size_t)B * CP);
+    t.bufa = take(act);
+    t.bufb = take(act);
+    t.dz = take(act);
+    t.dsa = take(act);
+    t.dsb = take(act);
+    t.wpart = take((size_t)G * CP * 432);
+    t.c0part = take((size_t)G * NMAP * 9);
+    if (w) *w = t;
+    return off;
+}
+
+int conv_grid(int B) {
+    int g = howl_num_cus();
+    return B < g ? B : g;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t howl_res8_workspace_bytes(int B, int T) {
+    const int H = T / 3;
+    return ws_layout(nullptr, nullptr, B, H, conv_grid(B));
+}
+
+int howl_res8_fwd(const HowlRes8Params* prm, const float* feat, long sb, long st, long sm, int B, int T, int M, int C,
+                  int training, const HowlRes8Saved* sv, float* logits, void* ws, size_t ws_bytes, hipStream_t stream) {
+    HOWL_REQUIRE(prm && feat && sv && logits && ws, "howl_res8_fwd: null pointer");
+    HOWL_REQUIRE(M == 40, "howl_res8_fwd: res8 pools (3,4) over 40 mel bins; got M=%d", M);
+    const int H = T / 3;
+    HOWL_REQUIRE(B >= 1 && H >= 1 && H <= MAX_H, "howl_res8_fwd: B=%d T=%d unsupported (3 <= T <= 83)", B, T);
+    HOWL_REQUIRE(C >= 1, "howl_res8_fwd: C must be positive");
+    const int G = conv_grid(B);
+    Ws w;
+    const size_t need = ws_layout(&w, static_cast<char*>(ws), B, H, G);
+    if (ws_bytes < need) {
+        howl_set_error("howl_res8_fwd: workspace %zu < %zu bytes", ws_bytes, need);
+        return HOWL_E_WORKSPACE;
+    }
+    const int P = H * PW;
+    HowlPtrs6 cw, rm, rv;
+    for (int i = 0; i < 6; ++i) {
+        cw.p[i] = const_cast<float*>(prm->conv_w[i]);
+        rm.p[i] = prm->bn_running_mean[i];
+        rv.p[i] = prm->bn_running_var[i];
+    }
+    hipLaunchKernelGGL(pack_weights_kernel, dim3((3 * KSTEPS * 64 + 255) / 256, 6, 2), dim3(256), 0, stream, cw, w.wp_fwd,
+                       w.wp_bwd);
+    if (!training) hipLaunchKernelGGL(bn_eval_stats_kernel, dim3(6), dim3(64), 0, stream, rm, rv, sv->bn_stats);
+
+    const size_t l0 = conv0_lds_bytes(T, M);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(conv0_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l0);
+    hipLaunchKernelGGL(conv0_fwd_kernel, dim3(G), dim3(C0_THREADS), l0, stream, feat, sb, st, sm, prm->conv0_w, sv->s[0], B,
+                       T, M, H);
+    const size_t lc = conv_lds_bytes(H);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_mfma_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                        (int)lc);
+    const double count = (double)B * (double)P;
+    for (int i = 1; i <= 6; ++i) {
+        const float* in_stats = (i == 1) ? nullptr : sv->bn_stats + (size_t)(i - 2) * 2 * CP;
+        const bool even = (i % 2) == 0;
+        const float* res = even ? sv->s[i - 2] : nullptr;
+        float* yo = even ? sv->y[i / 2 - 1] : nullptr;
+        hipLaunchKernelGGL(conv3x3_mfma_kernel<0>, dim3(G), dim3(CONV_THREADS), lc, stream, sv->s[i - 1], in_stats,
+                           w.wp_fwd + (size_t)(i - 1) * 3 * KSTEPS * 64, res, yo, sv->s[i], (const float*)nullptr,
+                           (const float*)nullptr, training ? w.part : (float*)nullptr, B, H);
+        if (training)
+            hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(64), 0, stream, w.part, G, count,
+                               sv->bn_stats + (size_t)(i - 1) * 2 * CP, prm->bn_running_mean[i - 1],
+                               prm->bn_running_var[i - 1], prm->bn_num_batches[i - 1]);
+    }
+    hipLaunchKernelGGL(head_fwd_kernel, dim3(B < 1024 ? B : 1024), dim3(256), 0, stream, sv->s[6],
+                       sv->bn_stats + (size_t)5 * 2 * CP, prm->out_w, prm->out_b, sv->pooled, logits, B, P, C);
+    HOWL_CHECK_LAUNCH("howl_res8_fwd");
+    return HOWL_OK;
+}
+
+int howl_res8_bwd(const HowlRes8Params* prm, const float* feat, long sb, long st, long sm, int B, int T, int M, int C,
+                  const HowlRes8Saved* sv, const float* dlogits, const HowlRes8Grads* gr, void* ws, size_t ws_bytes,
+                  hipStream_t stream) {
+    HOWL_REQUIRE(prm && feat && sv && dlogits && gr && ws, "howl_res8_bwd: null pointer");
+    HOWL_REQUIRE(M == 40, "howl_res8_bwd: M must be 40");
+    const int H = T / 3;
+    HOWL_REQUIRE(B >= 1 && H >= 1 && H <= MAX_H, "howl_res8_bwd: B=%d T=%d unsupported", B, T);
+    const int G = conv_grid(B);
+    Ws w;
+    const size_t need = ws_layout(&w, static_cast<char*>(ws), B, H, G);
+    if (ws_bytes < need) {
+        howl_set_error("howl_res8_bwd: workspace %zu < %zu bytes", ws_bytes, need);
+        return HOWL_E_WORKSPACE;
+    }
+    const int P = H * PW;
+    const double count = (double)B * (double)P;
+    const size_t act = (size_t)B * NMAP * P;
+    int eg = (int)((act / 2 + 255) / 256);
+    if (eg > howl_num_cus() * 8) eg = howl_num_cus() * 8;
+
+    hipLaunchKernelGGL(head_bwd_pool_kernel, dim3((B * CP + 255) / 256), dim3(256), 0, stream, dlogits, prm->out_w, w.dpool,
+                       B, C);
+    hipLaunchKernelGGL(head_bwd_param_kernel, dim3(C + 1), dim3(64), 0, stream, dlogits, sv->pooled, w.dpool, gr->out_w,
+                       gr->out_b, w.m12, B, C, P);
+    const size_t lc = conv_lds_bytes(H);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_mfma_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                        (int)lc);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                        (int)lc);
+    float* dx_cur = nullptr;      // gradient w.r.t. the BN output of layer i (nullptr: broadcast of dpool)
+    float* dx_next = w.bufa;
+    float* ds_prev = nullptr;     // ds_{i+2}
+    float* ds_free = w.dsa;
+    for (int i = 6; i >= 1; --i) {
+        const bool even = (i % 2) == 0;
+        const float* stats_i = sv->bn_stats + (size_t)(i - 1) * 2 * CP;
+        const float* msrc = even ? sv->y[i / 2 - 1] : sv->s[i];
+        float* ds_out = even ? ds_free : nullptr;
+        hipLaunchKernelGGL(bn_relu_bwd_kernel, dim3(eg), dim3(256), 0, stream, (const float*)dx_cur, w.dpool, sv->s[i],
+                           stats_i, w.m12, even ? (const float*)ds_prev : (const float*)nullptr, msrc, ds_out, w.dz, B, P);
+        if (even) {
+            float* t = ds_prev ? ds_prev : w.dsb;
+            ds_prev = ds_out;
+            ds_free = t;
+        }
+        // weight gradient of layer i: input x_{i-1} = BN_{i-1}(s_{i-1}) (identity for i = 1)
+        const float* in_stats = (i == 1) ? nullptr : sv->bn_stats + (size_t)(i - 2) * 2 * CP;
+        hipLaunchKernelGGL(wgrad_mfma_kernel, dim3(G), dim3(CONV_THREADS), lc, stream, (const float*)w.dz, sv->s[i - 1],
+                           in_stats, w.wpart, B, H);
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((NMAP * NMAP * 9 + 255) / 256), dim3(256), 0, stream,
+                           (const float*)w.wpart, G, gr->conv_w[i - 1]);
+        // data gradient: dx_{i-1} (w.r.t. the normalised input of layer i), with BN_{i-1} backward statistics
+        const bool need_stats = i > 1;
+        hipLaunchKernelGGL(conv3x3_mfma_kernel<1>, dim3(G), dim3(CONV_THREADS), lc, stream, (const float*)w.dz,
+                           (const float*)nullptr, w.wp_bwd + (size_t)(i - 1) * 3 * KSTEPS * 64, (const float*)nullptr,
+                           (float*)nullptr, dx_next, need_stats ? sv->s[i - 1] : (const float*)nullptr, in_stats,
+                           need_stats ? w.part : (float*)nullptr, B, H);
+        if (need_stats)
+            hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(64), 0, stream, (const float*)w.part, G, count, w.m12);
+        dx_cur = dx_next;
+        dx_next = (dx_next == w.bufa) ? w.bufb : w.bufa;
+    }
+    // conv0: dy0 = dx_0 (from layer 1's dgrad) + ds_2 (skip into s_2 = y_2 + y_0)
+    const size_t l0 = conv0_lds_bytes(T, M);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(conv0_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                        (int)l0);
+    hipLaunchKernelGGL(conv0_wgrad_kernel, dim3(G), dim3(C0_THREADS), l0, stream, feat, sb, st, sm, prm->conv0_w,
+                       (const float*)dx_cur, (const float*)ds_prev, w.c0part, B, T, M, H);
+    hipLaunchKernelGGL(reduce_parts_kernel, dim3((NMAP * 9 + 255) / 256), dim3(256), 0, stream, (const float*)w.c0part, G,
+                       NMAP * 9, gr->conv0_w);
+    HOWL_CHECK_LAUNCH("howl_res8_bwd");
+    return HOWL_OK;
+}
+
+int howl_xent_fwd_bwd(const float* logits, const long long* labels, int B, int C, float* loss, float* dlogits,
+                      hipStream_t stream) {
+    HOWL_REQUIRE(logits && labels && loss, "howl_xent_fwd_bwd: null pointer");
+    HOWL_REQUIRE(B >= 1 && C >= 1, "howl_xent_fwd_bwd: bad shape");
+    hipLaunchKernelGGL(xent_kernel, dim3(1), dim3(256), 0, stream, logits, labels, B, C, loss, dlogits);
+    HOWL_CHECK_LAUNCH("howl_xent_fwd_bwd");
+    return HOWL_OK;
+}
+
+int howl_adamw_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps,
+                    float weight_decay, int step, float grad_scale, hipStream_t stream) {
+    HOWL_REQUIRE(p && g && m && v, "howl_adamw_step: null pointer");
+    HOWL_REQUIRE(step >= 1, "howl_adamw_step: step counts from 1");
+    if (n == 0) return HOWL_OK;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, p, g, m, v, n, lr, beta1, beta2, eps,
+                       weight_decay, (float)bc1, (float)sqrt(bc2), grad_scale);
+    HOWL_CHECK_LAUNCH("howl_adamw_step");
+    return HOWL_OK;
+}
+
+}  // extern "C"

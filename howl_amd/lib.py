@@ -21,6 +21,19 @@ class HowlMelPoints(ctypes.Structure):
     _fields_ = [("f", c_float * (MAX_MELS + 2))]
 
 
+class HowlRes8Params(ctypes.Structure):
+    _fields_ = [("conv0_w", P), ("conv_w", P * 6), ("bn_running_mean", P * 6), ("bn_running_var", P * 6),
+                ("bn_num_batches", P * 6), ("out_w", P), ("out_b", P)]
+
+
+class HowlRes8Grads(ctypes.Structure):
+    _fields_ = [("conv0_w", P), ("conv_w", P * 6), ("out_w", P), ("out_b", P)]
+
+
+class HowlRes8Saved(ctypes.Structure):
+    _fields_ = [("s", P * 7), ("y", P * 3), ("bn_stats", P), ("pooled", P)]
+
+
 SIGNATURES = {
     "howl_version": [POINTER(c_int), POINTER(c_int)],
     "howl_fb_pack": [P, c_int, P, STREAM],
@@ -30,7 +43,15 @@ SIGNATURES = {
     "howl_zmuv_update": [P, c_size_t, P, P, P, P, STREAM],
     "howl_zmuv_pair": [P, P, P, STREAM],
     "howl_specaug_mask": [P, c_int, c_int, c_int, c_int, P, P, P, P, STREAM],
+    "howl_res8_fwd": [POINTER(HowlRes8Params), P, c_long, c_long, c_long, c_int, c_int, c_int, c_int, c_int,
+                      POINTER(HowlRes8Saved), P, P, c_size_t, STREAM],
+    "howl_res8_bwd": [POINTER(HowlRes8Params), P, c_long, c_long, c_long, c_int, c_int, c_int, c_int,
+                      POINTER(HowlRes8Saved), P, POINTER(HowlRes8Grads), P, c_size_t, STREAM],
+    "howl_xent_fwd_bwd": [P, P, c_int, c_int, P, P, STREAM],
+    "howl_adamw_step": [P, P, P, P, c_size_t, c_float, c_float, c_float, c_float, c_float, c_int, c_float, STREAM],
 }
+# entry points that do not return an int status
+SIZE_FUNCS = {"howl_res8_workspace_bytes": [c_int, c_int]}
 
 
 class HowlHipError(RuntimeError):
@@ -51,6 +72,10 @@ class Library:
         for name, argtypes in SIGNATURES.items():
             fn = getattr(self.cdll, name)  # AttributeError if the library lacks a declared symbol
             fn.restype = c_int
+            fn.argtypes = argtypes
+        for name, argtypes in SIZE_FUNCS.items():
+            fn = getattr(self.cdll, name)
+            fn.restype = c_size_t
             fn.argtypes = argtypes
 
     def call(self, name, *args):

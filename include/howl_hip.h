@@ -70,6 +70,61 @@ int howl_zmuv_pair(const float* mean, const float* mean2, float* pair, hipStream
 int howl_specaug_mask(float* x, int B, int C, int M, int T, const int* f0, const int* f, const int* t0,
                       const int* t, hipStream_t stream);
 
+/* ---------------------------------------------------------------------------------------------------
+ * res8 classifier: howl/model/cnn.py:113-145 (Res8.forward) and its autograd backward, as driven by
+ * training/run/pretrain_gsc.py:126-133 and training/run/train.py:288-302.
+ * Parameter tensors keep the reference's state_dict shapes (howl/workspace.py:31-67 round-trips them).
+ * ------------------------------------------------------------------------------------------------- */
+typedef struct {
+    const float* conv0_w;           /* conv0.weight (45,1,3,3) */
+    const float* conv_w[6];         /* conv{1..6}.weight (45,45,3,3) */
+    float* bn_running_mean[6];      /* bn{1..6}.running_mean (45): updated in place when training */
+    float* bn_running_var[6];       /* bn{1..6}.running_var (45) */
+    long long* bn_num_batches[6];   /* bn{1..6}.num_batches_tracked: int64 scalars */
+    const float* out_w;             /* output.weight (C,45) */
+    const float* out_b;             /* output.bias (C) */
+} HowlRes8Params;
+
+typedef struct {
+    float* conv0_w;
+    float* conv_w[6];
+    float* out_w;
+    float* out_b;
+} HowlRes8Grads;
+
+/* activations the backward pass needs; all caller-allocated */
+typedef struct {
+    float* s[7];       /* s[0] = avgpool(relu(conv0(x))); s[i] = layer i's pre-BatchNorm output; each (B,45,T/3,10) */
+    float* y[3];       /* relu(conv_i(.)) before the residual add for i = 2,4,6 (ReLU mask of the backward) */
+    float* bn_stats;   /* (6, 2, 48): per layer {mean[48], rstd[48]} used by this forward */
+    float* pooled;     /* (B, 48): spatial mean of BN6's output */
+} HowlRes8Saved;
+
+size_t howl_res8_workspace_bytes(int B, int T);
+
+/* feat: log-mel features, element (b, t, m) at feat[b*sb + t*st + m*sm] (so both the (B,T,M) model layout and
+ * channel 0 of the reference's (B,3,M,T) tensor are accepted; replaces x[:, :1].permute(0,1,3,2), cnn.py:128-129).
+ * training != 0: BatchNorm uses batch statistics and updates the running buffers; else uses the running buffers.
+ * logits: (B, C). */
+int howl_res8_fwd(const HowlRes8Params* prm, const float* feat, long sb, long st, long sm, int B, int T, int M, int C,
+                  int training, const HowlRes8Saved* saved, float* logits, void* ws, size_t ws_bytes,
+                  hipStream_t stream);
+
+/* backward of a training-mode forward: dlogits (B,C) -> parameter gradients (overwritten, not accumulated). */
+int howl_res8_bwd(const HowlRes8Params* prm, const float* feat, long sb, long st, long sm, int B, int T, int M, int C,
+                  const HowlRes8Saved* saved, const float* dlogits, const HowlRes8Grads* grads, void* ws,
+                  size_t ws_bytes, hipStream_t stream);
+
+/* mean cross-entropy over (B,C) logits with int64 labels and its gradient (dlogits may be NULL):
+ * nn.CrossEntropyLoss() at pretrain_gsc.py:95,131 / train.py:251,293. */
+int howl_xent_fwd_bwd(const float* logits, const long long* labels, int B, int C, float* loss, float* dlogits,
+                      hipStream_t stream);
+
+/* Fused AdamW over one flat buffer (torch.optim.AdamW semantics; pretrain_gsc.py:93,133, train.py:256,302).
+ * step counts from 1; grad_scale multiplies g on the fly (1/world_size after a sum all-reduce). */
+int howl_adamw_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
+                    float eps, float weight_decay, int step, float grad_scale, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -66,6 +66,7 @@ void hipemu_syncthreads();
 const uint32_t* hipemu_wave_exchange(const uint32_t* words, int n);
 int hipemu_lane();
 
+#define HIP_DYNAMIC_SHARED(type, var) type* var = reinterpret_cast<type*>(hipemu_dynamic_lds);
 #define hipLaunchKernelGGL(kernel, grid, block, lds, stream, ...) \
     hipemu_launch([=]() { kernel(__VA_ARGS__); }, dim3(grid), dim3(block), (size_t)(lds))
 
