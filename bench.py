@@ -1,0 +1,194 @@
+"""Headline benchmark: end-to-end res8 training step on synthetic 16 kHz audio (BASELINE.json metric
+"utterances/sec/node (res8, 1s@16kHz, 40-mel)").
+
+    python bench.py --gpus N --steps K --warmup W
+
+One step = one pass of the hot path over one batch already resident in HBM:
+    PCM (B,16000) -> fused log-mel frontend (+ZMUV) -> res8 forward (training-mode BN) -> cross-entropy
+    -> res8 backward -> [sum all-reduce of the flat 441 KB gradient over RCCL when N > 1] -> AdamW.
+Workload per GPU: BASELINE.json configs[2] at its per-GPU share -- res8, 12 labels, 512 utterances of 1 s per GPU
+(global batch 4096 at 8 GPUs); weak scaling.  Synthetic PCM and closed-form weights (no dataset / checkpoint on the box).
+
+Rank 0 prints ONE JSON line; it also carries
+  "roofline":     the dominant kernel (MFMA conv3x3 45->45, forward+dgrad launches) -- algorithmic FLOPs per launch
+                  (2*9*45*45*270 per utterance x B) / mean launch duration measured with HIP events on the launch stream,
+                  against the 157.3 TFLOP/s fp32 MFMA peak;
+  "cpu_baseline": the oracle (CPU restatement of the reference step, torch-CPU) timed on this box's host cores on a
+                  bounded sample (rank 0, N = 1 only).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+os.environ.setdefault("NUM_MELS", "40")
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch-per-gpu", type=int, default=512)
+    ap.add_argument("--seconds", type=float, default=1.0, help="utterance length")
+    ap.add_argument("--labels", type=int, default=12)
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(L, C, budget_s):
+    """Oracle training step (frontend + res8 fwd/bwd + AdamW, mirrors pretrain_gsc.py:124-133) on the host cores."""
+    from oracle import frontend as ofe, models as om
+    from howl_amd.utils.synth import synthetic_pcm
+    B = 64  # BASELINE.json configs[0] batch size
+    pcm = synthetic_pcm(B, L)
+    labels = torch.arange(B) % C
+    fb = ofe.mel_fb(40)
+    z = ofe.Zmuv()
+    z.update(ofe.standard_audio_transform(pcm[:2], fb))
+    sd = om.res8_init(C)
+    names = om.res8_param_names()
+    opt = om.AdamWState([sd[n] for n in names], 0.01, 1e-5)
+
+    def step():
+        x = z(ofe.standard_audio_transform(pcm, fb))
+        om.train_step(lambda s, xx: om.res8_forward(s, xx, True), sd, names, opt, x, labels)
+
+    for _ in range(2):
+        step()
+    t0 = time.perf_counter()
+    n = 0
+    while n < 3 or (time.perf_counter() - t0 < budget_s and n < 200):
+        step()
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": round(B * n / dt, 1), "unit": "utterances/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} oracle training steps of batch {B} x {L / 16000:g} s (torch-CPU, {torch.get_num_threads()} threads)"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device(f"cuda:{local_rank}")
+
+    from howl_amd import lib as hlib
+    from howl_amd.data.transform.operator import ZmuvTransform
+    from howl_amd.data.transform.transform import StandardAudioTransform
+    from howl_amd.model import RegisteredModel
+    from howl_amd.training.fused import FusedRes8Trainer
+    from howl_amd.utils.synth import res8_closed_form_state, synthetic_pcm
+
+    B, C = args.batch_per_gpu, args.labels
+    L = int(round(args.seconds * 16000))
+    pcm = synthetic_pcm(B, L, seed=1234 + rank).to(dev)
+    labels = (torch.arange(B) % C).to(dev)
+
+    std = StandardAudioTransform().to(dev).eval()   # eval-mode filterbank; VTLP is exercised by the tests
+    zmuv = ZmuvTransform().to(dev)
+    zmuv.update(std(pcm[:8]))
+    model = RegisteredModel.find_registered_class("res8")(C).to(dev)
+    model.load_state_dict(res8_closed_form_state(C), strict=False)
+    model.train()
+    trainer = FusedRes8Trainer(model, std, zmuv, lr=0.01, weight_decay=1e-5)
+    trainer.broadcast_parameters()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        trainer.step(pcm, labels)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = trainer.step(pcm, labels)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = tmax.item()
+    final_loss = loss.item()
+
+    roof = None
+    if not args.no_roofline and rank == 0:
+        # second pass of the same K steps with HIP-event brackets around the dominant kernels
+        lb = hlib.get()
+        lb.call("howl_profile_enable", 1)
+        for _ in range(args.steps):
+            trainer.step(pcm, labels)
+        torch.cuda.synchronize()
+        lb.call("howl_profile_enable", 0)
+
+        def read(tag, reset=0):
+            tot, cnt = ctypes.c_double(0), ctypes.c_int(0)
+            lb.call("howl_profile_read", tag.encode(), ctypes.byref(tot), ctypes.byref(cnt), reset)
+            return tot.value, cnt.value
+
+        tf, nf = read("conv3x3_fwd")
+        td, nd = read("conv3x3_dgrad")
+        tw, nw = read("wgrad")
+        tl, nl = read("logmel", reset=1)
+        H = (1 + L // 200) // 3
+        flops_launch = 2.0 * 9 * 45 * 45 * (H * 10) * B
+        avg_ms = (tf + td) / max(nf + nd, 1)
+        achieved = flops_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+        roof = {"bound": "mfma", "kernel": "conv3x3_mfma_kernel (45->45 conv, fwd + dgrad launches)",
+                "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                "avg_launch_ms": round(avg_ms, 4), "launches": nf + nd,
+                "other_kernels": {
+                    "wgrad_mfma": {"avg_launch_ms": round(tw / max(nw, 1), 4),
+                                   "tflops": round(flops_launch / (tw / max(nw, 1) * 1e-3) / 1e12, 2) if tw > 0 else None},
+                    "logmel": {"avg_launch_ms": round(tl / max(nl, 1), 4),
+                               "hbm_gbs": round((4.0 * L + 4.0 * 40 * (1 + L // 200)) * B / (tl / max(nl, 1) * 1e-3) / 1e9, 1)
+                               if tl > 0 else None, "hbm_frac": round((4.0 * L + 4.0 * 40 * (1 + L // 200)) * B /
+                                                                      (tl / max(nl, 1) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                               if tl > 0 else None}}}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(L, C, args.cpu_baseline_seconds)
+
+    if rank == 0:
+        total_utts = B * world * args.steps
+        out = {
+            "metric": "utterances/sec/node (res8 end-to-end training step, 1s@16kHz, 40-mel)",
+            "value": round(total_utts / dt, 1), "unit": "utterances/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"res8 GSC-12 training step (frontend+fwd+loss+bwd+AdamW), {B} x {L / 16000:g} s "
+                                   f"utterances per GPU (BASELINE configs[2] per-GPU share)",
+                       "global_batch": B * world, "samples_per_utterance": L, "labels": C,
+                       "parallelism": f"dp{world}" if world > 1 else "single"},
+            "final_loss": round(final_loss, 5),
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -4,8 +4,38 @@
 #include "howl_common.hip.h"
 #include "../../include/howl_hip.h"
 
+#include <mutex>
+#include <string>
+#include <vector>
+
 namespace {
 thread_local char g_err[512] = "";
+
+// optional per-kernel timing with HIP events on the launch stream (bench.py's roofline leg)
+struct ProfRec {
+    std::string tag;
+    hipEvent_t start, stop;
+};
+std::mutex g_prof_mu;
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof;
+}  // namespace
+
+bool howl_prof_begin(const char* tag, hipStream_t stream, size_t* slot) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (!g_prof_on) return false;
+    ProfRec r;
+    r.tag = tag;
+    if (hipEventCreate(&r.start) != hipSuccess || hipEventCreate(&r.stop) != hipSuccess) return false;
+    hipEventRecord(r.start, stream);
+    g_prof.push_back(r);
+    *slot = g_prof.size() - 1;
+    return true;
+}
+
+void howl_prof_end(size_t slot, hipStream_t stream) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (slot < g_prof.size()) hipEventRecord(g_prof[slot].stop, stream);
 }
 
 void howl_set_error(const char* fmt, ...) {
@@ -38,5 +68,36 @@ int howl_version(int* major, int* minor) {
 }
 
 const char* howl_last_error(void) { return g_err; }
+
+int howl_profile_enable(int on) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_on = on != 0;
+    return HOWL_OK;
+}
+
+int howl_profile_read(const char* tag, double* total_ms, int* count, int reset) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    double tot = 0.0;
+    int n = 0;
+    for (auto& r : g_prof) {
+        if (tag != nullptr && r.tag != tag) continue;
+        if (hipEventSynchronize(r.stop) != hipSuccess) continue;
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, r.start, r.stop) == hipSuccess) {
+            tot += (double)ms;
+            ++n;
+        }
+    }
+    if (total_ms) *total_ms = tot;
+    if (count) *count = n;
+    if (reset) {
+        for (auto& r : g_prof) {
+            hipEventDestroy(r.start);
+            hipEventDestroy(r.stop);
+        }
+        g_prof.clear();
+    }
+    return HOWL_OK;
+}
 
 }  // extern "C"

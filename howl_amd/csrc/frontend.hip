@@ -331,6 +331,14 @@ __global__ void zmuv_pair_kernel(const float* mean, const float* mean2, float* p
     pair[1] = sqrtf(mean2[0] - m * m);
 }
 
+// operator.py:145-146: (x - mean) / std, elementwise
+__global__ void zmuv_apply_kernel(const float* __restrict__ x, size_t n, const float* __restrict__ pair,
+                                  float* __restrict__ out) {
+    const float mean = pair[0], sd = pair[1];
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        out[i] = (x[i] - mean) / sd;
+}
+
 // K5: zero x[b, :, f0:f0+f, :] and x[b, :, :, t0:t0+t] for every sample (negative width = no mask)
 __global__ void specaug_kernel(float* __restrict__ x, int B, int C, int M, int T, const int* __restrict__ f0,
                                const int* __restrict__ f, const int* __restrict__ t0, const int* __restrict__ t) {
@@ -382,8 +390,11 @@ int howl_logmel_fwd(const float* pcm, int B, int L, long ld, const float* fbp, i
     const int n_chunks = (int)((total + CHUNK - 1) / CHUNK);
     int grid = howl_num_cus() * 4;
     if (grid > n_chunks) grid = n_chunks;
-    hipLaunchKernelGGL(logmel_kernel<HOWL_FB_COLS / 16>, dim3(grid), dim3(256), 0, stream, pcm, L, ld, T, total, fbp, M,
-                       log_eps, zmuv, out, layout, n_chunks);
+    {
+        HowlProfScope prof("logmel", stream);
+        hipLaunchKernelGGL(logmel_kernel<HOWL_FB_COLS / 16>, dim3(grid), dim3(256), 0, stream, pcm, L, ld, T, total, fbp, M,
+                           log_eps, zmuv, out, layout, n_chunks);
+    }
     HOWL_CHECK_LAUNCH("howl_logmel_fwd");
     return HOWL_OK;
 }
@@ -416,6 +427,16 @@ int howl_zmuv_pair(const float* mean, const float* mean2, float* pair, hipStream
     HOWL_REQUIRE(mean && mean2 && pair, "howl_zmuv_pair: null pointer");
     hipLaunchKernelGGL(zmuv_pair_kernel, dim3(1), dim3(64), 0, stream, mean, mean2, pair);
     HOWL_CHECK_LAUNCH("howl_zmuv_pair");
+    return HOWL_OK;
+}
+
+int howl_zmuv_apply(const float* x, size_t n, const float* pair, float* out, hipStream_t stream) {
+    HOWL_REQUIRE(x && pair && out, "howl_zmuv_apply: null pointer");
+    if (n == 0) return HOWL_OK;
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(zmuv_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, x, n, pair, out);
+    HOWL_CHECK_LAUNCH("howl_zmuv_apply");
     return HOWL_OK;
 }
 

@@ -13,6 +13,19 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 void howl_set_error(const char* fmt, ...);
 int howl_num_cus();
+bool howl_prof_begin(const char* tag, hipStream_t stream, size_t* slot);
+void howl_prof_end(size_t slot, hipStream_t stream);
+
+// brackets the launches in its scope with HIP events when howl_profile_enable(1) is active (no-op otherwise)
+struct HowlProfScope {
+    size_t slot = 0;
+    bool on;
+    hipStream_t stream;
+    HowlProfScope(const char* tag, hipStream_t s) : stream(s) { on = howl_prof_begin(tag, s, &slot); }
+    ~HowlProfScope() {
+        if (on) howl_prof_end(slot, stream);
+    }
+};
 
 #define HOWL_REQUIRE(cond, ...)                 \
     do {                                        \

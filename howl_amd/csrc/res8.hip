@@ -821,9 +821,12 @@ int howl_res8_fwd(const HowlRes8Params* prm, const float* feat, long sb, long st
         const bool even = (i % 2) == 0;
         const float* res = even ? sv->s[i - 2] : nullptr;
         float* yo = even ? sv->y[i / 2 - 1] : nullptr;
-        hipLaunchKernelGGL(conv3x3_mfma_kernel<0>, dim3(G), dim3(CONV_THREADS), lc, stream, sv->s[i - 1], in_stats,
-                           w.wp_fwd + (size_t)(i - 1) * 3 * KSTEPS * 64, res, yo, sv->s[i], (const float*)nullptr,
-                           (const float*)nullptr, training ? w.part : (float*)nullptr, B, H);
+        {
+            HowlProfScope prof("conv3x3_fwd", stream);
+            hipLaunchKernelGGL(conv3x3_mfma_kernel<0>, dim3(G), dim3(CONV_THREADS), lc, stream, sv->s[i - 1], in_stats,
+                               w.wp_fwd + (size_t)(i - 1) * 3 * KSTEPS * 64, res, yo, sv->s[i], (const float*)nullptr,
+                               (const float*)nullptr, training ? w.part : (float*)nullptr, B, H);
+        }
         if (training)
             hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(64), 0, stream, w.part, G, count,
                                sv->bn_stats + (size_t)(i - 1) * 2 * CP, prm->bn_running_mean[i - 1],
@@ -882,16 +885,22 @@ int howl_res8_bwd(const HowlRes8Params* prm, const float* feat, long sb, long st
         }
         // weight gradient of layer i: input x_{i-1} = BN_{i-1}(s_{i-1}) (identity for i = 1)
         const float* in_stats = (i == 1) ? nullptr : sv->bn_stats + (size_t)(i - 2) * 2 * CP;
-        hipLaunchKernelGGL(wgrad_mfma_kernel, dim3(G), dim3(CONV_THREADS), lc, stream, (const float*)w.dz, sv->s[i - 1],
-                           in_stats, w.wpart, B, H);
+        {
+            HowlProfScope prof("wgrad", stream);
+            hipLaunchKernelGGL(wgrad_mfma_kernel, dim3(G), dim3(CONV_THREADS), lc, stream, (const float*)w.dz, sv->s[i - 1],
+                               in_stats, w.wpart, B, H);
+        }
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((NMAP * NMAP * 9 + 255) / 256), dim3(256), 0, stream,
                            (const float*)w.wpart, G, gr->conv_w[i - 1]);
         // data gradient: dx_{i-1} (w.r.t. the normalised input of layer i), with BN_{i-1} backward statistics
         const bool need_stats = i > 1;
-        hipLaunchKernelGGL(conv3x3_mfma_kernel<1>, dim3(G), dim3(CONV_THREADS), lc, stream, (const float*)w.dz,
-                           (const float*)nullptr, w.wp_bwd + (size_t)(i - 1) * 3 * KSTEPS * 64, (const float*)nullptr,
-                           (float*)nullptr, dx_next, need_stats ? sv->s[i - 1] : (const float*)nullptr, in_stats,
-                           need_stats ? w.part : (float*)nullptr, B, H);
+        {
+            HowlProfScope prof("conv3x3_dgrad", stream);
+            hipLaunchKernelGGL(conv3x3_mfma_kernel<1>, dim3(G), dim3(CONV_THREADS), lc, stream, (const float*)w.dz,
+                               (const float*)nullptr, w.wp_bwd + (size_t)(i - 1) * 3 * KSTEPS * 64, (const float*)nullptr,
+                               (float*)nullptr, dx_next, need_stats ? sv->s[i - 1] : (const float*)nullptr, in_stats,
+                               need_stats ? w.part : (float*)nullptr, B, H);
+        }
         if (need_stats)
             hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(64), 0, stream, (const float*)w.part, G, count, w.m12);
         dx_cur = dx_next;

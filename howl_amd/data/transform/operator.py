@@ -1,0 +1,80 @@
+"""``ZmuvTransform`` and the collate helpers of ``howl/data/transform/operator.py`` on the MI355X path."""
+from typing import Iterable
+
+import torch
+import torch.nn as nn
+
+from howl_amd import ops
+
+__all__ = ["ZmuvTransform", "Composition", "compose", "identity"]
+
+
+class Composition(nn.Module):
+    """``operator.py:24-34``."""
+
+    def __init__(self, modules):
+        super().__init__()
+        self.modules_ = modules
+        self._module_list = nn.ModuleList([m for m in modules if isinstance(m, nn.Module)])
+
+    def forward(self, *args):
+        for mod in self.modules_:
+            args = (mod(*args),)
+        return args[0]
+
+
+def compose(*collate_modules):
+    return Composition(collate_modules)
+
+
+def identity(x):
+    return x
+
+
+class ZmuvTransform(nn.Module):
+    """Running scalar mean / mean-of-squares normaliser (``operator.py:119-146``); buffers ``total, mean, mean2``
+    (each shape ``(1,)``) so ``zmuv.pt.bin`` files are interchangeable.  ``update`` and ``forward`` run in the
+    ``howl_zmuv_update`` / ``howl_zmuv_apply`` kernels; nothing synchronises the host."""
+
+    def __init__(self):
+        super().__init__()
+        self.register_buffer("total", torch.zeros(1))
+        self.register_buffer("mean", torch.zeros(1))
+        self.register_buffer("mean2", torch.zeros(1))
+        self._scratch = None
+        self._pair = None
+
+    def _dev_scratch(self):
+        dev = self.mean.device
+        if self._scratch is None or self._scratch.device != dev:
+            self._scratch = torch.zeros(2, dtype=torch.float64, device=dev)
+            self._pair = torch.zeros(2, dtype=torch.float32, device=dev)
+        return self._scratch
+
+    def update(self, data, mask=None):
+        with torch.no_grad():
+            if mask is not None:
+                # masked variant (operator.py:128-130): the count is data dependent -> stays in torch ops on the device
+                data = data * mask
+                mask_size = mask.sum()
+                self.mean = (data.sum() + self.mean * self.total) / (self.total + mask_size)
+                self.mean2 = ((data ** 2).sum() + self.mean2 * self.total) / (self.total + mask_size)
+                self.total += mask_size
+                return
+            ops.zmuv_update(data.contiguous(), self.total, self.mean, self.mean2, self._dev_scratch())
+
+    def initialize(self, iterable: Iterable[torch.Tensor]):
+        for ex in iterable:
+            self.update(ex)
+
+    @property
+    def std(self):
+        return (self.mean2 - self.mean ** 2).sqrt()
+
+    def pair(self) -> torch.Tensor:
+        """Device tensor ``[mean, std]`` for the fused epilogues (recomputed from the buffers each call, no sync)."""
+        self._dev_scratch()
+        return ops.zmuv_pair(self.mean, self.mean2, self._pair)
+
+    def forward(self, x):
+        return ops.zmuv_apply(x.contiguous(), self.pair())

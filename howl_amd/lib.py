@@ -36,12 +36,15 @@ class HowlRes8Saved(ctypes.Structure):
 
 SIGNATURES = {
     "howl_version": [POINTER(c_int), POINTER(c_int)],
+    "howl_profile_enable": [c_int],
+    "howl_profile_read": [c_char_p, POINTER(c_double), POINTER(c_int), c_int],
     "howl_fb_pack": [P, c_int, P, STREAM],
     "howl_fb_from_points": [POINTER(HowlMelPoints), c_int, c_float, P, STREAM],
     "howl_logmel_fwd": [P, c_int, c_int, c_long, P, c_int, c_float, P, P, c_int, STREAM],
     "howl_deltas_fwd": [P, c_int, c_int, c_int, P, P, STREAM],
     "howl_zmuv_update": [P, c_size_t, P, P, P, P, STREAM],
     "howl_zmuv_pair": [P, P, P, STREAM],
+    "howl_zmuv_apply": [P, c_size_t, P, P, STREAM],
     "howl_specaug_mask": [P, c_int, c_int, c_int, c_int, P, P, P, P, STREAM],
     "howl_res8_fwd": [POINTER(HowlRes8Params), P, c_long, c_long, c_long, c_int, c_int, c_int, c_int, c_int,
                       POINTER(HowlRes8Saved), P, P, c_size_t, STREAM],

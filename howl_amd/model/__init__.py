@@ -1,0 +1,2 @@
+from .base import *  # noqa: F401,F403
+from .cnn import *  # noqa: F401,F403

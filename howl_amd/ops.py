@@ -1,0 +1,113 @@
+"""Thin torch-tensor front of the C ABI: pointer / stream plumbing only, no arithmetic.
+
+Every function requires HIP-resident, contiguous fp32 tensors and enqueues on torch's current stream.  There is
+deliberately no CPU branch: a CPU tensor raises.
+"""
+import ctypes
+import math
+
+import torch
+
+from . import lib as _lib
+
+HOP = 200
+N_FFT = 512
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t, dtype=torch.float32, allow_none=False):
+    if t is None:
+        if allow_none:
+            return None
+        raise ValueError("tensor required")
+    if not t.is_cuda:
+        raise _lib.HowlHipError("howl_amd ops need HIP-device tensors (no CPU fallback); got a CPU tensor")
+    if t.dtype != dtype:
+        raise TypeError(f"expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError("expected a contiguous tensor")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def num_frames(length: int) -> int:
+    return 1 + length // HOP
+
+
+def fb_pack(fb: torch.Tensor) -> torch.Tensor:
+    """(257, M) filterbank on the device -> packed (260, 48) operand."""
+    out = torch.empty(_lib.FB_PACKED_FLOATS, dtype=torch.float32, device=fb.device)
+    _lib.get().call("howl_fb_pack", _p(fb), fb.shape[1], _p(out), _stream())
+    return out
+
+
+def fb_from_points(f_pts, n_mels: int, nyquist: float, out: torch.Tensor) -> torch.Tensor:
+    """M+2 corner frequencies (host floats) -> packed filterbank written into ``out`` (device, 260*48 floats)."""
+    pts = _lib.HowlMelPoints()
+    for i, v in enumerate(f_pts):
+        pts.f[i] = v
+    _lib.get().call("howl_fb_from_points", ctypes.byref(pts), n_mels, float(nyquist), _p(out), _stream())
+    return out
+
+
+def logmel(pcm: torch.Tensor, fbp: torch.Tensor, n_mels: int, zmuv_pair=None, layout: int = 0,
+           log_eps: float = 1e-7) -> torch.Tensor:
+    """(B, L) PCM -> log-mel (B, M, T) [layout 0] or (B, T, M) [layout 1]; optional fused ZMUV."""
+    if pcm.dim() != 2:
+        raise ValueError("pcm must be (B, L)")
+    if pcm.stride(1) != 1:
+        pcm = pcm.contiguous()
+    B, L = pcm.shape
+    T = num_frames(L)
+    out = torch.empty((B, n_mels, T) if layout == 0 else (B, T, n_mels), dtype=torch.float32, device=pcm.device)
+    if not pcm.is_cuda or pcm.dtype != torch.float32:
+        _p(pcm)
+    _lib.get().call("howl_logmel_fwd", ctypes.c_void_p(pcm.data_ptr()), B, L, pcm.stride(0), _p(fbp), n_mels,
+                    log_eps, _p(zmuv_pair, allow_none=True), _p(out), layout, _stream())
+    return out
+
+
+def deltas(logmel_bmt: torch.Tensor, zmuv_pair=None) -> torch.Tensor:
+    B, M, T = logmel_bmt.shape
+    out = torch.empty((B, 3, M, T), dtype=torch.float32, device=logmel_bmt.device)
+    _lib.get().call("howl_deltas_fwd", _p(logmel_bmt), B, M, T, _p(zmuv_pair, allow_none=True), _p(out), _stream())
+    return out
+
+
+def zmuv_update(x, total, mean, mean2, scratch):
+    _lib.get().call("howl_zmuv_update", _p(x), x.numel(), _p(total), _p(mean), _p(mean2),
+                    _p(scratch, torch.float64), _stream())
+
+
+def zmuv_pair(mean, mean2, out):
+    _lib.get().call("howl_zmuv_pair", _p(mean), _p(mean2), _p(out), _stream())
+    return out
+
+
+def zmuv_apply(x, pair):
+    out = torch.empty_like(x)
+    _lib.get().call("howl_zmuv_apply", _p(x), x.numel(), _p(pair), _p(out), _stream())
+    return out
+
+
+def specaug_mask(x, f0, f, t0, t):
+    B, C, M, T = x.shape
+    _lib.get().call("howl_specaug_mask", _p(x), B, C, M, T, _p(f0, torch.int32), _p(f, torch.int32),
+                    _p(t0, torch.int32), _p(t, torch.int32), _stream())
+    return x
+
+
+def xent(logits, labels, want_grad=True):
+    B, C = logits.shape
+    loss = torch.empty(1, dtype=torch.float32, device=logits.device)
+    dlogits = torch.empty_like(logits) if want_grad else None
+    _lib.get().call("howl_xent_fwd_bwd", _p(logits), _p(labels, torch.int64), B, C, _p(loss),
+                    _p(dlogits, allow_none=True), _stream())
+    return loss, dlogits
+
+
+def adamw_step(p, g, m, v, lr, betas, eps, weight_decay, step, grad_scale=1.0):
+    _lib.get().call("howl_adamw_step", _p(p), _p(g), _p(m), _p(v), p.numel(), lr, betas[0], betas[1], eps,
+                    weight_decay, step, grad_scale, _stream())

@@ -1,0 +1,80 @@
+"""Fused res8 training step: frontend -> forward -> cross-entropy -> backward -> (RCCL all-reduce) -> AdamW.
+
+This is the loop body of ``training/run/pretrain_gsc.py:124-133`` / ``training/run/train.py:286-302`` with every
+stage a C-ABI call on the current HIP stream, gradients written straight into one flat fp32 buffer (the unit of the
+single data-parallel all-reduce per step) and no host synchronisation (the loss stays on the device).
+"""
+import torch
+import torch.distributed as dist
+
+from howl_amd import ops
+
+
+class FlatParams:
+    """Re-homes a list of parameters into one contiguous buffer (and a matching flat gradient buffer)."""
+
+    def __init__(self, params):
+        self.params = list(params)
+        dev = self.params[0].device
+        sizes = [p.numel() for p in self.params]
+        self.numel = sum(sizes)
+        self.flat = torch.empty(self.numel, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(self.numel, dtype=torch.float32, device=dev)
+        self.grad_views = []
+        off = 0
+        with torch.no_grad():
+            for p, n in zip(self.params, sizes):
+                self.flat[off:off + n].copy_(p.data.reshape(-1))
+                p.data = self.flat[off:off + n].view(p.shape)
+                self.grad_views.append(self.grad[off:off + n].view(p.shape))
+                off += n
+
+    def attach_grads(self):
+        """Expose the flat gradient through ``p.grad`` (for torch optimisers / inspection)."""
+        for p, g in zip(self.params, self.grad_views):
+            p.grad = g
+
+
+class FusedRes8Trainer:
+    def __init__(self, model, std_transform, zmuv_transform, lr, weight_decay=0.0, betas=(0.9, 0.999), eps=1e-8,
+                 process_group=None):
+        self.model, self.std, self.zmuv = model, std_transform, zmuv_transform
+        self.lr, self.weight_decay, self.betas, self.eps = lr, weight_decay, betas, eps
+        self.fp = FlatParams(model.hot_parameters())
+        self.m = torch.zeros_like(self.fp.flat)
+        self.v = torch.zeros_like(self.fp.flat)
+        self.step_count = 0
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+
+    def broadcast_parameters(self, src=0):
+        """Make every replica start from rank ``src``'s weights and BatchNorm buffers."""
+        if self.world > 1:
+            dist.broadcast(self.fp.flat, src, group=self.group)
+            for b in self.model.buffers():
+                dist.broadcast(b, src, group=self.group)
+
+    def features(self, audio):
+        return self.std.log_mel_for_model(audio, self.zmuv)
+
+    def step(self, audio, labels):
+        """One optimisation step on a (B, L) PCM batch; returns the (local) mean loss as a device tensor."""
+        feat = self.features(audio)
+        return self.step_on_features(feat, labels)
+
+    def step_on_features(self, feat, labels):
+        logits = self.model._launch_forward(feat)
+        loss, dlogits = ops.xent(logits, labels)
+        self.model._launch_backward(feat, dlogits, out_grads=self.fp.grad_views)
+        scale = 1.0
+        if self.world > 1:
+            dist.all_reduce(self.fp.grad, op=dist.ReduceOp.SUM, group=self.group)
+            scale = 1.0 / self.world
+        self.step_count += 1
+        ops.adamw_step(self.fp.flat, self.fp.grad, self.m, self.v, self.lr, self.betas, self.eps, self.weight_decay,
+                       self.step_count, scale)
+        self.last_logits = logits
+        return loss
+
+    def decay_lr(self, factor):
+        self.lr *= factor

@@ -30,6 +30,12 @@ typedef struct ihipStream_t* hipStream_t;
 int howl_version(int* major, int* minor);
 const char* howl_last_error(void);
 
+/* Optional kernel timing for bench.py's roofline leg: while enabled, the dominant kernels (tags "logmel",
+ * "conv3x3_fwd", "conv3x3_dgrad", "wgrad") are bracketed by hipEvents recorded on their launch stream.
+ * howl_profile_read synchronises those events and returns the summed duration and launch count for one tag. */
+int howl_profile_enable(int on);
+int howl_profile_read(const char* tag, double* total_ms, int* count, int reset);
+
 /* ---------------------------------------------------------------------------------------------------
  * Frontend: howl/data/transform/transform.py:234-296 (StandardAudioTransform) and the torchaudio
  * MelSpectrogram / ComputeDeltas it calls; howl/data/transform/operator.py:119-146 (ZmuvTransform).
@@ -65,6 +71,9 @@ int howl_zmuv_update(const float* x, size_t n, float* total, float* mean, float*
                      hipStream_t stream);
 /* pair = {mean, sqrt(mean2 - mean^2)}: operator.py:141-143 (`ZmuvTransform.std`). */
 int howl_zmuv_pair(const float* mean, const float* mean2, float* pair, hipStream_t stream);
+
+/* out = (x - pair[0]) / pair[1] elementwise (in place allowed): operator.py:145-146 (`ZmuvTransform.forward`). */
+int howl_zmuv_apply(const float* x, size_t n, const float* pair, float* out, hipStream_t stream);
 
 /* SpecAugment masks with host-drawn parameters (per sample; width <= 0 = no mask): transform.py:309-327. */
 int howl_specaug_mask(float* x, int B, int C, int M, int T, const int* f0, const int* f, const int* t0,

@@ -1,0 +1,115 @@
+"""-m gpu parity: HIP frontend (through the Python modules -> C ABI) vs golden vectors and the oracle.
+
+Tolerances (fp32): log-mel <= 2e-4 abs where the mel power is above the 1e-7 floor region (log > -8), <= 2e-3 abs
+everywhere (log amplifies relative error near the eps floor); integer outputs exact.
+"""
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from gpu_util import DEV, maxerr, t
+from oracle import frontend as ofe
+
+pytestmark = pytest.mark.gpu
+
+
+def logmel_close(out, ref):
+    out, ref = out.detach().cpu(), torch.as_tensor(ref)
+    assert out.shape == ref.shape
+    d = (out - ref).abs()
+    assert d.max().item() < 2e-3, d.max().item()
+    strong = ref > -8
+    assert d[strong].max().item() < 2e-4, d[strong].max().item()
+
+
+@pytest.fixture(scope="module")
+def std():
+    from howl_amd.data.transform.transform import StandardAudioTransform
+    return StandardAudioTransform().to(DEV).eval()
+
+
+def test_golden_gsc_eval(std, golden):
+    g = golden("g2_frontend_gsc")
+    audio = t(g["audio"]).to(DEV)
+    feats = std(audio)
+    assert feats.shape == (6, 3, 40, 81)
+    logmel_close(feats[:, 0], g["feats"][:, 0])
+    assert maxerr(feats[:, 1], g["feats"][:, 1]) < 2e-3 and maxerr(feats[:, 2], g["feats"][:, 2]) < 2e-3
+    logmel_close(std(audio, mels_only=True), g["mels"])
+    d = std(t(g["mels"]).to(DEV), deltas_only=True)   # exact inputs -> tight tolerance on the delta kernel alone
+    assert maxerr(d, g["feats"]) < 2e-6
+    assert torch.equal(std.compute_lengths(t(g["lens_in"]).to(DEV)).cpu(), t(g["lens_out"]))
+
+
+def test_golden_synth_edges(std, golden):
+    g = golden("g2_frontend_synth")   # tone+noise, silence, full-scale square, impulses at n=0 and n=L-1
+    for L in (8000, 16000, 13527):
+        logmel_close(std(t(g[f"audio_{L}"]).to(DEV), mels_only=True), g[f"mels_{L}"])
+
+
+def test_vtlp_train_mode(golden):
+    from howl_amd.data.transform.transform import StandardAudioTransform
+    g = golden("g2_frontend_gsc")
+    std = StandardAudioTransform().to(DEV).train()
+    random.seed(11)   # same global-RNG protocol as the reference: one gate draw, then alpha
+    feats = std(t(g["audio"]).to(DEV))
+    assert abs(std.last_vtlp_alpha - float(g["vtlp_alpha"])) == 0.0
+    logmel_close(feats[:, 0], g["mels_vtlp"])
+    for alpha in (0.9, 1.0999):   # alpha > 1 exercises the re-mapped corner points (transform.py:397-401)
+        fb = ofe.mel_fb(40, alpha=alpha)
+        from howl_amd import ops
+        from howl_amd.data.transform.transform import mel_corner_points, vtlp_warp_points
+        out = torch.empty(260 * 48, device=DEV)
+        ops.fb_from_points(vtlp_warp_points(mel_corner_points(40, 16000), alpha, 16000).tolist(), 40, 8000, out)
+        assert maxerr(out.view(260, 48)[:257, :40], fb) < 2e-7
+
+
+def test_zmuv_golden(std, golden):
+    from howl_amd.data.transform.operator import ZmuvTransform
+    g2, g4 = golden("g2_frontend_gsc"), golden("g4_zmuv")
+    audio, lengths = t(g2["audio"]), g2["lengths"]
+    z = ZmuvTransform().to(DEV)
+    for pos in [0, 2, 3, 5, 4, 1]:   # file order of the clips inside the length-sorted batch
+        z.update(std(audio[pos:pos + 1, : int(lengths[pos])].to(DEV)))
+    assert z.total.item() == g4["total"][0]
+    assert abs(z.mean.item() - g4["mean"][0]) < 2e-5 and abs(z.mean2.item() - g4["mean2"][0]) < 2e-4
+    z.mean.copy_(t(g4["mean"]))
+    z.mean2.copy_(t(g4["mean2"]))
+    normed = z(std(audio.to(DEV)))
+    d = (normed[:, 0].cpu() - t(g4["normed_ch0"])).abs()
+    assert d.max().item() < 1e-3
+    fused = std.log_mel_for_model(audio.to(DEV), z)   # (B,1,M,T) view of the (B,T,M) fused output
+    assert fused.shape == (6, 1, 40, 81) and maxerr(fused[:, 0], normed[:, 0]) < 1e-5
+
+
+def test_specaug_golden(golden):
+    from howl_amd.data.transform.transform import SpecAugmentTransform
+    g = golden("g7_specaug")
+    sa = SpecAugmentTransform().train()
+    sa.rand = random.Random(5)
+    for p in sa.augment_params:
+        p.prob = 1.1
+    sa.augment_params[1].domain = [10, 50, 60, 125, 150]
+    out = sa(t(g["x"]).to(DEV))
+    assert torch.equal(out.cpu(), t(g["out"]))
+
+
+def test_full_size_properties(std):
+    """BASELINE sizes (512 x 1 s): spot-check against the oracle and size-independent invariants."""
+    from howl_amd.utils.synth import synthetic_pcm
+    pcm = synthetic_pcm(512, 16000)
+    out = std(pcm.to(DEV), mels_only=True)
+    idx = [0, 1, 63, 200, 511]
+    logmel_close(out[idx], ofe.standard_audio_transform(pcm[idx], ofe.mel_fb(40), mels_only=True))
+    alone = std(pcm[200:201].to(DEV), mels_only=True)
+    assert torch.equal(alone[0], out[200])                     # batch-composition invariance, bit for bit
+    from howl_amd import ops
+    tm = ops.logmel(pcm.to(DEV), std._standard_fb(), 40, None, layout=1)
+    assert torch.equal(tm.permute(0, 2, 1), out)               # the two layouts are the same numbers
+    assert torch.equal(std(pcm.to(DEV), mels_only=True), out)  # run-to-run determinism
+    with pytest.raises(Exception):
+        std(pcm[:, :200].to(DEV), mels_only=True)              # too short for reflect padding: loud error, like torch.stft
+    with pytest.raises(Exception):
+        std(pcm[:2])                                           # CPU tensor: no fallback

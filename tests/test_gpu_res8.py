@@ -1,0 +1,142 @@
+"""-m gpu parity: res8 forward / backward / loss / AdamW on the HIP path vs golden vectors (captured from the
+reference) and the oracle.  Tolerances: logits <= 1e-3 abs (north_star), argmax exact; in practice ~1e-5."""
+import numpy as np
+import pytest
+import torch
+
+from gpu_util import DEV, golden_features, make_res8, maxerr, t
+from oracle import frontend as ofe
+from oracle import models as om
+
+pytestmark = pytest.mark.gpu
+LOGIT_TOL = 1e-3
+
+
+@pytest.mark.parametrize("C", [4, 12, 30])
+def test_golden_eval_and_train(golden, C):
+    g = golden(f"g5_res8_c{C}")
+    x, _ = golden_features(golden)
+    xd = x.to(DEV)
+    model = make_res8(C, train=False)
+    with torch.no_grad():
+        logits = model(xd, None)
+    assert maxerr(logits, g["eval_logits"]) < LOGIT_TOL
+    assert torch.equal(logits.argmax(1).cpu(), t(g["eval_logits"]).argmax(1))
+
+    # three optimisation steps through the autograd seam + torch.optim.AdamW, exactly as pretrain_gsc.py:126-133
+    model.train()
+    labels = t(g["labels"]).to(DEV)
+    opt = torch.optim.AdamW(model.parameters(), 0.01, weight_decay=1e-5)
+    crit = torch.nn.CrossEntropyLoss()
+    for step in range(3):
+        scores = model(xd, None)
+        opt.zero_grad()
+        model.zero_grad()
+        loss = crit(scores, labels)
+        loss.backward()
+        if step == 0:
+            assert maxerr(scores, g["train_logits"]) < LOGIT_TOL
+            for n, p in model.named_parameters():
+                ref = g["grad0." + n]
+                assert maxerr(p.grad, ref) < 2e-5 * max(1.0, float(np.abs(ref).max())), n
+            for i in (1, 6):
+                bn = getattr(model, f"bn{i}")
+                assert maxerr(bn.running_mean, g[f"bn{i}.running_mean.1"]) < 1e-5
+                assert maxerr(bn.running_var, g[f"bn{i}.running_var.1"]) < 1e-5
+        assert abs(loss.item() - float(g[f"loss{step}"])) < 1e-4
+        opt.step()
+    sd = model.state_dict()
+    for k, v in sd.items():
+        assert maxerr(v, g["sd3." + k]) < 1e-4, k
+    assert int(sd["bn3.num_batches_tracked"]) == 3
+    model.eval()
+    with torch.no_grad():
+        assert maxerr(model(xd, None), g["eval_logits_after3"]) < 5e-3
+
+
+def test_golden_half_second_window(golden):
+    g, g4 = golden("g5_res8_c4_half"), golden("g4_zmuv")
+    from howl_amd.data.transform.operator import ZmuvTransform
+    from howl_amd.data.transform.transform import StandardAudioTransform
+    std = StandardAudioTransform().to(DEV).eval()
+    z = ZmuvTransform().to(DEV)
+    z.mean.copy_(t(g4["mean"]))
+    z.mean2.copy_(t(g4["mean2"]))
+    x = std.log_mel_for_model(t(g["audio"]).to(DEV), z)      # end to end: PCM -> fused frontend -> res8 (T = 41)
+    model = make_res8(4, train=False)
+    with torch.no_grad():
+        ev = model(x, None)
+    assert maxerr(ev, g["eval_logits"]) < LOGIT_TOL and torch.equal(ev.argmax(1).cpu(), t(g["eval_logits"]).argmax(1))
+    model.train()
+    sc = model(x, None)
+    loss = torch.nn.functional.cross_entropy(sc, (torch.arange(6) % 4).to(DEV))
+    loss.backward()
+    assert maxerr(sc, g["train_logits"]) < LOGIT_TOL and abs(loss.item() - float(g["loss0"])) < 1e-4
+    for n in ("conv0.weight", "conv1.weight", "conv6.weight", "output.weight"):
+        p = dict(model.named_parameters())[n]
+        assert maxerr(p.grad, g["grad0." + n]) < 5e-5, n
+
+
+@pytest.mark.parametrize("B,L,C", [(64, 16000, 30), (256, 8000, 4), (512, 16000, 12)])
+def test_fused_step_vs_oracle_at_baseline_sizes(B, L, C):
+    """BASELINE configs 1-3 geometry: one fused training step (PCM in, updated weights out) against the oracle."""
+    from howl_amd.data.transform.operator import ZmuvTransform
+    from howl_amd.data.transform.transform import StandardAudioTransform
+    from howl_amd.training.fused import FusedRes8Trainer
+    from howl_amd.utils.synth import synthetic_pcm
+    pcm = synthetic_pcm(B, L)
+    labels = torch.arange(B) % C
+    std = StandardAudioTransform().to(DEV).eval()
+    zmuv = ZmuvTransform().to(DEV)
+    zmuv.update(std(pcm[:4].to(DEV)))
+    model = make_res8(C)
+    trainer = FusedRes8Trainer(model, std, zmuv, lr=0.01, weight_decay=1e-5)
+    loss = trainer.step(pcm.to(DEV), labels.to(DEV))
+    grads = [g.clone() for g in trainer.fp.grad_views]
+
+    fb = ofe.mel_fb(40)
+    z = ofe.Zmuv()
+    z.update(ofe.standard_audio_transform(pcm[:4], fb))
+    x = z(ofe.standard_audio_transform(pcm, fb))
+    sd = om.res8_init(C)
+    names = om.res8_param_names()
+    opt = om.AdamWState([sd[n] for n in names], 0.01, 1e-5)
+    ref_loss, ref_logits, ref_grads = om.train_step(lambda s, xx: om.res8_forward(s, xx, True), sd, names, opt, x, labels)
+    assert maxerr(trainer.last_logits, ref_logits) < LOGIT_TOL
+    assert torch.equal(trainer.last_logits.argmax(1).cpu(), ref_logits.argmax(1))
+    assert abs(loss.item() - ref_loss.item()) < 1e-4
+    for n, g in zip(names, grads):
+        ref = ref_grads[n]
+        assert maxerr(g, ref) < 5e-5 * max(1.0, ref.abs().max().item()), n
+    for n, p in zip(names, model.hot_parameters()):
+        assert maxerr(p, sd[n]) < 2e-4, n
+    for i in range(1, 7):
+        assert maxerr(getattr(model, f"bn{i}").running_var, sd[f"bn{i}.running_var"]) < 1e-4
+
+    # determinism: the same step from the same state gives bit-identical gradients
+    model2 = make_res8(C)
+    trainer2 = FusedRes8Trainer(model2, std, zmuv, lr=0.01, weight_decay=1e-5)
+    trainer2.step(pcm.to(DEV), labels.to(DEV))
+    assert torch.equal(trainer2.fp.grad, trainer.fp.grad) and torch.equal(trainer2.fp.flat, trainer.fp.flat)
+
+
+def test_loss_decreases_and_errors_are_loud():
+    from howl_amd.data.transform.operator import ZmuvTransform
+    from howl_amd.data.transform.transform import StandardAudioTransform
+    from howl_amd.training.fused import FusedRes8Trainer
+    from howl_amd.utils.synth import synthetic_pcm
+    B, C = 64, 12
+    pcm = synthetic_pcm(B, 16000).to(DEV)
+    labels = (torch.arange(B) % C).to(DEV)
+    std = StandardAudioTransform().to(DEV).eval()
+    zmuv = ZmuvTransform().to(DEV)
+    zmuv.update(std(pcm[:4]))
+    model = make_res8(C)
+    trainer = FusedRes8Trainer(model, std, zmuv, lr=0.01)
+    losses = [trainer.step(pcm, labels).item() for _ in range(30)]
+    assert losses[-1] < 0.5 * losses[0], losses
+    cpu_model = make_res8(C).cpu()
+    with pytest.raises(Exception):
+        cpu_model(torch.zeros(2, 1, 40, 81), None)            # no CPU fallback
+    with pytest.raises(Exception):
+        model(torch.zeros(2, 1, 40, 300, device=DEV), None)   # T beyond the supported window: error, not garbage

@@ -1,0 +1,76 @@
+"""CPU tests of the host-side logic (settings, registry, RNG protocol helpers, no-fallback guards)."""
+import importlib
+import os
+
+import pytest
+import torch
+
+
+def test_settings_env(monkeypatch):
+    from howl_amd import settings
+    monkeypatch.setenv("NUM_MELS", "40")
+    monkeypatch.setenv("VOCAB", '["hey","fire","fox"]')
+    monkeypatch.setenv("LEARNING_RATE", "0.01")
+    monkeypatch.setenv("USE_NOISE_DATASET", "False")
+    monkeypatch.setenv("INFERENCE_SEQUENCE", "[0,1,2]")
+    s = settings.HowlSettings()
+    assert s.audio_transform.num_mels == 40 and s.audio_transform.hop_length == 200
+    assert s.training.vocab == ["hey", "fire", "fox"] and s.training.learning_rate == 0.01
+    assert s.training.use_noise_dataset is False and s.inference_engine.inference_sequence == [0, 1, 2]
+    monkeypatch.delenv("NUM_MELS")
+    s.reset()
+    assert s.audio_transform.num_mels == 80   # the reference's default (settings.py:32)
+
+
+def test_registry_and_state_dict_keys():
+    from howl_amd.model import RegisteredModel
+    assert "res8" in RegisteredModel.registered_names()
+    with pytest.raises(KeyError):
+        RegisteredModel.find_registered_class("nope")
+    m = RegisteredModel.find_registered_class("res8")(12)
+    keys = list(m.state_dict().keys())
+    assert keys[:5] == ["conv0.weight", "bn1.running_mean", "bn1.running_var", "bn1.num_batches_tracked", "conv1.weight"]
+    assert keys[-2:] == ["output.weight", "output.bias"] and len(keys) == 27
+    assert sum(p.numel() for p in m.parameters()) == 110307
+    assert m.streaming().is_streaming and not m.static().is_streaming and m.compute_length(7) == 7
+
+
+def test_same_seed_same_init_as_reference_order():
+    """Construction order matches cnn.py:116-125, so a seed gives the weights a stock nn build would get."""
+    import torch.nn as nn
+    from howl_amd.model import RegisteredModel
+    torch.manual_seed(0)
+    m = RegisteredModel.find_registered_class("res8")(12)
+    torch.manual_seed(0)
+    conv0 = nn.Conv2d(1, 45, (3, 3), padding=(1, 1), bias=False)
+    convs = [nn.Conv2d(45, 45, (3, 3), padding=1, bias=False) for _ in range(6)]
+    out = nn.Linear(45, 12)
+    assert torch.equal(m.conv0.weight, conv0.weight) and torch.equal(m.conv6.weight, convs[5].weight)
+    assert torch.equal(m.output.weight, out.weight)
+
+
+def test_closed_form_matches_oracle_copy():
+    from howl_amd.utils.synth import res8_closed_form_state
+    from oracle import models as om
+    a, b = res8_closed_form_state(12), om.res8_init(12)
+    for k, v in a.items():
+        assert torch.equal(v, b[k]), k
+
+
+def test_vtlp_points_reproduce_reference_filterbank(golden):
+    """Host-side corner-point warp + the triangle formula == the reference's create_vtlp_fb_matrix goldens."""
+    from howl_amd.data.transform.transform import mel_corner_points, vtlp_warp_points
+    g = golden("g1_filterbanks")
+    all_freqs = torch.linspace(0, 8000, 257)
+    for a in g["alphas"]:
+        pts = vtlp_warp_points(mel_corner_points(40, 16000), float(a), 16000)
+        f_diff = pts[1:] - pts[:-1]
+        slopes = pts.unsqueeze(0) - all_freqs.unsqueeze(1)
+        fb = torch.max(torch.zeros(1), torch.min((-1.0 * slopes[:, :-2]) / f_diff[:-1], slopes[:, 2:] / f_diff[1:]))
+        assert torch.equal(fb, torch.from_numpy(g[f"fb_vtlp_{a}"])), a
+
+
+def test_no_cpu_fallback():
+    from howl_amd import lib, ops
+    with pytest.raises(lib.HowlHipError):
+        ops._p(torch.zeros(4))
