@@ -68,16 +68,28 @@ def cpu_baseline(L, C, budget_s):
         x = z(ofe.standard_audio_transform(pcm, fb))
         om.train_step(lambda s, xx: om.res8_forward(s, xx, True), sd, names, opt, x, labels)
 
-    for _ in range(2):
-        step()
-    t0 = time.perf_counter()
-    n = 0
-    while n < 3 or (time.perf_counter() - t0 < budget_s and n < 200):
-        step()
-        n += 1
-    dt = time.perf_counter() - t0
-    return {"value": round(B * n / dt, 1), "unit": "utterances/sec", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n} oracle training steps of batch {B} x {L / 16000:g} s (torch-CPU, {torch.get_num_threads()} threads)"}
+    # torch's default thread count (= physical cores) oversubscribes these small convolutions on a many-core host:
+    # time a few thread counts inside the budget and report the fastest, with the count used
+    default_threads = torch.get_num_threads()
+    candidates = sorted({min(default_threads, c) for c in (16, 32, 64)} | {default_threads})
+    best = None
+    for nthreads in candidates:
+        torch.set_num_threads(nthreads)
+        for _ in range(2):
+            step()
+        t0 = time.perf_counter()
+        n = 0
+        while n < 3 or (time.perf_counter() - t0 < budget_s / len(candidates) and n < 200):
+            step()
+            n += 1
+        dt = time.perf_counter() - t0
+        rate = B * n / dt
+        if best is None or rate > best[0]:
+            best = (rate, nthreads, n)
+    torch.set_num_threads(default_threads)
+    rate, nthreads, n = best
+    return {"value": round(rate, 1), "unit": "utterances/sec", "cores": nthreads, "kind": "port",
+            "sample": f"{n} oracle training steps of batch {B} x {L / 16000:g} s (torch-CPU, best of {candidates} threads)"}
 
 
 def main():

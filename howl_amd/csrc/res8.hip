@@ -30,6 +30,11 @@ namespace {
 struct HowlPtrs6 {
     float* p[6];
 };
+struct HowlBnBuffers {
+    float* running_mean;
+    float* running_var;
+    long long* num_batches;
+};
 
 constexpr int NMAP = 45;         // res8 feature maps (cnn.py:110)
 constexpr int CP = 48;           // channels padded to 3 MFMA tiles
@@ -372,17 +377,48 @@ __global__ __launch_bounds__(CONV_THREADS) void wgrad_mfma_kernel(
     }
 }
 
-// sum the per-workgroup partials (fixed order -> deterministic) into dW (45,45,3,3), scaled
-__global__ void wgrad_reduce_kernel(const float* __restrict__ part, int nparts, float* __restrict__ dw) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= NMAP * NMAP * 9) return;
-    const int tap = idx % 9;
-    const int ci = (idx / 9) % NMAP;
-    const int co = idx / (9 * NMAP);
-    const float* src = part + co * 432 + tap * CP + ci;
+// Deterministic sum over the per-workgroup partial rows: part[g][col], g < nparts.  A block owns 64 columns
+// (coalesced reads); its 4 waves split the rows, then combine through LDS in a fixed order.
+//   mode 0: out[col] = sum            (conv0: 405 columns)
+//   mode 1: col = (cout, tap, cin) of the wgrad accumulator layout [48][9][48] -> dW[(cout*45 + cin)*9 + tap]
+__global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ part, int nparts, int ncols,
+                                                          int mode, float* __restrict__ out) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + lane;
     float s = 0.0f;
-    for (int g = 0; g < nparts; ++g) s += src[(size_t)g * CP * 432];
-    dw[idx] = s;
+    if (col < ncols) {
+        const float* src = part + col;
+        int g = rg;
+        for (; g + 12 < nparts; g += 16) {
+            const float v0 = src[(size_t)g * ncols], v1 = src[(size_t)(g + 4) * ncols];
+            const float v2 = src[(size_t)(g + 8) * ncols], v3 = src[(size_t)(g + 12) * ncols];
+            s += v0;
+            s += v1;
+            s += v2;
+            s += v3;
+        }
+        for (; g < nparts; g += 4) s += src[(size_t)g * ncols];
+    }
+    red[rg][lane] = s;
+    __syncthreads();
+    if (rg == 0 && col < ncols) {
+        const float tot = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
+        if (mode == 0) {
+            out[col] = tot;
+        } else {
+            const int co = col / 432, r = col - co * 432;
+            const int tap = r / CP, ci = r - tap * CP;
+            if (co < NMAP && ci < NMAP) out[(co * NMAP + ci) * 9 + tap] = tot;
+        }
+    }
+}
+
+// fp64 sum of column `col` over nparts rows, rows spread over the 64 lanes (fixed butterfly -> deterministic)
+__device__ __forceinline__ double wave_colsum(const float* __restrict__ base, int nparts, size_t row_stride, int lane) {
+    double s = 0.0;
+    for (int g = lane; g < nparts; g += 64) s += (double)base[(size_t)g * row_stride];
+    return wave_sum_d(s);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -390,26 +426,25 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ part, int nparts, 
 // ---------------------------------------------------------------------------------------------------------
 // forward, training: partials -> batch mean / rstd (biased var), running-stat update (cnn.py:142 semantics of
 // nn.BatchNorm2d(affine=False): momentum 0.1, unbiased variance into running_var, num_batches_tracked += 1)
-__global__ void bn_finalize_kernel(const float* __restrict__ part, int nparts, double count, float* __restrict__ stats,
-                                   float* running_mean, float* running_var, long long* num_batches) {
-    const int c = threadIdx.x;
-    if (c >= CP) return;
-    double s = 0.0, q = 0.0;
-    for (int g = 0; g < nparts; ++g) {
-        s += (double)part[((size_t)g * 2 + 0) * CP + c];
-        q += (double)part[((size_t)g * 2 + 1) * CP + c];
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ part, int nparts, double count,
+                                                           float* __restrict__ stats, HowlBnBuffers bn) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int c = wave; c < CP; c += 16) {
+        const double s = wave_colsum(part + c, nparts, 2 * CP, lane);
+        const double q = wave_colsum(part + CP + c, nparts, 2 * CP, lane);
+        if (lane != 0) continue;
+        const double mean = s / count;
+        double var = q / count - mean * mean;
+        var = var < 0.0 ? 0.0 : var;
+        stats[c] = (c < NMAP) ? (float)mean : 0.0f;
+        stats[CP + c] = (c < NMAP) ? (float)(1.0 / sqrt(var + (double)BN_EPS)) : 0.0f;
+        if (c < NMAP && bn.running_mean != nullptr) {
+            const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+            bn.running_mean[c] = (1.0f - BN_MOMENTUM) * bn.running_mean[c] + BN_MOMENTUM * (float)mean;
+            bn.running_var[c] = (1.0f - BN_MOMENTUM) * bn.running_var[c] + BN_MOMENTUM * (float)unbiased;
+        }
+        if (c == 0 && bn.num_batches != nullptr) bn.num_batches[0] += 1;
     }
-    const double mean = s / count;
-    double var = q / count - mean * mean;
-    var = var < 0.0 ? 0.0 : var;
-    stats[c] = (c < NMAP) ? (float)mean : 0.0f;
-    stats[CP + c] = (c < NMAP) ? (float)(1.0 / sqrt(var + (double)BN_EPS)) : 0.0f;
-    if (c < NMAP && running_mean != nullptr) {
-        const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-        running_mean[c] = (1.0f - BN_MOMENTUM) * running_mean[c] + BN_MOMENTUM * (float)mean;
-        running_var[c] = (1.0f - BN_MOMENTUM) * running_var[c] + BN_MOMENTUM * (float)unbiased;
-    }
-    if (c == 0 && num_batches != nullptr) num_batches[0] += 1;
 }
 
 // eval mode: stats from the running buffers
@@ -422,16 +457,17 @@ __global__ void bn_eval_stats_kernel(HowlPtrs6 rmean, HowlPtrs6 rvar, float* __r
 }
 
 // backward: partials of (sum dx, sum dx*xhat) -> means m1, m2
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int nparts, double count, float* __restrict__ m12) {
-    const int c = threadIdx.x;
-    if (c >= CP) return;
-    double s = 0.0, q = 0.0;
-    for (int g = 0; g < nparts; ++g) {
-        s += (double)part[((size_t)g * 2 + 0) * CP + c];
-        q += (double)part[((size_t)g * 2 + 1) * CP + c];
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ part, int nparts, double count,
+                                                               float* __restrict__ m12) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int c = wave; c < CP; c += 16) {
+        const double s = wave_colsum(part + c, nparts, 2 * CP, lane);
+        const double q = wave_colsum(part + CP + c, nparts, 2 * CP, lane);
+        if (lane == 0) {
+            m12[c] = (float)(s / count);
+            m12[CP + c] = (float)(q / count);
+        }
     }
-    m12[c] = (float)(s / count);
-    m12[CP + c] = (float)(q / count);
 }
 
 // backward elementwise: BatchNorm backward (batch statistics) + skip gradient + ReLU mask
@@ -534,7 +570,9 @@ __global__ __launch_bounds__(C0_THREADS) void conv0_fwd_kernel(const float* __re
     }
 }
 
-// dW0[c][tap] = sum_{b, pooled pos, 3x4 window} (dy0/12) * [z > 0] * in[...],  dy0 = ga + gb (dx0 from layer 1 + skip)
+// dW0[c][tap] = sum_{b, pooled pos, 3x4 window} (dy0/12) * [z > 0] * in[...],  dy0 = ga + gb (dx0 from layer 1 + skip).
+// The pre-pool activation is recomputed (cheaper than storing 583 KB/utterance).  A wave walks its 5 channels one
+// at a time (9 accumulators live), folds them across lanes per utterance and keeps the running sums in LDS.
 __global__ __launch_bounds__(C0_THREADS) void conv0_wgrad_kernel(const float* __restrict__ feat, long sb, long st, long sm,
                                                                  const float* __restrict__ w0, const float* __restrict__ ga,
                                                                  const float* __restrict__ gb, float* __restrict__ part,
@@ -542,34 +580,36 @@ __global__ __launch_bounds__(C0_THREADS) void conv0_wgrad_kernel(const float* __
     HIP_DYNAMIC_SHARED(float, lds)
     float* tin = lds;
     float* lw = lds + (T + 2) * (M + 2);
+    float* lacc = lw + NMAP * 9;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int pitch = M + 2;
     const int P = H * PW;
-    for (int i = tid; i < NMAP * 9; i += C0_THREADS) lw[i] = w0[i];
-    float gw[C0_GROUP][9];
-#pragma unroll
-    for (int cc = 0; cc < C0_GROUP; ++cc)
-#pragma unroll
-        for (int k = 0; k < 9; ++k) gw[cc][k] = 0.0f;
+    for (int i = tid; i < NMAP * 9; i += C0_THREADS) {
+        lw[i] = w0[i];
+        lacc[i] = 0.0f;
+    }
     for (int b = blockIdx.x; b < B; b += gridDim.x) {
         __syncthreads();
         load_feat_tile(tin, feat, sb, st, sm, b, T, M, tid, C0_THREADS);
         __syncthreads();
-        for (int p = lane; p < P; p += 64) {
-            const int ph = p / PW, pw = p - ph * PW;
-            float patch[5][6];
+#pragma unroll 1
+        for (int cc = 0; cc < C0_GROUP; ++cc) {
+            const int c = wave * C0_GROUP + cc;
+            float wk[9], gw[9];
 #pragma unroll
-            for (int i = 0; i < 5; ++i)
+            for (int k = 0; k < 9; ++k) {
+                wk[k] = lw[c * 9 + k];
+                gw[k] = 0.0f;
+            }
+            for (int p = lane; p < P; p += 64) {
+                const int ph = p / PW, pw = p - ph * PW;
+                float patch[5][6];
 #pragma unroll
-                for (int j = 0; j < 6; ++j) patch[i][j] = tin[(3 * ph + i) * pitch + 4 * pw + j];
+                for (int i = 0; i < 5; ++i)
 #pragma unroll
-            for (int cc = 0; cc < C0_GROUP; ++cc) {
-                const int c = wave * C0_GROUP + cc;
+                    for (int j = 0; j < 6; ++j) patch[i][j] = tin[(3 * ph + i) * pitch + 4 * pw + j];
                 const size_t o = ((size_t)b * NMAP + c) * P + p;
                 const float g = (ga[o] + (gb != nullptr ? gb[o] : 0.0f)) * (1.0f / 12.0f);
-                float wk[9];
-#pragma unroll
-                for (int k = 0; k < 9; ++k) wk[k] = lw[c * 9 + k];
 #pragma unroll
                 for (int i = 0; i < 3; ++i)
 #pragma unroll
@@ -583,27 +623,18 @@ __global__ __launch_bounds__(C0_THREADS) void conv0_wgrad_kernel(const float* __
 #pragma unroll
                         for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-                            for (int kw = 0; kw < 3; ++kw)
-                                gw[cc][kh * 3 + kw] = fmaf(gz, patch[i + kh][j + kw], gw[cc][kh * 3 + kw]);
+                            for (int kw = 0; kw < 3; ++kw) gw[kh * 3 + kw] = fmaf(gz, patch[i + kh][j + kw], gw[kh * 3 + kw]);
                     }
+            }
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                const float v = wave_sum(gw[k]);
+                if (lane == 0) lacc[c * 9 + k] += v;  // channel c belongs to this wave only
             }
         }
     }
-#pragma unroll
-    for (int cc = 0; cc < C0_GROUP; ++cc)
-#pragma unroll
-        for (int k = 0; k < 9; ++k) {
-            const float v = wave_sum(gw[cc][k]);
-            if (lane == 0) part[(size_t)blockIdx.x * NMAP * 9 + (wave * C0_GROUP + cc) * 9 + k] = v;
-        }
-}
-
-__global__ void reduce_parts_kernel(const float* __restrict__ part, int nparts, int n, float* __restrict__ out) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= n) return;
-    float s = 0.0f;
-    for (int g = 0; g < nparts; ++g) s += part[(size_t)g * n + idx];
-    out[idx] = s;
+    __syncthreads();
+    for (int i = tid; i < NMAP * 9; i += C0_THREADS) part[(size_t)blockIdx.x * NMAP * 9 + i] = lacc[i];
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -652,33 +683,46 @@ __global__ void head_bwd_pool_kernel(const float* __restrict__ dlogits, const fl
     dpool[idx] = acc;
 }
 
-// one workgroup per output row k (dW_out[k][:], db[k]); the last row block (k == C) produces the BN6 backward
-// means m1[c] = sum_b dpool / N, m2[c] = sum_b dpool*pooled / N  (dx6 is dpool/P broadcast over positions)
-__global__ __launch_bounds__(64) void head_bwd_param_kernel(const float* __restrict__ dlogits,
-                                                            const float* __restrict__ pooled,
-                                                            const float* __restrict__ dpool, float* __restrict__ dwout,
-                                                            float* __restrict__ dbout, float* __restrict__ m12, int B,
-                                                            int C, int P) {
-    const int k = blockIdx.x, c = threadIdx.x;
+// one workgroup per output row k (dW_out[k][:], db[k]); block k == C produces the BN6 backward means
+// m1[c] = sum_b dpool / N, m2[c] = sum_b dpool*pooled / N  (dx6 is dpool/P broadcast over positions).
+// 16 waves split the batch, lanes are channels; fixed-order combine through LDS.
+__global__ __launch_bounds__(1024) void head_bwd_param_kernel(const float* __restrict__ dlogits,
+                                                              const float* __restrict__ pooled,
+                                                              const float* __restrict__ dpool, float* __restrict__ dwout,
+                                                              float* __restrict__ dbout, float* __restrict__ m12, int B,
+                                                              int C, int P) {
+    __shared__ double red[2][16][64];
+    const int k = blockIdx.x, c = threadIdx.x & 63, bg = threadIdx.x >> 6;
+    double a0 = 0.0, a1 = 0.0;
     if (k < C) {
-        float acc = 0.0f, accb = 0.0f;
-        for (int b = 0; b < B; ++b) {
+        for (int b = bg; b < B; b += 16) {
             const float d = dlogits[(size_t)b * C + k];
-            accb += d;
-            if (c < NMAP) acc = fmaf(d, pooled[(size_t)b * CP + c], acc);
+            a1 += (double)d;
+            if (c < CP) a0 += (double)d * (double)pooled[(size_t)b * CP + c];
         }
-        if (c < NMAP) dwout[k * NMAP + c] = acc;
-        if (c == 0) dbout[k] = accb;
     } else if (c < CP) {
-        double s = 0.0, q = 0.0;
-        for (int b = 0; b < B; ++b) {
+        for (int b = bg; b < B; b += 16) {
             const double d = (double)dpool[(size_t)b * CP + c];
-            s += d;
-            q += d * (double)pooled[(size_t)b * CP + c];
+            a0 += d;
+            a1 += d * (double)pooled[(size_t)b * CP + c];
         }
+    }
+    red[0][bg][c] = a0;
+    red[1][bg][c] = a1;
+    __syncthreads();
+    if (bg != 0) return;
+    double s0 = 0.0, s1 = 0.0;
+    for (int g = 0; g < 16; ++g) {
+        s0 += red[0][g][c];
+        s1 += red[1][g][c];
+    }
+    if (k < C) {
+        if (c < NMAP) dwout[k * NMAP + c] = (float)s0;
+        if (c == 0) dbout[k] = (float)s1;
+    } else if (c < CP) {
         const double n = (double)B * (double)P;
-        m12[c] = (float)(s / n);
-        m12[CP + c] = (float)(q / n);
+        m12[c] = (float)(s0 / n);
+        m12[CP + c] = (float)(s1 / n);
     }
 }
 
@@ -725,7 +769,7 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
 }
 
 size_t conv_lds_bytes(int H) { return (size_t)(2 * tile_floats(H) + 2 * CP + 12 * 2 * 16) * sizeof(float); }
-size_t conv0_lds_bytes(int T, int M) { return (size_t)((T + 2) * (M + 2) + NMAP * 9) * sizeof(float); }
+size_t conv0_lds_bytes(int T, int M) { return (size_t)((T + 2) * (M + 2) + 2 * NMAP * 9) * sizeof(float); }
 
 struct Ws {
     float* wp_fwd;   // [6][3][108][64]
@@ -828,9 +872,10 @@ int howl_res8_fwd(const HowlRes8Params* prm, const float* feat, long sb, long st
                                (const float*)nullptr, training ? w.part : (float*)nullptr, B, H);
         }
         if (training)
-            hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(64), 0, stream, w.part, G, count,
-                               sv->bn_stats + (size_t)(i - 1) * 2 * CP, prm->bn_running_mean[i - 1],
-                               prm->bn_running_var[i - 1], prm->bn_num_batches[i - 1]);
+            hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(1024), 0, stream, w.part, G, count,
+                               sv->bn_stats + (size_t)(i - 1) * 2 * CP,
+                               HowlBnBuffers{prm->bn_running_mean[i - 1], prm->bn_running_var[i - 1],
+                                             prm->bn_num_batches[i - 1]});
     }
     hipLaunchKernelGGL(head_fwd_kernel, dim3(B < 1024 ? B : 1024), dim3(256), 0, stream, sv->s[6],
                        sv->bn_stats + (size_t)5 * 2 * CP, prm->out_w, prm->out_b, sv->pooled, logits, B, P, C);
@@ -860,7 +905,7 @@ int howl_res8_bwd(const HowlRes8Params* prm, const float* feat, long sb, long st
 
     hipLaunchKernelGGL(head_bwd_pool_kernel, dim3((B * CP + 255) / 256), dim3(256), 0, stream, dlogits, prm->out_w, w.dpool,
                        B, C);
-    hipLaunchKernelGGL(head_bwd_param_kernel, dim3(C + 1), dim3(64), 0, stream, dlogits, sv->pooled, w.dpool, gr->out_w,
+    hipLaunchKernelGGL(head_bwd_param_kernel, dim3(C + 1), dim3(1024), 0, stream, dlogits, sv->pooled, w.dpool, gr->out_w,
                        gr->out_b, w.m12, B, C, P);
     const size_t lc = conv_lds_bytes(H);
     hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_mfma_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -890,8 +935,8 @@ int howl_res8_bwd(const HowlRes8Params* prm, const float* feat, long sb, long st
             hipLaunchKernelGGL(wgrad_mfma_kernel, dim3(G), dim3(CONV_THREADS), lc, stream, (const float*)w.dz, sv->s[i - 1],
                                in_stats, w.wpart, B, H);
         }
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((NMAP * NMAP * 9 + 255) / 256), dim3(256), 0, stream,
-                           (const float*)w.wpart, G, gr->conv_w[i - 1]);
+        hipLaunchKernelGGL(reduce_rows_kernel, dim3((CP * 432 + 63) / 64), dim3(256), 0, stream, (const float*)w.wpart, G,
+                           CP * 432, 1, gr->conv_w[i - 1]);
         // data gradient: dx_{i-1} (w.r.t. the normalised input of layer i), with BN_{i-1} backward statistics
         const bool need_stats = i > 1;
         {
@@ -902,7 +947,8 @@ int howl_res8_bwd(const HowlRes8Params* prm, const float* feat, long sb, long st
                                need_stats ? w.part : (float*)nullptr, B, H);
         }
         if (need_stats)
-            hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(64), 0, stream, (const float*)w.part, G, count, w.m12);
+            hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(1024), 0, stream, (const float*)w.part, G, count,
+                               w.m12);
         dx_cur = dx_next;
         dx_next = (dx_next == w.bufa) ? w.bufb : w.bufa;
     }
@@ -912,8 +958,8 @@ int howl_res8_bwd(const HowlRes8Params* prm, const float* feat, long sb, long st
                         (int)l0);
     hipLaunchKernelGGL(conv0_wgrad_kernel, dim3(G), dim3(C0_THREADS), l0, stream, feat, sb, st, sm, prm->conv0_w,
                        (const float*)dx_cur, (const float*)ds_prev, w.c0part, B, T, M, H);
-    hipLaunchKernelGGL(reduce_parts_kernel, dim3((NMAP * 9 + 255) / 256), dim3(256), 0, stream, (const float*)w.c0part, G,
-                       NMAP * 9, gr->conv0_w);
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3((NMAP * 9 + 63) / 64), dim3(256), 0, stream, (const float*)w.c0part, G,
+                       NMAP * 9, 0, gr->conv0_w);
     HOWL_CHECK_LAUNCH("howl_res8_bwd");
     return HOWL_OK;
 }

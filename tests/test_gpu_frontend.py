@@ -104,7 +104,9 @@ def test_full_size_properties(std):
     idx = [0, 1, 63, 200, 511]
     logmel_close(out[idx], ofe.standard_audio_transform(pcm[idx], ofe.mel_fb(40), mels_only=True))
     alone = std(pcm[200:201].to(DEV), mels_only=True)
-    assert torch.equal(alone[0], out[200])                     # batch-composition invariance, bit for bit
+    # two frames share one complex FFT, and which neighbour a frame is paired with depends on its flattened index,
+    # so batch composition changes results at rounding level only
+    assert maxerr(alone[0], out[200]) < 2e-5
     from howl_amd import ops
     tm = ops.logmel(pcm.to(DEV), std._standard_fb(), 40, None, layout=1)
     assert torch.equal(tm.permute(0, 2, 1), out)               # the two layouts are the same numbers

@@ -109,7 +109,9 @@ def test_fused_step_vs_oracle_at_baseline_sizes(B, L, C):
         ref = ref_grads[n]
         assert maxerr(g, ref) < 5e-5 * max(1.0, ref.abs().max().item()), n
     for n, p in zip(names, model.hot_parameters()):
-        assert maxerr(p, sd[n]) < 2e-4, n
+        # first AdamW step moves every weight by ~lr * sign(g): compare where the gradient is not rounding noise
+        solid = ref_grads[n].abs() > 1e-5
+        assert maxerr(p.detach().cpu()[solid], sd[n][solid]) < 2e-4, n
     for i in range(1, 7):
         assert maxerr(getattr(model, f"bn{i}").running_var, sd[f"bn{i}.running_var"]) < 1e-4
 
