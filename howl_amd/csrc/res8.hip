@@ -207,15 +207,27 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_mfma_kernel(
             const int h0 = m0 / PW;
             const float* a0 = tile + (lane >> 4) * CS + h0 * WP + (m0 - h0 * PW);
             f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+            // software pipeline: the 9 A fragments of cin block c0+1 are in flight while block c0 multiplies
+            float acur[9], anxt[9];
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) acur[tap] = a0[(tap / 3) * WP + (tap % 3)];
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int c0 = 0; c0 < 12; ++c0) {
-#pragma unroll
-                for (int tap = 0; tap < 9; ++tap) {
-                    const int off = (tap / 3) * WP + (tap % 3);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[off], wreg[c0 * 9 + tap], acc, 0, 0, 0);
-                }
                 a0 += 4 * CS;
-                __builtin_amdgcn_sched_barrier(0);  // keep the A-fragment loads of one cin block from piling up
+                if (c0 < 11) {
+#pragma unroll
+                    for (int tap = 0; tap < 9; ++tap) anxt[tap] = a0[(tap / 3) * WP + (tap % 3)];
+                }
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap)
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(acur[tap], wreg[c0 * 9 + tap], acc, 0, 0, 0);
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) acur[tap] = anxt[tap];
+                // pin the order "next block's DS reads, then this block's 9 MFMAs" (hipcc otherwise sinks the reads
+                // to just before their use and the wave stalls on LDS latency three times per block)
+                __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 9, 0);
             }
             // epilogue: lane holds cout = 16nt + (lane&15), positions 16j + 4*(lane>>4) + {0,1,2,3}
             const int mbase = 16 * j + 4 * (lane >> 4);
@@ -308,7 +320,7 @@ __global__ __launch_bounds__(CONV_THREADS) void wgrad_mfma_kernel(
         const int tap = (q < 27) ? q / 3 : 0, ct = (q < 27) ? q % 3 : 0;
         boff[i] = (16 * ct + (lane & 15)) * CS + (tap / 3) * WP + (tap % 3);  // cin row + tap shift (halo origin)
     }
-    const bool has3 = wave + 24 < 27;
+    const bool has3 = __builtin_amdgcn_readfirstlane(wave) + 24 < 27;  // wave-uniform: a scalar branch, not exec masking
     const int aoff = (lane & 15) * CS + WP + 1;  // cout row, interior origin
 
     float2 pz[PREF], px[PREF];
@@ -329,16 +341,25 @@ __global__ __launch_bounds__(CONV_THREADS) void wgrad_mfma_kernel(
             prefetch_tile(pz, dz + (size_t)bn * NMAP * P, n2, tid);
             prefetch_tile(px, s_prev + (size_t)bn * NMAP * P, n2, tid);
         }
-        // K loop over positions, 4 per MFMA: this lane feeds position p = 4*kk + (lane >> 4)
-        int p = lane >> 4;
-        int h = 0, w = p;  // p < 4 < PW
+        // K loop over positions, 4 per MFMA: this lane feeds position p = 4*kk + (lane >> 4).  Operands of step
+        // kk+1 are loaded before the MFMAs of step kk (software pipeline), so LDS latency hides under the matrix pipe.
+        int h = 0, w = lane >> 4;  // p < 4 < PW
+        int pos = h * WP + w;      // positions >= P land in the zero bottom halo row
+        float az0 = tz[aoff + pos], az1 = tz[aoff + 16 * CS + pos], az2 = tz[aoff + 32 * CS + pos];
+        float bx0 = tx[boff[0] + pos], bx1 = tx[boff[1] + pos], bx2 = has3 ? tx[boff[2] + pos] : 0.0f;
         for (int kk = 0; kk < ksteps; ++kk) {
-            const int pos = h * WP + w;  // positions >= P land in the zero bottom halo row
-            const float az0 = tz[aoff + pos];
-            const float az1 = tz[aoff + 16 * CS + pos];
-            const float az2 = tz[aoff + 32 * CS + pos];
-            const float bx0 = tx[boff[0] + pos];
-            const float bx1 = tx[boff[1] + pos];
+            if (kk + 1 < ksteps) {
+                w += 4;
+                if (w >= PW) {
+                    w -= PW;
+                    h += 1;
+                }
+                pos = h * WP + w;
+            }
+            const float nz0 = tz[aoff + pos], nz1 = tz[aoff + 16 * CS + pos], nz2 = tz[aoff + 32 * CS + pos];
+            const float nx0 = tx[boff[0] + pos], nx1 = tx[boff[1] + pos];
+            float nx2 = 0.0f;
+            if (has3) nx2 = tx[boff[2] + pos];
             acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(az0, bx0, acc[0][0], 0, 0, 0);
             acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(az1, bx0, acc[0][1], 0, 0, 0);
             acc[0][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(az2, bx0, acc[0][2], 0, 0, 0);
@@ -346,16 +367,16 @@ __global__ __launch_bounds__(CONV_THREADS) void wgrad_mfma_kernel(
             acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(az1, bx1, acc[1][1], 0, 0, 0);
             acc[1][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(az2, bx1, acc[1][2], 0, 0, 0);
             if (has3) {
-                const float bx2 = tx[boff[2] + pos];
                 acc[2][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(az0, bx2, acc[2][0], 0, 0, 0);
                 acc[2][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(az1, bx2, acc[2][1], 0, 0, 0);
                 acc[2][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(az2, bx2, acc[2][2], 0, 0, 0);
             }
-            w += 4;
-            if (w >= PW) {
-                w -= PW;
-                h += 1;
-            }
+            az0 = nz0;
+            az1 = nz1;
+            az2 = nz2;
+            bx0 = nx0;
+            bx1 = nx1;
+            bx2 = nx2;
         }
         __syncthreads();  // single-buffered tiles: everyone done before the next stage overwrites them
     }
@@ -414,11 +435,27 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restric
     }
 }
 
-// fp64 sum of column `col` over nparts rows, rows spread over the 64 lanes (fixed butterfly -> deterministic)
-__device__ __forceinline__ double wave_colsum(const float* __restrict__ base, int nparts, size_t row_stride, int lane) {
-    double s = 0.0;
-    for (int g = lane; g < nparts; g += 64) s += (double)base[(size_t)g * row_stride];
-    return wave_sum_d(s);
+// Column sums of the [nparts][2][48] statistics partials in fp64, deterministic: thread (col = tid % 96, rg = tid / 96)
+// adds rows rg, rg+10, ... (coalesced 384-byte rows), then the 10 row groups are combined in a fixed order.
+// Returns (sum stat0[c], sum stat1[c]) to threads c < 48.
+__device__ __forceinline__ void stats_colsum(const float* __restrict__ part, int nparts, double (*red)[2 * CP],
+                                             double& s, double& q) {
+    const int tid = threadIdx.x;
+    const int col = tid % (2 * CP), rg = tid / (2 * CP);
+    if (rg < 10) {
+        double a = 0.0;
+        for (int g = rg; g < nparts; g += 10) a += (double)part[(size_t)g * 2 * CP + col];
+        red[rg][col] = a;
+    }
+    __syncthreads();
+    s = 0.0;
+    q = 0.0;
+    if (tid < CP) {
+        for (int g = 0; g < 10; ++g) {
+            s += red[g][tid];
+            q += red[g][CP + tid];
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -428,23 +465,22 @@ __device__ __forceinline__ double wave_colsum(const float* __restrict__ base, in
 // nn.BatchNorm2d(affine=False): momentum 0.1, unbiased variance into running_var, num_batches_tracked += 1)
 __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ part, int nparts, double count,
                                                            float* __restrict__ stats, HowlBnBuffers bn) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int c = wave; c < CP; c += 16) {
-        const double s = wave_colsum(part + c, nparts, 2 * CP, lane);
-        const double q = wave_colsum(part + CP + c, nparts, 2 * CP, lane);
-        if (lane != 0) continue;
-        const double mean = s / count;
-        double var = q / count - mean * mean;
-        var = var < 0.0 ? 0.0 : var;
-        stats[c] = (c < NMAP) ? (float)mean : 0.0f;
-        stats[CP + c] = (c < NMAP) ? (float)(1.0 / sqrt(var + (double)BN_EPS)) : 0.0f;
-        if (c < NMAP && bn.running_mean != nullptr) {
-            const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-            bn.running_mean[c] = (1.0f - BN_MOMENTUM) * bn.running_mean[c] + BN_MOMENTUM * (float)mean;
-            bn.running_var[c] = (1.0f - BN_MOMENTUM) * bn.running_var[c] + BN_MOMENTUM * (float)unbiased;
-        }
-        if (c == 0 && bn.num_batches != nullptr) bn.num_batches[0] += 1;
+    __shared__ double red[10][2 * CP];
+    double s, q;
+    stats_colsum(part, nparts, red, s, q);
+    const int c = threadIdx.x;
+    if (c >= CP) return;
+    const double mean = s / count;
+    double var = q / count - mean * mean;
+    var = var < 0.0 ? 0.0 : var;
+    stats[c] = (c < NMAP) ? (float)mean : 0.0f;
+    stats[CP + c] = (c < NMAP) ? (float)(1.0 / sqrt(var + (double)BN_EPS)) : 0.0f;
+    if (c < NMAP && bn.running_mean != nullptr) {
+        const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+        bn.running_mean[c] = (1.0f - BN_MOMENTUM) * bn.running_mean[c] + BN_MOMENTUM * (float)mean;
+        bn.running_var[c] = (1.0f - BN_MOMENTUM) * bn.running_var[c] + BN_MOMENTUM * (float)unbiased;
     }
+    if (c == 0 && bn.num_batches != nullptr) bn.num_batches[0] += 1;
 }
 
 // eval mode: stats from the running buffers
@@ -459,14 +495,13 @@ __global__ void bn_eval_stats_kernel(HowlPtrs6 rmean, HowlPtrs6 rvar, float* __r
 // backward: partials of (sum dx, sum dx*xhat) -> means m1, m2
 __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ part, int nparts, double count,
                                                                float* __restrict__ m12) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int c = wave; c < CP; c += 16) {
-        const double s = wave_colsum(part + c, nparts, 2 * CP, lane);
-        const double q = wave_colsum(part + CP + c, nparts, 2 * CP, lane);
-        if (lane == 0) {
-            m12[c] = (float)(s / count);
-            m12[CP + c] = (float)(q / count);
-        }
+    __shared__ double red[10][2 * CP];
+    double s, q;
+    stats_colsum(part, nparts, red, s, q);
+    const int c = threadIdx.x;
+    if (c < CP) {
+        m12[c] = (float)(s / count);
+        m12[CP + c] = (float)(q / count);
     }
 }
 

@@ -79,6 +79,7 @@ int hipemu_lane();
 static inline void __syncthreads() { hipemu_syncthreads(); }
 static inline void __builtin_amdgcn_s_barrier() { hipemu_syncthreads(); }
 static inline void __builtin_amdgcn_sched_barrier(int) {}
+static inline void __builtin_amdgcn_sched_group_barrier(int, int, int) {}
 static inline void __builtin_amdgcn_s_setprio(int) {}
 static inline void __threadfence() {}
 

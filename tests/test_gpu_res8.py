@@ -47,7 +47,7 @@ def test_golden_eval_and_train(golden, C):
         opt.step()
     sd = model.state_dict()
     for k, v in sd.items():
-        assert maxerr(v, g["sd3." + k]) < 1e-4, k
+        assert maxerr(v, g["sd3." + k]) < 1e-4 * max(1.0, float(np.abs(g["sd3." + k]).max())), k
     assert int(sd["bn3.num_batches_tracked"]) == 3
     model.eval()
     with torch.no_grad():

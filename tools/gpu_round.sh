@@ -12,3 +12,4 @@ echo "== rocprof" ; cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof -o r01 -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-roofline > $GRAFT_REPO_ROOT/gpurun_out/rocprof.log 2>&1
 cd $GRAFT_REPO_ROOT
 find gpurun_out/prof -name "*stats*" | head; f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -30 "$f"
+echo "== kernel scaling"; timeout 300 python tools/kernel_scaling.py 2>&1 | tee gpurun_out/kernel_scaling.log | tail -6
