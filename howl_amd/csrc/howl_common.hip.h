@@ -5,6 +5,9 @@
 #include <stdio.h>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+// explicit LDS (address space 3) pointer: keeps pointer arithmetic on tile addresses as ds_read with immediate
+// offsets (a generic float* that the optimiser cannot trace back to LDS degrades to flat_load)
+typedef __attribute__((address_space(3))) float lds_f32;
 
 #define HOWL_OK 0
 #define HOWL_E_ARG (-1)       // bad argument (shape / null pointer / unsupported size)

@@ -132,6 +132,84 @@ __device__ __forceinline__ void prefetch_tile(float2 (&pre)[PREF], const float* 
     }
 }
 
+// One wave's share of an utterance: NTW position tiles (j = mg, mg+4, ...) of cout tile nt, all NTW accumulator
+// chains advanced together so that one weight fragment read feeds NTW MFMAs and the chains hide each other's latency.
+//   A[position][k] from the zero-haloed activation tile, B[k][cout] from the packed weights in LDS.
+template <int NTW>
+__device__ __forceinline__ void conv_tiles(const lds_f32* tile, const lds_f32* wl, int CS, int P, int mg, int lane,
+                                           f32x4 (&acc)[NTW]) {
+    const lds_f32* ap[NTW];
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) {
+        int m = 16 * (mg + 4 * i) + (lane & 15);
+        m = m < P ? m : P - 1;  // the last tile may overhang: clamp the read, the store is masked
+        const int h = m / PW;
+        ap[i] = tile + (lane >> 4) * CS + h * WP + (m - h * PW);
+        acc[i] = {0.0f, 0.0f, 0.0f, 0.0f};
+    }
+    const lds_f32* bp = wl + lane;
+    for (int c0 = 0; c0 < 12; ++c0) {
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const float b = bp[tap * 64];
+            const int off = (tap / 3) * WP + (tap % 3);
+#pragma unroll
+            for (int i = 0; i < NTW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[i][off], b, acc[i], 0, 0, 0);
+        }
+        bp += 9 * 64;
+#pragma unroll
+        for (int i = 0; i < NTW; ++i) ap[i] += 4 * CS;
+    }
+}
+
+struct ConvEpilogue {
+    const float* res;
+    float* y_out;
+    float* out;
+    const float* xs;
+    float xmean, xrstd;
+    int cout, P;
+    bool cvalid;
+};
+
+// MFMA phase + epilogue for one utterance; lane holds cout = 16nt + (lane&15) and, for tile j = mg + 4i, positions
+// 16j + 4*(lane>>4) + {0,1,2,3}
+template <int MODE, int NTW>
+__device__ __forceinline__ void conv_utterance(const lds_f32* tile, const lds_f32* wl, int CS, int mg, int lane,
+                                               size_t ubase, const ConvEpilogue& e, float& st0, float& st1) {
+    f32x4 acc[NTW];
+    conv_tiles<NTW>(tile, wl, CS, e.P, mg, lane, acc);
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) {
+        const int mbase = 16 * (mg + 4 * i) + 4 * (lane >> 4);
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const int m = mbase + 2 * hh;
+            if (e.cvalid && m < e.P) {
+                const size_t o = ubase + (size_t)e.cout * e.P + m;
+                float v0 = acc[i][2 * hh], v1 = acc[i][2 * hh + 1];
+                if (MODE == 0) {
+                    v0 = fmaxf(v0, 0.0f);
+                    v1 = fmaxf(v1, 0.0f);
+                    if (e.y_out != nullptr) *reinterpret_cast<float2*>(e.y_out + o) = make_float2(v0, v1);
+                    if (e.res != nullptr) {
+                        const float2 r = *reinterpret_cast<const float2*>(e.res + o);
+                        v0 += r.x;
+                        v1 += r.y;
+                    }
+                    st0 += v0 + v1;
+                    st1 += v0 * v0 + v1 * v1;
+                } else if (e.xs != nullptr) {
+                    const float2 sv = *reinterpret_cast<const float2*>(e.xs + o);
+                    st0 += v0 + v1;
+                    st1 += v0 * ((sv.x - e.xmean) * e.xrstd) + v1 * ((sv.y - e.xmean) * e.xrstd);
+                }
+                *reinterpret_cast<float2*>(e.out + o) = make_float2(v0, v1);
+            }
+        }
+    }
+}
+
 // MODE 0: forward   out = relu(conv(x)) [+ res]; stats = (sum, sumsq) of out per cout
 // MODE 1: dgrad     out = conv(x);               stats = (sum out, sum out * xhat) per cout, xhat from s_prev
 template <int MODE>
@@ -150,28 +228,25 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_mfma_kernel(
     const int P = H * PW;
     const int CS = chan_stride(H);
     const int TF = tile_floats(H);
-    float* tile0 = lds;
-    float* tile1 = lds + TF;
-    float* lmean = lds + 2 * TF;
+    float* wl = lds;                       // [3][108][64] weight fragments, 82,944 B
+    float* tile = lds + 3 * KSTEPS * 64;   // one utterance's zero-haloed input map
+    float* lmean = tile + TF;
     float* lrstd = lmean + CP;
     float* red = lrstd + CP;  // [12][2][16]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int nt = wave % 3;
-    const int mg = wave / 3;
+    const int nt = __builtin_amdgcn_readfirstlane(wave % 3);
+    const int mg = __builtin_amdgcn_readfirstlane(wave / 3);
     const int n2 = NMAP * P / 2;
     const int ntiles = (P + 15) / 16;
+    const int ntw = (ntiles - mg + 3) / 4;  // tiles j = mg, mg+4, ... < ntiles (wave-uniform, <= 5)
     const bool affine = in_stats != nullptr;
 
-    float wreg[KSTEPS];
-    {
-        const float* wsrc = wp + (size_t)nt * KSTEPS * 64 + lane;
-#pragma unroll
-        for (int k = 0; k < KSTEPS; ++k) wreg[k] = wsrc[k * 64];
-    }
-    zero_lds(lds, 2 * TF, tid, CONV_THREADS);
+    for (int i = tid; i < 3 * KSTEPS * 16; i += CONV_THREADS)
+        reinterpret_cast<float4*>(wl)[i] = reinterpret_cast<const float4*>(wp)[i];
+    zero_lds(tile, TF, tid, CONV_THREADS);
     if (tid < CP) {
         lmean[tid] = affine ? in_stats[tid] : 0.0f;
         lrstd[tid] = affine ? in_stats[CP + tid] : 1.0f;
@@ -184,79 +259,33 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_mfma_kernel(
         xrstd = xs_stats[CP + cout];
     }
     float st0 = 0.0f, st1 = 0.0f;
+    const ConvEpilogue epi{res, y_out, out, xs, xmean, xrstd, cout, P, cvalid};
 
     float2 pre[PREF];
     int pk[PREF];
     stage_slots(pk, P, CS, n2, tid);
     int b = blockIdx.x;
     if (b < B) prefetch_tile(pre, in + (size_t)b * NMAP * P, n2, tid);
-    __syncthreads();  // zero fill + stats visible before the first stage
+    __syncthreads();  // weights, zero fill and stats visible before the first stage
 
-    int it = 0;
-    for (; b < B; b += gridDim.x, ++it) {
-        float* tile = (it & 1) ? tile1 : tile0;
+    for (; b < B; b += gridDim.x) {
         stage_tile(pre, pk, tile, lmean, lrstd, affine);
         __syncthreads();
         const int bn = b + gridDim.x;
         if (bn < B) prefetch_tile(pre, in + (size_t)bn * NMAP * P, n2, tid);
 
+        const lds_f32* ltile = (const lds_f32*)tile;
+        const lds_f32* wnt = (const lds_f32*)wl + nt * KSTEPS * 64;
         const size_t ubase = (size_t)b * NMAP * P;
-        for (int j = mg; j < ntiles; j += 4) {
-            int m0 = 16 * j + (lane & 15);
-            m0 = m0 < P ? m0 : P - 1;
-            const int h0 = m0 / PW;
-            const float* a0 = tile + (lane >> 4) * CS + h0 * WP + (m0 - h0 * PW);
-            f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
-            // software pipeline: the 9 A fragments of cin block c0+1 are in flight while block c0 multiplies
-            float acur[9], anxt[9];
-#pragma unroll
-            for (int tap = 0; tap < 9; ++tap) acur[tap] = a0[(tap / 3) * WP + (tap % 3)];
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int c0 = 0; c0 < 12; ++c0) {
-                a0 += 4 * CS;
-                if (c0 < 11) {
-#pragma unroll
-                    for (int tap = 0; tap < 9; ++tap) anxt[tap] = a0[(tap / 3) * WP + (tap % 3)];
-                }
-#pragma unroll
-                for (int tap = 0; tap < 9; ++tap)
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(acur[tap], wreg[c0 * 9 + tap], acc, 0, 0, 0);
-#pragma unroll
-                for (int tap = 0; tap < 9; ++tap) acur[tap] = anxt[tap];
-                // pin the order "next block's DS reads, then this block's 9 MFMAs" (hipcc otherwise sinks the reads
-                // to just before their use and the wave stalls on LDS latency three times per block)
-                __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 9, 0);
-            }
-            // epilogue: lane holds cout = 16nt + (lane&15), positions 16j + 4*(lane>>4) + {0,1,2,3}
-            const int mbase = 16 * j + 4 * (lane >> 4);
-#pragma unroll
-            for (int hh = 0; hh < 2; ++hh) {
-                const int m = mbase + 2 * hh;
-                if (cvalid && m < P) {
-                    const size_t o = ubase + (size_t)cout * P + m;
-                    float v0 = acc[2 * hh], v1 = acc[2 * hh + 1];
-                    if (MODE == 0) {
-                        v0 = fmaxf(v0, 0.0f);
-                        v1 = fmaxf(v1, 0.0f);
-                        if (y_out != nullptr) *reinterpret_cast<float2*>(y_out + o) = make_float2(v0, v1);
-                        if (res != nullptr) {
-                            const float2 r = *reinterpret_cast<const float2*>(res + o);
-                            v0 += r.x;
-                            v1 += r.y;
-                        }
-                        st0 += v0 + v1;
-                        st1 += v0 * v0 + v1 * v1;
-                    } else if (xs != nullptr) {
-                        const float2 sv = *reinterpret_cast<const float2*>(xs + o);
-                        st0 += v0 + v1;
-                        st1 += v0 * ((sv.x - xmean) * xrstd) + v1 * ((sv.y - xmean) * xrstd);
-                    }
-                    *reinterpret_cast<float2*>(out + o) = make_float2(v0, v1);
-                }
-            }
+        switch (ntw) {
+            case 5: conv_utterance<MODE, 5>(ltile, wnt, CS, mg, lane, ubase, epi, st0, st1); break;
+            case 4: conv_utterance<MODE, 4>(ltile, wnt, CS, mg, lane, ubase, epi, st0, st1); break;
+            case 3: conv_utterance<MODE, 3>(ltile, wnt, CS, mg, lane, ubase, epi, st0, st1); break;
+            case 2: conv_utterance<MODE, 2>(ltile, wnt, CS, mg, lane, ubase, epi, st0, st1); break;
+            case 1: conv_utterance<MODE, 1>(ltile, wnt, CS, mg, lane, ubase, epi, st0, st1); break;
+            default: break;
         }
+        __syncthreads();  // single tile buffer: every wave is done reading before the next utterance is staged
     }
 
     if (part != nullptr) {
@@ -265,7 +294,6 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_mfma_kernel(
         st0 += __shfl_xor(st0, 32);
         st1 += __shfl_xor(st1, 16);
         st1 += __shfl_xor(st1, 32);
-        __syncthreads();
         if (lane < 16) {
             red[(wave * 2 + 0) * 16 + lane] = st0;
             red[(wave * 2 + 1) * 16 + lane] = st1;
@@ -803,7 +831,8 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
     }
 }
 
-size_t conv_lds_bytes(int H) { return (size_t)(2 * tile_floats(H) + 2 * CP + 12 * 2 * 16) * sizeof(float); }
+size_t conv_lds_bytes(int H) { return (size_t)(3 * KSTEPS * 64 + tile_floats(H) + 2 * CP + 12 * 2 * 16) * sizeof(float); }
+size_t wgrad_lds_bytes(int H) { return (size_t)(2 * tile_floats(H) + 2 * CP) * sizeof(float); }
 size_t conv0_lds_bytes(int T, int M) { return (size_t)((T + 2) * (M + 2) + 2 * NMAP * 9) * sizeof(float); }
 
 struct Ws {
@@ -945,8 +974,9 @@ int howl_res8_bwd(const HowlRes8Params* prm, const float* feat, long sb, long st
     const size_t lc = conv_lds_bytes(H);
     hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_mfma_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
                         (int)lc);
+    const size_t lw = wgrad_lds_bytes(H);
     hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                        (int)lc);
+                        (int)lw);
     float* dx_cur = nullptr;      // gradient w.r.t. the BN output of layer i (nullptr: broadcast of dpool)
     float* dx_next = w.bufa;
     float* ds_prev = nullptr;     // ds_{i+2}
@@ -967,7 +997,7 @@ int howl_res8_bwd(const HowlRes8Params* prm, const float* feat, long sb, long st
         const float* in_stats = (i == 1) ? nullptr : sv->bn_stats + (size_t)(i - 2) * 2 * CP;
         {
             HowlProfScope prof("wgrad", stream);
-            hipLaunchKernelGGL(wgrad_mfma_kernel, dim3(G), dim3(CONV_THREADS), lc, stream, (const float*)w.dz, sv->s[i - 1],
+            hipLaunchKernelGGL(wgrad_mfma_kernel, dim3(G), dim3(CONV_THREADS), lw, stream, (const float*)w.dz, sv->s[i - 1],
                                in_stats, w.wpart, B, H);
         }
         hipLaunchKernelGGL(reduce_rows_kernel, dim3((CP * 432 + 63) / 64), dim3(256), 0, stream, (const float*)w.wpart, G,
