@@ -244,9 +244,24 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_mfma_kernel(
     const int ntw = (ntiles - mg + 3) / 4;  // tiles j = mg, mg+4, ... < ntiles (wave-uniform, <= 5)
     const bool affine = in_stats != nullptr;
 
-    for (int i = tid; i < 3 * KSTEPS * 16; i += CONV_THREADS)
-        reinterpret_cast<float4*>(wl)[i] = reinterpret_cast<const float4*>(wp)[i];
-    zero_lds(tile, TF, tid, CONV_THREADS);
+    // first utterance's activations are requested before anything else so that HBM latency overlaps the setup
+    float2 pre[PREF];
+    int b = blockIdx.x;
+    if (b < B) prefetch_tile(pre, in + (size_t)b * NMAP * P, n2, tid);
+    {
+        float4 wv[7];  // 3*108*16 float4 = 5184 <= 7 * 768: all loads in flight, then the LDS stores
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+            const int i = tid + j * CONV_THREADS;
+            wv[j] = (i < 3 * KSTEPS * 16) ? reinterpret_cast<const float4*>(wp)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        zero_lds(tile, TF, tid, CONV_THREADS);
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+            const int i = tid + j * CONV_THREADS;
+            if (i < 3 * KSTEPS * 16) reinterpret_cast<float4*>(wl)[i] = wv[j];
+        }
+    }
     if (tid < CP) {
         lmean[tid] = affine ? in_stats[tid] : 0.0f;
         lrstd[tid] = affine ? in_stats[CP + tid] : 1.0f;
@@ -261,11 +276,8 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_mfma_kernel(
     float st0 = 0.0f, st1 = 0.0f;
     const ConvEpilogue epi{res, y_out, out, xs, xmean, xrstd, cout, P, cvalid};
 
-    float2 pre[PREF];
     int pk[PREF];
     stage_slots(pk, P, CS, n2, tid);
-    int b = blockIdx.x;
-    if (b < B) prefetch_tile(pre, in + (size_t)b * NMAP * P, n2, tid);
     __syncthreads();  // weights, zero fill and stats visible before the first stage
 
     for (; b < B; b += gridDim.x) {
@@ -330,6 +342,13 @@ __global__ __launch_bounds__(CONV_THREADS) void wgrad_mfma_kernel(
     const bool affine = in_stats != nullptr;
     const int ksteps = (P + 3) / 4;
 
+    // first utterance's tiles are requested before the LDS setup so that HBM latency overlaps it
+    float2 pz[PREF], px[PREF];
+    int b = blockIdx.x;
+    if (b < B) {
+        prefetch_tile(pz, dz + (size_t)b * NMAP * P, n2, tid);
+        prefetch_tile(px, s_prev + (size_t)b * NMAP * P, n2, tid);
+    }
     zero_lds(lds, 2 * TF, tid, CONV_THREADS);
     if (tid < CP) {
         lmean[tid] = affine ? in_stats[tid] : 0.0f;
@@ -351,14 +370,8 @@ __global__ __launch_bounds__(CONV_THREADS) void wgrad_mfma_kernel(
     const bool has3 = __builtin_amdgcn_readfirstlane(wave) + 24 < 27;  // wave-uniform: a scalar branch, not exec masking
     const int aoff = (lane & 15) * CS + WP + 1;  // cout row, interior origin
 
-    float2 pz[PREF], px[PREF];
     int pk[PREF];
     stage_slots(pk, P, CS, n2, tid);
-    int b = blockIdx.x;
-    if (b < B) {
-        prefetch_tile(pz, dz + (size_t)b * NMAP * P, n2, tid);
-        prefetch_tile(px, s_prev + (size_t)b * NMAP * P, n2, tid);
-    }
     __syncthreads();
     for (; b < B; b += gridDim.x) {
         stage_tile(pz, pk, tz, lmean, lrstd, false);
@@ -463,26 +476,41 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restric
     }
 }
 
-// Column sums of the [nparts][2][48] statistics partials in fp64, deterministic: thread (col = tid % 96, rg = tid / 96)
-// adds rows rg, rg+10, ... (coalesced 384-byte rows), then the 10 row groups are combined in a fixed order.
-// Returns (sum stat0[c], sum stat1[c]) to threads c < 48.
+// Column sums of the [nparts][2][48] statistics partials in fp64, deterministic.  Thread (cg = tid % 24, rg = tid / 24)
+// adds rows rg, rg+42, ... of its float4 column group (coalesced 384-byte rows, a handful of independent loads per
+// thread), then threads < 96 combine the 42 row groups in a fixed order.  Returns the two sums to threads c < 48.
+constexpr int SC_RG = 42;
 __device__ __forceinline__ void stats_colsum(const float* __restrict__ part, int nparts, double (*red)[2 * CP],
                                              double& s, double& q) {
     const int tid = threadIdx.x;
-    const int col = tid % (2 * CP), rg = tid / (2 * CP);
-    if (rg < 10) {
-        double a = 0.0;
-        for (int g = rg; g < nparts; g += 10) a += (double)part[(size_t)g * 2 * CP + col];
-        red[rg][col] = a;
+    const int cg = tid % 24, rg = tid / 24;
+    if (rg < SC_RG) {
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll 8
+        for (int g = rg; g < nparts; g += SC_RG) {
+            const float4 v = reinterpret_cast<const float4*>(part + (size_t)g * 2 * CP)[cg];
+            a0 += (double)v.x;
+            a1 += (double)v.y;
+            a2 += (double)v.z;
+            a3 += (double)v.w;
+        }
+        red[rg][4 * cg + 0] = a0;
+        red[rg][4 * cg + 1] = a1;
+        red[rg][4 * cg + 2] = a2;
+        red[rg][4 * cg + 3] = a3;
+    }
+    __syncthreads();
+    double t = 0.0;
+    if (tid < 2 * CP) {
+        for (int g = 0; g < SC_RG; ++g) t += red[g][tid];
+        red[0][tid] = t;
     }
     __syncthreads();
     s = 0.0;
     q = 0.0;
     if (tid < CP) {
-        for (int g = 0; g < 10; ++g) {
-            s += red[g][tid];
-            q += red[g][CP + tid];
-        }
+        s = red[0][tid];
+        q = red[0][CP + tid];
     }
 }
 
@@ -493,7 +521,7 @@ __device__ __forceinline__ void stats_colsum(const float* __restrict__ part, int
 // nn.BatchNorm2d(affine=False): momentum 0.1, unbiased variance into running_var, num_batches_tracked += 1)
 __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ part, int nparts, double count,
                                                            float* __restrict__ stats, HowlBnBuffers bn) {
-    __shared__ double red[10][2 * CP];
+    __shared__ double red[SC_RG][2 * CP];
     double s, q;
     stats_colsum(part, nparts, red, s, q);
     const int c = threadIdx.x;
@@ -523,7 +551,7 @@ __global__ void bn_eval_stats_kernel(HowlPtrs6 rmean, HowlPtrs6 rvar, float* __r
 // backward: partials of (sum dx, sum dx*xhat) -> means m1, m2
 __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ part, int nparts, double count,
                                                                float* __restrict__ m12) {
-    __shared__ double red[10][2 * CP];
+    __shared__ double red[SC_RG][2 * CP];
     double s, q;
     stats_colsum(part, nparts, red, s, q);
     const int c = threadIdx.x;

@@ -25,23 +25,23 @@ namespace {
 
 struct HowlPtrs6""")
 # stamps inside the MODE-templated kernel
-sub("    float wreg[KSTEPS];\n    {", "    int pi = 0;\n    STAMP(pi++);\n    float wreg[KSTEPS];\n    {")
-sub("    __syncthreads();  // zero fill + stats visible before the first stage\n", "    STAMP(pi++);\n    __syncthreads();  // zero fill + stats visible before the first stage\n    STAMP(pi++);\n")
-sub("        stage_tile(pre, pk, tile, lmean, lrstd, affine);\n        __syncthreads();\n", "        STAMP(pi++);\n        stage_tile(pre, pk, tile, lmean, lrstd, affine);\n        STAMP(pi++);\n        __syncthreads();\n        STAMP(pi++);\n")
-sub("            f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};\n            // software pipeline", "            STAMP(pi++);\n            f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};\n            // software pipeline")
-sub("            // epilogue: lane holds cout", "            asm volatile(\"\" : \"+v\"(acc));\n            STAMP(pi++);\n            // epilogue: lane holds cout")
-sub("    if (part != nullptr) {\n        // lanes l, l^16", "    STAMP(pi++);\n    if (part != nullptr) {\n        // lanes l, l^16")
+sub("    for (int i = tid; i < 3 * KSTEPS * 16; i += CONV_THREADS)\n        reinterpret_cast<float4*>(wl)[i]", "    int pi = 0;\n    STAMP(pi);\n    ++pi;\n    for (int i = tid; i < 3 * KSTEPS * 16; i += CONV_THREADS)\n        reinterpret_cast<float4*>(wl)[i]")
+sub("    __syncthreads();  // weights, zero fill and stats visible before the first stage\n", "    STAMP(pi);\n    ++pi;\n    __syncthreads();  // weights, zero fill and stats visible before the first stage\n    STAMP(pi);\n    ++pi;\n")
+sub("        stage_tile(pre, pk, tile, lmean, lrstd, affine);\n        __syncthreads();\n        const int bn = b + gridDim.x;\n        if (bn < B) prefetch_tile(pre, in + (size_t)bn * NMAP * P, n2, tid);\n",
+    "        STAMP(pi);\n        ++pi;\n        stage_tile(pre, pk, tile, lmean, lrstd, affine);\n        STAMP(pi);\n        ++pi;\n        __syncthreads();\n        STAMP(pi);\n        ++pi;\n        const int bn = b + gridDim.x;\n        if (bn < B) prefetch_tile(pre, in + (size_t)bn * NMAP * P, n2, tid);\n        STAMP(pi);\n        ++pi;\n")
+sub("        __syncthreads();  // single tile buffer: every wave is done reading before the next utterance is staged",
+    "        STAMP(pi);\n        ++pi;\n        __syncthreads();  // single tile buffer: every wave is done reading before the next utterance is staged\n        STAMP(pi);\n        ++pi;")
 # ---- wgrad kernel stamps (second STAMP family writes to g_probe2)
 sub("__device__ int g_probe_block = 0;", """__device__ int g_probe_block = 0;
 __device__ long long g_probe2[12 * 128];
 #define STAMP2(i) do { if (blockIdx.x == g_probe_block && lane == 0 && (i) < 128) g_probe2[wave * 128 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)""")
 sub("    zero_lds(lds, 2 * TF, tid, CONV_THREADS);\n    if (tid < CP) {\n        lmean[tid] = affine ? in_stats[tid] : 0.0f;\n        lrstd[tid] = affine ? in_stats[CP + tid] : 1.0f;\n    }\n    // this wave's N tiles",
-    "    int pi = 0;\n    STAMP2(pi++);\n    zero_lds(lds, 2 * TF, tid, CONV_THREADS);\n    if (tid < CP) {\n        lmean[tid] = affine ? in_stats[tid] : 0.0f;\n        lrstd[tid] = affine ? in_stats[CP + tid] : 1.0f;\n    }\n    // this wave's N tiles")
+    "    int pi = 0;\n    STAMP2(pi);\n        ++pi;\n    zero_lds(lds, 2 * TF, tid, CONV_THREADS);\n    if (tid < CP) {\n        lmean[tid] = affine ? in_stats[tid] : 0.0f;\n        lrstd[tid] = affine ? in_stats[CP + tid] : 1.0f;\n    }\n    // this wave's N tiles")
 sub("        stage_tile(pz, pk, tz, lmean, lrstd, false);\n        stage_tile(px, pk, tx, lmean, lrstd, affine);\n        __syncthreads();\n",
-    "        STAMP2(pi++);\n        stage_tile(pz, pk, tz, lmean, lrstd, false);\n        stage_tile(px, pk, tx, lmean, lrstd, affine);\n        STAMP2(pi++);\n        __syncthreads();\n        STAMP2(pi++);\n")
-sub("        // K loop over positions, 4 per MFMA", "        STAMP2(pi++);\n        // K loop over positions, 4 per MFMA")
+    "        STAMP2(pi);\n        ++pi;\n        stage_tile(pz, pk, tz, lmean, lrstd, false);\n        stage_tile(px, pk, tx, lmean, lrstd, affine);\n        STAMP2(pi);\n        ++pi;\n        __syncthreads();\n        STAMP2(pi);\n        ++pi;\n")
+sub("        // K loop over positions, 4 per MFMA", "        STAMP2(pi);\n        ++pi;\n        // K loop over positions, 4 per MFMA")
 sub("        __syncthreads();  // single-buffered tiles: everyone done before the next stage overwrites them",
-    "        STAMP2(pi++);\n        __syncthreads();  // single-buffered tiles: everyone done before the next stage overwrites them\n        STAMP2(pi++);")
+    "        STAMP2(pi);\n        ++pi;\n        __syncthreads();  // single-buffered tiles: everyone done before the next stage overwrites them\n        STAMP2(pi);\n        ++pi;")
 src += r'''
 extern "C" int probe_wgrad(int B, int H, long long* host_out, float* ms_out) {
     const int P = H * PW;
@@ -95,12 +95,12 @@ lib = ctypes.CDLL("/tmp/libprobe.so")
 buf = (ctypes.c_longlong * (12 * 128))()
 ms = ctypes.c_float()
 def show(tag, nshow=40):
-    print("raw", [buf[i] for i in range(4)], [buf[128 * 4 + i] for i in range(4)])
     t = [[buf[w * 128 + i] for i in range(128)] for w in range(12)]
     t0 = min([t[w][0] for w in range(12) if t[w][0]] or [0])
     for w in (0, 4, 8, 3, 7, 11):
         ev = [x - t0 for x in t[w] if x]
-        print(f"{tag} wave {w:2d}: " + " ".join(f"{e / 100:.0f}" for e in ev[:nshow]))
+        d = [ev[0]] + [ev[i] - ev[i - 1] for i in range(1, len(ev))]
+        print(f"{tag} wave {w:2d} deltas(x100cyc): " + " ".join(f"{e / 100:.0f}" for e in d[:nshow]))
 
 
 for B in (512, 2048):
@@ -111,5 +111,5 @@ for B in (512, 2048):
 for B, with_res in ((512, 0), (512, 1), (2048, 0)):
     rc = lib.probe_run(B, 27, with_res, buf, ctypes.byref(ms))
     print(f"\n=== conv B={B} res={with_res} rc={rc} kernel {ms.value * 1e3:.1f} us; units: 100 shader cycles; events: start, "
-          "setup-end, barrier-end, [stage-begin, stage-end, barrier-end, (tile-begin, mfma-end)*]*, end")
+          "setup-end, barrier-end, [stage-begin, stage-end, barrier-end, prefetch-issued, compute+epilogue-end, barrier-end]*")
     show("conv")
