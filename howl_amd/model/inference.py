@@ -1,0 +1,209 @@
+"""Streaming decision logic over model outputs: ``InferenceEngine`` / ``FrameInferenceEngine`` with the reference's
+API and finite-state machine (``howl/model/inference.py:19-267``), running on the MI355X hot path.
+
+``FrameInferenceEngine.infer`` evaluates ALL strided windows of a clip in one batched launch of the fused frontend +
+model (instead of one launch and one device->host sync per 63 ms stride, ``inference.py:247-261``) and then replays
+the reference's per-window loop on the host, so ``label_history`` / ``pred_history`` and the early exit are identical.
+Models that carry streaming state between windows keep the sequential path.
+"""
+import itertools
+import time
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from howl_amd.context import InferenceContext
+from howl_amd.data.transform.operator import ZmuvTransform
+from howl_amd.data.transform.transform import StandardAudioTransform
+from howl_amd.settings import SETTINGS
+from howl_amd.utils import audio_utils
+
+from .base import RegisteredModel
+
+__all__ = ["FrameInferenceEngine", "InferenceEngine"]
+
+
+class InferenceEngine:
+    def __init__(self, model: RegisteredModel, zmuv_transform: ZmuvTransform, context: InferenceContext,
+                 time_provider=time.time):
+        self.model = model
+        self.zmuv = zmuv_transform
+        self.std = StandardAudioTransform().eval()
+        self.settings = SETTINGS.inference_engine
+        self.context = context
+
+        self.inference_weights = 1
+        if self.settings.inference_weights:
+            pad_size = context.num_labels - len(self.settings.inference_weights)
+            self.inference_weights = np.pad(self.settings.inference_weights, (0, pad_size), "constant", constant_values=1)
+
+        self.coloring = context.coloring
+        self.negative_label = context.negative_label
+        if self.coloring:
+            self.negative_label = self.coloring.color_map[self.negative_label]
+
+        self.sample_rate = SETTINGS.audio.sample_rate
+        self.threshold = self.settings.inference_threshold
+        self.inference_window_ms = self.settings.inference_window_ms
+        self.smoothing_window_ms = self.settings.smoothing_window_ms
+        self.tolerance_window_ms = self.settings.tolerance_window_ms
+        self.sequence = self.settings.inference_sequence
+        self.blank_idx = self.context.blank_label
+        self.time_provider = time_provider
+
+        self.curr_time = 0
+        self.pred_history = []
+        self.label_history = []
+        self.reset()
+
+    def to(self, device: torch.device):
+        self.model = self.model.to(device)
+        self.zmuv = self.zmuv.to(device)
+        return self
+
+    def reset(self):
+        self.model.streaming_state = None
+        self.curr_time = 0
+        self.pred_history = []
+        self.label_history = []
+
+    def append_label(self, label: int, curr_time: float = None):
+        if curr_time is None:
+            curr_time = self.time_provider() * 1000
+        self.label_history.append((curr_time, label))
+
+    def sequence_present(self, curr_time: float = None) -> bool:
+        """FSM over ``label_history`` (``inference.py:91-137``)."""
+        if not self.sequence:
+            return False
+        if len(self.sequence) == 0:
+            return True
+        if curr_time is None:
+            curr_time = self.time_provider() * 1000
+        self.label_history = list(
+            itertools.dropwhile(lambda x: curr_time - x[0] > self.inference_window_ms, self.label_history))
+        curr_label = None
+        target_state = 0
+        last_valid_timestamp = 0
+        for curr_timestamp, label in self.label_history:
+            target_label = self.sequence[target_state]
+            if label == target_label:
+                target_state += 1
+                if target_state == len(self.sequence):
+                    return True
+                curr_label = self.sequence[target_state - 1]
+                last_valid_timestamp = curr_timestamp
+            elif label == curr_label:
+                last_valid_timestamp = curr_timestamp
+            elif last_valid_timestamp + self.tolerance_window_ms < curr_timestamp:
+                curr_label = None
+                target_state = 0
+                last_valid_timestamp = 0
+        return False
+
+    def _get_prediction(self, curr_time: float) -> int:
+        """Smoothing max over ``smoothing_window_ms`` (``inference.py:139-161``)."""
+        self.pred_history = list(
+            itertools.dropwhile(lambda x: curr_time - x[0] > self.smoothing_window_ms, self.pred_history))
+        lattice = np.vstack([t for _, t in self.pred_history])
+        lattice_max = np.max(lattice, 0)
+        max_label = lattice_max.argmax()
+        max_prob = lattice_max[max_label]
+        if self.coloring:
+            max_label = self.coloring.color_map.get(max_label, self.negative_label)
+        if max_prob < self.threshold:
+            max_label = self.negative_label
+        self.label_history.append((curr_time, max_label))
+        return max_label
+
+    def _append_probability_frame(self, prediction: np.ndarray, curr_time: float = None) -> int:
+        if curr_time is None:
+            curr_time = self.time_provider() * 1000
+        self.pred_history.append((curr_time, prediction))
+        return self._get_prediction(curr_time)
+
+    def _weighted(self, prediction: np.ndarray) -> np.ndarray:
+        prediction = prediction * self.inference_weights
+        return prediction / prediction.sum()
+
+    @torch.no_grad()
+    def infer(self, audio_data: torch.Tensor) -> bool:
+        """Whole clip as one batch through a sequential model (``inference.py:179-211``)."""
+        delta_ms = int(audio_data.size(-1) / self.sample_rate * 1000)
+        self.std = self.std.to(audio_data.device)
+        transformed = self.std.log_mel_for_model(audio_data.unsqueeze(0), self.zmuv)
+        predictions = self.model(transformed, lengths=None)
+        predictions = F.softmax(predictions, -1).squeeze(1).cpu().numpy()   # one device->host copy for all frames
+        sequence_present = False
+        delta_ms /= len(predictions)
+        for prediction in predictions:
+            prediction = self._weighted(prediction)
+            self.curr_time += delta_ms
+            if np.argmax(prediction) == self.blank_idx:
+                continue
+            self._append_probability_frame(prediction, curr_time=self.curr_time)
+            if self.sequence_present(self.curr_time):
+                sequence_present = True
+                break
+        return sequence_present
+
+
+class FrameInferenceEngine(InferenceEngine):
+    def __init__(self, max_window_size_ms: int, eval_stride_size_ms: int, *args):
+        super().__init__(*args)
+        self.max_window_size_ms, self.eval_stride_size_ms = max_window_size_ms, eval_stride_size_ms
+
+    def _stateless(self) -> bool:
+        return not self.model.is_streaming or type(self.model).streaming_state is RegisteredModel.streaming_state
+
+    @torch.no_grad()
+    def window_probabilities(self, audio_data: torch.Tensor) -> np.ndarray:
+        """softmax(model(zmuv(std(window)))) for every complete strided window, one batched launch -> (W, C)."""
+        starts, chunk = audio_utils.stride_starts(audio_data.size(-1), self.max_window_size_ms, self.eval_stride_size_ms,
+                                                  self.sample_rate)
+        if not starts or chunk < 1000:
+            return np.zeros((0, self.context.num_labels), np.float32)
+        self.std = self.std.to(audio_data.device)
+        stride_sz = starts[1] - starts[0] if len(starts) > 1 else chunk
+        flat = audio_data.reshape(-1).contiguous()
+        windows = flat.as_strided((len(starts), chunk), (stride_sz, 1))   # overlapping views, no copy
+        feats = self.std.log_mel_for_model(windows, self.zmuv)
+        lengths = self.std.compute_lengths(torch.full((len(starts),), chunk, device=audio_data.device))
+        return self.model(feats, lengths).softmax(-1).cpu().numpy()
+
+    @torch.no_grad()
+    def infer(self, audio_data: torch.Tensor) -> bool:
+        if not self._stateless():
+            return self._infer_sequential(audio_data)
+        probs = self.window_probabilities(audio_data)
+        sequence_present = False
+        for prediction in probs:
+            self._append_probability_frame(self._weighted(prediction), curr_time=self.curr_time)
+            self.curr_time += self.eval_stride_size_ms
+            if self.sequence_present(self.curr_time):
+                sequence_present = True
+                break
+        return sequence_present
+
+    def _infer_sequential(self, audio_data: torch.Tensor) -> bool:
+        sequence_present = False
+        for window in audio_utils.stride(audio_data, self.max_window_size_ms, self.eval_stride_size_ms, self.sample_rate):
+            if window.size(-1) < 1000:
+                break
+            self.ingest_frame(window.squeeze(0), self.curr_time)
+            self.curr_time += self.eval_stride_size_ms
+            if self.sequence_present(self.curr_time):
+                sequence_present = True
+                break
+        return sequence_present
+
+    @torch.no_grad()
+    def ingest_frame(self, frame: torch.Tensor, curr_time: float = None) -> int:
+        """One window, as the live client feeds it (``inference.py:247-267``)."""
+        self.std = self.std.to(frame.device)
+        lengths = torch.tensor([frame.size(-1)]).to(frame.device)
+        transformed_lengths = self.std.compute_lengths(lengths)
+        transformed_frame = self.std.log_mel_for_model(frame.unsqueeze(0), self.zmuv)
+        prediction = self.model(transformed_frame, transformed_lengths).softmax(-1)[0].cpu().numpy()
+        return self._append_probability_frame(self._weighted(prediction), curr_time=curr_time)

@@ -1,0 +1,79 @@
+"""Minimal data plumbing for the entry points: a Google-Speech-Commands reader that needs no librosa (GSC clips are
+16 kHz mono int16 wav) with the split / label rules of ``howl/data/dataset/gsc_dataset_loader.py:19-47``, a synthetic
+stand-in for boxes without a dataset, and a device-resident clip bank with ``batchify`` semantics
+(``howl/data/transform/operator.py:77-86``: sort by length descending, zero-pad right)."""
+import wave
+from pathlib import Path
+from typing import List, Tuple
+
+import numpy as np
+import torch
+
+from howl_amd.data.common.batch import ClassificationBatch
+from howl_amd.utils.synth import synthetic_pcm
+
+
+def read_wav16k(path) -> torch.Tensor:
+    with wave.open(str(path), "rb") as w:
+        if w.getframerate() != 16000 or w.getnchannels() != 1 or w.getsampwidth() != 2:
+            raise ValueError(f"{path}: expected 16 kHz mono int16 (resampling is outside the MI355X hot path)")
+        return torch.from_numpy(np.frombuffer(w.readframes(w.getnframes()), dtype="<i2").astype(np.float32) / 32768.0)
+
+
+def load_gsc_splits(path: Path, vocab: List[str]):
+    """-> (train, dev, test), each a list of (path, label); labels: index in vocab, else len(vocab)."""
+    path = Path(path)
+    split = {}
+    for name, tag in (("testing_list.txt", "test"), ("validation_list.txt", "dev")):
+        with (path / name).open() as f:
+            split.update({k: tag for k in f.read().split("\n")})
+    files = [p for p in sorted(path.glob("*/*.wav")) if "noise" not in str(p)]
+    label_of = {k: i for i, k in enumerate(vocab)}
+    out = {"train": [], "dev": [], "test": []}
+    for p in files:
+        key = str(Path(p.parent.name) / p.name)
+        out[split.get(key, "train")].append((p, label_of.get(p.parent.name, len(vocab))))
+    return out["train"], out["dev"], out["test"]
+
+
+class ClipBank:
+    """All clips of a split decoded once, truncated to ``max_len`` and kept on the device as one (N, max_len) matrix."""
+
+    def __init__(self, clips: List[torch.Tensor], labels: List[int], max_len: int, device):
+        n = len(clips)
+        self.max_len = max_len
+        audio = torch.zeros(n, max_len)
+        lengths = torch.zeros(n, dtype=torch.long)
+        for i, c in enumerate(clips):
+            c = c[:max_len]                      # truncate_length (operator.py:73-74)
+            audio[i, : c.numel()] = c
+            lengths[i] = c.numel()
+        self.audio = audio.to(device)
+        self.lengths = lengths.to(device)
+        self.labels = torch.tensor(labels, dtype=torch.long).to(device)
+
+    def __len__(self):
+        return self.audio.size(0)
+
+    def batch(self, idx: torch.Tensor) -> ClassificationBatch:
+        """batchify: longest first, zero padded to the batch maximum."""
+        lengths = self.lengths[idx]
+        order = torch.argsort(lengths, descending=True, stable=True)
+        idx = idx[order]
+        lengths = lengths[order]
+        lmax = int(self.max_len)   # a fixed width keeps shapes static (padding is zero either way)
+        return ClassificationBatch(self.audio[idx, :lmax], self.labels[idx], lengths)
+
+    def batches(self, batch_size: int, shuffle: bool, drop_last: bool, generator=None):
+        n = len(self)
+        perm = torch.randperm(n, generator=generator) if shuffle else torch.arange(n)
+        perm = perm.to(self.audio.device)
+        end = n - (n % batch_size) if drop_last else n
+        for i in range(0, end, batch_size):
+            yield self.batch(perm[i:i + batch_size])
+
+
+def synthetic_bank(n: int, max_len: int, num_labels: int, device, seed=0) -> ClipBank:
+    pcm = synthetic_pcm(n, max_len, seed=seed)
+    labels = [(i % 64) % num_labels for i in range(n)]     # the tone frequency of clip i encodes its label
+    return ClipBank([pcm[i] for i in range(n)], labels, max_len, device)

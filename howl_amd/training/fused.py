@@ -5,9 +5,8 @@ stage a C-ABI call on the current HIP stream, gradients written straight into on
 single data-parallel all-reduce per step) and no host synchronisation (the loss stays on the device).
 """
 import torch
-import torch.distributed as dist
 
-from howl_amd import ops
+from howl_amd import ops, parallel
 
 
 class FlatParams:
@@ -45,14 +44,11 @@ class FusedRes8Trainer:
         self.v = torch.zeros_like(self.fp.flat)
         self.step_count = 0
         self.group = process_group
-        self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.rank, self.world = parallel.world_info(process_group)
 
     def broadcast_parameters(self, src=0):
         """Make every replica start from rank ``src``'s weights and BatchNorm buffers."""
-        if self.world > 1:
-            dist.broadcast(self.fp.flat, src, group=self.group)
-            for b in self.model.buffers():
-                dist.broadcast(b, src, group=self.group)
+        parallel.broadcast_([self.fp.flat] + list(self.model.buffers()), src, self.group)
 
     def features(self, audio):
         return self.std.log_mel_for_model(audio, self.zmuv)
@@ -66,10 +62,7 @@ class FusedRes8Trainer:
         logits = self.model._launch_forward(feat)
         loss, dlogits = ops.xent(logits, labels)
         self.model._launch_backward(feat, dlogits, out_grads=self.fp.grad_views)
-        scale = 1.0
-        if self.world > 1:
-            dist.all_reduce(self.fp.grad, op=dist.ReduceOp.SUM, group=self.group)
-            scale = 1.0 / self.world
+        scale = parallel.allreduce_sum_(self.fp.grad, self.group)
         self.step_count += 1
         ops.adamw_step(self.fp.flat, self.fp.grad, self.m, self.v, self.lr, self.betas, self.eps, self.weight_decay,
                        self.step_count, scale)

@@ -1,0 +1,66 @@
+"""-m gpu: inference engines and the pretrain_gsc entry point on the HIP path."""
+import numpy as np
+import pytest
+import torch
+
+from gpu_util import DEV, make_res8, t
+
+pytestmark = pytest.mark.gpu
+
+
+def test_frame_engine_matches_reference_history(golden):
+    """G8: label history of FrameInferenceEngine.infer on a fixture clip (500 ms window / 63 ms stride), captured from
+    the reference's engine with the same closed-form res8 weights; the batched engine must reproduce it exactly."""
+    from howl_amd.context import InferenceContext
+    from howl_amd.data.transform.operator import ZmuvTransform
+    from howl_amd.model.inference import FrameInferenceEngine
+    from howl_amd.settings import SETTINGS
+    g, g4 = golden("g8_frame_engine"), golden("g4_zmuv")
+    SETTINGS.inference_engine.inference_sequence = [0, 1, 2]
+    ctx = InferenceContext(["hey", "fire", "fox"], token_type="word")
+    assert (ctx.num_labels, ctx.negative_label, ctx.blank_label) == (int(g["num_labels"]), int(g["negative_label"]),
+                                                                     int(g["blank_label"]))
+    model = make_res8(ctx.num_labels, train=False).streaming()
+    zmuv = ZmuvTransform().to(DEV)
+    zmuv.mean.copy_(t(g4["mean"]))
+    zmuv.mean2.copy_(t(g4["mean2"]))
+    zmuv.total.copy_(t(g4["total"]))
+    engine = FrameInferenceEngine(500, 63, model, zmuv, ctx)
+    clip = t(g["clip"]).to(DEV)
+    probs = engine.window_probabilities(clip)
+    assert probs.shape[0] == int(g["n_windows"])
+    present = engine.infer(clip)
+    assert bool(present) == bool(g["present"])
+    hist = np.array(engine.label_history, dtype=np.float64)
+    assert hist.shape == g["label_history"].shape
+    assert np.array_equal(hist, g["label_history"])          # timestamps and label indices, bit-exact
+    assert np.abs(engine.pred_history[-1][1] - g["last_probs"][-1]).max() < 1e-4
+    # sequential path (what the live client calls per frame) gives the same labels
+    engine.reset()
+    labels = [engine.ingest_frame(clip[i * 1008: i * 1008 + 8000], curr_time=63.0 * i) for i in range(5)]
+    assert labels == [int(x) for x in g["label_history"][:5, 1]]
+
+
+def test_pretrain_gsc_entry_point_synthetic(tmp_path, monkeypatch):
+    """`python -m training.run.pretrain_gsc --model res8` flow on generated clips: ZMUV pass, fused training epochs,
+    dev accuracy, workspace artefacts with the reference's file names and state_dict keys."""
+    for k, v in dict(NUM_EPOCHS="2", BATCH_SIZE="64", MAX_WINDOW_SIZE_SECONDS="1", LEARNING_RATE="0.01", LR_DECAY="0.8",
+                     NUM_MELS="40", DEVICE="cuda:0").items():
+        monkeypatch.setenv(k, v)
+    from howl_amd.settings import SETTINGS
+    SETTINGS.reset()
+    from howl_amd.training.run import pretrain_gsc
+    ws = tmp_path / "ws"
+    pretrain_gsc.main(["--model", "res8", "--workspace", str(ws), "--synthetic", "512"])
+    for name in ("model.pt.bin", "model-best.pt.bin", "zmuv.pt.bin", "settings.json", "cmd-args.json"):
+        assert (ws / name).exists(), name
+    sd = torch.load(ws / "model-best.pt.bin")
+    assert list(sd)[:2] == ["conv0.weight", "bn1.running_mean"] and sd["output.weight"].shape == (30, 45)
+    assert set(torch.load(ws / "zmuv.pt.bin")) == {"total", "mean", "mean2"}
+    import json
+    lines = [json.loads(l) for l in (ws / "logs" / "scalars.jsonl").read_text().splitlines()]
+    losses = [l["value"] for l in lines if l["tag"] == "Training/Loss"]
+    assert len(losses) == 16 and losses[-1] < losses[0]
+    accs = [l["value"] for l in lines if l["tag"] == "Dev/Metric/acc"]
+    assert len(accs) == 2 and accs[-1] > 0.2     # tones are separable: well above 1/30 chance after two epochs
+    SETTINGS.reset()
