@@ -382,7 +382,7 @@ int howl_logmel_fwd(const float* pcm, int B, int L, long ld, const float* fbp, i
     HOWL_REQUIRE(pcm && fbp && out, "howl_logmel_fwd: null pointer");
     HOWL_REQUIRE(B >= 1, "howl_logmel_fwd: empty batch");
     HOWL_REQUIRE(L > N_FFT / 2, "howl_logmel_fwd: L=%d too short for reflect padding (needs > 256, as torch.stft)", L);
-    HOWL_REQUIRE(ld >= L, "howl_logmel_fwd: row stride %ld < L", ld);
+    HOWL_REQUIRE(ld >= 0, "howl_logmel_fwd: negative row stride %ld", ld);  // rows may overlap (strided windows of one clip)
     HOWL_REQUIRE(M >= 1 && M <= HOWL_MAX_MELS, "howl_logmel_fwd: M=%d unsupported (1..%d)", M, HOWL_MAX_MELS);
     HOWL_REQUIRE(layout == 0 || layout == 1, "howl_logmel_fwd: layout must be 0 (B,M,T) or 1 (B,T,M)");
     const int T = 1 + L / HOP;

@@ -54,7 +54,7 @@ typedef struct {
 int howl_fb_from_points(const HowlMelPoints* pts /* host */, int M, float nyquist, float* fbp, hipStream_t stream);
 
 /* Fused reflect-pad + Hann + rFFT-512 (hop 200) + |.|^2 + mel contraction + log(x + log_eps) [+ ZMUV].
- *   pcm (B, L) row stride ld;  T = 1 + L/200 frames;  zmuv = {mean, std} device pair or NULL
+ *   pcm (B, L) row stride ld (rows may overlap: ld < L gives strided windows of one clip);  T = 1 + L/200 frames;  zmuv = {mean, std} device pair or NULL
  *   layout 0: out (B, M, T)  -- the reference's `mels_only` tensor (transform.py:275-277)
  *   layout 1: out (B, T, M)  -- the (time, frequency) layout res8 consumes (cnn.py:128-129), no permute needed
  * Replaces transform.py:249-254 + :275 (MelSpectrogram, add_(1e-7).log_()) and operator.py:145-146. */
