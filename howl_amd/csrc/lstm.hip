@@ -1,0 +1,496 @@
+// LSTM classifiers for gfx950 (MI355X): single-layer LSTM(40 -> 128) forward + BPTT backward and the Linear heads.
+//
+// Replaces, for howl/model/rnn.py:41-91 (SequentialLstm "seq-lstm", SimpleLstm "lstm"):
+//   pack_padded_sequence + nn.LSTM (rnn.py:65-66,88) .......... howl_lstm_fwd / howl_lstm_bwd
+//   nn.Linear(128,256) - ReLU - nn.Linear(256,C) (rnn.py:44-48,71,91) ... howl_linear_fwd / howl_linear_bwd
+// (log_softmax + CTCLoss stay ATen ops on the device; north_star does not name them.)
+//
+// Internal layout is batch-major: x (B,T,40) [what the fused frontend writes], gate pre-activations / activations
+// (B,T,512), cell c (B,T,128), hidden hseq (B,T+1,128) with hseq[b][0] = h0 and hseq[b][t+1] = h_t, so that both
+// "h_t" and "h_{t-1}" are plain strided views for the GEMMs.
+//
+// The recurrence is the latency-critical part: 38-81 strictly sequential steps.  One workgroup owns 16 sequences (one
+// MFMA M tile) and all 512 gate columns; its 16 waves keep the whole W_hh (256 KB as 1024 B-fragments, 64 VGPRs per
+// lane) in registers for the entire launch; h_t lives in LDS; the gate columns are permuted so that each wave holds
+// i,f,g,o of the same 8 hidden units and the cell update is register-local (one xor-8 shuffle).  One barrier per step.
+// The input projection x W_ih^T and all weight gradients are batched GEMMs outside the recurrence (gemm_kernel).
+#include "howl_common.hip.h"
+#include "../../include/howl_hip.h"
+
+namespace {
+
+constexpr int HID = 128;
+constexpr int G4 = 4 * HID;          // 512 gate columns, PyTorch order i, f, g, o
+constexpr int LSTM_THREADS = 1024;   // 16 waves
+constexpr int HS = HID + 4;          // LDS row stride of the h tile (16 rows)
+constexpr int DGS = G4 + 4;          // LDS row stride of the dG tile
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// ---------------------------------------------------------------------------------------------------------
+// Generic fp32 MFMA GEMM:  C[m][n] = sum_k A(m,k) * B(k,n)  (+ bias[n]) (ReLU)
+//   A(m,k) = a[am(m) + k*a_ks], B(k,n) = b[bk(k) + n*b_ns]; am/bk are two-level affine maps
+//   off(x) = (x / inner) * s_outer + (x % inner) * s_inner, which lets (B,T,.) tensors with per-utterance gaps
+//   (e.g. hseq (B,T+1,128)) be used as row sets without copies.  Split-K over gridDim.z writes partial slabs.
+// 64x64 tile, BK = 16, 4 waves in a 2x2 grid, 2x2 16x16x4 MFMA tiles per wave.
+// ---------------------------------------------------------------------------------------------------------
+struct RowMap {
+    int inner;
+    long s_outer, s_inner;
+};
+__device__ __forceinline__ long rmap(const RowMap& r, int x) { return (long)(x / r.inner) * r.s_outer + (long)(x % r.inner) * r.s_inner; }
+
+constexpr int GT = 64, GK = 16, GLD = 80;  // tile edge, k depth, LDS row stride (80 = 16 mod 32: conflict-free frags)
+
+template <bool A_MAJOR_IS_K>  // true: A's unit-stride index is k (row-major [m][k]); false: unit stride is m ([k][m])
+__global__ __launch_bounds__(256) void gemm_kernel(const float* __restrict__ a, RowMap am, long a_ks, RowMap ak,
+                                                   const float* __restrict__ b, RowMap bk, long b_ns, int M, int N, int K,
+                                                   int k_per_split, const float* __restrict__ bias, int relu,
+                                                   float* __restrict__ c, long c_ms, long c_split_stride) {
+    __shared__ float As[GK * GLD];
+    __shared__ float Bs[GK * GLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int m0 = blockIdx.y * GT, n0 = blockIdx.x * GT;
+    const int kbeg = blockIdx.z * k_per_split;
+    const int kend = min(K, kbeg + k_per_split);
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = {0.0f, 0.0f, 0.0f, 0.0f};
+
+    for (int k0 = kbeg; k0 < kend; k0 += GK) {
+        // stage A tile (64 m x 16 k) and B tile (16 k x 64 n); thread mapping follows the unit-stride index
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int mm, kk;
+            if (A_MAJOR_IS_K) {
+                kk = tid & 15;
+                mm = (tid >> 4) + 16 * j;
+            } else {
+                mm = tid & 63;
+                kk = (tid >> 6) + 4 * j;
+            }
+            const int m = m0 + mm, k = k0 + kk;
+            float v = 0.0f;
+            if (m < M && k < kend) v = a[rmap(am, m) + (A_MAJOR_IS_K ? (long)k * a_ks : rmap(ak, k))];
+            As[kk * GLD + mm] = v;
+            const int nn = tid & 63, kb = (tid >> 6) + 4 * j;
+            const int n = n0 + nn, k2 = k0 + kb;
+            float w = 0.0f;
+            if (n < N && k2 < kend) w = b[rmap(bk, k2) + (long)n * b_ns];
+            Bs[kb * GLD + nn] = w;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < GK / 4; ++ks) {
+            const int kr = 4 * ks + (lane >> 4);
+            float af[2], bf[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) af[i] = As[kr * GLD + 32 * wr + 16 * i + (lane & 15)];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bf[j] = Bs[kr * GLD + 32 * wc + 16 * j + (lane & 15)];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    float* cz = c + (long)blockIdx.z * c_split_stride;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + 32 * wc + 16 * j + (lane & 15);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + 32 * wr + 16 * i + 4 * (lane >> 4) + r;
+                if (m < M && n < N) {
+                    float v = acc[i][j][r];
+                    if (bias != nullptr) v += bias[n];
+                    if (relu) v = fmaxf(v, 0.0f);
+                    cz[(long)m * c_ms + n] = v;
+                }
+            }
+        }
+}
+
+// deterministic sum of `nparts` slabs of n floats (split-K partials), optional accumulate of a second term
+__global__ void sum_slabs_kernel(const float* __restrict__ part, int nparts, long n, float* __restrict__ out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.0f;
+    for (int g = 0; g < nparts; ++g) s += part[(long)g * n + i];
+    out[i] = s;
+}
+
+// column sums of a (rows, n) matrix with a row map, two stages so that long row counts use the whole chip:
+// block (x = 64 columns, y = row chunk) writes part[y][col] in fp32 from an fp64 running sum; sum_slabs_kernel folds
+// the chunks in a fixed order (deterministic).
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, RowMap rm, int rows, int n,
+                                                     int rows_per_chunk, float* __restrict__ part) {
+    __shared__ double red[4][64];
+    const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + lane;
+    const int r0 = blockIdx.y * rows_per_chunk;
+    const int r1 = min(rows, r0 + rows_per_chunk);
+    double s = 0.0;
+    if (col < n)
+        for (int r = r0 + rg; r < r1; r += 4) s += (double)x[rmap(rm, r) + col];
+    red[rg][lane] = s;
+    __syncthreads();
+    if (rg == 0 && col < n)
+        part[(size_t)blockIdx.y * n + col] = (float)(((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane]);
+}
+
+__global__ void add2_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ o, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) o[i] = a[i] + b[i];
+}
+
+// dz = dy * (y > 0), elementwise (ReLU backward of the head's hidden layer)
+__global__ void relu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, long n, float* __restrict__ dz) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        dz[i] = y[i] > 0.0f ? dy[i] : 0.0f;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// W_hh (512,128) -> register fragments.
+//   forward : wave w, tile a in {0,1}, k-step kk: B[k][n] = W_hh[col(w,a,n)][4kk + k],
+//             col = (2a + (n >> 3)) * 128 + 8w + (n & 7)   (tile 0 = [i | f], tile 1 = [g | o] of units 8w..8w+7)
+//   backward: wave w -> hidden tile nt = w & 7, K half kh = w >> 3, k-step kk (64 per half):
+//             B[k][n] = W_hh[256kh + 4kk + k][16nt + n]      (dh = dG . W_hh)
+// packed as [wave][frag 0..63][lane]
+// ---------------------------------------------------------------------------------------------------------
+__global__ void lstm_pack_kernel(const float* __restrict__ whh, float* __restrict__ pf, float* __restrict__ pb) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= 16 * 64 * 64) return;
+    const int lane = idx & 63, frag = (idx >> 6) & 63, w = idx >> 12;
+    const int k = lane >> 4, n = lane & 15;
+    {
+        const int a = frag >> 5, kk = frag & 31;
+        const int col = (2 * a + (n >> 3)) * HID + 8 * w + (n & 7);
+        pf[idx] = whh[col * HID + 4 * kk + k];
+    }
+    {
+        const int nt = w & 7, kh = w >> 3;
+        pb[idx] = whh[(256 * kh + 4 * frag + k) * HID + 16 * nt + n];
+    }
+}
+
+// forward recurrence.  gx: (B,T,512) = x W_ih^T + b_ih + b_hh.  Outputs gates (B,T,512) post-activation, c (B,T,128),
+// hseq (B,T+1,128) [row 0 = h0], and the final (h, c).  lengths == nullptr: every sequence runs T steps.
+__global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(const float* __restrict__ gx, const float* __restrict__ pf,
+                                                                const long long* __restrict__ lengths,
+                                                                const float* __restrict__ h0, const float* __restrict__ c0,
+                                                                float* __restrict__ gates, float* __restrict__ cs,
+                                                                float* __restrict__ hseq, float* __restrict__ hT,
+                                                                float* __restrict__ cT, int B, int T, int Tout) {
+    __shared__ float hbuf[2][16 * HS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b0 = blockIdx.x * 16;
+    float wA[32], wB[32];
+#pragma unroll
+    for (int kk = 0; kk < 32; ++kk) {
+        wA[kk] = pf[((size_t)wave * 64 + kk) * 64 + lane];
+        wB[kk] = pf[((size_t)wave * 64 + 32 + kk) * 64 + lane];
+    }
+    const int n = lane & 15, u = 8 * wave + (n & 7);
+    const bool owner = n < 8;   // lanes with n < 8 own the cell state of unit u for rows 4*(lane>>4) + r
+    float cst[4], hst[4];
+    int len[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int b = b0 + 4 * (lane >> 4) + r;
+        const bool vb = b < B;
+        cst[r] = (vb && c0 != nullptr) ? c0[(size_t)b * HID + u] : 0.0f;
+        hst[r] = (vb && h0 != nullptr) ? h0[(size_t)b * HID + u] : 0.0f;
+        len[r] = vb ? (lengths != nullptr ? (int)lengths[b] : T) : 0;
+        if (owner) {
+            hbuf[0][(4 * (lane >> 4) + r) * HS + u] = hst[r];
+            if (vb) hseq[((size_t)b * (T + 1)) * HID + u] = hst[r];
+        }
+    }
+    __syncthreads();
+    const int colA = (n >> 3) * HID + u, colB = (2 + (n >> 3)) * HID + u;   // this lane's columns in tiles [i|f], [g|o]
+    for (int t = 0; t < Tout; ++t) {
+        const float* hcur = hbuf[t & 1];
+        float* hnxt = hbuf[(t + 1) & 1];
+        f32x4 accA, accB;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int b = b0 + 4 * (lane >> 4) + r;
+            const size_t go = ((size_t)b * T + t) * G4;
+            accA[r] = b < B ? gx[go + colA] : 0.0f;
+            accB[r] = b < B ? gx[go + colB] : 0.0f;
+        }
+        const float* arow = hcur + (lane & 15) * HS + (lane >> 4);
+#pragma unroll
+        for (int kk = 0; kk < 32; ++kk) {
+            const float a = arow[4 * kk];
+            accA = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wA[kk], accA, 0, 0, 0);
+            accB = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wB[kk], accB, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float pf_ = __shfl_xor(accA[r], 8);   // owner lanes receive the f pre-activation of their unit
+            const float po_ = __shfl_xor(accB[r], 8);   // ... and o
+            if (owner) {
+                const int b = b0 + 4 * (lane >> 4) + r;
+                const bool live = t < len[r];
+                const float ig = sigmoidf_(accA[r]), fg = sigmoidf_(pf_), gg = tanhf(accB[r]), og = sigmoidf_(po_);
+                const float cn = fg * cst[r] + ig * gg;
+                const float hn = og * tanhf(cn);
+                if (live) {
+                    cst[r] = cn;
+                    hst[r] = hn;
+                }
+                hnxt[(4 * (lane >> 4) + r) * HS + u] = hst[r];
+                if (b < B) {
+                    const size_t o = (size_t)b * T + t;
+                    gates[o * G4 + u] = ig;
+                    gates[o * G4 + HID + u] = fg;
+                    gates[o * G4 + 2 * HID + u] = gg;
+                    gates[o * G4 + 3 * HID + u] = og;
+                    cs[o * HID + u] = cn;
+                    hseq[((size_t)b * (T + 1) + t + 1) * HID + u] = live ? hn : 0.0f;   // padded outputs are zero
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (owner)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int b = b0 + 4 * (lane >> 4) + r;
+            if (b < B) {
+                hT[(size_t)b * HID + u] = hst[r];
+                cT[(size_t)b * HID + u] = cst[r];
+            }
+        }
+}
+
+// BPTT recurrence.  dy: (B,T,128) gradient w.r.t. the padded outputs h_t (nullptr: none); dhT/dcT: gradient w.r.t. the
+// final states (nullptr: none).  Writes dG (B,T,512), the pre-activation gate gradients (zero beyond each length),
+// for the batched weight-gradient GEMMs.
+__global__ __launch_bounds__(LSTM_THREADS) void lstm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ dhT,
+                                                                const float* __restrict__ dcT, const float* __restrict__ pb,
+                                                                const long long* __restrict__ lengths,
+                                                                const float* __restrict__ gates, const float* __restrict__ cs,
+                                                                const float* __restrict__ c0, float* __restrict__ dG, int B,
+                                                                int T, int Tout) {
+    __shared__ float dgt[16 * DGS];          // this step's dG tile (MFMA A operand)
+    __shared__ float part[2][16 * HS];       // the two K halves of dh_{t-1} = dG_t . W_hh
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b0 = blockIdx.x * 16;
+    float wk[64];
+#pragma unroll
+    for (int kk = 0; kk < 64; ++kk) wk[kk] = pb[((size_t)wave * 64 + kk) * 64 + lane];
+    const int nt = wave & 7, kh = wave >> 3;
+    // elementwise phase: thread owns cells (row = tid >> 6, unit = tid & 63) and (row, unit + 64)
+    const int row = tid >> 6, b = b0 + row;
+    const bool vb = b < B;
+    const int len = vb ? (lengths != nullptr ? (int)lengths[b] : T) : 0;
+    float dc[2], dhp[2];   // running dL/dc_t and the pass-through part of dL/dh_t
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int uu = (tid & 63) + 64 * q;
+        dc[q] = (vb && dcT != nullptr) ? dcT[(size_t)b * HID + uu] : 0.0f;
+        dhp[q] = (vb && dhT != nullptr) ? dhT[(size_t)b * HID + uu] : 0.0f;
+        part[0][row * HS + uu] = 0.0f;
+        part[1][row * HS + uu] = 0.0f;
+    }
+    __syncthreads();
+    for (int t = Tout - 1; t >= 0; --t) {
+        const bool live = t < len;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int uu = (tid & 63) + 64 * q;
+            // dL/dh_t = (recurrent term from step t+1) + (pass-through when h was frozen) + (output gradient)
+            float dh = part[0][row * HS + uu] + part[1][row * HS + uu] + dhp[q];
+            float di = 0.0f, df = 0.0f, dg = 0.0f, dov = 0.0f;
+            if (live) {
+                const size_t o = (size_t)b * T + t;
+                if (dy != nullptr) dh += dy[o * HID + uu];
+                const float ig = gates[o * G4 + uu], fg = gates[o * G4 + HID + uu];
+                const float gg = gates[o * G4 + 2 * HID + uu], og = gates[o * G4 + 3 * HID + uu];
+                const float cn = cs[o * HID + uu];
+                const float cp = t > 0 ? cs[(o - 1) * HID + uu] : (c0 != nullptr ? c0[(size_t)b * HID + uu] : 0.0f);
+                const float tc = tanhf(cn);
+                dov = dh * tc * og * (1.0f - og);
+                const float dct = dc[q] + dh * og * (1.0f - tc * tc);
+                di = dct * gg * ig * (1.0f - ig);
+                dg = dct * ig * (1.0f - gg * gg);
+                df = dct * cp * fg * (1.0f - fg);
+                dc[q] = dct * fg;
+                dhp[q] = 0.0f;      // h_t was produced by the cell: everything flows through the gates
+            } else {
+                dhp[q] = dh;        // frozen step (t >= length): h_t = h_{t-1}, c_t = c_{t-1}
+            }
+            dgt[row * DGS + uu] = di;
+            dgt[row * DGS + HID + uu] = df;
+            dgt[row * DGS + 2 * HID + uu] = dg;
+            dgt[row * DGS + 3 * HID + uu] = dov;
+            if (vb) {
+                const size_t o = ((size_t)b * T + t) * G4;
+                dG[o + uu] = di;
+                dG[o + HID + uu] = df;
+                dG[o + 2 * HID + uu] = dg;
+                dG[o + 3 * HID + uu] = dov;
+            }
+        }
+        __syncthreads();
+        // dh_{t-1}[row][16nt + n] (K half kh) = sum_col dG[row][256kh + col] * W_hh[256kh + col][16nt + n]
+        f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+        const float* arow = dgt + (lane & 15) * DGS + 256 * kh + (lane >> 4);
+#pragma unroll
+        for (int kk = 0; kk < 64; ++kk) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[4 * kk], wk[kk], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part[kh][(4 * (lane >> 4) + r) * HS + 16 * nt + (lane & 15)] = acc[r];
+        __syncthreads();
+    }
+}
+
+int gemm(hipStream_t s, bool a_major_k, const float* a, RowMap am, long a_ks, RowMap ak, const float* b, RowMap bk, long b_ns,
+         int M, int N, int K, int splits, const float* bias, int relu, float* c, long c_ms, long c_split_stride) {
+    const int kps = ((K + splits - 1) / splits + GK - 1) / GK * GK;
+    dim3 grid((N + GT - 1) / GT, (M + GT - 1) / GT, (K + kps - 1) / kps);
+    if (a_major_k)
+        hipLaunchKernelGGL(gemm_kernel<true>, grid, dim3(256), 0, s, a, am, a_ks, ak, b, bk, b_ns, M, N, K, kps, bias, relu, c,
+                           c_ms, c_split_stride);
+    else
+        hipLaunchKernelGGL(gemm_kernel<false>, grid, dim3(256), 0, s, a, am, a_ks, ak, b, bk, b_ns, M, N, K, kps, bias, relu,
+                           c, c_ms, c_split_stride);
+    return (int)grid.z;
+}
+
+constexpr int BIG = 1 << 30;
+inline RowMap lin(long stride) { return RowMap{BIG, 0, stride}; }
+
+// dW (N_out, K_in) = dOut^T (N_out x rows) . In (rows x K_in), rows given by row maps; split-K + deterministic sum
+void wgrad_gemm(hipStream_t s, const float* dout, RowMap dm, int n_out, const float* in, RowMap im, int k_in, int rows,
+                float* scratch, float* dw) {
+    int splits = rows / 512;
+    splits = splits < 1 ? 1 : (splits > 64 ? 64 : splits);
+    // A(m = out col, k = row) = dout[dm(k) + m]  -> unit stride is m
+    const int z = gemm(s, false, dout, lin(1), 0, dm, in, im, 1, n_out, k_in, rows, splits, nullptr, 0, scratch, k_in,
+                       (long)n_out * k_in);
+    const long n = (long)n_out * k_in;
+    hipLaunchKernelGGL(sum_slabs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float*)scratch, z, n, dw);
+}
+
+// out0 (and out1) = column sums of x over `rows` mapped rows; scratch holds <= 64 * n floats
+void colsum(hipStream_t s, const float* x, RowMap rm, int rows, int n, float* scratch, float* out0, float* out1) {
+    int chunks = rows / 256;
+    chunks = chunks < 1 ? 1 : (chunks > 64 ? 64 : chunks);
+    const int rpc = (rows + chunks - 1) / chunks;
+    hipLaunchKernelGGL(colsum_kernel, dim3((n + 63) / 64, chunks), dim3(256), 0, s, x, rm, rows, n, rpc, scratch);
+    hipLaunchKernelGGL(sum_slabs_kernel, dim3((n + 255) / 256), dim3(256), 0, s, (const float*)scratch, chunks, (long)n, out0);
+    if (out1 != nullptr)
+        hipLaunchKernelGGL(sum_slabs_kernel, dim3((n + 255) / 256), dim3(256), 0, s, (const float*)scratch, chunks, (long)n, out1);
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t howl_lstm_workspace_bytes(int B, int T) {
+    // packed W_hh (2 x 64K floats) + bias sum (512) + split-K scratch (64 x 512 x 128)
+    return ((size_t)2 * 16 * 64 * 64 + G4 + (size_t)64 * G4 * HID) * sizeof(float) + 1024;
+}
+
+int howl_lstm_fwd(const HowlLstmParams* p, const float* x, int B, int T, int M, const long long* lengths, const float* h0,
+                  const float* c0, const HowlLstmSaved* sv, float* hT, float* cT, void* ws, size_t ws_bytes,
+                  hipStream_t stream) {
+    HOWL_REQUIRE(p && x && sv && hT && cT && ws, "howl_lstm_fwd: null pointer");
+    HOWL_REQUIRE(B >= 1 && T >= 1 && M >= 1, "howl_lstm_fwd: bad shape");
+    HOWL_REQUIRE(sv->t_out >= 1 && sv->t_out <= T, "howl_lstm_fwd: t_out=%d outside 1..T", sv->t_out);
+    if (ws_bytes < howl_lstm_workspace_bytes(B, T)) {
+        howl_set_error("howl_lstm_fwd: workspace too small");
+        return HOWL_E_WORKSPACE;
+    }
+    float* pf = static_cast<float*>(ws);
+    float* pb = pf + 16 * 64 * 64;
+    float* bsum = pb + 16 * 64 * 64;
+    hipLaunchKernelGGL(lstm_pack_kernel, dim3(16 * 64 * 64 / 256), dim3(256), 0, stream, p->w_hh, pf, pb);
+    // bias = b_ih + b_hh folded into the input projection: gx = x W_ih^T + bias   (B*T, 512), K = M
+    hipLaunchKernelGGL(add2_kernel, dim3(G4 / 256), dim3(256), 0, stream, p->b_ih, p->b_hh, bsum, G4);
+    gemm(stream, true, x, lin(M), 1, lin(0), p->w_ih, lin(1), M, B * T, G4, M, 1, bsum, 0, sv->gx, G4, 0);
+    if (sv->t_out < T)   // rows of steps that never run are read (times zero) by the weight-gradient GEMM: keep them finite
+        hipMemsetAsync(sv->hseq, 0, (size_t)B * (T + 1) * HID * sizeof(float), stream);
+    hipLaunchKernelGGL(lstm_fwd_kernel, dim3((B + 15) / 16), dim3(LSTM_THREADS), 0, stream, (const float*)sv->gx,
+                       (const float*)pf, lengths, h0, c0, sv->gates, sv->c, sv->hseq, hT, cT, B, T, sv->t_out);
+    HOWL_CHECK_LAUNCH("howl_lstm_fwd");
+    return HOWL_OK;
+}
+
+int howl_lstm_bwd(const HowlLstmParams* p, const float* x, int B, int T, int M, const long long* lengths, const float* c0,
+                  const HowlLstmSaved* sv, const float* dy, const float* dhT, const float* dcT, const HowlLstmGrads* g,
+                  void* ws, size_t ws_bytes, hipStream_t stream) {
+    HOWL_REQUIRE(p && x && sv && g && ws, "howl_lstm_bwd: null pointer");
+    HOWL_REQUIRE(dy || dhT, "howl_lstm_bwd: no incoming gradient");
+    if (ws_bytes < howl_lstm_workspace_bytes(B, T)) {
+        howl_set_error("howl_lstm_bwd: workspace too small");
+        return HOWL_E_WORKSPACE;
+    }
+    float* pf = static_cast<float*>(ws);
+    float* pb = pf + 16 * 64 * 64;
+    float* scratch = pb + 16 * 64 * 64 + G4;
+    const int Tout = sv->t_out;
+    // steps t >= t_out never ran: their dG rows must read as zero in the weight-gradient GEMMs
+    hipMemsetAsync(sv->dgates, 0, (size_t)B * T * G4 * sizeof(float), stream);
+    hipLaunchKernelGGL(lstm_bwd_kernel, dim3((B + 15) / 16), dim3(LSTM_THREADS), 0, stream, dy, dhT, dcT, (const float*)pb,
+                       lengths, (const float*)sv->gates, (const float*)sv->c, c0, sv->dgates, B, T, Tout);
+    // dW_ih = dG^T X, dW_hh = dG^T H_prev (hseq rows t = 0..T-1 of each utterance), db = column sums of dG
+    const RowMap rows_bt = lin(G4);
+    wgrad_gemm(stream, sv->dgates, rows_bt, G4, x, lin(M), M, B * T, scratch, g->w_ih);
+    wgrad_gemm(stream, sv->dgates, rows_bt, G4, sv->hseq, RowMap{T, (long)(T + 1) * HID, HID}, HID, B * T, scratch, g->w_hh);
+    colsum(stream, sv->dgates, rows_bt, B * T, G4, scratch, g->b_ih, g->b_hh);
+    HOWL_CHECK_LAUNCH("howl_lstm_bwd");
+    return HOWL_OK;
+}
+
+size_t howl_linear_workspace_bytes(int n_out, int n_in) { return (size_t)64 * n_out * (n_in > 1 ? n_in : 1) * sizeof(float) + 256; }
+
+// y = x W^T + b (ReLU optional);  x rows: rows_outer x rows_inner with strides (elements), unit stride along features
+int howl_linear_fwd(const float* x, int rows_inner, long s_outer, long s_inner, int rows, int n_in, const float* w,
+                    const float* bias, int n_out, int relu, float* y, hipStream_t stream) {
+    HOWL_REQUIRE(x && w && y, "howl_linear_fwd: null pointer");
+    HOWL_REQUIRE(rows >= 1 && n_in >= 1 && n_out >= 1 && rows_inner >= 1, "howl_linear_fwd: bad shape");
+    gemm(stream, true, x, RowMap{rows_inner, s_outer, s_inner}, 1, lin(0), w, lin(1), n_in, rows, n_out, n_in, 1, bias, relu,
+         y, n_out, 0);
+    HOWL_CHECK_LAUNCH("howl_linear_fwd");
+    return HOWL_OK;
+}
+
+// dy (rows, n_out) contiguous [already masked by the caller's ReLU backward if any] -> dx (rows, n_in) contiguous
+// (nullable), dW (n_out, n_in), db (n_out)
+int howl_linear_bwd(const float* x, int rows_inner, long s_outer, long s_inner, int rows, int n_in, const float* w, int n_out,
+                    const float* dy, float* dx, float* dw, float* db, void* ws, size_t ws_bytes, hipStream_t stream) {
+    HOWL_REQUIRE(x && w && dy && dw && db && ws, "howl_linear_bwd: null pointer");
+    if (ws_bytes < howl_linear_workspace_bytes(n_out, n_in)) {
+        howl_set_error("howl_linear_bwd: workspace too small");
+        return HOWL_E_WORKSPACE;
+    }
+    if (dx != nullptr)   // dx = dy W : A = dy [m][k = n_out], B(k, n) = w[k * n_in + n]
+        gemm(stream, true, dy, lin(n_out), 1, lin(0), w, lin(n_in), 1, rows, n_in, n_out, 1, nullptr, 0, dx, n_in, 0);
+    wgrad_gemm(stream, dy, lin(n_out), n_out, x, RowMap{rows_inner, s_outer, s_inner}, n_in, rows, static_cast<float*>(ws),
+               dw);
+    colsum(stream, dy, lin(n_out), rows, n_out, static_cast<float*>(ws), db, nullptr);
+    HOWL_CHECK_LAUNCH("howl_linear_bwd");
+    return HOWL_OK;
+}
+
+int howl_relu_bwd(const float* dy, const float* y, size_t n, float* dz, hipStream_t stream) {
+    HOWL_REQUIRE(dy && y && dz, "howl_relu_bwd: null pointer");
+    if (n == 0) return HOWL_OK;
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(relu_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, dy, y, (long)n, dz);
+    HOWL_CHECK_LAUNCH("howl_relu_bwd");
+    return HOWL_OK;
+}
+
+}  // extern "C"

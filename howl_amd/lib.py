@@ -34,6 +34,18 @@ class HowlRes8Saved(ctypes.Structure):
     _fields_ = [("s", P * 7), ("y", P * 3), ("bn_stats", P), ("pooled", P)]
 
 
+class HowlLstmParams(ctypes.Structure):
+    _fields_ = [("w_ih", P), ("w_hh", P), ("b_ih", P), ("b_hh", P)]
+
+
+class HowlLstmGrads(ctypes.Structure):
+    _fields_ = [("w_ih", P), ("w_hh", P), ("b_ih", P), ("b_hh", P)]
+
+
+class HowlLstmSaved(ctypes.Structure):
+    _fields_ = [("gx", P), ("gates", P), ("c", P), ("hseq", P), ("dgates", P), ("t_out", c_int)]
+
+
 SIGNATURES = {
     "howl_version": [POINTER(c_int), POINTER(c_int)],
     "howl_profile_enable": [c_int],
@@ -51,10 +63,18 @@ SIGNATURES = {
     "howl_res8_bwd": [POINTER(HowlRes8Params), P, c_long, c_long, c_long, c_int, c_int, c_int, c_int,
                       POINTER(HowlRes8Saved), P, POINTER(HowlRes8Grads), P, c_size_t, STREAM],
     "howl_xent_fwd_bwd": [P, P, c_int, c_int, P, P, STREAM],
+    "howl_lstm_fwd": [POINTER(HowlLstmParams), P, c_int, c_int, c_int, P, P, P, POINTER(HowlLstmSaved), P, P, P, c_size_t,
+                      STREAM],
+    "howl_lstm_bwd": [POINTER(HowlLstmParams), P, c_int, c_int, c_int, P, P, POINTER(HowlLstmSaved), P, P, P,
+                      POINTER(HowlLstmGrads), P, c_size_t, STREAM],
+    "howl_linear_fwd": [P, c_int, c_long, c_long, c_int, c_int, P, P, c_int, c_int, P, STREAM],
+    "howl_linear_bwd": [P, c_int, c_long, c_long, c_int, c_int, P, c_int, P, P, P, P, P, c_size_t, STREAM],
+    "howl_relu_bwd": [P, P, c_size_t, P, STREAM],
     "howl_adamw_step": [P, P, P, P, c_size_t, c_float, c_float, c_float, c_float, c_float, c_int, c_float, STREAM],
 }
 # entry points that do not return an int status
-SIZE_FUNCS = {"howl_res8_workspace_bytes": [c_int, c_int]}
+SIZE_FUNCS = {"howl_res8_workspace_bytes": [c_int, c_int], "howl_lstm_workspace_bytes": [c_int, c_int],
+              "howl_linear_workspace_bytes": [c_int, c_int]}
 
 
 class HowlHipError(RuntimeError):

@@ -1,0 +1,185 @@
+"""``SequentialLstm`` ("seq-lstm") and ``SimpleLstm`` ("lstm") of ``howl/model/rnn.py:41-91`` on MI355X kernels
+(``howl_amd/csrc/lstm.hip``): packed-sequence LSTM(40 -> 128) + Linear(128,256)-ReLU-Linear(256,C).
+
+Same construction order / ``state_dict`` keys (``lstm.weight_ih_l0 ...``, ``dnn.0.*``, ``dnn.2.*``), same call protocol
+``model(x: (B, C>=1, M, T), lengths)`` and streaming-state protocol as the reference; ``nn.LSTM`` / ``nn.Linear`` are
+parameter containers only.  Like ``pack_padded_sequence`` the lengths must be sorted in decreasing order.
+"""
+import ctypes
+from typing import Any
+
+import torch
+import torch.nn as nn
+
+from howl_amd import lib as _lib
+from howl_amd import ops
+from howl_amd.settings import _EnvSettings
+
+from .base import RegisteredModel
+
+__all__ = ["LstmConfig", "SequentialLstm", "SimpleLstm"]
+
+HID = 128
+
+
+class LstmConfig(_EnvSettings):
+    num_mels: int = 40
+    hidden_size: int = 128
+    num_labels: int = 2
+
+
+def _vp(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+class _LstmFunction(torch.autograd.Function):
+    """x (B,T,M) contiguous, lengths (B) int64 on the device or None -> (hs (B,t_out,128) view, hT (B,128), cT (B,128))."""
+
+    @staticmethod
+    def forward(ctx, x, lengths, t_out, h0, c0, w_ih, w_hh, b_ih, b_hh):
+        B, T, M = x.shape
+        dev = x.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        bufs = dict(gx=torch.empty((B, T, 4 * HID), **f32), gates=torch.empty((B, T, 4 * HID), **f32),
+                    c=torch.empty((B, T, HID), **f32), hseq=torch.empty((B, T + 1, HID), **f32))
+        ws = torch.empty(_lib.get().cdll.howl_lstm_workspace_bytes(B, T), dtype=torch.uint8, device=dev)
+        hT, cT = torch.empty((B, HID), **f32), torch.empty((B, HID), **f32)
+        prm = _lib.HowlLstmParams(_vp(w_ih), _vp(w_hh), _vp(b_ih), _vp(b_hh))
+        sv = _lib.HowlLstmSaved(_vp(bufs["gx"]), _vp(bufs["gates"]), _vp(bufs["c"]), _vp(bufs["hseq"]), None, t_out)
+        _lib.get().call("howl_lstm_fwd", ctypes.byref(prm), _vp(x), B, T, M, _vp(lengths), _vp(h0), _vp(c0), ctypes.byref(sv),
+                        _vp(hT), _vp(cT), _vp(ws), ws.numel(), ops._stream())
+        ctx.save_for_backward(x, lengths, c0, w_ih, w_hh, b_ih, b_hh, bufs["gates"], bufs["c"], bufs["hseq"], ws)
+        ctx.t_out = t_out
+        hs = bufs["hseq"][:, 1:t_out + 1]
+        return hs, hT, cT
+
+    @staticmethod
+    def backward(ctx, d_hs, d_hT, d_cT):
+        x, lengths, c0, w_ih, w_hh, b_ih, b_hh, gates, cs, hseq, ws = ctx.saved_tensors
+        B, T, M = x.shape
+        t_out = ctx.t_out
+        dy = None
+        if d_hs is not None:
+            if t_out == T:
+                dy = d_hs.contiguous()
+            else:
+                dy = torch.zeros((B, T, HID), dtype=torch.float32, device=x.device)
+                dy[:, :t_out].copy_(d_hs)
+        d_hT = None if d_hT is None else d_hT.contiguous()
+        d_cT = None if d_cT is None else d_cT.contiguous()
+        dgates = torch.empty((B, T, 4 * HID), dtype=torch.float32, device=x.device)
+        grads = [torch.empty_like(p) for p in (w_ih, w_hh, b_ih, b_hh)]
+        prm = _lib.HowlLstmParams(_vp(w_ih), _vp(w_hh), _vp(b_ih), _vp(b_hh))
+        sv = _lib.HowlLstmSaved(None, _vp(gates), _vp(cs), _vp(hseq), _vp(dgates), t_out)
+        gr = _lib.HowlLstmGrads(*[_vp(g) for g in grads])
+        _lib.get().call("howl_lstm_bwd", ctypes.byref(prm), _vp(x), B, T, M, _vp(lengths), _vp(c0), ctypes.byref(sv), _vp(dy),
+                        _vp(d_hT), _vp(d_cT), ctypes.byref(gr), _vp(ws), ws.numel(), ops._stream())
+        return (None, None, None, None, None) + tuple(grads)
+
+
+class _LinearFunction(torch.autograd.Function):
+    """y = x W^T + b (+ReLU) for x of shape (..., n_in) whose rows follow a (rows_outer, rows_inner) stride pattern."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, relu):
+        n_out, n_in = w.shape
+        if x.dim() == 3:
+            outer, inner = x.shape[0], x.shape[1]
+            s_outer, s_inner = x.stride(0), x.stride(1)
+        else:
+            outer, inner, s_outer, s_inner = 1, x.shape[0], 0, x.stride(0)
+        if x.stride(-1) != 1:
+            raise ValueError("linear: features must be unit-stride")
+        rows = outer * inner
+        y = torch.empty(x.shape[:-1] + (n_out,), dtype=torch.float32, device=x.device)
+        _lib.get().call("howl_linear_fwd", _vp(x), inner, s_outer, s_inner, rows, n_in, _vp(w), _vp(b), n_out, int(relu), _vp(y),
+                        ops._stream())
+        ctx.save_for_backward(x, w, y if relu else None)
+        ctx.geom = (inner, s_outer, s_inner, rows, relu)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        inner, s_outer, s_inner, rows, relu = ctx.geom
+        n_out, n_in = w.shape
+        dy = dy.contiguous()
+        if relu:
+            dz = torch.empty_like(dy)
+            _lib.get().call("howl_relu_bwd", _vp(dy), _vp(y), dy.numel(), _vp(dz), ops._stream())
+            dy = dz
+        dx = torch.empty(x.shape, dtype=torch.float32, device=x.device) if ctx.needs_input_grad[0] else None
+        dw, db = torch.empty_like(w), torch.empty(n_out, dtype=torch.float32, device=w.device)
+        ws = torch.empty(_lib.get().cdll.howl_linear_workspace_bytes(n_out, n_in), dtype=torch.uint8, device=w.device)
+        _lib.get().call("howl_linear_bwd", _vp(x), inner, s_outer, s_inner, rows, n_in, _vp(w), n_out, _vp(dy), _vp(dx), _vp(dw),
+                        _vp(db), _vp(ws), ws.numel(), ops._stream())
+        return dx, dw, db, None
+
+
+class _LstmBase(RegisteredModel):
+    def __init__(self, num_labels: int, config: LstmConfig = None):
+        super().__init__(num_labels)
+        config = config or LstmConfig()
+        if config.hidden_size != HID:
+            raise NotImplementedError("the MI355X LSTM kernels are specialised for hidden_size=128")
+        self.lstm = nn.LSTM(config.num_mels, config.hidden_size)
+        self.dnn = nn.Sequential(nn.Linear(config.hidden_size, int(2 * config.hidden_size)), nn.ReLU(),
+                                 nn.Linear(int(2 * config.hidden_size), num_labels))
+        self.hc = None
+
+    def _run_lstm(self, x, lengths):
+        x0 = x[:, 0]                                   # (B, M, T), log-mels only (rnn.py:61,86)
+        if not x0.is_cuda:
+            raise _lib.HowlHipError("LSTM input must be on a HIP device (no CPU fallback)")
+        xb = x0.permute(0, 2, 1)
+        if not xb.is_contiguous():                     # the fused frontend already hands over a (B,T,M) buffer
+            xb = xb.contiguous()
+        B, T, _ = xb.shape
+        if lengths is not None:
+            lc = lengths.detach().cpu().long()
+            if lc.numel() != B:
+                raise RuntimeError("lengths must have one entry per sequence")
+            if (lc[:-1] < lc[1:]).any():
+                raise RuntimeError("`lengths` array must be sorted in decreasing order (pack_padded_sequence semantics)")
+            if lc.min() <= 0 or lc.max() > T:
+                raise RuntimeError("lengths must be in 1..T")
+            t_out = int(lc.max())
+            lengths = lc.to(xb.device)
+        else:
+            t_out = T
+        hx = self.streaming_state if self.is_streaming and self.streaming_state is not None else None
+        h0 = hx[0][0].contiguous() if hx is not None else None
+        c0 = hx[1][0].contiguous() if hx is not None else None
+        l = self.lstm
+        return _LstmFunction.apply(xb, lengths, t_out, h0, c0, l.weight_ih_l0, l.weight_hh_l0, l.bias_ih_l0, l.bias_hh_l0)
+
+    def _head(self, h):
+        y = _LinearFunction.apply(h, self.dnn[0].weight, self.dnn[0].bias, True)
+        return _LinearFunction.apply(y, self.dnn[2].weight, self.dnn[2].bias, False)
+
+
+class SequentialLstm(_LstmBase, name="seq-lstm"):
+    @property
+    def streaming_state(self) -> Any:
+        return self.hc
+
+    @streaming_state.setter
+    def streaming_state(self, x: Any):
+        self.hc = x
+
+    def forward(self, x, lengths):
+        hs, hT, cT = self._run_lstm(x, lengths)
+        if self.is_streaming:
+            self.streaming_state = (hT.detach().clone().unsqueeze(0), cT.detach().clone().unsqueeze(0))
+        return self._head(hs).permute(1, 0, 2)         # (T_len, B, num_labels), as dnn(rnn_seq) in rnn.py:71
+
+
+class SimpleLstm(_LstmBase, name="lstm"):
+    def forward(self, x, lengths):
+        if lengths is None:
+            raise TypeError("SimpleLstm needs lengths (rnn.py:88 packs unconditionally)")
+        hs, hT, cT = self._run_lstm(x, lengths)
+        if self.is_streaming:
+            # rnn.py:89-90 assigns streaming_state, which the base class setter drops (base.py:35-37): stays stateless
+            self.streaming_state = (hT.unsqueeze(0), cT.unsqueeze(0))
+        return self._head(hT)

@@ -134,6 +134,56 @@ int howl_xent_fwd_bwd(const float* logits, const long long* labels, int B, int C
 int howl_adamw_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
                     float eps, float weight_decay, int step, float grad_scale, hipStream_t stream);
 
+/* ---------------------------------------------------------------------------------------------------
+ * LSTM classifiers: howl/model/rnn.py:41-91 (SequentialLstm "seq-lstm", SimpleLstm "lstm"):
+ * pack_padded_sequence + nn.LSTM(40,128) (rnn.py:65-66,88) and the Linear-ReLU-Linear head (rnn.py:44-48,71,91).
+ * Batch-major internal layout: x (B,T,M) log-mels; lengths int64 (B) or NULL (= T for all).
+ * ------------------------------------------------------------------------------------------------- */
+typedef struct {
+    const float* w_ih; /* lstm.weight_ih_l0 (512, M) */
+    const float* w_hh; /* lstm.weight_hh_l0 (512, 128) */
+    const float* b_ih; /* lstm.bias_ih_l0 (512) */
+    const float* b_hh; /* lstm.bias_hh_l0 (512) */
+} HowlLstmParams;
+
+typedef struct {
+    float* w_ih;
+    float* w_hh;
+    float* b_ih;
+    float* b_hh;
+} HowlLstmGrads;
+
+typedef struct {
+    float* gx;     /* (B,T,512) input projection x W_ih^T + b_ih + b_hh */
+    float* gates;  /* (B,T,512) gate activations i,f,g,o */
+    float* c;      /* (B,T,128) cell states */
+    float* hseq;   /* (B,T+1,128): hseq[b][0] = h0, hseq[b][t+1] = h_t (zero for t >= length, as pad_packed_sequence) */
+    float* dgates; /* (B,T,512) gate pre-activation gradients (backward scratch) */
+    int t_out;     /* number of steps to run = max(lengths) (host int; the reference syncs for it too) */
+} HowlLstmSaved;
+
+size_t howl_lstm_workspace_bytes(int B, int T);
+/* h0/c0: (B,128) initial state or NULL (zeros) -- the streaming carry of rnn.py:62,67-68; hT/cT: final state (B,128). */
+int howl_lstm_fwd(const HowlLstmParams* p, const float* x, int B, int T, int M, const long long* lengths,
+                  const float* h0, const float* c0, const HowlLstmSaved* saved, float* hT, float* cT, void* ws,
+                  size_t ws_bytes, hipStream_t stream);
+/* dy: (B,T,128) gradient w.r.t. the padded outputs or NULL; dhT/dcT: (B,128) gradient w.r.t. the final state or NULL. */
+int howl_lstm_bwd(const HowlLstmParams* p, const float* x, int B, int T, int M, const long long* lengths,
+                  const float* c0, const HowlLstmSaved* saved, const float* dy, const float* dhT, const float* dcT,
+                  const HowlLstmGrads* grads, void* ws, size_t ws_bytes, hipStream_t stream);
+
+/* y = x W^T + b (optional ReLU).  x has `rows` rows of n_in contiguous floats; row r lives at
+ * (r / rows_inner) * s_outer + (r % rows_inner) * s_inner (elements), so (B,T+1,128) slices are usable in place. */
+size_t howl_linear_workspace_bytes(int n_out, int n_in);
+int howl_linear_fwd(const float* x, int rows_inner, long s_outer, long s_inner, int rows, int n_in, const float* w,
+                    const float* bias, int n_out, int relu, float* y, hipStream_t stream);
+/* dy (rows, n_out) contiguous -> dx (rows, n_in) contiguous (NULL to skip), dW (n_out, n_in), db (n_out). */
+int howl_linear_bwd(const float* x, int rows_inner, long s_outer, long s_inner, int rows, int n_in, const float* w,
+                    int n_out, const float* dy, float* dx, float* dw, float* db, void* ws, size_t ws_bytes,
+                    hipStream_t stream);
+/* dz = dy * (y > 0). */
+int howl_relu_bwd(const float* dy, const float* y, size_t n, float* dz, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

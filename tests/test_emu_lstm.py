@@ -1,0 +1,110 @@
+"""LSTM recurrence / BPTT / Linear kernels on the hipemu CPU emulator vs the oracle (and golden G6)."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from emu_util import emu_lib, ptr
+from howl_amd.lib import HowlLstmGrads, HowlLstmParams, HowlLstmSaved
+from oracle import models as om
+
+
+@pytest.fixture(scope="module")
+def lib():
+    return emu_lib()
+
+
+def run_lstm(lib, sd, x_btm, lengths, h0=None, c0=None):
+    B, T, M = x_btm.shape
+    npz = {k: np.ascontiguousarray(sd["lstm." + k].numpy()) for k in ("weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0")}
+    prm = HowlLstmParams(ptr(npz["weight_ih_l0"]), ptr(npz["weight_hh_l0"]), ptr(npz["bias_ih_l0"]), ptr(npz["bias_hh_l0"]))
+    bufs = dict(gx=np.zeros((B, T, 512), np.float32), gates=np.zeros((B, T, 512), np.float32),
+                c=np.zeros((B, T, 128), np.float32), hseq=np.full((B, T + 1, 128), np.nan, np.float32),
+                dgates=np.zeros((B, T, 512), np.float32))
+    t_out = int(lengths.max()) if lengths is not None else T
+    sv = HowlLstmSaved(ptr(bufs["gx"]), ptr(bufs["gates"]), ptr(bufs["c"]), ptr(bufs["hseq"]), ptr(bufs["dgates"]), t_out)
+    hT, cT = np.zeros((B, 128), np.float32), np.zeros((B, 128), np.float32)
+    ws = np.zeros(lib.cdll.howl_lstm_workspace_bytes(B, T), np.uint8)
+    x = np.ascontiguousarray(x_btm, np.float32)
+    ln = None if lengths is None else np.ascontiguousarray(lengths, np.int64)
+    lib.call("howl_lstm_fwd", ctypes.byref(prm), ptr(x), B, T, M, ptr(ln), ptr(h0), ptr(c0), ctypes.byref(sv), ptr(hT), ptr(cT),
+             ptr(ws), ws.size, None)
+    keep = dict(prm=prm, sv=sv, ws=ws, x=x, ln=ln, npz=npz, bufs=bufs, t_out=t_out)
+    return bufs["hseq"][:, 1:t_out + 1].copy(), hT, cT, keep
+
+
+def test_lstm_forward_backward_ragged(lib, golden):
+    g = golden("g6_seq_lstm")
+    g2, g4 = golden("g2_frontend_gsc"), golden("g4_zmuv")
+    lengths = g["frame_lengths"].astype(np.int64)          # descending, ragged: [78, 78, 78, 78, 69, 62]
+    x4 = torch.from_numpy((g2["feats"] - g4["mean"]) / g4["std"])          # (6,3,40,81)
+    x_btm = x4[:, 0].permute(0, 2, 1).contiguous().numpy()                 # (6,81,40)
+    sd = om.lstm_init(5)
+    hs, hT, cT, keep = run_lstm(lib, sd, x_btm, lengths)
+    # oracle (explicit cell loop, packed-sequence semantics)
+    xr = x4[:, 0].permute(2, 0, 1).contiguous()
+    p = {k: v.clone().requires_grad_(True) for k, v in sd.items() if k.startswith("lstm.")}
+    seq, (h_ref, c_ref) = om._lstm_cell_seq(p, xr, torch.from_numpy(lengths), None)
+    np.testing.assert_allclose(hs, seq.detach().permute(1, 0, 2).numpy(), rtol=0, atol=2e-6)
+    np.testing.assert_allclose(hT, h_ref[0].detach().numpy(), rtol=0, atol=2e-6)
+    np.testing.assert_allclose(cT, c_ref[0].detach().numpy(), rtol=0, atol=2e-6)
+    # seq-lstm logits through the Linear kernels vs the reference golden
+    B, T = x_btm.shape[:2]
+    t_out = keep["t_out"]
+    w1, b1, w2, b2 = (np.ascontiguousarray(sd[k].numpy()) for k in ("dnn.0.weight", "dnn.0.bias", "dnn.2.weight", "dnn.2.bias"))
+    hid = np.zeros((B * t_out, 256), np.float32)
+    hseq = keep["bufs"]["hseq"]
+    h1 = np.ascontiguousarray(hseq.reshape(-1)[128:])   # skip hseq[0][0] (h0): row (b,t) -> hseq[b][t+1]
+    lib.call("howl_linear_fwd", ptr(h1), t_out, (T + 1) * 128, 128, B * t_out, 128, ptr(w1), ptr(b1), 256, 1, ptr(hid), None)
+    logits = np.zeros((B * t_out, 5), np.float32)
+    lib.call("howl_linear_fwd", ptr(hid), 1 << 30, 0, 256, B * t_out, 256, ptr(w2), ptr(b2), 5, 0, ptr(logits), None)
+    np.testing.assert_allclose(logits.reshape(B, t_out, 5).transpose(1, 0, 2), g["logits"], rtol=0, atol=5e-6)
+
+    # BPTT: random output gradient + final-state gradients
+    rng = np.random.default_rng(0)
+    dy = np.zeros((B, T, 128), np.float32)
+    dy[:, :t_out] = rng.standard_normal((B, t_out, 128)).astype(np.float32)
+    dhT = rng.standard_normal((B, 128)).astype(np.float32)
+    dcT = rng.standard_normal((B, 128)).astype(np.float32)
+    gr = {k: np.full_like(v, np.nan) for k, v in keep["npz"].items()}
+    grads = HowlLstmGrads(ptr(gr["weight_ih_l0"]), ptr(gr["weight_hh_l0"]), ptr(gr["bias_ih_l0"]), ptr(gr["bias_hh_l0"]))
+    lib.call("howl_lstm_bwd", ctypes.byref(keep["prm"]), ptr(keep["x"]), B, T, 40, ptr(keep["ln"]), None, ctypes.byref(keep["sv"]),
+             ptr(dy), ptr(dhT), ptr(dcT), ctypes.byref(grads), ptr(keep["ws"]), keep["ws"].size, None)
+    loss = (seq * torch.from_numpy(dy[:, :t_out]).permute(1, 0, 2)).sum() + (h_ref[0] * torch.from_numpy(dhT)).sum() + \
+           (c_ref[0] * torch.from_numpy(dcT)).sum()
+    loss.backward()
+    for k in ("weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0"):
+        ref = p["lstm." + k].grad.numpy()
+        np.testing.assert_allclose(gr[k], ref, rtol=0, atol=2e-5 * max(1.0, np.abs(ref).max()), err_msg=k)
+
+
+def test_lstm_streaming_carry_and_no_lengths(lib):
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal((3, 9, 40)).astype(np.float32)
+    sd = om.lstm_init(5)
+    a, hT, cT, _ = run_lstm(lib, sd, x[:, :5], None)
+    b, hT2, cT2, _ = run_lstm(lib, sd, x[:, 5:], None, h0=hT, c0=cT)      # carry (h, c) across calls (rnn.py:62,67-68)
+    full, hTf, cTf, _ = run_lstm(lib, sd, x, None)
+    np.testing.assert_allclose(np.concatenate([a, b], 1), full, rtol=0, atol=1e-6)
+    np.testing.assert_allclose(hT2, hTf, rtol=0, atol=1e-6)
+
+
+def test_linear_backward(lib):
+    rng = np.random.default_rng(2)
+    rows, n_in, n_out = 77, 128, 256
+    x = rng.standard_normal((rows, n_in)).astype(np.float32)
+    w = rng.standard_normal((n_out, n_in)).astype(np.float32) * 0.1
+    dy = rng.standard_normal((rows, n_out)).astype(np.float32)
+    dx, dw, db = np.zeros_like(x), np.zeros_like(w), np.zeros(n_out, np.float32)
+    ws = np.zeros(lib.cdll.howl_linear_workspace_bytes(n_out, n_in), np.uint8)
+    lib.call("howl_linear_bwd", ptr(x), 1 << 30, 0, n_in, rows, n_in, ptr(w), n_out, ptr(dy), ptr(dx), ptr(dw), ptr(db), ptr(ws),
+             ws.size, None)
+    np.testing.assert_allclose(dx, dy @ w, rtol=0, atol=2e-5)
+    np.testing.assert_allclose(dw, dy.T @ x, rtol=0, atol=5e-5)
+    np.testing.assert_allclose(db, dy.sum(0), rtol=0, atol=2e-5)
+    y = rng.standard_normal(1000).astype(np.float32)
+    dz = np.zeros(1000, np.float32)
+    g = rng.standard_normal(1000).astype(np.float32)
+    lib.call("howl_relu_bwd", ptr(g), ptr(y), 1000, ptr(dz), None)
+    np.testing.assert_array_equal(dz, np.where(y > 0, g, 0))

@@ -1,0 +1,88 @@
+"""-m gpu parity: lstm / seq-lstm on the HIP path vs golden vectors captured from the reference (G6) and the oracle at
+the BASELINE config-4 size (seq-lstm, batch 512, 0.5 s windows, CTC)."""
+import numpy as np
+import pytest
+import torch
+
+from gpu_util import DEV, golden_features, maxerr, t
+from oracle import frontend as ofe
+from oracle import models as om
+
+pytestmark = pytest.mark.gpu
+
+
+def make(name, C):
+    from howl_amd.model import RegisteredModel
+    m = RegisteredModel.find_registered_class(name)(C)
+    m.load_state_dict({k: v.clone() for k, v in om.lstm_init(C).items()})
+    return m.to(DEV)
+
+
+@pytest.mark.parametrize("name", ["lstm", "seq-lstm"])
+def test_golden_forward_backward_streaming(golden, name):
+    g = golden("g6_" + name.replace("-", "_"))
+    x, _ = golden_features(golden)
+    xd = x.to(DEV)
+    flen = t(g["frame_lengths"])
+    model = make(name, 5).eval()
+    with torch.no_grad():
+        logits = model(xd, flen)
+    assert logits.shape == g["logits"].shape
+    assert maxerr(logits, g["logits"]) < 1e-3 and maxerr(logits, g["logits"]) < 2e-5
+    model.train()
+    sc = model(xd, flen)
+    if name == "lstm":
+        loss = torch.nn.functional.cross_entropy(sc, (torch.arange(6) % 5).to(DEV))
+    else:
+        lp = torch.nn.functional.log_softmax(sc, -1)
+        loss = torch.nn.CTCLoss(4)(lp, torch.tensor([[0, 1, 2]] * 6).to(DEV), flen, torch.tensor([3] * 6))
+    loss.backward()
+    assert abs(loss.item() - float(g["loss0"])) < 1e-4
+    for n, p in model.named_parameters():
+        ref = g["grad0." + n]
+        assert maxerr(p.grad, ref) < 5e-5 * max(1.0, float(np.abs(ref).max())), n
+    # streaming carry over two consecutive calls (rnn.py:62,67-68)
+    model.eval().streaming()
+    with torch.no_grad():
+        if name == "seq-lstm":
+            a = model(xd[:1, :, :, :40], None)
+            b = model(xd[:1, :, :, 40:], None)
+        else:
+            a = model(xd[:1, :, :, :40], torch.tensor([40]))
+            b = model(xd[:1, :, :, 40:], torch.tensor([41]))
+    assert maxerr(a, g["stream_a"]) < 2e-5 and maxerr(b, g["stream_b"]) < 2e-5
+    with pytest.raises(RuntimeError):
+        model(xd, torch.tensor([10, 78, 78, 78, 69, 62]))        # unsorted lengths: same error class as pack_padded_sequence
+
+
+def test_config4_seq_lstm_ctc_step_vs_oracle():
+    """BASELINE configs[3]: seq-lstm, batch 512, 0.5 s (T=41, 38 valid frames), CTC blank=4; ragged variant included."""
+    from howl_amd.data.transform.operator import ZmuvTransform
+    from howl_amd.data.transform.transform import StandardAudioTransform
+    from howl_amd.utils.synth import synthetic_pcm
+    B, L, C = 512, 8000, 5
+    pcm = synthetic_pcm(B, L)
+    std = StandardAudioTransform().to(DEV).eval()
+    zmuv = ZmuvTransform().to(DEV)
+    zmuv.update(std(pcm[:4].to(DEV)))
+    feats = std.log_mel_for_model(pcm.to(DEV), zmuv)
+    fb = ofe.mel_fb(40)
+    z = ofe.Zmuv()
+    z.update(ofe.standard_audio_transform(pcm[:4], fb))
+    x_ref = z(ofe.standard_audio_transform(pcm, fb))
+    targets = torch.tensor([[0, 1, 2]] * B)
+    for lengths in (torch.full((B,), 38), torch.sort(20 + torch.arange(B) % 19, descending=True).values):
+        model = make("seq-lstm", C).train()
+        sc = model(feats, lengths)
+        loss = torch.nn.CTCLoss(4)(torch.log_softmax(sc, -1), targets.to(DEV), lengths, torch.tensor([3] * B))
+        loss.backward()
+        sd = {k: v.clone().requires_grad_(True) for k, v in om.lstm_init(C).items()}
+        ref, _ = om.seq_lstm_forward(sd, x_ref, lengths)
+        ref_loss = torch.nn.CTCLoss(4)(torch.log_softmax(ref, -1), targets, lengths, torch.tensor([3] * B))
+        ref_loss.backward()
+        assert sc.shape == ref.shape and maxerr(sc, ref) < 1e-3
+        assert torch.equal(sc.argmax(-1).cpu(), ref.argmax(-1))
+        assert abs(loss.item() - ref_loss.item()) < 1e-4
+        for n, p in model.named_parameters():
+            r = sd[n].grad
+            assert maxerr(p.grad, r) < 1e-4 * max(1.0, r.abs().max().item()), n
