@@ -618,7 +618,8 @@ __device__ __forceinline__ void load_feat_tile(float* tin, const float* feat, lo
 
 __global__ __launch_bounds__(C0_THREADS) void conv0_fwd_kernel(const float* __restrict__ feat, long sb, long st, long sm,
                                                                const float* __restrict__ w0, float* __restrict__ s0,
-                                                               int B, int T, int M, int H) {
+                                                               unsigned short* __restrict__ mask0, int B, int T, int M,
+                                                               int H) {
     HIP_DYNAMIC_SHARED(float, lds)
     float* tin = lds;                       // (T+2) x (M+2)
     float* lw = lds + (T + 2) * (M + 2);    // 405 weights
@@ -644,6 +645,7 @@ __global__ __launch_bounds__(C0_THREADS) void conv0_fwd_kernel(const float* __re
 #pragma unroll
                 for (int k = 0; k < 9; ++k) wk[k] = lw[c * 9 + k];
                 float sum = 0.0f;
+                unsigned bits = 0;   // bit (4i + j): pre-pool activation (3ph + i, 4pw + j) is positive
 #pragma unroll
                 for (int i = 0; i < 3; ++i)
 #pragma unroll
@@ -654,31 +656,30 @@ __global__ __launch_bounds__(C0_THREADS) void conv0_fwd_kernel(const float* __re
 #pragma unroll
                             for (int kw = 0; kw < 3; ++kw) z = fmaf(patch[i + kh][j + kw], wk[kh * 3 + kw], z);
                         sum += fmaxf(z, 0.0f);
+                        bits |= (z > 0.0f ? 1u : 0u) << (4 * i + j);
                     }
                 s0[((size_t)b * NMAP + c) * P + p] = sum * (1.0f / 12.0f);
+                if (mask0 != nullptr) mask0[((size_t)b * NMAP + c) * P + p] = (unsigned short)bits;
             }
         }
     }
 }
 
 // dW0[c][tap] = sum_{b, pooled pos, 3x4 window} (dy0/12) * [z > 0] * in[...],  dy0 = ga + gb (dx0 from layer 1 + skip).
-// The pre-pool activation is recomputed (cheaper than storing 583 KB/utterance).  A wave walks its 5 channels one
-// at a time (9 accumulators live), folds them across lanes per utterance and keeps the running sums in LDS.
+// The ReLU pattern of the pre-pool activation comes from the forward's 12-bit masks (2 B per pooled output instead of
+// the 583 KB/utterance tensor or a recomputation).  A wave walks its 5 channels one at a time (9 accumulators live),
+// folds them across lanes per utterance and keeps the running sums in LDS.
 __global__ __launch_bounds__(C0_THREADS) void conv0_wgrad_kernel(const float* __restrict__ feat, long sb, long st, long sm,
-                                                                 const float* __restrict__ w0, const float* __restrict__ ga,
-                                                                 const float* __restrict__ gb, float* __restrict__ part,
-                                                                 int B, int T, int M, int H) {
+                                                                 const unsigned short* __restrict__ mask0,
+                                                                 const float* __restrict__ ga, const float* __restrict__ gb,
+                                                                 float* __restrict__ part, int B, int T, int M, int H) {
     HIP_DYNAMIC_SHARED(float, lds)
     float* tin = lds;
-    float* lw = lds + (T + 2) * (M + 2);
-    float* lacc = lw + NMAP * 9;
+    float* lacc = lds + (T + 2) * (M + 2);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int pitch = M + 2;
     const int P = H * PW;
-    for (int i = tid; i < NMAP * 9; i += C0_THREADS) {
-        lw[i] = w0[i];
-        lacc[i] = 0.0f;
-    }
+    for (int i = tid; i < NMAP * 9; i += C0_THREADS) lacc[i] = 0.0f;
     for (int b = blockIdx.x; b < B; b += gridDim.x) {
         __syncthreads();
         load_feat_tile(tin, feat, sb, st, sm, b, T, M, tid, C0_THREADS);
@@ -686,12 +687,9 @@ __global__ __launch_bounds__(C0_THREADS) void conv0_wgrad_kernel(const float* __
 #pragma unroll 1
         for (int cc = 0; cc < C0_GROUP; ++cc) {
             const int c = wave * C0_GROUP + cc;
-            float wk[9], gw[9];
+            float gw[9];
 #pragma unroll
-            for (int k = 0; k < 9; ++k) {
-                wk[k] = lw[c * 9 + k];
-                gw[k] = 0.0f;
-            }
+            for (int k = 0; k < 9; ++k) gw[k] = 0.0f;
             for (int p = lane; p < P; p += 64) {
                 const int ph = p / PW, pw = p - ph * PW;
                 float patch[5][6];
@@ -701,16 +699,12 @@ __global__ __launch_bounds__(C0_THREADS) void conv0_wgrad_kernel(const float* __
                     for (int j = 0; j < 6; ++j) patch[i][j] = tin[(3 * ph + i) * pitch + 4 * pw + j];
                 const size_t o = ((size_t)b * NMAP + c) * P + p;
                 const float g = (ga[o] + (gb != nullptr ? gb[o] : 0.0f)) * (1.0f / 12.0f);
+                const unsigned bits = mask0[o];
 #pragma unroll
                 for (int i = 0; i < 3; ++i)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        float z = 0.0f;
-#pragma unroll
-                        for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-                            for (int kw = 0; kw < 3; ++kw) z = fmaf(patch[i + kh][j + kw], wk[kh * 3 + kw], z);
-                        const float gz = z > 0.0f ? g : 0.0f;
+                        const float gz = ((bits >> (4 * i + j)) & 1u) ? g : 0.0f;
 #pragma unroll
                         for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
@@ -946,8 +940,8 @@ int howl_res8_fwd(const HowlRes8Params* prm, const float* feat, long sb, long st
 
     const size_t l0 = conv0_lds_bytes(T, M);
     hipFuncSetAttribute(reinterpret_cast<const void*>(conv0_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l0);
-    hipLaunchKernelGGL(conv0_fwd_kernel, dim3(G), dim3(C0_THREADS), l0, stream, feat, sb, st, sm, prm->conv0_w, sv->s[0], B,
-                       T, M, H);
+    hipLaunchKernelGGL(conv0_fwd_kernel, dim3(G), dim3(C0_THREADS), l0, stream, feat, sb, st, sm, prm->conv0_w, sv->s[0],
+                       sv->mask0, B, T, M, H);
     const size_t lc = conv_lds_bytes(H);
     hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_mfma_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
                         (int)lc);
@@ -1049,7 +1043,9 @@ int howl_res8_bwd(const HowlRes8Params* prm, const float* feat, long sb, long st
     const size_t l0 = conv0_lds_bytes(T, M);
     hipFuncSetAttribute(reinterpret_cast<const void*>(conv0_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                         (int)l0);
-    hipLaunchKernelGGL(conv0_wgrad_kernel, dim3(G), dim3(C0_THREADS), l0, stream, feat, sb, st, sm, prm->conv0_w,
+    HOWL_REQUIRE(sv->mask0 != nullptr, "howl_res8_bwd: saved->mask0 is required");
+    hipLaunchKernelGGL(conv0_wgrad_kernel, dim3(G), dim3(C0_THREADS), l0, stream, feat, sb, st, sm,
+                       (const unsigned short*)sv->mask0,
                        (const float*)dx_cur, (const float*)ds_prev, w.c0part, B, T, M, H);
     hipLaunchKernelGGL(reduce_rows_kernel, dim3((NMAP * 9 + 63) / 64), dim3(256), 0, stream, (const float*)w.c0part, G,
                        NMAP * 9, 0, gr->conv0_w);

@@ -41,6 +41,7 @@ class _Res8Buffers:
         self.y = [torch.empty((B, 45, H, 10), **f32) for _ in range(3)]
         self.bn_stats = torch.zeros((6, 2, 48), **f32)
         self.pooled = torch.empty((B, 48), **f32)
+        self.mask0 = torch.empty((B, 45, H, 10), dtype=torch.int16, device=device)
         nbytes = _lib.get().cdll.howl_res8_workspace_bytes(B, T)
         self.ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
         self.saved = _lib.HowlRes8Saved()
@@ -50,6 +51,7 @@ class _Res8Buffers:
             self.saved.y[i] = _vp(self.y[i])
         self.saved.bn_stats = _vp(self.bn_stats)
         self.saved.pooled = _vp(self.pooled)
+        self.saved.mask0 = _vp(self.mask0)
 
 
 class _Res8Function(torch.autograd.Function):

@@ -107,6 +107,7 @@ typedef struct {
     float* y[3];       /* relu(conv_i(.)) before the residual add for i = 2,4,6 (ReLU mask of the backward) */
     float* bn_stats;   /* (6, 2, 48): per layer {mean[48], rstd[48]} used by this forward */
     float* pooled;     /* (B, 48): spatial mean of BN6's output */
+    unsigned short* mask0; /* (B,45,T/3,10) uint16: ReLU pattern of conv0's 3x4 pre-pool window (bit 4i+j); NULL in eval */
 } HowlRes8Saved;
 
 size_t howl_res8_workspace_bytes(int B, int T);

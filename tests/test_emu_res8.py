@@ -45,6 +45,8 @@ class Res8Harness:
             self.saved.y[i] = ptr(self.y[i]).value
         self.saved.bn_stats = ptr(self.bn_stats)
         self.saved.pooled = ptr(self.pooled)
+        self.mask0 = np.zeros((B, 45, self.H, 10), np.uint16)
+        self.saved.mask0 = ptr(self.mask0)
         self.grads_np = {k: np.full_like(self.np[k], np.nan) for k in om.res8_param_names()}
         self.gr = HowlRes8Grads()
         self.gr.conv0_w = ptr(self.grads_np["conv0.weight"])

@@ -13,3 +13,4 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_
 cd $GRAFT_REPO_ROOT
 find gpurun_out/prof -name "*stats*" | head; f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -30 "$f"
 echo "== kernel scaling"; timeout 300 python tools/kernel_scaling.py 2>&1 | tee gpurun_out/kernel_scaling.log | tail -6
+echo "== other configs"; timeout 300 python tools/bench_configs.py 2>&1 | tee gpurun_out/bench_configs.log | tail -6
