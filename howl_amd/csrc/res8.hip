@@ -606,13 +606,29 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_kernel(
 constexpr int C0_THREADS = 576;
 constexpr int C0_GROUP = 5;
 
+// tin[(T+2)][M+4] with a zero halo; the row pitch is a multiple of 4 floats so that the 6-wide patch row of pooled
+// column pw (tile columns 4pw .. 4pw+5) is one aligned ds_read_b128 + one ds_read_b64 instead of six strided b32 reads
 __device__ __forceinline__ void load_feat_tile(float* tin, const float* feat, long sb, long st, long sm, int b, int T,
                                                int M, int tid, int nthreads) {
-    // tin[(T+2)][M+2], zero halo
-    const int pitch = M + 2;
+    const int pitch = M + 4;
     for (int i = tid; i < (T + 2) * pitch; i += nthreads) {
         const int t = i / pitch - 1, m = i % pitch - 1;
         tin[i] = (t >= 0 && t < T && m >= 0 && m < M) ? feat[b * sb + t * st + m * sm] : 0.0f;
+    }
+}
+
+__device__ __forceinline__ void load_patch(const float* tin, int pitch, int ph, int pw, float (&patch)[5][6]) {
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const float* row = tin + (3 * ph + i) * pitch + 4 * pw;
+        const float4 a = *reinterpret_cast<const float4*>(row);
+        const float2 c = *reinterpret_cast<const float2*>(row + 4);
+        patch[i][0] = a.x;
+        patch[i][1] = a.y;
+        patch[i][2] = a.z;
+        patch[i][3] = a.w;
+        patch[i][4] = c.x;
+        patch[i][5] = c.y;
     }
 }
 
@@ -622,9 +638,9 @@ __global__ __launch_bounds__(C0_THREADS) void conv0_fwd_kernel(const float* __re
                                                                int H) {
     HIP_DYNAMIC_SHARED(float, lds)
     float* tin = lds;                       // (T+2) x (M+2)
-    float* lw = lds + (T + 2) * (M + 2);    // 405 weights
+    float* lw = lds + (T + 2) * (M + 4);    // 405 weights
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int pitch = M + 2;
+    const int pitch = M + 4;
     const int P = H * PW;
     for (int i = tid; i < NMAP * 9; i += C0_THREADS) lw[i] = w0[i];
     for (int b = blockIdx.x; b < B; b += gridDim.x) {
@@ -634,12 +650,9 @@ __global__ __launch_bounds__(C0_THREADS) void conv0_fwd_kernel(const float* __re
         for (int p = lane; p < P; p += 64) {
             const int ph = p / PW, pw = p - ph * PW;
             float patch[5][6];
-#pragma unroll
-            for (int i = 0; i < 5; ++i)
-#pragma unroll
-                for (int j = 0; j < 6; ++j) patch[i][j] = tin[(3 * ph + i) * pitch + 4 * pw + j];
-#pragma unroll
-            for (int cc = 0; cc < C0_GROUP; ++cc) {
+            load_patch(tin, pitch, ph, pw, patch);
+#pragma unroll 1
+            for (int cc = 0; cc < C0_GROUP; ++cc) {   // one channel at a time: interleaving five blows the register file
                 const int c = wave * C0_GROUP + cc;
                 float wk[9];
 #pragma unroll
@@ -675,9 +688,9 @@ __global__ __launch_bounds__(C0_THREADS) void conv0_wgrad_kernel(const float* __
                                                                  float* __restrict__ part, int B, int T, int M, int H) {
     HIP_DYNAMIC_SHARED(float, lds)
     float* tin = lds;
-    float* lacc = lds + (T + 2) * (M + 2);
+    float* lacc = lds + (T + 2) * (M + 4);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int pitch = M + 2;
+    const int pitch = M + 4;
     const int P = H * PW;
     for (int i = tid; i < NMAP * 9; i += C0_THREADS) lacc[i] = 0.0f;
     for (int b = blockIdx.x; b < B; b += gridDim.x) {
@@ -693,10 +706,7 @@ __global__ __launch_bounds__(C0_THREADS) void conv0_wgrad_kernel(const float* __
             for (int p = lane; p < P; p += 64) {
                 const int ph = p / PW, pw = p - ph * PW;
                 float patch[5][6];
-#pragma unroll
-                for (int i = 0; i < 5; ++i)
-#pragma unroll
-                    for (int j = 0; j < 6; ++j) patch[i][j] = tin[(3 * ph + i) * pitch + 4 * pw + j];
+                load_patch(tin, pitch, ph, pw, patch);
                 const size_t o = ((size_t)b * NMAP + c) * P + p;
                 const float g = (ga[o] + (gb != nullptr ? gb[o] : 0.0f)) * (1.0f / 12.0f);
                 const unsigned bits = mask0[o];
@@ -855,7 +865,7 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
 
 size_t conv_lds_bytes(int H) { return (size_t)(3 * KSTEPS * 64 + tile_floats(H) + 2 * CP + 12 * 2 * 16) * sizeof(float); }
 size_t wgrad_lds_bytes(int H) { return (size_t)(2 * tile_floats(H) + 2 * CP) * sizeof(float); }
-size_t conv0_lds_bytes(int T, int M) { return (size_t)((T + 2) * (M + 2) + 2 * NMAP * 9) * sizeof(float); }
+size_t conv0_lds_bytes(int T, int M) { return (size_t)((T + 2) * (M + 4) + 2 * NMAP * 9) * sizeof(float); }
 
 struct Ws {
     float* wp_fwd;   // [6][3][108][64]
