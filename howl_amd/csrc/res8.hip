@@ -651,8 +651,8 @@ __global__ __launch_bounds__(C0_THREADS) void conv0_fwd_kernel(const float* __re
             const int ph = p / PW, pw = p - ph * PW;
             float patch[5][6];
             load_patch(tin, pitch, ph, pw, patch);
-#pragma unroll 1
-            for (int cc = 0; cc < C0_GROUP; ++cc) {   // one channel at a time: interleaving five blows the register file
+#pragma unroll 2
+            for (int cc = 0; cc < C0_GROUP; ++cc) {   // two channels in flight: interleaving all five blows the register file
                 const int c = wave * C0_GROUP + cc;
                 float wk[9];
 #pragma unroll
@@ -692,10 +692,19 @@ __global__ __launch_bounds__(C0_THREADS) void conv0_wgrad_kernel(const float* __
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int pitch = M + 4;
     const int P = H * PW;
+    float* lg = lacc + NMAP * 9;                                               // (45, P) pooled gradients / 12
+    unsigned short* lm = reinterpret_cast<unsigned short*>(lg + NMAP * P);     // (45, P) ReLU masks
     for (int i = tid; i < NMAP * 9; i += C0_THREADS) lacc[i] = 0.0f;
     for (int b = blockIdx.x; b < B; b += gridDim.x) {
         __syncthreads();
         load_feat_tile(tin, feat, sb, st, sm, b, T, M, tid, C0_THREADS);
+        // the utterance's gradients and masks are staged in bulk (coalesced, all loads in flight together); reading
+        // them one dependent global load per inner-loop iteration was latency-bound
+        const size_t ub = (size_t)b * NMAP * P;
+        for (int i = tid; i < NMAP * P; i += C0_THREADS) {
+            lg[i] = (ga[ub + i] + (gb != nullptr ? gb[ub + i] : 0.0f)) * (1.0f / 12.0f);
+            lm[i] = mask0[ub + i];
+        }
         __syncthreads();
 #pragma unroll 1
         for (int cc = 0; cc < C0_GROUP; ++cc) {
@@ -707,9 +716,8 @@ __global__ __launch_bounds__(C0_THREADS) void conv0_wgrad_kernel(const float* __
                 const int ph = p / PW, pw = p - ph * PW;
                 float patch[5][6];
                 load_patch(tin, pitch, ph, pw, patch);
-                const size_t o = ((size_t)b * NMAP + c) * P + p;
-                const float g = (ga[o] + (gb != nullptr ? gb[o] : 0.0f)) * (1.0f / 12.0f);
-                const unsigned bits = mask0[o];
+                const float g = lg[c * P + p];
+                const unsigned bits = lm[c * P + p];
 #pragma unroll
                 for (int i = 0; i < 3; ++i)
 #pragma unroll
@@ -866,6 +874,10 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
 size_t conv_lds_bytes(int H) { return (size_t)(3 * KSTEPS * 64 + tile_floats(H) + 2 * CP + 12 * 2 * 16) * sizeof(float); }
 size_t wgrad_lds_bytes(int H) { return (size_t)(2 * tile_floats(H) + 2 * CP) * sizeof(float); }
 size_t conv0_lds_bytes(int T, int M) { return (size_t)((T + 2) * (M + 4) + 2 * NMAP * 9) * sizeof(float); }
+size_t conv0_wgrad_lds_bytes(int T, int M) {
+    const int P = (T / 3) * PW;
+    return conv0_lds_bytes(T, M) + (size_t)NMAP * P * (sizeof(float) + sizeof(unsigned short)) + 16;
+}
 
 struct Ws {
     float* wp_fwd;   // [6][3][108][64]
@@ -1051,10 +1063,11 @@ int howl_res8_bwd(const HowlRes8Params* prm, const float* feat, long sb, long st
     }
     // conv0: dy0 = dx_0 (from layer 1's dgrad) + ds_2 (skip into s_2 = y_2 + y_0)
     const size_t l0 = conv0_lds_bytes(T, M);
+    const size_t l0w = conv0_wgrad_lds_bytes(T, M);
     hipFuncSetAttribute(reinterpret_cast<const void*>(conv0_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                        (int)l0);
+                        (int)l0w);
     HOWL_REQUIRE(sv->mask0 != nullptr, "howl_res8_bwd: saved->mask0 is required");
-    hipLaunchKernelGGL(conv0_wgrad_kernel, dim3(G), dim3(C0_THREADS), l0, stream, feat, sb, st, sm,
+    hipLaunchKernelGGL(conv0_wgrad_kernel, dim3(G), dim3(C0_THREADS), l0w, stream, feat, sb, st, sm,
                        (const unsigned short*)sv->mask0,
                        (const float*)dx_cur, (const float*)ds_prev, w.c0part, B, T, M, H);
     hipLaunchKernelGGL(reduce_rows_kernel, dim3((NMAP * 9 + 63) / 64), dim3(256), 0, stream, (const float*)w.c0part, G,
