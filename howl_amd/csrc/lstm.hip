@@ -215,16 +215,28 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(const float* __r
     }
     __syncthreads();
     const int colA = (n >> 3) * HID + u, colB = (2 + (n >> 3)) * HID + u;   // this lane's columns in tiles [i|f], [g|o]
+    // input-projection terms of step t+1 are fetched while step t multiplies (a dependent global load per step would
+    // put HBM latency on the critical path of every one of the 38-81 sequential steps)
+    f32x4 nxA, nxB;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int b = b0 + 4 * (lane >> 4) + r;
+        const size_t go = ((size_t)b * T) * G4;
+        nxA[r] = b < B ? gx[go + colA] : 0.0f;
+        nxB[r] = b < B ? gx[go + colB] : 0.0f;
+    }
     for (int t = 0; t < Tout; ++t) {
         const float* hcur = hbuf[t & 1];
         float* hnxt = hbuf[(t + 1) & 1];
-        f32x4 accA, accB;
+        f32x4 accA = nxA, accB = nxB;
+        if (t + 1 < Tout) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int b = b0 + 4 * (lane >> 4) + r;
-            const size_t go = ((size_t)b * T + t) * G4;
-            accA[r] = b < B ? gx[go + colA] : 0.0f;
-            accB[r] = b < B ? gx[go + colB] : 0.0f;
+            for (int r = 0; r < 4; ++r) {
+                const int b = b0 + 4 * (lane >> 4) + r;
+                const size_t go = ((size_t)b * T + t + 1) * G4;
+                nxA[r] = b < B ? gx[go + colA] : 0.0f;
+                nxB[r] = b < B ? gx[go + colB] : 0.0f;
+            }
         }
         const float* arow = hcur + (lane & 15) * HS + (lane >> 4);
 #pragma unroll
@@ -303,8 +315,28 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_bwd_kernel(const float* __r
         part[1][row * HS + uu] = 0.0f;
     }
     __syncthreads();
+    // saved activations of the current step, fetched one step ahead (see lstm_fwd_kernel)
+    struct Step {
+        float ig, fg, gg, og, cn, cp, dyv;
+    };
+    auto fetch = [&](int t, int uu, Step& st) {
+        const bool lv = vb && t >= 0 && t < len;
+        const size_t o = (size_t)b * T + (lv ? t : 0);
+        st.ig = lv ? gates[o * G4 + uu] : 0.0f;
+        st.fg = lv ? gates[o * G4 + HID + uu] : 0.0f;
+        st.gg = lv ? gates[o * G4 + 2 * HID + uu] : 0.0f;
+        st.og = lv ? gates[o * G4 + 3 * HID + uu] : 0.0f;
+        st.cn = lv ? cs[o * HID + uu] : 0.0f;
+        st.cp = lv ? (t > 0 ? cs[(o - 1) * HID + uu] : (c0 != nullptr ? c0[(size_t)b * HID + uu] : 0.0f)) : 0.0f;
+        st.dyv = (lv && dy != nullptr) ? dy[o * HID + uu] : 0.0f;
+    };
+    Step cur[2], nxt[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) fetch(Tout - 1, (tid & 63) + 64 * q, cur[q]);
     for (int t = Tout - 1; t >= 0; --t) {
         const bool live = t < len;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) fetch(t - 1, (tid & 63) + 64 * q, nxt[q]);
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int uu = (tid & 63) + 64 * q;
@@ -312,19 +344,15 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_bwd_kernel(const float* __r
             float dh = part[0][row * HS + uu] + part[1][row * HS + uu] + dhp[q];
             float di = 0.0f, df = 0.0f, dg = 0.0f, dov = 0.0f;
             if (live) {
-                const size_t o = (size_t)b * T + t;
-                if (dy != nullptr) dh += dy[o * HID + uu];
-                const float ig = gates[o * G4 + uu], fg = gates[o * G4 + HID + uu];
-                const float gg = gates[o * G4 + 2 * HID + uu], og = gates[o * G4 + 3 * HID + uu];
-                const float cn = cs[o * HID + uu];
-                const float cp = t > 0 ? cs[(o - 1) * HID + uu] : (c0 != nullptr ? c0[(size_t)b * HID + uu] : 0.0f);
-                const float tc = tanhf(cn);
-                dov = dh * tc * og * (1.0f - og);
-                const float dct = dc[q] + dh * og * (1.0f - tc * tc);
-                di = dct * gg * ig * (1.0f - ig);
-                dg = dct * ig * (1.0f - gg * gg);
-                df = dct * cp * fg * (1.0f - fg);
-                dc[q] = dct * fg;
+                const Step& st = cur[q];
+                dh += st.dyv;
+                const float tc = tanhf(st.cn);
+                dov = dh * tc * st.og * (1.0f - st.og);
+                const float dct = dc[q] + dh * st.og * (1.0f - tc * tc);
+                di = dct * st.gg * st.ig * (1.0f - st.ig);
+                dg = dct * st.ig * (1.0f - st.gg * st.gg);
+                df = dct * st.cp * st.fg * (1.0f - st.fg);
+                dc[q] = dct * st.fg;
                 dhp[q] = 0.0f;      // h_t was produced by the cell: everything flows through the gates
             } else {
                 dhp[q] = dh;        // frozen step (t >= length): h_t = h_{t-1}, c_t = c_{t-1}
@@ -340,6 +368,7 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_bwd_kernel(const float* __r
                 dG[o + 2 * HID + uu] = dg;
                 dG[o + 3 * HID + uu] = dov;
             }
+            cur[q] = nxt[q];
         }
         __syncthreads();
         // dh_{t-1}[row][16nt + n] (K half kh) = sum_col dG[row][256kh + col] * W_hh[256kh + col][16nt + n]

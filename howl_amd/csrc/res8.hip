@@ -611,9 +611,21 @@ constexpr int C0_GROUP = 5;
 __device__ __forceinline__ void load_feat_tile(float* tin, const float* feat, long sb, long st, long sm, int b, int T,
                                                int M, int tid, int nthreads) {
     const int pitch = M + 4;
-    for (int i = tid; i < (T + 2) * pitch; i += nthreads) {
-        const int t = i / pitch - 1, m = i % pitch - 1;
-        tin[i] = (t >= 0 && t < T && m >= 0 && m < M) ? feat[b * sb + t * st + m * sm] : 0.0f;
+    const int n = (T + 2) * pitch;
+    // batches of 8 independent loads per thread: a one-load-per-iteration loop is bound by HBM latency, not bandwidth
+    for (int i0 = tid; i0 < n; i0 += 8 * nthreads) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int i = i0 + j * nthreads;
+            const int t = i / pitch - 1, m = i % pitch - 1;
+            v[j] = (i < n && t >= 0 && t < T && m >= 0 && m < M) ? feat[b * sb + t * st + m * sm] : 0.0f;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int i = i0 + j * nthreads;
+            if (i < n) tin[i] = v[j];
+        }
     }
 }
 
@@ -701,9 +713,25 @@ __global__ __launch_bounds__(C0_THREADS) void conv0_wgrad_kernel(const float* __
         // the utterance's gradients and masks are staged in bulk (coalesced, all loads in flight together); reading
         // them one dependent global load per inner-loop iteration was latency-bound
         const size_t ub = (size_t)b * NMAP * P;
-        for (int i = tid; i < NMAP * P; i += C0_THREADS) {
-            lg[i] = (ga[ub + i] + (gb != nullptr ? gb[ub + i] : 0.0f)) * (1.0f / 12.0f);
-            lm[i] = mask0[ub + i];
+        for (int i0 = tid; i0 < NMAP * P; i0 += 8 * C0_THREADS) {
+            float va[8], vb[8];
+            unsigned short vm[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int i = i0 + j * C0_THREADS;
+                const bool ok = i < NMAP * P;
+                va[j] = ok ? ga[ub + i] : 0.0f;
+                vb[j] = (ok && gb != nullptr) ? gb[ub + i] : 0.0f;
+                vm[j] = ok ? mask0[ub + i] : (unsigned short)0;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int i = i0 + j * C0_THREADS;
+                if (i < NMAP * P) {
+                    lg[i] = (va[j] + vb[j]) * (1.0f / 12.0f);
+                    lm[i] = vm[j];
+                }
+            }
         }
         __syncthreads();
 #pragma unroll 1
@@ -755,8 +783,10 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
             float v = 0.0f;
             if (c < NMAP) {
                 const float* src = s6 + ((size_t)b * NMAP + c) * P;
-                float acc = 0.0f;
-                for (int p = lane; p < P; p += 64) acc += src[p];
+                float a8[8];   // <= 8 x 64 positions per channel (P <= 270): all loads in flight at once
+#pragma unroll
+                for (int j = 0; j < 8; ++j) a8[j] = (lane + 64 * j < P) ? src[lane + 64 * j] : 0.0f;
+                float acc = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
                 acc = wave_sum(acc);
                 v = (acc / (float)P - stats[c]) * stats[CP + c];
             }
