@@ -601,10 +601,11 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_kernel(
 
 // ---------------------------------------------------------------------------------------------------------
 // conv0 (1 -> 45, 3x3, pad 1) + ReLU + AvgPool(3,4), forward and weight gradient.  VALU: 2.6 MFLOP/utterance.
-// One wave owns a group of 5 output channels (9 waves), lanes stride over the pooled positions.
+// Waves own output channels, lanes stride over the pooled positions.
 // ---------------------------------------------------------------------------------------------------------
-constexpr int C0_THREADS = 576;
-constexpr int C0_GROUP = 5;
+constexpr int C0_THREADS = 512;    // forward: 8 waves, wave w takes channels w, w+8, ... (two waves per SIMD, balanced)
+constexpr int C0W_THREADS = 960;   // weight gradient: 15 waves x 3 channels (SIMD loads 12,12,12,9 channels)
+constexpr int C0_GROUP = 3;
 
 // tin[(T+2)][M+4] with a zero halo; the row pitch is a multiple of 4 floats so that the 6-wide patch row of pooled
 // column pw (tile columns 4pw .. 4pw+5) is one aligned ds_read_b128 + one ds_read_b64 instead of six strided b32 reads
@@ -664,8 +665,7 @@ __global__ __launch_bounds__(C0_THREADS) void conv0_fwd_kernel(const float* __re
             float patch[5][6];
             load_patch(tin, pitch, ph, pw, patch);
 #pragma unroll 2
-            for (int cc = 0; cc < C0_GROUP; ++cc) {   // two channels in flight: interleaving all five blows the register file
-                const int c = wave * C0_GROUP + cc;
+            for (int c = wave; c < NMAP; c += C0_THREADS / 64) {   // two channels in flight (all of them blows the register file)
                 float wk[9];
 #pragma unroll
                 for (int k = 0; k < 9; ++k) wk[k] = lw[c * 9 + k];
@@ -694,7 +694,7 @@ __global__ __launch_bounds__(C0_THREADS) void conv0_fwd_kernel(const float* __re
 // The ReLU pattern of the pre-pool activation comes from the forward's 12-bit masks (2 B per pooled output instead of
 // the 583 KB/utterance tensor or a recomputation).  A wave walks its 5 channels one at a time (9 accumulators live),
 // folds them across lanes per utterance and keeps the running sums in LDS.
-__global__ __launch_bounds__(C0_THREADS) void conv0_wgrad_kernel(const float* __restrict__ feat, long sb, long st, long sm,
+__global__ __launch_bounds__(C0W_THREADS) void conv0_wgrad_kernel(const float* __restrict__ feat, long sb, long st, long sm,
                                                                  const unsigned short* __restrict__ mask0,
                                                                  const float* __restrict__ ga, const float* __restrict__ gb,
                                                                  float* __restrict__ part, int B, int T, int M, int H) {
@@ -706,19 +706,19 @@ __global__ __launch_bounds__(C0_THREADS) void conv0_wgrad_kernel(const float* __
     const int P = H * PW;
     float* lg = lacc + NMAP * 9;                                               // (45, P) pooled gradients / 12
     unsigned short* lm = reinterpret_cast<unsigned short*>(lg + NMAP * P);     // (45, P) ReLU masks
-    for (int i = tid; i < NMAP * 9; i += C0_THREADS) lacc[i] = 0.0f;
+    for (int i = tid; i < NMAP * 9; i += C0W_THREADS) lacc[i] = 0.0f;
     for (int b = blockIdx.x; b < B; b += gridDim.x) {
         __syncthreads();
-        load_feat_tile(tin, feat, sb, st, sm, b, T, M, tid, C0_THREADS);
+        load_feat_tile(tin, feat, sb, st, sm, b, T, M, tid, C0W_THREADS);
         // the utterance's gradients and masks are staged in bulk (coalesced, all loads in flight together); reading
         // them one dependent global load per inner-loop iteration was latency-bound
         const size_t ub = (size_t)b * NMAP * P;
-        for (int i0 = tid; i0 < NMAP * P; i0 += 8 * C0_THREADS) {
+        for (int i0 = tid; i0 < NMAP * P; i0 += 8 * C0W_THREADS) {
             float va[8], vb[8];
             unsigned short vm[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const int i = i0 + j * C0_THREADS;
+                const int i = i0 + j * C0W_THREADS;
                 const bool ok = i < NMAP * P;
                 va[j] = ok ? ga[ub + i] : 0.0f;
                 vb[j] = (ok && gb != nullptr) ? gb[ub + i] : 0.0f;
@@ -726,7 +726,7 @@ __global__ __launch_bounds__(C0_THREADS) void conv0_wgrad_kernel(const float* __
             }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const int i = i0 + j * C0_THREADS;
+                const int i = i0 + j * C0W_THREADS;
                 if (i < NMAP * P) {
                     lg[i] = (va[j] + vb[j]) * (1.0f / 12.0f);
                     lm[i] = vm[j];
@@ -765,7 +765,7 @@ __global__ __launch_bounds__(C0_THREADS) void conv0_wgrad_kernel(const float* __
         }
     }
     __syncthreads();
-    for (int i = tid; i < NMAP * 9; i += C0_THREADS) part[(size_t)blockIdx.x * NMAP * 9 + i] = lacc[i];
+    for (int i = tid; i < NMAP * 9; i += C0W_THREADS) part[(size_t)blockIdx.x * NMAP * 9 + i] = lacc[i];
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1097,7 +1097,7 @@ int howl_res8_bwd(const HowlRes8Params* prm, const float* feat, long sb, long st
     hipFuncSetAttribute(reinterpret_cast<const void*>(conv0_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                         (int)l0w);
     HOWL_REQUIRE(sv->mask0 != nullptr, "howl_res8_bwd: saved->mask0 is required");
-    hipLaunchKernelGGL(conv0_wgrad_kernel, dim3(G), dim3(C0_THREADS), l0w, stream, feat, sb, st, sm,
+    hipLaunchKernelGGL(conv0_wgrad_kernel, dim3(G), dim3(C0W_THREADS), l0w, stream, feat, sb, st, sm,
                        (const unsigned short*)sv->mask0,
                        (const float*)dx_cur, (const float*)ds_prev, w.c0part, B, T, M, H);
     hipLaunchKernelGGL(reduce_rows_kernel, dim3((NMAP * 9 + 63) / 64), dim3(256), 0, stream, (const float*)w.c0part, G,
