@@ -354,9 +354,65 @@ __global__ void specaug_kernel(float* __restrict__ x, int B, int C, int M, int T
     if (fm || tm) x[idx] = 0.0f;
 }
 
+// Collate + waveform augmentation on the device (operator.py:73-86, transform.py:120-196): gather clip idx[b] from the
+// bank, drop `shift[b]` samples from the head (from_head) or the tail (TimeshiftTransform), add white noise
+// N(0, sigma[b]) and salt-and-pepper Bern(p/2) - Bern(p/2) (NoiseTransform; each clamped to [-1,1] like the reference),
+// zero-pad right to Lout (batchify).  Randomness is a counter-based hash of (seed, b, n): reproducible, order-free.
+__device__ __forceinline__ unsigned long long mix64(unsigned long long x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+__device__ __forceinline__ float u01(unsigned long long h) { return ((unsigned)(h >> 40) + 0.5f) * (1.0f / 16777216.0f); }
+
+__global__ __launch_bounds__(256) void collate_augment_kernel(const float* __restrict__ bank, long bank_ld,
+                                                              const int* __restrict__ idx, const int* __restrict__ src_len,
+                                                              const int* __restrict__ shift, const int* __restrict__ from_head,
+                                                              const float* __restrict__ sigma, const float* __restrict__ sp_prob,
+                                                              unsigned long long seed, float* __restrict__ out, int Lout) {
+    const int b = blockIdx.y;
+    const int len = src_len[b] - shift[b];
+    const int off = from_head[b] ? shift[b] : 0;
+    const float* src = bank + (long)idx[b] * bank_ld + off;
+    const float sg = sigma[b], pp = sp_prob[b];
+    for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < Lout; n += gridDim.x * blockDim.x) {
+        float v = 0.0f;
+        if (n < len) {
+            v = src[n];
+            const unsigned long long key = mix64(seed ^ ((unsigned long long)b << 32) ^ (unsigned long long)n);
+            if (sg > 0.0f) {
+                const float u1 = u01(key), u2 = u01(mix64(key));
+                const float z = sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);   // Box-Muller
+                v = fminf(fmaxf(v + fminf(fmaxf(z * sg, -1.0f), 1.0f), -1.0f), 1.0f);
+            }
+            if (pp > 0.0f) {
+                const unsigned long long k2 = mix64(key ^ 0xD1B54A32D192ED03ull);
+                const float salt = u01(k2) < 0.5f * pp ? 1.0f : 0.0f;
+                const float pepper = u01(mix64(k2)) < 0.5f * pp ? 1.0f : 0.0f;
+                v = fminf(fmaxf(v + (salt - pepper), -1.0f), 1.0f);
+            }
+        }
+        out[(long)b * Lout + n] = v;
+    }
+}
+
 }  // namespace
 
 extern "C" {
+
+int howl_collate_augment(const float* bank, long bank_ld, const int* idx, const int* src_len, const int* shift,
+                         const int* from_head, const float* sigma, const float* sp_prob, unsigned long long seed, int B,
+                         int Lout, float* out, hipStream_t stream) {
+    HOWL_REQUIRE(bank && idx && src_len && shift && from_head && sigma && sp_prob && out, "howl_collate_augment: null pointer");
+    HOWL_REQUIRE(B >= 1 && Lout >= 1, "howl_collate_augment: bad shape");
+    int gx = (Lout + 255) / 256;
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(collate_augment_kernel, dim3(gx, B), dim3(256), 0, stream, bank, bank_ld, idx, src_len, shift, from_head,
+                       sigma, sp_prob, seed, out, Lout);
+    HOWL_CHECK_LAUNCH("howl_collate_augment");
+    return HOWL_OK;
+}
 
 int howl_fb_pack(const float* fb, int M, float* fbp, hipStream_t stream) {
     HOWL_REQUIRE(fb && fbp, "howl_fb_pack: null pointer");

@@ -90,7 +90,7 @@ class Res8(RegisteredModel, name="res8"):
             self.add_module(f"bn{i + 1}", nn.BatchNorm2d(n_maps, affine=False))
             self.add_module(f"conv{i + 1}", conv)
         self.output = nn.Linear(n_maps, num_labels)
-        self._buffers_cache = None
+        self._buffers_cache = {}   # (B, T, C, device) -> _Res8Buffers; a handful of geometries (batch max length varies)
         self._fwd_version = 0
 
     # ---- parameter plumbing ------------------------------------------------------------------------------
@@ -119,9 +119,13 @@ class Res8(RegisteredModel, name="res8"):
 
     def _get_buffers(self, B, T, device):
         key = (B, T, self.num_labels, str(device))
-        if self._buffers_cache is None or self._buffers_cache.key != key:
-            self._buffers_cache = _Res8Buffers(B, T, self.num_labels, device)
-        return self._buffers_cache
+        buf = self._buffers_cache.pop(key, None)
+        if buf is None:
+            if len(self._buffers_cache) >= 6:
+                self._buffers_cache.pop(next(iter(self._buffers_cache)))   # drop the least recently used geometry
+            buf = _Res8Buffers(B, T, self.num_labels, device)
+        self._buffers_cache[key] = buf
+        return buf
 
     @staticmethod
     def _feat_view(x):

@@ -92,6 +92,15 @@ def zmuv_apply(x, pair):
     return out
 
 
+def collate_augment(bank, idx, src_len, shift, from_head, sigma, sp_prob, seed, lout):
+    B = idx.numel()
+    out = torch.empty((B, lout), dtype=torch.float32, device=bank.device)
+    _lib.get().call("howl_collate_augment", _p(bank), bank.stride(0), _p(idx, torch.int32), _p(src_len, torch.int32),
+                    _p(shift, torch.int32), _p(from_head, torch.int32), _p(sigma), _p(sp_prob),
+                    ctypes.c_ulonglong(seed & 0xFFFFFFFFFFFFFFFF), B, lout, _p(out), _stream())
+    return out
+
+
 def specaug_mask(x, f0, f, t0, t):
     B, C, M, T = x.shape
     _lib.get().call("howl_specaug_mask", _p(x), B, C, M, T, _p(f0, torch.int32), _p(f, torch.int32),

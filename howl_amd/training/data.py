@@ -64,6 +64,14 @@ class ClipBank:
         lmax = int(self.max_len)   # a fixed width keeps shapes static (padding is zero either way)
         return ClassificationBatch(self.audio[idx, :lmax], self.labels[idx], lengths)
 
+    def index_batches(self, batch_size: int, shuffle: bool, drop_last: bool, generator=None):
+        """Lists of clip ids per batch (for DeviceCollate, which gathers / augments / pads on the device)."""
+        n = len(self)
+        perm = (torch.randperm(n, generator=generator) if shuffle else torch.arange(n)).tolist()
+        end = n - (n % batch_size) if drop_last else n
+        for i in range(0, end, batch_size):
+            yield perm[i:i + batch_size]
+
     def batches(self, batch_size: int, shuffle: bool, drop_last: bool, generator=None):
         n = len(self)
         perm = torch.randperm(n, generator=generator) if shuffle else torch.arange(n)

@@ -12,6 +12,7 @@ from pathlib import Path
 
 import torch
 
+from howl_amd.data.collate import DeviceCollate
 from howl_amd.data.transform.operator import ZmuvTransform
 from howl_amd.data.transform.transform import StandardAudioTransform
 from howl_amd.model import RegisteredModel
@@ -98,11 +99,14 @@ def main(argv=None):
     else:
         optimizer = torch.optim.AdamW(params, SETTINGS.training.learning_rate, weight_decay=SETTINGS.training.weight_decay)
         criterion = torch.nn.CrossEntropyLoss()
+    # train_comp = compose(truncate, Timeshift.train(), Noise.train(), batchify) (pretrain_gsc.py:78-80), on the device
+    train_collate = DeviceCollate(train.audio, train.lengths, train.labels, max_len, sr=sample_rate)
     dev_acc = 0
     for epoch_idx in range(SETTINGS.training.num_epochs):
         model.train()
         std_transform.train()
-        for batch in train.batches(SETTINGS.training.batch_size, shuffle=True, drop_last=True):
+        for ids in train.index_batches(SETTINGS.training.batch_size, shuffle=True, drop_last=True):
+            batch = train_collate(ids)
             if fused:
                 loss = trainer.step(batch.audio_data, batch.labels)
             else:

@@ -75,6 +75,15 @@ int howl_zmuv_pair(const float* mean, const float* mean2, float* pair, hipStream
 /* out = (x - pair[0]) / pair[1] elementwise (in place allowed): operator.py:145-146 (`ZmuvTransform.forward`). */
 int howl_zmuv_apply(const float* x, size_t n, const float* pair, float* out, hipStream_t stream);
 
+/* Collate + waveform augmentation on the device: out[b] = pad(noise(timeshift(bank[idx[b]][:src_len[b]]))), (B, Lout).
+ * Replaces, for device-resident clips, the DataLoader-worker chain truncate_length -> TimeshiftTransform ->
+ * NoiseTransform -> batchify (operator.py:73-86, transform.py:120-196).  Per-sample parameters are drawn on the host with
+ * the reference's RNG protocol (shift / head-or-tail, white sigma, salt-pepper prob; 0 disables); the noise samples
+ * themselves come from a counter-based generator keyed by (seed, b, n), so they match torch's only in distribution. */
+int howl_collate_augment(const float* bank, long bank_ld, const int* idx, const int* src_len, const int* shift,
+                         const int* from_head, const float* sigma, const float* sp_prob, unsigned long long seed, int B,
+                         int Lout, float* out, hipStream_t stream);
+
 /* SpecAugment masks with host-drawn parameters (per sample; width <= 0 = no mask): transform.py:309-327. */
 int howl_specaug_mask(float* x, int B, int C, int M, int T, const int* f0, const int* f, const int* t0,
                       const int* t, hipStream_t stream);

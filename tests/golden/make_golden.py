@@ -258,5 +258,50 @@ def main():
          blank_label=np.array(ctx_b.blank_label))
 
 
+
+
+def collate_protocol_golden():
+    """G7b: RNG protocol of the training collate chain (pretrain_gsc.py:78-80): which random.random() draws
+    compose(truncate, Timeshift.train(), Noise.train()) consumes, and the crops that result."""
+    from functools import partial
+    from howl.data.transform.operator import compose, truncate_length
+    from howl.data.transform.transform import NoiseTransform, TimeshiftTransform
+
+    class Ex:
+        def __init__(self, audio):
+            self.audio_data = audio
+
+        def update_audio_data(self, audio, **kw):
+            return Ex(audio)
+
+    draws = []
+    real = random.random
+
+    def recording():
+        v = real()
+        draws.append(v)
+        return v
+
+    lens = [16000, 12971, 16000, 14336, 9000, 20000]
+    out = {}
+    for trial, seed in enumerate((0, 1, 2, 5)):
+        random.seed(seed)
+        torch.manual_seed(seed)
+        draws.clear()
+        random.random = recording
+        try:
+            chain = compose(partial(truncate_length, length=16000), TimeshiftTransform().train(), NoiseTransform().train())
+            # ramp signals make the crop offset observable
+            exs = chain([Ex(torch.arange(L, dtype=torch.float32) * 1e-5) for L in lens])
+        finally:
+            random.random = real
+        out[f"draws_{trial}"] = np.array(draws)
+        out[f"out_len_{trial}"] = np.array([e.audio_data.numel() for e in exs])
+        out[f"first_{trial}"] = np.array([float(e.audio_data[0]) for e in exs])   # ~ offset * 1e-5 (+ noise <= ~0.004)
+    save("g7b_collate_protocol", lens=np.array(lens), **out)
+
+
 if __name__ == "__main__":
-    main()
+    if "--only-collate" not in sys.argv:
+        main()
+    collate_protocol_golden()

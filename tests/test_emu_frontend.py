@@ -112,3 +112,35 @@ def test_zmuv_update_and_specaug(lib, golden):
     f0, f, t0, t = (np.ascontiguousarray(g[k], np.int32) for k in ("f0", "f", "t0", "t"))  # keep alive
     lib.call("howl_specaug_mask", ptr(x), 6, 3, 40, 81, ptr(f0), ptr(f), ptr(t0), ptr(t), None)
     assert np.array_equal(x, g["out"])
+
+
+def test_collate_augment(lib):
+    """gather + timeshift crop + right zero-pad exactly; noise: clamped, right scale, deterministic per (seed, b, n)."""
+    rng = np.random.default_rng(4)
+    bank = (0.1 * rng.standard_normal((5, 3000))).astype(np.float32)
+    idx = np.array([3, 0, 4], np.int32)
+    src_len = np.array([3000, 2500, 2000], np.int32)
+    shift = np.array([100, 0, 700], np.int32)
+    head = np.array([1, 0, 0], np.int32)
+    zero = np.zeros(3, np.float32)
+    out = np.full((3, 2950), np.nan, np.float32)
+    args = lambda sg, sp, seed, o: ("howl_collate_augment", ptr(bank), 3000, ptr(idx), ptr(src_len), ptr(shift), ptr(head),
+                                    ptr(sg), ptr(sp), seed, 3, 2950, ptr(o), None)
+    lib.call(*args(zero, zero, 7, out))
+    assert np.array_equal(out[0, :2900], bank[3, 100:3000]) and not out[0, 2900:].any()      # head crop
+    assert np.array_equal(out[1, :2500], bank[0, :2500]) and not out[1, 2500:].any()         # no shift, zero pad
+    assert np.array_equal(out[2, :1300], bank[4, :1300]) and not out[2, 1300:].any()         # tail crop
+    sg = np.array([0.05, 0.0, 0.0], np.float32)
+    sp = np.array([0.0, 0.2, 0.0], np.float32)
+    a, b = np.zeros_like(out), np.zeros_like(out)
+    lib.call(*args(sg, sp, 7, a))
+    lib.call(*args(sg, sp, 7, b))
+    assert np.array_equal(a, b)                                                              # reproducible
+    d0 = a[0, :2900] - bank[3, 100:3000]
+    assert abs(d0.std() - 0.05) < 0.005 and abs(d0.mean()) < 0.005                           # N(0, sigma)
+    d1 = a[1, :2500] - bank[0, :2500]
+    frac = (np.abs(d1) > 0.5).mean()
+    assert 0.12 < frac < 0.25 and np.abs(a).max() <= 1.0                                     # ~p/2 salt + ~p/2 pepper (minus overlaps)
+    assert np.array_equal(a[2], out[2])                                                      # untouched sample
+    lib.call(*args(sg, sp, 8, b))
+    assert not np.array_equal(a[0], b[0])                                                    # seed changes the noise

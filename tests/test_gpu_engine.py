@@ -64,3 +64,26 @@ def test_pretrain_gsc_entry_point_synthetic(tmp_path, monkeypatch):
     accs = [l["value"] for l in lines if l["tag"] == "Dev/Metric/acc"]
     assert len(accs) == 4 and max(accs) > 1.0 / 30     # above chance after a handful of steps on separable tones
     SETTINGS.reset()
+
+
+def test_device_collate_batch():
+    """a12: truncate -> timeshift -> noise -> batchify on the device: sorted by length, zero padded, clamped, labelled."""
+    import random
+    from howl_amd.data.collate import DeviceCollate
+    from howl_amd.utils.synth import synthetic_pcm
+    pcm = synthetic_pcm(32, 16000).to(DEV)
+    lengths = torch.tensor([16000 - 311 * (i % 7) for i in range(32)])
+    labels = (torch.arange(32) % 5).to(DEV)
+    random.seed(1)
+    dc = DeviceCollate(pcm, lengths, labels, 16000, seed=None)
+    batch = dc(list(range(32)))
+    L = batch.lengths.cpu()
+    assert (L[:-1] >= L[1:]).all() and batch.audio_data.shape == (32, int(L.max()))
+    assert batch.audio_data.abs().max().item() <= 1.0
+    for row in (0, 31):
+        assert not batch.audio_data[row, int(L[row]):].any()
+    assert batch.labels.shape == (32,)
+    dc.training = False        # eval: no augmentation, plain batchify
+    plain = dc(list(range(32)))
+    order = sorted(range(32), key=lambda k: -int(lengths[k]))
+    assert torch.equal(plain.audio_data[0, : int(lengths[order[0]])], pcm[order[0], : int(lengths[order[0]])])

@@ -74,3 +74,32 @@ def test_no_cpu_fallback():
     from howl_amd import lib, ops
     with pytest.raises(lib.HowlHipError):
         ops._p(torch.zeros(4))
+
+
+def test_device_collate_follows_reference_rng_protocol(golden):
+    """DeviceCollate.draw consumes random.random() in exactly the order/roles of the reference chain
+    truncate -> Timeshift.train() -> Noise.train() (G7b captured from the reference's modules)."""
+    from howl_amd.data.collate import DeviceCollate
+    g = golden("g7b_collate_protocol")
+    lens = g["lens"].tolist()
+
+    class Replay:
+        def __init__(self, values):
+            self.values, self.i = list(values), 0
+
+        def random(self):
+            v = self.values[self.i]
+            self.i += 1
+            return v
+
+    for trial in range(4):
+        dc = DeviceCollate(torch.zeros(1, 1), torch.tensor(lens), torch.zeros(len(lens), dtype=torch.long), 16000)
+        dc.rand = Replay(g[f"draws_{trial}"])
+        tl, shift, head, sigma, sp = dc.draw(list(range(len(lens))))
+        assert dc.rand.i == len(g[f"draws_{trial}"]), "consumed a different number of draws than the reference"
+        assert [l - w for l, w in zip(tl, shift)] == g[f"out_len_{trial}"].tolist()
+        for k in range(len(lens)):          # ramp input: first sample ~ crop offset * 1e-5 (noise is <= ~4e-3)
+            off = shift[k] if head[k] else 0
+            assert abs(g[f"first_{trial}"][k] - off * 1e-5) < 6e-3
+            if shift[k] > 600 and head[k]:
+                assert g[f"first_{trial}"][k] > 0.5 * shift[k] * 1e-5 - 5e-3
