@@ -340,18 +340,20 @@ __global__ void zmuv_apply_kernel(const float* __restrict__ x, size_t n, const f
 }
 
 // K5: zero x[b, :, f0:f0+f, :] and x[b, :, :, t0:t0+t] for every sample (negative width = no mask)
-__global__ void specaug_kernel(float* __restrict__ x, int B, int C, int M, int T, const int* __restrict__ f0,
-                               const int* __restrict__ f, const int* __restrict__ t0, const int* __restrict__ t) {
+__global__ void specaug_kernel(float* __restrict__ x, int B, int C, int M, int T, long sb, long sc, long sm, long st,
+                               const int* __restrict__ f0, const int* __restrict__ f, const int* __restrict__ t0,
+                               const int* __restrict__ t) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long per = (long)C * M * T;
     if (idx >= (long)B * per) return;
     const int b = (int)(idx / per);
     const long r = idx - (long)b * per;
+    const int c = (int)(r / ((long)M * T));
     const int m = (int)((r / T) % M);
     const int tt = (int)(r % T);
     const bool fm = f[b] > 0 && m >= f0[b] && m < f0[b] + f[b];
     const bool tm = t[b] > 0 && tt >= t0[b] && tt < t0[b] + t[b];
-    if (fm || tm) x[idx] = 0.0f;
+    if (fm || tm) x[b * sb + c * sc + m * sm + tt * st] = 0.0f;
 }
 
 // Collate + waveform augmentation on the device (operator.py:73-86, transform.py:120-196): gather clip idx[b] from the
@@ -496,13 +498,13 @@ int howl_zmuv_apply(const float* x, size_t n, const float* pair, float* out, hip
     return HOWL_OK;
 }
 
-int howl_specaug_mask(float* x, int B, int C, int M, int T, const int* f0, const int* f, const int* t0, const int* t,
-                      hipStream_t stream) {
+int howl_specaug_mask(float* x, int B, int C, int M, int T, long sb, long sc, long sm, long st, const int* f0, const int* f,
+                      const int* t0, const int* t, hipStream_t stream) {
     HOWL_REQUIRE(x && f0 && f && t0 && t, "howl_specaug_mask: null pointer");
     HOWL_REQUIRE(B >= 1 && C >= 1 && M >= 1 && T >= 1, "howl_specaug_mask: bad shape");
     const long n = (long)B * C * M * T;
-    hipLaunchKernelGGL(specaug_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, x, B, C, M, T, f0, f, t0,
-                       t);
+    hipLaunchKernelGGL(specaug_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, x, B, C, M, T, sb, sc, sm, st,
+                       f0, f, t0, t);
     HOWL_CHECK_LAUNCH("howl_specaug_mask");
     return HOWL_OK;
 }

@@ -183,8 +183,6 @@ class SpecAugmentTransform(AugmentModule):
     def _launch(self, x, f0, f, t0, t):
         dev = x.device
         as_dev = lambda a: torch.tensor(a, dtype=torch.int32).to(dev, non_blocking=True)
-        if not x.is_contiguous():
-            raise ValueError("SpecAugmentTransform masks in place and needs a contiguous (B, C, M, T) tensor")
         return ops.specaug_mask(x, as_dev(f0), as_dev(f), as_dev(t0), as_dev(t))
 
     def tmask(self, x, T):

@@ -103,8 +103,11 @@ def collate_augment(bank, idx, src_len, shift, from_head, sigma, sp_prob, seed, 
 
 def specaug_mask(x, f0, f, t0, t):
     B, C, M, T = x.shape
-    _lib.get().call("howl_specaug_mask", _p(x), B, C, M, T, _p(f0, torch.int32), _p(f, torch.int32),
-                    _p(t0, torch.int32), _p(t, torch.int32), _stream())
+    if not x.is_cuda or x.dtype != torch.float32:
+        _p(x)
+    sb, sc, sm, st = x.stride()
+    _lib.get().call("howl_specaug_mask", ctypes.c_void_p(x.data_ptr()), B, C, M, T, sb, sc, sm, st, _p(f0, torch.int32),
+                    _p(f, torch.int32), _p(t0, torch.int32), _p(t, torch.int32), _stream())
     return x
 
 

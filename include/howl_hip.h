@@ -84,9 +84,10 @@ int howl_collate_augment(const float* bank, long bank_ld, const int* idx, const 
                          const int* from_head, const float* sigma, const float* sp_prob, unsigned long long seed, int B,
                          int Lout, float* out, hipStream_t stream);
 
-/* SpecAugment masks with host-drawn parameters (per sample; width <= 0 = no mask): transform.py:309-327. */
-int howl_specaug_mask(float* x, int B, int C, int M, int T, const int* f0, const int* f, const int* t0,
-                      const int* t, hipStream_t stream);
+/* SpecAugment masks with host-drawn parameters (per sample; width <= 0 = no mask): transform.py:309-327.
+ * x is a (B,C,M,T) view with element strides (sb,sc,sm,st), masked in place. */
+int howl_specaug_mask(float* x, int B, int C, int M, int T, long sb, long sc, long sm, long st, const int* f0,
+                      const int* f, const int* t0, const int* t, hipStream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * res8 classifier: howl/model/cnn.py:113-145 (Res8.forward) and its autograd backward, as driven by

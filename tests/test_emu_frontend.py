@@ -110,7 +110,7 @@ def test_zmuv_update_and_specaug(lib, golden):
     g = golden("g7_specaug")
     x = np.ascontiguousarray(g["x"])
     f0, f, t0, t = (np.ascontiguousarray(g[k], np.int32) for k in ("f0", "f", "t0", "t"))  # keep alive
-    lib.call("howl_specaug_mask", ptr(x), 6, 3, 40, 81, ptr(f0), ptr(f), ptr(t0), ptr(t), None)
+    lib.call("howl_specaug_mask", ptr(x), 6, 3, 40, 81, 3 * 40 * 81, 40 * 81, 81, 1, ptr(f0), ptr(f), ptr(t0), ptr(t), None)
     assert np.array_equal(x, g["out"])
 
 
