@@ -104,14 +104,20 @@ __device__ __forceinline__ void stage_slots(int (&pk)[PREF], int P, int CS, int 
     }
 }
 
-// registers -> LDS tile, applying x = (v - mean[c]) * rstd[c] (identity when !affine)
+// registers -> LDS tile, applying x = (|v| - mean[c]) * rstd[c] (no normalisation when !affine).  Stored activations
+// are non-negative by construction (sums of ReLU outputs); layers with a residual add keep the ReLU mask of their own
+// convolution in the sign bit (see conv_utterance), hence the fabs (`absval` is false for gradient tiles).
 __device__ __forceinline__ void stage_tile(const float2 (&pre)[PREF], const int (&pk)[PREF], float* tile,
-                                           const float* lmean, const float* lrstd, bool affine) {
+                                           const float* lmean, const float* lrstd, bool affine, bool absval) {
 #pragma unroll
     for (int j = 0; j < PREF; ++j) {
         if (pk[j] >= 0) {
             const int c = pk[j] >> 20;
             float v0 = pre[j].x, v1 = pre[j].y;
+            if (absval) {
+                v0 = fabsf(v0);
+                v1 = fabsf(v1);
+            }
             if (affine) {
                 const float m = lmean[c], r = lrstd[c];
                 v0 = (v0 - m) * r;
@@ -120,6 +126,66 @@ __device__ __forceinline__ void stage_tile(const float2 (&pre)[PREF], const int 
             float* d = tile + (pk[j] & 0xFFFFF);
             d[0] = v0;
             d[1] = v1;
+        }
+    }
+}
+
+// Backward fusion (MODE 1): the dgrad kernel builds its input tile dz_i on the fly,
+//   ds = rstd * (dx' - m1 - xhat * m2)            (BatchNorm backward with batch statistics; for layers with a skip
+//                                                  connection the producer of dx already folded the skip-path gradient
+//                                                  in as dx' = dx + dskip / rstd, see conv_utterance)
+//   dz = ds * [ReLU mask of layer i]                (mask: s > 0 for odd layers, sign bit of s for even layers)
+// and writes dz (for the weight-gradient kernel) and ds (even layers: the skip gradient of layer i-2) on the way.
+struct BwdStage {
+    const float* dx;      // (B,45,P) gradient w.r.t. BN_i's output; nullptr -> dpool[b][c] / P broadcast (layer 6)
+    const float* dpool;   // (B,48)
+    const float* s;       // s_i
+    const float* stats;   // {mean[48], rstd[48]} of BN_i
+    const float* m12;     // {mean(dx)[48], mean(dx*xhat)[48]}
+    float* ds_out;        // ds_i or nullptr
+    float* dz_out;        // dz_i
+    int even;
+};
+
+__device__ __forceinline__ void prefetch_bwd(float2 (&pdx)[PREF], float2 (&ps)[PREF], const int (&pk)[PREF],
+                                             const BwdStage& bw, int b, int P, int n2, int tid) {
+    const size_t ub2 = (size_t)b * NMAP * P / 2;
+#pragma unroll
+    for (int j = 0; j < PREF; ++j) {
+        const int e2 = tid + j * CONV_THREADS;
+        const bool ok = e2 < n2;
+        if (bw.dx != nullptr) {
+            pdx[j] = ok ? reinterpret_cast<const float2*>(bw.dx)[ub2 + e2] : make_float2(0.0f, 0.0f);
+        } else {
+            const float v = ok ? bw.dpool[(size_t)b * CP + (pk[j] >> 20)] * (1.0f / (float)P) : 0.0f;
+            pdx[j] = make_float2(v, v);
+        }
+        ps[j] = ok ? reinterpret_cast<const float2*>(bw.s)[ub2 + e2] : make_float2(0.0f, 0.0f);
+    }
+}
+
+__device__ __forceinline__ void stage_bwd(const float2 (&pdx)[PREF], const float2 (&ps)[PREF], const int (&pk)[PREF],
+                                          float* tile, const float* lconst /* [4][48] */, const BwdStage& bw, int b, int P,
+                                          int tid) {
+    const size_t ub2 = (size_t)b * NMAP * P / 2;
+#pragma unroll
+    for (int j = 0; j < PREF; ++j) {
+        if (pk[j] >= 0) {
+            const int c = pk[j] >> 20;
+            const float mean = lconst[c], rstd = lconst[CP + c], m1 = lconst[2 * CP + c], m2 = lconst[3 * CP + c];
+            const float s0 = ps[j].x, s1 = ps[j].y;
+            float d0 = rstd * (pdx[j].x - m1 - ((fabsf(s0) - mean) * rstd) * m2);
+            float d1 = rstd * (pdx[j].y - m1 - ((fabsf(s1) - mean) * rstd) * m2);
+            const int e2 = tid + j * CONV_THREADS;
+            if (bw.ds_out != nullptr) reinterpret_cast<float2*>(bw.ds_out)[ub2 + e2] = make_float2(d0, d1);
+            const bool k0 = bw.even ? (s0 < 0.0f) : (s0 > 0.0f);
+            const bool k1 = bw.even ? (s1 < 0.0f) : (s1 > 0.0f);
+            d0 = k0 ? d0 : 0.0f;
+            d1 = k1 ? d1 : 0.0f;
+            reinterpret_cast<float2*>(bw.dz_out)[ub2 + e2] = make_float2(d0, d1);
+            float* d = tile + (pk[j] & 0xFFFFF);
+            d[0] = d0;
+            d[1] = d1;
         }
     }
 }
@@ -163,8 +229,7 @@ __device__ __forceinline__ void conv_tiles(const lds_f32* tile, const lds_f32* w
 }
 
 struct ConvEpilogue {
-    const float* res;
-    float* y_out;
+    const float* res;      // fwd: residual input;  dgrad: skip-path gradient ds_{j+2} folded into dx_j (or nullptr)
     float* out;
     const float* xs;
     float xmean, xrstd;
@@ -191,18 +256,33 @@ __device__ __forceinline__ void conv_utterance(const lds_f32* tile, const lds_f3
                 if (MODE == 0) {
                     v0 = fmaxf(v0, 0.0f);
                     v1 = fmaxf(v1, 0.0f);
-                    if (e.y_out != nullptr) *reinterpret_cast<float2*>(e.y_out + o) = make_float2(v0, v1);
                     if (e.res != nullptr) {
+                        // s = relu(conv) + skip >= 0; the ReLU mask of THIS convolution rides in the sign bit of the
+                        // stored value (relu > 0 implies s > 0, so -s is a proper negative number); readers take |s|
                         const float2 r = *reinterpret_cast<const float2*>(e.res + o);
-                        v0 += r.x;
-                        v1 += r.y;
+                        const bool k0 = v0 > 0.0f, k1 = v1 > 0.0f;
+                        v0 += fabsf(r.x);
+                        v1 += fabsf(r.y);
+                        st0 += v0 + v1;
+                        st1 += v0 * v0 + v1 * v1;
+                        v0 = k0 ? -v0 : v0;
+                        v1 = k1 ? -v1 : v1;
+                    } else {
+                        st0 += v0 + v1;
+                        st1 += v0 * v0 + v1 * v1;
                     }
-                    st0 += v0 + v1;
-                    st1 += v0 * v0 + v1 * v1;
                 } else if (e.xs != nullptr) {
                     const float2 sv = *reinterpret_cast<const float2*>(e.xs + o);
                     st0 += v0 + v1;
-                    st1 += v0 * ((sv.x - e.xmean) * e.xrstd) + v1 * ((sv.y - e.xmean) * e.xrstd);
+                    st1 += v0 * ((fabsf(sv.x) - e.xmean) * e.xrstd) + v1 * ((fabsf(sv.y) - e.xmean) * e.xrstd);
+                    if (e.res != nullptr) {
+                        // layer j = i-1 has a skip connection: its BatchNorm backward computes rstd * (dx' - ...), so
+                        // adding dskip / rstd here (after the statistics, which are of dx alone) yields ds_j = ... + dskip
+                        const float2 k = *reinterpret_cast<const float2*>(e.res + o);
+                        const float inv = 1.0f / e.xrstd;
+                        v0 += k.x * inv;
+                        v1 += k.y * inv;
+                    }
                 }
                 *reinterpret_cast<float2*>(e.out + o) = make_float2(v0, v1);
             }
@@ -218,11 +298,11 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_mfma_kernel(
     const float* __restrict__ in_stats,   // {mean[48], rstd[48]} applied on load, or nullptr
     const float* __restrict__ wp,         // packed weights [3][108][64]
     const float* __restrict__ res,        // fwd: residual (B,45,P) or nullptr
-    float* __restrict__ y_out,            // fwd: relu output before the residual add (B,45,P) or nullptr
     float* __restrict__ out,              // (B,45,P)
     const float* __restrict__ xs,         // dgrad: s_{i-1} for xhat, or nullptr (no stats)
     const float* __restrict__ xs_stats,   // dgrad: {mean, rstd} of layer i-1
     float* __restrict__ part,             // [gridDim.x][2][48] partial statistics, or nullptr
+    BwdStage bw,                          // dgrad: how to build the input tile (unused in MODE 0)
     int B, int H) {
     HIP_DYNAMIC_SHARED(float, lds)
     const int P = H * PW;
@@ -232,7 +312,8 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_mfma_kernel(
     float* tile = lds + 3 * KSTEPS * 64;   // one utterance's zero-haloed input map
     float* lmean = tile + TF;
     float* lrstd = lmean + CP;
-    float* red = lrstd + CP;  // [12][2][16]
+    float* lm12 = lrstd + CP;   // MODE 1: {m1[48], m2[48]} right behind {mean, rstd}
+    float* red = lm12 + 2 * CP;  // [12][2][16]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -245,9 +326,16 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_mfma_kernel(
     const bool affine = in_stats != nullptr;
 
     // first utterance's activations are requested before anything else so that HBM latency overlaps the setup
-    float2 pre[PREF];
+    float2 pre[PREF], pss[MODE == 1 ? PREF : 1];
+    int pk[PREF];
+    stage_slots(pk, P, CS, n2, tid);
     int b = blockIdx.x;
-    if (b < B) prefetch_tile(pre, in + (size_t)b * NMAP * P, n2, tid);
+    if (b < B) {
+        if constexpr (MODE == 1)
+            prefetch_bwd(pre, pss, pk, bw, b, P, n2, tid);
+        else
+            prefetch_tile(pre, in + (size_t)b * NMAP * P, n2, tid);
+    }
     {
         float4 wv[7];  // 3*108*16 float4 = 5184 <= 7 * 768: all loads in flight, then the LDS stores
 #pragma unroll
@@ -263,8 +351,15 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_mfma_kernel(
         }
     }
     if (tid < CP) {
-        lmean[tid] = affine ? in_stats[tid] : 0.0f;
-        lrstd[tid] = affine ? in_stats[CP + tid] : 1.0f;
+        if (MODE == 1) {
+            lmean[tid] = bw.stats[tid];
+            lrstd[tid] = bw.stats[CP + tid];
+            lm12[tid] = bw.m12[tid];
+            lm12[CP + tid] = bw.m12[CP + tid];
+        } else {
+            lmean[tid] = affine ? in_stats[tid] : 0.0f;
+            lrstd[tid] = affine ? in_stats[CP + tid] : 1.0f;
+        }
     }
     const int cout = 16 * nt + (lane & 15);
     const bool cvalid = cout < NMAP;
@@ -274,17 +369,22 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_mfma_kernel(
         xrstd = xs_stats[CP + cout];
     }
     float st0 = 0.0f, st1 = 0.0f;
-    const ConvEpilogue epi{res, y_out, out, xs, xmean, xrstd, cout, P, cvalid};
-
-    int pk[PREF];
-    stage_slots(pk, P, CS, n2, tid);
+    const ConvEpilogue epi{res, out, xs, xmean, xrstd, cout, P, cvalid};
     __syncthreads();  // weights, zero fill and stats visible before the first stage
 
     for (; b < B; b += gridDim.x) {
-        stage_tile(pre, pk, tile, lmean, lrstd, affine);
+        if constexpr (MODE == 1)
+            stage_bwd(pre, pss, pk, tile, lmean, bw, b, P, tid);
+        else
+            stage_tile(pre, pk, tile, lmean, lrstd, affine, true);
         __syncthreads();
         const int bn = b + gridDim.x;
-        if (bn < B) prefetch_tile(pre, in + (size_t)bn * NMAP * P, n2, tid);
+        if (bn < B) {
+            if constexpr (MODE == 1)
+                prefetch_bwd(pre, pss, pk, bw, bn, P, n2, tid);
+            else
+                prefetch_tile(pre, in + (size_t)bn * NMAP * P, n2, tid);
+        }
 
         const lds_f32* ltile = (const lds_f32*)tile;
         const lds_f32* wnt = (const lds_f32*)wl + nt * KSTEPS * 64;
@@ -374,8 +474,8 @@ __global__ __launch_bounds__(CONV_THREADS) void wgrad_mfma_kernel(
     stage_slots(pk, P, CS, n2, tid);
     __syncthreads();
     for (; b < B; b += gridDim.x) {
-        stage_tile(pz, pk, tz, lmean, lrstd, false);
-        stage_tile(px, pk, tx, lmean, lrstd, affine);
+        stage_tile(pz, pk, tz, lmean, lrstd, false, false);
+        stage_tile(px, pk, tx, lmean, lrstd, affine, true);
         __syncthreads();
         const int bn = b + gridDim.x;
         if (bn < B) {
@@ -558,44 +658,6 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __re
     if (c < CP) {
         m12[c] = (float)(s / count);
         m12[CP + c] = (float)(q / count);
-    }
-}
-
-// backward elementwise: BatchNorm backward (batch statistics) + skip gradient + ReLU mask
-//   ds = rstd * (dx - m1 - xhat * m2) [+ dskip];  dz = ds * (msrc > 0)
-__global__ __launch_bounds__(256) void bn_relu_bwd_kernel(
-    const float* __restrict__ dx,      // (B,45,P) or nullptr -> broadcast of dpool
-    const float* __restrict__ dpool,   // (B,48) used when dx == nullptr, scaled by 1/P
-    const float* __restrict__ s, const float* __restrict__ stats, const float* __restrict__ m12,
-    const float* __restrict__ dskip,   // nullable
-    const float* __restrict__ msrc,    // ReLU output whose sign gives the mask
-    float* __restrict__ ds_out,        // nullable
-    float* __restrict__ dz_out, int B, int P) {
-    const size_t n2 = (size_t)B * NMAP * P / 2;
-    const float invP = 1.0f / (float)P;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (size_t)gridDim.x * blockDim.x) {
-        const size_t e = 2 * i;
-        const int bc = (int)(e / P);
-        const int b = bc / NMAP, c = bc - b * NMAP;
-        float2 g;
-        if (dx != nullptr) {
-            g = reinterpret_cast<const float2*>(dx)[i];
-        } else {
-            const float v = dpool[b * CP + c] * invP;
-            g = make_float2(v, v);
-        }
-        const float2 sv = reinterpret_cast<const float2*>(s)[i];
-        const float mean = stats[c], rstd = stats[CP + c], m1 = m12[c], m2 = m12[CP + c];
-        float d0 = rstd * (g.x - m1 - ((sv.x - mean) * rstd) * m2);
-        float d1 = rstd * (g.y - m1 - ((sv.y - mean) * rstd) * m2);
-        if (dskip != nullptr) {
-            const float2 k = reinterpret_cast<const float2*>(dskip)[i];
-            d0 += k.x;
-            d1 += k.y;
-        }
-        if (ds_out != nullptr) reinterpret_cast<float2*>(ds_out)[i] = make_float2(d0, d1);
-        const float2 mv = reinterpret_cast<const float2*>(msrc)[i];
-        reinterpret_cast<float2*>(dz_out)[i] = make_float2(mv.x > 0.0f ? d0 : 0.0f, mv.y > 0.0f ? d1 : 0.0f);
     }
 }
 
@@ -785,7 +847,7 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
                 const float* src = s6 + ((size_t)b * NMAP + c) * P;
                 float a8[8];   // <= 8 x 64 positions per channel (P <= 270): all loads in flight at once
 #pragma unroll
-                for (int j = 0; j < 8; ++j) a8[j] = (lane + 64 * j < P) ? src[lane + 64 * j] : 0.0f;
+                for (int j = 0; j < 8; ++j) a8[j] = (lane + 64 * j < P) ? fabsf(src[lane + 64 * j]) : 0.0f;   // |s|: see conv_utterance
                 float acc = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
                 acc = wave_sum(acc);
                 v = (acc / (float)P - stats[c]) * stats[CP + c];
@@ -901,7 +963,7 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
     }
 }
 
-size_t conv_lds_bytes(int H) { return (size_t)(3 * KSTEPS * 64 + tile_floats(H) + 2 * CP + 12 * 2 * 16) * sizeof(float); }
+size_t conv_lds_bytes(int H) { return (size_t)(3 * KSTEPS * 64 + tile_floats(H) + 4 * CP + 12 * 2 * 16) * sizeof(float); }
 size_t wgrad_lds_bytes(int H) { return (size_t)(2 * tile_floats(H) + 2 * CP) * sizeof(float); }
 size_t conv0_lds_bytes(int T, int M) { return (size_t)((T + 2) * (M + 4) + 2 * NMAP * 9) * sizeof(float); }
 size_t conv0_wgrad_lds_bytes(int T, int M) {
@@ -1002,12 +1064,11 @@ int howl_res8_fwd(const HowlRes8Params* prm, const float* feat, long sb, long st
         const float* in_stats = (i == 1) ? nullptr : sv->bn_stats + (size_t)(i - 2) * 2 * CP;
         const bool even = (i % 2) == 0;
         const float* res = even ? sv->s[i - 2] : nullptr;
-        float* yo = even ? sv->y[i / 2 - 1] : nullptr;
         {
             HowlProfScope prof("conv3x3_fwd", stream);
             hipLaunchKernelGGL(conv3x3_mfma_kernel<0>, dim3(G), dim3(CONV_THREADS), lc, stream, sv->s[i - 1], in_stats,
-                               w.wp_fwd + (size_t)(i - 1) * 3 * KSTEPS * 64, res, yo, sv->s[i], (const float*)nullptr,
-                               (const float*)nullptr, training ? w.part : (float*)nullptr, B, H);
+                               w.wp_fwd + (size_t)(i - 1) * 3 * KSTEPS * 64, res, sv->s[i], (const float*)nullptr,
+                               (const float*)nullptr, training ? w.part : (float*)nullptr, BwdStage{}, B, H);
         }
         if (training)
             hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(1024), 0, stream, w.part, G, count,
@@ -1038,8 +1099,6 @@ int howl_res8_bwd(const HowlRes8Params* prm, const float* feat, long sb, long st
     const int P = H * PW;
     const double count = (double)B * (double)P;
     const size_t act = (size_t)B * NMAP * P;
-    int eg = (int)((act / 2 + 255) / 256);
-    if (eg > howl_num_cus() * 8) eg = howl_num_cus() * 8;
 
     hipLaunchKernelGGL(head_bwd_pool_kernel, dim3((B * CP + 255) / 256), dim3(256), 0, stream, dlogits, prm->out_w, w.dpool,
                        B, C);
@@ -1057,18 +1116,29 @@ int howl_res8_bwd(const HowlRes8Params* prm, const float* feat, long sb, long st
     float* ds_free = w.dsa;
     for (int i = 6; i >= 1; --i) {
         const bool even = (i % 2) == 0;
-        const float* stats_i = sv->bn_stats + (size_t)(i - 1) * 2 * CP;
-        const float* msrc = even ? sv->y[i / 2 - 1] : sv->s[i];
         float* ds_out = even ? ds_free : nullptr;
-        hipLaunchKernelGGL(bn_relu_bwd_kernel, dim3(eg), dim3(256), 0, stream, (const float*)dx_cur, w.dpool, sv->s[i],
-                           stats_i, w.m12, even ? (const float*)ds_prev : (const float*)nullptr, msrc, ds_out, w.dz, B, P);
+        // data gradient of layer i, with the BatchNorm/ReLU backward of layer i fused into its input staging:
+        //   dz_i -> w.dz (for the weight gradient), ds_i -> ds_out (skip gradient of layer i-2), dx_{i-1} -> dx_next,
+        //   plus the statistics BN_{i-1}'s backward needs
+        const float* in_stats = (i == 1) ? nullptr : sv->bn_stats + (size_t)(i - 2) * 2 * CP;
+        const bool need_stats = i > 1;
+        BwdStage bw{dx_cur, w.dpool, sv->s[i], sv->bn_stats + (size_t)(i - 1) * 2 * CP, w.m12, ds_out, w.dz, even ? 1 : 0};
+        // the consumer of dx_{i-1} is layer i-1's BatchNorm backward; if that layer has a skip connection (i-1 even and
+        // below 6) its skip gradient ds_{i+1} (= the ds just kept from layer i+1) is folded into dx_{i-1} here
+        const float* fold = (i % 2 == 1 && i >= 3) ? (const float*)ds_prev : (const float*)nullptr;
+        {
+            HowlProfScope prof("conv3x3_dgrad", stream);
+            hipLaunchKernelGGL(conv3x3_mfma_kernel<1>, dim3(G), dim3(CONV_THREADS), lc, stream, (const float*)nullptr,
+                               (const float*)nullptr, w.wp_bwd + (size_t)(i - 1) * 3 * KSTEPS * 64, fold,
+                               dx_next, need_stats ? sv->s[i - 1] : (const float*)nullptr, in_stats,
+                               need_stats ? w.part : (float*)nullptr, bw, B, H);
+        }
         if (even) {
             float* t = ds_prev ? ds_prev : w.dsb;
             ds_prev = ds_out;
             ds_free = t;
         }
         // weight gradient of layer i: input x_{i-1} = BN_{i-1}(s_{i-1}) (identity for i = 1)
-        const float* in_stats = (i == 1) ? nullptr : sv->bn_stats + (size_t)(i - 2) * 2 * CP;
         {
             HowlProfScope prof("wgrad", stream);
             hipLaunchKernelGGL(wgrad_mfma_kernel, dim3(G), dim3(CONV_THREADS), lw, stream, (const float*)w.dz, sv->s[i - 1],
@@ -1076,16 +1146,7 @@ int howl_res8_bwd(const HowlRes8Params* prm, const float* feat, long sb, long st
         }
         hipLaunchKernelGGL(reduce_rows_kernel, dim3((CP * 432 + 63) / 64), dim3(256), 0, stream, (const float*)w.wpart, G,
                            CP * 432, 1, gr->conv_w[i - 1]);
-        // data gradient: dx_{i-1} (w.r.t. the normalised input of layer i), with BN_{i-1} backward statistics
-        const bool need_stats = i > 1;
-        {
-            HowlProfScope prof("conv3x3_dgrad", stream);
-            hipLaunchKernelGGL(conv3x3_mfma_kernel<1>, dim3(G), dim3(CONV_THREADS), lc, stream, (const float*)w.dz,
-                               (const float*)nullptr, w.wp_bwd + (size_t)(i - 1) * 3 * KSTEPS * 64, (const float*)nullptr,
-                               (float*)nullptr, dx_next, need_stats ? sv->s[i - 1] : (const float*)nullptr, in_stats,
-                               need_stats ? w.part : (float*)nullptr, B, H);
-        }
-        if (need_stats)
+        if (need_stats)   // m12 of BN_{i-1}; safe to overwrite now: layer i's staging has consumed the old values
             hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(1024), 0, stream, (const float*)w.part, G, count,
                                w.m12);
         dx_cur = dx_next;

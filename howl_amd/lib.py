@@ -31,7 +31,7 @@ class HowlRes8Grads(ctypes.Structure):
 
 
 class HowlRes8Saved(ctypes.Structure):
-    _fields_ = [("s", P * 7), ("y", P * 3), ("bn_stats", P), ("pooled", P), ("mask0", P)]
+    _fields_ = [("s", P * 7), ("bn_stats", P), ("pooled", P), ("mask0", P)]
 
 
 class HowlLstmParams(ctypes.Structure):

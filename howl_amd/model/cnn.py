@@ -38,7 +38,6 @@ class _Res8Buffers:
         f32 = dict(dtype=torch.float32, device=device)
         self.key = (B, T, C, str(device))
         self.s = [torch.empty((B, 45, H, 10), **f32) for _ in range(7)]
-        self.y = [torch.empty((B, 45, H, 10), **f32) for _ in range(3)]
         self.bn_stats = torch.zeros((6, 2, 48), **f32)
         self.pooled = torch.empty((B, 48), **f32)
         self.mask0 = torch.empty((B, 45, H, 10), dtype=torch.int16, device=device)
@@ -47,8 +46,6 @@ class _Res8Buffers:
         self.saved = _lib.HowlRes8Saved()
         for i in range(7):
             self.saved.s[i] = _vp(self.s[i])
-        for i in range(3):
-            self.saved.y[i] = _vp(self.y[i])
         self.saved.bn_stats = _vp(self.bn_stats)
         self.saved.pooled = _vp(self.pooled)
         self.saved.mask0 = _vp(self.mask0)

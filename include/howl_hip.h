@@ -113,8 +113,9 @@ typedef struct {
 
 /* activations the backward pass needs; all caller-allocated */
 typedef struct {
-    float* s[7];       /* s[0] = avgpool(relu(conv0(x))); s[i] = layer i's pre-BatchNorm output; each (B,45,T/3,10) */
-    float* y[3];       /* relu(conv_i(.)) before the residual add for i = 2,4,6 (ReLU mask of the backward) */
+    float* s[7];       /* s[0] = avgpool(relu(conv0(x))); s[i] = layer i's pre-BatchNorm output; each (B,45,T/3,10).
+                        * Values are >= 0 by construction; for i = 2,4,6 the sign bit carries the ReLU mask of conv_i
+                        * (the backward needs it), so readers take |s|. */
     float* bn_stats;   /* (6, 2, 48): per layer {mean[48], rstd[48]} used by this forward */
     float* pooled;     /* (B, 48): spatial mean of BN6's output */
     unsigned short* mask0; /* (B,45,T/3,10) uint16: ReLU pattern of conv0's 3x4 pre-pool window (bit 4i+j); NULL in eval */

@@ -35,14 +35,11 @@ class Res8Harness:
         self.prm.out_w = ptr(self.np["output.weight"])
         self.prm.out_b = ptr(self.np["output.bias"])
         self.s = [np.full((B, 45, self.H, 10), np.nan, np.float32) for _ in range(7)]
-        self.y = [np.full((B, 45, self.H, 10), np.nan, np.float32) for _ in range(3)]
         self.bn_stats = np.zeros((6, 2, 48), np.float32)
         self.pooled = np.zeros((B, 48), np.float32)
         self.saved = HowlRes8Saved()
         for i in range(7):
             self.saved.s[i] = ptr(self.s[i]).value
-        for i in range(3):
-            self.saved.y[i] = ptr(self.y[i]).value
         self.saved.bn_stats = ptr(self.bn_stats)
         self.saved.pooled = ptr(self.pooled)
         self.mask0 = np.zeros((B, 45, self.H, 10), np.uint16)
