@@ -130,66 +130,6 @@ __device__ __forceinline__ void stage_tile(const float2 (&pre)[PREF], const int 
     }
 }
 
-// Backward fusion (MODE 1): the dgrad kernel builds its input tile dz_i on the fly,
-//   ds = rstd * (dx' - m1 - xhat * m2)            (BatchNorm backward with batch statistics; for layers with a skip
-//                                                  connection the producer of dx already folded the skip-path gradient
-//                                                  in as dx' = dx + dskip / rstd, see conv_utterance)
-//   dz = ds * [ReLU mask of layer i]                (mask: s > 0 for odd layers, sign bit of s for even layers)
-// and writes dz (for the weight-gradient kernel) and ds (even layers: the skip gradient of layer i-2) on the way.
-struct BwdStage {
-    const float* dx;      // (B,45,P) gradient w.r.t. BN_i's output; nullptr -> dpool[b][c] / P broadcast (layer 6)
-    const float* dpool;   // (B,48)
-    const float* s;       // s_i
-    const float* stats;   // {mean[48], rstd[48]} of BN_i
-    const float* m12;     // {mean(dx)[48], mean(dx*xhat)[48]}
-    float* ds_out;        // ds_i or nullptr
-    float* dz_out;        // dz_i
-    int even;
-};
-
-__device__ __forceinline__ void prefetch_bwd(float2 (&pdx)[PREF], float2 (&ps)[PREF], const int (&pk)[PREF],
-                                             const BwdStage& bw, int b, int P, int n2, int tid) {
-    const size_t ub2 = (size_t)b * NMAP * P / 2;
-#pragma unroll
-    for (int j = 0; j < PREF; ++j) {
-        const int e2 = tid + j * CONV_THREADS;
-        const bool ok = e2 < n2;
-        if (bw.dx != nullptr) {
-            pdx[j] = ok ? reinterpret_cast<const float2*>(bw.dx)[ub2 + e2] : make_float2(0.0f, 0.0f);
-        } else {
-            const float v = ok ? bw.dpool[(size_t)b * CP + (pk[j] >> 20)] * (1.0f / (float)P) : 0.0f;
-            pdx[j] = make_float2(v, v);
-        }
-        ps[j] = ok ? reinterpret_cast<const float2*>(bw.s)[ub2 + e2] : make_float2(0.0f, 0.0f);
-    }
-}
-
-__device__ __forceinline__ void stage_bwd(const float2 (&pdx)[PREF], const float2 (&ps)[PREF], const int (&pk)[PREF],
-                                          float* tile, const float* lconst /* [4][48] */, const BwdStage& bw, int b, int P,
-                                          int tid) {
-    const size_t ub2 = (size_t)b * NMAP * P / 2;
-#pragma unroll
-    for (int j = 0; j < PREF; ++j) {
-        if (pk[j] >= 0) {
-            const int c = pk[j] >> 20;
-            const float mean = lconst[c], rstd = lconst[CP + c], m1 = lconst[2 * CP + c], m2 = lconst[3 * CP + c];
-            const float s0 = ps[j].x, s1 = ps[j].y;
-            float d0 = rstd * (pdx[j].x - m1 - ((fabsf(s0) - mean) * rstd) * m2);
-            float d1 = rstd * (pdx[j].y - m1 - ((fabsf(s1) - mean) * rstd) * m2);
-            const int e2 = tid + j * CONV_THREADS;
-            if (bw.ds_out != nullptr) reinterpret_cast<float2*>(bw.ds_out)[ub2 + e2] = make_float2(d0, d1);
-            const bool k0 = bw.even ? (s0 < 0.0f) : (s0 > 0.0f);
-            const bool k1 = bw.even ? (s1 < 0.0f) : (s1 > 0.0f);
-            d0 = k0 ? d0 : 0.0f;
-            d1 = k1 ? d1 : 0.0f;
-            reinterpret_cast<float2*>(bw.dz_out)[ub2 + e2] = make_float2(d0, d1);
-            float* d = tile + (pk[j] & 0xFFFFF);
-            d[0] = d0;
-            d[1] = d1;
-        }
-    }
-}
-
 __device__ __forceinline__ void prefetch_tile(float2 (&pre)[PREF], const float* src, int n2, int tid) {
 #pragma unroll
     for (int j = 0; j < PREF; ++j) {
@@ -202,34 +142,59 @@ __device__ __forceinline__ void prefetch_tile(float2 (&pre)[PREF], const float* 
 // chains advanced together so that one weight fragment read feeds NTW MFMAs and the chains hide each other's latency.
 //   A[position][k] from the zero-haloed activation tile, B[k][cout] from the packed weights in LDS.
 template <int NTW>
-__device__ __forceinline__ void conv_tiles(const lds_f32* tile, const lds_f32* wl, int CS, int P, int mg, int lane,
-                                           f32x4 (&acc)[NTW]) {
+struct KCursor {
     const lds_f32* ap[NTW];
+    const lds_f32* bp;
+};
+
+template <int NTW>
+__device__ __forceinline__ void k_begin(KCursor<NTW>& k, f32x4 (&acc)[NTW], const lds_f32* tile, const lds_f32* wl,
+                                        int CS, int P, int mg, int lane) {
 #pragma unroll
     for (int i = 0; i < NTW; ++i) {
         int m = 16 * (mg + 4 * i) + (lane & 15);
         m = m < P ? m : P - 1;  // the last tile may overhang: clamp the read, the store is masked
         const int h = m / PW;
-        ap[i] = tile + (lane >> 4) * CS + h * WP + (m - h * PW);
+        k.ap[i] = tile + (lane >> 4) * CS + h * WP + (m - h * PW);
         acc[i] = {0.0f, 0.0f, 0.0f, 0.0f};
     }
-    const lds_f32* bp = wl + lane;
-    for (int c0 = 0; c0 < 12; ++c0) {
+    k.bp = wl + lane;
+}
+
+// `groups` channel groups (4 input channels x 9 taps each) of the K loop
+template <int NTW>
+__device__ __forceinline__ void k_run(KCursor<NTW>& k, f32x4 (&acc)[NTW], int CS, int groups) {
+#pragma nounroll
+    for (int g = 0; g < groups; ++g) {
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
-            const float b = bp[tap * 64];
+            const float b = k.bp[tap * 64];
             const int off = (tap / 3) * WP + (tap % 3);
 #pragma unroll
-            for (int i = 0; i < NTW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[i][off], b, acc[i], 0, 0, 0);
+            for (int i = 0; i < NTW; ++i)
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(k.ap[i][off], b, acc[i], 0, 0, 0);
         }
-        bp += 9 * 64;
+        k.bp += 9 * 64;
 #pragma unroll
-        for (int i = 0; i < NTW; ++i) ap[i] += 4 * CS;
+        for (int i = 0; i < NTW; ++i) k.ap[i] += 4 * CS;
+    }
+}
+
+// two staging slots of the next utterance (straight-line code between K-loop segments: issuing all 8 slots of all 12
+// waves back to back keeps the CU's vector-memory path busy for ~2.5k cycles; spread out, that hides under the MFMAs)
+template <int J>
+__device__ __forceinline__ void prefetch_pair(float2 (&pre)[PREF], const float* nsrc, int n2, int tid) {
+    if (nsrc != nullptr) {
+#pragma unroll
+        for (int j = J; j < J + 2; ++j) {
+            const int e2 = tid + j * CONV_THREADS;
+            if (e2 < n2) pre[j] = reinterpret_cast<const float2*>(nsrc)[e2];
+        }
     }
 }
 
 struct ConvEpilogue {
-    const float* res;      // fwd: residual input;  dgrad: skip-path gradient ds_{j+2} folded into dx_j (or nullptr)
+    const float* res;
     float* out;
     const float* xs;
     float xmean, xrstd;
@@ -238,20 +203,52 @@ struct ConvEpilogue {
 };
 
 // MFMA phase + epilogue for one utterance; lane holds cout = 16nt + (lane&15) and, for tile j = mg + 4i, positions
-// 16j + 4*(lane>>4) + {0,1,2,3}
+// 16j + 4*(lane>>4) + {0,1,2,3}.  The epilogue's own operands (residual / saved activation at the output positions)
+// are requested before the K loop so that their HBM latency is not exposed after it.
 template <int MODE, int NTW>
 __device__ __forceinline__ void conv_utterance(const lds_f32* tile, const lds_f32* wl, int CS, int mg, int lane,
-                                               size_t ubase, const ConvEpilogue& e, float& st0, float& st1) {
+                                               size_t ubase, const ConvEpilogue& e, float& st0, float& st1,
+                                               float2 (&pre)[PREF], const float* nsrc, int n2, int tid) {
+    const float* eop = (MODE == 0) ? e.res : e.xs;
+    float2 ev[NTW][2];
+    // uniform base + one 32-bit lane offset + immediates; only a wave's last tile can overhang P (clamped)
+    const char* ebase = reinterpret_cast<const char*>(eop + ubase);
+    const unsigned crow = (unsigned)((e.cvalid ? e.cout : NMAP - 1) * e.P);
+    const unsigned boff = 4u * (crow + 16u * mg + 4u * (lane >> 4));
+    const unsigned bmax = 4u * (crow + e.P - 2);
+    auto fetch_operands = [&](int i) {  // branch-free: all loads in flight together
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            unsigned off = boff + 256u * i + 8u * hh;
+            if (i == NTW - 1) off = off < bmax ? off : bmax;
+            ev[i][hh] = *reinterpret_cast<const float2*>(ebase + off);
+        }
+    };
+    static_assert(PREF == 8, "four prefetch pairs below");
     f32x4 acc[NTW];
-    conv_tiles<NTW>(tile, wl, CS, e.P, mg, lane, acc);
+    KCursor<NTW> k;
+    k_begin<NTW>(k, acc, tile, wl, CS, e.P, mg, lane);
+    prefetch_pair<0>(pre, nsrc, n2, tid);
+    k_run<NTW>(k, acc, CS, 2);
+    prefetch_pair<2>(pre, nsrc, n2, tid);
+    k_run<NTW>(k, acc, CS, 2);
+    prefetch_pair<4>(pre, nsrc, n2, tid);
+    k_run<NTW>(k, acc, CS, 2);
+    prefetch_pair<6>(pre, nsrc, n2, tid);
+    k_run<NTW>(k, acc, CS, 3);
+    k_run<NTW>(k, acc, CS, 3);
+    if (eop != nullptr) {
+#pragma unroll
+        for (int i = 0; i < NTW; ++i) fetch_operands(i);
+    }
+    char* obase = reinterpret_cast<char*>(e.out + ubase);
 #pragma unroll
     for (int i = 0; i < NTW; ++i) {
         const int mbase = 16 * (mg + 4 * i) + 4 * (lane >> 4);
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
             const int m = mbase + 2 * hh;
-            if (e.cvalid && m < e.P) {
-                const size_t o = ubase + (size_t)e.cout * e.P + m;
+            if (e.cvalid && (i < NTW - 1 || m < e.P)) {
                 float v0 = acc[i][2 * hh], v1 = acc[i][2 * hh + 1];
                 if (MODE == 0) {
                     v0 = fmaxf(v0, 0.0f);
@@ -259,7 +256,7 @@ __device__ __forceinline__ void conv_utterance(const lds_f32* tile, const lds_f3
                     if (e.res != nullptr) {
                         // s = relu(conv) + skip >= 0; the ReLU mask of THIS convolution rides in the sign bit of the
                         // stored value (relu > 0 implies s > 0, so -s is a proper negative number); readers take |s|
-                        const float2 r = *reinterpret_cast<const float2*>(e.res + o);
+                        const float2 r = ev[i][hh];
                         const bool k0 = v0 > 0.0f, k1 = v1 > 0.0f;
                         v0 += fabsf(r.x);
                         v1 += fabsf(r.y);
@@ -272,21 +269,45 @@ __device__ __forceinline__ void conv_utterance(const lds_f32* tile, const lds_f3
                         st1 += v0 * v0 + v1 * v1;
                     }
                 } else if (e.xs != nullptr) {
-                    const float2 sv = *reinterpret_cast<const float2*>(e.xs + o);
+                    const float2 sv = ev[i][hh];
                     st0 += v0 + v1;
                     st1 += v0 * ((fabsf(sv.x) - e.xmean) * e.xrstd) + v1 * ((fabsf(sv.y) - e.xmean) * e.xrstd);
-                    if (e.res != nullptr) {
-                        // layer j = i-1 has a skip connection: its BatchNorm backward computes rstd * (dx' - ...), so
-                        // adding dskip / rstd here (after the statistics, which are of dx alone) yields ds_j = ... + dskip
-                        const float2 k = *reinterpret_cast<const float2*>(e.res + o);
-                        const float inv = 1.0f / e.xrstd;
-                        v0 += k.x * inv;
-                        v1 += k.y * inv;
-                    }
                 }
-                *reinterpret_cast<float2*>(e.out + o) = make_float2(v0, v1);
+                *reinterpret_cast<float2*>(obase + (boff + 256u * i + 8u * hh)) = make_float2(v0, v1);
             }
         }
+    }
+}
+
+struct ConvLoop {
+    const float* in;
+    const lds_f32* ltile;
+    const lds_f32* wnt;
+    float* tile;
+    const float* lmean;
+    const float* lrstd;
+    int B, CS, n2, mg, lane, tid;
+    bool affine;
+};
+
+// all utterances b, b + gridDim.x, ... of this workgroup; `pre` holds utterance b's activations on entry
+template <int MODE, int NTW>
+__device__ __forceinline__ void conv_loop(const ConvLoop& c, const ConvEpilogue& epi, float2 (&pre)[PREF],
+                                          const int (&pk)[PREF], int b, float& st0, float& st1) {
+    const int P = epi.P;
+    for (; b < c.B; b += gridDim.x) {
+        stage_tile(pre, pk, c.tile, c.lmean, c.lrstd, c.affine, MODE == 0);  // gradient tiles (dgrad) are signed
+        __syncthreads();
+        const int bn = b + gridDim.x;
+        const float* nsrc = (bn < c.B) ? c.in + (size_t)bn * NMAP * P : nullptr;  // fetched from inside the K loop
+        const size_t ubase = (size_t)b * NMAP * P;
+        if constexpr (NTW > 0) {
+            conv_utterance<MODE, NTW>(c.ltile, c.wnt, c.CS, c.mg, c.lane, ubase, epi, st0, st1, pre, nsrc, c.n2, c.tid);
+        } else {
+            // no position tile for this wave (tiny H): it still owns its share of the next utterance's loads
+            if (nsrc != nullptr) prefetch_tile(pre, nsrc, c.n2, c.tid);
+        }
+        __syncthreads();  // single tile buffer: every wave is done reading before the next utterance is staged
     }
 }
 
@@ -302,7 +323,6 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_mfma_kernel(
     const float* __restrict__ xs,         // dgrad: s_{i-1} for xhat, or nullptr (no stats)
     const float* __restrict__ xs_stats,   // dgrad: {mean, rstd} of layer i-1
     float* __restrict__ part,             // [gridDim.x][2][48] partial statistics, or nullptr
-    BwdStage bw,                          // dgrad: how to build the input tile (unused in MODE 0)
     int B, int H) {
     HIP_DYNAMIC_SHARED(float, lds)
     const int P = H * PW;
@@ -312,8 +332,7 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_mfma_kernel(
     float* tile = lds + 3 * KSTEPS * 64;   // one utterance's zero-haloed input map
     float* lmean = tile + TF;
     float* lrstd = lmean + CP;
-    float* lm12 = lrstd + CP;   // MODE 1: {m1[48], m2[48]} right behind {mean, rstd}
-    float* red = lm12 + 2 * CP;  // [12][2][16]
+    float* red = lrstd + CP;  // [12][2][16]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -326,16 +345,9 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_mfma_kernel(
     const bool affine = in_stats != nullptr;
 
     // first utterance's activations are requested before anything else so that HBM latency overlaps the setup
-    float2 pre[PREF], pss[MODE == 1 ? PREF : 1];
-    int pk[PREF];
-    stage_slots(pk, P, CS, n2, tid);
+    float2 pre[PREF];
     int b = blockIdx.x;
-    if (b < B) {
-        if constexpr (MODE == 1)
-            prefetch_bwd(pre, pss, pk, bw, b, P, n2, tid);
-        else
-            prefetch_tile(pre, in + (size_t)b * NMAP * P, n2, tid);
-    }
+    if (b < B) prefetch_tile(pre, in + (size_t)b * NMAP * P, n2, tid);
     {
         float4 wv[7];  // 3*108*16 float4 = 5184 <= 7 * 768: all loads in flight, then the LDS stores
 #pragma unroll
@@ -351,15 +363,8 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_mfma_kernel(
         }
     }
     if (tid < CP) {
-        if (MODE == 1) {
-            lmean[tid] = bw.stats[tid];
-            lrstd[tid] = bw.stats[CP + tid];
-            lm12[tid] = bw.m12[tid];
-            lm12[CP + tid] = bw.m12[CP + tid];
-        } else {
-            lmean[tid] = affine ? in_stats[tid] : 0.0f;
-            lrstd[tid] = affine ? in_stats[CP + tid] : 1.0f;
-        }
+        lmean[tid] = affine ? in_stats[tid] : 0.0f;
+        lrstd[tid] = affine ? in_stats[CP + tid] : 1.0f;
     }
     const int cout = 16 * nt + (lane & 15);
     const bool cvalid = cout < NMAP;
@@ -370,34 +375,23 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_mfma_kernel(
     }
     float st0 = 0.0f, st1 = 0.0f;
     const ConvEpilogue epi{res, out, xs, xmean, xrstd, cout, P, cvalid};
+
+    int pk[PREF];
+    stage_slots(pk, P, CS, n2, tid);
     __syncthreads();  // weights, zero fill and stats visible before the first stage
 
-    for (; b < B; b += gridDim.x) {
-        if constexpr (MODE == 1)
-            stage_bwd(pre, pss, pk, tile, lmean, bw, b, P, tid);
-        else
-            stage_tile(pre, pk, tile, lmean, lrstd, affine, true);
-        __syncthreads();
-        const int bn = b + gridDim.x;
-        if (bn < B) {
-            if constexpr (MODE == 1)
-                prefetch_bwd(pre, pss, pk, bw, bn, P, n2, tid);
-            else
-                prefetch_tile(pre, in + (size_t)bn * NMAP * P, n2, tid);
-        }
-
-        const lds_f32* ltile = (const lds_f32*)tile;
-        const lds_f32* wnt = (const lds_f32*)wl + nt * KSTEPS * 64;
-        const size_t ubase = (size_t)b * NMAP * P;
-        switch (ntw) {
-            case 5: conv_utterance<MODE, 5>(ltile, wnt, CS, mg, lane, ubase, epi, st0, st1); break;
-            case 4: conv_utterance<MODE, 4>(ltile, wnt, CS, mg, lane, ubase, epi, st0, st1); break;
-            case 3: conv_utterance<MODE, 3>(ltile, wnt, CS, mg, lane, ubase, epi, st0, st1); break;
-            case 2: conv_utterance<MODE, 2>(ltile, wnt, CS, mg, lane, ubase, epi, st0, st1); break;
-            case 1: conv_utterance<MODE, 1>(ltile, wnt, CS, mg, lane, ubase, epi, st0, st1); break;
-            default: break;
-        }
-        __syncthreads();  // single tile buffer: every wave is done reading before the next utterance is staged
+    // The utterance loop is instantiated once per tile count (waves of one workgroup run different instances; every
+    // instance executes the same two barriers per utterance): the register allocator then sees one variant's live
+    // values, not the union of all five.
+    const ConvLoop cl{in, (const lds_f32*)tile, (const lds_f32*)wl + nt * KSTEPS * 64, tile, lmean, lrstd, B, CS, n2,
+                      mg, lane, tid, affine};
+    switch (ntw) {
+        case 5: conv_loop<MODE, 5>(cl, epi, pre, pk, b, st0, st1); break;
+        case 4: conv_loop<MODE, 4>(cl, epi, pre, pk, b, st0, st1); break;
+        case 3: conv_loop<MODE, 3>(cl, epi, pre, pk, b, st0, st1); break;
+        case 2: conv_loop<MODE, 2>(cl, epi, pre, pk, b, st0, st1); break;
+        case 1: conv_loop<MODE, 1>(cl, epi, pre, pk, b, st0, st1); break;
+        default: conv_loop<MODE, 0>(cl, epi, pre, pk, b, st0, st1); break;
     }
 
     if (part != nullptr) {
@@ -658,6 +652,45 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __re
     if (c < CP) {
         m12[c] = (float)(s / count);
         m12[CP + c] = (float)(q / count);
+    }
+}
+
+// backward elementwise: BatchNorm backward (batch statistics) + skip gradient + ReLU mask
+//   ds = rstd * (dx - m1 - xhat * m2) [+ dskip];  dz = ds * mask,  mask = (s > 0) for odd layers and the sign bit of
+//   the stored s for the layers with a residual add (see conv_utterance); xhat = (|s| - mean) * rstd
+__global__ __launch_bounds__(256) void bn_relu_bwd_kernel(
+    const float* __restrict__ dx,      // (B,45,P) or nullptr -> broadcast of dpool
+    const float* __restrict__ dpool,   // (B,48) used when dx == nullptr, scaled by 1/P
+    const float* __restrict__ s, const float* __restrict__ stats, const float* __restrict__ m12,
+    const float* __restrict__ dskip,   // nullable
+    int even,                          // layer has a residual add: mask in the sign bit of s
+    float* __restrict__ ds_out,        // nullable
+    float* __restrict__ dz_out, int B, int P) {
+    const size_t n2 = (size_t)B * NMAP * P / 2;
+    const float invP = 1.0f / (float)P;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t e = 2 * i;
+        const int bc = (int)(e / P);
+        const int b = bc / NMAP, c = bc - b * NMAP;
+        float2 g;
+        if (dx != nullptr) {
+            g = reinterpret_cast<const float2*>(dx)[i];
+        } else {
+            const float v = dpool[b * CP + c] * invP;
+            g = make_float2(v, v);
+        }
+        const float2 sv = reinterpret_cast<const float2*>(s)[i];
+        const float mean = stats[c], rstd = stats[CP + c], m1 = m12[c], m2 = m12[CP + c];
+        float d0 = rstd * (g.x - m1 - ((fabsf(sv.x) - mean) * rstd) * m2);
+        float d1 = rstd * (g.y - m1 - ((fabsf(sv.y) - mean) * rstd) * m2);
+        if (dskip != nullptr) {
+            const float2 k = reinterpret_cast<const float2*>(dskip)[i];
+            d0 += k.x;
+            d1 += k.y;
+        }
+        if (ds_out != nullptr) reinterpret_cast<float2*>(ds_out)[i] = make_float2(d0, d1);
+        const bool k0 = even ? (sv.x < 0.0f) : (sv.x > 0.0f), k1 = even ? (sv.y < 0.0f) : (sv.y > 0.0f);
+        reinterpret_cast<float2*>(dz_out)[i] = make_float2(k0 ? d0 : 0.0f, k1 ? d1 : 0.0f);
     }
 }
 
@@ -963,7 +996,7 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
     }
 }
 
-size_t conv_lds_bytes(int H) { return (size_t)(3 * KSTEPS * 64 + tile_floats(H) + 4 * CP + 12 * 2 * 16) * sizeof(float); }
+size_t conv_lds_bytes(int H) { return (size_t)(3 * KSTEPS * 64 + tile_floats(H) + 2 * CP + 12 * 2 * 16) * sizeof(float); }
 size_t wgrad_lds_bytes(int H) { return (size_t)(2 * tile_floats(H) + 2 * CP) * sizeof(float); }
 size_t conv0_lds_bytes(int T, int M) { return (size_t)((T + 2) * (M + 4) + 2 * NMAP * 9) * sizeof(float); }
 size_t conv0_wgrad_lds_bytes(int T, int M) {
@@ -1068,7 +1101,7 @@ int howl_res8_fwd(const HowlRes8Params* prm, const float* feat, long sb, long st
             HowlProfScope prof("conv3x3_fwd", stream);
             hipLaunchKernelGGL(conv3x3_mfma_kernel<0>, dim3(G), dim3(CONV_THREADS), lc, stream, sv->s[i - 1], in_stats,
                                w.wp_fwd + (size_t)(i - 1) * 3 * KSTEPS * 64, res, sv->s[i], (const float*)nullptr,
-                               (const float*)nullptr, training ? w.part : (float*)nullptr, BwdStage{}, B, H);
+                               (const float*)nullptr, training ? w.part : (float*)nullptr, B, H);
         }
         if (training)
             hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(1024), 0, stream, w.part, G, count,
@@ -1099,6 +1132,8 @@ int howl_res8_bwd(const HowlRes8Params* prm, const float* feat, long sb, long st
     const int P = H * PW;
     const double count = (double)B * (double)P;
     const size_t act = (size_t)B * NMAP * P;
+    int eg = (int)((act / 2 + 255) / 256);
+    if (eg > howl_num_cus() * 8) eg = howl_num_cus() * 8;
 
     hipLaunchKernelGGL(head_bwd_pool_kernel, dim3((B * CP + 255) / 256), dim3(256), 0, stream, dlogits, prm->out_w, w.dpool,
                        B, C);
@@ -1116,29 +1151,17 @@ int howl_res8_bwd(const HowlRes8Params* prm, const float* feat, long sb, long st
     float* ds_free = w.dsa;
     for (int i = 6; i >= 1; --i) {
         const bool even = (i % 2) == 0;
+        const float* stats_i = sv->bn_stats + (size_t)(i - 1) * 2 * CP;
         float* ds_out = even ? ds_free : nullptr;
-        // data gradient of layer i, with the BatchNorm/ReLU backward of layer i fused into its input staging:
-        //   dz_i -> w.dz (for the weight gradient), ds_i -> ds_out (skip gradient of layer i-2), dx_{i-1} -> dx_next,
-        //   plus the statistics BN_{i-1}'s backward needs
-        const float* in_stats = (i == 1) ? nullptr : sv->bn_stats + (size_t)(i - 2) * 2 * CP;
-        const bool need_stats = i > 1;
-        BwdStage bw{dx_cur, w.dpool, sv->s[i], sv->bn_stats + (size_t)(i - 1) * 2 * CP, w.m12, ds_out, w.dz, even ? 1 : 0};
-        // the consumer of dx_{i-1} is layer i-1's BatchNorm backward; if that layer has a skip connection (i-1 even and
-        // below 6) its skip gradient ds_{i+1} (= the ds just kept from layer i+1) is folded into dx_{i-1} here
-        const float* fold = (i % 2 == 1 && i >= 3) ? (const float*)ds_prev : (const float*)nullptr;
-        {
-            HowlProfScope prof("conv3x3_dgrad", stream);
-            hipLaunchKernelGGL(conv3x3_mfma_kernel<1>, dim3(G), dim3(CONV_THREADS), lc, stream, (const float*)nullptr,
-                               (const float*)nullptr, w.wp_bwd + (size_t)(i - 1) * 3 * KSTEPS * 64, fold,
-                               dx_next, need_stats ? sv->s[i - 1] : (const float*)nullptr, in_stats,
-                               need_stats ? w.part : (float*)nullptr, bw, B, H);
-        }
+        hipLaunchKernelGGL(bn_relu_bwd_kernel, dim3(eg), dim3(256), 0, stream, (const float*)dx_cur, w.dpool, sv->s[i],
+                           stats_i, w.m12, even ? (const float*)ds_prev : (const float*)nullptr, even ? 1 : 0, ds_out, w.dz, B, P);
         if (even) {
             float* t = ds_prev ? ds_prev : w.dsb;
             ds_prev = ds_out;
             ds_free = t;
         }
         // weight gradient of layer i: input x_{i-1} = BN_{i-1}(s_{i-1}) (identity for i = 1)
+        const float* in_stats = (i == 1) ? nullptr : sv->bn_stats + (size_t)(i - 2) * 2 * CP;
         {
             HowlProfScope prof("wgrad", stream);
             hipLaunchKernelGGL(wgrad_mfma_kernel, dim3(G), dim3(CONV_THREADS), lw, stream, (const float*)w.dz, sv->s[i - 1],
@@ -1146,7 +1169,16 @@ int howl_res8_bwd(const HowlRes8Params* prm, const float* feat, long sb, long st
         }
         hipLaunchKernelGGL(reduce_rows_kernel, dim3((CP * 432 + 63) / 64), dim3(256), 0, stream, (const float*)w.wpart, G,
                            CP * 432, 1, gr->conv_w[i - 1]);
-        if (need_stats)   // m12 of BN_{i-1}; safe to overwrite now: layer i's staging has consumed the old values
+        // data gradient: dx_{i-1} (w.r.t. the normalised input of layer i), with BN_{i-1} backward statistics
+        const bool need_stats = i > 1;
+        {
+            HowlProfScope prof("conv3x3_dgrad", stream);
+            hipLaunchKernelGGL(conv3x3_mfma_kernel<1>, dim3(G), dim3(CONV_THREADS), lc, stream, (const float*)w.dz,
+                               (const float*)nullptr, w.wp_bwd + (size_t)(i - 1) * 3 * KSTEPS * 64, (const float*)nullptr,
+                               dx_next, need_stats ? sv->s[i - 1] : (const float*)nullptr, in_stats,
+                               need_stats ? w.part : (float*)nullptr, B, H);
+        }
+        if (need_stats)
             hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(1024), 0, stream, (const float*)w.part, G, count,
                                w.m12);
         dx_cur = dx_next;
