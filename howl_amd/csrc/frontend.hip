@@ -112,32 +112,44 @@ __global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ p
         zm_std = zmuv[1];
     }
 
+    // Raw samples of one frame pair (this wave's pair `pr` of chunk `chunk`): reflect-padded centre framing.  They are
+    // requested one pair ahead of the FFT that consumes them, so the HBM round trip is spent under the previous pair's
+    // butterflies instead of in front of every FFT.
+    auto fetch_pair = [&](int chunk, int pr, float (&xa)[8], float (&xb)[8]) {
+        const long ga = (long)chunk * CHUNK + 4 * wave + 2 * pr, gb = ga + 1;
+        const bool va = chunk < n_chunks && ga < total_frames, vb = chunk < n_chunks && gb < total_frames;
+        const long ba = va ? ga / T : 0, bb = vb ? gb / T : 0;
+        const int ta = va ? (int)(ga - ba * T) : 0, tb = vb ? (int)(gb - bb * T) : 0;
+        const float* rowa = pcm + ba * ld;
+        const float* rowb = pcm + bb * ld;
+#pragma unroll
+        for (int n1 = 0; n1 < 8; ++n1) {
+            const int n = 64 * n1 + lane;
+            int sa = HOP * ta - N_FFT / 2 + n;
+            int sb = HOP * tb - N_FFT / 2 + n;
+            sa = sa < 0 ? -sa : sa;
+            sb = sb < 0 ? -sb : sb;
+            sa = sa >= L ? 2 * (L - 1) - sa : sa;
+            sb = sb >= L ? 2 * (L - 1) - sb : sb;
+            const float a = rowa[sa], b = rowb[sb];  // always in range (frame 0 of row 0 for invalid frames)
+            xa[n1] = va ? a : 0.0f;
+            xb[n1] = vb ? b : 0.0f;
+        }
+    };
+    float xa[8], xb[8], na[8], nb[8];
+    fetch_pair(blockIdx.x, 0, xa, xb);
+
     for (int chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
         const long g0 = (long)chunk * CHUNK;
         // ---- FFT phase: this wave transforms frame pairs (4w, 4w+1) and (4w+2, 4w+3) -----------------
-#pragma unroll 1
+#pragma unroll
         for (int pr = 0; pr < 2; ++pr) {
             const int fa = 4 * wave + 2 * pr;  // frame slot of the "real" frame; the "imag" frame is fa + 1
-            const long ga = g0 + fa, gb = ga + 1;
-            const bool va = ga < total_frames, vb = gb < total_frames;
-            const long ba = va ? ga / T : 0, bb = vb ? gb / T : 0;
-            const int ta = va ? (int)(ga - ba * T) : 0, tb = vb ? (int)(gb - bb * T) : 0;
-            const float* rowa = pcm + ba * ld;
-            const float* rowb = pcm + bb * ld;
+            if (pr == 0) fetch_pair(chunk, 1, na, nb);
+            else fetch_pair(chunk + (int)gridDim.x, 0, na, nb);
             cf v[8];
 #pragma unroll
-            for (int n1 = 0; n1 < 8; ++n1) {
-                const int n = 64 * n1 + lane;
-                int sa = HOP * ta - N_FFT / 2 + n;
-                int sb = HOP * tb - N_FFT / 2 + n;
-                sa = sa < 0 ? -sa : sa;
-                sb = sb < 0 ? -sb : sb;
-                sa = sa >= L ? 2 * (L - 1) - sa : sa;
-                sb = sb >= L ? 2 * (L - 1) - sb : sb;
-                const float xa = va ? rowa[sa] : 0.0f;
-                const float xb = vb ? rowb[sb] : 0.0f;
-                v[n1] = {xa * win[n1], xb * win[n1]};
-            }
+            for (int n1 = 0; n1 < 8; ++n1) v[n1] = {xa[n1] * win[n1], xb[n1] * win[n1]};
             // stage 1: radix-8 over n1 (stride 64), twiddle W_512^(lane*k1)
             dft8(v);
 #pragma unroll
@@ -185,6 +197,11 @@ __global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ p
                     Pa[k] = 0.0f;
                     Pb[k] = 0.0f;
                 }
+            }
+#pragma unroll
+            for (int n1 = 0; n1 < 8; ++n1) {
+                xa[n1] = na[n1];
+                xb[n1] = nb[n1];
             }
         }
         __syncthreads();

@@ -164,15 +164,28 @@ __device__ __forceinline__ void k_begin(KCursor<NTW>& k, f32x4 (&acc)[NTW], cons
 // `groups` channel groups (4 input channels x 9 taps each) of the K loop
 template <int NTW>
 __device__ __forceinline__ void k_run(KCursor<NTW>& k, f32x4 (&acc)[NTW], int CS, int groups) {
+#if defined(HOWL_DIAG_CONV_NOK)  // diagnostic build: everything but the K loop
+    groups = 0;
+#endif
 #pragma nounroll
     for (int g = 0; g < groups; ++g) {
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
-            const float b = k.bp[tap * 64];
             const int off = (tap / 3) * WP + (tap % 3);
+#if defined(HOWL_DIAG_CONV_NOLDS)   // diagnostic build: MFMA chain fed from registers (tools/variants.py)
+            const float b = __builtin_bit_cast(float, g + tap);
+#pragma unroll
+            for (int i = 0; i < NTW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(b, b, acc[i], 0, 0, 0);
+#elif defined(HOWL_DIAG_CONV_NOMFMA)  // diagnostic build: LDS traffic only
+            const float b = k.bp[tap * 64];
+#pragma unroll
+            for (int i = 0; i < NTW; ++i) acc[i][0] += k.ap[i][off] * b;
+#else
+            const float b = k.bp[tap * 64];
 #pragma unroll
             for (int i = 0; i < NTW; ++i)
                 acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(k.ap[i][off], b, acc[i], 0, 0, 0);
+#endif
         }
         k.bp += 9 * 64;
 #pragma unroll
@@ -208,7 +221,7 @@ struct ConvEpilogue {
 template <int MODE, int NTW>
 __device__ __forceinline__ void conv_utterance(const lds_f32* tile, const lds_f32* wl, int CS, int mg, int lane,
                                                size_t ubase, const ConvEpilogue& e, float& st0, float& st1,
-                                               float2 (&pre)[PREF], const float* nsrc, int n2, int tid) {
+                                               float2 (&pre)[PREF], const float* nsrc, int n2, int tid, int prio) {
     const float* eop = (MODE == 0) ? e.res : e.xs;
     float2 ev[NTW][2];
     // uniform base + one 32-bit lane offset + immediates; only a wave's last tile can overhang P (clamped)
@@ -228,6 +241,16 @@ __device__ __forceinline__ void conv_utterance(const lds_f32* tile, const lds_f3
     f32x4 acc[NTW];
     KCursor<NTW> k;
     k_begin<NTW>(k, acc, tile, wl, CS, e.P, mg, lane);
+    // The three waves of a SIMD (wave, wave+4, wave+8) would otherwise share the matrix pipe evenly, finish their K
+    // loops together and run their epilogues (operand loads, stores) with the pipe idle.  Staggered priorities let
+    // them finish one after the other, so two of the three epilogues run under another wave's MFMAs.
+#if !defined(HOWL_DIAG_CONV_NOPRIO)
+    switch (prio) {
+        case 0: __builtin_amdgcn_s_setprio(3); break;
+        case 1: __builtin_amdgcn_s_setprio(2); break;
+        default: __builtin_amdgcn_s_setprio(1); break;
+    }
+#endif
     prefetch_pair<0>(pre, nsrc, n2, tid);
     k_run<NTW>(k, acc, CS, 2);
     prefetch_pair<2>(pre, nsrc, n2, tid);
@@ -237,6 +260,7 @@ __device__ __forceinline__ void conv_utterance(const lds_f32* tile, const lds_f3
     prefetch_pair<6>(pre, nsrc, n2, tid);
     k_run<NTW>(k, acc, CS, 3);
     k_run<NTW>(k, acc, CS, 3);
+    __builtin_amdgcn_s_setprio(0);
     if (eop != nullptr) {
 #pragma unroll
         for (int i = 0; i < NTW; ++i) fetch_operands(i);
@@ -273,7 +297,15 @@ __device__ __forceinline__ void conv_utterance(const lds_f32* tile, const lds_f3
                     st0 += v0 + v1;
                     st1 += v0 * ((fabsf(sv.x) - e.xmean) * e.xrstd) + v1 * ((fabsf(sv.y) - e.xmean) * e.xrstd);
                 }
+#if defined(HOWL_DIAG_CONV_NOSTORE)
+                if (v0 == 123.456f)  // diagnostic build: epilogue without its global stores
+                    *reinterpret_cast<float2*>(obase + (boff + 256u * i + 8u * hh)) = make_float2(v0, v1);
+#elif defined(HOWL_DIAG_CONV_NTSTORE)
+                __builtin_nontemporal_store(v0, reinterpret_cast<float*>(obase + (boff + 256u * i + 8u * hh)));
+                __builtin_nontemporal_store(v1, reinterpret_cast<float*>(obase + (boff + 256u * i + 8u * hh)) + 1);
+#else
                 *reinterpret_cast<float2*>(obase + (boff + 256u * i + 8u * hh)) = make_float2(v0, v1);
+#endif
             }
         }
     }
@@ -302,7 +334,8 @@ __device__ __forceinline__ void conv_loop(const ConvLoop& c, const ConvEpilogue&
         const float* nsrc = (bn < c.B) ? c.in + (size_t)bn * NMAP * P : nullptr;  // fetched from inside the K loop
         const size_t ubase = (size_t)b * NMAP * P;
         if constexpr (NTW > 0) {
-            conv_utterance<MODE, NTW>(c.ltile, c.wnt, c.CS, c.mg, c.lane, ubase, epi, st0, st1, pre, nsrc, c.n2, c.tid);
+            conv_utterance<MODE, NTW>(c.ltile, c.wnt, c.CS, c.mg, c.lane, ubase, epi, st0, st1, pre, nsrc, c.n2, c.tid,
+                                      c.tid >> 8);  // wave / 4: position among the waves of this SIMD
         } else {
             // no position tile for this wave (tiny H): it still owns its share of the next utterance's loads
             if (nsrc != nullptr) prefetch_tile(pre, nsrc, c.n2, c.tid);
@@ -353,7 +386,11 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_mfma_kernel(
 #pragma unroll
         for (int j = 0; j < 7; ++j) {
             const int i = tid + j * CONV_THREADS;
+#if defined(HOWL_DIAG_CONV_NOWLOAD)  // diagnostic build: weights not fetched
+            wv[j] = make_float4(0.f, 0.f, 0.f, (float)i);
+#else
             wv[j] = (i < 3 * KSTEPS * 16) ? reinterpret_cast<const float4*>(wp)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+#endif
         }
         zero_lds(tile, TF, tid, CONV_THREADS);
 #pragma unroll
@@ -472,47 +509,82 @@ __global__ __launch_bounds__(CONV_THREADS) void wgrad_mfma_kernel(
         stage_tile(px, pk, tx, lmean, lrstd, affine, true);
         __syncthreads();
         const int bn = b + gridDim.x;
-        if (bn < B) {
-            prefetch_tile(pz, dz + (size_t)bn * NMAP * P, n2, tid);
-            prefetch_tile(px, s_prev + (size_t)bn * NMAP * P, n2, tid);
-        }
+        const float* nz = (bn < B) ? dz + (size_t)bn * NMAP * P : nullptr;
+        const float* nx = (bn < B) ? s_prev + (size_t)bn * NMAP * P : nullptr;
         // K loop over positions, 4 per MFMA: this lane feeds position p = 4*kk + (lane >> 4).  Operands of step
         // kk+1 are loaded before the MFMAs of step kk (software pipeline), so LDS latency hides under the matrix pipe.
+        // The next utterance's 16 loads per thread are issued in four bursts between quarters of the loop (see
+        // prefetch_pair): back to back they would hold up the first MFMAs for several thousand cycles.
         int h = 0, w = lane >> 4;  // p < 4 < PW
         int pos = h * WP + w;      // positions >= P land in the zero bottom halo row
         float az0 = tz[aoff + pos], az1 = tz[aoff + 16 * CS + pos], az2 = tz[aoff + 32 * CS + pos];
         float bx0 = tx[boff[0] + pos], bx1 = tx[boff[1] + pos], bx2 = has3 ? tx[boff[2] + pos] : 0.0f;
-        for (int kk = 0; kk < ksteps; ++kk) {
-            if (kk + 1 < ksteps) {
-                w += 4;
-                if (w >= PW) {
-                    w -= PW;
-                    h += 1;
+        auto k_steps = [&](int kbeg, int kend) {
+#if defined(HOWL_DIAG_WGRAD_UNROLL)
+#pragma unroll HOWL_DIAG_WGRAD_UNROLL
+#else
+#pragma nounroll
+#endif
+            for (int kk = kbeg; kk < kend; ++kk) {
+                if (kk + 1 < ksteps) {
+                    w += 4;
+                    if (w >= PW) {
+                        w -= PW;
+                        h += 1;
+                    }
+                    pos = h * WP + w;
                 }
-                pos = h * WP + w;
+#if defined(HOWL_DIAG_WGRAD_NOLDS)  // diagnostic build: MFMA chains fed from registers (tools/variants.py)
+                const float nz0 = __builtin_bit_cast(float, pos), nz1 = nz0, nz2 = nz0, nx0 = nz0, nx1 = nz0;
+                float nx2 = nz0;
+#else
+                const float nz0 = tz[aoff + pos], nz1 = tz[aoff + 16 * CS + pos], nz2 = tz[aoff + 32 * CS + pos];
+                const float nx0 = tx[boff[0] + pos], nx1 = tx[boff[1] + pos];
+                float nx2 = 0.0f;
+                if (has3) nx2 = tx[boff[2] + pos];
+#endif
+#if defined(HOWL_DIAG_WGRAD_NOMFMA)  // diagnostic build: LDS traffic and address arithmetic only
+                acc[0][0][0] += az0 * bx0 + az1 * bx1 + az2 * bx2;
+                if (false)
+#endif
+                acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(az0, bx0, acc[0][0], 0, 0, 0);
+#if defined(HOWL_DIAG_WGRAD_NOMFMA)
+                if (false) {
+#endif
+                acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(az1, bx0, acc[0][1], 0, 0, 0);
+                acc[0][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(az2, bx0, acc[0][2], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(az0, bx1, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(az1, bx1, acc[1][1], 0, 0, 0);
+                acc[1][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(az2, bx1, acc[1][2], 0, 0, 0);
+                if (has3) {
+                    acc[2][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(az0, bx2, acc[2][0], 0, 0, 0);
+                    acc[2][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(az1, bx2, acc[2][1], 0, 0, 0);
+                    acc[2][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(az2, bx2, acc[2][2], 0, 0, 0);
+                }
+#if defined(HOWL_DIAG_WGRAD_NOMFMA)
+                }
+#endif
+                az0 = nz0;
+                az1 = nz1;
+                az2 = nz2;
+                bx0 = nx0;
+                bx1 = nx1;
+                bx2 = nx2;
             }
-            const float nz0 = tz[aoff + pos], nz1 = tz[aoff + 16 * CS + pos], nz2 = tz[aoff + 32 * CS + pos];
-            const float nx0 = tx[boff[0] + pos], nx1 = tx[boff[1] + pos];
-            float nx2 = 0.0f;
-            if (has3) nx2 = tx[boff[2] + pos];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(az0, bx0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(az1, bx0, acc[0][1], 0, 0, 0);
-            acc[0][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(az2, bx0, acc[0][2], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(az0, bx1, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(az1, bx1, acc[1][1], 0, 0, 0);
-            acc[1][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(az2, bx1, acc[1][2], 0, 0, 0);
-            if (has3) {
-                acc[2][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(az0, bx2, acc[2][0], 0, 0, 0);
-                acc[2][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(az1, bx2, acc[2][1], 0, 0, 0);
-                acc[2][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(az2, bx2, acc[2][2], 0, 0, 0);
-            }
-            az0 = nz0;
-            az1 = nz1;
-            az2 = nz2;
-            bx0 = nx0;
-            bx1 = nx1;
-            bx2 = nx2;
-        }
+        };
+        const int kq = ksteps / 5;
+        prefetch_pair<0>(pz, nz, n2, tid);
+        prefetch_pair<0>(px, nx, n2, tid);
+        k_steps(0, kq);
+        prefetch_pair<2>(pz, nz, n2, tid);
+        prefetch_pair<2>(px, nx, n2, tid);
+        k_steps(kq, 2 * kq);
+        prefetch_pair<4>(pz, nz, n2, tid);
+        prefetch_pair<4>(px, nx, n2, tid);
+        k_steps(2 * kq, 3 * kq);
+        prefetch_pair<6>(pz, nz, n2, tid);
+        prefetch_pair<6>(px, nx, n2, tid);
+        k_steps(3 * kq, ksteps);
         __syncthreads();  // single-buffered tiles: everyone done before the next stage overwrites them
     }
     // D[row = cout = 16mt + 4*(lane>>4) + r][col = n = lane&15 -> cin = 16ct + col] for N tile q = (tap, ct)
@@ -878,9 +950,12 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
             float v = 0.0f;
             if (c < NMAP) {
                 const float* src = s6 + ((size_t)b * NMAP + c) * P;
-                float a8[8];   // <= 8 x 64 positions per channel (P <= 270): all loads in flight at once
+                float a8[8];   // <= 8 x 64 positions per channel (P <= 270): all loads in flight at once (clamped
+                               // addresses instead of predicated loads, which would each wait for their own data)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) a8[j] = (lane + 64 * j < P) ? fabsf(src[lane + 64 * j]) : 0.0f;   // |s|: see conv_utterance
+                for (int j = 0; j < 8; ++j) a8[j] = src[min(lane + 64 * j, P - 1)];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) a8[j] = (lane + 64 * j < P) ? fabsf(a8[j]) : 0.0f;  // |s|: see conv_utterance
                 float acc = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
                 acc = wave_sum(acc);
                 v = (acc / (float)P - stats[c]) * stats[CP + c];

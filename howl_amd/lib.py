@@ -5,10 +5,12 @@ header and against the symbols the built library exports.  ``get()`` loads the i
 loudly when it is absent -- there is no fallback path.
 """
 import ctypes
+import os
 from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_long, c_size_t, c_void_p
 from pathlib import Path
 
-LIB_PATH = Path(__file__).resolve().parent / "libhowl_hip.so"
+# HOWL_HIP_LIBRARY selects another build of the same C ABI (diagnostic kernel variants, tools/variants.py)
+LIB_PATH = Path(os.environ.get("HOWL_HIP_LIBRARY") or Path(__file__).resolve().parent / "libhowl_hip.so")
 MAX_MELS = 48
 FB_COLS = 48
 FB_PACKED_FLOATS = 260 * FB_COLS
