@@ -16,6 +16,7 @@
 // The input projection x W_ih^T and all weight gradients are batched GEMMs outside the recurrence (gemm_kernel).
 #include "howl_common.hip.h"
 #include "../../include/howl_hip.h"
+#include "howl_gemm.hip.h"
 
 namespace {
 
@@ -26,135 +27,6 @@ constexpr int HS = HID + 4;          // LDS row stride of the h tile (16 rows)
 constexpr int DGS = G4 + 4;          // LDS row stride of the dG tile
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
-
-// ---------------------------------------------------------------------------------------------------------
-// Generic fp32 MFMA GEMM:  C[m][n] = sum_k A(m,k) * B(k,n)  (+ bias[n]) (ReLU)
-//   A(m,k) = a[am(m) + k*a_ks], B(k,n) = b[bk(k) + n*b_ns]; am/bk are two-level affine maps
-//   off(x) = (x / inner) * s_outer + (x % inner) * s_inner, which lets (B,T,.) tensors with per-utterance gaps
-//   (e.g. hseq (B,T+1,128)) be used as row sets without copies.  Split-K over gridDim.z writes partial slabs.
-// 64x64 tile, BK = 16, 4 waves in a 2x2 grid, 2x2 16x16x4 MFMA tiles per wave.
-// ---------------------------------------------------------------------------------------------------------
-struct RowMap {
-    int inner;
-    long s_outer, s_inner;
-};
-__device__ __forceinline__ long rmap(const RowMap& r, int x) { return (long)(x / r.inner) * r.s_outer + (long)(x % r.inner) * r.s_inner; }
-
-constexpr int GT = 64, GK = 16, GLD = 80;  // tile edge, k depth, LDS row stride (80 = 16 mod 32: conflict-free frags)
-
-template <bool A_MAJOR_IS_K>  // true: A's unit-stride index is k (row-major [m][k]); false: unit stride is m ([k][m])
-__global__ __launch_bounds__(256) void gemm_kernel(const float* __restrict__ a, RowMap am, long a_ks, RowMap ak,
-                                                   const float* __restrict__ b, RowMap bk, long b_ns, int M, int N, int K,
-                                                   int k_per_split, const float* __restrict__ bias, int relu,
-                                                   float* __restrict__ c, long c_ms, long c_split_stride) {
-    __shared__ float As[GK * GLD];
-    __shared__ float Bs[GK * GLD];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
-    const int m0 = blockIdx.y * GT, n0 = blockIdx.x * GT;
-    const int kbeg = blockIdx.z * k_per_split;
-    const int kend = min(K, kbeg + k_per_split);
-    f32x4 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = {0.0f, 0.0f, 0.0f, 0.0f};
-
-    for (int k0 = kbeg; k0 < kend; k0 += GK) {
-        // stage A tile (64 m x 16 k) and B tile (16 k x 64 n); thread mapping follows the unit-stride index
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            int mm, kk;
-            if (A_MAJOR_IS_K) {
-                kk = tid & 15;
-                mm = (tid >> 4) + 16 * j;
-            } else {
-                mm = tid & 63;
-                kk = (tid >> 6) + 4 * j;
-            }
-            const int m = m0 + mm, k = k0 + kk;
-            float v = 0.0f;
-            if (m < M && k < kend) v = a[rmap(am, m) + (A_MAJOR_IS_K ? (long)k * a_ks : rmap(ak, k))];
-            As[kk * GLD + mm] = v;
-            const int nn = tid & 63, kb = (tid >> 6) + 4 * j;
-            const int n = n0 + nn, k2 = k0 + kb;
-            float w = 0.0f;
-            if (n < N && k2 < kend) w = b[rmap(bk, k2) + (long)n * b_ns];
-            Bs[kb * GLD + nn] = w;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int ks = 0; ks < GK / 4; ++ks) {
-            const int kr = 4 * ks + (lane >> 4);
-            float af[2], bf[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) af[i] = As[kr * GLD + 32 * wr + 16 * i + (lane & 15)];
-#pragma unroll
-            for (int j = 0; j < 2; ++j) bf[j] = Bs[kr * GLD + 32 * wc + 16 * j + (lane & 15)];
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
-        }
-        __syncthreads();
-    }
-    float* cz = c + (long)blockIdx.z * c_split_stride;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int n = n0 + 32 * wc + 16 * j + (lane & 15);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = m0 + 32 * wr + 16 * i + 4 * (lane >> 4) + r;
-                if (m < M && n < N) {
-                    float v = acc[i][j][r];
-                    if (bias != nullptr) v += bias[n];
-                    if (relu) v = fmaxf(v, 0.0f);
-                    cz[(long)m * c_ms + n] = v;
-                }
-            }
-        }
-}
-
-// deterministic sum of `nparts` slabs of n floats (split-K partials), optional accumulate of a second term
-__global__ void sum_slabs_kernel(const float* __restrict__ part, int nparts, long n, float* __restrict__ out) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    float s = 0.0f;
-    for (int g = 0; g < nparts; ++g) s += part[(long)g * n + i];
-    out[i] = s;
-}
-
-// column sums of a (rows, n) matrix with a row map, two stages so that long row counts use the whole chip:
-// block (x = 64 columns, y = row chunk) writes part[y][col] in fp32 from an fp64 running sum; sum_slabs_kernel folds
-// the chunks in a fixed order (deterministic).
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, RowMap rm, int rows, int n,
-                                                     int rows_per_chunk, float* __restrict__ part) {
-    __shared__ double red[4][64];
-    const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
-    const int col = blockIdx.x * 64 + lane;
-    const int r0 = blockIdx.y * rows_per_chunk;
-    const int r1 = min(rows, r0 + rows_per_chunk);
-    double s = 0.0;
-    if (col < n)
-        for (int r = r0 + rg; r < r1; r += 4) s += (double)x[rmap(rm, r) + col];
-    red[rg][lane] = s;
-    __syncthreads();
-    if (rg == 0 && col < n)
-        part[(size_t)blockIdx.y * n + col] = (float)(((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane]);
-}
-
-__global__ void add2_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ o, int n) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) o[i] = a[i] + b[i];
-}
-
-// dz = dy * (y > 0), elementwise (ReLU backward of the head's hidden layer)
-__global__ void relu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, long n, float* __restrict__ dz) {
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
-        dz[i] = y[i] > 0.0f ? dy[i] : 0.0f;
-}
 
 // ---------------------------------------------------------------------------------------------------------
 // W_hh (512,128) -> register fragments.
@@ -380,45 +252,6 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_bwd_kernel(const float* __r
         for (int r = 0; r < 4; ++r) part[kh][(4 * (lane >> 4) + r) * HS + 16 * nt + (lane & 15)] = acc[r];
         __syncthreads();
     }
-}
-
-int gemm(hipStream_t s, bool a_major_k, const float* a, RowMap am, long a_ks, RowMap ak, const float* b, RowMap bk, long b_ns,
-         int M, int N, int K, int splits, const float* bias, int relu, float* c, long c_ms, long c_split_stride) {
-    const int kps = ((K + splits - 1) / splits + GK - 1) / GK * GK;
-    dim3 grid((N + GT - 1) / GT, (M + GT - 1) / GT, (K + kps - 1) / kps);
-    if (a_major_k)
-        hipLaunchKernelGGL(gemm_kernel<true>, grid, dim3(256), 0, s, a, am, a_ks, ak, b, bk, b_ns, M, N, K, kps, bias, relu, c,
-                           c_ms, c_split_stride);
-    else
-        hipLaunchKernelGGL(gemm_kernel<false>, grid, dim3(256), 0, s, a, am, a_ks, ak, b, bk, b_ns, M, N, K, kps, bias, relu,
-                           c, c_ms, c_split_stride);
-    return (int)grid.z;
-}
-
-constexpr int BIG = 1 << 30;
-inline RowMap lin(long stride) { return RowMap{BIG, 0, stride}; }
-
-// dW (N_out, K_in) = dOut^T (N_out x rows) . In (rows x K_in), rows given by row maps; split-K + deterministic sum
-void wgrad_gemm(hipStream_t s, const float* dout, RowMap dm, int n_out, const float* in, RowMap im, int k_in, int rows,
-                float* scratch, float* dw) {
-    int splits = rows / 512;
-    splits = splits < 1 ? 1 : (splits > 64 ? 64 : splits);
-    // A(m = out col, k = row) = dout[dm(k) + m]  -> unit stride is m
-    const int z = gemm(s, false, dout, lin(1), 0, dm, in, im, 1, n_out, k_in, rows, splits, nullptr, 0, scratch, k_in,
-                       (long)n_out * k_in);
-    const long n = (long)n_out * k_in;
-    hipLaunchKernelGGL(sum_slabs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float*)scratch, z, n, dw);
-}
-
-// out0 (and out1) = column sums of x over `rows` mapped rows; scratch holds <= 64 * n floats
-void colsum(hipStream_t s, const float* x, RowMap rm, int rows, int n, float* scratch, float* out0, float* out1) {
-    int chunks = rows / 256;
-    chunks = chunks < 1 ? 1 : (chunks > 64 ? 64 : chunks);
-    const int rpc = (rows + chunks - 1) / chunks;
-    hipLaunchKernelGGL(colsum_kernel, dim3((n + 63) / 64, chunks), dim3(256), 0, s, x, rm, rows, n, rpc, scratch);
-    hipLaunchKernelGGL(sum_slabs_kernel, dim3((n + 255) / 256), dim3(256), 0, s, (const float*)scratch, chunks, (long)n, out0);
-    if (out1 != nullptr)
-        hipLaunchKernelGGL(sum_slabs_kernel, dim3((n + 255) / 256), dim3(256), 0, s, (const float*)scratch, chunks, (long)n, out1);
 }
 
 }  // namespace
