@@ -48,6 +48,12 @@ class HowlLstmSaved(ctypes.Structure):
     _fields_ = [("gx", P), ("gates", P), ("c", P), ("hseq", P), ("dgates", P), ("t_out", c_int)]
 
 
+class HowlMbLayer(ctypes.Structure):
+    _fields_ = [(n, c_int) for n in ("kind", "cin", "cout", "stride", "pad_h", "pad_w", "act", "bias", "pool", "res_src",
+                                     "feat", "sub", "wrapped")] + \
+               [(n, ctypes.c_longlong) for n in ("w_off", "b_off", "gamma_off", "beta_off", "rmean_off", "rvar_off")]
+
+
 SIGNATURES = {
     "howl_version": [POINTER(c_int), POINTER(c_int)],
     "howl_profile_enable": [c_int],
@@ -74,10 +80,16 @@ SIGNATURES = {
     "howl_linear_bwd": [P, c_int, c_long, c_long, c_int, c_int, P, c_int, P, P, P, P, P, c_size_t, STREAM],
     "howl_relu_bwd": [P, P, c_size_t, P, STREAM],
     "howl_adamw_step": [P, P, P, P, c_size_t, c_float, c_float, c_float, c_float, c_float, c_int, c_float, STREAM],
+    "howl_mobilenet_layer": [c_int, POINTER(HowlMbLayer)],
+    "howl_mobilenet_fwd": [P, P, c_int, P, c_long, c_long, c_long, c_int, c_int, c_int, c_int, P, c_float, P, P, c_size_t,
+                           STREAM],
+    "howl_mobilenet_bwd": [P, c_int, P, c_long, c_long, c_long, c_int, c_int, c_int, P, c_float, P, P, P, c_size_t, STREAM],
 }
 # entry points that do not return an int status
 SIZE_FUNCS = {"howl_res8_workspace_bytes": [c_int, c_int], "howl_lstm_workspace_bytes": [c_int, c_int],
-              "howl_linear_workspace_bytes": [c_int, c_int]}
+              "howl_linear_workspace_bytes": [c_int, c_int], "howl_mobilenet_num_layers": [],
+              "howl_mobilenet_param_floats": [c_int], "howl_mobilenet_buffer_floats": [],
+              "howl_mobilenet_workspace_bytes": [c_int, c_int, c_int, c_int]}
 
 
 class HowlHipError(RuntimeError):

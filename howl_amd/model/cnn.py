@@ -17,7 +17,7 @@ from howl_amd.settings import _EnvSettings
 
 from .base import RegisteredModel
 
-__all__ = ["Res8", "Res8Settings"]
+__all__ = ["Res8", "Res8Settings", "MobileNetClassifier"]
 
 
 class Res8Settings(_EnvSettings):
@@ -170,4 +170,256 @@ class Res8(RegisteredModel, name="res8"):
         """x: (B, C>=1, M, T); channel 0 (log-mels) is used, ``lengths`` is ignored (``cnn.py:127-128``)."""
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.hot_parameters()):
             return _Res8Function.apply(self, x, *self.hot_parameters())
+        return self._launch_forward(x)
+
+
+# =============================================================================================================
+# MobileNetClassifier ("mobilenet", howl/model/cnn.py:15-29; BASELINE configs[4])
+# =============================================================================================================
+class _InvertedResidualParams(nn.Module):
+    """Parameter container with torchvision's ``InvertedResidual`` key layout (``.conv.{j}...``)."""
+
+    def __init__(self, inp, oup, stride, t):
+        super().__init__()
+        hidden = inp * t
+        layers = []
+        if t != 1:
+            layers.append(nn.Sequential(nn.Conv2d(inp, hidden, 1, bias=False), nn.BatchNorm2d(hidden), nn.ReLU6()))
+        layers.append(nn.Sequential(nn.Conv2d(hidden, hidden, 3, stride, 1, groups=hidden, bias=False), nn.BatchNorm2d(hidden),
+                                    nn.ReLU6()))
+        layers += [nn.Conv2d(hidden, oup, 1, bias=False), nn.BatchNorm2d(oup)]
+        self.conv = nn.Sequential(*layers)
+
+
+class _MobileNetV2Params(nn.Module):
+    """torchvision ``MobileNetV2`` (width 1.0) as a parameter container: same module tree, hence the same ``state_dict``
+    keys and shapes, and torchvision's initialisation (kaiming-normal fan-out convolutions, unit BatchNorm,
+    N(0, 0.01) classifier).  The reference starts from ImageNet weights (``mobilenet_v2(pretrained=True)``, cnn.py:22),
+    which need the network; load them with ``load_state_dict`` where available."""
+    SETTING = [[1, 16, 1, 1], [6, 24, 2, 2], [6, 32, 3, 2], [6, 64, 4, 2], [6, 96, 3, 1], [6, 160, 3, 2], [6, 320, 1, 1]]
+
+    def __init__(self, num_classes):
+        super().__init__()
+        feats = [nn.Sequential(nn.Conv2d(3, 32, 3, 2, 1, bias=False), nn.BatchNorm2d(32), nn.ReLU6())]
+        inp = 32
+        for t, c, n, s in self.SETTING:
+            for i in range(n):
+                feats.append(_InvertedResidualParams(inp, c, s if i == 0 else 1, t))
+                inp = c
+        feats.append(nn.Sequential(nn.Conv2d(inp, 1280, 1, bias=False), nn.BatchNorm2d(1280), nn.ReLU6()))
+        self.features = nn.Sequential(*feats)
+        self.classifier = nn.Sequential(nn.Dropout(0.2), nn.Linear(1280, num_classes))
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out")
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.ones_(m.weight)
+                nn.init.zeros_(m.bias)
+            elif isinstance(m, nn.Linear):
+                nn.init.normal_(m.weight, 0, 0.01)
+                nn.init.zeros_(m.bias)
+
+
+class _MobileNetFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, module, feat, *params):
+        logits = module._launch_forward(feat)
+        ctx.module, ctx.feat, ctx.version = module, feat, module._fwd_version
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        module = ctx.module
+        if ctx.version != module._fwd_version:
+            raise RuntimeError("MobileNetClassifier: backward called after a newer forward overwrote the saved activations")
+        grads = module._launch_backward(ctx.feat, dlogits.contiguous())
+        return (None, None) + tuple(grads)
+
+
+class MobileNetClassifier(RegisteredModel, name="mobilenet"):
+    """``MobileNetClassifier`` of ``cnn.py:15-29`` on the kernels of ``howl_amd/csrc/mobilenet.hip``.  The submodules are
+    parameter containers (reference / torchvision ``state_dict`` keys); all parameters are views into one flat buffer whose
+    layout the library defines (``howl_mobilenet_layer``), forward and backward are single C-ABI calls."""
+
+    def __init__(self, num_labels: int):
+        super().__init__(num_labels)
+        self.downsample = nn.Sequential(nn.Conv2d(1, 3, 3, padding=(1, 3)), nn.BatchNorm2d(3), nn.ReLU(),
+                                        nn.MaxPool2d((1, 2)))
+        self.model = _MobileNetV2Params(num_labels)
+        self.dropout_p = 0.2
+        self.forced_keep_mask = None     # tests: (B, 1280) 0/1 mask used instead of a fresh draw
+        self._table = None
+        self._flat = self._bflat = None
+        self._ws_cache = {}
+        self._fwd_version = 0
+        self._last_mask = None
+
+    # ---- layer table / parameter plumbing ----------------------------------------------------------------------
+    def _layer_modules(self):
+        """[(conv, bn, HowlMbLayer)] in the library's layer order, resolved from its state-dict key scheme."""
+        if self._table is None:
+            lb = _lib.get()
+            table = []
+            for i in range(lb.cdll.howl_mobilenet_num_layers()):
+                d = _lib.HowlMbLayer()
+                lb.call("howl_mobilenet_layer", i, ctypes.byref(d))
+                if d.feat < 0:
+                    conv, bn = self.downsample[0], self.downsample[1]
+                elif d.sub < 0:
+                    conv, bn = self.model.features[d.feat][0], self.model.features[d.feat][1]
+                elif d.wrapped:
+                    conv, bn = self.model.features[d.feat].conv[d.sub][0], self.model.features[d.feat].conv[d.sub][1]
+                else:
+                    conv, bn = self.model.features[d.feat].conv[d.sub], self.model.features[d.feat].conv[d.sub + 1]
+                table.append((conv, bn, d))
+            self._table = table
+        return self._table
+
+    def hot_parameters(self):
+        """Parameters in the flat layout's order."""
+        ps = []
+        for conv, bn, d in self._layer_modules():
+            ps.append(conv.weight)
+            if d.bias:
+                ps.append(conv.bias)
+            ps += [bn.weight, bn.bias]
+        lin = self.model.classifier[1]
+        return ps + [lin.weight, lin.bias]
+
+    def _stat_buffers(self):
+        out = []
+        for _, bn, _ in self._layer_modules():
+            out += [bn.running_mean, bn.running_var]
+        return out
+
+    @staticmethod
+    def _is_flat(tensors, flat):
+        if flat is None or not tensors[0].is_cuda or tensors[0].device != flat.device:
+            return False
+        off = 0
+        for t in tensors:
+            if t.data_ptr() != flat.data_ptr() + 4 * off or not t.is_contiguous():
+                return False
+            off += t.numel()
+        return off == flat.numel()
+
+    def _ensure_flat(self):
+        """Re-home parameters / BN statistics into flat buffers if they are not already laid out that way (first call,
+        after ``.to(device)``, after ``load_state_dict`` with ``assign``, or when a trainer re-homed them itself)."""
+        ps = self.hot_parameters()
+        for p in ps:
+            if not (p.is_cuda and p.dtype == torch.float32):
+                raise _lib.HowlHipError("MobileNetClassifier parameters must be fp32 tensors on a HIP device "
+                                        "(call .to('cuda') first; there is no CPU fallback)")
+        if not self._is_flat(ps, self._flat):
+            # another owner (training.fused.FlatParams) may already hold them contiguously in the right order
+            base = ps[0]
+            n = sum(p.numel() for p in ps)
+            probe = None
+            if base.is_contiguous() and base.untyped_storage().nbytes() >= 4 * (base.storage_offset() + n):
+                probe = torch.as_strided(base.detach(), (n,), (1,), base.storage_offset())
+            if probe is not None and self._is_flat(ps, probe):
+                self._flat = probe
+            else:
+                flat = torch.empty(n, dtype=torch.float32, device=base.device)
+                off = 0
+                with torch.no_grad():
+                    for p in ps:
+                        flat[off:off + p.numel()].copy_(p.data.reshape(-1))
+                        p.data = flat[off:off + p.numel()].view(p.shape)
+                        off += p.numel()
+                self._flat = flat
+        bs = self._stat_buffers()
+        if not self._is_flat(bs, self._bflat):
+            n = sum(b.numel() for b in bs)
+            bflat = torch.empty(n, dtype=torch.float32, device=bs[0].device)
+            off = 0
+            with torch.no_grad():
+                for _, bn, _ in self._layer_modules():
+                    for name in ("running_mean", "running_var"):
+                        b = getattr(bn, name)
+                        bflat[off:off + b.numel()].copy_(b.reshape(-1))
+                        setattr(bn, name, bflat[off:off + b.numel()].view(b.shape))
+                        off += b.numel()
+            self._bflat = bflat
+        lb = _lib.get()
+        assert self._flat.numel() == lb.cdll.howl_mobilenet_param_floats(self.num_labels)
+        assert self._bflat.numel() == lb.cdll.howl_mobilenet_buffer_floats()
+
+    def _workspace(self, B, M, T, device):
+        key = (B, M, T, str(device))
+        ws = self._ws_cache.pop(key, None)
+        if ws is None:
+            if len(self._ws_cache) >= 3:
+                self._ws_cache.pop(next(iter(self._ws_cache)))
+            nbytes = _lib.get().cdll.howl_mobilenet_workspace_bytes(B, M, T, self.num_labels)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        self._ws_cache[key] = ws
+        return ws
+
+    @staticmethod
+    def _feat_view(x):
+        x0 = x[:, 0]
+        if not x0.is_cuda or x0.dtype != torch.float32:
+            raise _lib.HowlHipError("MobileNetClassifier input must be an fp32 tensor on a HIP device (no CPU fallback)")
+        return x0, x0.stride(0), x0.stride(1), x0.stride(2)   # (B, M, T): sb, sm, st
+
+    def _mask_args(self):
+        m = self._last_mask
+        if m is None:
+            return None, 1.0
+        return ctypes.c_void_p(m.data_ptr()), 1.0 / (1.0 - self.dropout_p)
+
+    # ---- launches ----------------------------------------------------------------------------------------------
+    def _launch_forward(self, feat):
+        self._ensure_flat()
+        x0, sb, sm, st = self._feat_view(feat)
+        B, M, T = x0.shape
+        ws = self._workspace(B, M, T, x0.device)
+        logits = torch.empty((B, self.num_labels), dtype=torch.float32, device=x0.device)
+        self._last_mask = None
+        if self.training:
+            if self.forced_keep_mask is not None:
+                self._last_mask = self.forced_keep_mask.to(device=x0.device, dtype=torch.float32).contiguous()
+            elif self.dropout_p > 0:
+                self._last_mask = (torch.rand((B, 1280), device=x0.device) >= self.dropout_p).to(torch.float32)
+            torch._foreach_add_([bn.num_batches_tracked for _, bn, _ in self._layer_modules()], 1)
+        mask, scale = self._mask_args()
+        self._fwd_version += 1
+        _lib.get().call("howl_mobilenet_fwd", ctypes.c_void_p(self._flat.data_ptr()), ctypes.c_void_p(self._bflat.data_ptr()),
+                        self.num_labels, ctypes.c_void_p(x0.data_ptr()), sb, sm, st, B, M, T, int(self.training), mask, scale,
+                        ctypes.c_void_p(logits.data_ptr()), ctypes.c_void_p(ws.data_ptr()), ws.numel(), ops._stream())
+        return logits
+
+    def _launch_backward(self, feat, dlogits, out_grads=None):
+        if not self.training:
+            raise NotImplementedError("MobileNetClassifier backward is implemented for training-mode BatchNorm")
+        x0, sb, sm, st = self._feat_view(feat)
+        B, M, T = x0.shape
+        ws = self._workspace(B, M, T, x0.device)
+        ps = self.hot_parameters()
+        if out_grads is not None:
+            g0, n = out_grads[0], self._flat.numel()
+            if g0.untyped_storage().nbytes() < 4 * (g0.storage_offset() + n):
+                raise _lib.HowlHipError("out_grads must be views of one flat buffer in hot_parameters() order")
+            gflat = torch.as_strided(g0, (n,), (1,), g0.storage_offset())
+            if not self._is_flat(list(out_grads), gflat):
+                raise _lib.HowlHipError("out_grads must be views of one flat buffer in hot_parameters() order")
+            grads = out_grads
+        else:
+            gflat = torch.empty_like(self._flat)
+            grads, off = [], 0
+            for p in ps:
+                grads.append(gflat[off:off + p.numel()].view(p.shape))
+                off += p.numel()
+        mask, scale = self._mask_args()
+        _lib.get().call("howl_mobilenet_bwd", ctypes.c_void_p(self._flat.data_ptr()), self.num_labels,
+                        ctypes.c_void_p(x0.data_ptr()), sb, sm, st, B, M, T, mask, scale, ctypes.c_void_p(dlogits.data_ptr()),
+                        ctypes.c_void_p(gflat.data_ptr()), ctypes.c_void_p(ws.data_ptr()), ws.numel(), ops._stream())
+        return grads
+
+    def forward(self, x, lengths=None):
+        """x: (B, C>=1, M, T); only channel 0 (log-Mels) is used (``cnn.py:27``), ``lengths`` is ignored."""
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.hot_parameters()):
+            return _MobileNetFunction.apply(self, x, *self.hot_parameters())
         return self._launch_forward(x)

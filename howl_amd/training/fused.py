@@ -1,4 +1,4 @@
-"""Fused res8 training step: frontend -> forward -> cross-entropy -> backward -> (RCCL all-reduce) -> AdamW.
+"""Fused training step (res8, mobilenet): frontend -> forward -> cross-entropy -> backward -> (RCCL all-reduce) -> AdamW.
 
 This is the loop body of ``training/run/pretrain_gsc.py:124-133`` / ``training/run/train.py:286-302`` with every
 stage a C-ABI call on the current HIP stream, gradients written straight into one flat fp32 buffer (the unit of the
@@ -34,7 +34,10 @@ class FlatParams:
             p.grad = g
 
 
-class FusedRes8Trainer:
+class FusedTrainer:
+    """Works with any model that exposes ``hot_parameters()`` (flat-buffer order), ``_launch_forward(feat)`` and
+    ``_launch_backward(feat, dlogits, out_grads=views)``: ``Res8`` and ``MobileNetClassifier``."""
+
     def __init__(self, model, std_transform, zmuv_transform, lr, weight_decay=0.0, betas=(0.9, 0.999), eps=1e-8,
                  process_group=None):
         self.model, self.std, self.zmuv = model, std_transform, zmuv_transform
@@ -71,3 +74,6 @@ class FusedRes8Trainer:
 
     def decay_lr(self, factor):
         self.lr *= factor
+
+
+FusedRes8Trainer = FusedTrainer

@@ -196,6 +196,44 @@ int howl_linear_bwd(const float* x, int rows_inner, long s_outer, long s_inner, 
 /* dz = dy * (y > 0). */
 int howl_relu_bwd(const float* dy, const float* y, size_t n, float* dz, hipStream_t stream);
 
+/* ---------------------------------------------------------------------------------------------------------
+ * MobileNetClassifier, registry name "mobilenet" (replaces howl/model/cnn.py:15-29: downsample conv/BN/ReLU/pool +
+ * torchvision mobilenet_v2 + Linear(1280, num_labels); BASELINE configs[4]).
+ * The layer table is owned by the library: layer 0 is `downsample`, layer 1 `features[0]`, then the 17 inverted
+ * residual blocks, last `features[18]`.  Parameters live in ONE flat float buffer (per layer: conv weight in PyTorch's
+ * own shape, [conv bias], BN weight, BN bias; then classifier weight (num_labels,1280) and bias) and the BatchNorm
+ * running statistics in a second one (per layer: running_mean, running_var); gradients use the parameter layout.
+ * State-dict key of layer i: feat < 0: "downsample.0" / "downsample.1"; sub < 0: "model.features.{feat}.0" / ".1";
+ * wrapped: "model.features.{feat}.conv.{sub}.0" / ".{sub}.1"; else "model.features.{feat}.conv.{sub}" / ".conv.{sub+1}".
+ * ------------------------------------------------------------------------------------------------------- */
+typedef struct {
+    int kind;    /* 0 dense 3x3, 1 pointwise 1x1, 2 depthwise 3x3 */
+    int cin, cout, stride, pad_h, pad_w;
+    int act;     /* 0 none, 1 ReLU6, 2 ReLU */
+    int bias;    /* convolution has a bias (downsample only) */
+    int pool;    /* MaxPool2d((1,2)) after the activation (downsample only) */
+    int res_src; /* >= 0: output adds the output of that layer (inverted-residual skip) */
+    int feat, sub, wrapped;
+    long long w_off, b_off, gamma_off, beta_off; /* float offsets in the parameter buffer (b_off = -1: none) */
+    long long rmean_off, rvar_off;               /* float offsets in the BN buffer */
+} HowlMbLayer;
+size_t howl_mobilenet_num_layers(void);
+int howl_mobilenet_layer(int i, HowlMbLayer* out);
+size_t howl_mobilenet_param_floats(int num_labels);
+size_t howl_mobilenet_buffer_floats(void);
+size_t howl_mobilenet_workspace_bytes(int B, int M, int T, int num_labels);
+/* x: element (b, mel, t) at x[b*sb + mel*sm + t*st] (the log-Mel channel of the (B,3,M,T) features).  training != 0:
+ * batch statistics (running buffers updated, momentum 0.1) and, if drop_mask (B,1280 of 0/1) is given, dropout with
+ * kept activations scaled by drop_scale = 1/(1-p).  The workspace keeps what howl_mobilenet_bwd needs: pass the SAME
+ * workspace, inputs and mask to it.  logits: (B, num_labels). */
+int howl_mobilenet_fwd(const float* params, float* buffers, int num_labels, const float* x, long sb, long sm, long st, int B,
+                       int M, int T, int training, const float* drop_mask, float drop_scale, float* logits, void* ws,
+                       size_t ws_bytes, hipStream_t stream);
+/* dlogits (B, num_labels) -> grads (parameter layout, every entry written). */
+int howl_mobilenet_bwd(const float* params, int num_labels, const float* x, long sb, long sm, long st, int B, int M, int T,
+                       const float* drop_mask, float drop_scale, const float* dlogits, float* grads, void* ws, size_t ws_bytes,
+                       hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

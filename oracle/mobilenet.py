@@ -57,14 +57,6 @@ def layer_table() -> List[dict]:
     return layers
 
 
-def _closed_form(shape, scale, phase, freq=0.37):
-    n = 1
-    for s in shape:
-        n *= s
-    k = torch.arange(n, dtype=torch.float64)
-    return (scale * torch.sin(freq * k + phase)).to(torch.float32).reshape(shape)
-
-
 def conv_shape(l):
     if l["kind"] == "dense":
         return (l["cout"], l["cin"], 3, 3)
@@ -73,22 +65,26 @@ def conv_shape(l):
     return (l["cout"], l["cin"], 1, 1)
 
 
-def mobilenet_init(num_labels: int) -> Dict[str, torch.Tensor]:
-    """Closed-form (RNG-free) parameters with kaiming-like magnitudes, non-trivial BN affine terms, fresh BN buffers."""
+def mobilenet_init(num_labels: int, seed: int = 1234) -> Dict[str, torch.Tensor]:
+    """Seeded parameters with torchvision's initial distributions (kaiming-normal fan-out convolutions, N(0, 0.01)
+    classifier) but non-trivial BatchNorm affine terms and conv bias, so that every gradient path is exercised; fresh BN
+    buffers.  (Closed-form sinusoid weights as used for res8 are rank-2 as matrices: the 1x1 convolutions would feed
+    BatchNorm degenerate channels.)"""
+    gen = torch.Generator().manual_seed(seed)
     sd = {}
-    for i, l in enumerate(layer_table()):
+    for l in layer_table():
         shape = conv_shape(l)
-        fan_in = shape[1] * shape[2] * shape[3]
-        sd[l["key"] + ".weight"] = _closed_form(shape, math.sqrt(2.0 / fan_in) * 1.4, phase=0.1 + 0.7 * i)
+        fan_out = shape[0] * shape[2] * shape[3] // (l["cin"] if l["kind"] == "dw" else 1)
+        sd[l["key"] + ".weight"] = torch.randn(shape, generator=gen) * math.sqrt(2.0 / fan_out)
         if l["bias"]:
-            sd[l["key"] + ".bias"] = _closed_form((l["cout"],), 0.1, phase=0.4)
-        sd[l["bn"] + ".weight"] = 1.0 + _closed_form((l["cout"],), 0.2, phase=1.1 + i)
-        sd[l["bn"] + ".bias"] = _closed_form((l["cout"],), 0.1, phase=2.3 + i)
+            sd[l["key"] + ".bias"] = torch.randn(l["cout"], generator=gen) * 0.1
+        sd[l["bn"] + ".weight"] = 1.0 + 0.2 * torch.randn(l["cout"], generator=gen)
+        sd[l["bn"] + ".bias"] = 0.1 * torch.randn(l["cout"], generator=gen)
         sd[l["bn"] + ".running_mean"] = torch.zeros(l["cout"])
         sd[l["bn"] + ".running_var"] = torch.ones(l["cout"])
         sd[l["bn"] + ".num_batches_tracked"] = torch.tensor(0, dtype=torch.long)
-    sd["model.classifier.1.weight"] = _closed_form((num_labels, LAST_CHANNEL), 0.05, phase=2.5)
-    sd["model.classifier.1.bias"] = _closed_form((num_labels,), 0.1, phase=0.7)
+    sd["model.classifier.1.weight"] = torch.randn((num_labels, LAST_CHANNEL), generator=gen) * 0.05
+    sd["model.classifier.1.bias"] = torch.randn(num_labels, generator=gen) * 0.1
     return sd
 
 

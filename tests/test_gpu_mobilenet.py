@@ -1,0 +1,115 @@
+"""-m gpu parity of MobileNetClassifier ("mobilenet", BASELINE configs[4]) against the oracle restatement
+(oracle/mobilenet.py -- parity unpinned against torchvision, see its header), through the Python drop-in boundary."""
+import pytest
+import torch
+
+from gpu_util import DEV, maxerr
+from mb_util import check_grads, oracle_step
+from oracle import frontend as ofe
+from oracle import mobilenet as omb
+from oracle import models as om
+
+pytestmark = pytest.mark.gpu
+
+
+def make_mobilenet(C, train=True):
+    from howl_amd.model import RegisteredModel
+    model = RegisteredModel.find_registered_class("mobilenet")(C)
+    sd = omb.mobilenet_init(C)
+    model.load_state_dict({k: v.clone() for k, v in sd.items()})
+    model = model.to(DEV)
+    return (model.train() if train else model.eval()), sd
+
+
+def test_registry_and_state_dict():
+    from howl_amd.model import RegisteredModel
+    assert "mobilenet" in RegisteredModel.registered_names()
+    model, sd = make_mobilenet(12)
+    x = torch.randn(4, 3, 40, 81, device=DEV)
+    model(x, None)                                    # re-homes the parameters into the flat buffer
+    out = model.state_dict()
+    assert set(out) == set(sd)
+    for k in sd:
+        if "running" not in k and "num_batches" not in k:
+            assert torch.equal(out[k].cpu(), sd[k]), k
+    assert out["downsample.1.num_batches_tracked"].item() == 1
+
+
+@pytest.mark.parametrize("B,T,C,dropout", [(8, 81, 12, True), (16, 41, 4, False)])
+def test_autograd_forward_backward_vs_oracle(B, T, C, dropout):
+    torch.manual_seed(B + T)
+    x = torch.randn(B, 3, 40, T) * 1.5
+    labels = torch.arange(B) % C
+    keep = (torch.rand(B, omb.LAST_CHANNEL) >= 0.2).float() if dropout else None
+    model, sd = make_mobilenet(C)
+    model.forced_keep_mask = keep
+    model.dropout_p = 0.2 if dropout else 0.0
+    logits = model(x.to(DEV), None)
+    loss = torch.nn.functional.cross_entropy(logits, labels.to(DEV))
+    loss.backward()
+
+    ref, ref_grads, osd = oracle_step(sd, x, labels, keep)
+    assert maxerr(logits, ref) < 1e-3
+    assert torch.equal(logits.argmax(1).cpu(), ref.argmax(1))
+    check_grads([p.grad for p in model.hot_parameters()], sd, x, labels, keep, ref_grads)
+    got = model.state_dict()
+    for l in omb.layer_table():
+        assert maxerr(got[l["bn"] + ".running_var"], osd[l["bn"] + ".running_var"].detach()) < 1e-4
+
+    # eval mode on the updated running statistics
+    model.eval()
+    with torch.no_grad():
+        elog = model(x.to(DEV), None)
+    esd = {k: v.detach().cpu().clone() for k, v in got.items()}
+    eref = omb.mobilenet_forward(esd, x, False)
+    assert maxerr(elog, eref) < 2e-4
+    assert torch.equal(elog.argmax(1).cpu(), eref.argmax(1))
+
+
+def test_fused_step_vs_oracle_at_baseline_size():
+    """BASELINE configs[4] geometry per GPU at a reduced batch: PCM in -> updated weights out, two AdamW steps."""
+    from howl_amd.data.transform.operator import ZmuvTransform
+    from howl_amd.data.transform.transform import StandardAudioTransform
+    from howl_amd.training.fused import FusedTrainer
+    from howl_amd.utils.synth import synthetic_pcm
+    B, L, C = 32, 16000, 12
+    pcm = synthetic_pcm(B, L)
+    labels = torch.arange(B) % C
+    std = StandardAudioTransform().to(DEV).eval()
+    zmuv = ZmuvTransform().to(DEV)
+    zmuv.update(std(pcm[:4].to(DEV)))
+    model, sd = make_mobilenet(C)
+    model.dropout_p = 0.0                              # the dropout draw is the only RNG in the step
+    trainer = FusedTrainer(model, std, zmuv, lr=0.001, weight_decay=0.0)   # envs/mobilenet.env
+    fb = ofe.mel_fb(40)
+    z = ofe.Zmuv()
+    z.update(ofe.standard_audio_transform(pcm[:4], fb))
+    x = z(ofe.standard_audio_transform(pcm, fb))
+    names = omb.mobilenet_param_names()
+    opt = om.AdamWState([sd[n] for n in names], 0.001, 0.0)
+    before = {k: v.clone() for k, v in sd.items()}
+    loss = trainer.step(pcm.to(DEV), labels.to(DEV))
+    ref_loss, ref_logits, ref_grads = om.train_step(lambda s, xx: omb.mobilenet_forward(s, xx, True), sd, names, opt, x, labels)
+    assert maxerr(trainer.last_logits, ref_logits) < 1e-3
+    assert torch.equal(trainer.last_logits.argmax(1).cpu(), ref_logits.argmax(1))
+    assert abs(loss.item() - ref_loss.item()) < 1e-4
+    check_grads(trainer.fp.grad_views, before, x, labels, None, [ref_grads[n] for n in names], eps=2e-5)
+    # the first AdamW step moves every weight by ~lr * sign(g): compare where both gradients agree on a solid value (a
+    # gradient that is rounding noise, or that flipped with a ReLU6 mask, moves the weight the other way on one side)
+    moved = agree = 0
+    for n, p, g in zip(names, model.hot_parameters(), trainer.fp.grad_views):
+        ref_g = ref_grads[n]
+        solid = (ref_g.abs() > 1e-3 * ref_g.abs().max()) & ((g.detach().cpu() - ref_g).abs() < 0.1 * ref_g.abs())
+        if solid.any():
+            assert maxerr(p.detach().cpu()[solid], sd[n][solid]) < 1e-4, n   # lr = 1e-3
+        moved += solid.numel()
+        agree += int(solid.sum())
+    assert agree > 0.5 * moved
+    trainer.step(pcm.to(DEV), labels.to(DEV))          # second step: exercised for the determinism check below
+    # determinism
+    model2, _ = make_mobilenet(C)
+    model2.dropout_p = 0.0
+    trainer2 = FusedTrainer(model2, std, zmuv, lr=0.001, weight_decay=0.0)
+    for step in range(2):
+        trainer2.step(pcm.to(DEV), labels.to(DEV))
+    assert torch.equal(trainer2.fp.flat, trainer.fp.flat)

@@ -83,3 +83,32 @@ def lstm_step():
 
 dt = timeit(lstm_step, steps=20)
 print(f"C4 seq-lstm B=512 0.5s CTC: {dt * 1e3:.3f} ms/step {B / dt:.0f} utt/s", flush=True)
+
+# configs[4]: mobilenet GSC-12, 512 x 1 s per GPU (2048 over 4 GPUs), noise-augment collate on device in front of the step
+B, L, C = 512, 16000, 12
+pcm = synthetic_pcm(B, L).to(dev)
+labels = (torch.arange(B) % C).to(dev)
+std = StandardAudioTransform().to(dev).eval()
+zmuv = ZmuvTransform().to(dev)
+zmuv.update(std(pcm[:8]))
+model = RegisteredModel.find_registered_class("mobilenet")(C).to(dev).train()
+tr = FusedRes8Trainer(model, std, zmuv, lr=0.001)   # envs/mobilenet.env: LEARNING_RATE=0.001, WEIGHT_DECAY=0
+from howl_amd.data.collate import DeviceCollate  # noqa: E402
+
+bank_lengths = torch.full((B,), L, dtype=torch.long)
+collate = DeviceCollate(pcm, bank_lengths, labels, max_len=L, seed=0)   # timeshift + white / salt-pepper noise on device
+ids = list(range(B))
+
+
+def mb_step():
+    batch = collate(ids)
+    audio = batch.audio_data
+    if audio.shape[1] != L:   # timeshift crops; the step geometry is fixed at 1 s -> right-pad like batchify
+        audio = torch.nn.functional.pad(audio, (0, L - audio.shape[1]))
+    tr.step(audio, batch.labels)
+
+
+dt = timeit(mb_step, warmup=3, steps=10)
+dt0 = timeit(lambda: tr.step(pcm, labels), warmup=2, steps=10)
+print(f"C5 mobilenet B=512 1s C=12: {dt * 1e3:.3f} ms/step {B / dt:.0f} utt/s with the device collate/augment in the loop "
+      f"({dt0 * 1e3:.3f} ms, {B / dt0:.0f} utt/s without)", flush=True)
