@@ -96,13 +96,25 @@ __global__ __launch_bounds__(256) void gemm_kernel(const float* __restrict__ a, 
         }
 }
 
-// deterministic sum of `nparts` slabs of n floats (split-K partials), optional accumulate of a second term
-__global__ void sum_slabs_kernel(const float* __restrict__ part, int nparts, long n, float* __restrict__ out) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    float s = 0.0f;
-    for (int g = 0; g < nparts; ++g) s += part[(long)g * n + i];
-    out[i] = s;
+// deterministic sum of `nparts` slabs of n floats (split-K partials): a block owns 64 outputs, its 4 waves take the
+// slabs g = wave, wave+4, ... (four loads in flight each) and combine through LDS in a fixed order
+__global__ __launch_bounds__(256) void sum_slabs_kernel(const float* __restrict__ part, int nparts, long n,
+                                                        float* __restrict__ out) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const long i = (long)blockIdx.x * 64 + lane;
+    float s[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (i < n) {
+        int g = rg;
+        for (; g + 12 < nparts; g += 16) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) s[u] += part[(long)(g + 4 * u) * n + i];
+        }
+        for (; g < nparts; g += 4) s[0] += part[(long)g * n + i];
+    }
+    red[rg][lane] = (s[0] + s[1]) + (s[2] + s[3]);
+    __syncthreads();
+    if (rg == 0 && i < n) out[i] = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
 }
 
 // column sums of a (rows, n) matrix with a row map, two stages so that long row counts use the whole chip:
@@ -153,15 +165,16 @@ constexpr int BIG = 1 << 30;
 inline RowMap lin(long stride) { return RowMap{BIG, 0, stride}; }
 
 // dW (N_out, K_in) = dOut^T (N_out x rows) . In (rows x K_in), rows given by row maps; split-K + deterministic sum
+// (scratch: splits x N_out x K_in floats, splits = clamp(rows / 512, 1, max_splits))
 void wgrad_gemm(hipStream_t s, const float* dout, RowMap dm, int n_out, const float* in, RowMap im, int k_in, int rows,
-                float* scratch, float* dw) {
+                float* scratch, float* dw, int max_splits = 64) {
     int splits = rows / 512;
-    splits = splits < 1 ? 1 : (splits > 64 ? 64 : splits);
+    splits = splits < 1 ? 1 : (splits > max_splits ? max_splits : splits);
     // A(m = out col, k = row) = dout[dm(k) + m]  -> unit stride is m
     const int z = gemm(s, false, dout, lin(1), 0, dm, in, im, 1, n_out, k_in, rows, splits, nullptr, 0, scratch, k_in,
                        (long)n_out * k_in);
     const long n = (long)n_out * k_in;
-    hipLaunchKernelGGL(sum_slabs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float*)scratch, z, n, dw);
+    hipLaunchKernelGGL(sum_slabs_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, s, (const float*)scratch, z, n, dw);
 }
 
 // out0 (and out1) = column sums of x over `rows` mapped rows; scratch holds <= 64 * n floats
@@ -170,9 +183,9 @@ void colsum(hipStream_t s, const float* x, RowMap rm, int rows, int n, float* sc
     chunks = chunks < 1 ? 1 : (chunks > 64 ? 64 : chunks);
     const int rpc = (rows + chunks - 1) / chunks;
     hipLaunchKernelGGL(colsum_kernel, dim3((n + 63) / 64, chunks), dim3(256), 0, s, x, rm, rows, n, rpc, scratch);
-    hipLaunchKernelGGL(sum_slabs_kernel, dim3((n + 255) / 256), dim3(256), 0, s, (const float*)scratch, chunks, (long)n, out0);
+    hipLaunchKernelGGL(sum_slabs_kernel, dim3((n + 63) / 64), dim3(256), 0, s, (const float*)scratch, chunks, (long)n, out0);
     if (out1 != nullptr)
-        hipLaunchKernelGGL(sum_slabs_kernel, dim3((n + 255) / 256), dim3(256), 0, s, (const float*)scratch, chunks, (long)n, out1);
+        hipLaunchKernelGGL(sum_slabs_kernel, dim3((n + 63) / 64), dim3(256), 0, s, (const float*)scratch, chunks, (long)n, out1);
 }
 
 

@@ -32,7 +32,8 @@ enum { MB_ACT_NONE = 0, MB_ACT_RELU6 = 1, MB_ACT_RELU = 2 };
 constexpr int MB_LAST = 1280;
 constexpr float MB_EPS = 1e-5f;
 constexpr double MB_MOMENTUM = 0.1;
-constexpr int MB_CHUNKS = 64;  // row chunks of the two-stage column reductions
+constexpr int MB_CHUNKS = 512;      // upper bound on the row chunks of the two-stage column reductions
+constexpr int MB_WGRAD_SPLITS = 1024;  // split-K bound of the weight-gradient GEMMs (long, thin reductions over pixels)
 
 struct Net {
     std::vector<HowlMbLayer> layers;
@@ -128,7 +129,21 @@ struct Plan {
 
 int wgrad_splits(long rows) {  // must match wgrad_gemm() in howl_gemm.hip.h
     long s = rows / 512;
-    return (int)(s < 1 ? 1 : (s > 64 ? 64 : s));
+    return (int)(s < 1 ? 1 : (s > MB_WGRAD_SPLITS ? MB_WGRAD_SPLITS : s));
+}
+
+// Column reductions: a wave covers 64 / Cp rows at a time when the matrix is narrow (Cp = C rounded up to a power of
+// two <= 32), else 64 columns of one row; the rows are cut into chunks so that the launch fills the chip.
+inline int col_pack(int C) {
+    if (C > 32) return 64;
+    int cp = 1;
+    while (cp < C) cp <<= 1;
+    return cp;
+}
+inline int chunks_for(long rows, int C) {
+    const long rows_per_wave_iter = 64 / col_pack(C);
+    long c = rows / (64 * rows_per_wave_iter);   // >= 16 row-iterations per wave
+    return (int)(c < 1 ? 1 : (c > MB_CHUNKS ? MB_CHUNKS : c));
 }
 
 Plan make_plan(int B, int H0, int W0, int num_labels) {
@@ -141,7 +156,7 @@ Plan make_plan(int B, int H0, int W0, int num_labels) {
         return o;
     };
     int h = H0, w = W0;
-    size_t max_dz = 0, max_col = 0, max_scr = (size_t)64 * num_labels * MB_LAST;
+    size_t max_dz = 0, max_col = 0, max_scr = (size_t)64 * num_labels * MB_LAST, max_part = 0;
     for (const HowlMbLayer& l : n.layers) {
         Geo g{};
         g.hin = h;
@@ -167,7 +182,8 @@ Plan make_plan(int B, int H0, int W0, int num_labels) {
         if (l.kind == MB_DENSE3) max_col = std::max(max_col, (size_t)g.mz * 9 * l.cin);
         const size_t wn = (l.kind == MB_DENSE3) ? (size_t)l.cout * l.cin * 9 : (size_t)l.cout * l.cin;
         if (l.kind != MB_DW) max_scr = std::max(max_scr, (size_t)wgrad_splits(g.mz) * wn);
-        if (l.kind == MB_DW) max_scr = std::max(max_scr, (size_t)MB_CHUNKS * l.cout * 9);
+        if (l.kind == MB_DW) max_scr = std::max(max_scr, (size_t)chunks_for(g.mz, 64) * l.cout * 9);
+        max_part = std::max(max_part, (size_t)chunks_for(g.mz, l.cout) * 2 * l.cout * 2);
         h = g.hy;
         w = g.wy;
     }
@@ -175,7 +191,7 @@ Plan make_plan(int B, int H0, int W0, int num_labels) {
     p.dyp = take(max_dz);
     p.col = take(max_col);
     p.dcol = take(max_col);
-    p.part = take((size_t)MB_CHUNKS * 2 * MB_LAST * 2);  // doubles
+    p.part = take(max_part);  // doubles
     p.gemm_scratch = take(max_scr);
     p.m12 = take(2 * MB_LAST);
     p.pooled = take((size_t)B * MB_LAST);
@@ -347,18 +363,23 @@ __device__ __forceinline__ bool mb_act_passes(float v, int act) {  // derivative
 
 // Two-stage per-channel reductions over the rows of an (M x C) matrix.  MODE 0: (sum z, sum z^2).
 // MODE 1 (BatchNorm backward): g = dy * act'(gamma*xhat + beta), xhat = (z - mean) * rstd -> (sum g, sum g*xhat).
+// Lane -> (row slot rs = lane / cp, column blockIdx.x*64 + lane % cp): cp = 64 for wide matrices, a power of two <= 32
+// for narrow ones so that no lane idles on the 3..32-channel layers that have the most rows.  Rows advance by
+// 4 waves x (64/cp) slots; four independent accumulator pairs keep four loads in flight.
 template <int MODE>
 __global__ __launch_bounds__(256) void col_reduce_kernel(const float* __restrict__ z, const float* __restrict__ dy,
                                                          const float* __restrict__ stats, const float* __restrict__ gamma,
-                                                         const float* __restrict__ beta, int act, long rows, int C,
+                                                         const float* __restrict__ beta, int act, long rows, int C, int cp,
                                                          long rows_per_chunk, double* __restrict__ part) {
     __shared__ double red[2][4][64];
     const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + lane;
+    const int rsub = 64 / cp;
+    const int cl = lane & (cp - 1), rs = lane / cp;
+    const int c = blockIdx.x * 64 + cl;
     const long r0 = (long)blockIdx.y * rows_per_chunk;
     const long r1 = rows < r0 + rows_per_chunk ? rows : r0 + rows_per_chunk;
     double s0 = 0.0, s1 = 0.0;
-    if (c < C) {
+    if (c < C && cl < cp) {
         float mean = 0.0f, rstd = 1.0f, ga = 1.0f, be = 0.0f;
         if (MODE == 1) {
             mean = stats[c];
@@ -366,38 +387,95 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const float* __restrict
             ga = gamma[c];
             be = beta[c];
         }
-        for (long m = r0 + rg; m < r1; m += 4) {
-            const float v = z[m * C + c];
-            if (MODE == 0) {
-                s0 += (double)v;
-                s1 += (double)v * (double)v;
-            } else {
-                const float xh = (v - mean) * rstd;
-                const float g = mb_act_passes(fmaf(ga, xh, be), act) ? dy[m * C + c] : 0.0f;
-                s0 += (double)g;
-                s1 += (double)g * (double)xh;
+        const long step = 4L * rsub;
+        float a0[4], a1[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) a0[u] = a1[u] = 0.0f;
+        long m = r0 + (long)rg * rsub + rs;
+        int since_flush = 0;
+        for (; m < r1; m += 4 * step) {
+            float v[4], d[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const long mm = m + u * step;
+                const bool ok = mm < r1;
+                const long idx = (ok ? mm : m) * C + c;
+                v[u] = z[idx];
+                d[u] = MODE == 1 ? dy[idx] : 0.0f;
+                if (!ok) {
+                    v[u] = MODE == 1 ? mean : 0.0f;   // contributes nothing
+                    d[u] = 0.0f;
+                }
             }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (MODE == 0) {
+                    a0[u] += v[u];
+                    a1[u] = fmaf(v[u], v[u], a1[u]);
+                } else {
+                    const float xh = (v[u] - mean) * rstd;
+                    const float g = mb_act_passes(fmaf(ga, xh, be), act) ? d[u] : 0.0f;
+                    a0[u] += g;
+                    a1[u] = fmaf(g, xh, a1[u]);
+                }
+            }
+            if (++since_flush == 16) {   // short fp32 runs, fp64 totals
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    s0 += (double)a0[u];
+                    s1 += (double)a1[u];
+                    a0[u] = a1[u] = 0.0f;
+                }
+                since_flush = 0;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            s0 += (double)a0[u];
+            s1 += (double)a1[u];
         }
     }
     red[0][rg][lane] = s0;
     red[1][rg][lane] = s1;
     __syncthreads();
-    if (rg == 0 && c < C) {
-        part[((size_t)blockIdx.y * 2 + 0) * C + c] = ((red[0][0][lane] + red[0][1][lane]) + red[0][2][lane]) + red[0][3][lane];
-        part[((size_t)blockIdx.y * 2 + 1) * C + c] = ((red[1][0][lane] + red[1][1][lane]) + red[1][2][lane]) + red[1][3][lane];
+    if (rg == 0 && rs == 0 && c < C) {
+        double t0 = 0.0, t1 = 0.0;
+        for (int w = 0; w < 4; ++w)
+            for (int q = 0; q < rsub; ++q) {
+                t0 += red[0][w][q * cp + cl];
+                t1 += red[1][w][q * cp + cl];
+            }
+        part[((size_t)blockIdx.y * 2 + 0) * C + c] = t0;
+        part[((size_t)blockIdx.y * 2 + 1) * C + c] = t1;
     }
 }
 
+// folds the chunk partials of 64 columns: the 4 waves split the chunks, lanes are columns (coalesced), fixed order
+__device__ __forceinline__ void fold_chunks(const double* __restrict__ part, int chunks, int C, int c, int rg, double& s0,
+                                            double& s1, double (&red)[2][4][64], int lane) {
+    double a0 = 0.0, a1 = 0.0;
+    if (c < C)
+        for (int k = rg; k < chunks; k += 4) {
+            a0 += part[((size_t)k * 2 + 0) * C + c];
+            a1 += part[((size_t)k * 2 + 1) * C + c];
+        }
+    red[0][rg][lane] = a0;
+    red[1][rg][lane] = a1;
+    __syncthreads();
+    s0 = ((red[0][0][lane] + red[0][1][lane]) + red[0][2][lane]) + red[0][3][lane];
+    s1 = ((red[1][0][lane] + red[1][1][lane]) + red[1][2][lane]) + red[1][3][lane];
+}
+
 // batch statistics (biased variance for normalisation, unbiased for the running estimate: nn.BatchNorm2d)
-__global__ void bn_stats_finalize_kernel(const double* __restrict__ part, int chunks, int C, double count,
-                                         float* __restrict__ stats, float* __restrict__ rmean, float* __restrict__ rvar) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s0 = 0.0, s1 = 0.0;
-    for (int k = 0; k < chunks; ++k) {
-        s0 += part[((size_t)k * 2 + 0) * C + c];
-        s1 += part[((size_t)k * 2 + 1) * C + c];
-    }
+__global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const double* __restrict__ part, int chunks, int C,
+                                                                double count, float* __restrict__ stats,
+                                                                float* __restrict__ rmean, float* __restrict__ rvar) {
+    __shared__ double red[2][4][64];
+    const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    double s0, s1;
+    fold_chunks(part, chunks, C, c, rg, s0, s1, red, lane);
+    if (rg != 0 || c >= C) return;
     const double mean = s0 / count;
     double var = s1 / count - mean * mean;
     var = var < 0.0 ? 0.0 : var;
@@ -429,19 +507,30 @@ __global__ void bn_act_fwd_kernel(const float* __restrict__ z, const float* __re
 }
 
 // dgamma = sum g*xhat, dbeta = sum g; m1 = dbeta / M, m2 = dgamma / M for the apply pass
-__global__ void bn_bwd_finalize_mb_kernel(const double* __restrict__ part, int chunks, int C, double count,
-                                          float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ m12) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s0 = 0.0, s1 = 0.0;
-    for (int k = 0; k < chunks; ++k) {
-        s0 += part[((size_t)k * 2 + 0) * C + c];
-        s1 += part[((size_t)k * 2 + 1) * C + c];
-    }
+__global__ __launch_bounds__(256) void bn_bwd_finalize_mb_kernel(const double* __restrict__ part, int chunks, int C,
+                                                                 double count, float* __restrict__ dgamma,
+                                                                 float* __restrict__ dbeta, float* __restrict__ m12) {
+    __shared__ double red[2][4][64];
+    const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    double s0, s1;
+    fold_chunks(part, chunks, C, c, rg, s0, s1, red, lane);
+    if (rg != 0 || c >= C) return;
     dbeta[c] = (float)s0;
     dgamma[c] = (float)s1;
     m12[c] = (float)(s0 / count);
     m12[C + c] = (float)(s1 / count);
+}
+
+// column sums only (conv-bias gradient): out[c] = sum over chunks of part[k][0][c]
+__global__ __launch_bounds__(256) void colsum_finalize_kernel(const double* __restrict__ part, int chunks, int C,
+                                                              float* __restrict__ out) {
+    __shared__ double red[2][4][64];
+    const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    double s0, s1;
+    fold_chunks(part, chunks, C, c, rg, s0, s1, red, lane);
+    if (rg == 0 && c < C) out[c] = (float)s0;
 }
 
 // dz = gamma * rstd * (g - m1 - xhat * m2)
@@ -520,11 +609,6 @@ inline unsigned flat_grid(long total) {
     return (unsigned)(blocks < 1 ? 1 : (blocks > 65536 ? 65536 : blocks));
 }
 
-inline int chunks_for(long rows) {
-    long c = rows / 256;
-    return (int)(c < 1 ? 1 : (c > MB_CHUNKS ? MB_CHUNKS : c));
-}
-
 struct Ctx {
     const Net* n;
     Plan p;
@@ -599,12 +683,12 @@ int howl_mobilenet_fwd(const float* params, float* buffers, int num_labels, cons
         float* stats = c.ws + c.p.stats[k];
         conv_forward(c, k, in, isb, ish, isw, isc, z);
         if (training) {
-            const int chunks = chunks_for(g.mz);
+            const int chunks = chunks_for(g.mz, l.cout);
             const long rpc = (g.mz + chunks - 1) / chunks;
             hipLaunchKernelGGL(col_reduce_kernel<0>, dim3((l.cout + 63) / 64, chunks), dim3(256), 0, stream, (const float*)z,
                                (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0,
-                               g.mz, l.cout, rpc, part);
-            hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((l.cout + 255) / 256), dim3(256), 0, stream, (const double*)part,
+                               g.mz, l.cout, col_pack(l.cout), rpc, part);
+            hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((l.cout + 63) / 64), dim3(256), 0, stream, (const double*)part,
                                chunks, l.cout, (double)g.mz, stats, buffers + l.rmean_off, buffers + l.rvar_off);
         } else {
             hipLaunchKernelGGL(bn_eval_stats_mb_kernel, dim3((l.cout + 255) / 256), dim3(256), 0, stream,
@@ -685,11 +769,11 @@ int howl_mobilenet_bwd(const float* params, int num_labels, const float* x, long
             hipMemcpyAsync(dsrc, dy, (size_t)total * sizeof(float), hipMemcpyDeviceToDevice, stream);
             has_grad[l.res_src] = 1;
         }
-        const int chunks = chunks_for(g.mz);
+        const int chunks = chunks_for(g.mz, l.cout);
         const long rpc = (g.mz + chunks - 1) / chunks;
         hipLaunchKernelGGL(col_reduce_kernel<1>, dim3((l.cout + 63) / 64, chunks), dim3(256), 0, stream, z, dy, stats,
-                           params + l.gamma_off, params + l.beta_off, l.act, g.mz, l.cout, rpc, part);
-        hipLaunchKernelGGL(bn_bwd_finalize_mb_kernel, dim3((l.cout + 255) / 256), dim3(256), 0, stream, (const double*)part,
+                           params + l.gamma_off, params + l.beta_off, l.act, g.mz, l.cout, col_pack(l.cout), rpc, part);
+        hipLaunchKernelGGL(bn_bwd_finalize_mb_kernel, dim3((l.cout + 63) / 64), dim3(256), 0, stream, (const double*)part,
                            chunks, l.cout, (double)g.mz, grads + l.gamma_off, grads + l.beta_off, m12);
         float* dz = c.ws + c.p.dz;
         hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(flat_grid(total)), dim3(256), 0, stream, z, dy, stats, params + l.gamma_off,
@@ -707,17 +791,17 @@ int howl_mobilenet_bwd(const float* params, int num_labels, const float* x, long
         }
         const long in_total = (long)B * g.hin * g.win * l.cin;
         if (l.kind == MB_PW) {
-            wgrad_gemm(stream, dz, lin(l.cout), l.cout, in, lin(l.cin), l.cin, (int)g.mz, scratch, gw);
+            wgrad_gemm(stream, dz, lin(l.cout), l.cout, in, lin(l.cin), l.cin, (int)g.mz, scratch, gw, MB_WGRAD_SPLITS);
             if (dx != nullptr)
                 gemm(stream, true, dz, lin(l.cout), 1, lin(0), w, lin(l.cin), 1, (int)g.mz, l.cin, l.cout, 1, nullptr, 0, dx, l.cin,
                      0);
         } else if (l.kind == MB_DW) {
-            const int wch = chunks_for(g.mz);
+            const int wch = chunks_for(g.mz, 64);
             const long wrpc = (g.mz + wch - 1) / wch;
             hipLaunchKernelGGL(dw3x3_wgrad_kernel, dim3((l.cout + 63) / 64, wch), dim3(256), 0, stream, (const float*)dz, in, g.hin,
                                g.win, l.cin, g.ho, g.wo, l.stride, g.mz, wrpc, scratch);
             const long nw = (long)l.cout * 9;
-            hipLaunchKernelGGL(sum_slabs_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, stream, (const float*)scratch,
+            hipLaunchKernelGGL(sum_slabs_kernel, dim3((unsigned)((nw + 63) / 64)), dim3(256), 0, stream, (const float*)scratch,
                                wch, nw, gw);
             if (dx != nullptr)
                 hipLaunchKernelGGL(dw3x3_dgrad_kernel, dim3(flat_grid(in_total)), dim3(256), 0, stream, (const float*)dz, w, g.hin,
@@ -734,8 +818,14 @@ int howl_mobilenet_bwd(const float* params, int num_labels, const float* x, long
             }
             hipLaunchKernelGGL(im2col3x3_kernel, dim3(flat_grid(ctot)), dim3(256), 0, stream, in, isb, ish, isw, isc, g.hin, g.win,
                                l.cin, g.ho, g.wo, l.stride, l.pad_h, l.pad_w, ctot, col);
-            wgrad_gemm(stream, dz, lin(l.cout), l.cout, col, lin(K), K, (int)g.mz, scratch, gw);
-            if (l.bias) colsum(stream, dz, lin(l.cout), (int)g.mz, l.cout, scratch, grads + l.b_off, nullptr);
+            wgrad_gemm(stream, dz, lin(l.cout), l.cout, col, lin(K), K, (int)g.mz, scratch, gw, MB_WGRAD_SPLITS);
+            if (l.bias) {   // sum over pixels of dz (rounding noise in exact arithmetic: a BatchNorm follows the bias)
+                hipLaunchKernelGGL(col_reduce_kernel<0>, dim3((l.cout + 63) / 64, chunks), dim3(256), 0, stream, (const float*)dz,
+                                   (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
+                                   0, g.mz, l.cout, col_pack(l.cout), rpc, part);
+                hipLaunchKernelGGL(colsum_finalize_kernel, dim3((l.cout + 63) / 64), dim3(256), 0, stream, (const double*)part,
+                                   chunks, l.cout, grads + l.b_off);
+            }
             if (dx != nullptr) {
                 float* dcol = c.ws + c.p.dcol;
                 gemm(stream, true, dz, lin(l.cout), 1, lin(0), w, lin(K), 1, (int)g.mz, K, l.cout, 1, nullptr, 0, dcol, K, 0);
