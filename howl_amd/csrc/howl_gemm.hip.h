@@ -2,6 +2,8 @@
 // translation unit gets its own copy in an anonymous namespace): the generic fp32 MFMA GEMM with row maps and
 // split-K, deterministic slab / column sums, and their host-side launch helpers.
 #pragma once
+#include <cstdint>
+
 #include "howl_common.hip.h"
 
 namespace {
@@ -96,6 +98,98 @@ __global__ __launch_bounds__(256) void gemm_kernel(const float* __restrict__ a, 
         }
 }
 
+// Fast path of the same GEMM for plain strided matrices whose unit-stride extents are multiples of 4 floats (every
+// MobileNet 1x1 convolution and weight gradient, the LSTM projections): operands move as 16-byte vectors, one per
+// thread and tile, and the next K tile is requested before the MFMAs of the current one (register double buffering).
+//   A_UNIT_K: A(m,k) = a[m*lda + k]   else a[k*lda + m]
+//   B_UNIT_K: B(k,n) = b[n*ldb + k]   else b[k*ldb + n]
+template <bool A_UNIT_K, bool B_UNIT_K>
+__global__ __launch_bounds__(256) void gemm_vec_kernel(const float* __restrict__ a, long lda, const float* __restrict__ b,
+                                                       long ldb, int M, int N, int K, int k_per_split,
+                                                       const float* __restrict__ bias, int relu, float* __restrict__ c,
+                                                       long c_ms, long c_split_stride) {
+    __shared__ float As[GK * GLD];
+    __shared__ float Bs[GK * GLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int m0 = blockIdx.y * GT, n0 = blockIdx.x * GT;
+    const int kbeg = blockIdx.z * k_per_split;
+    const int kend = min(K, kbeg + k_per_split);
+    // this thread's 4-float piece of each operand tile: unit-k -> (row = tid/4, k4 = tid%4); unit-row -> (k = tid/16, r4 = tid%16)
+    const int a_r = A_UNIT_K ? tid >> 2 : (tid & 15) * 4, a_k = A_UNIT_K ? (tid & 3) * 4 : tid >> 4;
+    const int b_r = B_UNIT_K ? tid >> 2 : (tid & 15) * 4, b_k = B_UNIT_K ? (tid & 3) * 4 : tid >> 4;
+    auto fetch_a = [&](int k0) -> float4 {
+        const int m = m0 + a_r, k = k0 + a_k;
+        if (m < M && k < kend) return *reinterpret_cast<const float4*>(A_UNIT_K ? a + (long)m * lda + k : a + (long)k * lda + m);
+        return make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    auto fetch_b = [&](int k0) -> float4 {
+        const int n = n0 + b_r, k = k0 + b_k;
+        if (n < N && k < kend) return *reinterpret_cast<const float4*>(B_UNIT_K ? b + (long)n * ldb + k : b + (long)k * ldb + n);
+        return make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = {0.0f, 0.0f, 0.0f, 0.0f};
+    float4 va = fetch_a(kbeg), vb = fetch_b(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += GK) {
+        if (A_UNIT_K) {
+            As[(a_k + 0) * GLD + a_r] = va.x;
+            As[(a_k + 1) * GLD + a_r] = va.y;
+            As[(a_k + 2) * GLD + a_r] = va.z;
+            As[(a_k + 3) * GLD + a_r] = va.w;
+        } else {
+            *reinterpret_cast<float4*>(&As[a_k * GLD + a_r]) = va;
+        }
+        if (B_UNIT_K) {
+            Bs[(b_k + 0) * GLD + b_r] = vb.x;
+            Bs[(b_k + 1) * GLD + b_r] = vb.y;
+            Bs[(b_k + 2) * GLD + b_r] = vb.z;
+            Bs[(b_k + 3) * GLD + b_r] = vb.w;
+        } else {
+            *reinterpret_cast<float4*>(&Bs[b_k * GLD + b_r]) = vb;
+        }
+        __syncthreads();
+        if (k0 + GK < kend) {
+            va = fetch_a(k0 + GK);
+            vb = fetch_b(k0 + GK);
+        }
+#pragma unroll
+        for (int ks = 0; ks < GK / 4; ++ks) {
+            const int kr = 4 * ks + (lane >> 4);
+            float af[2], bf[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) af[i] = As[kr * GLD + 32 * wr + 16 * i + (lane & 15)];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bf[j] = Bs[kr * GLD + 32 * wc + 16 * j + (lane & 15)];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    float* cz = c + (long)blockIdx.z * c_split_stride;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + 32 * wc + 16 * j + (lane & 15);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + 32 * wr + 16 * i + 4 * (lane >> 4) + r;
+                if (m < M && n < N) {
+                    float v = acc[i][j][r];
+                    if (bias != nullptr) v += bias[n];
+                    if (relu) v = fmaxf(v, 0.0f);
+                    cz[(long)m * c_ms + n] = v;
+                }
+            }
+        }
+}
+
 // deterministic sum of `nparts` slabs of n floats (split-K partials): a block owns 64 outputs, its 4 waves take the
 // slabs g = wave, wave+4, ... (four loads in flight each) and combine through LDS in a fixed order
 __global__ __launch_bounds__(256) void sum_slabs_kernel(const float* __restrict__ part, int nparts, long n,
@@ -148,10 +242,35 @@ __global__ void relu_bwd_kernel(const float* __restrict__ dy, const float* __res
 }
 
 
+constexpr int BIG = 1 << 30;
+inline RowMap lin(long stride) { return RowMap{BIG, 0, stride}; }
+inline bool is_lin(const RowMap& r) { return r.inner == BIG; }
+inline bool vec_ok(const float* p, long ld) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0 && (ld & 3) == 0; }
+
 int gemm(hipStream_t s, bool a_major_k, const float* a, RowMap am, long a_ks, RowMap ak, const float* b, RowMap bk, long b_ns,
          int M, int N, int K, int splits, const float* bias, int relu, float* c, long c_ms, long c_split_stride) {
     const int kps = ((K + splits - 1) / splits + GK - 1) / GK * GK;
     dim3 grid((N + GT - 1) / GT, (M + GT - 1) / GT, (K + kps - 1) / kps);
+    // plain strided operands with 16-byte-aligned unit-stride runs take the vector kernel
+    if (is_lin(am) && is_lin(bk) && (a_major_k ? a_ks == 1 : (is_lin(ak) && am.s_inner == 1))) {
+        const long lda = a_major_k ? am.s_inner : ak.s_inner;
+        const bool b_unit_k = bk.s_inner == 1 && b_ns != 1;
+        const bool b_unit_n = b_ns == 1;
+        const long ldb = b_unit_k ? b_ns : bk.s_inner;
+        const bool a_fits = vec_ok(a, lda) && (a_major_k ? (K & 3) == 0 : (M & 3) == 0);
+        const bool b_fits = (b_unit_k || b_unit_n) && vec_ok(b, ldb) && (b_unit_k ? (K & 3) == 0 : (N & 3) == 0);
+        if (a_fits && b_fits && (b_unit_k ? true : b_unit_n)) {
+#define HOWL_GEMM_VEC(AK, BK)                                                                                            \
+    hipLaunchKernelGGL((gemm_vec_kernel<AK, BK>), grid, dim3(256), 0, s, a, lda, b, ldb, M, N, K, kps, bias, relu, c, c_ms, \
+                       c_split_stride)
+            if (a_major_k && b_unit_k) HOWL_GEMM_VEC(true, true);
+            else if (a_major_k) HOWL_GEMM_VEC(true, false);
+            else if (b_unit_k) HOWL_GEMM_VEC(false, true);
+            else HOWL_GEMM_VEC(false, false);
+#undef HOWL_GEMM_VEC
+            return (int)grid.z;
+        }
+    }
     if (a_major_k)
         hipLaunchKernelGGL(gemm_kernel<true>, grid, dim3(256), 0, s, a, am, a_ks, ak, b, bk, b_ns, M, N, K, kps, bias, relu, c,
                            c_ms, c_split_stride);
@@ -160,9 +279,6 @@ int gemm(hipStream_t s, bool a_major_k, const float* a, RowMap am, long a_ks, Ro
                            c, c_ms, c_split_stride);
     return (int)grid.z;
 }
-
-constexpr int BIG = 1 << 30;
-inline RowMap lin(long stride) { return RowMap{BIG, 0, stride}; }
 
 // dW (N_out, K_in) = dOut^T (N_out x rows) . In (rows x K_in), rows given by row maps; split-K + deterministic sum
 // (scratch: splits x N_out x K_in floats, splits = clamp(rows / 512, 1, max_splits))
