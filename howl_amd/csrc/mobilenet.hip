@@ -453,14 +453,23 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const float* __restrict
 // folds the chunk partials of 64 columns: the 4 waves split the chunks, lanes are columns (coalesced), fixed order
 __device__ __forceinline__ void fold_chunks(const double* __restrict__ part, int chunks, int C, int c, int rg, double& s0,
                                             double& s1, double (&red)[2][4][64], int lane) {
-    double a0 = 0.0, a1 = 0.0;
-    if (c < C)
-        for (int k = rg; k < chunks; k += 4) {
-            a0 += part[((size_t)k * 2 + 0) * C + c];
-            a1 += part[((size_t)k * 2 + 1) * C + c];
+    double a0[4] = {0.0, 0.0, 0.0, 0.0}, a1[4] = {0.0, 0.0, 0.0, 0.0};
+    if (c < C) {
+        int k = rg;
+        for (; k + 12 < chunks; k += 16) {   // four independent loads per sum in flight
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                a0[u] += part[((size_t)(k + 4 * u) * 2 + 0) * C + c];
+                a1[u] += part[((size_t)(k + 4 * u) * 2 + 1) * C + c];
+            }
         }
-    red[0][rg][lane] = a0;
-    red[1][rg][lane] = a1;
+        for (; k < chunks; k += 4) {
+            a0[0] += part[((size_t)k * 2 + 0) * C + c];
+            a1[0] += part[((size_t)k * 2 + 1) * C + c];
+        }
+    }
+    red[0][rg][lane] = (a0[0] + a0[1]) + (a0[2] + a0[3]);
+    red[1][rg][lane] = (a1[0] + a1[1]) + (a1[2] + a1[3]);
     __syncthreads();
     s0 = ((red[0][0][lane] + red[0][1][lane]) + red[0][2][lane]) + red[0][3][lane];
     s1 = ((red[1][0][lane] + red[1][1][lane]) + red[1][2][lane]) + red[1][3][lane];
