@@ -92,7 +92,7 @@ def main(argv=None):
     workspace.write_args(args)
     workspace.save_settings(SETTINGS)
     writer.add_scalar("Meta/Parameters", sum(p.numel() for p in params))
-    fused = args.model == "res8"
+    fused = args.model in ("res8", "mobilenet")
     if fused:
         trainer = FusedRes8Trainer(model, std_transform, zmuv_transform, SETTINGS.training.learning_rate,
                                    weight_decay=SETTINGS.training.weight_decay)

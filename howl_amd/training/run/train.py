@@ -156,7 +156,7 @@ def main(argv=None):
     ws.write_args(args)
     ws.save_settings(SETTINGS)
     params = [p for p in model.parameters() if p.requires_grad]
-    fused = use_frame and args.model == "res8"
+    fused = use_frame and args.model in ("res8", "mobilenet")
     if fused:
         trainer = FusedRes8Trainer(model, std_transform, zmuv_transform, SETTINGS.training.learning_rate,
                                    weight_decay=SETTINGS.training.weight_decay)

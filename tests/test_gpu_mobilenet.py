@@ -113,3 +113,25 @@ def test_fused_step_vs_oracle_at_baseline_size():
     for step in range(2):
         trainer2.step(pcm.to(DEV), labels.to(DEV))
     assert torch.equal(trainer2.fp.flat, trainer.fp.flat)
+
+
+def test_pretrain_gsc_entry_point_mobilenet(tmp_path, monkeypatch):
+    """`python -m training.run.pretrain_gsc --model mobilenet` (envs/mobilenet.env: lr 0.001, weight decay 0) on generated
+    clips: variable batch lengths from the device collate, fused step, eval-mode accuracy pass, checkpoint keys."""
+    for k, v in dict(NUM_EPOCHS="2", BATCH_SIZE="32", MAX_WINDOW_SIZE_SECONDS="1", LEARNING_RATE="0.001", WEIGHT_DECAY="0",
+                     NUM_MELS="40", DEVICE="cuda:0").items():
+        monkeypatch.setenv(k, v)
+    from howl_amd.settings import SETTINGS
+    SETTINGS.reset()
+    from howl_amd.training.run import pretrain_gsc
+    ws = tmp_path / "ws"
+    pretrain_gsc.main(["--model", "mobilenet", "--workspace", str(ws), "--synthetic", "256"])
+    sd = torch.load(ws / "model-best.pt.bin")
+    assert set(sd) == set(omb.mobilenet_init(30))
+    assert sd["model.classifier.1.weight"].shape == (30, 1280)
+    assert sd["downsample.1.num_batches_tracked"].item() > 0
+    import json
+    lines = [json.loads(l) for l in (ws / "logs" / "scalars.jsonl").read_text().splitlines()]
+    losses = [l["value"] for l in lines if l["tag"] == "Training/Loss"]
+    assert len(losses) > 4 and all(v == v for v in losses)
+    SETTINGS.reset()
