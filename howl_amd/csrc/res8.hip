@@ -453,355 +453,6 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_mfma_kernel(
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// Two-piece pipelined variant of the same convolution for the reference's window lengths (H = 27: 1 s, H = 13:
-// 0.5 s; everything compile-time in H).  The K loop of conv3x3_mfma_kernel already runs at the MFMA peak rate; what
-// keeps that kernel at ~0.55 of the roofline is the staging phase between its two barriers, in which the matrix pipe
-// idles, because weights (83 KB) + one utterance tile (65 KB) leave no room for a second tile.  Here an utterance is
-// processed as two pieces of (about) half its position tiles; a piece needs only the input rows it touches (17 / 15 of
-// 29 at H = 27), so TWO piece buffers fit beside the weights (2 x 37.6 KB).  While the MFMAs of one piece run out of one
-// buffer, the same waves stage the next piece into the other buffer and request the piece after that from HBM:
-//   piece 0 of u   : K loop on buf0 | stage piece 1 of u   -> buf1 | load piece 0 of u+1 | epilogue | barrier
-//   piece 1 of u   : K loop on buf1 | stage piece 0 of u+1 -> buf0 | load piece 1 of u+1 | epilogue | barrier
-// The three waves of a SIMD stage at different points of their K loops (after 2, 4, 6 channel groups), so that two of
-// them always feed the matrix pipe; the epilogue's own operands are requested three channel groups before they are used.
-// ---------------------------------------------------------------------------------------------------------
-#if defined(HOWL_DIAG_PROBE)  // diagnostic build (tools/variants.py probe): s_memtime stamps of workgroup 0, [wave][slot]
-__device__ unsigned long long* g_howl_probe = nullptr;
-#define HOWL_PROBE(wave_, lane_, slot_)                                                         \
-    do {                                                                                        \
-        if (g_howl_probe != nullptr && blockIdx.x == 0 && (lane_) == 0 && (slot_) < 64)          \
-            g_howl_probe[(wave_) * 64 + (slot_)] = __builtin_amdgcn_s_memtime();                 \
-    } while (0)
-#else
-#define HOWL_PROBE(wave_, lane_, slot_) ((void)0)
-#endif
-
-template <int H>
-struct PipeGeo {
-    static constexpr int P = H * PW;
-    static constexpr int NT = (P + 15) / 16;            // position tiles per utterance
-    static constexpr int N0 = (NT + 1) / 2, N1 = NT - N0;  // tiles of piece 0 / piece 1
-    static constexpr int RB0 = (16 * N0 - 1) / PW;      // last output row touched by piece 0
-    static constexpr int RA1 = (16 * N0) / PW;          // first output row of piece 1
-    static constexpr int HI0 = RB0 + 1;                 // last input row piece 0 reads (real)
-    static constexpr int LO1 = RA1 - 1;                 // first input row piece 1 reads (real)
-    static constexpr int RR0 = HI0 + 1, RR1 = H - LO1;  // real input rows staged per piece
-    static constexpr int RR = RR0 > RR1 ? RR0 : RR1;
-    static constexpr int RL0 = RR0 + 1, RL1 = RR1 + 1;  // + one zero halo row (top for piece 0, bottom for piece 1)
-    static constexpr int RL = RL0 > RL1 ? RL0 : RL1;
-    static constexpr int CSP = RL * WP + ((17 - (RL * WP) % 32 + 32) % 32);  // channel stride = 17 (mod 32)
-    static constexpr int BUF = NMAP * CSP;              // floats per piece buffer (45 channels: see the pad below)
-    static constexpr int PAD = 3 * CSP;                 // k-group 11 reads channels 45..47 (weights zero): keep them in range
-    static constexpr int PAIRS = RR * (PW / 2);         // float2 elements per channel of a piece
-    static constexpr int NCH = CONV_THREADS / PAIRS;    // channels staged per slot
-    static constexpr int SLOTS = (NMAP + NCH - 1) / NCH;
-    static constexpr int LDS_FLOATS = 3 * KSTEPS * 64 + 2 * BUF + PAD + 2 * CP + 12 * 2 * 16;
-    static_assert(N1 >= 1 && HI0 <= H - 1 && LO1 >= 0, "two non-empty pieces");
-    static_assert(LDS_FLOATS * 4 <= 160 * 1024, "weights + two piece buffers must fit the LDS");
-    static constexpr int ntw(int n, int mg) { return n > mg ? (n - mg + 3) / 4 : 0; }
-};
-
-template <int H>
-struct PipeThread {  // this thread's share of a piece: float2 (row r, column pair wp) of channels cg, cg + NCH, ...
-    int cg, r, wp;
-    bool active;
-};
-
-template <int H, int Q>
-__device__ __forceinline__ void pipe_fetch(float2 (&pre)[PipeGeo<H>::SLOTS], const float* src, const PipeThread<H>& t) {
-    using G = PipeGeo<H>;
-    constexpr int RRQ = Q == 0 ? G::RR0 : G::RR1, ROW0 = Q == 0 ? 0 : G::LO1;
-    if (src == nullptr || !t.active || t.r >= RRQ) return;
-    const float* base = src + (ROW0 + t.r) * PW + 2 * t.wp;
-#pragma unroll
-    for (int j = 0; j < G::SLOTS; ++j) {
-        const int c = t.cg + G::NCH * j;
-        if (c < NMAP) pre[j] = *reinterpret_cast<const float2*>(base + c * G::P);
-    }
-}
-
-template <int H, int Q>
-__device__ __forceinline__ void pipe_stage(const float2 (&pre)[PipeGeo<H>::SLOTS], float* buf, const float* lmean,
-                                           const float* lrstd, bool affine, bool absval, const PipeThread<H>& t) {
-    using G = PipeGeo<H>;
-    constexpr int RRQ = Q == 0 ? G::RR0 : G::RR1, LR = Q == 0 ? 1 : 0;
-    if (!t.active || t.r >= RRQ) return;
-    float* base = buf + (t.r + LR) * WP + 2 * t.wp + 1;
-#pragma unroll
-    for (int j = 0; j < G::SLOTS; ++j) {
-        const int c = t.cg + G::NCH * j;
-        if (c < NMAP) {
-            float v0 = pre[j].x, v1 = pre[j].y;
-            if (absval) {
-                v0 = fabsf(v0);
-                v1 = fabsf(v1);
-            }
-            if (affine) {
-                const float m = lmean[c], rs = lrstd[c];
-                v0 = (v0 - m) * rs;
-                v1 = (v1 - m) * rs;
-            }
-            base[c * G::CSP] = v0;
-            base[c * G::CSP + 1] = v1;
-        }
-    }
-}
-
-// K loop of a piece.  A dependent chain of 16x16x4 MFMAs issues one instruction per ~64 cycles, i.e. a single chain
-// drives the matrix pipe at half rate and a SIMD needs >= 4 independent chains in flight to saturate it (s_memtime
-// probe: a lone wave with 2 chains runs its channel groups in 1.1k cycles instead of 576).  The 4-5 chains per wave of
-// conv3x3_mfma_kernel give that for free; with the 2-3 position tiles a wave owns in a piece, and waves leaving the K loop
-// one at a time to stage, they do not.  Each tile therefore accumulates even and odd taps in two separate chains (summed
-// at the end), so that every wave can saturate the pipe on its own.
-template <int NTW>
-__device__ __forceinline__ void k_run2(KCursor<NTW>& k, f32x4 (&acc)[NTW][2], int CS, int groups) {
-#if defined(HOWL_DIAG_CONV_NOK)  // diagnostic build: everything but the K loop
-    groups = 0;
-#endif
-#pragma nounroll
-    for (int g = 0; g < groups; ++g) {
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int off = (tap / 3) * WP + (tap % 3);
-            const float b = k.bp[tap * 64];
-#pragma unroll
-            for (int i = 0; i < NTW; ++i)
-                acc[i][tap & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(k.ap[i][off], b, acc[i][tap & 1], 0, 0, 0);
-        }
-        k.bp += 9 * 64;
-#pragma unroll
-        for (int i = 0; i < NTW; ++i) k.ap[i] += 4 * CS;
-    }
-}
-
-struct PipeCtx {
-    const float* in;
-    const lds_f32* wnt;
-    float* buf0;
-    float* buf1;
-    const float* lmean;
-    const float* lrstd;
-    int B, mg, lane, g1;
-    bool affine;
-    int wave;
-    int* slot;   // probe slot counter (diagnostic builds)
-};
-
-// K loop of one piece (with the other buffer's staging and the next loads inside it) + epilogue
-template <int MODE, int H, int Q, int NTW>
-__device__ __forceinline__ void pipe_piece(const PipeCtx& c, const ConvEpilogue& e, size_t ubase, const float* next_src,
-                                           bool stage_next, float2 (&pre)[PipeGeo<H>::SLOTS], const PipeThread<H>& t,
-                                           float& st0, float& st1) {
-    using G = PipeGeo<H>;
-    constexpr int T0 = Q == 0 ? 0 : G::N0;              // first position tile of this piece
-    constexpr int RBASE = Q == 0 ? -1 : G::LO1;         // input row held by LDS row 0 of this piece's buffer
-    const lds_f32* tile = (const lds_f32*)(Q == 0 ? c.buf0 : c.buf1);
-    float* other = Q == 0 ? c.buf1 : c.buf0;
-    f32x4 acc2[NTW > 0 ? NTW : 1][2];
-    KCursor<(NTW > 0 ? NTW : 1)> k;
-    if constexpr (NTW > 0) {
-#pragma unroll
-        for (int i = 0; i < NTW; ++i) {
-            int m = 16 * (T0 + c.mg + 4 * i) + (c.lane & 15);
-            m = m < G::P ? m : G::P - 1;  // the last tile may overhang: clamp the read, the store is masked
-            const int h = m / PW;
-            k.ap[i] = tile + (c.lane >> 4) * G::CSP + (h - 1 - RBASE) * WP + (m - h * PW);  // window's top-left corner
-            acc2[i][0] = {0.0f, 0.0f, 0.0f, 0.0f};
-            acc2[i][1] = {0.0f, 0.0f, 0.0f, 0.0f};
-        }
-        k.bp = c.wnt + c.lane;
-        HOWL_PROBE(c.wave, c.lane, (*c.slot)++);   // piece start
-        k_run2<NTW>(k, acc2, G::CSP, c.g1);
-        HOWL_PROBE(c.wave, c.lane, (*c.slot)++);   // first K segment done
-    }
-    // the other buffer was last read before the previous barrier: refill it with the next piece, then ask for the one after
-    if (stage_next) {
-        if (Q == 0) pipe_stage<H, 1>(pre, other, c.lmean, c.lrstd, c.affine, MODE == 0, t);
-        else pipe_stage<H, 0>(pre, other, c.lmean, c.lrstd, c.affine, MODE == 0, t);
-    }
-    if (Q == 0) pipe_fetch<H, 0>(pre, next_src, t);     // piece 0 of the next utterance (staged during piece 1)
-    else pipe_fetch<H, 1>(pre, next_src, t);            // piece 1 of the next utterance (staged during its piece 0)
-    if constexpr (NTW > 0) {
-        HOWL_PROBE(c.wave, c.lane, (*c.slot)++);   // staged + next loads issued
-        k_run2<NTW>(k, acc2, G::CSP, 9 - c.g1);
-        const float* eop = (MODE == 0) ? e.res : e.xs;
-        float2 ev[NTW][2];
-        const char* ebase = reinterpret_cast<const char*>(eop + ubase);
-        const unsigned crow = (unsigned)((e.cvalid ? e.cout : NMAP - 1) * G::P);
-        const unsigned boff = 4u * (crow + 16u * (T0 + c.mg) + 4u * (c.lane >> 4));
-        const unsigned bmax = 4u * (crow + G::P - 2);
-        if (eop != nullptr) {  // operands of the epilogue, three channel groups (~3-4k cycles of MFMAs) ahead of their use
-#pragma unroll
-            for (int i = 0; i < NTW; ++i)
-#pragma unroll
-                for (int hh = 0; hh < 2; ++hh) {
-                    unsigned off = boff + 256u * i + 8u * hh;
-                    off = off < bmax ? off : bmax;
-                    ev[i][hh] = *reinterpret_cast<const float2*>(ebase + off);
-                }
-        }
-        k_run2<NTW>(k, acc2, G::CSP, 3);
-        HOWL_PROBE(c.wave, c.lane, (*c.slot)++);   // K loop done
-        f32x4 acc[NTW];
-#pragma unroll
-        for (int i = 0; i < NTW; ++i) acc[i] = acc2[i][0] + acc2[i][1];
-        char* obase = reinterpret_cast<char*>(e.out + ubase);
-#pragma unroll
-        for (int i = 0; i < NTW; ++i) {
-            const int mbase = 16 * (T0 + c.mg + 4 * i) + 4 * (c.lane >> 4);
-#pragma unroll
-            for (int hh = 0; hh < 2; ++hh) {
-                const int m = mbase + 2 * hh;
-                if (e.cvalid && m < G::P) {
-                    float v0 = acc[i][2 * hh], v1 = acc[i][2 * hh + 1];
-                    if (MODE == 0) {
-                        v0 = fmaxf(v0, 0.0f);
-                        v1 = fmaxf(v1, 0.0f);
-                        if (e.res != nullptr) {  // sign-bit ReLU mask: see conv_utterance
-                            const float2 r = ev[i][hh];
-                            const bool k0 = v0 > 0.0f, k1 = v1 > 0.0f;
-                            v0 += fabsf(r.x);
-                            v1 += fabsf(r.y);
-                            st0 += v0 + v1;
-                            st1 += v0 * v0 + v1 * v1;
-                            v0 = k0 ? -v0 : v0;
-                            v1 = k1 ? -v1 : v1;
-                        } else {
-                            st0 += v0 + v1;
-                            st1 += v0 * v0 + v1 * v1;
-                        }
-                    } else if (e.xs != nullptr) {
-                        const float2 sv = ev[i][hh];
-                        st0 += v0 + v1;
-                        st1 += v0 * ((fabsf(sv.x) - e.xmean) * e.xrstd) + v1 * ((fabsf(sv.y) - e.xmean) * e.xrstd);
-                    }
-                    *reinterpret_cast<float2*>(obase + (boff + 256u * i + 8u * hh)) = make_float2(v0, v1);
-                }
-            }
-        }
-    }
-}
-
-template <int MODE, int H, int NTW0, int NTW1>
-__device__ __forceinline__ void pipe_loop(const PipeCtx& c, const ConvEpilogue& e, float2 (&pre)[PipeGeo<H>::SLOTS],
-                                          const PipeThread<H>& t, int b, float& st0, float& st1) {
-    using G = PipeGeo<H>;
-    for (; b < c.B; b += gridDim.x) {
-        const int bn = b + gridDim.x;
-        const float* nsrc = (bn < c.B) ? c.in + (size_t)bn * NMAP * G::P : nullptr;
-        const size_t ubase = (size_t)b * NMAP * G::P;
-        pipe_piece<MODE, H, 0, NTW0>(c, e, ubase, nsrc, true, pre, t, st0, st1);
-        HOWL_PROBE(c.wave, c.lane, (*c.slot)++);   // epilogue done
-        __syncthreads();  // buf1 staged and visible; every wave is done reading buf0
-        HOWL_PROBE(c.wave, c.lane, (*c.slot)++);   // barrier passed
-        pipe_piece<MODE, H, 1, NTW1>(c, e, ubase, nsrc, nsrc != nullptr, pre, t, st0, st1);
-        HOWL_PROBE(c.wave, c.lane, (*c.slot)++);
-        __syncthreads();  // buf0 holds piece 0 of the next utterance; every wave is done reading buf1
-        HOWL_PROBE(c.wave, c.lane, (*c.slot)++);
-    }
-}
-
-template <int MODE, int H>
-__global__ __launch_bounds__(CONV_THREADS) void conv3x3_pipe_kernel(
-    const float* __restrict__ in, const float* __restrict__ in_stats, const float* __restrict__ wp,
-    const float* __restrict__ res, float* __restrict__ out, const float* __restrict__ xs,
-    const float* __restrict__ xs_stats, float* __restrict__ part, int B) {
-    using G = PipeGeo<H>;
-    HIP_DYNAMIC_SHARED(float, lds)
-    float* wl = lds;                          // [3][108][64] weight fragments
-    float* buf0 = lds + 3 * KSTEPS * 64;      // piece 0: LDS row 0 = zero halo, row r+1 = input row r
-    float* buf1 = buf0 + G::BUF;              // piece 1: LDS row r - LO1 = input row r, last row = zero halo
-    float* lmean = buf1 + G::BUF + G::PAD;
-    float* lrstd = lmean + CP;
-    float* red = lrstd + CP;                  // [12][2][16]
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int nt = __builtin_amdgcn_readfirstlane(wave % 3);
-    const int mg = __builtin_amdgcn_readfirstlane(wave / 3);
-    const bool affine = in_stats != nullptr;
-
-    HOWL_PROBE(wave, lane, 0);
-    PipeThread<H> t;
-    t.cg = tid / G::PAIRS;
-    const int rem = tid - t.cg * G::PAIRS;
-    t.r = rem / (PW / 2);
-    t.wp = rem - t.r * (PW / 2);
-    t.active = t.cg < G::NCH;
-
-    // first piece's activations are requested before anything else so that HBM latency overlaps the setup
-    float2 pre[G::SLOTS];
-    int b = blockIdx.x;
-    const float* src0 = (b < B) ? in + (size_t)b * NMAP * G::P : nullptr;
-    pipe_fetch<H, 0>(pre, src0, t);
-    {
-        float4 wv[7];  // 3*108*16 float4 = 5184 <= 7 * 768: all loads in flight, then the LDS stores
-#pragma unroll
-        for (int j = 0; j < 7; ++j) {
-            const int i = tid + j * CONV_THREADS;
-            wv[j] = (i < 3 * KSTEPS * 16) ? reinterpret_cast<const float4*>(wp)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        zero_lds(buf0, 2 * G::BUF + G::PAD + 2 * CP + 12 * 2 * 16, tid, CONV_THREADS);
-#pragma unroll
-        for (int j = 0; j < 7; ++j) {
-            const int i = tid + j * CONV_THREADS;
-            if (i < 3 * KSTEPS * 16) reinterpret_cast<float4*>(wl)[i] = wv[j];
-        }
-    }
-    __syncthreads();  // zero fill done before the statistics / first piece land in it
-    if (tid < CP) {
-        lmean[tid] = affine ? in_stats[tid] : 0.0f;
-        lrstd[tid] = affine ? in_stats[CP + tid] : 1.0f;
-    }
-    const int cout = 16 * nt + (lane & 15);
-    const bool cvalid = cout < NMAP;
-    float xmean = 0.0f, xrstd = 1.0f;
-    if (MODE == 1 && xs != nullptr && cvalid) {
-        xmean = xs_stats[cout];
-        xrstd = xs_stats[CP + cout];
-    }
-    float st0 = 0.0f, st1 = 0.0f;
-    const ConvEpilogue epi{res, out, xs, xmean, xrstd, cout, G::P, cvalid};
-    __syncthreads();  // statistics visible to the staging below
-    pipe_stage<H, 0>(pre, buf0, lmean, lrstd, affine, MODE == 0, t);
-    pipe_fetch<H, 1>(pre, src0, t);
-    __syncthreads();  // piece 0 of the first utterance visible
-
-    int probe_slot = 2;
-    HOWL_PROBE(wave, lane, 1);   // prologue done (slot 0: kernel entry)
-    const PipeCtx c{in, (const lds_f32*)wl + nt * KSTEPS * 64, buf0, buf1, lmean, lrstd, B, mg, lane, 2 + 2 * (wave >> 2),
-                    affine, wave, &probe_slot};
-    switch (mg) {  // tile counts of this wave in the two pieces (identical instantiations merge)
-        case 0: pipe_loop<MODE, H, G::ntw(G::N0, 0), G::ntw(G::N1, 0)>(c, epi, pre, t, b, st0, st1); break;
-        case 1: pipe_loop<MODE, H, G::ntw(G::N0, 1), G::ntw(G::N1, 1)>(c, epi, pre, t, b, st0, st1); break;
-        case 2: pipe_loop<MODE, H, G::ntw(G::N0, 2), G::ntw(G::N1, 2)>(c, epi, pre, t, b, st0, st1); break;
-        default: pipe_loop<MODE, H, G::ntw(G::N0, 3), G::ntw(G::N1, 3)>(c, epi, pre, t, b, st0, st1); break;
-    }
-
-    if (part != nullptr) {
-        // lanes l, l^16, l^32, l^48 hold the same cout: fold them, then fold the 4 position groups via LDS
-        st0 += __shfl_xor(st0, 16);
-        st0 += __shfl_xor(st0, 32);
-        st1 += __shfl_xor(st1, 16);
-        st1 += __shfl_xor(st1, 32);
-        if (lane < 16) {
-            red[(wave * 2 + 0) * 16 + lane] = st0;
-            red[(wave * 2 + 1) * 16 + lane] = st1;
-        }
-        __syncthreads();
-        if (tid < 2 * CP) {
-            const int which = tid / CP, ch = tid - which * CP;
-            const int t3 = ch >> 4, cl = ch & 15;
-            float sum = 0.0f;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) sum += red[((g * 3 + t3) * 2 + which) * 16 + cl];
-            part[((size_t)blockIdx.x * 2 + which) * CP + ch] = sum;
-        }
-    }
-}
-
 // wgrad: dW[cout][cin][tap] += sum_{b,p} dz[b,cout,p] * x[b,cin,p + tap shift],  x = (s_prev - mean) * rstd
 __global__ __launch_bounds__(CONV_THREADS) void wgrad_mfma_kernel(
     const float* __restrict__ dz, const float* __restrict__ s_prev, const float* __restrict__ in_stats,
@@ -1421,41 +1072,6 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
 }
 
 size_t conv_lds_bytes(int H) { return (size_t)(3 * KSTEPS * 64 + tile_floats(H) + 2 * CP + 12 * 2 * 16) * sizeof(float); }
-// conv 45->45 forward (MODE 0) / data gradient (MODE 1): the pipelined kernel at the reference's window lengths, the
-// general one otherwise
-template <int MODE>
-void launch_conv3x3(hipStream_t stream, int G, int H, const float* in, const float* in_stats, const float* wp,
-                    const float* res, float* out, const float* xs, const float* xs_stats, float* part, int B) {
-    if (H == 27 || H == 13) {
-        const size_t lds = (size_t)(H == 27 ? PipeGeo<27>::LDS_FLOATS : PipeGeo<13>::LDS_FLOATS) * sizeof(float);
-        if (H == 27) {
-            hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_pipe_kernel<MODE, 27>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL((conv3x3_pipe_kernel<MODE, 27>), dim3(G), dim3(CONV_THREADS), lds, stream, in, in_stats, wp, res,
-                               out, xs, xs_stats, part, B);
-        } else {
-            hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_pipe_kernel<MODE, 13>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL((conv3x3_pipe_kernel<MODE, 13>), dim3(G), dim3(CONV_THREADS), lds, stream, in, in_stats, wp, res,
-                               out, xs, xs_stats, part, B);
-        }
-        return;
-    }
-    const size_t lc = conv_lds_bytes(H);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_mfma_kernel<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                        (int)lc);
-    hipLaunchKernelGGL(conv3x3_mfma_kernel<MODE>, dim3(G), dim3(CONV_THREADS), lc, stream, in, in_stats, wp, res, out, xs,
-                       xs_stats, part, B, H);
-}
-
-#if defined(HOWL_DIAG_PROBE)
-}  // namespace
-extern "C" int howl_diag_set_probe(unsigned long long* buf) {
-    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_howl_probe), &buf, sizeof(buf));
-}
-namespace {
-#endif
-
 size_t wgrad_lds_bytes(int H) { return (size_t)(2 * tile_floats(H) + 2 * CP) * sizeof(float); }
 size_t conv0_lds_bytes(int T, int M) { return (size_t)((T + 2) * (M + 4) + 2 * NMAP * 9) * sizeof(float); }
 size_t conv0_wgrad_lds_bytes(int T, int M) {
@@ -1558,8 +1174,9 @@ int howl_res8_fwd(const HowlRes8Params* prm, const float* feat, long sb, long st
         const float* res = even ? sv->s[i - 2] : nullptr;
         {
             HowlProfScope prof("conv3x3_fwd", stream);
-            launch_conv3x3<0>(stream, G, H, sv->s[i - 1], in_stats, w.wp_fwd + (size_t)(i - 1) * 3 * KSTEPS * 64, res, sv->s[i],
-                              nullptr, nullptr, training ? w.part : (float*)nullptr, B);
+            hipLaunchKernelGGL(conv3x3_mfma_kernel<0>, dim3(G), dim3(CONV_THREADS), lc, stream, sv->s[i - 1], in_stats,
+                               w.wp_fwd + (size_t)(i - 1) * 3 * KSTEPS * 64, res, sv->s[i], (const float*)nullptr,
+                               (const float*)nullptr, training ? w.part : (float*)nullptr, B, H);
         }
         if (training)
             hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(1024), 0, stream, w.part, G, count,
@@ -1631,9 +1248,10 @@ int howl_res8_bwd(const HowlRes8Params* prm, const float* feat, long sb, long st
         const bool need_stats = i > 1;
         {
             HowlProfScope prof("conv3x3_dgrad", stream);
-            launch_conv3x3<1>(stream, G, H, w.dz, nullptr, w.wp_bwd + (size_t)(i - 1) * 3 * KSTEPS * 64, nullptr, dx_next,
-                              need_stats ? sv->s[i - 1] : (const float*)nullptr, in_stats,
-                              need_stats ? w.part : (float*)nullptr, B);
+            hipLaunchKernelGGL(conv3x3_mfma_kernel<1>, dim3(G), dim3(CONV_THREADS), lc, stream, (const float*)w.dz,
+                               (const float*)nullptr, w.wp_bwd + (size_t)(i - 1) * 3 * KSTEPS * 64, (const float*)nullptr,
+                               dx_next, need_stats ? sv->s[i - 1] : (const float*)nullptr, in_stats,
+                               need_stats ? w.part : (float*)nullptr, B, H);
         }
         if (need_stats)
             hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(1024), 0, stream, (const float*)w.part, G, count,

