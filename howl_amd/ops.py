@@ -92,12 +92,18 @@ def zmuv_apply(x, pair):
     return out
 
 
-def collate_augment(bank, idx, src_len, shift, from_head, sigma, sp_prob, seed, lout):
+def collate_augment(bank, idx, src_len, shift, from_head, sigma, sp_prob, seed, lout, mix=None):
+    """``mix`` = (bg_bank (N, Lbg), bg_idx, bg_off, alpha) puts DatasetMixer in front of the chain."""
     B = idx.numel()
     out = torch.empty((B, lout), dtype=torch.float32, device=bank.device)
-    _lib.get().call("howl_collate_augment", _p(bank), bank.stride(0), _p(idx, torch.int32), _p(src_len, torch.int32),
+    if mix is None:
+        bg, bg_ld, bg_idx, bg_off, alpha = None, 0, None, None, None
+    else:
+        bg, bg_ld = _p(mix[0]), mix[0].stride(0)
+        bg_idx, bg_off, alpha = _p(mix[1], torch.int32), _p(mix[2], torch.int32), _p(mix[3])
+    _lib.get().call("howl_collate_augment_mix", _p(bank), bank.stride(0), _p(idx, torch.int32), _p(src_len, torch.int32),
                     _p(shift, torch.int32), _p(from_head, torch.int32), _p(sigma), _p(sp_prob),
-                    ctypes.c_ulonglong(seed & 0xFFFFFFFFFFFFFFFF), B, lout, _p(out), _stream())
+                    ctypes.c_ulonglong(seed & 0xFFFFFFFFFFFFFFFF), bg, bg_ld, bg_idx, bg_off, alpha, B, lout, _p(out), _stream())
     return out
 
 

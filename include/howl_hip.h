@@ -83,6 +83,14 @@ int howl_zmuv_apply(const float* x, size_t n, const float* pair, float* out, hip
 int howl_collate_augment(const float* bank, long bank_ld, const int* idx, const int* src_len, const int* shift,
                          const int* from_head, const float* sigma, const float* sp_prob, unsigned long long seed, int B,
                          int Lout, float* out, hipStream_t stream);
+/* The same with DatasetMixer (transform.py:199-231) in front of the chain, as train.py:218 composes it: before the time
+ * shift, sample n of clip b becomes x*(1-alpha[b]) + bg[bg_idx[b]][bg_off[b] + n]*alpha[b] (alpha 0 = not mixed, 1 =
+ * replaced).  The background clip, its offset (rand.randint(len, bg_len) - len) and alpha are host draws in the
+ * reference's order.  bg == NULL: identical to howl_collate_augment. */
+int howl_collate_augment_mix(const float* bank, long bank_ld, const int* idx, const int* src_len, const int* shift,
+                             const int* from_head, const float* sigma, const float* sp_prob, unsigned long long seed,
+                             const float* bg, long bg_ld, const int* bg_idx, const int* bg_off, const float* alpha, int B,
+                             int Lout, float* out, hipStream_t stream);
 
 /* SpecAugment masks with host-drawn parameters (per sample; width <= 0 = no mask): transform.py:309-327.
  * x is a (B,C,M,T) view with element strides (sb,sc,sm,st), masked in place. */

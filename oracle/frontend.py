@@ -123,3 +123,27 @@ def spec_augment_apply(x: torch.Tensor, f0, f, t0, t) -> torch.Tensor:
         if t[i] >= 0:
             x[i, :, :, t0[i]:t0[i] + t[i]] = 0
     return x
+
+
+MIXER_STRENGTH_DOMAIN, MIXER_STRENGTH_IDX, MIXER_PROB = [0.1, 0.2, 0.3, 0.4, 0.5], 1, 0.75
+
+
+def dataset_mixer(rand, waveforms, backgrounds, training: bool = True, do_replace: bool = False):
+    """``DatasetMixer.forward`` (``transform.py:90-97,199-231``) with ``rand`` a ``random.Random``-like stream: one gate draw
+    per augmentation parameter ("strength" prob 0.75, "replace" prob 0.1 if do_replace else 0 -- the draw is consumed
+    either way); when "strength" fires, per example: background = rand.choice (redrawn while shorter than the waveform),
+    b = rand.randint(len, bg_len), alpha = rand.random() * 0.2, out = wf * (1 - alpha) + bg[b - len:b] * alpha."""
+    out = list(waveforms)
+    for name, prob in (("strength", MIXER_PROB), ("replace", 0.1 if do_replace else 0.0)):
+        if rand.random() < prob and training:
+            mixed = []
+            for wf in out:
+                n = wf.numel()
+                bg = rand.choice(backgrounds)
+                while bg.numel() < n:
+                    bg = rand.choice(backgrounds)
+                b = rand.randint(n, bg.numel())
+                alpha = 1.0 if name == "replace" else rand.random() * MIXER_STRENGTH_DOMAIN[MIXER_STRENGTH_IDX]
+                mixed.append(wf * (1 - alpha) + bg[b - n:b] * alpha)
+            out = mixed
+    return out

@@ -301,7 +301,37 @@ def collate_protocol_golden():
     save("g7b_collate_protocol", lens=np.array(lens), **out)
 
 
+def mixer_golden():
+    """G9: DatasetMixer (transform.py:199-231) in front of the training collate chain, as train.py:218 composes it:
+    outputs of the reference class itself for a seeded ``random`` stream, ramp waveforms and constant-level backgrounds
+    (so the chosen clip, its offset and alpha are all readable from the result)."""
+    from howl.data.transform.transform import DatasetMixer
+
+    class Ex:
+        def __init__(self, audio):
+            self.audio_data = audio
+
+        def update_audio_data(self, audio, **kw):
+            return Ex(audio)
+
+    wf_lens = [16000, 12971, 16000, 9000]
+    bg_lens = [40000, 8000, 25000, 16000, 31000]
+    out = {}
+    for trial, seed in enumerate((0, 3, 11)):
+        random.seed(seed)
+        bgs = [Ex(torch.full((L,), 0.1 * (i + 1)) + torch.arange(L, dtype=torch.float32) * 1e-6) for i, L in enumerate(bg_lens)]
+        mixer = DatasetMixer(bgs).train()
+        exs = mixer([Ex(torch.arange(L, dtype=torch.float32) * 1e-5) for L in wf_lens])
+        for i, e in enumerate(exs):
+            a = e.audio_data.numpy().astype(np.float32)
+            out[f"mixed_{trial}_{i}"] = np.concatenate([a[:8], a[8:-8:61], a[-8:]])   # subsampled: head, every 61st, tail
+        out[f"next_draw_{trial}"] = np.array(random.random())      # position of the random stream afterwards
+    save("g9_mixer", wf_lens=np.array(wf_lens), bg_lens=np.array(bg_lens), **out)
+
+
 if __name__ == "__main__":
-    if "--only-collate" not in sys.argv:
+    if "--only-collate" not in sys.argv and "--only-mixer" not in sys.argv:
         main()
-    collate_protocol_golden()
+    if "--only-mixer" not in sys.argv:
+        collate_protocol_golden()
+    mixer_golden()

@@ -144,3 +144,27 @@ def test_collate_augment(lib):
     assert np.array_equal(a[2], out[2])                                                      # untouched sample
     lib.call(*args(sg, sp, 8, b))
     assert not np.array_equal(a[0], b[0])                                                    # seed changes the noise
+
+
+def test_collate_augment_mix(lib):
+    """DatasetMixer in front of the chain: x*(1-alpha) + bg[off + n]*alpha on the pre-shift coordinates, then crop / pad."""
+    rng = np.random.default_rng(5)
+    bank = (0.1 * rng.standard_normal((4, 3000))).astype(np.float32)
+    bg = (0.2 * rng.standard_normal((3, 5000))).astype(np.float32)
+    idx = np.array([1, 3, 0], np.int32)
+    src_len = np.array([3000, 2500, 2000], np.int32)
+    shift = np.array([100, 0, 700], np.int32)
+    head = np.array([1, 0, 0], np.int32)
+    zero = np.zeros(3, np.float32)
+    bg_idx = np.array([2, 0, 1], np.int32)
+    bg_off = np.array([1234, 0, 2999], np.int32)
+    alpha = np.array([0.15, 0.0, 1.0], np.float32)
+    out = np.full((3, 2950), np.nan, np.float32)
+    lib.call("howl_collate_augment_mix", ptr(bank), 3000, ptr(idx), ptr(src_len), ptr(shift), ptr(head), ptr(zero), ptr(zero), 9,
+             ptr(bg), 5000, ptr(bg_idx), ptr(bg_off), ptr(alpha), 3, 2950, ptr(out), None)
+    m0 = bank[1, :3000] * np.float32(0.85) + bg[2, 1234:4234] * np.float32(0.15)
+    np.testing.assert_allclose(out[0, :2900], m0[100:], rtol=0, atol=1e-7)        # mixed, then head crop
+    assert not out[0, 2900:].any()
+    assert np.array_equal(out[1, :2500], bank[3, :2500]) and not out[1, 2500:].any()   # alpha 0: untouched
+    np.testing.assert_allclose(out[2, :1300], bg[1, 2999:4299], rtol=0, atol=1e-7)     # alpha 1: replaced, tail crop
+    assert not out[2, 1300:].any()

@@ -115,3 +115,39 @@ def test_full_size_properties(std):
         std(pcm[:, :200].to(DEV), mels_only=True)              # too short for reflect padding: loud error, like torch.stft
     with pytest.raises(Exception):
         std(pcm[:2])                                           # CPU tensor: no fallback
+
+
+def test_device_collate_with_dataset_mixer(golden):
+    """a12 / train.py:218: DatasetMixer -> truncate -> Timeshift -> Noise -> batchify as one launch.  With the noise
+    parameters' gates closed the batch equals the oracle's DatasetMixer + crop on the same `random` stream exactly."""
+    from howl_amd.data.collate import DeviceCollate
+    from howl_amd.data import collate as collate_mod
+    g = golden("g9_mixer")
+    wf_lens, bg_lens = g["wf_lens"].tolist(), g["bg_lens"].tolist()
+    rng = np.random.default_rng(3)
+    bank = torch.zeros(len(wf_lens), max(wf_lens))
+    for i, L in enumerate(wf_lens):
+        bank[i, :L] = t(0.1 * rng.standard_normal(L).astype(np.float32))
+    bgb = torch.zeros(len(bg_lens), max(bg_lens))
+    for i, L in enumerate(bg_lens):
+        bgb[i, :L] = t(0.2 * rng.standard_normal(L).astype(np.float32))
+    labels = torch.arange(len(wf_lens))
+    seen_mix = False
+    for seed in (0, 3, 11, 12):
+        dc = DeviceCollate(bank.to(DEV), torch.tensor(wf_lens), labels.to(DEV), max_len=16000, seed=seed,
+                           background=(bgb.to(DEV), bg_lens))
+        old = collate_mod.NOISE_PROB, collate_mod.TIMESHIFT_PROB
+        collate_mod.NOISE_PROB, collate_mod.TIMESHIFT_PROB = -1.0, -1.0   # gates still draw, never fire
+        try:
+            batch = dc(list(range(len(wf_lens))))
+        finally:
+            collate_mod.NOISE_PROB, collate_mod.TIMESHIFT_PROB = old
+        ref = ofe.dataset_mixer(random.Random(seed), [bank[i, :L] for i, L in enumerate(wf_lens)],
+                                [bgb[i, :L] for i, L in enumerate(bg_lens)])
+        order = sorted(range(len(wf_lens)), key=lambda k: -wf_lens[k])
+        assert batch.lengths.tolist() == [wf_lens[k] for k in order]
+        for row, k in enumerate(order):
+            assert maxerr(batch.audio_data[row, :wf_lens[k]], ref[k]) < 1e-6
+            assert not batch.audio_data[row, wf_lens[k]:].any()
+        seen_mix |= any(a != 0 for a in dc.last_mix[2])
+    assert seen_mix

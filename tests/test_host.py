@@ -3,6 +3,7 @@ import importlib
 import os
 
 import pytest
+import numpy as np
 import torch
 
 
@@ -103,3 +104,25 @@ def test_device_collate_follows_reference_rng_protocol(golden):
             assert abs(g[f"first_{trial}"][k] - off * 1e-5) < 6e-3
             if shift[k] > 600 and head[k]:
                 assert g[f"first_{trial}"][k] > 0.5 * shift[k] * 1e-5 - 5e-3
+
+
+def test_device_collate_mixer_draws_match_reference(golden):
+    """DeviceCollate.draw_mixer makes DatasetMixer's draws (background choice, window, alpha) in the reference's order: the
+    mix rebuilt from them equals the reference class's output (G9) and the random stream ends at the same position."""
+    import random
+    from howl_amd.data.collate import DeviceCollate
+    g = golden("g9_mixer")
+    wf_lens, bg_lens = g["wf_lens"].tolist(), g["bg_lens"].tolist()
+    for trial, seed in enumerate((0, 3, 11)):
+        dc = DeviceCollate(torch.zeros(1, 1), torch.tensor(wf_lens), torch.zeros(len(wf_lens), dtype=torch.long), 1 << 20,
+                           background=(torch.zeros(1, 1), bg_lens))
+        dc.rand = random.Random(seed)
+        bg_id, bg_off, alpha = dc.draw_mixer(wf_lens)
+        assert dc.rand.random() == float(g[f"next_draw_{trial}"])
+        for i, L in enumerate(wf_lens):
+            n = np.arange(L, dtype=np.float32)
+            wf = n * np.float32(1e-5)
+            bg = np.float32(0.1 * (bg_id[i] + 1)) + (n + np.float32(bg_off[i])) * np.float32(1e-6)
+            mixed = wf * np.float32(1 - alpha[i]) + bg * np.float32(alpha[i]) if alpha[i] else wf
+            sub = np.concatenate([mixed[:8], mixed[8:-8:61], mixed[-8:]])
+            np.testing.assert_allclose(sub, g[f"mixed_{trial}_{i}"], rtol=0, atol=2e-6)

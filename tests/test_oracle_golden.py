@@ -159,3 +159,28 @@ def test_g7_specaug(golden):
     g = golden("g7_specaug")
     out = fe.spec_augment_apply(t(g["x"]), g["f0"], g["f"], g["t0"], g["t"])
     assert torch.equal(out, t(g["out"]))
+
+
+def _g9_inputs(g):
+    wfs = [torch.arange(int(L), dtype=torch.float32) * 1e-5 for L in g["wf_lens"]]
+    bgs = [torch.full((int(L),), 0.1 * (i + 1)) + torch.arange(int(L), dtype=torch.float32) * 1e-6
+           for i, L in enumerate(g["bg_lens"])]
+    return wfs, bgs
+
+
+def _g9_sub(a):
+    a = np.asarray(a, np.float32)
+    return np.concatenate([a[:8], a[8:-8:61], a[-8:]])
+
+
+def test_g9_dataset_mixer(golden):
+    """DatasetMixer restatement vs the reference class's own outputs (same `random` stream)."""
+    import random
+    g = golden("g9_mixer")
+    wfs, bgs = _g9_inputs(g)
+    for trial, seed in enumerate((0, 3, 11)):
+        rand = random.Random(seed)
+        out = fe.dataset_mixer(rand, wfs, bgs)
+        for i, o in enumerate(out):
+            np.testing.assert_allclose(_g9_sub(o.numpy()), g[f"mixed_{trial}_{i}"], rtol=0, atol=1e-7)
+        assert rand.random() == float(g[f"next_draw_{trial}"])
