@@ -119,11 +119,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
     assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback)"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device(f"cuda:{local_rank}")
+    # HOWL_BENCH_BACKEND=gloo lets the multi-rank control flow be exercised with several ranks on ONE GPU (RCCL refuses two
+    # ranks per device); the default, and what the driver runs, is one rank per GPU over RCCL
+    backend = os.environ.get("HOWL_BENCH_BACKEND", "nccl")
+    dev_index = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
+    if world > 1:
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{dev_index}"))
+        else:
+            dist.init_process_group(backend)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device(f"cuda:{dev_index}")
 
     from howl_amd import lib as hlib
     from howl_amd.data.transform.operator import ZmuvTransform
@@ -166,14 +173,18 @@ def main():
     final_loss = loss.item()
 
     roof = None
-    if not args.no_roofline and rank == 0:
-        # second pass of the same K steps with HIP-event brackets around the dominant kernels
+    if not args.no_roofline:
+        # second pass of the same K steps with HIP-event brackets around the dominant kernels.  EVERY rank runs it (the
+        # step contains the gradient all-reduce: a rank stepping alone would wait for its peers forever); rank 0 reports.
         lb = hlib.get()
-        lb.call("howl_profile_enable", 1)
+        if rank == 0:
+            lb.call("howl_profile_enable", 1)
         for _ in range(args.steps):
             trainer.step(pcm, labels)
-        torch.cuda.synchronize()
-        lb.call("howl_profile_enable", 0)
+        barrier()
+        if rank == 0:
+            lb.call("howl_profile_enable", 0)
+    if not args.no_roofline and rank == 0:
 
         def read(tag, reset=0):
             tot, cnt = ctypes.c_double(0), ctypes.c_int(0)
