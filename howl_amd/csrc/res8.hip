@@ -767,12 +767,8 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// conv0 (1 -> 45, 3x3, pad 1) + ReLU + AvgPool(3,4), forward and weight gradient.  VALU: 2.6 MFLOP/utterance.
-// Waves own output channels, lanes stride over the pooled positions.
+// conv0 (1 -> 45, 3x3, pad 1) + ReLU + AvgPool(3,4), forward and weight gradient: 2.6 MFLOP/utterance each.
 // ---------------------------------------------------------------------------------------------------------
-constexpr int C0_THREADS = 512;    // forward: 8 waves, wave w takes channels w, w+8, ... (two waves per SIMD, balanced)
-constexpr int C0W_THREADS = 960;   // weight gradient: 15 waves x 3 channels (SIMD loads 12,12,12,9 channels)
-constexpr int C0_GROUP = 3;
 
 // tin[(T+2)][M+4] with a zero halo; the row pitch is a multiple of 4 floats so that the 6-wide patch row of pooled
 // column pw (tile columns 4pw .. 4pw+5) is one aligned ds_read_b128 + one ds_read_b64 instead of six strided b32 reads
@@ -797,95 +793,130 @@ __device__ __forceinline__ void load_feat_tile(float* tin, const float* feat, lo
     }
 }
 
-__device__ __forceinline__ void load_patch(const float* tin, int pitch, int ph, int pw, float (&patch)[5][6]) {
-#pragma unroll
-    for (int i = 0; i < 5; ++i) {
-        const float* row = tin + (3 * ph + i) * pitch + 4 * pw;
-        const float4 a = *reinterpret_cast<const float4*>(row);
-        const float2 c = *reinterpret_cast<const float2*>(row + 4);
-        patch[i][0] = a.x;
-        patch[i][1] = a.y;
-        patch[i][2] = a.z;
-        patch[i][3] = a.w;
-        patch[i][4] = c.x;
-        patch[i][5] = c.y;
-    }
-}
+// ---------------------------------------------------------------------------------------------------------
+// Both run on the matrix cores (a VALU formulation of the same kernels took 45 / 86 us per launch at B = 512, these take
+// 40 / 53 us; git history has it).  dy0 = ga + gb is the gradient of the pooled output (dx_0 from layer 1 + the skip), the
+// ReLU pattern of the pre-pool activation comes from the forward's 12-bit masks (2 B per pooled output instead of the
+// 583 KB/utterance tensor or a recomputation).
+//   forward: D[position][cout] = sum_tap patch[position][tap] * w[tap][cout]   (K = 9 taps padded to 12: 3 k-steps);
+//   wgrad  : D[cout][tap] += sum_position (g[cout][cell] * mask bit) * patch[position][tap]   (one pooled cell = 12
+//            positions = 3 k-steps, no padding; N = 9 taps of 16), accumulators live in registers across all cells and
+//            utterances of a wave.
+// ~2,200-2,400 MFMAs per utterance either way, i.e. ~16 us of matrix-pipe time per launch at B = 512.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int C0M_THREADS = 512;   // 8 waves, two per SIMD
 
-__global__ __launch_bounds__(C0_THREADS) void conv0_fwd_kernel(const float* __restrict__ feat, long sb, long st, long sm,
-                                                               const float* __restrict__ w0, float* __restrict__ s0,
-                                                               unsigned short* __restrict__ mask0, int B, int T, int M,
-                                                               int H) {
+// Forward tile = one frame of FOUR neighbouring pooled cells: row i = 4*pwl + fl <-> mel bin 16*blk + i of frame
+// 3ph + tl.  The three frames of a cell are three tiles accumulated by the SAME lanes, and a lane holds the 4 mel bins of
+// one cell (rows 4g + r, g = pwl): ReLU, the 3x4 sum and the 12 mask bits are all lane-local, no cross-lane traffic.
+// 40 mel bins = 2.5 blocks of 16: the third block computes two cells of padding.
+__global__ __launch_bounds__(C0M_THREADS) void conv0_fwd_mfma_kernel(const float* __restrict__ feat, long sb, long st,
+                                                                    long sm, const float* __restrict__ w0,
+                                                                    float* __restrict__ s0, unsigned short* __restrict__ mask0,
+                                                                    int B, int T, int M, int H) {
     HIP_DYNAMIC_SHARED(float, lds)
-    float* tin = lds;                       // (T+2) x (M+2)
-    float* lw = lds + (T + 2) * (M + 4);    // 405 weights
+    float* tin = lds;  // (T+2) x (M+4), zero halo (+ 16 floats of slack for the padding cells of the last block)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int pitch = M + 4;
     const int P = H * PW;
-    for (int i = tid; i < NMAP * 9; i += C0_THREADS) lw[i] = w0[i];
+    const int g = lane >> 4, n = lane & 15;
+    // B fragments: B[k = tap = 4ks + g][col = cout = 16nt + n]
+    float bw[3][3];
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks)
+#pragma unroll
+        for (int nt = 0; nt < 3; ++nt) {
+            const int tap = 4 * ks + g, c = 16 * nt + n;
+            bw[ks][nt] = (tap < 9 && c < NMAP) ? w0[c * 9 + tap] : 0.0f;
+        }
+    // A fragments: A[row i = n][k = tap = 4ks + g] = tin[frame 3ph + tl + tap/3][mel 16blk + i + tap%3]  (halo origin)
+    int aoff[3];
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks) {
+        const int tap = min(4 * ks + g, 8);  // taps 9..11 meet zero weights: any finite value will do
+        aoff[ks] = (tap / 3) * pitch + tap % 3 + n;
+    }
+    if (tid < 16) tin[(T + 2) * pitch + tid] = 0.0f;  // slack read by the padding cells
     for (int b = blockIdx.x; b < B; b += gridDim.x) {
         __syncthreads();
-        load_feat_tile(tin, feat, sb, st, sm, b, T, M, tid, C0_THREADS);
+        load_feat_tile(tin, feat, sb, st, sm, b, T, M, tid, C0M_THREADS);
         __syncthreads();
-        for (int p = lane; p < P; p += 64) {
-            const int ph = p / PW, pw = p - ph * PW;
-            float patch[5][6];
-            load_patch(tin, pitch, ph, pw, patch);
-#pragma unroll 2
-            for (int c = wave; c < NMAP; c += C0_THREADS / 64) {   // two channels in flight (all of them blows the register file)
-                float wk[9];
+        for (int ph = wave; ph < H; ph += C0M_THREADS / 64) {
+            const float* rowp = tin + 3 * ph * pitch;
 #pragma unroll
-                for (int k = 0; k < 9; ++k) wk[k] = lw[c * 9 + k];
-                float sum = 0.0f;
-                unsigned bits = 0;   // bit (4i + j): pre-pool activation (3ph + i, 4pw + j) is positive
+            for (int blk = 0; blk < 3; ++blk) {
+                f32x4 acc[3][3];  // [frame tl][cout tile nt]
 #pragma unroll
-                for (int i = 0; i < 3; ++i)
+                for (int tl = 0; tl < 3; ++tl)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        float z = 0.0f;
+                    for (int nt = 0; nt < 3; ++nt) acc[tl][nt] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-                        for (int kh = 0; kh < 3; ++kh)
+                for (int tl = 0; tl < 3; ++tl)
 #pragma unroll
-                            for (int kw = 0; kw < 3; ++kw) z = fmaf(patch[i + kh][j + kw], wk[kh * 3 + kw], z);
-                        sum += fmaxf(z, 0.0f);
-                        bits |= (z > 0.0f ? 1u : 0u) << (4 * i + j);
+                    for (int ks = 0; ks < 3; ++ks) {
+                        const float a = rowp[aoff[ks] + tl * pitch + 16 * blk];
+#pragma unroll
+                        for (int nt = 0; nt < 3; ++nt)
+                            acc[tl][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bw[ks][nt], acc[tl][nt], 0, 0, 0);
                     }
-                s0[((size_t)b * NMAP + c) * P + p] = sum * (1.0f / 12.0f);
-                if (mask0 != nullptr) mask0[((size_t)b * NMAP + c) * P + p] = (unsigned short)bits;
+                const int pw = 4 * blk + g;  // this lane's cell
+#pragma unroll
+                for (int nt = 0; nt < 3; ++nt) {
+                    float sum = 0.0f;
+                    unsigned bits = 0;  // bit (4 tl + fl): pre-pool activation (3ph + tl, 4pw + fl) is positive
+#pragma unroll
+                    for (int tl = 0; tl < 3; ++tl)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float z = acc[tl][nt][r];
+                            sum += fmaxf(z, 0.0f);
+                            bits |= (z > 0.0f ? 1u : 0u) << (4 * tl + r);
+                        }
+                    const int c = 16 * nt + n;
+                    if (pw < PW && c < NMAP) {
+                        const size_t o = ((size_t)b * NMAP + c) * P + (size_t)ph * PW + pw;
+                        s0[o] = sum * (1.0f / 12.0f);
+                        if (mask0 != nullptr) mask0[o] = (unsigned short)bits;
+                    }
+                }
             }
         }
     }
 }
 
-// dW0[c][tap] = sum_{b, pooled pos, 3x4 window} (dy0/12) * [z > 0] * in[...],  dy0 = ga + gb (dx0 from layer 1 + skip).
-// The ReLU pattern of the pre-pool activation comes from the forward's 12-bit masks (2 B per pooled output instead of
-// the 583 KB/utterance tensor or a recomputation).  A wave walks its 5 channels one at a time (9 accumulators live),
-// folds them across lanes per utterance and keeps the running sums in LDS.
-__global__ __launch_bounds__(C0W_THREADS) void conv0_wgrad_kernel(const float* __restrict__ feat, long sb, long st, long sm,
-                                                                 const unsigned short* __restrict__ mask0,
-                                                                 const float* __restrict__ ga, const float* __restrict__ gb,
-                                                                 float* __restrict__ part, int B, int T, int M, int H) {
+__global__ __launch_bounds__(C0M_THREADS) void conv0_wgrad_mfma_kernel(const float* __restrict__ feat, long sb, long st,
+                                                                      long sm, const unsigned short* __restrict__ mask0,
+                                                                      const float* __restrict__ ga, const float* __restrict__ gb,
+                                                                      float* __restrict__ part, int B, int T, int M, int H) {
     HIP_DYNAMIC_SHARED(float, lds)
     float* tin = lds;
-    float* lacc = lds + (T + 2) * (M + 4);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int pitch = M + 4;
     const int P = H * PW;
-    float* lg = lacc + NMAP * 9;                                               // (45, P) pooled gradients / 12
-    unsigned short* lm = reinterpret_cast<unsigned short*>(lg + NMAP * P);     // (45, P) ReLU masks
-    for (int i = tid; i < NMAP * 9; i += C0W_THREADS) lacc[i] = 0.0f;
+    float* lg = lds + (T + 2) * pitch;                                          // (45, P) pooled gradients / 12
+    unsigned short* lm = reinterpret_cast<unsigned short*>(lg + NMAP * P);      // (45, P) ReLU masks
+    float* red = reinterpret_cast<float*>(lm + NMAP * P + (NMAP * P & 1));      // [8 waves][48][16]
+    const int g = lane >> 4, n = lane & 15;
+    // B fragments: B[k = position 4ks + g -> (tl = ks, fl = g)][col = tap n] = patch[ks + n/3][g + n%3]
+    int boff[3];
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks) {
+        const int tap = min(n, 8);   // columns 9..15 are padding (results unused)
+        boff[ks] = (ks + tap / 3) * pitch + g + tap % 3;
+    }
+    f32x4 acc[3];
+#pragma unroll
+    for (int mt = 0; mt < 3; ++mt) acc[mt] = {0.0f, 0.0f, 0.0f, 0.0f};
     for (int b = blockIdx.x; b < B; b += gridDim.x) {
         __syncthreads();
-        load_feat_tile(tin, feat, sb, st, sm, b, T, M, tid, C0W_THREADS);
-        // the utterance's gradients and masks are staged in bulk (coalesced, all loads in flight together); reading
-        // them one dependent global load per inner-loop iteration was latency-bound
+        load_feat_tile(tin, feat, sb, st, sm, b, T, M, tid, C0M_THREADS);
         const size_t ub = (size_t)b * NMAP * P;
-        for (int i0 = tid; i0 < NMAP * P; i0 += 8 * C0W_THREADS) {
+        for (int i0 = tid; i0 < NMAP * P; i0 += 8 * C0M_THREADS) {   // bulk, coalesced, 8 loads in flight per thread
             float va[8], vb[8];
             unsigned short vm[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const int i = i0 + j * C0W_THREADS;
+                const int i = i0 + j * C0M_THREADS;
                 const bool ok = i < NMAP * P;
                 va[j] = ok ? ga[ub + i] : 0.0f;
                 vb[j] = (ok && gb != nullptr) ? gb[ub + i] : 0.0f;
@@ -893,7 +924,7 @@ __global__ __launch_bounds__(C0W_THREADS) void conv0_wgrad_kernel(const float* _
             }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const int i = i0 + j * C0W_THREADS;
+                const int i = i0 + j * C0M_THREADS;
                 if (i < NMAP * P) {
                     lg[i] = (va[j] + vb[j]) * (1.0f / 12.0f);
                     lm[i] = vm[j];
@@ -901,38 +932,40 @@ __global__ __launch_bounds__(C0W_THREADS) void conv0_wgrad_kernel(const float* _
             }
         }
         __syncthreads();
-#pragma unroll 1
-        for (int cc = 0; cc < C0_GROUP; ++cc) {
-            const int c = wave * C0_GROUP + cc;
-            float gw[9];
+        for (int cell = wave; cell < P; cell += C0M_THREADS / 64) {
+            const int ph = cell / PW, pw = cell - ph * PW;
+            const float* base = tin + 3 * ph * pitch + 4 * pw;
+            float bfr[3];
 #pragma unroll
-            for (int k = 0; k < 9; ++k) gw[k] = 0.0f;
-            for (int p = lane; p < P; p += 64) {
-                const int ph = p / PW, pw = p - ph * PW;
-                float patch[5][6];
-                load_patch(tin, pitch, ph, pw, patch);
-                const float g = lg[c * P + p];
-                const unsigned bits = lm[c * P + p];
+            for (int ks = 0; ks < 3; ++ks) bfr[ks] = base[boff[ks]];
 #pragma unroll
-                for (int i = 0; i < 3; ++i)
+            for (int mt = 0; mt < 3; ++mt) {
+                // A[row = cout 16mt + n][k = position 4ks + g] = g[cout][cell] where that pre-pool activation was positive
+                const int c = 16 * mt + n;
+                const float gv = (c < NMAP) ? lg[c * P + cell] : 0.0f;
+                const unsigned mb = (c < NMAP) ? (unsigned)lm[c * P + cell] : 0u;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const float gz = ((bits >> (4 * i + j)) & 1u) ? g : 0.0f;
-#pragma unroll
-                        for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-                            for (int kw = 0; kw < 3; ++kw) gw[kh * 3 + kw] = fmaf(gz, patch[i + kh][j + kw], gw[kh * 3 + kw]);
-                    }
-            }
-#pragma unroll
-            for (int k = 0; k < 9; ++k) {
-                const float v = wave_sum(gw[k]);
-                if (lane == 0) lacc[c * 9 + k] += v;  // channel c belongs to this wave only
+                for (int ks = 0; ks < 3; ++ks) {
+                    const float a = ((mb >> (4 * ks + g)) & 1u) ? gv : 0.0f;
+                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bfr[ks], acc[mt], 0, 0, 0);
+                }
             }
         }
     }
+    // D[row = cout 16mt + 4g + r][col = tap n]: fold the 8 waves in a fixed order
     __syncthreads();
-    for (int i = tid; i < NMAP * 9; i += C0W_THREADS) part[(size_t)blockIdx.x * NMAP * 9 + i] = lacc[i];
+#pragma unroll
+    for (int mt = 0; mt < 3; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[(wave * CP + 16 * mt + 4 * g + r) * 16 + n] = acc[mt][r];
+    __syncthreads();
+    for (int i = tid; i < NMAP * 9; i += C0M_THREADS) {
+        const int c = i / 9, tap = i - 9 * c;
+        float sum = 0.0f;
+#pragma unroll
+        for (int w = 0; w < C0M_THREADS / 64; ++w) sum += red[(w * CP + c) * 16 + tap];
+        part[(size_t)blockIdx.x * NMAP * 9 + i] = sum;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1073,10 +1106,10 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
 
 size_t conv_lds_bytes(int H) { return (size_t)(3 * KSTEPS * 64 + tile_floats(H) + 2 * CP + 12 * 2 * 16) * sizeof(float); }
 size_t wgrad_lds_bytes(int H) { return (size_t)(2 * tile_floats(H) + 2 * CP) * sizeof(float); }
-size_t conv0_lds_bytes(int T, int M) { return (size_t)((T + 2) * (M + 4) + 2 * NMAP * 9) * sizeof(float); }
-size_t conv0_wgrad_lds_bytes(int T, int M) {
-    const int P = (T / 3) * PW;
-    return conv0_lds_bytes(T, M) + (size_t)NMAP * P * (sizeof(float) + sizeof(unsigned short)) + 16;
+size_t conv0_wgrad_mfma_lds_bytes(int T, int M) {
+    const int P = ((T / 3)) * PW;
+    return (size_t)(T + 2) * (M + 4) * sizeof(float) + (size_t)NMAP * P * sizeof(float) +
+           (size_t)(NMAP * P + 1) * sizeof(unsigned short) + (size_t)(C0M_THREADS / 64) * CP * 16 * sizeof(float) + 16;
 }
 
 struct Ws {
@@ -1160,10 +1193,11 @@ int howl_res8_fwd(const HowlRes8Params* prm, const float* feat, long sb, long st
                        w.wp_bwd);
     if (!training) hipLaunchKernelGGL(bn_eval_stats_kernel, dim3(6), dim3(64), 0, stream, rm, rv, sv->bn_stats);
 
-    const size_t l0 = conv0_lds_bytes(T, M);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(conv0_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l0);
-    hipLaunchKernelGGL(conv0_fwd_kernel, dim3(G), dim3(C0_THREADS), l0, stream, feat, sb, st, sm, prm->conv0_w, sv->s[0],
-                       sv->mask0, B, T, M, H);
+    const size_t l0 = ((size_t)(T + 2) * (M + 4) + 16) * sizeof(float);
+    // 103 VGPRs and 15 KB of LDS: two workgroups per CU overlap one's tile load / stores with the other's MFMAs
+    const int G0 = B < 2 * howl_num_cus() ? B : 2 * howl_num_cus();
+    hipLaunchKernelGGL(conv0_fwd_mfma_kernel, dim3(G0), dim3(C0M_THREADS), l0, stream, feat, sb, st, sm, prm->conv0_w,
+                       sv->s[0], sv->mask0, B, T, M, H);
     const size_t lc = conv_lds_bytes(H);
     hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_mfma_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
                         (int)lc);
@@ -1260,12 +1294,11 @@ int howl_res8_bwd(const HowlRes8Params* prm, const float* feat, long sb, long st
         dx_next = (dx_next == w.bufa) ? w.bufb : w.bufa;
     }
     // conv0: dy0 = dx_0 (from layer 1's dgrad) + ds_2 (skip into s_2 = y_2 + y_0)
-    const size_t l0 = conv0_lds_bytes(T, M);
-    const size_t l0w = conv0_wgrad_lds_bytes(T, M);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(conv0_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+    const size_t l0w = conv0_wgrad_mfma_lds_bytes(T, M);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(conv0_wgrad_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                         (int)l0w);
     HOWL_REQUIRE(sv->mask0 != nullptr, "howl_res8_bwd: saved->mask0 is required");
-    hipLaunchKernelGGL(conv0_wgrad_kernel, dim3(G), dim3(C0W_THREADS), l0w, stream, feat, sb, st, sm,
+    hipLaunchKernelGGL(conv0_wgrad_mfma_kernel, dim3(G), dim3(C0M_THREADS), l0w, stream, feat, sb, st, sm,
                        (const unsigned short*)sv->mask0,
                        (const float*)dx_cur, (const float*)ds_prev, w.c0part, B, T, M, H);
     hipLaunchKernelGGL(reduce_rows_kernel, dim3((NMAP * 9 + 63) / 64), dim3(256), 0, stream, (const float*)w.c0part, G,
