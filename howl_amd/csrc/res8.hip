@@ -884,7 +884,9 @@ __global__ __launch_bounds__(C0M_THREADS) void conv0_fwd_mfma_kernel(const float
     }
 }
 
-__global__ __launch_bounds__(C0M_THREADS) void conv0_wgrad_mfma_kernel(const float* __restrict__ feat, long sb, long st,
+constexpr int C0W_THREADS = 1024;  // weight gradient: 16 waves, four per SIMD (this kernel is bound by LDS / VALU latency per cell)
+
+__global__ __launch_bounds__(C0W_THREADS) void conv0_wgrad_mfma_kernel(const float* __restrict__ feat, long sb, long st,
                                                                       long sm, const unsigned short* __restrict__ mask0,
                                                                       const float* __restrict__ ga, const float* __restrict__ gb,
                                                                       float* __restrict__ part, int B, int T, int M, int H) {
@@ -895,7 +897,7 @@ __global__ __launch_bounds__(C0M_THREADS) void conv0_wgrad_mfma_kernel(const flo
     const int P = H * PW;
     float* lg = lds + (T + 2) * pitch;                                          // (45, P) pooled gradients / 12
     unsigned short* lm = reinterpret_cast<unsigned short*>(lg + NMAP * P);      // (45, P) ReLU masks
-    float* red = reinterpret_cast<float*>(lm + NMAP * P + (NMAP * P & 1));      // [8 waves][48][16]
+    float* red = reinterpret_cast<float*>(lm + NMAP * P + (NMAP * P & 1));      // [16 waves][48][16]
     const int g = lane >> 4, n = lane & 15;
     // B fragments: B[k = position 4ks + g -> (tl = ks, fl = g)][col = tap n] = patch[ks + n/3][g + n%3]
     int boff[3];
@@ -909,14 +911,14 @@ __global__ __launch_bounds__(C0M_THREADS) void conv0_wgrad_mfma_kernel(const flo
     for (int mt = 0; mt < 3; ++mt) acc[mt] = {0.0f, 0.0f, 0.0f, 0.0f};
     for (int b = blockIdx.x; b < B; b += gridDim.x) {
         __syncthreads();
-        load_feat_tile(tin, feat, sb, st, sm, b, T, M, tid, C0M_THREADS);
+        load_feat_tile(tin, feat, sb, st, sm, b, T, M, tid, C0W_THREADS);
         const size_t ub = (size_t)b * NMAP * P;
-        for (int i0 = tid; i0 < NMAP * P; i0 += 8 * C0M_THREADS) {   // bulk, coalesced, 8 loads in flight per thread
+        for (int i0 = tid; i0 < NMAP * P; i0 += 8 * C0W_THREADS) {   // bulk, coalesced, 8 loads in flight per thread
             float va[8], vb[8];
             unsigned short vm[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const int i = i0 + j * C0M_THREADS;
+                const int i = i0 + j * C0W_THREADS;
                 const bool ok = i < NMAP * P;
                 va[j] = ok ? ga[ub + i] : 0.0f;
                 vb[j] = (ok && gb != nullptr) ? gb[ub + i] : 0.0f;
@@ -924,7 +926,7 @@ __global__ __launch_bounds__(C0M_THREADS) void conv0_wgrad_mfma_kernel(const flo
             }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const int i = i0 + j * C0M_THREADS;
+                const int i = i0 + j * C0W_THREADS;
                 if (i < NMAP * P) {
                     lg[i] = (va[j] + vb[j]) * (1.0f / 12.0f);
                     lm[i] = vm[j];
@@ -932,7 +934,7 @@ __global__ __launch_bounds__(C0M_THREADS) void conv0_wgrad_mfma_kernel(const flo
             }
         }
         __syncthreads();
-        for (int cell = wave; cell < P; cell += C0M_THREADS / 64) {
+        for (int cell = wave; cell < P; cell += C0W_THREADS / 64) {
             const int ph = cell / PW, pw = cell - ph * PW;
             const float* base = tin + 3 * ph * pitch + 4 * pw;
             float bfr[3];
@@ -959,11 +961,11 @@ __global__ __launch_bounds__(C0M_THREADS) void conv0_wgrad_mfma_kernel(const flo
 #pragma unroll
         for (int r = 0; r < 4; ++r) red[(wave * CP + 16 * mt + 4 * g + r) * 16 + n] = acc[mt][r];
     __syncthreads();
-    for (int i = tid; i < NMAP * 9; i += C0M_THREADS) {
+    for (int i = tid; i < NMAP * 9; i += C0W_THREADS) {
         const int c = i / 9, tap = i - 9 * c;
         float sum = 0.0f;
 #pragma unroll
-        for (int w = 0; w < C0M_THREADS / 64; ++w) sum += red[(w * CP + c) * 16 + tap];
+        for (int w = 0; w < C0W_THREADS / 64; ++w) sum += red[(w * CP + c) * 16 + tap];
         part[(size_t)blockIdx.x * NMAP * 9 + i] = sum;
     }
 }
@@ -1109,7 +1111,7 @@ size_t wgrad_lds_bytes(int H) { return (size_t)(2 * tile_floats(H) + 2 * CP) * s
 size_t conv0_wgrad_mfma_lds_bytes(int T, int M) {
     const int P = ((T / 3)) * PW;
     return (size_t)(T + 2) * (M + 4) * sizeof(float) + (size_t)NMAP * P * sizeof(float) +
-           (size_t)(NMAP * P + 1) * sizeof(unsigned short) + (size_t)(C0M_THREADS / 64) * CP * 16 * sizeof(float) + 16;
+           (size_t)(NMAP * P + 1) * sizeof(unsigned short) + (size_t)(C0W_THREADS / 64) * CP * 16 * sizeof(float) + 16;
 }
 
 struct Ws {
@@ -1298,7 +1300,7 @@ int howl_res8_bwd(const HowlRes8Params* prm, const float* feat, long sb, long st
     hipFuncSetAttribute(reinterpret_cast<const void*>(conv0_wgrad_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                         (int)l0w);
     HOWL_REQUIRE(sv->mask0 != nullptr, "howl_res8_bwd: saved->mask0 is required");
-    hipLaunchKernelGGL(conv0_wgrad_mfma_kernel, dim3(G), dim3(C0M_THREADS), l0w, stream, feat, sb, st, sm,
+    hipLaunchKernelGGL(conv0_wgrad_mfma_kernel, dim3(G), dim3(C0W_THREADS), l0w, stream, feat, sb, st, sm,
                        (const unsigned short*)sv->mask0,
                        (const float*)dx_cur, (const float*)ds_prev, w.c0part, B, T, M, H);
     hipLaunchKernelGGL(reduce_rows_kernel, dim3((NMAP * 9 + 63) / 64), dim3(256), 0, stream, (const float*)w.c0part, G,
