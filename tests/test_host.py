@@ -126,3 +126,21 @@ def test_device_collate_mixer_draws_match_reference(golden):
             mixed = wf * np.float32(1 - alpha[i]) + bg * np.float32(alpha[i]) if alpha[i] else wf
             sub = np.concatenate([mixed[:8], mixed[8:-8:61], mixed[-8:]])
             np.testing.assert_allclose(sub, g[f"mixed_{trial}_{i}"], rtol=0, atol=2e-6)
+
+
+def test_export_honkling_wire_format(tmp_path):
+    """export_honkling.py:19-35: `weights['RES8'] = {json of the state_dict + unit scale vectors}` with the reference's keys."""
+    import json
+    from howl_amd.training.run import export_honkling
+    from oracle import models as om
+    sd = om.res8_init(12)
+    src, dst = tmp_path / "model-best.pt.bin", tmp_path / "w.js"
+    torch.save(sd, src)
+    export_honkling.main(["-i", str(src), "-o", str(dst), "--name", "RES8"])
+    text = dst.read_text()
+    prefix = "weights['RES8'] = "
+    assert text.startswith(prefix)
+    d = json.loads(text[len(prefix):])
+    assert set(d) == set(sd) | {"scale1.scale", "scale3.scale", "scale5.scale"}
+    assert d["scale3.scale"] == [1.0] * 45
+    assert np.allclose(np.array(d["conv3.weight"], np.float32), sd["conv3.weight"].numpy())
