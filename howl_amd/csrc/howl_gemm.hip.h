@@ -19,7 +19,10 @@ struct RowMap {
     int inner;
     long s_outer, s_inner;
 };
-__device__ __forceinline__ long rmap(const RowMap& r, int x) { return (long)(x / r.inner) * r.s_outer + (long)(x % r.inner) * r.s_inner; }
+__device__ __forceinline__ long rmap(const RowMap& r, int x) {
+    if (r.inner >= (1 << 30)) return (long)x * r.s_inner;   // plain stride (uniform branch): no integer division
+    return (long)(x / r.inner) * r.s_outer + (long)(x % r.inner) * r.s_inner;
+}
 
 constexpr int GT = 64, GK = 16, GLD = 80;  // tile edge, k depth, LDS row stride (80 = 16 mod 32: conflict-free frags)
 
@@ -101,11 +104,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(const float* __restrict__ a, 
 // Fast path of the same GEMM for plain strided matrices whose unit-stride extents are multiples of 4 floats (every
 // MobileNet 1x1 convolution and weight gradient, the LSTM projections): operands move as 16-byte vectors, one per
 // thread and tile, and the next K tile is requested before the MFMAs of the current one (register double buffering).
-//   A_UNIT_K: A(m,k) = a[m*lda + k]   else a[k*lda + m]
-//   B_UNIT_K: B(k,n) = b[n*ldb + k]   else b[k*ldb + n]
+//   A_UNIT_K: A(m,k) = a[amap(m) + k]   else a[amap(k) + m]      (amap / bmap: two-level row maps, strides multiples of 4)
+//   B_UNIT_K: B(k,n) = b[bmap(n) + k]   else b[bmap(k) + n]
 template <bool A_UNIT_K, bool B_UNIT_K>
-__global__ __launch_bounds__(256) void gemm_vec_kernel(const float* __restrict__ a, long lda, const float* __restrict__ b,
-                                                       long ldb, int M, int N, int K, int k_per_split,
+__global__ __launch_bounds__(256) void gemm_vec_kernel(const float* __restrict__ a, RowMap amap, const float* __restrict__ b,
+                                                       RowMap bmap, int M, int N, int K, int k_per_split,
                                                        const float* __restrict__ bias, int relu, float* __restrict__ c,
                                                        long c_ms, long c_split_stride) {
     __shared__ float As[GK * GLD];
@@ -120,12 +123,12 @@ __global__ __launch_bounds__(256) void gemm_vec_kernel(const float* __restrict__
     const int b_r = B_UNIT_K ? tid >> 2 : (tid & 15) * 4, b_k = B_UNIT_K ? (tid & 3) * 4 : tid >> 4;
     auto fetch_a = [&](int k0) -> float4 {
         const int m = m0 + a_r, k = k0 + a_k;
-        if (m < M && k < kend) return *reinterpret_cast<const float4*>(A_UNIT_K ? a + (long)m * lda + k : a + (long)k * lda + m);
+        if (m < M && k < kend) return *reinterpret_cast<const float4*>(A_UNIT_K ? a + rmap(amap, m) + k : a + rmap(amap, k) + m);
         return make_float4(0.f, 0.f, 0.f, 0.f);
     };
     auto fetch_b = [&](int k0) -> float4 {
         const int n = n0 + b_r, k = k0 + b_k;
-        if (n < N && k < kend) return *reinterpret_cast<const float4*>(B_UNIT_K ? b + (long)n * ldb + k : b + (long)k * ldb + n);
+        if (n < N && k < kend) return *reinterpret_cast<const float4*>(B_UNIT_K ? b + rmap(bmap, n) + k : b + rmap(bmap, k) + n);
         return make_float4(0.f, 0.f, 0.f, 0.f);
     };
     f32x4 acc[2][2];
@@ -222,8 +225,16 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
     const int r0 = blockIdx.y * rows_per_chunk;
     const int r1 = min(rows, r0 + rows_per_chunk);
     double s = 0.0;
-    if (col < n)
-        for (int r = r0 + rg; r < r1; r += 4) s += (double)x[rmap(rm, r) + col];
+    if (col < n) {
+        double s4[4] = {0.0, 0.0, 0.0, 0.0};   // four independent loads in flight (a dependent one-load loop is latency-bound)
+        int r = r0 + rg;
+        for (; r + 12 < r1; r += 16) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) s4[u] += (double)x[rmap(rm, r + 4 * u) + col];
+        }
+        for (; r < r1; r += 4) s4[0] += (double)x[rmap(rm, r) + col];
+        s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+    }
     red[rg][lane] = s;
     __syncthreads();
     if (rg == 0 && col < n)
@@ -245,23 +256,27 @@ __global__ void relu_bwd_kernel(const float* __restrict__ dy, const float* __res
 constexpr int BIG = 1 << 30;
 inline RowMap lin(long stride) { return RowMap{BIG, 0, stride}; }
 inline bool is_lin(const RowMap& r) { return r.inner == BIG; }
-inline bool vec_ok(const float* p, long ld) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0 && (ld & 3) == 0; }
 
 int gemm(hipStream_t s, bool a_major_k, const float* a, RowMap am, long a_ks, RowMap ak, const float* b, RowMap bk, long b_ns,
          int M, int N, int K, int splits, const float* bias, int relu, float* c, long c_ms, long c_split_stride) {
     const int kps = ((K + splits - 1) / splits + GK - 1) / GK * GK;
     dim3 grid((N + GT - 1) / GT, (M + GT - 1) / GT, (K + kps - 1) / kps);
-    // plain strided operands with 16-byte-aligned unit-stride runs take the vector kernel
-    if (is_lin(am) && is_lin(bk) && (a_major_k ? a_ks == 1 : (is_lin(ak) && am.s_inner == 1))) {
-        const long lda = a_major_k ? am.s_inner : ak.s_inner;
-        const bool b_unit_k = bk.s_inner == 1 && b_ns != 1;
+    // operands whose unit-stride runs are 16-byte aligned multiples of 4 floats take the vector kernel
+    {
+        auto map_ok = [](const RowMap& r) { return (r.s_outer & 3) == 0 && (r.s_inner & 3) == 0; };
+        auto aligned = [](const float* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+        // A: unit stride along k (a_major_k, rows mapped by am) or along m (am == lin(1), k mapped by ak)
+        const bool a_fits = aligned(a) && (a_major_k ? (a_ks == 1 && map_ok(am) && (K & 3) == 0)
+                                                     : (is_lin(am) && am.s_inner == 1 && map_ok(ak) && (M & 3) == 0));
+        // B: unit stride along k (bk == lin(1), column stride b_ns) or along n (b_ns == 1, k mapped by bk)
+        const bool b_unit_k = is_lin(bk) && bk.s_inner == 1 && b_ns != 1;
         const bool b_unit_n = b_ns == 1;
-        const long ldb = b_unit_k ? b_ns : bk.s_inner;
-        const bool a_fits = vec_ok(a, lda) && (a_major_k ? (K & 3) == 0 : (M & 3) == 0);
-        const bool b_fits = (b_unit_k || b_unit_n) && vec_ok(b, ldb) && (b_unit_k ? (K & 3) == 0 : (N & 3) == 0);
-        if (a_fits && b_fits && (b_unit_k ? true : b_unit_n)) {
-#define HOWL_GEMM_VEC(AK, BK)                                                                                            \
-    hipLaunchKernelGGL((gemm_vec_kernel<AK, BK>), grid, dim3(256), 0, s, a, lda, b, ldb, M, N, K, kps, bias, relu, c, c_ms, \
+        const bool b_fits = aligned(b) && (b_unit_k ? ((b_ns & 3) == 0 && (K & 3) == 0) : (b_unit_n && map_ok(bk) && (N & 3) == 0));
+        if (a_fits && b_fits) {
+            const RowMap amap = a_major_k ? am : ak;
+            const RowMap bmap = b_unit_k ? lin(b_ns) : bk;
+#define HOWL_GEMM_VEC(AK, BK)                                                                                              \
+    hipLaunchKernelGGL((gemm_vec_kernel<AK, BK>), grid, dim3(256), 0, s, a, amap, b, bmap, M, N, K, kps, bias, relu, c, c_ms, \
                        c_split_stride)
             if (a_major_k && b_unit_k) HOWL_GEMM_VEC(true, true);
             else if (a_major_k) HOWL_GEMM_VEC(true, false);
@@ -296,7 +311,7 @@ void wgrad_gemm(hipStream_t s, const float* dout, RowMap dm, int n_out, const fl
 // out0 (and out1) = column sums of x over `rows` mapped rows; scratch holds <= 64 * n floats
 void colsum(hipStream_t s, const float* x, RowMap rm, int rows, int n, float* scratch, float* out0, float* out1) {
     int chunks = rows / 256;
-    chunks = chunks < 1 ? 1 : (chunks > 64 ? 64 : chunks);
+    chunks = chunks < 1 ? 1 : (chunks > 64 ? 64 : chunks);   // scratch holds <= 64 slabs
     const int rpc = (rows + chunks - 1) / chunks;
     hipLaunchKernelGGL(colsum_kernel, dim3((n + 63) / 64, chunks), dim3(256), 0, s, x, rm, rows, n, rpc, scratch);
     hipLaunchKernelGGL(sum_slabs_kernel, dim3((n + 63) / 64), dim3(256), 0, s, (const float*)scratch, chunks, (long)n, out0);
