@@ -60,9 +60,31 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(const float* __r
                                                                 float* __restrict__ gates, float* __restrict__ cs,
                                                                 float* __restrict__ hseq, float* __restrict__ hT,
                                                                 float* __restrict__ cT, int B, int T, int Tout) {
-    __shared__ float hbuf[2][16 * HS];
+    HIP_DYNAMIC_SHARED(float, lds_fwd)   // 115 KB: above the static limit
+    float (*hbuf)[16 * HS] = reinterpret_cast<float (*)[16 * HS]>(lds_fwd);
+    // Saved activations of a step (gates i,f,g,o | c | h: 768 floats per sequence) are collected in LDS and written out by
+    // all 1024 threads as three 16-byte stores each during the NEXT step's MFMAs.  Written straight from the owner lanes
+    // they were 24 scattered 4-byte stores per lane and step -- ~400 store instructions per CU and step, more
+    // vector-memory issue time than the step's matrix work.
+    constexpr int SROW = 6 * HID;
+    float (*sbuf)[16 * SROW] = reinterpret_cast<float (*)[16 * SROW]>(lds_fwd + 2 * 16 * HS);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b0 = blockIdx.x * 16;
+    auto flush = [&](int t, const float* sb) {   // step t's rows -> gates / cs / hseq
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int i4 = tid + i * LSTM_THREADS;          // float4 index: 16 rows x 192
+            const int row = i4 / (SROW / 4), c4 = i4 - row * (SROW / 4);
+            const int b = b0 + row;
+            if (b < B) {
+                const float4 v = *reinterpret_cast<const float4*>(sb + row * SROW + 4 * c4);
+                const size_t o = (size_t)b * T + t;
+                if (c4 < G4 / 4) *reinterpret_cast<float4*>(gates + o * G4 + 4 * c4) = v;
+                else if (c4 < (G4 + HID) / 4) *reinterpret_cast<float4*>(cs + o * HID + 4 * (c4 - G4 / 4)) = v;
+                else *reinterpret_cast<float4*>(hseq + ((size_t)b * (T + 1) + t + 1) * HID + 4 * (c4 - (G4 + HID) / 4)) = v;
+            }
+        }
+    };
     float wA[32], wB[32];
 #pragma unroll
     for (int kk = 0; kk < 32; ++kk) {
@@ -100,6 +122,8 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(const float* __r
     for (int t = 0; t < Tout; ++t) {
         const float* hcur = hbuf[t & 1];
         float* hnxt = hbuf[(t + 1) & 1];
+        float* scur = sbuf[t & 1];
+        if (t > 0) flush(t - 1, sbuf[(t - 1) & 1]);   // complete and visible since the barrier that ended step t-1
         f32x4 accA = nxA, accB = nxB;
         if (t + 1 < Tout) {
 #pragma unroll
@@ -132,19 +156,19 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(const float* __r
                     hst[r] = hn;
                 }
                 hnxt[(4 * (lane >> 4) + r) * HS + u] = hst[r];
-                if (b < B) {
-                    const size_t o = (size_t)b * T + t;
-                    gates[o * G4 + u] = ig;
-                    gates[o * G4 + HID + u] = fg;
-                    gates[o * G4 + 2 * HID + u] = gg;
-                    gates[o * G4 + 3 * HID + u] = og;
-                    cs[o * HID + u] = cn;
-                    hseq[((size_t)b * (T + 1) + t + 1) * HID + u] = live ? hn : 0.0f;   // padded outputs are zero
-                }
+                float* sr = scur + (4 * (lane >> 4) + r) * SROW + u;
+                sr[0] = ig;
+                sr[HID] = fg;
+                sr[2 * HID] = gg;
+                sr[3 * HID] = og;
+                sr[4 * HID] = cn;
+                sr[5 * HID] = live ? hn : 0.0f;   // padded outputs are zero
+                (void)b;
             }
         }
         __syncthreads();
     }
+    if (Tout > 0) flush(Tout - 1, sbuf[(Tout - 1) & 1]);
     if (owner)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -282,7 +306,9 @@ int howl_lstm_fwd(const HowlLstmParams* p, const float* x, int B, int T, int M, 
     gemm(stream, true, x, lin(M), 1, lin(0), p->w_ih, lin(1), M, B * T, G4, M, 1, bsum, 0, sv->gx, G4, 0);
     if (sv->t_out < T)   // rows of steps that never run are read (times zero) by the weight-gradient GEMM: keep them finite
         hipMemsetAsync(sv->hseq, 0, (size_t)B * (T + 1) * HID * sizeof(float), stream);
-    hipLaunchKernelGGL(lstm_fwd_kernel, dim3((B + 15) / 16), dim3(LSTM_THREADS), 0, stream, (const float*)sv->gx,
+    const size_t lds_fwd = (size_t)(2 * 16 * HS + 2 * 16 * 6 * HID) * sizeof(float);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fwd);
+    hipLaunchKernelGGL(lstm_fwd_kernel, dim3((B + 15) / 16), dim3(LSTM_THREADS), lds_fwd, stream, (const float*)sv->gx,
                        (const float*)pf, lengths, h0, c0, sv->gates, sv->c, sv->hseq, hT, cT, B, T, sv->t_out);
     HOWL_CHECK_LAUNCH("howl_lstm_fwd");
     return HOWL_OK;
