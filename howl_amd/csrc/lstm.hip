@@ -26,7 +26,16 @@ constexpr int LSTM_THREADS = 1024;   // 16 waves
 constexpr int HS = HID + 4;          // LDS row stride of the h tile (16 rows)
 constexpr int DGS = G4 + 4;          // LDS row stride of the dG tile
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+// Gate nonlinearities on the hardware exp2 / reciprocal (1 ulp each): the cell update sits on the critical path of every
+// one of the 38-81 sequential steps, and the library expf / tanhf / division cost ~10x the instructions.  Absolute error
+// ~1e-7, far inside the 2e-6 the parity tests hold the hidden states to.
+__device__ __forceinline__ float sigmoidf_(float x) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896341f * x));
+}
+__device__ __forceinline__ float tanhf_(float x) {
+    const float xc = fminf(fmaxf(x, -15.0f), 15.0f);   // exp2 stays finite; tanh is +-1 to fp32 precision beyond |x| = 9
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.88539008177792681f * xc));
+}
 
 // ---------------------------------------------------------------------------------------------------------
 // W_hh (512,128) -> register fragments.
@@ -92,20 +101,22 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(const float* __r
         wB[kk] = pf[((size_t)wave * 64 + 32 + kk) * 64 + lane];
     }
     const int n = lane & 15, u = 8 * wave + (n & 7);
-    const bool owner = n < 8;   // lanes with n < 8 own the cell state of unit u for rows 4*(lane>>4) + r
-    float cst[4], hst[4];
-    int len[4];
+    // Lane pair (l, l^8) holds the i|f and g|o pre-activations of unit u for rows 4*(lane>>4) + {0..3}.  Both lanes work
+    // on the cell update: the lane with n < 8 takes rows +0,+1, its partner rows +2,+3 (they swap the two gate values the
+    // other one needs), so the transcendental-heavy update costs half the instructions of an owner-lane-only scheme.
+    const bool hi = n >= 8;
+    float cst[2], hst[2];
+    int len[2];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int b = b0 + 4 * (lane >> 4) + r;
+    for (int q = 0; q < 2; ++q) {
+        const int row = 4 * (lane >> 4) + (hi ? 2 : 0) + q;
+        const int b = b0 + row;
         const bool vb = b < B;
-        cst[r] = (vb && c0 != nullptr) ? c0[(size_t)b * HID + u] : 0.0f;
-        hst[r] = (vb && h0 != nullptr) ? h0[(size_t)b * HID + u] : 0.0f;
-        len[r] = vb ? (lengths != nullptr ? (int)lengths[b] : T) : 0;
-        if (owner) {
-            hbuf[0][(4 * (lane >> 4) + r) * HS + u] = hst[r];
-            if (vb) hseq[((size_t)b * (T + 1)) * HID + u] = hst[r];
-        }
+        cst[q] = (vb && c0 != nullptr) ? c0[(size_t)b * HID + u] : 0.0f;
+        hst[q] = (vb && h0 != nullptr) ? h0[(size_t)b * HID + u] : 0.0f;
+        len[q] = vb ? (lengths != nullptr ? (int)lengths[b] : T) : 0;
+        hbuf[0][row * HS + u] = hst[q];
+        if (vb) hseq[((size_t)b * (T + 1)) * HID + u] = hst[q];
     }
     __syncthreads();
     const int colA = (n >> 3) * HID + u, colB = (2 + (n >> 3)) * HID + u;   // this lane's columns in tiles [i|f], [g|o]
@@ -142,42 +153,42 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(const float* __r
             accB = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wB[kk], accB, 0, 0, 0);
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float pf_ = __shfl_xor(accA[r], 8);   // owner lanes receive the f pre-activation of their unit
-            const float po_ = __shfl_xor(accB[r], 8);   // ... and o
-            if (owner) {
-                const int b = b0 + 4 * (lane >> 4) + r;
-                const bool live = t < len[r];
-                const float ig = sigmoidf_(accA[r]), fg = sigmoidf_(pf_), gg = tanhf(accB[r]), og = sigmoidf_(po_);
-                const float cn = fg * cst[r] + ig * gg;
-                const float hn = og * tanhf(cn);
-                if (live) {
-                    cst[r] = cn;
-                    hst[r] = hn;
-                }
-                hnxt[(4 * (lane >> 4) + r) * HS + u] = hst[r];
-                float* sr = scur + (4 * (lane >> 4) + r) * SROW + u;
-                sr[0] = ig;
-                sr[HID] = fg;
-                sr[2 * HID] = gg;
-                sr[3 * HID] = og;
-                sr[4 * HID] = cn;
-                sr[5 * HID] = live ? hn : 0.0f;   // padded outputs are zero
-                (void)b;
+        for (int q = 0; q < 2; ++q) {
+            // this lane updates row +(2 hi + q): it holds (i,g) [low lane] or (f,o) [high lane] of that row and receives
+            // the other pair from its partner, to which it sends its values of the partner's row
+            const float ownA = hi ? accA[2 + q] : accA[q], ownB = hi ? accB[2 + q] : accB[q];
+            const float sendA = hi ? accA[q] : accA[2 + q], sendB = hi ? accB[q] : accB[2 + q];
+            const float recvA = __shfl_xor(sendA, 8), recvB = __shfl_xor(sendB, 8);
+            const int row = 4 * (lane >> 4) + (hi ? 2 : 0) + q;
+            const bool live = t < len[q];
+            const float ig = sigmoidf_(hi ? recvA : ownA), fg = sigmoidf_(hi ? ownA : recvA);
+            const float gg = tanhf_(hi ? recvB : ownB), og = sigmoidf_(hi ? ownB : recvB);
+            const float cn = fg * cst[q] + ig * gg;
+            const float hn = og * tanhf_(cn);
+            if (live) {
+                cst[q] = cn;
+                hst[q] = hn;
             }
+            hnxt[row * HS + u] = hst[q];
+            float* sr = scur + row * SROW + u;
+            sr[0] = ig;
+            sr[HID] = fg;
+            sr[2 * HID] = gg;
+            sr[3 * HID] = og;
+            sr[4 * HID] = cn;
+            sr[5 * HID] = live ? hn : 0.0f;   // padded outputs are zero
         }
         __syncthreads();
     }
     if (Tout > 0) flush(Tout - 1, sbuf[(Tout - 1) & 1]);
-    if (owner)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int b = b0 + 4 * (lane >> 4) + r;
-            if (b < B) {
-                hT[(size_t)b * HID + u] = hst[r];
-                cT[(size_t)b * HID + u] = cst[r];
-            }
+    for (int q = 0; q < 2; ++q) {
+        const int b = b0 + 4 * (lane >> 4) + (hi ? 2 : 0) + q;
+        if (b < B) {
+            hT[(size_t)b * HID + u] = hst[q];
+            cT[(size_t)b * HID + u] = cst[q];
         }
+    }
 }
 
 // BPTT recurrence.  dy: (B,T,128) gradient w.r.t. the padded outputs h_t (nullptr: none); dhT/dcT: gradient w.r.t. the
@@ -242,7 +253,7 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_bwd_kernel(const float* __r
             if (live) {
                 const Step& st = cur[q];
                 dh += st.dyv;
-                const float tc = tanhf(st.cn);
+                const float tc = tanhf_(st.cn);
                 dov = dh * tc * st.og * (1.0f - st.og);
                 const float dct = dc[q] + dh * st.og * (1.0f - tc * tc);
                 di = dct * st.gg * st.ig * (1.0f - st.ig);

@@ -150,6 +150,7 @@ static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
 static inline float __fdividef(float a, float b) { return a / b; }
 static inline float __frcp_rn(float a) { return 1.0f / a; }
 static inline float __builtin_amdgcn_rcpf(float a) { return 1.0f / a; }
+static inline float __builtin_amdgcn_exp2f(float a) { return exp2f(a); }
 using std::max;
 using std::min;
 
