@@ -1032,17 +1032,36 @@ __global__ __launch_bounds__(1024) void head_bwd_param_kernel(const float* __res
     __shared__ double red[2][16][64];
     const int k = blockIdx.x, c = threadIdx.x & 63, bg = threadIdx.x >> 6;
     double a0 = 0.0, a1 = 0.0;
+    // four rows per iteration: the loads of a one-row-per-iteration loop are serialised by their own latency
     if (k < C) {
-        for (int b = bg; b < B; b += 16) {
-            const float d = dlogits[(size_t)b * C + k];
-            a1 += (double)d;
-            if (c < CP) a0 += (double)d * (double)pooled[(size_t)b * CP + c];
+        for (int b = bg; b < B; b += 64) {
+            float d[4], pv[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int bb = b + 16 * j;
+                d[j] = bb < B ? dlogits[(size_t)bb * C + k] : 0.0f;
+                pv[j] = (bb < B && c < CP) ? pooled[(size_t)bb * CP + c] : 0.0f;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                a1 += (double)d[j];
+                a0 += (double)d[j] * (double)pv[j];
+            }
         }
     } else if (c < CP) {
-        for (int b = bg; b < B; b += 16) {
-            const double d = (double)dpool[(size_t)b * CP + c];
-            a0 += d;
-            a1 += d * (double)pooled[(size_t)b * CP + c];
+        for (int b = bg; b < B; b += 64) {
+            float d[4], pv[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int bb = b + 16 * j;
+                d[j] = bb < B ? dpool[(size_t)bb * CP + c] : 0.0f;
+                pv[j] = bb < B ? pooled[(size_t)bb * CP + c] : 0.0f;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                a0 += (double)d[j];
+                a1 += (double)d[j] * (double)pv[j];
+            }
         }
     }
     red[0][bg][c] = a0;
@@ -1065,12 +1084,12 @@ __global__ __launch_bounds__(1024) void head_bwd_param_kernel(const float* __res
 }
 
 // mean cross-entropy and its gradient (pretrain_gsc.py:95,131; train.py:251,293): one workgroup
-__global__ __launch_bounds__(256) void xent_kernel(const float* __restrict__ logits, const long long* __restrict__ labels,
-                                                   int B, int C, float* __restrict__ loss, float* __restrict__ dlogits) {
-    __shared__ double red[4];
+__global__ __launch_bounds__(1024) void xent_kernel(const float* __restrict__ logits, const long long* __restrict__ labels,
+                                                    int B, int C, float* __restrict__ loss, float* __restrict__ dlogits) {
+    __shared__ double red[16];
     double acc = 0.0;
     const float invB = 1.0f / (float)B;
-    for (int b = threadIdx.x; b < B; b += 256) {
+    for (int b = threadIdx.x; b < B; b += 1024) {
         const float* row = logits + (size_t)b * C;
         float mx = row[0];
         for (int k = 1; k < C; ++k) mx = fmaxf(mx, row[k]);
@@ -1086,7 +1105,11 @@ __global__ __launch_bounds__(256) void xent_kernel(const float* __restrict__ log
     acc = wave_sum_d(acc);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) loss[0] = (float)((red[0] + red[1] + red[2] + red[3]) / (double)B);
+    if (threadIdx.x == 0) {
+        double tot = 0.0;
+        for (int w = 0; w < 16; ++w) tot += red[w];
+        loss[0] = (float)(tot / (double)B);
+    }
 }
 
 // fused flat AdamW (torch.optim.AdamW defaults; pretrain_gsc.py:93,133)
@@ -1313,7 +1336,7 @@ int howl_xent_fwd_bwd(const float* logits, const long long* labels, int B, int C
                       hipStream_t stream) {
     HOWL_REQUIRE(logits && labels && loss, "howl_xent_fwd_bwd: null pointer");
     HOWL_REQUIRE(B >= 1 && C >= 1, "howl_xent_fwd_bwd: bad shape");
-    hipLaunchKernelGGL(xent_kernel, dim3(1), dim3(256), 0, stream, logits, labels, B, C, loss, dlogits);
+    hipLaunchKernelGGL(xent_kernel, dim3(1), dim3(1024), 0, stream, logits, labels, B, C, loss, dlogits);
     HOWL_CHECK_LAUNCH("howl_xent_fwd_bwd");
     return HOWL_OK;
 }
