@@ -1,0 +1,47 @@
+"""Longer sanity runs on the GPU box: a few hundred fused steps of each trainable model on separable synthetic tones; the loss
+must fall, every parameter must stay finite, and a repeat from the same state must be bit-identical."""
+import os
+import sys
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+os.environ.setdefault("NUM_MELS", "40")
+import torch  # noqa: E402
+
+from howl_amd.data.transform.operator import ZmuvTransform  # noqa: E402
+from howl_amd.data.transform.transform import StandardAudioTransform  # noqa: E402
+from howl_amd.model import RegisteredModel  # noqa: E402
+from howl_amd.training.fused import FusedTrainer  # noqa: E402
+from howl_amd.utils.synth import synthetic_pcm  # noqa: E402
+
+dev = torch.device("cuda:0")
+for name, B, C, lr, steps in (("res8", 256, 12, 0.01, 300), ("mobilenet", 128, 12, 0.001, 150)):
+    finals = []
+    for rep in range(2):
+        torch.manual_seed(0)
+        pcm = synthetic_pcm(B, 16000).to(dev)              # tone frequency depends on b mod 64: labels are learnable
+        labels = (torch.arange(B) % C).to(dev)
+        std = StandardAudioTransform().to(dev).eval()
+        zmuv = ZmuvTransform().to(dev)
+        zmuv.update(std(pcm[:8]))
+        model = RegisteredModel.find_registered_class(name)(C).to(dev).train()
+        if name == "mobilenet":
+            model.dropout_p = 0.0
+        tr = FusedTrainer(model, std, zmuv, lr=lr)
+        losses = []
+        for i in range(steps):
+            loss = tr.step(pcm, labels)
+            if i % 25 == 0 or i == steps - 1:
+                losses.append(round(loss.item(), 4))
+        assert all(torch.isfinite(p).all() for p in model.parameters()), name
+        finals.append(tr.fp.flat.clone())
+        if rep == 0:
+            model.eval()
+            with torch.no_grad():
+                acc = (model(tr.features(pcm), None).argmax(1) == labels).float().mean().item()
+            print(f"{name}: loss {losses[0]} -> {losses[-1]} over {steps} steps (every 25th: {losses}); train-set accuracy in eval "
+                  f"mode {acc:.3f}", flush=True)
+            assert losses[-1] < 0.5 * losses[0], (name, losses)
+    print(f"{name}: repeat run bit-identical: {torch.equal(finals[0], finals[1])}", flush=True)
+    assert torch.equal(finals[0], finals[1])
+print("soak ok")
