@@ -254,6 +254,8 @@ __global__ void col2im3x3_kernel(const float* __restrict__ dcol, int H, int W, i
 }
 
 // depthwise 3x3, padding 1: z[b,oh,ow,c] = sum_tap w[c*9+tap] * x[b, oh*s-1+kh, ow*s-1+kw, c]
+// All nine taps are loaded unconditionally from clamped addresses and masked afterwards: a load inside an `if` is followed
+// by its own wait, which serialises nine HBM/L2 round trips per output (the forward of the largest layer ran at 1.4 TB/s).
 __global__ void dw3x3_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, int H, int W, int C, int Ho, int Wo,
                                  int stride, long total, float* __restrict__ z) {
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
@@ -263,18 +265,23 @@ __global__ void dw3x3_fwd_kernel(const float* __restrict__ x, const float* __res
         const long t = pix / Wo;
         const int oh = (int)(t % Ho);
         const long b = t / Ho;
-        float acc = 0.0f;
+        const float* xb = x + b * H * W * C + c;
+        float v[9], wk[9];
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh) {
             const int ih = oh * stride - 1 + kh;
-            if (ih < 0 || ih >= H) continue;
+            const int ihc = min(max(ih, 0), H - 1);
 #pragma unroll
             for (int kw = 0; kw < 3; ++kw) {
                 const int iw = ow * stride - 1 + kw;
-                if (iw < 0 || iw >= W) continue;
-                acc = fmaf(w[c * 9 + kh * 3 + kw], x[((b * H + ih) * W + iw) * C + c], acc);
+                const int iwc = min(max(iw, 0), W - 1);
+                v[kh * 3 + kw] = xb[((long)ihc * W + iwc) * C];
+                wk[kh * 3 + kw] = (ih == ihc && iw == iwc) ? w[c * 9 + kh * 3 + kw] : 0.0f;
             }
         }
+        float acc = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) acc = fmaf(wk[k], v[k], acc);
         z[idx] = acc;
     }
 }
@@ -288,22 +295,27 @@ __global__ void dw3x3_dgrad_kernel(const float* __restrict__ dz, const float* __
         const long t = pix / W;
         const int ih = (int)(t % H);
         const long b = t / H;
-        float acc = 0.0f;
+        const float* zb = dz + b * Ho * Wo * C + c;
+        float v[9], wk[9];
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh) {
             const int nh = ih + 1 - kh;
-            if (nh < 0 || nh % stride != 0) continue;
-            const int oh = nh / stride;
-            if (oh >= Ho) continue;
+            const int oh = nh / stride;   // nh >= -1; -1 / stride == 0 but then nh != oh * stride
+            const bool okh = nh >= 0 && oh * stride == nh && oh < Ho;
+            const int ohc = min(max(oh, 0), Ho - 1);
 #pragma unroll
             for (int kw = 0; kw < 3; ++kw) {
                 const int nw = iw + 1 - kw;
-                if (nw < 0 || nw % stride != 0) continue;
                 const int ow = nw / stride;
-                if (ow >= Wo) continue;
-                acc = fmaf(w[c * 9 + kh * 3 + kw], dz[((b * Ho + oh) * Wo + ow) * C + c], acc);
+                const bool okw = nw >= 0 && ow * stride == nw && ow < Wo;
+                const int owc = min(max(ow, 0), Wo - 1);
+                v[kh * 3 + kw] = zb[((long)ohc * Wo + owc) * C];
+                wk[kh * 3 + kw] = (okh && okw) ? w[c * 9 + kh * 3 + kw] : 0.0f;
             }
         }
+        float acc = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) acc = fmaf(wk[k], v[k], acc);
         dx[idx] = acc;
     }
 }
@@ -327,17 +339,24 @@ __global__ __launch_bounds__(256) void dw3x3_wgrad_kernel(const float* __restric
             const long t = m / Wo;
             const int oh = (int)(t % Ho);
             const long b = t / Ho;
+            const float* xb = x + b * H * W * C + c;
             const float g = dz[m * C + c];
+            float v[9];
+            bool ok[9];
 #pragma unroll
             for (int kh = 0; kh < 3; ++kh) {
                 const int ih = oh * stride - 1 + kh;
+                const int ihc = min(max(ih, 0), H - 1);
 #pragma unroll
                 for (int kw = 0; kw < 3; ++kw) {
                     const int iw = ow * stride - 1 + kw;
-                    if (ih >= 0 && ih < H && iw >= 0 && iw < W)
-                        acc[kh * 3 + kw] = fmaf(g, x[((b * H + ih) * W + iw) * C + c], acc[kh * 3 + kw]);
+                    const int iwc = min(max(iw, 0), W - 1);
+                    v[kh * 3 + kw] = xb[((long)ihc * W + iwc) * C];   // unconditional: all ten loads of a pixel in flight
+                    ok[kh * 3 + kw] = ih == ihc && iw == iwc;
                 }
             }
+#pragma unroll
+            for (int k = 0; k < 9; ++k) acc[k] = fmaf(g, ok[k] ? v[k] : 0.0f, acc[k]);
         }
     }
 #pragma unroll
