@@ -256,68 +256,64 @@ __global__ void col2im3x3_kernel(const float* __restrict__ dcol, int H, int W, i
 // depthwise 3x3, padding 1: z[b,oh,ow,c] = sum_tap w[c*9+tap] * x[b, oh*s-1+kh, ow*s-1+kw, c]
 // All nine taps are loaded unconditionally from clamped addresses and masked afterwards: a load inside an `if` is followed
 // by its own wait, which serialises nine HBM/L2 round trips per output (the forward of the largest layer ran at 1.4 TB/s).
-__global__ void dw3x3_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, int H, int W, int C, int Ho, int Wo,
-                                 int stride, long total, float* __restrict__ z) {
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(idx % C);
-        const long pix = idx / C;
-        const int ow = (int)(pix % Wo);
-        const long t = pix / Wo;
-        const int oh = (int)(t % Ho);
-        const long b = t / Ho;
-        const float* xb = x + b * H * W * C + c;
-        float v[9], wk[9];
+// Launch geometry: blockIdx.x = image row (b, oh), blockIdx.y * 256 + threadIdx.x = (ow, c) within the row, so the only
+// integer division per thread is one 32-bit (ow, c) split; STRIDE is a template parameter (divisions by it are shifts).
+template <int STRIDE>
+__global__ __launch_bounds__(256) void dw3x3_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, int H, int W,
+                                                        int C, int Ho, int Wo, float* __restrict__ z) {
+    const int rc = blockIdx.y * 256 + threadIdx.x;
+    if (rc >= Wo * C) return;
+    const int ow = rc / C, c = rc - ow * C;
+    const int b = blockIdx.x / Ho, oh = blockIdx.x - b * Ho;
+    const float* xb = x + (long)b * H * W * C + c;
+    float v[9], wk[9];
 #pragma unroll
-        for (int kh = 0; kh < 3; ++kh) {
-            const int ih = oh * stride - 1 + kh;
-            const int ihc = min(max(ih, 0), H - 1);
+    for (int kh = 0; kh < 3; ++kh) {
+        const int ih = oh * STRIDE - 1 + kh;
+        const int ihc = min(max(ih, 0), H - 1);
 #pragma unroll
-            for (int kw = 0; kw < 3; ++kw) {
-                const int iw = ow * stride - 1 + kw;
-                const int iwc = min(max(iw, 0), W - 1);
-                v[kh * 3 + kw] = xb[((long)ihc * W + iwc) * C];
-                wk[kh * 3 + kw] = (ih == ihc && iw == iwc) ? w[c * 9 + kh * 3 + kw] : 0.0f;
-            }
+        for (int kw = 0; kw < 3; ++kw) {
+            const int iw = ow * STRIDE - 1 + kw;
+            const int iwc = min(max(iw, 0), W - 1);
+            v[kh * 3 + kw] = xb[((long)ihc * W + iwc) * C];
+            wk[kh * 3 + kw] = (ih == ihc && iw == iwc) ? w[c * 9 + kh * 3 + kw] : 0.0f;
         }
-        float acc = 0.0f;
-#pragma unroll
-        for (int k = 0; k < 9; ++k) acc = fmaf(wk[k], v[k], acc);
-        z[idx] = acc;
     }
+    float acc = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) acc = fmaf(wk[k], v[k], acc);
+    z[(long)blockIdx.x * Wo * C + rc] = acc;
 }
 
-__global__ void dw3x3_dgrad_kernel(const float* __restrict__ dz, const float* __restrict__ w, int H, int W, int C, int Ho,
-                                   int Wo, int stride, long total, float* __restrict__ dx) {
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(idx % C);
-        const long pix = idx / C;
-        const int iw = (int)(pix % W);
-        const long t = pix / W;
-        const int ih = (int)(t % H);
-        const long b = t / H;
-        const float* zb = dz + b * Ho * Wo * C + c;
-        float v[9], wk[9];
+template <int STRIDE>
+__global__ __launch_bounds__(256) void dw3x3_dgrad_kernel(const float* __restrict__ dz, const float* __restrict__ w, int H,
+                                                          int W, int C, int Ho, int Wo, float* __restrict__ dx) {
+    const int rc = blockIdx.y * 256 + threadIdx.x;
+    if (rc >= W * C) return;
+    const int iw = rc / C, c = rc - iw * C;
+    const int b = blockIdx.x / H, ih = blockIdx.x - b * H;
+    const float* zb = dz + (long)b * Ho * Wo * C + c;
+    float v[9], wk[9];
 #pragma unroll
-        for (int kh = 0; kh < 3; ++kh) {
-            const int nh = ih + 1 - kh;
-            const int oh = nh / stride;   // nh >= -1; -1 / stride == 0 but then nh != oh * stride
-            const bool okh = nh >= 0 && oh * stride == nh && oh < Ho;
-            const int ohc = min(max(oh, 0), Ho - 1);
+    for (int kh = 0; kh < 3; ++kh) {
+        const int nh = ih + 1 - kh;          // >= -1
+        const int oh = (nh + STRIDE) / STRIDE - 1;   // floor division for nh >= -STRIDE
+        const bool okh = nh >= 0 && oh * STRIDE == nh && oh < Ho;
+        const int ohc = min(max(oh, 0), Ho - 1);
 #pragma unroll
-            for (int kw = 0; kw < 3; ++kw) {
-                const int nw = iw + 1 - kw;
-                const int ow = nw / stride;
-                const bool okw = nw >= 0 && ow * stride == nw && ow < Wo;
-                const int owc = min(max(ow, 0), Wo - 1);
-                v[kh * 3 + kw] = zb[((long)ohc * Wo + owc) * C];
-                wk[kh * 3 + kw] = (okh && okw) ? w[c * 9 + kh * 3 + kw] : 0.0f;
-            }
+        for (int kw = 0; kw < 3; ++kw) {
+            const int nw = iw + 1 - kw;
+            const int ow = (nw + STRIDE) / STRIDE - 1;
+            const bool okw = nw >= 0 && ow * STRIDE == nw && ow < Wo;
+            const int owc = min(max(ow, 0), Wo - 1);
+            v[kh * 3 + kw] = zb[((long)ohc * Wo + owc) * C];
+            wk[kh * 3 + kw] = (okh && okw) ? w[c * 9 + kh * 3 + kw] : 0.0f;
         }
-        float acc = 0.0f;
-#pragma unroll
-        for (int k = 0; k < 9; ++k) acc = fmaf(wk[k], v[k], acc);
-        dx[idx] = acc;
     }
+    float acc = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) acc = fmaf(wk[k], v[k], acc);
+    dx[(long)blockIdx.x * W * C + rc] = acc;
 }
 
 // dW[c][tap] = sum_{b,oh,ow} dz[.,c] * x[shifted, c]: block = 64 channels x one chunk of output rows (pixels), its 4
@@ -335,11 +331,10 @@ __global__ __launch_bounds__(256) void dw3x3_wgrad_kernel(const float* __restric
     for (int t = 0; t < 9; ++t) acc[t] = 0.0f;
     if (c < C) {
         for (long m = r0 + rg; m < r1; m += 4) {
-            const int ow = (int)(m % Wo);
-            const long t = m / Wo;
-            const int oh = (int)(t % Ho);
-            const long b = t / Ho;
-            const float* xb = x + b * H * W * C + c;
+            const int mi = (int)m;   // pixel counts are far below 2^31: 32-bit divisions
+            const int t = mi / Wo, ow = mi - t * Wo;
+            const int b = t / Ho, oh = t - b * Ho;
+            const float* xb = x + (long)b * H * W * C + c;
             const float g = dz[m * C + c];
             float v[9];
             bool ok[9];
@@ -654,9 +649,11 @@ void conv_forward(const Ctx& c, int k, const float* in, long sb, long sh, long s
     if (l.kind == MB_PW) {
         gemm(c.s, true, in, lin(l.cin), 1, lin(0), w, lin(1), l.cin, (int)g.mz, l.cout, l.cin, 1, nullptr, 0, z, l.cout, 0);
     } else if (l.kind == MB_DW) {
-        const long total = g.mz * l.cout;
-        hipLaunchKernelGGL(dw3x3_fwd_kernel, dim3(flat_grid(total)), dim3(256), 0, c.s, in, w, g.hin, g.win, l.cin, g.ho, g.wo,
-                           l.stride, total, z);
+        const dim3 grid((unsigned)(c.B * g.ho), (g.wo * l.cin + 255) / 256);
+        if (l.stride == 1)
+            hipLaunchKernelGGL(dw3x3_fwd_kernel<1>, grid, dim3(256), 0, c.s, in, w, g.hin, g.win, l.cin, g.ho, g.wo, z);
+        else
+            hipLaunchKernelGGL(dw3x3_fwd_kernel<2>, grid, dim3(256), 0, c.s, in, w, g.hin, g.win, l.cin, g.ho, g.wo, z);
     } else {
         float* col = c.ws + c.p.col;
         const int K = 9 * l.cin;
@@ -831,9 +828,15 @@ int howl_mobilenet_bwd(const float* params, int num_labels, const float* x, long
             const long nw = (long)l.cout * 9;
             hipLaunchKernelGGL(sum_slabs_kernel, dim3((unsigned)((nw + 63) / 64)), dim3(256), 0, stream, (const float*)scratch,
                                wch, nw, gw);
-            if (dx != nullptr)
-                hipLaunchKernelGGL(dw3x3_dgrad_kernel, dim3(flat_grid(in_total)), dim3(256), 0, stream, (const float*)dz, w, g.hin,
-                                   g.win, l.cin, g.ho, g.wo, l.stride, in_total, dx);
+            if (dx != nullptr) {
+                const dim3 grid((unsigned)(B * g.hin), (g.win * l.cin + 255) / 256);
+                if (l.stride == 1)
+                    hipLaunchKernelGGL(dw3x3_dgrad_kernel<1>, grid, dim3(256), 0, stream, (const float*)dz, w, g.hin, g.win, l.cin,
+                                       g.ho, g.wo, dx);
+                else
+                    hipLaunchKernelGGL(dw3x3_dgrad_kernel<2>, grid, dim3(256), 0, stream, (const float*)dz, w, g.hin, g.win, l.cin,
+                                       g.ho, g.wo, dx);
+            }
         } else {
             float* col = c.ws + c.p.col;
             const int K = 9 * l.cin;
