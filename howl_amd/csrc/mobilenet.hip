@@ -204,6 +204,12 @@ Plan make_plan(int B, int H0, int W0, int num_labels) {
 // ---------------------------------------------------------------------------------------------------------
 // kernels (channels-last; `c` is always the unit-stride index)
 // ---------------------------------------------------------------------------------------------------------
+// channel of flat element idx of an (M x C) matrix: 32-bit arithmetic whenever the index fits (a 64-bit % is ~100
+// instructions, more than the rest of an elementwise kernel)
+__device__ __forceinline__ int chan_of(long idx, int C) {
+    return idx < (1L << 31) ? (int)((unsigned)idx % (unsigned)C) : (int)(idx % C);
+}
+
 // col[m][c*9 + tap] = x[b, oh*s - ph + tap/3, ow*s - pw + tap%3, c]  (zero outside); x addressed through strides so
 // that the network input can be a (B,1,M,T) view of a multi-channel feature tensor
 __global__ void im2col3x3_kernel(const float* __restrict__ x, long sb, long sh, long sw, long sc, int H, int W, int C, int Ho,
@@ -227,7 +233,7 @@ __global__ void im2col3x3_kernel(const float* __restrict__ x, long sb, long sh, 
 __global__ void col2im3x3_kernel(const float* __restrict__ dcol, int H, int W, int C, int Ho, int Wo, int stride, int ph, int pw,
                                  long total, float* __restrict__ dx) {
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(idx % C);
+        const int c = chan_of(idx, C);
         const long pix = idx / C;
         const int iw = (int)(pix % W);
         const long t = pix / W;
@@ -522,7 +528,7 @@ __global__ void bn_act_fwd_kernel(const float* __restrict__ z, const float* __re
                                   const float* __restrict__ beta, const float* __restrict__ res, int act, int C, long total,
                                   float* __restrict__ y) {
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(idx % C);
+        const int c = chan_of(idx, C);
         float v = mb_act(fmaf(gamma[c], (z[idx] - stats[c]) * stats[C + c], beta[c]), act);
         if (res != nullptr) v += res[idx];
         y[idx] = v;
@@ -561,7 +567,7 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ z, const float* __
                                     const float* __restrict__ gamma, const float* __restrict__ beta,
                                     const float* __restrict__ m12, int act, int C, long total, float* __restrict__ dz) {
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(idx % C);
+        const int c = chan_of(idx, C);
         const float rstd = stats[C + c];
         const float xh = (z[idx] - stats[c]) * rstd;
         const float g = mb_act_passes(fmaf(gamma[c], xh, beta[c]), act) ? dy[idx] : 0.0f;
@@ -572,7 +578,7 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ z, const float* __
 // MaxPool2d((1,2)) over W (floor), channels-last
 __global__ void maxpool12_fwd_kernel(const float* __restrict__ x, int W, int Wp, int C, long total, float* __restrict__ y) {
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(idx % C);
+        const int c = chan_of(idx, C);
         const long pix = idx / C;
         const int wp = (int)(pix % Wp);
         const long bh = pix / Wp;
@@ -584,7 +590,7 @@ __global__ void maxpool12_fwd_kernel(const float* __restrict__ x, int W, int Wp,
 __global__ void maxpool12_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, int W, int Wp, int C, long total,
                                      float* __restrict__ dx) {
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(idx % C);
+        const int c = chan_of(idx, C);
         const long pix = idx / C;
         const int w = (int)(pix % W);
         const long bh = pix / W;
@@ -603,7 +609,7 @@ __global__ void maxpool12_bwd_kernel(const float* __restrict__ x, const float* _
 __global__ void avgpool_fwd_kernel(const float* __restrict__ x, int HW, int C, const float* __restrict__ mask, float scale,
                                    long total, float* __restrict__ pooled, float* __restrict__ pooled_d) {
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(idx % C);
+        const int c = chan_of(idx, C);
         const long b = idx / C;
         float acc = 0.0f;
         for (int p = 0; p < HW; ++p) acc += x[(b * HW + p) * C + c];
@@ -615,7 +621,7 @@ __global__ void avgpool_fwd_kernel(const float* __restrict__ x, int HW, int C, c
 __global__ void avgpool_bwd_kernel(const float* __restrict__ dpooled, int HW, int C, const float* __restrict__ mask, float scale,
                                    long total, float* __restrict__ dx) {
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(idx % C);
+        const int c = chan_of(idx, C);
         const long b = idx / ((long)HW * C);
         float g = dpooled[b * C + c];
         if (mask != nullptr) g *= mask[b * C + c] * scale;
