@@ -78,7 +78,7 @@ def feats(B, T, seed):
     return torch.from_numpy(x)
 
 
-@pytest.mark.parametrize("B,T,C", [(2, 81, 12), (3, 41, 4)])
+@pytest.mark.parametrize("B,T,C", [(2, 81, 12), (3, 41, 4), (2, 20, 4)])
 def test_res8_eval_forward(lib, B, T, C):
     x = feats(B, T, 0)
     sd = om.res8_init(C)
@@ -92,7 +92,7 @@ def test_res8_eval_forward(lib, B, T, C):
     assert np.array_equal(out.argmax(1), ref.argmax(1))
 
 
-@pytest.mark.parametrize("B,T,C", [(2, 81, 12), (3, 41, 4)])
+@pytest.mark.parametrize("B,T,C", [(2, 81, 12), (3, 41, 4), (2, 20, 4)])
 def test_res8_train_step(lib, B, T, C):
     x = feats(B, T, 1)
     labels = torch.arange(B) % C

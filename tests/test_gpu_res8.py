@@ -148,3 +148,33 @@ def test_loss_decreases_and_errors_are_loud():
         cpu_model(torch.zeros(2, 1, 40, 81), None)            # no CPU fallback
     with pytest.raises(Exception):
         model(torch.zeros(2, 1, 40, 300, device=DEV), None)   # T beyond the supported window: error, not garbage
+
+
+@pytest.mark.parametrize("B,T,C", [(1, 83, 4), (3, 82, 12), (5, 64, 12), (2, 44, 30), (7, 10, 4), (4, 3, 12)])
+def test_odd_geometries_vs_oracle(B, T, C):
+    """Frame counts other than the reference's two window lengths (H = T // 3 from 1 to the 27 maximum, frames beyond 3H
+    dropped by the pooling, single-utterance batch, position-tile counts that leave some waves without work): training
+    forward + every gradient and the eval forward against the oracle, through the strided (B,1,M,T) feature view."""
+    torch.manual_seed(B * 100 + T)
+    feats = torch.randn(B, T, 40) * 1.2                       # (B,T,M) memory, viewed as (B,1,M,T) like the frontend's output
+    x = feats.permute(0, 2, 1).unsqueeze(1)
+    labels = torch.arange(B) % C
+    model = make_res8(C)
+    logits = model(x.to(DEV), None)
+    torch.nn.functional.cross_entropy(logits, labels.to(DEV)).backward()
+    sd = om.res8_init(C)
+    names = om.res8_param_names()
+    params = [sd[n].requires_grad_(True) for n in names]
+    ref = om.res8_forward(sd, x.contiguous(), True)
+    ref_grads = torch.autograd.grad(torch.nn.functional.cross_entropy(ref, labels), params)
+    assert maxerr(logits, ref) < LOGIT_TOL
+    assert torch.equal(logits.argmax(1).cpu(), ref.argmax(1))
+    for n, p, g in zip(names, model.hot_parameters(), ref_grads):
+        assert maxerr(p.grad, g) < 1e-4 * max(1.0, g.abs().max().item()), n
+    model.eval()
+    with torch.no_grad():
+        ev = model(x.to(DEV), None)
+    sd_eval = {k: v.detach() for k, v in sd.items()}
+    assert maxerr(ev, om.res8_forward(sd_eval, x.contiguous(), False)) < LOGIT_TOL
+    with pytest.raises(Exception):
+        model(torch.randn(2, 1, 40, 84, device=DEV), None)    # T > 83: outside the supported window, loudly
