@@ -89,11 +89,11 @@ def test_device_collate_batch():
     assert torch.equal(plain.audio_data[0, : int(lengths[order[0]])], pcm[order[0], : int(lengths[order[0]])])
 
 
-@pytest.mark.parametrize("model,objective", [("res8", "frame"), ("seq-lstm", "ctc")])
+@pytest.mark.parametrize("model,objective", [("res8", "frame"), ("seq-lstm", "ctc"), ("mobilenet", "frame")])
 def test_train_entry_point_synthetic(tmp_path, monkeypatch, model, objective):
     """`python -m training.run.train` flow (envs/res8.env / envs/seq-lstm.env presets, shortened) on generated wake-word
     clips: runs end to end, loss goes down, detection results + workspace artefacts are written."""
-    env = dict(NUM_EPOCHS="3", BATCH_SIZE="16", MAX_WINDOW_SIZE_SECONDS="0.5", LEARNING_RATE="0.01" if model == "res8" else "0.002",
+    env = dict(NUM_EPOCHS="3", BATCH_SIZE="16", MAX_WINDOW_SIZE_SECONDS="0.5", LEARNING_RATE={"res8": "0.01", "mobilenet": "0.001"}.get(model, "0.002"),
                LR_DECAY="0.955", WEIGHT_DECAY="0.00001", NUM_MELS="40", DEVICE="cuda:0", OBJECTIVE=objective,
                TOKEN_TYPE="word", VOCAB='["hey","fire","fox"]', INFERENCE_SEQUENCE="[0,1,2]", INFERENCE_THRESHOLD="0",
                SMOOTHING_WINDOW_MS="0" if objective == "ctc" else "50")
