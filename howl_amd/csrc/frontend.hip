@@ -131,7 +131,11 @@ __global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ p
             sb = sb < 0 ? -sb : sb;
             sa = sa >= L ? 2 * (L - 1) - sa : sa;
             sb = sb >= L ? 2 * (L - 1) - sb : sb;
+#if defined(HOWL_DIAG_LOGMEL_NOLOAD)   // diagnostic build (tools/variants.py): no PCM reads
+            const float a = 1e-3f * (float)sa, b = 1e-3f * (float)sb;
+#else
             const float a = rowa[sa], b = rowb[sb];  // always in range (frame 0 of row 0 for invalid frames)
+#endif
             xa[n1] = va ? a : 0.0f;
             xb[n1] = vb ? b : 0.0f;
         }
@@ -150,6 +154,7 @@ __global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ p
             cf v[8];
 #pragma unroll
             for (int n1 = 0; n1 < 8; ++n1) v[n1] = {xa[n1] * win[n1], xb[n1] * win[n1]};
+#if !defined(HOWL_DIAG_LOGMEL_NOFFT)   // diagnostic build: butterflies and LDS exchanges removed
             // stage 1: radix-8 over n1 (stride 64), twiddle W_512^(lane*k1)
             dft8(v);
 #pragma unroll
@@ -176,6 +181,7 @@ __global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ p
                 for (int b = 0; b < 8; ++b) v[b] = scr[k1 * X2_STRIDE + c * 8 + b];
                 dft8(v);
             }
+#endif
             wave_lds_sync();
 #pragma unroll
             for (int d = 0; d < 8; ++d) scr[lane + 64 * d] = v[d];
@@ -213,12 +219,16 @@ __global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ p
             const float* arow = P + (lane & 15) * P_STRIDE + 4 * ks0 + (lane >> 4);
 #pragma unroll
             for (int i = 0; i < 17; ++i) {
+#if defined(HOWL_DIAG_LOGMEL_NOMEL)   // diagnostic build: mel contraction removed
+                if (i == 0) acc[0][0] = arow[0];
+#else
                 if (i < nks) {
                     const float a = arow[4 * i];
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt)
                         acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bfrag[i][nt], acc[nt], 0, 0, 0);
                 }
+#endif
             }
         }
         float* part = reinterpret_cast<float*>(scratch);

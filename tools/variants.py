@@ -11,6 +11,9 @@ ROOT = Path(__file__).resolve().parent.parent
 CSRC = ROOT / "howl_amd" / "csrc"
 VARIANTS = {
     "base": [],
+    "logmel_nofft": ["-DHOWL_DIAG_LOGMEL_NOFFT"],
+    "logmel_nomel": ["-DHOWL_DIAG_LOGMEL_NOMEL"],
+    "logmel_noload": ["-DHOWL_DIAG_LOGMEL_NOLOAD"],
     "conv_nolds": ["-DHOWL_DIAG_CONV_NOLDS"],
     "conv_nomfma": ["-DHOWL_DIAG_CONV_NOMFMA"],
     "conv_ntstore": ["-DHOWL_DIAG_CONV_NTSTORE"],
@@ -49,7 +52,7 @@ lb.call("howl_profile_enable", 1)
 for _ in range(10): tr.step(pcm, labels)
 torch.cuda.synchronize(); lb.call("howl_profile_enable", 0)
 row = ["step %%.3f ms |" %% (dt * 1e3)]
-for tag in ("conv3x3_fwd", "conv3x3_dgrad", "wgrad"):
+for tag in ("conv3x3_fwd", "conv3x3_dgrad", "wgrad", "logmel"):
     tot, cnt = ctypes.c_double(0), ctypes.c_int(0)
     lb.call("howl_profile_read", tag.encode(), ctypes.byref(tot), ctypes.byref(cnt), 0)
     row.append("%%s %%.1f us" %% (tag, tot.value / max(cnt.value, 1) * 1e3))
@@ -62,18 +65,24 @@ def main():
     out = Path("/tmp/howl_variants")
     out.mkdir(exist_ok=True)
     objs = []
-    for f in ("capi", "frontend", "lstm", "mobilenet"):
+    for f in ("capi", "lstm", "mobilenet"):
         o = out / f"{f}.o"
         subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-c", str(CSRC / f"{f}.hip"), "-o", str(o)],
                        check=True)
         objs.append(str(o))
     for name in names:
         so = out / f"libhowl_{name}.so"
-        obj = out / f"res8_{name}.o"
-        r = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", *VARIANTS[name],
-                            "-c", str(CSRC / "res8.hip"), "-o", str(obj)], capture_output=True, text=True)
+        vobjs = []
+        r = None
+        for f in ("res8", "frontend"):   # the two files that carry HOWL_DIAG_* switches
+            obj = out / f"{f}_{name}.o"
+            r = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", *VARIANTS[name],
+                                "-c", str(CSRC / f"{f}.hip"), "-o", str(obj)], capture_output=True, text=True)
+            if r.returncode != 0:
+                break
+            vobjs.append(str(obj))
         if r.returncode == 0:
-            r = subprocess.run(["hipcc", "--offload-arch=gfx950", "-fPIC", "-shared", str(obj), *objs, "-o", str(so)],
+            r = subprocess.run(["hipcc", "--offload-arch=gfx950", "-fPIC", "-shared", *vobjs, *objs, "-o", str(so)],
                                capture_output=True, text=True)
         if r.returncode != 0:
             print(f"{name}: build failed\n{r.stderr[-2000:]}")
