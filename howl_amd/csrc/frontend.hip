@@ -489,7 +489,7 @@ int howl_logmel_fwd(const float* pcm, int B, int L, long ld, const float* fbp, i
     const int T = 1 + L / HOP;
     const long total = (long)B * T;
     const int n_chunks = (int)((total + CHUNK - 1) / CHUNK);
-    int grid = howl_num_cus() * 4;
+    int grid = howl_num_cus() * 2;   // two workgroups are resident per CU (206 VGPRs): each pays the constant prologue once
     if (grid > n_chunks) grid = n_chunks;
     {
         HowlProfScope prof("logmel", stream);
