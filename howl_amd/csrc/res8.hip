@@ -55,6 +55,16 @@ __host__ __device__ inline int chan_stride(int H) {
     return cs + pad;
 }
 __host__ __device__ inline int tile_floats(int H) { return CP * chan_stride(H) + 32; }
+// The weight-gradient kernel reads its two tiles CHANNEL-major: lane l & 15 selects the channel (stride CS), lane >> 4 one of
+// 4 consecutive positions.  ds_read_b32 is served per 32-lane half over 32 banks: halves {channels 0..15} x {position p, p+1}
+// are conflict-free iff {CS*i mod 32} are 16 values no two of which are adjacent, i.e. CS = 2 (mod 32) (all even banks, the
+// partner position takes the odd ones).  With the 17 (mod 32) stride of the forward tiles every read was 2-way conflicted.
+__host__ __device__ inline int chan_stride_wgrad(int H) {
+    int cs = (H + 1) * WP + 1;
+    int pad = (2 - (cs % 32) + 32) % 32;
+    return cs + pad;
+}
+__host__ __device__ inline int tile_floats_wgrad(int H) { return CP * chan_stride_wgrad(H) + 32; }
 
 // ---------------------------------------------------------------------------------------------------------
 // weight packing: (45,45,3,3) -> per-wave MFMA B fragments  wp[nt][kstep][lane]
@@ -459,8 +469,8 @@ __global__ __launch_bounds__(CONV_THREADS) void wgrad_mfma_kernel(
     float* __restrict__ part /* [gridDim.x][48][432] */, int B, int H) {
     HIP_DYNAMIC_SHARED(float, lds)
     const int P = H * PW;
-    const int CS = chan_stride(H);
-    const int TF = tile_floats(H);
+    const int CS = chan_stride_wgrad(H);
+    const int TF = tile_floats_wgrad(H);
     float* tz = lds;
     float* tx = lds + TF;
     float* lmean = lds + 2 * TF;
@@ -1130,7 +1140,7 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
 }
 
 size_t conv_lds_bytes(int H) { return (size_t)(3 * KSTEPS * 64 + tile_floats(H) + 2 * CP + 12 * 2 * 16) * sizeof(float); }
-size_t wgrad_lds_bytes(int H) { return (size_t)(2 * tile_floats(H) + 2 * CP) * sizeof(float); }
+size_t wgrad_lds_bytes(int H) { return (size_t)(2 * tile_floats_wgrad(H) + 2 * CP) * sizeof(float); }
 size_t conv0_wgrad_mfma_lds_bytes(int T, int M) {
     const int P = ((T / 3)) * PW;
     return (size_t)(T + 2) * (M + 4) * sizeof(float) + (size_t)NMAP * P * sizeof(float) +
