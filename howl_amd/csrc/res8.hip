@@ -463,6 +463,17 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_mfma_kernel(
     }
 }
 
+#if defined(HOWL_DIAG_PROBE)  // diagnostic build (tools/probe_wgrad.py): s_memtime stamps of workgroup 0, [wave][slot]
+__device__ unsigned long long* g_howl_probe = nullptr;
+#define HOWL_PROBE(wave_, lane_, slot_)                                                \
+    do {                                                                               \
+        if (g_howl_probe != nullptr && blockIdx.x == 0 && (lane_) == 0 && (slot_) < 64) \
+            g_howl_probe[(wave_) * 64 + (slot_)] = __builtin_amdgcn_s_memtime();        \
+    } while (0)
+#else
+#define HOWL_PROBE(wave_, lane_, slot_) ((void)0)
+#endif
+
 // wgrad: dW[cout][cin][tap] += sum_{b,p} dz[b,cout,p] * x[b,cin,p + tap shift],  x = (s_prev - mean) * rstd
 __global__ __launch_bounds__(CONV_THREADS) void wgrad_mfma_kernel(
     const float* __restrict__ dz, const float* __restrict__ s_prev, const float* __restrict__ in_stats,
@@ -482,6 +493,8 @@ __global__ __launch_bounds__(CONV_THREADS) void wgrad_mfma_kernel(
     const int n2 = NMAP * P / 2;
     const bool affine = in_stats != nullptr;
     const int ksteps = (P + 3) / 4;
+    int pslot = 0;
+    HOWL_PROBE(wave, lane, pslot++);   // entry
 
     // first utterance's tiles are requested before the LDS setup so that HBM latency overlaps it
     float2 pz[PREF], px[PREF];
@@ -514,10 +527,13 @@ __global__ __launch_bounds__(CONV_THREADS) void wgrad_mfma_kernel(
     int pk[PREF];
     stage_slots(pk, P, CS, n2, tid);
     __syncthreads();
+    HOWL_PROBE(wave, lane, pslot++);   // prologue done
     for (; b < B; b += gridDim.x) {
         stage_tile(pz, pk, tz, lmean, lrstd, false, false);
         stage_tile(px, pk, tx, lmean, lrstd, affine, true);
+        HOWL_PROBE(wave, lane, pslot++);   // staged
         __syncthreads();
+        HOWL_PROBE(wave, lane, pslot++);   // barrier
         const int bn = b + gridDim.x;
         const float* nz = (bn < B) ? dz + (size_t)bn * NMAP * P : nullptr;
         const float* nx = (bn < B) ? s_prev + (size_t)bn * NMAP * P : nullptr;
@@ -595,7 +611,9 @@ __global__ __launch_bounds__(CONV_THREADS) void wgrad_mfma_kernel(
         prefetch_pair<6>(pz, nz, n2, tid);
         prefetch_pair<6>(px, nx, n2, tid);
         k_steps(3 * kq, ksteps);
+        HOWL_PROBE(wave, lane, pslot++);   // K loop done
         __syncthreads();  // single-buffered tiles: everyone done before the next stage overwrites them
+        HOWL_PROBE(wave, lane, pslot++);   // barrier
     }
     // D[row = cout = 16mt + 4*(lane>>4) + r][col = n = lane&15 -> cin = 16ct + col] for N tile q = (tap, ct)
     float* dst = part + (size_t)blockIdx.x * CP * 432;
@@ -613,6 +631,7 @@ __global__ __launch_bounds__(CONV_THREADS) void wgrad_mfma_kernel(
                 }
         }
     }
+    HOWL_PROBE(wave, lane, pslot++);   // partials written
 }
 
 // Deterministic sum over the per-workgroup partial rows: part[g][col], g < nparts.  A block owns 64 columns
@@ -1140,6 +1159,14 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
 }
 
 size_t conv_lds_bytes(int H) { return (size_t)(3 * KSTEPS * 64 + tile_floats(H) + 2 * CP + 12 * 2 * 16) * sizeof(float); }
+#if defined(HOWL_DIAG_PROBE)
+}  // namespace
+extern "C" int howl_diag_set_probe(unsigned long long* buf) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_howl_probe), &buf, sizeof(buf));
+}
+namespace {
+#endif
+
 size_t wgrad_lds_bytes(int H) { return (size_t)(2 * tile_floats_wgrad(H) + 2 * CP) * sizeof(float); }
 size_t conv0_wgrad_mfma_lds_bytes(int T, int M) {
     const int P = ((T / 3)) * PW;
