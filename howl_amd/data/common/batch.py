@@ -1,5 +1,6 @@
-"""Host containers feeding the hot path (``howl/data/common/batch.py:12-61``), same field names."""
-from dataclasses import dataclass
+"""Batch containers handed to the hot path; field names and methods follow ``howl/data/common/batch.py:12-61`` so that
+collate functions and training loops written against the reference keep working."""
+from dataclasses import dataclass, fields
 from typing import Optional
 
 import torch
@@ -7,43 +8,38 @@ import torch
 __all__ = ["ClassificationBatch", "SequenceBatch"]
 
 
+class _TensorBundle:
+    """Moves / pins every tensor-valued dataclass field in place (``None`` fields are skipped) and returns ``self``."""
+
+    def _map_tensors(self, fn):
+        for f in fields(self):
+            value = getattr(self, f.name)
+            if torch.is_tensor(value):
+                setattr(self, f.name, fn(value))
+        return self
+
+    def to(self, device):
+        return self._map_tensors(lambda t: t.to(device))
+
+    def pin_memory(self):
+        return self._map_tensors(lambda t: t.pin_memory())
+
+
 @dataclass
-class ClassificationBatch:
-    audio_data: torch.Tensor
-    labels: Optional[torch.Tensor]
-    lengths: torch.Tensor
+class ClassificationBatch(_TensorBundle):
+    audio_data: torch.Tensor                 # (B, Lmax) right-padded waveforms
+    labels: Optional[torch.Tensor]           # (B,) class indices
+    lengths: torch.Tensor                    # (B,) valid samples per row
 
     @classmethod
     def from_single(cls, audio_clip: torch.Tensor, label: int) -> "ClassificationBatch":
-        return cls(audio_clip.unsqueeze(0), torch.tensor([label]), torch.tensor([audio_clip.size(-1)]))
-
-    def pin_memory(self):
-        self.audio_data = self.audio_data.pin_memory()
-        if self.labels is not None:
-            self.labels = self.labels.pin_memory()
-        self.lengths = self.lengths.pin_memory()
-        return self
-
-    def to(self, device: torch.device) -> "ClassificationBatch":
-        self.audio_data = self.audio_data.to(device)
-        if self.labels is not None:
-            self.labels = self.labels.to(device)
-        self.lengths = self.lengths.to(device)
-        return self
+        n = audio_clip.size(-1)
+        return cls(audio_data=audio_clip[None], labels=torch.tensor([label]), lengths=torch.tensor([n]))
 
 
 @dataclass
-class SequenceBatch:
-    audio_data: torch.Tensor
-    labels: torch.Tensor
+class SequenceBatch(_TensorBundle):
+    audio_data: torch.Tensor                 # (B, Lmax)
+    labels: torch.Tensor                     # (B, Smax) token ids
     audio_lengths: Optional[torch.Tensor]
     label_lengths: Optional[torch.Tensor]
-
-    def to(self, device: torch.device) -> "SequenceBatch":
-        self.audio_data = self.audio_data.to(device)
-        self.labels = self.labels.to(device)
-        if self.audio_lengths is not None:
-            self.audio_lengths = self.audio_lengths.to(device)
-        if self.label_lengths is not None:
-            self.label_lengths = self.label_lengths.to(device)
-        return self

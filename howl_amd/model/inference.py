@@ -6,7 +6,6 @@ model (instead of one launch and one device->host sync per 63 ms stride, ``infer
 the reference's per-window loop on the host, so ``label_history`` / ``pred_history`` and the early exit are identical.
 Models that carry streaming state between windows keep the sequential path.
 """
-import itertools
 import time
 
 import numpy as np
@@ -20,108 +19,82 @@ from howl_amd.settings import SETTINGS
 from howl_amd.utils import audio_utils
 
 from .base import RegisteredModel
+from .decision import ProbabilitySmoother, SequenceMatcher
 
 __all__ = ["FrameInferenceEngine", "InferenceEngine"]
 
 
 class InferenceEngine:
+    """Sequential-model engine: one forward over the whole clip, then the frame-by-frame decision logic on the host."""
+
     def __init__(self, model: RegisteredModel, zmuv_transform: ZmuvTransform, context: InferenceContext,
                  time_provider=time.time):
-        self.model = model
-        self.zmuv = zmuv_transform
+        cfg = SETTINGS.inference_engine
+        self.model, self.zmuv, self.context, self.settings = model, zmuv_transform, context, cfg
         self.std = StandardAudioTransform().eval()
-        self.settings = SETTINGS.inference_engine
-        self.context = context
-
-        self.inference_weights = 1
-        if self.settings.inference_weights:
-            pad_size = context.num_labels - len(self.settings.inference_weights)
-            self.inference_weights = np.pad(self.settings.inference_weights, (0, pad_size), "constant", constant_values=1)
-
-        self.coloring = context.coloring
-        self.negative_label = context.negative_label
-        if self.coloring:
-            self.negative_label = self.coloring.color_map[self.negative_label]
-
-        self.sample_rate = SETTINGS.audio.sample_rate
-        self.threshold = self.settings.inference_threshold
-        self.inference_window_ms = self.settings.inference_window_ms
-        self.smoothing_window_ms = self.settings.smoothing_window_ms
-        self.tolerance_window_ms = self.settings.tolerance_window_ms
-        self.sequence = self.settings.inference_sequence
-        self.blank_idx = self.context.blank_label
         self.time_provider = time_provider
-
+        self.sample_rate = SETTINGS.audio.sample_rate
+        self.blank_idx = context.blank_label
+        # per-class reweighting of the probabilities (missing entries count as 1)
+        self.inference_weights = 1
+        if cfg.inference_weights:
+            w = np.ones(context.num_labels)
+            w[:len(cfg.inference_weights)] = cfg.inference_weights
+            self.inference_weights = w
+        self.coloring = context.coloring
+        negative = context.negative_label
+        if self.coloring:
+            negative = self.coloring.color_map[negative]
+        self.negative_label = negative
+        self.threshold = cfg.inference_threshold
+        self.inference_window_ms = cfg.inference_window_ms
+        self.smoothing_window_ms = cfg.smoothing_window_ms
+        self.tolerance_window_ms = cfg.tolerance_window_ms
+        self.sequence = cfg.inference_sequence
+        self._smoother = ProbabilitySmoother(self.smoothing_window_ms, self.threshold, negative,
+                                             self.coloring.color_map if self.coloring else None)
+        self._matcher = SequenceMatcher(self.sequence, self.inference_window_ms, self.tolerance_window_ms)
         self.curr_time = 0
-        self.pred_history = []
         self.label_history = []
         self.reset()
 
+    # the reference exposes both histories as plain attributes; pred_history lives in the smoother
+    @property
+    def pred_history(self):
+        return self._smoother.frames
+
+    @pred_history.setter
+    def pred_history(self, frames):
+        self._smoother.frames = list(frames)
+
     def to(self, device: torch.device):
-        self.model = self.model.to(device)
-        self.zmuv = self.zmuv.to(device)
+        self.model, self.zmuv = self.model.to(device), self.zmuv.to(device)
         return self
 
     def reset(self):
         self.model.streaming_state = None
         self.curr_time = 0
-        self.pred_history = []
+        self._smoother.clear()
         self.label_history = []
 
+    def _now_ms(self, curr_time):
+        return self.time_provider() * 1000 if curr_time is None else curr_time
+
     def append_label(self, label: int, curr_time: float = None):
-        if curr_time is None:
-            curr_time = self.time_provider() * 1000
-        self.label_history.append((curr_time, label))
+        self.label_history.append((self._now_ms(curr_time), label))
 
     def sequence_present(self, curr_time: float = None) -> bool:
-        """FSM over ``label_history`` (``inference.py:91-137``)."""
-        if not self.sequence:
-            return False
-        if len(self.sequence) == 0:
-            return True
-        if curr_time is None:
-            curr_time = self.time_provider() * 1000
-        self.label_history = list(
-            itertools.dropwhile(lambda x: curr_time - x[0] > self.inference_window_ms, self.label_history))
-        curr_label = None
-        target_state = 0
-        last_valid_timestamp = 0
-        for curr_timestamp, label in self.label_history:
-            target_label = self.sequence[target_state]
-            if label == target_label:
-                target_state += 1
-                if target_state == len(self.sequence):
-                    return True
-                curr_label = self.sequence[target_state - 1]
-                last_valid_timestamp = curr_timestamp
-            elif label == curr_label:
-                last_valid_timestamp = curr_timestamp
-            elif last_valid_timestamp + self.tolerance_window_ms < curr_timestamp:
-                curr_label = None
-                target_state = 0
-                last_valid_timestamp = 0
-        return False
-
-    def _get_prediction(self, curr_time: float) -> int:
-        """Smoothing max over ``smoothing_window_ms`` (``inference.py:139-161``)."""
-        self.pred_history = list(
-            itertools.dropwhile(lambda x: curr_time - x[0] > self.smoothing_window_ms, self.pred_history))
-        lattice = np.vstack([t for _, t in self.pred_history])
-        lattice_max = np.max(lattice, 0)
-        max_label = lattice_max.argmax()
-        max_prob = lattice_max[max_label]
-        if self.coloring:
-            max_label = self.coloring.color_map.get(max_label, self.negative_label)
-        if max_prob < self.threshold:
-            max_label = self.negative_label
-        self.label_history.append((curr_time, max_label))
-        return max_label
+        # the matcher reads the settings through the engine so that tests / callers may retune them after construction
+        self._matcher.sequence, self._matcher.window_ms = self.sequence, self.inference_window_ms
+        self._matcher.tolerance_ms = self.tolerance_window_ms
+        return self._matcher.present(self.label_history, self._now_ms(curr_time))
 
     def _append_probability_frame(self, prediction: np.ndarray, curr_time: float = None) -> int:
-        if curr_time is None:
-            curr_time = self.time_provider() * 1000
-        self.pred_history.append((curr_time, prediction))
-        return self._get_prediction(curr_time)
+        now = self._now_ms(curr_time)
+        self._smoother.window_ms, self._smoother.threshold = self.smoothing_window_ms, self.threshold
+        label = self._smoother.push(now, prediction)
+        self.label_history.append((now, label))
+        return label
 
     def _weighted(self, prediction: np.ndarray) -> np.ndarray:
         prediction = prediction * self.inference_weights

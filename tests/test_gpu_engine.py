@@ -41,6 +41,39 @@ def test_frame_engine_matches_reference_history(golden):
     assert labels == [int(x) for x in g["label_history"][:5, 1]]
 
 
+def test_sequence_engine_matches_reference_history(golden):
+    """G8: InferenceEngine.infer (seq-lstm with a CTC blank, whole clip in one forward, smoothing window 0) -- the label history
+    the reference's engine produced with the same closed-form weights must be reproduced exactly."""
+    from howl_amd.context import InferenceContext
+    from howl_amd.data.transform.operator import ZmuvTransform
+    from howl_amd.model import RegisteredModel
+    from howl_amd.model.inference import InferenceEngine
+    from howl_amd.settings import SETTINGS
+    from oracle import models as om
+    g, g4 = golden("g8_seq_engine"), golden("g4_zmuv")
+    SETTINGS.inference_engine.inference_sequence = [0, 1, 2]
+    SETTINGS.inference_engine.smoothing_window_ms = 0
+    try:
+        ctx = InferenceContext(["hey", "fire", "fox"], token_type="word", use_blank=True)
+        assert (ctx.num_labels, ctx.blank_label) == (int(g["num_labels"]), int(g["blank_label"]))
+        model = RegisteredModel.find_registered_class("seq-lstm")(ctx.num_labels)
+        model.load_state_dict(om.lstm_init(ctx.num_labels))
+        model = model.to(DEV).eval().streaming()
+        zmuv = ZmuvTransform().to(DEV)
+        zmuv.mean.copy_(t(g4["mean"]))
+        zmuv.mean2.copy_(t(g4["mean2"]))
+        zmuv.total.copy_(t(g4["total"]))
+        engine = InferenceEngine(model, zmuv, ctx)
+        present = engine.infer(t(g["clip"]).to(DEV))
+        assert bool(present) == bool(g["present"])
+        hist = np.array(engine.label_history, dtype=np.float64)
+        assert hist.shape == g["label_history"].shape
+        assert np.array_equal(hist[:, 1], g["label_history"][:, 1])              # label indices, bit-exact
+        assert np.abs(hist[:, 0] - g["label_history"][:, 0]).max() < 1e-6        # frame times
+    finally:
+        SETTINGS.reset()
+
+
 def test_pretrain_gsc_entry_point_synthetic(tmp_path, monkeypatch):
     """`python -m training.run.pretrain_gsc --model res8` flow on generated clips: ZMUV pass, fused training epochs,
     dev accuracy, workspace artefacts with the reference's file names and state_dict keys."""
