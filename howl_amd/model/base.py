@@ -39,27 +39,31 @@ class RegisteredModel(nn.Module, ClassRegistry):
 
 
 class ConvertedStaticModel(RegisteredModel, name="converted"):
-    """Sliding-window wrapper (``base.py:40-62``), including its first-window quirk (:53)."""
+    """Turns a fixed-window classifier into a sequence model by sliding it over the time axis
+    (``base.py:40-62``).  Output: ``(n_windows, B, num_labels)``.
+
+    The reference's loop has a quirk that is kept on purpose (results must match): the FIRST window is not
+    ``x[..., 0:window]`` but everything from ``window`` onwards, ``x[..., window:]`` (whatever its length); the regular
+    windows ``x[..., k*stride : k*stride + window]``, k = 1, 2, ..., follow for as long as they are complete."""
 
     def __init__(self, model: RegisteredModel, frame_window_size: int, frame_stride_size: int):
         super().__init__(model.num_labels)
         self.model = model
-        self.frame_window_size = frame_window_size
-        self.frame_stride_size = frame_stride_size
+        self.frame_window_size, self.frame_stride_size = frame_window_size, frame_stride_size
 
     def compute_length(self, length: int):
         if length is None:
             return None
-        return max(1, (length - self.frame_window_size) // self.frame_stride_size)
+        n = (length - self.frame_window_size) // self.frame_stride_size
+        return n if n > 1 else 1
+
+    def _windows(self, x):
+        win, hop = self.frame_window_size, self.frame_stride_size
+        yield x[..., win:]                       # the quirk described above
+        start = hop
+        while start + win <= x.size(-1):
+            yield x[..., start:start + win]
+            start += hop
 
     def forward(self, x, lengths):
-        first = True
-        window = x[:, :, :, self.frame_window_size:]
-        idx = self.frame_stride_size
-        outputs = []
-        while first or window.size(3) == self.frame_window_size:
-            first = False
-            outputs.append(self.model(window, lengths))
-            window = x[:, :, :, idx: idx + self.frame_window_size]
-            idx += self.frame_stride_size
-        return torch.stack(outputs)
+        return torch.stack([self.model(w, lengths) for w in self._windows(x)])
