@@ -144,3 +144,31 @@ def test_export_honkling_wire_format(tmp_path):
     assert set(d) == set(sd) | {"scale1.scale", "scale3.scale", "scale5.scale"}
     assert d["scale3.scale"] == [1.0] * 45
     assert np.allclose(np.array(d["conv3.weight"], np.float32), sd["conv3.weight"].numpy())
+
+
+def test_converted_static_model_windows():
+    """ConvertedStaticModel (base.py:40-62): window sequence incl. the first-window quirk, against a direct restatement of
+    the reference loop (first window = x[..., win:], then complete strided windows)."""
+    from howl_amd.model.base import ConvertedStaticModel
+
+    class Probe(torch.nn.Module):
+        num_labels = 3
+
+        def forward(self, w, lengths):
+            return torch.stack([torch.tensor(float(w.size(-1))), w.sum(), w.abs().max()])
+
+    def reference_loop(model, x, win, hop):
+        first, window, idx, outs = True, x[:, :, :, win:], hop, []
+        while first or window.size(3) == win:
+            first = False
+            outs.append(model(window, None))
+            window = x[:, :, :, idx: idx + win]
+            idx += hop
+        return torch.stack(outs)
+
+    for T, win, hop in [(100, 20, 10), (55, 20, 7), (20, 20, 5), (19, 20, 5), (41, 10, 10)]:
+        x = torch.randn(2, 1, 4, T)
+        m = ConvertedStaticModel(Probe(), win, hop)
+        got, want = m(x, None), reference_loop(Probe(), x, win, hop)
+        assert got.shape == want.shape and torch.allclose(got, want), (T, win, hop)
+        assert m.compute_length(T) == max(1, (T - win) // hop) and m.compute_length(None) is None
