@@ -295,12 +295,85 @@ int gemm(hipStream_t s, bool a_major_k, const float* a, RowMap am, long a_ks, Ro
     return (int)grid.z;
 }
 
+// Weight gradient with a THIN output (N_out <= 8: the 5-label Linear head, MobileNet's 3-channel downsample conv): a 64x64
+// MFMA tile would be > 87 % padding and the operands do not meet the vector path's alignment, so this is a plain streaming
+// reduction instead: lane -> input column k (narrow matrices pack 64/Kp rows per wave, Kp = K_in rounded up to a power of
+// two <= 32), the N_out values of a row are broadcast loads, four rows in flight per lane, fp32 partials per row chunk folded
+// by sum_slabs_kernel in a fixed order.   part[chunk][n][k]
+template <int NO>
+__global__ __launch_bounds__(256) void thin_wgrad_kernel(const float* __restrict__ dout, RowMap dm, const float* __restrict__ in,
+                                                         RowMap im, int k_in, int kp, int rows, int rows_per_chunk,
+                                                         float* __restrict__ part) {
+    __shared__ float red[4][NO][64];
+    const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int rsub = 64 / kp;                       // rows per wave iteration
+    const int kl = lane & (kp - 1), rs = lane / kp;
+    const int k = blockIdx.x * 64 + kl;
+    const int r0 = blockIdx.y * rows_per_chunk;
+    const int r1 = min(rows, r0 + rows_per_chunk);
+    float acc[NO];
+#pragma unroll
+    for (int n = 0; n < NO; ++n) acc[n] = 0.0f;
+    if (k < k_in) {
+        const int step = 4 * rsub;
+        for (int r = r0 + rg * rsub + rs; r < r1; r += 4 * step) {
+            float b[4], a[4][NO];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int rr = r + u * step;
+                const bool ok = rr < r1;
+                const int rc = ok ? rr : r;       // clamped: branch-free loads, all in flight
+                const float bv = in[rmap(im, rc) + k];
+                b[u] = ok ? bv : 0.0f;
+                const float* ap = dout + rmap(dm, rc);
+#pragma unroll
+                for (int n = 0; n < NO; ++n) a[u][n] = ap[n];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int n = 0; n < NO; ++n) acc[n] = fmaf(a[u][n], b[u], acc[n]);
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < NO; ++n) red[rg][n][lane] = acc[n];
+    __syncthreads();
+    if (rg == 0 && rs == 0 && k < k_in) {
+#pragma unroll
+        for (int n = 0; n < NO; ++n) {
+            float t = 0.0f;
+            for (int w = 0; w < 4; ++w)
+                for (int q = 0; q < rsub; ++q) t += red[w][n][q * kp + kl];
+            part[((size_t)blockIdx.y * NO + n) * k_in + k] = t;
+        }
+    }
+}
+
 // dW (N_out, K_in) = dOut^T (N_out x rows) . In (rows x K_in), rows given by row maps; split-K + deterministic sum
 // (scratch: splits x N_out x K_in floats, splits = clamp(rows / 512, 1, max_splits))
 void wgrad_gemm(hipStream_t s, const float* dout, RowMap dm, int n_out, const float* in, RowMap im, int k_in, int rows,
                 float* scratch, float* dw, int max_splits = 64) {
     int splits = rows / 512;
     splits = splits < 1 ? 1 : (splits > max_splits ? max_splits : splits);
+    if (n_out <= 8 && ((n_out & 3) != 0 || (k_in & 3) != 0)) {   // thin output that the vector GEMM cannot take
+        int kp = 64;
+        if (k_in <= 32) {
+            kp = 1;
+            while (kp < k_in) kp <<= 1;
+        }
+        const int rpc = (rows + splits - 1) / splits;
+        const int chunks = (rows + rpc - 1) / rpc;
+        const dim3 grid((k_in + 63) / 64, chunks);
+#define HOWL_THIN(NO) \
+    case NO: hipLaunchKernelGGL(thin_wgrad_kernel<NO>, grid, dim3(256), 0, s, dout, dm, in, im, k_in, kp, rows, rpc, scratch); break;
+        switch (n_out) {
+            HOWL_THIN(1) HOWL_THIN(2) HOWL_THIN(3) HOWL_THIN(4) HOWL_THIN(5) HOWL_THIN(6) HOWL_THIN(7) HOWL_THIN(8)
+        }
+#undef HOWL_THIN
+        const long n = (long)n_out * k_in;
+        hipLaunchKernelGGL(sum_slabs_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, s, (const float*)scratch, chunks, n, dw);
+        return;
+    }
     // A(m = out col, k = row) = dout[dm(k) + m]  -> unit stride is m
     const int z = gemm(s, false, dout, lin(1), 0, dm, in, im, 1, n_out, k_in, rows, splits, nullptr, 0, scratch, k_in,
                        (long)n_out * k_in);
