@@ -55,12 +55,18 @@ __host__ __device__ inline int chan_stride(int H) {
     return cs + pad;
 }
 __host__ __device__ inline int tile_floats(int H) { return CP * chan_stride(H) + 32; }
-// The weight-gradient kernel reads its two tiles CHANNEL-major: lane l & 15 selects the channel (stride CS), lane >> 4 one of
-// 4 consecutive positions.  ds_read_b32 is served per 32-lane half over 32 banks: halves {channels 0..15} x {position p, p+1}
-// are conflict-free iff {CS*i mod 32} are 16 values no two of which are adjacent, i.e. CS = 2 (mod 32) (all even banks, the
-// partner position takes the odd ones).  With the 17 (mod 32) stride of the forward tiles every read was 2-way conflicted.
+// The weight-gradient kernel reads its two tiles CHANNEL-major: lane l & 15 selects the channel (stride CS), lane >> 4 = g one
+// of the four positions of a k-step.  Group g walks along the rows h = g, g + 4, g + 8, ... of the map, one column per k-step,
+// so inside a row every operand address is "lane base + immediate" (no address arithmetic in the K loop, cf. k_run).
+// ds_read_b32 is served per 32-lane half over 32 banks; a half holds {channels 0..15} x {groups g, g+1}: conflict-free iff
+// {CS*i mod 32} are 16 values no two of which are adjacent, i.e. CS = 2 (mod 32) (all even banks), and the two groups' rows
+// are an odd number of floats apart -- hence the row pitch of 13 here (12 in the forward tiles).  A channel holds rows
+// 0 .. 4*ceil(H/4): top halo, H data rows, zero rows up to the last row any group touches; the bottom halo of the last of
+// them is the next channel's top halo.
+constexpr int WPW = 13;
+__host__ __device__ inline int wgrad_rounds(int H) { return (H + 3) / 4; }
 __host__ __device__ inline int chan_stride_wgrad(int H) {
-    int cs = (H + 1) * WP + 1;
+    int cs = (4 * wgrad_rounds(H) + 1) * WPW;
     int pad = (2 - (cs % 32) + 32) % 32;
     return cs + pad;
 }
@@ -101,7 +107,7 @@ __device__ __forceinline__ void zero_lds(float* p, int n, int tid, int nthreads)
 // Per-thread staging slots: slot j moves the float2 at element pair e2 = tid + j*768 of an utterance's
 // (45, P) map to its place in the zero-haloed LDS tile.  The destination (and channel, for the BatchNorm
 // parameters) depends only on the thread, so it is packed once: bits 0..19 LDS float offset, 20..25 channel.
-__device__ __forceinline__ void stage_slots(int (&pk)[PREF], int P, int CS, int n2, int tid) {
+__device__ __forceinline__ void stage_slots(int (&pk)[PREF], int P, int CS, int n2, int tid, int pitch = WP) {
 #pragma unroll
     for (int j = 0; j < PREF; ++j) {
         const int e2 = tid + j * CONV_THREADS;
@@ -110,7 +116,7 @@ __device__ __forceinline__ void stage_slots(int (&pk)[PREF], int P, int CS, int 
         const int p = e - c * P;
         const int h = p / PW;
         const int w = p - h * PW;
-        pk[j] = (e2 < n2) ? ((c * CS + (h + 1) * WP + (w + 1)) | (c << 20)) : -1;
+        pk[j] = (e2 < n2) ? ((c * CS + (h + 1) * pitch + (w + 1)) | (c << 20)) : -1;
     }
 }
 
@@ -212,6 +218,19 @@ __device__ __forceinline__ void prefetch_pair(float2 (&pre)[PREF], const float* 
         for (int j = J; j < J + 2; ++j) {
             const int e2 = tid + j * CONV_THREADS;
             if (e2 < n2) pre[j] = reinterpret_cast<const float2*>(nsrc)[e2];
+        }
+    }
+}
+
+// the same for the weight-gradient kernel, which issues four loads per burst: `cond ? load : 0` writes a fresh register
+// under the execution mask, whereas "keep the old value" makes every load wait for the one before it (vmcnt(0))
+template <int J>
+__device__ __forceinline__ void prefetch_pair_fresh(float2 (&pre)[PREF], const float* nsrc, int n2, int tid) {
+    if (nsrc != nullptr) {
+#pragma unroll
+        for (int j = J; j < J + 2; ++j) {
+            const int e2 = tid + j * CONV_THREADS;
+            pre[j] = (e2 < n2) ? reinterpret_cast<const float2*>(nsrc)[e2] : make_float2(0.0f, 0.0f);
         }
     }
 }
@@ -475,6 +494,145 @@ __device__ unsigned long long* g_howl_probe = nullptr;
 #endif
 
 // wgrad: dW[cout][cin][tap] += sum_{b,p} dz[b,cout,p] * x[b,cin,p + tap shift],  x = (s_prev - mean) * rstd
+//
+// One wave owns NB of the 27 N tiles (tap, cin tile) and all three cout tiles: 3*NB accumulator chains that live in
+// registers across every utterance of the workgroup.
+template <int NB>
+struct WCursor {
+    const lds_f32* ap[3];    // dz rows of the three cout tiles (interior origin), this lane's channel and position group
+    const lds_f32* bp[NB];   // x rows of the N tiles (halo origin + tap shift)
+};
+
+// `rounds` rows per position group = 10 k-steps each.  The operands of k-step s+1 are requested before the MFMAs of step
+// s; all offsets inside a round are immediates (next column: +1 float, next row of this group: +4 rows).
+template <int NB>
+__device__ __forceinline__ void wgrad_k_run(WCursor<NB>& c, f32x4 (&acc)[NB][3], float (&az)[3], float (&bx)[NB],
+                                            int rounds) {
+#pragma nounroll
+    for (int r = 0; r < rounds; ++r) {
+#pragma unroll
+        for (int w = 0; w < PW; ++w) {
+            const int noff = (w + 1 < PW) ? (w + 1) : 4 * WPW;
+            float nz[3], nx[NB];
+#if defined(HOWL_DIAG_WGRAD_NOLDS)  // diagnostic build: MFMA chains fed from registers (tools/variants.py)
+#pragma unroll
+            for (int mt = 0; mt < 3; ++mt) nz[mt] = az[mt];
+#pragma unroll
+            for (int i = 0; i < NB; ++i) nx[i] = bx[i];
+#else
+#pragma unroll
+            for (int mt = 0; mt < 3; ++mt) nz[mt] = c.ap[mt][noff];
+#pragma unroll
+            for (int i = 0; i < NB; ++i) nx[i] = c.bp[i][noff];
+#endif
+#pragma unroll
+            for (int i = 0; i < NB; ++i)
+#pragma unroll
+                for (int mt = 0; mt < 3; ++mt) {
+#if defined(HOWL_DIAG_WGRAD_NOMFMA)  // diagnostic build: LDS traffic only
+                    acc[i][mt][0] += az[mt] * bx[i];
+#else
+                    acc[i][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(az[mt], bx[i], acc[i][mt], 0, 0, 0);
+#endif
+                }
+#pragma unroll
+            for (int mt = 0; mt < 3; ++mt) az[mt] = nz[mt];
+#pragma unroll
+            for (int i = 0; i < NB; ++i) bx[i] = nx[i];
+        }
+#pragma unroll
+        for (int mt = 0; mt < 3; ++mt) c.ap[mt] += 4 * WPW;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) c.bp[i] += 4 * WPW;
+    }
+}
+
+struct WgradArgs {
+    const float* dz;
+    const float* s_prev;
+    float* part;
+    float* tz;
+    float* tx;
+    const float* lmean;
+    const float* lrstd;
+    int B, P, CS, R, n2, tid, lane, wave;
+    bool affine;
+};
+
+// all utterances b, b + gridDim.x, ... of this workgroup (pz / px hold utterance b on entry), then this wave's partials
+template <int NB>
+__device__ __forceinline__ void wgrad_loop(const WgradArgs& a, float2 (&pz)[PREF], float2 (&px)[PREF],
+                                           const int (&pk)[PREF], int b, int& pslot) {
+    const int lane = a.lane, wave = a.wave, CS = a.CS;
+    const int g = lane >> 4, n = lane & 15;
+    f32x4 acc[NB][3];
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+        for (int mt = 0; mt < 3; ++mt) acc[i][mt] = {0.0f, 0.0f, 0.0f, 0.0f};
+    // N tiles q = wave, wave + 12, wave + 24 (< 27): q = 3 * tap + cin tile
+    int boff[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int q = wave + 12 * i;
+        const int tap = q / 3, ct = q - 3 * tap;
+        boff[i] = (16 * ct + n) * CS + (g + tap / 3) * WPW + (tap % 3);   // cin row, halo origin + tap shift
+    }
+    const int aoff = n * CS + (g + 1) * WPW + 1;                           // cout row, interior origin
+    for (; b < a.B; b += gridDim.x) {
+        stage_tile(pz, pk, a.tz, a.lmean, a.lrstd, false, false);
+        stage_tile(px, pk, a.tx, a.lmean, a.lrstd, a.affine, true);
+        HOWL_PROBE(wave, lane, pslot++);   // staged
+        __syncthreads();
+        HOWL_PROBE(wave, lane, pslot++);   // barrier
+        const int bn = b + gridDim.x;
+        const float* nz = (bn < a.B) ? a.dz + (size_t)bn * NMAP * a.P : nullptr;
+        const float* nx = (bn < a.B) ? a.s_prev + (size_t)bn * NMAP * a.P : nullptr;
+        WCursor<NB> c;
+#pragma unroll
+        for (int mt = 0; mt < 3; ++mt) c.ap[mt] = (const lds_f32*)a.tz + aoff + 16 * mt * CS;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) c.bp[i] = (const lds_f32*)a.tx + boff[i];
+        float az[3], bx[NB];
+#pragma unroll
+        for (int mt = 0; mt < 3; ++mt) az[mt] = c.ap[mt][0];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) bx[i] = c.bp[i][0];
+        // The next utterance's 16 loads per thread are issued in four bursts between segments of the K loop (see
+        // prefetch_pair): back to back they would hold up the first MFMAs for several thousand cycles.
+        const int rq = a.R / 4;
+        prefetch_pair_fresh<0>(pz, nz, a.n2, a.tid);
+        prefetch_pair_fresh<0>(px, nx, a.n2, a.tid);
+        wgrad_k_run<NB>(c, acc, az, bx, rq);
+        prefetch_pair_fresh<2>(pz, nz, a.n2, a.tid);
+        prefetch_pair_fresh<2>(px, nx, a.n2, a.tid);
+        wgrad_k_run<NB>(c, acc, az, bx, rq);
+        prefetch_pair_fresh<4>(pz, nz, a.n2, a.tid);
+        prefetch_pair_fresh<4>(px, nx, a.n2, a.tid);
+        wgrad_k_run<NB>(c, acc, az, bx, rq);
+        prefetch_pair_fresh<6>(pz, nz, a.n2, a.tid);
+        prefetch_pair_fresh<6>(px, nx, a.n2, a.tid);
+        wgrad_k_run<NB>(c, acc, az, bx, a.R - 3 * rq);
+        HOWL_PROBE(wave, lane, pslot++);   // K loop done
+        __syncthreads();  // single-buffered tiles: everyone done before the next stage overwrites them
+        HOWL_PROBE(wave, lane, pslot++);   // barrier
+    }
+    // D[row = cout = 16mt + 4*(lane>>4) + r][col = n = lane&15 -> cin = 16ct + col] for N tile q = (tap, ct)
+    float* dst = a.part + (size_t)blockIdx.x * CP * 432;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int q = wave + 12 * i;
+        const int tap = q / 3, ct = q - 3 * tap;
+#pragma unroll
+        for (int mt = 0; mt < 3; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = 16 * mt + 4 * g + r;
+                dst[co * 432 + tap * CP + 16 * ct + n] = acc[i][mt][r];
+            }
+    }
+}
+
 __global__ __launch_bounds__(CONV_THREADS) void wgrad_mfma_kernel(
     const float* __restrict__ dz, const float* __restrict__ s_prev, const float* __restrict__ in_stats,
     float* __restrict__ part /* [gridDim.x][48][432] */, int B, int H) {
@@ -489,16 +647,15 @@ __global__ __launch_bounds__(CONV_THREADS) void wgrad_mfma_kernel(
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n2 = NMAP * P / 2;
     const bool affine = in_stats != nullptr;
-    const int ksteps = (P + 3) / 4;
     int pslot = 0;
     HOWL_PROBE(wave, lane, pslot++);   // entry
 
     // first utterance's tiles are requested before the LDS setup so that HBM latency overlaps it
     float2 pz[PREF], px[PREF];
-    int b = blockIdx.x;
+    const int b = blockIdx.x;
     if (b < B) {
         prefetch_tile(pz, dz + (size_t)b * NMAP * P, n2, tid);
         prefetch_tile(px, s_prev + (size_t)b * NMAP * P, n2, tid);
@@ -508,129 +665,17 @@ __global__ __launch_bounds__(CONV_THREADS) void wgrad_mfma_kernel(
         lmean[tid] = affine ? in_stats[tid] : 0.0f;
         lrstd[tid] = affine ? in_stats[CP + tid] : 1.0f;
     }
-    // this wave's N tiles (tap, cin tile): q = wave, wave+12, wave+24 (< 27); all 3 cout tiles each
-    f32x4 acc[3][3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int mt = 0; mt < 3; ++mt) acc[i][mt] = {0.0f, 0.0f, 0.0f, 0.0f};
-    int boff[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const int q = wave + 12 * i;
-        const int tap = (q < 27) ? q / 3 : 0, ct = (q < 27) ? q % 3 : 0;
-        boff[i] = (16 * ct + (lane & 15)) * CS + (tap / 3) * WP + (tap % 3);  // cin row + tap shift (halo origin)
-    }
-    const bool has3 = __builtin_amdgcn_readfirstlane(wave) + 24 < 27;  // wave-uniform: a scalar branch, not exec masking
-    const int aoff = (lane & 15) * CS + WP + 1;  // cout row, interior origin
-
     int pk[PREF];
-    stage_slots(pk, P, CS, n2, tid);
+    stage_slots(pk, P, CS, n2, tid, WPW);
     __syncthreads();
     HOWL_PROBE(wave, lane, pslot++);   // prologue done
-    for (; b < B; b += gridDim.x) {
-        stage_tile(pz, pk, tz, lmean, lrstd, false, false);
-        stage_tile(px, pk, tx, lmean, lrstd, affine, true);
-        HOWL_PROBE(wave, lane, pslot++);   // staged
-        __syncthreads();
-        HOWL_PROBE(wave, lane, pslot++);   // barrier
-        const int bn = b + gridDim.x;
-        const float* nz = (bn < B) ? dz + (size_t)bn * NMAP * P : nullptr;
-        const float* nx = (bn < B) ? s_prev + (size_t)bn * NMAP * P : nullptr;
-        // K loop over positions, 4 per MFMA: this lane feeds position p = 4*kk + (lane >> 4).  Operands of step
-        // kk+1 are loaded before the MFMAs of step kk (software pipeline), so LDS latency hides under the matrix pipe.
-        // The next utterance's 16 loads per thread are issued in four bursts between quarters of the loop (see
-        // prefetch_pair): back to back they would hold up the first MFMAs for several thousand cycles.
-        int h = 0, w = lane >> 4;  // p < 4 < PW
-        int pos = h * WP + w;      // positions >= P land in the zero bottom halo row
-        float az0 = tz[aoff + pos], az1 = tz[aoff + 16 * CS + pos], az2 = tz[aoff + 32 * CS + pos];
-        float bx0 = tx[boff[0] + pos], bx1 = tx[boff[1] + pos], bx2 = has3 ? tx[boff[2] + pos] : 0.0f;
-        auto k_steps = [&](int kbeg, int kend) {
-#if defined(HOWL_DIAG_WGRAD_UNROLL)
-#pragma unroll HOWL_DIAG_WGRAD_UNROLL
-#else
-#pragma nounroll
-#endif
-            for (int kk = kbeg; kk < kend; ++kk) {
-                if (kk + 1 < ksteps) {
-                    w += 4;
-                    if (w >= PW) {
-                        w -= PW;
-                        h += 1;
-                    }
-                    pos = h * WP + w;
-                }
-#if defined(HOWL_DIAG_WGRAD_NOLDS)  // diagnostic build: MFMA chains fed from registers (tools/variants.py)
-                const float nz0 = __builtin_bit_cast(float, pos), nz1 = nz0, nz2 = nz0, nx0 = nz0, nx1 = nz0;
-                float nx2 = nz0;
-#else
-                const float nz0 = tz[aoff + pos], nz1 = tz[aoff + 16 * CS + pos], nz2 = tz[aoff + 32 * CS + pos];
-                const float nx0 = tx[boff[0] + pos], nx1 = tx[boff[1] + pos];
-                float nx2 = 0.0f;
-                if (has3) nx2 = tx[boff[2] + pos];
-#endif
-#if defined(HOWL_DIAG_WGRAD_NOMFMA)  // diagnostic build: LDS traffic and address arithmetic only
-                acc[0][0][0] += az0 * bx0 + az1 * bx1 + az2 * bx2;
-                if (false)
-#endif
-                acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(az0, bx0, acc[0][0], 0, 0, 0);
-#if defined(HOWL_DIAG_WGRAD_NOMFMA)
-                if (false) {
-#endif
-                acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(az1, bx0, acc[0][1], 0, 0, 0);
-                acc[0][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(az2, bx0, acc[0][2], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(az0, bx1, acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(az1, bx1, acc[1][1], 0, 0, 0);
-                acc[1][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(az2, bx1, acc[1][2], 0, 0, 0);
-                if (has3) {
-                    acc[2][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(az0, bx2, acc[2][0], 0, 0, 0);
-                    acc[2][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(az1, bx2, acc[2][1], 0, 0, 0);
-                    acc[2][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(az2, bx2, acc[2][2], 0, 0, 0);
-                }
-#if defined(HOWL_DIAG_WGRAD_NOMFMA)
-                }
-#endif
-                az0 = nz0;
-                az1 = nz1;
-                az2 = nz2;
-                bx0 = nx0;
-                bx1 = nx1;
-                bx2 = nx2;
-            }
-        };
-        const int kq = ksteps / 5;
-        prefetch_pair<0>(pz, nz, n2, tid);
-        prefetch_pair<0>(px, nx, n2, tid);
-        k_steps(0, kq);
-        prefetch_pair<2>(pz, nz, n2, tid);
-        prefetch_pair<2>(px, nx, n2, tid);
-        k_steps(kq, 2 * kq);
-        prefetch_pair<4>(pz, nz, n2, tid);
-        prefetch_pair<4>(px, nx, n2, tid);
-        k_steps(2 * kq, 3 * kq);
-        prefetch_pair<6>(pz, nz, n2, tid);
-        prefetch_pair<6>(px, nx, n2, tid);
-        k_steps(3 * kq, ksteps);
-        HOWL_PROBE(wave, lane, pslot++);   // K loop done
-        __syncthreads();  // single-buffered tiles: everyone done before the next stage overwrites them
-        HOWL_PROBE(wave, lane, pslot++);   // barrier
-    }
-    // D[row = cout = 16mt + 4*(lane>>4) + r][col = n = lane&15 -> cin = 16ct + col] for N tile q = (tap, ct)
-    float* dst = part + (size_t)blockIdx.x * CP * 432;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const int q = wave + 12 * i;
-        if (q < 27) {
-            const int tap = q / 3, ct = q % 3;
-#pragma unroll
-            for (int mt = 0; mt < 3; ++mt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int co = 16 * mt + 4 * (lane >> 4) + r;
-                    dst[co * 432 + tap * CP + 16 * ct + (lane & 15)] = acc[i][mt][r];
-                }
-        }
-    }
+    // instantiated per tile count (waves 0..2 carry a third N tile): no branches inside the K loop, and the register
+    // allocator sees one variant's live values (waves of a workgroup run different instances with the same barriers)
+    const WgradArgs a{dz, s_prev, part, tz, tx, lmean, lrstd, B, P, CS, wgrad_rounds(H), n2, tid, lane, wave, affine};
+    if (wave + 24 < 27)
+        wgrad_loop<3>(a, pz, px, pk, b, pslot);
+    else
+        wgrad_loop<2>(a, pz, px, pk, b, pslot);
     HOWL_PROBE(wave, lane, pslot++);   // partials written
 }
 
