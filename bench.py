@@ -104,7 +104,7 @@ def pmc_traffic():
     vals = []
     lines = files[-1].read_text().splitlines()
     for i, line in enumerate(lines):
-        if line.startswith("conv3x3_mfma_kernel<") and i + 1 < len(lines):
+        if line.startswith("conv3x3_mfma_kernel<0>") and i + 1 < len(lines):
             d = json.loads(lines[i + 1].strip())
             if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
                 vals.append(((2 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024.0, d.get("launches", 1)))
@@ -197,21 +197,25 @@ def main():
         tl, nl = read("logmel", reset=1)
         H = (1 + L // 200) // 3
         flops_launch = 2.0 * 9 * 45 * 45 * (H * 10) * B
-        avg_ms = (tf + td) / max(nf + nd, 1)
+        # the forward launches run alone on the device; dgrad and wgrad of a layer share it (two HIP queues, half the CUs
+        # each), so their event-bracketed durations include the sharing and are listed under other_kernels only
+        avg_ms = tf / max(nf, 1)
         achieved = flops_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
         traffic, traffic_src = pmc_traffic() if (B == 512 and L == 16000) else (None, None)
-        roof = {"bound": "mfma", "kernel": "conv3x3_mfma_kernel (45->45 conv, fwd + dgrad launches)",
+        roof = {"bound": "mfma", "kernel": "conv3x3_mfma_kernel<0> (45->45 3x3 convolution, forward launches)",
                 "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
                 "traffic": None if traffic is None else round(traffic),
                 "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)", "traffic_source": traffic_src,
-                # input + output maps always; the residual on half of the forward launches, the saved activation
-                # (for the BatchNorm-backward statistics) on 5 of 6 dgrad launches
-                "algorithmic_bytes": round(4.0 * 45 * (H * 10) * B * (2 + (0.5 + 5.0 / 6.0) / 2)),
-                "avg_launch_ms": round(avg_ms, 4), "launches": nf + nd,
+                # input + output maps always; the residual on half of the forward launches
+                "algorithmic_bytes": round(4.0 * 45 * (H * 10) * B * 2.5),
+                "avg_launch_ms": round(avg_ms, 4), "launches": nf,
                 "other_kernels": {
-                    "wgrad_mfma": {"avg_launch_ms": round(tw / max(nw, 1), 4),
-                                   "tflops": round(flops_launch / (tw / max(nw, 1) * 1e-3) / 1e12, 2) if tw > 0 else None},
+                    "note": "dgrad and wgrad of a layer run concurrently on half the CUs each: per-launch durations overlap",
+                    "conv3x3_dgrad": {"avg_launch_ms": round(td / max(nd, 1), 4), "launches": nd},
+                    "wgrad_mfma": {"avg_launch_ms": round(tw / max(nw, 1), 4), "launches": nw},
+                    "dgrad+wgrad_pair": {"tflops": round(2 * flops_launch / (max(td / max(nd, 1), tw / max(nw, 1)) * 1e-3) / 1e12, 2)
+                                         if tw > 0 and td > 0 else None},
                     "logmel": {"avg_launch_ms": round(tl / max(nl, 1), 4),
                                "hbm_gbs": round((4.0 * L + 4.0 * 40 * (1 + L // 200)) * B / (tl / max(nl, 1) * 1e-3) / 1e9, 1)
                                if tl > 0 else None, "hbm_frac": round((4.0 * L + 4.0 * 40 * (1 + L // 200)) * B /

@@ -22,6 +22,11 @@
 //     BatchNorm needs (per-workgroup partials, reduced deterministically by a tiny finalize kernel).
 // wgrad is the transposed GEMM (M = cout, N = tap x cin, K = positions) with the 45x405 accumulators resident
 // in registers across all utterances of a workgroup, written once as per-workgroup partials.
+#include <cstdlib>
+#include <map>
+#include <mutex>
+#include <utility>
+
 #include "howl_common.hip.h"
 #include "../../include/howl_hip.h"
 
@@ -1226,9 +1231,10 @@ struct Ws {
     float* stats;    // eval-mode stats [6][2][48]
     float* m12;      // [2][48]
     float* dpool;    // [B][48]
-    float* bufa;     // (B,45,P) x4: dx ping-pong, dz, ds ping-pong
+    float* bufa;     // (B,45,P) x6: dx ping-pong, dz ping-pong, ds ping-pong
     float* bufb;
     float* dz;
+    float* dz2;
     float* dsa;
     float* dsb;
     float* wpart;    // [G][48][432]
@@ -1253,12 +1259,53 @@ size_t ws_layout(Ws* w, char* base, int B, int H, int G) {
     t.bufa = take(act);
     t.bufb = take(act);
     t.dz = take(act);
+    t.dz2 = take(act);
     t.dsa = take(act);
     t.dsb = take(act);
     t.wpart = take((size_t)G * CP * 432);
     t.c0part = take((size_t)G * NMAP * 9);
     if (w) *w = t;
     return off;
+}
+
+// The backward pass runs on two HIP queues.  A layer's data gradient (dgrad, on the caller's stream: the chain the next
+// layer waits for) and its weight gradient (wgrad + the reduction of its partials, which only AdamW waits for) both hang
+// off dz_i and are independent, so they are launched side by side, each on HALF the CUs: a workgroup then carries twice
+// the utterances per launch, i.e. the per-launch costs (dispatch, weight / LDS prologue, first-tile fetch, tail) are paid
+// once per two utterance passes instead of once per pass, and the small reduction leaves the critical path.  Fork and
+// join are plain event record / wait pairs (capturable into a hipGraph); dz is double-buffered so that layer i-2's BN
+// backward cannot overwrite what wgrad_i is still reading.  One side queue per (device, caller stream), created on
+// first use and kept for the life of the process.  HOWL_RES8_BWD_QUEUES=1 keeps everything on the caller's stream.
+struct SideQueue {
+    hipStream_t stream = nullptr;
+    hipEvent_t dz_ready[6];
+    hipEvent_t dz_free[6];
+    hipEvent_t done;
+};
+std::mutex g_side_mu;
+std::map<std::pair<int, hipStream_t>, SideQueue*> g_side;
+
+SideQueue* side_queue(hipStream_t main) {
+    const char* env = getenv("HOWL_RES8_BWD_QUEUES");
+    if (env != nullptr && env[0] == '1') return nullptr;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lk(g_side_mu);
+    auto key = std::make_pair(dev, main);
+    auto it = g_side.find(key);
+    if (it != g_side.end()) return it->second;
+    SideQueue* q = new SideQueue;
+    bool ok = hipStreamCreateWithFlags(&q->stream, hipStreamNonBlocking) == hipSuccess;
+    for (int i = 0; ok && i < 6; ++i)
+        ok = hipEventCreateWithFlags(&q->dz_ready[i], hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&q->dz_free[i], hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&q->done, hipEventDisableTiming) == hipSuccess;
+    if (!ok) {
+        delete q;
+        q = nullptr;   // everything on the caller's stream (same kernels, full-width grids)
+    }
+    g_side[key] = q;
+    return q;
 }
 
 int conv_grid(int B) {
@@ -1361,6 +1408,13 @@ int howl_res8_bwd(const HowlRes8Params* prm, const float* feat, long sb, long st
     const size_t lw = wgrad_lds_bytes(H);
     hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                         (int)lw);
+    SideQueue* sq = side_queue(stream);
+    hipStream_t wstream = sq ? sq->stream : stream;   // weight-gradient queue
+    int Gh = G;   // dgrad and wgrad side by side: at most half the CUs each
+    if (sq) {
+        const int half = howl_num_cus() / 2 > 0 ? howl_num_cus() / 2 : 1;
+        Gh = B < half ? B : half;
+    }
     float* dx_cur = nullptr;      // gradient w.r.t. the BN output of layer i (nullptr: broadcast of dpool)
     float* dx_next = w.bufa;
     float* ds_prev = nullptr;     // ds_{i+2}
@@ -1369,33 +1423,40 @@ int howl_res8_bwd(const HowlRes8Params* prm, const float* feat, long sb, long st
         const bool even = (i % 2) == 0;
         const float* stats_i = sv->bn_stats + (size_t)(i - 1) * 2 * CP;
         float* ds_out = even ? ds_free : nullptr;
+        float* dz = even ? w.dz : w.dz2;
+        if (sq && i <= 4) hipStreamWaitEvent(stream, sq->dz_free[i + 1], 0);   // wgrad_{i+2} has finished with this dz buffer
         hipLaunchKernelGGL(bn_relu_bwd_kernel, dim3(eg), dim3(256), 0, stream, (const float*)dx_cur, w.dpool, sv->s[i],
-                           stats_i, w.m12, even ? (const float*)ds_prev : (const float*)nullptr, even ? 1 : 0, ds_out, w.dz, B, P);
+                           stats_i, w.m12, even ? (const float*)ds_prev : (const float*)nullptr, even ? 1 : 0, ds_out, dz, B, P);
+        if (sq) {
+            hipEventRecord(sq->dz_ready[i - 1], stream);
+            hipStreamWaitEvent(wstream, sq->dz_ready[i - 1], 0);
+        }
         if (even) {
             float* t = ds_prev ? ds_prev : w.dsb;
             ds_prev = ds_out;
             ds_free = t;
         }
-        // weight gradient of layer i: input x_{i-1} = BN_{i-1}(s_{i-1}) (identity for i = 1)
-        const float* in_stats = (i == 1) ? nullptr : sv->bn_stats + (size_t)(i - 2) * 2 * CP;
-        {
-            HowlProfScope prof("wgrad", stream);
-            hipLaunchKernelGGL(wgrad_mfma_kernel, dim3(G), dim3(CONV_THREADS), lw, stream, (const float*)w.dz, sv->s[i - 1],
-                               in_stats, w.wpart, B, H);
-        }
-        hipLaunchKernelGGL(reduce_rows_kernel, dim3((CP * 432 + 63) / 64), dim3(256), 0, stream, (const float*)w.wpart, G,
-                           CP * 432, 1, gr->conv_w[i - 1]);
         // data gradient: dx_{i-1} (w.r.t. the normalised input of layer i), with BN_{i-1} backward statistics
+        const float* in_stats = (i == 1) ? nullptr : sv->bn_stats + (size_t)(i - 2) * 2 * CP;
         const bool need_stats = i > 1;
         {
             HowlProfScope prof("conv3x3_dgrad", stream);
-            hipLaunchKernelGGL(conv3x3_mfma_kernel<1>, dim3(G), dim3(CONV_THREADS), lc, stream, (const float*)w.dz,
+            hipLaunchKernelGGL(conv3x3_mfma_kernel<1>, dim3(Gh), dim3(CONV_THREADS), lc, stream, (const float*)dz,
                                (const float*)nullptr, w.wp_bwd + (size_t)(i - 1) * 3 * KSTEPS * 64, (const float*)nullptr,
                                dx_next, need_stats ? sv->s[i - 1] : (const float*)nullptr, in_stats,
                                need_stats ? w.part : (float*)nullptr, B, H);
         }
+        // weight gradient of layer i: input x_{i-1} = BN_{i-1}(s_{i-1}) (identity for i = 1)
+        {
+            HowlProfScope prof("wgrad", wstream);
+            hipLaunchKernelGGL(wgrad_mfma_kernel, dim3(Gh), dim3(CONV_THREADS), lw, wstream, (const float*)dz, sv->s[i - 1],
+                               in_stats, w.wpart, B, H);
+        }
+        if (sq) hipEventRecord(sq->dz_free[i - 1], wstream);
+        hipLaunchKernelGGL(reduce_rows_kernel, dim3((CP * 432 + 63) / 64), dim3(256), 0, wstream, (const float*)w.wpart, Gh,
+                           CP * 432, 1, gr->conv_w[i - 1]);
         if (need_stats)
-            hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(1024), 0, stream, (const float*)w.part, G, count,
+            hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(1024), 0, stream, (const float*)w.part, Gh, count,
                                w.m12);
         dx_cur = dx_next;
         dx_next = (dx_next == w.bufa) ? w.bufb : w.bufa;
@@ -1410,6 +1471,10 @@ int howl_res8_bwd(const HowlRes8Params* prm, const float* feat, long sb, long st
                        (const float*)dx_cur, (const float*)ds_prev, w.c0part, B, T, M, H);
     hipLaunchKernelGGL(reduce_rows_kernel, dim3((NMAP * 9 + 63) / 64), dim3(256), 0, stream, (const float*)w.c0part, G,
                        NMAP * 9, 0, gr->conv0_w);
+    if (sq) {   // join: everything after this call on the caller's stream sees all weight gradients
+        hipEventRecord(sq->done, wstream);
+        hipStreamWaitEvent(stream, sq->done, 0);
+    }
     HOWL_CHECK_LAUNCH("howl_res8_bwd");
     return HOWL_OK;
 }

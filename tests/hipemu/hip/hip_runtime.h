@@ -56,6 +56,10 @@ static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMem
 typedef int hipEvent_t;
 static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = 0; return hipSuccess; }
 static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
+enum { hipEventDisableTiming = 2, hipStreamNonBlocking = 1 };
+static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = 0; return hipSuccess; }
+static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
+static inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = nullptr; return hipSuccess; }  // the emulator runs launches synchronously
 static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.0f; return hipSuccess; }
 static inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }

@@ -53,7 +53,11 @@ def test_golden_eval_and_train(golden, C):
         d = (v.detach().cpu().double() - ref).abs()
         tol = 1e-4 * max(1.0, float(ref.abs().max()))
         assert d.max().item() < 3 * 0.01 + tol, k
-        assert (d > tol).double().mean().item() < 1e-1, (k, (d > tol).double().mean().item())
+        if "running_" in k:
+            # BatchNorm statistics sit downstream of those few O(lr) weight differences: relative agreement only
+            assert d.max().item() < 1e-3 * max(1.0, float(ref.abs().max())), k
+        else:
+            assert (d > tol).double().mean().item() < 1e-1, (k, (d > tol).double().mean().item())
     assert int(sd["bn3.num_batches_tracked"]) == 3
     model.eval()
     with torch.no_grad():
@@ -178,3 +182,29 @@ def test_odd_geometries_vs_oracle(B, T, C):
     assert maxerr(ev, om.res8_forward(sd_eval, x.contiguous(), False)) < LOGIT_TOL
     with pytest.raises(Exception):
         model(torch.randn(2, 1, 40, 84, device=DEV), None)    # T > 83: outside the supported window, loudly
+
+
+def test_two_queue_backward_repeats_bit_identically(monkeypatch):
+    """howl_res8_bwd launches dgrad and wgrad of a layer side by side on two HIP queues (half the CUs each).  Repeating the
+    same step must give bit-identical gradients (no race on the double-buffered dz / the partial buffers), and the
+    single-queue schedule (HOWL_RES8_BWD_QUEUES=1, full-width grids, different partial counts) must agree to rounding."""
+    B, T, C = 96, 81, 12
+    torch.manual_seed(7)
+    x = (torch.randn(B, T, 40) * 1.2).permute(0, 2, 1).unsqueeze(1).to(DEV)
+    labels = (torch.arange(B) % C).to(DEV)
+
+    def grads():
+        model = make_res8(C)
+        torch.nn.functional.cross_entropy(model(x, None), labels).backward()
+        torch.cuda.synchronize()
+        return [p.grad.clone() for p in model.hot_parameters()]
+
+    first = grads()
+    for _ in range(8):
+        again = grads()
+        for a, b in zip(first, again):
+            assert torch.equal(a, b)
+    monkeypatch.setenv("HOWL_RES8_BWD_QUEUES", "1")
+    single = grads()
+    for a, b in zip(first, single):
+        assert maxerr(a, b.cpu()) < 2e-5 * max(1.0, b.abs().max().item())
