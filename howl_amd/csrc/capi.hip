@@ -4,8 +4,12 @@
 #include "howl_common.hip.h"
 #include "../../include/howl_hip.h"
 
+#include <stdlib.h>
+
+#include <map>
 #include <mutex>
 #include <string>
+#include <tuple>
 #include <vector>
 
 namespace {
@@ -19,7 +23,31 @@ struct ProfRec {
 std::mutex g_prof_mu;
 bool g_prof_on = false;
 std::vector<ProfRec> g_prof;
+
+std::mutex g_side_mu;
+std::map<std::tuple<int, hipStream_t, int>, HowlSideQueue*> g_side;
 }  // namespace
+
+HowlSideQueue* howl_side_queue(hipStream_t caller, int purpose, const char* disable_env) {
+    const char* env = getenv(disable_env);
+    if (env != nullptr && env[0] == '1') return nullptr;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lk(g_side_mu);
+    const auto key = std::make_tuple(dev, caller, purpose);
+    auto it = g_side.find(key);
+    if (it != g_side.end()) return it->second;
+    HowlSideQueue* q = new HowlSideQueue;
+    bool ok = hipStreamCreateWithFlags(&q->stream, hipStreamNonBlocking) == hipSuccess;
+    for (int i = 0; ok && i < HOWL_SIDE_EVENTS; ++i)
+        ok = hipEventCreateWithFlags(&q->ev[i], hipEventDisableTiming) == hipSuccess;
+    if (!ok) {
+        delete q;
+        q = nullptr;
+    }
+    g_side[key] = q;
+    return q;
+}
 
 bool howl_prof_begin(const char* tag, hipStream_t stream, size_t* slot) {
     std::lock_guard<std::mutex> lk(g_prof_mu);

@@ -123,7 +123,7 @@ struct Geo {
 struct Plan {
     std::vector<Geo> g;
     std::vector<size_t> z, y, yp, stats, dact;  // float offsets
-    size_t dz = 0, col = 0, dcol = 0, part = 0, gemm_scratch = 0, m12 = 0, pooled = 0, pooled_d = 0, dpooled = 0, dyp = 0;
+    size_t dz = 0, dz2 = 0, col = 0, dcol = 0, part = 0, gemm_scratch = 0, m12 = 0, pooled = 0, pooled_d = 0, dpooled = 0, dyp = 0;
     size_t total_floats = 0;
 };
 
@@ -188,6 +188,7 @@ Plan make_plan(int B, int H0, int W0, int num_labels) {
         w = g.wy;
     }
     p.dz = take(max_dz);
+    p.dz2 = take(max_dz);
     p.dyp = take(max_dz);
     p.col = take(max_col);
     p.dcol = take(max_col);
@@ -781,6 +782,14 @@ int howl_mobilenet_bwd(const float* params, int num_labels, const float* x, long
     }
     std::vector<char> has_grad(nl, 0);  // dact[k] already holds a residual contribution
     has_grad[nl - 1] = 1;
+    // Two HIP queues (cf. howl_res8_bwd): the BatchNorm-backward -> data-gradient chain stays on the caller's stream; a
+    // layer's weight gradient (split-K GEMM / depthwise reduction + slab sums, im2col for the dense layers) only hangs
+    // off dz_k and goes to the side queue, where its launches overlap the chain's -- at ~740 short launches per step the
+    // backward pass is bound by launch latency, not by the device.  dz is double-buffered (layer k-2 reuses layer k's
+    // buffer and waits for wgrad_k); events 0/1: dz ready, 2/3: wgrad done with that dz buffer, 4: join.
+    HowlSideQueue* sq = howl_side_queue(stream, 1, "HOWL_MOBILENET_BWD_QUEUES");
+    hipStream_t wst = sq ? sq->stream : stream;
+    int par = 0, forked = 0;
     for (int k = nl - 1; k >= 0; --k) {
         const HowlMbLayer& l = c.n->layers[k];
         const Geo& g = c.p.g[k];
@@ -806,9 +815,14 @@ int howl_mobilenet_bwd(const float* params, int num_labels, const float* x, long
                            params + l.gamma_off, params + l.beta_off, l.act, g.mz, l.cout, col_pack(l.cout), rpc, part);
         hipLaunchKernelGGL(bn_bwd_finalize_mb_kernel, dim3((l.cout + 63) / 64), dim3(256), 0, stream, (const double*)part,
                            chunks, l.cout, (double)g.mz, grads + l.gamma_off, grads + l.beta_off, m12);
-        float* dz = c.ws + c.p.dz;
+        float* dz = c.ws + (par ? c.p.dz2 : c.p.dz);
+        if (sq && forked >= 2) hipStreamWaitEvent(stream, sq->ev[2 + par], 0);
         hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(flat_grid(total)), dim3(256), 0, stream, z, dy, stats, params + l.gamma_off,
                            params + l.beta_off, (const float*)m12, l.act, l.cout, total, dz);
+        if (sq) {
+            hipEventRecord(sq->ev[par], stream);
+            hipStreamWaitEvent(wst, sq->ev[par], 0);
+        }
         // convolution backward
         const float* in = k > 0 ? c.ws + c.p.y[k - 1] : x;
         const float* w = params + l.w_off;
@@ -822,17 +836,17 @@ int howl_mobilenet_bwd(const float* params, int num_labels, const float* x, long
         }
         const long in_total = (long)B * g.hin * g.win * l.cin;
         if (l.kind == MB_PW) {
-            wgrad_gemm(stream, dz, lin(l.cout), l.cout, in, lin(l.cin), l.cin, (int)g.mz, scratch, gw, MB_WGRAD_SPLITS);
+            wgrad_gemm(wst, dz, lin(l.cout), l.cout, in, lin(l.cin), l.cin, (int)g.mz, scratch, gw, MB_WGRAD_SPLITS);
             if (dx != nullptr)
                 gemm(stream, true, dz, lin(l.cout), 1, lin(0), w, lin(l.cin), 1, (int)g.mz, l.cin, l.cout, 1, nullptr, 0, dx, l.cin,
                      0);
         } else if (l.kind == MB_DW) {
             const int wch = chunks_for(g.mz, 64);
             const long wrpc = (g.mz + wch - 1) / wch;
-            hipLaunchKernelGGL(dw3x3_wgrad_kernel, dim3((l.cout + 63) / 64, wch), dim3(256), 0, stream, (const float*)dz, in, g.hin,
+            hipLaunchKernelGGL(dw3x3_wgrad_kernel, dim3((l.cout + 63) / 64, wch), dim3(256), 0, wst, (const float*)dz, in, g.hin,
                                g.win, l.cin, g.ho, g.wo, l.stride, g.mz, wrpc, scratch);
             const long nw = (long)l.cout * 9;
-            hipLaunchKernelGGL(sum_slabs_kernel, dim3((unsigned)((nw + 63) / 64)), dim3(256), 0, stream, (const float*)scratch,
+            hipLaunchKernelGGL(sum_slabs_kernel, dim3((unsigned)((nw + 63) / 64)), dim3(256), 0, wst, (const float*)scratch,
                                wch, nw, gw);
             if (dx != nullptr) {
                 const dim3 grid((unsigned)(B * g.hin), (g.win * l.cin + 255) / 256);
@@ -853,10 +867,11 @@ int howl_mobilenet_bwd(const float* params, int num_labels, const float* x, long
             } else {
                 isb = (long)g.hin * g.win * l.cin, ish = (long)g.win * l.cin, isw = l.cin, isc = 1;
             }
-            hipLaunchKernelGGL(im2col3x3_kernel, dim3(flat_grid(ctot)), dim3(256), 0, stream, in, isb, ish, isw, isc, g.hin, g.win,
+            hipLaunchKernelGGL(im2col3x3_kernel, dim3(flat_grid(ctot)), dim3(256), 0, wst, in, isb, ish, isw, isc, g.hin, g.win,
                                l.cin, g.ho, g.wo, l.stride, l.pad_h, l.pad_w, ctot, col);
-            wgrad_gemm(stream, dz, lin(l.cout), l.cout, col, lin(K), K, (int)g.mz, scratch, gw, MB_WGRAD_SPLITS);
-            if (l.bias) {   // sum over pixels of dz (rounding noise in exact arithmetic: a BatchNorm follows the bias)
+            wgrad_gemm(wst, dz, lin(l.cout), l.cout, col, lin(K), K, (int)g.mz, scratch, gw, MB_WGRAD_SPLITS);
+            if (l.bias) {   // sum over pixels of dz (rounding noise in exact arithmetic: a BatchNorm follows the bias);
+                            // `part` belongs to the chain, so this reduction stays on the caller's stream
                 hipLaunchKernelGGL(col_reduce_kernel<0>, dim3((l.cout + 63) / 64, chunks), dim3(256), 0, stream, (const float*)dz,
                                    (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
                                    0, g.mz, l.cout, col_pack(l.cout), rpc, part);
@@ -873,6 +888,13 @@ int howl_mobilenet_bwd(const float* params, int num_labels, const float* x, long
         if (dtmp != nullptr)
             hipLaunchKernelGGL(add_inplace_kernel, dim3(flat_grid(in_total)), dim3(256), 0, stream, c.ws + c.p.dact[k - 1],
                                (const float*)dtmp, in_total);
+        if (sq) hipEventRecord(sq->ev[2 + par], wst);   // this layer's weight gradient no longer needs dz
+        par ^= 1;
+        ++forked;
+    }
+    if (sq) {   // join: everything after this call on the caller's stream sees all weight gradients
+        hipEventRecord(sq->ev[4], wst);
+        hipStreamWaitEvent(stream, sq->ev[4], 0);
     }
     HOWL_CHECK_LAUNCH("howl_mobilenet_bwd");
     return HOWL_OK;

@@ -22,11 +22,6 @@
 //     BatchNorm needs (per-workgroup partials, reduced deterministically by a tiny finalize kernel).
 // wgrad is the transposed GEMM (M = cout, N = tap x cin, K = positions) with the 45x405 accumulators resident
 // in registers across all utterances of a workgroup, written once as per-workgroup partials.
-#include <cstdlib>
-#include <map>
-#include <mutex>
-#include <utility>
-
 #include "howl_common.hip.h"
 #include "../../include/howl_hip.h"
 
@@ -1275,39 +1270,8 @@ size_t ws_layout(Ws* w, char* base, int B, int H, int G) {
 // once per two utterance passes instead of once per pass, and the small reduction leaves the critical path.  Fork and
 // join are plain event record / wait pairs (capturable into a hipGraph); dz is double-buffered so that layer i-2's BN
 // backward cannot overwrite what wgrad_i is still reading.  One side queue per (device, caller stream), created on
-// first use and kept for the life of the process.  HOWL_RES8_BWD_QUEUES=1 keeps everything on the caller's stream.
-struct SideQueue {
-    hipStream_t stream = nullptr;
-    hipEvent_t dz_ready[6];
-    hipEvent_t dz_free[6];
-    hipEvent_t done;
-};
-std::mutex g_side_mu;
-std::map<std::pair<int, hipStream_t>, SideQueue*> g_side;
-
-SideQueue* side_queue(hipStream_t main) {
-    const char* env = getenv("HOWL_RES8_BWD_QUEUES");
-    if (env != nullptr && env[0] == '1') return nullptr;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-    std::lock_guard<std::mutex> lk(g_side_mu);
-    auto key = std::make_pair(dev, main);
-    auto it = g_side.find(key);
-    if (it != g_side.end()) return it->second;
-    SideQueue* q = new SideQueue;
-    bool ok = hipStreamCreateWithFlags(&q->stream, hipStreamNonBlocking) == hipSuccess;
-    for (int i = 0; ok && i < 6; ++i)
-        ok = hipEventCreateWithFlags(&q->dz_ready[i], hipEventDisableTiming) == hipSuccess &&
-             hipEventCreateWithFlags(&q->dz_free[i], hipEventDisableTiming) == hipSuccess;
-    ok = ok && hipEventCreateWithFlags(&q->done, hipEventDisableTiming) == hipSuccess;
-    if (!ok) {
-        delete q;
-        q = nullptr;   // everything on the caller's stream (same kernels, full-width grids)
-    }
-    g_side[key] = q;
-    return q;
-}
-
+// first use and kept for the life of the process (howl_side_queue).  HOWL_RES8_BWD_QUEUES=1 keeps everything on the
+// caller's stream.  Events: 0..5 dz_i ready, 6..11 wgrad_i done with its dz buffer, 12 all weight gradients written.
 int conv_grid(int B) {
     int g = howl_num_cus();
     return B < g ? B : g;
@@ -1408,7 +1372,7 @@ int howl_res8_bwd(const HowlRes8Params* prm, const float* feat, long sb, long st
     const size_t lw = wgrad_lds_bytes(H);
     hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                         (int)lw);
-    SideQueue* sq = side_queue(stream);
+    HowlSideQueue* sq = howl_side_queue(stream, 0, "HOWL_RES8_BWD_QUEUES");
     hipStream_t wstream = sq ? sq->stream : stream;   // weight-gradient queue
     int Gh = G;   // dgrad and wgrad side by side: at most half the CUs each
     if (sq) {
@@ -1424,12 +1388,12 @@ int howl_res8_bwd(const HowlRes8Params* prm, const float* feat, long sb, long st
         const float* stats_i = sv->bn_stats + (size_t)(i - 1) * 2 * CP;
         float* ds_out = even ? ds_free : nullptr;
         float* dz = even ? w.dz : w.dz2;
-        if (sq && i <= 4) hipStreamWaitEvent(stream, sq->dz_free[i + 1], 0);   // wgrad_{i+2} has finished with this dz buffer
+        if (sq && i <= 4) hipStreamWaitEvent(stream, sq->ev[6 + i + 1], 0);   // wgrad_{i+2} has finished with this dz buffer
         hipLaunchKernelGGL(bn_relu_bwd_kernel, dim3(eg), dim3(256), 0, stream, (const float*)dx_cur, w.dpool, sv->s[i],
                            stats_i, w.m12, even ? (const float*)ds_prev : (const float*)nullptr, even ? 1 : 0, ds_out, dz, B, P);
         if (sq) {
-            hipEventRecord(sq->dz_ready[i - 1], stream);
-            hipStreamWaitEvent(wstream, sq->dz_ready[i - 1], 0);
+            hipEventRecord(sq->ev[i - 1], stream);
+            hipStreamWaitEvent(wstream, sq->ev[i - 1], 0);
         }
         if (even) {
             float* t = ds_prev ? ds_prev : w.dsb;
@@ -1452,7 +1416,7 @@ int howl_res8_bwd(const HowlRes8Params* prm, const float* feat, long sb, long st
             hipLaunchKernelGGL(wgrad_mfma_kernel, dim3(Gh), dim3(CONV_THREADS), lw, wstream, (const float*)dz, sv->s[i - 1],
                                in_stats, w.wpart, B, H);
         }
-        if (sq) hipEventRecord(sq->dz_free[i - 1], wstream);
+        if (sq) hipEventRecord(sq->ev[6 + i - 1], wstream);
         hipLaunchKernelGGL(reduce_rows_kernel, dim3((CP * 432 + 63) / 64), dim3(256), 0, wstream, (const float*)w.wpart, Gh,
                            CP * 432, 1, gr->conv_w[i - 1]);
         if (need_stats)
@@ -1472,8 +1436,8 @@ int howl_res8_bwd(const HowlRes8Params* prm, const float* feat, long sb, long st
     hipLaunchKernelGGL(reduce_rows_kernel, dim3((NMAP * 9 + 63) / 64), dim3(256), 0, stream, (const float*)w.c0part, G,
                        NMAP * 9, 0, gr->conv0_w);
     if (sq) {   // join: everything after this call on the caller's stream sees all weight gradients
-        hipEventRecord(sq->done, wstream);
-        hipStreamWaitEvent(stream, sq->done, 0);
+        hipEventRecord(sq->ev[12], wstream);
+        hipStreamWaitEvent(stream, sq->ev[12], 0);
     }
     HOWL_CHECK_LAUNCH("howl_res8_bwd");
     return HOWL_OK;

@@ -135,3 +135,34 @@ def test_pretrain_gsc_entry_point_mobilenet(tmp_path, monkeypatch):
     losses = [l["value"] for l in lines if l["tag"] == "Training/Loss"]
     assert len(losses) > 4 and all(v == v for v in losses)
     SETTINGS.reset()
+
+
+def test_two_queue_backward_is_bit_identical_to_single_queue(monkeypatch):
+    """howl_mobilenet_bwd puts the weight gradients on a side HIP queue (same kernels, same grids): four fused steps must
+    leave exactly the weights of the single-queue schedule (HOWL_MOBILENET_BWD_QUEUES=1) -- any race on the double-buffered
+    dz or the shared scratch would show up as a difference."""
+    from howl_amd.data.transform.operator import ZmuvTransform
+    from howl_amd.data.transform.transform import StandardAudioTransform
+    from howl_amd.training.fused import FusedTrainer
+    from howl_amd.utils.synth import synthetic_pcm
+    B, C = 192, 12
+    pcm = synthetic_pcm(B, 16000).to(DEV)
+    labels = (torch.arange(B) % C).to(DEV)
+    std = StandardAudioTransform().to(DEV).eval()
+    zmuv = ZmuvTransform().to(DEV)
+    zmuv.update(std(pcm[:4]))
+
+    def run():
+        torch.manual_seed(11)
+        torch.cuda.manual_seed(11)                     # dropout masks
+        model, _ = make_mobilenet(C)
+        trainer = FusedTrainer(model, std, zmuv, lr=0.001, weight_decay=0.0)
+        for _ in range(4):
+            trainer.step(pcm, labels)
+        torch.cuda.synchronize()
+        return trainer.fp.flat.clone()
+
+    two = run()
+    assert torch.equal(run(), two)
+    monkeypatch.setenv("HOWL_MOBILENET_BWD_QUEUES", "1")
+    assert torch.equal(run(), two)
