@@ -9,7 +9,13 @@
  *     (thread-local).  No function allocates, frees, synchronises the device or takes ownership: the caller
  *     (PyTorch's caching allocator on the host side) owns every pointer, including workspaces.
  *   - all pointers are DEVICE pointers unless marked "host"; all tensors are contiguous fp32 unless noted.
- *   - every call takes the hipStream_t to enqueue on and is re-entrant.
+ *   - every call takes the hipStream_t to enqueue on and is re-entrant.  Work is ordered on that stream only: the two
+ *     backward entry points (howl_res8_bwd, howl_mobilenet_bwd) fork their weight-gradient launches onto a second,
+ *     library-owned HIP queue and join it back with event record / wait pairs before they return, so from the caller's
+ *     side they behave like any other call on `stream` (and can be captured into a hipGraph).  That queue (one
+ *     non-blocking stream + 16 events per device, caller stream and entry point) is created on first use and lives as
+ *     long as the process; HOWL_RES8_BWD_QUEUES=1 / HOWL_MOBILENET_BWD_QUEUES=1 in the environment keep everything on
+ *     `stream`.
  */
 #ifndef HOWL_HIP_H
 #define HOWL_HIP_H
@@ -139,7 +145,10 @@ int howl_res8_fwd(const HowlRes8Params* prm, const float* feat, long sb, long st
                   int training, const HowlRes8Saved* saved, float* logits, void* ws, size_t ws_bytes,
                   hipStream_t stream);
 
-/* backward of a training-mode forward: dlogits (B,C) -> parameter gradients (overwritten, not accumulated). */
+/* backward of a training-mode forward: dlogits (B,C) -> parameter gradients (overwritten, not accumulated).
+ * Replaces loss.backward() through cnn.py:127-145 (pretrain_gsc.py:131, train.py:294).  Per layer, the data gradient and
+ * the weight gradient are launched side by side on two HIP queues (see Conventions); the results do not depend on the
+ * schedule beyond fp32 summation order (fixed for a given schedule: repeated calls are bit-identical). */
 int howl_res8_bwd(const HowlRes8Params* prm, const float* feat, long sb, long st, long sm, int B, int T, int M, int C,
                   const HowlRes8Saved* saved, const float* dlogits, const HowlRes8Grads* grads, void* ws,
                   size_t ws_bytes, hipStream_t stream);
