@@ -719,7 +719,7 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restric
 // Column sums of the [nparts][2][48] statistics partials in fp64, deterministic.  Thread (cg = tid % 24, rg = tid / 24)
 // adds rows rg, rg+42, ... of its float4 column group (coalesced 384-byte rows, a handful of independent loads per
 // thread), then threads < 96 combine the 42 row groups in a fixed order.  Returns the two sums to threads c < 48.
-constexpr int SC_RG = 42;
+constexpr int SC_RG = 42;   // = 6 x 7, see the fold below
 __device__ __forceinline__ void stats_colsum(const float* __restrict__ part, int nparts, double (*red)[2 * CP],
                                              double& s, double& q) {
     const int tid = threadIdx.x;
@@ -740,9 +740,19 @@ __device__ __forceinline__ void stats_colsum(const float* __restrict__ part, int
         red[rg][4 * cg + 3] = a3;
     }
     __syncthreads();
-    double t = 0.0;
+    // 42 row groups -> 6 sums of 7 (in place, 576 threads) -> 1: two short chains of LDS reads instead of one of 42
+    if (tid < 6 * 2 * CP) {
+        const int j = tid / (2 * CP), col = tid - j * 2 * CP;
+        double t = 0.0;
+#pragma unroll
+        for (int g = 0; g < 7; ++g) t += red[7 * j + g][col];
+        red[7 * j][col] = t;
+    }
+    __syncthreads();
     if (tid < 2 * CP) {
-        for (int g = 0; g < SC_RG; ++g) t += red[g][tid];
+        double t = 0.0;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) t += red[7 * j][tid];
         red[0][tid] = t;
     }
     __syncthreads();
@@ -1055,23 +1065,30 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int b = blockIdx.x; b < B; b += gridDim.x) {
         __syncthreads();
-        for (int c = wave; c < CP; c += 4) {
-            float v = 0.0f;
-            if (c < NMAP) {
+        // a wave owns channels wave, wave+4, ...: three of them per trip (24 loads in flight) -- one channel per trip is a
+        // chain of twelve load latencies
+        for (int c0 = wave; c0 < CP; c0 += 12) {
+            float a8[3][8];   // <= 8 x 64 positions per channel (P <= 270); clamped addresses instead of predicated loads,
+                              // which would each wait for their own data
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const int c = c0 + 4 * u < NMAP ? c0 + 4 * u : NMAP - 1;
                 const float* src = s6 + ((size_t)b * NMAP + c) * P;
-                float a8[8];   // <= 8 x 64 positions per channel (P <= 270): all loads in flight at once (clamped
-                               // addresses instead of predicated loads, which would each wait for their own data)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) a8[j] = src[min(lane + 64 * j, P - 1)];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) a8[j] = (lane + 64 * j < P) ? fabsf(a8[j]) : 0.0f;  // |s|: see conv_utterance
-                float acc = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
-                acc = wave_sum(acc);
-                v = (acc / (float)P - stats[c]) * stats[CP + c];
+                for (int j = 0; j < 8; ++j) a8[u][j] = src[min(lane + 64 * j, P - 1)];
             }
-            if (lane == 0) {
-                lp[c] = v;
-                pooled[(size_t)b * CP + c] = v;
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const int c = c0 + 4 * u;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) a8[u][j] = (lane + 64 * j < P) ? fabsf(a8[u][j]) : 0.0f;  // |s|: see conv_utterance
+                float acc = ((a8[u][0] + a8[u][1]) + (a8[u][2] + a8[u][3])) + ((a8[u][4] + a8[u][5]) + (a8[u][6] + a8[u][7]));
+                acc = wave_sum(acc);
+                const float v = c < NMAP ? (acc / (float)P - stats[c]) * stats[CP + c] : 0.0f;
+                if (lane == 0 && c < CP) {
+                    lp[c] = v;
+                    pooled[(size_t)b * CP + c] = v;
+                }
             }
         }
         __syncthreads();
@@ -1106,35 +1123,40 @@ __global__ __launch_bounds__(1024) void head_bwd_param_kernel(const float* __res
     __shared__ double red[2][16][64];
     const int k = blockIdx.x, c = threadIdx.x & 63, bg = threadIdx.x >> 6;
     double a0 = 0.0, a1 = 0.0;
-    // four rows per iteration: the loads of a one-row-per-iteration loop are serialised by their own latency
+    // 16 rows per iteration, clamped unconditional loads: a loop with few rows per trip is serialised by the latency of
+    // its own loads (B = 512: two trips per wave instead of eight)
+    constexpr int HR = 16;
+    const int cc = c < CP ? c : CP - 1;
     if (k < C) {
-        for (int b = bg; b < B; b += 64) {
-            float d[4], pv[4];
+        for (int b = bg; b < B; b += 16 * HR) {
+            float d[HR], pv[HR];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int bb = b + 16 * j;
-                d[j] = bb < B ? dlogits[(size_t)bb * C + k] : 0.0f;
-                pv[j] = (bb < B && c < CP) ? pooled[(size_t)bb * CP + c] : 0.0f;
+            for (int j = 0; j < HR; ++j) {
+                const int bb = b + 16 * j < B ? b + 16 * j : B - 1;
+                d[j] = dlogits[(size_t)bb * C + k];
+                pv[j] = pooled[(size_t)bb * CP + cc];
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                a1 += (double)d[j];
-                a0 += (double)d[j] * (double)pv[j];
+            for (int j = 0; j < HR; ++j) {
+                const bool ok = b + 16 * j < B;
+                a1 += ok ? (double)d[j] : 0.0;
+                a0 += (ok && c < CP) ? (double)d[j] * (double)pv[j] : 0.0;
             }
         }
     } else if (c < CP) {
-        for (int b = bg; b < B; b += 64) {
-            float d[4], pv[4];
+        for (int b = bg; b < B; b += 16 * HR) {
+            float d[HR], pv[HR];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int bb = b + 16 * j;
-                d[j] = bb < B ? dpool[(size_t)bb * CP + c] : 0.0f;
-                pv[j] = bb < B ? pooled[(size_t)bb * CP + c] : 0.0f;
+            for (int j = 0; j < HR; ++j) {
+                const int bb = b + 16 * j < B ? b + 16 * j : B - 1;
+                d[j] = dpool[(size_t)bb * CP + c];
+                pv[j] = pooled[(size_t)bb * CP + c];
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                a0 += (double)d[j];
-                a1 += (double)d[j] * (double)pv[j];
+            for (int j = 0; j < HR; ++j) {
+                const bool ok = b + 16 * j < B;
+                a0 += ok ? (double)d[j] : 0.0;
+                a1 += ok ? (double)d[j] * (double)pv[j] : 0.0;
             }
         }
     }
