@@ -941,7 +941,11 @@ __global__ __launch_bounds__(C0M_THREADS) void conv0_fwd_mfma_kernel(const float
                         const float a = rowp[aoff[ks] + tl * pitch + 16 * blk];
 #pragma unroll
                         for (int nt = 0; nt < 3; ++nt)
+#if defined(HOWL_DIAG_C0_NOMFMA)   // diagnostic build (tools/variants.py): everything but the matrix pipe
+                            acc[tl][nt][0] += a * bw[ks][nt];
+#else
                             acc[tl][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bw[ks][nt], acc[tl][nt], 0, 0, 0);
+#endif
                     }
                 const int pw = 4 * blk + g;  // this lane's cell
 #pragma unroll
@@ -957,7 +961,11 @@ __global__ __launch_bounds__(C0M_THREADS) void conv0_fwd_mfma_kernel(const float
                             bits |= (z > 0.0f ? 1u : 0u) << (4 * tl + r);
                         }
                     const int c = 16 * nt + n;
+#if defined(HOWL_DIAG_C0_NOSTORE)   // diagnostic build: no global stores
+                    if (pw < PW && c < NMAP && sum == 123.456f) {
+#else
                     if (pw < PW && c < NMAP) {
+#endif
                         const size_t o = ((size_t)b * NMAP + c) * P + (size_t)ph * PW + pw;
                         s0[o] = sum * (1.0f / 12.0f);
                         if (mask0 != nullptr) mask0[o] = (unsigned short)bits;
@@ -1336,8 +1344,11 @@ int howl_res8_fwd(const HowlRes8Params* prm, const float* feat, long sb, long st
     const size_t l0 = ((size_t)(T + 2) * (M + 4) + 16) * sizeof(float);
     // 103 VGPRs and 15 KB of LDS: two workgroups per CU overlap one's tile load / stores with the other's MFMAs
     const int G0 = B < 2 * howl_num_cus() ? B : 2 * howl_num_cus();
-    hipLaunchKernelGGL(conv0_fwd_mfma_kernel, dim3(G0), dim3(C0M_THREADS), l0, stream, feat, sb, st, sm, prm->conv0_w,
-                       sv->s[0], sv->mask0, B, T, M, H);
+    {
+        HowlProfScope prof("conv0_fwd", stream);
+        hipLaunchKernelGGL(conv0_fwd_mfma_kernel, dim3(G0), dim3(C0M_THREADS), l0, stream, feat, sb, st, sm, prm->conv0_w,
+                           sv->s[0], sv->mask0, B, T, M, H);
+    }
     const size_t lc = conv_lds_bytes(H);
     hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_mfma_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
                         (int)lc);

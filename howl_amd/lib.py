@@ -73,6 +73,7 @@ SIGNATURES = {
     "howl_res8_bwd": [POINTER(HowlRes8Params), P, c_long, c_long, c_long, c_int, c_int, c_int, c_int,
                       POINTER(HowlRes8Saved), P, POINTER(HowlRes8Grads), P, c_size_t, STREAM],
     "howl_xent_fwd_bwd": [P, P, c_int, c_int, P, P, STREAM],
+    "howl_ctc_loss": [P, c_long, c_long, c_int, c_int, c_int, P, c_long, c_int, P, P, c_int, P, P, P, c_long, c_long, STREAM],
     "howl_lstm_fwd": [POINTER(HowlLstmParams), P, c_int, c_int, c_int, P, P, P, POINTER(HowlLstmSaved), P, P, P, c_size_t,
                       STREAM],
     "howl_lstm_bwd": [POINTER(HowlLstmParams), P, c_int, c_int, c_int, P, P, POINTER(HowlLstmSaved), P, P, P,
@@ -90,7 +91,8 @@ SIGNATURES = {
 SIZE_FUNCS = {"howl_res8_workspace_bytes": [c_int, c_int], "howl_lstm_workspace_bytes": [c_int, c_int],
               "howl_linear_workspace_bytes": [c_int, c_int], "howl_mobilenet_num_layers": [],
               "howl_mobilenet_param_floats": [c_int], "howl_mobilenet_buffer_floats": [],
-              "howl_mobilenet_workspace_bytes": [c_int, c_int, c_int, c_int]}
+              "howl_mobilenet_workspace_bytes": [c_int, c_int, c_int, c_int],
+              "howl_ctc_supported": [c_int, c_int, c_int]}
 
 
 class HowlHipError(RuntimeError):

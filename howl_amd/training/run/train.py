@@ -20,6 +20,7 @@ from pathlib import Path
 import numpy as np
 import torch
 
+from howl_amd import ops
 from howl_amd.context import InferenceContext
 from howl_amd.data.transform.operator import ZmuvTransform
 from howl_amd.data.transform.transform import SpecAugmentTransform, StandardAudioTransform
@@ -162,7 +163,7 @@ def main(argv=None):
                                    weight_decay=SETTINGS.training.weight_decay)
     else:
         optimizer = torch.optim.AdamW(params, SETTINGS.training.learning_rate, weight_decay=SETTINGS.training.weight_decay)
-    criterion = torch.nn.CrossEntropyLoss() if use_frame else torch.nn.CTCLoss(ctx.blank_label)
+    criterion = torch.nn.CrossEntropyLoss()                        # frame objective; the CTC objective is ops.ctc_loss below
     B = SETTINGS.training.batch_size
     for epoch_idx in range(SETTINGS.training.num_epochs):
         std_transform.train()
@@ -194,13 +195,14 @@ def main(argv=None):
                     audio[k, : len(pcm)] = torch.from_numpy(pcm)
                 lengths = std_transform.compute_lengths(torch.tensor([len(p) for p, _ in batch]))
                 feats = std_transform.log_mel_for_model(audio.to(device), zmuv_transform)
-                scores = torch.log_softmax(model(feats, lengths), -1)
+                scores = model(feats, lengths)
                 tl = torch.tensor([len(e) for _, e in batch])
-                targets = torch.zeros(len(batch), int(tl.max()), dtype=torch.long)
+                targets = torch.zeros(len(batch), max(1, int(tl.max())), dtype=torch.long)
                 for k, (_, ends) in enumerate(batch):
                     targets[k, : len(ends)] = torch.tensor([w for w, _ in ends])
                 optimizer.zero_grad()
-                loss = criterion(scores, targets.to(device), lengths, tl)
+                # log_softmax + CTCLoss(blank) of train.py:291-296 as one fused kernel (loss and d loss / d scores)
+                loss = ops.ctc_loss(scores, targets, lengths, tl, ctx.blank_label)
                 loss.backward()
                 optimizer.step()
             total_loss += loss.detach().reshape(())                       # accumulated on the device (train.py:303-304)

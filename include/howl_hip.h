@@ -158,6 +158,20 @@ int howl_res8_bwd(const HowlRes8Params* prm, const float* feat, long sb, long st
 int howl_xent_fwd_bwd(const float* logits, const long long* labels, int B, int C, float* loss, float* dlogits,
                       hipStream_t stream);
 
+/* Fused log_softmax + CTC loss and its gradient w.r.t. the logits:
+ *     scores = log_softmax(model(...), -1); loss = nn.CTCLoss(blank)(scores, targets, input_lengths, target_lengths)
+ * at training/run/train.py:250-256,291-296 (sequence objective, envs/seq-lstm.env), reduction "mean", zero_infinity False.
+ * logits: (T, B, C) addressed as t*st_t + b*st_b + c (so the model's (B,T,C) buffer can be passed as its (T,B,C) view);
+ * targets: (B, >= max_target_length) int64, row stride tgt_stride; input_lengths / target_lengths: (B) int64, device.
+ * nll: (B) per-utterance negative log likelihood; loss: (1) mean_b nll_b / max(target_length_b, 1);
+ * dlogits (nullable): d loss / d logits, addressed as t*dst_t + b*dst_b + c, rows t >= input_length_b are zero.
+ * Range: howl_ctc_supported(T, C, max_target_length) -- T <= 128, C <= 64, targets <= 31 labels; outside it the call
+ * returns HOWL_E_ARG (the host side then keeps torch's own device kernels for that batch). */
+int howl_ctc_supported(int T, int C, int max_target_length);
+int howl_ctc_loss(const float* logits, long st_t, long st_b, int T, int B, int C, const long long* targets, long tgt_stride,
+                  int max_target_length, const long long* input_lengths, const long long* target_lengths, int blank,
+                  float* nll, float* loss, float* dlogits, long dst_t, long dst_b, hipStream_t stream);
+
 /* Fused AdamW over one flat buffer (torch.optim.AdamW semantics; pretrain_gsc.py:93,133, train.py:256,302).
  * step counts from 1; grad_scale multiplies g on the fly (1/world_size after a sum all-reduce). */
 int howl_adamw_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,

@@ -74,7 +74,8 @@ def test_config4_seq_lstm_ctc_step_vs_oracle():
     for lengths in (torch.full((B,), 38), torch.sort(20 + torch.arange(B) % 19, descending=True).values):
         model = make("seq-lstm", C).train()
         sc = model(feats, lengths)
-        loss = torch.nn.CTCLoss(4)(torch.log_softmax(sc, -1), targets.to(DEV), lengths, torch.tensor([3] * B))
+        from howl_amd import ops
+        loss = ops.ctc_loss(sc, targets, lengths, torch.tensor([3] * B), 4)     # fused log_softmax + CTCLoss(blank=4)
         loss.backward()
         sd = {k: v.clone().requires_grad_(True) for k, v in om.lstm_init(C).items()}
         ref, _ = om.seq_lstm_forward(sd, x_ref, lengths)
@@ -86,3 +87,38 @@ def test_config4_seq_lstm_ctc_step_vs_oracle():
         for n, p in model.named_parameters():
             r = sd[n].grad
             assert maxerr(p.grad, r) < 1e-4 * max(1.0, r.abs().max().item()), n
+
+
+@pytest.mark.parametrize("T,B,C,Lmax,seed", [(38, 64, 5, 3, 0), (81, 33, 12, 8, 1), (128, 16, 64, 31, 2), (9, 5, 3, 2, 3)])
+def test_fused_ctc_loss_vs_torch_cpu(T, B, C, Lmax, seed):
+    """ops.ctc_loss (one fused log_softmax + CTC forward/backward kernel) against the reference's arithmetic, torch's CPU
+    log_softmax + ctc_loss + autograd: ragged input lengths, repeated labels, empty targets, the kernel's maximum sizes,
+    host-side length vectors as in train.py; the (T,B,C) scores are the permuted view of a (B,T,C) buffer like the model's."""
+    from ctc_util import make_case, reference
+    from howl_amd import ops
+    logits, targets, in_len, tgt_len, blank = make_case(T, B, C, Lmax, seed, tight=True)
+    per, loss, grad = reference(logits, targets, in_len, tgt_len, blank)
+    z = logits.to(DEV).requires_grad_(True)
+    out = ops.ctc_loss(z.permute(1, 0, 2), targets, in_len, tgt_len, blank)
+    out.backward()
+    assert abs(out.item() - loss.item()) < 2e-5 * max(1.0, abs(loss.item()))
+    assert maxerr(z.grad, grad) < 1e-5
+    for b in range(B):
+        assert not z.grad[b, int(in_len[b]):].any()
+    # upstream gradient scaling and bit-identical repeats
+    z2 = logits.to(DEV).requires_grad_(True)
+    (3.0 * ops.ctc_loss(z2.permute(1, 0, 2), targets.to(DEV), in_len.to(DEV), tgt_len.to(DEV), blank)).backward()
+    assert torch.equal(z2.grad, 3.0 * z.grad)
+
+
+def test_fused_ctc_out_of_range_uses_torch_device_kernels():
+    from ctc_util import make_case, reference
+    from howl_amd import ops
+    logits, targets, in_len, tgt_len, blank = make_case(140, 4, 5, 3, 4)      # T > 128
+    per, loss, grad = reference(logits, targets, in_len, tgt_len, blank)
+    z = logits.to(DEV).requires_grad_(True)
+    out = ops.ctc_loss(z.permute(1, 0, 2), targets.to(DEV), in_len, tgt_len, blank)
+    out.backward()
+    assert abs(out.item() - loss.item()) < 1e-4 and maxerr(z.grad, grad) < 1e-5
+    with pytest.raises(Exception):
+        ops.ctc_loss(logits.permute(1, 0, 2), targets, in_len, tgt_len, blank)   # CPU scores: no CPU fallback

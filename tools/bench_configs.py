@@ -9,6 +9,7 @@ sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 os.environ.setdefault("NUM_MELS", "40")
 import torch  # noqa: E402
 
+from howl_amd import ops  # noqa: E402
 from howl_amd.data.transform.operator import ZmuvTransform  # noqa: E402
 from howl_amd.data.transform.transform import StandardAudioTransform  # noqa: E402
 from howl_amd.model import RegisteredModel  # noqa: E402
@@ -69,13 +70,12 @@ opt = torch.optim.AdamW(model.parameters(), 1e-4, weight_decay=1e-5)
 lengths = torch.full((B,), 38)
 targets = torch.tensor([[0, 1, 2]] * B).to(dev)
 tl = torch.tensor([3] * B)
-crit = torch.nn.CTCLoss(4)
 
 
 def lstm_step():
     feats = std.log_mel_for_model(pcm, zmuv)
     sc = model(feats, lengths)
-    loss = crit(torch.log_softmax(sc, -1), targets, lengths, tl)
+    loss = ops.ctc_loss(sc, targets, lengths, tl, 4)       # fused log_softmax + CTCLoss(blank=4)
     opt.zero_grad()
     loss.backward()
     opt.step()

@@ -21,8 +21,8 @@ VARIANTS = {
     "conv_nok": ["-DHOWL_DIAG_CONV_NOK"],
     "conv_nowload": ["-DHOWL_DIAG_CONV_NOWLOAD"],
     "conv_noprio": ["-DHOWL_DIAG_CONV_NOPRIO"],
-    "wgrad_unroll2": ["-DHOWL_DIAG_WGRAD_UNROLL=2"],
-    "wgrad_unroll4": ["-DHOWL_DIAG_WGRAD_UNROLL=4"],
+    "conv0_nostore": ["-DHOWL_DIAG_C0_NOSTORE"],
+    "conv0_nomfma": ["-DHOWL_DIAG_C0_NOMFMA"],
     "wgrad_nolds": ["-DHOWL_DIAG_WGRAD_NOLDS"],
     "wgrad_nomfma": ["-DHOWL_DIAG_WGRAD_NOMFMA"],
 }
@@ -52,7 +52,7 @@ lb.call("howl_profile_enable", 1)
 for _ in range(10): tr.step(pcm, labels)
 torch.cuda.synchronize(); lb.call("howl_profile_enable", 0)
 row = ["step %%.3f ms |" %% (dt * 1e3)]
-for tag in ("conv3x3_fwd", "conv3x3_dgrad", "wgrad", "logmel"):
+for tag in ("conv3x3_fwd", "conv3x3_dgrad", "wgrad", "logmel", "conv0_fwd"):
     tot, cnt = ctypes.c_double(0), ctypes.c_int(0)
     lb.call("howl_profile_read", tag.encode(), ctypes.byref(tot), ctypes.byref(cnt), 0)
     row.append("%%s %%.1f us" %% (tag, tot.value / max(cnt.value, 1) * 1e3))
