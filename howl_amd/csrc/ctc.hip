@@ -5,10 +5,12 @@
 // and the autograd backward of the two: the result is the loss and d loss / d logits directly.
 //
 // One wavefront per utterance: lane s is state s of the extended label sequence l' = (blank, l1, blank, ..., lL, blank),
-// S = 2L + 1 <= 63.  The alpha recursion runs forward in time with the two predecessor states fetched by lane shuffles,
-// alpha_t and the log-softmax rows stay in LDS, the beta recursion runs backward and emits the gradient row of its time
-// step on the way:  d/dz[t][c] = (softmax[t][c] - sum_{s: l'_s = c} gamma_t(s)) / (B * max(L, 1)),
-// gamma_t(s) = exp(alpha_t(s) + beta_t(s) - lp[t][l'_s] + nll)  (the state posteriors; rows t >= input_length are zero).
+// S = 2L + 1 <= 63.  Three phases, all in LDS ([T][65] rows of log-softmax, alpha, beta, class posteriors):
+//   1. log_softmax of every row, the rows spread over the lanes (no cross-lane reduction);
+//   2. the alpha recursion forward in time and the beta recursion backward in time IN THE SAME LOOP (they are independent,
+//      so each hides the other's shuffle / exp / log latency); the two predecessor states come from lane shuffles;
+//   3. time steps are independent again and spread over the lanes: gamma_t(s) = exp(alpha_t(s) + beta_t(s) - lp[t][l'_s] + nll),
+//      d/dz[t][c] = (softmax[t][c] - sum_{s: l'_s = c} gamma_t(s)) / (B * max(L, 1)); rows t >= input_length are zero.
 // Same arithmetic as torch's ctc_loss (log-space three-way logsumexp with the running maximum), reduction "mean",
 // zero_infinity = False.  Everything is a fixed-order computation: repeated calls are bit-identical.
 #include <math.h>
@@ -22,17 +24,20 @@ constexpr int CTC_MAX_C = 64;
 constexpr int CTC_MAX_L = 31;
 constexpr int CTC_MAX_T = 128;
 
-__device__ __forceinline__ float wave_max(float v) {
-    for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m));
-    return v;
-}
-
-// log(exp(a) + exp(b) + exp(c)) with -inf operands allowed
+// log(exp(a) + exp(b) + exp(c)) with -inf operands allowed.  This sits on the serial path of the recursions (one wave,
+// T dependent steps): the hardware exp2 / log2 instructions (1 ulp) instead of ~150 instructions of library expf / logf.
+// The arguments of the exponentials are <= 0 and only the ones near 0 carry weight, so the scaling by log2(e) costs
+// nothing measurable (parity with torch's CPU ctc_loss: tests/test_gpu_lstm.py, tests/test_emu_ctc.py).
 __device__ __forceinline__ float lse3(float a, float b, float c) {
+    constexpr float LOG2E = 1.44269504088896341f, LN2 = 0.693147180559945309f;
     float m = fmaxf(a, fmaxf(b, c));
     if (m == -INFINITY) m = 0.0f;
-    return logf(expf(a - m) + expf(b - m) + expf(c - m)) + m;
+    const float e = __builtin_amdgcn_exp2f((a - m) * LOG2E) + __builtin_amdgcn_exp2f((b - m) * LOG2E) +
+                    __builtin_amdgcn_exp2f((c - m) * LOG2E);
+    return __builtin_amdgcn_logf(e) * LN2 + m;
 }
+
+constexpr int RP = 65;   // LDS row pitch: lanes that walk down a column (lane = time step) hit 64 different banks
 
 __global__ __launch_bounds__(64) void ctc_kernel(const float* __restrict__ logits, long st_t, long st_b, int T, int B, int C,
                                                  const long long* __restrict__ targets, long tgt_stride,
@@ -41,42 +46,85 @@ __global__ __launch_bounds__(64) void ctc_kernel(const float* __restrict__ logit
                                                  float* __restrict__ nll_out, float* __restrict__ dlogits, long dst_t,
                                                  long dst_b) {
     HIP_DYNAMIC_SHARED(float, lds)
-    float* abuf = lds;            // [T][64] alpha
-    float* lpbuf = lds + 64 * T;  // [T][64] log-softmax rows
+    float* lpbuf = lds;                  // [T][RP] logits, then log-softmax rows (columns >= C unused)
+    float* abuf = lds + RP * T;          // [T][RP] alpha
+    float* bbuf = lds + 2 * RP * T;      // [T][RP] beta            (only when the gradient is wanted)
+    float* qbuf = lds + 3 * RP * T;      // [T][RP] class posteriors (only when the gradient is wanted)
+    int* labbuf = reinterpret_cast<int*>(lds + 4 * RP * T);   // [64]
     const int b = blockIdx.x, lane = threadIdx.x;
     int Tb = (int)input_lengths[b];
     Tb = Tb < 0 ? 0 : (Tb > T ? T : Tb);
     const int L = (int)target_lengths[b];
     const int S = 2 * L + 1;
     const bool live = lane < S;
+    const bool want_grad = dlogits != nullptr;
     // extended labels and the "may skip the blank between two different labels" flags
     int lab = blank;
     if (live && (lane & 1)) lab = (int)targets[(size_t)b * tgt_stride + (lane >> 1)];
     lab &= 63;
+    labbuf[lane] = lab;
     const int lab_m2 = __shfl(lab, lane >= 2 ? lane - 2 : lane);
     const int lab_p2 = __shfl(lab, lane + 2 < 64 ? lane + 2 : lane);
     const bool skip_a = live && (lane & 1) && lane >= 2 && lab != lab_m2;
     const bool skip_b = (lane & 1) && lane + 2 < S && lab != lab_p2;
     const float* zb = logits + (size_t)b * st_b;
 
-    float a = -INFINITY;
-    for (int t = 0; t < Tb; ++t) {
-        const float z = lane < C ? zb[(size_t)t * st_t + lane] : -INFINITY;
-        const float m = wave_max(z);
-        const float e = lane < C ? expf(z - m) : 0.0f;
-        const float lse = m + logf(wave_sum(e));
-        const float lp = lane < C ? z - lse : -INFINITY;
-        lpbuf[t * 64 + lane] = lp;
-        const float lps = __shfl(lp, lab);
-        if (t == 0) {
-            a = (live && lane < 2) ? lps : -INFINITY;
+    // phase 1: logits -> LDS (flat, independent loads), then lane t turns rows t, t + 64 into log-softmax rows in place
+    const int n = Tb * C;
+    for (int i0 = lane; i0 < n; i0 += 4 * 64) {
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + 64 * u < n ? i0 + 64 * u : n - 1;
+            const int t = i / C;
+            v[u] = zb[(size_t)t * st_t + (i - t * C)];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + 64 * u;
+            if (i < n) {
+                const int t = i / C;
+                lpbuf[t * RP + (i - t * C)] = v[u];
+            }
+        }
+    }
+    __syncthreads();
+    for (int t = lane; t < Tb; t += 64) {
+        float* row = lpbuf + t * RP;
+        float m = row[0];
+        for (int c = 1; c < C; ++c) m = fmaxf(m, row[c]);
+        float se = 0.0f;
+        for (int c = 0; c < C; ++c) se += expf(row[c] - m);
+        const float lse = m + logf(se);
+        for (int c = 0; c < C; ++c) row[c] -= lse;
+        if (want_grad)
+            for (int c = 0; c < C; ++c) qbuf[t * RP + c] = 0.0f;
+    }
+    __syncthreads();
+
+    // phase 2: alpha forward and beta backward, interleaved
+    float a = -INFINITY, bt = -INFINITY;
+    for (int k = 0; k < Tb; ++k) {
+        const int tb = Tb - 1 - k;
+        const float lpa = lpbuf[k * RP + lab];
+        const float lpb = lpbuf[tb * RP + lab];
+        if (k == 0) {
+            a = (live && lane < 2) ? lpa : -INFINITY;
+            bt = (live && lane >= S - 2) ? lpb : -INFINITY;
         } else {
             const float a1 = __shfl(a, lane >= 1 ? lane - 1 : lane);
             const float a2 = __shfl(a, lane >= 2 ? lane - 2 : lane);
-            const float v = lse3(a, lane >= 1 ? a1 : -INFINITY, skip_a ? a2 : -INFINITY) + lps;
-            a = live ? v : -INFINITY;
+            const float b1 = __shfl(bt, lane + 1 < 64 ? lane + 1 : lane);
+            const float b2 = __shfl(bt, lane + 2 < 64 ? lane + 2 : lane);
+            const float va = lse3(a, lane >= 1 ? a1 : -INFINITY, skip_a ? a2 : -INFINITY) + lpa;
+            a = live ? va : -INFINITY;
+            if (want_grad) {
+                const float vb = lse3(bt, lane + 1 < S ? b1 : -INFINITY, skip_b ? b2 : -INFINITY) + lpb;
+                bt = live ? vb : -INFINITY;
+            }
         }
-        abuf[t * 64 + lane] = a;
+        abuf[k * RP + lane] = a;
+        if (want_grad) bbuf[tb * RP + lane] = bt;
     }
     float nll;
     if (Tb > 0) {
@@ -86,35 +134,33 @@ __global__ __launch_bounds__(64) void ctc_kernel(const float* __restrict__ logit
         nll = L == 0 ? 0.0f : INFINITY;
     }
     if (lane == 0) nll_out[b] = nll;
-    if (dlogits == nullptr) return;
+    if (!want_grad) return;
+    __syncthreads();
 
+    // phase 3a: lane = time step.  Walk the states of this row: gamma_t(s) = exp(alpha + beta - lp[l'_s] + nll) goes to
+    // its class; the even states are all the blank (kept in a register), the odd ones add to their label's slot.
+    for (int t = lane; t < Tb; t += 64) {
+        const float* ar = abuf + t * RP;
+        const float* br = bbuf + t * RP;
+        const float* lr = lpbuf + t * RP;
+        float* qr = qbuf + t * RP;
+        const float lpblank = lr[blank];
+        float qblank = 0.0f;
+        for (int s2 = 0; s2 < S; s2 += 2) qblank += expf(ar[s2] + br[s2] - lpblank + nll);
+        for (int s2 = 1; s2 < S; s2 += 2) {
+            const int c = labbuf[s2];
+            qr[c] += expf(ar[s2] + br[s2] - lr[c] + nll);
+        }
+        qr[blank] += qblank;
+    }
+    __syncthreads();
+    // phase 3b: flat over (t, c), coalesced stores
     float* db = dlogits + (size_t)b * dst_b;
     const float scale = 1.0f / ((float)B * (float)(L > 0 ? L : 1));
-    float bt = -INFINITY;
-    for (int t = Tb - 1; t >= 0; --t) {
-        const float lp = lpbuf[t * 64 + lane];
-        const float lps = __shfl(lp, lab);
-        if (t == Tb - 1) {
-            bt = (live && lane >= S - 2) ? lps : -INFINITY;
-        } else {
-            const float b1 = __shfl(bt, lane + 1 < 64 ? lane + 1 : lane);
-            const float b2 = __shfl(bt, lane + 2 < 64 ? lane + 2 : lane);
-            const float v = lse3(bt, lane + 1 < S ? b1 : -INFINITY, skip_b ? b2 : -INFINITY) + lps;
-            bt = live ? v : -INFINITY;
-        }
-        const float gamma = live ? expf(abuf[t * 64 + lane] + bt - lps + nll) : 0.0f;
-        // posterior mass per class: all even states are the blank, the odd ones are looked at one by one
-        float q = wave_sum((lane & 1) ? 0.0f : gamma);
-        q = lane == (blank & 63) ? q : 0.0f;
-        for (int i = 0; i < L; ++i) {
-            const float gi = __shfl(gamma, 2 * i + 1);
-            const int li = __shfl(lab, 2 * i + 1);
-            q += lane == li ? gi : 0.0f;
-        }
-        if (lane < C) db[(size_t)t * dst_t + lane] = (expf(lp) - q) * scale;
+    for (int i = lane; i < T * C; i += 64) {
+        const int t = i / C, c = i - t * C;
+        db[(size_t)t * dst_t + c] = t < Tb ? (expf(lpbuf[t * RP + c]) - qbuf[t * RP + c]) * scale : 0.0f;
     }
-    for (int t = Tb; t < T; ++t)
-        if (lane < C) db[(size_t)t * dst_t + lane] = 0.0f;
 }
 
 // loss = mean_b nll_b / max(L_b, 1)  (torch's reduction="mean"), fixed summation order
@@ -148,7 +194,8 @@ int howl_ctc_loss(const float* logits, long st_t, long st_b, int T, int B, int C
     HOWL_REQUIRE(howl_ctc_supported(T, C, max_target_length),
                  "howl_ctc_loss: T=%d C=%d target length %d outside the kernel's range (T <= %d, C <= %d, targets <= %d)", T,
                  C, max_target_length, CTC_MAX_T, CTC_MAX_C, CTC_MAX_L);
-    const size_t lds = (size_t)2 * T * 64 * sizeof(float);
+    const size_t lds = ((size_t)4 * T * RP + 64) * sizeof(float);   // 133 KB at T = 128
+    hipFuncSetAttribute(reinterpret_cast<const void*>(ctc_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(ctc_kernel, dim3(B), dim3(64), lds, stream, logits, st_t, st_b, T, B, C, targets, tgt_stride,
                        input_lengths, target_lengths, blank, nll, dlogits, dst_t, dst_b);
     hipLaunchKernelGGL(ctc_mean_kernel, dim3(1), dim3(256), 0, stream, (const float*)nll, target_lengths, B, loss);

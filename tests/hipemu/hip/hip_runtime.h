@@ -155,6 +155,7 @@ static inline float __fdividef(float a, float b) { return a / b; }
 static inline float __frcp_rn(float a) { return 1.0f / a; }
 static inline float __builtin_amdgcn_rcpf(float a) { return 1.0f / a; }
 static inline float __builtin_amdgcn_exp2f(float a) { return exp2f(a); }
+static inline float __builtin_amdgcn_logf(float a) { return log2f(a); }
 using std::max;
 using std::min;
 
