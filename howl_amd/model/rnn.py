@@ -32,49 +32,101 @@ def _vp(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
+def _lstm_forward_raw(x, lengths, t_out, h0, c0, w_ih, w_hh, b_ih, b_hh):
+    """``howl_lstm_fwd`` on x (B,T,M) contiguous: returns (hs (B,t_out,128) view, hT, cT, saved buffers for the backward)."""
+    B, T, M = x.shape
+    dev = x.device
+    f32 = dict(dtype=torch.float32, device=dev)
+    bufs = dict(gx=torch.empty((B, T, 4 * HID), **f32), gates=torch.empty((B, T, 4 * HID), **f32),
+                c=torch.empty((B, T, HID), **f32), hseq=torch.empty((B, T + 1, HID), **f32))
+    ws = torch.empty(_lib.get().cdll.howl_lstm_workspace_bytes(B, T), dtype=torch.uint8, device=dev)
+    hT, cT = torch.empty((B, HID), **f32), torch.empty((B, HID), **f32)
+    prm = _lib.HowlLstmParams(_vp(w_ih), _vp(w_hh), _vp(b_ih), _vp(b_hh))
+    sv = _lib.HowlLstmSaved(_vp(bufs["gx"]), _vp(bufs["gates"]), _vp(bufs["c"]), _vp(bufs["hseq"]), None, t_out)
+    _lib.get().call("howl_lstm_fwd", ctypes.byref(prm), _vp(x), B, T, M, _vp(lengths), _vp(h0), _vp(c0), ctypes.byref(sv),
+                    _vp(hT), _vp(cT), _vp(ws), ws.numel(), ops._stream())
+    saved = (x, lengths, c0, w_ih, w_hh, b_ih, b_hh, bufs["gates"], bufs["c"], bufs["hseq"], ws)
+    return bufs["hseq"][:, 1:t_out + 1], hT, cT, saved
+
+
+def _lstm_backward_raw(saved, t_out, d_hs, d_hT, d_cT, grads=None):
+    """``howl_lstm_bwd``: gradients of (w_ih, w_hh, b_ih, b_hh), written into ``grads`` when given (flat-buffer views)."""
+    x, lengths, c0, w_ih, w_hh, b_ih, b_hh, gates, cs, hseq, ws = saved
+    B, T, M = x.shape
+    dy = None
+    if d_hs is not None:
+        if t_out == T and d_hs.is_contiguous():
+            dy = d_hs
+        elif t_out == T:
+            dy = d_hs.contiguous()
+        else:
+            dy = torch.zeros((B, T, HID), dtype=torch.float32, device=x.device)
+            dy[:, :t_out].copy_(d_hs)
+    d_hT = None if d_hT is None else d_hT.contiguous()
+    d_cT = None if d_cT is None else d_cT.contiguous()
+    dgates = torch.empty((B, T, 4 * HID), dtype=torch.float32, device=x.device)
+    if grads is None:
+        grads = [torch.empty_like(p) for p in (w_ih, w_hh, b_ih, b_hh)]
+    prm = _lib.HowlLstmParams(_vp(w_ih), _vp(w_hh), _vp(b_ih), _vp(b_hh))
+    sv = _lib.HowlLstmSaved(None, _vp(gates), _vp(cs), _vp(hseq), _vp(dgates), t_out)
+    gr = _lib.HowlLstmGrads(*[_vp(g) for g in grads])
+    _lib.get().call("howl_lstm_bwd", ctypes.byref(prm), _vp(x), B, T, M, _vp(lengths), _vp(c0), ctypes.byref(sv), _vp(dy),
+                    _vp(d_hT), _vp(d_cT), ctypes.byref(gr), _vp(ws), ws.numel(), ops._stream())
+    return grads
+
+
 class _LstmFunction(torch.autograd.Function):
     """x (B,T,M) contiguous, lengths (B) int64 on the device or None -> (hs (B,t_out,128) view, hT (B,128), cT (B,128))."""
 
     @staticmethod
     def forward(ctx, x, lengths, t_out, h0, c0, w_ih, w_hh, b_ih, b_hh):
-        B, T, M = x.shape
-        dev = x.device
-        f32 = dict(dtype=torch.float32, device=dev)
-        bufs = dict(gx=torch.empty((B, T, 4 * HID), **f32), gates=torch.empty((B, T, 4 * HID), **f32),
-                    c=torch.empty((B, T, HID), **f32), hseq=torch.empty((B, T + 1, HID), **f32))
-        ws = torch.empty(_lib.get().cdll.howl_lstm_workspace_bytes(B, T), dtype=torch.uint8, device=dev)
-        hT, cT = torch.empty((B, HID), **f32), torch.empty((B, HID), **f32)
-        prm = _lib.HowlLstmParams(_vp(w_ih), _vp(w_hh), _vp(b_ih), _vp(b_hh))
-        sv = _lib.HowlLstmSaved(_vp(bufs["gx"]), _vp(bufs["gates"]), _vp(bufs["c"]), _vp(bufs["hseq"]), None, t_out)
-        _lib.get().call("howl_lstm_fwd", ctypes.byref(prm), _vp(x), B, T, M, _vp(lengths), _vp(h0), _vp(c0), ctypes.byref(sv),
-                        _vp(hT), _vp(cT), _vp(ws), ws.numel(), ops._stream())
-        ctx.save_for_backward(x, lengths, c0, w_ih, w_hh, b_ih, b_hh, bufs["gates"], bufs["c"], bufs["hseq"], ws)
+        hs, hT, cT, saved = _lstm_forward_raw(x, lengths, t_out, h0, c0, w_ih, w_hh, b_ih, b_hh)
+        ctx.save_for_backward(*saved)
         ctx.t_out = t_out
-        hs = bufs["hseq"][:, 1:t_out + 1]
         return hs, hT, cT
 
     @staticmethod
     def backward(ctx, d_hs, d_hT, d_cT):
-        x, lengths, c0, w_ih, w_hh, b_ih, b_hh, gates, cs, hseq, ws = ctx.saved_tensors
-        B, T, M = x.shape
-        t_out = ctx.t_out
-        dy = None
-        if d_hs is not None:
-            if t_out == T:
-                dy = d_hs.contiguous()
-            else:
-                dy = torch.zeros((B, T, HID), dtype=torch.float32, device=x.device)
-                dy[:, :t_out].copy_(d_hs)
-        d_hT = None if d_hT is None else d_hT.contiguous()
-        d_cT = None if d_cT is None else d_cT.contiguous()
-        dgates = torch.empty((B, T, 4 * HID), dtype=torch.float32, device=x.device)
-        grads = [torch.empty_like(p) for p in (w_ih, w_hh, b_ih, b_hh)]
-        prm = _lib.HowlLstmParams(_vp(w_ih), _vp(w_hh), _vp(b_ih), _vp(b_hh))
-        sv = _lib.HowlLstmSaved(None, _vp(gates), _vp(cs), _vp(hseq), _vp(dgates), t_out)
-        gr = _lib.HowlLstmGrads(*[_vp(g) for g in grads])
-        _lib.get().call("howl_lstm_bwd", ctypes.byref(prm), _vp(x), B, T, M, _vp(lengths), _vp(c0), ctypes.byref(sv), _vp(dy),
-                        _vp(d_hT), _vp(d_cT), ctypes.byref(gr), _vp(ws), ws.numel(), ops._stream())
+        grads = _lstm_backward_raw(ctx.saved_tensors, ctx.t_out, d_hs, d_hT, d_cT)
         return (None, None, None, None, None) + tuple(grads)
+
+
+def _linear_geom(x):
+    if x.dim() == 3:
+        outer, inner = x.shape[0], x.shape[1]
+        s_outer, s_inner = x.stride(0), x.stride(1)
+    else:
+        outer, inner, s_outer, s_inner = 1, x.shape[0], 0, x.stride(0)
+    if x.stride(-1) != 1:
+        raise ValueError("linear: features must be unit-stride")
+    return inner, s_outer, s_inner, outer * inner
+
+
+def _linear_forward_raw(x, w, b, relu):
+    n_out, n_in = w.shape
+    inner, s_outer, s_inner, rows = _linear_geom(x)
+    y = torch.empty(x.shape[:-1] + (n_out,), dtype=torch.float32, device=x.device)
+    _lib.get().call("howl_linear_fwd", _vp(x), inner, s_outer, s_inner, rows, n_in, _vp(w), _vp(b), n_out, int(relu), _vp(y),
+                    ops._stream())
+    return y
+
+
+def _linear_backward_raw(x, w, y, dy, relu, need_dx, dw=None, db=None):
+    """dy (..., n_out) -> (dx or None, dW, db); ``y`` is the forward output when a ReLU followed (its mask)."""
+    inner, s_outer, s_inner, rows = _linear_geom(x)
+    n_out, n_in = w.shape
+    dy = dy.contiguous()
+    if relu:
+        dz = torch.empty_like(dy)
+        _lib.get().call("howl_relu_bwd", _vp(dy), _vp(y), dy.numel(), _vp(dz), ops._stream())
+        dy = dz
+    dx = torch.empty(x.shape, dtype=torch.float32, device=x.device) if need_dx else None
+    dw = torch.empty_like(w) if dw is None else dw
+    db = torch.empty(n_out, dtype=torch.float32, device=w.device) if db is None else db
+    ws = torch.empty(_lib.get().cdll.howl_linear_workspace_bytes(n_out, n_in), dtype=torch.uint8, device=w.device)
+    _lib.get().call("howl_linear_bwd", _vp(x), inner, s_outer, s_inner, rows, n_in, _vp(w), n_out, _vp(dy), _vp(dx), _vp(dw),
+                    _vp(db), _vp(ws), ws.numel(), ops._stream())
+    return dx, dw, db
 
 
 class _LinearFunction(torch.autograd.Function):
@@ -82,37 +134,15 @@ class _LinearFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, b, relu):
-        n_out, n_in = w.shape
-        if x.dim() == 3:
-            outer, inner = x.shape[0], x.shape[1]
-            s_outer, s_inner = x.stride(0), x.stride(1)
-        else:
-            outer, inner, s_outer, s_inner = 1, x.shape[0], 0, x.stride(0)
-        if x.stride(-1) != 1:
-            raise ValueError("linear: features must be unit-stride")
-        rows = outer * inner
-        y = torch.empty(x.shape[:-1] + (n_out,), dtype=torch.float32, device=x.device)
-        _lib.get().call("howl_linear_fwd", _vp(x), inner, s_outer, s_inner, rows, n_in, _vp(w), _vp(b), n_out, int(relu), _vp(y),
-                        ops._stream())
+        y = _linear_forward_raw(x, w, b, relu)
         ctx.save_for_backward(x, w, y if relu else None)
-        ctx.geom = (inner, s_outer, s_inner, rows, relu)
+        ctx.relu = relu
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, w, y = ctx.saved_tensors
-        inner, s_outer, s_inner, rows, relu = ctx.geom
-        n_out, n_in = w.shape
-        dy = dy.contiguous()
-        if relu:
-            dz = torch.empty_like(dy)
-            _lib.get().call("howl_relu_bwd", _vp(dy), _vp(y), dy.numel(), _vp(dz), ops._stream())
-            dy = dz
-        dx = torch.empty(x.shape, dtype=torch.float32, device=x.device) if ctx.needs_input_grad[0] else None
-        dw, db = torch.empty_like(w), torch.empty(n_out, dtype=torch.float32, device=w.device)
-        ws = torch.empty(_lib.get().cdll.howl_linear_workspace_bytes(n_out, n_in), dtype=torch.uint8, device=w.device)
-        _lib.get().call("howl_linear_bwd", _vp(x), inner, s_outer, s_inner, rows, n_in, _vp(w), n_out, _vp(dy), _vp(dx), _vp(dw),
-                        _vp(db), _vp(ws), ws.numel(), ops._stream())
+        dx, dw, db = _linear_backward_raw(x, w, y, dy, ctx.relu, ctx.needs_input_grad[0])
         return dx, dw, db, None
 
 
@@ -127,7 +157,7 @@ class _LstmBase(RegisteredModel):
                                  nn.Linear(int(2 * config.hidden_size), num_labels))
         self.hc = None
 
-    def _run_lstm(self, x, lengths):
+    def _lstm_inputs(self, x, lengths):
         x0 = x[:, 0]                                   # (B, M, T), log-mels only (rnn.py:61,86)
         if not x0.is_cuda:
             raise _lib.HowlHipError("LSTM input must be on a HIP device (no CPU fallback)")
@@ -148,10 +178,22 @@ class _LstmBase(RegisteredModel):
         else:
             t_out = T
         hx = self.streaming_state if self.is_streaming and self.streaming_state is not None else None
+        if hx is not None and (tuple(hx[0].shape) != (1, B, HID) or tuple(hx[1].shape) != (1, B, HID)):
+            raise RuntimeError(f"Expected hidden size (1, {B}, {HID}), got {tuple(hx[0].shape)}")     # as nn.LSTM does
         h0 = hx[0][0].contiguous() if hx is not None else None
         c0 = hx[1][0].contiguous() if hx is not None else None
+        return xb, lengths, t_out, h0, c0
+
+    def _run_lstm(self, x, lengths):
+        xb, lengths, t_out, h0, c0 = self._lstm_inputs(x, lengths)
         l = self.lstm
         return _LstmFunction.apply(xb, lengths, t_out, h0, c0, l.weight_ih_l0, l.weight_hh_l0, l.bias_ih_l0, l.bias_hh_l0)
+
+    def hot_parameters(self):
+        """Parameters in the order the fused trainer lays them out (and ``_launch_backward`` fills their gradients)."""
+        l = self.lstm
+        return [l.weight_ih_l0, l.weight_hh_l0, l.bias_ih_l0, l.bias_hh_l0, self.dnn[0].weight, self.dnn[0].bias,
+                self.dnn[2].weight, self.dnn[2].bias]
 
     def _head(self, h):
         y = _LinearFunction.apply(h, self.dnn[0].weight, self.dnn[0].bias, True)
@@ -172,6 +214,31 @@ class SequentialLstm(_LstmBase, name="seq-lstm"):
         if self.is_streaming:
             self.streaming_state = (hT.detach().clone().unsqueeze(0), cT.detach().clone().unsqueeze(0))
         return self._head(hs).permute(1, 0, 2)         # (T_len, B, num_labels), as dnn(rnn_seq) in rnn.py:71
+
+    # --- training.fused.FusedTrainer hooks: the same launches as forward() / autograd, without the autograd graph -----
+    def _launch_forward(self, feat, lengths):
+        """feat (B, C>=1, M, T) -> scores (T_len, B, num_labels) view; keeps what ``_launch_backward`` needs."""
+        xb, lengths, t_out, h0, c0 = self._lstm_inputs(feat, lengths)
+        ps = self.hot_parameters()
+        hs, hT, cT, saved = _lstm_forward_raw(xb, lengths, t_out, h0, c0, *ps[:4])
+        y1 = _linear_forward_raw(hs, ps[4], ps[5], True)
+        y2 = _linear_forward_raw(y1, ps[6], ps[7], False)
+        self._seq_saved = (saved, t_out, hs, y1)
+        if self.is_streaming:                          # same carry as forward() (rnn.py:64-68)
+            self.streaming_state = (hT.detach().clone().unsqueeze(0), cT.detach().clone().unsqueeze(0))
+        return y2.permute(1, 0, 2)
+
+    def _launch_backward(self, dscores, out_grads=None):
+        """dscores: d loss / d scores as a (T_len, B, num_labels) view of a (B, T_len, num_labels) buffer (ops.ctc_loss_fwd_bwd)."""
+        saved, t_out, hs, y1 = self._seq_saved
+        ps = self.hot_parameters()
+        grads = out_grads if out_grads is not None else [torch.empty_like(p) for p in ps]
+        dy2 = dscores.permute(1, 0, 2)
+        dy1, _, _ = _linear_backward_raw(y1, ps[6], None, dy2, False, True, grads[6], grads[7])
+        dhs, _, _ = _linear_backward_raw(hs, ps[4], y1, dy1, True, True, grads[4], grads[5])
+        _lstm_backward_raw(saved, t_out, dhs, None, None, grads[:4])
+        self._seq_saved = None
+        return grads
 
 
 class SimpleLstm(_LstmBase, name="lstm"):

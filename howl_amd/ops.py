@@ -126,24 +126,29 @@ def xent(logits, labels, want_grad=True):
     return loss, dlogits
 
 
+def _ctc_launch(scores, targets, input_lengths, target_lengths, blank, max_target, want_grad):
+    T, B, C = scores.shape
+    dev = scores.device
+    # the gradient takes the memory layout of the model's (B, T, C) output buffer, handed back as a (T, B, C) view
+    dlogits = torch.empty((B, T, C), dtype=torch.float32, device=dev).permute(1, 0, 2) if want_grad else None
+    nll = torch.empty(B, dtype=torch.float32, device=dev)
+    loss = torch.empty((), dtype=torch.float32, device=dev)
+    vp = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())     # strided views: strides are passed explicitly
+    _lib.get().call("howl_ctc_loss", vp(scores), scores.stride(0), scores.stride(1), T, B, C, vp(targets),
+                    targets.stride(0), max_target, _p(input_lengths, torch.int64), _p(target_lengths, torch.int64), blank,
+                    _p(nll), _p(loss), vp(dlogits), 0 if dlogits is None else dlogits.stride(0),
+                    0 if dlogits is None else dlogits.stride(1), _stream())
+    return loss, dlogits
+
+
 class _CtcLoss(torch.autograd.Function):
     """loss = CTCLoss(blank)(log_softmax(scores, -1), targets, input_lengths, target_lengths), reduction "mean": the fused
     kernel returns the loss and d loss / d scores in one pass (``howl_ctc_loss``)."""
 
     @staticmethod
     def forward(ctx, scores, targets, input_lengths, target_lengths, blank, max_target):
-        T, B, C = scores.shape
-        dev = scores.device
-        want_grad = ctx.needs_input_grad[0]
-        # the gradient takes the memory layout of the model's (B, T, C) output buffer, handed back as a (T, B, C) view
-        dlogits = torch.empty((B, T, C), dtype=torch.float32, device=dev).permute(1, 0, 2) if want_grad else None
-        nll = torch.empty(B, dtype=torch.float32, device=dev)
-        loss = torch.empty((), dtype=torch.float32, device=dev)
-        vp = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())     # strided views: strides are passed explicitly
-        _lib.get().call("howl_ctc_loss", vp(scores), scores.stride(0), scores.stride(1), T, B, C, vp(targets),
-                        targets.stride(0), max_target, _p(input_lengths, torch.int64), _p(target_lengths, torch.int64), blank,
-                        _p(nll), _p(loss), vp(dlogits), 0 if dlogits is None else dlogits.stride(0),
-                        0 if dlogits is None else dlogits.stride(1), _stream())
+        loss, dlogits = _ctc_launch(scores, targets, input_lengths, target_lengths, blank, max_target,
+                                    ctx.needs_input_grad[0])
         ctx.save_for_backward(dlogits)
         return loss
 
@@ -153,29 +158,48 @@ class _CtcLoss(torch.autograd.Function):
         return dlogits * grad_out, None, None, None, None, None
 
 
+def _ctc_args(scores, targets, input_lengths, target_lengths, max_target):
+    if not scores.is_cuda:
+        raise _lib.HowlHipError("ctc_loss: scores must be on a HIP device (no CPU fallback)")
+    if scores.dim() != 3 or targets.dim() != 2:
+        raise ValueError("ctc_loss: scores must be (T, B, C) and targets the padded (B, L) matrix")
+    if max_target is None:
+        max_target = int(target_lengths.max()) if target_lengths.numel() else 0
+    if max_target > targets.shape[1]:
+        raise ValueError("ctc_loss: a target length exceeds the width of the target matrix")
+    dev = scores.device
+    targets = targets.to(dev, torch.int64)
+    if targets.shape[1] > 0 and targets.stride(1) != 1:
+        targets = targets.contiguous()
+    return (targets, input_lengths.to(dev, torch.int64).contiguous(), target_lengths.to(dev, torch.int64).contiguous(),
+            max_target)
+
+
+def ctc_supported(T: int, C: int, max_target: int) -> bool:
+    return bool(_lib.get().cdll.howl_ctc_supported(int(T), int(C), int(max_target)))
+
+
+def ctc_loss_fwd_bwd(scores, targets, input_lengths, target_lengths, blank: int, max_target=None):
+    """Loss and d loss / d scores without an autograd graph (training.fused.FusedTrainer.step_sequence): same kernel as
+    ``ctc_loss``; the batch must be inside the kernel's range."""
+    targets, input_lengths, target_lengths, max_target = _ctc_args(scores, targets, input_lengths, target_lengths, max_target)
+    if scores.stride(2) != 1 or scores.dtype != torch.float32:
+        raise ValueError("ctc_loss_fwd_bwd: scores must be fp32 with unit stride over the classes")
+    return _ctc_launch(scores, targets, input_lengths, target_lengths, int(blank), max_target, True)
+
+
 def ctc_loss(scores, targets, input_lengths, target_lengths, blank: int):
     """``nn.CTCLoss(blank)(torch.log_softmax(scores, -1), targets, input_lengths, target_lengths)`` of the reference's training
     loop (train.py:250-256, 291-296) for ``scores`` of shape (T, B, C) on the device, as ONE fused kernel.  ``targets`` is the
     padded (B, L) int64 matrix; the two length vectors may live on the host (as in the reference) or on the device.  Batches
     outside the kernel's range (T > 128, C > 64, a target longer than 31 labels) go through torch's own device kernels."""
-    if not scores.is_cuda:
-        raise _lib.HowlHipError("ctc_loss: scores must be on a HIP device (no CPU fallback)")
-    if scores.dim() != 3 or targets.dim() != 2:
-        raise ValueError("ctc_loss: scores must be (T, B, C) and targets the padded (B, L) matrix")
+    targets_d, in_d, tl_d, max_target = _ctc_args(scores, targets, input_lengths, target_lengths, None)
     T, B, C = scores.shape
-    max_target = int(target_lengths.max()) if target_lengths.numel() else 0
-    if max_target > targets.shape[1]:
-        raise ValueError("ctc_loss: a target length exceeds the width of the target matrix")
     if not _lib.get().cdll.howl_ctc_supported(T, C, max_target) or scores.dtype != torch.float32:
         return torch.nn.functional.ctc_loss(torch.log_softmax(scores, -1), targets, input_lengths, target_lengths, blank)
     if scores.stride(2) != 1:
         scores = scores.contiguous()
-    dev = scores.device
-    targets = targets.to(dev, torch.int64)
-    if targets.shape[1] > 0 and targets.stride(1) != 1:
-        targets = targets.contiguous()
-    return _CtcLoss.apply(scores, targets, input_lengths.to(dev, torch.int64).contiguous(),
-                          target_lengths.to(dev, torch.int64).contiguous(), int(blank), max_target)
+    return _CtcLoss.apply(scores, targets_d, in_d, tl_d, int(blank), max_target)
 
 
 def adamw_step(p, g, m, v, lr, betas, eps, weight_decay, step, grad_scale=1.0):

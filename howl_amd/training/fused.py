@@ -1,4 +1,5 @@
-"""Fused training step (res8, mobilenet): frontend -> forward -> cross-entropy -> backward -> (RCCL all-reduce) -> AdamW.
+"""Fused training step: frontend -> forward -> loss -> backward -> (RCCL all-reduce) -> AdamW.  Frame objective
+(res8, mobilenet: cross-entropy) and sequence objective (seq-lstm: log_softmax + CTC).
 
 This is the loop body of ``training/run/pretrain_gsc.py:124-133`` / ``training/run/train.py:286-302`` with every
 stage a C-ABI call on the current HIP stream, gradients written straight into one flat fp32 buffer (the unit of the
@@ -36,7 +37,8 @@ class FlatParams:
 
 class FusedTrainer:
     """Works with any model that exposes ``hot_parameters()`` (flat-buffer order), ``_launch_forward(feat)`` and
-    ``_launch_backward(feat, dlogits, out_grads=views)``: ``Res8`` and ``MobileNetClassifier``."""
+    ``_launch_backward(feat, dlogits, out_grads=views)``: ``Res8`` and ``MobileNetClassifier`` (``step``), and with
+    ``SequentialLstm`` (``step_sequence``: ``_launch_forward(feat, lengths)`` / ``_launch_backward(dscores, out_grads)``)."""
 
     def __init__(self, model, std_transform, zmuv_transform, lr, weight_decay=0.0, betas=(0.9, 0.999), eps=1e-8,
                  process_group=None):
@@ -70,6 +72,32 @@ class FusedTrainer:
         ops.adamw_step(self.fp.flat, self.fp.grad, self.m, self.v, self.lr, self.betas, self.eps, self.weight_decay,
                        self.step_count, scale)
         self.last_logits = logits
+        return loss
+
+    def step_sequence(self, audio, frame_lengths, targets, target_lengths, blank, max_target=None):
+        """One optimisation step of the sequence objective (train.py:286-302 with ``objective=ctc``) on a (B, L) PCM batch
+        sorted by decreasing length: ``frame_lengths`` = ``StandardAudioTransform.compute_lengths`` of the sample counts,
+        ``targets`` the padded (B, Lmax) label matrix.  Returns the mean CTC loss as a device tensor."""
+        return self.step_sequence_on_features(self.features(audio), frame_lengths, targets, target_lengths, blank, max_target)
+
+    def step_sequence_on_features(self, feat, frame_lengths, targets, target_lengths, blank, max_target=None):
+        scores = self.model._launch_forward(feat, frame_lengths)           # (T_len, B, C) view of a (B, T_len, C) buffer
+        if max_target is None:
+            max_target = int(target_lengths.max()) if target_lengths.numel() else 0
+        if ops.ctc_supported(scores.shape[0], scores.shape[2], max_target):
+            loss, dscores = ops.ctc_loss_fwd_bwd(scores, targets, frame_lengths, target_lengths, blank, max_target)
+        else:   # longer than the fused kernel's range (T > 128 frames, ...): torch's device kernels for the loss only
+            z = scores.detach().requires_grad_(True)
+            loss = torch.nn.functional.ctc_loss(torch.log_softmax(z, -1), targets.to(z.device), frame_lengths, target_lengths,
+                                                blank)
+            loss.backward()
+            loss, dscores = loss.detach(), z.grad
+        self.model._launch_backward(dscores, out_grads=self.fp.grad_views)
+        scale = parallel.allreduce_sum_(self.fp.grad, self.group)
+        self.step_count += 1
+        ops.adamw_step(self.fp.flat, self.fp.grad, self.m, self.v, self.lr, self.betas, self.eps, self.weight_decay,
+                       self.step_count, scale)
+        self.last_logits = scores
         return loss
 
     def decay_lr(self, factor):

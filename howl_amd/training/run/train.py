@@ -157,7 +157,7 @@ def main(argv=None):
     ws.write_args(args)
     ws.save_settings(SETTINGS)
     params = [p for p in model.parameters() if p.requires_grad]
-    fused = use_frame and args.model in ("res8", "mobilenet")
+    fused = (use_frame and args.model in ("res8", "mobilenet")) or (not use_frame and args.model == "seq-lstm")
     if fused:
         trainer = FusedRes8Trainer(model, std_transform, zmuv_transform, SETTINGS.training.learning_rate,
                                    weight_decay=SETTINGS.training.weight_decay)
@@ -195,16 +195,19 @@ def main(argv=None):
                     audio[k, : len(pcm)] = torch.from_numpy(pcm)
                 lengths = std_transform.compute_lengths(torch.tensor([len(p) for p, _ in batch]))
                 feats = std_transform.log_mel_for_model(audio.to(device), zmuv_transform)
-                scores = model(feats, lengths)
                 tl = torch.tensor([len(e) for _, e in batch])
                 targets = torch.zeros(len(batch), max(1, int(tl.max())), dtype=torch.long)
                 for k, (_, ends) in enumerate(batch):
                     targets[k, : len(ends)] = torch.tensor([w for w, _ in ends])
-                optimizer.zero_grad()
                 # log_softmax + CTCLoss(blank) of train.py:291-296 as one fused kernel (loss and d loss / d scores)
-                loss = ops.ctc_loss(scores, targets, lengths, tl, ctx.blank_label)
-                loss.backward()
-                optimizer.step()
+                if fused:
+                    loss = trainer.step_sequence_on_features(feats, lengths, targets, tl, ctx.blank_label, int(tl.max()))
+                else:
+                    scores = model(feats, lengths)
+                    optimizer.zero_grad()
+                    loss = ops.ctc_loss(scores, targets, lengths, tl, ctx.blank_label)
+                    loss.backward()
+                    optimizer.step()
             total_loss += loss.detach().reshape(())                       # accumulated on the device (train.py:303-304)
         if fused:
             trainer.decay_lr(SETTINGS.training.lr_decay)

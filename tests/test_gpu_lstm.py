@@ -122,3 +122,55 @@ def test_fused_ctc_out_of_range_uses_torch_device_kernels():
     assert abs(out.item() - loss.item()) < 1e-4 and maxerr(z.grad, grad) < 1e-5
     with pytest.raises(Exception):
         ops.ctc_loss(logits.permute(1, 0, 2), targets, in_len, tgt_len, blank)   # CPU scores: no CPU fallback
+
+
+def test_fused_sequence_step_matches_autograd_path_and_oracle():
+    """FusedTrainer.step_sequence (explicit launches, gradients straight into the flat buffer, flat AdamW) against (a) the
+    autograd path through the same kernels + torch.optim.AdamW and (b) the oracle's CTC step; ragged lengths."""
+    from howl_amd import ops
+    from howl_amd.data.transform.operator import ZmuvTransform
+    from howl_amd.data.transform.transform import StandardAudioTransform
+    from howl_amd.training.fused import FusedTrainer
+    from howl_amd.utils.synth import synthetic_pcm
+    B, L, C = 48, 8000, 5
+    pcm = synthetic_pcm(B, L).to(DEV)
+    std = StandardAudioTransform().to(DEV).eval()
+    zmuv = ZmuvTransform().to(DEV)
+    zmuv.update(std(pcm[:4]))
+    lengths = torch.sort(24 + torch.arange(B) % 15, descending=True).values
+    targets = torch.tensor([[0, 1, 2]] * B)
+    tl = torch.tensor([3, 2, 1] * (B // 3))
+    feats = std.log_mel_for_model(pcm, zmuv)
+
+    fused_model = make("seq-lstm", C).train()
+    trainer = FusedTrainer(fused_model, std, zmuv, lr=1e-3, weight_decay=1e-5)
+    loss_f = trainer.step_sequence(pcm, lengths, targets, tl, 4)
+    grads_f = [g.clone() for g in trainer.fp.grad_views]
+
+    ref_model = make("seq-lstm", C).train()
+    opt = torch.optim.AdamW(ref_model.parameters(), 1e-3, weight_decay=1e-5)
+    loss_a = ops.ctc_loss(ref_model(feats, lengths), targets, lengths, tl, 4)
+    loss_a.backward()
+    assert abs(loss_f.item() - loss_a.item()) < 1e-6
+    for p, g in zip(ref_model.hot_parameters(), grads_f):
+        assert torch.equal(p.grad, g)                                  # same kernels, same order: bit-identical
+    opt.step()
+    for p, q in zip(ref_model.hot_parameters(), fused_model.hot_parameters()):
+        assert maxerr(p, q) < 1e-6                                      # torch AdamW vs the flat kernel: rounding only
+
+    sd = {k: v.clone().requires_grad_(True) for k, v in om.lstm_init(C).items()}
+    fb = ofe.mel_fb(40)
+    z = ofe.Zmuv()
+    z.update(ofe.standard_audio_transform(pcm[:4].cpu(), fb))
+    ref, _ = om.seq_lstm_forward(sd, z(ofe.standard_audio_transform(pcm.cpu(), fb)), lengths)
+    ref_loss = torch.nn.CTCLoss(4)(torch.log_softmax(ref, -1), targets, lengths, tl)
+    ref_loss.backward()
+    assert abs(loss_f.item() - ref_loss.item()) < 1e-4
+    names = ["lstm.weight_ih_l0", "lstm.weight_hh_l0", "lstm.bias_ih_l0", "lstm.bias_hh_l0", "dnn.0.weight", "dnn.0.bias",
+             "dnn.2.weight", "dnn.2.bias"]
+    for n, g in zip(names, grads_f):
+        r = sd[n].grad
+        assert maxerr(g, r) < 1e-4 * max(1.0, r.abs().max().item()), n
+    # a second step runs (saved state is per step) and the loss moves
+    loss2 = trainer.step_sequence(pcm, lengths, targets, tl, 4)
+    assert loss2.item() < loss_f.item()

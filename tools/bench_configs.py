@@ -13,7 +13,7 @@ from howl_amd import ops  # noqa: E402
 from howl_amd.data.transform.operator import ZmuvTransform  # noqa: E402
 from howl_amd.data.transform.transform import StandardAudioTransform  # noqa: E402
 from howl_amd.model import RegisteredModel  # noqa: E402
-from howl_amd.training.fused import FusedRes8Trainer  # noqa: E402
+from howl_amd.training.fused import FusedRes8Trainer, FusedTrainer  # noqa: E402
 from howl_amd.utils.synth import res8_closed_form_state, synthetic_pcm  # noqa: E402
 
 dev = torch.device("cuda:0")
@@ -66,19 +66,14 @@ std = StandardAudioTransform().to(dev).eval()
 zmuv = ZmuvTransform().to(dev)
 zmuv.update(std(pcm[:8]))
 model = RegisteredModel.find_registered_class("seq-lstm")(C).to(dev).train()
-opt = torch.optim.AdamW(model.parameters(), 1e-4, weight_decay=1e-5)
 lengths = torch.full((B,), 38)
 targets = torch.tensor([[0, 1, 2]] * B).to(dev)
 tl = torch.tensor([3] * B)
+seq_trainer = FusedTrainer(model, std, zmuv, lr=1e-4, weight_decay=1e-5)
 
 
-def lstm_step():
-    feats = std.log_mel_for_model(pcm, zmuv)
-    sc = model(feats, lengths)
-    loss = ops.ctc_loss(sc, targets, lengths, tl, 4)       # fused log_softmax + CTCLoss(blank=4)
-    opt.zero_grad()
-    loss.backward()
-    opt.step()
+def lstm_step():      # frontend -> LSTM + head -> fused log_softmax + CTC(blank=4) -> backward -> flat AdamW
+    seq_trainer.step_sequence(pcm, lengths, targets, tl, 4, max_target=3)
 
 
 dt = timeit(lstm_step, steps=20)
