@@ -338,15 +338,17 @@ int howl_lstm_bwd(const HowlLstmParams* p, const float* x, int B, int T, int M, 
     float* pb = pf + 16 * 64 * 64;
     float* scratch = pb + 16 * 64 * 64 + G4;
     const int Tout = sv->t_out;
-    // steps t >= t_out never ran: their dG rows must read as zero in the weight-gradient GEMMs
-    hipMemsetAsync(sv->dgates, 0, (size_t)B * T * G4 * sizeof(float), stream);
     hipLaunchKernelGGL(lstm_bwd_kernel, dim3((B + 15) / 16), dim3(LSTM_THREADS), 0, stream, dy, dhT, dcT, (const float*)pb,
                        lengths, (const float*)sv->gates, (const float*)sv->c, c0, sv->dgates, B, T, Tout);
-    // dW_ih = dG^T X, dW_hh = dG^T H_prev (hseq rows t = 0..T-1 of each utterance), db = column sums of dG
-    const RowMap rows_bt = lin(G4);
-    wgrad_gemm(stream, sv->dgates, rows_bt, G4, x, lin(M), M, B * T, scratch, g->w_ih);
-    wgrad_gemm(stream, sv->dgates, rows_bt, G4, sv->hseq, RowMap{T, (long)(T + 1) * HID, HID}, HID, B * T, scratch, g->w_hh);
-    colsum(stream, sv->dgates, rows_bt, B * T, G4, scratch, g->b_ih, g->b_hh);
+    // dW_ih = dG^T X, dW_hh = dG^T H_prev (hseq rows t = 0..t_out-1 of each utterance), db = column sums of dG.  Steps
+    // t >= t_out never ran and their dG rows are never written: the reductions walk rows (b, t < t_out) only.
+    const bool full = Tout == T;
+    const RowMap rows_g = full ? lin(G4) : RowMap{Tout, (long)T * G4, G4};
+    const RowMap rows_x = full ? lin(M) : RowMap{Tout, (long)T * M, M};
+    const int rows = B * Tout;
+    wgrad_gemm(stream, sv->dgates, rows_g, G4, x, rows_x, M, rows, scratch, g->w_ih);
+    wgrad_gemm(stream, sv->dgates, rows_g, G4, sv->hseq, RowMap{Tout, (long)(T + 1) * HID, HID}, HID, rows, scratch, g->w_hh);
+    colsum(stream, sv->dgates, rows_g, rows, G4, scratch, g->b_ih, g->b_hh);
     HOWL_CHECK_LAUNCH("howl_lstm_bwd");
     return HOWL_OK;
 }

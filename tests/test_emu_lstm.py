@@ -21,7 +21,7 @@ def run_lstm(lib, sd, x_btm, lengths, h0=None, c0=None):
     prm = HowlLstmParams(ptr(npz["weight_ih_l0"]), ptr(npz["weight_hh_l0"]), ptr(npz["bias_ih_l0"]), ptr(npz["bias_hh_l0"]))
     bufs = dict(gx=np.zeros((B, T, 512), np.float32), gates=np.zeros((B, T, 512), np.float32),
                 c=np.zeros((B, T, 128), np.float32), hseq=np.full((B, T + 1, 128), np.nan, np.float32),
-                dgates=np.zeros((B, T, 512), np.float32))
+                dgates=np.full((B, T, 512), np.nan, np.float32))   # rows t >= t_out must never be read
     t_out = int(lengths.max()) if lengths is not None else T
     sv = HowlLstmSaved(ptr(bufs["gx"]), ptr(bufs["gates"]), ptr(bufs["c"]), ptr(bufs["hseq"]), ptr(bufs["dgates"]), t_out)
     hT, cT = np.zeros((B, 128), np.float32), np.zeros((B, 128), np.float32)
