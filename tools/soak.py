@@ -44,4 +44,35 @@ for name, B, C, lr, steps in (("res8", 256, 12, 0.01, 300), ("mobilenet", 128, 1
             assert losses[-1] < 0.5 * losses[0], (name, losses)
     print(f"{name}: repeat run bit-identical: {torch.equal(finals[0], finals[1])}", flush=True)
     assert torch.equal(finals[0], finals[1])
+# sequence objective: seq-lstm + fused log_softmax/CTC on 0.5 s tones whose frequency class picks one of four label sequences
+finals = []
+for rep in range(2):
+    torch.manual_seed(0)
+    B, C, blank = 256, 5, 4
+    pcm = synthetic_pcm(B, 8000).to(dev)
+    seqs = [[0, 1, 2], [2, 1], [3], [1, 1, 0]]                 # incl. a repeated label and different lengths
+    targets = torch.zeros(B, 3, dtype=torch.long)
+    tl = torch.zeros(B, dtype=torch.long)
+    for b in range(B):
+        q = seqs[b % 4]
+        targets[b, : len(q)] = torch.tensor(q)
+        tl[b] = len(q)
+    std = StandardAudioTransform().to(dev).eval()
+    zmuv = ZmuvTransform().to(dev)
+    zmuv.update(std(pcm[:8]))
+    model = RegisteredModel.find_registered_class("seq-lstm")(C).to(dev).train()
+    tr = FusedTrainer(model, std, zmuv, lr=0.003)
+    lengths = torch.full((B,), 38)
+    losses = []
+    for i in range(200):
+        loss = tr.step_sequence(pcm, lengths, targets, tl, blank, max_target=3)
+        if i % 25 == 0 or i == 199:
+            losses.append(round(loss.item(), 4))
+    assert all(torch.isfinite(p).all() for p in model.parameters())
+    finals.append(tr.fp.flat.clone())
+    if rep == 0:
+        print(f"seq-lstm/ctc: loss {losses[0]} -> {losses[-1]} over 200 steps (every 25th: {losses})", flush=True)
+        assert losses[-1] < 0.5 * losses[0], losses
+print(f"seq-lstm/ctc: repeat run bit-identical: {torch.equal(finals[0], finals[1])}", flush=True)
+assert torch.equal(finals[0], finals[1])
 print("soak ok")
