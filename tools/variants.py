@@ -65,7 +65,7 @@ def main():
     out = Path("/tmp/howl_variants")
     out.mkdir(exist_ok=True)
     objs = []
-    for f in ("capi", "lstm", "mobilenet"):
+    for f in ("capi", "lstm", "mobilenet", "ctc"):
         o = out / f"{f}.o"
         subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-c", str(CSRC / f"{f}.hip"), "-o", str(o)],
                        check=True)
