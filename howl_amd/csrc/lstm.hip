@@ -79,19 +79,41 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(const float* __r
     float (*sbuf)[16 * SROW] = reinterpret_cast<float (*)[16 * SROW]>(lds_fwd + 2 * 16 * HS);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b0 = blockIdx.x * 16;
+    // Destination of this thread's three float4 slots: a 32-bit element offset at t = 0 plus a per-step stride, packed so
+    // that nothing 64-bit has to stay live across the steps (the compiler used to hoist six 64-bit bases, spill them at the
+    // 128-VGPR limit of a 16-wave workgroup and reload each one from scratch -- with a full vmcnt(0) wait -- in front of
+    // every store of every step: ~2 us of each 6.7 us step).  kind: 0 gates, 1 cs, 2 hseq, 3 nothing.
+    unsigned foff[3];
+    int fkind[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int i4 = tid + i * LSTM_THREADS;          // float4 index: 16 rows x 192
+        const int row = i4 / (SROW / 4), c4 = i4 - row * (SROW / 4);
+        const int b = b0 + row;
+        if (b >= B) {
+            fkind[i] = 3;
+            foff[i] = 0u;
+        } else if (c4 < G4 / 4) {
+            fkind[i] = 0;
+            foff[i] = (unsigned)b * (unsigned)T * G4 + 4u * c4;
+        } else if (c4 < (G4 + HID) / 4) {
+            fkind[i] = 1;
+            foff[i] = (unsigned)b * (unsigned)T * HID + 4u * (c4 - G4 / 4);
+        } else {
+            fkind[i] = 2;
+            foff[i] = ((unsigned)b * (unsigned)(T + 1) + 1u) * HID + 4u * (c4 - (G4 + HID) / 4);
+        }
+    }
     auto flush = [&](int t, const float* sb) {   // step t's rows -> gates / cs / hseq
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            const int i4 = tid + i * LSTM_THREADS;          // float4 index: 16 rows x 192
-            const int row = i4 / (SROW / 4), c4 = i4 - row * (SROW / 4);
-            const int b = b0 + row;
-            if (b < B) {
-                const float4 v = *reinterpret_cast<const float4*>(sb + row * SROW + 4 * c4);
-                const size_t o = (size_t)b * T + t;
-                if (c4 < G4 / 4) *reinterpret_cast<float4*>(gates + o * G4 + 4 * c4) = v;
-                else if (c4 < (G4 + HID) / 4) *reinterpret_cast<float4*>(cs + o * HID + 4 * (c4 - G4 / 4)) = v;
-                else *reinterpret_cast<float4*>(hseq + ((size_t)b * (T + 1) + t + 1) * HID + 4 * (c4 - (G4 + HID) / 4)) = v;
-            }
+            const int i4 = tid + i * LSTM_THREADS;
+            const float4 v = *reinterpret_cast<const float4*>(sb + 4 * i4);   // row * SROW + 4 * c4 == 4 * i4
+            const unsigned o = foff[i] + (unsigned)t * (fkind[i] == 0 ? (unsigned)G4 : (unsigned)HID);
+            // three predicated stores off uniform base pointers (a selected pointer would go through a table in scratch)
+            if (fkind[i] == 0) *reinterpret_cast<float4*>(gates + o) = v;
+            else if (fkind[i] == 1) *reinterpret_cast<float4*>(cs + o) = v;
+            else if (fkind[i] == 2) *reinterpret_cast<float4*>(hseq + o) = v;
         }
     };
     float wA[32], wB[32];
