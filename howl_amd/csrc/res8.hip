@@ -653,7 +653,10 @@ __global__ __launch_bounds__(CONV_THREADS) void wgrad_mfma_kernel(
     int pslot = 0;
     HOWL_PROBE(wave, lane, pslot++);   // entry
 
-    // first utterance's tiles are requested before the LDS setup so that HBM latency overlaps it
+    // staging slots first (integer divisions: many temporaries), then the first utterance's tiles are requested before
+    // the LDS setup so that HBM latency overlaps it
+    int pk[PREF];
+    stage_slots(pk, P, CS, n2, tid, WPW);
     float2 pz[PREF], px[PREF];
     const int b = blockIdx.x;
     if (b < B) {
@@ -665,8 +668,6 @@ __global__ __launch_bounds__(CONV_THREADS) void wgrad_mfma_kernel(
         lmean[tid] = affine ? in_stats[tid] : 0.0f;
         lrstd[tid] = affine ? in_stats[CP + tid] : 1.0f;
     }
-    int pk[PREF];
-    stage_slots(pk, P, CS, n2, tid, WPW);
     __syncthreads();
     HOWL_PROBE(wave, lane, pslot++);   // prologue done
     // instantiated per tile count (waves 0..2 carry a third N tile): no branches inside the K loop, and the register
