@@ -868,12 +868,17 @@ __device__ __forceinline__ void load_feat_tile(float* tin, const float* feat, lo
         for (int j = 0; j < 8; ++j) {
             const int i = i0 + j * nthreads;
             const int t = i / pitch - 1, m = i % pitch - 1;
-            v[j] = (i < n && t >= 0 && t < T && m >= 0 && m < M) ? feat[b * sb + t * st + m * sm] : 0.0f;
+            const bool ok = i < n && t >= 0 && t < T && m >= 0 && m < M;
+            // clamped unconditional loads (halo / tail slots read element (b,0,0)), zeroed below: predicated loads were
+            // compiled into a chain with vmcnt(0) waits between them, i.e. several HBM round trips back to back
+            v[j] = feat[b * sb + (ok ? t * st + m * sm : 0)];
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int i = i0 + j * nthreads;
-            if (i < n) tin[i] = v[j];
+            const int t = i / pitch - 1, m = i % pitch - 1;
+            const bool ok = t >= 0 && t < T && m >= 0 && m < M;
+            if (i < n) tin[i] = ok ? v[j] : 0.0f;
         }
     }
 }
