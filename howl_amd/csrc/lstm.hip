@@ -248,24 +248,37 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_bwd_kernel(const float* __r
     struct Step {
         float ig, fg, gg, og, cn, cp, dyv;
     };
-    auto fetch = [&](int t, int uu, Step& st) {
+    // Unconditional loads from clamped addresses, zeroed afterwards: predicated loads (and the two alternative sources of
+    // c_{t-1}) were compiled into groups separated by vmcnt(0) waits, i.e. several HBM round trips per step.
+    const size_t bclamp = vb ? (size_t)b : 0;
+    float c0v[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) c0v[q] = (vb && c0 != nullptr) ? c0[(size_t)b * HID + (tid & 63) + 64 * q] : 0.0f;
+    auto fetch = [&](int t, int q, Step& st) {
+        const int uu = (tid & 63) + 64 * q;
         const bool lv = vb && t >= 0 && t < len;
-        const size_t o = (size_t)b * T + (lv ? t : 0);
-        st.ig = lv ? gates[o * G4 + uu] : 0.0f;
-        st.fg = lv ? gates[o * G4 + HID + uu] : 0.0f;
-        st.gg = lv ? gates[o * G4 + 2 * HID + uu] : 0.0f;
-        st.og = lv ? gates[o * G4 + 3 * HID + uu] : 0.0f;
-        st.cn = lv ? cs[o * HID + uu] : 0.0f;
-        st.cp = lv ? (t > 0 ? cs[(o - 1) * HID + uu] : (c0 != nullptr ? c0[(size_t)b * HID + uu] : 0.0f)) : 0.0f;
-        st.dyv = (lv && dy != nullptr) ? dy[o * HID + uu] : 0.0f;
+        const size_t o = bclamp * T + (lv ? t : 0);
+        const size_t op = o - ((lv && t > 0) ? 1 : 0);
+        const float ig = gates[o * G4 + uu], fg = gates[o * G4 + HID + uu];
+        const float gg = gates[o * G4 + 2 * HID + uu], og = gates[o * G4 + 3 * HID + uu];
+        const float cn = cs[o * HID + uu], cpv = cs[op * HID + uu];
+        float dyv = 0.0f;
+        if (dy != nullptr) dyv = dy[o * HID + uu];   // uniform branch
+        st.ig = lv ? ig : 0.0f;
+        st.fg = lv ? fg : 0.0f;
+        st.gg = lv ? gg : 0.0f;
+        st.og = lv ? og : 0.0f;
+        st.cn = lv ? cn : 0.0f;
+        st.cp = lv ? (t > 0 ? cpv : c0v[q]) : 0.0f;
+        st.dyv = lv ? dyv : 0.0f;
     };
     Step cur[2], nxt[2];
 #pragma unroll
-    for (int q = 0; q < 2; ++q) fetch(Tout - 1, (tid & 63) + 64 * q, cur[q]);
+    for (int q = 0; q < 2; ++q) fetch(Tout - 1, q, cur[q]);
     for (int t = Tout - 1; t >= 0; --t) {
         const bool live = t < len;
 #pragma unroll
-        for (int q = 0; q < 2; ++q) fetch(t - 1, (tid & 63) + 64 * q, nxt[q]);
+        for (int q = 0; q < 2; ++q) fetch(t - 1, q, nxt[q]);
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int uu = (tid & 63) + 64 * q;
