@@ -45,26 +45,27 @@ __global__ __launch_bounds__(256) void gemm_kernel(const float* __restrict__ a, 
         for (int j = 0; j < 2; ++j) acc[i][j] = {0.0f, 0.0f, 0.0f, 0.0f};
 
     for (int k0 = kbeg; k0 < kend; k0 += GK) {
-        // stage A tile (64 m x 16 k) and B tile (16 k x 64 n); thread mapping follows the unit-stride index
+        // stage A tile (64 m x 16 k) and B tile (16 k x 64 n); thread mapping follows the unit-stride index.  The eight
+        // loads of a thread go out together from clamped addresses and are zeroed afterwards: guarded loads were compiled
+        // into load / s_waitcnt vmcnt(0) pairs, eight dependent memory round trips per K tile.
+        float va[4], vb[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            int mm, kk;
-            if (A_MAJOR_IS_K) {
-                kk = tid & 15;
-                mm = (tid >> 4) + 16 * j;
-            } else {
-                mm = tid & 63;
-                kk = (tid >> 6) + 4 * j;
-            }
-            const int m = m0 + mm, k = k0 + kk;
-            float v = 0.0f;
-            if (m < M && k < kend) v = a[rmap(am, m) + (A_MAJOR_IS_K ? (long)k * a_ks : rmap(ak, k))];
-            As[kk * GLD + mm] = v;
+            const int mm = A_MAJOR_IS_K ? (tid >> 4) + 16 * j : tid & 63;
+            const int kk = A_MAJOR_IS_K ? tid & 15 : (tid >> 6) + 4 * j;
+            const int m = min(m0 + mm, M - 1), k = min(k0 + kk, kend - 1);
+            va[j] = a[rmap(am, m) + (A_MAJOR_IS_K ? (long)k * a_ks : rmap(ak, k))];
             const int nn = tid & 63, kb = (tid >> 6) + 4 * j;
-            const int n = n0 + nn, k2 = k0 + kb;
-            float w = 0.0f;
-            if (n < N && k2 < kend) w = b[rmap(bk, k2) + (long)n * b_ns];
-            Bs[kb * GLD + nn] = w;
+            const int n = min(n0 + nn, N - 1), k2 = min(k0 + kb, kend - 1);
+            vb[j] = b[rmap(bk, k2) + (long)n * b_ns];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int mm = A_MAJOR_IS_K ? (tid >> 4) + 16 * j : tid & 63;
+            const int kk = A_MAJOR_IS_K ? tid & 15 : (tid >> 6) + 4 * j;
+            As[kk * GLD + mm] = (m0 + mm < M && k0 + kk < kend) ? va[j] : 0.0f;
+            const int nn = tid & 63, kb = (tid >> 6) + 4 * j;
+            Bs[kb * GLD + nn] = (n0 + nn < N && k0 + kb < kend) ? vb[j] : 0.0f;
         }
         __syncthreads();
 #pragma unroll
@@ -83,6 +84,29 @@ __global__ __launch_bounds__(256) void gemm_kernel(const float* __restrict__ a, 
         __syncthreads();
     }
     float* cz = c + (long)blockIdx.z * c_split_stride;
+    // Bias and ReLU are applied to all 16 results in registers BEFORE the first store.  A bias load inside the guarded
+    // store was 16 dependent round trips per lane; and even with the two values loaded up front, their first use inside
+    // each guarded block put an s_waitcnt vmcnt there -- vmcnt also counts stores on gfx9, so every store waited for the
+    // previous one to complete.
+    if (bias != nullptr) {
+        float bv[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) bv[j] = bias[min(n0 + 32 * wc + 16 * j + (lane & 15), N - 1)];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][j][r] += bv[j];
+    }
+    if (relu) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][j][r] = fmaxf(acc[i][j][r], 0.0f);
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -91,12 +115,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const float* __restrict__ a, 
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int m = m0 + 32 * wr + 16 * i + 4 * (lane >> 4) + r;
-                if (m < M && n < N) {
-                    float v = acc[i][j][r];
-                    if (bias != nullptr) v += bias[n];
-                    if (relu) v = fmaxf(v, 0.0f);
-                    cz[(long)m * c_ms + n] = v;
-                }
+                if (m < M && n < N) cz[(long)m * c_ms + n] = acc[i][j][r];
             }
         }
 }
@@ -175,6 +194,29 @@ __global__ __launch_bounds__(256) void gemm_vec_kernel(const float* __restrict__
         __syncthreads();
     }
     float* cz = c + (long)blockIdx.z * c_split_stride;
+    // Bias and ReLU are applied to all 16 results in registers BEFORE the first store.  A bias load inside the guarded
+    // store was 16 dependent round trips per lane; and even with the two values loaded up front, their first use inside
+    // each guarded block put an s_waitcnt vmcnt there -- vmcnt also counts stores on gfx9, so every store waited for the
+    // previous one to complete.
+    if (bias != nullptr) {
+        float bv[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) bv[j] = bias[min(n0 + 32 * wc + 16 * j + (lane & 15), N - 1)];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][j][r] += bv[j];
+    }
+    if (relu) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][j][r] = fmaxf(acc[i][j][r], 0.0f);
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -183,12 +225,7 @@ __global__ __launch_bounds__(256) void gemm_vec_kernel(const float* __restrict__
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int m = m0 + 32 * wr + 16 * i + 4 * (lane >> 4) + r;
-                if (m < M && n < N) {
-                    float v = acc[i][j][r];
-                    if (bias != nullptr) v += bias[n];
-                    if (relu) v = fmaxf(v, 0.0f);
-                    cz[(long)m * c_ms + n] = v;
-                }
+                if (m < M && n < N) cz[(long)m * c_ms + n] = acc[i][j][r];
             }
         }
 }
