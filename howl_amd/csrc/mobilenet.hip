@@ -240,22 +240,26 @@ __global__ void col2im3x3_kernel(const float* __restrict__ dcol, int H, int W, i
         const long t = pix / W;
         const int ih = (int)(t % H);
         const long b = t / H;
-        float acc = 0.0f;
+        // all nine candidate taps are loaded from clamped addresses and masked afterwards (see dw3x3_fwd_kernel)
+        float v[9];
+        bool ok[9];
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh) {
             const int nh = ih + ph - kh;
-            if (nh < 0 || nh % stride != 0) continue;
-            const int oh = nh / stride;
-            if (oh >= Ho) continue;
+            const bool okh = nh >= 0 && nh % stride == 0 && nh / stride < Ho;
+            const int oh = okh ? nh / stride : 0;
 #pragma unroll
             for (int kw = 0; kw < 3; ++kw) {
                 const int nw = iw + pw - kw;
-                if (nw < 0 || nw % stride != 0) continue;
-                const int ow = nw / stride;
-                if (ow >= Wo) continue;
-                acc += dcol[((b * Ho + oh) * Wo + ow) * (9L * C) + c * 9 + kh * 3 + kw];
+                const bool okw = nw >= 0 && nw % stride == 0 && nw / stride < Wo;
+                const int ow = okw ? nw / stride : 0;
+                ok[kh * 3 + kw] = okh && okw;
+                v[kh * 3 + kw] = dcol[((b * Ho + oh) * Wo + ow) * (9L * C) + c * 9 + kh * 3 + kw];
             }
         }
+        float acc = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) acc += ok[i] ? v[i] : 0.0f;
         dx[idx] = acc;
     }
 }
@@ -472,35 +476,48 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const float* __restrict
 }
 
 // folds the chunk partials of 64 columns: the 4 waves split the chunks, lanes are columns (coalesced), fixed order
+constexpr int FIN_RG = 16;   // row groups of a finalize block (1024 threads): <= 512 chunk rows are two trips of 16 loads
+constexpr int FIN_THREADS = 64 * FIN_RG;
 __device__ __forceinline__ void fold_chunks(const double* __restrict__ part, int chunks, int C, int c, int rg, double& s0,
-                                            double& s1, double (&red)[2][4][64], int lane) {
-    double a0[4] = {0.0, 0.0, 0.0, 0.0}, a1[4] = {0.0, 0.0, 0.0, 0.0};
-    if (c < C) {
-        int k = rg;
-        for (; k + 12 < chunks; k += 16) {   // four independent loads per sum in flight
+                                            double& s1, double (&red)[2][FIN_RG][64], int lane) {
+    // Sixteen row groups x eight rows per trip, the 16 loads of a trip in flight together (clamped row, masked sum).  With 4
+    // row groups this was 8+ dependent trips to L2 in a kernel that is nothing but latency (53 + 53 launches per step).
+    double a0 = 0.0, a1 = 0.0;
+    const int cc = c < C ? c : C - 1;
+    for (int k0 = rg; k0 < chunks; k0 += 8 * FIN_RG) {
+        double v0[8], v1[8];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                a0[u] += part[((size_t)(k + 4 * u) * 2 + 0) * C + c];
-                a1[u] += part[((size_t)(k + 4 * u) * 2 + 1) * C + c];
-            }
+        for (int u = 0; u < 8; ++u) {
+            const int k = k0 + u * FIN_RG < chunks ? k0 + u * FIN_RG : chunks - 1;
+            v0[u] = part[((size_t)k * 2 + 0) * C + cc];
+            v1[u] = part[((size_t)k * 2 + 1) * C + cc];
         }
-        for (; k < chunks; k += 4) {
-            a0[0] += part[((size_t)k * 2 + 0) * C + c];
-            a1[0] += part[((size_t)k * 2 + 1) * C + c];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const bool ok = k0 + u * FIN_RG < chunks;
+            a0 += ok ? v0[u] : 0.0;
+            a1 += ok ? v1[u] : 0.0;
         }
     }
-    red[0][rg][lane] = (a0[0] + a0[1]) + (a0[2] + a0[3]);
-    red[1][rg][lane] = (a1[0] + a1[1]) + (a1[2] + a1[3]);
+    red[0][rg][lane] = a0;
+    red[1][rg][lane] = a1;
     __syncthreads();
-    s0 = ((red[0][0][lane] + red[0][1][lane]) + red[0][2][lane]) + red[0][3][lane];
-    s1 = ((red[1][0][lane] + red[1][1][lane]) + red[1][2][lane]) + red[1][3][lane];
+    s0 = 0.0;
+    s1 = 0.0;
+    if (rg == 0) {
+#pragma unroll
+        for (int g = 0; g < FIN_RG; ++g) {
+            s0 += red[0][g][lane];
+            s1 += red[1][g][lane];
+        }
+    }
 }
 
 // batch statistics (biased variance for normalisation, unbiased for the running estimate: nn.BatchNorm2d)
-__global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const double* __restrict__ part, int chunks, int C,
+__global__ __launch_bounds__(FIN_THREADS) void bn_stats_finalize_kernel(const double* __restrict__ part, int chunks, int C,
                                                                 double count, float* __restrict__ stats,
                                                                 float* __restrict__ rmean, float* __restrict__ rvar) {
-    __shared__ double red[2][4][64];
+    __shared__ double red[2][FIN_RG][64];
     const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
     double s0, s1;
@@ -537,10 +554,10 @@ __global__ void bn_act_fwd_kernel(const float* __restrict__ z, const float* __re
 }
 
 // dgamma = sum g*xhat, dbeta = sum g; m1 = dbeta / M, m2 = dgamma / M for the apply pass
-__global__ __launch_bounds__(256) void bn_bwd_finalize_mb_kernel(const double* __restrict__ part, int chunks, int C,
+__global__ __launch_bounds__(FIN_THREADS) void bn_bwd_finalize_mb_kernel(const double* __restrict__ part, int chunks, int C,
                                                                  double count, float* __restrict__ dgamma,
                                                                  float* __restrict__ dbeta, float* __restrict__ m12) {
-    __shared__ double red[2][4][64];
+    __shared__ double red[2][FIN_RG][64];
     const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
     double s0, s1;
@@ -553,9 +570,9 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_mb_kernel(const double* _
 }
 
 // column sums only (conv-bias gradient): out[c] = sum over chunks of part[k][0][c]
-__global__ __launch_bounds__(256) void colsum_finalize_kernel(const double* __restrict__ part, int chunks, int C,
+__global__ __launch_bounds__(FIN_THREADS) void colsum_finalize_kernel(const double* __restrict__ part, int chunks, int C,
                                                               float* __restrict__ out) {
-    __shared__ double red[2][4][64];
+    __shared__ double red[2][FIN_RG][64];
     const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
     double s0, s1;
@@ -720,7 +737,7 @@ int howl_mobilenet_fwd(const float* params, float* buffers, int num_labels, cons
             hipLaunchKernelGGL(col_reduce_kernel<0>, dim3((l.cout + 63) / 64, chunks), dim3(256), 0, stream, (const float*)z,
                                (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0,
                                g.mz, l.cout, col_pack(l.cout), rpc, part);
-            hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((l.cout + 63) / 64), dim3(256), 0, stream, (const double*)part,
+            hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((l.cout + 63) / 64), dim3(FIN_THREADS), 0, stream, (const double*)part,
                                chunks, l.cout, (double)g.mz, stats, buffers + l.rmean_off, buffers + l.rvar_off);
         } else {
             hipLaunchKernelGGL(bn_eval_stats_mb_kernel, dim3((l.cout + 255) / 256), dim3(256), 0, stream,
@@ -813,7 +830,7 @@ int howl_mobilenet_bwd(const float* params, int num_labels, const float* x, long
         const long rpc = (g.mz + chunks - 1) / chunks;
         hipLaunchKernelGGL(col_reduce_kernel<1>, dim3((l.cout + 63) / 64, chunks), dim3(256), 0, stream, z, dy, stats,
                            params + l.gamma_off, params + l.beta_off, l.act, g.mz, l.cout, col_pack(l.cout), rpc, part);
-        hipLaunchKernelGGL(bn_bwd_finalize_mb_kernel, dim3((l.cout + 63) / 64), dim3(256), 0, stream, (const double*)part,
+        hipLaunchKernelGGL(bn_bwd_finalize_mb_kernel, dim3((l.cout + 63) / 64), dim3(FIN_THREADS), 0, stream, (const double*)part,
                            chunks, l.cout, (double)g.mz, grads + l.gamma_off, grads + l.beta_off, m12);
         float* dz = c.ws + (par ? c.p.dz2 : c.p.dz);
         if (sq && forked >= 2) hipStreamWaitEvent(stream, sq->ev[2 + par], 0);
@@ -875,7 +892,7 @@ int howl_mobilenet_bwd(const float* params, int num_labels, const float* x, long
                 hipLaunchKernelGGL(col_reduce_kernel<0>, dim3((l.cout + 63) / 64, chunks), dim3(256), 0, stream, (const float*)dz,
                                    (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
                                    0, g.mz, l.cout, col_pack(l.cout), rpc, part);
-                hipLaunchKernelGGL(colsum_finalize_kernel, dim3((l.cout + 63) / 64), dim3(256), 0, stream, (const double*)part,
+                hipLaunchKernelGGL(colsum_finalize_kernel, dim3((l.cout + 63) / 64), dim3(FIN_THREADS), 0, stream, (const double*)part,
                                    chunks, l.cout, grads + l.b_off);
             }
             if (dx != nullptr) {

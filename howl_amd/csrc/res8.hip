@@ -727,13 +727,23 @@ __device__ __forceinline__ void stats_colsum(const float* __restrict__ part, int
     const int cg = tid % 24, rg = tid / 24;
     if (rg < SC_RG) {
         double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-#pragma unroll 8
-        for (int g = rg; g < nparts; g += SC_RG) {
-            const float4 v = reinterpret_cast<const float4*>(part + (size_t)g * 2 * CP)[cg];
-            a0 += (double)v.x;
-            a1 += (double)v.y;
-            a2 += (double)v.z;
-            a3 += (double)v.w;
+        // eight rows per trip, all eight loads in flight (clamped row, contribution masked): a plain guarded loop was
+        // compiled into load / s_waitcnt vmcnt(0) pairs -- 6-7 dependent L2 round trips in a 6 us kernel
+        for (int g0 = rg; g0 < nparts; g0 += 8 * SC_RG) {
+            float4 v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int g = g0 + j * SC_RG;
+                v[j] = reinterpret_cast<const float4*>(part + (size_t)(g < nparts ? g : nparts - 1) * 2 * CP)[cg];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const bool ok = g0 + j * SC_RG < nparts;
+                a0 += ok ? (double)v[j].x : 0.0;
+                a1 += ok ? (double)v[j].y : 0.0;
+                a2 += ok ? (double)v[j].z : 0.0;
+                a3 += ok ? (double)v[j].w : 0.0;
+            }
         }
         red[rg][4 * cg + 0] = a0;
         red[rg][4 * cg + 1] = a1;
@@ -1201,16 +1211,41 @@ __global__ __launch_bounds__(1024) void xent_kernel(const float* __restrict__ lo
     const float invB = 1.0f / (float)B;
     for (int b = threadIdx.x; b < B; b += 1024) {
         const float* row = logits + (size_t)b * C;
-        float mx = row[0];
-        for (int k = 1; k < C; ++k) mx = fmaxf(mx, row[k]);
-        float se = 0.0f;
-        for (int k = 0; k < C; ++k) se += expf(row[k] - mx);
-        const float lse = mx + logf(se);
         const int y = (int)labels[b];
-        acc += (double)(lse - row[y]);
+        // eight logits per trip, loaded together from clamped indices (a one-load-per-iteration loop waits for every
+        // load before the next one is issued)
+        float mx = -INFINITY;
+        for (int k0 = 0; k0 < C; k0 += 8) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = row[min(k0 + j, C - 1)];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) mx = fmaxf(mx, v[j]);       // clamped duplicates do not change the maximum
+        }
+        float se = 0.0f, zy = 0.0f;
+        for (int k0 = 0; k0 < C; k0 += 8) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = row[min(k0 + j, C - 1)];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (k0 + j < C) {
+                    se += expf(v[j] - mx);
+                    if (k0 + j == y) zy = v[j];
+                }
+        }
+        const float lse = mx + logf(se);
+        acc += (double)(lse - zy);
         if (dlogits != nullptr)
-            for (int k = 0; k < C; ++k)
-                dlogits[(size_t)b * C + k] = (expf(row[k] - lse) - (k == y ? 1.0f : 0.0f)) * invB;
+            for (int k0 = 0; k0 < C; k0 += 8) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = row[min(k0 + j, C - 1)];
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (k0 + j < C)
+                        dlogits[(size_t)b * C + k0 + j] = (expf(v[j] - lse) - (k0 + j == y ? 1.0f : 0.0f)) * invB;
+            }
     }
     acc = wave_sum_d(acc);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
