@@ -240,26 +240,22 @@ __global__ void col2im3x3_kernel(const float* __restrict__ dcol, int H, int W, i
         const long t = pix / W;
         const int ih = (int)(t % H);
         const long b = t / H;
-        // all nine candidate taps are loaded from clamped addresses and masked afterwards (see dw3x3_fwd_kernel)
-        float v[9];
-        bool ok[9];
+        float acc = 0.0f;
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh) {
             const int nh = ih + ph - kh;
-            const bool okh = nh >= 0 && nh % stride == 0 && nh / stride < Ho;
-            const int oh = okh ? nh / stride : 0;
+            if (nh < 0 || nh % stride != 0) continue;
+            const int oh = nh / stride;
+            if (oh >= Ho) continue;
 #pragma unroll
             for (int kw = 0; kw < 3; ++kw) {
                 const int nw = iw + pw - kw;
-                const bool okw = nw >= 0 && nw % stride == 0 && nw / stride < Wo;
-                const int ow = okw ? nw / stride : 0;
-                ok[kh * 3 + kw] = okh && okw;
-                v[kh * 3 + kw] = dcol[((b * Ho + oh) * Wo + ow) * (9L * C) + c * 9 + kh * 3 + kw];
+                if (nw < 0 || nw % stride != 0) continue;
+                const int ow = nw / stride;
+                if (ow >= Wo) continue;
+                acc += dcol[((b * Ho + oh) * Wo + ow) * (9L * C) + c * 9 + kh * 3 + kw];
             }
         }
-        float acc = 0.0f;
-#pragma unroll
-        for (int i = 0; i < 9; ++i) acc += ok[i] ? v[i] : 0.0f;
         dx[idx] = acc;
     }
 }

@@ -1211,41 +1211,16 @@ __global__ __launch_bounds__(1024) void xent_kernel(const float* __restrict__ lo
     const float invB = 1.0f / (float)B;
     for (int b = threadIdx.x; b < B; b += 1024) {
         const float* row = logits + (size_t)b * C;
-        const int y = (int)labels[b];
-        // eight logits per trip, loaded together from clamped indices (a one-load-per-iteration loop waits for every
-        // load before the next one is issued)
-        float mx = -INFINITY;
-        for (int k0 = 0; k0 < C; k0 += 8) {
-            float v[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = row[min(k0 + j, C - 1)];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) mx = fmaxf(mx, v[j]);       // clamped duplicates do not change the maximum
-        }
-        float se = 0.0f, zy = 0.0f;
-        for (int k0 = 0; k0 < C; k0 += 8) {
-            float v[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = row[min(k0 + j, C - 1)];
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-                if (k0 + j < C) {
-                    se += expf(v[j] - mx);
-                    if (k0 + j == y) zy = v[j];
-                }
-        }
+        float mx = row[0];
+        for (int k = 1; k < C; ++k) mx = fmaxf(mx, row[k]);
+        float se = 0.0f;
+        for (int k = 0; k < C; ++k) se += expf(row[k] - mx);
         const float lse = mx + logf(se);
-        acc += (double)(lse - zy);
+        const int y = (int)labels[b];
+        acc += (double)(lse - row[y]);
         if (dlogits != nullptr)
-            for (int k0 = 0; k0 < C; k0 += 8) {
-                float v[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = row[min(k0 + j, C - 1)];
-#pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    if (k0 + j < C)
-                        dlogits[(size_t)b * C + k0 + j] = (expf(v[j] - lse) - (k0 + j == y ? 1.0f : 0.0f)) * invB;
-            }
+            for (int k = 0; k < C; ++k)
+                dlogits[(size_t)b * C + k] = (expf(row[k] - lse) - (k == y ? 1.0f : 0.0f)) * invB;
     }
     acc = wave_sum_d(acc);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
