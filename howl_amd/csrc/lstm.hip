@@ -45,11 +45,18 @@ __device__ __forceinline__ float tanhf_(float x) {
 //             B[k][n] = W_hh[256kh + 4kk + k][16nt + n]      (dh = dG . W_hh)
 // packed as [wave][frag 0..63][lane]
 // ---------------------------------------------------------------------------------------------------------
-__global__ void lstm_pack_kernel(const float* __restrict__ whh, float* __restrict__ pf, float* __restrict__ pb) {
+__global__ void lstm_pack_kernel(const float* __restrict__ whh, float* __restrict__ pf, float* __restrict__ pb,
+                                 float* __restrict__ pf4) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= 16 * 64 * 64) return;
     const int lane = idx & 63, frag = (idx >> 6) & 63, w = idx >> 12;
     const int k = lane >> 4, n = lane & 15;
+    if (pf4 != nullptr) {
+        // lstm_fwd4_kernel: wave w = (column chunk c = w & 7, K half kh = w >> 3); lane = 4 * unit_local + gate holds
+        // W_hh[gate * 128 + 16 c + unit_local][64 kh + frag]
+        const int c = w & 7, kh = w >> 3;
+        pf4[idx] = whh[((lane & 3) * HID + 16 * c + (lane >> 2)) * HID + 64 * kh + frag];
+    }
     {
         const int a = frag >> 5, kk = frag & 31;
         const int col = (2 * a + (n >> 3)) * HID + 8 * w + (n & 7);
@@ -58,6 +65,160 @@ __global__ void lstm_pack_kernel(const float* __restrict__ whh, float* __restric
     {
         const int nt = w & 7, kh = w >> 3;
         pb[idx] = whh[(256 * kh + 4 * frag + k) * HID + 16 * nt + n];
+    }
+}
+
+// Forward recurrence with FOUR sequences per workgroup on v_mfma_f32_4x4x1_16b_f32 (16 independent 4x4 outer products
+// per instruction: block = hidden unit, block column = gate, block row = sequence), so the batch dimension is not padded to
+// the 16 rows of the 16x16x4 tile: 128 workgroups at B = 512 and a 1.2 us matrix floor per step instead of 3.3 us.
+//   wave w = (column chunk c = w & 7: units 16c..16c+15 x 4 gates, K half kh = w >> 3: h[64kh .. 64kh+63]);
+//   four accumulator chains per wave (k = 0,1,2,3 mod 4) hide the ~50-cycle dependent latency of the instruction;
+//   the two K halves meet through LDS: wave (c, kh) finishes sequences 2kh, 2kh+1 and hands the other two to its partner;
+//   lane 4j+g then holds gate g of unit 16c+j for its two sequences: each lane applies its own gate's nonlinearity, the four
+//   gates of a cell are gathered by quad shuffles and all four lanes of the quad carry the cell state redundantly.
+constexpr int F4_HS = HID + 4;          // h rows in LDS (16-byte aligned rows for the float4 A-fragment reads)
+constexpr int F4_PS = G4 + 4;           // row stride of the K-half partial sums
+constexpr int F4_SROW = 6 * HID;        // saved activations of a step per sequence: gates i,f,g,o | c | h
+__global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd4_kernel(const float* __restrict__ gx, const float* __restrict__ pf4,
+                                                                 const long long* __restrict__ lengths,
+                                                                 const float* __restrict__ h0, const float* __restrict__ c0,
+                                                                 float* __restrict__ gates, float* __restrict__ cs,
+                                                                 float* __restrict__ hseq, float* __restrict__ hT,
+                                                                 float* __restrict__ cT, int B, int T, int Tout) {
+    __shared__ __attribute__((aligned(16))) float hbuf[2][4 * F4_HS];
+    __shared__ float part[2][4 * F4_PS];
+    __shared__ __attribute__((aligned(16))) float sbuf[2][4 * F4_SROW];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = wave & 7, kh = wave >> 3;
+    const int j = lane >> 2, g = lane & 3;
+    const int u = 16 * c + j;                       // hidden unit of this lane's quad
+    const int col = g * HID + u;                    // its gate column in PyTorch order (i, f, g, o)
+    const int b0 = blockIdx.x * 4;
+    float wB[64];
+#pragma unroll
+    for (int kk = 0; kk < 64; ++kk) wB[kk] = pf4[((size_t)wave * 64 + kk) * 64 + lane];
+    // this lane finishes sequences s0, s0 + 1 (rows of the workgroup's four)
+    const int s0 = 2 * kh;
+    float cst[2], hst[2];
+    int len[2];
+    bool vb[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int b = b0 + s0 + q;
+        vb[q] = b < B;
+        cst[q] = (vb[q] && c0 != nullptr) ? c0[(size_t)b * HID + u] : 0.0f;
+        hst[q] = (vb[q] && h0 != nullptr) ? h0[(size_t)b * HID + u] : 0.0f;
+        len[q] = vb[q] ? (lengths != nullptr ? (int)lengths[b] : T) : 0;
+        if (g == 0) {
+            hbuf[0][(s0 + q) * F4_HS + u] = hst[q];
+            if (vb[q]) hseq[((size_t)b * (T + 1)) * HID + u] = hst[q];
+        }
+    }
+    // destination of this thread's float4 slot of a step's saved rows (4 x 768 floats = 768 float4: threads 0..767)
+    int fkind = 3;
+    unsigned foff = 0u;
+    if (tid < 4 * F4_SROW / 4) {
+        const int row = tid / (F4_SROW / 4), c4 = tid - row * (F4_SROW / 4);
+        const int b = b0 + row;
+        if (b < B) {
+            if (c4 < G4 / 4) {
+                fkind = 0;
+                foff = (unsigned)b * (unsigned)T * G4 + 4u * c4;
+            } else if (c4 < (G4 + HID) / 4) {
+                fkind = 1;
+                foff = (unsigned)b * (unsigned)T * HID + 4u * (c4 - G4 / 4);
+            } else {
+                fkind = 2;
+                foff = ((unsigned)b * (unsigned)(T + 1) + 1u) * HID + 4u * (c4 - (G4 + HID) / 4);
+            }
+        }
+    }
+    auto flush = [&](int t, const float* sb) {
+        if (fkind == 3) return;
+        const float4 v = *reinterpret_cast<const float4*>(sb + 4 * tid);
+        const unsigned o = foff + (unsigned)t * (fkind == 0 ? (unsigned)G4 : (unsigned)HID);
+        if (fkind == 0) *reinterpret_cast<float4*>(gates + o) = v;
+        else if (fkind == 1) *reinterpret_cast<float4*>(cs + o) = v;
+        else *reinterpret_cast<float4*>(hseq + o) = v;
+    };
+    // input-projection terms of this lane's two (sequence, column) pairs, one step ahead
+    const size_t gbase[2] = {((size_t)(vb[0] ? b0 + s0 : 0) * T) * G4 + col, ((size_t)(vb[1] ? b0 + s0 + 1 : 0) * T) * G4 + col};
+    float nx[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) nx[q] = gx[gbase[q]];
+    __syncthreads();
+    const float kscale = g == 2 ? 2.0f : 1.0f;     // tanh(x) = 2 sigmoid(2x) - 1 for the cell-candidate gate
+    for (int t = 0; t < Tout; ++t) {
+        const float* hcur = hbuf[t & 1];
+        float* hnxt = hbuf[(t + 1) & 1];
+        float* scur = sbuf[t & 1];
+        const float gxv[2] = {nx[0], nx[1]};
+        if (t + 1 < Tout) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) nx[q] = gx[gbase[q] + (size_t)(t + 1) * G4];
+        }
+        f32x4 acc[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = {0.0f, 0.0f, 0.0f, 0.0f};
+        const float* arow = hcur + g * F4_HS + 64 * kh;     // A_j[i] comes from lane 4j+i: row i = lane & 3 = g
+#pragma unroll
+        for (int q4 = 0; q4 < 16; ++q4) {
+            const float4 a = *reinterpret_cast<const float4*>(arow + 4 * q4);
+            acc[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(a.x, wB[4 * q4 + 0], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(a.y, wB[4 * q4 + 1], acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_4x4x1f32(a.z, wB[4 * q4 + 2], acc[2], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_f32_4x4x1f32(a.w, wB[4 * q4 + 3], acc[3], 0, 0, 0);
+        }
+        f32x4 sum;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sum[r] = (acc[0][r] + acc[1][r]) + (acc[2][r] + acc[3][r]);
+        // hand the partner's two sequences over, keep mine
+        float* pmine = part[kh];
+        const int so = 2 * (1 - kh);
+        pmine[(so + 0) * F4_PS + 64 * c + lane] = sum[so + 0];
+        pmine[(so + 1) * F4_PS + 64 * c + lane] = sum[so + 1];
+        __syncthreads();
+        const float* pother = part[1 - kh];
+        float act[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const float pre = (kh == 0 ? sum[s0 + q] + pother[(s0 + q) * F4_PS + 64 * c + lane]
+                                       : pother[(s0 + q) * F4_PS + 64 * c + lane] + sum[s0 + q]) + gxv[q];
+            const float sg = sigmoidf_(kscale * pre);
+            act[q] = g == 2 ? 2.0f * sg - 1.0f : sg;
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int qb = lane & ~3;
+            const float ig = __shfl(act[q], qb + 0), fg = __shfl(act[q], qb + 1);
+            const float gg = __shfl(act[q], qb + 2), og = __shfl(act[q], qb + 3);
+            const bool live = t < len[q];
+            const float cn = fg * cst[q] + ig * gg;
+            const float hn = og * tanhf_(cn);
+            if (live) {
+                cst[q] = cn;
+                hst[q] = hn;
+            }
+            float* sr = scur + (s0 + q) * F4_SROW;
+            sr[col] = act[q];
+            if (g == 0) {
+                hnxt[(s0 + q) * F4_HS + u] = hst[q];
+                sr[4 * HID + u] = cn;
+                sr[5 * HID + u] = live ? hn : 0.0f;   // padded outputs are zero
+            }
+        }
+        __syncthreads();
+        flush(t, scur);
+    }
+    if (g == 0) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int b = b0 + s0 + q;
+            if (b < B) {
+                hT[(size_t)b * HID + u] = hst[q];
+                cT[(size_t)b * HID + u] = cst[q];
+            }
+        }
     }
 }
 
@@ -346,16 +507,22 @@ int howl_lstm_fwd(const HowlLstmParams* p, const float* x, int B, int T, int M, 
     float* pf = static_cast<float*>(ws);
     float* pb = pf + 16 * 64 * 64;
     float* bsum = pb + 16 * 64 * 64;
-    hipLaunchKernelGGL(lstm_pack_kernel, dim3(16 * 64 * 64 / 256), dim3(256), 0, stream, p->w_hh, pf, pb);
+    float* pf4 = bsum + G4;   // the split-K scratch region is free during the forward pass
+    hipLaunchKernelGGL(lstm_pack_kernel, dim3(16 * 64 * 64 / 256), dim3(256), 0, stream, p->w_hh, pf, pb, pf4);
     // bias = b_ih + b_hh folded into the input projection: gx = x W_ih^T + bias   (B*T, 512), K = M
     hipLaunchKernelGGL(add2_kernel, dim3(G4 / 256), dim3(256), 0, stream, p->b_ih, p->b_hh, bsum, G4);
     gemm(stream, true, x, lin(M), 1, lin(0), p->w_ih, lin(1), M, B * T, G4, M, 1, bsum, 0, sv->gx, G4, 0);
     if (sv->t_out < T)   // rows of steps that never run are read (times zero) by the weight-gradient GEMM: keep them finite
         hipMemsetAsync(sv->hseq, 0, (size_t)B * (T + 1) * HID * sizeof(float), stream);
-    const size_t lds_fwd = (size_t)(2 * 16 * HS + 2 * 16 * 6 * HID) * sizeof(float);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fwd);
-    hipLaunchKernelGGL(lstm_fwd_kernel, dim3((B + 15) / 16), dim3(LSTM_THREADS), lds_fwd, stream, (const float*)sv->gx,
-                       (const float*)pf, lengths, h0, c0, sv->gates, sv->c, sv->hseq, hT, cT, B, T, sv->t_out);
+    if (getenv("HOWL_LSTM_FWD16") == nullptr) {
+        hipLaunchKernelGGL(lstm_fwd4_kernel, dim3((B + 3) / 4), dim3(LSTM_THREADS), 0, stream, (const float*)sv->gx,
+                           (const float*)pf4, lengths, h0, c0, sv->gates, sv->c, sv->hseq, hT, cT, B, T, sv->t_out);
+    } else {
+        const size_t lds_fwd = (size_t)(2 * 16 * HS + 2 * 16 * 6 * HID) * sizeof(float);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fwd);
+        hipLaunchKernelGGL(lstm_fwd_kernel, dim3((B + 15) / 16), dim3(LSTM_THREADS), lds_fwd, stream, (const float*)sv->gx,
+                           (const float*)pf, lengths, h0, c0, sv->gates, sv->c, sv->hseq, hT, cT, B, T, sv->t_out);
+    }
     HOWL_CHECK_LAUNCH("howl_lstm_fwd");
     return HOWL_OK;
 }
