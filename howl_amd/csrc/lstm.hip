@@ -46,7 +46,7 @@ __device__ __forceinline__ float tanhf_(float x) {
 // packed as [wave][frag 0..63][lane]
 // ---------------------------------------------------------------------------------------------------------
 __global__ void lstm_pack_kernel(const float* __restrict__ whh, float* __restrict__ pf, float* __restrict__ pb,
-                                 float* __restrict__ pf4) {
+                                 float* __restrict__ pf4, float* __restrict__ pb4) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= 16 * 64 * 64) return;
     const int lane = idx & 63, frag = (idx >> 6) & 63, w = idx >> 12;
@@ -56,6 +56,12 @@ __global__ void lstm_pack_kernel(const float* __restrict__ whh, float* __restric
         // W_hh[gate * 128 + 16 c + unit_local][64 kh + frag]
         const int c = w & 7, kh = w >> 3;
         pf4[idx] = whh[((lane & 3) * HID + 16 * c + (lane >> 2)) * HID + 64 * kh + frag];
+    }
+    if (pb4 != nullptr) {
+        // lstm_bwd4_kernel: wave w = (hidden-column chunk ch = w & 1, gate-column range kr = w >> 1); lane = column
+        // 64 ch + lane of dh, fragment = gate column 64 kr + frag:  W_hh[64 kr + frag][64 ch + lane]
+        const int ch = w & 1, kr = w >> 1;
+        pb4[idx] = whh[(64 * kr + frag) * HID + 64 * ch + lane];
     }
     {
         const int a = frag >> 5, kk = frag & 31;
@@ -485,6 +491,126 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_bwd_kernel(const float* __r
     }
 }
 
+// Backward recurrence with four sequences per workgroup (see lstm_fwd4_kernel): dh_{t-1}[4][128] = dG_t[4][512] . W_hh on
+// v_mfma_f32_4x4x1_16b_f32.  wave w = (hidden-column chunk ch = w & 1, gate-column range kr = w >> 1: 64 of the 512 K
+// values); four accumulator chains per wave; the eight K ranges meet in LDS and are summed in a fixed order by the thread
+// that owns the cell.  Threads 0..511 own one cell (sequence tid >> 7, unit tid & 127) each for the elementwise part.
+constexpr int B4_DGS = G4 + 4;          // dG rows in LDS (16-byte aligned rows for the float4 A-fragment reads)
+constexpr int B4_PS = HID + 4;
+__global__ __launch_bounds__(LSTM_THREADS) void lstm_bwd4_kernel(const float* __restrict__ dy, const float* __restrict__ dhT,
+                                                                 const float* __restrict__ dcT, const float* __restrict__ pb4,
+                                                                 const long long* __restrict__ lengths,
+                                                                 const float* __restrict__ gates, const float* __restrict__ cs,
+                                                                 const float* __restrict__ c0, float* __restrict__ dG, int B,
+                                                                 int T, int Tout) {
+    __shared__ __attribute__((aligned(16))) float dgt[4 * B4_DGS];   // this step's dG rows (MFMA A operand)
+    __shared__ float partd[8][4 * B4_PS];                             // the eight K ranges of dh_{t-1}
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ch = wave & 1, kr = wave >> 1;
+    const int b0 = blockIdx.x * 4;
+    float wk[64];
+#pragma unroll
+    for (int kk = 0; kk < 64; ++kk) wk[kk] = pb4[((size_t)wave * 64 + kk) * 64 + lane];
+    // elementwise part: one cell per thread (threads 512..1023 only multiply)
+    const bool cell = tid < 4 * HID;
+    const int s = (tid >> 7) & 3, u = tid & (HID - 1);
+    const int b = b0 + s;
+    const bool vb = cell && b < B;
+    const int len = vb ? (lengths != nullptr ? (int)lengths[b] : T) : 0;
+    float dc = (vb && dcT != nullptr) ? dcT[(size_t)b * HID + u] : 0.0f;     // running dL/dc_t
+    float dhp = (vb && dhT != nullptr) ? dhT[(size_t)b * HID + u] : 0.0f;    // pass-through part of dL/dh_t
+    for (int i = tid; i < 8 * 4 * B4_PS; i += LSTM_THREADS) (&partd[0][0])[i] = 0.0f;
+    struct Step {
+        float ig, fg, gg, og, cn, cp, dyv;
+    };
+    const size_t bclamp = vb ? (size_t)b : 0;
+    const float c0v = (vb && c0 != nullptr) ? c0[(size_t)b * HID + u] : 0.0f;
+    auto fetch = [&](int t, Step& st) {   // unconditional loads from clamped addresses, zeroed afterwards
+        const bool lv = vb && t >= 0 && t < len;
+        const size_t o = bclamp * T + (lv ? t : 0);
+        const size_t op = o - ((lv && t > 0) ? 1 : 0);
+        const float ig = gates[o * G4 + u], fg = gates[o * G4 + HID + u];
+        const float gg = gates[o * G4 + 2 * HID + u], og = gates[o * G4 + 3 * HID + u];
+        const float cn = cs[o * HID + u], cpv = cs[op * HID + u];
+        float dyv = 0.0f;
+        if (dy != nullptr) dyv = dy[o * HID + u];
+        st.ig = lv ? ig : 0.0f;
+        st.fg = lv ? fg : 0.0f;
+        st.gg = lv ? gg : 0.0f;
+        st.og = lv ? og : 0.0f;
+        st.cn = lv ? cn : 0.0f;
+        st.cp = lv ? (t > 0 ? cpv : c0v) : 0.0f;
+        st.dyv = lv ? dyv : 0.0f;
+    };
+    Step cur, nxt;
+    fetch(Tout - 1, cur);
+    __syncthreads();
+    for (int t = Tout - 1; t >= 0; --t) {
+        fetch(t - 1, nxt);
+        if (cell) {
+            // dL/dh_t = (recurrent term from step t+1) + (pass-through when h was frozen) + (output gradient)
+            float dh = dhp;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) dh += partd[r][s * B4_PS + u];
+            float di = 0.0f, df = 0.0f, dg = 0.0f, dov = 0.0f;
+            if (t < len) {
+                dh += cur.dyv;
+                const float tc = tanhf_(cur.cn);
+                dov = dh * tc * cur.og * (1.0f - cur.og);
+                const float dct = dc + dh * cur.og * (1.0f - tc * tc);
+                di = dct * cur.gg * cur.ig * (1.0f - cur.ig);
+                dg = dct * cur.ig * (1.0f - cur.gg * cur.gg);
+                df = dct * cur.cp * cur.fg * (1.0f - cur.fg);
+                dc = dct * cur.fg;
+                dhp = 0.0f;      // h_t was produced by the cell: everything flows through the gates
+            } else {
+                dhp = dh;        // frozen step (t >= length): h_t = h_{t-1}, c_t = c_{t-1}
+            }
+            float* dr = dgt + s * B4_DGS + u;
+            dr[0] = di;
+            dr[HID] = df;
+            dr[2 * HID] = dg;
+            dr[3 * HID] = dov;
+            if (vb) {
+                float* go = dG + ((size_t)b * T + t) * G4 + u;
+                go[0] = di;
+                go[HID] = df;
+                go[2 * HID] = dg;
+                go[3 * HID] = dov;
+            }
+        }
+        __syncthreads();
+        // dh_{t-1}[seq][64 ch + lane] (K range kr) = sum_k dG[seq][64 kr + k] * W_hh[64 kr + k][64 ch + lane]
+        f32x4 acc[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = {0.0f, 0.0f, 0.0f, 0.0f};
+        const float* arow = dgt + (lane & 3) * B4_DGS + 64 * kr;   // A_j[i] comes from lane 4j+i
+#pragma unroll
+        for (int q4 = 0; q4 < 16; ++q4) {
+            const float4 a = *reinterpret_cast<const float4*>(arow + 4 * q4);
+            acc[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(a.x, wk[4 * q4 + 0], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(a.y, wk[4 * q4 + 1], acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_4x4x1f32(a.z, wk[4 * q4 + 2], acc[2], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_f32_4x4x1f32(a.w, wk[4 * q4 + 3], acc[3], 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            partd[kr][r * B4_PS + 64 * ch + lane] = (acc[0][r] + acc[1][r]) + (acc[2][r] + acc[3][r]);
+        cur = nxt;
+        __syncthreads();
+    }
+}
+
+// Which recurrence pair runs: four sequences per workgroup (v_mfma 4x4x1_16b: 93 / 73 us per 38-step launch, one workgroup
+// per CU) while that leaves at most two rounds of workgroups, sixteen per workgroup (16x16x4: 213 / 198 us) beyond --
+// B <= 8 x CUs = 2048 on this part.  HOWL_LSTM_ROWS=4|16 forces one (tests exercise both).
+bool lstm_rows16(int B) {
+    const char* env = getenv("HOWL_LSTM_ROWS");
+    if (env != nullptr && env[0] == '1') return true;
+    if (env != nullptr && env[0] == '4') return false;
+    return B > 8 * howl_num_cus();
+}
+
 }  // namespace
 
 extern "C" {
@@ -507,14 +633,18 @@ int howl_lstm_fwd(const HowlLstmParams* p, const float* x, int B, int T, int M, 
     float* pf = static_cast<float*>(ws);
     float* pb = pf + 16 * 64 * 64;
     float* bsum = pb + 16 * 64 * 64;
-    float* pf4 = bsum + G4;   // the split-K scratch region is free during the forward pass
-    hipLaunchKernelGGL(lstm_pack_kernel, dim3(16 * 64 * 64 / 256), dim3(256), 0, stream, p->w_hh, pf, pb, pf4);
+    // fragments for both recurrence variants (the 4-row pair lives at the head of the split-K scratch region, which nothing
+    // touches between this call and the recurrence of the backward call)
+    float* pf4 = bsum + G4;
+    float* pb4 = pf4 + 16 * 64 * 64;
+    const bool rows16 = lstm_rows16(B);
+    hipLaunchKernelGGL(lstm_pack_kernel, dim3(16 * 64 * 64 / 256), dim3(256), 0, stream, p->w_hh, pf, pb, pf4, pb4);
     // bias = b_ih + b_hh folded into the input projection: gx = x W_ih^T + bias   (B*T, 512), K = M
     hipLaunchKernelGGL(add2_kernel, dim3(G4 / 256), dim3(256), 0, stream, p->b_ih, p->b_hh, bsum, G4);
     gemm(stream, true, x, lin(M), 1, lin(0), p->w_ih, lin(1), M, B * T, G4, M, 1, bsum, 0, sv->gx, G4, 0);
     if (sv->t_out < T)   // rows of steps that never run are read (times zero) by the weight-gradient GEMM: keep them finite
         hipMemsetAsync(sv->hseq, 0, (size_t)B * (T + 1) * HID * sizeof(float), stream);
-    if (getenv("HOWL_LSTM_FWD16") == nullptr) {
+    if (!rows16) {
         hipLaunchKernelGGL(lstm_fwd4_kernel, dim3((B + 3) / 4), dim3(LSTM_THREADS), 0, stream, (const float*)sv->gx,
                            (const float*)pf4, lengths, h0, c0, sv->gates, sv->c, sv->hseq, hT, cT, B, T, sv->t_out);
     } else {
@@ -540,8 +670,13 @@ int howl_lstm_bwd(const HowlLstmParams* p, const float* x, int B, int T, int M, 
     float* pb = pf + 16 * 64 * 64;
     float* scratch = pb + 16 * 64 * 64 + G4;
     const int Tout = sv->t_out;
-    hipLaunchKernelGGL(lstm_bwd_kernel, dim3((B + 15) / 16), dim3(LSTM_THREADS), 0, stream, dy, dhT, dcT, (const float*)pb,
-                       lengths, (const float*)sv->gates, (const float*)sv->c, c0, sv->dgates, B, T, Tout);
+    if (!lstm_rows16(B))
+        hipLaunchKernelGGL(lstm_bwd4_kernel, dim3((B + 3) / 4), dim3(LSTM_THREADS), 0, stream, dy, dhT, dcT,
+                           (const float*)(scratch + 16 * 64 * 64),
+                           lengths, (const float*)sv->gates, (const float*)sv->c, c0, sv->dgates, B, T, Tout);
+    else
+        hipLaunchKernelGGL(lstm_bwd_kernel, dim3((B + 15) / 16), dim3(LSTM_THREADS), 0, stream, dy, dhT, dcT, (const float*)pb,
+                           lengths, (const float*)sv->gates, (const float*)sv->c, c0, sv->dgates, B, T, Tout);
     // dW_ih = dG^T X, dW_hh = dG^T H_prev (hseq rows t = 0..t_out-1 of each utterance), db = column sums of dG.  Steps
     // t >= t_out never ran and their dG rows are never written: the reductions walk rows (b, t < t_out) only.
     const bool full = Tout == T;

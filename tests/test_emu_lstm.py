@@ -34,7 +34,9 @@ def run_lstm(lib, sd, x_btm, lengths, h0=None, c0=None):
     return bufs["hseq"][:, 1:t_out + 1].copy(), hT, cT, keep
 
 
-def test_lstm_forward_backward_ragged(lib, golden):
+@pytest.mark.parametrize("rows", ["4", "16"])
+def test_lstm_forward_backward_ragged(lib, golden, monkeypatch, rows):
+    monkeypatch.setenv("HOWL_LSTM_ROWS", rows)     # both recurrence pairs: 4x4x1_16b (4 sequences / workgroup) and 16x16x4
     g = golden("g6_seq_lstm")
     g2, g4 = golden("g2_frontend_gsc"), golden("g4_zmuv")
     lengths = g["frame_lengths"].astype(np.int64)          # descending, ragged: [78, 78, 78, 78, 69, 62]

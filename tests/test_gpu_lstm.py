@@ -18,8 +18,10 @@ def make(name, C):
     return m.to(DEV)
 
 
+@pytest.mark.parametrize("rows", ["4", "16"])
 @pytest.mark.parametrize("name", ["lstm", "seq-lstm"])
-def test_golden_forward_backward_streaming(golden, name):
+def test_golden_forward_backward_streaming(golden, name, rows, monkeypatch):
+    monkeypatch.setenv("HOWL_LSTM_ROWS", rows)        # both recurrence pairs (4 / 16 sequences per workgroup)
     g = golden("g6_" + name.replace("-", "_"))
     x, _ = golden_features(golden)
     xd = x.to(DEV)
@@ -71,7 +73,10 @@ def test_config4_seq_lstm_ctc_step_vs_oracle():
     z.update(ofe.standard_audio_transform(pcm[:4], fb))
     x_ref = z(ofe.standard_audio_transform(pcm, fb))
     targets = torch.tensor([[0, 1, 2]] * B)
-    for lengths in (torch.full((B,), 38), torch.sort(20 + torch.arange(B) % 19, descending=True).values):
+    import os
+    for lengths, rows in ((torch.full((B,), 38), "4"), (torch.sort(20 + torch.arange(B) % 19, descending=True).values, "4"),
+                          (torch.sort(20 + torch.arange(B) % 19, descending=True).values, "16")):
+        os.environ["HOWL_LSTM_ROWS"] = rows
         model = make("seq-lstm", C).train()
         sc = model(feats, lengths)
         from howl_amd import ops
@@ -87,6 +92,7 @@ def test_config4_seq_lstm_ctc_step_vs_oracle():
         for n, p in model.named_parameters():
             r = sd[n].grad
             assert maxerr(p.grad, r) < 1e-4 * max(1.0, r.abs().max().item()), n
+    os.environ.pop("HOWL_LSTM_ROWS", None)
 
 
 @pytest.mark.parametrize("T,B,C,Lmax,seed", [(38, 64, 5, 3, 0), (81, 33, 12, 8, 1), (128, 16, 64, 31, 2), (9, 5, 3, 2, 3)])
