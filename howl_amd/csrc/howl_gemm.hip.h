@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const float* __restrict__ a, 
 // thread and tile, and the next K tile is requested before the MFMAs of the current one (register double buffering).
 //   A_UNIT_K: A(m,k) = a[amap(m) + k]   else a[amap(k) + m]      (amap / bmap: two-level row maps, strides multiples of 4)
 //   B_UNIT_K: B(k,n) = b[bmap(n) + k]   else b[bmap(k) + n]
-template <bool A_UNIT_K, bool B_UNIT_K>
+template <bool A_UNIT_K, bool B_UNIT_K, bool KMAP_LIN>
 __global__ __launch_bounds__(256) void gemm_vec_kernel(const float* __restrict__ a, RowMap amap, const float* __restrict__ b,
                                                        RowMap bmap, int M, int N, int K, int k_per_split,
                                                        const float* __restrict__ bias, int relu, float* __restrict__ c,
@@ -140,23 +140,38 @@ __global__ __launch_bounds__(256) void gemm_vec_kernel(const float* __restrict__
     // this thread's 4-float piece of each operand tile: unit-k -> (row = tid/4, k4 = tid%4); unit-row -> (k = tid/16, r4 = tid%16)
     const int a_r = A_UNIT_K ? tid >> 2 : (tid & 15) * 4, a_k = A_UNIT_K ? (tid & 3) * 4 : tid >> 4;
     const int b_r = B_UNIT_K ? tid >> 2 : (tid & 15) * 4, b_k = B_UNIT_K ? (tid & 3) * 4 : tid >> 4;
+    // operand pieces are loaded unconditionally from clamped coordinates and zeroed when they are staged (ok_a / ok_b): a
+    // guarded load would make the compiler wait for every outstanding load (vmcnt(0)) instead of only the oldest tile.
+    // Row maps indexed by this thread's fixed row are evaluated once; maps indexed by k are a plain multiply when
+    // KMAP_LIN (compile time: a run-time choice inside the loads had the same effect as a guard).
+    auto kmap = [&](const RowMap& r, int k) -> long {
+        if (KMAP_LIN) return (long)k * r.s_inner;
+        return (long)(k / r.inner) * r.s_outer + (long)(k % r.inner) * r.s_inner;
+    };
+    const long a_fix = A_UNIT_K ? rmap(amap, min(m0 + a_r, M - 1)) : (long)min(m0 + a_r, M - 4);
+    const long b_fix = B_UNIT_K ? rmap(bmap, min(n0 + b_r, N - 1)) : (long)min(n0 + b_r, N - 4);
     auto fetch_a = [&](int k0) -> float4 {
-        const int m = m0 + a_r, k = k0 + a_k;
-        if (m < M && k < kend) return *reinterpret_cast<const float4*>(A_UNIT_K ? a + rmap(amap, m) + k : a + rmap(amap, k) + m);
-        return make_float4(0.f, 0.f, 0.f, 0.f);
+        const int k = min(k0 + a_k, A_UNIT_K ? kend - 4 : kend - 1);
+        return *reinterpret_cast<const float4*>(A_UNIT_K ? a + a_fix + k : a + kmap(amap, k) + a_fix);
     };
     auto fetch_b = [&](int k0) -> float4 {
-        const int n = n0 + b_r, k = k0 + b_k;
-        if (n < N && k < kend) return *reinterpret_cast<const float4*>(B_UNIT_K ? b + rmap(bmap, n) + k : b + rmap(bmap, k) + n);
-        return make_float4(0.f, 0.f, 0.f, 0.f);
+        const int k = min(k0 + b_k, B_UNIT_K ? kend - 4 : kend - 1);
+        return *reinterpret_cast<const float4*>(B_UNIT_K ? b + b_fix + k : b + kmap(bmap, k) + b_fix);
     };
+    auto ok_a = [&](int k0) { return m0 + a_r < M && k0 + a_k < kend; };
+    auto ok_b = [&](int k0) { return n0 + b_r < N && k0 + b_k < kend; };
     f32x4 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = {0.0f, 0.0f, 0.0f, 0.0f};
-    float4 va = fetch_a(kbeg), vb = fetch_b(kbeg);
-    for (int k0 = kbeg; k0 < kend; k0 += GK) {
+    // Two K tiles in flight: tile k0 sits in one register pair while tiles k0+16 AND k0+32 are on their way (the loop is
+    // unrolled by two so that the pairs swap roles without copies).  With one tile in flight a block paid one full
+    // memory latency per 16-deep K step -- the long split-K weight-gradient GEMMs run one or two blocks per CU, so
+    // nothing else hid it.
+    auto stage = [&](float4 va, float4 vb, int k0) {
+        if (!ok_a(k0)) va = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!ok_b(k0)) vb = make_float4(0.f, 0.f, 0.f, 0.f);
         if (A_UNIT_K) {
             As[(a_k + 0) * GLD + a_r] = va.x;
             As[(a_k + 1) * GLD + a_r] = va.y;
@@ -173,11 +188,8 @@ __global__ __launch_bounds__(256) void gemm_vec_kernel(const float* __restrict__
         } else {
             *reinterpret_cast<float4*>(&Bs[b_k * GLD + b_r]) = vb;
         }
-        __syncthreads();
-        if (k0 + GK < kend) {
-            va = fetch_a(k0 + GK);
-            vb = fetch_b(k0 + GK);
-        }
+    };
+    auto multiply = [&]() {
 #pragma unroll
         for (int ks = 0; ks < GK / 4; ++ks) {
             const int kr = 4 * ks + (lane >> 4);
@@ -191,6 +203,24 @@ __global__ __launch_bounds__(256) void gemm_vec_kernel(const float* __restrict__
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
+    };
+    float4 va0 = fetch_a(kbeg), vb0 = fetch_b(kbeg);
+    float4 va1 = fetch_a(kbeg + GK), vb1 = fetch_b(kbeg + GK);   // past the end: a clamped (re)load that is never staged
+    for (int k0 = kbeg; k0 < kend; k0 += 2 * GK) {
+        stage(va0, vb0, k0);
+        __syncthreads();
+        va0 = fetch_a(k0 + 2 * GK);
+        vb0 = fetch_b(k0 + 2 * GK);
+        __builtin_amdgcn_sched_barrier(0);   // keep the requests in front of the MFMAs (the scheduler sinks them otherwise)
+        multiply();
+        __syncthreads();
+        if (k0 + GK >= kend) break;
+        stage(va1, vb1, k0 + GK);
+        __syncthreads();
+        va1 = fetch_a(k0 + 3 * GK);
+        vb1 = fetch_b(k0 + 3 * GK);
+        __builtin_amdgcn_sched_barrier(0);
+        multiply();
         __syncthreads();
     }
     float* cz = c + (long)blockIdx.z * c_split_stride;
@@ -312,9 +342,17 @@ int gemm(hipStream_t s, bool a_major_k, const float* a, RowMap am, long a_ks, Ro
         if (a_fits && b_fits) {
             const RowMap amap = a_major_k ? am : ak;
             const RowMap bmap = b_unit_k ? lin(b_ns) : bk;
-#define HOWL_GEMM_VEC(AK, BK)                                                                                              \
-    hipLaunchKernelGGL((gemm_vec_kernel<AK, BK>), grid, dim3(256), 0, s, a, amap, b, bmap, M, N, K, kps, bias, relu, c, c_ms, \
-                       c_split_stride)
+            // the maps that are indexed by k inside the kernel (the other ones are evaluated once per thread)
+            const bool klin = (a_major_k || is_lin(amap)) && (b_unit_k || is_lin(bmap));
+#define HOWL_GEMM_VEC(AK, BK)                                                                                                  \
+    do {                                                                                                                       \
+        if (klin)                                                                                                              \
+            hipLaunchKernelGGL((gemm_vec_kernel<AK, BK, true>), grid, dim3(256), 0, s, a, amap, b, bmap, M, N, K, kps, bias,   \
+                               relu, c, c_ms, c_split_stride);                                                                 \
+        else                                                                                                                   \
+            hipLaunchKernelGGL((gemm_vec_kernel<AK, BK, false>), grid, dim3(256), 0, s, a, amap, b, bmap, M, N, K, kps, bias,  \
+                               relu, c, c_ms, c_split_stride);                                                                 \
+    } while (0)
             if (a_major_k && b_unit_k) HOWL_GEMM_VEC(true, true);
             else if (a_major_k) HOWL_GEMM_VEC(true, false);
             else if (b_unit_k) HOWL_GEMM_VEC(false, true);
