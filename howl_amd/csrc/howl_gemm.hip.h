@@ -427,8 +427,8 @@ __global__ __launch_bounds__(256) void thin_wgrad_kernel(const float* __restrict
 // dW (N_out, K_in) = dOut^T (N_out x rows) . In (rows x K_in), rows given by row maps; split-K + deterministic sum
 // (scratch: splits x N_out x K_in floats, splits = clamp(rows / 512, 1, max_splits))
 void wgrad_gemm(hipStream_t s, const float* dout, RowMap dm, int n_out, const float* in, RowMap im, int k_in, int rows,
-                float* scratch, float* dw, int max_splits = 64) {
-    int splits = rows / 512;
+                float* scratch, float* dw, int max_splits = 64, int rows_per_split = 512) {
+    int splits = rows / rows_per_split;
     splits = splits < 1 ? 1 : (splits > max_splits ? max_splits : splits);
     if (n_out <= 8 && ((n_out & 3) != 0 || (k_in & 3) != 0)) {   // thin output that the vector GEMM cannot take
         int kp = 64;

@@ -23,6 +23,7 @@ namespace {
 constexpr int HID = 128;
 constexpr int G4 = 4 * HID;          // 512 gate columns, PyTorch order i, f, g, o
 constexpr int LSTM_THREADS = 1024;   // 16 waves
+constexpr int LSTM_WGRAD_SPLITS = 128;
 constexpr int HS = HID + 4;          // LDS row stride of the h tile (16 rows)
 constexpr int DGS = G4 + 4;          // LDS row stride of the dG tile
 
@@ -616,8 +617,8 @@ bool lstm_rows16(int B) {
 extern "C" {
 
 size_t howl_lstm_workspace_bytes(int B, int T) {
-    // packed W_hh (2 x 64K floats) + bias sum (512) + split-K scratch (64 x 512 x 128)
-    return ((size_t)2 * 16 * 64 * 64 + G4 + (size_t)64 * G4 * HID) * sizeof(float) + 1024;
+    // packed W_hh (2 x 64K floats) + bias sum (512) + split-K scratch (128 x 512 x 128; its head also holds the 4-row fragments)
+    return ((size_t)2 * 16 * 64 * 64 + G4 + (size_t)LSTM_WGRAD_SPLITS * G4 * HID) * sizeof(float) + 1024;
 }
 
 int howl_lstm_fwd(const HowlLstmParams* p, const float* x, int B, int T, int M, const long long* lengths, const float* h0,
@@ -683,8 +684,10 @@ int howl_lstm_bwd(const HowlLstmParams* p, const float* x, int B, int T, int M, 
     const RowMap rows_g = full ? lin(G4) : RowMap{Tout, (long)T * G4, G4};
     const RowMap rows_x = full ? lin(M) : RowMap{Tout, (long)T * M, M};
     const int rows = B * Tout;
-    wgrad_gemm(stream, sv->dgates, rows_g, G4, x, rows_x, M, rows, scratch, g->w_ih);
-    wgrad_gemm(stream, sv->dgates, rows_g, G4, sv->hseq, RowMap{Tout, (long)(T + 1) * HID, HID}, HID, rows, scratch, g->w_hh);
+    // 256 rows per K slice (up to 128 slices): the 512-row slices of the generic rule leave ~1 block per CU on these shapes
+    wgrad_gemm(stream, sv->dgates, rows_g, G4, x, rows_x, M, rows, scratch, g->w_ih, LSTM_WGRAD_SPLITS, 256);
+    wgrad_gemm(stream, sv->dgates, rows_g, G4, sv->hseq, RowMap{Tout, (long)(T + 1) * HID, HID}, HID, rows, scratch, g->w_hh,
+               LSTM_WGRAD_SPLITS, 256);
     colsum(stream, sv->dgates, rows_g, rows, G4, scratch, g->b_ih, g->b_hh);
     HOWL_CHECK_LAUNCH("howl_lstm_bwd");
     return HOWL_OK;
