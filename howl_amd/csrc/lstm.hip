@@ -693,7 +693,13 @@ int howl_lstm_bwd(const HowlLstmParams* p, const float* x, int B, int T, int M, 
     return HOWL_OK;
 }
 
-size_t howl_linear_workspace_bytes(int n_out, int n_in) { return (size_t)64 * n_out * (n_in > 1 ? n_in : 1) * sizeof(float) + 256; }
+// split-K slabs of the weight gradient: 64 for wide outputs; thin outputs (<= 8 columns: the 128-row slices that fill the chip
+// cost almost nothing in slab traffic) up to 512
+constexpr int LIN_THIN_SPLITS = 512;
+size_t howl_linear_workspace_bytes(int n_out, int n_in) {
+    const size_t slabs = n_out <= 8 ? LIN_THIN_SPLITS : 64;
+    return slabs * n_out * (n_in > 1 ? n_in : 1) * sizeof(float) + 256;
+}
 
 // y = x W^T + b (ReLU optional);  x rows: rows_outer x rows_inner with strides (elements), unit stride along features
 int howl_linear_fwd(const float* x, int rows_inner, long s_outer, long s_inner, int rows, int n_in, const float* w,
@@ -717,8 +723,12 @@ int howl_linear_bwd(const float* x, int rows_inner, long s_outer, long s_inner, 
     }
     if (dx != nullptr)   // dx = dy W : A = dy [m][k = n_out], B(k, n) = w[k * n_in + n]
         gemm(stream, true, dy, lin(n_out), 1, lin(0), w, lin(n_in), 1, rows, n_in, n_out, 1, nullptr, 0, dx, n_in, 0);
-    wgrad_gemm(stream, dy, lin(n_out), n_out, x, RowMap{rows_inner, s_outer, s_inner}, n_in, rows, static_cast<float*>(ws),
-               dw);
+    if (n_out <= 8)   // 152 blocks of 512 rows each left most CUs idle on the (5 x 256) head: 128-row slices instead
+        wgrad_gemm(stream, dy, lin(n_out), n_out, x, RowMap{rows_inner, s_outer, s_inner}, n_in, rows, static_cast<float*>(ws),
+                   dw, LIN_THIN_SPLITS, 128);
+    else
+        wgrad_gemm(stream, dy, lin(n_out), n_out, x, RowMap{rows_inner, s_outer, s_inner}, n_in, rows, static_cast<float*>(ws),
+                   dw);
     colsum(stream, dy, lin(n_out), rows, n_out, static_cast<float*>(ws), db, nullptr);
     HOWL_CHECK_LAUNCH("howl_linear_bwd");
     return HOWL_OK;
