@@ -457,9 +457,10 @@ void wgrad_gemm(hipStream_t s, const float* dout, RowMap dm, int n_out, const fl
 }
 
 // out0 (and out1) = column sums of x over `rows` mapped rows; scratch holds <= 64 * n floats
-void colsum(hipStream_t s, const float* x, RowMap rm, int rows, int n, float* scratch, float* out0, float* out1) {
-    int chunks = rows / 256;
-    chunks = chunks < 1 ? 1 : (chunks > 64 ? 64 : chunks);   // scratch holds <= 64 slabs
+void colsum(hipStream_t s, const float* x, RowMap rm, int rows, int n, float* scratch, float* out0, float* out1,
+            int max_chunks = 64, int rows_per_chunk = 256) {
+    int chunks = rows / rows_per_chunk;
+    chunks = chunks < 1 ? 1 : (chunks > max_chunks ? max_chunks : chunks);   // scratch holds <= max_chunks slabs of n floats
     const int rpc = (rows + chunks - 1) / chunks;
     hipLaunchKernelGGL(colsum_kernel, dim3((n + 63) / 64, chunks), dim3(256), 0, s, x, rm, rows, n, rpc, scratch);
     hipLaunchKernelGGL(sum_slabs_kernel, dim3((n + 63) / 64), dim3(256), 0, s, (const float*)scratch, chunks, (long)n, out0);

@@ -688,7 +688,7 @@ int howl_lstm_bwd(const HowlLstmParams* p, const float* x, int B, int T, int M, 
     wgrad_gemm(stream, sv->dgates, rows_g, G4, x, rows_x, M, rows, scratch, g->w_ih, LSTM_WGRAD_SPLITS, 256);
     wgrad_gemm(stream, sv->dgates, rows_g, G4, sv->hseq, RowMap{Tout, (long)(T + 1) * HID, HID}, HID, rows, scratch, g->w_hh,
                LSTM_WGRAD_SPLITS, 256);
-    colsum(stream, sv->dgates, rows_g, rows, G4, scratch, g->b_ih, g->b_hh);
+    colsum(stream, sv->dgates, rows_g, rows, G4, scratch, g->b_ih, g->b_hh, 256, 64);
     HOWL_CHECK_LAUNCH("howl_lstm_bwd");
     return HOWL_OK;
 }
@@ -729,7 +729,8 @@ int howl_linear_bwd(const float* x, int rows_inner, long s_outer, long s_inner, 
     else
         wgrad_gemm(stream, dy, lin(n_out), n_out, x, RowMap{rows_inner, s_outer, s_inner}, n_in, rows, static_cast<float*>(ws),
                    dw);
-    colsum(stream, dy, lin(n_out), rows, n_out, static_cast<float*>(ws), db, nullptr);
+    // the workspace holds 64 * n_out * n_in (512 * ... for thin outputs) floats: room for 256 slabs of n_out whenever n_in >= 4
+    colsum(stream, dy, lin(n_out), rows, n_out, static_cast<float*>(ws), db, nullptr, n_in >= 4 ? 256 : 64, 64);
     HOWL_CHECK_LAUNCH("howl_linear_bwd");
     return HOWL_OK;
 }
