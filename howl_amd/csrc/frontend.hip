@@ -433,9 +433,54 @@ __global__ __launch_bounds__(256) void collate_augment_kernel(const float* __res
     }
 }
 
+// Frame-window gather (batchifier.py:56-118 + operator.py:89-109): row b of the (B, Lout) batch is zeros except for
+// out[b, dst_off[b] + n] = bank[idx[b]][start[b] + n], n < len[b] -- the window cut of WakeWordFrameBatchifier followed by
+// tensorize_audio_data's zero padding on either side (rand_append).  float4 stores; the source offset is arbitrary so
+// the loads stay scalar (L2-served: a window is re-read by no one).
+__global__ __launch_bounds__(256) void gather_windows_kernel(const float* __restrict__ bank, long bank_ld,
+                                                             const int* __restrict__ idx, const int* __restrict__ start,
+                                                             const int* __restrict__ len, const int* __restrict__ dst_off,
+                                                             float* __restrict__ out, int Lout) {
+    const int b = blockIdx.y;
+    const int n0 = dst_off[b], n1 = n0 + len[b];
+    const float* src = bank + (long)idx[b] * bank_ld + start[b] - n0;
+    float* dst = out + (long)b * Lout;
+    const int L4 = Lout & ~3;
+    for (int n = (blockIdx.x * blockDim.x + threadIdx.x) * 4; n < L4; n += gridDim.x * blockDim.x * 4) {
+        float4 v;
+        v.x = (n >= n0 && n < n1) ? src[n] : 0.0f;
+        v.y = (n + 1 >= n0 && n + 1 < n1) ? src[n + 1] : 0.0f;
+        v.z = (n + 2 >= n0 && n + 2 < n1) ? src[n + 2] : 0.0f;
+        v.w = (n + 3 >= n0 && n + 3 < n1) ? src[n + 3] : 0.0f;
+        if ((((long)b * Lout) & 3) == 0) {
+            *reinterpret_cast<float4*>(dst + n) = v;
+        } else {
+            dst[n] = v.x; dst[n + 1] = v.y; dst[n + 2] = v.z; dst[n + 3] = v.w;
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x < Lout - L4) {
+        const int n = L4 + threadIdx.x;
+        dst[n] = (n >= n0 && n < n1) ? src[n] : 0.0f;
+    }
+}
+
 }  // namespace
 
 extern "C" {
+
+int howl_gather_windows(const float* bank, long bank_ld, const int* idx, const int* start, const int* len,
+                        const int* dst_off, int B, int Lout, float* out, hipStream_t stream) {
+    HOWL_REQUIRE(bank && idx && start && len && dst_off && out, "howl_gather_windows: null pointer");
+    HOWL_REQUIRE(B >= 1 && Lout >= 1, "howl_gather_windows: bad shape");
+    HOWL_REQUIRE((reinterpret_cast<uintptr_t>(out) & 15) == 0, "howl_gather_windows: out must be 16-byte aligned");
+    int gx = (Lout / 4 + 255) / 256;
+    if (gx < 1) gx = 1;
+    if (gx > 16) gx = 16;
+    hipLaunchKernelGGL(gather_windows_kernel, dim3(gx, B), dim3(256), 0, stream, bank, bank_ld, idx, start, len, dst_off, out,
+                       Lout);
+    HOWL_CHECK_LAUNCH("howl_gather_windows");
+    return HOWL_OK;
+}
 
 int howl_collate_augment_mix(const float* bank, long bank_ld, const int* idx, const int* src_len, const int* shift,
                              const int* from_head, const float* sigma, const float* sp_prob, unsigned long long seed,

@@ -40,30 +40,39 @@ class VocabTrie:
 
 
 class Vocab:
+    """Word <-> label-id table behind ``InferenceContext`` (interface of ``howl/data/common/vocab.py:64-102``:
+    ``len()``, ``vocab[word]`` / ``vocab[idx]``, ``.trie``, ``.oov_token_id``, ``.wakeword()``).
+
+    Lookups are case-insensitive on the word side.  An unknown word maps to ``oov_token_id`` (``ValueError`` when no
+    OOV id was configured); an unknown id renders as ``oov_word_repr``."""
+
     def __init__(self, word2idx: Union[Mapping[str, int], List[str]], oov_token_id: int = None,
                  oov_word_repr: str = "[OOV]"):
-        if isinstance(word2idx, list):
-            word2idx = {word: idx for idx, word in enumerate(word2idx)}
-        self.word2idx = {k.lower(): v for k, v in word2idx.items()}
-        self.idx2word = {v: k for k, v in word2idx.items()}
-        self.oov_token_id = oov_token_id
-        self.oov_word_repr = oov_word_repr
-        self.trie = VocabTrie()
-        for word in self.word2idx:
-            self.trie.add_word(word.lower())
+        pairs = list(word2idx.items()) if isinstance(word2idx, Mapping) else [(w, i) for i, w in enumerate(word2idx)]
+        self.oov_token_id, self.oov_word_repr = oov_token_id, oov_word_repr
+        self.word2idx, self.idx2word, self.trie = {}, {}, VocabTrie()
+        for word, idx in pairs:
+            self.word2idx[word.lower()] = idx
+            self.idx2word[idx] = word            # ids render with the caller's spelling
+            self.trie.add_word(word)
 
     def __len__(self):
         return len(self.word2idx)
 
-    def __getitem__(self, item: Union[str, int]) -> Union[str, int]:
-        ret = self.word2idx.get(item.lower(), self.oov_token_id) if isinstance(item, str) else \
-            self.idx2word.get(item, self.oov_word_repr)
-        if ret is None:
-            raise ValueError(f"couldn't find token for {item}")
-        return ret
+    def id_of(self, word: str) -> int:
+        idx = self.word2idx.get(word.lower(), self.oov_token_id)
+        if idx is None:
+            raise ValueError(f"couldn't find token for {word}")
+        return idx
 
-    def wakeword(self, sequence: List[int], separator: str = " "):
-        return separator.join([self[i] for i in sequence])
+    def word_of(self, idx: int) -> str:
+        return self.idx2word.get(idx, self.oov_word_repr)
+
+    def __getitem__(self, item: Union[str, int]) -> Union[str, int]:
+        return self.id_of(item) if isinstance(item, str) else self.word_of(item)
+
+    def wakeword(self, sequence: List[int], separator: str = " ") -> str:
+        return separator.join(self.word_of(i) for i in sequence)
 
     def __repr__(self):
-        return str(self.idx2word)
+        return repr(self.idx2word)

@@ -130,6 +130,11 @@ class Res8(RegisteredModel, name="res8"):
         x0 = x[:, 0]
         if not x0.is_cuda or x0.dtype != torch.float32:
             raise _lib.HowlHipError("Res8 input must be an fp32 tensor on a HIP device (no CPU fallback)")
+        if x0.shape[1] != 40:
+            raise ValueError(f"Res8 on MI355X is built for NUM_MELS=40 (envs/res8.env; pooling (3,4) over 40 mel bins); got "
+                             f"{x0.shape[1]} mel bins -- set NUM_MELS=40 before howl_amd.settings is imported")
+        if x0.shape[2] < 3:
+            raise ValueError(f"Res8 needs at least 3 frames (one pooled row); got T={x0.shape[2]}")
         return x0, x0.stride(0), x0.stride(2), x0.stride(1)
 
     # ---- launches ----------------------------------------------------------------------------------------------

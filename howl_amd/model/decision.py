@@ -37,7 +37,7 @@ class ProbabilitySmoother:
         envelope = np.max(np.vstack([p for _, p in self.frames]), axis=0)   # per-class maximum over the window
         label = int(envelope.argmax())
         confident = envelope[label] >= self.threshold
-        if self.color_map:
+        if self.color_map is not None:      # a colouring is configured (even an empty map recolours every label)
             label = self.color_map.get(label, self.negative_label)
         return label if confident else self.negative_label
 

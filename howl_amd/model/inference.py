@@ -97,7 +97,9 @@ class InferenceEngine:
         return label
 
     def _weighted(self, prediction: np.ndarray) -> np.ndarray:
-        prediction = prediction * self.inference_weights
+        # the reference multiplies in place (inference.py:200,263): the product is rounded back to the probabilities' own
+        # dtype (fp32) before the renormalisation, which matters for comparisons right at the threshold
+        prediction = (prediction * self.inference_weights).astype(prediction.dtype, copy=False)
         return prediction / prediction.sum()
 
     @torch.no_grad()

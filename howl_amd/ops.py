@@ -107,6 +107,15 @@ def collate_augment(bank, idx, src_len, shift, from_head, sigma, sp_prob, seed, 
     return out
 
 
+def gather_windows(bank, idx, start, length, dst_off, lout):
+    """Rows ``bank[idx[b], start[b]:start[b]+length[b]]`` placed at column ``dst_off[b]`` of a zero (B, lout) batch."""
+    B = idx.numel()
+    out = torch.empty((B, lout), dtype=torch.float32, device=bank.device)
+    _lib.get().call("howl_gather_windows", _p(bank), bank.stride(0), _p(idx, torch.int32), _p(start, torch.int32),
+                    _p(length, torch.int32), _p(dst_off, torch.int32), B, lout, _p(out), _stream())
+    return out
+
+
 def specaug_mask(x, f0, f, t0, t):
     B, C, M, T = x.shape
     if not x.is_cuda or x.dtype != torch.float32:

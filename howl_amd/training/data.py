@@ -61,7 +61,7 @@ class ClipBank:
         order = torch.argsort(lengths, descending=True, stable=True)
         idx = idx[order]
         lengths = lengths[order]
-        lmax = int(self.max_len)   # a fixed width keeps shapes static (padding is zero either way)
+        lmax = int(lengths[0])     # the batch maximum, as batchify pads (res8's time-mean sees no extra pad frames)
         return ClassificationBatch(self.audio[idx, :lmax], self.labels[idx], lengths)
 
     def index_batches(self, batch_size: int, shuffle: bool, drop_last: bool, generator=None):

@@ -98,6 +98,14 @@ int howl_collate_augment_mix(const float* bank, long bank_ld, const int* idx, co
                              const float* bg, long bg_ld, const int* bg_idx, const int* bg_off, const float* alpha, int B,
                              int Lout, float* out, hipStream_t stream);
 
+/* Frame-window gather: out (B, Lout) row b = zeros except out[b][dst_off[b] + n] = bank[idx[b]][start[b] + n], n < len[b].
+ * Replaces, for device-resident clips, the window cut of WakeWordFrameBatchifier.__call__ (batchifier.py:56-118:
+ * `ex.audio_data[..., a:b]`) and the zero padding of tensorize_audio_data(rand_append=True, max_length=window)
+ * (operator.py:89-109: zeros before or after the samples); which window, and which side, are host draws in the
+ * reference's order (howl_amd/data/transform/batchifier.py).  Requires dst_off[b] + len[b] <= Lout. */
+int howl_gather_windows(const float* bank, long bank_ld, const int* idx, const int* start, const int* len,
+                        const int* dst_off, int B, int Lout, float* out, hipStream_t stream);
+
 /* SpecAugment masks with host-drawn parameters (per sample; width <= 0 = no mask): transform.py:309-327.
  * x is a (B,C,M,T) view with element strides (sb,sc,sm,st), masked in place. */
 int howl_specaug_mask(float* x, int B, int C, int M, int T, long sb, long sc, long sm, long st, const int* f0,

@@ -329,9 +329,59 @@ def mixer_golden():
     save("g9_mixer", wf_lens=np.array(wf_lens), bg_lens=np.array(bg_lens), **out)
 
 
+FRAME_CLIP_LENS = [30000, 5000, 40000, 16000, 9000, 24000, 32000, 8000, 12000, 20000]
+FRAME_LABEL_MAPS = [{450.0: 0, 900.0: 1, 1400.0: 2}, {}, {}, {300.0: 1}, {120.5: 0, 480.0: 2}, {1450.0: 2, 700.0: 0},
+                    {1999.0: 1}, {}, {10.0: 0}, {600.0: 3, 1100.0: 0}]
+
+
+def frame_clip(i, L):
+    """Ramp with a per-clip base: a sample's value names (clip, offset)."""
+    return torch.arange(L, dtype=torch.float32) * 1e-6 + 0.05 * (i + 1)
+
+
+def frame_batchifier_golden():
+    """G10: WakeWordFrameBatchifier (batchifier.py:37-118) + tensorize_audio_data(rand_append) (operator.py:89-109), outputs
+    of the reference class itself under a seeded ``random`` stream; ramp clips make clip / offset / padding side readable."""
+    from types import SimpleNamespace
+    from howl.data.transform.batchifier import WakeWordFrameBatchifier
+
+    class Ex:
+        def __init__(self, audio, tl):
+            self.audio_data, self.label_data = audio, SimpleNamespace(timestamp_label_map=tl)
+
+        def update_audio_data(self, audio, **kw):
+            return Ex(audio, self.label_data)
+
+    out = {"clip_lens": np.array(FRAME_CLIP_LENS),          # the label maps in CSR form (insertion order kept)
+           "map_ptr": np.cumsum([0] + [len(m) for m in FRAME_LABEL_MAPS]),
+           "map_end_ms": np.array([k for m in FRAME_LABEL_MAPS for k in m], np.float64),
+           "map_label": np.array([v for m in FRAME_LABEL_MAPS for v in m.values()], np.int64)}
+    variants = [dict(), dict(), dict(positive_sample_prob=0.8, window_size_ms=1000), dict(pad_to_window=False, window_size_ms=250)]
+    for trial, (seed, kw) in enumerate(zip((0, 7, 21, 3), variants)):
+        random.seed(seed)
+        fb = WakeWordFrameBatchifier(4, **kw)
+        batch = fb([Ex(frame_clip(i, L), dict(tl)) for i, (L, tl) in enumerate(zip(FRAME_CLIP_LENS, FRAME_LABEL_MAPS))])
+        a = batch.audio_data.numpy()
+        nz = a != 0
+        out[f"labels_{trial}"] = batch.labels.numpy()
+        out[f"lengths_{trial}"] = batch.lengths.numpy()
+        out[f"width_{trial}"] = np.array(a.shape[1])
+        out[f"nz_start_{trial}"] = np.array([int(r.argmax()) if r.any() else -1 for r in nz])
+        out[f"nz_count_{trial}"] = nz.sum(1)
+        out[f"first_{trial}"] = np.array([r[m][0] if m.any() else 0.0 for r, m in zip(a, nz)], np.float32)
+        out[f"last_{trial}"] = np.array([r[m][-1] if m.any() else 0.0 for r, m in zip(a, nz)], np.float32)
+        out[f"every53_{trial}"] = a[:, ::53]
+        out[f"next_draw_{trial}"] = np.array(random.random())
+    save("g10_frame_batchifier", **out)
+
+
 if __name__ == "__main__":
-    if "--only-collate" not in sys.argv and "--only-mixer" not in sys.argv:
+    only = [a for a in sys.argv[1:] if a.startswith("--only-")]
+    if not only:
         main()
-    if "--only-mixer" not in sys.argv:
+    if not only or "--only-collate" in only:
         collate_protocol_golden()
-    mixer_golden()
+    if not only or "--only-mixer" in only:
+        mixer_golden()
+    if not only or "--only-frame-batchifier" in only:
+        frame_batchifier_golden()

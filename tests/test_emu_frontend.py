@@ -168,3 +168,45 @@ def test_collate_augment_mix(lib):
     assert np.array_equal(out[1, :2500], bank[3, :2500]) and not out[1, 2500:].any()   # alpha 0: untouched
     np.testing.assert_allclose(out[2, :1300], bg[1, 2999:4299], rtol=0, atol=1e-7)     # alpha 1: replaced, tail crop
     assert not out[2, 1300:].any()
+
+
+def test_frame_batchifier_vs_golden(lib, golden):
+    """a12/f1: the product's WakeWordFrameBatchifier host decisions (same `random` stream as the reference class) + the
+    howl_gather_windows kernel (emulated) reproduce the reference's batches of golden G10 bit for bit."""
+    import random
+    from howl_amd.data.transform.batchifier import DeviceClip, WakeWordFrameBatchifier
+    from test_oracle_golden import G10_VARIANTS, g10_check, g10_inputs
+    g = golden("g10_frame_batchifier")
+    clips, maps = g10_inputs(g)
+    lmax = max(c.numel() for c in clips)
+    bank = np.zeros((len(clips), lmax), np.float32)
+    for i, c in enumerate(clips):
+        bank[i, : c.numel()] = c.numpy()
+    examples = [DeviceClip(i, c.numel(), m) for i, (c, m) in enumerate(zip(clips, maps))]
+    for trial, (seed, kw) in enumerate(G10_VARIANTS):
+        rand = random.Random(seed)
+        plan = WakeWordFrameBatchifier(4, rand=rand, **kw).plan(examples)
+        i32 = lambda a: np.ascontiguousarray(a, np.int32)
+        idx, start, length, dst = i32(plan.clip_id), i32(plan.start), i32(plan.length), i32(plan.dst_off)
+        out = np.full((len(examples), plan.width), np.nan, np.float32)
+        lib.call("howl_gather_windows", ptr(bank), lmax, ptr(idx), ptr(start), ptr(length), ptr(dst), len(examples),
+                 plan.width, ptr(out), None)
+        g10_check(g, trial, out, plan.labels, plan.length)
+        assert rand.random() == float(g[f"next_draw_{trial}"])
+
+
+def test_gather_windows_edges(lib):
+    """Widths that are not a multiple of 4, empty windows, windows at either end of the row."""
+    rng = np.random.default_rng(8)
+    bank = rng.standard_normal((3, 1000)).astype(np.float32)
+    for width in (1, 5, 250, 1003):
+        idx = np.array([2, 0, 1, 1], np.int32)
+        length = np.array([min(width, 1000), 0, min(3, width), min(width, 7)], np.int32)
+        start = np.array([0, 10, 997, 500], np.int32)
+        dst = np.array([width - length[0], 0, width - length[2], 0], np.int32)
+        out = np.full((4, width), np.nan, np.float32)
+        lib.call("howl_gather_windows", ptr(bank), 1000, ptr(idx), ptr(start), ptr(length), ptr(dst), 4, width, ptr(out), None)
+        for b in range(4):
+            exp = np.zeros(width, np.float32)
+            exp[dst[b]:dst[b] + length[b]] = bank[idx[b], start[b]:start[b] + length[b]]
+            assert np.array_equal(out[b], exp), (width, b)

@@ -184,3 +184,66 @@ def test_g9_dataset_mixer(golden):
         for i, o in enumerate(out):
             np.testing.assert_allclose(_g9_sub(o.numpy()), g[f"mixed_{trial}_{i}"], rtol=0, atol=1e-7)
         assert rand.random() == float(g[f"next_draw_{trial}"])
+
+
+def g10_inputs(g):
+    """Clips and label maps of golden G10 (ramps whose values name (clip, offset); maps stored in CSR form)."""
+    clips = [torch.arange(int(L), dtype=torch.float32) * 1e-6 + 0.05 * (i + 1) for i, L in enumerate(g["clip_lens"])]
+    ptr = g["map_ptr"]
+    maps = [{float(k): int(v) for k, v in zip(g["map_end_ms"][a:b], g["map_label"][a:b])} for a, b in zip(ptr[:-1], ptr[1:])]
+    return clips, maps
+
+
+G10_VARIANTS = [(0, {}), (7, {}), (21, dict(positive_sample_prob=0.8, window_size_ms=1000)),
+                (3, dict(pad_to_window=False, window_size_ms=250))]
+
+
+def g10_check(g, trial, audio, labels, lengths):
+    a = np.asarray(audio, np.float32)
+    assert a.shape[1] == int(g[f"width_{trial}"])
+    assert np.array_equal(np.asarray(labels), g[f"labels_{trial}"])
+    assert np.array_equal(np.asarray(lengths), g[f"lengths_{trial}"])
+    nz = a != 0
+    assert np.array_equal(nz.sum(1), g[f"nz_count_{trial}"])
+    assert np.array_equal([int(r.argmax()) if r.any() else -1 for r in nz], g[f"nz_start_{trial}"])
+    assert np.array_equal(a[:, ::53], g[f"every53_{trial}"])                    # bit-exact: pure data movement
+    assert np.array_equal([r[m][0] if m.any() else 0.0 for r, m in zip(a, nz)], g[f"first_{trial}"])
+    assert np.array_equal([r[m][-1] if m.any() else 0.0 for r, m in zip(a, nz)], g[f"last_{trial}"])
+
+
+def test_g10_frame_batchifier(golden):
+    """WakeWordFrameBatchifier restatement vs the reference class's own batches under the same `random` stream."""
+    import random
+    from oracle import collate as oc
+    g = golden("g10_frame_batchifier")
+    clips, maps = g10_inputs(g)
+    for trial, (seed, kw) in enumerate(G10_VARIANTS):
+        rand = random.Random(seed)
+        audio, labels, lengths = oc.frame_batchify(rand, clips, maps, 4, **kw)
+        g10_check(g, trial, audio.numpy(), labels.numpy(), lengths.numpy())
+        assert rand.random() == float(g[f"next_draw_{trial}"])
+
+
+def test_g7b_collate_chain(golden):
+    """truncate -> Timeshift -> Noise restatement: consumes the reference's draws and produces its crops."""
+    import random
+    from oracle import collate as oc
+    g = golden("g7b_collate_protocol")
+    lens = [int(v) for v in g["lens"]]
+    for trial, seed in enumerate((0, 1, 2, 5)):
+        rand = random.Random(seed)
+        draws = []
+
+        class Rec:
+            def random(self):
+                v = rand.random()
+                draws.append(v)
+                return v
+
+        torch.manual_seed(seed)
+        clips = oc.truncate_length([torch.arange(L, dtype=torch.float32) * 1e-5 for L in lens], 16000)
+        out = oc.noise(Rec(), oc.timeshift(Rec(), clips))
+        assert np.array_equal(np.array(draws), g[f"draws_{trial}"])
+        assert [o.numel() for o in out] == g[f"out_len_{trial}"].tolist()
+        # torch's CPU generator is the reference's too: same seed, same noise samples, bit-identical first samples
+        assert np.array_equal(np.array([float(o[0]) for o in out]), g[f"first_{trial}"])
