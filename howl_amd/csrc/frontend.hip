@@ -402,18 +402,20 @@ __global__ __launch_bounds__(256) void collate_augment_kernel(const float* __res
                                                               unsigned long long seed, const float* __restrict__ bg,
                                                               long bg_ld, const int* __restrict__ bg_idx,
                                                               const int* __restrict__ bg_off, const float* __restrict__ alpha,
-                                                              float* __restrict__ out, int Lout) {
+                                                              const int* __restrict__ dst_off, float* __restrict__ out,
+                                                              int Lout) {
     const int b = blockIdx.y;
     const int len = src_len[b] - shift[b];
     const int off = from_head[b] ? shift[b] : 0;
-    const float* src = bank + (long)idx[b] * bank_ld + off;
+    const int d0 = dst_off != nullptr ? dst_off[b] : 0;      // zeros in front of the samples (tensorize rand_append)
+    const float* src = bank + (long)idx[b] * bank_ld + off - d0;
     const float sg = sigma[b], pp = sp_prob[b];
     // DatasetMixer runs before the time shift (train.py:218): the background window follows the crop
     const float al = (bg != nullptr) ? alpha[b] : 0.0f;
-    const float* bsrc = (al != 0.0f) ? bg + (long)bg_idx[b] * bg_ld + bg_off[b] + off : nullptr;
+    const float* bsrc = (al != 0.0f) ? bg + (long)bg_idx[b] * bg_ld + bg_off[b] + off - d0 : nullptr;
     for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < Lout; n += gridDim.x * blockDim.x) {
         float v = 0.0f;
-        if (n < len) {
+        if (n >= d0 && n < d0 + len) {
             v = src[n];
             if (bsrc != nullptr) v = v * (1.0f - al) + bsrc[n] * al;
             const unsigned long long key = mix64(seed ^ ((unsigned long long)b << 32) ^ (unsigned long long)n);
@@ -482,19 +484,27 @@ int howl_gather_windows(const float* bank, long bank_ld, const int* idx, const i
     return HOWL_OK;
 }
 
-int howl_collate_augment_mix(const float* bank, long bank_ld, const int* idx, const int* src_len, const int* shift,
-                             const int* from_head, const float* sigma, const float* sp_prob, unsigned long long seed,
-                             const float* bg, long bg_ld, const int* bg_idx, const int* bg_off, const float* alpha, int B,
-                             int Lout, float* out, hipStream_t stream) {
+int howl_collate_augment_window(const float* bank, long bank_ld, const int* idx, const int* src_len, const int* shift,
+                                const int* from_head, const float* sigma, const float* sp_prob, unsigned long long seed,
+                                const float* bg, long bg_ld, const int* bg_idx, const int* bg_off, const float* alpha,
+                                const int* dst_off, int B, int Lout, float* out, hipStream_t stream) {
     HOWL_REQUIRE(bank && idx && src_len && shift && from_head && sigma && sp_prob && out, "howl_collate_augment: null pointer");
     HOWL_REQUIRE(bg == nullptr || (bg_idx && bg_off && alpha), "howl_collate_augment: background given without its parameters");
     HOWL_REQUIRE(B >= 1 && Lout >= 1, "howl_collate_augment: bad shape");
     int gx = (Lout + 255) / 256;
     if (gx > 64) gx = 64;
     hipLaunchKernelGGL(collate_augment_kernel, dim3(gx, B), dim3(256), 0, stream, bank, bank_ld, idx, src_len, shift, from_head,
-                       sigma, sp_prob, seed, bg, bg_ld, bg_idx, bg_off, alpha, out, Lout);
+                       sigma, sp_prob, seed, bg, bg_ld, bg_idx, bg_off, alpha, dst_off, out, Lout);
     HOWL_CHECK_LAUNCH("howl_collate_augment");
     return HOWL_OK;
+}
+
+int howl_collate_augment_mix(const float* bank, long bank_ld, const int* idx, const int* src_len, const int* shift,
+                             const int* from_head, const float* sigma, const float* sp_prob, unsigned long long seed,
+                             const float* bg, long bg_ld, const int* bg_idx, const int* bg_off, const float* alpha, int B,
+                             int Lout, float* out, hipStream_t stream) {
+    return howl_collate_augment_window(bank, bank_ld, idx, src_len, shift, from_head, sigma, sp_prob, seed, bg, bg_ld, bg_idx,
+                                       bg_off, alpha, nullptr, B, Lout, out, stream);
 }
 
 int howl_collate_augment(const float* bank, long bank_ld, const int* idx, const int* src_len, const int* shift,

@@ -75,21 +75,58 @@ class DeviceCollate:
                     bg_id[k], bg_off[k], alpha[k] = j, b - lens[k], a   # "replace" (alpha 1) overrides an earlier mix
         return bg_id, bg_off, alpha
 
+    def _launch(self, clip_ids, rows, shift, src_end, sigma, sp, lout, dst_off=None):
+        """One ``howl_collate_augment_window`` launch: batch row r takes samples [shift[r], src_end[r]) of clip
+        ``clip_ids[rows[r]]`` (mixed with its background first, noise added), at column ``dst_off[r]``."""
+        dev = self.audio.device
+        i32 = lambda a: torch.tensor(a, dtype=torch.int32).to(dev, non_blocking=True)
+        f32 = lambda a: torch.tensor(a, dtype=torch.float32).to(dev, non_blocking=True)
+        pick = lambda a: [a[k] for k in rows]
+        self._calls += 1
+        mix = None
+        if self.last_mix is not None and any(a != 0.0 for a in self.last_mix[2]):
+            mix = (self.bg_audio, i32(pick(self.last_mix[0])), i32(pick(self.last_mix[1])), f32(pick(self.last_mix[2])))
+        return ops.collate_augment(self.audio, i32(pick(clip_ids)), i32(src_end), i32(shift), i32([1] * len(rows)),
+                                   f32(pick(sigma)), f32(pick(sp)), (self._seed << 32) ^ self._calls, lout, mix=mix,
+                                   dst_off=None if dst_off is None else i32(dst_off))
+
     def __call__(self, clip_ids) -> ClassificationBatch:
+        """compose(truncate_length, Timeshift, Noise, batchify) (pretrain_gsc.py:78-80)."""
         clip_ids = list(clip_ids)
         lens, shift, head, sigma, sp = self.draw(clip_ids)
         out_len = [l - w for l, w in zip(lens, shift)]
         order = sorted(range(len(clip_ids)), key=lambda k: -out_len[k])          # batchify: longest first (stable)
-        pick = lambda a: [a[k] for k in order]
+        first = [shift[k] if head[k] else 0 for k in order]                      # head crop drops the first w samples,
+        audio = self._launch(clip_ids, order, first, [f + out_len[k] for f, k in zip(first, order)], sigma, sp,
+                             max(out_len))                                       # tail crop the last w
         dev = self.audio.device
-        i32 = lambda a: torch.tensor(pick(a), dtype=torch.int32).to(dev, non_blocking=True)
-        f32 = lambda a: torch.tensor(pick(a), dtype=torch.float32).to(dev, non_blocking=True)
-        lmax = max(out_len)
-        self._calls += 1
-        mix = None
-        if self.last_mix is not None and any(a != 0.0 for a in self.last_mix[2]):
-            mix = (self.bg_audio, i32(self.last_mix[0]), i32(self.last_mix[1]), f32(self.last_mix[2]))
-        audio = ops.collate_augment(self.audio, i32(clip_ids), i32(lens), i32(shift), i32(head), f32(sigma), f32(sp),
-                                    (self._seed << 32) ^ self._calls, lmax, mix=mix)
-        idx = torch.tensor(pick(clip_ids), dtype=torch.long).to(dev, non_blocking=True)
-        return ClassificationBatch(audio, self.labels[idx], torch.tensor(pick(out_len)).to(dev, non_blocking=True))
+        idx = torch.tensor([clip_ids[k] for k in order], dtype=torch.long).to(dev, non_blocking=True)
+        return ClassificationBatch(audio, self.labels[idx], torch.tensor([out_len[k] for k in order]).to(dev, non_blocking=True))
+
+    def frame_batch(self, examples, batchifier) -> ClassificationBatch:
+        """compose([DatasetMixer,] Timeshift, Noise, WakeWordFrameBatchifier) (train.py:211-229) on device clips: the
+        augmentation draws come first (per batch, reference order), the batchifier then picks one window per augmented
+        clip -- word end times are NOT corrected for a head crop, as in the reference -- and one launch produces the batch."""
+        from howl_amd.data.transform.batchifier import DeviceClip
+        clip_ids = [ex.clip_id for ex in examples]
+        lens, shift, head, sigma, sp = self.draw(clip_ids)
+        cropped = [DeviceClip(ex.clip_id, l - w, ex.timestamp_label_map, ex.transcription)
+                   for ex, l, w in zip(examples, lens, shift)]
+        plan = batchifier.plan(cropped)
+        first = [(shift[k] if head[k] else 0) + a for k, a in zip(plan.source, plan.start)]
+        audio = self._launch(clip_ids, plan.source, first, [f + n for f, n in zip(first, plan.length)], sigma, sp,
+                             plan.width, dst_off=plan.dst_off)
+        dev = self.audio.device
+        return ClassificationBatch(audio, torch.tensor(plan.labels).to(dev, non_blocking=True), torch.tensor(plan.length))
+
+    def sequence_batch(self, examples, batchifier):
+        """compose([DatasetMixer,] Timeshift, Noise, AudioSequenceBatchifier) (train.py:206-229): whole augmented clips,
+        ``np.argsort(-lengths)`` order, zero padded on the right; labels from the batchifier's tokenizer."""
+        from howl_amd.data.common.batch import SequenceBatch
+        clip_ids = [ex.clip_id for ex in examples]
+        lens, shift, head, sigma, sp = self.draw(clip_ids)
+        out_len = [l - w for l, w in zip(lens, shift)]
+        order, labels, label_lengths = batchifier.order_and_labels(examples, out_len)
+        first = [shift[k] if head[k] else 0 for k in order]
+        audio = self._launch(clip_ids, order, first, [f + out_len[k] for f, k in zip(first, order)], sigma, sp, max(out_len))
+        return SequenceBatch(audio, labels, torch.tensor([out_len[k] for k in order]), label_lengths)

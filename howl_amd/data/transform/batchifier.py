@@ -44,6 +44,7 @@ class WindowPlan:
     dst_off: List[int]
     labels: List[int]
     width: int
+    source: List[int] = field(default_factory=list)      # index (into the examples passed in) each row came from
 
 
 def _clamped(a: int, b: int, n: int):
@@ -117,6 +118,7 @@ class WakeWordFrameBatchifier:
             plan.length.append(length)
             plan.dst_off.append(width - length if pad_front else 0)
             plan.labels.append(label)
+            plan.source.append(int(k))
         return plan
 
     # ---- device work ----------------------------------------------------------------------------------------------
@@ -138,19 +140,22 @@ class AudioSequenceBatchifier:
     def __init__(self, negative_label: int, tokenizer, sample_rate: int = 16000, bank: torch.Tensor = None):
         self.negative_label, self.tokenizer, self.sample_rate, self.bank = negative_label, tokenizer, sample_rate, bank
 
+    def order_and_labels(self, examples: Sequence[DeviceClip], lengths):
+        """Batch order (``np.argsort(-lengths)``, ``operator.py:91-92``) and the padded label matrix in that order."""
+        order = [int(k) for k in np.argsort(-np.asarray(lengths))]
+        labels = [self.tokenizer.encode(examples[k].transcription) for k in order]
+        smax = max(len(l) for l in labels)
+        padded = torch.tensor([l + [self.negative_label] * (smax - len(l)) for l in labels], dtype=torch.long)
+        return order, padded.reshape(len(order), smax), torch.tensor([len(l) for l in labels])
+
     def __call__(self, examples: Sequence[DeviceClip]) -> SequenceBatch:
         if self.bank is None:
             raise ValueError("AudioSequenceBatchifier needs the device clip bank the examples index (bank=...)")
-        labels = [self.tokenizer.encode(ex.transcription) for ex in examples]
-        lengths = np.array([ex.num_samples for ex in examples])
-        order = np.argsort(-lengths)
+        lengths = [ex.num_samples for ex in examples]
+        order, padded, label_lengths = self.order_and_labels(examples, lengths)
         dev = self.bank.device
         i32 = lambda a: torch.tensor(a, dtype=torch.int32).to(dev, non_blocking=True)
         n = len(examples)
         audio = ops.gather_windows(self.bank, i32([examples[k].clip_id for k in order]), i32([0] * n),
-                                   i32([int(lengths[k]) for k in order]), i32([0] * n), int(lengths.max()))
-        labels = [labels[k] for k in order]
-        smax = max(1, max(len(l) for l in labels))
-        padded = torch.tensor([l + [self.negative_label] * (smax - len(l)) for l in labels])
-        return SequenceBatch(audio, padded, torch.tensor([int(lengths[k]) for k in order]),
-                             torch.tensor([len(l) for l in labels]))
+                                   i32([lengths[k] for k in order]), i32([0] * n), max(lengths))
+        return SequenceBatch(audio, padded, torch.tensor([lengths[k] for k in order]), label_lengths)

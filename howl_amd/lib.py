@@ -67,6 +67,8 @@ SIGNATURES = {
     "howl_zmuv_apply": [P, c_size_t, P, P, STREAM],
     "howl_collate_augment": [P, c_long, P, P, P, P, P, P, ctypes.c_ulonglong, c_int, c_int, P, STREAM],
     "howl_collate_augment_mix": [P, c_long, P, P, P, P, P, P, ctypes.c_ulonglong, P, c_long, P, P, P, c_int, c_int, P, STREAM],
+    "howl_collate_augment_window": [P, c_long, P, P, P, P, P, P, ctypes.c_ulonglong, P, c_long, P, P, P, P, c_int, c_int, P,
+                                    STREAM],
     "howl_gather_windows": [P, c_long, P, P, P, P, c_int, c_int, P, STREAM],
     "howl_specaug_mask": [P, c_int, c_int, c_int, c_int, c_long, c_long, c_long, c_long, P, P, P, P, STREAM],
     "howl_res8_fwd": [POINTER(HowlRes8Params), P, c_long, c_long, c_long, c_int, c_int, c_int, c_int, c_int,

@@ -100,7 +100,7 @@ class Res8(RegisteredModel, name="res8"):
         prm = _lib.HowlRes8Params()
         ps = self.hot_parameters()
         for p in ps:
-            if not (p.is_cuda and p.is_contiguous() and p.dtype == torch.float32):
+            if not (ops.on_device(p) and p.is_contiguous() and p.dtype == torch.float32):
                 raise _lib.HowlHipError("Res8 parameters must be contiguous fp32 tensors on a HIP device "
                                         "(call .to('cuda') first; there is no CPU fallback)")
         prm.conv0_w = _vp(ps[0])
@@ -128,7 +128,7 @@ class Res8(RegisteredModel, name="res8"):
     def _feat_view(x):
         """(B, C, M, T) any strides -> channel-0 base pointer + (sb, st, sm) element strides."""
         x0 = x[:, 0]
-        if not x0.is_cuda or x0.dtype != torch.float32:
+        if not ops.on_device(x0) or x0.dtype != torch.float32:
             raise _lib.HowlHipError("Res8 input must be an fp32 tensor on a HIP device (no CPU fallback)")
         if x0.shape[1] != 40:
             raise ValueError(f"Res8 on MI355X is built for NUM_MELS=40 (envs/res8.env; pooling (3,4) over 40 mel bins); got "
@@ -299,7 +299,7 @@ class MobileNetClassifier(RegisteredModel, name="mobilenet"):
 
     @staticmethod
     def _is_flat(tensors, flat):
-        if flat is None or not tensors[0].is_cuda or tensors[0].device != flat.device:
+        if flat is None or not ops.on_device(tensors[0]) or tensors[0].device != flat.device:
             return False
         off = 0
         for t in tensors:
@@ -313,7 +313,7 @@ class MobileNetClassifier(RegisteredModel, name="mobilenet"):
         after ``.to(device)``, after ``load_state_dict`` with ``assign``, or when a trainer re-homed them itself)."""
         ps = self.hot_parameters()
         for p in ps:
-            if not (p.is_cuda and p.dtype == torch.float32):
+            if not (ops.on_device(p) and p.dtype == torch.float32):
                 raise _lib.HowlHipError("MobileNetClassifier parameters must be fp32 tensors on a HIP device "
                                         "(call .to('cuda') first; there is no CPU fallback)")
         if not self._is_flat(ps, self._flat):
@@ -365,7 +365,7 @@ class MobileNetClassifier(RegisteredModel, name="mobilenet"):
     @staticmethod
     def _feat_view(x):
         x0 = x[:, 0]
-        if not x0.is_cuda or x0.dtype != torch.float32:
+        if not ops.on_device(x0) or x0.dtype != torch.float32:
             raise _lib.HowlHipError("MobileNetClassifier input must be an fp32 tensor on a HIP device (no CPU fallback)")
         return x0, x0.stride(0), x0.stride(1), x0.stride(2)   # (B, M, T): sb, sm, st
 

@@ -159,7 +159,7 @@ class _LstmBase(RegisteredModel):
 
     def _lstm_inputs(self, x, lengths):
         x0 = x[:, 0]                                   # (B, M, T), log-mels only (rnn.py:61,86)
-        if not x0.is_cuda:
+        if not ops.on_device(x0):
             raise _lib.HowlHipError("LSTM input must be on a HIP device (no CPU fallback)")
         xb = x0.permute(0, 2, 1)
         if not xb.is_contiguous():                     # the fused frontend already hands over a (B,T,M) buffer

@@ -14,6 +14,11 @@ HOP = 200
 N_FFT = 512
 
 
+def on_device(t) -> bool:
+    """The single residency check of the package: every tensor handed to the C ABI must live in HIP device memory."""
+    return t.is_cuda
+
+
 def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -23,7 +28,7 @@ def _p(t, dtype=torch.float32, allow_none=False):
         if allow_none:
             return None
         raise ValueError("tensor required")
-    if not t.is_cuda:
+    if not on_device(t):
         raise _lib.HowlHipError("howl_amd ops need HIP-device tensors (no CPU fallback); got a CPU tensor")
     if t.dtype != dtype:
         raise TypeError(f"expected {dtype}, got {t.dtype}")
@@ -62,7 +67,7 @@ def logmel(pcm: torch.Tensor, fbp: torch.Tensor, n_mels: int, zmuv_pair=None, la
     B, L = pcm.shape
     T = num_frames(L)
     out = torch.empty((B, n_mels, T) if layout == 0 else (B, T, n_mels), dtype=torch.float32, device=pcm.device)
-    if not pcm.is_cuda or pcm.dtype != torch.float32:
+    if not on_device(pcm) or pcm.dtype != torch.float32:
         _p(pcm)
     _lib.get().call("howl_logmel_fwd", ctypes.c_void_p(pcm.data_ptr()), B, L, pcm.stride(0), _p(fbp), n_mels,
                     log_eps, _p(zmuv_pair, allow_none=True), _p(out), layout, _stream())
@@ -92,8 +97,9 @@ def zmuv_apply(x, pair):
     return out
 
 
-def collate_augment(bank, idx, src_len, shift, from_head, sigma, sp_prob, seed, lout, mix=None):
-    """``mix`` = (bg_bank (N, Lbg), bg_idx, bg_off, alpha) puts DatasetMixer in front of the chain."""
+def collate_augment(bank, idx, src_len, shift, from_head, sigma, sp_prob, seed, lout, mix=None, dst_off=None):
+    """``mix`` = (bg_bank (N, Lbg), bg_idx, bg_off, alpha) puts DatasetMixer in front of the chain; ``dst_off`` (int32 per
+    row) places the samples that many columns into the zero row (frame batchifier's front padding)."""
     B = idx.numel()
     out = torch.empty((B, lout), dtype=torch.float32, device=bank.device)
     if mix is None:
@@ -101,9 +107,10 @@ def collate_augment(bank, idx, src_len, shift, from_head, sigma, sp_prob, seed, 
     else:
         bg, bg_ld = _p(mix[0]), mix[0].stride(0)
         bg_idx, bg_off, alpha = _p(mix[1], torch.int32), _p(mix[2], torch.int32), _p(mix[3])
-    _lib.get().call("howl_collate_augment_mix", _p(bank), bank.stride(0), _p(idx, torch.int32), _p(src_len, torch.int32),
+    _lib.get().call("howl_collate_augment_window", _p(bank), bank.stride(0), _p(idx, torch.int32), _p(src_len, torch.int32),
                     _p(shift, torch.int32), _p(from_head, torch.int32), _p(sigma), _p(sp_prob),
-                    ctypes.c_ulonglong(seed & 0xFFFFFFFFFFFFFFFF), bg, bg_ld, bg_idx, bg_off, alpha, B, lout, _p(out), _stream())
+                    ctypes.c_ulonglong(seed & 0xFFFFFFFFFFFFFFFF), bg, bg_ld, bg_idx, bg_off, alpha,
+                    _p(dst_off, torch.int32, allow_none=True), B, lout, _p(out), _stream())
     return out
 
 
@@ -118,7 +125,7 @@ def gather_windows(bank, idx, start, length, dst_off, lout):
 
 def specaug_mask(x, f0, f, t0, t):
     B, C, M, T = x.shape
-    if not x.is_cuda or x.dtype != torch.float32:
+    if not on_device(x) or x.dtype != torch.float32:
         _p(x)
     sb, sc, sm, st = x.stride()
     _lib.get().call("howl_specaug_mask", ctypes.c_void_p(x.data_ptr()), B, C, M, T, sb, sc, sm, st, _p(f0, torch.int32),
@@ -168,7 +175,7 @@ class _CtcLoss(torch.autograd.Function):
 
 
 def _ctc_args(scores, targets, input_lengths, target_lengths, max_target):
-    if not scores.is_cuda:
+    if not on_device(scores):
         raise _lib.HowlHipError("ctc_loss: scores must be on a HIP device (no CPU fallback)")
     if scores.dim() != 3 or targets.dim() != 2:
         raise ValueError("ctc_loss: scores must be (T, B, C) and targets the padded (B, L) matrix")

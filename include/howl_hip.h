@@ -98,6 +98,15 @@ int howl_collate_augment_mix(const float* bank, long bank_ld, const int* idx, co
                              const float* bg, long bg_ld, const int* bg_idx, const int* bg_off, const float* alpha, int B,
                              int Lout, float* out, hipStream_t stream);
 
+/* The same chain feeding WakeWordFrameBatchifier (train.py:211-225 composes Timeshift -> Noise -> batchifier): row b holds
+ * the samples [shift[b], src_len[b]) (from_head = 1) of the mixed / noised clip at columns dst_off[b].., zeros on both
+ * sides, i.e. a window of the augmented clip padded on the side tensorize_audio_data(rand_append=True) drew
+ * (batchifier.py:108-115, operator.py:104-107).  dst_off == NULL: identical to howl_collate_augment_mix. */
+int howl_collate_augment_window(const float* bank, long bank_ld, const int* idx, const int* src_len, const int* shift,
+                                const int* from_head, const float* sigma, const float* sp_prob, unsigned long long seed,
+                                const float* bg, long bg_ld, const int* bg_idx, const int* bg_off, const float* alpha,
+                                const int* dst_off, int B, int Lout, float* out, hipStream_t stream);
+
 /* Frame-window gather: out (B, Lout) row b = zeros except out[b][dst_off[b] + n] = bank[idx[b]][start[b] + n], n < len[b].
  * Replaces, for device-resident clips, the window cut of WakeWordFrameBatchifier.__call__ (batchifier.py:56-118:
  * `ex.audio_data[..., a:b]`) and the zero padding of tensorize_audio_data(rand_append=True, max_length=window)
