@@ -19,6 +19,7 @@ thread_local char g_err[512] = "";
 struct ProfRec {
     std::string tag;
     hipEvent_t start, stop;
+    double work;   // algorithmic FLOPs or bytes of the bracketed launches (whatever the call site counts)
 };
 std::mutex g_prof_mu;
 bool g_prof_on = false;
@@ -49,11 +50,12 @@ HowlSideQueue* howl_side_queue(hipStream_t caller, int purpose, const char* disa
     return q;
 }
 
-bool howl_prof_begin(const char* tag, hipStream_t stream, size_t* slot) {
+bool howl_prof_begin(const char* tag, hipStream_t stream, size_t* slot, double work) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
     if (!g_prof_on) return false;
     ProfRec r;
     r.tag = tag;
+    r.work = work;
     if (hipEventCreate(&r.start) != hipSuccess || hipEventCreate(&r.stop) != hipSuccess) return false;
     hipEventRecord(r.start, stream);
     g_prof.push_back(r);
@@ -103,9 +105,9 @@ int howl_profile_enable(int on) {
     return HOWL_OK;
 }
 
-int howl_profile_read(const char* tag, double* total_ms, int* count, int reset) {
+int howl_profile_read_work(const char* tag, double* total_ms, int* count, double* work, int reset) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
-    double tot = 0.0;
+    double tot = 0.0, wk = 0.0;
     int n = 0;
     for (auto& r : g_prof) {
         if (tag != nullptr && r.tag != tag) continue;
@@ -113,11 +115,13 @@ int howl_profile_read(const char* tag, double* total_ms, int* count, int reset) 
         float ms = 0.0f;
         if (hipEventElapsedTime(&ms, r.start, r.stop) == hipSuccess) {
             tot += (double)ms;
+            wk += r.work;
             ++n;
         }
     }
     if (total_ms) *total_ms = tot;
     if (count) *count = n;
+    if (work) *work = wk;
     if (reset) {
         for (auto& r : g_prof) {
             hipEventDestroy(r.start);
@@ -125,6 +129,37 @@ int howl_profile_read(const char* tag, double* total_ms, int* count, int reset) 
         }
         g_prof.clear();
     }
+    return HOWL_OK;
+}
+
+int howl_profile_read(const char* tag, double* total_ms, int* count, int reset) {
+    return howl_profile_read_work(tag, total_ms, count, nullptr, reset);
+}
+
+int howl_shutdown(void) {
+    {
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        g_prof_on = false;
+        for (auto& r : g_prof) {
+            hipEventDestroy(r.start);
+            hipEventDestroy(r.stop);
+        }
+        g_prof.clear();
+    }
+    std::lock_guard<std::mutex> lk(g_side_mu);
+    int saved = 0;
+    hipGetDevice(&saved);
+    for (auto& kv : g_side) {
+        HowlSideQueue* q = kv.second;
+        if (q == nullptr) continue;
+        hipSetDevice(std::get<0>(kv.first));
+        hipStreamSynchronize(q->stream);
+        for (int i = 0; i < HOWL_SIDE_EVENTS; ++i) hipEventDestroy(q->ev[i]);
+        hipStreamDestroy(q->stream);
+        delete q;
+    }
+    g_side.clear();
+    hipSetDevice(saved);
     return HOWL_OK;
 }
 

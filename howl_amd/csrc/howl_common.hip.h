@@ -26,15 +26,16 @@ struct HowlSideQueue {
     hipEvent_t ev[HOWL_SIDE_EVENTS];
 };
 HowlSideQueue* howl_side_queue(hipStream_t caller, int purpose, const char* disable_env);
-bool howl_prof_begin(const char* tag, hipStream_t stream, size_t* slot);
+bool howl_prof_begin(const char* tag, hipStream_t stream, size_t* slot, double work);
 void howl_prof_end(size_t slot, hipStream_t stream);
 
-// brackets the launches in its scope with HIP events when howl_profile_enable(1) is active (no-op otherwise)
+// brackets the launches in its scope with HIP events when howl_profile_enable(1) is active (no-op otherwise); `work` =
+// the algorithmic FLOPs (or bytes) of those launches, summed per tag by howl_profile_read_work
 struct HowlProfScope {
     size_t slot = 0;
     bool on;
     hipStream_t stream;
-    HowlProfScope(const char* tag, hipStream_t s) : stream(s) { on = howl_prof_begin(tag, s, &slot); }
+    HowlProfScope(const char* tag, hipStream_t s, double work = 0.0) : stream(s) { on = howl_prof_begin(tag, s, &slot, work); }
     ~HowlProfScope() {
         if (on) howl_prof_end(slot, stream);
     }

@@ -328,6 +328,7 @@ int gemm(hipStream_t s, bool a_major_k, const float* a, RowMap am, long a_ks, Ro
          int M, int N, int K, int splits, const float* bias, int relu, float* c, long c_ms, long c_split_stride) {
     const int kps = ((K + splits - 1) / splits + GK - 1) / GK * GK;
     dim3 grid((N + GT - 1) / GT, (M + GT - 1) / GT, (K + kps - 1) / kps);
+    HowlProfScope prof("gemm", s, 2.0 * (double)M * N * K);
     // operands whose unit-stride runs are 16-byte aligned multiples of 4 floats take the vector kernel
     {
         auto map_ok = [](const RowMap& r) { return (r.s_outer & 3) == 0 && (r.s_inner & 3) == 0; };

@@ -645,6 +645,7 @@ int howl_lstm_fwd(const HowlLstmParams* p, const float* x, int B, int T, int M, 
     gemm(stream, true, x, lin(M), 1, lin(0), p->w_ih, lin(1), M, B * T, G4, M, 1, bsum, 0, sv->gx, G4, 0);
     if (sv->t_out < T)   // rows of steps that never run are read (times zero) by the weight-gradient GEMM: keep them finite
         hipMemsetAsync(sv->hseq, 0, (size_t)B * (T + 1) * HID * sizeof(float), stream);
+    HowlProfScope prof("lstm_fwd", stream, 2.0 * HID * G4 * (double)B * sv->t_out);     // h_{t-1} W_hh^T of every step
     if (!rows16) {
         hipLaunchKernelGGL(lstm_fwd4_kernel, dim3((B + 3) / 4), dim3(LSTM_THREADS), 0, stream, (const float*)sv->gx,
                            (const float*)pf4, lengths, h0, c0, sv->gates, sv->c, sv->hseq, hT, cT, B, T, sv->t_out);
@@ -671,6 +672,8 @@ int howl_lstm_bwd(const HowlLstmParams* p, const float* x, int B, int T, int M, 
     float* pb = pf + 16 * 64 * 64;
     float* scratch = pb + 16 * 64 * 64 + G4;
     const int Tout = sv->t_out;
+    {
+    HowlProfScope prof("lstm_bwd", stream, 2.0 * HID * G4 * (double)B * Tout);           // dG_t W_hh of every step
     if (!lstm_rows16(B))
         hipLaunchKernelGGL(lstm_bwd4_kernel, dim3((B + 3) / 4), dim3(LSTM_THREADS), 0, stream, dy, dhT, dcT,
                            (const float*)(scratch + 16 * 64 * 64),
@@ -678,6 +681,7 @@ int howl_lstm_bwd(const HowlLstmParams* p, const float* x, int B, int T, int M, 
     else
         hipLaunchKernelGGL(lstm_bwd_kernel, dim3((B + 15) / 16), dim3(LSTM_THREADS), 0, stream, dy, dhT, dcT, (const float*)pb,
                            lengths, (const float*)sv->gates, (const float*)sv->c, c0, sv->dgates, B, T, Tout);
+    }
     // dW_ih = dG^T X, dW_hh = dG^T H_prev (hseq rows t = 0..t_out-1 of each utterance), db = column sums of dG.  Steps
     // t >= t_out never ran and their dG rows are never written: the reductions walk rows (b, t < t_out) only.
     const bool full = Tout == T;

@@ -730,9 +730,12 @@ int howl_mobilenet_fwd(const float* params, float* buffers, int num_labels, cons
         if (training) {
             const int chunks = chunks_for(g.mz, l.cout);
             const long rpc = (g.mz + chunks - 1) / chunks;
-            hipLaunchKernelGGL(col_reduce_kernel<0>, dim3((l.cout + 63) / 64, chunks), dim3(256), 0, stream, (const float*)z,
-                               (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0,
-                               g.mz, l.cout, col_pack(l.cout), rpc, part);
+            {
+                HowlProfScope prof("mb_sweep", stream, 4.0 * (double)g.mz * l.cout);     // reads z once
+                hipLaunchKernelGGL(col_reduce_kernel<0>, dim3((l.cout + 63) / 64, chunks), dim3(256), 0, stream, (const float*)z,
+                                   (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
+                                   0, g.mz, l.cout, col_pack(l.cout), rpc, part);
+            }
             hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((l.cout + 63) / 64), dim3(FIN_THREADS), 0, stream, (const double*)part,
                                chunks, l.cout, (double)g.mz, stats, buffers + l.rmean_off, buffers + l.rvar_off);
         } else {
@@ -742,8 +745,11 @@ int howl_mobilenet_fwd(const float* params, float* buffers, int num_labels, cons
         const float* res = l.res_src >= 0 ? c.ws + c.p.y[l.res_src] : nullptr;
         float* ypre = l.pool ? c.ws + c.p.yp[k] : c.ws + c.p.y[k];
         const long total = g.mz * l.cout;
-        hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(flat_grid(total)), dim3(256), 0, stream, (const float*)z, (const float*)stats,
-                           params + l.gamma_off, params + l.beta_off, res, l.act, l.cout, total, ypre);
+        {
+            HowlProfScope prof("mb_sweep", stream, (res != nullptr ? 12.0 : 8.0) * (double)total);   // z (+ residual) in, y out
+            hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(flat_grid(total)), dim3(256), 0, stream, (const float*)z,
+                               (const float*)stats, params + l.gamma_off, params + l.beta_off, res, l.act, l.cout, total, ypre);
+        }
         if (l.pool) {
             const long tp = g.my * l.cout;
             hipLaunchKernelGGL(maxpool12_fwd_kernel, dim3(flat_grid(tp)), dim3(256), 0, stream, (const float*)ypre, g.wo, g.wy,
@@ -824,14 +830,20 @@ int howl_mobilenet_bwd(const float* params, int num_labels, const float* x, long
         }
         const int chunks = chunks_for(g.mz, l.cout);
         const long rpc = (g.mz + chunks - 1) / chunks;
-        hipLaunchKernelGGL(col_reduce_kernel<1>, dim3((l.cout + 63) / 64, chunks), dim3(256), 0, stream, z, dy, stats,
-                           params + l.gamma_off, params + l.beta_off, l.act, g.mz, l.cout, col_pack(l.cout), rpc, part);
+        {
+            HowlProfScope prof("mb_sweep", stream, 8.0 * (double)total);                 // z and dy in
+            hipLaunchKernelGGL(col_reduce_kernel<1>, dim3((l.cout + 63) / 64, chunks), dim3(256), 0, stream, z, dy, stats,
+                               params + l.gamma_off, params + l.beta_off, l.act, g.mz, l.cout, col_pack(l.cout), rpc, part);
+        }
         hipLaunchKernelGGL(bn_bwd_finalize_mb_kernel, dim3((l.cout + 63) / 64), dim3(FIN_THREADS), 0, stream, (const double*)part,
                            chunks, l.cout, (double)g.mz, grads + l.gamma_off, grads + l.beta_off, m12);
         float* dz = c.ws + (par ? c.p.dz2 : c.p.dz);
         if (sq && forked >= 2) hipStreamWaitEvent(stream, sq->ev[2 + par], 0);
-        hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(flat_grid(total)), dim3(256), 0, stream, z, dy, stats, params + l.gamma_off,
-                           params + l.beta_off, (const float*)m12, l.act, l.cout, total, dz);
+        {
+            HowlProfScope prof("mb_sweep", stream, 12.0 * (double)total);                // z and dy in, dz out
+            hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(flat_grid(total)), dim3(256), 0, stream, z, dy, stats,
+                               params + l.gamma_off, params + l.beta_off, (const float*)m12, l.act, l.cout, total, dz);
+        }
         if (sq) {
             hipEventRecord(sq->ev[par], stream);
             hipStreamWaitEvent(wst, sq->ev[par], 0);

@@ -58,6 +58,8 @@ SIGNATURES = {
     "howl_version": [POINTER(c_int), POINTER(c_int)],
     "howl_profile_enable": [c_int],
     "howl_profile_read": [c_char_p, POINTER(c_double), POINTER(c_int), c_int],
+    "howl_profile_read_work": [c_char_p, POINTER(c_double), POINTER(c_int), POINTER(c_double), c_int],
+    "howl_shutdown": [],
     "howl_fb_pack": [P, c_int, P, STREAM],
     "howl_fb_from_points": [POINTER(HowlMelPoints), c_int, c_float, P, STREAM],
     "howl_logmel_fwd": [P, c_int, c_int, c_long, P, c_int, c_float, P, P, c_int, STREAM],
@@ -135,4 +137,6 @@ def get() -> Library:
     global _LIB
     if _LIB is None:
         _LIB = Library(LIB_PATH)
+        import atexit
+        atexit.register(_LIB.cdll.howl_shutdown)     # side HIP queues / events go before the runtime does
     return _LIB

@@ -36,11 +36,19 @@ typedef struct ihipStream_t* hipStream_t;
 int howl_version(int* major, int* minor);
 const char* howl_last_error(void);
 
-/* Optional kernel timing for bench.py's roofline leg: while enabled, the dominant kernels (tags "logmel",
- * "conv3x3_fwd", "conv3x3_dgrad", "wgrad") are bracketed by hipEvents recorded on their launch stream.
- * howl_profile_read synchronises those events and returns the summed duration and launch count for one tag. */
+/* Optional kernel timing for bench.py's roofline leg: while enabled, the dominant kernels (tags "logmel", "conv0_fwd",
+ * "conv3x3_fwd", "conv3x3_dgrad", "wgrad"; "lstm_fwd", "lstm_bwd", "gemm"; "mb_gemm", "mb_sweep") are bracketed by hipEvents
+ * recorded on their launch stream.  howl_profile_read synchronises those events and returns the summed duration and
+ * launch count for one tag; howl_profile_read_work also returns the summed algorithmic work (FLOPs for the matrix
+ * kernels, HBM bytes for the "mb_sweep" activation sweeps) the call sites attached to those launches. */
 int howl_profile_enable(int on);
 int howl_profile_read(const char* tag, double* total_ms, int* count, int reset);
+int howl_profile_read_work(const char* tag, double* total_ms, int* count, double* work, int reset);
+
+/* Releases what the library keeps for the life of the process (the side HIP queues + events of howl_res8_bwd /
+ * howl_mobilenet_bwd, profiling events).  Call once before the HIP runtime goes away (howl_amd/lib.py registers it with
+ * atexit); the library recreates the resources if it is used again. */
+int howl_shutdown(void);
 
 /* ---------------------------------------------------------------------------------------------------
  * Frontend: howl/data/transform/transform.py:234-296 (StandardAudioTransform) and the torchaudio

@@ -65,6 +65,9 @@ static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) 
 static inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
 struct hipDeviceProp_t { int multiProcessorCount; };
 static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+static inline hipError_t hipSetDevice(int) { return hipSuccess; }
+static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
 static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) { p->multiProcessorCount = 4; return hipSuccess; }
 static inline hipError_t hipFuncSetAttribute(const void*, int, int) { return hipSuccess; }
 static constexpr int hipFuncAttributeMaxDynamicSharedMemorySize = 8;
