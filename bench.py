@@ -1,25 +1,40 @@
-"""Headline benchmark: end-to-end res8 training step on synthetic 16 kHz audio (BASELINE.json metric
+"""Headline benchmark: end-to-end training step of Howl's audio hot path on synthetic 16 kHz audio (BASELINE.json metric
 "utterances/sec/node (res8, 1s@16kHz, 40-mel)").
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config c3]
 
 One step = one pass of the hot path over one batch already resident in HBM:
-    PCM (B,16000) -> fused log-mel frontend (+ZMUV) -> res8 forward (training-mode BN) -> cross-entropy
-    -> res8 backward -> [sum all-reduce of the flat 441 KB gradient over RCCL when N > 1] -> AdamW.
-Workload per GPU: BASELINE.json configs[2] at its per-GPU share -- res8, 12 labels, 512 utterances of 1 s per GPU
-(global batch 4096 at 8 GPUs); weak scaling.  Synthetic PCM and closed-form weights (no dataset / checkpoint on the box).
+    PCM (B, L) -> fused log-mel frontend (+ZMUV) -> model forward -> loss -> backward
+    -> [sum all-reduce of the flat gradient buffer over RCCL when N > 1] -> AdamW.
 
-Rank 0 prints ONE JSON line; it also carries
-  "roofline":     the dominant kernel (MFMA conv3x3 45->45, forward+dgrad launches) -- algorithmic FLOPs per launch
-                  (2*9*45*45*270 per utterance x B) / mean launch duration measured with HIP events on the launch stream,
-                  against the 157.3 TFLOP/s fp32 MFMA peak;
+``--config`` selects the BASELINE.json configuration (default ``c3``, the one the metric is quoted on, at its per-GPU share):
+    c1  res8 GSC-30,  64 x 1 s    (configs[0], the reference's own CPU-runnable case)
+    c2  res8 hey-fire-fox (4 labels), 256 x 0.5 s   (configs[1])
+    c3  res8 GSC-12, 512 x 1 s per GPU (4096 over 8 GPUs; configs[2])           <- the bench line
+    c4  seq-lstm hey-fire-fox, CTC, 512 x 0.5 s      (configs[3])
+    c5  mobilenet GSC-12, 512 x 1 s per GPU (2048 over 4 GPUs) with the timeshift/noise collate on the device (configs[4])
+Weak scaling: the per-GPU batch is fixed as N grows.  Synthetic PCM and closed-form / seeded weights (no dataset or
+checkpoint on the box).
+
+Launch: under ``torch.distributed.run`` (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment) each process is one
+rank; started plainly with ``--gpus N`` > 1 the script spawns the N ranks itself (one process per GPU, RCCL backend) and
+relays rank 0's line.  ``HOWL_BENCH_BACKEND=gloo`` lets several ranks share one GPU (control-flow check; RCCL refuses that).
+
+Rank 0 prints ONE JSON line; besides the contract fields it carries
+  "roofline":     the dominant kernel of the configuration: algorithmic FLOPs (or bytes) per launch / mean launch duration
+                  measured with HIP events on the launch stream in a second pass of the same K steps
+                  (res8: conv3x3 45->45 forward launches vs the 157.3 TFLOP/s fp32 MFMA peak; seq-lstm: recurrences + GEMMs
+                  vs the same peak; mobilenet: BatchNorm/activation sweeps vs 8 TB/s HBM);
   "cpu_baseline": the oracle (CPU restatement of the reference step, torch-CPU) timed on this box's host cores on a
-                  bounded sample (rank 0, N = 1 only).
+                  bounded sample (rank 0, N = 1 only);
+  "rccl":         (N > 1) world size, backend, and the all-reduce of the flat gradient buffer timed on its own.
 """
 import argparse
 import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -29,11 +44,18 @@ sys.path.insert(0, str(ROOT))
 os.environ.setdefault("NUM_MELS", "40")
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
 FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
+
+CONFIGS = {
+    #      model       labels  batch/GPU  seconds  BASELINE.json entry
+    "c1": ("res8", 30, 64, 1.0, "configs[0]: res8 GSC-30, batch 64, 1 s"),
+    "c2": ("res8", 4, 256, 0.5, "configs[1]: res8 hey-fire-fox, batch 256, 0.5 s"),
+    "c3": ("res8", 12, 512, 1.0, "configs[2] per-GPU share: res8 GSC-12, 512 x 1 s per GPU (4096 over 8)"),
+    "c4": ("seq-lstm", 5, 512, 0.5, "configs[3]: seq-lstm hey-fire-fox CTC, batch 512, 0.5 s"),
+    "c5": ("mobilenet", 12, 512, 1.0, "configs[4] per-GPU share: mobilenet GSC-12, 512 x 1 s per GPU (2048 over 4), device "
+                                      "timeshift/noise collate in the step"),
+}
 
 
 def parse():
@@ -41,62 +63,139 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--batch-per-gpu", type=int, default=512)
-    ap.add_argument("--seconds", type=float, default=1.0, help="utterance length")
-    ap.add_argument("--labels", type=int, default=12)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="c3")
+    ap.add_argument("--batch-per-gpu", type=int, default=None, help="override the configuration's per-GPU batch")
+    ap.add_argument("--seconds", type=float, default=None, help="override the utterance length")
+    ap.add_argument("--labels", type=int, default=None)
     ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
 
 
-def cpu_baseline(L, C, budget_s):
-    """Oracle training step (frontend + res8 fwd/bwd + AdamW, mirrors pretrain_gsc.py:124-133) on the host cores."""
+# ---------------------------------------------------------------------------------------------------------------------
+# launcher: `python bench.py --gpus N` without a distributed environment starts the N ranks itself
+# ---------------------------------------------------------------------------------------------------------------------
+def spawn_ranks(n):
+    import torch
+    backend = os.environ.get("HOWL_BENCH_BACKEND", "nccl")
+    have = torch.cuda.device_count()
+    if backend == "nccl" and have < n:
+        raise SystemExit(f"bench.py --gpus {n}: only {have} HIP device(s) visible; one rank per GPU is required for RCCL")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for rank in range(n):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HOWL_BENCH_SPAWNED="1")
+        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve())] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    if any(codes):
+        raise SystemExit(f"bench.py: rank exit codes {codes}")
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# CPU baseline (oracle = checker code; only this leg and smoke() may touch it)
+# ---------------------------------------------------------------------------------------------------------------------
+def host_info():
+    model, cores = "unknown", set()
+    try:
+        phys = core = None
+        for line in Path("/proc/cpuinfo").read_text().splitlines():
+            if line.startswith("model name") and model == "unknown":
+                model = line.split(":", 1)[1].strip()
+            elif line.startswith("physical id"):
+                phys = line.split(":", 1)[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":", 1)[1].strip()
+            elif not line.strip() and phys is not None:
+                cores.add((phys, core))
+                phys = core = None
+    except OSError:
+        pass
+    return model, (len(cores) or os.cpu_count() or 1)
+
+
+def cpu_baseline(model_name, L, C, budget_s):
+    """The oracle's training step (frontend + forward + loss + backward + AdamW, mirrors pretrain_gsc.py:124-133 /
+    train.py:286-302) on the host cores, on a bounded sample: batch 64 (configs[0]'s batch size), a few thread counts inside
+    the time budget, the fastest reported together with the single-thread figure and the machine's physical core count."""
+    import torch
     from oracle import frontend as ofe, models as om
     from howl_amd.utils.synth import synthetic_pcm
-    B = 64  # BASELINE.json configs[0] batch size
+    B = 64 if model_name != "mobilenet" else 32
     pcm = synthetic_pcm(B, L)
-    labels = torch.arange(B) % C
     fb = ofe.mel_fb(40)
     z = ofe.Zmuv()
     z.update(ofe.standard_audio_transform(pcm[:2], fb))
-    sd = om.res8_init(C)
-    names = om.res8_param_names()
-    opt = om.AdamWState([sd[n] for n in names], 0.01, 1e-5)
+    if model_name == "res8":
+        labels = torch.arange(B) % C
+        sd, names = om.res8_init(C), om.res8_param_names()
+        opt = om.AdamWState([sd[n] for n in names], 0.01, 1e-5)
 
-    def step():
-        x = z(ofe.standard_audio_transform(pcm, fb))
-        om.train_step(lambda s, xx: om.res8_forward(s, xx, True), sd, names, opt, x, labels)
+        def step():
+            x = z(ofe.standard_audio_transform(pcm, fb))
+            om.train_step(lambda s, xx: om.res8_forward(s, xx, True), sd, names, opt, x, labels)
+    elif model_name == "seq-lstm":
+        sd, names = om.lstm_init(C), om.lstm_param_names()
+        opt = om.AdamWState([sd[n] for n in names], 1e-4, 1e-5)
+        flen = ofe.compute_lengths(torch.full((B,), L))
+        targets, tl = torch.tensor([[0, 1, 2]] * B), torch.tensor([3] * B)
 
-    # torch's default thread count (= physical cores) oversubscribes these small convolutions on a many-core host:
-    # time a few thread counts inside the budget and report the fastest, with the count used
+        def step():
+            x = z(ofe.standard_audio_transform(pcm, fb))
+            params = [sd[n].requires_grad_(True) for n in names]
+            scores, _ = om.seq_lstm_forward(sd, x, flen, aten=True)
+            loss = torch.nn.functional.ctc_loss(torch.log_softmax(scores, -1), targets, flen, tl, blank=C - 1)
+            grads = torch.autograd.grad(loss, params)
+            for n in names:
+                sd[n] = sd[n].detach()
+            opt.step([sd[n] for n in names], grads)
+    else:
+        from oracle import mobilenet as omb
+        labels = torch.arange(B) % C
+        sd, names = omb.mobilenet_init(C), omb.mobilenet_param_names()
+        opt = om.AdamWState([sd[n] for n in names], 0.001, 0.0)
+
+        def step():
+            x = z(ofe.standard_audio_transform(pcm, fb))
+            om.train_step(lambda s, xx: omb.mobilenet_forward(s, xx, True), sd, names, opt, x, labels)
+
+    cpu_model, physical = host_info()
     default_threads = torch.get_num_threads()
-    candidates = sorted({min(default_threads, c) for c in (16, 32, 64)} | {default_threads})
-    best = None
+    # torch's default thread count oversubscribes these small convolutions on a many-core host: time a few counts inside
+    # the budget and report the fastest with the count used; 1 thread gives the per-core figure
+    candidates = sorted({1} | {min(default_threads, c) for c in (16, 32, 64)} | {min(default_threads, physical)})
+    results = {}
     for nthreads in candidates:
         torch.set_num_threads(nthreads)
-        for _ in range(2):
+        for _ in range(2 if nthreads > 1 else 1):
             step()
         t0 = time.perf_counter()
         n = 0
-        while n < 3 or (time.perf_counter() - t0 < budget_s / len(candidates) and n < 200):
+        while n < 2 or (time.perf_counter() - t0 < budget_s / len(candidates) and n < 200):
             step()
             n += 1
-        dt = time.perf_counter() - t0
-        rate = B * n / dt
-        if best is None or rate > best[0]:
-            best = (rate, nthreads, n)
+        results[nthreads] = (B * n / (time.perf_counter() - t0), n)
     torch.set_num_threads(default_threads)
-    rate, nthreads, n = best
-    return {"value": round(rate, 1), "unit": "utterances/sec", "cores": nthreads, "kind": "port",
-            "sample": f"{n} oracle training steps of batch {B} x {L / 16000:g} s (torch-CPU, best of {candidates} threads)"}
+    best = max(results, key=lambda k: results[k][0])
+    return {"value": round(results[best][0], 1), "unit": "utterances/sec", "cores": best, "kind": "port",
+            "physical_cores": physical, "cpu_model": cpu_model, "value_1_thread": round(results[1][0], 1),
+            "by_threads": {str(k): round(v[0], 1) for k, v in results.items()},
+            "sample": f"{results[best][1]} oracle training steps ({model_name}) of batch {B} x {L / 16000:g} s "
+                      f"(torch-CPU; threads tried: {candidates})"}
 
 
 def pmc_traffic():
-    """HBM bytes per launch of the dominant kernel from the newest committed PMC summary (profiles/*pmc*.txt, written by
+    """HBM bytes per launch of the dominant res8 kernel from the newest committed PMC summary (profiles/*pmc*.txt, written by
     tools/pmc_round.sh + tools/pmc_summary.py: separate rocprofv3 --pmc passes for FETCH_SIZE and WRITE_SIZE, in KB, read
     side doubled per the gfx950 correction in MI355X_MICROARCH.md).  Counters cannot be collected from inside this
-    process, so the figure is the one measured on the same command line when the summary was taken."""
+    process, so the figure is the one measured on the same command line when the summary was taken (the file is named)."""
     import re
     files = sorted((ROOT / "profiles").glob("*pmc*.txt"), key=lambda f: [int(x) for x in re.findall(r"\d+", f.name)])
     if not files:
@@ -114,44 +213,80 @@ def pmc_traffic():
     return tot, files[-1].name
 
 
+# ---------------------------------------------------------------------------------------------------------------------
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        spawn_ranks(args.gpus)
+        return
+    import torch
+    import torch.distributed as dist
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback)"
-    # HOWL_BENCH_BACKEND=gloo lets the multi-rank control flow be exercised with several ranks on ONE GPU (RCCL refuses two
-    # ranks per device); the default, and what the driver runs, is one rank per GPU over RCCL
+    if args.gpus != world:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; the launcher's world size wins", file=sys.stderr)
     backend = os.environ.get("HOWL_BENCH_BACKEND", "nccl")
+    if backend == "nccl":
+        assert torch.cuda.device_count() > local_rank, (f"rank {rank}: LOCAL_RANK={local_rank} but only "
+                                                        f"{torch.cuda.device_count()} HIP device(s) visible")
     dev_index = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
-    if world > 1:
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{dev_index}"))
-        else:
-            dist.init_process_group(backend)
     torch.cuda.set_device(dev_index)
     dev = torch.device(f"cuda:{dev_index}")
+    if world > 1:
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from howl_amd import lib as hlib
     from howl_amd.data.transform.operator import ZmuvTransform
     from howl_amd.data.transform.transform import StandardAudioTransform
     from howl_amd.model import RegisteredModel
-    from howl_amd.training.fused import FusedRes8Trainer
+    from howl_amd.training.fused import FusedTrainer
     from howl_amd.utils.synth import res8_closed_form_state, synthetic_pcm
 
-    B, C = args.batch_per_gpu, args.labels
-    L = int(round(args.seconds * 16000))
+    model_name, C, B, seconds, cfg_desc = CONFIGS[args.config]
+    B = args.batch_per_gpu or B
+    C = args.labels or C
+    L = int(round((args.seconds or seconds) * 16000))
     pcm = synthetic_pcm(B, L, seed=1234 + rank).to(dev)
     labels = (torch.arange(B) % C).to(dev)
 
     std = StandardAudioTransform().to(dev).eval()   # eval-mode filterbank; VTLP is exercised by the tests
     zmuv = ZmuvTransform().to(dev)
     zmuv.update(std(pcm[:8]))
-    model = RegisteredModel.find_registered_class("res8")(C).to(dev)
-    model.load_state_dict(res8_closed_form_state(C), strict=False)
+    model = RegisteredModel.find_registered_class(model_name)(C).to(dev)
+    if model_name == "res8":
+        model.load_state_dict(res8_closed_form_state(C), strict=False)
     model.train()
-    trainer = FusedRes8Trainer(model, std, zmuv, lr=0.01, weight_decay=1e-5)
+    lr, wd = {"res8": (0.01, 1e-5), "seq-lstm": (1e-4, 1e-5), "mobilenet": (0.001, 0.0)}[model_name]   # envs/*.env
+    trainer = FusedTrainer(model, std, zmuv, lr=lr, weight_decay=wd)
     trainer.broadcast_parameters()
+
+    if model_name == "seq-lstm":
+        frame_lengths = torch.full((B,), (L - 512) // 200 + 1)
+        targets = torch.tensor([[0, 1, 2]] * B).to(dev)
+        target_lengths = torch.tensor([3] * B)
+
+        def step():    # frontend -> LSTM + head -> fused log_softmax + CTC(blank = C-1) -> backward -> flat AdamW
+            return trainer.step_sequence(pcm, frame_lengths, targets, target_lengths, C - 1, max_target=3)
+    elif model_name == "mobilenet":
+        from howl_amd.data.collate import DeviceCollate
+        collate = DeviceCollate(pcm, torch.full((B,), L, dtype=torch.long), labels, max_len=L, seed=rank)
+        ids = list(range(B))
+
+        def step():    # timeshift + white / salt-pepper noise + batchify on the device, then the training step
+            batch = collate(ids)
+            audio = batch.audio_data
+            if audio.shape[1] != L:   # timeshift crops; the step geometry is fixed at L samples -> right-pad like batchify
+                audio = torch.nn.functional.pad(audio, (0, L - audio.shape[1]))
+            return trainer.step(audio, batch.labels)
+    else:
+        def step():
+            return trainer.step(pcm, labels)
 
     def barrier():
         if world > 1:
@@ -159,11 +294,11 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        trainer.step(pcm, labels)
+        step()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = trainer.step(pcm, labels)
+        loss = step()
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -172,73 +307,127 @@ def main():
         dt = tmax.item()
     final_loss = loss.item()
 
+    rccl = None
+    if world > 1:
+        # the step's one collective, timed on its own (HIP events on the compute stream, which the process group's stream
+        # joins on both sides): the flat gradient buffer, sum over ranks
+        buf = torch.zeros_like(trainer.fp.grad)
+        for _ in range(5):
+            dist.all_reduce(buf)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        barrier()
+        e0.record()
+        for _ in range(20):
+            dist.all_reduce(buf)
+        e1.record()
+        torch.cuda.synchronize()
+        rccl = {"world_size": dist.get_world_size(), "backend": dist.get_backend(),
+                "allreduce_bytes": buf.numel() * 4, "allreduce_us": round(e0.elapsed_time(e1) * 1e3 / 20, 1),
+                "collectives_per_step": 1}
+
     roof = None
+    lb = hlib.get()
     if not args.no_roofline:
         # second pass of the same K steps with HIP-event brackets around the dominant kernels.  EVERY rank runs it (the
         # step contains the gradient all-reduce: a rank stepping alone would wait for its peers forever); rank 0 reports.
-        lb = hlib.get()
         if rank == 0:
             lb.call("howl_profile_enable", 1)
         for _ in range(args.steps):
-            trainer.step(pcm, labels)
+            step()
         barrier()
         if rank == 0:
             lb.call("howl_profile_enable", 0)
     if not args.no_roofline and rank == 0:
 
         def read(tag, reset=0):
-            tot, cnt = ctypes.c_double(0), ctypes.c_int(0)
-            lb.call("howl_profile_read", tag.encode(), ctypes.byref(tot), ctypes.byref(cnt), reset)
-            return tot.value, cnt.value
+            tot, cnt, work = ctypes.c_double(0), ctypes.c_int(0), ctypes.c_double(0)
+            lb.call("howl_profile_read_work", tag.encode(), ctypes.byref(tot), ctypes.byref(cnt), ctypes.byref(work), reset)
+            return tot.value, cnt.value, work.value
 
-        tf, nf = read("conv3x3_fwd")
-        td, nd = read("conv3x3_dgrad")
-        tw, nw = read("wgrad")
-        tl, nl = read("logmel", reset=1)
-        H = (1 + L // 200) // 3
-        flops_launch = 2.0 * 9 * 45 * 45 * (H * 10) * B
-        # the forward launches run alone on the device; dgrad and wgrad of a layer share it (two HIP queues, half the CUs
-        # each), so their event-bracketed durations include the sharing and are listed under other_kernels only
-        avg_ms = tf / max(nf, 1)
-        achieved = flops_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
-        traffic, traffic_src = pmc_traffic() if (B == 512 and L == 16000) else (None, None)
-        roof = {"bound": "mfma", "kernel": "conv3x3_mfma_kernel<0> (45->45 3x3 convolution, forward launches)",
-                "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
-                "traffic": None if traffic is None else round(traffic),
-                "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)", "traffic_source": traffic_src,
-                # input + output maps always; the residual on half of the forward launches
-                "algorithmic_bytes": round(4.0 * 45 * (H * 10) * B * 2.5),
-                "avg_launch_ms": round(avg_ms, 4), "launches": nf,
-                "other_kernels": {
-                    "note": "dgrad and wgrad of a layer run concurrently on half the CUs each: per-launch durations overlap",
-                    "conv3x3_dgrad": {"avg_launch_ms": round(td / max(nd, 1), 4), "launches": nd},
-                    "wgrad_mfma": {"avg_launch_ms": round(tw / max(nw, 1), 4), "launches": nw},
-                    "dgrad+wgrad_pair": {"tflops": round(2 * flops_launch / (max(td / max(nd, 1), tw / max(nw, 1)) * 1e-3) / 1e12, 2)
-                                         if tw > 0 and td > 0 else None},
-                    "logmel": {"avg_launch_ms": round(tl / max(nl, 1), 4),
-                               "hbm_gbs": round((4.0 * L + 4.0 * 40 * (1 + L // 200)) * B / (tl / max(nl, 1) * 1e-3) / 1e9, 1)
-                               if tl > 0 else None, "hbm_frac": round((4.0 * L + 4.0 * 40 * (1 + L // 200)) * B /
-                                                                      (tl / max(nl, 1) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
-                               if tl > 0 else None}}}
+        T = 1 + L // 200
+        tl, nl, _ = read("logmel")
+        fe_bytes = (4.0 * L + 4.0 * 40 * T) * B
+        logmel = {"avg_launch_ms": round(tl / max(nl, 1), 4),
+                  "hbm_gbs": round(fe_bytes / (tl / max(nl, 1) * 1e-3) / 1e9, 1) if tl > 0 else None,
+                  "hbm_frac": round(fe_bytes / (tl / max(nl, 1) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if tl > 0 else None,
+                  "algorithmic_bytes": round(fe_bytes)}
+        if model_name == "res8":
+            tf, nf, _ = read("conv3x3_fwd")
+            td, nd, _ = read("conv3x3_dgrad")
+            tw, nw, _ = read("wgrad")
+            H = T // 3
+            flops_launch = 2.0 * 9 * 45 * 45 * (H * 10) * B
+            # the forward launches run alone on the device; dgrad and wgrad of a layer share it (two HIP queues, half the
+            # CUs each), so their event-bracketed durations include the sharing and are listed under other_kernels only
+            avg_ms = tf / max(nf, 1)
+            achieved = flops_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+            traffic, traffic_src = pmc_traffic() if (B == 512 and L == 16000) else (None, None)
+            roof = {"bound": "mfma", "kernel": "conv3x3_mfma_kernel<0> (45->45 3x3 convolution, forward launches)",
+                    "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
+                    "traffic": None if traffic is None else round(traffic),
+                    "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)", "traffic_source": traffic_src,
+                    # input + output maps always; the residual on half of the forward launches
+                    "algorithmic_bytes": round(4.0 * 45 * (H * 10) * B * 2.5),
+                    "algorithmic_flops": round(flops_launch),
+                    "avg_launch_ms": round(avg_ms, 4), "launches": nf,
+                    "other_kernels": {
+                        "note": "dgrad and wgrad of a layer run concurrently on half the CUs each: per-launch durations overlap",
+                        "conv3x3_dgrad": {"avg_launch_ms": round(td / max(nd, 1), 4), "launches": nd},
+                        "wgrad_mfma": {"avg_launch_ms": round(tw / max(nw, 1), 4), "launches": nw},
+                        "dgrad+wgrad_pair": {"tflops": round(2 * flops_launch / (max(td / max(nd, 1), tw / max(nw, 1)) * 1e-3)
+                                                             / 1e12, 2) if tw > 0 and td > 0 else None},
+                        "logmel": logmel}}
+        elif model_name == "seq-lstm":
+            parts = {t: read(t) for t in ("lstm_fwd", "lstm_bwd", "gemm")}
+            tot_ms = sum(p[0] for p in parts.values())
+            tot_fl = sum(p[2] for p in parts.values())
+            per_step = args.steps
+            achieved = tot_fl / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
+            roof = {"bound": "mfma", "kernel": "lstm_fwd4/lstm_bwd4 recurrences + the GEMMs around them (input projection, "
+                                               "head, weight gradients), summed",
+                    "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                    "algorithmic_flops": round(tot_fl / per_step), "avg_launch_ms": round(tot_ms / per_step, 4),
+                    "launches": sum(p[1] for p in parts.values()),
+                    "note": "algorithmic FLOPs and summed kernel time per STEP (the recurrences are latency-bound: T dependent steps)",
+                    "other_kernels": {k: {"ms_per_step": round(v[0] / per_step, 4), "launches_per_step": v[1] / per_step,
+                                          "tflops": round(v[2] / (v[0] * 1e-3) / 1e12, 2) if v[0] > 0 else None}
+                                      for k, v in parts.items()} | {"logmel": logmel}}
+        else:
+            ts, ns, wb = read("mb_sweep")
+            tg, ng, wf = read("gemm")
+            achieved = wb / (ts * 1e-3) / 1e9 if ts > 0 else 0.0
+            roof = {"bound": "hbm", "kernel": "BatchNorm / activation sweeps of the 53 conv+BN layers (col_reduce, bn_act_fwd, "
+                                              "bn_bwd_apply), summed",
+                    "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "algorithmic_bytes": round(wb / args.steps), "avg_launch_ms": round(ts / max(ns, 1), 4), "launches": ns,
+                    "note": "algorithmic bytes and summed kernel time per STEP; every sweep reads/writes its tensors once",
+                    "other_kernels": {"gemm": {"ms_per_step": round(tg / args.steps, 4), "launches_per_step": ng / args.steps,
+                                               "tflops": round(wf / (tg * 1e-3) / 1e12, 2) if tg > 0 else None},
+                                      "mb_sweep_ms_per_step": round(ts / args.steps, 4), "logmel": logmel}}
+        read("logmel", reset=1)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(L, C, args.cpu_baseline_seconds)
+        cpu = cpu_baseline(model_name, L, C, args.cpu_baseline_seconds)
 
     if rank == 0:
         total_utts = B * world * args.steps
+        step_desc = {"res8": "frontend+fwd+xent+bwd+AdamW", "seq-lstm": "frontend+LSTM+head+CTC+bwd+AdamW",
+                     "mobilenet": "device collate (timeshift+noise)+frontend+fwd+xent+bwd+AdamW"}[model_name]
         out = {
-            "metric": "utterances/sec/node (res8 end-to-end training step, 1s@16kHz, 40-mel)",
+            "metric": f"utterances/sec/node ({model_name} end-to-end training step, {L / 16000:g}s@16kHz, 40-mel)",
             "value": round(total_utts / dt, 1), "unit": "utterances/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"res8 GSC-12 training step (frontend+fwd+loss+bwd+AdamW), {B} x {L / 16000:g} s "
-                                   f"utterances per GPU (BASELINE configs[2] per-GPU share)",
-                       "global_batch": B * world, "samples_per_utterance": L, "labels": C,
+            "config": {"workload": f"{model_name} training step ({step_desc}), {B} x {L / 16000:g} s utterances per GPU, "
+                                   f"{C} labels -- BASELINE {cfg_desc}",
+                       "name": args.config, "global_batch": B * world, "samples_per_utterance": L, "labels": C,
                        "parallelism": f"dp{world}" if world > 1 else "single"},
             "final_loss": round(final_loss, 5),
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "cpu_baseline": cpu, "rccl": rccl,
         }
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -2,8 +2,10 @@
 16 kHz mono int16 wav) with the split / label rules of ``howl/data/dataset/gsc_dataset_loader.py:19-47``, a synthetic
 stand-in for boxes without a dataset, and a device-resident clip bank with ``batchify`` semantics
 (``howl/data/transform/operator.py:77-86``: sort by length descending, zero-pad right)."""
+import json
 import wave
 from pathlib import Path
+from types import SimpleNamespace
 from typing import List, Tuple
 
 import numpy as np
@@ -85,3 +87,50 @@ def synthetic_bank(n: int, max_len: int, num_labels: int, device, seed=0) -> Cli
     pcm = synthetic_pcm(n, max_len, seed=seed)
     labels = [(i % 64) % num_labels for i in range(n)]     # the tone frequency of clip i encodes its label
     return ClipBank([pcm[i] for i in range(n)], labels, max_len, device)
+
+
+# ---- wake-word datasets (training.run.train) --------------------------------------------------------------------------
+def load_howl_splits(path: Path, prefix: str = "aligned-"):
+    """A Howl-format dataset directory (``howl/data/dataset/dataset_loader.py:34-70``, ``WakeWordDatasetLoader``):
+    ``<prefix>metadata-{training,dev,test}.jsonl`` with one JSON object per line (``path``, ``transcription``,
+    ``end_timestamps`` per character in ms) and the clips under ``audio/``.  -> three lists of metadata records."""
+    path = Path(path)
+
+    def load(name):
+        out = []
+        with (path / f"{prefix}metadata-{name}.jsonl").open() as f:
+            for line in f:
+                if line.strip():
+                    d = json.loads(line)
+                    out.append(SimpleNamespace(path=(path / "audio" / d["path"]).absolute(), transcription=d["transcription"],
+                                               end_timestamps=d.get("end_timestamps")))
+        return out
+
+    return load("training"), load("dev"), load("test")
+
+
+class WakeWordClipBank:
+    """Clips of a wake-word split decoded once and kept on the device as one (N, Lmax) matrix, each with the descriptor the
+    batchifiers work on (``DeviceClip``: bank row, length, frame labels from the context's labeler, transcription)."""
+
+    def __init__(self, clips: List[torch.Tensor], metadata: list, labeler, device):
+        from howl_amd.data.transform.batchifier import DeviceClip
+        lmax = max(c.numel() for c in clips)
+        audio = torch.zeros(len(clips), lmax)
+        for i, c in enumerate(clips):
+            audio[i, : c.numel()] = c
+        self.audio = audio.to(device)
+        self.lengths = torch.tensor([c.numel() for c in clips])
+        self.examples = []
+        for i, (c, m) in enumerate(zip(clips, metadata)):
+            tl = labeler.compute_frame_labels(m).timestamp_label_map if m.end_timestamps is not None else {}
+            self.examples.append(DeviceClip(i, c.numel(), tl, m.transcription))
+
+    def __len__(self):
+        return len(self.examples)
+
+    def clip(self, i: int) -> torch.Tensor:
+        return self.audio[i, : self.examples[i].num_samples]
+
+    def subset(self, keep) -> List[int]:
+        return [i for i, ex in enumerate(self.examples) if keep(ex)]

@@ -1,33 +1,43 @@
-"""``python -m training.run.train --model res8 --workspace W [--load-weights --load-last --eval-freq N --eval]`` on MI355X.
+"""``python -m training.run.train --model M --workspace W -i DS... [--load-weights --load-last --eval-freq N --eval]`` on MI355X.
 
 The training / evaluation flow of ``training/run/train.py:35-324`` of the reference for the two objectives its presets
 use (``envs/res8.env``: frame-level cross-entropy; ``envs/seq-lstm.env``: CTC): InferenceContext label space, ZMUV pass,
-``model.streaming()``, per-step  frontend -> ZMUV -> SpecAugment -> model -> loss -> AdamW, per-epoch LR decay, evaluation
-every ``--eval-freq`` epochs through ``FrameInferenceEngine`` / ``InferenceEngine`` with TP/FN (positive clips) and FP/TN
-(negative clips) counts written to ``<threshold>_results.csv`` like ``train.py:66-94``.
+``model.streaming()``, per step  collate -> frontend -> ZMUV -> SpecAugment -> model -> loss -> AdamW, per-epoch LR decay and
+``streaming_state`` reset, evaluation every ``--eval-freq`` epochs through ``FrameInferenceEngine`` / ``InferenceEngine`` with
+TP/FN (positive clips) and FP/TN (negative clips) counts written to ``<threshold>_results.csv`` like ``train.py:66-94``.
 
-Datasets: the reference's aligned-metadata dataset stack (``howl/data/dataset``, ``howl/dataset*``) is disk I/O outside the
-MI355X hot path; this entry point trains on generated wake-word clips (``--synthetic N``): word w of the vocabulary is a
-tone burst of its own pitch, positives are the full sequence, negatives are shuffled / partial sequences, and the frame
-batchifier semantics (window ending at a word's end timestamp -> that word's label, else the negative label;
-``batchifier.py:56-118``) are applied to the known burst boundaries.
+What is different is where the work happens.  The reference decodes and collates in DataLoader worker processes; here every
+split is decoded once into a device-resident clip bank (``WakeWordClipBank``) and the collate chain of ``train.py:211-229``
+-- ``[DatasetMixer,] TimeshiftTransform, NoiseTransform, WakeWordFrameBatchifier | AudioSequenceBatchifier`` -- is a set of
+host decisions (the reference's draws, in its order) followed by ONE device launch per batch (``DeviceCollate``).
+``TimestretchTransform`` (librosa phase vocoder) is outside the hot path and not applied.
+
+Datasets: ``-i`` takes Howl-format dataset directories (``aligned-metadata-{training,dev,test}.jsonl`` + ``audio/*.wav``,
+16 kHz mono int16 -- resampling / other codecs are the reference's librosa path and out of scope); ``--synthetic N``
+generates wake-word clips instead (word w of the vocabulary is a tone burst of its own pitch; positives are the wake
+sequence, negatives shuffled / partial sequences) in the same metadata form, so both go through the same labeler.
 """
 import argparse
 import csv
 import random
 from pathlib import Path
+from types import SimpleNamespace
 
 import numpy as np
 import torch
 
 from howl_amd import ops
 from howl_amd.context import InferenceContext
+from howl_amd.data.collate import DeviceCollate
+from howl_amd.data.common.tokenizer import WakeWordTokenizer
+from howl_amd.data.transform.batchifier import AudioSequenceBatchifier, WakeWordFrameBatchifier
 from howl_amd.data.transform.operator import ZmuvTransform
 from howl_amd.data.transform.transform import SpecAugmentTransform, StandardAudioTransform
 from howl_amd.model import RegisteredModel
 from howl_amd.model.inference import FrameInferenceEngine, InferenceEngine
 from howl_amd.settings import SETTINGS
-from howl_amd.training.fused import FusedRes8Trainer
+from howl_amd.training.data import WakeWordClipBank, load_howl_splits, read_wav16k
+from howl_amd.training.fused import FusedTrainer
 from howl_amd.utils.random_utils import set_random_seed
 from howl_amd.workspace import Workspace
 
@@ -36,46 +46,38 @@ WORD_S = 0.3     # seconds per word burst
 GAP_S = 0.08
 
 
-def make_clip(words, n_vocab, rng):
-    """Tone bursts for the word ids in ``words``; returns (pcm, [(word, end_sample), ...])."""
-    parts, ends, pos = [np.zeros(int(0.15 * SR), np.float32)], [], int(0.15 * SR)
-    for w in words:
+def make_clip(word_ids, vocab, rng):
+    """Tone bursts for ``word_ids``; returns (pcm, metadata) with per-character end timestamps (ms) like an aligned
+    dataset record: the characters of a word are spread evenly over its burst, the space after it ends with the word."""
+    lead = int(0.15 * SR)
+    parts, stamps, pos = [np.zeros(lead, np.float32)], [], lead
+    words = [vocab[w] for w in word_ids]
+    for k, (w, text) in enumerate(zip(word_ids, words)):
         n = int(WORD_S * SR)
-        f = 300.0 + 450.0 * w
         t = np.arange(n) / SR
-        burst = (0.3 * np.sin(2 * np.pi * f * t) * np.hanning(n)).astype(np.float32)
-        parts += [burst, np.zeros(int(GAP_S * SR), np.float32)]
-        pos += n
-        ends.append((w, pos))
-        pos += int(GAP_S * SR)
+        parts += [(0.3 * np.sin(2 * np.pi * (300.0 + 450.0 * w) * t) * np.hanning(n)).astype(np.float32),
+                  np.zeros(int(GAP_S * SR), np.float32)]
+        start_ms, end_ms = pos / SR * 1000, (pos + n) / SR * 1000
+        stamps += [start_ms + (end_ms - start_ms) * (c + 1) / len(text) for c in range(len(text))]
+        if k + 1 < len(words):
+            stamps.append(end_ms)
+        pos += n + int(GAP_S * SR)
     parts.append(np.zeros(int(0.2 * SR), np.float32))
-    pcm = np.concatenate(parts) + 0.01 * rng.standard_normal(sum(len(p) for p in parts)).astype(np.float32)
-    return pcm, ends
+    pcm = np.concatenate(parts)
+    pcm = pcm + 0.01 * rng.standard_normal(pcm.size).astype(np.float32)
+    return torch.from_numpy(pcm), SimpleNamespace(path=None, transcription=" ".join(words), end_timestamps=stamps)
 
 
-def frame_examples(pcm, ends, window, negative_label, rng):
-    """WakeWordFrameBatchifier semantics: one window ending at each word's end (label = word), plus one random window
-    labelled negative unless it ends within 45 ms of a word end (batchifier.py:74-110, simplified to known boundaries)."""
-    out = []
-    for w, e in ends:
-        a = max(0, e - window)
-        out.append((pcm[a:e], w))
-    e = int(rng.integers(window // 2, len(pcm)))
-    if all(abs(e - we) > 0.045 * SR for _, we in ends):
-        out.append((pcm[max(0, e - window):e], negative_label))
-    return out
-
-
-def pad_batch(clips, window, device):
-    """tensorize_audio_data(max_length=window, rand_append=True): zero padding on a random side (operator.py:89-109)."""
-    audio = torch.zeros(len(clips), window)
-    for i, c in enumerate(clips):
-        c = torch.from_numpy(c)
-        if random.random() < 0.5:
-            audio[i, window - c.numel():] = c
-        else:
-            audio[i, : c.numel()] = c
-    return audio.to(device)
+def synthetic_split(n, positive, vocab, seq, rng):
+    clips, meta = [], []
+    for _ in range(n):
+        ids = list(seq) if positive else [int(v) for v in rng.permutation(len(vocab))[: int(rng.integers(1, len(vocab) + 1))]]
+        if not positive and ids == list(seq):
+            ids = ids[::-1]
+        c, m = make_clip(ids, vocab, rng)
+        clips.append(c)
+        meta.append(m)
+    return clips, meta
 
 
 def main(argv=None):
@@ -84,83 +86,101 @@ def main(argv=None):
     ap.add_argument("--workspace", type=str, default=str(Path("workspaces") / "default"))
     ap.add_argument("--load-weights", action="store_true")
     ap.add_argument("--load-last", action="store_true")
+    ap.add_argument("--dataset-paths", "-i", type=str, nargs="+", default=[])
     ap.add_argument("--eval-freq", type=int, default=10)
     ap.add_argument("--eval", action="store_true")
-    ap.add_argument("--synthetic", type=int, default=0, help="number of generated training clips")
+    ap.add_argument("--synthetic", type=int, default=0, help="number of generated positive training clips (no -i needed)")
     args = ap.parse_args(argv)
-    if not args.synthetic:
-        raise SystemExit("training.run.train on MI355X: dataset loading (howl/data/dataset) is outside the hot path; "
-                         "pass --synthetic N to train on generated wake-word clips")
+    if not args.synthetic and not args.dataset_paths:
+        raise SystemExit("training.run.train: give Howl-format dataset directories with -i, or --synthetic N")
 
     use_frame = SETTINGS.training.objective == "frame"
-    ctx = InferenceContext(SETTINGS.training.vocab, token_type=SETTINGS.training.token_type, use_blank=not use_frame)
+    set_random_seed(SETTINGS.training.seed)
     ws = Workspace(Path(args.workspace), delete_existing=not args.eval)
     writer = ws.summary_writer
     device = torch.device(SETTINGS.training.device)
-    set_random_seed(SETTINGS.training.seed)
+    ctx = InferenceContext(SETTINGS.training.vocab, token_type=SETTINGS.training.token_type, use_blank=not use_frame)
     rng = np.random.default_rng(SETTINGS.training.seed)
-    n_vocab = len(SETTINGS.training.vocab)
+    vocab = list(SETTINGS.training.vocab)
     seq = list(SETTINGS.inference_engine.inference_sequence)
-    window = int(SETTINGS.training.max_window_size_seconds * SR)
 
-    def dataset(n, positive):
-        clips = []
-        for _ in range(n):
-            words = list(seq) if positive else list(rng.permutation(n_vocab))[: int(rng.integers(1, n_vocab + 1))]
-            if not positive and words == seq:
-                words = words[::-1]
-            clips.append(make_clip(words, n_vocab, rng))
-        return clips
+    # ---- datasets -> device clip banks ----------------------------------------------------------------------------
+    splits = {"training": ([], []), "dev": ([], []), "test": ([], [])}
+    for ds_path in args.dataset_paths:
+        for name, records in zip(("training", "dev", "test"), load_howl_splits(Path(ds_path))):
+            for m in records:
+                splits[name][0].append(read_wav16k(m.path))
+                splits[name][1].append(m)
+    if args.synthetic:
+        for name, n_pos, n_neg in (("training", args.synthetic, args.synthetic // 2), ("dev", 32, 32)):
+            for positive, n in ((True, n_pos), (False, n_neg)):
+                c, m = synthetic_split(n, positive, vocab, seq, rng)
+                splits[name][0].extend(c)
+                splits[name][1].extend(m)
+    train_bank = WakeWordClipBank(*splits["training"], ctx.labeler, device)
+    dev_bank = WakeWordClipBank(*splits["dev"], ctx.labeler, device) if splits["dev"][0] else train_bank
+    is_pos = lambda ex: ctx.searcher.search(ex.transcription)      # train.py:176-183
+    dev_pos, dev_neg = dev_bank.subset(is_pos), dev_bank.subset(lambda ex: not is_pos(ex))
 
-    train_clips = dataset(args.synthetic, True) + dataset(args.synthetic // 2, False)
-    dev_pos, dev_neg = dataset(32, True), dataset(32, False)
+    # ---- collate chain: host draws + one launch per batch (train.py:196-229) ------------------------------------------------
+    window_ms = int(SETTINGS.training.max_window_size_seconds * 1000)
+    if use_frame:
+        batchifier = WakeWordFrameBatchifier(ctx.negative_label, window_size_ms=window_ms)
+    else:
+        batchifier = AudioSequenceBatchifier(ctx.negative_label, WakeWordTokenizer(ctx.vocab, ignore_oov=False))
+    collate = DeviceCollate(train_bank.audio, train_bank.lengths, None, max_len=train_bank.audio.shape[1])
 
     std_transform = StandardAudioTransform().to(device).eval()
     zmuv_transform = ZmuvTransform().to(device)
     model = RegisteredModel.find_registered_class(args.model)(ctx.num_labels).to(device).streaming()
-    spectrogram_augmentations = (SpecAugmentTransform(),)      # train.py:277-278
-    for pcm, _ in train_clips[:256]:
-        zmuv_transform.update(std_transform(torch.from_numpy(pcm[:window * 4]).to(device)[None]))
+    spectrogram_augmentations = (SpecAugmentTransform().train(),)      # train.py:277-278
+    if (ws.path / "zmuv.pt.bin").exists():
+        zmuv_transform.load_state_dict(torch.load(str(ws.path / "zmuv.pt.bin")))
+        zmuv_transform.to(device)
+    else:
+        for i in rng.permutation(len(train_bank))[:2001]:              # prep_dl: single shuffled examples (train.py:231-245)
+            zmuv_transform.update(std_transform(train_bank.clip(int(i))[None]))
     torch.save({k: v.cpu() for k, v in zmuv_transform.state_dict().items()}, str(ws.path / "zmuv.pt.bin"))
     if args.load_weights:
         ws.load_model(model, best=not args.load_last)
         model.to(device)
 
-    def evaluate_engine(clips, prefix, positive, epoch):
+    def evaluate_engine(bank, ids, prefix, positive, epoch):
         """train.py:42-94: run the engine over each clip, count detections."""
         std_transform.eval()
         model.eval()
         if use_frame:
-            engine = FrameInferenceEngine(int(SETTINGS.training.max_window_size_seconds * 1000),
-                                          int(SETTINGS.training.eval_stride_size_seconds * 1000), model, zmuv_transform, ctx)
+            engine = FrameInferenceEngine(window_ms, int(SETTINGS.training.eval_stride_size_seconds * 1000), model,
+                                          zmuv_transform, ctx)
         else:
             engine = InferenceEngine(model, zmuv_transform, ctx)
-        tp = sum(int(bool(_infer(engine, pcm))) for pcm, _ in clips)
-        n = len(clips)
-        conf = dict(tp=tp, fn=n - tp, fp=0, tn=0) if positive else dict(tp=0, fn=0, fp=tp, tn=n - tp)
+        hits = 0
+        for i in ids:
+            engine.reset()
+            model.streaming_state = None
+            hits += int(bool(engine.infer(bank.clip(i))))
+        model.streaming_state = None       # whatever the last clip left behind must not leak into training batches
+        n = len(ids)
+        conf = dict(tp=hits, fn=n - hits, fp=0, tn=0) if positive else dict(tp=0, fn=0, fp=hits, tn=n - hits)
         with (ws.path / f"{engine.threshold}_results.csv").open("a") as f:
             csv.writer(f).writerow([prefix, epoch, conf["tp"], conf["tn"], conf["fp"], conf["fn"]])
-        writer.add_scalar(f"{prefix}/Metric/tp_rate" if positive else f"{prefix}/Metric/fp_rate", tp / n, epoch)
+        writer.add_scalar(f"{prefix}/Metric/tp_rate" if positive else f"{prefix}/Metric/fp_rate", hits / max(n, 1), epoch)
         return conf
-
-    def _infer(engine, pcm):
-        engine.reset()
-        model.streaming_state = None
-        return engine.infer(torch.from_numpy(pcm).to(device))
 
     if args.eval:
         ws.load_model(model, best=not args.load_last)
         model.to(device)
-        print(evaluate_engine(dev_pos, "Dev positive", True, 0), evaluate_engine(dev_neg, "Dev negative", False, 0))
-        return
+        pos, neg = evaluate_engine(dev_bank, dev_pos, "Dev positive", True, 0), evaluate_engine(dev_bank, dev_neg, "Dev negative", False, 0)
+        print(pos, neg)
+        return pos, neg
 
     ws.write_args(args)
     ws.save_settings(SETTINGS)
     params = [p for p in model.parameters() if p.requires_grad]
     fused = (use_frame and args.model in ("res8", "mobilenet")) or (not use_frame and args.model == "seq-lstm")
     if fused:
-        trainer = FusedRes8Trainer(model, std_transform, zmuv_transform, SETTINGS.training.learning_rate,
-                                   weight_decay=SETTINGS.training.weight_decay)
+        trainer = FusedTrainer(model, std_transform, zmuv_transform, SETTINGS.training.learning_rate,
+                               weight_decay=SETTINGS.training.weight_decay)
     else:
         optimizer = torch.optim.AdamW(params, SETTINGS.training.learning_rate, weight_decay=SETTINGS.training.weight_decay)
     criterion = torch.nn.CrossEntropyLoss()                        # frame objective; the CTC objective is ops.ctc_loss below
@@ -168,59 +188,59 @@ def main(argv=None):
     for epoch_idx in range(SETTINGS.training.num_epochs):
         std_transform.train()
         model.train()
-        order = rng.permutation(len(train_clips))
+        model.streaming_state = None                               # train.py:284
+        order = [int(v) for v in rng.permutation(len(train_bank))]
         total_loss = torch.zeros((), device=device)
-        for i in range(0, len(order) - B + 1, B):
-            batch = [train_clips[j] for j in order[i:i + B]]
+        n_batches = 0
+        for i in range(0, len(order), B):
+            examples = [train_bank.examples[j] for j in order[i:i + B]]
             if use_frame:
-                ex = [e for pcm, ends in batch for e in frame_examples(pcm, ends, window, ctx.negative_label, rng)][:B * 4]
-                audio = pad_batch([c for c, _ in ex], window, device)
-                labels = torch.tensor([l for _, l in ex]).to(device)
-                feats = std_transform.log_mel_for_model(audio, zmuv_transform)
-                for aug in spectrogram_augmentations:
+                batch = collate.frame_batch(examples, batchifier)
+                frame_lengths = std_transform.compute_lengths(batch.lengths)
+                feats = std_transform.log_mel_for_model(batch.audio_data, zmuv_transform)
+                for aug in spectrogram_augmentations:              # after ZMUV, for both objectives (train.py:289-290)
                     feats = aug(feats)
                 if fused:
-                    loss = trainer.step_on_features(feats, labels)
+                    loss = trainer.step_on_features(feats, batch.labels)
                 else:
-                    scores = model(feats, std_transform.compute_lengths(torch.full((len(ex),), window)))
+                    scores = model(feats, frame_lengths)
                     optimizer.zero_grad()
-                    loss = criterion(scores, labels)
+                    loss = criterion(scores, batch.labels)
                     loss.backward()
                     optimizer.step()
             else:
-                batch = sorted(batch, key=lambda c: -len(c[0]))            # AudioSequenceBatchifier: longest first
-                lmax = len(batch[0][0])
-                audio = torch.zeros(len(batch), lmax)
-                for k, (pcm, _) in enumerate(batch):
-                    audio[k, : len(pcm)] = torch.from_numpy(pcm)
-                lengths = std_transform.compute_lengths(torch.tensor([len(p) for p, _ in batch]))
-                feats = std_transform.log_mel_for_model(audio.to(device), zmuv_transform)
-                tl = torch.tensor([len(e) for _, e in batch])
-                targets = torch.zeros(len(batch), max(1, int(tl.max())), dtype=torch.long)
-                for k, (_, ends) in enumerate(batch):
-                    targets[k, : len(ends)] = torch.tensor([w for w, _ in ends])
+                batch = collate.sequence_batch(examples, batchifier)
+                frame_lengths = std_transform.compute_lengths(batch.audio_lengths)
+                feats = std_transform.log_mel_for_model(batch.audio_data, zmuv_transform)
+                for aug in spectrogram_augmentations:
+                    feats = aug(feats)
+                if model.streaming_state is not None and model.streaming_state[0].shape[1] != feats.shape[0]:
+                    model.streaming_state = None                   # a ragged last batch cannot inherit the carried state
+                max_target = int(batch.label_lengths.max())
                 # log_softmax + CTCLoss(blank) of train.py:291-296 as one fused kernel (loss and d loss / d scores)
                 if fused:
-                    loss = trainer.step_sequence_on_features(feats, lengths, targets, tl, ctx.blank_label, int(tl.max()))
+                    loss = trainer.step_sequence_on_features(feats, frame_lengths, batch.labels, batch.label_lengths,
+                                                             ctx.blank_label, max_target)
                 else:
-                    scores = model(feats, lengths)
+                    scores = model(feats, frame_lengths)
                     optimizer.zero_grad()
-                    loss = ops.ctc_loss(scores, targets, lengths, tl, ctx.blank_label)
+                    loss = ops.ctc_loss(scores, batch.labels, frame_lengths, batch.label_lengths, ctx.blank_label)
                     loss.backward()
                     optimizer.step()
             total_loss += loss.detach().reshape(())                       # accumulated on the device (train.py:303-304)
+            n_batches += 1
         if fused:
             trainer.decay_lr(SETTINGS.training.lr_decay)
         else:
             for group in optimizer.param_groups:
                 group["lr"] *= SETTINGS.training.lr_decay
-        writer.add_scalar("Training/Loss", total_loss / max(1, len(order) // B), epoch_idx)
+        writer.add_scalar("Training/Loss", total_loss / max(1, n_batches), epoch_idx)
         if epoch_idx % args.eval_freq == 0 and epoch_idx != 0:
-            evaluate_engine(dev_pos, "Dev positive", True, epoch_idx)
-            evaluate_engine(dev_neg, "Dev negative", False, epoch_idx)
+            evaluate_engine(dev_bank, dev_pos, "Dev positive", True, epoch_idx)
+            evaluate_engine(dev_bank, dev_neg, "Dev negative", False, epoch_idx)
         ws.save_model(model, best=False)
-    pos = evaluate_engine(dev_pos, "Dev positive", True, SETTINGS.training.num_epochs)
-    neg = evaluate_engine(dev_neg, "Dev negative", False, SETTINGS.training.num_epochs)
+    pos = evaluate_engine(dev_bank, dev_pos, "Dev positive", True, SETTINGS.training.num_epochs)
+    neg = evaluate_engine(dev_bank, dev_neg, "Dev negative", False, SETTINGS.training.num_epochs)
     ws.increment_model(model, pos["tp"] - neg["fp"])
     writer.close()
     print("dev positive:", pos, "dev negative:", neg)

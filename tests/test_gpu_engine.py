@@ -136,11 +136,56 @@ def test_train_entry_point_synthetic(tmp_path, monkeypatch, model, objective):
     SETTINGS.reset()
     from howl_amd.training.run import train
     ws = tmp_path / "ws"
-    pos, neg = train.main(["--model", model, "--workspace", str(ws), "--synthetic", "96", "--eval-freq", "2"])
+    # --eval-freq 1: an in-training evaluation after every epoch (streaming state left behind by the engines must not leak
+    # into the next epoch's batches; train.py:284)
+    pos, neg = train.main(["--model", model, "--workspace", str(ws), "--synthetic", "96", "--eval-freq", "1"])
     assert pos["tp"] + pos["fn"] == 32 and neg["fp"] + neg["tn"] == 32
     import json
     lines = [json.loads(l) for l in (ws / "logs" / "scalars.jsonl").read_text().splitlines()]
     losses = [l["value"] for l in lines if l["tag"] == "Training/Loss"]
     assert len(losses) == 3 and losses[-1] < losses[0]
     assert (ws / "model.pt.bin").exists() and (ws / "zmuv.pt.bin").exists() and (ws / "0.0_results.csv").exists()
+    SETTINGS.reset()
+
+
+def test_train_entry_point_on_a_howl_format_dataset(tmp_path, monkeypatch):
+    """`python -m training.run.train -i DS`: a dataset directory in the reference's layout (aligned-metadata-*.jsonl +
+    audio/*.wav, dataset_loader.py:34-70) is decoded into the device clip bank, labelled by the context's frame labeler and
+    trained on through the device collate chain."""
+    import json
+    import wave
+    import numpy as np
+    from types import SimpleNamespace
+    env = dict(NUM_EPOCHS="2", BATCH_SIZE="16", MAX_WINDOW_SIZE_SECONDS="0.5", LEARNING_RATE="0.01", LR_DECAY="0.955",
+               WEIGHT_DECAY="0.00001", NUM_MELS="40", DEVICE="cuda:0", OBJECTIVE="frame", TOKEN_TYPE="word",
+               VOCAB='["hey","fire","fox"]', INFERENCE_SEQUENCE="[0,1,2]", INFERENCE_THRESHOLD="0", SMOOTHING_WINDOW_MS="50")
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    from howl_amd.settings import SETTINGS
+    SETTINGS.reset()
+    from howl_amd.training.run import train
+    ds = tmp_path / "ds"
+    (ds / "audio").mkdir(parents=True)
+    rng = np.random.default_rng(0)
+    vocab = ["hey", "fire", "fox"]
+    for split, n in (("training", 48), ("dev", 12), ("test", 4)):
+        with (ds / f"aligned-metadata-{split}.jsonl").open("w") as f:
+            for i in range(n):
+                ids = [0, 1, 2] if i % 2 == 0 else [int(v) for v in rng.permutation(3)[: 1 + i % 3]]
+                if ids == [0, 1, 2] and i % 2:
+                    ids = [2, 1, 0]
+                pcm, meta = train.make_clip(ids, vocab, rng)
+                name = f"{split}_{i}.wav"
+                with wave.open(str(ds / "audio" / name), "wb") as w:
+                    w.setnchannels(1); w.setsampwidth(2); w.setframerate(16000)
+                    w.writeframes((pcm.numpy().clip(-1, 1) * 32767).astype("<i2").tobytes())
+                f.write(json.dumps(dict(path=name, transcription=meta.transcription, end_timestamps=meta.end_timestamps,
+                                        phone_strings=None, words=None, phone_end_timestamps=None)) + "\n")
+    ws = tmp_path / "ws"
+    pos, neg = train.main(["--model", "res8", "--workspace", str(ws), "-i", str(ds), "--eval-freq", "1"])
+    assert pos["tp"] + pos["fn"] == 6 and neg["fp"] + neg["tn"] == 6
+    lines = [json.loads(l) for l in (ws / "logs" / "scalars.jsonl").read_text().splitlines()]
+    losses = [l["value"] for l in lines if l["tag"] == "Training/Loss"]
+    assert len(losses) == 2 and all(v == v for v in losses)
+    assert (ws / "model.pt.bin").exists() and (ws / "zmuv.pt.bin").exists()
     SETTINGS.reset()

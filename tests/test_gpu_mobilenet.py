@@ -166,3 +166,57 @@ def test_two_queue_backward_is_bit_identical_to_single_queue(monkeypatch):
     assert torch.equal(run(), two)
     monkeypatch.setenv("HOWL_MOBILENET_BWD_QUEUES", "1")
     assert torch.equal(run(), two)
+
+
+def test_config5_at_full_size_with_device_collate():
+    """BASELINE configs[4] at its per-GPU size: 512 x 1 s, 12 labels, the timeshift + white / salt-pepper collate on the
+    device (all gates OPEN) feeding FusedTrainer.step.  (a) the first step's training-mode logits at B = 512 agree with the
+    oracle's forward on the very batch the device collate produced (<= 1e-3, argmax exact) -- BatchNorm couples the whole
+    batch, so this is the full-size comparison, not a slice; (b) the loss is the oracle's; (c) two steps are finite and
+    (d) bit-repeatable from the same seeds."""
+    from howl_amd.data.collate import DeviceCollate
+    from howl_amd.data.transform.operator import ZmuvTransform
+    from howl_amd.data.transform.transform import StandardAudioTransform
+    from howl_amd.training.fused import FusedTrainer
+    from howl_amd.utils.synth import synthetic_pcm
+    from test_gpu_collate import _seed_with
+    B, L, C = 512, 16000, 12
+    pcm = synthetic_pcm(B, L)
+    lens = [L - 31 * (i % 40) for i in range(B)]
+    labels = torch.arange(B) % C
+    seed = _seed_with(lens, True, True, True)
+    std = StandardAudioTransform().to(DEV).eval()
+    zmuv = ZmuvTransform().to(DEV)
+    zmuv.update(std(pcm[:4].to(DEV)))
+    keep = (torch.rand(B, omb.LAST_CHANNEL, generator=torch.Generator().manual_seed(3)) >= 0.2).float()
+
+    def run():
+        model, sd = make_mobilenet(C)
+        model.forced_keep_mask = keep                    # the Dropout(0.2) draw of training mode, fixed for the comparison
+        trainer = FusedTrainer(model, std, zmuv, lr=0.001, weight_decay=0.0)      # envs/mobilenet.env
+        collate = DeviceCollate(pcm.to(DEV), torch.tensor(lens), labels.to(DEV), max_len=L, seed=seed)
+        first = None
+        for _ in range(2):
+            batch = collate(list(range(B)))
+            audio = torch.nn.functional.pad(batch.audio_data, (0, L - batch.audio_data.shape[1]))
+            loss = trainer.step(audio, batch.labels)
+            if first is None:
+                first = (audio.cpu(), batch.labels.cpu(), trainer.last_logits.cpu().clone(), loss.item())
+        torch.cuda.synchronize()
+        return sd, first, trainer.fp.flat.clone(), loss.item()
+
+    sd, (audio, lab, logits, loss0), flat, loss1 = run()
+    assert audio.abs().max().item() <= 1.0 and (audio[:, -1] == 0).any()          # cropped + padded rows are present
+    fb = ofe.mel_fb(40)
+    z = ofe.Zmuv()
+    z.update(ofe.standard_audio_transform(pcm[:4], fb))
+    x = z(ofe.standard_audio_transform(audio, fb))
+    osd = {k: v.clone() for k, v in sd.items()}
+    with torch.no_grad():
+        ref = omb.mobilenet_forward(osd, x, True, keep)
+    assert maxerr(logits, ref) < 1e-3, maxerr(logits, ref)
+    assert torch.equal(logits.argmax(1), ref.argmax(1))
+    assert abs(loss0 - torch.nn.functional.cross_entropy(ref, lab).item()) < 1e-4
+    assert torch.isfinite(flat).all() and loss1 == loss1
+    _, (audio2, _, logits2, _), flat2, _ = run()
+    assert torch.equal(audio2, audio) and torch.equal(logits2, logits) and torch.equal(flat2, flat)

@@ -45,23 +45,35 @@ def test_golden_eval_and_train(golden, C):
                 assert maxerr(bn.running_var, g[f"bn{i}.running_var.1"]) < 1e-5
         assert abs(loss.item() - float(g[f"loss{step}"])) < 1e-4
         opt.step()
+    # AdamW divides by sqrt(v): a weight whose gradient is rounding noise still moves by ~lr per step with the sign of that
+    # noise.  The oracle (pinned to these goldens by test_oracle_golden.py) replays the three steps to tell which weights
+    # had a gradient above rounding noise at EVERY step: those must match the reference's weights to 1e-4, the others may
+    # differ by the 3 * lr they can move.
+    sd_o, names = om.res8_init(C), om.res8_param_names()
+    opt_o = om.AdamWState([sd_o[n] for n in names], 0.01, 1e-5)
+    solid = {n: torch.ones_like(sd_o[n], dtype=torch.bool) for n in names}
+    for step in range(3):
+        _, _, og = om.train_step(lambda s_, xx: om.res8_forward(s_, xx, True), sd_o, names, opt_o, x, t(g["labels"]))
+        for n in names:
+            solid[n] &= og[n].abs() > 1e-5 * max(1.0, og[n].abs().max().item())
     sd = model.state_dict()
+    checked = 0
     for k, v in sd.items():
-        # AdamW divides by sqrt(v): a weight whose gradient is rounding noise still moves by ~lr per step with the sign
-        # of that noise, so a few elements legitimately differ by O(lr); everything else must agree tightly
         ref = t(g["sd3." + k]).double()
         d = (v.detach().cpu().double() - ref).abs()
         tol = 1e-4 * max(1.0, float(ref.abs().max()))
-        assert d.max().item() < 3 * 0.01 + tol, k
         if "running_" in k:
-            # BatchNorm statistics sit downstream of those few O(lr) weight differences: relative agreement only
+            # BatchNorm statistics sit downstream of the few O(lr) weight differences: relative agreement
             assert d.max().item() < 1e-3 * max(1.0, float(ref.abs().max())), k
-        else:
-            assert (d > tol).double().mean().item() < 1e-1, (k, (d > tol).double().mean().item())
+        elif k in solid:
+            assert d[solid[k]].max().item() < tol, (k, d[solid[k]].max().item())
+            assert d.max().item() < 3 * 0.01 + tol, k
+            checked += int(solid[k].sum())
+    assert checked > 0.9 * sum(v.numel() for v in solid.values())      # the mask excuses a small minority only
     assert int(sd["bn3.num_batches_tracked"]) == 3
     model.eval()
     with torch.no_grad():
-        assert maxerr(model(xd, None), g["eval_logits_after3"]) < 5e-3
+        assert maxerr(model(xd, None), g["eval_logits_after3"]) < LOGIT_TOL
 
 
 def test_golden_half_second_window(golden):
