@@ -133,7 +133,7 @@ def _trainer_worker(rank, world, port, out):
     sdl.update(dict(zip(names, params)))
     ref = torch.autograd.grad(torch.nn.functional.cross_entropy(om.res8_forward(sdl, x, True), labels[lo:hi]), params)
     ref = torch.cat([g.reshape(-1) for g in ref])
-    shard_err = ((seen["local"] - ref).abs().max() / ref.abs().max()).item()
+    shard_err = ((seen["local"] - ref).abs().max() / max(1.0, ref.abs().max().item())).item()
     locals_ = [torch.zeros_like(ref) for _ in range(world)]
     dist.all_gather(locals_, seen["local"])
     ws = [torch.zeros_like(weights) for _ in range(world)]

@@ -84,7 +84,7 @@ def _worker(rank, world, port, backend, out):
     ref = torch.autograd.grad(torch.nn.functional.cross_entropy(om.res8_forward(sdl, x, True), labels[lo:hi]), params)
     ref = torch.cat([g.reshape(-1) for g in ref])
     local = seen["local"].cpu()
-    shard_err = ((local - ref).abs().max() / ref.abs().max()).item()
+    shard_err = ((local - ref).abs().max() / max(1.0, ref.abs().max().item())).item()   # tolerance of test_gpu_res8
     gather = lambda t: [torch.zeros_like(t) for _ in range(world)]
     locals_, ws = gather(seen["local"]), gather(tr.fp.flat)
     dist.all_gather(locals_, seen["local"])
