@@ -353,12 +353,11 @@ def main():
                   "algorithmic_bytes": round(fe_bytes)}
         if model_name == "res8":
             tf, nf, _ = read("conv3x3_fwd")
-            td, nd, _ = read("conv3x3_dgrad")
-            tw, nw, _ = read("wgrad")
+            tp, npair, _ = read("bwd_pair")
             H = T // 3
             flops_launch = 2.0 * 9 * 45 * 45 * (H * 10) * B
-            # the forward launches run alone on the device; dgrad and wgrad of a layer share it (two HIP queues, half the
-            # CUs each), so their event-bracketed durations include the sharing and are listed under other_kernels only
+            # the forward launches run alone on the device; dgrad and wgrad of a layer share ONE launch (half the CUs
+            # each): its duration covers both and is listed under other_kernels
             avg_ms = tf / max(nf, 1)
             achieved = flops_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
             traffic, traffic_src = pmc_traffic() if (B == 512 and L == 16000) else (None, None)
@@ -372,11 +371,9 @@ def main():
                     "algorithmic_flops": round(flops_launch),
                     "avg_launch_ms": round(avg_ms, 4), "launches": nf,
                     "other_kernels": {
-                        "note": "dgrad and wgrad of a layer run concurrently on half the CUs each: per-launch durations overlap",
-                        "conv3x3_dgrad": {"avg_launch_ms": round(td / max(nd, 1), 4), "launches": nd},
-                        "wgrad_mfma": {"avg_launch_ms": round(tw / max(nw, 1), 4), "launches": nw},
-                        "dgrad+wgrad_pair": {"tflops": round(2 * flops_launch / (max(td / max(nd, 1), tw / max(nw, 1)) * 1e-3)
-                                                             / 1e12, 2) if tw > 0 and td > 0 else None},
+                        "bwd_pair_kernel (dgrad + wgrad of a layer in one launch)": {
+                            "avg_launch_ms": round(tp / max(npair, 1), 4), "launches": npair,
+                            "tflops": round(2 * flops_launch / (tp / max(npair, 1) * 1e-3) / 1e12, 2) if tp > 0 else None},
                         "logmel": logmel}}
         elif model_name == "seq-lstm":
             parts = {t: read(t) for t in ("lstm_fwd", "lstm_bwd", "gemm")}

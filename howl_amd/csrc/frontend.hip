@@ -7,18 +7,22 @@
 //   howl/data/transform/operator.py:119-146           (ZmuvTransform)
 //   howl/data/transform/transform.py:299-339          (SpecAugmentTransform masks)
 //
-// K1 design (one launch for the whole batch):
-//  * frames are flattened over (utterance, t): g = b*T + t; a workgroup (4 waves) owns 16 consecutive frames
-//    per iteration and is persistent over chunks (grid-stride), so its filterbank fragments, Hann window and
-//    twiddles stay in registers;
-//  * PCM is read straight from HBM/L2 as 256-B coalesced rows (lane j reads sample 64*n1 + j), with the
-//    reflect padding of torch.stft(center=True) folded into the index;
-//  * two real frames ride in one complex FFT-512 (frame A = re, frame B = im). The FFT is radix-8 x 3 on one
-//    wavefront: 8 points per lane in registers, two transposes through a private LDS scratch;
-//  * |X|^2 for 257 bins lands in LDS as a [16][260] tile, and the dense mel contraction runs on
-//    v_mfma_f32_16x16x4_f32 (exact fp32 FMA chain): M = 16 frames, N = 16*NT mel bins, K = 260 split
-//    over the 4 waves, partials combined through LDS;
-//  * epilogue: log(x + eps), optional ZMUV (x - mean) / std, store as (B,T,M) [model layout] or (B,M,T).
+// K1 design (one launch for the whole batch): every WAVEFRONT is an independent worker -- no workgroup barrier anywhere.
+//  * frames are flattened over (utterance, t): g = b*T + t; a wave owns "quads" of 4 consecutive frames (grid-stride), i.e.
+//    two frame PAIRS, and keeps its Hann window and twiddles in registers;
+//  * PCM is read straight from HBM/L2 as 256-B coalesced rows (lane j reads sample 64*n1 + j), with the reflect padding of
+//    torch.stft(center=True) folded into the index; the next pair's samples are requested before the current FFT starts;
+//  * two real frames ride in one complex FFT-512 (frame A = re, frame B = im): radix-8 x 3 on one wavefront, 8 points per
+//    lane in registers, two transposes through the wave's private LDS scratch (wave-scope syncs only);
+//  * |X|^2 for bins 0..256 of the quad's 4 frames lands in the wave's private [4][296] LDS tile, and the mel contraction
+//    runs on v_mfma_f32_4x4x1_16b_f32 (16 independent 4x4 outer products per instruction, exact fp32 FMA chains): block j
+//    takes bin 16*kg + j, its 4 rows are the 4 frames, its 4 columns one group of 4 mel bins -- no padding of the frame
+//    dimension to a 16-row tile, so a quad needs ~56 instructions for the standard banded filterbank.  The B operands come
+//    from a fragment-ordered copy of the filterbank (built once by howl_fb_pack / howl_fb_from_points together with the
+//    band limits [lo, hi) of every mel group) through L1; the 16 blocks are summed by a 15-shuffle reduce-scatter that
+//    leaves lane 16*frame + mel%16 holding one output value;
+//  * epilogue: log(x + eps), optional ZMUV (x - mean) / std, 64-B contiguous stores as (B,T,M) [model layout] or (B,M,T).
+// 9 KB of LDS and <= 128 VGPRs per wave: 16 waves per CU hide the LDS / L2 latencies of the serial FFT stages.
 // Algorithmic HBM bytes per utterance: 4*L read + 4*M*T written (76,960 B at L=16000, M=40).
 #include "howl_common.hip.h"
 #include "howl_tables.h"
@@ -29,13 +33,19 @@ namespace {
 constexpr int N_FFT = 512;
 constexpr int HOP = 200;
 constexpr int N_FREQ = 257;
-constexpr int K_PAD = 260;          // 257 padded to a multiple of the MFMA K (4)
-constexpr int K_STEPS = K_PAD / 4;  // 65
-constexpr int P_STRIDE = 261;       // LDS row stride of the power tile (odd: spreads frames over banks)
+constexpr int K_PAD = 260;          // rows of the row-major packed filterbank (257 padded to a multiple of 4)
 constexpr int X1_STRIDE = 68;       // exchange-1 row stride (complex elements), conflict-free
 constexpr int X2_STRIDE = 66;       // exchange-2 row stride
 constexpr int SCR_CF = 8 * X1_STRIDE;  // complex elements of scratch per wave (544 >= 512)
-constexpr int CHUNK = 16;           // frames per workgroup iteration == MFMA M
+constexpr int QUAD = 4;             // frames per wave iteration == rows of a 4x4x1 MFMA block
+constexpr int KG = 17;              // bin groups of 16 (one bin per MFMA block): 17 * 16 = 272 >= 257
+constexpr int NG = HOWL_FB_COLS / 4;   // mel groups of 4 (columns of a block): 12
+constexpr int PQ_STRIDE = 296;      // row stride of the power tile: >= 272 and = 8 (mod 32), so the A-operand read
+                                    // (lane 4j+i -> row i, bin 16kg + j) touches 32 distinct banks per half wave
+// packed filterbank buffer: [ (260, 48) row-major | KG x NG fragments of 64 lanes | 2 * NG band limits (int32) | pad ]
+constexpr int FBQ_OFF = K_PAD * HOWL_FB_COLS;
+constexpr int FBQ_BAND_OFF = FBQ_OFF + KG * NG * 64;
+static_assert(FBQ_BAND_OFF + 32 == HOWL_FB_PACKED_FLOATS, "include/howl_hip.h and the kernels disagree on the packed filterbank size");
 
 struct cf {
     float re, im;
@@ -67,57 +77,64 @@ __device__ __forceinline__ void dft8(cf (&v)[8]) {
     dft4(d0, d1, d2, d3, v[1], v[3], v[5], v[7]);
 }
 
-template <int NT>
-__global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ pcm, int L, long ld, int T,
-                                                     long total_frames, const float* __restrict__ fbp, int M,
-                                                     float log_eps, const float* __restrict__ zmuv,
-                                                     float* __restrict__ out, int layout, int n_chunks) {
-    constexpr int NCOL = 16 * NT;
-    __shared__ float P[CHUNK * P_STRIDE];
-    __shared__ cf scratch[4 * SCR_CF];  // FFT transposes; reused as the 4 x [16][NCOL] partial-sum tiles
-    static_assert(4 * SCR_CF * 2 >= 4 * CHUNK * NCOL, "partial tiles must fit in the FFT scratch");
+// One butterfly step of the 16-block reduce-scatter: lanes whose bit `XOR` is set keep the upper half of v[0..2n), the
+// others the lower half; each adds what its partner (lane ^ XOR) gives up.
+template <int N, int XOR>
+__device__ __forceinline__ void reduce_scatter_step(float (&v)[16], bool upper) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const float send = upper ? v[i] : v[i + N];
+        const float keep = upper ? v[i + N] : v[i];
+        v[i] = keep + __shfl_xor(send, XOR);
+    }
+}
+
+__global__ __launch_bounds__(256, 4) void logmel_kernel(const float* __restrict__ pcm, int L, long ld, int T,
+                                                        long total_frames, const float* __restrict__ fbp, int M,
+                                                        float log_eps, const float* __restrict__ zmuv,
+                                                        float* __restrict__ out, int layout, long n_quads) {
+    __shared__ cf scratch[4 * SCR_CF];            // FFT transposes, private per wave
+    __shared__ float Pq[4 * QUAD * PQ_STRIDE];    // power tile, private per wave
+    __shared__ cf tw1[7 * 64];                    // stage-1 twiddles W_512^(lane*k), k = 1..7 (read-only after the prologue)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     cf* scr = scratch + wave * SCR_CF;
+    float* P = Pq + wave * QUAD * PQ_STRIDE;
 
     // ---- per-lane constants, resident for the whole persistent loop ----------------------------------
     float win[8];
 #pragma unroll
     for (int n1 = 0; n1 < 8; ++n1) win[n1] = HOWL_HANN512[64 * n1 + lane];
-    float tw1r[8], tw1i[8], tw2r[8], tw2i[8];
+    float tw2r[8], tw2i[8];
     const int b_of_lane = lane >> 3;  // stage-2 ownership: lane = k1 + 8*b
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        tw1r[k] = HOWL_TW512[(lane * 8 + k) * 2];
-        tw1i[k] = HOWL_TW512[(lane * 8 + k) * 2 + 1];
         tw2r[k] = HOWL_TW64[(b_of_lane * 8 + k) * 2];
         tw2i[k] = HOWL_TW64[(b_of_lane * 8 + k) * 2 + 1];
     }
-    // this wave's K slice of the mel contraction: wave 0 -> k-steps [0,17), wave w -> [17+16(w-1), +16)
-    const int ks0 = (wave == 0) ? 0 : 17 + 16 * (wave - 1);
-    const int nks = (wave == 0) ? 17 : 16;
-    float bfrag[17][NT];
-#pragma unroll
-    for (int i = 0; i < 17; ++i) {
-        const int krow = 4 * (ks0 + i) + (lane >> 4);
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-            bfrag[i][nt] = (i < nks) ? fbp[(long)krow * NCOL + 16 * nt + (lane & 15)] : 0.0f;
+    for (int i = tid; i < 7 * 64; i += 256) {     // [k-1][lane]: a wave reads 64 consecutive entries per k
+        const int k = 1 + i / 64, l = i & 63;
+        tw1[i] = {HOWL_TW512[(l * 8 + k) * 2], HOWL_TW512[(l * 8 + k) * 2 + 1]};
     }
+    __syncthreads();                              // the only workgroup barrier of the kernel
     float zm_mean = 0.0f, zm_std = 1.0f;
     if (zmuv != nullptr) {
         zm_mean = zmuv[0];
         zm_std = zmuv[1];
     }
+    // bins 257..271 of the tile are read by the last bin group (times a zero filterbank entry): keep them zero
+    if (lane < QUAD * 16) P[(lane >> 4) * PQ_STRIDE + 256 + (lane & 15)] = 0.0f;
+    const int* band = reinterpret_cast<const int*>(fbp + FBQ_BAND_OFF);
+    const float* frag = fbp + FBQ_OFF + lane;
+    const int n_groups = (M + 3) >> 2;
 
-    // Raw samples of one frame pair (this wave's pair `pr` of chunk `chunk`): reflect-padded centre framing.  They are
-    // requested one pair ahead of the FFT that consumes them, so the HBM round trip is spent under the previous pair's
-    // butterflies instead of in front of every FFT.
-    auto fetch_pair = [&](int chunk, int pr, float (&xa)[8], float (&xb)[8]) {
-        const long ga = (long)chunk * CHUNK + 4 * wave + 2 * pr, gb = ga + 1;
-        const bool va = chunk < n_chunks && ga < total_frames, vb = chunk < n_chunks && gb < total_frames;
+    // Raw samples of one frame pair (frames ga, ga + 1): reflect-padded centre framing.  They are requested one pair ahead
+    // of the FFT that consumes them, so the HBM round trip is spent under the previous pair's butterflies.
+    auto fetch_pair = [&](long ga, float (&xa)[8], float (&xb)[8]) {
+        const long gb = ga + 1;
+        const bool va = ga < total_frames, vb = gb < total_frames;
         const long ba = va ? ga / T : 0, bb = vb ? gb / T : 0;
         const int ta = va ? (int)(ga - ba * T) : 0, tb = vb ? (int)(gb - bb * T) : 0;
         const float* rowa = pcm + ba * ld;
@@ -131,34 +148,33 @@ __global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ p
             sb = sb < 0 ? -sb : sb;
             sa = sa >= L ? 2 * (L - 1) - sa : sa;
             sb = sb >= L ? 2 * (L - 1) - sb : sb;
-#if defined(HOWL_DIAG_LOGMEL_NOLOAD)   // diagnostic build (tools/variants.py): no PCM reads
-            const float a = 1e-3f * (float)sa, b = 1e-3f * (float)sb;
-#else
             const float a = rowa[sa], b = rowb[sb];  // always in range (frame 0 of row 0 for invalid frames)
-#endif
             xa[n1] = va ? a : 0.0f;
             xb[n1] = vb ? b : 0.0f;
         }
     };
-    float xa[8], xb[8], na[8], nb[8];
-    fetch_pair(blockIdx.x, 0, xa, xb);
 
-    for (int chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
-        const long g0 = (long)chunk * CHUNK;
-        // ---- FFT phase: this wave transforms frame pairs (4w, 4w+1) and (4w+2, 4w+3) -----------------
+    const long wave_id = (long)blockIdx.x * 4 + wave, n_waves = (long)gridDim.x * 4;
+    float xa[8], xb[8], na[8], nb[8];
+    if (wave_id < n_quads) fetch_pair(QUAD * wave_id, xa, xb);
+
+    for (long quad = wave_id; quad < n_quads; quad += n_waves) {
+        const long g0 = QUAD * quad;
+        // ---- FFT phase: frame pairs (g0, g0+1) and (g0+2, g0+3) -------------------------------------------------
 #pragma unroll
         for (int pr = 0; pr < 2; ++pr) {
-            const int fa = 4 * wave + 2 * pr;  // frame slot of the "real" frame; the "imag" frame is fa + 1
-            if (pr == 0) fetch_pair(chunk, 1, na, nb);
-            else fetch_pair(chunk + (int)gridDim.x, 0, na, nb);
+            if (pr == 0) fetch_pair(g0 + 2, na, nb);
+            else fetch_pair(QUAD * (quad + n_waves), na, nb);     // beyond the last quad: frames are invalid, reads frame 0
             cf v[8];
 #pragma unroll
             for (int n1 = 0; n1 < 8; ++n1) v[n1] = {xa[n1] * win[n1], xb[n1] * win[n1]};
-#if !defined(HOWL_DIAG_LOGMEL_NOFFT)   // diagnostic build: butterflies and LDS exchanges removed
             // stage 1: radix-8 over n1 (stride 64), twiddle W_512^(lane*k1)
             dft8(v);
 #pragma unroll
-            for (int k = 1; k < 8; ++k) v[k] = cmul(v[k], tw1r[k], tw1i[k]);
+            for (int k = 1; k < 8; ++k) {
+                const cf w = tw1[(k - 1) * 64 + lane];
+                v[k] = cmul(v[k], w.re, w.im);
+            }
             wave_lds_sync();  // previous users of this scratch (power phase of the last pair) are done
 #pragma unroll
             for (int k1 = 0; k1 < 8; ++k1) scr[k1 * X1_STRIDE + lane] = v[k1];
@@ -181,14 +197,13 @@ __global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ p
                 for (int b = 0; b < 8; ++b) v[b] = scr[k1 * X2_STRIDE + c * 8 + b];
                 dft8(v);
             }
-#endif
             wave_lds_sync();
 #pragma unroll
             for (int d = 0; d < 8; ++d) scr[lane + 64 * d] = v[d];
             wave_lds_sync();
             // separate the two real spectra and take |X|^2 for bins 0..256 (lane 0 also does bin 256)
-            float* Pa = P + fa * P_STRIDE;
-            float* Pb = Pa + P_STRIDE;
+            float* Pa = P + 2 * pr * PQ_STRIDE;
+            float* Pb = Pa + PQ_STRIDE;
 #pragma unroll
             for (int r = 0; r < 5; ++r) {
                 const int k = lane + 64 * r;
@@ -199,9 +214,6 @@ __global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ p
                     const float bre = 0.5f * (zk.im + zn.im), bim = -0.5f * (zk.re - zn.re);
                     Pa[k] = are * are + aim * aim;
                     Pb[k] = bre * bre + bim * bim;
-                } else if (lane < 4) {  // zero the K padding (bins 257..259)
-                    Pa[k] = 0.0f;
-                    Pb[k] = 0.0f;
                 }
             }
 #pragma unroll
@@ -210,54 +222,66 @@ __global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ p
                 xb[n1] = nb[n1];
             }
         }
-        __syncthreads();
-        // ---- mel contraction on the matrix cores: D[frame][mel] += P[frame][k] * fb[k][mel] ------------
-        f32x4 acc[NT];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[nt] = {0.0f, 0.0f, 0.0f, 0.0f};
-        {
-            const float* arow = P + (lane & 15) * P_STRIDE + 4 * ks0 + (lane >> 4);
-#pragma unroll
-            for (int i = 0; i < 17; ++i) {
-#if defined(HOWL_DIAG_LOGMEL_NOMEL)   // diagnostic build: mel contraction removed
-                if (i == 0) acc[0][0] = arow[0];
-#else
-                if (i < nks) {
-                    const float a = arow[4 * i];
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
-                        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bfrag[i][nt], acc[nt], 0, 0, 0);
-                }
-#endif
-            }
+        wave_lds_sync();
+        // ---- mel contraction: D_j[frame][mel] += P[frame][16 kg + j] * fb[16 kg + j][mel], blocks j summed afterwards ----
+        const float* arow = P + (lane & 3) * PQ_STRIDE + (lane >> 2);
+        // this lane's output after the reduce-scatter: frame r_out of the quad, mel column 16 * batch + c_out
+        const int r_out = lane >> 4, c_out = lane & 15;
+        const long g_out = g0 + r_out;
+        long o_base;      // element offset of (frame g_out, mel 0); mel stride o_ms
+        long o_ms;
+        if (layout == 1) {
+            o_base = g_out * M;
+            o_ms = 1;
+        } else {
+            const long b = g_out / T;
+            o_base = b * M * T + (g_out - b * T);
+            o_ms = T;
         }
-        float* part = reinterpret_cast<float*>(scratch);
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
+        for (int batch = 0; batch < NG / 4; ++batch) {
+            if (4 * batch >= n_groups) break;
+            int lo[4], hi[4];
+            int klo = KG, khi = 0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                lo[c] = band[2 * (4 * batch + c)];
+                hi[c] = band[2 * (4 * batch + c) + 1];
+                if (hi[c] > lo[c]) {
+                    klo = lo[c] < klo ? lo[c] : klo;
+                    khi = hi[c] > khi ? hi[c] : khi;
+                }
+            }
+            f32x4 acc[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[c] = {0.0f, 0.0f, 0.0f, 0.0f};
+            for (int kg = klo; kg < khi; ++kg) {
+                const float a = arow[16 * kg];
+                const float* fk = frag + (long)(kg * NG + 4 * batch) * 64;
+                float bv[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) bv[c] = fk[64 * c];      // zero outside a group's band: no predicate needed
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f32_4x4x1f32(a, bv[c], acc[c], 0, 0, 0);
+            }
+            // lane 4j+i holds D_j[r][4c + i] in acc[c][r]: index the 16 values by 4r + c, the block that will own the sum
+            float v16[16];
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                part[(wave * CHUNK + (lane >> 4) * 4 + r) * NCOL + 16 * nt + (lane & 15)] = acc[nt][r];
-        __syncthreads();
-        // ---- epilogue: combine the 4 K-slices, log, ZMUV, store ---------------------------------------
-        for (int idx = tid; idx < CHUNK * NCOL; idx += 256) {
-            const int f = idx / NCOL, m = idx - f * NCOL;
-            const long g = g0 + f;
-            if (m < M && g < total_frames) {
-                float s = part[(0 * CHUNK + f) * NCOL + m] + part[(1 * CHUNK + f) * NCOL + m];
-                s += part[(2 * CHUNK + f) * NCOL + m];
-                s += part[(3 * CHUNK + f) * NCOL + m];
-                float y = logf(s + log_eps);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v16[4 * r + c] = acc[c][r];
+            reduce_scatter_step<8, 32>(v16, (lane & 32) != 0);
+            reduce_scatter_step<4, 16>(v16, (lane & 16) != 0);
+            reduce_scatter_step<2, 8>(v16, (lane & 8) != 0);
+            reduce_scatter_step<1, 4>(v16, (lane & 4) != 0);
+            // lane 4j+i now holds the full sum for (r, c) = (j >> 2, j & 3), column i: frame r_out, mel 16*batch + c_out
+            const int m = 16 * batch + c_out;
+            if (m < M && g_out < total_frames) {
+                float y = logf(v16[0] + log_eps);
                 if (zmuv != nullptr) y = (y - zm_mean) / zm_std;
-                if (layout == 1) {
-                    out[g * M + m] = y;
-                } else {
-                    const long b = g / T;
-                    const int t = (int)(g - b * T);
-                    out[(b * M + m) * T + t] = y;
-                }
+                out[o_base + (long)m * o_ms] = y;
             }
         }
-        __syncthreads();
     }
 }
 
@@ -267,6 +291,37 @@ __global__ void fb_pack_kernel(const float* __restrict__ fb, int M, float* __res
     if (idx >= K_PAD * ncol) return;
     const int k = idx / ncol, m = idx - k * ncol;
     fbp[idx] = (k < N_FREQ && m < M) ? fb[k * M + m] : 0.0f;
+}
+
+// Second half of a filterbank build (same stream, after the row-major part is written): the fragment-ordered copy read by
+// the 4x4x1 MFMAs of logmel_kernel -- fragment (kg, g), lane 4j+c = fb[16 kg + j][4 g + c] -- and, per mel group g, the range
+// [lo, hi) of bin groups kg that hold a non-zero weight (lo = hi = 0 for an empty group).  One workgroup: 13 K elements.
+__global__ __launch_bounds__(1024) void fb_fragments_kernel(float* __restrict__ fbp) {
+    __shared__ int nz[KG * NG];
+    const float* rm = fbp;                 // (K_PAD, HOWL_FB_COLS) row-major
+    float* fq = fbp + FBQ_OFF;
+    for (int p = threadIdx.x; p < KG * NG; p += blockDim.x) nz[p] = 0;
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < KG * NG * 64; idx += blockDim.x) {
+        const int lane = idx & 63, pair = idx >> 6;
+        const int kg = pair / NG, g = pair - kg * NG;
+        const int k = 16 * kg + (lane >> 2), m = 4 * g + (lane & 3);
+        const float v = (k < N_FREQ) ? rm[k * HOWL_FB_COLS + m] : 0.0f;
+        fq[idx] = v;
+        if (v != 0.0f) nz[pair] = 1;       // benign race: every writer stores 1
+    }
+    __syncthreads();
+    if (threadIdx.x < NG) {
+        const int g = threadIdx.x;
+        int lo = 0, hi = 0;
+        for (int kg = KG - 1; kg >= 0; --kg)
+            if (nz[kg * NG + g]) lo = kg;
+        for (int kg = 0; kg < KG; ++kg)
+            if (nz[kg * NG + g]) hi = kg + 1;
+        int* band = reinterpret_cast<int*>(fbp + FBQ_BAND_OFF);
+        band[2 * g] = lo;
+        band[2 * g + 1] = hi;
+    }
 }
 
 // triangles from M+2 corner frequencies (already VTLP-warped on the host: 42 scalars), exactly the
@@ -519,6 +574,7 @@ int howl_fb_pack(const float* fb, int M, float* fbp, hipStream_t stream) {
     HOWL_REQUIRE(M >= 1 && M <= HOWL_MAX_MELS, "howl_fb_pack: M=%d unsupported (1..%d)", M, HOWL_MAX_MELS);
     const int ncol = HOWL_FB_COLS;
     hipLaunchKernelGGL(fb_pack_kernel, dim3((K_PAD * ncol + 255) / 256), dim3(256), 0, stream, fb, M, fbp, ncol);
+    hipLaunchKernelGGL(fb_fragments_kernel, dim3(1), dim3(1024), 0, stream, fbp);
     HOWL_CHECK_LAUNCH("howl_fb_pack");
     return HOWL_OK;
 }
@@ -529,6 +585,7 @@ int howl_fb_from_points(const HowlMelPoints* pts, int M, float nyquist, float* f
     const int ncol = HOWL_FB_COLS;
     hipLaunchKernelGGL(fb_points_kernel, dim3((K_PAD * ncol + 255) / 256), dim3(256), 0, stream, *pts, M, nyquist, fbp,
                        ncol);
+    hipLaunchKernelGGL(fb_fragments_kernel, dim3(1), dim3(1024), 0, stream, fbp);
     HOWL_CHECK_LAUNCH("howl_fb_from_points");
     return HOWL_OK;
 }
@@ -543,13 +600,14 @@ int howl_logmel_fwd(const float* pcm, int B, int L, long ld, const float* fbp, i
     HOWL_REQUIRE(layout == 0 || layout == 1, "howl_logmel_fwd: layout must be 0 (B,M,T) or 1 (B,T,M)");
     const int T = 1 + L / HOP;
     const long total = (long)B * T;
-    const int n_chunks = (int)((total + CHUNK - 1) / CHUNK);
-    int grid = howl_num_cus() * 2;   // two workgroups are resident per CU (206 VGPRs): each pays the constant prologue once
-    if (grid > n_chunks) grid = n_chunks;
+    const long n_quads = (total + QUAD - 1) / QUAD;
+    // four 4-wave workgroups are resident per CU (9 KB of LDS and <= 128 VGPRs per wave); a wave strides over the quads
+    long grid = (long)howl_num_cus() * 4;
+    if (grid > (n_quads + 3) / 4) grid = (n_quads + 3) / 4;
     {
         HowlProfScope prof("logmel", stream);
-        hipLaunchKernelGGL(logmel_kernel<HOWL_FB_COLS / 16>, dim3(grid), dim3(256), 0, stream, pcm, L, ld, T, total, fbp, M,
-                           log_eps, zmuv, out, layout, n_chunks);
+        hipLaunchKernelGGL(logmel_kernel, dim3((unsigned)grid), dim3(256), 0, stream, pcm, L, ld, T, total, fbp, M, log_eps, zmuv,
+                           out, layout, n_quads);
     }
     HOWL_CHECK_LAUNCH("howl_logmel_fwd");
     return HOWL_OK;

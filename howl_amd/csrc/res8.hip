@@ -349,17 +349,18 @@ struct ConvLoop {
     const float* lrstd;
     int B, CS, n2, mg, lane, tid;
     bool affine;
+    int nblk;   // workgroups sharing the batch (the launch's grid, or this role's share of a merged launch)
 };
 
-// all utterances b, b + gridDim.x, ... of this workgroup; `pre` holds utterance b's activations on entry
+// all utterances b, b + nblk, ... of this workgroup; `pre` holds utterance b's activations on entry
 template <int MODE, int NTW>
 __device__ __forceinline__ void conv_loop(const ConvLoop& c, const ConvEpilogue& epi, float2 (&pre)[PREF],
                                           const int (&pk)[PREF], int b, float& st0, float& st1) {
     const int P = epi.P;
-    for (; b < c.B; b += gridDim.x) {
+    for (; b < c.B; b += c.nblk) {
         stage_tile(pre, pk, c.tile, c.lmean, c.lrstd, c.affine, MODE == 0);  // gradient tiles (dgrad) are signed
         __syncthreads();
-        const int bn = b + gridDim.x;
+        const int bn = b + c.nblk;
         const float* nsrc = (bn < c.B) ? c.in + (size_t)bn * NMAP * P : nullptr;  // fetched from inside the K loop
         const size_t ubase = (size_t)b * NMAP * P;
         if constexpr (NTW > 0) {
@@ -376,7 +377,7 @@ __device__ __forceinline__ void conv_loop(const ConvLoop& c, const ConvEpilogue&
 // MODE 0: forward   out = relu(conv(x)) [+ res]; stats = (sum, sumsq) of out per cout
 // MODE 1: dgrad     out = conv(x);               stats = (sum out, sum out * xhat) per cout, xhat from s_prev
 template <int MODE>
-__global__ __launch_bounds__(CONV_THREADS) void conv3x3_mfma_kernel(
+__device__ __forceinline__ void conv3x3_body(
     const float* __restrict__ in,         // (B,45,P) input activations (s_{i-1}) or dz_i
     const float* __restrict__ in_stats,   // {mean[48], rstd[48]} applied on load, or nullptr
     const float* __restrict__ wp,         // packed weights [3][108][64]
@@ -384,8 +385,8 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_mfma_kernel(
     float* __restrict__ out,              // (B,45,P)
     const float* __restrict__ xs,         // dgrad: s_{i-1} for xhat, or nullptr (no stats)
     const float* __restrict__ xs_stats,   // dgrad: {mean, rstd} of layer i-1
-    float* __restrict__ part,             // [gridDim.x][2][48] partial statistics, or nullptr
-    int B, int H) {
+    float* __restrict__ part,             // [nblk][2][48] partial statistics, or nullptr
+    int B, int H, int bid, int nblk) {    // workgroup `bid` of the `nblk` that share this convolution
     HIP_DYNAMIC_SHARED(float, lds)
     const int P = H * PW;
     const int CS = chan_stride(H);
@@ -408,7 +409,7 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_mfma_kernel(
 
     // first utterance's activations are requested before anything else so that HBM latency overlaps the setup
     float2 pre[PREF];
-    int b = blockIdx.x;
+    int b = bid;
     if (b < B) prefetch_tile(pre, in + (size_t)b * NMAP * P, n2, tid);
     {
         float4 wv[7];  // 3*108*16 float4 = 5184 <= 7 * 768: all loads in flight, then the LDS stores
@@ -450,7 +451,7 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_mfma_kernel(
     // instance executes the same two barriers per utterance): the register allocator then sees one variant's live
     // values, not the union of all five.
     const ConvLoop cl{in, (const lds_f32*)tile, (const lds_f32*)wl + nt * KSTEPS * 64, tile, lmean, lrstd, B, CS, n2,
-                      mg, lane, tid, affine};
+                      mg, lane, tid, affine, nblk};
     switch (ntw) {
         case 5: conv_loop<MODE, 5>(cl, epi, pre, pk, b, st0, st1); break;
         case 4: conv_loop<MODE, 4>(cl, epi, pre, pk, b, st0, st1); break;
@@ -477,9 +478,20 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_mfma_kernel(
             float s = 0.0f;
 #pragma unroll
             for (int g = 0; g < 4; ++g) s += red[((g * 3 + t3) * 2 + which) * 16 + cl];
-            part[((size_t)blockIdx.x * 2 + which) * CP + c] = s;
+            part[((size_t)bid * 2 + which) * CP + c] = s;
         }
     }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(CONV_THREADS) void conv3x3_mfma_kernel(const float* __restrict__ in,
+                                                                    const float* __restrict__ in_stats,
+                                                                    const float* __restrict__ wp,
+                                                                    const float* __restrict__ res, float* __restrict__ out,
+                                                                    const float* __restrict__ xs,
+                                                                    const float* __restrict__ xs_stats,
+                                                                    float* __restrict__ part, int B, int H) {
+    conv3x3_body<MODE>(in, in_stats, wp, res, out, xs, xs_stats, part, B, H, blockIdx.x, gridDim.x);
 }
 
 #if defined(HOWL_DIAG_PROBE)  // diagnostic build (tools/probe_wgrad.py): s_memtime stamps of workgroup 0, [wave][slot]
@@ -557,9 +569,10 @@ struct WgradArgs {
     const float* lrstd;
     int B, P, CS, R, n2, tid, lane, wave;
     bool affine;
+    int bid, nblk;   // this workgroup's index among the nblk that share the weight gradient
 };
 
-// all utterances b, b + gridDim.x, ... of this workgroup (pz / px hold utterance b on entry), then this wave's partials
+// all utterances b, b + nblk, ... of this workgroup (pz / px hold utterance b on entry), then this wave's partials
 template <int NB>
 __device__ __forceinline__ void wgrad_loop(const WgradArgs& a, float2 (&pz)[PREF], float2 (&px)[PREF],
                                            const int (&pk)[PREF], int b, int& pslot) {
@@ -579,13 +592,13 @@ __device__ __forceinline__ void wgrad_loop(const WgradArgs& a, float2 (&pz)[PREF
         boff[i] = (16 * ct + n) * CS + (g + tap / 3) * WPW + (tap % 3);   // cin row, halo origin + tap shift
     }
     const int aoff = n * CS + (g + 1) * WPW + 1;                           // cout row, interior origin
-    for (; b < a.B; b += gridDim.x) {
+    for (; b < a.B; b += a.nblk) {
         stage_tile(pz, pk, a.tz, a.lmean, a.lrstd, false, false);
         stage_tile(px, pk, a.tx, a.lmean, a.lrstd, a.affine, true);
         HOWL_PROBE(wave, lane, pslot++);   // staged
         __syncthreads();
         HOWL_PROBE(wave, lane, pslot++);   // barrier
-        const int bn = b + gridDim.x;
+        const int bn = b + a.nblk;
         const float* nz = (bn < a.B) ? a.dz + (size_t)bn * NMAP * a.P : nullptr;
         const float* nx = (bn < a.B) ? a.s_prev + (size_t)bn * NMAP * a.P : nullptr;
         WCursor<NB> c;
@@ -618,7 +631,7 @@ __device__ __forceinline__ void wgrad_loop(const WgradArgs& a, float2 (&pz)[PREF
         HOWL_PROBE(wave, lane, pslot++);   // barrier
     }
     // D[row = cout = 16mt + 4*(lane>>4) + r][col = n = lane&15 -> cin = 16ct + col] for N tile q = (tap, ct)
-    float* dst = a.part + (size_t)blockIdx.x * CP * 432;
+    float* dst = a.part + (size_t)a.bid * CP * 432;
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
         const int q = wave + 12 * i;
@@ -633,9 +646,9 @@ __device__ __forceinline__ void wgrad_loop(const WgradArgs& a, float2 (&pz)[PREF
     }
 }
 
-__global__ __launch_bounds__(CONV_THREADS) void wgrad_mfma_kernel(
+__device__ __forceinline__ void wgrad_body(
     const float* __restrict__ dz, const float* __restrict__ s_prev, const float* __restrict__ in_stats,
-    float* __restrict__ part /* [gridDim.x][48][432] */, int B, int H) {
+    float* __restrict__ part /* [nblk][48][432] */, int B, int H, int bid, int nblk) {
     HIP_DYNAMIC_SHARED(float, lds)
     const int P = H * PW;
     const int CS = chan_stride_wgrad(H);
@@ -658,7 +671,7 @@ __global__ __launch_bounds__(CONV_THREADS) void wgrad_mfma_kernel(
     int pk[PREF];
     stage_slots(pk, P, CS, n2, tid, WPW);
     float2 pz[PREF], px[PREF];
-    const int b = blockIdx.x;
+    const int b = bid;
     if (b < B) {
         prefetch_tile(pz, dz + (size_t)b * NMAP * P, n2, tid);
         prefetch_tile(px, s_prev + (size_t)b * NMAP * P, n2, tid);
@@ -672,7 +685,8 @@ __global__ __launch_bounds__(CONV_THREADS) void wgrad_mfma_kernel(
     HOWL_PROBE(wave, lane, pslot++);   // prologue done
     // instantiated per tile count (waves 0..2 carry a third N tile): no branches inside the K loop, and the register
     // allocator sees one variant's live values (waves of a workgroup run different instances with the same barriers)
-    const WgradArgs a{dz, s_prev, part, tz, tx, lmean, lrstd, B, P, CS, wgrad_rounds(H), n2, tid, lane, wave, affine};
+    const WgradArgs a{dz, s_prev, part, tz, tx, lmean, lrstd, B, P, CS, wgrad_rounds(H), n2, tid, lane, wave, affine,
+                      bid, nblk};
     if (wave + 24 < 27)
         wgrad_loop<3>(a, pz, px, pk, b, pslot);
     else
@@ -680,12 +694,38 @@ __global__ __launch_bounds__(CONV_THREADS) void wgrad_mfma_kernel(
     HOWL_PROBE(wave, lane, pslot++);   // partials written
 }
 
+__global__ __launch_bounds__(CONV_THREADS) void wgrad_mfma_kernel(const float* __restrict__ dz,
+                                                                  const float* __restrict__ s_prev,
+                                                                  const float* __restrict__ in_stats,
+                                                                  float* __restrict__ part, int B, int H) {
+    wgrad_body(dz, s_prev, in_stats, part, B, H, blockIdx.x, gridDim.x);
+}
+
+// Data gradient and weight gradient of one layer in ONE launch.  Both hang off dz_i and are independent; side by side on
+// half the CUs each, a workgroup carries twice the utterances, so the per-launch costs (dispatch, weight / LDS prologue,
+// first-tile fetch, tail) are paid once per two utterance passes.  (Round 1 ran them on two HIP queues: the event
+// record / wait pairs that fork and join the second queue cost ~6.5 us each on this stack, twice per layer on the
+// critical path.)  Blocks come in groups of 16: the first 8 run the data gradient, the other 8 the weight gradient, so
+// that pair j of either role lands on the same XCD (block b runs on XCD b % 8) and shares its L2 copy of dz.
+__global__ __launch_bounds__(CONV_THREADS) void bwd_pair_kernel(
+    const float* __restrict__ dz, const float* __restrict__ wp, float* __restrict__ dx, const float* __restrict__ xs,
+    const float* __restrict__ xs_stats, float* __restrict__ spart, const float* __restrict__ s_prev,
+    const float* __restrict__ in_stats, float* __restrict__ wpart, int B, int H, int nblk) {
+    const int role = (blockIdx.x >> 3) & 1;
+    const int j = (int)(blockIdx.x >> 4) * 8 + (int)(blockIdx.x & 7);
+    if (j >= nblk) return;
+    if (role == 0)
+        conv3x3_body<1>(dz, nullptr, wp, nullptr, dx, xs, xs_stats, spart, B, H, j, nblk);
+    else
+        wgrad_body(dz, s_prev, in_stats, wpart, B, H, j, nblk);
+}
+
 // Deterministic sum over the per-workgroup partial rows: part[g][col], g < nparts.  A block owns 64 columns
 // (coalesced reads); its 4 waves split the rows, then combine through LDS in a fixed order.
 //   mode 0: out[col] = sum            (conv0: 405 columns)
 //   mode 1: col = (cout, tap, cin) of the wgrad accumulator layout [48][9][48] -> dW[(cout*45 + cin)*9 + tap]
-__global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ part, int nparts, int ncols,
-                                                          int mode, float* __restrict__ out) {
+__device__ __forceinline__ void reduce_rows_body(const float* __restrict__ part, int nparts, int ncols, int mode,
+                                                 float* __restrict__ out) {
     __shared__ float red[4][64];
     const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
     const int col = blockIdx.x * 64 + lane;
@@ -714,6 +754,23 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restric
             const int tap = r / CP, ci = r - tap * CP;
             if (co < NMAP && ci < NMAP) out[(co * NMAP + ci) * 9 + tap] = tot;
         }
+    }
+}
+
+__global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ part, int nparts, int ncols,
+                                                          int mode, float* __restrict__ out) {
+    reduce_rows_body(part, nparts, ncols, mode, out);
+}
+
+// every weight gradient of the backward pass in one launch: blockIdx.y = 0..5 -> conv layer y+1 (partials of layer l at
+// part + l * layer_stride), blockIdx.y = 6 -> conv0 (its own partial rows)
+__global__ __launch_bounds__(256) void reduce_rows_all_kernel(const float* __restrict__ part, size_t layer_stride, int nparts,
+                                                              HowlPtrs6 out, const float* __restrict__ c0part, int c0parts,
+                                                              float* __restrict__ c0out) {
+    if (blockIdx.y < 6) {
+        reduce_rows_body(part + blockIdx.y * layer_stride, nparts, CP * 432, 1, out.p[blockIdx.y]);
+    } else if (blockIdx.x * 64 < NMAP * 9) {
+        reduce_rows_body(c0part, c0parts, NMAP * 9, 0, c0out);
     }
 }
 
@@ -1278,7 +1335,7 @@ struct Ws {
     float* dz2;
     float* dsa;
     float* dsb;
-    float* wpart;    // [G][48][432]
+    float* wpart;    // [6][G][48][432]: one set of weight-gradient partials per layer (reduced together at the end)
     float* c0part;   // [G][405]
 };
 
@@ -1303,21 +1360,16 @@ size_t ws_layout(Ws* w, char* base, int B, int H, int G) {
     t.dz2 = take(act);
     t.dsa = take(act);
     t.dsb = take(act);
-    t.wpart = take((size_t)G * CP * 432);
+    t.wpart = take((size_t)6 * G * CP * 432);
     t.c0part = take((size_t)G * NMAP * 9);
     if (w) *w = t;
     return off;
 }
 
-// The backward pass runs on two HIP queues.  A layer's data gradient (dgrad, on the caller's stream: the chain the next
-// layer waits for) and its weight gradient (wgrad + the reduction of its partials, which only AdamW waits for) both hang
-// off dz_i and are independent, so they are launched side by side, each on HALF the CUs: a workgroup then carries twice
-// the utterances per launch, i.e. the per-launch costs (dispatch, weight / LDS prologue, first-tile fetch, tail) are paid
-// once per two utterance passes instead of once per pass, and the small reduction leaves the critical path.  Fork and
-// join are plain event record / wait pairs (capturable into a hipGraph); dz is double-buffered so that layer i-2's BN
-// backward cannot overwrite what wgrad_i is still reading.  One side queue per (device, caller stream), created on
-// first use and kept for the life of the process (howl_side_queue).  HOWL_RES8_BWD_QUEUES=1 keeps everything on the
-// caller's stream.  Events: 0..5 dz_i ready, 6..11 wgrad_i done with its dz buffer, 12 all weight gradients written.
+// Backward pass: per layer  bn_relu_bwd -> [dgrad || wgrad in one launch, half the CUs each] -> bn_bwd_finalize, all on the
+// caller's stream; every layer's weight-gradient partials stay in the workspace and ONE launch reduces them all at the
+// end (nothing but AdamW waits for them).  HOWL_RES8_BWD_PAIR=0 launches the two halves one after the other with the
+// same grids (bit-identical results; the reference point of the tests).
 int conv_grid(int B) {
     int g = howl_num_cus();
     return B < g ? B : g;
@@ -1421,13 +1473,14 @@ int howl_res8_bwd(const HowlRes8Params* prm, const float* feat, long sb, long st
     const size_t lw = wgrad_lds_bytes(H);
     hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                         (int)lw);
-    HowlSideQueue* sq = howl_side_queue(stream, 0, "HOWL_RES8_BWD_QUEUES");
-    hipStream_t wstream = sq ? sq->stream : stream;   // weight-gradient queue
-    int Gh = G;   // dgrad and wgrad side by side: at most half the CUs each
-    if (sq) {
-        const int half = howl_num_cus() / 2 > 0 ? howl_num_cus() / 2 : 1;
-        Gh = B < half ? B : half;
-    }
+    const size_t lp = lc > lw ? lc : lw;
+    hipFuncSetAttribute(reinterpret_cast<const void*>(bwd_pair_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lp);
+    const char* pair_env = getenv("HOWL_RES8_BWD_PAIR");
+    const bool merged = !(pair_env != nullptr && pair_env[0] == '0');
+    // dgrad and wgrad side by side: half the CUs each
+    const int half = howl_num_cus() / 2 > 0 ? howl_num_cus() / 2 : 1;
+    const int Gh = B < half ? B : half;
+    const size_t wpart_stride = (size_t)Gh * CP * 432;
     float* dx_cur = nullptr;      // gradient w.r.t. the BN output of layer i (nullptr: broadcast of dpool)
     float* dx_next = w.bufa;
     float* ds_prev = nullptr;     // ds_{i+2}
@@ -1437,37 +1490,35 @@ int howl_res8_bwd(const HowlRes8Params* prm, const float* feat, long sb, long st
         const float* stats_i = sv->bn_stats + (size_t)(i - 1) * 2 * CP;
         float* ds_out = even ? ds_free : nullptr;
         float* dz = even ? w.dz : w.dz2;
-        if (sq && i <= 4) hipStreamWaitEvent(stream, sq->ev[6 + i + 1], 0);   // wgrad_{i+2} has finished with this dz buffer
         hipLaunchKernelGGL(bn_relu_bwd_kernel, dim3(eg), dim3(256), 0, stream, (const float*)dx_cur, w.dpool, sv->s[i],
                            stats_i, w.m12, even ? (const float*)ds_prev : (const float*)nullptr, even ? 1 : 0, ds_out, dz, B, P);
-        if (sq) {
-            hipEventRecord(sq->ev[i - 1], stream);
-            hipStreamWaitEvent(wstream, sq->ev[i - 1], 0);
-        }
         if (even) {
             float* t = ds_prev ? ds_prev : w.dsb;
             ds_prev = ds_out;
             ds_free = t;
         }
-        // data gradient: dx_{i-1} (w.r.t. the normalised input of layer i), with BN_{i-1} backward statistics
+        // data gradient: dx_{i-1} (w.r.t. the normalised input of layer i), with BN_{i-1} backward statistics;
+        // weight gradient of layer i: input x_{i-1} = BN_{i-1}(s_{i-1}) (identity for i = 1)
         const float* in_stats = (i == 1) ? nullptr : sv->bn_stats + (size_t)(i - 2) * 2 * CP;
         const bool need_stats = i > 1;
-        {
-            HowlProfScope prof("conv3x3_dgrad", stream);
-            hipLaunchKernelGGL(conv3x3_mfma_kernel<1>, dim3(Gh), dim3(CONV_THREADS), lc, stream, (const float*)dz,
-                               (const float*)nullptr, w.wp_bwd + (size_t)(i - 1) * 3 * KSTEPS * 64, (const float*)nullptr,
-                               dx_next, need_stats ? sv->s[i - 1] : (const float*)nullptr, in_stats,
-                               need_stats ? w.part : (float*)nullptr, B, H);
+        const float* wpb = w.wp_bwd + (size_t)(i - 1) * 3 * KSTEPS * 64;
+        const float* xs = need_stats ? sv->s[i - 1] : (const float*)nullptr;
+        float* spart = need_stats ? w.part : (float*)nullptr;
+        float* wpart = w.wpart + (size_t)(i - 1) * wpart_stride;
+        if (merged) {
+            HowlProfScope prof("bwd_pair", stream);
+            hipLaunchKernelGGL(bwd_pair_kernel, dim3(16 * ((Gh + 7) / 8)), dim3(CONV_THREADS), lp, stream, (const float*)dz, wpb,
+                               dx_next, xs, in_stats, spart, sv->s[i - 1], in_stats, wpart, B, H, Gh);
+        } else {
+            {
+                HowlProfScope prof("conv3x3_dgrad", stream);
+                hipLaunchKernelGGL(conv3x3_mfma_kernel<1>, dim3(Gh), dim3(CONV_THREADS), lc, stream, (const float*)dz,
+                                   (const float*)nullptr, wpb, (const float*)nullptr, dx_next, xs, in_stats, spart, B, H);
+            }
+            HowlProfScope prof("wgrad", stream);
+            hipLaunchKernelGGL(wgrad_mfma_kernel, dim3(Gh), dim3(CONV_THREADS), lw, stream, (const float*)dz, sv->s[i - 1],
+                               in_stats, wpart, B, H);
         }
-        // weight gradient of layer i: input x_{i-1} = BN_{i-1}(s_{i-1}) (identity for i = 1)
-        {
-            HowlProfScope prof("wgrad", wstream);
-            hipLaunchKernelGGL(wgrad_mfma_kernel, dim3(Gh), dim3(CONV_THREADS), lw, wstream, (const float*)dz, sv->s[i - 1],
-                               in_stats, w.wpart, B, H);
-        }
-        if (sq) hipEventRecord(sq->ev[6 + i - 1], wstream);
-        hipLaunchKernelGGL(reduce_rows_kernel, dim3((CP * 432 + 63) / 64), dim3(256), 0, wstream, (const float*)w.wpart, Gh,
-                           CP * 432, 1, gr->conv_w[i - 1]);
         if (need_stats)
             hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(1024), 0, stream, (const float*)w.part, Gh, count,
                                w.m12);
@@ -1482,12 +1533,10 @@ int howl_res8_bwd(const HowlRes8Params* prm, const float* feat, long sb, long st
     hipLaunchKernelGGL(conv0_wgrad_mfma_kernel, dim3(G), dim3(C0W_THREADS), l0w, stream, feat, sb, st, sm,
                        (const unsigned short*)sv->mask0,
                        (const float*)dx_cur, (const float*)ds_prev, w.c0part, B, T, M, H);
-    hipLaunchKernelGGL(reduce_rows_kernel, dim3((NMAP * 9 + 63) / 64), dim3(256), 0, stream, (const float*)w.c0part, G,
-                       NMAP * 9, 0, gr->conv0_w);
-    if (sq) {   // join: everything after this call on the caller's stream sees all weight gradients
-        hipEventRecord(sq->ev[12], wstream);
-        hipStreamWaitEvent(stream, sq->ev[12], 0);
-    }
+    HowlPtrs6 gw;
+    for (int i = 0; i < 6; ++i) gw.p[i] = gr->conv_w[i];
+    hipLaunchKernelGGL(reduce_rows_all_kernel, dim3((CP * 432 + 63) / 64, 7), dim3(256), 0, stream, (const float*)w.wpart,
+                       wpart_stride, Gh, gw, (const float*)w.c0part, G, gr->conv0_w);
     HOWL_CHECK_LAUNCH("howl_res8_bwd");
     return HOWL_OK;
 }

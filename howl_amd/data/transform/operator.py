@@ -43,6 +43,7 @@ class ZmuvTransform(nn.Module):
         self.register_buffer("mean2", torch.zeros(1))
         self._scratch = None
         self._pair = None
+        self._pair_key = None      # (data_ptr, version) of mean / mean2 the cached pair was computed from
 
     def _dev_scratch(self):
         dev = self.mean.device
@@ -62,6 +63,7 @@ class ZmuvTransform(nn.Module):
                 self.total += mask_size
                 return
             ops.zmuv_update(data.contiguous(), self.total, self.mean, self.mean2, self._dev_scratch())
+            self._pair_key = None      # the kernel wrote the buffers behind torch's back
 
     def initialize(self, iterable: Iterable[torch.Tensor]):
         for ex in iterable:
@@ -72,9 +74,14 @@ class ZmuvTransform(nn.Module):
         return (self.mean2 - self.mean ** 2).sqrt()
 
     def pair(self) -> torch.Tensor:
-        """Device tensor ``[mean, std]`` for the fused epilogues (recomputed from the buffers each call, no sync)."""
+        """Device tensor ``[mean, std]`` for the fused epilogues; recomputed (one tiny launch, no sync) only when the
+        statistics changed since the last call -- not once per training step."""
         self._dev_scratch()
-        return ops.zmuv_pair(self.mean, self.mean2, self._pair)
+        key = (self.mean.data_ptr(), self.mean._version, self.mean2.data_ptr(), self.mean2._version, self._pair.data_ptr())
+        if key != self._pair_key:
+            ops.zmuv_pair(self.mean, self.mean2, self._pair)
+            self._pair_key = key
+        return self._pair
 
     def forward(self, x):
         return ops.zmuv_apply(x.contiguous(), self.pair())

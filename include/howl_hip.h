@@ -31,7 +31,9 @@ typedef struct ihipStream_t* hipStream_t;
 
 #define HOWL_MAX_MELS 48 /* mel bins supported by the MFMA contraction (3 tiles of 16); BASELINE configs use 40 */
 #define HOWL_FB_COLS 48  /* column count of a packed filterbank: (260, 48) fp32, zero padded */
-#define HOWL_FB_PACKED_FLOATS (260 * HOWL_FB_COLS)
+/* A packed filterbank is (260, 48) row-major floats followed by the same matrix in the fragment order of the mel
+ * contraction (17 bin groups x 12 mel groups x 64 lanes) and 24 int32 band limits (+ 8 words of padding). */
+#define HOWL_FB_PACKED_FLOATS (260 * HOWL_FB_COLS + 17 * (HOWL_FB_COLS / 4) * 64 + 32)
 
 int howl_version(int* major, int* minor);
 const char* howl_last_error(void);
@@ -55,7 +57,8 @@ int howl_shutdown(void);
  * MelSpectrogram / ComputeDeltas it calls; howl/data/transform/operator.py:119-146 (ZmuvTransform).
  * ------------------------------------------------------------------------------------------------- */
 
-/* (257, M) mel filterbank -> packed (260, 48) operand of howl_logmel_fwd.
+/* (257, M) mel filterbank -> packed operand of howl_logmel_fwd (HOWL_FB_PACKED_FLOATS floats; the first 260 x 48 are the
+ * zero-padded matrix itself).
  * Replaces the `.to(device)` of the CPU-built matrix at transform.py:435-443. */
 int howl_fb_pack(const float* fb, int M, float* fbp, hipStream_t stream);
 

@@ -31,7 +31,7 @@ def logmel(lib, audio, fbp, M=40, zmuv=None, layout=0):
 
 def test_fb_pack_and_points(lib):
     fb = fe.mel_fb(40).numpy()
-    fbp = pack_fb(lib, fb).reshape(260, 48)
+    fbp = pack_fb(lib, fb)[:260 * 48].reshape(260, 48)
     assert np.array_equal(fbp[:257, :40], fb) and not fbp[257:].any() and not fbp[:, 40:].any()
     # corner points -> triangles on the "device", standard and VTLP-warped (alpha > 1 quirk included)
     import math
@@ -49,7 +49,7 @@ def test_fb_pack_and_points(lib):
         out = np.zeros(FB_PACKED_FLOATS, np.float32)
         lib.call("howl_fb_from_points", pts, 40, 8000.0, ptr(out), None)
         ref = fe.mel_fb(40, alpha=alpha).numpy()
-        np.testing.assert_allclose(out.reshape(260, 48)[:257, :40], ref, rtol=0, atol=2e-7)
+        np.testing.assert_allclose(out[:260 * 48].reshape(260, 48)[:257, :40], ref, rtol=0, atol=2e-7)
 
 
 def test_logmel_matches_oracle_and_golden(lib, golden):
@@ -210,3 +210,26 @@ def test_gather_windows_edges(lib):
             exp = np.zeros(width, np.float32)
             exp[dst[b]:dst[b] + length[b]] = bank[idx[b], start[b]:start[b] + length[b]]
             assert np.array_equal(out[b], exp), (width, b)
+
+
+@pytest.mark.parametrize("M", [1, 7, 40, 48])
+def test_logmel_dense_filterbank_and_group_edges(lib, M):
+    """The mel contraction walks band limits per group of 4 mel bins: a dense random filterbank (every band = all 17 bin
+    groups), a filterbank with an empty column group in the middle, and mel counts that end inside / at the edge of a group."""
+    rng = np.random.default_rng(M)
+    B, L = 3, 1000                      # T = 6 frames per clip: 18 frames = 4.5 quads, frames straddle clips
+    audio = (0.3 * rng.standard_normal((B, L))).astype(np.float32)
+    power = fe.power_spectrogram(torch.from_numpy(audio))            # (B, 257, T)
+    for variant in ("dense", "holes"):
+        fb = rng.uniform(0.1, 1.0, (257, M)).astype(np.float32)
+        if variant == "holes":
+            fb[:, 4:8] = 0.0                                          # a whole group without weights (when M > 4)
+            fb[:100, : M // 2] = 0.0
+            fb[30:, M // 2:] *= (np.arange(257 - 30)[:, None] < 60)   # bands of different extent
+            fb[0, 0] = 0.5                                            # keep column 0 alive for M = 1
+        fbp = pack_fb(lib, fb)
+        ref = torch.log(torch.matmul(power.transpose(-1, -2), torch.from_numpy(fb)) + 1e-7).numpy()   # (B, T, M)
+        out = logmel(lib, audio, fbp, M=M, layout=1)
+        np.testing.assert_allclose(out, ref, rtol=0, atol=3e-4)
+        out0 = logmel(lib, audio, fbp, M=M, layout=0)
+        np.testing.assert_array_equal(out0.transpose(0, 2, 1), out)
