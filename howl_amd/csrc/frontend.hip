@@ -89,17 +89,23 @@ __device__ __forceinline__ void reduce_scatter_step(float (&v)[16], bool upper) 
     }
 }
 
+// A frame of the flattened (utterance, t) sequence; every field is wave-uniform (lives in SGPRs).
+struct FrameRef {
+    int b, t;
+    bool valid;
+};
+
 __global__ __launch_bounds__(256, 4) void logmel_kernel(const float* __restrict__ pcm, int L, long ld, int T,
-                                                        long total_frames, const float* __restrict__ fbp, int M,
+                                                        int total_frames, const float* __restrict__ fbp, int M,
                                                         float log_eps, const float* __restrict__ zmuv,
-                                                        float* __restrict__ out, int layout, long n_quads) {
+                                                        float* __restrict__ out, int layout, int n_quads) {
     __shared__ cf scratch[4 * SCR_CF];            // FFT transposes, private per wave
     __shared__ float Pq[4 * QUAD * PQ_STRIDE];    // power tile, private per wave
     __shared__ cf tw1[7 * 64];                    // stage-1 twiddles W_512^(lane*k), k = 1..7 (read-only after the prologue)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     cf* scr = scratch + wave * SCR_CF;
     float* P = Pq + wave * QUAD * PQ_STRIDE;
 
@@ -118,7 +124,6 @@ __global__ __launch_bounds__(256, 4) void logmel_kernel(const float* __restrict_
         const int k = 1 + i / 64, l = i & 63;
         tw1[i] = {HOWL_TW512[(l * 8 + k) * 2], HOWL_TW512[(l * 8 + k) * 2 + 1]};
     }
-    __syncthreads();                              // the only workgroup barrier of the kernel
     float zm_mean = 0.0f, zm_std = 1.0f;
     if (zmuv != nullptr) {
         zm_mean = zmuv[0];
@@ -126,143 +131,177 @@ __global__ __launch_bounds__(256, 4) void logmel_kernel(const float* __restrict_
     }
     // bins 257..271 of the tile are read by the last bin group (times a zero filterbank entry): keep them zero
     if (lane < QUAD * 16) P[(lane >> 4) * PQ_STRIDE + 256 + (lane & 15)] = 0.0f;
+    __syncthreads();                              // the only workgroup barrier of the kernel (tw1 filled)
     const int* band = reinterpret_cast<const int*>(fbp + FBQ_BAND_OFF);
     const float* frag = fbp + FBQ_OFF + lane;
     const int n_groups = (M + 3) >> 2;
 
-    // Raw samples of one frame pair (frames ga, ga + 1): reflect-padded centre framing.  They are requested one pair ahead
-    // of the FFT that consumes them, so the HBM round trip is spent under the previous pair's butterflies.
-    auto fetch_pair = [&](long ga, float (&xa)[8], float (&xb)[8]) {
-        const long gb = ga + 1;
-        const bool va = ga < total_frames, vb = gb < total_frames;
-        const long ba = va ? ga / T : 0, bb = vb ? gb / T : 0;
-        const int ta = va ? (int)(ga - ba * T) : 0, tb = vb ? (int)(gb - bb * T) : 0;
-        const float* rowa = pcm + ba * ld;
-        const float* rowb = pcm + bb * ld;
+    // frame g of the flattened sequence -> (utterance, t): one scalar division per quad, the other frames by stepping
+    auto frame_at = [&](int g) {
+        FrameRef f;
+        f.valid = g < total_frames;
+        const int gg = f.valid ? g : 0;
+        f.b = gg / T;
+        f.t = gg - f.b * T;
+        return f;
+    };
+    auto next_frame = [&](FrameRef f, int g) {    // g = index of the frame after f
+        ++f.t;
+        if (f.t >= T) {
+            f.t = 0;
+            ++f.b;
+        }
+        f.valid = g < total_frames;
+        if (!f.valid) f.b = f.t = 0;
+        return f;
+    };
+    // Raw samples of one frame, centre framing with reflect padding (torch.stft(center=True)).  Interior frames (all but
+    // the first two and last two or three of an utterance) are eight coalesced 256-B rows at immediate offsets from one
+    // wave-uniform base; only edge frames pay for the per-sample index arithmetic.  Invalid frames read nothing.
+    auto fetch_frame = [&](const FrameRef& f, float (&x)[8]) {
+        const float* row = pcm + (long)f.b * ld;
+        const int s0 = HOP * f.t - N_FFT / 2;
+        if (!f.valid) {
 #pragma unroll
-        for (int n1 = 0; n1 < 8; ++n1) {
-            const int n = 64 * n1 + lane;
-            int sa = HOP * ta - N_FFT / 2 + n;
-            int sb = HOP * tb - N_FFT / 2 + n;
-            sa = sa < 0 ? -sa : sa;
-            sb = sb < 0 ? -sb : sb;
-            sa = sa >= L ? 2 * (L - 1) - sa : sa;
-            sb = sb >= L ? 2 * (L - 1) - sb : sb;
-            const float a = rowa[sa], b = rowb[sb];  // always in range (frame 0 of row 0 for invalid frames)
-            xa[n1] = va ? a : 0.0f;
-            xb[n1] = vb ? b : 0.0f;
+            for (int n1 = 0; n1 < 8; ++n1) x[n1] = 0.0f;
+        } else if (s0 >= 0 && s0 + N_FFT <= L) {
+            const float* p0 = row + s0 + lane;
+#pragma unroll
+            for (int n1 = 0; n1 < 8; ++n1) x[n1] = p0[64 * n1];
+        } else {
+#pragma unroll
+            for (int n1 = 0; n1 < 8; ++n1) {
+                int sa = s0 + 64 * n1 + lane;
+                sa = sa < 0 ? -sa : sa;
+                sa = sa >= L ? 2 * (L - 1) - sa : sa;
+                x[n1] = row[sa];
+            }
+        }
+    };
+    // Two real frames (xa -> real part, xb -> imaginary part) through one complex FFT-512; |X|^2 of both to rows Pa, Pb.
+    auto fft_pair = [&](const float (&xa)[8], const float (&xb)[8], float* Pa, float* Pb) {
+        cf v[8];
+#pragma unroll
+        for (int n1 = 0; n1 < 8; ++n1) v[n1] = {xa[n1] * win[n1], xb[n1] * win[n1]};
+        // stage 1: radix-8 over n1 (stride 64), twiddle W_512^(lane*k1)
+        dft8(v);
+#pragma unroll
+        for (int k = 1; k < 8; ++k) {
+            const cf w = tw1[(k - 1) * 64 + lane];
+            v[k] = cmul(v[k], w.re, w.im);
+        }
+        wave_lds_sync();  // previous users of this scratch (power phase of the last pair) are done
+#pragma unroll
+        for (int k1 = 0; k1 < 8; ++k1) scr[k1 * X1_STRIDE + lane] = v[k1];
+        wave_lds_sync();
+        {   // stage 2: lane owns (k1 = lane & 7, b = lane >> 3), radix-8 over a with n2 = 8a + b
+            const int k1 = lane & 7, b = lane >> 3;
+#pragma unroll
+            for (int a = 0; a < 8; ++a) v[a] = scr[k1 * X1_STRIDE + 8 * a + b];
+            dft8(v);
+#pragma unroll
+            for (int c = 1; c < 8; ++c) v[c] = cmul(v[c], tw2r[c], tw2i[c]);
+            wave_lds_sync();
+#pragma unroll
+            for (int c = 0; c < 8; ++c) scr[k1 * X2_STRIDE + c * 8 + b] = v[c];
+            wave_lds_sync();
+        }
+        {   // stage 3: lane owns (k1 = lane & 7, c = lane >> 3), radix-8 over b -> Z[lane + 64 d]
+            const int k1 = lane & 7, c = lane >> 3;
+#pragma unroll
+            for (int b = 0; b < 8; ++b) v[b] = scr[k1 * X2_STRIDE + c * 8 + b];
+            dft8(v);
+        }
+        wave_lds_sync();
+#pragma unroll
+        for (int d = 0; d < 8; ++d) scr[lane + 64 * d] = v[d];
+        wave_lds_sync();
+        // separate the two real spectra and take |X|^2 for bins 0..256 (lane 0 also does bin 256)
+#pragma unroll
+        for (int r = 0; r < 5; ++r) {
+            const int k = lane + 64 * r;
+            if (r < 4 || lane == 0) {
+                const cf zk = (r < 4) ? v[r] : v[4];
+                const cf zn = scr[(N_FFT - k) & (N_FFT - 1)];
+                const float are = 0.5f * (zk.re + zn.re), aim = 0.5f * (zk.im - zn.im);
+                const float bre = 0.5f * (zk.im + zn.im), bim = -0.5f * (zk.re - zn.re);
+                Pa[k] = are * are + aim * aim;
+                Pb[k] = bre * bre + bim * bim;
+            }
         }
     };
 
-    const long wave_id = (long)blockIdx.x * 4 + wave, n_waves = (long)gridDim.x * 4;
-    float xa[8], xb[8], na[8], nb[8];
-    if (wave_id < n_quads) fetch_pair(QUAD * wave_id, xa, xb);
+    const int wave_id = (int)blockIdx.x * 4 + wave, n_waves = (int)gridDim.x * 4;
+    float xa[8], xb[8], ya[8], yb[8];
+    FrameRef f0 = frame_at(QUAD * wave_id);
+    FrameRef f1 = next_frame(f0, QUAD * wave_id + 1);
+    if (wave_id < n_quads) {
+        fetch_frame(f0, xa);
+        fetch_frame(f1, xb);
+    }
 
-    for (long quad = wave_id; quad < n_quads; quad += n_waves) {
-        const long g0 = QUAD * quad;
-        // ---- FFT phase: frame pairs (g0, g0+1) and (g0+2, g0+3) -------------------------------------------------
-#pragma unroll
-        for (int pr = 0; pr < 2; ++pr) {
-            if (pr == 0) fetch_pair(g0 + 2, na, nb);
-            else fetch_pair(QUAD * (quad + n_waves), na, nb);     // beyond the last quad: frames are invalid, reads frame 0
-            cf v[8];
-#pragma unroll
-            for (int n1 = 0; n1 < 8; ++n1) v[n1] = {xa[n1] * win[n1], xb[n1] * win[n1]};
-            // stage 1: radix-8 over n1 (stride 64), twiddle W_512^(lane*k1)
-            dft8(v);
-#pragma unroll
-            for (int k = 1; k < 8; ++k) {
-                const cf w = tw1[(k - 1) * 64 + lane];
-                v[k] = cmul(v[k], w.re, w.im);
-            }
-            wave_lds_sync();  // previous users of this scratch (power phase of the last pair) are done
-#pragma unroll
-            for (int k1 = 0; k1 < 8; ++k1) scr[k1 * X1_STRIDE + lane] = v[k1];
-            wave_lds_sync();
-            {   // stage 2: lane owns (k1 = lane & 7, b = lane >> 3), radix-8 over a with n2 = 8a + b
-                const int k1 = lane & 7, b = lane >> 3;
-#pragma unroll
-                for (int a = 0; a < 8; ++a) v[a] = scr[k1 * X1_STRIDE + 8 * a + b];
-                dft8(v);
-#pragma unroll
-                for (int c = 1; c < 8; ++c) v[c] = cmul(v[c], tw2r[c], tw2i[c]);
-                wave_lds_sync();
-#pragma unroll
-                for (int c = 0; c < 8; ++c) scr[k1 * X2_STRIDE + c * 8 + b] = v[c];
-                wave_lds_sync();
-            }
-            {   // stage 3: lane owns (k1 = lane & 7, c = lane >> 3), radix-8 over b -> Z[lane + 64 d]
-                const int k1 = lane & 7, c = lane >> 3;
-#pragma unroll
-                for (int b = 0; b < 8; ++b) v[b] = scr[k1 * X2_STRIDE + c * 8 + b];
-                dft8(v);
-            }
-            wave_lds_sync();
-#pragma unroll
-            for (int d = 0; d < 8; ++d) scr[lane + 64 * d] = v[d];
-            wave_lds_sync();
-            // separate the two real spectra and take |X|^2 for bins 0..256 (lane 0 also does bin 256)
-            float* Pa = P + 2 * pr * PQ_STRIDE;
-            float* Pb = Pa + PQ_STRIDE;
-#pragma unroll
-            for (int r = 0; r < 5; ++r) {
-                const int k = lane + 64 * r;
-                if (r < 4 || lane == 0) {
-                    const cf zk = (r < 4) ? v[r] : v[4];
-                    const cf zn = scr[(N_FFT - k) & (N_FFT - 1)];
-                    const float are = 0.5f * (zk.re + zn.re), aim = 0.5f * (zk.im - zn.im);
-                    const float bre = 0.5f * (zk.im + zn.im), bim = -0.5f * (zk.re - zn.re);
-                    Pa[k] = are * are + aim * aim;
-                    Pb[k] = bre * bre + bim * bim;
-                }
-            }
-#pragma unroll
-            for (int n1 = 0; n1 < 8; ++n1) {
-                xa[n1] = na[n1];
-                xb[n1] = nb[n1];
-            }
-        }
+    for (int quad = wave_id; quad < n_quads; quad += n_waves) {
+        const int g0 = QUAD * quad;
+        // ---- FFT phase: frame pairs (g0, g0+1) and (g0+2, g0+3); the next pair's samples are requested first ---------
+        const FrameRef f2 = next_frame(f1, g0 + 2), f3 = next_frame(f2, g0 + 3);
+        fetch_frame(f2, ya);
+        fetch_frame(f3, yb);
+        fft_pair(xa, xb, P, P + PQ_STRIDE);
+        const FrameRef q0 = f0, q1 = f1;          // this quad's frames, for the epilogue
+        const int gn = QUAD * (quad + n_waves);   // first frame of this wave's next quad (invalid beyond the batch)
+        f0 = frame_at(gn);
+        f1 = next_frame(f0, gn + 1);
+        fetch_frame(f0, xa);
+        fetch_frame(f1, xb);
+        fft_pair(ya, yb, P + 2 * PQ_STRIDE, P + 3 * PQ_STRIDE);
         wave_lds_sync();
         // ---- mel contraction: D_j[frame][mel] += P[frame][16 kg + j] * fb[16 kg + j][mel], blocks j summed afterwards ----
         const float* arow = P + (lane & 3) * PQ_STRIDE + (lane >> 2);
         // this lane's output after the reduce-scatter: frame r_out of the quad, mel column 16 * batch + c_out
         const int r_out = lane >> 4, c_out = lane & 15;
-        const long g_out = g0 + r_out;
+        const int g_out = g0 + r_out;
         long o_base;      // element offset of (frame g_out, mel 0); mel stride o_ms
         long o_ms;
         if (layout == 1) {
-            o_base = g_out * M;
+            o_base = (long)g_out * M;
             o_ms = 1;
         } else {
-            const long b = g_out / T;
-            o_base = b * M * T + (g_out - b * T);
+            const int b_out = r_out == 0 ? q0.b : (r_out == 1 ? q1.b : (r_out == 2 ? f2.b : f3.b));
+            const int t_out = r_out == 0 ? q0.t : (r_out == 1 ? q1.t : (r_out == 2 ? f2.t : f3.t));
+            o_base = (long)b_out * M * T + t_out;
             o_ms = T;
         }
 #pragma unroll
         for (int batch = 0; batch < NG / 4; ++batch) {
             if (4 * batch >= n_groups) break;
-            int lo[4], hi[4];
             int klo = KG, khi = 0;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                lo[c] = band[2 * (4 * batch + c)];
-                hi[c] = band[2 * (4 * batch + c) + 1];
-                if (hi[c] > lo[c]) {
-                    klo = lo[c] < klo ? lo[c] : klo;
-                    khi = hi[c] > khi ? hi[c] : khi;
+                const int lo = band[2 * (4 * batch + c)], hi = band[2 * (4 * batch + c) + 1];
+                if (hi > lo) {
+                    klo = lo < klo ? lo : klo;
+                    khi = hi > khi ? hi : khi;
                 }
             }
             f32x4 acc[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) acc[c] = {0.0f, 0.0f, 0.0f, 0.0f};
-            for (int kg = klo; kg < khi; ++kg) {
-                const float a = arow[16 * kg];
+            // two bin groups per trip, the second one's operands requested before the first one's MFMAs (a fragment is
+            // zero outside its group's band, so every group of the batch runs over the union [klo, khi) unpredicated)
+            for (int kg = klo; kg < khi; kg += 2) {
+                const bool two = kg + 1 < khi;
                 const float* fk = frag + (long)(kg * NG + 4 * batch) * 64;
-                float bv[4];
+                const float a0 = arow[16 * kg];
+                float b0[4], b1[4];
 #pragma unroll
-                for (int c = 0; c < 4; ++c) bv[c] = fk[64 * c];      // zero outside a group's band: no predicate needed
+                for (int c = 0; c < 4; ++c) b0[c] = fk[64 * c];
+                const float a1 = two ? arow[16 * kg + 16] : 0.0f;
 #pragma unroll
-                for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f32_4x4x1f32(a, bv[c], acc[c], 0, 0, 0);
+                for (int c = 0; c < 4; ++c) b1[c] = two ? fk[NG * 64 + 64 * c] : 0.0f;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f32_4x4x1f32(a0, b0[c], acc[c], 0, 0, 0);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f32_4x4x1f32(a1, b1[c], acc[c], 0, 0, 0);
             }
             // lane 4j+i holds D_j[r][4c + i] in acc[c][r]: index the 16 values by 4r + c, the block that will own the sum
             float v16[16];
@@ -599,10 +638,11 @@ int howl_logmel_fwd(const float* pcm, int B, int L, long ld, const float* fbp, i
     HOWL_REQUIRE(M >= 1 && M <= HOWL_MAX_MELS, "howl_logmel_fwd: M=%d unsupported (1..%d)", M, HOWL_MAX_MELS);
     HOWL_REQUIRE(layout == 0 || layout == 1, "howl_logmel_fwd: layout must be 0 (B,M,T) or 1 (B,T,M)");
     const int T = 1 + L / HOP;
-    const long total = (long)B * T;
-    const long n_quads = (total + QUAD - 1) / QUAD;
+    HOWL_REQUIRE((long)B * T < (1L << 31) - 4 * QUAD * 65536L, "howl_logmel_fwd: B*T = %ld frames exceeds the 32-bit frame index", (long)B * T);
+    const int total = B * T;
+    const int n_quads = (total + QUAD - 1) / QUAD;
     // four 4-wave workgroups are resident per CU (9 KB of LDS and <= 128 VGPRs per wave); a wave strides over the quads
-    long grid = (long)howl_num_cus() * 4;
+    int grid = howl_num_cus() * 4;
     if (grid > (n_quads + 3) / 4) grid = (n_quads + 3) / 4;
     {
         HowlProfScope prof("logmel", stream);
