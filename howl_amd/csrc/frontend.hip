@@ -24,6 +24,8 @@
 //  * epilogue: log(x + eps), optional ZMUV (x - mean) / std, 64-B contiguous stores as (B,T,M) [model layout] or (B,M,T).
 // 9 KB of LDS and <= 128 VGPRs per wave: 16 waves per CU hide the LDS / L2 latencies of the serial FFT stages.
 // Algorithmic HBM bytes per utterance: 4*L read + 4*M*T written (76,960 B at L=16000, M=40).
+#include <stdlib.h>
+
 #include "howl_common.hip.h"
 #include "howl_tables.h"
 #include "../../include/howl_hip.h"
@@ -88,6 +90,17 @@ __device__ __forceinline__ void reduce_scatter_step(float (&v)[16], bool upper) 
         v[i] = keep + __shfl_xor(send, XOR);
     }
 }
+
+#if defined(HOWL_DIAG_PROBE)  // diagnostic build (tools/probe_logmel.py): s_memtime stamps of workgroup 0, [wave][slot]
+__device__ unsigned long long* g_howl_probe_fe = nullptr;
+#define HOWL_FE_PROBE(wave_, lane_, slot_)                                                 \
+    do {                                                                                   \
+        if (g_howl_probe_fe != nullptr && blockIdx.x == 0 && (lane_) == 0 && (slot_) < 64) \
+            g_howl_probe_fe[(wave_) * 64 + (slot_)] = __builtin_amdgcn_s_memtime();         \
+    } while (0)
+#else
+#define HOWL_FE_PROBE(wave_, lane_, slot_) ((void)0)
+#endif
 
 // A frame of the flattened (utterance, t) sequence; every field is wave-uniform (lives in SGPRs).
 struct FrameRef {
@@ -232,6 +245,8 @@ __global__ __launch_bounds__(256, 4) void logmel_kernel(const float* __restrict_
     };
 
     const int wave_id = (int)blockIdx.x * 4 + wave, n_waves = (int)gridDim.x * 4;
+    int pslot = 0;
+    HOWL_FE_PROBE(wave, lane, pslot++);   // prologue done
     float xa[8], xb[8], ya[8], yb[8];
     FrameRef f0 = frame_at(QUAD * wave_id);
     FrameRef f1 = next_frame(f0, QUAD * wave_id + 1);
@@ -244,9 +259,11 @@ __global__ __launch_bounds__(256, 4) void logmel_kernel(const float* __restrict_
         const int g0 = QUAD * quad;
         // ---- FFT phase: frame pairs (g0, g0+1) and (g0+2, g0+3); the next pair's samples are requested first ---------
         const FrameRef f2 = next_frame(f1, g0 + 2), f3 = next_frame(f2, g0 + 3);
+        HOWL_FE_PROBE(wave, lane, pslot++);   // quad start
         fetch_frame(f2, ya);
         fetch_frame(f3, yb);
         fft_pair(xa, xb, P, P + PQ_STRIDE);
+        HOWL_FE_PROBE(wave, lane, pslot++);   // first pair transformed
         const FrameRef q0 = f0, q1 = f1;          // this quad's frames, for the epilogue
         const int gn = QUAD * (quad + n_waves);   // first frame of this wave's next quad (invalid beyond the batch)
         f0 = frame_at(gn);
@@ -255,6 +272,7 @@ __global__ __launch_bounds__(256, 4) void logmel_kernel(const float* __restrict_
         fetch_frame(f1, xb);
         fft_pair(ya, yb, P + 2 * PQ_STRIDE, P + 3 * PQ_STRIDE);
         wave_lds_sync();
+        HOWL_FE_PROBE(wave, lane, pslot++);   // second pair transformed
         // ---- mel contraction: D_j[frame][mel] += P[frame][16 kg + j] * fb[16 kg + j][mel], blocks j summed afterwards ----
         const float* arow = P + (lane & 3) * PQ_STRIDE + (lane >> 2);
         // this lane's output after the reduce-scatter: frame r_out of the quad, mel column 16 * batch + c_out
@@ -321,6 +339,7 @@ __global__ __launch_bounds__(256, 4) void logmel_kernel(const float* __restrict_
                 out[o_base + (long)m * o_ms] = y;
             }
         }
+        HOWL_FE_PROBE(wave, lane, pslot++);   // mel + epilogue done
     }
 }
 
@@ -562,6 +581,12 @@ __global__ __launch_bounds__(256) void gather_windows_kernel(const float* __rest
 
 }  // namespace
 
+#if defined(HOWL_DIAG_PROBE)
+extern "C" int howl_diag_set_probe_fe(unsigned long long* buf) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_howl_probe_fe), &buf, sizeof(buf));
+}
+#endif
+
 extern "C" {
 
 int howl_gather_windows(const float* bank, long bank_ld, const int* idx, const int* start, const int* len,
@@ -642,7 +667,9 @@ int howl_logmel_fwd(const float* pcm, int B, int L, long ld, const float* fbp, i
     const int total = B * T;
     const int n_quads = (total + QUAD - 1) / QUAD;
     // four 4-wave workgroups are resident per CU (9 KB of LDS and <= 128 VGPRs per wave); a wave strides over the quads
-    int grid = howl_num_cus() * 4;
+    int per_cu = 4;
+    if (const char* e = getenv("HOWL_LOGMEL_WGS_PER_CU")) per_cu = atoi(e) > 0 ? atoi(e) : 4;   // occupancy experiments
+    int grid = howl_num_cus() * per_cu;
     if (grid > (n_quads + 3) / 4) grid = (n_quads + 3) / 4;
     {
         HowlProfScope prof("logmel", stream);

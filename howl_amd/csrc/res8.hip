@@ -35,6 +35,18 @@ struct HowlBnBuffers {
     float* running_var;
     long long* num_batches;
 };
+// Statistics partials of the PRODUCING convolution handed to the consuming one: every workgroup of the consumer folds the
+// [nparts][2][48] rows itself (fp64, fixed order: identical in all workgroups) while its weights are in flight, instead of
+// a separate one-block kernel between the two launches; workgroup 0 also publishes mean / rstd for the later readers
+// (backward pass, head) and updates the running buffers.
+struct BnFold {
+    const float* part;   // nullptr: statistics come ready-made (in_stats), nothing to fold
+    int nparts;
+    double count;
+    float* stats_out;    // [2][48]
+    HowlBnBuffers bn;
+};
+
 
 constexpr int NMAP = 45;         // res8 feature maps (cnn.py:110)
 constexpr int CP = 48;           // channels padded to 3 MFMA tiles
@@ -77,11 +89,9 @@ __host__ __device__ inline int tile_floats_wgrad(int H) { return CP * chan_strid
 //   forward : B[k][n] = w[cout = 16nt + n][cin = 4*c0 + k][tap]
 //   dgrad   : B[k][n] = w[cout = 4*c0 + k][cin = 16nt + n][8 - tap]   (transposed, spatially flipped)
 // ---------------------------------------------------------------------------------------------------------
-__global__ void pack_weights_kernel(HowlPtrs6 w, float* __restrict__ wp_fwd, float* __restrict__ wp_bwd) {
-    const int layer = blockIdx.y;
-    const int mode = blockIdx.z;
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= 3 * KSTEPS * 64) return;
+constexpr int PACK_ELEMS = 3 * KSTEPS * 64;   // fragments of one layer, one direction
+__device__ __forceinline__ void pack_weights_one(const HowlPtrs6& w, float* __restrict__ wp_fwd, float* __restrict__ wp_bwd,
+                                                 int layer, int mode, int idx) {
     const int lane = idx & 63;
     const int ks = (idx >> 6) % KSTEPS;
     const int nt = idx / (64 * KSTEPS);
@@ -386,7 +396,8 @@ __device__ __forceinline__ void conv3x3_body(
     const float* __restrict__ xs,         // dgrad: s_{i-1} for xhat, or nullptr (no stats)
     const float* __restrict__ xs_stats,   // dgrad: {mean, rstd} of layer i-1
     float* __restrict__ part,             // [nblk][2][48] partial statistics, or nullptr
-    int B, int H, int bid, int nblk) {    // workgroup `bid` of the `nblk` that share this convolution
+    int B, int H, int bid, int nblk,      // workgroup `bid` of the `nblk` that share this convolution
+    const BnFold& fold) {                 // forward: the input's BatchNorm statistics still as partials (or part == nullptr)
     HIP_DYNAMIC_SHARED(float, lds)
     const int P = H * PW;
     const int CS = chan_stride(H);
@@ -405,7 +416,8 @@ __device__ __forceinline__ void conv3x3_body(
     const int n2 = NMAP * P / 2;
     const int ntiles = (P + 15) / 16;
     const int ntw = (ntiles - mg + 3) / 4;  // tiles j = mg, mg+4, ... < ntiles (wave-uniform, <= 5)
-    const bool affine = in_stats != nullptr;
+    const bool folding = MODE == 0 && fold.part != nullptr;
+    const bool affine = in_stats != nullptr || folding;
 
     // first utterance's activations are requested before anything else so that HBM latency overlaps the setup
     float2 pre[PREF];
@@ -422,6 +434,62 @@ __device__ __forceinline__ void conv3x3_body(
             wv[j] = (i < 3 * KSTEPS * 16) ? reinterpret_cast<const float4*>(wp)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
 #endif
         }
+        if (MODE == 0 && folding) {
+            // column sums of the producer's partials while the weight loads are in flight.  Thread (cg = tid % 24,
+            // rg = tid / 24): float4 column group cg of rows rg, rg + 32, ...; the 32 row groups meet in LDS (the weight
+            // region: its 83 KB are still in registers at this point) and 48 threads finish the two sums of their channel
+            // in a fixed order.
+            double* red = reinterpret_cast<double*>(wl);     // [32][96]
+            const int cg = tid % 24, rg = tid / 24;
+            double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+            for (int g0 = rg; g0 < fold.nparts; g0 += 8 * 32) {
+                float4 v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int g = g0 + j * 32;
+                    v[j] = reinterpret_cast<const float4*>(fold.part + (size_t)(g < fold.nparts ? g : fold.nparts - 1) * 2 * CP)[cg];
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const bool ok = g0 + j * 32 < fold.nparts;
+                    a0 += ok ? (double)v[j].x : 0.0;
+                    a1 += ok ? (double)v[j].y : 0.0;
+                    a2 += ok ? (double)v[j].z : 0.0;
+                    a3 += ok ? (double)v[j].w : 0.0;
+                }
+            }
+            red[rg * 2 * CP + 4 * cg + 0] = a0;
+            red[rg * 2 * CP + 4 * cg + 1] = a1;
+            red[rg * 2 * CP + 4 * cg + 2] = a2;
+            red[rg * 2 * CP + 4 * cg + 3] = a3;
+            __syncthreads();
+            if (tid < CP) {
+                double sum = 0.0, sq = 0.0;
+#pragma unroll 8
+                for (int g = 0; g < 32; ++g) {
+                    sum += red[g * 2 * CP + tid];
+                    sq += red[g * 2 * CP + CP + tid];
+                }
+                const double mean = sum / fold.count;
+                double var = sq / fold.count - mean * mean;
+                var = var < 0.0 ? 0.0 : var;
+                const float fm = (tid < NMAP) ? (float)mean : 0.0f;
+                const float fr = (tid < NMAP) ? (float)(1.0 / sqrt(var + (double)BN_EPS)) : 0.0f;
+                lmean[tid] = fm;
+                lrstd[tid] = fr;
+                if (bid == 0) {   // one publisher: later readers (backward pass) and the running buffers (cnn.py:142)
+                    fold.stats_out[tid] = fm;
+                    fold.stats_out[CP + tid] = fr;
+                    if (tid < NMAP && fold.bn.running_mean != nullptr) {
+                        const double unbiased = fold.count > 1.0 ? var * fold.count / (fold.count - 1.0) : var;
+                        fold.bn.running_mean[tid] = (1.0f - BN_MOMENTUM) * fold.bn.running_mean[tid] + BN_MOMENTUM * (float)mean;
+                        fold.bn.running_var[tid] = (1.0f - BN_MOMENTUM) * fold.bn.running_var[tid] + BN_MOMENTUM * (float)unbiased;
+                    }
+                    if (tid == 0 && fold.bn.num_batches != nullptr) fold.bn.num_batches[0] += 1;
+                }
+            }
+            __syncthreads();   // the sums are read before the weights take their region
+        }
         zero_lds(tile, TF, tid, CONV_THREADS);
 #pragma unroll
         for (int j = 0; j < 7; ++j) {
@@ -429,7 +497,7 @@ __device__ __forceinline__ void conv3x3_body(
             if (i < 3 * KSTEPS * 16) reinterpret_cast<float4*>(wl)[i] = wv[j];
         }
     }
-    if (tid < CP) {
+    if (!folding && tid < CP) {
         lmean[tid] = affine ? in_stats[tid] : 0.0f;
         lrstd[tid] = affine ? in_stats[CP + tid] : 1.0f;
     }
@@ -490,8 +558,8 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_mfma_kernel(const float*
                                                                     const float* __restrict__ res, float* __restrict__ out,
                                                                     const float* __restrict__ xs,
                                                                     const float* __restrict__ xs_stats,
-                                                                    float* __restrict__ part, int B, int H) {
-    conv3x3_body<MODE>(in, in_stats, wp, res, out, xs, xs_stats, part, B, H, blockIdx.x, gridDim.x);
+                                                                    float* __restrict__ part, int B, int H, BnFold fold) {
+    conv3x3_body<MODE>(in, in_stats, wp, res, out, xs, xs_stats, part, B, H, blockIdx.x, gridDim.x, fold);
 }
 
 #if defined(HOWL_DIAG_PROBE)  // diagnostic build (tools/probe_wgrad.py): s_memtime stamps of workgroup 0, [wave][slot]
@@ -715,7 +783,7 @@ __global__ __launch_bounds__(CONV_THREADS) void bwd_pair_kernel(
     const int j = (int)(blockIdx.x >> 4) * 8 + (int)(blockIdx.x & 7);
     if (j >= nblk) return;
     if (role == 0)
-        conv3x3_body<1>(dz, nullptr, wp, nullptr, dx, xs, xs_stats, spart, B, H, j, nblk);
+        conv3x3_body<1>(dz, nullptr, wp, nullptr, dx, xs, xs_stats, spart, B, H, j, nblk, BnFold{});
     else
         wgrad_body(dz, s_prev, in_stats, wpart, B, H, j, nblk);
 }
@@ -967,10 +1035,19 @@ constexpr int C0M_THREADS = 512;   // 8 waves, two per SIMD
 // 3ph + tl.  The three frames of a cell are three tiles accumulated by the SAME lanes, and a lane holds the 4 mel bins of
 // one cell (rows 4g + r, g = pwl): ReLU, the 3x4 sum and the 12 mask bits are all lane-local, no cross-lane traffic.
 // 40 mel bins = 2.5 blocks of 16: the third block computes two cells of padding.
+// Workgroups beyond the first `nconv` do an unrelated, independent job in the same launch: they rebuild the packed 3x3
+// weight fragments of the six following layers (the weights may have changed since the last call), which the first 3x3
+// convolution needs only after this kernel has finished anyway.
 __global__ __launch_bounds__(C0M_THREADS) void conv0_fwd_mfma_kernel(const float* __restrict__ feat, long sb, long st,
                                                                     long sm, const float* __restrict__ w0,
                                                                     float* __restrict__ s0, unsigned short* __restrict__ mask0,
-                                                                    int B, int T, int M, int H) {
+                                                                    int B, int T, int M, int H, int nconv, HowlPtrs6 cw,
+                                                                    float* __restrict__ wp_fwd, float* __restrict__ wp_bwd) {
+    if ((int)blockIdx.x >= nconv) {
+        const int e = ((int)blockIdx.x - nconv) * C0M_THREADS + (int)threadIdx.x;   // (mode, layer, fragment element)
+        if (e < 2 * 6 * PACK_ELEMS) pack_weights_one(cw, wp_fwd, wp_bwd, (e / PACK_ELEMS) % 6, e / (6 * PACK_ELEMS), e % PACK_ELEMS);
+        return;
+    }
     HIP_DYNAMIC_SHARED(float, lds)
     float* tin = lds;  // (T+2) x (M+4), zero halo (+ 16 floats of slack for the padding cells of the last block)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -994,7 +1071,7 @@ __global__ __launch_bounds__(C0M_THREADS) void conv0_fwd_mfma_kernel(const float
         aoff[ks] = (tap / 3) * pitch + tap % 3 + n;
     }
     if (tid < 16) tin[(T + 2) * pitch + tid] = 0.0f;  // slack read by the padding cells
-    for (int b = blockIdx.x; b < B; b += gridDim.x) {
+    for (int b = blockIdx.x; b < B; b += nconv) {
         __syncthreads();
         load_feat_tile(tin, feat, sb, st, sm, b, T, M, tid, C0M_THREADS);
         __syncthreads();
@@ -1326,6 +1403,7 @@ struct Ws {
     float* wp_fwd;   // [6][3][108][64]
     float* wp_bwd;
     float* part;     // statistics partials [G][2][48]
+    float* part2;    // second set: a forward layer writes one while the next layer's prologue may still read the other
     float* stats;    // eval-mode stats [6][2][48]
     float* m12;      // [2][48]
     float* dpool;    // [B][48]
@@ -1351,6 +1429,7 @@ size_t ws_layout(Ws* w, char* base, int B, int H, int G) {
     t.wp_fwd = take((size_t)6 * 3 * KSTEPS * 64);
     t.wp_bwd = take((size_t)6 * 3 * KSTEPS * 64);
     t.part = take((size_t)G * 2 * CP);
+    t.part2 = take((size_t)G * 2 * CP);
     t.stats = take((size_t)6 * 2 * CP);
     t.m12 = take(2 * CP);
     t.dpool = take((size_t)B * CP);
@@ -1405,8 +1484,6 @@ int howl_res8_fwd(const HowlRes8Params* prm, const float* feat, long sb, long st
         rm.p[i] = prm->bn_running_mean[i];
         rv.p[i] = prm->bn_running_var[i];
     }
-    hipLaunchKernelGGL(pack_weights_kernel, dim3((3 * KSTEPS * 64 + 255) / 256, 6, 2), dim3(256), 0, stream, cw, w.wp_fwd,
-                       w.wp_bwd);
     if (!training) hipLaunchKernelGGL(bn_eval_stats_kernel, dim3(6), dim3(64), 0, stream, rm, rv, sv->bn_stats);
 
     const size_t l0 = ((size_t)(T + 2) * (M + 4) + 16) * sizeof(float);
@@ -1414,29 +1491,40 @@ int howl_res8_fwd(const HowlRes8Params* prm, const float* feat, long sb, long st
     const int G0 = B < 2 * howl_num_cus() ? B : 2 * howl_num_cus();
     {
         HowlProfScope prof("conv0_fwd", stream);
-        hipLaunchKernelGGL(conv0_fwd_mfma_kernel, dim3(G0), dim3(C0M_THREADS), l0, stream, feat, sb, st, sm, prm->conv0_w,
-                           sv->s[0], sv->mask0, B, T, M, H);
+        const int npack = (2 * 6 * PACK_ELEMS + C0M_THREADS - 1) / C0M_THREADS;
+        hipLaunchKernelGGL(conv0_fwd_mfma_kernel, dim3(G0 + npack), dim3(C0M_THREADS), l0, stream, feat, sb, st, sm,
+                           prm->conv0_w, sv->s[0], sv->mask0, B, T, M, H, G0, cw, w.wp_fwd, w.wp_bwd);
     }
     const size_t lc = conv_lds_bytes(H);
     hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_mfma_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
                         (int)lc);
     const double count = (double)B * (double)P;
+    // Training: layer i leaves its statistics as per-workgroup partials; layer i+1 folds them in its own prologue (BnFold),
+    // so only the last layer needs the stand-alone finalize.  The partial buffers alternate between layers.
     for (int i = 1; i <= 6; ++i) {
-        const float* in_stats = (i == 1) ? nullptr : sv->bn_stats + (size_t)(i - 2) * 2 * CP;
         const bool even = (i % 2) == 0;
         const float* res = even ? sv->s[i - 2] : nullptr;
+        float* part_out = training ? ((i & 1) ? w.part : w.part2) : (float*)nullptr;
+        BnFold fold{};
+        const float* in_stats = nullptr;
+        if (i > 1) {
+            if (training)
+                fold = BnFold{(i & 1) ? w.part2 : w.part, G, count, sv->bn_stats + (size_t)(i - 2) * 2 * CP,
+                              HowlBnBuffers{prm->bn_running_mean[i - 2], prm->bn_running_var[i - 2], prm->bn_num_batches[i - 2]}};
+            else
+                in_stats = sv->bn_stats + (size_t)(i - 2) * 2 * CP;
+        }
         {
             HowlProfScope prof("conv3x3_fwd", stream);
             hipLaunchKernelGGL(conv3x3_mfma_kernel<0>, dim3(G), dim3(CONV_THREADS), lc, stream, sv->s[i - 1], in_stats,
                                w.wp_fwd + (size_t)(i - 1) * 3 * KSTEPS * 64, res, sv->s[i], (const float*)nullptr,
-                               (const float*)nullptr, training ? w.part : (float*)nullptr, B, H);
+                               (const float*)nullptr, part_out, B, H, fold);
         }
-        if (training)
-            hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(1024), 0, stream, w.part, G, count,
-                               sv->bn_stats + (size_t)(i - 1) * 2 * CP,
-                               HowlBnBuffers{prm->bn_running_mean[i - 1], prm->bn_running_var[i - 1],
-                                             prm->bn_num_batches[i - 1]});
     }
+    if (training)
+        hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(1024), 0, stream, w.part2, G, count,
+                           sv->bn_stats + (size_t)5 * 2 * CP,
+                           HowlBnBuffers{prm->bn_running_mean[5], prm->bn_running_var[5], prm->bn_num_batches[5]});
     hipLaunchKernelGGL(head_fwd_kernel, dim3(B < 1024 ? B : 1024), dim3(256), 0, stream, sv->s[6],
                        sv->bn_stats + (size_t)5 * 2 * CP, prm->out_w, prm->out_b, sv->pooled, logits, B, P, C);
     HOWL_CHECK_LAUNCH("howl_res8_fwd");
@@ -1513,7 +1601,7 @@ int howl_res8_bwd(const HowlRes8Params* prm, const float* feat, long sb, long st
             {
                 HowlProfScope prof("conv3x3_dgrad", stream);
                 hipLaunchKernelGGL(conv3x3_mfma_kernel<1>, dim3(Gh), dim3(CONV_THREADS), lc, stream, (const float*)dz,
-                                   (const float*)nullptr, wpb, (const float*)nullptr, dx_next, xs, in_stats, spart, B, H);
+                                   (const float*)nullptr, wpb, (const float*)nullptr, dx_next, xs, in_stats, spart, B, H, BnFold{});
             }
             HowlProfScope prof("wgrad", stream);
             hipLaunchKernelGGL(wgrad_mfma_kernel, dim3(Gh), dim3(CONV_THREADS), lw, stream, (const float*)dz, sv->s[i - 1],
