@@ -30,6 +30,10 @@ namespace {
 struct HowlPtrs6 {
     float* p[6];
 };
+constexpr int MAX_WINDOWS = 64;   // howl_res8_fwd_long: 64 windows of 13 new pooled rows each = clips up to ~2,500 frames (25 s)
+struct HowlWinRows {
+    int lo[MAX_WINDOWS], hi[MAX_WINDOWS];
+};
 struct HowlBnBuffers {
     float* running_mean;
     float* running_var;
@@ -1042,7 +1046,8 @@ __global__ __launch_bounds__(C0M_THREADS) void conv0_fwd_mfma_kernel(const float
                                                                     long sm, const float* __restrict__ w0,
                                                                     float* __restrict__ s0, unsigned short* __restrict__ mask0,
                                                                     int B, int T, int M, int H, int nconv, HowlPtrs6 cw,
-                                                                    float* __restrict__ wp_fwd, float* __restrict__ wp_bwd) {
+                                                                    float* __restrict__ wp_fwd, float* __restrict__ wp_bwd,
+                                                                    int nwin, int win_step, int win_last) {
     if ((int)blockIdx.x >= nconv) {
         const int e = ((int)blockIdx.x - nconv) * C0M_THREADS + (int)threadIdx.x;   // (mode, layer, fragment element)
         if (e < 2 * 6 * PACK_ELEMS) pack_weights_one(cw, wp_fwd, wp_bwd, (e / PACK_ELEMS) % 6, e / (6 * PACK_ELEMS), e % PACK_ELEMS);
@@ -1073,7 +1078,10 @@ __global__ __launch_bounds__(C0M_THREADS) void conv0_fwd_mfma_kernel(const float
     if (tid < 16) tin[(T + 2) * pitch + tid] = 0.0f;  // slack read by the padding cells
     for (int b = blockIdx.x; b < B; b += nconv) {
         __syncthreads();
-        load_feat_tile(tin, feat, sb, st, sm, b, T, M, tid, C0M_THREADS);
+        // long inputs (howl_res8_fwd_long): "utterance" b is window b % nwin of clip b / nwin, T frames from its start frame
+        const int clip = b / nwin, wi = b - clip * nwin;
+        const int t0 = min(wi * win_step, win_last);
+        load_feat_tile(tin, feat + (long)clip * sb + (long)t0 * st, 0, st, sm, 0, T, M, tid, C0M_THREADS);
         __syncthreads();
         for (int ph = wave; ph < H; ph += C0M_THREADS / 64) {
             const float* rowp = tin + 3 * ph * pitch;
@@ -1248,6 +1256,38 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
                     pooled[(size_t)b * CP + c] = v;
                 }
             }
+        }
+        __syncthreads();
+        for (int k = tid; k < C; k += 256) {
+            float acc = bout[k];
+            for (int c = 0; c < NMAP; ++c) acc = fmaf(wout[k * NMAP + c], lp[c], acc);
+            logits[(size_t)b * C + k] = acc;
+        }
+    }
+}
+
+// Long inputs: clip b was processed as nwin overlapping windows of Hw pooled rows (virtual utterances b*nwin + w); window w
+// contributes its rows [lo[w], hi[w]) -- a partition of the clip's rows, away from the windows' own zero padding -- to the
+// spatial mean.  Otherwise head_fwd_kernel: BatchNorm (running statistics), mean, Linear.
+__global__ __launch_bounds__(256) void head_fwd_windows_kernel(const float* __restrict__ s6, const float* __restrict__ stats,
+                                                               const float* __restrict__ wout, const float* __restrict__ bout,
+                                                               float* __restrict__ logits, int B, int nwin, int Hw,
+                                                               HowlWinRows rows, float inv_count, int C) {
+    __shared__ float lp[CP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int Pw = Hw * PW;
+    for (int b = blockIdx.x; b < B; b += gridDim.x) {
+        __syncthreads();
+        for (int c = wave; c < CP; c += 4) {
+            float acc = 0.0f;
+            if (c < NMAP) {
+                for (int w = 0; w < nwin; ++w) {
+                    const float* src = s6 + ((size_t)(b * nwin + w) * NMAP + c) * Pw;
+                    for (int i = rows.lo[w] * PW + lane; i < rows.hi[w] * PW; i += 64) acc += fabsf(src[i]);
+                }
+            }
+            acc = wave_sum(acc);
+            if (lane == 0) lp[c] = c < NMAP ? (acc * inv_count - stats[c]) * stats[CP + c] : 0.0f;
         }
         __syncthreads();
         for (int k = tid; k < C; k += 256) {
@@ -1493,7 +1533,7 @@ int howl_res8_fwd(const HowlRes8Params* prm, const float* feat, long sb, long st
         HowlProfScope prof("conv0_fwd", stream);
         const int npack = (2 * 6 * PACK_ELEMS + C0M_THREADS - 1) / C0M_THREADS;
         hipLaunchKernelGGL(conv0_fwd_mfma_kernel, dim3(G0 + npack), dim3(C0M_THREADS), l0, stream, feat, sb, st, sm,
-                           prm->conv0_w, sv->s[0], sv->mask0, B, T, M, H, G0, cw, w.wp_fwd, w.wp_bwd);
+                           prm->conv0_w, sv->s[0], sv->mask0, B, T, M, H, G0, cw, w.wp_fwd, w.wp_bwd, 1, 0, 0);
     }
     const size_t lc = conv_lds_bytes(H);
     hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_mfma_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1528,6 +1568,94 @@ int howl_res8_fwd(const HowlRes8Params* prm, const float* feat, long sb, long st
     hipLaunchKernelGGL(head_fwd_kernel, dim3(B < 1024 ? B : 1024), dim3(256), 0, stream, sv->s[6],
                        sv->bn_stats + (size_t)5 * 2 * CP, prm->out_w, prm->out_b, sv->pooled, logits, B, P, C);
     HOWL_CHECK_LAUNCH("howl_res8_fwd");
+    return HOWL_OK;
+}
+
+// ---- long inputs (eval mode) --------------------------------------------------------------------------------------------------
+// The kernels keep one utterance's whole (45, H, 10) map in LDS, H <= 27 pooled rows (83 frames).  A longer clip is cut into
+// windows of 27 pooled rows that overlap by 14: the six 3x3 convolutions (and conv0's own frame) spread a window's zero
+// padding 7 rows inwards, so a window's rows [7, 20) -- [0, 20) for the first, [7, 27) for the last -- are exactly what the
+// unbounded convolution stack computes, and those ranges tile the clip.  Inference statistics are per channel constants,
+// so nothing couples the windows except the final spatial mean.  (Training on such windows would need BatchNorm batch
+// statistics over the de-duplicated rows: not offered; the reference's training windows are <= 1 s.)
+namespace {
+constexpr int WIN_H = MAX_H, WIN_MARGIN = 7, WIN_STEP = WIN_H - 2 * WIN_MARGIN;   // 27, 7, 13
+int long_windows(int H) { return H <= WIN_H ? 1 : (H - WIN_H + WIN_STEP - 1) / WIN_STEP + 1; }
+}  // namespace
+
+size_t howl_res8_long_workspace_bytes(int B, int T) {
+    const int H = T / 3, nw = long_windows(H);
+    const size_t Bv = (size_t)B * nw;
+    // three rotating activation maps + eval statistics + the regular workspace of the virtual batch
+    static_assert((6 * 2 * CP * sizeof(float)) % 256 == 0, "statistics block keeps the 256-byte alignment");
+    return 3 * (((Bv * NMAP * WIN_H * PW * sizeof(float)) + 255) / 256 * 256) + 6 * 2 * CP * sizeof(float) + 256 +
+           howl_res8_workspace_bytes((int)Bv, 3 * WIN_H);
+}
+
+int howl_res8_fwd_long(const HowlRes8Params* prm, const float* feat, long sb, long st, long sm, int B, int T, int M, int C,
+                       float* logits, void* ws, size_t ws_bytes, hipStream_t stream) {
+    HOWL_REQUIRE(prm && feat && logits && ws, "howl_res8_fwd_long: null pointer");
+    HOWL_REQUIRE(M == 40, "howl_res8_fwd_long: res8 pools (3,4) over 40 mel bins; got M=%d", M);
+    const int H = T / 3;
+    HOWL_REQUIRE(B >= 1 && H > WIN_H && C >= 1, "howl_res8_fwd_long: for T > 83 frames (got B=%d T=%d); shorter inputs use howl_res8_fwd", B, T);
+    const int nw = long_windows(H);
+    HOWL_REQUIRE(nw <= MAX_WINDOWS, "howl_res8_fwd_long: T=%d needs %d windows (max %d)", T, nw, MAX_WINDOWS);
+    if (ws_bytes < howl_res8_long_workspace_bytes(B, T)) {
+        howl_set_error("howl_res8_fwd_long: workspace %zu < %zu bytes", ws_bytes, howl_res8_long_workspace_bytes(B, T));
+        return HOWL_E_WORKSPACE;
+    }
+    // T % 3 trailing frames take no part in the pooling but are conv0's neighbours of the clip's last frame: every window
+    // reads them too (inner windows simply see real samples there instead of padding, inside their discarded margin)
+    const int Bv = B * nw, Tw = 3 * WIN_H + T % 3, P = WIN_H * PW;
+    const size_t act = ((size_t)Bv * NMAP * P * sizeof(float) + 255) / 256 * 256;
+    char* base = static_cast<char*>(ws);
+    float* buf[3] = {reinterpret_cast<float*>(base), reinterpret_cast<float*>(base + act), reinterpret_cast<float*>(base + 2 * act)};
+    float* stats = reinterpret_cast<float*>(base + 3 * act);
+    Ws w;
+    ws_layout(&w, base + 3 * act + 6 * 2 * CP * sizeof(float) + 256, Bv, WIN_H, conv_grid(Bv));
+    HowlWinRows rows;
+    for (int i = 0; i < nw; ++i) {
+        const int a = i * WIN_STEP < H - WIN_H ? i * WIN_STEP : H - WIN_H;          // first pooled row of window i
+        const int a_next = (i + 1) * WIN_STEP < H - WIN_H ? (i + 1) * WIN_STEP : H - WIN_H;
+        const int g_lo = i == 0 ? 0 : a + WIN_MARGIN;                              // clip rows [g_lo, g_hi) come from window i
+        const int g_hi = i == nw - 1 ? H : a_next + WIN_MARGIN;
+        rows.lo[i] = g_lo - a;
+        rows.hi[i] = g_hi - a;
+    }
+    HowlPtrs6 cw, rm, rv;
+    for (int i = 0; i < 6; ++i) {
+        cw.p[i] = const_cast<float*>(prm->conv_w[i]);
+        rm.p[i] = prm->bn_running_mean[i];
+        rv.p[i] = prm->bn_running_var[i];
+    }
+    hipLaunchKernelGGL(bn_eval_stats_kernel, dim3(6), dim3(64), 0, stream, rm, rv, stats);
+    const size_t l0 = ((size_t)(Tw + 2) * (M + 4) + 16) * sizeof(float);
+    const int G0 = Bv < 2 * howl_num_cus() ? Bv : 2 * howl_num_cus();
+    const int npack = (2 * 6 * PACK_ELEMS + C0M_THREADS - 1) / C0M_THREADS;
+    hipLaunchKernelGGL(conv0_fwd_mfma_kernel, dim3(G0 + npack), dim3(C0M_THREADS), l0, stream, feat, sb, st, sm, prm->conv0_w,
+                       buf[0], (unsigned short*)nullptr, Bv, Tw, M, WIN_H, G0, cw, w.wp_fwd, w.wp_bwd, nw, 3 * WIN_STEP,
+                       3 * (H - WIN_H));
+    const size_t lc = conv_lds_bytes(WIN_H);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_mfma_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                        (int)lc);
+    const int G = conv_grid(Bv);
+    // x_i lives in buf[cur]; even layers add the map two layers back (kept in buf[skip])
+    int cur = 0, skip = 0;
+    for (int i = 1; i <= 6; ++i) {
+        const bool even = (i % 2) == 0;
+        int out = 0;
+        while (out == cur || out == skip) ++out;
+        hipLaunchKernelGGL(conv3x3_mfma_kernel<0>, dim3(G), dim3(CONV_THREADS), lc, stream, (const float*)buf[cur],
+                           i == 1 ? (const float*)nullptr : (const float*)(stats + (size_t)(i - 2) * 2 * CP),
+                           w.wp_fwd + (size_t)(i - 1) * 3 * KSTEPS * 64, even ? (const float*)buf[skip] : (const float*)nullptr,
+                           buf[out], (const float*)nullptr, (const float*)nullptr, (float*)nullptr, Bv, WIN_H, BnFold{});
+        if (even) skip = out;      // s_i (i even) is the next residual source; s_0 is the first one
+        cur = out;
+    }
+    hipLaunchKernelGGL(head_fwd_windows_kernel, dim3(B < 1024 ? B : 1024), dim3(256), 0, stream, (const float*)buf[cur],
+                       (const float*)(stats + (size_t)5 * 2 * CP), prm->out_w, prm->out_b, logits, B, nw, WIN_H, rows,
+                       1.0f / ((float)H * PW), C);
+    HOWL_CHECK_LAUNCH("howl_res8_fwd_long");
     return HOWL_OK;
 }
 

@@ -75,6 +75,7 @@ SIGNATURES = {
     "howl_specaug_mask": [P, c_int, c_int, c_int, c_int, c_long, c_long, c_long, c_long, P, P, P, P, STREAM],
     "howl_res8_fwd": [POINTER(HowlRes8Params), P, c_long, c_long, c_long, c_int, c_int, c_int, c_int, c_int,
                       POINTER(HowlRes8Saved), P, P, c_size_t, STREAM],
+    "howl_res8_fwd_long": [POINTER(HowlRes8Params), P, c_long, c_long, c_long, c_int, c_int, c_int, c_int, P, P, c_size_t, STREAM],
     "howl_res8_bwd": [POINTER(HowlRes8Params), P, c_long, c_long, c_long, c_int, c_int, c_int, c_int,
                       POINTER(HowlRes8Saved), P, POINTER(HowlRes8Grads), P, c_size_t, STREAM],
     "howl_xent_fwd_bwd": [P, P, c_int, c_int, P, P, STREAM],
@@ -93,7 +94,7 @@ SIGNATURES = {
     "howl_mobilenet_bwd": [P, c_int, P, c_long, c_long, c_long, c_int, c_int, c_int, P, c_float, P, P, P, c_size_t, STREAM],
 }
 # entry points that do not return an int status
-SIZE_FUNCS = {"howl_res8_workspace_bytes": [c_int, c_int], "howl_lstm_workspace_bytes": [c_int, c_int],
+SIZE_FUNCS = {"howl_res8_workspace_bytes": [c_int, c_int], "howl_res8_long_workspace_bytes": [c_int, c_int], "howl_lstm_workspace_bytes": [c_int, c_int],
               "howl_linear_workspace_bytes": [c_int, c_int], "howl_mobilenet_num_layers": [],
               "howl_mobilenet_param_floats": [c_int], "howl_mobilenet_buffer_floats": [],
               "howl_mobilenet_workspace_bytes": [c_int, c_int, c_int, c_int],

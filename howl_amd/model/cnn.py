@@ -138,9 +138,29 @@ class Res8(RegisteredModel, name="res8"):
         return x0, x0.stride(0), x0.stride(2), x0.stride(1)
 
     # ---- launches ----------------------------------------------------------------------------------------------
+    MAX_FRAMES = 83     # one utterance's pooled map (27 rows) lives in LDS; longer inputs are windowed (inference only)
+
+    def _launch_forward_long(self, x0, sb, st, sm):
+        """Inputs beyond 83 frames (``ConvertedStaticModel``'s first window, engine clips > 1 s): ``howl_res8_fwd_long``."""
+        if self.training:
+            raise NotImplementedError(f"Res8 on MI355X trains on windows of up to {self.MAX_FRAMES} frames (1.03 s; the "
+                                      f"reference's presets use 0.5 s / 1 s); got T={x0.shape[2]}. Longer inputs are "
+                                      "supported in eval mode")
+        B, M, T = x0.shape
+        nbytes = _lib.get().cdll.howl_res8_long_workspace_bytes(B, T)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=x0.device)
+        logits = torch.empty((B, self.num_labels), dtype=torch.float32, device=x0.device)
+        prm = self._params_struct()
+        _lib.get().call("howl_res8_fwd_long", ctypes.byref(prm), ctypes.c_void_p(x0.data_ptr()), sb, st, sm, B, T, M,
+                        self.num_labels, ctypes.c_void_p(logits.data_ptr()), ctypes.c_void_p(ws.data_ptr()), ws.numel(),
+                        ops._stream())
+        return logits
+
     def _launch_forward(self, feat, grads_struct=None):
         x0, sb, st, sm = self._feat_view(feat)
         B, M, T = x0.shape
+        if T > self.MAX_FRAMES:
+            return self._launch_forward_long(x0, sb, st, sm)
         buf = self._get_buffers(B, T, x0.device)
         logits = torch.empty((B, self.num_labels), dtype=torch.float32, device=x0.device)
         prm = self._params_struct()

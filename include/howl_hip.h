@@ -173,6 +173,15 @@ int howl_res8_fwd(const HowlRes8Params* prm, const float* feat, long sb, long st
                   int training, const HowlRes8Saved* saved, float* logits, void* ws, size_t ws_bytes,
                   hipStream_t stream);
 
+/* Inference-mode forward for inputs longer than the kernels' on-chip map (T > 83 frames, up to ~2,500): the clip is cut
+ * into overlapping 27-row windows whose interiors tile it exactly (the six 3x3 convolutions spread a window's padding 7 pooled
+ * rows inwards), the windows run as a virtual batch and only the final spatial mean sees them together.  Same arguments
+ * as howl_res8_fwd without `training` (running statistics are used) and without saved activations; results equal
+ * cnn.py:127-145 on the whole clip (ConvertedStaticModel's first window, base.py:52-62, and engine clips > 1 s). */
+size_t howl_res8_long_workspace_bytes(int B, int T);
+int howl_res8_fwd_long(const HowlRes8Params* prm, const float* feat, long sb, long st, long sm, int B, int T, int M, int C,
+                       float* logits, void* ws, size_t ws_bytes, hipStream_t stream);
+
 /* backward of a training-mode forward: dlogits (B,C) -> parameter gradients (overwritten, not accumulated).
  * Replaces loss.backward() through cnn.py:127-145 (pretrain_gsc.py:131, train.py:294).  Per layer, the data gradient and
  * the weight gradient are launched side by side on two HIP queues (see Conventions); the results do not depend on the

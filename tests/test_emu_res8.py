@@ -141,3 +141,30 @@ def test_adamw(lib):
         tp.grad = torch.from_numpy(g.copy())
         opt.step()
         np.testing.assert_allclose(p, tp.detach().numpy(), rtol=0, atol=2e-6)
+
+
+@pytest.mark.parametrize("B,T", [(2, 84), (1, 120), (2, 201), (1, 164)])
+def test_long_input_windows_vs_oracle(lib, B, T):
+    """howl_res8_fwd_long: clips beyond the 83-frame on-chip map run as overlapping 27-row windows; the logits must equal the
+    oracle's eval-mode forward over the whole clip (cnn.py:127-145 accepts any T).  T = 84: one row more than fits;
+    T % 3 != 0: trailing frames that only conv0 sees; 201: five windows; 164: the last window overlaps its neighbour most."""
+    C = 12
+    sd = om.res8_init(C)
+    rng = np.random.default_rng(T)
+    for i in range(1, 7):      # non-trivial running statistics
+        sd[f"bn{i}.running_mean"] = torch.from_numpy(rng.uniform(0.1, 0.6, 45).astype(np.float32))
+        sd[f"bn{i}.running_var"] = torch.from_numpy(rng.uniform(0.5, 2.0, 45).astype(np.float32))
+    h = Res8Harness(lib, 1, 81, C, sd=sd)           # parameter plumbing only
+    x = feats(B, T, seed=T + 1)
+    ref = om.res8_forward({k: v.clone() for k, v in sd.items()}, x, False).numpy()
+    f = np.ascontiguousarray(x[:, 0].permute(0, 2, 1).numpy())      # (B, T, M)
+    ws = np.zeros(lib.cdll.howl_res8_long_workspace_bytes(B, T), np.uint8)
+    logits = np.full((B, C), np.nan, np.float32)
+    lib.call("howl_res8_fwd_long", ctypes.byref(h.prm), ptr(f), T * 40, 40, 1, B, T, 40, C, ptr(logits), ptr(ws), ws.size, None)
+    np.testing.assert_allclose(logits, ref, rtol=0, atol=1e-4 * max(1.0, float(np.abs(ref).max())))
+    assert np.array_equal(logits.argmax(1), ref.argmax(1))
+    # the same clip through the strided (B, 1, M, T) view the frontend hands out
+    g = np.ascontiguousarray(x[:, 0].numpy())                        # (B, M, T)
+    logits2 = np.full((B, C), np.nan, np.float32)
+    lib.call("howl_res8_fwd_long", ctypes.byref(h.prm), ptr(g), 40 * T, 1, T, B, T, 40, C, ptr(logits2), ptr(ws), ws.size, None)
+    assert np.array_equal(logits2, logits)

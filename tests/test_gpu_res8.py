@@ -229,3 +229,25 @@ def test_merged_dgrad_wgrad_launch_is_bit_identical_to_separate_launches(monkeyp
     separate = grads()
     for a, b in zip(first, separate):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("B,T", [(3, 84), (2, 120), (4, 201), (1, 500)])
+def test_long_inputs_in_eval_mode_vs_oracle(B, T):
+    """Res8 accepts any T in the reference (cnn.py:127-145).  Beyond the 83 frames that fit the on-chip map the HIP path runs
+    overlapping 27-row windows (howl_res8_fwd_long); eval-mode logits vs the oracle over the whole clip, through the module."""
+    C = 12
+    sd = om.res8_init(C)
+    gen = torch.Generator().manual_seed(T)
+    for i in range(1, 7):
+        sd[f"bn{i}.running_mean"] = torch.rand(45, generator=gen) * 0.5 + 0.1
+        sd[f"bn{i}.running_var"] = torch.rand(45, generator=gen) * 1.5 + 0.5
+    x = torch.randn(B, 3, 40, T, generator=gen)
+    ref = om.res8_forward({k: v.clone() for k, v in sd.items()}, x, False)
+    model = make_res8(C, state=sd, train=False)
+    with torch.no_grad():
+        got = model(x.to(DEV), None)
+    assert maxerr(got, ref) < LOGIT_TOL
+    assert torch.equal(got.argmax(1).cpu(), ref.argmax(1))
+    model.train()
+    with pytest.raises(NotImplementedError):
+        model(x.to(DEV), None)           # training windows are <= 83 frames: loud, not wrong
