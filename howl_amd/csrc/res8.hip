@@ -57,7 +57,9 @@ constexpr int CP = 48;           // channels padded to 3 MFMA tiles
 constexpr int PW = 10;           // pooled width = 40 mels / 4
 constexpr int WP = 12;           // LDS row pitch: 10 + left/right halo
 constexpr int CONV_THREADS = 768;
-constexpr int KSTEPS = 108;      // 12 cin blocks x 9 taps
+constexpr int KFULL = 11;        // full input-channel blocks (4 channels x 9 taps = 9 k-steps each): channels 0..43
+constexpr int KSTEPS = 9 * KFULL + 3;   // + channel 44 alone: its 9 taps as 3 k-steps (taps 4s + k); 102 instead of the 108
+                                 // of a zero-padded 12th block: 5.6 % fewer MFMAs in the forward / dgrad K loops
 constexpr int PREF = 8;          // float2 prefetch slots per thread: 768*8*2 >= 45*270
 constexpr int MAX_H = 27;
 constexpr float BN_EPS = 1e-5f;
@@ -99,17 +101,35 @@ __device__ __forceinline__ void pack_weights_one(const HowlPtrs6& w, float* __re
     const int lane = idx & 63;
     const int ks = (idx >> 6) % KSTEPS;
     const int nt = idx / (64 * KSTEPS);
-    const int c0 = ks / 9, tap = ks - 9 * c0;
-    const int kk = 4 * c0 + (lane >> 4);
+    int kk, tap;
+    if (ks < 9 * KFULL) {                 // block c0 of four channels, one tap per k-step
+        const int c0 = ks / 9;
+        tap = ks - 9 * c0;
+        kk = 4 * c0 + (lane >> 4);
+    } else {                              // channel 44: k = lane >> 4 walks four taps per k-step (taps 9..11 are padding)
+        tap = 4 * (ks - 9 * KFULL) + (lane >> 4);
+        kk = 4 * KFULL;
+    }
     const int n = 16 * nt + (lane & 15);
     float v = 0.0f;
-    if (kk < NMAP && n < NMAP) {
+    if (kk < NMAP && n < NMAP && tap < 9) {
         const float* wl = w.p[layer];
         v = (mode == 0) ? wl[(n * NMAP + kk) * 9 + tap] : wl[(kk * NMAP + n) * 9 + (8 - tap)];
     }
     float* dst = (mode == 0 ? wp_fwd : wp_bwd) + (size_t)layer * (3 * KSTEPS * 64);
     dst[idx] = v;
 }
+
+#if defined(HOWL_DIAG_PROBE)  // diagnostic build (tools/probe_wgrad.py): s_memtime stamps of workgroup 0, [wave][slot]
+__device__ unsigned long long* g_howl_probe = nullptr;
+#define HOWL_PROBE(wave_, lane_, slot_)                                                \
+    do {                                                                               \
+        if (g_howl_probe != nullptr && blockIdx.x == 0 && (lane_) == 0 && (slot_) < 64) \
+            g_howl_probe[(wave_) * 64 + (slot_)] = __builtin_amdgcn_s_memtime();        \
+    } while (0)
+#else
+#define HOWL_PROBE(wave_, lane_, slot_) ((void)0)
+#endif
 
 // ---------------------------------------------------------------------------------------------------------
 // shared pieces of the MFMA kernels
@@ -223,6 +243,22 @@ __device__ __forceinline__ void k_run(KCursor<NTW>& k, f32x4 (&acc)[NTW], int CS
     }
 }
 
+// The last input channel (44) after the KFULL full blocks: three k-steps whose four k lanes groups take four different TAPS
+// of that one channel, so the A operand's tap offset depends on the lane group: `dl[s]` = (offset of tap 4s + g) - g * CS
+// relative to the cursor (which carries the lane group's channel offset g * CS of the full blocks).
+template <int NTW>
+__device__ __forceinline__ void k_tail(KCursor<NTW>& k, f32x4 (&acc)[NTW], const int (&dl)[3]) {
+#if defined(HOWL_DIAG_CONV_NOK)
+    return;
+#endif
+#pragma unroll
+    for (int s3 = 0; s3 < 3; ++s3) {
+        const float b = k.bp[s3 * 64];
+#pragma unroll
+        for (int i = 0; i < NTW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(k.ap[i][dl[s3]], b, acc[i], 0, 0, 0);
+    }
+}
+
 // two staging slots of the next utterance (straight-line code between K-loop segments: issuing all 8 slots of all 12
 // waves back to back keeps the CU's vector-memory path busy for ~2.5k cycles; spread out, that hides under the MFMAs)
 template <int J>
@@ -302,7 +338,16 @@ __device__ __forceinline__ void conv_utterance(const lds_f32* tile, const lds_f3
     k_run<NTW>(k, acc, CS, 2);
     prefetch_pair<6>(pre, nsrc, n2, tid);
     k_run<NTW>(k, acc, CS, 3);
-    k_run<NTW>(k, acc, CS, 3);
+    k_run<NTW>(k, acc, CS, KFULL - 9);
+    {
+        int dl[3];
+#pragma unroll
+        for (int s3 = 0; s3 < 3; ++s3) {
+            const int tap = min(4 * s3 + (lane >> 4), 8);   // taps 9..11 meet zero weights: any finite value will do
+            dl[s3] = (tap / 3) * WP + tap % 3 - (lane >> 4) * CS;
+        }
+        k_tail<NTW>(k, acc, dl);
+    }
     __builtin_amdgcn_s_setprio(0);
     if (eop != nullptr) {
 #pragma unroll
@@ -426,6 +471,8 @@ __device__ __forceinline__ void conv3x3_body(
     // first utterance's activations are requested before anything else so that HBM latency overlaps the setup
     float2 pre[PREF];
     int b = bid;
+    int pslot = 0;
+    HOWL_PROBE(wave, lane, pslot++);   // entry
     if (b < B) prefetch_tile(pre, in + (size_t)b * NMAP * P, n2, tid);
     {
         float4 wv[7];  // 3*108*16 float4 = 5184 <= 7 * 768: all loads in flight, then the LDS stores
@@ -438,6 +485,7 @@ __device__ __forceinline__ void conv3x3_body(
             wv[j] = (i < 3 * KSTEPS * 16) ? reinterpret_cast<const float4*>(wp)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
 #endif
         }
+        HOWL_PROBE(wave, lane, pslot++);   // first tile + weights requested
         if (MODE == 0 && folding) {
             // column sums of the producer's partials while the weight loads are in flight.  Thread (cg = tid % 24,
             // rg = tid / 24): float4 column group cg of rows rg, rg + 32, ...; the 32 row groups meet in LDS (the weight
@@ -494,12 +542,15 @@ __device__ __forceinline__ void conv3x3_body(
             }
             __syncthreads();   // the sums are read before the weights take their region
         }
+        HOWL_PROBE(wave, lane, pslot++);   // statistics folded
         zero_lds(tile, TF, tid, CONV_THREADS);
+        HOWL_PROBE(wave, lane, pslot++);   // tile zeroed
 #pragma unroll
         for (int j = 0; j < 7; ++j) {
             const int i = tid + j * CONV_THREADS;
             if (i < 3 * KSTEPS * 16) reinterpret_cast<float4*>(wl)[i] = wv[j];
         }
+        HOWL_PROBE(wave, lane, pslot++);   // weights in LDS
     }
     if (!folding && tid < CP) {
         lmean[tid] = affine ? in_stats[tid] : 0.0f;
@@ -517,7 +568,9 @@ __device__ __forceinline__ void conv3x3_body(
 
     int pk[PREF];
     stage_slots(pk, P, CS, n2, tid);
+    HOWL_PROBE(wave, lane, pslot++);   // staging slots computed
     __syncthreads();  // weights, zero fill and stats visible before the first stage
+    HOWL_PROBE(wave, lane, pslot++);   // setup barrier passed
 
     // The utterance loop is instantiated once per tile count (waves of one workgroup run different instances; every
     // instance executes the same two barriers per utterance): the register allocator then sees one variant's live
@@ -533,6 +586,7 @@ __device__ __forceinline__ void conv3x3_body(
         default: conv_loop<MODE, 0>(cl, epi, pre, pk, b, st0, st1); break;
     }
 
+    HOWL_PROBE(wave, lane, pslot++);   // all utterances done
     if (part != nullptr) {
         // lanes l, l^16, l^32, l^48 hold the same cout: fold them, then fold the 4 position groups via LDS
         st0 += __shfl_xor(st0, 16);
@@ -566,16 +620,6 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_mfma_kernel(const float*
     conv3x3_body<MODE>(in, in_stats, wp, res, out, xs, xs_stats, part, B, H, blockIdx.x, gridDim.x, fold);
 }
 
-#if defined(HOWL_DIAG_PROBE)  // diagnostic build (tools/probe_wgrad.py): s_memtime stamps of workgroup 0, [wave][slot]
-__device__ unsigned long long* g_howl_probe = nullptr;
-#define HOWL_PROBE(wave_, lane_, slot_)                                                \
-    do {                                                                               \
-        if (g_howl_probe != nullptr && blockIdx.x == 0 && (lane_) == 0 && (slot_) < 64) \
-            g_howl_probe[(wave_) * 64 + (slot_)] = __builtin_amdgcn_s_memtime();        \
-    } while (0)
-#else
-#define HOWL_PROBE(wave_, lane_, slot_) ((void)0)
-#endif
 
 // wgrad: dW[cout][cin][tap] += sum_{b,p} dz[b,cout,p] * x[b,cin,p + tap shift],  x = (s_prev - mean) * rstd
 //

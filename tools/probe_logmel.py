@@ -42,7 +42,7 @@ else:
     ops.logmel(pcm, fbp, 40, pair, layout=1)
     torch.cuda.synchronize()
     t = buf.cpu().view(4, 64)
-    t0 = int(t[:, 0][t[:, 0] > 0].min())
+    first = t[:, 0]; t0 = int(first[first > 0].min()) if (first > 0).any() else 0
     print("B=%%d ticks relative to the first stamp; columns: prologue-done [quad-start pair1 pair2 mel]*" %% B)
     for w in range(4):
         row = [int(v) - t0 for v in t[w] if int(v) != 0]
