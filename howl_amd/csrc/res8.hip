@@ -134,8 +134,10 @@ __device__ unsigned long long* g_howl_probe = nullptr;
 // ---------------------------------------------------------------------------------------------------------
 // shared pieces of the MFMA kernels
 // ---------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void zero_lds(float* p, int n, int tid, int nthreads) {
-    for (int i = tid; i < n; i += nthreads) p[i] = 0.0f;
+__device__ __forceinline__ void zero_lds(float* p, int n, int tid, int nthreads) {   // p 16-byte aligned
+    const int n4 = n >> 2;
+    for (int i = tid; i < n4; i += nthreads) reinterpret_cast<float4*>(p)[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    for (int i = 4 * n4 + tid; i < n; i += nthreads) p[i] = 0.0f;
 }
 
 // Per-thread staging slots: slot j moves the float2 at element pair e2 = tid + j*768 of an utterance's
@@ -487,60 +489,48 @@ __device__ __forceinline__ void conv3x3_body(
         }
         HOWL_PROBE(wave, lane, pslot++);   // first tile + weights requested
         if (MODE == 0 && folding) {
-            // column sums of the producer's partials while the weight loads are in flight.  Thread (cg = tid % 24,
-            // rg = tid / 24): float4 column group cg of rows rg, rg + 32, ...; the 32 row groups meet in LDS (the weight
-            // region: its 83 KB are still in registers at this point) and 48 threads finish the two sums of their channel
-            // in a fixed order.
-            double* red = reinterpret_cast<double*>(wl);     // [32][96]
-            const int cg = tid % 24, rg = tid / 24;
-            double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-            for (int g0 = rg; g0 < fold.nparts; g0 += 8 * 32) {
-                float4 v[8];
+            // Column sums of the producer's partials while the weight loads are in flight, wave by wave with no LDS
+            // scratch and no barrier of their own: wave w owns channels 4w..4w+3 -- lane (col = lane & 7, slice = lane >> 3)
+            // adds rows slice, slice + 8, ... of column col (< 4: the channel's sum, >= 4: its sum of squares) in fp64,
+            // the 8 slices meet through three shuffles (fixed order: every workgroup gets the same bits), and the lanes
+            // that end up with a channel's two totals write its mean / rstd straight to LDS for the setup barrier below.
+            const int col = lane & 7, slice = lane >> 3;
+            const int ch = 4 * wave + (col & 3);
+            const float* src = fold.part + (col < 4 ? 0 : CP) + ch;
+            double acc = 0.0;
+            for (int g0 = slice; g0 < fold.nparts; g0 += 8 * 8) {
+                float v[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const int g = g0 + j * 32;
-                    v[j] = reinterpret_cast<const float4*>(fold.part + (size_t)(g < fold.nparts ? g : fold.nparts - 1) * 2 * CP)[cg];
+                    const int g = g0 + 8 * j;
+                    v[j] = src[(size_t)(g < fold.nparts ? g : fold.nparts - 1) * 2 * CP];
                 }
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const bool ok = g0 + j * 32 < fold.nparts;
-                    a0 += ok ? (double)v[j].x : 0.0;
-                    a1 += ok ? (double)v[j].y : 0.0;
-                    a2 += ok ? (double)v[j].z : 0.0;
-                    a3 += ok ? (double)v[j].w : 0.0;
-                }
+                for (int j = 0; j < 8; ++j) acc += (g0 + 8 * j < fold.nparts) ? (double)v[j] : 0.0;
             }
-            red[rg * 2 * CP + 4 * cg + 0] = a0;
-            red[rg * 2 * CP + 4 * cg + 1] = a1;
-            red[rg * 2 * CP + 4 * cg + 2] = a2;
-            red[rg * 2 * CP + 4 * cg + 3] = a3;
-            __syncthreads();
-            if (tid < CP) {
-                double sum = 0.0, sq = 0.0;
-#pragma unroll 8
-                for (int g = 0; g < 32; ++g) {
-                    sum += red[g * 2 * CP + tid];
-                    sq += red[g * 2 * CP + CP + tid];
-                }
-                const double mean = sum / fold.count;
+            acc += __shfl_xor(acc, 8);
+            acc += __shfl_xor(acc, 16);
+            acc += __shfl_xor(acc, 32);
+            const double sq = __shfl_xor(acc, 4);      // lanes 0..3 hold the sums, 4..7 the sums of squares
+            if (lane < 4) {
+                const double mean = acc / fold.count;
                 double var = sq / fold.count - mean * mean;
                 var = var < 0.0 ? 0.0 : var;
-                const float fm = (tid < NMAP) ? (float)mean : 0.0f;
-                const float fr = (tid < NMAP) ? (float)(1.0 / sqrt(var + (double)BN_EPS)) : 0.0f;
-                lmean[tid] = fm;
-                lrstd[tid] = fr;
+                const float fm = (ch < NMAP) ? (float)mean : 0.0f;
+                const float fr = (ch < NMAP) ? (float)(1.0 / sqrt(var + (double)BN_EPS)) : 0.0f;
+                lmean[ch] = fm;
+                lrstd[ch] = fr;
                 if (bid == 0) {   // one publisher: later readers (backward pass) and the running buffers (cnn.py:142)
-                    fold.stats_out[tid] = fm;
-                    fold.stats_out[CP + tid] = fr;
-                    if (tid < NMAP && fold.bn.running_mean != nullptr) {
+                    fold.stats_out[ch] = fm;
+                    fold.stats_out[CP + ch] = fr;
+                    if (ch < NMAP && fold.bn.running_mean != nullptr) {
                         const double unbiased = fold.count > 1.0 ? var * fold.count / (fold.count - 1.0) : var;
-                        fold.bn.running_mean[tid] = (1.0f - BN_MOMENTUM) * fold.bn.running_mean[tid] + BN_MOMENTUM * (float)mean;
-                        fold.bn.running_var[tid] = (1.0f - BN_MOMENTUM) * fold.bn.running_var[tid] + BN_MOMENTUM * (float)unbiased;
+                        fold.bn.running_mean[ch] = (1.0f - BN_MOMENTUM) * fold.bn.running_mean[ch] + BN_MOMENTUM * (float)mean;
+                        fold.bn.running_var[ch] = (1.0f - BN_MOMENTUM) * fold.bn.running_var[ch] + BN_MOMENTUM * (float)unbiased;
                     }
-                    if (tid == 0 && fold.bn.num_batches != nullptr) fold.bn.num_batches[0] += 1;
+                    if (ch == 0 && fold.bn.num_batches != nullptr) fold.bn.num_batches[0] += 1;
                 }
             }
-            __syncthreads();   // the sums are read before the weights take their region
         }
         HOWL_PROBE(wave, lane, pslot++);   // statistics folded
         zero_lds(tile, TF, tid, CONV_THREADS);
