@@ -454,9 +454,35 @@ __global__ __launch_bounds__(256) void sum_sumsq_kernel(const float* __restrict_
     }
 }
 
-// running update of operator.py:133-135 on the device buffers (no host sync)
+// the masked variant (operator.py:128-130): sums of x*m and (x*m)^2, and the mask's own sum as the element count
+__global__ __launch_bounds__(256) void sum_sumsq_masked_kernel(const float* __restrict__ x, const float* __restrict__ m, size_t n,
+                                                               double* __restrict__ out3) {
+    __shared__ double red[3][4];
+    double s = 0.0, q = 0.0, c = 0.0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float mv = m[i];
+        const double v = (double)(x[i] * mv);      // the reference squares the fp32 product data * mask
+        s += v;
+        q += v * v;
+        c += (double)mv;
+    }
+    s = wave_sum_d(s);
+    q = wave_sum_d(q);
+    c = wave_sum_d(c);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+        red[0][wave] = s;
+        red[1][wave] = q;
+        red[2][wave] = c;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) atomicAdd(&out3[threadIdx.x], red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3]);
+}
+
+// running update of operator.py:133-135 on the device buffers (no host sync); count < 0: taken from sums[2] (mask sum)
 __global__ void zmuv_update_kernel(const double* __restrict__ sums, double count, float* total, float* mean, float* mean2) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (count < 0.0) count = sums[2];
     const double tot = (double)total[0];
     mean[0] = (float)((sums[0] + (double)mean[0] * tot) / (tot + count));
     mean2[0] = (float)((sums[1] + (double)mean2[0] * tot) / (tot + count));
@@ -701,6 +727,19 @@ int howl_zmuv_update(const float* x, size_t n, float* total, float* mean, float*
     hipLaunchKernelGGL(sum_sumsq_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, x, n, scratch2);
     hipLaunchKernelGGL(zmuv_update_kernel, dim3(1), dim3(64), 0, stream, scratch2, (double)n, total, mean, mean2);
     HOWL_CHECK_LAUNCH("howl_zmuv_update");
+    return HOWL_OK;
+}
+
+int howl_zmuv_update_masked(const float* x, const float* mask, size_t n, float* total, float* mean, float* mean2,
+                            double* scratch3, hipStream_t stream) {
+    HOWL_REQUIRE(x && mask && total && mean && mean2 && scratch3, "howl_zmuv_update_masked: null pointer");
+    HOWL_REQUIRE(n >= 1, "howl_zmuv_update_masked: empty input");
+    hipMemsetAsync(scratch3, 0, 3 * sizeof(double), stream);
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(sum_sumsq_masked_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, x, mask, n, scratch3);
+    hipLaunchKernelGGL(zmuv_update_kernel, dim3(1), dim3(64), 0, stream, scratch3, -1.0, total, mean, mean2);
+    HOWL_CHECK_LAUNCH("howl_zmuv_update_masked");
     return HOWL_OK;
 }
 

@@ -48,19 +48,17 @@ class ZmuvTransform(nn.Module):
     def _dev_scratch(self):
         dev = self.mean.device
         if self._scratch is None or self._scratch.device != dev:
-            self._scratch = torch.zeros(2, dtype=torch.float64, device=dev)
+            self._scratch = torch.zeros(3, dtype=torch.float64, device=dev)
             self._pair = torch.zeros(2, dtype=torch.float32, device=dev)
         return self._scratch
 
     def update(self, data, mask=None):
         with torch.no_grad():
             if mask is not None:
-                # masked variant (operator.py:128-130): the count is data dependent -> stays in torch ops on the device
-                data = data * mask
-                mask_size = mask.sum()
-                self.mean = (data.sum() + self.mean * self.total) / (self.total + mask_size)
-                self.mean2 = ((data ** 2).sum() + self.mean2 * self.total) / (self.total + mask_size)
-                self.total += mask_size
+                # masked variant (operator.py:128-130): sums over data * mask, element count = mask.sum(), all on the device
+                m = mask.to(device=data.device, dtype=torch.float32).expand_as(data).contiguous()
+                ops.zmuv_update_masked(data.contiguous(), m, self.total, self.mean, self.mean2, self._dev_scratch())
+                self._pair_key = None
                 return
             ops.zmuv_update(data.contiguous(), self.total, self.mean, self.mean2, self._dev_scratch())
             self._pair_key = None      # the kernel wrote the buffers behind torch's back

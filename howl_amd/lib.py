@@ -65,6 +65,7 @@ SIGNATURES = {
     "howl_logmel_fwd": [P, c_int, c_int, c_long, P, c_int, c_float, P, P, c_int, STREAM],
     "howl_deltas_fwd": [P, c_int, c_int, c_int, P, P, STREAM],
     "howl_zmuv_update": [P, c_size_t, P, P, P, P, STREAM],
+    "howl_zmuv_update_masked": [P, P, c_size_t, P, P, P, P, STREAM],
     "howl_zmuv_pair": [P, P, P, STREAM],
     "howl_zmuv_apply": [P, c_size_t, P, P, STREAM],
     "howl_collate_augment": [P, c_long, P, P, P, P, P, P, ctypes.c_ulonglong, c_int, c_int, P, STREAM],

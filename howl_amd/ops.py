@@ -86,6 +86,11 @@ def zmuv_update(x, total, mean, mean2, scratch):
                     _p(scratch, torch.float64), _stream())
 
 
+def zmuv_update_masked(x, mask, total, mean, mean2, scratch):
+    _lib.get().call("howl_zmuv_update_masked", _p(x), _p(mask), x.numel(), _p(total), _p(mean), _p(mean2),
+                    _p(scratch, torch.float64), _stream())
+
+
 def zmuv_pair(mean, mean2, out):
     _lib.get().call("howl_zmuv_pair", _p(mean), _p(mean2), _p(out), _stream())
     return out

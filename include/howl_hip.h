@@ -86,6 +86,10 @@ int howl_deltas_fwd(const float* logmel, int B, int M, int T, const float* zmuv,
  * scratch2: 2 doubles of device scratch. */
 int howl_zmuv_update(const float* x, size_t n, float* total, float* mean, float* mean2, double* scratch2,
                      hipStream_t stream);
+/* The same with a mask of x's shape (operator.py:128-130): sums run over x*mask, the element count is mask.sum() -- taken
+ * on the device, no host sync.  scratch3: 3 doubles of device scratch. */
+int howl_zmuv_update_masked(const float* x, const float* mask, size_t n, float* total, float* mean, float* mean2,
+                            double* scratch3, hipStream_t stream);
 /* pair = {mean, sqrt(mean2 - mean^2)}: operator.py:141-143 (`ZmuvTransform.std`). */
 int howl_zmuv_pair(const float* mean, const float* mean2, float* pair, hipStream_t stream);
 

@@ -106,6 +106,16 @@ def test_zmuv_update_and_specaug(lib, golden):
     pair = np.zeros(2, np.float32)
     lib.call("howl_zmuv_pair", ptr(mean), ptr(mean2), ptr(pair), None)
     np.testing.assert_allclose(pair, [z.mean.item(), z.std.item()], rtol=1e-5)
+    # masked updates (operator.py:128-130) continue the same running statistics: count = mask.sum()
+    scratch3 = np.zeros(3, np.float64)
+    for n in (640, 3001):
+        x = rng.standard_normal(n).astype(np.float32) * 2 + 1
+        m = (rng.uniform(size=n) < 0.6).astype(np.float32)
+        lib.call("howl_zmuv_update_masked", ptr(x), ptr(m), n, ptr(total), ptr(mean), ptr(mean2), ptr(scratch3), None)
+        z.update(torch.from_numpy(x), torch.from_numpy(m))
+    assert total[0] == float(z.total)
+    np.testing.assert_allclose(mean, np.asarray(z.mean).reshape(-1), rtol=1e-6)
+    np.testing.assert_allclose(mean2, np.asarray(z.mean2).reshape(-1), rtol=1e-6)
 
     g = golden("g7_specaug")
     x = np.ascontiguousarray(g["x"])

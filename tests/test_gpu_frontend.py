@@ -85,6 +85,27 @@ def test_zmuv_golden(std, golden):
     assert fused.shape == (6, 1, 40, 81) and maxerr(fused[:, 0], normed[:, 0]) < 1e-5
 
 
+def test_zmuv_masked_update_vs_oracle(std, golden):
+    """ZmuvTransform.update(data, mask) (operator.py:128-130) on the device, broadcast mask included, against the oracle;
+    the cached (mean, std) pair follows the new statistics."""
+    from howl_amd.data.transform.operator import ZmuvTransform
+    g2 = golden("g2_frontend_gsc")
+    feats = t(g2["feats"])                                     # (6, 3, 40, 81)
+    gen = torch.Generator().manual_seed(4)
+    z, zo = ZmuvTransform().to(DEV), ofe.Zmuv()
+    z.update(feats[:2].to(DEV))
+    zo.update(feats[:2])
+    before = z.pair().clone()
+    for mask in ((torch.rand(4, 3, 40, 81, generator=gen) < 0.5).float(), (torch.rand(4, 1, 1, 81, generator=gen) < 0.7).float()):
+        z.update(feats[2:].to(DEV), mask.to(DEV))
+        zo.update(feats[2:], mask.expand(4, 3, 40, 81))
+    assert z.total.item() == float(zo.total)
+    assert abs(z.mean.item() - float(zo.mean)) < 2e-6 * max(1.0, abs(float(zo.mean)))
+    assert abs(z.mean2.item() - float(zo.mean2)) < 2e-6 * max(1.0, abs(float(zo.mean2)))
+    after = z.pair()
+    assert not torch.equal(after, before) and abs(after[1].item() - float(zo.std)) < 1e-5
+
+
 def test_specaug_golden(golden):
     from howl_amd.data.transform.transform import SpecAugmentTransform
     g = golden("g7_specaug")
