@@ -972,36 +972,65 @@ __global__ void bn_eval_stats_kernel(HowlPtrs6 rmean, HowlPtrs6 rvar, float* __r
     st[CP + c] = (c < NMAP) ? 1.0f / sqrtf(rvar.p[layer][c] + BN_EPS) : 0.0f;
 }
 
-// backward: partials of (sum dx, sum dx*xhat) -> means m1, m2
-__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ part, int nparts, double count,
-                                                               float* __restrict__ m12) {
-    __shared__ double red[SC_RG][2 * CP];
-    double s, q;
-    stats_colsum(part, nparts, red, s, q);
-    const int c = threadIdx.x;
-    if (c < CP) {
-        m12[c] = (float)(s / count);
-        m12[CP + c] = (float)(q / count);
-    }
-}
-
 // backward elementwise: BatchNorm backward (batch statistics) + skip gradient + ReLU mask
 //   ds = rstd * (dx - m1 - xhat * m2) [+ dskip];  dz = ds * mask,  mask = (s > 0) for odd layers and the sign bit of
 //   the stored s for the layers with a residual add (see conv_utterance); xhat = (|s| - mean) * rstd
-__global__ __launch_bounds__(256) void bn_relu_bwd_kernel(
+// One 1024-thread workgroup per CU.  The two means m1 = sum dx / N, m2 = sum dx*xhat / N come either ready-made (`m12`, layer
+// 6: from the head) or as the data-gradient kernel's per-workgroup partials `part` [nparts][2][48], which every workgroup
+// folds itself before its sweep (wave w: channels 3w..3w+2, lane = (column, row slice), fp64, three shuffles -- the same bits
+// in every workgroup; 49 KB of L2 reads per workgroup instead of a one-block kernel between two launches).
+constexpr int BRB_THREADS = 1024;
+__global__ __launch_bounds__(BRB_THREADS) void bn_relu_bwd_kernel(
     const float* __restrict__ dx,      // (B,45,P) or nullptr -> broadcast of dpool
     const float* __restrict__ dpool,   // (B,48) used when dx == nullptr, scaled by 1/P
     const float* __restrict__ s, const float* __restrict__ stats, const float* __restrict__ m12,
+    const float* __restrict__ part, int nparts, double count,
     const float* __restrict__ dskip,   // nullable
     int even,                          // layer has a residual add: mask in the sign bit of s
     float* __restrict__ ds_out,        // nullable
     float* __restrict__ dz_out, int B, int P) {
-    const size_t n2 = (size_t)B * NMAP * P / 2;
+    __shared__ float lm[4 * CP];       // mean, rstd, m1, m2
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < CP) {
+        lm[tid] = stats[tid];
+        lm[CP + tid] = stats[CP + tid];
+        if (part == nullptr) {
+            lm[2 * CP + tid] = m12[tid];
+            lm[3 * CP + tid] = m12[CP + tid];
+        }
+    }
+    if (part != nullptr) {
+        const int col = lane & 7, slice = lane >> 3;
+        const int ch = 3 * wave + (col & 3);
+        const bool used = (col & 3) < 3;
+        const float* src = part + (col < 4 ? 0 : CP) + (used ? ch : 0);
+        double acc = 0.0;
+        for (int g0 = slice; g0 < nparts; g0 += 8 * 8) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int g = g0 + 8 * j;
+                v[j] = src[(size_t)(g < nparts ? g : nparts - 1) * 2 * CP];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc += (g0 + 8 * j < nparts) ? (double)v[j] : 0.0;
+        }
+        acc += __shfl_xor(acc, 8);
+        acc += __shfl_xor(acc, 16);
+        acc += __shfl_xor(acc, 32);
+        const double second = __shfl_xor(acc, 4);      // lanes 0..2: sum dx, their partners 4..6: sum dx*xhat
+        if (lane < 3) {
+            lm[2 * CP + ch] = (float)(acc / count);
+            lm[3 * CP + ch] = (float)(second / count);
+        }
+    }
+    __syncthreads();
+    const unsigned n2 = (unsigned)((size_t)B * NMAP * P / 2);
     const float invP = 1.0f / (float)P;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (size_t)gridDim.x * blockDim.x) {
-        const size_t e = 2 * i;
-        const int bc = (int)(e / P);
-        const int b = bc / NMAP, c = bc - b * NMAP;
+    for (unsigned i = blockIdx.x * BRB_THREADS + tid; i < n2; i += gridDim.x * BRB_THREADS) {
+        const unsigned e = 2u * i;
+        const unsigned bc = e / (unsigned)P;
+        const unsigned b = bc / NMAP, c = bc - b * NMAP;
         float2 g;
         if (dx != nullptr) {
             g = reinterpret_cast<const float2*>(dx)[i];
@@ -1010,7 +1039,7 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_kernel(
             g = make_float2(v, v);
         }
         const float2 sv = reinterpret_cast<const float2*>(s)[i];
-        const float mean = stats[c], rstd = stats[CP + c], m1 = m12[c], m2 = m12[CP + c];
+        const float mean = lm[c], rstd = lm[CP + c], m1 = lm[2 * CP + c], m2 = lm[3 * CP + c];
         float d0 = rstd * (g.x - m1 - ((fabsf(sv.x) - mean) * rstd) * m2);
         float d1 = rstd * (g.y - m1 - ((fabsf(sv.y) - mean) * rstd) * m2);
         if (dskip != nullptr) {
@@ -1332,27 +1361,30 @@ __global__ __launch_bounds__(256) void head_fwd_windows_kernel(const float* __re
     }
 }
 
-// dpool[b][c] = sum_k dlogits[b][k] W[k][c]
-__global__ void head_bwd_pool_kernel(const float* __restrict__ dlogits, const float* __restrict__ wout,
-                                     float* __restrict__ dpool, int B, int C) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= B * CP) return;
-    const int b = idx / CP, c = idx - b * CP;
+// one workgroup per output row k (dW_out[k][:], db[k]); block k == C produces the BN6 backward means
+// m1[c] = sum_b dpool / N, m2[c] = sum_b dpool*pooled / N  (dx6 is dpool/P broadcast over positions); blocks beyond that
+// write dpool[b][c] = sum_k dlogits[b][k] W[k][c] for the elementwise kernel that follows (block C recomputes the values it
+// needs with the same fmaf chain, so it does not wait for them).  16 waves split the batch, lanes are channels;
+// fixed-order combine through LDS.
+__device__ __forceinline__ float head_dpool(const float* __restrict__ dlogits, const float* __restrict__ wout, int b, int c,
+                                            int C) {
     float acc = 0.0f;
     if (c < NMAP)
         for (int k = 0; k < C; ++k) acc = fmaf(dlogits[(size_t)b * C + k], wout[k * NMAP + c], acc);
-    dpool[idx] = acc;
+    return acc;
 }
 
-// one workgroup per output row k (dW_out[k][:], db[k]); block k == C produces the BN6 backward means
-// m1[c] = sum_b dpool / N, m2[c] = sum_b dpool*pooled / N  (dx6 is dpool/P broadcast over positions).
-// 16 waves split the batch, lanes are channels; fixed-order combine through LDS.
 __global__ __launch_bounds__(1024) void head_bwd_param_kernel(const float* __restrict__ dlogits,
                                                               const float* __restrict__ pooled,
-                                                              const float* __restrict__ dpool, float* __restrict__ dwout,
-                                                              float* __restrict__ dbout, float* __restrict__ m12, int B,
-                                                              int C, int P) {
+                                                              const float* __restrict__ wout, float* __restrict__ dpool,
+                                                              float* __restrict__ dwout, float* __restrict__ dbout,
+                                                              float* __restrict__ m12, int B, int C, int P) {
     __shared__ double red[2][16][64];
+    if ((int)blockIdx.x > C) {   // dpool writers
+        const int idx = ((int)blockIdx.x - C - 1) * 1024 + (int)threadIdx.x;
+        if (idx < B * CP) dpool[idx] = head_dpool(dlogits, wout, idx / CP, idx % CP, C);
+        return;
+    }
     const int k = blockIdx.x, c = threadIdx.x & 63, bg = threadIdx.x >> 6;
     double a0 = 0.0, a1 = 0.0;
     // 16 rows per iteration, clamped unconditional loads: a loop with few rows per trip is serialised by the latency of
@@ -1381,7 +1413,7 @@ __global__ __launch_bounds__(1024) void head_bwd_param_kernel(const float* __res
 #pragma unroll
             for (int j = 0; j < HR; ++j) {
                 const int bb = b + 16 * j < B ? b + 16 * j : B - 1;
-                d[j] = dpool[(size_t)bb * CP + c];
+                d[j] = head_dpool(dlogits, wout, bb, c, C);
                 pv[j] = pooled[(size_t)bb * CP + c];
             }
 #pragma unroll
@@ -1710,13 +1742,12 @@ int howl_res8_bwd(const HowlRes8Params* prm, const float* feat, long sb, long st
     const int P = H * PW;
     const double count = (double)B * (double)P;
     const size_t act = (size_t)B * NMAP * P;
-    int eg = (int)((act / 2 + 255) / 256);
-    if (eg > howl_num_cus() * 8) eg = howl_num_cus() * 8;
+    HOWL_REQUIRE(act / 2 < (size_t)1 << 31, "howl_res8_bwd: B=%d too large for the 32-bit element index of the elementwise pass", B);
+    int eg = (int)((act / 2 + BRB_THREADS - 1) / BRB_THREADS);
+    if (eg > howl_num_cus()) eg = howl_num_cus();
 
-    hipLaunchKernelGGL(head_bwd_pool_kernel, dim3((B * CP + 255) / 256), dim3(256), 0, stream, dlogits, prm->out_w, w.dpool,
-                       B, C);
-    hipLaunchKernelGGL(head_bwd_param_kernel, dim3(C + 1), dim3(1024), 0, stream, dlogits, sv->pooled, w.dpool, gr->out_w,
-                       gr->out_b, w.m12, B, C, P);
+    hipLaunchKernelGGL(head_bwd_param_kernel, dim3(C + 1 + (B * CP + 1023) / 1024), dim3(1024), 0, stream, dlogits, sv->pooled,
+                       prm->out_w, w.dpool, gr->out_w, gr->out_b, w.m12, B, C, P);
     const size_t lc = conv_lds_bytes(H);
     hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_mfma_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
                         (int)lc);
@@ -1740,8 +1771,10 @@ int howl_res8_bwd(const HowlRes8Params* prm, const float* feat, long sb, long st
         const float* stats_i = sv->bn_stats + (size_t)(i - 1) * 2 * CP;
         float* ds_out = even ? ds_free : nullptr;
         float* dz = even ? w.dz : w.dz2;
-        hipLaunchKernelGGL(bn_relu_bwd_kernel, dim3(eg), dim3(256), 0, stream, (const float*)dx_cur, w.dpool, sv->s[i],
-                           stats_i, w.m12, even ? (const float*)ds_prev : (const float*)nullptr, even ? 1 : 0, ds_out, dz, B, P);
+        // layer 6 takes its two means from the head (m12); the others fold the partials of the data gradient above them
+        hipLaunchKernelGGL(bn_relu_bwd_kernel, dim3(eg), dim3(BRB_THREADS), 0, stream, (const float*)dx_cur, w.dpool, sv->s[i],
+                           stats_i, w.m12, i == 6 ? (const float*)nullptr : (const float*)w.part, Gh, count,
+                           even ? (const float*)ds_prev : (const float*)nullptr, even ? 1 : 0, ds_out, dz, B, P);
         if (even) {
             float* t = ds_prev ? ds_prev : w.dsb;
             ds_prev = ds_out;
@@ -1769,9 +1802,6 @@ int howl_res8_bwd(const HowlRes8Params* prm, const float* feat, long sb, long st
             hipLaunchKernelGGL(wgrad_mfma_kernel, dim3(Gh), dim3(CONV_THREADS), lw, stream, (const float*)dz, sv->s[i - 1],
                                in_stats, wpart, B, H);
         }
-        if (need_stats)
-            hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(1024), 0, stream, (const float*)w.part, Gh, count,
-                               w.m12);
         dx_cur = dx_next;
         dx_next = (dx_next == w.bufa) ? w.bufb : w.bufa;
     }
