@@ -975,7 +975,7 @@ __global__ void bn_eval_stats_kernel(HowlPtrs6 rmean, HowlPtrs6 rvar, float* __r
 // backward elementwise: BatchNorm backward (batch statistics) + skip gradient + ReLU mask
 //   ds = rstd * (dx - m1 - xhat * m2) [+ dskip];  dz = ds * mask,  mask = (s > 0) for odd layers and the sign bit of
 //   the stored s for the layers with a residual add (see conv_utterance); xhat = (|s| - mean) * rstd
-// One 1024-thread workgroup per CU.  The two means m1 = sum dx / N, m2 = sum dx*xhat / N come either ready-made (`m12`, layer
+// Two 1024-thread workgroups per CU (a bandwidth-bound sweep wants every wave slot).  The two means m1 = sum dx / N, m2 = sum dx*xhat / N come either ready-made (`m12`, layer
 // 6: from the head) or as the data-gradient kernel's per-workgroup partials `part` [nparts][2][48], which every workgroup
 // folds itself before its sweep (wave w: channels 3w..3w+2, lane = (column, row slice), fp64, three shuffles -- the same bits
 // in every workgroup; 49 KB of L2 reads per workgroup instead of a one-block kernel between two launches).
@@ -1027,29 +1027,43 @@ __global__ __launch_bounds__(BRB_THREADS) void bn_relu_bwd_kernel(
     __syncthreads();
     const unsigned n2 = (unsigned)((size_t)B * NMAP * P / 2);
     const float invP = 1.0f / (float)P;
-    for (unsigned i = blockIdx.x * BRB_THREADS + tid; i < n2; i += gridDim.x * BRB_THREADS) {
-        const unsigned e = 2u * i;
-        const unsigned bc = e / (unsigned)P;
-        const unsigned b = bc / NMAP, c = bc - b * NMAP;
-        float2 g;
-        if (dx != nullptr) {
-            g = reinterpret_cast<const float2*>(dx)[i];
-        } else {
-            const float v = dpool[b * CP + c] * invP;
-            g = make_float2(v, v);
+    const unsigned stride = gridDim.x * BRB_THREADS;
+    // two element pairs per trip, all their loads requested before the arithmetic (the second index is clamped, its stores
+    // masked): twice the bytes in flight per wave
+    for (unsigned i0 = blockIdx.x * BRB_THREADS + tid; i0 < n2; i0 += 2 * stride) {
+        unsigned idx[2];
+        bool ok[2];
+        float2 g[2], sv[2], kk[2];
+        unsigned cc[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const unsigned i = i0 + u * stride;
+            ok[u] = i < n2;
+            idx[u] = ok[u] ? i : i0;
+            const unsigned bc = (2u * idx[u]) / (unsigned)P;
+            const unsigned b = bc / NMAP;
+            cc[u] = bc - b * NMAP;
+            if (dx != nullptr) {
+                g[u] = reinterpret_cast<const float2*>(dx)[idx[u]];
+            } else {
+                const float v = dpool[b * CP + cc[u]] * invP;
+                g[u] = make_float2(v, v);
+            }
+            sv[u] = reinterpret_cast<const float2*>(s)[idx[u]];
+            kk[u] = dskip != nullptr ? reinterpret_cast<const float2*>(dskip)[idx[u]] : make_float2(0.0f, 0.0f);
         }
-        const float2 sv = reinterpret_cast<const float2*>(s)[i];
-        const float mean = lm[c], rstd = lm[CP + c], m1 = lm[2 * CP + c], m2 = lm[3 * CP + c];
-        float d0 = rstd * (g.x - m1 - ((fabsf(sv.x) - mean) * rstd) * m2);
-        float d1 = rstd * (g.y - m1 - ((fabsf(sv.y) - mean) * rstd) * m2);
-        if (dskip != nullptr) {
-            const float2 k = reinterpret_cast<const float2*>(dskip)[i];
-            d0 += k.x;
-            d1 += k.y;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const unsigned c = cc[u];
+            const float mean = lm[c], rstd = lm[CP + c], m1 = lm[2 * CP + c], m2 = lm[3 * CP + c];
+            const float d0 = rstd * (g[u].x - m1 - ((fabsf(sv[u].x) - mean) * rstd) * m2) + kk[u].x;
+            const float d1 = rstd * (g[u].y - m1 - ((fabsf(sv[u].y) - mean) * rstd) * m2) + kk[u].y;
+            if (ok[u]) {
+                if (ds_out != nullptr) reinterpret_cast<float2*>(ds_out)[idx[u]] = make_float2(d0, d1);
+                const bool k0 = even ? (sv[u].x < 0.0f) : (sv[u].x > 0.0f), k1 = even ? (sv[u].y < 0.0f) : (sv[u].y > 0.0f);
+                reinterpret_cast<float2*>(dz_out)[idx[u]] = make_float2(k0 ? d0 : 0.0f, k1 ? d1 : 0.0f);
+            }
         }
-        if (ds_out != nullptr) reinterpret_cast<float2*>(ds_out)[i] = make_float2(d0, d1);
-        const bool k0 = even ? (sv.x < 0.0f) : (sv.x > 0.0f), k1 = even ? (sv.y < 0.0f) : (sv.y > 0.0f);
-        reinterpret_cast<float2*>(dz_out)[i] = make_float2(k0 ? d0 : 0.0f, k1 ? d1 : 0.0f);
     }
 }
 
@@ -1361,30 +1375,27 @@ __global__ __launch_bounds__(256) void head_fwd_windows_kernel(const float* __re
     }
 }
 
-// one workgroup per output row k (dW_out[k][:], db[k]); block k == C produces the BN6 backward means
-// m1[c] = sum_b dpool / N, m2[c] = sum_b dpool*pooled / N  (dx6 is dpool/P broadcast over positions); blocks beyond that
-// write dpool[b][c] = sum_k dlogits[b][k] W[k][c] for the elementwise kernel that follows (block C recomputes the values it
-// needs with the same fmaf chain, so it does not wait for them).  16 waves split the batch, lanes are channels;
-// fixed-order combine through LDS.
-__device__ __forceinline__ float head_dpool(const float* __restrict__ dlogits, const float* __restrict__ wout, int b, int c,
-                                            int C) {
+// dpool[b][c] = sum_k dlogits[b][k] W[k][c]
+__global__ void head_bwd_pool_kernel(const float* __restrict__ dlogits, const float* __restrict__ wout,
+                                     float* __restrict__ dpool, int B, int C) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * CP) return;
+    const int b = idx / CP, c = idx - b * CP;
     float acc = 0.0f;
     if (c < NMAP)
         for (int k = 0; k < C; ++k) acc = fmaf(dlogits[(size_t)b * C + k], wout[k * NMAP + c], acc);
-    return acc;
+    dpool[idx] = acc;
 }
 
+// one workgroup per output row k (dW_out[k][:], db[k]); block k == C produces the BN6 backward means
+// m1[c] = sum_b dpool / N, m2[c] = sum_b dpool*pooled / N  (dx6 is dpool/P broadcast over positions).
+// 16 waves split the batch, lanes are channels; fixed-order combine through LDS.
 __global__ __launch_bounds__(1024) void head_bwd_param_kernel(const float* __restrict__ dlogits,
                                                               const float* __restrict__ pooled,
-                                                              const float* __restrict__ wout, float* __restrict__ dpool,
-                                                              float* __restrict__ dwout, float* __restrict__ dbout,
-                                                              float* __restrict__ m12, int B, int C, int P) {
+                                                              const float* __restrict__ dpool, float* __restrict__ dwout,
+                                                              float* __restrict__ dbout, float* __restrict__ m12, int B,
+                                                              int C, int P) {
     __shared__ double red[2][16][64];
-    if ((int)blockIdx.x > C) {   // dpool writers
-        const int idx = ((int)blockIdx.x - C - 1) * 1024 + (int)threadIdx.x;
-        if (idx < B * CP) dpool[idx] = head_dpool(dlogits, wout, idx / CP, idx % CP, C);
-        return;
-    }
     const int k = blockIdx.x, c = threadIdx.x & 63, bg = threadIdx.x >> 6;
     double a0 = 0.0, a1 = 0.0;
     // 16 rows per iteration, clamped unconditional loads: a loop with few rows per trip is serialised by the latency of
@@ -1413,7 +1424,7 @@ __global__ __launch_bounds__(1024) void head_bwd_param_kernel(const float* __res
 #pragma unroll
             for (int j = 0; j < HR; ++j) {
                 const int bb = b + 16 * j < B ? b + 16 * j : B - 1;
-                d[j] = head_dpool(dlogits, wout, bb, c, C);
+                d[j] = dpool[(size_t)bb * CP + c];
                 pv[j] = pooled[(size_t)bb * CP + c];
             }
 #pragma unroll
@@ -1744,10 +1755,12 @@ int howl_res8_bwd(const HowlRes8Params* prm, const float* feat, long sb, long st
     const size_t act = (size_t)B * NMAP * P;
     HOWL_REQUIRE(act / 2 < (size_t)1 << 31, "howl_res8_bwd: B=%d too large for the 32-bit element index of the elementwise pass", B);
     int eg = (int)((act / 2 + BRB_THREADS - 1) / BRB_THREADS);
-    if (eg > howl_num_cus()) eg = howl_num_cus();
+    if (eg > 2 * howl_num_cus()) eg = 2 * howl_num_cus();
 
-    hipLaunchKernelGGL(head_bwd_param_kernel, dim3(C + 1 + (B * CP + 1023) / 1024), dim3(1024), 0, stream, dlogits, sv->pooled,
-                       prm->out_w, w.dpool, gr->out_w, gr->out_b, w.m12, B, C, P);
+    hipLaunchKernelGGL(head_bwd_pool_kernel, dim3((B * CP + 255) / 256), dim3(256), 0, stream, dlogits, prm->out_w, w.dpool,
+                       B, C);
+    hipLaunchKernelGGL(head_bwd_param_kernel, dim3(C + 1), dim3(1024), 0, stream, dlogits, sv->pooled, w.dpool, gr->out_w,
+                       gr->out_b, w.m12, B, C, P);
     const size_t lc = conv_lds_bytes(H);
     hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_mfma_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
                         (int)lc);
