@@ -140,6 +140,39 @@ __device__ __forceinline__ void zero_lds(float* p, int n, int tid, int nthreads)
     for (int i = 4 * n4 + tid; i < n; i += nthreads) p[i] = 0.0f;
 }
 
+// BatchNorm partial statistics travel as a TRANSPOSED matrix part[column][nps] (column < 2*48: sums, then second moments;
+// row = producing workgroup, nps = row count rounded up to 4), so that a consumer wave folds eight columns with coalesced
+// 16-byte loads: lane = (column group c8 = lane >> 3, slice = lane & 7) reads rows 4*(slice + 8j)..+3 of its column for
+// j = 0, 1, ... (eight full 128-byte lines per wave instruction), adds in fp64 and meets its 7 neighbours through three
+// shuffles.  Every lane of a column group returns the column total; the order is fixed, so every workgroup (and every
+// run) gets the same bits.
+__host__ __device__ inline int part_stride(int nparts) { return (nparts + 3) & ~3; }
+__device__ __forceinline__ double fold_part_column(const float* __restrict__ part, int nps, int nparts, int column, int lane) {
+    const int slice = lane & 7;
+    const float* src = part + (size_t)column * nps;
+    double acc = 0.0;
+    for (int r0 = 4 * slice; r0 < nparts; r0 += 8 * 32) {
+        float4 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int r = r0 + 32 * j;
+            v[j] = *reinterpret_cast<const float4*>(src + (r < nps ? r : 0));      // clamped: all eight in flight
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int r = r0 + 32 * j;
+            acc += (r + 0 < nparts) ? (double)v[j].x : 0.0;
+            acc += (r + 1 < nparts) ? (double)v[j].y : 0.0;
+            acc += (r + 2 < nparts) ? (double)v[j].z : 0.0;
+            acc += (r + 3 < nparts) ? (double)v[j].w : 0.0;
+        }
+    }
+    acc += __shfl_xor(acc, 1);
+    acc += __shfl_xor(acc, 2);
+    acc += __shfl_xor(acc, 4);
+    return acc;
+}
+
 // Per-thread staging slots: slot j moves the float2 at element pair e2 = tid + j*768 of an utterance's
 // (45, P) map to its place in the zero-haloed LDS tile.  The destination (and channel, for the BatchNorm
 // parameters) depends only on the thread, so it is packed once: bits 0..19 LDS float offset, 20..25 channel.
@@ -490,29 +523,14 @@ __device__ __forceinline__ void conv3x3_body(
         HOWL_PROBE(wave, lane, pslot++);   // first tile + weights requested
         if (MODE == 0 && folding) {
             // Column sums of the producer's partials while the weight loads are in flight, wave by wave with no LDS
-            // scratch and no barrier of their own: wave w owns channels 4w..4w+3 -- lane (col = lane & 7, slice = lane >> 3)
-            // adds rows slice, slice + 8, ... of column col (< 4: the channel's sum, >= 4: its sum of squares) in fp64,
-            // the 8 slices meet through three shuffles (fixed order: every workgroup gets the same bits), and the lanes
-            // that end up with a channel's two totals write its mean / rstd straight to LDS for the setup barrier below.
-            const int col = lane & 7, slice = lane >> 3;
-            const int ch = 4 * wave + (col & 3);
-            const float* src = fold.part + (col < 4 ? 0 : CP) + ch;
-            double acc = 0.0;
-            for (int g0 = slice; g0 < fold.nparts; g0 += 8 * 8) {
-                float v[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int g = g0 + 8 * j;
-                    v[j] = src[(size_t)(g < fold.nparts ? g : fold.nparts - 1) * 2 * CP];
-                }
-#pragma unroll
-                for (int j = 0; j < 8; ++j) acc += (g0 + 8 * j < fold.nparts) ? (double)v[j] : 0.0;
-            }
-            acc += __shfl_xor(acc, 8);
-            acc += __shfl_xor(acc, 16);
-            acc += __shfl_xor(acc, 32);
-            const double sq = __shfl_xor(acc, 4);      // lanes 0..3 hold the sums, 4..7 the sums of squares
-            if (lane < 4) {
+            // scratch and no barrier of their own: wave w owns channels 4w..4w+3 (column groups 0..3: the channels' sums,
+            // 4..7: their sums of squares; fold_part_column), and the lanes that end up with a channel's two totals write
+            // its mean / rstd straight to LDS for the setup barrier below.
+            const int c8 = lane >> 3;
+            const int ch = 4 * wave + (c8 & 3);
+            const double acc = fold_part_column(fold.part, part_stride(fold.nparts), fold.nparts, (c8 < 4 ? 0 : CP) + ch, lane);
+            const double sq = __shfl_xor(acc, 32);     // column groups 0..3 hold the sums, 4..7 the sums of squares
+            if (c8 < 4 && (lane & 7) == 0) {
                 const double mean = acc / fold.count;
                 double var = sq / fold.count - mean * mean;
                 var = var < 0.0 ? 0.0 : var;
@@ -594,7 +612,7 @@ __device__ __forceinline__ void conv3x3_body(
             float s = 0.0f;
 #pragma unroll
             for (int g = 0; g < 4; ++g) s += red[((g * 3 + t3) * 2 + which) * 16 + cl];
-            part[((size_t)bid * 2 + which) * CP + c] = s;
+            part[((size_t)which * CP + c) * part_stride(nblk) + bid] = s;      // transposed: see fold_part_column
         }
     }
 }
@@ -880,76 +898,18 @@ __global__ __launch_bounds__(256) void reduce_rows_all_kernel(const float* __res
     }
 }
 
-// Column sums of the [nparts][2][48] statistics partials in fp64, deterministic.  Thread (cg = tid % 24, rg = tid / 24)
-// adds rows rg, rg+42, ... of its float4 column group (coalesced 384-byte rows, a handful of independent loads per
-// thread), then threads < 96 combine the 42 row groups in a fixed order.  Returns the two sums to threads c < 48.
-constexpr int SC_RG = 42;   // = 6 x 7, see the fold below
-__device__ __forceinline__ void stats_colsum(const float* __restrict__ part, int nparts, double (*red)[2 * CP],
-                                             double& s, double& q) {
-    const int tid = threadIdx.x;
-    const int cg = tid % 24, rg = tid / 24;
-    if (rg < SC_RG) {
-        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-        // eight rows per trip, all eight loads in flight (clamped row, contribution masked): a plain guarded loop was
-        // compiled into load / s_waitcnt vmcnt(0) pairs -- 6-7 dependent L2 round trips in a 6 us kernel
-        for (int g0 = rg; g0 < nparts; g0 += 8 * SC_RG) {
-            float4 v[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int g = g0 + j * SC_RG;
-                v[j] = reinterpret_cast<const float4*>(part + (size_t)(g < nparts ? g : nparts - 1) * 2 * CP)[cg];
-            }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const bool ok = g0 + j * SC_RG < nparts;
-                a0 += ok ? (double)v[j].x : 0.0;
-                a1 += ok ? (double)v[j].y : 0.0;
-                a2 += ok ? (double)v[j].z : 0.0;
-                a3 += ok ? (double)v[j].w : 0.0;
-            }
-        }
-        red[rg][4 * cg + 0] = a0;
-        red[rg][4 * cg + 1] = a1;
-        red[rg][4 * cg + 2] = a2;
-        red[rg][4 * cg + 3] = a3;
-    }
-    __syncthreads();
-    // 42 row groups -> 6 sums of 7 (in place, 576 threads) -> 1: two short chains of LDS reads instead of one of 42
-    if (tid < 6 * 2 * CP) {
-        const int j = tid / (2 * CP), col = tid - j * 2 * CP;
-        double t = 0.0;
-#pragma unroll
-        for (int g = 0; g < 7; ++g) t += red[7 * j + g][col];
-        red[7 * j][col] = t;
-    }
-    __syncthreads();
-    if (tid < 2 * CP) {
-        double t = 0.0;
-#pragma unroll
-        for (int j = 0; j < 6; ++j) t += red[7 * j][tid];
-        red[0][tid] = t;
-    }
-    __syncthreads();
-    s = 0.0;
-    q = 0.0;
-    if (tid < CP) {
-        s = red[0][tid];
-        q = red[0][CP + tid];
-    }
-}
-
 // ---------------------------------------------------------------------------------------------------------
 // BatchNorm statistics
 // ---------------------------------------------------------------------------------------------------------
 // forward, training: partials -> batch mean / rstd (biased var), running-stat update (cnn.py:142 semantics of
 // nn.BatchNorm2d(affine=False): momentum 0.1, unbiased variance into running_var, num_batches_tracked += 1)
-__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ part, int nparts, double count,
-                                                           float* __restrict__ stats, HowlBnBuffers bn) {
-    __shared__ double red[SC_RG][2 * CP];
-    double s, q;
-    stats_colsum(part, nparts, red, s, q);
-    const int c = threadIdx.x;
-    if (c >= CP) return;
+__global__ __launch_bounds__(768) void bn_finalize_kernel(const float* __restrict__ part, int nparts, double count,
+                                                          float* __restrict__ stats, HowlBnBuffers bn) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c8 = lane >> 3;
+    const int c = 4 * wave + (c8 & 3);                       // 12 waves x 4 channels
+    const double s = fold_part_column(part, part_stride(nparts), nparts, (c8 < 4 ? 0 : CP) + c, lane);
+    const double q = __shfl_xor(s, 32);
+    if (c8 >= 4 || (lane & 7) != 0) return;
     const double mean = s / count;
     double var = q / count - mean * mean;
     var = var < 0.0 ? 0.0 : var;
@@ -977,8 +937,8 @@ __global__ void bn_eval_stats_kernel(HowlPtrs6 rmean, HowlPtrs6 rvar, float* __r
 //   the stored s for the layers with a residual add (see conv_utterance); xhat = (|s| - mean) * rstd
 // Two 1024-thread workgroups per CU (a bandwidth-bound sweep wants every wave slot).  The two means m1 = sum dx / N, m2 = sum dx*xhat / N come either ready-made (`m12`, layer
 // 6: from the head) or as the data-gradient kernel's per-workgroup partials `part` [nparts][2][48], which every workgroup
-// folds itself before its sweep (wave w: channels 3w..3w+2, lane = (column, row slice), fp64, three shuffles -- the same bits
-// in every workgroup; 49 KB of L2 reads per workgroup instead of a one-block kernel between two launches).
+// folds itself before its sweep (wave w: channels 3w..3w+2; fold_part_column -- the same bits in every workgroup; 49 KB of coalesced L2
+// reads per workgroup instead of a one-block kernel between two launches).
 constexpr int BRB_THREADS = 1024;
 __global__ __launch_bounds__(BRB_THREADS) void bn_relu_bwd_kernel(
     const float* __restrict__ dx,      // (B,45,P) or nullptr -> broadcast of dpool
@@ -1000,26 +960,12 @@ __global__ __launch_bounds__(BRB_THREADS) void bn_relu_bwd_kernel(
         }
     }
     if (part != nullptr) {
-        const int col = lane & 7, slice = lane >> 3;
-        const int ch = 3 * wave + (col & 3);
-        const bool used = (col & 3) < 3;
-        const float* src = part + (col < 4 ? 0 : CP) + (used ? ch : 0);
-        double acc = 0.0;
-        for (int g0 = slice; g0 < nparts; g0 += 8 * 8) {
-            float v[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int g = g0 + 8 * j;
-                v[j] = src[(size_t)(g < nparts ? g : nparts - 1) * 2 * CP];
-            }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) acc += (g0 + 8 * j < nparts) ? (double)v[j] : 0.0;
-        }
-        acc += __shfl_xor(acc, 8);
-        acc += __shfl_xor(acc, 16);
-        acc += __shfl_xor(acc, 32);
-        const double second = __shfl_xor(acc, 4);      // lanes 0..2: sum dx, their partners 4..6: sum dx*xhat
-        if (lane < 3) {
+        const int c8 = lane >> 3;
+        const int ch = 3 * wave + (c8 & 3);
+        const bool used = (c8 & 3) < 3;
+        const double acc = fold_part_column(part, part_stride(nparts), nparts, (c8 < 4 ? 0 : CP) + (used ? ch : 0), lane);
+        const double second = __shfl_xor(acc, 32);     // column groups 0..2: sum dx, their partners 4..6: sum dx*xhat
+        if (c8 < 3 && (lane & 7) == 0) {
             lm[2 * CP + ch] = (float)(acc / count);
             lm[3 * CP + ch] = (float)(second / count);
         }
@@ -1519,7 +1465,7 @@ size_t conv0_wgrad_mfma_lds_bytes(int T, int M) {
 struct Ws {
     float* wp_fwd;   // [6][3][108][64]
     float* wp_bwd;
-    float* part;     // statistics partials [G][2][48]
+    float* part;     // statistics partials, transposed [2][48][part_stride(G)] (fold_part_column)
     float* part2;    // second set: a forward layer writes one while the next layer's prologue may still read the other
     float* stats;    // eval-mode stats [6][2][48]
     float* m12;      // [2][48]
@@ -1545,8 +1491,8 @@ size_t ws_layout(Ws* w, char* base, int B, int H, int G) {
     Ws t;
     t.wp_fwd = take((size_t)6 * 3 * KSTEPS * 64);
     t.wp_bwd = take((size_t)6 * 3 * KSTEPS * 64);
-    t.part = take((size_t)G * 2 * CP);
-    t.part2 = take((size_t)G * 2 * CP);
+    t.part = take((size_t)part_stride(G) * 2 * CP);
+    t.part2 = take((size_t)part_stride(G) * 2 * CP);
     t.stats = take((size_t)6 * 2 * CP);
     t.m12 = take(2 * CP);
     t.dpool = take((size_t)B * CP);
@@ -1639,7 +1585,7 @@ int howl_res8_fwd(const HowlRes8Params* prm, const float* feat, long sb, long st
         }
     }
     if (training)
-        hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(1024), 0, stream, w.part2, G, count,
+        hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(768), 0, stream, w.part2, G, count,
                            sv->bn_stats + (size_t)5 * 2 * CP,
                            HowlBnBuffers{prm->bn_running_mean[5], prm->bn_running_var[5], prm->bn_num_batches[5]});
     hipLaunchKernelGGL(head_fwd_kernel, dim3(B < 1024 ? B : 1024), dim3(256), 0, stream, sv->s[6],
