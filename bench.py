@@ -267,12 +267,13 @@ def main():
     trainer.broadcast_parameters()
 
     if model_name == "seq-lstm":
-        frame_lengths = torch.full((B,), (L - 512) // 200 + 1)
+        n_frames = (L - 512) // 200 + 1                      # StandardAudioTransform.compute_lengths
+        frame_lengths = torch.full((B,), n_frames).to(dev)   # the whole batch, lengths and targets included, is resident in HBM
         targets = torch.tensor([[0, 1, 2]] * B).to(dev)
-        target_lengths = torch.tensor([3] * B)
+        target_lengths = torch.tensor([3] * B).to(dev)
 
         def step():    # frontend -> LSTM + head -> fused log_softmax + CTC(blank = C-1) -> backward -> flat AdamW
-            return trainer.step_sequence(pcm, frame_lengths, targets, target_lengths, C - 1, max_target=3)
+            return trainer.step_sequence(pcm, frame_lengths, targets, target_lengths, C - 1, max_target=3, max_frames=n_frames)
     elif model_name == "mobilenet":
         from howl_amd.data.collate import DeviceCollate
         collate = DeviceCollate(pcm, torch.full((B,), L, dtype=torch.long), labels, max_len=L, seed=rank)

@@ -157,15 +157,22 @@ class _LstmBase(RegisteredModel):
                                  nn.Linear(int(2 * config.hidden_size), num_labels))
         self.hc = None
 
-    def _lstm_inputs(self, x, lengths):
+    def _lstm_inputs(self, x, lengths, t_out=None):
+        """-> (xb (B, t_out, M) contiguous, device lengths or None, t_out, h0, c0).
+
+        ``lengths`` follows ``pack_padded_sequence``: one entry per sequence, sorted in decreasing order, 1..T.  A host tensor
+        (the reference's batches carry them on the host) is checked here.  A DEVICE tensor together with ``t_out`` = its
+        maximum is trusted as already checked -- reading it back would stall the stream the step is queued on."""
         x0 = x[:, 0]                                   # (B, M, T), log-mels only (rnn.py:61,86)
         if not ops.on_device(x0):
             raise _lib.HowlHipError("LSTM input must be on a HIP device (no CPU fallback)")
         xb = x0.permute(0, 2, 1)
-        if not xb.is_contiguous():                     # the fused frontend already hands over a (B,T,M) buffer
-            xb = xb.contiguous()
         B, T, _ = xb.shape
-        if lengths is not None:
+        if lengths is not None and t_out is not None and ops.on_device(lengths):
+            if lengths.numel() != B or not 1 <= t_out <= T:
+                raise RuntimeError("lengths must have one entry per sequence and t_out must be in 1..T")
+            lengths = lengths.to(torch.int64)
+        elif lengths is not None:
             lc = lengths.detach().cpu().long()
             if lc.numel() != B:
                 raise RuntimeError("lengths must have one entry per sequence")
@@ -177,6 +184,10 @@ class _LstmBase(RegisteredModel):
             lengths = lc.to(xb.device)
         else:
             t_out = T
+        if t_out < T:                                  # frames no sequence reaches: drop them up front (one small copy) so that
+            xb = xb[:, :t_out]                         # the kernels and the saved buffers only see t_out steps
+        if not xb.is_contiguous():                     # the fused frontend already hands over a (B,T,M) buffer
+            xb = xb.contiguous()
         hx = self.streaming_state if self.is_streaming and self.streaming_state is not None else None
         if hx is not None and (tuple(hx[0].shape) != (1, B, HID) or tuple(hx[1].shape) != (1, B, HID)):
             raise RuntimeError(f"Expected hidden size (1, {B}, {HID}), got {tuple(hx[0].shape)}")     # as nn.LSTM does
@@ -216,9 +227,10 @@ class SequentialLstm(_LstmBase, name="seq-lstm"):
         return self._head(hs).permute(1, 0, 2)         # (T_len, B, num_labels), as dnn(rnn_seq) in rnn.py:71
 
     # --- training.fused.FusedTrainer hooks: the same launches as forward() / autograd, without the autograd graph -----
-    def _launch_forward(self, feat, lengths):
-        """feat (B, C>=1, M, T) -> scores (T_len, B, num_labels) view; keeps what ``_launch_backward`` needs."""
-        xb, lengths, t_out, h0, c0 = self._lstm_inputs(feat, lengths)
+    def _launch_forward(self, feat, lengths, t_out=None):
+        """feat (B, C>=1, M, T) -> scores (T_len, B, num_labels) view; keeps what ``_launch_backward`` needs.  ``t_out`` with
+        device-resident ``lengths``: see ``_lstm_inputs``."""
+        xb, lengths, t_out, h0, c0 = self._lstm_inputs(feat, lengths, t_out)
         ps = self.hot_parameters()
         hs, hT, cT, saved = _lstm_forward_raw(xb, lengths, t_out, h0, c0, *ps[:4])
         y1 = _linear_forward_raw(hs, ps[4], ps[5], True)

@@ -74,14 +74,17 @@ class FusedTrainer:
         self.last_logits = logits
         return loss
 
-    def step_sequence(self, audio, frame_lengths, targets, target_lengths, blank, max_target=None):
+    def step_sequence(self, audio, frame_lengths, targets, target_lengths, blank, max_target=None, max_frames=None):
         """One optimisation step of the sequence objective (train.py:286-302 with ``objective=ctc``) on a (B, L) PCM batch
         sorted by decreasing length: ``frame_lengths`` = ``StandardAudioTransform.compute_lengths`` of the sample counts,
-        ``targets`` the padded (B, Lmax) label matrix.  Returns the mean CTC loss as a device tensor."""
-        return self.step_sequence_on_features(self.features(audio), frame_lengths, targets, target_lengths, blank, max_target)
+        ``targets`` the padded (B, Lmax) label matrix.  The length vectors may live on the host (as the reference's batches
+        do: copied over each step) or on the device; for device-resident ones pass their maxima (``max_frames``,
+        ``max_target``) so that nothing is read back.  Returns the mean CTC loss as a device tensor."""
+        return self.step_sequence_on_features(self.features(audio), frame_lengths, targets, target_lengths, blank, max_target,
+                                              max_frames)
 
-    def step_sequence_on_features(self, feat, frame_lengths, targets, target_lengths, blank, max_target=None):
-        scores = self.model._launch_forward(feat, frame_lengths)           # (T_len, B, C) view of a (B, T_len, C) buffer
+    def step_sequence_on_features(self, feat, frame_lengths, targets, target_lengths, blank, max_target=None, max_frames=None):
+        scores = self.model._launch_forward(feat, frame_lengths, max_frames)   # (T_len, B, C) view of a (B, T_len, C) buffer
         if max_target is None:
             max_target = int(target_lengths.max()) if target_lengths.numel() else 0
         if ops.ctc_supported(scores.shape[0], scores.shape[2], max_target):
