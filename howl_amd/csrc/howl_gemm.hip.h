@@ -281,6 +281,61 @@ __global__ __launch_bounds__(256) void sum_slabs_kernel(const float* __restrict_
     if (rg == 0 && i < n) out[i] = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
 }
 
+// Several slab sums in ONE launch: the split-K weight gradients and bias column sums of a backward call each end in a
+// sum_slabs of their own scratch region; queued here (SlabSums::add) and folded together, a call pays one ~5 us launch
+// instead of three to five.  blockIdx.y picks the job, blocks beyond a job's 64-column count return.
+struct SlabJob {
+    const float* part;
+    float* out;
+    float* out2;     // optional second destination (the LSTM's two bias vectors share one gradient)
+    long n;
+    int nparts;
+};
+constexpr int MAX_SLAB_JOBS = 6;
+struct SlabJobs {
+    SlabJob j[MAX_SLAB_JOBS];
+};
+__global__ __launch_bounds__(256) void sum_slabs_multi_kernel(SlabJobs jobs) {
+    __shared__ float red[4][64];
+    const SlabJob& jb = jobs.j[blockIdx.y];
+    const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const long i = (long)blockIdx.x * 64 + lane;
+    if ((long)blockIdx.x * 64 >= jb.n) return;
+    float s[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (i < jb.n) {
+        int g = rg;
+        for (; g + 12 < jb.nparts; g += 16) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) s[u] += jb.part[(long)(g + 4 * u) * jb.n + i];
+        }
+        for (; g < jb.nparts; g += 4) s[0] += jb.part[(long)g * jb.n + i];
+    }
+    red[rg][lane] = (s[0] + s[1]) + (s[2] + s[3]);
+    __syncthreads();
+    if (rg == 0 && i < jb.n) {
+        const float t = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
+        jb.out[i] = t;
+        if (jb.out2 != nullptr) jb.out2[i] = t;
+    }
+}
+
+// collector: pass to wgrad_gemm / colsum to defer their final sum, call flush() once per backward call
+struct SlabSums {
+    SlabJobs jobs;
+    int count = 0;
+    long max_n = 0;
+    void add(const float* part, int nparts, long n, float* out, float* out2 = nullptr) {
+        jobs.j[count++] = SlabJob{part, out, out2, n, nparts};
+        max_n = n > max_n ? n : max_n;
+    }
+    void flush(hipStream_t s) {
+        if (count == 0) return;
+        hipLaunchKernelGGL(sum_slabs_multi_kernel, dim3((unsigned)((max_n + 63) / 64), count), dim3(256), 0, s, jobs);
+        count = 0;
+        max_n = 0;
+    }
+};
+
 // column sums of a (rows, n) matrix with a row map, two stages so that long row counts use the whole chip:
 // block (x = 64 columns, y = row chunk) writes part[y][col] in fp32 from an fp64 running sum; sum_slabs_kernel folds
 // the chunks in a fixed order (deterministic).
@@ -428,7 +483,7 @@ __global__ __launch_bounds__(256) void thin_wgrad_kernel(const float* __restrict
 // dW (N_out, K_in) = dOut^T (N_out x rows) . In (rows x K_in), rows given by row maps; split-K + deterministic sum
 // (scratch: splits x N_out x K_in floats, splits = clamp(rows / 512, 1, max_splits))
 void wgrad_gemm(hipStream_t s, const float* dout, RowMap dm, int n_out, const float* in, RowMap im, int k_in, int rows,
-                float* scratch, float* dw, int max_splits = 64, int rows_per_split = 512) {
+                float* scratch, float* dw, int max_splits = 64, int rows_per_split = 512, SlabSums* defer = nullptr) {
     int splits = rows / rows_per_split;
     splits = splits < 1 ? 1 : (splits > max_splits ? max_splits : splits);
     if (n_out <= 8 && ((n_out & 3) != 0 || (k_in & 3) != 0)) {   // thin output that the vector GEMM cannot take
@@ -447,6 +502,10 @@ void wgrad_gemm(hipStream_t s, const float* dout, RowMap dm, int n_out, const fl
         }
 #undef HOWL_THIN
         const long n = (long)n_out * k_in;
+        if (defer != nullptr) {
+            defer->add(scratch, chunks, n, dw);
+            return;
+        }
         hipLaunchKernelGGL(sum_slabs_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, s, (const float*)scratch, chunks, n, dw);
         return;
     }
@@ -454,16 +513,24 @@ void wgrad_gemm(hipStream_t s, const float* dout, RowMap dm, int n_out, const fl
     const int z = gemm(s, false, dout, lin(1), 0, dm, in, im, 1, n_out, k_in, rows, splits, nullptr, 0, scratch, k_in,
                        (long)n_out * k_in);
     const long n = (long)n_out * k_in;
+    if (defer != nullptr) {
+        defer->add(scratch, z, n, dw);
+        return;
+    }
     hipLaunchKernelGGL(sum_slabs_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, s, (const float*)scratch, z, n, dw);
 }
 
 // out0 (and out1) = column sums of x over `rows` mapped rows; scratch holds <= 64 * n floats
 void colsum(hipStream_t s, const float* x, RowMap rm, int rows, int n, float* scratch, float* out0, float* out1,
-            int max_chunks = 64, int rows_per_chunk = 256) {
+            int max_chunks = 64, int rows_per_chunk = 256, SlabSums* defer = nullptr) {
     int chunks = rows / rows_per_chunk;
     chunks = chunks < 1 ? 1 : (chunks > max_chunks ? max_chunks : chunks);   // scratch holds <= max_chunks slabs of n floats
     const int rpc = (rows + chunks - 1) / chunks;
     hipLaunchKernelGGL(colsum_kernel, dim3((n + 63) / 64, chunks), dim3(256), 0, s, x, rm, rows, n, rpc, scratch);
+    if (defer != nullptr) {
+        defer->add(scratch, chunks, n, out0, out1);
+        return;
+    }
     hipLaunchKernelGGL(sum_slabs_kernel, dim3((n + 63) / 64), dim3(256), 0, s, (const float*)scratch, chunks, (long)n, out0);
     if (out1 != nullptr)
         hipLaunchKernelGGL(sum_slabs_kernel, dim3((n + 63) / 64), dim3(256), 0, s, (const float*)scratch, chunks, (long)n, out1);

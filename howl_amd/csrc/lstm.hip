@@ -24,6 +24,7 @@ constexpr int HID = 128;
 constexpr int G4 = 4 * HID;          // 512 gate columns, PyTorch order i, f, g, o
 constexpr int LSTM_THREADS = 1024;   // 16 waves
 constexpr int LSTM_WGRAD_SPLITS = 128;
+constexpr int LSTM_MAX_IN = 48;     // input features (mel bins) the workspace is sized for
 constexpr int HS = HID + 4;          // LDS row stride of the h tile (16 rows)
 constexpr int DGS = G4 + 4;          // LDS row stride of the dG tile
 
@@ -617,8 +618,11 @@ bool lstm_rows16(int B) {
 extern "C" {
 
 size_t howl_lstm_workspace_bytes(int B, int T) {
-    // packed W_hh (2 x 64K floats) + bias sum (512) + split-K scratch (128 x 512 x 128; its head also holds the 4-row fragments)
-    return ((size_t)2 * 16 * 64 * 64 + G4 + (size_t)LSTM_WGRAD_SPLITS * G4 * HID) * sizeof(float) + 1024;
+    // packed W_hh (2 x 64K floats) + bias sum (512) + split-K scratch of the W_hh gradient (128 x 512 x 128; its head also
+    // holds the 4-row fragments) + the W_ih gradient's own scratch (128 x 512 x 48 at most) + the bias column sums' (256 x 512):
+    // three regions, so that the three final slab sums can run as one launch
+    return ((size_t)2 * 16 * 64 * 64 + G4 + (size_t)LSTM_WGRAD_SPLITS * G4 * HID + (size_t)LSTM_WGRAD_SPLITS * G4 * LSTM_MAX_IN +
+            (size_t)256 * G4) * sizeof(float) + 1024;
 }
 
 int howl_lstm_fwd(const HowlLstmParams* p, const float* x, int B, int T, int M, const long long* lengths, const float* h0,
@@ -689,10 +693,15 @@ int howl_lstm_bwd(const HowlLstmParams* p, const float* x, int B, int T, int M, 
     const RowMap rows_x = full ? lin(M) : RowMap{Tout, (long)T * M, M};
     const int rows = B * Tout;
     // 256 rows per K slice (up to 128 slices): the 512-row slices of the generic rule leave ~1 block per CU on these shapes
-    wgrad_gemm(stream, sv->dgates, rows_g, G4, x, rows_x, M, rows, scratch, g->w_ih, LSTM_WGRAD_SPLITS, 256);
+    HOWL_REQUIRE(M <= LSTM_MAX_IN, "howl_lstm_bwd: M=%d input features exceed the workspace layout (max %d)", M, LSTM_MAX_IN);
+    float* scratch_ih = scratch + (size_t)LSTM_WGRAD_SPLITS * G4 * HID;
+    float* scratch_b = scratch_ih + (size_t)LSTM_WGRAD_SPLITS * G4 * LSTM_MAX_IN;
+    SlabSums sums;
+    wgrad_gemm(stream, sv->dgates, rows_g, G4, x, rows_x, M, rows, scratch_ih, g->w_ih, LSTM_WGRAD_SPLITS, 256, &sums);
     wgrad_gemm(stream, sv->dgates, rows_g, G4, sv->hseq, RowMap{Tout, (long)(T + 1) * HID, HID}, HID, rows, scratch, g->w_hh,
-               LSTM_WGRAD_SPLITS, 256);
-    colsum(stream, sv->dgates, rows_g, rows, G4, scratch, g->b_ih, g->b_hh, 256, 64);
+               LSTM_WGRAD_SPLITS, 256, &sums);
+    colsum(stream, sv->dgates, rows_g, rows, G4, scratch_b, g->b_ih, g->b_hh, 256, 64, &sums);
+    sums.flush(stream);
     HOWL_CHECK_LAUNCH("howl_lstm_bwd");
     return HOWL_OK;
 }
@@ -702,7 +711,8 @@ int howl_lstm_bwd(const HowlLstmParams* p, const float* x, int B, int T, int M, 
 constexpr int LIN_THIN_SPLITS = 512;
 size_t howl_linear_workspace_bytes(int n_out, int n_in) {
     const size_t slabs = n_out <= 8 ? LIN_THIN_SPLITS : 64;
-    return slabs * n_out * (n_in > 1 ? n_in : 1) * sizeof(float) + 256;
+    // weight-gradient slabs, then 256 slabs of n_out for the bias column sums (their own region: both sums fold in one launch)
+    return (slabs * n_out * (n_in > 1 ? n_in : 1) + (size_t)256 * n_out) * sizeof(float) + 256;
 }
 
 // y = x W^T + b (ReLU optional);  x rows: rows_outer x rows_inner with strides (elements), unit stride along features
@@ -727,14 +737,17 @@ int howl_linear_bwd(const float* x, int rows_inner, long s_outer, long s_inner, 
     }
     if (dx != nullptr)   // dx = dy W : A = dy [m][k = n_out], B(k, n) = w[k * n_in + n]
         gemm(stream, true, dy, lin(n_out), 1, lin(0), w, lin(n_in), 1, rows, n_in, n_out, 1, nullptr, 0, dx, n_in, 0);
+    SlabSums sums;
+    const size_t slabs = n_out <= 8 ? LIN_THIN_SPLITS : 64;
+    float* scratch_b = static_cast<float*>(ws) + slabs * n_out * (n_in > 1 ? n_in : 1);
     if (n_out <= 8)   // 152 blocks of 512 rows each left most CUs idle on the (5 x 256) head: 128-row slices instead
         wgrad_gemm(stream, dy, lin(n_out), n_out, x, RowMap{rows_inner, s_outer, s_inner}, n_in, rows, static_cast<float*>(ws),
-                   dw, LIN_THIN_SPLITS, 128);
+                   dw, LIN_THIN_SPLITS, 128, &sums);
     else
         wgrad_gemm(stream, dy, lin(n_out), n_out, x, RowMap{rows_inner, s_outer, s_inner}, n_in, rows, static_cast<float*>(ws),
-                   dw);
-    // the workspace holds 64 * n_out * n_in (512 * ... for thin outputs) floats: room for 256 slabs of n_out whenever n_in >= 4
-    colsum(stream, dy, lin(n_out), rows, n_out, static_cast<float*>(ws), db, nullptr, n_in >= 4 ? 256 : 64, 64);
+                   dw, 64, 512, &sums);
+    colsum(stream, dy, lin(n_out), rows, n_out, scratch_b, db, nullptr, 256, 64, &sums);
+    sums.flush(stream);
     HOWL_CHECK_LAUNCH("howl_linear_bwd");
     return HOWL_OK;
 }
