@@ -130,8 +130,8 @@ __global__ __launch_bounds__(256) void gemm_vec_kernel(const float* __restrict__
                                                        RowMap bmap, int M, int N, int K, int k_per_split,
                                                        const float* __restrict__ bias, int relu, float* __restrict__ c,
                                                        long c_ms, long c_split_stride) {
-    __shared__ float Asb[2][GK * GLD];   // two K tiles: one is multiplied while the next one is staged (one barrier per tile)
-    __shared__ float Bsb[2][GK * GLD];
+    __shared__ float As[GK * GLD];
+    __shared__ float Bs[GK * GLD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     const int m0 = blockIdx.y * GT, n0 = blockIdx.x * GT;
@@ -165,14 +165,11 @@ __global__ __launch_bounds__(256) void gemm_vec_kernel(const float* __restrict__
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = {0.0f, 0.0f, 0.0f, 0.0f};
-    // Two K tiles in flight in registers and two in LDS: while tile k0 is multiplied out of one LDS buffer, tile k0+16 is
-    // staged into the other and tiles k0+32, k0+48 are on their way (the loop is unrolled by two so that register pairs and
-    // buffers swap roles without copies; one barrier per tile).  With one tile in flight a block paid one full
+    // Two K tiles in flight: tile k0 sits in one register pair while tiles k0+16 AND k0+32 are on their way (the loop is
+    // unrolled by two so that the pairs swap roles without copies).  With one tile in flight a block paid one full
     // memory latency per 16-deep K step -- the long split-K weight-gradient GEMMs run one or two blocks per CU, so
     // nothing else hid it.
-    auto stage = [&](float4 va, float4 vb, int k0, int buf) {
-        float* As = Asb[buf];
-        float* Bs = Bsb[buf];
+    auto stage = [&](float4 va, float4 vb, int k0) {
         if (!ok_a(k0)) va = make_float4(0.f, 0.f, 0.f, 0.f);
         if (!ok_b(k0)) vb = make_float4(0.f, 0.f, 0.f, 0.f);
         if (A_UNIT_K) {
@@ -192,9 +189,7 @@ __global__ __launch_bounds__(256) void gemm_vec_kernel(const float* __restrict__
             *reinterpret_cast<float4*>(&Bs[b_k * GLD + b_r]) = vb;
         }
     };
-    auto multiply = [&](int buf) {
-        const float* As = Asb[buf];
-        const float* Bs = Bsb[buf];
+    auto multiply = [&]() {
 #pragma unroll
         for (int ks = 0; ks < GK / 4; ++ks) {
             const int kr = 4 * ks + (lane >> 4);
@@ -211,24 +206,21 @@ __global__ __launch_bounds__(256) void gemm_vec_kernel(const float* __restrict__
     };
     float4 va0 = fetch_a(kbeg), vb0 = fetch_b(kbeg);
     float4 va1 = fetch_a(kbeg + GK), vb1 = fetch_b(kbeg + GK);   // past the end: a clamped (re)load that is never staged
-    stage(va0, vb0, kbeg, 0);
-    va0 = fetch_a(kbeg + 2 * GK);
-    vb0 = fetch_b(kbeg + 2 * GK);
-    __syncthreads();
-    // invariant at the top: tile k0 staged in buffer 0, tile k0+16 in (va1, vb1), tile k0+32 on its way in (va0, vb0)
     for (int k0 = kbeg; k0 < kend; k0 += 2 * GK) {
-        if (k0 + GK < kend) stage(va1, vb1, k0 + GK, 1);          // buffer 1 was last read before the previous barrier
-        va1 = fetch_a(k0 + 3 * GK);
-        vb1 = fetch_b(k0 + 3 * GK);
+        stage(va0, vb0, k0);
+        __syncthreads();
+        va0 = fetch_a(k0 + 2 * GK);
+        vb0 = fetch_b(k0 + 2 * GK);
         __builtin_amdgcn_sched_barrier(0);   // keep the requests in front of the MFMAs (the scheduler sinks them otherwise)
-        multiply(0);
+        multiply();
         __syncthreads();
         if (k0 + GK >= kend) break;
-        if (k0 + 2 * GK < kend) stage(va0, vb0, k0 + 2 * GK, 0);
-        va0 = fetch_a(k0 + 4 * GK);
-        vb0 = fetch_b(k0 + 4 * GK);
+        stage(va1, vb1, k0 + GK);
+        __syncthreads();
+        va1 = fetch_a(k0 + 3 * GK);
+        vb1 = fetch_b(k0 + 3 * GK);
         __builtin_amdgcn_sched_barrier(0);
-        multiply(1);
+        multiply();
         __syncthreads();
     }
     float* cz = c + (long)blockIdx.z * c_split_stride;
