@@ -261,66 +261,112 @@ __global__ void col2im3x3_kernel(const float* __restrict__ dcol, int H, int W, i
 }
 
 // depthwise 3x3, padding 1: z[b,oh,ow,c] = sum_tap w[c*9+tap] * x[b, oh*s-1+kh, ow*s-1+kw, c]
-// All nine taps are loaded unconditionally from clamped addresses and masked afterwards: a load inside an `if` is followed
-// by its own wait, which serialises nine HBM/L2 round trips per output (the forward of the largest layer ran at 1.4 TB/s).
-// Launch geometry: blockIdx.x = image row (b, oh), blockIdx.y * 256 + threadIdx.x = (ow, c) within the row, so the only
-// integer division per thread is one 32-bit (ow, c) split; STRIDE is a template parameter (divisions by it are shifts).
+// A thread produces DW_SEG = 4 consecutive outputs along W for one channel from ONE window of inputs (3 rows x 6 columns at
+// stride 1, 3 x 9 at stride 2): 4.5 / 6.75 loads per output instead of 9 (+ the nine weights once per thread instead of once
+// per output); a one-output-per-thread version was bound by the number of vector-memory instructions, not by bytes.  All
+// loads are unconditional from clamped addresses and zeroed afterwards (a load inside an `if` is followed by its own wait).
+// Every output accumulates its nine taps in the order (kh, kw) with fmaf, exactly like the scalar version.
+// Launch geometry: blockIdx.x = image row (b, oh), blockIdx.y * 256 + threadIdx.x = (segment of 4 columns, c), channel
+// fastest: a wave's loads are 256 contiguous bytes per tap.
+constexpr int DW_SEG = 4;
 template <int STRIDE>
 __global__ __launch_bounds__(256) void dw3x3_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, int H, int W,
                                                         int C, int Ho, int Wo, float* __restrict__ z) {
+    constexpr int NIN = (DW_SEG - 1) * STRIDE + 3;     // input columns under DW_SEG outputs
+    const int nseg = (Wo + DW_SEG - 1) / DW_SEG;
     const int rc = blockIdx.y * 256 + threadIdx.x;
-    if (rc >= Wo * C) return;
-    const int ow = rc / C, c = rc - ow * C;
+    if (rc >= nseg * C) return;
+    const int seg = rc / C, c = rc - seg * C;
+    const int ow0 = seg * DW_SEG;
     const int b = blockIdx.x / Ho, oh = blockIdx.x - b * Ho;
     const float* xb = x + (long)b * H * W * C + c;
-    float v[9], wk[9];
+    float wk[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wk[k] = w[c * 9 + k];
+    float v[3][NIN];
 #pragma unroll
     for (int kh = 0; kh < 3; ++kh) {
         const int ih = oh * STRIDE - 1 + kh;
         const int ihc = min(max(ih, 0), H - 1);
 #pragma unroll
-        for (int kw = 0; kw < 3; ++kw) {
-            const int iw = ow * STRIDE - 1 + kw;
+        for (int j = 0; j < NIN; ++j) {
+            const int iw = ow0 * STRIDE - 1 + j;
             const int iwc = min(max(iw, 0), W - 1);
-            v[kh * 3 + kw] = xb[((long)ihc * W + iwc) * C];
-            wk[kh * 3 + kw] = (ih == ihc && iw == iwc) ? w[c * 9 + kh * 3 + kw] : 0.0f;
+            v[kh][j] = xb[((long)ihc * W + iwc) * C];
+        }
+#pragma unroll
+        for (int j = 0; j < NIN; ++j) {
+            const int iw = ow0 * STRIDE - 1 + j;
+            if (ih < 0 || ih >= H || iw < 0 || iw >= W) v[kh][j] = 0.0f;
         }
     }
-    float acc = 0.0f;
+    float* zr = z + (long)blockIdx.x * Wo * C + c;
 #pragma unroll
-    for (int k = 0; k < 9; ++k) acc = fmaf(wk[k], v[k], acc);
-    z[(long)blockIdx.x * Wo * C + rc] = acc;
+    for (int o = 0; o < DW_SEG; ++o) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) acc = fmaf(wk[kh * 3 + kw], v[kh][o * STRIDE + kw], acc);
+        if (ow0 + o < Wo) zr[(long)(ow0 + o) * C] = acc;
+    }
 }
 
+// dx[b,ih,iw,c] = sum_tap w[c*9+tap] * dz[b, oh, ow, c] over the outputs (oh, ow) whose window holds (ih, iw) at that tap:
+// oh*s - 1 + kh = ih, ow*s - 1 + kw = iw.  Same thread geometry over the INPUT positions (4 consecutive iw per thread); the
+// gradient window under them is 3 rows x 6 columns at stride 1 and 2 x 3 at stride 2 (loaded for every tap parity, masked).
 template <int STRIDE>
 __global__ __launch_bounds__(256) void dw3x3_dgrad_kernel(const float* __restrict__ dz, const float* __restrict__ w, int H,
                                                           int W, int C, int Ho, int Wo, float* __restrict__ dx) {
+    const int nseg = (W + DW_SEG - 1) / DW_SEG;
     const int rc = blockIdx.y * 256 + threadIdx.x;
-    if (rc >= W * C) return;
-    const int iw = rc / C, c = rc - iw * C;
+    if (rc >= nseg * C) return;
+    const int seg = rc / C, c = rc - seg * C;
+    const int iw0 = seg * DW_SEG;
     const int b = blockIdx.x / H, ih = blockIdx.x - b * H;
     const float* zb = dz + (long)b * Ho * Wo * C + c;
-    float v[9], wk[9];
+    float wk[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wk[k] = w[c * 9 + k];
+    // gradient columns that can touch inputs iw0 .. iw0+3: ow = (iw + 1 - kw) / s  ->  from (iw0 - 1) / s (floor) upwards
+    constexpr int NCOL = STRIDE == 1 ? DW_SEG + 2 : (DW_SEG + 1) / STRIDE + 2;   // 6 at stride 1, 4 at stride 2
+    const int owb = (iw0 - 1 + STRIDE) / STRIDE - 1;               // floor((iw0 - 1) / s) for iw0 >= 0
+    float v[3][NCOL];
+    bool okh[3];
+    int ohs[3];
 #pragma unroll
     for (int kh = 0; kh < 3; ++kh) {
-        const int nh = ih + 1 - kh;          // >= -1
-        const int oh = (nh + STRIDE) / STRIDE - 1;   // floor division for nh >= -STRIDE
-        const bool okh = nh >= 0 && oh * STRIDE == nh && oh < Ho;
-        const int ohc = min(max(oh, 0), Ho - 1);
+        const int nh = ih + 1 - kh;                                // = oh * s
+        const int oh = (nh + STRIDE) / STRIDE - 1;                 // floor division for nh >= -s
+        okh[kh] = nh >= 0 && oh * STRIDE == nh && oh < Ho;
+        ohs[kh] = min(max(oh, 0), Ho - 1);
 #pragma unroll
-        for (int kw = 0; kw < 3; ++kw) {
-            const int nw = iw + 1 - kw;
-            const int ow = (nw + STRIDE) / STRIDE - 1;
-            const bool okw = nw >= 0 && ow * STRIDE == nw && ow < Wo;
-            const int owc = min(max(ow, 0), Wo - 1);
-            v[kh * 3 + kw] = zb[((long)ohc * Wo + owc) * C];
-            wk[kh * 3 + kw] = (okh && okw) ? w[c * 9 + kh * 3 + kw] : 0.0f;
+        for (int j = 0; j < NCOL; ++j) {
+            const int owc = min(max(owb + j, 0), Wo - 1);
+            v[kh][j] = zb[((long)ohs[kh] * Wo + owc) * C];
         }
     }
-    float acc = 0.0f;
+    float* xr = dx + (long)blockIdx.x * W * C + c;
 #pragma unroll
-    for (int k = 0; k < 9; ++k) acc = fmaf(wk[k], v[k], acc);
-    dx[(long)blockIdx.x * W * C + rc] = acc;
+    for (int o = 0; o < DW_SEG; ++o) {
+        const int iw = iw0 + o;
+        float acc = 0.0f;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int nw = iw + 1 - kw;                        // = ow * s
+                const int ow = (nw + STRIDE) / STRIDE - 1;
+                const bool ok = okh[kh] && nw >= 0 && ow * STRIDE == nw && ow < Wo;
+                // window slot of ow; clamped only to keep the (masked) register index inside the array
+                const int j = min(max(ow - owb, 0), NCOL - 1);
+                float g = v[kh][0];
+#pragma unroll
+                for (int q = 1; q < NCOL; ++q) g = (j == q) ? v[kh][q] : g;
+                acc = fmaf(ok ? wk[kh * 3 + kw] : 0.0f, g, acc);
+            }
+        if (iw < W) xr[(long)iw * C] = acc;
+    }
 }
 
 // dW[c][tap] = sum_{b,oh,ow} dz[.,c] * x[shifted, c]: block = 64 channels x one chunk of output rows (pixels), its 4
@@ -669,7 +715,7 @@ void conv_forward(const Ctx& c, int k, const float* in, long sb, long sh, long s
     if (l.kind == MB_PW) {
         gemm(c.s, true, in, lin(l.cin), 1, lin(0), w, lin(1), l.cin, (int)g.mz, l.cout, l.cin, 1, nullptr, 0, z, l.cout, 0);
     } else if (l.kind == MB_DW) {
-        const dim3 grid((unsigned)(c.B * g.ho), (g.wo * l.cin + 255) / 256);
+        const dim3 grid((unsigned)(c.B * g.ho), (((g.wo + DW_SEG - 1) / DW_SEG) * l.cin + 255) / 256);
         if (l.stride == 1)
             hipLaunchKernelGGL(dw3x3_fwd_kernel<1>, grid, dim3(256), 0, c.s, in, w, g.hin, g.win, l.cin, g.ho, g.wo, z);
         else
@@ -874,7 +920,7 @@ int howl_mobilenet_bwd(const float* params, int num_labels, const float* x, long
             hipLaunchKernelGGL(sum_slabs_kernel, dim3((unsigned)((nw + 63) / 64)), dim3(256), 0, wst, (const float*)scratch,
                                wch, nw, gw);
             if (dx != nullptr) {
-                const dim3 grid((unsigned)(B * g.hin), (g.win * l.cin + 255) / 256);
+                const dim3 grid((unsigned)(B * g.hin), (((g.win + DW_SEG - 1) / DW_SEG) * l.cin + 255) / 256);
                 if (l.stride == 1)
                     hipLaunchKernelGGL(dw3x3_dgrad_kernel<1>, grid, dim3(256), 0, stream, (const float*)dz, w, g.hin, g.win, l.cin,
                                        g.ho, g.wo, dx);
