@@ -369,42 +369,60 @@ __global__ __launch_bounds__(256) void dw3x3_dgrad_kernel(const float* __restric
     }
 }
 
-// dW[c][tap] = sum_{b,oh,ow} dz[.,c] * x[shifted, c]: block = 64 channels x one chunk of output rows (pixels), its 4
-// waves split the rows; part[chunk][c*9+tap]
+// dW[c][tap] = sum_{b,oh,ow} dz[.,c] * x[shifted, c]: block = 64 channels x one chunk of IMAGE rows (b, oh); its 4 waves
+// split the rows, and a lane (= channel) walks a row in segments of DW_SEG = 4 outputs that share one input window
+// (3 rows x 6 columns at stride 1, 3 x 9 at stride 2: 5.5 / 7.75 loads per pixel instead of 10, all unconditional from
+// clamped addresses).  part[chunk][c*9+tap]; the chunks are folded in a fixed order by sum_slabs_kernel.
+template <int STRIDE>
 __global__ __launch_bounds__(256) void dw3x3_wgrad_kernel(const float* __restrict__ dz, const float* __restrict__ x, int H,
-                                                          int W, int C, int Ho, int Wo, int stride, long rows,
-                                                          long rows_per_chunk, float* __restrict__ part) {
+                                                          int W, int C, int Ho, int Wo, int nrows, int rows_per_chunk,
+                                                          float* __restrict__ part) {
+    constexpr int NIN = (DW_SEG - 1) * STRIDE + 3;
     __shared__ float red[4][9][64];
     const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
-    const long r0 = (long)blockIdx.y * rows_per_chunk;
-    const long r1 = rows < r0 + rows_per_chunk ? rows : r0 + rows_per_chunk;
+    const int r0 = blockIdx.y * rows_per_chunk;
+    const int r1 = nrows < r0 + rows_per_chunk ? nrows : r0 + rows_per_chunk;
     float acc[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t) acc[t] = 0.0f;
     if (c < C) {
-        for (long m = r0 + rg; m < r1; m += 4) {
-            const int mi = (int)m;   // pixel counts are far below 2^31: 32-bit divisions
-            const int t = mi / Wo, ow = mi - t * Wo;
+        for (int t = r0 + rg; t < r1; t += 4) {
             const int b = t / Ho, oh = t - b * Ho;
             const float* xb = x + (long)b * H * W * C + c;
-            const float g = dz[m * C + c];
-            float v[9];
-            bool ok[9];
+            const float* zr = dz + (long)t * Wo * C + c;
+            for (int ow0 = 0; ow0 < Wo; ow0 += DW_SEG) {
+                float g[DW_SEG], v[3][NIN];
 #pragma unroll
-            for (int kh = 0; kh < 3; ++kh) {
-                const int ih = oh * stride - 1 + kh;
-                const int ihc = min(max(ih, 0), H - 1);
+                for (int o = 0; o < DW_SEG; ++o) g[o] = zr[(long)min(ow0 + o, Wo - 1) * C];
 #pragma unroll
-                for (int kw = 0; kw < 3; ++kw) {
-                    const int iw = ow * stride - 1 + kw;
-                    const int iwc = min(max(iw, 0), W - 1);
-                    v[kh * 3 + kw] = xb[((long)ihc * W + iwc) * C];   // unconditional: all ten loads of a pixel in flight
-                    ok[kh * 3 + kw] = ih == ihc && iw == iwc;
+                for (int kh = 0; kh < 3; ++kh) {
+                    const int ihc = min(max(oh * STRIDE - 1 + kh, 0), H - 1);
+#pragma unroll
+                    for (int j = 0; j < NIN; ++j) {
+                        const int iwc = min(max(ow0 * STRIDE - 1 + j, 0), W - 1);
+                        v[kh][j] = xb[((long)ihc * W + iwc) * C];
+                    }
                 }
-            }
 #pragma unroll
-            for (int k = 0; k < 9; ++k) acc[k] = fmaf(g, ok[k] ? v[k] : 0.0f, acc[k]);
+                for (int o = 0; o < DW_SEG; ++o)
+                    if (ow0 + o >= Wo) g[o] = 0.0f;
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh) {
+                    const int ih = oh * STRIDE - 1 + kh;
+#pragma unroll
+                    for (int j = 0; j < NIN; ++j) {
+                        const int iw = ow0 * STRIDE - 1 + j;
+                        if (ih < 0 || ih >= H || iw < 0 || iw >= W) v[kh][j] = 0.0f;
+                    }
+                }
+#pragma unroll
+                for (int o = 0; o < DW_SEG; ++o)
+#pragma unroll
+                    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                        for (int kw = 0; kw < 3; ++kw) acc[kh * 3 + kw] = fmaf(g[o], v[kh][o * STRIDE + kw], acc[kh * 3 + kw]);
+            }
         }
     }
 #pragma unroll
@@ -912,10 +930,18 @@ int howl_mobilenet_bwd(const float* params, int num_labels, const float* x, long
                 gemm(stream, true, dz, lin(l.cout), 1, lin(0), w, lin(l.cin), 1, (int)g.mz, l.cin, l.cout, 1, nullptr, 0, dx, l.cin,
                      0);
         } else if (l.kind == MB_DW) {
-            const int wch = chunks_for(g.mz, 64);
-            const long wrpc = (g.mz + wch - 1) / wch;
-            hipLaunchKernelGGL(dw3x3_wgrad_kernel, dim3((l.cout + 63) / 64, wch), dim3(256), 0, wst, (const float*)dz, in, g.hin,
-                               g.win, l.cin, g.ho, g.wo, l.stride, g.mz, wrpc, scratch);
+            // chunks of image rows (b, oh): as many as the pixel-chunk rule would give, at least one row each
+            const int nrows = B * g.ho;
+            int wch = chunks_for(g.mz, 64);
+            if (wch > nrows) wch = nrows;
+            const int wrpc = (nrows + wch - 1) / wch;
+            wch = (nrows + wrpc - 1) / wrpc;
+            if (l.stride == 1)
+                hipLaunchKernelGGL(dw3x3_wgrad_kernel<1>, dim3((l.cout + 63) / 64, wch), dim3(256), 0, wst, (const float*)dz, in,
+                                   g.hin, g.win, l.cin, g.ho, g.wo, nrows, wrpc, scratch);
+            else
+                hipLaunchKernelGGL(dw3x3_wgrad_kernel<2>, dim3((l.cout + 63) / 64, wch), dim3(256), 0, wst, (const float*)dz, in,
+                                   g.hin, g.win, l.cin, g.ho, g.wo, nrows, wrpc, scratch);
             const long nw = (long)l.cout * 9;
             hipLaunchKernelGGL(sum_slabs_kernel, dim3((unsigned)((nw + 63) / 64)), dim3(256), 0, wst, (const float*)scratch,
                                wch, nw, gw);
