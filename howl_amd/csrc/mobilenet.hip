@@ -120,30 +120,57 @@ struct Geo {
     long mz, my;           // rows of z_k and y_k
 };
 
+constexpr int MB_G = 32;          // blocks of one first-level group of a fused per-channel reduction
+constexpr int MB_R2 = 64;         // groups (second level); a reduction has at most MB_R = MB_G * MB_R2 blocks along the rows
+constexpr int MB_R = MB_G * MB_R2;
+constexpr int MB_MAXC = 1280;     // widest layer
+constexpr int MB_MAXK = 960;      // widest input of a pointwise layer that is normalised on load
+constexpr int MB_CBLOCKS = 32;    // 64-channel blocks of the widest layer (20), rounded up
+constexpr int MB_COUNTERS = MB_CBLOCKS * (MB_R2 + 1);   // arrival counters: per channel block, one per group + one for the groups
+constexpr int MB_MAX_JOBS = 60;   // deferred slab sums of one backward call (53 convolution weights)
+constexpr int DW_SEG = 4;
+
+// y_k exists in memory only where something other than one convolution reads it: the linear bottleneck outputs (narrow;
+// residual sources and sums) and the pooled downsample output.  Every other layer's BatchNorm + ReLU6 is applied by its
+// consumer while it loads z_k.
+inline bool materialized(const HowlMbLayer& l) { return l.act == MB_ACT_NONE || l.pool; }
+
 struct Plan {
     std::vector<Geo> g;
-    std::vector<size_t> z, y, yp, stats, dact;  // float offsets
-    size_t dz = 0, dz2 = 0, col = 0, dcol = 0, part = 0, gemm_scratch = 0, m12 = 0, pooled = 0, pooled_d = 0, dpooled = 0, dyp = 0;
+    std::vector<size_t> z, y, yp, gr, ss, bc, slab;  // float offsets (y / yp: 0 when not materialised)
+    std::vector<int> nslab;                          // slabs of the layer's weight gradient
+    size_t dz = 0, dyp = 0, dy0 = 0, col = 0, dcol = 0, part = 0, part2 = 0, counters = 0, head_scratch = 0, bias_scratch = 0, pooled = 0,
+           pooled_d = 0, dpooled = 0;
     size_t total_floats = 0;
 };
 
-int wgrad_splits(long rows) {  // must match wgrad_gemm() in howl_gemm.hip.h
+inline int pw_wgrad_rows_per_split(long rows, int n, int c) {
+    const int tiles = ((n + 63) / 64) * ((c + 63) / 64);
+    long splits = 768 / tiles;
+    const long by_rows = rows / 128;
+    if (splits > by_rows) splits = by_rows;
+    if (splits < 1) splits = 1;
+    long rps = (rows + splits - 1) / splits;
+    return (int)((rps + GK - 1) / GK * GK);
+}
+inline int dense_wgrad_splits(long rows) {  // must match wgrad_gemm() in howl_gemm.hip.h
     long s = rows / 512;
     return (int)(s < 1 ? 1 : (s > MB_WGRAD_SPLITS ? MB_WGRAD_SPLITS : s));
 }
-
-// Column reductions: a wave covers 64 / Cp rows at a time when the matrix is narrow (Cp = C rounded up to a power of
-// two <= 32), else 64 columns of one row; the rows are cut into chunks so that the launch fills the chip.
+// chunks of image rows for the depthwise kernels / pixel rows for the narrow column reductions: >= `min_per` units each
+inline int row_chunks(long units, int min_per, int* per_chunk) {
+    long c = units / min_per;
+    c = c < 1 ? 1 : (c > MB_R ? MB_R : c);
+    const long per = (units + c - 1) / c;
+    *per_chunk = (int)per;
+    return (int)((units + per - 1) / per);
+}
+// Narrow column reductions (stem): a wave covers 64 / Cp rows at a time (Cp = C rounded up to a power of two <= 32)
 inline int col_pack(int C) {
     if (C > 32) return 64;
     int cp = 1;
     while (cp < C) cp <<= 1;
     return cp;
-}
-inline int chunks_for(long rows, int C) {
-    const long rows_per_wave_iter = 64 / col_pack(C);
-    long c = rows / (64 * rows_per_wave_iter);   // >= 16 row-iterations per wave
-    return (int)(c < 1 ? 1 : (c > MB_CHUNKS ? MB_CHUNKS : c));
 }
 
 Plan make_plan(int B, int H0, int W0, int num_labels) {
@@ -156,7 +183,7 @@ Plan make_plan(int B, int H0, int W0, int num_labels) {
         return o;
     };
     int h = H0, w = W0;
-    size_t max_dz = 0, max_col = 0, max_scr = (size_t)64 * num_labels * MB_LAST, max_part = 0;
+    size_t max_dz = 0, max_col = 0;
     for (const HowlMbLayer& l : n.layers) {
         Geo g{};
         g.hin = h;
@@ -174,27 +201,42 @@ Plan make_plan(int B, int H0, int W0, int num_labels) {
         g.my = (long)B * g.hy * g.wy;
         p.g.push_back(g);
         p.z.push_back(take((size_t)g.mz * l.cout));
+        p.gr.push_back(take((size_t)g.mz * l.cout));
         p.yp.push_back(l.pool ? take((size_t)g.mz * l.cout) : 0);
-        p.y.push_back(take((size_t)g.my * l.cout));
-        p.stats.push_back(take(2 * (size_t)l.cout));
-        p.dact.push_back(take((size_t)g.my * l.cout));
-        max_dz = std::max(max_dz, (size_t)g.mz * l.cout);
-        if (l.kind == MB_DENSE3) max_col = std::max(max_col, (size_t)g.mz * 9 * l.cin);
-        const size_t wn = (l.kind == MB_DENSE3) ? (size_t)l.cout * l.cin * 9 : (size_t)l.cout * l.cin;
-        if (l.kind != MB_DW) max_scr = std::max(max_scr, (size_t)wgrad_splits(g.mz) * wn);
-        if (l.kind == MB_DW) max_scr = std::max(max_scr, (size_t)chunks_for(g.mz, 64) * l.cout * 9);
-        max_part = std::max(max_part, (size_t)chunks_for(g.mz, l.cout) * 2 * l.cout * 2);
+        p.y.push_back(materialized(l) ? take((size_t)g.my * l.cout) : 0);
+        p.ss.push_back(take(4 * (size_t)l.cout));
+        p.bc.push_back(take(4 * (size_t)l.cout));
+        int ns;
+        size_t wn;
+        if (l.kind == MB_PW) {
+            const int rps = pw_wgrad_rows_per_split(g.mz, l.cout, l.cin);
+            ns = (int)((g.mz + rps - 1) / rps);
+            wn = (size_t)l.cout * l.cin;
+        } else if (l.kind == MB_DW) {
+            int per;
+            ns = row_chunks((long)B * g.ho, 4, &per);
+            wn = (size_t)l.cout * 9;
+        } else {
+            ns = dense_wgrad_splits(g.mz);
+            wn = (size_t)l.cout * l.cin * 9;
+            max_dz = std::max(max_dz, (size_t)g.mz * l.cout);
+            max_col = std::max(max_col, (size_t)g.mz * 9 * l.cin);
+        }
+        p.nslab.push_back(ns);
+        p.slab.push_back(take((size_t)ns * wn));
         h = g.hy;
         w = g.wy;
     }
     p.dz = take(max_dz);
-    p.dz2 = take(max_dz);
     p.dyp = take(max_dz);
+    p.dy0 = take(max_dz);
     p.col = take(max_col);
     p.dcol = take(max_col);
-    p.part = take(max_part);  // doubles
-    p.gemm_scratch = take(max_scr);
-    p.m12 = take(2 * MB_LAST);
+    p.part = take((size_t)MB_R * 2 * MB_MAXC);
+    p.part2 = take((size_t)MB_R2 * 2 * MB_MAXC);
+    p.counters = take(MB_COUNTERS);
+    p.head_scratch = take((size_t)64 * num_labels * MB_LAST);
+    p.bias_scratch = take((size_t)64 * std::max(num_labels, 64));
     p.pooled = take((size_t)B * MB_LAST);
     p.pooled_d = take((size_t)B * MB_LAST);
     p.dpooled = take((size_t)B * MB_LAST);
@@ -203,14 +245,555 @@ Plan make_plan(int B, int H0, int W0, int num_labels) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// kernels (channels-last; `c` is always the unit-stride index)
+// device helpers
 // ---------------------------------------------------------------------------------------------------------
-// channel of flat element idx of an (M x C) matrix: 32-bit arithmetic whenever the index fits (a 64-bit % is ~100
-// instructions, more than the rest of an elementwise kernel)
 __device__ __forceinline__ int chan_of(long idx, int C) {
     return idx < (1L << 31) ? (int)((unsigned)idx % (unsigned)C) : (int)(idx % C);
 }
+__device__ __forceinline__ float mb_act(float v, int act) {
+    if (act == MB_ACT_RELU6) return fminf(fmaxf(v, 0.0f), 6.0f);
+    if (act == MB_ACT_RELU) return fmaxf(v, 0.0f);
+    return v;
+}
+__device__ __forceinline__ bool mb_act_passes(float v, int act) {  // derivative of the activation is 1
+    if (act == MB_ACT_RELU6) return v > 0.0f && v < 6.0f;
+    if (act == MB_ACT_RELU) return v > 0.0f;
+    return true;
+}
+__device__ __forceinline__ float relu6f(float v) { return fminf(fmaxf(v, 0.0f), 6.0f); }
 
+// BatchNorm in the form every kernel uses: y = act(z * scale + shift), scale = gamma * rstd, shift = beta - mean * scale
+// (ss_k = [scale | shift | mean | rstd], 4 C floats); the SAME fmaf decides the ReLU6 mask in the backward pass.
+// Backward: with g = dy * act'(.), m1 = mean(g), m2 = mean(g * xhat):
+//   dz = scale * (g - m1 - xhat * m2) = scale * g + c1 * z + c0,  c1 = -scale * m2 * rstd,  c0 = -scale * m1 - c1 * mean
+// (bc_k = [scale | c1 | c0]) so that the consumers of dz_k rebuild it from g_k and z_k with two fmaf.
+struct FinFwd {
+    const float* gamma;
+    const float* beta;
+    float* rmean;
+    float* rvar;
+    float* ss;
+    double count;
+};
+struct FinBwd {
+    const float* ss;
+    float* dgamma;
+    float* dbeta;
+    float* bc;
+    double count;
+};
+
+// ---- "the last block to finish folds everybody's partials", without a device-wide fence ---------------------------------
+// A release fence at device scope writes back the whole L2 of the XCD (measured: ~90 ns per block, serialised, when every
+// thread fences; tools/fence_probe.hip).  Instead the few floats that cross blocks INSIDE a launch -- one row of per-channel
+// partial sums per block -- are written with device-scope relaxed atomic stores (write-through), the storing thread waits
+// for them (vmcnt(0)), the block meets at a barrier, and thread 0 bumps an arrival counter with a relaxed device-scope
+// atomic; the block that draws the last ticket reads the rows back with device-scope atomic loads.  Everything else a
+// kernel writes is only read by later launches.  Two levels keep every fold to one round trip to memory (~1.5 us): the last
+// block of each group of MB_G blocks folds the group's rows into one row, the last group folds the <= MB_R2 group rows and
+// finalises.  Rows are folded in index order, so WHICH block is last does not change a bit of the result; counters are
+// left at zero for the next launch in stream order.
+struct Arrive {
+    float* part1;      // [blocks along rows][2][C]
+    float* part2;      // [groups][2][C]
+    unsigned* cnt1;    // [channel block][MB_R2]
+    unsigned* cnt2;    // [channel block]
+};
+__device__ __forceinline__ void st_agent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__device__ __forceinline__ bool arrive(unsigned* counter, unsigned expected) {
+    __shared__ unsigned ticket;
+    __atomic_signal_fence(__ATOMIC_SEQ_CST);
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this thread's write-through stores are visible device-wide
+    __atomic_signal_fence(__ATOMIC_SEQ_CST);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t == expected - 1) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ticket = t;
+    }
+    __syncthreads();
+    return ticket == expected - 1;
+}
+
+// The thread with `own` holds this block's (v0, v1) of column c_own.  Returns true in the one block of channel block
+// blockIdx.x (64 channels from c0) that must finalise; a.part2 then holds all groups' rows.
+__device__ __forceinline__ bool publish_and_arrive(const Arrive& a, int C, int c0, bool own, int c_own, float v0, float v1) {
+    __shared__ float red[2][4][64];
+    const int by = blockIdx.y, R1 = gridDim.y;
+    if (own) {
+        st_agent(&a.part1[((size_t)by * 2 + 0) * C + c_own], v0);
+        st_agent(&a.part1[((size_t)by * 2 + 1) * C + c_own], v1);
+    }
+    const int group = by / MB_G, g0 = group * MB_G;
+    const int gsize = R1 - g0 < MB_G ? R1 - g0 : MB_G;
+    const int R2 = (R1 + MB_G - 1) / MB_G;
+    if (!arrive(a.cnt1 + blockIdx.x * MB_R2 + group, gsize)) return false;
+    const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int c = c0 + lane < C ? c0 + lane : C - 1;
+    float r0[MB_G / 4], r1[MB_G / 4];
+#pragma unroll
+    for (int u = 0; u < MB_G / 4; ++u) {     // rows g0 + rg, g0 + rg + 4, ...: all loads in flight together
+        const int k = g0 + rg + 4 * u < g0 + gsize ? g0 + rg + 4 * u : g0 + gsize - 1;
+        r0[u] = ld_agent(&a.part1[((size_t)k * 2 + 0) * C + c]);
+        r1[u] = ld_agent(&a.part1[((size_t)k * 2 + 1) * C + c]);
+    }
+    float t0 = 0.0f, t1 = 0.0f;
+#pragma unroll
+    for (int u = 0; u < MB_G / 4; ++u) {
+        const bool ok = rg + 4 * u < gsize;
+        t0 += ok ? r0[u] : 0.0f;
+        t1 += ok ? r1[u] : 0.0f;
+    }
+    red[0][rg][lane] = t0;
+    red[1][rg][lane] = t1;
+    __syncthreads();
+    if (rg == 0 && c0 + lane < C) {
+        st_agent(&a.part2[((size_t)group * 2 + 0) * C + c], ((red[0][0][lane] + red[0][1][lane]) + red[0][2][lane]) + red[0][3][lane]);
+        st_agent(&a.part2[((size_t)group * 2 + 1) * C + c], ((red[1][0][lane] + red[1][1][lane]) + red[1][2][lane]) + red[1][3][lane]);
+    }
+    return arrive(a.cnt2 + blockIdx.x, R2);
+}
+
+// part[k][0..1][C] (k < R <= MB_R2) -> column totals of column c; called by all 256 threads of the finalising block, lane =
+// column, the 4 waves take k = wave, wave + 4, ... (all loads in flight together), combined in a fixed order in fp64.
+__device__ __forceinline__ void fold_partials(const float* part, int R, int C, int c, double& s0, double& s1) {
+    __shared__ double red[2][4][64];
+    const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int cc = c < C ? c : C - 1;
+    float v0[MB_R2 / 4], v1[MB_R2 / 4];
+#pragma unroll
+    for (int u = 0; u < MB_R2 / 4; ++u) {
+        const int k = rg + 4 * u < R ? rg + 4 * u : R - 1;
+        v0[u] = ld_agent(&part[((size_t)k * 2 + 0) * C + cc]);
+        v1[u] = ld_agent(&part[((size_t)k * 2 + 1) * C + cc]);
+    }
+    double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+    for (int u = 0; u < MB_R2 / 4; ++u) {
+        const bool ok = rg + 4 * u < R;
+        a0 += ok ? (double)v0[u] : 0.0;
+        a1 += ok ? (double)v1[u] : 0.0;
+    }
+    red[0][rg][lane] = a0;
+    red[1][rg][lane] = a1;
+    __syncthreads();
+    s0 = ((red[0][0][lane] + red[0][1][lane]) + red[0][2][lane]) + red[0][3][lane];
+    s1 = ((red[1][0][lane] + red[1][1][lane]) + red[1][2][lane]) + red[1][3][lane];
+}
+
+// batch statistics of column c (biased variance for normalisation, unbiased for the running estimate: nn.BatchNorm2d)
+__device__ __forceinline__ void finalize_fwd(const float* part, int R, int C, int c, const FinFwd& f) {
+    double s0, s1;
+    fold_partials(part, R, C, c, s0, s1);
+    if ((threadIdx.x >> 6) != 0 || c >= C) return;
+    const double mean = s0 / f.count;
+    double var = s1 / f.count - mean * mean;
+    var = var < 0.0 ? 0.0 : var;
+    const double rstd = 1.0 / sqrt(var + (double)MB_EPS);
+    const double scale = (double)f.gamma[c] * rstd;
+    f.ss[c] = (float)scale;
+    f.ss[C + c] = (float)((double)f.beta[c] - mean * scale);
+    f.ss[2 * C + c] = (float)mean;
+    f.ss[3 * C + c] = (float)rstd;
+    const double unbiased = f.count > 1.0 ? var * f.count / (f.count - 1.0) : var;
+    f.rmean[c] = (float)((1.0 - MB_MOMENTUM) * (double)f.rmean[c] + MB_MOMENTUM * mean);
+    f.rvar[c] = (float)((1.0 - MB_MOMENTUM) * (double)f.rvar[c] + MB_MOMENTUM * unbiased);
+}
+
+// BatchNorm backward of column c: dbeta = sum g, dgamma = sum g * xhat, and the coefficients of dz (see above)
+__device__ __forceinline__ void finalize_bwd(const float* part, int R, int C, int c, const FinBwd& f) {
+    double s0, s1;
+    fold_partials(part, R, C, c, s0, s1);
+    if ((threadIdx.x >> 6) != 0 || c >= C) return;
+    f.dbeta[c] = (float)s0;
+    f.dgamma[c] = (float)s1;
+    const double scale = (double)f.ss[c], mean = (double)f.ss[2 * C + c], rstd = (double)f.ss[3 * C + c];
+    const double m1 = s0 / f.count, m2 = s1 / f.count;
+    const double c1 = -scale * m2 * rstd;
+    f.bc[c] = (float)scale;
+    f.bc[C + c] = (float)c1;
+    f.bc[2 * C + c] = (float)(-scale * m1 - c1 * mean);
+}
+
+// one 64 x 64 x 16 step of the fp32 MFMA tile product shared by the pointwise kernels (As[k][row], Bs[k][col])
+__device__ __forceinline__ void mma_tile(const float* As, const float* Bs, f32x4 (&acc)[2][2], int wr, int wc, int lane) {
+#pragma unroll
+    for (int ks = 0; ks < GK / 4; ++ks) {
+        const int kr = 4 * ks + (lane >> 4);
+        float af[2], bf[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) af[i] = As[kr * GLD + 32 * wr + 16 * i + (lane & 15)];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) bf[j] = Bs[kr * GLD + 32 * wc + 16 * j + (lane & 15)];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Pointwise (1x1) convolution, forward:  z[m][n] = sum_k T(a[m][k]) * w[n][k]
+//   XF: a = z_{k-1} and T(v) = relu6(v * scale[k] + shift[k]) (the producer's BatchNorm + ReLU6, applied while the tile
+//   is staged); else a = y_{k-1}, T = identity.  A block owns 64 output channels and `tiles_per_block` consecutive 64-row
+//   tiles; beside z it keeps the per-channel sum and sum of squares of everything it wrote, publishes them as ONE partial
+//   row, and the last block of the channel block turns the partials into this layer's ss (and running statistics).
+// Same tile engine as gemm_vec_kernel (64x64x16, 2x2 waves x 2x2 MFMA 16x16x4, two K tiles in flight).
+// ---------------------------------------------------------------------------------------------------------
+template <bool XF>
+__global__ __launch_bounds__(256) void pw_fwd_kernel(const float* __restrict__ a, const float* __restrict__ ss_in,
+                                                     const float* __restrict__ w, int M, int N, int K, int tiles_per_block,
+                                                     float* __restrict__ z, Arrive arr, FinFwd fin) {
+    __shared__ float As[GK * GLD];
+    __shared__ float Bs[GK * GLD];
+    __shared__ float xs[XF ? 2 * MB_MAXK : 4];
+    __shared__ float sred[2][2][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int n0 = blockIdx.x * GT;
+    const int p_r = tid >> 2, p_k = (tid & 3) * 4;   // this thread's piece of both operand tiles: (row, 4 consecutive k)
+    if (XF) {
+        for (int i = tid; i < K; i += 256) {
+            xs[i] = ss_in[i];
+            xs[MB_MAXK + i] = ss_in[K + i];
+        }
+        __syncthreads();
+    }
+    const float* bp = w + (long)min(n0 + p_r, N - 1) * K;
+    const bool b_row_ok = n0 + p_r < N;
+    const int row_tiles = (M + GT - 1) / GT;
+    const int t0 = blockIdx.y * tiles_per_block;
+    const int t1 = min(row_tiles, t0 + tiles_per_block);
+    float cs[2] = {0.0f, 0.0f}, cq[2] = {0.0f, 0.0f};
+    for (int t = t0; t < t1; ++t) {
+        const int m0 = t * GT;
+        const float* ap = a + (long)min(m0 + p_r, M - 1) * K;
+        const bool a_row_ok = m0 + p_r < M;
+        auto fetch_a = [&](int k0) -> float4 { return *reinterpret_cast<const float4*>(ap + min(k0 + p_k, K - 4)); };
+        auto fetch_b = [&](int k0) -> float4 { return *reinterpret_cast<const float4*>(bp + min(k0 + p_k, K - 4)); };
+        auto stage = [&](float4 va, float4 vb, int k0) {
+            const bool kok = k0 + p_k < K;
+            if (XF) {
+                const int k = min(k0 + p_k, K - 4);
+                va.x = relu6f(fmaf(va.x, xs[k + 0], xs[MB_MAXK + k + 0]));
+                va.y = relu6f(fmaf(va.y, xs[k + 1], xs[MB_MAXK + k + 1]));
+                va.z = relu6f(fmaf(va.z, xs[k + 2], xs[MB_MAXK + k + 2]));
+                va.w = relu6f(fmaf(va.w, xs[k + 3], xs[MB_MAXK + k + 3]));
+            }
+            if (!(a_row_ok && kok)) va = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!(b_row_ok && kok)) vb = make_float4(0.f, 0.f, 0.f, 0.f);
+            As[(p_k + 0) * GLD + p_r] = va.x;
+            As[(p_k + 1) * GLD + p_r] = va.y;
+            As[(p_k + 2) * GLD + p_r] = va.z;
+            As[(p_k + 3) * GLD + p_r] = va.w;
+            Bs[(p_k + 0) * GLD + p_r] = vb.x;
+            Bs[(p_k + 1) * GLD + p_r] = vb.y;
+            Bs[(p_k + 2) * GLD + p_r] = vb.z;
+            Bs[(p_k + 3) * GLD + p_r] = vb.w;
+        };
+        f32x4 acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = {0.0f, 0.0f, 0.0f, 0.0f};
+        float4 va0 = fetch_a(0), vb0 = fetch_b(0);
+        float4 va1 = fetch_a(GK), vb1 = fetch_b(GK);
+        for (int k0 = 0; k0 < K; k0 += 2 * GK) {
+            stage(va0, vb0, k0);
+            __syncthreads();
+            va0 = fetch_a(k0 + 2 * GK);
+            vb0 = fetch_b(k0 + 2 * GK);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_tile(As, Bs, acc, wr, wc, lane);
+            __syncthreads();
+            if (k0 + GK >= K) break;
+            stage(va1, vb1, k0 + GK);
+            __syncthreads();
+            va1 = fetch_a(k0 + 3 * GK);
+            vb1 = fetch_b(k0 + 3 * GK);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_tile(As, Bs, acc, wr, wc, lane);
+            __syncthreads();
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int n = n0 + 32 * wc + 16 * j + (lane & 15);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = m0 + 32 * wr + 16 * i + 4 * (lane >> 4) + r;
+                    const float v = acc[i][j][r];          // rows >= M and columns >= N are exact zeros
+                    if (m < M && n < N) z[(long)m * N + n] = v;
+                    cs[j] += v;
+                    cq[j] = fmaf(v, v, cq[j]);
+                }
+            }
+    }
+    if (arr.part1 == nullptr) return;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        cs[j] += __shfl_xor(cs[j], 16);
+        cs[j] += __shfl_xor(cs[j], 32);
+        cq[j] += __shfl_xor(cq[j], 16);
+        cq[j] += __shfl_xor(cq[j], 32);
+        if (lane < 16) {
+            sred[0][wr][32 * wc + 16 * j + lane] = cs[j];
+            sred[1][wr][32 * wc + 16 * j + lane] = cq[j];
+        }
+    }
+    __syncthreads();
+    const bool own = tid < 64 && n0 + tid < N;
+    const float v0 = own ? sred[0][0][tid] + sred[0][1][tid] : 0.0f, v1 = own ? sred[1][0][tid] + sred[1][1][tid] : 0.0f;
+    if (publish_and_arrive(arr, N, n0, own, n0 + tid, v0, v1))
+        finalize_fwd(arr.part2, (gridDim.y + MB_G - 1) / MB_G, N, n0 + lane, fin);
+}
+
+// What the producer of a data gradient does with its result before it leaves the registers: dy_j (+ the gradient that
+// reaches y_j through a residual connection) -> g_j = dy_j * act'(.) is stored, and sum g_j, sum g_j * xhat_j per channel
+// go to the partials that end in layer j's BatchNorm parameter gradients and bc_j.
+struct EpiBwd {
+    const float* addend;   // g of the later layer whose output adds y_j, or nullptr
+    const float* zj;
+    const float* ssj;
+    float* gj;
+    int act;
+};
+
+// ---------------------------------------------------------------------------------------------------------
+// Pointwise convolution, data gradient:  dy_j[m][c] = sum_n dz[m][n] * w[n][c],  dz = bc.scale*g + bc.c1*z + bc.c0 rebuilt
+// while the tile is staged (g_k, z_k: two 16-byte loads per piece); epilogue = EpiBwd for layer j = k-1 (C = its channels).
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pw_dgrad_kernel(const float* __restrict__ g, const float* __restrict__ zk,
+                                                       const float* __restrict__ bc, const float* __restrict__ w, int M, int N,
+                                                       int C, int tiles_per_block, EpiBwd e, Arrive arr, FinBwd fin) {
+    __shared__ float As[GK * GLD];
+    __shared__ float Bs[GK * GLD];
+    __shared__ float bcs[3 * MB_MAXC];
+    __shared__ float sred[2][2][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int c0 = blockIdx.x * GT;
+    const int a_r = tid >> 2, a_k = (tid & 3) * 4;    // dz piece: (row m, 4 consecutive n)
+    const int b_k = tid >> 4, b_c = (tid & 15) * 4;   // weight piece: (n, 4 consecutive c)
+    for (int i = tid; i < N; i += 256) {
+        bcs[i] = bc[i];
+        bcs[MB_MAXC + i] = bc[N + i];
+        bcs[2 * MB_MAXC + i] = bc[2 * N + i];
+    }
+    __syncthreads();
+    const int bcol = min(c0 + b_c, C - 4);
+    const bool b_col_ok = c0 + b_c < C;
+    // layer j's constants of this thread's two output columns
+    float jsc[2], jsh[2], jme[2], jrs[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int c = min(c0 + 32 * wc + 16 * j + (lane & 15), C - 1);
+        jsc[j] = e.ssj[c];
+        jsh[j] = e.ssj[C + c];
+        jme[j] = e.ssj[2 * C + c];
+        jrs[j] = e.ssj[3 * C + c];
+    }
+    const int row_tiles = (M + GT - 1) / GT;
+    const int t0 = blockIdx.y * tiles_per_block;
+    const int t1 = min(row_tiles, t0 + tiles_per_block);
+    float s1[2] = {0.0f, 0.0f}, s2[2] = {0.0f, 0.0f};
+    for (int t = t0; t < t1; ++t) {
+        const int m0 = t * GT;
+        const long arow = (long)min(m0 + a_r, M - 1) * N;
+        const bool a_row_ok = m0 + a_r < M;
+        auto fetch_g = [&](int k0) -> float4 { return *reinterpret_cast<const float4*>(g + arow + min(k0 + a_k, N - 4)); };
+        auto fetch_z = [&](int k0) -> float4 { return *reinterpret_cast<const float4*>(zk + arow + min(k0 + a_k, N - 4)); };
+        auto fetch_b = [&](int k0) -> float4 {
+            return *reinterpret_cast<const float4*>(w + (long)min(k0 + b_k, N - 1) * C + bcol);
+        };
+        auto stage = [&](float4 vg, float4 vz, float4 vb, int k0) {
+            const int k = min(k0 + a_k, N - 4);
+            float4 va;
+            va.x = fmaf(bcs[k + 0], vg.x, fmaf(bcs[MB_MAXC + k + 0], vz.x, bcs[2 * MB_MAXC + k + 0]));
+            va.y = fmaf(bcs[k + 1], vg.y, fmaf(bcs[MB_MAXC + k + 1], vz.y, bcs[2 * MB_MAXC + k + 1]));
+            va.z = fmaf(bcs[k + 2], vg.z, fmaf(bcs[MB_MAXC + k + 2], vz.z, bcs[2 * MB_MAXC + k + 2]));
+            va.w = fmaf(bcs[k + 3], vg.w, fmaf(bcs[MB_MAXC + k + 3], vz.w, bcs[2 * MB_MAXC + k + 3]));
+            if (!(a_row_ok && k0 + a_k < N)) va = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!(b_col_ok && k0 + b_k < N)) vb = make_float4(0.f, 0.f, 0.f, 0.f);
+            As[(a_k + 0) * GLD + a_r] = va.x;
+            As[(a_k + 1) * GLD + a_r] = va.y;
+            As[(a_k + 2) * GLD + a_r] = va.z;
+            As[(a_k + 3) * GLD + a_r] = va.w;
+            *reinterpret_cast<float4*>(&Bs[b_k * GLD + b_c]) = vb;
+        };
+        f32x4 acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = {0.0f, 0.0f, 0.0f, 0.0f};
+        float4 g0 = fetch_g(0), z0 = fetch_z(0), b0 = fetch_b(0);
+        float4 g1 = fetch_g(GK), z1 = fetch_z(GK), b1 = fetch_b(GK);
+        for (int k0 = 0; k0 < N; k0 += 2 * GK) {
+            stage(g0, z0, b0, k0);
+            __syncthreads();
+            g0 = fetch_g(k0 + 2 * GK);
+            z0 = fetch_z(k0 + 2 * GK);
+            b0 = fetch_b(k0 + 2 * GK);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_tile(As, Bs, acc, wr, wc, lane);
+            __syncthreads();
+            if (k0 + GK >= N) break;
+            stage(g1, z1, b1, k0 + GK);
+            __syncthreads();
+            g1 = fetch_g(k0 + 3 * GK);
+            z1 = fetch_z(k0 + 3 * GK);
+            b1 = fetch_b(k0 + 3 * GK);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_tile(As, Bs, acc, wr, wc, lane);
+            __syncthreads();
+        }
+        // epilogue: all loads first (clamped, unconditional), then arithmetic, then the guarded stores
+        float zj[2][2][4], ad[2][2][4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int c = min(c0 + 32 * wc + 16 * j + (lane & 15), C - 1);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = min(m0 + 32 * wr + 16 * i + 4 * (lane >> 4) + r, M - 1);
+                    zj[i][j][r] = e.zj[(long)m * C + c];
+                    ad[i][j][r] = e.addend != nullptr ? e.addend[(long)m * C + c] : 0.0f;
+                }
+            }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int c = c0 + 32 * wc + 16 * j + (lane & 15);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = m0 + 32 * wr + 16 * i + 4 * (lane >> 4) + r;
+                    const bool ok = m < M && c < C;
+                    const float dy = acc[i][j][r] + ad[i][j][r];
+                    const float zv = zj[i][j][r];
+                    const bool pass = mb_act_passes(fmaf(zv, jsc[j], jsh[j]), e.act);
+                    const float gg = (ok && pass) ? dy : 0.0f;
+                    if (ok) e.gj[(long)m * C + c] = gg;
+                    s1[j] += gg;
+                    s2[j] = fmaf(gg, (zv - jme[j]) * jrs[j], s2[j]);
+                }
+            }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        s1[j] += __shfl_xor(s1[j], 16);
+        s1[j] += __shfl_xor(s1[j], 32);
+        s2[j] += __shfl_xor(s2[j], 16);
+        s2[j] += __shfl_xor(s2[j], 32);
+        if (lane < 16) {
+            sred[0][wr][32 * wc + 16 * j + lane] = s1[j];
+            sred[1][wr][32 * wc + 16 * j + lane] = s2[j];
+        }
+    }
+    __syncthreads();
+    const bool own = tid < 64 && c0 + tid < C;
+    const float v0 = own ? sred[0][0][tid] + sred[0][1][tid] : 0.0f, v1 = own ? sred[1][0][tid] + sred[1][1][tid] : 0.0f;
+    if (publish_and_arrive(arr, C, c0, own, c0 + tid, v0, v1))
+        finalize_bwd(arr.part2, (gridDim.y + MB_G - 1) / MB_G, C, c0 + lane, fin);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Pointwise convolution, weight gradient:  dW[n][c] = sum_m dz[m][n] * T(in[m][c]) over this split's rows; both operands
+// are rebuilt while they are staged (dz from g_k, z_k, bc_k; T as in pw_fwd_kernel).  A thread's piece is 4 consecutive
+// columns of one row, so its per-column constants live in registers for the whole launch.  slabs[split][n][c].
+// ---------------------------------------------------------------------------------------------------------
+template <bool XF>
+__global__ __launch_bounds__(256) void pw_wgrad_kernel(const float* __restrict__ g, const float* __restrict__ zk,
+                                                       const float* __restrict__ bc, const float* __restrict__ in,
+                                                       const float* __restrict__ ss_in, int M, int N, int C,
+                                                       int rows_per_split, float* __restrict__ slabs) {
+    __shared__ float As[GK * GLD];
+    __shared__ float Bs[GK * GLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int c0 = blockIdx.x * GT, n0 = blockIdx.y * GT;
+    const int p_k = tid >> 4, p_c = (tid & 15) * 4;
+    const int an = min(n0 + p_c, N - 4), bcn = min(c0 + p_c, C - 4);
+    const bool a_ok = n0 + p_c < N, b_ok = c0 + p_c < C;
+    const float4 ksc = *reinterpret_cast<const float4*>(bc + an);
+    const float4 kc1 = *reinterpret_cast<const float4*>(bc + N + an);
+    const float4 kc0 = *reinterpret_cast<const float4*>(bc + 2 * N + an);
+    float4 isc = make_float4(1.f, 1.f, 1.f, 1.f), ish = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (XF) {
+        isc = *reinterpret_cast<const float4*>(ss_in + bcn);
+        ish = *reinterpret_cast<const float4*>(ss_in + C + bcn);
+    }
+    const int mbeg = blockIdx.z * rows_per_split;
+    const int mend = min(M, mbeg + rows_per_split);
+    auto row = [&](int k0) -> long { return (long)min(k0 + p_k, M - 1); };
+    auto fetch_g = [&](int k0) -> float4 { return *reinterpret_cast<const float4*>(g + row(k0) * N + an); };
+    auto fetch_z = [&](int k0) -> float4 { return *reinterpret_cast<const float4*>(zk + row(k0) * N + an); };
+    auto fetch_b = [&](int k0) -> float4 { return *reinterpret_cast<const float4*>(in + row(k0) * C + bcn); };
+    auto stage = [&](float4 vg, float4 vz, float4 vb, int k0) {
+        const bool rok = k0 + p_k < mend;
+        float4 va;
+        va.x = fmaf(ksc.x, vg.x, fmaf(kc1.x, vz.x, kc0.x));
+        va.y = fmaf(ksc.y, vg.y, fmaf(kc1.y, vz.y, kc0.y));
+        va.z = fmaf(ksc.z, vg.z, fmaf(kc1.z, vz.z, kc0.z));
+        va.w = fmaf(ksc.w, vg.w, fmaf(kc1.w, vz.w, kc0.w));
+        if (XF) {
+            vb.x = relu6f(fmaf(vb.x, isc.x, ish.x));
+            vb.y = relu6f(fmaf(vb.y, isc.y, ish.y));
+            vb.z = relu6f(fmaf(vb.z, isc.z, ish.z));
+            vb.w = relu6f(fmaf(vb.w, isc.w, ish.w));
+        }
+        if (!(a_ok && rok)) va = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!(b_ok && rok)) vb = make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(&As[p_k * GLD + p_c]) = va;
+        *reinterpret_cast<float4*>(&Bs[p_k * GLD + p_c]) = vb;
+    };
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = {0.0f, 0.0f, 0.0f, 0.0f};
+    float4 g0 = fetch_g(mbeg), z0 = fetch_z(mbeg), b0 = fetch_b(mbeg);
+    float4 g1 = fetch_g(mbeg + GK), z1 = fetch_z(mbeg + GK), b1 = fetch_b(mbeg + GK);
+    for (int k0 = mbeg; k0 < mend; k0 += 2 * GK) {
+        stage(g0, z0, b0, k0);
+        __syncthreads();
+        g0 = fetch_g(k0 + 2 * GK);
+        z0 = fetch_z(k0 + 2 * GK);
+        b0 = fetch_b(k0 + 2 * GK);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_tile(As, Bs, acc, wr, wc, lane);
+        __syncthreads();
+        if (k0 + GK >= mend) break;
+        stage(g1, z1, b1, k0 + GK);
+        __syncthreads();
+        g1 = fetch_g(k0 + 3 * GK);
+        z1 = fetch_z(k0 + 3 * GK);
+        b1 = fetch_b(k0 + 3 * GK);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_tile(As, Bs, acc, wr, wc, lane);
+        __syncthreads();
+    }
+    float* out = slabs + (size_t)blockIdx.z * N * C;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int c = c0 + 32 * wc + 16 * j + (lane & 15);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + 32 * wr + 16 * i + 4 * (lane >> 4) + r;
+                if (n < N && c < C) out[(long)n * C + c] = acc[i][j][r];
+            }
+        }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// stem helpers: im2col / col2im for the two dense 3x3 convolutions, MaxPool2d((1,2))
+// ---------------------------------------------------------------------------------------------------------
 // col[m][c*9 + tap] = x[b, oh*s - ph + tap/3, ow*s - pw + tap%3, c]  (zero outside); x addressed through strides so
 // that the network input can be a (B,1,M,T) view of a multi-channel feature tensor
 __global__ void im2col3x3_kernel(const float* __restrict__ x, long sb, long sh, long sw, long sc, int H, int W, int C, int Ho,
@@ -260,399 +843,6 @@ __global__ void col2im3x3_kernel(const float* __restrict__ dcol, int H, int W, i
     }
 }
 
-// depthwise 3x3, padding 1: z[b,oh,ow,c] = sum_tap w[c*9+tap] * x[b, oh*s-1+kh, ow*s-1+kw, c]
-// A thread produces DW_SEG = 4 consecutive outputs along W for one channel from ONE window of inputs (3 rows x 6 columns at
-// stride 1, 3 x 9 at stride 2): 4.5 / 6.75 loads per output instead of 9 (+ the nine weights once per thread instead of once
-// per output); a one-output-per-thread version was bound by the number of vector-memory instructions, not by bytes.  All
-// loads are unconditional from clamped addresses and zeroed afterwards (a load inside an `if` is followed by its own wait).
-// Every output accumulates its nine taps in the order (kh, kw) with fmaf, exactly like the scalar version.
-// Launch geometry: blockIdx.x = image row (b, oh), blockIdx.y * 256 + threadIdx.x = (segment of 4 columns, c), channel
-// fastest: a wave's loads are 256 contiguous bytes per tap.
-constexpr int DW_SEG = 4;
-template <int STRIDE>
-__global__ __launch_bounds__(256) void dw3x3_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, int H, int W,
-                                                        int C, int Ho, int Wo, float* __restrict__ z) {
-    constexpr int NIN = (DW_SEG - 1) * STRIDE + 3;     // input columns under DW_SEG outputs
-    const int nseg = (Wo + DW_SEG - 1) / DW_SEG;
-    const int rc = blockIdx.y * 256 + threadIdx.x;
-    if (rc >= nseg * C) return;
-    const int seg = rc / C, c = rc - seg * C;
-    const int ow0 = seg * DW_SEG;
-    const int b = blockIdx.x / Ho, oh = blockIdx.x - b * Ho;
-    const float* xb = x + (long)b * H * W * C + c;
-    float wk[9];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) wk[k] = w[c * 9 + k];
-    float v[3][NIN];
-#pragma unroll
-    for (int kh = 0; kh < 3; ++kh) {
-        const int ih = oh * STRIDE - 1 + kh;
-        const int ihc = min(max(ih, 0), H - 1);
-#pragma unroll
-        for (int j = 0; j < NIN; ++j) {
-            const int iw = ow0 * STRIDE - 1 + j;
-            const int iwc = min(max(iw, 0), W - 1);
-            v[kh][j] = xb[((long)ihc * W + iwc) * C];
-        }
-#pragma unroll
-        for (int j = 0; j < NIN; ++j) {
-            const int iw = ow0 * STRIDE - 1 + j;
-            if (ih < 0 || ih >= H || iw < 0 || iw >= W) v[kh][j] = 0.0f;
-        }
-    }
-    float* zr = z + (long)blockIdx.x * Wo * C + c;
-#pragma unroll
-    for (int o = 0; o < DW_SEG; ++o) {
-        float acc = 0.0f;
-#pragma unroll
-        for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-            for (int kw = 0; kw < 3; ++kw) acc = fmaf(wk[kh * 3 + kw], v[kh][o * STRIDE + kw], acc);
-        if (ow0 + o < Wo) zr[(long)(ow0 + o) * C] = acc;
-    }
-}
-
-// dx[b,ih,iw,c] = sum_tap w[c*9+tap] * dz[b, oh, ow, c] over the outputs (oh, ow) whose window holds (ih, iw) at that tap:
-// oh*s - 1 + kh = ih, ow*s - 1 + kw = iw.  Same thread geometry over the INPUT positions (4 consecutive iw per thread); the
-// gradient window under them is 3 rows x 6 columns at stride 1 and 2 x 3 at stride 2 (loaded for every tap parity, masked).
-template <int STRIDE>
-__global__ __launch_bounds__(256) void dw3x3_dgrad_kernel(const float* __restrict__ dz, const float* __restrict__ w, int H,
-                                                          int W, int C, int Ho, int Wo, float* __restrict__ dx) {
-    const int nseg = (W + DW_SEG - 1) / DW_SEG;
-    const int rc = blockIdx.y * 256 + threadIdx.x;
-    if (rc >= nseg * C) return;
-    const int seg = rc / C, c = rc - seg * C;
-    const int iw0 = seg * DW_SEG;
-    const int b = blockIdx.x / H, ih = blockIdx.x - b * H;
-    const float* zb = dz + (long)b * Ho * Wo * C + c;
-    float wk[9];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) wk[k] = w[c * 9 + k];
-    // gradient columns that can touch inputs iw0 .. iw0+3: ow = (iw + 1 - kw) / s  ->  from (iw0 - 1) / s (floor) upwards
-    constexpr int NCOL = STRIDE == 1 ? DW_SEG + 2 : (DW_SEG + 1) / STRIDE + 2;   // 6 at stride 1, 4 at stride 2
-    const int owb = (iw0 - 1 + STRIDE) / STRIDE - 1;               // floor((iw0 - 1) / s) for iw0 >= 0
-    float v[3][NCOL];
-    bool okh[3];
-    int ohs[3];
-#pragma unroll
-    for (int kh = 0; kh < 3; ++kh) {
-        const int nh = ih + 1 - kh;                                // = oh * s
-        const int oh = (nh + STRIDE) / STRIDE - 1;                 // floor division for nh >= -s
-        okh[kh] = nh >= 0 && oh * STRIDE == nh && oh < Ho;
-        ohs[kh] = min(max(oh, 0), Ho - 1);
-#pragma unroll
-        for (int j = 0; j < NCOL; ++j) {
-            const int owc = min(max(owb + j, 0), Wo - 1);
-            v[kh][j] = zb[((long)ohs[kh] * Wo + owc) * C];
-        }
-    }
-    float* xr = dx + (long)blockIdx.x * W * C + c;
-#pragma unroll
-    for (int o = 0; o < DW_SEG; ++o) {
-        const int iw = iw0 + o;
-        float acc = 0.0f;
-#pragma unroll
-        for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-            for (int kw = 0; kw < 3; ++kw) {
-                const int nw = iw + 1 - kw;                        // = ow * s
-                const int ow = (nw + STRIDE) / STRIDE - 1;
-                const bool ok = okh[kh] && nw >= 0 && ow * STRIDE == nw && ow < Wo;
-                // window slot of ow; clamped only to keep the (masked) register index inside the array
-                const int j = min(max(ow - owb, 0), NCOL - 1);
-                float g = v[kh][0];
-#pragma unroll
-                for (int q = 1; q < NCOL; ++q) g = (j == q) ? v[kh][q] : g;
-                acc = fmaf(ok ? wk[kh * 3 + kw] : 0.0f, g, acc);
-            }
-        if (iw < W) xr[(long)iw * C] = acc;
-    }
-}
-
-// dW[c][tap] = sum_{b,oh,ow} dz[.,c] * x[shifted, c]: block = 64 channels x one chunk of IMAGE rows (b, oh); its 4 waves
-// split the rows, and a lane (= channel) walks a row in segments of DW_SEG = 4 outputs that share one input window
-// (3 rows x 6 columns at stride 1, 3 x 9 at stride 2: 5.5 / 7.75 loads per pixel instead of 10, all unconditional from
-// clamped addresses).  part[chunk][c*9+tap]; the chunks are folded in a fixed order by sum_slabs_kernel.
-template <int STRIDE>
-__global__ __launch_bounds__(256) void dw3x3_wgrad_kernel(const float* __restrict__ dz, const float* __restrict__ x, int H,
-                                                          int W, int C, int Ho, int Wo, int nrows, int rows_per_chunk,
-                                                          float* __restrict__ part) {
-    constexpr int NIN = (DW_SEG - 1) * STRIDE + 3;
-    __shared__ float red[4][9][64];
-    const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + lane;
-    const int r0 = blockIdx.y * rows_per_chunk;
-    const int r1 = nrows < r0 + rows_per_chunk ? nrows : r0 + rows_per_chunk;
-    float acc[9];
-#pragma unroll
-    for (int t = 0; t < 9; ++t) acc[t] = 0.0f;
-    if (c < C) {
-        for (int t = r0 + rg; t < r1; t += 4) {
-            const int b = t / Ho, oh = t - b * Ho;
-            const float* xb = x + (long)b * H * W * C + c;
-            const float* zr = dz + (long)t * Wo * C + c;
-            for (int ow0 = 0; ow0 < Wo; ow0 += DW_SEG) {
-                float g[DW_SEG], v[3][NIN];
-#pragma unroll
-                for (int o = 0; o < DW_SEG; ++o) g[o] = zr[(long)min(ow0 + o, Wo - 1) * C];
-#pragma unroll
-                for (int kh = 0; kh < 3; ++kh) {
-                    const int ihc = min(max(oh * STRIDE - 1 + kh, 0), H - 1);
-#pragma unroll
-                    for (int j = 0; j < NIN; ++j) {
-                        const int iwc = min(max(ow0 * STRIDE - 1 + j, 0), W - 1);
-                        v[kh][j] = xb[((long)ihc * W + iwc) * C];
-                    }
-                }
-#pragma unroll
-                for (int o = 0; o < DW_SEG; ++o)
-                    if (ow0 + o >= Wo) g[o] = 0.0f;
-#pragma unroll
-                for (int kh = 0; kh < 3; ++kh) {
-                    const int ih = oh * STRIDE - 1 + kh;
-#pragma unroll
-                    for (int j = 0; j < NIN; ++j) {
-                        const int iw = ow0 * STRIDE - 1 + j;
-                        if (ih < 0 || ih >= H || iw < 0 || iw >= W) v[kh][j] = 0.0f;
-                    }
-                }
-#pragma unroll
-                for (int o = 0; o < DW_SEG; ++o)
-#pragma unroll
-                    for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-                        for (int kw = 0; kw < 3; ++kw) acc[kh * 3 + kw] = fmaf(g[o], v[kh][o * STRIDE + kw], acc[kh * 3 + kw]);
-            }
-        }
-    }
-#pragma unroll
-    for (int t = 0; t < 9; ++t) red[rg][t][lane] = acc[t];
-    __syncthreads();
-    if (rg == 0 && c < C) {
-#pragma unroll
-        for (int t = 0; t < 9; ++t)
-            part[(size_t)blockIdx.y * C * 9 + c * 9 + t] = ((red[0][t][lane] + red[1][t][lane]) + red[2][t][lane]) + red[3][t][lane];
-    }
-}
-
-__device__ __forceinline__ float mb_act(float v, int act) {
-    if (act == MB_ACT_RELU6) return fminf(fmaxf(v, 0.0f), 6.0f);
-    if (act == MB_ACT_RELU) return fmaxf(v, 0.0f);
-    return v;
-}
-__device__ __forceinline__ bool mb_act_passes(float v, int act) {  // derivative of the activation is 1
-    if (act == MB_ACT_RELU6) return v > 0.0f && v < 6.0f;
-    if (act == MB_ACT_RELU) return v > 0.0f;
-    return true;
-}
-
-// Two-stage per-channel reductions over the rows of an (M x C) matrix.  MODE 0: (sum z, sum z^2).
-// MODE 1 (BatchNorm backward): g = dy * act'(gamma*xhat + beta), xhat = (z - mean) * rstd -> (sum g, sum g*xhat).
-// Lane -> (row slot rs = lane / cp, column blockIdx.x*64 + lane % cp): cp = 64 for wide matrices, a power of two <= 32
-// for narrow ones so that no lane idles on the 3..32-channel layers that have the most rows.  Rows advance by
-// 4 waves x (64/cp) slots; four independent accumulator pairs keep four loads in flight.
-template <int MODE>
-__global__ __launch_bounds__(256) void col_reduce_kernel(const float* __restrict__ z, const float* __restrict__ dy,
-                                                         const float* __restrict__ stats, const float* __restrict__ gamma,
-                                                         const float* __restrict__ beta, int act, long rows, int C, int cp,
-                                                         long rows_per_chunk, double* __restrict__ part) {
-    __shared__ double red[2][4][64];
-    const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
-    const int rsub = 64 / cp;
-    const int cl = lane & (cp - 1), rs = lane / cp;
-    const int c = blockIdx.x * 64 + cl;
-    const long r0 = (long)blockIdx.y * rows_per_chunk;
-    const long r1 = rows < r0 + rows_per_chunk ? rows : r0 + rows_per_chunk;
-    double s0 = 0.0, s1 = 0.0;
-    if (c < C && cl < cp) {
-        float mean = 0.0f, rstd = 1.0f, ga = 1.0f, be = 0.0f;
-        if (MODE == 1) {
-            mean = stats[c];
-            rstd = stats[C + c];
-            ga = gamma[c];
-            be = beta[c];
-        }
-        const long step = 4L * rsub;
-        float a0[4], a1[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) a0[u] = a1[u] = 0.0f;
-        long m = r0 + (long)rg * rsub + rs;
-        int since_flush = 0;
-        for (; m < r1; m += 4 * step) {
-            float v[4], d[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const long mm = m + u * step;
-                const bool ok = mm < r1;
-                const long idx = (ok ? mm : m) * C + c;
-                v[u] = z[idx];
-                d[u] = MODE == 1 ? dy[idx] : 0.0f;
-                if (!ok) {
-                    v[u] = MODE == 1 ? mean : 0.0f;   // contributes nothing
-                    d[u] = 0.0f;
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (MODE == 0) {
-                    a0[u] += v[u];
-                    a1[u] = fmaf(v[u], v[u], a1[u]);
-                } else {
-                    const float xh = (v[u] - mean) * rstd;
-                    const float g = mb_act_passes(fmaf(ga, xh, be), act) ? d[u] : 0.0f;
-                    a0[u] += g;
-                    a1[u] = fmaf(g, xh, a1[u]);
-                }
-            }
-            if (++since_flush == 16) {   // short fp32 runs, fp64 totals
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    s0 += (double)a0[u];
-                    s1 += (double)a1[u];
-                    a0[u] = a1[u] = 0.0f;
-                }
-                since_flush = 0;
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            s0 += (double)a0[u];
-            s1 += (double)a1[u];
-        }
-    }
-    red[0][rg][lane] = s0;
-    red[1][rg][lane] = s1;
-    __syncthreads();
-    if (rg == 0 && rs == 0 && c < C) {
-        double t0 = 0.0, t1 = 0.0;
-        for (int w = 0; w < 4; ++w)
-            for (int q = 0; q < rsub; ++q) {
-                t0 += red[0][w][q * cp + cl];
-                t1 += red[1][w][q * cp + cl];
-            }
-        part[((size_t)blockIdx.y * 2 + 0) * C + c] = t0;
-        part[((size_t)blockIdx.y * 2 + 1) * C + c] = t1;
-    }
-}
-
-// folds the chunk partials of 64 columns: the 4 waves split the chunks, lanes are columns (coalesced), fixed order
-constexpr int FIN_RG = 16;   // row groups of a finalize block (1024 threads): <= 512 chunk rows are two trips of 16 loads
-constexpr int FIN_THREADS = 64 * FIN_RG;
-__device__ __forceinline__ void fold_chunks(const double* __restrict__ part, int chunks, int C, int c, int rg, double& s0,
-                                            double& s1, double (&red)[2][FIN_RG][64], int lane) {
-    // Sixteen row groups x eight rows per trip, the 16 loads of a trip in flight together (clamped row, masked sum).  With 4
-    // row groups this was 8+ dependent trips to L2 in a kernel that is nothing but latency (53 + 53 launches per step).
-    double a0 = 0.0, a1 = 0.0;
-    const int cc = c < C ? c : C - 1;
-    for (int k0 = rg; k0 < chunks; k0 += 8 * FIN_RG) {
-        double v0[8], v1[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int k = k0 + u * FIN_RG < chunks ? k0 + u * FIN_RG : chunks - 1;
-            v0[u] = part[((size_t)k * 2 + 0) * C + cc];
-            v1[u] = part[((size_t)k * 2 + 1) * C + cc];
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const bool ok = k0 + u * FIN_RG < chunks;
-            a0 += ok ? v0[u] : 0.0;
-            a1 += ok ? v1[u] : 0.0;
-        }
-    }
-    red[0][rg][lane] = a0;
-    red[1][rg][lane] = a1;
-    __syncthreads();
-    s0 = 0.0;
-    s1 = 0.0;
-    if (rg == 0) {
-#pragma unroll
-        for (int g = 0; g < FIN_RG; ++g) {
-            s0 += red[0][g][lane];
-            s1 += red[1][g][lane];
-        }
-    }
-}
-
-// batch statistics (biased variance for normalisation, unbiased for the running estimate: nn.BatchNorm2d)
-__global__ __launch_bounds__(FIN_THREADS) void bn_stats_finalize_kernel(const double* __restrict__ part, int chunks, int C,
-                                                                double count, float* __restrict__ stats,
-                                                                float* __restrict__ rmean, float* __restrict__ rvar) {
-    __shared__ double red[2][FIN_RG][64];
-    const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + lane;
-    double s0, s1;
-    fold_chunks(part, chunks, C, c, rg, s0, s1, red, lane);
-    if (rg != 0 || c >= C) return;
-    const double mean = s0 / count;
-    double var = s1 / count - mean * mean;
-    var = var < 0.0 ? 0.0 : var;
-    stats[c] = (float)mean;
-    stats[C + c] = (float)(1.0 / sqrt(var + (double)MB_EPS));
-    const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-    rmean[c] = (float)((1.0 - MB_MOMENTUM) * (double)rmean[c] + MB_MOMENTUM * mean);
-    rvar[c] = (float)((1.0 - MB_MOMENTUM) * (double)rvar[c] + MB_MOMENTUM * unbiased);
-}
-
-__global__ void bn_eval_stats_mb_kernel(const float* __restrict__ rmean, const float* __restrict__ rvar, int C,
-                                        float* __restrict__ stats) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    stats[c] = rmean[c];
-    stats[C + c] = 1.0f / sqrtf(rvar[c] + MB_EPS);
-}
-
-// y = act(gamma * (z - mean) * rstd + beta) [+ res]
-__global__ void bn_act_fwd_kernel(const float* __restrict__ z, const float* __restrict__ stats, const float* __restrict__ gamma,
-                                  const float* __restrict__ beta, const float* __restrict__ res, int act, int C, long total,
-                                  float* __restrict__ y) {
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int c = chan_of(idx, C);
-        float v = mb_act(fmaf(gamma[c], (z[idx] - stats[c]) * stats[C + c], beta[c]), act);
-        if (res != nullptr) v += res[idx];
-        y[idx] = v;
-    }
-}
-
-// dgamma = sum g*xhat, dbeta = sum g; m1 = dbeta / M, m2 = dgamma / M for the apply pass
-__global__ __launch_bounds__(FIN_THREADS) void bn_bwd_finalize_mb_kernel(const double* __restrict__ part, int chunks, int C,
-                                                                 double count, float* __restrict__ dgamma,
-                                                                 float* __restrict__ dbeta, float* __restrict__ m12) {
-    __shared__ double red[2][FIN_RG][64];
-    const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + lane;
-    double s0, s1;
-    fold_chunks(part, chunks, C, c, rg, s0, s1, red, lane);
-    if (rg != 0 || c >= C) return;
-    dbeta[c] = (float)s0;
-    dgamma[c] = (float)s1;
-    m12[c] = (float)(s0 / count);
-    m12[C + c] = (float)(s1 / count);
-}
-
-// column sums only (conv-bias gradient): out[c] = sum over chunks of part[k][0][c]
-__global__ __launch_bounds__(FIN_THREADS) void colsum_finalize_kernel(const double* __restrict__ part, int chunks, int C,
-                                                              float* __restrict__ out) {
-    __shared__ double red[2][FIN_RG][64];
-    const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + lane;
-    double s0, s1;
-    fold_chunks(part, chunks, C, c, rg, s0, s1, red, lane);
-    if (rg == 0 && c < C) out[c] = (float)s0;
-}
-
-// dz = gamma * rstd * (g - m1 - xhat * m2)
-__global__ void bn_bwd_apply_kernel(const float* __restrict__ z, const float* __restrict__ dy, const float* __restrict__ stats,
-                                    const float* __restrict__ gamma, const float* __restrict__ beta,
-                                    const float* __restrict__ m12, int act, int C, long total, float* __restrict__ dz) {
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int c = chan_of(idx, C);
-        const float rstd = stats[C + c];
-        const float xh = (z[idx] - stats[c]) * rstd;
-        const float g = mb_act_passes(fmaf(gamma[c], xh, beta[c]), act) ? dy[idx] : 0.0f;
-        dz[idx] = gamma[c] * rstd * (g - m12[c] - xh * m12[C + c]);
-    }
-}
-
 // MaxPool2d((1,2)) over W (floor), channels-last
 __global__ void maxpool12_fwd_kernel(const float* __restrict__ x, int W, int Wp, int C, long total, float* __restrict__ y) {
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
@@ -683,33 +873,510 @@ __global__ void maxpool12_bwd_kernel(const float* __restrict__ x, const float* _
     }
 }
 
-// adaptive_avg_pool2d(1): pooled[b][c] = mean over the HW pixels; optional dropout mask applied to a second output
-__global__ void avgpool_fwd_kernel(const float* __restrict__ x, int HW, int C, const float* __restrict__ mask, float scale,
-                                   long total, float* __restrict__ pooled, float* __restrict__ pooled_d) {
+// ---------------------------------------------------------------------------------------------------------
+// Depthwise 3x3 (padding 1).  All three kernels share one geometry: block = 64 channels (lane = channel: every load of a
+// wave is 256 contiguous bytes) x one chunk of IMAGE rows; the 4 waves take the rows of the chunk in turn and walk a row
+// in segments of DW_SEG = 4 outputs that share one window of inputs (3 rows x 6 columns at stride 1, 3 x 9 at stride 2),
+// loaded unconditionally from clamped addresses and masked afterwards.  A lane's channel never changes, so the nine
+// weights and every BatchNorm constant it needs are registers, and per-channel sums are running registers that leave the
+// block as one row of partials.
+// ---------------------------------------------------------------------------------------------------------
+// forward: z[b,oh,ow,c] = sum_tap w[c*9+tap] * y_in[b, oh*s-1+kh, ow*s-1+kw, c],  y_in = relu6(z_in * scale + shift) inside
+// the image, 0 in the padding; taps accumulate in the order (kh, kw) with fmaf.
+template <int STRIDE>
+__global__ __launch_bounds__(256) void dw_fwd_kernel(const float* __restrict__ x, const float* __restrict__ ss_in,
+                                                     const float* __restrict__ w, int H, int W, int C, int Ho, int Wo, int nrows,
+                                                     int rows_per_chunk, float* __restrict__ z, Arrive arr, FinFwd fin) {
+    constexpr int NIN = (DW_SEG - 1) * STRIDE + 3;     // input columns under DW_SEG outputs
+    __shared__ float red[2][4][64];
+    const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    const bool cok = c < C;
+    const int cc = cok ? c : C - 1;
+    float wk[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wk[k] = w[cc * 9 + k];
+    const float sc = ss_in[cc], sh = ss_in[C + cc];
+    const int r0 = blockIdx.y * rows_per_chunk;
+    const int r1 = min(nrows, r0 + rows_per_chunk);
+    float s = 0.0f, q = 0.0f;
+    for (int t = r0 + rg; t < r1; t += 4) {
+        const int b = t / Ho, oh = t - b * Ho;
+        const float* xb = x + (long)b * H * W * C + cc;
+        float* zr = z + (long)t * Wo * C + cc;
+        for (int ow0 = 0; ow0 < Wo; ow0 += DW_SEG) {
+            float v[3][NIN];
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                const int ihc = min(max(oh * STRIDE - 1 + kh, 0), H - 1);
+#pragma unroll
+                for (int j = 0; j < NIN; ++j) {
+                    const int iwc = min(max(ow0 * STRIDE - 1 + j, 0), W - 1);
+                    v[kh][j] = xb[((long)ihc * W + iwc) * C];
+                }
+            }
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                const int ih = oh * STRIDE - 1 + kh;
+#pragma unroll
+                for (int j = 0; j < NIN; ++j) {
+                    const int iw = ow0 * STRIDE - 1 + j;
+                    const bool inb = ih >= 0 && ih < H && iw >= 0 && iw < W;
+                    v[kh][j] = inb ? relu6f(fmaf(v[kh][j], sc, sh)) : 0.0f;
+                }
+            }
+#pragma unroll
+            for (int o = 0; o < DW_SEG; ++o) {
+                float acc = 0.0f;
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw) acc = fmaf(wk[kh * 3 + kw], v[kh][o * STRIDE + kw], acc);
+                if (ow0 + o < Wo) {
+                    if (cok) zr[(long)(ow0 + o) * C] = acc;
+                    s += acc;
+                    q = fmaf(acc, acc, q);
+                }
+            }
+        }
+    }
+    if (arr.part1 == nullptr) return;
+    red[0][rg][lane] = s;
+    red[1][rg][lane] = q;
+    __syncthreads();
+    const bool own = rg == 0 && cok;
+    const float v0 = ((red[0][0][lane] + red[0][1][lane]) + red[0][2][lane]) + red[0][3][lane];
+    const float v1 = ((red[1][0][lane] + red[1][1][lane]) + red[1][2][lane]) + red[1][3][lane];
+    if (publish_and_arrive(arr, C, blockIdx.x * 64, own, c, v0, v1))
+        finalize_fwd(arr.part2, (gridDim.y + MB_G - 1) / MB_G, C, c, fin);
+}
+
+// data gradient over the INPUT rows (b, ih): dy_j[b,ih,iw,c] = sum_tap w[c*9+tap] * dz[b,oh,ow,c] over the outputs whose
+// window holds (ih, iw) at that tap (oh*s - 1 + kh = ih, ow*s - 1 + kw = iw); dz rebuilt from (g_k, z_k, bc_k) per loaded
+// window element; the gradient window under 4 inputs is 3 rows x 6 columns at stride 1, 2 x 4 at stride 2 (loaded for every
+// tap parity, masked).  Epilogue = EpiBwd for the layer in front (same channels).
+template <int STRIDE>
+__global__ __launch_bounds__(256) void dw_dgrad_kernel(const float* __restrict__ g, const float* __restrict__ zk,
+                                                       const float* __restrict__ bc, const float* __restrict__ w, int H, int W,
+                                                       int C, int Ho, int Wo, int nrows, int rows_per_chunk, EpiBwd e, Arrive arr,
+                                                       FinBwd fin) {
+    constexpr int NCOL = STRIDE == 1 ? DW_SEG + 2 : (DW_SEG + 1) / STRIDE + 2;   // 6 at stride 1, 4 at stride 2
+    __shared__ float red[2][4][64];
+    const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    const bool cok = c < C;
+    const int cc = cok ? c : C - 1;
+    float wk[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wk[k] = w[cc * 9 + k];
+    const float ksc = bc[cc], kc1 = bc[C + cc], kc0 = bc[2 * C + cc];
+    const float jsc = e.ssj[cc], jsh = e.ssj[C + cc], jme = e.ssj[2 * C + cc], jrs = e.ssj[3 * C + cc];
+    const int r0 = blockIdx.y * rows_per_chunk;
+    const int r1 = min(nrows, r0 + rows_per_chunk);
+    float s1 = 0.0f, s2 = 0.0f;
+    for (int t = r0 + rg; t < r1; t += 4) {
+        const int b = t / H, ih = t - b * H;
+        const float* gb = g + (long)b * Ho * Wo * C + cc;
+        const float* zb = zk + (long)b * Ho * Wo * C + cc;
+        const float* zjr = e.zj + (long)t * W * C + cc;
+        float* gjr = e.gj + (long)t * W * C + cc;
+        bool okh[3];
+        int ohs[3];
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int nh = ih + 1 - kh;                                // = oh * s
+            const int oh = (nh + STRIDE) / STRIDE - 1;                 // floor division for nh >= -s
+            okh[kh] = nh >= 0 && oh * STRIDE == nh && oh < Ho;
+            ohs[kh] = min(max(oh, 0), Ho - 1);
+        }
+        for (int iw0 = 0; iw0 < W; iw0 += DW_SEG) {
+            // gradient columns that can touch inputs iw0 .. iw0+3: ow = (iw + 1 - kw) / s -> from floor((iw0 - 1) / s) upwards
+            const int owb = (iw0 - 1 + STRIDE) / STRIDE - 1;
+            float v[3][NCOL], vz[3][NCOL], zj[DW_SEG];
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int j = 0; j < NCOL; ++j) {
+                    const int owc = min(max(owb + j, 0), Wo - 1);
+                    v[kh][j] = gb[((long)ohs[kh] * Wo + owc) * C];
+                    vz[kh][j] = zb[((long)ohs[kh] * Wo + owc) * C];
+                }
+#pragma unroll
+            for (int o = 0; o < DW_SEG; ++o) zj[o] = zjr[(long)min(iw0 + o, W - 1) * C];
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int j = 0; j < NCOL; ++j) v[kh][j] = fmaf(ksc, v[kh][j], fmaf(kc1, vz[kh][j], kc0));
+#pragma unroll
+            for (int o = 0; o < DW_SEG; ++o) {
+                const int iw = iw0 + o;
+                float acc = 0.0f;
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw) {
+                        const int nw = iw + 1 - kw;                        // = ow * s
+                        const int ow = (nw + STRIDE) / STRIDE - 1;
+                        const bool ok = okh[kh] && nw >= 0 && ow * STRIDE == nw && ow < Wo;
+                        // window slot of ow; clamped only to keep the (masked) register index inside the array
+                        const int j = min(max(ow - owb, 0), NCOL - 1);
+                        float gv = v[kh][0];
+#pragma unroll
+                        for (int qq = 1; qq < NCOL; ++qq) gv = (j == qq) ? v[kh][qq] : gv;
+                        acc = fmaf(ok ? wk[kh * 3 + kw] : 0.0f, gv, acc);
+                    }
+                if (iw < W) {
+                    const bool pass = mb_act_passes(fmaf(zj[o], jsc, jsh), e.act);
+                    const float gg = pass ? acc : 0.0f;
+                    if (cok) gjr[(long)iw * C] = gg;
+                    s1 += gg;
+                    s2 = fmaf(gg, (zj[o] - jme) * jrs, s2);
+                }
+            }
+        }
+    }
+    red[0][rg][lane] = s1;
+    red[1][rg][lane] = s2;
+    __syncthreads();
+    const bool own = rg == 0 && cok;
+    const float v0 = ((red[0][0][lane] + red[0][1][lane]) + red[0][2][lane]) + red[0][3][lane];
+    const float v1 = ((red[1][0][lane] + red[1][1][lane]) + red[1][2][lane]) + red[1][3][lane];
+    if (publish_and_arrive(arr, C, blockIdx.x * 64, own, c, v0, v1))
+        finalize_bwd(arr.part2, (gridDim.y + MB_G - 1) / MB_G, C, c, fin);
+}
+
+// weight gradient: dW[c][tap] = sum_{b,oh,ow} dz[.,c] * y_in[shifted, c]; both factors rebuilt on load.
+// part[chunk][c*9+tap]; the chunks are folded in a fixed order by the deferred slab sum.
+template <int STRIDE>
+__global__ __launch_bounds__(256) void dw_wgrad_kernel(const float* __restrict__ g, const float* __restrict__ zk,
+                                                       const float* __restrict__ bc, const float* __restrict__ x,
+                                                       const float* __restrict__ ss_in, int H, int W, int C, int Ho, int Wo,
+                                                       int nrows, int rows_per_chunk, float* __restrict__ part) {
+    constexpr int NIN = (DW_SEG - 1) * STRIDE + 3;
+    __shared__ float red[4][9][64];
+    const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    const bool cok = c < C;
+    const int cc = cok ? c : C - 1;
+    const float ksc = bc[cc], kc1 = bc[C + cc], kc0 = bc[2 * C + cc];
+    const float sc = ss_in[cc], sh = ss_in[C + cc];
+    const int r0 = blockIdx.y * rows_per_chunk;
+    const int r1 = min(nrows, r0 + rows_per_chunk);
+    float acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[t] = 0.0f;
+    for (int t = r0 + rg; t < r1; t += 4) {
+        const int b = t / Ho, oh = t - b * Ho;
+        const float* xb = x + (long)b * H * W * C + cc;
+        const float* gr = g + (long)t * Wo * C + cc;
+        const float* zr = zk + (long)t * Wo * C + cc;
+        for (int ow0 = 0; ow0 < Wo; ow0 += DW_SEG) {
+            float d[DW_SEG], dzv[DW_SEG], v[3][NIN];
+#pragma unroll
+            for (int o = 0; o < DW_SEG; ++o) {
+                d[o] = gr[(long)min(ow0 + o, Wo - 1) * C];
+                dzv[o] = zr[(long)min(ow0 + o, Wo - 1) * C];
+            }
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                const int ihc = min(max(oh * STRIDE - 1 + kh, 0), H - 1);
+#pragma unroll
+                for (int j = 0; j < NIN; ++j) {
+                    const int iwc = min(max(ow0 * STRIDE - 1 + j, 0), W - 1);
+                    v[kh][j] = xb[((long)ihc * W + iwc) * C];
+                }
+            }
+#pragma unroll
+            for (int o = 0; o < DW_SEG; ++o) d[o] = ow0 + o < Wo ? fmaf(ksc, d[o], fmaf(kc1, dzv[o], kc0)) : 0.0f;
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                const int ih = oh * STRIDE - 1 + kh;
+#pragma unroll
+                for (int j = 0; j < NIN; ++j) {
+                    const int iw = ow0 * STRIDE - 1 + j;
+                    const bool inb = ih >= 0 && ih < H && iw >= 0 && iw < W;
+                    v[kh][j] = inb ? relu6f(fmaf(v[kh][j], sc, sh)) : 0.0f;
+                }
+            }
+#pragma unroll
+            for (int o = 0; o < DW_SEG; ++o)
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw) acc[kh * 3 + kw] = fmaf(d[o], v[kh][o * STRIDE + kw], acc[kh * 3 + kw]);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) red[rg][t][lane] = acc[t];
+    __syncthreads();
+    if (rg == 0 && cok) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+            part[(size_t)blockIdx.y * C * 9 + c * 9 + t] = ((red[0][t][lane] + red[1][t][lane]) + red[2][t][lane]) + red[3][t][lane];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// network tail: adaptive_avg_pool2d(1) over relu6(bn(z_last)) (+ dropout), and its backward fused with the last layer's
+// BatchNorm-backward reduction
+// ---------------------------------------------------------------------------------------------------------
+__global__ void avgpool_bn_fwd_kernel(const float* __restrict__ z, const float* __restrict__ ss, int HW, int C,
+                                      const float* __restrict__ mask, float scale, long total, float* __restrict__ pooled,
+                                      float* __restrict__ pooled_d) {
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         const int c = chan_of(idx, C);
         const long b = idx / C;
+        const float sc = ss[c], sh = ss[C + c];
         float acc = 0.0f;
-        for (int p = 0; p < HW; ++p) acc += x[(b * HW + p) * C + c];
+        for (int p = 0; p < HW; ++p) acc += relu6f(fmaf(z[(b * HW + p) * C + c], sc, sh));
         const float v = acc / (float)HW;
         pooled[idx] = v;
         pooled_d[idx] = mask != nullptr ? v * mask[idx] * scale : v;
     }
 }
-__global__ void avgpool_bwd_kernel(const float* __restrict__ dpooled, int HW, int C, const float* __restrict__ mask, float scale,
-                                   long total, float* __restrict__ dx) {
+
+// dy[b,p,c] = dpooled[b,c] (* mask * scale) / HW -> g, partial sums, finalize (block = 64 channels x a chunk of pixel rows)
+__global__ __launch_bounds__(256) void avgpool_bwd_reduce_kernel(const float* __restrict__ dpooled, const float* __restrict__ mask,
+                                                                 float scale, int HW, int C, long rows, int rows_per_chunk,
+                                                                 EpiBwd e, Arrive arr, FinBwd fin) {
+    __shared__ float red[2][4][64];
+    const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    const bool cok = c < C;
+    const int cc = cok ? c : C - 1;
+    const float jsc = e.ssj[cc], jsh = e.ssj[C + cc], jme = e.ssj[2 * C + cc], jrs = e.ssj[3 * C + cc];
+    const long r0 = (long)blockIdx.y * rows_per_chunk;
+    const long r1 = rows < r0 + rows_per_chunk ? rows : r0 + rows_per_chunk;
+    float s1 = 0.0f, s2 = 0.0f;
+    for (long m = r0 + rg; m < r1; m += 4) {
+        const long b = m / HW;
+        float d = dpooled[b * C + cc];
+        if (mask != nullptr) d *= mask[b * C + cc] * scale;
+        d = d / (float)HW;
+        const float zv = e.zj[m * C + cc];
+        const float gg = mb_act_passes(fmaf(zv, jsc, jsh), e.act) ? d : 0.0f;
+        if (cok) e.gj[m * C + c] = gg;
+        s1 += gg;
+        s2 = fmaf(gg, (zv - jme) * jrs, s2);
+    }
+    red[0][rg][lane] = s1;
+    red[1][rg][lane] = s2;
+    __syncthreads();
+    const bool own = rg == 0 && cok;
+    const float v0 = ((red[0][0][lane] + red[0][1][lane]) + red[0][2][lane]) + red[0][3][lane];
+    const float v1 = ((red[1][0][lane] + red[1][1][lane]) + red[1][2][lane]) + red[1][3][lane];
+    if (publish_and_arrive(arr, C, blockIdx.x * 64, own, c, v0, v1))
+        finalize_bwd(arr.part2, (gridDim.y + MB_G - 1) / MB_G, C, c, fin);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// elementwise pieces (materialised outputs, stem)
+// ---------------------------------------------------------------------------------------------------------
+// y = act(z * scale + shift) [+ res]
+__global__ void bn_act_kernel(const float* __restrict__ z, const float* __restrict__ ss, const float* __restrict__ res, int act,
+                              int C, long total, float* __restrict__ y) {
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         const int c = chan_of(idx, C);
-        const long b = idx / ((long)HW * C);
-        float g = dpooled[b * C + c];
-        if (mask != nullptr) g *= mask[b * C + c] * scale;
-        dx[idx] = g / (float)HW;
+        float v = mb_act(fmaf(z[idx], ss[c], ss[C + c]), act);
+        if (res != nullptr) v += res[idx];
+        y[idx] = v;
     }
 }
 
-__global__ void add_inplace_kernel(float* __restrict__ a, const float* __restrict__ b, long n) {
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) a[i] += b[i];
+// dz = scale * g + c1 * z + c0 in memory (stem only: its dense 3x3 convolutions go through im2col + the shared GEMM)
+__global__ void dz_apply_kernel(const float* __restrict__ g, const float* __restrict__ z, const float* __restrict__ bc, int C,
+                                long total, float* __restrict__ dz) {
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int c = chan_of(idx, C);
+        dz[idx] = fmaf(bc[c], g[idx], fmaf(bc[C + c], z[idx], bc[2 * C + c]));
+    }
 }
+
+// eval mode: ss of every layer from the running statistics, one launch (blockIdx.y = layer)
+struct EvalJobs {
+    int c[64];
+    long long gamma_off[64], rmean_off[64], ss_off[64];
+};
+__global__ void bn_eval_ss_kernel(EvalJobs jobs, const float* __restrict__ params, const float* __restrict__ buffers,
+                                  float* __restrict__ ws) {
+    const int k = blockIdx.y;
+    const int C = jobs.c[k];
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float* gamma = params + jobs.gamma_off[k];     // beta follows gamma, running_var follows running_mean
+    const float* rmean = buffers + jobs.rmean_off[k];
+    float* ss = ws + jobs.ss_off[k];
+    const float mean = rmean[c];
+    const float rstd = 1.0f / sqrtf(rmean[C + c] + MB_EPS);
+    const float scale = gamma[c] * rstd;
+    ss[c] = scale;
+    ss[C + c] = gamma[C + c] - mean * scale;
+    ss[2 * C + c] = mean;
+    ss[3 * C + c] = rstd;
+}
+
+// Narrow column reductions over the rows of an (M x C) matrix, C <= 64 (the 3- and 32-channel stem layers).
+// Lane -> (row slot rs = lane / cp, column lane % cp), cp = col_pack(C); rows advance by 4 waves x (64/cp) slots, four loads
+// in flight.  MODE 0: (sum z, sum z^2) -> finalize_fwd, or with colsum_out the plain column sums (conv-bias gradient).
+// MODE 1: BatchNorm backward of a materialised dy: g = dy * act'(.) is stored, (sum g, sum g * xhat) -> finalize_bwd.
+template <int MODE>
+__global__ __launch_bounds__(256) void col_reduce_kernel(const float* __restrict__ z, const float* __restrict__ dy,
+                                                         const float* __restrict__ ss, int act, long rows, int C, int cp,
+                                                         long rows_per_chunk, float* __restrict__ gout, Arrive arr,
+                                                         FinFwd ff, FinBwd fb, float* colsum_out) {
+    __shared__ float red[2][4][64];
+    const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int rsub = 64 / cp;
+    const int cl = lane & (cp - 1), rs = lane / cp;
+    const int c = cl;
+    const long r0 = (long)blockIdx.y * rows_per_chunk;
+    const long r1 = rows < r0 + rows_per_chunk ? rows : r0 + rows_per_chunk;
+    float s0 = 0.0f, s1 = 0.0f;
+    if (c < C) {
+        float sc = 1.0f, sh = 0.0f, mean = 0.0f, rstd = 1.0f;
+        if (MODE == 1) {
+            sc = ss[c];
+            sh = ss[C + c];
+            mean = ss[2 * C + c];
+            rstd = ss[3 * C + c];
+        }
+        const long step = 4L * rsub;
+        double t0 = 0.0, t1 = 0.0;
+        float a0[4], a1[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) a0[u] = a1[u] = 0.0f;
+        int since_flush = 0;
+        for (long m = r0 + (long)rg * rsub + rs; m < r1; m += 4 * step) {
+            float v[4], d[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const long mm = m + u * step;
+                const bool ok = mm < r1;
+                const long idx = (ok ? mm : m) * C + c;
+                v[u] = z[idx];
+                d[u] = MODE == 1 ? dy[idx] : 0.0f;
+                if (!ok) {
+                    v[u] = MODE == 1 ? mean : 0.0f;   // contributes nothing
+                    d[u] = 0.0f;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (MODE == 0) {
+                    a0[u] += v[u];
+                    a1[u] = fmaf(v[u], v[u], a1[u]);
+                } else {
+                    const float gg = mb_act_passes(fmaf(v[u], sc, sh), act) ? d[u] : 0.0f;
+                    if (m + u * step < r1) gout[(m + u * step) * C + c] = gg;
+                    a0[u] += gg;
+                    a1[u] = fmaf(gg, (v[u] - mean) * rstd, a1[u]);
+                }
+            }
+            if (++since_flush == 16) {   // short fp32 runs, fp64 totals
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    t0 += (double)a0[u];
+                    t1 += (double)a1[u];
+                    a0[u] = a1[u] = 0.0f;
+                }
+                since_flush = 0;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            t0 += (double)a0[u];
+            t1 += (double)a1[u];
+        }
+        s0 = (float)t0;
+        s1 = (float)t1;
+    }
+    red[0][rg][lane] = s0;
+    red[1][rg][lane] = s1;
+    __syncthreads();
+    const bool own = rg == 0 && rs == 0 && c < C;
+    float v0 = 0.0f, v1 = 0.0f;
+    if (own) {
+        double t0 = 0.0, t1 = 0.0;
+        for (int w = 0; w < 4; ++w)
+            for (int qq = 0; qq < rsub; ++qq) {
+                t0 += (double)red[0][w][qq * cp + cl];
+                t1 += (double)red[1][w][qq * cp + cl];
+            }
+        v0 = (float)t0;
+        v1 = (float)t1;
+    }
+    if (!publish_and_arrive(arr, C, 0, own, c, v0, v1)) return;
+    const int R2 = (gridDim.y + MB_G - 1) / MB_G;
+    if (colsum_out != nullptr) {
+        double t0, t1;
+        fold_partials(arr.part2, R2, C, lane, t0, t1);
+        if (rg == 0 && lane < C) colsum_out[lane] = (float)t0;
+    } else if (MODE == 0) {
+        finalize_fwd(arr.part2, R2, C, lane, ff);
+    } else {
+        finalize_bwd(arr.part2, R2, C, lane, fb);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Deferred slab sums: every weight gradient of a backward call leaves `nparts` slabs of n floats; ONE launch folds them all
+// (a block owns 64 consecutive outputs of one job, found through the jobs' block prefix; its 4 waves take the slabs
+// wave, wave+4, ..., four loads in flight, and combine through LDS in a fixed order).
+// ---------------------------------------------------------------------------------------------------------
+struct MbSumJob {
+    const float* part;
+    float* out;
+    int n, nparts, blk0, pad;
+};
+struct MbSumJobs {
+    MbSumJob j[MB_MAX_JOBS];
+    int count, blocks;
+};
+__global__ __launch_bounds__(256) void sum_jobs_kernel(MbSumJobs jobs) {
+    __shared__ float red[4][64];
+    int lo = 0, hi = jobs.count - 1;
+    while (lo < hi) {   // last job whose first block is <= blockIdx.x
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs.j[mid].blk0 <= (int)blockIdx.x) lo = mid;
+        else hi = mid - 1;
+    }
+    const MbSumJob& jb = jobs.j[lo];
+    const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const long n = jb.n;
+    const long i = (long)((int)blockIdx.x - jb.blk0) * 64 + lane;
+    float s[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (i < n) {
+        int gq = rg;
+        for (; gq + 12 < jb.nparts; gq += 16) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) s[u] += jb.part[(long)(gq + 4 * u) * n + i];
+        }
+        for (; gq < jb.nparts; gq += 4) s[0] += jb.part[(long)gq * n + i];
+    }
+    red[rg][lane] = (s[0] + s[1]) + (s[2] + s[3]);
+    __syncthreads();
+    if (rg == 0 && i < n) jb.out[i] = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
+}
+struct JobList {
+    MbSumJobs jobs;
+    JobList() { jobs.count = 0; jobs.blocks = 0; }
+    void add(const float* part, int nparts, long n, float* out) {
+        MbSumJob& jb = jobs.j[jobs.count++];
+        jb.part = part;
+        jb.out = out;
+        jb.n = (int)n;
+        jb.nparts = nparts;
+        jb.blk0 = jobs.blocks;
+        jb.pad = 0;
+        jobs.blocks += (int)((n + 63) / 64);
+    }
+    void flush(hipStream_t s) {
+        if (jobs.count == 0) return;
+        hipLaunchKernelGGL(sum_jobs_kernel, dim3((unsigned)jobs.blocks), dim3(256), 0, s, jobs);
+        jobs.count = 0;
+        jobs.blocks = 0;
+    }
+};
 
 inline unsigned flat_grid(long total) {
     long blocks = (total + 255) / 256;
@@ -723,30 +1390,49 @@ struct Ctx {
     const float* params;
     hipStream_t s;
     int B;
+    unsigned* counters() const { return reinterpret_cast<unsigned*>(ws + p.counters); }
+    Arrive arrive() const { return Arrive{ws + p.part, ws + p.part2, counters(), counters() + MB_CBLOCKS * MB_R2}; }
 };
 
-// convolution of layer k: z = conv(in)
-void conv_forward(const Ctx& c, int k, const float* in, long sb, long sh, long sw, long sc, float* z) {
+// row tiles of a pointwise launch: each block takes a run of consecutive 64-row tiles
+inline void pw_rows(long M, int col_tiles, int* tiles_per_block, int* blocks) {
+    const int row_tiles = (int)((M + GT - 1) / GT);
+    int tpb = (int)(((long)row_tiles * col_tiles + 4095) / 4096);     // ~4096 blocks at most ...
+    if (tpb < (row_tiles + MB_R - 1) / MB_R) tpb = (row_tiles + MB_R - 1) / MB_R;   // ... and <= MB_R of them along the rows
+    if (tpb < 1) tpb = 1;
+    *tiles_per_block = tpb;
+    *blocks = (row_tiles + tpb - 1) / tpb;
+}
+
+// the stem's dense 3x3 convolutions: im2col + the shared GEMM
+void dense_forward(const Ctx& c, int k, const float* in, long sb, long sh, long sw, long sc, float* z) {
     const HowlMbLayer& l = c.n->layers[k];
     const Geo& g = c.p.g[k];
-    const float* w = c.params + l.w_off;
-    if (l.kind == MB_PW) {
-        gemm(c.s, true, in, lin(l.cin), 1, lin(0), w, lin(1), l.cin, (int)g.mz, l.cout, l.cin, 1, nullptr, 0, z, l.cout, 0);
-    } else if (l.kind == MB_DW) {
-        const dim3 grid((unsigned)(c.B * g.ho), (((g.wo + DW_SEG - 1) / DW_SEG) * l.cin + 255) / 256);
-        if (l.stride == 1)
-            hipLaunchKernelGGL(dw3x3_fwd_kernel<1>, grid, dim3(256), 0, c.s, in, w, g.hin, g.win, l.cin, g.ho, g.wo, z);
-        else
-            hipLaunchKernelGGL(dw3x3_fwd_kernel<2>, grid, dim3(256), 0, c.s, in, w, g.hin, g.win, l.cin, g.ho, g.wo, z);
-    } else {
-        float* col = c.ws + c.p.col;
-        const int K = 9 * l.cin;
-        const long total = g.mz * K;
-        hipLaunchKernelGGL(im2col3x3_kernel, dim3(flat_grid(total)), dim3(256), 0, c.s, in, sb, sh, sw, sc, g.hin, g.win, l.cin,
-                           g.ho, g.wo, l.stride, l.pad_h, l.pad_w, total, col);
-        gemm(c.s, true, col, lin(K), 1, lin(0), w, lin(1), K, (int)g.mz, l.cout, K, 1, l.bias ? c.params + l.b_off : nullptr, 0, z,
-             l.cout, 0);
-    }
+    float* col = c.ws + c.p.col;
+    const int K = 9 * l.cin;
+    const long total = g.mz * K;
+    hipLaunchKernelGGL(im2col3x3_kernel, dim3(flat_grid(total)), dim3(256), 0, c.s, in, sb, sh, sw, sc, g.hin, g.win, l.cin, g.ho,
+                       g.wo, l.stride, l.pad_h, l.pad_w, total, col);
+    gemm(c.s, true, col, lin(K), 1, lin(0), c.params + l.w_off, lin(1), K, (int)g.mz, l.cout, K, 1,
+         l.bias ? c.params + l.b_off : nullptr, 0, z, l.cout, 0);
+}
+
+FinFwd fin_fwd(const Ctx& c, int k, float* buffers) {
+    const HowlMbLayer& l = c.n->layers[k];
+    return FinFwd{c.params + l.gamma_off, c.params + l.beta_off, buffers + l.rmean_off, buffers + l.rvar_off,
+                  c.ws + c.p.ss[k], (double)c.p.g[k].mz};
+}
+FinBwd fin_bwd(const Ctx& c, int j, float* grads) {
+    const HowlMbLayer& l = c.n->layers[j];
+    return FinBwd{c.ws + c.p.ss[j], grads + l.gamma_off, grads + l.beta_off, c.ws + c.p.bc[j], (double)c.p.g[j].mz};
+}
+// the epilogue of the kernel that produces layer j's incoming gradient
+EpiBwd epi_bwd(const Ctx& c, int j) {
+    const int nl = (int)c.n->layers.size();
+    const float* addend = nullptr;
+    for (int k2 = j + 1; k2 < nl; ++k2)
+        if (c.n->layers[k2].res_src == j) addend = c.ws + c.p.gr[k2];   // y_k2 = bn(z_k2) + y_j, no activation: dy_k2 = g_k2
+    return EpiBwd{addend, c.ws + c.p.z[j], c.ws + c.p.ss[j], c.ws + c.p.gr[j], c.n->layers[j].act};
 }
 
 }  // namespace
@@ -782,57 +1468,90 @@ int howl_mobilenet_fwd(const float* params, float* buffers, int num_labels, cons
     Ctx c{&net(), make_plan(B, M, T, num_labels), reinterpret_cast<float*>(ws), params, stream, B};
     const int nl = (int)c.n->layers.size();
     HOWL_REQUIRE(c.p.g[nl - 1].hy >= 1 && c.p.g[nl - 1].wy >= 1, "howl_mobilenet_fwd: input too small for the network");
-    double* part = reinterpret_cast<double*>(c.ws + c.p.part);
-    const float* in = x;
-    long isb = sb, ish = sm, isw = st, isc = 0;  // network input: (B, 1, M, T) view, H = mel, W = time
+    HOWL_REQUIRE(nl <= 64, "howl_mobilenet_fwd: layer table too long");
+    Arrive arr = c.arrive();
+    if (!training) arr.part1 = nullptr;     // no statistics: ss comes from the running estimates
+    hipMemsetAsync(c.counters(), 0, MB_COUNTERS * sizeof(unsigned), stream);
+    if (!training) {
+        EvalJobs jobs{};
+        for (int k = 0; k < nl; ++k) {
+            const HowlMbLayer& l = c.n->layers[k];
+            jobs.c[k] = l.cout;
+            jobs.gamma_off[k] = l.gamma_off;
+            jobs.rmean_off[k] = l.rmean_off;
+            jobs.ss_off[k] = (long long)c.p.ss[k];
+        }
+        hipLaunchKernelGGL(bn_eval_ss_kernel, dim3((MB_MAXC + 255) / 256, nl), dim3(256), 0, stream, jobs, params,
+                           (const float*)buffers, c.ws);
+    }
     for (int k = 0; k < nl; ++k) {
         const HowlMbLayer& l = c.n->layers[k];
         const Geo& g = c.p.g[k];
         float* z = c.ws + c.p.z[k];
-        float* stats = c.ws + c.p.stats[k];
-        conv_forward(c, k, in, isb, ish, isw, isc, z);
-        if (training) {
-            const int chunks = chunks_for(g.mz, l.cout);
-            const long rpc = (g.mz + chunks - 1) / chunks;
-            {
-                HowlProfScope prof("mb_sweep", stream, 4.0 * (double)g.mz * l.cout);     // reads z once
-                hipLaunchKernelGGL(col_reduce_kernel<0>, dim3((l.cout + 63) / 64, chunks), dim3(256), 0, stream, (const float*)z,
-                                   (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
-                                   0, g.mz, l.cout, col_pack(l.cout), rpc, part);
-            }
-            hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((l.cout + 63) / 64), dim3(FIN_THREADS), 0, stream, (const double*)part,
-                               chunks, l.cout, (double)g.mz, stats, buffers + l.rmean_off, buffers + l.rvar_off);
+        // the layer's input: y_{k-1} where it exists, else z_{k-1} with the BatchNorm + ReLU6 of layer k-1 applied on load
+        const bool in_mat = k == 0 || materialized(c.n->layers[k - 1]);
+        const float* in = k == 0 ? x : (in_mat ? c.ws + c.p.y[k - 1] : c.ws + c.p.z[k - 1]);
+        const float* ss_in = in_mat ? nullptr : c.ws + c.p.ss[k - 1];
+        const FinFwd fin = fin_fwd(c, k, buffers);
+        if (l.kind == MB_PW) {
+            int tpb, rb;
+            pw_rows(g.mz, (l.cout + GT - 1) / GT, &tpb, &rb);
+            const dim3 grid((l.cout + GT - 1) / GT, rb);
+            HowlProfScope prof("mb_conv", stream, 4.0 * (double)g.mz * (l.cin + l.cout));
+            if (ss_in != nullptr)
+                hipLaunchKernelGGL(pw_fwd_kernel<true>, grid, dim3(256), 0, stream, in, ss_in, params + l.w_off, (int)g.mz, l.cout,
+                                   l.cin, tpb, z, arr, fin);
+            else
+                hipLaunchKernelGGL(pw_fwd_kernel<false>, grid, dim3(256), 0, stream, in, ss_in, params + l.w_off, (int)g.mz,
+                                   l.cout, l.cin, tpb, z, arr, fin);
+        } else if (l.kind == MB_DW) {
+            int rpc;
+            const int nrows = B * g.ho;
+            const int chunks = row_chunks(nrows, 4, &rpc);
+            const dim3 grid((l.cout + 63) / 64, chunks);
+            HowlProfScope prof("mb_conv", stream, 4.0 * ((double)B * g.hin * g.win + (double)g.mz) * l.cout);
+            if (l.stride == 1)
+                hipLaunchKernelGGL(dw_fwd_kernel<1>, grid, dim3(256), 0, stream, in, ss_in, params + l.w_off, g.hin, g.win, l.cin,
+                                   g.ho, g.wo, nrows, rpc, z, arr, fin);
+            else
+                hipLaunchKernelGGL(dw_fwd_kernel<2>, grid, dim3(256), 0, stream, in, ss_in, params + l.w_off, g.hin, g.win, l.cin,
+                                   g.ho, g.wo, nrows, rpc, z, arr, fin);
         } else {
-            hipLaunchKernelGGL(bn_eval_stats_mb_kernel, dim3((l.cout + 255) / 256), dim3(256), 0, stream,
-                               (const float*)(buffers + l.rmean_off), (const float*)(buffers + l.rvar_off), l.cout, stats);
+            if (k == 0)
+                dense_forward(c, k, in, sb, sm, st, 0, z);   // network input: (B, 1, M, T) view, H = mel, W = time
+            else
+                dense_forward(c, k, in, (long)g.hin * g.win * l.cin, (long)g.win * l.cin, l.cin, 1, z);
+            if (training) {
+                int rpc;
+                const int cp = col_pack(l.cout);
+                const int chunks = row_chunks(g.mz, 64 * (64 / cp), &rpc);
+                hipLaunchKernelGGL(col_reduce_kernel<0>, dim3(1, chunks), dim3(256), 0, stream, (const float*)z,
+                                   (const float*)nullptr, (const float*)nullptr, 0, g.mz, l.cout, cp, (long)rpc, (float*)nullptr,
+                                   arr, fin, FinBwd{}, (float*)nullptr);
+            }
         }
-        const float* res = l.res_src >= 0 ? c.ws + c.p.y[l.res_src] : nullptr;
-        float* ypre = l.pool ? c.ws + c.p.yp[k] : c.ws + c.p.y[k];
-        const long total = g.mz * l.cout;
-        {
-            HowlProfScope prof("mb_sweep", stream, (res != nullptr ? 12.0 : 8.0) * (double)total);   // z (+ residual) in, y out
-            hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(flat_grid(total)), dim3(256), 0, stream, (const float*)z,
-                               (const float*)stats, params + l.gamma_off, params + l.beta_off, res, l.act, l.cout, total, ypre);
+        if (materialized(l)) {
+            const float* res = l.res_src >= 0 ? c.ws + c.p.y[l.res_src] : nullptr;
+            float* ypre = l.pool ? c.ws + c.p.yp[k] : c.ws + c.p.y[k];
+            const long total = g.mz * l.cout;
+            hipLaunchKernelGGL(bn_act_kernel, dim3(flat_grid(total)), dim3(256), 0, stream, (const float*)z,
+                               (const float*)(c.ws + c.p.ss[k]), res, l.act, l.cout, total, ypre);
+            if (l.pool) {
+                const long tp = g.my * l.cout;
+                hipLaunchKernelGGL(maxpool12_fwd_kernel, dim3(flat_grid(tp)), dim3(256), 0, stream, (const float*)ypre, g.wo, g.wy,
+                                   l.cout, tp, c.ws + c.p.y[k]);
+            }
         }
-        if (l.pool) {
-            const long tp = g.my * l.cout;
-            hipLaunchKernelGGL(maxpool12_fwd_kernel, dim3(flat_grid(tp)), dim3(256), 0, stream, (const float*)ypre, g.wo, g.wy,
-                               l.cout, tp, c.ws + c.p.y[k]);
-        }
-        in = c.ws + c.p.y[k];
-        isb = (long)g.hy * g.wy * l.cout;
-        ish = (long)g.wy * l.cout;
-        isw = l.cout;
-        isc = 1;
     }
     const Geo& gl = c.p.g[nl - 1];
     const long tp = (long)B * MB_LAST;
-    hipLaunchKernelGGL(avgpool_fwd_kernel, dim3(flat_grid(tp)), dim3(256), 0, stream, (const float*)in, gl.hy * gl.wy, MB_LAST,
-                       training ? drop_mask : (const float*)nullptr, drop_scale, tp, c.ws + c.p.pooled, c.ws + c.p.pooled_d);
+    hipLaunchKernelGGL(avgpool_bn_fwd_kernel, dim3(flat_grid(tp)), dim3(256), 0, stream, (const float*)(c.ws + c.p.z[nl - 1]),
+                       (const float*)(c.ws + c.p.ss[nl - 1]), gl.hy * gl.wy, MB_LAST, training ? drop_mask : (const float*)nullptr,
+                       drop_scale, tp, c.ws + c.p.pooled, c.ws + c.p.pooled_d);
     const float* wc = params + c.n->feature_params;
-    const float* bc = wc + (size_t)num_labels * MB_LAST;
-    gemm(stream, true, c.ws + c.p.pooled_d, lin(MB_LAST), 1, lin(0), wc, lin(1), MB_LAST, B, num_labels, MB_LAST, 1, bc, 0, logits,
-         num_labels, 0);
+    const float* bcl = wc + (size_t)num_labels * MB_LAST;
+    gemm(stream, true, c.ws + c.p.pooled_d, lin(MB_LAST), 1, lin(0), wc, lin(1), MB_LAST, B, num_labels, MB_LAST, 1, bcl, 0,
+         logits, num_labels, 0);
     HOWL_CHECK_LAUNCH("howl_mobilenet_fwd");
     return HOWL_OK;
 }
@@ -845,153 +1564,169 @@ int howl_mobilenet_bwd(const float* params, int num_labels, const float* x, long
     HOWL_REQUIRE(ws_bytes >= howl_mobilenet_workspace_bytes(B, M, T, num_labels), "howl_mobilenet_bwd: workspace too small");
     Ctx c{&net(), make_plan(B, M, T, num_labels), reinterpret_cast<float*>(ws), params, stream, B};
     const int nl = (int)c.n->layers.size();
-    double* part = reinterpret_cast<double*>(c.ws + c.p.part);
-    float* scratch = c.ws + c.p.gemm_scratch;
-    float* m12 = c.ws + c.p.m12;
+    const Arrive arr = c.arrive();
+    hipMemsetAsync(c.counters(), 0, MB_COUNTERS * sizeof(unsigned), stream);
+    // Two HIP queues: the chain of data gradients (each launch also reduces the BatchNorm backward of the layer in front,
+    // so layer k's dz exists -- as g_k, z_k, bc_k -- the moment the data gradient of layer k+1 ends) stays on the caller's
+    // stream; the weight gradient of layer k only needs that triple and goes to the side queue, where it overlaps the
+    // chain.  Nothing on the side queue is ever waited for before the join at the end: every g_k has its own buffer.
+    HowlSideQueue* sq = howl_side_queue(stream, 1, "HOWL_MOBILENET_BWD_QUEUES");
+    hipStream_t wst = sq ? sq->stream : stream;
+    int evi = 0;
+    auto fork = [&]() {   // what the side queue launches next may use everything the caller's stream has been given so far
+        if (!sq) return;
+        hipEventRecord(sq->ev[evi], stream);
+        hipStreamWaitEvent(wst, sq->ev[evi], 0);
+        evi = (evi + 1) % 8;
+    };
+    JobList jobs;     // every weight gradient's slab sum, one launch at the end of the side queue
+    SlabSums head;    // classifier
     // classifier: logits = pooled_d W^T + b
     const float* wc = params + c.n->feature_params;
     float* gwc = grads + c.n->feature_params;
     float* gbc = gwc + (size_t)num_labels * MB_LAST;
-    wgrad_gemm(stream, dlogits, lin(num_labels), num_labels, c.ws + c.p.pooled_d, lin(MB_LAST), MB_LAST, B, scratch, gwc);
-    colsum(stream, dlogits, lin(num_labels), B, num_labels, scratch, gbc, nullptr);
     float* dpooled = c.ws + c.p.dpooled;
     gemm(stream, true, dlogits, lin(num_labels), 1, lin(0), wc, lin(MB_LAST), 1, B, MB_LAST, num_labels, 1, nullptr, 0, dpooled,
          MB_LAST, 0);
     {
-        const Geo& gl = c.p.g[nl - 1];
-        const long total = gl.my * MB_LAST;
-        hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(flat_grid(total)), dim3(256), 0, stream, (const float*)dpooled, gl.hy * gl.wy,
-                           MB_LAST, drop_mask, drop_scale, total, c.ws + c.p.dact[nl - 1]);
+        // gradient of the pooled features -> g, bc of the last layer
+        const int L = nl - 1;
+        const Geo& gl = c.p.g[L];
+        int rpc;
+        const int chunks = row_chunks(gl.mz, 8, &rpc);
+        hipLaunchKernelGGL(avgpool_bwd_reduce_kernel, dim3((MB_LAST + 63) / 64, chunks), dim3(256), 0, stream,
+                           (const float*)dpooled, drop_mask, drop_scale, gl.hy * gl.wy, MB_LAST, gl.mz, rpc, epi_bwd(c, L), arr,
+                           fin_bwd(c, L, grads));
     }
-    std::vector<char> has_grad(nl, 0);  // dact[k] already holds a residual contribution
-    has_grad[nl - 1] = 1;
-    // Two HIP queues (cf. howl_res8_bwd): the BatchNorm-backward -> data-gradient chain stays on the caller's stream; a
-    // layer's weight gradient (split-K GEMM / depthwise reduction + slab sums, im2col for the dense layers) only hangs
-    // off dz_k and goes to the side queue, where its launches overlap the chain's -- at ~740 short launches per step the
-    // backward pass is bound by launch latency, not by the device.  dz is double-buffered (layer k-2 reuses layer k's
-    // buffer and waits for wgrad_k); events 0/1: dz ready, 2/3: wgrad done with that dz buffer, 4: join.
-    HowlSideQueue* sq = howl_side_queue(stream, 1, "HOWL_MOBILENET_BWD_QUEUES");
-    hipStream_t wst = sq ? sq->stream : stream;
-    int par = 0, forked = 0;
-    for (int k = nl - 1; k >= 0; --k) {
+    fork();
+    wgrad_gemm(wst, dlogits, lin(num_labels), num_labels, c.ws + c.p.pooled_d, lin(MB_LAST), MB_LAST, B, c.ws + c.p.head_scratch,
+               gwc, 64, 512, &head);
+    colsum(wst, dlogits, lin(num_labels), B, num_labels, c.ws + c.p.bias_scratch, gbc, nullptr, 64, 256, &head);
+    head.flush(wst);
+    for (int k = nl - 1; k >= 2; --k) {
         const HowlMbLayer& l = c.n->layers[k];
         const Geo& g = c.p.g[k];
-        const float* z = c.ws + c.p.z[k];
-        const float* stats = c.ws + c.p.stats[k];
-        const float* dy = c.ws + c.p.dact[k];
-        const long total = g.mz * l.cout;
-        if (l.pool) {
-            float* dyp = c.ws + c.p.dyp;
-            hipLaunchKernelGGL(maxpool12_bwd_kernel, dim3(flat_grid(total)), dim3(256), 0, stream,
-                               (const float*)(c.ws + c.p.yp[k]), dy, g.wo, g.wy, l.cout, total, dyp);
-            dy = dyp;
-        }
-        if (l.res_src >= 0) {
-            // y_k = bn(z_k) + y_src: the same gradient also reaches the block input
-            float* dsrc = c.ws + c.p.dact[l.res_src];
-            hipMemcpyAsync(dsrc, dy, (size_t)total * sizeof(float), hipMemcpyDeviceToDevice, stream);
-            has_grad[l.res_src] = 1;
-        }
-        const int chunks = chunks_for(g.mz, l.cout);
-        const long rpc = (g.mz + chunks - 1) / chunks;
-        {
-            HowlProfScope prof("mb_sweep", stream, 8.0 * (double)total);                 // z and dy in
-            hipLaunchKernelGGL(col_reduce_kernel<1>, dim3((l.cout + 63) / 64, chunks), dim3(256), 0, stream, z, dy, stats,
-                               params + l.gamma_off, params + l.beta_off, l.act, g.mz, l.cout, col_pack(l.cout), rpc, part);
-        }
-        hipLaunchKernelGGL(bn_bwd_finalize_mb_kernel, dim3((l.cout + 63) / 64), dim3(FIN_THREADS), 0, stream, (const double*)part,
-                           chunks, l.cout, (double)g.mz, grads + l.gamma_off, grads + l.beta_off, m12);
-        float* dz = c.ws + (par ? c.p.dz2 : c.p.dz);
-        if (sq && forked >= 2) hipStreamWaitEvent(stream, sq->ev[2 + par], 0);
-        {
-            HowlProfScope prof("mb_sweep", stream, 12.0 * (double)total);                // z and dy in, dz out
-            hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(flat_grid(total)), dim3(256), 0, stream, z, dy, stats,
-                               params + l.gamma_off, params + l.beta_off, (const float*)m12, l.act, l.cout, total, dz);
-        }
-        if (sq) {
-            hipEventRecord(sq->ev[par], stream);
-            hipStreamWaitEvent(wst, sq->ev[par], 0);
-        }
-        // convolution backward
-        const float* in = k > 0 ? c.ws + c.p.y[k - 1] : x;
-        const float* w = params + l.w_off;
-        float* gw = grads + l.w_off;
-        float* dx = nullptr;
-        float* dtmp = nullptr;
-        if (k > 0) {
-            // the data gradient is written straight into dact[k-1] unless a residual gradient already sits there
-            dx = has_grad[k - 1] ? c.ws + c.p.dyp : c.ws + c.p.dact[k - 1];
-            dtmp = has_grad[k - 1] ? dx : nullptr;
-        }
-        const long in_total = (long)B * g.hin * g.win * l.cin;
+        const int j = k - 1;
+        const HowlMbLayer& lj = c.n->layers[j];
+        const float* gk = c.ws + c.p.gr[k];
+        const float* zk = c.ws + c.p.z[k];
+        const float* bck = c.ws + c.p.bc[k];
+        const bool in_mat = materialized(lj);
+        const float* in = in_mat ? c.ws + c.p.y[j] : c.ws + c.p.z[j];
+        const float* ss_in = in_mat ? nullptr : c.ws + c.p.ss[j];
+        float* slab = c.ws + c.p.slab[k];
         if (l.kind == MB_PW) {
-            wgrad_gemm(wst, dz, lin(l.cout), l.cout, in, lin(l.cin), l.cin, (int)g.mz, scratch, gw, MB_WGRAD_SPLITS);
-            if (dx != nullptr)
-                gemm(stream, true, dz, lin(l.cout), 1, lin(0), w, lin(l.cin), 1, (int)g.mz, l.cin, l.cout, 1, nullptr, 0, dx, l.cin,
-                     0);
-        } else if (l.kind == MB_DW) {
-            // chunks of image rows (b, oh): as many as the pixel-chunk rule would give, at least one row each
-            const int nrows = B * g.ho;
-            int wch = chunks_for(g.mz, 64);
-            if (wch > nrows) wch = nrows;
-            const int wrpc = (nrows + wch - 1) / wch;
-            wch = (nrows + wrpc - 1) / wrpc;
-            if (l.stride == 1)
-                hipLaunchKernelGGL(dw3x3_wgrad_kernel<1>, dim3((l.cout + 63) / 64, wch), dim3(256), 0, wst, (const float*)dz, in,
-                                   g.hin, g.win, l.cin, g.ho, g.wo, nrows, wrpc, scratch);
-            else
-                hipLaunchKernelGGL(dw3x3_wgrad_kernel<2>, dim3((l.cout + 63) / 64, wch), dim3(256), 0, wst, (const float*)dz, in,
-                                   g.hin, g.win, l.cin, g.ho, g.wo, nrows, wrpc, scratch);
-            const long nw = (long)l.cout * 9;
-            hipLaunchKernelGGL(sum_slabs_kernel, dim3((unsigned)((nw + 63) / 64)), dim3(256), 0, wst, (const float*)scratch,
-                               wch, nw, gw);
-            if (dx != nullptr) {
-                const dim3 grid((unsigned)(B * g.hin), (((g.win + DW_SEG - 1) / DW_SEG) * l.cin + 255) / 256);
-                if (l.stride == 1)
-                    hipLaunchKernelGGL(dw3x3_dgrad_kernel<1>, grid, dim3(256), 0, stream, (const float*)dz, w, g.hin, g.win, l.cin,
-                                       g.ho, g.wo, dx);
+            {   // weight gradient (side queue)
+                const int rps = pw_wgrad_rows_per_split(g.mz, l.cout, l.cin);
+                const int splits = (int)((g.mz + rps - 1) / rps);
+                const dim3 grid((l.cin + GT - 1) / GT, (l.cout + GT - 1) / GT, splits);
+                HowlProfScope prof("mb_conv", wst, 4.0 * (double)g.mz * (2.0 * l.cout + l.cin));
+                if (ss_in != nullptr)
+                    hipLaunchKernelGGL(pw_wgrad_kernel<true>, grid, dim3(256), 0, wst, gk, zk, bck, in, ss_in, (int)g.mz, l.cout,
+                                       l.cin, rps, slab);
                 else
-                    hipLaunchKernelGGL(dw3x3_dgrad_kernel<2>, grid, dim3(256), 0, stream, (const float*)dz, w, g.hin, g.win, l.cin,
-                                       g.ho, g.wo, dx);
+                    hipLaunchKernelGGL(pw_wgrad_kernel<false>, grid, dim3(256), 0, wst, gk, zk, bck, in, ss_in, (int)g.mz, l.cout,
+                                       l.cin, rps, slab);
+                jobs.add(slab, splits, (long)l.cout * l.cin, grads + l.w_off);
             }
-        } else {
-            float* col = c.ws + c.p.col;
-            const int K = 9 * l.cin;
-            const long ctot = g.mz * K;
-            long isb, ish, isw, isc;
-            if (k == 0) {
-                isb = sb, ish = sm, isw = st, isc = 0;
-            } else {
-                isb = (long)g.hin * g.win * l.cin, ish = (long)g.win * l.cin, isw = l.cin, isc = 1;
+            {   // data gradient + BatchNorm-backward reduction of layer j
+                int tpb, rb;
+                pw_rows(g.mz, (l.cin + GT - 1) / GT, &tpb, &rb);
+                const dim3 grid((l.cin + GT - 1) / GT, rb);
+                HowlProfScope prof("mb_conv", stream, 4.0 * (double)g.mz * (2.0 * l.cout + 3.0 * l.cin));
+                hipLaunchKernelGGL(pw_dgrad_kernel, grid, dim3(256), 0, stream, gk, zk, bck, params + l.w_off, (int)g.mz, l.cout,
+                                   l.cin, tpb, epi_bwd(c, j), arr, fin_bwd(c, j, grads));
             }
-            hipLaunchKernelGGL(im2col3x3_kernel, dim3(flat_grid(ctot)), dim3(256), 0, wst, in, isb, ish, isw, isc, g.hin, g.win,
-                               l.cin, g.ho, g.wo, l.stride, l.pad_h, l.pad_w, ctot, col);
-            wgrad_gemm(wst, dz, lin(l.cout), l.cout, col, lin(K), K, (int)g.mz, scratch, gw, MB_WGRAD_SPLITS);
-            if (l.bias) {   // sum over pixels of dz (rounding noise in exact arithmetic: a BatchNorm follows the bias);
-                            // `part` belongs to the chain, so this reduction stays on the caller's stream
-                hipLaunchKernelGGL(col_reduce_kernel<0>, dim3((l.cout + 63) / 64, chunks), dim3(256), 0, stream, (const float*)dz,
-                                   (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
-                                   0, g.mz, l.cout, col_pack(l.cout), rpc, part);
-                hipLaunchKernelGGL(colsum_finalize_kernel, dim3((l.cout + 63) / 64), dim3(FIN_THREADS), 0, stream, (const double*)part,
-                                   chunks, l.cout, grads + l.b_off);
+        } else {   // depthwise (layers 0 and 1 are the only dense ones)
+            {
+                int rpc;
+                const int nrows = B * g.ho;
+                const int chunks = row_chunks(nrows, 4, &rpc);
+                const dim3 grid((l.cout + 63) / 64, chunks);
+                HowlProfScope prof("mb_conv", wst, 4.0 * (2.0 * (double)g.mz + (double)B * g.hin * g.win) * l.cout);
+                if (l.stride == 1)
+                    hipLaunchKernelGGL(dw_wgrad_kernel<1>, grid, dim3(256), 0, wst, gk, zk, bck, in, ss_in, g.hin, g.win, l.cin,
+                                       g.ho, g.wo, nrows, rpc, slab);
+                else
+                    hipLaunchKernelGGL(dw_wgrad_kernel<2>, grid, dim3(256), 0, wst, gk, zk, bck, in, ss_in, g.hin, g.win, l.cin,
+                                       g.ho, g.wo, nrows, rpc, slab);
+                jobs.add(slab, chunks, (long)l.cout * 9, grads + l.w_off);
             }
-            if (dx != nullptr) {
-                float* dcol = c.ws + c.p.dcol;
-                gemm(stream, true, dz, lin(l.cout), 1, lin(0), w, lin(K), 1, (int)g.mz, K, l.cout, 1, nullptr, 0, dcol, K, 0);
-                hipLaunchKernelGGL(col2im3x3_kernel, dim3(flat_grid(in_total)), dim3(256), 0, stream, (const float*)dcol, g.hin,
-                                   g.win, l.cin, g.ho, g.wo, l.stride, l.pad_h, l.pad_w, in_total, dx);
+            {
+                int rpc;
+                const int nrows = B * g.hin;
+                const int chunks = row_chunks(nrows, 4, &rpc);
+                const dim3 grid((l.cin + 63) / 64, chunks);
+                HowlProfScope prof("mb_conv", stream, 4.0 * (2.0 * (double)g.mz + 2.0 * (double)B * g.hin * g.win) * l.cout);
+                if (l.stride == 1)
+                    hipLaunchKernelGGL(dw_dgrad_kernel<1>, grid, dim3(256), 0, stream, gk, zk, bck, params + l.w_off, g.hin, g.win,
+                                       l.cin, g.ho, g.wo, nrows, rpc, epi_bwd(c, j), arr, fin_bwd(c, j, grads));
+                else
+                    hipLaunchKernelGGL(dw_dgrad_kernel<2>, grid, dim3(256), 0, stream, gk, zk, bck, params + l.w_off, g.hin, g.win,
+                                       l.cin, g.ho, g.wo, nrows, rpc, epi_bwd(c, j), arr, fin_bwd(c, j, grads));
             }
         }
-        if (dtmp != nullptr)
-            hipLaunchKernelGGL(add_inplace_kernel, dim3(flat_grid(in_total)), dim3(256), 0, stream, c.ws + c.p.dact[k - 1],
-                               (const float*)dtmp, in_total);
-        if (sq) hipEventRecord(sq->ev[2 + par], wst);   // this layer's weight gradient no longer needs dz
-        par ^= 1;
-        ++forked;
+        fork();   // g_j, bc_j are complete: the side queue may start layer j's weight gradient
     }
+    // ---- stem: the two dense 3x3 convolutions go through im2col + the shared GEMM on a materialised dz -----------------
+    SlabSums stem;
+    for (int k = 1; k >= 0; --k) {
+        const HowlMbLayer& l = c.n->layers[k];
+        const Geo& g = c.p.g[k];
+        const long total = g.mz * l.cout;
+        float* dz = c.ws + c.p.dz;
+        hipLaunchKernelGGL(dz_apply_kernel, dim3(flat_grid(total)), dim3(256), 0, stream, (const float*)(c.ws + c.p.gr[k]),
+                           (const float*)(c.ws + c.p.z[k]), (const float*)(c.ws + c.p.bc[k]), l.cout, total, dz);
+        const float* in = k > 0 ? c.ws + c.p.y[k - 1] : x;
+        float* col = c.ws + c.p.col;
+        const int K = 9 * l.cin;
+        const long ctot = g.mz * K;
+        long isb, ish, isw, isc;
+        if (k == 0) {
+            isb = sb, ish = sm, isw = st, isc = 0;
+        } else {
+            isb = (long)g.hin * g.win * l.cin, ish = (long)g.win * l.cin, isw = l.cin, isc = 1;
+        }
+        hipLaunchKernelGGL(im2col3x3_kernel, dim3(flat_grid(ctot)), dim3(256), 0, stream, in, isb, ish, isw, isc, g.hin, g.win,
+                           l.cin, g.ho, g.wo, l.stride, l.pad_h, l.pad_w, ctot, col);
+        wgrad_gemm(stream, dz, lin(l.cout), l.cout, col, lin(K), K, (int)g.mz, c.ws + c.p.slab[k], grads + l.w_off, MB_WGRAD_SPLITS,
+                   512, &stem);
+        if (l.bias) {   // sum over pixels of dz (rounding noise in exact arithmetic: a BatchNorm follows the bias)
+            int rpc;
+            const int cp = col_pack(l.cout);
+            const int chunks = row_chunks(g.mz, 64 * (64 / cp), &rpc);
+            hipLaunchKernelGGL(col_reduce_kernel<0>, dim3(1, chunks), dim3(256), 0, stream, (const float*)dz, (const float*)nullptr,
+                               (const float*)nullptr, 0, g.mz, l.cout, cp, (long)rpc, (float*)nullptr, arr, FinFwd{},
+                               FinBwd{}, grads + l.b_off);
+        }
+        if (k > 0) {
+            // dz -> gradient of the pooled downsample output -> through the max pool -> BatchNorm backward of layer 0
+            const HowlMbLayer& l0 = c.n->layers[0];
+            const Geo& g0 = c.p.g[0];
+            const long in_total = (long)B * g.hin * g.win * l.cin;
+            float* dcol = c.ws + c.p.dcol;
+            gemm(stream, true, dz, lin(l.cout), 1, lin(0), params + l.w_off, lin(K), 1, (int)g.mz, K, l.cout, 1, nullptr, 0, dcol, K,
+                 0);
+            float* dy0p = c.ws + c.p.dyp;   // (B, 40, 52, 3)
+            hipLaunchKernelGGL(col2im3x3_kernel, dim3(flat_grid(in_total)), dim3(256), 0, stream, (const float*)dcol, g.hin, g.win,
+                               l.cin, g.ho, g.wo, l.stride, l.pad_h, l.pad_w, in_total, dy0p);
+            const long t0 = g0.mz * l0.cout;
+            float* dy0 = c.ws + c.p.dy0;    // (B, 40, 105, 3)
+            hipLaunchKernelGGL(maxpool12_bwd_kernel, dim3(flat_grid(t0)), dim3(256), 0, stream, (const float*)(c.ws + c.p.yp[0]),
+                               (const float*)dy0p, g0.wo, g0.wy, l0.cout, t0, dy0);
+            int rpc;
+            const int cp = col_pack(l0.cout);
+            const int chunks = row_chunks(g0.mz, 64 * (64 / cp), &rpc);
+            hipLaunchKernelGGL(col_reduce_kernel<1>, dim3(1, chunks), dim3(256), 0, stream, (const float*)(c.ws + c.p.z[0]),
+                               (const float*)dy0, (const float*)(c.ws + c.p.ss[0]), l0.act, g0.mz, l0.cout, cp, (long)rpc,
+                               c.ws + c.p.gr[0], arr, FinFwd{}, fin_bwd(c, 0, grads), (float*)nullptr);
+        }
+    }
+    stem.flush(stream);
+    jobs.flush(wst);
     if (sq) {   // join: everything after this call on the caller's stream sees all weight gradients
-        hipEventRecord(sq->ev[4], wst);
-        hipStreamWaitEvent(stream, sq->ev[4], 0);
+        hipEventRecord(sq->ev[8], wst);
+        hipStreamWaitEvent(stream, sq->ev[8], 0);
     }
     HOWL_CHECK_LAUNCH("howl_mobilenet_bwd");
     return HOWL_OK;

@@ -89,6 +89,13 @@ static inline void __builtin_amdgcn_sched_barrier(int) {}
 static inline void __builtin_amdgcn_sched_group_barrier(int, int, int) {}
 static inline void __builtin_amdgcn_s_setprio(int) {}
 static inline void __threadfence() {}
+// device-scope relaxed atomics / wait counters: workgroups run one after another here, plain accesses are equivalent
+#define __HIP_MEMORY_SCOPE_AGENT 4
+#define __hip_atomic_store(p, v, order, scope) ((void)(*(p) = (v)))
+#define __hip_atomic_load(p, order, scope) (*(p))
+template <class T> static inline T hipemu_fetch_add(T* p, T v) { T o = *p; *p = o + v; return o; }
+#define __hip_atomic_fetch_add(p, v, order, scope) hipemu_fetch_add((p), (v))
+static inline void __builtin_amdgcn_s_waitcnt(int) {}
 
 template <class T> static inline uint32_t hipemu_bits(T v) { uint32_t u; static_assert(sizeof(T) == 4, ""); memcpy(&u, &v, 4); return u; }
 template <class T> static inline T hipemu_from(uint32_t u) { T v; memcpy(&v, &u, 4); return v; }
