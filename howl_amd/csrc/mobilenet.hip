@@ -317,11 +317,13 @@ __device__ __forceinline__ bool arrive(unsigned* counter, unsigned expected) {
     return ticket == expected - 1;
 }
 
-// The thread with `own` holds this block's (v0, v1) of column c_own.  Returns true in the one block of channel block
-// blockIdx.x (64 channels from c0) that must finalise; a.part2 then holds all groups' rows.
-__device__ __forceinline__ bool publish_and_arrive(const Arrive& a, int C, int c0, bool own, int c_own, float v0, float v1) {
+// Block `by` of the R1 blocks that share channel block `cb` (64 channels from 64 cb); the thread with `own` holds this
+// block's (v0, v1) of column c_own.  Returns true in the one block of the channel block that must finalise; a.part2 then
+// holds all groups' rows.
+__device__ __forceinline__ bool publish_and_arrive(const Arrive& a, int C, int cb, int by, int R1, bool own, int c_own, float v0,
+                                                   float v1) {
     __shared__ float red[2][4][64];
-    const int by = blockIdx.y, R1 = gridDim.y;
+    const int c0 = cb * 64;
     if (own) {
         st_agent(&a.part1[((size_t)by * 2 + 0) * C + c_own], v0);
         st_agent(&a.part1[((size_t)by * 2 + 1) * C + c_own], v1);
@@ -329,7 +331,7 @@ __device__ __forceinline__ bool publish_and_arrive(const Arrive& a, int C, int c
     const int group = by / MB_G, g0 = group * MB_G;
     const int gsize = R1 - g0 < MB_G ? R1 - g0 : MB_G;
     const int R2 = (R1 + MB_G - 1) / MB_G;
-    if (!arrive(a.cnt1 + blockIdx.x * MB_R2 + group, gsize)) return false;
+    if (!arrive(a.cnt1 + cb * MB_R2 + group, gsize)) return false;
     const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
     const int c = c0 + lane < C ? c0 + lane : C - 1;
     float r0[MB_G / 4], r1[MB_G / 4];
@@ -353,7 +355,7 @@ __device__ __forceinline__ bool publish_and_arrive(const Arrive& a, int C, int c
         st_agent(&a.part2[((size_t)group * 2 + 0) * C + c], ((red[0][0][lane] + red[0][1][lane]) + red[0][2][lane]) + red[0][3][lane]);
         st_agent(&a.part2[((size_t)group * 2 + 1) * C + c], ((red[1][0][lane] + red[1][1][lane]) + red[1][2][lane]) + red[1][3][lane]);
     }
-    return arrive(a.cnt2 + blockIdx.x, R2);
+    return arrive(a.cnt2 + cb, R2);
 }
 
 // part[k][0..1][C] (k < R <= MB_R2) -> column totals of column c; called by all 256 threads of the finalising block, lane =
@@ -417,104 +419,174 @@ __device__ __forceinline__ void finalize_bwd(const float* part, int R, int C, in
     f.bc[2 * C + c] = (float)(-scale * m1 - c1 * mean);
 }
 
-// one 64 x 64 x 16 step of the fp32 MFMA tile product shared by the pointwise kernels (As[k][row], Bs[k][col])
-__device__ __forceinline__ void mma_tile(const float* As, const float* Bs, f32x4 (&acc)[2][2], int wr, int wc, int lane) {
+// ---------------------------------------------------------------------------------------------------------
+// Pointwise (1x1) convolutions.  Shared tile engine: 64 x 64 outputs per step, 64 deep (PK), 2x2 waves x 2x2 fp32 MFMA
+// 16x16x4; the operand pieces of the NEXT step are requested (16-byte loads, one step in flight) before the MFMAs of the
+// current one.  The late layers of this network are tiny matrices with a deep reduction (2048 x 960 x 160): what they cost
+// is steps x memory latency, so a step is as deep as registers allow and a thread's piece keeps ONE k offset for the whole
+// launch -- the per-channel constants of the on-load transforms are a few registers per step.
+// Operand tiles whose unit-stride index is the reduction index are kept [row][k] (stride LDK): 16-byte stores, and a lane
+// group q = lane / 16 reads k = 16t + 4q .. + 3 with ONE 16-byte LDS load and feeds them to four consecutive MFMAs (the order
+// in which the 64 k of a step enter the sum is a fixed permutation).  Tiles whose unit stride is the output column stay
+// [k][col] (stride LDC).
+// ---------------------------------------------------------------------------------------------------------
+constexpr int PK = 64;
+constexpr int LDK = PK + 4;   // floats: 16-byte aligned rows, conflict-free fragment loads
+constexpr int LDC = 80;
+constexpr int PW_LDS_FLOATS = 2 * PK * LDC;   // the largest role (weight gradient: two [k][col] tiles)
+
+__device__ __forceinline__ float4 f4_zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+// T(v) = relu6(v * scale + shift), four channels
+__device__ __forceinline__ float4 bn_relu6_4(float4 v, float4 sc, float4 sh) {
+    v.x = relu6f(fmaf(v.x, sc.x, sh.x));
+    v.y = relu6f(fmaf(v.y, sc.y, sh.y));
+    v.z = relu6f(fmaf(v.z, sc.z, sh.z));
+    v.w = relu6f(fmaf(v.w, sc.w, sh.w));
+    return v;
+}
+// dz = scale * g + c1 * z + c0, four channels
+__device__ __forceinline__ float4 dz4(float4 g, float4 z, float4 sc, float4 c1, float4 c0) {
+    float4 v;
+    v.x = fmaf(sc.x, g.x, fmaf(c1.x, z.x, c0.x));
+    v.y = fmaf(sc.y, g.y, fmaf(c1.y, z.y, c0.y));
+    v.z = fmaf(sc.z, g.z, fmaf(c1.z, z.z, c0.z));
+    v.w = fmaf(sc.w, g.w, fmaf(c1.w, z.w, c0.w));
+    return v;
+}
+__device__ __forceinline__ float f4_get(const float4& v, int e) { return e == 0 ? v.x : (e == 1 ? v.y : (e == 2 ? v.z : v.w)); }
+
+// `groups` x 16 k of the step: A and B both [row][k]
+__device__ __forceinline__ void mma_kk(const float* As, const float* Bs, f32x4 (&acc)[2][2], int groups, int wr, int wc,
+                                       int lane) {
+    const int q = lane >> 4, l15 = lane & 15;
+    for (int t = 0; t < groups; ++t) {
+        float4 a[2], b[2];
 #pragma unroll
-    for (int ks = 0; ks < GK / 4; ++ks) {
-        const int kr = 4 * ks + (lane >> 4);
-        float af[2], bf[2];
+        for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const float4*>(&As[(32 * wr + 16 * i + l15) * LDK + 16 * t + 4 * q]);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) af[i] = As[kr * GLD + 32 * wr + 16 * i + (lane & 15)];
+        for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const float4*>(&Bs[(32 * wc + 16 * j + l15) * LDK + 16 * t + 4 * q]);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) bf[j] = Bs[kr * GLD + 32 * wc + 16 * j + (lane & 15)];
+        for (int e = 0; e < 4; ++e)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4_get(a[i], e), f4_get(b[j], e), acc[i][j], 0, 0, 0);
+    }
+}
+// A [row][k], B [k][col]
+__device__ __forceinline__ void mma_kc(const float* As, const float* Bs, f32x4 (&acc)[2][2], int groups, int wr, int wc,
+                                       int lane) {
+    const int q = lane >> 4, l15 = lane & 15;
+    for (int t = 0; t < groups; ++t) {
+        float4 a[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const float4*>(&As[(32 * wr + 16 * i + l15) * LDK + 16 * t + 4 * q]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float b[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) b[j] = Bs[(16 * t + 4 * q + e) * LDC + 32 * wc + 16 * j + l15];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4_get(a[i], e), b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+}
+// A [k][row], B [k][col]
+__device__ __forceinline__ void mma_cc(const float* As, const float* Bs, f32x4 (&acc)[2][2], int groups, int wr, int wc,
+                                       int lane) {
+    const int q = lane >> 4, l15 = lane & 15;
+    for (int t = 0; t < groups; ++t) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) a[i] = As[(16 * t + 4 * q + e) * LDC + 32 * wr + 16 * i + l15];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) b[j] = Bs[(16 * t + 4 * q + e) * LDC + 32 * wc + 16 * j + l15];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
     }
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Pointwise (1x1) convolution, forward:  z[m][n] = sum_k T(a[m][k]) * w[n][k]
+// forward:  z[m][n] = sum_k T(a[m][k]) * w[n][k]
 //   XF: a = z_{k-1} and T(v) = relu6(v * scale[k] + shift[k]) (the producer's BatchNorm + ReLU6, applied while the tile
 //   is staged); else a = y_{k-1}, T = identity.  A block owns 64 output channels and `tiles_per_block` consecutive 64-row
 //   tiles; beside z it keeps the per-channel sum and sum of squares of everything it wrote, publishes them as ONE partial
 //   row, and the last block of the channel block turns the partials into this layer's ss (and running statistics).
-// Same tile engine as gemm_vec_kernel (64x64x16, 2x2 waves x 2x2 MFMA 16x16x4, two K tiles in flight).
 // ---------------------------------------------------------------------------------------------------------
 template <bool XF>
 __global__ __launch_bounds__(256) void pw_fwd_kernel(const float* __restrict__ a, const float* __restrict__ ss_in,
                                                      const float* __restrict__ w, int M, int N, int K, int tiles_per_block,
                                                      float* __restrict__ z, Arrive arr, FinFwd fin) {
-    __shared__ float As[GK * GLD];
-    __shared__ float Bs[GK * GLD];
-    __shared__ float xs[XF ? 2 * MB_MAXK : 4];
+    __shared__ __attribute__((aligned(16))) float lds[2 * 64 * LDK];
     __shared__ float sred[2][2][64];
+    float* As = lds;
+    float* Bs = lds + 64 * LDK;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     const int n0 = blockIdx.x * GT;
-    const int p_r = tid >> 2, p_k = (tid & 3) * 4;   // this thread's piece of both operand tiles: (row, 4 consecutive k)
-    if (XF) {
-        for (int i = tid; i < K; i += 256) {
-            xs[i] = ss_in[i];
-            xs[MB_MAXK + i] = ss_in[K + i];
-        }
-        __syncthreads();
+    const int p_r = tid >> 4, p_k = (tid & 15) * 4;   // pieces: rows p_r + 16 i (i < 4), 4 consecutive k from p_k
+    const float* bp[4];
+    bool b_ok[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        bp[i] = w + (long)min(n0 + p_r + 16 * i, N - 1) * K;
+        b_ok[i] = n0 + p_r + 16 * i < N;
     }
-    const float* bp = w + (long)min(n0 + p_r, N - 1) * K;
-    const bool b_row_ok = n0 + p_r < N;
     const int row_tiles = (M + GT - 1) / GT;
     const int t0 = blockIdx.y * tiles_per_block;
     const int t1 = min(row_tiles, t0 + tiles_per_block);
     float cs[2] = {0.0f, 0.0f}, cq[2] = {0.0f, 0.0f};
     for (int t = t0; t < t1; ++t) {
         const int m0 = t * GT;
-        const float* ap = a + (long)min(m0 + p_r, M - 1) * K;
-        const bool a_row_ok = m0 + p_r < M;
-        auto fetch_a = [&](int k0) -> float4 { return *reinterpret_cast<const float4*>(ap + min(k0 + p_k, K - 4)); };
-        auto fetch_b = [&](int k0) -> float4 { return *reinterpret_cast<const float4*>(bp + min(k0 + p_k, K - 4)); };
-        auto stage = [&](float4 va, float4 vb, int k0) {
-            const bool kok = k0 + p_k < K;
-            if (XF) {
-                const int k = min(k0 + p_k, K - 4);
-                va.x = relu6f(fmaf(va.x, xs[k + 0], xs[MB_MAXK + k + 0]));
-                va.y = relu6f(fmaf(va.y, xs[k + 1], xs[MB_MAXK + k + 1]));
-                va.z = relu6f(fmaf(va.z, xs[k + 2], xs[MB_MAXK + k + 2]));
-                va.w = relu6f(fmaf(va.w, xs[k + 3], xs[MB_MAXK + k + 3]));
+        const float* ap[4];
+        bool a_ok[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ap[i] = a + (long)min(m0 + p_r + 16 * i, M - 1) * K;
+            a_ok[i] = m0 + p_r + 16 * i < M;
+        }
+        float4 va[4], vb[4], xsc = f4_zero(), xsh = f4_zero();
+        auto fetch = [&](int k0) {
+            const int k = min(k0 + p_k, K - 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                va[i] = ldg4(ap[i] + k);
+                vb[i] = ldg4(bp[i] + k);
             }
-            if (!(a_row_ok && kok)) va = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (!(b_row_ok && kok)) vb = make_float4(0.f, 0.f, 0.f, 0.f);
-            As[(p_k + 0) * GLD + p_r] = va.x;
-            As[(p_k + 1) * GLD + p_r] = va.y;
-            As[(p_k + 2) * GLD + p_r] = va.z;
-            As[(p_k + 3) * GLD + p_r] = va.w;
-            Bs[(p_k + 0) * GLD + p_r] = vb.x;
-            Bs[(p_k + 1) * GLD + p_r] = vb.y;
-            Bs[(p_k + 2) * GLD + p_r] = vb.z;
-            Bs[(p_k + 3) * GLD + p_r] = vb.w;
+            if (XF) {
+                xsc = ldg4(ss_in + k);
+                xsh = ldg4(ss_in + K + k);
+            }
         };
         f32x4 acc[2][2];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) acc[i][j] = {0.0f, 0.0f, 0.0f, 0.0f};
-        float4 va0 = fetch_a(0), vb0 = fetch_b(0);
-        float4 va1 = fetch_a(GK), vb1 = fetch_b(GK);
-        for (int k0 = 0; k0 < K; k0 += 2 * GK) {
-            stage(va0, vb0, k0);
+        fetch(0);
+        for (int k0 = 0; k0 < K; k0 += PK) {
+            const bool kok = k0 + p_k < K;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float4 v = XF ? bn_relu6_4(va[i], xsc, xsh) : va[i];
+                if (!(a_ok[i] && kok)) v = f4_zero();
+                *reinterpret_cast<float4*>(&As[(p_r + 16 * i) * LDK + p_k]) = v;
+                *reinterpret_cast<float4*>(&Bs[(p_r + 16 * i) * LDK + p_k]) = (b_ok[i] && kok) ? vb[i] : f4_zero();
+            }
             __syncthreads();
-            va0 = fetch_a(k0 + 2 * GK);
-            vb0 = fetch_b(k0 + 2 * GK);
+            fetch(k0 + PK);     // past the end: a clamped (re)load that is never staged
             __builtin_amdgcn_sched_barrier(0);
-            mma_tile(As, Bs, acc, wr, wc, lane);
-            __syncthreads();
-            if (k0 + GK >= K) break;
-            stage(va1, vb1, k0 + GK);
-            __syncthreads();
-            va1 = fetch_a(k0 + 3 * GK);
-            vb1 = fetch_b(k0 + 3 * GK);
-            __builtin_amdgcn_sched_barrier(0);
-            mma_tile(As, Bs, acc, wr, wc, lane);
+            mma_kk(As, Bs, acc, min(PK, K - k0 + 15) / 16, wr, wc, lane);
             __syncthreads();
         }
 #pragma unroll
@@ -547,7 +619,7 @@ __global__ __launch_bounds__(256) void pw_fwd_kernel(const float* __restrict__ a
     __syncthreads();
     const bool own = tid < 64 && n0 + tid < N;
     const float v0 = own ? sred[0][0][tid] + sred[0][1][tid] : 0.0f, v1 = own ? sred[1][0][tid] + sred[1][1][tid] : 0.0f;
-    if (publish_and_arrive(arr, N, n0, own, n0 + tid, v0, v1))
+    if (publish_and_arrive(arr, N, blockIdx.x, blockIdx.y, gridDim.y, own, n0 + tid, v0, v1))
         finalize_fwd(arr.part2, (gridDim.y + MB_G - 1) / MB_G, N, n0 + lane, fin);
 }
 
@@ -562,92 +634,92 @@ struct EpiBwd {
     int act;
 };
 
-// ---------------------------------------------------------------------------------------------------------
-// Pointwise convolution, data gradient:  dy_j[m][c] = sum_n dz[m][n] * w[n][c],  dz = bc.scale*g + bc.c1*z + bc.c0 rebuilt
-// while the tile is staged (g_k, z_k: two 16-byte loads per piece); epilogue = EpiBwd for layer j = k-1 (C = its channels).
-// ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void pw_dgrad_kernel(const float* __restrict__ g, const float* __restrict__ zk,
-                                                       const float* __restrict__ bc, const float* __restrict__ w, int M, int N,
-                                                       int C, int tiles_per_block, EpiBwd e, Arrive arr, FinBwd fin) {
-    __shared__ float As[GK * GLD];
-    __shared__ float Bs[GK * GLD];
-    __shared__ float bcs[3 * MB_MAXC];
+// Backward of a pointwise layer k, ONE launch: the first d_cx * d_ry blocks compute the data gradient (and reduce the
+// BatchNorm backward of layer j = k-1), the rest the weight gradient -- both only need (g_k, z_k, bc_k), and together they
+// fill the chip where either alone would not.
+struct PwBwd {
+    const float* g;        // g_k, z_k: (M x N); bc_k: 3 N
+    const float* zk;
+    const float* bc;
+    const float* w;        // (N x C)
+    const float* in;       // (M x C): y_{k-1}, or z_{k-1} with ss_in
+    const float* ss_in;
+    int M, N, C;
+    int tiles_per_block, d_cx, d_ry;        // data gradient: column blocks x row blocks
+    int rows_per_split, w_cx, w_ny, w_nz;   // weight gradient: (C / 64) x (N / 64) x splits
+    EpiBwd e;
+    Arrive arr;
+    FinBwd fin;
+    float* slabs;
+};
+
+// data gradient:  dy_j[m][c] = sum_n dz[m][n] * w[n][c],  dz = bc.scale*g + bc.c1*z + bc.c0 rebuilt while the tile is staged
+// (g_k, z_k: two 16-byte loads per piece); epilogue = EpiBwd for layer j (C = its channels).
+__device__ __forceinline__ void pw_dgrad_body(float* lds, const PwBwd& p, int bx, int by) {
     __shared__ float sred[2][2][64];
+    float* As = lds;                 // [m][n]   (64 x LDK)
+    float* Bs = lds + 64 * LDK;      // [n][c]   (PK x LDC)
+    const int M = p.M, N = p.N, C = p.C;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
-    const int c0 = blockIdx.x * GT;
-    const int a_r = tid >> 2, a_k = (tid & 3) * 4;    // dz piece: (row m, 4 consecutive n)
-    const int b_k = tid >> 4, b_c = (tid & 15) * 4;   // weight piece: (n, 4 consecutive c)
-    for (int i = tid; i < N; i += 256) {
-        bcs[i] = bc[i];
-        bcs[MB_MAXC + i] = bc[N + i];
-        bcs[2 * MB_MAXC + i] = bc[2 * N + i];
-    }
-    __syncthreads();
-    const int bcol = min(c0 + b_c, C - 4);
-    const bool b_col_ok = c0 + b_c < C;
-    // layer j's constants of this thread's two output columns
-    float jsc[2], jsh[2], jme[2], jrs[2];
+    const int c0 = bx * GT;
+    const int p_r = tid >> 4, p_k = (tid & 15) * 4;
+    const int bcol = min(c0 + p_k, C - 4);          // weight piece: rows (= n) p_r + 16 i, 4 consecutive c from p_k
+    const bool b_col_ok = c0 + p_k < C;
+    float jsc[2], jsh[2], jme[2], jrs[2];           // layer j's constants of this thread's two output columns
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int c = min(c0 + 32 * wc + 16 * j + (lane & 15), C - 1);
-        jsc[j] = e.ssj[c];
-        jsh[j] = e.ssj[C + c];
-        jme[j] = e.ssj[2 * C + c];
-        jrs[j] = e.ssj[3 * C + c];
+        jsc[j] = p.e.ssj[c];
+        jsh[j] = p.e.ssj[C + c];
+        jme[j] = p.e.ssj[2 * C + c];
+        jrs[j] = p.e.ssj[3 * C + c];
     }
     const int row_tiles = (M + GT - 1) / GT;
-    const int t0 = blockIdx.y * tiles_per_block;
-    const int t1 = min(row_tiles, t0 + tiles_per_block);
+    const int t0 = by * p.tiles_per_block;
+    const int t1 = min(row_tiles, t0 + p.tiles_per_block);
     float s1[2] = {0.0f, 0.0f}, s2[2] = {0.0f, 0.0f};
     for (int t = t0; t < t1; ++t) {
         const int m0 = t * GT;
-        const long arow = (long)min(m0 + a_r, M - 1) * N;
-        const bool a_row_ok = m0 + a_r < M;
-        auto fetch_g = [&](int k0) -> float4 { return *reinterpret_cast<const float4*>(g + arow + min(k0 + a_k, N - 4)); };
-        auto fetch_z = [&](int k0) -> float4 { return *reinterpret_cast<const float4*>(zk + arow + min(k0 + a_k, N - 4)); };
-        auto fetch_b = [&](int k0) -> float4 {
-            return *reinterpret_cast<const float4*>(w + (long)min(k0 + b_k, N - 1) * C + bcol);
-        };
-        auto stage = [&](float4 vg, float4 vz, float4 vb, int k0) {
-            const int k = min(k0 + a_k, N - 4);
-            float4 va;
-            va.x = fmaf(bcs[k + 0], vg.x, fmaf(bcs[MB_MAXC + k + 0], vz.x, bcs[2 * MB_MAXC + k + 0]));
-            va.y = fmaf(bcs[k + 1], vg.y, fmaf(bcs[MB_MAXC + k + 1], vz.y, bcs[2 * MB_MAXC + k + 1]));
-            va.z = fmaf(bcs[k + 2], vg.z, fmaf(bcs[MB_MAXC + k + 2], vz.z, bcs[2 * MB_MAXC + k + 2]));
-            va.w = fmaf(bcs[k + 3], vg.w, fmaf(bcs[MB_MAXC + k + 3], vz.w, bcs[2 * MB_MAXC + k + 3]));
-            if (!(a_row_ok && k0 + a_k < N)) va = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (!(b_col_ok && k0 + b_k < N)) vb = make_float4(0.f, 0.f, 0.f, 0.f);
-            As[(a_k + 0) * GLD + a_r] = va.x;
-            As[(a_k + 1) * GLD + a_r] = va.y;
-            As[(a_k + 2) * GLD + a_r] = va.z;
-            As[(a_k + 3) * GLD + a_r] = va.w;
-            *reinterpret_cast<float4*>(&Bs[b_k * GLD + b_c]) = vb;
+        long arow[4];
+        bool a_ok[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            arow[i] = (long)min(m0 + p_r + 16 * i, M - 1) * N;
+            a_ok[i] = m0 + p_r + 16 * i < M;
+        }
+        float4 vg[4], vz[4], vb[4], ksc, kc1, kc0;
+        auto fetch = [&](int k0) {
+            const int k = min(k0 + p_k, N - 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                vg[i] = ldg4(p.g + arow[i] + k);
+                vz[i] = ldg4(p.zk + arow[i] + k);
+                vb[i] = ldg4(p.w + (long)min(k0 + p_r + 16 * i, N - 1) * C + bcol);
+            }
+            ksc = ldg4(p.bc + k);
+            kc1 = ldg4(p.bc + N + k);
+            kc0 = ldg4(p.bc + 2 * N + k);
         };
         f32x4 acc[2][2];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) acc[i][j] = {0.0f, 0.0f, 0.0f, 0.0f};
-        float4 g0 = fetch_g(0), z0 = fetch_z(0), b0 = fetch_b(0);
-        float4 g1 = fetch_g(GK), z1 = fetch_z(GK), b1 = fetch_b(GK);
-        for (int k0 = 0; k0 < N; k0 += 2 * GK) {
-            stage(g0, z0, b0, k0);
+        fetch(0);
+        for (int k0 = 0; k0 < N; k0 += PK) {
+            const bool kok = k0 + p_k < N;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float4 v = dz4(vg[i], vz[i], ksc, kc1, kc0);
+                if (!(a_ok[i] && kok)) v = f4_zero();
+                *reinterpret_cast<float4*>(&As[(p_r + 16 * i) * LDK + p_k]) = v;
+                *reinterpret_cast<float4*>(&Bs[(p_r + 16 * i) * LDC + p_k]) = (b_col_ok && k0 + p_r + 16 * i < N) ? vb[i] : f4_zero();
+            }
             __syncthreads();
-            g0 = fetch_g(k0 + 2 * GK);
-            z0 = fetch_z(k0 + 2 * GK);
-            b0 = fetch_b(k0 + 2 * GK);
+            fetch(k0 + PK);
             __builtin_amdgcn_sched_barrier(0);
-            mma_tile(As, Bs, acc, wr, wc, lane);
-            __syncthreads();
-            if (k0 + GK >= N) break;
-            stage(g1, z1, b1, k0 + GK);
-            __syncthreads();
-            g1 = fetch_g(k0 + 3 * GK);
-            z1 = fetch_z(k0 + 3 * GK);
-            b1 = fetch_b(k0 + 3 * GK);
-            __builtin_amdgcn_sched_barrier(0);
-            mma_tile(As, Bs, acc, wr, wc, lane);
+            mma_kc(As, Bs, acc, min(PK, N - k0 + 15) / 16, wr, wc, lane);
             __syncthreads();
         }
         // epilogue: all loads first (clamped, unconditional), then arithmetic, then the guarded stores
@@ -660,8 +732,8 @@ __global__ __launch_bounds__(256) void pw_dgrad_kernel(const float* __restrict__
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int m = min(m0 + 32 * wr + 16 * i + 4 * (lane >> 4) + r, M - 1);
-                    zj[i][j][r] = e.zj[(long)m * C + c];
-                    ad[i][j][r] = e.addend != nullptr ? e.addend[(long)m * C + c] : 0.0f;
+                    zj[i][j][r] = p.e.zj[(long)m * C + c];
+                    ad[i][j][r] = p.e.addend != nullptr ? p.e.addend[(long)m * C + c] : 0.0f;
                 }
             }
 #pragma unroll
@@ -675,9 +747,9 @@ __global__ __launch_bounds__(256) void pw_dgrad_kernel(const float* __restrict__
                     const bool ok = m < M && c < C;
                     const float dy = acc[i][j][r] + ad[i][j][r];
                     const float zv = zj[i][j][r];
-                    const bool pass = mb_act_passes(fmaf(zv, jsc[j], jsh[j]), e.act);
+                    const bool pass = mb_act_passes(fmaf(zv, jsc[j], jsh[j]), p.e.act);
                     const float gg = (ok && pass) ? dy : 0.0f;
-                    if (ok) e.gj[(long)m * C + c] = gg;
+                    if (ok) p.e.gj[(long)m * C + c] = gg;
                     s1[j] += gg;
                     s2[j] = fmaf(gg, (zv - jme[j]) * jrs[j], s2[j]);
                 }
@@ -697,87 +769,66 @@ __global__ __launch_bounds__(256) void pw_dgrad_kernel(const float* __restrict__
     __syncthreads();
     const bool own = tid < 64 && c0 + tid < C;
     const float v0 = own ? sred[0][0][tid] + sred[0][1][tid] : 0.0f, v1 = own ? sred[1][0][tid] + sred[1][1][tid] : 0.0f;
-    if (publish_and_arrive(arr, C, c0, own, c0 + tid, v0, v1))
-        finalize_bwd(arr.part2, (gridDim.y + MB_G - 1) / MB_G, C, c0 + lane, fin);
+    if (publish_and_arrive(p.arr, C, bx, by, p.d_ry, own, c0 + tid, v0, v1))
+        finalize_bwd(p.arr.part2, (p.d_ry + MB_G - 1) / MB_G, C, c0 + lane, p.fin);
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// Pointwise convolution, weight gradient:  dW[n][c] = sum_m dz[m][n] * T(in[m][c]) over this split's rows; both operands
-// are rebuilt while they are staged (dz from g_k, z_k, bc_k; T as in pw_fwd_kernel).  A thread's piece is 4 consecutive
-// columns of one row, so its per-column constants live in registers for the whole launch.  slabs[split][n][c].
-// ---------------------------------------------------------------------------------------------------------
+// weight gradient:  dW[n][c] = sum_m dz[m][n] * T(in[m][c]) over this split's rows; both operands are rebuilt while they are
+// staged (dz from g_k, z_k, bc_k; T as in pw_fwd_kernel).  A thread's pieces are 4 consecutive columns of rows p_r + 16 i, so
+// its per-column constants live in registers for the whole launch.  slabs[split][n][c].
 template <bool XF>
-__global__ __launch_bounds__(256) void pw_wgrad_kernel(const float* __restrict__ g, const float* __restrict__ zk,
-                                                       const float* __restrict__ bc, const float* __restrict__ in,
-                                                       const float* __restrict__ ss_in, int M, int N, int C,
-                                                       int rows_per_split, float* __restrict__ slabs) {
-    __shared__ float As[GK * GLD];
-    __shared__ float Bs[GK * GLD];
+__device__ __forceinline__ void pw_wgrad_body(float* lds, const PwBwd& p, int bx, int by, int bz) {
+    float* As = lds;                 // [m][n]   (PK x LDC)
+    float* Bs = lds + PK * LDC;      // [m][c]
+    const int M = p.M, N = p.N, C = p.C;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
-    const int c0 = blockIdx.x * GT, n0 = blockIdx.y * GT;
-    const int p_k = tid >> 4, p_c = (tid & 15) * 4;
+    const int c0 = bx * GT, n0 = by * GT;
+    const int p_r = tid >> 4, p_c = (tid & 15) * 4;
     const int an = min(n0 + p_c, N - 4), bcn = min(c0 + p_c, C - 4);
     const bool a_ok = n0 + p_c < N, b_ok = c0 + p_c < C;
-    const float4 ksc = *reinterpret_cast<const float4*>(bc + an);
-    const float4 kc1 = *reinterpret_cast<const float4*>(bc + N + an);
-    const float4 kc0 = *reinterpret_cast<const float4*>(bc + 2 * N + an);
-    float4 isc = make_float4(1.f, 1.f, 1.f, 1.f), ish = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 ksc = ldg4(p.bc + an), kc1 = ldg4(p.bc + N + an), kc0 = ldg4(p.bc + 2 * N + an);
+    float4 isc = f4_zero(), ish = f4_zero();
     if (XF) {
-        isc = *reinterpret_cast<const float4*>(ss_in + bcn);
-        ish = *reinterpret_cast<const float4*>(ss_in + C + bcn);
+        isc = ldg4(p.ss_in + bcn);
+        ish = ldg4(p.ss_in + C + bcn);
     }
-    const int mbeg = blockIdx.z * rows_per_split;
-    const int mend = min(M, mbeg + rows_per_split);
-    auto row = [&](int k0) -> long { return (long)min(k0 + p_k, M - 1); };
-    auto fetch_g = [&](int k0) -> float4 { return *reinterpret_cast<const float4*>(g + row(k0) * N + an); };
-    auto fetch_z = [&](int k0) -> float4 { return *reinterpret_cast<const float4*>(zk + row(k0) * N + an); };
-    auto fetch_b = [&](int k0) -> float4 { return *reinterpret_cast<const float4*>(in + row(k0) * C + bcn); };
-    auto stage = [&](float4 vg, float4 vz, float4 vb, int k0) {
-        const bool rok = k0 + p_k < mend;
-        float4 va;
-        va.x = fmaf(ksc.x, vg.x, fmaf(kc1.x, vz.x, kc0.x));
-        va.y = fmaf(ksc.y, vg.y, fmaf(kc1.y, vz.y, kc0.y));
-        va.z = fmaf(ksc.z, vg.z, fmaf(kc1.z, vz.z, kc0.z));
-        va.w = fmaf(ksc.w, vg.w, fmaf(kc1.w, vz.w, kc0.w));
-        if (XF) {
-            vb.x = relu6f(fmaf(vb.x, isc.x, ish.x));
-            vb.y = relu6f(fmaf(vb.y, isc.y, ish.y));
-            vb.z = relu6f(fmaf(vb.z, isc.z, ish.z));
-            vb.w = relu6f(fmaf(vb.w, isc.w, ish.w));
+    const int mbeg = bz * p.rows_per_split;
+    const int mend = min(M, mbeg + p.rows_per_split);
+    float4 vg[4], vz[4], vb[4];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const long m = (long)min(k0 + p_r + 16 * i, M - 1);
+            vg[i] = ldg4(p.g + m * N + an);
+            vz[i] = ldg4(p.zk + m * N + an);
+            vb[i] = ldg4(p.in + m * C + bcn);
         }
-        if (!(a_ok && rok)) va = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (!(b_ok && rok)) vb = make_float4(0.f, 0.f, 0.f, 0.f);
-        *reinterpret_cast<float4*>(&As[p_k * GLD + p_c]) = va;
-        *reinterpret_cast<float4*>(&Bs[p_k * GLD + p_c]) = vb;
     };
     f32x4 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = {0.0f, 0.0f, 0.0f, 0.0f};
-    float4 g0 = fetch_g(mbeg), z0 = fetch_z(mbeg), b0 = fetch_b(mbeg);
-    float4 g1 = fetch_g(mbeg + GK), z1 = fetch_z(mbeg + GK), b1 = fetch_b(mbeg + GK);
-    for (int k0 = mbeg; k0 < mend; k0 += 2 * GK) {
-        stage(g0, z0, b0, k0);
+    fetch(mbeg);
+    for (int k0 = mbeg; k0 < mend; k0 += PK) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool rok = k0 + p_r + 16 * i < mend;
+            float4 va = dz4(vg[i], vz[i], ksc, kc1, kc0);
+            float4 vv = XF ? bn_relu6_4(vb[i], isc, ish) : vb[i];
+            if (!(a_ok && rok)) va = f4_zero();
+            if (!(b_ok && rok)) vv = f4_zero();
+            *reinterpret_cast<float4*>(&As[(p_r + 16 * i) * LDC + p_c]) = va;
+            *reinterpret_cast<float4*>(&Bs[(p_r + 16 * i) * LDC + p_c]) = vv;
+        }
         __syncthreads();
-        g0 = fetch_g(k0 + 2 * GK);
-        z0 = fetch_z(k0 + 2 * GK);
-        b0 = fetch_b(k0 + 2 * GK);
+        fetch(k0 + PK);
         __builtin_amdgcn_sched_barrier(0);
-        mma_tile(As, Bs, acc, wr, wc, lane);
-        __syncthreads();
-        if (k0 + GK >= mend) break;
-        stage(g1, z1, b1, k0 + GK);
-        __syncthreads();
-        g1 = fetch_g(k0 + 3 * GK);
-        z1 = fetch_z(k0 + 3 * GK);
-        b1 = fetch_b(k0 + 3 * GK);
-        __builtin_amdgcn_sched_barrier(0);
-        mma_tile(As, Bs, acc, wr, wc, lane);
+        mma_cc(As, Bs, acc, min(PK, mend - k0 + 15) / 16, wr, wc, lane);
         __syncthreads();
     }
-    float* out = slabs + (size_t)blockIdx.z * N * C;
+    float* out = p.slabs + (size_t)bz * N * C;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -789,6 +840,19 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(const float* __restrict__
                 if (n < N && c < C) out[(long)n * C + c] = acc[i][j][r];
             }
         }
+}
+
+template <bool XF>
+__global__ __launch_bounds__(256) void pw_bwd_kernel(PwBwd p) {
+    __shared__ __attribute__((aligned(16))) float lds[PW_LDS_FLOATS];
+    const int b = blockIdx.x, nd = p.d_cx * p.d_ry;
+    if (b < nd) {
+        pw_dgrad_body(lds, p, b % p.d_cx, b / p.d_cx);
+    } else {
+        const int wb = b - nd;
+        const int bx = wb % p.w_cx, r = wb / p.w_cx;
+        pw_wgrad_body<XF>(lds, p, bx, r % p.w_ny, r / p.w_ny);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -947,7 +1011,7 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const float* __restrict__ x
     const bool own = rg == 0 && cok;
     const float v0 = ((red[0][0][lane] + red[0][1][lane]) + red[0][2][lane]) + red[0][3][lane];
     const float v1 = ((red[1][0][lane] + red[1][1][lane]) + red[1][2][lane]) + red[1][3][lane];
-    if (publish_and_arrive(arr, C, blockIdx.x * 64, own, c, v0, v1))
+    if (publish_and_arrive(arr, C, blockIdx.x, blockIdx.y, gridDim.y, own, c, v0, v1))
         finalize_fwd(arr.part2, (gridDim.y + MB_G - 1) / MB_G, C, c, fin);
 }
 
@@ -955,15 +1019,35 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const float* __restrict__ x
 // window holds (ih, iw) at that tap (oh*s - 1 + kh = ih, ow*s - 1 + kw = iw); dz rebuilt from (g_k, z_k, bc_k) per loaded
 // window element; the gradient window under 4 inputs is 3 rows x 6 columns at stride 1, 2 x 4 at stride 2 (loaded for every
 // tap parity, masked).  Epilogue = EpiBwd for the layer in front (same channels).
+struct DwBwd {
+    const float* g;        // g_k, z_k: (B, Ho, Wo, C); bc_k: 3 C
+    const float* zk;
+    const float* bc;
+    const float* w;        // (C, 9)
+    const float* x;        // z_{k-1} (B, H, W, C) with ss_in
+    const float* ss_in;
+    int H, W, C, Ho, Wo;
+    int ncb;                          // channel blocks
+    int d_rows, d_rpc, d_chunks;      // data gradient: image rows of the INPUT, rows per chunk, chunks
+    int w_rows, w_rpc, w_chunks;      // weight gradient: image rows of the OUTPUT
+    EpiBwd e;
+    Arrive arr;
+    FinBwd fin;
+    float* slabs;
+};
+
 template <int STRIDE>
-__global__ __launch_bounds__(256) void dw_dgrad_kernel(const float* __restrict__ g, const float* __restrict__ zk,
-                                                       const float* __restrict__ bc, const float* __restrict__ w, int H, int W,
-                                                       int C, int Ho, int Wo, int nrows, int rows_per_chunk, EpiBwd e, Arrive arr,
-                                                       FinBwd fin) {
+__device__ __forceinline__ void dw_dgrad_body(const DwBwd& p, int cb, int by) {
+    const float* __restrict__ g = p.g;
+    const float* __restrict__ zk = p.zk;
+    const float* __restrict__ bc = p.bc;
+    const float* __restrict__ w = p.w;
+    const int H = p.H, W = p.W, C = p.C, Ho = p.Ho, Wo = p.Wo, nrows = p.d_rows, rows_per_chunk = p.d_rpc;
+    const EpiBwd& e = p.e;
     constexpr int NCOL = STRIDE == 1 ? DW_SEG + 2 : (DW_SEG + 1) / STRIDE + 2;   // 6 at stride 1, 4 at stride 2
     __shared__ float red[2][4][64];
     const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + lane;
+    const int c = cb * 64 + lane;
     const bool cok = c < C;
     const int cc = cok ? c : C - 1;
     float wk[9];
@@ -971,7 +1055,7 @@ __global__ __launch_bounds__(256) void dw_dgrad_kernel(const float* __restrict__
     for (int k = 0; k < 9; ++k) wk[k] = w[cc * 9 + k];
     const float ksc = bc[cc], kc1 = bc[C + cc], kc0 = bc[2 * C + cc];
     const float jsc = e.ssj[cc], jsh = e.ssj[C + cc], jme = e.ssj[2 * C + cc], jrs = e.ssj[3 * C + cc];
-    const int r0 = blockIdx.y * rows_per_chunk;
+    const int r0 = by * rows_per_chunk;
     const int r1 = min(nrows, r0 + rows_per_chunk);
     float s1 = 0.0f, s2 = 0.0f;
     for (int t = r0 + rg; t < r1; t += 4) {
@@ -1041,26 +1125,30 @@ __global__ __launch_bounds__(256) void dw_dgrad_kernel(const float* __restrict__
     const bool own = rg == 0 && cok;
     const float v0 = ((red[0][0][lane] + red[0][1][lane]) + red[0][2][lane]) + red[0][3][lane];
     const float v1 = ((red[1][0][lane] + red[1][1][lane]) + red[1][2][lane]) + red[1][3][lane];
-    if (publish_and_arrive(arr, C, blockIdx.x * 64, own, c, v0, v1))
-        finalize_bwd(arr.part2, (gridDim.y + MB_G - 1) / MB_G, C, c, fin);
+    if (publish_and_arrive(p.arr, C, cb, by, p.d_chunks, own, c, v0, v1))
+        finalize_bwd(p.arr.part2, (p.d_chunks + MB_G - 1) / MB_G, C, c, p.fin);
 }
 
 // weight gradient: dW[c][tap] = sum_{b,oh,ow} dz[.,c] * y_in[shifted, c]; both factors rebuilt on load.
 // part[chunk][c*9+tap]; the chunks are folded in a fixed order by the deferred slab sum.
 template <int STRIDE>
-__global__ __launch_bounds__(256) void dw_wgrad_kernel(const float* __restrict__ g, const float* __restrict__ zk,
-                                                       const float* __restrict__ bc, const float* __restrict__ x,
-                                                       const float* __restrict__ ss_in, int H, int W, int C, int Ho, int Wo,
-                                                       int nrows, int rows_per_chunk, float* __restrict__ part) {
+__device__ __forceinline__ void dw_wgrad_body(const DwBwd& p, int cb, int by) {
+    const float* __restrict__ g = p.g;
+    const float* __restrict__ zk = p.zk;
+    const float* __restrict__ bc = p.bc;
+    const float* __restrict__ x = p.x;
+    const float* __restrict__ ss_in = p.ss_in;
+    float* __restrict__ part = p.slabs;
+    const int H = p.H, W = p.W, C = p.C, Ho = p.Ho, Wo = p.Wo, nrows = p.w_rows, rows_per_chunk = p.w_rpc;
     constexpr int NIN = (DW_SEG - 1) * STRIDE + 3;
     __shared__ float red[4][9][64];
     const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + lane;
+    const int c = cb * 64 + lane;
     const bool cok = c < C;
     const int cc = cok ? c : C - 1;
     const float ksc = bc[cc], kc1 = bc[C + cc], kc0 = bc[2 * C + cc];
     const float sc = ss_in[cc], sh = ss_in[C + cc];
-    const int r0 = blockIdx.y * rows_per_chunk;
+    const int r0 = by * rows_per_chunk;
     const int r1 = min(nrows, r0 + rows_per_chunk);
     float acc[9];
 #pragma unroll
@@ -1112,7 +1200,20 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(const float* __restrict__
     if (rg == 0 && cok) {
 #pragma unroll
         for (int t = 0; t < 9; ++t)
-            part[(size_t)blockIdx.y * C * 9 + c * 9 + t] = ((red[0][t][lane] + red[1][t][lane]) + red[2][t][lane]) + red[3][t][lane];
+            part[(size_t)by * C * 9 + c * 9 + t] = ((red[0][t][lane] + red[1][t][lane]) + red[2][t][lane]) + red[3][t][lane];
+    }
+}
+
+// Backward of a depthwise layer, ONE launch: blocks [0, ncb * d_chunks) are the data gradient (+ BatchNorm-backward reduction
+// of the layer in front), the rest the weight gradient.
+template <int STRIDE>
+__global__ __launch_bounds__(256) void dw_bwd_kernel(DwBwd p) {
+    const int b = blockIdx.x, nd = p.ncb * p.d_chunks;
+    if (b < nd) {
+        dw_dgrad_body<STRIDE>(p, b % p.ncb, b / p.ncb);
+    } else {
+        const int wb = b - nd;
+        dw_wgrad_body<STRIDE>(p, wb % p.ncb, wb / p.ncb);
     }
 }
 
@@ -1165,7 +1266,7 @@ __global__ __launch_bounds__(256) void avgpool_bwd_reduce_kernel(const float* __
     const bool own = rg == 0 && cok;
     const float v0 = ((red[0][0][lane] + red[0][1][lane]) + red[0][2][lane]) + red[0][3][lane];
     const float v1 = ((red[1][0][lane] + red[1][1][lane]) + red[1][2][lane]) + red[1][3][lane];
-    if (publish_and_arrive(arr, C, blockIdx.x * 64, own, c, v0, v1))
+    if (publish_and_arrive(arr, C, blockIdx.x, blockIdx.y, gridDim.y, own, c, v0, v1))
         finalize_bwd(arr.part2, (gridDim.y + MB_G - 1) / MB_G, C, c, fin);
 }
 
@@ -1305,7 +1406,7 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const float* __restrict
         v0 = (float)t0;
         v1 = (float)t1;
     }
-    if (!publish_and_arrive(arr, C, 0, own, c, v0, v1)) return;
+    if (!publish_and_arrive(arr, C, 0, blockIdx.y, gridDim.y, own, c, v0, v1)) return;
     const int R2 = (gridDim.y + MB_G - 1) / MB_G;
     if (colsum_out != nullptr) {
         double t0, t1;
@@ -1566,20 +1667,9 @@ int howl_mobilenet_bwd(const float* params, int num_labels, const float* x, long
     const int nl = (int)c.n->layers.size();
     const Arrive arr = c.arrive();
     hipMemsetAsync(c.counters(), 0, MB_COUNTERS * sizeof(unsigned), stream);
-    // Two HIP queues: the chain of data gradients (each launch also reduces the BatchNorm backward of the layer in front,
-    // so layer k's dz exists -- as g_k, z_k, bc_k -- the moment the data gradient of layer k+1 ends) stays on the caller's
-    // stream; the weight gradient of layer k only needs that triple and goes to the side queue, where it overlaps the
-    // chain.  Nothing on the side queue is ever waited for before the join at the end: every g_k has its own buffer.
-    HowlSideQueue* sq = howl_side_queue(stream, 1, "HOWL_MOBILENET_BWD_QUEUES");
-    hipStream_t wst = sq ? sq->stream : stream;
-    int evi = 0;
-    auto fork = [&]() {   // what the side queue launches next may use everything the caller's stream has been given so far
-        if (!sq) return;
-        hipEventRecord(sq->ev[evi], stream);
-        hipStreamWaitEvent(wst, sq->ev[evi], 0);
-        evi = (evi + 1) % 8;
-    };
-    JobList jobs;     // every weight gradient's slab sum, one launch at the end of the side queue
+    // One launch per layer: the data gradient of layer k (which also reduces the BatchNorm backward of the layer in front,
+    // so layer k-1's dz exists -- as g, z, bc -- the moment the launch ends) and the weight gradient of layer k share a grid.
+    JobList jobs;     // every weight gradient's slab sum, one launch at the end
     SlabSums head;    // classifier
     // classifier: logits = pooled_d W^T + b
     const float* wc = params + c.n->feature_params;
@@ -1598,75 +1688,76 @@ int howl_mobilenet_bwd(const float* params, int num_labels, const float* x, long
                            (const float*)dpooled, drop_mask, drop_scale, gl.hy * gl.wy, MB_LAST, gl.mz, rpc, epi_bwd(c, L), arr,
                            fin_bwd(c, L, grads));
     }
-    fork();
-    wgrad_gemm(wst, dlogits, lin(num_labels), num_labels, c.ws + c.p.pooled_d, lin(MB_LAST), MB_LAST, B, c.ws + c.p.head_scratch,
-               gwc, 64, 512, &head);
-    colsum(wst, dlogits, lin(num_labels), B, num_labels, c.ws + c.p.bias_scratch, gbc, nullptr, 64, 256, &head);
-    head.flush(wst);
+    wgrad_gemm(stream, dlogits, lin(num_labels), num_labels, c.ws + c.p.pooled_d, lin(MB_LAST), MB_LAST, B,
+               c.ws + c.p.head_scratch, gwc, 64, 512, &head);
+    colsum(stream, dlogits, lin(num_labels), B, num_labels, c.ws + c.p.bias_scratch, gbc, nullptr, 64, 256, &head);
     for (int k = nl - 1; k >= 2; --k) {
         const HowlMbLayer& l = c.n->layers[k];
         const Geo& g = c.p.g[k];
         const int j = k - 1;
         const HowlMbLayer& lj = c.n->layers[j];
-        const float* gk = c.ws + c.p.gr[k];
-        const float* zk = c.ws + c.p.z[k];
-        const float* bck = c.ws + c.p.bc[k];
         const bool in_mat = materialized(lj);
         const float* in = in_mat ? c.ws + c.p.y[j] : c.ws + c.p.z[j];
         const float* ss_in = in_mat ? nullptr : c.ws + c.p.ss[j];
         float* slab = c.ws + c.p.slab[k];
         if (l.kind == MB_PW) {
-            {   // weight gradient (side queue)
-                const int rps = pw_wgrad_rows_per_split(g.mz, l.cout, l.cin);
-                const int splits = (int)((g.mz + rps - 1) / rps);
-                const dim3 grid((l.cin + GT - 1) / GT, (l.cout + GT - 1) / GT, splits);
-                HowlProfScope prof("mb_conv", wst, 4.0 * (double)g.mz * (2.0 * l.cout + l.cin));
-                if (ss_in != nullptr)
-                    hipLaunchKernelGGL(pw_wgrad_kernel<true>, grid, dim3(256), 0, wst, gk, zk, bck, in, ss_in, (int)g.mz, l.cout,
-                                       l.cin, rps, slab);
-                else
-                    hipLaunchKernelGGL(pw_wgrad_kernel<false>, grid, dim3(256), 0, wst, gk, zk, bck, in, ss_in, (int)g.mz, l.cout,
-                                       l.cin, rps, slab);
-                jobs.add(slab, splits, (long)l.cout * l.cin, grads + l.w_off);
-            }
-            {   // data gradient + BatchNorm-backward reduction of layer j
-                int tpb, rb;
-                pw_rows(g.mz, (l.cin + GT - 1) / GT, &tpb, &rb);
-                const dim3 grid((l.cin + GT - 1) / GT, rb);
-                HowlProfScope prof("mb_conv", stream, 4.0 * (double)g.mz * (2.0 * l.cout + 3.0 * l.cin));
-                hipLaunchKernelGGL(pw_dgrad_kernel, grid, dim3(256), 0, stream, gk, zk, bck, params + l.w_off, (int)g.mz, l.cout,
-                                   l.cin, tpb, epi_bwd(c, j), arr, fin_bwd(c, j, grads));
-            }
+            PwBwd a{};
+            a.g = c.ws + c.p.gr[k];
+            a.zk = c.ws + c.p.z[k];
+            a.bc = c.ws + c.p.bc[k];
+            a.w = params + l.w_off;
+            a.in = in;
+            a.ss_in = ss_in;
+            a.M = (int)g.mz;
+            a.N = l.cout;
+            a.C = l.cin;
+            a.d_cx = (l.cin + GT - 1) / GT;
+            pw_rows(g.mz, a.d_cx, &a.tiles_per_block, &a.d_ry);
+            a.rows_per_split = pw_wgrad_rows_per_split(g.mz, l.cout, l.cin);
+            a.w_cx = (l.cin + GT - 1) / GT;
+            a.w_ny = (l.cout + GT - 1) / GT;
+            a.w_nz = (int)((g.mz + a.rows_per_split - 1) / a.rows_per_split);
+            a.e = epi_bwd(c, j);
+            a.arr = arr;
+            a.fin = fin_bwd(c, j, grads);
+            a.slabs = slab;
+            const unsigned blocks = (unsigned)(a.d_cx * a.d_ry + a.w_cx * a.w_ny * a.w_nz);
+            HowlProfScope prof("mb_conv", stream, 4.0 * (double)g.mz * (4.0 * l.cout + 4.0 * l.cin));
+            if (ss_in != nullptr)
+                hipLaunchKernelGGL(pw_bwd_kernel<true>, dim3(blocks), dim3(256), 0, stream, a);
+            else
+                hipLaunchKernelGGL(pw_bwd_kernel<false>, dim3(blocks), dim3(256), 0, stream, a);
+            jobs.add(slab, a.w_nz, (long)l.cout * l.cin, grads + l.w_off);
         } else {   // depthwise (layers 0 and 1 are the only dense ones)
-            {
-                int rpc;
-                const int nrows = B * g.ho;
-                const int chunks = row_chunks(nrows, 4, &rpc);
-                const dim3 grid((l.cout + 63) / 64, chunks);
-                HowlProfScope prof("mb_conv", wst, 4.0 * (2.0 * (double)g.mz + (double)B * g.hin * g.win) * l.cout);
-                if (l.stride == 1)
-                    hipLaunchKernelGGL(dw_wgrad_kernel<1>, grid, dim3(256), 0, wst, gk, zk, bck, in, ss_in, g.hin, g.win, l.cin,
-                                       g.ho, g.wo, nrows, rpc, slab);
-                else
-                    hipLaunchKernelGGL(dw_wgrad_kernel<2>, grid, dim3(256), 0, wst, gk, zk, bck, in, ss_in, g.hin, g.win, l.cin,
-                                       g.ho, g.wo, nrows, rpc, slab);
-                jobs.add(slab, chunks, (long)l.cout * 9, grads + l.w_off);
-            }
-            {
-                int rpc;
-                const int nrows = B * g.hin;
-                const int chunks = row_chunks(nrows, 4, &rpc);
-                const dim3 grid((l.cin + 63) / 64, chunks);
-                HowlProfScope prof("mb_conv", stream, 4.0 * (2.0 * (double)g.mz + 2.0 * (double)B * g.hin * g.win) * l.cout);
-                if (l.stride == 1)
-                    hipLaunchKernelGGL(dw_dgrad_kernel<1>, grid, dim3(256), 0, stream, gk, zk, bck, params + l.w_off, g.hin, g.win,
-                                       l.cin, g.ho, g.wo, nrows, rpc, epi_bwd(c, j), arr, fin_bwd(c, j, grads));
-                else
-                    hipLaunchKernelGGL(dw_dgrad_kernel<2>, grid, dim3(256), 0, stream, gk, zk, bck, params + l.w_off, g.hin, g.win,
-                                       l.cin, g.ho, g.wo, nrows, rpc, epi_bwd(c, j), arr, fin_bwd(c, j, grads));
-            }
+            DwBwd a{};
+            a.g = c.ws + c.p.gr[k];
+            a.zk = c.ws + c.p.z[k];
+            a.bc = c.ws + c.p.bc[k];
+            a.w = params + l.w_off;
+            a.x = in;
+            a.ss_in = ss_in;
+            a.H = g.hin;
+            a.W = g.win;
+            a.C = l.cin;
+            a.Ho = g.ho;
+            a.Wo = g.wo;
+            a.ncb = (l.cout + 63) / 64;
+            a.d_rows = B * g.hin;
+            a.d_chunks = row_chunks(a.d_rows, 4, &a.d_rpc);
+            a.w_rows = B * g.ho;
+            a.w_chunks = row_chunks(a.w_rows, 4, &a.w_rpc);
+            a.e = epi_bwd(c, j);
+            a.arr = arr;
+            a.fin = fin_bwd(c, j, grads);
+            a.slabs = slab;
+            const unsigned blocks = (unsigned)(a.ncb * (a.d_chunks + a.w_chunks));
+            HowlProfScope prof("mb_conv", stream, 4.0 * (4.0 * (double)g.mz + 3.0 * (double)B * g.hin * g.win) * l.cout);
+            if (l.stride == 1)
+                hipLaunchKernelGGL(dw_bwd_kernel<1>, dim3(blocks), dim3(256), 0, stream, a);
+            else
+                hipLaunchKernelGGL(dw_bwd_kernel<2>, dim3(blocks), dim3(256), 0, stream, a);
+            jobs.add(slab, a.w_chunks, (long)l.cout * 9, grads + l.w_off);
         }
-        fork();   // g_j, bc_j are complete: the side queue may start layer j's weight gradient
     }
     // ---- stem: the two dense 3x3 convolutions go through im2col + the shared GEMM on a materialised dz -----------------
     SlabSums stem;
@@ -1722,12 +1813,9 @@ int howl_mobilenet_bwd(const float* params, int num_labels, const float* x, long
                                c.ws + c.p.gr[0], arr, FinFwd{}, fin_bwd(c, 0, grads), (float*)nullptr);
         }
     }
+    head.flush(stream);
     stem.flush(stream);
-    jobs.flush(wst);
-    if (sq) {   // join: everything after this call on the caller's stream sees all weight gradients
-        hipEventRecord(sq->ev[8], wst);
-        hipStreamWaitEvent(stream, sq->ev[8], 0);
-    }
+    jobs.flush(stream);
     HOWL_CHECK_LAUNCH("howl_mobilenet_bwd");
     return HOWL_OK;
 }
