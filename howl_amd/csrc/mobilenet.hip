@@ -131,31 +131,48 @@ constexpr int MB_MAX_JOBS = 60;   // deferred slab sums of one backward call (53
 constexpr int DW_SEG = 4;
 
 // y_k exists in memory only where something other than one convolution reads it: the linear bottleneck outputs (narrow;
-// residual sources and sums) and the pooled downsample output.  Every other layer's BatchNorm + ReLU6 is applied by its
+// residual sources and sums).  Every other layer's BatchNorm + activation (+ the downsample's max pool) is applied by its
 // consumer while it loads z_k.
-inline bool materialized(const HowlMbLayer& l) { return l.act == MB_ACT_NONE || l.pool; }
+inline bool materialized(const HowlMbLayer& l) { return l.act == MB_ACT_NONE; }
 
 struct Plan {
     std::vector<Geo> g;
-    std::vector<size_t> z, y, yp, gr, ss, bc, slab;  // float offsets (y / yp: 0 when not materialised)
+    std::vector<size_t> z, y, gr, ss, bc, slab;  // float offsets (y: 0 when not materialised)
     std::vector<int> nslab;                          // slabs of the layer's weight gradient
-    size_t dz = 0, dyp = 0, dy0 = 0, col = 0, dcol = 0, part = 0, part2 = 0, counters = 0, head_scratch = 0, bias_scratch = 0, pooled = 0,
+    size_t dz = 0, slab0b = 0, part = 0, part2 = 0, counters = 0, head_scratch = 0, bias_scratch = 0, pooled = 0,
            pooled_d = 0, dpooled = 0;
     size_t total_floats = 0;
 };
 
-inline int pw_wgrad_rows_per_split(long rows, int n, int c) {
-    const int tiles = ((n + 63) / 64) * ((c + 63) / 64);
-    long splits = 768 / tiles;
-    const long by_rows = rows / 128;
-    if (splits > by_rows) splits = by_rows;
-    if (splits < 1) splits = 1;
-    long rps = (rows + splits - 1) / splits;
-    return (int)((rps + GK - 1) / GK * GK);
+// row tiles of a pointwise launch: each block takes a run of consecutive 64-row tiles
+inline void pw_rows(long M, int col_tiles, int* tiles_per_block, int* blocks) {
+    const int row_tiles = (int)((M + 63) / 64);
+    int tpb = (int)(((long)row_tiles * col_tiles + 4095) / 4096);     // ~4096 blocks at most ...
+    if (tpb < (row_tiles + MB_R - 1) / MB_R) tpb = (row_tiles + MB_R - 1) / MB_R;   // ... and <= MB_R of them along the rows
+    if (tpb < 1) tpb = 1;
+    *tiles_per_block = tpb;
+    *blocks = (row_tiles + tpb - 1) / tpb;
 }
-inline int dense_wgrad_splits(long rows) {  // must match wgrad_gemm() in howl_gemm.hip.h
-    long s = rows / 512;
-    return (int)(s < 1 ? 1 : (s > MB_WGRAD_SPLITS ? MB_WGRAD_SPLITS : s));
+// The weight-gradient blocks of a pointwise backward launch run beside its data-gradient blocks: a split is sized so that both
+// kinds take about the same number of 64-deep steps (data gradient: tiles_per_block x ceil(N / 64)), which keeps the slabs
+// that the deferred sum has to read few.
+inline int pw_wgrad_rows_per_split(long rows, int n, int c) {
+    int tpb, blocks;
+    pw_rows(rows, (c + 63) / 64, &tpb, &blocks);
+    long rps = 64L * tpb * ((n + 63) / 64);
+    if (rps < 128) rps = 128;
+    if (rps > rows) rps = (rows + 63) / 64 * 64;
+    return (int)rps;
+}
+// blocks of the stem's weight-gradient reductions: whole multiples of 256 pixels each, at most 1024 blocks
+inline int stem_px_per_block(long pixels) {
+    long per = (pixels + 1023) / 1024;
+    per = (per + 255) / 256 * 256;
+    return (int)(per < 256 ? 256 : per);
+}
+inline int stem_blocks(long pixels) {
+    const long per = stem_px_per_block(pixels);
+    return (int)((pixels + per - 1) / per);
 }
 // chunks of image rows for the depthwise kernels / pixel rows for the narrow column reductions: >= `min_per` units each
 inline int row_chunks(long units, int min_per, int* per_chunk) {
@@ -183,7 +200,6 @@ Plan make_plan(int B, int H0, int W0, int num_labels) {
         return o;
     };
     int h = H0, w = W0;
-    size_t max_dz = 0, max_col = 0;
     for (const HowlMbLayer& l : n.layers) {
         Geo g{};
         g.hin = h;
@@ -202,7 +218,6 @@ Plan make_plan(int B, int H0, int W0, int num_labels) {
         p.g.push_back(g);
         p.z.push_back(take((size_t)g.mz * l.cout));
         p.gr.push_back(take((size_t)g.mz * l.cout));
-        p.yp.push_back(l.pool ? take((size_t)g.mz * l.cout) : 0);
         p.y.push_back(materialized(l) ? take((size_t)g.my * l.cout) : 0);
         p.ss.push_back(take(4 * (size_t)l.cout));
         p.bc.push_back(take(4 * (size_t)l.cout));
@@ -214,24 +229,19 @@ Plan make_plan(int B, int H0, int W0, int num_labels) {
             wn = (size_t)l.cout * l.cin;
         } else if (l.kind == MB_DW) {
             int per;
-            ns = row_chunks((long)B * g.ho, 4, &per);
+            ns = row_chunks((long)B * g.ho, 8, &per);
             wn = (size_t)l.cout * 9;
         } else {
-            ns = dense_wgrad_splits(g.mz);
+            ns = stem_blocks(g.mz);
             wn = (size_t)l.cout * l.cin * 9;
-            max_dz = std::max(max_dz, (size_t)g.mz * l.cout);
-            max_col = std::max(max_col, (size_t)g.mz * 9 * l.cin);
         }
         p.nslab.push_back(ns);
         p.slab.push_back(take((size_t)ns * wn));
         h = g.hy;
         w = g.wy;
     }
-    p.dz = take(max_dz);
-    p.dyp = take(max_dz);
-    p.dy0 = take(max_dz);
-    p.col = take(max_col);
-    p.dcol = take(max_col);
+    p.dz = take((size_t)p.g[1].mz * n.layers[1].cout);     // materialised dz of features[0]
+    p.slab0b = take((size_t)p.nslab[0] * n.layers[0].cout);  // conv-bias gradient slabs of the downsample layer
     p.part = take((size_t)MB_R * 2 * MB_MAXC);
     p.part2 = take((size_t)MB_R2 * 2 * MB_MAXC);
     p.counters = take(MB_COUNTERS);
@@ -324,13 +334,23 @@ __device__ __forceinline__ bool publish_and_arrive(const Arrive& a, int C, int c
                                                    float v1) {
     __shared__ float red[2][4][64];
     const int c0 = cb * 64;
+    // groups of G blocks, G the smallest size that leaves <= MB_R2 groups: launches with few blocks along the rows (most of
+    // this network) have G = 1 and skip the first level altogether -- their rows ARE the group rows
+    const int G = (R1 + MB_R2 - 1) / MB_R2;
+    const int R2 = (R1 + G - 1) / G;
+    if (G == 1) {
+        if (own) {
+            st_agent(&a.part2[((size_t)by * 2 + 0) * C + c_own], v0);
+            st_agent(&a.part2[((size_t)by * 2 + 1) * C + c_own], v1);
+        }
+        return arrive(a.cnt2 + cb, R2);
+    }
     if (own) {
         st_agent(&a.part1[((size_t)by * 2 + 0) * C + c_own], v0);
         st_agent(&a.part1[((size_t)by * 2 + 1) * C + c_own], v1);
     }
-    const int group = by / MB_G, g0 = group * MB_G;
-    const int gsize = R1 - g0 < MB_G ? R1 - g0 : MB_G;
-    const int R2 = (R1 + MB_G - 1) / MB_G;
+    const int group = by / G, g0 = group * G;
+    const int gsize = R1 - g0 < G ? R1 - g0 : G;
     if (!arrive(a.cnt1 + cb * MB_R2 + group, gsize)) return false;
     const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
     const int c = c0 + lane < C ? c0 + lane : C - 1;
@@ -356,6 +376,11 @@ __device__ __forceinline__ bool publish_and_arrive(const Arrive& a, int C, int c
         st_agent(&a.part2[((size_t)group * 2 + 1) * C + c], ((red[1][0][lane] + red[1][1][lane]) + red[1][2][lane]) + red[1][3][lane]);
     }
     return arrive(a.cnt2 + cb, R2);
+}
+
+__device__ __forceinline__ int arrive_rows(int R1) {   // rows of part2 after publish_and_arrive over R1 blocks
+    const int G = (R1 + MB_R2 - 1) / MB_R2;
+    return (R1 + G - 1) / G;
 }
 
 // part[k][0..1][C] (k < R <= MB_R2) -> column totals of column c; called by all 256 threads of the finalising block, lane =
@@ -620,7 +645,7 @@ __global__ __launch_bounds__(256) void pw_fwd_kernel(const float* __restrict__ a
     const bool own = tid < 64 && n0 + tid < N;
     const float v0 = own ? sred[0][0][tid] + sred[0][1][tid] : 0.0f, v1 = own ? sred[1][0][tid] + sred[1][1][tid] : 0.0f;
     if (publish_and_arrive(arr, N, blockIdx.x, blockIdx.y, gridDim.y, own, n0 + tid, v0, v1))
-        finalize_fwd(arr.part2, (gridDim.y + MB_G - 1) / MB_G, N, n0 + lane, fin);
+        finalize_fwd(arr.part2, arrive_rows(gridDim.y), N, n0 + lane, fin);
 }
 
 // What the producer of a data gradient does with its result before it leaves the registers: dy_j (+ the gradient that
@@ -770,7 +795,7 @@ __device__ __forceinline__ void pw_dgrad_body(float* lds, const PwBwd& p, int bx
     const bool own = tid < 64 && c0 + tid < C;
     const float v0 = own ? sred[0][0][tid] + sred[0][1][tid] : 0.0f, v1 = own ? sred[1][0][tid] + sred[1][1][tid] : 0.0f;
     if (publish_and_arrive(p.arr, C, bx, by, p.d_ry, own, c0 + tid, v0, v1))
-        finalize_bwd(p.arr.part2, (p.d_ry + MB_G - 1) / MB_G, C, c0 + lane, p.fin);
+        finalize_bwd(p.arr.part2, arrive_rows(p.d_ry), C, c0 + lane, p.fin);
 }
 
 // weight gradient:  dW[n][c] = sum_m dz[m][n] * T(in[m][c]) over this split's rows; both operands are rebuilt while they are
@@ -856,84 +881,380 @@ __global__ __launch_bounds__(256) void pw_bwd_kernel(PwBwd p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// stem helpers: im2col / col2im for the two dense 3x3 convolutions, MaxPool2d((1,2))
+// Stem: downsample (Conv2d(1,3,3,padding=(1,3)) + bias, BatchNorm, ReLU, MaxPool2d((1,2))) and features[0]
+// (Conv2d(3,32,3,stride 2,padding 1)), direct convolutions with one thread per pixel -- 3 and 27 inputs per pixel are far
+// too thin for the tile engine, and an im2col matrix would be 9x the data.
+//   z0: (B, H, W0, 3), W0 = T + 4;   pooled y0 = maxpool(relu(bn(z0))): (B, H, Wp, 3), Wp = W0 / 2, never stored;
+//   z1: (B, H1, W1, 32).
 // ---------------------------------------------------------------------------------------------------------
-// col[m][c*9 + tap] = x[b, oh*s - ph + tap/3, ow*s - pw + tap%3, c]  (zero outside); x addressed through strides so
-// that the network input can be a (B,1,M,T) view of a multi-channel feature tensor
-__global__ void im2col3x3_kernel(const float* __restrict__ x, long sb, long sh, long sw, long sc, int H, int W, int C, int Ho,
-                                 int Wo, int stride, int ph, int pw, long total, float* __restrict__ col) {
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int K = 9 * C;
-        const long m = idx / K;
-        const int k = (int)(idx - m * K);
-        const int c = k / 9, tap = k - 9 * c;
-        const long b = m / ((long)Ho * Wo);
-        const int r = (int)(m - b * Ho * Wo);
-        const int oh = r / Wo, ow = r - oh * Wo;
-        const int ih = oh * stride - ph + tap / 3, iw = ow * stride - pw + tap % 3;
-        float v = 0.0f;
-        if (ih >= 0 && ih < H && iw >= 0 && iw < W) v = x[b * sb + ih * sh + iw * sw + c * sc];
-        col[idx] = v;
-    }
-}
+struct StemGeo {
+    int B, H, T, W0, Wp, H1, W1;
+};
 
-// dx[b,ih,iw,c] = sum over the (oh,ow,tap) that read it of dcol[m][c*9 + tap]   (gather form: no atomics)
-__global__ void col2im3x3_kernel(const float* __restrict__ dcol, int H, int W, int C, int Ho, int Wo, int stride, int ph, int pw,
-                                 long total, float* __restrict__ dx) {
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int c = chan_of(idx, C);
-        const long pix = idx / C;
-        const int iw = (int)(pix % W);
-        const long t = pix / W;
-        const int ih = (int)(t % H);
-        const long b = t / H;
-        float acc = 0.0f;
+// z0 = conv(x) + bias, with the BatchNorm statistics of layer 0 (3 channels) reduced in the same launch
+__global__ __launch_bounds__(256) void stem0_fwd_kernel(const float* __restrict__ x, long sb, long sm, long st,
+                                                        const float* __restrict__ w, const float* __restrict__ bias, StemGeo s,
+                                                        long pixels, int px_per_block, float* __restrict__ z0, Arrive arr,
+                                                        FinFwd fin) {
+    __shared__ float red[6][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float wk[3][9], bk[3];
 #pragma unroll
-        for (int kh = 0; kh < 3; ++kh) {
-            const int nh = ih + ph - kh;
-            if (nh < 0 || nh % stride != 0) continue;
-            const int oh = nh / stride;
-            if (oh >= Ho) continue;
+    for (int co = 0; co < 3; ++co) {
+        bk[co] = bias[co];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) wk[co][k] = w[co * 9 + k];
+    }
+    float sum[3] = {0.f, 0.f, 0.f}, sq[3] = {0.f, 0.f, 0.f};
+    const long p0 = (long)blockIdx.y * px_per_block;
+    const long p1 = pixels < p0 + px_per_block ? pixels : p0 + px_per_block;
+    for (long px = p0 + tid; px < p1; px += 256) {
+        const int b = (int)(px / ((long)s.H * s.W0));
+        const int r = (int)(px - (long)b * s.H * s.W0);
+        const int oh = r / s.W0, ow = r - oh * s.W0;
+        float v[9];
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
             for (int kw = 0; kw < 3; ++kw) {
-                const int nw = iw + pw - kw;
-                if (nw < 0 || nw % stride != 0) continue;
-                const int ow = nw / stride;
-                if (ow >= Wo) continue;
-                acc += dcol[((b * Ho + oh) * Wo + ow) * (9L * C) + c * 9 + kh * 3 + kw];
+                const int ih = oh - 1 + kh, it = ow - 3 + kw;
+                const float xv = x[b * sb + (long)min(max(ih, 0), s.H - 1) * sm + (long)min(max(it, 0), s.T - 1) * st];
+                v[kh * 3 + kw] = (ih >= 0 && ih < s.H && it >= 0 && it < s.T) ? xv : 0.0f;
+            }
+#pragma unroll
+        for (int co = 0; co < 3; ++co) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) acc = fmaf(wk[co][k], v[k], acc);
+            acc += bk[co];
+            z0[px * 3 + co] = acc;
+            sum[co] += acc;
+            sq[co] = fmaf(acc, acc, sq[co]);
+        }
+    }
+    if (arr.part1 == nullptr) return;
+#pragma unroll
+    for (int co = 0; co < 3; ++co) {
+        const float a = wave_sum(sum[co]), q = wave_sum(sq[co]);
+        if (lane == 0) {
+            red[co][wave] = a;
+            red[3 + co][wave] = q;
+        }
+    }
+    __syncthreads();
+    const bool own = tid < 3;
+    const float v0 = own ? ((red[tid][0] + red[tid][1]) + red[tid][2]) + red[tid][3] : 0.0f;
+    const float v1 = own ? ((red[3 + tid][0] + red[3 + tid][1]) + red[3 + tid][2]) + red[3 + tid][3] : 0.0f;
+    if (publish_and_arrive(arr, 3, 0, blockIdx.y, gridDim.y, own, tid, v0, v1))
+        finalize_fwd(arr.part2, arrive_rows(gridDim.y), 3, lane, fin);
+}
+
+// the 27 inputs of output pixel (b, oh, ow) of features[0]: pooled y0 at (2 oh - 1 + kh, 2 ow - 1 + kw), index ci*9 + kh*3 + kw
+__device__ __forceinline__ void stem1_inputs(const float* __restrict__ z0, const float (&sc)[3], const float (&sh)[3],
+                                             const StemGeo& s, int b, int oh, int ow, float (&v)[27]) {
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            const int ih = 2 * oh - 1 + kh, iw = 2 * ow - 1 + kw;
+            const bool inb = ih >= 0 && ih < s.H && iw >= 0 && iw < s.Wp;
+            const float* p = z0 + (((long)b * s.H + min(max(ih, 0), s.H - 1)) * s.W0 + 2 * min(max(iw, 0), s.Wp - 1)) * 3;
+            float t[6];
+#pragma unroll
+            for (int e = 0; e < 6; ++e) t[e] = p[e];
+#pragma unroll
+            for (int ci = 0; ci < 3; ++ci) {
+                const float a = fmaxf(fmaf(t[ci], sc[ci], sh[ci]), 0.0f), c = fmaxf(fmaf(t[3 + ci], sc[ci], sh[ci]), 0.0f);
+                v[ci * 9 + kh * 3 + kw] = inb ? fmaxf(a, c) : 0.0f;
             }
         }
-        dx[idx] = acc;
+}
+
+// z1 = conv(y0), stride 2, padding 1; y0 rebuilt from z0 on load.  One thread per output pixel, all 32 output channels; the
+// weights are uniform across the wave (scalar operands).
+__global__ __launch_bounds__(256) void stem1_fwd_kernel(const float* __restrict__ z0, const float* __restrict__ ss0,
+                                                        const float* __restrict__ w, StemGeo s, long pixels,
+                                                        float* __restrict__ z1) {
+    const long px = (long)blockIdx.x * 256 + threadIdx.x;
+    if (px >= pixels) return;
+    float sc[3], sh[3];
+#pragma unroll
+    for (int ci = 0; ci < 3; ++ci) {
+        sc[ci] = ss0[ci];
+        sh[ci] = ss0[3 + ci];
+    }
+    const int b = (int)(px / ((long)s.H1 * s.W1));
+    const int r = (int)(px - (long)b * s.H1 * s.W1);
+    const int oh = r / s.W1, ow = r - oh * s.W1;
+    float v[27];
+    stem1_inputs(z0, sc, sh, s, b, oh, ow, v);
+    float* out = z1 + px * 32;
+#pragma unroll
+    for (int c4 = 0; c4 < 8; ++c4) {
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int k = 0; k < 27; ++k) acc[e] = fmaf(w[(c4 * 4 + e) * 27 + k], v[k], acc[e]);
+        *reinterpret_cast<float4*>(out + c4 * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
     }
 }
 
-// MaxPool2d((1,2)) over W (floor), channels-last
-__global__ void maxpool12_fwd_kernel(const float* __restrict__ x, int W, int Wp, int C, long total, float* __restrict__ y) {
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int c = chan_of(idx, C);
-        const long pix = idx / C;
-        const int wp = (int)(pix % Wp);
-        const long bh = pix / Wp;
-        const float a = x[(bh * W + 2 * wp) * C + c], b = x[(bh * W + 2 * wp + 1) * C + c];
-        y[idx] = fmaxf(a, b);
+// Backward of features[0], ONE launch over the materialised dz1 (B, H1, W1, 32):
+//   blocks [0, wblocks): weight gradient dW1[co][ci*9+tap] = sum_px dz1[px][co] * in[px][ci*9+tap].  A wave takes 64 pixels at a
+//     time: every lane rebuilds its pixel's 27 inputs and loads its 32 dz, the wave parks them in LDS (two halves of 32
+//     pixels) and multiplies in^T (32 x 32 px) by dz (32 px x 32) with the fp32 MFMA; slabs[block][co*27 + k].
+//   the rest: data gradient to the pooled y0, un-pooled (first maximum wins, as PyTorch), through the ReLU, together with the
+//     BatchNorm-backward reduction of layer 0: g0 (B, H, W0, 3) + partials.  Pooled pixels are taken by parity class
+//     (ih % 2, iw % 2) -- a class shares its set of taps, so the weights stay scalar operands; a thread owns one pooled pixel =
+//     two z0 columns.
+struct Stem1Bwd {
+    const float* dz1;
+    const float* z0;
+    const float* ss0;
+    const float* w;        // (32, 27)
+    StemGeo s;
+    int wblocks, px_per_wblock;     // weight gradient
+    int cls_blocks, px_per_thread;  // data gradient: blocks per parity class
+    float* slabs;
+    float* g0;
+    Arrive arr;
+    FinBwd fin;
+};
+constexpr int S1_LD = 72;   // floats per pixel row of the wave's LDS tile: 32 inputs | 32 dz | pad (72 = 8 mod 32)
+
+__device__ __forceinline__ void stem1_wgrad_body(const Stem1Bwd& p, int wb) {
+    __shared__ __attribute__((aligned(16))) float tile[4][32 * S1_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = lane >> 4, l15 = lane & 15;
+    const StemGeo& s = p.s;
+    float sc[3], sh[3];
+#pragma unroll
+    for (int ci = 0; ci < 3; ++ci) {
+        sc[ci] = p.ss0[ci];
+        sh[ci] = p.ss0[3 + ci];
+    }
+    const long pixels = (long)s.B * s.H1 * s.W1;
+    const long p0 = (long)wb * p.px_per_wblock;
+    const long p1 = pixels < p0 + p.px_per_wblock ? pixels : p0 + p.px_per_wblock;
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = {0.0f, 0.0f, 0.0f, 0.0f};
+    float* my = tile[wave];
+    for (long base = p0 + wave * 64; base < p1; base += 256) {
+        const long px = base + lane;
+        const bool ok = px < p1;
+        const long pc = ok ? px : p1 - 1;
+        const int b = (int)(pc / ((long)s.H1 * s.W1));
+        const int r = (int)(pc - (long)b * s.H1 * s.W1);
+        const int oh = r / s.W1, ow = r - oh * s.W1;
+        float v[27];
+        stem1_inputs(p.z0, sc, sh, s, b, oh, ow, v);
+        float4 d[8];
+#pragma unroll
+        for (int c4 = 0; c4 < 8; ++c4) d[c4] = ldg4(p.dz1 + pc * 32 + c4 * 4);
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            if ((lane >> 5) == half) {
+                float* row = my + (lane & 31) * S1_LD;
+#pragma unroll
+                for (int k = 0; k < 27; ++k) row[k] = ok ? v[k] : 0.0f;
+#pragma unroll
+                for (int k = 27; k < 32; ++k) row[k] = 0.0f;
+#pragma unroll
+                for (int c4 = 0; c4 < 8; ++c4) *reinterpret_cast<float4*>(row + 32 + c4 * 4) = ok ? d[c4] : f4_zero();
+            }
+            wave_lds_sync();
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                const float* row = my + (4 * ks + q) * S1_LD;
+                float a[2], bb[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) a[i] = row[16 * i + l15];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) bb[j] = row[32 + 16 * j + l15];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], bb[j], acc[i][j], 0, 0, 0);
+            }
+            wave_lds_sync();
+        }
+    }
+    // the four waves' 32 x 32 partial products -> one slab row (fixed order)
+    __syncthreads();
+    float* red = &tile[0][0];     // [wave][k (32)][co (32)]
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[(wave * 32 + 16 * i + 4 * q + r) * 32 + 16 * j + l15] = acc[i][j][r];
+    __syncthreads();
+    for (int o = tid; o < 32 * 27; o += 256) {
+        const int co = o / 27, k = o - co * 27;
+        const float t = ((red[(0 * 32 + k) * 32 + co] + red[(1 * 32 + k) * 32 + co]) + red[(2 * 32 + k) * 32 + co]) +
+                        red[(3 * 32 + k) * 32 + co];
+        p.slabs[(size_t)wb * (32 * 27) + o] = t;
     }
 }
-// the gradient goes to the first maximal element (PyTorch's argmax rule); columns past 2*Wp get none
-__global__ void maxpool12_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, int W, int Wp, int C, long total,
-                                     float* __restrict__ dx) {
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int c = chan_of(idx, C);
-        const long pix = idx / C;
-        const int w = (int)(pix % W);
-        const long bh = pix / W;
-        const int wp = w >> 1;
-        float g = 0.0f;
-        if (wp < Wp) {
-            const float a = x[(bh * W + 2 * wp) * C + c], b = x[(bh * W + 2 * wp + 1) * C + c];
-            const bool first = a >= b;  // ties: the earlier index wins
-            if ((w & 1) == 0 ? first : !first) g = dy[(bh * Wp + wp) * C + c];
+
+__device__ __forceinline__ void stem1_dgrad_body(const Stem1Bwd& p, int db) {
+    __shared__ float red[6][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const StemGeo& s = p.s;
+    const int cls = db / p.cls_blocks, cb = db - cls * p.cls_blocks;
+    const int ph = cls >> 1, pw = cls & 1;
+    const int na = (s.H + 1) / 2, nc = (s.Wp + 1) / 2;
+    const long per_class = (long)s.B * na * nc;
+    float sc[3], sh[3], me[3], rs[3];
+#pragma unroll
+    for (int ci = 0; ci < 3; ++ci) {
+        sc[ci] = p.ss0[ci];
+        sh[ci] = p.ss0[3 + ci];
+        me[ci] = p.ss0[6 + ci];
+        rs[ci] = p.ss0[9 + ci];
+    }
+    float s1[3] = {0.f, 0.f, 0.f}, s2[3] = {0.f, 0.f, 0.f};
+    for (int it = 0; it < p.px_per_thread; ++it) {
+        const long idx = ((long)cb * p.px_per_thread + it) * 256 + tid;
+        if (idx >= per_class) continue;      // (no barrier inside the loop)
+        const int b = (int)(idx / ((long)na * nc));
+        const int r = (int)(idx - (long)b * na * nc);
+        const int a = r / nc, c = r - a * nc;
+        const int ih = 2 * a + ph, iw = 2 * c + pw;
+        if (ih >= s.H || iw >= s.Wp) continue;
+        // gradient of the pooled pixel: outputs (oh, ow) with 2 oh - 1 + kh = ih, 2 ow - 1 + kw = iw
+        float dy[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            if (hh == 1 && ph == 0) break;
+            const int kh = ph == 0 ? 1 : (hh == 0 ? 0 : 2);
+            const int oh = ph == 0 ? a : (hh == 0 ? a + 1 : a);
+#pragma unroll
+            for (int ww = 0; ww < 2; ++ww) {
+                if (ww == 1 && pw == 0) break;
+                const int kw = pw == 0 ? 1 : (ww == 0 ? 0 : 2);
+                const int ow = pw == 0 ? c : (ww == 0 ? c + 1 : c);
+                const bool ok = oh < s.H1 && ow < s.W1;
+                const float* dp = p.dz1 + (((long)b * s.H1 + min(oh, s.H1 - 1)) * s.W1 + min(ow, s.W1 - 1)) * 32;
+                float4 d[8];
+#pragma unroll
+                for (int c4 = 0; c4 < 8; ++c4) d[c4] = ldg4(dp + c4 * 4);
+                const int tap = kh * 3 + kw;     // uniform over the block (parity class)
+#pragma unroll
+                for (int ci = 0; ci < 3; ++ci) {
+                    float t = 0.0f;
+#pragma unroll
+                    for (int c4 = 0; c4 < 8; ++c4)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) t = fmaf(f4_get(d[c4], e), p.w[(c4 * 4 + e) * 27 + ci * 9 + tap], t);
+                    dy[ci] += ok ? t : 0.0f;
+                }
+            }
         }
-        dx[idx] = g;
+        // through the max pool and the ReLU to the two z0 columns of this pooled pixel
+        const long zoff = (((long)b * s.H + ih) * s.W0 + 2 * iw) * 3;
+        float t[6], gq[6];
+#pragma unroll
+        for (int e = 0; e < 6; ++e) t[e] = p.z0[zoff + e];
+#pragma unroll
+        for (int ci = 0; ci < 3; ++ci) {
+            const float ya = fmaf(t[ci], sc[ci], sh[ci]), yb = fmaf(t[3 + ci], sc[ci], sh[ci]);
+            const bool first = fmaxf(ya, 0.0f) >= fmaxf(yb, 0.0f);     // ties: the earlier index wins
+            gq[ci] = (first && ya > 0.0f) ? dy[ci] : 0.0f;
+            gq[3 + ci] = (!first && yb > 0.0f) ? dy[ci] : 0.0f;
+            s1[ci] += gq[ci] + gq[3 + ci];
+            s2[ci] = fmaf(gq[ci], (t[ci] - me[ci]) * rs[ci], s2[ci]);
+            s2[ci] = fmaf(gq[3 + ci], (t[3 + ci] - me[ci]) * rs[ci], s2[ci]);
+        }
+#pragma unroll
+        for (int e = 0; e < 6; ++e) p.g0[zoff + e] = gq[e];
+        if (iw == s.Wp - 1) {     // an odd last column of z0 has no pooled pixel: no gradient
+            for (int col = 2 * s.Wp; col < s.W0; ++col)
+#pragma unroll
+                for (int ci = 0; ci < 3; ++ci) p.g0[(((long)b * s.H + ih) * s.W0 + col) * 3 + ci] = 0.0f;
+        }
+    }
+#pragma unroll
+    for (int ci = 0; ci < 3; ++ci) {
+        const float a = wave_sum(s1[ci]), qq = wave_sum(s2[ci]);
+        if (lane == 0) {
+            red[ci][wave] = a;
+            red[3 + ci][wave] = qq;
+        }
+    }
+    __syncthreads();
+    const bool own = tid < 3;
+    const float v0 = own ? ((red[tid][0] + red[tid][1]) + red[tid][2]) + red[tid][3] : 0.0f;
+    const float v1 = own ? ((red[3 + tid][0] + red[3 + tid][1]) + red[3 + tid][2]) + red[3 + tid][3] : 0.0f;
+    const int R1 = 4 * p.cls_blocks;
+    if (publish_and_arrive(p.arr, 3, 0, db, R1, own, tid, v0, v1)) finalize_bwd(p.arr.part2, arrive_rows(R1), 3, lane, p.fin);
+}
+
+__global__ __launch_bounds__(256) void stem1_bwd_kernel(Stem1Bwd p) {
+    if ((int)blockIdx.x < p.wblocks)
+        stem1_wgrad_body(p, blockIdx.x);
+    else
+        stem1_dgrad_body(p, blockIdx.x - p.wblocks);
+}
+
+// Backward of the downsample convolution: dz0 from (g0, z0, bc0) per pixel; dW0[co][tap] = sum dz0[co] * x[tap], db0[co] = sum
+// dz0[co].  slab_w[block][27], slab_b[block][3].
+__global__ __launch_bounds__(256) void stem0_bwd_kernel(const float* __restrict__ x, long sb, long sm, long st,
+                                                        const float* __restrict__ g0, const float* __restrict__ z0,
+                                                        const float* __restrict__ bc0, StemGeo s, long pixels, int px_per_block,
+                                                        float* __restrict__ slab_w, float* __restrict__ slab_b) {
+    __shared__ float red[30][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float ksc[3], kc1[3], kc0[3];
+#pragma unroll
+    for (int co = 0; co < 3; ++co) {
+        ksc[co] = bc0[co];
+        kc1[co] = bc0[3 + co];
+        kc0[co] = bc0[6 + co];
+    }
+    float acc[30];
+#pragma unroll
+    for (int k = 0; k < 30; ++k) acc[k] = 0.0f;
+    const long p0 = (long)blockIdx.x * px_per_block;
+    const long p1 = pixels < p0 + px_per_block ? pixels : p0 + px_per_block;
+    for (long px = p0 + tid; px < p1; px += 256) {
+        const int b = (int)(px / ((long)s.H * s.W0));
+        const int r = (int)(px - (long)b * s.H * s.W0);
+        const int oh = r / s.W0, ow = r - oh * s.W0;
+        float v[9], dz[3];
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int ih = oh - 1 + kh, it = ow - 3 + kw;
+                const float xv = x[b * sb + (long)min(max(ih, 0), s.H - 1) * sm + (long)min(max(it, 0), s.T - 1) * st];
+                v[kh * 3 + kw] = (ih >= 0 && ih < s.H && it >= 0 && it < s.T) ? xv : 0.0f;
+            }
+#pragma unroll
+        for (int co = 0; co < 3; ++co) dz[co] = fmaf(ksc[co], g0[px * 3 + co], fmaf(kc1[co], z0[px * 3 + co], kc0[co]));
+#pragma unroll
+        for (int co = 0; co < 3; ++co) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) acc[co * 9 + k] = fmaf(dz[co], v[k], acc[co * 9 + k]);
+            acc[27 + co] += dz[co];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 30; ++k) {
+        const float t = wave_sum(acc[k]);
+        if (lane == 0) red[k][wave] = t;
+    }
+    __syncthreads();
+    if (tid < 30) {
+        const float t = ((red[tid][0] + red[tid][1]) + red[tid][2]) + red[tid][3];
+        if (tid < 27)
+            slab_w[(size_t)blockIdx.x * 27 + tid] = t;
+        else
+            slab_b[(size_t)blockIdx.x * 3 + (tid - 27)] = t;
     }
 }
 
@@ -1012,7 +1333,7 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const float* __restrict__ x
     const float v0 = ((red[0][0][lane] + red[0][1][lane]) + red[0][2][lane]) + red[0][3][lane];
     const float v1 = ((red[1][0][lane] + red[1][1][lane]) + red[1][2][lane]) + red[1][3][lane];
     if (publish_and_arrive(arr, C, blockIdx.x, blockIdx.y, gridDim.y, own, c, v0, v1))
-        finalize_fwd(arr.part2, (gridDim.y + MB_G - 1) / MB_G, C, c, fin);
+        finalize_fwd(arr.part2, arrive_rows(gridDim.y), C, c, fin);
 }
 
 // data gradient over the INPUT rows (b, ih): dy_j[b,ih,iw,c] = sum_tap w[c*9+tap] * dz[b,oh,ow,c] over the outputs whose
@@ -1126,7 +1447,7 @@ __device__ __forceinline__ void dw_dgrad_body(const DwBwd& p, int cb, int by) {
     const float v0 = ((red[0][0][lane] + red[0][1][lane]) + red[0][2][lane]) + red[0][3][lane];
     const float v1 = ((red[1][0][lane] + red[1][1][lane]) + red[1][2][lane]) + red[1][3][lane];
     if (publish_and_arrive(p.arr, C, cb, by, p.d_chunks, own, c, v0, v1))
-        finalize_bwd(p.arr.part2, (p.d_chunks + MB_G - 1) / MB_G, C, c, p.fin);
+        finalize_bwd(p.arr.part2, arrive_rows(p.d_chunks), C, c, p.fin);
 }
 
 // weight gradient: dW[c][tap] = sum_{b,oh,ow} dz[.,c] * y_in[shifted, c]; both factors rebuilt on load.
@@ -1267,7 +1588,7 @@ __global__ __launch_bounds__(256) void avgpool_bwd_reduce_kernel(const float* __
     const float v0 = ((red[0][0][lane] + red[0][1][lane]) + red[0][2][lane]) + red[0][3][lane];
     const float v1 = ((red[1][0][lane] + red[1][1][lane]) + red[1][2][lane]) + red[1][3][lane];
     if (publish_and_arrive(arr, C, blockIdx.x, blockIdx.y, gridDim.y, own, c, v0, v1))
-        finalize_bwd(arr.part2, (gridDim.y + MB_G - 1) / MB_G, C, c, fin);
+        finalize_bwd(arr.part2, arrive_rows(gridDim.y), C, c, fin);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1407,7 +1728,7 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const float* __restrict
         v1 = (float)t1;
     }
     if (!publish_and_arrive(arr, C, 0, blockIdx.y, gridDim.y, own, c, v0, v1)) return;
-    const int R2 = (gridDim.y + MB_G - 1) / MB_G;
+    const int R2 = arrive_rows(gridDim.y);
     if (colsum_out != nullptr) {
         double t0, t1;
         fold_partials(arr.part2, R2, C, lane, t0, t1);
@@ -1495,27 +1816,10 @@ struct Ctx {
     Arrive arrive() const { return Arrive{ws + p.part, ws + p.part2, counters(), counters() + MB_CBLOCKS * MB_R2}; }
 };
 
-// row tiles of a pointwise launch: each block takes a run of consecutive 64-row tiles
-inline void pw_rows(long M, int col_tiles, int* tiles_per_block, int* blocks) {
-    const int row_tiles = (int)((M + GT - 1) / GT);
-    int tpb = (int)(((long)row_tiles * col_tiles + 4095) / 4096);     // ~4096 blocks at most ...
-    if (tpb < (row_tiles + MB_R - 1) / MB_R) tpb = (row_tiles + MB_R - 1) / MB_R;   // ... and <= MB_R of them along the rows
-    if (tpb < 1) tpb = 1;
-    *tiles_per_block = tpb;
-    *blocks = (row_tiles + tpb - 1) / tpb;
-}
-
-// the stem's dense 3x3 convolutions: im2col + the shared GEMM
-void dense_forward(const Ctx& c, int k, const float* in, long sb, long sh, long sw, long sc, float* z) {
-    const HowlMbLayer& l = c.n->layers[k];
-    const Geo& g = c.p.g[k];
-    float* col = c.ws + c.p.col;
-    const int K = 9 * l.cin;
-    const long total = g.mz * K;
-    hipLaunchKernelGGL(im2col3x3_kernel, dim3(flat_grid(total)), dim3(256), 0, c.s, in, sb, sh, sw, sc, g.hin, g.win, l.cin, g.ho,
-                       g.wo, l.stride, l.pad_h, l.pad_w, total, col);
-    gemm(c.s, true, col, lin(K), 1, lin(0), c.params + l.w_off, lin(1), K, (int)g.mz, l.cout, K, 1,
-         l.bias ? c.params + l.b_off : nullptr, 0, z, l.cout, 0);
+StemGeo stem_geo(const Ctx& c) {
+    const Geo& g0 = c.p.g[0];
+    const Geo& g1 = c.p.g[1];
+    return StemGeo{c.B, g0.ho, g0.win, g0.wo, g0.wy, g1.ho, g1.wo};
 }
 
 FinFwd fin_fwd(const Ctx& c, int k, float* buffers) {
@@ -1590,7 +1894,7 @@ int howl_mobilenet_fwd(const float* params, float* buffers, int num_labels, cons
         const Geo& g = c.p.g[k];
         float* z = c.ws + c.p.z[k];
         // the layer's input: y_{k-1} where it exists, else z_{k-1} with the BatchNorm + ReLU6 of layer k-1 applied on load
-        const bool in_mat = k == 0 || materialized(c.n->layers[k - 1]);
+        const bool in_mat = k == 0 || materialized(c.n->layers[k - 1]);   // (the stem kernels find their own inputs)
         const float* in = k == 0 ? x : (in_mat ? c.ws + c.p.y[k - 1] : c.ws + c.p.z[k - 1]);
         const float* ss_in = in_mat ? nullptr : c.ws + c.p.ss[k - 1];
         const FinFwd fin = fin_fwd(c, k, buffers);
@@ -1617,11 +1921,15 @@ int howl_mobilenet_fwd(const float* params, float* buffers, int num_labels, cons
             else
                 hipLaunchKernelGGL(dw_fwd_kernel<2>, grid, dim3(256), 0, stream, in, ss_in, params + l.w_off, g.hin, g.win, l.cin,
                                    g.ho, g.wo, nrows, rpc, z, arr, fin);
+        } else if (k == 0) {
+            int ppb;
+            const int chunks = row_chunks(g.mz, 1024, &ppb);
+            hipLaunchKernelGGL(stem0_fwd_kernel, dim3(1, chunks), dim3(256), 0, stream, x, sb, sm, st, params + l.w_off,
+                               params + l.b_off, stem_geo(c), g.mz, ppb, z, arr, fin);
         } else {
-            if (k == 0)
-                dense_forward(c, k, in, sb, sm, st, 0, z);   // network input: (B, 1, M, T) view, H = mel, W = time
-            else
-                dense_forward(c, k, in, (long)g.hin * g.win * l.cin, (long)g.win * l.cin, l.cin, 1, z);
+            hipLaunchKernelGGL(stem1_fwd_kernel, dim3((unsigned)((g.mz + 255) / 256)), dim3(256), 0, stream,
+                               (const float*)(c.ws + c.p.z[0]), (const float*)(c.ws + c.p.ss[0]), params + l.w_off, stem_geo(c),
+                               g.mz, z);
             if (training) {
                 int rpc;
                 const int cp = col_pack(l.cout);
@@ -1633,15 +1941,9 @@ int howl_mobilenet_fwd(const float* params, float* buffers, int num_labels, cons
         }
         if (materialized(l)) {
             const float* res = l.res_src >= 0 ? c.ws + c.p.y[l.res_src] : nullptr;
-            float* ypre = l.pool ? c.ws + c.p.yp[k] : c.ws + c.p.y[k];
             const long total = g.mz * l.cout;
             hipLaunchKernelGGL(bn_act_kernel, dim3(flat_grid(total)), dim3(256), 0, stream, (const float*)z,
-                               (const float*)(c.ws + c.p.ss[k]), res, l.act, l.cout, total, ypre);
-            if (l.pool) {
-                const long tp = g.my * l.cout;
-                hipLaunchKernelGGL(maxpool12_fwd_kernel, dim3(flat_grid(tp)), dim3(256), 0, stream, (const float*)ypre, g.wo, g.wy,
-                                   l.cout, tp, c.ws + c.p.y[k]);
-            }
+                               (const float*)(c.ws + c.p.ss[k]), res, l.act, l.cout, total, c.ws + c.p.y[k]);
         }
     }
     const Geo& gl = c.p.g[nl - 1];
@@ -1745,7 +2047,7 @@ int howl_mobilenet_bwd(const float* params, int num_labels, const float* x, long
             a.d_rows = B * g.hin;
             a.d_chunks = row_chunks(a.d_rows, 4, &a.d_rpc);
             a.w_rows = B * g.ho;
-            a.w_chunks = row_chunks(a.w_rows, 4, &a.w_rpc);
+            a.w_chunks = row_chunks(a.w_rows, 8, &a.w_rpc);
             a.e = epi_bwd(c, j);
             a.arr = arr;
             a.fin = fin_bwd(c, j, grads);
@@ -1759,62 +2061,42 @@ int howl_mobilenet_bwd(const float* params, int num_labels, const float* x, long
             jobs.add(slab, a.w_chunks, (long)l.cout * 9, grads + l.w_off);
         }
     }
-    // ---- stem: the two dense 3x3 convolutions go through im2col + the shared GEMM on a materialised dz -----------------
-    SlabSums stem;
-    for (int k = 1; k >= 0; --k) {
-        const HowlMbLayer& l = c.n->layers[k];
-        const Geo& g = c.p.g[k];
-        const long total = g.mz * l.cout;
-        float* dz = c.ws + c.p.dz;
-        hipLaunchKernelGGL(dz_apply_kernel, dim3(flat_grid(total)), dim3(256), 0, stream, (const float*)(c.ws + c.p.gr[k]),
-                           (const float*)(c.ws + c.p.z[k]), (const float*)(c.ws + c.p.bc[k]), l.cout, total, dz);
-        const float* in = k > 0 ? c.ws + c.p.y[k - 1] : x;
-        float* col = c.ws + c.p.col;
-        const int K = 9 * l.cin;
-        const long ctot = g.mz * K;
-        long isb, ish, isw, isc;
-        if (k == 0) {
-            isb = sb, ish = sm, isw = st, isc = 0;
-        } else {
-            isb = (long)g.hin * g.win * l.cin, ish = (long)g.win * l.cin, isw = l.cin, isc = 1;
-        }
-        hipLaunchKernelGGL(im2col3x3_kernel, dim3(flat_grid(ctot)), dim3(256), 0, stream, in, isb, ish, isw, isc, g.hin, g.win,
-                           l.cin, g.ho, g.wo, l.stride, l.pad_h, l.pad_w, ctot, col);
-        wgrad_gemm(stream, dz, lin(l.cout), l.cout, col, lin(K), K, (int)g.mz, c.ws + c.p.slab[k], grads + l.w_off, MB_WGRAD_SPLITS,
-                   512, &stem);
-        if (l.bias) {   // sum over pixels of dz (rounding noise in exact arithmetic: a BatchNorm follows the bias)
-            int rpc;
-            const int cp = col_pack(l.cout);
-            const int chunks = row_chunks(g.mz, 64 * (64 / cp), &rpc);
-            hipLaunchKernelGGL(col_reduce_kernel<0>, dim3(1, chunks), dim3(256), 0, stream, (const float*)dz, (const float*)nullptr,
-                               (const float*)nullptr, 0, g.mz, l.cout, cp, (long)rpc, (float*)nullptr, arr, FinFwd{},
-                               FinBwd{}, grads + l.b_off);
-        }
-        if (k > 0) {
-            // dz -> gradient of the pooled downsample output -> through the max pool -> BatchNorm backward of layer 0
-            const HowlMbLayer& l0 = c.n->layers[0];
-            const Geo& g0 = c.p.g[0];
-            const long in_total = (long)B * g.hin * g.win * l.cin;
-            float* dcol = c.ws + c.p.dcol;
-            gemm(stream, true, dz, lin(l.cout), 1, lin(0), params + l.w_off, lin(K), 1, (int)g.mz, K, l.cout, 1, nullptr, 0, dcol, K,
-                 0);
-            float* dy0p = c.ws + c.p.dyp;   // (B, 40, 52, 3)
-            hipLaunchKernelGGL(col2im3x3_kernel, dim3(flat_grid(in_total)), dim3(256), 0, stream, (const float*)dcol, g.hin, g.win,
-                               l.cin, g.ho, g.wo, l.stride, l.pad_h, l.pad_w, in_total, dy0p);
-            const long t0 = g0.mz * l0.cout;
-            float* dy0 = c.ws + c.p.dy0;    // (B, 40, 105, 3)
-            hipLaunchKernelGGL(maxpool12_bwd_kernel, dim3(flat_grid(t0)), dim3(256), 0, stream, (const float*)(c.ws + c.p.yp[0]),
-                               (const float*)dy0p, g0.wo, g0.wy, l0.cout, t0, dy0);
-            int rpc;
-            const int cp = col_pack(l0.cout);
-            const int chunks = row_chunks(g0.mz, 64 * (64 / cp), &rpc);
-            hipLaunchKernelGGL(col_reduce_kernel<1>, dim3(1, chunks), dim3(256), 0, stream, (const float*)(c.ws + c.p.z[0]),
-                               (const float*)dy0, (const float*)(c.ws + c.p.ss[0]), l0.act, g0.mz, l0.cout, cp, (long)rpc,
-                               c.ws + c.p.gr[0], arr, FinFwd{}, fin_bwd(c, 0, grads), (float*)nullptr);
-        }
+    // ---- stem ---------------------------------------------------------------------------------------------------------
+    {
+        const HowlMbLayer& l0 = c.n->layers[0];
+        const HowlMbLayer& l1 = c.n->layers[1];
+        const Geo& g0 = c.p.g[0];
+        const Geo& g1 = c.p.g[1];
+        const StemGeo sg = stem_geo(c);
+        float* dz1 = c.ws + c.p.dz;
+        const long t1 = g1.mz * l1.cout;
+        hipLaunchKernelGGL(dz_apply_kernel, dim3(flat_grid(t1)), dim3(256), 0, stream, (const float*)(c.ws + c.p.gr[1]),
+                           (const float*)(c.ws + c.p.z[1]), (const float*)(c.ws + c.p.bc[1]), l1.cout, t1, dz1);
+        Stem1Bwd a{};
+        a.dz1 = dz1;
+        a.z0 = c.ws + c.p.z[0];
+        a.ss0 = c.ws + c.p.ss[0];
+        a.w = params + l1.w_off;
+        a.s = sg;
+        a.px_per_wblock = stem_px_per_block(g1.mz);
+        a.wblocks = stem_blocks(g1.mz);
+        const long per_class = (long)B * ((sg.H + 1) / 2) * ((sg.Wp + 1) / 2);
+        a.px_per_thread = (int)((per_class + 256L * (MB_R / 4) - 1) / (256L * (MB_R / 4)));
+        a.cls_blocks = (int)((per_class + 256L * a.px_per_thread - 1) / (256L * a.px_per_thread));
+        a.slabs = c.ws + c.p.slab[1];
+        a.g0 = c.ws + c.p.gr[0];
+        a.arr = arr;
+        a.fin = fin_bwd(c, 0, grads);
+        hipLaunchKernelGGL(stem1_bwd_kernel, dim3((unsigned)(a.wblocks + 4 * a.cls_blocks)), dim3(256), 0, stream, a);
+        jobs.add(a.slabs, a.wblocks, (long)l1.cout * l1.cin * 9, grads + l1.w_off);
+        const int nb0 = stem_blocks(g0.mz);
+        hipLaunchKernelGGL(stem0_bwd_kernel, dim3((unsigned)nb0), dim3(256), 0, stream, x, sb, sm, st,
+                           (const float*)(c.ws + c.p.gr[0]), (const float*)(c.ws + c.p.z[0]), (const float*)(c.ws + c.p.bc[0]), sg,
+                           g0.mz, stem_px_per_block(g0.mz), c.ws + c.p.slab[0], c.ws + c.p.slab0b);
+        jobs.add(c.ws + c.p.slab[0], nb0, (long)l0.cout * l0.cin * 9, grads + l0.w_off);
+        jobs.add(c.ws + c.p.slab0b, nb0, (long)l0.cout, grads + l0.b_off);
     }
     head.flush(stream);
-    stem.flush(stream);
     jobs.flush(stream);
     HOWL_CHECK_LAUNCH("howl_mobilenet_bwd");
     return HOWL_OK;
