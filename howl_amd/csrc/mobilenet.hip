@@ -160,7 +160,7 @@ inline int pw_wgrad_rows_per_split(long rows, int n, int c) {
     int tpb, blocks;
     pw_rows(rows, (c + 63) / 64, &tpb, &blocks);
     long rps = 64L * tpb * ((n + 63) / 64);
-    if (rps < 128) rps = 128;
+    if (rps < 256) rps = 256;
     if (rps > rows) rps = (rows + 63) / 64 * 64;
     return (int)rps;
 }
@@ -458,9 +458,15 @@ __device__ __forceinline__ void finalize_bwd(const float* part, int R, int C, in
 constexpr int PK = 64;
 constexpr int LDK = PK + 4;   // floats: 16-byte aligned rows, conflict-free fragment loads
 constexpr int LDC = 80;
+constexpr int PW_DEEP = 192;    // reductions at least this deep keep two steps in flight
 constexpr int PW_LDS_FLOATS = 2 * PK * LDC;   // the largest role (weight gradient: two [k][col] tiles)
 
+enum { PW_IN_PLAIN = 0, PW_IN_RELU6 = 1, PW_IN_LINEAR = 2 };
 __device__ __forceinline__ float4 f4_zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 bn_lin_4(float4 v, float4 sc, float4 sh) {
+    return make_float4(fmaf(v.x, sc.x, sh.x), fmaf(v.y, sc.y, sh.y), fmaf(v.z, sc.z, sh.z), fmaf(v.w, sc.w, sh.w));
+}
 __device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 // T(v) = relu6(v * scale + shift), four channels
 __device__ __forceinline__ float4 bn_relu6_4(float4 v, float4 sc, float4 sh) {
@@ -542,15 +548,21 @@ __device__ __forceinline__ void mma_cc(const float* As, const float* Bs, f32x4 (
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// forward:  z[m][n] = sum_k T(a[m][k]) * w[n][k]
-//   XF: a = z_{k-1} and T(v) = relu6(v * scale[k] + shift[k]) (the producer's BatchNorm + ReLU6, applied while the tile
-//   is staged); else a = y_{k-1}, T = identity.  A block owns 64 output channels and `tiles_per_block` consecutive 64-row
+// forward:  z[m][n] = sum_k T(a[m][k]) * w[n][k], the input's BatchNorm applied while the tile is staged:
+//   PW_IN_RELU6:  a = z_{k-1}, T(v) = relu6(v * scale[k] + shift[k])                       (input = a depthwise layer)
+//   PW_IN_LINEAR: a = z_{k-1}, T(v) = v * scale[k] + shift[k] (+ res[m][k]); T(a) = y_{k-1} is also stored, once, because the
+//                 residual sums and the weight gradient read it again                          (input = a linear bottleneck)
+//   PW_IN_PLAIN:  a is used as it is.  A block owns 64 output channels and `tiles_per_block` consecutive 64-row
 //   tiles; beside z it keeps the per-channel sum and sum of squares of everything it wrote, publishes them as ONE partial
 //   row, and the last block of the channel block turns the partials into this layer's ss (and running statistics).
 // ---------------------------------------------------------------------------------------------------------
-template <bool XF>
+struct PwFwdStage {
+    float4 va[4], vb[4], vr[4], xsc, xsh;
+};
+template <int XF, bool DEEP>
 __global__ __launch_bounds__(256) void pw_fwd_kernel(const float* __restrict__ a, const float* __restrict__ ss_in,
-                                                     const float* __restrict__ w, int M, int N, int K, int tiles_per_block,
+                                                     const float* __restrict__ w, const float* __restrict__ res,
+                                                     float* __restrict__ y_out, int M, int N, int K, int tiles_per_block,
                                                      float* __restrict__ z, Arrive arr, FinFwd fin) {
     __shared__ __attribute__((aligned(16))) float lds[2 * 64 * LDK];
     __shared__ float sred[2][2][64];
@@ -580,17 +592,39 @@ __global__ __launch_bounds__(256) void pw_fwd_kernel(const float* __restrict__ a
             ap[i] = a + (long)min(m0 + p_r + 16 * i, M - 1) * K;
             a_ok[i] = m0 + p_r + 16 * i < M;
         }
-        float4 va[4], vb[4], xsc = f4_zero(), xsh = f4_zero();
-        auto fetch = [&](int k0) {
+        // DEEP: two steps in flight (the step being staged + the next two requested) -- the late layers are a chain of
+        // K / 64 dependent steps on a chip that is mostly idle, so what a step costs is the memory latency it exposes
+        auto fetch = [&](PwFwdStage& sg, int k0) {
             const int k = min(k0 + p_k, K - 4);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                va[i] = ldg4(ap[i] + k);
-                vb[i] = ldg4(bp[i] + k);
+                sg.va[i] = ldg4(ap[i] + k);
+                sg.vb[i] = ldg4(bp[i] + k);
             }
-            if (XF) {
-                xsc = ldg4(ss_in + k);
-                xsh = ldg4(ss_in + K + k);
+            if (XF != PW_IN_PLAIN) {
+                sg.xsc = ldg4(ss_in + k);
+                sg.xsh = ldg4(ss_in + K + k);
+            }
+            if (XF == PW_IN_LINEAR && res != nullptr) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) sg.vr[i] = ldg4(res + (ap[i] - a) + k);
+            }
+        };
+        auto stage = [&](const PwFwdStage& sg, int k0) {
+            const bool kok = k0 + p_k < K;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float4 v = sg.va[i];
+                if (XF == PW_IN_RELU6) v = bn_relu6_4(v, sg.xsc, sg.xsh);
+                if (XF == PW_IN_LINEAR) {
+                    v = bn_lin_4(v, sg.xsc, sg.xsh);
+                    if (res != nullptr) v = add4(v, sg.vr[i]);
+                    // y_{k-1} itself is needed again (residual source, weight gradient): the first channel block stores it
+                    if (blockIdx.x == 0 && a_ok[i] && kok) *reinterpret_cast<float4*>(y_out + (ap[i] - a) + k0 + p_k) = v;
+                }
+                if (!(a_ok[i] && kok)) v = f4_zero();
+                *reinterpret_cast<float4*>(&As[(p_r + 16 * i) * LDK + p_k]) = v;
+                *reinterpret_cast<float4*>(&Bs[(p_r + 16 * i) * LDK + p_k]) = (b_ok[i] && kok) ? sg.vb[i] : f4_zero();
             }
         };
         f32x4 acc[2][2];
@@ -598,21 +632,26 @@ __global__ __launch_bounds__(256) void pw_fwd_kernel(const float* __restrict__ a
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) acc[i][j] = {0.0f, 0.0f, 0.0f, 0.0f};
-        fetch(0);
-        for (int k0 = 0; k0 < K; k0 += PK) {
-            const bool kok = k0 + p_k < K;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                float4 v = XF ? bn_relu6_4(va[i], xsc, xsh) : va[i];
-                if (!(a_ok[i] && kok)) v = f4_zero();
-                *reinterpret_cast<float4*>(&As[(p_r + 16 * i) * LDK + p_k]) = v;
-                *reinterpret_cast<float4*>(&Bs[(p_r + 16 * i) * LDK + p_k]) = (b_ok[i] && kok) ? vb[i] : f4_zero();
-            }
+        PwFwdStage st0, st1;
+        constexpr int AHEAD = DEEP ? 2 * PK : PK;
+        fetch(st0, 0);
+        if (DEEP) fetch(st1, PK);     // past the end: a clamped (re)load that is never staged
+        for (int k0 = 0; k0 < K; k0 += AHEAD) {
+            stage(st0, k0);
             __syncthreads();
-            fetch(k0 + PK);     // past the end: a clamped (re)load that is never staged
+            fetch(st0, k0 + AHEAD);
             __builtin_amdgcn_sched_barrier(0);
             mma_kk(As, Bs, acc, min(PK, K - k0 + 15) / 16, wr, wc, lane);
             __syncthreads();
+            if (DEEP) {
+                if (k0 + PK >= K) break;
+                stage(st1, k0 + PK);
+                __syncthreads();
+                fetch(st1, k0 + PK + AHEAD);
+                __builtin_amdgcn_sched_barrier(0);
+                mma_kk(As, Bs, acc, min(PK, K - k0 - PK + 15) / 16, wr, wc, lane);
+                __syncthreads();
+            }
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -680,6 +719,10 @@ struct PwBwd {
 
 // data gradient:  dy_j[m][c] = sum_n dz[m][n] * w[n][c],  dz = bc.scale*g + bc.c1*z + bc.c0 rebuilt while the tile is staged
 // (g_k, z_k: two 16-byte loads per piece); epilogue = EpiBwd for layer j (C = its channels).
+struct PwBwdStage {
+    float4 vg[4], vz[4], vb[4], ksc, kc1, kc0;
+};
+template <bool DEEP>
 __device__ __forceinline__ void pw_dgrad_body(float* lds, const PwBwd& p, int bx, int by) {
     __shared__ float sred[2][2][64];
     float* As = lds;                 // [m][n]   (64 x LDK)
@@ -713,39 +756,54 @@ __device__ __forceinline__ void pw_dgrad_body(float* lds, const PwBwd& p, int bx
             arow[i] = (long)min(m0 + p_r + 16 * i, M - 1) * N;
             a_ok[i] = m0 + p_r + 16 * i < M;
         }
-        float4 vg[4], vz[4], vb[4], ksc, kc1, kc0;
-        auto fetch = [&](int k0) {
+        auto fetch = [&](PwBwdStage& sg, int k0) {
             const int k = min(k0 + p_k, N - 4);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                vg[i] = ldg4(p.g + arow[i] + k);
-                vz[i] = ldg4(p.zk + arow[i] + k);
-                vb[i] = ldg4(p.w + (long)min(k0 + p_r + 16 * i, N - 1) * C + bcol);
+                sg.vg[i] = ldg4(p.g + arow[i] + k);
+                sg.vz[i] = ldg4(p.zk + arow[i] + k);
+                sg.vb[i] = ldg4(p.w + (long)min(k0 + p_r + 16 * i, N - 1) * C + bcol);
             }
-            ksc = ldg4(p.bc + k);
-            kc1 = ldg4(p.bc + N + k);
-            kc0 = ldg4(p.bc + 2 * N + k);
+            sg.ksc = ldg4(p.bc + k);
+            sg.kc1 = ldg4(p.bc + N + k);
+            sg.kc0 = ldg4(p.bc + 2 * N + k);
+        };
+        auto stage = [&](const PwBwdStage& sg, int k0) {
+            const bool kok = k0 + p_k < N;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float4 v = dz4(sg.vg[i], sg.vz[i], sg.ksc, sg.kc1, sg.kc0);
+                if (!(a_ok[i] && kok)) v = f4_zero();
+                *reinterpret_cast<float4*>(&As[(p_r + 16 * i) * LDK + p_k]) = v;
+                *reinterpret_cast<float4*>(&Bs[(p_r + 16 * i) * LDC + p_k]) =
+                    (b_col_ok && k0 + p_r + 16 * i < N) ? sg.vb[i] : f4_zero();
+            }
         };
         f32x4 acc[2][2];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) acc[i][j] = {0.0f, 0.0f, 0.0f, 0.0f};
-        fetch(0);
-        for (int k0 = 0; k0 < N; k0 += PK) {
-            const bool kok = k0 + p_k < N;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                float4 v = dz4(vg[i], vz[i], ksc, kc1, kc0);
-                if (!(a_ok[i] && kok)) v = f4_zero();
-                *reinterpret_cast<float4*>(&As[(p_r + 16 * i) * LDK + p_k]) = v;
-                *reinterpret_cast<float4*>(&Bs[(p_r + 16 * i) * LDC + p_k]) = (b_col_ok && k0 + p_r + 16 * i < N) ? vb[i] : f4_zero();
-            }
+        PwBwdStage st0, st1;
+        constexpr int AHEAD = DEEP ? 2 * PK : PK;
+        fetch(st0, 0);
+        if (DEEP) fetch(st1, PK);
+        for (int k0 = 0; k0 < N; k0 += AHEAD) {
+            stage(st0, k0);
             __syncthreads();
-            fetch(k0 + PK);
+            fetch(st0, k0 + AHEAD);
             __builtin_amdgcn_sched_barrier(0);
             mma_kc(As, Bs, acc, min(PK, N - k0 + 15) / 16, wr, wc, lane);
             __syncthreads();
+            if (DEEP) {
+                if (k0 + PK >= N) break;
+                stage(st1, k0 + PK);
+                __syncthreads();
+                fetch(st1, k0 + PK + AHEAD);
+                __builtin_amdgcn_sched_barrier(0);
+                mma_kc(As, Bs, acc, min(PK, N - k0 - PK + 15) / 16, wr, wc, lane);
+                __syncthreads();
+            }
         }
         // epilogue: all loads first (clamped, unconditional), then arithmetic, then the guarded stores
         float zj[2][2][4], ad[2][2][4];
@@ -867,12 +925,12 @@ __device__ __forceinline__ void pw_wgrad_body(float* lds, const PwBwd& p, int bx
         }
 }
 
-template <bool XF>
+template <bool XF, bool DEEP>
 __global__ __launch_bounds__(256) void pw_bwd_kernel(PwBwd p) {
     __shared__ __attribute__((aligned(16))) float lds[PW_LDS_FLOATS];
     const int b = blockIdx.x, nd = p.d_cx * p.d_ry;
     if (b < nd) {
-        pw_dgrad_body(lds, p, b % p.d_cx, b / p.d_cx);
+        pw_dgrad_body<DEEP>(lds, p, b % p.d_cx, b / p.d_cx);
     } else {
         const int wb = b - nd;
         const int bx = wb % p.w_cx, r = wb / p.w_cx;
@@ -909,8 +967,8 @@ __global__ __launch_bounds__(256) void stem0_fwd_kernel(const float* __restrict_
     const long p0 = (long)blockIdx.y * px_per_block;
     const long p1 = pixels < p0 + px_per_block ? pixels : p0 + px_per_block;
     for (long px = p0 + tid; px < p1; px += 256) {
-        const int b = (int)(px / ((long)s.H * s.W0));
-        const int r = (int)(px - (long)b * s.H * s.W0);
+        const int b = (int)((unsigned)px / (unsigned)(s.H * s.W0));     // pixel counts fit 31 bits (checked on the host)
+        const int r = (int)px - b * s.H * s.W0;
         const int oh = r / s.W0, ow = r - oh * s.W0;
         float v[9];
 #pragma unroll
@@ -983,8 +1041,8 @@ __global__ __launch_bounds__(256) void stem1_fwd_kernel(const float* __restrict_
         sc[ci] = ss0[ci];
         sh[ci] = ss0[3 + ci];
     }
-    const int b = (int)(px / ((long)s.H1 * s.W1));
-    const int r = (int)(px - (long)b * s.H1 * s.W1);
+    const int b = (int)((unsigned)px / (unsigned)(s.H1 * s.W1));
+    const int r = (int)px - b * s.H1 * s.W1;
     const int oh = r / s.W1, ow = r - oh * s.W1;
     float v[27];
     stem1_inputs(z0, sc, sh, s, b, oh, ow, v);
@@ -1047,8 +1105,8 @@ __device__ __forceinline__ void stem1_wgrad_body(const Stem1Bwd& p, int wb) {
         const long px = base + lane;
         const bool ok = px < p1;
         const long pc = ok ? px : p1 - 1;
-        const int b = (int)(pc / ((long)s.H1 * s.W1));
-        const int r = (int)(pc - (long)b * s.H1 * s.W1);
+        const int b = (int)((unsigned)pc / (unsigned)(s.H1 * s.W1));
+        const int r = (int)pc - b * s.H1 * s.W1;
         const int oh = r / s.W1, ow = r - oh * s.W1;
         float v[27];
         stem1_inputs(p.z0, sc, sh, s, b, oh, ow, v);
@@ -1103,6 +1161,7 @@ __device__ __forceinline__ void stem1_wgrad_body(const Stem1Bwd& p, int wb) {
 
 __device__ __forceinline__ void stem1_dgrad_body(const Stem1Bwd& p, int db) {
     __shared__ float red[6][4];
+    __shared__ float wl[32 * 27];     // the weights: every thread of the block reads the same taps (LDS broadcast)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const StemGeo& s = p.s;
     const int cls = db / p.cls_blocks, cb = db - cls * p.cls_blocks;
@@ -1117,12 +1176,14 @@ __device__ __forceinline__ void stem1_dgrad_body(const Stem1Bwd& p, int db) {
         me[ci] = p.ss0[6 + ci];
         rs[ci] = p.ss0[9 + ci];
     }
+    for (int i = tid; i < 32 * 27; i += 256) wl[i] = p.w[i];
+    __syncthreads();
     float s1[3] = {0.f, 0.f, 0.f}, s2[3] = {0.f, 0.f, 0.f};
     for (int it = 0; it < p.px_per_thread; ++it) {
         const long idx = ((long)cb * p.px_per_thread + it) * 256 + tid;
         if (idx >= per_class) continue;      // (no barrier inside the loop)
-        const int b = (int)(idx / ((long)na * nc));
-        const int r = (int)(idx - (long)b * na * nc);
+        const int b = (int)((unsigned)idx / (unsigned)(na * nc));
+        const int r = (int)idx - b * na * nc;
         const int a = r / nc, c = r - a * nc;
         const int ih = 2 * a + ph, iw = 2 * c + pw;
         if (ih >= s.H || iw >= s.Wp) continue;
@@ -1150,7 +1211,7 @@ __device__ __forceinline__ void stem1_dgrad_body(const Stem1Bwd& p, int db) {
 #pragma unroll
                     for (int c4 = 0; c4 < 8; ++c4)
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) t = fmaf(f4_get(d[c4], e), p.w[(c4 * 4 + e) * 27 + ci * 9 + tap], t);
+                        for (int e = 0; e < 4; ++e) t = fmaf(f4_get(d[c4], e), wl[(c4 * 4 + e) * 27 + ci * 9 + tap], t);
                     dy[ci] += ok ? t : 0.0f;
                 }
             }
@@ -1222,8 +1283,8 @@ __global__ __launch_bounds__(256) void stem0_bwd_kernel(const float* __restrict_
     const long p0 = (long)blockIdx.x * px_per_block;
     const long p1 = pixels < p0 + px_per_block ? pixels : p0 + px_per_block;
     for (long px = p0 + tid; px < p1; px += 256) {
-        const int b = (int)(px / ((long)s.H * s.W0));
-        const int r = (int)(px - (long)b * s.H * s.W0);
+        const int b = (int)((unsigned)px / (unsigned)(s.H * s.W0));     // pixel counts fit 31 bits (checked on the host)
+        const int r = (int)px - b * s.H * s.W0;
         const int oh = r / s.W0, ow = r - oh * s.W0;
         float v[9], dz[3];
 #pragma unroll
@@ -1769,6 +1830,13 @@ __global__ __launch_bounds__(256) void sum_jobs_kernel(MbSumJobs jobs) {
     float s[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     if (i < n) {
         int gq = rg;
+        for (; gq + 28 < jb.nparts; gq += 32) {     // eight loads in flight
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = jb.part[(long)(gq + 4 * u) * n + i];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s[u & 3] += v[u];
+        }
         for (; gq + 12 < jb.nparts; gq += 16) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) s[u] += jb.part[(long)(gq + 4 * u) * n + i];
@@ -1874,6 +1942,7 @@ int howl_mobilenet_fwd(const float* params, float* buffers, int num_labels, cons
     const int nl = (int)c.n->layers.size();
     HOWL_REQUIRE(c.p.g[nl - 1].hy >= 1 && c.p.g[nl - 1].wy >= 1, "howl_mobilenet_fwd: input too small for the network");
     HOWL_REQUIRE(nl <= 64, "howl_mobilenet_fwd: layer table too long");
+    HOWL_REQUIRE(c.p.g[0].mz * 3 < (1L << 31), "howl_mobilenet_fwd: batch too large for the stem kernels' 32-bit pixel indices");
     Arrive arr = c.arrive();
     if (!training) arr.part1 = nullptr;     // no statistics: ss comes from the running estimates
     hipMemsetAsync(c.counters(), 0, MB_COUNTERS * sizeof(unsigned), stream);
@@ -1903,12 +1972,29 @@ int howl_mobilenet_fwd(const float* params, float* buffers, int num_labels, cons
             pw_rows(g.mz, (l.cout + GT - 1) / GT, &tpb, &rb);
             const dim3 grid((l.cout + GT - 1) / GT, rb);
             HowlProfScope prof("mb_conv", stream, 4.0 * (double)g.mz * (l.cin + l.cout));
-            if (ss_in != nullptr)
-                hipLaunchKernelGGL(pw_fwd_kernel<true>, grid, dim3(256), 0, stream, in, ss_in, params + l.w_off, (int)g.mz, l.cout,
-                                   l.cin, tpb, z, arr, fin);
-            else
-                hipLaunchKernelGGL(pw_fwd_kernel<false>, grid, dim3(256), 0, stream, in, ss_in, params + l.w_off, (int)g.mz,
-                                   l.cout, l.cin, tpb, z, arr, fin);
+            const bool deep = l.cin >= PW_DEEP;
+            const HowlMbLayer& lp = c.n->layers[k - 1];
+            const float* res = nullptr;
+            float* y_out = nullptr;
+            const float* src = in;
+            const float* ssp = ss_in;
+            if (in_mat) {     // y_{k-1} = bn(z_{k-1}) (+ y_res) is built here, on load, and stored for its later readers
+                src = c.ws + c.p.z[k - 1];
+                ssp = c.ws + c.p.ss[k - 1];
+                res = lp.res_src >= 0 ? c.ws + c.p.y[lp.res_src] : nullptr;
+                y_out = c.ws + c.p.y[k - 1];
+            }
+#define HOWL_PW_FWD(XF, DEEP)                                                                                                   \
+    hipLaunchKernelGGL((pw_fwd_kernel<XF, DEEP>), grid, dim3(256), 0, stream, src, ssp, params + l.w_off, res, y_out, (int)g.mz, \
+                       l.cout, l.cin, tpb, z, arr, fin)
+            if (!in_mat) {
+                if (deep) HOWL_PW_FWD(PW_IN_RELU6, true);
+                else HOWL_PW_FWD(PW_IN_RELU6, false);
+            } else {
+                if (deep) HOWL_PW_FWD(PW_IN_LINEAR, true);
+                else HOWL_PW_FWD(PW_IN_LINEAR, false);
+            }
+#undef HOWL_PW_FWD
         } else if (l.kind == MB_DW) {
             int rpc;
             const int nrows = B * g.ho;
@@ -1938,12 +2024,6 @@ int howl_mobilenet_fwd(const float* params, float* buffers, int num_labels, cons
                                    (const float*)nullptr, (const float*)nullptr, 0, g.mz, l.cout, cp, (long)rpc, (float*)nullptr,
                                    arr, fin, FinBwd{}, (float*)nullptr);
             }
-        }
-        if (materialized(l)) {
-            const float* res = l.res_src >= 0 ? c.ws + c.p.y[l.res_src] : nullptr;
-            const long total = g.mz * l.cout;
-            hipLaunchKernelGGL(bn_act_kernel, dim3(flat_grid(total)), dim3(256), 0, stream, (const float*)z,
-                               (const float*)(c.ws + c.p.ss[k]), res, l.act, l.cout, total, c.ws + c.p.y[k]);
         }
     }
     const Geo& gl = c.p.g[nl - 1];
@@ -2025,10 +2105,14 @@ int howl_mobilenet_bwd(const float* params, int num_labels, const float* x, long
             a.slabs = slab;
             const unsigned blocks = (unsigned)(a.d_cx * a.d_ry + a.w_cx * a.w_ny * a.w_nz);
             HowlProfScope prof("mb_conv", stream, 4.0 * (double)g.mz * (4.0 * l.cout + 4.0 * l.cin));
-            if (ss_in != nullptr)
-                hipLaunchKernelGGL(pw_bwd_kernel<true>, dim3(blocks), dim3(256), 0, stream, a);
-            else
-                hipLaunchKernelGGL(pw_bwd_kernel<false>, dim3(blocks), dim3(256), 0, stream, a);
+            const bool deep = l.cout >= PW_DEEP;     // the data gradient reduces over the output channels
+            if (ss_in != nullptr) {
+                if (deep) hipLaunchKernelGGL((pw_bwd_kernel<true, true>), dim3(blocks), dim3(256), 0, stream, a);
+                else hipLaunchKernelGGL((pw_bwd_kernel<true, false>), dim3(blocks), dim3(256), 0, stream, a);
+            } else {
+                if (deep) hipLaunchKernelGGL((pw_bwd_kernel<false, true>), dim3(blocks), dim3(256), 0, stream, a);
+                else hipLaunchKernelGGL((pw_bwd_kernel<false, false>), dim3(blocks), dim3(256), 0, stream, a);
+            }
             jobs.add(slab, a.w_nz, (long)l.cout * l.cin, grads + l.w_off);
         } else {   // depthwise (layers 0 and 1 are the only dense ones)
             DwBwd a{};
