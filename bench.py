@@ -24,7 +24,7 @@ Rank 0 prints ONE JSON line; besides the contract fields it carries
   "roofline":     the dominant kernel of the configuration: algorithmic FLOPs (or bytes) per launch / mean launch duration
                   measured with HIP events on the launch stream in a second pass of the same K steps
                   (res8: conv3x3 45->45 forward launches vs the 157.3 TFLOP/s fp32 MFMA peak; seq-lstm: recurrences + GEMMs
-                  vs the same peak; mobilenet: BatchNorm/activation sweeps vs 8 TB/s HBM);
+                  vs the same peak; mobilenet: the fused convolution launches vs 8 TB/s HBM);
   "cpu_baseline": the oracle (CPU restatement of the reference step, torch-CPU) timed on this box's host cores on a
                   bounded sample (rank 0, N = 1 only);
   "rccl":         (N > 1) world size, backend, and the all-reduce of the flat gradient buffer timed on its own.
@@ -393,18 +393,21 @@ def main():
                                           "tflops": round(v[2] / (v[0] * 1e-3) / 1e12, 2) if v[0] > 0 else None}
                                       for k, v in parts.items()} | {"logmel": logmel}}
         else:
-            ts, ns, wb = read("mb_sweep")
+            ts, ns, wb = read("mb_conv")
             tg, ng, wf = read("gemm")
             achieved = wb / (ts * 1e-3) / 1e9 if ts > 0 else 0.0
-            roof = {"bound": "hbm", "kernel": "BatchNorm / activation sweeps of the 53 conv+BN layers (col_reduce, bn_act_fwd, "
-                                              "bn_bwd_apply), summed",
+            roof = {"bound": "hbm", "kernel": "the fused convolution launches of the 51 pointwise / depthwise layers (forward: "
+                                              "conv + BatchNorm statistics, input normalised on load; backward: data + weight "
+                                              "gradient + BatchNorm-backward reduction in one launch), summed",
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                     "algorithmic_bytes": round(wb / args.steps), "avg_launch_ms": round(ts / max(ns, 1), 4), "launches": ns,
-                    "note": "algorithmic bytes and summed kernel time per STEP; every sweep reads/writes its tensors once",
-                    "other_kernels": {"gemm": {"ms_per_step": round(tg / args.steps, 4), "launches_per_step": ng / args.steps,
-                                               "tflops": round(wf / (tg * 1e-3) / 1e12, 2) if tg > 0 else None},
-                                      "mb_sweep_ms_per_step": round(ts / args.steps, 4), "logmel": logmel}}
+                    "note": "algorithmic bytes (every operand read once, every result written once) and summed kernel time per "
+                            "STEP; most layers are a few MB and latency-bound, see DESIGN.md 5c",
+                    "other_kernels": {"gemm (classifier)": {"ms_per_step": round(tg / args.steps, 4),
+                                                            "launches_per_step": ng / args.steps},
+                                      "mb_conv_ms_per_step": round(ts / args.steps, 4),
+                                      "mb_conv_launches_per_step": ns / args.steps, "logmel": logmel}}
         read("logmel", reset=1)
 
     cpu = None

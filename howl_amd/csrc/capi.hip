@@ -6,10 +6,8 @@
 
 #include <stdlib.h>
 
-#include <map>
 #include <mutex>
 #include <string>
-#include <tuple>
 #include <vector>
 
 namespace {
@@ -25,30 +23,7 @@ std::mutex g_prof_mu;
 bool g_prof_on = false;
 std::vector<ProfRec> g_prof;
 
-std::mutex g_side_mu;
-std::map<std::tuple<int, hipStream_t, int>, HowlSideQueue*> g_side;
 }  // namespace
-
-HowlSideQueue* howl_side_queue(hipStream_t caller, int purpose, const char* disable_env) {
-    const char* env = getenv(disable_env);
-    if (env != nullptr && env[0] == '1') return nullptr;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-    std::lock_guard<std::mutex> lk(g_side_mu);
-    const auto key = std::make_tuple(dev, caller, purpose);
-    auto it = g_side.find(key);
-    if (it != g_side.end()) return it->second;
-    HowlSideQueue* q = new HowlSideQueue;
-    bool ok = hipStreamCreateWithFlags(&q->stream, hipStreamNonBlocking) == hipSuccess;
-    for (int i = 0; ok && i < HOWL_SIDE_EVENTS; ++i)
-        ok = hipEventCreateWithFlags(&q->ev[i], hipEventDisableTiming) == hipSuccess;
-    if (!ok) {
-        delete q;
-        q = nullptr;
-    }
-    g_side[key] = q;
-    return q;
-}
 
 bool howl_prof_begin(const char* tag, hipStream_t stream, size_t* slot, double work) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
@@ -146,20 +121,6 @@ int howl_shutdown(void) {
         }
         g_prof.clear();
     }
-    std::lock_guard<std::mutex> lk(g_side_mu);
-    int saved = 0;
-    hipGetDevice(&saved);
-    for (auto& kv : g_side) {
-        HowlSideQueue* q = kv.second;
-        if (q == nullptr) continue;
-        hipSetDevice(std::get<0>(kv.first));
-        hipStreamSynchronize(q->stream);
-        for (int i = 0; i < HOWL_SIDE_EVENTS; ++i) hipEventDestroy(q->ev[i]);
-        hipStreamDestroy(q->stream);
-        delete q;
-    }
-    g_side.clear();
-    hipSetDevice(saved);
     return HOWL_OK;
 }
 

@@ -16,16 +16,6 @@ typedef __attribute__((address_space(3))) float lds_f32;
 
 void howl_set_error(const char* fmt, ...);
 int howl_num_cus();
-// A second HIP queue beside the caller's stream, for work that hangs off the critical path of a backward pass (weight
-// gradients): fork and join are plain event record / wait pairs (capturable into a hipGraph).  One per (device, caller
-// stream, purpose), created on first use and kept for the life of the process; nullptr (= keep everything on the
-// caller's stream) when the environment variable `disable_env` is set to 1 or the runtime refuses the resources.
-constexpr int HOWL_SIDE_EVENTS = 16;
-struct HowlSideQueue {
-    hipStream_t stream = nullptr;
-    hipEvent_t ev[HOWL_SIDE_EVENTS];
-};
-HowlSideQueue* howl_side_queue(hipStream_t caller, int purpose, const char* disable_env);
 bool howl_prof_begin(const char* tag, hipStream_t stream, size_t* slot, double work);
 void howl_prof_end(size_t slot, hipStream_t stream);
 

@@ -7,17 +7,23 @@
 // architecture (Sandler et al. 2018 table 2 == torchvision mobilenetv2.py, width 1.0): see oracle/mobilenet.py.
 //
 // Design.  Activations are channels-last, one row per pixel: tensor k is an (M_k = B*H_k*W_k) x C_k row-major matrix.
-//   * 1x1 convolutions (35 of the 53) ARE matrix products on that layout -> the fp32 MFMA GEMM (howl_gemm.hip.h),
-//     forward, data gradient and weight gradient (split-K + fixed-order slab sum); the two dense 3x3 convolutions
-//     (1->3 and 3->32) go through an im2col matrix and the same GEMM;
-//   * depthwise 3x3, BatchNorm statistics / apply / backward, ReLU6, pooling are bandwidth-bound row sweeps with the
-//     channel as the unit-stride index (coalesced at any C); per-channel reductions are two-stage and fixed-order
-//     (fp64 partials), so results do not depend on scheduling;
+// At batch 512 the whole network is ~0.7 GB of activations in 53 layers, most of them a few MB: what a layer costs is the
+// number of launches and dependent memory round trips it takes, not bytes.  So a layer is ONE launch forward and ONE backward:
+//   * every convolution kernel also reduces the BatchNorm statistics of what it writes (per-channel partial sums -> the last
+//     block to finish folds them in a fixed order: `Arrive`), and no BatchNorm / ReLU6 / residual pass exists as a kernel of
+//     its own -- the consumer of z_k applies y_k = act(z_k * scale + shift) (+ residual) while it loads its operand
+//     (ss_k = [scale | shift | mean | rstd]); only the narrow linear-bottleneck outputs are also stored, by that consumer;
+//   * backward: the kernel that produces layer j's incoming gradient multiplies it by the activation mask, stores it (g_j)
+//     and reduces sum g, sum g*xhat; dz_j = scale*g_j + c1*z_j + c0 (bc_j) is rebuilt on load by the data- and weight-
+//     gradient blocks of layer j, which share one launch; weight-gradient slabs of all layers are folded by one launch;
+//   * 1x1 convolutions are fp32 MFMA tile products (64 x 64 x 64 steps); depthwise 3x3 kernels keep lane = channel; the two
+//     stem convolutions (1->3, 3->32) are direct, one thread per pixel;
 //   * the layer table is built once on the host and published through howl_mobilenet_layer(): the Python module lays
 //     its parameters out in ONE flat buffer at those offsets, in PyTorch's own shapes, so gradients land in a flat
 //     buffer of the same layout and the optimiser is a single fused AdamW launch.
-// Saved for the backward pass (in the caller's workspace): each layer's convolution output z_k, its batch statistics
-// and its output y_k; ReLU6 masks and normalised values are recomputed from z_k.
+// Saved for the backward pass (in the caller's workspace): each layer's convolution output z_k, ss_k, the stored y_k of the
+// linear bottlenecks; masks and normalised values are recomputed from z_k.  Reductions are fixed-order: results do not
+// depend on scheduling.
 #include <algorithm>
 #include <vector>
 
@@ -32,8 +38,6 @@ enum { MB_ACT_NONE = 0, MB_ACT_RELU6 = 1, MB_ACT_RELU = 2 };
 constexpr int MB_LAST = 1280;
 constexpr float MB_EPS = 1e-5f;
 constexpr double MB_MOMENTUM = 0.1;
-constexpr int MB_CHUNKS = 512;      // upper bound on the row chunks of the two-stage column reductions
-constexpr int MB_WGRAD_SPLITS = 1024;  // split-K bound of the weight-gradient GEMMs (long, thin reductions over pixels)
 
 struct Net {
     std::vector<HowlMbLayer> layers;
@@ -949,6 +953,27 @@ struct StemGeo {
     int B, H, T, W0, Wp, H1, W1;
 };
 
+// the nine inputs of downsample pixel (b, oh, ow): x[b, oh - 1 + kh, ow - 3 + kw], zero outside.  All nine loads are issued
+// from clamped addresses BEFORE any of them is masked (two loops): written as one `inside ? x[..] : 0` per tap the compiler
+// turns every tap into a branch around its load with a full wait behind it -- nine dependent memory round trips per pixel.
+__device__ __forceinline__ void stem0_taps(const float* __restrict__ x, long sb, long sm, long st, const StemGeo& s, int b, int oh,
+                                           int ow, float (&v)[9]) {
+    const float* xb = x + b * sb;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+        const float* xr = xb + (long)min(max(oh - 1 + kh, 0), s.H - 1) * sm;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) v[kh * 3 + kw] = xr[(long)min(max(ow - 3 + kw, 0), s.T - 1) * st];
+    }
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            const int ih = oh - 1 + kh, it = ow - 3 + kw;
+            if (ih < 0 || ih >= s.H || it < 0 || it >= s.T) v[kh * 3 + kw] = 0.0f;
+        }
+}
+
 // z0 = conv(x) + bias, with the BatchNorm statistics of layer 0 (3 channels) reduced in the same launch
 __global__ __launch_bounds__(256) void stem0_fwd_kernel(const float* __restrict__ x, long sb, long sm, long st,
                                                         const float* __restrict__ w, const float* __restrict__ bias, StemGeo s,
@@ -971,14 +996,7 @@ __global__ __launch_bounds__(256) void stem0_fwd_kernel(const float* __restrict_
         const int r = (int)px - b * s.H * s.W0;
         const int oh = r / s.W0, ow = r - oh * s.W0;
         float v[9];
-#pragma unroll
-        for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-            for (int kw = 0; kw < 3; ++kw) {
-                const int ih = oh - 1 + kh, it = ow - 3 + kw;
-                const float xv = x[b * sb + (long)min(max(ih, 0), s.H - 1) * sm + (long)min(max(it, 0), s.T - 1) * st];
-                v[kh * 3 + kw] = (ih >= 0 && ih < s.H && it >= 0 && it < s.T) ? xv : 0.0f;
-            }
+        stem0_taps(x, sb, sm, st, s, b, oh, ow, v);
 #pragma unroll
         for (int co = 0; co < 3; ++co) {
             float acc = 0.0f;
@@ -1010,20 +1028,29 @@ __global__ __launch_bounds__(256) void stem0_fwd_kernel(const float* __restrict_
 // the 27 inputs of output pixel (b, oh, ow) of features[0]: pooled y0 at (2 oh - 1 + kh, 2 ow - 1 + kw), index ci*9 + kh*3 + kw
 __device__ __forceinline__ void stem1_inputs(const float* __restrict__ z0, const float (&sc)[3], const float (&sh)[3],
                                              const StemGeo& s, int b, int oh, int ow, float (&v)[27]) {
+    float t[9][6];     // all 54 loads first, from clamped addresses (see stem0_taps)
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            const int ih = min(max(2 * oh - 1 + kh, 0), s.H - 1), iw = min(max(2 * ow - 1 + kw, 0), s.Wp - 1);
+            const float* p = z0 + (((long)b * s.H + ih) * s.W0 + 2 * iw) * 3;
+#pragma unroll
+            for (int e = 0; e < 6; ++e) t[kh * 3 + kw][e] = p[e];
+        }
 #pragma unroll
     for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
         for (int kw = 0; kw < 3; ++kw) {
             const int ih = 2 * oh - 1 + kh, iw = 2 * ow - 1 + kw;
             const bool inb = ih >= 0 && ih < s.H && iw >= 0 && iw < s.Wp;
-            const float* p = z0 + (((long)b * s.H + min(max(ih, 0), s.H - 1)) * s.W0 + 2 * min(max(iw, 0), s.Wp - 1)) * 3;
-            float t[6];
-#pragma unroll
-            for (int e = 0; e < 6; ++e) t[e] = p[e];
 #pragma unroll
             for (int ci = 0; ci < 3; ++ci) {
-                const float a = fmaxf(fmaf(t[ci], sc[ci], sh[ci]), 0.0f), c = fmaxf(fmaf(t[3 + ci], sc[ci], sh[ci]), 0.0f);
-                v[ci * 9 + kh * 3 + kw] = inb ? fmaxf(a, c) : 0.0f;
+                const float a = fmaxf(fmaf(t[kh * 3 + kw][ci], sc[ci], sh[ci]), 0.0f);
+                const float c = fmaxf(fmaf(t[kh * 3 + kw][3 + ci], sc[ci], sh[ci]), 0.0f);
+                float y = fmaxf(a, c);
+                if (!inb) y = 0.0f;
+                v[ci * 9 + kh * 3 + kw] = y;
             }
         }
 }
@@ -1287,14 +1314,7 @@ __global__ __launch_bounds__(256) void stem0_bwd_kernel(const float* __restrict_
         const int r = (int)px - b * s.H * s.W0;
         const int oh = r / s.W0, ow = r - oh * s.W0;
         float v[9], dz[3];
-#pragma unroll
-        for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-            for (int kw = 0; kw < 3; ++kw) {
-                const int ih = oh - 1 + kh, it = ow - 3 + kw;
-                const float xv = x[b * sb + (long)min(max(ih, 0), s.H - 1) * sm + (long)min(max(it, 0), s.T - 1) * st];
-                v[kh * 3 + kw] = (ih >= 0 && ih < s.H && it >= 0 && it < s.T) ? xv : 0.0f;
-            }
+        stem0_taps(x, sb, sm, st, s, b, oh, ow, v);
 #pragma unroll
         for (int co = 0; co < 3; ++co) dz[co] = fmaf(ksc[co], g0[px * 3 + co], fmaf(kc1[co], z0[px * 3 + co], kc0[co]));
 #pragma unroll
@@ -1655,18 +1675,7 @@ __global__ __launch_bounds__(256) void avgpool_bwd_reduce_kernel(const float* __
 // ---------------------------------------------------------------------------------------------------------
 // elementwise pieces (materialised outputs, stem)
 // ---------------------------------------------------------------------------------------------------------
-// y = act(z * scale + shift) [+ res]
-__global__ void bn_act_kernel(const float* __restrict__ z, const float* __restrict__ ss, const float* __restrict__ res, int act,
-                              int C, long total, float* __restrict__ y) {
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int c = chan_of(idx, C);
-        float v = mb_act(fmaf(z[idx], ss[c], ss[C + c]), act);
-        if (res != nullptr) v += res[idx];
-        y[idx] = v;
-    }
-}
-
-// dz = scale * g + c1 * z + c0 in memory (stem only: its dense 3x3 convolutions go through im2col + the shared GEMM)
+// dz = scale * g + c1 * z + c0 in memory (features[0] only: both roles of its backward launch read dz many times)
 __global__ void dz_apply_kernel(const float* __restrict__ g, const float* __restrict__ z, const float* __restrict__ bc, int C,
                                 long total, float* __restrict__ dz) {
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
@@ -1698,31 +1707,20 @@ __global__ void bn_eval_ss_kernel(EvalJobs jobs, const float* __restrict__ param
     ss[3 * C + c] = rstd;
 }
 
-// Narrow column reductions over the rows of an (M x C) matrix, C <= 64 (the 3- and 32-channel stem layers).
+// BatchNorm statistics of a narrow (M x C) matrix, C <= 32 (features[0]'s 32 channels: its kernel has one thread per pixel
+// and all 32 channels in registers -- reducing 64 sums across the block there would cost more than this pass).
 // Lane -> (row slot rs = lane / cp, column lane % cp), cp = col_pack(C); rows advance by 4 waves x (64/cp) slots, four loads
-// in flight.  MODE 0: (sum z, sum z^2) -> finalize_fwd, or with colsum_out the plain column sums (conv-bias gradient).
-// MODE 1: BatchNorm backward of a materialised dy: g = dy * act'(.) is stored, (sum g, sum g * xhat) -> finalize_bwd.
-template <int MODE>
-__global__ __launch_bounds__(256) void col_reduce_kernel(const float* __restrict__ z, const float* __restrict__ dy,
-                                                         const float* __restrict__ ss, int act, long rows, int C, int cp,
-                                                         long rows_per_chunk, float* __restrict__ gout, Arrive arr,
-                                                         FinFwd ff, FinBwd fb, float* colsum_out) {
+// in flight; (sum z, sum z^2) -> partial row -> finalize_fwd by the last block.
+__global__ __launch_bounds__(256) void col_stats_kernel(const float* __restrict__ z, long rows, int C, int cp, long rows_per_chunk,
+                                                        Arrive arr, FinFwd fin) {
     __shared__ float red[2][4][64];
     const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
     const int rsub = 64 / cp;
-    const int cl = lane & (cp - 1), rs = lane / cp;
-    const int c = cl;
+    const int c = lane & (cp - 1), rs = lane / cp;
     const long r0 = (long)blockIdx.y * rows_per_chunk;
     const long r1 = rows < r0 + rows_per_chunk ? rows : r0 + rows_per_chunk;
     float s0 = 0.0f, s1 = 0.0f;
     if (c < C) {
-        float sc = 1.0f, sh = 0.0f, mean = 0.0f, rstd = 1.0f;
-        if (MODE == 1) {
-            sc = ss[c];
-            sh = ss[C + c];
-            mean = ss[2 * C + c];
-            rstd = ss[3 * C + c];
-        }
         const long step = 4L * rsub;
         double t0 = 0.0, t1 = 0.0;
         float a0[4], a1[4];
@@ -1730,30 +1728,17 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const float* __restrict
         for (int u = 0; u < 4; ++u) a0[u] = a1[u] = 0.0f;
         int since_flush = 0;
         for (long m = r0 + (long)rg * rsub + rs; m < r1; m += 4 * step) {
-            float v[4], d[4];
+            float v[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const long mm = m + u * step;
-                const bool ok = mm < r1;
-                const long idx = (ok ? mm : m) * C + c;
-                v[u] = z[idx];
-                d[u] = MODE == 1 ? dy[idx] : 0.0f;
-                if (!ok) {
-                    v[u] = MODE == 1 ? mean : 0.0f;   // contributes nothing
-                    d[u] = 0.0f;
-                }
+                const float t = z[(mm < r1 ? mm : m) * C + c];
+                v[u] = mm < r1 ? t : 0.0f;
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                if (MODE == 0) {
-                    a0[u] += v[u];
-                    a1[u] = fmaf(v[u], v[u], a1[u]);
-                } else {
-                    const float gg = mb_act_passes(fmaf(v[u], sc, sh), act) ? d[u] : 0.0f;
-                    if (m + u * step < r1) gout[(m + u * step) * C + c] = gg;
-                    a0[u] += gg;
-                    a1[u] = fmaf(gg, (v[u] - mean) * rstd, a1[u]);
-                }
+                a0[u] += v[u];
+                a1[u] = fmaf(v[u], v[u], a1[u]);
             }
             if (++since_flush == 16) {   // short fp32 runs, fp64 totals
 #pragma unroll
@@ -1782,23 +1767,13 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const float* __restrict
         double t0 = 0.0, t1 = 0.0;
         for (int w = 0; w < 4; ++w)
             for (int qq = 0; qq < rsub; ++qq) {
-                t0 += (double)red[0][w][qq * cp + cl];
-                t1 += (double)red[1][w][qq * cp + cl];
+                t0 += (double)red[0][w][qq * cp + c];
+                t1 += (double)red[1][w][qq * cp + c];
             }
         v0 = (float)t0;
         v1 = (float)t1;
     }
-    if (!publish_and_arrive(arr, C, 0, blockIdx.y, gridDim.y, own, c, v0, v1)) return;
-    const int R2 = arrive_rows(gridDim.y);
-    if (colsum_out != nullptr) {
-        double t0, t1;
-        fold_partials(arr.part2, R2, C, lane, t0, t1);
-        if (rg == 0 && lane < C) colsum_out[lane] = (float)t0;
-    } else if (MODE == 0) {
-        finalize_fwd(arr.part2, R2, C, lane, ff);
-    } else {
-        finalize_bwd(arr.part2, R2, C, lane, fb);
-    }
+    if (publish_and_arrive(arr, C, 0, blockIdx.y, gridDim.y, own, c, v0, v1)) finalize_fwd(arr.part2, arrive_rows(gridDim.y), C, lane, fin);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -2020,9 +1995,8 @@ int howl_mobilenet_fwd(const float* params, float* buffers, int num_labels, cons
                 int rpc;
                 const int cp = col_pack(l.cout);
                 const int chunks = row_chunks(g.mz, 64 * (64 / cp), &rpc);
-                hipLaunchKernelGGL(col_reduce_kernel<0>, dim3(1, chunks), dim3(256), 0, stream, (const float*)z,
-                                   (const float*)nullptr, (const float*)nullptr, 0, g.mz, l.cout, cp, (long)rpc, (float*)nullptr,
-                                   arr, fin, FinBwd{}, (float*)nullptr);
+                hipLaunchKernelGGL(col_stats_kernel, dim3(1, chunks), dim3(256), 0, stream, (const float*)z, g.mz, l.cout, cp,
+                                   (long)rpc, arr, fin);
             }
         }
     }

@@ -9,13 +9,8 @@
  *     (thread-local).  No function allocates, frees, synchronises the device or takes ownership: the caller
  *     (PyTorch's caching allocator on the host side) owns every pointer, including workspaces.
  *   - all pointers are DEVICE pointers unless marked "host"; all tensors are contiguous fp32 unless noted.
- *   - every call takes the hipStream_t to enqueue on and is re-entrant.  Work is ordered on that stream only: the two
- *     backward entry points (howl_res8_bwd, howl_mobilenet_bwd) fork their weight-gradient launches onto a second,
- *     library-owned HIP queue and join it back with event record / wait pairs before they return, so from the caller's
- *     side they behave like any other call on `stream` (and can be captured into a hipGraph).  That queue (one
- *     non-blocking stream + 16 events per device, caller stream and entry point) is created on first use and lives as
- *     long as the process; HOWL_RES8_BWD_QUEUES=1 / HOWL_MOBILENET_BWD_QUEUES=1 in the environment keep everything on
- *     `stream`.
+ *   - every call takes the hipStream_t to enqueue on and is re-entrant.  All work is launched on that stream and on no
+ *     other (the calls can be captured into a hipGraph); the library owns no streams.
  */
 #ifndef HOWL_HIP_H
 #define HOWL_HIP_H
@@ -47,9 +42,8 @@ int howl_profile_enable(int on);
 int howl_profile_read(const char* tag, double* total_ms, int* count, int reset);
 int howl_profile_read_work(const char* tag, double* total_ms, int* count, double* work, int reset);
 
-/* Releases what the library keeps for the life of the process (the side HIP queues + events of howl_res8_bwd /
- * howl_mobilenet_bwd, profiling events).  Call once before the HIP runtime goes away (howl_amd/lib.py registers it with
- * atexit); the library recreates the resources if it is used again. */
+/* Releases what the library keeps for the life of the process (the HIP events of howl_profile_enable).  Call once before
+ * the HIP runtime goes away (howl_amd/lib.py registers it with atexit). */
 int howl_shutdown(void);
 
 /* ---------------------------------------------------------------------------------------------------

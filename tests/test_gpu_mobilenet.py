@@ -137,10 +137,11 @@ def test_pretrain_gsc_entry_point_mobilenet(tmp_path, monkeypatch):
     SETTINGS.reset()
 
 
-def test_two_queue_backward_is_bit_identical_to_single_queue(monkeypatch):
-    """howl_mobilenet_bwd puts the weight gradients on a side HIP queue (same kernels, same grids): four fused steps must
-    leave exactly the weights of the single-queue schedule (HOWL_MOBILENET_BWD_QUEUES=1) -- any race on the double-buffered
-    dz or the shared scratch would show up as a difference."""
+def test_fused_steps_are_bit_repeatable():
+    """Every per-channel reduction of the MobileNet kernels ends in "the last block to arrive folds the partial rows in index
+    order" (device-scope relaxed atomics, no fence: csrc/mobilenet.hip `Arrive`), and the data- and weight-gradient blocks of a
+    layer share a launch: four fused steps, run twice from the same seeds, must leave exactly the same weights -- a stale
+    partial row, a race on the shared partial buffers or an arrival counter left non-zero would show up as a difference."""
     from howl_amd.data.transform.operator import ZmuvTransform
     from howl_amd.data.transform.transform import StandardAudioTransform
     from howl_amd.training.fused import FusedTrainer
@@ -162,10 +163,10 @@ def test_two_queue_backward_is_bit_identical_to_single_queue(monkeypatch):
         torch.cuda.synchronize()
         return trainer.fp.flat.clone()
 
-    two = run()
-    assert torch.equal(run(), two)
-    monkeypatch.setenv("HOWL_MOBILENET_BWD_QUEUES", "1")
-    assert torch.equal(run(), two)
+    first = run()
+    assert torch.isfinite(first).all()
+    for _ in range(3):
+        assert torch.equal(run(), first)
 
 
 def test_config5_at_full_size_with_device_collate():
