@@ -316,7 +316,13 @@ struct Arrive {
 __device__ __forceinline__ void st_agent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ float ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-__device__ __forceinline__ bool arrive(unsigned* counter, unsigned expected) {
+// `overlap()` runs in every thread while thread 0's arrival is on its way (~2 us to the device-coherent level and back): the
+// pointwise kernels issue the stores of their last output tile there, so the arrival does not wait for them.
+struct NoOverlap {
+    __device__ __forceinline__ void operator()() const {}
+};
+template <class Overlap>
+__device__ __forceinline__ bool arrive(unsigned* counter, unsigned expected, const Overlap& overlap) {
     __shared__ unsigned ticket;
     __atomic_signal_fence(__ATOMIC_SEQ_CST);
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this thread's write-through stores are visible device-wide
@@ -327,6 +333,7 @@ __device__ __forceinline__ bool arrive(unsigned* counter, unsigned expected) {
         if (t == expected - 1) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         ticket = t;
     }
+    overlap();
     __syncthreads();
     return ticket == expected - 1;
 }
@@ -334,8 +341,9 @@ __device__ __forceinline__ bool arrive(unsigned* counter, unsigned expected) {
 // Block `by` of the R1 blocks that share channel block `cb` (64 channels from 64 cb); the thread with `own` holds this
 // block's (v0, v1) of column c_own.  Returns true in the one block of the channel block that must finalise; a.part2 then
 // holds all groups' rows.
+template <class Overlap = NoOverlap>
 __device__ __forceinline__ bool publish_and_arrive(const Arrive& a, int C, int cb, int by, int R1, bool own, int c_own, float v0,
-                                                   float v1) {
+                                                   float v1, const Overlap& overlap = Overlap()) {
     __shared__ float red[2][4][64];
     const int c0 = cb * 64;
     // groups of G blocks, G the smallest size that leaves <= MB_R2 groups: launches with few blocks along the rows (most of
@@ -347,7 +355,7 @@ __device__ __forceinline__ bool publish_and_arrive(const Arrive& a, int C, int c
             st_agent(&a.part2[((size_t)by * 2 + 0) * C + c_own], v0);
             st_agent(&a.part2[((size_t)by * 2 + 1) * C + c_own], v1);
         }
-        return arrive(a.cnt2 + cb, R2);
+        return arrive(a.cnt2 + cb, R2, overlap);
     }
     if (own) {
         st_agent(&a.part1[((size_t)by * 2 + 0) * C + c_own], v0);
@@ -355,7 +363,7 @@ __device__ __forceinline__ bool publish_and_arrive(const Arrive& a, int C, int c
     }
     const int group = by / G, g0 = group * G;
     const int gsize = R1 - g0 < G ? R1 - g0 : G;
-    if (!arrive(a.cnt1 + cb * MB_R2 + group, gsize)) return false;
+    if (!arrive(a.cnt1 + cb * MB_R2 + group, gsize, overlap)) return false;
     const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
     const int c = c0 + lane < C ? c0 + lane : C - 1;
     float r0[MB_G / 4], r1[MB_G / 4];
@@ -379,7 +387,7 @@ __device__ __forceinline__ bool publish_and_arrive(const Arrive& a, int C, int c
         st_agent(&a.part2[((size_t)group * 2 + 0) * C + c], ((red[0][0][lane] + red[0][1][lane]) + red[0][2][lane]) + red[0][3][lane]);
         st_agent(&a.part2[((size_t)group * 2 + 1) * C + c], ((red[1][0][lane] + red[1][1][lane]) + red[1][2][lane]) + red[1][3][lane]);
     }
-    return arrive(a.cnt2 + cb, R2);
+    return arrive(a.cnt2 + cb, R2, NoOverlap());
 }
 
 __device__ __forceinline__ int arrive_rows(int R1) {   // rows of part2 after publish_and_arrive over R1 blocks
@@ -587,6 +595,21 @@ __global__ __launch_bounds__(256) void pw_fwd_kernel(const float* __restrict__ a
     const int t0 = blockIdx.y * tiles_per_block;
     const int t1 = min(row_tiles, t0 + tiles_per_block);
     float cs[2] = {0.0f, 0.0f}, cq[2] = {0.0f, 0.0f};
+    f32x4 acc[2][2];     // the last tile's results stay in registers: its stores are issued under the arrival (see `arrive`)
+    auto store_tile = [&](int m0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int n = n0 + 32 * wc + 16 * j + (lane & 15);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = m0 + 32 * wr + 16 * i + 4 * (lane >> 4) + r;
+                    if (m < M && n < N) z[(long)m * N + n] = acc[i][j][r];
+                }
+            }
+    };
+    const bool stats = arr.part1 != nullptr;
     for (int t = t0; t < t1; ++t) {
         const int m0 = t * GT;
         const float* ap[4];
@@ -631,7 +654,6 @@ __global__ __launch_bounds__(256) void pw_fwd_kernel(const float* __restrict__ a
                 *reinterpret_cast<float4*>(&Bs[(p_r + 16 * i) * LDK + p_k]) = (b_ok[i] && kok) ? sg.vb[i] : f4_zero();
             }
         };
-        f32x4 acc[2][2];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -657,22 +679,19 @@ __global__ __launch_bounds__(256) void pw_fwd_kernel(const float* __restrict__ a
                 __syncthreads();
             }
         }
+        if (!(stats && t == t1 - 1)) store_tile(m0);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int n = n0 + 32 * wc + 16 * j + (lane & 15);
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int m = m0 + 32 * wr + 16 * i + 4 * (lane >> 4) + r;
                     const float v = acc[i][j][r];          // rows >= M and columns >= N are exact zeros
-                    if (m < M && n < N) z[(long)m * N + n] = v;
                     cs[j] += v;
                     cq[j] = fmaf(v, v, cq[j]);
                 }
-            }
     }
-    if (arr.part1 == nullptr) return;
+    if (!stats) return;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         cs[j] += __shfl_xor(cs[j], 16);
@@ -687,7 +706,8 @@ __global__ __launch_bounds__(256) void pw_fwd_kernel(const float* __restrict__ a
     __syncthreads();
     const bool own = tid < 64 && n0 + tid < N;
     const float v0 = own ? sred[0][0][tid] + sred[0][1][tid] : 0.0f, v1 = own ? sred[1][0][tid] + sred[1][1][tid] : 0.0f;
-    if (publish_and_arrive(arr, N, blockIdx.x, blockIdx.y, gridDim.y, own, n0 + tid, v0, v1))
+    const int m_last = (t1 - 1) * GT;
+    if (publish_and_arrive(arr, N, blockIdx.x, blockIdx.y, gridDim.y, own, n0 + tid, v0, v1, [&]() { store_tile(m_last); }))
         finalize_fwd(arr.part2, arrive_rows(gridDim.y), N, n0 + lane, fin);
 }
 
@@ -751,6 +771,20 @@ __device__ __forceinline__ void pw_dgrad_body(float* lds, const PwBwd& p, int bx
     const int t0 = by * p.tiles_per_block;
     const int t1 = min(row_tiles, t0 + p.tiles_per_block);
     float s1[2] = {0.0f, 0.0f}, s2[2] = {0.0f, 0.0f};
+    float gq[2][2][4];     // g_j of the current tile; the last tile's stores are issued under the arrival
+    auto store_tile = [&](int m0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int c = c0 + 32 * wc + 16 * j + (lane & 15);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = m0 + 32 * wr + 16 * i + 4 * (lane >> 4) + r;
+                    if (m < M && c < C) p.e.gj[(long)m * C + c] = gq[i][j][r];
+                }
+            }
+    };
     for (int t = t0; t < t1; ++t) {
         const int m0 = t * GT;
         long arow[4];
@@ -836,11 +870,12 @@ __device__ __forceinline__ void pw_dgrad_body(float* lds, const PwBwd& p, int bx
                     const float zv = zj[i][j][r];
                     const bool pass = mb_act_passes(fmaf(zv, jsc[j], jsh[j]), p.e.act);
                     const float gg = (ok && pass) ? dy : 0.0f;
-                    if (ok) p.e.gj[(long)m * C + c] = gg;
+                    gq[i][j][r] = gg;
                     s1[j] += gg;
                     s2[j] = fmaf(gg, (zv - jme[j]) * jrs[j], s2[j]);
                 }
             }
+        if (t != t1 - 1) store_tile(m0);
     }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -856,7 +891,8 @@ __device__ __forceinline__ void pw_dgrad_body(float* lds, const PwBwd& p, int bx
     __syncthreads();
     const bool own = tid < 64 && c0 + tid < C;
     const float v0 = own ? sred[0][0][tid] + sred[0][1][tid] : 0.0f, v1 = own ? sred[1][0][tid] + sred[1][1][tid] : 0.0f;
-    if (publish_and_arrive(p.arr, C, bx, by, p.d_ry, own, c0 + tid, v0, v1))
+    const int m_last = (t1 - 1) * GT;
+    if (publish_and_arrive(p.arr, C, bx, by, p.d_ry, own, c0 + tid, v0, v1, [&]() { store_tile(m_last); }))
         finalize_bwd(p.arr.part2, arrive_rows(p.d_ry), C, c0 + lane, p.fin);
 }
 
@@ -1356,7 +1392,9 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const float* __restrict__ x
     constexpr int NIN = (DW_SEG - 1) * STRIDE + 3;     // input columns under DW_SEG outputs
     __shared__ float red[2][4][64];
     const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + lane;
+    // layers of <= 32 channels (the 266 k-pixel first block) put TWO image rows into a wave, 32 lanes each
+    const int rsub = C <= 32 ? 2 : 1, rs = rsub == 2 ? lane >> 5 : 0;
+    const int c = blockIdx.x * 64 + (rsub == 2 ? lane & 31 : lane);
     const bool cok = c < C;
     const int cc = cok ? c : C - 1;
     float wk[9];
@@ -1366,7 +1404,7 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const float* __restrict__ x
     const int r0 = blockIdx.y * rows_per_chunk;
     const int r1 = min(nrows, r0 + rows_per_chunk);
     float s = 0.0f, q = 0.0f;
-    for (int t = r0 + rg; t < r1; t += 4) {
+    for (int t = r0 + rg * rsub + rs; t < r1; t += 4 * rsub) {
         const int b = t / Ho, oh = t - b * Ho;
         const float* xb = x + (long)b * H * W * C + cc;
         float* zr = z + (long)t * Wo * C + cc;
@@ -1407,14 +1445,18 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const float* __restrict__ x
         }
     }
     if (arr.part1 == nullptr) return;
+    if (rsub == 2) {
+        s += __shfl_xor(s, 32);
+        q += __shfl_xor(q, 32);
+    }
     red[0][rg][lane] = s;
     red[1][rg][lane] = q;
     __syncthreads();
-    const bool own = rg == 0 && cok;
+    const bool own = rg == 0 && rs == 0 && cok;
     const float v0 = ((red[0][0][lane] + red[0][1][lane]) + red[0][2][lane]) + red[0][3][lane];
     const float v1 = ((red[1][0][lane] + red[1][1][lane]) + red[1][2][lane]) + red[1][3][lane];
     if (publish_and_arrive(arr, C, blockIdx.x, blockIdx.y, gridDim.y, own, c, v0, v1))
-        finalize_fwd(arr.part2, arrive_rows(gridDim.y), C, c, fin);
+        finalize_fwd(arr.part2, arrive_rows(gridDim.y), C, blockIdx.x * 64 + lane, fin);     // one lane per column
 }
 
 // data gradient over the INPUT rows (b, ih): dy_j[b,ih,iw,c] = sum_tap w[c*9+tap] * dz[b,oh,ow,c] over the outputs whose
@@ -1449,7 +1491,9 @@ __device__ __forceinline__ void dw_dgrad_body(const DwBwd& p, int cb, int by) {
     constexpr int NCOL = STRIDE == 1 ? DW_SEG + 2 : (DW_SEG + 1) / STRIDE + 2;   // 6 at stride 1, 4 at stride 2
     __shared__ float red[2][4][64];
     const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
-    const int c = cb * 64 + lane;
+    // layers of <= 32 channels (the 266 k-pixel first block) put TWO image rows into a wave, 32 lanes each
+    const int rsub = C <= 32 ? 2 : 1, rs = rsub == 2 ? lane >> 5 : 0;
+    const int c = cb * 64 + (rsub == 2 ? lane & 31 : lane);
     const bool cok = c < C;
     const int cc = cok ? c : C - 1;
     float wk[9];
@@ -1460,7 +1504,7 @@ __device__ __forceinline__ void dw_dgrad_body(const DwBwd& p, int cb, int by) {
     const int r0 = by * rows_per_chunk;
     const int r1 = min(nrows, r0 + rows_per_chunk);
     float s1 = 0.0f, s2 = 0.0f;
-    for (int t = r0 + rg; t < r1; t += 4) {
+    for (int t = r0 + rg * rsub + rs; t < r1; t += 4 * rsub) {
         const int b = t / H, ih = t - b * H;
         const float* gb = g + (long)b * Ho * Wo * C + cc;
         const float* zb = zk + (long)b * Ho * Wo * C + cc;
@@ -1521,14 +1565,18 @@ __device__ __forceinline__ void dw_dgrad_body(const DwBwd& p, int cb, int by) {
             }
         }
     }
+    if (rsub == 2) {
+        s1 += __shfl_xor(s1, 32);
+        s2 += __shfl_xor(s2, 32);
+    }
     red[0][rg][lane] = s1;
     red[1][rg][lane] = s2;
     __syncthreads();
-    const bool own = rg == 0 && cok;
+    const bool own = rg == 0 && rs == 0 && cok;
     const float v0 = ((red[0][0][lane] + red[0][1][lane]) + red[0][2][lane]) + red[0][3][lane];
     const float v1 = ((red[1][0][lane] + red[1][1][lane]) + red[1][2][lane]) + red[1][3][lane];
     if (publish_and_arrive(p.arr, C, cb, by, p.d_chunks, own, c, v0, v1))
-        finalize_bwd(p.arr.part2, arrive_rows(p.d_chunks), C, c, p.fin);
+        finalize_bwd(p.arr.part2, arrive_rows(p.d_chunks), C, cb * 64 + lane, p.fin);     // one lane per column
 }
 
 // weight gradient: dW[c][tap] = sum_{b,oh,ow} dz[.,c] * y_in[shifted, c]; both factors rebuilt on load.
@@ -1545,7 +1593,9 @@ __device__ __forceinline__ void dw_wgrad_body(const DwBwd& p, int cb, int by) {
     constexpr int NIN = (DW_SEG - 1) * STRIDE + 3;
     __shared__ float red[4][9][64];
     const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
-    const int c = cb * 64 + lane;
+    // layers of <= 32 channels (the 266 k-pixel first block) put TWO image rows into a wave, 32 lanes each
+    const int rsub = C <= 32 ? 2 : 1, rs = rsub == 2 ? lane >> 5 : 0;
+    const int c = cb * 64 + (rsub == 2 ? lane & 31 : lane);
     const bool cok = c < C;
     const int cc = cok ? c : C - 1;
     const float ksc = bc[cc], kc1 = bc[C + cc], kc0 = bc[2 * C + cc];
@@ -1555,7 +1605,7 @@ __device__ __forceinline__ void dw_wgrad_body(const DwBwd& p, int cb, int by) {
     float acc[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t) acc[t] = 0.0f;
-    for (int t = r0 + rg; t < r1; t += 4) {
+    for (int t = r0 + rg * rsub + rs; t < r1; t += 4 * rsub) {
         const int b = t / Ho, oh = t - b * Ho;
         const float* xb = x + (long)b * H * W * C + cc;
         const float* gr = g + (long)t * Wo * C + cc;
@@ -1597,9 +1647,9 @@ __device__ __forceinline__ void dw_wgrad_body(const DwBwd& p, int cb, int by) {
         }
     }
 #pragma unroll
-    for (int t = 0; t < 9; ++t) red[rg][t][lane] = acc[t];
+    for (int t = 0; t < 9; ++t) red[rg][t][lane] = rsub == 2 ? acc[t] + __shfl_xor(acc[t], 32) : acc[t];
     __syncthreads();
-    if (rg == 0 && cok) {
+    if (rg == 0 && rs == 0 && cok) {
 #pragma unroll
         for (int t = 0; t < 9; ++t)
             part[(size_t)by * C * 9 + c * 9 + t] = ((red[0][t][lane] + red[1][t][lane]) + red[2][t][lane]) + red[3][t][lane];
