@@ -144,7 +144,7 @@ struct Plan {
     std::vector<size_t> z, y, gr, ss, bc, slab;  // float offsets (y: 0 when not materialised)
     std::vector<int> nslab;                          // slabs of the layer's weight gradient
     size_t dz = 0, slab0b = 0, part = 0, part2 = 0, counters = 0, head_scratch = 0, bias_scratch = 0, pooled = 0,
-           pooled_d = 0, dpooled = 0;
+           pooled_d = 0;
     size_t total_floats = 0;
 };
 
@@ -253,7 +253,6 @@ Plan make_plan(int B, int H0, int W0, int num_labels) {
     p.bias_scratch = take((size_t)64 * std::max(num_labels, 64));
     p.pooled = take((size_t)B * MB_LAST);
     p.pooled_d = take((size_t)B * MB_LAST);
-    p.dpooled = take((size_t)B * MB_LAST);
     p.total_floats = off;
     return p;
 }
@@ -1673,44 +1672,76 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(DwBwd p) {
 // network tail: adaptive_avg_pool2d(1) over relu6(bn(z_last)) (+ dropout), and its backward fused with the last layer's
 // BatchNorm-backward reduction
 // ---------------------------------------------------------------------------------------------------------
-__global__ void avgpool_bn_fwd_kernel(const float* __restrict__ z, const float* __restrict__ ss, int HW, int C,
-                                      const float* __restrict__ mask, float scale, long total, float* __restrict__ pooled,
-                                      float* __restrict__ pooled_d) {
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int c = chan_of(idx, C);
-        const long b = idx / C;
-        const float sc = ss[c], sh = ss[C + c];
-        float acc = 0.0f;
-        for (int p = 0; p < HW; ++p) acc += relu6f(fmaf(z[(b * HW + p) * C + c], sc, sh));
-        const float v = acc / (float)HW;
-        pooled[idx] = v;
-        pooled_d[idx] = mask != nullptr ? v * mask[idx] * scale : v;
+// One block per utterance: pooled[b][c] = mean_p relu6(bn(z_last[b,p,c])), pooled_d = dropout(pooled), and the classifier
+// logits[b][l] = pooled_d[b] . W[l] + bias[l] (a (B x 1280) x (1280 x L) product with L ~ 12: as a tile GEMM it was 80 dependent
+// k-steps on 8 blocks).  A thread keeps its channels' pooled_d in registers; per label: partial dot product, wave sum, four
+// wave results folded in order.
+constexpr int POOL_CPT = 8;     // channels per thread: up to 2048 channels per block
+__global__ __launch_bounds__(256) void pool_classify_kernel(const float* __restrict__ z, const float* __restrict__ ss, int HW, int C,
+                                                            const float* __restrict__ mask, float scale,
+                                                            const float* __restrict__ wc, const float* __restrict__ bias, int L,
+                                                            float* __restrict__ pooled, float* __restrict__ pooled_d,
+                                                            float* __restrict__ logits) {
+    __shared__ float red[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long b = blockIdx.x;
+    float pd[POOL_CPT];
+#pragma unroll
+    for (int u = 0; u < POOL_CPT; ++u) {
+        const int c = tid + 256 * u;
+        pd[u] = 0.0f;
+        if (c < C) {
+            const float sc = ss[c], sh = ss[C + c];
+            float acc = 0.0f;
+            for (int p = 0; p < HW; ++p) acc += relu6f(fmaf(z[(b * HW + p) * C + c], sc, sh));
+            const float v = acc / (float)HW;
+            pooled[b * C + c] = v;
+            pd[u] = mask != nullptr ? v * mask[b * C + c] * scale : v;
+            pooled_d[b * C + c] = pd[u];
+        }
+    }
+    for (int l = 0; l < L; ++l) {
+        float t = 0.0f;
+#pragma unroll
+        for (int u = 0; u < POOL_CPT; ++u) {
+            const int c = tid + 256 * u;
+            t = fmaf(pd[u], c < C ? wc[(long)l * C + c] : 0.0f, t);
+        }
+        t = wave_sum(t);
+        __syncthreads();     // the previous label's readers are done with `red`
+        if (lane == 0) red[wave] = t;
+        __syncthreads();
+        if (tid == 0) logits[b * L + l] = (((red[0] + red[1]) + red[2]) + red[3]) + bias[l];
     }
 }
 
+// dpooled[b,c] = sum_l dlogits[b,l] * W[l,c] (the classifier's data gradient, L ~ 12 terms, rebuilt per element);
 // dy[b,p,c] = dpooled[b,c] (* mask * scale) / HW -> g, partial sums, finalize (block = 64 channels x a chunk of pixel rows)
-__global__ __launch_bounds__(256) void avgpool_bwd_reduce_kernel(const float* __restrict__ dpooled, const float* __restrict__ mask,
-                                                                 float scale, int HW, int C, long rows, int rows_per_chunk,
-                                                                 EpiBwd e, Arrive arr, FinBwd fin) {
+__global__ __launch_bounds__(256) void avgpool_bwd_reduce_kernel(const float* __restrict__ dlogits, const float* __restrict__ wc,
+                                                                 int L, const float* __restrict__ mask, float scale, int HW, int C,
+                                                                 int B, int utts_per_chunk, EpiBwd e, Arrive arr, FinBwd fin) {
     __shared__ float red[2][4][64];
     const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
     const bool cok = c < C;
     const int cc = cok ? c : C - 1;
     const float jsc = e.ssj[cc], jsh = e.ssj[C + cc], jme = e.ssj[2 * C + cc], jrs = e.ssj[3 * C + cc];
-    const long r0 = (long)blockIdx.y * rows_per_chunk;
-    const long r1 = rows < r0 + rows_per_chunk ? rows : r0 + rows_per_chunk;
+    const int b0 = blockIdx.y * utts_per_chunk;
+    const int b1 = min(B, b0 + utts_per_chunk);
     float s1 = 0.0f, s2 = 0.0f;
-    for (long m = r0 + rg; m < r1; m += 4) {
-        const long b = m / HW;
-        float d = dpooled[b * C + cc];
+    for (long b = b0 + rg; b < b1; b += 4) {     // a wave takes an utterance: its gradient once, then its HW pixels
+        float d = 0.0f;
+        for (int l = 0; l < L; ++l) d = fmaf(dlogits[b * L + l], wc[(long)l * C + cc], d);
         if (mask != nullptr) d *= mask[b * C + cc] * scale;
         d = d / (float)HW;
-        const float zv = e.zj[m * C + cc];
-        const float gg = mb_act_passes(fmaf(zv, jsc, jsh), e.act) ? d : 0.0f;
-        if (cok) e.gj[m * C + c] = gg;
-        s1 += gg;
-        s2 = fmaf(gg, (zv - jme) * jrs, s2);
+        for (int px = 0; px < HW; ++px) {
+            const long m = b * HW + px;
+            const float zv = e.zj[m * C + cc];
+            const float gg = mb_act_passes(fmaf(zv, jsc, jsh), e.act) ? d : 0.0f;
+            if (cok) e.gj[m * C + c] = gg;
+            s1 += gg;
+            s2 = fmaf(gg, (zv - jme) * jrs, s2);
+        }
     }
     red[0][rg][lane] = s1;
     red[1][rg][lane] = s2;
@@ -2051,14 +2082,12 @@ int howl_mobilenet_fwd(const float* params, float* buffers, int num_labels, cons
         }
     }
     const Geo& gl = c.p.g[nl - 1];
-    const long tp = (long)B * MB_LAST;
-    hipLaunchKernelGGL(avgpool_bn_fwd_kernel, dim3(flat_grid(tp)), dim3(256), 0, stream, (const float*)(c.ws + c.p.z[nl - 1]),
-                       (const float*)(c.ws + c.p.ss[nl - 1]), gl.hy * gl.wy, MB_LAST, training ? drop_mask : (const float*)nullptr,
-                       drop_scale, tp, c.ws + c.p.pooled, c.ws + c.p.pooled_d);
     const float* wc = params + c.n->feature_params;
     const float* bcl = wc + (size_t)num_labels * MB_LAST;
-    gemm(stream, true, c.ws + c.p.pooled_d, lin(MB_LAST), 1, lin(0), wc, lin(1), MB_LAST, B, num_labels, MB_LAST, 1, bcl, 0,
-         logits, num_labels, 0);
+    static_assert(MB_LAST <= 256 * POOL_CPT, "pool_classify_kernel: channels per block");
+    hipLaunchKernelGGL(pool_classify_kernel, dim3((unsigned)B), dim3(256), 0, stream, (const float*)(c.ws + c.p.z[nl - 1]),
+                       (const float*)(c.ws + c.p.ss[nl - 1]), gl.hy * gl.wy, MB_LAST, training ? drop_mask : (const float*)nullptr,
+                       drop_scale, wc, bcl, num_labels, c.ws + c.p.pooled, c.ws + c.p.pooled_d, logits);
     HOWL_CHECK_LAUNCH("howl_mobilenet_fwd");
     return HOWL_OK;
 }
@@ -2081,17 +2110,14 @@ int howl_mobilenet_bwd(const float* params, int num_labels, const float* x, long
     const float* wc = params + c.n->feature_params;
     float* gwc = grads + c.n->feature_params;
     float* gbc = gwc + (size_t)num_labels * MB_LAST;
-    float* dpooled = c.ws + c.p.dpooled;
-    gemm(stream, true, dlogits, lin(num_labels), 1, lin(0), wc, lin(MB_LAST), 1, B, MB_LAST, num_labels, 1, nullptr, 0, dpooled,
-         MB_LAST, 0);
     {
         // gradient of the pooled features -> g, bc of the last layer
         const int L = nl - 1;
         const Geo& gl = c.p.g[L];
-        int rpc;
-        const int chunks = row_chunks(gl.mz, 8, &rpc);
+        int upc;
+        const int chunks = row_chunks(B, 4, &upc);
         hipLaunchKernelGGL(avgpool_bwd_reduce_kernel, dim3((MB_LAST + 63) / 64, chunks), dim3(256), 0, stream,
-                           (const float*)dpooled, drop_mask, drop_scale, gl.hy * gl.wy, MB_LAST, gl.mz, rpc, epi_bwd(c, L), arr,
+                           dlogits, wc, num_labels, drop_mask, drop_scale, gl.hy * gl.wy, MB_LAST, B, upc, epi_bwd(c, L), arr,
                            fin_bwd(c, L, grads));
     }
     wgrad_gemm(stream, dlogits, lin(num_labels), num_labels, c.ws + c.p.pooled_d, lin(MB_LAST), MB_LAST, B,
