@@ -129,7 +129,7 @@ constexpr int MB_R2 = 64;         // groups (second level); a reduction has at m
 constexpr int MB_R = MB_G * MB_R2;
 constexpr int MB_MAXC = 1280;     // widest layer
 constexpr int MB_MAXK = 960;      // widest input of a pointwise layer that is normalised on load
-constexpr int MB_CBLOCKS = 32;    // 64-channel blocks of the widest layer (20), rounded up
+constexpr int MB_CBLOCKS = 64;    // channel blocks of a launch: 64 wide (<= 20) or 32 wide (<= 40)
 constexpr int MB_COUNTERS = MB_CBLOCKS * (MB_R2 + 1);   // arrival counters: per channel block, one per group + one for the groups
 constexpr int MB_MAX_JOBS = 60;   // deferred slab sums of one backward call (53 convolution weights)
 constexpr int DW_SEG = 4;
@@ -149,13 +149,18 @@ struct Plan {
 };
 
 // row tiles of a pointwise launch: each block takes a run of consecutive 64-row tiles
-inline void pw_rows(long M, int col_tiles, int* tiles_per_block, int* blocks) {
-    const int row_tiles = (int)((M + 63) / 64);
+inline void pw_rows(long M, int col_tiles, int* tiles_per_block, int* blocks, int tile = 64) {
+    const int row_tiles = (int)((M + tile - 1) / tile);
     int tpb = (int)(((long)row_tiles * col_tiles + 4095) / 4096);     // ~4096 blocks at most ...
     if (tpb < (row_tiles + MB_R - 1) / MB_R) tpb = (row_tiles + MB_R - 1) / MB_R;   // ... and <= MB_R of them along the rows
     if (tpb < 1) tpb = 1;
     *tiles_per_block = tpb;
     *blocks = (row_tiles + tpb - 1) / tpb;
+}
+// tile edge of a pointwise product with an (M x n) result: 32 when 64 x 64 tiles would not give every CU a block
+inline int pw_tile(long M, int n) {
+    const long tiles64 = ((M + 63) / 64) * ((n + 63) / 64);
+    return tiles64 < (long)howl_num_cus() ? 32 : 64;
 }
 // The weight-gradient blocks of a pointwise backward launch run beside its data-gradient blocks: a split is sized so that both
 // kinds take about the same number of 64-deep steps (data gradient: tiles_per_block x ceil(N / 64)), which keeps the slabs
@@ -337,14 +342,14 @@ __device__ __forceinline__ bool arrive(unsigned* counter, unsigned expected, con
     return ticket == expected - 1;
 }
 
-// Block `by` of the R1 blocks that share channel block `cb` (64 channels from 64 cb); the thread with `own` holds this
+// Block `by` of the R1 blocks that share channel block `cb` (cw channels from cw * cb); the thread with `own` holds this
 // block's (v0, v1) of column c_own.  Returns true in the one block of the channel block that must finalise; a.part2 then
 // holds all groups' rows.
 template <class Overlap = NoOverlap>
 __device__ __forceinline__ bool publish_and_arrive(const Arrive& a, int C, int cb, int by, int R1, bool own, int c_own, float v0,
-                                                   float v1, const Overlap& overlap = Overlap()) {
+                                                   float v1, const Overlap& overlap = Overlap(), int cw = 64) {
     __shared__ float red[2][4][64];
-    const int c0 = cb * 64;
+    const int c0 = cb * cw;     // channel blocks are cw <= 64 channels wide (lanes >= cw idle in the folds)
     // groups of G blocks, G the smallest size that leaves <= MB_R2 groups: launches with few blocks along the rows (most of
     // this network) have G = 1 and skip the first level altogether -- their rows ARE the group rows
     const int G = (R1 + MB_R2 - 1) / MB_R2;
@@ -382,7 +387,7 @@ __device__ __forceinline__ bool publish_and_arrive(const Arrive& a, int C, int c
     red[0][rg][lane] = t0;
     red[1][rg][lane] = t1;
     __syncthreads();
-    if (rg == 0 && c0 + lane < C) {
+    if (rg == 0 && lane < cw && c0 + lane < C) {
         st_agent(&a.part2[((size_t)group * 2 + 0) * C + c], ((red[0][0][lane] + red[0][1][lane]) + red[0][2][lane]) + red[0][3][lane]);
         st_agent(&a.part2[((size_t)group * 2 + 1) * C + c], ((red[1][0][lane] + red[1][1][lane]) + red[1][2][lane]) + red[1][3][lane]);
     }
@@ -499,41 +504,43 @@ __device__ __forceinline__ float4 dz4(float4 g, float4 z, float4 sc, float4 c1, 
 __device__ __forceinline__ float f4_get(const float4& v, int e) { return e == 0 ? v.x : (e == 1 ? v.y : (e == 2 ? v.z : v.w)); }
 
 // `groups` x 16 k of the step: A and B both [row][k]
-__device__ __forceinline__ void mma_kk(const float* As, const float* Bs, f32x4 (&acc)[2][2], int groups, int wr, int wc,
-                                       int lane) {
+template <int WT>
+__device__ __forceinline__ void mma_kk(const float* As, const float* Bs, f32x4 (&acc)[WT][WT], int groups, int wr,
+                                       int wc, int lane) {
     const int q = lane >> 4, l15 = lane & 15;
     for (int t = 0; t < groups; ++t) {
-        float4 a[2], b[2];
+        float4 a[WT], b[WT];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const float4*>(&As[(32 * wr + 16 * i + l15) * LDK + 16 * t + 4 * q]);
+        for (int i = 0; i < WT; ++i) a[i] = *reinterpret_cast<const float4*>(&As[(16 * WT * wr + 16 * i + l15) * LDK + 16 * t + 4 * q]);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const float4*>(&Bs[(32 * wc + 16 * j + l15) * LDK + 16 * t + 4 * q]);
+        for (int j = 0; j < WT; ++j) b[j] = *reinterpret_cast<const float4*>(&Bs[(16 * WT * wc + 16 * j + l15) * LDK + 16 * t + 4 * q]);
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < WT; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < WT; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4_get(a[i], e), f4_get(b[j], e), acc[i][j], 0, 0, 0);
     }
 }
 // A [row][k], B [k][col]
-__device__ __forceinline__ void mma_kc(const float* As, const float* Bs, f32x4 (&acc)[2][2], int groups, int wr, int wc,
-                                       int lane) {
+template <int WT>
+__device__ __forceinline__ void mma_kc(const float* As, const float* Bs, f32x4 (&acc)[WT][WT], int groups, int wr,
+                                       int wc, int lane) {
     const int q = lane >> 4, l15 = lane & 15;
     for (int t = 0; t < groups; ++t) {
-        float4 a[2];
+        float4 a[WT];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const float4*>(&As[(32 * wr + 16 * i + l15) * LDK + 16 * t + 4 * q]);
+        for (int i = 0; i < WT; ++i) a[i] = *reinterpret_cast<const float4*>(&As[(16 * WT * wr + 16 * i + l15) * LDK + 16 * t + 4 * q]);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            float b[2];
+            float b[WT];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) b[j] = Bs[(16 * t + 4 * q + e) * LDC + 32 * wc + 16 * j + l15];
+            for (int j = 0; j < WT; ++j) b[j] = Bs[(16 * t + 4 * q + e) * LDC + 16 * WT * wc + 16 * j + l15];
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < WT; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < WT; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4_get(a[i], e), b[j], acc[i][j], 0, 0, 0);
         }
     }
@@ -570,51 +577,55 @@ __device__ __forceinline__ void mma_cc(const float* As, const float* Bs, f32x4 (
 struct PwFwdStage {
     float4 va[4], vb[4], vr[4], xsc, xsh;
 };
-template <int XF, bool DEEP>
+template <int XF, bool DEEP, int WT>
 __global__ __launch_bounds__(256) void pw_fwd_kernel(const float* __restrict__ a, const float* __restrict__ ss_in,
                                                      const float* __restrict__ w, const float* __restrict__ res,
                                                      float* __restrict__ y_out, int M, int N, int K, int tiles_per_block,
                                                      float* __restrict__ z, Arrive arr, FinFwd fin) {
-    __shared__ __attribute__((aligned(16))) float lds[2 * 64 * LDK];
-    __shared__ float sred[2][2][64];
+    constexpr int TR = 32 * WT;      // rows and columns of the block tile (2 x 2 waves x WT x WT MFMA tiles)
+    constexpr int NP = TR / 16;      // operand pieces per thread and step
+    __shared__ __attribute__((aligned(16))) float lds[2 * TR * LDK];
+    __shared__ float sred[2][2][TR];
     float* As = lds;
-    float* Bs = lds + 64 * LDK;
+    float* Bs = lds + TR * LDK;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
-    const int n0 = blockIdx.x * GT;
-    const int p_r = tid >> 4, p_k = (tid & 15) * 4;   // pieces: rows p_r + 16 i (i < 4), 4 consecutive k from p_k
-    const float* bp[4];
-    bool b_ok[4];
+    const int n0 = blockIdx.x * TR;
+    const int p_r = tid >> 4, p_k = (tid & 15) * 4;   // pieces: rows p_r + 16 i (i < NP), 4 consecutive k from p_k
+    const float* bp[NP];
+    bool b_ok[NP];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NP; ++i) {
         bp[i] = w + (long)min(n0 + p_r + 16 * i, N - 1) * K;
         b_ok[i] = n0 + p_r + 16 * i < N;
     }
-    const int row_tiles = (M + GT - 1) / GT;
+    const int row_tiles = (M + TR - 1) / TR;
     const int t0 = blockIdx.y * tiles_per_block;
     const int t1 = min(row_tiles, t0 + tiles_per_block);
-    float cs[2] = {0.0f, 0.0f}, cq[2] = {0.0f, 0.0f};
-    f32x4 acc[2][2];     // the last tile's results stay in registers: its stores are issued under the arrival (see `arrive`)
+    float cs[WT], cq[WT];
+#pragma unroll
+    for (int j = 0; j < WT; ++j) cs[j] = cq[j] = 0.0f;
+    f32x4 acc[WT][WT];     // the last tile's results stay in registers: its stores are issued under the arrival (see `arrive`)
     auto store_tile = [&](int m0) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < WT; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int n = n0 + 32 * wc + 16 * j + (lane & 15);
+            for (int j = 0; j < WT; ++j) {
+                const int n = n0 + 16 * WT * wc + 16 * j + (lane & 15);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int m = m0 + 32 * wr + 16 * i + 4 * (lane >> 4) + r;
+                    const int m = m0 + 16 * WT * wr + 16 * i + 4 * (lane >> 4) + r;
                     if (m < M && n < N) z[(long)m * N + n] = acc[i][j][r];
                 }
             }
     };
     const bool stats = arr.part1 != nullptr;
     for (int t = t0; t < t1; ++t) {
-        const int m0 = t * GT;
-        const float* ap[4];
-        bool a_ok[4];
+        const int m0 = t * TR;
+        const float* ap[NP];
+        bool a_ok[NP];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NP; ++i) {
             ap[i] = a + (long)min(m0 + p_r + 16 * i, M - 1) * K;
             a_ok[i] = m0 + p_r + 16 * i < M;
         }
@@ -623,7 +634,7 @@ __global__ __launch_bounds__(256) void pw_fwd_kernel(const float* __restrict__ a
         auto fetch = [&](PwFwdStage& sg, int k0) {
             const int k = min(k0 + p_k, K - 4);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < NP; ++i) {
                 sg.va[i] = ldg4(ap[i] + k);
                 sg.vb[i] = ldg4(bp[i] + k);
             }
@@ -633,13 +644,13 @@ __global__ __launch_bounds__(256) void pw_fwd_kernel(const float* __restrict__ a
             }
             if (XF == PW_IN_LINEAR && res != nullptr) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) sg.vr[i] = ldg4(res + (ap[i] - a) + k);
+                for (int i = 0; i < NP; ++i) sg.vr[i] = ldg4(res + (ap[i] - a) + k);
             }
         };
         auto stage = [&](const PwFwdStage& sg, int k0) {
             const bool kok = k0 + p_k < K;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < NP; ++i) {
                 float4 v = sg.va[i];
                 if (XF == PW_IN_RELU6) v = bn_relu6_4(v, sg.xsc, sg.xsh);
                 if (XF == PW_IN_LINEAR) {
@@ -654,9 +665,9 @@ __global__ __launch_bounds__(256) void pw_fwd_kernel(const float* __restrict__ a
             }
         };
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < WT; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) acc[i][j] = {0.0f, 0.0f, 0.0f, 0.0f};
+            for (int j = 0; j < WT; ++j) acc[i][j] = {0.0f, 0.0f, 0.0f, 0.0f};
         PwFwdStage st0, st1;
         constexpr int AHEAD = DEEP ? 2 * PK : PK;
         fetch(st0, 0);
@@ -666,7 +677,7 @@ __global__ __launch_bounds__(256) void pw_fwd_kernel(const float* __restrict__ a
             __syncthreads();
             fetch(st0, k0 + AHEAD);
             __builtin_amdgcn_sched_barrier(0);
-            mma_kk(As, Bs, acc, min(PK, K - k0 + 15) / 16, wr, wc, lane);
+            mma_kk<WT>(As, Bs, acc, min(PK, K - k0 + 15) / 16, wr, wc, lane);
             __syncthreads();
             if (DEEP) {
                 if (k0 + PK >= K) break;
@@ -674,15 +685,15 @@ __global__ __launch_bounds__(256) void pw_fwd_kernel(const float* __restrict__ a
                 __syncthreads();
                 fetch(st1, k0 + PK + AHEAD);
                 __builtin_amdgcn_sched_barrier(0);
-                mma_kk(As, Bs, acc, min(PK, K - k0 - PK + 15) / 16, wr, wc, lane);
+                mma_kk<WT>(As, Bs, acc, min(PK, K - k0 - PK + 15) / 16, wr, wc, lane);
                 __syncthreads();
             }
         }
         if (!(stats && t == t1 - 1)) store_tile(m0);
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < WT; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < WT; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float v = acc[i][j][r];          // rows >= M and columns >= N are exact zeros
@@ -692,22 +703,22 @@ __global__ __launch_bounds__(256) void pw_fwd_kernel(const float* __restrict__ a
     }
     if (!stats) return;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < WT; ++j) {
         cs[j] += __shfl_xor(cs[j], 16);
         cs[j] += __shfl_xor(cs[j], 32);
         cq[j] += __shfl_xor(cq[j], 16);
         cq[j] += __shfl_xor(cq[j], 32);
         if (lane < 16) {
-            sred[0][wr][32 * wc + 16 * j + lane] = cs[j];
-            sred[1][wr][32 * wc + 16 * j + lane] = cq[j];
+            sred[0][wr][16 * WT * wc + 16 * j + lane] = cs[j];
+            sred[1][wr][16 * WT * wc + 16 * j + lane] = cq[j];
         }
     }
     __syncthreads();
-    const bool own = tid < 64 && n0 + tid < N;
+    const bool own = tid < TR && n0 + tid < N;
     const float v0 = own ? sred[0][0][tid] + sred[0][1][tid] : 0.0f, v1 = own ? sred[1][0][tid] + sred[1][1][tid] : 0.0f;
-    const int m_last = (t1 - 1) * GT;
-    if (publish_and_arrive(arr, N, blockIdx.x, blockIdx.y, gridDim.y, own, n0 + tid, v0, v1, [&]() { store_tile(m_last); }))
-        finalize_fwd(arr.part2, arrive_rows(gridDim.y), N, n0 + lane, fin);
+    const int m_last = (t1 - 1) * TR;
+    if (publish_and_arrive(arr, N, blockIdx.x, blockIdx.y, gridDim.y, own, n0 + tid, v0, v1, [&]() { store_tile(m_last); }, TR))
+        finalize_fwd(arr.part2, arrive_rows(gridDim.y), N, lane < TR ? n0 + lane : N, fin);
 }
 
 // What the producer of a data gradient does with its result before it leaves the registers: dy_j (+ the gradient that
@@ -745,62 +756,67 @@ struct PwBwd {
 struct PwBwdStage {
     float4 vg[4], vz[4], vb[4], ksc, kc1, kc0;
 };
-template <bool DEEP>
+template <bool DEEP, int WT>
 __device__ __forceinline__ void pw_dgrad_body(float* lds, const PwBwd& p, int bx, int by) {
-    __shared__ float sred[2][2][64];
-    float* As = lds;                 // [m][n]   (64 x LDK)
-    float* Bs = lds + 64 * LDK;      // [n][c]   (PK x LDC)
+    constexpr int TR = 32 * WT;      // rows and columns of the block tile
+    constexpr int NP = TR / 16;      // dz pieces per thread and step
+    __shared__ float sred[2][2][TR];
+    float* As = lds;                 // [m][n]   (TR x LDK)
+    float* Bs = lds + TR * LDK;      // [n][c]   (PK x LDC, TR columns used)
     const int M = p.M, N = p.N, C = p.C;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
-    const int c0 = bx * GT;
+    const int c0 = bx * TR;
     const int p_r = tid >> 4, p_k = (tid & 15) * 4;
     const int bcol = min(c0 + p_k, C - 4);          // weight piece: rows (= n) p_r + 16 i, 4 consecutive c from p_k
-    const bool b_col_ok = c0 + p_k < C;
-    float jsc[2], jsh[2], jme[2], jrs[2];           // layer j's constants of this thread's two output columns
+    const bool b_col_ok = c0 + p_k < C && p_k < TR;
+    float jsc[WT], jsh[WT], jme[WT], jrs[WT];           // layer j's constants of this thread's two output columns
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int c = min(c0 + 32 * wc + 16 * j + (lane & 15), C - 1);
+    for (int j = 0; j < WT; ++j) {
+        const int c = min(c0 + 16 * WT * wc + 16 * j + (lane & 15), C - 1);
         jsc[j] = p.e.ssj[c];
         jsh[j] = p.e.ssj[C + c];
         jme[j] = p.e.ssj[2 * C + c];
         jrs[j] = p.e.ssj[3 * C + c];
     }
-    const int row_tiles = (M + GT - 1) / GT;
+    const int row_tiles = (M + TR - 1) / TR;
     const int t0 = by * p.tiles_per_block;
     const int t1 = min(row_tiles, t0 + p.tiles_per_block);
-    float s1[2] = {0.0f, 0.0f}, s2[2] = {0.0f, 0.0f};
-    float gq[2][2][4];     // g_j of the current tile; the last tile's stores are issued under the arrival
+    float s1[WT], s2[WT];
+#pragma unroll
+    for (int j = 0; j < WT; ++j) s1[j] = s2[j] = 0.0f;
+    float gq[WT][WT][4];     // g_j of the current tile; the last tile's stores are issued under the arrival
     auto store_tile = [&](int m0) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < WT; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int c = c0 + 32 * wc + 16 * j + (lane & 15);
+            for (int j = 0; j < WT; ++j) {
+                const int c = c0 + 16 * WT * wc + 16 * j + (lane & 15);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int m = m0 + 32 * wr + 16 * i + 4 * (lane >> 4) + r;
+                    const int m = m0 + 16 * WT * wr + 16 * i + 4 * (lane >> 4) + r;
                     if (m < M && c < C) p.e.gj[(long)m * C + c] = gq[i][j][r];
                 }
             }
     };
     for (int t = t0; t < t1; ++t) {
-        const int m0 = t * GT;
-        long arow[4];
-        bool a_ok[4];
+        const int m0 = t * TR;
+        long arow[NP];
+        bool a_ok[NP];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NP; ++i) {
             arow[i] = (long)min(m0 + p_r + 16 * i, M - 1) * N;
             a_ok[i] = m0 + p_r + 16 * i < M;
         }
         auto fetch = [&](PwBwdStage& sg, int k0) {
             const int k = min(k0 + p_k, N - 4);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < NP; ++i) {
                 sg.vg[i] = ldg4(p.g + arow[i] + k);
                 sg.vz[i] = ldg4(p.zk + arow[i] + k);
-                sg.vb[i] = ldg4(p.w + (long)min(k0 + p_r + 16 * i, N - 1) * C + bcol);
             }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) sg.vb[i] = ldg4(p.w + (long)min(k0 + p_r + 16 * i, N - 1) * C + bcol);
             sg.ksc = ldg4(p.bc + k);
             sg.kc1 = ldg4(p.bc + N + k);
             sg.kc0 = ldg4(p.bc + 2 * N + k);
@@ -808,19 +824,23 @@ __device__ __forceinline__ void pw_dgrad_body(float* lds, const PwBwd& p, int bx
         auto stage = [&](const PwBwdStage& sg, int k0) {
             const bool kok = k0 + p_k < N;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < NP; ++i) {
                 float4 v = dz4(sg.vg[i], sg.vz[i], sg.ksc, sg.kc1, sg.kc0);
                 if (!(a_ok[i] && kok)) v = f4_zero();
                 *reinterpret_cast<float4*>(&As[(p_r + 16 * i) * LDK + p_k]) = v;
-                *reinterpret_cast<float4*>(&Bs[(p_r + 16 * i) * LDC + p_k]) =
-                    (b_col_ok && k0 + p_r + 16 * i < N) ? sg.vb[i] : f4_zero();
+            }
+            if (p_k < TR) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    *reinterpret_cast<float4*>(&Bs[(p_r + 16 * i) * LDC + p_k]) =
+                        (b_col_ok && k0 + p_r + 16 * i < N) ? sg.vb[i] : f4_zero();
             }
         };
-        f32x4 acc[2][2];
+        f32x4 acc[WT][WT];
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < WT; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) acc[i][j] = {0.0f, 0.0f, 0.0f, 0.0f};
+            for (int j = 0; j < WT; ++j) acc[i][j] = {0.0f, 0.0f, 0.0f, 0.0f};
         PwBwdStage st0, st1;
         constexpr int AHEAD = DEEP ? 2 * PK : PK;
         fetch(st0, 0);
@@ -830,7 +850,7 @@ __device__ __forceinline__ void pw_dgrad_body(float* lds, const PwBwd& p, int bx
             __syncthreads();
             fetch(st0, k0 + AHEAD);
             __builtin_amdgcn_sched_barrier(0);
-            mma_kc(As, Bs, acc, min(PK, N - k0 + 15) / 16, wr, wc, lane);
+            mma_kc<WT>(As, Bs, acc, min(PK, N - k0 + 15) / 16, wr, wc, lane);
             __syncthreads();
             if (DEEP) {
                 if (k0 + PK >= N) break;
@@ -838,32 +858,32 @@ __device__ __forceinline__ void pw_dgrad_body(float* lds, const PwBwd& p, int bx
                 __syncthreads();
                 fetch(st1, k0 + PK + AHEAD);
                 __builtin_amdgcn_sched_barrier(0);
-                mma_kc(As, Bs, acc, min(PK, N - k0 - PK + 15) / 16, wr, wc, lane);
+                mma_kc<WT>(As, Bs, acc, min(PK, N - k0 - PK + 15) / 16, wr, wc, lane);
                 __syncthreads();
             }
         }
         // epilogue: all loads first (clamped, unconditional), then arithmetic, then the guarded stores
-        float zj[2][2][4], ad[2][2][4];
+        float zj[WT][WT][4], ad[WT][WT][4];
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < WT; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int c = min(c0 + 32 * wc + 16 * j + (lane & 15), C - 1);
+            for (int j = 0; j < WT; ++j) {
+                const int c = min(c0 + 16 * WT * wc + 16 * j + (lane & 15), C - 1);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int m = min(m0 + 32 * wr + 16 * i + 4 * (lane >> 4) + r, M - 1);
+                    const int m = min(m0 + 16 * WT * wr + 16 * i + 4 * (lane >> 4) + r, M - 1);
                     zj[i][j][r] = p.e.zj[(long)m * C + c];
                     ad[i][j][r] = p.e.addend != nullptr ? p.e.addend[(long)m * C + c] : 0.0f;
                 }
             }
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < WT; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int c = c0 + 32 * wc + 16 * j + (lane & 15);
+            for (int j = 0; j < WT; ++j) {
+                const int c = c0 + 16 * WT * wc + 16 * j + (lane & 15);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int m = m0 + 32 * wr + 16 * i + 4 * (lane >> 4) + r;
+                    const int m = m0 + 16 * WT * wr + 16 * i + 4 * (lane >> 4) + r;
                     const bool ok = m < M && c < C;
                     const float dy = acc[i][j][r] + ad[i][j][r];
                     const float zv = zj[i][j][r];
@@ -877,22 +897,22 @@ __device__ __forceinline__ void pw_dgrad_body(float* lds, const PwBwd& p, int bx
         if (t != t1 - 1) store_tile(m0);
     }
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < WT; ++j) {
         s1[j] += __shfl_xor(s1[j], 16);
         s1[j] += __shfl_xor(s1[j], 32);
         s2[j] += __shfl_xor(s2[j], 16);
         s2[j] += __shfl_xor(s2[j], 32);
         if (lane < 16) {
-            sred[0][wr][32 * wc + 16 * j + lane] = s1[j];
-            sred[1][wr][32 * wc + 16 * j + lane] = s2[j];
+            sred[0][wr][16 * WT * wc + 16 * j + lane] = s1[j];
+            sred[1][wr][16 * WT * wc + 16 * j + lane] = s2[j];
         }
     }
     __syncthreads();
-    const bool own = tid < 64 && c0 + tid < C;
+    const bool own = tid < TR && c0 + tid < C;
     const float v0 = own ? sred[0][0][tid] + sred[0][1][tid] : 0.0f, v1 = own ? sred[1][0][tid] + sred[1][1][tid] : 0.0f;
-    const int m_last = (t1 - 1) * GT;
-    if (publish_and_arrive(p.arr, C, bx, by, p.d_ry, own, c0 + tid, v0, v1, [&]() { store_tile(m_last); }))
-        finalize_bwd(p.arr.part2, arrive_rows(p.d_ry), C, c0 + lane, p.fin);
+    const int m_last = (t1 - 1) * TR;
+    if (publish_and_arrive(p.arr, C, bx, by, p.d_ry, own, c0 + tid, v0, v1, [&]() { store_tile(m_last); }, TR))
+        finalize_bwd(p.arr.part2, arrive_rows(p.d_ry), C, lane < TR ? c0 + lane : C, p.fin);
 }
 
 // weight gradient:  dW[n][c] = sum_m dz[m][n] * T(in[m][c]) over this split's rows; both operands are rebuilt while they are
@@ -964,12 +984,12 @@ __device__ __forceinline__ void pw_wgrad_body(float* lds, const PwBwd& p, int bx
         }
 }
 
-template <bool XF, bool DEEP>
+template <bool XF, bool DEEP, int WT>
 __global__ __launch_bounds__(256) void pw_bwd_kernel(PwBwd p) {
     __shared__ __attribute__((aligned(16))) float lds[PW_LDS_FLOATS];
     const int b = blockIdx.x, nd = p.d_cx * p.d_ry;
     if (b < nd) {
-        pw_dgrad_body<DEEP>(lds, p, b % p.d_cx, b / p.d_cx);
+        pw_dgrad_body<DEEP, WT>(lds, p, b % p.d_cx, b / p.d_cx);
     } else {
         const int wb = b - nd;
         const int bx = wb % p.w_cx, r = wb / p.w_cx;
@@ -2024,9 +2044,12 @@ int howl_mobilenet_fwd(const float* params, float* buffers, int num_labels, cons
         const float* ss_in = in_mat ? nullptr : c.ws + c.p.ss[k - 1];
         const FinFwd fin = fin_fwd(c, k, buffers);
         if (l.kind == MB_PW) {
+            // layers whose 64 x 64 tiles would leave CUs idle (the late, deep-reduction bottleneck layers: 96-192 tiles) take
+            // 32 x 32 tiles: four times the blocks, a quarter of the MFMA chain per step
+            const int tile = pw_tile(g.mz, l.cout);
             int tpb, rb;
-            pw_rows(g.mz, (l.cout + GT - 1) / GT, &tpb, &rb);
-            const dim3 grid((l.cout + GT - 1) / GT, rb);
+            pw_rows(g.mz, (l.cout + tile - 1) / tile, &tpb, &rb, tile);
+            const dim3 grid((l.cout + tile - 1) / tile, rb);
             HowlProfScope prof("mb_conv", stream, 4.0 * (double)g.mz * (l.cin + l.cout));
             const bool deep = l.cin >= PW_DEEP;
             const HowlMbLayer& lp = c.n->layers[k - 1];
@@ -2040,9 +2063,15 @@ int howl_mobilenet_fwd(const float* params, float* buffers, int num_labels, cons
                 res = lp.res_src >= 0 ? c.ws + c.p.y[lp.res_src] : nullptr;
                 y_out = c.ws + c.p.y[k - 1];
             }
-#define HOWL_PW_FWD(XF, DEEP)                                                                                                   \
-    hipLaunchKernelGGL((pw_fwd_kernel<XF, DEEP>), grid, dim3(256), 0, stream, src, ssp, params + l.w_off, res, y_out, (int)g.mz, \
-                       l.cout, l.cin, tpb, z, arr, fin)
+#define HOWL_PW_FWD(XF, DEEP)                                                                                             \
+    do {                                                                                                                  \
+        if (tile == 64)                                                                                                   \
+            hipLaunchKernelGGL((pw_fwd_kernel<XF, DEEP, 2>), grid, dim3(256), 0, stream, src, ssp, params + l.w_off, res, \
+                               y_out, (int)g.mz, l.cout, l.cin, tpb, z, arr, fin);                                        \
+        else                                                                                                              \
+            hipLaunchKernelGGL((pw_fwd_kernel<XF, DEEP, 1>), grid, dim3(256), 0, stream, src, ssp, params + l.w_off, res, \
+                               y_out, (int)g.mz, l.cout, l.cin, tpb, z, arr, fin);                                        \
+    } while (0)
             if (!in_mat) {
                 if (deep) HOWL_PW_FWD(PW_IN_RELU6, true);
                 else HOWL_PW_FWD(PW_IN_RELU6, false);
@@ -2143,8 +2172,9 @@ int howl_mobilenet_bwd(const float* params, int num_labels, const float* x, long
             a.M = (int)g.mz;
             a.N = l.cout;
             a.C = l.cin;
-            a.d_cx = (l.cin + GT - 1) / GT;
-            pw_rows(g.mz, a.d_cx, &a.tiles_per_block, &a.d_ry);
+            const int tile = pw_tile(g.mz, l.cin);     // the data gradient's output is (M x cin)
+            a.d_cx = (l.cin + tile - 1) / tile;
+            pw_rows(g.mz, a.d_cx, &a.tiles_per_block, &a.d_ry, tile);
             a.rows_per_split = pw_wgrad_rows_per_split(g.mz, l.cout, l.cin);
             a.w_cx = (l.cin + GT - 1) / GT;
             a.w_ny = (l.cout + GT - 1) / GT;
@@ -2156,13 +2186,19 @@ int howl_mobilenet_bwd(const float* params, int num_labels, const float* x, long
             const unsigned blocks = (unsigned)(a.d_cx * a.d_ry + a.w_cx * a.w_ny * a.w_nz);
             HowlProfScope prof("mb_conv", stream, 4.0 * (double)g.mz * (4.0 * l.cout + 4.0 * l.cin));
             const bool deep = l.cout >= PW_DEEP;     // the data gradient reduces over the output channels
+#define HOWL_PW_BWD(XF, DEEP)                                                                               \
+    do {                                                                                                    \
+        if (tile == 64) hipLaunchKernelGGL((pw_bwd_kernel<XF, DEEP, 2>), dim3(blocks), dim3(256), 0, stream, a); \
+        else hipLaunchKernelGGL((pw_bwd_kernel<XF, DEEP, 1>), dim3(blocks), dim3(256), 0, stream, a);            \
+    } while (0)
             if (ss_in != nullptr) {
-                if (deep) hipLaunchKernelGGL((pw_bwd_kernel<true, true>), dim3(blocks), dim3(256), 0, stream, a);
-                else hipLaunchKernelGGL((pw_bwd_kernel<true, false>), dim3(blocks), dim3(256), 0, stream, a);
+                if (deep) HOWL_PW_BWD(true, true);
+                else HOWL_PW_BWD(true, false);
             } else {
-                if (deep) hipLaunchKernelGGL((pw_bwd_kernel<false, true>), dim3(blocks), dim3(256), 0, stream, a);
-                else hipLaunchKernelGGL((pw_bwd_kernel<false, false>), dim3(blocks), dim3(256), 0, stream, a);
+                if (deep) HOWL_PW_BWD(false, true);
+                else HOWL_PW_BWD(false, false);
             }
+#undef HOWL_PW_BWD
             jobs.add(slab, a.w_nz, (long)l.cout * l.cin, grads + l.w_off);
         } else {   // depthwise (layers 0 and 1 are the only dense ones)
             DwBwd a{};
