@@ -24,6 +24,8 @@
 // Saved for the backward pass (in the caller's workspace): each layer's convolution output z_k, ss_k, the stored y_k of the
 // linear bottlenecks; masks and normalised values are recomputed from z_k.  Reductions are fixed-order: results do not
 // depend on scheduling.
+#include <stdlib.h>
+
 #include <algorithm>
 #include <vector>
 
@@ -158,9 +160,14 @@ inline void pw_rows(long M, int col_tiles, int* tiles_per_block, int* blocks, in
     *blocks = (row_tiles + tpb - 1) / tpb;
 }
 // tile edge of a pointwise product with an (M x n) result: 32 when 64 x 64 tiles would not give every CU a block
+inline int env_int(const char* name, int fallback) {
+    const char* v = getenv(name);
+    return v != nullptr && v[0] != 0 ? atoi(v) : fallback;
+}
 inline int pw_tile(long M, int n) {
     const long tiles64 = ((M + 63) / 64) * ((n + 63) / 64);
-    return tiles64 < (long)howl_num_cus() ? 32 : 64;
+    static const int per_cu = env_int("HOWL_MB_TILE_BLOCKS_PER_CU", 1);    // fewer 64 x 64 tiles than this per CU -> 32-row tiles
+    return tiles64 < (long)per_cu * howl_num_cus() ? 32 : 64;
 }
 // The weight-gradient blocks of a pointwise backward launch run beside its data-gradient blocks: a split is sized so that both
 // kinds take about the same number of 64-deep steps (data gradient: tiles_per_block x ceil(N / 64)), which keeps the slabs
@@ -504,43 +511,43 @@ __device__ __forceinline__ float4 dz4(float4 g, float4 z, float4 sc, float4 c1, 
 __device__ __forceinline__ float f4_get(const float4& v, int e) { return e == 0 ? v.x : (e == 1 ? v.y : (e == 2 ? v.z : v.w)); }
 
 // `groups` x 16 k of the step: A and B both [row][k]
-template <int WT>
-__device__ __forceinline__ void mma_kk(const float* As, const float* Bs, f32x4 (&acc)[WT][WT], int groups, int wr,
+template <int WTR, int WTC>
+__device__ __forceinline__ void mma_kk(const float* As, const float* Bs, f32x4 (&acc)[WTR][WTC], int groups, int wr,
                                        int wc, int lane) {
     const int q = lane >> 4, l15 = lane & 15;
     for (int t = 0; t < groups; ++t) {
-        float4 a[WT], b[WT];
+        float4 a[WTR], b[WTC];
 #pragma unroll
-        for (int i = 0; i < WT; ++i) a[i] = *reinterpret_cast<const float4*>(&As[(16 * WT * wr + 16 * i + l15) * LDK + 16 * t + 4 * q]);
+        for (int i = 0; i < WTR; ++i) a[i] = *reinterpret_cast<const float4*>(&As[(16 * WTR * wr + 16 * i + l15) * LDK + 16 * t + 4 * q]);
 #pragma unroll
-        for (int j = 0; j < WT; ++j) b[j] = *reinterpret_cast<const float4*>(&Bs[(16 * WT * wc + 16 * j + l15) * LDK + 16 * t + 4 * q]);
+        for (int j = 0; j < WTC; ++j) b[j] = *reinterpret_cast<const float4*>(&Bs[(16 * WTC * wc + 16 * j + l15) * LDK + 16 * t + 4 * q]);
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
-            for (int i = 0; i < WT; ++i)
+            for (int i = 0; i < WTR; ++i)
 #pragma unroll
-                for (int j = 0; j < WT; ++j)
+                for (int j = 0; j < WTC; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4_get(a[i], e), f4_get(b[j], e), acc[i][j], 0, 0, 0);
     }
 }
 // A [row][k], B [k][col]
-template <int WT>
-__device__ __forceinline__ void mma_kc(const float* As, const float* Bs, f32x4 (&acc)[WT][WT], int groups, int wr,
+template <int WTR, int WTC>
+__device__ __forceinline__ void mma_kc(const float* As, const float* Bs, f32x4 (&acc)[WTR][WTC], int groups, int wr,
                                        int wc, int lane) {
     const int q = lane >> 4, l15 = lane & 15;
     for (int t = 0; t < groups; ++t) {
-        float4 a[WT];
+        float4 a[WTR];
 #pragma unroll
-        for (int i = 0; i < WT; ++i) a[i] = *reinterpret_cast<const float4*>(&As[(16 * WT * wr + 16 * i + l15) * LDK + 16 * t + 4 * q]);
+        for (int i = 0; i < WTR; ++i) a[i] = *reinterpret_cast<const float4*>(&As[(16 * WTR * wr + 16 * i + l15) * LDK + 16 * t + 4 * q]);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            float b[WT];
+            float b[WTC];
 #pragma unroll
-            for (int j = 0; j < WT; ++j) b[j] = Bs[(16 * t + 4 * q + e) * LDC + 16 * WT * wc + 16 * j + l15];
+            for (int j = 0; j < WTC; ++j) b[j] = Bs[(16 * t + 4 * q + e) * LDC + 16 * WTC * wc + 16 * j + l15];
 #pragma unroll
-            for (int i = 0; i < WT; ++i)
+            for (int i = 0; i < WTR; ++i)
 #pragma unroll
-                for (int j = 0; j < WT; ++j)
+                for (int j = 0; j < WTC; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4_get(a[i], e), b[j], acc[i][j], 0, 0, 0);
         }
     }
@@ -577,44 +584,44 @@ __device__ __forceinline__ void mma_cc(const float* As, const float* Bs, f32x4 (
 struct PwFwdStage {
     float4 va[4], vb[4], vr[4], xsc, xsh;
 };
-template <int XF, bool DEEP, int WT>
+template <int XF, bool DEEP, int WTR, int WTC>
 __global__ __launch_bounds__(256) void pw_fwd_kernel(const float* __restrict__ a, const float* __restrict__ ss_in,
                                                      const float* __restrict__ w, const float* __restrict__ res,
                                                      float* __restrict__ y_out, int M, int N, int K, int tiles_per_block,
                                                      float* __restrict__ z, Arrive arr, FinFwd fin) {
-    constexpr int TR = 32 * WT;      // rows and columns of the block tile (2 x 2 waves x WT x WT MFMA tiles)
-    constexpr int NP = TR / 16;      // operand pieces per thread and step
-    __shared__ __attribute__((aligned(16))) float lds[2 * TR * LDK];
-    __shared__ float sred[2][2][TR];
+    constexpr int TR = 32 * WTR, TC = 32 * WTC;    // block tile: 2 x 2 waves x (WTR x WTC) MFMA tiles
+    constexpr int NPA = TR / 16, NPB = TC / 16;    // operand pieces per thread and step
+    __shared__ __attribute__((aligned(16))) float lds[(TR + TC) * LDK];
+    __shared__ float sred[2][2][TC];
     float* As = lds;
     float* Bs = lds + TR * LDK;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
-    const int n0 = blockIdx.x * TR;
-    const int p_r = tid >> 4, p_k = (tid & 15) * 4;   // pieces: rows p_r + 16 i (i < NP), 4 consecutive k from p_k
-    const float* bp[NP];
-    bool b_ok[NP];
+    const int n0 = blockIdx.x * TC;
+    const int p_r = tid >> 4, p_k = (tid & 15) * 4;   // pieces: rows p_r + 16 i, 4 consecutive k from p_k
+    const float* bp[NPB];
+    bool b_ok[NPB];
 #pragma unroll
-    for (int i = 0; i < NP; ++i) {
+    for (int i = 0; i < NPB; ++i) {
         bp[i] = w + (long)min(n0 + p_r + 16 * i, N - 1) * K;
         b_ok[i] = n0 + p_r + 16 * i < N;
     }
     const int row_tiles = (M + TR - 1) / TR;
     const int t0 = blockIdx.y * tiles_per_block;
     const int t1 = min(row_tiles, t0 + tiles_per_block);
-    float cs[WT], cq[WT];
+    float cs[WTC], cq[WTC];
 #pragma unroll
-    for (int j = 0; j < WT; ++j) cs[j] = cq[j] = 0.0f;
-    f32x4 acc[WT][WT];     // the last tile's results stay in registers: its stores are issued under the arrival (see `arrive`)
+    for (int j = 0; j < WTC; ++j) cs[j] = cq[j] = 0.0f;
+    f32x4 acc[WTR][WTC];     // the last tile's results stay in registers: its stores are issued under the arrival (see `arrive`)
     auto store_tile = [&](int m0) {
 #pragma unroll
-        for (int i = 0; i < WT; ++i)
+        for (int i = 0; i < WTR; ++i)
 #pragma unroll
-            for (int j = 0; j < WT; ++j) {
-                const int n = n0 + 16 * WT * wc + 16 * j + (lane & 15);
+            for (int j = 0; j < WTC; ++j) {
+                const int n = n0 + 16 * WTC * wc + 16 * j + (lane & 15);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int m = m0 + 16 * WT * wr + 16 * i + 4 * (lane >> 4) + r;
+                    const int m = m0 + 16 * WTR * wr + 16 * i + 4 * (lane >> 4) + r;
                     if (m < M && n < N) z[(long)m * N + n] = acc[i][j][r];
                 }
             }
@@ -622,10 +629,10 @@ __global__ __launch_bounds__(256) void pw_fwd_kernel(const float* __restrict__ a
     const bool stats = arr.part1 != nullptr;
     for (int t = t0; t < t1; ++t) {
         const int m0 = t * TR;
-        const float* ap[NP];
-        bool a_ok[NP];
+        const float* ap[NPA];
+        bool a_ok[NPA];
 #pragma unroll
-        for (int i = 0; i < NP; ++i) {
+        for (int i = 0; i < NPA; ++i) {
             ap[i] = a + (long)min(m0 + p_r + 16 * i, M - 1) * K;
             a_ok[i] = m0 + p_r + 16 * i < M;
         }
@@ -634,23 +641,22 @@ __global__ __launch_bounds__(256) void pw_fwd_kernel(const float* __restrict__ a
         auto fetch = [&](PwFwdStage& sg, int k0) {
             const int k = min(k0 + p_k, K - 4);
 #pragma unroll
-            for (int i = 0; i < NP; ++i) {
-                sg.va[i] = ldg4(ap[i] + k);
-                sg.vb[i] = ldg4(bp[i] + k);
-            }
+            for (int i = 0; i < NPA; ++i) sg.va[i] = ldg4(ap[i] + k);
+#pragma unroll
+            for (int i = 0; i < NPB; ++i) sg.vb[i] = ldg4(bp[i] + k);
             if (XF != PW_IN_PLAIN) {
                 sg.xsc = ldg4(ss_in + k);
                 sg.xsh = ldg4(ss_in + K + k);
             }
             if (XF == PW_IN_LINEAR && res != nullptr) {
 #pragma unroll
-                for (int i = 0; i < NP; ++i) sg.vr[i] = ldg4(res + (ap[i] - a) + k);
+                for (int i = 0; i < NPA; ++i) sg.vr[i] = ldg4(res + (ap[i] - a) + k);
             }
         };
         auto stage = [&](const PwFwdStage& sg, int k0) {
             const bool kok = k0 + p_k < K;
 #pragma unroll
-            for (int i = 0; i < NP; ++i) {
+            for (int i = 0; i < NPA; ++i) {
                 float4 v = sg.va[i];
                 if (XF == PW_IN_RELU6) v = bn_relu6_4(v, sg.xsc, sg.xsh);
                 if (XF == PW_IN_LINEAR) {
@@ -661,13 +667,15 @@ __global__ __launch_bounds__(256) void pw_fwd_kernel(const float* __restrict__ a
                 }
                 if (!(a_ok[i] && kok)) v = f4_zero();
                 *reinterpret_cast<float4*>(&As[(p_r + 16 * i) * LDK + p_k]) = v;
-                *reinterpret_cast<float4*>(&Bs[(p_r + 16 * i) * LDK + p_k]) = (b_ok[i] && kok) ? sg.vb[i] : f4_zero();
             }
+#pragma unroll
+            for (int i = 0; i < NPB; ++i)
+                *reinterpret_cast<float4*>(&Bs[(p_r + 16 * i) * LDK + p_k]) = (b_ok[i] && kok) ? sg.vb[i] : f4_zero();
         };
 #pragma unroll
-        for (int i = 0; i < WT; ++i)
+        for (int i = 0; i < WTR; ++i)
 #pragma unroll
-            for (int j = 0; j < WT; ++j) acc[i][j] = {0.0f, 0.0f, 0.0f, 0.0f};
+            for (int j = 0; j < WTC; ++j) acc[i][j] = {0.0f, 0.0f, 0.0f, 0.0f};
         PwFwdStage st0, st1;
         constexpr int AHEAD = DEEP ? 2 * PK : PK;
         fetch(st0, 0);
@@ -677,7 +685,7 @@ __global__ __launch_bounds__(256) void pw_fwd_kernel(const float* __restrict__ a
             __syncthreads();
             fetch(st0, k0 + AHEAD);
             __builtin_amdgcn_sched_barrier(0);
-            mma_kk<WT>(As, Bs, acc, min(PK, K - k0 + 15) / 16, wr, wc, lane);
+            mma_kk<WTR, WTC>(As, Bs, acc, min(PK, K - k0 + 15) / 16, wr, wc, lane);
             __syncthreads();
             if (DEEP) {
                 if (k0 + PK >= K) break;
@@ -685,15 +693,15 @@ __global__ __launch_bounds__(256) void pw_fwd_kernel(const float* __restrict__ a
                 __syncthreads();
                 fetch(st1, k0 + PK + AHEAD);
                 __builtin_amdgcn_sched_barrier(0);
-                mma_kk<WT>(As, Bs, acc, min(PK, K - k0 - PK + 15) / 16, wr, wc, lane);
+                mma_kk<WTR, WTC>(As, Bs, acc, min(PK, K - k0 - PK + 15) / 16, wr, wc, lane);
                 __syncthreads();
             }
         }
         if (!(stats && t == t1 - 1)) store_tile(m0);
 #pragma unroll
-        for (int i = 0; i < WT; ++i)
+        for (int i = 0; i < WTR; ++i)
 #pragma unroll
-            for (int j = 0; j < WT; ++j)
+            for (int j = 0; j < WTC; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float v = acc[i][j][r];          // rows >= M and columns >= N are exact zeros
@@ -703,22 +711,22 @@ __global__ __launch_bounds__(256) void pw_fwd_kernel(const float* __restrict__ a
     }
     if (!stats) return;
 #pragma unroll
-    for (int j = 0; j < WT; ++j) {
+    for (int j = 0; j < WTC; ++j) {
         cs[j] += __shfl_xor(cs[j], 16);
         cs[j] += __shfl_xor(cs[j], 32);
         cq[j] += __shfl_xor(cq[j], 16);
         cq[j] += __shfl_xor(cq[j], 32);
         if (lane < 16) {
-            sred[0][wr][16 * WT * wc + 16 * j + lane] = cs[j];
-            sred[1][wr][16 * WT * wc + 16 * j + lane] = cq[j];
+            sred[0][wr][16 * WTC * wc + 16 * j + lane] = cs[j];
+            sred[1][wr][16 * WTC * wc + 16 * j + lane] = cq[j];
         }
     }
     __syncthreads();
-    const bool own = tid < TR && n0 + tid < N;
+    const bool own = tid < TC && n0 + tid < N;
     const float v0 = own ? sred[0][0][tid] + sred[0][1][tid] : 0.0f, v1 = own ? sred[1][0][tid] + sred[1][1][tid] : 0.0f;
     const int m_last = (t1 - 1) * TR;
-    if (publish_and_arrive(arr, N, blockIdx.x, blockIdx.y, gridDim.y, own, n0 + tid, v0, v1, [&]() { store_tile(m_last); }, TR))
-        finalize_fwd(arr.part2, arrive_rows(gridDim.y), N, lane < TR ? n0 + lane : N, fin);
+    if (publish_and_arrive(arr, N, blockIdx.x, blockIdx.y, gridDim.y, own, n0 + tid, v0, v1, [&]() { store_tile(m_last); }, TC))
+        finalize_fwd(arr.part2, arrive_rows(gridDim.y), N, lane < TC ? n0 + lane : N, fin);
 }
 
 // What the producer of a data gradient does with its result before it leaves the registers: dy_j (+ the gradient that
@@ -756,24 +764,24 @@ struct PwBwd {
 struct PwBwdStage {
     float4 vg[4], vz[4], vb[4], ksc, kc1, kc0;
 };
-template <bool DEEP, int WT>
+template <bool DEEP, int WTR, int WTC>
 __device__ __forceinline__ void pw_dgrad_body(float* lds, const PwBwd& p, int bx, int by) {
-    constexpr int TR = 32 * WT;      // rows and columns of the block tile
-    constexpr int NP = TR / 16;      // dz pieces per thread and step
-    __shared__ float sred[2][2][TR];
+    constexpr int TR = 32 * WTR, TC = 32 * WTC;    // block tile
+    constexpr int NP = TR / 16;                    // dz pieces per thread and step
+    __shared__ float sred[2][2][TC];
     float* As = lds;                 // [m][n]   (TR x LDK)
-    float* Bs = lds + TR * LDK;      // [n][c]   (PK x LDC, TR columns used)
+    float* Bs = lds + TR * LDK;      // [n][c]   (PK x LDC, TC columns used)
     const int M = p.M, N = p.N, C = p.C;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
-    const int c0 = bx * TR;
+    const int c0 = bx * TC;
     const int p_r = tid >> 4, p_k = (tid & 15) * 4;
     const int bcol = min(c0 + p_k, C - 4);          // weight piece: rows (= n) p_r + 16 i, 4 consecutive c from p_k
-    const bool b_col_ok = c0 + p_k < C && p_k < TR;
-    float jsc[WT], jsh[WT], jme[WT], jrs[WT];           // layer j's constants of this thread's two output columns
+    const bool b_col_ok = c0 + p_k < C && p_k < TC;
+    float jsc[WTC], jsh[WTC], jme[WTC], jrs[WTC];           // layer j's constants of this thread's two output columns
 #pragma unroll
-    for (int j = 0; j < WT; ++j) {
-        const int c = min(c0 + 16 * WT * wc + 16 * j + (lane & 15), C - 1);
+    for (int j = 0; j < WTC; ++j) {
+        const int c = min(c0 + 16 * WTC * wc + 16 * j + (lane & 15), C - 1);
         jsc[j] = p.e.ssj[c];
         jsh[j] = p.e.ssj[C + c];
         jme[j] = p.e.ssj[2 * C + c];
@@ -782,19 +790,19 @@ __device__ __forceinline__ void pw_dgrad_body(float* lds, const PwBwd& p, int bx
     const int row_tiles = (M + TR - 1) / TR;
     const int t0 = by * p.tiles_per_block;
     const int t1 = min(row_tiles, t0 + p.tiles_per_block);
-    float s1[WT], s2[WT];
+    float s1[WTC], s2[WTC];
 #pragma unroll
-    for (int j = 0; j < WT; ++j) s1[j] = s2[j] = 0.0f;
-    float gq[WT][WT][4];     // g_j of the current tile; the last tile's stores are issued under the arrival
+    for (int j = 0; j < WTC; ++j) s1[j] = s2[j] = 0.0f;
+    float gq[WTR][WTC][4];     // g_j of the current tile; the last tile's stores are issued under the arrival
     auto store_tile = [&](int m0) {
 #pragma unroll
-        for (int i = 0; i < WT; ++i)
+        for (int i = 0; i < WTR; ++i)
 #pragma unroll
-            for (int j = 0; j < WT; ++j) {
-                const int c = c0 + 16 * WT * wc + 16 * j + (lane & 15);
+            for (int j = 0; j < WTC; ++j) {
+                const int c = c0 + 16 * WTC * wc + 16 * j + (lane & 15);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int m = m0 + 16 * WT * wr + 16 * i + 4 * (lane >> 4) + r;
+                    const int m = m0 + 16 * WTR * wr + 16 * i + 4 * (lane >> 4) + r;
                     if (m < M && c < C) p.e.gj[(long)m * C + c] = gq[i][j][r];
                 }
             }
@@ -829,18 +837,18 @@ __device__ __forceinline__ void pw_dgrad_body(float* lds, const PwBwd& p, int bx
                 if (!(a_ok[i] && kok)) v = f4_zero();
                 *reinterpret_cast<float4*>(&As[(p_r + 16 * i) * LDK + p_k]) = v;
             }
-            if (p_k < TR) {
+            if (p_k < TC) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
                     *reinterpret_cast<float4*>(&Bs[(p_r + 16 * i) * LDC + p_k]) =
                         (b_col_ok && k0 + p_r + 16 * i < N) ? sg.vb[i] : f4_zero();
             }
         };
-        f32x4 acc[WT][WT];
+        f32x4 acc[WTR][WTC];
 #pragma unroll
-        for (int i = 0; i < WT; ++i)
+        for (int i = 0; i < WTR; ++i)
 #pragma unroll
-            for (int j = 0; j < WT; ++j) acc[i][j] = {0.0f, 0.0f, 0.0f, 0.0f};
+            for (int j = 0; j < WTC; ++j) acc[i][j] = {0.0f, 0.0f, 0.0f, 0.0f};
         PwBwdStage st0, st1;
         constexpr int AHEAD = DEEP ? 2 * PK : PK;
         fetch(st0, 0);
@@ -850,7 +858,7 @@ __device__ __forceinline__ void pw_dgrad_body(float* lds, const PwBwd& p, int bx
             __syncthreads();
             fetch(st0, k0 + AHEAD);
             __builtin_amdgcn_sched_barrier(0);
-            mma_kc<WT>(As, Bs, acc, min(PK, N - k0 + 15) / 16, wr, wc, lane);
+            mma_kc<WTR, WTC>(As, Bs, acc, min(PK, N - k0 + 15) / 16, wr, wc, lane);
             __syncthreads();
             if (DEEP) {
                 if (k0 + PK >= N) break;
@@ -858,32 +866,32 @@ __device__ __forceinline__ void pw_dgrad_body(float* lds, const PwBwd& p, int bx
                 __syncthreads();
                 fetch(st1, k0 + PK + AHEAD);
                 __builtin_amdgcn_sched_barrier(0);
-                mma_kc<WT>(As, Bs, acc, min(PK, N - k0 - PK + 15) / 16, wr, wc, lane);
+                mma_kc<WTR, WTC>(As, Bs, acc, min(PK, N - k0 - PK + 15) / 16, wr, wc, lane);
                 __syncthreads();
             }
         }
         // epilogue: all loads first (clamped, unconditional), then arithmetic, then the guarded stores
-        float zj[WT][WT][4], ad[WT][WT][4];
+        float zj[WTR][WTC][4], ad[WTR][WTC][4];
 #pragma unroll
-        for (int i = 0; i < WT; ++i)
+        for (int i = 0; i < WTR; ++i)
 #pragma unroll
-            for (int j = 0; j < WT; ++j) {
-                const int c = min(c0 + 16 * WT * wc + 16 * j + (lane & 15), C - 1);
+            for (int j = 0; j < WTC; ++j) {
+                const int c = min(c0 + 16 * WTC * wc + 16 * j + (lane & 15), C - 1);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int m = min(m0 + 16 * WT * wr + 16 * i + 4 * (lane >> 4) + r, M - 1);
+                    const int m = min(m0 + 16 * WTR * wr + 16 * i + 4 * (lane >> 4) + r, M - 1);
                     zj[i][j][r] = p.e.zj[(long)m * C + c];
                     ad[i][j][r] = p.e.addend != nullptr ? p.e.addend[(long)m * C + c] : 0.0f;
                 }
             }
 #pragma unroll
-        for (int i = 0; i < WT; ++i)
+        for (int i = 0; i < WTR; ++i)
 #pragma unroll
-            for (int j = 0; j < WT; ++j) {
-                const int c = c0 + 16 * WT * wc + 16 * j + (lane & 15);
+            for (int j = 0; j < WTC; ++j) {
+                const int c = c0 + 16 * WTC * wc + 16 * j + (lane & 15);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int m = m0 + 16 * WT * wr + 16 * i + 4 * (lane >> 4) + r;
+                    const int m = m0 + 16 * WTR * wr + 16 * i + 4 * (lane >> 4) + r;
                     const bool ok = m < M && c < C;
                     const float dy = acc[i][j][r] + ad[i][j][r];
                     const float zv = zj[i][j][r];
@@ -897,22 +905,22 @@ __device__ __forceinline__ void pw_dgrad_body(float* lds, const PwBwd& p, int bx
         if (t != t1 - 1) store_tile(m0);
     }
 #pragma unroll
-    for (int j = 0; j < WT; ++j) {
+    for (int j = 0; j < WTC; ++j) {
         s1[j] += __shfl_xor(s1[j], 16);
         s1[j] += __shfl_xor(s1[j], 32);
         s2[j] += __shfl_xor(s2[j], 16);
         s2[j] += __shfl_xor(s2[j], 32);
         if (lane < 16) {
-            sred[0][wr][16 * WT * wc + 16 * j + lane] = s1[j];
-            sred[1][wr][16 * WT * wc + 16 * j + lane] = s2[j];
+            sred[0][wr][16 * WTC * wc + 16 * j + lane] = s1[j];
+            sred[1][wr][16 * WTC * wc + 16 * j + lane] = s2[j];
         }
     }
     __syncthreads();
-    const bool own = tid < TR && c0 + tid < C;
+    const bool own = tid < TC && c0 + tid < C;
     const float v0 = own ? sred[0][0][tid] + sred[0][1][tid] : 0.0f, v1 = own ? sred[1][0][tid] + sred[1][1][tid] : 0.0f;
     const int m_last = (t1 - 1) * TR;
-    if (publish_and_arrive(p.arr, C, bx, by, p.d_ry, own, c0 + tid, v0, v1, [&]() { store_tile(m_last); }, TR))
-        finalize_bwd(p.arr.part2, arrive_rows(p.d_ry), C, lane < TR ? c0 + lane : C, p.fin);
+    if (publish_and_arrive(p.arr, C, bx, by, p.d_ry, own, c0 + tid, v0, v1, [&]() { store_tile(m_last); }, TC))
+        finalize_bwd(p.arr.part2, arrive_rows(p.d_ry), C, lane < TC ? c0 + lane : C, p.fin);
 }
 
 // weight gradient:  dW[n][c] = sum_m dz[m][n] * T(in[m][c]) over this split's rows; both operands are rebuilt while they are
@@ -984,12 +992,12 @@ __device__ __forceinline__ void pw_wgrad_body(float* lds, const PwBwd& p, int bx
         }
 }
 
-template <bool XF, bool DEEP, int WT>
+template <bool XF, bool DEEP, int WTR, int WTC>
 __global__ __launch_bounds__(256) void pw_bwd_kernel(PwBwd p) {
     __shared__ __attribute__((aligned(16))) float lds[PW_LDS_FLOATS];
     const int b = blockIdx.x, nd = p.d_cx * p.d_ry;
     if (b < nd) {
-        pw_dgrad_body<DEEP, WT>(lds, p, b % p.d_cx, b / p.d_cx);
+        pw_dgrad_body<DEEP, WTR, WTC>(lds, p, b % p.d_cx, b / p.d_cx);
     } else {
         const int wb = b - nd;
         const int bx = wb % p.w_cx, r = wb / p.w_cx;
@@ -2047,9 +2055,10 @@ int howl_mobilenet_fwd(const float* params, float* buffers, int num_labels, cons
             // layers whose 64 x 64 tiles would leave CUs idle (the late, deep-reduction bottleneck layers: 96-192 tiles) take
             // 32 x 32 tiles: four times the blocks, a quarter of the MFMA chain per step
             const int tile = pw_tile(g.mz, l.cout);
+            const int tc = tile == 32 ? env_int("HOWL_MB_FWD_TC", 32) : 64;    // tile columns (rows = `tile`)
             int tpb, rb;
-            pw_rows(g.mz, (l.cout + tile - 1) / tile, &tpb, &rb, tile);
-            const dim3 grid((l.cout + tile - 1) / tile, rb);
+            pw_rows(g.mz, (l.cout + tc - 1) / tc, &tpb, &rb, tile);
+            const dim3 grid((l.cout + tc - 1) / tc, rb);
             HowlProfScope prof("mb_conv", stream, 4.0 * (double)g.mz * (l.cin + l.cout));
             const bool deep = l.cin >= PW_DEEP;
             const HowlMbLayer& lp = c.n->layers[k - 1];
@@ -2065,12 +2074,15 @@ int howl_mobilenet_fwd(const float* params, float* buffers, int num_labels, cons
             }
 #define HOWL_PW_FWD(XF, DEEP)                                                                                             \
     do {                                                                                                                  \
-        if (tile == 64)                                                                                                   \
-            hipLaunchKernelGGL((pw_fwd_kernel<XF, DEEP, 2>), grid, dim3(256), 0, stream, src, ssp, params + l.w_off, res, \
-                               y_out, (int)g.mz, l.cout, l.cin, tpb, z, arr, fin);                                        \
-        else                                                                                                              \
-            hipLaunchKernelGGL((pw_fwd_kernel<XF, DEEP, 1>), grid, dim3(256), 0, stream, src, ssp, params + l.w_off, res, \
-                               y_out, (int)g.mz, l.cout, l.cin, tpb, z, arr, fin);                                        \
+        if (tile == 64)                                                                                                      \
+            hipLaunchKernelGGL((pw_fwd_kernel<XF, DEEP, 2, 2>), grid, dim3(256), 0, stream, src, ssp, params + l.w_off, res, \
+                               y_out, (int)g.mz, l.cout, l.cin, tpb, z, arr, fin);                                           \
+        else if (tc == 64)                                                                                                   \
+            hipLaunchKernelGGL((pw_fwd_kernel<XF, DEEP, 1, 2>), grid, dim3(256), 0, stream, src, ssp, params + l.w_off, res, \
+                               y_out, (int)g.mz, l.cout, l.cin, tpb, z, arr, fin);                                           \
+        else                                                                                                                 \
+            hipLaunchKernelGGL((pw_fwd_kernel<XF, DEEP, 1, 1>), grid, dim3(256), 0, stream, src, ssp, params + l.w_off, res, \
+                               y_out, (int)g.mz, l.cout, l.cin, tpb, z, arr, fin);                                           \
     } while (0)
             if (!in_mat) {
                 if (deep) HOWL_PW_FWD(PW_IN_RELU6, true);
@@ -2173,7 +2185,8 @@ int howl_mobilenet_bwd(const float* params, int num_labels, const float* x, long
             a.N = l.cout;
             a.C = l.cin;
             const int tile = pw_tile(g.mz, l.cin);     // the data gradient's output is (M x cin)
-            a.d_cx = (l.cin + tile - 1) / tile;
+            const int tc = tile == 32 ? env_int("HOWL_MB_BWD_TC", 64) : 64;
+            a.d_cx = (l.cin + tc - 1) / tc;
             pw_rows(g.mz, a.d_cx, &a.tiles_per_block, &a.d_ry, tile);
             a.rows_per_split = pw_wgrad_rows_per_split(g.mz, l.cout, l.cin);
             a.w_cx = (l.cin + GT - 1) / GT;
@@ -2188,8 +2201,9 @@ int howl_mobilenet_bwd(const float* params, int num_labels, const float* x, long
             const bool deep = l.cout >= PW_DEEP;     // the data gradient reduces over the output channels
 #define HOWL_PW_BWD(XF, DEEP)                                                                               \
     do {                                                                                                    \
-        if (tile == 64) hipLaunchKernelGGL((pw_bwd_kernel<XF, DEEP, 2>), dim3(blocks), dim3(256), 0, stream, a); \
-        else hipLaunchKernelGGL((pw_bwd_kernel<XF, DEEP, 1>), dim3(blocks), dim3(256), 0, stream, a);            \
+        if (tile == 64) hipLaunchKernelGGL((pw_bwd_kernel<XF, DEEP, 2, 2>), dim3(blocks), dim3(256), 0, stream, a);       \
+        else if (tc == 64) hipLaunchKernelGGL((pw_bwd_kernel<XF, DEEP, 1, 2>), dim3(blocks), dim3(256), 0, stream, a);    \
+        else hipLaunchKernelGGL((pw_bwd_kernel<XF, DEEP, 1, 1>), dim3(blocks), dim3(256), 0, stream, a);                  \
     } while (0)
             if (ss_in != nullptr) {
                 if (deep) HOWL_PW_BWD(true, true);
