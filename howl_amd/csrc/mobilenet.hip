@@ -468,11 +468,15 @@ __device__ __forceinline__ void finalize_bwd(const float* part, int R, int C, in
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Pointwise (1x1) convolutions.  Shared tile engine: 64 x 64 outputs per step, 64 deep (PK), 2x2 waves x 2x2 fp32 MFMA
-// 16x16x4; the operand pieces of the NEXT step are requested (16-byte loads, one step in flight) before the MFMAs of the
-// current one.  The late layers of this network are tiny matrices with a deep reduction (2048 x 960 x 160): what they cost
-// is steps x memory latency, so a step is as deep as registers allow and a thread's piece keeps ONE k offset for the whole
-// launch -- the per-channel constants of the on-load transforms are a few registers per step.
+// Pointwise (1x1) convolutions.  Shared tile engine: a (32 WTR) x (32 WTC) block of outputs per step, 64 deep (PK), 2x2 waves
+// x (WTR x WTC) fp32 MFMA 16x16x4 tiles; the operand pieces of the NEXT step are requested (16-byte loads) before the MFMAs of
+// the current one (two steps in flight was measured: slower, the registers cost occupancy).
+// The late layers of this network are small matrices with a deep reduction (2048 x 960 x 160).  On 64 x 64 tiles that is 96
+// blocks for 256 CUs, each a chain of 15 steps of 64 MFMAs per wave (32 cycles each): MFMA-bound per block on a mostly idle
+// chip.  Launches with fewer 64 x 64 tiles than CUs take 32-row tiles instead (forward 32 x 32, data gradient 32 x 64: its A
+// operand is two tensors, re-reading it per column block costs more than it buys) -- shorter chains on more CUs.
+// A thread's piece keeps ONE k offset for the whole launch: the per-channel constants of the on-load transforms are a few
+// registers per step.
 // Operand tiles whose unit-stride index is the reduction index are kept [row][k] (stride LDK): 16-byte stores, and a lane
 // group q = lane / 16 reads k = 16t + 4q .. + 3 with ONE 16-byte LDS load and feeds them to four consecutive MFMAs (the order
 // in which the 64 k of a step enter the sum is a fixed permutation).  Tiles whose unit stride is the output column stay
@@ -481,7 +485,6 @@ __device__ __forceinline__ void finalize_bwd(const float* part, int R, int C, in
 constexpr int PK = 64;
 constexpr int LDK = PK + 4;   // floats: 16-byte aligned rows, conflict-free fragment loads
 constexpr int LDC = 80;
-constexpr int PW_DEEP = 192;    // reductions at least this deep keep two steps in flight
 constexpr int PW_LDS_FLOATS = 2 * PK * LDC;   // the largest role (weight gradient: two [k][col] tiles)
 
 enum { PW_IN_PLAIN = 0, PW_IN_RELU6 = 1, PW_IN_LINEAR = 2 };
@@ -584,7 +587,7 @@ __device__ __forceinline__ void mma_cc(const float* As, const float* Bs, f32x4 (
 struct PwFwdStage {
     float4 va[4], vb[4], vr[4], xsc, xsh;
 };
-template <int XF, bool DEEP, int WTR, int WTC>
+template <int XF, int WTR, int WTC>
 __global__ __launch_bounds__(256) void pw_fwd_kernel(const float* __restrict__ a, const float* __restrict__ ss_in,
                                                      const float* __restrict__ w, const float* __restrict__ res,
                                                      float* __restrict__ y_out, int M, int N, int K, int tiles_per_block,
@@ -636,8 +639,6 @@ __global__ __launch_bounds__(256) void pw_fwd_kernel(const float* __restrict__ a
             ap[i] = a + (long)min(m0 + p_r + 16 * i, M - 1) * K;
             a_ok[i] = m0 + p_r + 16 * i < M;
         }
-        // DEEP: two steps in flight (the step being staged + the next two requested) -- the late layers are a chain of
-        // K / 64 dependent steps on a chip that is mostly idle, so what a step costs is the memory latency it exposes
         auto fetch = [&](PwFwdStage& sg, int k0) {
             const int k = min(k0 + p_k, K - 4);
 #pragma unroll
@@ -676,26 +677,15 @@ __global__ __launch_bounds__(256) void pw_fwd_kernel(const float* __restrict__ a
         for (int i = 0; i < WTR; ++i)
 #pragma unroll
             for (int j = 0; j < WTC; ++j) acc[i][j] = {0.0f, 0.0f, 0.0f, 0.0f};
-        PwFwdStage st0, st1;
-        constexpr int AHEAD = DEEP ? 2 * PK : PK;
+        PwFwdStage st0;
         fetch(st0, 0);
-        if (DEEP) fetch(st1, PK);     // past the end: a clamped (re)load that is never staged
-        for (int k0 = 0; k0 < K; k0 += AHEAD) {
+        for (int k0 = 0; k0 < K; k0 += PK) {
             stage(st0, k0);
             __syncthreads();
-            fetch(st0, k0 + AHEAD);
+            fetch(st0, k0 + PK);     // past the end: a clamped (re)load that is never staged
             __builtin_amdgcn_sched_barrier(0);
             mma_kk<WTR, WTC>(As, Bs, acc, min(PK, K - k0 + 15) / 16, wr, wc, lane);
             __syncthreads();
-            if (DEEP) {
-                if (k0 + PK >= K) break;
-                stage(st1, k0 + PK);
-                __syncthreads();
-                fetch(st1, k0 + PK + AHEAD);
-                __builtin_amdgcn_sched_barrier(0);
-                mma_kk<WTR, WTC>(As, Bs, acc, min(PK, K - k0 - PK + 15) / 16, wr, wc, lane);
-                __syncthreads();
-            }
         }
         if (!(stats && t == t1 - 1)) store_tile(m0);
 #pragma unroll
@@ -764,7 +754,7 @@ struct PwBwd {
 struct PwBwdStage {
     float4 vg[4], vz[4], vb[4], ksc, kc1, kc0;
 };
-template <bool DEEP, int WTR, int WTC>
+template <int WTR, int WTC>
 __device__ __forceinline__ void pw_dgrad_body(float* lds, const PwBwd& p, int bx, int by) {
     constexpr int TR = 32 * WTR, TC = 32 * WTC;    // block tile
     constexpr int NP = TR / 16;                    // dz pieces per thread and step
@@ -849,26 +839,15 @@ __device__ __forceinline__ void pw_dgrad_body(float* lds, const PwBwd& p, int bx
         for (int i = 0; i < WTR; ++i)
 #pragma unroll
             for (int j = 0; j < WTC; ++j) acc[i][j] = {0.0f, 0.0f, 0.0f, 0.0f};
-        PwBwdStage st0, st1;
-        constexpr int AHEAD = DEEP ? 2 * PK : PK;
+        PwBwdStage st0;
         fetch(st0, 0);
-        if (DEEP) fetch(st1, PK);
-        for (int k0 = 0; k0 < N; k0 += AHEAD) {
+        for (int k0 = 0; k0 < N; k0 += PK) {
             stage(st0, k0);
             __syncthreads();
-            fetch(st0, k0 + AHEAD);
+            fetch(st0, k0 + PK);
             __builtin_amdgcn_sched_barrier(0);
             mma_kc<WTR, WTC>(As, Bs, acc, min(PK, N - k0 + 15) / 16, wr, wc, lane);
             __syncthreads();
-            if (DEEP) {
-                if (k0 + PK >= N) break;
-                stage(st1, k0 + PK);
-                __syncthreads();
-                fetch(st1, k0 + PK + AHEAD);
-                __builtin_amdgcn_sched_barrier(0);
-                mma_kc<WTR, WTC>(As, Bs, acc, min(PK, N - k0 - PK + 15) / 16, wr, wc, lane);
-                __syncthreads();
-            }
         }
         // epilogue: all loads first (clamped, unconditional), then arithmetic, then the guarded stores
         float zj[WTR][WTC][4], ad[WTR][WTC][4];
@@ -992,12 +971,12 @@ __device__ __forceinline__ void pw_wgrad_body(float* lds, const PwBwd& p, int bx
         }
 }
 
-template <bool XF, bool DEEP, int WTR, int WTC>
+template <bool XF, int WTR, int WTC>
 __global__ __launch_bounds__(256) void pw_bwd_kernel(PwBwd p) {
     __shared__ __attribute__((aligned(16))) float lds[PW_LDS_FLOATS];
     const int b = blockIdx.x, nd = p.d_cx * p.d_ry;
     if (b < nd) {
-        pw_dgrad_body<DEEP, WTR, WTC>(lds, p, b % p.d_cx, b / p.d_cx);
+        pw_dgrad_body<WTR, WTC>(lds, p, b % p.d_cx, b / p.d_cx);
     } else {
         const int wb = b - nd;
         const int bx = wb % p.w_cx, r = wb / p.w_cx;
@@ -2060,7 +2039,6 @@ int howl_mobilenet_fwd(const float* params, float* buffers, int num_labels, cons
             pw_rows(g.mz, (l.cout + tc - 1) / tc, &tpb, &rb, tile);
             const dim3 grid((l.cout + tc - 1) / tc, rb);
             HowlProfScope prof("mb_conv", stream, 4.0 * (double)g.mz * (l.cin + l.cout));
-            const bool deep = l.cin >= PW_DEEP;
             const HowlMbLayer& lp = c.n->layers[k - 1];
             const float* res = nullptr;
             float* y_out = nullptr;
@@ -2072,25 +2050,20 @@ int howl_mobilenet_fwd(const float* params, float* buffers, int num_labels, cons
                 res = lp.res_src >= 0 ? c.ws + c.p.y[lp.res_src] : nullptr;
                 y_out = c.ws + c.p.y[k - 1];
             }
-#define HOWL_PW_FWD(XF, DEEP)                                                                                             \
+#define HOWL_PW_FWD(XF)                                                                                                   \
     do {                                                                                                                  \
         if (tile == 64)                                                                                                      \
-            hipLaunchKernelGGL((pw_fwd_kernel<XF, DEEP, 2, 2>), grid, dim3(256), 0, stream, src, ssp, params + l.w_off, res, \
+            hipLaunchKernelGGL((pw_fwd_kernel<XF, 2, 2>), grid, dim3(256), 0, stream, src, ssp, params + l.w_off, res, \
                                y_out, (int)g.mz, l.cout, l.cin, tpb, z, arr, fin);                                           \
         else if (tc == 64)                                                                                                   \
-            hipLaunchKernelGGL((pw_fwd_kernel<XF, DEEP, 1, 2>), grid, dim3(256), 0, stream, src, ssp, params + l.w_off, res, \
+            hipLaunchKernelGGL((pw_fwd_kernel<XF, 1, 2>), grid, dim3(256), 0, stream, src, ssp, params + l.w_off, res, \
                                y_out, (int)g.mz, l.cout, l.cin, tpb, z, arr, fin);                                           \
         else                                                                                                                 \
-            hipLaunchKernelGGL((pw_fwd_kernel<XF, DEEP, 1, 1>), grid, dim3(256), 0, stream, src, ssp, params + l.w_off, res, \
+            hipLaunchKernelGGL((pw_fwd_kernel<XF, 1, 1>), grid, dim3(256), 0, stream, src, ssp, params + l.w_off, res, \
                                y_out, (int)g.mz, l.cout, l.cin, tpb, z, arr, fin);                                           \
     } while (0)
-            if (!in_mat) {
-                if (deep) HOWL_PW_FWD(PW_IN_RELU6, true);
-                else HOWL_PW_FWD(PW_IN_RELU6, false);
-            } else {
-                if (deep) HOWL_PW_FWD(PW_IN_LINEAR, true);
-                else HOWL_PW_FWD(PW_IN_LINEAR, false);
-            }
+            if (!in_mat) HOWL_PW_FWD(PW_IN_RELU6);
+            else HOWL_PW_FWD(PW_IN_LINEAR);
 #undef HOWL_PW_FWD
         } else if (l.kind == MB_DW) {
             int rpc;
@@ -2198,20 +2171,14 @@ int howl_mobilenet_bwd(const float* params, int num_labels, const float* x, long
             a.slabs = slab;
             const unsigned blocks = (unsigned)(a.d_cx * a.d_ry + a.w_cx * a.w_ny * a.w_nz);
             HowlProfScope prof("mb_conv", stream, 4.0 * (double)g.mz * (4.0 * l.cout + 4.0 * l.cin));
-            const bool deep = l.cout >= PW_DEEP;     // the data gradient reduces over the output channels
-#define HOWL_PW_BWD(XF, DEEP)                                                                               \
+#define HOWL_PW_BWD(XF)                                                                                     \
     do {                                                                                                    \
-        if (tile == 64) hipLaunchKernelGGL((pw_bwd_kernel<XF, DEEP, 2, 2>), dim3(blocks), dim3(256), 0, stream, a);       \
-        else if (tc == 64) hipLaunchKernelGGL((pw_bwd_kernel<XF, DEEP, 1, 2>), dim3(blocks), dim3(256), 0, stream, a);    \
-        else hipLaunchKernelGGL((pw_bwd_kernel<XF, DEEP, 1, 1>), dim3(blocks), dim3(256), 0, stream, a);                  \
+        if (tile == 64) hipLaunchKernelGGL((pw_bwd_kernel<XF, 2, 2>), dim3(blocks), dim3(256), 0, stream, a);       \
+        else if (tc == 64) hipLaunchKernelGGL((pw_bwd_kernel<XF, 1, 2>), dim3(blocks), dim3(256), 0, stream, a);    \
+        else hipLaunchKernelGGL((pw_bwd_kernel<XF, 1, 1>), dim3(blocks), dim3(256), 0, stream, a);                  \
     } while (0)
-            if (ss_in != nullptr) {
-                if (deep) HOWL_PW_BWD(true, true);
-                else HOWL_PW_BWD(true, false);
-            } else {
-                if (deep) HOWL_PW_BWD(false, true);
-                else HOWL_PW_BWD(false, false);
-            }
+            if (ss_in != nullptr) HOWL_PW_BWD(true);
+            else HOWL_PW_BWD(false);
 #undef HOWL_PW_BWD
             jobs.add(slab, a.w_nz, (long)l.cout * l.cin, grads + l.w_off);
         } else {   // depthwise (layers 0 and 1 are the only dense ones)
