@@ -1,13 +1,16 @@
 """``InferenceContext`` (``howl/context.py:14-125``): vocab -> label ids; sizes the model head.
 
-Word-level tokens are implemented (all BASELINE configs use ``TOKEN_TYPE='word'``); the phone-level branch needs the
-pronunciation-dictionary / phone plumbing that SURVEY 2 lists as out of scope, and raises.
+Both token types of the reference: ``word`` (all BASELINE configs) and ``phone`` (``context.py:52-61``: every vocab word is
+replaced by the phones of its first dictionary pronunciation, one colour per word).
 """
 import logging
+from pathlib import Path
 from typing import List
 
-from howl_amd.data.common.labeler import WordFrameLabeler
-from howl_amd.data.common.searcher import WordTranscriptSearcher
+from howl_amd.data.common.labeler import PhoneticFrameLabeler, WordFrameLabeler
+from howl_amd.data.common.phone import PhonePhrase, PronunciationDictionary
+from howl_amd.data.common.searcher import LabelColoring, PhoneticTranscriptSearcher, WordTranscriptSearcher
+from howl_amd.settings import SETTINGS
 from howl_amd.data.common.tokenizer import TokenType
 from howl_amd.data.common.vocab import Vocab
 
@@ -25,16 +28,29 @@ class InferenceContext:
         self.num_labels = 0
         self.token_type = token_type
         self.pronounce_dict = None
-        if token_type != "word":
-            raise NotImplementedError("InferenceContext: only token_type='word' is on the MI355X hot path "
-                                      "(context.py:52-61 phone branch needs the pronunciation dictionary stack)")
-        self.add_vocab(vocab)
+        if token_type not in ("word", "phone"):
+            raise ValueError(f"InferenceContext: unknown token_type {token_type!r} (word | phone)")
+        phone = token_type == "phone"
+        if phone:
+            self.pronounce_dict = PronunciationDictionary.from_file(Path(SETTINGS.training.phone_dictionary))
+            self.coloring = LabelColoring()
+            for word in vocab:
+                phrase = self.pronounce_dict.encode(word)[0]       # single pronunciation, as the reference
+                logging.info(f"Word {word: <10} has phonemes of {str(phrase)}")
+                self.add_vocab([str(ph) for ph in phrase.phones])
+        else:
+            self.add_vocab(vocab)
         self.negative_label = len(self.adjusted_vocab)
         self.vocab = Vocab({word: idx for idx, word in enumerate(self.adjusted_vocab)},
                            oov_token_id=self.negative_label)
-        self.labeler = WordFrameLabeler(self.vocab)
+        # the labeler sees the targets only: built before the [OOV] / [BLANK] labels are appended
+        if phone:
+            phrases = [PhonePhrase.from_string(x) for x in self.adjusted_vocab]
+            self.labeler = PhoneticFrameLabeler(phrases, self.pronounce_dict)
+        else:
+            self.labeler = WordFrameLabeler(self.vocab)
         self.add_vocab(["[OOV]"])
-        self.searcher = WordTranscriptSearcher(self.vocab)
+        self.searcher = PhoneticTranscriptSearcher(phrases, self.coloring) if phone else WordTranscriptSearcher(self.vocab)
         self.blank_label = -1
         if use_blank:
             self.blank_label = len(self.adjusted_vocab)
@@ -43,8 +59,9 @@ class InferenceContext:
             logging.info(f"target {word:10} is assigned to label {idx}")
 
     def add_vocab(self, vocabs: List[str]):
-        for v in vocabs:
-            self.adjusted_vocab.append(v)
+        self.adjusted_vocab.extend(vocabs)
+        if self.coloring:
+            self.coloring.extend_sequence(len(vocabs))
         self.num_labels += len(vocabs)
 
     @property

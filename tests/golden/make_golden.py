@@ -375,6 +375,66 @@ def frame_batchifier_golden():
     save("g10_frame_batchifier", **out)
 
 
+PHONE_DICT_TEXT = """;;; test pronunciation dictionary (CMUdict layout)
+HEY  HH EY1
+HEY(2)  HH EH1
+FIRE  F AY1 ER0
+FOX  F AA1 K S
+FIREFOX  F AY1 ER0 F AA1 K S
+HELLO  HH AH0 L OW1
+WORLD  W ER1 L D
+IT'S  IH1 T S
+A  AH0
+PAUSE  sil
+"""
+PHONE_VOCAB = ["hey", "fire", "fox"]
+PHONE_TRANSCRIPTS = ["hey fire fox", "hello world hey firefox", "it\u2019s a fox, hey! pause fire fox", "<unk> hey hey fire",
+                     "world helloworld xyzzy fox"]
+PHONE_QUERIES = ["hh ey1 f ay1 er0 f aa1 k s", "hh ey1 sil f ay1 er0 sp f aa1 k s", "f aa1 k s hh ey1", "hh ah0 l ow1",
+                 "f ay1 er0 f aa1 k s", "hh ey1 f ay1 er0 w er1 l d f aa1 k s", ""]
+
+
+def phone_context_golden():
+    """G11: InferenceContext(token_type="phone") (context.py:52-99) with its PhoneticFrameLabeler / PhoneticTranscriptSearcher /
+    LabelColoring, and the PhonePhrase index helpers -- outputs of the reference classes on a small dictionary."""
+    import json
+    import tempfile
+    from types import SimpleNamespace
+    from howl.context import InferenceContext
+    from howl.data.common.phone import PhonePhrase
+    from howl.settings import SETTINGS
+    with tempfile.NamedTemporaryFile("w", suffix=".dict", delete=False) as f:
+        f.write(PHONE_DICT_TEXT)
+    SETTINGS.training.phone_dictionary = f.name
+    SETTINGS.inference_engine.inference_sequence = [0, 1, 2]
+    out = {}
+    for tag, use_blank in (("noblank", False), ("blank", True)):
+        ctx = InferenceContext(PHONE_VOCAB, token_type="phone", use_blank=use_blank)
+        out[tag] = {"adjusted_vocab": list(ctx.adjusted_vocab), "num_labels": ctx.num_labels, "negative_label": ctx.negative_label,
+                    "blank_label": ctx.blank_label, "color_map": {str(k): v for k, v in ctx.coloring.color_map.items()},
+                    "pattern": ctx.searcher.pattern.pattern}
+    labels = []
+    for tr in PHONE_TRANSCRIPTS:
+        md = SimpleNamespace(transcription=tr, end_timestamps=[10.0 * (i + 1) for i in range(len(tr))])
+        labels.append({str(k): v for k, v in ctx.labeler.compute_frame_labels(md).timestamp_label_map.items()})
+    out["frame_labels"] = labels
+    out["search"] = [bool(ctx.searcher.search(q)) for q in PHONE_QUERIES]
+    out["contains_any"] = [bool(ctx.searcher.contains_any(q)) for q in PHONE_QUERIES]
+    pp = PhonePhrase.from_string("hh ey1 sil f ay1 sp er0 spn")
+    out["phrase"] = {"audible": pp.audible_transcript, "sil": pp.sil_indices,
+                     "all_to_transcript": [pp.all_idx_to_transcript_idx(i) for i in range(len(pp.phones))],
+                     "audible_to_all": [pp.audible_idx_to_all_idx(i) for i in range(len(pp.audible_phones))],
+                     "index_er0": pp.audible_index(PhonePhrase.from_string("sil er0")),
+                     "index_from1": pp.audible_index(PhonePhrase.from_string("ay1 er0"), 1)}
+    out["inputs"] = {"dictionary": PHONE_DICT_TEXT, "vocab": PHONE_VOCAB, "transcripts": PHONE_TRANSCRIPTS, "queries": PHONE_QUERIES}
+    words = {}
+    for w in ("firefox", "helloworld", "heyfox", "it's"):
+        words[w] = str(ctx.labeler.transform(w))
+    out["transform"] = words
+    (HERE / "g11_phone_context.json").write_text(json.dumps(out, indent=1, sort_keys=True) + "\n")
+    print("g11_phone_context.json", {k: (len(v) if hasattr(v, "__len__") else v) for k, v in out.items()})
+
+
 if __name__ == "__main__":
     only = [a for a in sys.argv[1:] if a.startswith("--only-")]
     if not only:
@@ -385,3 +445,5 @@ if __name__ == "__main__":
         mixer_golden()
     if not only or "--only-frame-batchifier" in only:
         frame_batchifier_golden()
+    if not only or "--only-phone" in only:
+        phone_context_golden()

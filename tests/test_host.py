@@ -172,3 +172,59 @@ def test_converted_static_model_windows():
         got, want = m(x, None), reference_loop(Probe(), x, win, hop)
         assert got.shape == want.shape and torch.allclose(got, want), (T, win, hop)
         assert m.compute_length(T) == max(1, (T - win) // hop) and m.compute_length(None) is None
+
+
+def test_phone_token_context_vs_reference_golden(tmp_path):
+    """InferenceContext(token_type="phone") with PhoneticFrameLabeler / PhoneticTranscriptSearcher / LabelColoring / PhonePhrase
+    against golden G11 -- the reference's own classes on the same small pronunciation dictionary
+    (tests/golden/make_golden.py::phone_context_golden)."""
+    import json
+    from pathlib import Path
+    from types import SimpleNamespace
+    from howl_amd.context import InferenceContext
+    from howl_amd.data.common.phone import PhonePhrase, PronunciationDictionary
+    from howl_amd.settings import SETTINGS
+    g = json.loads((Path(__file__).parent / "golden" / "g11_phone_context.json").read_text())
+    inp = g["inputs"]
+    dpath = tmp_path / "test.dict"
+    dpath.write_text(inp["dictionary"])
+    saved = (SETTINGS.training.phone_dictionary, SETTINGS.inference_engine.inference_sequence)
+    SETTINGS.training.phone_dictionary = str(dpath)
+    SETTINGS.inference_engine.inference_sequence = [0, 1, 2]
+    try:
+        d = PronunciationDictionary.from_file(dpath)
+        assert "HEY" in d and " fox " in d and "xyzzy" not in d and len(d.encode("hey")) == 1 and str(d.encode("it's")[0]) == "ih1 t s"
+        with pytest.raises(ValueError):
+            d.encode("xyzzy")
+        for tag, use_blank in (("noblank", False), ("blank", True)):
+            ctx = InferenceContext(inp["vocab"], token_type="phone", use_blank=use_blank)
+            want = g[tag]
+            assert list(ctx.adjusted_vocab) == want["adjusted_vocab"]
+            assert (ctx.num_labels, ctx.negative_label, ctx.blank_label) == (want["num_labels"], want["negative_label"], want["blank_label"])
+            assert {str(k): v for k, v in ctx.coloring.color_map.items()} == want["color_map"]
+            assert ctx.searcher.pattern.pattern == want["pattern"]
+        for tr, want in zip(inp["transcripts"], g["frame_labels"]):
+            md = SimpleNamespace(transcription=tr, end_timestamps=[10.0 * (i + 1) for i in range(len(tr))])
+            got = ctx.labeler.compute_frame_labels(md).timestamp_label_map
+            assert {str(k): v for k, v in got.items()} == want, tr
+        assert [ctx.searcher.search(q) for q in inp["queries"]] == g["search"]
+        assert [ctx.searcher.contains_any(q) for q in inp["queries"]] == g["contains_any"]
+        pp = PhonePhrase.from_string("hh ey1 sil f ay1 sp er0 spn")
+        ph = g["phrase"]
+        assert pp.audible_transcript == ph["audible"] and pp.sil_indices == ph["sil"]
+        assert [pp.all_idx_to_transcript_idx(i) for i in range(len(pp.phones))] == ph["all_to_transcript"]
+        assert [pp.audible_idx_to_all_idx(i) for i in range(len(pp.audible_phones))] == ph["audible_to_all"]
+        assert pp.audible_index(PhonePhrase.from_string("sil er0")) == ph["index_er0"]
+        assert pp.audible_index(PhonePhrase.from_string("ay1 er0"), 1) == ph["index_from1"]
+        with pytest.raises(ValueError):
+            pp.audible_index(PhonePhrase.from_string("sil"))
+        with pytest.raises(ValueError):
+            pp.all_idx_to_transcript_idx(len(pp.phones))
+        for w, want in g["transform"].items():
+            assert str(ctx.labeler.transform(w)) == want, w
+        with pytest.raises(ValueError):
+            ctx.labeler.transform("<unk>")           # the reference's loop resumes at '>' and fails (labeler.py:77-89)
+        with pytest.raises(ValueError):
+            InferenceContext(inp["vocab"], token_type="syllable")
+    finally:
+        SETTINGS.training.phone_dictionary, SETTINGS.inference_engine.inference_sequence = saved
