@@ -15,7 +15,7 @@ from howl_amd.training.fused import FusedTrainer  # noqa: E402
 from howl_amd.utils.synth import synthetic_pcm  # noqa: E402
 
 dev = torch.device("cuda:0")
-for name, B, C, lr, steps in (("res8", 256, 12, 0.01, 300), ("mobilenet", 128, 12, 0.001, 150)):
+for name, B, C, lr, steps in (("res8", 256, 12, 0.01, 300), ("mobilenet", 128, 12, 0.001, 150), ("mobilenet", 512, 12, 0.001, 120)):
     finals = []
     for rep in range(2):
         torch.manual_seed(0)
