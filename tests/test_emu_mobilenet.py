@@ -65,6 +65,12 @@ def test_layer_table_matches_oracle(lib):
         assert d.w_off == off
         off += int(np.prod(om.conv_shape(o))) + (o["cout"] if o["bias"] else 0) + 2 * o["cout"]
     assert lib.cdll.howl_mobilenet_buffer_floats() == sum(2 * o["cout"] for o in otab)
+    # known answer from the literature: torchvision's mobilenet_v2 (width 1.0) has 3,504,872 parameters with its 1000-way
+    # classifier, 2,223,872 of them in `features` -- the layer table (+ the 36-parameter downsample stem in front) must add up to
+    # exactly that.  (torchvision itself is not available here: this pins the architecture, not the arithmetic.)
+    downsample = 3 * 1 * 9 + 3 + 3 + 3
+    assert lib.cdll.howl_mobilenet_param_floats(1000) - downsample == 3504872
+    assert lib.cdll.howl_mobilenet_param_floats(1000) - downsample - (1000 * 1280 + 1000) == 2223872
 
 
 @pytest.mark.parametrize("B,T,dropout", [(6, 41, False), (5, 30, True)])
