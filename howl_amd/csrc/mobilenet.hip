@@ -176,7 +176,7 @@ inline int pw_wgrad_rows_per_split(long rows, int n, int c) {
     int tpb, blocks;
     pw_rows(rows, (c + 63) / 64, &tpb, &blocks);
     long rps = 64L * tpb * ((n + 63) / 64);
-    if (rps < 256) rps = 256;
+    if (rps < 256) rps = 256;     // (128 .. 256 rows measured the same; 512 and more make these blocks the long pole)
     if (rps > rows) rps = (rows + 63) / 64 * 64;
     return (int)rps;
 }
