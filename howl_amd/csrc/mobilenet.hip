@@ -130,7 +130,6 @@ constexpr int MB_G = 32;          // blocks of one first-level group of a fused 
 constexpr int MB_R2 = 64;         // groups (second level); a reduction has at most MB_R = MB_G * MB_R2 blocks along the rows
 constexpr int MB_R = MB_G * MB_R2;
 constexpr int MB_MAXC = 1280;     // widest layer
-constexpr int MB_MAXK = 960;      // widest input of a pointwise layer that is normalised on load
 constexpr int MB_CBLOCKS = 64;    // channel blocks of a launch: 64 wide (<= 20) or 32 wide (<= 40)
 constexpr int MB_COUNTERS = MB_CBLOCKS * (MB_R2 + 1);   // arrival counters: per channel block, one per group + one for the groups
 constexpr int MB_MAX_JOBS = 60;   // deferred slab sums of one backward call (53 convolution weights)
@@ -274,11 +273,6 @@ Plan make_plan(int B, int H0, int W0, int num_labels) {
 // ---------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int chan_of(long idx, int C) {
     return idx < (1L << 31) ? (int)((unsigned)idx % (unsigned)C) : (int)(idx % C);
-}
-__device__ __forceinline__ float mb_act(float v, int act) {
-    if (act == MB_ACT_RELU6) return fminf(fmaxf(v, 0.0f), 6.0f);
-    if (act == MB_ACT_RELU) return fmaxf(v, 0.0f);
-    return v;
 }
 __device__ __forceinline__ bool mb_act_passes(float v, int act) {  // derivative of the activation is 1
     if (act == MB_ACT_RELU6) return v > 0.0f && v < 6.0f;
