@@ -73,6 +73,18 @@ def parse():
     return ap.parse_args()
 
 
+def c5_traffic():
+    """HBM bytes per STEP of the MobileNet kernels from profiles/*c5_hbm_traffic*.txt (tools/pmc_round.sh c5: separate
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, read side doubled per MI355X_MICROARCH.md)."""
+    import re
+    files = sorted((ROOT / "profiles").glob("*c5_hbm_traffic*.txt"))
+    for f in reversed(files):
+        m = re.search(r"total: read (\d+) MB \+ write (\d+) MB", f.read_text())
+        if m:
+            return (int(m.group(1)) + int(m.group(2))) * 1e6, f.name
+    return None, None
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # launcher: `python bench.py --gpus N` without a distributed environment starts the N ranks itself
 # ---------------------------------------------------------------------------------------------------------------------
@@ -400,7 +412,10 @@ def main():
                                               "conv + BatchNorm statistics, input normalised on load; backward: data + weight "
                                               "gradient + BatchNorm-backward reduction in one launch), summed",
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "frac": round(achieved / HBM_PEAK_GBS, 4),
+                    "traffic": None if c5_traffic()[0] is None or (B, L) != (512, 16000) else round(c5_traffic()[0]),
+                    "traffic_unit": "HBM bytes per STEP, all MobileNet kernels (PMC FETCH_SIZE x2 + WRITE_SIZE)",
+                    "traffic_source": c5_traffic()[1],
                     "algorithmic_bytes": round(wb / args.steps), "avg_launch_ms": round(ts / max(ns, 1), 4), "launches": ns,
                     "note": "algorithmic bytes (every operand read once, every result written once) and summed kernel time per "
                             "STEP; most layers are a few MB and latency-bound, see DESIGN.md 5c",
