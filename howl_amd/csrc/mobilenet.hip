@@ -1886,19 +1886,18 @@ __global__ __launch_bounds__(256) void sum_jobs_kernel(MbSumJobs jobs) {
     const long i = (long)((int)blockIdx.x - jb.blk0) * 64 + lane;
     float s[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     if (i < n) {
-        int gq = rg;
-        for (; gq + 28 < jb.nparts; gq += 32) {     // eight loads in flight
+        // eight slabs per trip, requested together from clamped rows and masked afterwards: jobs with few slabs (the wide late
+        // layers have 7-24) are ONE round trip per wave instead of a chain of dependent ones
+        for (int gq = rg; gq < jb.nparts; gq += 32) {
             float v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = jb.part[(long)(gq + 4 * u) * n + i];
+            for (int u = 0; u < 8; ++u) {
+                const int g = gq + 4 * u < jb.nparts ? gq + 4 * u : jb.nparts - 1;
+                v[u] = jb.part[(long)g * n + i];
+            }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) s[u & 3] += v[u];
+            for (int u = 0; u < 8; ++u) s[u & 3] += gq + 4 * u < jb.nparts ? v[u] : 0.0f;
         }
-        for (; gq + 12 < jb.nparts; gq += 16) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) s[u] += jb.part[(long)(gq + 4 * u) * n + i];
-        }
-        for (; gq < jb.nparts; gq += 4) s[0] += jb.part[(long)gq * n + i];
     }
     red[rg][lane] = (s[0] + s[1]) + (s[2] + s[3]);
     __syncthreads();
