@@ -37,7 +37,8 @@ def test_registry_and_state_dict():
 
 # (96, 101, 12): the first block has 203 k pixels -- multi-tile blocks, two-level arrival (more than 64 partial rows), 64 x 64 and
 # 32-row tiles side by side; (7, 57, 3): nothing divides anything (odd batch, odd widths at every stride, 3 labels)
-@pytest.mark.parametrize("B,T,C,dropout", [(8, 81, 12, True), (16, 41, 4, False), (7, 57, 3, True), (96, 101, 12, False)])
+@pytest.mark.parametrize("B,T,C,dropout", [(8, 81, 12, True), (16, 41, 4, False), (7, 57, 3, True), (96, 101, 12, False),
+                                            (9, 61, 35, False)])
 def test_autograd_forward_backward_vs_oracle(B, T, C, dropout):
     torch.manual_seed(B + T)
     x = torch.randn(B, 3, 40, T) * 1.5
