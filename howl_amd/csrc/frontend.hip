@@ -7,22 +7,26 @@
 //   howl/data/transform/operator.py:119-146           (ZmuvTransform)
 //   howl/data/transform/transform.py:299-339          (SpecAugmentTransform masks)
 //
-// K1 design (one launch for the whole batch): every WAVEFRONT is an independent worker -- no workgroup barrier anywhere.
-//  * frames are flattened over (utterance, t): g = b*T + t; a wave owns "quads" of 4 consecutive frames (grid-stride), i.e.
-//    two frame PAIRS, and keeps its Hann window and twiddles in registers;
-//  * PCM is read straight from HBM/L2 as 256-B coalesced rows (lane j reads sample 64*n1 + j), with the reflect padding of
-//    torch.stft(center=True) folded into the index; the next pair's samples are requested before the current FFT starts;
-//  * two real frames ride in one complex FFT-512 (frame A = re, frame B = im): radix-8 x 3 on one wavefront, 8 points per
-//    lane in registers, two transposes through the wave's private LDS scratch (wave-scope syncs only);
-//  * |X|^2 for bins 0..256 of the quad's 4 frames lands in the wave's private [4][296] LDS tile, and the mel contraction
-//    runs on v_mfma_f32_4x4x1_16b_f32 (16 independent 4x4 outer products per instruction, exact fp32 FMA chains): block j
-//    takes bin 16*kg + j, its 4 rows are the 4 frames, its 4 columns one group of 4 mel bins -- no padding of the frame
-//    dimension to a 16-row tile, so a quad needs ~56 instructions for the standard banded filterbank.  The B operands come
-//    from a fragment-ordered copy of the filterbank (built once by howl_fb_pack / howl_fb_from_points together with the
-//    band limits [lo, hi) of every mel group) through L1; the 16 blocks are summed by a 15-shuffle reduce-scatter that
-//    leaves lane 16*frame + mel%16 holding one output value;
-//  * epilogue: log(x + eps), optional ZMUV (x - mean) / std, 64-B contiguous stores as (B,T,M) [model layout] or (B,M,T).
-// 9 KB of LDS and <= 128 VGPRs per wave: 16 waves per CU hide the LDS / L2 latencies of the serial FFT stages.
+// K1 design (one launch for the whole batch, one persistent workgroup per CU, every WAVEFRONT an independent worker):
+//  * frames are flattened over (utterance, t): g = b*T + t; a wave owns "quads" of 4 consecutive frames and runs one real-input
+//    FFT-512 per frame as a complex FFT-256 of z[n] = x[2n] + i x[2n+1] on 16 lanes x 16 points, 4 frames side by side;
+//  * FFT-256 = 16 x 16: lane (frame i, n2) loads its 16 complex points as sixteen 8-byte loads at immediate offsets (a frame
+//    row of 16 lanes reads 128 contiguous bytes; torch.stft's centre / reflect padding only costs index arithmetic on the
+//    quads that touch an utterance edge), multiplies the window, runs a 16-point DFT entirely in registers (radix 4 x 4,
+//    compile-time twiddles), applies W_256^(n2 k1) and hands the result to lane (k1, frame i) through ONE transpose in the
+//    wave's private LDS tile (no workgroup barrier, no wait: a wave's DS operations execute in order); the second in-register
+//    DFT-16 leaves Z[j + 16 k2], k2 = 0..15, in lane 4j + i;
+//  * real-input recombination without another exchange: lane class j pairs bin k = j + 16 r with 256 - k, whose Z lives in
+//    lane class 16 - j; eight ds_bpermute pairs fetch them, and each lane produces |X|^2 for its 16 bins
+//    (slot r: bin j + 16 r, slot 8 + r: bin 256 - j - 16 r; bin 128 rides in a 17th slot of class 0);
+//  * the power values never leave the registers: with lane = 4j + i they ARE the A operand of v_mfma_f32_4x4x1_16b_f32
+//    (block j, row = frame i), 16 independent 4x4 outer products per instruction against filterbank fragments
+//    (lane 4j + c = fb[bin(j, slot)][4g + c]) staged once per workgroup in LDS; only the (slot, mel group) pairs the HTK
+//    triangles can touch (standard or VTLP-warped: 49 of 170) are multiplied, a flag built with the fragments sends any
+//    other matrix through all pairs;
+//  * the 16 blocks are summed by a reduce-scatter (v_permlane32_swap, v_permlane16_swap, two DPP levels) that leaves 2-3
+//    (frame, mel) sums per lane; log(x + eps), optional ZMUV, stores as (B,T,M) [model layout] or (B,M,T).
+// 132 KB of LDS per 12-wave workgroup (9.1 KB transpose tile per wave + 23 KB of tables), 150 VGPRs.
 // Algorithmic HBM bytes per utterance: 4*L read + 4*M*T written (76,960 B at L=16000, M=40).
 #include <stdlib.h>
 
@@ -36,60 +40,169 @@ constexpr int N_FFT = 512;
 constexpr int HOP = 200;
 constexpr int N_FREQ = 257;
 constexpr int K_PAD = 260;          // rows of the row-major packed filterbank (257 padded to a multiple of 4)
-constexpr int X1_STRIDE = 68;       // exchange-1 row stride (complex elements), conflict-free
-constexpr int X2_STRIDE = 66;       // exchange-2 row stride
-constexpr int SCR_CF = 8 * X1_STRIDE;  // complex elements of scratch per wave (544 >= 512)
 constexpr int QUAD = 4;             // frames per wave iteration == rows of a 4x4x1 MFMA block
-constexpr int KG = 17;              // bin groups of 16 (one bin per MFMA block): 17 * 16 = 272 >= 257
-constexpr int NG = HOWL_FB_COLS / 4;   // mel groups of 4 (columns of a block): 12
-constexpr int PQ_STRIDE = 296;      // row stride of the power tile: >= 272 and = 8 (mod 32), so the A-operand read
-                                    // (lane 4j+i -> row i, bin 16kg + j) touches 32 distinct banks per half wave
-// packed filterbank buffer: [ (260, 48) row-major | KG x NG fragments of 64 lanes | 2 * NG band limits (int32) | pad ]
+constexpr int NSLOT = 17;           // power values per lane: 16 bins of its class + bin 128 (class 0 only)
+constexpr int NG_MAX = HOWL_FB_COLS / 4;   // mel groups of 4 (columns of a block): 12
+constexpr int NG_BANDED = 10;       // the banded fragment table covers 40 mel bins
+// packed filterbank buffer: [ (260, 48) row-major | banded fragments [17][64][4] | dense fragments [17][12][64] | 32 ints ]
 constexpr int FBQ_OFF = K_PAD * HOWL_FB_COLS;
-constexpr int FBQ_BAND_OFF = FBQ_OFF + KG * NG * 64;
-static_assert(FBQ_BAND_OFF + 32 == HOWL_FB_PACKED_FLOATS, "include/howl_hip.h and the kernels disagree on the packed filterbank size");
+constexpr int FBQ_FLOATS = NSLOT * 64 * 4;
+constexpr int FBD_OFF = FBQ_OFF + FBQ_FLOATS;
+constexpr int FBD_FLOATS = NSLOT * NG_MAX * 64;
+constexpr int FBF_OFF = FBD_OFF + FBD_FLOATS;     // [0]: 1 when every non-zero weight is covered by the banded table
+static_assert(FBF_OFF + 32 == HOWL_FB_PACKED_FLOATS, "include/howl_hip.h and the kernels disagree on the packed filterbank size");
+constexpr int C_WIN = 0, C_TW = 16 * HOWL_FE_WIN_PITCH, C_PT = 32 * HOWL_FE_WIN_PITCH;
+static_assert(C_PT + 16 * HOWL_FE_PT_PITCH == HOWL_FE_CONST_FLOATS && HOWL_FE_CONST_FLOATS % 4 == 0, "constant table layout");
 
-struct cf {
-    float re, im;
-};
-
-__device__ __forceinline__ cf cmul(cf a, float wr, float wi) { return {a.re * wr - a.im * wi, a.re * wi + a.im * wr}; }
-__device__ __forceinline__ cf cadd(cf a, cf b) { return {a.re + b.re, a.im + b.im}; }
-__device__ __forceinline__ cf csub(cf a, cf b) { return {a.re - b.re, a.im - b.im}; }
-
-// 4-point DFT of (a0..a3), forward sign; results in natural order o0..o3
-__device__ __forceinline__ void dft4(cf a0, cf a1, cf a2, cf a3, cf& o0, cf& o1, cf& o2, cf& o3) {
-    cf b0 = cadd(a0, a2), b1 = cadd(a1, a3), b2 = csub(a0, a2), d = csub(a1, a3);
-    cf b3 = {d.im, -d.re};  // (a1 - a3) * (-i)
-    o0 = cadd(b0, b1);
-    o2 = csub(b0, b1);
-    o1 = cadd(b2, b3);
-    o3 = csub(b2, b3);
+// Bin held by lane class j (= lane >> 2) in power slot s; -1: the slot is empty for this class.
+__host__ __device__ constexpr int bin_of(int s, int j) {
+    return s < 8 ? j + 16 * s : (s < 16 ? 256 - j - 16 * (s - 8) : (j == 0 ? 128 : -1));
+}
+// Inverse: bin k -> slot (class = class_of_bin).
+__host__ __device__ constexpr int slot_of_bin(int k) { return k < 128 ? (k >> 4) : (k == 128 ? 16 : 8 + ((256 - k) >> 4)); }
+// The mel groups (of 4 bins) a slot can reach: union over the standard HTK filterbank (40 mels, 0-8 kHz, 257 bins) and its
+// VTLP warps for alpha in [0.9, 1.1] (transform.py:373-410, the alpha > 1 re-mask quirk included; swept offline).  Component
+// q of the slot's 16-byte fragment entry belongs to group slot_group(s, q); -1 = unused.
+__host__ __device__ constexpr int slot_group(int s, int q) {
+    constexpr signed char t[NSLOT][4] = {{0, 1, 2, 8},   {1, 2, 3, 8},   {3, 4, 8, -1},  {4, 5, 8, -1},  {4, 5, 6, 8},  {5, 6, 7, 8},
+                                         {6, 7, 8, -1},  {6, 7, 8, -1},  {7, 9, -1, -1}, {7, 9, -1, -1}, {7, 9, -1, -1}, {7, 8, 9, -1},
+                                         {7, 8, 9, -1},  {7, 8, 9, -1},  {7, 8, -1, -1}, {7, 8, -1, -1}, {7, 8, -1, -1}};
+    return t[s][q];
+}
+__host__ __device__ constexpr bool slot_has_group(int s, int g) {
+    return slot_group(s, 0) == g || slot_group(s, 1) == g || slot_group(s, 2) == g || slot_group(s, 3) == g;
 }
 
-// in-place 8-point forward DFT: v[k] = sum_n v[n] * exp(-2 pi i n k / 8)
-__device__ __forceinline__ void dft8(cf (&v)[8]) {
-    const float h = 0.70710678118654752440f;
-    cf t0 = cadd(v[0], v[4]), t1 = cadd(v[1], v[5]), t2 = cadd(v[2], v[6]), t3 = cadd(v[3], v[7]);
-    cf d0 = csub(v[0], v[4]), e1 = csub(v[1], v[5]), e2 = csub(v[2], v[6]), e3 = csub(v[3], v[7]);
-    cf d1 = {(e1.re + e1.im) * h, (e1.im - e1.re) * h};   // * W8^1 = (1 - i)/sqrt2
-    cf d2 = {e2.im, -e2.re};                              // * W8^2 = -i
-    cf d3 = {(e3.im - e3.re) * h, -(e3.re + e3.im) * h};  // * W8^3 = (-1 - i)/sqrt2
-    dft4(t0, t1, t2, t3, v[0], v[2], v[4], v[6]);
-    dft4(d0, d1, d2, d3, v[1], v[3], v[5], v[7]);
+// ---- packed complex arithmetic: a complex number is a register pair (re, im); every helper is ONE v_pk_* instruction whose
+// operand modifiers (op_sel: which half feeds which result half; neg_lo / neg_hi) do the swaps and sign flips.  The clean
+// cases are plain vector C++ (v_pk_add_f32 / v_pk_mul_f32); the ones with modifiers are spelled out, because the compiler
+// otherwise builds the swizzled operand with v_mov / v_pk_mov first (a wave issues one instruction per ~4.4 cycles whatever
+// its kind: measured with tools/valu_ubench.hip, so every instruction saved is time saved).
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+#if defined(HIPEMU)
+__device__ __forceinline__ v2f cadd_mi(v2f a, v2f b) { return v2f{a.x + b.y, a.y - b.x}; }          // a + (-i) b
+__device__ __forceinline__ v2f csub_mi(v2f a, v2f b) { return v2f{a.x - b.y, a.y + b.x}; }          // a - (-i) b
+__device__ __forceinline__ v2f cmul(v2f a, v2f w) { return v2f{fmaf(-a.y, w.y, a.x * w.x), fmaf(a.x, w.y, a.y * w.x)}; }
+__device__ __forceinline__ v2f cmul_s(v2f a, v2f w) { return cmul(a, w); }
+__device__ __forceinline__ v2f pk_scale_s(v2f a, v2f w) { return a * w; }
+__device__ __forceinline__ v2f recomb_e(v2f zk, v2f zn) { return v2f{zk.x + zn.x, zk.y - zn.y}; }   // Z[k] + conj Z[256-k]
+__device__ __forceinline__ v2f recomb_o(v2f zk, v2f zn) { return v2f{zk.y + zn.y, zn.x - zk.x}; }   // (Z[k] - conj Z[256-k]) / i
+#else
+__device__ __forceinline__ v2f cadd_mi(v2f a, v2f b) {
+    v2f d;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ v2f csub_mi(v2f a, v2f b) {
+    v2f d;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+// (a.x w.x - a.y w.y, a.y w.x + a.x w.y): the twiddle pair w = (re, im) in VGPRs (cmul) or SGPRs (cmul_s)
+__device__ __forceinline__ v2f cmul(v2f a, v2f w) {
+    v2f t, d;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "v"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "=v"(d) : "v"(a), "v"(w), "v"(t));
+    return d;
+}
+__device__ __forceinline__ v2f cmul_s(v2f a, v2f w) {
+    v2f t, d;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "s"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "=v"(d) : "v"(a), "s"(w), "v"(t));
+    return d;
+}
+__device__ __forceinline__ v2f pk_scale_s(v2f a, v2f w) {
+    v2f d;
+    asm("v_pk_mul_f32 %0, %1, %2" : "=v"(d) : "v"(a), "s"(w));
+    return d;
+}
+__device__ __forceinline__ v2f recomb_e(v2f zk, v2f zn) {
+    v2f d;
+    asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(d) : "v"(zk), "v"(zn));
+    return d;
+}
+__device__ __forceinline__ v2f recomb_o(v2f zk, v2f zn) {
+    v2f d;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,0] neg_hi:[1,0]" : "=v"(d) : "v"(zk), "v"(zn));
+    return d;
+}
+#endif
+
+// 4-point forward DFT in place, natural order; ROT2: input 2 still carries a pending factor -i
+template <bool ROT2 = false>
+__device__ __forceinline__ void dft4(v2f& a0, v2f& a1, v2f& a2, v2f& a3) {
+    const v2f s0 = ROT2 ? cadd_mi(a0, a2) : a0 + a2, d0 = ROT2 ? csub_mi(a0, a2) : a0 - a2;
+    const v2f s1 = a1 + a3, d1 = a1 - a3;
+    a0 = s0 + s1;
+    a2 = s0 - s1;
+    a1 = cadd_mi(d0, d1);
+    a3 = csub_mi(d0, d1);
 }
 
-// One butterfly step of the 16-block reduce-scatter: lanes whose bit `XOR` is set keep the upper half of v[0..2n), the
-// others the lower half; each adds what its partner (lane ^ XOR) gives up.
-template <int N, int XOR>
-__device__ __forceinline__ void reduce_scatter_step(float (&v)[16], bool upper) {
+// 16-point forward DFT in registers: v[k] = sum_n v[n] exp(-2 pi i n k / 16), natural order in and out.  Radix 4 x 4 with
+// n = 4p + q, k = ka + 4 kb; 32 + 16 + 32 packed instructions.
+__device__ __forceinline__ void dft16(v2f (&v)[16]) {
+    const float C1 = 0.92387953251128675613f, S1 = 0.38268343236508977173f, H = 0.70710678118654752440f;
+    const v2f W1 = {C1, -S1}, W3 = {S1, -C1}, W9 = {-C1, S1}, HP = {H, H}, HN = {-H, -H};
 #pragma unroll
-    for (int i = 0; i < N; ++i) {
-        const float send = upper ? v[i] : v[i + N];
-        const float keep = upper ? v[i + N] : v[i];
-        v[i] = keep + __shfl_xor(send, XOR);
-    }
+    for (int q = 0; q < 4; ++q) dft4(v[q], v[4 + q], v[8 + q], v[12 + q]);
+    // position 4 ka + q now holds B_q[ka]; multiply by W16^(q ka)
+    v[5] = cmul_s(v[5], W1);                              // W^1
+    v[6] = pk_scale_s(cadd_mi(v[6], v[6]), HP);           // W^2 = H (1 - i): (x + y, y - x) H
+    v[7] = cmul_s(v[7], W3);                              // W^3
+    v[9] = pk_scale_s(cadd_mi(v[9], v[9]), HP);           // W^2
+    //   v[10] * W^4 = -i v[10]: folded into the consuming butterfly (ROT2)
+    v[11] = pk_scale_s(csub_mi(v[11], v[11]), HN);        // W^6 = H (-1 - i): (x - y, x + y) (-H)
+    v[13] = cmul_s(v[13], W3);                            // W^3
+    v[14] = pk_scale_s(csub_mi(v[14], v[14]), HN);        // W^6
+    v[15] = cmul_s(v[15], W9);                            // W^9 = -W^1
+    dft4(v[0], v[1], v[2], v[3]);
+    dft4(v[4], v[5], v[6], v[7]);
+    dft4<true>(v[8], v[9], v[10], v[11]);
+    dft4(v[12], v[13], v[14], v[15]);
+    // position 4 ka + kb holds X[ka + 4 kb]: transpose the 4 x 4 index grid (register renaming)
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = a + 1; b < 4; ++b) {
+            const v2f t = v[4 * a + b];
+            v[4 * a + b] = v[4 * b + a];
+            v[4 * b + a] = t;
+        }
 }
+
+// ---- cross-lane primitives of the block reduction (each returns the sum over one bit of the lane index and leaves the
+// sum of `lo` in the lanes where that bit is 0, the sum of `hi` where it is 1) ----------------------------------------------
+__device__ __forceinline__ float fold_bit5(float lo, float hi) {        // lanes l <-> l ^ 32
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(lo), __float_as_uint(hi), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float fold_bit4(float lo, float hi) {        // lanes l <-> l ^ 16
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(lo), __float_as_uint(hi), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float fold_bit3(float lo, float hi, bool bit) {   // lanes l <-> l ^ 8 (row_ror:8)
+    const float give = bit ? lo : hi, keep = bit ? hi : lo;
+    return keep + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(give), 0x128, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float fold_bit2(float lo, float hi, bool bit) {   // lanes l <-> l ^ 4 (row_half_mirror, then quad reverse)
+    const float give = bit ? lo : hi, keep = bit ? hi : lo;
+    const int m = __builtin_amdgcn_update_dpp(0, __float_as_int(give), 0x141, 0xf, 0xf, true);
+    return keep + __int_as_float(__builtin_amdgcn_update_dpp(0, m, 0x1b, 0xf, 0xf, true));
+}
+
+// Table reads inside the persistent loop are loop-invariant; left alone, the compiler hoists all of them (window, twiddles,
+// fragments: 150+ registers) in front of the loop and spills.  An index laundered once per trip keeps them where they are.
+#if defined(HIPEMU)
+#define HOWL_OPAQUE_V(x) asm volatile("" : "+r"(x))
+#define HOWL_OPAQUE_S(x) asm volatile("" : "+r"(x))
+#define HOWL_OPAQUE_F(x) asm("" : "+x"(x))
+#else
+#define HOWL_OPAQUE_F(x) asm("" : "+v"(x))
+#define HOWL_OPAQUE_V(x) asm volatile("" : "+v"(x))
+#define HOWL_OPAQUE_S(x) asm volatile("" : "+s"(x))
+#endif
 
 #if defined(HOWL_DIAG_PROBE)  // diagnostic build (tools/probe_logmel.py): s_memtime stamps of workgroup 0, [wave][slot]
 __device__ unsigned long long* g_howl_probe_fe = nullptr;
@@ -102,244 +215,252 @@ __device__ unsigned long long* g_howl_probe_fe = nullptr;
 #define HOWL_FE_PROBE(wave_, lane_, slot_) ((void)0)
 #endif
 
-// A frame of the flattened (utterance, t) sequence; every field is wave-uniform (lives in SGPRs).
-struct FrameRef {
-    int b, t;
-    bool valid;
-};
+// Twelve waves per CU (three per SIMD, 168 VGPRs): sixteen were measured too -- they only fit the LDS with a conflicting tile
+// (17 / 272) and cannot keep the next quad's samples in registers across the transform (128 VGPRs): 24.4 us against 23.3 us
+// at 512 x 1 s.
+constexpr int FE_WAVES = 12;
+// Transpose tile of a wave: [frame][n2 row][k1] complex elements with row pitch XR and frame pitch XF.  The compiler pairs the
+// 8-byte accesses (ds_write2_b64: 8-lane groups writing 16 contiguous bytes each; ds_read2_b64: 16-lane groups, 32 banks), so
+// conflict-free means 2 XR = 4 (mod 32) dwords and XF = 4 (mod 16) elements.
+constexpr int XR = 18, XF = 292;
 
-__global__ __launch_bounds__(256, 4) void logmel_kernel(const float* __restrict__ pcm, int L, long ld, int T,
-                                                        int total_frames, const float* __restrict__ fbp, int M,
-                                                        float log_eps, const float* __restrict__ zmuv,
-                                                        float* __restrict__ out, int layout, int n_quads) {
-    __shared__ cf scratch[4 * SCR_CF];            // FFT transposes, private per wave
-    __shared__ float Pq[4 * QUAD * PQ_STRIDE];    // power tile, private per wave
-    __shared__ cf tw1[7 * 64];                    // stage-1 twiddles W_512^(lane*k), k = 1..7 (read-only after the prologue)
+// NGRP = 10: filterbanks of up to 40 mel bins (banded fragments when the flag allows); 12: up to 48, all pairs.
+template <int NWAVES, int NGRP>
+__global__ __launch_bounds__(NWAVES * 64) void logmel_kernel(const float* __restrict__ pcm, int L, long ld, int T,
+                                                             int total_frames, const float* __restrict__ fbp, int M,
+                                                             float log_eps, const float* __restrict__ zmuv,
+                                                             float* __restrict__ out, int layout, int n_quads, int aligned) {
+    __shared__ v2f xch[NWAVES * QUAD * XF];             // FFT transpose tiles, private per wave
+    __shared__ v4f c_tab[HOWL_FE_CONST_FLOATS / 4];     // window | W_256 | W_512 rows (read-only after the prologue)
+    __shared__ v4f c_frag[NSLOT * 64];                  // banded filterbank fragments
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    cf* scr = scratch + wave * SCR_CF;
-    float* P = Pq + wave * QUAD * PQ_STRIDE;
+    const int i1 = lane >> 4, n2 = lane & 15;              // FFT step 1: frame i1 of the quad, column n2
+    const int j = lane >> 2, i2 = lane & 3;                // FFT step 2 and everything after: bin class j, frame i2
 
-    // ---- per-lane constants, resident for the whole persistent loop ----------------------------------
-    float win[8];
+    // this workgroup's contiguous share of the quads, dealt round-robin to its waves
+    const int q_lo = (int)(((long)n_quads * blockIdx.x) / gridDim.x);
+    const int q_hi = (int)(((long)n_quads * (blockIdx.x + 1)) / gridDim.x);
+    int q = q_lo + wave;
+    // (utterance, t) of the quad's first frame: one scalar division here, then stepping
+    int b0 = (QUAD * q) / T, t0 = QUAD * q - b0 * T;
+    const int step_b = (QUAD * NWAVES) / T, step_t = QUAD * NWAVES - step_b * T;
+
+    // Raw samples of one quad: lane (i1, n2) takes z[16 n1 + n2] = (x[32 n1 + 2 n2], x[.. + 1]) of frame i1, centre framing with
+    // reflect padding (torch.stft(center=True)).  Quads whose four frames lie inside one utterance and need no padding are
+    // sixteen 8-byte loads at immediate offsets from one base; the others pay per-sample index arithmetic.
+    auto fetch = [&](int qq, int bq, int tq, v2f (&x)[16]) {
+        const int g0 = QUAD * qq;
+        const bool fast = aligned != 0 && tq + 3 < T && HOP * tq >= N_FFT / 2 && HOP * (tq + 3) + N_FFT / 2 <= L && g0 + 3 < total_frames;
+        if (fast) {
+            // uniform base (SGPRs) + one 32-bit lane offset + immediates
+            const float* base = pcm + ((long)bq * ld + (HOP * tq - N_FFT / 2));
+            const unsigned off = (unsigned)(HOP * i1 + 2 * n2);
 #pragma unroll
-    for (int n1 = 0; n1 < 8; ++n1) win[n1] = HOWL_HANN512[64 * n1 + lane];
-    float tw2r[8], tw2i[8];
-    const int b_of_lane = lane >> 3;  // stage-2 ownership: lane = k1 + 8*b
+            for (int n1 = 0; n1 < 16; ++n1) x[n1] = *reinterpret_cast<const v2f*>(base + (off + 32u * n1));
+        } else {
+            int t = tq + i1, b = bq;
+            if (t >= T) { t -= T; ++b; }
+            if (t >= T) { t -= T; ++b; }
+            const bool valid = g0 + i1 < total_frames;
+            if (!valid) b = t = 0;
+            const unsigned row = (unsigned)b * (unsigned)ld;       // the host checked that the batch spans < 2^31 samples
+            const int s0 = HOP * t - N_FFT / 2 + 2 * n2;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        tw2r[k] = HOWL_TW64[(b_of_lane * 8 + k) * 2];
-        tw2i[k] = HOWL_TW64[(b_of_lane * 8 + k) * 2 + 1];
+            for (int n1 = 0; n1 < 16; ++n1) {
+                int sa = s0 + 32 * n1, sb = sa + 1;
+                sa = sa < 0 ? -sa : sa;
+                sb = sb < 0 ? -sb : sb;
+                sa = sa >= L ? 2 * (L - 1) - sa : sa;
+                sb = sb >= L ? 2 * (L - 1) - sb : sb;
+                const float va = pcm[row + (unsigned)sa], vb = pcm[row + (unsigned)sb];      // unconditional loads, masked afterwards
+                x[n1].x = valid ? va : 0.0f;
+                x[n1].y = valid ? vb : 0.0f;
+            }
+        }
+    };
+
+    v2f x0[16];
+    if (q < q_hi) fetch(q, b0, t0, x0);
+
+    // ---- workgroup prologue: tables into LDS -----------------------------------------------------------
+    {
+        const v4f* src = reinterpret_cast<const v4f*>(HOWL_FE_CONST);
+        for (int i = tid; i < HOWL_FE_CONST_FLOATS / 4; i += NWAVES * 64) c_tab[i] = src[i];
+        const v4f* fq = reinterpret_cast<const v4f*>(fbp + FBQ_OFF);
+        for (int i = tid; i < NSLOT * 64; i += NWAVES * 64) c_frag[i] = fq[i];
     }
-    for (int i = tid; i < 7 * 64; i += 256) {     // [k-1][lane]: a wave reads 64 consecutive entries per k
-        const int k = 1 + i / 64, l = i & 63;
-        tw1[i] = {HOWL_TW512[(l * 8 + k) * 2], HOWL_TW512[(l * 8 + k) * 2 + 1]};
-    }
-    float zm_mean = 0.0f, zm_std = 1.0f;
+    const bool banded = NGRP == NG_BANDED && reinterpret_cast<const int*>(fbp + FBF_OFF)[0] != 0;   // wave-uniform
+    float zm_mean = 0.0f, zm_rstd = 1.0f;
     if (zmuv != nullptr) {
         zm_mean = zmuv[0];
-        zm_std = zmuv[1];
+        zm_rstd = 1.0f / zmuv[1];
     }
-    // bins 257..271 of the tile are read by the last bin group (times a zero filterbank entry): keep them zero
-    if (lane < QUAD * 16) P[(lane >> 4) * PQ_STRIDE + 256 + (lane & 15)] = 0.0f;
-    __syncthreads();                              // the only workgroup barrier of the kernel (tw1 filled)
-    const int* band = reinterpret_cast<const int*>(fbp + FBQ_BAND_OFF);
-    const float* frag = fbp + FBQ_OFF + lane;
-    const int n_groups = (M + 3) >> 2;
+    __syncthreads();                                       // the only workgroup barrier of the kernel
 
-    // frame g of the flattened sequence -> (utterance, t): one scalar division per quad, the other frames by stepping
-    auto frame_at = [&](int g) {
-        FrameRef f;
-        f.valid = g < total_frames;
-        const int gg = f.valid ? g : 0;
-        f.b = gg / T;
-        f.t = gg - f.b * T;
-        return f;
-    };
-    auto next_frame = [&](FrameRef f, int g) {    // g = index of the frame after f
-        ++f.t;
-        if (f.t >= T) {
-            f.t = 0;
-            ++f.b;
-        }
-        f.valid = g < total_frames;
-        if (!f.valid) f.b = f.t = 0;
-        return f;
-    };
-    // Raw samples of one frame, centre framing with reflect padding (torch.stft(center=True)).  Interior frames (all but
-    // the first two and last two or three of an utterance) are eight coalesced 256-B rows at immediate offsets from one
-    // wave-uniform base; only edge frames pay for the per-sample index arithmetic.  Invalid frames read nothing.
-    auto fetch_frame = [&](const FrameRef& f, float (&x)[8]) {
-        const float* row = pcm + (long)f.b * ld;
-        const int s0 = HOP * f.t - N_FFT / 2;
-        if (!f.valid) {
-#pragma unroll
-            for (int n1 = 0; n1 < 8; ++n1) x[n1] = 0.0f;
-        } else if (s0 >= 0 && s0 + N_FFT <= L) {
-            const float* p0 = row + s0 + lane;
-#pragma unroll
-            for (int n1 = 0; n1 < 8; ++n1) x[n1] = p0[64 * n1];
-        } else {
-#pragma unroll
-            for (int n1 = 0; n1 < 8; ++n1) {
-                int sa = s0 + 64 * n1 + lane;
-                sa = sa < 0 ? -sa : sa;
-                sa = sa >= L ? 2 * (L - 1) - sa : sa;
-                x[n1] = row[sa];
-            }
-        }
-    };
-    // Two real frames (xa -> real part, xb -> imaginary part) through one complex FFT-512; |X|^2 of both to rows Pa, Pb.
-    auto fft_pair = [&](const float (&xa)[8], const float (&xb)[8], float* Pa, float* Pb) {
-        cf v[8];
-#pragma unroll
-        for (int n1 = 0; n1 < 8; ++n1) v[n1] = {xa[n1] * win[n1], xb[n1] * win[n1]};
-        // stage 1: radix-8 over n1 (stride 64), twiddle W_512^(lane*k1)
-        dft8(v);
-#pragma unroll
-        for (int k = 1; k < 8; ++k) {
-            const cf w = tw1[(k - 1) * 64 + lane];
-            v[k] = cmul(v[k], w.re, w.im);
-        }
-        wave_lds_sync();  // previous users of this scratch (power phase of the last pair) are done
-#pragma unroll
-        for (int k1 = 0; k1 < 8; ++k1) scr[k1 * X1_STRIDE + lane] = v[k1];
-        wave_lds_sync();
-        {   // stage 2: lane owns (k1 = lane & 7, b = lane >> 3), radix-8 over a with n2 = 8a + b
-            const int k1 = lane & 7, b = lane >> 3;
-#pragma unroll
-            for (int a = 0; a < 8; ++a) v[a] = scr[k1 * X1_STRIDE + 8 * a + b];
-            dft8(v);
-#pragma unroll
-            for (int c = 1; c < 8; ++c) v[c] = cmul(v[c], tw2r[c], tw2i[c]);
-            wave_lds_sync();
-#pragma unroll
-            for (int c = 0; c < 8; ++c) scr[k1 * X2_STRIDE + c * 8 + b] = v[c];
-            wave_lds_sync();
-        }
-        {   // stage 3: lane owns (k1 = lane & 7, c = lane >> 3), radix-8 over b -> Z[lane + 64 d]
-            const int k1 = lane & 7, c = lane >> 3;
-#pragma unroll
-            for (int b = 0; b < 8; ++b) v[b] = scr[k1 * X2_STRIDE + c * 8 + b];
-            dft8(v);
-        }
-        wave_lds_sync();
-#pragma unroll
-        for (int d = 0; d < 8; ++d) scr[lane + 64 * d] = v[d];
-        wave_lds_sync();
-        // separate the two real spectra and take |X|^2 for bins 0..256 (lane 0 also does bin 256)
-#pragma unroll
-        for (int r = 0; r < 5; ++r) {
-            const int k = lane + 64 * r;
-            if (r < 4 || lane == 0) {
-                const cf zk = (r < 4) ? v[r] : v[4];
-                const cf zn = scr[(N_FFT - k) & (N_FFT - 1)];
-                const float are = 0.5f * (zk.re + zn.re), aim = 0.5f * (zk.im - zn.im);
-                const float bre = 0.5f * (zk.im + zn.im), bim = -0.5f * (zk.re - zn.re);
-                Pa[k] = are * are + aim * aim;
-                Pb[k] = bre * bre + bim * bim;
-            }
-        }
-    };
-
-    const int wave_id = (int)blockIdx.x * 4 + wave, n_waves = (int)gridDim.x * 4;
+    // ---- per-lane constants ----------------------------------------------------------------------------
+    v2f* const xw = xch + wave * (QUAD * XF) + i1 * XF + n2 * XR;          // step-1 lane writes row n2: + k1
+    const v2f* const xr = xch + wave * (QUAD * XF) + i2 * XF + j;          // step-2 lane reads column j: + n2 * XR
+    const int wrow0 = (C_WIN + n2 * HOWL_FE_WIN_PITCH) / 4, trow0 = (C_TW + n2 * HOWL_FE_WIN_PITCH) / 4;
+    const int prow0 = (C_PT + j * HOWL_FE_PT_PITCH) / 4;
+    const int partner = 4 * (4 * ((16 - j) & 15) + i2);    // byte address of the lane holding Z[256 - k] (ds_bpermute)
+    const bool class0 = j == 0;
+    const bool bit3 = (lane & 8) != 0, bit2 = (lane & 4) != 0;
+    // what this lane owns after the block reduction: frame r_out of the quad, mel groups g_out .. g_out + 2
+    constexpr int NC = NGRP / 2;                           // values per lane entering the last two (DPP) levels
+    constexpr int ND = (NC + 1) / 2;                       // ... and leaving them
+    const int r_out = ((lane >> 5) & 1) * 2 + ((lane >> 4) & 1);
+    const int g_out = (bit3 ? NC : 0) + (bit2 ? ND : 0);
+    const int n_out = bit2 ? NC - ND : ND;
+    const int c_out = lane & 3;
     int pslot = 0;
     HOWL_FE_PROBE(wave, lane, pslot++);   // prologue done
-    float xa[8], xb[8], ya[8], yb[8];
-    FrameRef f0 = frame_at(QUAD * wave_id);
-    FrameRef f1 = next_frame(f0, QUAD * wave_id + 1);
-    if (wave_id < n_quads) {
-        fetch_frame(f0, xa);
-        fetch_frame(f1, xb);
-    }
 
-    for (int quad = wave_id; quad < n_quads; quad += n_waves) {
-        const int g0 = QUAD * quad;
-        // ---- FFT phase: frame pairs (g0, g0+1) and (g0+2, g0+3); the next pair's samples are requested first ---------
-        const FrameRef f2 = next_frame(f1, g0 + 2), f3 = next_frame(f2, g0 + 3);
+    // The loop carries the WINDOWED samples z of the quad it is about to transform: the raw samples of the next quad are
+    // requested at the top of the trip (a whole trip ahead) and multiplied by the window at its bottom,
+    // so they are defined and consumed inside one trip -- a loop-carried load result costs a second register set, a copy
+    // and a full vmcnt(0) wait at the latch.
+    v2f z[16];
+    auto apply_window = [&](const v2f (&xs)[16]) {
+        int wrow = wrow0;
+        HOWL_OPAQUE_V(wrow);
+#pragma unroll
+        for (int h = 0; h < 8; ++h) {
+            const v4f w = c_tab[wrow + h];
+            z[2 * h] = xs[2 * h] * w.xy;
+            z[2 * h + 1] = xs[2 * h + 1] * w.zw;
+        }
+    };
+    if (q < q_hi) apply_window(x0);
+
+    for (; q < q_hi; q += NWAVES) {
+        const int g0 = QUAD * q;
         HOWL_FE_PROBE(wave, lane, pslot++);   // quad start
-        fetch_frame(f2, ya);
-        fetch_frame(f3, yb);
-        fft_pair(xa, xb, P, P + PQ_STRIDE);
-        HOWL_FE_PROBE(wave, lane, pslot++);   // first pair transformed
-        const FrameRef q0 = f0, q1 = f1;          // this quad's frames, for the epilogue
-        const int gn = QUAD * (quad + n_waves);   // first frame of this wave's next quad (invalid beyond the batch)
-        f0 = frame_at(gn);
-        f1 = next_frame(f0, gn + 1);
-        fetch_frame(f0, xa);
-        fetch_frame(f1, xb);
-        fft_pair(ya, yb, P + 2 * PQ_STRIDE, P + 3 * PQ_STRIDE);
+        int trow = trow0, prow = prow0, frow = lane;
+        HOWL_OPAQUE_V(trow);
+        HOWL_OPAQUE_V(prow);
+        HOWL_OPAQUE_V(frow);
+        // the wave's next quad
+        const int qn = q + NWAVES;
+        const bool has_next = qn < q_hi;
+        int bn = b0 + step_b, tn = t0 + step_t;
+        if (tn >= T) { tn -= T; ++bn; }
+        v2f xn[16];
+        if (has_next) fetch(qn, bn, tn, xn);
+        // ---- FFT step 1: DFT-16 over n1 of the windowed samples, twiddle, transpose through LDS ------------------------
+        dft16(z);
+#pragma unroll
+        for (int h = 0; h < 8; ++h) {
+            const v4f w = c_tab[trow + h];
+            if (h > 0) z[2 * h] = cmul(z[2 * h], w.xy);
+            z[2 * h + 1] = cmul(z[2 * h + 1], w.zw);
+        }
+        wave_lds_sync();   // the previous trip's column reads are done
+#pragma unroll
+        for (int k1 = 0; k1 < 16; ++k1) xw[k1] = z[k1];
         wave_lds_sync();
-        HOWL_FE_PROBE(wave, lane, pslot++);   // second pair transformed
-        // ---- mel contraction: D_j[frame][mel] += P[frame][16 kg + j] * fb[16 kg + j][mel], blocks j summed afterwards ----
-        const float* arow = P + (lane & 3) * PQ_STRIDE + (lane >> 2);
-        // this lane's output after the reduce-scatter: frame r_out of the quad, mel column 16 * batch + c_out
-        const int r_out = lane >> 4, c_out = lane & 15;
-        const int g_out = g0 + r_out;
-        long o_base;      // element offset of (frame g_out, mel 0); mel stride o_ms
-        long o_ms;
+        // ---- FFT step 2: lane (j, i2) gathers column k1 = j, DFT-16 over n2 -> Z[j + 16 k2] ------------------------------
+#pragma unroll
+        for (int n = 0; n < 16; ++n) z[n] = xr[n * XR];
+        dft16(z);
+        HOWL_FE_PROBE(wave, lane, pslot++);   // transformed
+        // ---- real-input recombination: X[k] = E + W O, X[256 - k] = conj(E - W O); powers of both ----------------------
+        float P[NSLOT];
+        v2f zn[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            // Z[256 - k] sits in register 15 - r of the partner class (register (16 - r) & 15 of class 0 itself); all sixteen
+            // exchanges are issued before the first result is used.  (The values pass through an empty asm: otherwise the
+            // select of two array elements becomes one element at a selected index, i.e. a 16-way v_cndmask chain per value.)
+            float own_r = z[(16 - r) & 15].x, own_i = z[(16 - r) & 15].y;
+            HOWL_OPAQUE_F(own_r);
+            HOWL_OPAQUE_F(own_i);
+            const float pub_r = class0 ? own_r : z[15 - r].x;
+            const float pub_i = class0 ? own_i : z[15 - r].y;
+            zn[r].x = __int_as_float(__builtin_amdgcn_ds_bpermute(partner, __float_as_int(pub_r)));
+            zn[r].y = __int_as_float(__builtin_amdgcn_ds_bpermute(partner, __float_as_int(pub_i)));
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const v4f w4 = c_tab[prow + (r >> 1)];
+            const v2f e = recomb_e(z[r], zn[r]), o = recomb_o(z[r], zn[r]);
+            const v2f t = cmul(o, (r & 1) ? w4.zw : w4.xy);
+            const v2f xk = e + t, yk = e - t;
+            P[r] = xk.x * xk.x + xk.y * xk.y;
+            P[8 + r] = yk.x * yk.x + yk.y * yk.y;
+        }
+        P[16] = 4.0f * (z[8].x * z[8].x + z[8].y * z[8].y);   // bin 128 = Z[128] itself (class 0; the other classes' weight is 0)
+        // ---- mel contraction: D_j[frame][mel] += P[frame][bin(j, s)] * fb[bin(j, s)][mel], blocks j summed afterwards ------
+        f32x4 acc[NGRP];
+#pragma unroll
+        for (int g = 0; g < NGRP; ++g) acc[g] = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (banded) {
+#pragma unroll
+            for (int s = 0; s < NSLOT; ++s) {
+                const v4f f = c_frag[s * 64 + frow];
+                const float fv[4] = {f.x, f.y, f.z, f.w};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int g = slot_group(s, c);            // compile-time after unrolling
+                    if (g >= 0 && g < NGRP) acc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(P[s], fv[c], acc[g], 0, 0, 0);
+                }
+            }
+        } else {
+            // the rare path (a matrix the banded table does not cover, or more than 40 mel bins): every (slot, group) pair,
+            // fragments from global memory at a uniform base + lane
+            const unsigned ulane = (unsigned)frow;
+            const float* fdense = fbp + FBD_OFF;
+            HOWL_OPAQUE_S(fdense);
+#pragma unroll
+            for (int s = 0; s < NSLOT; ++s) {
+                const float* fs = fdense + s * (NG_MAX * 64);
+#pragma unroll
+                for (int g = 0; g < NGRP; ++g) acc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(P[s], fs[g * 64 + ulane], acc[g], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);   // keep the 170+ fragment loads from piling up in registers
+            }
+        }
+        HOWL_FE_PROBE(wave, lane, pslot++);   // contracted
+        // ---- sum the 16 blocks: lane 4j + c holds D_j[r][4g + c] in acc[g][r]; value index e = r * NGRP + g ------------------
+        float v2[2 * NGRP];
+#pragma unroll
+        for (int e = 0; e < 2 * NGRP; ++e) v2[e] = fold_bit5(acc[e % NGRP][e / NGRP], acc[e % NGRP][e / NGRP + 2]);
+        float v1[NGRP];
+#pragma unroll
+        for (int g = 0; g < NGRP; ++g) v1[g] = fold_bit4(v2[g], v2[NGRP + g]);
+        float vc[NC];
+#pragma unroll
+        for (int g = 0; g < NC; ++g) vc[g] = fold_bit3(v1[g], v1[NC + g], bit3);
+        float vd[ND];
+#pragma unroll
+        for (int g = 0; g < ND; ++g) vd[g] = fold_bit2(vc[g], ND + g < NC ? vc[ND + g] : 0.0f, bit2);
+        // ---- epilogue: log(x + eps), ZMUV, store -----------------------------------------------------------------------
+        const int g_frame = g0 + r_out;
+        long o_base, o_ms;
         if (layout == 1) {
-            o_base = (long)g_out * M;
+            o_base = (long)g_frame * M;
             o_ms = 1;
         } else {
-            const int b_out = r_out == 0 ? q0.b : (r_out == 1 ? q1.b : (r_out == 2 ? f2.b : f3.b));
-            const int t_out = r_out == 0 ? q0.t : (r_out == 1 ? q1.t : (r_out == 2 ? f2.t : f3.t));
-            o_base = (long)b_out * M * T + t_out;
+            int t = t0 + r_out, b = b0;
+            if (t >= T) { t -= T; ++b; }
+            if (t >= T) { t -= T; ++b; }
+            o_base = (long)b * M * T + t;
             o_ms = T;
         }
 #pragma unroll
-        for (int batch = 0; batch < NG / 4; ++batch) {
-            if (4 * batch >= n_groups) break;
-            int klo = KG, khi = 0;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const int lo = band[2 * (4 * batch + c)], hi = band[2 * (4 * batch + c) + 1];
-                if (hi > lo) {
-                    klo = lo < klo ? lo : klo;
-                    khi = hi > khi ? hi : khi;
-                }
-            }
-            f32x4 acc[4];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) acc[c] = {0.0f, 0.0f, 0.0f, 0.0f};
-            // two bin groups per trip, the second one's operands requested before the first one's MFMAs (a fragment is
-            // zero outside its group's band, so every group of the batch runs over the union [klo, khi) unpredicated)
-            for (int kg = klo; kg < khi; kg += 2) {
-                const bool two = kg + 1 < khi;
-                const float* fk = frag + (long)(kg * NG + 4 * batch) * 64;
-                const float a0 = arow[16 * kg];
-                float b0[4], b1[4];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) b0[c] = fk[64 * c];
-                const float a1 = two ? arow[16 * kg + 16] : 0.0f;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) b1[c] = two ? fk[NG * 64 + 64 * c] : 0.0f;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f32_4x4x1f32(a0, b0[c], acc[c], 0, 0, 0);
-#pragma unroll
-                for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f32_4x4x1f32(a1, b1[c], acc[c], 0, 0, 0);
-            }
-            // lane 4j+i holds D_j[r][4c + i] in acc[c][r]: index the 16 values by 4r + c, the block that will own the sum
-            float v16[16];
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int c = 0; c < 4; ++c) v16[4 * r + c] = acc[c][r];
-            reduce_scatter_step<8, 32>(v16, (lane & 32) != 0);
-            reduce_scatter_step<4, 16>(v16, (lane & 16) != 0);
-            reduce_scatter_step<2, 8>(v16, (lane & 8) != 0);
-            reduce_scatter_step<1, 4>(v16, (lane & 4) != 0);
-            // lane 4j+i now holds the full sum for (r, c) = (j >> 2, j & 3), column i: frame r_out, mel 16*batch + c_out
-            const int m = 16 * batch + c_out;
-            if (m < M && g_out < total_frames) {
-                float y = logf(v16[0] + log_eps);
-                if (zmuv != nullptr) y = (y - zm_mean) / zm_std;
+        for (int h = 0; h < ND; ++h) {
+            const int m = 4 * (g_out + h) + c_out;
+            if (h < n_out && m < M && g_frame < total_frames) {
+                float y = __builtin_amdgcn_logf(vd[h] + log_eps) * 0.69314718055994530942f;
+                y = (y - zm_mean) * zm_rstd;
                 out[o_base + (long)m * o_ms] = y;
             }
         }
-        HOWL_FE_PROBE(wave, lane, pslot++);   // mel + epilogue done
+        HOWL_FE_PROBE(wave, lane, pslot++);   // stored
+        if (has_next) apply_window(xn);
+        b0 = bn;
+        t0 = tn;
     }
 }
 
@@ -351,35 +472,33 @@ __global__ void fb_pack_kernel(const float* __restrict__ fb, int M, float* __res
     fbp[idx] = (k < N_FREQ && m < M) ? fb[k * M + m] : 0.0f;
 }
 
-// Second half of a filterbank build (same stream, after the row-major part is written): the fragment-ordered copy read by
-// the 4x4x1 MFMAs of logmel_kernel -- fragment (kg, g), lane 4j+c = fb[16 kg + j][4 g + c] -- and, per mel group g, the range
-// [lo, hi) of bin groups kg that hold a non-zero weight (lo = hi = 0 for an empty group).  One workgroup: 13 K elements.
+// Second half of a filterbank build (same stream, after the row-major part is written): the fragment-ordered copies read by
+// the 4x4x1 MFMAs of logmel_kernel -- lane 4j + c of fragment (slot s, group g) = fb[bin_of(s, j)][4 g + c] -- once as the
+// banded LDS image ([s][lane][4]: the four groups slot_group(s, .) of a slot side by side) and once for every (s, g) pair,
+// plus the flag that tells the kernel whether the banded image covers every non-zero weight.  One workgroup.
 __global__ __launch_bounds__(1024) void fb_fragments_kernel(float* __restrict__ fbp) {
-    __shared__ int nz[KG * NG];
+    __shared__ int uncovered;
     const float* rm = fbp;                 // (K_PAD, HOWL_FB_COLS) row-major
+    if (threadIdx.x == 0) uncovered = 0;
+    __syncthreads();
     float* fq = fbp + FBQ_OFF;
-    for (int p = threadIdx.x; p < KG * NG; p += blockDim.x) nz[p] = 0;
-    __syncthreads();
-    for (int idx = threadIdx.x; idx < KG * NG * 64; idx += blockDim.x) {
+    for (int idx = threadIdx.x; idx < FBQ_FLOATS; idx += blockDim.x) {
+        const int c = idx & 3, lane = (idx >> 2) & 63, s = idx >> 8;
+        const int g = slot_group(s, c), bin = bin_of(s, lane >> 2);
+        fq[idx] = (g >= 0 && bin >= 0) ? rm[bin * HOWL_FB_COLS + 4 * g + (lane & 3)] : 0.0f;
+    }
+    float* fd = fbp + FBD_OFF;
+    for (int idx = threadIdx.x; idx < FBD_FLOATS; idx += blockDim.x) {
         const int lane = idx & 63, pair = idx >> 6;
-        const int kg = pair / NG, g = pair - kg * NG;
-        const int k = 16 * kg + (lane >> 2), m = 4 * g + (lane & 3);
-        const float v = (k < N_FREQ) ? rm[k * HOWL_FB_COLS + m] : 0.0f;
-        fq[idx] = v;
-        if (v != 0.0f) nz[pair] = 1;       // benign race: every writer stores 1
+        const int s = pair / NG_MAX, g = pair - s * NG_MAX, bin = bin_of(s, lane >> 2);
+        fd[idx] = bin >= 0 ? rm[bin * HOWL_FB_COLS + 4 * g + (lane & 3)] : 0.0f;
+    }
+    for (int idx = threadIdx.x; idx < N_FREQ * HOWL_FB_COLS; idx += blockDim.x) {
+        const int k = idx / HOWL_FB_COLS, m = idx - k * HOWL_FB_COLS;
+        if (rm[idx] != 0.0f && !slot_has_group(slot_of_bin(k), m >> 2)) uncovered = 1;   // benign race: every writer stores 1
     }
     __syncthreads();
-    if (threadIdx.x < NG) {
-        const int g = threadIdx.x;
-        int lo = 0, hi = 0;
-        for (int kg = KG - 1; kg >= 0; --kg)
-            if (nz[kg * NG + g]) lo = kg;
-        for (int kg = 0; kg < KG; ++kg)
-            if (nz[kg * NG + g]) hi = kg + 1;
-        int* band = reinterpret_cast<int*>(fbp + FBQ_BAND_OFF);
-        band[2 * g] = lo;
-        band[2 * g + 1] = hi;
-    }
+    if (threadIdx.x == 0) reinterpret_cast<int*>(fbp + FBF_OFF)[0] = uncovered ? 0 : 1;
 }
 
 // triangles from M+2 corner frequencies (already VTLP-warped on the host: 42 scalars), exactly the
@@ -689,18 +808,23 @@ int howl_logmel_fwd(const float* pcm, int B, int L, long ld, const float* fbp, i
     HOWL_REQUIRE(M >= 1 && M <= HOWL_MAX_MELS, "howl_logmel_fwd: M=%d unsupported (1..%d)", M, HOWL_MAX_MELS);
     HOWL_REQUIRE(layout == 0 || layout == 1, "howl_logmel_fwd: layout must be 0 (B,M,T) or 1 (B,T,M)");
     const int T = 1 + L / HOP;
-    HOWL_REQUIRE((long)B * T < (1L << 31) - 4 * QUAD * 65536L, "howl_logmel_fwd: B*T = %ld frames exceeds the 32-bit frame index", (long)B * T);
+    HOWL_REQUIRE((long)(B - 1) * ld + L < (1L << 31), "howl_logmel_fwd: the batch spans %ld samples (32-bit sample offsets)", (long)(B - 1) * ld + L);
+    HOWL_REQUIRE((long)B * T < (1L << 31) - 4096L, "howl_logmel_fwd: B*T = %ld frames exceeds the 32-bit frame index", (long)B * T);
     const int total = B * T;
     const int n_quads = (total + QUAD - 1) / QUAD;
-    // four 4-wave workgroups are resident per CU (9 KB of LDS and <= 128 VGPRs per wave); a wave strides over the quads
-    int per_cu = 4;
-    if (const char* e = getenv("HOWL_LOGMEL_WGS_PER_CU")) per_cu = atoi(e) > 0 ? atoi(e) : 4;   // occupancy experiments
-    int grid = howl_num_cus() * per_cu;
-    if (grid > (n_quads + 3) / 4) grid = (n_quads + 3) / 4;
+    // one persistent workgroup per CU (its LDS holds the tables once); each takes a contiguous share of the quads
+    int grid = howl_num_cus();
+    if (grid > n_quads) grid = n_quads;
+    // 8-byte sample loads need even row strides and an 8-byte aligned base; anything else takes the per-sample path
+    const int aligned = ((ld & 1) == 0 && (reinterpret_cast<uintptr_t>(pcm) & 7) == 0) ? 1 : 0;
     {
         HowlProfScope prof("logmel", stream);
-        hipLaunchKernelGGL(logmel_kernel, dim3((unsigned)grid), dim3(256), 0, stream, pcm, L, ld, T, total, fbp, M, log_eps, zmuv,
-                           out, layout, n_quads);
+        if (M <= 4 * NG_BANDED)
+            hipLaunchKernelGGL((logmel_kernel<FE_WAVES, NG_BANDED>), dim3((unsigned)grid), dim3(FE_WAVES * 64), 0, stream, pcm, L, ld, T,
+                               total, fbp, M, log_eps, zmuv, out, layout, n_quads, aligned);
+        else
+            hipLaunchKernelGGL((logmel_kernel<FE_WAVES, NG_MAX>), dim3((unsigned)grid), dim3(FE_WAVES * 64), 0, stream, pcm, L, ld, T,
+                               total, fbp, M, log_eps, zmuv, out, layout, n_quads, aligned);
     }
     HOWL_CHECK_LAUNCH("howl_logmel_fwd");
     return HOWL_OK;

@@ -13,7 +13,7 @@ from pathlib import Path
 LIB_PATH = Path(os.environ.get("HOWL_HIP_LIBRARY") or Path(__file__).resolve().parent / "libhowl_hip.so")
 MAX_MELS = 48
 FB_COLS = 48
-FB_PACKED_FLOATS = 260 * FB_COLS + 17 * (FB_COLS // 4) * 64 + 32      # HOWL_FB_PACKED_FLOATS
+FB_PACKED_FLOATS = 260 * FB_COLS + 17 * 64 * 4 + 17 * (FB_COLS // 4) * 64 + 32      # HOWL_FB_PACKED_FLOATS
 
 P = c_void_p  # device pointer
 STREAM = c_void_p

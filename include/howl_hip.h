@@ -27,8 +27,9 @@ typedef struct ihipStream_t* hipStream_t;
 #define HOWL_MAX_MELS 48 /* mel bins supported by the MFMA contraction (3 tiles of 16); BASELINE configs use 40 */
 #define HOWL_FB_COLS 48  /* column count of a packed filterbank: (260, 48) fp32, zero padded */
 /* A packed filterbank is (260, 48) row-major floats followed by the same matrix in the fragment order of the mel
- * contraction (17 bin groups x 12 mel groups x 64 lanes) and 24 int32 band limits (+ 8 words of padding). */
-#define HOWL_FB_PACKED_FLOATS (260 * HOWL_FB_COLS + 17 * (HOWL_FB_COLS / 4) * 64 + 32)
+ * contraction: the banded LDS image (17 bin slots x 64 lanes x 4 mel groups), every (slot, group) fragment
+ * (17 x 12 x 64 lanes), and 32 int32 words of flags. */
+#define HOWL_FB_PACKED_FLOATS (260 * HOWL_FB_COLS + 17 * 64 * 4 + 17 * (HOWL_FB_COLS / 4) * 64 + 32)
 
 int howl_version(int* major, int* minor);
 const char* howl_last_error(void);

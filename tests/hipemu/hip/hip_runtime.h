@@ -167,6 +167,57 @@ template <class V4> static inline V4 hipemu_mfma4(float a, float b, V4 c) {
 }
 #define __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, x, y, z) hipemu_mfma4((a), (b), (c))
 
+
+// ---- bit casts, DPP / permlane / bpermute (semantics: cdna_hip_programming.md T12/T21, ISA ch. DPP) ----------------------
+static inline unsigned __float_as_uint(float f) { return hipemu_bits(f); }
+static inline int __float_as_int(float f) { return (int)hipemu_bits(f); }
+static inline float __uint_as_float(unsigned u) { return hipemu_from<float>(u); }
+static inline float __int_as_float(int i) { return hipemu_from<float>((uint32_t)i); }
+typedef unsigned hipemu_u2 __attribute__((ext_vector_type(2)));
+// v_permlane32_swap vdst, src: lanes 32..63 of vdst <-> lanes 0..31 of src; returns {new vdst, new src}
+static inline hipemu_u2 __builtin_amdgcn_permlane32_swap(unsigned a, unsigned b, bool, bool) {
+    uint32_t w[2] = {a, b};
+    const uint32_t* t = hipemu_wave_exchange(w, 2);
+    const int l = hipemu_lane();
+    hipemu_u2 r;
+    r[0] = l < 32 ? a : t[(l - 32) * 16 + 1];
+    r[1] = l < 32 ? t[(l + 32) * 16 + 0] : b;
+    return r;
+}
+// v_permlane16_swap vdst, src: odd rows (of 16 lanes) of vdst <-> even rows of src
+static inline hipemu_u2 __builtin_amdgcn_permlane16_swap(unsigned a, unsigned b, bool, bool) {
+    uint32_t w[2] = {a, b};
+    const uint32_t* t = hipemu_wave_exchange(w, 2);
+    const int l = hipemu_lane();
+    const bool odd = (l >> 4) & 1;
+    hipemu_u2 r;
+    r[0] = odd ? t[(l - 16) * 16 + 1] : a;
+    r[1] = odd ? b : t[(l + 16) * 16 + 0];
+    return r;
+}
+// v_mov_b32_dpp with row_mask = bank_mask = 0xf: quad_perm, row_shl/shr/ror, row_mirror, row_half_mirror
+static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
+    uint32_t w = (uint32_t)src;
+    const uint32_t* t = hipemu_wave_exchange(&w, 1);
+    if (row_mask != 0xf || bank_mask != 0xf) { fprintf(stderr, "hipemu: update_dpp with partial masks\n"); abort(); }
+    const int l = hipemu_lane(), row = l & ~15, p = l & 15;
+    int sp = -1;   // source position inside the row; -1 = out of range
+    if (ctrl >= 0 && ctrl <= 0xff) sp = (p & ~3) | ((ctrl >> (2 * (p & 3))) & 3);
+    else if (ctrl >= 0x101 && ctrl <= 0x10f) { sp = p + (ctrl - 0x100); if (sp > 15) sp = -1; }
+    else if (ctrl >= 0x111 && ctrl <= 0x11f) { sp = p - (ctrl - 0x110); }
+    else if (ctrl >= 0x121 && ctrl <= 0x12f) sp = (p - (ctrl - 0x120)) & 15;
+    else if (ctrl == 0x140) sp = 15 - p;
+    else if (ctrl == 0x141) sp = (p & 8) | (7 - (p & 7));
+    else { fprintf(stderr, "hipemu: unsupported dpp_ctrl 0x%x\n", ctrl); abort(); }
+    if (sp < 0) return bound_ctrl ? 0 : old;
+    return (int)t[(row + sp) * 16];
+}
+static inline int __builtin_amdgcn_ds_bpermute(int addr, int data) {
+    uint32_t w = (uint32_t)data;
+    const uint32_t* t = hipemu_wave_exchange(&w, 1);
+    return (int)t[((addr >> 2) & 63) * 16];
+}
+
 static inline float atomicAdd(float* p, float v) { float o = *p; *p = o + v; return o; }
 static inline double atomicAdd(double* p, double v) { double o = *p; *p = o + v; return o; }
 static inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }

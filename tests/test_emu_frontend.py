@@ -243,3 +243,29 @@ def test_logmel_dense_filterbank_and_group_edges(lib, M):
         np.testing.assert_allclose(out, ref, rtol=0, atol=3e-4)
         out0 = logmel(lib, audio, fbp, M=M, layout=0)
         np.testing.assert_array_equal(out0.transpose(0, 2, 1), out)
+
+
+def test_logmel_vtlp_banded_and_unaligned_rows(lib):
+    """VTLP-warped filterbanks stay on the banded fragment table (flag set by howl_fb_pack), also at the alpha > 1 quirk; rows
+    with an odd stride take the per-sample load path and give the same numbers as 8-byte aligned rows."""
+    rng = np.random.default_rng(11)
+    B, L = 3, 2601                      # T = 14: interior quads (fast loads) and edge quads
+    buf = (0.3 * rng.standard_normal((B, L + 2))).astype(np.float32)
+    even = np.ascontiguousarray(buf[:, :L + 1])        # row stride L + 1 = 2602 (even)
+    odd = np.ascontiguousarray(buf[:, :L + 2][:, :L + 2])
+    audio = np.ascontiguousarray(buf[:, :L])
+    T = 1 + L // 200
+    for alpha in (0.9, 1.0999):
+        fb = fe.mel_fb(40, alpha=alpha).numpy()
+        fbp = pack_fb(lib, fb)
+        assert fbp[260 * 48 + 17 * 64 * 4 + 17 * 12 * 64:].view(np.int32)[0] == 1      # banded table covers it
+        ref = fe.standard_audio_transform(torch.from_numpy(audio), torch.from_numpy(fb), mels_only=True).numpy()
+        outs = []
+        for rows, ld in ((even, L + 1), (odd, L + 2)):
+            out = np.full((B, 40, T), np.nan, np.float32)
+            lib.call("howl_logmel_fwd", ptr(rows), B, L, ld, ptr(fbp), 40, 1e-7, None, ptr(out), 0, None)
+            outs.append(out)
+        np.testing.assert_allclose(outs[0], ref, rtol=0, atol=3e-4)
+        np.testing.assert_array_equal(outs[0], outs[1])
+    dense = pack_fb(lib, rng.uniform(0.1, 1.0, (257, 40)).astype(np.float32))
+    assert dense[260 * 48 + 17 * 64 * 4 + 17 * 12 * 64:].view(np.int32)[0] == 0

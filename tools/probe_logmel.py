@@ -30,24 +30,28 @@ def bench(B, L=16000, n=30):
     return e0.elapsed_time(e1) / n * 1e3
 mode = sys.argv[1]
 if mode == "time":
-    print("WGS_PER_CU=%%s:" %% os.environ.get("HOWL_LOGMEL_WGS_PER_CU", "4"),
+    print("logmel:",
           " ".join("B=%%d %%.1f us" %% (B, bench(B)) for B in (8, 64, 128, 256, 512, 1024, 2048)), flush=True)
 else:
     B = int(sys.argv[2])
     pcm = synthetic_pcm(B, 16000).to(dev)
     for _ in range(3): ops.logmel(pcm, fbp, 40, pair, layout=1)
-    buf = torch.zeros(4 * 64, dtype=torch.int64, device=dev)
+    buf = torch.zeros(16 * 64, dtype=torch.int64, device=dev)
     lb.cdll.howl_diag_set_probe_fe.argtypes = [ctypes.c_void_p]
     assert lb.cdll.howl_diag_set_probe_fe(buf.data_ptr()) == 0
     ops.logmel(pcm, fbp, 40, pair, layout=1)
     torch.cuda.synchronize()
-    t = buf.cpu().view(4, 64)
+    t = buf.cpu().view(16, 64)
     first = t[:, 0]; t0 = int(first[first > 0].min()) if (first > 0).any() else 0
-    print("B=%%d ticks relative to the first stamp; columns: prologue-done [quad-start pair1 pair2 mel]*" %% B)
-    for w in range(4):
+    print("B=%%d ticks relative to the first stamp; columns per quad: start transformed contracted stored" %% B)
+    for w in range(16):
         row = [int(v) - t0 for v in t[w] if int(v) != 0]
-        d = [row[0]] + [row[i] - row[i - 1] for i in range(1, len(row))]
-        print("wave %%d deltas:" %% w, " ".join("%%6d" %% v for v in d), "| total", row[-1])
+        if not row: continue
+        d = [row[i] - row[i - 1] for i in range(1, len(row))]
+        print("wave %%2d prologue %%6d" %% (w, row[0]))
+        for k in range(0, len(d), 4):
+            print("   quad:", " ".join("%%5d" %% v for v in d[k:k + 4]), "| sum", sum(d[k:k + 4]))
+        print("   end at", row[-1])
 """ % str(ROOT)
 
 
@@ -62,8 +66,8 @@ def main():
         objs.append(str(o))
     so = out / "libhowl_probe.so"
     subprocess.run(["hipcc", "--offload-arch=gfx950", "-fPIC", "-shared", *objs, "-o", str(so)], check=True)
-    for per_cu in ("1", "2", "3", "4"):
-        env = dict(os.environ, HOWL_LOGMEL_WGS_PER_CU=per_cu)      # the product library: timing by occupancy
+    for waves in ("12",):
+        env = dict(os.environ)
         r = subprocess.run([sys.executable, "-c", CHILD, "time"], env=env, capture_output=True, text=True, timeout=300)
         print(r.stdout.strip() or r.stderr[-1500:], flush=True)
     env = dict(os.environ, HOWL_HIP_LIBRARY=str(so))
