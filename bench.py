@@ -20,13 +20,22 @@ Launch: under ``torch.distributed.run`` (RANK / LOCAL_RANK / WORLD_SIZE / MASTER
 rank; started plainly with ``--gpus N`` > 1 the script spawns the N ranks itself (one process per GPU, RCCL backend) and
 relays rank 0's line.  ``HOWL_BENCH_BACKEND=gloo`` lets several ranks share one GPU (control-flow check; RCCL refuses that).
 
+    eval  (f2, not a training step) batched streaming evaluation: FrameInferenceEngine.window_probabilities over 10 s clips,
+          500 ms windows / 63 ms stride, against the reference's one-window-at-a-time loop (inference.py:223-267)
+
 Rank 0 prints ONE JSON line; besides the contract fields it carries
-  "roofline":     the dominant kernel of the configuration: algorithmic FLOPs (or bytes) per launch / mean launch duration
-                  measured with HIP events on the launch stream in a second pass of the same K steps
-                  (res8: conv3x3 45->45 forward launches vs the 157.3 TFLOP/s fp32 MFMA peak; seq-lstm: recurrences + GEMMs
-                  vs the same peak; mobilenet: the fused convolution launches vs 8 TB/s HBM);
+  "roofline":     the time-dominant kernel of the configuration: algorithmic FLOPs (or bytes) per launch / mean launch
+                  duration measured with HIP events on the launch stream in a second pass of the same K steps
+                  (res8: bwd_pair_kernel = data + weight gradient of a 45->45 layer in one launch, 48 % of the step, vs the
+                  157.3 TFLOP/s fp32 MFMA peak, the forward convolution and the log-mel kernel beside it; seq-lstm:
+                  recurrences + GEMMs vs the same peak; mobilenet: the fused convolution launches vs 8 TB/s HBM);
+  "repeats":      the K timed steps as 5 consecutive segments (HIP events on the compute stream, no extra syncs):
+                  median / min / max ms per step over the segments;
   "cpu_baseline": the oracle (CPU restatement of the reference step, torch-CPU) timed on this box's host cores on a
-                  bounded sample (rank 0, N = 1 only);
+                  bounded sample: a thread sweep at batch 64 and a few steps at the bench's own batch (rank 0, N = 1 only);
+  "eval_agreement": eval-mode logits of the trained bench model on a slice of the bench batch, HIP path vs the oracle at
+                  identical weights (the "eval acc vs CPU ref" half of BASELINE.json's metric): argmax agreement and max
+                  |logit difference| (rank 0, N = 1 only, with the CPU baseline leg);
   "rccl":         (N > 1) world size, backend, and the all-reduce of the flat gradient buffer timed on its own.
 """
 import argparse
@@ -63,7 +72,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--config", choices=sorted(CONFIGS), default="c3")
+    ap.add_argument("--config", choices=sorted(CONFIGS) + ["eval"], default="c3")
     ap.add_argument("--batch-per-gpu", type=int, default=None, help="override the configuration's per-GPU batch")
     ap.add_argument("--seconds", type=float, default=None, help="override the utterance length")
     ap.add_argument("--labels", type=int, default=None)
@@ -133,7 +142,7 @@ def host_info():
     return model, (len(cores) or os.cpu_count() or 1)
 
 
-def cpu_baseline(model_name, L, C, budget_s):
+def cpu_baseline(model_name, L, C, budget_s, bench_batch=None):
     """The oracle's training step (frontend + forward + loss + backward + AdamW, mirrors pretrain_gsc.py:124-133 /
     train.py:286-302) on the host cores, on a bounded sample: batch 64 (configs[0]'s batch size), a few thread counts inside
     the time budget, the fastest reported together with the single-thread figure and the machine's physical core count."""
@@ -194,17 +203,62 @@ def cpu_baseline(model_name, L, C, budget_s):
             step()
             n += 1
         results[nthreads] = (B * n / (time.perf_counter() - t0), n)
-    torch.set_num_threads(default_threads)
     best = max(results, key=lambda k: results[k][0])
+    # the same step at the bench's own batch ("same synthetic tensors, same step definition"), threads pinned
+    # to the best count of the sweep: a few steps are enough (0.3-1 s each)
+    at_bench = None
+    if bench_batch and bench_batch != B and model_name == "res8":
+        torch.set_num_threads(best)
+        pcm_b = synthetic_pcm(bench_batch, L)
+        labels_b = torch.arange(bench_batch) % C
+
+        def step_b():
+            x = z(ofe.standard_audio_transform(pcm_b, fb))
+            om.train_step(lambda s, xx: om.res8_forward(s, xx, True), sd, names, opt, x, labels_b)
+
+        step_b()
+        t0, n = time.perf_counter(), 0
+        while n < 3 or (time.perf_counter() - t0 < 4.0 and n < 10):
+            step_b()
+            n += 1
+        at_bench = {"batch": bench_batch, "value": round(bench_batch * n / (time.perf_counter() - t0), 1), "threads": best,
+                    "steps": n}
+    torch.set_num_threads(default_threads)
     return {"value": round(results[best][0], 1), "unit": "utterances/sec", "cores": best, "kind": "port",
             "physical_cores": physical, "cpu_model": cpu_model, "value_1_thread": round(results[1][0], 1),
-            "by_threads": {str(k): round(v[0], 1) for k, v in results.items()},
+            "by_threads": {str(k): round(v[0], 1) for k, v in results.items()}, "at_bench_batch": at_bench,
             "sample": f"{results[best][1]} oracle training steps ({model_name}) of batch {B} x {L / 16000:g} s "
-                      f"(torch-CPU; threads tried: {candidates})"}
+                      f"(torch-CPU; threads tried: {candidates}; box-to-box spread of this figure is large: 1.0-1.8 k utt/s "
+                      f"on nominally identical hosts)"}
 
 
-def pmc_traffic():
-    """HBM bytes per launch of the dominant res8 kernel from the newest committed PMC summary (profiles/*pmc*.txt, written by
+def eval_agreement(model_name, model, std, zmuv, pcm_dev, C, n=64):
+    """The "eval acc vs CPU ref" half of the metric: eval-mode logits of the bench model (as trained by the timed steps) on the
+    first n utterances of the bench batch, HIP path (frontend + model) vs the oracle (its own frontend + model) at identical
+    weights and ZMUV statistics.  north_star: label indices bit-exact, logits within 1e-3."""
+    import torch
+    from oracle import frontend as ofe, models as om
+    if model_name != "res8":
+        return None
+    n = min(n, pcm_dev.shape[0])
+    was_training = model.training
+    model.eval()
+    with torch.no_grad():
+        got = model(std.log_mel_for_model(pcm_dev[:n], zmuv), None).float().cpu()
+    model.train(was_training)
+    sd = {k: v.detach().float().cpu() if v.is_floating_point() else v.detach().cpu() for k, v in model.state_dict().items()}
+    z = ofe.Zmuv()
+    z.total, z.mean, z.mean2 = (t.detach().cpu() for t in (zmuv.total, zmuv.mean, zmuv.mean2))
+    with torch.no_grad():
+        ref = om.res8_forward(sd, z(ofe.standard_audio_transform(pcm_dev[:n].cpu(), ofe.mel_fb(40))), False)
+    return {"utterances": n, "argmax_match": bool(torch.equal(got.argmax(1), ref.argmax(1))),
+            "argmax_agreement": round((got.argmax(1) == ref.argmax(1)).float().mean().item(), 4),
+            "max_abs_logit_diff": float(f"{(got - ref).abs().max().item():.3e}"), "tolerance": 1e-3,
+            "weights": "the bench model after its timed training steps, eval-mode BatchNorm (running statistics)"}
+
+
+def pmc_traffic(kernel="bwd_pair_kernel"):
+    """HBM bytes per launch of a res8 kernel from the newest committed PMC summary (profiles/*pmc*.txt, written by
     tools/pmc_round.sh + tools/pmc_summary.py: separate rocprofv3 --pmc passes for FETCH_SIZE and WRITE_SIZE, in KB, read
     side doubled per the gfx950 correction in MI355X_MICROARCH.md).  Counters cannot be collected from inside this
     process, so the figure is the one measured on the same command line when the summary was taken (the file is named)."""
@@ -215,7 +269,7 @@ def pmc_traffic():
     vals = []
     lines = files[-1].read_text().splitlines()
     for i, line in enumerate(lines):
-        if line.startswith("conv3x3_mfma_kernel<0>") and i + 1 < len(lines):
+        if line.startswith(kernel) and i + 1 < len(lines):
             d = json.loads(lines[i + 1].strip())
             if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
                 vals.append(((2 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024.0, d.get("launches", 1)))
@@ -223,6 +277,73 @@ def pmc_traffic():
         return None, None
     tot = sum(v * n for v, n in vals) / sum(n for _, n in vals)
     return tot, files[-1].name
+
+
+def bench_eval(args, dev):
+    """f2: the evaluation side of the metric.  The reference's ``FrameInferenceEngine`` scores a clip one 500 ms window per
+    63 ms stride, each a batch-1 forward with a device->host copy (``inference.py:223-267``); the product scores all windows
+    of a clip in ONE strided batch (``window_probabilities``).  Both paths run the same kernels here; the line reports
+    windows/s of each over 10 s synthetic clips and their agreement."""
+    import numpy as np
+    import torch
+    from howl_amd.context import InferenceContext
+    from howl_amd.data.transform.operator import ZmuvTransform
+    from howl_amd.data.transform.transform import StandardAudioTransform
+    from howl_amd.model import RegisteredModel
+    from howl_amd.model.inference import FrameInferenceEngine
+    from howl_amd.utils import audio_utils
+    from howl_amd.utils.synth import res8_closed_form_state, synthetic_pcm
+    ctx = InferenceContext(["hey", "fire", "fox"], token_type="word", use_blank=False)
+    model = RegisteredModel.find_registered_class("res8")(ctx.num_labels).to(dev)
+    model.load_state_dict(res8_closed_form_state(ctx.num_labels), strict=False)
+    model.eval()
+    std = StandardAudioTransform().to(dev).eval()
+    zmuv = ZmuvTransform().to(dev)
+    clips = synthetic_pcm(8, 160000, seed=77).to(dev)                  # 8 clips of 10 s
+    zmuv.update(std(clips[:1, :16000]))
+    engine = FrameInferenceEngine(500, 63, model, zmuv, ctx)
+    n_win = len(audio_utils.stride_starts(160000, 500, 63, 16000)[0])
+
+    def batched():
+        return [engine.window_probabilities(c) for c in clips]
+
+    def sequential():
+        out = []
+        for c in clips:
+            rows = []
+            for window in audio_utils.stride(c, 500, 63, 16000):
+                if window.size(-1) < 1000:
+                    break
+                lengths = std.compute_lengths(torch.tensor([window.size(-1)]).to(dev))
+                feats = std.log_mel_for_model(window.reshape(1, -1), zmuv)
+                rows.append(model(feats, lengths).softmax(-1)[0].cpu().numpy())      # the per-window host copy of the reference loop
+            out.append(np.stack(rows))
+        return out
+
+    res = {}
+    for name, fn, reps in (("batched", batched, max(args.steps, 5)), ("sequential", sequential, 2)):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            out = fn()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        res[name] = (len(clips) * n_win / dt, dt, out)
+    diff = max(float(np.abs(a - b).max()) for a, b in zip(res["batched"][2], res["sequential"][2]))
+    same = all(np.array_equal(a.argmax(1), b.argmax(1)) for a, b in zip(res["batched"][2], res["sequential"][2]))
+    print(json.dumps({
+        "metric": "windows/sec (res8 streaming evaluation, 500 ms windows / 63 ms stride, 10 s clips)",
+        "value": round(res["batched"][0], 1), "unit": "windows/sec", "n_gpus": 1, "steps": max(args.steps, 5), "warmup": 1,
+        "ms_per_step": round(res["batched"][1] * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"FrameInferenceEngine.window_probabilities: {len(clips)} clips x 10 s, {n_win} windows each, one "
+                               "strided batch per clip (frontend + res8 eval forward + softmax + one host copy)", "name": "eval"},
+        "sequential_windows_per_sec": round(res["sequential"][0], 1),
+        "speedup_vs_one_window_per_launch": round(res["batched"][0] / res["sequential"][0], 1),
+        "agreement": {"argmax_match": same, "max_abs_prob_diff": float(f"{diff:.3e}")},
+        "note": "sequential = the reference loop's structure (inference.py:223-267: per window a batch-1 forward and a "
+                "device->host copy) on the same kernels"}), flush=True)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -239,7 +360,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback)"
     if args.gpus != world:
-        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; the launcher's world size wins", file=sys.stderr)
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     backend = os.environ.get("HOWL_BENCH_BACKEND", "nccl")
     if backend == "nccl":
         assert torch.cuda.device_count() > local_rank, (f"rank {rank}: LOCAL_RANK={local_rank} but only "
@@ -252,6 +373,10 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
+        if dist.get_world_size() != world:      # fail loudly: a scaling number from fewer ranks than announced is worthless
+            raise SystemExit(f"bench.py: the {backend} process group has {dist.get_world_size()} ranks, expected {world}")
+    if args.config == "eval":
+        return bench_eval(args, dev)
 
     from howl_amd import lib as hlib
     from howl_amd.data.transform.operator import ZmuvTransform
@@ -308,12 +433,24 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    # the K timed steps are also cut into (up to) 5 consecutive segments by HIP events on the compute stream: no extra
+    # synchronisation, the bracket below is the contract's
+    n_seg = min(5, args.steps)
+    bounds = [round(i * args.steps / n_seg) for i in range(n_seg + 1)]
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(n_seg + 1)]
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for k in range(args.steps):
+        if k in bounds:
+            marks[bounds.index(k)].record()
         loss = step()
+    marks[n_seg].record()
     barrier()
     dt = time.perf_counter() - t0
+    seg_ms = sorted(marks[i].elapsed_time(marks[i + 1]) / (bounds[i + 1] - bounds[i]) for i in range(n_seg))
+    repeats = {"segments": n_seg, "steps_per_segment": args.steps / n_seg, "ms_per_step_median": round(seg_ms[n_seg // 2], 4),
+               "ms_per_step_min": round(seg_ms[0], 4), "ms_per_step_max": round(seg_ms[-1], 4),
+               "timer": "HIP events on the compute stream between segments of the K timed steps (rank 0)"}
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -371,22 +508,31 @@ def main():
             flops_launch = 2.0 * 9 * 45 * 45 * (H * 10) * B
             # the forward launches run alone on the device; dgrad and wgrad of a layer share ONE launch (half the CUs
             # each): its duration covers both and is listed under other_kernels
-            avg_ms = tf / max(nf, 1)
-            achieved = flops_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
-            traffic, traffic_src = pmc_traffic() if (B == 512 and L == 16000) else (None, None)
-            roof = {"bound": "mfma", "kernel": "conv3x3_mfma_kernel<0> (45->45 3x3 convolution, forward launches)",
+            fwd_ms = tf / max(nf, 1)
+            fwd_tf = flops_launch / (fwd_ms * 1e-3) / 1e12 if fwd_ms > 0 else 0.0
+            avg_ms = tp / max(npair, 1)
+            achieved = 2 * flops_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+            full = B == 512 and L == 16000
+            traffic, traffic_src = pmc_traffic("bwd_pair_kernel") if full else (None, None)
+            fwd_traffic, _ = pmc_traffic("conv3x3_mfma_kernel<0>") if full else (None, None)
+            act = 4.0 * 45 * (H * 10) * B      # one (B, 45, H, 10) fp32 map
+            roof = {"bound": "mfma",
+                    "kernel": "bwd_pair_kernel (data gradient + weight gradient of one 45->45 3x3 layer in ONE launch, half of "
+                              "the CUs each): the time-dominant kernel, 6 launches = 48 % of the step",
                     "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
                     "traffic": None if traffic is None else round(traffic),
                     "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)", "traffic_source": traffic_src,
-                    # input + output maps always; the residual on half of the forward launches
-                    "algorithmic_bytes": round(4.0 * 45 * (H * 10) * B * 2.5),
-                    "algorithmic_flops": round(flops_launch),
-                    "avg_launch_ms": round(avg_ms, 4), "launches": nf,
+                    # dz in (both roles share it through L2), the layer input in (wgrad operand and the BatchNorm-backward
+                    # sums of dgrad), dx out, and the per-workgroup weight-gradient partials out
+                    "algorithmic_bytes": round(act * 3 + 4.0 * 48 * 432 * min(B, 128)),
+                    "algorithmic_flops": round(2 * flops_launch),
+                    "avg_launch_ms": round(avg_ms, 4), "launches": npair,
                     "other_kernels": {
-                        "bwd_pair_kernel (dgrad + wgrad of a layer in one launch)": {
-                            "avg_launch_ms": round(tp / max(npair, 1), 4), "launches": npair,
-                            "tflops": round(2 * flops_launch / (tp / max(npair, 1) * 1e-3) / 1e12, 2) if tp > 0 else None},
+                        "conv3x3_mfma_kernel<0> (45->45 3x3 convolution, forward launches; 6 = 27 % of the step)": {
+                            "avg_launch_ms": round(fwd_ms, 4), "launches": nf, "tflops": round(fwd_tf, 2),
+                            "frac": round(fwd_tf / FP32_MFMA_PEAK_TFLOPS, 4), "algorithmic_bytes": round(act * 2.5),
+                            "traffic": None if fwd_traffic is None else round(fwd_traffic)},
                         "logmel": logmel}}
         elif model_name == "seq-lstm":
             parts = {t: read(t) for t in ("lstm_fwd", "lstm_bwd", "gemm")}
@@ -425,9 +571,10 @@ def main():
                                       "mb_conv_launches_per_step": ns / args.steps, "logmel": logmel}}
         read("logmel", reset=1)
 
-    cpu = None
+    cpu = agree = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(model_name, L, C, args.cpu_baseline_seconds)
+        agree = eval_agreement(model_name, model, std, zmuv, pcm, C)
+        cpu = cpu_baseline(model_name, L, C, args.cpu_baseline_seconds, bench_batch=B)
 
     if rank == 0:
         total_utts = B * world * args.steps
@@ -442,8 +589,8 @@ def main():
                                    f"{C} labels -- BASELINE {cfg_desc}",
                        "name": args.config, "global_batch": B * world, "samples_per_utterance": L, "labels": C,
                        "parallelism": f"dp{world}" if world > 1 else "single"},
-            "final_loss": round(final_loss, 5),
-            "roofline": roof, "cpu_baseline": cpu, "rccl": rccl,
+            "final_loss": round(final_loss, 5), "repeats": repeats,
+            "roofline": roof, "cpu_baseline": cpu, "eval_agreement": agree, "rccl": rccl,
         }
         print(json.dumps(out), flush=True)
     if world > 1:

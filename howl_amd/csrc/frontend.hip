@@ -601,7 +601,7 @@ __global__ __launch_bounds__(256) void sum_sumsq_masked_kernel(const float* __re
 // running update of operator.py:133-135 on the device buffers (no host sync); count < 0: taken from sums[2] (mask sum)
 __global__ void zmuv_update_kernel(const double* __restrict__ sums, double count, float* total, float* mean, float* mean2) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    if (count < 0.0) count = sums[2];
+    if (count < 0.0) count = sums[2] * -count;      // masked: -count = unexpanded / expanded mask size
     const double tot = (double)total[0];
     mean[0] = (float)((sums[0] + (double)mean[0] * tot) / (tot + count));
     mean2[0] = (float)((sums[1] + (double)mean2[0] * tot) / (tot + count));
@@ -854,15 +854,16 @@ int howl_zmuv_update(const float* x, size_t n, float* total, float* mean, float*
     return HOWL_OK;
 }
 
-int howl_zmuv_update_masked(const float* x, const float* mask, size_t n, float* total, float* mean, float* mean2,
-                            double* scratch3, hipStream_t stream) {
+int howl_zmuv_update_masked(const float* x, const float* mask, size_t n, double count_scale, float* total, float* mean,
+                            float* mean2, double* scratch3, hipStream_t stream) {
+    HOWL_REQUIRE(count_scale > 0.0 && count_scale <= 1.0, "howl_zmuv_update_masked: count_scale %g outside (0, 1]", count_scale);
     HOWL_REQUIRE(x && mask && total && mean && mean2 && scratch3, "howl_zmuv_update_masked: null pointer");
     HOWL_REQUIRE(n >= 1, "howl_zmuv_update_masked: empty input");
     hipMemsetAsync(scratch3, 0, 3 * sizeof(double), stream);
     size_t blocks = (n + 255) / 256;
     if (blocks > 1024) blocks = 1024;
     hipLaunchKernelGGL(sum_sumsq_masked_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, x, mask, n, scratch3);
-    hipLaunchKernelGGL(zmuv_update_kernel, dim3(1), dim3(64), 0, stream, scratch3, -1.0, total, mean, mean2);
+    hipLaunchKernelGGL(zmuv_update_kernel, dim3(1), dim3(64), 0, stream, scratch3, -count_scale, total, mean, mean2);
     HOWL_CHECK_LAUNCH("howl_zmuv_update_masked");
     return HOWL_OK;
 }

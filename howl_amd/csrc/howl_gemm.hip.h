@@ -324,15 +324,28 @@ struct SlabSums {
     SlabJobs jobs;
     int count = 0;
     long max_n = 0;
+    bool overflow = false;     // a caller queued more than MAX_SLAB_JOBS folds without a flush: reported by flush()
     void add(const float* part, int nparts, long n, float* out, float* out2 = nullptr) {
+        if (count >= MAX_SLAB_JOBS) {           // never write past the kernel-argument array
+            overflow = true;
+            return;
+        }
         jobs.j[count++] = SlabJob{part, out, out2, n, nparts};
         max_n = n > max_n ? n : max_n;
     }
-    void flush(hipStream_t s) {
-        if (count == 0) return;
+    // returns false (and sets the library's error string) when a fold was dropped by add(): the caller fails its call
+    bool flush(hipStream_t s) {
+        if (overflow) {
+            howl_set_error("SlabSums: more than %d folds queued between two flushes", MAX_SLAB_JOBS);
+            overflow = false;
+            count = 0;
+            return false;
+        }
+        if (count == 0) return true;
         hipLaunchKernelGGL(sum_slabs_multi_kernel, dim3((unsigned)((max_n + 63) / 64), count), dim3(256), 0, s, jobs);
         count = 0;
         max_n = 0;
+        return true;
     }
 };
 

@@ -701,7 +701,7 @@ int howl_lstm_bwd(const HowlLstmParams* p, const float* x, int B, int T, int M, 
     wgrad_gemm(stream, sv->dgates, rows_g, G4, sv->hseq, RowMap{Tout, (long)(T + 1) * HID, HID}, HID, rows, scratch, g->w_hh,
                LSTM_WGRAD_SPLITS, 256, &sums);
     colsum(stream, sv->dgates, rows_g, rows, G4, scratch_b, g->b_ih, g->b_hh, 256, 64, &sums);
-    sums.flush(stream);
+    if (!sums.flush(stream)) return HOWL_E_ARG;
     HOWL_CHECK_LAUNCH("howl_lstm_bwd");
     return HOWL_OK;
 }
@@ -747,7 +747,7 @@ int howl_linear_bwd(const float* x, int rows_inner, long s_outer, long s_inner, 
         wgrad_gemm(stream, dy, lin(n_out), n_out, x, RowMap{rows_inner, s_outer, s_inner}, n_in, rows, static_cast<float*>(ws),
                    dw, 64, 512, &sums);
     colsum(stream, dy, lin(n_out), rows, n_out, scratch_b, db, nullptr, 256, 64, &sums);
-    sums.flush(stream);
+    if (!sums.flush(stream)) return HOWL_E_ARG;
     HOWL_CHECK_LAUNCH("howl_linear_bwd");
     return HOWL_OK;
 }

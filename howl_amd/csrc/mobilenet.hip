@@ -326,11 +326,20 @@ __device__ __forceinline__ float ld_agent(const float* p) { return __hip_atomic_
 struct NoOverlap {
     __device__ __forceinline__ void operator()() const {}
 };
+// The hand-off above is a gfx950 protocol, not HIP memory-model code: it relies on device-scope atomic stores being
+// write-through to the device-coherent level, on vmcnt(0) meaning "acknowledged there", and on the gfx9 encoding of s_waitcnt
+// (simm16 0x0F70 = vmcnt(0), expcnt / lgkmcnt unconstrained).  A release / acquire pair on the counter would be portable and
+// costs a write-back of the XCD's L2 per block (tools/fence_probe.hip: 28-90 ns per block, serialised) -- unaffordable here.
+// This library is built for gfx950 only; any other target must not compile this silently.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "mobilenet.hip: the fence-free arrival protocol is validated on gfx950 only (see the comment above arrive())"
+#endif
+constexpr int HOWL_GFX9_WAIT_VMCNT0 = 0x0F70;
 template <class Overlap>
 __device__ __forceinline__ bool arrive(unsigned* counter, unsigned expected, const Overlap& overlap) {
     __shared__ unsigned ticket;
     __atomic_signal_fence(__ATOMIC_SEQ_CST);
-    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this thread's write-through stores are visible device-wide
+    __builtin_amdgcn_s_waitcnt(HOWL_GFX9_WAIT_VMCNT0);   // vmcnt(0): this thread's write-through stores are visible device-wide
     __atomic_signal_fence(__ATOMIC_SEQ_CST);
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -2240,7 +2249,7 @@ int howl_mobilenet_bwd(const float* params, int num_labels, const float* x, long
         jobs.add(c.ws + c.p.slab[0], nb0, (long)l0.cout * l0.cin * 9, grads + l0.w_off);
         jobs.add(c.ws + c.p.slab0b, nb0, (long)l0.cout, grads + l0.b_off);
     }
-    head.flush(stream);
+    if (!head.flush(stream)) return HOWL_E_ARG;
     jobs.flush(stream);
     HOWL_CHECK_LAUNCH("howl_mobilenet_bwd");
     return HOWL_OK;

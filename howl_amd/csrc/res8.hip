@@ -12,14 +12,16 @@
 // conv3x3 45->45 (12 of the 13 GFLOP-heavy launches per step: 6 forward, 6 dgrad) is an implicit GEMM on
 // v_mfma_f32_16x16x4_f32 (exact fp32 FMA chains, 157 TFLOP/s peak):
 //     D[position 16][cout 16] += A[position][k] * B[k][cout],   k = (cin block of 4, tap)
-//   * one workgroup = 12 wavefronts = 3 cout tiles x 4 position groups; each wave keeps its 108 weight
-//     fragments (48 padded cin x 9 taps / 4 per MFMA) in VGPRs for the whole launch -- weights never touch LDS;
-//   * one utterance's whole (48, H+1, 12) zero-haloed input map lives in LDS (64.7 KB at H=27), double
-//     buffered; the next utterance is prefetched into registers while the current one is multiplied, and the
-//     previous layer's BatchNorm is applied on the way into LDS ((s - mean) * rstd), so normalised activations
-//     are never materialised in HBM;
+//   * one workgroup = 12 wavefronts = 3 cout tiles x 4 position groups; the packed weight fragments (102 k-steps of 4:
+//     11 blocks of 4 input channels x 9 taps + channel 44's nine taps as a 3-step tail) are staged ONCE per workgroup into
+//     LDS (83 KB; round 1 kept them in VGPRs, which spilled address registers and serialised the staging code);
+//   * one utterance's whole (48, H+1, 12) zero-haloed input map lives in LDS next to them (64.7 KB at H=27, single
+//     buffered: weights + one tile fill the 160 KB); the next utterance's loads are issued in four bursts between segments
+//     of the K loop and the previous layer's BatchNorm is applied on the way into LDS ((s - mean) * rstd), so normalised
+//     activations are never materialised in HBM; in training the launch also folds the producer's BatchNorm partials in its
+//     prologue (no finalize launch between two convolutions);
 //   * epilogue fuses ReLU, the residual add, the store, and the per-channel sum / sum-of-squares that the next
-//     BatchNorm needs (per-workgroup partials, reduced deterministically by a tiny finalize kernel).
+//     BatchNorm needs (per-workgroup partials, folded deterministically by the consumer).
 // wgrad is the transposed GEMM (M = cout, N = tap x cin, K = positions) with the 45x405 accumulators resident
 // in registers across all utterances of a workgroup, written once as per-workgroup partials.
 #include "howl_common.hip.h"
@@ -890,9 +892,10 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restric
 // part + l * layer_stride), blockIdx.y = 6 -> conv0 (its own partial rows)
 __global__ __launch_bounds__(256) void reduce_rows_all_kernel(const float* __restrict__ part, size_t layer_stride, int nparts,
                                                               HowlPtrs6 out, const float* __restrict__ c0part, int c0parts,
-                                                              float* __restrict__ c0out) {
-    if (blockIdx.y < 6) {
-        reduce_rows_body(part + blockIdx.y * layer_stride, nparts, CP * 432, 1, out.p[blockIdx.y]);
+                                                              float* __restrict__ c0out, int y0) {
+    const int y = (int)blockIdx.y + y0;      // a launch covers rows y0 .. y0 + gridDim.y - 1 of {layer 1..6, conv0}
+    if (y < 6) {
+        reduce_rows_body(part + y * layer_stride, nparts, CP * 432, 1, out.p[y]);
     } else if (blockIdx.x * 64 < NMAP * 9) {
         reduce_rows_body(c0part, c0parts, NMAP * 9, 0, c0out);
     }
@@ -1682,10 +1685,16 @@ int howl_res8_fwd_long(const HowlRes8Params* prm, const float* feat, long sb, lo
     return HOWL_OK;
 }
 
-int howl_res8_bwd(const HowlRes8Params* prm, const float* feat, long sb, long st, long sm, int B, int T, int M, int C,
-                  const HowlRes8Saved* sv, const float* dlogits, const HowlRes8Grads* gr, void* ws, size_t ws_bytes,
-                  hipStream_t stream) {
+// part 0: the whole backward pass.  Data-parallel steps call it in two parts so that the gradient all-reduce of everything
+// but conv0 runs under conv0's weight gradient: part 1 = head + layers 6..1 (data and weight gradients) + the fold of the six
+// layers' weight-gradient partials -- after it gr->conv_w[0..5], gr->out_w, gr->out_b are final; part 2 = conv0's weight
+// gradient and its fold (gr->conv0_w).  The two parts of a pass must be called in order with identical arguments.
+int howl_res8_bwd_part(const HowlRes8Params* prm, const float* feat, long sb, long st, long sm, int B, int T, int M, int C,
+                       const HowlRes8Saved* sv, const float* dlogits, const HowlRes8Grads* gr, void* ws, size_t ws_bytes,
+                       int part, hipStream_t stream) {
     HOWL_REQUIRE(prm && feat && sv && dlogits && gr && ws, "howl_res8_bwd: null pointer");
+    HOWL_REQUIRE(part >= 0 && part <= 2, "howl_res8_bwd_part: part must be 0 (all), 1 or 2");
+    const bool run_layers = part != 2, run_conv0 = part != 1;
     HOWL_REQUIRE(M == 40, "howl_res8_bwd: M must be 40");
     const int H = T / 3;
     HOWL_REQUIRE(B >= 1 && H >= 1 && H <= MAX_H, "howl_res8_bwd: B=%d T=%d unsupported", B, T);
@@ -1703,10 +1712,12 @@ int howl_res8_bwd(const HowlRes8Params* prm, const float* feat, long sb, long st
     int eg = (int)((act / 2 + BRB_THREADS - 1) / BRB_THREADS);
     if (eg > 2 * howl_num_cus()) eg = 2 * howl_num_cus();
 
-    hipLaunchKernelGGL(head_bwd_pool_kernel, dim3((B * CP + 255) / 256), dim3(256), 0, stream, dlogits, prm->out_w, w.dpool,
-                       B, C);
-    hipLaunchKernelGGL(head_bwd_param_kernel, dim3(C + 1), dim3(1024), 0, stream, dlogits, sv->pooled, w.dpool, gr->out_w,
-                       gr->out_b, w.m12, B, C, P);
+    if (run_layers) {
+        hipLaunchKernelGGL(head_bwd_pool_kernel, dim3((B * CP + 255) / 256), dim3(256), 0, stream, dlogits, prm->out_w, w.dpool,
+                           B, C);
+        hipLaunchKernelGGL(head_bwd_param_kernel, dim3(C + 1), dim3(1024), 0, stream, dlogits, sv->pooled, w.dpool, gr->out_w,
+                           gr->out_b, w.m12, B, C, P);
+    }
     const size_t lc = conv_lds_bytes(H);
     hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_mfma_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
                         (int)lc);
@@ -1731,7 +1742,7 @@ int howl_res8_bwd(const HowlRes8Params* prm, const float* feat, long sb, long st
         float* ds_out = even ? ds_free : nullptr;
         float* dz = even ? w.dz : w.dz2;
         // layer 6 takes its two means from the head (m12); the others fold the partials of the data gradient above them
-        hipLaunchKernelGGL(bn_relu_bwd_kernel, dim3(eg), dim3(BRB_THREADS), 0, stream, (const float*)dx_cur, w.dpool, sv->s[i],
+        if (run_layers) hipLaunchKernelGGL(bn_relu_bwd_kernel, dim3(eg), dim3(BRB_THREADS), 0, stream, (const float*)dx_cur, w.dpool, sv->s[i],
                            stats_i, w.m12, i == 6 ? (const float*)nullptr : (const float*)w.part, Gh, count,
                            even ? (const float*)ds_prev : (const float*)nullptr, even ? 1 : 0, ds_out, dz, B, P);
         if (even) {
@@ -1747,7 +1758,9 @@ int howl_res8_bwd(const HowlRes8Params* prm, const float* feat, long sb, long st
         const float* xs = need_stats ? sv->s[i - 1] : (const float*)nullptr;
         float* spart = need_stats ? w.part : (float*)nullptr;
         float* wpart = w.wpart + (size_t)(i - 1) * wpart_stride;
-        if (merged) {
+        if (!run_layers) {
+            // part 2 only replays the buffer rotation of the loop
+        } else if (merged) {
             HowlProfScope prof("bwd_pair", stream);
             hipLaunchKernelGGL(bwd_pair_kernel, dim3(16 * ((Gh + 7) / 8)), dim3(CONV_THREADS), lp, stream, (const float*)dz, wpb,
                                dx_next, xs, in_stats, spart, sv->s[i - 1], in_stats, wpart, B, H, Gh);
@@ -1769,15 +1782,30 @@ int howl_res8_bwd(const HowlRes8Params* prm, const float* feat, long sb, long st
     hipFuncSetAttribute(reinterpret_cast<const void*>(conv0_wgrad_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                         (int)l0w);
     HOWL_REQUIRE(sv->mask0 != nullptr, "howl_res8_bwd: saved->mask0 is required");
-    hipLaunchKernelGGL(conv0_wgrad_mfma_kernel, dim3(G), dim3(C0W_THREADS), l0w, stream, feat, sb, st, sm,
-                       (const unsigned short*)sv->mask0,
-                       (const float*)dx_cur, (const float*)ds_prev, w.c0part, B, T, M, H);
     HowlPtrs6 gw;
     for (int i = 0; i < 6; ++i) gw.p[i] = gr->conv_w[i];
-    hipLaunchKernelGGL(reduce_rows_all_kernel, dim3((CP * 432 + 63) / 64, 7), dim3(256), 0, stream, (const float*)w.wpart,
-                       wpart_stride, Gh, gw, (const float*)w.c0part, G, gr->conv0_w);
+    if (part == 1)      // the six layers' weight gradients are final before conv0's is even started
+        hipLaunchKernelGGL(reduce_rows_all_kernel, dim3((CP * 432 + 63) / 64, 6), dim3(256), 0, stream, (const float*)w.wpart,
+                           wpart_stride, Gh, gw, (const float*)w.c0part, G, gr->conv0_w, 0);
+    if (run_conv0) {
+        hipLaunchKernelGGL(conv0_wgrad_mfma_kernel, dim3(G), dim3(C0W_THREADS), l0w, stream, feat, sb, st, sm,
+                           (const unsigned short*)sv->mask0,
+                           (const float*)dx_cur, (const float*)ds_prev, w.c0part, B, T, M, H);
+        if (part == 0)
+            hipLaunchKernelGGL(reduce_rows_all_kernel, dim3((CP * 432 + 63) / 64, 7), dim3(256), 0, stream,
+                               (const float*)w.wpart, wpart_stride, Gh, gw, (const float*)w.c0part, G, gr->conv0_w, 0);
+        else
+            hipLaunchKernelGGL(reduce_rows_all_kernel, dim3((NMAP * 9 + 63) / 64, 1), dim3(256), 0, stream,
+                               (const float*)w.wpart, wpart_stride, Gh, gw, (const float*)w.c0part, G, gr->conv0_w, 6);
+    }
     HOWL_CHECK_LAUNCH("howl_res8_bwd");
     return HOWL_OK;
+}
+
+int howl_res8_bwd(const HowlRes8Params* prm, const float* feat, long sb, long st, long sm, int B, int T, int M, int C,
+                  const HowlRes8Saved* sv, const float* dlogits, const HowlRes8Grads* gr, void* ws, size_t ws_bytes,
+                  hipStream_t stream) {
+    return howl_res8_bwd_part(prm, feat, sb, st, sm, B, T, M, C, sv, dlogits, gr, ws, ws_bytes, 0, stream);
 }
 
 int howl_xent_fwd_bwd(const float* logits, const long long* labels, int B, int C, float* loss, float* dlogits,

@@ -29,7 +29,8 @@ class DeviceCollate:
     def __init__(self, bank_audio, bank_lengths, bank_labels, max_len: int, sr: int = 16000, seed: int = None,
                  training: bool = True, background=None, do_replace: bool = False):
         """``background`` = (bg_audio (N, Lbg) on the device, bg_lengths): the noise dataset of ``DatasetMixer``."""
-        self.audio, self.lengths, self.labels = bank_audio, bank_lengths.tolist(), bank_labels
+        self.audio, self.lengths, self.labels = bank_audio, [int(v) for v in bank_lengths.tolist()], bank_labels
+        self.last_max_len = 0      # longest row of the last batch (host knowledge: no read-back for the frame count)
         self.bg_audio = None if background is None else background[0]
         self.bg_lengths = None if background is None else [int(v) for v in background[1]]
         self.do_replace = do_replace
@@ -95,6 +96,7 @@ class DeviceCollate:
         clip_ids = list(clip_ids)
         lens, shift, head, sigma, sp = self.draw(clip_ids)
         out_len = [l - w for l, w in zip(lens, shift)]
+        self.last_max_len = max(out_len)
         order = sorted(range(len(clip_ids)), key=lambda k: -out_len[k])          # batchify: longest first (stable)
         first = [shift[k] if head[k] else 0 for k in order]                      # head crop drops the first w samples,
         audio = self._launch(clip_ids, order, first, [f + out_len[k] for f, k in zip(first, order)], sigma, sp,

@@ -55,9 +55,12 @@ class ZmuvTransform(nn.Module):
     def update(self, data, mask=None):
         with torch.no_grad():
             if mask is not None:
-                # masked variant (operator.py:128-130): sums over data * mask, element count = mask.sum(), all on the device
-                m = mask.to(device=data.device, dtype=torch.float32).expand_as(data).contiguous()
-                ops.zmuv_update_masked(data.contiguous(), m, self.total, self.mean, self.mean2, self._dev_scratch())
+                # masked variant (operator.py:128-130): sums over data * mask (broadcast), element count = the sum of the mask AS
+                # GIVEN (a (B,1,1,T) mask counts B*T, not B*3*M*T), all on the device
+                m = mask.to(device=data.device, dtype=torch.float32)
+                scale = m.numel() / data.numel()
+                ops.zmuv_update_masked(data.contiguous(), m.expand_as(data).contiguous(), self.total, self.mean, self.mean2,
+                                       self._dev_scratch(), count_scale=scale)
                 self._pair_key = None
                 return
             ops.zmuv_update(data.contiguous(), self.total, self.mean, self.mean2, self._dev_scratch())

@@ -65,7 +65,7 @@ SIGNATURES = {
     "howl_logmel_fwd": [P, c_int, c_int, c_long, P, c_int, c_float, P, P, c_int, STREAM],
     "howl_deltas_fwd": [P, c_int, c_int, c_int, P, P, STREAM],
     "howl_zmuv_update": [P, c_size_t, P, P, P, P, STREAM],
-    "howl_zmuv_update_masked": [P, P, c_size_t, P, P, P, P, STREAM],
+    "howl_zmuv_update_masked": [P, P, c_size_t, c_double, P, P, P, P, STREAM],
     "howl_zmuv_pair": [P, P, P, STREAM],
     "howl_zmuv_apply": [P, c_size_t, P, P, STREAM],
     "howl_collate_augment": [P, c_long, P, P, P, P, P, P, ctypes.c_ulonglong, c_int, c_int, P, STREAM],
@@ -79,6 +79,8 @@ SIGNATURES = {
     "howl_res8_fwd_long": [POINTER(HowlRes8Params), P, c_long, c_long, c_long, c_int, c_int, c_int, c_int, P, P, c_size_t, STREAM],
     "howl_res8_bwd": [POINTER(HowlRes8Params), P, c_long, c_long, c_long, c_int, c_int, c_int, c_int,
                       POINTER(HowlRes8Saved), P, POINTER(HowlRes8Grads), P, c_size_t, STREAM],
+    "howl_res8_bwd_part": [POINTER(HowlRes8Params), P, c_long, c_long, c_long, c_int, c_int, c_int, c_int,
+                           POINTER(HowlRes8Saved), P, POINTER(HowlRes8Grads), P, c_size_t, c_int, STREAM],
     "howl_xent_fwd_bwd": [P, P, c_int, c_int, P, P, STREAM],
     "howl_ctc_loss": [P, c_long, c_long, c_int, c_int, c_int, P, c_long, c_int, P, P, c_int, P, P, P, c_long, c_long, STREAM],
     "howl_lstm_fwd": [POINTER(HowlLstmParams), P, c_int, c_int, c_int, P, P, P, POINTER(HowlLstmSaved), P, P, P, c_size_t,

@@ -170,7 +170,12 @@ class Res8(RegisteredModel, name="res8"):
                         ctypes.c_void_p(buf.ws.data_ptr()), buf.ws.numel(), ops._stream())
         return logits
 
-    def _launch_backward(self, feat, dlogits, out_grads=None):
+    # flat-buffer offset up to which gradients are final only after part 2 of a two-part backward (conv0.weight comes first)
+    LATE_GRAD_PARAMS = 1
+
+    def _launch_backward(self, feat, dlogits, out_grads=None, part=0):
+        """``part`` 0: the whole pass; 1 then 2: the same pass in two calls, everything but conv0's gradient final after
+        the first (``howl_res8_bwd_part``; the data-parallel step starts its all-reduce in between)."""
         if not self.training:
             raise NotImplementedError("Res8 backward is implemented for training-mode BatchNorm (batch statistics), "
                                       "the only mode the reference trains in")
@@ -186,9 +191,9 @@ class Res8(RegisteredModel, name="res8"):
         gr.out_w = _vp(grads[7])
         gr.out_b = _vp(grads[8])
         prm = self._params_struct()
-        _lib.get().call("howl_res8_bwd", ctypes.byref(prm), ctypes.c_void_p(x0.data_ptr()), sb, st, sm, B, T, M,
+        _lib.get().call("howl_res8_bwd_part", ctypes.byref(prm), ctypes.c_void_p(x0.data_ptr()), sb, st, sm, B, T, M,
                         self.num_labels, ctypes.byref(buf.saved), ctypes.c_void_p(dlogits.data_ptr()), ctypes.byref(gr),
-                        ctypes.c_void_p(buf.ws.data_ptr()), buf.ws.numel(), ops._stream())
+                        ctypes.c_void_p(buf.ws.data_ptr()), buf.ws.numel(), int(part), ops._stream())
         return grads
 
     def forward(self, x, lengths=None):

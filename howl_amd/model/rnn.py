@@ -254,6 +254,30 @@ class SequentialLstm(_LstmBase, name="seq-lstm"):
 
 
 class SimpleLstm(_LstmBase, name="lstm"):
+    NEEDS_LENGTHS = True       # FusedTrainer.step passes the frame lengths through
+
+    # --- training.fused.FusedTrainer hooks (cross-entropy on the last hidden state, pretrain_gsc.py:126-133) ---------
+    def _launch_forward(self, feat, lengths, t_out=None):
+        """feat (B, C>=1, M, T), frame lengths -> logits (B, num_labels); keeps what ``_launch_backward`` needs."""
+        if lengths is None:
+            raise TypeError("SimpleLstm needs lengths (rnn.py:88 packs unconditionally)")
+        xb, lengths, t_out, h0, c0 = self._lstm_inputs(feat, lengths, t_out)
+        ps = self.hot_parameters()
+        _, hT, _, saved = _lstm_forward_raw(xb, lengths, t_out, h0, c0, *ps[:4])
+        y1 = _linear_forward_raw(hT, ps[4], ps[5], True)
+        self._cls_saved = (saved, t_out, hT, y1)
+        return _linear_forward_raw(y1, ps[6], ps[7], False)
+
+    def _launch_backward(self, feat, dlogits, out_grads=None):
+        saved, t_out, hT, y1 = self._cls_saved
+        ps = self.hot_parameters()
+        grads = out_grads if out_grads is not None else [torch.empty_like(p) for p in ps]
+        dy1, _, _ = _linear_backward_raw(y1, ps[6], None, dlogits, False, True, grads[6], grads[7])
+        dhT, _, _ = _linear_backward_raw(hT, ps[4], y1, dy1, True, True, grads[4], grads[5])
+        _lstm_backward_raw(saved, t_out, None, dhT, None, grads[:4])
+        self._cls_saved = None
+        return grads
+
     def forward(self, x, lengths):
         if lengths is None:
             raise TypeError("SimpleLstm needs lengths (rnn.py:88 packs unconditionally)")

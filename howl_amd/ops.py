@@ -86,8 +86,9 @@ def zmuv_update(x, total, mean, mean2, scratch):
                     _p(scratch, torch.float64), _stream())
 
 
-def zmuv_update_masked(x, mask, total, mean, mean2, scratch):
-    _lib.get().call("howl_zmuv_update_masked", _p(x), _p(mask), x.numel(), _p(total), _p(mean), _p(mean2),
+def zmuv_update_masked(x, mask, total, mean, mean2, scratch, count_scale=1.0):
+    """``mask`` already expanded to ``x``'s shape; ``count_scale`` = (unexpanded mask size) / x.numel()."""
+    _lib.get().call("howl_zmuv_update_masked", _p(x), _p(mask), x.numel(), float(count_scale), _p(total), _p(mean), _p(mean2),
                     _p(scratch, torch.float64), _stream())
 
 

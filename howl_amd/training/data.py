@@ -51,6 +51,7 @@ class ClipBank:
             audio[i, : c.numel()] = c
             lengths[i] = c.numel()
         self.audio = audio.to(device)
+        self.lengths_host = lengths                      # batch maxima / sort orders are host decisions: no read-back per batch
         self.lengths = lengths.to(device)
         self.labels = torch.tensor(labels, dtype=torch.long).to(device)
 
@@ -59,12 +60,14 @@ class ClipBank:
 
     def batch(self, idx: torch.Tensor) -> ClassificationBatch:
         """batchify: longest first, zero padded to the batch maximum."""
-        lengths = self.lengths[idx]
+        idx_host = idx.cpu()
+        lengths = self.lengths_host[idx_host]
         order = torch.argsort(lengths, descending=True, stable=True)
-        idx = idx[order]
-        lengths = lengths[order]
+        idx_host, lengths = idx_host[order], lengths[order]
         lmax = int(lengths[0])     # the batch maximum, as batchify pads (res8's time-mean sees no extra pad frames)
-        return ClassificationBatch(self.audio[idx, :lmax], self.labels[idx], lengths)
+        dev = self.audio.device
+        idx = idx_host.to(dev)
+        return ClassificationBatch(self.audio[idx, :lmax], self.labels[idx], lengths.to(dev))
 
     def index_batches(self, batch_size: int, shuffle: bool, drop_last: bool, generator=None):
         """Lists of clip ids per batch (for DeviceCollate, which gathers / augments / pads on the device)."""
@@ -76,8 +79,7 @@ class ClipBank:
 
     def batches(self, batch_size: int, shuffle: bool, drop_last: bool, generator=None):
         n = len(self)
-        perm = torch.randperm(n, generator=generator) if shuffle else torch.arange(n)
-        perm = perm.to(self.audio.device)
+        perm = torch.randperm(n, generator=generator) if shuffle else torch.arange(n)      # host: batch() sorts on the host
         end = n - (n % batch_size) if drop_last else n
         for i in range(0, end, batch_size):
             yield self.batch(perm[i:i + batch_size])
@@ -113,9 +115,14 @@ class WakeWordClipBank:
     """Clips of a wake-word split decoded once and kept on the device as one (N, Lmax) matrix, each with the descriptor the
     batchifiers work on (``DeviceClip``: bank row, length, frame labels from the context's labeler, transcription)."""
 
+    MAX_BANK_BYTES = 64 << 30      # one long clip sets the row width of the whole dense bank: fail loudly, do not thrash
+
     def __init__(self, clips: List[torch.Tensor], metadata: list, labeler, device):
         from howl_amd.data.transform.batchifier import DeviceClip
         lmax = max(c.numel() for c in clips)
+        if len(clips) * lmax * 4 > self.MAX_BANK_BYTES:
+            raise MemoryError(f"dense clip bank of {len(clips)} x {lmax} samples ({len(clips) * lmax * 4 / 2**30:.0f} GiB): the longest "
+                              f"clip sets the row width -- truncate or bucket the split (MAX_WINDOW_SIZE_SECONDS) before loading it")
         audio = torch.zeros(len(clips), lmax)
         for i, c in enumerate(clips):
             audio[i, : c.numel()] = c

@@ -37,8 +37,10 @@ class FlatParams:
 
 class FusedTrainer:
     """Works with any model that exposes ``hot_parameters()`` (flat-buffer order), ``_launch_forward(feat)`` and
-    ``_launch_backward(feat, dlogits, out_grads=views)``: ``Res8`` and ``MobileNetClassifier`` (``step``), and with
-    ``SequentialLstm`` (``step_sequence``: ``_launch_forward(feat, lengths)`` / ``_launch_backward(dscores, out_grads)``)."""
+    ``_launch_backward(feat, dlogits, out_grads=views)``: ``Res8``, ``MobileNetClassifier`` and ``SimpleLstm`` (``step``; the
+    latter with frame lengths), and with ``SequentialLstm`` (``step_sequence``: ``_launch_forward(feat, lengths)`` /
+    ``_launch_backward(dscores, out_grads)``).  With more than one rank the flat gradient is summed over RCCL before the
+    fused AdamW (which applies 1/world); res8 overlaps that all-reduce with the tail of its backward pass."""
 
     def __init__(self, model, std_transform, zmuv_transform, lr, weight_decay=0.0, betas=(0.9, 0.999), eps=1e-8,
                  process_group=None):
@@ -58,16 +60,31 @@ class FusedTrainer:
     def features(self, audio):
         return self.std.log_mel_for_model(audio, self.zmuv)
 
-    def step(self, audio, labels):
+    def step(self, audio, labels, lengths=None, max_frames=None):
         """One optimisation step on a (B, L) PCM batch; returns the (local) mean loss as a device tensor."""
         feat = self.features(audio)
-        return self.step_on_features(feat, labels)
+        return self.step_on_features(feat, labels, lengths, max_frames)
 
-    def step_on_features(self, feat, labels):
-        logits = self.model._launch_forward(feat)
+    def step_on_features(self, feat, labels, lengths=None, max_frames=None):
+        """``lengths`` / ``max_frames``: frame counts for models that pack their input (``SimpleLstm``); ignored otherwise."""
+        if getattr(self.model, "NEEDS_LENGTHS", False):
+            logits = self.model._launch_forward(feat, lengths, max_frames)
+        else:
+            logits = self.model._launch_forward(feat)
         loss, dlogits = ops.xent(logits, labels)
-        self.model._launch_backward(feat, dlogits, out_grads=self.fp.grad_views)
-        scale = parallel.allreduce_sum_(self.fp.grad, self.group)
+        late = getattr(self.model, "LATE_GRAD_PARAMS", 0)
+        if self.world > 1 and late:
+            # two-part backward: the all-reduce of everything but the first `late` parameters (res8: conv0.weight, whose
+            # gradient needs the last data gradient) runs on the process group's stream while their kernels still execute
+            n0 = sum(p.numel() for p in self.fp.params[:late])
+            self.model._launch_backward(feat, dlogits, out_grads=self.fp.grad_views, part=1)
+            pending = parallel.allreduce_start_(self.fp.grad[n0:], self.group)
+            self.model._launch_backward(feat, dlogits, out_grads=self.fp.grad_views, part=2)
+            scale = parallel.allreduce_sum_(self.fp.grad[:n0], self.group)
+            pending.wait()
+        else:
+            self.model._launch_backward(feat, dlogits, out_grads=self.fp.grad_views)
+            scale = parallel.allreduce_sum_(self.fp.grad, self.group)
         self.step_count += 1
         ops.adamw_step(self.fp.flat, self.fp.grad, self.m, self.v, self.lr, self.betas, self.eps, self.weight_decay,
                        self.step_count, scale)

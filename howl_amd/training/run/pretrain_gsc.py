@@ -3,8 +3,14 @@
 Same flow, settings (env vars) and workspace artefacts as ``training/run/pretrain_gsc.py:22-144`` of the reference:
 ZMUV pass (<= 2001 single-clip updates), per-epoch training with LR decay, dev/test accuracy, model(-best) checkpoints.
 Differences that do not change the arithmetic of the hot path: clips live on the device (``ClipBank``) instead of
-DataLoader workers, the res8 step is the fused C-ABI pipeline, and the loss is logged without a per-step host sync.
+DataLoader workers, the training step is the fused C-ABI pipeline, and the loss is logged without a per-step host sync.
 ``--synthetic N`` trains on N generated clips when no dataset is mounted (as on the GPU box).
+
+Data parallel (BASELINE configs[2]: batch 4096 over 8 GPUs): start one process per GPU with
+``python -m torch.distributed.run --nproc-per-node N -m training.run.pretrain_gsc ...``.  ``BATCH_SIZE`` is then the GLOBAL
+batch: every rank draws the same shuffled batches and takes its contiguous share (``howl_amd.parallel.shard``), rank 0's
+initial weights / BatchNorm buffers / ZMUV statistics are broadcast, the flat gradient is summed over RCCL inside the fused
+step, evaluation batches are dealt round-robin and their counts summed, and only rank 0 writes the workspace.
 """
 import argparse
 import logging
@@ -12,13 +18,14 @@ from pathlib import Path
 
 import torch
 
+from howl_amd import parallel
 from howl_amd.data.collate import DeviceCollate
 from howl_amd.data.transform.operator import ZmuvTransform
 from howl_amd.data.transform.transform import StandardAudioTransform
 from howl_amd.model import RegisteredModel
 from howl_amd.settings import SETTINGS
 from howl_amd.training.data import ClipBank, load_gsc_splits, read_wav16k, synthetic_bank
-from howl_amd.training.fused import FusedRes8Trainer
+from howl_amd.training.fused import FusedTrainer
 from howl_amd.utils.random_utils import set_random_seed
 from howl_amd.workspace import Workspace
 
@@ -32,10 +39,17 @@ def main(argv=None):
     ap.add_argument("--synthetic", type=int, default=0, help="train on this many generated clips (no dataset needed)")
     args = ap.parse_args(argv)
 
-    workspace = Workspace(Path(args.workspace), delete_existing=not args.eval)
+    device = torch.device(SETTINGS.training.device)
+    rank, world, device = parallel.init_from_env(device)
+    main_rank = rank == 0
+    zmuv_on_disk = (Path(args.workspace) / "zmuv.pt.bin").exists()      # asked before rank 0 writes anything
+    if main_rank:
+        workspace = Workspace(Path(args.workspace), delete_existing=not args.eval)
+    parallel.barrier()
+    if not main_rank:
+        workspace = Workspace(Path(args.workspace), delete_existing=False, writable=False)
     writer = workspace.summary_writer
     set_random_seed(SETTINGS.training.seed)
-    device = torch.device(SETTINGS.training.device)
     sample_rate = SETTINGS.audio.sample_rate
     max_len = int(SETTINGS.training.max_window_size_seconds * sample_rate)
     num_labels = 30   # pretrain_gsc.py:91 hard-codes the head size
@@ -55,27 +69,35 @@ def main(argv=None):
     logging.info(f"{sum(p.numel() for p in params)} parameters")
 
     zmuv_path = workspace.path / "zmuv.pt.bin"
-    if zmuv_path.exists():
+    if zmuv_on_disk:
         zmuv_transform.load_state_dict(torch.load(str(zmuv_path), map_location="cpu"))
     else:
-        perm = torch.randperm(len(train))[:2001]                       # prep_dl: batch size 1, shuffled, <= 2001 clips
-        for i in perm.tolist():
-            n = int(train.lengths[i])
-            zmuv_transform.update(std_transform(train.audio[i:i + 1, :n]))
-    torch.save({k: v.cpu() for k, v in zmuv_transform.state_dict().items()}, str(zmuv_path))
+        if main_rank:
+            gen = torch.Generator().manual_seed(SETTINGS.training.seed)
+            perm = torch.randperm(len(train), generator=gen)[:2001]        # prep_dl: batch size 1, shuffled, <= 2001 clips
+            for i in perm.tolist():
+                n = int(train.lengths_host[i])
+                zmuv_transform.update(std_transform(train.audio[i:i + 1, :n]))
+        parallel.broadcast_([zmuv_transform.total, zmuv_transform.mean, zmuv_transform.mean2])
+    if main_rank:
+        torch.save({k: v.cpu() for k, v in zmuv_transform.state_dict().items()}, str(zmuv_path))
 
     def evaluate_accuracy(bank, prefix, epoch_idx=None, save=False):
         std_transform.eval()
         model.eval()
-        num_corr = torch.zeros((), device=device)
-        num_tot = 0
+        counts = torch.zeros(2, device=device)            # [correct, total]; batches dealt round-robin to the ranks
         with torch.no_grad():
-            for batch in bank.batches(SETTINGS.training.batch_size, shuffle=False, drop_last=False):
+            for k, ids in enumerate(bank.index_batches(SETTINGS.training.batch_size, shuffle=False, drop_last=False)):
+                if k % world != rank:
+                    continue
+                batch = bank.batch(torch.tensor(ids))
                 scores = model(std_transform.log_mel_for_model(batch.audio_data, zmuv_transform),
                                std_transform.compute_lengths(batch.lengths))
-                num_tot += scores.size(0)
-                num_corr += (scores.max(1)[1] == batch.labels).float().sum()
-        acc = num_corr.item() / max(num_tot, 1)
+                counts[0] += (scores.max(1)[1] == batch.labels).float().sum()
+                counts[1] += scores.size(0)
+        parallel.allreduce_scalars_(counts)
+        correct, total = counts.tolist()
+        acc = correct / max(total, 1)
         if save and not args.eval:
             writer.add_scalar(f"{prefix}/Metric/acc", acc, epoch_idx)
             workspace.increment_model(model, acc / 10)
@@ -85,49 +107,48 @@ def main(argv=None):
         workspace.load_model(model, best=True)
         model.to(device)
     if args.eval:
-        print("dev_acc: ", evaluate_accuracy(dev, "Dev"))
-        print("test_acc: ", evaluate_accuracy(test, "Test"))
+        dev_acc, test_acc = evaluate_accuracy(dev, "Dev"), evaluate_accuracy(test, "Test")
+        if main_rank:
+            print("dev_acc: ", dev_acc)
+            print("test_acc: ", test_acc)
         return
 
     workspace.write_args(args)
     workspace.save_settings(SETTINGS)
     writer.add_scalar("Meta/Parameters", sum(p.numel() for p in params))
-    fused = args.model in ("res8", "mobilenet")
-    if fused:
-        trainer = FusedRes8Trainer(model, std_transform, zmuv_transform, SETTINGS.training.learning_rate,
-                                   weight_decay=SETTINGS.training.weight_decay)
-    else:
-        optimizer = torch.optim.AdamW(params, SETTINGS.training.learning_rate, weight_decay=SETTINGS.training.weight_decay)
-        criterion = torch.nn.CrossEntropyLoss()
+    if not hasattr(model, "hot_parameters"):
+        raise NotImplementedError(f"{args.model}: no fused MI355X training step (res8, mobilenet, lstm have one)")
+    trainer = FusedTrainer(model, std_transform, zmuv_transform, SETTINGS.training.learning_rate,
+                           weight_decay=SETTINGS.training.weight_decay)
+    trainer.broadcast_parameters()                                     # rank 0's initial weights and BatchNorm buffers
+    needs_lengths = getattr(model, "NEEDS_LENGTHS", False)
     # train_comp = compose(truncate, Timeshift.train(), Noise.train(), batchify) (pretrain_gsc.py:78-80), on the device
-    train_collate = DeviceCollate(train.audio, train.lengths, train.labels, max_len, sr=sample_rate)
+    train_collate = DeviceCollate(train.audio, train.lengths_host, train.labels, max_len, sr=sample_rate)
     dev_acc = 0
     for epoch_idx in range(SETTINGS.training.num_epochs):
         model.train()
         std_transform.train()
-        for ids in train.index_batches(SETTINGS.training.batch_size, shuffle=True, drop_last=True):
+        gen = torch.Generator().manual_seed(SETTINGS.training.seed + 7919 * (epoch_idx + 1))   # the same order on every rank
+        for ids in train.index_batches(SETTINGS.training.batch_size, shuffle=True, drop_last=True, generator=gen):
+            ids = parallel.shard(ids)
+            if not ids:
+                raise RuntimeError(f"BATCH_SIZE={SETTINGS.training.batch_size} leaves rank {rank} of {world} without utterances")
             batch = train_collate(ids)
-            if fused:
-                loss = trainer.step(batch.audio_data, batch.labels)
+            if needs_lengths:
+                loss = trainer.step(batch.audio_data, batch.labels, std_transform.compute_lengths(batch.lengths),
+                                    int(std_transform.compute_lengths(torch.tensor(train_collate.last_max_len))))
             else:
-                scores = model(std_transform.log_mel_for_model(batch.audio_data, zmuv_transform),
-                               std_transform.compute_lengths(batch.lengths))
-                optimizer.zero_grad()
-                loss = criterion(scores, batch.labels)
-                loss.backward()
-                optimizer.step()
+                loss = trainer.step(batch.audio_data, batch.labels)
             writer.add_scalar("Training/Loss", loss.detach(), epoch_idx)     # stays on the device until flush
-        if fused:
-            trainer.decay_lr(SETTINGS.training.lr_decay)
-        else:
-            for group in optimizer.param_groups:
-                group["lr"] *= SETTINGS.training.lr_decay
+        trainer.decay_lr(SETTINGS.training.lr_decay)
         dev_acc = evaluate_accuracy(dev, "Dev", epoch_idx, save=True)
     test_acc = evaluate_accuracy(test, "Test")
     writer.close()
-    print("model: ", args.model)
-    print("dev_acc: ", dev_acc)
-    print("test_acc: ", test_acc)
+    parallel.barrier()
+    if main_rank:
+        print("model: ", args.model)
+        print("dev_acc: ", dev_acc)
+        print("test_acc: ", test_acc)
 
 
 if __name__ == "__main__":

@@ -19,6 +19,7 @@ sequence, negatives shuffled / partial sequences) in the same metadata form, so 
 """
 import argparse
 import csv
+import logging
 import random
 from pathlib import Path
 from types import SimpleNamespace
@@ -26,7 +27,7 @@ from types import SimpleNamespace
 import numpy as np
 import torch
 
-from howl_amd import ops
+from howl_amd import ops, parallel
 from howl_amd.context import InferenceContext
 from howl_amd.data.collate import DeviceCollate
 from howl_amd.data.common.tokenizer import WakeWordTokenizer
@@ -96,9 +97,18 @@ def main(argv=None):
 
     use_frame = SETTINGS.training.objective == "frame"
     set_random_seed(SETTINGS.training.seed)
-    ws = Workspace(Path(args.workspace), delete_existing=not args.eval)
-    writer = ws.summary_writer
+    # data parallel (one process per GPU under torch.distributed.run): BATCH_SIZE is the global batch, every rank takes its
+    # contiguous share of each (identically drawn) batch, the fused steps sum the flat gradient over RCCL, rank 0 writes
     device = torch.device(SETTINGS.training.device)
+    rank, world, device = parallel.init_from_env(device)
+    main_rank = rank == 0
+    zmuv_on_disk = (Path(args.workspace) / "zmuv.pt.bin").exists()      # asked before rank 0 writes anything
+    if main_rank:
+        ws = Workspace(Path(args.workspace), delete_existing=not args.eval)
+    parallel.barrier()
+    if not main_rank:
+        ws = Workspace(Path(args.workspace), delete_existing=False, writable=False)
+    writer = ws.summary_writer
     ctx = InferenceContext(SETTINGS.training.vocab, token_type=SETTINGS.training.token_type, use_blank=not use_frame)
     rng = np.random.default_rng(SETTINGS.training.seed)
     vocab = list(SETTINGS.training.vocab)
@@ -118,7 +128,11 @@ def main(argv=None):
                 splits[name][0].extend(c)
                 splits[name][1].extend(m)
     train_bank = WakeWordClipBank(*splits["training"], ctx.labeler, device)
-    dev_bank = WakeWordClipBank(*splits["dev"], ctx.labeler, device) if splits["dev"][0] else train_bank
+    if splits["dev"][0]:
+        dev_bank = WakeWordClipBank(*splits["dev"], ctx.labeler, device)
+    else:
+        logging.warning("no dev split in the datasets: the engine evaluation (results CSV, best-model score) runs on TRAINING clips")
+        dev_bank = train_bank
     is_pos = lambda ex: ctx.searcher.search(ex.transcription)      # train.py:176-183
     dev_pos, dev_neg = dev_bank.subset(is_pos), dev_bank.subset(lambda ex: not is_pos(ex))
 
@@ -134,13 +148,17 @@ def main(argv=None):
     zmuv_transform = ZmuvTransform().to(device)
     model = RegisteredModel.find_registered_class(args.model)(ctx.num_labels).to(device).streaming()
     spectrogram_augmentations = (SpecAugmentTransform().train(),)      # train.py:277-278
-    if (ws.path / "zmuv.pt.bin").exists():
+    if zmuv_on_disk:
         zmuv_transform.load_state_dict(torch.load(str(ws.path / "zmuv.pt.bin")))
         zmuv_transform.to(device)
     else:
+        # every rank makes the same pass (same clips, same kernels, same order: `rng` stays in step across the ranks);
+        # rank 0's statistics are broadcast anyway
         for i in rng.permutation(len(train_bank))[:2001]:              # prep_dl: single shuffled examples (train.py:231-245)
             zmuv_transform.update(std_transform(train_bank.clip(int(i))[None]))
-    torch.save({k: v.cpu() for k, v in zmuv_transform.state_dict().items()}, str(ws.path / "zmuv.pt.bin"))
+        parallel.broadcast_([zmuv_transform.total, zmuv_transform.mean, zmuv_transform.mean2])
+    if main_rank:
+        torch.save({k: v.cpu() for k, v in zmuv_transform.state_dict().items()}, str(ws.path / "zmuv.pt.bin"))
     if args.load_weights:
         ws.load_model(model, best=not args.load_last)
         model.to(device)
@@ -155,15 +173,17 @@ def main(argv=None):
         else:
             engine = InferenceEngine(model, zmuv_transform, ctx)
         hits = 0
-        for i in ids:
+        for i in ids[rank::world]:         # clips dealt round-robin to the ranks, detections summed
             engine.reset()
             model.streaming_state = None
             hits += int(bool(engine.infer(bank.clip(i))))
         model.streaming_state = None       # whatever the last clip left behind must not leak into training batches
+        hits = int(parallel.allreduce_scalars_(torch.tensor([float(hits)], device=device)).item())
         n = len(ids)
         conf = dict(tp=hits, fn=n - hits, fp=0, tn=0) if positive else dict(tp=0, fn=0, fp=hits, tn=n - hits)
-        with (ws.path / f"{engine.threshold}_results.csv").open("a") as f:
-            csv.writer(f).writerow([prefix, epoch, conf["tp"], conf["tn"], conf["fp"], conf["fn"]])
+        if main_rank:
+            with (ws.path / f"{engine.threshold}_results.csv").open("a") as f:
+                csv.writer(f).writerow([prefix, epoch, conf["tp"], conf["tn"], conf["fp"], conf["fn"]])
         writer.add_scalar(f"{prefix}/Metric/tp_rate" if positive else f"{prefix}/Metric/fp_rate", hits / max(n, 1), epoch)
         return conf
 
@@ -171,16 +191,22 @@ def main(argv=None):
         ws.load_model(model, best=not args.load_last)
         model.to(device)
         pos, neg = evaluate_engine(dev_bank, dev_pos, "Dev positive", True, 0), evaluate_engine(dev_bank, dev_neg, "Dev negative", False, 0)
-        print(pos, neg)
+        if main_rank:
+            print(pos, neg)
         return pos, neg
 
     ws.write_args(args)
     ws.save_settings(SETTINGS)
     params = [p for p in model.parameters() if p.requires_grad]
-    fused = (use_frame and args.model in ("res8", "mobilenet")) or (not use_frame and args.model == "seq-lstm")
+    fused = (use_frame and args.model in ("res8", "mobilenet", "lstm")) or (not use_frame and args.model == "seq-lstm")
+    needs_lengths = getattr(model, "NEEDS_LENGTHS", False)
     if fused:
         trainer = FusedTrainer(model, std_transform, zmuv_transform, SETTINGS.training.learning_rate,
                                weight_decay=SETTINGS.training.weight_decay)
+        trainer.broadcast_parameters()                             # rank 0's initial weights and BatchNorm buffers
+    elif world > 1:
+        raise NotImplementedError(f"{args.model} with the {'frame' if use_frame else 'ctc'} objective has no fused step: "
+                                  "data-parallel training needs one (res8 / mobilenet / lstm: frame, seq-lstm: ctc)")
     else:
         optimizer = torch.optim.AdamW(params, SETTINGS.training.learning_rate, weight_decay=SETTINGS.training.weight_decay)
     criterion = torch.nn.CrossEntropyLoss()                        # frame objective; the CTC objective is ops.ctc_loss below
@@ -193,14 +219,18 @@ def main(argv=None):
         total_loss = torch.zeros((), device=device)
         n_batches = 0
         for i in range(0, len(order), B):
-            examples = [train_bank.examples[j] for j in order[i:i + B]]
+            if len(order) - i < world:
+                continue                                           # a ragged last batch smaller than the world size: every rank skips it
+            examples = parallel.shard([train_bank.examples[j] for j in order[i:i + B]])
             if use_frame:
                 batch = collate.frame_batch(examples, batchifier)
                 frame_lengths = std_transform.compute_lengths(batch.lengths)
                 feats = std_transform.log_mel_for_model(batch.audio_data, zmuv_transform)
                 for aug in spectrogram_augmentations:              # after ZMUV, for both objectives (train.py:289-290)
                     feats = aug(feats)
-                if fused:
+                if fused and needs_lengths:
+                    loss = trainer.step_on_features(feats, batch.labels, frame_lengths)
+                elif fused:
                     loss = trainer.step_on_features(feats, batch.labels)
                 else:
                     scores = model(feats, frame_lengths)
@@ -243,7 +273,9 @@ def main(argv=None):
     neg = evaluate_engine(dev_bank, dev_neg, "Dev negative", False, SETTINGS.training.num_epochs)
     ws.increment_model(model, pos["tp"] - neg["fp"])
     writer.close()
-    print("dev positive:", pos, "dev negative:", neg)
+    parallel.barrier()
+    if main_rank:
+        print("dev positive:", pos, "dev negative:", neg)
     return pos, neg
 
 

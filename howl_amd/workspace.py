@@ -13,6 +13,19 @@ import torch.nn as nn
 from howl_amd.settings import KEY_TO_SETTINGS_CLASS, SETTINGS, HowlSettings
 
 
+class NullWriter:
+    """What the non-zero ranks of a data-parallel job log to."""
+
+    def add_scalar(self, tag, value, step=None):
+        pass
+
+    def flush(self):
+        pass
+
+    def close(self):
+        pass
+
+
 class ScalarWriter:
     def __init__(self, log_dir: Path):
         self.path = Path(log_dir) / "scalars.jsonl"
@@ -40,9 +53,13 @@ class Workspace:
     path: Path
     best_quality: float = float("-inf")
     delete_existing: bool = True
+    writable: bool = True      # False on the non-zero ranks of a data-parallel job: they read checkpoints, rank 0 writes
 
     def __post_init__(self):
         self.path = Path(self.path)
+        if not self.writable:
+            self.summary_writer = NullWriter()
+            return
         self.path.mkdir(parents=True, exist_ok=True)
         log_path = self.path / "logs"
         if self.delete_existing:
@@ -53,6 +70,8 @@ class Workspace:
         return str(self.path / f'model{"-best" if best else ""}.pt.bin')
 
     def write_args(self, args):
+        if not self.writable:
+            return
         with (self.path / "cmd-args.json").open("w") as f:
             json.dump({k: v for k, v in vars(args).items()}, f, indent=2, default=str)
 
@@ -63,12 +82,16 @@ class Workspace:
         self.save_model(model, best=False)
 
     def save_model(self, model: nn.Module, best: bool = False):
+        if not self.writable:
+            return
         torch.save({k: v.detach().cpu() for k, v in model.state_dict().items()}, self.model_path(best=best))
 
     def load_model(self, model: nn.Module, best=True):
         model.load_state_dict(torch.load(self.model_path(best=best), map_location="cpu"))
 
     def save_settings(self, settings: HowlSettings = SETTINGS):
+        if not self.writable:
+            return
         with (self.path / "settings.json").open("w") as f:
             out = {k: getattr(settings, k).dict() for k in KEY_TO_SETTINGS_CLASS
                    if k not in ("_dataset", "_raw_dataset", "_resource") and getattr(settings, k) is not None}

@@ -81,10 +81,11 @@ int howl_deltas_fwd(const float* logmel, int B, int M, int T, const float* zmuv,
  * scratch2: 2 doubles of device scratch. */
 int howl_zmuv_update(const float* x, size_t n, float* total, float* mean, float* mean2, double* scratch2,
                      hipStream_t stream);
-/* The same with a mask of x's shape (operator.py:128-130): sums run over x*mask, the element count is mask.sum() -- taken
- * on the device, no host sync.  scratch3: 3 doubles of device scratch. */
-int howl_zmuv_update_masked(const float* x, const float* mask, size_t n, float* total, float* mean, float* mean2,
-                            double* scratch3, hipStream_t stream);
+/* The same with a mask expanded to x's shape (operator.py:128-130): sums run over x*mask, the element count is the sum of the
+ * caller's UNEXPANDED mask = (sum of the expanded mask) * count_scale, count_scale = mask.numel() / x.numel() before the
+ * broadcast (1 for a full-shape mask) -- taken on the device, no host sync.  scratch3: 3 doubles of device scratch. */
+int howl_zmuv_update_masked(const float* x, const float* mask, size_t n, double count_scale, float* total, float* mean,
+                            float* mean2, double* scratch3, hipStream_t stream);
 /* pair = {mean, sqrt(mean2 - mean^2)}: operator.py:141-143 (`ZmuvTransform.std`). */
 int howl_zmuv_pair(const float* mean, const float* mean2, float* pair, hipStream_t stream);
 
@@ -183,11 +184,16 @@ int howl_res8_fwd_long(const HowlRes8Params* prm, const float* feat, long sb, lo
 
 /* backward of a training-mode forward: dlogits (B,C) -> parameter gradients (overwritten, not accumulated).
  * Replaces loss.backward() through cnn.py:127-145 (pretrain_gsc.py:131, train.py:294).  Per layer, the data gradient and
- * the weight gradient are launched side by side on two HIP queues (see Conventions); the results do not depend on the
- * schedule beyond fp32 summation order (fixed for a given schedule: repeated calls are bit-identical). */
+ * the weight gradient share one launch (half of the CUs each); summation orders are fixed: repeated calls are bit-identical. */
 int howl_res8_bwd(const HowlRes8Params* prm, const float* feat, long sb, long st, long sm, int B, int T, int M, int C,
                   const HowlRes8Saved* saved, const float* dlogits, const HowlRes8Grads* grads, void* ws,
                   size_t ws_bytes, hipStream_t stream);
+/* The same pass in two calls for data-parallel steps (same arguments, part 1 then part 2; part 0 = howl_res8_bwd):
+ * after part 1 grads->conv_w[0..5], out_w, out_b are final, so their all-reduce can run under part 2 (conv0's weight
+ * gradient -> grads->conv0_w).  Same launches and the same bits as the single call, plus one small fold launch. */
+int howl_res8_bwd_part(const HowlRes8Params* prm, const float* feat, long sb, long st, long sm, int B, int T, int M, int C,
+                       const HowlRes8Saved* saved, const float* dlogits, const HowlRes8Grads* grads, void* ws,
+                       size_t ws_bytes, int part, hipStream_t stream);
 
 /* mean cross-entropy over (B,C) logits with int64 labels and its gradient (dlogits may be NULL):
  * nn.CrossEntropyLoss() at pretrain_gsc.py:95,131 / train.py:251,293. */

@@ -103,22 +103,29 @@ def _trainer_worker(rank, world, port, out):
         model.train()
         tr = FusedTrainer(model, std, zmuv, lr=0.01, weight_decay=1e-5)
         tr.broadcast_parameters()
-        # spy on the all-reduce: keep this rank's local gradient of step 1
-        seen = {}
-        real = parallel.allreduce_sum_
+        # this rank's local gradient of step 1: the same launches outside the trainer (single-call backward), BatchNorm
+        # buffers restored afterwards
+        from howl_amd import ops
+        bufs0 = [b.clone() for b in model.buffers()]
+        feat0 = tr.features(pcm[lo:hi])
+        _, dl0 = ops.xent(model._launch_forward(feat0), labels[lo:hi])
+        seen = {"local": torch.cat([g.reshape(-1) for g in model._launch_backward(feat0, dl0)])}
+        for b, b0 in zip(model.buffers(), bufs0):
+            b.copy_(b0)
+        # ... and what the optimiser is handed in step 1: the two-part backward with the all-reduce started in between
+        real_adamw, calls = ops.adamw_step, []
 
-        def spy(flat, group=None):
-            seen.setdefault("local", flat.clone())
-            scale = real(flat, group)
-            seen.setdefault("reduced", flat.clone())
-            return scale
+        def spy(flat, grad, *a, **k):
+            seen.setdefault("reduced", grad.clone())
+            calls.append(a[-1] if a else None)
+            return real_adamw(flat, grad, *a, **k)
 
-        parallel.allreduce_sum_ = spy
+        ops.adamw_step = spy
         try:
             for _ in range(2):
                 loss = tr.step(pcm[lo:hi], labels[lo:hi])
         finally:
-            parallel.allreduce_sum_ = real
+            ops.adamw_step = real_adamw
         weights = tr.fp.flat.clone()
         bn = torch.cat([b.reshape(-1).float() for b in model.buffers()])
     # (i) this rank's local gradient == oracle on this rank's shard
@@ -164,3 +171,56 @@ def test_two_rank_fused_trainer_on_emulated_kernels():
         assert out["sum_err"] < 1e-6, out["sum_err"]
         assert out["identical"]
         assert out["bn_differs"]
+
+
+def _entry_worker(rank, world, port, wsdir, out):
+    """`python -m torch.distributed.run ... -m training.run.pretrain_gsc` as the launcher would start it: the environment
+    carries the rendezvous, the entry point does the rest (kernels on the hipemu build, gloo because the tensors are on the
+    host)."""
+    import sys
+    from pathlib import Path
+    sys.path.insert(0, str(Path(__file__).resolve().parent))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank),
+                      WORLD_SIZE=str(world), NUM_MELS="40", DEVICE="cpu", BATCH_SIZE="8", NUM_EPOCHS="1",
+                      MAX_WINDOW_SIZE_SECONDS="0.5", LEARNING_RATE="0.01", SEED="3")
+    torch.set_num_threads(2)
+    from emu_util import emulated_package
+    from howl_amd import ops
+    from howl_amd.training import fused
+    from howl_amd.training.run import pretrain_gsc
+    shards, finals = [], []
+    real_step = fused.FusedTrainer.step
+
+    def step(self, audio, labels, *a, **k):
+        shards.append(int(audio.shape[0]))
+        r = real_step(self, audio, labels, *a, **k)
+        finals.append(self.fp.flat.clone())
+        return r
+
+    fused.FusedTrainer.step = step
+    with emulated_package():
+        pretrain_gsc.main(["--model", "res8", "--workspace", wsdir, "--synthetic", "16"])
+    flat = finals[-1]
+    gathered = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    if rank == 0:
+        out["steps"] = len(shards)
+        out["shards"] = shards
+        out["identical"] = all(torch.equal(gathered[0], g) for g in gathered)
+    dist.destroy_process_group()
+
+
+def test_two_rank_pretrain_gsc_entry_point(tmp_path):
+    """The entry point itself under a 2-rank launcher environment: it joins the process group, splits every global batch of 8
+    into shards of 4, broadcasts rank 0's start, all-reduces inside the fused step (two-part backward), evaluates in shards,
+    and only rank 0 writes the workspace; the replicas end with bit-identical weights."""
+    world = 2
+    wsdir = tmp_path / "ws"
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_entry_worker, args=(world, _free_port(), str(wsdir), out), nprocs=world, join=True)
+        assert out["steps"] == 2 and list(out["shards"]) == [4, 4]          # 16 clips / global batch 8, half of it per rank
+        assert out["identical"]
+    for name in ("model.pt.bin", "model-best.pt.bin", "zmuv.pt.bin", "settings.json", "cmd-args.json"):
+        assert (wsdir / name).exists(), name
+    assert (wsdir / "logs" / "scalars.jsonl").exists()

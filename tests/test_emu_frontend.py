@@ -111,7 +111,7 @@ def test_zmuv_update_and_specaug(lib, golden):
     for n in (640, 3001):
         x = rng.standard_normal(n).astype(np.float32) * 2 + 1
         m = (rng.uniform(size=n) < 0.6).astype(np.float32)
-        lib.call("howl_zmuv_update_masked", ptr(x), ptr(m), n, ptr(total), ptr(mean), ptr(mean2), ptr(scratch3), None)
+        lib.call("howl_zmuv_update_masked", ptr(x), ptr(m), n, 1.0, ptr(total), ptr(mean), ptr(mean2), ptr(scratch3), None)
         z.update(torch.from_numpy(x), torch.from_numpy(m))
     assert total[0] == float(z.total)
     np.testing.assert_allclose(mean, np.asarray(z.mean).reshape(-1), rtol=1e-6)

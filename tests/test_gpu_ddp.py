@@ -57,19 +57,25 @@ def _worker(rank, world, port, backend, out):
     model = model.to(dev).train()
     tr = FusedTrainer(model, std, zmuv, lr=0.01, weight_decay=1e-5)
     tr.broadcast_parameters()
-    seen = {}
-    real = parallel.allreduce_sum_
+    # this rank's local gradient of step 1 (single-call backward outside the trainer; BatchNorm buffers restored) ...
+    from howl_amd import ops
+    bufs0 = [b.clone() for b in model.buffers()]
+    feat0 = tr.features(pcm[lo:hi].to(dev))
+    _, dl0 = ops.xent(model._launch_forward(feat0), labels[lo:hi].to(dev))
+    seen = {"local": torch.cat([g.reshape(-1) for g in model._launch_backward(feat0, dl0)])}
+    for b, b0 in zip(model.buffers(), bufs0):
+        b.copy_(b0)
+    # ... and what the optimiser is handed in step 1 (two-part backward, all-reduce started in between)
+    real_adamw = ops.adamw_step
 
-    def spy(flat, group=None):
-        seen.setdefault("local", flat.clone())
-        scale = real(flat, group)
-        seen.setdefault("reduced", flat.clone())
-        return scale
+    def spy(flat, grad, *a, **k):
+        seen.setdefault("reduced", grad.clone())
+        return real_adamw(flat, grad, *a, **k)
 
-    parallel.allreduce_sum_ = spy
+    ops.adamw_step = spy
     for _ in range(3):
         tr.step(pcm[lo:hi].to(dev), labels[lo:hi].to(dev))
-    parallel.allreduce_sum_ = real
+    ops.adamw_step = real_adamw
     torch.cuda.synchronize()
     # (i) local gradient == oracle on this rank's shard
     fb = ofe.mel_fb(40)

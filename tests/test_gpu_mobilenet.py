@@ -172,6 +172,40 @@ def test_fused_steps_are_bit_repeatable():
         assert torch.equal(run(), first)
 
 
+def test_arrival_protocol_stress_across_xcds():
+    """Stress of the fence-free "last block folds" hand-off (csrc/mobilenet.hip `arrive`): 40 training-mode forward + backward
+    passes over the same 512-utterance batch (every per-channel reduction spans hundreds of blocks on all eight XCDs, two-level
+    arrivals included) must reproduce logits, every gradient and the BatchNorm buffers bit for bit -- one stale partial row in
+    any of the ~200 folds of a pass would change them."""
+    from howl_amd.utils.synth import synthetic_pcm
+    from howl_amd.data.transform.transform import StandardAudioTransform
+    B, C = 512, 12
+    std = StandardAudioTransform().to(DEV).eval()
+    x = std(synthetic_pcm(B, 16000).to(DEV))
+    labels = (torch.arange(B) % C).to(DEV)
+    model, _ = make_mobilenet(C)
+    model.train()
+    state = {k: v.clone() for k, v in model.state_dict().items()}
+
+    def run():
+        model.load_state_dict(state)
+        model.zero_grad(set_to_none=True)
+        torch.manual_seed(3)
+        torch.cuda.manual_seed(3)                      # dropout mask
+        logits = model(x, None)
+        torch.nn.functional.cross_entropy(logits, labels).backward()
+        grads = torch.cat([p.grad.reshape(-1) for p in model.parameters()])
+        bufs = torch.cat([b.reshape(-1).float() for b in model.buffers()])
+        return logits.detach().clone(), grads.clone(), bufs.clone()
+
+    ref = run()
+    assert all(torch.isfinite(t).all() for t in ref)
+    for it in range(40):
+        out = run()
+        for a, b in zip(out, ref):
+            assert torch.equal(a, b), f"pass {it}: a reduction folded a stale or missing partial row"
+
+
 def test_config5_at_full_size_with_device_collate():
     """BASELINE configs[4] at its per-GPU size: 512 x 1 s, 12 labels, the timeshift + white / salt-pepper collate on the
     device (all gates OPEN) feeding FusedTrainer.step.  (a) the first step's training-mode logits at B = 512 agree with the
