@@ -307,6 +307,7 @@ def bench_eval(args, dev):
     def batched():
         return [engine.window_probabilities(c) for c in clips]
 
+    @torch.no_grad()
     def sequential():
         out = []
         for c in clips:

@@ -693,6 +693,13 @@ __global__ __launch_bounds__(256) void collate_augment_kernel(const float* __res
     }
 }
 
+// Dropout keep-mask (nn.Dropout(0.2) in front of MobileNet's classifier, cnn.py:22 via torchvision): mask[i] = 1 with
+// probability 1 - p from the same counter-based generator, one launch instead of torch's rand / compare / cast chain.
+__global__ __launch_bounds__(256) void dropout_mask_kernel(float* __restrict__ mask, size_t n, float p, unsigned long long seed) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        mask[i] = u01(mix64(seed ^ (0xA0761D6478BD642Full * (i + 1)))) >= p ? 1.0f : 0.0f;
+}
+
 // Frame-window gather (batchifier.py:56-118 + operator.py:89-109): row b of the (B, Lout) batch is zeros except for
 // out[b, dst_off[b] + n] = bank[idx[b]][start[b] + n], n < len[b] -- the window cut of WakeWordFrameBatchifier followed by
 // tensorize_audio_data's zero padding on either side (rand_append).  float4 stores; the source offset is arbitrary so
@@ -733,6 +740,17 @@ extern "C" int howl_diag_set_probe_fe(unsigned long long* buf) {
 #endif
 
 extern "C" {
+
+int howl_dropout_mask(float* mask, size_t n, float p, unsigned long long seed, hipStream_t stream) {
+    HOWL_REQUIRE(mask, "howl_dropout_mask: null pointer");
+    HOWL_REQUIRE(p >= 0.0f && p < 1.0f, "howl_dropout_mask: p=%g outside [0, 1)", p);
+    if (n == 0) return HOWL_OK;
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, mask, n, p, seed);
+    HOWL_CHECK_LAUNCH("howl_dropout_mask");
+    return HOWL_OK;
+}
 
 int howl_gather_windows(const float* bank, long bank_ld, const int* idx, const int* start, const int* len,
                         const int* dst_off, int B, int Lout, float* out, hipStream_t stream) {

@@ -225,7 +225,8 @@ __device__ __forceinline__ void prefetch_tile(float2 (&pre)[PREF], const float* 
     }
 }
 
-// One wave's share of an utterance: NTW position tiles (j = mg, mg+4, ...) of cout tile nt, all NTW accumulator
+// One wave's share of an utterance: NTW position tiles (j = t0, t0 + ts, ...: t0 = position group + 4 * slice, ts = 4 * slices
+// when `slices` workgroups share an utterance's position tiles, see conv3x3_body) of cout tile nt, all NTW accumulator
 // chains advanced together so that one weight fragment read feeds NTW MFMAs and the chains hide each other's latency.
 //   A[position][k] from the zero-haloed activation tile, B[k][cout] from the packed weights in LDS.
 template <int NTW>
@@ -234,12 +235,13 @@ struct KCursor {
     const lds_f32* bp;
 };
 
-template <int NTW>
+template <int NTW, int TS>
 __device__ __forceinline__ void k_begin(KCursor<NTW>& k, f32x4 (&acc)[NTW], const lds_f32* tile, const lds_f32* wl,
-                                        int CS, int P, int mg, int lane) {
+                                        int CS, int P, int t0, int lane) {
+    constexpr int ts = TS;
 #pragma unroll
     for (int i = 0; i < NTW; ++i) {
-        int m = 16 * (mg + 4 * i) + (lane & 15);
+        int m = 16 * (t0 + ts * i) + (lane & 15);
         m = m < P ? m : P - 1;  // the last tile may overhang: clamp the read, the store is masked
         const int h = m / PW;
         k.ap[i] = tile + (lane >> 4) * CS + h * WP + (m - h * PW);
@@ -331,11 +333,11 @@ struct ConvEpilogue {
     bool cvalid;
 };
 
-// MFMA phase + epilogue for one utterance; lane holds cout = 16nt + (lane&15) and, for tile j = mg + 4i, positions
+// MFMA phase + epilogue for one utterance; lane holds cout = 16nt + (lane&15) and, for tile j = t0 + ts * i, positions
 // 16j + 4*(lane>>4) + {0,1,2,3}.  The epilogue's own operands (residual / saved activation at the output positions)
 // are requested before the K loop so that their HBM latency is not exposed after it.
-template <int MODE, int NTW>
-__device__ __forceinline__ void conv_utterance(const lds_f32* tile, const lds_f32* wl, int CS, int mg, int lane,
+template <int MODE, int NTW, int TS>
+__device__ __forceinline__ void conv_utterance(const lds_f32* tile, const lds_f32* wl, int CS, int t0, int lane,
                                                size_t ubase, const ConvEpilogue& e, float& st0, float& st1,
                                                float2 (&pre)[PREF], const float* nsrc, int n2, int tid, int prio) {
     const float* eop = (MODE == 0) ? e.res : e.xs;
@@ -343,12 +345,14 @@ __device__ __forceinline__ void conv_utterance(const lds_f32* tile, const lds_f3
     // uniform base + one 32-bit lane offset + immediates; only a wave's last tile can overhang P (clamped)
     const char* ebase = reinterpret_cast<const char*>(eop + ubase);
     const unsigned crow = (unsigned)((e.cvalid ? e.cout : NMAP - 1) * e.P);
-    const unsigned boff = 4u * (crow + 16u * mg + 4u * (lane >> 4));
+    const unsigned boff = 4u * (crow + 16u * t0 + 4u * (lane >> 4));
     const unsigned bmax = 4u * (crow + e.P - 2);
+    constexpr int ts = TS;
+    constexpr unsigned tstep = 64u * TS;                 // bytes between two tiles of this wave
     auto fetch_operands = [&](int i) {  // branch-free: all loads in flight together
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
-            unsigned off = boff + 256u * i + 8u * hh;
+            unsigned off = boff + tstep * i + 8u * hh;
             if (i == NTW - 1) off = off < bmax ? off : bmax;
             ev[i][hh] = *reinterpret_cast<const float2*>(ebase + off);
         }
@@ -356,7 +360,7 @@ __device__ __forceinline__ void conv_utterance(const lds_f32* tile, const lds_f3
     static_assert(PREF == 8, "four prefetch pairs below");
     f32x4 acc[NTW];
     KCursor<NTW> k;
-    k_begin<NTW>(k, acc, tile, wl, CS, e.P, mg, lane);
+    k_begin<NTW, TS>(k, acc, tile, wl, CS, e.P, t0, lane);
     // The three waves of a SIMD (wave, wave+4, wave+8) would otherwise share the matrix pipe evenly, finish their K
     // loops together and run their epilogues (operand loads, stores) with the pipe idle.  Staggered priorities let
     // them finish one after the other, so two of the three epilogues run under another wave's MFMAs.
@@ -393,7 +397,7 @@ __device__ __forceinline__ void conv_utterance(const lds_f32* tile, const lds_f3
     char* obase = reinterpret_cast<char*>(e.out + ubase);
 #pragma unroll
     for (int i = 0; i < NTW; ++i) {
-        const int mbase = 16 * (mg + 4 * i) + 4 * (lane >> 4);
+        const int mbase = 16 * (t0 + ts * i) + 4 * (lane >> 4);
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
             const int m = mbase + 2 * hh;
@@ -424,12 +428,12 @@ __device__ __forceinline__ void conv_utterance(const lds_f32* tile, const lds_f3
                 }
 #if defined(HOWL_DIAG_CONV_NOSTORE)
                 if (v0 == 123.456f)  // diagnostic build: epilogue without its global stores
-                    *reinterpret_cast<float2*>(obase + (boff + 256u * i + 8u * hh)) = make_float2(v0, v1);
+                    *reinterpret_cast<float2*>(obase + (boff + tstep * i + 8u * hh)) = make_float2(v0, v1);
 #elif defined(HOWL_DIAG_CONV_NTSTORE)
-                __builtin_nontemporal_store(v0, reinterpret_cast<float*>(obase + (boff + 256u * i + 8u * hh)));
-                __builtin_nontemporal_store(v1, reinterpret_cast<float*>(obase + (boff + 256u * i + 8u * hh)) + 1);
+                __builtin_nontemporal_store(v0, reinterpret_cast<float*>(obase + (boff + tstep * i + 8u * hh)));
+                __builtin_nontemporal_store(v1, reinterpret_cast<float*>(obase + (boff + tstep * i + 8u * hh)) + 1);
 #else
-                *reinterpret_cast<float2*>(obase + (boff + 256u * i + 8u * hh)) = make_float2(v0, v1);
+                *reinterpret_cast<float2*>(obase + (boff + tstep * i + 8u * hh)) = make_float2(v0, v1);
 #endif
             }
         }
@@ -443,13 +447,13 @@ struct ConvLoop {
     float* tile;
     const float* lmean;
     const float* lrstd;
-    int B, CS, n2, mg, lane, tid;
+    int B, CS, n2, t0, lane, tid;
     bool affine;
-    int nblk;   // workgroups sharing the batch (the launch's grid, or this role's share of a merged launch)
+    int nblk;   // utterance strides of the batch loop: workgroups (or groups of `slices` workgroups) sharing the batch
 };
 
 // all utterances b, b + nblk, ... of this workgroup; `pre` holds utterance b's activations on entry
-template <int MODE, int NTW>
+template <int MODE, int NTW, int TS>
 __device__ __forceinline__ void conv_loop(const ConvLoop& c, const ConvEpilogue& epi, float2 (&pre)[PREF],
                                           const int (&pk)[PREF], int b, float& st0, float& st1) {
     const int P = epi.P;
@@ -460,7 +464,7 @@ __device__ __forceinline__ void conv_loop(const ConvLoop& c, const ConvEpilogue&
         const float* nsrc = (bn < c.B) ? c.in + (size_t)bn * NMAP * P : nullptr;  // fetched from inside the K loop
         const size_t ubase = (size_t)b * NMAP * P;
         if constexpr (NTW > 0) {
-            conv_utterance<MODE, NTW>(c.ltile, c.wnt, c.CS, c.mg, c.lane, ubase, epi, st0, st1, pre, nsrc, c.n2, c.tid,
+            conv_utterance<MODE, NTW, TS>(c.ltile, c.wnt, c.CS, c.t0, c.lane, ubase, epi, st0, st1, pre, nsrc, c.n2, c.tid,
                                       c.tid >> 8);  // wave / 4: position among the waves of this SIMD
         } else {
             // no position tile for this wave (tiny H): it still owns its share of the next utterance's loads
@@ -472,7 +476,7 @@ __device__ __forceinline__ void conv_loop(const ConvLoop& c, const ConvEpilogue&
 
 // MODE 0: forward   out = relu(conv(x)) [+ res]; stats = (sum, sumsq) of out per cout
 // MODE 1: dgrad     out = conv(x);               stats = (sum out, sum out * xhat) per cout, xhat from s_prev
-template <int MODE>
+template <int MODE, int SLICES>
 __device__ __forceinline__ void conv3x3_body(
     const float* __restrict__ in,         // (B,45,P) input activations (s_{i-1}) or dz_i
     const float* __restrict__ in_stats,   // {mean[48], rstd[48]} applied on load, or nullptr
@@ -482,7 +486,8 @@ __device__ __forceinline__ void conv3x3_body(
     const float* __restrict__ xs,         // dgrad: s_{i-1} for xhat, or nullptr (no stats)
     const float* __restrict__ xs_stats,   // dgrad: {mean, rstd} of layer i-1
     float* __restrict__ part,             // [nblk][2][48] partial statistics, or nullptr
-    int B, int H, int bid, int nblk,      // workgroup `bid` of the `nblk` that share this convolution
+    int B, int H, int bid, int nblk,      // utterances bid, bid + nblk, ... of this convolution
+    int slice,                            // small batches: SLICES (1, 2, 4) workgroups share every utterance's position tiles
     const BnFold& fold) {                 // forward: the input's BatchNorm statistics still as partials (or part == nullptr)
     HIP_DYNAMIC_SHARED(float, lds)
     const int P = H * PW;
@@ -501,7 +506,15 @@ __device__ __forceinline__ void conv3x3_body(
     const int mg = __builtin_amdgcn_readfirstlane(wave / 3);
     const int n2 = NMAP * P / 2;
     const int ntiles = (P + 15) / 16;
-    const int ntw = (ntiles - mg + 3) / 4;  // tiles j = mg, mg+4, ... < ntiles (wave-uniform, <= 5)
+    // With fewer utterances than CUs, `slices` workgroups take an utterance each: all of them stage the whole map (the 3x3
+    // neighbourhoods need it; the copies come from L2) and the weights, and split the position tiles -- workgroup `slice`
+    // owns tiles t0 + ts * i with t0 = mg + 4 * slice, ts = 4 * slices -- so the K loop, which is what a launch of 64
+    // one-utterance workgroups spends its time in, shrinks by `slices`.  Statistics partials get one row per workgroup.
+    // (SLICES is a template parameter: the tile stride sits in immediates of the epilogue's addresses, and the kernels run at
+    // the register limit of three waves per SIMD)
+    constexpr int slices = SLICES, ts = 4 * SLICES;
+    const int t0 = mg + 4 * slice;
+    const int ntw = t0 < ntiles ? (ntiles - t0 + ts - 1) / ts : 0;  // wave-uniform, <= 5
     const bool folding = MODE == 0 && fold.part != nullptr;
     const bool affine = in_stats != nullptr || folding;
 
@@ -540,7 +553,7 @@ __device__ __forceinline__ void conv3x3_body(
                 const float fr = (ch < NMAP) ? (float)(1.0 / sqrt(var + (double)BN_EPS)) : 0.0f;
                 lmean[ch] = fm;
                 lrstd[ch] = fr;
-                if (bid == 0) {   // one publisher: later readers (backward pass) and the running buffers (cnn.py:142)
+                if (bid == 0 && slice == 0) {   // one publisher: later readers (backward pass) and the running buffers (cnn.py:142)
                     fold.stats_out[ch] = fm;
                     fold.stats_out[CP + ch] = fr;
                     if (ch < NMAP && fold.bn.running_mean != nullptr) {
@@ -586,14 +599,14 @@ __device__ __forceinline__ void conv3x3_body(
     // instance executes the same two barriers per utterance): the register allocator then sees one variant's live
     // values, not the union of all five.
     const ConvLoop cl{in, (const lds_f32*)tile, (const lds_f32*)wl + nt * KSTEPS * 64, tile, lmean, lrstd, B, CS, n2,
-                      mg, lane, tid, affine, nblk};
+                      t0, lane, tid, affine, nblk};
     switch (ntw) {
-        case 5: conv_loop<MODE, 5>(cl, epi, pre, pk, b, st0, st1); break;
-        case 4: conv_loop<MODE, 4>(cl, epi, pre, pk, b, st0, st1); break;
-        case 3: conv_loop<MODE, 3>(cl, epi, pre, pk, b, st0, st1); break;
-        case 2: conv_loop<MODE, 2>(cl, epi, pre, pk, b, st0, st1); break;
-        case 1: conv_loop<MODE, 1>(cl, epi, pre, pk, b, st0, st1); break;
-        default: conv_loop<MODE, 0>(cl, epi, pre, pk, b, st0, st1); break;
+        case 5: conv_loop<MODE, 5, ts>(cl, epi, pre, pk, b, st0, st1); break;
+        case 4: conv_loop<MODE, 4, ts>(cl, epi, pre, pk, b, st0, st1); break;
+        case 3: conv_loop<MODE, 3, ts>(cl, epi, pre, pk, b, st0, st1); break;
+        case 2: conv_loop<MODE, 2, ts>(cl, epi, pre, pk, b, st0, st1); break;
+        case 1: conv_loop<MODE, 1, ts>(cl, epi, pre, pk, b, st0, st1); break;
+        default: conv_loop<MODE, 0, ts>(cl, epi, pre, pk, b, st0, st1); break;
     }
 
     HOWL_PROBE(wave, lane, pslot++);   // all utterances done
@@ -614,20 +627,26 @@ __device__ __forceinline__ void conv3x3_body(
             float s = 0.0f;
 #pragma unroll
             for (int g = 0; g < 4; ++g) s += red[((g * 3 + t3) * 2 + which) * 16 + cl];
-            part[((size_t)which * CP + c) * part_stride(nblk) + bid] = s;      // transposed: see fold_part_column
+            part[((size_t)which * CP + c) * part_stride(nblk * slices) + bid * slices + slice] = s;   // transposed: see fold_part_column
         }
     }
 }
 
-template <int MODE>
+template <int MODE, int SLICES>
 __global__ __launch_bounds__(CONV_THREADS) void conv3x3_mfma_kernel(const float* __restrict__ in,
                                                                     const float* __restrict__ in_stats,
                                                                     const float* __restrict__ wp,
                                                                     const float* __restrict__ res, float* __restrict__ out,
                                                                     const float* __restrict__ xs,
                                                                     const float* __restrict__ xs_stats,
-                                                                    float* __restrict__ part, int B, int H, BnFold fold) {
-    conv3x3_body<MODE>(in, in_stats, wp, res, out, xs, xs_stats, part, B, H, blockIdx.x, gridDim.x, fold);
+                                                                    float* __restrict__ part, int B, int H, int nblk,
+                                                                    BnFold fold) {
+    // blocks x, x + 8, ... run on XCD x (the hardware deals blocks round-robin): the SLICES workgroups of an utterance
+    // group sit on one XCD and share its L2 copy of the maps
+    const int x = blockIdx.x & 7, y = blockIdx.x >> 3;
+    const int slice = y % SLICES, bid = (y / SLICES) * 8 + x;
+    if (bid >= nblk) return;
+    conv3x3_body<MODE, SLICES>(in, in_stats, wp, res, out, xs, xs_stats, part, B, H, bid, nblk, slice, fold);
 }
 
 
@@ -695,11 +714,12 @@ struct WgradArgs {
     const float* lrstd;
     int B, P, CS, R, n2, tid, lane, wave;
     bool affine;
-    int bid, nblk;   // this workgroup's index among the nblk that share the weight gradient
+    int bid, nblk;   // utterances bid, bid + nblk, ...; partial row bid
+    int gw;          // this wave's index among the GWS = 12 * slices waves that share the 27 N tiles of those utterances
 };
 
 // all utterances b, b + nblk, ... of this workgroup (pz / px hold utterance b on entry), then this wave's partials
-template <int NB>
+template <int NB, int GWS>
 __device__ __forceinline__ void wgrad_loop(const WgradArgs& a, float2 (&pz)[PREF], float2 (&px)[PREF],
                                            const int (&pk)[PREF], int b, int& pslot) {
     const int lane = a.lane, wave = a.wave, CS = a.CS;
@@ -709,11 +729,11 @@ __device__ __forceinline__ void wgrad_loop(const WgradArgs& a, float2 (&pz)[PREF
     for (int i = 0; i < NB; ++i)
 #pragma unroll
         for (int mt = 0; mt < 3; ++mt) acc[i][mt] = {0.0f, 0.0f, 0.0f, 0.0f};
-    // N tiles q = wave, wave + 12, wave + 24 (< 27): q = 3 * tap + cin tile
+    // N tiles q = gw, gw + GWS, ... (< 27): q = 3 * tap + cin tile
     int boff[NB];
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
-        const int q = wave + 12 * i;
+        const int q = a.gw + GWS * i;
         const int tap = q / 3, ct = q - 3 * tap;
         boff[i] = (16 * ct + n) * CS + (g + tap / 3) * WPW + (tap % 3);   // cin row, halo origin + tap shift
     }
@@ -760,7 +780,7 @@ __device__ __forceinline__ void wgrad_loop(const WgradArgs& a, float2 (&pz)[PREF
     float* dst = a.part + (size_t)a.bid * CP * 432;
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
-        const int q = wave + 12 * i;
+        const int q = a.gw + GWS * i;
         const int tap = q / 3, ct = q - 3 * tap;
 #pragma unroll
         for (int mt = 0; mt < 3; ++mt)
@@ -772,9 +792,10 @@ __device__ __forceinline__ void wgrad_loop(const WgradArgs& a, float2 (&pz)[PREF
     }
 }
 
+template <int SLICES>
 __device__ __forceinline__ void wgrad_body(
     const float* __restrict__ dz, const float* __restrict__ s_prev, const float* __restrict__ in_stats,
-    float* __restrict__ part /* [nblk][48][432] */, int B, int H, int bid, int nblk) {
+    float* __restrict__ part /* [nblk][48][432] */, int B, int H, int bid, int nblk, int slice) {
     HIP_DYNAMIC_SHARED(float, lds)
     const int P = H * PW;
     const int CS = chan_stride_wgrad(H);
@@ -811,20 +832,35 @@ __device__ __forceinline__ void wgrad_body(
     HOWL_PROBE(wave, lane, pslot++);   // prologue done
     // instantiated per tile count (waves 0..2 carry a third N tile): no branches inside the K loop, and the register
     // allocator sees one variant's live values (waves of a workgroup run different instances with the same barriers)
+    // small batches: two workgroups share an utterance group's 27 N tiles (each stages both maps; wave gw of the 24 owns tiles
+    // gw, gw + 24) and write disjoint columns of the same partial row
+    constexpr int GWS = 12 * SLICES;
+    const int gw = wave + 12 * slice;
     const WgradArgs a{dz, s_prev, part, tz, tx, lmean, lrstd, B, P, CS, wgrad_rounds(H), n2, tid, lane, wave, affine,
-                      bid, nblk};
-    if (wave + 24 < 27)
-        wgrad_loop<3>(a, pz, px, pk, b, pslot);
-    else
-        wgrad_loop<2>(a, pz, px, pk, b, pslot);
+                      bid, nblk, gw};
+    if constexpr (SLICES == 1) {       // tiles wave, wave + 12, wave + 24 (< 27): waves 0..2 carry a third one
+        if (wave + 24 < 27)
+            wgrad_loop<3, GWS>(a, pz, px, pk, b, pslot);
+        else
+            wgrad_loop<2, GWS>(a, pz, px, pk, b, pslot);
+    } else {                           // tiles gw, gw + 24 (< 27)
+        if (gw + 24 < 27)
+            wgrad_loop<2, GWS>(a, pz, px, pk, b, pslot);
+        else
+            wgrad_loop<1, GWS>(a, pz, px, pk, b, pslot);
+    }
     HOWL_PROBE(wave, lane, pslot++);   // partials written
 }
 
+template <int SLICES>
 __global__ __launch_bounds__(CONV_THREADS) void wgrad_mfma_kernel(const float* __restrict__ dz,
                                                                   const float* __restrict__ s_prev,
                                                                   const float* __restrict__ in_stats,
-                                                                  float* __restrict__ part, int B, int H) {
-    wgrad_body(dz, s_prev, in_stats, part, B, H, blockIdx.x, gridDim.x);
+                                                                  float* __restrict__ part, int B, int H, int nblk) {
+    const int x = blockIdx.x & 7, y = blockIdx.x >> 3;
+    const int slice = y % SLICES, bid = (y / SLICES) * 8 + x;
+    if (bid >= nblk) return;
+    wgrad_body<SLICES>(dz, s_prev, in_stats, part, B, H, bid, nblk, slice);
 }
 
 // Data gradient and weight gradient of one layer in ONE launch.  Both hang off dz_i and are independent; side by side on
@@ -833,17 +869,21 @@ __global__ __launch_bounds__(CONV_THREADS) void wgrad_mfma_kernel(const float* _
 // record / wait pairs that fork and join the second queue cost ~6.5 us each on this stack, twice per layer on the
 // critical path.)  Blocks come in groups of 16: the first 8 run the data gradient, the other 8 the weight gradient, so
 // that pair j of either role lands on the same XCD (block b runs on XCD b % 8) and shares its L2 copy of dz.
+template <int SD, int SW>
 __global__ __launch_bounds__(CONV_THREADS) void bwd_pair_kernel(
     const float* __restrict__ dz, const float* __restrict__ wp, float* __restrict__ dx, const float* __restrict__ xs,
     const float* __restrict__ xs_stats, float* __restrict__ spart, const float* __restrict__ s_prev,
     const float* __restrict__ in_stats, float* __restrict__ wpart, int B, int H, int nblk) {
-    const int role = (blockIdx.x >> 3) & 1;
-    const int j = (int)(blockIdx.x >> 4) * 8 + (int)(blockIdx.x & 7);
+    // groups of 8 * (SD + SW) blocks: utterance group j = 8 * (group index) + x on XCD x gets SD data-gradient workgroups
+    // (position slices) and SW weight-gradient workgroups (N-tile slices); SD = SW = 1 at full batches
+    const int x = blockIdx.x & 7, y = blockIdx.x >> 3;
+    const int r = y % (SD + SW);
+    const int j = (y / (SD + SW)) * 8 + x;
     if (j >= nblk) return;
-    if (role == 0)
-        conv3x3_body<1>(dz, nullptr, wp, nullptr, dx, xs, xs_stats, spart, B, H, j, nblk, BnFold{});
+    if (r < SD)
+        conv3x3_body<1, SD>(dz, nullptr, wp, nullptr, dx, xs, xs_stats, spart, B, H, j, nblk, r, BnFold{});
     else
-        wgrad_body(dz, s_prev, in_stats, wpart, B, H, j, nblk);
+        wgrad_body<SW>(dz, s_prev, in_stats, wpart, B, H, j, nblk, r - SD);
 }
 
 // Deterministic sum over the per-workgroup partial rows: part[g][col], g < nparts.  A block owns 64 columns
@@ -1494,8 +1534,9 @@ size_t ws_layout(Ws* w, char* base, int B, int H, int G) {
     Ws t;
     t.wp_fwd = take((size_t)6 * 3 * KSTEPS * 64);
     t.wp_bwd = take((size_t)6 * 3 * KSTEPS * 64);
-    t.part = take((size_t)part_stride(G) * 2 * CP);
-    t.part2 = take((size_t)part_stride(G) * 2 * CP);
+    const int max_parts = G > howl_num_cus() ? G : howl_num_cus();     // one row per workgroup; slicing never exceeds the CU count
+    t.part = take((size_t)part_stride(max_parts) * 2 * CP);
+    t.part2 = take((size_t)part_stride(max_parts) * 2 * CP);
     t.stats = take((size_t)6 * 2 * CP);
     t.m12 = take(2 * CP);
     t.dpool = take((size_t)B * CP);
@@ -1518,6 +1559,76 @@ size_t ws_layout(Ws* w, char* base, int B, int H, int G) {
 int conv_grid(int B) {
     int g = howl_num_cus();
     return B < g ? B : g;
+}
+// Small batches (the reference's presets train at 16, its engines run at batch 1): how many workgroups share one utterance.
+// Forward / data gradient split the position tiles (4 or 2 ways: every position group of a workgroup keeps at least one
+// tile), the weight gradient its 27 N tiles (2 ways).
+int launch_blocks(int nblk, int per_group) { return 8 * per_group * ((nblk + 7) / 8); }
+bool slicing_enabled() {     // HOWL_RES8_SLICES=0: one workgroup per utterance whatever the batch (the reference point of the tests)
+    const char* e = getenv("HOWL_RES8_SLICES");
+    return !(e != nullptr && e[0] == '0');
+}
+int conv_slices(int nblk, int H, int budget) {
+    const int ntiles = (H * PW + 15) / 16;
+    if (!slicing_enabled()) return 1;
+    for (int sl = 4; sl > 1; sl >>= 1)
+        if (nblk * sl <= budget && 4 * sl <= ntiles) return sl;
+    return 1;
+}
+void pair_slices(int nblk, int H, int* sd, int* sw) {
+    const int cus = howl_num_cus(), ntiles = (H * PW + 15) / 16;
+    const int opts[4][2] = {{4, 2}, {2, 2}, {2, 1}, {1, 1}};
+    *sd = *sw = 1;
+    if (!slicing_enabled()) return;
+    for (const auto& o : opts)
+        if (nblk * (o[0] + o[1]) <= cus && 4 * o[0] <= ntiles) {
+            *sd = o[0];
+            *sw = o[1];
+            return;
+        }
+    *sd = *sw = 1;
+}
+
+// launchers: one instantiation per slicing factor (dynamic LDS limit raised on the instance that is launched)
+template <int MODE, int SLICES>
+void launch_conv3x3_inst(int nblk, size_t lds, hipStream_t stream, const float* in, const float* in_stats, const float* wp,
+                         const float* res, float* out, const float* xs, const float* xs_stats, float* part, int B, int H,
+                         const BnFold& fold) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_mfma_kernel<MODE, SLICES>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((conv3x3_mfma_kernel<MODE, SLICES>), dim3(launch_blocks(nblk, SLICES)), dim3(CONV_THREADS), lds, stream, in,
+                       in_stats, wp, res, out, xs, xs_stats, part, B, H, nblk, fold);
+}
+template <int MODE>
+void launch_conv3x3(int slices, int nblk, size_t lds, hipStream_t stream, const float* in, const float* in_stats, const float* wp,
+                    const float* res, float* out, const float* xs, const float* xs_stats, float* part, int B, int H,
+                    const BnFold& fold) {
+    if (slices == 4)
+        launch_conv3x3_inst<MODE, 4>(nblk, lds, stream, in, in_stats, wp, res, out, xs, xs_stats, part, B, H, fold);
+    else if (slices == 2)
+        launch_conv3x3_inst<MODE, 2>(nblk, lds, stream, in, in_stats, wp, res, out, xs, xs_stats, part, B, H, fold);
+    else
+        launch_conv3x3_inst<MODE, 1>(nblk, lds, stream, in, in_stats, wp, res, out, xs, xs_stats, part, B, H, fold);
+}
+template <int SD, int SW>
+void launch_pair_inst(int nblk, size_t lds, hipStream_t stream, const float* dz, const float* wp, float* dx, const float* xs,
+                      const float* xs_stats, float* spart, const float* s_prev, const float* in_stats, float* wpart, int B, int H) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(bwd_pair_kernel<SD, SW>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                        (int)lds);
+    hipLaunchKernelGGL((bwd_pair_kernel<SD, SW>), dim3(launch_blocks(nblk, SD + SW)), dim3(CONV_THREADS), lds, stream, dz, wp, dx, xs,
+                       xs_stats, spart, s_prev, in_stats, wpart, B, H, nblk);
+}
+void launch_pair(int sd, int sw, int nblk, size_t lds, hipStream_t stream, const float* dz, const float* wp, float* dx,
+                 const float* xs, const float* xs_stats, float* spart, const float* s_prev, const float* in_stats, float* wpart,
+                 int B, int H) {
+    if (sd == 4 && sw == 2)
+        launch_pair_inst<4, 2>(nblk, lds, stream, dz, wp, dx, xs, xs_stats, spart, s_prev, in_stats, wpart, B, H);
+    else if (sd == 2 && sw == 2)
+        launch_pair_inst<2, 2>(nblk, lds, stream, dz, wp, dx, xs, xs_stats, spart, s_prev, in_stats, wpart, B, H);
+    else if (sd == 2 && sw == 1)
+        launch_pair_inst<2, 1>(nblk, lds, stream, dz, wp, dx, xs, xs_stats, spart, s_prev, in_stats, wpart, B, H);
+    else
+        launch_pair_inst<1, 1>(nblk, lds, stream, dz, wp, dx, xs, xs_stats, spart, s_prev, in_stats, wpart, B, H);
 }
 
 }  // namespace
@@ -1562,9 +1673,8 @@ int howl_res8_fwd(const HowlRes8Params* prm, const float* feat, long sb, long st
                            prm->conv0_w, sv->s[0], sv->mask0, B, T, M, H, G0, cw, w.wp_fwd, w.wp_bwd, 1, 0, 0);
     }
     const size_t lc = conv_lds_bytes(H);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_mfma_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                        (int)lc);
     const double count = (double)B * (double)P;
+    const int SL = conv_slices(G, H, howl_num_cus());
     // Training: layer i leaves its statistics as per-workgroup partials; layer i+1 folds them in its own prologue (BnFold),
     // so only the last layer needs the stand-alone finalize.  The partial buffers alternate between layers.
     for (int i = 1; i <= 6; ++i) {
@@ -1575,20 +1685,19 @@ int howl_res8_fwd(const HowlRes8Params* prm, const float* feat, long sb, long st
         const float* in_stats = nullptr;
         if (i > 1) {
             if (training)
-                fold = BnFold{(i & 1) ? w.part2 : w.part, G, count, sv->bn_stats + (size_t)(i - 2) * 2 * CP,
+                fold = BnFold{(i & 1) ? w.part2 : w.part, G * SL, count, sv->bn_stats + (size_t)(i - 2) * 2 * CP,
                               HowlBnBuffers{prm->bn_running_mean[i - 2], prm->bn_running_var[i - 2], prm->bn_num_batches[i - 2]}};
             else
                 in_stats = sv->bn_stats + (size_t)(i - 2) * 2 * CP;
         }
         {
             HowlProfScope prof("conv3x3_fwd", stream);
-            hipLaunchKernelGGL(conv3x3_mfma_kernel<0>, dim3(G), dim3(CONV_THREADS), lc, stream, sv->s[i - 1], in_stats,
-                               w.wp_fwd + (size_t)(i - 1) * 3 * KSTEPS * 64, res, sv->s[i], (const float*)nullptr,
-                               (const float*)nullptr, part_out, B, H, fold);
+            launch_conv3x3<0>(SL, G, lc, stream, sv->s[i - 1], in_stats, w.wp_fwd + (size_t)(i - 1) * 3 * KSTEPS * 64, res, sv->s[i],
+                              nullptr, nullptr, part_out, B, H, fold);
         }
     }
     if (training)
-        hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(768), 0, stream, w.part2, G, count,
+        hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(768), 0, stream, w.part2, G * SL, count,
                            sv->bn_stats + (size_t)5 * 2 * CP,
                            HowlBnBuffers{prm->bn_running_mean[5], prm->bn_running_var[5], prm->bn_num_batches[5]});
     hipLaunchKernelGGL(head_fwd_kernel, dim3(B < 1024 ? B : 1024), dim3(256), 0, stream, sv->s[6],
@@ -1662,19 +1771,17 @@ int howl_res8_fwd_long(const HowlRes8Params* prm, const float* feat, long sb, lo
                        buf[0], (unsigned short*)nullptr, Bv, Tw, M, WIN_H, G0, cw, w.wp_fwd, w.wp_bwd, nw, 3 * WIN_STEP,
                        3 * (H - WIN_H));
     const size_t lc = conv_lds_bytes(WIN_H);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_mfma_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                        (int)lc);
     const int G = conv_grid(Bv);
+    const int SL = conv_slices(G, WIN_H, howl_num_cus());
     // x_i lives in buf[cur]; even layers add the map two layers back (kept in buf[skip])
     int cur = 0, skip = 0;
     for (int i = 1; i <= 6; ++i) {
         const bool even = (i % 2) == 0;
         int out = 0;
         while (out == cur || out == skip) ++out;
-        hipLaunchKernelGGL(conv3x3_mfma_kernel<0>, dim3(G), dim3(CONV_THREADS), lc, stream, (const float*)buf[cur],
-                           i == 1 ? (const float*)nullptr : (const float*)(stats + (size_t)(i - 2) * 2 * CP),
-                           w.wp_fwd + (size_t)(i - 1) * 3 * KSTEPS * 64, even ? (const float*)buf[skip] : (const float*)nullptr,
-                           buf[out], (const float*)nullptr, (const float*)nullptr, (float*)nullptr, Bv, WIN_H, BnFold{});
+        launch_conv3x3<0>(SL, G, lc, stream, buf[cur], i == 1 ? (const float*)nullptr : (const float*)(stats + (size_t)(i - 2) * 2 * CP),
+                          w.wp_fwd + (size_t)(i - 1) * 3 * KSTEPS * 64, even ? (const float*)buf[skip] : (const float*)nullptr, buf[out],
+                          nullptr, nullptr, nullptr, Bv, WIN_H, BnFold{});
         if (even) skip = out;      // s_i (i even) is the next residual source; s_0 is the first one
         cur = out;
     }
@@ -1719,19 +1826,16 @@ int howl_res8_bwd_part(const HowlRes8Params* prm, const float* feat, long sb, lo
                            gr->out_b, w.m12, B, C, P);
     }
     const size_t lc = conv_lds_bytes(H);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_mfma_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                        (int)lc);
     const size_t lw = wgrad_lds_bytes(H);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                        (int)lw);
     const size_t lp = lc > lw ? lc : lw;
-    hipFuncSetAttribute(reinterpret_cast<const void*>(bwd_pair_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lp);
     const char* pair_env = getenv("HOWL_RES8_BWD_PAIR");
     const bool merged = !(pair_env != nullptr && pair_env[0] == '0');
     // dgrad and wgrad side by side: half the CUs each
     const int half = howl_num_cus() / 2 > 0 ? howl_num_cus() / 2 : 1;
     const int Gh = B < half ? B : half;
     const size_t wpart_stride = (size_t)Gh * CP * 432;
+    int SD = 1, SW = 1;
+    pair_slices(Gh, H, &SD, &SW);
     float* dx_cur = nullptr;      // gradient w.r.t. the BN output of layer i (nullptr: broadcast of dpool)
     float* dx_next = w.bufa;
     float* ds_prev = nullptr;     // ds_{i+2}
@@ -1743,7 +1847,7 @@ int howl_res8_bwd_part(const HowlRes8Params* prm, const float* feat, long sb, lo
         float* dz = even ? w.dz : w.dz2;
         // layer 6 takes its two means from the head (m12); the others fold the partials of the data gradient above them
         if (run_layers) hipLaunchKernelGGL(bn_relu_bwd_kernel, dim3(eg), dim3(BRB_THREADS), 0, stream, (const float*)dx_cur, w.dpool, sv->s[i],
-                           stats_i, w.m12, i == 6 ? (const float*)nullptr : (const float*)w.part, Gh, count,
+                           stats_i, w.m12, i == 6 ? (const float*)nullptr : (const float*)w.part, Gh * SD, count,
                            even ? (const float*)ds_prev : (const float*)nullptr, even ? 1 : 0, ds_out, dz, B, P);
         if (even) {
             float* t = ds_prev ? ds_prev : w.dsb;
@@ -1762,17 +1866,24 @@ int howl_res8_bwd_part(const HowlRes8Params* prm, const float* feat, long sb, lo
             // part 2 only replays the buffer rotation of the loop
         } else if (merged) {
             HowlProfScope prof("bwd_pair", stream);
-            hipLaunchKernelGGL(bwd_pair_kernel, dim3(16 * ((Gh + 7) / 8)), dim3(CONV_THREADS), lp, stream, (const float*)dz, wpb,
-                               dx_next, xs, in_stats, spart, sv->s[i - 1], in_stats, wpart, B, H, Gh);
+            launch_pair(SD, SW, Gh, lp, stream, dz, wpb, dx_next, xs, in_stats, spart, sv->s[i - 1], in_stats, wpart, B, H);
         } else {
             {
                 HowlProfScope prof("conv3x3_dgrad", stream);
-                hipLaunchKernelGGL(conv3x3_mfma_kernel<1>, dim3(Gh), dim3(CONV_THREADS), lc, stream, (const float*)dz,
-                                   (const float*)nullptr, wpb, (const float*)nullptr, dx_next, xs, in_stats, spart, B, H, BnFold{});
+                launch_conv3x3<1>(SD, Gh, lc, stream, dz, nullptr, wpb, nullptr, dx_next, xs, in_stats, spart, B, H, BnFold{});
             }
             HowlProfScope prof("wgrad", stream);
-            hipLaunchKernelGGL(wgrad_mfma_kernel, dim3(Gh), dim3(CONV_THREADS), lw, stream, (const float*)dz, sv->s[i - 1],
-                               in_stats, wpart, B, H);
+            if (SW == 2) {
+                hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_mfma_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lw);
+                hipLaunchKernelGGL(wgrad_mfma_kernel<2>, dim3(launch_blocks(Gh, 2)), dim3(CONV_THREADS), lw, stream, (const float*)dz,
+                                   sv->s[i - 1], in_stats, wpart, B, H, Gh);
+            } else {
+                hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_mfma_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lw);
+                hipLaunchKernelGGL(wgrad_mfma_kernel<1>, dim3(launch_blocks(Gh, 1)), dim3(CONV_THREADS), lw, stream, (const float*)dz,
+                                   sv->s[i - 1], in_stats, wpart, B, H, Gh);
+            }
         }
         dx_cur = dx_next;
         dx_next = (dx_next == w.bufa) ? w.bufb : w.bufa;

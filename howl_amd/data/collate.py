@@ -31,6 +31,7 @@ class DeviceCollate:
         """``background`` = (bg_audio (N, Lbg) on the device, bg_lengths): the noise dataset of ``DatasetMixer``."""
         self.audio, self.lengths, self.labels = bank_audio, [int(v) for v in bank_lengths.tolist()], bank_labels
         self.last_max_len = 0      # longest row of the last batch (host knowledge: no read-back for the frame count)
+        self.labels_host = None if bank_labels is None else [int(v) for v in bank_labels.tolist()]   # gathered on the host
         self.bg_audio = None if background is None else background[0]
         self.bg_lengths = None if background is None else [int(v) for v in background[1]]
         self.do_replace = do_replace
@@ -76,20 +77,51 @@ class DeviceCollate:
                     bg_id[k], bg_off[k], alpha[k] = j, b - lens[k], a   # "replace" (alpha 1) overrides an earlier mix
         return bg_id, bg_off, alpha
 
-    def _launch(self, clip_ids, rows, shift, src_end, sigma, sp, lout, dst_off=None):
-        """One ``howl_collate_augment_window`` launch: batch row r takes samples [shift[r], src_end[r]) of clip
-        ``clip_ids[rows[r]]`` (mixed with its background first, noise added), at column ``dst_off[r]``."""
+    def _upload(self, sections):
+        """Per-batch host decisions -> device tensors through ONE host->device copy: ``sections`` is a list of
+        (kind, values) with kind "i" (int32), "f" (float32) or "l" (int64); returns one device tensor per section, views of
+        a single packed buffer.  (One ``torch.tensor(...).to(device)`` per array was a dozen small copies per batch --
+        4 % of a MobileNet step.)"""
+        import numpy as np
+        words, spans = [], []
+        off = 0
+        for kind, vals in sections:
+            a = np.ascontiguousarray(vals, dtype={"i": np.int32, "f": np.float32, "l": np.int64}[kind])
+            if kind == "l" and off % 2:
+                words.append(np.zeros(1, np.int32))      # int64 views need an 8-byte aligned offset
+                off += 1
+            raw = a.view(np.int32).reshape(-1)
+            spans.append((kind, off, raw.size, a.shape))
+            words.append(raw)
+            off += raw.size
         dev = self.audio.device
-        i32 = lambda a: torch.tensor(a, dtype=torch.int32).to(dev, non_blocking=True)
-        f32 = lambda a: torch.tensor(a, dtype=torch.float32).to(dev, non_blocking=True)
+        buf = torch.from_numpy(np.concatenate(words) if words else np.zeros(0, np.int32)).to(dev, non_blocking=True)
+        out = []
+        for kind, o, n, shape in spans:
+            v = buf[o:o + n]
+            out.append(v if kind == "i" else v.view(torch.float32 if kind == "f" else torch.int64).reshape(shape))
+        return out
+
+    def _launch(self, clip_ids, rows, shift, src_end, sigma, sp, lout, dst_off=None, extra=()):
+        """One ``howl_collate_augment_window`` launch: batch row r takes samples [shift[r], src_end[r]) of clip
+        ``clip_ids[rows[r]]`` (mixed with its background first, noise added), at column ``dst_off[r]``.  ``extra``: more
+        (kind, values) sections to ride in the same upload (labels, lengths); returns (audio, [extra tensors])."""
         pick = lambda a: [a[k] for k in rows]
         self._calls += 1
-        mix = None
-        if self.last_mix is not None and any(a != 0.0 for a in self.last_mix[2]):
-            mix = (self.bg_audio, i32(pick(self.last_mix[0])), i32(pick(self.last_mix[1])), f32(pick(self.last_mix[2])))
-        return ops.collate_augment(self.audio, i32(pick(clip_ids)), i32(src_end), i32(shift), i32([1] * len(rows)),
-                                   f32(pick(sigma)), f32(pick(sp)), (self._seed << 32) ^ self._calls, lout, mix=mix,
-                                   dst_off=None if dst_off is None else i32(dst_off))
+        sections = [("i", pick(clip_ids)), ("i", src_end), ("i", shift), ("i", [1] * len(rows)), ("f", pick(sigma)),
+                    ("f", pick(sp))]
+        has_mix = self.last_mix is not None and any(a != 0.0 for a in self.last_mix[2])
+        if has_mix:
+            sections += [("i", pick(self.last_mix[0])), ("i", pick(self.last_mix[1])), ("f", pick(self.last_mix[2]))]
+        if dst_off is not None:
+            sections.append(("i", dst_off))
+        n_own = len(sections)
+        dev_t = self._upload(sections + list(extra))
+        idx, end, sh, ones, sg, spp = dev_t[:6]
+        mix = (self.bg_audio, dev_t[6], dev_t[7], dev_t[8]) if has_mix else None
+        audio = ops.collate_augment(self.audio, idx, end, sh, ones, sg, spp, (self._seed << 32) ^ self._calls, lout, mix=mix,
+                                    dst_off=dev_t[n_own - 1] if dst_off is not None else None)
+        return audio, dev_t[n_own:]
 
     def __call__(self, clip_ids) -> ClassificationBatch:
         """compose(truncate_length, Timeshift, Noise, batchify) (pretrain_gsc.py:78-80)."""
@@ -99,11 +131,12 @@ class DeviceCollate:
         self.last_max_len = max(out_len)
         order = sorted(range(len(clip_ids)), key=lambda k: -out_len[k])          # batchify: longest first (stable)
         first = [shift[k] if head[k] else 0 for k in order]                      # head crop drops the first w samples,
-        audio = self._launch(clip_ids, order, first, [f + out_len[k] for f, k in zip(first, order)], sigma, sp,
-                             max(out_len))                                       # tail crop the last w
-        dev = self.audio.device
-        idx = torch.tensor([clip_ids[k] for k in order], dtype=torch.long).to(dev, non_blocking=True)
-        return ClassificationBatch(audio, self.labels[idx], torch.tensor([out_len[k] for k in order]).to(dev, non_blocking=True))
+        extra = [("l", [out_len[k] for k in order])]
+        if self.labels_host is not None:
+            extra.append(("l", [self.labels_host[clip_ids[k]] for k in order]))
+        audio, ex = self._launch(clip_ids, order, first, [f + out_len[k] for f, k in zip(first, order)], sigma, sp,
+                                 max(out_len), extra=extra)                      # tail crop the last w
+        return ClassificationBatch(audio, ex[1] if self.labels_host is not None else None, ex[0])
 
     def frame_batch(self, examples, batchifier) -> ClassificationBatch:
         """compose([DatasetMixer,] Timeshift, Noise, WakeWordFrameBatchifier) (train.py:211-229) on device clips: the
@@ -116,10 +149,9 @@ class DeviceCollate:
                    for ex, l, w in zip(examples, lens, shift)]
         plan = batchifier.plan(cropped)
         first = [(shift[k] if head[k] else 0) + a for k, a in zip(plan.source, plan.start)]
-        audio = self._launch(clip_ids, plan.source, first, [f + n for f, n in zip(first, plan.length)], sigma, sp,
-                             plan.width, dst_off=plan.dst_off)
-        dev = self.audio.device
-        return ClassificationBatch(audio, torch.tensor(plan.labels).to(dev, non_blocking=True), torch.tensor(plan.length))
+        audio, ex = self._launch(clip_ids, plan.source, first, [f + n for f, n in zip(first, plan.length)], sigma, sp,
+                                 plan.width, dst_off=plan.dst_off, extra=[("l", list(plan.labels))])
+        return ClassificationBatch(audio, ex[0], torch.tensor(plan.length))
 
     def sequence_batch(self, examples, batchifier):
         """compose([DatasetMixer,] Timeshift, Noise, AudioSequenceBatchifier) (train.py:206-229): whole augmented clips,
@@ -130,5 +162,5 @@ class DeviceCollate:
         out_len = [l - w for l, w in zip(lens, shift)]
         order, labels, label_lengths = batchifier.order_and_labels(examples, out_len)
         first = [shift[k] if head[k] else 0 for k in order]
-        audio = self._launch(clip_ids, order, first, [f + out_len[k] for f, k in zip(first, order)], sigma, sp, max(out_len))
+        audio, _ = self._launch(clip_ids, order, first, [f + out_len[k] for f, k in zip(first, order)], sigma, sp, max(out_len))
         return SequenceBatch(audio, labels, torch.tensor([out_len[k] for k in order]), label_lengths)

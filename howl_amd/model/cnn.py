@@ -412,7 +412,12 @@ class MobileNetClassifier(RegisteredModel, name="mobilenet"):
             if self.forced_keep_mask is not None:
                 self._last_mask = self.forced_keep_mask.to(device=x0.device, dtype=torch.float32).contiguous()
             elif self.dropout_p > 0:
-                self._last_mask = (torch.rand((B, 1280), device=x0.device) >= self.dropout_p).to(torch.float32)
+                # one launch of the counter-based device generator; the key comes from torch's CPU generator (a host draw:
+                # reproducible under torch.manual_seed, nothing read back from the device)
+                self._last_mask = torch.empty((B, 1280), dtype=torch.float32, device=x0.device)
+                key = int(torch.randint(0, 2 ** 62, (1,)).item())
+                _lib.get().call("howl_dropout_mask", ctypes.c_void_p(self._last_mask.data_ptr()), self._last_mask.numel(),
+                                float(self.dropout_p), ctypes.c_ulonglong(key), ops._stream())
             torch._foreach_add_([bn.num_batches_tracked for _, bn, _ in self._layer_modules()], 1)
         mask, scale = self._mask_args()
         self._fwd_version += 1

@@ -295,6 +295,10 @@ int howl_mobilenet_layer(int i, HowlMbLayer* out);
 size_t howl_mobilenet_param_floats(int num_labels);
 size_t howl_mobilenet_buffer_floats(void);
 size_t howl_mobilenet_workspace_bytes(int B, int M, int T, int num_labels);
+/* n keep flags (1.0 with probability 1 - p, else 0.0) from the counter-based device generator keyed by `seed`: the
+ * drop_mask operand of howl_mobilenet_fwd / _bwd, replacing nn.Dropout's torch.rand chain (cnn.py:22 via torchvision's classifier). */
+int howl_dropout_mask(float* mask, size_t n, float p, unsigned long long seed, hipStream_t stream);
+
 /* x: element (b, mel, t) at x[b*sb + mel*sm + t*st] (the log-Mel channel of the (B,3,M,T) features).  training != 0:
  * batch statistics (running buffers updated, momentum 0.1) and, if drop_mask (B,1280 of 0/1) is given, dropout with
  * kept activations scaled by drop_scale = 1/(1-p).  The workspace keeps what howl_mobilenet_bwd needs: pass the SAME

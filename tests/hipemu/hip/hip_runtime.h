@@ -68,7 +68,13 @@ static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 static inline hipError_t hipSetDevice(int) { return hipSuccess; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 static inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
-static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) { p->multiProcessorCount = 4; return hipSuccess; }
+// 4 "CUs" by default (grids stay tiny); HIPEMU_CUS=n (read when the library is loaded: howl_num_cus caches) lets a test
+// process reach the launch geometries that need more of them
+static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) {
+    const char* e = getenv("HIPEMU_CUS");
+    p->multiProcessorCount = (e && atoi(e) > 0) ? atoi(e) : 4;
+    return hipSuccess;
+}
 static inline hipError_t hipFuncSetAttribute(const void*, int, int) { return hipSuccess; }
 static constexpr int hipFuncAttributeMaxDynamicSharedMemorySize = 8;
 

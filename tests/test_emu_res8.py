@@ -168,3 +168,63 @@ def test_long_input_windows_vs_oracle(lib, B, T):
     logits2 = np.full((B, C), np.nan, np.float32)
     lib.call("howl_res8_fwd_long", ctypes.byref(h.prm), ptr(g), 40 * T, 1, T, B, T, 40, C, ptr(logits2), ptr(ws), ws.size, None)
     assert np.array_equal(logits2, logits)
+
+
+def test_small_batch_slicing_matches_unsliced():
+    """Batches smaller than the CU count: several workgroups share an utterance (forward / data gradient: position tiles 2- or
+    4-way, weight gradient: its N tiles 2-way; csrc/res8.hip conv_slices / pair_slices).  The same one-utterance step in a
+    process whose emulated device has 8 CUs (forward 4-way, backward 4 + 2) and in one with a single CU (no slicing) must
+    give the same logits, statistics and gradients up to summation order, and both must match the oracle."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+    code = r"""
+import json, os, sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+os.environ.setdefault("NUM_MELS", "40")
+import numpy as np, torch
+from emu_util import emu_lib, ptr
+import test_emu_res8 as T
+lib = emu_lib()
+out = {}
+for B, Tf, C in ((1, 81, 12), (2, 41, 4)):
+    x = T.feats(B, Tf, 5)
+    h = T.Res8Harness(lib, B, Tf, C)
+    logits = h.fwd(x[:, 0].permute(0, 2, 1).numpy(), training=True)
+    dlogits = np.zeros((B, C), np.float32); loss = np.zeros(1, np.float32)
+    lab = np.ascontiguousarray((torch.arange(B) %% C).numpy(), np.int64)
+    lib.call("howl_xent_fwd_bwd", ptr(h.logits), ptr(lab), B, C, ptr(loss), ptr(dlogits), None)
+    g = h.bwd(dlogits)
+    out["%%d_%%d" %% (B, Tf)] = {"logits": logits.tolist(), "grads": {k: v.reshape(-1)[:: max(1, v.size // 50)].tolist() for k, v in g.items()},
+                               "rm": h.np["bn3.running_mean"].tolist()}
+print("RESULT" + json.dumps(out))
+""" % (str(Path(__file__).resolve().parent.parent), str(Path(__file__).resolve().parent))
+    res = {}
+    for cus in ("1", "8"):
+        import os
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, HIPEMU_CUS=cus), capture_output=True, text=True,
+                           timeout=1500)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[cus] = json.loads(r.stdout.split("RESULT", 1)[1])
+    for key in res["1"]:
+        a, b = res["1"][key], res["8"][key]
+        np.testing.assert_allclose(a["logits"], b["logits"], rtol=0, atol=2e-6)
+        np.testing.assert_allclose(a["rm"], b["rm"], rtol=0, atol=1e-6)
+        for n in a["grads"]:
+            ga, gb = np.asarray(a["grads"][n]), np.asarray(b["grads"][n])
+            np.testing.assert_allclose(ga, gb, rtol=0, atol=2e-5 * max(1.0, np.abs(ga).max()), err_msg=n)
+    # and the sliced run against the oracle
+    x = feats(1, 81, 5)
+    sd = om.res8_init(12)
+    names = om.res8_param_names()
+    params = {n: sd[n].clone().requires_grad_(True) for n in names}
+    sd_ref = dict(sd)
+    sd_ref.update(params)
+    ref_logits = om.res8_forward(sd_ref, x, True)
+    np.testing.assert_allclose(res["8"]["1_81"]["logits"], ref_logits.detach().numpy(), rtol=0, atol=2e-5)
+    gref = torch.autograd.grad(torch.nn.functional.cross_entropy(ref_logits, torch.arange(1) % 12), [params[n] for n in names])
+    for n, g in zip(names, gref):
+        got = np.asarray(res["8"]["1_81"]["grads"][n])
+        want = g.numpy().reshape(-1)[:: max(1, g.numel() // 50)]
+        np.testing.assert_allclose(got, want, rtol=0, atol=2e-5 * max(1.0, float(g.abs().max())), err_msg=n)
