@@ -515,7 +515,7 @@ def main():
             achieved = 2 * flops_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
             full = B == 512 and L == 16000
             traffic, traffic_src = pmc_traffic("bwd_pair_kernel") if full else (None, None)
-            fwd_traffic, _ = pmc_traffic("conv3x3_mfma_kernel<0>") if full else (None, None)
+            fwd_traffic, _ = pmc_traffic("conv3x3_mfma_kernel<0") if full else (None, None)
             act = 4.0 * 45 * (H * 10) * B      # one (B, 45, H, 10) fp32 map
             roof = {"bound": "mfma",
                     "kernel": "bwd_pair_kernel (data gradient + weight gradient of one 45->45 3x3 layer in ONE launch, half of "

@@ -15,7 +15,7 @@ dev = torch.device("cuda:0")
 std = StandardAudioTransform().to(dev).eval()
 fbp = std._standard_fb()
 pair = torch.tensor([0.0, 1.0], device=dev)
-for B in (512, 64, 16, 1):
+for B in [int(v) for v in os.environ.get("FE_BATCHES", "512,64,16,1").split(",")]:
     pcm = synthetic_pcm(B, 16000).to(dev)
     for _ in range(20): ops.logmel(pcm, fbp, 40, pair, layout=1)
     torch.cuda.synchronize()
@@ -39,7 +39,7 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
            "SQ_INSTS_SALU SQ_ACTIVE_INST_SCA SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_ACTIVE_INST_MISC SQ_INST_LEVEL_LDS SQ_INSTS_MFMA SQ_THREAD_CYCLES_VALU" \
            "FETCH_SIZE" "WRITE_SIZE" ; do
   i=$((i+1))
-  timeout 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $R/gpurun_out/fe_prof -o pass$i -- python /tmp/fe_loop.py > $R/gpurun_out/fe_prof/pass$i.log 2>&1
+  FE_BATCHES=512 timeout 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $R/gpurun_out/fe_prof -o pass$i -- python /tmp/fe_loop.py > $R/gpurun_out/fe_prof/pass$i.log 2>&1
   echo "pass $i rc=$? : $set"
 done
 python - <<PY
@@ -49,7 +49,7 @@ for ps in range(1, 6):
     except Exception as e: print("pass", ps, e); continue
     agg = collections.defaultdict(list)
     for r in rows:
-        if "logmel" in r["Kernel_Name"] and r.get("Grid_Size", r.get("Grid_Size_X", "")) in ("262144",):
+        if "logmel" in r["Kernel_Name"] and r.get("Grid_Size", r.get("Grid_Size_X", "")) in ("196608",):
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
     print("pass", ps, json.dumps({k: round(sum(v) / len(v), 1) for k, v in agg.items()}), "n", {k: len(v) for k, v in agg.items()})
 PY
