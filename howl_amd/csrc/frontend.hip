@@ -26,9 +26,10 @@
 //    other matrix through all pairs;
 //  * the 16 blocks are summed by a reduce-scatter (v_permlane32_swap, v_permlane16_swap, two DPP levels) that leaves 2-3
 //    (frame, mel) sums per lane; log(x + eps), optional ZMUV, stores as (B,T,M) [model layout] or (B,M,T).
-// 132 KB of LDS per 12-wave workgroup (9.1 KB transpose tile per wave + 23 KB of tables), 150 VGPRs.
+// 132 KB of LDS per 12-wave workgroup (9.1 KB transpose tile per wave + 23 KB of tables), 126 VGPRs.
 // Algorithmic HBM bytes per utterance: 4*L read + 4*M*T written (76,960 B at L=16000, M=40).
 #include <stdlib.h>
+#include <type_traits>
 
 #include "howl_common.hip.h"
 #include "howl_tables.h"
@@ -215,14 +216,17 @@ __device__ unsigned long long* g_howl_probe_fe = nullptr;
 #define HOWL_FE_PROBE(wave_, lane_, slot_) ((void)0)
 #endif
 
-// Twelve waves per CU (three per SIMD, 168 VGPRs): sixteen were measured too -- they only fit the LDS with a conflicting tile
-// (17 / 272) and cannot keep the next quad's samples in registers across the transform (128 VGPRs): 24.4 us against 23.3 us
-// at 512 x 1 s.
-constexpr int FE_WAVES = 12;
-// Transpose tile of a wave: [frame][n2 row][k1] complex elements with row pitch XR and frame pitch XF.  The compiler pairs the
-// 8-byte accesses (ds_write2_b64: 8-lane groups writing 16 contiguous bytes each; ds_read2_b64: 16-lane groups, 32 banks), so
-// conflict-free means 2 XR = 4 (mod 32) dwords and XF = 4 (mod 16) elements.
-constexpr int XR = 18, XF = 292;
+// Waves per CU and the transpose tile of a wave: [frame][n2 row][k1] complex elements with row pitch XR and frame pitch XF.
+// The compiler pairs the 8-byte accesses (ds_write2_b64: 8-lane groups writing 16 contiguous bytes each; ds_read2_b64: 16-lane
+// groups, 32 banks), so conflict-free means 2 XR = 4 (mod 32) dwords and XF = 4 (mod 16) elements: 18 / 292, which fits twelve
+// waves (three per SIMD); sixteen (four per SIMD, 128 VGPRs) only fit the LDS with 17 / 272 and two- to four-way conflicts on
+// the 16 transpose instructions of a quad.
+template <int NWAVES>
+struct FeGeom {
+    static constexpr int XR = NWAVES > 12 ? 17 : 18;
+    static constexpr int XF = NWAVES > 12 ? 272 : 292;
+};
+constexpr int FE_WAVES = 12;     // measured at 512 x 1 s: 23.9 us with twelve waves, 24.7 us with sixteen (HOWL_LOGMEL_WAVES=16)
 
 // NGRP = 10: filterbanks of up to 40 mel bins (banded fragments when the flag allows); 12: up to 48, all pairs.
 template <int NWAVES, int NGRP>
@@ -230,6 +234,7 @@ __global__ __launch_bounds__(NWAVES * 64) void logmel_kernel(const float* __rest
                                                              int total_frames, const float* __restrict__ fbp, int M,
                                                              float log_eps, const float* __restrict__ zmuv,
                                                              float* __restrict__ out, int layout, int n_quads, int aligned) {
+    constexpr int XR = FeGeom<NWAVES>::XR, XF = FeGeom<NWAVES>::XF;
     __shared__ v2f xch[NWAVES * QUAD * XF];             // FFT transpose tiles, private per wave
     __shared__ v4f c_tab[HOWL_FE_CONST_FLOATS / 4];     // window | W_256 | W_512 rows (read-only after the prologue)
     __shared__ v4f c_frag[NSLOT * 64];                  // banded filterbank fragments
@@ -308,12 +313,12 @@ __global__ __launch_bounds__(NWAVES * 64) void logmel_kernel(const float* __rest
     const int partner = 4 * (4 * ((16 - j) & 15) + i2);    // byte address of the lane holding Z[256 - k] (ds_bpermute)
     const bool class0 = j == 0;
     const bool bit3 = (lane & 8) != 0, bit2 = (lane & 4) != 0;
-    // what this lane owns after the block reduction: frame r_out of the quad, mel groups g_out .. g_out + 2
-    constexpr int NC = NGRP / 2;                           // values per lane entering the last two (DPP) levels
-    constexpr int ND = (NC + 1) / 2;                       // ... and leaving them
+    // the mel groups go through the contraction in two passes of NH; after the block reduction a lane owns frame r_out of the
+    // quad and <= NE groups of the pass
+    constexpr int NH = NGRP / 2;                           // groups per pass
+    constexpr int ND = (NH + 1) / 2;                       // values per lane after the bit-3 level
+    constexpr int NE = (ND + 1) / 2;                       // ... after the bit-2 level
     const int r_out = ((lane >> 5) & 1) * 2 + ((lane >> 4) & 1);
-    const int g_out = (bit3 ? NC : 0) + (bit2 ? ND : 0);
-    const int n_out = bit2 ? NC - ND : ND;
     const int c_out = lane & 3;
     int pslot = 0;
     HOWL_FE_PROBE(wave, lane, pslot++);   // prologue done
@@ -392,50 +397,12 @@ __global__ __launch_bounds__(NWAVES * 64) void logmel_kernel(const float* __rest
             P[8 + r] = yk.x * yk.x + yk.y * yk.y;
         }
         P[16] = 4.0f * (z[8].x * z[8].x + z[8].y * z[8].y);   // bin 128 = Z[128] itself (class 0; the other classes' weight is 0)
-        // ---- mel contraction: D_j[frame][mel] += P[frame][bin(j, s)] * fb[bin(j, s)][mel], blocks j summed afterwards ------
-        f32x4 acc[NGRP];
-#pragma unroll
-        for (int g = 0; g < NGRP; ++g) acc[g] = {0.0f, 0.0f, 0.0f, 0.0f};
-        if (banded) {
-#pragma unroll
-            for (int s = 0; s < NSLOT; ++s) {
-                const v4f f = c_frag[s * 64 + frow];
-                const float fv[4] = {f.x, f.y, f.z, f.w};
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const int g = slot_group(s, c);            // compile-time after unrolling
-                    if (g >= 0 && g < NGRP) acc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(P[s], fv[c], acc[g], 0, 0, 0);
-                }
-            }
-        } else {
-            // the rare path (a matrix the banded table does not cover, or more than 40 mel bins): every (slot, group) pair,
-            // fragments from global memory at a uniform base + lane
-            const unsigned ulane = (unsigned)frow;
-            const float* fdense = fbp + FBD_OFF;
-            HOWL_OPAQUE_S(fdense);
-#pragma unroll
-            for (int s = 0; s < NSLOT; ++s) {
-                const float* fs = fdense + s * (NG_MAX * 64);
-#pragma unroll
-                for (int g = 0; g < NGRP; ++g) acc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(P[s], fs[g * 64 + ulane], acc[g], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);   // keep the 170+ fragment loads from piling up in registers
-            }
-        }
-        HOWL_FE_PROBE(wave, lane, pslot++);   // contracted
-        // ---- sum the 16 blocks: lane 4j + c holds D_j[r][4g + c] in acc[g][r]; value index e = r * NGRP + g ------------------
-        float v2[2 * NGRP];
-#pragma unroll
-        for (int e = 0; e < 2 * NGRP; ++e) v2[e] = fold_bit5(acc[e % NGRP][e / NGRP], acc[e % NGRP][e / NGRP + 2]);
-        float v1[NGRP];
-#pragma unroll
-        for (int g = 0; g < NGRP; ++g) v1[g] = fold_bit4(v2[g], v2[NGRP + g]);
-        float vc[NC];
-#pragma unroll
-        for (int g = 0; g < NC; ++g) vc[g] = fold_bit3(v1[g], v1[NC + g], bit3);
-        float vd[ND];
-#pragma unroll
-        for (int g = 0; g < ND; ++g) vd[g] = fold_bit2(vc[g], ND + g < NC ? vc[ND + g] : 0.0f, bit2);
-        // ---- epilogue: log(x + eps), ZMUV, store -----------------------------------------------------------------------
+        // ---- mel contraction + block sum + epilogue, in two passes over the mel groups (halves the live accumulators: the whole
+        // kernel has to fit the register budget of its wave count) -----------------------------------------------------
+        // D_j[frame][mel] += P[frame][bin(j, s)] * fb[bin(j, s)][mel] on 16 independent 4x4 blocks j; lane 4j + c then holds
+        // D_j[r][4g + c] in acc[g][r] and the 16 blocks are summed by a reduce-scatter over the lane bits of j:
+        // v_permlane32_swap (bit 5: frames 0,1 | 2,3), v_permlane16_swap (bit 4: even | odd frame), two DPP levels (bits 3, 2:
+        // which groups), leaving <= NE (frame, group) sums per lane.
         const int g_frame = g0 + r_out;
         long o_base, o_ms;
         if (layout == 1) {
@@ -448,15 +415,68 @@ __global__ __launch_bounds__(NWAVES * 64) void logmel_kernel(const float* __rest
             o_base = (long)b * M * T + t;
             o_ms = T;
         }
+        auto mel_pass = [&](auto g0c) {
+            constexpr int G0 = decltype(g0c)::value;
+            f32x4 acc[NH];
 #pragma unroll
-        for (int h = 0; h < ND; ++h) {
-            const int m = 4 * (g_out + h) + c_out;
-            if (h < n_out && m < M && g_frame < total_frames) {
-                float y = __builtin_amdgcn_logf(vd[h] + log_eps) * 0.69314718055994530942f;
-                y = (y - zm_mean) * zm_rstd;
-                out[o_base + (long)m * o_ms] = y;
+            for (int g = 0; g < NH; ++g) acc[g] = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (banded) {
+#pragma unroll
+                for (int s = 0; s < NSLOT; ++s) {
+                    constexpr int lo = G0, hi = G0 + NH;
+                    const bool any = (slot_group(s, 0) >= lo && slot_group(s, 0) < hi) || (slot_group(s, 1) >= lo && slot_group(s, 1) < hi) ||
+                                     (slot_group(s, 2) >= lo && slot_group(s, 2) < hi) || (slot_group(s, 3) >= lo && slot_group(s, 3) < hi);
+                    if (!any) continue;                            // compile-time after unrolling
+                    const v4f f = c_frag[s * 64 + frow];
+                    const float fv[4] = {f.x, f.y, f.z, f.w};
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const int g = slot_group(s, c);
+                        if (g >= lo && g < hi) acc[g - lo] = __builtin_amdgcn_mfma_f32_4x4x1f32(P[s], fv[c], acc[g - lo], 0, 0, 0);
+                    }
+                }
+            } else {
+                // the rare path (a matrix the banded table does not cover, or more than 40 mel bins): every (slot, group) pair,
+                // fragments from global memory at a uniform base + lane
+                const unsigned ulane = (unsigned)frow;
+                const float* fdense = fbp + FBD_OFF;
+                HOWL_OPAQUE_S(fdense);
+#pragma unroll
+                for (int s = 0; s < NSLOT; ++s) {
+                    const float* fs = fdense + s * (NG_MAX * 64);
+#pragma unroll
+                    for (int g = 0; g < NH; ++g)
+                        acc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(P[s], fs[(G0 + g) * 64 + ulane], acc[g], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);   // keep the fragment loads from piling up in registers
+                }
             }
-        }
+            float v2[2 * NH];
+#pragma unroll
+            for (int e = 0; e < 2 * NH; ++e) v2[e] = fold_bit5(acc[e % NH][e / NH], acc[e % NH][e / NH + 2]);
+            float v1[NH];
+#pragma unroll
+            for (int g = 0; g < NH; ++g) v1[g] = fold_bit4(v2[g], v2[NH + g]);
+            float vc[ND];
+#pragma unroll
+            for (int g = 0; g < ND; ++g) vc[g] = fold_bit3(v1[g], ND + g < NH ? v1[ND + g] : 0.0f, bit3);
+            float vd[NE];
+#pragma unroll
+            for (int g = 0; g < NE; ++g) vd[g] = fold_bit2(vc[g], NE + g < ND ? vc[NE + g] : 0.0f, bit2);
+            // log(x + eps), ZMUV, store: this lane's groups of the pass
+#pragma unroll
+            for (int h = 0; h < NE; ++h) {
+                const int w = (bit2 ? NE : 0) + h, u = (bit3 ? ND : 0) + w;      // position at the two DPP levels
+                const int m = 4 * (G0 + u) + c_out;
+                if (w < ND && u < NH && m < M && g_frame < total_frames) {
+                    float y = __builtin_amdgcn_logf(vd[h] + log_eps) * 0.69314718055994530942f;
+                    y = (y - zm_mean) * zm_rstd;
+                    out[o_base + (long)m * o_ms] = y;
+                }
+            }
+        };
+        mel_pass(std::integral_constant<int, 0>{});
+        HOWL_FE_PROBE(wave, lane, pslot++);   // contracted (first half)
+        mel_pass(std::integral_constant<int, NH>{});
         HOWL_FE_PROBE(wave, lane, pslot++);   // stored
         if (has_next) apply_window(xn);
         b0 = bn;
@@ -835,14 +855,19 @@ int howl_logmel_fwd(const float* pcm, int B, int L, long ld, const float* fbp, i
     if (grid > n_quads) grid = n_quads;
     // 8-byte sample loads need even row strides and an 8-byte aligned base; anything else takes the per-sample path
     const int aligned = ((ld & 1) == 0 && (reinterpret_cast<uintptr_t>(pcm) & 7) == 0) ? 1 : 0;
+    int waves = FE_WAVES;
+    if (const char* e = getenv("HOWL_LOGMEL_WAVES")) waves = atoi(e) == 12 ? 12 : 16;   // occupancy experiments
     {
         HowlProfScope prof("logmel", stream);
-        if (M <= 4 * NG_BANDED)
-            hipLaunchKernelGGL((logmel_kernel<FE_WAVES, NG_BANDED>), dim3((unsigned)grid), dim3(FE_WAVES * 64), 0, stream, pcm, L, ld, T,
-                               total, fbp, M, log_eps, zmuv, out, layout, n_quads, aligned);
+        if (M > 4 * NG_BANDED)
+            hipLaunchKernelGGL((logmel_kernel<12, NG_MAX>), dim3((unsigned)grid), dim3(12 * 64), 0, stream, pcm, L, ld, T, total, fbp, M,
+                               log_eps, zmuv, out, layout, n_quads, aligned);
+        else if (waves == 16)
+            hipLaunchKernelGGL((logmel_kernel<16, NG_BANDED>), dim3((unsigned)grid), dim3(16 * 64), 0, stream, pcm, L, ld, T, total, fbp,
+                               M, log_eps, zmuv, out, layout, n_quads, aligned);
         else
-            hipLaunchKernelGGL((logmel_kernel<FE_WAVES, NG_MAX>), dim3((unsigned)grid), dim3(FE_WAVES * 64), 0, stream, pcm, L, ld, T,
-                               total, fbp, M, log_eps, zmuv, out, layout, n_quads, aligned);
+            hipLaunchKernelGGL((logmel_kernel<12, NG_BANDED>), dim3((unsigned)grid), dim3(12 * 64), 0, stream, pcm, L, ld, T, total, fbp,
+                               M, log_eps, zmuv, out, layout, n_quads, aligned);
     }
     HOWL_CHECK_LAUNCH("howl_logmel_fwd");
     return HOWL_OK;

@@ -30,7 +30,7 @@ def bench(B, L=16000, n=30):
     return e0.elapsed_time(e1) / n * 1e3
 mode = sys.argv[1]
 if mode == "time":
-    print("logmel:",
+    print("logmel waves=%%s:" %% os.environ.get("HOWL_LOGMEL_WAVES"),
           " ".join("B=%%d %%.1f us" %% (B, bench(B)) for B in (8, 64, 128, 256, 512, 1024, 2048)), flush=True)
 else:
     B = int(sys.argv[2])
@@ -66,8 +66,8 @@ def main():
         objs.append(str(o))
     so = out / "libhowl_probe.so"
     subprocess.run(["hipcc", "--offload-arch=gfx950", "-fPIC", "-shared", *objs, "-o", str(so)], check=True)
-    for waves in ("12",):
-        env = dict(os.environ)
+    for waves in ("12", "16"):
+        env = dict(os.environ, HOWL_LOGMEL_WAVES=waves)
         r = subprocess.run([sys.executable, "-c", CHILD, "time"], env=env, capture_output=True, text=True, timeout=300)
         print(r.stdout.strip() or r.stderr[-1500:], flush=True)
     env = dict(os.environ, HOWL_HIP_LIBRARY=str(so))
