@@ -257,6 +257,11 @@ __global__ __launch_bounds__(NWAVES * 64) void logmel_kernel(const float* __rest
     // reflect padding (torch.stft(center=True)).  Quads whose four frames lie inside one utterance and need no padding are
     // sixteen 8-byte loads at immediate offsets from one base; the others pay per-sample index arithmetic.
     auto fetch = [&](int qq, int bq, int tq, v2f (&x)[16]) {
+#if defined(HOWL_DIAG_LOGMEL_NOLOAD)   // diagnostic build (tools/logmel_variants.py): no global loads
+#pragma unroll
+        for (int n1 = 0; n1 < 16; ++n1) x[n1] = v2f{(float)(lane + n1 + qq) * 1e-3f, (float)(lane - n1) * 1e-3f};
+        return;
+#endif
         const int g0 = QUAD * qq;
         const bool fast = aligned != 0 && tq + 3 < T && HOP * tq >= N_FFT / 2 && HOP * (tq + 3) + N_FFT / 2 <= L && g0 + 3 < total_frames;
         if (fast) {
@@ -354,6 +359,11 @@ __global__ __launch_bounds__(NWAVES * 64) void logmel_kernel(const float* __rest
         if (tn >= T) { tn -= T; ++bn; }
         v2f xn[16];
         if (has_next) fetch(qn, bn, tn, xn);
+        float P[NSLOT];
+#if defined(HOWL_DIAG_LOGMEL_NOFFT)   // diagnostic build: the transform and the recombination replaced by a copy
+#pragma unroll
+        for (int sl = 0; sl < NSLOT; ++sl) P[sl] = z[sl & 15].x * z[sl & 15].y;
+#else
         // ---- FFT step 1: DFT-16 over n1 of the windowed samples, twiddle, transpose through LDS ------------------------
         dft16(z);
 #pragma unroll
@@ -372,7 +382,6 @@ __global__ __launch_bounds__(NWAVES * 64) void logmel_kernel(const float* __rest
         dft16(z);
         HOWL_FE_PROBE(wave, lane, pslot++);   // transformed
         // ---- real-input recombination: X[k] = E + W O, X[256 - k] = conj(E - W O); powers of both ----------------------
-        float P[NSLOT];
         v2f zn[8];
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
@@ -397,6 +406,7 @@ __global__ __launch_bounds__(NWAVES * 64) void logmel_kernel(const float* __rest
             P[8 + r] = yk.x * yk.x + yk.y * yk.y;
         }
         P[16] = 4.0f * (z[8].x * z[8].x + z[8].y * z[8].y);   // bin 128 = Z[128] itself (class 0; the other classes' weight is 0)
+#endif
         // ---- mel contraction + block sum + epilogue, in two passes over the mel groups (halves the live accumulators: the whole
         // kernel has to fit the register budget of its wave count) -----------------------------------------------------
         // D_j[frame][mel] += P[frame][bin(j, s)] * fb[bin(j, s)][mel] on 16 independent 4x4 blocks j; lane 4j + c then holds
@@ -474,9 +484,18 @@ __global__ __launch_bounds__(NWAVES * 64) void logmel_kernel(const float* __rest
                 }
             }
         };
+#if defined(HOWL_DIAG_LOGMEL_NOMEL)   // diagnostic build: no contraction / block sum / epilogue, one store keeps the powers alive
+        {
+            float acc0 = 0.0f;
+#pragma unroll
+            for (int sl = 0; sl < NSLOT; ++sl) acc0 += P[sl];
+            if (g_frame < total_frames && c_out == 0 && (lane >> 2) < 10) out[o_base + (long)(4 * (lane >> 2)) * o_ms] = acc0;
+        }
+#else
         mel_pass(std::integral_constant<int, 0>{});
         HOWL_FE_PROBE(wave, lane, pslot++);   // contracted (first half)
         mel_pass(std::integral_constant<int, NH>{});
+#endif
         HOWL_FE_PROBE(wave, lane, pslot++);   // stored
         if (has_next) apply_window(xn);
         b0 = bn;
