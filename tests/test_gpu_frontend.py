@@ -126,9 +126,9 @@ def test_full_size_properties(std):
     idx = [0, 1, 63, 200, 511]
     logmel_close(out[idx], ofe.standard_audio_transform(pcm[idx], ofe.mel_fb(40), mels_only=True))
     alone = std(pcm[200:201].to(DEV), mels_only=True)
-    # two frames share one complex FFT, and which neighbour a frame is paired with depends on its flattened index,
-    # so batch composition changes results at rounding level only
-    assert maxerr(alone[0], out[200]) < 2e-5
+    # every frame is transformed by its own 16 lanes (real-input FFT-256, no pairing with a neighbour): a clip's features do
+    # not depend on what else is in the batch, not even in the last bit
+    assert torch.equal(alone[0], out[200])
     from howl_amd import ops
     tm = ops.logmel(pcm.to(DEV), std._standard_fb(), 40, None, layout=1)
     assert torch.equal(tm.permute(0, 2, 1), out)               # the two layouts are the same numbers
@@ -173,3 +173,30 @@ def test_device_collate_with_dataset_mixer(golden):
             assert not batch.audio_data[row, wf_lens[k]:].any()
         seen_mix |= any(a != 0 for a in dc.last_mix[2])
     assert seen_mix
+
+
+@pytest.mark.parametrize("L", [257, 399, 600, 1000, 3001])
+def test_short_and_odd_lengths_vs_oracle(std, L):
+    """Clips of two to sixteen frames, lengths that are not multiples of the hop, every frame an edge frame (reflect padding on
+    both sides at once for L < 512), frame counts that are not multiples of the 4 frames a wave works on."""
+    gen = torch.Generator().manual_seed(L)
+    pcm = (torch.rand(5, L, generator=gen) * 2 - 1) * 0.5
+    out = std(pcm.to(DEV), mels_only=True)
+    assert out.shape == (5, 40, 1 + L // 200)
+    logmel_close(out, ofe.standard_audio_transform(pcm, ofe.mel_fb(40), mels_only=True))
+
+
+@pytest.mark.parametrize("stride", [1008, 1009, 200, 7])
+def test_overlapping_strided_rows(std, stride):
+    """The frame engine hands the kernel all windows of a clip as ONE strided view (rows overlap, row stride = the evaluation
+    stride in samples).  Even strides take the 8-byte sample loads, odd ones the per-sample path: both must give exactly what
+    the same windows give as a contiguous batch."""
+    from howl_amd import ops
+    from howl_amd.utils.synth import synthetic_pcm
+    clip = synthetic_pcm(1, 40000, seed=5)[0].to(DEV)
+    n, L = 12, 8000
+    windows = clip.as_strided((n, L), (stride, 1))
+    got = ops.logmel(windows, std._standard_fb(), 40, None, layout=0)
+    want = ops.logmel(windows.contiguous(), std._standard_fb(), 40, None, layout=0)
+    assert torch.equal(got, want)
+    logmel_close(got, ofe.standard_audio_transform(windows.cpu().contiguous(), ofe.mel_fb(40), mels_only=True))
