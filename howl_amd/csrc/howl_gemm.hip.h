@@ -290,8 +290,9 @@ struct SlabJob {
     float* out2;     // optional second destination (the LSTM's two bias vectors share one gradient)
     long n;
     int nparts;
+    long stride;     // distance between slabs in floats (= n when the slabs are packed)
 };
-constexpr int MAX_SLAB_JOBS = 6;
+constexpr int MAX_SLAB_JOBS = 8;
 struct SlabJobs {
     SlabJob j[MAX_SLAB_JOBS];
 };
@@ -306,9 +307,9 @@ __global__ __launch_bounds__(256) void sum_slabs_multi_kernel(SlabJobs jobs) {
         int g = rg;
         for (; g + 12 < jb.nparts; g += 16) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) s[u] += jb.part[(long)(g + 4 * u) * jb.n + i];
+            for (int u = 0; u < 4; ++u) s[u] += jb.part[(long)(g + 4 * u) * jb.stride + i];
         }
-        for (; g < jb.nparts; g += 4) s[0] += jb.part[(long)g * jb.n + i];
+        for (; g < jb.nparts; g += 4) s[0] += jb.part[(long)g * jb.stride + i];
     }
     red[rg][lane] = (s[0] + s[1]) + (s[2] + s[3]);
     __syncthreads();
@@ -325,12 +326,14 @@ struct SlabSums {
     int count = 0;
     long max_n = 0;
     bool overflow = false;     // a caller queued more than MAX_SLAB_JOBS folds without a flush: reported by flush()
-    void add(const float* part, int nparts, long n, float* out, float* out2 = nullptr) {
+    void add(const float* part, int nparts, long n, float* out, float* out2 = nullptr) { add_strided(part, nparts, n, n, out, out2); }
+    // slabs that sit `stride` floats apart (several partial results interleaved per producer block)
+    void add_strided(const float* part, int nparts, long stride, long n, float* out, float* out2 = nullptr) {
         if (count >= MAX_SLAB_JOBS) {           // never write past the kernel-argument array
             overflow = true;
             return;
         }
-        jobs.j[count++] = SlabJob{part, out, out2, n, nparts};
+        jobs.j[count++] = SlabJob{part, out, out2, n, nparts, stride};
         max_n = n > max_n ? n : max_n;
     }
     // returns false (and sets the library's error string) when a fold was dropped by add(): the caller fails its call
@@ -374,11 +377,6 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
     __syncthreads();
     if (rg == 0 && col < n)
         part[(size_t)blockIdx.y * n + col] = (float)(((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane]);
-}
-
-__global__ void add2_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ o, int n) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) o[i] = a[i] + b[i];
 }
 
 // dz = dy * (y > 0), elementwise (ReLU backward of the head's hidden layer)

@@ -2,8 +2,8 @@
 //
 // Replaces, for howl/model/rnn.py:41-91 (SequentialLstm "seq-lstm", SimpleLstm "lstm"):
 //   pack_padded_sequence + nn.LSTM (rnn.py:65-66,88) .......... howl_lstm_fwd / howl_lstm_bwd
-//   nn.Linear(128,256) - ReLU - nn.Linear(256,C) (rnn.py:44-48,71,91) ... howl_linear_fwd / howl_linear_bwd
-// (log_softmax + CTCLoss stay ATen ops on the device; north_star does not name them.)
+//   nn.Linear(128,256) - ReLU - nn.Linear(256,C) (rnn.py:44-48,71,91) ... howl_head_fwd / howl_head_bwd
+// (log_softmax + CTCLoss: howl_ctc_loss, ctc.hip)
 //
 // Internal layout is batch-major: x (B,T,40) [what the fused frontend writes], gate pre-activations / activations
 // (B,T,512), cell c (B,T,128), hidden hseq (B,T+1,128) with hseq[b][0] = h0 and hseq[b][t+1] = h_t, so that both
@@ -47,10 +47,13 @@ __device__ __forceinline__ float tanhf_(float x) {
 //             B[k][n] = W_hh[256kh + 4kk + k][16nt + n]      (dh = dG . W_hh)
 // packed as [wave][frag 0..63][lane]
 // ---------------------------------------------------------------------------------------------------------
+// The same launch folds the two bias vectors of the input projection (bsum = b_ih + b_hh).
 __global__ void lstm_pack_kernel(const float* __restrict__ whh, float* __restrict__ pf, float* __restrict__ pb,
-                                 float* __restrict__ pf4, float* __restrict__ pb4) {
+                                 float* __restrict__ pf4, float* __restrict__ pb4, const float* __restrict__ b_ih,
+                                 const float* __restrict__ b_hh, float* __restrict__ bsum) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= 16 * 64 * 64) return;
+    if (idx < G4) bsum[idx] = b_ih[idx] + b_hh[idx];
     const int lane = idx & 63, frag = (idx >> 6) & 63, w = idx >> 12;
     const int k = lane >> 4, n = lane & 15;
     if (pf4 != nullptr) {
@@ -65,15 +68,34 @@ __global__ void lstm_pack_kernel(const float* __restrict__ whh, float* __restric
         const int ch = w & 1, kr = w >> 1;
         pb4[idx] = whh[(64 * kr + frag) * HID + 64 * ch + lane];
     }
-    {
+    if (pf != nullptr) {
         const int a = frag >> 5, kk = frag & 31;
         const int col = (2 * a + (n >> 3)) * HID + 8 * w + (n & 7);
         pf[idx] = whh[col * HID + 4 * kk + k];
     }
-    {
+    if (pb != nullptr) {
         const int nt = w & 7, kh = w >> 3;
         pb[idx] = whh[(256 * kh + 4 * frag + k) * HID + 16 * nt + n];
     }
+}
+
+// The A operand of the four-sequence recurrences is the same for all sixteen blocks of v_mfma_f32_4x4x1_16b_f32 (the four
+// sequences' h or dG values of one k).  With cbsz = 4 the instruction takes A from the lanes of ONE block (abid) for all
+// sixteen, so a lane (block J, row i) loads only the four k values 4J..4J+3 of its row -- one 16-byte LDS read per wave and
+// step instead of sixteen (which was as much LDS-pipe time per step, 256 x 1 KB, as the step's matrix work) -- and the
+// sixty-four instructions walk abid over the blocks.  acc[e] is the chain of k = e mod 4.
+template <int J>
+__device__ __forceinline__ void bcast_mfma64(const float4& a, const float (&w)[64], f32x4 (&acc)[4]) {
+    acc[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(a.x, w[4 * J + 0], acc[0], 4, J, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(a.y, w[4 * J + 1], acc[1], 4, J, 0);
+    acc[2] = __builtin_amdgcn_mfma_f32_4x4x1f32(a.z, w[4 * J + 2], acc[2], 4, J, 0);
+    acc[3] = __builtin_amdgcn_mfma_f32_4x4x1f32(a.w, w[4 * J + 3], acc[3], 4, J, 0);
+    if constexpr (J + 1 < 16) bcast_mfma64<J + 1>(a, w, acc);
+}
+// value of lane 4 * (lane / 4) + K of the same quad (v_mov_b32_dpp quad_perm: no LDS crossbar trip)
+template <int K>
+__device__ __forceinline__ float quad_bcast(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), K * 0x55, 0xf, 0xf, true));
 }
 
 // Forward recurrence with FOUR sequences per workgroup on v_mfma_f32_4x4x1_16b_f32 (16 independent 4x4 outer products
@@ -96,7 +118,7 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd4_kernel(const float* __
     __shared__ __attribute__((aligned(16))) float hbuf[2][4 * F4_HS];
     __shared__ float part[2][4 * F4_PS];
     __shared__ __attribute__((aligned(16))) float sbuf[2][4 * F4_SROW];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c = wave & 7, kh = wave >> 3;
     const int j = lane >> 2, g = lane & 3;
     const int u = 16 * c + j;                       // hidden unit of this lane's quad
@@ -168,38 +190,32 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd4_kernel(const float* __
         f32x4 acc[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[e] = {0.0f, 0.0f, 0.0f, 0.0f};
-        const float* arow = hcur + g * F4_HS + 64 * kh;     // A_j[i] comes from lane 4j+i: row i = lane & 3 = g
-#pragma unroll
-        for (int q4 = 0; q4 < 16; ++q4) {
-            const float4 a = *reinterpret_cast<const float4*>(arow + 4 * q4);
-            acc[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(a.x, wB[4 * q4 + 0], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(a.y, wB[4 * q4 + 1], acc[1], 0, 0, 0);
-            acc[2] = __builtin_amdgcn_mfma_f32_4x4x1f32(a.z, wB[4 * q4 + 2], acc[2], 0, 0, 0);
-            acc[3] = __builtin_amdgcn_mfma_f32_4x4x1f32(a.w, wB[4 * q4 + 3], acc[3], 0, 0, 0);
-        }
+        // A_j[i] comes from lane 4j+i: row i = lane & 3 = g; this lane's four k values are 64 kh + 4j .. 4j+3
+        bcast_mfma64<0>(*reinterpret_cast<const float4*>(hcur + g * F4_HS + 64 * kh + 4 * j), wB, acc);
         f32x4 sum;
 #pragma unroll
         for (int r = 0; r < 4; ++r) sum[r] = (acc[0][r] + acc[1][r]) + (acc[2][r] + acc[3][r]);
         // hand the partner's two sequences over, keep mine
+        const float give0 = kh ? sum[0] : sum[2], give1 = kh ? sum[1] : sum[3];
+        const float keep[2] = {kh ? sum[2] : sum[0], kh ? sum[3] : sum[1]};
         float* pmine = part[kh];
         const int so = 2 * (1 - kh);
-        pmine[(so + 0) * F4_PS + 64 * c + lane] = sum[so + 0];
-        pmine[(so + 1) * F4_PS + 64 * c + lane] = sum[so + 1];
+        pmine[(so + 0) * F4_PS + 64 * c + lane] = give0;
+        pmine[(so + 1) * F4_PS + 64 * c + lane] = give1;
         __syncthreads();
         const float* pother = part[1 - kh];
         float act[2];
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            const float pre = (kh == 0 ? sum[s0 + q] + pother[(s0 + q) * F4_PS + 64 * c + lane]
-                                       : pother[(s0 + q) * F4_PS + 64 * c + lane] + sum[s0 + q]) + gxv[q];
+            const float po = pother[(s0 + q) * F4_PS + 64 * c + lane];
+            const float pre = (keep[q] + po) + gxv[q];     // the two K halves, then the input projection
             const float sg = sigmoidf_(kscale * pre);
             act[q] = g == 2 ? 2.0f * sg - 1.0f : sg;
         }
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            const int qb = lane & ~3;
-            const float ig = __shfl(act[q], qb + 0), fg = __shfl(act[q], qb + 1);
-            const float gg = __shfl(act[q], qb + 2), og = __shfl(act[q], qb + 3);
+            const float ig = quad_bcast<0>(act[q]), fg = quad_bcast<1>(act[q]);
+            const float gg = quad_bcast<2>(act[q]), og = quad_bcast<3>(act[q]);
             const bool live = t < len[q];
             const float cn = fg * cst[q] + ig * gg;
             const float hn = og * tanhf_(cn);
@@ -503,8 +519,8 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_bwd4_kernel(const float* __
                                                                  const float* __restrict__ dcT, const float* __restrict__ pb4,
                                                                  const long long* __restrict__ lengths,
                                                                  const float* __restrict__ gates, const float* __restrict__ cs,
-                                                                 const float* __restrict__ c0, float* __restrict__ dG, int B,
-                                                                 int T, int Tout) {
+                                                                 const float* __restrict__ c0, float* __restrict__ dG,
+                                                                 float* __restrict__ bpart, int B, int T, int Tout) {
     __shared__ __attribute__((aligned(16))) float dgt[4 * B4_DGS];   // this step's dG rows (MFMA A operand)
     __shared__ float partd[8][4 * B4_PS];                             // the eight K ranges of dh_{t-1}
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -521,6 +537,7 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_bwd4_kernel(const float* __
     const int len = vb ? (lengths != nullptr ? (int)lengths[b] : T) : 0;
     float dc = (vb && dcT != nullptr) ? dcT[(size_t)b * HID + u] : 0.0f;     // running dL/dc_t
     float dhp = (vb && dhT != nullptr) ? dhT[(size_t)b * HID + u] : 0.0f;    // pass-through part of dL/dh_t
+    float bs_i = 0.0f, bs_f = 0.0f, bs_g = 0.0f, bs_o = 0.0f;               // this cell's dG summed over the steps (bias gradient)
     for (int i = tid; i < 8 * 4 * B4_PS; i += LSTM_THREADS) (&partd[0][0])[i] = 0.0f;
     struct Step {
         float ig, fg, gg, og, cn, cp, dyv;
@@ -573,6 +590,10 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_bwd4_kernel(const float* __
             dr[HID] = df;
             dr[2 * HID] = dg;
             dr[3 * HID] = dov;
+            bs_i += di;
+            bs_f += df;
+            bs_g += dg;
+            bs_o += dov;
             if (vb) {
                 float* go = dG + ((size_t)b * T + t) * G4 + u;
                 go[0] = di;
@@ -586,22 +607,203 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_bwd4_kernel(const float* __
         f32x4 acc[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[e] = {0.0f, 0.0f, 0.0f, 0.0f};
-        const float* arow = dgt + (lane & 3) * B4_DGS + 64 * kr;   // A_j[i] comes from lane 4j+i
-#pragma unroll
-        for (int q4 = 0; q4 < 16; ++q4) {
-            const float4 a = *reinterpret_cast<const float4*>(arow + 4 * q4);
-            acc[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(a.x, wk[4 * q4 + 0], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(a.y, wk[4 * q4 + 1], acc[1], 0, 0, 0);
-            acc[2] = __builtin_amdgcn_mfma_f32_4x4x1f32(a.z, wk[4 * q4 + 2], acc[2], 0, 0, 0);
-            acc[3] = __builtin_amdgcn_mfma_f32_4x4x1f32(a.w, wk[4 * q4 + 3], acc[3], 0, 0, 0);
-        }
+        // A_j[i] comes from lane 4j+i: this lane's four k values are gate columns 64 kr + 4j .. 4j+3 of sequence lane & 3
+        bcast_mfma64<0>(*reinterpret_cast<const float4*>(dgt + (lane & 3) * B4_DGS + 64 * kr + 4 * (lane >> 2)), wk, acc);
 #pragma unroll
         for (int r = 0; r < 4; ++r)
             partd[kr][r * B4_PS + 64 * ch + lane] = (acc[0][r] + acc[1][r]) + (acc[2][r] + acc[3][r]);
         cur = nxt;
         __syncthreads();
     }
+    // bias gradient: column sums of dG over (sequence, step) -- the step sums are in registers, the four sequences meet in
+    // the dG tile; bpart[workgroup][512] is folded with the weight gradients' split-K slabs (no pass over dG in HBM)
+    if (cell) {
+        float* dr = dgt + s * B4_DGS + u;
+        dr[0] = bs_i;
+        dr[HID] = bs_f;
+        dr[2 * HID] = bs_g;
+        dr[3 * HID] = bs_o;
+    }
+    __syncthreads();
+    if (tid < G4)
+        bpart[(size_t)blockIdx.x * G4 + tid] = ((dgt[tid] + dgt[B4_DGS + tid]) + dgt[2 * B4_DGS + tid]) + dgt[3 * B4_DGS + tid];
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// The classifier head of both LSTM models: Linear(n_in, n_hid) - ReLU - Linear(n_hid, n_out)  (rnn.py:44-48).
+// With the handful of labels these models have (n_out <= 8) the second layer is HBM-bound vector work on the hidden
+// activations y1 (rows x n_hid), not a matrix-core problem: a 64-wide MFMA tile would multiply 59 columns of padding.
+//   forward : head_out_kernel    y2 = y1 W2^T + b2, sixteen lanes per row
+//   backward: head_thin_bwd_kernel, ONE pass over y1 that produces everything of the second layer and the ReLU:
+//             dz1 = (y1 > 0) * (dy2 W2)  [stored, feeds the two first-layer GEMMs],  dW2 = dy2^T y1,  db2 = colsum dy2,
+//             db1 = colsum dz1  -- per-workgroup partials, folded with the first layer's split-K slabs in one launch.
+// (replaces gemm + thin_wgrad + colsum + relu_bwd + colsum: 5 launches and three more passes over rows x n_hid)
+// ---------------------------------------------------------------------------------------------------------
+constexpr int HEAD_MAX_HID = 256;      // the vector kernels keep a 16-float (forward) / 8-float (backward) strip per lane
+constexpr int HEAD_BWD_BLOCKS = 512;   // row chunks of the backward pass = slabs of its partial sums
+
+// sum over the 16 lanes of a DPP row, result in every lane
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true));    // quad_perm [1,0,3,2]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, true));    // quad_perm [2,3,0,1]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, true));   // row_half_mirror
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xf, 0xf, true));   // row_mirror
+    return v;
+}
+
+// lane = (row slot rs = lane >> 4, strip c = lane & 15): columns 4 (c + 16 i) .. +3, i = 0..3 (coalesced 256-byte runs)
+template <int NO>
+__global__ __launch_bounds__(256) void head_out_kernel(const float* __restrict__ y1, int rows, int n_hid,
+                                                       const float* __restrict__ w2, const float* __restrict__ b2,
+                                                       float* __restrict__ y2) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int rs = lane >> 4, c = lane & 15;
+    float4 w[NO][4];
+    bool okc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        okc[i] = 4 * (c + 16 * i) < n_hid;
+#pragma unroll
+        for (int n = 0; n < NO; ++n)
+            w[n][i] = okc[i] ? *reinterpret_cast<const float4*>(w2 + (size_t)n * n_hid + 4 * (c + 16 * i)) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const float bias = c < NO ? b2[c] : 0.0f;
+    const int stride = gridDim.x * 16;
+    for (int r0 = (blockIdx.x * 4 + wave) * 4; r0 < rows; r0 += stride) {
+        const int r = r0 + rs;
+        const bool okr = r < rows;
+        const float* src = y1 + (size_t)(okr ? r : rows - 1) * n_hid;
+        float4 v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = okc[i] ? *reinterpret_cast<const float4*>(src + 4 * (c + 16 * i)) : make_float4(0.f, 0.f, 0.f, 0.f);
+        float out = 0.0f;
+#pragma unroll
+        for (int n = 0; n < NO; ++n) {
+            float sn = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                sn += (v[i].x * w[n][i].x + v[i].y * w[n][i].y) + (v[i].z * w[n][i].z + v[i].w * w[n][i].w);
+            sn = row16_sum(sn);
+            out = c == n ? sn : out;
+        }
+        if (okr && c < NO) y2[(size_t)r * NO + c] = out + bias;
+    }
+}
+
+// lane = (row slot rs = lane >> 5, strip c = lane & 31): columns 4 (c + 32 i) .. +3, i = 0, 1; a workgroup walks its row
+// chunk eight rows at a time.  part: [block][NO * n_hid (dW2) | n_hid (db1) | NO (db2)]
+template <int NO>
+__global__ __launch_bounds__(256) void head_thin_bwd_kernel(const float* __restrict__ y1, const float* __restrict__ dy2,
+                                                            int rows, int n_hid, int rows_per_block,
+                                                            const float* __restrict__ w2, float* __restrict__ dz1,
+                                                            float* __restrict__ part) {
+    __shared__ float red[4][NO * 8 + 8 + NO][32];      // [wave][value][strip]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int rs = lane >> 5, c = lane & 31;
+    float4 w[NO][2], aw[NO][2], ab[2];
+    float ad[NO];
+    bool okc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        okc[i] = 4 * (c + 32 * i) < n_hid;
+        ab[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int n = 0; n < NO; ++n) {
+            w[n][i] = okc[i] ? *reinterpret_cast<const float4*>(w2 + (size_t)n * n_hid + 4 * (c + 32 * i)) : make_float4(0.f, 0.f, 0.f, 0.f);
+            aw[n][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < NO; ++n) ad[n] = 0.0f;
+    const int rbeg = blockIdx.x * rows_per_block, rend = min(rows, rbeg + rows_per_block);
+    for (int r0 = rbeg + 2 * wave; r0 < rend; r0 += 8) {
+        const int r = r0 + rs;
+        const bool okr = r < rend;
+        const size_t rc = (size_t)(okr ? r : rend - 1);
+        float d[NO];
+#pragma unroll
+        for (int n = 0; n < NO; ++n) {
+            const float t = dy2[rc * NO + n];
+            d[n] = okr ? t : 0.0f;
+            ad[n] += d[n];
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (!okc[i]) continue;
+            const float4 v = *reinterpret_cast<const float4*>(y1 + rc * n_hid + 4 * (c + 32 * i));
+            float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int n = 0; n < NO; ++n) {
+                z.x = fmaf(d[n], w[n][i].x, z.x);
+                z.y = fmaf(d[n], w[n][i].y, z.y);
+                z.z = fmaf(d[n], w[n][i].z, z.z);
+                z.w = fmaf(d[n], w[n][i].w, z.w);
+                aw[n][i].x = fmaf(d[n], v.x, aw[n][i].x);
+                aw[n][i].y = fmaf(d[n], v.y, aw[n][i].y);
+                aw[n][i].z = fmaf(d[n], v.z, aw[n][i].z);
+                aw[n][i].w = fmaf(d[n], v.w, aw[n][i].w);
+            }
+            z.x = v.x > 0.0f ? z.x : 0.0f;
+            z.y = v.y > 0.0f ? z.y : 0.0f;
+            z.z = v.z > 0.0f ? z.z : 0.0f;
+            z.w = v.w > 0.0f ? z.w : 0.0f;
+            ab[i].x += z.x;
+            ab[i].y += z.y;
+            ab[i].z += z.z;
+            ab[i].w += z.w;
+            if (okr) *reinterpret_cast<float4*>(dz1 + rc * n_hid + 4 * (c + 32 * i)) = z;
+        }
+    }
+    // fold the eight row slots of the workgroup in a fixed order: the two of a wave in registers, the four waves through LDS
+    auto pair = [&](float v) { return v + __shfl_xor(v, 32); };
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int n = 0; n < NO; ++n) {
+            const float4 t = aw[n][i];
+            const float a0 = pair(t.x), a1 = pair(t.y), a2 = pair(t.z), a3 = pair(t.w);
+            if (rs == 0) {
+                red[wave][(n * 2 + i) * 4 + 0][c] = a0;
+                red[wave][(n * 2 + i) * 4 + 1][c] = a1;
+                red[wave][(n * 2 + i) * 4 + 2][c] = a2;
+                red[wave][(n * 2 + i) * 4 + 3][c] = a3;
+            }
+        }
+        const float b0 = pair(ab[i].x), b1 = pair(ab[i].y), b2 = pair(ab[i].z), b3 = pair(ab[i].w);
+        if (rs == 0) {
+            red[wave][NO * 8 + i * 4 + 0][c] = b0;
+            red[wave][NO * 8 + i * 4 + 1][c] = b1;
+            red[wave][NO * 8 + i * 4 + 2][c] = b2;
+            red[wave][NO * 8 + i * 4 + 3][c] = b3;
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < NO; ++n) {
+        const float t = pair(ad[n]);     // identical in the 32 strips of a row slot
+        if (rs == 0) red[wave][NO * 8 + 8 + n][c] = t;
+    }
+    __syncthreads();
+    float* pb = part + (size_t)blockIdx.x * ((size_t)(NO + 1) * n_hid + NO);
+    constexpr int NV = NO * 8 + 8;
+    for (int idx = threadIdx.x; idx < NV * 32; idx += 256) {
+        const int val = idx >> 5, cc = idx & 31;
+        const float t = ((red[0][val][cc] + red[1][val][cc]) + red[2][val][cc]) + red[3][val][cc];
+        // val = (n * 2 + i) * 4 + e  -> dW2[n][4 (cc + 32 i) + e];   val = NO * 8 + i * 4 + e -> db1[4 (cc + 32 i) + e]
+        const int e = val & 3, i = (val >> 2) & 1, n = val >> 3;
+        const int col = 4 * (cc + 32 * i) + e;
+        if (col < n_hid) pb[(size_t)n * n_hid + col] = t;      // n == NO is the db1 row
+    }
+    if (threadIdx.x < NO) {
+        const int val = NV + threadIdx.x;
+        pb[(size_t)(NO + 1) * n_hid + threadIdx.x] = ((red[0][val][0] + red[1][val][0]) + red[2][val][0]) + red[3][val][0];
+    }
+}
+
+// workspace of one Linear layer's backward on the GEMM path, in floats: split-K slabs of the weight gradient (64) + 256 slabs
+// of n_out for the bias column sums
+size_t linear_ws_floats(int n_out, int n_in) { return (size_t)64 * n_out * (n_in > 1 ? n_in : 1) + (size_t)256 * n_out + 64; }
+
+bool head_is_thin(int n_hid, int n_out) { return n_out >= 1 && n_out <= 8 && n_hid <= HEAD_MAX_HID && (n_hid & 3) == 0; }
 
 // Which recurrence pair runs: four sequences per workgroup (v_mfma 4x4x1_16b: 93 / 73 us per 38-step launch, one workgroup
 // per CU) while that leaves at most two rounds of workgroups, sixteen per workgroup (16x16x4: 213 / 198 us) beyond --
@@ -620,9 +822,11 @@ extern "C" {
 size_t howl_lstm_workspace_bytes(int B, int T) {
     // packed W_hh (2 x 64K floats) + bias sum (512) + split-K scratch of the W_hh gradient (128 x 512 x 128; its head also
     // holds the 4-row fragments) + the W_ih gradient's own scratch (128 x 512 x 48 at most) + the bias column sums' (256 x 512):
-    // three regions, so that the three final slab sums can run as one launch
+    // three regions, so that the three final slab sums can run as one launch (the bias region holds one slab per workgroup
+    // of the four-sequence recurrence, or the 256 of the column-sum kernel)
+    const size_t bias_slabs = (size_t)(B + 3) / 4 > 256 ? (size_t)(B + 3) / 4 : 256;
     return ((size_t)2 * 16 * 64 * 64 + G4 + (size_t)LSTM_WGRAD_SPLITS * G4 * HID + (size_t)LSTM_WGRAD_SPLITS * G4 * LSTM_MAX_IN +
-            (size_t)256 * G4) * sizeof(float) + 1024;
+            bias_slabs * G4) * sizeof(float) + 1024;
 }
 
 int howl_lstm_fwd(const HowlLstmParams* p, const float* x, int B, int T, int M, const long long* lengths, const float* h0,
@@ -643,9 +847,10 @@ int howl_lstm_fwd(const HowlLstmParams* p, const float* x, int B, int T, int M, 
     float* pf4 = bsum + G4;
     float* pb4 = pf4 + 16 * 64 * 64;
     const bool rows16 = lstm_rows16(B);
-    hipLaunchKernelGGL(lstm_pack_kernel, dim3(16 * 64 * 64 / 256), dim3(256), 0, stream, p->w_hh, pf, pb, pf4, pb4);
+    // (only the fragments of the variant that runs are packed)
+    hipLaunchKernelGGL(lstm_pack_kernel, dim3(16 * 64 * 64 / 256), dim3(256), 0, stream, p->w_hh, rows16 ? pf : nullptr,
+                       rows16 ? pb : nullptr, rows16 ? nullptr : pf4, rows16 ? nullptr : pb4, p->b_ih, p->b_hh, bsum);
     // bias = b_ih + b_hh folded into the input projection: gx = x W_ih^T + bias   (B*T, 512), K = M
-    hipLaunchKernelGGL(add2_kernel, dim3(G4 / 256), dim3(256), 0, stream, p->b_ih, p->b_hh, bsum, G4);
     gemm(stream, true, x, lin(M), 1, lin(0), p->w_ih, lin(1), M, B * T, G4, M, 1, bsum, 0, sv->gx, G4, 0);
     if (sv->t_out < T)   // rows of steps that never run are read (times zero) by the weight-gradient GEMM: keep them finite
         hipMemsetAsync(sv->hseq, 0, (size_t)B * (T + 1) * HID * sizeof(float), stream);
@@ -675,13 +880,16 @@ int howl_lstm_bwd(const HowlLstmParams* p, const float* x, int B, int T, int M, 
     float* pf = static_cast<float*>(ws);
     float* pb = pf + 16 * 64 * 64;
     float* scratch = pb + 16 * 64 * 64 + G4;
+    float* scratch_ih = scratch + (size_t)LSTM_WGRAD_SPLITS * G4 * HID;
+    float* scratch_b = scratch_ih + (size_t)LSTM_WGRAD_SPLITS * G4 * LSTM_MAX_IN;
     const int Tout = sv->t_out;
+    const bool rows16 = lstm_rows16(B);
     {
     HowlProfScope prof("lstm_bwd", stream, 2.0 * HID * G4 * (double)B * Tout);           // dG_t W_hh of every step
-    if (!lstm_rows16(B))
+    if (!rows16)
         hipLaunchKernelGGL(lstm_bwd4_kernel, dim3((B + 3) / 4), dim3(LSTM_THREADS), 0, stream, dy, dhT, dcT,
                            (const float*)(scratch + 16 * 64 * 64),
-                           lengths, (const float*)sv->gates, (const float*)sv->c, c0, sv->dgates, B, T, Tout);
+                           lengths, (const float*)sv->gates, (const float*)sv->c, c0, sv->dgates, scratch_b, B, T, Tout);
     else
         hipLaunchKernelGGL(lstm_bwd_kernel, dim3((B + 15) / 16), dim3(LSTM_THREADS), 0, stream, dy, dhT, dcT, (const float*)pb,
                            lengths, (const float*)sv->gates, (const float*)sv->c, c0, sv->dgates, B, T, Tout);
@@ -694,71 +902,98 @@ int howl_lstm_bwd(const HowlLstmParams* p, const float* x, int B, int T, int M, 
     const int rows = B * Tout;
     // 256 rows per K slice (up to 128 slices): the 512-row slices of the generic rule leave ~1 block per CU on these shapes
     HOWL_REQUIRE(M <= LSTM_MAX_IN, "howl_lstm_bwd: M=%d input features exceed the workspace layout (max %d)", M, LSTM_MAX_IN);
-    float* scratch_ih = scratch + (size_t)LSTM_WGRAD_SPLITS * G4 * HID;
-    float* scratch_b = scratch_ih + (size_t)LSTM_WGRAD_SPLITS * G4 * LSTM_MAX_IN;
     SlabSums sums;
     wgrad_gemm(stream, sv->dgates, rows_g, G4, x, rows_x, M, rows, scratch_ih, g->w_ih, LSTM_WGRAD_SPLITS, 256, &sums);
     wgrad_gemm(stream, sv->dgates, rows_g, G4, sv->hseq, RowMap{Tout, (long)(T + 1) * HID, HID}, HID, rows, scratch, g->w_hh,
                LSTM_WGRAD_SPLITS, 256, &sums);
-    colsum(stream, sv->dgates, rows_g, rows, G4, scratch_b, g->b_ih, g->b_hh, 256, 64, &sums);
+    if (!rows16)   // the four-sequence recurrence left one slab of step-and-sequence sums per workgroup
+        sums.add(scratch_b, (B + 3) / 4, G4, g->b_ih, g->b_hh);
+    else
+        colsum(stream, sv->dgates, rows_g, rows, G4, scratch_b, g->b_ih, g->b_hh, 256, 64, &sums);
     if (!sums.flush(stream)) return HOWL_E_ARG;
     HOWL_CHECK_LAUNCH("howl_lstm_bwd");
     return HOWL_OK;
 }
 
-// split-K slabs of the weight gradient: 64 for wide outputs; thin outputs (<= 8 columns: the 128-row slices that fill the chip
-// cost almost nothing in slab traffic) up to 512
-constexpr int LIN_THIN_SPLITS = 512;
-size_t howl_linear_workspace_bytes(int n_out, int n_in) {
-    const size_t slabs = n_out <= 8 ? LIN_THIN_SPLITS : 64;
-    // weight-gradient slabs, then 256 slabs of n_out for the bias column sums (their own region: both sums fold in one launch)
-    return (slabs * n_out * (n_in > 1 ? n_in : 1) + (size_t)256 * n_out) * sizeof(float) + 256;
+size_t howl_head_workspace_bytes(int n_in, int n_hid, int n_out) {
+    // [first layer: 64 split-K slabs of n_hid x n_in] [second layer, thin: HEAD_BWD_BLOCKS slabs of (n_out + 1) n_hid + n_out]
+    // (other shapes: the GEMM path's slabs of both layers)
+    const size_t first = (size_t)64 * n_hid * n_in;
+    const size_t thin = (size_t)HEAD_BWD_BLOCKS * ((size_t)(n_out + 1) * n_hid + n_out);
+    const size_t general = linear_ws_floats(n_hid, n_in) + linear_ws_floats(n_out, n_hid);
+    const size_t a = first + thin + 64, b = general + 64;
+    return (a > b ? a : b) * sizeof(float);
 }
 
-// y = x W^T + b (ReLU optional);  x rows: rows_outer x rows_inner with strides (elements), unit stride along features
-int howl_linear_fwd(const float* x, int rows_inner, long s_outer, long s_inner, int rows, int n_in, const float* w,
-                    const float* bias, int n_out, int relu, float* y, hipStream_t stream) {
-    HOWL_REQUIRE(x && w && y, "howl_linear_fwd: null pointer");
-    HOWL_REQUIRE(rows >= 1 && n_in >= 1 && n_out >= 1 && rows_inner >= 1, "howl_linear_fwd: bad shape");
-    gemm(stream, true, x, RowMap{rows_inner, s_outer, s_inner}, 1, lin(0), w, lin(1), n_in, rows, n_out, n_in, 1, bias, relu,
-         y, n_out, 0);
-    HOWL_CHECK_LAUNCH("howl_linear_fwd");
+int howl_head_fwd(const HowlHeadParams* p, const float* x, int rows_inner, long s_outer, long s_inner, int rows, int n_in,
+                  int n_hid, int n_out, float* y1, float* y2, hipStream_t stream) {
+    HOWL_REQUIRE(p && p->w1 && p->b1 && p->w2 && p->b2 && x && y1 && y2, "howl_head_fwd: null pointer");
+    HOWL_REQUIRE(rows >= 1 && n_in >= 1 && n_hid >= 1 && n_out >= 1 && rows_inner >= 1, "howl_head_fwd: bad shape");
+    gemm(stream, true, x, RowMap{rows_inner, s_outer, s_inner}, 1, lin(0), p->w1, lin(1), n_in, rows, n_hid, n_in, 1, p->b1, 1,
+         y1, n_hid, 0);
+    if (head_is_thin(n_hid, n_out)) {
+        int blocks = (rows + 15) / 16;
+        const int cap = 4 * howl_num_cus();
+        blocks = blocks > cap ? cap : blocks;
+#define HOWL_HEAD_OUT(NO) \
+    case NO: hipLaunchKernelGGL(head_out_kernel<NO>, dim3(blocks), dim3(256), 0, stream, (const float*)y1, rows, n_hid, p->w2, p->b2, y2); break;
+        switch (n_out) {
+            HOWL_HEAD_OUT(1) HOWL_HEAD_OUT(2) HOWL_HEAD_OUT(3) HOWL_HEAD_OUT(4) HOWL_HEAD_OUT(5) HOWL_HEAD_OUT(6) HOWL_HEAD_OUT(7)
+            HOWL_HEAD_OUT(8)
+        }
+#undef HOWL_HEAD_OUT
+    } else {
+        gemm(stream, true, y1, lin(n_hid), 1, lin(0), p->w2, lin(1), n_hid, rows, n_out, n_hid, 1, p->b2, 0, y2, n_out, 0);
+    }
+    HOWL_CHECK_LAUNCH("howl_head_fwd");
     return HOWL_OK;
 }
 
-// dy (rows, n_out) contiguous [already masked by the caller's ReLU backward if any] -> dx (rows, n_in) contiguous
-// (nullable), dW (n_out, n_in), db (n_out)
-int howl_linear_bwd(const float* x, int rows_inner, long s_outer, long s_inner, int rows, int n_in, const float* w, int n_out,
-                    const float* dy, float* dx, float* dw, float* db, void* ws, size_t ws_bytes, hipStream_t stream) {
-    HOWL_REQUIRE(x && w && dy && dw && db && ws, "howl_linear_bwd: null pointer");
-    if (ws_bytes < howl_linear_workspace_bytes(n_out, n_in)) {
-        howl_set_error("howl_linear_bwd: workspace too small");
+int howl_head_bwd(const HowlHeadParams* p, const float* x, int rows_inner, long s_outer, long s_inner, int rows, int n_in,
+                  int n_hid, int n_out, const float* y1, const float* dy2, float* dz1, float* dx, const HowlHeadGrads* g,
+                  void* ws, size_t ws_bytes, hipStream_t stream) {
+    HOWL_REQUIRE(p && p->w1 && p->w2 && x && y1 && dy2 && dz1 && g && g->w1 && g->b1 && g->w2 && g->b2 && ws,
+                 "howl_head_bwd: null pointer");
+    HOWL_REQUIRE(rows >= 1 && n_in >= 1 && n_hid >= 1 && n_out >= 1 && rows_inner >= 1, "howl_head_bwd: bad shape");
+    if (ws_bytes < howl_head_workspace_bytes(n_in, n_hid, n_out)) {
+        howl_set_error("howl_head_bwd: workspace too small");
         return HOWL_E_WORKSPACE;
     }
-    if (dx != nullptr)   // dx = dy W : A = dy [m][k = n_out], B(k, n) = w[k * n_in + n]
-        gemm(stream, true, dy, lin(n_out), 1, lin(0), w, lin(n_in), 1, rows, n_in, n_out, 1, nullptr, 0, dx, n_in, 0);
+    float* first = static_cast<float*>(ws);
+    const RowMap xm{rows_inner, s_outer, s_inner};
     SlabSums sums;
-    const size_t slabs = n_out <= 8 ? LIN_THIN_SPLITS : 64;
-    float* scratch_b = static_cast<float*>(ws) + slabs * n_out * (n_in > 1 ? n_in : 1);
-    if (n_out <= 8)   // 152 blocks of 512 rows each left most CUs idle on the (5 x 256) head: 128-row slices instead
-        wgrad_gemm(stream, dy, lin(n_out), n_out, x, RowMap{rows_inner, s_outer, s_inner}, n_in, rows, static_cast<float*>(ws),
-                   dw, LIN_THIN_SPLITS, 128, &sums);
-    else
-        wgrad_gemm(stream, dy, lin(n_out), n_out, x, RowMap{rows_inner, s_outer, s_inner}, n_in, rows, static_cast<float*>(ws),
-                   dw, 64, 512, &sums);
-    colsum(stream, dy, lin(n_out), rows, n_out, scratch_b, db, nullptr, 256, 64, &sums);
+    if (head_is_thin(n_hid, n_out)) {
+        float* thin = first + (size_t)64 * n_hid * n_in;
+        int rpb = (rows + HEAD_BWD_BLOCKS - 1) / HEAD_BWD_BLOCKS;
+        rpb = (rpb + 7) / 8 * 8;
+        const int blocks = (rows + rpb - 1) / rpb;
+#define HOWL_HEAD_BWD(NO) \
+    case NO: hipLaunchKernelGGL(head_thin_bwd_kernel<NO>, dim3(blocks), dim3(256), 0, stream, y1, dy2, rows, n_hid, rpb, p->w2, dz1, thin); break;
+        switch (n_out) {
+            HOWL_HEAD_BWD(1) HOWL_HEAD_BWD(2) HOWL_HEAD_BWD(3) HOWL_HEAD_BWD(4) HOWL_HEAD_BWD(5) HOWL_HEAD_BWD(6) HOWL_HEAD_BWD(7)
+            HOWL_HEAD_BWD(8)
+        }
+#undef HOWL_HEAD_BWD
+        const long slab = (long)(n_out + 1) * n_hid + n_out;
+        sums.add_strided(thin, blocks, slab, (long)n_out * n_hid, g->w2);
+        sums.add_strided(thin + (size_t)n_out * n_hid, blocks, slab, n_hid, g->b1);
+        sums.add_strided(thin + (size_t)(n_out + 1) * n_hid, blocks, slab, n_out, g->b2);
+    } else {
+        // general shapes: second layer by the GEMM path (its own folds), ReLU mask, then the first layer below
+        float* ws2 = first + linear_ws_floats(n_hid, n_in);
+        float* scratch_b2 = ws2 + (size_t)64 * n_out * n_hid;
+        gemm(stream, true, dy2, lin(n_out), 1, lin(0), p->w2, lin(n_hid), 1, rows, n_hid, n_out, 1, nullptr, 0, dz1, n_hid, 0);
+        hipLaunchKernelGGL(relu_bwd_kernel, dim3(1024), dim3(256), 0, stream, (const float*)dz1, y1, (long)rows * n_hid, dz1);
+        wgrad_gemm(stream, dy2, lin(n_out), n_out, y1, lin(n_hid), n_hid, rows, ws2, g->w2, 64, 512, &sums);
+        colsum(stream, dy2, lin(n_out), rows, n_out, scratch_b2, g->b2, nullptr, 256, 64, &sums);
+        float* scratch_b1 = first + (size_t)64 * n_hid * n_in;
+        colsum(stream, dz1, lin(n_hid), rows, n_hid, scratch_b1, g->b1, nullptr, 256, 64, &sums);
+    }
+    if (dx != nullptr)   // dx = dz1 W1
+        gemm(stream, true, dz1, lin(n_hid), 1, lin(0), p->w1, lin(n_in), 1, rows, n_in, n_hid, 1, nullptr, 0, dx, n_in, 0);
+    wgrad_gemm(stream, dz1, lin(n_hid), n_hid, x, xm, n_in, rows, first, g->w1, 64, 512, &sums);
     if (!sums.flush(stream)) return HOWL_E_ARG;
-    HOWL_CHECK_LAUNCH("howl_linear_bwd");
-    return HOWL_OK;
-}
-
-int howl_relu_bwd(const float* dy, const float* y, size_t n, float* dz, hipStream_t stream) {
-    HOWL_REQUIRE(dy && y && dz, "howl_relu_bwd: null pointer");
-    if (n == 0) return HOWL_OK;
-    size_t blocks = (n + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(relu_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, dy, y, (long)n, dz);
-    HOWL_CHECK_LAUNCH("howl_relu_bwd");
+    HOWL_CHECK_LAUNCH("howl_head_bwd");
     return HOWL_OK;
 }
 

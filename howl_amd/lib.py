@@ -44,6 +44,14 @@ class HowlLstmGrads(ctypes.Structure):
     _fields_ = [("w_ih", P), ("w_hh", P), ("b_ih", P), ("b_hh", P)]
 
 
+class HowlHeadParams(ctypes.Structure):
+    _fields_ = [("w1", P), ("b1", P), ("w2", P), ("b2", P)]
+
+
+class HowlHeadGrads(ctypes.Structure):
+    _fields_ = [("w1", P), ("b1", P), ("w2", P), ("b2", P)]
+
+
 class HowlLstmSaved(ctypes.Structure):
     _fields_ = [("gx", P), ("gates", P), ("c", P), ("hseq", P), ("dgates", P), ("t_out", c_int)]
 
@@ -88,9 +96,9 @@ SIGNATURES = {
                       STREAM],
     "howl_lstm_bwd": [POINTER(HowlLstmParams), P, c_int, c_int, c_int, P, P, POINTER(HowlLstmSaved), P, P, P,
                       POINTER(HowlLstmGrads), P, c_size_t, STREAM],
-    "howl_linear_fwd": [P, c_int, c_long, c_long, c_int, c_int, P, P, c_int, c_int, P, STREAM],
-    "howl_linear_bwd": [P, c_int, c_long, c_long, c_int, c_int, P, c_int, P, P, P, P, P, c_size_t, STREAM],
-    "howl_relu_bwd": [P, P, c_size_t, P, STREAM],
+    "howl_head_fwd": [POINTER(HowlHeadParams), P, c_int, c_long, c_long, c_int, c_int, c_int, c_int, P, P, STREAM],
+    "howl_head_bwd": [POINTER(HowlHeadParams), P, c_int, c_long, c_long, c_int, c_int, c_int, c_int, P, P, P, P,
+                      POINTER(HowlHeadGrads), P, c_size_t, STREAM],
     "howl_adamw_step": [P, P, P, P, c_size_t, c_float, c_float, c_float, c_float, c_float, c_int, c_float, STREAM],
     "howl_mobilenet_layer": [c_int, POINTER(HowlMbLayer)],
     "howl_mobilenet_fwd": [P, P, c_int, P, c_long, c_long, c_long, c_int, c_int, c_int, c_int, P, c_float, P, P, c_size_t,
@@ -99,7 +107,8 @@ SIGNATURES = {
 }
 # entry points that do not return an int status
 SIZE_FUNCS = {"howl_res8_workspace_bytes": [c_int, c_int], "howl_res8_long_workspace_bytes": [c_int, c_int], "howl_lstm_workspace_bytes": [c_int, c_int],
-              "howl_linear_workspace_bytes": [c_int, c_int], "howl_mobilenet_num_layers": [],
+              "howl_head_workspace_bytes": [c_int, c_int, c_int],
+              "howl_mobilenet_num_layers": [],
               "howl_mobilenet_param_floats": [c_int], "howl_mobilenet_buffer_floats": [],
               "howl_mobilenet_workspace_bytes": [c_int, c_int, c_int, c_int],
               "howl_ctc_supported": [c_int, c_int, c_int]}

@@ -91,59 +91,64 @@ class _LstmFunction(torch.autograd.Function):
         return (None, None, None, None, None) + tuple(grads)
 
 
-def _linear_geom(x):
+def _row_geom(x):
     if x.dim() == 3:
         outer, inner = x.shape[0], x.shape[1]
         s_outer, s_inner = x.stride(0), x.stride(1)
     else:
         outer, inner, s_outer, s_inner = 1, x.shape[0], 0, x.stride(0)
     if x.stride(-1) != 1:
-        raise ValueError("linear: features must be unit-stride")
+        raise ValueError("head: features must be unit-stride")
     return inner, s_outer, s_inner, outer * inner
 
 
-def _linear_forward_raw(x, w, b, relu):
-    n_out, n_in = w.shape
-    inner, s_outer, s_inner, rows = _linear_geom(x)
-    y = torch.empty(x.shape[:-1] + (n_out,), dtype=torch.float32, device=x.device)
-    _lib.get().call("howl_linear_fwd", _vp(x), inner, s_outer, s_inner, rows, n_in, _vp(w), _vp(b), n_out, int(relu), _vp(y),
-                    ops._stream())
-    return y
+def _head_forward_raw(x, w1, b1, w2, b2):
+    """``howl_head_fwd``: (y1 = relu(x W1^T + b1), y2 = y1 W2^T + b2) for x (..., n_in) with unit-stride features."""
+    n_hid, n_in = w1.shape
+    n_out = w2.shape[0]
+    inner, s_outer, s_inner, rows = _row_geom(x)
+    f32 = dict(dtype=torch.float32, device=x.device)
+    y1 = torch.empty(x.shape[:-1] + (n_hid,), **f32)
+    y2 = torch.empty(x.shape[:-1] + (n_out,), **f32)
+    prm = _lib.HowlHeadParams(_vp(w1), _vp(b1), _vp(w2), _vp(b2))
+    _lib.get().call("howl_head_fwd", ctypes.byref(prm), _vp(x), inner, s_outer, s_inner, rows, n_in, n_hid, n_out, _vp(y1),
+                    _vp(y2), ops._stream())
+    return y1, y2
 
 
-def _linear_backward_raw(x, w, y, dy, relu, need_dx, dw=None, db=None):
-    """dy (..., n_out) -> (dx or None, dW, db); ``y`` is the forward output when a ReLU followed (its mask)."""
-    inner, s_outer, s_inner, rows = _linear_geom(x)
-    n_out, n_in = w.shape
-    dy = dy.contiguous()
-    if relu:
-        dz = torch.empty_like(dy)
-        _lib.get().call("howl_relu_bwd", _vp(dy), _vp(y), dy.numel(), _vp(dz), ops._stream())
-        dy = dz
-    dx = torch.empty(x.shape, dtype=torch.float32, device=x.device) if need_dx else None
-    dw = torch.empty_like(w) if dw is None else dw
-    db = torch.empty(n_out, dtype=torch.float32, device=w.device) if db is None else db
-    ws = torch.empty(_lib.get().cdll.howl_linear_workspace_bytes(n_out, n_in), dtype=torch.uint8, device=w.device)
-    _lib.get().call("howl_linear_bwd", _vp(x), inner, s_outer, s_inner, rows, n_in, _vp(w), n_out, _vp(dy), _vp(dx), _vp(dw),
-                    _vp(db), _vp(ws), ws.numel(), ops._stream())
-    return dx, dw, db
+def _head_backward_raw(x, y1, dy2, w1, b1, w2, b2, need_dx=True, grads=None):
+    """``howl_head_bwd``: dy2 (..., n_out) -> (dx or None, [dW1, db1, dW2, db2]), written into ``grads`` when given."""
+    n_hid, n_in = w1.shape
+    n_out = w2.shape[0]
+    inner, s_outer, s_inner, rows = _row_geom(x)
+    f32 = dict(dtype=torch.float32, device=x.device)
+    dy2 = dy2.contiguous()
+    dz1 = torch.empty_like(y1)
+    dx = torch.empty(x.shape, **f32) if need_dx else None
+    if grads is None:
+        grads = [torch.empty_like(t) for t in (w1, b1, w2, b2)]
+    ws = torch.empty(_lib.get().cdll.howl_head_workspace_bytes(n_in, n_hid, n_out), dtype=torch.uint8, device=x.device)
+    prm = _lib.HowlHeadParams(_vp(w1), _vp(b1), _vp(w2), _vp(b2))
+    gr = _lib.HowlHeadGrads(*[_vp(g) for g in grads])
+    _lib.get().call("howl_head_bwd", ctypes.byref(prm), _vp(x), inner, s_outer, s_inner, rows, n_in, n_hid, n_out, _vp(y1),
+                    _vp(dy2), _vp(dz1), _vp(dx), ctypes.byref(gr), _vp(ws), ws.numel(), ops._stream())
+    return dx, grads
 
 
-class _LinearFunction(torch.autograd.Function):
-    """y = x W^T + b (+ReLU) for x of shape (..., n_in) whose rows follow a (rows_outer, rows_inner) stride pattern."""
+class _HeadFunction(torch.autograd.Function):
+    """Linear - ReLU - Linear (``self.dnn``, rnn.py:44-48) on the library's head kernels."""
 
     @staticmethod
-    def forward(ctx, x, w, b, relu):
-        y = _linear_forward_raw(x, w, b, relu)
-        ctx.save_for_backward(x, w, y if relu else None)
-        ctx.relu = relu
-        return y
+    def forward(ctx, x, w1, b1, w2, b2):
+        y1, y2 = _head_forward_raw(x, w1, b1, w2, b2)
+        ctx.save_for_backward(x, y1, w1, b1, w2, b2)
+        return y2
 
     @staticmethod
-    def backward(ctx, dy):
-        x, w, y = ctx.saved_tensors
-        dx, dw, db = _linear_backward_raw(x, w, y, dy, ctx.relu, ctx.needs_input_grad[0])
-        return dx, dw, db, None
+    def backward(ctx, dy2):
+        x, y1, w1, b1, w2, b2 = ctx.saved_tensors
+        dx, grads = _head_backward_raw(x, y1, dy2, w1, b1, w2, b2, ctx.needs_input_grad[0])
+        return (dx,) + tuple(grads)
 
 
 class _LstmBase(RegisteredModel):
@@ -207,8 +212,7 @@ class _LstmBase(RegisteredModel):
                 self.dnn[2].weight, self.dnn[2].bias]
 
     def _head(self, h):
-        y = _LinearFunction.apply(h, self.dnn[0].weight, self.dnn[0].bias, True)
-        return _LinearFunction.apply(y, self.dnn[2].weight, self.dnn[2].bias, False)
+        return _HeadFunction.apply(h, self.dnn[0].weight, self.dnn[0].bias, self.dnn[2].weight, self.dnn[2].bias)
 
 
 class SequentialLstm(_LstmBase, name="seq-lstm"):
@@ -233,8 +237,7 @@ class SequentialLstm(_LstmBase, name="seq-lstm"):
         xb, lengths, t_out, h0, c0 = self._lstm_inputs(feat, lengths, t_out)
         ps = self.hot_parameters()
         hs, hT, cT, saved = _lstm_forward_raw(xb, lengths, t_out, h0, c0, *ps[:4])
-        y1 = _linear_forward_raw(hs, ps[4], ps[5], True)
-        y2 = _linear_forward_raw(y1, ps[6], ps[7], False)
+        y1, y2 = _head_forward_raw(hs, *ps[4:8])
         self._seq_saved = (saved, t_out, hs, y1)
         if self.is_streaming:                          # same carry as forward() (rnn.py:64-68)
             self.streaming_state = (hT.detach().clone().unsqueeze(0), cT.detach().clone().unsqueeze(0))
@@ -245,9 +248,7 @@ class SequentialLstm(_LstmBase, name="seq-lstm"):
         saved, t_out, hs, y1 = self._seq_saved
         ps = self.hot_parameters()
         grads = out_grads if out_grads is not None else [torch.empty_like(p) for p in ps]
-        dy2 = dscores.permute(1, 0, 2)
-        dy1, _, _ = _linear_backward_raw(y1, ps[6], None, dy2, False, True, grads[6], grads[7])
-        dhs, _, _ = _linear_backward_raw(hs, ps[4], y1, dy1, True, True, grads[4], grads[5])
+        dhs, _ = _head_backward_raw(hs, y1, dscores.permute(1, 0, 2), *ps[4:8], True, grads[4:8])
         _lstm_backward_raw(saved, t_out, dhs, None, None, grads[:4])
         self._seq_saved = None
         return grads
@@ -264,16 +265,15 @@ class SimpleLstm(_LstmBase, name="lstm"):
         xb, lengths, t_out, h0, c0 = self._lstm_inputs(feat, lengths, t_out)
         ps = self.hot_parameters()
         _, hT, _, saved = _lstm_forward_raw(xb, lengths, t_out, h0, c0, *ps[:4])
-        y1 = _linear_forward_raw(hT, ps[4], ps[5], True)
+        y1, y2 = _head_forward_raw(hT, *ps[4:8])
         self._cls_saved = (saved, t_out, hT, y1)
-        return _linear_forward_raw(y1, ps[6], ps[7], False)
+        return y2
 
     def _launch_backward(self, feat, dlogits, out_grads=None):
         saved, t_out, hT, y1 = self._cls_saved
         ps = self.hot_parameters()
         grads = out_grads if out_grads is not None else [torch.empty_like(p) for p in ps]
-        dy1, _, _ = _linear_backward_raw(y1, ps[6], None, dlogits, False, True, grads[6], grads[7])
-        dhT, _, _ = _linear_backward_raw(hT, ps[4], y1, dy1, True, True, grads[4], grads[5])
+        dhT, _ = _head_backward_raw(hT, y1, dlogits, *ps[4:8], True, grads[4:8])
         _lstm_backward_raw(saved, t_out, None, dhT, None, grads[:4])
         self._cls_saved = None
         return grads

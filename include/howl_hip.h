@@ -257,17 +257,34 @@ int howl_lstm_bwd(const HowlLstmParams* p, const float* x, int B, int T, int M, 
                   const float* c0, const HowlLstmSaved* saved, const float* dy, const float* dhT, const float* dcT,
                   const HowlLstmGrads* grads, void* ws, size_t ws_bytes, hipStream_t stream);
 
-/* y = x W^T + b (optional ReLU).  x has `rows` rows of n_in contiguous floats; row r lives at
- * (r / rows_inner) * s_outer + (r % rows_inner) * s_inner (elements), so (B,T+1,128) slices are usable in place. */
-size_t howl_linear_workspace_bytes(int n_out, int n_in);
-int howl_linear_fwd(const float* x, int rows_inner, long s_outer, long s_inner, int rows, int n_in, const float* w,
-                    const float* bias, int n_out, int relu, float* y, hipStream_t stream);
-/* dy (rows, n_out) contiguous -> dx (rows, n_in) contiguous (NULL to skip), dW (n_out, n_in), db (n_out). */
-int howl_linear_bwd(const float* x, int rows_inner, long s_outer, long s_inner, int rows, int n_in, const float* w,
-                    int n_out, const float* dy, float* dx, float* dw, float* db, void* ws, size_t ws_bytes,
-                    hipStream_t stream);
-/* dz = dy * (y > 0). */
-int howl_relu_bwd(const float* dy, const float* y, size_t n, float* dz, hipStream_t stream);
+/* The classifier head of both LSTM models as one unit: Linear(n_in, n_hid) - ReLU - Linear(n_hid, n_out)
+ * (replaces `self.dnn` of howl/model/rnn.py:44-48 applied at rnn.py:71 / rnn.py:91).  x has `rows` rows of n_in contiguous
+ * floats; row r lives at (r / rows_inner) * s_outer + (r % rows_inner) * s_inner (elements), so (B,T+1,128) slices of the
+ * hidden-state buffer are usable in place.
+ * With n_out <= 8 and n_hid <= 256 the second layer runs as vector kernels on the hidden activations: its backward is ONE
+ * pass that yields dz1 = (y1 > 0) * (dy2 W2), dW2, db2 and db1, folded with the first layer's split-K slabs in one launch;
+ * other shapes take the library's generic GEMM path.  Same results either way up to fp32 summation order. */
+typedef struct {
+    const float* w1; /* dnn[0].weight (n_hid, n_in) */
+    const float* b1; /* dnn[0].bias (n_hid) */
+    const float* w2; /* dnn[2].weight (n_out, n_hid) */
+    const float* b2; /* dnn[2].bias (n_out) */
+} HowlHeadParams;
+typedef struct {
+    float* w1;
+    float* b1;
+    float* w2;
+    float* b2;
+} HowlHeadGrads;
+size_t howl_head_workspace_bytes(int n_in, int n_hid, int n_out);
+/* y1 (rows, n_hid) = relu(x W1^T + b1) [kept for the backward], y2 (rows, n_out) = y1 W2^T + b2. */
+int howl_head_fwd(const HowlHeadParams* p, const float* x, int rows_inner, long s_outer, long s_inner, int rows, int n_in,
+                  int n_hid, int n_out, float* y1, float* y2, hipStream_t stream);
+/* dy2 (rows, n_out) contiguous -> grads, dx (rows, n_in) contiguous (NULL to skip); dz1 (rows, n_hid) is scratch the caller
+ * provides (it holds the gradient at the hidden pre-activations afterwards). */
+int howl_head_bwd(const HowlHeadParams* p, const float* x, int rows_inner, long s_outer, long s_inner, int rows, int n_in,
+                  int n_hid, int n_out, const float* y1, const float* dy2, float* dz1, float* dx, const HowlHeadGrads* grads,
+                  void* ws, size_t ws_bytes, hipStream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * MobileNetClassifier, registry name "mobilenet" (replaces howl/model/cnn.py:15-29: downsample conv/BN/ReLU/pool +

@@ -163,15 +163,17 @@ template <class V4> static inline V4 hipemu_mfma16(float a, float b, V4 c) {
 
 // v_mfma_f32_4x4x1_16b_f32: 16 independent blocks j = l>>2; A_j[i] from lane 4j+i, B_j[c] from lane 4j+c; lane 4j+c holds
 // D_j[r = 0..3][c] in its four result registers (layout probed on gfx950: tools/mfma4x4_probe.hip)
-template <class V4> static inline V4 hipemu_mfma4(float a, float b, V4 c) {
+// cbsz / abid: block abid of every group of 2^cbsz blocks supplies A to the whole group (CDNA3 ISA 7.1.4; probed on gfx950)
+template <class V4> static inline V4 hipemu_mfma4(float a, float b, V4 c, int cbsz = 0, int abid = 0) {
     uint32_t w[2] = {hipemu_bits(a), hipemu_bits(b)};
     const uint32_t* t = hipemu_wave_exchange(w, 2);
     const int l = hipemu_lane(), blk = l >> 2;
+    const int ablk = (blk & ~((1 << cbsz) - 1)) | (cbsz ? abid : 0);
     const float bv = hipemu_from<float>(t[l * 16 + 1]);
-    for (int r = 0; r < 4; ++r) c[r] = fmaf(hipemu_from<float>(t[(4 * blk + r) * 16 + 0]), bv, c[r]);
+    for (int r = 0; r < 4; ++r) c[r] = fmaf(hipemu_from<float>(t[(4 * ablk + r) * 16 + 0]), bv, c[r]);
     return c;
 }
-#define __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, x, y, z) hipemu_mfma4((a), (b), (c))
+#define __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, x, y, z) hipemu_mfma4((a), (b), (c), (x), (y))
 
 
 // ---- bit casts, DPP / permlane / bpermute (semantics: cdna_hip_programming.md T12/T21, ISA ch. DPP) ----------------------

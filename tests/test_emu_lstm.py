@@ -1,4 +1,4 @@
-"""LSTM recurrence / BPTT / Linear kernels on the hipemu CPU emulator vs the oracle (and golden G6)."""
+"""LSTM recurrence / BPTT / classifier-head kernels on the hipemu CPU emulator vs the oracle (and golden G6)."""
 import ctypes
 
 import numpy as np
@@ -6,7 +6,7 @@ import pytest
 import torch
 
 from emu_util import emu_lib, ptr
-from howl_amd.lib import HowlLstmGrads, HowlLstmParams, HowlLstmSaved
+from howl_amd.lib import HowlHeadGrads, HowlHeadParams, HowlLstmGrads, HowlLstmParams, HowlLstmSaved
 from oracle import models as om
 
 
@@ -51,16 +51,17 @@ def test_lstm_forward_backward_ragged(lib, golden, monkeypatch, rows):
     np.testing.assert_allclose(hs, seq.detach().permute(1, 0, 2).numpy(), rtol=0, atol=2e-6)
     np.testing.assert_allclose(hT, h_ref[0].detach().numpy(), rtol=0, atol=2e-6)
     np.testing.assert_allclose(cT, c_ref[0].detach().numpy(), rtol=0, atol=2e-6)
-    # seq-lstm logits through the Linear kernels vs the reference golden
+    # seq-lstm logits through the head kernels vs the reference golden
     B, T = x_btm.shape[:2]
     t_out = keep["t_out"]
     w1, b1, w2, b2 = (np.ascontiguousarray(sd[k].numpy()) for k in ("dnn.0.weight", "dnn.0.bias", "dnn.2.weight", "dnn.2.bias"))
     hid = np.zeros((B * t_out, 256), np.float32)
     hseq = keep["bufs"]["hseq"]
     h1 = np.ascontiguousarray(hseq.reshape(-1)[128:])   # skip hseq[0][0] (h0): row (b,t) -> hseq[b][t+1]
-    lib.call("howl_linear_fwd", ptr(h1), t_out, (T + 1) * 128, 128, B * t_out, 128, ptr(w1), ptr(b1), 256, 1, ptr(hid), None)
     logits = np.zeros((B * t_out, 5), np.float32)
-    lib.call("howl_linear_fwd", ptr(hid), 1 << 30, 0, 256, B * t_out, 256, ptr(w2), ptr(b2), 5, 0, ptr(logits), None)
+    hp = HowlHeadParams(ptr(w1), ptr(b1), ptr(w2), ptr(b2))
+    lib.call("howl_head_fwd", ctypes.byref(hp), ptr(h1), t_out, (T + 1) * 128, 128, B * t_out, 128, 256, 5, ptr(hid), ptr(logits),
+             None)
     np.testing.assert_allclose(logits.reshape(B, t_out, 5).transpose(1, 0, 2), g["logits"], rtol=0, atol=5e-6)
 
     # BPTT: random output gradient + final-state gradients
@@ -92,21 +93,44 @@ def test_lstm_streaming_carry_and_no_lengths(lib):
     np.testing.assert_allclose(hT2, hTf, rtol=0, atol=1e-6)
 
 
-def test_linear_backward(lib):
-    rng = np.random.default_rng(2)
-    rows, n_in, n_out = 77, 128, 256
-    x = rng.standard_normal((rows, n_in)).astype(np.float32)
-    w = rng.standard_normal((n_out, n_in)).astype(np.float32) * 0.1
-    dy = rng.standard_normal((rows, n_out)).astype(np.float32)
-    dx, dw, db = np.zeros_like(x), np.zeros_like(w), np.zeros(n_out, np.float32)
-    ws = np.zeros(lib.cdll.howl_linear_workspace_bytes(n_out, n_in), np.uint8)
-    lib.call("howl_linear_bwd", ptr(x), 1 << 30, 0, n_in, rows, n_in, ptr(w), n_out, ptr(dy), ptr(dx), ptr(dw), ptr(db), ptr(ws),
+@pytest.mark.parametrize("rows,n_in,n_hid,n_out", [(77, 128, 256, 5), (1, 128, 256, 3), (300, 128, 256, 8), (41, 40, 64, 1),
+                                                   (50, 128, 256, 12), (33, 64, 320, 4)])
+def test_head_forward_backward(lib, rows, n_in, n_hid, n_out):
+    """Linear - ReLU - Linear: the vector kernels (n_out <= 8, n_hid <= 256) and the GEMM path of the other shapes against
+    numpy in float64; x rows through a two-level row map as the (B, T+1, 128) hidden-state buffer has."""
+    rng = np.random.default_rng(2 + rows)
+    inner = 7 if rows % 7 == 0 else rows
+    outer = rows // inner
+    xbuf = rng.standard_normal((outer, inner + 1, n_in)).astype(np.float32)      # row (o, i) lives at xbuf[o][i + 1]
+    x = xbuf[:, 1:].reshape(rows, n_in)
+    w1 = (rng.standard_normal((n_hid, n_in)) * 0.1).astype(np.float32)
+    b1 = (rng.standard_normal(n_hid) * 0.1).astype(np.float32)
+    w2 = (rng.standard_normal((n_out, n_hid)) * 0.1).astype(np.float32)
+    b2 = (rng.standard_normal(n_out) * 0.1).astype(np.float32)
+    dy2 = rng.standard_normal((rows, n_out)).astype(np.float32)
+    y1, y2 = np.full((rows, n_hid), np.nan, np.float32), np.full((rows, n_out), np.nan, np.float32)
+    hp = HowlHeadParams(ptr(w1), ptr(b1), ptr(w2), ptr(b2))
+    x0 = np.ascontiguousarray(xbuf.reshape(-1)[n_in:])
+    geom = (inner, (inner + 1) * n_in, n_in, rows, n_in, n_hid, n_out)
+    lib.call("howl_head_fwd", ctypes.byref(hp), ptr(x0), *geom, ptr(y1), ptr(y2), None)
+    z1 = x.astype(np.float64) @ w1.T.astype(np.float64) + b1
+    r1 = np.maximum(z1, 0)
+    np.testing.assert_allclose(y1, r1, rtol=0, atol=2e-5)
+    np.testing.assert_allclose(y2, r1 @ w2.T.astype(np.float64) + b2, rtol=0, atol=2e-5)
+    g = [np.full_like(a, np.nan) for a in (w1, b1, w2, b2)]
+    gr = HowlHeadGrads(*[ptr(a) for a in g])
+    dz1, dx = np.full((rows, n_hid), np.nan, np.float32), np.full((rows, n_in), np.nan, np.float32)
+    ws = np.zeros(lib.cdll.howl_head_workspace_bytes(n_in, n_hid, n_out), np.uint8)
+    lib.call("howl_head_bwd", ctypes.byref(hp), ptr(x0), *geom, ptr(y1), ptr(dy2), ptr(dz1), ptr(dx), ctypes.byref(gr), ptr(ws),
              ws.size, None)
-    np.testing.assert_allclose(dx, dy @ w, rtol=0, atol=2e-5)
-    np.testing.assert_allclose(dw, dy.T @ x, rtol=0, atol=5e-5)
-    np.testing.assert_allclose(db, dy.sum(0), rtol=0, atol=2e-5)
-    y = rng.standard_normal(1000).astype(np.float32)
-    dz = np.zeros(1000, np.float32)
-    g = rng.standard_normal(1000).astype(np.float32)
-    lib.call("howl_relu_bwd", ptr(g), ptr(y), 1000, ptr(dz), None)
-    np.testing.assert_array_equal(dz, np.where(y > 0, g, 0))
+    dz_ref = (dy2.astype(np.float64) @ w2) * (y1 > 0)
+    scale = lambda a: max(1.0, np.abs(a).max())
+    np.testing.assert_allclose(dz1, dz_ref, rtol=0, atol=2e-5)
+    np.testing.assert_allclose(dx, dz_ref @ w1, rtol=0, atol=2e-5 * scale(dz_ref @ w1))
+    for got, ref, name in ((g[0], dz_ref.T @ x, "dW1"), (g[1], dz_ref.sum(0), "db1"), (g[2], dy2.T.astype(np.float64) @ y1, "dW2"),
+                           (g[3], dy2.sum(0, dtype=np.float64), "db2")):
+        np.testing.assert_allclose(got, ref, rtol=0, atol=2e-5 * scale(ref), err_msg=name)
+    # dx is optional (the first layer of a model that does not need its input's gradient)
+    lib.call("howl_head_bwd", ctypes.byref(hp), ptr(x0), *geom, ptr(y1), ptr(dy2), ptr(dz1), None, ctypes.byref(gr), ptr(ws),
+             ws.size, None)
+    np.testing.assert_allclose(g[0], dz_ref.T @ x, rtol=0, atol=2e-5 * scale(dz_ref.T @ x))

@@ -15,6 +15,14 @@ __global__ void layout(float* out, int which) {
     for (int r = 0; r < 4; ++r) out[lane * 4 + r] = acc[r];
 }
 
+// cbsz = 4, abid = 5: every block takes its A operand from block 5 (lanes 20..23)
+__global__ void layout_bcast(float* out) {
+    const int lane = threadIdx.x;
+    f32x4 acc = {0, 0, 0, 0};
+    acc = __builtin_amdgcn_mfma_f32_4x4x1f32(1.0f + lane, 1.0f, acc, 4, 5, 0);
+    for (int r = 0; r < 4; ++r) out[lane * 4 + r] = acc[r];
+}
+
 template <int NACC>
 __global__ __launch_bounds__(1024) void rate(float* out, int iters) {
     f32x4 acc[NACC];
@@ -46,6 +54,14 @@ int main() {
             for (int r = 0; r < 4; ++r) printf("  (%2d,%2d)", (int)ha[lane * 4 + r] - 1, (int)hb[lane * 4 + r] - 1);
             printf("\n");
         }
+    layout_bcast<<<1, 64>>>(d);
+    hipMemcpy(ha, d, sizeof(ha), hipMemcpyDeviceToHost);
+    bool bc_ok = true;
+    for (int lane = 0; lane < 64; ++lane)
+        for (int r = 0; r < 4; ++r) bc_ok = bc_ok && (int)ha[lane * 4 + r] - 1 == 20 + r;
+    printf("cbsz=4 abid=5: every D[r] fed by A lane 20 + r: %s (lane 0: %d %d %d %d, lane 63: %d %d %d %d)\n", bc_ok ? "yes" : "NO",
+           (int)ha[0] - 1, (int)ha[1] - 1, (int)ha[2] - 1, (int)ha[3] - 1, (int)ha[252] - 1, (int)ha[253] - 1, (int)ha[254] - 1,
+           (int)ha[255] - 1);
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
