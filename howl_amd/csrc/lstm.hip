@@ -35,8 +35,8 @@ __device__ __forceinline__ float sigmoidf_(float x) {
     return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896341f * x));
 }
 __device__ __forceinline__ float tanhf_(float x) {
-    const float xc = fminf(fmaxf(x, -15.0f), 15.0f);   // exp2 stays finite; tanh is +-1 to fp32 precision beyond |x| = 9
-    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.88539008177792681f * xc));
+    // no clamp needed: 2^(+big) = inf -> rcp 0 -> 1; 2^(-big) = 0 -> rcp 1 -> -1 (v_exp_f32 / v_rcp_f32 saturate cleanly)
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.88539008177792681f * x));
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -57,10 +57,10 @@ __global__ void lstm_pack_kernel(const float* __restrict__ whh, float* __restric
     const int lane = idx & 63, frag = (idx >> 6) & 63, w = idx >> 12;
     const int k = lane >> 4, n = lane & 15;
     if (pf4 != nullptr) {
-        // lstm_fwd4_kernel: wave w = (column chunk c = w & 7, K half kh = w >> 3); lane = 4 * unit_local + gate holds
-        // W_hh[gate * 128 + 16 c + unit_local][64 kh + frag]
-        const int c = w & 7, kh = w >> 3;
-        pf4[idx] = whh[((lane & 3) * HID + 16 * c + (lane >> 2)) * HID + 64 * kh + frag];
+        // lstm_fwd4_kernel: [column chunk c = 0..7][k = 0..127][lane]; lane = 4 * unit_local + gate holds
+        // W_hh[gate * 128 + 16 c + unit_local][k]
+        const int c = w >> 1, kk = 64 * (w & 1) + frag;
+        pf4[idx] = whh[((lane & 3) * HID + 16 * c + (lane >> 2)) * HID + kk];
     }
     if (pb4 != nullptr) {
         // lstm_bwd4_kernel: wave w = (hidden-column chunk ch = w & 1, gate-column range kr = w >> 1); lane = column
@@ -84,166 +84,145 @@ __global__ void lstm_pack_kernel(const float* __restrict__ whh, float* __restric
 // sixteen, so a lane (block J, row i) loads only the four k values 4J..4J+3 of its row -- one 16-byte LDS read per wave and
 // step instead of sixteen (which was as much LDS-pipe time per step, 256 x 1 KB, as the step's matrix work) -- and the
 // sixty-four instructions walk abid over the blocks.  acc[e] is the chain of k = e mod 4.
-template <int J>
-__device__ __forceinline__ void bcast_mfma64(const float4& a, const float (&w)[64], f32x4 (&acc)[4]) {
-    acc[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(a.x, w[4 * J + 0], acc[0], 4, J, 0);
-    acc[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(a.y, w[4 * J + 1], acc[1], 4, J, 0);
-    acc[2] = __builtin_amdgcn_mfma_f32_4x4x1f32(a.z, w[4 * J + 2], acc[2], 4, J, 0);
-    acc[3] = __builtin_amdgcn_mfma_f32_4x4x1f32(a.w, w[4 * J + 3], acc[3], 4, J, 0);
-    if constexpr (J + 1 < 16) bcast_mfma64<J + 1>(a, w, acc);
+template <int J, int OFF, int N>
+__device__ __forceinline__ void bcast_mfma64(const float4& a, const float (&w)[N], f32x4 (&acc)[4]) {
+    acc[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(a.x, w[OFF + 4 * J + 0], acc[0], 4, J, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(a.y, w[OFF + 4 * J + 1], acc[1], 4, J, 0);
+    acc[2] = __builtin_amdgcn_mfma_f32_4x4x1f32(a.z, w[OFF + 4 * J + 2], acc[2], 4, J, 0);
+    acc[3] = __builtin_amdgcn_mfma_f32_4x4x1f32(a.w, w[OFF + 4 * J + 3], acc[3], 4, J, 0);
+    if constexpr (J + 1 < 16) bcast_mfma64<J + 1, OFF, N>(a, w, acc);
 }
-// value of lane 4 * (lane / 4) + K of the same quad (v_mov_b32_dpp quad_perm: no LDS crossbar trip)
-template <int K>
-__device__ __forceinline__ float quad_bcast(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), K * 0x55, 0xf, 0xf, true));
+// 4 x 4 transpose inside every quad of lanes: v[r] of lane 4q + l  <->  v[l] of lane 4q + r.  Two butterfly stages on
+// v_mov_b32_dpp with a bank mask (the lanes of one parity take the partner's register, the others keep theirs): 12 moves.
+__device__ __forceinline__ void quad_transpose(float (&v)[4]) {
+    // stage 1: lane bit 0 <-> register bit 0   (quad_perm [1,0,3,2])
+    {
+        const float n1 = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v[1]), __float_as_int(v[0]), 0xB1, 0xf, 0x5, false));
+        const float n0 = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v[0]), __float_as_int(v[1]), 0xB1, 0xf, 0xA, false));
+        const float n3 = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v[3]), __float_as_int(v[2]), 0xB1, 0xf, 0x5, false));
+        const float n2 = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v[2]), __float_as_int(v[3]), 0xB1, 0xf, 0xA, false));
+        v[0] = n0;
+        v[1] = n1;
+        v[2] = n2;
+        v[3] = n3;
+    }
+    // stage 2: lane bit 1 <-> register bit 1   (quad_perm [2,3,0,1])
+    {
+        const float n2 = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v[2]), __float_as_int(v[0]), 0x4E, 0xf, 0x3, false));
+        const float n0 = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v[0]), __float_as_int(v[2]), 0x4E, 0xf, 0xC, false));
+        const float n3 = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v[3]), __float_as_int(v[1]), 0x4E, 0xf, 0x3, false));
+        const float n1 = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v[1]), __float_as_int(v[3]), 0x4E, 0xf, 0xC, false));
+        v[0] = n0;
+        v[1] = n1;
+        v[2] = n2;
+        v[3] = n3;
+    }
 }
-
 // Forward recurrence with FOUR sequences per workgroup on v_mfma_f32_4x4x1_16b_f32 (16 independent 4x4 outer products
 // per instruction: block = hidden unit, block column = gate, block row = sequence), so the batch dimension is not padded to
-// the 16 rows of the 16x16x4 tile: 128 workgroups at B = 512 and a 1.2 us matrix floor per step instead of 3.3 us.
-//   wave w = (column chunk c = w & 7: units 16c..16c+15 x 4 gates, K half kh = w >> 3: h[64kh .. 64kh+63]);
-//   four accumulator chains per wave (k = 0,1,2,3 mod 4) hide the ~50-cycle dependent latency of the instruction;
-//   the two K halves meet through LDS: wave (c, kh) finishes sequences 2kh, 2kh+1 and hands the other two to its partner;
-//   lane 4j+g then holds gate g of unit 16c+j for its two sequences: each lane applies its own gate's nonlinearity, the four
-//   gates of a cell are gathered by quad shuffles and all four lanes of the quad carry the cell state redundantly.
-constexpr int F4_HS = HID + 4;          // h rows in LDS (16-byte aligned rows for the float4 A-fragment reads)
-constexpr int F4_PS = G4 + 4;           // row stride of the K-half partial sums
-constexpr int F4_SROW = 6 * HID;        // saved activations of a step per sequence: gates i,f,g,o | c | h
-__global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd4_kernel(const float* __restrict__ gx, const float* __restrict__ pf4,
-                                                                 const long long* __restrict__ lengths,
-                                                                 const float* __restrict__ h0, const float* __restrict__ c0,
-                                                                 float* __restrict__ gates, float* __restrict__ cs,
-                                                                 float* __restrict__ hseq, float* __restrict__ hT,
-                                                                 float* __restrict__ cT, int B, int T, int Tout) {
-    __shared__ __attribute__((aligned(16))) float hbuf[2][4 * F4_HS];
-    __shared__ float part[2][4 * F4_PS];
-    __shared__ __attribute__((aligned(16))) float sbuf[2][4 * F4_SROW];
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int c = wave & 7, kh = wave >> 3;
+// the 16 rows of the 16x16x4 tile: 128 workgroups at B = 512 and a ~1 us matrix floor per step (256 instructions per SIMD).
+// Everything around the matrix work is sized to stay out of its way -- measured (tools/lstm_variants.py) the previous
+// sixteen-wave version spent 1.15 us of each 2.1 us step outside the MFMAs: four waves per SIMD all running the gate
+// arithmetic (with each cell updated in four lanes), two barriers and an LDS exchange of the K halves:
+//   eight waves, wave c = units 16c..16c+15 x 4 gates over the WHOLE K (128 W_hh registers per lane, two waves per SIMD):
+//   no partial sums to exchange;
+//   MFMA role of lane 4j+g: gate g of unit 16c+j for the four sequences (its four accumulator rows); after the gate
+//   nonlinearity a 4x4 transpose inside the quad hands lane 4j+g the four gates of (sequence g, unit 16c+j): every cell is
+//   updated exactly once;
+//   saved activations go straight to HBM from the lanes that hold them (no staging, no second barrier); sequences past the
+//   end of the batch are computed as copies of the last one, so that every store is unconditional (identical values) and
+//   the compiler can count outstanding memory operations instead of draining them at every step;
+//   ONE barrier per step: h_t is double-buffered in LDS.
+constexpr int F8_THREADS = 512;
+constexpr int F8_HS = HID + 4;          // h rows in LDS (16-byte aligned rows for the float4 A-fragment reads)
+__global__ __launch_bounds__(F8_THREADS) void lstm_fwd4_kernel(const float* __restrict__ gx, const float* __restrict__ pf4,
+                                                               const long long* __restrict__ lengths,
+                                                               const float* __restrict__ h0, const float* __restrict__ c0,
+                                                               float* __restrict__ gates, float* __restrict__ cs,
+                                                               float* __restrict__ hseq, float* __restrict__ hT,
+                                                               float* __restrict__ cT, int B, int T, int Tout) {
+    __shared__ __attribute__((aligned(16))) float hbuf[2][4 * F8_HS];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int c = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane >> 2, g = lane & 3;
     const int u = 16 * c + j;                       // hidden unit of this lane's quad
-    const int col = g * HID + u;                    // its gate column in PyTorch order (i, f, g, o)
+    const int col = g * HID + u;                    // MFMA role: its gate column in PyTorch order (i, f, g, o)
     const int b0 = blockIdx.x * 4;
-    float wB[64];
+    float wB[128];
 #pragma unroll
-    for (int kk = 0; kk < 64; ++kk) wB[kk] = pf4[((size_t)wave * 64 + kk) * 64 + lane];
-    // this lane finishes sequences s0, s0 + 1 (rows of the workgroup's four)
-    const int s0 = 2 * kh;
-    float cst[2], hst[2];
-    int len[2];
-    bool vb[2];
+    for (int kk = 0; kk < 128; ++kk) wB[kk] = pf4[((size_t)c * 128 + kk) * 64 + lane];
+    // cell role: sequence g of the workgroup, unit u
+    const int bc = min(b0 + g, B - 1);
+    float cst = c0 != nullptr ? c0[(size_t)bc * HID + u] : 0.0f;
+    float hst = h0 != nullptr ? h0[(size_t)bc * HID + u] : 0.0f;
+    const int len = lengths != nullptr ? (int)lengths[bc] : T;
+    hbuf[0][g * F8_HS + u] = hst;
+    hseq[((size_t)bc * (T + 1)) * HID + u] = hst;
+    // Running BYTE offsets from the (uniform) buffer bases, advanced once per step: the accesses become
+    // global_load/store v, v_offset, s[base] with nothing else to compute (element indices cost an add and a 64-bit
+    // shift-add per access and step: 28 VALU instructions of a ~130-instruction step).  < 4 GB by the launcher's check.
+    auto ldg = [](const float* base, unsigned boff) { return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + boff); };
+    auto stg = [](float* base, unsigned boff, float v) { *reinterpret_cast<float*>(reinterpret_cast<char*>(base) + boff) = v; };
+    unsigned cb = ((unsigned)bc * (unsigned)T * HID + u) * 4u;                  // cs[bc][t][u]
+    unsigned hb = (((unsigned)bc * (unsigned)(T + 1) + 1u) * HID + u) * 4u;     // hseq[bc][t + 1][u]
+    // MFMA role: (sequence r, step t, column col) in gx and gates (same shape)
+    unsigned gb[4];
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int b = b0 + s0 + q;
-        vb[q] = b < B;
-        cst[q] = (vb[q] && c0 != nullptr) ? c0[(size_t)b * HID + u] : 0.0f;
-        hst[q] = (vb[q] && h0 != nullptr) ? h0[(size_t)b * HID + u] : 0.0f;
-        len[q] = vb[q] ? (lengths != nullptr ? (int)lengths[b] : T) : 0;
-        if (g == 0) {
-            hbuf[0][(s0 + q) * F4_HS + u] = hst[q];
-            if (vb[q]) hseq[((size_t)b * (T + 1)) * HID + u] = hst[q];
-        }
-    }
-    // destination of this thread's float4 slot of a step's saved rows (4 x 768 floats = 768 float4: threads 0..767)
-    int fkind = 3;
-    unsigned foff = 0u;
-    if (tid < 4 * F4_SROW / 4) {
-        const int row = tid / (F4_SROW / 4), c4 = tid - row * (F4_SROW / 4);
-        const int b = b0 + row;
-        if (b < B) {
-            if (c4 < G4 / 4) {
-                fkind = 0;
-                foff = (unsigned)b * (unsigned)T * G4 + 4u * c4;
-            } else if (c4 < (G4 + HID) / 4) {
-                fkind = 1;
-                foff = (unsigned)b * (unsigned)T * HID + 4u * (c4 - G4 / 4);
-            } else {
-                fkind = 2;
-                foff = ((unsigned)b * (unsigned)(T + 1) + 1u) * HID + 4u * (c4 - (G4 + HID) / 4);
-            }
-        }
-    }
-    auto flush = [&](int t, const float* sb) {
-        if (fkind == 3) return;
-        const float4 v = *reinterpret_cast<const float4*>(sb + 4 * tid);
-        const unsigned o = foff + (unsigned)t * (fkind == 0 ? (unsigned)G4 : (unsigned)HID);
-        if (fkind == 0) *reinterpret_cast<float4*>(gates + o) = v;
-        else if (fkind == 1) *reinterpret_cast<float4*>(cs + o) = v;
-        else *reinterpret_cast<float4*>(hseq + o) = v;
-    };
-    // input-projection terms of this lane's two (sequence, column) pairs, one step ahead
-    const size_t gbase[2] = {((size_t)(vb[0] ? b0 + s0 : 0) * T) * G4 + col, ((size_t)(vb[1] ? b0 + s0 + 1 : 0) * T) * G4 + col};
-    float nx[2];
+    for (int r = 0; r < 4; ++r) gb[r] = ((unsigned)min(b0 + r, B - 1) * (unsigned)T * G4 + col) * 4u;
+    float nx[4];
 #pragma unroll
-    for (int q = 0; q < 2; ++q) nx[q] = gx[gbase[q]];
+    for (int r = 0; r < 4; ++r) nx[r] = ldg(gx, gb[r]);
+    // sigmoid(x) = 1 / (1 + 2^(-x log2 e)); the cell-candidate gate is tanh(x) = 2 sigmoid(2x) - 1
+    const float kneg = g == 2 ? -2.88539008177792681f : -1.44269504088896341f;
+    const float amul = g == 2 ? 2.0f : 1.0f, aadd = g == 2 ? -1.0f : 0.0f;
     __syncthreads();
-    const float kscale = g == 2 ? 2.0f : 1.0f;     // tanh(x) = 2 sigmoid(2x) - 1 for the cell-candidate gate
+    // the 128 fragment loads are complete before the loop (otherwise the first trip's bookkeeping, one s_waitcnt per
+    // fragment, stays in the loop body for every step)
+    __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0) on gfx9
     for (int t = 0; t < Tout; ++t) {
         const float* hcur = hbuf[t & 1];
         float* hnxt = hbuf[(t + 1) & 1];
-        float* scur = sbuf[t & 1];
-        const float gxv[2] = {nx[0], nx[1]};
-        if (t + 1 < Tout) {
+        float pre[4];
 #pragma unroll
-            for (int q = 0; q < 2; ++q) nx[q] = gx[gbase[q] + (size_t)(t + 1) * G4];
+        for (int r = 0; r < 4; ++r) pre[r] = nx[r];
+        {   // next step's input-projection terms (the last step re-reads its own: an unconditional load keeps the count exact)
+            const float* gxn = gx + (t + 1 < Tout ? G4 : 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) nx[r] = ldg(gxn, gb[r]);
         }
+        // A_j[i] comes from lane 4j+i: row i = lane & 3 = g; this lane's k values are 4j .. 4j+3 and 64 + 4j .. 64 + 4j+3
+        const float4 alo = *reinterpret_cast<const float4*>(hcur + g * F8_HS + 4 * j);
+        const float4 ahi = *reinterpret_cast<const float4*>(hcur + g * F8_HS + 64 + 4 * j);
         f32x4 acc[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[e] = {0.0f, 0.0f, 0.0f, 0.0f};
-        // A_j[i] comes from lane 4j+i: row i = lane & 3 = g; this lane's four k values are 64 kh + 4j .. 4j+3
-        bcast_mfma64<0>(*reinterpret_cast<const float4*>(hcur + g * F4_HS + 64 * kh + 4 * j), wB, acc);
-        f32x4 sum;
+        bcast_mfma64<0, 0>(alo, wB, acc);
+        bcast_mfma64<0, 64>(ahi, wB, acc);
+        const f32x4 sum = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+        float act[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) sum[r] = (acc[0][r] + acc[1][r]) + (acc[2][r] + acc[3][r]);
-        // hand the partner's two sequences over, keep mine
-        const float give0 = kh ? sum[0] : sum[2], give1 = kh ? sum[1] : sum[3];
-        const float keep[2] = {kh ? sum[2] : sum[0], kh ? sum[3] : sum[1]};
-        float* pmine = part[kh];
-        const int so = 2 * (1 - kh);
-        pmine[(so + 0) * F4_PS + 64 * c + lane] = give0;
-        pmine[(so + 1) * F4_PS + 64 * c + lane] = give1;
+        for (int r = 0; r < 4; ++r) {
+            const float p = sum[r] + pre[r];
+            const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(kneg * p));
+            act[r] = fmaf(sg, amul, aadd);
+            stg(gates, gb[r], act[r]);
+            gb[r] += G4 * 4u;
+        }
+        quad_transpose(act);        // -> i, f, g, o of (sequence g, unit u)
+        const bool live = t < len;
+        const float cn = act[1] * cst + act[0] * act[2];
+        const float hn = act[3] * tanhf_(cn);
+        cst = live ? cn : cst;
+        hst = live ? hn : hst;
+        hnxt[g * F8_HS + u] = hst;
+        stg(cs, cb, cn);
+        stg(hseq, hb, live ? hn : 0.0f);      // padded outputs are zero
+        cb += HID * 4u;
+        hb += HID * 4u;
         __syncthreads();
-        const float* pother = part[1 - kh];
-        float act[2];
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const float po = pother[(s0 + q) * F4_PS + 64 * c + lane];
-            const float pre = (keep[q] + po) + gxv[q];     // the two K halves, then the input projection
-            const float sg = sigmoidf_(kscale * pre);
-            act[q] = g == 2 ? 2.0f * sg - 1.0f : sg;
-        }
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const float ig = quad_bcast<0>(act[q]), fg = quad_bcast<1>(act[q]);
-            const float gg = quad_bcast<2>(act[q]), og = quad_bcast<3>(act[q]);
-            const bool live = t < len[q];
-            const float cn = fg * cst[q] + ig * gg;
-            const float hn = og * tanhf_(cn);
-            if (live) {
-                cst[q] = cn;
-                hst[q] = hn;
-            }
-            float* sr = scur + (s0 + q) * F4_SROW;
-            sr[col] = act[q];
-            if (g == 0) {
-                hnxt[(s0 + q) * F4_HS + u] = hst[q];
-                sr[4 * HID + u] = cn;
-                sr[5 * HID + u] = live ? hn : 0.0f;   // padded outputs are zero
-            }
-        }
-        __syncthreads();
-        flush(t, scur);
     }
-    if (g == 0) {
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int b = b0 + s0 + q;
-            if (b < B) {
-                hT[(size_t)b * HID + u] = hst[q];
-                cT[(size_t)b * HID + u] = cst[q];
-            }
-        }
-    }
+    hT[(size_t)bc * HID + u] = hst;
+    cT[(size_t)bc * HID + u] = cst;
 }
 
 // forward recurrence.  gx: (B,T,512) = x W_ih^T + b_ih + b_hh.  Outputs gates (B,T,512) post-activation, c (B,T,128),
@@ -529,43 +508,56 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_bwd4_kernel(const float* __
     float wk[64];
 #pragma unroll
     for (int kk = 0; kk < 64; ++kk) wk[kk] = pb4[((size_t)wave * 64 + kk) * 64 + lane];
-    // elementwise part: one cell per thread (threads 512..1023 only multiply)
+    // elementwise part: one cell per thread (threads 512..1023 only multiply).  Sequences past the end of the batch are
+    // computed as copies of the last one (identical loads, identical stores, left out of the bias sums): no store of the
+    // step loop is conditional.
     const bool cell = tid < 4 * HID;
     const int s = (tid >> 7) & 3, u = tid & (HID - 1);
-    const int b = b0 + s;
-    const bool vb = cell && b < B;
-    const int len = vb ? (lengths != nullptr ? (int)lengths[b] : T) : 0;
-    float dc = (vb && dcT != nullptr) ? dcT[(size_t)b * HID + u] : 0.0f;     // running dL/dc_t
-    float dhp = (vb && dhT != nullptr) ? dhT[(size_t)b * HID + u] : 0.0f;    // pass-through part of dL/dh_t
-    float bs_i = 0.0f, bs_f = 0.0f, bs_g = 0.0f, bs_o = 0.0f;               // this cell's dG summed over the steps (bias gradient)
+    const int b = min(b0 + s, B - 1);
+    const bool dup = b0 + s >= B;
+    const int len = lengths != nullptr ? (int)lengths[b] : T;
+    float dc = dcT != nullptr ? dcT[(size_t)b * HID + u] : 0.0f;     // running dL/dc_t
+    float dhp = dhT != nullptr ? dhT[(size_t)b * HID + u] : 0.0f;    // pass-through part of dL/dh_t
+    float bs_i = 0.0f, bs_f = 0.0f, bs_g = 0.0f, bs_o = 0.0f;       // this cell's dG summed over the steps (bias gradient)
     for (int i = tid; i < 8 * 4 * B4_PS; i += LSTM_THREADS) (&partd[0][0])[i] = 0.0f;
     struct Step {
         float ig, fg, gg, og, cn, cp, dyv;
     };
-    const size_t bclamp = vb ? (size_t)b : 0;
-    const float c0v = (vb && c0 != nullptr) ? c0[(size_t)b * HID + u] : 0.0f;
-    auto fetch = [&](int t, Step& st) {   // unconditional loads from clamped addresses, zeroed afterwards
-        const bool lv = vb && t >= 0 && t < len;
-        const size_t o = bclamp * T + (lv ? t : 0);
+    const float c0v = c0 != nullptr ? c0[(size_t)b * HID + u] : 0.0f;
+    // A step's saved activations are REQUESTED right after the previous step's gate gradients went out and TAKEN (masked)
+    // after the matrix work of that step: a full step of latency cover.  Taken where they were requested -- as the
+    // compiler scheduled it when left alone -- every step waited ~0.35 us for HBM (tools/lstm_variants.py: noload).
+    Step raw;
+    auto request = [&](int t) {   // unconditional loads from clamped addresses
+        const bool lv = t >= 0 && t < len;
+        const size_t o = (size_t)b * T + (lv ? t : 0);
         const size_t op = o - ((lv && t > 0) ? 1 : 0);
-        const float ig = gates[o * G4 + u], fg = gates[o * G4 + HID + u];
-        const float gg = gates[o * G4 + 2 * HID + u], og = gates[o * G4 + 3 * HID + u];
-        const float cn = cs[o * HID + u], cpv = cs[op * HID + u];
-        float dyv = 0.0f;
-        if (dy != nullptr) dyv = dy[o * HID + u];
-        st.ig = lv ? ig : 0.0f;
-        st.fg = lv ? fg : 0.0f;
-        st.gg = lv ? gg : 0.0f;
-        st.og = lv ? og : 0.0f;
-        st.cn = lv ? cn : 0.0f;
-        st.cp = lv ? (t > 0 ? cpv : c0v) : 0.0f;
-        st.dyv = lv ? dyv : 0.0f;
+        raw.ig = gates[o * G4 + u];
+        raw.fg = gates[o * G4 + HID + u];
+        raw.gg = gates[o * G4 + 2 * HID + u];
+        raw.og = gates[o * G4 + 3 * HID + u];
+        raw.cn = cs[o * HID + u];
+        raw.cp = cs[op * HID + u];
+        raw.dyv = dy != nullptr ? dy[o * HID + u] : 0.0f;
     };
-    Step cur, nxt;
-    fetch(Tout - 1, cur);
+    auto take = [&](int t, Step& st) {
+        const bool lv = t >= 0 && t < len;
+        st.ig = lv ? raw.ig : 0.0f;
+        st.fg = lv ? raw.fg : 0.0f;
+        st.gg = lv ? raw.gg : 0.0f;
+        st.og = lv ? raw.og : 0.0f;
+        st.cn = lv ? raw.cn : 0.0f;
+        st.cp = lv ? (t > 0 ? raw.cp : c0v) : 0.0f;
+        st.dyv = lv ? raw.dyv : 0.0f;
+    };
+    Step cur;
+    if (cell) {
+        request(Tout - 1);
+        take(Tout - 1, cur);
+    }
     __syncthreads();
+    __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0): the fragment loads are not the loop's business (see lstm_fwd4_kernel)
     for (int t = Tout - 1; t >= 0; --t) {
-        fetch(t - 1, nxt);
         if (cell) {
             // dL/dh_t = (recurrent term from step t+1) + (pass-through when h was frozen) + (output gradient)
             float dh = dhp;
@@ -594,13 +586,12 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_bwd4_kernel(const float* __
             bs_f += df;
             bs_g += dg;
             bs_o += dov;
-            if (vb) {
-                float* go = dG + ((size_t)b * T + t) * G4 + u;
-                go[0] = di;
-                go[HID] = df;
-                go[2 * HID] = dg;
-                go[3 * HID] = dov;
-            }
+            float* go = dG + ((size_t)b * T + t) * G4 + u;
+            go[0] = di;
+            go[HID] = df;
+            go[2 * HID] = dg;
+            go[3 * HID] = dov;
+            request(t - 1);
         }
         __syncthreads();
         // dh_{t-1}[seq][64 ch + lane] (K range kr) = sum_k dG[seq][64 kr + k] * W_hh[64 kr + k][64 ch + lane]
@@ -608,13 +599,15 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_bwd4_kernel(const float* __
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[e] = {0.0f, 0.0f, 0.0f, 0.0f};
         // A_j[i] comes from lane 4j+i: this lane's four k values are gate columns 64 kr + 4j .. 4j+3 of sequence lane & 3
-        bcast_mfma64<0>(*reinterpret_cast<const float4*>(dgt + (lane & 3) * B4_DGS + 64 * kr + 4 * (lane >> 2)), wk, acc);
+        bcast_mfma64<0, 0>(*reinterpret_cast<const float4*>(dgt + (lane & 3) * B4_DGS + 64 * kr + 4 * (lane >> 2)), wk, acc);
+        const f32x4 sum = (acc[0] + acc[1]) + (acc[2] + acc[3]);
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-            partd[kr][r * B4_PS + 64 * ch + lane] = (acc[0][r] + acc[1][r]) + (acc[2][r] + acc[3][r]);
-        cur = nxt;
+        for (int r = 0; r < 4; ++r) partd[kr][r * B4_PS + 64 * ch + lane] = sum[r];
+        __builtin_amdgcn_sched_barrier(0);     // the saved activations are not touched before this point
+        if (cell) take(t - 1, cur);
         __syncthreads();
     }
+    if (dup) bs_i = bs_f = bs_g = bs_o = 0.0f;
     // bias gradient: column sums of dG over (sequence, step) -- the step sums are in registers, the four sequences meet in
     // the dG tile; bpart[workgroup][512] is folded with the weight gradients' split-K slabs (no pass over dG in HBM)
     if (cell) {
@@ -808,7 +801,8 @@ bool head_is_thin(int n_hid, int n_out) { return n_out >= 1 && n_out <= 8 && n_h
 // Which recurrence pair runs: four sequences per workgroup (v_mfma 4x4x1_16b: 93 / 73 us per 38-step launch, one workgroup
 // per CU) while that leaves at most two rounds of workgroups, sixteen per workgroup (16x16x4: 213 / 198 us) beyond --
 // B <= 8 x CUs = 2048 on this part.  HOWL_LSTM_ROWS=4|16 forces one (tests exercise both).
-bool lstm_rows16(int B) {
+bool lstm_rows16(int B, int T) {
+    if ((size_t)B * (size_t)(T + 1) * G4 * sizeof(float) >= ((size_t)1 << 32)) return true;   // the 4-row kernels index bytes in 32 bits
     const char* env = getenv("HOWL_LSTM_ROWS");
     if (env != nullptr && env[0] == '1') return true;
     if (env != nullptr && env[0] == '4') return false;
@@ -846,7 +840,7 @@ int howl_lstm_fwd(const HowlLstmParams* p, const float* x, int B, int T, int M, 
     // touches between this call and the recurrence of the backward call)
     float* pf4 = bsum + G4;
     float* pb4 = pf4 + 16 * 64 * 64;
-    const bool rows16 = lstm_rows16(B);
+    const bool rows16 = lstm_rows16(B, T);
     // (only the fragments of the variant that runs are packed)
     hipLaunchKernelGGL(lstm_pack_kernel, dim3(16 * 64 * 64 / 256), dim3(256), 0, stream, p->w_hh, rows16 ? pf : nullptr,
                        rows16 ? pb : nullptr, rows16 ? nullptr : pf4, rows16 ? nullptr : pb4, p->b_ih, p->b_hh, bsum);
@@ -856,7 +850,7 @@ int howl_lstm_fwd(const HowlLstmParams* p, const float* x, int B, int T, int M, 
         hipMemsetAsync(sv->hseq, 0, (size_t)B * (T + 1) * HID * sizeof(float), stream);
     HowlProfScope prof("lstm_fwd", stream, 2.0 * HID * G4 * (double)B * sv->t_out);     // h_{t-1} W_hh^T of every step
     if (!rows16) {
-        hipLaunchKernelGGL(lstm_fwd4_kernel, dim3((B + 3) / 4), dim3(LSTM_THREADS), 0, stream, (const float*)sv->gx,
+        hipLaunchKernelGGL(lstm_fwd4_kernel, dim3((B + 3) / 4), dim3(F8_THREADS), 0, stream, (const float*)sv->gx,
                            (const float*)pf4, lengths, h0, c0, sv->gates, sv->c, sv->hseq, hT, cT, B, T, sv->t_out);
     } else {
         const size_t lds_fwd = (size_t)(2 * 16 * HS + 2 * 16 * 6 * HID) * sizeof(float);
@@ -883,7 +877,7 @@ int howl_lstm_bwd(const HowlLstmParams* p, const float* x, int B, int T, int M, 
     float* scratch_ih = scratch + (size_t)LSTM_WGRAD_SPLITS * G4 * HID;
     float* scratch_b = scratch_ih + (size_t)LSTM_WGRAD_SPLITS * G4 * LSTM_MAX_IN;
     const int Tout = sv->t_out;
-    const bool rows16 = lstm_rows16(B);
+    const bool rows16 = lstm_rows16(B, T);
     {
     HowlProfScope prof("lstm_bwd", stream, 2.0 * HID * G4 * (double)B * Tout);           // dG_t W_hh of every step
     if (!rows16)
