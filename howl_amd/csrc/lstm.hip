@@ -92,32 +92,30 @@ __device__ __forceinline__ void bcast_mfma64(const float4& a, const float (&w)[N
     acc[3] = __builtin_amdgcn_mfma_f32_4x4x1f32(a.w, w[OFF + 4 * J + 3], acc[3], 4, J, 0);
     if constexpr (J + 1 < 16) bcast_mfma64<J + 1, OFF, N>(a, w, acc);
 }
-// 4 x 4 transpose inside every quad of lanes: v[r] of lane 4q + l  <->  v[l] of lane 4q + r.  Two butterfly stages on
-// v_mov_b32_dpp with a bank mask (the lanes of one parity take the partner's register, the others keep theirs): 12 moves.
-__device__ __forceinline__ void quad_transpose(float (&v)[4]) {
-    // stage 1: lane bit 0 <-> register bit 0   (quad_perm [1,0,3,2])
+// 4 x 4 transpose inside every quad of lanes: v[r] of lane 4q + l  <->  v[l] of lane 4q + r.  Two butterfly stages: the
+// partner's registers arrive by v_mov_b32_dpp quad_perm, a select on the lane's parity keeps or takes (16 instructions; a DPP
+// bank mask cannot do the select: its banks are whole quads).
+__device__ __forceinline__ void quad_transpose(float (&v)[4], bool bit0, bool bit1) {
+    auto xor1 = [](float x) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xf, 0xf, true)); };
+    auto xor2 = [](float x) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x4E, 0xf, 0xf, true)); };
+    // stage 1: lane bit 0 <-> register bit 0: even lanes take the partner's v[0] as v[1], odd lanes its v[1] as v[0]
     {
-        const float n1 = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v[1]), __float_as_int(v[0]), 0xB1, 0xf, 0x5, false));
-        const float n0 = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v[0]), __float_as_int(v[1]), 0xB1, 0xf, 0xA, false));
-        const float n3 = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v[3]), __float_as_int(v[2]), 0xB1, 0xf, 0x5, false));
-        const float n2 = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v[2]), __float_as_int(v[3]), 0xB1, 0xf, 0xA, false));
-        v[0] = n0;
-        v[1] = n1;
-        v[2] = n2;
-        v[3] = n3;
+        const float p0 = xor1(v[0]), p1 = xor1(v[1]), p2 = xor1(v[2]), p3 = xor1(v[3]);
+        v[0] = bit0 ? p1 : v[0];
+        v[1] = bit0 ? v[1] : p0;
+        v[2] = bit0 ? p3 : v[2];
+        v[3] = bit0 ? v[3] : p2;
     }
-    // stage 2: lane bit 1 <-> register bit 1   (quad_perm [2,3,0,1])
+    // stage 2: lane bit 1 <-> register bit 1
     {
-        const float n2 = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v[2]), __float_as_int(v[0]), 0x4E, 0xf, 0x3, false));
-        const float n0 = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v[0]), __float_as_int(v[2]), 0x4E, 0xf, 0xC, false));
-        const float n3 = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v[3]), __float_as_int(v[1]), 0x4E, 0xf, 0x3, false));
-        const float n1 = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v[1]), __float_as_int(v[3]), 0x4E, 0xf, 0xC, false));
-        v[0] = n0;
-        v[1] = n1;
-        v[2] = n2;
-        v[3] = n3;
+        const float p0 = xor2(v[0]), p1 = xor2(v[1]), p2 = xor2(v[2]), p3 = xor2(v[3]);
+        v[0] = bit1 ? p2 : v[0];
+        v[2] = bit1 ? v[2] : p0;
+        v[1] = bit1 ? p3 : v[1];
+        v[3] = bit1 ? v[3] : p1;
     }
 }
+
 // Forward recurrence with FOUR sequences per workgroup on v_mfma_f32_4x4x1_16b_f32 (16 independent 4x4 outer products
 // per instruction: block = hidden unit, block column = gate, block row = sequence), so the batch dimension is not padded to
 // the 16 rows of the 16x16x4 tile: 128 workgroups at B = 512 and a ~1 us matrix floor per step (256 instructions per SIMD).
@@ -208,7 +206,7 @@ __global__ __launch_bounds__(F8_THREADS) void lstm_fwd4_kernel(const float* __re
             stg(gates, gb[r], act[r]);
             gb[r] += G4 * 4u;
         }
-        quad_transpose(act);        // -> i, f, g, o of (sequence g, unit u)
+        quad_transpose(act, (g & 1) != 0, (g & 2) != 0);        // -> i, f, g, o of (sequence g, unit u)
         const bool live = t < len;
         const float cn = act[1] * cst + act[0] * act[2];
         const float hn = act[3] * tanhf_(cn);

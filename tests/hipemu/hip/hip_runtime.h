@@ -204,12 +204,12 @@ static inline hipemu_u2 __builtin_amdgcn_permlane16_swap(unsigned a, unsigned b,
     return r;
 }
 // v_mov_b32_dpp: quad_perm, row_shl/shr/ror, row_mirror, row_half_mirror; row_mask bit (lane >> 4) and bank_mask bit
-// (lane & 3) enable the write, disabled lanes keep `old`
+// ((lane >> 2) & 3: a bank is four CONSECUTIVE lanes of a row) enable the write, disabled lanes keep `old`
 static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
     uint32_t w = (uint32_t)src;
     const uint32_t* t = hipemu_wave_exchange(&w, 1);
     const int l = hipemu_lane(), row = l & ~15, p = l & 15;
-    if (!((row_mask >> ((l >> 4) & 3)) & 1) || !((bank_mask >> (l & 3)) & 1)) return old;
+    if (!((row_mask >> ((l >> 4) & 3)) & 1) || !((bank_mask >> ((l >> 2) & 3)) & 1)) return old;
     int sp = -1;   // source position inside the row; -1 = out of range
     if (ctrl >= 0 && ctrl <= 0xff) sp = (p & ~3) | ((ctrl >> (2 * (p & 3))) & 3);
     else if (ctrl >= 0x101 && ctrl <= 0x10f) { sp = p + (ctrl - 0x100); if (sp > 15) sp = -1; }
