@@ -120,6 +120,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(const float* __restrict__ a, 
         }
 }
 
+// (Measured alternative, round 3: 128 x 128 / 128 x 64 block tiles with 16-byte LDS fragment reads and the same two-tile
+// prefetch ran the six GEMMs of the seq-lstm step 3-20 % SLOWER than this 64 x 64 kernel -- 19456 rows give 1216 or 2432 small
+// blocks, which balance over 256 CUs and keep 4x more loads in flight; with the MFMAs removed the kernel still takes 55-65 %
+// of its time: it is bound by load latency / memory-level parallelism, not by LDS or matrix issue.  tools/gemm_variants.py)
 // Fast path of the same GEMM for plain strided matrices whose unit-stride extents are multiples of 4 floats (every
 // MobileNet 1x1 convolution and weight gradient, the LSTM projections): operands move as 16-byte vectors, one per
 // thread and tile, and the next K tile is requested before the MFMAs of the current one (register double buffering).
@@ -255,161 +259,6 @@ __global__ __launch_bounds__(256) void gemm_vec_kernel(const float* __restrict__
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int m = m0 + 32 * wr + 16 * i + 4 * (lane >> 4) + r;
-                if (m < M && n < N) cz[(long)m * c_ms + n] = acc[i][j][r];
-            }
-        }
-}
-
-// Large-tile variant of the vector GEMM for the big row counts of the LSTM path (B*T rows by 128..512 columns and their
-// weight gradients): 128 x TN block tile (TN = 128 or 64), four waves in a 2 x 2 grid with 64 x TN/2 each, K tile 16.
-//   * operands sit in LDS as [row][k] (stride 20 floats), so that a lane's A (or B) values for FOUR consecutive MFMA steps are one
-//     ds_read_b128: step s of a K tile multiplies k = 4 q + s of lane group q = lane >> 4 on both sides (the order of the
-//     sixteen k inside a tile is free as long as A and B agree) -- 8 LDS instructions per 64 MFMAs instead of 64;
-//   * 32 FLOP per byte staged (64 x 64: 16) and one barrier per K tile: the next tile is fetched into registers before the
-//     MFMAs of the current one and written to the other LDS buffer after them.
-// Same operand conventions, split-K slabs, bias / ReLU epilogue as gemm_vec_kernel.
-constexpr int BT_M = 128, BT_LD = 20;
-template <bool A_UNIT_K, bool B_UNIT_K, bool KMAP_LIN, int TN>
-__global__ __launch_bounds__(256) void gemm_big_kernel(const float* __restrict__ a, RowMap amap, const float* __restrict__ b,
-                                                       RowMap bmap, int M, int N, int K, int k_per_split,
-                                                       const float* __restrict__ bias, int relu, float* __restrict__ c,
-                                                       long c_ms, long c_split_stride) {
-    constexpr int NI = TN / 32;                 // 16-column MFMA tiles per wave
-    constexpr int NB4 = TN / 64;                // float4 pieces of the B tile per thread (TN x 16 floats / 256 threads / 4)
-    __shared__ __attribute__((aligned(16))) float As[2][BT_M * BT_LD];
-    __shared__ __attribute__((aligned(16))) float Bs[2][TN * BT_LD];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
-    const int m0 = blockIdx.y * BT_M, n0 = blockIdx.x * TN;
-    const int kbeg = blockIdx.z * k_per_split;
-    const int kend = min(K, kbeg + k_per_split);
-    auto kmap = [&](const RowMap& r, int k) -> long {
-        if (KMAP_LIN) return (long)k * r.s_inner;
-        return (long)(k / r.inner) * r.s_outer + (long)(k % r.inner) * r.s_inner;
-    };
-    // piece f (0 .. rows*4-1) of an operand tile: unit-k -> (row = f / 4, k4 = f % 4); unit-row -> (k = f / (rows/4), r4 = f % (rows/4))
-    int a_r[2], a_k[2], b_r[NB4], b_k[NB4];
-    long a_fix[2], b_fix[NB4];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int f = tid + 256 * i;
-        a_r[i] = A_UNIT_K ? f >> 2 : (f & 31) * 4;
-        a_k[i] = A_UNIT_K ? (f & 3) * 4 : f >> 5;
-        a_fix[i] = A_UNIT_K ? rmap(amap, min(m0 + a_r[i], M - 1)) : (long)min(m0 + a_r[i], M - 4);
-    }
-#pragma unroll
-    for (int i = 0; i < NB4; ++i) {
-        const int f = tid + 256 * i;
-        b_r[i] = B_UNIT_K ? f >> 2 : (f & (TN / 4 - 1)) * 4;
-        b_k[i] = B_UNIT_K ? (f & 3) * 4 : f / (TN / 4);
-        b_fix[i] = B_UNIT_K ? rmap(bmap, min(n0 + b_r[i], N - 1)) : (long)min(n0 + b_r[i], N - 4);
-    }
-    // unconditional loads from clamped coordinates, zeroed when staged (see gemm_vec_kernel)
-    auto fetch_a = [&](int k0, int i) -> float4 {
-        const int k = min(k0 + a_k[i], A_UNIT_K ? kend - 4 : kend - 1);
-        return *reinterpret_cast<const float4*>(A_UNIT_K ? a + a_fix[i] + k : a + kmap(amap, k) + a_fix[i]);
-    };
-    auto fetch_b = [&](int k0, int i) -> float4 {
-        const int k = min(k0 + b_k[i], B_UNIT_K ? kend - 4 : kend - 1);
-        return *reinterpret_cast<const float4*>(B_UNIT_K ? b + b_fix[i] + k : b + kmap(bmap, k) + b_fix[i]);
-    };
-    auto stage = [&](float* as, float* bs, const float4 (&va)[2], const float4 (&vb)[NB4], int k0) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            float4 v = va[i];
-            if (!(m0 + a_r[i] < M && k0 + a_k[i] < kend)) v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (A_UNIT_K) {
-                *reinterpret_cast<float4*>(&as[a_r[i] * BT_LD + a_k[i]]) = v;
-            } else {
-                as[(a_r[i] + 0) * BT_LD + a_k[i]] = v.x;
-                as[(a_r[i] + 1) * BT_LD + a_k[i]] = v.y;
-                as[(a_r[i] + 2) * BT_LD + a_k[i]] = v.z;
-                as[(a_r[i] + 3) * BT_LD + a_k[i]] = v.w;
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < NB4; ++i) {
-            float4 v = vb[i];
-            if (!(n0 + b_r[i] < N && k0 + b_k[i] < kend)) v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (B_UNIT_K) {
-                *reinterpret_cast<float4*>(&bs[b_r[i] * BT_LD + b_k[i]]) = v;
-            } else {
-                bs[(b_r[i] + 0) * BT_LD + b_k[i]] = v.x;
-                bs[(b_r[i] + 1) * BT_LD + b_k[i]] = v.y;
-                bs[(b_r[i] + 2) * BT_LD + b_k[i]] = v.z;
-                bs[(b_r[i] + 3) * BT_LD + b_k[i]] = v.w;
-            }
-        }
-    };
-    f32x4 acc[4][NI];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < NI; ++j) acc[i][j] = {0.0f, 0.0f, 0.0f, 0.0f};
-    float4 va[2], vb[NB4];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) va[i] = fetch_a(kbeg, i);
-#pragma unroll
-    for (int i = 0; i < NB4; ++i) vb[i] = fetch_b(kbeg, i);
-    stage(As[0], Bs[0], va, vb, kbeg);
-    __syncthreads();
-    int buf = 0;
-    for (int k0 = kbeg; k0 < kend; k0 += GK) {
-        const bool more = k0 + GK < kend;
-        // (past the end: clamped re-loads that are never staged)
-#pragma unroll
-        for (int i = 0; i < 2; ++i) va[i] = fetch_a(k0 + GK, i);
-#pragma unroll
-        for (int i = 0; i < NB4; ++i) vb[i] = fetch_b(k0 + GK, i);
-        __builtin_amdgcn_sched_barrier(0);   // keep the requests in front of the MFMAs
-        const float* as = As[buf] + (64 * wr + (lane & 15)) * BT_LD + 4 * (lane >> 4);
-        const float* bs = Bs[buf] + ((TN / 2) * wc + (lane & 15)) * BT_LD + 4 * (lane >> 4);
-        float4 af[4], bf[NI];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const float4*>(as + 16 * i * BT_LD);
-#pragma unroll
-        for (int j = 0; j < NI; ++j) bf[j] = *reinterpret_cast<const float4*>(bs + 16 * j * BT_LD);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < NI; ++j) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
-            }
-        if (more) stage(As[buf ^ 1], Bs[buf ^ 1], va, vb, k0 + GK);
-        __syncthreads();
-        buf ^= 1;
-    }
-    float* cz = c + (long)blockIdx.z * c_split_stride;
-    if (bias != nullptr) {
-        float bv[NI];
-#pragma unroll
-        for (int j = 0; j < NI; ++j) bv[j] = bias[min(n0 + (TN / 2) * wc + 16 * j + (lane & 15), N - 1)];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < NI; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc[i][j][r] += bv[j];
-    }
-    if (relu) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < NI; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc[i][j][r] = fmaxf(acc[i][j][r], 0.0f);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < NI; ++j) {
-            const int n = n0 + (TN / 2) * wc + 16 * j + (lane & 15);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = m0 + 64 * wr + 16 * i + 4 * (lane >> 4) + r;
                 if (m < M && n < N) cz[(long)m * c_ms + n] = acc[i][j][r];
             }
         }
@@ -566,35 +415,6 @@ int gemm(hipStream_t s, bool a_major_k, const float* a, RowMap am, long a_ks, Ro
             const RowMap bmap = b_unit_k ? lin(b_ns) : bk;
             // the maps that are indexed by k inside the kernel (the other ones are evaluated once per thread)
             const bool klin = (a_major_k || is_lin(amap)) && (b_unit_k || is_lin(bmap));
-            // large row counts: 128-row tiles (128 x 128 while that still leaves >= 1.5 blocks per CU, 128 x 64 otherwise)
-            const char* tile_env = getenv("HOWL_GEMM_TILE");
-            if (M >= 128 && !(tile_env != nullptr && tile_env[0] == '6')) {
-                const int zsplits = (K + kps - 1) / kps;
-                const long nb128 = (long)((M + 127) / 128) * ((N + 127) / 128) * zsplits;
-                const bool wide = N > 64 && 2 * nb128 >= 3L * howl_num_cus();
-                const dim3 bgrid(wide ? (N + 127) / 128 : (N + 63) / 64, (M + 127) / 128, zsplits);
-#define HOWL_GEMM_BIG(AK, BK, KL)                                                                                              \
-    do {                                                                                                                       \
-        if (wide)                                                                                                              \
-            hipLaunchKernelGGL((gemm_big_kernel<AK, BK, KL, 128>), bgrid, dim3(256), 0, s, a, amap, b, bmap, M, N, K, kps,     \
-                               bias, relu, c, c_ms, c_split_stride);                                                           \
-        else                                                                                                                   \
-            hipLaunchKernelGGL((gemm_big_kernel<AK, BK, KL, 64>), bgrid, dim3(256), 0, s, a, amap, b, bmap, M, N, K, kps,      \
-                               bias, relu, c, c_ms, c_split_stride);                                                           \
-    } while (0)
-#define HOWL_GEMM_BIG2(AK, BK)               \
-    do {                                     \
-        if (klin) HOWL_GEMM_BIG(AK, BK, true); \
-        else HOWL_GEMM_BIG(AK, BK, false);   \
-    } while (0)
-                if (a_major_k && b_unit_k) HOWL_GEMM_BIG2(true, true);
-                else if (a_major_k) HOWL_GEMM_BIG2(true, false);
-                else if (b_unit_k) HOWL_GEMM_BIG2(false, true);
-                else HOWL_GEMM_BIG2(false, false);
-#undef HOWL_GEMM_BIG2
-#undef HOWL_GEMM_BIG
-                return zsplits;
-            }
 #define HOWL_GEMM_VEC(AK, BK)                                                                                                  \
     do {                                                                                                                       \
         if (klin)                                                                                                              \

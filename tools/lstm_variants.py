@@ -12,15 +12,18 @@ SRC = ROOT / "howl_amd" / "csrc" / "lstm.hip"
 OUT = ROOT / "build" / "diag"
 EDITS = {
     "base": [],
-    "nomfma": [("bcast_mfma64<0>(*reinterpret_cast<const float4*>(hcur + g * F4_HS + 64 * kh + 4 * j), wB, acc);",
-                "acc[0][0] = hcur[g * F4_HS + 64 * kh + 4 * j] * wB[0];"),
-               ("bcast_mfma64<0>(*reinterpret_cast<const float4*>(dgt + (lane & 3) * B4_DGS + 64 * kr + 4 * (lane >> 2)), wk, acc);",
+    "nomfma": [("        bcast_mfma64<0, 0>(alo, wB, acc);\n        bcast_mfma64<0, 64>(ahi, wB, acc);",
+                "        acc[0][0] = alo.x * wB[0] + ahi.x * wB[64];"),
+               ("bcast_mfma64<0, 0>(*reinterpret_cast<const float4*>(dgt + (lane & 3) * B4_DGS + 64 * kr + 4 * (lane >> 2)), wk, acc);",
                 "acc[0][0] = dgt[(lane & 3) * B4_DGS + 64 * kr + 4 * (lane >> 2)] * wk[0];")],
-    "nostore": [("        flush(t, scur);\n    }\n    if (g == 0) {", "    }\n    if (g == 0) {"),
-                ("                go[0] = di;\n                go[HID] = df;\n                go[2 * HID] = dg;\n                go[3 * HID] = dov;\n            }\n        }\n        __syncthreads();\n        // dh_{t-1}[seq][64 ch + lane]",
-                 "                if (t == 0) { go[0] = di; go[HID] = df; go[2 * HID] = dg; go[3 * HID] = dov; }\n            }\n        }\n        __syncthreads();\n        // dh_{t-1}[seq][64 ch + lane]")],
-    "noload": [("            for (int q = 0; q < 2; ++q) nx[q] = gx[gbase[q] + (size_t)(t + 1) * G4];", "            for (int q = 0; q < 2; ++q) nx[q] += 0.5f;"),
-               ("        fetch(t - 1, nxt);\n        if (cell) {", "        if (t == Tout - 1) fetch(t - 1, nxt);\n        if (cell) {")],
+    "nostore": [("            stg(gates, gb[r], act[r]);\n", "            if (t == 0) stg(gates, gb[r], act[r]);\n"),
+                ("        stg(cs, cb, cn);\n        stg(hseq, hb, live ? hn : 0.0f);      // padded outputs are zero\n",
+                 "        if (t == 0) stg(cs, cb, cn);\n"),
+                ("            go[0] = di;\n            go[HID] = df;\n            go[2 * HID] = dg;\n            go[3 * HID] = dov;\n            request(t - 1);",
+                 "            if (t == 0) { go[0] = di; go[HID] = df; go[2 * HID] = dg; go[3 * HID] = dov; }\n            request(t - 1);")],
+    "noload": [("            for (int r = 0; r < 4; ++r) nx[r] = ldg(gxn, gb[r]);\n        }\n        // A_j[i] comes from lane 4j+i: row i",
+                "            for (int r = 0; r < 4; ++r) nx[r] += gxn == gx ? 0.5f : 0.25f;\n        }\n        // A_j[i] comes from lane 4j+i: row i"),
+               ("            request(t - 1);\n        }\n        __syncthreads();", "            if (t == Tout - 1) request(t - 1);\n        }\n        __syncthreads();")],
 }
 
 
