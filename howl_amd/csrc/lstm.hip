@@ -63,10 +63,10 @@ __global__ void lstm_pack_kernel(const float* __restrict__ whh, float* __restric
         pf4[idx] = whh[((lane & 3) * HID + 16 * c + (lane >> 2)) * HID + kk];
     }
     if (pb4 != nullptr) {
-        // lstm_bwd4_kernel: wave w = (hidden-column chunk ch = w & 1, gate-column range kr = w >> 1); lane = column
-        // 64 ch + lane of dh, fragment = gate column 64 kr + frag:  W_hh[64 kr + frag][64 ch + lane]
-        const int ch = w & 1, kr = w >> 1;
-        pb4[idx] = whh[(64 * kr + frag) * HID + 64 * ch + lane];
+        // lstm_bwd4_kernel: [wave w8 = 0..7][k = 0..127][lane]; w8 = (hidden-column chunk ch = w8 & 1, gate-column range
+        // kr = w8 >> 1); lane = column 64 ch + lane of dh:  W_hh[128 kr + k][64 ch + lane]
+        const int w8 = w >> 1, kk = 64 * (w & 1) + frag;
+        pb4[idx] = whh[(128 * (w8 >> 1) + kk) * HID + 64 * (w8 & 1) + lane];
     }
     if (pf != nullptr) {
         const int a = frag >> 5, kk = frag & 31;
@@ -487,37 +487,36 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_bwd_kernel(const float* __r
 }
 
 // Backward recurrence with four sequences per workgroup (see lstm_fwd4_kernel): dh_{t-1}[4][128] = dG_t[4][512] . W_hh on
-// v_mfma_f32_4x4x1_16b_f32.  wave w = (hidden-column chunk ch = w & 1, gate-column range kr = w >> 1: 64 of the 512 K
-// values); four accumulator chains per wave; the eight K ranges meet in LDS and are summed in a fixed order by the thread
-// that owns the cell.  Threads 0..511 own one cell (sequence tid >> 7, unit tid & 127) each for the elementwise part.
+// v_mfma_f32_4x4x1_16b_f32.  Eight waves: wave w = (hidden-column chunk ch = w & 1, gate-column range kr = w >> 1: 128 of the
+// 512 K values, 128 W_hh registers per lane); the four K ranges meet in LDS and are summed in a fixed order by the thread that
+// owns the cell: thread (sequence tid >> 7, unit tid & 127) -- every thread has one.
 constexpr int B4_DGS = G4 + 4;          // dG rows in LDS (16-byte aligned rows for the float4 A-fragment reads)
 constexpr int B4_PS = HID + 4;
-__global__ __launch_bounds__(LSTM_THREADS) void lstm_bwd4_kernel(const float* __restrict__ dy, const float* __restrict__ dhT,
+constexpr int B8_THREADS = 512;
+__global__ __launch_bounds__(B8_THREADS) void lstm_bwd4_kernel(const float* __restrict__ dy, const float* __restrict__ dhT,
                                                                  const float* __restrict__ dcT, const float* __restrict__ pb4,
                                                                  const long long* __restrict__ lengths,
                                                                  const float* __restrict__ gates, const float* __restrict__ cs,
                                                                  const float* __restrict__ c0, float* __restrict__ dG,
                                                                  float* __restrict__ bpart, int B, int T, int Tout) {
     __shared__ __attribute__((aligned(16))) float dgt[4 * B4_DGS];   // this step's dG rows (MFMA A operand)
-    __shared__ float partd[8][4 * B4_PS];                             // the eight K ranges of dh_{t-1}
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ float partd[4][4 * B4_PS];                             // the four K ranges of dh_{t-1}
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ch = wave & 1, kr = wave >> 1;
     const int b0 = blockIdx.x * 4;
-    float wk[64];
+    float wk[128];
 #pragma unroll
-    for (int kk = 0; kk < 64; ++kk) wk[kk] = pb4[((size_t)wave * 64 + kk) * 64 + lane];
-    // elementwise part: one cell per thread (threads 512..1023 only multiply).  Sequences past the end of the batch are
-    // computed as copies of the last one (identical loads, identical stores, left out of the bias sums): no store of the
-    // step loop is conditional.
-    const bool cell = tid < 4 * HID;
-    const int s = (tid >> 7) & 3, u = tid & (HID - 1);
+    for (int kk = 0; kk < 128; ++kk) wk[kk] = pb4[((size_t)wave * 128 + kk) * 64 + lane];
+    // elementwise part: one cell per thread.  Sequences past the end of the batch are computed as copies of the last one
+    // (identical loads, identical stores, left out of the bias sums): no store of the step loop is conditional.
+    const int s = tid >> 7, u = tid & (HID - 1);
     const int b = min(b0 + s, B - 1);
     const bool dup = b0 + s >= B;
     const int len = lengths != nullptr ? (int)lengths[b] : T;
     float dc = dcT != nullptr ? dcT[(size_t)b * HID + u] : 0.0f;     // running dL/dc_t
     float dhp = dhT != nullptr ? dhT[(size_t)b * HID + u] : 0.0f;    // pass-through part of dL/dh_t
     float bs_i = 0.0f, bs_f = 0.0f, bs_g = 0.0f, bs_o = 0.0f;       // this cell's dG summed over the steps (bias gradient)
-    for (int i = tid; i < 8 * 4 * B4_PS; i += LSTM_THREADS) (&partd[0][0])[i] = 0.0f;
+    for (int i = tid; i < 4 * 4 * B4_PS; i += B8_THREADS) (&partd[0][0])[i] = 0.0f;
     struct Step {
         float ig, fg, gg, og, cn, cp, dyv;
     };
@@ -549,18 +548,16 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_bwd4_kernel(const float* __
         st.dyv = lv ? raw.dyv : 0.0f;
     };
     Step cur;
-    if (cell) {
-        request(Tout - 1);
-        take(Tout - 1, cur);
-    }
+    request(Tout - 1);
+    take(Tout - 1, cur);
     __syncthreads();
     __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0): the fragment loads are not the loop's business (see lstm_fwd4_kernel)
     for (int t = Tout - 1; t >= 0; --t) {
-        if (cell) {
+        {
             // dL/dh_t = (recurrent term from step t+1) + (pass-through when h was frozen) + (output gradient)
             float dh = dhp;
 #pragma unroll
-            for (int r = 0; r < 8; ++r) dh += partd[r][s * B4_PS + u];
+            for (int r = 0; r < 4; ++r) dh += partd[r][s * B4_PS + u];
             float di = 0.0f, df = 0.0f, dg = 0.0f, dov = 0.0f;
             if (t < len) {
                 dh += cur.dyv;
@@ -592,23 +589,26 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_bwd4_kernel(const float* __
             request(t - 1);
         }
         __syncthreads();
-        // dh_{t-1}[seq][64 ch + lane] (K range kr) = sum_k dG[seq][64 kr + k] * W_hh[64 kr + k][64 ch + lane]
+        // dh_{t-1}[seq][64 ch + lane] (K range kr) = sum_k dG[seq][128 kr + k] * W_hh[128 kr + k][64 ch + lane]
         f32x4 acc[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[e] = {0.0f, 0.0f, 0.0f, 0.0f};
-        // A_j[i] comes from lane 4j+i: this lane's four k values are gate columns 64 kr + 4j .. 4j+3 of sequence lane & 3
-        bcast_mfma64<0, 0>(*reinterpret_cast<const float4*>(dgt + (lane & 3) * B4_DGS + 64 * kr + 4 * (lane >> 2)), wk, acc);
+        // A_j[i] comes from lane 4j+i: this lane's k values are gate columns 128 kr + 4j .. 4j+3 and + 64 of sequence lane & 3
+        const float* arow = dgt + (lane & 3) * B4_DGS + 128 * kr + 4 * (lane >> 2);
+        const float4 alo = *reinterpret_cast<const float4*>(arow), ahi = *reinterpret_cast<const float4*>(arow + 64);
+        bcast_mfma64<0, 0>(alo, wk, acc);
+        bcast_mfma64<0, 64>(ahi, wk, acc);
         const f32x4 sum = (acc[0] + acc[1]) + (acc[2] + acc[3]);
 #pragma unroll
         for (int r = 0; r < 4; ++r) partd[kr][r * B4_PS + 64 * ch + lane] = sum[r];
         __builtin_amdgcn_sched_barrier(0);     // the saved activations are not touched before this point
-        if (cell) take(t - 1, cur);
+        take(t - 1, cur);
         __syncthreads();
     }
     if (dup) bs_i = bs_f = bs_g = bs_o = 0.0f;
     // bias gradient: column sums of dG over (sequence, step) -- the step sums are in registers, the four sequences meet in
     // the dG tile; bpart[workgroup][512] is folded with the weight gradients' split-K slabs (no pass over dG in HBM)
-    if (cell) {
+    {
         float* dr = dgt + s * B4_DGS + u;
         dr[0] = bs_i;
         dr[HID] = bs_f;
@@ -843,7 +843,10 @@ int howl_lstm_fwd(const HowlLstmParams* p, const float* x, int B, int T, int M, 
     hipLaunchKernelGGL(lstm_pack_kernel, dim3(16 * 64 * 64 / 256), dim3(256), 0, stream, p->w_hh, rows16 ? pf : nullptr,
                        rows16 ? pb : nullptr, rows16 ? nullptr : pf4, rows16 ? nullptr : pb4, p->b_ih, p->b_hh, bsum);
     // bias = b_ih + b_hh folded into the input projection: gx = x W_ih^T + bias   (B*T, 512), K = M
-    gemm(stream, true, x, lin(M), 1, lin(0), p->w_ih, lin(1), M, B * T, G4, M, 1, bsum, 0, sv->gx, G4, 0);
+    const int xf = sv->x_frames > 0 ? sv->x_frames : T;
+    HOWL_REQUIRE(xf >= T, "howl_lstm_fwd: x_frames=%d < T=%d", xf, T);
+    gemm(stream, true, x, xf == T ? lin(M) : RowMap{T, (long)xf * M, M}, 1, lin(0), p->w_ih, lin(1), M, B * T, G4, M, 1, bsum, 0,
+         sv->gx, G4, 0);
     if (sv->t_out < T)   // rows of steps that never run are read (times zero) by the weight-gradient GEMM: keep them finite
         hipMemsetAsync(sv->hseq, 0, (size_t)B * (T + 1) * HID * sizeof(float), stream);
     HowlProfScope prof("lstm_fwd", stream, 2.0 * HID * G4 * (double)B * sv->t_out);     // h_{t-1} W_hh^T of every step
@@ -879,7 +882,7 @@ int howl_lstm_bwd(const HowlLstmParams* p, const float* x, int B, int T, int M, 
     {
     HowlProfScope prof("lstm_bwd", stream, 2.0 * HID * G4 * (double)B * Tout);           // dG_t W_hh of every step
     if (!rows16)
-        hipLaunchKernelGGL(lstm_bwd4_kernel, dim3((B + 3) / 4), dim3(LSTM_THREADS), 0, stream, dy, dhT, dcT,
+        hipLaunchKernelGGL(lstm_bwd4_kernel, dim3((B + 3) / 4), dim3(B8_THREADS), 0, stream, dy, dhT, dcT,
                            (const float*)(scratch + 16 * 64 * 64),
                            lengths, (const float*)sv->gates, (const float*)sv->c, c0, sv->dgates, scratch_b, B, T, Tout);
     else
@@ -890,7 +893,9 @@ int howl_lstm_bwd(const HowlLstmParams* p, const float* x, int B, int T, int M, 
     // t >= t_out never ran and their dG rows are never written: the reductions walk rows (b, t < t_out) only.
     const bool full = Tout == T;
     const RowMap rows_g = full ? lin(G4) : RowMap{Tout, (long)T * G4, G4};
-    const RowMap rows_x = full ? lin(M) : RowMap{Tout, (long)T * M, M};
+    const int xf = sv->x_frames > 0 ? sv->x_frames : T;
+    HOWL_REQUIRE(xf >= T, "howl_lstm_bwd: x_frames=%d < T=%d", xf, T);
+    const RowMap rows_x = (full && xf == T) ? lin(M) : RowMap{Tout, (long)xf * M, M};
     const int rows = B * Tout;
     // 256 rows per K slice (up to 128 slices): the 512-row slices of the generic rule leave ~1 block per CU on these shapes
     HOWL_REQUIRE(M <= LSTM_MAX_IN, "howl_lstm_bwd: M=%d input features exceed the workspace layout (max %d)", M, LSTM_MAX_IN);

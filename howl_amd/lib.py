@@ -53,7 +53,7 @@ class HowlHeadGrads(ctypes.Structure):
 
 
 class HowlLstmSaved(ctypes.Structure):
-    _fields_ = [("gx", P), ("gates", P), ("c", P), ("hseq", P), ("dgates", P), ("t_out", c_int)]
+    _fields_ = [("gx", P), ("gates", P), ("c", P), ("hseq", P), ("dgates", P), ("t_out", c_int), ("x_frames", c_int)]
 
 
 class HowlMbLayer(ctypes.Structure):

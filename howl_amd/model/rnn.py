@@ -32,8 +32,18 @@ def _vp(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
+def _x_frames(x):
+    """Frames per utterance of the buffer behind x (B,T,M): a leading-frames view of a longer (B,T_x,M) feature buffer is used in
+    place (``HowlLstmSaved.x_frames``)."""
+    M = x.shape[2]
+    if x.stride(2) != 1 or x.stride(1) != M or x.stride(0) % M or x.stride(0) < x.shape[1] * M:
+        raise ValueError("LSTM input must be a (B,T,M) tensor with contiguous rows and a whole number of frames per utterance")
+    return x.stride(0) // M
+
+
 def _lstm_forward_raw(x, lengths, t_out, h0, c0, w_ih, w_hh, b_ih, b_hh):
-    """``howl_lstm_fwd`` on x (B,T,M) contiguous: returns (hs (B,t_out,128) view, hT, cT, saved buffers for the backward)."""
+    """``howl_lstm_fwd`` on x (B,T,M), contiguous or the leading frames of a longer contiguous buffer: returns (hs (B,t_out,128)
+    view, hT, cT, saved buffers for the backward)."""
     B, T, M = x.shape
     dev = x.device
     f32 = dict(dtype=torch.float32, device=dev)
@@ -42,7 +52,7 @@ def _lstm_forward_raw(x, lengths, t_out, h0, c0, w_ih, w_hh, b_ih, b_hh):
     ws = torch.empty(_lib.get().cdll.howl_lstm_workspace_bytes(B, T), dtype=torch.uint8, device=dev)
     hT, cT = torch.empty((B, HID), **f32), torch.empty((B, HID), **f32)
     prm = _lib.HowlLstmParams(_vp(w_ih), _vp(w_hh), _vp(b_ih), _vp(b_hh))
-    sv = _lib.HowlLstmSaved(_vp(bufs["gx"]), _vp(bufs["gates"]), _vp(bufs["c"]), _vp(bufs["hseq"]), None, t_out)
+    sv = _lib.HowlLstmSaved(_vp(bufs["gx"]), _vp(bufs["gates"]), _vp(bufs["c"]), _vp(bufs["hseq"]), None, t_out, _x_frames(x))
     _lib.get().call("howl_lstm_fwd", ctypes.byref(prm), _vp(x), B, T, M, _vp(lengths), _vp(h0), _vp(c0), ctypes.byref(sv),
                     _vp(hT), _vp(cT), _vp(ws), ws.numel(), ops._stream())
     saved = (x, lengths, c0, w_ih, w_hh, b_ih, b_hh, bufs["gates"], bufs["c"], bufs["hseq"], ws)
@@ -68,7 +78,7 @@ def _lstm_backward_raw(saved, t_out, d_hs, d_hT, d_cT, grads=None):
     if grads is None:
         grads = [torch.empty_like(p) for p in (w_ih, w_hh, b_ih, b_hh)]
     prm = _lib.HowlLstmParams(_vp(w_ih), _vp(w_hh), _vp(b_ih), _vp(b_hh))
-    sv = _lib.HowlLstmSaved(None, _vp(gates), _vp(cs), _vp(hseq), _vp(dgates), t_out)
+    sv = _lib.HowlLstmSaved(None, _vp(gates), _vp(cs), _vp(hseq), _vp(dgates), t_out, _x_frames(x))
     gr = _lib.HowlLstmGrads(*[_vp(g) for g in grads])
     _lib.get().call("howl_lstm_bwd", ctypes.byref(prm), _vp(x), B, T, M, _vp(lengths), _vp(c0), ctypes.byref(sv), _vp(dy),
                     _vp(d_hT), _vp(d_cT), ctypes.byref(gr), _vp(ws), ws.numel(), ops._stream())
@@ -189,9 +199,10 @@ class _LstmBase(RegisteredModel):
             lengths = lc.to(xb.device)
         else:
             t_out = T
-        if t_out < T:                                  # frames no sequence reaches: drop them up front (one small copy) so that
-            xb = xb[:, :t_out]                         # the kernels and the saved buffers only see t_out steps
-        if not xb.is_contiguous():                     # the fused frontend already hands over a (B,T,M) buffer
+        if t_out < T:                                  # frames no sequence reaches: the kernels and the saved buffers only see
+            xb = xb[:, :t_out]                         # t_out steps (a view: the library takes the buffer's frame stride)
+        M = xb.shape[2]
+        if xb.stride(2) != 1 or xb.stride(1) != M or xb.stride(0) % M:     # the fused frontend already hands over a (B,T,M) buffer
             xb = xb.contiguous()
         hx = self.streaming_state if self.is_streaming and self.streaming_state is not None else None
         if hx is not None and (tuple(hx[0].shape) != (1, B, HID) or tuple(hx[1].shape) != (1, B, HID)):

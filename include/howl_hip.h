@@ -245,6 +245,8 @@ typedef struct {
     float* hseq;   /* (B,T+1,128): hseq[b][0] = h0, hseq[b][t+1] = h_t (zero for t >= length, as pad_packed_sequence) */
     float* dgates; /* (B,T,512) gate pre-activation gradients (backward scratch) */
     int t_out;     /* number of steps to run = max(lengths) (host int; the reference syncs for it too) */
+    int x_frames;  /* frames per utterance in x's buffer (>= T): row (b, t) of x starts at (b * x_frames + t) * M floats, so
+                      that the first T frames of a longer feature buffer are used in place; 0 = T */
 } HowlLstmSaved;
 
 size_t howl_lstm_workspace_bytes(int B, int T);

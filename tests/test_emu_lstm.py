@@ -15,15 +15,19 @@ def lib():
     return emu_lib()
 
 
-def run_lstm(lib, sd, x_btm, lengths, h0=None, c0=None):
+def run_lstm(lib, sd, x_btm, lengths, h0=None, c0=None, x_frames=0):
+    """x_frames > T: x_btm is the flat (B, x_frames, M) buffer whose first T frames per utterance are the input."""
     B, T, M = x_btm.shape
+    if x_frames:
+        assert x_btm.shape[1] == x_frames and lengths is not None
+        T = int(lengths.max())
     npz = {k: np.ascontiguousarray(sd["lstm." + k].numpy()) for k in ("weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0")}
     prm = HowlLstmParams(ptr(npz["weight_ih_l0"]), ptr(npz["weight_hh_l0"]), ptr(npz["bias_ih_l0"]), ptr(npz["bias_hh_l0"]))
     bufs = dict(gx=np.zeros((B, T, 512), np.float32), gates=np.zeros((B, T, 512), np.float32),
                 c=np.zeros((B, T, 128), np.float32), hseq=np.full((B, T + 1, 128), np.nan, np.float32),
                 dgates=np.full((B, T, 512), np.nan, np.float32))   # rows t >= t_out must never be read
     t_out = int(lengths.max()) if lengths is not None else T
-    sv = HowlLstmSaved(ptr(bufs["gx"]), ptr(bufs["gates"]), ptr(bufs["c"]), ptr(bufs["hseq"]), ptr(bufs["dgates"]), t_out)
+    sv = HowlLstmSaved(ptr(bufs["gx"]), ptr(bufs["gates"]), ptr(bufs["c"]), ptr(bufs["hseq"]), ptr(bufs["dgates"]), t_out, x_frames)
     hT, cT = np.zeros((B, 128), np.float32), np.zeros((B, 128), np.float32)
     ws = np.zeros(lib.cdll.howl_lstm_workspace_bytes(B, T), np.uint8)
     x = np.ascontiguousarray(x_btm, np.float32)
@@ -80,6 +84,30 @@ def test_lstm_forward_backward_ragged(lib, golden, monkeypatch, rows):
     for k in ("weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0"):
         ref = p["lstm." + k].grad.numpy()
         np.testing.assert_allclose(gr[k], ref, rtol=0, atol=2e-5 * max(1.0, np.abs(ref).max()), err_msg=k)
+
+
+def test_lstm_input_inside_a_longer_feature_buffer(lib):
+    """HowlLstmSaved.x_frames: the first T frames of a (B, T + 3, M) buffer used in place == the same frames copied out."""
+    rng = np.random.default_rng(5)
+    B, T, M = 5, 7, 40
+    xbuf = rng.standard_normal((B, T + 3, M)).astype(np.float32)
+    lengths = np.array([7, 7, 6, 4, 2], np.int64)
+    sd = om.lstm_init(5)
+    a, hTa, cTa, ka = run_lstm(lib, sd, np.ascontiguousarray(xbuf[:, :T]), lengths)
+    b, hTb, cTb, kb = run_lstm(lib, sd, xbuf, lengths, x_frames=T + 3)
+    np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(hTa, hTb)
+    dy = np.zeros((B, T, 128), np.float32)
+    dy[:] = rng.standard_normal((B, T, 128)).astype(np.float32)
+    out = []
+    for keep in (ka, kb):
+        gr = {k: np.full_like(v, np.nan) for k, v in keep["npz"].items()}
+        grads = HowlLstmGrads(ptr(gr["weight_ih_l0"]), ptr(gr["weight_hh_l0"]), ptr(gr["bias_ih_l0"]), ptr(gr["bias_hh_l0"]))
+        lib.call("howl_lstm_bwd", ctypes.byref(keep["prm"]), ptr(keep["x"]), B, T, M, ptr(keep["ln"]), None, ctypes.byref(keep["sv"]),
+                 ptr(dy), None, None, ctypes.byref(grads), ptr(keep["ws"]), keep["ws"].size, None)
+        out.append(gr)
+    for k in out[0]:
+        np.testing.assert_array_equal(out[0][k], out[1][k], err_msg=k)
 
 
 def test_lstm_streaming_carry_and_no_lengths(lib):
