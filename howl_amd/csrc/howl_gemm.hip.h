@@ -308,7 +308,15 @@ __global__ __launch_bounds__(256) void sum_slabs_multi_kernel(SlabJobs jobs) {
     if ((long)blockIdx.x * 64 >= jb.n) return;
     float s[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     if (i < jb.n) {
+        // eight loads in flight per lane: the long jobs (128 .. 512 slabs) are a chain of dependent round trips otherwise
         int g = rg;
+        for (; g + 28 < jb.nparts; g += 32) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = jb.part[(long)(g + 4 * u) * jb.stride + i];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s[u & 3] += v[u];
+        }
         for (; g + 12 < jb.nparts; g += 16) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) s[u] += jb.part[(long)(g + 4 * u) * jb.stride + i];

@@ -47,33 +47,21 @@ __device__ __forceinline__ float tanhf_(float x) {
 //             B[k][n] = W_hh[256kh + 4kk + k][16nt + n]      (dh = dG . W_hh)
 // packed as [wave][frag 0..63][lane]
 // ---------------------------------------------------------------------------------------------------------
+// (the four-sequence kernels read W_hh in place: their fragments are rows / coalesced columns of the matrix as it is)
 // The same launch folds the two bias vectors of the input projection (bsum = b_ih + b_hh).
 __global__ void lstm_pack_kernel(const float* __restrict__ whh, float* __restrict__ pf, float* __restrict__ pb,
-                                 float* __restrict__ pf4, float* __restrict__ pb4, const float* __restrict__ b_ih,
-                                 const float* __restrict__ b_hh, float* __restrict__ bsum) {
+                                 const float* __restrict__ b_ih, const float* __restrict__ b_hh, float* __restrict__ bsum) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= 16 * 64 * 64) return;
     if (idx < G4) bsum[idx] = b_ih[idx] + b_hh[idx];
     const int lane = idx & 63, frag = (idx >> 6) & 63, w = idx >> 12;
     const int k = lane >> 4, n = lane & 15;
-    if (pf4 != nullptr) {
-        // lstm_fwd4_kernel: [column chunk c = 0..7][k = 0..127][lane]; lane = 4 * unit_local + gate holds
-        // W_hh[gate * 128 + 16 c + unit_local][k]
-        const int c = w >> 1, kk = 64 * (w & 1) + frag;
-        pf4[idx] = whh[((lane & 3) * HID + 16 * c + (lane >> 2)) * HID + kk];
-    }
-    if (pb4 != nullptr) {
-        // lstm_bwd4_kernel: [wave w8 = 0..7][k = 0..127][lane]; w8 = (hidden-column chunk ch = w8 & 1, gate-column range
-        // kr = w8 >> 1); lane = column 64 ch + lane of dh:  W_hh[128 kr + k][64 ch + lane]
-        const int w8 = w >> 1, kk = 64 * (w & 1) + frag;
-        pb4[idx] = whh[(128 * (w8 >> 1) + kk) * HID + 64 * (w8 & 1) + lane];
-    }
-    if (pf != nullptr) {
+    {
         const int a = frag >> 5, kk = frag & 31;
         const int col = (2 * a + (n >> 3)) * HID + 8 * w + (n & 7);
         pf[idx] = whh[col * HID + 4 * kk + k];
     }
-    if (pb != nullptr) {
+    {
         const int nt = w & 7, kh = w >> 3;
         pb[idx] = whh[(256 * kh + 4 * frag + k) * HID + 16 * nt + n];
     }
@@ -133,7 +121,8 @@ __device__ __forceinline__ void quad_transpose(float (&v)[4], bool bit0, bool bi
 //   ONE barrier per step: h_t is double-buffered in LDS.
 constexpr int F8_THREADS = 512;
 constexpr int F8_HS = HID + 4;          // h rows in LDS (16-byte aligned rows for the float4 A-fragment reads)
-__global__ __launch_bounds__(F8_THREADS) void lstm_fwd4_kernel(const float* __restrict__ gx, const float* __restrict__ pf4,
+__global__ __launch_bounds__(F8_THREADS) void lstm_fwd4_kernel(const float* __restrict__ gx, const float* __restrict__ whh,
+                                                               const float* __restrict__ b_ih, const float* __restrict__ b_hh,
                                                                const long long* __restrict__ lengths,
                                                                const float* __restrict__ h0, const float* __restrict__ c0,
                                                                float* __restrict__ gates, float* __restrict__ cs,
@@ -146,9 +135,18 @@ __global__ __launch_bounds__(F8_THREADS) void lstm_fwd4_kernel(const float* __re
     const int u = 16 * c + j;                       // hidden unit of this lane's quad
     const int col = g * HID + u;                    // MFMA role: its gate column in PyTorch order (i, f, g, o)
     const int b0 = blockIdx.x * 4;
+    // W_hh[col][0..127] straight from the parameter (a 512-byte row per lane, 64 KB per wave out of L2) and the lane's bias
+    // b_ih[col] + b_hh[col], which the input projection leaves out for this kernel: no packing launch
     float wB[128];
 #pragma unroll
-    for (int kk = 0; kk < 128; ++kk) wB[kk] = pf4[((size_t)c * 128 + kk) * 64 + lane];
+    for (int q = 0; q < 32; ++q) {
+        const float4 v = *reinterpret_cast<const float4*>(whh + (size_t)col * HID + 4 * q);
+        wB[4 * q + 0] = v.x;
+        wB[4 * q + 1] = v.y;
+        wB[4 * q + 2] = v.z;
+        wB[4 * q + 3] = v.w;
+    }
+    const float bias = b_ih[col] + b_hh[col];
     // cell role: sequence g of the workgroup, unit u
     const int bc = min(b0 + g, B - 1);
     float cst = c0 != nullptr ? c0[(size_t)bc * HID + u] : 0.0f;
@@ -182,7 +180,7 @@ __global__ __launch_bounds__(F8_THREADS) void lstm_fwd4_kernel(const float* __re
         float* hnxt = hbuf[(t + 1) & 1];
         float pre[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) pre[r] = nx[r];
+        for (int r = 0; r < 4; ++r) pre[r] = nx[r] + bias;
         {   // next step's input-projection terms (the last step re-reads its own: an unconditional load keeps the count exact)
             const float* gxn = gx + (t + 1 < Tout ? G4 : 0);
 #pragma unroll
@@ -494,7 +492,7 @@ constexpr int B4_DGS = G4 + 4;          // dG rows in LDS (16-byte aligned rows 
 constexpr int B4_PS = HID + 4;
 constexpr int B8_THREADS = 512;
 __global__ __launch_bounds__(B8_THREADS) void lstm_bwd4_kernel(const float* __restrict__ dy, const float* __restrict__ dhT,
-                                                                 const float* __restrict__ dcT, const float* __restrict__ pb4,
+                                                                 const float* __restrict__ dcT, const float* __restrict__ whh,
                                                                  const long long* __restrict__ lengths,
                                                                  const float* __restrict__ gates, const float* __restrict__ cs,
                                                                  const float* __restrict__ c0, float* __restrict__ dG,
@@ -504,9 +502,9 @@ __global__ __launch_bounds__(B8_THREADS) void lstm_bwd4_kernel(const float* __re
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ch = wave & 1, kr = wave >> 1;
     const int b0 = blockIdx.x * 4;
-    float wk[128];
+    float wk[128];      // W_hh[128 kr + k][64 ch + lane], read in place (coalesced over the lanes)
 #pragma unroll
-    for (int kk = 0; kk < 128; ++kk) wk[kk] = pb4[((size_t)wave * 128 + kk) * 64 + lane];
+    for (int kk = 0; kk < 128; ++kk) wk[kk] = whh[(size_t)(128 * kr + kk) * HID + 64 * ch + lane];
     // elementwise part: one cell per thread.  Sequences past the end of the batch are computed as copies of the last one
     // (identical loads, identical stores, left out of the bias sums): no store of the step loop is conditional.
     const int s = tid >> 7, u = tid & (HID - 1);
@@ -834,25 +832,21 @@ int howl_lstm_fwd(const HowlLstmParams* p, const float* x, int B, int T, int M, 
     float* pf = static_cast<float*>(ws);
     float* pb = pf + 16 * 64 * 64;
     float* bsum = pb + 16 * 64 * 64;
-    // fragments for both recurrence variants (the 4-row pair lives at the head of the split-K scratch region, which nothing
-    // touches between this call and the recurrence of the backward call)
-    float* pf4 = bsum + G4;
-    float* pb4 = pf4 + 16 * 64 * 64;
     const bool rows16 = lstm_rows16(B, T);
-    // (only the fragments of the variant that runs are packed)
-    hipLaunchKernelGGL(lstm_pack_kernel, dim3(16 * 64 * 64 / 256), dim3(256), 0, stream, p->w_hh, rows16 ? pf : nullptr,
-                       rows16 ? pb : nullptr, rows16 ? nullptr : pf4, rows16 ? nullptr : pb4, p->b_ih, p->b_hh, bsum);
-    // bias = b_ih + b_hh folded into the input projection: gx = x W_ih^T + bias   (B*T, 512), K = M
+    // the 16-row recurrences take packed W_hh fragments and a folded bias (one launch); the 4-row ones read the parameters
+    // in place and add the bias themselves: gx = x W_ih^T (+ b_ih + b_hh)   (B*T, 512), K = M
+    if (rows16)
+        hipLaunchKernelGGL(lstm_pack_kernel, dim3(16 * 64 * 64 / 256), dim3(256), 0, stream, p->w_hh, pf, pb, p->b_ih, p->b_hh, bsum);
     const int xf = sv->x_frames > 0 ? sv->x_frames : T;
     HOWL_REQUIRE(xf >= T, "howl_lstm_fwd: x_frames=%d < T=%d", xf, T);
-    gemm(stream, true, x, xf == T ? lin(M) : RowMap{T, (long)xf * M, M}, 1, lin(0), p->w_ih, lin(1), M, B * T, G4, M, 1, bsum, 0,
-         sv->gx, G4, 0);
+    gemm(stream, true, x, xf == T ? lin(M) : RowMap{T, (long)xf * M, M}, 1, lin(0), p->w_ih, lin(1), M, B * T, G4, M, 1,
+         rows16 ? bsum : nullptr, 0, sv->gx, G4, 0);
     if (sv->t_out < T)   // rows of steps that never run are read (times zero) by the weight-gradient GEMM: keep them finite
         hipMemsetAsync(sv->hseq, 0, (size_t)B * (T + 1) * HID * sizeof(float), stream);
     HowlProfScope prof("lstm_fwd", stream, 2.0 * HID * G4 * (double)B * sv->t_out);     // h_{t-1} W_hh^T of every step
     if (!rows16) {
         hipLaunchKernelGGL(lstm_fwd4_kernel, dim3((B + 3) / 4), dim3(F8_THREADS), 0, stream, (const float*)sv->gx,
-                           (const float*)pf4, lengths, h0, c0, sv->gates, sv->c, sv->hseq, hT, cT, B, T, sv->t_out);
+                           p->w_hh, p->b_ih, p->b_hh, lengths, h0, c0, sv->gates, sv->c, sv->hseq, hT, cT, B, T, sv->t_out);
     } else {
         const size_t lds_fwd = (size_t)(2 * 16 * HS + 2 * 16 * 6 * HID) * sizeof(float);
         hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fwd);
@@ -883,8 +877,7 @@ int howl_lstm_bwd(const HowlLstmParams* p, const float* x, int B, int T, int M, 
     HowlProfScope prof("lstm_bwd", stream, 2.0 * HID * G4 * (double)B * Tout);           // dG_t W_hh of every step
     if (!rows16)
         hipLaunchKernelGGL(lstm_bwd4_kernel, dim3((B + 3) / 4), dim3(B8_THREADS), 0, stream, dy, dhT, dcT,
-                           (const float*)(scratch + 16 * 64 * 64),
-                           lengths, (const float*)sv->gates, (const float*)sv->c, c0, sv->dgates, scratch_b, B, T, Tout);
+                           p->w_hh, lengths, (const float*)sv->gates, (const float*)sv->c, c0, sv->dgates, scratch_b, B, T, Tout);
     else
         hipLaunchKernelGGL(lstm_bwd_kernel, dim3((B + 15) / 16), dim3(LSTM_THREADS), 0, stream, dy, dhT, dcT, (const float*)pb,
                            lengths, (const float*)sv->gates, (const float*)sv->c, c0, sv->dgates, B, T, Tout);
