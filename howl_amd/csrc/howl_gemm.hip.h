@@ -2,6 +2,7 @@
 // translation unit gets its own copy in an anonymous namespace): the generic fp32 MFMA GEMM with row maps and
 // split-K, deterministic slab / column sums, and their host-side launch helpers.
 #pragma once
+#include <algorithm>
 #include <cstdint>
 
 #include "howl_common.hip.h"
@@ -503,6 +504,121 @@ __global__ __launch_bounds__(256) void thin_wgrad_kernel(const float* __restrict
     }
 }
 
+// Weight gradient of a WIDE layer over many rows (the LSTM's W_hh / W_ih and the head's first layer: 128..512 outputs, 19,456 rows):
+//   part[z][m][n] = sum over the rows k of split z of dout[dm(k) + m] * in[im(k) + n]
+// Both operands are row-major with the reduction index as the ROW, so a K tile of sixteen rows goes to LDS as it is ([k][column],
+// 16-byte stores, no transpose) and a lane's fragment values are plain 4-byte reads.  128 (m) x TN (n) block tile, sixteen waves
+// (4 x 4, 32 x TN/4 each: four waves per SIMD, so that fragment reads, staging and address arithmetic of some run under the
+// MFMAs of others), two LDS buffers and two K tiles in flight in registers: one barrier per K tile, the next tile's stores
+// land while the other buffer is multiplied.  The launcher sizes the split count so that the grid is ONE block per CU (or two):
+// the 64 x 64 kernel moved every operand element through the cache hierarchy 2-8 times (160 MB for 50 MB of operands in the
+// W_hh gradient) and its 1216 blocks did not overlap their staging with their MFMAs; here each element is read once or twice.
+constexpr int WG_M = 128, WG_K = 16, WG_THREADS = 1024;
+template <int TN, bool KMAP_LIN>
+__global__ __launch_bounds__(WG_THREADS) void wgrad_big_kernel(const float* __restrict__ dout, RowMap dm,
+                                                              const float* __restrict__ in, RowMap im, int M, int N, int K,
+                                                              int k_per_split, float* __restrict__ part) {
+    constexpr int LDA = WG_M + 4, LDB = TN + 4;     // pitch = 4 mod 32 banks: the four k rows of a fragment read do not collide
+    constexpr int NJ = TN / 64;                     // 16-column tiles per wave (sixteen waves: 4 x 4, 32 x TN/4 each)
+    __shared__ __attribute__((aligned(16))) float As[2][WG_K * LDA];
+    __shared__ __attribute__((aligned(16))) float Bs[2][WG_K * LDB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 2, wc = wave & 3;
+    const int m0 = blockIdx.y * WG_M, n0 = blockIdx.x * TN;
+    const int kbeg = blockIdx.z * k_per_split, kend = min(K, kbeg + k_per_split);
+    // One 16-byte piece of ONE operand per thread and K tile (wave-uniform role): threads 0..511 carry dout's tile
+    // (k = t / 32, column 4 (t % 32)), threads 512.. the input's (TN = 128: the same map; TN = 64: k = t / 16, 256 threads).
+    const bool is_a = tid < 512;
+    const int t2 = tid & 511;
+    const int p_k = (is_a || TN == 128) ? t2 >> 5 : (t2 >> 4) & 15;
+    const int p_c = (is_a || TN == 128) ? (t2 & 31) * 4 : (t2 & 15) * 4;
+    const bool p_thread = is_a || TN == 128 || t2 < 256;
+    const float* src = is_a ? dout : in;
+    const RowMap rm = is_a ? dm : im;
+    const int col = is_a ? min(m0 + p_c, M - 4) : min(n0 + p_c, N - 4);      // clamped loads, zeroed when staged
+    const bool p_ok = p_thread && (is_a ? m0 + p_c < M : n0 + p_c < N);
+    float* const dst0 = is_a ? &As[0][p_k * LDA + p_c] : &Bs[0][p_k * LDB + p_c];
+    float* const dst1 = is_a ? &As[1][p_k * LDA + p_c] : &Bs[1][p_k * LDB + p_c];
+    // Row cursor: successive fetches are sixteen rows apart, so the two-level row maps ((b, t) rows of buffers with a gap per
+    // utterance) advance by addition -- one division at the start instead of one per K tile (~50 VALU instructions each).  Past
+    // the end of the split the cursor stays on the split's last row (the staged value is zeroed anyway).
+    int ck = min(kbeg + p_k, kend - 1);
+    int cin = KMAP_LIN ? 0 : ck % rm.inner;
+    long coff = KMAP_LIN ? (long)ck * rm.s_inner : (long)(ck / rm.inner) * rm.s_outer + (long)cin * rm.s_inner;
+    auto fetch = [&]() {     // loads the cursor's row and moves on: calls are in K-tile order (kbeg, kbeg + 16, ...)
+        const float4 v = *reinterpret_cast<const float4*>(src + coff + col);
+        const int step = min(WG_K, kend - 1 - ck);
+        ck += step;
+        coff += (long)step * rm.s_inner;
+        if (!KMAP_LIN) {
+            cin += step;
+            while (cin >= rm.inner) {
+                cin -= rm.inner;
+                coff += rm.s_outer - (long)rm.inner * rm.s_inner;
+            }
+        }
+        return v;
+    };
+    auto stage = [&](float* dst, float4 v, int k0) {
+        if (!(p_ok && k0 + p_k < kend)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p_thread) *reinterpret_cast<float4*>(dst) = v;
+    };
+    f32x4 acc[2][NJ];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = {0.0f, 0.0f, 0.0f, 0.0f};
+    auto multiply = [&](int buf) {
+        const float* as = &As[buf][(lane >> 4) * LDA + 32 * wr + (lane & 15)];
+        const float* bs = &Bs[buf][(lane >> 4) * LDB + (TN / 4) * wc + (lane & 15)];
+#pragma unroll
+        for (int ks = 0; ks < WG_K / 4; ++ks) {
+            float af[2], bf[NJ];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) af[i] = as[4 * ks * LDA + 16 * i];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) bf[j] = bs[4 * ks * LDB + 16 * j];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+    };
+    // Two K tiles per trip, no early exit (an odd tile count multiplies one all-zero tile at the end): with `break`s in the body
+    // the compiler's vmcnt bookkeeping gives up and every staging step waits for ALL outstanding loads (vmcnt(0)).
+    float4 v0 = fetch();
+    float4 v1 = fetch();      // past the end: clamped re-loads, staged as zeros
+    stage(dst0, v0, kbeg);
+    __syncthreads();
+    v0 = fetch();
+    const int pairs = ((kend - kbeg + WG_K - 1) / WG_K + 1) / 2;
+    int k0 = kbeg;
+    for (int p = 0; p < pairs; ++p, k0 += 2 * WG_K) {
+        __builtin_amdgcn_sched_barrier(0);   // keep the requests in front of the MFMAs
+        multiply(0);
+        stage(dst1, v1, k0 + WG_K);
+        __syncthreads();
+        v1 = fetch();
+        __builtin_amdgcn_sched_barrier(0);
+        multiply(1);
+        stage(dst0, v0, k0 + 2 * WG_K);
+        __syncthreads();
+        v0 = fetch();
+    }
+    float* pz = part + (long)blockIdx.z * M * N;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int n = n0 + (TN / 4) * wc + 16 * j + (lane & 15);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + 32 * wr + 16 * i + 4 * (lane >> 4) + r;
+                if (m < M && n < N) pz[(long)m * N + n] = acc[i][j][r];
+            }
+        }
+}
+
 // dW (N_out, K_in) = dOut^T (N_out x rows) . In (rows x K_in), rows given by row maps; split-K + deterministic sum
 // (scratch: splits x N_out x K_in floats, splits = clamp(rows / 512, 1, max_splits))
 void wgrad_gemm(hipStream_t s, const float* dout, RowMap dm, int n_out, const float* in, RowMap im, int k_in, int rows,
@@ -532,9 +648,33 @@ void wgrad_gemm(hipStream_t s, const float* dout, RowMap dm, int n_out, const fl
         hipLaunchKernelGGL(sum_slabs_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, s, (const float*)scratch, chunks, n, dw);
         return;
     }
-    // A(m = out col, k = row) = dout[dm(k) + m]  -> unit stride is m
-    const int z = gemm(s, false, dout, lin(1), 0, dm, in, im, 1, n_out, k_in, rows, splits, nullptr, 0, scratch, k_in,
-                       (long)n_out * k_in);
+    int z;
+    auto map4 = [](const RowMap& r) { return (r.s_outer & 3) == 0 && (r.s_inner & 3) == 0; };
+    auto al16 = [](const float* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    if (n_out >= 128 && rows >= 2048 && (n_out & 3) == 0 && (k_in & 3) == 0 && k_in >= 16 && map4(dm) && map4(im) && al16(dout) &&
+        al16(in) && max_splits >= 16) {
+        // wide layer, many rows: 128-row tiles, split count = one block per CU (two when the slabs stay small)
+        HowlProfScope prof("gemm", s, 2.0 * (double)n_out * k_in * rows);
+        const int tn = k_in > 64 ? 128 : 64;
+        const int tiles = ((n_out + WG_M - 1) / WG_M) * ((k_in + tn - 1) / tn);
+        int sp = std::max(1, howl_num_cus() / tiles);
+        sp = std::min(sp, max_splits);
+        int kps = ((rows + sp - 1) / sp + WG_K - 1) / WG_K * WG_K;
+        kps = std::max(kps, 4 * WG_K);
+        z = (rows + kps - 1) / kps;
+        const dim3 grid((k_in + tn - 1) / tn, (n_out + WG_M - 1) / WG_M, z);
+        const bool klin = is_lin(dm) && is_lin(im);
+        if (tn == 128) {
+            if (klin) hipLaunchKernelGGL((wgrad_big_kernel<128, true>), grid, dim3(WG_THREADS), 0, s, dout, dm, in, im, n_out, k_in, rows, kps, scratch);
+            else hipLaunchKernelGGL((wgrad_big_kernel<128, false>), grid, dim3(WG_THREADS), 0, s, dout, dm, in, im, n_out, k_in, rows, kps, scratch);
+        } else {
+            if (klin) hipLaunchKernelGGL((wgrad_big_kernel<64, true>), grid, dim3(WG_THREADS), 0, s, dout, dm, in, im, n_out, k_in, rows, kps, scratch);
+            else hipLaunchKernelGGL((wgrad_big_kernel<64, false>), grid, dim3(WG_THREADS), 0, s, dout, dm, in, im, n_out, k_in, rows, kps, scratch);
+        }
+    } else {
+        // A(m = out col, k = row) = dout[dm(k) + m]  -> unit stride is m
+        z = gemm(s, false, dout, lin(1), 0, dm, in, im, 1, n_out, k_in, rows, splits, nullptr, 0, scratch, k_in, (long)n_out * k_in);
+    }
     const long n = (long)n_out * k_in;
     if (defer != nullptr) {
         defer->add(scratch, z, n, dw);

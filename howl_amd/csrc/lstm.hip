@@ -629,7 +629,8 @@ __global__ __launch_bounds__(B8_THREADS) void lstm_bwd4_kernel(const float* __re
 // (replaces gemm + thin_wgrad + colsum + relu_bwd + colsum: 5 launches and three more passes over rows x n_hid)
 // ---------------------------------------------------------------------------------------------------------
 constexpr int HEAD_MAX_HID = 256;      // the vector kernels keep a 16-float (forward) / 8-float (backward) strip per lane
-constexpr int HEAD_BWD_BLOCKS = 512;   // row chunks of the backward pass = slabs of its partial sums
+constexpr int HEAD_BWD_BLOCKS = 512;
+constexpr int HEAD_W1_SPLITS = 128;     // split-K slabs of the first layer's weight gradient (one 128-row tile per CU)   // row chunks of the backward pass = slabs of its partial sums
 
 // sum over the 16 lanes of a DPP row, result in every lane
 __device__ __forceinline__ float row16_sum(float v) {
@@ -788,9 +789,9 @@ __global__ __launch_bounds__(256) void head_thin_bwd_kernel(const float* __restr
     }
 }
 
-// workspace of one Linear layer's backward on the GEMM path, in floats: split-K slabs of the weight gradient (64) + 256 slabs
+// workspace of one Linear layer's backward on the GEMM path, in floats: split-K slabs of the weight gradient (<= 128) + 256 slabs
 // of n_out for the bias column sums
-size_t linear_ws_floats(int n_out, int n_in) { return (size_t)64 * n_out * (n_in > 1 ? n_in : 1) + (size_t)256 * n_out + 64; }
+size_t linear_ws_floats(int n_out, int n_in) { return (size_t)HEAD_W1_SPLITS * n_out * (n_in > 1 ? n_in : 1) + (size_t)256 * n_out + 64; }
 
 bool head_is_thin(int n_hid, int n_out) { return n_out >= 1 && n_out <= 8 && n_hid <= HEAD_MAX_HID && (n_hid & 3) == 0; }
 
@@ -906,9 +907,9 @@ int howl_lstm_bwd(const HowlLstmParams* p, const float* x, int B, int T, int M, 
 }
 
 size_t howl_head_workspace_bytes(int n_in, int n_hid, int n_out) {
-    // [first layer: 64 split-K slabs of n_hid x n_in] [second layer, thin: HEAD_BWD_BLOCKS slabs of (n_out + 1) n_hid + n_out]
+    // [first layer: up to 128 split-K slabs of n_hid x n_in] [second layer, thin: HEAD_BWD_BLOCKS slabs of (n_out + 1) n_hid + n_out]
     // (other shapes: the GEMM path's slabs of both layers)
-    const size_t first = (size_t)64 * n_hid * n_in;
+    const size_t first = (size_t)HEAD_W1_SPLITS * n_hid * n_in;
     const size_t thin = (size_t)HEAD_BWD_BLOCKS * ((size_t)(n_out + 1) * n_hid + n_out);
     const size_t general = linear_ws_floats(n_hid, n_in) + linear_ws_floats(n_out, n_hid);
     const size_t a = first + thin + 64, b = general + 64;
@@ -953,7 +954,7 @@ int howl_head_bwd(const HowlHeadParams* p, const float* x, int rows_inner, long 
     const RowMap xm{rows_inner, s_outer, s_inner};
     SlabSums sums;
     if (head_is_thin(n_hid, n_out)) {
-        float* thin = first + (size_t)64 * n_hid * n_in;
+        float* thin = first + (size_t)HEAD_W1_SPLITS * n_hid * n_in;
         int rpb = (rows + HEAD_BWD_BLOCKS - 1) / HEAD_BWD_BLOCKS;
         rpb = (rpb + 7) / 8 * 8;
         const int blocks = (rows + rpb - 1) / rpb;
@@ -971,17 +972,17 @@ int howl_head_bwd(const HowlHeadParams* p, const float* x, int rows_inner, long 
     } else {
         // general shapes: second layer by the GEMM path (its own folds), ReLU mask, then the first layer below
         float* ws2 = first + linear_ws_floats(n_hid, n_in);
-        float* scratch_b2 = ws2 + (size_t)64 * n_out * n_hid;
+        float* scratch_b2 = ws2 + (size_t)HEAD_W1_SPLITS * n_out * n_hid;
         gemm(stream, true, dy2, lin(n_out), 1, lin(0), p->w2, lin(n_hid), 1, rows, n_hid, n_out, 1, nullptr, 0, dz1, n_hid, 0);
         hipLaunchKernelGGL(relu_bwd_kernel, dim3(1024), dim3(256), 0, stream, (const float*)dz1, y1, (long)rows * n_hid, dz1);
         wgrad_gemm(stream, dy2, lin(n_out), n_out, y1, lin(n_hid), n_hid, rows, ws2, g->w2, 64, 512, &sums);
         colsum(stream, dy2, lin(n_out), rows, n_out, scratch_b2, g->b2, nullptr, 256, 64, &sums);
-        float* scratch_b1 = first + (size_t)64 * n_hid * n_in;
+        float* scratch_b1 = first + (size_t)HEAD_W1_SPLITS * n_hid * n_in;
         colsum(stream, dz1, lin(n_hid), rows, n_hid, scratch_b1, g->b1, nullptr, 256, 64, &sums);
     }
     if (dx != nullptr)   // dx = dz1 W1
         gemm(stream, true, dz1, lin(n_hid), 1, lin(0), p->w1, lin(n_in), 1, rows, n_in, n_hid, 1, nullptr, 0, dx, n_in, 0);
-    wgrad_gemm(stream, dz1, lin(n_hid), n_hid, x, xm, n_in, rows, first, g->w1, 64, 512, &sums);
+    wgrad_gemm(stream, dz1, lin(n_hid), n_hid, x, xm, n_in, rows, first, g->w1, HEAD_W1_SPLITS, 512, &sums);
     if (!sums.flush(stream)) return HOWL_E_ARG;
     HOWL_CHECK_LAUNCH("howl_head_bwd");
     return HOWL_OK;

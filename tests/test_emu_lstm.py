@@ -122,10 +122,11 @@ def test_lstm_streaming_carry_and_no_lengths(lib):
 
 
 @pytest.mark.parametrize("rows,n_in,n_hid,n_out", [(77, 128, 256, 5), (1, 128, 256, 3), (300, 128, 256, 8), (41, 40, 64, 1),
-                                                   (50, 128, 256, 12), (33, 64, 320, 4)])
+                                                   (50, 128, 256, 12), (33, 64, 320, 4), (2100, 128, 256, 5)])
 def test_head_forward_backward(lib, rows, n_in, n_hid, n_out):
     """Linear - ReLU - Linear: the vector kernels (n_out <= 8, n_hid <= 256) and the GEMM path of the other shapes against
-    numpy in float64; x rows through a two-level row map as the (B, T+1, 128) hidden-state buffer has."""
+    numpy in float64; x rows through a two-level row map as the (B, T+1, 128) hidden-state buffer has; 2100 rows reach the
+    wide weight-gradient kernel (128-row tiles, one block per CU) for the first layer."""
     rng = np.random.default_rng(2 + rows)
     inner = 7 if rows % 7 == 0 else rows
     outer = rows // inner

@@ -9,8 +9,12 @@ ROOT = Path(__file__).resolve().parent.parent
 HDR = ROOT / "howl_amd" / "csrc" / "howl_gemm.hip.h"
 OUT = ROOT / "build" / "diag"
 VEC_STORE = "                if (m < M && n < N) cz[(long)m * c_ms + n] = acc[i][j][r];\n            }\n        }\n}\n\n// deterministic sum of `nparts` slabs"
+WG_STORE = "                if (m < M && n < N) pz[(long)m * N + n] = acc[i][j][r];"
 EDITS = {
     "gbase": [],
+    "wnostore": [(WG_STORE, WG_STORE.replace("if (m < M && n < N)", "if (m < M && n < N && acc[i][j][r] == 123.456f)"))],
+    "wnomfma": [("        multiply(0);\n        stage(1, va1, vb1, k0 + WG_K);", "        acc[0][0][0] += As[0][tid] * Bs[0][tid & 255];\n        stage(1, va1, vb1, k0 + WG_K);"),
+                ("        multiply(1);\n        stage(0, va0, vb0, k0 + 2 * WG_K);", "        acc[0][0][1] += As[1][tid] * Bs[1][tid & 255];\n        stage(0, va0, vb0, k0 + 2 * WG_K);")],
     "gnostore": [(VEC_STORE, VEC_STORE.replace("if (m < M && n < N)", "if (m < M && n < N && acc[i][j][r] == 123.456f)"))],
     "gnomfma": [("        __builtin_amdgcn_sched_barrier(0);   // keep the requests in front of the MFMAs (the scheduler sinks them otherwise)\n        multiply();\n        __syncthreads();\n        if (k0 + GK >= kend) break;",
                  "        __builtin_amdgcn_sched_barrier(0);\n        acc[0][0][0] += As[tid] * Bs[tid];\n        __syncthreads();\n        if (k0 + GK >= kend) break;"),
@@ -51,7 +55,7 @@ def run():
         f = next(d.rglob("*kernel_trace.csv"))
         r = subprocess.run([sys.executable, str(ROOT / "tools" / "step_timeline.py"), str(f)], capture_output=True, text=True)
         print("==", name)
-        print("\n".join(l for l in r.stdout.splitlines() if "gemm" in l or "step:" in l), flush=True)
+        print("\n".join(l for l in r.stdout.splitlines() if "gemm" in l or "wgrad" in l or "step:" in l), flush=True)
 
 
 if __name__ == "__main__":
