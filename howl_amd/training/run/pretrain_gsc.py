@@ -56,8 +56,8 @@ def main(argv=None):
 
     if args.synthetic:
         train = synthetic_bank(args.synthetic, max_len, num_labels, device, seed=1)
-        dev = synthetic_bank(max(args.synthetic // 8, 64), max_len, num_labels, device, seed=2)
-        test = synthetic_bank(max(args.synthetic // 8, 64), max_len, num_labels, device, seed=3)
+        dev = synthetic_bank(max(args.synthetic // 8, 16), max_len, num_labels, device, seed=2)
+        test = synthetic_bank(max(args.synthetic // 8, 16), max_len, num_labels, device, seed=3)
     else:
         splits = load_gsc_splits(Path(SETTINGS.dataset.dataset_path), SETTINGS.training.vocab)
         train, dev, test = (ClipBank([read_wav16k(p) for p, _ in s], [l for _, l in s], max_len, device) for s in splits)
