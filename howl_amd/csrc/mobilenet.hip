@@ -1897,7 +1897,17 @@ __global__ __launch_bounds__(256) void sum_jobs_kernel(MbSumJobs jobs) {
     if (i < n) {
         // eight slabs per trip, requested together from clamped rows and masked afterwards: jobs with few slabs (the wide late
         // layers have 7-24) are ONE round trip per wave instead of a chain of dependent ones
-        for (int gq = rg; gq < jb.nparts; gq += 32) {
+        int gq = rg;
+        // the first blocks' layers have ~1000 slabs of a few hundred outputs: sixteen in flight per lane (their fold is a chain of
+        // dependent round trips: 33 of them at eight per lane were most of this launch's 58 us)
+        for (; gq + 64 <= jb.nparts; gq += 64) {
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = jb.part[(long)(gq + 4 * u) * n + i];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) s[u & 3] += v[u];
+        }
+        for (; gq < jb.nparts; gq += 32) {
             float v[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
