@@ -263,7 +263,7 @@ def pmc_traffic(kernel="bwd_pair_kernel"):
     side doubled per the gfx950 correction in MI355X_MICROARCH.md).  Counters cannot be collected from inside this
     process, so the figure is the one measured on the same command line when the summary was taken (the file is named)."""
     import re
-    files = sorted((ROOT / "profiles").glob("*pmc*.txt"), key=lambda f: [int(x) for x in re.findall(r"\d+", f.name)])
+    files = sorted((ROOT / "profiles").glob("*pmc*.txt"), key=lambda f: ([int(x) for x in re.findall(r"\d+", f.name)], f.name))
     if not files:
         return None, None
     vals = []
