@@ -13,8 +13,8 @@ WG_STORE = "                if (m < M && n < N) pz[(long)m * N + n] = acc[i][j][
 EDITS = {
     "gbase": [],
     "wnostore": [(WG_STORE, WG_STORE.replace("if (m < M && n < N)", "if (m < M && n < N && acc[i][j][r] == 123.456f)"))],
-    "wnomfma": [("        multiply(0);\n        stage(1, va1, vb1, k0 + WG_K);", "        acc[0][0][0] += As[0][tid] * Bs[0][tid & 255];\n        stage(1, va1, vb1, k0 + WG_K);"),
-                ("        multiply(1);\n        stage(0, va0, vb0, k0 + 2 * WG_K);", "        acc[0][0][1] += As[1][tid] * Bs[1][tid & 255];\n        stage(0, va0, vb0, k0 + 2 * WG_K);")],
+    "wnomfma": [("        multiply(0);\n        stage(dst1, v1, k0 + WG_K);", "        acc[0][0][0] += As[0][tid] * Bs[0][tid & 255];\n        stage(dst1, v1, k0 + WG_K);"),
+                ("        multiply(1);\n        stage(dst0, v0, k0 + 2 * WG_K);", "        acc[0][0][1] += As[1][tid] * Bs[1][tid & 255];\n        stage(dst0, v0, k0 + 2 * WG_K);")],
     "gnostore": [(VEC_STORE, VEC_STORE.replace("if (m < M && n < N)", "if (m < M && n < N && acc[i][j][r] == 123.456f)"))],
     "gnomfma": [("        __builtin_amdgcn_sched_barrier(0);   // keep the requests in front of the MFMAs (the scheduler sinks them otherwise)\n        multiply();\n        __syncthreads();\n        if (k0 + GK >= kend) break;",
                  "        __builtin_amdgcn_sched_barrier(0);\n        acc[0][0][0] += As[tid] * Bs[tid];\n        __syncthreads();\n        if (k0 + GK >= kend) break;"),

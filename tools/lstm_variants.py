@@ -14,8 +14,8 @@ EDITS = {
     "base": [],
     "nomfma": [("        bcast_mfma64<0, 0>(alo, wB, acc);\n        bcast_mfma64<0, 64>(ahi, wB, acc);",
                 "        acc[0][0] = alo.x * wB[0] + ahi.x * wB[64];"),
-               ("bcast_mfma64<0, 0>(*reinterpret_cast<const float4*>(dgt + (lane & 3) * B4_DGS + 64 * kr + 4 * (lane >> 2)), wk, acc);",
-                "acc[0][0] = dgt[(lane & 3) * B4_DGS + 64 * kr + 4 * (lane >> 2)] * wk[0];")],
+               ("        bcast_mfma64<0, 0>(alo, wk, acc);\n        bcast_mfma64<0, 64>(ahi, wk, acc);",
+                "        acc[0][0] = alo.x * wk[0] + ahi.x * wk[64];")],
     "nostore": [("            stg(gates, gb[r], act[r]);\n", "            if (t == 0) stg(gates, gb[r], act[r]);\n"),
                 ("        stg(cs, cb, cn);\n        stg(hseq, hb, live ? hn : 0.0f);      // padded outputs are zero\n",
                  "        if (t == 0) stg(cs, cb, cn);\n"),
