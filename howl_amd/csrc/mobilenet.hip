@@ -1542,10 +1542,20 @@ __device__ __forceinline__ void dw_dgrad_body(const DwBwd& p, int cb, int by) {
                 }
 #pragma unroll
             for (int o = 0; o < DW_SEG; ++o) zj[o] = zjr[(long)min(iw0 + o, W - 1) * C];
+            // dz of the window, zero outside the gradient map (rows by okh, columns by their slot)
+            bool okc[NCOL];
+#pragma unroll
+            for (int j = 0; j < NCOL; ++j) okc[j] = owb + j >= 0 && owb + j < Wo;
 #pragma unroll
             for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-                for (int j = 0; j < NCOL; ++j) v[kh][j] = fmaf(ksc, v[kh][j], fmaf(kc1, vz[kh][j], kc0));
+                for (int j = 0; j < NCOL; ++j)
+                    v[kh][j] = (okh[kh] && okc[j]) ? fmaf(ksc, v[kh][j], fmaf(kc1, vz[kh][j], kc0)) : 0.0f;
+            // Which window slot a tap of input column iw0 + o reads is a compile-time fact (iw0 is a multiple of DW_SEG = 4, so the
+            // parity of iw0 + o + 1 - kw is that of o + 1 - kw): slot o + 2 - kw at stride 1; at stride 2 only taps with an even
+            // d = o + 1 - kw have an output column, slot d / 2 + 1.  (Measured: 3 % on the launch, which is not VALU-bound -- nor
+            // bound by address arithmetic: scalar row addresses changed nothing; tools/mb_variants.py: the data-gradient blocks are
+            // 90 % of the launch.)
 #pragma unroll
             for (int o = 0; o < DW_SEG; ++o) {
                 const int iw = iw0 + o;
@@ -1554,15 +1564,12 @@ __device__ __forceinline__ void dw_dgrad_body(const DwBwd& p, int cb, int by) {
                 for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
                     for (int kw = 0; kw < 3; ++kw) {
-                        const int nw = iw + 1 - kw;                        // = ow * s
-                        const int ow = (nw + STRIDE) / STRIDE - 1;
-                        const bool ok = okh[kh] && nw >= 0 && ow * STRIDE == nw && ow < Wo;
-                        // window slot of ow; clamped only to keep the (masked) register index inside the array
-                        const int j = min(max(ow - owb, 0), NCOL - 1);
-                        float gv = v[kh][0];
-#pragma unroll
-                        for (int qq = 1; qq < NCOL; ++qq) gv = (j == qq) ? v[kh][qq] : gv;
-                        acc = fmaf(ok ? wk[kh * 3 + kw] : 0.0f, gv, acc);
+                        if (STRIDE == 1) {
+                            acc = fmaf(wk[kh * 3 + kw], v[kh][o + 2 - kw], acc);
+                        } else {
+                            const int d = o + 1 - kw;
+                            if (d >= 0 && (d & 1) == 0) acc = fmaf(wk[kh * 3 + kw], v[kh][d / 2 + 1], acc);
+                        }
                     }
                 if (iw < W) {
                     const bool pass = mb_act_passes(fmaf(zj[o], jsc, jsh), e.act);
