@@ -9,11 +9,12 @@
 // (B,T,512), cell c (B,T,128), hidden hseq (B,T+1,128) with hseq[b][0] = h0 and hseq[b][t+1] = h_t, so that both
 // "h_t" and "h_{t-1}" are plain strided views for the GEMMs.
 //
-// The recurrence is the latency-critical part: 38-81 strictly sequential steps.  One workgroup owns 16 sequences (one
-// MFMA M tile) and all 512 gate columns; its 16 waves keep the whole W_hh (256 KB as 1024 B-fragments, 64 VGPRs per
-// lane) in registers for the entire launch; h_t lives in LDS; the gate columns are permuted so that each wave holds
-// i,f,g,o of the same 8 hidden units and the cell update is register-local (one xor-8 shuffle).  One barrier per step.
-// The input projection x W_ih^T and all weight gradients are batched GEMMs outside the recurrence (gemm_kernel).
+// The recurrence is the latency-critical part: 38-81 strictly sequential steps, W_hh (256 KB) held in registers for the whole
+// launch, h_t in LDS.  Two kernel pairs: FOUR sequences per workgroup on v_mfma_f32_4x4x1 (lstm_fwd4 / lstm_bwd4: eight waves,
+// 128 W_hh registers per lane, the MFMA A operand by block broadcast; used up to 8 x CUs sequences per GPU) and SIXTEEN per
+// workgroup on v_mfma_f32_16x16x4 (lstm_fwd / lstm_bwd: sixteen waves, gate columns permuted so that each wave holds i,f,g,o of
+// the same 8 hidden units) beyond.  The input projection x W_ih^T, the head's first layer and all weight gradients are batched
+// GEMMs outside the recurrence (howl_gemm.hip.h); the head's thin second layer is vector work (head_out / head_thin_bwd).
 #include "howl_common.hip.h"
 #include "../../include/howl_hip.h"
 #include "howl_gemm.hip.h"
@@ -811,8 +812,8 @@ bool lstm_rows16(int B, int T) {
 extern "C" {
 
 size_t howl_lstm_workspace_bytes(int B, int T) {
-    // packed W_hh (2 x 64K floats) + bias sum (512) + split-K scratch of the W_hh gradient (128 x 512 x 128; its head also
-    // holds the 4-row fragments) + the W_ih gradient's own scratch (128 x 512 x 48 at most) + the bias column sums' (256 x 512):
+    // packed W_hh of the 16-row recurrences (2 x 64K floats) + bias sum (512) + split-K scratch of the W_hh gradient
+    // (128 x 512 x 128) + the W_ih gradient's own scratch (128 x 512 x 48 at most) + the bias column sums' (256 x 512):
     // three regions, so that the three final slab sums can run as one launch (the bias region holds one slab per workgroup
     // of the four-sequence recurrence, or the 256 of the column-sum kernel)
     const size_t bias_slabs = (size_t)(B + 3) / 4 > 256 ? (size_t)(B + 3) / 4 : 256;
