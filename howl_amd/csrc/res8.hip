@@ -1141,7 +1141,7 @@ __global__ __launch_bounds__(C0M_THREADS) void conv0_fwd_mfma_kernel(const float
                                                                     float* __restrict__ s0, unsigned short* __restrict__ mask0,
                                                                     int B, int T, int M, int H, int nconv, HowlPtrs6 cw,
                                                                     float* __restrict__ wp_fwd, float* __restrict__ wp_bwd,
-                                                                    int nwin, int win_step, int win_last) {
+                                                                    int nwin, int win_step, int win_last, int slices) {
     if ((int)blockIdx.x >= nconv) {
         const int e = ((int)blockIdx.x - nconv) * C0M_THREADS + (int)threadIdx.x;   // (mode, layer, fragment element)
         if (e < 2 * 6 * PACK_ELEMS) pack_weights_one(cw, wp_fwd, wp_bwd, (e / PACK_ELEMS) % 6, e / (6 * PACK_ELEMS), e % PACK_ELEMS);
@@ -1170,17 +1170,22 @@ __global__ __launch_bounds__(C0M_THREADS) void conv0_fwd_mfma_kernel(const float
         aoff[ks] = (tap / 3) * pitch + tap % 3 + n;
     }
     if (tid < 16) tin[(T + 2) * pitch + tid] = 0.0f;  // slack read by the padding cells
-    for (int b = blockIdx.x; b < B; b += nconv) {
+    // Small batches: `slices` workgroups share an utterance's pooled rows (one utterance costs a workgroup ~20 us whatever the
+    // batch: at B <= 64 that was the whole launch with three quarters of the CUs idle); work item = (utterance, slice).
+    for (int item = blockIdx.x; item < B * slices; item += nconv) {
+        const int b = item / slices, sl = item - b * slices;
+        const int ph0 = (sl * H) / slices, ph1 = ((sl + 1) * H) / slices;
         __syncthreads();
         // long inputs (howl_res8_fwd_long): "utterance" b is window b % nwin of clip b / nwin, T frames from its start frame
         const int clip = b / nwin, wi = b - clip * nwin;
         const int t0 = min(wi * win_step, win_last);
         load_feat_tile(tin, feat + (long)clip * sb + (long)t0 * st, 0, st, sm, 0, T, M, tid, C0M_THREADS);
         __syncthreads();
-        for (int ph = wave; ph < H; ph += C0M_THREADS / 64) {
-            const float* rowp = tin + 3 * ph * pitch;
-#pragma unroll
-            for (int blk = 0; blk < 3; ++blk) {
+        // units (pooled row, 16-bin block) of this slice, dealt to the waves
+        for (int u = wave; u < 3 * (ph1 - ph0); u += C0M_THREADS / 64) {
+            const int ph = ph0 + u / 3, blk = u - 3 * (u / 3);
+            const float* rowp = tin + 3 * ph * pitch + 16 * blk;
+            {
                 f32x4 acc[3][3];  // [frame tl][cout tile nt]
 #pragma unroll
                 for (int tl = 0; tl < 3; ++tl)
@@ -1190,7 +1195,7 @@ __global__ __launch_bounds__(C0M_THREADS) void conv0_fwd_mfma_kernel(const float
                 for (int tl = 0; tl < 3; ++tl)
 #pragma unroll
                     for (int ks = 0; ks < 3; ++ks) {
-                        const float a = rowp[aoff[ks] + tl * pitch + 16 * blk];
+                        const float a = rowp[aoff[ks] + tl * pitch];
 #pragma unroll
                         for (int nt = 0; nt < 3; ++nt)
 #if defined(HOWL_DIAG_C0_NOMFMA)   // diagnostic build (tools/variants.py): everything but the matrix pipe
@@ -1233,7 +1238,8 @@ constexpr int C0W_THREADS = 1024;  // weight gradient: 16 waves, four per SIMD (
 __global__ __launch_bounds__(C0W_THREADS) void conv0_wgrad_mfma_kernel(const float* __restrict__ feat, long sb, long st,
                                                                       long sm, const unsigned short* __restrict__ mask0,
                                                                       const float* __restrict__ ga, const float* __restrict__ gb,
-                                                                      float* __restrict__ part, int B, int T, int M, int H) {
+                                                                      float* __restrict__ part, int B, int T, int M, int H,
+                                                                      int slices) {
     HIP_DYNAMIC_SHARED(float, lds)
     float* tin = lds;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1253,32 +1259,38 @@ __global__ __launch_bounds__(C0W_THREADS) void conv0_wgrad_mfma_kernel(const flo
     f32x4 acc[3];
 #pragma unroll
     for (int mt = 0; mt < 3; ++mt) acc[mt] = {0.0f, 0.0f, 0.0f, 0.0f};
-    for (int b = blockIdx.x; b < B; b += gridDim.x) {
+    // work item = (utterance, slice of its pooled cells): see conv0_fwd_mfma_kernel
+    for (int item = blockIdx.x; item < B * slices; item += gridDim.x) {
+        const int b = item / slices, sl = item - b * slices;
+        const int c0 = (sl * P) / slices, c1 = ((sl + 1) * P) / slices, nc = c1 - c0;
         __syncthreads();
         load_feat_tile(tin, feat, sb, st, sm, b, T, M, tid, C0W_THREADS);
         const size_t ub = (size_t)b * NMAP * P;
-        for (int i0 = tid; i0 < NMAP * P; i0 += 8 * C0W_THREADS) {   // bulk, coalesced, 8 loads in flight per thread
-            float va[8], vb[8];
+        for (int i0 = tid; i0 < NMAP * nc; i0 += 8 * C0W_THREADS) {   // bulk, 8 loads in flight per thread: the slice's cells of
+            float va[8], vb[8];                                       // every channel (runs of nc consecutive values)
             unsigned short vm[8];
+            int at[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int i = i0 + j * C0W_THREADS;
-                const bool ok = i < NMAP * P;
-                va[j] = ok ? ga[ub + i] : 0.0f;
-                vb[j] = (ok && gb != nullptr) ? gb[ub + i] : 0.0f;
-                vm[j] = ok ? mask0[ub + i] : (unsigned short)0;
+                const bool ok = i < NMAP * nc;
+                const int ch = ok ? i / nc : 0;
+                at[j] = ch * P + c0 + (ok ? i - ch * nc : 0);
+                va[j] = ga[ub + at[j]];
+                vb[j] = gb != nullptr ? gb[ub + at[j]] : 0.0f;
+                vm[j] = mask0[ub + at[j]];
             }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int i = i0 + j * C0W_THREADS;
-                if (i < NMAP * P) {
-                    lg[i] = (va[j] + vb[j]) * (1.0f / 12.0f);
-                    lm[i] = vm[j];
+                if (i < NMAP * nc) {
+                    lg[at[j]] = (va[j] + vb[j]) * (1.0f / 12.0f);
+                    lm[at[j]] = vm[j];
                 }
             }
         }
         __syncthreads();
-        for (int cell = wave; cell < P; cell += C0W_THREADS / 64) {
+        for (int cell = c0 + wave; cell < c1; cell += C0W_THREADS / 64) {
             const int ph = cell / PW, pw = cell - ph * PW;
             const float* base = tin + 3 * ph * pitch + 4 * pw;
             float bfr[3];
@@ -1575,7 +1587,7 @@ size_t ws_layout(Ws* w, char* base, int B, int H, int G) {
     t.dsa = take(act);
     t.dsb = take(act);
     t.wpart = take((size_t)6 * G * CP * 432);
-    t.c0part = take((size_t)G * NMAP * 9);
+    t.c0part = take((size_t)max_parts * NMAP * 9);     // one row per workgroup of conv0's weight gradient (<= CUs with slicing)
     if (w) *w = t;
     return off;
 }
@@ -1602,6 +1614,12 @@ int conv_slices(int nblk, int H, int budget) {
     for (int sl = 4; sl > 1; sl >>= 1)
         if (nblk * sl <= budget && 4 * sl <= ntiles) return sl;
     return 1;
+}
+// conv0 (forward and weight gradient): up to eight workgroups share an utterance's pooled rows / cells while B * slices <= CUs
+int conv0_slices(int B) {
+    if (!slicing_enabled()) return 1;
+    int sl = howl_num_cus() / (B > 0 ? B : 1);
+    return sl < 1 ? 1 : (sl > 8 ? 8 : sl);
 }
 void pair_slices(int nblk, int H, int* sd, int* sw) {
     const int cus = howl_num_cus(), ntiles = (H * PW + 15) / 16;
@@ -1693,12 +1711,13 @@ int howl_res8_fwd(const HowlRes8Params* prm, const float* feat, long sb, long st
 
     const size_t l0 = ((size_t)(T + 2) * (M + 4) + 16) * sizeof(float);
     // 103 VGPRs and 15 KB of LDS: two workgroups per CU overlap one's tile load / stores with the other's MFMAs
-    const int G0 = B < 2 * howl_num_cus() ? B : 2 * howl_num_cus();
+    const int S0 = conv0_slices(B);
+    const int G0 = B * S0 < 2 * howl_num_cus() ? B * S0 : 2 * howl_num_cus();
     {
         HowlProfScope prof("conv0_fwd", stream);
         const int npack = (2 * 6 * PACK_ELEMS + C0M_THREADS - 1) / C0M_THREADS;
         hipLaunchKernelGGL(conv0_fwd_mfma_kernel, dim3(G0 + npack), dim3(C0M_THREADS), l0, stream, feat, sb, st, sm,
-                           prm->conv0_w, sv->s[0], sv->mask0, B, T, M, H, G0, cw, w.wp_fwd, w.wp_bwd, 1, 0, 0);
+                           prm->conv0_w, sv->s[0], sv->mask0, B, T, M, H, G0, cw, w.wp_fwd, w.wp_bwd, 1, 0, 0, S0);
     }
     const size_t lc = conv_lds_bytes(H);
     const double count = (double)B * (double)P;
@@ -1797,7 +1816,7 @@ int howl_res8_fwd_long(const HowlRes8Params* prm, const float* feat, long sb, lo
     const int npack = (2 * 6 * PACK_ELEMS + C0M_THREADS - 1) / C0M_THREADS;
     hipLaunchKernelGGL(conv0_fwd_mfma_kernel, dim3(G0 + npack), dim3(C0M_THREADS), l0, stream, feat, sb, st, sm, prm->conv0_w,
                        buf[0], (unsigned short*)nullptr, Bv, Tw, M, WIN_H, G0, cw, w.wp_fwd, w.wp_bwd, nw, 3 * WIN_STEP,
-                       3 * (H - WIN_H));
+                       3 * (H - WIN_H), 1);
     const size_t lc = conv_lds_bytes(WIN_H);
     const int G = conv_grid(Bv);
     const int SL = conv_slices(G, WIN_H, howl_num_cus());
@@ -1924,19 +1943,21 @@ int howl_res8_bwd_part(const HowlRes8Params* prm, const float* feat, long sb, lo
     HOWL_REQUIRE(sv->mask0 != nullptr, "howl_res8_bwd: saved->mask0 is required");
     HowlPtrs6 gw;
     for (int i = 0; i < 6; ++i) gw.p[i] = gr->conv_w[i];
+    const int S0 = conv0_slices(B);
+    const int G0w = B * S0 < howl_num_cus() ? B * S0 : howl_num_cus();   // conv0's weight-gradient grid: one partial row each
     if (part == 1)      // the six layers' weight gradients are final before conv0's is even started
         hipLaunchKernelGGL(reduce_rows_all_kernel, dim3((CP * 432 + 63) / 64, 6), dim3(256), 0, stream, (const float*)w.wpart,
-                           wpart_stride, Gh, gw, (const float*)w.c0part, G, gr->conv0_w, 0);
+                           wpart_stride, Gh, gw, (const float*)w.c0part, G0w, gr->conv0_w, 0);
     if (run_conv0) {
-        hipLaunchKernelGGL(conv0_wgrad_mfma_kernel, dim3(G), dim3(C0W_THREADS), l0w, stream, feat, sb, st, sm,
+        hipLaunchKernelGGL(conv0_wgrad_mfma_kernel, dim3(G0w), dim3(C0W_THREADS), l0w, stream, feat, sb, st, sm,
                            (const unsigned short*)sv->mask0,
-                           (const float*)dx_cur, (const float*)ds_prev, w.c0part, B, T, M, H);
+                           (const float*)dx_cur, (const float*)ds_prev, w.c0part, B, T, M, H, S0);
         if (part == 0)
             hipLaunchKernelGGL(reduce_rows_all_kernel, dim3((CP * 432 + 63) / 64, 7), dim3(256), 0, stream,
-                               (const float*)w.wpart, wpart_stride, Gh, gw, (const float*)w.c0part, G, gr->conv0_w, 0);
+                               (const float*)w.wpart, wpart_stride, Gh, gw, (const float*)w.c0part, G0w, gr->conv0_w, 0);
         else
             hipLaunchKernelGGL(reduce_rows_all_kernel, dim3((NMAP * 9 + 63) / 64, 1), dim3(256), 0, stream,
-                               (const float*)w.wpart, wpart_stride, Gh, gw, (const float*)w.c0part, G, gr->conv0_w, 6);
+                               (const float*)w.wpart, wpart_stride, Gh, gw, (const float*)w.c0part, G0w, gr->conv0_w, 6);
     }
     HOWL_CHECK_LAUNCH("howl_res8_bwd");
     return HOWL_OK;
