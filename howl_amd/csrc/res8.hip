@@ -899,6 +899,15 @@ __device__ __forceinline__ void reduce_rows_body(const float* __restrict__ part,
     if (col < ncols) {
         const float* src = part + col;
         int g = rg;
+        // eight rows in flight per lane (a wave's share of 128-256 partial rows is a chain of dependent round trips otherwise);
+        // the order of the additions is that of the rows either way
+        for (; g + 28 < nparts; g += 32) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(g + 4 * u) * ncols];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
         for (; g + 12 < nparts; g += 16) {
             const float v0 = src[(size_t)g * ncols], v1 = src[(size_t)(g + 4) * ncols];
             const float v2 = src[(size_t)(g + 8) * ncols], v3 = src[(size_t)(g + 12) * ncols];
@@ -1489,14 +1498,38 @@ __global__ __launch_bounds__(1024) void xent_kernel(const float* __restrict__ lo
     __shared__ double red[16];
     double acc = 0.0;
     const float invB = 1.0f / (float)B;
+    constexpr int XC = 32;      // rows of up to XC classes are held in registers: ONE round trip for the row instead of three
+                                // passes of dependent loads (run-time trip counts: ~10 us for 64 x 12 logits)
     for (int b = threadIdx.x; b < B; b += 1024) {
         const float* row = logits + (size_t)b * C;
+        const int y = (int)labels[b];
+        if (C <= XC) {
+            float v[XC];
+#pragma unroll
+            for (int k = 0; k < XC; ++k) v[k] = row[k < C ? k : C - 1];
+            float mx = v[0];
+#pragma unroll
+            for (int k = 1; k < XC; ++k) mx = k < C ? fmaxf(mx, v[k]) : mx;
+            float se = 0.0f;
+#pragma unroll
+            for (int k = 0; k < XC; ++k) se += k < C ? expf(v[k] - mx) : 0.0f;
+            const float lse = mx + logf(se);
+            float vy = v[0];
+#pragma unroll
+            for (int k = 1; k < XC; ++k) vy = k == y ? v[k] : vy;
+            acc += (double)(lse - vy);
+            if (dlogits != nullptr) {
+#pragma unroll
+                for (int k = 0; k < XC; ++k)
+                    if (k < C) dlogits[(size_t)b * C + k] = (expf(v[k] - lse) - (k == y ? 1.0f : 0.0f)) * invB;
+            }
+            continue;
+        }
         float mx = row[0];
         for (int k = 1; k < C; ++k) mx = fmaxf(mx, row[k]);
         float se = 0.0f;
         for (int k = 0; k < C; ++k) se += expf(row[k] - mx);
         const float lse = mx + logf(se);
-        const int y = (int)labels[b];
         acc += (double)(lse - row[y]);
         if (dlogits != nullptr)
             for (int k = 0; k < C; ++k)
