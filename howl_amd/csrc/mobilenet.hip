@@ -27,6 +27,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <type_traits>
 #include <vector>
 
 #include "howl_common.hip.h"
@@ -1417,7 +1418,12 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const float* __restrict__ x
         const int b = t / Ho, oh = t - b * Ho;
         const float* xb = x + (long)b * H * W * C + cc;
         float* zr = z + (long)t * Wo * C + cc;
-        for (int ow0 = 0; ow0 < Wo; ow0 += DW_SEG) {
+        // A segment of DW_SEG outputs.  FULL segments (all DW_SEG columns inside the row) store unconditionally -- lanes past the
+        // last channel are clamped to it and write its values again -- so that the loop body has no branch around a store: with one,
+        // the compiler waits for vmcnt(0) before the next segment's arithmetic, i.e. for the stores just issued (vmcnt counts
+        // loads and stores alike), and the store and load streams of a wave take turns instead of overlapping.
+        auto segment = [&](int ow0, auto full_tag) {
+            constexpr bool FULL = decltype(full_tag)::value;
             float v[3][NIN];
 #pragma unroll
             for (int kh = 0; kh < 3; ++kh) {
@@ -1445,13 +1451,20 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const float* __restrict__ x
                 for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
                     for (int kw = 0; kw < 3; ++kw) acc = fmaf(wk[kh * 3 + kw], v[kh][o * STRIDE + kw], acc);
-                if (ow0 + o < Wo) {
+                if (FULL) {
+                    zr[(long)(ow0 + o) * C] = acc;
+                    s += acc;
+                    q = fmaf(acc, acc, q);
+                } else if (ow0 + o < Wo) {
                     if (cok) zr[(long)(ow0 + o) * C] = acc;
                     s += acc;
                     q = fmaf(acc, acc, q);
                 }
             }
-        }
+        };
+        int ow0 = 0;
+        for (; ow0 + DW_SEG <= Wo; ow0 += DW_SEG) segment(ow0, std::true_type{});
+        if (ow0 < Wo) segment(ow0, std::false_type{});
     }
     if (arr.part1 == nullptr) return;
     if (rsub == 2) {
@@ -1528,7 +1541,9 @@ __device__ __forceinline__ void dw_dgrad_body(const DwBwd& p, int cb, int by) {
             okh[kh] = nh >= 0 && oh * STRIDE == nh && oh < Ho;
             ohs[kh] = min(max(oh, 0), Ho - 1);
         }
-        for (int iw0 = 0; iw0 < W; iw0 += DW_SEG) {
+        // (FULL segments store unconditionally, clamped lanes repeating the last channel's values: see dw_fwd_kernel)
+        auto segment = [&](int iw0, auto full_tag) {
+            constexpr bool FULL = decltype(full_tag)::value;
             // gradient columns that can touch inputs iw0 .. iw0+3: ow = (iw + 1 - kw) / s -> from floor((iw0 - 1) / s) upwards
             const int owb = (iw0 - 1 + STRIDE) / STRIDE - 1;
             float v[3][NCOL], vz[3][NCOL], zj[DW_SEG];
@@ -1571,15 +1586,18 @@ __device__ __forceinline__ void dw_dgrad_body(const DwBwd& p, int cb, int by) {
                             if (d >= 0 && (d & 1) == 0) acc = fmaf(wk[kh * 3 + kw], v[kh][d / 2 + 1], acc);
                         }
                     }
-                if (iw < W) {
+                if (FULL || iw < W) {
                     const bool pass = mb_act_passes(fmaf(zj[o], jsc, jsh), e.act);
                     const float gg = pass ? acc : 0.0f;
-                    if (cok) gjr[(long)iw * C] = gg;
+                    if (FULL || cok) gjr[(long)iw * C] = gg;
                     s1 += gg;
                     s2 = fmaf(gg, (zj[o] - jme) * jrs, s2);
                 }
             }
-        }
+        };
+        int iw0 = 0;
+        for (; iw0 + DW_SEG <= W; iw0 += DW_SEG) segment(iw0, std::true_type{});
+        if (iw0 < W) segment(iw0, std::false_type{});
     }
     if (rsub == 2) {
         s1 += __shfl_xor(s1, 32);

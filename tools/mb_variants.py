@@ -11,6 +11,10 @@ OUT = ROOT / "build" / "diag"
 EDITS = {
     "mbase": [],
     "mnowgrad": [("        dw_wgrad_body<STRIDE>(p, wb % p.ncb, wb / p.ncb);", "        if (p.C < 0) dw_wgrad_body<STRIDE>(p, wb % p.ncb, wb / p.ncb);")],
+    "mdg_nostore": [("                    if (FULL || cok) gjr[(long)iw * C] = gg;", "                    if ((FULL || cok) && gg == 123.456f) gjr[(long)iw * C] = gg;")],
+    "mdg_nowin": [("                    v[kh][j] = gb[((long)ohs[kh] * Wo + owc) * C];\n                    vz[kh][j] = zb[((long)ohs[kh] * Wo + owc) * C];",
+                   "                    v[kh][j] = ksc + j;\n                    vz[kh][j] = kc1 + kh;")],
+    "mdg_nozj": [("            for (int o = 0; o < DW_SEG; ++o) zj[o] = zjr[(long)min(iw0 + o, W - 1) * C];", "            for (int o = 0; o < DW_SEG; ++o) zj[o] = jsc + o;")],
     "mnodgrad": [("        dw_dgrad_body<STRIDE>(p, b % p.ncb, b / p.ncb);", "        if (p.C < 0) dw_dgrad_body<STRIDE>(p, b % p.ncb, b / p.ncb);")],
 }
 
