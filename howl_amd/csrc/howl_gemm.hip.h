@@ -392,8 +392,8 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
         part[(size_t)blockIdx.y * n + col] = (float)(((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane]);
 }
 
-// dz = dy * (y > 0), elementwise (ReLU backward of the head's hidden layer)
-__global__ void relu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, long n, float* __restrict__ dz) {
+// dz = dy * (y > 0), elementwise (ReLU backward of the head's hidden layer); dz may be dy (in place)
+__global__ void relu_bwd_kernel(const float* dy, const float* __restrict__ y, long n, float* dz) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
         dz[i] = y[i] > 0.0f ? dy[i] : 0.0f;
 }
