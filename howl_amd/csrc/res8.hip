@@ -1338,11 +1338,19 @@ __global__ __launch_bounds__(C0W_THREADS) void conv0_wgrad_mfma_kernel(const flo
 // ---------------------------------------------------------------------------------------------------------
 // head: BN6 -> spatial mean -> Linear(45, C)   (cnn.py:143-145), and its backward
 // ---------------------------------------------------------------------------------------------------------
+// With `labels` the same launch is also the loss of the training step, utterance by utterance (what howl_xent_fwd_bwd and the
+// first launch of the backward pass would do, same arithmetic in the same order): nll[b] = lse - logit[label],
+// dlogits[b] = (softmax - onehot) * inv_batch, dpool[b] = dlogits[b] . W_out.  The batch mean of nll is taken by
+// head_bwd_param_kernel.  Needs C <= HEAD_XC classes.
+constexpr int HEAD_XC = 64;
 __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__ s6, const float* __restrict__ stats,
                                                        const float* __restrict__ wout, const float* __restrict__ bout,
                                                        float* __restrict__ pooled, float* __restrict__ logits, int B,
-                                                       int P, int C) {
+                                                       int P, int C, const long long* __restrict__ labels,
+                                                       float* __restrict__ nll, float* __restrict__ dlogits,
+                                                       float* __restrict__ dpool, float inv_batch) {
     __shared__ float lp[CP];
+    __shared__ float ll[HEAD_XC], dl[HEAD_XC], lse_s;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int b = blockIdx.x; b < B; b += gridDim.x) {
         __syncthreads();
@@ -1377,6 +1385,32 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
             float acc = bout[k];
             for (int c = 0; c < NMAP; ++c) acc = fmaf(wout[k * NMAP + c], lp[c], acc);
             logits[(size_t)b * C + k] = acc;
+            if (labels != nullptr) ll[k] = acc;
+        }
+        if (labels == nullptr) continue;       // (uniform)
+        __syncthreads();
+        const int y = (int)labels[b];
+        if (tid == 0) {                        // the row's log-sum-exp exactly as xent_kernel takes it (serial, in class order)
+            float mx = ll[0];
+            for (int k = 1; k < C; ++k) mx = fmaxf(mx, ll[k]);
+            float se = 0.0f;
+            for (int k = 0; k < C; ++k) se += expf(ll[k] - mx);
+            const float lse = mx + logf(se);
+            lse_s = lse;
+            nll[b] = lse - ll[y];
+        }
+        __syncthreads();
+        if (tid < C) {
+            const float d = (expf(ll[tid] - lse_s) - (tid == y ? 1.0f : 0.0f)) * inv_batch;
+            dl[tid] = d;
+            dlogits[(size_t)b * C + tid] = d;
+        }
+        __syncthreads();
+        if (tid < CP) {                        // head_bwd_pool_kernel's sum
+            float acc = 0.0f;
+            if (tid < NMAP)
+                for (int k = 0; k < C; ++k) acc = fmaf(dl[k], wout[k * NMAP + tid], acc);
+            dpool[(size_t)b * CP + tid] = acc;
         }
     }
 }
@@ -1432,8 +1466,22 @@ __global__ __launch_bounds__(1024) void head_bwd_param_kernel(const float* __res
                                                               const float* __restrict__ pooled,
                                                               const float* __restrict__ dpool, float* __restrict__ dwout,
                                                               float* __restrict__ dbout, float* __restrict__ m12, int B,
-                                                              int C, int P) {
+                                                              int C, int P, const float* __restrict__ nll,
+                                                              float* __restrict__ loss) {
     __shared__ double red[2][16][64];
+    if ((int)blockIdx.x == C + 1) {      // mean of the per-utterance losses, in xent_kernel's summation order
+        double acc = 0.0;
+        for (int b = threadIdx.x; b < B; b += 1024) acc += (double)nll[b];
+        acc = wave_sum_d(acc);
+        if ((threadIdx.x & 63) == 0) red[0][threadIdx.x >> 6][0] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double tot = 0.0;
+            for (int w = 0; w < 16; ++w) tot += red[0][w][0];
+            loss[0] = (float)(tot / (double)B);
+        }
+        return;
+    }
     const int k = blockIdx.x, c = threadIdx.x & 63, bg = threadIdx.x >> 6;
     double a0 = 0.0, a1 = 0.0;
     // 16 rows per iteration, clamped unconditional loads: a loop with few rows per trip is serialised by the latency of
@@ -1719,9 +1767,16 @@ size_t howl_res8_workspace_bytes(int B, int T) {
     return ws_layout(nullptr, nullptr, B, H, conv_grid(B));
 }
 
-int howl_res8_fwd(const HowlRes8Params* prm, const float* feat, long sb, long st, long sm, int B, int T, int M, int C,
-                  int training, const HowlRes8Saved* sv, float* logits, void* ws, size_t ws_bytes, hipStream_t stream) {
+}  // extern "C"
+
+namespace {
+// howl_res8_fwd, optionally with the cross-entropy of the step in its last launch (labels != nullptr: see head_fwd_kernel)
+int res8_fwd_impl(const HowlRes8Params* prm, const float* feat, long sb, long st, long sm, int B, int T, int M, int C,
+                  int training, const HowlRes8Saved* sv, float* logits, void* ws, size_t ws_bytes, const long long* labels,
+                  float* nll, float* dlogits, hipStream_t stream) {
     HOWL_REQUIRE(prm && feat && sv && logits && ws, "howl_res8_fwd: null pointer");
+    HOWL_REQUIRE(labels == nullptr || (nll != nullptr && dlogits != nullptr && C <= HEAD_XC),
+                 "howl_res8_fwd_xent: nll / dlogits missing or more than %d classes (C=%d)", HEAD_XC, C);
     HOWL_REQUIRE(M == 40, "howl_res8_fwd: res8 pools (3,4) over 40 mel bins; got M=%d", M);
     const int H = T / 3;
     HOWL_REQUIRE(B >= 1 && H >= 1 && H <= MAX_H, "howl_res8_fwd: B=%d T=%d unsupported (3 <= T <= 83)", B, T);
@@ -1781,9 +1836,25 @@ int howl_res8_fwd(const HowlRes8Params* prm, const float* feat, long sb, long st
                            sv->bn_stats + (size_t)5 * 2 * CP,
                            HowlBnBuffers{prm->bn_running_mean[5], prm->bn_running_var[5], prm->bn_num_batches[5]});
     hipLaunchKernelGGL(head_fwd_kernel, dim3(B < 1024 ? B : 1024), dim3(256), 0, stream, sv->s[6],
-                       sv->bn_stats + (size_t)5 * 2 * CP, prm->out_w, prm->out_b, sv->pooled, logits, B, P, C);
+                       sv->bn_stats + (size_t)5 * 2 * CP, prm->out_w, prm->out_b, sv->pooled, logits, B, P, C, labels, nll, dlogits,
+                       w.dpool, 1.0f / (float)B);
     HOWL_CHECK_LAUNCH("howl_res8_fwd");
     return HOWL_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int howl_res8_fwd(const HowlRes8Params* prm, const float* feat, long sb, long st, long sm, int B, int T, int M, int C,
+                  int training, const HowlRes8Saved* sv, float* logits, void* ws, size_t ws_bytes, hipStream_t stream) {
+    return res8_fwd_impl(prm, feat, sb, st, sm, B, T, M, C, training, sv, logits, ws, ws_bytes, nullptr, nullptr, nullptr, stream);
+}
+
+int howl_res8_fwd_xent(const HowlRes8Params* prm, const float* feat, long sb, long st, long sm, int B, int T, int M, int C,
+                       const HowlRes8Saved* sv, const long long* labels, float* logits, float* nll, float* dlogits, void* ws,
+                       size_t ws_bytes, hipStream_t stream) {
+    HOWL_REQUIRE(labels && nll && dlogits, "howl_res8_fwd_xent: null pointer");
+    return res8_fwd_impl(prm, feat, sb, st, sm, B, T, M, C, 1, sv, logits, ws, ws_bytes, labels, nll, dlogits, stream);
 }
 
 // ---- long inputs (eval mode) --------------------------------------------------------------------------------------------------
@@ -1876,9 +1947,14 @@ int howl_res8_fwd_long(const HowlRes8Params* prm, const float* feat, long sb, lo
 // but conv0 runs under conv0's weight gradient: part 1 = head + layers 6..1 (data and weight gradients) + the fold of the six
 // layers' weight-gradient partials -- after it gr->conv_w[0..5], gr->out_w, gr->out_b are final; part 2 = conv0's weight
 // gradient and its fold (gr->conv0_w).  The two parts of a pass must be called in order with identical arguments.
-int howl_res8_bwd_part(const HowlRes8Params* prm, const float* feat, long sb, long st, long sm, int B, int T, int M, int C,
-                       const HowlRes8Saved* sv, const float* dlogits, const HowlRes8Grads* gr, void* ws, size_t ws_bytes,
-                       int part, hipStream_t stream) {
+}  // extern "C"
+
+namespace {
+// howl_res8_bwd_part; with nll != nullptr the pass follows howl_res8_fwd_xent: the pooled gradient is already in the workspace
+// and the batch mean of nll goes to `loss` (one more block of the head's parameter-gradient launch)
+int res8_bwd_impl(const HowlRes8Params* prm, const float* feat, long sb, long st, long sm, int B, int T, int M, int C,
+                  const HowlRes8Saved* sv, const float* dlogits, const HowlRes8Grads* gr, void* ws, size_t ws_bytes,
+                  int part, const float* nll, float* loss, hipStream_t stream) {
     HOWL_REQUIRE(prm && feat && sv && dlogits && gr && ws, "howl_res8_bwd: null pointer");
     HOWL_REQUIRE(part >= 0 && part <= 2, "howl_res8_bwd_part: part must be 0 (all), 1 or 2");
     const bool run_layers = part != 2, run_conv0 = part != 1;
@@ -1901,10 +1977,11 @@ int howl_res8_bwd_part(const HowlRes8Params* prm, const float* feat, long sb, lo
     if (eg > 2 * howl_num_cus()) eg = 2 * howl_num_cus();
 
     if (run_layers) {
-        hipLaunchKernelGGL(head_bwd_pool_kernel, dim3((B * CP + 255) / 256), dim3(256), 0, stream, dlogits, prm->out_w, w.dpool,
-                           B, C);
-        hipLaunchKernelGGL(head_bwd_param_kernel, dim3(C + 1), dim3(1024), 0, stream, dlogits, sv->pooled, w.dpool, gr->out_w,
-                           gr->out_b, w.m12, B, C, P);
+        if (nll == nullptr)
+            hipLaunchKernelGGL(head_bwd_pool_kernel, dim3((B * CP + 255) / 256), dim3(256), 0, stream, dlogits, prm->out_w, w.dpool,
+                               B, C);
+        hipLaunchKernelGGL(head_bwd_param_kernel, dim3(C + (nll != nullptr ? 2 : 1)), dim3(1024), 0, stream, dlogits, sv->pooled,
+                           w.dpool, gr->out_w, gr->out_b, w.m12, B, C, P, nll, loss);
     }
     const size_t lc = conv_lds_bytes(H);
     const size_t lw = wgrad_lds_bytes(H);
@@ -1996,10 +2073,27 @@ int howl_res8_bwd_part(const HowlRes8Params* prm, const float* feat, long sb, lo
     return HOWL_OK;
 }
 
+}  // namespace
+
+extern "C" {
+
+int howl_res8_bwd_part(const HowlRes8Params* prm, const float* feat, long sb, long st, long sm, int B, int T, int M, int C,
+                       const HowlRes8Saved* sv, const float* dlogits, const HowlRes8Grads* gr, void* ws, size_t ws_bytes,
+                       int part, hipStream_t stream) {
+    return res8_bwd_impl(prm, feat, sb, st, sm, B, T, M, C, sv, dlogits, gr, ws, ws_bytes, part, nullptr, nullptr, stream);
+}
+
 int howl_res8_bwd(const HowlRes8Params* prm, const float* feat, long sb, long st, long sm, int B, int T, int M, int C,
                   const HowlRes8Saved* sv, const float* dlogits, const HowlRes8Grads* gr, void* ws, size_t ws_bytes,
                   hipStream_t stream) {
-    return howl_res8_bwd_part(prm, feat, sb, st, sm, B, T, M, C, sv, dlogits, gr, ws, ws_bytes, 0, stream);
+    return res8_bwd_impl(prm, feat, sb, st, sm, B, T, M, C, sv, dlogits, gr, ws, ws_bytes, 0, nullptr, nullptr, stream);
+}
+
+int howl_res8_bwd_xent(const HowlRes8Params* prm, const float* feat, long sb, long st, long sm, int B, int T, int M, int C,
+                       const HowlRes8Saved* sv, const float* dlogits, const float* nll, float* loss, const HowlRes8Grads* gr,
+                       void* ws, size_t ws_bytes, int part, hipStream_t stream) {
+    HOWL_REQUIRE(nll && loss, "howl_res8_bwd_xent: null pointer");
+    return res8_bwd_impl(prm, feat, sb, st, sm, B, T, M, C, sv, dlogits, gr, ws, ws_bytes, part, nll, loss, stream);
 }
 
 int howl_xent_fwd_bwd(const float* logits, const long long* labels, int B, int C, float* loss, float* dlogits,

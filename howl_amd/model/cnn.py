@@ -170,12 +170,36 @@ class Res8(RegisteredModel, name="res8"):
                         ctypes.c_void_p(buf.ws.data_ptr()), buf.ws.numel(), ops._stream())
         return logits
 
+    XENT_MAX_LABELS = 64    # howl_res8_fwd_xent keeps a row of logits in LDS
+
+    def _launch_forward_xent(self, feat, labels):
+        """Training-mode forward with ``nn.CrossEntropyLoss()`` in its last launch (``howl_res8_fwd_xent``): returns (logits,
+        nll (B,), dlogits (B, C)); the mean loss comes out of ``_launch_backward(..., xent=(nll, loss))``.  Same bits as
+        ``_launch_forward`` + ``ops.xent`` + ``_launch_backward``, two launches fewer."""
+        x0, sb, st, sm = self._feat_view(feat)
+        B, M, T = x0.shape
+        if T > self.MAX_FRAMES or not self.training or self.num_labels > self.XENT_MAX_LABELS:
+            raise NotImplementedError("fused forward + cross-entropy: training mode, T <= 83 frames, <= 64 labels")
+        buf = self._get_buffers(B, T, x0.device)
+        f32 = dict(dtype=torch.float32, device=x0.device)
+        logits = torch.empty((B, self.num_labels), **f32)
+        nll, dlogits = torch.empty((B,), **f32), torch.empty((B, self.num_labels), **f32)
+        labels = labels.to(device=x0.device, dtype=torch.int64).contiguous()
+        prm = self._params_struct()
+        self._fwd_version += 1
+        _lib.get().call("howl_res8_fwd_xent", ctypes.byref(prm), ctypes.c_void_p(x0.data_ptr()), sb, st, sm, B, T, M,
+                        self.num_labels, ctypes.byref(buf.saved), _vp(labels), _vp(logits), _vp(nll), _vp(dlogits),
+                        ctypes.c_void_p(buf.ws.data_ptr()), buf.ws.numel(), ops._stream())
+        return logits, nll, dlogits
+
     # flat-buffer offset up to which gradients are final only after part 2 of a two-part backward (conv0.weight comes first)
     LATE_GRAD_PARAMS = 1
 
-    def _launch_backward(self, feat, dlogits, out_grads=None, part=0):
+    def _launch_backward(self, feat, dlogits, out_grads=None, part=0, xent=None):
         """``part`` 0: the whole pass; 1 then 2: the same pass in two calls, everything but conv0's gradient final after
-        the first (``howl_res8_bwd_part``; the data-parallel step starts its all-reduce in between)."""
+        the first (``howl_res8_bwd_part``; the data-parallel step starts its all-reduce in between).  ``xent`` = (nll, loss)
+        after ``_launch_forward_xent``: ``howl_res8_bwd_xent`` (the pooled gradient is in the workspace already; ``loss`` (1,)
+        receives the batch mean)."""
         if not self.training:
             raise NotImplementedError("Res8 backward is implemented for training-mode BatchNorm (batch statistics), "
                                       "the only mode the reference trains in")
@@ -191,6 +215,12 @@ class Res8(RegisteredModel, name="res8"):
         gr.out_w = _vp(grads[7])
         gr.out_b = _vp(grads[8])
         prm = self._params_struct()
+        if xent is not None:
+            nll, loss = xent
+            _lib.get().call("howl_res8_bwd_xent", ctypes.byref(prm), ctypes.c_void_p(x0.data_ptr()), sb, st, sm, B, T, M,
+                            self.num_labels, ctypes.byref(buf.saved), ctypes.c_void_p(dlogits.data_ptr()), _vp(nll), _vp(loss),
+                            ctypes.byref(gr), ctypes.c_void_p(buf.ws.data_ptr()), buf.ws.numel(), int(part), ops._stream())
+            return grads
         _lib.get().call("howl_res8_bwd_part", ctypes.byref(prm), ctypes.c_void_p(x0.data_ptr()), sb, st, sm, B, T, M,
                         self.num_labels, ctypes.byref(buf.saved), ctypes.c_void_p(dlogits.data_ptr()), ctypes.byref(gr),
                         ctypes.c_void_p(buf.ws.data_ptr()), buf.ws.numel(), int(part), ops._stream())

@@ -67,23 +67,31 @@ class FusedTrainer:
 
     def step_on_features(self, feat, labels, lengths=None, max_frames=None):
         """``lengths`` / ``max_frames``: frame counts for models that pack their input (``SimpleLstm``); ignored otherwise."""
-        if getattr(self.model, "NEEDS_LENGTHS", False):
-            logits = self.model._launch_forward(feat, lengths, max_frames)
+        bwd_kw = {}
+        fused_xent = (hasattr(self.model, "_launch_forward_xent") and self.model.num_labels <= self.model.XENT_MAX_LABELS
+                      and feat.shape[-1] <= self.model.MAX_FRAMES)
+        if fused_xent:     # res8: the loss rides in the forward's last launch and the backward's second (two launches fewer)
+            logits, nll, dlogits = self.model._launch_forward_xent(feat, labels)
+            loss = torch.empty(1, dtype=torch.float32, device=logits.device)
+            bwd_kw = dict(xent=(nll, loss))
         else:
-            logits = self.model._launch_forward(feat)
-        loss, dlogits = ops.xent(logits, labels)
+            if getattr(self.model, "NEEDS_LENGTHS", False):
+                logits = self.model._launch_forward(feat, lengths, max_frames)
+            else:
+                logits = self.model._launch_forward(feat)
+            loss, dlogits = ops.xent(logits, labels)
         late = getattr(self.model, "LATE_GRAD_PARAMS", 0)
         if self.world > 1 and late:
             # two-part backward: the all-reduce of everything but the first `late` parameters (res8: conv0.weight, whose
             # gradient needs the last data gradient) runs on the process group's stream while their kernels still execute
             n0 = sum(p.numel() for p in self.fp.params[:late])
-            self.model._launch_backward(feat, dlogits, out_grads=self.fp.grad_views, part=1)
+            self.model._launch_backward(feat, dlogits, out_grads=self.fp.grad_views, part=1, **bwd_kw)
             pending = parallel.allreduce_start_(self.fp.grad[n0:], self.group)
-            self.model._launch_backward(feat, dlogits, out_grads=self.fp.grad_views, part=2)
+            self.model._launch_backward(feat, dlogits, out_grads=self.fp.grad_views, part=2, **bwd_kw)
             scale = parallel.allreduce_sum_(self.fp.grad[:n0], self.group)
             pending.wait()
         else:
-            self.model._launch_backward(feat, dlogits, out_grads=self.fp.grad_views)
+            self.model._launch_backward(feat, dlogits, out_grads=self.fp.grad_views, **bwd_kw)
             scale = parallel.allreduce_sum_(self.fp.grad, self.group)
         self.step_count += 1
         ops.adamw_step(self.fp.flat, self.fp.grad, self.m, self.v, self.lr, self.betas, self.eps, self.weight_decay,

@@ -195,6 +195,19 @@ int howl_res8_bwd_part(const HowlRes8Params* prm, const float* feat, long sb, lo
                        const HowlRes8Saved* saved, const float* dlogits, const HowlRes8Grads* grads, void* ws,
                        size_t ws_bytes, int part, hipStream_t stream);
 
+/* The training step's forward + nn.CrossEntropyLoss() (pretrain_gsc.py:126-133) with the loss inside the forward's last launch:
+ * howl_res8_fwd (training mode) that also writes, per utterance, nll[b] = logsumexp(logits[b]) - logits[b][labels[b]] and
+ * dlogits[b] = (softmax(logits[b]) - onehot) / B, and leaves the pooled gradient in the workspace; C <= 64.  The backward
+ * pass that follows is howl_res8_bwd_xent: howl_res8_bwd_part (same `part` convention, same workspace) without its first
+ * launch, and with loss[0] = mean_b nll[b].  Same arithmetic in the same order as howl_res8_fwd + howl_xent_fwd_bwd +
+ * howl_res8_bwd (bit-identical logits, loss and gradients), two launches fewer. */
+int howl_res8_fwd_xent(const HowlRes8Params* prm, const float* feat, long sb, long st, long sm, int B, int T, int M, int C,
+                       const HowlRes8Saved* saved, const long long* labels, float* logits, float* nll, float* dlogits,
+                       void* ws, size_t ws_bytes, hipStream_t stream);
+int howl_res8_bwd_xent(const HowlRes8Params* prm, const float* feat, long sb, long st, long sm, int B, int T, int M, int C,
+                       const HowlRes8Saved* saved, const float* dlogits, const float* nll, float* loss,
+                       const HowlRes8Grads* grads, void* ws, size_t ws_bytes, int part, hipStream_t stream);
+
 /* mean cross-entropy over (B,C) logits with int64 labels and its gradient (dlogits may be NULL):
  * nn.CrossEntropyLoss() at pretrain_gsc.py:95,131 / train.py:251,293. */
 int howl_xent_fwd_bwd(const float* logits, const long long* labels, int B, int C, float* loss, float* dlogits,

@@ -228,3 +228,32 @@ print("RESULT" + json.dumps(out))
         got = np.asarray(res["8"]["1_81"]["grads"][n])
         want = g.numpy().reshape(-1)[:: max(1, g.numel() // 50)]
         np.testing.assert_allclose(got, want, rtol=0, atol=2e-5 * max(1.0, float(g.abs().max())), err_msg=n)
+
+
+def test_fused_forward_cross_entropy_is_bit_identical(lib):
+    """howl_res8_fwd_xent + howl_res8_bwd_xent (the loss inside the forward's last launch, the pooled gradient left in the
+    workspace, the batch mean taken by the backward's head launch) == howl_res8_fwd + howl_xent_fwd_bwd + howl_res8_bwd, bit
+    for bit: logits, loss, dlogits, every gradient and the BatchNorm buffers; both `part` conventions."""
+    B, T, C = 3, 41, 12
+    x = feats(B, T, 11)[:, 0].permute(0, 2, 1).numpy()
+    labels = np.array([3, 0, 11], np.int64)
+    ref = Res8Harness(lib, B, T, C)
+    logits = ref.fwd(x, training=True)
+    loss, dl = np.zeros(1, np.float32), np.zeros((B, C), np.float32)
+    lib.call("howl_xent_fwd_bwd", ptr(ref.logits), ptr(labels), B, C, ptr(loss), ptr(dl), None)
+    g_ref = ref.bwd(dl)
+    for parts in ((0,), (1, 2)):
+        h = Res8Harness(lib, B, T, C)
+        f = np.ascontiguousarray(x, np.float32)
+        nll, dl2, loss2 = np.full(B, np.nan, np.float32), np.full((B, C), np.nan, np.float32), np.full(1, np.nan, np.float32)
+        lib.call("howl_res8_fwd_xent", ctypes.byref(h.prm), ptr(f), T * 40, 40, 1, B, T, 40, C, ctypes.byref(h.saved), ptr(labels),
+                 ptr(h.logits), ptr(nll), ptr(dl2), ptr(h.ws), h.ws.size, None)
+        for part in parts:
+            lib.call("howl_res8_bwd_xent", ctypes.byref(h.prm), ptr(f), T * 40, 40, 1, B, T, 40, C, ctypes.byref(h.saved), ptr(dl2),
+                     ptr(nll), ptr(loss2), ctypes.byref(h.gr), ptr(h.ws), h.ws.size, part, None)
+        np.testing.assert_array_equal(h.logits, logits)
+        np.testing.assert_array_equal(dl2, dl)
+        np.testing.assert_array_equal(loss2, loss)
+        for k, v in g_ref.items():
+            np.testing.assert_array_equal(h.grads_np[k], v, err_msg=k)
+        np.testing.assert_array_equal(h.np["bn3.running_mean"], ref.np["bn3.running_mean"])
