@@ -236,6 +236,42 @@ def test_merged_dgrad_wgrad_launch_is_bit_identical_to_separate_launches(monkeyp
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("B,C", [(1, 4), (64, 30), (512, 12)])
+def test_loss_inside_the_forward_launch_is_bit_identical(B, C):
+    """howl_res8_fwd_xent / howl_res8_bwd_xent (cross-entropy in the forward's last launch, batch mean in the backward's head
+    launch) against howl_res8_fwd + howl_xent_fwd_bwd + howl_res8_bwd on the device: same logits, loss, dlogits and gradients,
+    bit for bit, in one call and in the two-part form of the data-parallel step."""
+    from howl_amd import ops
+    T = 81
+    torch.manual_seed(11)
+    x = (torch.randn(B, T, 40) * 1.1).permute(0, 2, 1).unsqueeze(1).to(DEV)
+    labels = (torch.arange(B) * 7 % C).to(DEV)
+
+    def run(fused, parts):
+        model = make_res8(C).train()
+        if fused:
+            logits, nll, dlogits = model._launch_forward_xent(x, labels)
+            loss = torch.empty(1, device=DEV)
+            kw = dict(xent=(nll, loss))
+        else:
+            logits = model._launch_forward(x)
+            loss, dlogits = ops.xent(logits, labels)
+            kw = {}
+        grads = None
+        for part in parts:
+            grads = model._launch_backward(x, dlogits, out_grads=grads, part=part, **kw)
+        torch.cuda.synchronize()
+        return logits, loss, dlogits, grads, model.bn3.running_var.clone()
+
+    ref = run(False, (0,))
+    for parts in ((0,), (1, 2)):
+        got = run(True, parts)
+        assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]) and torch.equal(got[2], ref[2])
+        for a, b in zip(got[3], ref[3]):
+            assert torch.equal(a, b)
+        assert torch.equal(got[4], ref[4])
+
+
 @pytest.mark.parametrize("B,T", [(3, 84), (2, 120), (4, 201), (1, 500)])
 def test_long_inputs_in_eval_mode_vs_oracle(B, T):
     """Res8 accepts any T in the reference (cnn.py:127-145).  Beyond the 83 frames that fit the on-chip map the HIP path runs
