@@ -189,7 +189,7 @@ int howl_ctc_supported(int T, int C, int max_target_length) {
 int howl_ctc_loss(const float* logits, long st_t, long st_b, int T, int B, int C, const long long* targets, long tgt_stride,
                   int max_target_length, const long long* input_lengths, const long long* target_lengths, int blank,
                   float* nll, float* loss, float* dlogits, long dst_t, long dst_b, hipStream_t stream) {
-    HOWL_REQUIRE(logits && targets && input_lengths && target_lengths && nll && loss, "howl_ctc_loss: null pointer");
+    HOWL_REQUIRE(logits && targets && input_lengths && target_lengths && nll, "howl_ctc_loss: null pointer");
     HOWL_REQUIRE(B >= 1 && blank >= 0 && blank < C, "howl_ctc_loss: bad shape (B=%d, blank=%d, C=%d)", B, blank, C);
     HOWL_REQUIRE(howl_ctc_supported(T, C, max_target_length),
                  "howl_ctc_loss: T=%d C=%d target length %d outside the kernel's range (T <= %d, C <= %d, targets <= %d)", T,
@@ -198,7 +198,8 @@ int howl_ctc_loss(const float* logits, long st_t, long st_b, int T, int B, int C
     hipFuncSetAttribute(reinterpret_cast<const void*>(ctc_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(ctc_kernel, dim3(B), dim3(64), lds, stream, logits, st_t, st_b, T, B, C, targets, tgt_stride,
                        input_lengths, target_lengths, blank, nll, dlogits, dst_t, dst_b);
-    hipLaunchKernelGGL(ctc_mean_kernel, dim3(1), dim3(256), 0, stream, (const float*)nll, target_lengths, B, loss);
+    if (loss != nullptr)     // NULL: the caller takes the batch mean elsewhere (howl_head_bwd's HowlCtcMean: one launch fewer)
+        hipLaunchKernelGGL(ctc_mean_kernel, dim3(1), dim3(256), 0, stream, (const float*)nll, target_lengths, B, loss);
     HOWL_CHECK_LAUNCH("howl_ctc_loss");
     return HOWL_OK;
 }

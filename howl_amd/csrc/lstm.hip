@@ -683,11 +683,31 @@ __global__ __launch_bounds__(256) void head_out_kernel(const float* __restrict__
 
 // lane = (row slot rs = lane >> 5, strip c = lane & 31): columns 4 (c + 32 i) .. +3, i = 0, 1; a workgroup walks its row
 // chunk eight rows at a time.  part: [block][NO * n_hid (dW2) | n_hid (db1) | NO (db2)]
+// loss = mean_b nll_b / max(L_b, 1) (CTCLoss reduction "mean"), in ctc_mean_kernel's summation order (256 threads)
+__device__ __forceinline__ void ctc_mean_block(const float* __restrict__ nll, const long long* __restrict__ target_lengths, int B,
+                                               float* __restrict__ loss) {
+    __shared__ double mred[4];
+    double acc = 0.0;
+    for (int b = threadIdx.x; b < B; b += 256) {
+        const long long L = target_lengths[b];
+        acc += (double)(nll[b] / (float)(L > 0 ? L : 1));
+    }
+    acc = wave_sum_d(acc);
+    if ((threadIdx.x & 63) == 0) mred[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) loss[0] = (float)((((mred[0] + mred[1]) + mred[2]) + mred[3]) / (double)B);
+}
+__global__ __launch_bounds__(256) void ctc_mean_only_kernel(HowlCtcMean m) { ctc_mean_block(m.nll, m.target_lengths, m.B, m.loss); }
+
 template <int NO>
 __global__ __launch_bounds__(256) void head_thin_bwd_kernel(const float* __restrict__ y1, const float* __restrict__ dy2,
                                                             int rows, int n_hid, int rows_per_block,
                                                             const float* __restrict__ w2, float* __restrict__ dz1,
-                                                            float* __restrict__ part) {
+                                                            float* __restrict__ part, int nblocks, HowlCtcMean cm) {
+    if ((int)blockIdx.x == nblocks) {      // one extra block: the batch mean of a CTC loss whose launch was left out
+        ctc_mean_block(cm.nll, cm.target_lengths, cm.B, cm.loss);
+        return;
+    }
     __shared__ float red[4][NO * 8 + 8 + NO][32];      // [wave][value][strip]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int rs = lane >> 5, c = lane & 31;
@@ -943,7 +963,10 @@ int howl_head_fwd(const HowlHeadParams* p, const float* x, int rows_inner, long 
 
 int howl_head_bwd(const HowlHeadParams* p, const float* x, int rows_inner, long s_outer, long s_inner, int rows, int n_in,
                   int n_hid, int n_out, const float* y1, const float* dy2, float* dz1, float* dx, const HowlHeadGrads* g,
-                  void* ws, size_t ws_bytes, hipStream_t stream) {
+                  const HowlCtcMean* ctc_mean, void* ws, size_t ws_bytes, hipStream_t stream) {
+    HOWL_REQUIRE(ctc_mean == nullptr || (ctc_mean->nll && ctc_mean->target_lengths && ctc_mean->loss && ctc_mean->B >= 1),
+                 "howl_head_bwd: incomplete HowlCtcMean");
+    const HowlCtcMean cm = ctc_mean != nullptr ? *ctc_mean : HowlCtcMean{nullptr, nullptr, 0, nullptr};
     HOWL_REQUIRE(p && p->w1 && p->w2 && x && y1 && dy2 && dz1 && g && g->w1 && g->b1 && g->w2 && g->b2 && ws,
                  "howl_head_bwd: null pointer");
     HOWL_REQUIRE(rows >= 1 && n_in >= 1 && n_hid >= 1 && n_out >= 1 && rows_inner >= 1, "howl_head_bwd: bad shape");
@@ -960,7 +983,7 @@ int howl_head_bwd(const HowlHeadParams* p, const float* x, int rows_inner, long 
         rpb = (rpb + 7) / 8 * 8;
         const int blocks = (rows + rpb - 1) / rpb;
 #define HOWL_HEAD_BWD(NO) \
-    case NO: hipLaunchKernelGGL(head_thin_bwd_kernel<NO>, dim3(blocks), dim3(256), 0, stream, y1, dy2, rows, n_hid, rpb, p->w2, dz1, thin); break;
+    case NO: hipLaunchKernelGGL(head_thin_bwd_kernel<NO>, dim3(blocks + (ctc_mean != nullptr ? 1 : 0)), dim3(256), 0, stream, y1, dy2, rows, n_hid, rpb, p->w2, dz1, thin, blocks, cm); break;
         switch (n_out) {
             HOWL_HEAD_BWD(1) HOWL_HEAD_BWD(2) HOWL_HEAD_BWD(3) HOWL_HEAD_BWD(4) HOWL_HEAD_BWD(5) HOWL_HEAD_BWD(6) HOWL_HEAD_BWD(7)
             HOWL_HEAD_BWD(8)
@@ -972,6 +995,7 @@ int howl_head_bwd(const HowlHeadParams* p, const float* x, int rows_inner, long 
         sums.add_strided(thin + (size_t)(n_out + 1) * n_hid, blocks, slab, n_out, g->b2);
     } else {
         // general shapes: second layer by the GEMM path (its own folds), ReLU mask, then the first layer below
+        if (ctc_mean != nullptr) hipLaunchKernelGGL(ctc_mean_only_kernel, dim3(1), dim3(256), 0, stream, cm);
         float* ws2 = first + linear_ws_floats(n_hid, n_in);
         float* scratch_b2 = ws2 + (size_t)HEAD_W1_SPLITS * n_out * n_hid;
         gemm(stream, true, dy2, lin(n_out), 1, lin(0), p->w2, lin(n_hid), 1, rows, n_hid, n_out, 1, nullptr, 0, dz1, n_hid, 0);

@@ -52,6 +52,10 @@ class HowlHeadGrads(ctypes.Structure):
     _fields_ = [("w1", P), ("b1", P), ("w2", P), ("b2", P)]
 
 
+class HowlCtcMean(ctypes.Structure):
+    _fields_ = [("nll", P), ("target_lengths", P), ("B", c_int), ("loss", P)]
+
+
 class HowlLstmSaved(ctypes.Structure):
     _fields_ = [("gx", P), ("gates", P), ("c", P), ("hseq", P), ("dgates", P), ("t_out", c_int), ("x_frames", c_int)]
 
@@ -102,7 +106,7 @@ SIGNATURES = {
                       POINTER(HowlLstmGrads), P, c_size_t, STREAM],
     "howl_head_fwd": [POINTER(HowlHeadParams), P, c_int, c_long, c_long, c_int, c_int, c_int, c_int, P, P, STREAM],
     "howl_head_bwd": [POINTER(HowlHeadParams), P, c_int, c_long, c_long, c_int, c_int, c_int, c_int, P, P, P, P,
-                      POINTER(HowlHeadGrads), P, c_size_t, STREAM],
+                      POINTER(HowlHeadGrads), POINTER(HowlCtcMean), P, c_size_t, STREAM],
     "howl_adamw_step": [P, P, P, P, c_size_t, c_float, c_float, c_float, c_float, c_float, c_int, c_float, STREAM],
     "howl_mobilenet_layer": [c_int, POINTER(HowlMbLayer)],
     "howl_mobilenet_fwd": [P, P, c_int, P, c_long, c_long, c_long, c_int, c_int, c_int, c_int, P, c_float, P, P, c_size_t,

@@ -126,8 +126,9 @@ def _head_forward_raw(x, w1, b1, w2, b2):
     return y1, y2
 
 
-def _head_backward_raw(x, y1, dy2, w1, b1, w2, b2, need_dx=True, grads=None):
-    """``howl_head_bwd``: dy2 (..., n_out) -> (dx or None, [dW1, db1, dW2, db2]), written into ``grads`` when given."""
+def _head_backward_raw(x, y1, dy2, w1, b1, w2, b2, need_dx=True, grads=None, ctc_mean=None):
+    """``howl_head_bwd``: dy2 (..., n_out) -> (dx or None, [dW1, db1, dW2, db2]), written into ``grads`` when given.
+    ``ctc_mean`` = (nll, target_lengths, loss): the batch mean of a CTC loss taken by the same launch (``HowlCtcMean``)."""
     n_hid, n_in = w1.shape
     n_out = w2.shape[0]
     inner, s_outer, s_inner, rows = _row_geom(x)
@@ -140,8 +141,12 @@ def _head_backward_raw(x, y1, dy2, w1, b1, w2, b2, need_dx=True, grads=None):
     ws = torch.empty(_lib.get().cdll.howl_head_workspace_bytes(n_in, n_hid, n_out), dtype=torch.uint8, device=x.device)
     prm = _lib.HowlHeadParams(_vp(w1), _vp(b1), _vp(w2), _vp(b2))
     gr = _lib.HowlHeadGrads(*[_vp(g) for g in grads])
+    cm = None
+    if ctc_mean is not None:
+        nll, tl, loss = ctc_mean
+        cm = ctypes.byref(_lib.HowlCtcMean(_vp(nll), _vp(tl), int(nll.numel()), _vp(loss)))
     _lib.get().call("howl_head_bwd", ctypes.byref(prm), _vp(x), inner, s_outer, s_inner, rows, n_in, n_hid, n_out, _vp(y1),
-                    _vp(dy2), _vp(dz1), _vp(dx), ctypes.byref(gr), _vp(ws), ws.numel(), ops._stream())
+                    _vp(dy2), _vp(dz1), _vp(dx), ctypes.byref(gr), cm, _vp(ws), ws.numel(), ops._stream())
     return dx, grads
 
 
@@ -254,12 +259,13 @@ class SequentialLstm(_LstmBase, name="seq-lstm"):
             self.streaming_state = (hT.detach().clone().unsqueeze(0), cT.detach().clone().unsqueeze(0))
         return y2.permute(1, 0, 2)
 
-    def _launch_backward(self, dscores, out_grads=None):
-        """dscores: d loss / d scores as a (T_len, B, num_labels) view of a (B, T_len, num_labels) buffer (ops.ctc_loss_fwd_bwd)."""
+    def _launch_backward(self, dscores, out_grads=None, ctc_mean=None):
+        """dscores: d loss / d scores as a (T_len, B, num_labels) view of a (B, T_len, num_labels) buffer (ops.ctc_loss_fwd_bwd);
+        ``ctc_mean`` = (nll, target_lengths, loss) when the loss launch left its batch mean to the head's backward."""
         saved, t_out, hs, y1 = self._seq_saved
         ps = self.hot_parameters()
         grads = out_grads if out_grads is not None else [torch.empty_like(p) for p in ps]
-        dhs, _ = _head_backward_raw(hs, y1, dscores.permute(1, 0, 2), *ps[4:8], True, grads[4:8])
+        dhs, _ = _head_backward_raw(hs, y1, dscores.permute(1, 0, 2), *ps[4:8], True, grads[4:8], ctc_mean)
         _lstm_backward_raw(saved, t_out, dhs, None, None, grads[:4])
         self._seq_saved = None
         return grads

@@ -148,7 +148,7 @@ def xent(logits, labels, want_grad=True):
     return loss, dlogits
 
 
-def _ctc_launch(scores, targets, input_lengths, target_lengths, blank, max_target, want_grad):
+def _ctc_launch(scores, targets, input_lengths, target_lengths, blank, max_target, want_grad, defer_mean=False):
     T, B, C = scores.shape
     dev = scores.device
     # the gradient takes the memory layout of the model's (B, T, C) output buffer, handed back as a (T, B, C) view
@@ -158,8 +158,10 @@ def _ctc_launch(scores, targets, input_lengths, target_lengths, blank, max_targe
     vp = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())     # strided views: strides are passed explicitly
     _lib.get().call("howl_ctc_loss", vp(scores), scores.stride(0), scores.stride(1), T, B, C, vp(targets),
                     targets.stride(0), max_target, _p(input_lengths, torch.int64), _p(target_lengths, torch.int64), blank,
-                    _p(nll), _p(loss), vp(dlogits), 0 if dlogits is None else dlogits.stride(0),
+                    _p(nll), None if defer_mean else _p(loss), vp(dlogits), 0 if dlogits is None else dlogits.stride(0),
                     0 if dlogits is None else dlogits.stride(1), _stream())
+    if defer_mean:      # `loss` is filled by howl_head_bwd's HowlCtcMean rider
+        return loss, dlogits, nll
     return loss, dlogits
 
 
@@ -201,13 +203,16 @@ def ctc_supported(T: int, C: int, max_target: int) -> bool:
     return bool(_lib.get().cdll.howl_ctc_supported(int(T), int(C), int(max_target)))
 
 
-def ctc_loss_fwd_bwd(scores, targets, input_lengths, target_lengths, blank: int, max_target=None):
+def ctc_loss_fwd_bwd(scores, targets, input_lengths, target_lengths, blank: int, max_target=None, defer_mean=False):
     """Loss and d loss / d scores without an autograd graph (training.fused.FusedTrainer.step_sequence): same kernel as
-    ``ctc_loss``; the batch must be inside the kernel's range."""
+    ``ctc_loss``; the batch must be inside the kernel's range.  ``defer_mean``: returns (loss, dscores, nll, target_lengths)
+    with ``loss`` still unwritten -- the batch mean is left to ``howl_head_bwd`` (``SequentialLstm._launch_backward(...,
+    ctc_mean=(nll, target_lengths, loss))``), one launch fewer."""
     targets, input_lengths, target_lengths, max_target = _ctc_args(scores, targets, input_lengths, target_lengths, max_target)
     if scores.stride(2) != 1 or scores.dtype != torch.float32:
         raise ValueError("ctc_loss_fwd_bwd: scores must be fp32 with unit stride over the classes")
-    return _ctc_launch(scores, targets, input_lengths, target_lengths, int(blank), max_target, True)
+    out = _ctc_launch(scores, targets, input_lengths, target_lengths, int(blank), max_target, True, defer_mean)
+    return out + (target_lengths,) if defer_mean else out
 
 
 def ctc_loss(scores, targets, input_lengths, target_lengths, blank: int):

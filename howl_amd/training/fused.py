@@ -112,15 +112,19 @@ class FusedTrainer:
         scores = self.model._launch_forward(feat, frame_lengths, max_frames)   # (T_len, B, C) view of a (B, T_len, C) buffer
         if max_target is None:
             max_target = int(target_lengths.max()) if target_lengths.numel() else 0
+        ctc_mean = None
         if ops.ctc_supported(scores.shape[0], scores.shape[2], max_target):
-            loss, dscores = ops.ctc_loss_fwd_bwd(scores, targets, frame_lengths, target_lengths, blank, max_target)
+            # the batch mean of the loss rides in the head's backward launch (HowlCtcMean)
+            loss, dscores, nll, tl_dev = ops.ctc_loss_fwd_bwd(scores, targets, frame_lengths, target_lengths, blank, max_target,
+                                                              defer_mean=True)
+            ctc_mean = (nll, tl_dev, loss)
         else:   # longer than the fused kernel's range (T > 128 frames, ...): torch's device kernels for the loss only
             z = scores.detach().requires_grad_(True)
             loss = torch.nn.functional.ctc_loss(torch.log_softmax(z, -1), targets.to(z.device), frame_lengths, target_lengths,
                                                 blank)
             loss.backward()
             loss, dscores = loss.detach(), z.grad
-        self.model._launch_backward(dscores, out_grads=self.fp.grad_views)
+        self.model._launch_backward(dscores, out_grads=self.fp.grad_views, ctc_mean=ctc_mean)
         scale = parallel.allreduce_sum_(self.fp.grad, self.group)
         self.step_count += 1
         ops.adamw_step(self.fp.flat, self.fp.grad, self.m, self.v, self.lr, self.betas, self.eps, self.weight_decay,

@@ -218,7 +218,8 @@ int howl_xent_fwd_bwd(const float* logits, const long long* labels, int B, int C
  * at training/run/train.py:250-256,291-296 (sequence objective, envs/seq-lstm.env), reduction "mean", zero_infinity False.
  * logits: (T, B, C) addressed as t*st_t + b*st_b + c (so the model's (B,T,C) buffer can be passed as its (T,B,C) view);
  * targets: (B, >= max_target_length) int64, row stride tgt_stride; input_lengths / target_lengths: (B) int64, device.
- * nll: (B) per-utterance negative log likelihood; loss: (1) mean_b nll_b / max(target_length_b, 1);
+ * nll: (B) per-utterance negative log likelihood; loss: (1) mean_b nll_b / max(target_length_b, 1), or NULL to leave the
+ * mean to howl_head_bwd's HowlCtcMean rider (one launch fewer);
  * dlogits (nullable): d loss / d logits, addressed as t*dst_t + b*dst_b + c, rows t >= input_length_b are zero.
  * Range: howl_ctc_supported(T, C, max_target_length) -- T <= 128, C <= 64, targets <= 31 labels; outside it the call
  * returns HOWL_E_ARG (the host side then keeps torch's own device kernels for that batch). */
@@ -291,6 +292,15 @@ typedef struct {
     float* w2;
     float* b2;
 } HowlHeadGrads;
+/* Optional rider of howl_head_bwd in the sequence step: the batch mean of a CTC loss whose own mean launch was left out
+ * (howl_ctc_loss with loss = NULL): loss[0] = mean_b nll[b] / max(target_lengths[b], 1), the same arithmetic as
+ * howl_ctc_loss's, taken by one extra block of the head's backward launch. */
+typedef struct {
+    const float* nll;                 /* (B) per-utterance negative log-likelihoods from howl_ctc_loss */
+    const long long* target_lengths;  /* (B) */
+    int B;
+    float* loss;                      /* (1) */
+} HowlCtcMean;
 size_t howl_head_workspace_bytes(int n_in, int n_hid, int n_out);
 /* y1 (rows, n_hid) = relu(x W1^T + b1) [kept for the backward], y2 (rows, n_out) = y1 W2^T + b2. */
 int howl_head_fwd(const HowlHeadParams* p, const float* x, int rows_inner, long s_outer, long s_inner, int rows, int n_in,
@@ -299,7 +309,7 @@ int howl_head_fwd(const HowlHeadParams* p, const float* x, int rows_inner, long 
  * provides (it holds the gradient at the hidden pre-activations afterwards). */
 int howl_head_bwd(const HowlHeadParams* p, const float* x, int rows_inner, long s_outer, long s_inner, int rows, int n_in,
                   int n_hid, int n_out, const float* y1, const float* dy2, float* dz1, float* dx, const HowlHeadGrads* grads,
-                  void* ws, size_t ws_bytes, hipStream_t stream);
+                  const HowlCtcMean* ctc_mean /* NULL: none */, void* ws, size_t ws_bytes, hipStream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * MobileNetClassifier, registry name "mobilenet" (replaces howl/model/cnn.py:15-29: downsample conv/BN/ReLU/pool +

@@ -150,8 +150,8 @@ def test_head_forward_backward(lib, rows, n_in, n_hid, n_out):
     gr = HowlHeadGrads(*[ptr(a) for a in g])
     dz1, dx = np.full((rows, n_hid), np.nan, np.float32), np.full((rows, n_in), np.nan, np.float32)
     ws = np.zeros(lib.cdll.howl_head_workspace_bytes(n_in, n_hid, n_out), np.uint8)
-    lib.call("howl_head_bwd", ctypes.byref(hp), ptr(x0), *geom, ptr(y1), ptr(dy2), ptr(dz1), ptr(dx), ctypes.byref(gr), ptr(ws),
-             ws.size, None)
+    lib.call("howl_head_bwd", ctypes.byref(hp), ptr(x0), *geom, ptr(y1), ptr(dy2), ptr(dz1), ptr(dx), ctypes.byref(gr), None,
+             ptr(ws), ws.size, None)
     dz_ref = (dy2.astype(np.float64) @ w2) * (y1 > 0)
     scale = lambda a: max(1.0, np.abs(a).max())
     np.testing.assert_allclose(dz1, dz_ref, rtol=0, atol=2e-5)
@@ -160,6 +160,43 @@ def test_head_forward_backward(lib, rows, n_in, n_hid, n_out):
                            (g[3], dy2.sum(0, dtype=np.float64), "db2")):
         np.testing.assert_allclose(got, ref, rtol=0, atol=2e-5 * scale(ref), err_msg=name)
     # dx is optional (the first layer of a model that does not need its input's gradient)
-    lib.call("howl_head_bwd", ctypes.byref(hp), ptr(x0), *geom, ptr(y1), ptr(dy2), ptr(dz1), None, ctypes.byref(gr), ptr(ws),
-             ws.size, None)
+    lib.call("howl_head_bwd", ctypes.byref(hp), ptr(x0), *geom, ptr(y1), ptr(dy2), ptr(dz1), None, ctypes.byref(gr), None,
+             ptr(ws), ws.size, None)
     np.testing.assert_allclose(g[0], dz_ref.T @ x, rtol=0, atol=2e-5 * scale(dz_ref.T @ x))
+
+
+def test_ctc_batch_mean_rides_in_the_head_backward(lib):
+    """howl_ctc_loss(loss=NULL) leaves the batch mean to howl_head_bwd's HowlCtcMean rider: the same float as the loss launch's
+    own mean, thin and GEMM head paths."""
+    from howl_amd.lib import HowlCtcMean
+    rng = np.random.default_rng(9)
+    B, T, C = 7, 12, 5
+    z = rng.standard_normal((B, T, C)).astype(np.float32)
+    tg = np.ascontiguousarray(rng.integers(0, 4, (B, 3)), np.int64)
+    il = np.full(B, T, np.int64)
+    tl = np.array([3, 2, 3, 1, 0, 3, 2], np.int64)
+    nll, loss_ref = np.zeros(B, np.float32), np.zeros(1, np.float32)
+    lib.call("howl_ctc_loss", ptr(z), C, T * C, T, B, C, ptr(tg), 3, 3, ptr(il), ptr(tl), 4, ptr(nll), ptr(loss_ref), None, 0, 0, None)
+    nll2 = np.zeros(B, np.float32)
+    lib.call("howl_ctc_loss", ptr(z), C, T * C, T, B, C, ptr(tg), 3, 3, ptr(il), ptr(tl), 4, ptr(nll2), None, None, 0, 0, None)
+    np.testing.assert_array_equal(nll2, nll)
+    for n_out in (5, 12):       # vector kernels / GEMM path
+        rows, n_in, n_hid = 40, 128, 256
+        x = rng.standard_normal((rows, n_in)).astype(np.float32)
+        w1, b1 = (rng.standard_normal((n_hid, n_in)) * 0.1).astype(np.float32), np.zeros(n_hid, np.float32)
+        w2, b2 = (rng.standard_normal((n_out, n_hid)) * 0.1).astype(np.float32), np.zeros(n_out, np.float32)
+        y1, y2 = np.zeros((rows, n_hid), np.float32), np.zeros((rows, n_out), np.float32)
+        hp = HowlHeadParams(ptr(w1), ptr(b1), ptr(w2), ptr(b2))
+        geom = (rows, 0, n_in, rows, n_in, n_hid, n_out)
+        lib.call("howl_head_fwd", ctypes.byref(hp), ptr(x), *geom, ptr(y1), ptr(y2), None)
+        g = [np.zeros_like(a) for a in (w1, b1, w2, b2)]
+        gr = HowlHeadGrads(*[ptr(a) for a in g])
+        dy2 = rng.standard_normal((rows, n_out)).astype(np.float32)
+        dz1 = np.zeros((rows, n_hid), np.float32)
+        ws = np.zeros(lib.cdll.howl_head_workspace_bytes(n_in, n_hid, n_out), np.uint8)
+        loss = np.full(1, np.nan, np.float32)
+        cm = HowlCtcMean(ptr(nll), ptr(tl), B, ptr(loss))
+        lib.call("howl_head_bwd", ctypes.byref(hp), ptr(x), *geom, ptr(y1), ptr(dy2), ptr(dz1), None, ctypes.byref(gr),
+                 ctypes.byref(cm), ptr(ws), ws.size, None)
+        np.testing.assert_array_equal(loss, loss_ref)
+        np.testing.assert_allclose(g[3], dy2.sum(0), rtol=0, atol=2e-5 * max(1.0, np.abs(dy2.sum(0)).max()))
