@@ -79,6 +79,12 @@ def parse():
     ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--vtlp", action="store_true",
+                    help="frontend in train mode, as the reference loop runs it (pretrain_gsc.py:120-126): per step one host draw, "
+                         "VTLP-warped filterbank rebuilt on the device (howl_fb_from_points) on 75 %% of the steps")
+    ap.add_argument("--global-batch", type=int, default=None,
+                    help="strong scaling: a FIXED global batch split over the N ranks (configs[2]: 4096); default is weak "
+                         "scaling at the configuration's per-GPU batch")
     return ap.parse_args()
 
 
@@ -388,14 +394,23 @@ def main():
 
     model_name, C, B, seconds, cfg_desc = CONFIGS[args.config]
     B = args.batch_per_gpu or B
+    scaling = "weak"
+    if args.global_batch:
+        if args.global_batch % world:
+            raise SystemExit(f"bench.py: --global-batch {args.global_batch} is not a multiple of {world} ranks")
+        B, scaling = args.global_batch // world, "strong"
     C = args.labels or C
     L = int(round((args.seconds or seconds) * 16000))
     pcm = synthetic_pcm(B, L, seed=1234 + rank).to(dev)
     labels = (torch.arange(B) % C).to(dev)
 
-    std = StandardAudioTransform().to(dev).eval()   # eval-mode filterbank; VTLP is exercised by the tests
+    std = StandardAudioTransform().to(dev).eval()   # eval-mode filterbank unless --vtlp
     zmuv = ZmuvTransform().to(dev)
     zmuv.update(std(pcm[:8]))
+    if args.vtlp:
+        import random
+        random.seed(1234)       # the alpha draws (global `random`, transform.py:441): the same sequence on every rank
+        std.train()
     model = RegisteredModel.find_registered_class(model_name)(C).to(dev)
     if model_name == "res8":
         model.load_state_dict(res8_closed_form_state(C), strict=False)
@@ -414,7 +429,7 @@ def main():
             return trainer.step_sequence(pcm, frame_lengths, targets, target_lengths, C - 1, max_target=3, max_frames=n_frames)
     elif model_name == "mobilenet":
         from howl_amd.data.collate import DeviceCollate
-        collate = DeviceCollate(pcm, torch.full((B,), L, dtype=torch.long), labels, max_len=L, seed=rank)
+        collate = DeviceCollate(pcm, torch.full((B,), L, dtype=torch.long), labels, max_len=L, seed=0, replica=rank)
         ids = list(range(B))
 
         def step():    # timeshift + white / salt-pepper noise + batchify on the device, then the training step
@@ -472,9 +487,27 @@ def main():
             dist.all_reduce(buf)
         e1.record()
         torch.cuda.synchronize()
+        # what the collectives cost the step: the same K steps once more with the gradient all-reduce left out (every rank
+        # then steps on its local gradient: measurement only, the timed region above always reduces)
+        trainer.skip_allreduce = True
+        for _ in range(min(args.warmup, 3)):
+            step()
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        dt_local = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
+        dist.all_reduce(dt_local, op=dist.ReduceOp.MAX)
+        trainer.skip_allreduce = False
+        trainer.broadcast_parameters()          # the replicas diverged during the measurement: re-align before the roofline pass
+        for t_ in (trainer.m, trainer.v):
+            dist.broadcast(t_, 0)
         rccl = {"world_size": dist.get_world_size(), "backend": dist.get_backend(),
                 "allreduce_bytes": buf.numel() * 4, "allreduce_us": round(e0.elapsed_time(e1) * 1e3 / 20, 1),
-                "collectives_per_step": 1}
+                "collectives_per_step": trainer.collectives_last_step_reduced, "late_grads": trainer.late_grads,
+                "ms_per_step_without_allreduce": round(dt_local.item() / args.steps * 1e3, 4),
+                "allreduce_exposed_us": round((dt - dt_local.item()) / args.steps * 1e6, 1)}
 
     roof = None
     lb = hlib.get()
@@ -585,11 +618,14 @@ def main():
             "metric": f"utterances/sec/node ({model_name} end-to-end training step, {L / 16000:g}s@16kHz, 40-mel)",
             "value": round(total_utts / dt, 1), "unit": "utterances/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{model_name} training step ({step_desc}), {B} x {L / 16000:g} s utterances per GPU, "
-                                   f"{C} labels -- BASELINE {cfg_desc}",
+                                   f"{C} labels -- BASELINE {cfg_desc}"
+                                   + ("; frontend in train mode (VTLP filterbank on 75 % of the steps)" if args.vtlp else "")
+                                   + ("; parity unpinned (torchvision absent: oracle restates the published architecture)"
+                                      if model_name == "mobilenet" else ""),
                        "name": args.config, "global_batch": B * world, "samples_per_utterance": L, "labels": C,
-                       "parallelism": f"dp{world}" if world > 1 else "single"},
+                       "parallelism": f"dp{world}" if world > 1 else "single", "frontend": "vtlp-train" if args.vtlp else "eval"},
             "final_loss": round(final_loss, 5), "repeats": repeats,
             "roofline": roof, "cpu_baseline": cpu, "eval_agreement": agree, "rccl": rccl,
         }

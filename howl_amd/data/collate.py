@@ -27,18 +27,24 @@ MIXER_DOMAIN, MIXER_IDX, MIXER_PROB = [0.1, 0.2, 0.3, 0.4, 0.5], 1, 0.75
 
 class DeviceCollate:
     def __init__(self, bank_audio, bank_lengths, bank_labels, max_len: int, sr: int = 16000, seed: int = None,
-                 training: bool = True, background=None, do_replace: bool = False):
-        """``background`` = (bg_audio (N, Lbg) on the device, bg_lengths): the noise dataset of ``DatasetMixer``."""
+                 training: bool = True, background=None, do_replace: bool = False, replica: int = 0, row_offsets=None):
+        """``background`` = (bg_audio (N, Lbg) on the device, bg_lengths): the noise dataset of ``DatasetMixer``.
+        ``replica``: this process's rank in a data-parallel job -- it keys the device noise generator (and, with a ``seed``, the
+        host draws), so that row r of every rank's shard does not receive the same shift / noise pattern.
+        ``row_offsets``: ragged bank -- ``bank_audio`` is the (total, 1) view of a flat sample buffer and clip i starts at
+        sample ``row_offsets[i]`` (``WakeWordClipBank``); default: a dense (N, Lmax) matrix, clip i = row i."""
         self.audio, self.lengths, self.labels = bank_audio, [int(v) for v in bank_lengths.tolist()], bank_labels
         self.last_max_len = 0      # longest row of the last batch (host knowledge: no read-back for the frame count)
         self.labels_host = None if bank_labels is None else [int(v) for v in bank_labels.tolist()]   # gathered on the host
         self.bg_audio = None if background is None else background[0]
         self.bg_lengths = None if background is None else [int(v) for v in background[1]]
         self.do_replace = do_replace
+        self.row_offsets = None if row_offsets is None else [int(v) for v in row_offsets]
         self.max_len, self.sr, self.training = max_len, sr, training
-        self.rand = random if seed is None else random.Random(seed)
+        self.rand = random if seed is None else random.Random(seed * 1000003 + replica)
         self._calls = 0
         self._seed = 0 if seed is None else seed
+        self._replica_key = (replica * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF      # 0 for a single process: same stream as before
 
     def draw(self, clip_ids):
         """Host-side parameter draws in the reference's order; returns per-sample lists (before the length sort)."""
@@ -108,7 +114,8 @@ class DeviceCollate:
         (kind, values) sections to ride in the same upload (labels, lengths); returns (audio, [extra tensors])."""
         pick = lambda a: [a[k] for k in rows]
         self._calls += 1
-        sections = [("i", pick(clip_ids)), ("i", src_end), ("i", shift), ("i", [1] * len(rows)), ("f", pick(sigma)),
+        bank_rows = clip_ids if self.row_offsets is None else [self.row_offsets[i] for i in clip_ids]
+        sections = [("i", pick(bank_rows)), ("i", src_end), ("i", shift), ("i", [1] * len(rows)), ("f", pick(sigma)),
                     ("f", pick(sp))]
         has_mix = self.last_mix is not None and any(a != 0.0 for a in self.last_mix[2])
         if has_mix:
@@ -119,7 +126,7 @@ class DeviceCollate:
         dev_t = self._upload(sections + list(extra))
         idx, end, sh, ones, sg, spp = dev_t[:6]
         mix = (self.bg_audio, dev_t[6], dev_t[7], dev_t[8]) if has_mix else None
-        audio = ops.collate_augment(self.audio, idx, end, sh, ones, sg, spp, (self._seed << 32) ^ self._calls, lout, mix=mix,
+        audio = ops.collate_augment(self.audio, idx, end, sh, ones, sg, spp, ((self._seed << 32) ^ self._calls ^ self._replica_key) & 0xFFFFFFFFFFFFFFFF, lout, mix=mix,
                                     dst_off=dev_t[n_own - 1] if dst_off is not None else None)
         return audio, dev_t[n_own:]
 

@@ -12,7 +12,7 @@ import torch
 import torch.nn as nn
 
 from howl_amd import lib as _lib
-from howl_amd import ops
+from howl_amd import ops, parallel
 from howl_amd.settings import _EnvSettings
 
 from .base import RegisteredModel
@@ -79,6 +79,13 @@ class Res8(RegisteredModel, name="res8"):
         n_maps = config.num_maps
         if n_maps != 45 or tuple(config.pooling) != (3, 4):
             raise NotImplementedError("the MI355X res8 kernels are specialised for num_maps=45, pooling=(3,4)")
+        from howl_amd.settings import SETTINGS
+        if SETTINGS.audio_transform.num_mels != 40:
+            # the reference's default is 80 (settings.py:32) while every res8 preset sets 40 (envs/res8.env): say so when the
+            # model is built, not at the first forward deep inside a training run
+            raise ValueError(f"Res8 on MI355X is built for NUM_MELS=40 (envs/res8.env; AvgPool (3,4) over 40 mel bins), but "
+                             f"SETTINGS.audio_transform.num_mels is {SETTINGS.audio_transform.num_mels}: export NUM_MELS=40 "
+                             f"before howl_amd.settings is imported (stock Howl's default of 80 is not supported by the kernels)")
         self.conv0 = nn.Conv2d(1, n_maps, (3, 3), padding=(1, 1), bias=False)
         self.pool = nn.AvgPool2d(config.pooling)
         self.n_layers = n_layers = 6
@@ -446,6 +453,7 @@ class MobileNetClassifier(RegisteredModel, name="mobilenet"):
                 # reproducible under torch.manual_seed, nothing read back from the device)
                 self._last_mask = torch.empty((B, 1280), dtype=torch.float32, device=x0.device)
                 key = int(torch.randint(0, 2 ** 62, (1,)).item())
+                key ^= (parallel.world_info()[0] * 0x9E3779B97F4A7C15) & (2 ** 62 - 1)   # replicas share the CPU seed, not the mask
                 _lib.get().call("howl_dropout_mask", ctypes.c_void_p(self._last_mask.data_ptr()), self._last_mask.numel(),
                                 float(self.dropout_p), ctypes.c_ulonglong(key), ops._stream())
             torch._foreach_add_([bn.num_batches_tracked for _, bn, _ in self._layer_modules()], 1)

@@ -207,7 +207,8 @@ class _LstmBase(RegisteredModel):
         if t_out < T:                                  # frames no sequence reaches: the kernels and the saved buffers only see
             xb = xb[:, :t_out]                         # t_out steps (a view: the library takes the buffer's frame stride)
         M = xb.shape[2]
-        if xb.stride(2) != 1 or xb.stride(1) != M or xb.stride(0) % M:     # the fused frontend already hands over a (B,T,M) buffer
+        if (xb.stride(2) != 1 or xb.stride(1) != M or xb.stride(0) % M       # the fused frontend already hands over a (B,T,M) buffer;
+                or xb.stride(0) < xb.shape[1] * M):                            # expanded / overlapping batch views are copied
             xb = xb.contiguous()
         hx = self.streaming_state if self.is_streaming and self.streaming_state is not None else None
         if hx is not None and (tuple(hx[0].shape) != (1, B, HID) or tuple(hx[1].shape) != (1, B, HID)):

@@ -112,32 +112,43 @@ def load_howl_splits(path: Path, prefix: str = "aligned-"):
 
 
 class WakeWordClipBank:
-    """Clips of a wake-word split decoded once and kept on the device as one (N, Lmax) matrix, each with the descriptor the
-    batchifiers work on (``DeviceClip``: bank row, length, frame labels from the context's labeler, transcription)."""
+    """Clips of a wake-word split decoded once and kept on the device RAGGED: one flat sample buffer, clip i at
+    ``offsets[i] .. offsets[i] + lengths[i]`` (each start 16-byte aligned), so a single long negative costs its own length
+    and not a row of that width for every clip.  The collate / gather kernels address a clip as ``bank + idx * bank_ld``: the
+    bank is handed to them as the (total, 1) view ``rows`` (``bank_ld`` = 1) with ``idx`` = the clip's offset
+    (``DeviceCollate(row_offsets=...)``).  Each clip comes with the descriptor the batchifiers work on (``DeviceClip``: clip
+    id, length, frame labels from the context's labeler, transcription)."""
 
-    MAX_BANK_BYTES = 64 << 30      # one long clip sets the row width of the whole dense bank: fail loudly, do not thrash
+    MAX_OFFSET = (1 << 31) - 1     # offsets travel as int32 (8 GiB of samples, ~37 h of 16 kHz audio per split)
 
     def __init__(self, clips: List[torch.Tensor], metadata: list, labeler, device):
         from howl_amd.data.transform.batchifier import DeviceClip
-        lmax = max(c.numel() for c in clips)
-        if len(clips) * lmax * 4 > self.MAX_BANK_BYTES:
-            raise MemoryError(f"dense clip bank of {len(clips)} x {lmax} samples ({len(clips) * lmax * 4 / 2**30:.0f} GiB): the longest "
-                              f"clip sets the row width -- truncate or bucket the split (MAX_WINDOW_SIZE_SECONDS) before loading it")
-        audio = torch.zeros(len(clips), lmax)
-        for i, c in enumerate(clips):
-            audio[i, : c.numel()] = c
-        self.audio = audio.to(device)
-        self.lengths = torch.tensor([c.numel() for c in clips])
+        lengths = [int(c.numel()) for c in clips]
+        offsets, total = [], 0
+        for n in lengths:
+            offsets.append(total)
+            total += (n + 3) & ~3
+        if total > self.MAX_OFFSET:
+            raise MemoryError(f"clip bank of {total} samples ({total * 4 / 2**30:.0f} GiB) exceeds the 32-bit offsets of the collate "
+                              f"kernels: shard the split")
+        flat = torch.zeros(max(total, 1))
+        for c, o, n in zip(clips, offsets, lengths):
+            flat[o:o + n] = c
+        self.flat = flat.to(device)
+        self.rows = self.flat.unsqueeze(1)          # (total, 1): row stride 1, "row" index = sample offset
+        self.offsets = offsets
+        self.max_len = max(lengths) if lengths else 0
+        self.lengths = torch.tensor(lengths)
         self.examples = []
-        for i, (c, m) in enumerate(zip(clips, metadata)):
+        for i, (n, m) in enumerate(zip(lengths, metadata)):
             tl = labeler.compute_frame_labels(m).timestamp_label_map if m.end_timestamps is not None else {}
-            self.examples.append(DeviceClip(i, c.numel(), tl, m.transcription))
+            self.examples.append(DeviceClip(i, n, tl, m.transcription))
 
     def __len__(self):
         return len(self.examples)
 
     def clip(self, i: int) -> torch.Tensor:
-        return self.audio[i, : self.examples[i].num_samples]
+        return self.flat[self.offsets[i]: self.offsets[i] + self.examples[i].num_samples]
 
     def subset(self, keep) -> List[int]:
         return [i for i, ex in enumerate(self.examples) if keep(ex)]

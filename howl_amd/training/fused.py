@@ -5,6 +5,8 @@ This is the loop body of ``training/run/pretrain_gsc.py:124-133`` / ``training/r
 stage a C-ABI call on the current HIP stream, gradients written straight into one flat fp32 buffer (the unit of the
 single data-parallel all-reduce per step) and no host synchronisation (the loss stays on the device).
 """
+import os
+
 import torch
 
 from howl_amd import ops, parallel
@@ -43,7 +45,12 @@ class FusedTrainer:
     fused AdamW (which applies 1/world); res8 overlaps that all-reduce with the tail of its backward pass."""
 
     def __init__(self, model, std_transform, zmuv_transform, lr, weight_decay=0.0, betas=(0.9, 0.999), eps=1e-8,
-                 process_group=None):
+                 process_group=None, late_grads=None):
+        """``late_grads`` (data-parallel res8 only; default from ``HOWL_DP_LATE``, else "overlap"):
+        "overlap" -- two-part backward, TWO collectives per step: everything but conv0's 405 gradients is reduced under
+                     conv0's weight-gradient kernels (async), the 405 floats after them (on the critical path);
+        "merged"  -- one-part backward, ONE collective per step over the whole flat buffer (nothing overlapped: pays when
+                     the second small collective's latency exceeds what the overlap hides, i.e. part 2 < ~60 us)."""
         self.model, self.std, self.zmuv = model, std_transform, zmuv_transform
         self.lr, self.weight_decay, self.betas, self.eps = lr, weight_decay, betas, eps
         self.fp = FlatParams(model.hot_parameters())
@@ -52,6 +59,12 @@ class FusedTrainer:
         self.step_count = 0
         self.group = process_group
         self.rank, self.world = parallel.world_info(process_group)
+        self.late_grads = late_grads or os.environ.get("HOWL_DP_LATE", "overlap")
+        if self.late_grads not in ("overlap", "merged"):
+            raise ValueError(f"late_grads / HOWL_DP_LATE must be 'overlap' or 'merged', got {self.late_grads!r}")
+        self.collectives_last_step = 0     # gradient collectives the last step issued (bench.py reports it)
+        self.collectives_last_step_reduced = 0   # ... the last step that did reduce (skip_allreduce steps excluded)
+        self.skip_allreduce = False        # measurement only (bench.py: step time with vs without the collectives)
 
     def broadcast_parameters(self, src=0):
         """Make every replica start from rank ``src``'s weights and BatchNorm buffers."""
@@ -81,7 +94,10 @@ class FusedTrainer:
                 logits = self.model._launch_forward(feat)
             loss, dlogits = ops.xent(logits, labels)
         late = getattr(self.model, "LATE_GRAD_PARAMS", 0)
-        if self.world > 1 and late:
+        if self.skip_allreduce:
+            self.model._launch_backward(feat, dlogits, out_grads=self.fp.grad_views, **bwd_kw)
+            scale, self.collectives_last_step = 1.0 / self.world, 0
+        elif self.world > 1 and late and self.late_grads == "overlap":
             # two-part backward: the all-reduce of everything but the first `late` parameters (res8: conv0.weight, whose
             # gradient needs the last data gradient) runs on the process group's stream while their kernels still execute
             n0 = sum(p.numel() for p in self.fp.params[:late])
@@ -90,9 +106,11 @@ class FusedTrainer:
             self.model._launch_backward(feat, dlogits, out_grads=self.fp.grad_views, part=2, **bwd_kw)
             scale = parallel.allreduce_sum_(self.fp.grad[:n0], self.group)
             pending.wait()
+            self.collectives_last_step = self.collectives_last_step_reduced = 2
         else:
             self.model._launch_backward(feat, dlogits, out_grads=self.fp.grad_views, **bwd_kw)
             scale = parallel.allreduce_sum_(self.fp.grad, self.group)
+            self.collectives_last_step = self.collectives_last_step_reduced = 1 if self.world > 1 else 0
         self.step_count += 1
         ops.adamw_step(self.fp.flat, self.fp.grad, self.m, self.v, self.lr, self.betas, self.eps, self.weight_decay,
                        self.step_count, scale)
@@ -125,7 +143,11 @@ class FusedTrainer:
             loss.backward()
             loss, dscores = loss.detach(), z.grad
         self.model._launch_backward(dscores, out_grads=self.fp.grad_views, ctc_mean=ctc_mean)
-        scale = parallel.allreduce_sum_(self.fp.grad, self.group)
+        if self.skip_allreduce:
+            scale, self.collectives_last_step = 1.0 / self.world, 0
+        else:
+            scale = parallel.allreduce_sum_(self.fp.grad, self.group)
+            self.collectives_last_step = self.collectives_last_step_reduced = 1 if self.world > 1 else 0
         self.step_count += 1
         ops.adamw_step(self.fp.flat, self.fp.grad, self.m, self.v, self.lr, self.betas, self.eps, self.weight_decay,
                        self.step_count, scale)

@@ -79,8 +79,8 @@ def main(argv=None):
                 n = int(train.lengths_host[i])
                 zmuv_transform.update(std_transform(train.audio[i:i + 1, :n]))
         parallel.broadcast_([zmuv_transform.total, zmuv_transform.mean, zmuv_transform.mean2])
-    if main_rank:
-        torch.save({k: v.cpu() for k, v in zmuv_transform.state_dict().items()}, str(zmuv_path))
+        if main_rank:   # only freshly computed statistics are written: the other ranks may still be reading an existing file
+            torch.save({k: v.cpu() for k, v in zmuv_transform.state_dict().items()}, str(zmuv_path))
 
     def evaluate_accuracy(bank, prefix, epoch_idx=None, save=False):
         std_transform.eval()
@@ -123,7 +123,8 @@ def main(argv=None):
     trainer.broadcast_parameters()                                     # rank 0's initial weights and BatchNorm buffers
     needs_lengths = getattr(model, "NEEDS_LENGTHS", False)
     # train_comp = compose(truncate, Timeshift.train(), Noise.train(), batchify) (pretrain_gsc.py:78-80), on the device
-    train_collate = DeviceCollate(train.audio, train.lengths_host, train.labels, max_len, sr=sample_rate)
+    train_collate = DeviceCollate(train.audio, train.lengths_host, train.labels, max_len, sr=sample_rate,
+                                  seed=SETTINGS.training.seed if world > 1 else None, replica=rank)
     dev_acc = 0
     for epoch_idx in range(SETTINGS.training.num_epochs):
         model.train()

@@ -142,7 +142,8 @@ def main(argv=None):
         batchifier = WakeWordFrameBatchifier(ctx.negative_label, window_size_ms=window_ms)
     else:
         batchifier = AudioSequenceBatchifier(ctx.negative_label, WakeWordTokenizer(ctx.vocab, ignore_oov=False))
-    collate = DeviceCollate(train_bank.audio, train_bank.lengths, None, max_len=train_bank.audio.shape[1])
+    collate = DeviceCollate(train_bank.rows, train_bank.lengths, None, max_len=train_bank.max_len, row_offsets=train_bank.offsets,
+                            seed=SETTINGS.training.seed if world > 1 else None, replica=rank)
 
     std_transform = StandardAudioTransform().to(device).eval()
     zmuv_transform = ZmuvTransform().to(device)
@@ -157,8 +158,8 @@ def main(argv=None):
         for i in rng.permutation(len(train_bank))[:2001]:              # prep_dl: single shuffled examples (train.py:231-245)
             zmuv_transform.update(std_transform(train_bank.clip(int(i))[None]))
         parallel.broadcast_([zmuv_transform.total, zmuv_transform.mean, zmuv_transform.mean2])
-    if main_rank:
-        torch.save({k: v.cpu() for k, v in zmuv_transform.state_dict().items()}, str(ws.path / "zmuv.pt.bin"))
+        if main_rank:   # only freshly computed statistics are written: the other ranks may still be reading an existing file
+            torch.save({k: v.cpu() for k, v in zmuv_transform.state_dict().items()}, str(ws.path / "zmuv.pt.bin"))
     if args.load_weights:
         ws.load_model(model, best=not args.load_last)
         model.to(device)

@@ -435,6 +435,56 @@ def phone_context_golden():
     print("g11_phone_context.json", {k: (len(v) if hasattr(v, "__len__") else v) for k, v in out.items()})
 
 
+def checkpoint_golden():
+    """G12 (f4): a workspace WRITTEN BY THE REFERENCE -- ``howl.workspace.Workspace.save_model`` (workspace.py:56-63:
+    ``torch.save(model.state_dict())``) for a res8 after two AdamW steps (non-trivial weights and BatchNorm buffers), and
+    ``zmuv.pt.bin`` as ``pretrain_gsc.py:106`` writes it -- copied to ``tests/golden/ref_workspace/`` as data, together with
+    the eval logits the reference computes after loading that workspace back (``Workspace.load_model``, hubconf.py:53-84)."""
+    import shutil
+    import tempfile
+    import types
+    _reference_shims._module("torch.utils.tensorboard",
+                             SummaryWriter=lambda *a, **k: types.SimpleNamespace(add_scalar=lambda *a, **k: None))
+    from howl.workspace import Workspace
+    C = 12
+    clips = [read_wav(GSC / w) for w in WAVS]
+    audio, _ = batchify_like_reference(clips)
+    std = StandardAudioTransform().eval()
+    zmuv = ZmuvTransform()
+    for c in clips:
+        zmuv.update(std(torch.from_numpy(c)[None]))
+    x = zmuv(std(audio))
+    model = RegisteredModel.find_registered_class("res8")(C)
+    model.load_state_dict(om.res8_init(C))
+    model.train()
+    opt = torch.optim.AdamW(model.parameters(), 0.01, weight_decay=1e-5)
+    labels = torch.arange(x.size(0)) % C
+    for _ in range(2):
+        opt.zero_grad()
+        torch.nn.functional.cross_entropy(model(x, None), labels).backward()
+        opt.step()
+    with tempfile.TemporaryDirectory() as tmp:
+        ws = Workspace(Path(tmp) / "ws", delete_existing=False)
+        ws.save_model(model, best=True)
+        torch.save(zmuv.state_dict(), str(ws.path / "zmuv.pt.bin"))
+        fresh = RegisteredModel.find_registered_class("res8")(C)
+        ws.load_model(fresh, best=True)
+        fresh.eval()
+        z2 = ZmuvTransform()
+        z2.load_state_dict(torch.load(str(ws.path / "zmuv.pt.bin")))
+        with torch.no_grad():
+            logits = fresh(z2(std(audio)), None)
+        dst = HERE / "ref_workspace"
+        dst.mkdir(exist_ok=True)
+        for name in ("model-best.pt.bin", "zmuv.pt.bin"):
+            shutil.copyfile(ws.path / name, dst / name)
+    sd = fresh.state_dict()
+    save("g12_ref_workspace", audio=audio, eval_logits=logits, num_labels=np.array(C),
+         keys=np.array(list(sd.keys())), shapes=np.array([str(tuple(v.shape)) for v in sd.values()]),
+         dtypes=np.array([str(v.dtype) for v in sd.values()]),
+         zmuv_keys=np.array(list(z2.state_dict().keys())))
+
+
 if __name__ == "__main__":
     only = [a for a in sys.argv[1:] if a.startswith("--only-")]
     if not only:
@@ -447,3 +497,5 @@ if __name__ == "__main__":
         frame_batchifier_golden()
     if not only or "--only-phone" in only:
         phone_context_golden()
+    if not only or "--only-checkpoint" in only:
+        checkpoint_golden()

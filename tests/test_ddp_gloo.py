@@ -70,7 +70,7 @@ def test_shard_range_covers_batch():
             assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
 
 
-def _trainer_worker(rank, world, port, out):
+def _trainer_worker(rank, world, port, out, late_grads="overlap"):
     """The product's FusedTrainer (flat parameter / gradient buffers, broadcast, in-step all-reduce, fused AdamW) with its
     kernels running on the hipemu build, one process per rank over gloo."""
     import sys
@@ -101,7 +101,7 @@ def _trainer_worker(rank, world, port, out):
             sd0 = {k: (v + 0.01 if v.is_floating_point() else v) for k, v in sd0.items()}
         model.load_state_dict(sd0, strict=False)
         model.train()
-        tr = FusedTrainer(model, std, zmuv, lr=0.01, weight_decay=1e-5)
+        tr = FusedTrainer(model, std, zmuv, lr=0.01, weight_decay=1e-5, late_grads=late_grads)
         tr.broadcast_parameters()
         # this rank's local gradient of step 1: the same launches outside the trainer (single-call backward), BatchNorm
         # buffers restored afterwards
@@ -155,18 +155,24 @@ def _trainer_worker(rank, world, port, out):
         out["identical"] = all(torch.equal(ws[0], w) for w in ws)                     # (iii) replicas stay identical
         out["bn_differs"] = not torch.equal(bns[0], bns[1])                           # local-batch BN statistics (no SyncBN)
         out["world"] = tr.world
+        out["collectives"] = tr.collectives_last_step
     dist.destroy_process_group()
 
 
-def test_two_rank_fused_trainer_on_emulated_kernels():
+import pytest
+
+
+@pytest.mark.parametrize("late_grads,collectives", [("overlap", 2), ("merged", 1)])
+def test_two_rank_fused_trainer_on_emulated_kernels(late_grads, collectives):
     """(i) per-rank gradient == oracle on the rank's shard, (ii) all-reduced gradient == sum of the shard
     gradients (the 1/world mean is applied inside the AdamW kernel), (iii) bit-identical weights on all ranks after two
-    steps from deliberately different initial weights (broadcast_parameters)."""
+    steps from deliberately different initial weights (broadcast_parameters).  Both schedules of the late (conv0) gradients:
+    "overlap" = two-part backward with two collectives, "merged" = one collective over the whole buffer."""
     world = 2
     with mp.Manager() as mgr:
         out = mgr.dict()
-        mp.spawn(_trainer_worker, args=(world, _free_port(), out), nprocs=world, join=True)
-        assert out["world"] == 2
+        mp.spawn(_trainer_worker, args=(world, _free_port(), out, late_grads), nprocs=world, join=True)
+        assert out["world"] == 2 and out["collectives"] == collectives
         assert out["shard_err"] < 5e-5, out["shard_err"]
         assert out["sum_err"] < 1e-6, out["sum_err"]
         assert out["identical"]

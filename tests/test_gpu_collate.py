@@ -206,3 +206,39 @@ def test_augmented_frame_batches_vs_oracle():
         if exact >= 2 and noisy >= 4:
             break
     assert exact >= 2 and noisy >= 4
+
+
+def test_ragged_clip_bank_matches_the_dense_bank():
+    """``WakeWordClipBank`` keeps the clips ragged (flat buffer + offsets; one long clip costs its own length only).  The same
+    clips through a dense (N, Lmax) ``DeviceCollate`` and through the ragged bank's ``row_offsets`` form give bit-identical
+    frame and sequence batches (same seeds: same draws, same counter-based noise)."""
+    from types import SimpleNamespace
+    from howl_amd.data.collate import DeviceCollate
+    from howl_amd.data.common.tokenizer import WakeWordTokenizer
+    from howl_amd.data.common.vocab import Vocab
+    from howl_amd.data.transform.batchifier import AudioSequenceBatchifier, DeviceClip, WakeWordFrameBatchifier
+    from howl_amd.training.data import WakeWordClipBank
+    rng = np.random.default_rng(21)
+    lens = [int(v) for v in rng.integers(3000, 30000, 24)] + [200001]          # one long negative
+    clips, dense = _bank(lens, seed=5)
+    meta = [SimpleNamespace(path=f"c{i}", transcription="hey fire fox" if i % 2 else "other words", end_timestamps=None)
+            for i in range(len(lens))]
+    bank = WakeWordClipBank([c.reshape(-1) for c in clips], meta, labeler=None, device=DEV)
+    assert bank.flat.numel() < sum(lens) + 4 * len(lens) + 4 and bank.max_len == max(lens)
+    assert all(torch.equal(bank.clip(i).cpu(), clips[i].reshape(-1)) for i in range(len(lens)))
+    maps = [{float(100 + 37 * i): int(i % 3)} if i % 3 else {} for i in range(len(lens))]
+    examples = [DeviceClip(i, L, m, meta[i].transcription) for i, (L, m) in enumerate(zip(lens, maps))]
+    vocab = Vocab({"hey": 0, "fire": 1, "fox": 2}, oov_token_id=3)
+    for seed in (0, 1, 2, 3):
+        out = []
+        for ragged in (False, True):
+            if ragged:
+                dc = DeviceCollate(bank.rows, bank.lengths, None, max_len=bank.max_len, seed=seed, row_offsets=bank.offsets)
+            else:
+                dc = DeviceCollate(dense.to(DEV), torch.tensor(lens), None, max_len=max(lens), seed=seed)
+            fb = WakeWordFrameBatchifier(3, window_size_ms=500, rand=dc.rand)
+            a = dc.frame_batch(examples, fb)
+            b = dc.sequence_batch(examples, AudioSequenceBatchifier(3, WakeWordTokenizer(vocab, ignore_oov=False)))
+            out.append((a.audio_data.cpu(), a.labels.cpu(), a.lengths, b.audio_data.cpu(), b.labels.cpu(), b.audio_lengths))
+        for u, v in zip(*out):
+            assert torch.equal(torch.as_tensor(u), torch.as_tensor(v))

@@ -228,3 +228,64 @@ def test_phone_token_context_vs_reference_golden(tmp_path):
             InferenceContext(inp["vocab"], token_type="syllable")
     finally:
         SETTINGS.training.phone_dictionary, SETTINGS.inference_engine.inference_sequence = saved
+
+
+def test_reference_written_workspace_round_trip(golden, tmp_path):
+    """f4 against a file the REFERENCE wrote (tests/golden/ref_workspace: ``howl.workspace.Workspace.save_model`` and the
+    ``zmuv.pt.bin`` of ``pretrain_gsc.py:106``, captured by make_golden.py --only-checkpoint): the product's ``Workspace``
+    loads it into the product's ``Res8`` / ``ZmuvTransform`` with no key left over, the loaded weights reproduce the
+    reference's eval logits through the oracle, and a workspace the PRODUCT writes holds the same keys / shapes / dtypes (so
+    stock Howl's ``load_state_dict`` accepts it, ``hubconf.py:53-84``)."""
+    import shutil
+    from pathlib import Path
+    import numpy as np
+    import torch
+    from howl_amd.data.transform.operator import ZmuvTransform
+    from howl_amd.model import RegisteredModel
+    from howl_amd.workspace import Workspace
+    from oracle import frontend as ofe, models as om
+    g = golden("g12_ref_workspace")
+    src = Path(__file__).resolve().parent / "golden" / "ref_workspace"
+    ws = Workspace(tmp_path / "ws", delete_existing=False)
+    for name in ("model-best.pt.bin", "zmuv.pt.bin"):
+        shutil.copyfile(src / name, ws.path / name)
+    C = int(g["num_labels"])
+    model = RegisteredModel.find_registered_class("res8")(C)
+    ws.load_model(model, best=True)                                   # strict load: every key of the reference's file is consumed
+    zmuv = ZmuvTransform()
+    zmuv.load_state_dict(torch.load(str(ws.path / "zmuv.pt.bin"), map_location="cpu"))
+    sd = model.state_dict()
+    assert list(sd.keys()) == list(g["keys"])
+    assert [str(tuple(v.shape)) for v in sd.values()] == list(g["shapes"])
+    assert [str(v.dtype) for v in sd.values()] == list(g["dtypes"])
+    assert list(zmuv.state_dict().keys()) == list(g["zmuv_keys"])
+    # the loaded numbers are the reference's: its eval logits come back through the oracle (pinned elsewhere) to rounding
+    z = ofe.Zmuv()
+    z.total, z.mean, z.mean2 = zmuv.total.clone(), zmuv.mean.clone(), zmuv.mean2.clone()
+    x = z(ofe.standard_audio_transform(torch.from_numpy(g["audio"]), ofe.mel_fb(40)))
+    with torch.no_grad():
+        logits = om.res8_forward({k: v.clone() for k, v in sd.items()}, x, False)
+    assert np.abs(logits.numpy() - g["eval_logits"]).max() < 1e-5
+    # the reverse direction: a product-written workspace is a bare state_dict with the reference's keys, shapes and dtypes
+    ws2 = Workspace(tmp_path / "ws2", delete_existing=False)
+    ws2.save_model(model, best=True)
+    torch.save({k: v.cpu() for k, v in zmuv.state_dict().items()}, str(ws2.path / "zmuv.pt.bin"))
+    ref_file = torch.load(str(src / "model-best.pt.bin"), map_location="cpu")
+    own_file = torch.load(ws2.model_path(best=True), map_location="cpu")
+    assert type(own_file) is type(ref_file) or isinstance(own_file, dict)
+    assert list(own_file.keys()) == list(ref_file.keys())
+    for k in ref_file:
+        assert own_file[k].dtype == ref_file[k].dtype and own_file[k].shape == ref_file[k].shape and torch.equal(own_file[k], ref_file[k]), k
+    zr, zo = torch.load(str(src / "zmuv.pt.bin")), torch.load(str(ws2.path / "zmuv.pt.bin"))
+    assert list(zr.keys()) == list(zo.keys()) and all(torch.equal(zr[k], zo[k]) and zr[k].dtype == zo[k].dtype for k in zr)
+
+
+def test_res8_refuses_other_mel_counts_at_construction(monkeypatch):
+    """Stock Howl defaults to NUM_MELS=80 (settings.py:32); the res8 kernels pool (3,4) over 40 bins: the error comes when the
+    model is built and names the environment variable."""
+    import pytest
+    from howl_amd.model import RegisteredModel
+    from howl_amd.settings import SETTINGS
+    monkeypatch.setattr(SETTINGS.audio_transform, "num_mels", 80)
+    with pytest.raises(ValueError, match="NUM_MELS=40"):
+        RegisteredModel.find_registered_class("res8")(12)
