@@ -41,7 +41,7 @@ class DeviceCollate:
         self.do_replace = do_replace
         self.row_offsets = None if row_offsets is None else [int(v) for v in row_offsets]
         self.max_len, self.sr, self.training = max_len, sr, training
-        self.rand = random if seed is None else random.Random(seed * 1000003 + replica)
+        self.rand = random if seed is None else random.Random(seed + 1000003 * replica)     # replica 0: the stream of Random(seed)
         self._calls = 0
         self._seed = 0 if seed is None else seed
         self._replica_key = (replica * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF      # 0 for a single process: same stream as before
