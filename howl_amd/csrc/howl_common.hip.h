@@ -9,6 +9,16 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // offsets (a generic float* that the optimiser cannot trace back to LDS degrades to flat_load)
 typedef __attribute__((address_space(3))) float lds_f32;
 
+// Makes a VGPR value opaque to the optimiser at this point: what is derived from it afterwards (an LDS address, a byte
+// offset) is recomputed where it is used -- one or two VALU instructions -- instead of being hoisted out of the enclosing
+// loop into registers of its own (the 3x3 convolution kernels sit at the 168-VGPR line of three waves per SIMD; hoisted
+// per-slot addresses were spilled to scratch and reloaded in front of every use).  No code is emitted.
+#if defined(HIPEMU)
+#define HOWL_OPAQUE_V(x) ((void)(x))
+#else
+#define HOWL_OPAQUE_V(x) asm volatile("" : "+v"(x))
+#endif
+
 #define HOWL_OK 0
 #define HOWL_E_ARG (-1)       // bad argument (shape / null pointer / unsupported size)
 #define HOWL_E_LAUNCH (-2)    // hipGetLastError() after a launch reported a failure

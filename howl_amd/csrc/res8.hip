@@ -62,7 +62,6 @@ constexpr int CONV_THREADS = 768;
 constexpr int KFULL = 11;        // full input-channel blocks (4 channels x 9 taps = 9 k-steps each): channels 0..43
 constexpr int KSTEPS = 9 * KFULL + 3;   // + channel 44 alone: its 9 taps as 3 k-steps (taps 4s + k); 102 instead of the 108
                                  // of a zero-padded 12th block: 5.6 % fewer MFMAs in the forward / dgrad K loops
-constexpr int PREF = 8;          // float2 prefetch slots per thread: 768*8*2 >= 45*270
 constexpr int MAX_H = 27;
 constexpr float BN_EPS = 1e-5f;
 constexpr float BN_MOMENTUM = 0.1f;
@@ -75,22 +74,8 @@ __host__ __device__ inline int chan_stride(int H) {
     return cs + pad;
 }
 __host__ __device__ inline int tile_floats(int H) { return CP * chan_stride(H) + 32; }
-// The weight-gradient kernel reads its two tiles CHANNEL-major: lane l & 15 selects the channel (stride CS), lane >> 4 = g one
-// of the four positions of a k-step.  Group g walks along the rows h = g, g + 4, g + 8, ... of the map, one column per k-step,
-// so inside a row every operand address is "lane base + immediate" (no address arithmetic in the K loop, cf. k_run).
-// ds_read_b32 is served per 32-lane half over 32 banks; a half holds {channels 0..15} x {groups g, g+1}: conflict-free iff
-// {CS*i mod 32} are 16 values no two of which are adjacent, i.e. CS = 2 (mod 32) (all even banks), and the two groups' rows
-// are an odd number of floats apart -- hence the row pitch of 13 here (12 in the forward tiles).  A channel holds rows
-// 0 .. 4*ceil(H/4): top halo, H data rows, zero rows up to the last row any group touches; the bottom halo of the last of
-// them is the next channel's top halo.
-constexpr int WPW = 13;
+constexpr int WPW = 13;          // row pitch of the weight-gradient kernel's x tile (see wgrad_body)
 __host__ __device__ inline int wgrad_rounds(int H) { return (H + 3) / 4; }
-__host__ __device__ inline int chan_stride_wgrad(int H) {
-    int cs = (4 * wgrad_rounds(H) + 1) * WPW;
-    int pad = (2 - (cs % 32) + 32) % 32;
-    return cs + pad;
-}
-__host__ __device__ inline int tile_floats_wgrad(int H) { return CP * chan_stride_wgrad(H) + 32; }
 
 // ---------------------------------------------------------------------------------------------------------
 // weight packing: (45,45,3,3) -> per-wave MFMA B fragments  wp[nt][kstep][lane]
@@ -122,15 +107,15 @@ __device__ __forceinline__ void pack_weights_one(const HowlPtrs6& w, float* __re
     dst[idx] = v;
 }
 
-#if defined(HOWL_DIAG_PROBE)  // diagnostic build (tools/probe_wgrad.py): s_memtime stamps of workgroup 0, [wave][slot]
-__device__ unsigned long long* g_howl_probe = nullptr;
-#define HOWL_PROBE(wave_, lane_, slot_)                                                \
-    do {                                                                               \
-        if (g_howl_probe != nullptr && blockIdx.x == 0 && (lane_) == 0 && (slot_) < 64) \
-            g_howl_probe[(wave_) * 64 + (slot_)] = __builtin_amdgcn_s_memtime();        \
+#if defined(HOWL_DIAG_PROBE)  // diagnostic build (tools/probe_step4.py): s_memtime stamps of one workgroup, [wave][slot]; the
+                               // buffer and the block index travel in StageCfg (filled on the host from howl_diag_set_probe)
+#define HOWL_PROBE(cfg_, wave_, lane_, slot_)                                                                    \
+    do {                                                                                                         \
+        if ((cfg_).probe != nullptr && (int)blockIdx.x == (cfg_).probe_block && (lane_) == 0 && (slot_) < 64)    \
+            (cfg_).probe[(wave_) * 64 + (slot_)] = __builtin_amdgcn_s_memtime();                                  \
     } while (0)
 #else
-#define HOWL_PROBE(wave_, lane_, slot_) ((void)0)
+#define HOWL_PROBE(cfg_, wave_, lane_, slot_) ((void)0)
 #endif
 
 // ---------------------------------------------------------------------------------------------------------
@@ -173,56 +158,6 @@ __device__ __forceinline__ double fold_part_column(const float* __restrict__ par
     acc += __shfl_xor(acc, 2);
     acc += __shfl_xor(acc, 4);
     return acc;
-}
-
-// Per-thread staging slots: slot j moves the float2 at element pair e2 = tid + j*768 of an utterance's
-// (45, P) map to its place in the zero-haloed LDS tile.  The destination (and channel, for the BatchNorm
-// parameters) depends only on the thread, so it is packed once: bits 0..19 LDS float offset, 20..25 channel.
-__device__ __forceinline__ void stage_slots(int (&pk)[PREF], int P, int CS, int n2, int tid, int pitch = WP) {
-#pragma unroll
-    for (int j = 0; j < PREF; ++j) {
-        const int e2 = tid + j * CONV_THREADS;
-        const int e = 2 * e2;
-        const int c = e / P;
-        const int p = e - c * P;
-        const int h = p / PW;
-        const int w = p - h * PW;
-        pk[j] = (e2 < n2) ? ((c * CS + (h + 1) * pitch + (w + 1)) | (c << 20)) : -1;
-    }
-}
-
-// registers -> LDS tile, applying x = (|v| - mean[c]) * rstd[c] (no normalisation when !affine).  Stored activations
-// are non-negative by construction (sums of ReLU outputs); layers with a residual add keep the ReLU mask of their own
-// convolution in the sign bit (see conv_utterance), hence the fabs (`absval` is false for gradient tiles).
-__device__ __forceinline__ void stage_tile(const float2 (&pre)[PREF], const int (&pk)[PREF], float* tile,
-                                           const float* lmean, const float* lrstd, bool affine, bool absval) {
-#pragma unroll
-    for (int j = 0; j < PREF; ++j) {
-        if (pk[j] >= 0) {
-            const int c = pk[j] >> 20;
-            float v0 = pre[j].x, v1 = pre[j].y;
-            if (absval) {
-                v0 = fabsf(v0);
-                v1 = fabsf(v1);
-            }
-            if (affine) {
-                const float m = lmean[c], r = lrstd[c];
-                v0 = (v0 - m) * r;
-                v1 = (v1 - m) * r;
-            }
-            float* d = tile + (pk[j] & 0xFFFFF);
-            d[0] = v0;
-            d[1] = v1;
-        }
-    }
-}
-
-__device__ __forceinline__ void prefetch_tile(float2 (&pre)[PREF], const float* src, int n2, int tid) {
-#pragma unroll
-    for (int j = 0; j < PREF; ++j) {
-        const int e2 = tid + j * CONV_THREADS;
-        pre[j] = (e2 < n2) ? reinterpret_cast<const float2*>(src)[e2] : make_float2(0.0f, 0.0f);
-    }
 }
 
 // One wave's share of an utterance: NTW position tiles (j = t0, t0 + ts, ...: t0 = position group + 4 * slice, ts = 4 * slices
@@ -298,30 +233,139 @@ __device__ __forceinline__ void k_tail(KCursor<NTW>& k, f32x4 (&acc)[NTW], const
     }
 }
 
-// two staging slots of the next utterance (straight-line code between K-loop segments: issuing all 8 slots of all 12
-// waves back to back keeps the CU's vector-memory path busy for ~2.5k cycles; spread out, that hides under the MFMAs)
-template <int J>
-__device__ __forceinline__ void prefetch_pair(float2 (&pre)[PREF], const float* nsrc, int n2, int tid) {
-    if (nsrc != nullptr) {
+// ---------------------------------------------------------------------------------------------------------
+// Tile staging UNDER the K loop (round 4).  Rounds 1-3 staged an utterance's whole map between two barriers (registers ->
+// LDS with the K loop stopped: ~3 k cycles per utterance with one tensor, and what made fusing the BatchNorm / ReLU backward
+// into the data gradient's loads a loss: three tensors per element, all of it exposed).  The K loop walks the input channels
+// in order, so the tile is reused in halves instead:
+//   phase A = K groups 0..5  (channels 0..23)          -- meanwhile channels 24..44 of THIS utterance go to LDS
+//   barrier
+//   phase B = K groups 6..10 + channel 44's tail       -- meanwhile channels 0..23 of the NEXT utterance go to LDS
+//   barrier, epilogue
+// (same two barriers per utterance as before; a region is only overwritten after the barrier that ends its last reader).  The
+// global loads of a slot are issued two K groups (~8 k cycles) ahead of its LDS write, three slots at most in flight per thread.
+// What a tile is made of is described by StageCfg:
+//   forward           x = (|s_{i-1}| - mean) * rstd                                     (one tensor)
+//   data gradient     dz_i as stored by bn_relu_bwd_kernel                              (one tensor; HOWL_RES8_BWD_FUSED=0)
+//   data gradient,    dz_i = mask_i * ds_i,  ds_i = rstd * (dx_i - m1 - xhat * m2) + dskip   (three tensors: dx_i, s_i, dskip)
+//   fused             i.e. native_batch_norm_backward + the skip gradient + threshold_backward applied on the way into LDS:
+//                     dz_i never exists in HBM and the elementwise pass between two layers of the backward pass is gone;
+//                     ds_i (the skip gradient two layers down, and conv0's) is written from here on the layers that have one.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int SPLIT_C = 24;                 // channels [0, 24) = K groups 0..5, [24, 45) = groups 6..10 + the tail
+constexpr int KG_A = SPLIT_C / 4;           // K groups of phase A
+constexpr int KG_B = KFULL - KG_A;          // full K groups of phase B
+constexpr int NS0 = 5, NS1 = 4;             // slots per thread: 24 P / 2 <= 3240 and 21 P / 2 <= 2835 float2 over 768 threads
+static_assert(CONV_THREADS * NS0 >= SPLIT_C * MAX_H * PW / 2 && CONV_THREADS * NS1 >= (NMAP - SPLIT_C) * MAX_H * PW / 2, "slots");
+static_assert(KG_A == 6 && KG_B == 5, "the segment schedule of conv_loop is written for 6 + 5 K groups");
+
+// Falling wave priority along a phase (3, 2, 1 over its three K segments): a wave that is ahead yields the matrix pipe to the
+// ones behind it, so that the waves of a SIMD reach the barrier together instead of the oldest one finishing at 2/3 of the
+// phase and the last one running alone, at half the pipe rate (tools/probe_step4.py; -1 us per forward launch).
+#if defined(HOWL_DIAG_NOSTAIR)
+#define HOWL_STAIR(p_) ((void)0)
+#else
+#define HOWL_STAIR(p_) __builtin_amdgcn_s_setprio(p_)
+#endif
+
+struct StageCfg {
+    const float* a;       // forward: s_{i-1}; data gradient: dz_i (plain) or dx_i (fused; nullptr: broadcast of dpool / P, layer 6)
+    const float* s;       // fused: s_i (sign bit / sign = ReLU mask, |s| -> xhat)
+    const float* k;       // fused: ds_{i+2} (skip gradient into s_i) or nullptr
+    float* ds;            // fused: ds_i out, or nullptr
+    const float* dpool;   // fused, a == nullptr: (B, 48) pooled gradient
+    float invP;
+    bool fused;
+    bool even;            // fused: layer i has a residual add (mask in the sign bit of s_i) or not (mask = s_i > 0)
+    bool affine;          // forward: normalise on load
+#if defined(HOWL_DIAG_PROBE)
+    unsigned long long* probe;
+    int probe_block;
+#endif
+};
+
+struct SlotVal {
+    float2 a, s, k;
+};
+
+// slot j of a region (channels c0 .. c0 + nch - 1) moves float2 number tid + 768 j of the region to its place in the zero-haloed
+// tile; destination and channel depend only on the thread: bits 0..19 LDS float offset, 20..25 channel, -1 = no such element
+template <int NSL>
+__device__ __forceinline__ void region_slots(int (&pk)[NSL], int c0, int nch, int P, int CS, int tid) {
 #pragma unroll
-        for (int j = J; j < J + 2; ++j) {
-            const int e2 = tid + j * CONV_THREADS;
-            if (e2 < n2) pre[j] = reinterpret_cast<const float2*>(nsrc)[e2];
-        }
+    for (int j = 0; j < NSL; ++j) {
+        const int e = 2 * (tid + j * CONV_THREADS);
+        const int c = e / P;
+        const int p = e - c * P;
+        const int h = p / PW;
+        const int w = p - h * PW;
+        pk[j] = (e < nch * P) ? (((c0 + c) * CS + (h + 1) * WP + (w + 1)) | ((c0 + c) << 20)) : -1;
     }
 }
 
-// the same for the weight-gradient kernel, which issues four loads per burst: `cond ? load : 0` writes a fresh register
-// under the execution mask, whereas "keep the old value" makes every load wait for the one before it (vmcnt(0))
-template <int J>
-__device__ __forceinline__ void prefetch_pair_fresh(float2 (&pre)[PREF], const float* nsrc, int n2, int tid) {
-    if (nsrc != nullptr) {
-#pragma unroll
-        for (int j = J; j < J + 2; ++j) {
-            const int e2 = tid + j * CONV_THREADS;
-            pre[j] = (e2 < n2) ? reinterpret_cast<const float2*>(nsrc)[e2] : make_float2(0.0f, 0.0f);
+// `base` = float offset of (utterance, region) in every tensor of the configuration (uniform: the addresses are "scalar base
+// + 32-bit lane offset", no 64-bit address lives in a VGPR).  Unconditional loads from clamped offsets (a load under a lane
+// predicate waits for the one before it): slots without an element re-read the region's first.
+template <int MODE>
+__device__ __forceinline__ void slot_load(SlotVal& v, const StageCfg& cfg, size_t base, int i2, int pkj, int b) {
+    HOWL_OPAQUE_V(pkj);
+    const unsigned off = pkj >= 0 ? 8u * (unsigned)i2 : 0u;
+    if (MODE == 1 && cfg.fused) {
+        if (cfg.a != nullptr) {
+            v.a = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(cfg.a + base) + off);
+        } else {
+            const unsigned c4 = pkj >= 0 ? 4u * (unsigned)(pkj >> 20) : 0u;
+            const float g = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(cfg.dpool + (size_t)b * CP) + c4) * cfg.invP;
+            v.a = make_float2(g, g);
         }
+        v.s = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(cfg.s + base) + off);
+        v.k = cfg.k != nullptr ? *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(cfg.k + base) + off)
+                               : make_float2(0.0f, 0.0f);
+    } else {
+        v.a = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(cfg.a + base) + off);
     }
+}
+
+// BatchNorm backward + skip gradient + ReLU mask of one element pair: bn_relu_bwd_kernel's expression, term for term.
+// lm = [mean | rstd | m1 | m2][48] in LDS.
+__device__ __forceinline__ void bn_relu_bwd_pair(const SlotVal& v, const float* lmc, bool even, float2& ds, float2& dz) {
+    const float mean = lmc[0], rstd = lmc[CP], m1 = lmc[2 * CP], m2 = lmc[3 * CP];
+    ds.x = rstd * (v.a.x - m1 - ((fabsf(v.s.x) - mean) * rstd) * m2) + v.k.x;
+    ds.y = rstd * (v.a.y - m1 - ((fabsf(v.s.y) - mean) * rstd) * m2) + v.k.y;
+    // layers with a residual add keep their ReLU mask in the sign bit of s (conv_epilogue), the others in its sign
+    const float t0 = even ? -v.s.x : v.s.x, t1 = even ? -v.s.y : v.s.y;
+    dz.x = t0 > 0.0f ? ds.x : 0.0f;
+    dz.y = t1 > 0.0f ? ds.y : 0.0f;
+}
+
+template <int MODE>
+__device__ __forceinline__ void slot_write(const SlotVal& v, const StageCfg& cfg, size_t base, int i2, int pkj, float* tile,
+                                           const float* lm) {
+    HOWL_OPAQUE_V(pkj);
+    if (pkj < 0) return;
+    const int c = pkj >> 20;
+    float v0 = v.a.x, v1 = v.a.y;
+    if (MODE == 0) {
+        // stored activations are non-negative (sums of ReLU outputs); layers with a residual add keep the ReLU mask of
+        // their own convolution in the sign bit (conv_epilogue), hence the fabs
+        v0 = fabsf(v0);
+        v1 = fabsf(v1);
+        if (cfg.affine) {
+            const float m = lm[c], r = lm[CP + c];
+            v0 = (v0 - m) * r;
+            v1 = (v1 - m) * r;
+        }
+    } else if (cfg.fused) {
+        float2 ds, dz;
+        bn_relu_bwd_pair(v, lm + c, cfg.even, ds, dz);
+        if (cfg.ds != nullptr)
+            *reinterpret_cast<float2*>(reinterpret_cast<char*>(cfg.ds + base) + 8u * (unsigned)i2) = ds;
+        v0 = dz.x;
+        v1 = dz.y;
+    }
+    float* d = tile + (pkj & 0xFFFFF);
+    d[0] = v0;
+    d[1] = v1;
 }
 
 struct ConvEpilogue {
@@ -333,67 +377,31 @@ struct ConvEpilogue {
     bool cvalid;
 };
 
-// MFMA phase + epilogue for one utterance; lane holds cout = 16nt + (lane&15) and, for tile j = t0 + ts * i, positions
-// 16j + 4*(lane>>4) + {0,1,2,3}.  The epilogue's own operands (residual / saved activation at the output positions)
-// are requested before the K loop so that their HBM latency is not exposed after it.
+// Epilogue of one utterance for one wave: lane holds cout = 16nt + (lane&15) and, for tile j = t0 + ts * i, positions
+// 16j + 4*(lane>>4) + {0,1,2,3}.  Its own operands (residual / saved activation at the output positions) are requested before
+// the last K segment (conv_loop) so that their HBM latency is not exposed.
+template <int NTW, int TS>
+struct EpiAddr {
+    unsigned boff, bmax;
+    static constexpr unsigned tstep = 64u * TS;     // bytes between two tiles of this wave
+    __device__ __forceinline__ EpiAddr(const ConvEpilogue& e, int t0, int lane) {
+        // uniform base + one 32-bit lane offset + immediates; only a wave's last tile can overhang P (clamped)
+        const unsigned crow = (unsigned)((e.cvalid ? e.cout : NMAP - 1) * e.P);
+        boff = 4u * (crow + 16u * t0 + 4u * (lane >> 4));
+        bmax = 4u * (crow + e.P - 2);
+    }
+    __device__ __forceinline__ unsigned off(int i, int hh) const {
+        unsigned o = boff + tstep * i + 8u * hh;
+        if (i == NTW - 1) o = o < bmax ? o : bmax;
+        return o;
+    }
+};
+
 template <int MODE, int NTW, int TS>
-__device__ __forceinline__ void conv_utterance(const lds_f32* tile, const lds_f32* wl, int CS, int t0, int lane,
-                                               size_t ubase, const ConvEpilogue& e, float& st0, float& st1,
-                                               float2 (&pre)[PREF], const float* nsrc, int n2, int tid, int prio) {
-    const float* eop = (MODE == 0) ? e.res : e.xs;
-    float2 ev[NTW][2];
-    // uniform base + one 32-bit lane offset + immediates; only a wave's last tile can overhang P (clamped)
-    const char* ebase = reinterpret_cast<const char*>(eop + ubase);
-    const unsigned crow = (unsigned)((e.cvalid ? e.cout : NMAP - 1) * e.P);
-    const unsigned boff = 4u * (crow + 16u * t0 + 4u * (lane >> 4));
-    const unsigned bmax = 4u * (crow + e.P - 2);
+__device__ __forceinline__ void conv_epilogue(const f32x4 (&acc)[NTW], const float2 (&ev)[NTW > 0 ? NTW : 1][2], const ConvEpilogue& e,
+                                              size_t ubase, int t0, int lane, float& st0, float& st1) {
+    const EpiAddr<NTW, TS> ea(e, t0, lane);
     constexpr int ts = TS;
-    constexpr unsigned tstep = 64u * TS;                 // bytes between two tiles of this wave
-    auto fetch_operands = [&](int i) {  // branch-free: all loads in flight together
-#pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-            unsigned off = boff + tstep * i + 8u * hh;
-            if (i == NTW - 1) off = off < bmax ? off : bmax;
-            ev[i][hh] = *reinterpret_cast<const float2*>(ebase + off);
-        }
-    };
-    static_assert(PREF == 8, "four prefetch pairs below");
-    f32x4 acc[NTW];
-    KCursor<NTW> k;
-    k_begin<NTW, TS>(k, acc, tile, wl, CS, e.P, t0, lane);
-    // The three waves of a SIMD (wave, wave+4, wave+8) would otherwise share the matrix pipe evenly, finish their K
-    // loops together and run their epilogues (operand loads, stores) with the pipe idle.  Staggered priorities let
-    // them finish one after the other, so two of the three epilogues run under another wave's MFMAs.
-#if !defined(HOWL_DIAG_CONV_NOPRIO)
-    switch (prio) {
-        case 0: __builtin_amdgcn_s_setprio(3); break;
-        case 1: __builtin_amdgcn_s_setprio(2); break;
-        default: __builtin_amdgcn_s_setprio(1); break;
-    }
-#endif
-    prefetch_pair<0>(pre, nsrc, n2, tid);
-    k_run<NTW>(k, acc, CS, 2);
-    prefetch_pair<2>(pre, nsrc, n2, tid);
-    k_run<NTW>(k, acc, CS, 2);
-    prefetch_pair<4>(pre, nsrc, n2, tid);
-    k_run<NTW>(k, acc, CS, 2);
-    prefetch_pair<6>(pre, nsrc, n2, tid);
-    k_run<NTW>(k, acc, CS, 3);
-    k_run<NTW>(k, acc, CS, KFULL - 9);
-    {
-        int dl[3];
-#pragma unroll
-        for (int s3 = 0; s3 < 3; ++s3) {
-            const int tap = min(4 * s3 + (lane >> 4), 8);   // taps 9..11 meet zero weights: any finite value will do
-            dl[s3] = (tap / 3) * WP + tap % 3 - (lane >> 4) * CS;
-        }
-        k_tail<NTW>(k, acc, dl);
-    }
-    __builtin_amdgcn_s_setprio(0);
-    if (eop != nullptr) {
-#pragma unroll
-        for (int i = 0; i < NTW; ++i) fetch_operands(i);
-    }
     char* obase = reinterpret_cast<char*>(e.out + ubase);
 #pragma unroll
     for (int i = 0; i < NTW; ++i) {
@@ -428,12 +436,9 @@ __device__ __forceinline__ void conv_utterance(const lds_f32* tile, const lds_f3
                 }
 #if defined(HOWL_DIAG_CONV_NOSTORE)
                 if (v0 == 123.456f)  // diagnostic build: epilogue without its global stores
-                    *reinterpret_cast<float2*>(obase + (boff + tstep * i + 8u * hh)) = make_float2(v0, v1);
-#elif defined(HOWL_DIAG_CONV_NTSTORE)
-                __builtin_nontemporal_store(v0, reinterpret_cast<float*>(obase + (boff + tstep * i + 8u * hh)));
-                __builtin_nontemporal_store(v1, reinterpret_cast<float*>(obase + (boff + tstep * i + 8u * hh)) + 1);
+                    *reinterpret_cast<float2*>(obase + (ea.boff + ea.tstep * i + 8u * hh)) = make_float2(v0, v1);
 #else
-                *reinterpret_cast<float2*>(obase + (boff + tstep * i + 8u * hh)) = make_float2(v0, v1);
+                *reinterpret_cast<float2*>(obase + (ea.boff + ea.tstep * i + 8u * hh)) = make_float2(v0, v1);
 #endif
             }
         }
@@ -441,46 +446,173 @@ __device__ __forceinline__ void conv_utterance(const lds_f32* tile, const lds_f3
 }
 
 struct ConvLoop {
-    const float* in;
     const lds_f32* ltile;
     const lds_f32* wnt;
     float* tile;
-    const float* lmean;
-    const float* lrstd;
-    int B, CS, n2, t0, lane, tid;
-    bool affine;
+    const float* lm;
+    int B, CS, t0, lane, tid;
     int nblk;   // utterance strides of the batch loop: workgroups (or groups of `slices` workgroups) sharing the batch
 };
 
-// all utterances b, b + nblk, ... of this workgroup; `pre` holds utterance b's activations on entry
+// All utterances b, b + nblk, ... of this workgroup; on entry channels 0..23 of utterance b are in the tile (barrier passed).
+// Instantiated once per tile count (waves of one workgroup run different instances; every instance executes the same two
+// barriers per utterance): the register allocator then sees one variant's live values, not the union of all five.
 template <int MODE, int NTW, int TS>
-__device__ __forceinline__ void conv_loop(const ConvLoop& c, const ConvEpilogue& epi, float2 (&pre)[PREF],
-                                          const int (&pk)[PREF], int b, float& st0, float& st1) {
-    const int P = epi.P;
+__device__ __forceinline__ void conv_loop(const ConvLoop& c, const ConvEpilogue& epi, const StageCfg& cfg, const int (&pk0)[NS0],
+                                          const int (&pk1)[NS1], int b, float& st0, float& st1, int& pslot) {
+    const int P = epi.P, tid = c.tid, lane = c.lane;
+    const int wave = tid >> 6;
+    const size_t r1 = (size_t)SPLIT_C * P;
+    const float* eop = (MODE == 0) ? epi.res : epi.xs;
+    constexpr int NTV = NTW > 0 ? NTW : 1;
+    int dl[3];
+#pragma unroll
+    for (int s3 = 0; s3 < 3; ++s3) {
+        const int tap = min(4 * s3 + (lane >> 4), 8);   // taps 9..11 meet zero weights: any finite value will do
+        dl[s3] = (tap / 3) * WP + tap % 3 - (lane >> 4) * c.CS;
+    }
     for (; b < c.B; b += c.nblk) {
-        stage_tile(pre, pk, c.tile, c.lmean, c.lrstd, c.affine, MODE == 0);  // gradient tiles (dgrad) are signed
-        __syncthreads();
-        const int bn = b + c.nblk;
-        const float* nsrc = (bn < c.B) ? c.in + (size_t)bn * NMAP * P : nullptr;  // fetched from inside the K loop
         const size_t ubase = (size_t)b * NMAP * P;
-        if constexpr (NTW > 0) {
-            conv_utterance<MODE, NTW, TS>(c.ltile, c.wnt, c.CS, c.t0, c.lane, ubase, epi, st0, st1, pre, nsrc, c.n2, c.tid,
-                                      c.tid >> 8);  // wave / 4: position among the waves of this SIMD
-        } else {
-            // no position tile for this wave (tiny H): it still owns its share of the next utterance's loads
-            if (nsrc != nullptr) prefetch_tile(pre, nsrc, c.n2, c.tid);
+        const int bn = b + c.nblk;
+        const bool more = bn < c.B;                       // (uniform)
+        const size_t nbase = (size_t)bn * NMAP * P;
+        SlotVal v[3];
+        f32x4 acc[NTV];
+        KCursor<NTV> k;
+        if constexpr (NTW > 0) k_begin<NTW, TS>(k, acc, c.ltile, c.wnt, c.CS, P, c.t0, lane);
+        // ---- phase A: channels 0..23 feed the matrix pipe, channels 24..44 of this utterance arrive
+#if defined(HOWL_DIAG_NOSTAGE)   // diagnostic build (tools/variants4.py; WRONG results): the phases without their staging work
+        constexpr bool STAGE = false;
+#else
+        constexpr bool STAGE = true;
+#endif
+#if defined(HOWL_DIAG_DESYNC)    // diagnostic build: the three waves of a SIMD take their staging bursts at different K groups
+        const int wp = tid >> 8;
+        const int a0 = 1 + wp, a1 = 2, a2 = KG_A - 3 - wp;             // bursts after groups {1,3} {2,4} {3,5}
+        const int b0 = wp == 0 ? 1 : 2, b1 = wp == 1 ? 1 : 2, b2 = KG_B - b0 - b1;   // {1,3} {2,3} {2,4}
+#else
+        const int a0 = 2, a1 = 2, a2 = KG_A - 4, b0 = 2, b1 = 2, b2 = KG_B - 4;
+#endif
+        if constexpr (STAGE) {
+            slot_load<MODE>(v[0], cfg, ubase + r1, tid, pk1[0], b);
+            slot_load<MODE>(v[1], cfg, ubase + r1, tid + CONV_THREADS, pk1[1], b);
         }
-        __syncthreads();  // single tile buffer: every wave is done reading before the next utterance is staged
+        HOWL_STAIR(3);
+        if constexpr (NTW > 0) k_run<NTW>(k, acc, c.CS, a0);
+        if constexpr (STAGE) {
+            slot_write<MODE>(v[0], cfg, ubase + r1, tid, pk1[0], c.tile, c.lm);
+            slot_write<MODE>(v[1], cfg, ubase + r1, tid + CONV_THREADS, pk1[1], c.tile, c.lm);
+            slot_load<MODE>(v[0], cfg, ubase + r1, tid + 2 * CONV_THREADS, pk1[2], b);
+            slot_load<MODE>(v[1], cfg, ubase + r1, tid + 3 * CONV_THREADS, pk1[3], b);
+        }
+        HOWL_STAIR(2);
+        if constexpr (NTW > 0) k_run<NTW>(k, acc, c.CS, a1);
+        if constexpr (STAGE) {
+            slot_write<MODE>(v[0], cfg, ubase + r1, tid + 2 * CONV_THREADS, pk1[2], c.tile, c.lm);
+            slot_write<MODE>(v[1], cfg, ubase + r1, tid + 3 * CONV_THREADS, pk1[3], c.tile, c.lm);
+        }
+        HOWL_STAIR(1);
+        if constexpr (NTW > 0) k_run<NTW>(k, acc, c.CS, a2);
+        HOWL_STAIR(0);
+        HOWL_PROBE(cfg, wave, lane, pslot++);   // phase A done
+#if !defined(HOWL_DIAG_NOMIDBAR)   // diagnostic build (with HOWL_DIAG_NOSTAGE): what the barrier in the middle of the K loop costs
+        __syncthreads();      // channels 24..44 complete; every wave is past its reads of channels 0..23
+#endif
+        HOWL_PROBE(cfg, wave, lane, pslot++);   // barrier
+        // ---- phase B: channels 24..44 feed the matrix pipe, channels 0..23 of the NEXT utterance arrive
+        if (STAGE && more) {
+            slot_load<MODE>(v[0], cfg, nbase, tid, pk0[0], bn);
+            slot_load<MODE>(v[1], cfg, nbase, tid + CONV_THREADS, pk0[1], bn);
+            slot_load<MODE>(v[2], cfg, nbase, tid + 2 * CONV_THREADS, pk0[2], bn);
+        }
+        HOWL_STAIR(3);
+        if constexpr (NTW > 0) k_run<NTW>(k, acc, c.CS, b0);
+        if (STAGE && more) {
+            slot_write<MODE>(v[0], cfg, nbase, tid, pk0[0], c.tile, c.lm);
+            slot_write<MODE>(v[1], cfg, nbase, tid + CONV_THREADS, pk0[1], c.tile, c.lm);
+            slot_write<MODE>(v[2], cfg, nbase, tid + 2 * CONV_THREADS, pk0[2], c.tile, c.lm);
+            slot_load<MODE>(v[0], cfg, nbase, tid + 3 * CONV_THREADS, pk0[3], bn);
+            slot_load<MODE>(v[1], cfg, nbase, tid + 4 * CONV_THREADS, pk0[4], bn);
+        }
+        HOWL_STAIR(2);
+        if constexpr (NTW > 0) k_run<NTW>(k, acc, c.CS, b1);
+        if (STAGE && more) {
+            slot_write<MODE>(v[0], cfg, nbase, tid + 3 * CONV_THREADS, pk0[3], c.tile, c.lm);
+            slot_write<MODE>(v[1], cfg, nbase, tid + 4 * CONV_THREADS, pk0[4], c.tile, c.lm);
+        }
+        // the epilogue's operands take the registers the staging slots just released; they land under the last K segment
+        float2 ev[NTV][2];
+        if constexpr (NTW > 0) {
+            if (eop != nullptr) {
+                const EpiAddr<NTW, TS> ea(epi, c.t0, lane);
+                const char* ebase = reinterpret_cast<const char*>(eop + ubase);
+#pragma unroll
+                for (int i = 0; i < NTW; ++i)
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh) ev[i][hh] = *reinterpret_cast<const float2*>(ebase + ea.off(i, hh));
+            }
+            HOWL_STAIR(1);
+            k_run<NTW>(k, acc, c.CS, b2);
+            k_tail<NTW>(k, acc, dl);
+            HOWL_STAIR(0);
+        }
+        HOWL_PROBE(cfg, wave, lane, pslot++);   // phase B done
+        // the epilogue runs in front of the barrier: the waves of a SIMD leave the K loop a few hundred cycles apart, and an
+        // early one's stores go out under the others' last MFMAs (behind the barrier all twelve epilogues ran with the matrix
+        // pipe idle: +1.6 us per forward launch, tools/variants4.py)
+#if defined(HOWL_DIAG_EPI_AFTER)
+        __syncthreads();
+#endif
+        if constexpr (NTW > 0) conv_epilogue<MODE, NTW, TS>(acc, ev, epi, ubase, c.t0, lane, st0, st1);
+        HOWL_PROBE(cfg, wave, lane, pslot++);   // epilogue done
+#if !defined(HOWL_DIAG_EPI_AFTER)
+        __syncthreads();      // channels 0..23 of the next utterance complete; every wave is past its reads of 24..44
+#endif
+        HOWL_PROBE(cfg, wave, lane, pslot++);   // barrier
+    }
+}
+
+// BatchNorm-backward means of layer i for the fused data / weight gradient staging: m1 = sum dx / N, m2 = sum dx * xhat / N,
+// folded by every workgroup from the partials of the data gradient above it (wave w: channels 4w .. 4w+3; fold_part_column:
+// the same bits in every workgroup) -- what bn_relu_bwd_kernel's prologue did -- or copied from the head's m12 (layer 6).
+struct BwdFold {
+    const float* stats;   // {mean, rstd} of layer i
+    const float* m12;     // ready-made means, or
+    const float* part;    // partials [2][48][part_stride(nparts)]
+    int nparts;
+    double count;
+};
+__device__ __forceinline__ void bwd_fold_to_lds(float* lm, const BwdFold& f, int tid, int nthreads) {
+    const int lane = tid & 63, wave = tid >> 6;
+    if (tid < CP) {
+        lm[tid] = f.stats[tid];
+        lm[CP + tid] = f.stats[CP + tid];
+        if (f.part == nullptr) {
+            lm[2 * CP + tid] = f.m12[tid];
+            lm[3 * CP + tid] = f.m12[CP + tid];
+        }
+    }
+    if (f.part != nullptr) {
+        const int c8 = lane >> 3;
+        for (int ch0 = 4 * wave; ch0 < CP; ch0 += 4 * (nthreads >> 6)) {     // (12 waves: one trip)
+            const int ch = ch0 + (c8 & 3);
+            const double acc = fold_part_column(f.part, part_stride(f.nparts), f.nparts, (c8 < 4 ? 0 : CP) + ch, lane);
+            const double second = __shfl_xor(acc, 32);     // column groups 0..3: sum dx, their partners 4..7: sum dx * xhat
+            if (c8 < 4 && (lane & 7) == 0) {
+                lm[2 * CP + ch] = (float)(acc / f.count);
+                lm[3 * CP + ch] = (float)(second / f.count);
+            }
+        }
     }
 }
 
 // MODE 0: forward   out = relu(conv(x)) [+ res]; stats = (sum, sumsq) of out per cout
-// MODE 1: dgrad     out = conv(x);               stats = (sum out, sum out * xhat) per cout, xhat from s_prev
+// MODE 1: dgrad     out = conv(dz);              stats = (sum out, sum out * xhat) per cout, xhat from s_prev
 template <int MODE, int SLICES>
 __device__ __forceinline__ void conv3x3_body(
-    const float* __restrict__ in,         // (B,45,P) input activations (s_{i-1}) or dz_i
-    const float* __restrict__ in_stats,   // {mean[48], rstd[48]} applied on load, or nullptr
-    const float* __restrict__ wp,         // packed weights [3][108][64]
+    StageCfg cfg,                         // the input tile (see StageCfg)
+    const float* __restrict__ in_stats,   // forward: {mean[48], rstd[48]} applied on load, or nullptr
+    const float* __restrict__ wp,         // packed weights [3][102][64]
     const float* __restrict__ res,        // fwd: residual (B,45,P) or nullptr
     float* __restrict__ out,              // (B,45,P)
     const float* __restrict__ xs,         // dgrad: s_{i-1} for xhat, or nullptr (no stats)
@@ -488,23 +620,22 @@ __device__ __forceinline__ void conv3x3_body(
     float* __restrict__ part,             // [nblk][2][48] partial statistics, or nullptr
     int B, int H, int bid, int nblk,      // utterances bid, bid + nblk, ... of this convolution
     int slice,                            // small batches: SLICES (1, 2, 4) workgroups share every utterance's position tiles
-    const BnFold& fold) {                 // forward: the input's BatchNorm statistics still as partials (or part == nullptr)
+    const BnFold& fold,                   // forward: the input's BatchNorm statistics still as partials (or part == nullptr)
+    const BwdFold& bfold) {               // fused data gradient: where m1 / m2 come from
     HIP_DYNAMIC_SHARED(float, lds)
     const int P = H * PW;
     const int CS = chan_stride(H);
     const int TF = tile_floats(H);
-    float* wl = lds;                       // [3][108][64] weight fragments, 82,944 B
+    float* wl = lds;                       // [3][102][64] weight fragments
     float* tile = lds + 3 * KSTEPS * 64;   // one utterance's zero-haloed input map
-    float* lmean = tile + TF;
-    float* lrstd = lmean + CP;
-    float* red = lrstd + CP;  // [12][2][16]
+    float* lm = tile + TF;                 // [mean | rstd | m1 | m2][48]
+    float* red = lm + 4 * CP;              // [12][2][16]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int nt = __builtin_amdgcn_readfirstlane(wave % 3);
     const int mg = __builtin_amdgcn_readfirstlane(wave / 3);
-    const int n2 = NMAP * P / 2;
     const int ntiles = (P + 15) / 16;
     // With fewer utterances than CUs, `slices` workgroups take an utterance each: all of them stage the whole map (the 3x3
     // neighbourhoods need it; the copies come from L2) and the weights, and split the position tiles -- workgroup `slice`
@@ -516,16 +647,24 @@ __device__ __forceinline__ void conv3x3_body(
     const int t0 = mg + 4 * slice;
     const int ntw = t0 < ntiles ? (ntiles - t0 + ts - 1) / ts : 0;  // wave-uniform, <= 5
     const bool folding = MODE == 0 && fold.part != nullptr;
-    const bool affine = in_stats != nullptr || folding;
+    cfg.affine = MODE == 0 && (in_stats != nullptr || folding);
+    if (slice != 0) cfg.ds = nullptr;      // one writer per utterance
 
-    // first utterance's activations are requested before anything else so that HBM latency overlaps the setup
-    float2 pre[PREF];
+    int pk0[NS0], pk1[NS1];
+    region_slots<NS0>(pk0, 0, SPLIT_C, P, CS, tid);
+    region_slots<NS1>(pk1, SPLIT_C, NMAP - SPLIT_C, P, CS, tid);
+
+    // channels 0..23 of the first utterance are requested before anything else so that HBM latency overlaps the setup
     int b = bid;
     int pslot = 0;
-    HOWL_PROBE(wave, lane, pslot++);   // entry
-    if (b < B) prefetch_tile(pre, in + (size_t)b * NMAP * P, n2, tid);
+    HOWL_PROBE(cfg, wave, lane, pslot++);   // entry
+    SlotVal first[NS0];
+    if (b < B) {
+#pragma unroll
+        for (int j = 0; j < NS0; ++j) slot_load<MODE>(first[j], cfg, (size_t)b * NMAP * P, tid + j * CONV_THREADS, pk0[j], b);
+    }
     {
-        float4 wv[7];  // 3*108*16 float4 = 5184 <= 7 * 768: all loads in flight, then the LDS stores
+        float4 wv[7];  // 3*102*16 float4 = 4896 <= 7 * 768: all loads in flight, then the LDS stores
 #pragma unroll
         for (int j = 0; j < 7; ++j) {
             const int i = tid + j * CONV_THREADS;
@@ -535,7 +674,7 @@ __device__ __forceinline__ void conv3x3_body(
             wv[j] = (i < 3 * KSTEPS * 16) ? reinterpret_cast<const float4*>(wp)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
 #endif
         }
-        HOWL_PROBE(wave, lane, pslot++);   // first tile + weights requested
+        HOWL_PROBE(cfg, wave, lane, pslot++);   // first tile + weights requested
         if (MODE == 0 && folding) {
             // Column sums of the producer's partials while the weight loads are in flight, wave by wave with no LDS
             // scratch and no barrier of their own: wave w owns channels 4w..4w+3 (column groups 0..3: the channels' sums,
@@ -551,8 +690,8 @@ __device__ __forceinline__ void conv3x3_body(
                 var = var < 0.0 ? 0.0 : var;
                 const float fm = (ch < NMAP) ? (float)mean : 0.0f;
                 const float fr = (ch < NMAP) ? (float)(1.0 / sqrt(var + (double)BN_EPS)) : 0.0f;
-                lmean[ch] = fm;
-                lrstd[ch] = fr;
+                lm[ch] = fm;
+                lm[CP + ch] = fr;
                 if (bid == 0 && slice == 0) {   // one publisher: later readers (backward pass) and the running buffers (cnn.py:142)
                     fold.stats_out[ch] = fm;
                     fold.stats_out[CP + ch] = fr;
@@ -565,19 +704,20 @@ __device__ __forceinline__ void conv3x3_body(
                 }
             }
         }
-        HOWL_PROBE(wave, lane, pslot++);   // statistics folded
+        if (MODE == 1 && cfg.fused) bwd_fold_to_lds(lm, bfold, tid, CONV_THREADS);
+        HOWL_PROBE(cfg, wave, lane, pslot++);   // statistics folded
         zero_lds(tile, TF, tid, CONV_THREADS);
-        HOWL_PROBE(wave, lane, pslot++);   // tile zeroed
+        HOWL_PROBE(cfg, wave, lane, pslot++);   // tile zeroed
 #pragma unroll
         for (int j = 0; j < 7; ++j) {
             const int i = tid + j * CONV_THREADS;
             if (i < 3 * KSTEPS * 16) reinterpret_cast<float4*>(wl)[i] = wv[j];
         }
-        HOWL_PROBE(wave, lane, pslot++);   // weights in LDS
+        HOWL_PROBE(cfg, wave, lane, pslot++);   // weights in LDS
     }
-    if (!folding && tid < CP) {
-        lmean[tid] = affine ? in_stats[tid] : 0.0f;
-        lrstd[tid] = affine ? in_stats[CP + tid] : 1.0f;
+    if (MODE == 0 && !folding && tid < CP) {
+        lm[tid] = cfg.affine ? in_stats[tid] : 0.0f;
+        lm[CP + tid] = cfg.affine ? in_stats[CP + tid] : 1.0f;
     }
     const int cout = 16 * nt + (lane & 15);
     const bool cvalid = cout < NMAP;
@@ -588,28 +728,27 @@ __device__ __forceinline__ void conv3x3_body(
     }
     float st0 = 0.0f, st1 = 0.0f;
     const ConvEpilogue epi{res, out, xs, xmean, xrstd, cout, P, cvalid};
+    __syncthreads();  // weights, zero fill and the per-channel constants visible before the first stage
+    HOWL_PROBE(cfg, wave, lane, pslot++);   // setup barrier passed
+    if (b < B) {
+#pragma unroll
+        for (int j = 0; j < NS0; ++j)
+            slot_write<MODE>(first[j], cfg, (size_t)b * NMAP * P, tid + j * CONV_THREADS, pk0[j], tile, lm);
+    }
+    __syncthreads();  // channels 0..23 of the first utterance in place
+    HOWL_PROBE(cfg, wave, lane, pslot++);   // first half tile staged
 
-    int pk[PREF];
-    stage_slots(pk, P, CS, n2, tid);
-    HOWL_PROBE(wave, lane, pslot++);   // staging slots computed
-    __syncthreads();  // weights, zero fill and stats visible before the first stage
-    HOWL_PROBE(wave, lane, pslot++);   // setup barrier passed
-
-    // The utterance loop is instantiated once per tile count (waves of one workgroup run different instances; every
-    // instance executes the same two barriers per utterance): the register allocator then sees one variant's live
-    // values, not the union of all five.
-    const ConvLoop cl{in, (const lds_f32*)tile, (const lds_f32*)wl + nt * KSTEPS * 64, tile, lmean, lrstd, B, CS, n2,
-                      t0, lane, tid, affine, nblk};
+    const ConvLoop cl{(const lds_f32*)tile, (const lds_f32*)wl + nt * KSTEPS * 64, tile, lm, B, CS, t0, lane, tid, nblk};
     switch (ntw) {
-        case 5: conv_loop<MODE, 5, ts>(cl, epi, pre, pk, b, st0, st1); break;
-        case 4: conv_loop<MODE, 4, ts>(cl, epi, pre, pk, b, st0, st1); break;
-        case 3: conv_loop<MODE, 3, ts>(cl, epi, pre, pk, b, st0, st1); break;
-        case 2: conv_loop<MODE, 2, ts>(cl, epi, pre, pk, b, st0, st1); break;
-        case 1: conv_loop<MODE, 1, ts>(cl, epi, pre, pk, b, st0, st1); break;
-        default: conv_loop<MODE, 0, ts>(cl, epi, pre, pk, b, st0, st1); break;
+        case 5: conv_loop<MODE, 5, ts>(cl, epi, cfg, pk0, pk1, b, st0, st1, pslot); break;
+        case 4: conv_loop<MODE, 4, ts>(cl, epi, cfg, pk0, pk1, b, st0, st1, pslot); break;
+        case 3: conv_loop<MODE, 3, ts>(cl, epi, cfg, pk0, pk1, b, st0, st1, pslot); break;
+        case 2: conv_loop<MODE, 2, ts>(cl, epi, cfg, pk0, pk1, b, st0, st1, pslot); break;
+        case 1: conv_loop<MODE, 1, ts>(cl, epi, cfg, pk0, pk1, b, st0, st1, pslot); break;
+        default: conv_loop<MODE, 0, ts>(cl, epi, cfg, pk0, pk1, b, st0, st1, pslot); break;
     }
 
-    HOWL_PROBE(wave, lane, pslot++);   // all utterances done
+    HOWL_PROBE(cfg, wave, lane, pslot++);   // all utterances done
     if (part != nullptr) {
         // lanes l, l^16, l^32, l^48 hold the same cout: fold them, then fold the 4 position groups via LDS
         st0 += __shfl_xor(st0, 16);
@@ -633,20 +772,19 @@ __device__ __forceinline__ void conv3x3_body(
 }
 
 template <int MODE, int SLICES>
-__global__ __launch_bounds__(CONV_THREADS) void conv3x3_mfma_kernel(const float* __restrict__ in,
-                                                                    const float* __restrict__ in_stats,
+__global__ __launch_bounds__(CONV_THREADS) void conv3x3_mfma_kernel(StageCfg cfg, const float* __restrict__ in_stats,
                                                                     const float* __restrict__ wp,
                                                                     const float* __restrict__ res, float* __restrict__ out,
                                                                     const float* __restrict__ xs,
                                                                     const float* __restrict__ xs_stats,
                                                                     float* __restrict__ part, int B, int H, int nblk,
-                                                                    BnFold fold) {
+                                                                    BnFold fold, BwdFold bfold) {
     // blocks x, x + 8, ... run on XCD x (the hardware deals blocks round-robin): the SLICES workgroups of an utterance
     // group sit on one XCD and share its L2 copy of the maps
     const int x = blockIdx.x & 7, y = blockIdx.x >> 3;
     const int slice = y % SLICES, bid = (y / SLICES) * 8 + x;
     if (bid >= nblk) return;
-    conv3x3_body<MODE, SLICES>(in, in_stats, wp, res, out, xs, xs_stats, part, B, H, bid, nblk, slice, fold);
+    conv3x3_body<MODE, SLICES>(cfg, in_stats, wp, res, out, xs, xs_stats, part, B, H, bid, nblk, slice, fold, bfold);
 }
 
 
@@ -654,9 +792,39 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_mfma_kernel(const float*
 //
 // One wave owns NB of the 27 N tiles (tap, cin tile) and all three cout tiles: 3*NB accumulator chains that live in
 // registers across every utterance of the workgroup.
+//
+// Tiles (round 4; both CHANNEL-major for the reads: lane & 15 = channel, lane >> 4 = g = one of the four positions of a k-step,
+// group g walks rows g, g + 4, ... one column per k-step, every operand address "lane base + immediate"):
+//   tz  dz_i           [48][4R rows][pitch 11], no halo (read at the output positions only)
+//   tx  x_{i-1}        [48][4R + 4 rows][pitch 13], zero-haloed, in two ROW regions: halo rows 0 .. 4R1+1 for the rounds
+//                      0 .. R1-1 (phase 1), halo rows 4R1 .. 4R+1 for the rounds R1 .. R-1 (phase 2) stored two rows further
+//                      down, so the two data rows both phases read exist twice and a region is only ever overwritten while
+//                      the other phase runs:
+//   phase 1 (rounds < R1)   -- meanwhile the BOTTOM rows of this utterance go to LDS (z rows >= 4R1, x region 2)
+//   barrier
+//   phase 2 (rounds >= R1)  -- meanwhile the TOP rows of the next utterance go to LDS (z rows < 4R1, x region 1)
+//   barrier
+// ds_read_b32 is served per 32-lane half over 32 banks; a half holds {channels 0..15} x {groups g, g+1}: conflict-free iff the
+// channel stride is = 2 (mod 32) (all even banks) and the two groups' rows are an odd number of floats apart (pitches 11, 13).
+// With HOWL_RES8_BWD_FUSED (default) dz_i is built on the way into LDS from (dx_i, s_i, dskip) exactly as the data gradient's
+// staging does (slot_write<1>): neither role of the pair reads a dz tensor.
+constexpr int WPZ = 11;
+constexpr int WNT = 4, WNB = 5;   // staging slots per thread: top regions (<= 13 rows x 45 ch / 2 / 768), bottom regions (<= 16 rows)
+__host__ __device__ inline int wgrad_r1(int H) { return wgrad_rounds(H) / 2; }
+__host__ __device__ inline int chan_stride_z(int H) {
+    const int cs = 4 * wgrad_rounds(H) * WPZ;
+    return cs + (2 - (cs % 32) + 32) % 32;
+}
+__host__ __device__ inline int chan_stride_x(int H) {
+    const int cs = (4 * wgrad_rounds(H) + 4) * WPW;
+    return cs + (2 - (cs % 32) + 32) % 32;
+}
+__host__ __device__ inline int tile_floats_z(int H) { return CP * chan_stride_z(H) + 32; }
+__host__ __device__ inline int tile_floats_x(int H) { return CP * chan_stride_x(H) + 96; }   // slack: the K loop requests one k-step past the end
+
 template <int NB>
 struct WCursor {
-    const lds_f32* ap[3];    // dz rows of the three cout tiles (interior origin), this lane's channel and position group
+    const lds_f32* ap[3];    // dz rows of the three cout tiles, this lane's channel and position group
     const lds_f32* bp[NB];   // x rows of the N tiles (halo origin + tap shift)
 };
 
@@ -669,7 +837,8 @@ __device__ __forceinline__ void wgrad_k_run(WCursor<NB>& c, f32x4 (&acc)[NB][3],
     for (int r = 0; r < rounds; ++r) {
 #pragma unroll
         for (int w = 0; w < PW; ++w) {
-            const int noff = (w + 1 < PW) ? (w + 1) : 4 * WPW;
+            const int noz = (w + 1 < PW) ? (w + 1) : 4 * WPZ;
+            const int nox = (w + 1 < PW) ? (w + 1) : 4 * WPW;
             float nz[3], nx[NB];
 #if defined(HOWL_DIAG_WGRAD_NOLDS)  // diagnostic build: MFMA chains fed from registers (tools/variants.py)
 #pragma unroll
@@ -678,9 +847,9 @@ __device__ __forceinline__ void wgrad_k_run(WCursor<NB>& c, f32x4 (&acc)[NB][3],
             for (int i = 0; i < NB; ++i) nx[i] = bx[i];
 #else
 #pragma unroll
-            for (int mt = 0; mt < 3; ++mt) nz[mt] = c.ap[mt][noff];
+            for (int mt = 0; mt < 3; ++mt) nz[mt] = c.ap[mt][noz];
 #pragma unroll
-            for (int i = 0; i < NB; ++i) nx[i] = c.bp[i][noff];
+            for (int i = 0; i < NB; ++i) nx[i] = c.bp[i][nox];
 #endif
 #pragma unroll
             for (int i = 0; i < NB; ++i)
@@ -698,31 +867,115 @@ __device__ __forceinline__ void wgrad_k_run(WCursor<NB>& c, f32x4 (&acc)[NB][3],
             for (int i = 0; i < NB; ++i) bx[i] = nx[i];
         }
 #pragma unroll
-        for (int mt = 0; mt < 3; ++mt) c.ap[mt] += 4 * WPW;
+        for (int mt = 0; mt < 3; ++mt) c.ap[mt] += 4 * WPZ;
 #pragma unroll
         for (int i = 0; i < NB; ++i) c.bp[i] += 4 * WPW;
     }
 }
 
+// Slot j of a ROW region (data rows h0 .. h1-1 of all 45 channels) moves float2 number tid + 768 j of the region:
+// packed descriptor = LDS float offset (bits 0..14) | float offset inside the utterance's (45, P) map (bits 15..28); -1 = none.
+template <int NSL>
+__device__ __forceinline__ void row_region_slots(int (&pk)[NSL], int h0, int h1, int P, int CS, int pitch, int row0, int col0,
+                                                 int tid) {
+    const int nper = PW * (h1 > h0 ? h1 - h0 : 0);
+    const int nsafe = nper > 0 ? nper : 1;
+#pragma unroll
+    for (int j = 0; j < NSL; ++j) {
+        const int e = 2 * (tid + j * CONV_THREADS);
+        const int c = e / nsafe;
+        const int q = e - c * nsafe;
+        const int hh = q / PW;
+        const int w = q - hh * PW;
+        const int h = h0 + hh;
+        pk[j] = (e < NMAP * nper) ? ((c * CS + (h + row0) * pitch + w + col0) | ((c * P + h * PW + w) << 15)) : -1;
+    }
+}
+
+struct WStage {
+    StageCfg z;           // dz_i: plain (z.a = dz) or fused (z.a = dx_i ...), see StageCfg
+    const float* x;       // s_{i-1}
+    bool xaffine;         // x = (|s| - mean) * rstd, else |s|
+    float invP;
+};
+
+struct WSlot {
+    SlotVal z;
+    float2 x;
+};
+
+// z slot: the data gradient's staging arithmetic (slot_write<1>) with this kernel's addressing; addresses are "uniform base +
+// 32-bit lane offset" recomputed from the packed descriptor where they are used
+__device__ __forceinline__ void wz_load(SlotVal& v, const StageCfg& cfg, size_t ubase, int pkj, int b, float invP) {
+    HOWL_OPAQUE_V(pkj);
+    const unsigned g = pkj >= 0 ? (unsigned)(pkj >> 15) : 0u;
+    const unsigned off = 4u * g;
+    if (cfg.fused) {
+        if (cfg.a != nullptr) {
+            v.a = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(cfg.a + ubase) + off);
+        } else {
+            const unsigned c4 = 4u * (unsigned)(((float)g + 0.5f) * invP);
+            const float gg = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(cfg.dpool + (size_t)b * CP) + c4) * cfg.invP;
+            v.a = make_float2(gg, gg);
+        }
+        v.s = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(cfg.s + ubase) + off);
+        v.k = cfg.k != nullptr ? *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(cfg.k + ubase) + off)
+                               : make_float2(0.0f, 0.0f);
+    } else {
+        v.a = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(cfg.a + ubase) + off);
+    }
+}
+__device__ __forceinline__ void wz_write(const SlotVal& v, const StageCfg& cfg, int pkj, float* tz, const float* lm, float invP) {
+    HOWL_OPAQUE_V(pkj);
+    if (pkj < 0) return;
+    float v0 = v.a.x, v1 = v.a.y;
+    if (cfg.fused) {
+        const int c = (int)(((float)(pkj >> 15) + 0.5f) * invP);
+        float2 ds, dz;
+        bn_relu_bwd_pair(v, lm + c, cfg.even, ds, dz);
+        v0 = dz.x;
+        v1 = dz.y;
+    }
+    float* d = tz + (pkj & 0x7FFF);
+    d[0] = v0;
+    d[1] = v1;
+}
+__device__ __forceinline__ void wx_load(float2& v, const float* x, size_t ubase, int pkj) {
+    HOWL_OPAQUE_V(pkj);
+    const unsigned off = pkj >= 0 ? 4u * (unsigned)(pkj >> 15) : 0u;
+    v = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(x + ubase) + off);
+}
+__device__ __forceinline__ void wx_write(const float2& v, bool affine, int pkj, float* tx, const float* lm, float invP) {
+    HOWL_OPAQUE_V(pkj);
+    if (pkj < 0) return;
+    float v0 = fabsf(v.x), v1 = fabsf(v.y);      // |s|: see conv_epilogue
+    if (affine) {
+        const int c = (int)(((float)(pkj >> 15) + 0.5f) * invP);
+        const float m = lm[4 * CP + c], r = lm[5 * CP + c];
+        v0 = (v0 - m) * r;
+        v1 = (v1 - m) * r;
+    }
+    float* d = tx + (pkj & 0x7FFF);
+    d[0] = v0;
+    d[1] = v1;
+}
+
 struct WgradArgs {
-    const float* dz;
-    const float* s_prev;
+    WStage st;
     float* part;
     float* tz;
     float* tx;
-    const float* lmean;
-    const float* lrstd;
-    int B, P, CS, R, n2, tid, lane, wave;
-    bool affine;
+    const float* lm;
+    int B, P, CSZ, CSX, R, R1, tid, lane, wave;
     int bid, nblk;   // utterances bid, bid + nblk, ...; partial row bid
     int gw;          // this wave's index among the GWS = 12 * slices waves that share the 27 N tiles of those utterances
 };
 
-// all utterances b, b + nblk, ... of this workgroup (pz / px hold utterance b on entry), then this wave's partials
+// all utterances b, b + nblk, ... of this workgroup (the top rows of utterance b are in the tiles on entry), then this wave's partials
 template <int NB, int GWS>
-__device__ __forceinline__ void wgrad_loop(const WgradArgs& a, float2 (&pz)[PREF], float2 (&px)[PREF],
-                                           const int (&pk)[PREF], int b, int& pslot) {
-    const int lane = a.lane, wave = a.wave, CS = a.CS;
+__device__ __forceinline__ void wgrad_loop(const WgradArgs& a, const int (&zt)[WNT], const int (&xt)[WNT], const int (&zb)[WNB],
+                                           const int (&xb)[WNB], int b, int& pslot) {
+    const int lane = a.lane, wave = a.wave;
     const int g = lane >> 4, n = lane & 15;
     f32x4 acc[NB][3];
 #pragma unroll
@@ -735,46 +988,93 @@ __device__ __forceinline__ void wgrad_loop(const WgradArgs& a, float2 (&pz)[PREF
     for (int i = 0; i < NB; ++i) {
         const int q = a.gw + GWS * i;
         const int tap = q / 3, ct = q - 3 * tap;
-        boff[i] = (16 * ct + n) * CS + (g + tap / 3) * WPW + (tap % 3);   // cin row, halo origin + tap shift
+        boff[i] = (16 * ct + n) * a.CSX + (g + tap / 3) * WPW + (tap % 3);   // cin row, halo origin + tap shift
     }
-    const int aoff = n * CS + (g + 1) * WPW + 1;                           // cout row, interior origin
+    const int aoff = n * a.CSZ + g * WPZ;                                    // cout row g, column 0
+    const int R1 = a.R1, R2 = a.R - a.R1;
+    const float invP = a.st.invP;
     for (; b < a.B; b += a.nblk) {
-        stage_tile(pz, pk, a.tz, a.lmean, a.lrstd, false, false);
-        stage_tile(px, pk, a.tx, a.lmean, a.lrstd, a.affine, true);
-        HOWL_PROBE(wave, lane, pslot++);   // staged
-        __syncthreads();
-        HOWL_PROBE(wave, lane, pslot++);   // barrier
+        const size_t ubase = (size_t)b * NMAP * a.P;
         const int bn = b + a.nblk;
-        const float* nz = (bn < a.B) ? a.dz + (size_t)bn * NMAP * a.P : nullptr;
-        const float* nx = (bn < a.B) ? a.s_prev + (size_t)bn * NMAP * a.P : nullptr;
+        const bool more = bn < a.B;                          // (uniform)
+        const size_t nbase = (size_t)bn * NMAP * a.P;
         WCursor<NB> c;
 #pragma unroll
-        for (int mt = 0; mt < 3; ++mt) c.ap[mt] = (const lds_f32*)a.tz + aoff + 16 * mt * CS;
+        for (int mt = 0; mt < 3; ++mt) c.ap[mt] = (const lds_f32*)a.tz + aoff + 16 * mt * a.CSZ;
 #pragma unroll
         for (int i = 0; i < NB; ++i) c.bp[i] = (const lds_f32*)a.tx + boff[i];
         float az[3], bx[NB];
+        WSlot v[2];
+        // ---- phase 1: rounds 0 .. R1-1 on the top rows; the bottom rows of this utterance arrive
 #pragma unroll
         for (int mt = 0; mt < 3; ++mt) az[mt] = c.ap[mt][0];
 #pragma unroll
         for (int i = 0; i < NB; ++i) bx[i] = c.bp[i][0];
-        // The next utterance's 16 loads per thread are issued in four bursts between segments of the K loop (see
-        // prefetch_pair): back to back they would hold up the first MFMAs for several thousand cycles.
-        const int rq = a.R / 4;
-        prefetch_pair_fresh<0>(pz, nz, a.n2, a.tid);
-        prefetch_pair_fresh<0>(px, nx, a.n2, a.tid);
-        wgrad_k_run<NB>(c, acc, az, bx, rq);
-        prefetch_pair_fresh<2>(pz, nz, a.n2, a.tid);
-        prefetch_pair_fresh<2>(px, nx, a.n2, a.tid);
-        wgrad_k_run<NB>(c, acc, az, bx, rq);
-        prefetch_pair_fresh<4>(pz, nz, a.n2, a.tid);
-        prefetch_pair_fresh<4>(px, nx, a.n2, a.tid);
-        wgrad_k_run<NB>(c, acc, az, bx, rq);
-        prefetch_pair_fresh<6>(pz, nz, a.n2, a.tid);
-        prefetch_pair_fresh<6>(px, nx, a.n2, a.tid);
-        wgrad_k_run<NB>(c, acc, az, bx, a.R - 3 * rq);
-        HOWL_PROBE(wave, lane, pslot++);   // K loop done
-        __syncthreads();  // single-buffered tiles: everyone done before the next stage overwrites them
-        HOWL_PROBE(wave, lane, pslot++);   // barrier
+        static_assert(WNB == 5 && WNT == 4, "the staging schedule below is written for 5 + 4 slot pairs");
+#define HOWL_W_LOAD(slot_, j_, zpk_, xpk_, ub_, bb_)                          \
+    do {                                                                     \
+        wz_load(v[slot_].z, a.st.z, ub_, zpk_[j_], bb_, invP);               \
+        wx_load(v[slot_].x, a.st.x, ub_, xpk_[j_]);                          \
+    } while (0)
+#define HOWL_W_WRITE(slot_, j_, zpk_, xpk_)                                   \
+    do {                                                                     \
+        wz_write(v[slot_].z, a.st.z, zpk_[j_], a.tz, a.lm, invP);            \
+        wx_write(v[slot_].x, a.st.xaffine, xpk_[j_], a.tx, a.lm, invP);      \
+    } while (0)
+        HOWL_W_LOAD(0, 0, zb, xb, ubase, b);
+        HOWL_W_LOAD(1, 1, zb, xb, ubase, b);
+        HOWL_STAIR(3);
+        if (R1 > 0) wgrad_k_run<NB>(c, acc, az, bx, 1);
+        HOWL_W_WRITE(0, 0, zb, xb);
+        HOWL_W_WRITE(1, 1, zb, xb);
+        HOWL_W_LOAD(0, 2, zb, xb, ubase, b);
+        HOWL_W_LOAD(1, 3, zb, xb, ubase, b);
+        HOWL_STAIR(2);
+        if (R1 > 1) wgrad_k_run<NB>(c, acc, az, bx, 1);
+        HOWL_W_WRITE(0, 2, zb, xb);
+        HOWL_W_WRITE(1, 3, zb, xb);
+        HOWL_W_LOAD(0, 4, zb, xb, ubase, b);
+        HOWL_STAIR(1);
+        if (R1 > 2) wgrad_k_run<NB>(c, acc, az, bx, R1 - 2);
+        HOWL_STAIR(0);
+        HOWL_W_WRITE(0, 4, zb, xb);
+        HOWL_PROBE(a.st.z, wave, lane, pslot++);   // phase 1 done
+        __syncthreads();      // bottom rows complete; every wave is past its reads of the top rows
+        HOWL_PROBE(a.st.z, wave, lane, pslot++);   // barrier
+        // ---- phase 2: rounds R1 .. R-1 on the bottom rows (x: region 2, two tile rows further down); the top rows of the
+        // next utterance arrive.  The operands requested ahead by the last k-step of phase 1 predate the barrier: re-read.
+#pragma unroll
+        for (int i = 0; i < NB; ++i) c.bp[i] += 2 * WPW;
+#pragma unroll
+        for (int mt = 0; mt < 3; ++mt) az[mt] = c.ap[mt][0];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) bx[i] = c.bp[i][0];
+        if (more) {
+            HOWL_W_LOAD(0, 0, zt, xt, nbase, bn);
+            HOWL_W_LOAD(1, 1, zt, xt, nbase, bn);
+        }
+        HOWL_STAIR(3);
+        wgrad_k_run<NB>(c, acc, az, bx, 1);
+        if (more) {
+            HOWL_W_WRITE(0, 0, zt, xt);
+            HOWL_W_WRITE(1, 1, zt, xt);
+            HOWL_W_LOAD(0, 2, zt, xt, nbase, bn);
+            HOWL_W_LOAD(1, 3, zt, xt, nbase, bn);
+        }
+        HOWL_STAIR(2);
+        if (R2 > 1) wgrad_k_run<NB>(c, acc, az, bx, 1);
+        if (more) {
+            HOWL_W_WRITE(0, 2, zt, xt);
+            HOWL_W_WRITE(1, 3, zt, xt);
+        }
+        HOWL_STAIR(1);
+        if (R2 > 2) wgrad_k_run<NB>(c, acc, az, bx, R2 - 2);
+        HOWL_STAIR(0);
+#undef HOWL_W_LOAD
+#undef HOWL_W_WRITE
+        HOWL_PROBE(a.st.z, wave, lane, pslot++);   // phase 2 done
+        __syncthreads();      // top rows of the next utterance complete; every wave is past its reads of the bottom rows
+        HOWL_PROBE(a.st.z, wave, lane, pslot++);   // barrier
     }
     // D[row = cout = 16mt + 4*(lane>>4) + r][col = n = lane&15 -> cin = 16ct + col] for N tile q = (tap, ct)
     float* dst = a.part + (size_t)a.bid * CP * 432;
@@ -794,73 +1094,91 @@ __device__ __forceinline__ void wgrad_loop(const WgradArgs& a, float2 (&pz)[PREF
 
 template <int SLICES>
 __device__ __forceinline__ void wgrad_body(
-    const float* __restrict__ dz, const float* __restrict__ s_prev, const float* __restrict__ in_stats,
+    WStage st, const float* __restrict__ in_stats /* {mean, rstd} of layer i-1 or nullptr */, const BwdFold& bfold,
     float* __restrict__ part /* [nblk][48][432] */, int B, int H, int bid, int nblk, int slice) {
     HIP_DYNAMIC_SHARED(float, lds)
     const int P = H * PW;
-    const int CS = chan_stride_wgrad(H);
-    const int TF = tile_floats_wgrad(H);
+    const int CSZ = chan_stride_z(H), CSX = chan_stride_x(H);
     float* tz = lds;
-    float* tx = lds + TF;
-    float* lmean = lds + 2 * TF;
-    float* lrstd = lmean + CP;
+    float* tx = lds + tile_floats_z(H);
+    float* lm = tx + tile_floats_x(H);      // [mean_i | rstd_i | m1 | m2 | mean_{i-1} | rstd_{i-1}][48]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int n2 = NMAP * P / 2;
-    const bool affine = in_stats != nullptr;
+    const int R = wgrad_rounds(H), R1 = wgrad_r1(H);
+    st.xaffine = in_stats != nullptr;
+    st.invP = 1.0f / (float)P;
+    st.z.ds = nullptr;                      // ds_i is written by the data gradient's staging
     int pslot = 0;
-    HOWL_PROBE(wave, lane, pslot++);   // entry
+    HOWL_PROBE(st.z, wave, lane, pslot++);   // entry
 
-    // staging slots first (integer divisions: many temporaries), then the first utterance's tiles are requested before
-    // the LDS setup so that HBM latency overlaps it
-    int pk[PREF];
-    stage_slots(pk, P, CS, n2, tid, WPW);
-    float2 pz[PREF], px[PREF];
+    // row regions: phase 1 reads z rows < 4 R1 and x halo rows <= 4 R1 + 1 (data rows <= 4 R1); phase 2 the z rows >= 4 R1 and
+    // x halo rows >= 4 R1 (data rows >= 4 R1 - 1), kept two tile rows further down
+    const int zsplit = 4 * R1 < H ? 4 * R1 : H;
+    const int xtop = R1 > 0 ? (4 * R1 + 1 < H ? 4 * R1 + 1 : H) : 0;
+    const int xbot = 4 * R1 - 1 > 0 ? 4 * R1 - 1 : 0;
+    int zt[WNT], xt[WNT], zb[WNB], xb[WNB];
+    row_region_slots<WNT>(zt, 0, zsplit, P, CSZ, WPZ, 0, 0, tid);
+    row_region_slots<WNT>(xt, 0, xtop, P, CSX, WPW, 1, 1, tid);
+    row_region_slots<WNB>(zb, zsplit, H, P, CSZ, WPZ, 0, 0, tid);
+    row_region_slots<WNB>(xb, xbot, H, P, CSX, WPW, 3, 1, tid);
+    // the first utterance's top rows are requested before the LDS setup so that HBM latency overlaps it
     const int b = bid;
+    WSlot first[WNT];
     if (b < B) {
-        prefetch_tile(pz, dz + (size_t)b * NMAP * P, n2, tid);
-        prefetch_tile(px, s_prev + (size_t)b * NMAP * P, n2, tid);
+#pragma unroll
+        for (int j = 0; j < WNT; ++j) {
+            wz_load(first[j].z, st.z, (size_t)b * NMAP * P, zt[j], b, st.invP);
+            wx_load(first[j].x, st.x, (size_t)b * NMAP * P, xt[j]);
+        }
     }
-    zero_lds(lds, 2 * TF, tid, CONV_THREADS);
+    zero_lds(lds, tile_floats_z(H) + tile_floats_x(H), tid, CONV_THREADS);
+    if (st.z.fused) {
+        bwd_fold_to_lds(lm, bfold, tid, CONV_THREADS);
+    }
     if (tid < CP) {
-        lmean[tid] = affine ? in_stats[tid] : 0.0f;
-        lrstd[tid] = affine ? in_stats[CP + tid] : 1.0f;
+        lm[4 * CP + tid] = st.xaffine ? in_stats[tid] : 0.0f;
+        lm[5 * CP + tid] = st.xaffine ? in_stats[CP + tid] : 1.0f;
     }
     __syncthreads();
-    HOWL_PROBE(wave, lane, pslot++);   // prologue done
+    if (b < B) {
+#pragma unroll
+        for (int j = 0; j < WNT; ++j) {
+            wz_write(first[j].z, st.z, zt[j], tz, lm, st.invP);
+            wx_write(first[j].x, st.xaffine, xt[j], tx, lm, st.invP);
+        }
+    }
+    __syncthreads();
+    HOWL_PROBE(st.z, wave, lane, pslot++);   // prologue done
     // instantiated per tile count (waves 0..2 carry a third N tile): no branches inside the K loop, and the register
     // allocator sees one variant's live values (waves of a workgroup run different instances with the same barriers)
     // small batches: two workgroups share an utterance group's 27 N tiles (each stages both maps; wave gw of the 24 owns tiles
     // gw, gw + 24) and write disjoint columns of the same partial row
     constexpr int GWS = 12 * SLICES;
     const int gw = wave + 12 * slice;
-    const WgradArgs a{dz, s_prev, part, tz, tx, lmean, lrstd, B, P, CS, wgrad_rounds(H), n2, tid, lane, wave, affine,
-                      bid, nblk, gw};
+    const WgradArgs a{st, part, tz, tx, lm, B, P, CSZ, CSX, R, R1, tid, lane, wave, bid, nblk, gw};
     if constexpr (SLICES == 1) {       // tiles wave, wave + 12, wave + 24 (< 27): waves 0..2 carry a third one
         if (wave + 24 < 27)
-            wgrad_loop<3, GWS>(a, pz, px, pk, b, pslot);
+            wgrad_loop<3, GWS>(a, zt, xt, zb, xb, b, pslot);
         else
-            wgrad_loop<2, GWS>(a, pz, px, pk, b, pslot);
+            wgrad_loop<2, GWS>(a, zt, xt, zb, xb, b, pslot);
     } else {                           // tiles gw, gw + 24 (< 27)
         if (gw + 24 < 27)
-            wgrad_loop<2, GWS>(a, pz, px, pk, b, pslot);
+            wgrad_loop<2, GWS>(a, zt, xt, zb, xb, b, pslot);
         else
-            wgrad_loop<1, GWS>(a, pz, px, pk, b, pslot);
+            wgrad_loop<1, GWS>(a, zt, xt, zb, xb, b, pslot);
     }
-    HOWL_PROBE(wave, lane, pslot++);   // partials written
+    HOWL_PROBE(st.z, wave, lane, pslot++);   // partials written
 }
 
 template <int SLICES>
-__global__ __launch_bounds__(CONV_THREADS) void wgrad_mfma_kernel(const float* __restrict__ dz,
-                                                                  const float* __restrict__ s_prev,
-                                                                  const float* __restrict__ in_stats,
+__global__ __launch_bounds__(CONV_THREADS) void wgrad_mfma_kernel(WStage st, const float* __restrict__ in_stats, BwdFold bfold,
                                                                   float* __restrict__ part, int B, int H, int nblk) {
     const int x = blockIdx.x & 7, y = blockIdx.x >> 3;
     const int slice = y % SLICES, bid = (y / SLICES) * 8 + x;
     if (bid >= nblk) return;
-    wgrad_body<SLICES>(dz, s_prev, in_stats, part, B, H, bid, nblk, slice);
+    wgrad_body<SLICES>(st, in_stats, bfold, part, B, H, bid, nblk, slice);
 }
 
 // Data gradient and weight gradient of one layer in ONE launch.  Both hang off dz_i and are independent; side by side on
@@ -868,10 +1186,10 @@ __global__ __launch_bounds__(CONV_THREADS) void wgrad_mfma_kernel(const float* _
 // first-tile fetch, tail) are paid once per two utterance passes.  (Round 1 ran them on two HIP queues: the event
 // record / wait pairs that fork and join the second queue cost ~6.5 us each on this stack, twice per layer on the
 // critical path.)  Blocks come in groups of 16: the first 8 run the data gradient, the other 8 the weight gradient, so
-// that pair j of either role lands on the same XCD (block b runs on XCD b % 8) and shares its L2 copy of dz.
+// that pair j of either role lands on the same XCD (block b runs on XCD b % 8) and shares its L2 copy of what both stage.
 template <int SD, int SW>
 __global__ __launch_bounds__(CONV_THREADS) void bwd_pair_kernel(
-    const float* __restrict__ dz, const float* __restrict__ wp, float* __restrict__ dx, const float* __restrict__ xs,
+    StageCfg zc, BwdFold bfold, const float* __restrict__ wp, float* __restrict__ dx, const float* __restrict__ xs,
     const float* __restrict__ xs_stats, float* __restrict__ spart, const float* __restrict__ s_prev,
     const float* __restrict__ in_stats, float* __restrict__ wpart, int B, int H, int nblk) {
     // groups of 8 * (SD + SW) blocks: utterance group j = 8 * (group index) + x on XCD x gets SD data-gradient workgroups
@@ -881,9 +1199,9 @@ __global__ __launch_bounds__(CONV_THREADS) void bwd_pair_kernel(
     const int j = (y / (SD + SW)) * 8 + x;
     if (j >= nblk) return;
     if (r < SD)
-        conv3x3_body<1, SD>(dz, nullptr, wp, nullptr, dx, xs, xs_stats, spart, B, H, j, nblk, r, BnFold{});
+        conv3x3_body<1, SD>(zc, nullptr, wp, nullptr, dx, xs, xs_stats, spart, B, H, j, nblk, r, BnFold{}, bfold);
     else
-        wgrad_body<SW>(dz, s_prev, in_stats, wpart, B, H, j, nblk, r - SD);
+        wgrad_body<SW>(WStage{zc, s_prev, false, 0.0f}, in_stats, bfold, wpart, B, H, j, nblk, r - SD);
 }
 
 // Deterministic sum over the per-workgroup partial rows: part[g][col], g < nparts.  A block owns 64 columns
@@ -1610,16 +1928,27 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
     }
 }
 
-size_t conv_lds_bytes(int H) { return (size_t)(3 * KSTEPS * 64 + tile_floats(H) + 2 * CP + 12 * 2 * 16) * sizeof(float); }
+size_t conv_lds_bytes(int H) { return (size_t)(3 * KSTEPS * 64 + tile_floats(H) + 4 * CP + 12 * 2 * 16) * sizeof(float); }
 #if defined(HOWL_DIAG_PROBE)
+unsigned long long* g_probe_ptr = nullptr;
+int g_probe_blk = 0;
 }  // namespace
-extern "C" int howl_diag_set_probe(unsigned long long* buf) {
-    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_howl_probe), &buf, sizeof(buf));
+extern "C" int howl_diag_set_probe(unsigned long long* buf, int block) {
+    g_probe_ptr = buf;
+    g_probe_blk = block;
+    return 0;
 }
 namespace {
+StageCfg with_probe(StageCfg c) {
+    c.probe = g_probe_ptr;
+    c.probe_block = g_probe_blk;
+    return c;
+}
+#else
+StageCfg with_probe(StageCfg c) { return c; }
 #endif
 
-size_t wgrad_lds_bytes(int H) { return (size_t)(2 * tile_floats_wgrad(H) + 2 * CP) * sizeof(float); }
+size_t wgrad_lds_bytes(int H) { return (size_t)(tile_floats_z(H) + tile_floats_x(H) + 6 * CP) * sizeof(float); }
 size_t conv0_wgrad_mfma_lds_bytes(int T, int M) {
     const int P = ((T / 3)) * PW;
     return (size_t)(T + 2) * (M + 4) * sizeof(float) + (size_t)NMAP * P * sizeof(float) +
@@ -1717,45 +2046,54 @@ void pair_slices(int nblk, int H, int* sd, int* sw) {
 }
 
 // launchers: one instantiation per slicing factor (dynamic LDS limit raised on the instance that is launched)
+StageCfg plain_tile(const float* t) { return StageCfg{t, nullptr, nullptr, nullptr, nullptr, 0.0f, false, false, false}; }
 template <int MODE, int SLICES>
-void launch_conv3x3_inst(int nblk, size_t lds, hipStream_t stream, const float* in, const float* in_stats, const float* wp,
+void launch_conv3x3_inst(int nblk, size_t lds, hipStream_t stream, const StageCfg& in, const float* in_stats, const float* wp,
                          const float* res, float* out, const float* xs, const float* xs_stats, float* part, int B, int H,
-                         const BnFold& fold) {
+                         const BnFold& fold, const BwdFold& bfold) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_mfma_kernel<MODE, SLICES>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((conv3x3_mfma_kernel<MODE, SLICES>), dim3(launch_blocks(nblk, SLICES)), dim3(CONV_THREADS), lds, stream, in,
-                       in_stats, wp, res, out, xs, xs_stats, part, B, H, nblk, fold);
+    hipLaunchKernelGGL((conv3x3_mfma_kernel<MODE, SLICES>), dim3(launch_blocks(nblk, SLICES)), dim3(CONV_THREADS), lds, stream, with_probe(in),
+                       in_stats, wp, res, out, xs, xs_stats, part, B, H, nblk, fold, bfold);
 }
 template <int MODE>
-void launch_conv3x3(int slices, int nblk, size_t lds, hipStream_t stream, const float* in, const float* in_stats, const float* wp,
+void launch_conv3x3(int slices, int nblk, size_t lds, hipStream_t stream, const StageCfg& in, const float* in_stats, const float* wp,
                     const float* res, float* out, const float* xs, const float* xs_stats, float* part, int B, int H,
-                    const BnFold& fold) {
+                    const BnFold& fold, const BwdFold& bfold = BwdFold{}) {
     if (slices == 4)
-        launch_conv3x3_inst<MODE, 4>(nblk, lds, stream, in, in_stats, wp, res, out, xs, xs_stats, part, B, H, fold);
+        launch_conv3x3_inst<MODE, 4>(nblk, lds, stream, in, in_stats, wp, res, out, xs, xs_stats, part, B, H, fold, bfold);
     else if (slices == 2)
-        launch_conv3x3_inst<MODE, 2>(nblk, lds, stream, in, in_stats, wp, res, out, xs, xs_stats, part, B, H, fold);
+        launch_conv3x3_inst<MODE, 2>(nblk, lds, stream, in, in_stats, wp, res, out, xs, xs_stats, part, B, H, fold, bfold);
     else
-        launch_conv3x3_inst<MODE, 1>(nblk, lds, stream, in, in_stats, wp, res, out, xs, xs_stats, part, B, H, fold);
+        launch_conv3x3_inst<MODE, 1>(nblk, lds, stream, in, in_stats, wp, res, out, xs, xs_stats, part, B, H, fold, bfold);
+}
+template <int SW>
+void launch_wgrad_inst(int nblk, size_t lds, hipStream_t stream, const StageCfg& zc, const BwdFold& bfold, const float* s_prev,
+                       const float* in_stats, float* wpart, int B, int H) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_mfma_kernel<SW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(wgrad_mfma_kernel<SW>, dim3(launch_blocks(nblk, SW)), dim3(CONV_THREADS), lds, stream,
+                       WStage{with_probe(zc), s_prev, false, 0.0f}, in_stats, bfold, wpart, B, H, nblk);
 }
 template <int SD, int SW>
-void launch_pair_inst(int nblk, size_t lds, hipStream_t stream, const float* dz, const float* wp, float* dx, const float* xs,
-                      const float* xs_stats, float* spart, const float* s_prev, const float* in_stats, float* wpart, int B, int H) {
+void launch_pair_inst(int nblk, size_t lds, hipStream_t stream, const StageCfg& zc, const BwdFold& bfold, const float* wp, float* dx,
+                      const float* xs, const float* xs_stats, float* spart, const float* s_prev, const float* in_stats, float* wpart,
+                      int B, int H) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(bwd_pair_kernel<SD, SW>), hipFuncAttributeMaxDynamicSharedMemorySize,
                         (int)lds);
-    hipLaunchKernelGGL((bwd_pair_kernel<SD, SW>), dim3(launch_blocks(nblk, SD + SW)), dim3(CONV_THREADS), lds, stream, dz, wp, dx, xs,
-                       xs_stats, spart, s_prev, in_stats, wpart, B, H, nblk);
+    hipLaunchKernelGGL((bwd_pair_kernel<SD, SW>), dim3(launch_blocks(nblk, SD + SW)), dim3(CONV_THREADS), lds, stream, with_probe(zc), bfold, wp,
+                       dx, xs, xs_stats, spart, s_prev, in_stats, wpart, B, H, nblk);
 }
-void launch_pair(int sd, int sw, int nblk, size_t lds, hipStream_t stream, const float* dz, const float* wp, float* dx,
-                 const float* xs, const float* xs_stats, float* spart, const float* s_prev, const float* in_stats, float* wpart,
-                 int B, int H) {
+void launch_pair(int sd, int sw, int nblk, size_t lds, hipStream_t stream, const StageCfg& zc, const BwdFold& bfold, const float* wp,
+                 float* dx, const float* xs, const float* xs_stats, float* spart, const float* s_prev, const float* in_stats,
+                 float* wpart, int B, int H) {
     if (sd == 4 && sw == 2)
-        launch_pair_inst<4, 2>(nblk, lds, stream, dz, wp, dx, xs, xs_stats, spart, s_prev, in_stats, wpart, B, H);
+        launch_pair_inst<4, 2>(nblk, lds, stream, zc, bfold, wp, dx, xs, xs_stats, spart, s_prev, in_stats, wpart, B, H);
     else if (sd == 2 && sw == 2)
-        launch_pair_inst<2, 2>(nblk, lds, stream, dz, wp, dx, xs, xs_stats, spart, s_prev, in_stats, wpart, B, H);
+        launch_pair_inst<2, 2>(nblk, lds, stream, zc, bfold, wp, dx, xs, xs_stats, spart, s_prev, in_stats, wpart, B, H);
     else if (sd == 2 && sw == 1)
-        launch_pair_inst<2, 1>(nblk, lds, stream, dz, wp, dx, xs, xs_stats, spart, s_prev, in_stats, wpart, B, H);
+        launch_pair_inst<2, 1>(nblk, lds, stream, zc, bfold, wp, dx, xs, xs_stats, spart, s_prev, in_stats, wpart, B, H);
     else
-        launch_pair_inst<1, 1>(nblk, lds, stream, dz, wp, dx, xs, xs_stats, spart, s_prev, in_stats, wpart, B, H);
+        launch_pair_inst<1, 1>(nblk, lds, stream, zc, bfold, wp, dx, xs, xs_stats, spart, s_prev, in_stats, wpart, B, H);
 }
 
 }  // namespace
@@ -1827,7 +2165,7 @@ int res8_fwd_impl(const HowlRes8Params* prm, const float* feat, long sb, long st
         }
         {
             HowlProfScope prof("conv3x3_fwd", stream);
-            launch_conv3x3<0>(SL, G, lc, stream, sv->s[i - 1], in_stats, w.wp_fwd + (size_t)(i - 1) * 3 * KSTEPS * 64, res, sv->s[i],
+            launch_conv3x3<0>(SL, G, lc, stream, plain_tile(sv->s[i - 1]), in_stats, w.wp_fwd + (size_t)(i - 1) * 3 * KSTEPS * 64, res, sv->s[i],
                               nullptr, nullptr, part_out, B, H, fold);
         }
     }
@@ -1930,7 +2268,7 @@ int howl_res8_fwd_long(const HowlRes8Params* prm, const float* feat, long sb, lo
         const bool even = (i % 2) == 0;
         int out = 0;
         while (out == cur || out == skip) ++out;
-        launch_conv3x3<0>(SL, G, lc, stream, buf[cur], i == 1 ? (const float*)nullptr : (const float*)(stats + (size_t)(i - 2) * 2 * CP),
+        launch_conv3x3<0>(SL, G, lc, stream, plain_tile(buf[cur]), i == 1 ? (const float*)nullptr : (const float*)(stats + (size_t)(i - 2) * 2 * CP),
                           w.wp_fwd + (size_t)(i - 1) * 3 * KSTEPS * 64, even ? (const float*)buf[skip] : (const float*)nullptr, buf[out],
                           nullptr, nullptr, nullptr, Bv, WIN_H, BnFold{});
         if (even) skip = out;      // s_i (i even) is the next residual source; s_0 is the first one
@@ -1988,6 +2326,10 @@ int res8_bwd_impl(const HowlRes8Params* prm, const float* feat, long sb, long st
     const size_t lp = lc > lw ? lc : lw;
     const char* pair_env = getenv("HOWL_RES8_BWD_PAIR");
     const bool merged = !(pair_env != nullptr && pair_env[0] == '0');
+    // HOWL_RES8_BWD_FUSED=0: the elementwise BatchNorm / ReLU backward as its own launch per layer (bn_relu_bwd_kernel writes
+    // dz_i, the pair stages it as it is) -- the reference point of the tests; default: built inside the pair's staging
+    const char* fused_env = getenv("HOWL_RES8_BWD_FUSED");
+    const bool fused = !(fused_env != nullptr && fused_env[0] == '0');
     // dgrad and wgrad side by side: half the CUs each
     const int half = howl_num_cus() / 2 > 0 ? howl_num_cus() / 2 : 1;
     const int Gh = B < half ? B : half;
@@ -2003,10 +2345,20 @@ int res8_bwd_impl(const HowlRes8Params* prm, const float* feat, long sb, long st
         const float* stats_i = sv->bn_stats + (size_t)(i - 1) * 2 * CP;
         float* ds_out = even ? ds_free : nullptr;
         float* dz = even ? w.dz : w.dz2;
+        // the BatchNorm-backward statistics travel as partials from the data gradient of layer i+1 to the consumer of dx_i; the
+        // fused pair reads them in its prologue while its own data-gradient workgroups write theirs at their end: two buffers
+        float* part_in = fused ? ((i & 1) ? w.part2 : w.part) : w.part;
+        float* part_out = fused ? ((i & 1) ? w.part : w.part2) : w.part;
         // layer 6 takes its two means from the head (m12); the others fold the partials of the data gradient above them
-        if (run_layers) hipLaunchKernelGGL(bn_relu_bwd_kernel, dim3(eg), dim3(BRB_THREADS), 0, stream, (const float*)dx_cur, w.dpool, sv->s[i],
-                           stats_i, w.m12, i == 6 ? (const float*)nullptr : (const float*)w.part, Gh * SD, count,
-                           even ? (const float*)ds_prev : (const float*)nullptr, even ? 1 : 0, ds_out, dz, B, P);
+        const BwdFold bfold{stats_i, w.m12, i == 6 ? (const float*)nullptr : (const float*)part_in, Gh * SD, count};
+        StageCfg zc = plain_tile(dz);
+        if (fused)
+            zc = StageCfg{dx_cur, sv->s[i], even ? (const float*)ds_prev : (const float*)nullptr, ds_out, w.dpool, 1.0f / (float)P,
+                          true, even, false};
+        else if (run_layers)
+            hipLaunchKernelGGL(bn_relu_bwd_kernel, dim3(eg), dim3(BRB_THREADS), 0, stream, (const float*)dx_cur, w.dpool, sv->s[i],
+                               stats_i, w.m12, bfold.part, Gh * SD, count, even ? (const float*)ds_prev : (const float*)nullptr,
+                               even ? 1 : 0, ds_out, dz, B, P);
         if (even) {
             float* t = ds_prev ? ds_prev : w.dsb;
             ds_prev = ds_out;
@@ -2018,30 +2370,25 @@ int res8_bwd_impl(const HowlRes8Params* prm, const float* feat, long sb, long st
         const bool need_stats = i > 1;
         const float* wpb = w.wp_bwd + (size_t)(i - 1) * 3 * KSTEPS * 64;
         const float* xs = need_stats ? sv->s[i - 1] : (const float*)nullptr;
-        float* spart = need_stats ? w.part : (float*)nullptr;
+        float* spart = need_stats ? part_out : (float*)nullptr;
         float* wpart = w.wpart + (size_t)(i - 1) * wpart_stride;
         if (!run_layers) {
             // part 2 only replays the buffer rotation of the loop
         } else if (merged) {
             HowlProfScope prof("bwd_pair", stream);
-            launch_pair(SD, SW, Gh, lp, stream, dz, wpb, dx_next, xs, in_stats, spart, sv->s[i - 1], in_stats, wpart, B, H);
+            launch_pair(SD, SW, Gh, lp, stream, zc, bfold, wpb, dx_next, xs, in_stats, spart, sv->s[i - 1], in_stats, wpart, B, H);
         } else {
             {
                 HowlProfScope prof("conv3x3_dgrad", stream);
-                launch_conv3x3<1>(SD, Gh, lc, stream, dz, nullptr, wpb, nullptr, dx_next, xs, in_stats, spart, B, H, BnFold{});
+                launch_conv3x3<1>(SD, Gh, lc, stream, zc, nullptr, wpb, nullptr, dx_next, xs, in_stats, spart, B, H, BnFold{}, bfold);
             }
             HowlProfScope prof("wgrad", stream);
-            if (SW == 2) {
-                hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_mfma_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)lw);
-                hipLaunchKernelGGL(wgrad_mfma_kernel<2>, dim3(launch_blocks(Gh, 2)), dim3(CONV_THREADS), lw, stream, (const float*)dz,
-                                   sv->s[i - 1], in_stats, wpart, B, H, Gh);
-            } else {
-                hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_mfma_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)lw);
-                hipLaunchKernelGGL(wgrad_mfma_kernel<1>, dim3(launch_blocks(Gh, 1)), dim3(CONV_THREADS), lw, stream, (const float*)dz,
-                                   sv->s[i - 1], in_stats, wpart, B, H, Gh);
-            }
+            StageCfg zw = zc;
+            zw.ds = nullptr;
+            if (SW == 2)
+                launch_wgrad_inst<2>(Gh, lw, stream, zw, bfold, sv->s[i - 1], in_stats, wpart, B, H);
+            else
+                launch_wgrad_inst<1>(Gh, lw, stream, zw, bfold, sv->s[i - 1], in_stats, wpart, B, H);
         }
         dx_cur = dx_next;
         dx_next = (dx_next == w.bufa) ? w.bufb : w.bufa;

@@ -257,3 +257,59 @@ def test_fused_forward_cross_entropy_is_bit_identical(lib):
         for k, v in g_ref.items():
             np.testing.assert_array_equal(h.grads_np[k], v, err_msg=k)
         np.testing.assert_array_equal(h.np["bn3.running_mean"], ref.np["bn3.running_mean"])
+
+
+def test_many_utterances_per_workgroup_fused_and_unfused_backward():
+    """The tile staging runs UNDER the K loop (csrc/res8.hip, "Tile staging UNDER the K loop"): a workgroup with several
+    utterances stages the next one's halves while it multiplies the current one's.  Two emulated CUs, so that workgroups carry
+    2-5 utterances in the forward (conv grid 2) and in both roles of the backward pair (grid 1 each); geometries with an odd and
+    an even number of weight-gradient rounds.  The fused backward (BatchNorm / ReLU backward built inside the pair's staging,
+    default) and the unfused one (HOWL_RES8_BWD_FUSED=0: bn_relu_bwd_kernel writes dz) must agree with each other to rounding
+    and both with the oracle."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    code = r"""
+import json, os, sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+os.environ.setdefault("NUM_MELS", "40")
+import numpy as np, torch
+from emu_util import emu_lib, ptr
+import test_emu_res8 as T
+from oracle import models as om
+lib = emu_lib()
+out = {}
+for B, Tf, C in ((5, 41, 4), (4, 81, 12), (3, 62, 5)):
+    x = T.feats(B, Tf, 7)
+    labels = torch.arange(B) %% C
+    sd = om.res8_init(C); names = om.res8_param_names()
+    params = {n: sd[n].clone().requires_grad_(True) for n in names}
+    sd_ref = dict(sd); sd_ref.update(params)
+    ref_logits = om.res8_forward(sd_ref, x, True)
+    gref = torch.autograd.grad(torch.nn.functional.cross_entropy(ref_logits, labels), [params[n] for n in names])
+    res = {}
+    for fused in ("1", "0"):
+        os.environ["HOWL_RES8_BWD_FUSED"] = fused
+        h = T.Res8Harness(lib, B, Tf, C)
+        logits = h.fwd(x[:, 0].permute(0, 2, 1).numpy(), training=True)
+        dlogits = np.zeros((B, C), np.float32); loss = np.zeros(1, np.float32)
+        lab = np.ascontiguousarray(labels.numpy(), np.int64)
+        lib.call("howl_xent_fwd_bwd", ptr(h.logits), ptr(lab), B, C, ptr(loss), ptr(dlogits), None)
+        res[fused] = (logits, h.bwd(dlogits))
+    errs = {"logits": float(np.abs(res["1"][0] - ref_logits.detach().numpy()).max())}
+    for n, g in zip(names, gref):
+        scale = max(1.0, float(g.abs().max()))
+        errs["oracle." + n] = max(float(np.abs(res[f][1][n] - g.numpy()).max()) for f in ("1", "0")) / scale
+        errs["fused_vs_unfused." + n] = float(np.abs(res["1"][1][n] - res["0"][1][n]).max()) / scale
+    out["%%d_%%d" %% (B, Tf)] = errs
+print("RESULT" + json.dumps(out))
+""" % (str(Path(__file__).resolve().parent.parent), str(Path(__file__).resolve().parent))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, HIPEMU_CUS="2"), capture_output=True, text=True, timeout=2400)
+    assert r.returncode == 0, r.stderr[-3000:]
+    res = json.loads(r.stdout.split("RESULT", 1)[1])
+    for key, errs in res.items():
+        for name, e in errs.items():
+            tol = 2e-5 if name == "logits" or name.startswith("oracle.") else 2e-6
+            assert e < tol, (key, name, e)
