@@ -538,6 +538,8 @@ def main():
         if model_name == "res8":
             tf, nf, _ = read("conv3x3_fwd")
             tp, npair, _ = read("bwd_pair")
+            t0f, n0f, _ = read("conv0_fwd")
+            t0w, n0w, _ = read("conv0_wgrad")
             H = T // 3
             flops_launch = 2.0 * 9 * 45 * 45 * (H * 10) * B
             # the forward launches run alone on the device; dgrad and wgrad of a layer share ONE launch (half the CUs
@@ -567,6 +569,9 @@ def main():
                             "avg_launch_ms": round(fwd_ms, 4), "launches": nf, "tflops": round(fwd_tf, 2),
                             "frac": round(fwd_tf / FP32_MFMA_PEAK_TFLOPS, 4), "algorithmic_bytes": round(act * 2.5),
                             "traffic": None if fwd_traffic is None else round(fwd_traffic)},
+                        "conv0 (1->45 3x3 + ReLU + AvgPool(3,4): forward / weight gradient launches)": {
+                            "fwd_avg_launch_ms": round(t0f / max(n0f, 1), 4), "wgrad_avg_launch_ms": round(t0w / max(n0w, 1), 4),
+                            "algorithmic_flops_each": round(2.0 * 9 * 45 * (3 * H) * 40 * B)},
                         "logmel": logmel}}
         elif model_name == "seq-lstm":
             parts = {t: read(t) for t in ("lstm_fwd", "lstm_bwd", "gemm")}

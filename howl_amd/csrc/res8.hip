@@ -375,6 +375,10 @@ struct ConvEpilogue {
     float xmean, xrstd;
     int cout, P;
     bool cvalid;
+    bool xadd;       // data gradient, no statistics wanted (xs_stats == nullptr): xs is a tensor to ADD to the output (layer 1: the
+                     // skip gradient ds_2 joins dx_0 here, so conv0's weight gradient reads one map instead of two)
+    float* pool;     // forward, last layer: [B][npg][48] sums of |out| over a wave's positions (npg = 4 * slices position groups
+    int npg, pg;     // per utterance; this wave is group pg) -- the head's spatial mean without a second pass over s_6
 };
 
 // Epilogue of one utterance for one wave: lane holds cout = 16nt + (lane&15) and, for tile j = t0 + ts * i, positions
@@ -399,10 +403,11 @@ struct EpiAddr {
 
 template <int MODE, int NTW, int TS>
 __device__ __forceinline__ void conv_epilogue(const f32x4 (&acc)[NTW], const float2 (&ev)[NTW > 0 ? NTW : 1][2], const ConvEpilogue& e,
-                                              size_t ubase, int t0, int lane, float& st0, float& st1) {
+                                              size_t ubase, int t0, int lane, float& st0, float& st1, int b) {
     const EpiAddr<NTW, TS> ea(e, t0, lane);
     constexpr int ts = TS;
     char* obase = reinterpret_cast<char*>(e.out + ubase);
+    float u0 = 0.0f, u1 = 0.0f;      // this utterance's share of the two statistics sums
 #pragma unroll
     for (int i = 0; i < NTW; ++i) {
         const int mbase = 16 * (t0 + ts * i) + 4 * (lane >> 4);
@@ -421,18 +426,23 @@ __device__ __forceinline__ void conv_epilogue(const f32x4 (&acc)[NTW], const flo
                         const bool k0 = v0 > 0.0f, k1 = v1 > 0.0f;
                         v0 += fabsf(r.x);
                         v1 += fabsf(r.y);
-                        st0 += v0 + v1;
-                        st1 += v0 * v0 + v1 * v1;
+                        u0 += v0 + v1;
+                        u1 += v0 * v0 + v1 * v1;
                         v0 = k0 ? -v0 : v0;
                         v1 = k1 ? -v1 : v1;
                     } else {
-                        st0 += v0 + v1;
-                        st1 += v0 * v0 + v1 * v1;
+                        u0 += v0 + v1;
+                        u1 += v0 * v0 + v1 * v1;
                     }
                 } else if (e.xs != nullptr) {
                     const float2 sv = ev[i][hh];
-                    st0 += v0 + v1;
-                    st1 += v0 * ((fabsf(sv.x) - e.xmean) * e.xrstd) + v1 * ((fabsf(sv.y) - e.xmean) * e.xrstd);
+                    if (e.xadd) {
+                        v0 += sv.x;
+                        v1 += sv.y;
+                    } else {
+                        u0 += v0 + v1;
+                        u1 += v0 * ((fabsf(sv.x) - e.xmean) * e.xrstd) + v1 * ((fabsf(sv.y) - e.xmean) * e.xrstd);
+                    }
                 }
 #if defined(HOWL_DIAG_CONV_NOSTORE)
                 if (v0 == 123.456f)  // diagnostic build: epilogue without its global stores
@@ -442,6 +452,17 @@ __device__ __forceinline__ void conv_epilogue(const f32x4 (&acc)[NTW], const flo
 #endif
             }
         }
+    }
+    st0 += u0;
+    st1 += u1;
+    if (MODE == 0 && e.pool != nullptr) {
+        // last layer: the head's spatial mean without a second pass over s_6 -- u0 is the sum of the (non-negative) outputs over
+        // this wave's positions; fold the four lane groups (lanes l, l^16, l^32, l^48 hold the same cout) and leave one value
+        // per (utterance, position group, cout)
+        float up = u0;
+        up += __shfl_xor(up, 16);
+        up += __shfl_xor(up, 32);
+        if (lane < 16 && e.cvalid) e.pool[((size_t)b * e.npg + e.pg) * CP + e.cout] = up;
     }
 }
 
@@ -563,7 +584,7 @@ __device__ __forceinline__ void conv_loop(const ConvLoop& c, const ConvEpilogue&
 #if defined(HOWL_DIAG_EPI_AFTER)
         __syncthreads();
 #endif
-        if constexpr (NTW > 0) conv_epilogue<MODE, NTW, TS>(acc, ev, epi, ubase, c.t0, lane, st0, st1);
+        if constexpr (NTW > 0) conv_epilogue<MODE, NTW, TS>(acc, ev, epi, ubase, c.t0, lane, st0, st1, b);
         HOWL_PROBE(cfg, wave, lane, pslot++);   // epilogue done
 #if !defined(HOWL_DIAG_EPI_AFTER)
         __syncthreads();      // channels 0..23 of the next utterance complete; every wave is past its reads of 24..44
@@ -606,6 +627,16 @@ __device__ __forceinline__ void bwd_fold_to_lds(float* lm, const BwdFold& f, int
     }
 }
 
+// The weight-gradient partials of the layer ABOVE (written by the previous pair launch, one row of [48][432] per weight-gradient
+// workgroup) are folded by the data-gradient workgroups of this launch once their own work is done: the pair's duration is set
+// by its weight-gradient role, the data-gradient role finishes ~10 us earlier, so the fold of 10.6 MB per layer costs nothing
+// (it was one 18-us launch over all six layers at the end of the pass).  Fixed order: bit-reproducible.
+struct WFold {
+    const float* part;   // [nparts][48 * 432], or nullptr
+    int nparts;
+    float* out;          // dW (45,45,3,3) of that layer
+};
+
 // MODE 0: forward   out = relu(conv(x)) [+ res]; stats = (sum, sumsq) of out per cout
 // MODE 1: dgrad     out = conv(dz);              stats = (sum out, sum out * xhat) per cout, xhat from s_prev
 template <int MODE, int SLICES>
@@ -618,10 +649,12 @@ __device__ __forceinline__ void conv3x3_body(
     const float* __restrict__ xs,         // dgrad: s_{i-1} for xhat, or nullptr (no stats)
     const float* __restrict__ xs_stats,   // dgrad: {mean, rstd} of layer i-1
     float* __restrict__ part,             // [nblk][2][48] partial statistics, or nullptr
+    float* __restrict__ pool,             // forward, last layer: per-utterance sums for the head (ConvEpilogue::pool), or nullptr
     int B, int H, int bid, int nblk,      // utterances bid, bid + nblk, ... of this convolution
     int slice,                            // small batches: SLICES (1, 2, 4) workgroups share every utterance's position tiles
     const BnFold& fold,                   // forward: the input's BatchNorm statistics still as partials (or part == nullptr)
-    const BwdFold& bfold) {               // fused data gradient: where m1 / m2 come from
+    const BwdFold& bfold,                 // fused data gradient: where m1 / m2 come from
+    const WFold& wf = WFold{nullptr, 0, nullptr}) {   // data gradient: weight-gradient partials to fold at the end
     HIP_DYNAMIC_SHARED(float, lds)
     const int P = H * PW;
     const int CS = chan_stride(H);
@@ -722,12 +755,13 @@ __device__ __forceinline__ void conv3x3_body(
     const int cout = 16 * nt + (lane & 15);
     const bool cvalid = cout < NMAP;
     float xmean = 0.0f, xrstd = 1.0f;
-    if (MODE == 1 && xs != nullptr && cvalid) {
+    if (MODE == 1 && xs != nullptr && xs_stats != nullptr && cvalid) {
         xmean = xs_stats[cout];
         xrstd = xs_stats[CP + cout];
     }
     float st0 = 0.0f, st1 = 0.0f;
-    const ConvEpilogue epi{res, out, xs, xmean, xrstd, cout, P, cvalid};
+    const ConvEpilogue epi{res, out, xs, xmean, xrstd, cout, P, cvalid, MODE == 1 && xs != nullptr && xs_stats == nullptr,
+                           pool, 4 * slices, t0};
     __syncthreads();  // weights, zero fill and the per-channel constants visible before the first stage
     HOWL_PROBE(cfg, wave, lane, pslot++);   // setup barrier passed
     if (b < B) {
@@ -769,6 +803,54 @@ __device__ __forceinline__ void conv3x3_body(
             part[((size_t)which * CP + c) * part_stride(nblk * slices) + bid * slices + slice] = s;   // transposed: see fold_part_column
         }
     }
+    if (MODE == 1 && wf.part != nullptr) {
+        // this workgroup's share of the 48 * 432 columns, two at a time: 96 pair lanes x 8 row groups, up to 16 rows in flight
+        // per thread, the row groups combined through LDS (the tile is free: every wave is past the loop's last barrier)
+        constexpr int NCOL2 = CP * 432 / 2;
+        const int nwg = nblk * slices, wg = bid * slices + slice;
+        const int per = (NCOL2 + nwg - 1) / nwg;
+        const int q0 = wg * per, q1 = (q0 + per < NCOL2) ? q0 + per : NCOL2;
+        const int pl = tid % 96, rg = tid / 96;
+        float2* scratch = reinterpret_cast<float2*>(tile);
+        for (int qb = q0; qb < q1; qb += 96) {       // (uniform trip count)
+            const int q = qb + pl;
+            float2 acc = make_float2(0.0f, 0.0f);
+            if (q < q1) {
+                const float2* src = reinterpret_cast<const float2*>(wf.part) + q;
+                for (int g0 = rg; g0 < wf.nparts; g0 += 8 * 16) {
+                    float2 v[16];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) {
+                        const int g = g0 + 8 * u;
+                        v[u] = src[(size_t)(g < wf.nparts ? g : wf.nparts - 1) * NCOL2];      // clamped: all in flight
+                    }
+#pragma unroll
+                    for (int u = 0; u < 16; ++u)
+                        if (g0 + 8 * u < wf.nparts) {
+                            acc.x += v[u].x;
+                            acc.y += v[u].y;
+                        }
+                }
+            }
+            scratch[rg * 96 + pl] = acc;
+            __syncthreads();
+            if (rg == 0 && q < q1) {
+                float2 tot = scratch[pl];
+#pragma unroll
+                for (int r = 1; r < 8; ++r) {
+                    tot.x += scratch[r * 96 + pl].x;
+                    tot.y += scratch[r * 96 + pl].y;
+                }
+                // column (cout, tap, cin) of the accumulator layout [48][9][48] -> dW[(cout * 45 + cin) * 9 + tap]
+                const int col = 2 * q;
+                const int co = col / 432, r = col - co * 432;
+                const int tap = r / CP, ci = r - tap * CP;
+                if (co < NMAP && ci < NMAP) wf.out[(co * NMAP + ci) * 9 + tap] = tot.x;
+                if (co < NMAP && ci + 1 < NMAP) wf.out[(co * NMAP + ci + 1) * 9 + tap] = tot.y;
+            }
+            __syncthreads();
+        }
+    }
 }
 
 template <int MODE, int SLICES>
@@ -777,14 +859,14 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_mfma_kernel(StageCfg cfg
                                                                     const float* __restrict__ res, float* __restrict__ out,
                                                                     const float* __restrict__ xs,
                                                                     const float* __restrict__ xs_stats,
-                                                                    float* __restrict__ part, int B, int H, int nblk,
-                                                                    BnFold fold, BwdFold bfold) {
+                                                                    float* __restrict__ part, float* __restrict__ pool, int B,
+                                                                    int H, int nblk, BnFold fold, BwdFold bfold, WFold wf) {
     // blocks x, x + 8, ... run on XCD x (the hardware deals blocks round-robin): the SLICES workgroups of an utterance
     // group sit on one XCD and share its L2 copy of the maps
     const int x = blockIdx.x & 7, y = blockIdx.x >> 3;
     const int slice = y % SLICES, bid = (y / SLICES) * 8 + x;
     if (bid >= nblk) return;
-    conv3x3_body<MODE, SLICES>(cfg, in_stats, wp, res, out, xs, xs_stats, part, B, H, bid, nblk, slice, fold, bfold);
+    conv3x3_body<MODE, SLICES>(cfg, in_stats, wp, res, out, xs, xs_stats, part, pool, B, H, bid, nblk, slice, fold, bfold, wf);
 }
 
 
@@ -1191,7 +1273,7 @@ template <int SD, int SW>
 __global__ __launch_bounds__(CONV_THREADS) void bwd_pair_kernel(
     StageCfg zc, BwdFold bfold, const float* __restrict__ wp, float* __restrict__ dx, const float* __restrict__ xs,
     const float* __restrict__ xs_stats, float* __restrict__ spart, const float* __restrict__ s_prev,
-    const float* __restrict__ in_stats, float* __restrict__ wpart, int B, int H, int nblk) {
+    const float* __restrict__ in_stats, float* __restrict__ wpart, int B, int H, int nblk, WFold wf) {
     // groups of 8 * (SD + SW) blocks: utterance group j = 8 * (group index) + x on XCD x gets SD data-gradient workgroups
     // (position slices) and SW weight-gradient workgroups (N-tile slices); SD = SW = 1 at full batches
     const int x = blockIdx.x & 7, y = blockIdx.x >> 3;
@@ -1199,7 +1281,7 @@ __global__ __launch_bounds__(CONV_THREADS) void bwd_pair_kernel(
     const int j = (y / (SD + SW)) * 8 + x;
     if (j >= nblk) return;
     if (r < SD)
-        conv3x3_body<1, SD>(zc, nullptr, wp, nullptr, dx, xs, xs_stats, spart, B, H, j, nblk, r, BnFold{}, bfold);
+        conv3x3_body<1, SD>(zc, nullptr, wp, nullptr, dx, xs, xs_stats, spart, nullptr, B, H, j, nblk, r, BnFold{}, bfold, wf);
     else
         wgrad_body<SW>(WStage{zc, s_prev, false, 0.0f}, in_stats, bfold, wpart, B, H, j, nblk, r - SD);
 }
@@ -1210,36 +1292,30 @@ __global__ __launch_bounds__(CONV_THREADS) void bwd_pair_kernel(
 //   mode 1: col = (cout, tap, cin) of the wgrad accumulator layout [48][9][48] -> dW[(cout*45 + cin)*9 + tap]
 __device__ __forceinline__ void reduce_rows_body(const float* __restrict__ part, int nparts, int ncols, int mode,
                                                  float* __restrict__ out) {
-    __shared__ float red[4][64];
-    const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    __shared__ float red[16][64];
+    const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6, nrg = blockDim.x >> 6;     // up to 16 row groups
     const int col = blockIdx.x * 64 + lane;
     float s = 0.0f;
     if (col < ncols) {
         const float* src = part + col;
-        int g = rg;
-        // eight rows in flight per lane (a wave's share of 128-256 partial rows is a chain of dependent round trips otherwise);
+        // eight rows in flight per lane (a wave's share of the partial rows is a chain of dependent round trips otherwise);
         // the order of the additions is that of the rows either way
-        for (; g + 28 < nparts; g += 32) {
+        for (int g = rg; g < nparts; g += 8 * nrg) {
             float v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(g + 4 * u) * ncols];
+            for (int u = 0; u < 8; ++u) {
+                const int r = g + u * nrg;
+                v[u] = src[(size_t)(r < nparts ? r : nparts - 1) * ncols];
+            }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) s += v[u];
+            for (int u = 0; u < 8; ++u) s += (g + u * nrg < nparts) ? v[u] : 0.0f;
         }
-        for (; g + 12 < nparts; g += 16) {
-            const float v0 = src[(size_t)g * ncols], v1 = src[(size_t)(g + 4) * ncols];
-            const float v2 = src[(size_t)(g + 8) * ncols], v3 = src[(size_t)(g + 12) * ncols];
-            s += v0;
-            s += v1;
-            s += v2;
-            s += v3;
-        }
-        for (; g < nparts; g += 4) s += src[(size_t)g * ncols];
     }
     red[rg][lane] = s;
     __syncthreads();
     if (rg == 0 && col < ncols) {
-        const float tot = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
+        float tot = red[0][lane];
+        for (int r = 1; r < nrg; ++r) tot += red[r][lane];
         if (mode == 0) {
             out[col] = tot;
         } else {
@@ -1250,17 +1326,13 @@ __device__ __forceinline__ void reduce_rows_body(const float* __restrict__ part,
     }
 }
 
-__global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ part, int nparts, int ncols,
-                                                          int mode, float* __restrict__ out) {
-    reduce_rows_body(part, nparts, ncols, mode, out);
-}
-
 // every weight gradient of the backward pass in one launch: blockIdx.y = 0..5 -> conv layer y+1 (partials of layer l at
 // part + l * layer_stride), blockIdx.y = 6 -> conv0 (its own partial rows)
-__global__ __launch_bounds__(256) void reduce_rows_all_kernel(const float* __restrict__ part, size_t layer_stride, int nparts,
+__global__ __launch_bounds__(1024) void reduce_rows_all_kernel(const float* __restrict__ part, size_t layer_stride, int nparts,
                                                               HowlPtrs6 out, const float* __restrict__ c0part, int c0parts,
-                                                              float* __restrict__ c0out, int y0) {
-    const int y = (int)blockIdx.y + y0;      // a launch covers rows y0 .. y0 + gridDim.y - 1 of {layer 1..6, conv0}
+                                                              float* __restrict__ c0out, int y0, int yskip) {
+    // a launch covers rows y0, y0 + 1 + yskip, ... of {layer 1..6, conv0} (layers 2..6 are folded inside the pair launches)
+    const int y = y0 + (int)blockIdx.y * (1 + yskip);
     if (y < 6) {
         reduce_rows_body(part + y * layer_stride, nparts, CP * 432, 1, out.p[y]);
     } else if (blockIdx.x * 64 < NMAP * 9) {
@@ -1444,15 +1516,10 @@ __device__ __forceinline__ void load_feat_tile(float* tin, const float* feat, lo
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Both run on the matrix cores (a VALU formulation of the same kernels took 45 / 86 us per launch at B = 512, these take
-// 40 / 53 us; git history has it).  dy0 = ga + gb is the gradient of the pooled output (dx_0 from layer 1 + the skip), the
-// ReLU pattern of the pre-pool activation comes from the forward's 12-bit masks (2 B per pooled output instead of the
-// 583 KB/utterance tensor or a recomputation).
-//   forward: D[position][cout] = sum_tap patch[position][tap] * w[tap][cout]   (K = 9 taps padded to 12: 3 k-steps);
-//   wgrad  : D[cout][tap] += sum_position (g[cout][cell] * mask bit) * patch[position][tap]   (one pooled cell = 12
-//            positions = 3 k-steps, no padding; N = 9 taps of 16), accumulators live in registers across all cells and
-//            utterances of a wave.
-// ~2,200-2,400 MFMAs per utterance either way, i.e. ~16 us of matrix-pipe time per launch at B = 512.
+// The forward runs on the matrix cores: D[position][cout] = sum_tap patch[position][tap] * w[tap][cout] (K = 9 taps padded to
+// 12: 3 k-steps; ~2,200 MFMAs per utterance = ~16 us of matrix-pipe time per launch at B = 512 x 1 s).  The ReLU pattern of the
+// pre-pool activation goes to the backward pass as 12-bit masks (2 B per pooled output instead of the 583 KB/utterance tensor or
+// a recomputation).  The weight gradient runs on the vector pipe (conv0_wgrad_valu_kernel below).
 // ---------------------------------------------------------------------------------------------------------
 constexpr int C0M_THREADS = 512;   // 8 waves, two per SIMD
 
@@ -1506,7 +1573,9 @@ __global__ __launch_bounds__(C0M_THREADS) void conv0_fwd_mfma_kernel(const float
         // long inputs (howl_res8_fwd_long): "utterance" b is window b % nwin of clip b / nwin, T frames from its start frame
         const int clip = b / nwin, wi = b - clip * nwin;
         const int t0 = min(wi * win_step, win_last);
+#if !defined(HOWL_DIAG_C0_NOLOAD)   // diagnostic build: no feature tile load
         load_feat_tile(tin, feat + (long)clip * sb + (long)t0 * st, 0, st, sm, 0, T, M, tid, C0M_THREADS);
+#endif
         __syncthreads();
         // units (pooled row, 16-bin block) of this slice, dealt to the waves
         for (int u = wave; u < 3 * (ph1 - ph0); u += C0M_THREADS / 64) {
@@ -1532,6 +1601,9 @@ __global__ __launch_bounds__(C0M_THREADS) void conv0_fwd_mfma_kernel(const float
 #endif
                     }
                 const int pw = 4 * blk + g;  // this lane's cell
+#if defined(HOWL_DIAG_C0_NOEPI)   // diagnostic build: MFMAs only (one value keeps them alive)
+                if (acc[0][0][0] + acc[1][1][1] + acc[2][2][2] == 123.456f) s0[0] = 1.0f;
+#else
 #pragma unroll
                 for (int nt = 0; nt < 3; ++nt) {
                     float sum = 0.0f;
@@ -1555,102 +1627,107 @@ __global__ __launch_bounds__(C0M_THREADS) void conv0_fwd_mfma_kernel(const float
                         if (mask0 != nullptr) mask0[o] = (unsigned short)bits;
                     }
                 }
+#endif
             }
         }
     }
 }
 
-constexpr int C0W_THREADS = 1024;  // weight gradient: 16 waves, four per SIMD (this kernel is bound by LDS / VALU latency per cell)
+// ---------------------------------------------------------------------------------------------------------
+// conv0's weight gradient on the vector pipe (round 4).  The matrix-core version of rounds 2-3 (GEMM cout x taps over
+// positions: 9 useful tap columns of 16, the A operand rebuilt from mask bits per cell) took 50.6 us per launch at 512 x 1 s;
+// this one 48.4 us.  lane = pooled cell, wave = three output channels:
+//   * a lane keeps its cell's 5 x 6 input patch in registers (five aligned 16 + 8 byte LDS reads) and the 9 accumulators of each
+//     of its wave's channels across every cell block and utterance of the workgroup: 108 FMAs per (cell, channel), no padding;
+//   * consecutive lanes are consecutive cells = consecutive addresses of dx_0 / ds_2 / mask0: every global access is a
+//     coalesced row, straight from HBM (no LDS staging of the gradients);
+//   * the forward's ReLU pattern is applied as bfe + and (mask bit -> 0 / -1 -> gradient or +0).
+// The same formulation of the FORWARD (lane = cell, weights in scalar registers, coalesced stores) was built and measured at
+// 49.5 us against 43.3 us for conv0_fwd_mfma_kernel -- the vector pipe needs ~4 cycles per instruction here, not the 2.2-2.5 of
+// the microbenchmark -- and removed (tools/variants4.py: MFMA part 16.4 us, per-value epilogue 18 us, scattered stores 9 us,
+// and the three ADD UP: vector and matrix work of different waves do not overlap on this part).
+// ---------------------------------------------------------------------------------------------------------
+// weight gradient: its accumulators (9 per channel) stay in registers, so 3 channels per wave on 15 waves: one workgroup per CU
+// puts 4 / 4 / 4 / 3 waves on the SIMDs (nine 5-channel waves would be 3 / 2 / 2 / 2 at 168 VGPRs)
+constexpr int C0G_WAVES = 15, C0G_THREADS = 64 * C0G_WAVES, C0G_CPW = NMAP / C0G_WAVES;
+static_assert(C0G_CPW * C0G_WAVES == NMAP, "channels split evenly over the waves");
 
-__global__ __launch_bounds__(C0W_THREADS) void conv0_wgrad_mfma_kernel(const float* __restrict__ feat, long sb, long st,
-                                                                      long sm, const unsigned short* __restrict__ mask0,
+__device__ __forceinline__ void load_patch(float (&x)[5][6], const float* tin, int pitch, int ph, int pw) {
+    const float* base = tin + 3 * ph * pitch + 4 * pw;      // frames 3ph-1 .. 3ph+3, mel bins 4pw-1 .. 4pw+4 (halo origin)
+#pragma unroll
+    for (int r = 0; r < 5; ++r) {
+        const float4 a = *reinterpret_cast<const float4*>(base + r * pitch);
+        const float2 c = *reinterpret_cast<const float2*>(base + r * pitch + 4);
+        x[r][0] = a.x, x[r][1] = a.y, x[r][2] = a.z, x[r][3] = a.w, x[r][4] = c.x, x[r][5] = c.y;
+    }
+}
+
+// weight gradient: dW0[c][tap] = sum over utterances, cells, the 12 positions of a cell of  (g[c][cell] / 12 where the forward's
+// mask bit is set) * x[position + tap];  acc[5][9] per lane (its wave's channels) lives in registers across every cell block and
+// utterance of the workgroup, one wave-wide sum per accumulator at the end -> one partial row per workgroup.
+__global__ __launch_bounds__(C0G_THREADS) void conv0_wgrad_valu_kernel(const float* __restrict__ feat, long sb, long st, long sm,
+                                                                      const unsigned short* __restrict__ mask0,
                                                                       const float* __restrict__ ga, const float* __restrict__ gb,
                                                                       float* __restrict__ part, int B, int T, int M, int H,
                                                                       int slices) {
     HIP_DYNAMIC_SHARED(float, lds)
     float* tin = lds;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int pitch = M + 4;
     const int P = H * PW;
-    float* lg = lds + (T + 2) * pitch;                                          // (45, P) pooled gradients / 12
-    unsigned short* lm = reinterpret_cast<unsigned short*>(lg + NMAP * P);      // (45, P) ReLU masks
-    float* red = reinterpret_cast<float*>(lm + NMAP * P + (NMAP * P & 1));      // [16 waves][48][16]
-    const int g = lane >> 4, n = lane & 15;
-    // B fragments: B[k = position 4ks + g -> (tl = ks, fl = g)][col = tap n] = patch[ks + n/3][g + n%3]
-    int boff[3];
+    float acc[C0G_CPW][9];
 #pragma unroll
-    for (int ks = 0; ks < 3; ++ks) {
-        const int tap = min(n, 8);   // columns 9..15 are padding (results unused)
-        boff[ks] = (ks + tap / 3) * pitch + g + tap % 3;
-    }
-    f32x4 acc[3];
+    for (int j = 0; j < C0G_CPW; ++j)
 #pragma unroll
-    for (int mt = 0; mt < 3; ++mt) acc[mt] = {0.0f, 0.0f, 0.0f, 0.0f};
-    // work item = (utterance, slice of its pooled cells): see conv0_fwd_mfma_kernel
+        for (int t = 0; t < 9; ++t) acc[j][t] = 0.0f;
     for (int item = blockIdx.x; item < B * slices; item += gridDim.x) {
         const int b = item / slices, sl = item - b * slices;
-        const int c0 = (sl * P) / slices, c1 = ((sl + 1) * P) / slices, nc = c1 - c0;
+        const int cell0 = (sl * P) / slices, cell1 = ((sl + 1) * P) / slices;
         __syncthreads();
-        load_feat_tile(tin, feat, sb, st, sm, b, T, M, tid, C0W_THREADS);
-        const size_t ub = (size_t)b * NMAP * P;
-        for (int i0 = tid; i0 < NMAP * nc; i0 += 8 * C0W_THREADS) {   // bulk, 8 loads in flight per thread: the slice's cells of
-            float va[8], vb[8];                                       // every channel (runs of nc consecutive values)
-            unsigned short vm[8];
-            int at[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int i = i0 + j * C0W_THREADS;
-                const bool ok = i < NMAP * nc;
-                const int ch = ok ? i / nc : 0;
-                at[j] = ch * P + c0 + (ok ? i - ch * nc : 0);
-                va[j] = ga[ub + at[j]];
-                vb[j] = gb != nullptr ? gb[ub + at[j]] : 0.0f;
-                vm[j] = mask0[ub + at[j]];
-            }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int i = i0 + j * C0W_THREADS;
-                if (i < NMAP * nc) {
-                    lg[at[j]] = (va[j] + vb[j]) * (1.0f / 12.0f);
-                    lm[at[j]] = vm[j];
-                }
-            }
-        }
+        load_feat_tile(tin, feat, sb, st, sm, b, T, M, tid, C0G_THREADS);
         __syncthreads();
-        for (int cell = c0 + wave; cell < c1; cell += C0W_THREADS / 64) {
-            const int ph = cell / PW, pw = cell - ph * PW;
-            const float* base = tin + 3 * ph * pitch + 4 * pw;
-            float bfr[3];
+        const float* gab = ga + ((size_t)b * NMAP + C0G_CPW * wave) * P;      // (uniform bases, 32-bit lane offsets)
+        const float* gbb = gb != nullptr ? gb + ((size_t)b * NMAP + C0G_CPW * wave) * P : nullptr;
+        const unsigned short* mb = mask0 + ((size_t)b * NMAP + C0G_CPW * wave) * P;
+        for (int cb = cell0; cb < cell1; cb += 64) {
+            const int cell = cb + lane;
+            const bool valid = cell < cell1;
+            const unsigned cc = (unsigned)(valid ? cell : cell1 - 1);
+            float gv[C0G_CPW];
+            unsigned mv[C0G_CPW];
 #pragma unroll
-            for (int ks = 0; ks < 3; ++ks) bfr[ks] = base[boff[ks]];
+            for (int j = 0; j < C0G_CPW; ++j) {      // this block's operands of all five channels in flight together
+                const unsigned o = (unsigned)(j * P) + cc;
+                gv[j] = gab[o] + (gbb != nullptr ? gbb[o] : 0.0f);
+                mv[j] = mb[o];
+            }
+            const int ph = (int)cc / PW, pw = (int)cc - ph * PW;
+            float x[5][6];
+            load_patch(x, tin, pitch, ph, pw);
 #pragma unroll
-            for (int mt = 0; mt < 3; ++mt) {
-                // A[row = cout 16mt + n][k = position 4ks + g] = g[cout][cell] where that pre-pool activation was positive
-                const int c = 16 * mt + n;
-                const float gv = (c < NMAP) ? lg[c * P + cell] : 0.0f;
-                const unsigned mb = (c < NMAP) ? (unsigned)lm[c * P + cell] : 0u;
+            for (int j = 0; j < C0G_CPW; ++j) {
+                const int gbits = valid ? __float_as_int(gv[j] * (1.0f / 12.0f)) : 0;
 #pragma unroll
-                for (int ks = 0; ks < 3; ++ks) {
-                    const float a = ((mb >> (4 * ks + g)) & 1u) ? gv : 0.0f;
-                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bfr[ks], acc[mt], 0, 0, 0);
-                }
+                for (int tl = 0; tl < 3; ++tl)
+#pragma unroll
+                    for (int fl = 0; fl < 4; ++fl) {
+                        const int k = 4 * tl + fl;
+                        const int sel = ((int)(mv[j] << (31 - k))) >> 31;           // 0 or -1: the forward's ReLU pattern
+                        const float dy = __int_as_float(sel & gbits);
+#pragma unroll
+                        for (int tap = 0; tap < 9; ++tap) acc[j][tap] = fmaf(dy, x[tl + tap / 3][fl + tap % 3], acc[j][tap]);
+                    }
             }
         }
     }
-    // D[row = cout 16mt + 4g + r][col = tap n]: fold the 8 waves in a fixed order
-    __syncthreads();
 #pragma unroll
-    for (int mt = 0; mt < 3; ++mt)
+    for (int j = 0; j < C0G_CPW; ++j)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) red[(wave * CP + 16 * mt + 4 * g + r) * 16 + n] = acc[mt][r];
-    __syncthreads();
-    for (int i = tid; i < NMAP * 9; i += C0W_THREADS) {
-        const int c = i / 9, tap = i - 9 * c;
-        float sum = 0.0f;
-#pragma unroll
-        for (int w = 0; w < C0W_THREADS / 64; ++w) sum += red[(w * CP + c) * 16 + tap];
-        part[(size_t)blockIdx.x * NMAP * 9 + i] = sum;
-    }
+        for (int t = 0; t < 9; ++t) {
+            const float v = wave_sum(acc[j][t]);
+            if (lane == 0) part[(size_t)blockIdx.x * NMAP * 9 + (C0G_CPW * wave + j) * 9 + t] = v;
+        }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1666,12 +1743,23 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
                                                        float* __restrict__ pooled, float* __restrict__ logits, int B,
                                                        int P, int C, const long long* __restrict__ labels,
                                                        float* __restrict__ nll, float* __restrict__ dlogits,
-                                                       float* __restrict__ dpool, float inv_batch) {
+                                                       float* __restrict__ dpool, float inv_batch,
+                                                       const float* __restrict__ pool, int npg, int npg_used) {
     __shared__ float lp[CP];
     __shared__ float ll[HEAD_XC], dl[HEAD_XC], lse_s;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int b = blockIdx.x; b < B; b += gridDim.x) {
         __syncthreads();
+        if (pool != nullptr) {
+            // the last convolution left the sums of |s_6| per (utterance, position group, channel): add the groups in order
+            if (tid < CP) {
+                float acc = 0.0f;
+                for (int g = 0; g < npg_used; ++g) acc += pool[((size_t)b * npg + g) * CP + tid];
+                const float v = tid < NMAP ? (acc / (float)P - stats[tid]) * stats[CP + tid] : 0.0f;
+                lp[tid] = v;
+                pooled[(size_t)b * CP + tid] = v;
+            }
+        } else
         // a wave owns channels wave, wave+4, ...: three of them per trip (24 loads in flight) -- one channel per trip is a
         // chain of twelve load latencies
         for (int c0 = wave; c0 < CP; c0 += 12) {
@@ -1949,11 +2037,6 @@ StageCfg with_probe(StageCfg c) { return c; }
 #endif
 
 size_t wgrad_lds_bytes(int H) { return (size_t)(tile_floats_z(H) + tile_floats_x(H) + 6 * CP) * sizeof(float); }
-size_t conv0_wgrad_mfma_lds_bytes(int T, int M) {
-    const int P = ((T / 3)) * PW;
-    return (size_t)(T + 2) * (M + 4) * sizeof(float) + (size_t)NMAP * P * sizeof(float) +
-           (size_t)(NMAP * P + 1) * sizeof(unsigned short) + (size_t)(C0W_THREADS / 64) * CP * 16 * sizeof(float) + 16;
-}
 
 struct Ws {
     float* wp_fwd;   // [6][3][108][64]
@@ -1963,6 +2046,7 @@ struct Ws {
     float* stats;    // eval-mode stats [6][2][48]
     float* m12;      // [2][48]
     float* dpool;    // [B][48]
+    float* pool;     // [B][16][48] per-utterance sums of |s_6| per position group (ConvEpilogue::pool)
     float* bufa;     // (B,45,P) x6: dx ping-pong, dz ping-pong, ds ping-pong
     float* bufb;
     float* dz;
@@ -1990,6 +2074,7 @@ size_t ws_layout(Ws* w, char* base, int B, int H, int G) {
     t.stats = take((size_t)6 * 2 * CP);
     t.m12 = take(2 * CP);
     t.dpool = take((size_t)B * CP);
+    t.pool = take((size_t)B * 16 * CP);
     t.bufa = take(act);
     t.bufb = take(act);
     t.dz = take(act);
@@ -2050,22 +2135,23 @@ StageCfg plain_tile(const float* t) { return StageCfg{t, nullptr, nullptr, nullp
 template <int MODE, int SLICES>
 void launch_conv3x3_inst(int nblk, size_t lds, hipStream_t stream, const StageCfg& in, const float* in_stats, const float* wp,
                          const float* res, float* out, const float* xs, const float* xs_stats, float* part, int B, int H,
-                         const BnFold& fold, const BwdFold& bfold) {
+                         const BnFold& fold, const BwdFold& bfold, float* pool, const WFold& wf) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_mfma_kernel<MODE, SLICES>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((conv3x3_mfma_kernel<MODE, SLICES>), dim3(launch_blocks(nblk, SLICES)), dim3(CONV_THREADS), lds, stream, with_probe(in),
-                       in_stats, wp, res, out, xs, xs_stats, part, B, H, nblk, fold, bfold);
+                       in_stats, wp, res, out, xs, xs_stats, part, pool, B, H, nblk, fold, bfold, wf);
 }
 template <int MODE>
 void launch_conv3x3(int slices, int nblk, size_t lds, hipStream_t stream, const StageCfg& in, const float* in_stats, const float* wp,
                     const float* res, float* out, const float* xs, const float* xs_stats, float* part, int B, int H,
-                    const BnFold& fold, const BwdFold& bfold = BwdFold{}) {
+                    const BnFold& fold, const BwdFold& bfold = BwdFold{}, float* pool = nullptr,
+                    const WFold& wf = WFold{nullptr, 0, nullptr}) {
     if (slices == 4)
-        launch_conv3x3_inst<MODE, 4>(nblk, lds, stream, in, in_stats, wp, res, out, xs, xs_stats, part, B, H, fold, bfold);
+        launch_conv3x3_inst<MODE, 4>(nblk, lds, stream, in, in_stats, wp, res, out, xs, xs_stats, part, B, H, fold, bfold, pool, wf);
     else if (slices == 2)
-        launch_conv3x3_inst<MODE, 2>(nblk, lds, stream, in, in_stats, wp, res, out, xs, xs_stats, part, B, H, fold, bfold);
+        launch_conv3x3_inst<MODE, 2>(nblk, lds, stream, in, in_stats, wp, res, out, xs, xs_stats, part, B, H, fold, bfold, pool, wf);
     else
-        launch_conv3x3_inst<MODE, 1>(nblk, lds, stream, in, in_stats, wp, res, out, xs, xs_stats, part, B, H, fold, bfold);
+        launch_conv3x3_inst<MODE, 1>(nblk, lds, stream, in, in_stats, wp, res, out, xs, xs_stats, part, B, H, fold, bfold, pool, wf);
 }
 template <int SW>
 void launch_wgrad_inst(int nblk, size_t lds, hipStream_t stream, const StageCfg& zc, const BwdFold& bfold, const float* s_prev,
@@ -2077,23 +2163,23 @@ void launch_wgrad_inst(int nblk, size_t lds, hipStream_t stream, const StageCfg&
 template <int SD, int SW>
 void launch_pair_inst(int nblk, size_t lds, hipStream_t stream, const StageCfg& zc, const BwdFold& bfold, const float* wp, float* dx,
                       const float* xs, const float* xs_stats, float* spart, const float* s_prev, const float* in_stats, float* wpart,
-                      int B, int H) {
+                      int B, int H, const WFold& wf) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(bwd_pair_kernel<SD, SW>), hipFuncAttributeMaxDynamicSharedMemorySize,
                         (int)lds);
     hipLaunchKernelGGL((bwd_pair_kernel<SD, SW>), dim3(launch_blocks(nblk, SD + SW)), dim3(CONV_THREADS), lds, stream, with_probe(zc), bfold, wp,
-                       dx, xs, xs_stats, spart, s_prev, in_stats, wpart, B, H, nblk);
+                       dx, xs, xs_stats, spart, s_prev, in_stats, wpart, B, H, nblk, wf);
 }
 void launch_pair(int sd, int sw, int nblk, size_t lds, hipStream_t stream, const StageCfg& zc, const BwdFold& bfold, const float* wp,
                  float* dx, const float* xs, const float* xs_stats, float* spart, const float* s_prev, const float* in_stats,
-                 float* wpart, int B, int H) {
+                 float* wpart, int B, int H, const WFold& wf) {
     if (sd == 4 && sw == 2)
-        launch_pair_inst<4, 2>(nblk, lds, stream, zc, bfold, wp, dx, xs, xs_stats, spart, s_prev, in_stats, wpart, B, H);
+        launch_pair_inst<4, 2>(nblk, lds, stream, zc, bfold, wp, dx, xs, xs_stats, spart, s_prev, in_stats, wpart, B, H, wf);
     else if (sd == 2 && sw == 2)
-        launch_pair_inst<2, 2>(nblk, lds, stream, zc, bfold, wp, dx, xs, xs_stats, spart, s_prev, in_stats, wpart, B, H);
+        launch_pair_inst<2, 2>(nblk, lds, stream, zc, bfold, wp, dx, xs, xs_stats, spart, s_prev, in_stats, wpart, B, H, wf);
     else if (sd == 2 && sw == 1)
-        launch_pair_inst<2, 1>(nblk, lds, stream, zc, bfold, wp, dx, xs, xs_stats, spart, s_prev, in_stats, wpart, B, H);
+        launch_pair_inst<2, 1>(nblk, lds, stream, zc, bfold, wp, dx, xs, xs_stats, spart, s_prev, in_stats, wpart, B, H, wf);
     else
-        launch_pair_inst<1, 1>(nblk, lds, stream, zc, bfold, wp, dx, xs, xs_stats, spart, s_prev, in_stats, wpart, B, H);
+        launch_pair_inst<1, 1>(nblk, lds, stream, zc, bfold, wp, dx, xs, xs_stats, spart, s_prev, in_stats, wpart, B, H, wf);
 }
 
 }  // namespace
@@ -2166,7 +2252,7 @@ int res8_fwd_impl(const HowlRes8Params* prm, const float* feat, long sb, long st
         {
             HowlProfScope prof("conv3x3_fwd", stream);
             launch_conv3x3<0>(SL, G, lc, stream, plain_tile(sv->s[i - 1]), in_stats, w.wp_fwd + (size_t)(i - 1) * 3 * KSTEPS * 64, res, sv->s[i],
-                              nullptr, nullptr, part_out, B, H, fold);
+                              nullptr, nullptr, part_out, B, H, fold, BwdFold{}, i == 6 ? w.pool : (float*)nullptr);
         }
     }
     if (training)
@@ -2175,7 +2261,7 @@ int res8_fwd_impl(const HowlRes8Params* prm, const float* feat, long sb, long st
                            HowlBnBuffers{prm->bn_running_mean[5], prm->bn_running_var[5], prm->bn_num_batches[5]});
     hipLaunchKernelGGL(head_fwd_kernel, dim3(B < 1024 ? B : 1024), dim3(256), 0, stream, sv->s[6],
                        sv->bn_stats + (size_t)5 * 2 * CP, prm->out_w, prm->out_b, sv->pooled, logits, B, P, C, labels, nll, dlogits,
-                       w.dpool, 1.0f / (float)B);
+                       w.dpool, 1.0f / (float)B, (const float*)w.pool, 4 * SL, 4 * SL < (P + 15) / 16 ? 4 * SL : (P + 15) / 16);
     HOWL_CHECK_LAUNCH("howl_res8_fwd");
     return HOWL_OK;
 }
@@ -2369,18 +2455,23 @@ int res8_bwd_impl(const HowlRes8Params* prm, const float* feat, long sb, long st
         const float* in_stats = (i == 1) ? nullptr : sv->bn_stats + (size_t)(i - 2) * 2 * CP;
         const bool need_stats = i > 1;
         const float* wpb = w.wp_bwd + (size_t)(i - 1) * 3 * KSTEPS * 64;
-        const float* xs = need_stats ? sv->s[i - 1] : (const float*)nullptr;
+        // layer 1 needs no statistics (conv0 has no BatchNorm in front): its data gradient takes the skip gradient ds_2 as an
+        // addend instead, so that dx_0 + ds_2 = the gradient of conv0's pooled output leaves the launch as ONE map
+        const float* xs = need_stats ? sv->s[i - 1] : (const float*)ds_prev;
+        const float* xs_st = need_stats ? in_stats : (const float*)nullptr;
         float* spart = need_stats ? part_out : (float*)nullptr;
         float* wpart = w.wpart + (size_t)(i - 1) * wpart_stride;
+        // the partials of layer i+1's weight gradient (previous launch) are folded by this launch's data-gradient workgroups
+        const WFold wf = i < 6 ? WFold{w.wpart + (size_t)i * wpart_stride, Gh, gr->conv_w[i]} : WFold{nullptr, 0, nullptr};
         if (!run_layers) {
             // part 2 only replays the buffer rotation of the loop
         } else if (merged) {
             HowlProfScope prof("bwd_pair", stream);
-            launch_pair(SD, SW, Gh, lp, stream, zc, bfold, wpb, dx_next, xs, in_stats, spart, sv->s[i - 1], in_stats, wpart, B, H);
+            launch_pair(SD, SW, Gh, lp, stream, zc, bfold, wpb, dx_next, xs, xs_st, spart, sv->s[i - 1], in_stats, wpart, B, H, wf);
         } else {
             {
                 HowlProfScope prof("conv3x3_dgrad", stream);
-                launch_conv3x3<1>(SD, Gh, lc, stream, zc, nullptr, wpb, nullptr, dx_next, xs, in_stats, spart, B, H, BnFold{}, bfold);
+                launch_conv3x3<1>(SD, Gh, lc, stream, zc, nullptr, wpb, nullptr, dx_next, xs, xs_st, spart, B, H, BnFold{}, bfold, nullptr, wf);
             }
             HowlProfScope prof("wgrad", stream);
             StageCfg zw = zc;
@@ -2393,28 +2484,29 @@ int res8_bwd_impl(const HowlRes8Params* prm, const float* feat, long sb, long st
         dx_cur = dx_next;
         dx_next = (dx_next == w.bufa) ? w.bufb : w.bufa;
     }
-    // conv0: dy0 = dx_0 (from layer 1's dgrad) + ds_2 (skip into s_2 = y_2 + y_0)
-    const size_t l0w = conv0_wgrad_mfma_lds_bytes(T, M);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(conv0_wgrad_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                        (int)l0w);
+    // conv0: dy0 = dx_0 + ds_2 (skip into s_2 = y_2 + y_0), summed by layer 1's data gradient (ConvEpilogue::xadd)
     HOWL_REQUIRE(sv->mask0 != nullptr, "howl_res8_bwd: saved->mask0 is required");
     HowlPtrs6 gw;
     for (int i = 0; i < 6; ++i) gw.p[i] = gr->conv_w[i];
     const int S0 = conv0_slices(B);
     const int G0w = B * S0 < howl_num_cus() ? B * S0 : howl_num_cus();   // conv0's weight-gradient grid: one partial row each
+    // layers 2..6 were folded inside the pair launches (WFold); layer 1's partials and conv0's remain
     if (part == 1)      // the six layers' weight gradients are final before conv0's is even started
-        hipLaunchKernelGGL(reduce_rows_all_kernel, dim3((CP * 432 + 63) / 64, 6), dim3(256), 0, stream, (const float*)w.wpart,
-                           wpart_stride, Gh, gw, (const float*)w.c0part, G0w, gr->conv0_w, 0);
+        hipLaunchKernelGGL(reduce_rows_all_kernel, dim3((CP * 432 + 63) / 64, 1), dim3(1024), 0, stream, (const float*)w.wpart,
+                           wpart_stride, Gh, gw, (const float*)w.c0part, G0w, gr->conv0_w, 0, 0);
     if (run_conv0) {
-        hipLaunchKernelGGL(conv0_wgrad_mfma_kernel, dim3(G0w), dim3(C0W_THREADS), l0w, stream, feat, sb, st, sm,
-                           (const unsigned short*)sv->mask0,
-                           (const float*)dx_cur, (const float*)ds_prev, w.c0part, B, T, M, H, S0);
-        if (part == 0)
-            hipLaunchKernelGGL(reduce_rows_all_kernel, dim3((CP * 432 + 63) / 64, 7), dim3(256), 0, stream,
-                               (const float*)w.wpart, wpart_stride, Gh, gw, (const float*)w.c0part, G0w, gr->conv0_w, 0);
+        {
+        HowlProfScope prof("conv0_wgrad", stream);
+        hipLaunchKernelGGL(conv0_wgrad_valu_kernel, dim3(G0w), dim3(C0G_THREADS), ((size_t)(T + 2) * (M + 4) + 16) * sizeof(float),
+                           stream, feat, sb, st, sm, (const unsigned short*)sv->mask0, (const float*)dx_cur,
+                           (const float*)nullptr, w.c0part, B, T, M, H, S0);
+        }
+        if (part == 0)      // rows {layer 1, conv0} of the reduction
+            hipLaunchKernelGGL(reduce_rows_all_kernel, dim3((CP * 432 + 63) / 64, 2), dim3(1024), 0, stream,
+                               (const float*)w.wpart, wpart_stride, Gh, gw, (const float*)w.c0part, G0w, gr->conv0_w, 0, 5);
         else
-            hipLaunchKernelGGL(reduce_rows_all_kernel, dim3((NMAP * 9 + 63) / 64, 1), dim3(256), 0, stream,
-                               (const float*)w.wpart, wpart_stride, Gh, gw, (const float*)w.c0part, G0w, gr->conv0_w, 6);
+            hipLaunchKernelGGL(reduce_rows_all_kernel, dim3((NMAP * 9 + 63) / 64, 1), dim3(1024), 0, stream,
+                               (const float*)w.wpart, wpart_stride, Gh, gw, (const float*)w.c0part, G0w, gr->conv0_w, 6, 0);
     }
     HOWL_CHECK_LAUNCH("howl_res8_bwd");
     return HOWL_OK;

@@ -14,7 +14,7 @@ FLAGS = ["-std=c++17", "-O2", "-g", "-fPIC", "-Wno-unused-value", "-Wno-unknown-
 
 
 def build(verbose=False):
-    srcs = sorted((ROOT / "howl_amd" / "csrc").glob("*.hip")) + [HERE / "hipemu.cpp"]
+    srcs = sorted(p for p in (ROOT / "howl_amd" / "csrc").glob("*.hip") if not p.name.startswith("_")) + [HERE / "hipemu.cpp"]
     hdrs = [p for p in (ROOT / "howl_amd" / "csrc").glob("*") if p.suffix != ".hip"] + list((HERE / "hip").glob("*")) + \
         list((ROOT / "include").glob("*")) + [Path(__file__)]
     hdr_time = max(p.stat().st_mtime for p in hdrs)

@@ -20,6 +20,11 @@ EDITS = {
     "epi_after": [("-D", "HOWL_DIAG_EPI_AFTER")],      # epilogue behind the second barrier
     "nostage": [("-D", "HOWL_DIAG_NOSTAGE")],          # timing only (WRONG results): the conv phases without their staging work
     "desync": [("-D", "HOWL_DIAG_DESYNC")],
+    "c0_nostore": [("-D", "HOWL_DIAG_C0_NOSTORE")], "c0_nomfma": [("-D", "HOWL_DIAG_C0_NOMFMA")],
+    "c0_noload": [("-D", "HOWL_DIAG_C0_NOLOAD")], "c0_noepi": [("-D", "HOWL_DIAG_C0_NOEPI")],
+    "c0w_nocompute": [("        for (int cell = c0 + wave; cell < c1; cell += C0W_THREADS / 64) {", "        for (int cell = c0 + wave; cell < c1 && B < 0; cell += C0W_THREADS / 64) {")],
+    "c0w_noload": [("        for (int i0 = tid; i0 < NMAP * nc; i0 += 8 * C0W_THREADS) {   // bulk, 8 loads in flight per thread: the slice's cells of",
+                    "        for (int i0 = tid; i0 < NMAP * nc && B < 0; i0 += 8 * C0W_THREADS) {   // bulk, 8 loads in flight per thread: the slice's cells of")],
     "nostage_nomidbar": [("-D", "HOWL_DIAG_NOSTAGE"), ("-D", "HOWL_DIAG_NOMIDBAR")],
     "nostage_nolds": [("-D", "HOWL_DIAG_NOSTAGE"), ("-D", "HOWL_DIAG_CONV_NOLDS")],
     "nostage_nomfma": [("-D", "HOWL_DIAG_NOSTAGE"), ("-D", "HOWL_DIAG_CONV_NOMFMA")],
@@ -44,10 +49,11 @@ def build(names):
             assert t.count(old) == cnt, (name, old[:70], t.count(old))
             t = t.replace(old, new)
         name = name.replace("+", "_")
-        tmp = SRC.parent / f"_diag_{name}.hip"
+        (OUT / "_src").mkdir(exist_ok=True)      # not next to the product sources: builders glob csrc/*.hip
+        tmp = OUT / "_src" / f"{name}.hip"
         tmp.write_text(t)
         obj = OUT / f"res8_{name}.o"
-        jobs.append((name, tmp, obj, subprocess.Popen(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-w"] +
+        jobs.append((name, tmp, obj, subprocess.Popen(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-w", f"-I{SRC.parent}"] +
                                                        defs + ["-c", str(tmp), "-o", str(obj)])))
     for name, tmp, obj, proc in jobs:
         rc = proc.wait()
@@ -69,7 +75,8 @@ def run(names, extra):
                 d = json.loads(r.stdout.strip().splitlines()[-1])
                 ro = d["roofline"]
                 fwd = [v.get("avg_launch_ms") for k, v in ro["other_kernels"].items() if k.startswith("conv3x3")]
-                print(f"{name:18s} step {d['ms_per_step']:.4f} ms (median {d['repeats']['ms_per_step_median']:.4f})  pair {ro['avg_launch_ms']:.4f}  fwd {fwd}  "
+                c0 = [(v.get("fwd_avg_launch_ms"), v.get("wgrad_avg_launch_ms")) for k, v in ro["other_kernels"].items() if k.startswith("conv0")]
+                print(f"{name:18s} conv0 {c0} step {d['ms_per_step']:.4f} ms (median {d['repeats']['ms_per_step_median']:.4f})  pair {ro['avg_launch_ms']:.4f}  fwd {fwd}  "
                       f"loss {d['final_loss']}", flush=True)
             except Exception:
                 print(name, "FAILED", r.stderr[-600:], flush=True)
