@@ -18,6 +18,11 @@ typedef __attribute__((address_space(3))) float lds_f32;
 #else
 #define HOWL_OPAQUE_V(x) asm volatile("" : "+v"(x))
 #endif
+// The same for an LDS cursor (a 32-bit address in a VGPR): behind this point the pointer is a plain register value, so every
+// access off it is "register + immediate" -- otherwise the optimiser keeps cursors as (dynamic-LDS symbol + constant + lane
+// part) and re-adds the constant in front of each ds_read when it exceeds the 16-bit offset field (the 3x3 forward K loop
+// carried 43 v_add_u32 per 45 MFMAs, and vector instructions do not overlap the matrix pipe on this part).
+#define HOWL_OPAQUE_LDS(p) HOWL_OPAQUE_V(p)
 
 #define HOWL_OK 0
 #define HOWL_E_ARG (-1)       // bad argument (shape / null pointer / unsupported size)

@@ -75,6 +75,12 @@ __host__ __device__ inline int chan_stride(int H) {
 }
 __host__ __device__ inline int tile_floats(int H) { return CP * chan_stride(H) + 32; }
 constexpr int WPW = 13;          // row pitch of the weight-gradient kernel's x tile (see wgrad_body)
+// weight-gradient GEMM (wgrad_body): M = cout, N = (tap, cin) FLATTENED: column idx = 45 * tap + cin, 405 columns in 26 tiles of 16 (rounds 1-3 padded every tap to 48
+// columns: 27 tiles).  78 accumulator chains (26 N tiles x 3 cout tiles) instead of 81: with two whole N tiles per wave and the
+// six chains of tiles 24 and 25 dealt one each to waves 0, 4, 1, 5, 2, 3, the SIMDs carry 20 / 20 / 19 / 19 chains (was 21 / 21 /
+// 21 / 18): the role is matrix-pipe bound, so that is 4.8 % of its time.
+constexpr int WNCOL = 16 * 26;          // partial row: [48 cout][WNCOL]
+constexpr int WTAPS = 9 * NMAP;         // 405 real columns
 __host__ __device__ inline int wgrad_rounds(int H) { return (H + 3) / 4; }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -180,9 +186,11 @@ __device__ __forceinline__ void k_begin(KCursor<NTW>& k, f32x4 (&acc)[NTW], cons
         m = m < P ? m : P - 1;  // the last tile may overhang: clamp the read, the store is masked
         const int h = m / PW;
         k.ap[i] = tile + (lane >> 4) * CS + h * WP + (m - h * PW);
+        HOWL_OPAQUE_LDS(k.ap[i]);
         acc[i] = {0.0f, 0.0f, 0.0f, 0.0f};
     }
     k.bp = wl + lane;
+    HOWL_OPAQUE_LDS(k.bp);
 }
 
 // `groups` channel groups (4 input channels x 9 taps each) of the K loop
@@ -473,7 +481,41 @@ struct ConvLoop {
     const float* lm;
     int B, CS, t0, lane, tid;
     int nblk;   // utterance strides of the batch loop: workgroups (or groups of `slices` workgroups) sharing the batch
+#if defined(HOWL_DIAG_WINO)
+    const float* wino_w;   // global weights (streamed again per K chunk in the skeleton)
+    float* wino_l;         // LDS weight area
+#endif
 };
+
+#if defined(HOWL_DIAG_WINO)
+// TIMING SKELETON of a Winograd F(2x2, 3x3) forward (tools/variants4.py "wino"; WRONG results by design): what such a kernel
+// would have to execute per utterance around the same tiles -- 2,880 instead of 5,202 MFMAs (16 component GEMMs of 80 x 48 x 48
+// on 16x16x4 tiles = 55 %), the input and output transforms on the vector pipe (32 + 24 additions per 4x4 tile and channel:
+// ~230 per thread), the transformed tile through LDS (4x the input volume: ~63 more ds_write per thread), 16 x 48 x 48 fp32 of
+// transformed weights (147 KB: does not fit next to the map) streamed from L2 once per utterance in six input-channel chunks,
+// and a barrier on either side of every chunk's multiply.  One call per K chunk:
+__device__ __forceinline__ float wino_chunk_work(const ConvLoop& c, float seed) {
+    float t0 = seed, t1 = seed + 1.0f, t2 = seed + 2.0f, t3 = seed + 3.0f;
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {          // 40 of the ~230 transform instructions, four independent chains
+        t0 = fmaf(t0, 1.0001f, 0.5f);
+        t1 = fmaf(t1, 0.9999f, 0.25f);
+        t2 = fmaf(t2, 1.0002f, 0.125f);
+        t3 = fmaf(t3, 0.9998f, 0.0625f);
+    }
+    float4 wv[8];                           // 1/6 of the transformed weights: 8 x 16 B per thread from L2 -> LDS
+#pragma unroll
+    for (int j = 0; j < 8; ++j) wv[j] = reinterpret_cast<const float4*>(c.wino_w)[(c.tid + j * CONV_THREADS) % (3 * KSTEPS * 16)];
+#pragma unroll
+    for (int j = 0; j < 10; ++j) c.tile[CP * c.CS + ((c.tid + 37 * j) & 31)] = t0 + (float)j;      // (the tile's slack words)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        wv[j].x += t1;
+        reinterpret_cast<float4*>(c.wino_l)[(c.tid + j * CONV_THREADS) % (3 * KSTEPS * 16)] = wv[j];
+    }
+    return t0 + t1 + t2 + t3;
+}
+#endif
 
 // All utterances b, b + nblk, ... of this workgroup; on entry channels 0..23 of utterance b are in the tile (barrier passed).
 // Instantiated once per tile count (waves of one workgroup run different instances; every instance executes the same two
@@ -511,15 +553,30 @@ __device__ __forceinline__ void conv_loop(const ConvLoop& c, const ConvEpilogue&
         const int wp = tid >> 8;
         const int a0 = 1 + wp, a1 = 2, a2 = KG_A - 3 - wp;             // bursts after groups {1,3} {2,4} {3,5}
         const int b0 = wp == 0 ? 1 : 2, b1 = wp == 1 ? 1 : 2, b2 = KG_B - b0 - b1;   // {1,3} {2,3} {2,4}
+#elif defined(HOWL_DIAG_WINO)
+        const int a0 = 1, a1 = 1, a2 = 1, b0 = 1, b1 = 1, b2 = 1;      // 6 of the 11 K groups, no tail: 53 % of the MFMAs
 #else
         const int a0 = 2, a1 = 2, a2 = KG_A - 4, b0 = 2, b1 = 2, b2 = KG_B - 4;
+#endif
+#if defined(HOWL_DIAG_WINO)
+#define HOWL_WINO_CHUNK()                        \
+    do {                                         \
+        st1 += wino_chunk_work(c, st1);          \
+        __syncthreads();                         \
+    } while (0)
+#define HOWL_WINO_BAR() __syncthreads()
+#else
+#define HOWL_WINO_CHUNK() ((void)0)
+#define HOWL_WINO_BAR() ((void)0)
 #endif
         if constexpr (STAGE) {
             slot_load<MODE>(v[0], cfg, ubase + r1, tid, pk1[0], b);
             slot_load<MODE>(v[1], cfg, ubase + r1, tid + CONV_THREADS, pk1[1], b);
         }
         HOWL_STAIR(3);
+        HOWL_WINO_CHUNK();
         if constexpr (NTW > 0) k_run<NTW>(k, acc, c.CS, a0);
+        HOWL_WINO_BAR();
         if constexpr (STAGE) {
             slot_write<MODE>(v[0], cfg, ubase + r1, tid, pk1[0], c.tile, c.lm);
             slot_write<MODE>(v[1], cfg, ubase + r1, tid + CONV_THREADS, pk1[1], c.tile, c.lm);
@@ -527,13 +584,17 @@ __device__ __forceinline__ void conv_loop(const ConvLoop& c, const ConvEpilogue&
             slot_load<MODE>(v[1], cfg, ubase + r1, tid + 3 * CONV_THREADS, pk1[3], b);
         }
         HOWL_STAIR(2);
+        HOWL_WINO_CHUNK();
         if constexpr (NTW > 0) k_run<NTW>(k, acc, c.CS, a1);
+        HOWL_WINO_BAR();
         if constexpr (STAGE) {
             slot_write<MODE>(v[0], cfg, ubase + r1, tid + 2 * CONV_THREADS, pk1[2], c.tile, c.lm);
             slot_write<MODE>(v[1], cfg, ubase + r1, tid + 3 * CONV_THREADS, pk1[3], c.tile, c.lm);
         }
         HOWL_STAIR(1);
+        HOWL_WINO_CHUNK();
         if constexpr (NTW > 0) k_run<NTW>(k, acc, c.CS, a2);
+        HOWL_WINO_BAR();
         HOWL_STAIR(0);
         HOWL_PROBE(cfg, wave, lane, pslot++);   // phase A done
 #if !defined(HOWL_DIAG_NOMIDBAR)   // diagnostic build (with HOWL_DIAG_NOSTAGE): what the barrier in the middle of the K loop costs
@@ -547,7 +608,9 @@ __device__ __forceinline__ void conv_loop(const ConvLoop& c, const ConvEpilogue&
             slot_load<MODE>(v[2], cfg, nbase, tid + 2 * CONV_THREADS, pk0[2], bn);
         }
         HOWL_STAIR(3);
+        HOWL_WINO_CHUNK();
         if constexpr (NTW > 0) k_run<NTW>(k, acc, c.CS, b0);
+        HOWL_WINO_BAR();
         if (STAGE && more) {
             slot_write<MODE>(v[0], cfg, nbase, tid, pk0[0], c.tile, c.lm);
             slot_write<MODE>(v[1], cfg, nbase, tid + CONV_THREADS, pk0[1], c.tile, c.lm);
@@ -556,7 +619,9 @@ __device__ __forceinline__ void conv_loop(const ConvLoop& c, const ConvEpilogue&
             slot_load<MODE>(v[1], cfg, nbase, tid + 4 * CONV_THREADS, pk0[4], bn);
         }
         HOWL_STAIR(2);
+        HOWL_WINO_CHUNK();
         if constexpr (NTW > 0) k_run<NTW>(k, acc, c.CS, b1);
+        HOWL_WINO_BAR();
         if (STAGE && more) {
             slot_write<MODE>(v[0], cfg, nbase, tid + 3 * CONV_THREADS, pk0[3], c.tile, c.lm);
             slot_write<MODE>(v[1], cfg, nbase, tid + 4 * CONV_THREADS, pk0[4], c.tile, c.lm);
@@ -573,8 +638,15 @@ __device__ __forceinline__ void conv_loop(const ConvLoop& c, const ConvEpilogue&
                     for (int hh = 0; hh < 2; ++hh) ev[i][hh] = *reinterpret_cast<const float2*>(ebase + ea.off(i, hh));
             }
             HOWL_STAIR(1);
+#if defined(HOWL_DIAG_WINO)
+        }
+        HOWL_WINO_CHUNK();
+        if constexpr (NTW > 0) {
+            k_run<NTW>(k, acc, c.CS, b2);
+#else
             k_run<NTW>(k, acc, c.CS, b2);
             k_tail<NTW>(k, acc, dl);
+#endif
             HOWL_STAIR(0);
         }
         HOWL_PROBE(cfg, wave, lane, pslot++);   // phase B done
@@ -627,12 +699,12 @@ __device__ __forceinline__ void bwd_fold_to_lds(float* lm, const BwdFold& f, int
     }
 }
 
-// The weight-gradient partials of the layer ABOVE (written by the previous pair launch, one row of [48][432] per weight-gradient
+// The weight-gradient partials of the layer ABOVE (written by the previous pair launch, one row of [48][WNCOL] per weight-gradient
 // workgroup) are folded by the data-gradient workgroups of this launch once their own work is done: the pair's duration is set
 // by its weight-gradient role, the data-gradient role finishes ~10 us earlier, so the fold of 10.6 MB per layer costs nothing
 // (it was one 18-us launch over all six layers at the end of the pass).  Fixed order: bit-reproducible.
 struct WFold {
-    const float* part;   // [nparts][48 * 432], or nullptr
+    const float* part;   // [nparts][48 * WNCOL], or nullptr
     int nparts;
     float* out;          // dW (45,45,3,3) of that layer
 };
@@ -772,7 +844,11 @@ __device__ __forceinline__ void conv3x3_body(
     __syncthreads();  // channels 0..23 of the first utterance in place
     HOWL_PROBE(cfg, wave, lane, pslot++);   // first half tile staged
 
+#if defined(HOWL_DIAG_WINO)
+    const ConvLoop cl{(const lds_f32*)tile, (const lds_f32*)wl + nt * KSTEPS * 64, tile, lm, B, CS, t0, lane, tid, nblk, wp, wl};
+#else
     const ConvLoop cl{(const lds_f32*)tile, (const lds_f32*)wl + nt * KSTEPS * 64, tile, lm, B, CS, t0, lane, tid, nblk};
+#endif
     switch (ntw) {
         case 5: conv_loop<MODE, 5, ts>(cl, epi, cfg, pk0, pk1, b, st0, st1, pslot); break;
         case 4: conv_loop<MODE, 4, ts>(cl, epi, cfg, pk0, pk1, b, st0, st1, pslot); break;
@@ -804,9 +880,9 @@ __device__ __forceinline__ void conv3x3_body(
         }
     }
     if (MODE == 1 && wf.part != nullptr) {
-        // this workgroup's share of the 48 * 432 columns, two at a time: 96 pair lanes x 8 row groups, up to 16 rows in flight
+        // this workgroup's share of the 48 * WNCOL columns, two at a time: 96 pair lanes x 8 row groups, up to 16 rows in flight
         // per thread, the row groups combined through LDS (the tile is free: every wave is past the loop's last barrier)
-        constexpr int NCOL2 = CP * 432 / 2;
+        constexpr int NCOL2 = CP * WNCOL / 2;
         const int nwg = nblk * slices, wg = bid * slices + slice;
         const int per = (NCOL2 + nwg - 1) / nwg;
         const int q0 = wg * per, q1 = (q0 + per < NCOL2) ? q0 + per : NCOL2;
@@ -841,12 +917,11 @@ __device__ __forceinline__ void conv3x3_body(
                     tot.x += scratch[r * 96 + pl].x;
                     tot.y += scratch[r * 96 + pl].y;
                 }
-                // column (cout, tap, cin) of the accumulator layout [48][9][48] -> dW[(cout * 45 + cin) * 9 + tap]
+                // column (cout, idx = 45 tap + cin) of the accumulator layout [48][WNCOL] -> dW[(cout * 45 + cin) * 9 + tap]
                 const int col = 2 * q;
-                const int co = col / 432, r = col - co * 432;
-                const int tap = r / CP, ci = r - tap * CP;
-                if (co < NMAP && ci < NMAP) wf.out[(co * NMAP + ci) * 9 + tap] = tot.x;
-                if (co < NMAP && ci + 1 < NMAP) wf.out[(co * NMAP + ci + 1) * 9 + tap] = tot.y;
+                const int co = col / WNCOL, i0 = col - co * WNCOL;
+                if (co < NMAP && i0 < WTAPS) wf.out[(co * NMAP + i0 % NMAP) * 9 + i0 / NMAP] = tot.x;
+                if (co < NMAP && i0 + 1 < WTAPS) wf.out[(co * NMAP + (i0 + 1) % NMAP) * 9 + (i0 + 1) / NMAP] = tot.y;
             }
             __syncthreads();
         }
@@ -908,20 +983,22 @@ template <int NB>
 struct WCursor {
     const lds_f32* ap[3];    // dz rows of the three cout tiles, this lane's channel and position group
     const lds_f32* bp[NB];   // x rows of the N tiles (halo origin + tap shift)
+    const lds_f32* ape;      // the extra chain (EX): dz rows of its cout tile, x rows of its N tile
+    const lds_f32* bpe;
 };
 
 // `rounds` rows per position group = 10 k-steps each.  The operands of k-step s+1 are requested before the MFMAs of step
 // s; all offsets inside a round are immediates (next column: +1 float, next row of this group: +4 rows).
-template <int NB>
-__device__ __forceinline__ void wgrad_k_run(WCursor<NB>& c, f32x4 (&acc)[NB][3], float (&az)[3], float (&bx)[NB],
-                                            int rounds) {
+template <int NB, bool EX>
+__device__ __forceinline__ void wgrad_k_run(WCursor<NB>& c, f32x4 (&acc)[NB][3], f32x4& acce, float (&az)[3], float (&bx)[NB],
+                                            float& aze, float& bxe, int rounds) {
 #pragma nounroll
     for (int r = 0; r < rounds; ++r) {
 #pragma unroll
         for (int w = 0; w < PW; ++w) {
             const int noz = (w + 1 < PW) ? (w + 1) : 4 * WPZ;
             const int nox = (w + 1 < PW) ? (w + 1) : 4 * WPW;
-            float nz[3], nx[NB];
+            float nz[3], nx[NB], nze = 0.0f, nxe = 0.0f;
 #if defined(HOWL_DIAG_WGRAD_NOLDS)  // diagnostic build: MFMA chains fed from registers (tools/variants.py)
 #pragma unroll
             for (int mt = 0; mt < 3; ++mt) nz[mt] = az[mt];
@@ -932,6 +1009,10 @@ __device__ __forceinline__ void wgrad_k_run(WCursor<NB>& c, f32x4 (&acc)[NB][3],
             for (int mt = 0; mt < 3; ++mt) nz[mt] = c.ap[mt][noz];
 #pragma unroll
             for (int i = 0; i < NB; ++i) nx[i] = c.bp[i][nox];
+            if constexpr (EX) {
+                nze = c.ape[noz];
+                nxe = c.bpe[nox];
+            }
 #endif
 #pragma unroll
             for (int i = 0; i < NB; ++i)
@@ -943,15 +1024,24 @@ __device__ __forceinline__ void wgrad_k_run(WCursor<NB>& c, f32x4 (&acc)[NB][3],
                     acc[i][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(az[mt], bx[i], acc[i][mt], 0, 0, 0);
 #endif
                 }
+            if constexpr (EX) acce = __builtin_amdgcn_mfma_f32_16x16x4f32(aze, bxe, acce, 0, 0, 0);
 #pragma unroll
             for (int mt = 0; mt < 3; ++mt) az[mt] = nz[mt];
 #pragma unroll
             for (int i = 0; i < NB; ++i) bx[i] = nx[i];
+            if constexpr (EX) {
+                aze = nze;
+                bxe = nxe;
+            }
         }
 #pragma unroll
         for (int mt = 0; mt < 3; ++mt) c.ap[mt] += 4 * WPZ;
 #pragma unroll
         for (int i = 0; i < NB; ++i) c.bp[i] += 4 * WPW;
+        if constexpr (EX) {
+            c.ape += 4 * WPZ;
+            c.bpe += 4 * WPW;
+        }
     }
 }
 
@@ -1050,11 +1140,21 @@ struct WgradArgs {
     const float* lm;
     int B, P, CSZ, CSX, R, R1, tid, lane, wave;
     int bid, nblk;   // utterances bid, bid + nblk, ...; partial row bid
-    int gw;          // this wave's index among the GWS = 12 * slices waves that share the 27 N tiles of those utterances
+    int gw;          // this wave's index among the GWS = 12 * slices waves that share the 26 N tiles of those utterances
+    int qe, mte;     // EX: this wave's extra chain = (N tile qe, cout tile mte)
 };
 
 // all utterances b, b + nblk, ... of this workgroup (the top rows of utterance b are in the tiles on entry), then this wave's partials
-template <int NB, int GWS>
+// x-tile offset of this lane's column of N tile q: column idx = 16 q + n = 45 * tap + cin (the 11 columns past 405 read the
+// all-zero channel 45)
+__device__ __forceinline__ int wgrad_boff(int q, int n, int g, int CSX) {
+    const int idx = 16 * q + n;
+    const int tap = idx < WTAPS ? idx / NMAP : 0;
+    const int cin = idx < WTAPS ? idx - tap * NMAP : NMAP;
+    return cin * CSX + (g + tap / 3) * WPW + (tap % 3);     // cin row, halo origin + tap shift
+}
+
+template <int NB, bool EX, int GWS>
 __device__ __forceinline__ void wgrad_loop(const WgradArgs& a, const int (&zt)[WNT], const int (&xt)[WNT], const int (&zb)[WNB],
                                            const int (&xb)[WNB], int b, int& pslot) {
     const int lane = a.lane, wave = a.wave;
@@ -1064,14 +1164,12 @@ __device__ __forceinline__ void wgrad_loop(const WgradArgs& a, const int (&zt)[W
     for (int i = 0; i < NB; ++i)
 #pragma unroll
         for (int mt = 0; mt < 3; ++mt) acc[i][mt] = {0.0f, 0.0f, 0.0f, 0.0f};
-    // N tiles q = gw, gw + GWS, ... (< 27): q = 3 * tap + cin tile
+    // N tiles q = gw, gw + GWS, ... (< 26)
     int boff[NB];
 #pragma unroll
-    for (int i = 0; i < NB; ++i) {
-        const int q = a.gw + GWS * i;
-        const int tap = q / 3, ct = q - 3 * tap;
-        boff[i] = (16 * ct + n) * a.CSX + (g + tap / 3) * WPW + (tap % 3);   // cin row, halo origin + tap shift
-    }
+    for (int i = 0; i < NB; ++i) boff[i] = wgrad_boff(a.gw + GWS * i, n, g, a.CSX);
+    const int boffe = EX ? wgrad_boff(a.qe, n, g, a.CSX) : 0;
+    f32x4 acce = {0.0f, 0.0f, 0.0f, 0.0f};
     const int aoff = n * a.CSZ + g * WPZ;                                    // cout row g, column 0
     const int R1 = a.R1, R2 = a.R - a.R1;
     const float invP = a.st.invP;
@@ -1085,14 +1183,24 @@ __device__ __forceinline__ void wgrad_loop(const WgradArgs& a, const int (&zt)[W
         for (int mt = 0; mt < 3; ++mt) c.ap[mt] = (const lds_f32*)a.tz + aoff + 16 * mt * a.CSZ;
 #pragma unroll
         for (int i = 0; i < NB; ++i) c.bp[i] = (const lds_f32*)a.tx + boff[i];
-        float az[3], bx[NB];
+        c.ape = (const lds_f32*)a.tz + aoff + 16 * a.mte * a.CSZ;
+        c.bpe = (const lds_f32*)a.tx + boffe;
+        float az[3], bx[NB], aze = 0.0f, bxe = 0.0f;
         WSlot v[2];
         // ---- phase 1: rounds 0 .. R1-1 on the top rows; the bottom rows of this utterance arrive
 #pragma unroll
         for (int mt = 0; mt < 3; ++mt) az[mt] = c.ap[mt][0];
 #pragma unroll
         for (int i = 0; i < NB; ++i) bx[i] = c.bp[i][0];
+        if constexpr (EX) {
+            aze = c.ape[0];
+            bxe = c.bpe[0];
+        }
         static_assert(WNB == 5 && WNT == 4, "the staging schedule below is written for 5 + 4 slot pairs");
+#if defined(HOWL_DIAG_WNOSTAGE)   // diagnostic build (tools/variants4.py; WRONG results): the phases without their staging work
+#define HOWL_W_LOAD(slot_, j_, zpk_, xpk_, ub_, bb_) ((void)0)
+#define HOWL_W_WRITE(slot_, j_, zpk_, xpk_) ((void)0)
+#else
 #define HOWL_W_LOAD(slot_, j_, zpk_, xpk_, ub_, bb_)                          \
     do {                                                                     \
         wz_load(v[slot_].z, a.st.z, ub_, zpk_[j_], bb_, invP);               \
@@ -1103,21 +1211,22 @@ __device__ __forceinline__ void wgrad_loop(const WgradArgs& a, const int (&zt)[W
         wz_write(v[slot_].z, a.st.z, zpk_[j_], a.tz, a.lm, invP);            \
         wx_write(v[slot_].x, a.st.xaffine, xpk_[j_], a.tx, a.lm, invP);      \
     } while (0)
+#endif
         HOWL_W_LOAD(0, 0, zb, xb, ubase, b);
         HOWL_W_LOAD(1, 1, zb, xb, ubase, b);
         HOWL_STAIR(3);
-        if (R1 > 0) wgrad_k_run<NB>(c, acc, az, bx, 1);
+        if (R1 > 0) wgrad_k_run<NB, EX>(c, acc, acce, az, bx, aze, bxe, 1);
         HOWL_W_WRITE(0, 0, zb, xb);
         HOWL_W_WRITE(1, 1, zb, xb);
         HOWL_W_LOAD(0, 2, zb, xb, ubase, b);
         HOWL_W_LOAD(1, 3, zb, xb, ubase, b);
         HOWL_STAIR(2);
-        if (R1 > 1) wgrad_k_run<NB>(c, acc, az, bx, 1);
+        if (R1 > 1) wgrad_k_run<NB, EX>(c, acc, acce, az, bx, aze, bxe, 1);
         HOWL_W_WRITE(0, 2, zb, xb);
         HOWL_W_WRITE(1, 3, zb, xb);
         HOWL_W_LOAD(0, 4, zb, xb, ubase, b);
         HOWL_STAIR(1);
-        if (R1 > 2) wgrad_k_run<NB>(c, acc, az, bx, R1 - 2);
+        if (R1 > 2) wgrad_k_run<NB, EX>(c, acc, acce, az, bx, aze, bxe, R1 - 2);
         HOWL_STAIR(0);
         HOWL_W_WRITE(0, 4, zb, xb);
         HOWL_PROBE(a.st.z, wave, lane, pslot++);   // phase 1 done
@@ -1127,16 +1236,21 @@ __device__ __forceinline__ void wgrad_loop(const WgradArgs& a, const int (&zt)[W
         // next utterance arrive.  The operands requested ahead by the last k-step of phase 1 predate the barrier: re-read.
 #pragma unroll
         for (int i = 0; i < NB; ++i) c.bp[i] += 2 * WPW;
+        c.bpe += 2 * WPW;
 #pragma unroll
         for (int mt = 0; mt < 3; ++mt) az[mt] = c.ap[mt][0];
 #pragma unroll
         for (int i = 0; i < NB; ++i) bx[i] = c.bp[i][0];
+        if constexpr (EX) {
+            aze = c.ape[0];
+            bxe = c.bpe[0];
+        }
         if (more) {
             HOWL_W_LOAD(0, 0, zt, xt, nbase, bn);
             HOWL_W_LOAD(1, 1, zt, xt, nbase, bn);
         }
         HOWL_STAIR(3);
-        wgrad_k_run<NB>(c, acc, az, bx, 1);
+        wgrad_k_run<NB, EX>(c, acc, acce, az, bx, aze, bxe, 1);
         if (more) {
             HOWL_W_WRITE(0, 0, zt, xt);
             HOWL_W_WRITE(1, 1, zt, xt);
@@ -1144,13 +1258,13 @@ __device__ __forceinline__ void wgrad_loop(const WgradArgs& a, const int (&zt)[W
             HOWL_W_LOAD(1, 3, zt, xt, nbase, bn);
         }
         HOWL_STAIR(2);
-        if (R2 > 1) wgrad_k_run<NB>(c, acc, az, bx, 1);
+        if (R2 > 1) wgrad_k_run<NB, EX>(c, acc, acce, az, bx, aze, bxe, 1);
         if (more) {
             HOWL_W_WRITE(0, 2, zt, xt);
             HOWL_W_WRITE(1, 3, zt, xt);
         }
         HOWL_STAIR(1);
-        if (R2 > 2) wgrad_k_run<NB>(c, acc, az, bx, R2 - 2);
+        if (R2 > 2) wgrad_k_run<NB, EX>(c, acc, acce, az, bx, aze, bxe, R2 - 2);
         HOWL_STAIR(0);
 #undef HOWL_W_LOAD
 #undef HOWL_W_WRITE
@@ -1158,26 +1272,26 @@ __device__ __forceinline__ void wgrad_loop(const WgradArgs& a, const int (&zt)[W
         __syncthreads();      // top rows of the next utterance complete; every wave is past its reads of the bottom rows
         HOWL_PROBE(a.st.z, wave, lane, pslot++);   // barrier
     }
-    // D[row = cout = 16mt + 4*(lane>>4) + r][col = n = lane&15 -> cin = 16ct + col] for N tile q = (tap, ct)
-    float* dst = a.part + (size_t)a.bid * CP * 432;
+    // D[row = cout = 16mt + 4*(lane>>4) + r][col = n = lane&15] of N tile q -> partial row [48][WNCOL], column 16 q + n
+    float* dst = a.part + (size_t)a.bid * CP * WNCOL;
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
         const int q = a.gw + GWS * i;
-        const int tap = q / 3, ct = q - 3 * tap;
 #pragma unroll
         for (int mt = 0; mt < 3; ++mt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int co = 16 * mt + 4 * g + r;
-                dst[co * 432 + tap * CP + 16 * ct + n] = acc[i][mt][r];
-            }
+            for (int r = 0; r < 4; ++r) dst[(16 * mt + 4 * g + r) * WNCOL + 16 * q + n] = acc[i][mt][r];
+    }
+    if constexpr (EX) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dst[(16 * a.mte + 4 * g + r) * WNCOL + 16 * a.qe + n] = acce[r];
     }
 }
 
 template <int SLICES>
 __device__ __forceinline__ void wgrad_body(
     WStage st, const float* __restrict__ in_stats /* {mean, rstd} of layer i-1 or nullptr */, const BwdFold& bfold,
-    float* __restrict__ part /* [nblk][48][432] */, int B, int H, int bid, int nblk, int slice) {
+    float* __restrict__ part /* [nblk][48][WNCOL] */, int B, int H, int bid, int nblk, int slice) {
     HIP_DYNAMIC_SHARED(float, lds)
     const int P = H * PW;
     const int CSZ = chan_stride_z(H), CSX = chan_stride_x(H);
@@ -1239,17 +1353,30 @@ __device__ __forceinline__ void wgrad_body(
     // gw, gw + 24) and write disjoint columns of the same partial row
     constexpr int GWS = 12 * SLICES;
     const int gw = wave + 12 * slice;
-    const WgradArgs a{st, part, tz, tx, lm, B, P, CSZ, CSX, R, R1, tid, lane, wave, bid, nblk, gw};
-    if constexpr (SLICES == 1) {       // tiles wave, wave + 12, wave + 24 (< 27): waves 0..2 carry a third one
-        if (wave + 24 < 27)
-            wgrad_loop<3, GWS>(a, zt, xt, zb, xb, b, pslot);
+    if constexpr (SLICES == 1) {
+        // tiles wave, wave + 12 for everyone; the six chains of tiles 24 / 25 go to waves 0, 4 (SIMD 0), 1, 5 (SIMD 1), 2, 3
+        int qe = 0, mte = 0;
+        bool ex = true;
+        switch (wave) {
+            case 0: qe = 24, mte = 0; break;
+            case 4: qe = 24, mte = 1; break;
+            case 1: qe = 24, mte = 2; break;
+            case 5: qe = 25, mte = 0; break;
+            case 2: qe = 25, mte = 1; break;
+            case 3: qe = 25, mte = 2; break;
+            default: ex = false; break;
+        }
+        const WgradArgs a{st, part, tz, tx, lm, B, P, CSZ, CSX, R, R1, tid, lane, wave, bid, nblk, gw, qe, mte};
+        if (ex)
+            wgrad_loop<2, true, GWS>(a, zt, xt, zb, xb, b, pslot);
         else
-            wgrad_loop<2, GWS>(a, zt, xt, zb, xb, b, pslot);
-    } else {                           // tiles gw, gw + 24 (< 27)
-        if (gw + 24 < 27)
-            wgrad_loop<2, GWS>(a, zt, xt, zb, xb, b, pslot);
+            wgrad_loop<2, false, GWS>(a, zt, xt, zb, xb, b, pslot);
+    } else {                           // small batches: tiles gw, gw + 24 (< 26) over the 24 waves of two workgroups
+        const WgradArgs a{st, part, tz, tx, lm, B, P, CSZ, CSX, R, R1, tid, lane, wave, bid, nblk, gw, 0, 0};
+        if (gw + 24 < 26)
+            wgrad_loop<2, false, GWS>(a, zt, xt, zb, xb, b, pslot);
         else
-            wgrad_loop<1, GWS>(a, zt, xt, zb, xb, b, pslot);
+            wgrad_loop<1, false, GWS>(a, zt, xt, zb, xb, b, pslot);
     }
     HOWL_PROBE(st.z, wave, lane, pslot++);   // partials written
 }
@@ -1319,9 +1446,8 @@ __device__ __forceinline__ void reduce_rows_body(const float* __restrict__ part,
         if (mode == 0) {
             out[col] = tot;
         } else {
-            const int co = col / 432, r = col - co * 432;
-            const int tap = r / CP, ci = r - tap * CP;
-            if (co < NMAP && ci < NMAP) out[(co * NMAP + ci) * 9 + tap] = tot;
+            const int co = col / WNCOL, idx = col - co * WNCOL;      // idx = 45 tap + cin
+            if (co < NMAP && idx < WTAPS) out[(co * NMAP + idx % NMAP) * 9 + idx / NMAP] = tot;
         }
     }
 }
@@ -1334,7 +1460,7 @@ __global__ __launch_bounds__(1024) void reduce_rows_all_kernel(const float* __re
     // a launch covers rows y0, y0 + 1 + yskip, ... of {layer 1..6, conv0} (layers 2..6 are folded inside the pair launches)
     const int y = y0 + (int)blockIdx.y * (1 + yskip);
     if (y < 6) {
-        reduce_rows_body(part + y * layer_stride, nparts, CP * 432, 1, out.p[y]);
+        reduce_rows_body(part + y * layer_stride, nparts, CP * WNCOL, 1, out.p[y]);
     } else if (blockIdx.x * 64 < NMAP * 9) {
         reduce_rows_body(c0part, c0parts, NMAP * 9, 0, c0out);
     }
@@ -2053,7 +2179,7 @@ struct Ws {
     float* dz2;
     float* dsa;
     float* dsb;
-    float* wpart;    // [6][G][48][432]: one set of weight-gradient partials per layer (reduced together at the end)
+    float* wpart;    // [6][G][48][WNCOL]: one set of weight-gradient partials per layer (reduced together at the end)
     float* c0part;   // [G][405]
 };
 
@@ -2081,7 +2207,7 @@ size_t ws_layout(Ws* w, char* base, int B, int H, int G) {
     t.dz2 = take(act);
     t.dsa = take(act);
     t.dsb = take(act);
-    t.wpart = take((size_t)6 * G * CP * 432);
+    t.wpart = take((size_t)6 * G * CP * WNCOL);
     t.c0part = take((size_t)max_parts * NMAP * 9);     // one row per workgroup of conv0's weight gradient (<= CUs with slicing)
     if (w) *w = t;
     return off;
@@ -2419,7 +2545,7 @@ int res8_bwd_impl(const HowlRes8Params* prm, const float* feat, long sb, long st
     // dgrad and wgrad side by side: half the CUs each
     const int half = howl_num_cus() / 2 > 0 ? howl_num_cus() / 2 : 1;
     const int Gh = B < half ? B : half;
-    const size_t wpart_stride = (size_t)Gh * CP * 432;
+    const size_t wpart_stride = (size_t)Gh * CP * WNCOL;
     int SD = 1, SW = 1;
     pair_slices(Gh, H, &SD, &SW);
     float* dx_cur = nullptr;      // gradient w.r.t. the BN output of layer i (nullptr: broadcast of dpool)
@@ -2492,7 +2618,7 @@ int res8_bwd_impl(const HowlRes8Params* prm, const float* feat, long sb, long st
     const int G0w = B * S0 < howl_num_cus() ? B * S0 : howl_num_cus();   // conv0's weight-gradient grid: one partial row each
     // layers 2..6 were folded inside the pair launches (WFold); layer 1's partials and conv0's remain
     if (part == 1)      // the six layers' weight gradients are final before conv0's is even started
-        hipLaunchKernelGGL(reduce_rows_all_kernel, dim3((CP * 432 + 63) / 64, 1), dim3(1024), 0, stream, (const float*)w.wpart,
+        hipLaunchKernelGGL(reduce_rows_all_kernel, dim3((CP * WNCOL + 63) / 64, 1), dim3(1024), 0, stream, (const float*)w.wpart,
                            wpart_stride, Gh, gw, (const float*)w.c0part, G0w, gr->conv0_w, 0, 0);
     if (run_conv0) {
         {
@@ -2502,7 +2628,7 @@ int res8_bwd_impl(const HowlRes8Params* prm, const float* feat, long sb, long st
                            (const float*)nullptr, w.c0part, B, T, M, H, S0);
         }
         if (part == 0)      // rows {layer 1, conv0} of the reduction
-            hipLaunchKernelGGL(reduce_rows_all_kernel, dim3((CP * 432 + 63) / 64, 2), dim3(1024), 0, stream,
+            hipLaunchKernelGGL(reduce_rows_all_kernel, dim3((CP * WNCOL + 63) / 64, 2), dim3(1024), 0, stream,
                                (const float*)w.wpart, wpart_stride, Gh, gw, (const float*)w.c0part, G0w, gr->conv0_w, 0, 5);
         else
             hipLaunchKernelGGL(reduce_rows_all_kernel, dim3((NMAP * 9 + 63) / 64, 1), dim3(1024), 0, stream,

@@ -20,6 +20,9 @@ EDITS = {
     "epi_after": [("-D", "HOWL_DIAG_EPI_AFTER")],      # epilogue behind the second barrier
     "nostage": [("-D", "HOWL_DIAG_NOSTAGE")],          # timing only (WRONG results): the conv phases without their staging work
     "desync": [("-D", "HOWL_DIAG_DESYNC")],
+    "w_nostage": [("-D", "HOWL_DIAG_WNOSTAGE")], "w_nolds": [("-D", "HOWL_DIAG_WGRAD_NOLDS")], "w_nomfma": [("-D", "HOWL_DIAG_WGRAD_NOMFMA")],
+    "w_nostage_nolds": [("-D", "HOWL_DIAG_WNOSTAGE"), ("-D", "HOWL_DIAG_WGRAD_NOLDS")],
+    "wino": [("-D", "HOWL_DIAG_WINO")],                # timing skeleton of a Winograd F(2x2,3x3) forward (WRONG results), see res8.hip
     "c0_nostore": [("-D", "HOWL_DIAG_C0_NOSTORE")], "c0_nomfma": [("-D", "HOWL_DIAG_C0_NOMFMA")],
     "c0_noload": [("-D", "HOWL_DIAG_C0_NOLOAD")], "c0_noepi": [("-D", "HOWL_DIAG_C0_NOEPI")],
     "c0w_nocompute": [("        for (int cell = c0 + wave; cell < c1; cell += C0W_THREADS / 64) {", "        for (int cell = c0 + wave; cell < c1 && B < 0; cell += C0W_THREADS / 64) {")],
