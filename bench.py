@@ -26,7 +26,7 @@ relays rank 0's line.  ``HOWL_BENCH_BACKEND=gloo`` lets several ranks share one 
 Rank 0 prints ONE JSON line; besides the contract fields it carries
   "roofline":     the time-dominant kernel of the configuration: algorithmic FLOPs (or bytes) per launch / mean launch
                   duration measured with HIP events on the launch stream in a second pass of the same K steps
-                  (res8: bwd_pair_kernel = data + weight gradient of a 45->45 layer in one launch, 48 % of the step, vs the
+                  (res8: bwd_pair_kernel = data + weight gradient of a 45->45 layer in one launch, 58 % of the step, vs the
                   157.3 TFLOP/s fp32 MFMA peak, the forward convolution and the log-mel kernel beside it; seq-lstm:
                   recurrences + GEMMs vs the same peak; mobilenet: the fused convolution launches vs 8 TB/s HBM);
   "repeats":      the K timed steps as 5 consecutive segments (HIP events on the compute stream, no extra syncs):
@@ -270,19 +270,18 @@ def pmc_traffic(kernel="bwd_pair_kernel"):
     process, so the figure is the one measured on the same command line when the summary was taken (the file is named)."""
     import re
     files = sorted((ROOT / "profiles").glob("*pmc*.txt"), key=lambda f: ([int(x) for x in re.findall(r"\d+", f.name)], f.name))
-    if not files:
-        return None, None
-    vals = []
-    lines = files[-1].read_text().splitlines()
-    for i, line in enumerate(lines):
-        if line.startswith(kernel) and i + 1 < len(lines):
-            d = json.loads(lines[i + 1].strip())
-            if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
-                vals.append(((2 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024.0, d.get("launches", 1)))
-    if not vals:
-        return None, None
-    tot = sum(v * n for v, n in vals) / sum(n for _, n in vals)
-    return tot, files[-1].name
+    for f in reversed(files):        # the newest summary that lists this kernel (other summaries cover other configurations)
+        vals = []
+        lines = f.read_text().splitlines()
+        for i, line in enumerate(lines):
+            if line.startswith(kernel) and i + 1 < len(lines):
+                d = json.loads(lines[i + 1].strip())
+                if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
+                    vals.append(((2 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024.0, d.get("launches", 1)))
+        if vals:
+            tot = sum(v * n for v, n in vals) / sum(n for _, n in vals)
+            return tot, f.name
+    return None, None
 
 
 def bench_eval(args, dev):
@@ -554,18 +553,21 @@ def main():
             act = 4.0 * 45 * (H * 10) * B      # one (B, 45, H, 10) fp32 map
             roof = {"bound": "mfma",
                     "kernel": "bwd_pair_kernel (data gradient + weight gradient of one 45->45 3x3 layer in ONE launch, half of "
-                              "the CUs each): the time-dominant kernel, 6 launches = 48 % of the step",
+                              "the CUs each, the BatchNorm / ReLU backward built inside both roles' tile staging): the "
+                              "time-dominant kernel, 6 launches = 58 % of the step",
                     "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
                     "traffic": None if traffic is None else round(traffic),
                     "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)", "traffic_source": traffic_src,
-                    # dz in (both roles share it through L2), the layer input in (wgrad operand and the BatchNorm-backward
-                    # sums of dgrad), dx out, and the per-workgroup weight-gradient partials out
-                    "algorithmic_bytes": round(act * 3 + 4.0 * 48 * 432 * min(B, 128)),
+                    # per launch, averaged over the six layers: dx_i, s_i, s_{i-1} in (both roles stage them: the second
+                    # reader hits L2), the skip gradient in and ds_i out on the three layers that have one, dx_{i-1} out,
+                    # the weight-gradient partials out (one [48][416] row per weight-gradient workgroup) and the previous
+                    # layer's partials in (folded by the data-gradient workgroups, five of the six launches)
+                    "algorithmic_bytes": round(act * 5 + 4.0 * 48 * 416 * min(B, 128) * (1 + 5.0 / 6.0)),
                     "algorithmic_flops": round(2 * flops_launch),
                     "avg_launch_ms": round(avg_ms, 4), "launches": npair,
                     "other_kernels": {
-                        "conv3x3_mfma_kernel<0> (45->45 3x3 convolution, forward launches; 6 = 27 % of the step)": {
+                        "conv3x3_mfma_kernel<0> (45->45 3x3 convolution, forward launches; 6 = 30 % of the step)": {
                             "avg_launch_ms": round(fwd_ms, 4), "launches": nf, "tflops": round(fwd_tf, 2),
                             "frac": round(fwd_tf / FP32_MFMA_PEAK_TFLOPS, 4), "algorithmic_bytes": round(act * 2.5),
                             "traffic": None if fwd_traffic is None else round(fwd_traffic)},
