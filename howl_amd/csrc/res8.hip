@@ -2548,6 +2548,10 @@ int res8_bwd_impl(const HowlRes8Params* prm, const float* feat, long sb, long st
     const size_t wpart_stride = (size_t)Gh * CP * WNCOL;
     int SD = 1, SW = 1;
     pair_slices(Gh, H, &SD, &SW);
+    // the fold of a layer's weight-gradient partials rides in the NEXT pair launch when that launch has enough data-gradient
+    // workgroups to spread the 9,984 column pairs thin (a single utterance's four workgroups would walk 26 trips of two barriers
+    // each: +60 us at batch 1); small batches keep the one reduction launch at the end
+    const bool fold_in_pair = Gh * SD >= 64;
     float* dx_cur = nullptr;      // gradient w.r.t. the BN output of layer i (nullptr: broadcast of dpool)
     float* dx_next = w.bufa;
     float* ds_prev = nullptr;     // ds_{i+2}
@@ -2588,7 +2592,7 @@ int res8_bwd_impl(const HowlRes8Params* prm, const float* feat, long sb, long st
         float* spart = need_stats ? part_out : (float*)nullptr;
         float* wpart = w.wpart + (size_t)(i - 1) * wpart_stride;
         // the partials of layer i+1's weight gradient (previous launch) are folded by this launch's data-gradient workgroups
-        const WFold wf = i < 6 ? WFold{w.wpart + (size_t)i * wpart_stride, Gh, gr->conv_w[i]} : WFold{nullptr, 0, nullptr};
+        const WFold wf = (fold_in_pair && i < 6) ? WFold{w.wpart + (size_t)i * wpart_stride, Gh, gr->conv_w[i]} : WFold{nullptr, 0, nullptr};
         if (!run_layers) {
             // part 2 only replays the buffer rotation of the loop
         } else if (merged) {
@@ -2618,8 +2622,8 @@ int res8_bwd_impl(const HowlRes8Params* prm, const float* feat, long sb, long st
     const int G0w = B * S0 < howl_num_cus() ? B * S0 : howl_num_cus();   // conv0's weight-gradient grid: one partial row each
     // layers 2..6 were folded inside the pair launches (WFold); layer 1's partials and conv0's remain
     if (part == 1)      // the six layers' weight gradients are final before conv0's is even started
-        hipLaunchKernelGGL(reduce_rows_all_kernel, dim3((CP * WNCOL + 63) / 64, 1), dim3(1024), 0, stream, (const float*)w.wpart,
-                           wpart_stride, Gh, gw, (const float*)w.c0part, G0w, gr->conv0_w, 0, 0);
+        hipLaunchKernelGGL(reduce_rows_all_kernel, dim3((CP * WNCOL + 63) / 64, fold_in_pair ? 1 : 6), dim3(1024), 0, stream,
+                           (const float*)w.wpart, wpart_stride, Gh, gw, (const float*)w.c0part, G0w, gr->conv0_w, 0, 0);
     if (run_conv0) {
         {
         HowlProfScope prof("conv0_wgrad", stream);
@@ -2627,9 +2631,10 @@ int res8_bwd_impl(const HowlRes8Params* prm, const float* feat, long sb, long st
                            stream, feat, sb, st, sm, (const unsigned short*)sv->mask0, (const float*)dx_cur,
                            (const float*)nullptr, w.c0part, B, T, M, H, S0);
         }
-        if (part == 0)      // rows {layer 1, conv0} of the reduction
-            hipLaunchKernelGGL(reduce_rows_all_kernel, dim3((CP * WNCOL + 63) / 64, 2), dim3(1024), 0, stream,
-                               (const float*)w.wpart, wpart_stride, Gh, gw, (const float*)w.c0part, G0w, gr->conv0_w, 0, 5);
+        if (part == 0)      // rows {layer 1, conv0} of the reduction (small batches: all six layers and conv0)
+            hipLaunchKernelGGL(reduce_rows_all_kernel, dim3((CP * WNCOL + 63) / 64, fold_in_pair ? 2 : 7), dim3(1024), 0, stream,
+                               (const float*)w.wpart, wpart_stride, Gh, gw, (const float*)w.c0part, G0w, gr->conv0_w, 0,
+                               fold_in_pair ? 5 : 0);
         else
             hipLaunchKernelGGL(reduce_rows_all_kernel, dim3((NMAP * 9 + 63) / 64, 1), dim3(1024), 0, stream,
                                (const float*)w.wpart, wpart_stride, Gh, gw, (const float*)w.c0part, G0w, gr->conv0_w, 6, 0);
