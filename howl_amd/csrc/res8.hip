@@ -300,12 +300,16 @@ struct SlotVal {
 // tile; destination and channel depend only on the thread: bits 0..19 LDS float offset, 20..25 channel, -1 = no such element
 template <int NSL>
 __device__ __forceinline__ void region_slots(int (&pk)[NSL], int c0, int nch, int P, int CS, int tid) {
+    // integer divisions by run-time values cost ~25 instructions each, eighteen of them 2.5 k cycles of every workgroup's prologue:
+    // floor(e / P) as (int)((e + 0.5) * (1 / P)) -- exact: the quotient's fraction is a multiple of 1 / P, so the half step keeps
+    // the product >= 0.5 / P = 1.8e-3 away from an integer, float rounding of a value <= 48 is 3e-6
+    const float invP = 1.0f / (float)P;
 #pragma unroll
     for (int j = 0; j < NSL; ++j) {
         const int e = 2 * (tid + j * CONV_THREADS);
-        const int c = e / P;
+        const int c = (int)(((float)e + 0.5f) * invP);
         const int p = e - c * P;
-        const int h = p / PW;
+        const int h = (int)(((float)p + 0.5f) * 0.1f);
         const int w = p - h * PW;
         pk[j] = (e < nch * P) ? (((c0 + c) * CS + (h + 1) * WP + (w + 1)) | ((c0 + c) << 20)) : -1;
     }
@@ -941,6 +945,11 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_mfma_kernel(StageCfg cfg
     const int x = blockIdx.x & 7, y = blockIdx.x >> 3;
     const int slice = y % SLICES, bid = (y / SLICES) * 8 + x;
     if (bid >= nblk) return;
+#if defined(HOWL_DIAG_CONV_EMPTY)   // diagnostic build (tools/variants4.py): what dispatching 256 x 768 threads with 145 KB of LDS costs
+    if (MODE == 0) return;
+#elif defined(HOWL_DIAG_CONV_PROLOGUE_ONLY)   // ... plus the prologue (weights, statistics fold, first half tile), no utterances
+    if (MODE == 0) B = 0;
+#endif
     conv3x3_body<MODE, SLICES>(cfg, in_stats, wp, res, out, xs, xs_stats, part, pool, B, H, bid, nblk, slice, fold, bfold, wf);
 }
 
@@ -1052,12 +1061,13 @@ __device__ __forceinline__ void row_region_slots(int (&pk)[NSL], int h0, int h1,
                                                  int tid) {
     const int nper = PW * (h1 > h0 ? h1 - h0 : 0);
     const int nsafe = nper > 0 ? nper : 1;
+    const float inv = 1.0f / (float)nsafe;
 #pragma unroll
     for (int j = 0; j < NSL; ++j) {
         const int e = 2 * (tid + j * CONV_THREADS);
-        const int c = e / nsafe;
+        const int c = (int)(((float)e + 0.5f) * inv);          // floor(e / nsafe), exact (see region_slots)
         const int q = e - c * nsafe;
-        const int hh = q / PW;
+        const int hh = (int)(((float)q + 0.5f) * 0.1f);
         const int w = q - hh * PW;
         const int h = h0 + hh;
         pk[j] = (e < NMAP * nper) ? ((c * CS + (h + row0) * pitch + w + col0) | ((c * P + h * PW + w) << 15)) : -1;
@@ -1738,9 +1748,12 @@ __global__ __launch_bounds__(C0M_THREADS) void conv0_fwd_mfma_kernel(const float
                     for (int tl = 0; tl < 3; ++tl)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            const float z = acc[tl][nt][r];
-                            sum += fmaxf(z, 0.0f);
-                            bits |= (z > 0.0f ? 1u : 0u) << (4 * tl + r);
+                            // relu(z) as an INTEGER max (negatives and -0 -> +0, exact) and the mask bit as min(bits, 1):
+                            // four vector instructions per value (the compare / select / shift / or form took six, and
+                            // this epilogue does not overlap the MFMAs: 18 of the kernel's 43 us)
+                            const int rb = max(__float_as_int(acc[tl][nt][r]), 0);
+                            sum += __int_as_float(rb);
+                            bits |= min((unsigned)rb, 1u) << (4 * tl + r);
                         }
                     const int c = 16 * nt + n;
 #if defined(HOWL_DIAG_C0_NOSTORE)   // diagnostic build: no global stores

@@ -22,6 +22,7 @@ EDITS = {
     "desync": [("-D", "HOWL_DIAG_DESYNC")],
     "w_nostage": [("-D", "HOWL_DIAG_WNOSTAGE")], "w_nolds": [("-D", "HOWL_DIAG_WGRAD_NOLDS")], "w_nomfma": [("-D", "HOWL_DIAG_WGRAD_NOMFMA")],
     "w_nostage_nolds": [("-D", "HOWL_DIAG_WNOSTAGE"), ("-D", "HOWL_DIAG_WGRAD_NOLDS")],
+    "conv_empty": [("-D", "HOWL_DIAG_CONV_EMPTY")], "conv_prologue": [("-D", "HOWL_DIAG_CONV_PROLOGUE_ONLY")],
     "wino": [("-D", "HOWL_DIAG_WINO")],                # timing skeleton of a Winograd F(2x2,3x3) forward (WRONG results), see res8.hip
     "c0_nostore": [("-D", "HOWL_DIAG_C0_NOSTORE")], "c0_nomfma": [("-D", "HOWL_DIAG_C0_NOMFMA")],
     "c0_noload": [("-D", "HOWL_DIAG_C0_NOLOAD")], "c0_noepi": [("-D", "HOWL_DIAG_C0_NOEPI")],
