@@ -363,3 +363,30 @@ def test_reference_written_workspace_on_the_gpu(golden, tmp_path):
     for logits in (by_protocol, fused):
         assert maxerr(logits, g["eval_logits"]) < LOGIT_TOL
         assert torch.equal(logits.argmax(1).cpu(), t(g["eval_logits"]).argmax(1))
+
+
+@pytest.mark.parametrize("B,T", [(512, 81), (96, 41), (5, 62)])
+def test_fused_backward_matches_the_unfused_reference(monkeypatch, B, T):
+    """Round 4: BatchNorm backward + skip gradient + ReLU mask are applied inside the tile staging of both roles of the backward
+    pair (three tensors per element, staged under the K loop in half-tile phases), the weight-gradient partials are folded by
+    the next pair, ds_2 joins dx_0 in layer 1's data gradient.  HOWL_RES8_BWD_FUSED=0 runs the elementwise pass as its own
+    launch (bn_relu_bwd_kernel writes dz): both must give the same gradients to rounding, repeatably."""
+    C = 12
+    torch.manual_seed(11)
+    x = (torch.randn(B, T, 40) * 1.1).permute(0, 2, 1).unsqueeze(1).to(DEV)
+    labels = (torch.arange(B) % C).to(DEV)
+
+    def grads():
+        model = make_res8(C)
+        torch.nn.functional.cross_entropy(model(x, None), labels).backward()
+        torch.cuda.synchronize()
+        return [p.grad.clone() for p in model.hot_parameters()]
+
+    fused = grads()
+    for a, b in zip(fused, grads()):
+        assert torch.equal(a, b)                              # the staging phases race with nothing
+    monkeypatch.setenv("HOWL_RES8_BWD_FUSED", "0")
+    unfused = grads()
+    for a, b in zip(fused, unfused):
+        scale = max(1.0, b.abs().max().item())
+        assert (a - b).abs().max().item() < 5e-6 * scale
