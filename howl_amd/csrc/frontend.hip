@@ -542,18 +542,49 @@ __global__ __launch_bounds__(1024) void fb_fragments_kernel(float* __restrict__ 
 
 // triangles from M+2 corner frequencies (already VTLP-warped on the host: 42 scalars), exactly the
 // slope arithmetic of transform.py:402-409; all_freqs = linspace(0, sr/2, 257) = k * (sr/2) / 256.
-__global__ void fb_points_kernel(HowlMelPoints pts, int M, float nyquist, float* __restrict__ fbp, int ncol) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= K_PAD * ncol) return;
-    const int k = idx / ncol, m = idx - k * ncol;
-    float v = 0.0f;
-    if (k < N_FREQ && m < M) {
-        const float f = (k == N_FREQ - 1) ? nyquist : (float)k * (nyquist / (float)(N_FREQ - 1));
-        const float down = (-1.0f * (pts.f[m] - f)) / (pts.f[m + 1] - pts.f[m]);
-        const float up = (pts.f[m + 2] - f) / (pts.f[m + 2] - pts.f[m + 1]);
-        v = fmaxf(0.0f, fminf(down, up));
+__device__ __forceinline__ float fb_triangle(const HowlMelPoints& pts, int M, float nyquist, int k, int m) {
+    if (k < 0 || k >= N_FREQ || m >= M) return 0.0f;
+    const float f = (k == N_FREQ - 1) ? nyquist : (float)k * (nyquist / (float)(N_FREQ - 1));
+    const float down = (-1.0f * (pts.f[m] - f)) / (pts.f[m + 1] - pts.f[m]);
+    const float up = (pts.f[m + 2] - f) / (pts.f[m + 2] - pts.f[m + 1]);
+    return fmaxf(0.0f, fminf(down, up));
+}
+
+// The whole packed filterbank of howl_fb_from_points in ONE launch (round 4; it was the row-major matrix, then a one-workgroup
+// kernel gathering the fragment images from it: 5 + 11 us per VTLP step, i.e. on 75 % of the training steps): every element
+// of the three images is computed from the corner points where it is stored, the last block takes the coverage flag.
+__global__ __launch_bounds__(256) void fb_from_points_kernel(HowlMelPoints pts, int M, float nyquist, float* __restrict__ fbp) {
+    constexpr int N_RM = K_PAD * HOWL_FB_COLS;
+    if (blockIdx.x == gridDim.x - 1) {      // does the banded image cover every non-zero weight?
+        __shared__ int uncovered;
+        if (threadIdx.x == 0) uncovered = 0;
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < N_FREQ * HOWL_FB_COLS; idx += blockDim.x) {
+            const int k = idx / HOWL_FB_COLS, m = idx - k * HOWL_FB_COLS;
+            if (fb_triangle(pts, M, nyquist, k, m) != 0.0f && !slot_has_group(slot_of_bin(k), m >> 2)) uncovered = 1;   // benign race
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) reinterpret_cast<int*>(fbp + FBF_OFF)[0] = uncovered ? 0 : 1;
+        return;
     }
-    fbp[idx] = v;
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < N_RM) {                       // (K_PAD, HOWL_FB_COLS) row-major
+        fbp[idx] = fb_triangle(pts, M, nyquist, idx / HOWL_FB_COLS, idx % HOWL_FB_COLS);
+        return;
+    }
+    idx -= N_RM;
+    if (idx < FBQ_FLOATS) {                 // banded LDS image [s][lane][4]
+        const int c = idx & 3, lane = (idx >> 2) & 63, sl = idx >> 8;
+        const int g = slot_group(sl, c), bin = bin_of(sl, lane >> 2);
+        fbp[FBQ_OFF + idx] = (g >= 0 && bin >= 0) ? fb_triangle(pts, M, nyquist, bin, 4 * g + (lane & 3)) : 0.0f;
+        return;
+    }
+    idx -= FBQ_FLOATS;
+    if (idx < FBD_FLOATS) {                 // every (slot, group) fragment
+        const int lane = idx & 63, pair = idx >> 6;
+        const int sl = pair / NG_MAX, g = pair - sl * NG_MAX, bin = bin_of(sl, lane >> 2);
+        fbp[FBD_OFF + idx] = bin >= 0 ? fb_triangle(pts, M, nyquist, bin, 4 * g + (lane & 3)) : 0.0f;
+    }
 }
 
 // K2: (B,M,T) raw log-mels -> (B,3,M,T) [log-mel, delta, delta-delta], each optionally ZMUV-normalised.
@@ -849,9 +880,9 @@ int howl_fb_from_points(const HowlMelPoints* pts, int M, float nyquist, float* f
     HOWL_REQUIRE(pts && fbp, "howl_fb_from_points: null pointer");
     HOWL_REQUIRE(M >= 1 && M <= HOWL_MAX_MELS, "howl_fb_from_points: M=%d unsupported (1..%d)", M, HOWL_MAX_MELS);
     const int ncol = HOWL_FB_COLS;
-    hipLaunchKernelGGL(fb_points_kernel, dim3((K_PAD * ncol + 255) / 256), dim3(256), 0, stream, *pts, M, nyquist, fbp,
-                       ncol);
-    hipLaunchKernelGGL(fb_fragments_kernel, dim3(1), dim3(1024), 0, stream, fbp);
+    (void)ncol;
+    const int work = K_PAD * HOWL_FB_COLS + FBQ_FLOATS + FBD_FLOATS;
+    hipLaunchKernelGGL(fb_from_points_kernel, dim3((work + 255) / 256 + 1), dim3(256), 0, stream, *pts, M, nyquist, fbp);
     HOWL_CHECK_LAUNCH("howl_fb_from_points");
     return HOWL_OK;
 }
