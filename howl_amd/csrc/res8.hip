@@ -1678,7 +1678,7 @@ __global__ __launch_bounds__(C0M_THREADS) void conv0_fwd_mfma_kernel(const float
         return;
     }
     HIP_DYNAMIC_SHARED(float, lds)
-    float* tin = lds;  // (T+2) x (M+4), zero halo (+ 16 floats of slack for the padding cells of the last block)
+    float* tin = lds;  // (T+2) x (M+4), zero halo (+ conv0_tile_floats' slack for the second row of an odd last pair)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int pitch = M + 4;
     const int P = H * PW;
@@ -1692,14 +1692,17 @@ __global__ __launch_bounds__(C0M_THREADS) void conv0_fwd_mfma_kernel(const float
             const int tap = 4 * ks + g, c = 16 * nt + n;
             bw[ks][nt] = (tap < 9 && c < NMAP) ? w0[c * 9 + tap] : 0.0f;
         }
-    // A fragments: A[row i = n][k = tap = 4ks + g] = tin[frame 3ph + tl + tap/3][mel 16blk + i + tap%3]  (halo origin)
+    // A fragments: a 16-row tile is 8 mel bins (two neighbouring pooled cells) of one frame of TWO consecutive pooled rows --
+    // 40 mel bins are exactly five groups of eight (rounds 2-3 used 16 bins of one pooled row: 2.5 blocks, the third half
+    // padding: 81 units per utterance, now 70) -- row i = n: pooled row +(n >> 3), mel bin 8j + (n & 7):
+    //   A[i][k = tap = 4ks + g] = tin[frame 3(ph + (n >> 3)) + tl + tap/3][mel 8j + (n & 7) + tap%3]  (halo origin)
     int aoff[3];
 #pragma unroll
     for (int ks = 0; ks < 3; ++ks) {
         const int tap = min(4 * ks + g, 8);  // taps 9..11 meet zero weights: any finite value will do
-        aoff[ks] = (tap / 3) * pitch + tap % 3 + n;
+        aoff[ks] = (tap / 3) * pitch + tap % 3 + (n & 7) + (n >> 3) * 3 * pitch;
     }
-    if (tid < 16) tin[(T + 2) * pitch + tid] = 0.0f;  // slack read by the padding cells
+    for (int i = tid; i < 3 * pitch + 16; i += C0M_THREADS) tin[(T + 2) * pitch + i] = 0.0f;  // slack read by an odd last row pair
     // Small batches: `slices` workgroups share an utterance's pooled rows (one utterance costs a workgroup ~20 us whatever the
     // batch: at B <= 64 that was the whole launch with three quarters of the CUs idle); work item = (utterance, slice).
     for (int item = blockIdx.x; item < B * slices; item += nconv) {
@@ -1713,10 +1716,10 @@ __global__ __launch_bounds__(C0M_THREADS) void conv0_fwd_mfma_kernel(const float
         load_feat_tile(tin, feat + (long)clip * sb + (long)t0 * st, 0, st, sm, 0, T, M, tid, C0M_THREADS);
 #endif
         __syncthreads();
-        // units (pooled row, 16-bin block) of this slice, dealt to the waves
-        for (int u = wave; u < 3 * (ph1 - ph0); u += C0M_THREADS / 64) {
-            const int ph = ph0 + u / 3, blk = u - 3 * (u / 3);
-            const float* rowp = tin + 3 * ph * pitch + 16 * blk;
+        // units (pair of pooled rows, group of 8 mel bins) of this slice, dealt to the waves
+        for (int u = wave; u < 5 * ((ph1 - ph0 + 1) / 2); u += C0M_THREADS / 64) {
+            const int pp = u / 5, j8 = u - 5 * pp;
+            const float* rowp = tin + 3 * (ph0 + 2 * pp) * pitch + 8 * j8;
             {
                 f32x4 acc[3][3];  // [frame tl][cout tile nt]
 #pragma unroll
@@ -1736,7 +1739,7 @@ __global__ __launch_bounds__(C0M_THREADS) void conv0_fwd_mfma_kernel(const float
                             acc[tl][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bw[ks][nt], acc[tl][nt], 0, 0, 0);
 #endif
                     }
-                const int pw = 4 * blk + g;  // this lane's cell
+                const int pw = 2 * j8 + (g & 1), ph = ph0 + 2 * pp + (g >> 1);  // this lane's cell: rows 4g..4g+3 of the tile
 #if defined(HOWL_DIAG_C0_NOEPI)   // diagnostic build: MFMAs only (one value keeps them alive)
                 if (acc[0][0][0] + acc[1][1][1] + acc[2][2][2] == 123.456f) s0[0] = 1.0f;
 #else
@@ -1757,9 +1760,9 @@ __global__ __launch_bounds__(C0M_THREADS) void conv0_fwd_mfma_kernel(const float
                         }
                     const int c = 16 * nt + n;
 #if defined(HOWL_DIAG_C0_NOSTORE)   // diagnostic build: no global stores
-                    if (pw < PW && c < NMAP && sum == 123.456f) {
+                    if (ph < ph1 && c < NMAP && sum == 123.456f) {
 #else
-                    if (pw < PW && c < NMAP) {
+                    if (ph < ph1 && c < NMAP) {
 #endif
                         const size_t o = ((size_t)b * NMAP + c) * P + (size_t)ph * PW + pw;
                         s0[o] = sum * (1.0f / 12.0f);
@@ -2155,6 +2158,7 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
     }
 }
 
+size_t conv0_tile_floats(int T, int M) { return (size_t)(T + 2) * (M + 4) + 3 * (M + 4) + 16; }   // tile + slack (conv0_fwd_mfma_kernel)
 size_t conv_lds_bytes(int H) { return (size_t)(3 * KSTEPS * 64 + tile_floats(H) + 4 * CP + 12 * 2 * 16) * sizeof(float); }
 #if defined(HOWL_DIAG_PROBE)
 unsigned long long* g_probe_ptr = nullptr;
@@ -2360,7 +2364,7 @@ int res8_fwd_impl(const HowlRes8Params* prm, const float* feat, long sb, long st
     }
     if (!training) hipLaunchKernelGGL(bn_eval_stats_kernel, dim3(6), dim3(64), 0, stream, rm, rv, sv->bn_stats);
 
-    const size_t l0 = ((size_t)(T + 2) * (M + 4) + 16) * sizeof(float);
+    const size_t l0 = conv0_tile_floats(T, M) * sizeof(float);
     // 103 VGPRs and 15 KB of LDS: two workgroups per CU overlap one's tile load / stores with the other's MFMAs
     const int S0 = conv0_slices(B);
     const int G0 = B * S0 < 2 * howl_num_cus() ? B * S0 : 2 * howl_num_cus();
@@ -2478,7 +2482,7 @@ int howl_res8_fwd_long(const HowlRes8Params* prm, const float* feat, long sb, lo
         rv.p[i] = prm->bn_running_var[i];
     }
     hipLaunchKernelGGL(bn_eval_stats_kernel, dim3(6), dim3(64), 0, stream, rm, rv, stats);
-    const size_t l0 = ((size_t)(Tw + 2) * (M + 4) + 16) * sizeof(float);
+    const size_t l0 = conv0_tile_floats(Tw, M) * sizeof(float);
     const int G0 = Bv < 2 * howl_num_cus() ? Bv : 2 * howl_num_cus();
     const int npack = (2 * 6 * PACK_ELEMS + C0M_THREADS - 1) / C0M_THREADS;
     hipLaunchKernelGGL(conv0_fwd_mfma_kernel, dim3(G0 + npack), dim3(C0M_THREADS), l0, stream, feat, sb, st, sm, prm->conv0_w,
