@@ -101,6 +101,9 @@ class FusedTrainer:
             # two-part backward: the all-reduce of everything but the first `late` parameters (res8: conv0.weight, whose
             # gradient needs the last data gradient) runs on the process group's stream while their kernels still execute
             n0 = sum(p.numel() for p in self.fp.params[:late])
+            # split on a 256-byte boundary of the flat buffer (RCCL's vectorised paths want aligned base addresses): the few
+            # gradients of the next parameter that move to the late collective are final after part 1 as well
+            n0 = min(-(-n0 // 64) * 64, self.fp.numel)
             self.model._launch_backward(feat, dlogits, out_grads=self.fp.grad_views, part=1, **bwd_kw)
             pending = parallel.allreduce_start_(self.fp.grad[n0:], self.group)
             self.model._launch_backward(feat, dlogits, out_grads=self.fp.grad_views, part=2, **bwd_kw)
