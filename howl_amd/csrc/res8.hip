@@ -174,7 +174,18 @@ template <int NTW>
 struct KCursor {
     const lds_f32* ap[NTW];
     const lds_f32* bp;
+    float a[NTW], b;      // operands of the NEXT k-step, requested one step ahead (k_prime / k_run)
 };
+
+// The K loop is software-pipelined by hand: the operands of k-step s+1 are requested before the MFMAs of step s (as the weight
+// gradient's K loop has always done), and they travel in the cursor across the staging bursts between two segments.  Left to the
+// compiler, the third tap of every row was a ds_read_b32 issued right in front of the MFMA that needs it.
+template <int NTW>
+__device__ __forceinline__ void k_prime(KCursor<NTW>& k) {
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) k.a[i] = k.ap[i][0];
+    k.b = k.bp[0];
+}
 
 template <int NTW, int TS>
 __device__ __forceinline__ void k_begin(KCursor<NTW>& k, f32x4 (&acc)[NTW], const lds_f32* tile, const lds_f32* wl,
@@ -199,12 +210,19 @@ __device__ __forceinline__ void k_run(KCursor<NTW>& k, f32x4 (&acc)[NTW], int CS
 #if defined(HOWL_DIAG_CONV_NOK)  // diagnostic build: everything but the K loop
     groups = 0;
 #endif
+    // two K groups per trip: the segments of conv_loop are 2, 2, 2 | 2, 2, 1 groups long, i.e. straight-line code; the operand
+    // reads of a group are then scheduled under the MFMAs of the one before it (one group per trip: +16 us per c3 step)
+#if defined(HOWL_DIAG_KNOUNROLL)
 #pragma nounroll
+#else
+#pragma unroll 2
+#endif
     for (int g = 0; g < groups; ++g) {
+#if defined(HOWL_DIAG_CONV_NOLDS) || defined(HOWL_DIAG_CONV_NOMFMA) || defined(HOWL_DIAG_K_NOPIPE)
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int off = (tap / 3) * WP + (tap % 3);
-#if defined(HOWL_DIAG_CONV_NOLDS)   // diagnostic build: MFMA chain fed from registers (tools/variants.py)
+#if defined(HOWL_DIAG_CONV_NOLDS)   // diagnostic build: MFMA chain fed from registers (tools/variants4.py)
             const float b = __builtin_bit_cast(float, g + tap);
 #pragma unroll
             for (int i = 0; i < NTW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(b, b, acc[i], 0, 0, 0);
@@ -212,7 +230,7 @@ __device__ __forceinline__ void k_run(KCursor<NTW>& k, f32x4 (&acc)[NTW], int CS
             const float b = k.bp[tap * 64];
 #pragma unroll
             for (int i = 0; i < NTW; ++i) acc[i][0] += k.ap[i][off] * b;
-#else
+#else                                 // diagnostic build: the schedule left to the compiler (rounds 1-3)
             const float b = k.bp[tap * 64];
 #pragma unroll
             for (int i = 0; i < NTW; ++i)
@@ -222,6 +240,30 @@ __device__ __forceinline__ void k_run(KCursor<NTW>& k, f32x4 (&acc)[NTW], int CS
         k.bp += 9 * 64;
 #pragma unroll
         for (int i = 0; i < NTW; ++i) k.ap[i] += 4 * CS;
+#else
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            float na[NTW], nb;
+            if (tap < 8) {
+                const int off = ((tap + 1) / 3) * WP + ((tap + 1) % 3);
+#pragma unroll
+                for (int i = 0; i < NTW; ++i) na[i] = k.ap[i][off];
+                nb = k.bp[(tap + 1) * 64];
+            } else {            // the first tap of the next group (past the last group of a phase: discarded, see k_prime)
+                k.bp += 9 * 64;
+#pragma unroll
+                for (int i = 0; i < NTW; ++i) k.ap[i] += 4 * CS;
+#pragma unroll
+                for (int i = 0; i < NTW; ++i) na[i] = k.ap[i][0];
+                nb = k.bp[0];
+            }
+#pragma unroll
+            for (int i = 0; i < NTW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(k.a[i], k.b, acc[i], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < NTW; ++i) k.a[i] = na[i];
+            k.b = nb;
+        }
+#endif
     }
 }
 
@@ -547,6 +589,7 @@ __device__ __forceinline__ void conv_loop(const ConvLoop& c, const ConvEpilogue&
         f32x4 acc[NTV];
         KCursor<NTV> k;
         if constexpr (NTW > 0) k_begin<NTW, TS>(k, acc, c.ltile, c.wnt, c.CS, P, c.t0, lane);
+        if constexpr (NTW > 0) k_prime<NTW>(k);
         // ---- phase A: channels 0..23 feed the matrix pipe, channels 24..44 of this utterance arrive
 #if defined(HOWL_DIAG_NOSTAGE)   // diagnostic build (tools/variants4.py; WRONG results): the phases without their staging work
         constexpr bool STAGE = false;
@@ -606,6 +649,7 @@ __device__ __forceinline__ void conv_loop(const ConvLoop& c, const ConvEpilogue&
 #endif
         HOWL_PROBE(cfg, wave, lane, pslot++);   // barrier
         // ---- phase B: channels 24..44 feed the matrix pipe, channels 0..23 of the NEXT utterance arrive
+        if constexpr (NTW > 0) k_prime<NTW>(k);      // (what the last step of phase A requested ahead predates the barrier)
         if (STAGE && more) {
             slot_load<MODE>(v[0], cfg, nbase, tid, pk0[0], bn);
             slot_load<MODE>(v[1], cfg, nbase, tid + CONV_THREADS, pk0[1], bn);
@@ -1001,7 +1045,11 @@ struct WCursor {
 template <int NB, bool EX>
 __device__ __forceinline__ void wgrad_k_run(WCursor<NB>& c, f32x4 (&acc)[NB][3], f32x4& acce, float (&az)[3], float (&bx)[NB],
                                             float& aze, float& bxe, int rounds) {
+#if defined(HOWL_DIAG_WUNROLL2)   // diagnostic build (tools/variants4.py): two rounds per loop trip
+#pragma unroll 2
+#else
 #pragma nounroll
+#endif
     for (int r = 0; r < rounds; ++r) {
 #pragma unroll
         for (int w = 0; w < PW; ++w) {

@@ -16,13 +16,13 @@ OUT = ROOT / "build" / "diag"
 # name -> list of (old, new) substitutions; each `old` must occur exactly once unless a count is given as a third element
 EDITS = {
     "base": [],
-    "nostair": [("-D", "HOWL_DIAG_NOSTAIR")],          # no falling wave priorities along a phase
     "epi_after": [("-D", "HOWL_DIAG_EPI_AFTER")],      # epilogue behind the second barrier
     "nostage": [("-D", "HOWL_DIAG_NOSTAGE")],          # timing only (WRONG results): the conv phases without their staging work
     "desync": [("-D", "HOWL_DIAG_DESYNC")],
     "w_nostage": [("-D", "HOWL_DIAG_WNOSTAGE")], "w_nolds": [("-D", "HOWL_DIAG_WGRAD_NOLDS")], "w_nomfma": [("-D", "HOWL_DIAG_WGRAD_NOMFMA")],
     "w_nostage_nolds": [("-D", "HOWL_DIAG_WNOSTAGE"), ("-D", "HOWL_DIAG_WGRAD_NOLDS")],
     "conv_empty": [("-D", "HOWL_DIAG_CONV_EMPTY")], "conv_prologue": [("-D", "HOWL_DIAG_CONV_PROLOGUE_ONLY")],
+    "k_nopipe": [("-D", "HOWL_DIAG_K_NOPIPE")], "knounroll": [("-D", "HOWL_DIAG_KNOUNROLL")], "wunroll2": [("-D", "HOWL_DIAG_WUNROLL2")], "nostair": [("-D", "HOWL_DIAG_NOSTAIR")],
     "wino": [("-D", "HOWL_DIAG_WINO")],                # timing skeleton of a Winograd F(2x2,3x3) forward (WRONG results), see res8.hip
     "c0_nostore": [("-D", "HOWL_DIAG_C0_NOSTORE")], "c0_nomfma": [("-D", "HOWL_DIAG_C0_NOMFMA")],
     "c0_noload": [("-D", "HOWL_DIAG_C0_NOLOAD")], "c0_noepi": [("-D", "HOWL_DIAG_C0_NOEPI")],
