@@ -380,12 +380,15 @@ __device__ __forceinline__ void slot_load(SlotVal& v, const StageCfg& cfg, size_
     }
 }
 
-// BatchNorm backward + skip gradient + ReLU mask of one element pair: bn_relu_bwd_kernel's expression, term for term.
-// lm = [mean | rstd | m1 | m2][48] in LDS.
+// BatchNorm backward + skip gradient + ReLU mask of one element pair.  bn_relu_bwd_kernel's expression
+//     ds = rstd * (g - m1 - xhat * m2) + k,   xhat = (|s| - mean) * rstd
+// regrouped around per-channel constants (bwd_fold_to_lds): ds = A g + (Bc |s| + Cc) + k -- two fused multiply-adds and an add
+// per element instead of seven operations (staging instructions displace matrix instructions on this part).
+// lm = [A | Bc | Cc][48] in LDS.
 __device__ __forceinline__ void bn_relu_bwd_pair(const SlotVal& v, const float* lmc, bool even, float2& ds, float2& dz) {
-    const float mean = lmc[0], rstd = lmc[CP], m1 = lmc[2 * CP], m2 = lmc[3 * CP];
-    ds.x = rstd * (v.a.x - m1 - ((fabsf(v.s.x) - mean) * rstd) * m2) + v.k.x;
-    ds.y = rstd * (v.a.y - m1 - ((fabsf(v.s.y) - mean) * rstd) * m2) + v.k.y;
+    const float A = lmc[0], Bc = lmc[CP], Cc = lmc[2 * CP];
+    ds.x = fmaf(A, v.a.x, fmaf(Bc, fabsf(v.s.x), Cc)) + v.k.x;
+    ds.y = fmaf(A, v.a.y, fmaf(Bc, fabsf(v.s.y), Cc)) + v.k.y;
     // layers with a residual add keep their ReLU mask in the sign bit of s (conv_epilogue), the others in its sign
     const float t0 = even ? -v.s.x : v.s.x, t1 = even ? -v.s.y : v.s.y;
     dz.x = t0 > 0.0f ? ds.x : 0.0f;
@@ -404,10 +407,10 @@ __device__ __forceinline__ void slot_write(const SlotVal& v, const StageCfg& cfg
         // their own convolution in the sign bit (conv_epilogue), hence the fabs
         v0 = fabsf(v0);
         v1 = fabsf(v1);
-        if (cfg.affine) {
-            const float m = lm[c], r = lm[CP + c];
-            v0 = (v0 - m) * r;
-            v1 = (v1 - m) * r;
+        if (cfg.affine) {   // xhat = (|s| - mean) * rstd as one fused multiply-add: lm = [-mean * rstd | rstd]
+            const float sh = lm[c], r = lm[CP + c];
+            v0 = fmaf(v0, r, sh);
+            v1 = fmaf(v1, r, sh);
         }
     } else if (cfg.fused) {
         float2 ds, dz;
@@ -426,7 +429,7 @@ struct ConvEpilogue {
     const float* res;
     float* out;
     const float* xs;
-    float xmean, xrstd;
+    float xshift, xrstd;   // xhat = |xs| * xrstd + xshift (xshift = -mean * rstd)
     int cout, P;
     bool cvalid;
     bool xadd;       // data gradient, no statistics wanted (xs_stats == nullptr): xs is a tensor to ADD to the output (layer 1: the
@@ -495,7 +498,7 @@ __device__ __forceinline__ void conv_epilogue(const f32x4 (&acc)[NTW], const flo
                         v1 += sv.y;
                     } else {
                         u0 += v0 + v1;
-                        u1 += v0 * ((fabsf(sv.x) - e.xmean) * e.xrstd) + v1 * ((fabsf(sv.y) - e.xmean) * e.xrstd);
+                        u1 += v0 * fmaf(fabsf(sv.x), e.xrstd, e.xshift) + v1 * fmaf(fabsf(sv.y), e.xrstd, e.xshift);
                     }
                 }
 #if defined(HOWL_DIAG_CONV_NOSTORE)
@@ -723,26 +726,25 @@ struct BwdFold {
     int nparts;
     double count;
 };
+// Leaves bn_relu_bwd_pair's constants in lm = [A | Bc | Cc][48]: A = rstd, Bc = -rstd^2 m2, Cc = rstd (mean rstd m2 - m1).
+__device__ __forceinline__ void bwd_consts_to_lds(float* lm, int ch, float mean, float rstd, float m1, float m2) {
+    lm[ch] = rstd;
+    lm[CP + ch] = -rstd * rstd * m2;
+    lm[2 * CP + ch] = rstd * (mean * rstd * m2 - m1);
+}
 __device__ __forceinline__ void bwd_fold_to_lds(float* lm, const BwdFold& f, int tid, int nthreads) {
     const int lane = tid & 63, wave = tid >> 6;
-    if (tid < CP) {
-        lm[tid] = f.stats[tid];
-        lm[CP + tid] = f.stats[CP + tid];
-        if (f.part == nullptr) {
-            lm[2 * CP + tid] = f.m12[tid];
-            lm[3 * CP + tid] = f.m12[CP + tid];
-        }
-    }
-    if (f.part != nullptr) {
+    if (f.part == nullptr) {
+        if (tid < CP) bwd_consts_to_lds(lm, tid, f.stats[tid], f.stats[CP + tid], f.m12[tid], f.m12[CP + tid]);
+    } else {
         const int c8 = lane >> 3;
         for (int ch0 = 4 * wave; ch0 < CP; ch0 += 4 * (nthreads >> 6)) {     // (12 waves: one trip)
             const int ch = ch0 + (c8 & 3);
+            const float mean = f.stats[ch], rstd = f.stats[CP + ch];
             const double acc = fold_part_column(f.part, part_stride(f.nparts), f.nparts, (c8 < 4 ? 0 : CP) + ch, lane);
             const double second = __shfl_xor(acc, 32);     // column groups 0..3: sum dx, their partners 4..7: sum dx * xhat
-            if (c8 < 4 && (lane & 7) == 0) {
-                lm[2 * CP + ch] = (float)(acc / f.count);
-                lm[3 * CP + ch] = (float)(second / f.count);
-            }
+            if (c8 < 4 && (lane & 7) == 0)
+                bwd_consts_to_lds(lm, ch, mean, rstd, (float)(acc / f.count), (float)(second / f.count));
         }
     }
 }
@@ -781,7 +783,7 @@ __device__ __forceinline__ void conv3x3_body(
     const int TF = tile_floats(H);
     float* wl = lds;                       // [3][102][64] weight fragments
     float* tile = lds + 3 * KSTEPS * 64;   // one utterance's zero-haloed input map
-    float* lm = tile + TF;                 // [mean | rstd | m1 | m2][48]
+    float* lm = tile + TF;                 // forward: [-mean * rstd | rstd][48]; data gradient: [A | Bc | Cc][48] (bn_relu_bwd_pair)
     float* red = lm + 4 * CP;              // [12][2][16]
 
     const int tid = threadIdx.x;
@@ -843,7 +845,7 @@ __device__ __forceinline__ void conv3x3_body(
                 var = var < 0.0 ? 0.0 : var;
                 const float fm = (ch < NMAP) ? (float)mean : 0.0f;
                 const float fr = (ch < NMAP) ? (float)(1.0 / sqrt(var + (double)BN_EPS)) : 0.0f;
-                lm[ch] = fm;
+                lm[ch] = -fm * fr;
                 lm[CP + ch] = fr;
                 if (bid == 0 && slice == 0) {   // one publisher: later readers (backward pass) and the running buffers (cnn.py:142)
                     fold.stats_out[ch] = fm;
@@ -869,18 +871,18 @@ __device__ __forceinline__ void conv3x3_body(
         HOWL_PROBE(cfg, wave, lane, pslot++);   // weights in LDS
     }
     if (MODE == 0 && !folding && tid < CP) {
-        lm[tid] = cfg.affine ? in_stats[tid] : 0.0f;
+        lm[tid] = cfg.affine ? -in_stats[tid] * in_stats[CP + tid] : 0.0f;     // slot_write: xhat = |s| * rstd + this
         lm[CP + tid] = cfg.affine ? in_stats[CP + tid] : 1.0f;
     }
     const int cout = 16 * nt + (lane & 15);
     const bool cvalid = cout < NMAP;
-    float xmean = 0.0f, xrstd = 1.0f;
+    float xshift = 0.0f, xrstd = 1.0f;
     if (MODE == 1 && xs != nullptr && xs_stats != nullptr && cvalid) {
-        xmean = xs_stats[cout];
         xrstd = xs_stats[CP + cout];
+        xshift = -xs_stats[cout] * xrstd;
     }
     float st0 = 0.0f, st1 = 0.0f;
-    const ConvEpilogue epi{res, out, xs, xmean, xrstd, cout, P, cvalid, MODE == 1 && xs != nullptr && xs_stats == nullptr,
+    const ConvEpilogue epi{res, out, xs, xshift, xrstd, cout, P, cvalid, MODE == 1 && xs != nullptr && xs_stats == nullptr,
                            pool, 4 * slices, t0};
     __syncthreads();  // weights, zero fill and the per-channel constants visible before the first stage
     HOWL_PROBE(cfg, wave, lane, pslot++);   // setup barrier passed
@@ -1104,9 +1106,11 @@ __device__ __forceinline__ void wgrad_k_run(WCursor<NB>& c, f32x4 (&acc)[NB][3],
 
 // Slot j of a ROW region (data rows h0 .. h1-1 of all 45 channels) moves float2 number tid + 768 j of the region:
 // packed descriptor = LDS float offset (bits 0..14) | float offset inside the utterance's (45, P) map (bits 15..28); -1 = none.
+// The slot's channel goes to byte `cbyte` of ch[j] (the z and the x slot of a pair share one register: the per-channel constants
+// are then one bit-field extract away instead of a division of the map offset by P).
 template <int NSL>
-__device__ __forceinline__ void row_region_slots(int (&pk)[NSL], int h0, int h1, int P, int CS, int pitch, int row0, int col0,
-                                                 int tid) {
+__device__ __forceinline__ void row_region_slots(int (&pk)[NSL], int (&ch)[NSL], int cbyte, int h0, int h1, int P, int CS, int pitch,
+                                                 int row0, int col0, int tid) {
     const int nper = PW * (h1 > h0 ? h1 - h0 : 0);
     const int nsafe = nper > 0 ? nper : 1;
     const float inv = 1.0f / (float)nsafe;
@@ -1119,6 +1123,7 @@ __device__ __forceinline__ void row_region_slots(int (&pk)[NSL], int h0, int h1,
         const int w = q - hh * PW;
         const int h = h0 + hh;
         pk[j] = (e < NMAP * nper) ? ((c * CS + (h + row0) * pitch + w + col0) | ((c * P + h * PW + w) << 15)) : -1;
+        ch[j] |= (e < NMAP * nper ? c : 0) << (8 * cbyte);
     }
 }
 
@@ -1126,7 +1131,6 @@ struct WStage {
     StageCfg z;           // dz_i: plain (z.a = dz) or fused (z.a = dx_i ...), see StageCfg
     const float* x;       // s_{i-1}
     bool xaffine;         // x = (|s| - mean) * rstd, else |s|
-    float invP;
 };
 
 struct WSlot {
@@ -1136,15 +1140,16 @@ struct WSlot {
 
 // z slot: the data gradient's staging arithmetic (slot_write<1>) with this kernel's addressing; addresses are "uniform base +
 // 32-bit lane offset" recomputed from the packed descriptor where they are used
-__device__ __forceinline__ void wz_load(SlotVal& v, const StageCfg& cfg, size_t ubase, int pkj, int b, float invP) {
+__device__ __forceinline__ void wz_load(SlotVal& v, const StageCfg& cfg, size_t ubase, int pkj, int chj, int b) {
     HOWL_OPAQUE_V(pkj);
+    HOWL_OPAQUE_V(chj);
     const unsigned g = pkj >= 0 ? (unsigned)(pkj >> 15) : 0u;
     const unsigned off = 4u * g;
     if (cfg.fused) {
         if (cfg.a != nullptr) {
             v.a = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(cfg.a + ubase) + off);
         } else {
-            const unsigned c4 = 4u * (unsigned)(((float)g + 0.5f) * invP);
+            const unsigned c4 = 4u * (unsigned)(chj & 0xFF);
             const float gg = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(cfg.dpool + (size_t)b * CP) + c4) * cfg.invP;
             v.a = make_float2(gg, gg);
         }
@@ -1155,12 +1160,13 @@ __device__ __forceinline__ void wz_load(SlotVal& v, const StageCfg& cfg, size_t 
         v.a = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(cfg.a + ubase) + off);
     }
 }
-__device__ __forceinline__ void wz_write(const SlotVal& v, const StageCfg& cfg, int pkj, float* tz, const float* lm, float invP) {
+__device__ __forceinline__ void wz_write(const SlotVal& v, const StageCfg& cfg, int pkj, int chj, float* tz, const float* lm) {
     HOWL_OPAQUE_V(pkj);
+    HOWL_OPAQUE_V(chj);
     if (pkj < 0) return;
     float v0 = v.a.x, v1 = v.a.y;
     if (cfg.fused) {
-        const int c = (int)(((float)(pkj >> 15) + 0.5f) * invP);
+        const int c = chj & 0xFF;
         float2 ds, dz;
         bn_relu_bwd_pair(v, lm + c, cfg.even, ds, dz);
         v0 = dz.x;
@@ -1175,15 +1181,16 @@ __device__ __forceinline__ void wx_load(float2& v, const float* x, size_t ubase,
     const unsigned off = pkj >= 0 ? 4u * (unsigned)(pkj >> 15) : 0u;
     v = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(x + ubase) + off);
 }
-__device__ __forceinline__ void wx_write(const float2& v, bool affine, int pkj, float* tx, const float* lm, float invP) {
+__device__ __forceinline__ void wx_write(const float2& v, bool affine, int pkj, int chj, float* tx, const float* lm) {
     HOWL_OPAQUE_V(pkj);
+    HOWL_OPAQUE_V(chj);
     if (pkj < 0) return;
     float v0 = fabsf(v.x), v1 = fabsf(v.y);      // |s|: see conv_epilogue
     if (affine) {
-        const int c = (int)(((float)(pkj >> 15) + 0.5f) * invP);
-        const float m = lm[4 * CP + c], r = lm[5 * CP + c];
-        v0 = (v0 - m) * r;
-        v1 = (v1 - m) * r;
+        const int c = (chj >> 8) & 0xFF;
+        const float sh = lm[4 * CP + c], r = lm[5 * CP + c];
+        v0 = fmaf(v0, r, sh);
+        v1 = fmaf(v1, r, sh);
     }
     float* d = tx + (pkj & 0x7FFF);
     d[0] = v0;
@@ -1213,8 +1220,8 @@ __device__ __forceinline__ int wgrad_boff(int q, int n, int g, int CSX) {
 }
 
 template <int NB, bool EX, int GWS>
-__device__ __forceinline__ void wgrad_loop(const WgradArgs& a, const int (&zt)[WNT], const int (&xt)[WNT], const int (&zb)[WNB],
-                                           const int (&xb)[WNB], int b, int& pslot) {
+__device__ __forceinline__ void wgrad_loop(const WgradArgs& a, const int (&zt)[WNT], const int (&xt)[WNT], const int (&ct)[WNT],
+                                           const int (&zb)[WNB], const int (&xb)[WNB], const int (&cb)[WNB], int b, int& pslot) {
     const int lane = a.lane, wave = a.wave;
     const int g = lane >> 4, n = lane & 15;
     f32x4 acc[NB][3];
@@ -1230,7 +1237,6 @@ __device__ __forceinline__ void wgrad_loop(const WgradArgs& a, const int (&zt)[W
     f32x4 acce = {0.0f, 0.0f, 0.0f, 0.0f};
     const int aoff = n * a.CSZ + g * WPZ;                                    // cout row g, column 0
     const int R1 = a.R1, R2 = a.R - a.R1;
-    const float invP = a.st.invP;
     for (; b < a.B; b += a.nblk) {
         const size_t ubase = (size_t)b * NMAP * a.P;
         const int bn = b + a.nblk;
@@ -1256,37 +1262,37 @@ __device__ __forceinline__ void wgrad_loop(const WgradArgs& a, const int (&zt)[W
         }
         static_assert(WNB == 5 && WNT == 4, "the staging schedule below is written for 5 + 4 slot pairs");
 #if defined(HOWL_DIAG_WNOSTAGE)   // diagnostic build (tools/variants4.py; WRONG results): the phases without their staging work
-#define HOWL_W_LOAD(slot_, j_, zpk_, xpk_, ub_, bb_) ((void)0)
-#define HOWL_W_WRITE(slot_, j_, zpk_, xpk_) ((void)0)
+#define HOWL_W_LOAD(slot_, j_, zpk_, xpk_, cpk_, ub_, bb_) ((void)0)
+#define HOWL_W_WRITE(slot_, j_, zpk_, xpk_, cpk_) ((void)0)
 #else
-#define HOWL_W_LOAD(slot_, j_, zpk_, xpk_, ub_, bb_)                          \
+#define HOWL_W_LOAD(slot_, j_, zpk_, xpk_, cpk_, ub_, bb_)                    \
     do {                                                                     \
-        wz_load(v[slot_].z, a.st.z, ub_, zpk_[j_], bb_, invP);               \
+        wz_load(v[slot_].z, a.st.z, ub_, zpk_[j_], cpk_[j_], bb_);           \
         wx_load(v[slot_].x, a.st.x, ub_, xpk_[j_]);                          \
     } while (0)
-#define HOWL_W_WRITE(slot_, j_, zpk_, xpk_)                                   \
+#define HOWL_W_WRITE(slot_, j_, zpk_, xpk_, cpk_)                             \
     do {                                                                     \
-        wz_write(v[slot_].z, a.st.z, zpk_[j_], a.tz, a.lm, invP);            \
-        wx_write(v[slot_].x, a.st.xaffine, xpk_[j_], a.tx, a.lm, invP);      \
+        wz_write(v[slot_].z, a.st.z, zpk_[j_], cpk_[j_], a.tz, a.lm);        \
+        wx_write(v[slot_].x, a.st.xaffine, xpk_[j_], cpk_[j_], a.tx, a.lm);  \
     } while (0)
 #endif
-        HOWL_W_LOAD(0, 0, zb, xb, ubase, b);
-        HOWL_W_LOAD(1, 1, zb, xb, ubase, b);
+        HOWL_W_LOAD(0, 0, zb, xb, cb, ubase, b);
+        HOWL_W_LOAD(1, 1, zb, xb, cb, ubase, b);
         HOWL_STAIR(3);
         if (R1 > 0) wgrad_k_run<NB, EX>(c, acc, acce, az, bx, aze, bxe, 1);
-        HOWL_W_WRITE(0, 0, zb, xb);
-        HOWL_W_WRITE(1, 1, zb, xb);
-        HOWL_W_LOAD(0, 2, zb, xb, ubase, b);
-        HOWL_W_LOAD(1, 3, zb, xb, ubase, b);
+        HOWL_W_WRITE(0, 0, zb, xb, cb);
+        HOWL_W_WRITE(1, 1, zb, xb, cb);
+        HOWL_W_LOAD(0, 2, zb, xb, cb, ubase, b);
+        HOWL_W_LOAD(1, 3, zb, xb, cb, ubase, b);
         HOWL_STAIR(2);
         if (R1 > 1) wgrad_k_run<NB, EX>(c, acc, acce, az, bx, aze, bxe, 1);
-        HOWL_W_WRITE(0, 2, zb, xb);
-        HOWL_W_WRITE(1, 3, zb, xb);
-        HOWL_W_LOAD(0, 4, zb, xb, ubase, b);
+        HOWL_W_WRITE(0, 2, zb, xb, cb);
+        HOWL_W_WRITE(1, 3, zb, xb, cb);
+        HOWL_W_LOAD(0, 4, zb, xb, cb, ubase, b);
         HOWL_STAIR(1);
         if (R1 > 2) wgrad_k_run<NB, EX>(c, acc, acce, az, bx, aze, bxe, R1 - 2);
         HOWL_STAIR(0);
-        HOWL_W_WRITE(0, 4, zb, xb);
+        HOWL_W_WRITE(0, 4, zb, xb, cb);
         HOWL_PROBE(a.st.z, wave, lane, pslot++);   // phase 1 done
         __syncthreads();      // bottom rows complete; every wave is past its reads of the top rows
         HOWL_PROBE(a.st.z, wave, lane, pslot++);   // barrier
@@ -1304,22 +1310,22 @@ __device__ __forceinline__ void wgrad_loop(const WgradArgs& a, const int (&zt)[W
             bxe = c.bpe[0];
         }
         if (more) {
-            HOWL_W_LOAD(0, 0, zt, xt, nbase, bn);
-            HOWL_W_LOAD(1, 1, zt, xt, nbase, bn);
+            HOWL_W_LOAD(0, 0, zt, xt, ct, nbase, bn);
+            HOWL_W_LOAD(1, 1, zt, xt, ct, nbase, bn);
         }
         HOWL_STAIR(3);
         wgrad_k_run<NB, EX>(c, acc, acce, az, bx, aze, bxe, 1);
         if (more) {
-            HOWL_W_WRITE(0, 0, zt, xt);
-            HOWL_W_WRITE(1, 1, zt, xt);
-            HOWL_W_LOAD(0, 2, zt, xt, nbase, bn);
-            HOWL_W_LOAD(1, 3, zt, xt, nbase, bn);
+            HOWL_W_WRITE(0, 0, zt, xt, ct);
+            HOWL_W_WRITE(1, 1, zt, xt, ct);
+            HOWL_W_LOAD(0, 2, zt, xt, ct, nbase, bn);
+            HOWL_W_LOAD(1, 3, zt, xt, ct, nbase, bn);
         }
         HOWL_STAIR(2);
         if (R2 > 1) wgrad_k_run<NB, EX>(c, acc, acce, az, bx, aze, bxe, 1);
         if (more) {
-            HOWL_W_WRITE(0, 2, zt, xt);
-            HOWL_W_WRITE(1, 3, zt, xt);
+            HOWL_W_WRITE(0, 2, zt, xt, ct);
+            HOWL_W_WRITE(1, 3, zt, xt, ct);
         }
         HOWL_STAIR(1);
         if (R2 > 2) wgrad_k_run<NB, EX>(c, acc, acce, az, bx, aze, bxe, R2 - 2);
@@ -1355,14 +1361,13 @@ __device__ __forceinline__ void wgrad_body(
     const int CSZ = chan_stride_z(H), CSX = chan_stride_x(H);
     float* tz = lds;
     float* tx = lds + tile_floats_z(H);
-    float* lm = tx + tile_floats_x(H);      // [mean_i | rstd_i | m1 | m2 | mean_{i-1} | rstd_{i-1}][48]
+    float* lm = tx + tile_floats_x(H);      // [A | Bc | Cc (bn_relu_bwd_pair) | - | -mean_{i-1} rstd_{i-1} | rstd_{i-1}][48]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int R = wgrad_rounds(H), R1 = wgrad_r1(H);
     st.xaffine = in_stats != nullptr;
-    st.invP = 1.0f / (float)P;
     st.z.ds = nullptr;                      // ds_i is written by the data gradient's staging
     int pslot = 0;
     HOWL_PROBE(st.z, wave, lane, pslot++);   // entry
@@ -1372,18 +1377,18 @@ __device__ __forceinline__ void wgrad_body(
     const int zsplit = 4 * R1 < H ? 4 * R1 : H;
     const int xtop = R1 > 0 ? (4 * R1 + 1 < H ? 4 * R1 + 1 : H) : 0;
     const int xbot = 4 * R1 - 1 > 0 ? 4 * R1 - 1 : 0;
-    int zt[WNT], xt[WNT], zb[WNB], xb[WNB];
-    row_region_slots<WNT>(zt, 0, zsplit, P, CSZ, WPZ, 0, 0, tid);
-    row_region_slots<WNT>(xt, 0, xtop, P, CSX, WPW, 1, 1, tid);
-    row_region_slots<WNB>(zb, zsplit, H, P, CSZ, WPZ, 0, 0, tid);
-    row_region_slots<WNB>(xb, xbot, H, P, CSX, WPW, 3, 1, tid);
+    int zt[WNT], xt[WNT], zb[WNB], xb[WNB], ct[WNT] = {}, cb[WNB] = {};
+    row_region_slots<WNT>(zt, ct, 0, 0, zsplit, P, CSZ, WPZ, 0, 0, tid);
+    row_region_slots<WNT>(xt, ct, 1, 0, xtop, P, CSX, WPW, 1, 1, tid);
+    row_region_slots<WNB>(zb, cb, 0, zsplit, H, P, CSZ, WPZ, 0, 0, tid);
+    row_region_slots<WNB>(xb, cb, 1, xbot, H, P, CSX, WPW, 3, 1, tid);
     // the first utterance's top rows are requested before the LDS setup so that HBM latency overlaps it
     const int b = bid;
     WSlot first[WNT];
     if (b < B) {
 #pragma unroll
         for (int j = 0; j < WNT; ++j) {
-            wz_load(first[j].z, st.z, (size_t)b * NMAP * P, zt[j], b, st.invP);
+            wz_load(first[j].z, st.z, (size_t)b * NMAP * P, zt[j], ct[j], b);
             wx_load(first[j].x, st.x, (size_t)b * NMAP * P, xt[j]);
         }
     }
@@ -1392,15 +1397,15 @@ __device__ __forceinline__ void wgrad_body(
         bwd_fold_to_lds(lm, bfold, tid, CONV_THREADS);
     }
     if (tid < CP) {
-        lm[4 * CP + tid] = st.xaffine ? in_stats[tid] : 0.0f;
+        lm[4 * CP + tid] = st.xaffine ? -in_stats[tid] * in_stats[CP + tid] : 0.0f;    // wx_write: xhat = |s| * rstd + this
         lm[5 * CP + tid] = st.xaffine ? in_stats[CP + tid] : 1.0f;
     }
     __syncthreads();
     if (b < B) {
 #pragma unroll
         for (int j = 0; j < WNT; ++j) {
-            wz_write(first[j].z, st.z, zt[j], tz, lm, st.invP);
-            wx_write(first[j].x, st.xaffine, xt[j], tx, lm, st.invP);
+            wz_write(first[j].z, st.z, zt[j], ct[j], tz, lm);
+            wx_write(first[j].x, st.xaffine, xt[j], ct[j], tx, lm);
         }
     }
     __syncthreads();
@@ -1426,15 +1431,15 @@ __device__ __forceinline__ void wgrad_body(
         }
         const WgradArgs a{st, part, tz, tx, lm, B, P, CSZ, CSX, R, R1, tid, lane, wave, bid, nblk, gw, qe, mte};
         if (ex)
-            wgrad_loop<2, true, GWS>(a, zt, xt, zb, xb, b, pslot);
+            wgrad_loop<2, true, GWS>(a, zt, xt, ct, zb, xb, cb, b, pslot);
         else
-            wgrad_loop<2, false, GWS>(a, zt, xt, zb, xb, b, pslot);
+            wgrad_loop<2, false, GWS>(a, zt, xt, ct, zb, xb, cb, b, pslot);
     } else {                           // small batches: tiles gw, gw + 24 (< 26) over the 24 waves of two workgroups
         const WgradArgs a{st, part, tz, tx, lm, B, P, CSZ, CSX, R, R1, tid, lane, wave, bid, nblk, gw, 0, 0};
         if (gw + 24 < 26)
-            wgrad_loop<2, false, GWS>(a, zt, xt, zb, xb, b, pslot);
+            wgrad_loop<2, false, GWS>(a, zt, xt, ct, zb, xb, cb, b, pslot);
         else
-            wgrad_loop<1, false, GWS>(a, zt, xt, zb, xb, b, pslot);
+            wgrad_loop<1, false, GWS>(a, zt, xt, ct, zb, xb, cb, b, pslot);
     }
     HOWL_PROBE(st.z, wave, lane, pslot++);   // partials written
 }
@@ -1468,7 +1473,7 @@ __global__ __launch_bounds__(CONV_THREADS) void bwd_pair_kernel(
     if (r < SD)
         conv3x3_body<1, SD>(zc, nullptr, wp, nullptr, dx, xs, xs_stats, spart, nullptr, B, H, j, nblk, r, BnFold{}, bfold, wf);
     else
-        wgrad_body<SW>(WStage{zc, s_prev, false, 0.0f}, in_stats, bfold, wpart, B, H, j, nblk, r - SD);
+        wgrad_body<SW>(WStage{zc, s_prev, false}, in_stats, bfold, wpart, B, H, j, nblk, r - SD);
 }
 
 // Deterministic sum over the per-workgroup partial rows: part[g][col], g < nparts.  A block owns 64 columns
@@ -2349,7 +2354,7 @@ void launch_wgrad_inst(int nblk, size_t lds, hipStream_t stream, const StageCfg&
                        const float* in_stats, float* wpart, int B, int H) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_mfma_kernel<SW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(wgrad_mfma_kernel<SW>, dim3(launch_blocks(nblk, SW)), dim3(CONV_THREADS), lds, stream,
-                       WStage{with_probe(zc), s_prev, false, 0.0f}, in_stats, bfold, wpart, B, H, nblk);
+                       WStage{with_probe(zc), s_prev, false}, in_stats, bfold, wpart, B, H, nblk);
 }
 template <int SD, int SW>
 void launch_pair_inst(int nblk, size_t lds, hipStream_t stream, const StageCfg& zc, const BwdFold& bfold, const float* wp, float* dx,

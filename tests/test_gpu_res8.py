@@ -45,19 +45,24 @@ def test_golden_eval_and_train(golden, C):
                 assert maxerr(bn.running_var, g[f"bn{i}.running_var.1"]) < 1e-5
         assert abs(loss.item() - float(g[f"loss{step}"])) < 1e-4
         opt.step()
-    # AdamW divides by sqrt(v): a weight whose gradient is rounding noise still moves by ~lr per step with the sign of that
-    # noise.  The oracle (pinned to these goldens by test_oracle_golden.py) replays the three steps to tell which weights
-    # had a gradient above rounding noise at EVERY step: those must match the reference's weights to 1e-4, the others may
-    # differ by the 3 * lr they can move.
+    # AdamW divides by sqrt(v): a weight moves by ~lr per step times the RELATIVE error of its gradient, and fp32 gradients of two
+    # correct implementations agree to ~4e-6 of the tensor's largest entry (measured: 1e-6 .. 6e-6 against the reference's own
+    # fp32 gradients), so a weight whose gradient is small against that moves differently -- up to the full 3 * lr when its gradient
+    # is rounding noise.  The oracle (pinned to these goldens by test_oracle_golden.py) replays the three steps to give every
+    # weight its relative gradient noise, and with it a tolerance of its own: 1e-4 + 3 * lr * noise, plus the distance at which the
+    # oracle's own (float64-accumulating) trajectory ends from the reference's fp32 one -- a handful of conv weights per layer
+    # where the REFERENCE's rounding decided the direction (measured at C = 30: nine weights of conv4, up to 2.7e-4, the HIP
+    # path within 1e-6 of the oracle there).
     sd_o, names = om.res8_init(C), om.res8_param_names()
     opt_o = om.AdamWState([sd_o[n] for n in names], 0.01, 1e-5)
-    solid = {n: torch.ones_like(sd_o[n], dtype=torch.bool) for n in names}
+    noise = {n: torch.zeros_like(sd_o[n], dtype=torch.float64) for n in names}
     for step in range(3):
         _, _, og = om.train_step(lambda s_, xx: om.res8_forward(s_, xx, True), sd_o, names, opt_o, x, t(g["labels"]))
         for n in names:
-            solid[n] &= og[n].abs() > 1e-5 * max(1.0, og[n].abs().max().item())
+            a = og[n].abs().double()
+            noise[n] = torch.maximum(noise[n], (4e-6 * a.max() / a.clamp_min(1e-30)).clamp(max=1.0))
     sd = model.state_dict()
-    checked = 0
+    tight = 0
     for k, v in sd.items():
         ref = t(g["sd3." + k]).double()
         d = (v.detach().cpu().double() - ref).abs()
@@ -65,11 +70,11 @@ def test_golden_eval_and_train(golden, C):
         if "running_" in k:
             # BatchNorm statistics sit downstream of the few O(lr) weight differences: relative agreement
             assert d.max().item() < 1e-3 * max(1.0, float(ref.abs().max())), k
-        elif k in solid:
-            assert d[solid[k]].max().item() < tol, (k, d[solid[k]].max().item())
-            assert d.max().item() < 3 * 0.01 + tol, k
-            checked += int(solid[k].sum())
-    assert checked > 0.9 * sum(v.numel() for v in solid.values())      # the mask excuses a small minority only
+        elif k in noise:
+            excess = d - (tol + 3 * 0.01 * noise[k] + (sd_o[k].double() - ref).abs())
+            assert excess.max().item() < 0, (k, excess.max().item())
+            tight += int((noise[k] < 1e-2).sum())
+    assert tight > 0.95 * sum(v.numel() for v in noise.values())      # tolerances above 4e-4 for a small minority only
     assert int(sd["bn3.num_batches_tracked"]) == 3
     model.eval()
     with torch.no_grad():
@@ -79,8 +84,10 @@ def test_golden_eval_and_train(golden, C):
     assert maxerr(after, om.res8_forward(own, x, False)) < LOGIT_TOL
     # against the reference's own trajectory the few noise-gradient weights that moved the other way (see above) show up in
     # logits of magnitude ~40: relative 1e-4 of the largest logit (measured 6e-5 at C = 12), argmax exact
+    # (plus what the oracle's own trajectory on this host's CPU ends away from it, for the same reason)
     ref_after = t(g["eval_logits_after3"])
-    assert maxerr(after, ref_after) < max(LOGIT_TOL, 1e-4 * ref_after.abs().max().item())
+    slack = maxerr(om.res8_forward(sd_o, x, False), ref_after)
+    assert maxerr(after, ref_after) < max(LOGIT_TOL, 1e-4 * ref_after.abs().max().item()) + slack
     assert torch.equal(after.argmax(1).cpu(), ref_after.argmax(1))
 
 
