@@ -195,13 +195,12 @@ __device__ __forceinline__ float fold_bit2(float lo, float hi, bool bit) {   // 
 
 // Table reads inside the persistent loop are loop-invariant; left alone, the compiler hoists all of them (window, twiddles,
 // fragments: 150+ registers) in front of the loop and spills.  An index laundered once per trip keeps them where they are.
+// (HOWL_OPAQUE_V: howl_common.hip.h)
 #if defined(HIPEMU)
-#define HOWL_OPAQUE_V(x) asm volatile("" : "+r"(x))
 #define HOWL_OPAQUE_S(x) asm volatile("" : "+r"(x))
 #define HOWL_OPAQUE_F(x) asm("" : "+x"(x))
 #else
 #define HOWL_OPAQUE_F(x) asm("" : "+v"(x))
-#define HOWL_OPAQUE_V(x) asm volatile("" : "+v"(x))
 #define HOWL_OPAQUE_S(x) asm volatile("" : "+s"(x))
 #endif
 

@@ -4,6 +4,7 @@
 #pragma once
 #include <algorithm>
 #include <cstdint>
+#include <cstdlib>
 
 #include "howl_common.hip.h"
 
@@ -265,6 +266,167 @@ __global__ __launch_bounds__(256) void gemm_vec_kernel(const float* __restrict__
         }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Weights-stationary GEMM for tall row sets (round 4):  out[r][n] = act(sum_k in[r][k] W(k,n) + bias[n]),  rows >> K, N and
+// K * N <= 32 K floats -- the LSTM input projection (40 -> 512), the head's first layer (128 -> 256) and its data gradient
+// (256 -> 128) over 19456 rows.  The 64 x 64 tiles above re-read W for every row block and run their staging and multiply phases
+// one after the other (18.7 / 20.7 / 21.4 us for 0.8 / 1.27 / 1.27 GFLOP).  Here one workgroup per CU keeps its share of W in
+// registers for the whole launch (wave w: columns 16 NT w ..; 48-64 VGPRs per lane) and streams 16-row tiles of `in` through a
+// double-buffered LDS tile, one barrier per tile: the next tile's 16-byte loads are issued before the MFMAs of the current one.
+//   * operands swapped (A = W fragment, B = input rows), so a lane ends up with FOUR CONSECUTIVE columns of one output row:
+//     one 16-byte store per 16 x 16 tile and lane instead of four scattered 4-byte ones;
+//   * the reduction index is permuted inside a group of 16 (lane (m, q) reads in[m][16 j + 4 q .. + 3] as one ds_read_b128 and
+//     feeds component s to MFMA s of the group; the W registers are loaded in the same order), LDS row stride 16 KG + 4 floats:
+//     conflict-free 16-byte reads;
+//   * two accumulator chains per output tile (even / odd groups) so that a wave with one tile (N = 128) does not issue
+//     back-to-back dependent MFMAs.
+// KG = groups of 16 along K (K <= 16 KG, K % 4 == 0; columns K .. 16 KG - 1 are zero in LDS and in the registers).
+// W_UNIT_K: W(k,n) = w[n * w_stride + k] (a torch Linear weight), else w[k * w_stride + n].
+// ---------------------------------------------------------------------------------------------------------
+constexpr int RG_THREADS = 512;
+// below this many rows the 64 x 64 tiles keep more CUs busy (HOWL_ROWGEMM_MIN_ROWS overrides: the emulator tests run small shapes)
+inline int rowgemm_min_rows() {
+    const char* e = getenv("HOWL_ROWGEMM_MIN_ROWS");
+    return e != nullptr ? atoi(e) : 2048;
+}
+template <int KG, int NT, bool W_UNIT_K>
+__global__ __launch_bounds__(RG_THREADS) void rowgemm_kernel(const float* __restrict__ in, RowMap im, const float* __restrict__ w,
+                                                             long w_stride, int rows, int K, const float* __restrict__ bias, int relu,
+                                                             float* __restrict__ out, long out_stride) {
+    constexpr int LDW = 16 * KG + 4;
+    constexpr int NL = (64 * KG + RG_THREADS - 1) / RG_THREADS;      // 16-byte pieces of a tile per thread
+    __shared__ __attribute__((aligned(16))) float tile[2][16 * LDW + 4];      // + a dump slot for pieces without a place (see stage)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int mi = lane & 15, kq = lane >> 4;
+    const int nbase = wave * 16 * NT;
+    // this wave's share of W, in the order the MFMAs take it
+    float wv[NT][KG][4];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < KG; ++j) {
+            const int n = nbase + 16 * i + mi, k0 = 16 * j + 4 * kq;
+            // unconditional loads from clamped coordinates, zeroed afterwards (loads under a lane predicate are serialised)
+            if (W_UNIT_K) {
+                const float4 t = *reinterpret_cast<const float4*>(w + (long)n * w_stride + min(k0, K - 4));
+                wv[i][j][0] = k0 < K ? t.x : 0.0f;
+                wv[i][j][1] = k0 < K ? t.y : 0.0f;
+                wv[i][j][2] = k0 < K ? t.z : 0.0f;
+                wv[i][j][3] = k0 < K ? t.w : 0.0f;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float t = w[(long)min(k0 + e, K - 1) * w_stride + n];
+                    wv[i][j][e] = k0 + e < K ? t : 0.0f;
+                }
+            }
+        }
+    float4 bv[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+        bv[i] = bias != nullptr ? *reinterpret_cast<const float4*>(bias + nbase + 16 * i + 4 * kq) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = tid; i < 2 * (16 * LDW + 4); i += RG_THREADS) (&tile[0][0])[i] = 0.0f;
+    // the pieces this thread moves for every tile: piece e = tid + 512 l -> (row e / K4, columns 4 (e % K4) ..)
+    const int K4 = K >> 2;
+    const int ntiles = (rows + 15) >> 4;
+    const float inv_inner = 1.0f / (float)im.inner;
+    int prow[NL], pcol[NL], pdst[NL];
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+        const int e = tid + l * RG_THREADS;
+        prow[l] = e < 16 * K4 ? e / K4 : -1;
+        pcol[l] = e < 16 * K4 ? 4 * (e - (e / K4) * K4) : 0;
+        pdst[l] = e < 16 * K4 ? prow[l] * LDW + pcol[l] : 16 * LDW;
+    }
+    struct Pieces {
+        float4 v[NL];
+    };
+    auto fetch = [&](int t) -> Pieces {
+        Pieces pre;
+#pragma unroll
+        for (int l = 0; l < NL; ++l) {
+            const int r = min(16 * min(t, ntiles - 1) + max(prow[l], 0), rows - 1);      // unconditional loads from clamped rows
+            // two-level row map without a branch or an integer division: floor(r / inner) through the float reciprocal, exact
+            // for r < 2^22 (the quotient's fraction is a multiple of 1 / inner; a plain stride has inner = 2^30: quotient 0)
+            const int q = (int)(((float)r + 0.5f) * inv_inner);
+            pre.v[l] = *reinterpret_cast<const float4*>(in + ((long)q * im.s_outer + (long)(r - q * im.inner) * im.s_inner) + pcol[l]);
+        }
+        return pre;
+    };
+    // pieces without a place in the tile (narrow K: fewer pieces than threads) go to a dump row behind it, so that no LDS store
+    // sits under a lane predicate either
+    auto stage = [&](const Pieces& pre, int buf) {
+#pragma unroll
+        for (int l = 0; l < NL; ++l) *reinterpret_cast<float4*>(&tile[buf][pdst[l]]) = pre.v[l];
+    };
+    auto multiply = [&](int t, int cur) {
+        f32x4 acc[NT][2];
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            acc[i][0] = {0.0f, 0.0f, 0.0f, 0.0f};
+            acc[i][1] = {0.0f, 0.0f, 0.0f, 0.0f};
+        }
+        const float* arow = &tile[cur][mi * LDW + 4 * kq];
+#pragma unroll
+        for (int j = 0; j < KG; ++j) {
+            const float4 a = *reinterpret_cast<const float4*>(arow + 16 * j);
+            const float av[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < NT; ++i)
+                    acc[i][j & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[i][j][e], av[e], acc[i][j & 1], 0, 0, 0);
+        }
+        struct Out {
+            float4 v[NT];
+        } o;
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            float4 v = make_float4(acc[i][0][0] + acc[i][1][0] + bv[i].x, acc[i][0][1] + acc[i][1][1] + bv[i].y,
+                                   acc[i][0][2] + acc[i][1][2] + bv[i].z, acc[i][0][3] + acc[i][1][3] + bv[i].w);
+            if (relu) v = make_float4(fmaxf(v.x, 0.0f), fmaxf(v.y, 0.0f), fmaxf(v.z, 0.0f), fmaxf(v.w, 0.0f));
+            o.v[i] = v;
+        }
+        return o;
+    };
+    // D[n_local = 4 kq + r][m = mi]: four consecutive columns of output row 16 t + mi.  Rows past the end were loaded from the
+    // last row (fetch clamps), so their results ARE the last row's, bit for bit: they are stored there again, and no store sits
+    // under a lane predicate -- which would hide the number of outstanding memory operations from the compiler and turn the
+    // wait in front of the staging stores into vmcnt(0).
+    auto store = [&](const auto& o, int t) {
+        const int row = min(16 * t + mi, rows - 1);
+#pragma unroll
+        for (int i = 0; i < NT; ++i) *reinterpret_cast<float4*>(out + (long)row * out_stride + nbase + 16 * i + 4 * kq) = o.v[i];
+    };
+    // Two tiles are on their way while one is multiplied: tile t + 2 G is requested at the top of trip t; tile t + G (requested a
+    // trip earlier) goes to the other LDS buffer after the MFMAs and BEFORE this trip's result stores, so the wait for its data
+    // covers loads only (the counter is in order).  The loop is unrolled by two: the two register sets swap roles without copies.
+    const int G = gridDim.x;
+    int t = blockIdx.x;
+    __syncthreads();          // zero fill before the first pieces land
+    Pieces p0 = fetch(t);
+    Pieces p1 = fetch(t + G);
+    stage(p0, 0);
+    __syncthreads();
+    for (; t < ntiles; t += 2 * G) {
+        p0 = fetch(t + 2 * G);
+        __builtin_amdgcn_sched_barrier(0);      // keep the requests in front of the MFMAs
+        const auto o0 = multiply(t, 0);
+        stage(p1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        store(o0, t);
+        __syncthreads();      // next tile complete; every wave is past its reads of the current one
+        if (t + G >= ntiles) break;
+        p1 = fetch(t + 3 * G);
+        __builtin_amdgcn_sched_barrier(0);
+        const auto o1 = multiply(t + G, 1);
+        stage(p0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        store(o1, t + G);
+        __syncthreads();
+    }
+}
+
 // deterministic sum of `nparts` slabs of n floats (split-K partials): a block owns 64 outputs, its 4 waves take the
 // slabs g = wave, wave+4, ... (four loads in flight each) and combine through LDS in a fixed order
 __global__ __launch_bounds__(256) void sum_slabs_kernel(const float* __restrict__ part, int nparts, long n,
@@ -408,6 +570,34 @@ int gemm(hipStream_t s, bool a_major_k, const float* a, RowMap am, long a_ks, Ro
     const int kps = ((K + splits - 1) / splits + GK - 1) / GK * GK;
     dim3 grid((N + GT - 1) / GT, (M + GT - 1) / GT, (K + kps - 1) / kps);
     HowlProfScope prof("gemm", s, 2.0 * (double)M * N * K);
+    // tall row sets against a small weight matrix: the weights-stationary kernel
+    {
+        const bool w_unit_k = is_lin(bk) && bk.s_inner == 1;      // W(k,n) = b[n * b_ns + k]
+        const bool w_unit_n = b_ns == 1 && is_lin(bk);            // W(k,n) = b[k * bk.s_inner + n]
+        const long w_stride = w_unit_k ? b_ns : bk.s_inner;
+        auto al16 = [](const void* p_) { return (reinterpret_cast<uintptr_t>(p_) & 15) == 0; };
+        const bool fits = a_major_k && a_ks == 1 && splits == 1 && M < (1 << 22) && (w_unit_k || w_unit_n) && M >= rowgemm_min_rows() && (K & 3) == 0 &&
+                          (am.s_outer & 3) == 0 && (am.s_inner & 3) == 0 && al16(a) && al16(b) && al16(c) && (c_ms & 3) == 0 &&
+                          (!w_unit_k || (w_stride & 3) == 0) && (bias == nullptr || al16(bias)) && getenv("HOWL_GEMM_NO_ROWGEMM") == nullptr;
+        if (fits) {
+            const int ntiles = (M + 15) / 16;
+            const int blocks = std::min(ntiles, howl_num_cus());
+#define HOWL_ROWGEMM(KG_, NT_)                                                                                                \
+    do {                                                                                                                      \
+        if (w_unit_k)                                                                                                         \
+            hipLaunchKernelGGL((rowgemm_kernel<KG_, NT_, true>), dim3(blocks), dim3(RG_THREADS), 0, s, a, am, b, w_stride, M, K, \
+                               bias, relu, c, c_ms);                                                                          \
+        else                                                                                                                  \
+            hipLaunchKernelGGL((rowgemm_kernel<KG_, NT_, false>), dim3(blocks), dim3(RG_THREADS), 0, s, a, am, b, w_stride, M, K, \
+                               bias, relu, c, c_ms);                                                                          \
+        return 1;                                                                                                             \
+    } while (0)
+            if (N == 512 && K <= 48) HOWL_ROWGEMM(3, 4);
+            if (N == 256 && K > 64 && K <= 128) HOWL_ROWGEMM(8, 2);
+            if (N == 128 && K > 128 && K <= 256) HOWL_ROWGEMM(16, 1);
+#undef HOWL_ROWGEMM
+        }
+    }
     // operands whose unit-stride runs are 16-byte aligned multiples of 4 floats take the vector kernel
     {
         auto map_ok = [](const RowMap& r) { return (r.s_outer & 3) == 0 && (r.s_inner & 3) == 0; };
@@ -514,18 +704,18 @@ __global__ __launch_bounds__(256) void thin_wgrad_kernel(const float* __restrict
 // the 64 x 64 kernel moved every operand element through the cache hierarchy 2-8 times (160 MB for 50 MB of operands in the
 // W_hh gradient) and its 1216 blocks did not overlap their staging with their MFMAs; here each element is read once or twice.
 constexpr int WG_M = 128, WG_K = 16, WG_THREADS = 1024;
+constexpr int WG_LDA = WG_M + 4;                    // pitch = 4 mod 32 banks: the four k rows of a fragment read do not collide
+// (bx, by, bz) = the block's (input-column tile, output-column tile, row split); As / Bs: [2][WG_K * WG_LDA] floats of LDS each
 template <int TN, bool KMAP_LIN>
-__global__ __launch_bounds__(WG_THREADS) void wgrad_big_kernel(const float* __restrict__ dout, RowMap dm,
-                                                              const float* __restrict__ in, RowMap im, int M, int N, int K,
-                                                              int k_per_split, float* __restrict__ part) {
-    constexpr int LDA = WG_M + 4, LDB = TN + 4;     // pitch = 4 mod 32 banks: the four k rows of a fragment read do not collide
+__device__ __forceinline__ void wgrad_big_body(const float* __restrict__ dout, RowMap dm, const float* __restrict__ in, RowMap im,
+                                               int M, int N, int K, int k_per_split, float* __restrict__ part, int bx, int by,
+                                               int bz, float (*As)[WG_K * WG_LDA], float (*Bs)[WG_K * WG_LDA]) {
+    constexpr int LDA = WG_LDA, LDB = TN + 4;
     constexpr int NJ = TN / 64;                     // 16-column tiles per wave (sixteen waves: 4 x 4, 32 x TN/4 each)
-    __shared__ __attribute__((aligned(16))) float As[2][WG_K * LDA];
-    __shared__ __attribute__((aligned(16))) float Bs[2][WG_K * LDB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 2, wc = wave & 3;
-    const int m0 = blockIdx.y * WG_M, n0 = blockIdx.x * TN;
-    const int kbeg = blockIdx.z * k_per_split, kend = min(K, kbeg + k_per_split);
+    const int m0 = by * WG_M, n0 = bx * TN;
+    const int kbeg = bz * k_per_split, kend = min(K, kbeg + k_per_split);
     // One 16-byte piece of ONE operand per thread and K tile (wave-uniform role): threads 0..511 carry dout's tile
     // (k = t / 32, column 4 (t % 32)), threads 512.. the input's (TN = 128: the same map; TN = 64: k = t / 16, 256 threads).
     const bool is_a = tid < 512;
@@ -605,7 +795,7 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_big_kernel(const float* __re
         __syncthreads();
         v0 = fetch();
     }
-    float* pz = part + (long)blockIdx.z * M * N;
+    float* pz = part + (long)bz * M * N;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -619,10 +809,78 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_big_kernel(const float* __re
         }
 }
 
+template <int TN, bool KMAP_LIN>
+__global__ __launch_bounds__(WG_THREADS) void wgrad_big_kernel(const float* __restrict__ dout, RowMap dm,
+                                                              const float* __restrict__ in, RowMap im, int M, int N, int K,
+                                                              int k_per_split, float* __restrict__ part) {
+    __shared__ __attribute__((aligned(16))) float As[2][WG_K * WG_LDA];
+    __shared__ __attribute__((aligned(16))) float Bs[2][WG_K * WG_LDA];
+    wgrad_big_body<TN, KMAP_LIN>(dout, dm, in, im, M, N, K, k_per_split, part, blockIdx.x, blockIdx.y, blockIdx.z, As, Bs);
+}
+
+// Several weight gradients in ONE launch (round 4: the seq-lstm step's W_hh, W_ih and head layer-1 gradients -- three launches of
+// one block per CU each, whose ramps, prologues and tails (4-5 us apiece) did not overlap): blocks are numbered job by job, the
+// job with the longest blocks first, so that a CU picks up a block of the next job the moment its current one retires.
+struct WgradJob {
+    const float* dout;
+    RowMap dm;
+    const float* in;
+    RowMap im;
+    int M, N, K, kps;
+    float* part;
+    int gx, gy, gz;
+    int tn, klin;
+};
+constexpr int MAX_WGRAD_JOBS = 4;
+struct WgradJobs {
+    WgradJob j[MAX_WGRAD_JOBS];
+    int count = 0;
+    double flops = 0.0;
+};
+__global__ __launch_bounds__(WG_THREADS) void wgrad_big_multi_kernel(WgradJobs jobs) {
+    __shared__ __attribute__((aligned(16))) float As[2][WG_K * WG_LDA];
+    __shared__ __attribute__((aligned(16))) float Bs[2][WG_K * WG_LDA];
+    int b = blockIdx.x, q = 0;
+    while (q + 1 < jobs.count && b >= jobs.j[q].gx * jobs.j[q].gy * jobs.j[q].gz) {
+        b -= jobs.j[q].gx * jobs.j[q].gy * jobs.j[q].gz;
+        ++q;
+    }
+    const WgradJob& jb = jobs.j[q];
+    const int bx = b % jb.gx, by = (b / jb.gx) % jb.gy, bz = b / (jb.gx * jb.gy);
+#define HOWL_WG_BODY(TN_, KL_) \
+    wgrad_big_body<TN_, KL_>(jb.dout, jb.dm, jb.in, jb.im, jb.M, jb.N, jb.K, jb.kps, jb.part, bx, by, bz, As, Bs)
+    if (jb.tn == 128) {
+        if (jb.klin) HOWL_WG_BODY(128, true);
+        else HOWL_WG_BODY(128, false);
+    } else {
+        if (jb.klin) HOWL_WG_BODY(64, true);
+        else HOWL_WG_BODY(64, false);
+    }
+#undef HOWL_WG_BODY
+}
+// launches what wgrad_gemm(..., jobs) collected
+inline void wgrad_jobs_flush(hipStream_t s, WgradJobs& jobs) {
+    if (jobs.count == 0) return;
+    std::stable_sort(jobs.j, jobs.j + jobs.count, [](const WgradJob& a, const WgradJob& b) { return (long)a.kps * a.tn > (long)b.kps * b.tn; });
+    int blocks = 0;
+    for (int q = 0; q < jobs.count; ++q) blocks += jobs.j[q].gx * jobs.j[q].gy * jobs.j[q].gz;
+    HowlProfScope prof("gemm", s, jobs.flops);
+    hipLaunchKernelGGL(wgrad_big_multi_kernel, dim3(blocks), dim3(WG_THREADS), 0, s, jobs);
+    jobs.count = 0;
+    jobs.flops = 0.0;
+}
+
+// fewer rows than this: the 64 x 64 split-K path (HOWL_WGRAD_BIG_MIN_ROWS overrides: the emulator tests run small shapes)
+inline int wgrad_big_min_rows() {
+    const char* e = getenv("HOWL_WGRAD_BIG_MIN_ROWS");
+    return e != nullptr ? atoi(e) : 2048;
+}
+
 // dW (N_out, K_in) = dOut^T (N_out x rows) . In (rows x K_in), rows given by row maps; split-K + deterministic sum
 // (scratch: splits x N_out x K_in floats, splits = clamp(rows / 512, 1, max_splits))
 void wgrad_gemm(hipStream_t s, const float* dout, RowMap dm, int n_out, const float* in, RowMap im, int k_in, int rows,
-                float* scratch, float* dw, int max_splits = 64, int rows_per_split = 512, SlabSums* defer = nullptr) {
+                float* scratch, float* dw, int max_splits = 64, int rows_per_split = 512, SlabSums* defer = nullptr,
+                WgradJobs* jobs = nullptr) {
     int splits = rows / rows_per_split;
     splits = splits < 1 ? 1 : (splits > max_splits ? max_splits : splits);
     if (n_out <= 8 && ((n_out & 3) != 0 || (k_in & 3) != 0)) {   // thin output that the vector GEMM cannot take
@@ -651,10 +909,9 @@ void wgrad_gemm(hipStream_t s, const float* dout, RowMap dm, int n_out, const fl
     int z;
     auto map4 = [](const RowMap& r) { return (r.s_outer & 3) == 0 && (r.s_inner & 3) == 0; };
     auto al16 = [](const float* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
-    if (n_out >= 128 && rows >= 2048 && (n_out & 3) == 0 && (k_in & 3) == 0 && k_in >= 16 && map4(dm) && map4(im) && al16(dout) &&
+    if (n_out >= 128 && rows >= wgrad_big_min_rows() && (n_out & 3) == 0 && (k_in & 3) == 0 && k_in >= 16 && map4(dm) && map4(im) && al16(dout) &&
         al16(in) && max_splits >= 16) {
         // wide layer, many rows: 128-row tiles, split count = one block per CU (two when the slabs stay small)
-        HowlProfScope prof("gemm", s, 2.0 * (double)n_out * k_in * rows);
         const int tn = k_in > 64 ? 128 : 64;
         const int tiles = ((n_out + WG_M - 1) / WG_M) * ((k_in + tn - 1) / tn);
         int sp = std::max(1, howl_num_cus() / tiles);
@@ -664,6 +921,13 @@ void wgrad_gemm(hipStream_t s, const float* dout, RowMap dm, int n_out, const fl
         z = (rows + kps - 1) / kps;
         const dim3 grid((k_in + tn - 1) / tn, (n_out + WG_M - 1) / WG_M, z);
         const bool klin = is_lin(dm) && is_lin(im);
+        if (jobs != nullptr && defer != nullptr && jobs->count < MAX_WGRAD_JOBS) {     // launched by wgrad_jobs_flush with its companions
+            jobs->j[jobs->count++] = WgradJob{dout, dm, in, im, n_out, k_in, rows, kps, scratch, (int)grid.x, (int)grid.y, (int)grid.z, tn, klin ? 1 : 0};
+            jobs->flops += 2.0 * (double)n_out * k_in * rows;
+            defer->add(scratch, z, (long)n_out * k_in, dw);
+            return;
+        }
+        HowlProfScope prof("gemm", s, 2.0 * (double)n_out * k_in * rows);
         if (tn == 128) {
             if (klin) hipLaunchKernelGGL((wgrad_big_kernel<128, true>), grid, dim3(WG_THREADS), 0, s, dout, dm, in, im, n_out, k_in, rows, kps, scratch);
             else hipLaunchKernelGGL((wgrad_big_kernel<128, false>), grid, dim3(WG_THREADS), 0, s, dout, dm, in, im, n_out, k_in, rows, kps, scratch);

@@ -879,9 +879,11 @@ int howl_lstm_fwd(const HowlLstmParams* p, const float* x, int B, int T, int M, 
     return HOWL_OK;
 }
 
-int howl_lstm_bwd(const HowlLstmParams* p, const float* x, int B, int T, int M, const long long* lengths, const float* c0,
-                  const HowlLstmSaved* sv, const float* dy, const float* dhT, const float* dcT, const HowlLstmGrads* g,
-                  void* ws, size_t ws_bytes, hipStream_t stream) {
+// body of howl_lstm_bwd; with `jobs` the wide weight gradients are collected instead of launched (howl_seq_lstm_bwd runs them
+// together with the head's), and the slab folds go to `sums` (flushed by the caller)
+static int lstm_bwd_impl(const HowlLstmParams* p, const float* x, int B, int T, int M, const long long* lengths, const float* c0,
+                         const HowlLstmSaved* sv, const float* dy, const float* dhT, const float* dcT, const HowlLstmGrads* g,
+                         void* ws, size_t ws_bytes, hipStream_t stream, SlabSums& sums, WgradJobs* jobs) {
     HOWL_REQUIRE(p && x && sv && g && ws, "howl_lstm_bwd: null pointer");
     HOWL_REQUIRE(dy || dhT, "howl_lstm_bwd: no incoming gradient");
     if (ws_bytes < howl_lstm_workspace_bytes(B, T)) {
@@ -914,14 +916,23 @@ int howl_lstm_bwd(const HowlLstmParams* p, const float* x, int B, int T, int M, 
     const int rows = B * Tout;
     // 256 rows per K slice (up to 128 slices): the 512-row slices of the generic rule leave ~1 block per CU on these shapes
     HOWL_REQUIRE(M <= LSTM_MAX_IN, "howl_lstm_bwd: M=%d input features exceed the workspace layout (max %d)", M, LSTM_MAX_IN);
-    SlabSums sums;
-    wgrad_gemm(stream, sv->dgates, rows_g, G4, x, rows_x, M, rows, scratch_ih, g->w_ih, LSTM_WGRAD_SPLITS, 256, &sums);
+    wgrad_gemm(stream, sv->dgates, rows_g, G4, x, rows_x, M, rows, scratch_ih, g->w_ih, LSTM_WGRAD_SPLITS, 256, &sums, jobs);
     wgrad_gemm(stream, sv->dgates, rows_g, G4, sv->hseq, RowMap{Tout, (long)(T + 1) * HID, HID}, HID, rows, scratch, g->w_hh,
-               LSTM_WGRAD_SPLITS, 256, &sums);
+               LSTM_WGRAD_SPLITS, 256, &sums, jobs);
     if (!rows16)   // the four-sequence recurrence left one slab of step-and-sequence sums per workgroup
         sums.add(scratch_b, (B + 3) / 4, G4, g->b_ih, g->b_hh);
     else
         colsum(stream, sv->dgates, rows_g, rows, G4, scratch_b, g->b_ih, g->b_hh, 256, 64, &sums);
+    return HOWL_OK;
+}
+
+
+int howl_lstm_bwd(const HowlLstmParams* p, const float* x, int B, int T, int M, const long long* lengths, const float* c0,
+                  const HowlLstmSaved* sv, const float* dy, const float* dhT, const float* dcT, const HowlLstmGrads* g,
+                  void* ws, size_t ws_bytes, hipStream_t stream) {
+    SlabSums sums;
+    const int rc = lstm_bwd_impl(p, x, B, T, M, lengths, c0, sv, dy, dhT, dcT, g, ws, ws_bytes, stream, sums, nullptr);
+    if (rc != HOWL_OK) return rc;
     if (!sums.flush(stream)) return HOWL_E_ARG;
     HOWL_CHECK_LAUNCH("howl_lstm_bwd");
     return HOWL_OK;
@@ -961,9 +972,9 @@ int howl_head_fwd(const HowlHeadParams* p, const float* x, int rows_inner, long 
     return HOWL_OK;
 }
 
-int howl_head_bwd(const HowlHeadParams* p, const float* x, int rows_inner, long s_outer, long s_inner, int rows, int n_in,
-                  int n_hid, int n_out, const float* y1, const float* dy2, float* dz1, float* dx, const HowlHeadGrads* g,
-                  const HowlCtcMean* ctc_mean, void* ws, size_t ws_bytes, hipStream_t stream) {
+static int head_bwd_impl(const HowlHeadParams* p, const float* x, int rows_inner, long s_outer, long s_inner, int rows, int n_in,
+                         int n_hid, int n_out, const float* y1, const float* dy2, float* dz1, float* dx, const HowlHeadGrads* g,
+                         const HowlCtcMean* ctc_mean, void* ws, size_t ws_bytes, hipStream_t stream, SlabSums& sums, WgradJobs* jobs) {
     HOWL_REQUIRE(ctc_mean == nullptr || (ctc_mean->nll && ctc_mean->target_lengths && ctc_mean->loss && ctc_mean->B >= 1),
                  "howl_head_bwd: incomplete HowlCtcMean");
     const HowlCtcMean cm = ctc_mean != nullptr ? *ctc_mean : HowlCtcMean{nullptr, nullptr, 0, nullptr};
@@ -976,7 +987,6 @@ int howl_head_bwd(const HowlHeadParams* p, const float* x, int rows_inner, long 
     }
     float* first = static_cast<float*>(ws);
     const RowMap xm{rows_inner, s_outer, s_inner};
-    SlabSums sums;
     if (head_is_thin(n_hid, n_out)) {
         float* thin = first + (size_t)HEAD_W1_SPLITS * n_hid * n_in;
         int rpb = (rows + HEAD_BWD_BLOCKS - 1) / HEAD_BWD_BLOCKS;
@@ -1007,10 +1017,41 @@ int howl_head_bwd(const HowlHeadParams* p, const float* x, int rows_inner, long 
     }
     if (dx != nullptr)   // dx = dz1 W1
         gemm(stream, true, dz1, lin(n_hid), 1, lin(0), p->w1, lin(n_in), 1, rows, n_in, n_hid, 1, nullptr, 0, dx, n_in, 0);
-    wgrad_gemm(stream, dz1, lin(n_hid), n_hid, x, xm, n_in, rows, first, g->w1, HEAD_W1_SPLITS, 512, &sums);
+    wgrad_gemm(stream, dz1, lin(n_hid), n_hid, x, xm, n_in, rows, first, g->w1, HEAD_W1_SPLITS, 512, &sums, jobs);
+    return HOWL_OK;
+}
+
+int howl_head_bwd(const HowlHeadParams* p, const float* x, int rows_inner, long s_outer, long s_inner, int rows, int n_in,
+                  int n_hid, int n_out, const float* y1, const float* dy2, float* dz1, float* dx, const HowlHeadGrads* g,
+                  const HowlCtcMean* ctc_mean, void* ws, size_t ws_bytes, hipStream_t stream) {
+    SlabSums sums;
+    const int rc = head_bwd_impl(p, x, rows_inner, s_outer, s_inner, rows, n_in, n_hid, n_out, y1, dy2, dz1, dx, g, ctc_mean, ws,
+                                 ws_bytes, stream, sums, nullptr);
+    if (rc != HOWL_OK) return rc;
     if (!sums.flush(stream)) return HOWL_E_ARG;
     HOWL_CHECK_LAUNCH("howl_head_bwd");
     return HOWL_OK;
 }
+
+int howl_seq_lstm_bwd(const HowlHeadParams* hp, int n_hid, int n_out, const float* y1, const float* dy2, float* dz1, float* dhs,
+                      const HowlHeadGrads* hg, const HowlCtcMean* ctc_mean, void* head_ws, size_t head_ws_bytes,
+                      const HowlLstmParams* p, const float* x, int B, int T, int M, const long long* lengths, const float* c0,
+                      const HowlLstmSaved* sv, const HowlLstmGrads* g, void* ws, size_t ws_bytes, hipStream_t stream) {
+    HOWL_REQUIRE(sv && dhs, "howl_seq_lstm_bwd: null pointer");
+    HOWL_REQUIRE(sv->t_out == T, "howl_seq_lstm_bwd: t_out=%d != T=%d (use howl_head_bwd + howl_lstm_bwd)", sv->t_out, T);
+    SlabSums sums;
+    WgradJobs jobs;
+    // the head reads the hidden states h_1 .. h_T in place: row (b, t) of hseq (B, T + 1, 128) at offset 128
+    int rc = head_bwd_impl(hp, sv->hseq + HID, T, (long)(T + 1) * HID, HID, B * T, HID, n_hid, n_out, y1, dy2, dz1, dhs, hg, ctc_mean,
+                           head_ws, head_ws_bytes, stream, sums, &jobs);
+    if (rc != HOWL_OK) return rc;
+    rc = lstm_bwd_impl(p, x, B, T, M, lengths, c0, sv, dhs, nullptr, nullptr, g, ws, ws_bytes, stream, sums, &jobs);
+    if (rc != HOWL_OK) return rc;
+    wgrad_jobs_flush(stream, jobs);
+    if (!sums.flush(stream)) return HOWL_E_ARG;
+    HOWL_CHECK_LAUNCH("howl_seq_lstm_bwd");
+    return HOWL_OK;
+}
+
 
 }  // extern "C"

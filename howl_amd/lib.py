@@ -107,6 +107,9 @@ SIGNATURES = {
     "howl_head_fwd": [POINTER(HowlHeadParams), P, c_int, c_long, c_long, c_int, c_int, c_int, c_int, P, P, STREAM],
     "howl_head_bwd": [POINTER(HowlHeadParams), P, c_int, c_long, c_long, c_int, c_int, c_int, c_int, P, P, P, P,
                       POINTER(HowlHeadGrads), POINTER(HowlCtcMean), P, c_size_t, STREAM],
+    "howl_seq_lstm_bwd": [POINTER(HowlHeadParams), c_int, c_int, P, P, P, P, POINTER(HowlHeadGrads), POINTER(HowlCtcMean), P,
+                          c_size_t, POINTER(HowlLstmParams), P, c_int, c_int, c_int, P, P, POINTER(HowlLstmSaved),
+                          POINTER(HowlLstmGrads), P, c_size_t, STREAM],
     "howl_adamw_step": [P, P, P, P, c_size_t, c_float, c_float, c_float, c_float, c_float, c_int, c_float, STREAM],
     "howl_mobilenet_layer": [c_int, POINTER(HowlMbLayer)],
     "howl_mobilenet_fwd": [P, P, c_int, P, c_long, c_long, c_long, c_int, c_int, c_int, c_int, P, c_float, P, P, c_size_t,

@@ -150,6 +150,34 @@ def _head_backward_raw(x, y1, dy2, w1, b1, w2, b2, need_dx=True, grads=None, ctc
     return dx, grads
 
 
+def _seq_backward_raw(saved, y1, dy2, head_params, grads, ctc_mean=None):
+    """``howl_seq_lstm_bwd``: head + LSTM backward of the sequence model in one call (t_out == T); ``grads`` = the eight flat-buffer
+    views in ``hot_parameters()`` order."""
+    x, lengths, c0, w_ih, w_hh, b_ih, b_hh, gates, cs, hseq, ws = saved
+    w1, b1, w2, b2 = head_params
+    B, T, M = x.shape
+    n_hid, n_in = w1.shape
+    n_out = w2.shape[0]
+    f32 = dict(dtype=torch.float32, device=x.device)
+    dy2 = dy2.contiguous()
+    dz1 = torch.empty_like(y1)
+    dhs = torch.empty((B, T, HID), **f32)
+    dgates = torch.empty((B, T, 4 * HID), **f32)
+    head_ws = torch.empty(_lib.get().cdll.howl_head_workspace_bytes(n_in, n_hid, n_out), dtype=torch.uint8, device=x.device)
+    hp = _lib.HowlHeadParams(_vp(w1), _vp(b1), _vp(w2), _vp(b2))
+    hg = _lib.HowlHeadGrads(*[_vp(g) for g in grads[4:8]])
+    cm = None
+    if ctc_mean is not None:
+        nll, tl, loss = ctc_mean
+        cm = ctypes.byref(_lib.HowlCtcMean(_vp(nll), _vp(tl), int(nll.numel()), _vp(loss)))
+    prm = _lib.HowlLstmParams(_vp(w_ih), _vp(w_hh), _vp(b_ih), _vp(b_hh))
+    sv = _lib.HowlLstmSaved(None, _vp(gates), _vp(cs), _vp(hseq), _vp(dgates), T, _x_frames(x))
+    gr = _lib.HowlLstmGrads(*[_vp(g) for g in grads[:4]])
+    _lib.get().call("howl_seq_lstm_bwd", ctypes.byref(hp), n_hid, n_out, _vp(y1), _vp(dy2), _vp(dz1), _vp(dhs), ctypes.byref(hg), cm,
+                    _vp(head_ws), head_ws.numel(), ctypes.byref(prm), _vp(x), B, T, M, _vp(lengths), _vp(c0), ctypes.byref(sv),
+                    ctypes.byref(gr), _vp(ws), ws.numel(), ops._stream())
+
+
 class _HeadFunction(torch.autograd.Function):
     """Linear - ReLU - Linear (``self.dnn``, rnn.py:44-48) on the library's head kernels."""
 
@@ -266,8 +294,12 @@ class SequentialLstm(_LstmBase, name="seq-lstm"):
         saved, t_out, hs, y1 = self._seq_saved
         ps = self.hot_parameters()
         grads = out_grads if out_grads is not None else [torch.empty_like(p) for p in ps]
-        dhs, _ = _head_backward_raw(hs, y1, dscores.permute(1, 0, 2), *ps[4:8], True, grads[4:8], ctc_mean)
-        _lstm_backward_raw(saved, t_out, dhs, None, None, grads[:4])
+        x = saved[0]
+        if t_out == x.shape[1]:      # whole buffer ran: one call, the wide weight gradients and the slab folds merged (12 launches)
+            _seq_backward_raw(saved, y1, dscores.permute(1, 0, 2), ps[4:8], grads, ctc_mean)
+        else:
+            dhs, _ = _head_backward_raw(hs, y1, dscores.permute(1, 0, 2), *ps[4:8], True, grads[4:8], ctc_mean)
+            _lstm_backward_raw(saved, t_out, dhs, None, None, grads[:4])
         self._seq_saved = None
         return grads
 

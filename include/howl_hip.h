@@ -310,6 +310,15 @@ int howl_head_fwd(const HowlHeadParams* p, const float* x, int rows_inner, long 
 int howl_head_bwd(const HowlHeadParams* p, const float* x, int rows_inner, long s_outer, long s_inner, int rows, int n_in,
                   int n_hid, int n_out, const float* y1, const float* dy2, float* dz1, float* dx, const HowlHeadGrads* grads,
                   const HowlCtcMean* ctc_mean /* NULL: none */, void* ws, size_t ws_bytes, hipStream_t stream);
+/* Backward of the whole sequence model (SequentialLstm, rnn.py:60-71: dnn(lstm(x))) in one call: howl_head_bwd on the hidden
+ * states h_1 .. h_T read in place from saved->hseq, then howl_lstm_bwd on the gradient it leaves in dhs (B, T, 128) -- the same
+ * arithmetic, but the three wide weight gradients (dnn[0].weight, W_ih, W_hh) run as ONE launch and all slab folds as one
+ * (12 launches per seq-lstm training step instead of 15).  Requires saved->t_out == T; head_ws / ws as for the two calls. */
+int howl_seq_lstm_bwd(const HowlHeadParams* head, int n_hid, int n_out, const float* y1, const float* dy2, float* dz1, float* dhs,
+                      const HowlHeadGrads* head_grads, const HowlCtcMean* ctc_mean /* NULL: none */, void* head_ws,
+                      size_t head_ws_bytes, const HowlLstmParams* p, const float* x, int B, int T, int M,
+                      const long long* lengths, const float* c0, const HowlLstmSaved* saved, const HowlLstmGrads* grads, void* ws,
+                      size_t ws_bytes, hipStream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * MobileNetClassifier, registry name "mobilenet" (replaces howl/model/cnn.py:15-29: downsample conv/BN/ReLU/pool +

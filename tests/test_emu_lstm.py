@@ -41,6 +41,8 @@ def run_lstm(lib, sd, x_btm, lengths, h0=None, c0=None, x_frames=0):
 @pytest.mark.parametrize("rows", ["4", "16"])
 def test_lstm_forward_backward_ragged(lib, golden, monkeypatch, rows):
     monkeypatch.setenv("HOWL_LSTM_ROWS", rows)     # both recurrence pairs: 4x4x1_16b (4 sequences / workgroup) and 16x16x4
+    if rows == "4":      # ... and both GEMMs for the projections: weights-stationary row streaming (default from 2048 rows) / 64 x 64 tiles
+        monkeypatch.setenv("HOWL_ROWGEMM_MIN_ROWS", "1")
     g = golden("g6_seq_lstm")
     g2, g4 = golden("g2_frontend_gsc"), golden("g4_zmuv")
     lengths = g["frame_lengths"].astype(np.int64)          # descending, ragged: [78, 78, 78, 78, 69, 62]
@@ -86,8 +88,11 @@ def test_lstm_forward_backward_ragged(lib, golden, monkeypatch, rows):
         np.testing.assert_allclose(gr[k], ref, rtol=0, atol=2e-5 * max(1.0, np.abs(ref).max()), err_msg=k)
 
 
-def test_lstm_input_inside_a_longer_feature_buffer(lib):
-    """HowlLstmSaved.x_frames: the first T frames of a (B, T + 3, M) buffer used in place == the same frames copied out."""
+@pytest.mark.parametrize("min_rows", ["1", "1000000"])
+def test_lstm_input_inside_a_longer_feature_buffer(lib, monkeypatch, min_rows):
+    """HowlLstmSaved.x_frames: the first T frames of a (B, T + 3, M) buffer used in place == the same frames copied out
+    (input projection on the weights-stationary kernel and on the 64 x 64 tiles)."""
+    monkeypatch.setenv("HOWL_ROWGEMM_MIN_ROWS", min_rows)
     rng = np.random.default_rng(5)
     B, T, M = 5, 7, 40
     xbuf = rng.standard_normal((B, T + 3, M)).astype(np.float32)
@@ -200,3 +205,59 @@ def test_ctc_batch_mean_rides_in_the_head_backward(lib):
                  ctypes.byref(cm), ptr(ws), ws.size, None)
         np.testing.assert_array_equal(loss, loss_ref)
         np.testing.assert_allclose(g[3], dy2.sum(0), rtol=0, atol=2e-5 * max(1.0, np.abs(dy2.sum(0)).max()))
+
+
+@pytest.mark.parametrize("big", [False, True])
+def test_seq_lstm_backward_in_one_call(lib, monkeypatch, big):
+    """howl_seq_lstm_bwd (head + LSTM backward, the wide weight gradients as one job-array launch, one slab fold) == howl_head_bwd
+    followed by howl_lstm_bwd, bit for bit; ``big`` forces the 128-row-tile weight-gradient kernel onto this small shape so that
+    the job array really carries three jobs."""
+    if big:
+        monkeypatch.setenv("HOWL_WGRAD_BIG_MIN_ROWS", "1")
+    rng = np.random.default_rng(11)
+    B, T, M = 9, 11, 40
+    x = rng.standard_normal((B, T, M)).astype(np.float32)
+    lengths = np.array([11, 11, 10, 9, 9, 7, 4, 2, 1], np.int64)
+    sd = om.lstm_init(5)
+    _, _, _, keep = run_lstm(lib, sd, x, lengths)
+    assert keep["t_out"] == T
+    w1, b1, w2, b2 = (np.ascontiguousarray(sd[k].numpy()) for k in ("dnn.0.weight", "dnn.0.bias", "dnn.2.weight", "dnn.2.bias"))
+    hseq = keep["bufs"]["hseq"]
+    np.nan_to_num(hseq, copy=False)            # rows past an utterance's length hold what the kernel left; h_0 row is NaN-filled
+    h1 = np.ascontiguousarray(hseq.reshape(-1)[128:])
+    y1, y2 = np.zeros((B * T, 256), np.float32), np.zeros((B * T, 5), np.float32)
+    hp = HowlHeadParams(ptr(w1), ptr(b1), ptr(w2), ptr(b2))
+    lib.call("howl_head_fwd", ctypes.byref(hp), ptr(h1), T, (T + 1) * 128, 128, B * T, 128, 256, 5, ptr(y1), ptr(y2), None)
+    dy2 = rng.standard_normal((B * T, 5)).astype(np.float32)
+    head_ws = np.zeros(lib.cdll.howl_head_workspace_bytes(128, 256, 5), np.uint8)
+
+    def grads():
+        hg = [np.full_like(a, np.nan) for a in (w1, b1, w2, b2)]
+        lg = {k: np.full_like(v, np.nan) for k, v in keep["npz"].items()}
+        return hg, lg, HowlHeadGrads(*[ptr(a) for a in hg]), HowlLstmGrads(*[ptr(lg[k]) for k in
+                                                                              ("weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0")])
+
+    # two calls
+    hg_a, lg_a, hgs, lgs = grads()
+    dz1, dhs = np.zeros((B * T, 256), np.float32), np.zeros((B, T, 128), np.float32)
+    lib.call("howl_head_bwd", ctypes.byref(hp), ptr(h1), T, (T + 1) * 128, 128, B * T, 128, 256, 5, ptr(y1), ptr(dy2), ptr(dz1), ptr(dhs),
+             ctypes.byref(hgs), None, ptr(head_ws), head_ws.size, None)
+    lib.call("howl_lstm_bwd", ctypes.byref(keep["prm"]), ptr(keep["x"]), B, T, M, ptr(keep["ln"]), None, ctypes.byref(keep["sv"]),
+             ptr(dhs), None, None, ctypes.byref(lgs), ptr(keep["ws"]), keep["ws"].size, None)
+    dgates_a = keep["bufs"]["dgates"].copy()
+    # one call
+    hg_b, lg_b, hgs, lgs = grads()
+    dz1_b, dhs_b = np.zeros_like(dz1), np.zeros_like(dhs)
+    keep["bufs"]["dgates"][:] = np.nan
+    lib.call("howl_seq_lstm_bwd", ctypes.byref(hp), 256, 5, ptr(y1), ptr(dy2), ptr(dz1_b), ptr(dhs_b), ctypes.byref(hgs), None,
+             ptr(head_ws), head_ws.size, ctypes.byref(keep["prm"]), ptr(keep["x"]), B, T, M, ptr(keep["ln"]), None,
+             ctypes.byref(keep["sv"]), ctypes.byref(lgs), ptr(keep["ws"]), keep["ws"].size, None)
+    np.testing.assert_array_equal(dz1, dz1_b)
+    np.testing.assert_array_equal(dhs, dhs_b)
+    np.testing.assert_array_equal(dgates_a, keep["bufs"]["dgates"])
+    for a, b_ in zip(hg_a, hg_b):
+        assert np.isfinite(a).all()
+        np.testing.assert_array_equal(a, b_)
+    for k in lg_a:
+        assert np.isfinite(lg_a[k]).all(), k
+        np.testing.assert_array_equal(lg_a[k], lg_b[k], err_msg=k)
