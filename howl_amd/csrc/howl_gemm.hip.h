@@ -289,11 +289,25 @@ inline int rowgemm_min_rows() {
     const char* e = getenv("HOWL_ROWGEMM_MIN_ROWS");
     return e != nullptr ? atoi(e) : 2048;
 }
-template <int KG, int NT, bool W_UNIT_K>
+// NO2 > 0: a thin second layer rides in the epilogue (the classifier head: y2 = out W2^T + b2 with NO2 <= 8 outputs, W2 (NO2, N)
+// row-major).  A lane's four columns of an output row are exactly one B-operand value each for four more MFMAs per 16-column tile
+// (reduction index permuted as above; A = the wave's slice of W2, rows NO2 .. 15 zero): 4 NT instructions per wave leave the
+// wave's share of y2 (16 rows x NO2) in the lanes of groups 0 and 1, the eight waves meet in LDS, and 16 x NO2 results leave per
+// tile -- head_out_kernel's launch and its pass over `out` disappear.  (The same products on the vector pipe -- 8 NO2 FMAs, 2 NO2
+// cross-lane adds per lane -- cost 4.8 us per launch, almost what the separate kernel took: vector work does not overlap matrix
+// work on this part.)
+struct RowGemmThin {
+    const float* w2;
+    const float* b2;
+    float* y2;
+};
+template <int KG, int NT, bool W_UNIT_K, int NO2 = 0>
 __global__ __launch_bounds__(RG_THREADS) void rowgemm_kernel(const float* __restrict__ in, RowMap im, const float* __restrict__ w,
                                                              long w_stride, int rows, int K, const float* __restrict__ bias, int relu,
-                                                             float* __restrict__ out, long out_stride) {
+                                                             float* __restrict__ out, long out_stride, RowGemmThin thin) {
     constexpr int LDW = 16 * KG + 4;
+    constexpr int NO2P = NO2 > 0 ? NO2 : 1;
+    __shared__ __attribute__((aligned(16))) float red2[2][RG_THREADS / 64][16][8];      // [tile parity][wave][row][output]
     constexpr int NL = (64 * KG + RG_THREADS - 1) / RG_THREADS;      // 16-byte pieces of a tile per thread
     __shared__ __attribute__((aligned(16))) float tile[2][16 * LDW + 4];      // + a dump slot for pieces without a place (see stage)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -325,6 +339,14 @@ __global__ __launch_bounds__(RG_THREADS) void rowgemm_kernel(const float* __rest
 #pragma unroll
     for (int i = 0; i < NT; ++i)
         bv[i] = bias != nullptr ? *reinterpret_cast<const float4*>(bias + nbase + 16 * i + 4 * kq) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 w2v[NT];      // A fragment of the second layer: W2[n2 = mi][nbase + 16 i + 4 kq + e], zero rows from NO2 up
+    if constexpr (NO2 > 0) {
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            const float4 t4 = *reinterpret_cast<const float4*>(thin.w2 + (long)min(mi, NO2 - 1) * (RG_THREADS / 64 * 16 * NT) + nbase + 16 * i + 4 * kq);
+            w2v[i] = mi < NO2 ? t4 : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
     for (int i = tid; i < 2 * (16 * LDW + 4); i += RG_THREADS) (&tile[0][0])[i] = 0.0f;
     // the pieces this thread moves for every tile: piece e = tid + 512 l -> (row e / K4, columns 4 (e % K4) ..)
     const int K4 = K >> 2;
@@ -387,7 +409,31 @@ __global__ __launch_bounds__(RG_THREADS) void rowgemm_kernel(const float* __rest
             if (relu) v = make_float4(fmaxf(v.x, 0.0f), fmaxf(v.y, 0.0f), fmaxf(v.z, 0.0f), fmaxf(v.w, 0.0f));
             o.v[i] = v;
         }
+        if constexpr (NO2 > 0) {
+            f32x4 y = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                y = __builtin_amdgcn_mfma_f32_16x16x4f32(w2v[i].x, o.v[i].x, y, 0, 0, 0);
+                y = __builtin_amdgcn_mfma_f32_16x16x4f32(w2v[i].y, o.v[i].y, y, 0, 0, 0);
+                y = __builtin_amdgcn_mfma_f32_16x16x4f32(w2v[i].z, o.v[i].z, y, 0, 0, 0);
+                y = __builtin_amdgcn_mfma_f32_16x16x4f32(w2v[i].w, o.v[i].w, y, 0, 0, 0);
+            }
+            // D[n2 = 4 kq + r][row = mi]: outputs 0..7 live in lane groups 0 and 1
+            if (kq < 2) *reinterpret_cast<float4*>(&red2[cur][wave][mi][4 * kq]) = make_float4(y[0], y[1], y[2], y[3]);
+        }
         return o;
+    };
+    // second layer, after the tile's barrier: every thread folds the eight waves' partials of one (row, output) in a fixed order
+    // and stores it -- the 16 x NO2 results of a tile are written by all 512 threads (identical duplicates), because a store under
+    // a lane predicate would hide the count of outstanding memory operations from the compiler (see `store`)
+    auto store_thin = [&](int t, int cur) {
+        if constexpr (NO2 > 0) {
+            const int e = tid % (16 * NO2), r = e / NO2, n = e - r * NO2;
+            float y = thin.b2[n];
+#pragma unroll
+            for (int wv_ = 0; wv_ < RG_THREADS / 64; ++wv_) y += red2[cur][wv_][r][n];
+            thin.y2[(long)min(16 * t + r, rows - 1) * NO2 + n] = y;
+        }
     };
     // D[n_local = 4 kq + r][m = mi]: four consecutive columns of output row 16 t + mi.  Rows past the end were loaded from the
     // last row (fetch clamps), so their results ARE the last row's, bit for bit: they are stored there again, and no store sits
@@ -416,6 +462,7 @@ __global__ __launch_bounds__(RG_THREADS) void rowgemm_kernel(const float* __rest
         __builtin_amdgcn_sched_barrier(0);
         store(o0, t);
         __syncthreads();      // next tile complete; every wave is past its reads of the current one
+        store_thin(t, 0);
         if (t + G >= ntiles) break;
         p1 = fetch(t + 3 * G);
         __builtin_amdgcn_sched_barrier(0);
@@ -424,6 +471,7 @@ __global__ __launch_bounds__(RG_THREADS) void rowgemm_kernel(const float* __rest
         __builtin_amdgcn_sched_barrier(0);
         store(o1, t + G);
         __syncthreads();
+        store_thin(t + G, 1);
     }
 }
 
@@ -565,8 +613,12 @@ constexpr int BIG = 1 << 30;
 inline RowMap lin(long stride) { return RowMap{BIG, 0, stride}; }
 inline bool is_lin(const RowMap& r) { return r.inner == BIG; }
 
+// `thin` (optional): RowGemmThin of a second layer with thin_out <= 8 outputs for the weights-stationary kernel; *thin_done tells
+// the caller whether it rode along (otherwise the caller launches the second layer itself)
 int gemm(hipStream_t s, bool a_major_k, const float* a, RowMap am, long a_ks, RowMap ak, const float* b, RowMap bk, long b_ns,
-         int M, int N, int K, int splits, const float* bias, int relu, float* c, long c_ms, long c_split_stride) {
+         int M, int N, int K, int splits, const float* bias, int relu, float* c, long c_ms, long c_split_stride,
+         const RowGemmThin* thin = nullptr, int thin_out = 0, bool* thin_done = nullptr) {
+    if (thin_done != nullptr) *thin_done = false;
     const int kps = ((K + splits - 1) / splits + GK - 1) / GK * GK;
     dim3 grid((N + GT - 1) / GT, (M + GT - 1) / GT, (K + kps - 1) / kps);
     HowlProfScope prof("gemm", s, 2.0 * (double)M * N * K);
@@ -586,13 +638,29 @@ int gemm(hipStream_t s, bool a_major_k, const float* a, RowMap am, long a_ks, Ro
     do {                                                                                                                      \
         if (w_unit_k)                                                                                                         \
             hipLaunchKernelGGL((rowgemm_kernel<KG_, NT_, true>), dim3(blocks), dim3(RG_THREADS), 0, s, a, am, b, w_stride, M, K, \
-                               bias, relu, c, c_ms);                                                                          \
+                               bias, relu, c, c_ms, RowGemmThin{});                                                           \
         else                                                                                                                  \
             hipLaunchKernelGGL((rowgemm_kernel<KG_, NT_, false>), dim3(blocks), dim3(RG_THREADS), 0, s, a, am, b, w_stride, M, K, \
-                               bias, relu, c, c_ms);                                                                          \
+                               bias, relu, c, c_ms, RowGemmThin{});                                                           \
         return 1;                                                                                                             \
     } while (0)
             if (N == 512 && K <= 48) HOWL_ROWGEMM(3, 4);
+            if (N == 256 && K > 64 && K <= 128 && w_unit_k && thin != nullptr && thin_out >= 1 && thin_out <= 8 && c_ms == N &&
+                al16(thin->w2)) {
+                // the head: first layer + thin second layer in one launch
+#define HOWL_ROWGEMM_THIN(NO_)                                                                                                \
+    case NO_:                                                                                                                 \
+        hipLaunchKernelGGL((rowgemm_kernel<8, 2, true, NO_>), dim3(blocks), dim3(RG_THREADS), 0, s, a, am, b, w_stride, M, K,  \
+                           bias, relu, c, c_ms, *thin);                                                                       \
+        break;
+                switch (thin_out) {
+                    HOWL_ROWGEMM_THIN(1) HOWL_ROWGEMM_THIN(2) HOWL_ROWGEMM_THIN(3) HOWL_ROWGEMM_THIN(4) HOWL_ROWGEMM_THIN(5)
+                    HOWL_ROWGEMM_THIN(6) HOWL_ROWGEMM_THIN(7) HOWL_ROWGEMM_THIN(8)
+                }
+#undef HOWL_ROWGEMM_THIN
+                *thin_done = true;
+                return 1;
+            }
             if (N == 256 && K > 64 && K <= 128) HOWL_ROWGEMM(8, 2);
             if (N == 128 && K > 128 && K <= 256) HOWL_ROWGEMM(16, 1);
 #undef HOWL_ROWGEMM

@@ -952,9 +952,13 @@ int howl_head_fwd(const HowlHeadParams* p, const float* x, int rows_inner, long 
                   int n_hid, int n_out, float* y1, float* y2, hipStream_t stream) {
     HOWL_REQUIRE(p && p->w1 && p->b1 && p->w2 && p->b2 && x && y1 && y2, "howl_head_fwd: null pointer");
     HOWL_REQUIRE(rows >= 1 && n_in >= 1 && n_hid >= 1 && n_out >= 1 && rows_inner >= 1, "howl_head_fwd: bad shape");
+    const bool is_thin = head_is_thin(n_hid, n_out);
+    const RowGemmThin second{p->w2, p->b2, y2};
+    bool second_done = false;     // many rows: the second layer rides in the first layer's launch (rowgemm_kernel)
     gemm(stream, true, x, RowMap{rows_inner, s_outer, s_inner}, 1, lin(0), p->w1, lin(1), n_in, rows, n_hid, n_in, 1, p->b1, 1,
-         y1, n_hid, 0);
-    if (head_is_thin(n_hid, n_out)) {
+         y1, n_hid, 0, is_thin ? &second : nullptr, n_out, &second_done);
+    if (second_done) {
+    } else if (is_thin) {
         int blocks = (rows + 15) / 16;
         const int cap = 4 * howl_num_cus();
         blocks = blocks > cap ? cap : blocks;
