@@ -688,12 +688,12 @@ __device__ __forceinline__ void ctc_mean_block(const float* __restrict__ nll, co
                                                float* __restrict__ loss) {
     __shared__ double mred[4];
     double acc = 0.0;
-    for (int b = threadIdx.x; b < B; b += 256) {
+    for (int b = threadIdx.x; b < B && threadIdx.x < 256; b += 256) {      // (threads past 256 of a wider block: idle)
         const long long L = target_lengths[b];
         acc += (double)(nll[b] / (float)(L > 0 ? L : 1));
     }
     acc = wave_sum_d(acc);
-    if ((threadIdx.x & 63) == 0) mred[threadIdx.x >> 6] = acc;
+    if ((threadIdx.x & 63) == 0 && threadIdx.x < 256) mred[threadIdx.x >> 6] = acc;
     __syncthreads();
     if (threadIdx.x == 0) loss[0] = (float)((((mred[0] + mred[1]) + mred[2]) + mred[3]) / (double)B);
 }
@@ -807,6 +807,181 @@ __global__ __launch_bounds__(256) void head_thin_bwd_kernel(const float* __restr
     if (threadIdx.x < NO) {
         const int val = NV + threadIdx.x;
         pb[(size_t)(NO + 1) * n_hid + threadIdx.x] = ((red[0][val][0] + red[1][val][0]) + red[2][val][0]) + red[3][val][0];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Many rows (the sequence model: 19,456), n_hid = 256, n_in = 128: head_thin_bwd_kernel's work AND the first layer's data gradient
+// dx = dz1 W1 in one weights-stationary kernel on rowgemm_kernel's schedule (howl_gemm.hip.h): one workgroup per CU keeps W1 in
+// registers (wave w: input columns 16 w ..) and streams 16-row tiles; the tile that goes to LDS is not loaded but MADE -- thread
+// (wave w, lane) holds y1[row w (+ 8)][4 lane ..], the row's NO output gradients and its four columns of W2, forms
+// dz1 = (y1 > 0) * (dy2 W2), writes it to HBM (the first layer's weight gradient reads it) and to the LDS tile, and adds its
+// share of dW2 = dy2^T y1, db1 = colsum dz1, db2 = colsum dy2 in registers; the MFMAs then multiply the tile by W1.
+// dz1 is never re-read (20 MB), one launch and its ramp disappear (head_thin_bwd 12.0 + rowgemm 19.5 us apart).
+// part: head_thin_bwd_kernel's slab layout, one slab per workgroup.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int HB_THREADS = 512, HB_HID = 256, HB_IN = 128, HB_LDW = HB_HID + 4;
+template <int NO>
+__global__ __launch_bounds__(HB_THREADS) void head_bwd_rows_kernel(const float* __restrict__ y1, const float* __restrict__ dy2, int rows,
+                                                                   const float* __restrict__ w2, const float* __restrict__ w1,
+                                                                   float* __restrict__ dz1, float* __restrict__ dx,
+                                                                   float* __restrict__ part, int nblocks, HowlCtcMean cm) {
+    if ((int)blockIdx.x == nblocks) {      // one extra block: the batch mean of a CTC loss whose launch was left out
+        ctc_mean_block(cm.nll, cm.target_lengths, cm.B, cm.loss);
+        return;
+    }
+    constexpr int NV = NO * 4 + 4;          // per-lane partial sums: dW2[n][4 lane + e] (n < NO), db1[4 lane + e]
+    __shared__ __attribute__((aligned(16))) float tile[2][16 * HB_LDW];
+    __shared__ float red[HB_THREADS / 64][NV][64];
+    __shared__ float redd[HB_THREADS / 64][NO];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int mi = lane & 15, kq = lane >> 4;
+    // A fragments: W1(k = 16 j + 4 kq + e, n = 16 wave + mi) = w1[k * 128 + n]   (reduction index permuted inside a group of 16:
+    // see rowgemm_kernel)
+    float wv[HB_HID / 16][4];
+#pragma unroll
+    for (int j = 0; j < HB_HID / 16; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) wv[j][e] = w1[(long)(16 * j + 4 * kq + e) * HB_IN + 16 * wave + mi];
+    float4 w2r[NO], aw[NO];
+    float ad[NO];
+    float4 ab = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int n = 0; n < NO; ++n) {
+        w2r[n] = *reinterpret_cast<const float4*>(w2 + (long)n * HB_HID + 4 * lane);
+        aw[n] = make_float4(0.f, 0.f, 0.f, 0.f);
+        ad[n] = 0.0f;
+    }
+    const int ntiles = (rows + 15) >> 4;
+    struct Pieces {
+        float4 y[2];
+        float d[2][NO];
+    };
+    // rows wave and wave + 8 of tile t; unconditional loads from clamped rows
+    auto fetch = [&](int t) -> Pieces {
+        Pieces p;
+#pragma unroll
+        for (int l = 0; l < 2; ++l) {
+            const long r = min(16 * min(t, ntiles - 1) + wave + 8 * l, rows - 1);
+            p.y[l] = *reinterpret_cast<const float4*>(y1 + r * HB_HID + 4 * lane);
+#pragma unroll
+            for (int n = 0; n < NO; ++n) p.d[l][n] = dy2[r * NO + n];
+        }
+        return p;
+    };
+    // makes the dz1 rows of tile t: to LDS buffer `buf`, to HBM, and into the partial sums.  Rows past the end (and a whole tile
+    // past the end) were loaded from the last row, so what is stored for them IS the last row, bit for bit -- stored there again
+    // (no store under a lane predicate: rowgemm_kernel) -- and they stay out of the sums.
+    auto stage = [&](const Pieces& p, int t, int buf) {
+#pragma unroll
+        for (int l = 0; l < 2; ++l) {
+            const int r = 16 * t + wave + 8 * l;
+            const float4 v = p.y[l];
+            float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int n = 0; n < NO; ++n) {
+                z.x = fmaf(p.d[l][n], w2r[n].x, z.x);
+                z.y = fmaf(p.d[l][n], w2r[n].y, z.y);
+                z.z = fmaf(p.d[l][n], w2r[n].z, z.z);
+                z.w = fmaf(p.d[l][n], w2r[n].w, z.w);
+            }
+            z.x = v.x > 0.0f ? z.x : 0.0f;
+            z.y = v.y > 0.0f ? z.y : 0.0f;
+            z.z = v.z > 0.0f ? z.z : 0.0f;
+            z.w = v.w > 0.0f ? z.w : 0.0f;
+            *reinterpret_cast<float4*>(&tile[buf][(wave + 8 * l) * HB_LDW + 4 * lane]) = z;
+            const long rr = min(16 * min(t, ntiles - 1) + wave + 8 * l, rows - 1);      // the row fetch() read
+            *reinterpret_cast<float4*>(dz1 + rr * HB_HID + 4 * lane) = z;
+            if (r < rows) {      // (wave-uniform)
+#pragma unroll
+                for (int n = 0; n < NO; ++n) {
+                    aw[n].x = fmaf(p.d[l][n], v.x, aw[n].x);
+                    aw[n].y = fmaf(p.d[l][n], v.y, aw[n].y);
+                    aw[n].z = fmaf(p.d[l][n], v.z, aw[n].z);
+                    aw[n].w = fmaf(p.d[l][n], v.w, aw[n].w);
+                    ad[n] += p.d[l][n];
+                }
+                ab.x += z.x;
+                ab.y += z.y;
+                ab.z += z.z;
+                ab.w += z.w;
+            }
+        }
+    };
+    // dx rows of the tile in buffer `cur`: D[n_local = 4 kq + r][m = mi] -> four consecutive input columns of row 16 t + mi
+    auto multiply = [&](int cur) -> float4 {
+        f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
+        const float* arow = &tile[cur][mi * HB_LDW + 4 * kq];
+#pragma unroll
+        for (int j = 0; j < HB_HID / 16; j += 2) {
+            const float4 a = *reinterpret_cast<const float4*>(arow + 16 * j);
+            const float4 b = *reinterpret_cast<const float4*>(arow + 16 * j + 16);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[j][0], a.x, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[j + 1][0], b.x, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[j][1], a.y, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[j + 1][1], b.y, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[j][2], a.z, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[j + 1][2], b.z, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[j][3], a.w, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[j + 1][3], b.w, acc1, 0, 0, 0);
+        }
+        return make_float4(acc0[0] + acc1[0], acc0[1] + acc1[1], acc0[2] + acc1[2], acc0[3] + acc1[3]);
+    };
+    auto store = [&](const float4& o, int t) {
+        *reinterpret_cast<float4*>(dx + (long)min(16 * t + mi, rows - 1) * HB_IN + 16 * wave + 4 * kq) = o;
+    };
+    // schedule: rowgemm_kernel's (two tiles on their way, the next tile made after the MFMAs and before the result stores)
+    const int G = nblocks;
+    int t = blockIdx.x;
+    Pieces p0 = fetch(t);
+    Pieces p1 = fetch(t + G);
+    stage(p0, t, 0);
+    __syncthreads();
+    for (; t < ntiles; t += 2 * G) {
+        p0 = fetch(t + 2 * G);
+        __builtin_amdgcn_sched_barrier(0);      // keep the requests in front of the MFMAs
+        const float4 o0 = multiply(0);
+        stage(p1, t + G, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        store(o0, t);
+        __syncthreads();
+        if (t + G >= ntiles) break;
+        p1 = fetch(t + 3 * G);
+        __builtin_amdgcn_sched_barrier(0);
+        const float4 o1 = multiply(1);
+        stage(p0, t + 2 * G, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        store(o1, t + G);
+        __syncthreads();
+    }
+    // the eight waves' partial sums (rows w, w + 8 of every tile each) meet in LDS, folded in a fixed order
+#pragma unroll
+    for (int n = 0; n < NO; ++n) {
+        red[wave][n * 4 + 0][lane] = aw[n].x;
+        red[wave][n * 4 + 1][lane] = aw[n].y;
+        red[wave][n * 4 + 2][lane] = aw[n].z;
+        red[wave][n * 4 + 3][lane] = aw[n].w;
+        if (lane == 0) redd[wave][n] = ad[n];
+    }
+    red[wave][NO * 4 + 0][lane] = ab.x;
+    red[wave][NO * 4 + 1][lane] = ab.y;
+    red[wave][NO * 4 + 2][lane] = ab.z;
+    red[wave][NO * 4 + 3][lane] = ab.w;
+    __syncthreads();
+    float* pb = part + (size_t)blockIdx.x * ((size_t)(NO + 1) * HB_HID + NO);
+    for (int idx = tid; idx < NV * 64; idx += HB_THREADS) {
+        const int val = idx >> 6, ln = idx & 63;
+        float tsum = 0.0f;
+#pragma unroll
+        for (int w_ = 0; w_ < HB_THREADS / 64; ++w_) tsum += red[w_][val][ln];
+        // val = 4 n + e -> dW2[n][4 ln + e] (n < NO), db1[4 ln + e] (n == NO)
+        pb[(size_t)(val >> 2) * HB_HID + 4 * ln + (val & 3)] = tsum;
+    }
+    if (tid < NO) {
+        float tsum = 0.0f;
+#pragma unroll
+        for (int w_ = 0; w_ < HB_THREADS / 64; ++w_) tsum += redd[w_][tid];
+        pb[(size_t)(NO + 1) * HB_HID + tid] = tsum;
     }
 }
 
@@ -991,7 +1166,28 @@ static int head_bwd_impl(const HowlHeadParams* p, const float* x, int rows_inner
     }
     float* first = static_cast<float*>(ws);
     const RowMap xm{rows_inner, s_outer, s_inner};
-    if (head_is_thin(n_hid, n_out)) {
+    auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    bool dx_done = false;
+    if (head_is_thin(n_hid, n_out) && dx != nullptr && n_hid == HB_HID && n_in == HB_IN && rows >= rowgemm_min_rows() &&
+        rows < (1 << 22) && al16(y1) && al16(dz1) && al16(dx) && al16(p->w2) && getenv("HOWL_GEMM_NO_ROWGEMM") == nullptr) {
+        // many rows: second layer's backward + ReLU mask + dx = dz1 W1 in one launch, one slab of partial sums per workgroup
+        float* thin = first + (size_t)HEAD_W1_SPLITS * n_hid * n_in;
+        const int ntiles = (rows + 15) / 16;
+        const int blocks = std::min(std::min(ntiles, howl_num_cus()), HEAD_BWD_BLOCKS);
+        HowlProfScope prof("gemm", stream, 2.0 * (double)rows * n_in * n_hid);
+#define HOWL_HEAD_BWD_ROWS(NO) \
+    case NO: hipLaunchKernelGGL(head_bwd_rows_kernel<NO>, dim3(blocks + (ctc_mean != nullptr ? 1 : 0)), dim3(HB_THREADS), 0, stream, y1, dy2, rows, p->w2, p->w1, dz1, dx, thin, blocks, cm); break;
+        switch (n_out) {
+            HOWL_HEAD_BWD_ROWS(1) HOWL_HEAD_BWD_ROWS(2) HOWL_HEAD_BWD_ROWS(3) HOWL_HEAD_BWD_ROWS(4) HOWL_HEAD_BWD_ROWS(5)
+            HOWL_HEAD_BWD_ROWS(6) HOWL_HEAD_BWD_ROWS(7) HOWL_HEAD_BWD_ROWS(8)
+        }
+#undef HOWL_HEAD_BWD_ROWS
+        const long slab = (long)(n_out + 1) * n_hid + n_out;
+        sums.add_strided(thin, blocks, slab, (long)n_out * n_hid, g->w2);
+        sums.add_strided(thin + (size_t)n_out * n_hid, blocks, slab, n_hid, g->b1);
+        sums.add_strided(thin + (size_t)(n_out + 1) * n_hid, blocks, slab, n_out, g->b2);
+        dx_done = true;
+    } else if (head_is_thin(n_hid, n_out)) {
         float* thin = first + (size_t)HEAD_W1_SPLITS * n_hid * n_in;
         int rpb = (rows + HEAD_BWD_BLOCKS - 1) / HEAD_BWD_BLOCKS;
         rpb = (rpb + 7) / 8 * 8;
@@ -1019,7 +1215,7 @@ static int head_bwd_impl(const HowlHeadParams* p, const float* x, int rows_inner
         float* scratch_b1 = first + (size_t)HEAD_W1_SPLITS * n_hid * n_in;
         colsum(stream, dz1, lin(n_hid), rows, n_hid, scratch_b1, g->b1, nullptr, 256, 64, &sums);
     }
-    if (dx != nullptr)   // dx = dz1 W1
+    if (dx != nullptr && !dx_done)   // dx = dz1 W1
         gemm(stream, true, dz1, lin(n_hid), 1, lin(0), p->w1, lin(n_in), 1, rows, n_in, n_hid, 1, nullptr, 0, dx, n_in, 0);
     wgrad_gemm(stream, dz1, lin(n_hid), n_hid, x, xm, n_in, rows, first, g->w1, HEAD_W1_SPLITS, 512, &sums, jobs);
     return HOWL_OK;

@@ -129,6 +129,19 @@ def test_lstm_streaming_carry_and_no_lengths(lib):
 @pytest.mark.parametrize("rows,n_in,n_hid,n_out", [(77, 128, 256, 5), (1, 128, 256, 3), (300, 128, 256, 8), (41, 40, 64, 1),
                                                    (50, 128, 256, 12), (33, 64, 320, 4), (2100, 128, 256, 5)])
 def test_head_forward_backward(lib, rows, n_in, n_hid, n_out):
+    _head_case(lib, rows, n_in, n_hid, n_out)
+
+
+@pytest.mark.parametrize("rows,n_out", [(77, 5), (16, 3), (1, 8), (300, 8), (531, 1)])
+def test_head_row_streaming_kernels_on_small_shapes(lib, monkeypatch, rows, n_out):
+    """The weights-stationary kernels of the 128 -> 256 -> n_out head (first layer + output layer in one launch; second layer's
+    backward + ReLU mask + data gradient in one launch), which the library picks from 2048 rows: one tile per workgroup, partial
+    last tiles, fewer tiles than a workgroup prefetches."""
+    monkeypatch.setenv("HOWL_ROWGEMM_MIN_ROWS", "1")
+    _head_case(lib, rows, 128, 256, n_out)
+
+
+def _head_case(lib, rows, n_in, n_hid, n_out):
     """Linear - ReLU - Linear: the vector kernels (n_out <= 8, n_hid <= 256) and the GEMM path of the other shapes against
     numpy in float64; x rows through a two-level row map as the (B, T+1, 128) hidden-state buffer has; 2100 rows reach the
     wide weight-gradient kernel (128-row tiles, one block per CU) for the first layer."""
@@ -185,8 +198,8 @@ def test_ctc_batch_mean_rides_in_the_head_backward(lib):
     nll2 = np.zeros(B, np.float32)
     lib.call("howl_ctc_loss", ptr(z), C, T * C, T, B, C, ptr(tg), 3, 3, ptr(il), ptr(tl), 4, ptr(nll2), None, None, 0, 0, None)
     np.testing.assert_array_equal(nll2, nll)
-    for n_out in (5, 12):       # vector kernels / GEMM path
-        rows, n_in, n_hid = 40, 128, 256
+    for n_out, with_dx in ((5, False), (12, False), (5, True)):       # vector kernels / GEMM path / row-streaming kernel (from 2048 rows)
+        rows, n_in, n_hid = (2050 if with_dx else 40), 128, 256
         x = rng.standard_normal((rows, n_in)).astype(np.float32)
         w1, b1 = (rng.standard_normal((n_hid, n_in)) * 0.1).astype(np.float32), np.zeros(n_hid, np.float32)
         w2, b2 = (rng.standard_normal((n_out, n_hid)) * 0.1).astype(np.float32), np.zeros(n_out, np.float32)
@@ -201,7 +214,8 @@ def test_ctc_batch_mean_rides_in_the_head_backward(lib):
         ws = np.zeros(lib.cdll.howl_head_workspace_bytes(n_in, n_hid, n_out), np.uint8)
         loss = np.full(1, np.nan, np.float32)
         cm = HowlCtcMean(ptr(nll), ptr(tl), B, ptr(loss))
-        lib.call("howl_head_bwd", ctypes.byref(hp), ptr(x), *geom, ptr(y1), ptr(dy2), ptr(dz1), None, ctypes.byref(gr),
+        dx = np.zeros((rows, n_in), np.float32) if with_dx else None
+        lib.call("howl_head_bwd", ctypes.byref(hp), ptr(x), *geom, ptr(y1), ptr(dy2), ptr(dz1), ptr(dx), ctypes.byref(gr),
                  ctypes.byref(cm), ptr(ws), ws.size, None)
         np.testing.assert_array_equal(loss, loss_ref)
         np.testing.assert_allclose(g[3], dy2.sum(0), rtol=0, atol=2e-5 * max(1.0, np.abs(dy2.sum(0)).max()))
