@@ -73,13 +73,13 @@ __global__ void lstm_pack_kernel(const float* __restrict__ whh, float* __restric
 // sixteen, so a lane (block J, row i) loads only the four k values 4J..4J+3 of its row -- one 16-byte LDS read per wave and
 // step instead of sixteen (which was as much LDS-pipe time per step, 256 x 1 KB, as the step's matrix work) -- and the
 // sixty-four instructions walk abid over the blocks.  acc[e] is the chain of k = e mod 4.
-template <int J, int OFF, int N>
+template <int J, int OFF, int N, int JEND = 16>
 __device__ __forceinline__ void bcast_mfma64(const float4& a, const float (&w)[N], f32x4 (&acc)[4]) {
     acc[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(a.x, w[OFF + 4 * J + 0], acc[0], 4, J, 0);
     acc[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(a.y, w[OFF + 4 * J + 1], acc[1], 4, J, 0);
     acc[2] = __builtin_amdgcn_mfma_f32_4x4x1f32(a.z, w[OFF + 4 * J + 2], acc[2], 4, J, 0);
     acc[3] = __builtin_amdgcn_mfma_f32_4x4x1f32(a.w, w[OFF + 4 * J + 3], acc[3], 4, J, 0);
-    if constexpr (J + 1 < 16) bcast_mfma64<J + 1, OFF, N>(a, w, acc);
+    if constexpr (J + 1 < JEND) bcast_mfma64<J + 1, OFF, N, JEND>(a, w, acc);
 }
 // 4 x 4 transpose inside every quad of lanes: v[r] of lane 4q + l  <->  v[l] of lane 4q + r.  Two butterfly stages: the
 // partner's registers arrive by v_mov_b32_dpp quad_perm, a select on the lane's parity keeps or takes (16 instructions; a DPP
@@ -120,9 +120,16 @@ __device__ __forceinline__ void quad_transpose(float (&v)[4], bool bit0, bool bi
 //   end of the batch are computed as copies of the last one, so that every store is unconditional (identical values) and
 //   the compiler can count outstanding memory operations instead of draining them at every step;
 //   ONE barrier per step: h_t is double-buffered in LDS.
+//   XM > 0 (round 4): the INPUT PROJECTION x_t W_ih^T is part of the step -- XM / 4 more A blocks (the four sequences' x_t, 160
+//   floats per step, staged in LDS a step ahead) against XM more weight registers per lane: 4 XM more instructions on the 512 of
+//   a step, in exchange for the projection's launch (18 us at 512 x 38 x 40) and its (B, T, 512) buffer written and read back.
+//   `gx` is then x itself: row (b, t) at (b * xframes + t) * XM floats.
 constexpr int F8_THREADS = 512;
 constexpr int F8_HS = HID + 4;          // h rows in LDS (16-byte aligned rows for the float4 A-fragment reads)
-__global__ __launch_bounds__(F8_THREADS) void lstm_fwd4_kernel(const float* __restrict__ gx, const float* __restrict__ whh,
+constexpr int F8_XS = 64 + 4;           // x rows in LDS (every lane of a wave reads its float4; columns XM.. are never multiplied)
+template <int XM>
+__global__ __launch_bounds__(F8_THREADS) void lstm_fwd4_kernel(const float* __restrict__ gx, const float* __restrict__ wih, int xframes,
+                                                               const float* __restrict__ whh,
                                                                const float* __restrict__ b_ih, const float* __restrict__ b_hh,
                                                                const long long* __restrict__ lengths,
                                                                const float* __restrict__ h0, const float* __restrict__ c0,
@@ -130,6 +137,8 @@ __global__ __launch_bounds__(F8_THREADS) void lstm_fwd4_kernel(const float* __re
                                                                float* __restrict__ hseq, float* __restrict__ hT,
                                                                float* __restrict__ cT, int B, int T, int Tout) {
     __shared__ __attribute__((aligned(16))) float hbuf[2][4 * F8_HS];
+    __shared__ __attribute__((aligned(16))) float xbuf[2][4 * F8_XS];
+    constexpr int XP = XM > 0 ? XM : 4;
     const int tid = threadIdx.x, lane = tid & 63;
     const int c = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane >> 2, g = lane & 3;
@@ -148,6 +157,17 @@ __global__ __launch_bounds__(F8_THREADS) void lstm_fwd4_kernel(const float* __re
         wB[4 * q + 3] = v.w;
     }
     const float bias = b_ih[col] + b_hh[col];
+    float wI[XP];
+    if constexpr (XM > 0) {
+#pragma unroll
+        for (int q = 0; q < XM / 4; ++q) {
+            const float4 v = *reinterpret_cast<const float4*>(wih + (size_t)col * XM + 4 * q);
+            wI[4 * q + 0] = v.x;
+            wI[4 * q + 1] = v.y;
+            wI[4 * q + 2] = v.z;
+            wI[4 * q + 3] = v.w;
+        }
+    }
     // cell role: sequence g of the workgroup, unit u
     const int bc = min(b0 + g, B - 1);
     float cst = c0 != nullptr ? c0[(size_t)bc * HID + u] : 0.0f;
@@ -166,9 +186,20 @@ __global__ __launch_bounds__(F8_THREADS) void lstm_fwd4_kernel(const float* __re
     unsigned gb[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) gb[r] = ((unsigned)min(b0 + r, B - 1) * (unsigned)T * G4 + col) * 4u;
-    float nx[4];
+    float nx[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    // XM > 0: thread (sequence xr, feature xm) of the first 4 XM carries x_t of the NEXT step into xbuf (requested a step ahead)
+    const int xr = min(tid / XP, 3), xm = tid - (tid / XP) * XP;
+    const bool xthread = XM > 0 && tid < 4 * XM;
+    unsigned xb = ((unsigned)min(b0 + xr, B - 1) * (unsigned)xframes * XP + xm) * 4u;      // x[b][t][m]
+    float xn = 0.0f;
+    if constexpr (XM > 0) {
+        if (xthread) xbuf[0][xr * F8_XS + xm] = ldg(gx, xb);
+        xb += Tout > 1 ? XP * 4u : 0u;
+        xn = ldg(gx, xb);         // x_1
+    } else {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) nx[r] = ldg(gx, gb[r]);
+        for (int r = 0; r < 4; ++r) nx[r] = ldg(gx, gb[r]);
+    }
     // sigmoid(x) = 1 / (1 + 2^(-x log2 e)); the cell-candidate gate is tanh(x) = 2 sigmoid(2x) - 1
     const float kneg = g == 2 ? -2.88539008177792681f : -1.44269504088896341f;
     const float amul = g == 2 ? 2.0f : 1.0f, aadd = g == 2 ? -1.0f : 0.0f;
@@ -182,7 +213,11 @@ __global__ __launch_bounds__(F8_THREADS) void lstm_fwd4_kernel(const float* __re
         float pre[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) pre[r] = nx[r] + bias;
-        {   // next step's input-projection terms (the last step re-reads its own: an unconditional load keeps the count exact)
+        float xw = xn;      // x_{t+1}, requested a step ago; goes to LDS at the end of this step
+        if constexpr (XM > 0) {   // x_{t+2} (the last steps re-read the last frame: an unconditional load keeps the count exact)
+            xb += t + 2 < Tout ? XP * 4u : 0u;
+            xn = ldg(gx, xb);
+        } else {   // next step's input-projection terms (the last step re-reads its own)
             const float* gxn = gx + (t + 1 < Tout ? G4 : 0);
 #pragma unroll
             for (int r = 0; r < 4; ++r) nx[r] = ldg(gxn, gb[r]);
@@ -193,6 +228,12 @@ __global__ __launch_bounds__(F8_THREADS) void lstm_fwd4_kernel(const float* __re
         f32x4 acc[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[e] = {0.0f, 0.0f, 0.0f, 0.0f};
+        // (the input's share at the END of the previous step, in the shadow of its barrier -- it does not depend on h -- was
+        // measured SLOWER: 86.0 against 79.5 us per 38-step launch)
+        if constexpr (XM > 0) {
+            const float4 ax = *reinterpret_cast<const float4*>(&xbuf[t & 1][g * F8_XS + 4 * j]);
+            bcast_mfma64<0, 0, XP, XM / 4>(ax, wI, acc);
+        }
         bcast_mfma64<0, 0>(alo, wB, acc);
         bcast_mfma64<0, 64>(ahi, wB, acc);
         const f32x4 sum = (acc[0] + acc[1]) + (acc[2] + acc[3]);
@@ -212,6 +253,7 @@ __global__ __launch_bounds__(F8_THREADS) void lstm_fwd4_kernel(const float* __re
         cst = live ? cn : cst;
         hst = live ? hn : hst;
         hnxt[g * F8_HS + u] = hst;
+        if (xthread) xbuf[(t + 1) & 1][xr * F8_XS + xm] = xw;
         stg(cs, cb, cn);
         stg(hseq, hb, live ? hn : 0.0f);      // padded outputs are zero
         cb += HID * 4u;
@@ -1036,14 +1078,22 @@ int howl_lstm_fwd(const HowlLstmParams* p, const float* x, int B, int T, int M, 
         hipLaunchKernelGGL(lstm_pack_kernel, dim3(16 * 64 * 64 / 256), dim3(256), 0, stream, p->w_hh, pf, pb, p->b_ih, p->b_hh, bsum);
     const int xf = sv->x_frames > 0 ? sv->x_frames : T;
     HOWL_REQUIRE(xf >= T, "howl_lstm_fwd: x_frames=%d < T=%d", xf, T);
-    gemm(stream, true, x, xf == T ? lin(M) : RowMap{T, (long)xf * M, M}, 1, lin(0), p->w_ih, lin(1), M, B * T, G4, M, 1,
-         rows16 ? bsum : nullptr, 0, sv->gx, G4, 0);
+    // (the four-sequence recurrence multiplies x_t W_ih^T itself when M = 40: no projection launch, gx unused)
+    const bool fuse_x = !rows16 && M == 40 && (reinterpret_cast<uintptr_t>(p->w_ih) & 15) == 0 &&
+                        (size_t)B * (size_t)xf * M * sizeof(float) < ((size_t)1 << 32) && getenv("HOWL_LSTM_NO_FUSED_X") == nullptr;
+    if (!fuse_x)
+        gemm(stream, true, x, xf == T ? lin(M) : RowMap{T, (long)xf * M, M}, 1, lin(0), p->w_ih, lin(1), M, B * T, G4, M, 1,
+             rows16 ? bsum : nullptr, 0, sv->gx, G4, 0);
     if (sv->t_out < T)   // rows of steps that never run are read (times zero) by the weight-gradient GEMM: keep them finite
         hipMemsetAsync(sv->hseq, 0, (size_t)B * (T + 1) * HID * sizeof(float), stream);
     HowlProfScope prof("lstm_fwd", stream, 2.0 * HID * G4 * (double)B * sv->t_out);     // h_{t-1} W_hh^T of every step
-    if (!rows16) {
-        hipLaunchKernelGGL(lstm_fwd4_kernel, dim3((B + 3) / 4), dim3(F8_THREADS), 0, stream, (const float*)sv->gx,
+    if (fuse_x) {
+        hipLaunchKernelGGL(lstm_fwd4_kernel<40>, dim3((B + 3) / 4), dim3(F8_THREADS), 0, stream, x, p->w_ih, xf,
                            p->w_hh, p->b_ih, p->b_hh, lengths, h0, c0, sv->gates, sv->c, sv->hseq, hT, cT, B, T, sv->t_out);
+    } else if (!rows16) {
+        hipLaunchKernelGGL(lstm_fwd4_kernel<0>, dim3((B + 3) / 4), dim3(F8_THREADS), 0, stream, (const float*)sv->gx,
+                           (const float*)nullptr, 0, p->w_hh, p->b_ih, p->b_hh, lengths, h0, c0, sv->gates, sv->c, sv->hseq, hT, cT, B,
+                           T, sv->t_out);
     } else {
         const size_t lds_fwd = (size_t)(2 * 16 * HS + 2 * 16 * 6 * HID) * sizeof(float);
         hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fwd);
