@@ -1086,7 +1086,8 @@ int howl_lstm_fwd(const HowlLstmParams* p, const float* x, int B, int T, int M, 
              rows16 ? bsum : nullptr, 0, sv->gx, G4, 0);
     if (sv->t_out < T)   // rows of steps that never run are read (times zero) by the weight-gradient GEMM: keep them finite
         hipMemsetAsync(sv->hseq, 0, (size_t)B * (T + 1) * HID * sizeof(float), stream);
-    HowlProfScope prof("lstm_fwd", stream, 2.0 * HID * G4 * (double)B * sv->t_out);     // h_{t-1} W_hh^T of every step
+    // h_{t-1} W_hh^T of every step (+ x_t W_ih^T where the recurrence multiplies it itself)
+    HowlProfScope prof("lstm_fwd", stream, 2.0 * (HID + (fuse_x ? M : 0)) * G4 * (double)B * sv->t_out);
     if (fuse_x) {
         hipLaunchKernelGGL(lstm_fwd4_kernel<40>, dim3((B + 3) / 4), dim3(F8_THREADS), 0, stream, x, p->w_ih, xf,
                            p->w_hh, p->b_ih, p->b_hh, lengths, h0, c0, sv->gates, sv->c, sv->hseq, hT, cT, B, T, sv->t_out);
