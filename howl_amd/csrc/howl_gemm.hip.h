@@ -772,13 +772,13 @@ __global__ __launch_bounds__(256) void thin_wgrad_kernel(const float* __restrict
 // the 64 x 64 kernel moved every operand element through the cache hierarchy 2-8 times (160 MB for 50 MB of operands in the
 // W_hh gradient) and its 1216 blocks did not overlap their staging with their MFMAs; here each element is read once or twice.
 constexpr int WG_M = 128, WG_K = 16, WG_THREADS = 1024;
-constexpr int WG_LDA = WG_M + 4;                    // pitch = 4 mod 32 banks: the four k rows of a fragment read do not collide
+constexpr int WG_LDA = WG_M + 16;                   // pitch = 16 mod 32 banks: the two k rows of a 32-lane half of a fragment read do not collide (with + 4 they did: -1 %)
 // (bx, by, bz) = the block's (input-column tile, output-column tile, row split); As / Bs: [2][WG_K * WG_LDA] floats of LDS each
 template <int TN, bool KMAP_LIN>
 __device__ __forceinline__ void wgrad_big_body(const float* __restrict__ dout, RowMap dm, const float* __restrict__ in, RowMap im,
                                                int M, int N, int K, int k_per_split, float* __restrict__ part, int bx, int by,
                                                int bz, float (*As)[WG_K * WG_LDA], float (*Bs)[WG_K * WG_LDA]) {
-    constexpr int LDA = WG_LDA, LDB = TN + 4;
+    constexpr int LDA = WG_LDA, LDB = TN + 16;
     constexpr int NJ = TN / 64;                     // 16-column tiles per wave (sixteen waves: 4 x 4, 32 x TN/4 each)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 2, wc = wave & 3;
@@ -842,6 +842,8 @@ __device__ __forceinline__ void wgrad_big_body(const float* __restrict__ dout, R
                 for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
     };
+    // (Four tiles in flight instead of two -- four per trip -- measured 71 us against 64-66 for the three jobs of the seq-lstm step:
+    // the loop is not waiting for its loads, and the all-zero tiles that round the count up are paid in full.)
     // Two K tiles per trip, no early exit (an odd tile count multiplies one all-zero tile at the end): with `break`s in the body
     // the compiler's vmcnt bookkeeping gives up and every staging step waits for ALL outstanding loads (vmcnt(0)).
     float4 v0 = fetch();
