@@ -162,8 +162,19 @@ def _trainer_worker(rank, world, port, out, late_grads="overlap"):
 import pytest
 
 
+@pytest.fixture(scope="module")
+def emu_built():
+    """The emulator library is built HERE, once, before any rank is spawned: two ranks finding it stale would both recompile
+    every kernel source into the same object files at the same time (minutes, and a race)."""
+    import sys
+    from pathlib import Path
+    sys.path.insert(0, str(Path(__file__).resolve().parent))
+    import emu_util
+    emu_util.emu_lib()
+
+
 @pytest.mark.parametrize("late_grads,collectives", [("overlap", 2), ("merged", 1)])
-def test_two_rank_fused_trainer_on_emulated_kernels(late_grads, collectives):
+def test_two_rank_fused_trainer_on_emulated_kernels(emu_built, late_grads, collectives):
     """(i) per-rank gradient == oracle on the rank's shard, (ii) all-reduced gradient == sum of the shard
     gradients (the 1/world mean is applied inside the AdamW kernel), (iii) bit-identical weights on all ranks after two
     steps from deliberately different initial weights (broadcast_parameters).  Both schedules of the late (conv0) gradients:
@@ -216,7 +227,7 @@ def _entry_worker(rank, world, port, wsdir, out):
     dist.destroy_process_group()
 
 
-def test_two_rank_pretrain_gsc_entry_point(tmp_path):
+def test_two_rank_pretrain_gsc_entry_point(emu_built, tmp_path):
     """The entry point itself under a 2-rank launcher environment: it joins the process group, splits every global batch of 8
     into shards of 4, broadcasts rank 0's start, all-reduces inside the fused step (two-part backward), evaluates in shards,
     and only rank 0 writes the workspace; the replicas end with bit-identical weights."""

@@ -281,7 +281,7 @@ import test_emu_res8 as T
 from oracle import models as om
 lib = emu_lib()
 out = {}
-for B, Tf, C in ((5, 41, 4), (4, 81, 12), (3, 62, 5)):
+for B, Tf, C in ((5, 41, 4), (3, 62, 5), (2, 81, 12)):
     x = T.feats(B, Tf, 7)
     labels = torch.arange(B) %% C
     sd = om.res8_init(C); names = om.res8_param_names()
