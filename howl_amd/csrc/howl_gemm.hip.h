@@ -844,6 +844,8 @@ __device__ __forceinline__ void wgrad_big_body(const float* __restrict__ dout, R
     };
     // (Four tiles in flight instead of two -- four per trip -- measured 71 us against 64-66 for the three jobs of the seq-lstm step:
     // the loop is not waiting for its loads, and the all-zero tiles that round the count up are paid in full.)
+    // (Two K tiles per BARRIER -- four LDS buffers, 32 MFMAs per wave between two barriers instead of 16 -- measured 68.6 us against
+    // 64-66 as well: neither the load latency nor the barrier count is what keeps the matrix pipe at 0.485 here.)
     // Two K tiles per trip, no early exit (an odd tile count multiplies one all-zero tile at the end): with `break`s in the body
     // the compiler's vmcnt bookkeeping gives up and every staging step waits for ALL outstanding loads (vmcnt(0)).
     float4 v0 = fetch();
