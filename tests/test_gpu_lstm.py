@@ -130,22 +130,25 @@ def test_fused_ctc_out_of_range_uses_torch_device_kernels():
         ops.ctc_loss(logits.permute(1, 0, 2), targets, in_len, tgt_len, blank)   # CPU scores: no CPU fallback
 
 
-def test_fused_sequence_step_matches_autograd_path_and_oracle():
+@pytest.mark.parametrize("B", [48, 512])
+def test_fused_sequence_step_matches_autograd_path_and_oracle(B):
     """FusedTrainer.step_sequence (explicit launches, gradients straight into the flat buffer, flat AdamW) against (a) the
-    autograd path through the same kernels + torch.optim.AdamW and (b) the oracle's CTC step; ragged lengths."""
+    autograd path through the same kernels + torch.optim.AdamW and (b) the oracle's CTC step; ragged lengths.  B = 512 is the
+    size at which the library switches to its row-streaming head kernels and the trainer's one-call backward
+    (howl_seq_lstm_bwd: job-array weight gradients) meets the autograd path's two calls: still bit-identical."""
     from howl_amd import ops
     from howl_amd.data.transform.operator import ZmuvTransform
     from howl_amd.data.transform.transform import StandardAudioTransform
     from howl_amd.training.fused import FusedTrainer
     from howl_amd.utils.synth import synthetic_pcm
-    B, L, C = 48, 8000, 5
+    L, C = 8000, 5
     pcm = synthetic_pcm(B, L).to(DEV)
     std = StandardAudioTransform().to(DEV).eval()
     zmuv = ZmuvTransform().to(DEV)
     zmuv.update(std(pcm[:4]))
     lengths = torch.sort(24 + torch.arange(B) % 15, descending=True).values
     targets = torch.tensor([[0, 1, 2]] * B)
-    tl = torch.tensor([3, 2, 1] * (B // 3))
+    tl = torch.tensor(([3, 2, 1] * (B // 3 + 1))[:B])
     feats = std.log_mel_for_model(pcm, zmuv)
 
     fused_model = make("seq-lstm", C).train()
