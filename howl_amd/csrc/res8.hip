@@ -1532,28 +1532,6 @@ __global__ __launch_bounds__(1024) void reduce_rows_all_kernel(const float* __re
 // ---------------------------------------------------------------------------------------------------------
 // BatchNorm statistics
 // ---------------------------------------------------------------------------------------------------------
-// forward, training: partials -> batch mean / rstd (biased var), running-stat update (cnn.py:142 semantics of
-// nn.BatchNorm2d(affine=False): momentum 0.1, unbiased variance into running_var, num_batches_tracked += 1)
-__global__ __launch_bounds__(768) void bn_finalize_kernel(const float* __restrict__ part, int nparts, double count,
-                                                          float* __restrict__ stats, HowlBnBuffers bn) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c8 = lane >> 3;
-    const int c = 4 * wave + (c8 & 3);                       // 12 waves x 4 channels
-    const double s = fold_part_column(part, part_stride(nparts), nparts, (c8 < 4 ? 0 : CP) + c, lane);
-    const double q = __shfl_xor(s, 32);
-    if (c8 >= 4 || (lane & 7) != 0) return;
-    const double mean = s / count;
-    double var = q / count - mean * mean;
-    var = var < 0.0 ? 0.0 : var;
-    stats[c] = (c < NMAP) ? (float)mean : 0.0f;
-    stats[CP + c] = (c < NMAP) ? (float)(1.0 / sqrt(var + (double)BN_EPS)) : 0.0f;
-    if (c < NMAP && bn.running_mean != nullptr) {
-        const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-        bn.running_mean[c] = (1.0f - BN_MOMENTUM) * bn.running_mean[c] + BN_MOMENTUM * (float)mean;
-        bn.running_var[c] = (1.0f - BN_MOMENTUM) * bn.running_var[c] + BN_MOMENTUM * (float)unbiased;
-    }
-    if (c == 0 && bn.num_batches != nullptr) bn.num_batches[0] += 1;
-}
-
 // eval mode: stats from the running buffers
 __global__ void bn_eval_stats_kernel(HowlPtrs6 rmean, HowlPtrs6 rvar, float* __restrict__ stats) {
     const int layer = blockIdx.x, c = threadIdx.x;
@@ -1939,10 +1917,44 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
                                                        int P, int C, const long long* __restrict__ labels,
                                                        float* __restrict__ nll, float* __restrict__ dlogits,
                                                        float* __restrict__ dpool, float inv_batch,
-                                                       const float* __restrict__ pool, int npg, int npg_used) {
+                                                       const float* __restrict__ pool, int npg, int npg_used, BnFold fold) {
     __shared__ float lp[CP];
     __shared__ float ll[HEAD_XC], dl[HEAD_XC], lse_s;
+    __shared__ float lst[2 * CP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (fold.part != nullptr) {
+        // training: BatchNorm 6's batch statistics from the last convolution's partials, folded by every workgroup (the same bits
+        // everywhere: fold_part_column) -- without a one-block finalize launch between the last
+        // convolution and the head; workgroup 0 publishes them for the backward pass and updates the running buffers (cnn.py:142)
+        const int c8 = lane >> 3;
+        for (int w0 = wave; w0 < CP / 4; w0 += 4) {
+            const int c = 4 * w0 + (c8 & 3);
+            const double sm = fold_part_column(fold.part, part_stride(fold.nparts), fold.nparts, (c8 < 4 ? 0 : CP) + c, lane);
+            const double q = __shfl_xor(sm, 32);
+            if (c8 < 4 && (lane & 7) == 0) {
+                const double mean = sm / fold.count;
+                double var = q / fold.count - mean * mean;
+                var = var < 0.0 ? 0.0 : var;
+                const float fm = (c < NMAP) ? (float)mean : 0.0f;
+                const float fr = (c < NMAP) ? (float)(1.0 / sqrt(var + (double)BN_EPS)) : 0.0f;
+                lst[c] = fm;
+                lst[CP + c] = fr;
+                if (blockIdx.x == 0) {
+                    fold.stats_out[c] = fm;
+                    fold.stats_out[CP + c] = fr;
+                    if (c < NMAP && fold.bn.running_mean != nullptr) {
+                        const double unbiased = fold.count > 1.0 ? var * fold.count / (fold.count - 1.0) : var;
+                        fold.bn.running_mean[c] = (1.0f - BN_MOMENTUM) * fold.bn.running_mean[c] + BN_MOMENTUM * (float)mean;
+                        fold.bn.running_var[c] = (1.0f - BN_MOMENTUM) * fold.bn.running_var[c] + BN_MOMENTUM * (float)unbiased;
+                    }
+                    if (c == 0 && fold.bn.num_batches != nullptr) fold.bn.num_batches[0] += 1;
+                }
+            }
+        }
+    } else if (tid < 2 * CP) {
+        lst[tid] = stats[tid];
+    }
+    __syncthreads();
     for (int b = blockIdx.x; b < B; b += gridDim.x) {
         __syncthreads();
         if (pool != nullptr) {
@@ -1950,7 +1962,7 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
             if (tid < CP) {
                 float acc = 0.0f;
                 for (int g = 0; g < npg_used; ++g) acc += pool[((size_t)b * npg + g) * CP + tid];
-                const float v = tid < NMAP ? (acc / (float)P - stats[tid]) * stats[CP + tid] : 0.0f;
+                const float v = tid < NMAP ? (acc / (float)P - lst[tid]) * lst[CP + tid] : 0.0f;
                 lp[tid] = v;
                 pooled[(size_t)b * CP + tid] = v;
             }
@@ -1974,7 +1986,7 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
                 for (int j = 0; j < 8; ++j) a8[u][j] = (lane + 64 * j < P) ? fabsf(a8[u][j]) : 0.0f;  // |s|: see conv_utterance
                 float acc = ((a8[u][0] + a8[u][1]) + (a8[u][2] + a8[u][3])) + ((a8[u][4] + a8[u][5]) + (a8[u][6] + a8[u][7]));
                 acc = wave_sum(acc);
-                const float v = c < NMAP ? (acc / (float)P - stats[c]) * stats[CP + c] : 0.0f;
+                const float v = c < NMAP ? (acc / (float)P - lst[c]) * lst[CP + c] : 0.0f;
                 if (lane == 0 && c < CP) {
                     lp[c] = v;
                     pooled[(size_t)b * CP + c] = v;
@@ -2451,13 +2463,13 @@ int res8_fwd_impl(const HowlRes8Params* prm, const float* feat, long sb, long st
                               nullptr, nullptr, part_out, B, H, fold, BwdFold{}, i == 6 ? w.pool : (float*)nullptr);
         }
     }
-    if (training)
-        hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(768), 0, stream, w.part2, G * SL, count,
-                           sv->bn_stats + (size_t)5 * 2 * CP,
-                           HowlBnBuffers{prm->bn_running_mean[5], prm->bn_running_var[5], prm->bn_num_batches[5]});
+    // (training: the head folds BatchNorm 6's statistics itself -- no one-block finalize launch in between)
+    const BnFold hfold = training ? BnFold{w.part2, G * SL, count, sv->bn_stats + (size_t)5 * 2 * CP,
+                                           HowlBnBuffers{prm->bn_running_mean[5], prm->bn_running_var[5], prm->bn_num_batches[5]}}
+                                  : BnFold{};
     hipLaunchKernelGGL(head_fwd_kernel, dim3(B < 1024 ? B : 1024), dim3(256), 0, stream, sv->s[6],
                        sv->bn_stats + (size_t)5 * 2 * CP, prm->out_w, prm->out_b, sv->pooled, logits, B, P, C, labels, nll, dlogits,
-                       w.dpool, 1.0f / (float)B, (const float*)w.pool, 4 * SL, 4 * SL < (P + 15) / 16 ? 4 * SL : (P + 15) / 16);
+                       w.dpool, 1.0f / (float)B, (const float*)w.pool, 4 * SL, 4 * SL < (P + 15) / 16 ? 4 * SL : (P + 15) / 16, hfold);
     HOWL_CHECK_LAUNCH("howl_res8_fwd");
     return HOWL_OK;
 }
