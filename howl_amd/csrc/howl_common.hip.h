@@ -76,6 +76,19 @@ __device__ __forceinline__ float wave_sum(float v) {
     for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
     return v;
 }
+// The same sum with the first four butterfly stages inside a row of 16 lanes as DPP moves (quad_perm [1,0,3,2], quad_perm
+// [2,3,0,1], row_half_mirror, row_mirror: no LDS-pipe traffic) and only the two cross-row stages as ds_bpermute -- for kernels
+// that fold MANY accumulators per wave at their end (conv0's weight gradient: 27 per wave, 162 -> 54 ds_bpermute).  A different
+// association order than wave_sum: not interchangeable where bits are compared.
+__device__ __forceinline__ float wave_sum_rows(float v) {
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, true));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, true));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xf, 0xf, true));
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    return v;
+}
 __device__ __forceinline__ double wave_sum_d(double v) {
     for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
     return v;

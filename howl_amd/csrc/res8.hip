@@ -1898,7 +1898,7 @@ __global__ __launch_bounds__(C0G_THREADS) void conv0_wgrad_valu_kernel(const flo
     for (int j = 0; j < C0G_CPW; ++j)
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
-            const float v = wave_sum(acc[j][t]);
+            const float v = wave_sum_rows(acc[j][t]);
             if (lane == 0) part[(size_t)blockIdx.x * NMAP * 9 + (C0G_CPW * wave + j) * 9 + t] = v;
         }
 }
