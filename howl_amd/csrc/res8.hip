@@ -1870,6 +1870,8 @@ __global__ __launch_bounds__(C0G_THREADS) void conv0_wgrad_valu_kernel(const flo
             float gv[C0G_CPW];
             unsigned mv[C0G_CPW];
 #pragma unroll
+            // (requesting the NEXT block's operands here instead -- one block ahead -- needs six more registers at the 128-VGPR line of
+            // fifteen waves: 8-11 dwords of scratch whose reloads share the in-order memory counter with the prefetch; 60-64 us against 44.8)
             for (int j = 0; j < C0G_CPW; ++j) {      // this block's operands of all five channels in flight together
                 const unsigned o = (unsigned)(j * P) + cc;
                 gv[j] = gab[o] + (gbb != nullptr ? gbb[o] : 0.0f);
