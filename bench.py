@@ -82,6 +82,12 @@ def parse():
     ap.add_argument("--vtlp", action="store_true",
                     help="frontend in train mode, as the reference loop runs it (pretrain_gsc.py:120-126): per step one host draw, "
                          "VTLP-warped filterbank rebuilt on the device (howl_fb_from_points) on 75 %% of the steps")
+    ap.add_argument("--loop", choices=["step", "entry"], default="step",
+                    help="step (default, the bench line): the training step on a batch resident in HBM.  entry: the loop a user "
+                         "runs -- training.run.pretrain_gsc's epoch body (howl_amd.training.run.pretrain_gsc.train_epoch: shuffled "
+                         "clip ids -> device collate with Timeshift + Noise + batchify -> frontend in train mode (VTLP draw) -> fused "
+                         "step -> loss logged through the workspace writer) over a device-resident synthetic clip bank, reported "
+                         "beside the resident-tensor step of the same process (res8 configurations)")
     ap.add_argument("--global-batch", type=int, default=None,
                     help="strong scaling: a FIXED global batch split over the N ranks (configs[2]: 4096); default is weak "
                          "scaling at the configuration's per-GPU batch")
@@ -284,6 +290,181 @@ def pmc_traffic(kernel="bwd_pair_kernel"):
     return None, None
 
 
+def cpu_entry_baseline(L, C, B, budget_s):
+    """The oracle of the SAME loop (pretrain_gsc.py:120-133 with its collate, :78-80) on the host cores: timeshift + noise +
+    batchify on CPU clips, train-mode frontend (VTLP filterbank on 75 % of the steps), res8 step.  Bounded sample."""
+    import random
+    import torch
+    from oracle import collate as oc, frontend as ofe, models as om
+    from howl_amd.utils.synth import synthetic_pcm
+    Bc = min(B, 64)
+    bank = synthetic_pcm(4 * Bc, L, seed=5)
+    labels_all = [(i % 64) % C for i in range(4 * Bc)]
+    rand, fb_std = random.Random(0), ofe.mel_fb(40)
+    z = ofe.Zmuv()
+    z.update(ofe.standard_audio_transform(bank[:2], fb_std))
+    sd, names = om.res8_init(C), om.res8_param_names()
+    opt = om.AdamWState([sd[n] for n in names], 0.01, 1e-5)
+    cpu_model, physical = host_info()
+    default_threads = torch.get_num_threads()
+    torch.set_num_threads(min(default_threads, 16))
+    perm = torch.randperm(4 * Bc, generator=torch.Generator().manual_seed(0)).tolist()
+
+    def step(k):
+        ids = perm[(k % 4) * Bc:(k % 4 + 1) * Bc]
+        clips = oc.noise(rand, oc.timeshift(rand, oc.truncate_length([bank[i] for i in ids], L)))
+        audio, lab, _, _ = oc.batchify(clips, [labels_all[i] for i in ids])
+        fb = ofe.mel_fb(40, alpha=rand.random() * 0.2 + 0.9) if rand.random() < 0.75 else fb_std
+        om.train_step(lambda s, xx: om.res8_forward(s, xx, True), sd, names, opt, z(ofe.standard_audio_transform(audio, fb)), lab)
+
+    step(0)
+    t0, n = time.perf_counter(), 0
+    while n < 2 or (time.perf_counter() - t0 < budget_s and n < 200):
+        step(n + 1)
+        n += 1
+    dt = time.perf_counter() - t0
+    torch.set_num_threads(default_threads)
+    return {"value": round(Bc * n / dt, 1), "unit": "utterances/sec", "cores": min(default_threads, 16), "kind": "port",
+            "physical_cores": physical, "cpu_model": cpu_model,
+            "sample": f"{n} iterations of the oracle's entry-point loop (collate chain + train-mode frontend + res8 step) at batch "
+                      f"{Bc} x {L / 16000:g} s, torch-CPU, one process (the reference spreads the collate over cpu_count workers)"}
+
+
+def bench_entry(args, dev, rank, world):
+    """--loop entry: what `python -m training.run.pretrain_gsc` sustains per epoch, next to the resident-tensor step."""
+    import random
+    import tempfile
+    import torch
+    import torch.distributed as dist
+    from howl_amd.data.collate import DeviceCollate
+    from howl_amd.data.transform.operator import ZmuvTransform
+    from howl_amd.data.transform.transform import StandardAudioTransform
+    from howl_amd.model import RegisteredModel
+    from howl_amd.training.data import ClipBank
+    from howl_amd.training.fused import FusedTrainer
+    from howl_amd.training.run.pretrain_gsc import train_epoch
+    from howl_amd.utils.synth import res8_closed_form_state, synthetic_pcm
+    from howl_amd.workspace import Workspace
+
+    model_name, C, B, seconds, cfg_desc = CONFIGS[args.config]
+    if model_name != "res8":
+        raise SystemExit("bench.py --loop entry: res8 configurations (c1, c2, c3)")
+    B = args.batch_per_gpu or B
+    C = args.labels or C
+    L = int(round((args.seconds or seconds) * 16000))
+    n_batches = args.warmup + args.steps
+    n_clips = max(4 * B, min(8192, B * n_batches))
+    # the bank: tones + noise as everywhere, every tenth clip shorter than the window (as a GSC split has them)
+    pcm = synthetic_pcm(n_clips, L, seed=4321 + rank)
+    clips = [pcm[i][:L - 160 * (i % 37)] if i % 10 == 0 else pcm[i] for i in range(n_clips)]
+    bank = ClipBank(clips, [(i % 64) % C for i in range(n_clips)], L, dev)
+    del pcm, clips
+    std = StandardAudioTransform().to(dev).eval()
+    zmuv = ZmuvTransform().to(dev)
+    zmuv.update(std(bank.audio[:8]))
+    random.seed(1234)                 # VTLP's alpha draws (global `random`, transform.py:441)
+    std.train()
+    model = RegisteredModel.find_registered_class("res8")(C).to(dev)
+    model.load_state_dict(res8_closed_form_state(C), strict=False)
+    model.train()
+    trainer = FusedTrainer(model, std, zmuv, lr=0.01, weight_decay=1e-5)
+    trainer.broadcast_parameters()
+    tmp = tempfile.mkdtemp(prefix="howl_bench_ws_")
+    writer = Workspace(Path(tmp)).summary_writer if rank == 0 else Workspace(Path(tmp), writable=False).summary_writer
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def id_batches(n, seed):
+        gen = torch.Generator().manual_seed(seed)
+        out = []
+        while len(out) < n:
+            out += list(bank.index_batches(B, shuffle=True, drop_last=True, generator=gen))
+        return out[:n]
+
+    def timed(fn_warm, fn, reps=1):
+        fn_warm()
+        best = None
+        for _ in range(reps):
+            barrier()
+            t0 = time.perf_counter()
+            seen = fn()
+            t_host = time.perf_counter() - t0          # everything enqueued
+            barrier()
+            dt = time.perf_counter() - t0
+            if best is None or dt < best[0]:
+                best = (dt, t_host, seen)
+        return best
+
+    results = {}
+    for name, prefetch in (("prefetch", 2), ("inline", 0)):
+        collate = DeviceCollate(bank.audio, bank.lengths_host, bank.labels, L, seed=99, replica=rank)
+        run = lambda ids: train_epoch(trainer, collate, ids, std, writer, 0, prefetch=prefetch)
+        results[name] = timed(lambda: run(id_batches(args.warmup, 1)), lambda: run(id_batches(args.steps, 2)))
+    # the resident-tensor step of the bench line in the same process: same trainer, frontend in the same (train) mode
+    pcm_res = bank.audio[:B].contiguous()
+    labels_res = bank.labels[:B].contiguous()
+
+    def resident(n):
+        for _ in range(n):
+            trainer.step(pcm_res, labels_res)
+        return n * B
+
+    results["resident"] = timed(lambda: resident(args.warmup), lambda: resident(args.steps))
+    writer.close()
+    mode = "prefetch" if results["prefetch"][0] <= results["inline"][0] else "inline"
+    dt, t_host, seen = results[mode]
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = tmax.item()
+    # host cost of one batch's collate preparation on its own (draws + sort + packed staging buffer)
+    probe = DeviceCollate(bank.audio, bank.lengths_host, bank.labels, L, seed=7)
+    ids = id_batches(1, 3)[0]
+    t0 = time.perf_counter()
+    for _ in range(50):
+        probe.prepare(ids)
+    prep_us = (time.perf_counter() - t0) / 50 * 1e6
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_entry_baseline(L, C, B, args.cpu_baseline_seconds)
+    if rank == 0:
+        ms = lambda r: round(r[0] / args.steps * 1e3, 4)
+        res_ms = ms(results["resident"])
+        out = {
+            "metric": f"utterances/sec/node (res8 entry-point loop: device collate + train-mode frontend + training step, "
+                      f"{L / 16000:g}s@16kHz, 40-mel)",
+            "value": round(seen * world / dt, 1), "unit": "utterances/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"training.run.pretrain_gsc's epoch body (howl_amd.training.run.pretrain_gsc.train_epoch) on a "
+                                   f"device-resident bank of {n_clips} synthetic clips (every tenth shorter than the window): shuffled "
+                                   f"ids -> DeviceCollate (truncate, Timeshift, Noise, batchify; host draws in the reference's order) -> "
+                                   f"VTLP draw + log-mel -> res8 fwd + xent + bwd + AdamW -> loss to the workspace writer; "
+                                   f"{B} utterances per GPU and step, {C} labels -- BASELINE {cfg_desc}",
+                       "name": args.config, "loop": "entry", "collate": mode, "global_batch": B * world,
+                       "samples_per_utterance": L, "labels": C, "parallelism": f"dp{world}" if world > 1 else "single",
+                       "frontend": "vtlp-train"},
+            "loop": {"ms_per_step_prefetch_thread": ms(results["prefetch"]), "ms_per_step_inline_collate": ms(results["inline"]),
+                     "ms_per_step_resident_tensors": res_ms,
+                     "entry_over_resident": round(res_ms / (dt / args.steps * 1e3), 4),
+                     "host_enqueue_ms_per_step": round(t_host / args.steps * 1e3, 4),
+                     "host_enqueue_ms_per_step_resident": round(results["resident"][1] / args.steps * 1e3, 4),
+                     "collate_prepare_us_per_batch": round(prep_us, 1),
+                     "note": "resident = trainer.step on one batch already in HBM (the default bench line's loop, frontend in train "
+                             "mode here); host_enqueue = wall time until the last launch of the K steps was issued (when it is "
+                             "close to ms_per_step the host is the limiter)"},
+            "roofline": None, "cpu_baseline": cpu, "eval_agreement": None, "rccl": None,
+        }
+        print(json.dumps(out), flush=True)
+    import shutil
+    shutil.rmtree(tmp, ignore_errors=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def bench_eval(args, dev):
     """f2: the evaluation side of the metric.  The reference's ``FrameInferenceEngine`` scores a clip one 500 ms window per
     63 ms stride, each a batch-1 forward with a device->host copy (``inference.py:223-267``); the product scores all windows
@@ -383,6 +564,8 @@ def main():
             raise SystemExit(f"bench.py: the {backend} process group has {dist.get_world_size()} ranks, expected {world}")
     if args.config == "eval":
         return bench_eval(args, dev)
+    if args.loop == "entry":
+        return bench_entry(args, dev, rank, world)
 
     from howl_amd import lib as hlib
     from howl_amd.data.transform.operator import ZmuvTransform

@@ -1220,7 +1220,7 @@ static int head_bwd_impl(const HowlHeadParams* p, const float* x, int rows_inner
     auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
     bool dx_done = false;
     if (head_is_thin(n_hid, n_out) && dx != nullptr && n_hid == HB_HID && n_in == HB_IN && rows >= rowgemm_min_rows() &&
-        rows < (1 << 22) && al16(y1) && al16(dz1) && al16(dx) && al16(p->w2) && getenv("HOWL_GEMM_NO_ROWGEMM") == nullptr) {
+        rows < (1 << 20) && al16(y1) && al16(dz1) && al16(dx) && al16(p->w2) && getenv("HOWL_GEMM_NO_ROWGEMM") == nullptr) {
         // many rows: second layer's backward + ReLU mask + dx = dz1 W1 in one launch, one slab of partial sums per workgroup
         float* thin = first + (size_t)HEAD_W1_SPLITS * n_hid * n_in;
         const int ntiles = (rows + 15) / 16;

@@ -26,14 +26,6 @@ class WordTranscriptSearcher:
     def contains_any(self, item: str) -> bool:
         return any(e != self.vocab.oov_token_id for e in self.tokenizer.encode(item))
 
-    def count_vocab(self, item: str, ignore_oov: bool = True) -> dict:
-        counter = dict((self.vocab[i], 0) for i in range(len(self.vocab)))
-        for e in self.tokenizer.encode(item):
-            if ignore_oov and e == self.vocab.oov_token_id:
-                continue
-            counter[self.vocab[e]] += 1
-        return counter
-
 
 class LabelColoring:
     """label -> colour: labels that share a colour are alternatives for the same position of the wake sequence (the phones

@@ -72,8 +72,8 @@ class ClipBank:
     def index_batches(self, batch_size: int, shuffle: bool, drop_last: bool, generator=None):
         """Lists of clip ids per batch (for DeviceCollate, which gathers / augments / pads on the device)."""
         n = len(self)
-        perm = (torch.randperm(n, generator=generator) if shuffle else torch.arange(n)).tolist()
-        end = n - (n % batch_size) if drop_last else n
+        perm = (torch.randperm(n, generator=generator) if shuffle else torch.arange(n)).numpy()   # id arrays, not lists:
+        end = n - (n % batch_size) if drop_last else n                                            # the collate indexes with them
         for i in range(0, end, batch_size):
             yield perm[i:i + batch_size]
 

@@ -46,7 +46,8 @@ class FusedTrainer:
 
     def __init__(self, model, std_transform, zmuv_transform, lr, weight_decay=0.0, betas=(0.9, 0.999), eps=1e-8,
                  process_group=None, late_grads=None):
-        """``late_grads`` (data-parallel res8 only; default from ``HOWL_DP_LATE``, else "overlap"):
+        """``late_grads`` (data-parallel res8 only; default from ``HOWL_DP_LATE``, else "merged" -- the schedule with fewer
+        unknowns until a SCALE record on the 8-GPU node says which wins):
         "overlap" -- two-part backward, TWO collectives per step: everything but conv0's 405 gradients is reduced under
                      conv0's weight-gradient kernels (async), the 405 floats after them (on the critical path);
         "merged"  -- one-part backward, ONE collective per step over the whole flat buffer (nothing overlapped: pays when
@@ -59,7 +60,7 @@ class FusedTrainer:
         self.step_count = 0
         self.group = process_group
         self.rank, self.world = parallel.world_info(process_group)
-        self.late_grads = late_grads or os.environ.get("HOWL_DP_LATE", "overlap")
+        self.late_grads = late_grads or os.environ.get("HOWL_DP_LATE", "merged")
         if self.late_grads not in ("overlap", "merged"):
             raise ValueError(f"late_grads / HOWL_DP_LATE must be 'overlap' or 'merged', got {self.late_grads!r}")
         self.collectives_last_step = 0     # gradient collectives the last step issued (bench.py reports it)
@@ -104,6 +105,11 @@ class FusedTrainer:
             # split on a 256-byte boundary of the flat buffer (RCCL's vectorised paths want aligned base addresses): the few
             # gradients of the next parameter that move to the late collective are final after part 1 as well
             n0 = min(-(-n0 // 64) * 64, self.fp.numel)
+            # what that rounding relies on: an aligned base, and that the parameters the spill-over touches are complete
+            # after part 1 (the model declares how many leading parameters part 2 still writes: only the first `late`)
+            assert self.fp.grad.data_ptr() % 256 == 0, "flat gradient buffer must be 256-byte aligned for the split"
+            assert sum(p.numel() for p in self.fp.params[:late + 1]) >= n0 or late + 1 >= len(self.fp.params), \
+                "the rounded split must end inside the first parameter that is final after part 1"
             self.model._launch_backward(feat, dlogits, out_grads=self.fp.grad_views, part=1, **bwd_kw)
             pending = parallel.allreduce_start_(self.fp.grad[n0:], self.group)
             self.model._launch_backward(feat, dlogits, out_grads=self.fp.grad_views, part=2, **bwd_kw)

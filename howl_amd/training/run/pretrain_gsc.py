@@ -30,6 +30,25 @@ from howl_amd.utils.random_utils import set_random_seed
 from howl_amd.workspace import Workspace
 
 
+def train_epoch(trainer, collate, id_batches, std_transform, writer, epoch_idx, needs_lengths=False, prefetch=2):
+    """The loop body of ``training/run/pretrain_gsc.py:120-133`` over one epoch's batches of clip ids: collate (truncate,
+    Timeshift, Noise, batchify on the device) -> frontend in train mode (VTLP draw) -> fused training step -> loss logging
+    without a host synchronisation.  ``prefetch`` > 0: the host half of the collate (draws, sort, packed staging buffer) runs
+    that many batches ahead in a worker thread (``DeviceCollate.prefetch``), as the reference's DataLoader workers do.
+    Returns the number of utterances trained on.  (``bench.py --loop entry`` times exactly this function.)"""
+    batches = collate.prefetch(id_batches, depth=prefetch) if prefetch else (collate(ids) for ids in id_batches)
+    seen = 0
+    for batch in batches:
+        if needs_lengths:
+            loss = trainer.step(batch.audio_data, batch.labels, std_transform.compute_lengths(batch.lengths),
+                                int(std_transform.compute_lengths(torch.tensor(collate.last_max_len))))
+        else:
+            loss = trainer.step(batch.audio_data, batch.labels)
+        writer.add_scalar("Training/Loss", loss.detach(), epoch_idx)     # stays on the device until flush
+        seen += batch.audio_data.shape[0]
+    return seen
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--model", type=str, choices=RegisteredModel.registered_names(), default="res8")
@@ -122,25 +141,27 @@ def main(argv=None):
                            weight_decay=SETTINGS.training.weight_decay)
     trainer.broadcast_parameters()                                     # rank 0's initial weights and BatchNorm buffers
     needs_lengths = getattr(model, "NEEDS_LENGTHS", False)
-    # train_comp = compose(truncate, Timeshift.train(), Noise.train(), batchify) (pretrain_gsc.py:78-80), on the device
+    # train_comp = compose(truncate, Timeshift.train(), Noise.train(), batchify) (pretrain_gsc.py:78-80), on the device.  The
+    # collate owns its `random` stream, as each of the reference's DataLoader workers does (a worker thread prepares the next
+    # batches while the main thread -- whose global `random` VTLP draws from -- launches the current one)
     train_collate = DeviceCollate(train.audio, train.lengths_host, train.labels, max_len, sr=sample_rate,
-                                  seed=SETTINGS.training.seed if world > 1 else None, replica=rank)
+                                  seed=SETTINGS.training.seed, replica=rank)
     dev_acc = 0
+
+    def shards(id_batches):
+        for ids in id_batches:
+            ids = parallel.shard(ids)
+            if not len(ids):
+                raise RuntimeError(f"BATCH_SIZE={SETTINGS.training.batch_size} leaves rank {rank} of {world} without utterances")
+            yield ids
+
     for epoch_idx in range(SETTINGS.training.num_epochs):
         model.train()
         std_transform.train()
         gen = torch.Generator().manual_seed(SETTINGS.training.seed + 7919 * (epoch_idx + 1))   # the same order on every rank
-        for ids in train.index_batches(SETTINGS.training.batch_size, shuffle=True, drop_last=True, generator=gen):
-            ids = parallel.shard(ids)
-            if not ids:
-                raise RuntimeError(f"BATCH_SIZE={SETTINGS.training.batch_size} leaves rank {rank} of {world} without utterances")
-            batch = train_collate(ids)
-            if needs_lengths:
-                loss = trainer.step(batch.audio_data, batch.labels, std_transform.compute_lengths(batch.lengths),
-                                    int(std_transform.compute_lengths(torch.tensor(train_collate.last_max_len))))
-            else:
-                loss = trainer.step(batch.audio_data, batch.labels)
-            writer.add_scalar("Training/Loss", loss.detach(), epoch_idx)     # stays on the device until flush
+        train_epoch(trainer, train_collate,
+                    shards(train.index_batches(SETTINGS.training.batch_size, shuffle=True, drop_last=True, generator=gen)),
+                    std_transform, writer, epoch_idx, needs_lengths)
         trainer.decay_lr(SETTINGS.training.lr_decay)
         dev_acc = evaluate_accuracy(dev, "Dev", epoch_idx, save=True)
     test_acc = evaluate_accuracy(test, "Test")

@@ -38,9 +38,15 @@ class ScalarWriter:
             self.flush()
 
     def flush(self):
+        # device scalars come over in ONE copy (a .item() per value was one synchronising read-back each)
+        dev = [(i, v) for i, (_, v, _) in enumerate(self._pending) if torch.is_tensor(v) and v.is_cuda]
+        host = {}
+        if dev:
+            vals = torch.stack([v.detach().reshape(()).float() for _, v in dev]).cpu().tolist()
+            host = {i: x for (i, _), x in zip(dev, vals)}
         with self.path.open("a") as f:
-            for tag, value, step in self._pending:
-                v = float(value.item()) if torch.is_tensor(value) else float(value)
+            for i, (tag, value, step) in enumerate(self._pending):
+                v = host[i] if i in host else (float(value.item()) if torch.is_tensor(value) else float(value))
                 f.write(json.dumps({"tag": tag, "value": v, "step": step}) + "\n")
         self._pending = []
 

@@ -62,7 +62,7 @@ def test_golden_eval_and_train(golden, C):
             a = og[n].abs().double()
             noise[n] = torch.maximum(noise[n], (4e-6 * a.max() / a.clamp_min(1e-30)).clamp(max=1.0))
     sd = model.state_dict()
-    tight = 0
+    tight = drifted = 0
     for k, v in sd.items():
         ref = t(g["sd3." + k]).double()
         d = (v.detach().cpu().double() - ref).abs()
@@ -71,10 +71,21 @@ def test_golden_eval_and_train(golden, C):
             # BatchNorm statistics sit downstream of the few O(lr) weight differences: relative agreement
             assert d.max().item() < 1e-3 * max(1.0, float(ref.abs().max())), k
         elif k in noise:
-            excess = d - (tol + 3 * 0.01 * noise[k] + (sd_o[k].double() - ref).abs())
+            # the oracle's own distance from the reference's trajectory widens a weight's band, so it is BOUNDED here: a
+            # drifting oracle must fail this test instead of relaxing it (VERDICT r4 / ADVICE r4): at most 5e-4 anywhere
+            # (measured 2.7e-4), above 1e-4 on fewer than 0.1 % of the weights (measured nine of 111 k)
+            odist = (sd_o[k].double() - ref).abs()
+            assert odist.max().item() < 5e-4, (k, "oracle trajectory drifted from the golden", odist.max().item())
+            drifted += int((odist > 1e-4).sum())
+            excess = d - (tol + 3 * 0.01 * noise[k] + odist)
             assert excess.max().item() < 0, (k, excess.max().item())
+            # and, independently of the reference band, the HIP weights against the oracle's at the oracle-derived noise only
+            d_o = (v.detach().cpu().double() - sd_o[k].double()).abs()
+            assert (d_o - (tol + 3 * 0.01 * noise[k])).max().item() < 0, (k, "vs oracle")
             tight += int((noise[k] < 1e-2).sum())
-    assert tight > 0.95 * sum(v.numel() for v in noise.values())      # tolerances above 4e-4 for a small minority only
+    nw = sum(v.numel() for v in noise.values())
+    assert tight > 0.95 * nw                                          # tolerances above 4e-4 for a small minority only
+    assert drifted < 1e-3 * nw, drifted
     assert int(sd["bn3.num_batches_tracked"]) == 3
     model.eval()
     with torch.no_grad():
@@ -87,6 +98,7 @@ def test_golden_eval_and_train(golden, C):
     # (plus what the oracle's own trajectory on this host's CPU ends away from it, for the same reason)
     ref_after = t(g["eval_logits_after3"])
     slack = maxerr(om.res8_forward(sd_o, x, False), ref_after)
+    assert slack < 5e-4 * max(1.0, ref_after.abs().max().item() / 40), slack     # bounded: a drifting oracle fails here
     assert maxerr(after, ref_after) < max(LOGIT_TOL, 1e-4 * ref_after.abs().max().item()) + slack
     assert torch.equal(after.argmax(1).cpu(), ref_after.argmax(1))
 

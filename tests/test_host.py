@@ -106,6 +106,49 @@ def test_device_collate_follows_reference_rng_protocol(golden):
                 assert g[f"first_{trial}"][k] > 0.5 * shift[k] * 1e-5 - 5e-3
 
 
+def test_device_collate_array_draws_are_the_reference_draws(golden):
+    """The batched form the entry points use (``DeviceCollate.draw_arrays``: numpy's MT19937 loaded with the ``random``
+    stream's state) against G7b -- the golden's trials were drawn from ``random.seed(seed)``, so a ``random.Random(seed)`` must
+    give the same crops and end at the same position of the stream -- and against the scalar ``draw`` element for element, for
+    a private stream (kept in numpy between batches) and for the global ``random`` module (handed back after every batch)."""
+    import random
+    from howl_amd.data.collate import DeviceCollate
+    g = golden("g7b_collate_protocol")
+    lens = g["lens"].tolist()
+    mk = lambda ls, **kw: DeviceCollate(torch.zeros(1, 1), torch.tensor(ls), torch.zeros(len(ls), dtype=torch.long), 16000, **kw)
+    for trial, seed in enumerate((0, 1, 2, 5)):
+        dc = mk(lens)
+        dc.rand = random.Random(seed)
+        tl, shift, head, sigma, sp = dc.draw_arrays(list(range(len(lens))))
+        assert (tl - shift).tolist() == g[f"out_len_{trial}"].tolist()
+        probe = random.Random(seed)
+        for v in g[f"draws_{trial}"]:
+            assert probe.random() == float(v)
+        assert dc.rand.random() == probe.random(), "consumed a different number of draws than the reference"
+    rng = np.random.default_rng(3)
+    many = rng.integers(6000, 20000, size=700).tolist()
+    for seed in (0, 1, 7, None):
+        if seed is None:
+            random.seed(1234)
+            st = random.getstate()
+        a, b = mk(many, seed=seed), mk(many, seed=seed)
+        got, want = [], []
+        for rep in range(4):
+            ids = rng.permutation(len(many))[:256]
+            want.append((ids, a.draw(ids.tolist())))
+        tail = a.rand.random()
+        if seed is None:
+            random.setstate(st)
+        for ids, w in want:
+            r = b.draw_arrays(ids)
+            for x, y in zip(w, r):
+                assert x == [type(x[0])(v) for v in y.tolist()]
+        assert b.rand.random() == tail
+        if seed is not None:      # scalar draws after array draws see the advanced stream
+            ids = rng.permutation(len(many))[:64].tolist()
+            assert b.draw(ids) == a.draw(ids)
+
+
 def test_device_collate_mixer_draws_match_reference(golden):
     """DeviceCollate.draw_mixer makes DatasetMixer's draws (background choice, window, alpha) in the reference's order: the
     mix rebuilt from them equals the reference class's output (G9) and the random stream ends at the same position."""
