@@ -204,16 +204,7 @@ __device__ __forceinline__ float fold_bit2(float lo, float hi, bool bit) {   // 
 #define HOWL_OPAQUE_S(x) asm volatile("" : "+s"(x))
 #endif
 
-#if defined(HOWL_DIAG_PROBE)  // diagnostic build (tools/probe_logmel.py): s_memtime stamps of workgroup 0, [wave][slot]
-__device__ unsigned long long* g_howl_probe_fe = nullptr;
-#define HOWL_FE_PROBE(wave_, lane_, slot_)                                                 \
-    do {                                                                                   \
-        if (g_howl_probe_fe != nullptr && blockIdx.x == 0 && (lane_) == 0 && (slot_) < 64) \
-            g_howl_probe_fe[(wave_) * 64 + (slot_)] = __builtin_amdgcn_s_memtime();         \
-    } while (0)
-#else
 #define HOWL_FE_PROBE(wave_, lane_, slot_) ((void)0)
-#endif
 
 // Waves per CU and the transpose tile of a wave: [frame][n2 row][k1] complex elements with row pitch XR and frame pitch XF.
 // The compiler pairs the 8-byte accesses (ds_write2_b64: 8-lane groups writing 16 contiguous bytes each; ds_read2_b64: 16-lane
@@ -256,11 +247,6 @@ __global__ __launch_bounds__(NWAVES * 64) void logmel_kernel(const float* __rest
     // reflect padding (torch.stft(center=True)).  Quads whose four frames lie inside one utterance and need no padding are
     // sixteen 8-byte loads at immediate offsets from one base; the others pay per-sample index arithmetic.
     auto fetch = [&](int qq, int bq, int tq, v2f (&x)[16]) {
-#if defined(HOWL_DIAG_LOGMEL_NOLOAD)   // diagnostic build (tools/logmel_variants.py): no global loads
-#pragma unroll
-        for (int n1 = 0; n1 < 16; ++n1) x[n1] = v2f{(float)(lane + n1 + qq) * 1e-3f, (float)(lane - n1) * 1e-3f};
-        return;
-#endif
         const int g0 = QUAD * qq;
         const bool fast = aligned != 0 && tq + 3 < T && HOP * tq >= N_FFT / 2 && HOP * (tq + 3) + N_FFT / 2 <= L && g0 + 3 < total_frames;
         if (fast) {
@@ -359,10 +345,6 @@ __global__ __launch_bounds__(NWAVES * 64) void logmel_kernel(const float* __rest
         v2f xn[16];
         if (has_next) fetch(qn, bn, tn, xn);
         float P[NSLOT];
-#if defined(HOWL_DIAG_LOGMEL_NOFFT)   // diagnostic build: the transform and the recombination replaced by a copy
-#pragma unroll
-        for (int sl = 0; sl < NSLOT; ++sl) P[sl] = z[sl & 15].x * z[sl & 15].y;
-#else
         // ---- FFT step 1: DFT-16 over n1 of the windowed samples, twiddle, transpose through LDS ------------------------
         dft16(z);
 #pragma unroll
@@ -405,7 +387,6 @@ __global__ __launch_bounds__(NWAVES * 64) void logmel_kernel(const float* __rest
             P[8 + r] = yk.x * yk.x + yk.y * yk.y;
         }
         P[16] = 4.0f * (z[8].x * z[8].x + z[8].y * z[8].y);   // bin 128 = Z[128] itself (class 0; the other classes' weight is 0)
-#endif
         // ---- mel contraction + block sum + epilogue, in two passes over the mel groups (halves the live accumulators: the whole
         // kernel has to fit the register budget of its wave count) -----------------------------------------------------
         // D_j[frame][mel] += P[frame][bin(j, s)] * fb[bin(j, s)][mel] on 16 independent 4x4 blocks j; lane 4j + c then holds
@@ -483,18 +464,9 @@ __global__ __launch_bounds__(NWAVES * 64) void logmel_kernel(const float* __rest
                 }
             }
         };
-#if defined(HOWL_DIAG_LOGMEL_NOMEL)   // diagnostic build: no contraction / block sum / epilogue, one store keeps the powers alive
-        {
-            float acc0 = 0.0f;
-#pragma unroll
-            for (int sl = 0; sl < NSLOT; ++sl) acc0 += P[sl];
-            if (g_frame < total_frames && c_out == 0 && (lane >> 2) < 10) out[o_base + (long)(4 * (lane >> 2)) * o_ms] = acc0;
-        }
-#else
         mel_pass(std::integral_constant<int, 0>{});
         HOWL_FE_PROBE(wave, lane, pslot++);   // contracted (first half)
         mel_pass(std::integral_constant<int, NH>{});
-#endif
         HOWL_FE_PROBE(wave, lane, pslot++);   // stored
         if (has_next) apply_window(xn);
         b0 = bn;
@@ -802,11 +774,6 @@ __global__ __launch_bounds__(256) void gather_windows_kernel(const float* __rest
 
 }  // namespace
 
-#if defined(HOWL_DIAG_PROBE)
-extern "C" int howl_diag_set_probe_fe(unsigned long long* buf) {
-    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_howl_probe_fe), &buf, sizeof(buf));
-}
-#endif
 
 extern "C" {
 

@@ -1058,6 +1058,17 @@ size_t howl_lstm_workspace_bytes(int B, int T) {
             bias_slabs * G4) * sizeof(float) + 1024;
 }
 
+// (the four-sequence recurrence multiplies x_t W_ih^T itself when M = 40: no projection launch, gx unused)
+static bool lstm_fuse_x(const HowlLstmParams* p, int B, int T, int M, int xf) {
+    return !lstm_rows16(B, T) && M == 40 && (reinterpret_cast<uintptr_t>(p->w_ih) & 15) == 0 &&
+           (size_t)B * (size_t)xf * M * sizeof(float) < ((size_t)1 << 32) && getenv("HOWL_LSTM_NO_FUSED_X") == nullptr;
+}
+
+size_t howl_lstm_needs_gx(const HowlLstmParams* p, int B, int T, int M, int x_frames) {
+    if (p == nullptr || p->w_ih == nullptr) return 1;
+    return lstm_fuse_x(p, B, T, M, x_frames > 0 ? x_frames : T) ? 0 : 1;
+}
+
 int howl_lstm_fwd(const HowlLstmParams* p, const float* x, int B, int T, int M, const long long* lengths, const float* h0,
                   const float* c0, const HowlLstmSaved* sv, float* hT, float* cT, void* ws, size_t ws_bytes,
                   hipStream_t stream) {
@@ -1078,9 +1089,9 @@ int howl_lstm_fwd(const HowlLstmParams* p, const float* x, int B, int T, int M, 
         hipLaunchKernelGGL(lstm_pack_kernel, dim3(16 * 64 * 64 / 256), dim3(256), 0, stream, p->w_hh, pf, pb, p->b_ih, p->b_hh, bsum);
     const int xf = sv->x_frames > 0 ? sv->x_frames : T;
     HOWL_REQUIRE(xf >= T, "howl_lstm_fwd: x_frames=%d < T=%d", xf, T);
-    // (the four-sequence recurrence multiplies x_t W_ih^T itself when M = 40: no projection launch, gx unused)
-    const bool fuse_x = !rows16 && M == 40 && (reinterpret_cast<uintptr_t>(p->w_ih) & 15) == 0 &&
-                        (size_t)B * (size_t)xf * M * sizeof(float) < ((size_t)1 << 32) && getenv("HOWL_LSTM_NO_FUSED_X") == nullptr;
+    const bool fuse_x = lstm_fuse_x(p, B, T, M, xf);
+    HOWL_REQUIRE(fuse_x || sv->gx != nullptr, "howl_lstm_fwd: saved->gx is NULL but this shape runs the projection GEMM "
+                                              "(howl_lstm_needs_gx)");
     if (!fuse_x)
         gemm(stream, true, x, xf == T ? lin(M) : RowMap{T, (long)xf * M, M}, 1, lin(0), p->w_ih, lin(1), M, B * T, G4, M, 1,
              rows16 ? bsum : nullptr, 0, sv->gx, G4, 0);

@@ -113,16 +113,7 @@ __device__ __forceinline__ void pack_weights_one(const HowlPtrs6& w, float* __re
     dst[idx] = v;
 }
 
-#if defined(HOWL_DIAG_PROBE)  // diagnostic build (tools/probe_step4.py): s_memtime stamps of one workgroup, [wave][slot]; the
-                               // buffer and the block index travel in StageCfg (filled on the host from howl_diag_set_probe)
-#define HOWL_PROBE(cfg_, wave_, lane_, slot_)                                                                    \
-    do {                                                                                                         \
-        if ((cfg_).probe != nullptr && (int)blockIdx.x == (cfg_).probe_block && (lane_) == 0 && (slot_) < 64)    \
-            (cfg_).probe[(wave_) * 64 + (slot_)] = __builtin_amdgcn_s_memtime();                                  \
-    } while (0)
-#else
 #define HOWL_PROBE(cfg_, wave_, lane_, slot_) ((void)0)
-#endif
 
 // ---------------------------------------------------------------------------------------------------------
 // shared pieces of the MFMA kernels
@@ -207,40 +198,10 @@ __device__ __forceinline__ void k_begin(KCursor<NTW>& k, f32x4 (&acc)[NTW], cons
 // `groups` channel groups (4 input channels x 9 taps each) of the K loop
 template <int NTW>
 __device__ __forceinline__ void k_run(KCursor<NTW>& k, f32x4 (&acc)[NTW], int CS, int groups) {
-#if defined(HOWL_DIAG_CONV_NOK)  // diagnostic build: everything but the K loop
-    groups = 0;
-#endif
     // two K groups per trip: the segments of conv_loop are 2, 2, 2 | 2, 2, 1 groups long, i.e. straight-line code; the operand
     // reads of a group are then scheduled under the MFMAs of the one before it (one group per trip: +16 us per c3 step)
-#if defined(HOWL_DIAG_KNOUNROLL)
-#pragma nounroll
-#else
 #pragma unroll 2
-#endif
     for (int g = 0; g < groups; ++g) {
-#if defined(HOWL_DIAG_CONV_NOLDS) || defined(HOWL_DIAG_CONV_NOMFMA) || defined(HOWL_DIAG_K_NOPIPE)
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int off = (tap / 3) * WP + (tap % 3);
-#if defined(HOWL_DIAG_CONV_NOLDS)   // diagnostic build: MFMA chain fed from registers (tools/variants4.py)
-            const float b = __builtin_bit_cast(float, g + tap);
-#pragma unroll
-            for (int i = 0; i < NTW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(b, b, acc[i], 0, 0, 0);
-#elif defined(HOWL_DIAG_CONV_NOMFMA)  // diagnostic build: LDS traffic only
-            const float b = k.bp[tap * 64];
-#pragma unroll
-            for (int i = 0; i < NTW; ++i) acc[i][0] += k.ap[i][off] * b;
-#else                                 // diagnostic build: the schedule left to the compiler (rounds 1-3)
-            const float b = k.bp[tap * 64];
-#pragma unroll
-            for (int i = 0; i < NTW; ++i)
-                acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(k.ap[i][off], b, acc[i], 0, 0, 0);
-#endif
-        }
-        k.bp += 9 * 64;
-#pragma unroll
-        for (int i = 0; i < NTW; ++i) k.ap[i] += 4 * CS;
-#else
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             float na[NTW], nb;
@@ -263,7 +224,6 @@ __device__ __forceinline__ void k_run(KCursor<NTW>& k, f32x4 (&acc)[NTW], int CS
             for (int i = 0; i < NTW; ++i) k.a[i] = na[i];
             k.b = nb;
         }
-#endif
     }
 }
 
@@ -272,9 +232,6 @@ __device__ __forceinline__ void k_run(KCursor<NTW>& k, f32x4 (&acc)[NTW], int CS
 // relative to the cursor (which carries the lane group's channel offset g * CS of the full blocks).
 template <int NTW>
 __device__ __forceinline__ void k_tail(KCursor<NTW>& k, f32x4 (&acc)[NTW], const int (&dl)[3]) {
-#if defined(HOWL_DIAG_CONV_NOK)
-    return;
-#endif
 #pragma unroll
     for (int s3 = 0; s3 < 3; ++s3) {
         const float b = k.bp[s3 * 64];
@@ -312,11 +269,7 @@ static_assert(KG_A == 6 && KG_B == 5, "the segment schedule of conv_loop is writ
 // Falling wave priority along a phase (3, 2, 1 over its three K segments): a wave that is ahead yields the matrix pipe to the
 // ones behind it, so that the waves of a SIMD reach the barrier together instead of the oldest one finishing at 2/3 of the
 // phase and the last one running alone, at half the pipe rate (tools/probe_step4.py; -1 us per forward launch).
-#if defined(HOWL_DIAG_NOSTAIR)
-#define HOWL_STAIR(p_) ((void)0)
-#else
 #define HOWL_STAIR(p_) __builtin_amdgcn_s_setprio(p_)
-#endif
 
 struct StageCfg {
     const float* a;       // forward: s_{i-1}; data gradient: dz_i (plain) or dx_i (fused; nullptr: broadcast of dpool / P, layer 6)
@@ -328,10 +281,6 @@ struct StageCfg {
     bool fused;
     bool even;            // fused: layer i has a residual add (mask in the sign bit of s_i) or not (mask = s_i > 0)
     bool affine;          // forward: normalise on load
-#if defined(HOWL_DIAG_PROBE)
-    unsigned long long* probe;
-    int probe_block;
-#endif
 };
 
 struct SlotVal {
@@ -501,12 +450,7 @@ __device__ __forceinline__ void conv_epilogue(const f32x4 (&acc)[NTW], const flo
                         u1 += v0 * fmaf(fabsf(sv.x), e.xrstd, e.xshift) + v1 * fmaf(fabsf(sv.y), e.xrstd, e.xshift);
                     }
                 }
-#if defined(HOWL_DIAG_CONV_NOSTORE)
-                if (v0 == 123.456f)  // diagnostic build: epilogue without its global stores
-                    *reinterpret_cast<float2*>(obase + (ea.boff + ea.tstep * i + 8u * hh)) = make_float2(v0, v1);
-#else
                 *reinterpret_cast<float2*>(obase + (ea.boff + ea.tstep * i + 8u * hh)) = make_float2(v0, v1);
-#endif
             }
         }
     }
@@ -530,41 +474,8 @@ struct ConvLoop {
     const float* lm;
     int B, CS, t0, lane, tid;
     int nblk;   // utterance strides of the batch loop: workgroups (or groups of `slices` workgroups) sharing the batch
-#if defined(HOWL_DIAG_WINO)
-    const float* wino_w;   // global weights (streamed again per K chunk in the skeleton)
-    float* wino_l;         // LDS weight area
-#endif
 };
 
-#if defined(HOWL_DIAG_WINO)
-// TIMING SKELETON of a Winograd F(2x2, 3x3) forward (tools/variants4.py "wino"; WRONG results by design): what such a kernel
-// would have to execute per utterance around the same tiles -- 2,880 instead of 5,202 MFMAs (16 component GEMMs of 80 x 48 x 48
-// on 16x16x4 tiles = 55 %), the input and output transforms on the vector pipe (32 + 24 additions per 4x4 tile and channel:
-// ~230 per thread), the transformed tile through LDS (4x the input volume: ~63 more ds_write per thread), 16 x 48 x 48 fp32 of
-// transformed weights (147 KB: does not fit next to the map) streamed from L2 once per utterance in six input-channel chunks,
-// and a barrier on either side of every chunk's multiply.  One call per K chunk:
-__device__ __forceinline__ float wino_chunk_work(const ConvLoop& c, float seed) {
-    float t0 = seed, t1 = seed + 1.0f, t2 = seed + 2.0f, t3 = seed + 3.0f;
-#pragma unroll
-    for (int i = 0; i < 10; ++i) {          // 40 of the ~230 transform instructions, four independent chains
-        t0 = fmaf(t0, 1.0001f, 0.5f);
-        t1 = fmaf(t1, 0.9999f, 0.25f);
-        t2 = fmaf(t2, 1.0002f, 0.125f);
-        t3 = fmaf(t3, 0.9998f, 0.0625f);
-    }
-    float4 wv[8];                           // 1/6 of the transformed weights: 8 x 16 B per thread from L2 -> LDS
-#pragma unroll
-    for (int j = 0; j < 8; ++j) wv[j] = reinterpret_cast<const float4*>(c.wino_w)[(c.tid + j * CONV_THREADS) % (3 * KSTEPS * 16)];
-#pragma unroll
-    for (int j = 0; j < 10; ++j) c.tile[CP * c.CS + ((c.tid + 37 * j) & 31)] = t0 + (float)j;      // (the tile's slack words)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        wv[j].x += t1;
-        reinterpret_cast<float4*>(c.wino_l)[(c.tid + j * CONV_THREADS) % (3 * KSTEPS * 16)] = wv[j];
-    }
-    return t0 + t1 + t2 + t3;
-}
-#endif
 
 // All utterances b, b + nblk, ... of this workgroup; on entry channels 0..23 of utterance b are in the tile (barrier passed).
 // Instantiated once per tile count (waves of one workgroup run different instances; every instance executes the same two
@@ -594,31 +505,10 @@ __device__ __forceinline__ void conv_loop(const ConvLoop& c, const ConvEpilogue&
         if constexpr (NTW > 0) k_begin<NTW, TS>(k, acc, c.ltile, c.wnt, c.CS, P, c.t0, lane);
         if constexpr (NTW > 0) k_prime<NTW>(k);
         // ---- phase A: channels 0..23 feed the matrix pipe, channels 24..44 of this utterance arrive
-#if defined(HOWL_DIAG_NOSTAGE)   // diagnostic build (tools/variants4.py; WRONG results): the phases without their staging work
-        constexpr bool STAGE = false;
-#else
         constexpr bool STAGE = true;
-#endif
-#if defined(HOWL_DIAG_DESYNC)    // diagnostic build: the three waves of a SIMD take their staging bursts at different K groups
-        const int wp = tid >> 8;
-        const int a0 = 1 + wp, a1 = 2, a2 = KG_A - 3 - wp;             // bursts after groups {1,3} {2,4} {3,5}
-        const int b0 = wp == 0 ? 1 : 2, b1 = wp == 1 ? 1 : 2, b2 = KG_B - b0 - b1;   // {1,3} {2,3} {2,4}
-#elif defined(HOWL_DIAG_WINO)
-        const int a0 = 1, a1 = 1, a2 = 1, b0 = 1, b1 = 1, b2 = 1;      // 6 of the 11 K groups, no tail: 53 % of the MFMAs
-#else
         const int a0 = 2, a1 = 2, a2 = KG_A - 4, b0 = 2, b1 = 2, b2 = KG_B - 4;
-#endif
-#if defined(HOWL_DIAG_WINO)
-#define HOWL_WINO_CHUNK()                        \
-    do {                                         \
-        st1 += wino_chunk_work(c, st1);          \
-        __syncthreads();                         \
-    } while (0)
-#define HOWL_WINO_BAR() __syncthreads()
-#else
 #define HOWL_WINO_CHUNK() ((void)0)
 #define HOWL_WINO_BAR() ((void)0)
-#endif
         if constexpr (STAGE) {
             slot_load<MODE>(v[0], cfg, ubase + r1, tid, pk1[0], b);
             slot_load<MODE>(v[1], cfg, ubase + r1, tid + CONV_THREADS, pk1[1], b);
@@ -647,9 +537,7 @@ __device__ __forceinline__ void conv_loop(const ConvLoop& c, const ConvEpilogue&
         HOWL_WINO_BAR();
         HOWL_STAIR(0);
         HOWL_PROBE(cfg, wave, lane, pslot++);   // phase A done
-#if !defined(HOWL_DIAG_NOMIDBAR)   // diagnostic build (with HOWL_DIAG_NOSTAGE): what the barrier in the middle of the K loop costs
         __syncthreads();      // channels 24..44 complete; every wave is past its reads of channels 0..23
-#endif
         HOWL_PROBE(cfg, wave, lane, pslot++);   // barrier
         // ---- phase B: channels 24..44 feed the matrix pipe, channels 0..23 of the NEXT utterance arrive
         if constexpr (NTW > 0) k_prime<NTW>(k);      // (what the last step of phase A requested ahead predates the barrier)
@@ -689,29 +577,17 @@ __device__ __forceinline__ void conv_loop(const ConvLoop& c, const ConvEpilogue&
                     for (int hh = 0; hh < 2; ++hh) ev[i][hh] = *reinterpret_cast<const float2*>(ebase + ea.off(i, hh));
             }
             HOWL_STAIR(1);
-#if defined(HOWL_DIAG_WINO)
-        }
-        HOWL_WINO_CHUNK();
-        if constexpr (NTW > 0) {
-            k_run<NTW>(k, acc, c.CS, b2);
-#else
             k_run<NTW>(k, acc, c.CS, b2);
             k_tail<NTW>(k, acc, dl);
-#endif
             HOWL_STAIR(0);
         }
         HOWL_PROBE(cfg, wave, lane, pslot++);   // phase B done
         // the epilogue runs in front of the barrier: the waves of a SIMD leave the K loop a few hundred cycles apart, and an
         // early one's stores go out under the others' last MFMAs (behind the barrier all twelve epilogues ran with the matrix
         // pipe idle: +1.6 us per forward launch, tools/variants4.py)
-#if defined(HOWL_DIAG_EPI_AFTER)
-        __syncthreads();
-#endif
         if constexpr (NTW > 0) conv_epilogue<MODE, NTW, TS>(acc, ev, epi, ubase, c.t0, lane, st0, st1, b);
         HOWL_PROBE(cfg, wave, lane, pslot++);   // epilogue done
-#if !defined(HOWL_DIAG_EPI_AFTER)
         __syncthreads();      // channels 0..23 of the next utterance complete; every wave is past its reads of 24..44
-#endif
         HOWL_PROBE(cfg, wave, lane, pslot++);   // barrier
     }
 }
@@ -823,11 +699,7 @@ __device__ __forceinline__ void conv3x3_body(
 #pragma unroll
         for (int j = 0; j < 7; ++j) {
             const int i = tid + j * CONV_THREADS;
-#if defined(HOWL_DIAG_CONV_NOWLOAD)  // diagnostic build: weights not fetched
-            wv[j] = make_float4(0.f, 0.f, 0.f, (float)i);
-#else
             wv[j] = (i < 3 * KSTEPS * 16) ? reinterpret_cast<const float4*>(wp)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-#endif
         }
         HOWL_PROBE(cfg, wave, lane, pslot++);   // first tile + weights requested
         if (MODE == 0 && folding) {
@@ -894,11 +766,7 @@ __device__ __forceinline__ void conv3x3_body(
     __syncthreads();  // channels 0..23 of the first utterance in place
     HOWL_PROBE(cfg, wave, lane, pslot++);   // first half tile staged
 
-#if defined(HOWL_DIAG_WINO)
-    const ConvLoop cl{(const lds_f32*)tile, (const lds_f32*)wl + nt * KSTEPS * 64, tile, lm, B, CS, t0, lane, tid, nblk, wp, wl};
-#else
     const ConvLoop cl{(const lds_f32*)tile, (const lds_f32*)wl + nt * KSTEPS * 64, tile, lm, B, CS, t0, lane, tid, nblk};
-#endif
     switch (ntw) {
         case 5: conv_loop<MODE, 5, ts>(cl, epi, cfg, pk0, pk1, b, st0, st1, pslot); break;
         case 4: conv_loop<MODE, 4, ts>(cl, epi, cfg, pk0, pk1, b, st0, st1, pslot); break;
@@ -991,11 +859,6 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_mfma_kernel(StageCfg cfg
     const int x = blockIdx.x & 7, y = blockIdx.x >> 3;
     const int slice = y % SLICES, bid = (y / SLICES) * 8 + x;
     if (bid >= nblk) return;
-#if defined(HOWL_DIAG_CONV_EMPTY)   // diagnostic build (tools/variants4.py): what dispatching 256 x 768 threads with 145 KB of LDS costs
-    if (MODE == 0) return;
-#elif defined(HOWL_DIAG_CONV_PROLOGUE_ONLY)   // ... plus the prologue (weights, statistics fold, first half tile), no utterances
-    if (MODE == 0) B = 0;
-#endif
     conv3x3_body<MODE, SLICES>(cfg, in_stats, wp, res, out, xs, xs_stats, part, pool, B, H, bid, nblk, slice, fold, bfold, wf);
 }
 
@@ -1047,23 +910,13 @@ struct WCursor {
 template <int NB, bool EX>
 __device__ __forceinline__ void wgrad_k_run(WCursor<NB>& c, f32x4 (&acc)[NB][3], f32x4& acce, float (&az)[3], float (&bx)[NB],
                                             float& aze, float& bxe, int rounds) {
-#if defined(HOWL_DIAG_WUNROLL2)   // diagnostic build (tools/variants4.py): two rounds per loop trip
-#pragma unroll 2
-#else
 #pragma nounroll
-#endif
     for (int r = 0; r < rounds; ++r) {
 #pragma unroll
         for (int w = 0; w < PW; ++w) {
             const int noz = (w + 1 < PW) ? (w + 1) : 4 * WPZ;
             const int nox = (w + 1 < PW) ? (w + 1) : 4 * WPW;
             float nz[3], nx[NB], nze = 0.0f, nxe = 0.0f;
-#if defined(HOWL_DIAG_WGRAD_NOLDS)  // diagnostic build: MFMA chains fed from registers (tools/variants.py)
-#pragma unroll
-            for (int mt = 0; mt < 3; ++mt) nz[mt] = az[mt];
-#pragma unroll
-            for (int i = 0; i < NB; ++i) nx[i] = bx[i];
-#else
 #pragma unroll
             for (int mt = 0; mt < 3; ++mt) nz[mt] = c.ap[mt][noz];
 #pragma unroll
@@ -1072,16 +925,11 @@ __device__ __forceinline__ void wgrad_k_run(WCursor<NB>& c, f32x4 (&acc)[NB][3],
                 nze = c.ape[noz];
                 nxe = c.bpe[nox];
             }
-#endif
 #pragma unroll
             for (int i = 0; i < NB; ++i)
 #pragma unroll
                 for (int mt = 0; mt < 3; ++mt) {
-#if defined(HOWL_DIAG_WGRAD_NOMFMA)  // diagnostic build: LDS traffic only
-                    acc[i][mt][0] += az[mt] * bx[i];
-#else
                     acc[i][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(az[mt], bx[i], acc[i][mt], 0, 0, 0);
-#endif
                 }
             if constexpr (EX) acce = __builtin_amdgcn_mfma_f32_16x16x4f32(aze, bxe, acce, 0, 0, 0);
 #pragma unroll
@@ -1261,10 +1109,6 @@ __device__ __forceinline__ void wgrad_loop(const WgradArgs& a, const int (&zt)[W
             bxe = c.bpe[0];
         }
         static_assert(WNB == 5 && WNT == 4, "the staging schedule below is written for 5 + 4 slot pairs");
-#if defined(HOWL_DIAG_WNOSTAGE)   // diagnostic build (tools/variants4.py; WRONG results): the phases without their staging work
-#define HOWL_W_LOAD(slot_, j_, zpk_, xpk_, cpk_, ub_, bb_) ((void)0)
-#define HOWL_W_WRITE(slot_, j_, zpk_, xpk_, cpk_) ((void)0)
-#else
 #define HOWL_W_LOAD(slot_, j_, zpk_, xpk_, cpk_, ub_, bb_)                    \
     do {                                                                     \
         wz_load(v[slot_].z, a.st.z, ub_, zpk_[j_], cpk_[j_], bb_);           \
@@ -1275,7 +1119,6 @@ __device__ __forceinline__ void wgrad_loop(const WgradArgs& a, const int (&zt)[W
         wz_write(v[slot_].z, a.st.z, zpk_[j_], cpk_[j_], a.tz, a.lm);        \
         wx_write(v[slot_].x, a.st.xaffine, xpk_[j_], cpk_[j_], a.tx, a.lm);  \
     } while (0)
-#endif
         HOWL_W_LOAD(0, 0, zb, xb, cb, ubase, b);
         HOWL_W_LOAD(1, 1, zb, xb, cb, ubase, b);
         HOWL_STAIR(3);
@@ -1743,9 +1586,7 @@ __global__ __launch_bounds__(C0M_THREADS) void conv0_fwd_mfma_kernel(const float
         // long inputs (howl_res8_fwd_long): "utterance" b is window b % nwin of clip b / nwin, T frames from its start frame
         const int clip = b / nwin, wi = b - clip * nwin;
         const int t0 = min(wi * win_step, win_last);
-#if !defined(HOWL_DIAG_C0_NOLOAD)   // diagnostic build: no feature tile load
         load_feat_tile(tin, feat + (long)clip * sb + (long)t0 * st, 0, st, sm, 0, T, M, tid, C0M_THREADS);
-#endif
         __syncthreads();
         // units (pair of pooled rows, group of 8 mel bins) of this slice, dealt to the waves
         for (int u = wave; u < 5 * ((ph1 - ph0 + 1) / 2); u += C0M_THREADS / 64) {
@@ -1764,16 +1605,9 @@ __global__ __launch_bounds__(C0M_THREADS) void conv0_fwd_mfma_kernel(const float
                         const float a = rowp[aoff[ks] + tl * pitch];
 #pragma unroll
                         for (int nt = 0; nt < 3; ++nt)
-#if defined(HOWL_DIAG_C0_NOMFMA)   // diagnostic build (tools/variants.py): everything but the matrix pipe
-                            acc[tl][nt][0] += a * bw[ks][nt];
-#else
                             acc[tl][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bw[ks][nt], acc[tl][nt], 0, 0, 0);
-#endif
                     }
                 const int pw = 2 * j8 + (g & 1), ph = ph0 + 2 * pp + (g >> 1);  // this lane's cell: rows 4g..4g+3 of the tile
-#if defined(HOWL_DIAG_C0_NOEPI)   // diagnostic build: MFMAs only (one value keeps them alive)
-                if (acc[0][0][0] + acc[1][1][1] + acc[2][2][2] == 123.456f) s0[0] = 1.0f;
-#else
 #pragma unroll
                 for (int nt = 0; nt < 3; ++nt) {
                     float sum = 0.0f;
@@ -1790,17 +1624,12 @@ __global__ __launch_bounds__(C0M_THREADS) void conv0_fwd_mfma_kernel(const float
                             bits |= min((unsigned)rb, 1u) << (4 * tl + r);
                         }
                     const int c = 16 * nt + n;
-#if defined(HOWL_DIAG_C0_NOSTORE)   // diagnostic build: no global stores
-                    if (ph < ph1 && c < NMAP && sum == 123.456f) {
-#else
                     if (ph < ph1 && c < NMAP) {
-#endif
                         const size_t o = ((size_t)b * NMAP + c) * P + (size_t)ph * PW + pw;
                         s0[o] = sum * (1.0f / 12.0f);
                         if (mask0 != nullptr) mask0[o] = (unsigned short)bits;
                     }
                 }
-#endif
             }
         }
     }
@@ -2227,24 +2056,7 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
 
 size_t conv0_tile_floats(int T, int M) { return (size_t)(T + 2) * (M + 4) + 3 * (M + 4) + 16; }   // tile + slack (conv0_fwd_mfma_kernel)
 size_t conv_lds_bytes(int H) { return (size_t)(3 * KSTEPS * 64 + tile_floats(H) + 4 * CP + 12 * 2 * 16) * sizeof(float); }
-#if defined(HOWL_DIAG_PROBE)
-unsigned long long* g_probe_ptr = nullptr;
-int g_probe_blk = 0;
-}  // namespace
-extern "C" int howl_diag_set_probe(unsigned long long* buf, int block) {
-    g_probe_ptr = buf;
-    g_probe_blk = block;
-    return 0;
-}
-namespace {
-StageCfg with_probe(StageCfg c) {
-    c.probe = g_probe_ptr;
-    c.probe_block = g_probe_blk;
-    return c;
-}
-#else
 StageCfg with_probe(StageCfg c) { return c; }
-#endif
 
 size_t wgrad_lds_bytes(int H) { return (size_t)(tile_floats_z(H) + tile_floats_x(H) + 6 * CP) * sizeof(float); }
 

@@ -118,6 +118,7 @@ SIGNATURES = {
 }
 # entry points that do not return an int status
 SIZE_FUNCS = {"howl_res8_workspace_bytes": [c_int, c_int], "howl_res8_long_workspace_bytes": [c_int, c_int], "howl_lstm_workspace_bytes": [c_int, c_int],
+              "howl_lstm_needs_gx": [POINTER(HowlLstmParams), c_int, c_int, c_int, c_int],
               "howl_head_workspace_bytes": [c_int, c_int, c_int],
               "howl_mobilenet_num_layers": [],
               "howl_mobilenet_param_floats": [c_int], "howl_mobilenet_buffer_floats": [],

@@ -47,12 +47,15 @@ def _lstm_forward_raw(x, lengths, t_out, h0, c0, w_ih, w_hh, b_ih, b_hh):
     B, T, M = x.shape
     dev = x.device
     f32 = dict(dtype=torch.float32, device=dev)
-    bufs = dict(gx=torch.empty((B, T, 4 * HID), **f32), gates=torch.empty((B, T, 4 * HID), **f32),
-                c=torch.empty((B, T, HID), **f32), hseq=torch.empty((B, T + 1, HID), **f32))
+    bufs = dict(gates=torch.empty((B, T, 4 * HID), **f32), c=torch.empty((B, T, HID), **f32),
+                hseq=torch.empty((B, T + 1, HID), **f32))
     ws = torch.empty(_lib.get().cdll.howl_lstm_workspace_bytes(B, T), dtype=torch.uint8, device=dev)
     hT, cT = torch.empty((B, HID), **f32), torch.empty((B, HID), **f32)
     prm = _lib.HowlLstmParams(_vp(w_ih), _vp(w_hh), _vp(b_ih), _vp(b_hh))
-    sv = _lib.HowlLstmSaved(_vp(bufs["gx"]), _vp(bufs["gates"]), _vp(bufs["c"]), _vp(bufs["hseq"]), None, t_out, _x_frames(x))
+    xf = _x_frames(x)
+    # the (B, T, 512) projection buffer only where the library runs the projection GEMM (40 MB at 512 x 38 otherwise unused)
+    gx = torch.empty((B, T, 4 * HID), **f32) if _lib.get().cdll.howl_lstm_needs_gx(ctypes.byref(prm), B, T, M, xf) else None
+    sv = _lib.HowlLstmSaved(_vp(gx), _vp(bufs["gates"]), _vp(bufs["c"]), _vp(bufs["hseq"]), None, t_out, xf)
     _lib.get().call("howl_lstm_fwd", ctypes.byref(prm), _vp(x), B, T, M, _vp(lengths), _vp(h0), _vp(c0), ctypes.byref(sv),
                     _vp(hT), _vp(cT), _vp(ws), ws.numel(), ops._stream())
     saved = (x, lengths, c0, w_ih, w_hh, b_ih, b_hh, bufs["gates"], bufs["c"], bufs["hseq"], ws)

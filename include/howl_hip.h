@@ -253,7 +253,7 @@ typedef struct {
 } HowlLstmGrads;
 
 typedef struct {
-    float* gx;     /* (B,T,512) input projection x W_ih^T + b_ih + b_hh */
+    float* gx;     /* (B,T,512) input projection x W_ih^T + b_ih + b_hh; may be NULL when howl_lstm_needs_gx() says 0 */
     float* gates;  /* (B,T,512) gate activations i,f,g,o */
     float* c;      /* (B,T,128) cell states */
     float* hseq;   /* (B,T+1,128): hseq[b][0] = h0, hseq[b][t+1] = h_t (zero for t >= length, as pad_packed_sequence) */
@@ -264,6 +264,9 @@ typedef struct {
 } HowlLstmSaved;
 
 size_t howl_lstm_workspace_bytes(int B, int T);
+/* 1 when howl_lstm_fwd on this shape writes the (B,T,512) projection buffer saved->gx, 0 when the recurrence multiplies
+   x_t W_ih^T itself (four-sequence kernel, M = 40) and gx may be NULL.  x_frames as in HowlLstmSaved (0 = T). */
+size_t howl_lstm_needs_gx(const HowlLstmParams* p, int B, int T, int M, int x_frames);
 /* h0/c0: (B,128) initial state or NULL (zeros) -- the streaming carry of rnn.py:62,67-68; hT/cT: final state (B,128). */
 int howl_lstm_fwd(const HowlLstmParams* p, const float* x, int B, int T, int M, const long long* lengths,
                   const float* h0, const float* c0, const HowlLstmSaved* saved, float* hT, float* cT, void* ws,

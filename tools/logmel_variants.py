@@ -1,3 +1,5 @@
+# NOTE (round 5): the HOWL_DIAG_* branches this tool compiles were removed from the product kernels (tools/strip_diag.py);
+# it builds against the sources of commit 37e3835 (`git worktree add /tmp/howl_r4 37e3835` and run it there).
 """Diagnostic variants of logmel_kernel (results WRONG by design: each removes one part) timed at 512 / 2048 x 1 s.
 Runs on the GPU box:  python tools/logmel_variants.py"""
 import os

@@ -1,3 +1,5 @@
+# NOTE (round 5): the HOWL_DIAG_* branches this tool compiles were removed from the product kernels (tools/strip_diag.py);
+# it builds against the sources of commit 37e3835 (`git worktree add /tmp/howl_r4 37e3835` and run it there).
 """Timeline and occupancy probe of logmel_kernel (diagnostic build with -DHOWL_DIAG_PROBE: one s_memtime stamp per wave and
 phase of workgroup 0).  Runs on the GPU box:  python tools/probe_logmel.py"""
 import os

@@ -1,3 +1,5 @@
+# NOTE (round 5): the HOWL_DIAG_* branches this tool compiles were removed from the product kernels (tools/strip_diag.py);
+# it builds against the sources of commit 37e3835 (`git worktree add /tmp/howl_r4 37e3835` and run it there).
 """Per-phase timelines (one s_memtime stamp per wave and phase; diagnostic build with -DHOWL_DIAG_PROBE) of the round-4 3x3
 kernels at 512 x 1 s: the forward convolution (last layer's launch, workgroup 0) and both roles of the backward pair (layer
 1's launch: block 0 = data gradient, block 8 = weight gradient).

@@ -1,3 +1,5 @@
+# NOTE (round 5): the HOWL_DIAG_* branches this tool compiles were removed from the product kernels (tools/strip_diag.py);
+# it builds against the sources of commit 37e3835 (`git worktree add /tmp/howl_r4 37e3835` and run it there).
 """Round-4 A/B harness for the res8 kernels: builds copies of the library from EDITED copies of csrc/res8.hip (text
 substitutions, tools only -- nothing here ships) and times the c3 step with each on one GPU box, same minute.
     python tools/variants4.py build [name ...]     (here; hipcc cross-compiles, builds run side by side)
