@@ -76,6 +76,7 @@ def parse():
     ap.add_argument("--batch-per-gpu", type=int, default=None, help="override the configuration's per-GPU batch")
     ap.add_argument("--seconds", type=float, default=None, help="override the utterance length")
     ap.add_argument("--labels", type=int, default=None)
+    ap.add_argument("--prewarm", type=int, default=40, help="untimed steps in front of the W warmup steps (device clocks)")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -629,6 +630,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # clocks up before the contract's W warmup steps: the first ~30 ms of device work on an idle MI355X run below the sustained
+    # clock (round 4: the first timed segment was 9 % slow with --warmup 5); untimed, outside the W + K bracket
+    for _ in range(args.prewarm):
+        step()
+    torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     # the K timed steps are also cut into (up to) 5 consecutive segments by HIP events on the compute stream: no extra
