@@ -30,11 +30,14 @@ from howl_amd.utils.random_utils import set_random_seed
 from howl_amd.workspace import Workspace
 
 
-def train_epoch(trainer, collate, id_batches, std_transform, writer, epoch_idx, needs_lengths=False, prefetch=2):
+def train_epoch(trainer, collate, id_batches, std_transform, writer, epoch_idx, needs_lengths=False, prefetch=0):
     """The loop body of ``training/run/pretrain_gsc.py:120-133`` over one epoch's batches of clip ids: collate (truncate,
     Timeshift, Noise, batchify on the device) -> frontend in train mode (VTLP draw) -> fused training step -> loss logging
     without a host synchronisation.  ``prefetch`` > 0: the host half of the collate (draws, sort, packed staging buffer) runs
-    that many batches ahead in a worker thread (``DeviceCollate.prefetch``), as the reference's DataLoader workers do.
+    that many batches ahead in a worker thread (``DeviceCollate.prefetch``), as the reference's DataLoader workers do -- measured
+    SLOWER than preparing inline once the draws are array operations (round 5, 1xMI355X: 1.190 against 1.168 ms per step at
+    512 utterances, 0.391 against 0.334 at 64: 25-47 us of host work per batch do not pay for the hand-over between two Python
+    threads), hence off by default.
     Returns the number of utterances trained on.  (``bench.py --loop entry`` times exactly this function.)"""
     batches = collate.prefetch(id_batches, depth=prefetch) if prefetch else (collate(ids) for ids in id_batches)
     seen = 0
