@@ -64,6 +64,28 @@ int howl_num_cus() {
     return cached;
 }
 
+HowlSideLane* howl_side_lane() {
+    struct Slot {
+        int dev = -1;
+        bool tried = false, ok = false;
+        HowlSideLane lane;
+    };
+    static thread_local Slot slots[16];
+    if (getenv("HOWL_NO_SIDE_STREAM") != nullptr) return nullptr;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    Slot& s = slots[dev];
+    if (!s.tried) {
+        s.tried = true;
+        s.dev = dev;
+        s.ok = hipStreamCreateWithFlags(&s.lane.stream, hipStreamNonBlocking) == hipSuccess &&
+               hipEventCreateWithFlags(&s.lane.fork_ev, hipEventDisableTiming) == hipSuccess &&
+               hipEventCreateWithFlags(&s.lane.join_ev, hipEventDisableTiming) == hipSuccess;
+        if (!s.ok) (void)hipGetLastError();
+    }
+    return s.ok ? &s.lane : nullptr;
+}
+
 extern "C" {
 
 int howl_version(int* major, int* minor) {

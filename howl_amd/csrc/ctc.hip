@@ -37,6 +37,13 @@ __device__ __forceinline__ float lse3(float a, float b, float c) {
     return __builtin_amdgcn_logf(e) * LN2 + m;
 }
 
+__device__ __forceinline__ float wave_shr1(float v) {      // lane i <- lane i - 1 (lane 0 keeps its own)
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float wave_shl1(float v) {      // lane i <- lane i + 1 (lane 63 keeps its own)
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x130, 0xf, 0xf, false));
+}
+
 constexpr int RP = 65;   // LDS row pitch: lanes that walk down a column (lane = time step) hit 64 different banks
 
 __global__ __launch_bounds__(64) void ctc_kernel(const float* __restrict__ logits, long st_t, long st_b, int T, int B, int C,
@@ -112,10 +119,11 @@ __global__ __launch_bounds__(64) void ctc_kernel(const float* __restrict__ logit
             a = (live && lane < 2) ? lpa : -INFINITY;
             bt = (live && lane >= S - 2) ? lpb : -INFINITY;
         } else {
-            const float a1 = __shfl(a, lane >= 1 ? lane - 1 : lane);
-            const float a2 = __shfl(a, lane >= 2 ? lane - 2 : lane);
-            const float b1 = __shfl(bt, lane + 1 < 64 ? lane + 1 : lane);
-            const float b2 = __shfl(bt, lane + 2 < 64 ? lane + 2 : lane);
+            // the neighbour states by DPP wave shifts (wave_shr:1 / wave_shl:1, gfx9): a register move each, where the ds_bpermute
+            // behind __shfl was a round trip through the LDS pipe (~100 cycles) on the serial path of every time step; lanes the
+            // shift leaves without a source (0 / 63, and 1 / 62 on the second hop) are masked below as before
+            const float a1 = wave_shr1(a), a2 = wave_shr1(a1);
+            const float b1 = wave_shl1(bt), b2 = wave_shl1(b1);
             const float va = lse3(a, lane >= 1 ? a1 : -INFINITY, skip_a ? a2 : -INFINITY) + lpa;
             a = live ? va : -INFINITY;
             if (want_grad) {

@@ -34,6 +34,26 @@ int howl_num_cus();
 bool howl_prof_begin(const char* tag, hipStream_t stream, size_t* slot, double work);
 void howl_prof_end(size_t slot, hipStream_t stream);
 
+// A second HIP queue of the library's own for launches that do not depend on each other INSIDE one entry point (round 5: the
+// head's weight gradient next to the backward recurrence, which occupies half of the CUs).  One lane per host thread and device,
+// created on first use and kept; fork = the lane waits for everything queued on the caller's stream so far, join = the caller's
+// stream waits for everything queued on the lane -- stream-ordered on both sides, the host never blocks, and when the entry point
+// returns all of its work is ordered before whatever the caller queues next.  nullptr: no lane (HOWL_NO_SIDE_STREAM set, or the
+// runtime refused one): callers then launch on the caller's stream.
+struct HowlSideLane {
+    hipStream_t stream;
+    hipEvent_t fork_ev, join_ev;
+};
+HowlSideLane* howl_side_lane();
+inline void howl_lane_fork(HowlSideLane* l, hipStream_t main) {
+    hipEventRecord(l->fork_ev, main);
+    hipStreamWaitEvent(l->stream, l->fork_ev, 0);
+}
+inline void howl_lane_join(HowlSideLane* l, hipStream_t main) {
+    hipEventRecord(l->join_ev, l->stream);
+    hipStreamWaitEvent(main, l->join_ev, 0);
+}
+
 // brackets the launches in its scope with HIP events when howl_profile_enable(1) is active (no-op otherwise); `work` =
 // the algorithmic FLOPs (or bytes) of those launches, summed per tag by howl_profile_read_work
 struct HowlProfScope {

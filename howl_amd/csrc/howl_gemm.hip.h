@@ -775,11 +775,24 @@ __global__ __launch_bounds__(256) void thin_wgrad_kernel(const float* __restrict
 // W_hh gradient) and its 1216 blocks did not overlap their staging with their MFMAs; here each element is read once or twice.
 constexpr int WG_M = 128, WG_K = 16, WG_THREADS = 1024;
 constexpr int WG_LDA = WG_M + 16;                   // pitch = 16 mod 32 banks: the two k rows of a 32-lane half of a fragment read do not collide (with + 4 they did: -1 %)
-// (bx, by, bz) = the block's (input-column tile, output-column tile, row split); As / Bs: [2][WG_K * WG_LDA] floats of LDS each
-template <int TN, bool KMAP_LIN>
+constexpr int WG_LDB = 192 + 16;                    // the widest B tile (the dual job's 128 + 64 columns), same pitch rule
+// A second input matrix for the SAME dout rows (round 5: the LSTM's dW_hh = dG^T H and dW_ih = dG^T X as one job): its N2 <= 64
+// columns sit behind the first input's 128 in the block's B tile (TN = 192), so dG is read -- and staged, and its fragments
+// fetched -- once for both products; part2 receives the [splits][M][N2] slabs.
+struct WgradSecond {
+    const float* in2;
+    RowMap im2;
+    int N2;
+    float* part2;
+};
+// (bx, by, bz) = the block's (input-column tile, output-column tile, row split); As: [2][WG_K * WG_LDA], Bs: [2][WG_K * WG_LDB]
+// floats of LDS.  DUAL: TN = 192, N = 128 (the first input fills columns 0..127 exactly), KMAP_LIN = false.
+template <int TN, bool KMAP_LIN, bool DUAL = false>
 __device__ __forceinline__ void wgrad_big_body(const float* __restrict__ dout, RowMap dm, const float* __restrict__ in, RowMap im,
                                                int M, int N, int K, int k_per_split, float* __restrict__ part, int bx, int by,
-                                               int bz, float (*As)[WG_K * WG_LDA], float (*Bs)[WG_K * WG_LDA]) {
+                                               int bz, float (*As)[WG_K * WG_LDA], float (*Bs)[WG_K * WG_LDB],
+                                               const WgradSecond sec = WgradSecond{nullptr, RowMap{1, 0, 0}, 0, nullptr}) {
+    static_assert(!DUAL || (TN == 192 && !KMAP_LIN), "dual job: 128 + 64 columns, general row maps");
     constexpr int LDA = WG_LDA, LDB = TN + 16;
     constexpr int NJ = TN / 64;                     // 16-column tiles per wave (sixteen waves: 4 x 4, 32 x TN/4 each)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -790,9 +803,9 @@ __device__ __forceinline__ void wgrad_big_body(const float* __restrict__ dout, R
     // (k = t / 32, column 4 (t % 32)), threads 512.. the input's (TN = 128: the same map; TN = 64: k = t / 16, 256 threads).
     const bool is_a = tid < 512;
     const int t2 = tid & 511;
-    const int p_k = (is_a || TN == 128) ? t2 >> 5 : (t2 >> 4) & 15;
-    const int p_c = (is_a || TN == 128) ? (t2 & 31) * 4 : (t2 & 15) * 4;
-    const bool p_thread = is_a || TN == 128 || t2 < 256;
+    const int p_k = (is_a || TN != 64) ? t2 >> 5 : (t2 >> 4) & 15;
+    const int p_c = (is_a || TN != 64) ? (t2 & 31) * 4 : (t2 & 15) * 4;
+    const bool p_thread = is_a || TN != 64 || t2 < 256;
     const float* src = is_a ? dout : in;
     const RowMap rm = is_a ? dm : im;
     const int col = is_a ? min(m0 + p_c, M - 4) : min(n0 + p_c, N - 4);      // clamped loads, zeroed when staged
@@ -823,6 +836,40 @@ __device__ __forceinline__ void wgrad_big_body(const float* __restrict__ dout, R
         if (!(p_ok && k0 + p_k < kend)) v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (p_thread) *reinterpret_cast<float4*>(dst) = v;
     };
+    // DUAL: the second input's 16 x N2 tile = 4 N2 pieces, one more per K tile for the first 4 N2 threads (row e / (N2 / 4),
+    // columns 4 (e % (N2 / 4)) ..), with a row cursor of its own; B columns 128 + N2 .. 191 stay zero from the start
+    const int q4 = DUAL ? sec.N2 >> 2 : 1;
+    const bool x_thread = DUAL && tid < 16 * q4;
+    const int x_k = x_thread ? tid / q4 : 0;
+    const int x_c = x_thread ? 4 * (tid - x_k * q4) : 0;
+    int xk = min(kbeg + x_k, kend - 1);
+    int xin = DUAL ? xk % sec.im2.inner : 0;
+    long xoff = DUAL ? (long)(xk / sec.im2.inner) * sec.im2.s_outer + (long)xin * sec.im2.s_inner : 0;
+    auto fetch_x = [&]() {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (DUAL) {
+            if (x_thread) v = *reinterpret_cast<const float4*>(sec.in2 + xoff + x_c);
+            const int step = min(WG_K, kend - 1 - xk);
+            xk += step;
+            xoff += (long)step * sec.im2.s_inner;
+            xin += step;
+            while (xin >= sec.im2.inner) {
+                xin -= sec.im2.inner;
+                xoff += sec.im2.s_outer - (long)sec.im2.inner * sec.im2.s_inner;
+            }
+        }
+        return v;
+    };
+    auto stage_x = [&](int buf, float4 v, int k0) {
+        if constexpr (DUAL) {
+            if (!(k0 + x_k < kend)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (x_thread) *reinterpret_cast<float4*>(&Bs[buf][x_k * LDB + 128 + x_c]) = v;
+        }
+    };
+    if constexpr (DUAL) {
+        for (int i = tid; i < 2 * WG_K * WG_LDB; i += WG_THREADS) (&Bs[0][0])[i] = 0.0f;
+        __syncthreads();
+    }
     f32x4 acc[2][NJ];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -850,26 +897,33 @@ __device__ __forceinline__ void wgrad_big_body(const float* __restrict__ dout, R
     // 64-66 as well: neither the load latency nor the barrier count is what keeps the matrix pipe at 0.485 here.)
     // Two K tiles per trip, no early exit (an odd tile count multiplies one all-zero tile at the end): with `break`s in the body
     // the compiler's vmcnt bookkeeping gives up and every staging step waits for ALL outstanding loads (vmcnt(0)).
-    float4 v0 = fetch();
-    float4 v1 = fetch();      // past the end: clamped re-loads, staged as zeros
+    float4 v0 = fetch(), x0 = fetch_x();
+    float4 v1 = fetch(), x1 = fetch_x();      // past the end: clamped re-loads, staged as zeros
     stage(dst0, v0, kbeg);
+    stage_x(0, x0, kbeg);
     __syncthreads();
     v0 = fetch();
+    x0 = fetch_x();
     const int pairs = ((kend - kbeg + WG_K - 1) / WG_K + 1) / 2;
     int k0 = kbeg;
     for (int p = 0; p < pairs; ++p, k0 += 2 * WG_K) {
         __builtin_amdgcn_sched_barrier(0);   // keep the requests in front of the MFMAs
         multiply(0);
         stage(dst1, v1, k0 + WG_K);
+        stage_x(1, x1, k0 + WG_K);
         __syncthreads();
         v1 = fetch();
+        x1 = fetch_x();
         __builtin_amdgcn_sched_barrier(0);
         multiply(1);
         stage(dst0, v0, k0 + 2 * WG_K);
+        stage_x(0, x0, k0 + 2 * WG_K);
         __syncthreads();
         v0 = fetch();
+        x0 = fetch_x();
     }
     float* pz = part + (long)bz * M * N;
+    float* pz2 = DUAL ? sec.part2 + (long)bz * M * sec.N2 : nullptr;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -879,6 +933,9 @@ __device__ __forceinline__ void wgrad_big_body(const float* __restrict__ dout, R
             for (int r = 0; r < 4; ++r) {
                 const int m = m0 + 32 * wr + 16 * i + 4 * (lane >> 4) + r;
                 if (m < M && n < N) pz[(long)m * N + n] = acc[i][j][r];
+                if constexpr (DUAL) {
+                    if (m < M && n >= 128 && n - 128 < sec.N2) pz2[(long)m * sec.N2 + n - 128] = acc[i][j][r];
+                }
             }
         }
 }
@@ -888,7 +945,7 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_big_kernel(const float* __re
                                                               const float* __restrict__ in, RowMap im, int M, int N, int K,
                                                               int k_per_split, float* __restrict__ part) {
     __shared__ __attribute__((aligned(16))) float As[2][WG_K * WG_LDA];
-    __shared__ __attribute__((aligned(16))) float Bs[2][WG_K * WG_LDA];
+    __shared__ __attribute__((aligned(16))) float Bs[2][WG_K * WG_LDB];
     wgrad_big_body<TN, KMAP_LIN>(dout, dm, in, im, M, N, K, k_per_split, part, blockIdx.x, blockIdx.y, blockIdx.z, As, Bs);
 }
 
@@ -904,6 +961,7 @@ struct WgradJob {
     float* part;
     int gx, gy, gz;
     int tn, klin;
+    WgradSecond sec;      // tn == 192: the dual job's second input
 };
 constexpr int MAX_WGRAD_JOBS = 4;
 struct WgradJobs {
@@ -913,7 +971,7 @@ struct WgradJobs {
 };
 __global__ __launch_bounds__(WG_THREADS) void wgrad_big_multi_kernel(WgradJobs jobs) {
     __shared__ __attribute__((aligned(16))) float As[2][WG_K * WG_LDA];
-    __shared__ __attribute__((aligned(16))) float Bs[2][WG_K * WG_LDA];
+    __shared__ __attribute__((aligned(16))) float Bs[2][WG_K * WG_LDB];
     int b = blockIdx.x, q = 0;
     while (q + 1 < jobs.count && b >= jobs.j[q].gx * jobs.j[q].gy * jobs.j[q].gz) {
         b -= jobs.j[q].gx * jobs.j[q].gy * jobs.j[q].gz;
@@ -923,7 +981,9 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_big_multi_kernel(WgradJobs j
     const int bx = b % jb.gx, by = (b / jb.gx) % jb.gy, bz = b / (jb.gx * jb.gy);
 #define HOWL_WG_BODY(TN_, KL_) \
     wgrad_big_body<TN_, KL_>(jb.dout, jb.dm, jb.in, jb.im, jb.M, jb.N, jb.K, jb.kps, jb.part, bx, by, bz, As, Bs)
-    if (jb.tn == 128) {
+    if (jb.tn == 192) {
+        wgrad_big_body<192, false, true>(jb.dout, jb.dm, jb.in, jb.im, jb.M, jb.N, jb.K, jb.kps, jb.part, bx, by, bz, As, Bs, jb.sec);
+    } else if (jb.tn == 128) {
         if (jb.klin) HOWL_WG_BODY(128, true);
         else HOWL_WG_BODY(128, false);
     } else {
@@ -996,7 +1056,8 @@ void wgrad_gemm(hipStream_t s, const float* dout, RowMap dm, int n_out, const fl
         const dim3 grid((k_in + tn - 1) / tn, (n_out + WG_M - 1) / WG_M, z);
         const bool klin = is_lin(dm) && is_lin(im);
         if (jobs != nullptr && defer != nullptr && jobs->count < MAX_WGRAD_JOBS) {     // launched by wgrad_jobs_flush with its companions
-            jobs->j[jobs->count++] = WgradJob{dout, dm, in, im, n_out, k_in, rows, kps, scratch, (int)grid.x, (int)grid.y, (int)grid.z, tn, klin ? 1 : 0};
+            jobs->j[jobs->count++] = WgradJob{dout, dm, in, im, n_out, k_in, rows, kps, scratch, (int)grid.x, (int)grid.y, (int)grid.z, tn, klin ? 1 : 0,
+                                              WgradSecond{nullptr, RowMap{1, 0, 0}, 0, nullptr}};
             jobs->flops += 2.0 * (double)n_out * k_in * rows;
             defer->add(scratch, z, (long)n_out * k_in, dw);
             return;
@@ -1019,6 +1080,31 @@ void wgrad_gemm(hipStream_t s, const float* dout, RowMap dm, int n_out, const fl
         return;
     }
     hipLaunchKernelGGL(sum_slabs_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, s, (const float*)scratch, z, n, dw);
+}
+
+// dW (N_out, 128) = dOut^T In and dW2 (N_out, k2) = dOut^T In2 over the same `rows` mapped rows as ONE job of the multi-job launch
+// (dout read once for both): wide outputs, many rows, k2 <= 64.  Returns false when the shape does not fit (the caller then runs
+// the two products as separate wgrad_gemm jobs).
+bool wgrad_dual_gemm(const float* dout, RowMap dm, int n_out, const float* in, RowMap im, const float* in2, RowMap im2, int k2,
+                     int rows, float* scratch, float* dw, float* scratch2, float* dw2, int max_splits, SlabSums* defer,
+                     WgradJobs* jobs) {
+    auto map4 = [](const RowMap& r) { return (r.s_outer & 3) == 0 && (r.s_inner & 3) == 0; };
+    auto al16 = [](const float* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    if (jobs == nullptr || defer == nullptr || jobs->count >= MAX_WGRAD_JOBS || n_out < 128 || (n_out & 3) != 0 ||
+        rows < wgrad_big_min_rows() || k2 < 4 || k2 > 64 || (k2 & 3) != 0 || !map4(dm) || !map4(im) || !map4(im2) || !al16(dout) ||
+        !al16(in) || !al16(in2) || max_splits < 16 || getenv("HOWL_WGRAD_NO_DUAL") != nullptr)
+        return false;
+    const int tiles = (n_out + WG_M - 1) / WG_M;
+    int sp = std::max(1, howl_num_cus() / tiles);
+    sp = std::min(sp, max_splits);
+    int kps = ((rows + sp - 1) / sp + WG_K - 1) / WG_K * WG_K;
+    kps = std::max(kps, 4 * WG_K);
+    const int z = (rows + kps - 1) / kps;
+    jobs->j[jobs->count++] = WgradJob{dout, dm, in, im, n_out, 128, rows, kps, scratch, 1, tiles, z, 192, 0, WgradSecond{in2, im2, k2, scratch2}};
+    jobs->flops += 2.0 * (double)n_out * (128 + k2) * rows;
+    defer->add(scratch, z, (long)n_out * 128, dw);
+    defer->add(scratch2, z, (long)n_out * k2, dw2);
+    return true;
 }
 
 // out0 (and out1) = column sums of x over `rows` mapped rows; scratch holds <= 64 * n floats

@@ -1153,9 +1153,13 @@ static int lstm_bwd_impl(const HowlLstmParams* p, const float* x, int B, int T, 
     const int rows = B * Tout;
     // 256 rows per K slice (up to 128 slices): the 512-row slices of the generic rule leave ~1 block per CU on these shapes
     HOWL_REQUIRE(M <= LSTM_MAX_IN, "howl_lstm_bwd: M=%d input features exceed the workspace layout (max %d)", M, LSTM_MAX_IN);
-    wgrad_gemm(stream, sv->dgates, rows_g, G4, x, rows_x, M, rows, scratch_ih, g->w_ih, LSTM_WGRAD_SPLITS, 256, &sums, jobs);
-    wgrad_gemm(stream, sv->dgates, rows_g, G4, sv->hseq, RowMap{Tout, (long)(T + 1) * HID, HID}, HID, rows, scratch, g->w_hh,
-               LSTM_WGRAD_SPLITS, 256, &sums, jobs);
+    // one job for both products where the shape allows (dG -- 40 MB at 512 x 38 -- read and staged once): howl_gemm.hip.h
+    if (!wgrad_dual_gemm(sv->dgates, rows_g, G4, sv->hseq, RowMap{Tout, (long)(T + 1) * HID, HID}, x, rows_x, M, rows, scratch, g->w_hh,
+                         scratch_ih, g->w_ih, LSTM_WGRAD_SPLITS, &sums, jobs)) {
+        wgrad_gemm(stream, sv->dgates, rows_g, G4, x, rows_x, M, rows, scratch_ih, g->w_ih, LSTM_WGRAD_SPLITS, 256, &sums, jobs);
+        wgrad_gemm(stream, sv->dgates, rows_g, G4, sv->hseq, RowMap{Tout, (long)(T + 1) * HID, HID}, HID, rows, scratch, g->w_hh,
+                   LSTM_WGRAD_SPLITS, 256, &sums, jobs);
+    }
     if (!rows16)   // the four-sequence recurrence left one slab of step-and-sequence sums per workgroup
         sums.add(scratch_b, (B + 3) / 4, G4, g->b_ih, g->b_hh);
     else
@@ -1307,9 +1311,22 @@ int howl_seq_lstm_bwd(const HowlHeadParams* hp, int n_hid, int n_out, const floa
     int rc = head_bwd_impl(hp, sv->hseq + HID, T, (long)(T + 1) * HID, HID, B * T, HID, n_hid, n_out, y1, dy2, dz1, dhs, hg, ctc_mean,
                            head_ws, head_ws_bytes, stream, sums, &jobs);
     if (rc != HOWL_OK) return rc;
+    // The head's first-layer weight gradient (dz1^T H) depends on nothing the LSTM's backward produces, and the four-sequence
+    // recurrence occupies (B + 3) / 4 CUs for its 38-81 dependent steps: while that leaves at least half of the device idle the
+    // job runs on the library's side lane next to the recurrence (18 us of the 65-us job launch at 512 x 38) instead of behind it.
+    HowlSideLane* lane = nullptr;
+    if (jobs.count > 0 && !lstm_rows16(B, T) && (B + 3) / 4 <= howl_num_cus() / 2) lane = howl_side_lane();
+    if (lane != nullptr) {
+        howl_lane_fork(lane, stream);
+        wgrad_jobs_flush(lane->stream, jobs);
+    }
     rc = lstm_bwd_impl(p, x, B, T, M, lengths, c0, sv, dhs, nullptr, nullptr, g, ws, ws_bytes, stream, sums, &jobs);
-    if (rc != HOWL_OK) return rc;
+    if (rc != HOWL_OK) {
+        if (lane != nullptr) howl_lane_join(lane, stream);
+        return rc;
+    }
     wgrad_jobs_flush(stream, jobs);
+    if (lane != nullptr) howl_lane_join(lane, stream);
     if (!sums.flush(stream)) return HOWL_E_ARG;
     HOWL_CHECK_LAUNCH("howl_seq_lstm_bwd");
     return HOWL_OK;

@@ -210,6 +210,11 @@ static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int ro
     const uint32_t* t = hipemu_wave_exchange(&w, 1);
     const int l = hipemu_lane(), row = l & ~15, p = l & 15;
     if (!((row_mask >> ((l >> 4) & 3)) & 1) || !((bank_mask >> ((l >> 2) & 3)) & 1)) return old;
+    if (ctrl == 0x130 || ctrl == 0x138) {   // wave_shl:1 / wave_shr:1 (gfx9): whole-wave shifts by one lane
+        const int src_lane = ctrl == 0x130 ? l + 1 : l - 1;
+        if (src_lane < 0 || src_lane > 63) return bound_ctrl ? 0 : old;
+        return (int)t[src_lane * 16];
+    }
     int sp = -1;   // source position inside the row; -1 = out of range
     if (ctrl >= 0 && ctrl <= 0xff) sp = (p & ~3) | ((ctrl >> (2 * (p & 3))) & 3);
     else if (ctrl >= 0x101 && ctrl <= 0x10f) { sp = p + (ctrl - 0x100); if (sp > 15) sp = -1; }
