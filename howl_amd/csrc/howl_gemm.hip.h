@@ -992,6 +992,112 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_big_multi_kernel(WgradJobs j
     }
 #undef HOWL_WG_BODY
 }
+// An EIGHT-wave (512-thread) form of wgrad_big_body<128, false> for one block of a collected job, for blocks that ride in the
+// launch of a 512-thread kernel which leaves CUs idle (round 5: the head's first-layer weight gradient inside the backward
+// recurrence's launch -- on a second queue the same overlap cost two cross-queue waits of ~7 us each on the critical path).  Same
+// tile (128 x 128), same K tiles and split, same order of the products of every output element -- bit-identical slabs -- with
+// the sixteen-wave body's 4 x 4 waves of 32 x 32 as 2 x 4 waves of 64 x 32, and one 16-byte piece of EACH operand per thread and
+// K tile.  Two waves per SIMD instead of four: slower per block, which is what idle CUs are for.
+__device__ __forceinline__ void wgrad_w8_body(const WgradJob& jb, int bidx, float (*As)[WG_K * WG_LDA], float (*Bs)[WG_K * WG_LDA]) {
+    constexpr int LDA = WG_LDA, LDB = WG_LDA;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 2, wc = wave & 3;
+    const int bx = bidx % jb.gx, by = (bidx / jb.gx) % jb.gy, bz = bidx / (jb.gx * jb.gy);
+    const int M = jb.M, N = jb.N, K = jb.K;
+    const int m0 = by * WG_M, n0 = bx * 128;
+    const int kbeg = bz * jb.kps, kend = min(K, kbeg + jb.kps);
+    const int p_k = tid >> 5, p_c = (tid & 31) * 4;
+    const int cola = min(m0 + p_c, M - 4), colb = min(n0 + p_c, N - 4);      // clamped loads, zeroed when staged
+    const bool oka = m0 + p_c < M, okb = n0 + p_c < N;
+    int ck = min(kbeg + p_k, kend - 1);
+    int cina = ck % jb.dm.inner, cinb = ck % jb.im.inner;
+    long coffa = (long)(ck / jb.dm.inner) * jb.dm.s_outer + (long)cina * jb.dm.s_inner;
+    long coffb = (long)(ck / jb.im.inner) * jb.im.s_outer + (long)cinb * jb.im.s_inner;
+    struct Pair {
+        float4 a, b;
+    };
+    auto fetch = [&]() {     // loads the cursors' rows and moves on: calls are in K-tile order (kbeg, kbeg + 16, ...)
+        Pair v;
+        v.a = *reinterpret_cast<const float4*>(jb.dout + coffa + cola);
+        v.b = *reinterpret_cast<const float4*>(jb.in + coffb + colb);
+        const int step = min(WG_K, kend - 1 - ck);
+        ck += step;
+        coffa += (long)step * jb.dm.s_inner;
+        coffb += (long)step * jb.im.s_inner;
+        cina += step;
+        cinb += step;
+        while (cina >= jb.dm.inner) {
+            cina -= jb.dm.inner;
+            coffa += jb.dm.s_outer - (long)jb.dm.inner * jb.dm.s_inner;
+        }
+        while (cinb >= jb.im.inner) {
+            cinb -= jb.im.inner;
+            coffb += jb.im.s_outer - (long)jb.im.inner * jb.im.s_inner;
+        }
+        return v;
+    };
+    auto stage = [&](int buf, Pair v, int k0) {
+        const bool live = k0 + p_k < kend;
+        if (!(oka && live)) v.a = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!(okb && live)) v.b = make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(&As[buf][p_k * LDA + p_c]) = v.a;
+        *reinterpret_cast<float4*>(&Bs[buf][p_k * LDB + p_c]) = v.b;
+    };
+    f32x4 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = {0.0f, 0.0f, 0.0f, 0.0f};
+    auto multiply = [&](int buf) {
+        const float* as = &As[buf][(lane >> 4) * LDA + 64 * wr + (lane & 15)];
+        const float* bs = &Bs[buf][(lane >> 4) * LDB + 32 * wc + (lane & 15)];
+#pragma unroll
+        for (int ks = 0; ks < WG_K / 4; ++ks) {
+            float af[4], bf[2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = as[4 * ks * LDA + 16 * i];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bf[j] = bs[4 * ks * LDB + 16 * j];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+    };
+    Pair v0 = fetch();
+    Pair v1 = fetch();      // past the end: clamped re-loads, staged as zeros
+    stage(0, v0, kbeg);
+    __syncthreads();
+    v0 = fetch();
+    const int pairs = ((kend - kbeg + WG_K - 1) / WG_K + 1) / 2;
+    int k0 = kbeg;
+    for (int p = 0; p < pairs; ++p, k0 += 2 * WG_K) {
+        __builtin_amdgcn_sched_barrier(0);   // keep the requests in front of the MFMAs
+        multiply(0);
+        stage(1, v1, k0 + WG_K);
+        __syncthreads();
+        v1 = fetch();
+        __builtin_amdgcn_sched_barrier(0);
+        multiply(1);
+        stage(0, v0, k0 + 2 * WG_K);
+        __syncthreads();
+        v0 = fetch();
+    }
+    float* pz = jb.part + (long)bz * M * N;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + 32 * wc + 16 * j + (lane & 15);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + 64 * wr + 16 * i + 4 * (lane >> 4) + r;
+                if (m < M && n < N) pz[(long)m * N + n] = acc[i][j][r];
+            }
+        }
+}
+inline int wgrad_job_blocks(const WgradJob& j) { return j.gx * j.gy * j.gz; }
+
 // launches what wgrad_gemm(..., jobs) collected
 inline void wgrad_jobs_flush(hipStream_t s, WgradJobs& jobs) {
     if (jobs.count == 0) return;

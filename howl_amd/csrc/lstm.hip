@@ -539,7 +539,17 @@ __global__ __launch_bounds__(B8_THREADS) void lstm_bwd4_kernel(const float* __re
                                                                  const long long* __restrict__ lengths,
                                                                  const float* __restrict__ gates, const float* __restrict__ cs,
                                                                  const float* __restrict__ c0, float* __restrict__ dG,
-                                                                 float* __restrict__ bpart, int B, int T, int Tout) {
+                                                                 float* __restrict__ bpart, int B, int T, int Tout, int nrec,
+                                                                 WgradJob ride) {
+    // Blocks behind the first `nrec` do an unrelated job in the same launch: a weight gradient that does not depend on this
+    // recurrence (the head's first layer), on the CUs the recurrence leaves idle -- (B + 3) / 4 workgroups of 38-81 dependent
+    // steps occupy half of the device at B = 512.  The recurrence's blocks come first in dispatch order and wait for nobody.
+    if ((int)blockIdx.x >= nrec) {
+        __shared__ __attribute__((aligned(16))) float As[2][WG_K * WG_LDA];
+        __shared__ __attribute__((aligned(16))) float Bs[2][WG_K * WG_LDA];
+        wgrad_w8_body(ride, (int)blockIdx.x - nrec, As, Bs);
+        return;
+    }
     __shared__ __attribute__((aligned(16))) float dgt[4 * B4_DGS];   // this step's dG rows (MFMA A operand)
     __shared__ float partd[4][4 * B4_PS];                             // the four K ranges of dh_{t-1}
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1120,7 +1130,8 @@ int howl_lstm_fwd(const HowlLstmParams* p, const float* x, int B, int T, int M, 
 // together with the head's), and the slab folds go to `sums` (flushed by the caller)
 static int lstm_bwd_impl(const HowlLstmParams* p, const float* x, int B, int T, int M, const long long* lengths, const float* c0,
                          const HowlLstmSaved* sv, const float* dy, const float* dhT, const float* dcT, const HowlLstmGrads* g,
-                         void* ws, size_t ws_bytes, hipStream_t stream, SlabSums& sums, WgradJobs* jobs) {
+                         void* ws, size_t ws_bytes, hipStream_t stream, SlabSums& sums, WgradJobs* jobs,
+                         const WgradJob* ride = nullptr) {
     HOWL_REQUIRE(p && x && sv && g && ws, "howl_lstm_bwd: null pointer");
     HOWL_REQUIRE(dy || dhT, "howl_lstm_bwd: no incoming gradient");
     if (ws_bytes < howl_lstm_workspace_bytes(B, T)) {
@@ -1135,10 +1146,14 @@ static int lstm_bwd_impl(const HowlLstmParams* p, const float* x, int B, int T, 
     const int Tout = sv->t_out;
     const bool rows16 = lstm_rows16(B, T);
     {
-    HowlProfScope prof("lstm_bwd", stream, 2.0 * HID * G4 * (double)B * Tout);           // dG_t W_hh of every step
-    if (!rows16)
-        hipLaunchKernelGGL(lstm_bwd4_kernel, dim3((B + 3) / 4), dim3(B8_THREADS), 0, stream, dy, dhT, dcT,
-                           p->w_hh, lengths, (const float*)sv->gates, (const float*)sv->c, c0, sv->dgates, scratch_b, B, T, Tout);
+    // dG_t W_hh of every step (+ the job that rides along)
+    HowlProfScope prof("lstm_bwd", stream, 2.0 * HID * G4 * (double)B * Tout + (ride != nullptr ? 2.0 * (double)ride->M * ride->N * ride->K : 0.0));
+    if (!rows16) {
+        const int nrec = (B + 3) / 4;
+        hipLaunchKernelGGL(lstm_bwd4_kernel, dim3(nrec + (ride != nullptr ? wgrad_job_blocks(*ride) : 0)), dim3(B8_THREADS), 0, stream, dy,
+                           dhT, dcT, p->w_hh, lengths, (const float*)sv->gates, (const float*)sv->c, c0, sv->dgates, scratch_b, B, T,
+                           Tout, nrec, ride != nullptr ? *ride : WgradJob{});
+    }
     else
         hipLaunchKernelGGL(lstm_bwd_kernel, dim3((B + 15) / 16), dim3(LSTM_THREADS), 0, stream, dy, dhT, dcT, (const float*)pb,
                            lengths, (const float*)sv->gates, (const float*)sv->c, c0, sv->dgates, B, T, Tout);
@@ -1313,14 +1328,23 @@ int howl_seq_lstm_bwd(const HowlHeadParams* hp, int n_hid, int n_out, const floa
     if (rc != HOWL_OK) return rc;
     // The head's first-layer weight gradient (dz1^T H) depends on nothing the LSTM's backward produces, and the four-sequence
     // recurrence occupies (B + 3) / 4 CUs for its 38-81 dependent steps: while that leaves at least half of the device idle the
-    // job runs on the library's side lane next to the recurrence (18 us of the 65-us job launch at 512 x 38) instead of behind it.
-    HowlSideLane* lane = nullptr;
-    if (jobs.count > 0 && !lstm_rows16(B, T) && (B + 3) / 4 <= howl_num_cus() / 2) lane = howl_side_lane();
-    if (lane != nullptr) {
+    // job's blocks ride in the recurrence's launch (lstm_bwd4_kernel: 18 us of the 65-us job launch at 512 x 38).  HOWL_LSTM_RIDE:
+    // "lane" = the same job on the library's side lane instead (two cross-queue waits on the critical path: measured 9 us worse),
+    // "0" = behind the recurrence with the other weight gradients (round 4).
+    const char* ride_env = getenv("HOWL_LSTM_RIDE");
+    const bool idle_half = jobs.count == 1 && !lstm_rows16(B, T) && (B + 3) / 4 <= howl_num_cus() / 2;
+    const bool as_ride = idle_half && jobs.j[0].tn == 128 && (ride_env == nullptr || ride_env[0] == '1');
+    HowlSideLane* lane = idle_half && ride_env != nullptr && ride_env[0] == 'l' ? howl_side_lane() : nullptr;
+    WgradJob ride{};
+    if (as_ride) {
+        ride = jobs.j[0];
+        jobs.count = 0;
+        jobs.flops = 0.0;
+    } else if (lane != nullptr) {
         howl_lane_fork(lane, stream);
         wgrad_jobs_flush(lane->stream, jobs);
     }
-    rc = lstm_bwd_impl(p, x, B, T, M, lengths, c0, sv, dhs, nullptr, nullptr, g, ws, ws_bytes, stream, sums, &jobs);
+    rc = lstm_bwd_impl(p, x, B, T, M, lengths, c0, sv, dhs, nullptr, nullptr, g, ws, ws_bytes, stream, sums, &jobs, as_ride ? &ride : nullptr);
     if (rc != HOWL_OK) {
         if (lane != nullptr) howl_lane_join(lane, stream);
         return rc;
