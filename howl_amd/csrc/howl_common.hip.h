@@ -66,6 +66,24 @@ struct HowlProfScope {
     }
 };
 
+// One element of torch.optim.AdamW (decoupled weight decay; pretrain_gsc.py:93,133, train.py:256,302): the arithmetic of
+// howl_adamw_step's kernel, shared with the slab fold that applies the step to the gradients it has just summed.
+struct HowlAdamWCoef {
+    float lr, b1, b2, eps, wd, bc1, bc2_sqrt, gscale;
+};
+__device__ __forceinline__ void howl_adamw_element(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v, size_t i, float g,
+                                                   const HowlAdamWCoef& c) {
+    const float gi = g * c.gscale;
+    float pi = p[i] * (1.0f - c.lr * c.wd);
+    const float mi = m[i] + (gi - m[i]) * (1.0f - c.b1);
+    const float vi = c.b2 * v[i] + (1.0f - c.b2) * gi * gi;
+    const float denom = sqrtf(vi) / c.bc2_sqrt + c.eps;
+    pi -= (c.lr / c.bc1) * (mi / denom);
+    p[i] = pi;
+    m[i] = mi;
+    v[i] = vi;
+}
+
 #define HOWL_REQUIRE(cond, ...)                 \
     do {                                        \
         if (!(cond)) {                          \

@@ -513,7 +513,18 @@ constexpr int MAX_SLAB_JOBS = 8;
 struct SlabJobs {
     SlabJob j[MAX_SLAB_JOBS];
 };
-__global__ __launch_bounds__(256) void sum_slabs_multi_kernel(SlabJobs jobs) {
+// Optional optimiser step on the folded gradients (round 5: the seq-lstm step's AdamW launch -- 5 us of a 265-us step -- and its
+// pass over the gradients): p / m / v are the flat parameter and moment buffers, g0 the flat gradient buffer every job's `out`
+// points into; element `out - g0 + i` of the three is updated with the sum just written to out[i].
+struct SlabAdamW {
+    float* p;
+    const float* g0;
+    float* m;
+    float* v;
+    HowlAdamWCoef c;
+    int on;
+};
+__global__ __launch_bounds__(256) void sum_slabs_multi_kernel(SlabJobs jobs, SlabAdamW opt) {
     __shared__ float red[4][64];
     const SlabJob& jb = jobs.j[blockIdx.y];
     const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
@@ -542,6 +553,10 @@ __global__ __launch_bounds__(256) void sum_slabs_multi_kernel(SlabJobs jobs) {
         const float t = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
         jb.out[i] = t;
         if (jb.out2 != nullptr) jb.out2[i] = t;
+        if (opt.on) {
+            howl_adamw_element(opt.p, opt.m, opt.v, (size_t)(jb.out - opt.g0) + (size_t)i, t, opt.c);
+            if (jb.out2 != nullptr) howl_adamw_element(opt.p, opt.m, opt.v, (size_t)(jb.out2 - opt.g0) + (size_t)i, t, opt.c);
+        }
     }
 }
 
@@ -561,8 +576,23 @@ struct SlabSums {
         jobs.j[count++] = SlabJob{part, out, out2, n, nparts, stride};
         max_n = n > max_n ? n : max_n;
     }
+    // true when the queued folds write every element of the flat gradient buffer [g0, g0 + n) exactly once: only then may the
+    // optimiser step ride in the fold (a gradient that reaches the buffer by another path would miss its update)
+    bool covers(const float* g0, size_t n) const {
+        if (overflow || count == 0) return false;
+        size_t total = 0;
+        for (int q = 0; q < count; ++q) {
+            const SlabJob& jb = jobs.j[q];
+            for (const float* o : {(const float*)jb.out, (const float*)jb.out2}) {
+                if (o == nullptr) continue;
+                if (o < g0 || o + jb.n > g0 + n) return false;
+                total += (size_t)jb.n;
+            }
+        }
+        return total == n;      // (ranges of distinct parameters do not overlap: equal totals = a partition)
+    }
     // returns false (and sets the library's error string) when a fold was dropped by add(): the caller fails its call
-    bool flush(hipStream_t s) {
+    bool flush(hipStream_t s, const SlabAdamW* opt = nullptr) {
         if (overflow) {
             howl_set_error("SlabSums: more than %d folds queued between two flushes", MAX_SLAB_JOBS);
             overflow = false;
@@ -570,7 +600,8 @@ struct SlabSums {
             return false;
         }
         if (count == 0) return true;
-        hipLaunchKernelGGL(sum_slabs_multi_kernel, dim3((unsigned)((max_n + 63) / 64), count), dim3(256), 0, s, jobs);
+        hipLaunchKernelGGL(sum_slabs_multi_kernel, dim3((unsigned)((max_n + 63) / 64), count), dim3(256), 0, s, jobs,
+                           opt != nullptr ? *opt : SlabAdamW{nullptr, nullptr, nullptr, nullptr, HowlAdamWCoef{}, 0});
         count = 0;
         max_n = 0;
         return true;

@@ -15,6 +15,8 @@
 // workgroup on v_mfma_f32_16x16x4 (lstm_fwd / lstm_bwd: sixteen waves, gate columns permuted so that each wave holds i,f,g,o of
 // the same 8 hidden units) beyond.  The input projection x W_ih^T, the head's first layer and all weight gradients are batched
 // GEMMs outside the recurrence (howl_gemm.hip.h); the head's thin second layer is vector work (head_out / head_thin_bwd).
+#include <math.h>
+
 #include "howl_common.hip.h"
 #include "../../include/howl_hip.h"
 #include "howl_gemm.hip.h"
@@ -1317,8 +1319,11 @@ int howl_head_bwd(const HowlHeadParams* p, const float* x, int rows_inner, long 
 int howl_seq_lstm_bwd(const HowlHeadParams* hp, int n_hid, int n_out, const float* y1, const float* dy2, float* dz1, float* dhs,
                       const HowlHeadGrads* hg, const HowlCtcMean* ctc_mean, void* head_ws, size_t head_ws_bytes,
                       const HowlLstmParams* p, const float* x, int B, int T, int M, const long long* lengths, const float* c0,
-                      const HowlLstmSaved* sv, const HowlLstmGrads* g, void* ws, size_t ws_bytes, hipStream_t stream) {
+                      const HowlLstmSaved* sv, const HowlLstmGrads* g, void* ws, size_t ws_bytes, const HowlAdamW* adamw,
+                      hipStream_t stream) {
     HOWL_REQUIRE(sv && dhs, "howl_seq_lstm_bwd: null pointer");
+    HOWL_REQUIRE(adamw == nullptr || (adamw->p && adamw->g && adamw->m && adamw->v && adamw->n >= 1 && adamw->step >= 1),
+                 "howl_seq_lstm_bwd: incomplete HowlAdamW");
     HOWL_REQUIRE(sv->t_out == T, "howl_seq_lstm_bwd: t_out=%d != T=%d (use howl_head_bwd + howl_lstm_bwd)", sv->t_out, T);
     SlabSums sums;
     WgradJobs jobs;
@@ -1351,7 +1356,21 @@ int howl_seq_lstm_bwd(const HowlHeadParams* hp, int n_hid, int n_out, const floa
     }
     wgrad_jobs_flush(stream, jobs);
     if (lane != nullptr) howl_lane_join(lane, stream);
-    if (!sums.flush(stream)) return HOWL_E_ARG;
+    if (adamw != nullptr && sums.covers(adamw->g, adamw->n) && getenv("HOWL_NO_FOLD_ADAMW") == nullptr) {
+        // every gradient of the model leaves this call through the fold: the optimiser step rides in it
+        const double bc1 = 1.0 - pow((double)adamw->beta1, (double)adamw->step), bc2 = 1.0 - pow((double)adamw->beta2, (double)adamw->step);
+        const SlabAdamW opt{adamw->p, adamw->g, adamw->m, adamw->v,
+                            HowlAdamWCoef{adamw->lr, adamw->beta1, adamw->beta2, adamw->eps, adamw->weight_decay, (float)bc1,
+                                          (float)sqrt(bc2), adamw->grad_scale}, 1};
+        if (!sums.flush(stream, &opt)) return HOWL_E_ARG;
+    } else {
+        if (!sums.flush(stream)) return HOWL_E_ARG;
+        if (adamw != nullptr) {
+            const int rc2 = howl_adamw_step(adamw->p, adamw->g, adamw->m, adamw->v, adamw->n, adamw->lr, adamw->beta1, adamw->beta2,
+                                            adamw->eps, adamw->weight_decay, adamw->step, adamw->grad_scale, stream);
+            if (rc2 != HOWL_OK) return rc2;
+        }
+    }
     HOWL_CHECK_LAUNCH("howl_seq_lstm_bwd");
     return HOWL_OK;
 }

@@ -2039,19 +2039,9 @@ __global__ __launch_bounds__(1024) void xent_kernel(const float* __restrict__ lo
 
 // fused flat AdamW (torch.optim.AdamW defaults; pretrain_gsc.py:93,133)
 __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                             float* __restrict__ v, size_t n, float lr, float b1, float b2, float eps, float wd,
-                             float bc1, float bc2_sqrt, float gscale) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const float gi = g[i] * gscale;
-        float pi = p[i] * (1.0f - lr * wd);
-        const float mi = m[i] + (gi - m[i]) * (1.0f - b1);
-        const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
-        const float denom = sqrtf(vi) / bc2_sqrt + eps;
-        pi -= (lr / bc1) * (mi / denom);
-        p[i] = pi;
-        m[i] = mi;
-        v[i] = vi;
-    }
+                             float* __restrict__ v, size_t n, HowlAdamWCoef c) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        howl_adamw_element(p, m, v, i, g[i], c);
 }
 
 size_t conv0_tile_floats(int T, int M) { return (size_t)(T + 2) * (M + 4) + 3 * (M + 4) + 16; }   // tile + slack (conv0_fwd_mfma_kernel)
@@ -2580,8 +2570,8 @@ int howl_adamw_step(float* p, const float* g, float* m, float* v, size_t n, floa
     const double bc2 = 1.0 - pow((double)beta2, (double)step);
     size_t blocks = (n + 255) / 256;
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, p, g, m, v, n, lr, beta1, beta2, eps,
-                       weight_decay, (float)bc1, (float)sqrt(bc2), grad_scale);
+    hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, p, g, m, v, n,
+                       HowlAdamWCoef{lr, beta1, beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2), grad_scale});
     HOWL_CHECK_LAUNCH("howl_adamw_step");
     return HOWL_OK;
 }

@@ -56,6 +56,11 @@ class HowlCtcMean(ctypes.Structure):
     _fields_ = [("nll", P), ("target_lengths", P), ("B", c_int), ("loss", P)]
 
 
+class HowlAdamW(ctypes.Structure):
+    _fields_ = [("p", P), ("g", P), ("m", P), ("v", P), ("n", c_size_t), ("lr", c_float), ("beta1", c_float), ("beta2", c_float),
+                ("eps", c_float), ("weight_decay", c_float), ("step", c_int), ("grad_scale", c_float)]
+
+
 class HowlLstmSaved(ctypes.Structure):
     _fields_ = [("gx", P), ("gates", P), ("c", P), ("hseq", P), ("dgates", P), ("t_out", c_int), ("x_frames", c_int)]
 
@@ -109,7 +114,7 @@ SIGNATURES = {
                       POINTER(HowlHeadGrads), POINTER(HowlCtcMean), P, c_size_t, STREAM],
     "howl_seq_lstm_bwd": [POINTER(HowlHeadParams), c_int, c_int, P, P, P, P, POINTER(HowlHeadGrads), POINTER(HowlCtcMean), P,
                           c_size_t, POINTER(HowlLstmParams), P, c_int, c_int, c_int, P, P, POINTER(HowlLstmSaved),
-                          POINTER(HowlLstmGrads), P, c_size_t, STREAM],
+                          POINTER(HowlLstmGrads), P, c_size_t, POINTER(HowlAdamW), STREAM],
     "howl_adamw_step": [P, P, P, P, c_size_t, c_float, c_float, c_float, c_float, c_float, c_int, c_float, STREAM],
     "howl_mobilenet_layer": [c_int, POINTER(HowlMbLayer)],
     "howl_mobilenet_fwd": [P, P, c_int, P, c_long, c_long, c_long, c_int, c_int, c_int, c_int, P, c_float, P, P, c_size_t,

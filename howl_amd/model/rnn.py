@@ -153,9 +153,10 @@ def _head_backward_raw(x, y1, dy2, w1, b1, w2, b2, need_dx=True, grads=None, ctc
     return dx, grads
 
 
-def _seq_backward_raw(saved, y1, dy2, head_params, grads, ctc_mean=None):
+def _seq_backward_raw(saved, y1, dy2, head_params, grads, ctc_mean=None, adamw=None):
     """``howl_seq_lstm_bwd``: head + LSTM backward of the sequence model in one call (t_out == T); ``grads`` = the eight flat-buffer
-    views in ``hot_parameters()`` order."""
+    views in ``hot_parameters()`` order.  ``adamw`` = (flat params, flat grads, m, v, lr, (beta1, beta2), eps, weight_decay, step,
+    grad_scale): the optimiser step is part of the call (``HowlAdamW``)."""
     x, lengths, c0, w_ih, w_hh, b_ih, b_hh, gates, cs, hseq, ws = saved
     w1, b1, w2, b2 = head_params
     B, T, M = x.shape
@@ -176,9 +177,13 @@ def _seq_backward_raw(saved, y1, dy2, head_params, grads, ctc_mean=None):
     prm = _lib.HowlLstmParams(_vp(w_ih), _vp(w_hh), _vp(b_ih), _vp(b_hh))
     sv = _lib.HowlLstmSaved(None, _vp(gates), _vp(cs), _vp(hseq), _vp(dgates), T, _x_frames(x))
     gr = _lib.HowlLstmGrads(*[_vp(g) for g in grads[:4]])
+    opt = None
+    if adamw is not None:
+        flat, fgrad, m, v, lr, betas, eps, wd, step, gscale = adamw
+        opt = ctypes.byref(_lib.HowlAdamW(_vp(flat), _vp(fgrad), _vp(m), _vp(v), flat.numel(), lr, betas[0], betas[1], eps, wd, step, gscale))
     _lib.get().call("howl_seq_lstm_bwd", ctypes.byref(hp), n_hid, n_out, _vp(y1), _vp(dy2), _vp(dz1), _vp(dhs), ctypes.byref(hg), cm,
                     _vp(head_ws), head_ws.numel(), ctypes.byref(prm), _vp(x), B, T, M, _vp(lengths), _vp(c0), ctypes.byref(sv),
-                    ctypes.byref(gr), _vp(ws), ws.numel(), ops._stream())
+                    ctypes.byref(gr), _vp(ws), ws.numel(), opt, ops._stream())
 
 
 class _HeadFunction(torch.autograd.Function):
@@ -291,15 +296,18 @@ class SequentialLstm(_LstmBase, name="seq-lstm"):
             self.streaming_state = (hT.detach().clone().unsqueeze(0), cT.detach().clone().unsqueeze(0))
         return y2.permute(1, 0, 2)
 
-    def _launch_backward(self, dscores, out_grads=None, ctc_mean=None):
+    def _launch_backward(self, dscores, out_grads=None, ctc_mean=None, adamw=None):
         """dscores: d loss / d scores as a (T_len, B, num_labels) view of a (B, T_len, num_labels) buffer (ops.ctc_loss_fwd_bwd);
-        ``ctc_mean`` = (nll, target_lengths, loss) when the loss launch left its batch mean to the head's backward."""
+        ``ctc_mean`` = (nll, target_lengths, loss) when the loss launch left its batch mean to the head's backward;
+        ``adamw``: see ``_seq_backward_raw`` -- ``self.optimizer_step_done`` says whether the call took it."""
         saved, t_out, hs, y1 = self._seq_saved
         ps = self.hot_parameters()
         grads = out_grads if out_grads is not None else [torch.empty_like(p) for p in ps]
         x = saved[0]
+        self.optimizer_step_done = False
         if t_out == x.shape[1]:      # whole buffer ran: one call, the wide weight gradients and the slab folds merged (12 launches)
-            _seq_backward_raw(saved, y1, dscores.permute(1, 0, 2), ps[4:8], grads, ctc_mean)
+            _seq_backward_raw(saved, y1, dscores.permute(1, 0, 2), ps[4:8], grads, ctc_mean, adamw)
+            self.optimizer_step_done = adamw is not None
         else:
             dhs, _ = _head_backward_raw(hs, y1, dscores.permute(1, 0, 2), *ps[4:8], True, grads[4:8], ctc_mean)
             _lstm_backward_raw(saved, t_out, dhs, None, None, grads[:4])

@@ -151,15 +151,21 @@ class FusedTrainer:
                                                 blank)
             loss.backward()
             loss, dscores = loss.detach(), z.grad
-        self.model._launch_backward(dscores, out_grads=self.fp.grad_views, ctc_mean=ctc_mean)
+        # single replica: nothing sits between the backward's gradient fold and the optimiser, so the step rides in the fold
+        # (howl_seq_lstm_bwd's HowlAdamW: one launch and one pass over the gradients fewer)
+        adamw = None
+        if self.world == 1:
+            adamw = (self.fp.flat, self.fp.grad, self.m, self.v, self.lr, self.betas, self.eps, self.weight_decay, self.step_count + 1, 1.0)
+        self.model._launch_backward(dscores, out_grads=self.fp.grad_views, ctc_mean=ctc_mean, adamw=adamw)
         if self.skip_allreduce:
             scale, self.collectives_last_step = 1.0 / self.world, 0
         else:
             scale = parallel.allreduce_sum_(self.fp.grad, self.group)
             self.collectives_last_step = self.collectives_last_step_reduced = 1 if self.world > 1 else 0
         self.step_count += 1
-        ops.adamw_step(self.fp.flat, self.fp.grad, self.m, self.v, self.lr, self.betas, self.eps, self.weight_decay,
-                       self.step_count, scale)
+        if not getattr(self.model, "optimizer_step_done", False):
+            ops.adamw_step(self.fp.flat, self.fp.grad, self.m, self.v, self.lr, self.betas, self.eps, self.weight_decay,
+                           self.step_count, scale)
         self.last_logits = scores
         return loss
 

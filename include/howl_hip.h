@@ -232,6 +232,19 @@ int howl_ctc_loss(const float* logits, long st_t, long st_b, int T, int B, int C
  * step counts from 1; grad_scale multiplies g on the fly (1/world_size after a sum all-reduce). */
 int howl_adamw_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
                     float eps, float weight_decay, int step, float grad_scale, hipStream_t stream);
+/* The same step as an argument of a backward call that ends in a fold of ALL of the model's gradients (howl_seq_lstm_bwd): the
+ * fold applies it to each gradient element as it writes it (one launch and one pass over the gradients fewer).  p / g / m / v: the
+ * flat buffers of n floats the call's gradient pointers lie in. */
+typedef struct {
+    float* p;
+    float* g;
+    float* m;
+    float* v;
+    size_t n;
+    float lr, beta1, beta2, eps, weight_decay;
+    int step;
+    float grad_scale;
+} HowlAdamW;
 
 /* ---------------------------------------------------------------------------------------------------
  * LSTM classifiers: howl/model/rnn.py:41-91 (SequentialLstm "seq-lstm", SimpleLstm "lstm"):
@@ -316,12 +329,14 @@ int howl_head_bwd(const HowlHeadParams* p, const float* x, int rows_inner, long 
 /* Backward of the whole sequence model (SequentialLstm, rnn.py:60-71: dnn(lstm(x))) in one call: howl_head_bwd on the hidden
  * states h_1 .. h_T read in place from saved->hseq, then howl_lstm_bwd on the gradient it leaves in dhs (B, T, 128) -- the same
  * arithmetic, but the three wide weight gradients (dnn[0].weight, W_ih, W_hh) run as ONE launch and all slab folds as one
- * (12 launches per seq-lstm training step instead of 15).  Requires saved->t_out == T; head_ws / ws as for the two calls. */
+ * (12 launches per seq-lstm training step instead of 15).  Requires saved->t_out == T; head_ws / ws as for the two calls.
+ * adamw != NULL: the optimiser step on the flat buffers is part of the call (inside the fold when every gradient pointer lies in
+ * adamw->g and together they cover it; as howl_adamw_step's launch behind it otherwise). */
 int howl_seq_lstm_bwd(const HowlHeadParams* head, int n_hid, int n_out, const float* y1, const float* dy2, float* dz1, float* dhs,
                       const HowlHeadGrads* head_grads, const HowlCtcMean* ctc_mean /* NULL: none */, void* head_ws,
                       size_t head_ws_bytes, const HowlLstmParams* p, const float* x, int B, int T, int M,
                       const long long* lengths, const float* c0, const HowlLstmSaved* saved, const HowlLstmGrads* grads, void* ws,
-                      size_t ws_bytes, hipStream_t stream);
+                      size_t ws_bytes, const HowlAdamW* adamw /* NULL: gradients only */, hipStream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * MobileNetClassifier, registry name "mobilenet" (replaces howl/model/cnn.py:15-29: downsample conv/BN/ReLU/pool +

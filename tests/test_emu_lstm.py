@@ -6,7 +6,7 @@ import pytest
 import torch
 
 from emu_util import emu_lib, ptr
-from howl_amd.lib import HowlHeadGrads, HowlHeadParams, HowlLstmGrads, HowlLstmParams, HowlLstmSaved
+from howl_amd.lib import HowlAdamW, HowlHeadGrads, HowlHeadParams, HowlLstmGrads, HowlLstmParams, HowlLstmSaved
 from oracle import models as om
 
 
@@ -265,7 +265,7 @@ def test_seq_lstm_backward_in_one_call(lib, monkeypatch, big):
     keep["bufs"]["dgates"][:] = np.nan
     lib.call("howl_seq_lstm_bwd", ctypes.byref(hp), 256, 5, ptr(y1), ptr(dy2), ptr(dz1_b), ptr(dhs_b), ctypes.byref(hgs), None,
              ptr(head_ws), head_ws.size, ctypes.byref(keep["prm"]), ptr(keep["x"]), B, T, M, ptr(keep["ln"]), None,
-             ctypes.byref(keep["sv"]), ctypes.byref(lgs), ptr(keep["ws"]), keep["ws"].size, None)
+             ctypes.byref(keep["sv"]), ctypes.byref(lgs), ptr(keep["ws"]), keep["ws"].size, None, None)
     np.testing.assert_array_equal(dz1, dz1_b)
     np.testing.assert_array_equal(dhs, dhs_b)
     np.testing.assert_array_equal(dgates_a, keep["bufs"]["dgates"])
@@ -275,3 +275,60 @@ def test_seq_lstm_backward_in_one_call(lib, monkeypatch, big):
     for k in lg_a:
         assert np.isfinite(lg_a[k]).all(), k
         np.testing.assert_array_equal(lg_a[k], lg_b[k], err_msg=k)
+
+
+@pytest.mark.parametrize("big", [False, True])
+def test_seq_lstm_backward_with_the_optimiser_step_in_the_fold(lib, monkeypatch, big):
+    """howl_seq_lstm_bwd(..., HowlAdamW) == howl_seq_lstm_bwd + howl_adamw_step on the same flat buffers, bit for bit: gradients,
+    parameters and both moments -- whether the step rides in the slab fold (every gradient leaves through it: ``big``) or runs as
+    the optimiser's own launch behind it (the small-shape GEMM path folds some gradients elsewhere)."""
+    if big:
+        monkeypatch.setenv("HOWL_WGRAD_BIG_MIN_ROWS", "1")
+        monkeypatch.setenv("HOWL_ROWGEMM_MIN_ROWS", "1")
+    rng = np.random.default_rng(5)
+    B, T, M = 8, 9, 40
+    x = rng.standard_normal((B, T, M)).astype(np.float32)
+    lengths = np.array([9, 9, 8, 8, 6, 5, 3, 1], np.int64)
+    sd = om.lstm_init(5)
+    _, _, _, keep = run_lstm(lib, sd, x, lengths)
+    names = ["lstm.weight_ih_l0", "lstm.weight_hh_l0", "lstm.bias_ih_l0", "lstm.bias_hh_l0", "dnn.0.weight", "dnn.0.bias", "dnn.2.weight",
+             "dnn.2.bias"]
+    sizes = [sd[k].numel() for k in names]
+    offs = np.concatenate([[0], np.cumsum(sizes)])
+    n = int(offs[-1])
+    w1, b1, w2, b2 = (np.ascontiguousarray(sd[k].numpy()) for k in names[4:])
+    hseq = keep["bufs"]["hseq"]
+    np.nan_to_num(hseq, copy=False)
+    h1 = np.ascontiguousarray(hseq.reshape(-1)[128:])
+    y1, y2 = np.zeros((B * T, 256), np.float32), np.zeros((B * T, 5), np.float32)
+    hp = HowlHeadParams(ptr(w1), ptr(b1), ptr(w2), ptr(b2))
+    lib.call("howl_head_fwd", ctypes.byref(hp), ptr(h1), T, (T + 1) * 128, 128, B * T, 128, 256, 5, ptr(y1), ptr(y2), None)
+    dy2 = rng.standard_normal((B * T, 5)).astype(np.float32)
+    head_ws = np.zeros(lib.cdll.howl_head_workspace_bytes(128, 256, 5), np.uint8)
+
+    def run(fused):
+        flat = np.concatenate([sd[k].numpy().reshape(-1) for k in names]).astype(np.float32)
+        g = np.full(n, np.nan, np.float32)
+        m, v = rng.standard_normal(n).astype(np.float32) * 0.01, np.abs(rng.standard_normal(n)).astype(np.float32) * 1e-4
+        m0, v0 = m.copy(), v.copy()
+        views = [g[offs[i]:offs[i + 1]] for i in range(8)]
+        lgs = HowlLstmGrads(*[ptr(a) for a in views[:4]])
+        hgs = HowlHeadGrads(*[ptr(a) for a in views[4:]])
+        dz1, dhs = np.zeros((B * T, 256), np.float32), np.zeros((B, T, 128), np.float32)
+        keep["bufs"]["dgates"][:] = np.nan
+        opt = HowlAdamW(ptr(flat), ptr(g), ptr(m), ptr(v), n, 0.01, 0.9, 0.999, 1e-8, 1e-2, 3, 1.0)
+        lib.call("howl_seq_lstm_bwd", ctypes.byref(hp), 256, 5, ptr(y1), ptr(dy2), ptr(dz1), ptr(dhs), ctypes.byref(hgs), None,
+                 ptr(head_ws), head_ws.size, ctypes.byref(keep["prm"]), ptr(keep["x"]), B, T, M, ptr(keep["ln"]), None,
+                 ctypes.byref(keep["sv"]), ctypes.byref(lgs), ptr(keep["ws"]), keep["ws"].size, ctypes.byref(opt) if fused else None, None)
+        if not fused:
+            lib.call("howl_adamw_step", ptr(flat), ptr(g), ptr(m), ptr(v), n, 0.01, 0.9, 0.999, 1e-8, 1e-2, 3, 1.0, None)
+        return flat, g, m, v, m0, v0
+
+    rng_state = rng.bit_generator.state
+    a = run(False)
+    rng.bit_generator.state = rng_state      # the same starting moments for the second run
+    b_ = run(True)
+    for u, w in zip(a, b_):
+        assert np.isfinite(u).all()
+        np.testing.assert_array_equal(u, w)
+    assert not np.array_equal(a[0], np.concatenate([sd[k].numpy().reshape(-1) for k in names]))      # the step did move the weights
