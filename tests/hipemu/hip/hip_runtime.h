@@ -102,6 +102,7 @@ static inline void __threadfence() {}
 template <class T> static inline T hipemu_fetch_add(T* p, T v) { T o = *p; *p = o + v; return o; }
 #define __hip_atomic_fetch_add(p, v, order, scope) hipemu_fetch_add((p), (v))
 static inline void __builtin_amdgcn_s_waitcnt(int) {}
+static inline void __builtin_amdgcn_s_sleep(int) {}
 
 template <class T> static inline uint32_t hipemu_bits(T v) { uint32_t u; static_assert(sizeof(T) == 4, ""); memcpy(&u, &v, 4); return u; }
 template <class T> static inline T hipemu_from(uint32_t u) { T v; memcpy(&v, &u, 4); return v; }
