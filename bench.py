@@ -594,6 +594,7 @@ def main():
         import random
         random.seed(1234)       # the alpha draws (global `random`, transform.py:441): the same sequence on every rank
         std.train()
+    torch.manual_seed(1234)     # seq-lstm / mobilenet start from torch's initialisers: the same weights (and final_loss) every run
     model = RegisteredModel.find_registered_class(model_name)(C).to(dev)
     if model_name == "res8":
         model.load_state_dict(res8_closed_form_state(C), strict=False)

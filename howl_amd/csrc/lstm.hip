@@ -340,11 +340,18 @@ __global__ __launch_bounds__(F8_THREADS) void lstm_fwd4_kernel(const float* __re
             if (spins > (1 << 21)) __builtin_trap();      // ~1 s of polling: the riders are gone -- fail loudly, never hang
         }
     };
-    if constexpr (RIDE) {
+    float nx1[4] = {0.0f, 0.0f, 0.0f, 0.0f};      // RIDE: the terms of step t + 1 while nx holds step t's (requested TWO steps ahead:
+    if constexpr (RIDE) {                          // a load past the L2 takes longer than one 1.7-us step)
         wait_ready(min(2, Tout));
         if (tid == 0) s_ready[0] = s_ready[1] = ready;
 #pragma unroll
         for (int r = 0; r < 4; ++r) nx[r] = ldx(go[r]);
+        const unsigned adv = 1 < Tout ? gstep : 0u;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            go[r] += adv;
+            nx1[r] = ldx(go[r]);
+        }
     }
     // sigmoid(x) = 1 / (1 + 2^(-x log2 e)); the cell-candidate gate is tanh(x) = 2 sigmoid(2x) - 1
     const float kneg = g == 2 ? -2.88539008177792681f : -1.44269504088896341f;
@@ -364,10 +371,10 @@ __global__ __launch_bounds__(F8_THREADS) void lstm_fwd4_kernel(const float* __re
             xb += t + 2 < Tout ? XP * 4u : 0u;
             xn = ldg(gx, xb);
         } else if constexpr (RIDE) {
-            // step t + 1's terms: its tile must be up (two steps of lead are kept; wave 0 asks for more flags every step and
-            // reads the answers a step later, so this blocks only when the riders really are behind)
+            // step t + 2's terms: its tile must be up (wave 0 asks for more flags every step and reads the answers a step later,
+            // so this blocks only when the riders really are behind)
             ready = max(ready, s_ready[t & 1]);
-            if (ready < min(t + 2, Tout)) wait_ready(min(t + 2, Tout));
+            if (ready < min(t + 3, Tout)) wait_ready(min(t + 3, Tout));
             if (c == 0) {
                 int nr = ready;
                 if (fl_base >= 0) nr = max(nr, min(fl_base + harvest(), Tout));
@@ -375,11 +382,12 @@ __global__ __launch_bounds__(F8_THREADS) void lstm_fwd4_kernel(const float* __re
                 if (nr < Tout) request(nr);
                 else fl_base = -1;
             }
-            const unsigned adv = t + 1 < Tout ? gstep : 0u;
+            const unsigned adv = t + 2 < Tout ? gstep : 0u;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 go[r] += adv;
-                nx[r] = ldx(go[r]);
+                nx[r] = nx1[r];                 // (pre[] above took step t's)
+                nx1[r] = ldx(go[r]);
             }
         } else {   // next step's input-projection terms (the last step re-reads its own)
             const float* gxn = gx + (t + 1 < Tout ? G4 : 0);
