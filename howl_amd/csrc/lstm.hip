@@ -148,6 +148,7 @@ struct LstmRide {
     unsigned* flags;      // one per 16-row tile of gx: == epoch when the tile is written
     unsigned epoch;       // unique per call: stale flags of earlier calls never match
     int M, xframes, nproj, ntiles, rows;
+    int dbg;   // TEMPORARY measurement switches (HOWL_LSTM_RIDE_DBG): 1 = plain gx loads, 2 = wait for every tile first, never poll
 };
 constexpr int XPJ_KG = 3;                    // K groups of 16 the riders multiply: M <= 48 input features, zero-padded
 constexpr int XPJ_LDW = 16 * XPJ_KG + 4;
@@ -192,6 +193,11 @@ __device__ __forceinline__ void xproj_role(const LstmRide& rd, int B) {
     float4 pre = fetch(tile);
     stage(0, pre);
     __syncthreads();
+    // A tile's flag goes up ONE tile later: its stores are acknowledged while the next tile multiplies (waiting for them on the
+    // spot cost ~3 us per 1.4-us tile: the riders then produced a time step per 1.2 us, hardly ahead of the recurrence's 1.6).
+    // Stores of a wave are acknowledged in issue order, so "at most this tile's eight stores outstanding" (vmcnt(8)) means the
+    // previous tile's are through; the barrier that follows collects that statement from every thread.
+    int prev = -1;
     for (; tile < rd.ntiles; tile += rd.nproj, cur ^= 1) {
         pre = fetch(tile + rd.nproj);
         f32x4 acc[4];
@@ -214,11 +220,20 @@ __device__ __forceinline__ void xproj_role(const LstmRide& rd, int B) {
             st_agent8(orow + 16 * i, acc[i][0], acc[i][1]);
             st_agent8(orow + 16 * i + 2, acc[i][2], acc[i][3]);
         }
-        stage(cur ^ 1, pre);
-        __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): this thread's part of the tile is acknowledged at the coherent level
-        __syncthreads();                         // ... everybody's; and the next tile's pieces are in LDS
-        if (tid == 0) __hip_atomic_store(rd.flags + tile, rd.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_sched_barrier(0);
+        stage(cur ^ 1, pre);      // behind the stores: the wait for `pre` is then vmcnt(8) too, not a wait for the previous tile's stores
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);
+        __builtin_amdgcn_s_waitcnt(0x0F70 | 8);      // vmcnt(8) (gfx9 encoding: vmcnt[3:0] in bits 3:0, [5:4] in bits 15:14)
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);
+        __syncthreads();                             // the previous tile is acknowledged everywhere; the next tile's pieces are in LDS
+        if (tid == 0 && prev >= 0) __hip_atomic_store(rd.flags + prev, rd.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        prev = tile;
     }
+    __atomic_signal_fence(__ATOMIC_SEQ_CST);
+    __builtin_amdgcn_s_waitcnt(0x0F70);              // vmcnt(0)
+    __atomic_signal_fence(__ATOMIC_SEQ_CST);
+    __syncthreads();
+    if (tid == 0 && prev >= 0) __hip_atomic_store(rd.flags + prev, rd.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 constexpr int F8_HS = HID + 4;          // h rows in LDS (16-byte aligned rows for the float4 A-fragment reads)
@@ -311,12 +326,13 @@ __global__ __launch_bounds__(F8_THREADS) void lstm_fwd4_kernel(const float* __re
 #pragma unroll
     for (int r = 0; r < 4; ++r) go[r] = ((unsigned)min(b0 + r, B - 1) * G4 + col) * 4u;
     auto ldx = [&](unsigned boff) {      // past the XCD's L2 (global_load_dword sc1): the riders may sit on another XCD
+        if (ride.dbg & 1) return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(ride.gx) + boff);
         return __hip_atomic_load(reinterpret_cast<const float*>(reinterpret_cast<const char*>(ride.gx) + boff), __ATOMIC_RELAXED,
                                  __HIP_MEMORY_SCOPE_AGENT);
     };
     int ready = 0;
     unsigned fl = 0;         // wave 0: the flag of step fl_base + lane, requested a step ago
-    int fl_base = -1;
+    int fl_base = -1, fl_age = 0;
     auto request = [&](int base) {
         const unsigned tix = ((unsigned)min(base + lane, Tout - 1) * (unsigned)B + (unsigned)b0) >> 4;
         fl = __hip_atomic_load(ride.flags + tix, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -342,7 +358,7 @@ __global__ __launch_bounds__(F8_THREADS) void lstm_fwd4_kernel(const float* __re
     };
     float nx1[4] = {0.0f, 0.0f, 0.0f, 0.0f};      // RIDE: the terms of step t + 1 while nx holds step t's (requested TWO steps ahead:
     if constexpr (RIDE) {                          // a load past the L2 takes longer than one 1.7-us step)
-        wait_ready(min(2, Tout));
+        wait_ready((ride.dbg & 2) ? Tout : min(2, Tout));
         if (tid == 0) s_ready[0] = s_ready[1] = ready;
 #pragma unroll
         for (int r = 0; r < 4; ++r) nx[r] = ldx(go[r]);
@@ -375,12 +391,20 @@ __global__ __launch_bounds__(F8_THREADS) void lstm_fwd4_kernel(const float* __re
             // so this blocks only when the riders really are behind)
             ready = max(ready, s_ready[t & 1]);
             if (ready < min(t + 3, Tout)) wait_ready(min(t + 3, Tout));
-            if (c == 0) {
+            if (c == 0 && !(ride.dbg & 2)) {
+                // a request is read FOUR steps after it was made: a load past the L2 can take several microseconds while the
+                // riders stream 40 MB through the same path (read after one step, wave 0 -- and with it every step's barrier --
+                // waited for it: 77 us per launch against 62 for the bare recurrence)
                 int nr = ready;
-                if (fl_base >= 0) nr = max(nr, min(fl_base + harvest(), Tout));
+                if (fl_base >= 0 && ++fl_age >= 4) {
+                    nr = max(nr, min(fl_base + harvest(), Tout));
+                    fl_base = -1;
+                }
                 if (lane == 0) s_ready[(t + 1) & 1] = nr;
-                if (nr < Tout) request(nr);
-                else fl_base = -1;
+                if (fl_base < 0 && nr < Tout) {
+                    request(nr);
+                    fl_age = 0;
+                }
             }
             const unsigned adv = t + 2 < Tout ? gstep : 0u;
 #pragma unroll
@@ -1305,7 +1329,8 @@ int howl_lstm_fwd(const HowlLstmParams* p, const float* x, int B, int T, int M, 
         const int nrec = (B + 3) / 4, rows = B * sv->t_out, ntiles = (rows + 15) / 16;
         const int nproj = std::max(1, std::min(ntiles, howl_num_cus() - nrec));
         const LstmRide ride{x, p->w_ih, sv->gx, reinterpret_cast<unsigned*>(static_cast<char*>(ws) + lstm_ws_flags_offset(B)),
-                            0x40000000u | (++calls & 0x3FFFFFFFu), M, xf, nproj, ntiles, rows};
+                            0x40000000u | (++calls & 0x3FFFFFFFu), M, xf, nproj, ntiles, rows,
+                            getenv("HOWL_LSTM_RIDE_DBG") != nullptr ? atoi(getenv("HOWL_LSTM_RIDE_DBG")) : 0};
         hipLaunchKernelGGL((lstm_fwd4_kernel<0, true>), dim3(nproj + nrec), dim3(F8_THREADS), 0, stream, (const float*)nullptr,
                            (const float*)nullptr, 0, p->w_hh, p->b_ih, p->b_hh, lengths, h0, c0, sv->gates, sv->c, sv->hseq, hT, cT, B,
                            T, sv->t_out, ride);
