@@ -17,9 +17,6 @@
 // GEMMs outside the recurrence (howl_gemm.hip.h); the head's thin second layer is vector work (head_out / head_thin_bwd).
 #include <math.h>
 
-#include <algorithm>
-#include <atomic>
-
 #include "howl_common.hip.h"
 #include "../../include/howl_hip.h"
 #include "howl_gemm.hip.h"
@@ -130,115 +127,9 @@ __device__ __forceinline__ void quad_transpose(float (&v)[4], bool bit0, bool bi
 //   a step, in exchange for the projection's launch (18 us at 512 x 38 x 40) and its (B, T, 512) buffer written and read back.
 //   `gx` is then x itself: row (b, t) at (b * xframes + t) * XM floats.
 constexpr int F8_THREADS = 512;
-// RIDE (round 5): the input projection runs NEXT TO the recurrence instead of inside it (fused: 40 more matrix instructions on
-// the 128 of every dependent step, 0.43 of a 2.1-us step) or in front of it (a launch of its own: 18 us) -- as the first
-// `nproj` blocks of the recurrence's launch, on the CUs the recurrence leaves idle ((B + 3) / 4 workgroups: half of the device
-// at B = 512).  The rider blocks write gx TIME-MAJOR, gx[(t B + b)][512] = x[b][t][:] W_ih^T, sixteen rows (one MFMA tile) at a
-// time in time order, each tile with stores that go through to the device-coherent level, and then raise the tile's flag; a
-// recurrence workgroup reads the flag of the tile its four sequences' rows of step t sit in -- two steps ahead of its use,
-// from one wave, so that no step waits for a flag's round trip -- and loads gx past the (non-coherent) L2 of its XCD.
-//   * no deadlock by construction: the riders come first in dispatch order and wait for nobody;
-//   * the polls are bounded: a recurrence that does not see a flag within ~1 s traps (a loud failure, never a hang);
-//   * the protocol is mobilenet.hip's arrive(): relaxed device-scope atomics + vmcnt(0) = "acknowledged at the coherent level",
-//     validated on gfx950 only (this library builds for nothing else).
-struct LstmRide {
-    const float* x;       // (B, xframes, M) features
-    const float* wih;     // (512, M)
-    float* gx;            // (Tout B, 512), time-major
-    unsigned* flags;      // one per 16-row tile of gx: == epoch when the tile is written
-    unsigned epoch;       // unique per call: stale flags of earlier calls never match
-    int M, xframes, nproj, ntiles, rows;
-    int dbg;   // TEMPORARY measurement switches (HOWL_LSTM_RIDE_DBG): 1 = plain gx loads, 2 = wait for every tile first, never poll
-};
-constexpr int XPJ_KG = 3;                    // K groups of 16 the riders multiply: M <= 48 input features, zero-padded
-constexpr int XPJ_LDW = 16 * XPJ_KG + 4;
-__device__ __forceinline__ void st_agent8(float* p, float a, float b) {      // two floats, written through (global_store_dwordx2 sc1)
-    unsigned long long w = (unsigned long long)__float_as_uint(a) | ((unsigned long long)__float_as_uint(b) << 32);
-    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void xproj_role(const LstmRide& rd, int B) {
-    __shared__ __attribute__((aligned(16))) float xt[2][16 * XPJ_LDW];
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int mi = lane & 15, kq = lane >> 4;
-    const int nbase = 64 * wave;      // this wave's 64 gate columns (four 16-column tiles)
-    const int M = rd.M;
-    // A fragments: W_ih[n = nbase + 16 i + mi][k = 16 j + 4 kq + e] (reduction index permuted inside a group of 16: rowgemm_kernel)
-    float wv[4][XPJ_KG][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int jj = 0; jj < XPJ_KG; ++jj) {
-            const int n = nbase + 16 * i + mi, k0 = 16 * jj + 4 * kq;
-            const float4 t4 = *reinterpret_cast<const float4*>(rd.wih + (size_t)n * M + min(k0, M - 4));
-            wv[i][jj][0] = k0 < M ? t4.x : 0.0f;
-            wv[i][jj][1] = k0 < M ? t4.y : 0.0f;
-            wv[i][jj][2] = k0 < M ? t4.z : 0.0f;
-            wv[i][jj][3] = k0 < M ? t4.w : 0.0f;
-        }
-    for (int i = tid; i < 2 * 16 * XPJ_LDW; i += F8_THREADS) (&xt[0][0])[i] = 0.0f;      // columns M.. stay zero
-    // the 16 x M tile as 4 M float4 pieces: piece e -> (row e / (M / 4), columns 4 (e % (M / 4)) ..)
-    const int q4 = M >> 2;
-    const bool pthread = tid < 16 * q4;
-    const int prow = pthread ? tid / q4 : 0, pc4 = pthread ? tid - prow * q4 : 0;
-    auto fetch = [&](int tile) -> float4 {      // unconditional load from a clamped row
-        const int r = min(16 * min(tile, rd.ntiles - 1) + prow, rd.rows - 1);
-        const int t = r / B, b = r - t * B;
-        return *reinterpret_cast<const float4*>(rd.x + ((size_t)b * rd.xframes + t) * M + 4 * pc4);
-    };
-    auto stage = [&](int buf, const float4& v) {
-        if (pthread) *reinterpret_cast<float4*>(&xt[buf][prow * XPJ_LDW + 4 * pc4]) = v;
-    };
-    __syncthreads();
-    int tile = blockIdx.x, cur = 0;
-    float4 pre = fetch(tile);
-    stage(0, pre);
-    __syncthreads();
-    // A tile's flag goes up ONE tile later: its stores are acknowledged while the next tile multiplies (waiting for them on the
-    // spot cost ~3 us per 1.4-us tile: the riders then produced a time step per 1.2 us, hardly ahead of the recurrence's 1.6).
-    // Stores of a wave are acknowledged in issue order, so "at most this tile's eight stores outstanding" (vmcnt(8)) means the
-    // previous tile's are through; the barrier that follows collects that statement from every thread.
-    int prev = -1;
-    for (; tile < rd.ntiles; tile += rd.nproj, cur ^= 1) {
-        pre = fetch(tile + rd.nproj);
-        f32x4 acc[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) acc[i] = {0.0f, 0.0f, 0.0f, 0.0f};
-        const float* arow = &xt[cur][mi * XPJ_LDW + 4 * kq];
-#pragma unroll
-        for (int jj = 0; jj < XPJ_KG; ++jj) {
-            const float4 a = *reinterpret_cast<const float4*>(arow + 16 * jj);
-            const float av[4] = {a.x, a.y, a.z, a.w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[i][jj][e], av[e], acc[i], 0, 0, 0);
-        }
-        // D[n_local = 4 kq + r][m = mi]: four consecutive columns of row 16 tile + mi (rows past the end repeat the last row)
-        float* orow = rd.gx + (size_t)min(16 * tile + mi, rd.rows - 1) * G4 + nbase + 4 * kq;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            st_agent8(orow + 16 * i, acc[i][0], acc[i][1]);
-            st_agent8(orow + 16 * i + 2, acc[i][2], acc[i][3]);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        stage(cur ^ 1, pre);      // behind the stores: the wait for `pre` is then vmcnt(8) too, not a wait for the previous tile's stores
-        __atomic_signal_fence(__ATOMIC_SEQ_CST);
-        __builtin_amdgcn_s_waitcnt(0x0F70 | 8);      // vmcnt(8) (gfx9 encoding: vmcnt[3:0] in bits 3:0, [5:4] in bits 15:14)
-        __atomic_signal_fence(__ATOMIC_SEQ_CST);
-        __syncthreads();                             // the previous tile is acknowledged everywhere; the next tile's pieces are in LDS
-        if (tid == 0 && prev >= 0) __hip_atomic_store(rd.flags + prev, rd.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        prev = tile;
-    }
-    __atomic_signal_fence(__ATOMIC_SEQ_CST);
-    __builtin_amdgcn_s_waitcnt(0x0F70);              // vmcnt(0)
-    __atomic_signal_fence(__ATOMIC_SEQ_CST);
-    __syncthreads();
-    if (tid == 0 && prev >= 0) __hip_atomic_store(rd.flags + prev, rd.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
 constexpr int F8_HS = HID + 4;          // h rows in LDS (16-byte aligned rows for the float4 A-fragment reads)
 constexpr int F8_XS = 64 + 4;           // x rows in LDS (every lane of a wave reads its float4; columns XM.. are never multiplied)
-template <int XM, bool RIDE = false>
+template <int XM>
 __global__ __launch_bounds__(F8_THREADS) void lstm_fwd4_kernel(const float* __restrict__ gx, const float* __restrict__ wih, int xframes,
                                                                const float* __restrict__ whh,
                                                                const float* __restrict__ b_ih, const float* __restrict__ b_hh,
@@ -246,24 +137,16 @@ __global__ __launch_bounds__(F8_THREADS) void lstm_fwd4_kernel(const float* __re
                                                                const float* __restrict__ h0, const float* __restrict__ c0,
                                                                float* __restrict__ gates, float* __restrict__ cs,
                                                                float* __restrict__ hseq, float* __restrict__ hT,
-                                                               float* __restrict__ cT, int B, int T, int Tout, LstmRide ride) {
-    static_assert(!RIDE || XM == 0, "the riders' gx replaces the projection buffer of the XM = 0 form");
-    if constexpr (RIDE) {
-        if ((int)blockIdx.x < ride.nproj) {
-            xproj_role(ride, B);
-            return;
-        }
-    }
+                                                               float* __restrict__ cT, int B, int T, int Tout) {
     __shared__ __attribute__((aligned(16))) float hbuf[2][4 * F8_HS];
     __shared__ __attribute__((aligned(16))) float xbuf[2][4 * F8_XS];
-    __shared__ int s_ready[2], s_poll;
     constexpr int XP = XM > 0 ? XM : 4;
     const int tid = threadIdx.x, lane = tid & 63;
     const int c = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane >> 2, g = lane & 3;
     const int u = 16 * c + j;                       // hidden unit of this lane's quad
     const int col = g * HID + u;                    // MFMA role: its gate column in PyTorch order (i, f, g, o)
-    const int b0 = ((int)blockIdx.x - (RIDE ? ride.nproj : 0)) * 4;
+    const int b0 = blockIdx.x * 4;
     // W_hh[col][0..127] straight from the parameter (a 512-byte row per lane, 64 KB per wave out of L2) and the lane's bias
     // b_ih[col] + b_hh[col], which the input projection leaves out for this kernel: no packing launch
     float wB[128];
@@ -315,59 +198,9 @@ __global__ __launch_bounds__(F8_THREADS) void lstm_fwd4_kernel(const float* __re
         if (xthread) xbuf[0][xr * F8_XS + xm] = ldg(gx, xb);
         xb += Tout > 1 ? XP * 4u : 0u;
         xn = ldg(gx, xb);         // x_1
-    } else if constexpr (!RIDE) {
+    } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r) nx[r] = ldg(gx, gb[r]);
-    }
-    // RIDE: gx is time-major and written by the rider blocks of this launch.  `ready` = the number of leading time steps whose
-    // tile (the one this workgroup's four rows sit in) is known to be written; identical in every thread at every decision.
-    unsigned go[4];                                                             // gx[(t B + b0 + r)][col], byte offsets
-    const unsigned gstep = (unsigned)B * G4 * 4u;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) go[r] = ((unsigned)min(b0 + r, B - 1) * G4 + col) * 4u;
-    auto ldx = [&](unsigned boff) {      // past the XCD's L2 (global_load_dword sc1): the riders may sit on another XCD
-        if (ride.dbg & 1) return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(ride.gx) + boff);
-        return __hip_atomic_load(reinterpret_cast<const float*>(reinterpret_cast<const char*>(ride.gx) + boff), __ATOMIC_RELAXED,
-                                 __HIP_MEMORY_SCOPE_AGENT);
-    };
-    int ready = 0;
-    unsigned fl = 0;         // wave 0: the flag of step fl_base + lane, requested a step ago
-    int fl_base = -1, fl_age = 0;
-    auto request = [&](int base) {
-        const unsigned tix = ((unsigned)min(base + lane, Tout - 1) * (unsigned)B + (unsigned)b0) >> 4;
-        fl = __hip_atomic_load(ride.flags + tix, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        fl_base = base;
-    };
-    auto harvest = [&]() -> int {      // consecutive steps from fl_base whose flag was up when it was read
-        const unsigned long long bad = ~__ballot(fl == ride.epoch || fl_base + lane >= Tout);
-        return bad == 0 ? 64 : (int)__builtin_ctzll(bad);
-    };
-    auto wait_ready = [&](int need) {      // every thread, same `need`: block until that many steps are written (bounded)
-        for (int spins = 0; ready < need; ++spins) {
-            if (c == 0) {
-                request(ready);
-                const int cnt = harvest();
-                if (lane == 0) s_poll = min(ready + cnt, Tout);
-                if (cnt == 0) __builtin_amdgcn_s_sleep(16);
-            }
-            __syncthreads();
-            ready = s_poll;
-            __syncthreads();
-            if (spins > (1 << 21)) __builtin_trap();      // ~1 s of polling: the riders are gone -- fail loudly, never hang
-        }
-    };
-    float nx1[4] = {0.0f, 0.0f, 0.0f, 0.0f};      // RIDE: the terms of step t + 1 while nx holds step t's (requested TWO steps ahead:
-    if constexpr (RIDE) {                          // a load past the L2 takes longer than one 1.7-us step)
-        wait_ready((ride.dbg & 2) ? Tout : min(2, Tout));
-        if (tid == 0) s_ready[0] = s_ready[1] = ready;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) nx[r] = ldx(go[r]);
-        const unsigned adv = 1 < Tout ? gstep : 0u;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            go[r] += adv;
-            nx1[r] = ldx(go[r]);
-        }
     }
     // sigmoid(x) = 1 / (1 + 2^(-x log2 e)); the cell-candidate gate is tanh(x) = 2 sigmoid(2x) - 1
     const float kneg = g == 2 ? -2.88539008177792681f : -1.44269504088896341f;
@@ -386,33 +219,6 @@ __global__ __launch_bounds__(F8_THREADS) void lstm_fwd4_kernel(const float* __re
         if constexpr (XM > 0) {   // x_{t+2} (the last steps re-read the last frame: an unconditional load keeps the count exact)
             xb += t + 2 < Tout ? XP * 4u : 0u;
             xn = ldg(gx, xb);
-        } else if constexpr (RIDE) {
-            // step t + 2's terms: its tile must be up (wave 0 asks for more flags every step and reads the answers a step later,
-            // so this blocks only when the riders really are behind)
-            ready = max(ready, s_ready[t & 1]);
-            if (ready < min(t + 3, Tout)) wait_ready(min(t + 3, Tout));
-            if (c == 0 && !(ride.dbg & 2)) {
-                // a request is read FOUR steps after it was made: a load past the L2 can take several microseconds while the
-                // riders stream 40 MB through the same path (read after one step, wave 0 -- and with it every step's barrier --
-                // waited for it: 77 us per launch against 62 for the bare recurrence)
-                int nr = ready;
-                if (fl_base >= 0 && ++fl_age >= 4) {
-                    nr = max(nr, min(fl_base + harvest(), Tout));
-                    fl_base = -1;
-                }
-                if (lane == 0) s_ready[(t + 1) & 1] = nr;
-                if (fl_base < 0 && nr < Tout) {
-                    request(nr);
-                    fl_age = 0;
-                }
-            }
-            const unsigned adv = t + 2 < Tout ? gstep : 0u;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                go[r] += adv;
-                nx[r] = nx1[r];                 // (pre[] above took step t's)
-                nx1[r] = ldx(go[r]);
-            }
         } else {   // next step's input-projection terms (the last step re-reads its own)
             const float* gxn = gx + (t + 1 < Tout ? G4 : 0);
 #pragma unroll
@@ -1254,20 +1060,14 @@ bool lstm_rows16(int B, int T) {
 
 extern "C" {
 
-// [.. the regions below ..][tile flags of the riding input projection: one word per 16 rows of (T B), lstm_fwd4_kernel<0, true>]
-static size_t lstm_ws_flags_bytes(int B, int T) { return ((size_t)B * T / 16 + 2) * sizeof(unsigned) + 256; }
-static size_t lstm_ws_flags_offset(int B) {
-    const size_t bias_slabs = (size_t)(B + 3) / 4 > 256 ? (size_t)(B + 3) / 4 : 256;
-    return ((size_t)2 * 16 * 64 * 64 + G4 + (size_t)LSTM_WGRAD_SPLITS * G4 * HID + (size_t)LSTM_WGRAD_SPLITS * G4 * LSTM_MAX_IN +
-            bias_slabs * G4) * sizeof(float) + 1024;
-}
-
 size_t howl_lstm_workspace_bytes(int B, int T) {
     // packed W_hh of the 16-row recurrences (2 x 64K floats) + bias sum (512) + split-K scratch of the W_hh gradient
     // (128 x 512 x 128) + the W_ih gradient's own scratch (128 x 512 x 48 at most) + the bias column sums' (256 x 512):
     // three regions, so that the three final slab sums can run as one launch (the bias region holds one slab per workgroup
     // of the four-sequence recurrence, or the 256 of the column-sum kernel)
-    return lstm_ws_flags_offset(B) + lstm_ws_flags_bytes(B, T);
+    const size_t bias_slabs = (size_t)(B + 3) / 4 > 256 ? (size_t)(B + 3) / 4 : 256;
+    return ((size_t)2 * 16 * 64 * 64 + G4 + (size_t)LSTM_WGRAD_SPLITS * G4 * HID + (size_t)LSTM_WGRAD_SPLITS * G4 * LSTM_MAX_IN +
+            bias_slabs * G4) * sizeof(float) + 1024;
 }
 
 // (the four-sequence recurrence multiplies x_t W_ih^T itself when M = 40: no projection launch, gx unused)
@@ -1276,20 +1076,9 @@ static bool lstm_fuse_x(const HowlLstmParams* p, int B, int T, int M, int xf) {
            (size_t)B * (size_t)xf * M * sizeof(float) < ((size_t)1 << 32) && getenv("HOWL_LSTM_NO_FUSED_X") == nullptr;
 }
 
-// The projection as rider blocks of the recurrence's launch (lstm_fwd4_kernel<0, true>): the four-sequence recurrence with at
-// least half of the CUs to spare, whole workgroups of four sequences (a workgroup's rows of a step then sit in ONE tile),
-// M <= 48 features in float4 pieces.  HOWL_LSTM_RIDE_X=0 keeps the round-4 forms (fused into the step, or a launch in front).
-static bool lstm_ride_x(const HowlLstmParams* p, int B, int T, int M, int xf) {
-    const char* env = getenv("HOWL_LSTM_RIDE_X");
-    return !lstm_rows16(B, T) && (env == nullptr || env[0] != '0') && (B & 3) == 0 && (B + 3) / 4 <= howl_num_cus() / 2 && M >= 4 &&
-           M <= 16 * XPJ_KG && (M & 3) == 0 && (reinterpret_cast<uintptr_t>(p->w_ih) & 15) == 0 &&
-           (size_t)B * (size_t)(xf > T ? xf : T) * G4 * sizeof(float) < ((size_t)1 << 32);
-}
-
 size_t howl_lstm_needs_gx(const HowlLstmParams* p, int B, int T, int M, int x_frames) {
     if (p == nullptr || p->w_ih == nullptr) return 1;
-    const int xf = x_frames > 0 ? x_frames : T;
-    return lstm_ride_x(p, B, T, M, xf) || !lstm_fuse_x(p, B, T, M, xf) ? 1 : 0;
+    return lstm_fuse_x(p, B, T, M, x_frames > 0 ? x_frames : T) ? 0 : 1;
 }
 
 int howl_lstm_fwd(const HowlLstmParams* p, const float* x, int B, int T, int M, const long long* lengths, const float* h0,
@@ -1312,35 +1101,23 @@ int howl_lstm_fwd(const HowlLstmParams* p, const float* x, int B, int T, int M, 
         hipLaunchKernelGGL(lstm_pack_kernel, dim3(16 * 64 * 64 / 256), dim3(256), 0, stream, p->w_hh, pf, pb, p->b_ih, p->b_hh, bsum);
     const int xf = sv->x_frames > 0 ? sv->x_frames : T;
     HOWL_REQUIRE(xf >= T, "howl_lstm_fwd: x_frames=%d < T=%d", xf, T);
-    const bool ride_x = lstm_ride_x(p, B, T, M, xf) && sv->gx != nullptr && (reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
-                        (reinterpret_cast<uintptr_t>(sv->gx) & 15) == 0;
-    const bool fuse_x = !ride_x && lstm_fuse_x(p, B, T, M, xf);
+    const bool fuse_x = lstm_fuse_x(p, B, T, M, xf);
     HOWL_REQUIRE(fuse_x || sv->gx != nullptr, "howl_lstm_fwd: saved->gx is NULL but this shape runs the projection GEMM "
                                               "(howl_lstm_needs_gx)");
-    if (!fuse_x && !ride_x)
+    if (!fuse_x)
         gemm(stream, true, x, xf == T ? lin(M) : RowMap{T, (long)xf * M, M}, 1, lin(0), p->w_ih, lin(1), M, B * T, G4, M, 1,
              rows16 ? bsum : nullptr, 0, sv->gx, G4, 0);
     if (sv->t_out < T)   // rows of steps that never run are read (times zero) by the weight-gradient GEMM: keep them finite
         hipMemsetAsync(sv->hseq, 0, (size_t)B * (T + 1) * HID * sizeof(float), stream);
     // h_{t-1} W_hh^T of every step (+ x_t W_ih^T where the recurrence multiplies it itself)
-    HowlProfScope prof("lstm_fwd", stream, 2.0 * (HID + (fuse_x || ride_x ? M : 0)) * G4 * (double)B * sv->t_out);
-    if (ride_x) {
-        static std::atomic<unsigned> calls{0};
-        const int nrec = (B + 3) / 4, rows = B * sv->t_out, ntiles = (rows + 15) / 16;
-        const int nproj = std::max(1, std::min(ntiles, howl_num_cus() - nrec));
-        const LstmRide ride{x, p->w_ih, sv->gx, reinterpret_cast<unsigned*>(static_cast<char*>(ws) + lstm_ws_flags_offset(B)),
-                            0x40000000u | (++calls & 0x3FFFFFFFu), M, xf, nproj, ntiles, rows,
-                            getenv("HOWL_LSTM_RIDE_DBG") != nullptr ? atoi(getenv("HOWL_LSTM_RIDE_DBG")) : 0};
-        hipLaunchKernelGGL((lstm_fwd4_kernel<0, true>), dim3(nproj + nrec), dim3(F8_THREADS), 0, stream, (const float*)nullptr,
-                           (const float*)nullptr, 0, p->w_hh, p->b_ih, p->b_hh, lengths, h0, c0, sv->gates, sv->c, sv->hseq, hT, cT, B,
-                           T, sv->t_out, ride);
-    } else if (fuse_x) {
+    HowlProfScope prof("lstm_fwd", stream, 2.0 * (HID + (fuse_x ? M : 0)) * G4 * (double)B * sv->t_out);
+    if (fuse_x) {
         hipLaunchKernelGGL(lstm_fwd4_kernel<40>, dim3((B + 3) / 4), dim3(F8_THREADS), 0, stream, x, p->w_ih, xf,
-                           p->w_hh, p->b_ih, p->b_hh, lengths, h0, c0, sv->gates, sv->c, sv->hseq, hT, cT, B, T, sv->t_out, LstmRide{});
+                           p->w_hh, p->b_ih, p->b_hh, lengths, h0, c0, sv->gates, sv->c, sv->hseq, hT, cT, B, T, sv->t_out);
     } else if (!rows16) {
         hipLaunchKernelGGL(lstm_fwd4_kernel<0>, dim3((B + 3) / 4), dim3(F8_THREADS), 0, stream, (const float*)sv->gx,
                            (const float*)nullptr, 0, p->w_hh, p->b_ih, p->b_hh, lengths, h0, c0, sv->gates, sv->c, sv->hseq, hT, cT, B,
-                           T, sv->t_out, LstmRide{});
+                           T, sv->t_out);
     } else {
         const size_t lds_fwd = (size_t)(2 * 16 * HS + 2 * 16 * 6 * HID) * sizeof(float);
         hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fwd);

@@ -88,38 +88,6 @@ def test_lstm_forward_backward_ragged(lib, golden, monkeypatch, rows):
         np.testing.assert_allclose(gr[k], ref, rtol=0, atol=2e-5 * max(1.0, np.abs(ref).max()), err_msg=k)
 
 
-@pytest.mark.parametrize("B,extra", [(8, 0), (8, 3), (4, 0)])
-def test_forward_with_the_projection_riding_in_the_launch(lib, monkeypatch, B, extra):
-    """lstm_fwd4_kernel<0, true> (round 5): the input projection as rider blocks of the recurrence's launch -- time-major gx, one flag
-    per 16-row tile -- against the oracle's cell loop and against the projection fused into the step (HOWL_LSTM_RIDE_X=0): ragged
-    lengths, a feature buffer longer than T (x_frames); a 16-row tile holds two (B = 8) or four (B = 4) time steps (the emulated device has few CUs:
-    larger batches do not leave half of them idle and keep the fused form)."""
-    rng = np.random.default_rng(17 + B)
-    T, M = 11, 40
-    xbuf = rng.standard_normal((B, T + extra, M)).astype(np.float32)
-    lengths = np.sort(rng.integers(1, T + 1, size=B))[::-1].astype(np.int64).copy()
-    lengths[0] = T
-    sd = om.lstm_init(5)
-    h0 = rng.standard_normal((B, 128)).astype(np.float32) * 0.1
-    c0 = rng.standard_normal((B, 128)).astype(np.float32) * 0.1
-    out = {}
-    for mode in ("1", "0"):
-        monkeypatch.setenv("HOWL_LSTM_RIDE_X", mode)
-        prm = HowlLstmParams(*[ptr(np.ascontiguousarray(sd["lstm." + k].numpy())) for k in ("weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0")])
-        assert lib.cdll.howl_lstm_needs_gx(ctypes.byref(prm), B, T, M, T + extra) == (1 if mode == "1" else 0)
-        out[mode] = run_lstm(lib, sd, xbuf if extra else np.ascontiguousarray(xbuf[:, :T]), lengths, h0, c0, x_frames=T + extra if extra else 0)
-    xr = torch.from_numpy(np.ascontiguousarray(xbuf[:, :T])).permute(1, 0, 2).contiguous()
-    p = {k: v.clone() for k, v in sd.items() if k.startswith("lstm.")}
-    seq, (h_ref, c_ref) = om._lstm_cell_seq(p, xr, torch.from_numpy(lengths), (torch.from_numpy(h0)[None], torch.from_numpy(c0)[None]))
-    for mode in ("1", "0"):
-        hs, hT, cT, keep = out[mode]
-        np.testing.assert_allclose(hs, seq.detach().permute(1, 0, 2).numpy(), rtol=0, atol=2e-6, err_msg=mode)
-        np.testing.assert_allclose(hT, h_ref[0].detach().numpy(), rtol=0, atol=2e-6)
-        np.testing.assert_allclose(cT, c_ref[0].detach().numpy(), rtol=0, atol=2e-6)
-    # the saved activations the backward reads agree between the two forms to rounding
-    np.testing.assert_allclose(out["1"][3]["bufs"]["gates"], out["0"][3]["bufs"]["gates"], rtol=0, atol=2e-6)
-
-
 @pytest.mark.parametrize("min_rows", ["1", "1000000"])
 def test_lstm_input_inside_a_longer_feature_buffer(lib, monkeypatch, min_rows):
     """HowlLstmSaved.x_frames: the first T frames of a (B, T + 3, M) buffer used in place == the same frames copied out
