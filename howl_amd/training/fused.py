@@ -107,7 +107,8 @@ class FusedTrainer:
             n0 = min(-(-n0 // 64) * 64, self.fp.numel)
             # what that rounding relies on: an aligned base, and that the parameters the spill-over touches are complete
             # after part 1 (the model declares how many leading parameters part 2 still writes: only the first `late`)
-            assert self.fp.grad.data_ptr() % 256 == 0, "flat gradient buffer must be 256-byte aligned for the split"
+            assert not self.fp.grad.is_cuda or self.fp.grad.data_ptr() % 256 == 0, \
+                "flat gradient buffer must be 256-byte aligned for the split"
             assert sum(p.numel() for p in self.fp.params[:late + 1]) >= n0 or late + 1 >= len(self.fp.params), \
                 "the rounded split must end inside the first parameter that is final after part 1"
             self.model._launch_backward(feat, dlogits, out_grads=self.fp.grad_views, part=1, **bwd_kw)
