@@ -1323,8 +1323,20 @@ __global__ __launch_bounds__(CONV_THREADS) void bwd_pair_kernel(
 // (coalesced reads); its 4 waves split the rows, then combine through LDS in a fixed order.
 //   mode 0: out[col] = sum            (conv0: 405 columns)
 //   mode 1: col = (cout, tap, cin) of the wgrad accumulator layout [48][9][48] -> dW[(cout*45 + cin)*9 + tap]
+// Optional optimiser step in the backward's LAST launch (round 5, single replica): the rows this launch folds get their AdamW
+// update from the sum just written (`out - g0 + index` = the element's place in the flat parameter / moment buffers), and one
+// more row of blocks walks the rest of the flat buffer [rest_lo, rest_hi) -- the gradients that were final before this launch.
+struct RowsAdamW {
+    float* p;
+    const float* g0;
+    float* m;
+    float* v;
+    HowlAdamWCoef c;
+    long rest_lo, rest_hi;
+    int on;
+};
 __device__ __forceinline__ void reduce_rows_body(const float* __restrict__ part, int nparts, int ncols, int mode,
-                                                 float* __restrict__ out) {
+                                                 float* __restrict__ out, const RowsAdamW& opt) {
     __shared__ float red[16][64];
     const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6, nrg = blockDim.x >> 6;     // up to 16 row groups
     const int col = blockIdx.x * 64 + lane;
@@ -1349,11 +1361,16 @@ __device__ __forceinline__ void reduce_rows_body(const float* __restrict__ part,
     if (rg == 0 && col < ncols) {
         float tot = red[0][lane];
         for (int r = 1; r < nrg; ++r) tot += red[r][lane];
+        long d = -1;
         if (mode == 0) {
-            out[col] = tot;
+            d = col;
         } else {
             const int co = col / WNCOL, idx = col - co * WNCOL;      // idx = 45 tap + cin
-            if (co < NMAP && idx < WTAPS) out[(co * NMAP + idx % NMAP) * 9 + idx / NMAP] = tot;
+            if (co < NMAP && idx < WTAPS) d = (co * NMAP + idx % NMAP) * 9 + idx / NMAP;
+        }
+        if (d >= 0) {
+            out[d] = tot;
+            if (opt.on) howl_adamw_element(opt.p, opt.m, opt.v, (size_t)((out - opt.g0) + d), tot, opt.c);
         }
     }
 }
@@ -1362,13 +1379,19 @@ __device__ __forceinline__ void reduce_rows_body(const float* __restrict__ part,
 // part + l * layer_stride), blockIdx.y = 6 -> conv0 (its own partial rows)
 __global__ __launch_bounds__(1024) void reduce_rows_all_kernel(const float* __restrict__ part, size_t layer_stride, int nparts,
                                                               HowlPtrs6 out, const float* __restrict__ c0part, int c0parts,
-                                                              float* __restrict__ c0out, int y0, int yskip) {
-    // a launch covers rows y0, y0 + 1 + yskip, ... of {layer 1..6, conv0} (layers 2..6 are folded inside the pair launches)
+                                                              float* __restrict__ c0out, int y0, int yskip, int nrows, RowsAdamW opt) {
+    // a launch covers rows y0, y0 + 1 + yskip, ... of {layer 1..6, conv0} (layers 2..6 are folded inside the pair launches);
+    // blockIdx.y == nrows (one row more, with the optimiser step): the parameters whose gradients were final already
+    if ((int)blockIdx.y >= nrows) {
+        for (long i = opt.rest_lo + (long)blockIdx.x * blockDim.x + threadIdx.x; i < opt.rest_hi; i += (long)gridDim.x * blockDim.x)
+            howl_adamw_element(opt.p, opt.m, opt.v, (size_t)i, opt.g0[i], opt.c);
+        return;
+    }
     const int y = y0 + (int)blockIdx.y * (1 + yskip);
     if (y < 6) {
-        reduce_rows_body(part + y * layer_stride, nparts, CP * WNCOL, 1, out.p[y]);
+        reduce_rows_body(part + y * layer_stride, nparts, CP * WNCOL, 1, out.p[y], opt);
     } else if (blockIdx.x * 64 < NMAP * 9) {
-        reduce_rows_body(c0part, c0parts, NMAP * 9, 0, c0out);
+        reduce_rows_body(c0part, c0parts, NMAP * 9, 0, c0out, opt);
     }
 }
 
@@ -2390,8 +2413,10 @@ namespace {
 // and the batch mean of nll goes to `loss` (one more block of the head's parameter-gradient launch)
 int res8_bwd_impl(const HowlRes8Params* prm, const float* feat, long sb, long st, long sm, int B, int T, int M, int C,
                   const HowlRes8Saved* sv, const float* dlogits, const HowlRes8Grads* gr, void* ws, size_t ws_bytes,
-                  int part, const float* nll, float* loss, hipStream_t stream) {
+                  int part, const float* nll, float* loss, hipStream_t stream, const HowlAdamW* adamw = nullptr) {
     HOWL_REQUIRE(prm && feat && sv && dlogits && gr && ws, "howl_res8_bwd: null pointer");
+    HOWL_REQUIRE(adamw == nullptr || (part == 0 && adamw->p && adamw->g && adamw->m && adamw->v && adamw->n >= 1 && adamw->step >= 1),
+                 "howl_res8_bwd: HowlAdamW needs the whole pass (part 0) and complete buffers");
     HOWL_REQUIRE(part >= 0 && part <= 2, "howl_res8_bwd_part: part must be 0 (all), 1 or 2");
     const bool run_layers = part != 2, run_conv0 = part != 1;
     HOWL_REQUIRE(M == 40, "howl_res8_bwd: M must be 40");
@@ -2507,9 +2532,11 @@ int res8_bwd_impl(const HowlRes8Params* prm, const float* feat, long sb, long st
     const int S0 = conv0_slices(B);
     const int G0w = B * S0 < howl_num_cus() ? B * S0 : howl_num_cus();   // conv0's weight-gradient grid: one partial row each
     // layers 2..6 were folded inside the pair launches (WFold); layer 1's partials and conv0's remain
+    const RowsAdamW no_opt{nullptr, nullptr, nullptr, nullptr, HowlAdamWCoef{}, 0, 0, 0};
     if (part == 1)      // the six layers' weight gradients are final before conv0's is even started
         hipLaunchKernelGGL(reduce_rows_all_kernel, dim3((CP * WNCOL + 63) / 64, fold_in_pair ? 1 : 6), dim3(1024), 0, stream,
-                           (const float*)w.wpart, wpart_stride, Gh, gw, (const float*)w.c0part, G0w, gr->conv0_w, 0, 0);
+                           (const float*)w.wpart, wpart_stride, Gh, gw, (const float*)w.c0part, G0w, gr->conv0_w, 0, 0,
+                           fold_in_pair ? 1 : 6, no_opt);
     if (run_conv0) {
         {
         HowlProfScope prof("conv0_wgrad", stream);
@@ -2517,13 +2544,42 @@ int res8_bwd_impl(const HowlRes8Params* prm, const float* feat, long sb, long st
                            stream, feat, sb, st, sm, (const unsigned short*)sv->mask0, (const float*)dx_cur,
                            (const float*)nullptr, w.c0part, B, T, M, H, S0);
         }
-        if (part == 0)      // rows {layer 1, conv0} of the reduction (small batches: all six layers and conv0)
-            hipLaunchKernelGGL(reduce_rows_all_kernel, dim3((CP * WNCOL + 63) / 64, fold_in_pair ? 2 : 7), dim3(1024), 0, stream,
+        if (part == 0) {    // rows {layer 1, conv0} of the reduction (small batches: all six layers and conv0)
+            // ... and, on a single replica, the optimiser step (HowlAdamW): folded rows are updated as they are written, one more
+            // row of blocks takes the parameters whose gradients were final before this launch.  Only for gradient pointers
+            // that ARE the flat buffer in hot_parameters() order (conv0, conv1..6, output.weight, output.bias); otherwise the
+            // step runs as its own launch behind this one.
+            const int nrows = fold_in_pair ? 2 : 7;
+            RowsAdamW opt = no_opt;
+            bool own_launch = adamw != nullptr;
+            if (adamw != nullptr && getenv("HOWL_NO_FOLD_ADAMW") == nullptr) {
+                const float* g0 = adamw->g;
+                bool flat = gr->conv0_w == g0 && gr->out_b == gr->out_w + (size_t)NMAP * C &&
+                            adamw->n == (size_t)NMAP * 9 + (size_t)6 * NMAP * NMAP * 9 + (size_t)NMAP * C + (size_t)C &&
+                            gr->out_w == g0 + (size_t)NMAP * 9 + (size_t)6 * NMAP * NMAP * 9;
+                for (int i = 0; i < 6; ++i) flat = flat && gr->conv_w[i] == g0 + (size_t)NMAP * 9 + (size_t)i * NMAP * NMAP * 9;
+                if (flat) {
+                    const double bc1 = 1.0 - pow((double)adamw->beta1, (double)adamw->step);
+                    const double bc2 = 1.0 - pow((double)adamw->beta2, (double)adamw->step);
+                    opt = RowsAdamW{adamw->p, g0, adamw->m, adamw->v,
+                                    HowlAdamWCoef{adamw->lr, adamw->beta1, adamw->beta2, adamw->eps, adamw->weight_decay, (float)bc1,
+                                                  (float)sqrt(bc2), adamw->grad_scale},
+                                    (long)((fold_in_pair ? gr->conv_w[1] : gr->out_w) - g0), (long)adamw->n, 1};
+                    own_launch = false;
+                }
+            }
+            hipLaunchKernelGGL(reduce_rows_all_kernel, dim3((CP * WNCOL + 63) / 64, nrows + (opt.on ? 1 : 0)), dim3(1024), 0, stream,
                                (const float*)w.wpart, wpart_stride, Gh, gw, (const float*)w.c0part, G0w, gr->conv0_w, 0,
-                               fold_in_pair ? 5 : 0);
-        else
+                               fold_in_pair ? 5 : 0, nrows, opt);
+            if (own_launch) {
+                const int rc = howl_adamw_step(adamw->p, adamw->g, adamw->m, adamw->v, adamw->n, adamw->lr, adamw->beta1, adamw->beta2,
+                                               adamw->eps, adamw->weight_decay, adamw->step, adamw->grad_scale, stream);
+                if (rc != HOWL_OK) return rc;
+            }
+        } else {
             hipLaunchKernelGGL(reduce_rows_all_kernel, dim3((NMAP * 9 + 63) / 64, 1), dim3(1024), 0, stream,
-                               (const float*)w.wpart, wpart_stride, Gh, gw, (const float*)w.c0part, G0w, gr->conv0_w, 6, 0);
+                               (const float*)w.wpart, wpart_stride, Gh, gw, (const float*)w.c0part, G0w, gr->conv0_w, 6, 0, 1, no_opt);
+        }
     }
     HOWL_CHECK_LAUNCH("howl_res8_bwd");
     return HOWL_OK;
@@ -2547,9 +2603,9 @@ int howl_res8_bwd(const HowlRes8Params* prm, const float* feat, long sb, long st
 
 int howl_res8_bwd_xent(const HowlRes8Params* prm, const float* feat, long sb, long st, long sm, int B, int T, int M, int C,
                        const HowlRes8Saved* sv, const float* dlogits, const float* nll, float* loss, const HowlRes8Grads* gr,
-                       void* ws, size_t ws_bytes, int part, hipStream_t stream) {
+                       void* ws, size_t ws_bytes, int part, const HowlAdamW* adamw, hipStream_t stream) {
     HOWL_REQUIRE(nll && loss, "howl_res8_bwd_xent: null pointer");
-    return res8_bwd_impl(prm, feat, sb, st, sm, B, T, M, C, sv, dlogits, gr, ws, ws_bytes, part, nll, loss, stream);
+    return res8_bwd_impl(prm, feat, sb, st, sm, B, T, M, C, sv, dlogits, gr, ws, ws_bytes, part, nll, loss, stream, adamw);
 }
 
 int howl_xent_fwd_bwd(const float* logits, const long long* labels, int B, int C, float* loss, float* dlogits,

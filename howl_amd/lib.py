@@ -101,7 +101,7 @@ SIGNATURES = {
     "howl_res8_fwd_xent": [POINTER(HowlRes8Params), P, c_long, c_long, c_long, c_int, c_int, c_int, c_int,
                            POINTER(HowlRes8Saved), P, P, P, P, P, c_size_t, STREAM],
     "howl_res8_bwd_xent": [POINTER(HowlRes8Params), P, c_long, c_long, c_long, c_int, c_int, c_int, c_int,
-                           POINTER(HowlRes8Saved), P, P, P, POINTER(HowlRes8Grads), P, c_size_t, c_int, STREAM],
+                           POINTER(HowlRes8Saved), P, P, P, POINTER(HowlRes8Grads), P, c_size_t, c_int, POINTER(HowlAdamW), STREAM],
     "howl_dropout_mask": [P, c_size_t, c_float, ctypes.c_ulonglong, STREAM],
     "howl_xent_fwd_bwd": [P, P, c_int, c_int, P, P, STREAM],
     "howl_ctc_loss": [P, c_long, c_long, c_int, c_int, c_int, P, c_long, c_int, P, P, c_int, P, P, P, c_long, c_long, STREAM],

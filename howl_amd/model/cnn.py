@@ -202,11 +202,14 @@ class Res8(RegisteredModel, name="res8"):
     # flat-buffer offset up to which gradients are final only after part 2 of a two-part backward (conv0.weight comes first)
     LATE_GRAD_PARAMS = 1
 
-    def _launch_backward(self, feat, dlogits, out_grads=None, part=0, xent=None):
+    def _launch_backward(self, feat, dlogits, out_grads=None, part=0, xent=None, adamw=None):
         """``part`` 0: the whole pass; 1 then 2: the same pass in two calls, everything but conv0's gradient final after
         the first (``howl_res8_bwd_part``; the data-parallel step starts its all-reduce in between).  ``xent`` = (nll, loss)
         after ``_launch_forward_xent``: ``howl_res8_bwd_xent`` (the pooled gradient is in the workspace already; ``loss`` (1,)
-        receives the batch mean)."""
+        receives the batch mean).  ``adamw`` (with ``xent``, part 0) = (flat params, flat grads, m, v, lr, (beta1, beta2), eps,
+        weight_decay, step, grad_scale): the optimiser step is part of the call (``HowlAdamW``: inside the last fold launch when
+        ``out_grads`` are the flat buffer's views); ``self.optimizer_step_done`` says whether it was taken."""
+        self.optimizer_step_done = False
         if not self.training:
             raise NotImplementedError("Res8 backward is implemented for training-mode BatchNorm (batch statistics), "
                                       "the only mode the reference trains in")
@@ -224,9 +227,15 @@ class Res8(RegisteredModel, name="res8"):
         prm = self._params_struct()
         if xent is not None:
             nll, loss = xent
+            opt = None
+            if adamw is not None and part == 0:
+                flat, fgrad, m, v, lr, betas, eps, wd, step, gscale = adamw
+                opt = ctypes.byref(_lib.HowlAdamW(_vp(flat), _vp(fgrad), _vp(m), _vp(v), flat.numel(), lr, betas[0], betas[1], eps, wd,
+                                                  step, gscale))
             _lib.get().call("howl_res8_bwd_xent", ctypes.byref(prm), ctypes.c_void_p(x0.data_ptr()), sb, st, sm, B, T, M,
                             self.num_labels, ctypes.byref(buf.saved), ctypes.c_void_p(dlogits.data_ptr()), _vp(nll), _vp(loss),
-                            ctypes.byref(gr), ctypes.c_void_p(buf.ws.data_ptr()), buf.ws.numel(), int(part), ops._stream())
+                            ctypes.byref(gr), ctypes.c_void_p(buf.ws.data_ptr()), buf.ws.numel(), int(part), opt, ops._stream())
+            self.optimizer_step_done = opt is not None
             return grads
         _lib.get().call("howl_res8_bwd_part", ctypes.byref(prm), ctypes.c_void_p(x0.data_ptr()), sb, st, sm, B, T, M,
                         self.num_labels, ctypes.byref(buf.saved), ctypes.c_void_p(dlogits.data_ptr()), ctypes.byref(gr),

@@ -95,6 +95,12 @@ class FusedTrainer:
                 logits = self.model._launch_forward(feat)
             loss, dlogits = ops.xent(logits, labels)
         late = getattr(self.model, "LATE_GRAD_PARAMS", 0)
+        if fused_xent and self.world == 1:
+            # single replica: nothing sits between the backward's last fold and the optimiser, so the step rides in that launch
+            # (howl_res8_bwd_xent's HowlAdamW: one launch and one pass over the gradients fewer)
+            bwd_kw["adamw"] = (self.fp.flat, self.fp.grad, self.m, self.v, self.lr, self.betas, self.eps, self.weight_decay,
+                               self.step_count + 1, 1.0)
+        self.model.optimizer_step_done = False
         if self.skip_allreduce:
             self.model._launch_backward(feat, dlogits, out_grads=self.fp.grad_views, **bwd_kw)
             scale, self.collectives_last_step = 1.0 / self.world, 0
@@ -122,8 +128,9 @@ class FusedTrainer:
             scale = parallel.allreduce_sum_(self.fp.grad, self.group)
             self.collectives_last_step = self.collectives_last_step_reduced = 1 if self.world > 1 else 0
         self.step_count += 1
-        ops.adamw_step(self.fp.flat, self.fp.grad, self.m, self.v, self.lr, self.betas, self.eps, self.weight_decay,
-                       self.step_count, scale)
+        if not getattr(self.model, "optimizer_step_done", False):
+            ops.adamw_step(self.fp.flat, self.fp.grad, self.m, self.v, self.lr, self.betas, self.eps, self.weight_decay,
+                           self.step_count, scale)
         self.last_logits = logits
         return loss
 

@@ -195,6 +195,20 @@ int howl_res8_bwd_part(const HowlRes8Params* prm, const float* feat, long sb, lo
                        const HowlRes8Saved* saved, const float* dlogits, const HowlRes8Grads* grads, void* ws,
                        size_t ws_bytes, int part, hipStream_t stream);
 
+/* The same step as an argument of a backward call that ends in a fold of ALL of the model's gradients (howl_res8_bwd_xent, howl_seq_lstm_bwd): the
+ * fold applies it to each gradient element as it writes it (one launch and one pass over the gradients fewer).  p / g / m / v: the
+ * flat buffers of n floats the call's gradient pointers lie in. */
+typedef struct {
+    float* p;
+    float* g;
+    float* m;
+    float* v;
+    size_t n;
+    float lr, beta1, beta2, eps, weight_decay;
+    int step;
+    float grad_scale;
+} HowlAdamW;
+
 /* The training step's forward + nn.CrossEntropyLoss() (pretrain_gsc.py:126-133) with the loss inside the forward's last launch:
  * howl_res8_fwd (training mode) that also writes, per utterance, nll[b] = logsumexp(logits[b]) - logits[b][labels[b]] and
  * dlogits[b] = (softmax(logits[b]) - onehot) / B, and leaves the pooled gradient in the workspace; C <= 64.  The backward
@@ -206,7 +220,8 @@ int howl_res8_fwd_xent(const HowlRes8Params* prm, const float* feat, long sb, lo
                        void* ws, size_t ws_bytes, hipStream_t stream);
 int howl_res8_bwd_xent(const HowlRes8Params* prm, const float* feat, long sb, long st, long sm, int B, int T, int M, int C,
                        const HowlRes8Saved* saved, const float* dlogits, const float* nll, float* loss,
-                       const HowlRes8Grads* grads, void* ws, size_t ws_bytes, int part, hipStream_t stream);
+                       const HowlRes8Grads* grads, void* ws, size_t ws_bytes, int part,
+                       const HowlAdamW* adamw /* NULL: gradients only; else part must be 0 */, hipStream_t stream);
 
 /* mean cross-entropy over (B,C) logits with int64 labels and its gradient (dlogits may be NULL):
  * nn.CrossEntropyLoss() at pretrain_gsc.py:95,131 / train.py:251,293. */
@@ -232,19 +247,6 @@ int howl_ctc_loss(const float* logits, long st_t, long st_b, int T, int B, int C
  * step counts from 1; grad_scale multiplies g on the fly (1/world_size after a sum all-reduce). */
 int howl_adamw_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
                     float eps, float weight_decay, int step, float grad_scale, hipStream_t stream);
-/* The same step as an argument of a backward call that ends in a fold of ALL of the model's gradients (howl_seq_lstm_bwd): the
- * fold applies it to each gradient element as it writes it (one launch and one pass over the gradients fewer).  p / g / m / v: the
- * flat buffers of n floats the call's gradient pointers lie in. */
-typedef struct {
-    float* p;
-    float* g;
-    float* m;
-    float* v;
-    size_t n;
-    float lr, beta1, beta2, eps, weight_decay;
-    int step;
-    float grad_scale;
-} HowlAdamW;
 
 /* ---------------------------------------------------------------------------------------------------
  * LSTM classifiers: howl/model/rnn.py:41-91 (SequentialLstm "seq-lstm", SimpleLstm "lstm"):

@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from emu_util import emu_lib, ptr
-from howl_amd.lib import HowlRes8Grads, HowlRes8Params, HowlRes8Saved
+from howl_amd.lib import HowlAdamW, HowlRes8Grads, HowlRes8Params, HowlRes8Saved
 from oracle import models as om
 
 
@@ -250,13 +250,68 @@ def test_fused_forward_cross_entropy_is_bit_identical(lib):
                  ptr(h.logits), ptr(nll), ptr(dl2), ptr(h.ws), h.ws.size, None)
         for part in parts:
             lib.call("howl_res8_bwd_xent", ctypes.byref(h.prm), ptr(f), T * 40, 40, 1, B, T, 40, C, ctypes.byref(h.saved), ptr(dl2),
-                     ptr(nll), ptr(loss2), ctypes.byref(h.gr), ptr(h.ws), h.ws.size, part, None)
+                     ptr(nll), ptr(loss2), ctypes.byref(h.gr), ptr(h.ws), h.ws.size, part, None, None)
         np.testing.assert_array_equal(h.logits, logits)
         np.testing.assert_array_equal(dl2, dl)
         np.testing.assert_array_equal(loss2, loss)
         for k, v in g_ref.items():
             np.testing.assert_array_equal(h.grads_np[k], v, err_msg=k)
         np.testing.assert_array_equal(h.np["bn3.running_mean"], ref.np["bn3.running_mean"])
+
+
+@pytest.mark.parametrize("B", [3, 70])
+def test_optimiser_step_in_the_last_fold_launch(lib, B):
+    """howl_res8_bwd_xent(..., HowlAdamW) == howl_res8_bwd_xent + howl_adamw_step on the same flat buffers, bit for bit (gradients,
+    parameters, both moments): B = 3 folds all seven weight-gradient rows in the last launch, B = 70 only layer 1 and conv0 (the
+    others were folded inside the pair launches), the step's extra row of blocks takes the rest either way.  Gradient pointers
+    that are NOT the flat buffer fall back to the optimiser's own launch behind the fold."""
+    T, C = 30, 12
+    x = feats(B, T, 3)[:, 0].permute(0, 2, 1).numpy()
+    labels = (np.arange(B) % C).astype(np.int64)
+    names = om.res8_param_names()
+    rng = np.random.default_rng(2)
+
+    def run(mode):     # "apart" | "fold" | "scattered" (fused call with gradient arrays outside the flat buffer)
+        h = Res8Harness(lib, B, T, C)
+        sizes = [h.np[k].size for k in names]
+        offs = np.concatenate([[0], np.cumsum(sizes)])
+        n = int(offs[-1])
+        flat = np.concatenate([h.np[k].reshape(-1) for k in names]).astype(np.float32)
+        g = np.full(n, np.nan, np.float32)
+        m, v = np.linspace(-0.01, 0.01, n).astype(np.float32), np.linspace(1e-6, 1e-4, n).astype(np.float32)
+        views = {k: g[offs[i]:offs[i + 1]] for i, k in enumerate(names)}
+        if mode != "scattered":
+            h.grads_np = views
+            h.gr.conv0_w = ptr(views["conv0.weight"])
+            for i in range(6):
+                h.gr.conv_w[i] = ptr(views[f"conv{i+1}.weight"]).value
+            h.gr.out_w, h.gr.out_b = ptr(views["output.weight"]), ptr(views["output.bias"])
+        f = np.ascontiguousarray(x, np.float32)
+        nll, dl, loss = np.full(B, np.nan, np.float32), np.full((B, C), np.nan, np.float32), np.full(1, np.nan, np.float32)
+        lib.call("howl_res8_fwd_xent", ctypes.byref(h.prm), ptr(f), T * 40, 40, 1, B, T, 40, C, ctypes.byref(h.saved), ptr(labels),
+                 ptr(h.logits), ptr(nll), ptr(dl), ptr(h.ws), h.ws.size, None)
+        opt = HowlAdamW(ptr(flat), ptr(g), ptr(m), ptr(v), n, 0.01, 0.9, 0.999, 1e-8, 1e-5, 2, 1.0)
+        if mode == "scattered":      # the step then reads g: give it the separately computed gradients
+            lib.call("howl_res8_bwd_xent", ctypes.byref(h.prm), ptr(f), T * 40, 40, 1, B, T, 40, C, ctypes.byref(h.saved), ptr(dl), ptr(nll),
+                     ptr(loss), ctypes.byref(h.gr), ptr(h.ws), h.ws.size, 0, None, None)
+            for k in names:
+                views[k][:] = h.grads_np[k].reshape(-1)
+            lib.call("howl_res8_fwd_xent", ctypes.byref(h.prm), ptr(f), T * 40, 40, 1, B, T, 40, C, ctypes.byref(h.saved), ptr(labels),
+                     ptr(h.logits), ptr(nll), ptr(dl), ptr(h.ws), h.ws.size, None)
+        lib.call("howl_res8_bwd_xent", ctypes.byref(h.prm), ptr(f), T * 40, 40, 1, B, T, 40, C, ctypes.byref(h.saved), ptr(dl), ptr(nll),
+                 ptr(loss), ctypes.byref(h.gr), ptr(h.ws), h.ws.size, 0, None if mode == "apart" else ctypes.byref(opt), None)
+        if mode == "apart":
+            lib.call("howl_adamw_step", ptr(flat), ptr(g), ptr(m), ptr(v), n, 0.01, 0.9, 0.999, 1e-8, 1e-5, 2, 1.0, None)
+        return flat, g, m, v
+
+    a, b_ = run("apart"), run("fold")
+    for u, w in zip(a, b_):
+        assert np.isfinite(u).all()
+        np.testing.assert_array_equal(u, w)
+    if B == 3:
+        c = run("scattered")
+        for u, w in zip((a[0], a[2], a[3]), (c[0], c[2], c[3])):
+            np.testing.assert_array_equal(u, w)
 
 
 def test_many_utterances_per_workgroup_fused_and_unfused_backward():
