@@ -73,6 +73,9 @@ struct HowlAdamWCoef {
 };
 __device__ __forceinline__ void howl_adamw_element(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v, size_t i, float g,
                                                    const HowlAdamWCoef& c) {
+    // no multiply-add contraction here: the same element must come out bit-identical whichever kernel applies the step (the
+    // optimiser's own launch, a slab fold, res8's last fold launch) -- contraction is a per-call-site decision of the compiler
+#pragma clang fp contract(off)
     const float gi = g * c.gscale;
     float pi = p[i] * (1.0f - c.lr * c.wd);
     const float mi = m[i] + (gi - m[i]) * (1.0f - c.b1);

@@ -183,3 +183,37 @@ def test_fused_sequence_step_matches_autograd_path_and_oracle(B):
     # a second step runs (saved state is per step) and the loss moves
     loss2 = trainer.step_sequence(pcm, lengths, targets, tl, 4)
     assert loss2.item() < loss_f.item()
+
+
+def test_optimiser_step_in_the_fold_is_bit_identical_on_the_device(monkeypatch):
+    """Round 5: howl_seq_lstm_bwd takes the AdamW step inside its slab fold on a single replica (HowlAdamW); three steps that way
+    and three with the optimiser's own launch (HOWL_NO_FOLD_ADAMW=1) leave bit-identical parameters, moments and gradients --
+    likewise with the head's weight gradient riding in the backward recurrence's launch (default) or behind it (HOWL_LSTM_RIDE=0)."""
+    from howl_amd.data.transform.operator import ZmuvTransform
+    from howl_amd.data.transform.transform import StandardAudioTransform
+    from howl_amd.training.fused import FusedTrainer
+    from howl_amd.utils.synth import synthetic_pcm
+    B, L, C = 512, 8000, 5
+    pcm = synthetic_pcm(B, L).to(DEV)
+    std = StandardAudioTransform().to(DEV).eval()
+    zmuv = ZmuvTransform().to(DEV)
+    zmuv.update(std(pcm[:4]))
+    lengths = torch.full((B,), 38)
+    targets = torch.tensor([[0, 1, 2]] * B)
+    tl = torch.tensor(([3, 2, 1] * (B // 3 + 1))[:B])
+    out = []
+    for env in ({}, {"HOWL_NO_FOLD_ADAMW": "1"}, {"HOWL_LSTM_RIDE": "0"}):
+        for k in ("HOWL_NO_FOLD_ADAMW", "HOWL_LSTM_RIDE"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        model = make("seq-lstm", C).train()
+        tr = FusedTrainer(model, std, zmuv, lr=1e-3, weight_decay=1e-5)
+        for _ in range(3):
+            tr.step_sequence(pcm, lengths, targets, tl, 4)
+        torch.cuda.synchronize()
+        out.append([t.clone() for t in (tr.fp.flat, tr.m, tr.v, tr.fp.grad)])
+    for other in out[1:]:
+        for a, b in zip(out[0], other):
+            assert torch.isfinite(a).all()
+            assert torch.equal(a, b)

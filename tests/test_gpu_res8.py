@@ -419,3 +419,34 @@ def test_fused_backward_matches_the_unfused_reference(monkeypatch, B, T):
     for a, b in zip(fused, unfused):
         scale = max(1.0, b.abs().max().item())
         assert (a - b).abs().max().item() < 5e-6 * scale
+
+
+@pytest.mark.parametrize("B,L,C", [(64, 16000, 30), (512, 16000, 12)])
+def test_optimiser_step_in_the_fold_is_bit_identical_on_the_device(B, L, C, monkeypatch):
+    """Round 5: on a single replica the AdamW step rides in the backward's last fold launch (HowlAdamW).  Three steps that way
+    and three with the optimiser's own launch (HOWL_NO_FOLD_ADAMW=1) from the same state: parameters, both moments and the
+    gradients of the last step are bit-identical -- a block that read a gradient or a moment before its writer was done would
+    show here (B = 64: all seven weight-gradient rows fold in that launch; B = 512: two, the rest rides as the extra row)."""
+    from howl_amd.data.transform.operator import ZmuvTransform
+    from howl_amd.data.transform.transform import StandardAudioTransform
+    from howl_amd.training.fused import FusedRes8Trainer
+    from howl_amd.utils.synth import synthetic_pcm
+    pcm = synthetic_pcm(B, L).to(DEV)
+    labels = (torch.arange(B) % C).to(DEV)
+    std = StandardAudioTransform().to(DEV).eval()
+    zmuv = ZmuvTransform().to(DEV)
+    zmuv.update(std(pcm[:4]))
+    out = []
+    for apart in (False, True):
+        if apart:
+            monkeypatch.setenv("HOWL_NO_FOLD_ADAMW", "1")
+        model = make_res8(C)
+        tr = FusedRes8Trainer(model, std, zmuv, lr=0.01, weight_decay=1e-5)
+        for _ in range(3):
+            tr.step(pcm, labels)
+        torch.cuda.synchronize()
+        assert model.optimizer_step_done          # (with the switch the library still takes the step: as its own launch)
+        out.append([t.clone() for t in (tr.fp.flat, tr.m, tr.v, tr.fp.grad)])
+    for a, b in zip(*out):
+        assert torch.isfinite(a).all()
+        assert torch.equal(a, b)
