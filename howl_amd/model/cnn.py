@@ -6,6 +6,7 @@ The module keeps the reference's construction order (so ``set_random_seed`` give
 submodules are parameter containers only -- forward and backward are single C-ABI calls.
 """
 import ctypes
+import logging
 from typing import Tuple
 
 import torch
@@ -72,6 +73,22 @@ class _Res8Function(torch.autograd.Function):
         return (None, None) + tuple(grads)
 
 
+def res8_mels_message():
+    from howl_amd.settings import SETTINGS
+    n = SETTINGS.audio_transform.num_mels
+    if n == 40:
+        return None
+    return (f"Res8 on MI355X is built for NUM_MELS=40 (envs/res8.env; AvgPool (3,4) over 40 mel bins), but "
+            f"SETTINGS.audio_transform.num_mels is {n}: export NUM_MELS=40 before howl_amd.settings is imported (stock Howl's "
+            f"default of 80 is not supported by the kernels)")
+
+
+def require_supported_mels(model):
+    """For callers that build the frontend from SETTINGS and the model together (training.run.*): fail before the first batch."""
+    if isinstance(model, Res8) and res8_mels_message():
+        raise ValueError(res8_mels_message())
+
+
 class Res8(RegisteredModel, name="res8"):
     def __init__(self, num_labels: int, config: Res8Settings = None):
         super().__init__(num_labels)
@@ -79,13 +96,14 @@ class Res8(RegisteredModel, name="res8"):
         n_maps = config.num_maps
         if n_maps != 45 or tuple(config.pooling) != (3, 4):
             raise NotImplementedError("the MI355X res8 kernels are specialised for num_maps=45, pooling=(3,4)")
-        from howl_amd.settings import SETTINGS
-        if SETTINGS.audio_transform.num_mels != 40:
-            # the reference's default is 80 (settings.py:32) while every res8 preset sets 40 (envs/res8.env): say so when the
-            # model is built, not at the first forward deep inside a training run
-            raise ValueError(f"Res8 on MI355X is built for NUM_MELS=40 (envs/res8.env; AvgPool (3,4) over 40 mel bins), but "
-                             f"SETTINGS.audio_transform.num_mels is {SETTINGS.audio_transform.num_mels}: export NUM_MELS=40 "
-                             f"before howl_amd.settings is imported (stock Howl's default of 80 is not supported by the kernels)")
+        # the reference's default is 80 mel bins (settings.py:32) while every res8 preset sets 40 (envs/res8.env) and the kernels
+        # pool (3, 4) over 40: say so when the model is built -- as a warning, so that a model can still be constructed to load,
+        # convert or inspect a state_dict (cnn.py:113 constructs regardless of the settings); the entry points, which build the
+        # frontend and the model together, turn it into an error (require_supported_mels), and the first forward on anything
+        # but 40 bins raises in any case (_feat_view)
+        msg = res8_mels_message()
+        if msg:
+            logging.getLogger(__name__).warning(msg)
         self.conv0 = nn.Conv2d(1, n_maps, (3, 3), padding=(1, 1), bias=False)
         self.pool = nn.AvgPool2d(config.pooling)
         self.n_layers = n_layers = 6

@@ -23,6 +23,7 @@ from howl_amd.data.collate import DeviceCollate
 from howl_amd.data.transform.operator import ZmuvTransform
 from howl_amd.data.transform.transform import StandardAudioTransform
 from howl_amd.model import RegisteredModel
+from howl_amd.model.cnn import require_supported_mels
 from howl_amd.settings import SETTINGS
 from howl_amd.training.data import ClipBank, load_gsc_splits, read_wav16k, synthetic_bank
 from howl_amd.training.fused import FusedTrainer
@@ -87,6 +88,7 @@ def main(argv=None):
     std_transform = StandardAudioTransform().to(device).eval()
     zmuv_transform = ZmuvTransform().to(device)
     model = RegisteredModel.find_registered_class(args.model)(num_labels).to(device)
+    require_supported_mels(model)      # res8 with NUM_MELS != 40: an error here, not at the first batch
     params = [p for p in model.parameters() if p.requires_grad]
     logging.info(f"{sum(p.numel() for p in params)} parameters")
 

@@ -35,6 +35,7 @@ from howl_amd.data.transform.batchifier import AudioSequenceBatchifier, WakeWord
 from howl_amd.data.transform.operator import ZmuvTransform
 from howl_amd.data.transform.transform import SpecAugmentTransform, StandardAudioTransform
 from howl_amd.model import RegisteredModel
+from howl_amd.model.cnn import require_supported_mels
 from howl_amd.model.inference import FrameInferenceEngine, InferenceEngine
 from howl_amd.settings import SETTINGS
 from howl_amd.training.data import WakeWordClipBank, load_howl_splits, read_wav16k
@@ -148,6 +149,7 @@ def main(argv=None):
     std_transform = StandardAudioTransform().to(device).eval()
     zmuv_transform = ZmuvTransform().to(device)
     model = RegisteredModel.find_registered_class(args.model)(ctx.num_labels).to(device).streaming()
+    require_supported_mels(model)      # res8 with NUM_MELS != 40: an error here, not at the first batch
     spectrogram_augmentations = (SpecAugmentTransform().train(),)      # train.py:277-278
     if zmuv_on_disk:
         zmuv_transform.load_state_dict(torch.load(str(ws.path / "zmuv.pt.bin")))
