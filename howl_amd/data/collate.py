@@ -232,7 +232,9 @@ class DeviceCollate:
         """Host half of ``__call__``: the draws of the batch (reference order), the length sort and the packed staging buffer.
         No device work, so a worker thread may run it for batch k + 1 while batch k trains (``prefetch``); batches must be
         prepared in the order they are consumed (the draws are one stream)."""
-        if self.bg_audio is not None:           # DatasetMixer's rejection loops stay scalar draws
+        # DatasetMixer's rejection loops stay scalar draws; so does a generator that is not a Mersenne Twister with an
+        # exportable state (a test double assigned to ``self.rand``)
+        if self.bg_audio is not None or not (self._rand is random or isinstance(self._rand, random.Random)):
             return ("scalar", list(clip_ids))
         ids = np.asarray(clip_ids, dtype=np.int64)
         lens, shift, head, sigma, sp = self.draw_arrays(ids)
