@@ -747,7 +747,6 @@ struct PwBwd {
     int M, N, C;
     int tiles_per_block, d_cx, d_ry;        // data gradient: column blocks x row blocks
     int rows_per_split, w_cx, w_ny, w_nz;   // weight gradient: (C / 64) x (N / 64) x splits
-    int ilv_q;                              // > 0: blocks interleaved split by split (see pw_bwd_kernel): data-gradient row blocks per split
     EpiBwd e;
     Arrive arr;
     FinBwd fin;
@@ -980,22 +979,6 @@ template <bool XF, int WTR, int WTC>
 __global__ __launch_bounds__(256) void pw_bwd_kernel(PwBwd p) {
     __shared__ __attribute__((aligned(16))) float lds[PW_LDS_FLOATS];
     const int b = blockIdx.x, nd = p.d_cx * p.d_ry;
-    if (p.ilv_q > 0) {
-        // Both roles rebuild dz from the same rows of (g_k, z_k): numbered role by role, the data gradient's blocks of a row
-        // range ran in the first half of the launch and the weight gradient's in the second -- every row of both tensors came
-        // from HBM twice.  Numbered split by split (a split's ilv_q x d_cx data-gradient blocks, then its w_cx x w_ny weight-
-        // gradient blocks) the two readers of a row range are in flight together and the second one finds the rows in a cache.
-        const int gd = p.ilv_q * p.d_cx, gs = gd + p.w_cx * p.w_ny;
-        const int split = b / gs, r = b - split * gs;
-        if (r < gd) {
-            const int by = split * p.ilv_q + r / p.d_cx;
-            if (by < p.d_ry) pw_dgrad_body<WTR, WTC>(lds, p, r % p.d_cx, by);
-        } else {
-            const int wb = r - gd;
-            if (split < p.w_nz) pw_wgrad_body<XF>(lds, p, wb % p.w_cx, wb / p.w_cx, split);
-        }
-        return;
-    }
     if (b < nd) {
         pw_dgrad_body<WTR, WTC>(lds, p, b % p.d_cx, b / p.d_cx);
     } else {
@@ -2223,18 +2206,7 @@ int howl_mobilenet_bwd(const float* params, int num_labels, const float* x, long
             a.arr = arr;
             a.fin = fin_bwd(c, j, grads);
             a.slabs = slab;
-            unsigned blocks = (unsigned)(a.d_cx * a.d_ry + a.w_cx * a.w_ny * a.w_nz);
-            // interleave the two roles split by split where a split is a whole number of data-gradient row blocks
-            // (HOWL_MB_PW_INTERLEAVE=0: role by role, as rounds 2-4)
-            {
-                static const int ilv = env_int("HOWL_MB_PW_INTERLEAVE", 1);
-                const long drows = (long)a.tiles_per_block * tile;
-                if (ilv && a.rows_per_split % drows == 0) {
-                    a.ilv_q = (int)(a.rows_per_split / drows);
-                    const int splits = std::max(a.w_nz, (a.d_ry + a.ilv_q - 1) / a.ilv_q);
-                    blocks = (unsigned)splits * (unsigned)(a.ilv_q * a.d_cx + a.w_cx * a.w_ny);
-                }
-            }
+            const unsigned blocks = (unsigned)(a.d_cx * a.d_ry + a.w_cx * a.w_ny * a.w_nz);
             HowlProfScope prof("mb_conv", stream, 4.0 * (double)g.mz * (4.0 * l.cout + 4.0 * l.cin));
 #define HOWL_PW_BWD(XF)                                                                                     \
     do {                                                                                                    \
