@@ -107,6 +107,38 @@ def _worker(rank, world, port, backend, out):
     dist.destroy_process_group()
 
 
+def _rccl_single_rank(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    sys.path.insert(0, str(ROOT))
+    from howl_amd import parallel
+    flat = torch.arange(110307, dtype=torch.float32, device=dev)            # res8's flat gradient buffer
+    want = flat.clone()
+    scale = parallel.allreduce_sum_(flat)                                    # dist.all_reduce on the process group's stream
+    pending = parallel.allreduce_start_(flat[64:])                           # the async form of the overlap schedule
+    pending.wait()
+    parallel.broadcast_([flat, torch.zeros(3, dtype=torch.int64, device=dev)])
+    parallel.barrier()
+    counts = parallel.allreduce_scalars_(torch.tensor([3.0, 5.0], device=dev))
+    torch.cuda.synchronize()
+    out["ok"] = bool(torch.equal(flat, want)) and scale == 1.0 and counts.tolist() == [3.0, 5.0]
+    out["backend"] = dist.get_backend()
+    dist.destroy_process_group()
+
+
+def test_rccl_communicator_on_this_box():
+    """RCCL itself on the GPU box: a one-rank "nccl" process group (communicator creation, all-reduce -- blocking and async --,
+    broadcast, barrier) through howl_amd.parallel's helpers.  It cannot show scaling; it does show that the RCCL library loads
+    and runs collectives on this software stack with the environment the benches set (HSA_ENABLE_IPC_MODE_LEGACY=0)."""
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_rccl_single_rank, args=(1, _free_port(), out), nprocs=1, join=True)
+        out = dict(out)
+    assert out["backend"] == "nccl" and out["ok"], out
+
+
 def _run(world, backend):
     with mp.Manager() as mgr:
         out = mgr.dict()
