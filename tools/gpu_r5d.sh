@@ -1,4 +1,5 @@
 #!/bin/bash
+# NOTE: HOWL_LSTM_RIDE_X (the projection riders of the forward recurrence) exists in commits abe4f8a..08d1d79 only; at HEAD the switch is ignored.
 # Round 5, fourth visit: c4 with the input projection riding in the forward recurrence's launch + AdamW in the fold: A/B + timeline.
 set -u
 OUT=gpurun_out/r5d

@@ -1,4 +1,5 @@
 #!/bin/bash
+# NOTE: HOWL_MB_PW_INTERLEAVE exists in commit 6c95866 only (measured, reverted in a5ae4e5); at HEAD the switch is ignored.
 set -u
 OUT=gpurun_out/r5h
 mkdir -p $OUT
