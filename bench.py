@@ -23,6 +23,13 @@ relays rank 0's line.  ``HOWL_BENCH_BACKEND=gloo`` lets several ranks share one 
     eval  (f2, not a training step) batched streaming evaluation: FrameInferenceEngine.window_probabilities over 10 s clips,
           500 ms windows / 63 ms stride, against the reference's one-window-at-a-time loop (inference.py:223-267)
 
+``--loop entry`` (res8 configurations) times the loop a user runs instead of the step on resident tensors: the epoch body of
+``training.run.pretrain_gsc`` (``howl_amd.training.run.pretrain_gsc.train_epoch``) over a device-resident synthetic clip bank --
+shuffled ids -> device collate (truncate, Timeshift, Noise, batchify; host draws in the reference's order) -> train-mode frontend
+(VTLP draw) -> fused step -> loss to the workspace writer -- and reports it next to the resident-tensor step of the same process,
+with the oracle of the same loop as ``cpu_baseline``.  ``--prewarm N`` (default 40): untimed steps in front of the W warm-up steps,
+so that the contract's W + K bracket starts at the sustained clock.
+
 Rank 0 prints ONE JSON line; besides the contract fields it carries
   "roofline":     the time-dominant kernel of the configuration: algorithmic FLOPs (or bytes) per launch / mean launch
                   duration measured with HIP events on the launch stream in a second pass of the same K steps
