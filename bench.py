@@ -96,6 +96,8 @@ def parse():
                          "clip ids -> device collate with Timeshift + Noise + batchify -> frontend in train mode (VTLP draw) -> fused "
                          "step -> loss logged through the workspace writer) over a device-resident synthetic clip bank, reported "
                          "beside the resident-tensor step of the same process (res8 configurations)")
+    ap.add_argument("--no-lookahead", action="store_true",
+                    help="seq-lstm: compute every batch's log-mel in its own step instead of inside the previous step's forward call")
     ap.add_argument("--global-batch", type=int, default=None,
                     help="strong scaling: a FIXED global batch split over the N ranks (configs[2]: 4096); default is weak "
                          "scaling at the configuration's per-GPU batch")
@@ -616,8 +618,13 @@ def main():
         targets = torch.tensor([[0, 1, 2]] * B).to(dev)
         target_lengths = torch.tensor([3] * B).to(dev)
 
+        ahead = None if args.no_lookahead else pcm
+
         def step():    # frontend -> LSTM + head -> fused log_softmax + CTC(blank = C-1) -> backward -> flat AdamW
-            return trainer.step_sequence(pcm, frame_lengths, targets, target_lengths, C - 1, max_target=3, max_frames=n_frames)
+            # one-batch look-ahead (a prefetching loader's): the NEXT batch's frontend launch rides in this step's forward
+            # recurrence (howl_lstm_fwd_next); every step still runs exactly one frontend pass and one model step
+            return trainer.step_sequence(pcm, frame_lengths, targets, target_lengths, C - 1, max_target=3, max_frames=n_frames,
+                                         next_audio=ahead)
     elif model_name == "mobilenet":
         from howl_amd.data.collate import DeviceCollate
         collate = DeviceCollate(pcm, torch.full((B,), L, dtype=torch.long), labels, max_len=L, seed=0, replica=rank)
@@ -826,6 +833,8 @@ def main():
             "config": {"workload": f"{model_name} training step ({step_desc}), {B} x {L / 16000:g} s utterances per GPU, "
                                    f"{C} labels -- BASELINE {cfg_desc}"
                                    + ("; frontend in train mode (VTLP filterbank on 75 % of the steps)" if args.vtlp else "")
+                                   + ("; one-batch look-ahead: the next batch's log-mel runs as rider blocks of this step's forward "
+                                      "recurrence launch" if model_name == "seq-lstm" and not args.no_lookahead and not args.vtlp else "")
                                    + ("; parity unpinned (torchvision absent: oracle restates the published architecture)"
                                       if model_name == "mobilenet" else ""),
                        "name": args.config, "global_batch": B * world, "samples_per_utterance": L, "labels": C,

@@ -20,6 +20,7 @@
 #include "howl_common.hip.h"
 #include "../../include/howl_hip.h"
 #include "howl_gemm.hip.h"
+#include "howl_logmel.hip.h"
 
 namespace {
 
@@ -129,7 +130,11 @@ __device__ __forceinline__ void quad_transpose(float (&v)[4], bool bit0, bool bi
 constexpr int F8_THREADS = 512;
 constexpr int F8_HS = HID + 4;          // h rows in LDS (16-byte aligned rows for the float4 A-fragment reads)
 constexpr int F8_XS = 64 + 4;           // x rows in LDS (every lane of a wave reads its float4; columns XM.. are never multiplied)
-template <int XM>
+// RIDE (round 5): blocks behind the first `nrec` run the log-mel frontend of the NEXT batch (logmel_body, eight waves) on the CUs
+// this recurrence leaves idle -- (B + 3) / 4 workgroups of 38-81 dependent steps: half of the device at B = 512.  Independent work:
+// its output is read by later launches only, so there is no flag and nobody waits; the recurrence's blocks come first in dispatch
+// order.  (The same frontend as its own launch costs 15.7 us per 512 x 0.5 s step on the critical path.)
+template <int XM, bool RIDE = false>
 __global__ __launch_bounds__(F8_THREADS) void lstm_fwd4_kernel(const float* __restrict__ gx, const float* __restrict__ wih, int xframes,
                                                                const float* __restrict__ whh,
                                                                const float* __restrict__ b_ih, const float* __restrict__ b_hh,
@@ -137,7 +142,16 @@ __global__ __launch_bounds__(F8_THREADS) void lstm_fwd4_kernel(const float* __re
                                                                const float* __restrict__ h0, const float* __restrict__ c0,
                                                                float* __restrict__ gates, float* __restrict__ cs,
                                                                float* __restrict__ hseq, float* __restrict__ hT,
-                                                               float* __restrict__ cT, int B, int T, int Tout) {
+                                                               float* __restrict__ cT, int B, int T, int Tout, int nrec,
+                                                               LogmelLaunch next, int next_blocks) {
+    if constexpr (RIDE) {
+        if ((int)blockIdx.x >= nrec) {
+            logmel_body<F8_THREADS / 64, NG_BANDED>(next.pcm, next.L, next.ld, next.T, next.total, next.fbp, next.M, next.log_eps, next.zmuv,
+                                                    next.out, next.layout, next.n_quads, next.aligned, blockIdx.x - (unsigned)nrec,
+                                                    (unsigned)next_blocks);
+            return;
+        }
+    }
     __shared__ __attribute__((aligned(16))) float hbuf[2][4 * F8_HS];
     __shared__ __attribute__((aligned(16))) float xbuf[2][4 * F8_XS];
     constexpr int XP = XM > 0 ? XM : 4;
@@ -1081,10 +1095,16 @@ size_t howl_lstm_needs_gx(const HowlLstmParams* p, int B, int T, int M, int x_fr
     return lstm_fuse_x(p, B, T, M, x_frames > 0 ? x_frames : T) ? 0 : 1;
 }
 
-int howl_lstm_fwd(const HowlLstmParams* p, const float* x, int B, int T, int M, const long long* lengths, const float* h0,
-                  const float* c0, const HowlLstmSaved* sv, float* hT, float* cT, void* ws, size_t ws_bytes,
-                  hipStream_t stream) {
+static int lstm_fwd_impl(const HowlLstmParams* p, const float* x, int B, int T, int M, const long long* lengths, const float* h0,
+                         const float* c0, const HowlLstmSaved* sv, float* hT, float* cT, void* ws, size_t ws_bytes,
+                         const HowlLogmelArgs* next, hipStream_t stream) {
     HOWL_REQUIRE(p && x && sv && hT && cT && ws, "howl_lstm_fwd: null pointer");
+    LogmelLaunch ll{};
+    if (next != nullptr) {
+        const int rc = logmel_prepare(next->pcm, next->B, next->L, next->ld, next->fbp, next->M, next->log_eps, next->zmuv, next->out,
+                                      next->layout, &ll);
+        if (rc != HOWL_OK) return rc;
+    }
     HOWL_REQUIRE(B >= 1 && T >= 1 && M >= 1, "howl_lstm_fwd: bad shape");
     HOWL_REQUIRE(sv->t_out >= 1 && sv->t_out <= T, "howl_lstm_fwd: t_out=%d outside 1..T", sv->t_out);
     if (ws_bytes < howl_lstm_workspace_bytes(B, T)) {
@@ -1110,22 +1130,53 @@ int howl_lstm_fwd(const HowlLstmParams* p, const float* x, int B, int T, int M, 
     if (sv->t_out < T)   // rows of steps that never run are read (times zero) by the weight-gradient GEMM: keep them finite
         hipMemsetAsync(sv->hseq, 0, (size_t)B * (T + 1) * HID * sizeof(float), stream);
     // h_{t-1} W_hh^T of every step (+ x_t W_ih^T where the recurrence multiplies it itself)
+    // the next batch's frontend rides in this launch when the recurrence leaves half of the device idle (HOWL_LSTM_RIDE_LOGMEL=0:
+    // as its own launch behind the recurrence, as it is whenever the four-sequence kernel with the fused projection does not run)
+    const bool ride = next != nullptr && fuse_x && (B + 3) / 4 <= howl_num_cus() / 2 && next->M <= 4 * NG_BANDED &&
+                      (getenv("HOWL_LSTM_RIDE_LOGMEL") == nullptr || getenv("HOWL_LSTM_RIDE_LOGMEL")[0] != '0');
+    {
     HowlProfScope prof("lstm_fwd", stream, 2.0 * (HID + (fuse_x ? M : 0)) * G4 * (double)B * sv->t_out);
     if (fuse_x) {
-        hipLaunchKernelGGL(lstm_fwd4_kernel<40>, dim3((B + 3) / 4), dim3(F8_THREADS), 0, stream, x, p->w_ih, xf,
-                           p->w_hh, p->b_ih, p->b_hh, lengths, h0, c0, sv->gates, sv->c, sv->hseq, hT, cT, B, T, sv->t_out);
+        const int nrec = (B + 3) / 4;
+        if (ride) {
+            const int nb = std::max(1, std::min(ll.n_quads, howl_num_cus() - nrec));
+            hipLaunchKernelGGL((lstm_fwd4_kernel<40, true>), dim3(nrec + nb), dim3(F8_THREADS), 0, stream, x, p->w_ih, xf, p->w_hh, p->b_ih,
+                               p->b_hh, lengths, h0, c0, sv->gates, sv->c, sv->hseq, hT, cT, B, T, sv->t_out, nrec, ll, nb);
+        } else {
+            hipLaunchKernelGGL(lstm_fwd4_kernel<40>, dim3(nrec), dim3(F8_THREADS), 0, stream, x, p->w_ih, xf, p->w_hh, p->b_ih, p->b_hh,
+                               lengths, h0, c0, sv->gates, sv->c, sv->hseq, hT, cT, B, T, sv->t_out, nrec, LogmelLaunch{}, 0);
+        }
     } else if (!rows16) {
         hipLaunchKernelGGL(lstm_fwd4_kernel<0>, dim3((B + 3) / 4), dim3(F8_THREADS), 0, stream, (const float*)sv->gx,
                            (const float*)nullptr, 0, p->w_hh, p->b_ih, p->b_hh, lengths, h0, c0, sv->gates, sv->c, sv->hseq, hT, cT, B,
-                           T, sv->t_out);
+                           T, sv->t_out, (B + 3) / 4, LogmelLaunch{}, 0);
     } else {
         const size_t lds_fwd = (size_t)(2 * 16 * HS + 2 * 16 * 6 * HID) * sizeof(float);
         hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fwd);
         hipLaunchKernelGGL(lstm_fwd_kernel, dim3((B + 15) / 16), dim3(LSTM_THREADS), lds_fwd, stream, (const float*)sv->gx,
                            (const float*)pf, lengths, h0, c0, sv->gates, sv->c, sv->hseq, hT, cT, B, T, sv->t_out);
     }
+    }
+    if (next != nullptr && !ride) {
+        const int rc = howl_logmel_fwd(next->pcm, next->B, next->L, next->ld, next->fbp, next->M, next->log_eps, next->zmuv, next->out,
+                                       next->layout, stream);
+        if (rc != HOWL_OK) return rc;
+    }
     HOWL_CHECK_LAUNCH("howl_lstm_fwd");
     return HOWL_OK;
+}
+
+int howl_lstm_fwd(const HowlLstmParams* p, const float* x, int B, int T, int M, const long long* lengths, const float* h0,
+                  const float* c0, const HowlLstmSaved* sv, float* hT, float* cT, void* ws, size_t ws_bytes,
+                  hipStream_t stream) {
+    return lstm_fwd_impl(p, x, B, T, M, lengths, h0, c0, sv, hT, cT, ws, ws_bytes, nullptr, stream);
+}
+
+int howl_lstm_fwd_next(const HowlLstmParams* p, const float* x, int B, int T, int M, const long long* lengths, const float* h0,
+                       const float* c0, const HowlLstmSaved* sv, float* hT, float* cT, void* ws, size_t ws_bytes,
+                       const HowlLogmelArgs* next, hipStream_t stream) {
+    HOWL_REQUIRE(next != nullptr, "howl_lstm_fwd_next: null HowlLogmelArgs (howl_lstm_fwd is the call without one)");
+    return lstm_fwd_impl(p, x, B, T, M, lengths, h0, c0, sv, hT, cT, ws, ws_bytes, next, stream);
 }
 
 // body of howl_lstm_bwd; with `jobs` the wide weight gradients are collected instead of launched (howl_seq_lstm_bwd runs them

@@ -170,6 +170,21 @@ class StandardAudioTransform(AugmentModule):
         return feat.permute(0, 2, 1).unsqueeze(1)
 
 
+    @torch.no_grad()
+    def log_mel_for_model_args(self, audio: torch.Tensor, zmuv):
+        """``log_mel_for_model`` as a deferred call: (``HowlLogmelArgs`` record, the (B, 1, M, T) feature view its launch will fill,
+        keep-alive tensors) for an entry point that runs this batch's frontend inside ITS launch (``howl_lstm_fwd_next``: a
+        one-batch look-ahead).  Only without a VTLP draw pending (eval mode, or the augment disabled): the draw of a train-mode
+        call belongs to the step that consumes the features -- returns None then, and the caller computes them in that step."""
+        param = self.augment_params[0]
+        if param.enabled and self.training:
+            return None
+        if param.enabled:
+            self.rand.random()  # forward()'s draw happens on every call, eval mode included (transform.py:93): keep the stream's position
+        rec, feat, keep = ops.logmel_args(audio, self._standard_fb(), self.n_mels, zmuv.pair() if zmuv is not None else None, layout=1)
+        return rec, feat.permute(0, 2, 1).unsqueeze(1), keep
+
+
 class SpecAugmentTransform(AugmentModule):
     """``transform.py:299-339``: per-sample frequency / time masks.  The draws come from ``self.rand`` in the
     reference's order; the masking itself is one ``howl_specaug_mask`` launch per augment instead of a Python loop

@@ -56,6 +56,11 @@ class HowlCtcMean(ctypes.Structure):
     _fields_ = [("nll", P), ("target_lengths", P), ("B", c_int), ("loss", P)]
 
 
+class HowlLogmelArgs(ctypes.Structure):
+    _fields_ = [("pcm", P), ("B", c_int), ("L", c_int), ("ld", c_long), ("fbp", P), ("M", c_int), ("log_eps", c_float), ("zmuv", P),
+                ("out", P), ("layout", c_int)]
+
+
 class HowlAdamW(ctypes.Structure):
     _fields_ = [("p", P), ("g", P), ("m", P), ("v", P), ("n", c_size_t), ("lr", c_float), ("beta1", c_float), ("beta2", c_float),
                 ("eps", c_float), ("weight_decay", c_float), ("step", c_int), ("grad_scale", c_float)]
@@ -107,6 +112,8 @@ SIGNATURES = {
     "howl_ctc_loss": [P, c_long, c_long, c_int, c_int, c_int, P, c_long, c_int, P, P, c_int, P, P, P, c_long, c_long, STREAM],
     "howl_lstm_fwd": [POINTER(HowlLstmParams), P, c_int, c_int, c_int, P, P, P, POINTER(HowlLstmSaved), P, P, P, c_size_t,
                       STREAM],
+    "howl_lstm_fwd_next": [POINTER(HowlLstmParams), P, c_int, c_int, c_int, P, P, P, POINTER(HowlLstmSaved), P, P, P, c_size_t,
+                           POINTER(HowlLogmelArgs), STREAM],
     "howl_lstm_bwd": [POINTER(HowlLstmParams), P, c_int, c_int, c_int, P, P, POINTER(HowlLstmSaved), P, P, P,
                       POINTER(HowlLstmGrads), P, c_size_t, STREAM],
     "howl_head_fwd": [POINTER(HowlHeadParams), P, c_int, c_long, c_long, c_int, c_int, c_int, c_int, P, P, STREAM],

@@ -41,9 +41,10 @@ def _x_frames(x):
     return x.stride(0) // M
 
 
-def _lstm_forward_raw(x, lengths, t_out, h0, c0, w_ih, w_hh, b_ih, b_hh):
+def _lstm_forward_raw(x, lengths, t_out, h0, c0, w_ih, w_hh, b_ih, b_hh, next_logmel=None):
     """``howl_lstm_fwd`` on x (B,T,M), contiguous or the leading frames of a longer contiguous buffer: returns (hs (B,t_out,128)
-    view, hT, cT, saved buffers for the backward)."""
+    view, hT, cT, saved buffers for the backward).  ``next_logmel``: a ``HowlLogmelArgs`` record -- the frontend of the NEXT batch
+    runs with this call (``howl_lstm_fwd_next``: as rider blocks of the recurrence's launch where that leaves CUs idle)."""
     B, T, M = x.shape
     dev = x.device
     f32 = dict(dtype=torch.float32, device=dev)
@@ -56,8 +57,12 @@ def _lstm_forward_raw(x, lengths, t_out, h0, c0, w_ih, w_hh, b_ih, b_hh):
     # the (B, T, 512) projection buffer only where the library runs the projection GEMM (40 MB at 512 x 38 otherwise unused)
     gx = torch.empty((B, T, 4 * HID), **f32) if _lib.get().cdll.howl_lstm_needs_gx(ctypes.byref(prm), B, T, M, xf) else None
     sv = _lib.HowlLstmSaved(_vp(gx), _vp(bufs["gates"]), _vp(bufs["c"]), _vp(bufs["hseq"]), None, t_out, xf)
-    _lib.get().call("howl_lstm_fwd", ctypes.byref(prm), _vp(x), B, T, M, _vp(lengths), _vp(h0), _vp(c0), ctypes.byref(sv),
-                    _vp(hT), _vp(cT), _vp(ws), ws.numel(), ops._stream())
+    if next_logmel is not None:
+        _lib.get().call("howl_lstm_fwd_next", ctypes.byref(prm), _vp(x), B, T, M, _vp(lengths), _vp(h0), _vp(c0), ctypes.byref(sv),
+                        _vp(hT), _vp(cT), _vp(ws), ws.numel(), ctypes.byref(next_logmel), ops._stream())
+    else:
+        _lib.get().call("howl_lstm_fwd", ctypes.byref(prm), _vp(x), B, T, M, _vp(lengths), _vp(h0), _vp(c0), ctypes.byref(sv),
+                        _vp(hT), _vp(cT), _vp(ws), ws.numel(), ops._stream())
     saved = (x, lengths, c0, w_ih, w_hh, b_ih, b_hh, bufs["gates"], bufs["c"], bufs["hseq"], ws)
     return bufs["hseq"][:, 1:t_out + 1], hT, cT, saved
 
@@ -284,12 +289,14 @@ class SequentialLstm(_LstmBase, name="seq-lstm"):
         return self._head(hs).permute(1, 0, 2)         # (T_len, B, num_labels), as dnn(rnn_seq) in rnn.py:71
 
     # --- training.fused.FusedTrainer hooks: the same launches as forward() / autograd, without the autograd graph -----
-    def _launch_forward(self, feat, lengths, t_out=None):
+    TAKES_NEXT_LOGMEL = True      # FusedTrainer.step_sequence(next_audio=...): the next batch's frontend rides in the forward call
+
+    def _launch_forward(self, feat, lengths, t_out=None, next_logmel=None):
         """feat (B, C>=1, M, T) -> scores (T_len, B, num_labels) view; keeps what ``_launch_backward`` needs.  ``t_out`` with
-        device-resident ``lengths``: see ``_lstm_inputs``."""
+        device-resident ``lengths``: see ``_lstm_inputs``.  ``next_logmel``: see ``_lstm_forward_raw``."""
         xb, lengths, t_out, h0, c0 = self._lstm_inputs(feat, lengths, t_out)
         ps = self.hot_parameters()
-        hs, hT, cT, saved = _lstm_forward_raw(xb, lengths, t_out, h0, c0, *ps[:4])
+        hs, hT, cT, saved = _lstm_forward_raw(xb, lengths, t_out, h0, c0, *ps[:4], next_logmel=next_logmel)
         y1, y2 = _head_forward_raw(hs, *ps[4:8])
         self._seq_saved = (saved, t_out, hs, y1)
         if self.is_streaming:                          # same carry as forward() (rnn.py:64-68)

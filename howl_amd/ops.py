@@ -74,6 +74,23 @@ def logmel(pcm: torch.Tensor, fbp: torch.Tensor, n_mels: int, zmuv_pair=None, la
     return out
 
 
+def logmel_args(pcm: torch.Tensor, fbp: torch.Tensor, n_mels: int, zmuv_pair=None, layout: int = 0, log_eps: float = 1e-7):
+    """``logmel``'s call as a ``HowlLogmelArgs`` record for entry points that run the frontend of the NEXT batch themselves
+    (``howl_lstm_fwd_next``): returns (record, out tensor, tensors the record points into -- keep them alive until the call)."""
+    if pcm.dim() != 2:
+        raise ValueError("pcm must be (B, L)")
+    if pcm.stride(1) != 1:
+        pcm = pcm.contiguous()
+    B, L = pcm.shape
+    T = num_frames(L)
+    out = torch.empty((B, n_mels, T) if layout == 0 else (B, T, n_mels), dtype=torch.float32, device=pcm.device)
+    if not on_device(pcm) or pcm.dtype != torch.float32:
+        _p(pcm)
+    rec = _lib.HowlLogmelArgs(ctypes.c_void_p(pcm.data_ptr()), B, L, pcm.stride(0), _p(fbp), n_mels, log_eps,
+                              _p(zmuv_pair, allow_none=True), _p(out), layout)
+    return rec, out, (pcm, fbp, zmuv_pair)
+
+
 def deltas(logmel_bmt: torch.Tensor, zmuv_pair=None) -> torch.Tensor:
     B, M, T = logmel_bmt.shape
     out = torch.empty((B, 3, M, T), dtype=torch.float32, device=logmel_bmt.device)

@@ -66,6 +66,7 @@ class FusedTrainer:
         self.collectives_last_step = 0     # gradient collectives the last step issued (bench.py reports it)
         self.collectives_last_step_reduced = 0   # ... the last step that did reduce (skip_allreduce steps excluded)
         self.skip_allreduce = False        # measurement only (bench.py: step time with vs without the collectives)
+        self._ahead = None                 # (next_audio, its features, keep-alive) left by step_sequence(next_audio=...)
 
     def broadcast_parameters(self, src=0):
         """Make every replica start from rank ``src``'s weights and BatchNorm buffers."""
@@ -134,17 +135,37 @@ class FusedTrainer:
         self.last_logits = logits
         return loss
 
-    def step_sequence(self, audio, frame_lengths, targets, target_lengths, blank, max_target=None, max_frames=None):
+    def step_sequence(self, audio, frame_lengths, targets, target_lengths, blank, max_target=None, max_frames=None, next_audio=None):
         """One optimisation step of the sequence objective (train.py:286-302 with ``objective=ctc``) on a (B, L) PCM batch
         sorted by decreasing length: ``frame_lengths`` = ``StandardAudioTransform.compute_lengths`` of the sample counts,
         ``targets`` the padded (B, Lmax) label matrix.  The length vectors may live on the host (as the reference's batches
         do: copied over each step) or on the device; for device-resident ones pass their maxima (``max_frames``,
-        ``max_target``) so that nothing is read back.  Returns the mean CTC loss as a device tensor."""
-        return self.step_sequence_on_features(self.features(audio), frame_lengths, targets, target_lengths, blank, max_target,
-                                              max_frames)
+        ``max_target``) so that nothing is read back.  Returns the mean CTC loss as a device tensor.
+        ``next_audio``: the PCM batch of the NEXT step (a one-batch look-ahead, as a prefetching DataLoader gives): its frontend
+        runs inside this step's forward call -- on the CUs the recurrence leaves idle -- and the next call, given the same
+        tensor as ``audio``, finds its features ready.  Same launches' worth of work per step, one of them off the critical path;
+        only for frontends without a pending VTLP draw (see ``log_mel_for_model_args``)."""
+        feat = None
+        if self._ahead is not None and self._ahead[0] is audio:
+            feat = self._ahead[1]
+        self._ahead = None
+        if feat is None:
+            feat = self.features(audio)
+        nxt = None
+        if next_audio is not None and getattr(self.model, "TAKES_NEXT_LOGMEL", False):
+            nxt = self.std.log_mel_for_model_args(next_audio, self.zmuv)
+        loss = self.step_sequence_on_features(feat, frame_lengths, targets, target_lengths, blank, max_target, max_frames,
+                                              next_logmel=None if nxt is None else nxt[0])
+        if nxt is not None:
+            self._ahead = (next_audio, nxt[1], nxt[2])      # (the record's tensors stay alive with it)
+        return loss
 
-    def step_sequence_on_features(self, feat, frame_lengths, targets, target_lengths, blank, max_target=None, max_frames=None):
-        scores = self.model._launch_forward(feat, frame_lengths, max_frames)   # (T_len, B, C) view of a (B, T_len, C) buffer
+    def step_sequence_on_features(self, feat, frame_lengths, targets, target_lengths, blank, max_target=None, max_frames=None,
+                                  next_logmel=None):
+        if next_logmel is not None:
+            scores = self.model._launch_forward(feat, frame_lengths, max_frames, next_logmel=next_logmel)
+        else:
+            scores = self.model._launch_forward(feat, frame_lengths, max_frames)   # (T_len, B, C) view of a (B, T_len, C) buffer
         if max_target is None:
             max_target = int(target_lengths.max()) if target_lengths.numel() else 0
         ctc_mean = None

@@ -286,6 +286,25 @@ size_t howl_lstm_needs_gx(const HowlLstmParams* p, int B, int T, int M, int x_fr
 int howl_lstm_fwd(const HowlLstmParams* p, const float* x, int B, int T, int M, const long long* lengths,
                   const float* h0, const float* c0, const HowlLstmSaved* saved, float* hT, float* cT, void* ws,
                   size_t ws_bytes, hipStream_t stream);
+/* howl_lstm_fwd + the frontend of the NEXT batch (howl_logmel_fwd's arguments): where the recurrence leaves CUs idle (four
+ * sequences per workgroup: (B + 3) / 4 workgroups <= half of the device) the frontend runs as additional blocks of the
+ * recurrence's launch -- independent work, read by later calls only -- and as its own launch behind the recurrence otherwise;
+ * either way next->out holds the features when the call's work has run.  The training loop's one-batch look-ahead
+ * (FusedTrainer.step_sequence(next_audio=...)). */
+typedef struct {
+    const float* pcm;
+    int B, L;
+    long ld;
+    const float* fbp;
+    int M;
+    float log_eps;
+    const float* zmuv;
+    float* out;
+    int layout;
+} HowlLogmelArgs;
+int howl_lstm_fwd_next(const HowlLstmParams* p, const float* x, int B, int T, int M, const long long* lengths,
+                       const float* h0, const float* c0, const HowlLstmSaved* saved, float* hT, float* cT, void* ws,
+                       size_t ws_bytes, const HowlLogmelArgs* next, hipStream_t stream);
 /* dy: (B,T,128) gradient w.r.t. the padded outputs or NULL; dhT/dcT: (B,128) gradient w.r.t. the final state or NULL. */
 int howl_lstm_bwd(const HowlLstmParams* p, const float* x, int B, int T, int M, const long long* lengths,
                   const float* c0, const HowlLstmSaved* saved, const float* dy, const float* dhT, const float* dcT,

@@ -6,7 +6,8 @@ import pytest
 import torch
 
 from emu_util import emu_lib, ptr
-from howl_amd.lib import HowlAdamW, HowlHeadGrads, HowlHeadParams, HowlLstmGrads, HowlLstmParams, HowlLstmSaved
+from howl_amd.lib import (FB_PACKED_FLOATS, HowlAdamW, HowlHeadGrads, HowlHeadParams, HowlLogmelArgs, HowlLstmGrads, HowlLstmParams,
+                          HowlLstmSaved)
 from oracle import models as om
 
 
@@ -332,3 +333,44 @@ def test_seq_lstm_backward_with_the_optimiser_step_in_the_fold(lib, monkeypatch,
         assert np.isfinite(u).all()
         np.testing.assert_array_equal(u, w)
     assert not np.array_equal(a[0], np.concatenate([sd[k].numpy().reshape(-1) for k in names]))      # the step did move the weights
+
+
+def test_forward_with_the_next_batch_frontend_riding_in_the_launch(lib, monkeypatch):
+    """howl_lstm_fwd_next (round 5): the log-mel frontend of the NEXT batch as rider blocks of the forward recurrence's launch
+    (lstm_fwd4_kernel<40, true>: eight-wave logmel_body) == howl_lstm_fwd followed by howl_logmel_fwd, bit for bit -- the
+    recurrence's outputs and the features, in both output layouts and with the ZMUV pair; with HOWL_LSTM_RIDE_LOGMEL=0 (the
+    frontend as its own launch behind the recurrence) the same again."""
+    from oracle import frontend as ofe
+    rng = np.random.default_rng(23)
+    B, T, M = 8, 9, 40
+    x = rng.standard_normal((B, T, M)).astype(np.float32)
+    lengths = np.array([9, 9, 8, 7, 5, 4, 2, 1], np.int64)
+    sd = om.lstm_init(5)
+    fb = np.ascontiguousarray(ofe.mel_fb(40).numpy())
+    fbp = np.zeros(FB_PACKED_FLOATS, np.float32)
+    lib.call("howl_fb_pack", ptr(fb), 40, ptr(fbp), None)
+    Bn, L = 5, 3000
+    pcm = (0.3 * rng.standard_normal((Bn, L))).astype(np.float32)
+    zm = np.array([-3.0, 2.5], np.float32)
+    Tn = 1 + L // 200
+    ref_hs, ref_hT, ref_cT, ref_keep = run_lstm(lib, sd, x, lengths)
+    for layout, zmuv in ((1, zm), (0, None)):
+        want = np.full((Bn, Tn, 40) if layout else (Bn, 40, Tn), np.nan, np.float32)
+        lib.call("howl_logmel_fwd", ptr(pcm), Bn, L, L, ptr(fbp), 40, 1e-7, ptr(zmuv), ptr(want), layout, None)
+        for ride in ("1", "0"):
+            monkeypatch.setenv("HOWL_LSTM_RIDE_LOGMEL", ride)
+            npz = {k: np.ascontiguousarray(sd["lstm." + k].numpy()) for k in ("weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0")}
+            prm = HowlLstmParams(*[ptr(npz[k]) for k in ("weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0")])
+            bufs = dict(gates=np.zeros((B, T, 512), np.float32), c=np.zeros((B, T, 128), np.float32),
+                        hseq=np.full((B, T + 1, 128), np.nan, np.float32))
+            sv = HowlLstmSaved(None, ptr(bufs["gates"]), ptr(bufs["c"]), ptr(bufs["hseq"]), None, T, 0)
+            hT, cT = np.zeros((B, 128), np.float32), np.zeros((B, 128), np.float32)
+            ws = np.zeros(lib.cdll.howl_lstm_workspace_bytes(B, T), np.uint8)
+            got = np.full_like(want, np.nan)
+            nxt = HowlLogmelArgs(ptr(pcm), Bn, L, L, ptr(fbp), 40, 1e-7, ptr(zmuv), ptr(got), layout)
+            lib.call("howl_lstm_fwd_next", ctypes.byref(prm), ptr(x), B, T, M, ptr(lengths), None, None, ctypes.byref(sv), ptr(hT), ptr(cT),
+                     ptr(ws), ws.size, ctypes.byref(nxt), None)
+            np.testing.assert_array_equal(got, want)
+            np.testing.assert_array_equal(bufs["hseq"][:, 1:], ref_hs)
+            np.testing.assert_array_equal(hT, ref_hT)
+            np.testing.assert_array_equal(bufs["gates"], ref_keep["bufs"]["gates"])

@@ -217,3 +217,45 @@ def test_optimiser_step_in_the_fold_is_bit_identical_on_the_device(monkeypatch):
         for a, b in zip(out[0], other):
             assert torch.isfinite(a).all()
             assert torch.equal(a, b)
+
+
+def test_look_ahead_frontend_rides_in_the_forward_call(monkeypatch):
+    """Round 5: FusedTrainer.step_sequence(next_audio=...) -- the next batch's log-mel as rider blocks of this step's forward
+    recurrence launch (howl_lstm_fwd_next).  Three steps over three DIFFERENT batches with the look-ahead, without it, and with the
+    rider switched off inside the library (HOWL_LSTM_RIDE_LOGMEL=0: the frontend as its own launch behind the recurrence) leave
+    bit-identical parameters, moments and losses; the features the rider wrote are the frontend's own, bit for bit; a batch that
+    is NOT the one announced is recomputed (the look-ahead is dropped, never used for the wrong tensor)."""
+    from howl_amd.data.transform.operator import ZmuvTransform
+    from howl_amd.data.transform.transform import StandardAudioTransform
+    from howl_amd.training.fused import FusedTrainer
+    from howl_amd.utils.synth import synthetic_pcm
+    B, L, C = 512, 8000, 5
+    batches = [synthetic_pcm(B, L, seed=100 + i).to(DEV) for i in range(4)]
+    std = StandardAudioTransform().to(DEV).eval()
+    zmuv = ZmuvTransform().to(DEV)
+    zmuv.update(std(batches[0][:4]))
+    lengths = torch.full((B,), 38)
+    targets = torch.tensor([[0, 1, 2]] * B)
+    tl = torch.tensor(([3, 2, 1] * (B // 3 + 1))[:B])
+    out = []
+    for mode in ("ahead", "plain", "ahead-own-launch", "ahead-wrong-batch"):
+        monkeypatch.delenv("HOWL_LSTM_RIDE_LOGMEL", raising=False)
+        if mode == "ahead-own-launch":
+            monkeypatch.setenv("HOWL_LSTM_RIDE_LOGMEL", "0")
+        model = make("seq-lstm", C).train()
+        tr = FusedTrainer(model, std, zmuv, lr=1e-3, weight_decay=1e-5)
+        losses = []
+        for i in range(3):
+            nxt = None if mode == "plain" else batches[i + 1]
+            if mode == "ahead-wrong-batch" and i == 0:
+                nxt = batches[3]                 # announced, but step 1 trains on batches[1]: must be recomputed
+            losses.append(tr.step_sequence(batches[i], lengths, targets, tl, 4, next_audio=nxt))
+            if mode == "ahead" and i == 0:       # what the rider wrote for batch 1 == the frontend's own launch on batch 1
+                assert tr._ahead is not None and tr._ahead[0] is batches[1]
+                assert torch.equal(tr._ahead[1], std.log_mel_for_model(batches[1], zmuv))
+        torch.cuda.synchronize()
+        out.append([t.clone() for t in (tr.fp.flat, tr.m, tr.v, torch.stack([l.reshape(()) for l in losses]))])
+    for other in out[1:]:
+        for a, b in zip(out[0], other):
+            assert torch.isfinite(a).all()
+            assert torch.equal(a, b)
