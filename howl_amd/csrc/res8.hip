@@ -309,7 +309,7 @@ __device__ __forceinline__ void region_slots(int (&pk)[NSL], int c0, int nch, in
 // `base` = float offset of (utterance, region) in every tensor of the configuration (uniform: the addresses are "scalar base
 // + 32-bit lane offset", no 64-bit address lives in a VGPR).  Unconditional loads from clamped offsets (a load under a lane
 // predicate waits for the one before it): slots without an element re-read the region's first.
-template <int MODE>
+template <int MODE, bool HALO = false>
 __device__ __forceinline__ void slot_load(SlotVal& v, const StageCfg& cfg, size_t base, int i2, int pkj, int b) {
     HOWL_OPAQUE_V(pkj);
     const unsigned off = pkj >= 0 ? 8u * (unsigned)i2 : 0u;
@@ -318,7 +318,7 @@ __device__ __forceinline__ void slot_load(SlotVal& v, const StageCfg& cfg, size_
             v.a = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(cfg.a + base) + off);
         } else {
             const unsigned c4 = pkj >= 0 ? 4u * (unsigned)(pkj >> 20) : 0u;
-            const float g = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(cfg.dpool + (size_t)b * CP) + c4) * cfg.invP;
+            const float g = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(cfg.dpool + (size_t)(HALO ? b >> 1 : b) * CP) + c4) * cfg.invP;
             v.a = make_float2(g, g);
         }
         v.s = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(cfg.s + base) + off);
@@ -372,6 +372,64 @@ __device__ __forceinline__ void slot_write(const SlotVal& v, const StageCfg& cfg
     float* d = tile + (pkj & 0xFFFFF);
     d[0] = v0;
     d[1] = v1;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Wide maps (HALO; NUM_MELS = 80, the reference's stock default, settings.py:32): 20 pooled columns do not fit the tile, so an
+// utterance is kept as TWO strips of 10 columns, each a (45, H, 10) block of its own -- "virtual utterance" v = 2 b + strip,
+// the layout every kernel here already walks -- and the one thing a strip lacks is its neighbour's edge column, which takes
+// the place of the zero halo on that side: column 0 of strip 1 into tile column 11 of strip 0, column 9 of strip 0 into tile
+// column 0 of strip 1.  That is one more staging slot per thread and region (<= 24 channels x 27 rows = 648 elements <= 768
+// threads), read with a stride of 10 floats from the neighbour's block and pushed through the same arithmetic as the rest of
+// the tile.  A workgroup's utterances v, v + nblk, ... keep their parity (the launchers make nblk even), so the other side's
+// halo column stays at the zeros of the prologue.  Everything else -- K loop, epilogue, statistics, partials -- is unchanged.
+// ---------------------------------------------------------------------------------------------------------
+struct HaloSlot {
+    int pk;   // LDS float offset of tile column 0 of the element's row (bits 0..19) | channel << 20; -1 = no element
+    int g;    // float offset of column 0 of that row in an utterance's (45, P) map
+};
+__device__ __forceinline__ HaloSlot halo_slot(int c0, int nch, int H, int P, int CS, int tid) {
+    const int c = tid / H, h = tid - c * H;
+    HaloSlot hs;
+    hs.pk = (tid < nch * H) ? (((c0 + c) * CS + (h + 1) * WP) | ((c0 + c) << 20)) : -1;
+    hs.g = (tid < nch * H) ? (c0 + c) * P + h * PW : 0;
+    return hs;
+}
+// `nbase` = float offset of the NEIGHBOUR strip's block (uniform), gcol = its edge column (9: left neighbour, 0: right one)
+template <int MODE>
+__device__ __forceinline__ void halo_load(SlotVal& v, const StageCfg& cfg, size_t nbase, const HaloSlot& hs, int gcol, int b) {
+    const unsigned off = hs.pk >= 0 ? 4u * (unsigned)(hs.g + gcol) : 0u;
+    v.s = v.k = make_float2(0.0f, 0.0f);
+    if (MODE == 1 && cfg.fused) {
+        if (cfg.a != nullptr) {
+            v.a.x = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(cfg.a + nbase) + off);
+        } else {
+            const unsigned c4 = hs.pk >= 0 ? 4u * (unsigned)(hs.pk >> 20) : 0u;
+            v.a.x = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(cfg.dpool + (size_t)(b >> 1) * CP) + c4) * cfg.invP;
+        }
+        v.s.x = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(cfg.s + nbase) + off);
+        if (cfg.k != nullptr) v.k.x = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(cfg.k + nbase) + off);
+    } else {
+        v.a.x = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(cfg.a + nbase) + off);
+    }
+    v.a.y = v.a.x;
+}
+// lcol = tile column of the halo (0: left, WP - 1: right); the neighbour writes its own ds, so nothing goes back to HBM here
+template <int MODE>
+__device__ __forceinline__ void halo_write(const SlotVal& v, const StageCfg& cfg, const HaloSlot& hs, int lcol, float* tile,
+                                           const float* lm) {
+    if (hs.pk < 0) return;
+    const int c = hs.pk >> 20;
+    float v0 = v.a.x;
+    if (MODE == 0) {
+        v0 = fabsf(v0);
+        if (cfg.affine) v0 = fmaf(v0, lm[CP + c], lm[c]);
+    } else if (cfg.fused) {
+        float2 ds, dz;
+        bn_relu_bwd_pair(v, lm + c, cfg.even, ds, dz);
+        v0 = dz.x;
+    }
+    tile[(hs.pk & 0xFFFFF) + lcol] = v0;
 }
 
 struct ConvEpilogue {
@@ -480,9 +538,10 @@ struct ConvLoop {
 // All utterances b, b + nblk, ... of this workgroup; on entry channels 0..23 of utterance b are in the tile (barrier passed).
 // Instantiated once per tile count (waves of one workgroup run different instances; every instance executes the same two
 // barriers per utterance): the register allocator then sees one variant's live values, not the union of all five.
-template <int MODE, int NTW, int TS>
+template <int MODE, int NTW, int TS, bool HALO = false>
 __device__ __forceinline__ void conv_loop(const ConvLoop& c, const ConvEpilogue& epi, const StageCfg& cfg, const int (&pk0)[NS0],
-                                          const int (&pk1)[NS1], int b, float& st0, float& st1, int& pslot) {
+                                          const int (&pk1)[NS1], int b, float& st0, float& st1, int& pslot,
+                                          const HaloSlot (&hs)[2] = {HaloSlot{-1, 0}, HaloSlot{-1, 0}}) {
     const int P = epi.P, tid = c.tid, lane = c.lane;
     const int wave = tid >> 6;
     const size_t r1 = (size_t)SPLIT_C * P;
@@ -494,6 +553,8 @@ __device__ __forceinline__ void conv_loop(const ConvLoop& c, const ConvEpilogue&
         const int tap = min(4 * s3 + (lane >> 4), 8);   // taps 9..11 meet zero weights: any finite value will do
         dl[s3] = (tap / 3) * WP + tap % 3 - (lane >> 4) * c.CS;
     }
+    // HALO: strip parity of this workgroup's utterances (nblk is even) -> which edge column is fetched, and where it goes
+    const int gcol = (b & 1) ? PW - 1 : 0, lcol = (b & 1) ? 0 : WP - 1;
     for (; b < c.B; b += c.nblk) {
         const size_t ubase = (size_t)b * NMAP * P;
         const int bn = b + c.nblk;
@@ -510,8 +571,9 @@ __device__ __forceinline__ void conv_loop(const ConvLoop& c, const ConvEpilogue&
 #define HOWL_WINO_CHUNK() ((void)0)
 #define HOWL_WINO_BAR() ((void)0)
         if constexpr (STAGE) {
-            slot_load<MODE>(v[0], cfg, ubase + r1, tid, pk1[0], b);
-            slot_load<MODE>(v[1], cfg, ubase + r1, tid + CONV_THREADS, pk1[1], b);
+            slot_load<MODE, HALO>(v[0], cfg, ubase + r1, tid, pk1[0], b);
+            slot_load<MODE, HALO>(v[1], cfg, ubase + r1, tid + CONV_THREADS, pk1[1], b);
+            if constexpr (HALO) halo_load<MODE>(v[2], cfg, (size_t)(b ^ 1) * NMAP * P, hs[1], gcol, b);
         }
         HOWL_STAIR(3);
         HOWL_WINO_CHUNK();
@@ -520,8 +582,9 @@ __device__ __forceinline__ void conv_loop(const ConvLoop& c, const ConvEpilogue&
         if constexpr (STAGE) {
             slot_write<MODE>(v[0], cfg, ubase + r1, tid, pk1[0], c.tile, c.lm);
             slot_write<MODE>(v[1], cfg, ubase + r1, tid + CONV_THREADS, pk1[1], c.tile, c.lm);
-            slot_load<MODE>(v[0], cfg, ubase + r1, tid + 2 * CONV_THREADS, pk1[2], b);
-            slot_load<MODE>(v[1], cfg, ubase + r1, tid + 3 * CONV_THREADS, pk1[3], b);
+            if constexpr (HALO) halo_write<MODE>(v[2], cfg, hs[1], lcol, c.tile, c.lm);
+            slot_load<MODE, HALO>(v[0], cfg, ubase + r1, tid + 2 * CONV_THREADS, pk1[2], b);
+            slot_load<MODE, HALO>(v[1], cfg, ubase + r1, tid + 3 * CONV_THREADS, pk1[3], b);
         }
         HOWL_STAIR(2);
         HOWL_WINO_CHUNK();
@@ -542,9 +605,9 @@ __device__ __forceinline__ void conv_loop(const ConvLoop& c, const ConvEpilogue&
         // ---- phase B: channels 24..44 feed the matrix pipe, channels 0..23 of the NEXT utterance arrive
         if constexpr (NTW > 0) k_prime<NTW>(k);      // (what the last step of phase A requested ahead predates the barrier)
         if (STAGE && more) {
-            slot_load<MODE>(v[0], cfg, nbase, tid, pk0[0], bn);
-            slot_load<MODE>(v[1], cfg, nbase, tid + CONV_THREADS, pk0[1], bn);
-            slot_load<MODE>(v[2], cfg, nbase, tid + 2 * CONV_THREADS, pk0[2], bn);
+            slot_load<MODE, HALO>(v[0], cfg, nbase, tid, pk0[0], bn);
+            slot_load<MODE, HALO>(v[1], cfg, nbase, tid + CONV_THREADS, pk0[1], bn);
+            slot_load<MODE, HALO>(v[2], cfg, nbase, tid + 2 * CONV_THREADS, pk0[2], bn);
         }
         HOWL_STAIR(3);
         HOWL_WINO_CHUNK();
@@ -554,8 +617,9 @@ __device__ __forceinline__ void conv_loop(const ConvLoop& c, const ConvEpilogue&
             slot_write<MODE>(v[0], cfg, nbase, tid, pk0[0], c.tile, c.lm);
             slot_write<MODE>(v[1], cfg, nbase, tid + CONV_THREADS, pk0[1], c.tile, c.lm);
             slot_write<MODE>(v[2], cfg, nbase, tid + 2 * CONV_THREADS, pk0[2], c.tile, c.lm);
-            slot_load<MODE>(v[0], cfg, nbase, tid + 3 * CONV_THREADS, pk0[3], bn);
-            slot_load<MODE>(v[1], cfg, nbase, tid + 4 * CONV_THREADS, pk0[4], bn);
+            slot_load<MODE, HALO>(v[0], cfg, nbase, tid + 3 * CONV_THREADS, pk0[3], bn);
+            slot_load<MODE, HALO>(v[1], cfg, nbase, tid + 4 * CONV_THREADS, pk0[4], bn);
+            if constexpr (HALO) halo_load<MODE>(v[2], cfg, (size_t)(bn ^ 1) * NMAP * P, hs[0], gcol, bn);
         }
         HOWL_STAIR(2);
         HOWL_WINO_CHUNK();
@@ -564,6 +628,7 @@ __device__ __forceinline__ void conv_loop(const ConvLoop& c, const ConvEpilogue&
         if (STAGE && more) {
             slot_write<MODE>(v[0], cfg, nbase, tid + 3 * CONV_THREADS, pk0[3], c.tile, c.lm);
             slot_write<MODE>(v[1], cfg, nbase, tid + 4 * CONV_THREADS, pk0[4], c.tile, c.lm);
+            if constexpr (HALO) halo_write<MODE>(v[2], cfg, hs[0], lcol, c.tile, c.lm);
         }
         // the epilogue's operands take the registers the staging slots just released; they land under the last K segment
         float2 ev[NTV][2];
@@ -637,7 +702,7 @@ struct WFold {
 
 // MODE 0: forward   out = relu(conv(x)) [+ res]; stats = (sum, sumsq) of out per cout
 // MODE 1: dgrad     out = conv(dz);              stats = (sum out, sum out * xhat) per cout, xhat from s_prev
-template <int MODE, int SLICES>
+template <int MODE, int SLICES, bool HALO = false>
 __device__ __forceinline__ void conv3x3_body(
     StageCfg cfg,                         // the input tile (see StageCfg)
     const float* __restrict__ in_stats,   // forward: {mean[48], rstd[48]} applied on load, or nullptr
@@ -684,6 +749,11 @@ __device__ __forceinline__ void conv3x3_body(
     int pk0[NS0], pk1[NS1];
     region_slots<NS0>(pk0, 0, SPLIT_C, P, CS, tid);
     region_slots<NS1>(pk1, SPLIT_C, NMAP - SPLIT_C, P, CS, tid);
+    HaloSlot hs[2] = {HaloSlot{-1, 0}, HaloSlot{-1, 0}};
+    if constexpr (HALO) {
+        hs[0] = halo_slot(0, SPLIT_C, H, P, CS, tid);
+        hs[1] = halo_slot(SPLIT_C, NMAP - SPLIT_C, H, P, CS, tid);
+    }
 
     // channels 0..23 of the first utterance are requested before anything else so that HBM latency overlaps the setup
     int b = bid;
@@ -692,7 +762,11 @@ __device__ __forceinline__ void conv3x3_body(
     SlotVal first[NS0];
     if (b < B) {
 #pragma unroll
-        for (int j = 0; j < NS0; ++j) slot_load<MODE>(first[j], cfg, (size_t)b * NMAP * P, tid + j * CONV_THREADS, pk0[j], b);
+        for (int j = 0; j < NS0; ++j) slot_load<MODE, HALO>(first[j], cfg, (size_t)b * NMAP * P, tid + j * CONV_THREADS, pk0[j], b);
+    }
+    SlotVal firsth;
+    if constexpr (HALO) {
+        if (b < B) halo_load<MODE>(firsth, cfg, (size_t)(b ^ 1) * NMAP * P, hs[0], (b & 1) ? PW - 1 : 0, b);
     }
     {
         float4 wv[7];  // 3*102*16 float4 = 4896 <= 7 * 768: all loads in flight, then the LDS stores
@@ -762,18 +836,19 @@ __device__ __forceinline__ void conv3x3_body(
 #pragma unroll
         for (int j = 0; j < NS0; ++j)
             slot_write<MODE>(first[j], cfg, (size_t)b * NMAP * P, tid + j * CONV_THREADS, pk0[j], tile, lm);
+        if constexpr (HALO) halo_write<MODE>(firsth, cfg, hs[0], (b & 1) ? 0 : WP - 1, tile, lm);
     }
     __syncthreads();  // channels 0..23 of the first utterance in place
     HOWL_PROBE(cfg, wave, lane, pslot++);   // first half tile staged
 
     const ConvLoop cl{(const lds_f32*)tile, (const lds_f32*)wl + nt * KSTEPS * 64, tile, lm, B, CS, t0, lane, tid, nblk};
     switch (ntw) {
-        case 5: conv_loop<MODE, 5, ts>(cl, epi, cfg, pk0, pk1, b, st0, st1, pslot); break;
-        case 4: conv_loop<MODE, 4, ts>(cl, epi, cfg, pk0, pk1, b, st0, st1, pslot); break;
-        case 3: conv_loop<MODE, 3, ts>(cl, epi, cfg, pk0, pk1, b, st0, st1, pslot); break;
-        case 2: conv_loop<MODE, 2, ts>(cl, epi, cfg, pk0, pk1, b, st0, st1, pslot); break;
-        case 1: conv_loop<MODE, 1, ts>(cl, epi, cfg, pk0, pk1, b, st0, st1, pslot); break;
-        default: conv_loop<MODE, 0, ts>(cl, epi, cfg, pk0, pk1, b, st0, st1, pslot); break;
+        case 5: conv_loop<MODE, 5, ts, HALO>(cl, epi, cfg, pk0, pk1, b, st0, st1, pslot, hs); break;
+        case 4: conv_loop<MODE, 4, ts, HALO>(cl, epi, cfg, pk0, pk1, b, st0, st1, pslot, hs); break;
+        case 3: conv_loop<MODE, 3, ts, HALO>(cl, epi, cfg, pk0, pk1, b, st0, st1, pslot, hs); break;
+        case 2: conv_loop<MODE, 2, ts, HALO>(cl, epi, cfg, pk0, pk1, b, st0, st1, pslot, hs); break;
+        case 1: conv_loop<MODE, 1, ts, HALO>(cl, epi, cfg, pk0, pk1, b, st0, st1, pslot, hs); break;
+        default: conv_loop<MODE, 0, ts, HALO>(cl, epi, cfg, pk0, pk1, b, st0, st1, pslot, hs); break;
     }
 
     HOWL_PROBE(cfg, wave, lane, pslot++);   // all utterances done
@@ -846,7 +921,7 @@ __device__ __forceinline__ void conv3x3_body(
     }
 }
 
-template <int MODE, int SLICES>
+template <int MODE, int SLICES, bool HALO = false>
 __global__ __launch_bounds__(CONV_THREADS) void conv3x3_mfma_kernel(StageCfg cfg, const float* __restrict__ in_stats,
                                                                     const float* __restrict__ wp,
                                                                     const float* __restrict__ res, float* __restrict__ out,
@@ -859,7 +934,7 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_mfma_kernel(StageCfg cfg
     const int x = blockIdx.x & 7, y = blockIdx.x >> 3;
     const int slice = y % SLICES, bid = (y / SLICES) * 8 + x;
     if (bid >= nblk) return;
-    conv3x3_body<MODE, SLICES>(cfg, in_stats, wp, res, out, xs, xs_stats, part, pool, B, H, bid, nblk, slice, fold, bfold, wf);
+    conv3x3_body<MODE, SLICES, HALO>(cfg, in_stats, wp, res, out, xs, xs_stats, part, pool, B, H, bid, nblk, slice, fold, bfold, wf);
 }
 
 
@@ -988,6 +1063,7 @@ struct WSlot {
 
 // z slot: the data gradient's staging arithmetic (slot_write<1>) with this kernel's addressing; addresses are "uniform base +
 // 32-bit lane offset" recomputed from the packed descriptor where they are used
+template <bool HALO = false>
 __device__ __forceinline__ void wz_load(SlotVal& v, const StageCfg& cfg, size_t ubase, int pkj, int chj, int b) {
     HOWL_OPAQUE_V(pkj);
     HOWL_OPAQUE_V(chj);
@@ -998,7 +1074,7 @@ __device__ __forceinline__ void wz_load(SlotVal& v, const StageCfg& cfg, size_t 
             v.a = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(cfg.a + ubase) + off);
         } else {
             const unsigned c4 = 4u * (unsigned)(chj & 0xFF);
-            const float gg = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(cfg.dpool + (size_t)b * CP) + c4) * cfg.invP;
+            const float gg = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(cfg.dpool + (size_t)(HALO ? b >> 1 : b) * CP) + c4) * cfg.invP;
             v.a = make_float2(gg, gg);
         }
         v.s = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(cfg.s + ubase) + off);
@@ -1045,6 +1121,28 @@ __device__ __forceinline__ void wx_write(const float2& v, bool affine, int pkj, 
     d[1] = v1;
 }
 
+// HALO (wide maps, see HaloSlot): the x tile's halo column on the neighbour's side, one element per thread and row region
+struct WHalo {
+    int pk;   // LDS float offset of tile column 0 of the element's row in tx; -1 = no element
+    int g;    // float offset of column 0 of that row in an utterance's (45, P) map
+    int c;    // channel
+};
+__device__ __forceinline__ WHalo whalo_slot(int h0, int h1, int P, int CSX, int row0, int tid) {
+    const int nper = h1 > h0 ? h1 - h0 : 0, nsafe = nper > 0 ? nper : 1;
+    const int c = tid / nsafe, hh = tid - c * nsafe, h = h0 + hh;
+    const bool ok = tid < NMAP * nper;
+    return WHalo{ok ? c * CSX + (h + row0) * WPW : -1, ok ? c * P + h * PW : 0, ok ? c : 0};
+}
+__device__ __forceinline__ float whalo_load(const float* x, size_t nbase, const WHalo& wh, int gcol) {
+    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(x + nbase) + 4u * (unsigned)(wh.g + (wh.pk >= 0 ? gcol : 0)));
+}
+__device__ __forceinline__ void whalo_write(float v, bool affine, const WHalo& wh, int lcol, float* tx, const float* lm) {
+    if (wh.pk < 0) return;
+    float v0 = fabsf(v);
+    if (affine) v0 = fmaf(v0, lm[5 * CP + wh.c], lm[4 * CP + wh.c]);
+    tx[wh.pk + lcol] = v0;
+}
+
 struct WgradArgs {
     WStage st;
     float* part;
@@ -1067,9 +1165,10 @@ __device__ __forceinline__ int wgrad_boff(int q, int n, int g, int CSX) {
     return cin * CSX + (g + tap / 3) * WPW + (tap % 3);     // cin row, halo origin + tap shift
 }
 
-template <int NB, bool EX, int GWS>
+template <int NB, bool EX, int GWS, bool HALO = false>
 __device__ __forceinline__ void wgrad_loop(const WgradArgs& a, const int (&zt)[WNT], const int (&xt)[WNT], const int (&ct)[WNT],
-                                           const int (&zb)[WNB], const int (&xb)[WNB], const int (&cb)[WNB], int b, int& pslot) {
+                                           const int (&zb)[WNB], const int (&xb)[WNB], const int (&cb)[WNB], int b, int& pslot,
+                                           const WHalo (&wh)[2] = {WHalo{-1, 0, 0}, WHalo{-1, 0, 0}}) {
     const int lane = a.lane, wave = a.wave;
     const int g = lane >> 4, n = lane & 15;
     f32x4 acc[NB][3];
@@ -1085,6 +1184,8 @@ __device__ __forceinline__ void wgrad_loop(const WgradArgs& a, const int (&zt)[W
     f32x4 acce = {0.0f, 0.0f, 0.0f, 0.0f};
     const int aoff = n * a.CSZ + g * WPZ;                                    // cout row g, column 0
     const int R1 = a.R1, R2 = a.R - a.R1;
+    // HALO: tx columns 0 / 11 are the halo of the data columns 1..10; strip parity is fixed per workgroup (nblk is even)
+    const int gcol = (b & 1) ? PW - 1 : 0, lcol = (b & 1) ? 0 : PW + 1;
     for (; b < a.B; b += a.nblk) {
         const size_t ubase = (size_t)b * NMAP * a.P;
         const int bn = b + a.nblk;
@@ -1111,7 +1212,7 @@ __device__ __forceinline__ void wgrad_loop(const WgradArgs& a, const int (&zt)[W
         static_assert(WNB == 5 && WNT == 4, "the staging schedule below is written for 5 + 4 slot pairs");
 #define HOWL_W_LOAD(slot_, j_, zpk_, xpk_, cpk_, ub_, bb_)                    \
     do {                                                                     \
-        wz_load(v[slot_].z, a.st.z, ub_, zpk_[j_], cpk_[j_], bb_);           \
+        wz_load<HALO>(v[slot_].z, a.st.z, ub_, zpk_[j_], cpk_[j_], bb_);     \
         wx_load(v[slot_].x, a.st.x, ub_, xpk_[j_]);                          \
     } while (0)
 #define HOWL_W_WRITE(slot_, j_, zpk_, xpk_, cpk_)                             \
@@ -1121,10 +1222,13 @@ __device__ __forceinline__ void wgrad_loop(const WgradArgs& a, const int (&zt)[W
     } while (0)
         HOWL_W_LOAD(0, 0, zb, xb, cb, ubase, b);
         HOWL_W_LOAD(1, 1, zb, xb, cb, ubase, b);
+        float xh = 0.0f;
+        if constexpr (HALO) xh = whalo_load(a.st.x, (size_t)(b ^ 1) * NMAP * a.P, wh[1], gcol);
         HOWL_STAIR(3);
         if (R1 > 0) wgrad_k_run<NB, EX>(c, acc, acce, az, bx, aze, bxe, 1);
         HOWL_W_WRITE(0, 0, zb, xb, cb);
         HOWL_W_WRITE(1, 1, zb, xb, cb);
+        if constexpr (HALO) whalo_write(xh, a.st.xaffine, wh[1], lcol, a.tx, a.lm);
         HOWL_W_LOAD(0, 2, zb, xb, cb, ubase, b);
         HOWL_W_LOAD(1, 3, zb, xb, cb, ubase, b);
         HOWL_STAIR(2);
@@ -1155,12 +1259,14 @@ __device__ __forceinline__ void wgrad_loop(const WgradArgs& a, const int (&zt)[W
         if (more) {
             HOWL_W_LOAD(0, 0, zt, xt, ct, nbase, bn);
             HOWL_W_LOAD(1, 1, zt, xt, ct, nbase, bn);
+            if constexpr (HALO) xh = whalo_load(a.st.x, (size_t)(bn ^ 1) * NMAP * a.P, wh[0], gcol);
         }
         HOWL_STAIR(3);
         wgrad_k_run<NB, EX>(c, acc, acce, az, bx, aze, bxe, 1);
         if (more) {
             HOWL_W_WRITE(0, 0, zt, xt, ct);
             HOWL_W_WRITE(1, 1, zt, xt, ct);
+            if constexpr (HALO) whalo_write(xh, a.st.xaffine, wh[0], lcol, a.tx, a.lm);
             HOWL_W_LOAD(0, 2, zt, xt, ct, nbase, bn);
             HOWL_W_LOAD(1, 3, zt, xt, ct, nbase, bn);
         }
@@ -1195,7 +1301,7 @@ __device__ __forceinline__ void wgrad_loop(const WgradArgs& a, const int (&zt)[W
     }
 }
 
-template <int SLICES>
+template <int SLICES, bool HALO = false>
 __device__ __forceinline__ void wgrad_body(
     WStage st, const float* __restrict__ in_stats /* {mean, rstd} of layer i-1 or nullptr */, const BwdFold& bfold,
     float* __restrict__ part /* [nblk][48][WNCOL] */, int B, int H, int bid, int nblk, int slice) {
@@ -1225,15 +1331,24 @@ __device__ __forceinline__ void wgrad_body(
     row_region_slots<WNT>(xt, ct, 1, 0, xtop, P, CSX, WPW, 1, 1, tid);
     row_region_slots<WNB>(zb, cb, 0, zsplit, H, P, CSZ, WPZ, 0, 0, tid);
     row_region_slots<WNB>(xb, cb, 1, xbot, H, P, CSX, WPW, 3, 1, tid);
+    WHalo wh[2] = {WHalo{-1, 0, 0}, WHalo{-1, 0, 0}};
+    if constexpr (HALO) {
+        wh[0] = whalo_slot(0, xtop, P, CSX, 1, tid);
+        wh[1] = whalo_slot(xbot, H, P, CSX, 3, tid);
+    }
     // the first utterance's top rows are requested before the LDS setup so that HBM latency overlaps it
     const int b = bid;
     WSlot first[WNT];
     if (b < B) {
 #pragma unroll
         for (int j = 0; j < WNT; ++j) {
-            wz_load(first[j].z, st.z, (size_t)b * NMAP * P, zt[j], ct[j], b);
+            wz_load<HALO>(first[j].z, st.z, (size_t)b * NMAP * P, zt[j], ct[j], b);
             wx_load(first[j].x, st.x, (size_t)b * NMAP * P, xt[j]);
         }
+    }
+    float firsth = 0.0f;
+    if constexpr (HALO) {
+        if (b < B) firsth = whalo_load(st.x, (size_t)(b ^ 1) * NMAP * P, wh[0], (b & 1) ? PW - 1 : 0);
     }
     zero_lds(lds, tile_floats_z(H) + tile_floats_x(H), tid, CONV_THREADS);
     if (st.z.fused) {
@@ -1250,6 +1365,7 @@ __device__ __forceinline__ void wgrad_body(
             wz_write(first[j].z, st.z, zt[j], ct[j], tz, lm);
             wx_write(first[j].x, st.xaffine, xt[j], ct[j], tx, lm);
         }
+        if constexpr (HALO) whalo_write(firsth, st.xaffine, wh[0], (b & 1) ? 0 : PW + 1, tx, lm);
     }
     __syncthreads();
     HOWL_PROBE(st.z, wave, lane, pslot++);   // prologue done
@@ -1274,26 +1390,26 @@ __device__ __forceinline__ void wgrad_body(
         }
         const WgradArgs a{st, part, tz, tx, lm, B, P, CSZ, CSX, R, R1, tid, lane, wave, bid, nblk, gw, qe, mte};
         if (ex)
-            wgrad_loop<2, true, GWS>(a, zt, xt, ct, zb, xb, cb, b, pslot);
+            wgrad_loop<2, true, GWS, HALO>(a, zt, xt, ct, zb, xb, cb, b, pslot, wh);
         else
-            wgrad_loop<2, false, GWS>(a, zt, xt, ct, zb, xb, cb, b, pslot);
+            wgrad_loop<2, false, GWS, HALO>(a, zt, xt, ct, zb, xb, cb, b, pslot, wh);
     } else {                           // small batches: tiles gw, gw + 24 (< 26) over the 24 waves of two workgroups
         const WgradArgs a{st, part, tz, tx, lm, B, P, CSZ, CSX, R, R1, tid, lane, wave, bid, nblk, gw, 0, 0};
         if (gw + 24 < 26)
-            wgrad_loop<2, false, GWS>(a, zt, xt, ct, zb, xb, cb, b, pslot);
+            wgrad_loop<2, false, GWS, HALO>(a, zt, xt, ct, zb, xb, cb, b, pslot, wh);
         else
-            wgrad_loop<1, false, GWS>(a, zt, xt, ct, zb, xb, cb, b, pslot);
+            wgrad_loop<1, false, GWS, HALO>(a, zt, xt, ct, zb, xb, cb, b, pslot, wh);
     }
     HOWL_PROBE(st.z, wave, lane, pslot++);   // partials written
 }
 
-template <int SLICES>
+template <int SLICES, bool HALO = false>
 __global__ __launch_bounds__(CONV_THREADS) void wgrad_mfma_kernel(WStage st, const float* __restrict__ in_stats, BwdFold bfold,
                                                                   float* __restrict__ part, int B, int H, int nblk) {
     const int x = blockIdx.x & 7, y = blockIdx.x >> 3;
     const int slice = y % SLICES, bid = (y / SLICES) * 8 + x;
     if (bid >= nblk) return;
-    wgrad_body<SLICES>(st, in_stats, bfold, part, B, H, bid, nblk, slice);
+    wgrad_body<SLICES, HALO>(st, in_stats, bfold, part, B, H, bid, nblk, slice);
 }
 
 // Data gradient and weight gradient of one layer in ONE launch.  Both hang off dz_i and are independent; side by side on
@@ -1302,7 +1418,7 @@ __global__ __launch_bounds__(CONV_THREADS) void wgrad_mfma_kernel(WStage st, con
 // record / wait pairs that fork and join the second queue cost ~6.5 us each on this stack, twice per layer on the
 // critical path.)  Blocks come in groups of 16: the first 8 run the data gradient, the other 8 the weight gradient, so
 // that pair j of either role lands on the same XCD (block b runs on XCD b % 8) and shares its L2 copy of what both stage.
-template <int SD, int SW>
+template <int SD, int SW, bool HALO = false>
 __global__ __launch_bounds__(CONV_THREADS) void bwd_pair_kernel(
     StageCfg zc, BwdFold bfold, const float* __restrict__ wp, float* __restrict__ dx, const float* __restrict__ xs,
     const float* __restrict__ xs_stats, float* __restrict__ spart, const float* __restrict__ s_prev,
@@ -1314,9 +1430,9 @@ __global__ __launch_bounds__(CONV_THREADS) void bwd_pair_kernel(
     const int j = (y / (SD + SW)) * 8 + x;
     if (j >= nblk) return;
     if (r < SD)
-        conv3x3_body<1, SD>(zc, nullptr, wp, nullptr, dx, xs, xs_stats, spart, nullptr, B, H, j, nblk, r, BnFold{}, bfold, wf);
+        conv3x3_body<1, SD, HALO>(zc, nullptr, wp, nullptr, dx, xs, xs_stats, spart, nullptr, B, H, j, nblk, r, BnFold{}, bfold, wf);
     else
-        wgrad_body<SW>(WStage{zc, s_prev, false}, in_stats, bfold, wpart, B, H, j, nblk, r - SD);
+        wgrad_body<SW, HALO>(WStage{zc, s_prev, false}, in_stats, bfold, wpart, B, H, j, nblk, r - SD);
 }
 
 // Deterministic sum over the per-workgroup partial rows: part[g][col], g < nparts.  A block owns 64 columns
@@ -1563,6 +1679,8 @@ constexpr int C0M_THREADS = 512;   // 8 waves, two per SIMD
 // Workgroups beyond the first `nconv` do an unrelated, independent job in the same launch: they rebuild the packed 3x3
 // weight fragments of the six following layers (the weights may have changed since the last call), which the first 3x3
 // convolution needs only after this kernel has finished anyway.
+// NS = strips of 10 pooled columns per utterance (1: 40 mel bins; 2: 80, written as the two blocks v = 2 b + strip, see HaloSlot)
+template <int NS = 1>
 __global__ __launch_bounds__(C0M_THREADS) void conv0_fwd_mfma_kernel(const float* __restrict__ feat, long sb, long st,
                                                                     long sm, const float* __restrict__ w0,
                                                                     float* __restrict__ s0, unsigned short* __restrict__ mask0,
@@ -1612,8 +1730,9 @@ __global__ __launch_bounds__(C0M_THREADS) void conv0_fwd_mfma_kernel(const float
         load_feat_tile(tin, feat + (long)clip * sb + (long)t0 * st, 0, st, sm, 0, T, M, tid, C0M_THREADS);
         __syncthreads();
         // units (pair of pooled rows, group of 8 mel bins) of this slice, dealt to the waves
-        for (int u = wave; u < 5 * ((ph1 - ph0 + 1) / 2); u += C0M_THREADS / 64) {
-            const int pp = u / 5, j8 = u - 5 * pp;
+        constexpr int NJ = 5 * NS;      // groups of eight mel bins
+        for (int u = wave; u < NJ * ((ph1 - ph0 + 1) / 2); u += C0M_THREADS / 64) {
+            const int pp = u / NJ, j8 = u - NJ * pp;
             const float* rowp = tin + 3 * (ph0 + 2 * pp) * pitch + 8 * j8;
             {
                 f32x4 acc[3][3];  // [frame tl][cout tile nt]
@@ -1648,7 +1767,8 @@ __global__ __launch_bounds__(C0M_THREADS) void conv0_fwd_mfma_kernel(const float
                         }
                     const int c = 16 * nt + n;
                     if (ph < ph1 && c < NMAP) {
-                        const size_t o = ((size_t)b * NMAP + c) * P + (size_t)ph * PW + pw;
+                        const int strip = NS > 1 ? pw / PW : 0;
+                        const size_t o = (((size_t)b * NS + strip) * NMAP + c) * P + (size_t)ph * PW + (pw - strip * PW);
                         s0[o] = sum * (1.0f / 12.0f);
                         if (mask0 != nullptr) mask0[o] = (unsigned short)bits;
                     }
@@ -1690,6 +1810,7 @@ __device__ __forceinline__ void load_patch(float (&x)[5][6], const float* tin, i
 // weight gradient: dW0[c][tap] = sum over utterances, cells, the 12 positions of a cell of  (g[c][cell] / 12 where the forward's
 // mask bit is set) * x[position + tap];  acc[5][9] per lane (its wave's channels) lives in registers across every cell block and
 // utterance of the workgroup, one wave-wide sum per accumulator at the end -> one partial row per workgroup.
+template <int NS = 1>
 __global__ __launch_bounds__(C0G_THREADS) void conv0_wgrad_valu_kernel(const float* __restrict__ feat, long sb, long st, long sm,
                                                                       const unsigned short* __restrict__ mask0,
                                                                       const float* __restrict__ ga, const float* __restrict__ gb,
@@ -1706,15 +1827,17 @@ __global__ __launch_bounds__(C0G_THREADS) void conv0_wgrad_valu_kernel(const flo
     for (int j = 0; j < C0G_CPW; ++j)
 #pragma unroll
         for (int t = 0; t < 9; ++t) acc[j][t] = 0.0f;
-    for (int item = blockIdx.x; item < B * slices; item += gridDim.x) {
-        const int b = item / slices, sl = item - b * slices;
+    // work item = (utterance, strip of 10 pooled columns, slice of the strip's cells); B counts utterances
+    for (int item = blockIdx.x; item < B * NS * slices; item += gridDim.x) {
+        const int vb = item / slices, sl = item - vb * slices;   // gradient / mask block vb = NS * utterance + strip
+        const int b = NS > 1 ? vb / NS : vb, strip = NS > 1 ? vb - b * NS : 0;
         const int cell0 = (sl * P) / slices, cell1 = ((sl + 1) * P) / slices;
         __syncthreads();
         load_feat_tile(tin, feat, sb, st, sm, b, T, M, tid, C0G_THREADS);
         __syncthreads();
-        const float* gab = ga + ((size_t)b * NMAP + C0G_CPW * wave) * P;      // (uniform bases, 32-bit lane offsets)
-        const float* gbb = gb != nullptr ? gb + ((size_t)b * NMAP + C0G_CPW * wave) * P : nullptr;
-        const unsigned short* mb = mask0 + ((size_t)b * NMAP + C0G_CPW * wave) * P;
+        const float* gab = ga + ((size_t)vb * NMAP + C0G_CPW * wave) * P;      // (uniform bases, 32-bit lane offsets)
+        const float* gbb = gb != nullptr ? gb + ((size_t)vb * NMAP + C0G_CPW * wave) * P : nullptr;
+        const unsigned short* mb = mask0 + ((size_t)vb * NMAP + C0G_CPW * wave) * P;
         for (int cb = cell0; cb < cell1; cb += 64) {
             const int cell = cb + lane;
             const bool valid = cell < cell1;
@@ -1731,7 +1854,7 @@ __global__ __launch_bounds__(C0G_THREADS) void conv0_wgrad_valu_kernel(const flo
             }
             const int ph = (int)cc / PW, pw = (int)cc - ph * PW;
             float x[5][6];
-            load_patch(x, tin, pitch, ph, pw);
+            load_patch(x, tin, pitch, ph, pw + strip * PW);
 #pragma unroll
             for (int j = 0; j < C0G_CPW; ++j) {
                 const int gbits = valid ? __float_as_int(gv[j] * (1.0f / 12.0f)) : 0;
@@ -1771,7 +1894,8 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
                                                        int P, int C, const long long* __restrict__ labels,
                                                        float* __restrict__ nll, float* __restrict__ dlogits,
                                                        float* __restrict__ dpool, float inv_batch,
-                                                       const float* __restrict__ pool, int npg, int npg_used, BnFold fold) {
+                                                       const float* __restrict__ pool, int npg, int npg_used, BnFold fold,
+                                                       int ns /* strips per utterance: pool is [B * ns][npg][48], P counts all of them */) {
     __shared__ float lp[CP];
     __shared__ float ll[HEAD_XC], dl[HEAD_XC], lse_s;
     __shared__ float lst[2 * CP];
@@ -1815,7 +1939,8 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
             // the last convolution left the sums of |s_6| per (utterance, position group, channel): add the groups in order
             if (tid < CP) {
                 float acc = 0.0f;
-                for (int g = 0; g < npg_used; ++g) acc += pool[((size_t)b * npg + g) * CP + tid];
+                for (int sgi = 0; sgi < ns; ++sgi)
+                    for (int g = 0; g < npg_used; ++g) acc += pool[(((size_t)b * ns + sgi) * npg + g) * CP + tid];
                 const float v = tid < NMAP ? (acc / (float)P - lst[tid]) * lst[CP + tid] : 0.0f;
                 lp[tid] = v;
                 pooled[(size_t)b * CP + tid] = v;
@@ -1888,7 +2013,7 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
 __global__ __launch_bounds__(256) void head_fwd_windows_kernel(const float* __restrict__ s6, const float* __restrict__ stats,
                                                                const float* __restrict__ wout, const float* __restrict__ bout,
                                                                float* __restrict__ logits, int B, int nwin, int Hw,
-                                                               HowlWinRows rows, float inv_count, int C) {
+                                                               HowlWinRows rows, float inv_count, int C, int ns) {
     __shared__ float lp[CP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int Pw = Hw * PW;
@@ -1897,9 +2022,9 @@ __global__ __launch_bounds__(256) void head_fwd_windows_kernel(const float* __re
         for (int c = wave; c < CP; c += 4) {
             float acc = 0.0f;
             if (c < NMAP) {
-                for (int w = 0; w < nwin; ++w) {
-                    const float* src = s6 + ((size_t)(b * nwin + w) * NMAP + c) * Pw;
-                    for (int i = rows.lo[w] * PW + lane; i < rows.hi[w] * PW; i += 64) acc += fabsf(src[i]);
+                for (int w = 0; w < nwin * ns; ++w) {      // (window, strip of 10 pooled columns) blocks of clip b
+                    const float* src = s6 + ((size_t)(b * nwin * ns + w) * NMAP + c) * Pw;
+                    for (int i = rows.lo[w / ns] * PW + lane; i < rows.hi[w / ns] * PW; i += 64) acc += fabsf(src[i]);
                 }
             }
             acc = wave_sum(acc);
@@ -2130,6 +2255,10 @@ int conv_grid(int B) {
     int g = howl_num_cus();
     return B < g ? B : g;
 }
+// Mel bins -> strips of 10 pooled columns (see HaloSlot): 40 -> 1, 80 -> 2 (the reference's stock NUM_MELS, settings.py:32)
+int mel_strips(int M) { return M == 40 ? 1 : (M == 80 ? 2 : 0); }
+// a workgroup's utterances b, b + nblk, ... must keep their strip parity on wide maps: an even stride (B = 2 x utterances >= 2)
+int even_grid(int g, int strips) { return strips > 1 ? ((g & ~1) > 2 ? (g & ~1) : 2) : g; }
 // Small batches (the reference's presets train at 16, its engines run at batch 1): how many workgroups share one utterance.
 // Forward / data gradient split the position tiles (4 or 2 ways: every position group of a workgroup keeps at least one
 // tile), the weight gradient its 27 N tiles (2 ways).
@@ -2167,47 +2296,51 @@ void pair_slices(int nblk, int H, int* sd, int* sw) {
 
 // launchers: one instantiation per slicing factor (dynamic LDS limit raised on the instance that is launched)
 StageCfg plain_tile(const float* t) { return StageCfg{t, nullptr, nullptr, nullptr, nullptr, 0.0f, false, false, false}; }
-template <int MODE, int SLICES>
+template <int MODE, int SLICES, bool HALO = false>
 void launch_conv3x3_inst(int nblk, size_t lds, hipStream_t stream, const StageCfg& in, const float* in_stats, const float* wp,
                          const float* res, float* out, const float* xs, const float* xs_stats, float* part, int B, int H,
                          const BnFold& fold, const BwdFold& bfold, float* pool, const WFold& wf) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_mfma_kernel<MODE, SLICES>),
+    hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_mfma_kernel<MODE, SLICES, HALO>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((conv3x3_mfma_kernel<MODE, SLICES>), dim3(launch_blocks(nblk, SLICES)), dim3(CONV_THREADS), lds, stream, with_probe(in),
+    hipLaunchKernelGGL((conv3x3_mfma_kernel<MODE, SLICES, HALO>), dim3(launch_blocks(nblk, SLICES)), dim3(CONV_THREADS), lds, stream, with_probe(in),
                        in_stats, wp, res, out, xs, xs_stats, part, pool, B, H, nblk, fold, bfold, wf);
 }
 template <int MODE>
 void launch_conv3x3(int slices, int nblk, size_t lds, hipStream_t stream, const StageCfg& in, const float* in_stats, const float* wp,
                     const float* res, float* out, const float* xs, const float* xs_stats, float* part, int B, int H,
                     const BnFold& fold, const BwdFold& bfold = BwdFold{}, float* pool = nullptr,
-                    const WFold& wf = WFold{nullptr, 0, nullptr}) {
-    if (slices == 4)
+                    const WFold& wf = WFold{nullptr, 0, nullptr}, bool halo = false) {
+    if (halo)      // strips of a wide map (NUM_MELS = 80): one workgroup per strip, no position slicing
+        launch_conv3x3_inst<MODE, 1, true>(nblk, lds, stream, in, in_stats, wp, res, out, xs, xs_stats, part, B, H, fold, bfold, pool, wf);
+    else if (slices == 4)
         launch_conv3x3_inst<MODE, 4>(nblk, lds, stream, in, in_stats, wp, res, out, xs, xs_stats, part, B, H, fold, bfold, pool, wf);
     else if (slices == 2)
         launch_conv3x3_inst<MODE, 2>(nblk, lds, stream, in, in_stats, wp, res, out, xs, xs_stats, part, B, H, fold, bfold, pool, wf);
     else
         launch_conv3x3_inst<MODE, 1>(nblk, lds, stream, in, in_stats, wp, res, out, xs, xs_stats, part, B, H, fold, bfold, pool, wf);
 }
-template <int SW>
+template <int SW, bool HALO = false>
 void launch_wgrad_inst(int nblk, size_t lds, hipStream_t stream, const StageCfg& zc, const BwdFold& bfold, const float* s_prev,
                        const float* in_stats, float* wpart, int B, int H) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_mfma_kernel<SW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(wgrad_mfma_kernel<SW>, dim3(launch_blocks(nblk, SW)), dim3(CONV_THREADS), lds, stream,
+    hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_mfma_kernel<SW, HALO>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((wgrad_mfma_kernel<SW, HALO>), dim3(launch_blocks(nblk, SW)), dim3(CONV_THREADS), lds, stream,
                        WStage{with_probe(zc), s_prev, false}, in_stats, bfold, wpart, B, H, nblk);
 }
-template <int SD, int SW>
+template <int SD, int SW, bool HALO = false>
 void launch_pair_inst(int nblk, size_t lds, hipStream_t stream, const StageCfg& zc, const BwdFold& bfold, const float* wp, float* dx,
                       const float* xs, const float* xs_stats, float* spart, const float* s_prev, const float* in_stats, float* wpart,
                       int B, int H, const WFold& wf) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(bwd_pair_kernel<SD, SW>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    hipFuncSetAttribute(reinterpret_cast<const void*>(bwd_pair_kernel<SD, SW, HALO>), hipFuncAttributeMaxDynamicSharedMemorySize,
                         (int)lds);
-    hipLaunchKernelGGL((bwd_pair_kernel<SD, SW>), dim3(launch_blocks(nblk, SD + SW)), dim3(CONV_THREADS), lds, stream, with_probe(zc), bfold, wp,
+    hipLaunchKernelGGL((bwd_pair_kernel<SD, SW, HALO>), dim3(launch_blocks(nblk, SD + SW)), dim3(CONV_THREADS), lds, stream, with_probe(zc), bfold, wp,
                        dx, xs, xs_stats, spart, s_prev, in_stats, wpart, B, H, nblk, wf);
 }
 void launch_pair(int sd, int sw, int nblk, size_t lds, hipStream_t stream, const StageCfg& zc, const BwdFold& bfold, const float* wp,
                  float* dx, const float* xs, const float* xs_stats, float* spart, const float* s_prev, const float* in_stats,
-                 float* wpart, int B, int H, const WFold& wf) {
-    if (sd == 4 && sw == 2)
+                 float* wpart, int B, int H, const WFold& wf, bool halo = false) {
+    if (halo)
+        launch_pair_inst<1, 1, true>(nblk, lds, stream, zc, bfold, wp, dx, xs, xs_stats, spart, s_prev, in_stats, wpart, B, H, wf);
+    else if (sd == 4 && sw == 2)
         launch_pair_inst<4, 2>(nblk, lds, stream, zc, bfold, wp, dx, xs, xs_stats, spart, s_prev, in_stats, wpart, B, H, wf);
     else if (sd == 2 && sw == 2)
         launch_pair_inst<2, 2>(nblk, lds, stream, zc, bfold, wp, dx, xs, xs_stats, spart, s_prev, in_stats, wpart, B, H, wf);
@@ -2226,6 +2359,11 @@ size_t howl_res8_workspace_bytes(int B, int T) {
     return ws_layout(nullptr, nullptr, B, H, conv_grid(B));
 }
 
+size_t howl_res8_workspace_bytes_mels(int B, int T, int M) {
+    const int NS = mel_strips(M) > 0 ? mel_strips(M) : 1;
+    return ws_layout(nullptr, nullptr, B * NS, T / 3, even_grid(conv_grid(B * NS), NS));
+}
+
 }  // extern "C"
 
 namespace {
@@ -2236,13 +2374,17 @@ int res8_fwd_impl(const HowlRes8Params* prm, const float* feat, long sb, long st
     HOWL_REQUIRE(prm && feat && sv && logits && ws, "howl_res8_fwd: null pointer");
     HOWL_REQUIRE(labels == nullptr || (nll != nullptr && dlogits != nullptr && C <= HEAD_XC),
                  "howl_res8_fwd_xent: nll / dlogits missing or more than %d classes (C=%d)", HEAD_XC, C);
-    HOWL_REQUIRE(M == 40, "howl_res8_fwd: res8 pools (3,4) over 40 mel bins; got M=%d", M);
+    const int NS = mel_strips(M);
+    HOWL_REQUIRE(NS > 0, "howl_res8_fwd: res8 pools (3,4) over 40 or 80 mel bins; got M=%d", M);
     const int H = T / 3;
     HOWL_REQUIRE(B >= 1 && H >= 1 && H <= MAX_H, "howl_res8_fwd: B=%d T=%d unsupported (3 <= T <= 83)", B, T);
     HOWL_REQUIRE(C >= 1, "howl_res8_fwd: C must be positive");
-    const int G = conv_grid(B);
+    // wide maps: every utterance is NS strips of 10 pooled columns, each a block of the (Bv, 45, H, 10) activations (HaloSlot)
+    const int Bv = B * NS;
+    const bool halo = NS > 1;
+    const int G = even_grid(conv_grid(Bv), NS);
     Ws w;
-    const size_t need = ws_layout(&w, static_cast<char*>(ws), B, H, G);
+    const size_t need = ws_layout(&w, static_cast<char*>(ws), Bv, H, G);
     if (ws_bytes < need) {
         howl_set_error("howl_res8_fwd: workspace %zu < %zu bytes", ws_bytes, need);
         return HOWL_E_WORKSPACE;
@@ -2263,12 +2405,16 @@ int res8_fwd_impl(const HowlRes8Params* prm, const float* feat, long sb, long st
     {
         HowlProfScope prof("conv0_fwd", stream);
         const int npack = (2 * 6 * PACK_ELEMS + C0M_THREADS - 1) / C0M_THREADS;
-        hipLaunchKernelGGL(conv0_fwd_mfma_kernel, dim3(G0 + npack), dim3(C0M_THREADS), l0, stream, feat, sb, st, sm,
-                           prm->conv0_w, sv->s[0], sv->mask0, B, T, M, H, G0, cw, w.wp_fwd, w.wp_bwd, 1, 0, 0, S0);
+        if (halo)
+            hipLaunchKernelGGL(conv0_fwd_mfma_kernel<2>, dim3(G0 + npack), dim3(C0M_THREADS), l0, stream, feat, sb, st, sm,
+                               prm->conv0_w, sv->s[0], sv->mask0, B, T, M, H, G0, cw, w.wp_fwd, w.wp_bwd, 1, 0, 0, S0);
+        else
+            hipLaunchKernelGGL(conv0_fwd_mfma_kernel<1>, dim3(G0 + npack), dim3(C0M_THREADS), l0, stream, feat, sb, st, sm,
+                               prm->conv0_w, sv->s[0], sv->mask0, B, T, M, H, G0, cw, w.wp_fwd, w.wp_bwd, 1, 0, 0, S0);
     }
     const size_t lc = conv_lds_bytes(H);
-    const double count = (double)B * (double)P;
-    const int SL = conv_slices(G, H, howl_num_cus());
+    const double count = (double)Bv * (double)P;
+    const int SL = halo ? 1 : conv_slices(G, H, howl_num_cus());
     // Training: layer i leaves its statistics as per-workgroup partials; layer i+1 folds them in its own prologue (BnFold),
     // so only the last layer needs the stand-alone finalize.  The partial buffers alternate between layers.
     for (int i = 1; i <= 6; ++i) {
@@ -2287,16 +2433,18 @@ int res8_fwd_impl(const HowlRes8Params* prm, const float* feat, long sb, long st
         {
             HowlProfScope prof("conv3x3_fwd", stream);
             launch_conv3x3<0>(SL, G, lc, stream, plain_tile(sv->s[i - 1]), in_stats, w.wp_fwd + (size_t)(i - 1) * 3 * KSTEPS * 64, res, sv->s[i],
-                              nullptr, nullptr, part_out, B, H, fold, BwdFold{}, i == 6 ? w.pool : (float*)nullptr);
+                              nullptr, nullptr, part_out, Bv, H, fold, BwdFold{}, i == 6 ? w.pool : (float*)nullptr,
+                              WFold{nullptr, 0, nullptr}, halo);
         }
     }
     // (training: the head folds BatchNorm 6's statistics itself -- no one-block finalize launch in between)
     const BnFold hfold = training ? BnFold{w.part2, G * SL, count, sv->bn_stats + (size_t)5 * 2 * CP,
                                            HowlBnBuffers{prm->bn_running_mean[5], prm->bn_running_var[5], prm->bn_num_batches[5]}}
                                   : BnFold{};
+    // the spatial mean runs over all NS strips of an utterance: NS * (4 SL) position groups, NS * P positions
     hipLaunchKernelGGL(head_fwd_kernel, dim3(B < 1024 ? B : 1024), dim3(256), 0, stream, sv->s[6],
-                       sv->bn_stats + (size_t)5 * 2 * CP, prm->out_w, prm->out_b, sv->pooled, logits, B, P, C, labels, nll, dlogits,
-                       w.dpool, 1.0f / (float)B, (const float*)w.pool, 4 * SL, 4 * SL < (P + 15) / 16 ? 4 * SL : (P + 15) / 16, hfold);
+                       sv->bn_stats + (size_t)5 * 2 * CP, prm->out_w, prm->out_b, sv->pooled, logits, B, NS * P, C, labels, nll, dlogits,
+                       w.dpool, 1.0f / (float)B, (const float*)w.pool, 4 * SL, 4 * SL < (P + 15) / 16 ? 4 * SL : (P + 15) / 16, hfold, NS);
     HOWL_CHECK_LAUNCH("howl_res8_fwd");
     return HOWL_OK;
 }
@@ -2328,36 +2476,42 @@ constexpr int WIN_H = MAX_H, WIN_MARGIN = 7, WIN_STEP = WIN_H - 2 * WIN_MARGIN; 
 int long_windows(int H) { return H <= WIN_H ? 1 : (H - WIN_H + WIN_STEP - 1) / WIN_STEP + 1; }
 }  // namespace
 
-size_t howl_res8_long_workspace_bytes(int B, int T) {
+size_t howl_res8_long_workspace_bytes(int B, int T) { return howl_res8_long_workspace_bytes_mels(B, T, 40); }
+
+size_t howl_res8_long_workspace_bytes_mels(int B, int T, int M) {
     const int H = T / 3, nw = long_windows(H);
-    const size_t Bv = (size_t)B * nw;
+    const size_t Bv = (size_t)B * nw * (mel_strips(M) > 0 ? mel_strips(M) : 1);
     // three rotating activation maps + eval statistics + the regular workspace of the virtual batch
     static_assert((6 * 2 * CP * sizeof(float)) % 256 == 0, "statistics block keeps the 256-byte alignment");
     return 3 * (((Bv * NMAP * WIN_H * PW * sizeof(float)) + 255) / 256 * 256) + 6 * 2 * CP * sizeof(float) + 256 +
-           howl_res8_workspace_bytes((int)Bv, 3 * WIN_H);
+           ws_layout(nullptr, nullptr, (int)Bv, WIN_H, even_grid(conv_grid((int)Bv), mel_strips(M)));
 }
 
 int howl_res8_fwd_long(const HowlRes8Params* prm, const float* feat, long sb, long st, long sm, int B, int T, int M, int C,
                        float* logits, void* ws, size_t ws_bytes, hipStream_t stream) {
     HOWL_REQUIRE(prm && feat && logits && ws, "howl_res8_fwd_long: null pointer");
-    HOWL_REQUIRE(M == 40, "howl_res8_fwd_long: res8 pools (3,4) over 40 mel bins; got M=%d", M);
+    const int NS = mel_strips(M);
+    HOWL_REQUIRE(NS > 0, "howl_res8_fwd_long: res8 pools (3,4) over 40 or 80 mel bins; got M=%d", M);
     const int H = T / 3;
     HOWL_REQUIRE(B >= 1 && H > WIN_H && C >= 1, "howl_res8_fwd_long: for T > 83 frames (got B=%d T=%d); shorter inputs use howl_res8_fwd", B, T);
     const int nw = long_windows(H);
     HOWL_REQUIRE(nw <= MAX_WINDOWS, "howl_res8_fwd_long: T=%d needs %d windows (max %d)", T, nw, MAX_WINDOWS);
-    if (ws_bytes < howl_res8_long_workspace_bytes(B, T)) {
-        howl_set_error("howl_res8_fwd_long: workspace %zu < %zu bytes", ws_bytes, howl_res8_long_workspace_bytes(B, T));
+    if (ws_bytes < howl_res8_long_workspace_bytes_mels(B, T, M)) {
+        howl_set_error("howl_res8_fwd_long: workspace %zu < %zu bytes", ws_bytes, howl_res8_long_workspace_bytes_mels(B, T, M));
         return HOWL_E_WORKSPACE;
     }
     // T % 3 trailing frames take no part in the pooling but are conv0's neighbours of the clip's last frame: every window
     // reads them too (inner windows simply see real samples there instead of padding, inside their discarded margin)
-    const int Bv = B * nw, Tw = 3 * WIN_H + T % 3, P = WIN_H * PW;
+    // Bw windows, each NS strips of 10 pooled columns (wide maps: HaloSlot): Bv blocks of (45, WIN_H, 10)
+    const int Bw = B * nw, Bv = Bw * NS, Tw = 3 * WIN_H + T % 3, P = WIN_H * PW;
+    const bool halo = NS > 1;
     const size_t act = ((size_t)Bv * NMAP * P * sizeof(float) + 255) / 256 * 256;
     char* base = static_cast<char*>(ws);
     float* buf[3] = {reinterpret_cast<float*>(base), reinterpret_cast<float*>(base + act), reinterpret_cast<float*>(base + 2 * act)};
     float* stats = reinterpret_cast<float*>(base + 3 * act);
     Ws w;
-    ws_layout(&w, base + 3 * act + 6 * 2 * CP * sizeof(float) + 256, Bv, WIN_H, conv_grid(Bv));
+    const int G = even_grid(conv_grid(Bv), NS);
+    ws_layout(&w, base + 3 * act + 6 * 2 * CP * sizeof(float) + 256, Bv, WIN_H, G);
     HowlWinRows rows;
     for (int i = 0; i < nw; ++i) {
         const int a = i * WIN_STEP < H - WIN_H ? i * WIN_STEP : H - WIN_H;          // first pooled row of window i
@@ -2375,14 +2529,18 @@ int howl_res8_fwd_long(const HowlRes8Params* prm, const float* feat, long sb, lo
     }
     hipLaunchKernelGGL(bn_eval_stats_kernel, dim3(6), dim3(64), 0, stream, rm, rv, stats);
     const size_t l0 = conv0_tile_floats(Tw, M) * sizeof(float);
-    const int G0 = Bv < 2 * howl_num_cus() ? Bv : 2 * howl_num_cus();
+    const int G0 = Bw < 2 * howl_num_cus() ? Bw : 2 * howl_num_cus();
     const int npack = (2 * 6 * PACK_ELEMS + C0M_THREADS - 1) / C0M_THREADS;
-    hipLaunchKernelGGL(conv0_fwd_mfma_kernel, dim3(G0 + npack), dim3(C0M_THREADS), l0, stream, feat, sb, st, sm, prm->conv0_w,
-                       buf[0], (unsigned short*)nullptr, Bv, Tw, M, WIN_H, G0, cw, w.wp_fwd, w.wp_bwd, nw, 3 * WIN_STEP,
-                       3 * (H - WIN_H), 1);
+    if (halo)
+        hipLaunchKernelGGL(conv0_fwd_mfma_kernel<2>, dim3(G0 + npack), dim3(C0M_THREADS), l0, stream, feat, sb, st, sm, prm->conv0_w,
+                           buf[0], (unsigned short*)nullptr, Bw, Tw, M, WIN_H, G0, cw, w.wp_fwd, w.wp_bwd, nw, 3 * WIN_STEP,
+                           3 * (H - WIN_H), 1);
+    else
+        hipLaunchKernelGGL(conv0_fwd_mfma_kernel<1>, dim3(G0 + npack), dim3(C0M_THREADS), l0, stream, feat, sb, st, sm, prm->conv0_w,
+                           buf[0], (unsigned short*)nullptr, Bw, Tw, M, WIN_H, G0, cw, w.wp_fwd, w.wp_bwd, nw, 3 * WIN_STEP,
+                           3 * (H - WIN_H), 1);
     const size_t lc = conv_lds_bytes(WIN_H);
-    const int G = conv_grid(Bv);
-    const int SL = conv_slices(G, WIN_H, howl_num_cus());
+    const int SL = halo ? 1 : conv_slices(G, WIN_H, howl_num_cus());
     // x_i lives in buf[cur]; even layers add the map two layers back (kept in buf[skip])
     int cur = 0, skip = 0;
     for (int i = 1; i <= 6; ++i) {
@@ -2391,13 +2549,13 @@ int howl_res8_fwd_long(const HowlRes8Params* prm, const float* feat, long sb, lo
         while (out == cur || out == skip) ++out;
         launch_conv3x3<0>(SL, G, lc, stream, plain_tile(buf[cur]), i == 1 ? (const float*)nullptr : (const float*)(stats + (size_t)(i - 2) * 2 * CP),
                           w.wp_fwd + (size_t)(i - 1) * 3 * KSTEPS * 64, even ? (const float*)buf[skip] : (const float*)nullptr, buf[out],
-                          nullptr, nullptr, nullptr, Bv, WIN_H, BnFold{});
+                          nullptr, nullptr, nullptr, Bv, WIN_H, BnFold{}, BwdFold{}, nullptr, WFold{nullptr, 0, nullptr}, halo);
         if (even) skip = out;      // s_i (i even) is the next residual source; s_0 is the first one
         cur = out;
     }
     hipLaunchKernelGGL(head_fwd_windows_kernel, dim3(B < 1024 ? B : 1024), dim3(256), 0, stream, (const float*)buf[cur],
                        (const float*)(stats + (size_t)5 * 2 * CP), prm->out_w, prm->out_b, logits, B, nw, WIN_H, rows,
-                       1.0f / ((float)H * PW), C);
+                       1.0f / ((float)H * PW * NS), C, NS);
     HOWL_CHECK_LAUNCH("howl_res8_fwd_long");
     return HOWL_OK;
 }
@@ -2419,19 +2577,22 @@ int res8_bwd_impl(const HowlRes8Params* prm, const float* feat, long sb, long st
                  "howl_res8_bwd: HowlAdamW needs the whole pass (part 0) and complete buffers");
     HOWL_REQUIRE(part >= 0 && part <= 2, "howl_res8_bwd_part: part must be 0 (all), 1 or 2");
     const bool run_layers = part != 2, run_conv0 = part != 1;
-    HOWL_REQUIRE(M == 40, "howl_res8_bwd: M must be 40");
+    const int NS = mel_strips(M);
+    HOWL_REQUIRE(NS > 0, "howl_res8_bwd: M must be 40 or 80 (got %d)", M);
     const int H = T / 3;
     HOWL_REQUIRE(B >= 1 && H >= 1 && H <= MAX_H, "howl_res8_bwd: B=%d T=%d unsupported", B, T);
-    const int G = conv_grid(B);
+    const int Bv = B * NS;        // strips of 10 pooled columns, each a block of the activations (HaloSlot)
+    const bool halo = NS > 1;
+    const int G = even_grid(conv_grid(Bv), NS);
     Ws w;
-    const size_t need = ws_layout(&w, static_cast<char*>(ws), B, H, G);
+    const size_t need = ws_layout(&w, static_cast<char*>(ws), Bv, H, G);
     if (ws_bytes < need) {
         howl_set_error("howl_res8_bwd: workspace %zu < %zu bytes", ws_bytes, need);
         return HOWL_E_WORKSPACE;
     }
     const int P = H * PW;
-    const double count = (double)B * (double)P;
-    const size_t act = (size_t)B * NMAP * P;
+    const double count = (double)Bv * (double)P;
+    const size_t act = (size_t)Bv * NMAP * P;
     HOWL_REQUIRE(act / 2 < (size_t)1 << 31, "howl_res8_bwd: B=%d too large for the 32-bit element index of the elementwise pass", B);
     int eg = (int)((act / 4 + BRB_THREADS - 1) / BRB_THREADS);      // one 16-byte quad per thread and trip
     if (eg < 1) eg = 1;
@@ -2442,7 +2603,7 @@ int res8_bwd_impl(const HowlRes8Params* prm, const float* feat, long sb, long st
             hipLaunchKernelGGL(head_bwd_pool_kernel, dim3((B * CP + 255) / 256), dim3(256), 0, stream, dlogits, prm->out_w, w.dpool,
                                B, C);
         hipLaunchKernelGGL(head_bwd_param_kernel, dim3(C + (nll != nullptr ? 2 : 1)), dim3(1024), 0, stream, dlogits, sv->pooled,
-                           w.dpool, gr->out_w, gr->out_b, w.m12, B, C, P, nll, loss);
+                           w.dpool, gr->out_w, gr->out_b, w.m12, B, C, NS * P, nll, loss);
     }
     const size_t lc = conv_lds_bytes(H);
     const size_t lw = wgrad_lds_bytes(H);
@@ -2452,13 +2613,13 @@ int res8_bwd_impl(const HowlRes8Params* prm, const float* feat, long sb, long st
     // HOWL_RES8_BWD_FUSED=0: the elementwise BatchNorm / ReLU backward as its own launch per layer (bn_relu_bwd_kernel writes
     // dz_i, the pair stages it as it is) -- the reference point of the tests; default: built inside the pair's staging
     const char* fused_env = getenv("HOWL_RES8_BWD_FUSED");
-    const bool fused = !(fused_env != nullptr && fused_env[0] == '0');
+    const bool fused = halo || !(fused_env != nullptr && fused_env[0] == '0');   // (wide maps: the fused staging only)
     // dgrad and wgrad side by side: half the CUs each
     const int half = howl_num_cus() / 2 > 0 ? howl_num_cus() / 2 : 1;
-    const int Gh = B < half ? B : half;
+    const int Gh = even_grid(Bv < half ? Bv : half, NS);
     const size_t wpart_stride = (size_t)Gh * CP * WNCOL;
     int SD = 1, SW = 1;
-    pair_slices(Gh, H, &SD, &SW);
+    if (!halo) pair_slices(Gh, H, &SD, &SW);
     // the fold of a layer's weight-gradient partials rides in the NEXT pair launch when that launch has enough data-gradient
     // workgroups to spread the 9,984 column pairs thin (a single utterance's four workgroups would walk 26 trips of two barriers
     // each: +60 us at batch 1); small batches keep the one reduction launch at the end
@@ -2480,8 +2641,8 @@ int res8_bwd_impl(const HowlRes8Params* prm, const float* feat, long sb, long st
         const BwdFold bfold{stats_i, w.m12, i == 6 ? (const float*)nullptr : (const float*)part_in, Gh * SD, count};
         StageCfg zc = plain_tile(dz);
         if (fused)
-            zc = StageCfg{dx_cur, sv->s[i], even ? (const float*)ds_prev : (const float*)nullptr, ds_out, w.dpool, 1.0f / (float)P,
-                          true, even, false};
+            zc = StageCfg{dx_cur, sv->s[i], even ? (const float*)ds_prev : (const float*)nullptr, ds_out, w.dpool,
+                          1.0f / (float)(NS * P), true, even, false};
         else if (run_layers)
             hipLaunchKernelGGL(bn_relu_bwd_kernel, dim3(eg), dim3(BRB_THREADS), 0, stream, (const float*)dx_cur, w.dpool, sv->s[i],
                                stats_i, w.m12, bfold.part, Gh * SD, count, even ? (const float*)ds_prev : (const float*)nullptr,
@@ -2508,16 +2669,18 @@ int res8_bwd_impl(const HowlRes8Params* prm, const float* feat, long sb, long st
             // part 2 only replays the buffer rotation of the loop
         } else if (merged) {
             HowlProfScope prof("bwd_pair", stream);
-            launch_pair(SD, SW, Gh, lp, stream, zc, bfold, wpb, dx_next, xs, xs_st, spart, sv->s[i - 1], in_stats, wpart, B, H, wf);
+            launch_pair(SD, SW, Gh, lp, stream, zc, bfold, wpb, dx_next, xs, xs_st, spart, sv->s[i - 1], in_stats, wpart, Bv, H, wf, halo);
         } else {
             {
                 HowlProfScope prof("conv3x3_dgrad", stream);
-                launch_conv3x3<1>(SD, Gh, lc, stream, zc, nullptr, wpb, nullptr, dx_next, xs, xs_st, spart, B, H, BnFold{}, bfold, nullptr, wf);
+                launch_conv3x3<1>(SD, Gh, lc, stream, zc, nullptr, wpb, nullptr, dx_next, xs, xs_st, spart, Bv, H, BnFold{}, bfold, nullptr, wf, halo);
             }
             HowlProfScope prof("wgrad", stream);
             StageCfg zw = zc;
             zw.ds = nullptr;
-            if (SW == 2)
+            if (halo)
+                launch_wgrad_inst<1, true>(Gh, lw, stream, zw, bfold, sv->s[i - 1], in_stats, wpart, Bv, H);
+            else if (SW == 2)
                 launch_wgrad_inst<2>(Gh, lw, stream, zw, bfold, sv->s[i - 1], in_stats, wpart, B, H);
             else
                 launch_wgrad_inst<1>(Gh, lw, stream, zw, bfold, sv->s[i - 1], in_stats, wpart, B, H);
@@ -2529,8 +2692,8 @@ int res8_bwd_impl(const HowlRes8Params* prm, const float* feat, long sb, long st
     HOWL_REQUIRE(sv->mask0 != nullptr, "howl_res8_bwd: saved->mask0 is required");
     HowlPtrs6 gw;
     for (int i = 0; i < 6; ++i) gw.p[i] = gr->conv_w[i];
-    const int S0 = conv0_slices(B);
-    const int G0w = B * S0 < howl_num_cus() ? B * S0 : howl_num_cus();   // conv0's weight-gradient grid: one partial row each
+    const int S0 = conv0_slices(Bv);
+    const int G0w = Bv * S0 < howl_num_cus() ? Bv * S0 : howl_num_cus();   // conv0's weight-gradient grid: one partial row each
     // layers 2..6 were folded inside the pair launches (WFold); layer 1's partials and conv0's remain
     const RowsAdamW no_opt{nullptr, nullptr, nullptr, nullptr, HowlAdamWCoef{}, 0, 0, 0};
     if (part == 1)      // the six layers' weight gradients are final before conv0's is even started
@@ -2540,9 +2703,13 @@ int res8_bwd_impl(const HowlRes8Params* prm, const float* feat, long sb, long st
     if (run_conv0) {
         {
         HowlProfScope prof("conv0_wgrad", stream);
-        hipLaunchKernelGGL(conv0_wgrad_valu_kernel, dim3(G0w), dim3(C0G_THREADS), ((size_t)(T + 2) * (M + 4) + 16) * sizeof(float),
-                           stream, feat, sb, st, sm, (const unsigned short*)sv->mask0, (const float*)dx_cur,
-                           (const float*)nullptr, w.c0part, B, T, M, H, S0);
+        const size_t l0w = ((size_t)(T + 2) * (M + 4) + 16) * sizeof(float);
+        if (halo)
+            hipLaunchKernelGGL(conv0_wgrad_valu_kernel<2>, dim3(G0w), dim3(C0G_THREADS), l0w, stream, feat, sb, st, sm,
+                               (const unsigned short*)sv->mask0, (const float*)dx_cur, (const float*)nullptr, w.c0part, B, T, M, H, S0);
+        else
+            hipLaunchKernelGGL(conv0_wgrad_valu_kernel<1>, dim3(G0w), dim3(C0G_THREADS), l0w, stream, feat, sb, st, sm,
+                               (const unsigned short*)sv->mask0, (const float*)dx_cur, (const float*)nullptr, w.c0part, B, T, M, H, S0);
         }
         if (part == 0) {    // rows {layer 1, conv0} of the reduction (small batches: all six layers and conv0)
             // ... and, on a single replica, the optimiser step (HowlAdamW): folded rows are updated as they are written, one more

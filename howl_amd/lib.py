@@ -129,7 +129,8 @@ SIGNATURES = {
     "howl_mobilenet_bwd": [P, c_int, P, c_long, c_long, c_long, c_int, c_int, c_int, P, c_float, P, P, P, c_size_t, STREAM],
 }
 # entry points that do not return an int status
-SIZE_FUNCS = {"howl_res8_workspace_bytes": [c_int, c_int], "howl_res8_long_workspace_bytes": [c_int, c_int], "howl_lstm_workspace_bytes": [c_int, c_int],
+SIZE_FUNCS = {"howl_res8_workspace_bytes": [c_int, c_int], "howl_res8_long_workspace_bytes": [c_int, c_int],
+              "howl_res8_workspace_bytes_mels": [c_int, c_int, c_int], "howl_res8_long_workspace_bytes_mels": [c_int, c_int, c_int], "howl_lstm_workspace_bytes": [c_int, c_int],
               "howl_lstm_needs_gx": [POINTER(HowlLstmParams), c_int, c_int, c_int, c_int],
               "howl_head_workspace_bytes": [c_int, c_int, c_int],
               "howl_mobilenet_num_layers": [],

@@ -155,15 +155,20 @@ typedef struct {
 
 /* activations the backward pass needs; all caller-allocated */
 typedef struct {
-    float* s[7];       /* s[0] = avgpool(relu(conv0(x))); s[i] = layer i's pre-BatchNorm output; each (B,45,T/3,10).
+    float* s[7];       /* s[0] = avgpool(relu(conv0(x))); s[i] = layer i's pre-BatchNorm output; each (B,45,T/3,M/4) floats.
                         * Values are >= 0 by construction; for i = 2,4,6 the sign bit carries the ReLU mask of conv_i
-                        * (the backward needs it), so readers take |s|. */
+                        * (the backward needs it), so readers take |s|.  M = 40: the reference's NCHW layout; M = 80: the
+                        * library's own -- utterance b is the two blocks 2b, 2b+1 of (45,T/3,10): pooled columns 0..9, 10..19. */
     float* bn_stats;   /* (6, 2, 48): per layer {mean[48], rstd[48]} used by this forward */
     float* pooled;     /* (B, 48): spatial mean of BN6's output */
-    unsigned short* mask0; /* (B,45,T/3,10) uint16: ReLU pattern of conv0's 3x4 pre-pool window (bit 4i+j); NULL in eval */
+    unsigned short* mask0; /* (B,45,T/3,M/4) uint16, laid out like s[0]: ReLU pattern of conv0's 3x4 pre-pool window (bit 4i+j); NULL in eval */
 } HowlRes8Saved;
 
+/* M = NUM_MELS (howl/settings.py:32): 40 (every res8 preset, envs/res8.env) or 80 (the stock default).  The 3x3 kernels keep
+ * 10 pooled columns of one utterance on chip; at 80 bins an utterance runs as two such strips that fetch each other's edge
+ * column.  howl_res8_workspace_bytes(B, T) is the M = 40 size. */
 size_t howl_res8_workspace_bytes(int B, int T);
+size_t howl_res8_workspace_bytes_mels(int B, int T, int M);
 
 /* feat: log-mel features, element (b, t, m) at feat[b*sb + t*st + m*sm] (so both the (B,T,M) model layout and
  * channel 0 of the reference's (B,3,M,T) tensor are accepted; replaces x[:, :1].permute(0,1,3,2), cnn.py:128-129).
@@ -178,7 +183,8 @@ int howl_res8_fwd(const HowlRes8Params* prm, const float* feat, long sb, long st
  * rows inwards), the windows run as a virtual batch and only the final spatial mean sees them together.  Same arguments
  * as howl_res8_fwd without `training` (running statistics are used) and without saved activations; results equal
  * cnn.py:127-145 on the whole clip (ConvertedStaticModel's first window, base.py:52-62, and engine clips > 1 s). */
-size_t howl_res8_long_workspace_bytes(int B, int T);
+size_t howl_res8_long_workspace_bytes(int B, int T);          /* M = 40 */
+size_t howl_res8_long_workspace_bytes_mels(int B, int T, int M);
 int howl_res8_fwd_long(const HowlRes8Params* prm, const float* feat, long sb, long st, long sm, int B, int T, int M, int C,
                        float* logits, void* ws, size_t ws_bytes, hipStream_t stream);
 

@@ -19,10 +19,10 @@ def lib():
 class Res8Harness:
     """Owns numpy buffers for params / saved activations / grads and fills the C structs."""
 
-    def __init__(self, lib, B, T, C, sd=None):
+    def __init__(self, lib, B, T, C, sd=None, M=40):
         self.lib, self.B, self.T, self.C = lib, B, T, C
         self.H = T // 3
-        P = self.H * 10
+        W = M // 4      # pooled columns (80 mel bins: the library's own two-strip layout inside the same number of floats)
         self.sd = sd or om.res8_init(C)
         self.np = {k: np.ascontiguousarray(v.numpy()) for k, v in self.sd.items()}
         self.prm = HowlRes8Params()
@@ -34,7 +34,7 @@ class Res8Harness:
             self.prm.bn_num_batches[i] = ptr(self.np[f"bn{i+1}.num_batches_tracked"]).value
         self.prm.out_w = ptr(self.np["output.weight"])
         self.prm.out_b = ptr(self.np["output.bias"])
-        self.s = [np.full((B, 45, self.H, 10), np.nan, np.float32) for _ in range(7)]
+        self.s = [np.full((B, 45, self.H, W), np.nan, np.float32) for _ in range(7)]
         self.bn_stats = np.zeros((6, 2, 48), np.float32)
         self.pooled = np.zeros((B, 48), np.float32)
         self.saved = HowlRes8Saved()
@@ -42,7 +42,7 @@ class Res8Harness:
             self.saved.s[i] = ptr(self.s[i]).value
         self.saved.bn_stats = ptr(self.bn_stats)
         self.saved.pooled = ptr(self.pooled)
-        self.mask0 = np.zeros((B, 45, self.H, 10), np.uint16)
+        self.mask0 = np.zeros((B, 45, self.H, W), np.uint16)
         self.saved.mask0 = ptr(self.mask0)
         self.grads_np = {k: np.full_like(self.np[k], np.nan) for k in om.res8_param_names()}
         self.gr = HowlRes8Grads()
@@ -51,7 +51,8 @@ class Res8Harness:
             self.gr.conv_w[i] = ptr(self.grads_np[f"conv{i+1}.weight"]).value
         self.gr.out_w = ptr(self.grads_np["output.weight"])
         self.gr.out_b = ptr(self.grads_np["output.bias"])
-        nbytes = lib.cdll.howl_res8_workspace_bytes(B, T)
+        nbytes = lib.cdll.howl_res8_workspace_bytes_mels(B, T, M)
+        assert M != 40 or nbytes == lib.cdll.howl_res8_workspace_bytes(B, T)
         self.ws = np.zeros(nbytes, np.uint8)
         self.logits = np.zeros((B, C), np.float32)
 
@@ -72,9 +73,9 @@ class Res8Harness:
         return {k: v.copy() for k, v in self.grads_np.items()}
 
 
-def feats(B, T, seed):
+def feats(B, T, seed, M=40):
     rng = np.random.default_rng(seed)
-    x = rng.standard_normal((B, 3, 40, T)).astype(np.float32)
+    x = rng.standard_normal((B, 3, M, T)).astype(np.float32)
     return torch.from_numpy(x)
 
 
@@ -125,6 +126,80 @@ def test_res8_train_step(lib, B, T, C):
     for n, gref in zip(names, grads_ref):
         scale = max(1.0, float(gref.abs().max()))
         np.testing.assert_allclose(grads[n], gref.numpy(), rtol=0, atol=2e-5 * scale, err_msg=n)
+
+
+def _wide_step(lib, B, T, C, seed):
+    """One training step at 80 mel bins on the emulator and on the oracle: (harness, logits, grads, oracle logits, oracle grads)."""
+    x = feats(B, T, seed, M=80)
+    labels = torch.arange(B) % C
+    h = Res8Harness(lib, B, T, C, M=80)
+    sd = om.res8_init(C)
+    logits = h.fwd(x[:, 0].permute(0, 2, 1).numpy(), training=True)
+    names = om.res8_param_names()
+    params = {n: sd[n].clone().requires_grad_(True) for n in names}
+    sd_ref = dict(sd)
+    sd_ref.update(params)
+    ref_logits = om.res8_forward(sd_ref, x, True)
+    loss, dlogits = np.zeros(1, np.float32), np.zeros((B, C), np.float32)
+    lab = np.ascontiguousarray(labels.numpy(), np.int64)
+    lib.call("howl_xent_fwd_bwd", ptr(h.logits), ptr(lab), B, C, ptr(loss), ptr(dlogits), None)
+    grads = h.bwd(dlogits)
+    gref = torch.autograd.grad(torch.nn.functional.cross_entropy(ref_logits, labels), [params[n] for n in names])
+    return h, sd_ref, logits, grads, ref_logits.detach().numpy(), dict(zip(names, gref))
+
+
+@pytest.mark.parametrize("B,T,C", [(2, 81, 12), (1, 20, 4)])
+def test_res8_at_80_mel_bins_train_step(lib, B, T, C):
+    """NUM_MELS = 80 (the reference's stock default, settings.py:32; cnn.py:113-145 pools (3,4) over any width): 20 pooled columns
+    run as two strips of 10 that fetch each other's edge column in all three 3x3 roles (csrc/res8.hip HaloSlot).  Logits,
+    BatchNorm buffers and every gradient against the oracle; odd batches and a grid of one strip pair included."""
+    h, sd_ref, logits, grads, ref_logits, gref = _wide_step(lib, B, T, C, seed=21)
+    np.testing.assert_allclose(logits, ref_logits, rtol=0, atol=2e-5)
+    for i in (1, 3, 6):
+        np.testing.assert_allclose(h.np[f"bn{i}.running_mean"], sd_ref[f"bn{i}.running_mean"].numpy(), atol=1e-6)
+        np.testing.assert_allclose(h.np[f"bn{i}.running_var"], sd_ref[f"bn{i}.running_var"].numpy(), atol=1e-6)
+    for n, g in gref.items():
+        scale = max(1.0, float(g.abs().max()))
+        np.testing.assert_allclose(grads[n], g.numpy(), rtol=0, atol=2e-5 * scale, err_msg=n)
+
+
+@pytest.mark.parametrize("B,T", [(2, 81), (1, 41)])
+def test_res8_at_80_mel_bins_eval_forward(lib, B, T):
+    C = 12
+    x = feats(B, T, 4, M=80)
+    sd = om.res8_init(C)
+    for i in range(1, 7):
+        sd[f"bn{i}.running_mean"] = 0.1 * torch.arange(45, dtype=torch.float32).sin()
+        sd[f"bn{i}.running_var"] = 0.5 + 0.3 * torch.arange(45, dtype=torch.float32).cos() ** 2
+    h = Res8Harness(lib, B, T, C, sd={k: v.clone() for k, v in sd.items()}, M=80)
+    out = h.fwd(x[:, 0].permute(0, 2, 1).numpy(), training=False)
+    ref = om.res8_forward(sd, x, False).numpy()
+    np.testing.assert_allclose(out, ref, rtol=0, atol=2e-5)
+    # the strided (B, M, T) view of the frontend's output gives the same bits
+    g = np.ascontiguousarray(x[:, 0].numpy())
+    out2 = np.full_like(out, np.nan)
+    lib.call("howl_res8_fwd", ctypes.byref(h.prm), ptr(g), 80 * T, 1, T, B, T, 80, C, 0, ctypes.byref(h.saved), ptr(out2), ptr(h.ws),
+             h.ws.size, None)
+    np.testing.assert_array_equal(out2, out)
+
+
+def test_res8_at_80_mel_bins_long_input(lib):
+    """howl_res8_fwd_long at 80 mel bins: windows of 27 pooled rows x two strips each."""
+    B, T, C = 1, 120, 12
+    sd = om.res8_init(C)
+    rng = np.random.default_rng(9)
+    for i in range(1, 7):
+        sd[f"bn{i}.running_mean"] = torch.from_numpy(rng.uniform(0.1, 0.6, 45).astype(np.float32))
+        sd[f"bn{i}.running_var"] = torch.from_numpy(rng.uniform(0.5, 2.0, 45).astype(np.float32))
+    h = Res8Harness(lib, 1, 81, C, sd=sd)
+    x = feats(B, T, seed=10, M=80)
+    ref = om.res8_forward({k: v.clone() for k, v in sd.items()}, x, False).numpy()
+    f = np.ascontiguousarray(x[:, 0].permute(0, 2, 1).numpy())
+    ws = np.zeros(lib.cdll.howl_res8_long_workspace_bytes_mels(B, T, 80), np.uint8)
+    logits = np.full((B, C), np.nan, np.float32)
+    lib.call("howl_res8_fwd_long", ctypes.byref(h.prm), ptr(f), T * 80, 80, 1, B, T, 80, C, ptr(logits), ptr(ws), ws.size, None)
+    np.testing.assert_allclose(logits, ref, rtol=0, atol=1e-4 * max(1.0, float(np.abs(ref).max())))
+
 
 
 def test_adamw(lib):
@@ -360,6 +435,14 @@ for B, Tf, C in ((5, 41, 4), (3, 62, 5), (2, 81, 12)):
         errs["oracle." + n] = max(float(np.abs(res[f][1][n] - g.numpy()).max()) for f in ("1", "0")) / scale
         errs["fused_vs_unfused." + n] = float(np.abs(res["1"][1][n] - res["0"][1][n]).max()) / scale
     out["%%d_%%d" %% (B, Tf)] = errs
+# 80 mel bins (two strips per utterance, HaloSlot): five utterances = ten strips over a grid of two workgroups, so that every
+# workgroup stages a NEXT strip's halo column under its K loop (forward, and both roles of the backward pair with grid 2)
+os.environ.pop("HOWL_RES8_BWD_FUSED", None)
+h, sd_ref, logits, grads, ref_logits, gref = T._wide_step(lib, 5, 41, 4, seed=8)
+errs = {"logits": float(np.abs(logits - ref_logits).max())}
+for n, g in gref.items():
+    errs["oracle." + n] = float(np.abs(grads[n] - g.numpy()).max()) / max(1.0, float(g.abs().max()))
+out["wide_5_41"] = errs
 print("RESULT" + json.dumps(out))
 """ % (str(Path(__file__).resolve().parent.parent), str(Path(__file__).resolve().parent))
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, HIPEMU_CUS="2"), capture_output=True, text=True, timeout=2400)
