@@ -57,8 +57,9 @@ from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
-os.environ.setdefault("NUM_MELS", "40")
+os.environ.setdefault("NUM_MELS", "40")       # BASELINE.json's configurations; NUM_MELS=80 (stock Howl's default) runs too
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+MELS = int(os.environ["NUM_MELS"])
 
 FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
@@ -173,7 +174,7 @@ def cpu_baseline(model_name, L, C, budget_s, bench_batch=None):
     from howl_amd.utils.synth import synthetic_pcm
     B = 64 if model_name != "mobilenet" else 32
     pcm = synthetic_pcm(B, L)
-    fb = ofe.mel_fb(40)
+    fb = ofe.mel_fb(MELS)
     z = ofe.Zmuv()
     z.update(ofe.standard_audio_transform(pcm[:2], fb))
     if model_name == "res8":
@@ -272,7 +273,7 @@ def eval_agreement(model_name, model, std, zmuv, pcm_dev, C, n=64):
     z = ofe.Zmuv()
     z.total, z.mean, z.mean2 = (t.detach().cpu() for t in (zmuv.total, zmuv.mean, zmuv.mean2))
     with torch.no_grad():
-        ref = om.res8_forward(sd, z(ofe.standard_audio_transform(pcm_dev[:n].cpu(), ofe.mel_fb(40))), False)
+        ref = om.res8_forward(sd, z(ofe.standard_audio_transform(pcm_dev[:n].cpu(), ofe.mel_fb(MELS))), False)
     return {"utterances": n, "argmax_match": bool(torch.equal(got.argmax(1), ref.argmax(1))),
             "argmax_agreement": round((got.argmax(1) == ref.argmax(1)).float().mean().item(), 4),
             "max_abs_logit_diff": float(f"{(got - ref).abs().max().item():.3e}"), "tolerance": 1e-3,
@@ -310,7 +311,7 @@ def cpu_entry_baseline(L, C, B, budget_s):
     Bc = min(B, 64)
     bank = synthetic_pcm(4 * Bc, L, seed=5)
     labels_all = [(i % 64) % C for i in range(4 * Bc)]
-    rand, fb_std = random.Random(0), ofe.mel_fb(40)
+    rand, fb_std = random.Random(0), ofe.mel_fb(MELS)
     z = ofe.Zmuv()
     z.update(ofe.standard_audio_transform(bank[:2], fb_std))
     sd, names = om.res8_init(C), om.res8_param_names()
@@ -324,7 +325,7 @@ def cpu_entry_baseline(L, C, B, budget_s):
         ids = perm[(k % 4) * Bc:(k % 4 + 1) * Bc]
         clips = oc.noise(rand, oc.timeshift(rand, oc.truncate_length([bank[i] for i in ids], L)))
         audio, lab, _, _ = oc.batchify(clips, [labels_all[i] for i in ids])
-        fb = ofe.mel_fb(40, alpha=rand.random() * 0.2 + 0.9) if rand.random() < 0.75 else fb_std
+        fb = ofe.mel_fb(MELS, alpha=rand.random() * 0.2 + 0.9) if rand.random() < 0.75 else fb_std
         om.train_step(lambda s, xx: om.res8_forward(s, xx, True), sd, names, opt, z(ofe.standard_audio_transform(audio, fb)), lab)
 
     step(0)
@@ -445,7 +446,7 @@ def bench_entry(args, dev, rank, world):
         res_ms = ms(results["resident"])
         out = {
             "metric": f"utterances/sec/node (res8 entry-point loop: device collate + train-mode frontend + training step, "
-                      f"{L / 16000:g}s@16kHz, 40-mel)",
+                      f"{L / 16000:g}s@16kHz, {MELS}-mel)",
             "value": round(seen * world / dt, 1), "unit": "utterances/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -733,7 +734,7 @@ def main():
 
         T = 1 + L // 200
         tl, nl, _ = read("logmel")
-        fe_bytes = (4.0 * L + 4.0 * 40 * T) * B
+        fe_bytes = (4.0 * L + 4.0 * MELS * T) * B
         logmel = {"avg_launch_ms": round(tl / max(nl, 1), 4),
                   "hbm_gbs": round(fe_bytes / (tl / max(nl, 1) * 1e-3) / 1e9, 1) if tl > 0 else None,
                   "hbm_frac": round(fe_bytes / (tl / max(nl, 1) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if tl > 0 else None,
@@ -744,7 +745,7 @@ def main():
             t0f, n0f, _ = read("conv0_fwd")
             t0w, n0w, _ = read("conv0_wgrad")
             H = T // 3
-            flops_launch = 2.0 * 9 * 45 * 45 * (H * 10) * B
+            flops_launch = 2.0 * 9 * 45 * 45 * (H * (MELS // 4)) * B
             # the forward launches run alone on the device; dgrad and wgrad of a layer share ONE launch (half the CUs
             # each): its duration covers both and is listed under other_kernels
             fwd_ms = tf / max(nf, 1)
@@ -754,7 +755,7 @@ def main():
             full = B == 512 and L == 16000
             traffic, traffic_src = pmc_traffic("bwd_pair_kernel") if full else (None, None)
             fwd_traffic, _ = pmc_traffic("conv3x3_mfma_kernel<0") if full else (None, None)
-            act = 4.0 * 45 * (H * 10) * B      # one (B, 45, H, 10) fp32 map
+            act = 4.0 * 45 * (H * (MELS // 4)) * B      # one (B, 45, H, M/4) fp32 map
             roof = {"bound": "mfma",
                     "kernel": "bwd_pair_kernel (data gradient + weight gradient of one 45->45 3x3 layer in ONE launch, half of "
                               "the CUs each, the BatchNorm / ReLU backward built inside both roles' tile staging): the "
@@ -777,7 +778,7 @@ def main():
                             "traffic": None if fwd_traffic is None else round(fwd_traffic)},
                         "conv0 (1->45 3x3 + ReLU + AvgPool(3,4): forward / weight gradient launches)": {
                             "fwd_avg_launch_ms": round(t0f / max(n0f, 1), 4), "wgrad_avg_launch_ms": round(t0w / max(n0w, 1), 4),
-                            "algorithmic_flops_each": round(2.0 * 9 * 45 * (3 * H) * 40 * B)},
+                            "algorithmic_flops_each": round(2.0 * 9 * 45 * (3 * H) * MELS * B)},
                         "logmel": logmel}}
         elif model_name == "seq-lstm":
             parts = {t: read(t) for t in ("lstm_fwd", "lstm_bwd", "gemm")}
@@ -826,7 +827,7 @@ def main():
         step_desc = {"res8": "frontend+fwd+xent+bwd+AdamW", "seq-lstm": "frontend+LSTM+head+CTC+bwd+AdamW",
                      "mobilenet": "device collate (timeshift+noise)+frontend+fwd+xent+bwd+AdamW"}[model_name]
         out = {
-            "metric": f"utterances/sec/node ({model_name} end-to-end training step, {L / 16000:g}s@16kHz, 40-mel)",
+            "metric": f"utterances/sec/node ({model_name} end-to-end training step, {L / 16000:g}s@16kHz, {MELS}-mel)",
             "value": round(total_utts / dt, 1), "unit": "utterances/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",

@@ -39,16 +39,16 @@ template <int NWAVES, int NGRP>
 __global__ __launch_bounds__(NWAVES * 64) void logmel_kernel(const float* __restrict__ pcm, int L, long ld, int T,
                                                              int total_frames, const float* __restrict__ fbp, int M,
                                                              float log_eps, const float* __restrict__ zmuv,
-                                                             float* __restrict__ out, int layout, int n_quads, int aligned) {
-    logmel_body<NWAVES, NGRP>(pcm, L, ld, T, total_frames, fbp, M, log_eps, zmuv, out, layout, n_quads, aligned, blockIdx.x, gridDim.x);
+                                                             float* __restrict__ out, int layout, int n_quads, int aligned, int Mo) {
+    logmel_body<NWAVES, NGRP>(pcm, L, ld, T, total_frames, fbp, M, log_eps, zmuv, out, layout, n_quads, aligned, blockIdx.x, gridDim.x, Mo);
 }
 
-// fb (257, M) row-major -> fbp (260, NCOL) zero padded
-__global__ void fb_pack_kernel(const float* __restrict__ fb, int M, float* __restrict__ fbp, int ncol) {
+// columns [m0, m0 + Mb) of fb (257, M) row-major -> fbp (260, NCOL) zero padded
+__global__ void fb_pack_kernel(const float* __restrict__ fb, int M, float* __restrict__ fbp, int ncol, int m0, int Mb) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= K_PAD * ncol) return;
     const int k = idx / ncol, m = idx - k * ncol;
-    fbp[idx] = (k < N_FREQ && m < M) ? fb[k * M + m] : 0.0f;
+    fbp[idx] = (k < N_FREQ && m < Mb) ? fb[k * M + m0 + m] : 0.0f;
 }
 
 // Second half of a filterbank build (same stream, after the row-major part is written): the fragment-ordered copies read by
@@ -82,18 +82,20 @@ __global__ __launch_bounds__(1024) void fb_fragments_kernel(float* __restrict__ 
 
 // triangles from M+2 corner frequencies (already VTLP-warped on the host: 42 scalars), exactly the
 // slope arithmetic of transform.py:402-409; all_freqs = linspace(0, sr/2, 257) = k * (sr/2) / 256.
-__device__ __forceinline__ float fb_triangle(const HowlMelPoints& pts, int M, float nyquist, int k, int m) {
+// (bank column m = mel bin m0 + m of the filterbank; M = columns of this bank)
+__device__ __forceinline__ float fb_triangle(const HowlMelPoints& pts, int M, float nyquist, int k, int m, int m0) {
     if (k < 0 || k >= N_FREQ || m >= M) return 0.0f;
     const float f = (k == N_FREQ - 1) ? nyquist : (float)k * (nyquist / (float)(N_FREQ - 1));
-    const float down = (-1.0f * (pts.f[m] - f)) / (pts.f[m + 1] - pts.f[m]);
-    const float up = (pts.f[m + 2] - f) / (pts.f[m + 2] - pts.f[m + 1]);
+    const float* pf = pts.f + m0;
+    const float down = (-1.0f * (pf[m] - f)) / (pf[m + 1] - pf[m]);
+    const float up = (pf[m + 2] - f) / (pf[m + 2] - pf[m + 1]);
     return fmaxf(0.0f, fminf(down, up));
 }
 
 // The whole packed filterbank of howl_fb_from_points in ONE launch (round 4; it was the row-major matrix, then a one-workgroup
 // kernel gathering the fragment images from it: 5 + 11 us per VTLP step, i.e. on 75 % of the training steps): every element
 // of the three images is computed from the corner points where it is stored, the last block takes the coverage flag.
-__global__ __launch_bounds__(256) void fb_from_points_kernel(HowlMelPoints pts, int M, float nyquist, float* __restrict__ fbp) {
+__global__ __launch_bounds__(256) void fb_from_points_kernel(HowlMelPoints pts, int M, float nyquist, float* __restrict__ fbp, int m0) {
     constexpr int N_RM = K_PAD * HOWL_FB_COLS;
     if (blockIdx.x == gridDim.x - 1) {      // does the banded image cover every non-zero weight?
         __shared__ int uncovered;
@@ -101,7 +103,7 @@ __global__ __launch_bounds__(256) void fb_from_points_kernel(HowlMelPoints pts, 
         __syncthreads();
         for (int idx = threadIdx.x; idx < N_FREQ * HOWL_FB_COLS; idx += blockDim.x) {
             const int k = idx / HOWL_FB_COLS, m = idx - k * HOWL_FB_COLS;
-            if (fb_triangle(pts, M, nyquist, k, m) != 0.0f && !slot_has_group(slot_of_bin(k), m >> 2)) uncovered = 1;   // benign race
+            if (fb_triangle(pts, M, nyquist, k, m, m0) != 0.0f && !slot_has_group(slot_of_bin(k), m >> 2)) uncovered = 1;   // benign race
         }
         __syncthreads();
         if (threadIdx.x == 0) reinterpret_cast<int*>(fbp + FBF_OFF)[0] = uncovered ? 0 : 1;
@@ -109,21 +111,21 @@ __global__ __launch_bounds__(256) void fb_from_points_kernel(HowlMelPoints pts, 
     }
     int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx < N_RM) {                       // (K_PAD, HOWL_FB_COLS) row-major
-        fbp[idx] = fb_triangle(pts, M, nyquist, idx / HOWL_FB_COLS, idx % HOWL_FB_COLS);
+        fbp[idx] = fb_triangle(pts, M, nyquist, idx / HOWL_FB_COLS, idx % HOWL_FB_COLS, m0);
         return;
     }
     idx -= N_RM;
     if (idx < FBQ_FLOATS) {                 // banded LDS image [s][lane][4]
         const int c = idx & 3, lane = (idx >> 2) & 63, sl = idx >> 8;
         const int g = slot_group(sl, c), bin = bin_of(sl, lane >> 2);
-        fbp[FBQ_OFF + idx] = (g >= 0 && bin >= 0) ? fb_triangle(pts, M, nyquist, bin, 4 * g + (lane & 3)) : 0.0f;
+        fbp[FBQ_OFF + idx] = (g >= 0 && bin >= 0) ? fb_triangle(pts, M, nyquist, bin, 4 * g + (lane & 3), m0) : 0.0f;
         return;
     }
     idx -= FBQ_FLOATS;
     if (idx < FBD_FLOATS) {                 // every (slot, group) fragment
         const int lane = idx & 63, pair = idx >> 6;
         const int sl = pair / NG_MAX, g = pair - sl * NG_MAX, bin = bin_of(sl, lane >> 2);
-        fbp[FBD_OFF + idx] = bin >= 0 ? fb_triangle(pts, M, nyquist, bin, 4 * g + (lane & 3)) : 0.0f;
+        fbp[FBD_OFF + idx] = bin >= 0 ? fb_triangle(pts, M, nyquist, bin, 4 * g + (lane & 3), m0) : 0.0f;
     }
 }
 
@@ -401,12 +403,18 @@ int howl_collate_augment(const float* bank, long bank_ld, const int* idx, const 
                                     nullptr, nullptr, B, Lout, out, stream);
 }
 
+size_t howl_fb_packed_floats(int M) { return (size_t)fb_banks(M) * HOWL_FB_PACKED_FLOATS; }
+
 int howl_fb_pack(const float* fb, int M, float* fbp, hipStream_t stream) {
     HOWL_REQUIRE(fb && fbp, "howl_fb_pack: null pointer");
     HOWL_REQUIRE(M >= 1 && M <= HOWL_MAX_MELS, "howl_fb_pack: M=%d unsupported (1..%d)", M, HOWL_MAX_MELS);
     const int ncol = HOWL_FB_COLS;
-    hipLaunchKernelGGL(fb_pack_kernel, dim3((K_PAD * ncol + 255) / 256), dim3(256), 0, stream, fb, M, fbp, ncol);
-    hipLaunchKernelGGL(fb_fragments_kernel, dim3(1), dim3(1024), 0, stream, fbp);
+    for (int bank = 0; bank < fb_banks(M); ++bank) {
+        const int m0 = bank == 0 ? 0 : fb_bank_lo(M), Mb = bank == 0 ? fb_bank_lo(M) : M - fb_bank_lo(M);
+        float* dst = fbp + (size_t)bank * HOWL_FB_PACKED_FLOATS;
+        hipLaunchKernelGGL(fb_pack_kernel, dim3((K_PAD * ncol + 255) / 256), dim3(256), 0, stream, fb, M, dst, ncol, m0, Mb);
+        hipLaunchKernelGGL(fb_fragments_kernel, dim3(1), dim3(1024), 0, stream, dst);
+    }
     HOWL_CHECK_LAUNCH("howl_fb_pack");
     return HOWL_OK;
 }
@@ -417,7 +425,11 @@ int howl_fb_from_points(const HowlMelPoints* pts, int M, float nyquist, float* f
     const int ncol = HOWL_FB_COLS;
     (void)ncol;
     const int work = K_PAD * HOWL_FB_COLS + FBQ_FLOATS + FBD_FLOATS;
-    hipLaunchKernelGGL(fb_from_points_kernel, dim3((work + 255) / 256 + 1), dim3(256), 0, stream, *pts, M, nyquist, fbp);
+    for (int bank = 0; bank < fb_banks(M); ++bank) {
+        const int m0 = bank == 0 ? 0 : fb_bank_lo(M), Mb = bank == 0 ? fb_bank_lo(M) : M - fb_bank_lo(M);
+        hipLaunchKernelGGL(fb_from_points_kernel, dim3((work + 255) / 256 + 1), dim3(256), 0, stream, *pts, Mb, nyquist,
+                           fbp + (size_t)bank * HOWL_FB_PACKED_FLOATS, m0);
+    }
     HOWL_CHECK_LAUNCH("howl_fb_from_points");
     return HOWL_OK;
 }
@@ -432,17 +444,22 @@ int howl_logmel_fwd(const float* pcm, int B, int L, long ld, const float* fbp, i
     if (grid > ll.n_quads) grid = ll.n_quads;
     int waves = FE_WAVES;
     if (const char* e = getenv("HOWL_LOGMEL_WAVES")) waves = atoi(e) == 12 ? 12 : 16;   // occupancy experiments
-    {
+    for (int bank = 0; bank < fb_banks(M); ++bank) {
+        // more than 48 mel bins: one pass over the spectrum per bank, each writing its own columns of `out`
+        const int m0 = bank == 0 ? 0 : fb_bank_lo(M);
+        ll.fbp = fbp + (size_t)bank * HOWL_FB_PACKED_FLOATS;
+        ll.M = bank == 0 ? fb_bank_lo(M) : M - fb_bank_lo(M);
+        ll.out = out + (layout == 1 ? (long)m0 : (long)m0 * ll.T);
         HowlProfScope prof("logmel", stream);
-        if (M > 4 * NG_BANDED)
+        if (ll.M > 4 * NG_BANDED)
             hipLaunchKernelGGL((logmel_kernel<12, NG_MAX>), dim3((unsigned)grid), dim3(12 * 64), 0, stream, ll.pcm, ll.L, ll.ld, ll.T,
-                               ll.total, ll.fbp, ll.M, ll.log_eps, ll.zmuv, ll.out, ll.layout, ll.n_quads, ll.aligned);
+                               ll.total, ll.fbp, ll.M, ll.log_eps, ll.zmuv, ll.out, ll.layout, ll.n_quads, ll.aligned, ll.Mo);
         else if (waves == 16)
             hipLaunchKernelGGL((logmel_kernel<16, NG_BANDED>), dim3((unsigned)grid), dim3(16 * 64), 0, stream, ll.pcm, ll.L, ll.ld, ll.T,
-                               ll.total, ll.fbp, ll.M, ll.log_eps, ll.zmuv, ll.out, ll.layout, ll.n_quads, ll.aligned);
+                               ll.total, ll.fbp, ll.M, ll.log_eps, ll.zmuv, ll.out, ll.layout, ll.n_quads, ll.aligned, ll.Mo);
         else
             hipLaunchKernelGGL((logmel_kernel<12, NG_BANDED>), dim3((unsigned)grid), dim3(12 * 64), 0, stream, ll.pcm, ll.L, ll.ld, ll.T,
-                               ll.total, ll.fbp, ll.M, ll.log_eps, ll.zmuv, ll.out, ll.layout, ll.n_quads, ll.aligned);
+                               ll.total, ll.fbp, ll.M, ll.log_eps, ll.zmuv, ll.out, ll.layout, ll.n_quads, ll.aligned, ll.Mo);
     }
     HOWL_CHECK_LAUNCH("howl_logmel_fwd");
     return HOWL_OK;

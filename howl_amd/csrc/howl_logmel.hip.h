@@ -196,7 +196,8 @@ constexpr int FE_WAVES = 12;     // measured at 512 x 1 s: 23.9 us with twelve w
 template <int NWAVES, int NGRP>
 __device__ __forceinline__ void logmel_body(const float* __restrict__ pcm, int L, long ld, int T, int total_frames,
                                             const float* __restrict__ fbp, int M, float log_eps, const float* __restrict__ zmuv,
-                                            float* __restrict__ out, int layout, int n_quads, int aligned, unsigned bidx, unsigned nblk) {
+                                            float* __restrict__ out, int layout, int n_quads, int aligned, unsigned bidx, unsigned nblk,
+                                            int Mo /* mel bins per frame of `out` (= M, or the whole filterbank when this launch is one bank of it) */) {
     constexpr int XR = FeGeom<NWAVES>::XR, XF = FeGeom<NWAVES>::XF;
     __shared__ v2f xch[NWAVES * QUAD * XF];             // FFT transpose tiles, private per wave
     __shared__ v4f c_tab[HOWL_FE_CONST_FLOATS / 4];     // window | W_256 | W_512 rows (read-only after the prologue)
@@ -369,13 +370,13 @@ __device__ __forceinline__ void logmel_body(const float* __restrict__ pcm, int L
         const int g_frame = g0 + r_out;
         long o_base, o_ms;
         if (layout == 1) {
-            o_base = (long)g_frame * M;
+            o_base = (long)g_frame * Mo;
             o_ms = 1;
         } else {
             int t = t0 + r_out, b = b0;
             if (t >= T) { t -= T; ++b; }
             if (t >= T) { t -= T; ++b; }
-            o_base = (long)b * M * T + t;
+            o_base = (long)b * Mo * T + t;
             o_ms = T;
         }
         auto mel_pass = [&](auto g0c) {
@@ -461,7 +462,11 @@ struct LogmelLaunch {
     const float* zmuv;
     float* out;
     int layout, n_quads, aligned;
+    int Mo;      // mel bins per frame of `out`: M, or the whole filterbank's when the launch computes one bank of it
 };
+// More than HOWL_FB_COLS mel bins: two banks [0, lo) and [lo, M), lo a multiple of 4 (the contraction's group width)
+inline int fb_banks(int M) { return M <= HOWL_FB_COLS ? 1 : 2; }
+inline int fb_bank_lo(int M) { return M <= HOWL_FB_COLS ? M : 4 * ((M + 7) / 8); }
 inline int logmel_prepare(const float* pcm, int B, int L, long ld, const float* fbp, int M, float log_eps, const float* zmuv,
                           float* out, int layout, LogmelLaunch* ll) {
     HOWL_REQUIRE(pcm && fbp && out, "howl_logmel_fwd: null pointer");
@@ -476,7 +481,7 @@ inline int logmel_prepare(const float* pcm, int B, int L, long ld, const float* 
     const int total = B * T;
     // 8-byte sample loads need even row strides and an 8-byte aligned base; anything else takes the per-sample path
     const int aligned = ((ld & 1) == 0 && (reinterpret_cast<uintptr_t>(pcm) & 7) == 0) ? 1 : 0;
-    *ll = LogmelLaunch{pcm, L, ld, T, total, fbp, M, log_eps, zmuv, out, layout, (total + QUAD - 1) / QUAD, aligned};
+    *ll = LogmelLaunch{pcm, L, ld, T, total, fbp, M, log_eps, zmuv, out, layout, (total + QUAD - 1) / QUAD, aligned, M};
     return HOWL_OK;
 }
 

@@ -148,7 +148,7 @@ __global__ __launch_bounds__(F8_THREADS) void lstm_fwd4_kernel(const float* __re
         if ((int)blockIdx.x >= nrec) {
             logmel_body<F8_THREADS / 64, NG_BANDED>(next.pcm, next.L, next.ld, next.T, next.total, next.fbp, next.M, next.log_eps, next.zmuv,
                                                     next.out, next.layout, next.n_quads, next.aligned, blockIdx.x - (unsigned)nrec,
-                                                    (unsigned)next_blocks);
+                                                    (unsigned)next_blocks, next.Mo);
             return;
         }
     }

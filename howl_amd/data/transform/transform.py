@@ -14,7 +14,7 @@ import torch
 import torch.nn as nn
 
 from howl_amd import ops
-from howl_amd.lib import FB_PACKED_FLOATS
+from howl_amd.lib import MAX_MELS, fb_packed_floats
 from howl_amd.settings import SETTINGS
 
 __all__ = ["AugmentationParameter", "AugmentModule", "StandardAudioTransform", "SpecAugmentTransform",
@@ -112,8 +112,10 @@ class StandardAudioTransform(AugmentModule):
         self.spec_transform = spec
         self.vtlp_transform = spec
         self._points = mel_corner_points(self.n_mels, self.sample_rate)  # host, 42 floats
-        self.register_buffer("fb_standard", torch.zeros(FB_PACKED_FLOATS), persistent=False)
-        self.register_buffer("fb_vtlp", torch.zeros(FB_PACKED_FLOATS), persistent=False)
+        if not 1 <= self.n_mels <= MAX_MELS:
+            raise NotImplementedError(f"the frontend kernel contracts up to {MAX_MELS} mel bins (NUM_MELS={self.n_mels})")
+        self.register_buffer("fb_standard", torch.zeros(fb_packed_floats(self.n_mels)), persistent=False)
+        self.register_buffer("fb_vtlp", torch.zeros(fb_packed_floats(self.n_mels)), persistent=False)
         self._fb_ready = None
         self.last_vtlp_alpha = None
 

@@ -11,9 +11,15 @@ from pathlib import Path
 
 # HOWL_HIP_LIBRARY selects another build of the same C ABI (diagnostic kernel variants, tools/variants.py)
 LIB_PATH = Path(os.environ.get("HOWL_HIP_LIBRARY") or Path(__file__).resolve().parent / "libhowl_hip.so")
-MAX_MELS = 48
+MAX_MELS = 96                                                                       # HOWL_MAX_MELS
 FB_COLS = 48
-FB_PACKED_FLOATS = 260 * FB_COLS + 17 * 64 * 4 + 17 * (FB_COLS // 4) * 64 + 32      # HOWL_FB_PACKED_FLOATS
+FB_PACKED_FLOATS = 260 * FB_COLS + 17 * 64 * 4 + 17 * (FB_COLS // 4) * 64 + 32      # HOWL_FB_PACKED_FLOATS: one bank
+
+
+def fb_packed_floats(n_mels: int) -> int:
+    """``howl_fb_packed_floats``: a packed filterbank is one bank of up to 48 mel bins, or two back to back."""
+    return FB_PACKED_FLOATS * (1 if n_mels <= FB_COLS else 2)
+
 
 P = c_void_p  # device pointer
 STREAM = c_void_p
@@ -129,7 +135,7 @@ SIGNATURES = {
     "howl_mobilenet_bwd": [P, c_int, P, c_long, c_long, c_long, c_int, c_int, c_int, P, c_float, P, P, P, c_size_t, STREAM],
 }
 # entry points that do not return an int status
-SIZE_FUNCS = {"howl_res8_workspace_bytes": [c_int, c_int], "howl_res8_long_workspace_bytes": [c_int, c_int],
+SIZE_FUNCS = {"howl_fb_packed_floats": [c_int], "howl_res8_workspace_bytes": [c_int, c_int], "howl_res8_long_workspace_bytes": [c_int, c_int],
               "howl_res8_workspace_bytes_mels": [c_int, c_int, c_int], "howl_res8_long_workspace_bytes_mels": [c_int, c_int, c_int], "howl_lstm_workspace_bytes": [c_int, c_int],
               "howl_lstm_needs_gx": [POINTER(HowlLstmParams), c_int, c_int, c_int, c_int],
               "howl_head_workspace_bytes": [c_int, c_int, c_int],

@@ -32,17 +32,19 @@ def _vp(t):
 
 
 class _Res8Buffers:
-    """Caller-owned activations / workspace for one (B, T) geometry, reused across steps."""
+    """Caller-owned activations / workspace for one (B, T, M) geometry, reused across steps.  The activations are the
+    library's: (B, 45, T/3, M/4) floats each, in the reference's NCHW order at 40 mel bins and as two 10-column strips per
+    utterance at 80 (``include/howl_hip.h``, ``HowlRes8Saved``)."""
 
-    def __init__(self, B, T, C, device):
+    def __init__(self, B, T, C, device, M=40):
         H = T // 3
         f32 = dict(dtype=torch.float32, device=device)
-        self.key = (B, T, C, str(device))
-        self.s = [torch.empty((B, 45, H, 10), **f32) for _ in range(7)]
+        self.key = (B, T, M, C, str(device))
+        self.s = [torch.empty((B, 45, H, M // 4), **f32) for _ in range(7)]
         self.bn_stats = torch.zeros((6, 2, 48), **f32)
         self.pooled = torch.empty((B, 48), **f32)
-        self.mask0 = torch.empty((B, 45, H, 10), dtype=torch.int16, device=device)
-        nbytes = _lib.get().cdll.howl_res8_workspace_bytes(B, T)
+        self.mask0 = torch.empty((B, 45, H, M // 4), dtype=torch.int16, device=device)
+        nbytes = _lib.get().cdll.howl_res8_workspace_bytes_mels(B, T, M)
         self.ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
         self.saved = _lib.HowlRes8Saved()
         for i in range(7):
@@ -73,14 +75,16 @@ class _Res8Function(torch.autograd.Function):
         return (None, None) + tuple(grads)
 
 
+RES8_MELS = (40, 80)     # envs/res8.env sets 40; 80 is howl/settings.py:32's default
+
+
 def res8_mels_message():
     from howl_amd.settings import SETTINGS
     n = SETTINGS.audio_transform.num_mels
-    if n == 40:
+    if n in RES8_MELS:
         return None
-    return (f"Res8 on MI355X is built for NUM_MELS=40 (envs/res8.env; AvgPool (3,4) over 40 mel bins), but "
-            f"SETTINGS.audio_transform.num_mels is {n}: export NUM_MELS=40 before howl_amd.settings is imported (stock Howl's "
-            f"default of 80 is not supported by the kernels)")
+    return (f"Res8 on MI355X is built for NUM_MELS=40 (envs/res8.env) or 80 (stock Howl's default): AvgPool (3,4) over strips of "
+            f"40 mel bins, but SETTINGS.audio_transform.num_mels is {n}: export NUM_MELS before howl_amd.settings is imported")
 
 
 def require_supported_mels(model):
@@ -96,11 +100,11 @@ class Res8(RegisteredModel, name="res8"):
         n_maps = config.num_maps
         if n_maps != 45 or tuple(config.pooling) != (3, 4):
             raise NotImplementedError("the MI355X res8 kernels are specialised for num_maps=45, pooling=(3,4)")
-        # the reference's default is 80 mel bins (settings.py:32) while every res8 preset sets 40 (envs/res8.env) and the kernels
-        # pool (3, 4) over 40: say so when the model is built -- as a warning, so that a model can still be constructed to load,
+        # the reference's default is 80 mel bins (settings.py:32), every res8 preset sets 40 (envs/res8.env); the kernels take
+        # both.  Anything else: say so when the model is built -- as a warning, so that a model can still be constructed to load,
         # convert or inspect a state_dict (cnn.py:113 constructs regardless of the settings); the entry points, which build the
-        # frontend and the model together, turn it into an error (require_supported_mels), and the first forward on anything
-        # but 40 bins raises in any case (_feat_view)
+        # frontend and the model together, turn it into an error (require_supported_mels), and the first forward on another
+        # width raises in any case (_feat_view)
         msg = res8_mels_message()
         if msg:
             logging.getLogger(__name__).warning(msg)
@@ -139,13 +143,13 @@ class Res8(RegisteredModel, name="res8"):
         prm.out_b = _vp(ps[8])
         return prm
 
-    def _get_buffers(self, B, T, device):
-        key = (B, T, self.num_labels, str(device))
+    def _get_buffers(self, B, T, device, M=40):
+        key = (B, T, M, self.num_labels, str(device))
         buf = self._buffers_cache.pop(key, None)
         if buf is None:
             if len(self._buffers_cache) >= 6:
                 self._buffers_cache.pop(next(iter(self._buffers_cache)))   # drop the least recently used geometry
-            buf = _Res8Buffers(B, T, self.num_labels, device)
+            buf = _Res8Buffers(B, T, self.num_labels, device, M)
         self._buffers_cache[key] = buf
         return buf
 
@@ -155,9 +159,9 @@ class Res8(RegisteredModel, name="res8"):
         x0 = x[:, 0]
         if not ops.on_device(x0) or x0.dtype != torch.float32:
             raise _lib.HowlHipError("Res8 input must be an fp32 tensor on a HIP device (no CPU fallback)")
-        if x0.shape[1] != 40:
-            raise ValueError(f"Res8 on MI355X is built for NUM_MELS=40 (envs/res8.env; pooling (3,4) over 40 mel bins); got "
-                             f"{x0.shape[1]} mel bins -- set NUM_MELS=40 before howl_amd.settings is imported")
+        if x0.shape[1] not in RES8_MELS:
+            raise ValueError(f"Res8 on MI355X is built for NUM_MELS=40 (envs/res8.env) or 80 (stock default); got "
+                             f"{x0.shape[1]} mel bins -- set NUM_MELS before howl_amd.settings is imported")
         if x0.shape[2] < 3:
             raise ValueError(f"Res8 needs at least 3 frames (one pooled row); got T={x0.shape[2]}")
         return x0, x0.stride(0), x0.stride(2), x0.stride(1)
@@ -172,7 +176,7 @@ class Res8(RegisteredModel, name="res8"):
                                       f"reference's presets use 0.5 s / 1 s); got T={x0.shape[2]}. Longer inputs are "
                                       "supported in eval mode")
         B, M, T = x0.shape
-        nbytes = _lib.get().cdll.howl_res8_long_workspace_bytes(B, T)
+        nbytes = _lib.get().cdll.howl_res8_long_workspace_bytes_mels(B, T, M)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=x0.device)
         logits = torch.empty((B, self.num_labels), dtype=torch.float32, device=x0.device)
         prm = self._params_struct()
@@ -186,7 +190,7 @@ class Res8(RegisteredModel, name="res8"):
         B, M, T = x0.shape
         if T > self.MAX_FRAMES:
             return self._launch_forward_long(x0, sb, st, sm)
-        buf = self._get_buffers(B, T, x0.device)
+        buf = self._get_buffers(B, T, x0.device, M)
         logits = torch.empty((B, self.num_labels), dtype=torch.float32, device=x0.device)
         prm = self._params_struct()
         self._fwd_version += 1
@@ -205,7 +209,7 @@ class Res8(RegisteredModel, name="res8"):
         B, M, T = x0.shape
         if T > self.MAX_FRAMES or not self.training or self.num_labels > self.XENT_MAX_LABELS:
             raise NotImplementedError("fused forward + cross-entropy: training mode, T <= 83 frames, <= 64 labels")
-        buf = self._get_buffers(B, T, x0.device)
+        buf = self._get_buffers(B, T, x0.device, M)
         f32 = dict(dtype=torch.float32, device=x0.device)
         logits = torch.empty((B, self.num_labels), **f32)
         nll, dlogits = torch.empty((B,), **f32), torch.empty((B, self.num_labels), **f32)
@@ -233,7 +237,7 @@ class Res8(RegisteredModel, name="res8"):
                                       "the only mode the reference trains in")
         x0, sb, st, sm = self._feat_view(feat)
         B, M, T = x0.shape
-        buf = self._get_buffers(B, T, x0.device)
+        buf = self._get_buffers(B, T, x0.device, M)
         ps = self.hot_parameters()
         grads = out_grads if out_grads is not None else [torch.empty_like(p) for p in ps]
         gr = _lib.HowlRes8Grads()

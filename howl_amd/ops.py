@@ -42,14 +42,16 @@ def num_frames(length: int) -> int:
 
 
 def fb_pack(fb: torch.Tensor) -> torch.Tensor:
-    """(257, M) filterbank on the device -> packed (260, 48) operand."""
-    out = torch.empty(_lib.FB_PACKED_FLOATS, dtype=torch.float32, device=fb.device)
+    """(257, M) filterbank on the device -> packed operand (one (260, 48) bank, two beyond 48 mel bins)."""
+    out = torch.empty(_lib.fb_packed_floats(fb.shape[1]), dtype=torch.float32, device=fb.device)
     _lib.get().call("howl_fb_pack", _p(fb), fb.shape[1], _p(out), _stream())
     return out
 
 
 def fb_from_points(f_pts, n_mels: int, nyquist: float, out: torch.Tensor) -> torch.Tensor:
-    """M+2 corner frequencies (host floats) -> packed filterbank written into ``out`` (device, 260*48 floats)."""
+    """M+2 corner frequencies (host floats) -> packed filterbank written into ``out`` (device, ``fb_packed_floats(M)`` floats)."""
+    if out.numel() < _lib.fb_packed_floats(n_mels):
+        raise ValueError(f"packed filterbank buffer holds {out.numel()} floats, {n_mels} mel bins need {_lib.fb_packed_floats(n_mels)}")
     pts = _lib.HowlMelPoints()
     for i, v in enumerate(f_pts):
         pts.f[i] = v

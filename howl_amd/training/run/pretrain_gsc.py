@@ -88,7 +88,7 @@ def main(argv=None):
     std_transform = StandardAudioTransform().to(device).eval()
     zmuv_transform = ZmuvTransform().to(device)
     model = RegisteredModel.find_registered_class(args.model)(num_labels).to(device)
-    require_supported_mels(model)      # res8 with NUM_MELS != 40: an error here, not at the first batch
+    require_supported_mels(model)      # res8 with NUM_MELS other than 40 / 80: an error here, not at the first batch
     params = [p for p in model.parameters() if p.requires_grad]
     logging.info(f"{sum(p.numel() for p in params)} parameters")
 

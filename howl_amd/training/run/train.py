@@ -149,7 +149,7 @@ def main(argv=None):
     std_transform = StandardAudioTransform().to(device).eval()
     zmuv_transform = ZmuvTransform().to(device)
     model = RegisteredModel.find_registered_class(args.model)(ctx.num_labels).to(device).streaming()
-    require_supported_mels(model)      # res8 with NUM_MELS != 40: an error here, not at the first batch
+    require_supported_mels(model)      # res8 with NUM_MELS other than 40 / 80: an error here, not at the first batch
     spectrogram_augmentations = (SpecAugmentTransform().train(),)      # train.py:277-278
     if zmuv_on_disk:
         zmuv_transform.load_state_dict(torch.load(str(ws.path / "zmuv.pt.bin")))

@@ -24,11 +24,15 @@ extern "C" {
 
 typedef struct ihipStream_t* hipStream_t;
 
-#define HOWL_MAX_MELS 48 /* mel bins supported by the MFMA contraction (3 tiles of 16); BASELINE configs use 40 */
-#define HOWL_FB_COLS 48  /* column count of a packed filterbank: (260, 48) fp32, zero padded */
-/* A packed filterbank is (260, 48) row-major floats followed by the same matrix in the fragment order of the mel
+#define HOWL_FB_COLS 48  /* column count of one packed filterbank BANK: (260, 48) fp32, zero padded -- what one pass of the mel
+                          * contraction covers (12 groups of 4 bins) */
+#define HOWL_MAX_MELS 96 /* mel bins supported: up to two banks.  BASELINE configs use 40, the reference's stock NUM_MELS is 80
+                          * (howl/settings.py:32): more than 48 bins run as two passes over the spectrum, bins [0, lo) and [lo, M),
+                          * lo = 4 * ceil(M / 8) (80 -> 40 + 40) */
+/* A packed bank is (260, 48) row-major floats followed by the same matrix in the fragment order of the mel
  * contraction: the banded LDS image (17 bin slots x 64 lanes x 4 mel groups), every (slot, group) fragment
- * (17 x 12 x 64 lanes), and 32 int32 words of flags. */
+ * (17 x 12 x 64 lanes), and 32 int32 words of flags.  A packed filterbank is howl_fb_packed_floats(M) floats: one bank
+ * (M <= 48) or two, back to back. */
 #define HOWL_FB_PACKED_FLOATS (260 * HOWL_FB_COLS + 17 * 64 * 4 + 17 * (HOWL_FB_COLS / 4) * 64 + 32)
 
 int howl_version(int* major, int* minor);
@@ -52,9 +56,10 @@ int howl_shutdown(void);
  * MelSpectrogram / ComputeDeltas it calls; howl/data/transform/operator.py:119-146 (ZmuvTransform).
  * ------------------------------------------------------------------------------------------------- */
 
-/* (257, M) mel filterbank -> packed operand of howl_logmel_fwd (HOWL_FB_PACKED_FLOATS floats; the first 260 x 48 are the
- * zero-padded matrix itself).
+/* (257, M) mel filterbank -> packed operand of howl_logmel_fwd (howl_fb_packed_floats(M) floats; the first 260 x 48 of a bank
+ * are its zero-padded columns themselves).
  * Replaces the `.to(device)` of the CPU-built matrix at transform.py:435-443. */
+size_t howl_fb_packed_floats(int M);
 int howl_fb_pack(const float* fb, int M, float* fbp, hipStream_t stream);
 
 /* Build the packed filterbank on the device from the M+2 triangle corner frequencies (host struct, passed

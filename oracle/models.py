@@ -48,15 +48,23 @@ def res8_param_names():
     return ["conv0.weight"] + [f"conv{i}.weight" for i in range(1, N_LAYERS + 1)] + ["output.weight", "output.bias"]
 
 
-def res8_forward(sd: Dict[str, torch.Tensor], x: torch.Tensor, training: bool) -> torch.Tensor:
+def res8_forward(sd: Dict[str, torch.Tensor], x: torch.Tensor, training: bool, pre_relu=None, relu_masks=None) -> torch.Tensor:
     """``Res8.forward`` (``cnn.py:127-145``).  x: (B, C>=1, M, T).  In training mode the BN buffers in
     ``sd`` are updated in place exactly like ``nn.BatchNorm2d(affine=False)`` (momentum 0.1,
-    unbiased variance for the running estimate, ``num_batches_tracked += 1``)."""
+    unbiased variance for the running estimate, ``num_batches_tracked += 1``).
+    Test diagnostics (a ReLU whose input lies within fp32 rounding of zero comes out on either side depending on the summation
+    order, and one such flip moves small-batch gradients by O(1 / positions) -- for this function against its own fp64 run as much
+    as for a kernel): ``pre_relu`` (a list) receives every convolution's output z, (B, 45, T, M) for conv0 and (B, 45, T/3, M/4) for
+    the rest; ``relu_masks`` (seven bool tensors of those shapes) replaces relu(z) by z * mask, i.e. the same function with the
+    on/off decisions taken from elsewhere."""
     x = x[:, :1]
     x = x.permute(0, 1, 3, 2).contiguous()
     old_x = None
     for i in range(N_LAYERS + 1):
-        y = F.relu(F.conv2d(x, sd[f"conv{i}.weight"], None, padding=1))
+        z = F.conv2d(x, sd[f"conv{i}.weight"], None, padding=1)
+        if pre_relu is not None:
+            pre_relu.append(z.detach())
+        y = F.relu(z) if relu_masks is None else z * relu_masks[i].to(z.dtype)
         if i == 0:
             y = F.avg_pool2d(y, POOLING)
             old_x = y

@@ -34,3 +34,56 @@ def make_res8(C, state=None, train=True):
     model.load_state_dict({k: v.clone() for k, v in sd.items()})
     model = model.to(DEV)
     return model.train() if train else model.eval()
+
+
+def res8_relu_masks(model, B, T, M):
+    """The ReLU on/off decisions of the res8 kernels' last training forward, in the oracle's layouts (seven bool tensors:
+    (B, 45, T, M) for conv0 -- rows beyond 3 (T // 3) are dropped by the pooling and reported off --, (B, 45, T/3, M/4) for the
+    3x3 layers), read from what the forward saves for the backward (include/howl_hip.h HowlRes8Saved): conv0's 12-bit
+    patterns per pooled cell, the sign of s_i for the layers without a residual add, its sign BIT for those with one."""
+    buf = next(v for k, v in model._buffers_cache.items() if k[0] == B and k[1] == T and k[2] == M)
+    H, W = T // 3, M // 4
+
+    def unstrip(t):      # 80 mel bins: utterance b is the two blocks 2b, 2b+1 of (45, H, 10) -- pooled columns 0..9, 10..19
+        t = t.detach().cpu()
+        if W == 10:
+            return t.reshape(B, 45, H, 10)
+        return t.reshape(B, W // 10, 45, H, 10).permute(0, 2, 3, 1, 4).reshape(B, 45, H, W)
+
+    bits = unstrip(buf.mask0).to(torch.int32) & 0xFFFF
+    m0 = torch.zeros(B, 45, T, M, dtype=torch.bool)
+    for tl in range(3):
+        for fl in range(4):
+            m0[:, :, tl:3 * H:3, fl::4] = ((bits >> (4 * tl + fl)) & 1).bool()
+    masks = [m0]
+    for i in range(1, 7):
+        s_i = unstrip(buf.s[i])
+        masks.append(torch.signbit(s_i) if i % 2 == 0 else s_i > 0)
+    return masks
+
+
+def res8_oracle_with_kernel_relus(model, x, labels, B, T, M, C, flip_tol=3e-6):
+    """The oracle's training step on features x with the kernels' own ReLU decisions: where the two disagree the oracle's
+    pre-activation must lie within rounding of zero (asserted: |z| < flip_tol, a handful of elements), and with the decisions
+    shared the gradients have to agree to summation-order rounding whatever the batch size.  Returns (logits, grads by name,
+    number of flipped decisions)."""
+    names = om.res8_param_names()
+    pre = []
+    om.res8_forward(om.res8_init(C), x.contiguous(), True, pre_relu=pre)
+    masks = res8_relu_masks(model, B, T, M)
+    flips = 0
+    H = T // 3
+    for i, (z, m) in enumerate(zip(pre, masks)):
+        if i == 0:
+            z, m = z[:, :, :3 * H], m[:, :, :3 * H]
+        bad = (z > 0) != m
+        flips += int(bad.sum())
+        if bad.any():
+            assert z[bad].abs().max().item() < flip_tol, (i, int(bad.sum()), z[bad].abs().max().item())
+    masks[0][:, :, 3 * H:] = pre[0][:, :, 3 * H:] > 0      # rows the pooling drops: no gradient flows there
+    assert flips <= 2 + 2e-5 * sum(z.numel() for z in pre), flips
+    sd = om.res8_init(C)
+    params = [sd[n].requires_grad_(True) for n in names]
+    ref = om.res8_forward(sd, x.contiguous(), True, relu_masks=masks)
+    grads = torch.autograd.grad(torch.nn.functional.cross_entropy(ref, labels), params)
+    return ref.detach(), dict(zip(names, grads)), flips, sd

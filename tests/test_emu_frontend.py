@@ -5,7 +5,7 @@ import pytest
 import torch
 
 from emu_util import emu_lib, ptr
-from howl_amd.lib import FB_PACKED_FLOATS, HowlMelPoints
+from howl_amd.lib import FB_PACKED_FLOATS, HowlMelPoints, fb_packed_floats
 from oracle import frontend as fe
 
 
@@ -15,7 +15,8 @@ def lib():
 
 
 def pack_fb(lib, fb):
-    fbp = np.zeros(FB_PACKED_FLOATS, np.float32)
+    fbp = np.zeros(fb_packed_floats(fb.shape[1]), np.float32)
+    assert fbp.size == lib.cdll.howl_fb_packed_floats(fb.shape[1])
     fb = np.ascontiguousarray(fb, np.float32)
     lib.call("howl_fb_pack", ptr(fb), fb.shape[1], ptr(fbp), None)
     return fbp
@@ -65,6 +66,48 @@ def test_logmel_matches_oracle_and_golden(lib, golden):
         assert np.abs(out - ref)[strong].max() < 2e-4
         out_t = logmel(lib, audio, fbp, layout=1)
         assert np.array_equal(out_t, out.transpose(0, 2, 1))
+
+
+@pytest.mark.parametrize("M", [80, 64, 50])
+def test_more_than_48_mel_bins_run_as_two_banks(lib, M):
+    """NUM_MELS = 80 is the reference's stock default (settings.py:32): the contraction covers 48 bins per pass, so wider
+    filterbanks are packed as two banks ([0, lo), [lo, M), lo = 4 ceil(M / 8)) and howl_logmel_fwd makes one pass per bank into
+    the same output.  Packed images, the device-built triangles (standard and VTLP-warped) and the log-mels in both layouts
+    against the oracle; 64 and 50: uneven banks."""
+    import math
+    lo = 4 * ((M + 7) // 8)
+    fb = fe.mel_fb(M).numpy()
+    fbp = pack_fb(lib, fb)
+    assert fbp.size == 2 * FB_PACKED_FLOATS
+    b0 = fbp[:260 * 48].reshape(260, 48)
+    b1 = fbp[FB_PACKED_FLOATS:FB_PACKED_FLOATS + 260 * 48].reshape(260, 48)
+    assert np.array_equal(b0[:257, :lo], fb[:, :lo]) and not b0[:, lo:].any()
+    assert np.array_equal(b1[:257, :M - lo], fb[:, lo:]) and not b1[:, M - lo:].any()
+    for alpha in (None, 1.0999):
+        m_pts = torch.linspace(0.0, 2595.0 * math.log10(1.0 + 8000.0 / 700.0), M + 2)
+        f_pts = 700.0 * (10 ** (m_pts / 2595.0) - 1.0)
+        if alpha is not None:
+            thr = 4800 * min(alpha, 1) / alpha
+            f_pts[f_pts <= thr] *= alpha
+            f = f_pts[f_pts > thr]
+            f_pts[f_pts > thr] = 8000 - ((8000 - 4800 * min(alpha, 1)) / (8000 - thr)) * (8000 - f)
+        pts = HowlMelPoints()
+        for i, v in enumerate(f_pts.tolist()):
+            pts.f[i] = v
+        out = np.zeros(fb_packed_floats(M), np.float32)
+        lib.call("howl_fb_from_points", pts, M, 8000.0, ptr(out), None)
+        ref = fe.mel_fb(M, alpha=alpha).numpy()
+        np.testing.assert_allclose(out[:260 * 48].reshape(260, 48)[:257, :lo], ref[:, :lo], rtol=0, atol=2e-7)
+        np.testing.assert_allclose(out[FB_PACKED_FLOATS:FB_PACKED_FLOATS + 260 * 48].reshape(260, 48)[:257, :M - lo], ref[:, lo:],
+                                   rtol=0, atol=2e-7)
+    rng = np.random.default_rng(M)
+    audio = (0.1 * rng.standard_normal((3, 2377))).astype(np.float32)
+    zm = np.array([-2.0, 1.5], np.float32)
+    out = logmel(lib, audio, fbp, M=M, zmuv=zm)
+    ref = (fe.standard_audio_transform(torch.from_numpy(audio), fe.mel_fb(M), mels_only=True).numpy() + 2.0) / 1.5
+    np.testing.assert_allclose(out, ref, rtol=0, atol=1e-4)
+    out_t = logmel(lib, audio, fbp, M=M, zmuv=zm, layout=1)
+    assert np.array_equal(out_t, out.transpose(0, 2, 1))
 
 
 def test_logmel_zmuv_and_ragged_tail(lib):

@@ -200,3 +200,39 @@ def test_overlapping_strided_rows(std, stride):
     want = ops.logmel(windows.contiguous(), std._standard_fb(), 40, None, layout=0)
     assert torch.equal(got, want)
     logmel_close(got, ofe.standard_audio_transform(windows.cpu().contiguous(), ofe.mel_fb(40), mels_only=True))
+
+
+def test_frontend_at_80_mel_bins(monkeypatch, golden):
+    """NUM_MELS = 80 (stock Howl, settings.py:32): the mel contraction covers 48 bins per pass, so the filterbank is two banks of
+    40 and the kernel passes over the spectrum once per bank.  Eval and VTLP train mode through the module against the oracle
+    at full size, plus the golden clips (torchaudio's definition restated in the oracle, pinned at 40 bins by G1 / G2)."""
+    from howl_amd.data.transform.operator import ZmuvTransform
+    from howl_amd.data.transform.transform import StandardAudioTransform
+    from howl_amd.settings import SETTINGS
+    from howl_amd.utils.synth import synthetic_pcm
+    monkeypatch.setattr(SETTINGS.audio_transform, "num_mels", 80)
+    std = StandardAudioTransform().to(DEV).eval()
+    fb = ofe.mel_fb(80)
+    g = golden("g2_frontend_gsc")
+    audio = t(g["audio"])
+    feats = std(audio.to(DEV))
+    assert feats.shape == (6, 3, 80, 81)
+    ref = ofe.standard_audio_transform(audio, fb)
+    logmel_close(feats[:, 0], ref[:, 0])
+    assert maxerr(feats[:, 1], ref[:, 1]) < 2e-3 and maxerr(feats[:, 2], ref[:, 2]) < 2e-3
+    pcm = synthetic_pcm(512, 16000)
+    zmuv = ZmuvTransform().to(DEV)
+    zmuv.update(std(pcm[:4].to(DEV)))
+    view = std.log_mel_for_model(pcm.to(DEV), zmuv)        # (B, 1, 80, T) view of the (B, T, 80) buffer res8 reads
+    z = ofe.Zmuv()
+    z.update(ofe.standard_audio_transform(pcm[:4], fb))
+    refz = z(ofe.standard_audio_transform(pcm[::37], fb, mels_only=True))
+    d = (view[::37, 0].cpu() - refz).abs()
+    assert d.max().item() < 2e-3
+    std.train()
+    random.seed(5)
+    out = std(audio.to(DEV), mels_only=True)
+    random.seed(5)
+    gate = random.random()
+    alpha = random.random() * 0.2 + 0.9 if gate < 0.75 else None
+    logmel_close(out, ofe.standard_audio_transform(audio, ofe.mel_fb(80, alpha=alpha), mels_only=True))

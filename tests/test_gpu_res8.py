@@ -450,3 +450,92 @@ def test_optimiser_step_in_the_fold_is_bit_identical_on_the_device(B, L, C, monk
     for a, b in zip(*out):
         assert torch.isfinite(a).all()
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("B,T,C", [(512, 81, 12), (64, 81, 30), (3, 82, 12), (1, 83, 4), (16, 41, 4), (7, 10, 4), (129, 40, 12)])
+def test_res8_at_80_mel_bins_vs_oracle(B, T, C):
+    """NUM_MELS = 80, the reference's stock default (settings.py:32; cnn.py:113-145 pools (3,4) over whatever width it is given):
+    20 pooled columns run as two strips of 10 per utterance that fetch each other's edge column in the forward, the data
+    gradient and the weight gradient (csrc/res8.hip, HaloSlot).  Training forward, every gradient, the BatchNorm buffers and the
+    eval forward against the oracle, from a full 512-utterance batch (two strips per workgroup) down to one utterance; odd
+    batches; bit-repeatable."""
+    from gpu_util import res8_oracle_with_kernel_relus
+    names = om.res8_param_names()
+    labels = torch.arange(B) % C
+    torch.manual_seed(B * 100 + T)
+    feats = torch.randn(B, T, 80) * 1.2
+    x = feats.permute(0, 2, 1).unsqueeze(1)
+    model = make_res8(C)
+    logits = model(x.to(DEV), None)
+    torch.nn.functional.cross_entropy(logits, labels.to(DEV)).backward()
+    # One ReLU whose input lies within fp32 rounding of zero comes out on the other side in another summation order and moves a
+    # gradient by O(1 / positions) -- percent level at three utterances, for the oracle against its own fp64 run as much as for
+    # the kernels (measured: 3 of 6 random batches at 3 x 82 frames, 40 or 80 bins alike).  So the comparison shares the
+    # decisions: the kernels' saved ReLU patterns may differ from the oracle's only where the oracle's pre-activation is within
+    # rounding of zero (asserted), and with those patterns the oracle's gradients must match tightly at every batch size.
+    ref, ref_grads, flips, sd = res8_oracle_with_kernel_relus(model, x, labels, B, T, 80, C)
+    assert maxerr(logits, ref) < LOGIT_TOL
+    for n, p in zip(names, model.hot_parameters()):
+        g = ref_grads[n]
+        assert maxerr(p.grad, g) < 2e-5 * max(1.0, g.abs().max().item()), (n, flips)
+    for i in (1, 4, 6):
+        assert maxerr(getattr(model, f"bn{i}").running_mean, sd[f"bn{i}.running_mean"]) < 1e-5
+        assert maxerr(getattr(model, f"bn{i}").running_var, sd[f"bn{i}.running_var"]) < 1e-4
+    # the same step from the same state: the same bits
+    model2 = make_res8(C)
+    logits2 = model2(x.to(DEV), None)
+    torch.nn.functional.cross_entropy(logits2, labels.to(DEV)).backward()
+    assert torch.equal(logits2, logits)
+    for p, q in zip(model.hot_parameters(), model2.hot_parameters()):
+        assert torch.equal(p.grad, q.grad)
+    model.eval()
+    with torch.no_grad():
+        ev = model(x.to(DEV), None)
+    sd_eval = {k: v.detach() for k, v in sd.items()}
+    assert maxerr(ev, om.res8_forward(sd_eval, x.contiguous(), False)) < LOGIT_TOL
+
+
+def test_res8_at_80_mel_bins_long_input_and_fused_step(monkeypatch):
+    """80 mel bins end to end: the frontend (two filterbank banks of 40), the fused trainer step (PCM in, updated weights out:
+    loss inside the forward, AdamW inside the last fold) against the oracle; and clips beyond 83 frames in eval mode (windows x
+    strips)."""
+    from howl_amd.data.transform.operator import ZmuvTransform
+    from howl_amd.data.transform.transform import StandardAudioTransform
+    from howl_amd.settings import SETTINGS
+    from howl_amd.training.fused import FusedRes8Trainer
+    from howl_amd.utils.synth import synthetic_pcm
+    monkeypatch.setattr(SETTINGS.audio_transform, "num_mels", 80)
+    B, L, C = 96, 16000, 12
+    pcm = synthetic_pcm(B, L)
+    labels = torch.arange(B) % C
+    std = StandardAudioTransform().to(DEV).eval()
+    zmuv = ZmuvTransform().to(DEV)
+    zmuv.update(std(pcm[:4].to(DEV)))
+    model = make_res8(C)
+    trainer = FusedRes8Trainer(model, std, zmuv, lr=0.01, weight_decay=1e-5)
+    loss = trainer.step(pcm.to(DEV), labels.to(DEV))
+    grads = [g.clone() for g in trainer.fp.grad_views]
+    fb = ofe.mel_fb(80)
+    z = ofe.Zmuv()
+    z.update(ofe.standard_audio_transform(pcm[:4], fb))
+    x = z(ofe.standard_audio_transform(pcm, fb))
+    assert x.shape[2] == 80
+    sd = om.res8_init(C)
+    names = om.res8_param_names()
+    opt = om.AdamWState([sd[n] for n in names], 0.01, 1e-5)
+    ref_loss, ref_logits, ref_grads = om.train_step(lambda s_, xx: om.res8_forward(s_, xx, True), sd, names, opt, x, labels)
+    assert maxerr(trainer.last_logits, ref_logits) < LOGIT_TOL
+    assert abs(loss.item() - ref_loss.item()) < 1e-4
+    for n, g in zip(names, grads):
+        assert maxerr(g, ref_grads[n]) < 5e-5 * max(1.0, ref_grads[n].abs().max().item()), n
+    for n, p in zip(names, model.hot_parameters()):
+        solid = ref_grads[n].abs() > 1e-5
+        assert maxerr(p.detach().cpu()[solid], sd[n][solid]) < 2e-4, n
+    # long clips, eval mode
+    model.eval()
+    xl = torch.randn(2, 1, 80, 201)
+    with torch.no_grad():
+        ev = model(xl.to(DEV), None)
+    sd_eval = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    ref = om.res8_forward(sd_eval, xl, False)
+    assert maxerr(ev, ref) < 1e-4 * max(1.0, ref.abs().max().item())

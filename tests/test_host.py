@@ -324,20 +324,25 @@ def test_reference_written_workspace_round_trip(golden, tmp_path):
 
 
 def test_res8_warns_about_other_mel_counts_and_the_entry_points_refuse(monkeypatch, caplog):
-    """Stock Howl defaults to NUM_MELS=80 (settings.py:32); the res8 kernels pool (3,4) over 40 bins.  Constructing the model still
-    works (to load / convert / inspect a state_dict, as ``cnn.py:113`` allows) and says so; the entry points, which build the
-    frontend from the same settings, fail before the first batch and name the environment variable."""
+    """The res8 kernels take 40 mel bins (every res8 preset) and 80 (stock Howl's default, settings.py:32).  With any other count,
+    constructing the model still works (to load / convert / inspect a state_dict, as ``cnn.py:113`` allows) and says so; the entry
+    points, which build the frontend from the same settings, fail before the first batch and name the environment variable."""
     import logging
     import pytest
     from howl_amd.model import RegisteredModel
     from howl_amd.model.cnn import require_supported_mels
     from howl_amd.settings import SETTINGS
-    monkeypatch.setattr(SETTINGS.audio_transform, "num_mels", 80)
+    monkeypatch.setattr(SETTINGS.audio_transform, "num_mels", 64)
     with caplog.at_level(logging.WARNING):
         model = RegisteredModel.find_registered_class("res8")(12)
     assert "NUM_MELS=40" in caplog.text
     assert sorted(model.state_dict())[:2] == ["bn1.num_batches_tracked", "bn1.running_mean"]
     with pytest.raises(ValueError, match="NUM_MELS=40"):
         require_supported_mels(model)
-    monkeypatch.setattr(SETTINGS.audio_transform, "num_mels", 40)
-    require_supported_mels(model)
+    for ok in (40, 80):
+        monkeypatch.setattr(SETTINGS.audio_transform, "num_mels", ok)
+        caplog.clear()
+        with caplog.at_level(logging.WARNING):
+            RegisteredModel.find_registered_class("res8")(12)
+        assert "NUM_MELS" not in caplog.text
+        require_supported_mels(model)
