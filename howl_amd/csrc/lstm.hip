@@ -28,7 +28,7 @@ constexpr int HID = 128;
 constexpr int G4 = 4 * HID;          // 512 gate columns, PyTorch order i, f, g, o
 constexpr int LSTM_THREADS = 1024;   // 16 waves
 constexpr int LSTM_WGRAD_SPLITS = 128;
-constexpr int LSTM_MAX_IN = 48;     // input features (mel bins) the workspace is sized for
+constexpr int LSTM_MAX_IN = HOWL_MAX_MELS;   // input features (mel bins) the workspace is sized for: 96 (stock NUM_MELS is 80)
 constexpr int HS = HID + 4;          // LDS row stride of the h tile (16 rows)
 constexpr int DGS = G4 + 4;          // LDS row stride of the dG tile
 
@@ -1076,7 +1076,7 @@ extern "C" {
 
 size_t howl_lstm_workspace_bytes(int B, int T) {
     // packed W_hh of the 16-row recurrences (2 x 64K floats) + bias sum (512) + split-K scratch of the W_hh gradient
-    // (128 x 512 x 128) + the W_ih gradient's own scratch (128 x 512 x 48 at most) + the bias column sums' (256 x 512):
+    // (128 x 512 x 128) + the W_ih gradient's own scratch (128 x 512 x 96 at most) + the bias column sums' (256 x 512):
     // three regions, so that the three final slab sums can run as one launch (the bias region holds one slab per workgroup
     // of the four-sequence recurrence, or the 256 of the column-sum kernel)
     const size_t bias_slabs = (size_t)(B + 3) / 4 > 256 ? (size_t)(B + 3) / 4 : 256;

@@ -485,6 +485,62 @@ def checkpoint_golden():
          zmuv_keys=np.array(list(z2.state_dict().keys())))
 
 
+def wide_golden():
+    """G13: the reference at its STOCK mel count (``NUM_MELS`` unset -> 80, settings.py:32) -- filterbanks, the frontend's
+    output for the six GSC clips (eval and one VTLP draw), ZMUV statistics, and res8 (12 labels) on those features: eval logits,
+    one training step's logits / loss / gradients / BatchNorm buffers, the logits after the AdamW step."""
+    old = SETTINGS.audio_transform.num_mels
+    SETTINGS.audio_transform.num_mels = 80
+    try:
+        clips = [read_wav(GSC / w) for w in WAVS]
+        audio, _ = batchify_like_reference(clips)
+        std = StandardAudioTransform().eval()
+        out = {"audio": audio,
+               "fb_standard": create_vtlp_fb_matrix(257, 0.0, 8000.0, 80, 16000, 1.0, training=False),
+               "fb_vtlp_1.0999": create_vtlp_fb_matrix(257, 0.0, 8000.0, 80, 16000, 1.0999, training=True),
+               "fb_vtlp_0.9": create_vtlp_fb_matrix(257, 0.0, 8000.0, 80, 16000, 0.9, training=True)}
+        feats = std(audio)
+        assert feats.shape == (6, 3, 80, 81)
+        out["feats"] = feats
+        std.train()
+        random.seed(11)
+        assert random.random() < 0.75
+        out["vtlp_alpha"] = random.random() * 0.2 + 0.9
+        random.seed(11)
+        out["mels_vtlp"] = std(audio)[:, 0]
+        std.eval()
+        zmuv = ZmuvTransform()
+        for c in clips:
+            zmuv.update(std(torch.from_numpy(c)[None]))
+        out["zmuv_mean"], out["zmuv_mean2"] = zmuv.mean, zmuv.mean2
+        x = zmuv(feats)
+        C = 12
+        model = RegisteredModel.find_registered_class("res8")(C)
+        model.load_state_dict(om.res8_init(C))
+        model.eval()
+        with torch.no_grad():
+            out["eval_logits"] = model(x, None)
+        labels = torch.arange(x.size(0)) % C
+        model.train()
+        opt = torch.optim.AdamW(model.parameters(), 0.01, weight_decay=1e-5)
+        scores = model(x, None)
+        loss = torch.nn.CrossEntropyLoss()(scores, labels)
+        loss.backward()
+        out["train_logits"], out["loss0"], out["labels"] = scores.detach().clone(), loss.detach().clone(), labels
+        for n, p in model.named_parameters():
+            out["grad0." + n] = p.grad.detach().clone()
+        for i in (1, 6):
+            out[f"bn{i}.running_mean.1"] = getattr(model, f"bn{i}").running_mean.clone()
+            out[f"bn{i}.running_var.1"] = getattr(model, f"bn{i}").running_var.clone()
+        opt.step()
+        model.eval()
+        with torch.no_grad():
+            out["eval_logits_after1"] = model(x, None)
+        save("g13_res8_80mel", **out)
+    finally:
+        SETTINGS.audio_transform.num_mels = old
+
+
 if __name__ == "__main__":
     only = [a for a in sys.argv[1:] if a.startswith("--only-")]
     if not only:
@@ -499,3 +555,5 @@ if __name__ == "__main__":
         phone_context_golden()
     if not only or "--only-checkpoint" in only:
         checkpoint_golden()
+    if not only or "--only-wide" in only:
+        wide_golden()

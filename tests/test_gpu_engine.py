@@ -74,29 +74,39 @@ def test_sequence_engine_matches_reference_history(golden):
         SETTINGS.reset()
 
 
-def test_pretrain_gsc_entry_point_synthetic(tmp_path, monkeypatch):
+@pytest.mark.parametrize("num_mels", ["40", None])
+def test_pretrain_gsc_entry_point_synthetic(tmp_path, monkeypatch, num_mels):
     """`python -m training.run.pretrain_gsc --model res8` flow on generated clips: ZMUV pass, fused training epochs,
-    dev accuracy, workspace artefacts with the reference's file names and state_dict keys."""
+    dev accuracy, workspace artefacts with the reference's file names and state_dict keys.  NUM_MELS=40 as envs/res8.env sets
+    it, and UNSET: the reference's stock default of 80 bins (settings.py:32), what a user without the preset file runs."""
     for k, v in dict(NUM_EPOCHS="4", BATCH_SIZE="64", MAX_WINDOW_SIZE_SECONDS="1", LEARNING_RATE="0.01", LR_DECAY="0.8",
-                     NUM_MELS="40", DEVICE="cuda:0").items():
+                     DEVICE="cuda:0").items():
         monkeypatch.setenv(k, v)
+    if num_mels is None:
+        monkeypatch.delenv("NUM_MELS", raising=False)
+    else:
+        monkeypatch.setenv("NUM_MELS", num_mels)
     from howl_amd.settings import SETTINGS
     SETTINGS.reset()
-    from howl_amd.training.run import pretrain_gsc
-    ws = tmp_path / "ws"
-    pretrain_gsc.main(["--model", "res8", "--workspace", str(ws), "--synthetic", "512"])
-    for name in ("model.pt.bin", "model-best.pt.bin", "zmuv.pt.bin", "settings.json", "cmd-args.json"):
-        assert (ws / name).exists(), name
-    sd = torch.load(ws / "model-best.pt.bin")
-    assert list(sd)[:2] == ["conv0.weight", "bn1.running_mean"] and sd["output.weight"].shape == (30, 45)
-    assert set(torch.load(ws / "zmuv.pt.bin")) == {"total", "mean", "mean2"}
-    import json
-    lines = [json.loads(l) for l in (ws / "logs" / "scalars.jsonl").read_text().splitlines()]
-    losses = [l["value"] for l in lines if l["tag"] == "Training/Loss"]
-    assert len(losses) == 32 and min(losses[-8:]) < losses[0]
-    accs = [l["value"] for l in lines if l["tag"] == "Dev/Metric/acc"]
-    assert len(accs) == 4 and max(accs) > 1.0 / 30     # above chance after a handful of steps on separable tones
-    SETTINGS.reset()
+    assert SETTINGS.audio_transform.num_mels == (80 if num_mels is None else 40)
+    try:
+        from howl_amd.training.run import pretrain_gsc
+        ws = tmp_path / "ws"
+        pretrain_gsc.main(["--model", "res8", "--workspace", str(ws), "--synthetic", "512"])
+        for name in ("model.pt.bin", "model-best.pt.bin", "zmuv.pt.bin", "settings.json", "cmd-args.json"):
+            assert (ws / name).exists(), name
+        sd = torch.load(ws / "model-best.pt.bin")
+        assert list(sd)[:2] == ["conv0.weight", "bn1.running_mean"] and sd["output.weight"].shape == (30, 45)
+        assert set(torch.load(ws / "zmuv.pt.bin")) == {"total", "mean", "mean2"}
+        import json
+        lines = [json.loads(l) for l in (ws / "logs" / "scalars.jsonl").read_text().splitlines()]
+        losses = [l["value"] for l in lines if l["tag"] == "Training/Loss"]
+        assert len(losses) == 32 and min(losses[-8:]) < losses[0]
+        accs = [l["value"] for l in lines if l["tag"] == "Dev/Metric/acc"]
+        assert len(accs) == 4 and max(accs) > 1.0 / 30     # above chance after a handful of steps on separable tones
+    finally:
+        monkeypatch.setenv("NUM_MELS", "40")      # (tests/conftest.py's default for everything else)
+        SETTINGS.reset()
 
 
 def test_device_collate_batch():

@@ -259,3 +259,51 @@ def test_look_ahead_frontend_rides_in_the_forward_call(monkeypatch):
         for a, b in zip(out[0], other):
             assert torch.isfinite(a).all()
             assert torch.equal(a, b)
+
+
+def test_seq_lstm_at_80_mel_bins_vs_oracle(monkeypatch):
+    """NUM_MELS=80 exported (it configures the frontend, settings.py:32, AND the recurrent models' input width, rnn.py:36): the
+    frontend's two filterbank banks, the input projection as its own GEMM (the fused projection is the 40-bin kernel), fused CTC
+    step and the one-batch look-ahead (the next batch's frontend as its own launches behind the recurrence at this width)
+    against the oracle."""
+    from howl_amd.data.transform.operator import ZmuvTransform
+    from howl_amd.data.transform.transform import StandardAudioTransform
+    from howl_amd.model import RegisteredModel
+    from howl_amd.settings import SETTINGS
+    from howl_amd.training.fused import FusedTrainer
+    from howl_amd.utils.synth import synthetic_pcm
+    monkeypatch.setenv("NUM_MELS", "80")
+    monkeypatch.setattr(SETTINGS.audio_transform, "num_mels", 80)
+    B, L, C = 96, 8000, 5
+    pcm = synthetic_pcm(B, L)
+    std = StandardAudioTransform().to(DEV).eval()
+    zmuv = ZmuvTransform().to(DEV)
+    zmuv.update(std(pcm[:4].to(DEV)))
+    sd0 = om.lstm_init(C, num_mels=80)
+    model = RegisteredModel.find_registered_class("seq-lstm")(C)
+    assert model.lstm.input_size == 80
+    model.load_state_dict({k: v.clone() for k, v in sd0.items()})
+    model = model.to(DEV).train()
+    lengths = torch.sort(20 + torch.arange(B) % 19, descending=True).values
+    targets = torch.tensor([[0, 1, 2]] * B)
+    tl = torch.tensor([3] * B)
+    tr = FusedTrainer(model, std, zmuv, lr=1e-3, weight_decay=1e-5)
+    pcm2 = synthetic_pcm(B, L, seed=7)
+    loss = tr.step_sequence(pcm.to(DEV), lengths, targets, tl, 4, next_audio=pcm2.to(DEV))
+    grads = [g.clone() for g in tr.fp.grad_views]
+    fb = ofe.mel_fb(80)
+    z = ofe.Zmuv()
+    z.update(ofe.standard_audio_transform(pcm[:4], fb))
+    x_ref = z(ofe.standard_audio_transform(pcm, fb))
+    sd = {k: v.clone().requires_grad_(True) for k, v in sd0.items()}
+    ref, _ = om.seq_lstm_forward(sd, x_ref, lengths)
+    ref_loss = torch.nn.CTCLoss(4)(torch.log_softmax(ref, -1), targets, lengths, tl)
+    ref_loss.backward()
+    assert abs(loss.item() - ref_loss.item()) < 1e-4
+    for n, g in zip(om.lstm_param_names(), grads):       # (hot_parameters() order)
+        r = sd[n].grad
+        assert maxerr(g, r) < 1e-4 * max(1.0, r.abs().max().item()), n
+    # the look-ahead features are the frontend's own
+    assert tr._ahead is not None and torch.equal(tr._ahead[1], std.log_mel_for_model(pcm2.to(DEV), zmuv))
+    loss2 = tr.step_sequence(pcm2.to(DEV), lengths, targets, tl, 4)
+    assert torch.isfinite(loss2).all()

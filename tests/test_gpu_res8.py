@@ -539,3 +539,49 @@ def test_res8_at_80_mel_bins_long_input_and_fused_step(monkeypatch):
     sd_eval = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     ref = om.res8_forward(sd_eval, xl, False)
     assert maxerr(ev, ref) < 1e-4 * max(1.0, ref.abs().max().item())
+
+
+def test_golden_stock_80_mel_bins(golden, monkeypatch):
+    """G13: outputs of the REFERENCE's classes at its stock NUM_MELS = 80 (settings.py:32) for the six GSC clips -- the frontend
+    module (eval and the recorded VTLP draw), then res8 on the reference's own features: eval logits, one training step's logits /
+    loss / every gradient / BatchNorm buffers, and the logits after the AdamW step."""
+    import random
+    from howl_amd.data.transform.transform import StandardAudioTransform
+    from howl_amd.settings import SETTINGS
+    from gpu_util import t
+    g = golden("g13_res8_80mel")
+    monkeypatch.setattr(SETTINGS.audio_transform, "num_mels", 80)
+    std = StandardAudioTransform().to(DEV).eval()
+    audio = t(g["audio"]).to(DEV)
+    feats = std(audio)
+    ref = t(g["feats"])
+    d = (feats[:, 0].cpu() - ref[:, 0]).abs()
+    assert d.max().item() < 2e-3 and d[ref[:, 0] > -8].max().item() < 2e-4
+    std.train()
+    random.seed(11)
+    out = std(audio, mels_only=True)
+    assert abs(std.last_vtlp_alpha - float(g["vtlp_alpha"])) == 0.0
+    d = (out.cpu() - t(g["mels_vtlp"])).abs()
+    assert d.max().item() < 2e-3 and d[t(g["mels_vtlp"]) > -8].max().item() < 2e-4
+    z = ofe.Zmuv()
+    z.mean, z.mean2 = t(g["zmuv_mean"]), t(g["zmuv_mean2"])
+    x = z(ref).to(DEV)
+    C = 12
+    model = make_res8(C, train=False)
+    with torch.no_grad():
+        assert maxerr(model(x, None), g["eval_logits"]) < LOGIT_TOL
+    model.train()
+    opt = torch.optim.AdamW(model.parameters(), 0.01, weight_decay=1e-5)
+    sc = model(x, None)
+    loss = torch.nn.functional.cross_entropy(sc, t(g["labels"]).to(DEV))
+    loss.backward()
+    assert maxerr(sc, g["train_logits"]) < LOGIT_TOL and abs(loss.item() - float(g["loss0"])) < 1e-4
+    for n, p in model.named_parameters():
+        assert maxerr(p.grad, g["grad0." + n]) < 5e-5 * max(1.0, float(np.abs(g["grad0." + n]).max())), n
+    for i in (1, 6):
+        assert maxerr(getattr(model, f"bn{i}").running_mean, g[f"bn{i}.running_mean.1"]) < 1e-5
+        assert maxerr(getattr(model, f"bn{i}").running_var, g[f"bn{i}.running_var.1"]) < 1e-4
+    opt.step()
+    model.eval()
+    with torch.no_grad():
+        assert maxerr(model(x, None), g["eval_logits_after1"]) < 2e-3

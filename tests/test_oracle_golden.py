@@ -247,3 +247,33 @@ def test_g7b_collate_chain(golden):
         assert [o.numel() for o in out] == g[f"out_len_{trial}"].tolist()
         # torch's CPU generator is the reference's too: same seed, same noise samples, bit-identical first samples
         assert np.array_equal(np.array([float(o[0]) for o in out]), g[f"first_{trial}"])
+
+
+def test_g13_stock_80_mel_bins(golden):
+    """G13: the reference at its stock NUM_MELS = 80 (settings.py:32) -- filterbanks, frontend, ZMUV, res8 eval / one training step."""
+    g = golden("g13_res8_80mel")
+    assert torch.equal(fe.mel_fb(80), t(g["fb_standard"]))
+    for a in ("0.9", "1.0999"):
+        assert torch.equal(fe.mel_fb(80, alpha=float(a)), t(g[f"fb_vtlp_{a}"])), a
+    audio = t(g["audio"])
+    fb = fe.mel_fb(80)
+    feats = fe.standard_audio_transform(audio, fb)
+    close(feats, g["feats"])
+    close(fe.standard_audio_transform(audio, fe.mel_fb(80, alpha=float(g["vtlp_alpha"])), mels_only=True), g["mels_vtlp"])
+    z = fe.Zmuv()
+    z.mean, z.mean2 = t(g["zmuv_mean"]), t(g["zmuv_mean2"])
+    x = z(t(g["feats"]))
+    C = 12
+    sd = om.res8_init(C)
+    close(om.res8_forward(sd, x, False), g["eval_logits"], 1e-6)
+    names = om.res8_param_names()
+    opt = om.AdamWState([sd[n] for n in names], 0.01, 1e-5)
+    loss, logits, grads = om.train_step(lambda s, xx: om.res8_forward(s, xx, True), sd, names, opt, x, t(g["labels"]))
+    close(loss, g["loss0"], 2e-6)
+    close(logits, g["train_logits"], 2e-6)
+    for n in names:
+        close(grads[n], g["grad0." + n], 2e-6)
+    for i in (1, 6):
+        close(sd[f"bn{i}.running_mean"], g[f"bn{i}.running_mean.1"])
+        close(sd[f"bn{i}.running_var"], g[f"bn{i}.running_var.1"])
+    close(om.res8_forward(sd, x, False), g["eval_logits_after1"], 2e-4)
