@@ -66,14 +66,15 @@ constexpr int MAX_H = 27;
 constexpr float BN_EPS = 1e-5f;
 constexpr float BN_MOMENTUM = 0.1f;
 
-__host__ __device__ inline int chan_stride(int H) {
+__host__ __device__ inline int chan_stride(int H, bool own_rows = false) {
     // (H+1) rows of 12 (top halo + data; the bottom halo is the next channel's top halo), padded so that
     // CS = 17 (mod 32): position-major reads (forward/dgrad) and channel-major reads (wgrad) both spread over banks
-    int cs = (H + 1) * WP;
+    // (own_rows: H+2 rows -- row strips of a long map fetch REAL halo rows from their neighbours, see StripGeom)
+    int cs = (H + (own_rows ? 2 : 1)) * WP;
     int pad = (17 - (cs % 32) + 32) % 32;
     return cs + pad;
 }
-__host__ __device__ inline int tile_floats(int H) { return CP * chan_stride(H) + 32; }
+__host__ __device__ inline int tile_floats(int H, bool own_rows = false) { return CP * chan_stride(H, own_rows) + 32; }
 constexpr int WPW = 13;          // row pitch of the weight-gradient kernel's x tile (see wgrad_body)
 // weight-gradient GEMM (wgrad_body): M = cout, N = (tap, cin) FLATTENED: column idx = 45 * tap + cin, 405 columns in 26 tiles of 16 (rounds 1-3 padded every tap to 48
 // columns: 27 tiles).  78 accumulator chains (26 N tiles x 3 cout tiles) instead of 81: with two whole N tiles per wave and the
@@ -305,11 +306,22 @@ __device__ __forceinline__ void region_slots(int (&pk)[NSL], int c0, int nch, in
         pk[j] = (e < nch * P) ? (((c0 + c) * CS + (h + 1) * WP + (w + 1)) | ((c0 + c) << 20)) : -1;
     }
 }
+// the same, plus bit j of `padbits` = slot j lies in a row >= hv (StripGeom: rows beyond a last row strip's valid ones)
+template <int NSL>
+__device__ __forceinline__ void region_slots_pad(int (&pk)[NSL], int c0, int nch, int P, int CS, int tid, int hv, unsigned& padbits) {
+    region_slots<NSL>(pk, c0, nch, P, CS, tid);
+#pragma unroll
+    for (int j = 0; j < NSL; ++j) {
+        const int e = 2 * (tid + j * CONV_THREADS);
+        const int p = e % P;
+        if (pk[j] >= 0 && p / PW >= hv) padbits |= 1u << j;
+    }
+}
 
 // `base` = float offset of (utterance, region) in every tensor of the configuration (uniform: the addresses are "scalar base
 // + 32-bit lane offset", no 64-bit address lives in a VGPR).  Unconditional loads from clamped offsets (a load under a lane
 // predicate waits for the one before it): slots without an element re-read the region's first.
-template <int MODE, bool HALO = false>
+template <int MODE, int HALO = 0>
 __device__ __forceinline__ void slot_load(SlotVal& v, const StageCfg& cfg, size_t base, int i2, int pkj, int b) {
     HOWL_OPAQUE_V(pkj);
     const unsigned off = pkj >= 0 ? 8u * (unsigned)i2 : 0u;
@@ -318,7 +330,7 @@ __device__ __forceinline__ void slot_load(SlotVal& v, const StageCfg& cfg, size_
             v.a = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(cfg.a + base) + off);
         } else {
             const unsigned c4 = pkj >= 0 ? 4u * (unsigned)(pkj >> 20) : 0u;
-            const float g = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(cfg.dpool + (size_t)(HALO ? b >> 1 : b) * CP) + c4) * cfg.invP;
+            const float g = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(cfg.dpool + (size_t)(HALO == 1 ? b >> 1 : b) * CP) + c4) * cfg.invP;
             v.a = make_float2(g, g);
         }
         v.s = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(cfg.s + base) + off);
@@ -346,7 +358,7 @@ __device__ __forceinline__ void bn_relu_bwd_pair(const SlotVal& v, const float* 
 
 template <int MODE>
 __device__ __forceinline__ void slot_write(const SlotVal& v, const StageCfg& cfg, size_t base, int i2, int pkj, float* tile,
-                                           const float* lm) {
+                                           const float* lm, bool zero = false /* a row beyond the strip's valid ones: see StripGeom */) {
     HOWL_OPAQUE_V(pkj);
     if (pkj < 0) return;
     const int c = pkj >> 20;
@@ -369,6 +381,7 @@ __device__ __forceinline__ void slot_write(const SlotVal& v, const StageCfg& cfg
         v0 = dz.x;
         v1 = dz.y;
     }
+    if (zero) v0 = v1 = 0.0f;
     float* d = tile + (pkj & 0xFFFFF);
     d[0] = v0;
     d[1] = v1;
@@ -432,6 +445,117 @@ __device__ __forceinline__ void halo_write(const SlotVal& v, const StageCfg& cfg
     tile[(hs.pk & 0xFFFFF) + lcol] = v0;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Long maps (HALO == 2; training windows beyond 83 frames, cnn.py:127-145 accepts any T): more than 27 pooled rows do not
+// fit the tile either, so an utterance is cut into nr ROW strips of H rows (and, at 80 mel bins, ns = 2 column strips each):
+// virtual utterance v = (b * nr + r) * ns + c, every one a (45, H, 10) block.  Row strips fetch REAL halo rows -- the last row
+// of strip r - 1 above, the first of strip r + 1 below, twelve columns each: the two corners come from the diagonal
+// neighbours -- into a tile that has a top AND a bottom halo row per channel (chan_stride(H, true)); strips without a
+// neighbour on a side get zeros written there (a workgroup walks strips of every kind).  H * nr may exceed the map: the LAST row
+// strip then owns hv_last < H rows, and its rows beyond are "outside the image": zero on the way into every tile (they hold
+// whatever the previous layer's launch computed there), left out of every sum over positions (statistics, pooled sums,
+// weight gradients), never read by a neighbour.  The column halo of HALO == 1 rides along when ns == 2.
+// ---------------------------------------------------------------------------------------------------------
+struct StripGeom {
+    int nr, ns, hv_last;
+};
+struct StripPos {
+    int r, c, hv, bu;   // row strip, column strip, valid rows, utterance
+};
+__device__ __forceinline__ StripPos strip_pos(const StripGeom& g, int v, int H) {
+    StripPos p;
+    const int q = v / g.ns;
+    p.c = v - q * g.ns;
+    p.bu = q / g.nr;
+    p.r = q - p.bu * g.nr;
+    p.hv = (p.r == g.nr - 1) ? g.hv_last : H;
+    return p;
+}
+struct EdgeSlot {
+    int pk;   // LDS float offset of the element in the tile (top halo row for row slots) | channel << 20; -1 = no element
+    int g;    // float offset inside the SOURCE block: channel * P + (column halo: h * 10; row halo: source column)
+    int aux;  // column halo: the element's row h; row halo: column-strip delta of the source block (-1, 0, +1)
+};
+__device__ __forceinline__ EdgeSlot col_edge_slot(int c0, int nch, int H, int P, int CS, int tid) {
+    const int c = tid / H, h = tid - c * H;
+    const bool ok = tid < nch * H;
+    return EdgeSlot{ok ? (((c0 + c) * CS + (h + 1) * WP) | ((c0 + c) << 20)) : -1, ok ? (c0 + c) * P + h * PW : 0, ok ? h : 0};
+}
+__device__ __forceinline__ EdgeSlot row_edge_slot(int c0, int nch, int P, int CS, int tid) {
+    const int c = tid / WP, w = tid - c * WP;              // tile column w = map column w - 1
+    const bool ok = tid < nch * WP;
+    const int dc = w == 0 ? -1 : (w == WP - 1 ? 1 : 0);
+    const int col = w == 0 ? PW - 1 : (w == WP - 1 ? 0 : w - 1);
+    return EdgeSlot{ok ? (((c0 + c) * CS + w) | ((c0 + c) << 20)) : -1, ok ? (c0 + c) * P + col : 0, ok ? dc : 0};
+}
+// one element of block `blk` at float offset `off` inside it, through the configuration's staging arithmetic; !valid: zero
+template <int MODE>
+__device__ __forceinline__ void edge_load(SlotVal& v, const StageCfg& cfg, int blk, int off, bool valid, int chan, int bu, int P) {
+    const size_t idx = valid ? (size_t)blk * NMAP * P + (size_t)off : 0;
+    v.s = v.k = make_float2(0.0f, 0.0f);
+    if (MODE == 1 && cfg.fused) {
+        v.a.x = cfg.a != nullptr ? cfg.a[idx] : cfg.dpool[(size_t)bu * CP + chan] * cfg.invP;
+        v.s.x = cfg.s[idx];
+        if (cfg.k != nullptr) v.k.x = cfg.k[idx];
+    } else {
+        v.a.x = cfg.a[idx];
+    }
+    v.a.y = v.a.x;
+}
+template <int MODE>
+__device__ __forceinline__ void edge_write(const SlotVal& v, const StageCfg& cfg, int pk, int lds_extra, bool valid, float* tile,
+                                           const float* lm) {
+    if (pk < 0) return;
+    const int c = pk >> 20;
+    float v0 = v.a.x;
+    if (MODE == 0) {
+        v0 = fabsf(v0);
+        if (cfg.affine) v0 = fmaf(v0, lm[CP + c], lm[c]);
+    } else if (cfg.fused) {
+        float2 ds, dz;
+        bn_relu_bwd_pair(v, lm + c, cfg.even, ds, dz);
+        v0 = dz.x;
+    }
+    tile[(pk & 0xFFFFF) + lds_extra] = valid ? v0 : 0.0f;
+}
+// what a HALO == 2 workgroup carries through its utterance loop: geometry, the edge slots of the two channel regions, the
+// pad bits of the regular slots (rows >= hv_last: zeroed in the last row strips)
+struct GridCtx {
+    StripGeom sg;
+    EdgeSlot col[2], row[2];
+    unsigned pad[2];
+};
+// all three edges of region `reg` for strip v: loads (three SlotVals), then writes
+template <int MODE>
+__device__ __forceinline__ void grid_load(SlotVal (&e)[3], const StageCfg& cfg, const GridCtx& gx, int reg, int v, int H, int P) {
+    const StripPos p = strip_pos(gx.sg, v, H);
+    {   // column halo (ns == 2): the neighbour strip of the same row strip, its edge column; rows >= hv are outside the image
+        const EdgeSlot& es = gx.col[reg];
+        const bool valid = gx.sg.ns == 2 && es.pk >= 0 && es.aux < p.hv;
+        edge_load<MODE>(e[0], cfg, v ^ 1, es.g + (p.c ? PW - 1 : 0), valid, es.pk >= 0 ? es.pk >> 20 : 0, p.bu, P);
+    }
+    const EdgeSlot& rs = gx.row[reg];
+    const int cc = p.c + rs.aux;
+    const bool colok = rs.pk >= 0 && cc >= 0 && cc < gx.sg.ns;
+    const int chan = rs.pk >= 0 ? rs.pk >> 20 : 0;
+    edge_load<MODE>(e[1], cfg, v - gx.sg.ns + rs.aux, rs.g + (H - 1) * PW, colok && p.r > 0, chan, p.bu, P);            // row above
+    edge_load<MODE>(e[2], cfg, v + gx.sg.ns + rs.aux, rs.g, colok && p.r < gx.sg.nr - 1, chan, p.bu, P);                // row below
+}
+template <int MODE>
+__device__ __forceinline__ void grid_write(const SlotVal (&e)[3], const StageCfg& cfg, const GridCtx& gx, int reg, int v, int H,
+                                           float* tile, const float* lm) {
+    const StripPos p = strip_pos(gx.sg, v, H);
+    if (gx.sg.ns == 2) {
+        const EdgeSlot& es = gx.col[reg];
+        edge_write<MODE>(e[0], cfg, es.pk, p.c ? 0 : WP - 1, es.aux < p.hv, tile, lm);
+    }
+    const EdgeSlot& rs = gx.row[reg];
+    const int cc = p.c + rs.aux;
+    const bool colok = cc >= 0 && cc < gx.sg.ns;
+    edge_write<MODE>(e[1], cfg, rs.pk, 0, colok && p.r > 0, tile, lm);
+    edge_write<MODE>(e[2], cfg, rs.pk, (H + 1) * WP, colok && p.r < gx.sg.nr - 1, tile, lm);
+}
+
 struct ConvEpilogue {
     const float* res;
     float* out;
@@ -465,9 +589,10 @@ struct EpiAddr {
     }
 };
 
-template <int MODE, int NTW, int TS>
+template <int MODE, int NTW, int TS, int HALO = 0>
 __device__ __forceinline__ void conv_epilogue(const f32x4 (&acc)[NTW], const float2 (&ev)[NTW > 0 ? NTW : 1][2], const ConvEpilogue& e,
-                                              size_t ubase, int t0, int lane, float& st0, float& st1, int b) {
+                                              size_t ubase, int t0, int lane, float& st0, float& st1, int b,
+                                              int pv = 0 /* HALO == 2: positions >= pv are outside the image (no part in the sums) */) {
     const EpiAddr<NTW, TS> ea(e, t0, lane);
     constexpr int ts = TS;
     char* obase = reinterpret_cast<char*>(e.out + ubase);
@@ -490,11 +615,13 @@ __device__ __forceinline__ void conv_epilogue(const f32x4 (&acc)[NTW], const flo
                         const bool k0 = v0 > 0.0f, k1 = v1 > 0.0f;
                         v0 += fabsf(r.x);
                         v1 += fabsf(r.y);
-                        u0 += v0 + v1;
-                        u1 += v0 * v0 + v1 * v1;
+                        if (HALO != 2 || m < pv) {
+                            u0 += v0 + v1;
+                            u1 += v0 * v0 + v1 * v1;
+                        }
                         v0 = k0 ? -v0 : v0;
                         v1 = k1 ? -v1 : v1;
-                    } else {
+                    } else if (HALO != 2 || m < pv) {
                         u0 += v0 + v1;
                         u1 += v0 * v0 + v1 * v1;
                     }
@@ -503,7 +630,7 @@ __device__ __forceinline__ void conv_epilogue(const f32x4 (&acc)[NTW], const flo
                     if (e.xadd) {
                         v0 += sv.x;
                         v1 += sv.y;
-                    } else {
+                    } else if (HALO != 2 || m < pv) {
                         u0 += v0 + v1;
                         u1 += v0 * fmaf(fabsf(sv.x), e.xrstd, e.xshift) + v1 * fmaf(fabsf(sv.y), e.xrstd, e.xshift);
                     }
@@ -538,10 +665,11 @@ struct ConvLoop {
 // All utterances b, b + nblk, ... of this workgroup; on entry channels 0..23 of utterance b are in the tile (barrier passed).
 // Instantiated once per tile count (waves of one workgroup run different instances; every instance executes the same two
 // barriers per utterance): the register allocator then sees one variant's live values, not the union of all five.
-template <int MODE, int NTW, int TS, bool HALO = false>
+template <int MODE, int NTW, int TS, int HALO = 0>
 __device__ __forceinline__ void conv_loop(const ConvLoop& c, const ConvEpilogue& epi, const StageCfg& cfg, const int (&pk0)[NS0],
                                           const int (&pk1)[NS1], int b, float& st0, float& st1, int& pslot,
-                                          const HaloSlot (&hs)[2] = {HaloSlot{-1, 0}, HaloSlot{-1, 0}}) {
+                                          const HaloSlot (&hs)[2] = {HaloSlot{-1, 0}, HaloSlot{-1, 0}},
+                                          const GridCtx& gx = GridCtx{}) {
     const int P = epi.P, tid = c.tid, lane = c.lane;
     const int wave = tid >> 6;
     const size_t r1 = (size_t)SPLIT_C * P;
@@ -561,6 +689,16 @@ __device__ __forceinline__ void conv_loop(const ConvLoop& c, const ConvEpilogue&
         const bool more = bn < c.B;                       // (uniform)
         const size_t nbase = (size_t)bn * NMAP * P;
         SlotVal v[3];
+        // HALO == 2: three edge values per region (column halo, row above, row below), the utterance index for the pooled
+        // gradient's broadcast, and whether this strip / the next one is a last row strip (rows >= hv_last: zeros)
+        SlotVal ge[3];
+        int bsl = b, bnsl = bn, pv = P;
+        bool zb = false, zn = false;
+        if constexpr (HALO == 2) {
+            const StripPos pb = strip_pos(gx.sg, b, P / PW), pn = strip_pos(gx.sg, more ? bn : b, P / PW);
+            bsl = pb.bu, bnsl = pn.bu, pv = pb.hv * PW;
+            zb = pb.hv < P / PW, zn = pn.hv < P / PW;
+        }
         f32x4 acc[NTV];
         KCursor<NTV> k;
         if constexpr (NTW > 0) k_begin<NTW, TS>(k, acc, c.ltile, c.wnt, c.CS, P, c.t0, lane);
@@ -571,28 +709,30 @@ __device__ __forceinline__ void conv_loop(const ConvLoop& c, const ConvEpilogue&
 #define HOWL_WINO_CHUNK() ((void)0)
 #define HOWL_WINO_BAR() ((void)0)
         if constexpr (STAGE) {
-            slot_load<MODE, HALO>(v[0], cfg, ubase + r1, tid, pk1[0], b);
-            slot_load<MODE, HALO>(v[1], cfg, ubase + r1, tid + CONV_THREADS, pk1[1], b);
-            if constexpr (HALO) halo_load<MODE>(v[2], cfg, (size_t)(b ^ 1) * NMAP * P, hs[1], gcol, b);
+            slot_load<MODE, HALO>(v[0], cfg, ubase + r1, tid, pk1[0], bsl);
+            slot_load<MODE, HALO>(v[1], cfg, ubase + r1, tid + CONV_THREADS, pk1[1], bsl);
+            if constexpr (HALO == 1) halo_load<MODE>(v[2], cfg, (size_t)(b ^ 1) * NMAP * P, hs[1], gcol, b);
+            if constexpr (HALO == 2) grid_load<MODE>(ge, cfg, gx, 1, b, P / PW, P);
         }
         HOWL_STAIR(3);
         HOWL_WINO_CHUNK();
         if constexpr (NTW > 0) k_run<NTW>(k, acc, c.CS, a0);
         HOWL_WINO_BAR();
         if constexpr (STAGE) {
-            slot_write<MODE>(v[0], cfg, ubase + r1, tid, pk1[0], c.tile, c.lm);
-            slot_write<MODE>(v[1], cfg, ubase + r1, tid + CONV_THREADS, pk1[1], c.tile, c.lm);
-            if constexpr (HALO) halo_write<MODE>(v[2], cfg, hs[1], lcol, c.tile, c.lm);
-            slot_load<MODE, HALO>(v[0], cfg, ubase + r1, tid + 2 * CONV_THREADS, pk1[2], b);
-            slot_load<MODE, HALO>(v[1], cfg, ubase + r1, tid + 3 * CONV_THREADS, pk1[3], b);
+            slot_write<MODE>(v[0], cfg, ubase + r1, tid, pk1[0], c.tile, c.lm, HALO == 2 && zb && ((gx.pad[1] >> 0) & 1));
+            slot_write<MODE>(v[1], cfg, ubase + r1, tid + CONV_THREADS, pk1[1], c.tile, c.lm, HALO == 2 && zb && ((gx.pad[1] >> 1) & 1));
+            if constexpr (HALO == 1) halo_write<MODE>(v[2], cfg, hs[1], lcol, c.tile, c.lm);
+            if constexpr (HALO == 2) grid_write<MODE>(ge, cfg, gx, 1, b, P / PW, c.tile, c.lm);
+            slot_load<MODE, HALO>(v[0], cfg, ubase + r1, tid + 2 * CONV_THREADS, pk1[2], bsl);
+            slot_load<MODE, HALO>(v[1], cfg, ubase + r1, tid + 3 * CONV_THREADS, pk1[3], bsl);
         }
         HOWL_STAIR(2);
         HOWL_WINO_CHUNK();
         if constexpr (NTW > 0) k_run<NTW>(k, acc, c.CS, a1);
         HOWL_WINO_BAR();
         if constexpr (STAGE) {
-            slot_write<MODE>(v[0], cfg, ubase + r1, tid + 2 * CONV_THREADS, pk1[2], c.tile, c.lm);
-            slot_write<MODE>(v[1], cfg, ubase + r1, tid + 3 * CONV_THREADS, pk1[3], c.tile, c.lm);
+            slot_write<MODE>(v[0], cfg, ubase + r1, tid + 2 * CONV_THREADS, pk1[2], c.tile, c.lm, HALO == 2 && zb && ((gx.pad[1] >> 2) & 1));
+            slot_write<MODE>(v[1], cfg, ubase + r1, tid + 3 * CONV_THREADS, pk1[3], c.tile, c.lm, HALO == 2 && zb && ((gx.pad[1] >> 3) & 1));
         }
         HOWL_STAIR(1);
         HOWL_WINO_CHUNK();
@@ -605,30 +745,32 @@ __device__ __forceinline__ void conv_loop(const ConvLoop& c, const ConvEpilogue&
         // ---- phase B: channels 24..44 feed the matrix pipe, channels 0..23 of the NEXT utterance arrive
         if constexpr (NTW > 0) k_prime<NTW>(k);      // (what the last step of phase A requested ahead predates the barrier)
         if (STAGE && more) {
-            slot_load<MODE, HALO>(v[0], cfg, nbase, tid, pk0[0], bn);
-            slot_load<MODE, HALO>(v[1], cfg, nbase, tid + CONV_THREADS, pk0[1], bn);
-            slot_load<MODE, HALO>(v[2], cfg, nbase, tid + 2 * CONV_THREADS, pk0[2], bn);
+            slot_load<MODE, HALO>(v[0], cfg, nbase, tid, pk0[0], bnsl);
+            slot_load<MODE, HALO>(v[1], cfg, nbase, tid + CONV_THREADS, pk0[1], bnsl);
+            slot_load<MODE, HALO>(v[2], cfg, nbase, tid + 2 * CONV_THREADS, pk0[2], bnsl);
+            if constexpr (HALO == 2) grid_load<MODE>(ge, cfg, gx, 0, bn, P / PW, P);
         }
         HOWL_STAIR(3);
         HOWL_WINO_CHUNK();
         if constexpr (NTW > 0) k_run<NTW>(k, acc, c.CS, b0);
         HOWL_WINO_BAR();
         if (STAGE && more) {
-            slot_write<MODE>(v[0], cfg, nbase, tid, pk0[0], c.tile, c.lm);
-            slot_write<MODE>(v[1], cfg, nbase, tid + CONV_THREADS, pk0[1], c.tile, c.lm);
-            slot_write<MODE>(v[2], cfg, nbase, tid + 2 * CONV_THREADS, pk0[2], c.tile, c.lm);
-            slot_load<MODE, HALO>(v[0], cfg, nbase, tid + 3 * CONV_THREADS, pk0[3], bn);
-            slot_load<MODE, HALO>(v[1], cfg, nbase, tid + 4 * CONV_THREADS, pk0[4], bn);
-            if constexpr (HALO) halo_load<MODE>(v[2], cfg, (size_t)(bn ^ 1) * NMAP * P, hs[0], gcol, bn);
+            slot_write<MODE>(v[0], cfg, nbase, tid, pk0[0], c.tile, c.lm, HALO == 2 && zn && ((gx.pad[0] >> 0) & 1));
+            slot_write<MODE>(v[1], cfg, nbase, tid + CONV_THREADS, pk0[1], c.tile, c.lm, HALO == 2 && zn && ((gx.pad[0] >> 1) & 1));
+            slot_write<MODE>(v[2], cfg, nbase, tid + 2 * CONV_THREADS, pk0[2], c.tile, c.lm, HALO == 2 && zn && ((gx.pad[0] >> 2) & 1));
+            if constexpr (HALO == 2) grid_write<MODE>(ge, cfg, gx, 0, bn, P / PW, c.tile, c.lm);
+            slot_load<MODE, HALO>(v[0], cfg, nbase, tid + 3 * CONV_THREADS, pk0[3], bnsl);
+            slot_load<MODE, HALO>(v[1], cfg, nbase, tid + 4 * CONV_THREADS, pk0[4], bnsl);
+            if constexpr (HALO == 1) halo_load<MODE>(v[2], cfg, (size_t)(bn ^ 1) * NMAP * P, hs[0], gcol, bn);
         }
         HOWL_STAIR(2);
         HOWL_WINO_CHUNK();
         if constexpr (NTW > 0) k_run<NTW>(k, acc, c.CS, b1);
         HOWL_WINO_BAR();
         if (STAGE && more) {
-            slot_write<MODE>(v[0], cfg, nbase, tid + 3 * CONV_THREADS, pk0[3], c.tile, c.lm);
-            slot_write<MODE>(v[1], cfg, nbase, tid + 4 * CONV_THREADS, pk0[4], c.tile, c.lm);
-            if constexpr (HALO) halo_write<MODE>(v[2], cfg, hs[0], lcol, c.tile, c.lm);
+            slot_write<MODE>(v[0], cfg, nbase, tid + 3 * CONV_THREADS, pk0[3], c.tile, c.lm, HALO == 2 && zn && ((gx.pad[0] >> 3) & 1));
+            slot_write<MODE>(v[1], cfg, nbase, tid + 4 * CONV_THREADS, pk0[4], c.tile, c.lm, HALO == 2 && zn && ((gx.pad[0] >> 4) & 1));
+            if constexpr (HALO == 1) halo_write<MODE>(v[2], cfg, hs[0], lcol, c.tile, c.lm);
         }
         // the epilogue's operands take the registers the staging slots just released; they land under the last K segment
         float2 ev[NTV][2];
@@ -650,7 +792,7 @@ __device__ __forceinline__ void conv_loop(const ConvLoop& c, const ConvEpilogue&
         // the epilogue runs in front of the barrier: the waves of a SIMD leave the K loop a few hundred cycles apart, and an
         // early one's stores go out under the others' last MFMAs (behind the barrier all twelve epilogues ran with the matrix
         // pipe idle: +1.6 us per forward launch, tools/variants4.py)
-        if constexpr (NTW > 0) conv_epilogue<MODE, NTW, TS>(acc, ev, epi, ubase, c.t0, lane, st0, st1, b);
+        if constexpr (NTW > 0) conv_epilogue<MODE, NTW, TS, HALO>(acc, ev, epi, ubase, c.t0, lane, st0, st1, b, pv);
         HOWL_PROBE(cfg, wave, lane, pslot++);   // epilogue done
         __syncthreads();      // channels 0..23 of the next utterance complete; every wave is past its reads of 24..44
         HOWL_PROBE(cfg, wave, lane, pslot++);   // barrier
@@ -702,7 +844,7 @@ struct WFold {
 
 // MODE 0: forward   out = relu(conv(x)) [+ res]; stats = (sum, sumsq) of out per cout
 // MODE 1: dgrad     out = conv(dz);              stats = (sum out, sum out * xhat) per cout, xhat from s_prev
-template <int MODE, int SLICES, bool HALO = false>
+template <int MODE, int SLICES, int HALO = 0>
 __device__ __forceinline__ void conv3x3_body(
     StageCfg cfg,                         // the input tile (see StageCfg)
     const float* __restrict__ in_stats,   // forward: {mean[48], rstd[48]} applied on load, or nullptr
@@ -717,11 +859,12 @@ __device__ __forceinline__ void conv3x3_body(
     int slice,                            // small batches: SLICES (1, 2, 4) workgroups share every utterance's position tiles
     const BnFold& fold,                   // forward: the input's BatchNorm statistics still as partials (or part == nullptr)
     const BwdFold& bfold,                 // fused data gradient: where m1 / m2 come from
-    const WFold& wf = WFold{nullptr, 0, nullptr}) {   // data gradient: weight-gradient partials to fold at the end
+    const WFold& wf = WFold{nullptr, 0, nullptr},     // data gradient: weight-gradient partials to fold at the end
+    const StripGeom& sg = StripGeom{1, 1, 0}) {       // HALO == 2: how the utterances of this launch are strips of longer maps
     HIP_DYNAMIC_SHARED(float, lds)
     const int P = H * PW;
-    const int CS = chan_stride(H);
-    const int TF = tile_floats(H);
+    const int CS = chan_stride(H, HALO == 2);
+    const int TF = tile_floats(H, HALO == 2);
     float* wl = lds;                       // [3][102][64] weight fragments
     float* tile = lds + 3 * KSTEPS * 64;   // one utterance's zero-haloed input map
     float* lm = tile + TF;                 // forward: [-mean * rstd | rstd][48]; data gradient: [A | Bc | Cc][48] (bn_relu_bwd_pair)
@@ -747,10 +890,22 @@ __device__ __forceinline__ void conv3x3_body(
     if (slice != 0) cfg.ds = nullptr;      // one writer per utterance
 
     int pk0[NS0], pk1[NS1];
-    region_slots<NS0>(pk0, 0, SPLIT_C, P, CS, tid);
-    region_slots<NS1>(pk1, SPLIT_C, NMAP - SPLIT_C, P, CS, tid);
+    GridCtx gx{};
     HaloSlot hs[2] = {HaloSlot{-1, 0}, HaloSlot{-1, 0}};
-    if constexpr (HALO) {
+    if constexpr (HALO == 2) {
+        gx.sg = sg;
+        gx.pad[0] = gx.pad[1] = 0u;
+        region_slots_pad<NS0>(pk0, 0, SPLIT_C, P, CS, tid, sg.hv_last, gx.pad[0]);
+        region_slots_pad<NS1>(pk1, SPLIT_C, NMAP - SPLIT_C, P, CS, tid, sg.hv_last, gx.pad[1]);
+        gx.col[0] = col_edge_slot(0, SPLIT_C, H, P, CS, tid);
+        gx.col[1] = col_edge_slot(SPLIT_C, NMAP - SPLIT_C, H, P, CS, tid);
+        gx.row[0] = row_edge_slot(0, SPLIT_C, P, CS, tid);
+        gx.row[1] = row_edge_slot(SPLIT_C, NMAP - SPLIT_C, P, CS, tid);
+    } else {
+        region_slots<NS0>(pk0, 0, SPLIT_C, P, CS, tid);
+        region_slots<NS1>(pk1, SPLIT_C, NMAP - SPLIT_C, P, CS, tid);
+    }
+    if constexpr (HALO == 1) {
         hs[0] = halo_slot(0, SPLIT_C, H, P, CS, tid);
         hs[1] = halo_slot(SPLIT_C, NMAP - SPLIT_C, H, P, CS, tid);
     }
@@ -762,11 +917,17 @@ __device__ __forceinline__ void conv3x3_body(
     SlotVal first[NS0];
     if (b < B) {
 #pragma unroll
-        for (int j = 0; j < NS0; ++j) slot_load<MODE, HALO>(first[j], cfg, (size_t)b * NMAP * P, tid + j * CONV_THREADS, pk0[j], b);
+        for (int j = 0; j < NS0; ++j)
+            slot_load<MODE, HALO>(first[j], cfg, (size_t)b * NMAP * P, tid + j * CONV_THREADS, pk0[j],
+                                  HALO == 2 ? strip_pos(sg, b, H).bu : b);
     }
     SlotVal firsth;
-    if constexpr (HALO) {
+    SlotVal firstg[3];
+    if constexpr (HALO == 1) {
         if (b < B) halo_load<MODE>(firsth, cfg, (size_t)(b ^ 1) * NMAP * P, hs[0], (b & 1) ? PW - 1 : 0, b);
+    }
+    if constexpr (HALO == 2) {
+        if (b < B) grid_load<MODE>(firstg, cfg, gx, 0, b, H, P);
     }
     {
         float4 wv[7];  // 3*102*16 float4 = 4896 <= 7 * 768: all loads in flight, then the LDS stores
@@ -835,20 +996,22 @@ __device__ __forceinline__ void conv3x3_body(
     if (b < B) {
 #pragma unroll
         for (int j = 0; j < NS0; ++j)
-            slot_write<MODE>(first[j], cfg, (size_t)b * NMAP * P, tid + j * CONV_THREADS, pk0[j], tile, lm);
-        if constexpr (HALO) halo_write<MODE>(firsth, cfg, hs[0], (b & 1) ? 0 : WP - 1, tile, lm);
+            slot_write<MODE>(first[j], cfg, (size_t)b * NMAP * P, tid + j * CONV_THREADS, pk0[j], tile, lm,
+                             HALO == 2 && strip_pos(sg, b, H).hv < H && ((gx.pad[0] >> j) & 1));
+        if constexpr (HALO == 1) halo_write<MODE>(firsth, cfg, hs[0], (b & 1) ? 0 : WP - 1, tile, lm);
+        if constexpr (HALO == 2) grid_write<MODE>(firstg, cfg, gx, 0, b, H, tile, lm);
     }
     __syncthreads();  // channels 0..23 of the first utterance in place
     HOWL_PROBE(cfg, wave, lane, pslot++);   // first half tile staged
 
     const ConvLoop cl{(const lds_f32*)tile, (const lds_f32*)wl + nt * KSTEPS * 64, tile, lm, B, CS, t0, lane, tid, nblk};
     switch (ntw) {
-        case 5: conv_loop<MODE, 5, ts, HALO>(cl, epi, cfg, pk0, pk1, b, st0, st1, pslot, hs); break;
-        case 4: conv_loop<MODE, 4, ts, HALO>(cl, epi, cfg, pk0, pk1, b, st0, st1, pslot, hs); break;
-        case 3: conv_loop<MODE, 3, ts, HALO>(cl, epi, cfg, pk0, pk1, b, st0, st1, pslot, hs); break;
-        case 2: conv_loop<MODE, 2, ts, HALO>(cl, epi, cfg, pk0, pk1, b, st0, st1, pslot, hs); break;
-        case 1: conv_loop<MODE, 1, ts, HALO>(cl, epi, cfg, pk0, pk1, b, st0, st1, pslot, hs); break;
-        default: conv_loop<MODE, 0, ts, HALO>(cl, epi, cfg, pk0, pk1, b, st0, st1, pslot, hs); break;
+        case 5: conv_loop<MODE, 5, ts, HALO>(cl, epi, cfg, pk0, pk1, b, st0, st1, pslot, hs, gx); break;
+        case 4: conv_loop<MODE, 4, ts, HALO>(cl, epi, cfg, pk0, pk1, b, st0, st1, pslot, hs, gx); break;
+        case 3: conv_loop<MODE, 3, ts, HALO>(cl, epi, cfg, pk0, pk1, b, st0, st1, pslot, hs, gx); break;
+        case 2: conv_loop<MODE, 2, ts, HALO>(cl, epi, cfg, pk0, pk1, b, st0, st1, pslot, hs, gx); break;
+        case 1: conv_loop<MODE, 1, ts, HALO>(cl, epi, cfg, pk0, pk1, b, st0, st1, pslot, hs, gx); break;
+        default: conv_loop<MODE, 0, ts, HALO>(cl, epi, cfg, pk0, pk1, b, st0, st1, pslot, hs, gx); break;
     }
 
     HOWL_PROBE(cfg, wave, lane, pslot++);   // all utterances done
@@ -921,20 +1084,21 @@ __device__ __forceinline__ void conv3x3_body(
     }
 }
 
-template <int MODE, int SLICES, bool HALO = false>
+template <int MODE, int SLICES, int HALO = 0>
 __global__ __launch_bounds__(CONV_THREADS) void conv3x3_mfma_kernel(StageCfg cfg, const float* __restrict__ in_stats,
                                                                     const float* __restrict__ wp,
                                                                     const float* __restrict__ res, float* __restrict__ out,
                                                                     const float* __restrict__ xs,
                                                                     const float* __restrict__ xs_stats,
                                                                     float* __restrict__ part, float* __restrict__ pool, int B,
-                                                                    int H, int nblk, BnFold fold, BwdFold bfold, WFold wf) {
+                                                                    int H, int nblk, BnFold fold, BwdFold bfold, WFold wf,
+                                                                    StripGeom sg) {
     // blocks x, x + 8, ... run on XCD x (the hardware deals blocks round-robin): the SLICES workgroups of an utterance
     // group sit on one XCD and share its L2 copy of the maps
     const int x = blockIdx.x & 7, y = blockIdx.x >> 3;
     const int slice = y % SLICES, bid = (y / SLICES) * 8 + x;
     if (bid >= nblk) return;
-    conv3x3_body<MODE, SLICES, HALO>(cfg, in_stats, wp, res, out, xs, xs_stats, part, pool, B, H, bid, nblk, slice, fold, bfold, wf);
+    conv3x3_body<MODE, SLICES, HALO>(cfg, in_stats, wp, res, out, xs, xs_stats, part, pool, B, H, bid, nblk, slice, fold, bfold, wf, sg);
 }
 
 
@@ -1049,6 +1213,19 @@ __device__ __forceinline__ void row_region_slots(int (&pk)[NSL], int (&ch)[NSL],
         ch[j] |= (e < NMAP * nper ? c : 0) << (8 * cbyte);
     }
 }
+// the same, plus bit j of `padbits` = slot j lies in a row >= hv (a row beyond the valid ones of a last row strip: StripGeom)
+template <int NSL>
+__device__ __forceinline__ void row_region_slots_pad(int (&pk)[NSL], int (&ch)[NSL], int cbyte, int h0, int h1, int P, int CS,
+                                                     int pitch, int row0, int col0, int tid, int hv, unsigned& padbits) {
+    row_region_slots<NSL>(pk, ch, cbyte, h0, h1, P, CS, pitch, row0, col0, tid);
+    const int nper = PW * (h1 > h0 ? h1 - h0 : 0), nsafe = nper > 0 ? nper : 1;
+#pragma unroll
+    for (int j = 0; j < NSL; ++j) {
+        const int e = 2 * (tid + j * CONV_THREADS);
+        const int h = h0 + (e % nsafe) / PW;
+        if (pk[j] >= 0 && h >= hv) padbits |= 1u << j;
+    }
+}
 
 struct WStage {
     StageCfg z;           // dz_i: plain (z.a = dz) or fused (z.a = dx_i ...), see StageCfg
@@ -1063,7 +1240,7 @@ struct WSlot {
 
 // z slot: the data gradient's staging arithmetic (slot_write<1>) with this kernel's addressing; addresses are "uniform base +
 // 32-bit lane offset" recomputed from the packed descriptor where they are used
-template <bool HALO = false>
+template <int HALO = 0>
 __device__ __forceinline__ void wz_load(SlotVal& v, const StageCfg& cfg, size_t ubase, int pkj, int chj, int b) {
     HOWL_OPAQUE_V(pkj);
     HOWL_OPAQUE_V(chj);
@@ -1074,7 +1251,7 @@ __device__ __forceinline__ void wz_load(SlotVal& v, const StageCfg& cfg, size_t 
             v.a = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(cfg.a + ubase) + off);
         } else {
             const unsigned c4 = 4u * (unsigned)(chj & 0xFF);
-            const float gg = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(cfg.dpool + (size_t)(HALO ? b >> 1 : b) * CP) + c4) * cfg.invP;
+            const float gg = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(cfg.dpool + (size_t)(HALO == 1 ? b >> 1 : b) * CP) + c4) * cfg.invP;
             v.a = make_float2(gg, gg);
         }
         v.s = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(cfg.s + ubase) + off);
@@ -1084,7 +1261,8 @@ __device__ __forceinline__ void wz_load(SlotVal& v, const StageCfg& cfg, size_t 
         v.a = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(cfg.a + ubase) + off);
     }
 }
-__device__ __forceinline__ void wz_write(const SlotVal& v, const StageCfg& cfg, int pkj, int chj, float* tz, const float* lm) {
+__device__ __forceinline__ void wz_write(const SlotVal& v, const StageCfg& cfg, int pkj, int chj, float* tz, const float* lm,
+                                         bool zero = false) {
     HOWL_OPAQUE_V(pkj);
     HOWL_OPAQUE_V(chj);
     if (pkj < 0) return;
@@ -1096,6 +1274,7 @@ __device__ __forceinline__ void wz_write(const SlotVal& v, const StageCfg& cfg, 
         v0 = dz.x;
         v1 = dz.y;
     }
+    if (zero) v0 = v1 = 0.0f;
     float* d = tz + (pkj & 0x7FFF);
     d[0] = v0;
     d[1] = v1;
@@ -1105,7 +1284,8 @@ __device__ __forceinline__ void wx_load(float2& v, const float* x, size_t ubase,
     const unsigned off = pkj >= 0 ? 4u * (unsigned)(pkj >> 15) : 0u;
     v = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(x + ubase) + off);
 }
-__device__ __forceinline__ void wx_write(const float2& v, bool affine, int pkj, int chj, float* tx, const float* lm) {
+__device__ __forceinline__ void wx_write(const float2& v, bool affine, int pkj, int chj, float* tx, const float* lm,
+                                         bool zero = false) {
     HOWL_OPAQUE_V(pkj);
     HOWL_OPAQUE_V(chj);
     if (pkj < 0) return;
@@ -1116,6 +1296,7 @@ __device__ __forceinline__ void wx_write(const float2& v, bool affine, int pkj, 
         v0 = fmaf(v0, r, sh);
         v1 = fmaf(v1, r, sh);
     }
+    if (zero) v0 = v1 = 0.0f;
     float* d = tx + (pkj & 0x7FFF);
     d[0] = v0;
     d[1] = v1;
@@ -1126,21 +1307,64 @@ struct WHalo {
     int pk;   // LDS float offset of tile column 0 of the element's row in tx; -1 = no element
     int g;    // float offset of column 0 of that row in an utterance's (45, P) map
     int c;    // channel
+    int h;    // the element's row (HALO == 2: rows beyond a last row strip's valid ones stay zero)
 };
 __device__ __forceinline__ WHalo whalo_slot(int h0, int h1, int P, int CSX, int row0, int tid) {
     const int nper = h1 > h0 ? h1 - h0 : 0, nsafe = nper > 0 ? nper : 1;
     const int c = tid / nsafe, hh = tid - c * nsafe, h = h0 + hh;
     const bool ok = tid < NMAP * nper;
-    return WHalo{ok ? c * CSX + (h + row0) * WPW : -1, ok ? c * P + h * PW : 0, ok ? c : 0};
+    return WHalo{ok ? c * CSX + (h + row0) * WPW : -1, ok ? c * P + h * PW : 0, ok ? c : 0, ok ? h : 0};
 }
 __device__ __forceinline__ float whalo_load(const float* x, size_t nbase, const WHalo& wh, int gcol) {
-    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(x + nbase) + 4u * (unsigned)(wh.g + (wh.pk >= 0 ? gcol : 0)));
+    if (wh.pk < 0) return 0.0f;     // (no element: also keeps the address inside the tensor when there is no neighbour strip)
+    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(x + nbase) + 4u * (unsigned)(wh.g + gcol));
 }
-__device__ __forceinline__ void whalo_write(float v, bool affine, const WHalo& wh, int lcol, float* tx, const float* lm) {
+__device__ __forceinline__ void whalo_write(float v, bool affine, const WHalo& wh, int lcol, float* tx, const float* lm,
+                                            int hv = 1 << 20) {
     if (wh.pk < 0) return;
     float v0 = fabsf(v);
     if (affine) v0 = fmaf(v0, lm[5 * CP + wh.c], lm[4 * CP + wh.c]);
-    tx[wh.pk + lcol] = v0;
+    tx[wh.pk + lcol] = wh.h < hv ? v0 : 0.0f;
+}
+
+// HALO == 2 (StripGeom): the x tile's halo ROWS -- twelve columns of the last row of the strip above (tile row 0 of region 1)
+// and of the first row of the strip below (tile row H + 3 of region 2), corners from the diagonal neighbours -- one scalar per
+// thread and side (45 x 12 = 540 <= 768); what the workgroup carries through its utterance loop
+struct WRowSlot {
+    int pk;   // LDS float offset in tx of the element in tile row 0; -1 = none
+    int g;    // float offset inside the source block: channel * P + source column
+    int c;    // channel
+    int dc;   // column-strip delta of the source block
+};
+__device__ __forceinline__ WRowSlot wrow_slot(int P, int CSX, int tid) {
+    const int c = tid / WP, w = tid - c * WP;
+    const bool ok = tid < NMAP * WP;
+    const int dc = w == 0 ? -1 : (w == WP - 1 ? 1 : 0);
+    const int col = w == 0 ? PW - 1 : (w == WP - 1 ? 0 : w - 1);
+    return WRowSlot{ok ? c * CSX + w : -1, ok ? c * P + col : 0, ok ? c : 0, ok ? dc : 0};
+}
+struct WGridCtx {
+    StripGeom sg;
+    WRowSlot row;
+    unsigned pzt, pxt, pzb, pxb;     // pad bits of the four slot arrays (rows >= hv_last)
+};
+__device__ __forceinline__ float wrow_load(const float* x, const WGridCtx& gx, int v, int H, int P, bool below) {
+    const StripPos p = strip_pos(gx.sg, v, H);
+    const int cc = p.c + gx.row.dc;
+    const bool valid = gx.row.pk >= 0 && cc >= 0 && cc < gx.sg.ns && (below ? p.r < gx.sg.nr - 1 : p.r > 0);
+    const int blk = below ? v + gx.sg.ns + gx.row.dc : v - gx.sg.ns + gx.row.dc;
+    const size_t idx = valid ? (size_t)blk * NMAP * P + (size_t)(gx.row.g + (below ? 0 : (H - 1) * PW)) : 0;
+    return valid ? x[idx] : 0.0f;
+}
+__device__ __forceinline__ void wrow_write(float v, bool affine, const WGridCtx& gx, int vstrip, int H, bool below, float* tx,
+                                           const float* lm) {
+    if (gx.row.pk < 0) return;
+    const StripPos p = strip_pos(gx.sg, vstrip, H);
+    const int cc = p.c + gx.row.dc;
+    const bool valid = cc >= 0 && cc < gx.sg.ns && (below ? p.r < gx.sg.nr - 1 : p.r > 0);
+    float v0 = fabsf(v);
+    if (affine) v0 = fmaf(v0, lm[5 * CP + gx.row.c], lm[4 * CP + gx.row.c]);
+    tx[gx.row.pk + (below ? (H + 3) * WPW : 0)] = valid ? v0 : 0.0f;
 }
 
 struct WgradArgs {
@@ -1165,10 +1389,11 @@ __device__ __forceinline__ int wgrad_boff(int q, int n, int g, int CSX) {
     return cin * CSX + (g + tap / 3) * WPW + (tap % 3);     // cin row, halo origin + tap shift
 }
 
-template <int NB, bool EX, int GWS, bool HALO = false>
+template <int NB, bool EX, int GWS, int HALO = 0>
 __device__ __forceinline__ void wgrad_loop(const WgradArgs& a, const int (&zt)[WNT], const int (&xt)[WNT], const int (&ct)[WNT],
                                            const int (&zb)[WNB], const int (&xb)[WNB], const int (&cb)[WNB], int b, int& pslot,
-                                           const WHalo (&wh)[2] = {WHalo{-1, 0, 0}, WHalo{-1, 0, 0}}) {
+                                           const WHalo (&wh)[2] = {WHalo{-1, 0, 0, 0}, WHalo{-1, 0, 0, 0}},
+                                           const WGridCtx& gx = WGridCtx{}) {
     const int lane = a.lane, wave = a.wave;
     const int g = lane >> 4, n = lane & 15;
     f32x4 acc[NB][3];
@@ -1200,6 +1425,15 @@ __device__ __forceinline__ void wgrad_loop(const WgradArgs& a, const int (&zt)[W
         c.bpe = (const lds_f32*)a.tx + boffe;
         float az[3], bx[NB], aze = 0.0f, bxe = 0.0f;
         WSlot v[2];
+        // HALO == 2 (StripGeom): utterance index for the pooled gradient's broadcast, valid rows of this strip and the next one
+        int bsl = b, bnsl = bn, hvb = 1 << 20, hvn = 1 << 20;
+        bool zb_ = false, zn_ = false;
+        if constexpr (HALO == 2) {
+            const int Hs = a.P / PW;
+            const StripPos pb = strip_pos(gx.sg, b, Hs), pn = strip_pos(gx.sg, more ? bn : b, Hs);
+            bsl = pb.bu, bnsl = pn.bu, hvb = pb.hv, hvn = pn.hv;
+            zb_ = pb.hv < Hs, zn_ = pn.hv < Hs;
+        }
         // ---- phase 1: rounds 0 .. R1-1 on the top rows; the bottom rows of this utterance arrive
 #pragma unroll
         for (int mt = 0; mt < 3; ++mt) az[mt] = c.ap[mt][0];
@@ -1215,31 +1449,33 @@ __device__ __forceinline__ void wgrad_loop(const WgradArgs& a, const int (&zt)[W
         wz_load<HALO>(v[slot_].z, a.st.z, ub_, zpk_[j_], cpk_[j_], bb_);     \
         wx_load(v[slot_].x, a.st.x, ub_, xpk_[j_]);                          \
     } while (0)
-#define HOWL_W_WRITE(slot_, j_, zpk_, xpk_, cpk_)                             \
-    do {                                                                     \
-        wz_write(v[slot_].z, a.st.z, zpk_[j_], cpk_[j_], a.tz, a.lm);        \
-        wx_write(v[slot_].x, a.st.xaffine, xpk_[j_], cpk_[j_], a.tx, a.lm);  \
+#define HOWL_W_WRITE(slot_, j_, zpk_, xpk_, cpk_, zf_, zp_, xp_)                                                             \
+    do {                                                                                                                   \
+        wz_write(v[slot_].z, a.st.z, zpk_[j_], cpk_[j_], a.tz, a.lm, HALO == 2 && (zf_) && (((zp_) >> (j_)) & 1));         \
+        wx_write(v[slot_].x, a.st.xaffine, xpk_[j_], cpk_[j_], a.tx, a.lm, HALO == 2 && (zf_) && (((xp_) >> (j_)) & 1));   \
     } while (0)
-        HOWL_W_LOAD(0, 0, zb, xb, cb, ubase, b);
-        HOWL_W_LOAD(1, 1, zb, xb, cb, ubase, b);
-        float xh = 0.0f;
-        if constexpr (HALO) xh = whalo_load(a.st.x, (size_t)(b ^ 1) * NMAP * a.P, wh[1], gcol);
+        HOWL_W_LOAD(0, 0, zb, xb, cb, ubase, bsl);
+        HOWL_W_LOAD(1, 1, zb, xb, cb, ubase, bsl);
+        float xh = 0.0f, xr = 0.0f;
+        if constexpr (HALO != 0) xh = whalo_load(a.st.x, (size_t)(b ^ 1) * NMAP * a.P, wh[1], gcol);
+        if constexpr (HALO == 2) xr = wrow_load(a.st.x, gx, b, a.P / PW, a.P, true);
         HOWL_STAIR(3);
         if (R1 > 0) wgrad_k_run<NB, EX>(c, acc, acce, az, bx, aze, bxe, 1);
-        HOWL_W_WRITE(0, 0, zb, xb, cb);
-        HOWL_W_WRITE(1, 1, zb, xb, cb);
-        if constexpr (HALO) whalo_write(xh, a.st.xaffine, wh[1], lcol, a.tx, a.lm);
-        HOWL_W_LOAD(0, 2, zb, xb, cb, ubase, b);
-        HOWL_W_LOAD(1, 3, zb, xb, cb, ubase, b);
+        HOWL_W_WRITE(0, 0, zb, xb, cb, zb_, gx.pzb, gx.pxb);
+        HOWL_W_WRITE(1, 1, zb, xb, cb, zb_, gx.pzb, gx.pxb);
+        if constexpr (HALO != 0) whalo_write(xh, a.st.xaffine, wh[1], lcol, a.tx, a.lm, hvb);
+        if constexpr (HALO == 2) wrow_write(xr, a.st.xaffine, gx, b, a.P / PW, true, a.tx, a.lm);
+        HOWL_W_LOAD(0, 2, zb, xb, cb, ubase, bsl);
+        HOWL_W_LOAD(1, 3, zb, xb, cb, ubase, bsl);
         HOWL_STAIR(2);
         if (R1 > 1) wgrad_k_run<NB, EX>(c, acc, acce, az, bx, aze, bxe, 1);
-        HOWL_W_WRITE(0, 2, zb, xb, cb);
-        HOWL_W_WRITE(1, 3, zb, xb, cb);
-        HOWL_W_LOAD(0, 4, zb, xb, cb, ubase, b);
+        HOWL_W_WRITE(0, 2, zb, xb, cb, zb_, gx.pzb, gx.pxb);
+        HOWL_W_WRITE(1, 3, zb, xb, cb, zb_, gx.pzb, gx.pxb);
+        HOWL_W_LOAD(0, 4, zb, xb, cb, ubase, bsl);
         HOWL_STAIR(1);
         if (R1 > 2) wgrad_k_run<NB, EX>(c, acc, acce, az, bx, aze, bxe, R1 - 2);
         HOWL_STAIR(0);
-        HOWL_W_WRITE(0, 4, zb, xb, cb);
+        HOWL_W_WRITE(0, 4, zb, xb, cb, zb_, gx.pzb, gx.pxb);
         HOWL_PROBE(a.st.z, wave, lane, pslot++);   // phase 1 done
         __syncthreads();      // bottom rows complete; every wave is past its reads of the top rows
         HOWL_PROBE(a.st.z, wave, lane, pslot++);   // barrier
@@ -1257,24 +1493,26 @@ __device__ __forceinline__ void wgrad_loop(const WgradArgs& a, const int (&zt)[W
             bxe = c.bpe[0];
         }
         if (more) {
-            HOWL_W_LOAD(0, 0, zt, xt, ct, nbase, bn);
-            HOWL_W_LOAD(1, 1, zt, xt, ct, nbase, bn);
-            if constexpr (HALO) xh = whalo_load(a.st.x, (size_t)(bn ^ 1) * NMAP * a.P, wh[0], gcol);
+            HOWL_W_LOAD(0, 0, zt, xt, ct, nbase, bnsl);
+            HOWL_W_LOAD(1, 1, zt, xt, ct, nbase, bnsl);
+            if constexpr (HALO != 0) xh = whalo_load(a.st.x, (size_t)(bn ^ 1) * NMAP * a.P, wh[0], gcol);
+            if constexpr (HALO == 2) xr = wrow_load(a.st.x, gx, bn, a.P / PW, a.P, false);
         }
         HOWL_STAIR(3);
         wgrad_k_run<NB, EX>(c, acc, acce, az, bx, aze, bxe, 1);
         if (more) {
-            HOWL_W_WRITE(0, 0, zt, xt, ct);
-            HOWL_W_WRITE(1, 1, zt, xt, ct);
-            if constexpr (HALO) whalo_write(xh, a.st.xaffine, wh[0], lcol, a.tx, a.lm);
-            HOWL_W_LOAD(0, 2, zt, xt, ct, nbase, bn);
-            HOWL_W_LOAD(1, 3, zt, xt, ct, nbase, bn);
+            HOWL_W_WRITE(0, 0, zt, xt, ct, zn_, gx.pzt, gx.pxt);
+            HOWL_W_WRITE(1, 1, zt, xt, ct, zn_, gx.pzt, gx.pxt);
+            if constexpr (HALO != 0) whalo_write(xh, a.st.xaffine, wh[0], lcol, a.tx, a.lm, hvn);
+            if constexpr (HALO == 2) wrow_write(xr, a.st.xaffine, gx, bn, a.P / PW, false, a.tx, a.lm);
+            HOWL_W_LOAD(0, 2, zt, xt, ct, nbase, bnsl);
+            HOWL_W_LOAD(1, 3, zt, xt, ct, nbase, bnsl);
         }
         HOWL_STAIR(2);
         if (R2 > 1) wgrad_k_run<NB, EX>(c, acc, acce, az, bx, aze, bxe, 1);
         if (more) {
-            HOWL_W_WRITE(0, 2, zt, xt, ct);
-            HOWL_W_WRITE(1, 3, zt, xt, ct);
+            HOWL_W_WRITE(0, 2, zt, xt, ct, zn_, gx.pzt, gx.pxt);
+            HOWL_W_WRITE(1, 3, zt, xt, ct, zn_, gx.pzt, gx.pxt);
         }
         HOWL_STAIR(1);
         if (R2 > 2) wgrad_k_run<NB, EX>(c, acc, acce, az, bx, aze, bxe, R2 - 2);
@@ -1301,10 +1539,11 @@ __device__ __forceinline__ void wgrad_loop(const WgradArgs& a, const int (&zt)[W
     }
 }
 
-template <int SLICES, bool HALO = false>
+template <int SLICES, int HALO = 0>
 __device__ __forceinline__ void wgrad_body(
     WStage st, const float* __restrict__ in_stats /* {mean, rstd} of layer i-1 or nullptr */, const BwdFold& bfold,
-    float* __restrict__ part /* [nblk][48][WNCOL] */, int B, int H, int bid, int nblk, int slice) {
+    float* __restrict__ part /* [nblk][48][WNCOL] */, int B, int H, int bid, int nblk, int slice,
+    const StripGeom& sg = StripGeom{1, 1, 0} /* HALO == 2 */) {
     HIP_DYNAMIC_SHARED(float, lds)
     const int P = H * PW;
     const int CSZ = chan_stride_z(H), CSX = chan_stride_x(H);
@@ -1327,12 +1566,22 @@ __device__ __forceinline__ void wgrad_body(
     const int xtop = R1 > 0 ? (4 * R1 + 1 < H ? 4 * R1 + 1 : H) : 0;
     const int xbot = 4 * R1 - 1 > 0 ? 4 * R1 - 1 : 0;
     int zt[WNT], xt[WNT], zb[WNB], xb[WNB], ct[WNT] = {}, cb[WNB] = {};
-    row_region_slots<WNT>(zt, ct, 0, 0, zsplit, P, CSZ, WPZ, 0, 0, tid);
-    row_region_slots<WNT>(xt, ct, 1, 0, xtop, P, CSX, WPW, 1, 1, tid);
-    row_region_slots<WNB>(zb, cb, 0, zsplit, H, P, CSZ, WPZ, 0, 0, tid);
-    row_region_slots<WNB>(xb, cb, 1, xbot, H, P, CSX, WPW, 3, 1, tid);
-    WHalo wh[2] = {WHalo{-1, 0, 0}, WHalo{-1, 0, 0}};
-    if constexpr (HALO) {
+    WGridCtx gx{};
+    if constexpr (HALO == 2) {
+        gx.sg = sg;
+        gx.row = wrow_slot(P, CSX, tid);
+        row_region_slots_pad<WNT>(zt, ct, 0, 0, zsplit, P, CSZ, WPZ, 0, 0, tid, sg.hv_last, gx.pzt);
+        row_region_slots_pad<WNT>(xt, ct, 1, 0, xtop, P, CSX, WPW, 1, 1, tid, sg.hv_last, gx.pxt);
+        row_region_slots_pad<WNB>(zb, cb, 0, zsplit, H, P, CSZ, WPZ, 0, 0, tid, sg.hv_last, gx.pzb);
+        row_region_slots_pad<WNB>(xb, cb, 1, xbot, H, P, CSX, WPW, 3, 1, tid, sg.hv_last, gx.pxb);
+    } else {
+        row_region_slots<WNT>(zt, ct, 0, 0, zsplit, P, CSZ, WPZ, 0, 0, tid);
+        row_region_slots<WNT>(xt, ct, 1, 0, xtop, P, CSX, WPW, 1, 1, tid);
+        row_region_slots<WNB>(zb, cb, 0, zsplit, H, P, CSZ, WPZ, 0, 0, tid);
+        row_region_slots<WNB>(xb, cb, 1, xbot, H, P, CSX, WPW, 3, 1, tid);
+    }
+    WHalo wh[2] = {WHalo{-1, 0, 0, 0}, WHalo{-1, 0, 0, 0}};
+    if (HALO == 1 || (HALO == 2 && sg.ns == 2)) {      // the neighbour column strip's edge column
         wh[0] = whalo_slot(0, xtop, P, CSX, 1, tid);
         wh[1] = whalo_slot(xbot, H, P, CSX, 3, tid);
     }
@@ -1342,13 +1591,16 @@ __device__ __forceinline__ void wgrad_body(
     if (b < B) {
 #pragma unroll
         for (int j = 0; j < WNT; ++j) {
-            wz_load<HALO>(first[j].z, st.z, (size_t)b * NMAP * P, zt[j], ct[j], b);
+            wz_load<HALO>(first[j].z, st.z, (size_t)b * NMAP * P, zt[j], ct[j], HALO == 2 ? strip_pos(sg, b, H).bu : b);
             wx_load(first[j].x, st.x, (size_t)b * NMAP * P, xt[j]);
         }
     }
-    float firsth = 0.0f;
-    if constexpr (HALO) {
+    float firsth = 0.0f, firstr = 0.0f;
+    if constexpr (HALO != 0) {
         if (b < B) firsth = whalo_load(st.x, (size_t)(b ^ 1) * NMAP * P, wh[0], (b & 1) ? PW - 1 : 0);
+    }
+    if constexpr (HALO == 2) {
+        if (b < B) firstr = wrow_load(st.x, gx, b, H, P, false);
     }
     zero_lds(lds, tile_floats_z(H) + tile_floats_x(H), tid, CONV_THREADS);
     if (st.z.fused) {
@@ -1362,10 +1614,12 @@ __device__ __forceinline__ void wgrad_body(
     if (b < B) {
 #pragma unroll
         for (int j = 0; j < WNT; ++j) {
-            wz_write(first[j].z, st.z, zt[j], ct[j], tz, lm);
-            wx_write(first[j].x, st.xaffine, xt[j], ct[j], tx, lm);
+            const bool padded = HALO == 2 && strip_pos(sg, b, H).hv < H;
+            wz_write(first[j].z, st.z, zt[j], ct[j], tz, lm, padded && ((gx.pzt >> j) & 1));
+            wx_write(first[j].x, st.xaffine, xt[j], ct[j], tx, lm, padded && ((gx.pxt >> j) & 1));
         }
-        if constexpr (HALO) whalo_write(firsth, st.xaffine, wh[0], (b & 1) ? 0 : PW + 1, tx, lm);
+        if constexpr (HALO != 0) whalo_write(firsth, st.xaffine, wh[0], (b & 1) ? 0 : PW + 1, tx, lm, HALO == 2 ? strip_pos(sg, b, H).hv : 1 << 20);
+        if constexpr (HALO == 2) wrow_write(firstr, st.xaffine, gx, b, H, false, tx, lm);
     }
     __syncthreads();
     HOWL_PROBE(st.z, wave, lane, pslot++);   // prologue done
@@ -1390,26 +1644,26 @@ __device__ __forceinline__ void wgrad_body(
         }
         const WgradArgs a{st, part, tz, tx, lm, B, P, CSZ, CSX, R, R1, tid, lane, wave, bid, nblk, gw, qe, mte};
         if (ex)
-            wgrad_loop<2, true, GWS, HALO>(a, zt, xt, ct, zb, xb, cb, b, pslot, wh);
+            wgrad_loop<2, true, GWS, HALO>(a, zt, xt, ct, zb, xb, cb, b, pslot, wh, gx);
         else
-            wgrad_loop<2, false, GWS, HALO>(a, zt, xt, ct, zb, xb, cb, b, pslot, wh);
+            wgrad_loop<2, false, GWS, HALO>(a, zt, xt, ct, zb, xb, cb, b, pslot, wh, gx);
     } else {                           // small batches: tiles gw, gw + 24 (< 26) over the 24 waves of two workgroups
         const WgradArgs a{st, part, tz, tx, lm, B, P, CSZ, CSX, R, R1, tid, lane, wave, bid, nblk, gw, 0, 0};
         if (gw + 24 < 26)
-            wgrad_loop<2, false, GWS, HALO>(a, zt, xt, ct, zb, xb, cb, b, pslot, wh);
+            wgrad_loop<2, false, GWS, HALO>(a, zt, xt, ct, zb, xb, cb, b, pslot, wh, gx);
         else
-            wgrad_loop<1, false, GWS, HALO>(a, zt, xt, ct, zb, xb, cb, b, pslot, wh);
+            wgrad_loop<1, false, GWS, HALO>(a, zt, xt, ct, zb, xb, cb, b, pslot, wh, gx);
     }
     HOWL_PROBE(st.z, wave, lane, pslot++);   // partials written
 }
 
-template <int SLICES, bool HALO = false>
+template <int SLICES, int HALO = 0>
 __global__ __launch_bounds__(CONV_THREADS) void wgrad_mfma_kernel(WStage st, const float* __restrict__ in_stats, BwdFold bfold,
-                                                                  float* __restrict__ part, int B, int H, int nblk) {
+                                                                  float* __restrict__ part, int B, int H, int nblk, StripGeom sg) {
     const int x = blockIdx.x & 7, y = blockIdx.x >> 3;
     const int slice = y % SLICES, bid = (y / SLICES) * 8 + x;
     if (bid >= nblk) return;
-    wgrad_body<SLICES, HALO>(st, in_stats, bfold, part, B, H, bid, nblk, slice);
+    wgrad_body<SLICES, HALO>(st, in_stats, bfold, part, B, H, bid, nblk, slice, sg);
 }
 
 // Data gradient and weight gradient of one layer in ONE launch.  Both hang off dz_i and are independent; side by side on
@@ -1418,11 +1672,11 @@ __global__ __launch_bounds__(CONV_THREADS) void wgrad_mfma_kernel(WStage st, con
 // record / wait pairs that fork and join the second queue cost ~6.5 us each on this stack, twice per layer on the
 // critical path.)  Blocks come in groups of 16: the first 8 run the data gradient, the other 8 the weight gradient, so
 // that pair j of either role lands on the same XCD (block b runs on XCD b % 8) and shares its L2 copy of what both stage.
-template <int SD, int SW, bool HALO = false>
+template <int SD, int SW, int HALO = 0>
 __global__ __launch_bounds__(CONV_THREADS) void bwd_pair_kernel(
     StageCfg zc, BwdFold bfold, const float* __restrict__ wp, float* __restrict__ dx, const float* __restrict__ xs,
     const float* __restrict__ xs_stats, float* __restrict__ spart, const float* __restrict__ s_prev,
-    const float* __restrict__ in_stats, float* __restrict__ wpart, int B, int H, int nblk, WFold wf) {
+    const float* __restrict__ in_stats, float* __restrict__ wpart, int B, int H, int nblk, WFold wf, StripGeom sg) {
     // groups of 8 * (SD + SW) blocks: utterance group j = 8 * (group index) + x on XCD x gets SD data-gradient workgroups
     // (position slices) and SW weight-gradient workgroups (N-tile slices); SD = SW = 1 at full batches
     const int x = blockIdx.x & 7, y = blockIdx.x >> 3;
@@ -1430,9 +1684,9 @@ __global__ __launch_bounds__(CONV_THREADS) void bwd_pair_kernel(
     const int j = (y / (SD + SW)) * 8 + x;
     if (j >= nblk) return;
     if (r < SD)
-        conv3x3_body<1, SD, HALO>(zc, nullptr, wp, nullptr, dx, xs, xs_stats, spart, nullptr, B, H, j, nblk, r, BnFold{}, bfold, wf);
+        conv3x3_body<1, SD, HALO>(zc, nullptr, wp, nullptr, dx, xs, xs_stats, spart, nullptr, B, H, j, nblk, r, BnFold{}, bfold, wf, sg);
     else
-        wgrad_body<SW, HALO>(WStage{zc, s_prev, false}, in_stats, bfold, wpart, B, H, j, nblk, r - SD);
+        wgrad_body<SW, HALO>(WStage{zc, s_prev, false}, in_stats, bfold, wpart, B, H, j, nblk, r - SD, sg);
 }
 
 // Deterministic sum over the per-workgroup partial rows: part[g][col], g < nparts.  A block owns 64 columns
@@ -1638,8 +1892,11 @@ __global__ __launch_bounds__(BRB_THREADS) void bn_relu_bwd_kernel(
 
 // tin[(T+2)][M+4] with a zero halo; the row pitch is a multiple of 4 floats so that the 6-wide patch row of pooled
 // column pw (tile columns 4pw .. 4pw+5) is one aligned ds_read_b128 + one ds_read_b64 instead of six strided b32 reads
+// (t_lo, t_hi: frames of the tile that exist; a plain utterance or window: 0 .. T, everything else is the convolution's zero
+// padding.  A ROW STRIP of a longer clip (StripGeom) also sees the real frames next to it: -1 .. T + 1 clipped to the clip)
+template <bool EXACT = false>
 __device__ __forceinline__ void load_feat_tile(float* tin, const float* feat, long sb, long st, long sm, int b, int T,
-                                               int M, int tid, int nthreads) {
+                                               int M, int tid, int nthreads, int t_lo = 0, int t_hi = 0) {
     const int pitch = M + 4;
     const int n = (T + 2) * pitch;
     // batches of 8 independent loads per thread: a one-load-per-iteration loop is bound by HBM latency, not bandwidth
@@ -1649,7 +1906,7 @@ __device__ __forceinline__ void load_feat_tile(float* tin, const float* feat, lo
         for (int j = 0; j < 8; ++j) {
             const int i = i0 + j * nthreads;
             const int t = i / pitch - 1, m = i % pitch - 1;
-            const bool ok = i < n && t >= 0 && t < T && m >= 0 && m < M;
+            const bool ok = i < n && (EXACT ? t >= t_lo && t < t_hi : t >= 0 && t < T) && m >= 0 && m < M;
             // clamped unconditional loads (halo / tail slots read element (b,0,0)), zeroed below: predicated loads were
             // compiled into a chain with vmcnt(0) waits between them, i.e. several HBM round trips back to back
             v[j] = feat[b * sb + (ok ? t * st + m * sm : 0)];
@@ -1658,7 +1915,7 @@ __device__ __forceinline__ void load_feat_tile(float* tin, const float* feat, lo
         for (int j = 0; j < 8; ++j) {
             const int i = i0 + j * nthreads;
             const int t = i / pitch - 1, m = i % pitch - 1;
-            const bool ok = t >= 0 && t < T && m >= 0 && m < M;
+            const bool ok = (EXACT ? t >= t_lo && t < t_hi : t >= 0 && t < T) && m >= 0 && m < M;
             if (i < n) tin[i] = ok ? v[j] : 0.0f;
         }
     }
@@ -1680,7 +1937,9 @@ constexpr int C0M_THREADS = 512;   // 8 waves, two per SIMD
 // weight fragments of the six following layers (the weights may have changed since the last call), which the first 3x3
 // convolution needs only after this kernel has finished anyway.
 // NS = strips of 10 pooled columns per utterance (1: 40 mel bins; 2: 80, written as the two blocks v = 2 b + strip, see HaloSlot)
-template <int NS = 1>
+// EXACT: the nwin "windows" of a clip are ROW STRIPS of a training utterance (StripGeom): window wi starts at frame wi * win_step,
+// sees the clip's real frames on both sides (win_last = the clip's frame count) and is block (clip * nwin + wi) of the output
+template <int NS = 1, bool EXACT = false>
 __global__ __launch_bounds__(C0M_THREADS) void conv0_fwd_mfma_kernel(const float* __restrict__ feat, long sb, long st,
                                                                     long sm, const float* __restrict__ w0,
                                                                     float* __restrict__ s0, unsigned short* __restrict__ mask0,
@@ -1726,8 +1985,8 @@ __global__ __launch_bounds__(C0M_THREADS) void conv0_fwd_mfma_kernel(const float
         __syncthreads();
         // long inputs (howl_res8_fwd_long): "utterance" b is window b % nwin of clip b / nwin, T frames from its start frame
         const int clip = b / nwin, wi = b - clip * nwin;
-        const int t0 = min(wi * win_step, win_last);
-        load_feat_tile(tin, feat + (long)clip * sb + (long)t0 * st, 0, st, sm, 0, T, M, tid, C0M_THREADS);
+        const int t0 = EXACT ? wi * win_step : min(wi * win_step, win_last);
+        load_feat_tile<EXACT>(tin, feat + (long)clip * sb + (long)t0 * st, 0, st, sm, 0, T, M, tid, C0M_THREADS, -t0, win_last - t0);
         __syncthreads();
         // units (pair of pooled rows, group of 8 mel bins) of this slice, dealt to the waves
         constexpr int NJ = 5 * NS;      // groups of eight mel bins
@@ -1810,12 +2069,14 @@ __device__ __forceinline__ void load_patch(float (&x)[5][6], const float* tin, i
 // weight gradient: dW0[c][tap] = sum over utterances, cells, the 12 positions of a cell of  (g[c][cell] / 12 where the forward's
 // mask bit is set) * x[position + tap];  acc[5][9] per lane (its wave's channels) lives in registers across every cell block and
 // utterance of the workgroup, one wave-wide sum per accumulator at the end -> one partial row per workgroup.
-template <int NS = 1>
+// EXACT (StripGeom): every utterance is sg.nr row strips of H pooled rows (T = 3 H frames each, the clip has t_total), the last
+// one with sg.hv_last valid rows
+template <int NS = 1, bool EXACT = false>
 __global__ __launch_bounds__(C0G_THREADS) void conv0_wgrad_valu_kernel(const float* __restrict__ feat, long sb, long st, long sm,
                                                                       const unsigned short* __restrict__ mask0,
                                                                       const float* __restrict__ ga, const float* __restrict__ gb,
                                                                       float* __restrict__ part, int B, int T, int M, int H,
-                                                                      int slices) {
+                                                                      int slices, StripGeom sg, int t_total) {
     HIP_DYNAMIC_SHARED(float, lds)
     float* tin = lds;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1828,12 +2089,18 @@ __global__ __launch_bounds__(C0G_THREADS) void conv0_wgrad_valu_kernel(const flo
 #pragma unroll
         for (int t = 0; t < 9; ++t) acc[j][t] = 0.0f;
     // work item = (utterance, strip of 10 pooled columns, slice of the strip's cells); B counts utterances
-    for (int item = blockIdx.x; item < B * NS * slices; item += gridDim.x) {
-        const int vb = item / slices, sl = item - vb * slices;   // gradient / mask block vb = NS * utterance + strip
-        const int b = NS > 1 ? vb / NS : vb, strip = NS > 1 ? vb - b * NS : 0;
-        const int cell0 = (sl * P) / slices, cell1 = ((sl + 1) * P) / slices;
+    const int nrs = EXACT ? sg.nr : 1;
+    for (int item = blockIdx.x; item < B * nrs * NS * slices; item += gridDim.x) {
+        const int vb = item / slices, sl = item - vb * slices;   // gradient / mask block vb = (utterance * nr + row strip) * NS + strip
+        const int vq = NS > 1 ? vb / NS : vb, strip = NS > 1 ? vb - vq * NS : 0;
+        const int b = EXACT ? vq / nrs : vq, rs = EXACT ? vq - b * nrs : 0;
+        const int Pv = (EXACT && rs == nrs - 1) ? sg.hv_last * PW : P;      // cells of the strip that lie inside the map
+        const int cell0 = (sl * Pv) / slices, cell1 = ((sl + 1) * Pv) / slices;
         __syncthreads();
-        load_feat_tile(tin, feat, sb, st, sm, b, T, M, tid, C0G_THREADS);
+        if constexpr (EXACT)
+            load_feat_tile<true>(tin, feat + (long)rs * T * st, sb, st, sm, b, T, M, tid, C0G_THREADS, -rs * T, t_total - rs * T);
+        else
+            load_feat_tile(tin, feat, sb, st, sm, b, T, M, tid, C0G_THREADS);
         __syncthreads();
         const float* gab = ga + ((size_t)vb * NMAP + C0G_CPW * wave) * P;      // (uniform bases, 32-bit lane offsets)
         const float* gbb = gb != nullptr ? gb + ((size_t)vb * NMAP + C0G_CPW * wave) * P : nullptr;
@@ -2193,7 +2460,9 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
 }
 
 size_t conv0_tile_floats(int T, int M) { return (size_t)(T + 2) * (M + 4) + 3 * (M + 4) + 16; }   // tile + slack (conv0_fwd_mfma_kernel)
-size_t conv_lds_bytes(int H) { return (size_t)(3 * KSTEPS * 64 + tile_floats(H) + 4 * CP + 12 * 2 * 16) * sizeof(float); }
+size_t conv_lds_bytes(int H, bool own_rows = false) {
+    return (size_t)(3 * KSTEPS * 64 + tile_floats(H, own_rows) + 4 * CP + 12 * 2 * 16) * sizeof(float);
+}
 StageCfg with_probe(StageCfg c) { return c; }
 
 size_t wgrad_lds_bytes(int H) { return (size_t)(tile_floats_z(H) + tile_floats_x(H) + 6 * CP) * sizeof(float); }
@@ -2258,6 +2527,24 @@ int conv_grid(int B) {
 // Mel bins -> strips of 10 pooled columns (see HaloSlot): 40 -> 1, 80 -> 2 (the reference's stock NUM_MELS, settings.py:32)
 int mel_strips(int M) { return M == 40 ? 1 : (M == 80 ? 2 : 0); }
 // a workgroup's utterances b, b + nblk, ... must keep their strip parity on wide maps: an even stride (B = 2 x utterances >= 2)
+// How (B, T, M) runs as blocks of (45, Hs, 10): ns column strips (mel_strips) x nr row strips of Hs <= 27 pooled rows, the last row
+// strip with hv_last valid rows (StripGeom); halo = 0: plain utterances, 1: column strips only (HaloSlot), 2: row strips
+struct Strips {
+    int ns, nr, Hs, hv_last, Bv, halo;
+    StripGeom sg;
+};
+Strips strips_for(int B, int T, int M) {
+    Strips st;
+    const int H = T / 3;
+    st.ns = mel_strips(M) > 0 ? mel_strips(M) : 1;
+    st.nr = H <= MAX_H ? 1 : (H + MAX_H - 1) / MAX_H;
+    st.Hs = (H + st.nr - 1) / st.nr;
+    st.hv_last = H - (st.nr - 1) * st.Hs;
+    st.Bv = B * st.nr * st.ns;
+    st.halo = st.nr > 1 ? 2 : (st.ns > 1 ? 1 : 0);
+    st.sg = StripGeom{st.nr, st.ns, st.hv_last};
+    return st;
+}
 int even_grid(int g, int strips) { return strips > 1 ? ((g & ~1) > 2 ? (g & ~1) : 2) : g; }
 // Small batches (the reference's presets train at 16, its engines run at batch 1): how many workgroups share one utterance.
 // Forward / data gradient split the position tiles (4 or 2 ways: every position group of a workgroup keeps at least one
@@ -2296,22 +2583,25 @@ void pair_slices(int nblk, int H, int* sd, int* sw) {
 
 // launchers: one instantiation per slicing factor (dynamic LDS limit raised on the instance that is launched)
 StageCfg plain_tile(const float* t) { return StageCfg{t, nullptr, nullptr, nullptr, nullptr, 0.0f, false, false, false}; }
-template <int MODE, int SLICES, bool HALO = false>
+template <int MODE, int SLICES, int HALO = 0>
 void launch_conv3x3_inst(int nblk, size_t lds, hipStream_t stream, const StageCfg& in, const float* in_stats, const float* wp,
                          const float* res, float* out, const float* xs, const float* xs_stats, float* part, int B, int H,
-                         const BnFold& fold, const BwdFold& bfold, float* pool, const WFold& wf) {
+                         const BnFold& fold, const BwdFold& bfold, float* pool, const WFold& wf,
+                         const StripGeom& sg = StripGeom{1, 1, 0}) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_mfma_kernel<MODE, SLICES, HALO>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((conv3x3_mfma_kernel<MODE, SLICES, HALO>), dim3(launch_blocks(nblk, SLICES)), dim3(CONV_THREADS), lds, stream, with_probe(in),
-                       in_stats, wp, res, out, xs, xs_stats, part, pool, B, H, nblk, fold, bfold, wf);
+                       in_stats, wp, res, out, xs, xs_stats, part, pool, B, H, nblk, fold, bfold, wf, sg);
 }
 template <int MODE>
 void launch_conv3x3(int slices, int nblk, size_t lds, hipStream_t stream, const StageCfg& in, const float* in_stats, const float* wp,
                     const float* res, float* out, const float* xs, const float* xs_stats, float* part, int B, int H,
                     const BnFold& fold, const BwdFold& bfold = BwdFold{}, float* pool = nullptr,
-                    const WFold& wf = WFold{nullptr, 0, nullptr}, bool halo = false) {
-    if (halo)      // strips of a wide map (NUM_MELS = 80): one workgroup per strip, no position slicing
-        launch_conv3x3_inst<MODE, 1, true>(nblk, lds, stream, in, in_stats, wp, res, out, xs, xs_stats, part, B, H, fold, bfold, pool, wf);
+                    const WFold& wf = WFold{nullptr, 0, nullptr}, int halo = 0, const StripGeom& sg = StripGeom{1, 1, 0}) {
+    if (halo == 2)      // row (and column) strips of a long map: StripGeom
+        launch_conv3x3_inst<MODE, 1, 2>(nblk, lds, stream, in, in_stats, wp, res, out, xs, xs_stats, part, B, H, fold, bfold, pool, wf, sg);
+    else if (halo == 1)      // strips of a wide map (NUM_MELS = 80): one workgroup per strip, no position slicing
+        launch_conv3x3_inst<MODE, 1, 1>(nblk, lds, stream, in, in_stats, wp, res, out, xs, xs_stats, part, B, H, fold, bfold, pool, wf);
     else if (slices == 4)
         launch_conv3x3_inst<MODE, 4>(nblk, lds, stream, in, in_stats, wp, res, out, xs, xs_stats, part, B, H, fold, bfold, pool, wf);
     else if (slices == 2)
@@ -2319,27 +2609,29 @@ void launch_conv3x3(int slices, int nblk, size_t lds, hipStream_t stream, const 
     else
         launch_conv3x3_inst<MODE, 1>(nblk, lds, stream, in, in_stats, wp, res, out, xs, xs_stats, part, B, H, fold, bfold, pool, wf);
 }
-template <int SW, bool HALO = false>
+template <int SW, int HALO = 0>
 void launch_wgrad_inst(int nblk, size_t lds, hipStream_t stream, const StageCfg& zc, const BwdFold& bfold, const float* s_prev,
-                       const float* in_stats, float* wpart, int B, int H) {
+                       const float* in_stats, float* wpart, int B, int H, const StripGeom& sg = StripGeom{1, 1, 0}) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_mfma_kernel<SW, HALO>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((wgrad_mfma_kernel<SW, HALO>), dim3(launch_blocks(nblk, SW)), dim3(CONV_THREADS), lds, stream,
-                       WStage{with_probe(zc), s_prev, false}, in_stats, bfold, wpart, B, H, nblk);
+                       WStage{with_probe(zc), s_prev, false}, in_stats, bfold, wpart, B, H, nblk, sg);
 }
-template <int SD, int SW, bool HALO = false>
+template <int SD, int SW, int HALO = 0>
 void launch_pair_inst(int nblk, size_t lds, hipStream_t stream, const StageCfg& zc, const BwdFold& bfold, const float* wp, float* dx,
                       const float* xs, const float* xs_stats, float* spart, const float* s_prev, const float* in_stats, float* wpart,
-                      int B, int H, const WFold& wf) {
+                      int B, int H, const WFold& wf, const StripGeom& sg = StripGeom{1, 1, 0}) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(bwd_pair_kernel<SD, SW, HALO>), hipFuncAttributeMaxDynamicSharedMemorySize,
                         (int)lds);
     hipLaunchKernelGGL((bwd_pair_kernel<SD, SW, HALO>), dim3(launch_blocks(nblk, SD + SW)), dim3(CONV_THREADS), lds, stream, with_probe(zc), bfold, wp,
-                       dx, xs, xs_stats, spart, s_prev, in_stats, wpart, B, H, nblk, wf);
+                       dx, xs, xs_stats, spart, s_prev, in_stats, wpart, B, H, nblk, wf, sg);
 }
 void launch_pair(int sd, int sw, int nblk, size_t lds, hipStream_t stream, const StageCfg& zc, const BwdFold& bfold, const float* wp,
                  float* dx, const float* xs, const float* xs_stats, float* spart, const float* s_prev, const float* in_stats,
-                 float* wpart, int B, int H, const WFold& wf, bool halo = false) {
-    if (halo)
-        launch_pair_inst<1, 1, true>(nblk, lds, stream, zc, bfold, wp, dx, xs, xs_stats, spart, s_prev, in_stats, wpart, B, H, wf);
+                 float* wpart, int B, int H, const WFold& wf, int halo = 0, const StripGeom& sg = StripGeom{1, 1, 0}) {
+    if (halo == 2)
+        launch_pair_inst<1, 1, 2>(nblk, lds, stream, zc, bfold, wp, dx, xs, xs_stats, spart, s_prev, in_stats, wpart, B, H, wf, sg);
+    else if (halo == 1)
+        launch_pair_inst<1, 1, 1>(nblk, lds, stream, zc, bfold, wp, dx, xs, xs_stats, spart, s_prev, in_stats, wpart, B, H, wf);
     else if (sd == 4 && sw == 2)
         launch_pair_inst<4, 2>(nblk, lds, stream, zc, bfold, wp, dx, xs, xs_stats, spart, s_prev, in_stats, wpart, B, H, wf);
     else if (sd == 2 && sw == 2)
@@ -2354,14 +2646,16 @@ void launch_pair(int sd, int sw, int nblk, size_t lds, hipStream_t stream, const
 
 extern "C" {
 
-size_t howl_res8_workspace_bytes(int B, int T) {
-    const int H = T / 3;
-    return ws_layout(nullptr, nullptr, B, H, conv_grid(B));
-}
+size_t howl_res8_workspace_bytes(int B, int T) { return howl_res8_workspace_bytes_mels(B, T, 40); }
 
 size_t howl_res8_workspace_bytes_mels(int B, int T, int M) {
-    const int NS = mel_strips(M) > 0 ? mel_strips(M) : 1;
-    return ws_layout(nullptr, nullptr, B * NS, T / 3, even_grid(conv_grid(B * NS), NS));
+    const Strips sp = strips_for(B, T, M);
+    return ws_layout(nullptr, nullptr, sp.Bv, sp.Hs, even_grid(conv_grid(sp.Bv), sp.ns));
+}
+
+size_t howl_res8_saved_floats(int B, int T, int M) {
+    const Strips sp = strips_for(B, T, M);
+    return (size_t)sp.Bv * NMAP * sp.Hs * PW;
 }
 
 }  // extern "C"
@@ -2374,14 +2668,16 @@ int res8_fwd_impl(const HowlRes8Params* prm, const float* feat, long sb, long st
     HOWL_REQUIRE(prm && feat && sv && logits && ws, "howl_res8_fwd: null pointer");
     HOWL_REQUIRE(labels == nullptr || (nll != nullptr && dlogits != nullptr && C <= HEAD_XC),
                  "howl_res8_fwd_xent: nll / dlogits missing or more than %d classes (C=%d)", HEAD_XC, C);
-    const int NS = mel_strips(M);
-    HOWL_REQUIRE(NS > 0, "howl_res8_fwd: res8 pools (3,4) over 40 or 80 mel bins; got M=%d", M);
-    const int H = T / 3;
-    HOWL_REQUIRE(B >= 1 && H >= 1 && H <= MAX_H, "howl_res8_fwd: B=%d T=%d unsupported (3 <= T <= 83)", B, T);
+    HOWL_REQUIRE(mel_strips(M) > 0, "howl_res8_fwd: res8 pools (3,4) over 40 or 80 mel bins; got M=%d", M);
+    const int Ht = T / 3;         // pooled rows of the whole map
+    HOWL_REQUIRE(B >= 1 && Ht >= 1, "howl_res8_fwd: B=%d T=%d unsupported (T >= 3)", B, T);
     HOWL_REQUIRE(C >= 1, "howl_res8_fwd: C must be positive");
-    // wide maps: every utterance is NS strips of 10 pooled columns, each a block of the (Bv, 45, H, 10) activations (HaloSlot)
-    const int Bv = B * NS;
-    const bool halo = NS > 1;
+    // wide maps: every utterance is NS strips of 10 pooled columns (HaloSlot); long maps: NR row strips of H rows each (StripGeom);
+    // every strip is a block of the (Bv, 45, H, 10) activations
+    const Strips sp = strips_for(B, T, M);
+    HOWL_REQUIRE(sp.hv_last >= 1 && sp.nr <= 64, "howl_res8_fwd: T=%d frames unsupported (%d row strips)", T, sp.nr);
+    const int NS = sp.ns, H = sp.Hs, Bv = sp.Bv, halo = sp.halo;
+    const bool grid = halo == 2;
     const int G = even_grid(conv_grid(Bv), NS);
     Ws w;
     const size_t need = ws_layout(&w, static_cast<char*>(ws), Bv, H, G);
@@ -2390,6 +2686,7 @@ int res8_fwd_impl(const HowlRes8Params* prm, const float* feat, long sb, long st
         return HOWL_E_WORKSPACE;
     }
     const int P = H * PW;
+    const int Pt = Ht * PW * NS;      // positions of one utterance's whole map
     HowlPtrs6 cw, rm, rv;
     for (int i = 0; i < 6; ++i) {
         cw.p[i] = const_cast<float*>(prm->conv_w[i]);
@@ -2398,23 +2695,32 @@ int res8_fwd_impl(const HowlRes8Params* prm, const float* feat, long sb, long st
     }
     if (!training) hipLaunchKernelGGL(bn_eval_stats_kernel, dim3(6), dim3(64), 0, stream, rm, rv, sv->bn_stats);
 
-    const size_t l0 = conv0_tile_floats(T, M) * sizeof(float);
+    // conv0 sees an utterance (or, for row strips, its NR windows of 3 H frames with the clip's real frames on both sides)
+    const int Bw = B * sp.nr, Tw = grid ? 3 * H : T;
+    const size_t l0 = conv0_tile_floats(Tw, M) * sizeof(float);
     // 103 VGPRs and 15 KB of LDS: two workgroups per CU overlap one's tile load / stores with the other's MFMAs
-    const int S0 = conv0_slices(B);
-    const int G0 = B * S0 < 2 * howl_num_cus() ? B * S0 : 2 * howl_num_cus();
+    const int S0 = conv0_slices(Bw);
+    const int G0 = Bw * S0 < 2 * howl_num_cus() ? Bw * S0 : 2 * howl_num_cus();
     {
         HowlProfScope prof("conv0_fwd", stream);
         const int npack = (2 * 6 * PACK_ELEMS + C0M_THREADS - 1) / C0M_THREADS;
-        if (halo)
-            hipLaunchKernelGGL(conv0_fwd_mfma_kernel<2>, dim3(G0 + npack), dim3(C0M_THREADS), l0, stream, feat, sb, st, sm,
-                               prm->conv0_w, sv->s[0], sv->mask0, B, T, M, H, G0, cw, w.wp_fwd, w.wp_bwd, 1, 0, 0, S0);
+#define HOWL_CONV0_FWD(NS_, EX_)                                                                                                  \
+    hipLaunchKernelGGL((conv0_fwd_mfma_kernel<NS_, EX_>), dim3(G0 + npack), dim3(C0M_THREADS), l0, stream, feat, sb, st, sm,       \
+                       prm->conv0_w, sv->s[0], sv->mask0, Bw, Tw, M, H, G0, cw, w.wp_fwd, w.wp_bwd, grid ? sp.nr : 1,             \
+                       grid ? 3 * H : 0, grid ? T : 0, S0)
+        if (grid && NS == 2)
+            HOWL_CONV0_FWD(2, true);
+        else if (grid)
+            HOWL_CONV0_FWD(1, true);
+        else if (NS == 2)
+            HOWL_CONV0_FWD(2, false);
         else
-            hipLaunchKernelGGL(conv0_fwd_mfma_kernel<1>, dim3(G0 + npack), dim3(C0M_THREADS), l0, stream, feat, sb, st, sm,
-                               prm->conv0_w, sv->s[0], sv->mask0, B, T, M, H, G0, cw, w.wp_fwd, w.wp_bwd, 1, 0, 0, S0);
+            HOWL_CONV0_FWD(1, false);
+#undef HOWL_CONV0_FWD
     }
-    const size_t lc = conv_lds_bytes(H);
-    const double count = (double)Bv * (double)P;
-    const int SL = halo ? 1 : conv_slices(G, H, howl_num_cus());
+    const size_t lc = conv_lds_bytes(H, grid);
+    const double count = (double)B * (double)Pt;
+    const int SL = halo != 0 ? 1 : conv_slices(G, H, howl_num_cus());
     // Training: layer i leaves its statistics as per-workgroup partials; layer i+1 folds them in its own prologue (BnFold),
     // so only the last layer needs the stand-alone finalize.  The partial buffers alternate between layers.
     for (int i = 1; i <= 6; ++i) {
@@ -2434,17 +2740,18 @@ int res8_fwd_impl(const HowlRes8Params* prm, const float* feat, long sb, long st
             HowlProfScope prof("conv3x3_fwd", stream);
             launch_conv3x3<0>(SL, G, lc, stream, plain_tile(sv->s[i - 1]), in_stats, w.wp_fwd + (size_t)(i - 1) * 3 * KSTEPS * 64, res, sv->s[i],
                               nullptr, nullptr, part_out, Bv, H, fold, BwdFold{}, i == 6 ? w.pool : (float*)nullptr,
-                              WFold{nullptr, 0, nullptr}, halo);
+                              WFold{nullptr, 0, nullptr}, halo, sp.sg);
         }
     }
     // (training: the head folds BatchNorm 6's statistics itself -- no one-block finalize launch in between)
     const BnFold hfold = training ? BnFold{w.part2, G * SL, count, sv->bn_stats + (size_t)5 * 2 * CP,
                                            HowlBnBuffers{prm->bn_running_mean[5], prm->bn_running_var[5], prm->bn_num_batches[5]}}
                                   : BnFold{};
-    // the spatial mean runs over all NS strips of an utterance: NS * (4 SL) position groups, NS * P positions
+    // the spatial mean runs over all strips of an utterance: nr * ns blocks of 4 SL position groups, Pt positions
     hipLaunchKernelGGL(head_fwd_kernel, dim3(B < 1024 ? B : 1024), dim3(256), 0, stream, sv->s[6],
-                       sv->bn_stats + (size_t)5 * 2 * CP, prm->out_w, prm->out_b, sv->pooled, logits, B, NS * P, C, labels, nll, dlogits,
-                       w.dpool, 1.0f / (float)B, (const float*)w.pool, 4 * SL, 4 * SL < (P + 15) / 16 ? 4 * SL : (P + 15) / 16, hfold, NS);
+                       sv->bn_stats + (size_t)5 * 2 * CP, prm->out_w, prm->out_b, sv->pooled, logits, B, Pt, C, labels, nll, dlogits,
+                       w.dpool, 1.0f / (float)B, (const float*)w.pool, 4 * SL, 4 * SL < (P + 15) / 16 ? 4 * SL : (P + 15) / 16, hfold,
+                       sp.nr * NS);
     HOWL_CHECK_LAUNCH("howl_res8_fwd");
     return HOWL_OK;
 }
@@ -2577,12 +2884,14 @@ int res8_bwd_impl(const HowlRes8Params* prm, const float* feat, long sb, long st
                  "howl_res8_bwd: HowlAdamW needs the whole pass (part 0) and complete buffers");
     HOWL_REQUIRE(part >= 0 && part <= 2, "howl_res8_bwd_part: part must be 0 (all), 1 or 2");
     const bool run_layers = part != 2, run_conv0 = part != 1;
-    const int NS = mel_strips(M);
-    HOWL_REQUIRE(NS > 0, "howl_res8_bwd: M must be 40 or 80 (got %d)", M);
-    const int H = T / 3;
-    HOWL_REQUIRE(B >= 1 && H >= 1 && H <= MAX_H, "howl_res8_bwd: B=%d T=%d unsupported", B, T);
-    const int Bv = B * NS;        // strips of 10 pooled columns, each a block of the activations (HaloSlot)
-    const bool halo = NS > 1;
+    HOWL_REQUIRE(mel_strips(M) > 0, "howl_res8_bwd: M must be 40 or 80 (got %d)", M);
+    const int Ht = T / 3;
+    HOWL_REQUIRE(B >= 1 && Ht >= 1, "howl_res8_bwd: B=%d T=%d unsupported", B, T);
+    const Strips sp = strips_for(B, T, M);      // column strips (HaloSlot) x row strips (StripGeom), each a block of the activations
+    HOWL_REQUIRE(sp.hv_last >= 1 && sp.nr <= 64, "howl_res8_bwd: T=%d frames unsupported (%d row strips)", T, sp.nr);
+    const int NS = sp.ns, H = sp.Hs, Bv = sp.Bv, halo = sp.halo;
+    const bool grid = halo == 2;
+    const int Pt = Ht * PW * NS;      // positions of one utterance's whole map
     const int G = even_grid(conv_grid(Bv), NS);
     Ws w;
     const size_t need = ws_layout(&w, static_cast<char*>(ws), Bv, H, G);
@@ -2591,7 +2900,7 @@ int res8_bwd_impl(const HowlRes8Params* prm, const float* feat, long sb, long st
         return HOWL_E_WORKSPACE;
     }
     const int P = H * PW;
-    const double count = (double)Bv * (double)P;
+    const double count = (double)B * (double)Pt;
     const size_t act = (size_t)Bv * NMAP * P;
     HOWL_REQUIRE(act / 2 < (size_t)1 << 31, "howl_res8_bwd: B=%d too large for the 32-bit element index of the elementwise pass", B);
     int eg = (int)((act / 4 + BRB_THREADS - 1) / BRB_THREADS);      // one 16-byte quad per thread and trip
@@ -2603,9 +2912,9 @@ int res8_bwd_impl(const HowlRes8Params* prm, const float* feat, long sb, long st
             hipLaunchKernelGGL(head_bwd_pool_kernel, dim3((B * CP + 255) / 256), dim3(256), 0, stream, dlogits, prm->out_w, w.dpool,
                                B, C);
         hipLaunchKernelGGL(head_bwd_param_kernel, dim3(C + (nll != nullptr ? 2 : 1)), dim3(1024), 0, stream, dlogits, sv->pooled,
-                           w.dpool, gr->out_w, gr->out_b, w.m12, B, C, NS * P, nll, loss);
+                           w.dpool, gr->out_w, gr->out_b, w.m12, B, C, Pt, nll, loss);
     }
-    const size_t lc = conv_lds_bytes(H);
+    const size_t lc = conv_lds_bytes(H, grid);
     const size_t lw = wgrad_lds_bytes(H);
     const size_t lp = lc > lw ? lc : lw;
     const char* pair_env = getenv("HOWL_RES8_BWD_PAIR");
@@ -2613,13 +2922,13 @@ int res8_bwd_impl(const HowlRes8Params* prm, const float* feat, long sb, long st
     // HOWL_RES8_BWD_FUSED=0: the elementwise BatchNorm / ReLU backward as its own launch per layer (bn_relu_bwd_kernel writes
     // dz_i, the pair stages it as it is) -- the reference point of the tests; default: built inside the pair's staging
     const char* fused_env = getenv("HOWL_RES8_BWD_FUSED");
-    const bool fused = halo || !(fused_env != nullptr && fused_env[0] == '0');   // (wide maps: the fused staging only)
+    const bool fused = halo != 0 || !(fused_env != nullptr && fused_env[0] == '0');   // (strips: the fused staging only)
     // dgrad and wgrad side by side: half the CUs each
     const int half = howl_num_cus() / 2 > 0 ? howl_num_cus() / 2 : 1;
     const int Gh = even_grid(Bv < half ? Bv : half, NS);
     const size_t wpart_stride = (size_t)Gh * CP * WNCOL;
     int SD = 1, SW = 1;
-    if (!halo) pair_slices(Gh, H, &SD, &SW);
+    if (halo == 0) pair_slices(Gh, H, &SD, &SW);
     // the fold of a layer's weight-gradient partials rides in the NEXT pair launch when that launch has enough data-gradient
     // workgroups to spread the 9,984 column pairs thin (a single utterance's four workgroups would walk 26 trips of two barriers
     // each: +60 us at batch 1); small batches keep the one reduction launch at the end
@@ -2642,7 +2951,7 @@ int res8_bwd_impl(const HowlRes8Params* prm, const float* feat, long sb, long st
         StageCfg zc = plain_tile(dz);
         if (fused)
             zc = StageCfg{dx_cur, sv->s[i], even ? (const float*)ds_prev : (const float*)nullptr, ds_out, w.dpool,
-                          1.0f / (float)(NS * P), true, even, false};
+                          1.0f / (float)Pt, true, even, false};
         else if (run_layers)
             hipLaunchKernelGGL(bn_relu_bwd_kernel, dim3(eg), dim3(BRB_THREADS), 0, stream, (const float*)dx_cur, w.dpool, sv->s[i],
                                stats_i, w.m12, bfold.part, Gh * SD, count, even ? (const float*)ds_prev : (const float*)nullptr,
@@ -2669,17 +2978,19 @@ int res8_bwd_impl(const HowlRes8Params* prm, const float* feat, long sb, long st
             // part 2 only replays the buffer rotation of the loop
         } else if (merged) {
             HowlProfScope prof("bwd_pair", stream);
-            launch_pair(SD, SW, Gh, lp, stream, zc, bfold, wpb, dx_next, xs, xs_st, spart, sv->s[i - 1], in_stats, wpart, Bv, H, wf, halo);
+            launch_pair(SD, SW, Gh, lp, stream, zc, bfold, wpb, dx_next, xs, xs_st, spart, sv->s[i - 1], in_stats, wpart, Bv, H, wf, halo, sp.sg);
         } else {
             {
                 HowlProfScope prof("conv3x3_dgrad", stream);
-                launch_conv3x3<1>(SD, Gh, lc, stream, zc, nullptr, wpb, nullptr, dx_next, xs, xs_st, spart, Bv, H, BnFold{}, bfold, nullptr, wf, halo);
+                launch_conv3x3<1>(SD, Gh, lc, stream, zc, nullptr, wpb, nullptr, dx_next, xs, xs_st, spart, Bv, H, BnFold{}, bfold, nullptr, wf, halo, sp.sg);
             }
             HowlProfScope prof("wgrad", stream);
             StageCfg zw = zc;
             zw.ds = nullptr;
-            if (halo)
-                launch_wgrad_inst<1, true>(Gh, lw, stream, zw, bfold, sv->s[i - 1], in_stats, wpart, Bv, H);
+            if (halo == 2)
+                launch_wgrad_inst<1, 2>(Gh, lw, stream, zw, bfold, sv->s[i - 1], in_stats, wpart, Bv, H, sp.sg);
+            else if (halo == 1)
+                launch_wgrad_inst<1, 1>(Gh, lw, stream, zw, bfold, sv->s[i - 1], in_stats, wpart, Bv, H);
             else if (SW == 2)
                 launch_wgrad_inst<2>(Gh, lw, stream, zw, bfold, sv->s[i - 1], in_stats, wpart, B, H);
             else
@@ -2703,13 +3014,21 @@ int res8_bwd_impl(const HowlRes8Params* prm, const float* feat, long sb, long st
     if (run_conv0) {
         {
         HowlProfScope prof("conv0_wgrad", stream);
-        const size_t l0w = ((size_t)(T + 2) * (M + 4) + 16) * sizeof(float);
-        if (halo)
-            hipLaunchKernelGGL(conv0_wgrad_valu_kernel<2>, dim3(G0w), dim3(C0G_THREADS), l0w, stream, feat, sb, st, sm,
-                               (const unsigned short*)sv->mask0, (const float*)dx_cur, (const float*)nullptr, w.c0part, B, T, M, H, S0);
+        const int Tw = grid ? 3 * H : T;      // frames of one row strip (its window of the clip), or the utterance
+        const size_t l0w = ((size_t)(Tw + 2) * (M + 4) + 16) * sizeof(float);
+#define HOWL_CONV0_WGRAD(NS_, EX_)                                                                                                \
+    hipLaunchKernelGGL((conv0_wgrad_valu_kernel<NS_, EX_>), dim3(G0w), dim3(C0G_THREADS), l0w, stream, feat, sb, st, sm,           \
+                       (const unsigned short*)sv->mask0, (const float*)dx_cur, (const float*)nullptr, w.c0part, B, Tw, M, H, S0,  \
+                       sp.sg, T)
+        if (grid && NS == 2)
+            HOWL_CONV0_WGRAD(2, true);
+        else if (grid)
+            HOWL_CONV0_WGRAD(1, true);
+        else if (NS == 2)
+            HOWL_CONV0_WGRAD(2, false);
         else
-            hipLaunchKernelGGL(conv0_wgrad_valu_kernel<1>, dim3(G0w), dim3(C0G_THREADS), l0w, stream, feat, sb, st, sm,
-                               (const unsigned short*)sv->mask0, (const float*)dx_cur, (const float*)nullptr, w.c0part, B, T, M, H, S0);
+            HOWL_CONV0_WGRAD(1, false);
+#undef HOWL_CONV0_WGRAD
         }
         if (part == 0) {    // rows {layer 1, conv0} of the reduction (small batches: all six layers and conv0)
             // ... and, on a single replica, the optimiser step (HowlAdamW): folded rows are updated as they are written, one more

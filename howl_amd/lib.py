@@ -136,7 +136,7 @@ SIGNATURES = {
 }
 # entry points that do not return an int status
 SIZE_FUNCS = {"howl_fb_packed_floats": [c_int], "howl_res8_workspace_bytes": [c_int, c_int], "howl_res8_long_workspace_bytes": [c_int, c_int],
-              "howl_res8_workspace_bytes_mels": [c_int, c_int, c_int], "howl_res8_long_workspace_bytes_mels": [c_int, c_int, c_int], "howl_lstm_workspace_bytes": [c_int, c_int],
+              "howl_res8_workspace_bytes_mels": [c_int, c_int, c_int], "howl_res8_saved_floats": [c_int, c_int, c_int], "howl_res8_long_workspace_bytes_mels": [c_int, c_int, c_int], "howl_lstm_workspace_bytes": [c_int, c_int],
               "howl_lstm_needs_gx": [POINTER(HowlLstmParams), c_int, c_int, c_int, c_int],
               "howl_head_workspace_bytes": [c_int, c_int, c_int],
               "howl_mobilenet_num_layers": [],

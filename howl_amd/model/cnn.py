@@ -40,10 +40,11 @@ class _Res8Buffers:
         H = T // 3
         f32 = dict(dtype=torch.float32, device=device)
         self.key = (B, T, M, C, str(device))
-        self.s = [torch.empty((B, 45, H, M // 4), **f32) for _ in range(7)]
+        n = _lib.get().cdll.howl_res8_saved_floats(B, T, M)     # (B, 45, H, M/4) up to 83 frames; row strips beyond (padded)
+        self.s = [torch.empty(n, **f32) for _ in range(7)]
         self.bn_stats = torch.zeros((6, 2, 48), **f32)
         self.pooled = torch.empty((B, 48), **f32)
-        self.mask0 = torch.empty((B, 45, H, M // 4), dtype=torch.int16, device=device)
+        self.mask0 = torch.empty(n, dtype=torch.int16, device=device)
         nbytes = _lib.get().cdll.howl_res8_workspace_bytes_mels(B, T, M)
         self.ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
         self.saved = _lib.HowlRes8Saved()
@@ -167,14 +168,12 @@ class Res8(RegisteredModel, name="res8"):
         return x0, x0.stride(0), x0.stride(2), x0.stride(1)
 
     # ---- launches ----------------------------------------------------------------------------------------------
-    MAX_FRAMES = 83     # one utterance's pooled map (27 rows) lives in LDS; longer inputs are windowed (inference only)
+    MAX_FRAMES = 83     # one utterance's pooled map (27 rows) fits the kernels' tile; longer inputs run as overlapping windows in
+                        # eval mode (howl_res8_fwd_long) and as row strips with exchanged halo rows in training (howl_res8_fwd)
+    MAX_TRAIN_FRAMES = 64 * 27 * 3
 
     def _launch_forward_long(self, x0, sb, st, sm):
-        """Inputs beyond 83 frames (``ConvertedStaticModel``'s first window, engine clips > 1 s): ``howl_res8_fwd_long``."""
-        if self.training:
-            raise NotImplementedError(f"Res8 on MI355X trains on windows of up to {self.MAX_FRAMES} frames (1.03 s; the "
-                                      f"reference's presets use 0.5 s / 1 s); got T={x0.shape[2]}. Longer inputs are "
-                                      "supported in eval mode")
+        """Eval-mode inputs beyond 83 frames (``ConvertedStaticModel``'s first window, engine clips > 1 s): ``howl_res8_fwd_long``."""
         B, M, T = x0.shape
         nbytes = _lib.get().cdll.howl_res8_long_workspace_bytes_mels(B, T, M)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=x0.device)
@@ -188,7 +187,7 @@ class Res8(RegisteredModel, name="res8"):
     def _launch_forward(self, feat, grads_struct=None):
         x0, sb, st, sm = self._feat_view(feat)
         B, M, T = x0.shape
-        if T > self.MAX_FRAMES:
+        if T > self.MAX_FRAMES and not self.training:
             return self._launch_forward_long(x0, sb, st, sm)
         buf = self._get_buffers(B, T, x0.device, M)
         logits = torch.empty((B, self.num_labels), dtype=torch.float32, device=x0.device)
@@ -207,8 +206,8 @@ class Res8(RegisteredModel, name="res8"):
         ``_launch_forward`` + ``ops.xent`` + ``_launch_backward``, two launches fewer."""
         x0, sb, st, sm = self._feat_view(feat)
         B, M, T = x0.shape
-        if T > self.MAX_FRAMES or not self.training or self.num_labels > self.XENT_MAX_LABELS:
-            raise NotImplementedError("fused forward + cross-entropy: training mode, T <= 83 frames, <= 64 labels")
+        if not self.training or self.num_labels > self.XENT_MAX_LABELS:
+            raise NotImplementedError("fused forward + cross-entropy: training mode, <= 64 labels")
         buf = self._get_buffers(B, T, x0.device, M)
         f32 = dict(dtype=torch.float32, device=x0.device)
         logits = torch.empty((B, self.num_labels), **f32)

@@ -83,8 +83,7 @@ class FusedTrainer:
     def step_on_features(self, feat, labels, lengths=None, max_frames=None):
         """``lengths`` / ``max_frames``: frame counts for models that pack their input (``SimpleLstm``); ignored otherwise."""
         bwd_kw = {}
-        fused_xent = (hasattr(self.model, "_launch_forward_xent") and self.model.num_labels <= self.model.XENT_MAX_LABELS
-                      and feat.shape[-1] <= self.model.MAX_FRAMES)
+        fused_xent = hasattr(self.model, "_launch_forward_xent") and self.model.num_labels <= self.model.XENT_MAX_LABELS
         if fused_xent:     # res8: the loss rides in the forward's last launch and the backward's second (two launches fewer)
             logits, nll, dlogits = self.model._launch_forward_xent(feat, labels)
             loss = torch.empty(1, dtype=torch.float32, device=logits.device)

@@ -160,10 +160,11 @@ typedef struct {
 
 /* activations the backward pass needs; all caller-allocated */
 typedef struct {
-    float* s[7];       /* s[0] = avgpool(relu(conv0(x))); s[i] = layer i's pre-BatchNorm output; each (B,45,T/3,M/4) floats.
+    float* s[7];       /* s[0] = avgpool(relu(conv0(x))); s[i] = layer i's pre-BatchNorm output; each howl_res8_saved_floats(B,T,M) floats = (B,45,T/3,M/4) for T <= 83.
                         * Values are >= 0 by construction; for i = 2,4,6 the sign bit carries the ReLU mask of conv_i
                         * (the backward needs it), so readers take |s|.  M = 40: the reference's NCHW layout; M = 80: the
-                        * library's own -- utterance b is the two blocks 2b, 2b+1 of (45,T/3,10): pooled columns 0..9, 10..19. */
+                        * library's own -- utterance b is the two blocks 2b, 2b+1 of (45,T/3,10): pooled columns 0..9, 10..19;
+                        * T > 83: nr = ceil(T/3 / 27) row strips of Hs = ceil(T/3 / nr) pooled rows, block (b * nr + r) * (M/40) + c. */
     float* bn_stats;   /* (6, 2, 48): per layer {mean[48], rstd[48]} used by this forward */
     float* pooled;     /* (B, 48): spatial mean of BN6's output */
     unsigned short* mask0; /* (B,45,T/3,M/4) uint16, laid out like s[0]: ReLU pattern of conv0's 3x4 pre-pool window (bit 4i+j); NULL in eval */
@@ -174,6 +175,10 @@ typedef struct {
  * column.  howl_res8_workspace_bytes(B, T) is the M = 40 size. */
 size_t howl_res8_workspace_bytes(int B, int T);
 size_t howl_res8_workspace_bytes_mels(int B, int T, int M);
+/* Floats of ONE saved activation tensor (HowlRes8Saved.s[i]; mask0 has as many uint16).  B*45*(T/3)*(M/4) up to 83 frames; longer
+ * utterances (cnn.py:127-145 takes any T) run as row strips of equal height, the last one padded, so the tensors are a little
+ * larger: always size them with this. */
+size_t howl_res8_saved_floats(int B, int T, int M);
 
 /* feat: log-mel features, element (b, t, m) at feat[b*sb + t*st + m*sm] (so both the (B,T,M) model layout and
  * channel 0 of the reference's (B,3,M,T) tensor are accepted; replaces x[:, :1].permute(0,1,3,2), cnn.py:128-129).

@@ -43,12 +43,13 @@ def res8_relu_masks(model, B, T, M):
     patterns per pooled cell, the sign of s_i for the layers without a residual add, its sign BIT for those with one."""
     buf = next(v for k, v in model._buffers_cache.items() if k[0] == B and k[1] == T and k[2] == M)
     H, W = T // 3, M // 4
+    ns = W // 10                                  # column strips of 10 pooled columns (80 mel bins: two)
+    nr = 1 if H <= 27 else -(-H // 27)            # row strips beyond 83 frames, Hs rows each, the last one padded
+    Hs = -(-H // nr)
 
-    def unstrip(t):      # 80 mel bins: utterance b is the two blocks 2b, 2b+1 of (45, H, 10) -- pooled columns 0..9, 10..19
-        t = t.detach().cpu()
-        if W == 10:
-            return t.reshape(B, 45, H, 10)
-        return t.reshape(B, W // 10, 45, H, 10).permute(0, 2, 3, 1, 4).reshape(B, 45, H, W)
+    def unstrip(t):      # block (b * nr + r) * ns + c of (45, Hs, 10) = rows r Hs .., columns 10 c .. of utterance b
+        t = t.detach().cpu().reshape(B, nr, ns, 45, Hs, 10)
+        return t.permute(0, 3, 1, 4, 2, 5).reshape(B, 45, nr * Hs, W)[:, :, :H]
 
     bits = unstrip(buf.mask0).to(torch.int32) & 0xFFFF
     m0 = torch.zeros(B, 45, T, M, dtype=torch.bool)

@@ -34,7 +34,9 @@ class Res8Harness:
             self.prm.bn_num_batches[i] = ptr(self.np[f"bn{i+1}.num_batches_tracked"]).value
         self.prm.out_w = ptr(self.np["output.weight"])
         self.prm.out_b = ptr(self.np["output.bias"])
-        self.s = [np.full((B, 45, self.H, W), np.nan, np.float32) for _ in range(7)]
+        nsaved = lib.cdll.howl_res8_saved_floats(B, T, M)
+        assert nsaved >= B * 45 * self.H * W and (T > 83 or nsaved == B * 45 * self.H * W)
+        self.s = [np.full(nsaved, np.nan, np.float32) for _ in range(7)]
         self.bn_stats = np.zeros((6, 2, 48), np.float32)
         self.pooled = np.zeros((B, 48), np.float32)
         self.saved = HowlRes8Saved()
@@ -42,7 +44,7 @@ class Res8Harness:
             self.saved.s[i] = ptr(self.s[i]).value
         self.saved.bn_stats = ptr(self.bn_stats)
         self.saved.pooled = ptr(self.pooled)
-        self.mask0 = np.zeros((B, 45, self.H, W), np.uint16)
+        self.mask0 = np.zeros(nsaved, np.uint16)
         self.saved.mask0 = ptr(self.mask0)
         self.grads_np = {k: np.full_like(self.np[k], np.nan) for k in om.res8_param_names()}
         self.gr = HowlRes8Grads()
@@ -128,11 +130,11 @@ def test_res8_train_step(lib, B, T, C):
         np.testing.assert_allclose(grads[n], gref.numpy(), rtol=0, atol=2e-5 * scale, err_msg=n)
 
 
-def _wide_step(lib, B, T, C, seed):
-    """One training step at 80 mel bins on the emulator and on the oracle: (harness, logits, grads, oracle logits, oracle grads)."""
-    x = feats(B, T, seed, M=80)
+def _wide_step(lib, B, T, C, seed, M=80):
+    """One training step at M mel bins on the emulator and on the oracle: (harness, logits, grads, oracle logits, oracle grads)."""
+    x = feats(B, T, seed, M=M)
     labels = torch.arange(B) % C
-    h = Res8Harness(lib, B, T, C, M=80)
+    h = Res8Harness(lib, B, T, C, M=M)
     sd = om.res8_init(C)
     logits = h.fwd(x[:, 0].permute(0, 2, 1).numpy(), training=True)
     names = om.res8_param_names()
@@ -154,6 +156,23 @@ def test_res8_at_80_mel_bins_train_step(lib, B, T, C):
     run as two strips of 10 that fetch each other's edge column in all three 3x3 roles (csrc/res8.hip HaloSlot).  Logits,
     BatchNorm buffers and every gradient against the oracle; odd batches and a grid of one strip pair included."""
     h, sd_ref, logits, grads, ref_logits, gref = _wide_step(lib, B, T, C, seed=21)
+    np.testing.assert_allclose(logits, ref_logits, rtol=0, atol=2e-5)
+    for i in (1, 3, 6):
+        np.testing.assert_allclose(h.np[f"bn{i}.running_mean"], sd_ref[f"bn{i}.running_mean"].numpy(), atol=1e-6)
+        np.testing.assert_allclose(h.np[f"bn{i}.running_var"], sd_ref[f"bn{i}.running_var"].numpy(), atol=1e-6)
+    for n, g in gref.items():
+        scale = max(1.0, float(g.abs().max()))
+        np.testing.assert_allclose(grads[n], g.numpy(), rtol=0, atol=2e-5 * scale, err_msg=n)
+
+
+@pytest.mark.parametrize("B,T,C,M", [(2, 101, 4, 40), (1, 120, 4, 80), (1, 250, 12, 40)])
+def test_res8_trains_beyond_83_frames(lib, B, T, C, M):
+    """cnn.py:127-145 takes any T.  More than 27 pooled rows do not fit the kernels' tile, so a longer utterance runs as row strips
+    of equal height that fetch real halo rows (and corners) from their neighbours; the last strip may own fewer rows than its
+    block has -- those are zero on the way into every tile and left out of every sum (csrc/res8.hip StripGeom).  101 frames: two
+    strips of 17 rows, the second with 16; 120 at 80 bins: 2 x 2 strips; 250: four strips of 21 (20).  Logits, BatchNorm buffers
+    and every gradient against the oracle."""
+    h, sd_ref, logits, grads, ref_logits, gref = _wide_step(lib, B, T, C, seed=31, M=M)
     np.testing.assert_allclose(logits, ref_logits, rtol=0, atol=2e-5)
     for i in (1, 3, 6):
         np.testing.assert_allclose(h.np[f"bn{i}.running_mean"], sd_ref[f"bn{i}.running_mean"].numpy(), atol=1e-6)

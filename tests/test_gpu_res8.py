@@ -211,7 +211,7 @@ def test_loss_decreases_and_errors_are_loud():
     with pytest.raises(Exception):
         cpu_model(torch.zeros(2, 1, 40, 81), None)            # no CPU fallback
     with pytest.raises(Exception):
-        model(torch.zeros(2, 1, 40, 300, device=DEV), None)   # T beyond the supported window: error, not garbage
+        model(torch.zeros(2, 1, 48, 81, device=DEV), None)    # a mel count the kernels are not built for: error, not garbage
 
 
 @pytest.mark.parametrize("B,T,C", [(1, 83, 4), (3, 82, 12), (5, 64, 12), (2, 44, 30), (7, 10, 4), (4, 3, 12), (16, 81, 12),
@@ -327,9 +327,11 @@ def test_long_inputs_in_eval_mode_vs_oracle(B, T):
         got = model(x.to(DEV), None)
     assert maxerr(got, ref) < LOGIT_TOL
     assert torch.equal(got.argmax(1).cpu(), ref.argmax(1))
+    # training mode takes the same clip as row strips with exchanged halo rows (test_res8_trains_beyond_83_frames_vs_oracle)
     model.train()
-    with pytest.raises(NotImplementedError):
-        model(x.to(DEV), None)           # training windows are <= 83 frames: loud, not wrong
+    tr = model(x.to(DEV), None)
+    ref_tr = om.res8_forward({k: v.clone() for k, v in sd.items()}, x, True)
+    assert maxerr(tr, ref_tr) < LOGIT_TOL
 
 
 @pytest.mark.parametrize("B,T", [(24, 41), (16, 81), (64, 81), (1, 81)])
@@ -585,3 +587,77 @@ def test_golden_stock_80_mel_bins(golden, monkeypatch):
     model.eval()
     with torch.no_grad():
         assert maxerr(model(x, None), g["eval_logits_after1"]) < 2e-3
+
+
+@pytest.mark.parametrize("B,T,C,M", [(64, 101, 12, 40), (512, 121, 12, 40), (8, 161, 4, 80), (3, 250, 12, 40), (33, 84, 30, 80)])
+def test_res8_trains_beyond_83_frames_vs_oracle(B, T, C, M):
+    """cnn.py:127-145 takes any T (MAX_WINDOW_SIZE_SECONDS beyond 1.03 s).  More than 27 pooled rows do not fit the kernels' tile:
+    the utterance runs as row strips of equal height that fetch real halo rows (and corners, at 80 mel bins) from their
+    neighbours; a last strip that owns fewer rows than its block keeps the rest at zero in every tile and out of every sum
+    (csrc/res8.hip StripGeom).  1.25 s, 1.5 s at the full batch, 2 s at 80 bins (53 rows: 27 + 26), 3.1 s in four strips, 84 frames
+    (28 rows: 14 + 14): training forward, every gradient with the kernels' own ReLU decisions, BatchNorm buffers, bit-repeatable."""
+    from gpu_util import res8_oracle_with_kernel_relus
+    names = om.res8_param_names()
+    labels = torch.arange(B) % C
+    torch.manual_seed(B * 100 + T)
+    x = (torch.randn(B, T, M) * 1.2).permute(0, 2, 1).unsqueeze(1)
+    model = make_res8(C)
+    logits = model(x.to(DEV), None)
+    torch.nn.functional.cross_entropy(logits, labels.to(DEV)).backward()
+    ref, ref_grads, flips, sd = res8_oracle_with_kernel_relus(model, x, labels, B, T, M, C)
+    assert maxerr(logits, ref) < LOGIT_TOL
+    for n, p in zip(names, model.hot_parameters()):
+        g = ref_grads[n]
+        assert maxerr(p.grad, g) < 2e-5 * max(1.0, g.abs().max().item()), (n, flips)
+    for i in (1, 4, 6):
+        assert maxerr(getattr(model, f"bn{i}").running_mean, sd[f"bn{i}.running_mean"]) < 1e-5
+        assert maxerr(getattr(model, f"bn{i}").running_var, sd[f"bn{i}.running_var"]) < 1e-4
+    model2 = make_res8(C)
+    logits2 = model2(x.to(DEV), None)
+    torch.nn.functional.cross_entropy(logits2, labels.to(DEV)).backward()
+    assert torch.equal(logits2, logits)
+    for p, q in zip(model.hot_parameters(), model2.hot_parameters()):
+        assert torch.equal(p.grad, q.grad)
+    # eval mode on the same clip goes through the windowed path: same function
+    model.eval()
+    with torch.no_grad():
+        ev = model(x.to(DEV), None)
+    ref_ev = om.res8_forward({k: v.detach() for k, v in sd.items()}, x.contiguous(), False)
+    assert maxerr(ev, ref_ev) < 1e-4 * max(1.0, ref_ev.abs().max().item())
+
+
+def test_fused_trainer_on_two_second_windows():
+    """The fused step (loss inside the forward's last launch, AdamW inside the last fold) at MAX_WINDOW_SIZE_SECONDS=2: 161 frames,
+    two row strips (27 + 26 rows) per utterance, against the oracle's step."""
+    from howl_amd.data.transform.operator import ZmuvTransform
+    from howl_amd.data.transform.transform import StandardAudioTransform
+    from howl_amd.training.fused import FusedRes8Trainer
+    from howl_amd.utils.synth import synthetic_pcm
+    B, L, C = 96, 32000, 12
+    pcm = synthetic_pcm(B, L)
+    labels = torch.arange(B) % C
+    std = StandardAudioTransform().to(DEV).eval()
+    zmuv = ZmuvTransform().to(DEV)
+    zmuv.update(std(pcm[:4].to(DEV)))
+    model = make_res8(C)
+    trainer = FusedRes8Trainer(model, std, zmuv, lr=0.01, weight_decay=1e-5)
+    loss = trainer.step(pcm.to(DEV), labels.to(DEV))
+    grads = [g.clone() for g in trainer.fp.grad_views]
+    fb = ofe.mel_fb(40)
+    z = ofe.Zmuv()
+    z.update(ofe.standard_audio_transform(pcm[:4], fb))
+    x = z(ofe.standard_audio_transform(pcm, fb))
+    assert x.shape[-1] == 161
+    sd = om.res8_init(C)
+    names = om.res8_param_names()
+    opt = om.AdamWState([sd[n] for n in names], 0.01, 1e-5)
+    ref_loss, ref_logits, ref_grads = om.train_step(lambda s_, xx: om.res8_forward(s_, xx, True), sd, names, opt, x, labels)
+    assert maxerr(trainer.last_logits, ref_logits) < LOGIT_TOL
+    assert abs(loss.item() - ref_loss.item()) < 1e-4
+    for n, g in zip(names, grads):
+        assert maxerr(g, ref_grads[n]) < 5e-5 * max(1.0, ref_grads[n].abs().max().item()), n
+    for n, p in zip(names, model.hot_parameters()):
+        solid = ref_grads[n].abs() > 1e-5
+        assert maxerr(p.detach().cpu()[solid], sd[n][solid]) < 2e-4, n
+    losses = [trainer.step(pcm.to(DEV), labels.to(DEV)).item() for _ in range(12)]
+    assert losses[-1] < loss.item()
