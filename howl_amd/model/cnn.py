@@ -168,9 +168,10 @@ class Res8(RegisteredModel, name="res8"):
         return x0, x0.stride(0), x0.stride(2), x0.stride(1)
 
     # ---- launches ----------------------------------------------------------------------------------------------
-    MAX_FRAMES = 83     # one utterance's pooled map (27 rows) fits the kernels' tile; longer inputs run as overlapping windows in
-                        # eval mode (howl_res8_fwd_long) and as row strips with exchanged halo rows in training (howl_res8_fwd)
-    MAX_TRAIN_FRAMES = 64 * 27 * 3
+    MAX_FRAMES = 83     # one utterance's pooled map (27 rows) fits the kernels' tile; longer inputs run as row strips with exchanged
+                        # halo rows (howl_res8_fwd / _bwd, training and eval; up to 64 strips = 5,184 frames).  The windowed
+                        # eval-mode forward of rounds 2-5 (howl_res8_fwd_long: overlapping 27-row windows, 2.1 x the arithmetic)
+                        # stays in the library and behind _launch_forward_long
 
     def _launch_forward_long(self, x0, sb, st, sm):
         """Eval-mode inputs beyond 83 frames (``ConvertedStaticModel``'s first window, engine clips > 1 s): ``howl_res8_fwd_long``."""
@@ -187,8 +188,6 @@ class Res8(RegisteredModel, name="res8"):
     def _launch_forward(self, feat, grads_struct=None):
         x0, sb, st, sm = self._feat_view(feat)
         B, M, T = x0.shape
-        if T > self.MAX_FRAMES and not self.training:
-            return self._launch_forward_long(x0, sb, st, sm)
         buf = self._get_buffers(B, T, x0.device, M)
         logits = torch.empty((B, self.num_labels), dtype=torch.float32, device=x0.device)
         prm = self._params_struct()

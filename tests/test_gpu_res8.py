@@ -312,8 +312,9 @@ def test_loss_inside_the_forward_launch_is_bit_identical(B, C):
 
 @pytest.mark.parametrize("B,T", [(3, 84), (2, 120), (4, 201), (1, 500)])
 def test_long_inputs_in_eval_mode_vs_oracle(B, T):
-    """Res8 accepts any T in the reference (cnn.py:127-145).  Beyond the 83 frames that fit the on-chip map the HIP path runs
-    overlapping 27-row windows (howl_res8_fwd_long); eval-mode logits vs the oracle over the whole clip, through the module."""
+    """Res8 accepts any T in the reference (cnn.py:127-145).  Beyond the 83 frames that fit the on-chip map the HIP path runs row
+    strips with exchanged halo rows (the module, eval and training) or overlapping 27-row windows (howl_res8_fwd_long, eval only):
+    logits of both vs the oracle over the whole clip."""
     C = 12
     sd = om.res8_init(C)
     gen = torch.Generator().manual_seed(T)
@@ -327,6 +328,9 @@ def test_long_inputs_in_eval_mode_vs_oracle(B, T):
         got = model(x.to(DEV), None)
     assert maxerr(got, ref) < LOGIT_TOL
     assert torch.equal(got.argmax(1).cpu(), ref.argmax(1))
+    # (the module runs long clips as row strips since round 5; the windowed forward is still an entry point of the library)
+    x0, sb, st, sm = model._feat_view(x.to(DEV))
+    assert maxerr(model._launch_forward_long(x0, sb, st, sm), ref) < LOGIT_TOL
     # training mode takes the same clip as row strips with exchanged halo rows (test_res8_trains_beyond_83_frames_vs_oracle)
     model.train()
     tr = model(x.to(DEV), None)
