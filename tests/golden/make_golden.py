@@ -541,6 +541,48 @@ def wide_golden():
         SETTINGS.audio_transform.num_mels = old
 
 
+def long_window_golden():
+    """G14: the reference's res8 on 2-s windows (MAX_WINDOW_SIZE_SECONDS=2: 161 frames, cnn.py:127-145 takes any T) -- pairs of the
+    GSC clips concatenated, 40 and 80 mel bins: eval logits, one training step's logits / loss / gradients / BatchNorm buffers."""
+    clips = [read_wav(GSC / w) for w in WAVS]
+    pairs = [np.concatenate([np.pad(clips[i], (0, 16000 - len(clips[i]))), np.pad(clips[j], (0, 16000 - len(clips[j])))])
+             for i, j in ((0, 3), (4, 1), (2, 5))]
+    audio = torch.from_numpy(np.stack(pairs))
+    out = {"audio": audio}
+    old = SETTINGS.audio_transform.num_mels
+    try:
+        for mels in (40, 80):
+            SETTINGS.audio_transform.num_mels = mels
+            std = StandardAudioTransform().eval()
+            zmuv = ZmuvTransform()
+            for c in clips:
+                zmuv.update(std(torch.from_numpy(c)[None]))
+            x = zmuv(std(audio))
+            assert x.shape == (3, 3, mels, 161)
+            C = 12
+            model = RegisteredModel.find_registered_class("res8")(C)
+            model.load_state_dict(om.res8_init(C))
+            model.eval()
+            pre = f"m{mels}."
+            out[pre + "x"] = x[:, :1].clone()
+            with torch.no_grad():
+                out[pre + "eval_logits"] = model(x, None)
+            labels = torch.arange(x.size(0)) % C
+            model.train()
+            scores = model(x, None)
+            loss = torch.nn.CrossEntropyLoss()(scores, labels)
+            loss.backward()
+            out[pre + "train_logits"], out[pre + "loss0"] = scores.detach().clone(), loss.detach().clone()
+            for n, p in model.named_parameters():
+                out[pre + "grad0." + n] = p.grad.detach().clone()
+            for i in (1, 6):
+                out[pre + f"bn{i}.running_mean.1"] = getattr(model, f"bn{i}").running_mean.clone()
+                out[pre + f"bn{i}.running_var.1"] = getattr(model, f"bn{i}").running_var.clone()
+    finally:
+        SETTINGS.audio_transform.num_mels = old
+    save("g14_res8_two_second_windows", **out)
+
+
 if __name__ == "__main__":
     only = [a for a in sys.argv[1:] if a.startswith("--only-")]
     if not only:
@@ -557,3 +599,5 @@ if __name__ == "__main__":
         checkpoint_golden()
     if not only or "--only-wide" in only:
         wide_golden()
+    if not only or "--only-long" in only:
+        long_window_golden()

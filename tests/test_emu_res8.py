@@ -182,6 +182,28 @@ def test_res8_trains_beyond_83_frames(lib, B, T, C, M):
         np.testing.assert_allclose(grads[n], g.numpy(), rtol=0, atol=2e-5 * scale, err_msg=n)
 
 
+def test_golden_two_second_windows_on_the_emulator(lib, golden):
+    """G14 (outputs of the reference's res8 on 161-frame inputs: two row strips of 27 + 26 pooled rows per utterance): the kernels
+    on the emulator against the reference's training logits, loss gradient of every parameter and BatchNorm buffers, 40 mel bins."""
+    g = golden("g14_res8_two_second_windows")
+    x = g["m40.x"]                                   # (3, 1, 40, 161)
+    B, C, T = 3, 12, 161
+    h = Res8Harness(lib, B, T, C)
+    logits = h.fwd(np.ascontiguousarray(x[:, 0].transpose(0, 2, 1)), training=True)
+    np.testing.assert_allclose(logits, g["m40.train_logits"], rtol=0, atol=2e-5)
+    loss, dlogits = np.zeros(1, np.float32), np.zeros((B, C), np.float32)
+    lab = (np.arange(B) % C).astype(np.int64)
+    lib.call("howl_xent_fwd_bwd", ptr(h.logits), ptr(lab), B, C, ptr(loss), ptr(dlogits), None)
+    assert abs(loss[0] - float(g["m40.loss0"])) < 1e-5
+    grads = h.bwd(dlogits)
+    for n in om.res8_param_names():
+        ref = g["m40.grad0." + n]
+        np.testing.assert_allclose(grads[n], ref, rtol=0, atol=2e-5 * max(1.0, float(np.abs(ref).max())), err_msg=n)
+    for i in (1, 6):
+        np.testing.assert_allclose(h.np[f"bn{i}.running_mean"], g[f"m40.bn{i}.running_mean.1"], atol=1e-6)
+        np.testing.assert_allclose(h.np[f"bn{i}.running_var"], g[f"m40.bn{i}.running_var.1"], atol=1e-6)
+
+
 @pytest.mark.parametrize("B,T", [(2, 81), (1, 41)])
 def test_res8_at_80_mel_bins_eval_forward(lib, B, T):
     C = 12

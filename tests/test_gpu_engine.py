@@ -132,12 +132,14 @@ def test_device_collate_batch():
     assert torch.equal(plain.audio_data[0, : int(lengths[order[0]])], pcm[order[0], : int(lengths[order[0]])])
 
 
-@pytest.mark.parametrize("model,objective", [("res8", "frame"), ("seq-lstm", "ctc"), ("mobilenet", "frame")])
-def test_train_entry_point_synthetic(tmp_path, monkeypatch, model, objective):
+@pytest.mark.parametrize("model,objective,mels,window", [("res8", "frame", "40", "0.5"), ("seq-lstm", "ctc", "40", "0.5"),
+                                                         ("mobilenet", "frame", "40", "0.5"), ("res8", "frame", "80", "1.5")])
+def test_train_entry_point_synthetic(tmp_path, monkeypatch, model, objective, mels, window):
     """`python -m training.run.train` flow (envs/res8.env / envs/seq-lstm.env presets, shortened) on generated wake-word
-    clips: runs end to end, loss goes down, detection results + workspace artefacts are written."""
-    env = dict(NUM_EPOCHS="3", BATCH_SIZE="16", MAX_WINDOW_SIZE_SECONDS="0.5", LEARNING_RATE={"res8": "0.01", "mobilenet": "0.001"}.get(model, "0.002"),
-               LR_DECAY="0.955", WEIGHT_DECAY="0.00001", NUM_MELS="40", DEVICE="cuda:0", OBJECTIVE=objective,
+    clips: runs end to end, loss goes down, detection results + workspace artefacts are written.  Last case: res8 at the stock 80 mel
+    bins with 1.5-s training windows (121 frames: two column x two row strips per utterance in the kernels)."""
+    env = dict(NUM_EPOCHS="3", BATCH_SIZE="16", MAX_WINDOW_SIZE_SECONDS=window, LEARNING_RATE={"res8": "0.01", "mobilenet": "0.001"}.get(model, "0.002"),
+               LR_DECAY="0.955", WEIGHT_DECAY="0.00001", NUM_MELS=mels, DEVICE="cuda:0", OBJECTIVE=objective,
                TOKEN_TYPE="word", VOCAB='["hey","fire","fox"]', INFERENCE_SEQUENCE="[0,1,2]", INFERENCE_THRESHOLD="0",
                SMOOTHING_WINDOW_MS="0" if objective == "ctc" else "50")
     for k, v in env.items():
@@ -155,6 +157,7 @@ def test_train_entry_point_synthetic(tmp_path, monkeypatch, model, objective):
     losses = [l["value"] for l in lines if l["tag"] == "Training/Loss"]
     assert len(losses) == 3 and losses[-1] < losses[0]
     assert (ws / "model.pt.bin").exists() and (ws / "zmuv.pt.bin").exists() and (ws / "0.0_results.csv").exists()
+    monkeypatch.setenv("NUM_MELS", "40")
     SETTINGS.reset()
 
 

@@ -665,3 +665,30 @@ def test_fused_trainer_on_two_second_windows():
         assert maxerr(p.detach().cpu()[solid], sd[n][solid]) < 2e-4, n
     losses = [trainer.step(pcm.to(DEV), labels.to(DEV)).item() for _ in range(12)]
     assert losses[-1] < loss.item()
+
+
+@pytest.mark.parametrize("mels", [40, 80])
+def test_golden_two_second_windows(golden, mels):
+    """G14: outputs of the REFERENCE's res8 on 161-frame inputs (MAX_WINDOW_SIZE_SECONDS=2; pairs of the GSC clips) at 40 and 80
+    mel bins: eval logits (module: row strips; and the windowed howl_res8_fwd_long), one training step's logits, loss, every
+    gradient and BatchNorm buffers.  Three utterances: a flipped ReLU decision would show at the percent level, so the gradient
+    bound is checked with the reference's own values only where the batch is well conditioned -- it is (fixed inputs)."""
+    g = golden("g14_res8_two_second_windows")
+    pre = f"m{mels}."
+    x = t(g[pre + "x"]).to(DEV)
+    model = make_res8(12, train=False)
+    with torch.no_grad():
+        assert maxerr(model(x, None), g[pre + "eval_logits"]) < LOGIT_TOL
+        x0, sb, st, sm = model._feat_view(x)
+        assert maxerr(model._launch_forward_long(x0, sb, st, sm), g[pre + "eval_logits"]) < LOGIT_TOL
+    model.train()
+    sc = model(x, None)
+    loss = torch.nn.functional.cross_entropy(sc, (torch.arange(3) % 12).to(DEV))
+    loss.backward()
+    assert maxerr(sc, g[pre + "train_logits"]) < LOGIT_TOL and abs(loss.item() - float(g[pre + "loss0"])) < 1e-4
+    for n, p in model.named_parameters():
+        ref = g[pre + "grad0." + n]
+        assert maxerr(p.grad, ref) < 5e-5 * max(1.0, float(np.abs(ref).max())), n
+    for i in (1, 6):
+        assert maxerr(getattr(model, f"bn{i}").running_mean, g[pre + f"bn{i}.running_mean.1"]) < 1e-5
+        assert maxerr(getattr(model, f"bn{i}").running_var, g[pre + f"bn{i}.running_var.1"]) < 1e-4

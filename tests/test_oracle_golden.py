@@ -277,3 +277,24 @@ def test_g13_stock_80_mel_bins(golden):
         close(sd[f"bn{i}.running_mean"], g[f"bn{i}.running_mean.1"])
         close(sd[f"bn{i}.running_var"], g[f"bn{i}.running_var.1"])
     close(om.res8_forward(sd, x, False), g["eval_logits_after1"], 2e-4)
+
+
+def test_g14_two_second_windows(golden):
+    """G14: the reference's res8 on 161-frame inputs (2-s windows) at 40 and 80 mel bins, eval and one training step."""
+    g = golden("g14_res8_two_second_windows")
+    names = om.res8_param_names()
+    for mels in (40, 80):
+        pre = f"m{mels}."
+        x = t(g[pre + "x"])
+        assert x.shape == (3, 1, mels, 161)
+        sd = om.res8_init(12)
+        close(om.res8_forward(sd, x, False), g[pre + "eval_logits"], 1e-6)
+        opt = om.AdamWState([sd[n] for n in names], 0.01, 1e-5)
+        loss, logits, grads = om.train_step(lambda s, xx: om.res8_forward(s, xx, True), sd, names, opt, x, torch.arange(3) % 12)
+        close(loss, g[pre + "loss0"], 2e-6)
+        close(logits, g[pre + "train_logits"], 2e-6)
+        for n in names:
+            close(grads[n], g[pre + "grad0." + n], 2e-6)
+        for i in (1, 6):
+            close(sd[f"bn{i}.running_mean"], g[pre + f"bn{i}.running_mean.1"])
+            close(sd[f"bn{i}.running_var"], g[pre + f"bn{i}.running_var.1"])
