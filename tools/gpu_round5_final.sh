@@ -16,6 +16,9 @@ echo "== bench c3" ; timeout 600 python bench.py 2>&1 | tail -1 | tee -a $OUT/be
 for a in "--vtlp --no-cpu-baseline" "--config c1" "--config c2" "--config c4" "--config c5" "--config eval" "--config c1 --batch-per-gpu 16 --no-cpu-baseline" "--config c1 --batch-per-gpu 1 --no-cpu-baseline" "--loop entry --config c3 --steps 100 --warmup 20" "--loop entry --config c1 --steps 200 --warmup 30 --no-cpu-baseline" "--loop entry --config c2 --steps 200 --warmup 30 --no-cpu-baseline"; do
   echo "== bench $a" ; timeout 600 python bench.py $a --cpu-baseline-seconds 6 2>&1 | tail -1 | tee -a $OUT/bench_lines.jsonl | cut -c1-260
 done
+echo "== bench c3 at 80 mel bins (stock NUM_MELS)" ; NUM_MELS=80 timeout 600 python bench.py --no-cpu-baseline 2>&1 | tail -1 | tee -a $OUT/bench_lines.jsonl | cut -c1-260
+echo "== bench 256 x 2 s (161 frames: row strips)" ; timeout 600 python bench.py --seconds 2 --batch-per-gpu 256 --no-cpu-baseline 2>&1 | tail -1 | tee -a $OUT/bench_lines.jsonl | cut -c1-260
+echo "== bench 256 x 2 s at 80 mel bins" ; NUM_MELS=80 timeout 600 python bench.py --seconds 2 --batch-per-gpu 256 --no-cpu-baseline 2>&1 | tail -1 | tee -a $OUT/bench_lines.jsonl | cut -c1-260
 for mode in overlap merged; do
   echo "== bench c3, 2 ranks on one GPU over gloo ($mode): control flow of the rccl section" ; HOWL_DP_LATE=$mode HOWL_BENCH_BACKEND=gloo timeout 600 python bench.py --gpus 2 --steps 20 --warmup 5 --prewarm 5 --no-cpu-baseline --no-roofline 2>&1 | tail -1 | tee -a $OUT/bench_lines.jsonl | cut -c1-200
 done
