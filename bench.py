@@ -752,7 +752,7 @@ def main():
             fwd_tf = flops_launch / (fwd_ms * 1e-3) / 1e12 if fwd_ms > 0 else 0.0
             avg_ms = tp / max(npair, 1)
             achieved = 2 * flops_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
-            full = B == 512 and L == 16000
+            full = B == 512 and L == 16000 and MELS == 40      # the configuration the committed PMC summary was taken on
             traffic, traffic_src = pmc_traffic("bwd_pair_kernel") if full else (None, None)
             fwd_traffic, _ = pmc_traffic("conv3x3_mfma_kernel<0") if full else (None, None)
             act = 4.0 * 45 * (H * (MELS // 4)) * B      # one (B, 45, H, M/4) fp32 map
