@@ -14,12 +14,18 @@ from howl_amd.model import RegisteredModel  # noqa: E402
 from howl_amd.training.fused import FusedTrainer  # noqa: E402
 from howl_amd.utils.synth import synthetic_pcm  # noqa: E402
 
+from howl_amd.settings import SETTINGS  # noqa: E402
+
 dev = torch.device("cuda:0")
-for name, B, C, lr, steps in (("res8", 256, 12, 0.01, 300), ("mobilenet", 128, 12, 0.001, 150), ("mobilenet", 512, 12, 0.001, 120)):
+# (model, batch, labels, lr, steps, mel bins, samples): the last res8 run is the reference's STOCK 80 mel bins on 2-s windows -- every
+# utterance two column strips x two row strips in the kernels
+for name, B, C, lr, steps, mels, L in (("res8", 256, 12, 0.01, 300, 40, 16000), ("mobilenet", 128, 12, 0.001, 150, 40, 16000),
+                                       ("mobilenet", 512, 12, 0.001, 120, 40, 16000), ("res8", 128, 12, 0.01, 300, 80, 32000)):
     finals = []
+    SETTINGS.audio_transform.num_mels = mels
     for rep in range(2):
         torch.manual_seed(0)
-        pcm = synthetic_pcm(B, 16000).to(dev)              # tone frequency depends on b mod 64: labels are learnable
+        pcm = synthetic_pcm(B, L).to(dev)                  # tone frequency depends on b mod 64: labels are learnable
         labels = (torch.arange(B) % C).to(dev)
         std = StandardAudioTransform().to(dev).eval()
         zmuv = ZmuvTransform().to(dev)
@@ -39,11 +45,12 @@ for name, B, C, lr, steps in (("res8", 256, 12, 0.01, 300), ("mobilenet", 128, 1
             model.eval()
             with torch.no_grad():
                 acc = (model(tr.features(pcm), None).argmax(1) == labels).float().mean().item()
-            print(f"{name}: loss {losses[0]} -> {losses[-1]} over {steps} steps (every 25th: {losses}); train-set accuracy in eval "
+            print(f"{name} ({mels} mel bins, {L / 16000:g} s): loss {losses[0]} -> {losses[-1]} over {steps} steps (every 25th: {losses}); train-set accuracy in eval "
                   f"mode {acc:.3f}", flush=True)
             assert losses[-1] < 0.5 * losses[0], (name, losses)
     print(f"{name}: repeat run bit-identical: {torch.equal(finals[0], finals[1])}", flush=True)
     assert torch.equal(finals[0], finals[1])
+SETTINGS.audio_transform.num_mels = 40
 # sequence objective: seq-lstm + fused log_softmax/CTC on 0.5 s tones whose frequency class picks one of four label sequences
 finals = []
 for rep in range(2):
