@@ -1,6 +1,6 @@
 #!/bin/bash
 # c1 (64 x 1 s): the two roles of the backward pair launched apart (HOWL_RES8_BWD_PAIR=0) under rocprof: where do the 24 us go?
-OUT=gpurun_out/${1:-r5q}
+OUT=gpurun_out/${1:-c1roles}
 mkdir -p $OUT
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
