@@ -7,7 +7,10 @@
 //
 // Layouts (HBM, fp32): activations s_i are (B, 45, H, 10) exactly like the reference's NCHW tensors
 // (H = T/3, P = H*10 positions); weights keep the reference's (45,45,3,3) / (45,1,3,3) / (C,45) shapes so
-// state_dicts are interchangeable (howl/workspace.py:31-67).
+// state_dicts are interchangeable (howl/workspace.py:31-67).  Maps that do not fit this tile -- 80 mel bins (20 pooled columns:
+// settings.py:32's default), more than 83 frames (27 pooled rows) -- run as STRIPS: blocks of (45, <= 27, 10) that fetch their
+// neighbours' edge columns / rows on the way into LDS (HaloSlot, StripGeom below; separate template instances, the plain
+// kernels are compiled exactly as before).
 //
 // conv3x3 45->45 (12 of the 13 GFLOP-heavy launches per step: 6 forward, 6 dgrad) is an implicit GEMM on
 // v_mfma_f32_16x16x4_f32 (exact fp32 FMA chains, 157 TFLOP/s peak):

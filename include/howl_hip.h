@@ -182,6 +182,7 @@ size_t howl_res8_saved_floats(int B, int T, int M);
 
 /* feat: log-mel features, element (b, t, m) at feat[b*sb + t*st + m*sm] (so both the (B,T,M) model layout and
  * channel 0 of the reference's (B,3,M,T) tensor are accepted; replaces x[:, :1].permute(0,1,3,2), cnn.py:128-129).
+ * Any T >= 3 (cnn.py:127-145), M = 40 or 80; sizes from howl_res8_workspace_bytes_mels / howl_res8_saved_floats.
  * training != 0: BatchNorm uses batch statistics and updates the running buffers; else uses the running buffers.
  * logits: (B, C). */
 int howl_res8_fwd(const HowlRes8Params* prm, const float* feat, long sb, long st, long sm, int B, int T, int M, int C,
