@@ -148,6 +148,61 @@ class FrameInferenceEngine(InferenceEngine):
         return self.model(feats, lengths).softmax(-1).cpu().numpy()
 
     @torch.no_grad()
+    def window_probabilities_many(self, clips) -> list:
+        """``window_probabilities`` of several clips with ONE frontend launch, one model forward and one device->host copy for all
+        of their windows (clips whose windows have the same length share a batch: every clip at least one window long does)."""
+        out = [None] * len(clips)
+        groups = {}
+        for i, clip in enumerate(clips):
+            starts, chunk = audio_utils.stride_starts(clip.size(-1), self.max_window_size_ms, self.eval_stride_size_ms, self.sample_rate)
+            if not starts or chunk < 1000:
+                out[i] = np.zeros((0, self.context.num_labels), np.float32)
+                continue
+            stride_sz = starts[1] - starts[0] if len(starts) > 1 else chunk
+            groups.setdefault((chunk, clip.device), []).append((i, len(starts), stride_sz))
+        for (chunk, device), members in groups.items():
+            self.std = self.std.to(device)
+            views = [clips[i].reshape(-1).contiguous().as_strided((n, chunk), (stride_sz, 1)) for i, n, stride_sz in members]
+            windows = views[0] if len(views) == 1 else torch.cat(views)          # (all windows, chunk): the only copy
+            feats = self.std.log_mel_for_model(windows, self.zmuv)
+            lengths = self.std.compute_lengths(torch.full((windows.size(0),), chunk, device=device))
+            probs = self.model(feats, lengths).softmax(-1).cpu().numpy()
+            lo = 0
+            for i, n, _ in members:
+                out[i] = probs[lo:lo + n]
+                lo += n
+        return out
+
+    def _run_fsm(self, probs) -> bool:
+        sequence_present = False
+        for prediction in probs:
+            self._append_probability_frame(self._weighted(prediction), curr_time=self.curr_time)
+            self.curr_time += self.eval_stride_size_ms
+            if self.sequence_present(self.curr_time):
+                sequence_present = True
+                break
+        return sequence_present
+
+    @torch.no_grad()
+    def infer_many(self, clips) -> list:
+        """``[reset(); infer(clip) for clip in clips]`` with the windows of ALL clips scored in one batch (an evaluation pass over a
+        dataset, train.py:42-94, is host-bound clip by clip: one launch chain and one host copy per clip); the label
+        histories, smoothing and sequence search run per clip exactly as ``infer`` runs them.  Leaves the engine reset."""
+        if not self._stateless():
+            res = []
+            for clip in clips:
+                self.reset()
+                res.append(bool(self._infer_sequential(clip)))
+            self.reset()
+            return res
+        res = []
+        for probs in self.window_probabilities_many(clips):
+            self.reset()
+            res.append(self._run_fsm(probs))
+        self.reset()
+        return res
+
+    @torch.no_grad()
     def infer(self, audio_data: torch.Tensor) -> bool:
         if not self._stateless():
             return self._infer_sequential(audio_data)

@@ -176,7 +176,13 @@ def main(argv=None):
         else:
             engine = InferenceEngine(model, zmuv_transform, ctx)
         hits = 0
-        for i in ids[rank::world]:         # clips dealt round-robin to the ranks, detections summed
+        mine = ids[rank::world]            # clips dealt round-robin to the ranks, detections summed
+        if use_frame:                      # all windows of 64 clips at a time in one batch (FrameInferenceEngine.infer_many)
+            for lo in range(0, len(mine), 64):
+                model.streaming_state = None
+                hits += sum(int(h) for h in engine.infer_many([bank.clip(i) for i in mine[lo:lo + 64]]))
+            mine = []
+        for i in mine:
             engine.reset()
             model.streaming_state = None
             hits += int(bool(engine.infer(bank.clip(i))))

@@ -39,6 +39,20 @@ def test_frame_engine_matches_reference_history(golden):
     engine.reset()
     labels = [engine.ingest_frame(clip[i * 1008: i * 1008 + 8000], curr_time=63.0 * i) for i in range(5)]
     assert labels == [int(x) for x in g["label_history"][:5, 1]]
+    # several clips at once (an evaluation pass: one frontend launch, one forward, one host copy for all of their windows):
+    # the same probabilities per clip -- ragged lengths, a clip shorter than a window, one too short for any -- and the same verdicts
+    others = [clip[3000:40000], clip[:6000], clip[:500], clip]
+    many = engine.window_probabilities_many(others)
+    for c, p in zip(others, many):
+        engine.reset()
+        single = engine.window_probabilities(c)
+        assert p.shape == single.shape and (p.size == 0 or np.abs(p - single).max() < 1e-6)
+        assert np.array_equal(p.argmax(1), single.argmax(1))
+    singles = []
+    for c in others:
+        engine.reset()
+        singles.append(bool(engine.infer(c)))
+    assert engine.infer_many(others) == singles and singles[-1] == bool(g["present"])
 
 
 def test_sequence_engine_matches_reference_history(golden):
