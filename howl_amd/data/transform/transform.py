@@ -10,6 +10,7 @@ from dataclasses import dataclass
 from types import SimpleNamespace
 from typing import Sequence
 
+import numpy as np
 import torch
 import torch.nn as nn
 
@@ -94,6 +95,22 @@ def vtlp_warp_points(f_pts: torch.Tensor, alpha: float, sample_rate: int, f_hi: 
     return f_pts
 
 
+def vtlp_warp_points_np(f_pts32: np.ndarray, alpha: float, sample_rate: int, f_hi: int = 4800) -> np.ndarray:
+    """``vtlp_warp_points`` on a float32 numpy array: the same IEEE fp32 operations in the same order (scalar operands rounded to
+    fp32 first, as ATen does for a Python scalar next to a float tensor; no fused multiply-add on either side), bit for bit the same
+    corner points (``tests/test_host.py`` compares them over thousands of draws) at a fifteenth of the host time: the torch version
+    is eight tensor ops on 42 elements, ~100 us of a 300-us small-batch step on 75 % of the steps."""
+    S = sample_rate
+    f = f_pts32.copy()
+    thr = f_hi * min(alpha, 1) / alpha
+    f[f <= np.float32(thr)] *= np.float32(alpha)
+    hi = f > np.float32(thr)                          # re-evaluated on the scaled values: the alpha > 1 quirk (transform.py:399-401)
+    c = np.float32((S / 2 - f_hi * min(alpha, 1)) / (S / 2 - thr))
+    half = np.float32(S / 2)
+    f[hi] = half - c * (half - f[hi])
+    return f
+
+
 class StandardAudioTransform(AugmentModule):
     """``transform.py:234-296``.  (B, L) fp32 PCM on the device -> (B, 3, M, T) [log-mel, deltas, accels]."""
 
@@ -112,6 +129,7 @@ class StandardAudioTransform(AugmentModule):
         self.spec_transform = spec
         self.vtlp_transform = spec
         self._points = mel_corner_points(self.n_mels, self.sample_rate)  # host, 42 floats
+        self._points_np = self._points.numpy().copy()
         if not 1 <= self.n_mels <= MAX_MELS:
             raise NotImplementedError(f"the frontend kernel contracts up to {MAX_MELS} mel bins (NUM_MELS={self.n_mels})")
         self.register_buffer("fb_standard", torch.zeros(fb_packed_floats(self.n_mels)), persistent=False)
@@ -133,8 +151,8 @@ class StandardAudioTransform(AugmentModule):
     def _vtlp_fb(self):
         alpha = random.random() * 0.2 + 0.9  # global `random`, as transform.py:441
         self.last_vtlp_alpha = alpha
-        pts = vtlp_warp_points(self._points, alpha, self.sample_rate)
-        return ops.fb_from_points(pts.tolist(), self.n_mels, self.sample_rate // 2, self.fb_vtlp)
+        pts = vtlp_warp_points_np(self._points_np, alpha, self.sample_rate)
+        return ops.fb_from_points(pts, self.n_mels, self.sample_rate // 2, self.fb_vtlp)
 
     # -- reference protocol ------------------------------------------------------------------------------------
     @torch.no_grad()

@@ -346,3 +346,23 @@ def test_res8_warns_about_other_mel_counts_and_the_entry_points_refuse(monkeypat
             RegisteredModel.find_registered_class("res8")(12)
         assert "NUM_MELS" not in caplog.text
         require_supported_mels(model)
+
+
+def test_vtlp_corner_points_numpy_path_is_bit_identical():
+    """The frontend's per-step VTLP warp runs on numpy float32 (``vtlp_warp_points_np``: 8 us) instead of eight torch ops on a
+    42-element tensor (100 us of host time on 75 % of the training steps); both are restatements of transform.py:394-401 and
+    must give the same bits for every alpha the reference can draw (``random.random() * 0.2 + 0.9``), 40 / 80 / odd mel counts,
+    the alpha > 1 re-masking quirk included."""
+    import random
+    import numpy as np
+    from howl_amd.data.transform.transform import mel_corner_points, vtlp_warp_points, vtlp_warp_points_np
+    rnd = random.Random(7)
+    for mels in (40, 80, 13):
+        pts = mel_corner_points(mels, 16000)
+        p32 = pts.numpy().copy()
+        alphas = [0.9, 1.0, 1.0999999, 1.1, 0.9000001] + [rnd.random() * 0.2 + 0.9 for _ in range(3000)]
+        for alpha in alphas:
+            a = vtlp_warp_points(pts, alpha, 16000).numpy()
+            b = vtlp_warp_points_np(p32, alpha, 16000)
+            assert b.dtype == np.float32 and np.array_equal(a.view(np.uint32), b.view(np.uint32)), (mels, alpha)
+        assert np.array_equal(p32, pts.numpy())      # inputs untouched
