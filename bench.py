@@ -465,8 +465,9 @@ def bench_entry(args, dev, rank, world):
                      "host_enqueue_ms_per_step_resident": round(results["resident"][1] / args.steps * 1e3, 4),
                      "collate_prepare_us_per_batch": round(prep_us, 1),
                      "note": "resident = trainer.step on one batch already in HBM (the default bench line's loop, frontend in train "
-                             "mode here); host_enqueue = wall time until the last launch of the K steps was issued (when it is "
-                             "close to ms_per_step the host is the limiter)"},
+                             "mode here); host_enqueue = wall time until the last launch of the K steps was issued -- the entry loop's "
+                             "staging ring lets the host run at most eight batches ahead, so there it ends 8 / K before the "
+                             "device does whatever the host could do (host_enqueue_ms_per_step_resident is the host's own pace)"},
             "roofline": None, "cpu_baseline": cpu, "eval_agreement": None, "rccl": None,
         }
         print(json.dumps(out), flush=True)
