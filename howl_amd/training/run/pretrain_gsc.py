@@ -39,13 +39,17 @@ def train_epoch(trainer, collate, id_batches, std_transform, writer, epoch_idx, 
     SLOWER than preparing inline once the draws are array operations (round 5, 1xMI355X: 1.190 against 1.168 ms per step at
     512 utterances, 0.391 against 0.334 at 64: 25-47 us of host work per batch do not pay for the hand-over between two Python
     threads), hence off by default.
+    (Also measured and removed, round 5: the NEXT batch's upload and collate kernel on a side stream beside the current step --
+    bit-identical results, but 1.185 against 1.167 ms per step at 512 utterances and 0.354 against 0.317 at 64: the event record /
+    wait pairs between two queues cost more than the 20-60 us of device work they would hide, as every cross-queue experiment on
+    this stack has.)
     Returns the number of utterances trained on.  (``bench.py --loop entry`` times exactly this function.)"""
     batches = collate.prefetch(id_batches, depth=prefetch) if prefetch else (collate(ids) for ids in id_batches)
     seen = 0
     for batch in batches:
         if needs_lengths:
             loss = trainer.step(batch.audio_data, batch.labels, std_transform.compute_lengths(batch.lengths),
-                                int(std_transform.compute_lengths(torch.tensor(collate.last_max_len))))
+                                int(std_transform.compute_lengths(torch.tensor(batch.audio_data.shape[-1]))))      # (the batch's padded length)
         else:
             loss = trainer.step(batch.audio_data, batch.labels)
         writer.add_scalar("Training/Loss", loss.detach(), epoch_idx)     # stays on the device until flush
