@@ -43,6 +43,7 @@ Rank 0 prints ONE JSON line; besides the contract fields it carries
   "eval_agreement": eval-mode logits of the trained bench model on a slice of the bench batch, HIP path vs the oracle at
                   identical weights (the "eval acc vs CPU ref" half of BASELINE.json's metric): argmax agreement and max
                   |logit difference| (rank 0, N = 1 only, with the CPU baseline leg);
+  "like_for_like": (N = 1) the same K steps with the optimiser as its own launch, the structure every N > 1 step has.
   "rccl":         (N > 1) world size, backend, and the all-reduce of the flat gradient buffer timed on its own.
 """
 import argparse
@@ -88,6 +89,8 @@ def parse():
     ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-unfused-leg", action="store_true",
+                    help="skip the N = 1 `like_for_like` leg (the K steps once more with AdamW as its own launch)")
     ap.add_argument("--vtlp", action="store_true",
                     help="frontend in train mode, as the reference loop runs it (pretrain_gsc.py:120-126): per step one host draw, "
                          "VTLP-warped filterbank rebuilt on the device (howl_fb_from_points) on 75 %% of the steps")
@@ -625,13 +628,18 @@ def main():
         targets = torch.tensor([[0, 1, 2]] * B).to(dev)
         target_lengths = torch.tensor([3] * B).to(dev)
 
-        ahead = None if args.no_lookahead else pcm
+        # two resident batches, alternated: the look-ahead's "next batch" is a DIFFERENT tensor from the one the step trains on,
+        # as a prefetching loader would hand it over (round 5 passed the same tensor twice)
+        bufs = [pcm, synthetic_pcm(B, L, seed=4321 + rank).to(dev)]
+        turn = [0]
 
         def step():    # frontend -> LSTM + head -> fused log_softmax + CTC(blank = C-1) -> backward -> flat AdamW
             # one-batch look-ahead (a prefetching loader's): the NEXT batch's frontend launch rides in this step's forward
             # recurrence (howl_lstm_fwd_next); every step still runs exactly one frontend pass and one model step
-            return trainer.step_sequence(pcm, frame_lengths, targets, target_lengths, C - 1, max_target=3, max_frames=n_frames,
-                                         next_audio=ahead)
+            cur, nxt = bufs[turn[0] & 1], bufs[(turn[0] + 1) & 1]
+            turn[0] += 1
+            return trainer.step_sequence(cur, frame_lengths, targets, target_lengths, C - 1, max_target=3, max_frames=n_frames,
+                                         next_audio=None if args.no_lookahead else nxt)
     elif model_name == "mobilenet":
         from howl_amd.data.collate import DeviceCollate
         collate = DeviceCollate(pcm, torch.full((B,), L, dtype=torch.long), labels, max_len=L, seed=0, replica=rank)
@@ -683,6 +691,25 @@ def main():
         dt = tmax.item()
     final_loss = loss.item()
 
+    # Like-for-like denominator for a scaling curve: on ONE replica the optimiser step rides in the backward's last fold launch
+    # (fused.py: world == 1), on N > 1 replicas it is a launch of its own behind the collective (1 / world scale + AdamW in one
+    # kernel, queued behind the all-reduce without a host synchronisation).  At N = 1 the same K steps are therefore timed once
+    # more with the optimiser as its own launch (HOWL_NO_FOLD_ADAMW: same bits, tests/test_gpu_lstm.py / test_gpu_res8.py).
+    own_launch = None
+    if world == 1 and model_name in ("res8", "seq-lstm") and not args.no_unfused_leg:
+        os.environ["HOWL_NO_FOLD_ADAMW"] = "1"
+        for _ in range(min(args.warmup, 3)):
+            step()
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        own_launch = {"adamw_in_fold_at_n1": True,
+                      "ms_per_step_adamw_own_launch": round((time.perf_counter() - t1) / args.steps * 1e3, 4),
+                      "note": "N > 1 steps take the optimiser as its own launch behind the all-reduce: compare them with this line"}
+        del os.environ["HOWL_NO_FOLD_ADAMW"]
+
     rccl = None
     if world > 1:
         # the step's one collective, timed on its own (HIP events on the compute stream, which the process group's stream
@@ -717,7 +744,11 @@ def main():
                 "allreduce_bytes": buf.numel() * 4, "allreduce_us": round(e0.elapsed_time(e1) * 1e3 / 20, 1),
                 "collectives_per_step": trainer.collectives_last_step_reduced, "late_grads": trainer.late_grads,
                 "ms_per_step_without_allreduce": round(dt_local.item() / args.steps * 1e3, 4),
-                "allreduce_exposed_us": round((dt - dt_local.item()) / args.steps * 1e6, 1)}
+                "allreduce_exposed_us": round((dt - dt_local.item()) / args.steps * 1e6, 1),
+                "n1_step_has_adamw_in_fold": model_name in ("res8", "seq-lstm"),
+                "note": "N = 1 folds AdamW into the backward's last launch; N > 1 runs it (with the 1 / world scale) as one launch "
+                        "queued behind the all-reduce, no host sync in between: the N = 1 line's `like_for_like` block carries "
+                        "the N = 1 time of THIS step structure"}
 
     roof = None
     lb = hlib.get()
@@ -848,6 +879,7 @@ def main():
                        "parallelism": f"dp{world}" if world > 1 else "single", "frontend": "vtlp-train" if args.vtlp else "eval"},
             "final_loss": round(final_loss, 5), "repeats": repeats,
             "roofline": roof, "cpu_baseline": cpu, "eval_agreement": agree, "rccl": rccl,
+            "like_for_like": own_launch,
         }
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -64,26 +64,70 @@ int howl_num_cus() {
     return cached;
 }
 
+// Side lanes are handed out per host thread and device but owned by one process-wide list, so that howl_shutdown can
+// release all of them; a thread's cached slot is valid for the generation it was made in.
+namespace {
+std::mutex g_lane_mu;
+std::vector<HowlSideLane*> g_lanes;
+unsigned g_lane_generation = 1;
+thread_local bool g_pending_error = false;
+}  // namespace
+
 HowlSideLane* howl_side_lane() {
     struct Slot {
-        int dev = -1;
-        bool tried = false, ok = false;
-        HowlSideLane lane;
+        unsigned generation = 0;
+        bool ok = false;
+        HowlSideLane* lane = nullptr;
     };
     static thread_local Slot slots[16];
     if (getenv("HOWL_NO_SIDE_STREAM") != nullptr) return nullptr;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
     Slot& s = slots[dev];
-    if (!s.tried) {
-        s.tried = true;
-        s.dev = dev;
-        s.ok = hipStreamCreateWithFlags(&s.lane.stream, hipStreamNonBlocking) == hipSuccess &&
-               hipEventCreateWithFlags(&s.lane.fork_ev, hipEventDisableTiming) == hipSuccess &&
-               hipEventCreateWithFlags(&s.lane.join_ev, hipEventDisableTiming) == hipSuccess;
-        if (!s.ok) (void)hipGetLastError();
+    std::lock_guard<std::mutex> lk(g_lane_mu);
+    if (s.generation != g_lane_generation) {
+        s.generation = g_lane_generation;
+        HowlSideLane* l = new HowlSideLane();
+        bool st = hipStreamCreateWithFlags(&l->stream, hipStreamNonBlocking) == hipSuccess;
+        bool e1 = st && hipEventCreateWithFlags(&l->fork_ev, hipEventDisableTiming) == hipSuccess;
+        bool e2 = e1 && hipEventCreateWithFlags(&l->join_ev, hipEventDisableTiming) == hipSuccess;
+        s.ok = e2;
+        if (s.ok) {
+            s.lane = l;
+            g_lanes.push_back(l);
+        } else {
+            (void)hipGetLastError();
+            if (e1) hipEventDestroy(l->fork_ev);
+            if (st) hipStreamDestroy(l->stream);
+            delete l;
+            s.lane = nullptr;
+        }
     }
-    return s.ok ? &s.lane : nullptr;
+    return s.ok ? s.lane : nullptr;
+}
+
+// Raises a kernel's dynamic-LDS limit on the current device once per (host thread, device, size): `granted` is the caller's
+// per-kernel table of 16 devices.  A refused raise is reported (howl_last_error names the kernel's request) and NOT cached, so
+// the next call tries again; the entry point's HOWL_CHECK_LAUNCH returns HOWL_E_LAUNCH for it.
+bool howl_raise_lds(const void* kernel, size_t lds, size_t* granted, const char* what) {
+    int dev = 0;
+    const bool indexed = hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 16;
+    if (indexed && lds <= granted[dev]) return true;
+    const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        howl_set_error("%s: the runtime refused %zu bytes of dynamic LDS on device %d: %s", what, lds, dev, hipGetErrorString(e));
+        g_pending_error = true;
+        return false;
+    }
+    if (indexed) granted[dev] = lds;
+    return true;
+}
+
+bool howl_take_pending_error() {
+    const bool p = g_pending_error;
+    g_pending_error = false;
+    return p;
 }
 
 extern "C" {
@@ -143,6 +187,20 @@ int howl_shutdown(void) {
         }
         g_prof.clear();
     }
+    {
+        // the side lanes of every host thread (howl_side_lane): a later call on any thread makes a fresh one
+        std::lock_guard<std::mutex> lk(g_lane_mu);
+        for (HowlSideLane* l : g_lanes) {
+            hipStreamSynchronize(l->stream);
+            hipEventDestroy(l->fork_ev);
+            hipEventDestroy(l->join_ev);
+            hipStreamDestroy(l->stream);
+            delete l;
+        }
+        g_lanes.clear();
+        ++g_lane_generation;
+    }
+    (void)hipGetLastError();
     return HOWL_OK;
 }
 

@@ -45,6 +45,10 @@ struct HowlSideLane {
     hipEvent_t fork_ev, join_ev;
 };
 HowlSideLane* howl_side_lane();
+// dynamic-LDS limit of `kernel` on the current device raised to `lds` bytes (cached per host thread and device in the caller's
+// table of 16); false = refused: the error text is set and the entry point's HOWL_CHECK_LAUNCH will return HOWL_E_LAUNCH
+bool howl_raise_lds(const void* kernel, size_t lds, size_t* granted, const char* what);
+bool howl_take_pending_error();
 inline void howl_lane_fork(HowlSideLane* l, hipStream_t main) {
     hipEventRecord(l->fork_ev, main);
     hipStreamWaitEvent(l->stream, l->fork_ev, 0);
@@ -98,6 +102,7 @@ __device__ __forceinline__ void howl_adamw_element(float* __restrict__ p, float*
 #define HOWL_CHECK_LAUNCH(name)                                                     \
     do {                                                                            \
         hipError_t e_ = hipGetLastError();                                          \
+        if (howl_take_pending_error()) return HOWL_E_LAUNCH; /* text already set */  \
         if (e_ != hipSuccess) {                                                     \
             howl_set_error("%s: launch failed: %s", name, hipGetErrorString(e_));   \
             return HOWL_E_LAUNCH;                                                   \

@@ -2489,7 +2489,9 @@ struct Ws {
     float* c0part;   // [G][405]
 };
 
-size_t ws_layout(Ws* w, char* base, int B, int H, int G) {
+// `fwd_eval_bytes`: what an eval-mode forward touches (packed weights, statistics, pooled sums: everything in front of the
+// backward's activation-sized buffers)
+size_t ws_layout(Ws* w, char* base, int B, int H, int G, size_t* fwd_eval_bytes = nullptr) {
     size_t off = 0;
     auto take = [&](size_t floats) {
         float* p = base ? reinterpret_cast<float*>(base + off) : nullptr;
@@ -2507,6 +2509,7 @@ size_t ws_layout(Ws* w, char* base, int B, int H, int G) {
     t.m12 = take(2 * CP);
     t.dpool = take((size_t)B * CP);
     t.pool = take((size_t)B * 16 * CP);
+    if (fwd_eval_bytes) *fwd_eval_bytes = off;
     t.bufa = take(act);
     t.bufb = take(act);
     t.dz = take(act);
@@ -2591,13 +2594,8 @@ StageCfg plain_tile(const float* t) { return StageCfg{t, nullptr, nullptr, nullp
 // each on this stack, twelve per step -- nothing a step's timing shows).
 template <auto Kernel>      // (one table per kernel instantiation)
 void raise_lds_limit(size_t lds) {
-    static thread_local size_t granted[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    int dev = 0;
-    hipGetDevice(&dev);
-    if (dev < 0 || dev >= 8 || lds > granted[dev]) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(Kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (dev >= 0 && dev < 8) granted[dev] = lds;
-    }
+    static thread_local size_t granted[16] = {};
+    howl_raise_lds(reinterpret_cast<const void*>(Kernel), lds, granted, "res8 kernel");   // refused: reported by HOWL_CHECK_LAUNCH
 }
 
 template <int MODE, int SLICES, int HALO = 0>
@@ -2668,6 +2666,15 @@ size_t howl_res8_workspace_bytes_mels(int B, int T, int M) {
     return ws_layout(nullptr, nullptr, sp.Bv, sp.Hs, even_grid(conv_grid(sp.Bv), sp.ns));
 }
 
+size_t howl_res8_eval_workspace_bytes_mels(int B, int T, int M) {
+    const Strips sp = strips_for(B, T, M);
+    size_t eval_bytes = 0;
+    ws_layout(nullptr, nullptr, sp.Bv, sp.Hs, even_grid(conv_grid(sp.Bv), sp.ns), &eval_bytes);
+    return eval_bytes;
+}
+
+int howl_res8_row_strips(int T) { return strips_for(1, T, 40).nr; }
+
 size_t howl_res8_saved_floats(int B, int T, int M) {
     const Strips sp = strips_for(B, T, M);
     return (size_t)sp.Bv * NMAP * sp.Hs * PW;
@@ -2695,7 +2702,11 @@ int res8_fwd_impl(const HowlRes8Params* prm, const float* feat, long sb, long st
     const bool grid = halo == 2;
     const int G = even_grid(conv_grid(Bv), NS);
     Ws w;
-    const size_t need = ws_layout(&w, static_cast<char*>(ws), Bv, H, G);
+    size_t need_eval = 0;
+    const size_t need_train = ws_layout(&w, static_cast<char*>(ws), Bv, H, G, &need_eval);
+    // eval mode touches nothing behind the pooled sums (howl_res8_eval_workspace_bytes_mels), and reads s[i-1], s[i-2] while it
+    // writes s[i]: the caller may pass three activation buffers in rotation (s[i] = buffer i mod 3) instead of seven
+    const size_t need = training ? need_train : need_eval;
     if (ws_bytes < need) {
         howl_set_error("howl_res8_fwd: workspace %zu < %zu bytes", ws_bytes, need);
         return HOWL_E_WORKSPACE;

@@ -281,6 +281,10 @@ class DeviceCollate:
         own draws (VTLP's alpha)."""
         if self._rand is random:
             raise ValueError("DeviceCollate.prefetch needs a private stream: construct with seed=...")
+        if depth > self.RING - 2:
+            # prepare() stages into a ring of RING pinned buffers; a slot is only protected from re-use once launch() has issued
+            # its copy, so the worker may run at most RING - 2 batches ahead (queue depth + the one it holds + the one launching)
+            raise ValueError(f"DeviceCollate.prefetch: depth {depth} exceeds the staging ring ({self.RING} slots: depth <= {self.RING - 2})")
         q = queue.Queue(maxsize=max(depth, 1))
         stop = threading.Event()
 

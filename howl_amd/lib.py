@@ -115,7 +115,8 @@ SIGNATURES = {
                            POINTER(HowlRes8Saved), P, P, P, POINTER(HowlRes8Grads), P, c_size_t, c_int, POINTER(HowlAdamW), STREAM],
     "howl_dropout_mask": [P, c_size_t, c_float, ctypes.c_ulonglong, STREAM],
     "howl_xent_fwd_bwd": [P, P, c_int, c_int, P, P, STREAM],
-    "howl_ctc_loss": [P, c_long, c_long, c_int, c_int, c_int, P, c_long, c_int, P, P, c_int, P, P, P, c_long, c_long, STREAM],
+    "howl_ctc_loss": [P, c_long, c_long, c_int, c_int, c_int, P, c_long, c_int, P, P, c_int, P, P, P, c_long, c_long, P, c_size_t,
+                      STREAM],
     "howl_lstm_fwd": [POINTER(HowlLstmParams), P, c_int, c_int, c_int, P, P, P, POINTER(HowlLstmSaved), P, P, P, c_size_t,
                       STREAM],
     "howl_lstm_fwd_next": [POINTER(HowlLstmParams), P, c_int, c_int, c_int, P, P, P, POINTER(HowlLstmSaved), P, P, P, c_size_t,
@@ -136,13 +137,14 @@ SIGNATURES = {
 }
 # entry points that do not return an int status
 SIZE_FUNCS = {"howl_fb_packed_floats": [c_int], "howl_res8_workspace_bytes": [c_int, c_int], "howl_res8_long_workspace_bytes": [c_int, c_int],
-              "howl_res8_workspace_bytes_mels": [c_int, c_int, c_int], "howl_res8_saved_floats": [c_int, c_int, c_int], "howl_res8_long_workspace_bytes_mels": [c_int, c_int, c_int], "howl_lstm_workspace_bytes": [c_int, c_int],
+              "howl_res8_workspace_bytes_mels": [c_int, c_int, c_int], "howl_res8_saved_floats": [c_int, c_int, c_int],
+              "howl_res8_eval_workspace_bytes_mels": [c_int, c_int, c_int], "howl_res8_row_strips": [c_int], "howl_res8_long_workspace_bytes_mels": [c_int, c_int, c_int], "howl_lstm_workspace_bytes": [c_int, c_int],
               "howl_lstm_needs_gx": [POINTER(HowlLstmParams), c_int, c_int, c_int, c_int],
               "howl_head_workspace_bytes": [c_int, c_int, c_int],
               "howl_mobilenet_num_layers": [],
               "howl_mobilenet_param_floats": [c_int], "howl_mobilenet_buffer_floats": [],
               "howl_mobilenet_workspace_bytes": [c_int, c_int, c_int, c_int],
-              "howl_ctc_supported": [c_int, c_int, c_int]}
+              "howl_ctc_supported": [c_int, c_int, c_int], "howl_ctc_workspace_floats": [c_int, c_int]}
 
 
 class HowlHipError(RuntimeError):

@@ -55,6 +55,26 @@ class _Res8Buffers:
         self.saved.mask0 = _vp(self.mask0)
 
 
+class _Res8EvalBuffers:
+    """What an eval-mode forward needs: three activation buffers in rotation (layer i reads s[i-1], s[i-2] and writes s[i]), the
+    forward part of the workspace -- 4 activation-sized tensors instead of the 14 of a training step."""
+
+    def __init__(self, B, T, C, device, M=40):
+        f32 = dict(dtype=torch.float32, device=device)
+        n = _lib.get().cdll.howl_res8_saved_floats(B, T, M)
+        self.rot = [torch.empty(n, **f32) for _ in range(3)]
+        self.bn_stats = torch.zeros((6, 2, 48), **f32)
+        self.pooled = torch.empty((B, 48), **f32)
+        self.mask0 = torch.empty(n, dtype=torch.int16, device=device)
+        self.ws = torch.empty(_lib.get().cdll.howl_res8_eval_workspace_bytes_mels(B, T, M), dtype=torch.uint8, device=device)
+        self.saved = _lib.HowlRes8Saved()
+        for i in range(7):
+            self.saved.s[i] = _vp(self.rot[i % 3])
+        self.saved.bn_stats = _vp(self.bn_stats)
+        self.saved.pooled = _vp(self.pooled)
+        self.saved.mask0 = _vp(self.mask0)
+
+
 class _Res8Function(torch.autograd.Function):
     """autograd seam: forward = howl_res8_fwd, backward = howl_res8_bwd (parameter gradients only; the features
     carry no gradient, as in the reference where they come out of a no_grad frontend)."""
@@ -118,6 +138,7 @@ class Res8(RegisteredModel, name="res8"):
             self.add_module(f"conv{i + 1}", conv)
         self.output = nn.Linear(n_maps, num_labels)
         self._buffers_cache = {}   # (B, T, C, device) -> _Res8Buffers; a handful of geometries (batch max length varies)
+        self._eval_cache = {}      # the same for eval-mode forwards (_Res8EvalBuffers), bounded in BYTES: see _get_eval_buffers
         self._fwd_version = 0
 
     # ---- parameter plumbing ------------------------------------------------------------------------------
@@ -154,6 +175,22 @@ class Res8(RegisteredModel, name="res8"):
         self._buffers_cache[key] = buf
         return buf
 
+    EVAL_CACHE_BYTES = 256 << 20     # eval buffers kept between calls (streaming engines re-use one small geometry)
+
+    def _get_eval_buffers(self, B, T, device, M=40):
+        """Eval-mode buffers: cached while small (an engine's (1, 51..83)-frame windows), transient beyond -- an evaluation pass
+        batches the windows of many clips (``infer_many``) with a different B per call, and a long clip's strips are large."""
+        key = (B, T, M, self.num_labels, str(device))
+        buf = self._eval_cache.pop(key, None)
+        if buf is None:
+            buf = _Res8EvalBuffers(B, T, self.num_labels, device, M)
+        size = lambda b: b.ws.numel() + 4 * 3 * b.rot[0].numel() + 2 * b.mask0.numel()
+        if size(buf) <= self.EVAL_CACHE_BYTES // 4:
+            self._eval_cache[key] = buf
+            while sum(size(b) for b in self._eval_cache.values()) > self.EVAL_CACHE_BYTES:
+                self._eval_cache.pop(next(iter(self._eval_cache)))
+        return buf
+
     @staticmethod
     def _feat_view(x):
         """(B, C, M, T) any strides -> channel-0 base pointer + (sb, st, sm) element strides."""
@@ -171,7 +208,7 @@ class Res8(RegisteredModel, name="res8"):
     MAX_FRAMES = 83     # one utterance's pooled map (27 rows) fits the kernels' tile; longer inputs run as row strips with exchanged
                         # halo rows (howl_res8_fwd / _bwd, training and eval; up to 64 strips = 5,184 frames).  The windowed
                         # eval-mode forward of rounds 2-5 (howl_res8_fwd_long: overlapping 27-row windows, 2.1 x the arithmetic)
-                        # stays in the library and behind _launch_forward_long
+                        # takes eval-mode inputs beyond that (_launch_forward)
 
     def _launch_forward_long(self, x0, sb, st, sm):
         """Eval-mode inputs beyond 83 frames (``ConvertedStaticModel``'s first window, engine clips > 1 s): ``howl_res8_fwd_long``."""
@@ -185,10 +222,18 @@ class Res8(RegisteredModel, name="res8"):
                         ops._stream())
         return logits
 
+    MAX_ROW_STRIPS = 64   # howl_res8_fwd / _bwd
+
     def _launch_forward(self, feat, grads_struct=None):
         x0, sb, st, sm = self._feat_view(feat)
         B, M, T = x0.shape
-        buf = self._get_buffers(B, T, x0.device, M)
+        if not self.training:
+            # cnn.py:127-145 takes any T: beyond 64 row strips (5,184 frames, 65 s) the overlapping-window forward takes over
+            if T > self.MAX_FRAMES and _lib.get().cdll.howl_res8_row_strips(T) > self.MAX_ROW_STRIPS:
+                return self._launch_forward_long(x0, sb, st, sm)
+            buf = self._get_eval_buffers(B, T, x0.device, M)
+        else:
+            buf = self._get_buffers(B, T, x0.device, M)
         logits = torch.empty((B, self.num_labels), dtype=torch.float32, device=x0.device)
         prm = self._params_struct()
         self._fwd_version += 1
@@ -452,6 +497,22 @@ class MobileNetClassifier(RegisteredModel, name="mobilenet"):
             ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
         self._ws_cache[key] = ws
         return ws
+
+    EVAL_CACHE_BYTES = 256 << 20     # eval buffers kept between calls (streaming engines re-use one small geometry)
+
+    def _get_eval_buffers(self, B, T, device, M=40):
+        """Eval-mode buffers: cached while small (an engine's (1, 51..83)-frame windows), transient beyond -- an evaluation pass
+        batches the windows of many clips (``infer_many``) with a different B per call, and a long clip's strips are large."""
+        key = (B, T, M, self.num_labels, str(device))
+        buf = self._eval_cache.pop(key, None)
+        if buf is None:
+            buf = _Res8EvalBuffers(B, T, self.num_labels, device, M)
+        size = lambda b: b.ws.numel() + 4 * 3 * b.rot[0].numel() + 2 * b.mask0.numel()
+        if size(buf) <= self.EVAL_CACHE_BYTES // 4:
+            self._eval_cache[key] = buf
+            while sum(size(b) for b in self._eval_cache.values()) > self.EVAL_CACHE_BYTES:
+                self._eval_cache.pop(next(iter(self._eval_cache)))
+        return buf
 
     @staticmethod
     def _feat_view(x):

@@ -147,6 +147,8 @@ class FrameInferenceEngine(InferenceEngine):
         lengths = self.std.compute_lengths(torch.full((len(starts),), chunk, device=audio_data.device))
         return self.model(feats, lengths).softmax(-1).cpu().numpy()
 
+    MAX_WINDOWS_PER_LAUNCH = 8192
+
     @torch.no_grad()
     def window_probabilities_many(self, clips) -> list:
         """``window_probabilities`` of several clips with ONE frontend launch, one model forward and one device->host copy for all
@@ -163,10 +165,29 @@ class FrameInferenceEngine(InferenceEngine):
         for (chunk, device), members in groups.items():
             self.std = self.std.to(device)
             views = [clips[i].reshape(-1).contiguous().as_strided((n, chunk), (stride_sz, 1)) for i, n, stride_sz in members]
-            windows = views[0] if len(views) == 1 else torch.cat(views)          # (all windows, chunk): the only copy
-            feats = self.std.log_mel_for_model(windows, self.zmuv)
-            lengths = self.std.compute_lengths(torch.full((windows.size(0),), chunk, device=device))
-            probs = self.model(feats, lengths).softmax(-1).cpu().numpy()
+            # at most MAX_WINDOWS_PER_LAUNCH windows per forward: 64 clips of 30 s at a 63-ms stride are ~30 k windows, i.e. 1 GB of
+            # window copies and as much again per activation tensor -- the pass stays O(cap), not O(dataset)
+            pieces, held, parts = [], 0, []
+            def flush():
+                nonlocal pieces, held
+                if not pieces:
+                    return
+                windows = pieces[0] if len(pieces) == 1 else torch.cat(pieces)      # (windows of this launch, chunk): the only copy
+                feats = self.std.log_mel_for_model(windows, self.zmuv)
+                lengths = self.std.compute_lengths(torch.full((windows.size(0),), chunk, device=device))
+                parts.append(self.model(feats, lengths).softmax(-1).cpu().numpy())
+                pieces, held = [], 0
+            for v in views:
+                lo = 0
+                while lo < v.size(0):
+                    take = min(v.size(0) - lo, self.MAX_WINDOWS_PER_LAUNCH - held)
+                    pieces.append(v[lo:lo + take])
+                    held += take
+                    lo += take
+                    if held == self.MAX_WINDOWS_PER_LAUNCH:
+                        flush()
+            flush()
+            probs = parts[0] if len(parts) == 1 else np.concatenate(parts)
             lo = 0
             for i, n, _ in members:
                 out[i] = probs[lo:lo + n]

@@ -176,10 +176,13 @@ def _ctc_launch(scores, targets, input_lengths, target_lengths, blank, max_targe
     nll = torch.empty(B, dtype=torch.float32, device=dev)
     loss = torch.empty((), dtype=torch.float32, device=dev)
     vp = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())     # strided views: strides are passed explicitly
+    # whole clips (more than 128 frames): the alpha rows of the windows behind the last one wait in a workspace
+    ws_floats = int(_lib.get().cdll.howl_ctc_workspace_floats(T, B)) if want_grad else 0
+    ws = torch.empty(ws_floats, dtype=torch.float32, device=dev) if ws_floats else None
     _lib.get().call("howl_ctc_loss", vp(scores), scores.stride(0), scores.stride(1), T, B, C, vp(targets),
                     targets.stride(0), max_target, _p(input_lengths, torch.int64), _p(target_lengths, torch.int64), blank,
                     _p(nll), None if defer_mean else _p(loss), vp(dlogits), 0 if dlogits is None else dlogits.stride(0),
-                    0 if dlogits is None else dlogits.stride(1), _stream())
+                    0 if dlogits is None else dlogits.stride(1), vp(ws), ws_floats, _stream())
     if defer_mean:      # `loss` is filled by howl_head_bwd's HowlCtcMean rider
         return loss, dlogits, nll
     return loss, dlogits
@@ -238,12 +241,16 @@ def ctc_loss_fwd_bwd(scores, targets, input_lengths, target_lengths, blank: int,
 def ctc_loss(scores, targets, input_lengths, target_lengths, blank: int):
     """``nn.CTCLoss(blank)(torch.log_softmax(scores, -1), targets, input_lengths, target_lengths)`` of the reference's training
     loop (train.py:250-256, 291-296) for ``scores`` of shape (T, B, C) on the device, as ONE fused kernel.  ``targets`` is the
-    padded (B, L) int64 matrix; the two length vectors may live on the host (as in the reference) or on the device.  Batches
-    outside the kernel's range (T > 128, C > 64, a target longer than 31 labels) go through torch's own device kernels."""
+    padded (B, L) int64 matrix; the two length vectors may live on the host (as in the reference) or on the device.  Whole
+    clips are inside the kernel's range (T <= 8192 frames, walked in 128-frame windows); a batch outside it (C > 64, a
+    target longer than 31 labels, scores that are not fp32) raises -- the training path has no vendor fallback."""
     targets_d, in_d, tl_d, max_target = _ctc_args(scores, targets, input_lengths, target_lengths, None)
     T, B, C = scores.shape
-    if not _lib.get().cdll.howl_ctc_supported(T, C, max_target) or scores.dtype != torch.float32:
-        return torch.nn.functional.ctc_loss(torch.log_softmax(scores, -1), targets, input_lengths, target_lengths, blank)
+    if scores.dtype != torch.float32:
+        raise _lib.HowlHipError(f"ctc_loss: scores must be fp32 (got {scores.dtype})")
+    if not _lib.get().cdll.howl_ctc_supported(T, C, max_target):
+        raise _lib.HowlHipError(f"ctc_loss: T={T} frames, C={C} classes, targets of {max_target} labels: outside howl_ctc_loss's "
+                                "range (T <= 8192, C <= 64, targets <= 31)")
     if scores.stride(2) != 1:
         scores = scores.contiguous()
     return _CtcLoss.apply(scores, targets_d, in_d, tl_d, int(blank), max_target)

@@ -167,18 +167,12 @@ class FusedTrainer:
             scores = self.model._launch_forward(feat, frame_lengths, max_frames)   # (T_len, B, C) view of a (B, T_len, C) buffer
         if max_target is None:
             max_target = int(target_lengths.max()) if target_lengths.numel() else 0
-        ctc_mean = None
-        if ops.ctc_supported(scores.shape[0], scores.shape[2], max_target):
-            # the batch mean of the loss rides in the head's backward launch (HowlCtcMean)
-            loss, dscores, nll, tl_dev = ops.ctc_loss_fwd_bwd(scores, targets, frame_lengths, target_lengths, blank, max_target,
-                                                              defer_mean=True)
-            ctc_mean = (nll, tl_dev, loss)
-        else:   # longer than the fused kernel's range (T > 128 frames, ...): torch's device kernels for the loss only
-            z = scores.detach().requires_grad_(True)
-            loss = torch.nn.functional.ctc_loss(torch.log_softmax(z, -1), targets.to(z.device), frame_lengths, target_lengths,
-                                                blank)
-            loss.backward()
-            loss, dscores = loss.detach(), z.grad
+        # log-softmax + CTC + their backward as one launch at any clip length (128-frame windows beyond 128 frames); the batch
+        # mean of the loss rides in the head's backward launch (HowlCtcMean).  Outside the kernel's range (C > 64, a target
+        # of more than 31 labels, T > 8192): HowlHipError from the library -- no vendor kernels on the training path
+        loss, dscores, nll, tl_dev = ops.ctc_loss_fwd_bwd(scores, targets, frame_lengths, target_lengths, blank, max_target,
+                                                          defer_mean=True)
+        ctc_mean = (nll, tl_dev, loss)
         # single replica: nothing sits between the backward's gradient fold and the optimiser, so the step rides in the fold
         # (howl_seq_lstm_bwd's HowlAdamW: one launch and one pass over the gradients fewer)
         adamw = None

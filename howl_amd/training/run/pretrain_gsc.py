@@ -57,6 +57,9 @@ def train_epoch(trainer, collate, id_batches, std_transform, writer, epoch_idx, 
     return seen
 
 
+COLLATE_SEED_SALT = 0x5DEECE66D     # collate stream = Random(seed ^ salt + 1000003 rank): never the global Random(seed)
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--model", type=str, choices=RegisteredModel.registered_names(), default="res8")
@@ -152,9 +155,12 @@ def main(argv=None):
     needs_lengths = getattr(model, "NEEDS_LENGTHS", False)
     # train_comp = compose(truncate, Timeshift.train(), Noise.train(), batchify) (pretrain_gsc.py:78-80), on the device.  The
     # collate owns its `random` stream, as each of the reference's DataLoader workers does (a worker thread prepares the next
-    # batches while the main thread -- whose global `random` VTLP draws from -- launches the current one)
+    # batches while the main thread -- whose global `random` VTLP draws from -- launches the current one).  Its seed is derived so
+    # that it cannot coincide with the global stream's (set_random_seed(seed) seeds `random` with the same integer: with
+    # Random(seed) here, VTLP's gate and alpha would replay values the Timeshift / Noise draws had consumed); the single-process
+    # order of draws therefore differs from the reference's one shared stream ("Random streams")
     train_collate = DeviceCollate(train.audio, train.lengths_host, train.labels, max_len, sr=sample_rate,
-                                  seed=SETTINGS.training.seed, replica=rank)
+                                  seed=SETTINGS.training.seed ^ COLLATE_SEED_SALT, replica=rank)
     dev_acc = 0
 
     def shards(id_batches):

@@ -144,7 +144,7 @@ def main(argv=None):
     else:
         batchifier = AudioSequenceBatchifier(ctx.negative_label, WakeWordTokenizer(ctx.vocab, ignore_oov=False))
     collate = DeviceCollate(train_bank.rows, train_bank.lengths, None, max_len=train_bank.max_len, row_offsets=train_bank.offsets,
-                            seed=SETTINGS.training.seed if world > 1 else None, replica=rank)
+                            seed=(SETTINGS.training.seed ^ 0x5DEECE66D) if world > 1 else None, replica=rank)
 
     std_transform = StandardAudioTransform().to(device).eval()
     zmuv_transform = ZmuvTransform().to(device)

@@ -179,6 +179,12 @@ size_t howl_res8_workspace_bytes_mels(int B, int T, int M);
  * utterances (cnn.py:127-145 takes any T) run as row strips of equal height, the last one padded, so the tensors are a little
  * larger: always size them with this. */
 size_t howl_res8_saved_floats(int B, int T, int M);
+/* Eval mode (training = 0) needs less: the workspace only up to the pooled sums (no backward buffers), and layer i reads
+ * s[i-1], s[i-2] while it writes s[i], so THREE activation buffers in rotation (s[i] = buffer i mod 3) may stand in for the
+ * seven; mask0 is still written.  howl_res8_row_strips(T): the row strips a T-frame input runs as (howl_res8_fwd / _bwd take
+ * up to 64 = 5,184 frames; longer eval inputs: howl_res8_fwd_long). */
+size_t howl_res8_eval_workspace_bytes_mels(int B, int T, int M);
+int howl_res8_row_strips(int T);
 
 /* feat: log-mel features, element (b, t, m) at feat[b*sb + t*st + m*sm] (so both the (B,T,M) model layout and
  * channel 0 of the reference's (B,3,M,T) tensor are accepted; replaces x[:, :1].permute(0,1,3,2), cnn.py:128-129).
@@ -253,12 +259,17 @@ int howl_xent_fwd_bwd(const float* logits, const long long* labels, int B, int C
  * nll: (B) per-utterance negative log likelihood; loss: (1) mean_b nll_b / max(target_length_b, 1), or NULL to leave the
  * mean to howl_head_bwd's HowlCtcMean rider (one launch fewer);
  * dlogits (nullable): d loss / d logits, addressed as t*dst_t + b*dst_b + c, rows t >= input_length_b are zero.
- * Range: howl_ctc_supported(T, C, max_target_length) -- T <= 128, C <= 64, targets <= 31 labels; outside it the call
- * returns HOWL_E_ARG (the host side then keeps torch's own device kernels for that batch). */
+ * Range: howl_ctc_supported(T, C, max_target_length) -- T <= 8192 frames, C <= 64, targets <= 31 labels; outside it the call
+ * returns HOWL_E_ARG (the host side raises: the training path has no vendor fallback).  Up to 128 frames an utterance's
+ * rows stay in LDS; longer ones (whole clips: AudioSequenceBatchifier, howl/data/transform/batchifier.py:14-34, with the loss
+ * over all their frames, train.py:291-296) are walked in windows of 128 frames and, when the gradient is wanted, keep their
+ * alpha rows in `workspace`: howl_ctc_workspace_floats(T, B) floats (0 up to 128 frames; workspace may then be NULL). */
 int howl_ctc_supported(int T, int C, int max_target_length);
+size_t howl_ctc_workspace_floats(int T, int B);
 int howl_ctc_loss(const float* logits, long st_t, long st_b, int T, int B, int C, const long long* targets, long tgt_stride,
                   int max_target_length, const long long* input_lengths, const long long* target_lengths, int blank,
-                  float* nll, float* loss, float* dlogits, long dst_t, long dst_b, hipStream_t stream);
+                  float* nll, float* loss, float* dlogits, long dst_t, long dst_b, float* workspace, size_t workspace_floats,
+                  hipStream_t stream);
 
 /* Fused AdamW over one flat buffer (torch.optim.AdamW semantics; pretrain_gsc.py:93,133, train.py:256,302).
  * step counts from 1; grad_scale multiplies g on the fly (1/world_size after a sum all-reduce). */

@@ -583,6 +583,54 @@ def long_window_golden():
     save("g14_res8_two_second_windows", **out)
 
 
+def whole_clip_sequence_golden():
+    """G15: the recurrent models on WHOLE CLIPS, as the reference's sequence objective feeds them -- AudioSequenceBatchifier
+    (batchifier.py:14-34) batches clips, not windows, and CTCLoss runs over all their frames (train.py:198-200, 291-296).
+    Four clips of 4.0 / 3.25 / 2.6 / 1.6 s made of the GSC clips back to back (318 / 258 / 206 / 128 valid frames of 12.5 ms: three,
+    three, two and exactly one 128-frame window of the CTC kernel; 8 x the 41 frames of G6): eval logits, one training step's loss and gradients (seq-lstm: CTC with
+    targets of 3 / 2 / 1 / 3 labels, one of them with a repeated label; lstm: cross-entropy), and the streaming carry over a
+    160 + 161-frame split of the longest clip (rnn.py:62,67-68)."""
+    raw = [read_wav(GSC / w) for w in WAVS]
+    clips = [np.pad(c, (0, 16000))[:16000] for c in raw]
+    cat = [np.concatenate([clips[0], clips[3], clips[1], clips[4]]), np.concatenate([clips[4], clips[2], clips[5], clips[0]])[:52000],
+           np.concatenate([clips[5], clips[0], clips[4]])[:41600], np.concatenate([clips[2], clips[3]])[:26000]]
+    audio, lengths = batchify_like_reference(cat)
+    std = StandardAudioTransform().eval()
+    zmuv = ZmuvTransform()
+    for c in raw:                   # (G4's statistics)
+        zmuv.update(std(torch.from_numpy(c)[None]))
+    x = zmuv(std(audio))
+    flen = std.compute_lengths(lengths)
+    assert x.shape == (4, 3, 40, 321) and flen.tolist() == [318, 258, 206, 128]   # (the last: exactly one CTC window)
+    targets = torch.tensor([[0, 1, 2], [3, 3, 0], [2, 0, 0], [1, 0, 3]])
+    tlen = torch.tensor([3, 2, 1, 3])
+    for name in ("lstm", "seq-lstm"):
+        model = RegisteredModel.find_registered_class(name)(5)
+        model.load_state_dict(om.lstm_init(5))
+        model.eval()
+        with torch.no_grad():
+            logits = model(x, flen)
+        out = dict(lengths=lengths, x=x[:, :1].clone(), frame_lengths=flen, logits=logits, targets=targets, target_lengths=tlen)
+        if name == "seq-lstm":
+            out["audio"] = audio            # (once: the same clips for both models)
+        model.train()
+        sc = model(x, flen)
+        if name == "lstm":
+            loss = torch.nn.functional.cross_entropy(sc, torch.arange(4) % 5)
+        else:
+            loss = torch.nn.CTCLoss(4)(torch.nn.functional.log_softmax(sc, -1), targets, flen, tlen)
+        loss.backward()
+        out["loss0"] = loss.detach()
+        for n, p in model.named_parameters():
+            out["grad0." + n] = p.grad.detach().clone()
+        model.eval().streaming()
+        with torch.no_grad():
+            a = model(x[:1, :, :, :160], None) if name == "seq-lstm" else model(x[:1, :, :, :160], torch.tensor([160]))
+            b = model(x[:1, :, :, 160:], None) if name == "seq-lstm" else model(x[:1, :, :, 160:], torch.tensor([161]))
+        out["stream_a"], out["stream_b"] = a, b
+        save("g15_whole_clips_" + name.replace("-", "_"), **out)
+
+
 if __name__ == "__main__":
     only = [a for a in sys.argv[1:] if a.startswith("--only-")]
     if not only:
@@ -601,3 +649,5 @@ if __name__ == "__main__":
         wide_golden()
     if not only or "--only-long" in only:
         long_window_golden()
+    if not only or "--only-clips" in only:
+        whole_clip_sequence_golden()

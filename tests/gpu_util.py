@@ -88,3 +88,15 @@ def res8_oracle_with_kernel_relus(model, x, labels, B, T, M, C, flip_tol=3e-6):
     ref = om.res8_forward(sd, x.contiguous(), True, relu_masks=masks)
     grads = torch.autograd.grad(torch.nn.functional.cross_entropy(ref, labels), params)
     return ref.detach(), dict(zip(names, grads)), flips, sd
+
+
+def res8_plain_oracle_grads(x, labels, C):
+    """The oracle's training step with its OWN ReLU decisions (no mask plumbing): at full batch sizes one flipped decision moves
+    a gradient by ~1e-6 relative, so the kernels must also agree with this at 5e-5 (the shared-decision
+    comparison must never be the only thing between a strip bug and green)."""
+    names = om.res8_param_names()
+    sd = om.res8_init(C)
+    params = [sd[n].requires_grad_(True) for n in names]
+    ref = om.res8_forward(sd, x.contiguous(), True)
+    grads = torch.autograd.grad(torch.nn.functional.cross_entropy(ref, labels), params)
+    return ref.detach(), dict(zip(names, grads))

@@ -195,9 +195,9 @@ def test_ctc_batch_mean_rides_in_the_head_backward(lib):
     il = np.full(B, T, np.int64)
     tl = np.array([3, 2, 3, 1, 0, 3, 2], np.int64)
     nll, loss_ref = np.zeros(B, np.float32), np.zeros(1, np.float32)
-    lib.call("howl_ctc_loss", ptr(z), C, T * C, T, B, C, ptr(tg), 3, 3, ptr(il), ptr(tl), 4, ptr(nll), ptr(loss_ref), None, 0, 0, None)
+    lib.call("howl_ctc_loss", ptr(z), C, T * C, T, B, C, ptr(tg), 3, 3, ptr(il), ptr(tl), 4, ptr(nll), ptr(loss_ref), None, 0, 0, None, 0, None)
     nll2 = np.zeros(B, np.float32)
-    lib.call("howl_ctc_loss", ptr(z), C, T * C, T, B, C, ptr(tg), 3, 3, ptr(il), ptr(tl), 4, ptr(nll2), None, None, 0, 0, None)
+    lib.call("howl_ctc_loss", ptr(z), C, T * C, T, B, C, ptr(tg), 3, 3, ptr(il), ptr(tl), 4, ptr(nll2), None, None, 0, 0, None, 0, None)
     np.testing.assert_array_equal(nll2, nll)
     for n_out, with_dx in ((5, False), (12, False), (5, True)):       # vector kernels / GEMM path / row-streaming kernel (from 2048 rows)
         rows, n_in, n_hid = (2050 if with_dx else 40), 128, 256
@@ -374,3 +374,40 @@ def test_forward_with_the_next_batch_frontend_riding_in_the_launch(lib, monkeypa
             np.testing.assert_array_equal(bufs["hseq"][:, 1:], ref_hs)
             np.testing.assert_array_equal(hT, ref_hT)
             np.testing.assert_array_equal(bufs["gates"], ref_keep["bufs"]["gates"])
+
+
+@pytest.mark.parametrize("name", ["lstm", "seq-lstm"])
+def test_golden_whole_clips_on_the_emulator(golden, name):
+    """G15 (the reference's recurrent models on clips of 318 / 258 / 206 / 128 frames) through the product's modules on the
+    emulator: recurrences at eight times G6's length, the CTC kernel's 128-frame windows, streaming carry over a 160 + 161 split."""
+    from emu_util import emulated_package
+    from howl_amd import ops
+    from howl_amd.model import RegisteredModel
+    g = golden("g15_whole_clips_" + name.replace("-", "_"))
+    x = torch.from_numpy(g["x"])
+    flen = torch.from_numpy(g["frame_lengths"])
+    with emulated_package():
+        model = RegisteredModel.find_registered_class(name)(5)
+        model.load_state_dict({k: v.clone() for k, v in om.lstm_init(5).items()})
+        model.eval()
+        with torch.no_grad():
+            logits = model(x, flen)
+        assert logits.shape == g["logits"].shape and np.abs(logits.numpy() - g["logits"]).max() < 2e-5
+        model.train()
+        sc = model(x, flen)
+        if name == "lstm":
+            loss = torch.nn.functional.cross_entropy(sc, torch.arange(4) % 5)
+        else:
+            loss = ops.ctc_loss(sc, torch.from_numpy(g["targets"]), flen, torch.from_numpy(g["target_lengths"]), 4)
+        loss.backward()
+        assert abs(loss.item() - float(g["loss0"])) < 1e-4 * max(1.0, float(g["loss0"]))
+        for n, p in model.named_parameters():
+            ref = g["grad0." + n]
+            assert np.abs(p.grad.numpy() - ref).max() < 1e-4 * max(1.0, float(np.abs(ref).max())), n
+        model.eval().streaming()
+        with torch.no_grad():
+            if name == "seq-lstm":
+                a, b = model(x[:1, :, :, :160], None), model(x[:1, :, :, 160:], None)
+            else:
+                a, b = model(x[:1, :, :, :160], torch.tensor([160])), model(x[:1, :, :, 160:], torch.tensor([161]))
+        assert np.abs(a.numpy() - g["stream_a"]).max() < 2e-5 and np.abs(b.numpy() - g["stream_b"]).max() < 2e-5

@@ -487,6 +487,13 @@ def test_res8_at_80_mel_bins_vs_oracle(B, T, C):
     for i in (1, 4, 6):
         assert maxerr(getattr(model, f"bn{i}").running_mean, sd[f"bn{i}.running_mean"]) < 1e-5
         assert maxerr(getattr(model, f"bn{i}").running_var, sd[f"bn{i}.running_var"]) < 1e-4
+    if B >= 512:     # ... and against the oracle's own decisions, no masks involved (a flip moves a 512-utterance gradient by ~1e-6;
+                     # at 64 utterances one flip still moved conv4's gradient by 7e-5 of 7e-3 on the device)
+        from gpu_util import res8_plain_oracle_grads
+        plain, plain_grads = res8_plain_oracle_grads(x, labels, C)
+        assert maxerr(logits, plain) < LOGIT_TOL
+        for n, p in zip(names, model.hot_parameters()):
+            assert maxerr(p.grad, plain_grads[n]) < 5e-5 * max(1.0, plain_grads[n].abs().max().item()), n
     # the same step from the same state: the same bits
     model2 = make_res8(C)
     logits2 = model2(x.to(DEV), None)
@@ -616,6 +623,12 @@ def test_res8_trains_beyond_83_frames_vs_oracle(B, T, C, M):
     for i in (1, 4, 6):
         assert maxerr(getattr(model, f"bn{i}").running_mean, sd[f"bn{i}.running_mean"]) < 1e-5
         assert maxerr(getattr(model, f"bn{i}").running_var, sd[f"bn{i}.running_var"]) < 1e-4
+    if B >= 512:     # ... and against the oracle's own decisions, no masks involved
+        from gpu_util import res8_plain_oracle_grads
+        plain, plain_grads = res8_plain_oracle_grads(x, labels, C)
+        assert maxerr(logits, plain) < LOGIT_TOL
+        for n, p in zip(names, model.hot_parameters()):
+            assert maxerr(p.grad, plain_grads[n]) < 5e-5 * max(1.0, plain_grads[n].abs().max().item()), n
     model2 = make_res8(C)
     logits2 = model2(x.to(DEV), None)
     torch.nn.functional.cross_entropy(logits2, labels.to(DEV)).backward()
@@ -692,3 +705,25 @@ def test_golden_two_second_windows(golden, mels):
     for i in (1, 6):
         assert maxerr(getattr(model, f"bn{i}").running_mean, g[pre + f"bn{i}.running_mean.1"]) < 1e-5
         assert maxerr(getattr(model, f"bn{i}").running_var, g[pre + f"bn{i}.running_var.1"]) < 1e-4
+
+
+def test_eval_mode_takes_any_length_and_small_buffers():
+    """cnn.py:127-145 takes any T.  Eval mode: up to 64 row strips (5,184 frames) through howl_res8_fwd on three rotating activation
+    buffers and the forward part of the workspace (a long clip must not allocate a training step's 14 tensors, and
+    must not fail beyond 64 strips); longer clips through the overlapping-window forward.  Both against the oracle."""
+    from howl_amd import lib
+    model = make_res8(12, train=False)
+    L = lib.get().cdll
+    assert L.howl_res8_eval_workspace_bytes_mels(4, 2000, 40) < L.howl_res8_workspace_bytes_mels(4, 2000, 40) // 4
+    sd = {k: v.detach() for k, v in om.res8_init(12).items()}
+    torch.manual_seed(3)
+    for B, T in ((2, 5184), (1, 5400), (3, 700)):
+        x = (torch.randn(B, T, 40) * 1.2).permute(0, 2, 1).unsqueeze(1)
+        with torch.no_grad():
+            ev = model(x.to(DEV), None)
+        ref = om.res8_forward(sd, x.contiguous(), False)
+        assert maxerr(ev, ref) < 1e-4 * max(1.0, ref.abs().max().item()), (B, T)
+    assert L.howl_res8_row_strips(5184) == 64 and L.howl_res8_row_strips(5400) == 67
+    # nothing large stays cached between calls
+    held = sum(b.ws.numel() + 12 * b.rot[0].numel() for b in model._eval_cache.values())
+    assert held <= model.EVAL_CACHE_BYTES and not model._buffers_cache

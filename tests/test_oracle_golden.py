@@ -155,6 +155,41 @@ def test_g6_lstm(golden):
         close(b, g["stream_b"], 2e-6)
 
 
+def test_g15_whole_clips(golden):
+    """The recurrent oracles at whole-clip lengths (318 / 258 / 206 / 128 frames) against the reference's classes: the sequence
+    objective batches clips, not windows (batchifier.py:14-34, train.py:198-200,291-296)."""
+    for name, fwd in (("lstm", om.lstm_forward), ("seq_lstm", om.seq_lstm_forward)):
+        g = golden("g15_whole_clips_" + name)
+        x, flen = t(g["x"]), t(g["frame_lengths"])
+        assert flen.tolist() == [318, 258, 206, 128]
+        logits, _ = fwd(om.lstm_init(5), x, flen)
+        close(logits, g["logits"], 5e-6)
+        sd = {k: v.clone().requires_grad_(True) for k, v in om.lstm_init(5).items()}
+        sc, _ = fwd(sd, x, flen)
+        if name == "lstm":
+            loss = torch.nn.functional.cross_entropy(sc, torch.arange(4) % 5)
+        else:
+            loss = torch.nn.CTCLoss(4)(torch.log_softmax(sc, -1), t(g["targets"]), flen, t(g["target_lengths"]))
+        loss.backward()
+        close(loss.detach(), g["loss0"], 5e-6 * max(1.0, float(g["loss0"])))
+        for n in om.lstm_param_names():
+            close(sd[n].grad, g["grad0." + n], 4e-5 * max(1.0, float(np.abs(g["grad0." + n]).max())))   # BPTT over 318 steps in fp32
+        sd = om.lstm_init(5)
+        if name == "lstm":
+            a, hc = fwd(sd, x[:1, :, :, :160], torch.tensor([160]))
+            b, _ = fwd(sd, x[:1, :, :, 160:], torch.tensor([161]), hx=hc)
+        else:
+            a, hc = fwd(sd, x[:1, :, :, :160], None)
+            b, _ = fwd(sd, x[:1, :, :, 160:], None, hx=hc)
+        close(a, g["stream_a"], 5e-6)
+        close(b, g["stream_b"], 5e-6)
+    # the frontend oracle on the same clips (the seq-lstm file carries the audio)
+    g = golden("g15_whole_clips_seq_lstm")
+    z = _features(golden)[1]
+    feats = z(fe.standard_audio_transform(t(g["audio"]), fe.mel_fb(40)))
+    close(feats[:, :1], g["x"], 2e-4)
+
+
 def test_g7_specaug(golden):
     g = golden("g7_specaug")
     out = fe.spec_augment_apply(t(g["x"]), g["f0"], g["f"], g["t0"], g["t"])
