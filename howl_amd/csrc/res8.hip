@@ -66,6 +66,7 @@ constexpr int KFULL = 11;        // full input-channel blocks (4 channels x 9 ta
 constexpr int KSTEPS = 9 * KFULL + 3;   // + channel 44 alone: its 9 taps as 3 k-steps (taps 4s + k); 102 instead of the 108
                                  // of a zero-padded 12th block: 5.6 % fewer MFMAs in the forward / dgrad K loops
 constexpr int MAX_H = 27;
+constexpr int MAX_ROW_STRIPS = 1024;   // row strips per utterance (howl_res8_fwd / _bwd): 82,944 frames; nothing in the kernels depends on the count
 constexpr float BN_EPS = 1e-5f;
 constexpr float BN_MOMENTUM = 0.1f;
 
@@ -2158,7 +2159,11 @@ __global__ __launch_bounds__(C0G_THREADS) void conv0_wgrad_valu_kernel(const flo
 // dlogits[b] = (softmax - onehot) * inv_batch, dpool[b] = dlogits[b] . W_out.  The batch mean of nll is taken by
 // head_bwd_param_kernel.  Needs C <= HEAD_XC classes.
 constexpr int HEAD_XC = 64;
-__global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__ s6, const float* __restrict__ stats,
+// Round 6: twelve waves (every wave folds ONE quad of statistics columns: the three dependent fold trips of a four-wave block were
+// 5 us of a 15-us launch at batch 64), the output layer's weights in LDS (the logits and the pooled gradient were chains of global
+// loads), the per-group pooled sums fetched by all threads at once and added in the same order as before (bit-identical results).
+constexpr int HEAD_THREADS = 768, HEAD_PARTS = 16;
+__global__ __launch_bounds__(HEAD_THREADS) void head_fwd_kernel(const float* __restrict__ s6, const float* __restrict__ stats,
                                                        const float* __restrict__ wout, const float* __restrict__ bout,
                                                        float* __restrict__ pooled, float* __restrict__ logits, int B,
                                                        int P, int C, const long long* __restrict__ labels,
@@ -2169,13 +2174,18 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
     __shared__ float lp[CP];
     __shared__ float ll[HEAD_XC], dl[HEAD_XC], lse_s;
     __shared__ float lst[2 * CP];
+    __shared__ float lw[HEAD_XC * NMAP];          // output.weight when C <= HEAD_XC
+    __shared__ float lparts[HEAD_PARTS][CP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool w_in_lds = C <= HEAD_XC;
+    if (w_in_lds)
+        for (int i = tid; i < C * NMAP; i += HEAD_THREADS) lw[i] = wout[i];
     if (fold.part != nullptr) {
         // training: BatchNorm 6's batch statistics from the last convolution's partials, folded by every workgroup (the same bits
         // everywhere: fold_part_column) -- without a one-block finalize launch between the last
         // convolution and the head; workgroup 0 publishes them for the backward pass and updates the running buffers (cnn.py:142)
         const int c8 = lane >> 3;
-        for (int w0 = wave; w0 < CP / 4; w0 += 4) {
+        for (int w0 = wave; w0 < CP / 4; w0 += HEAD_THREADS / 64) {
             const int c = 4 * w0 + (c8 & 3);
             const double sm = fold_part_column(fold.part, part_stride(fold.nparts), fold.nparts, (c8 < 4 ? 0 : CP) + c, lane);
             const double q = __shfl_xor(sm, 32);
@@ -2206,16 +2216,30 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
     for (int b = blockIdx.x; b < B; b += gridDim.x) {
         __syncthreads();
         if (pool != nullptr) {
-            // the last convolution left the sums of |s_6| per (utterance, position group, channel): add the groups in order
+            // the last convolution left the sums of |s_6| per (utterance, position group, channel): all of an utterance's parts are
+            // requested at once (thread = (part, channel)), then added in part order by the channel's thread
+            const int nparts = ns * npg_used;
+            const int pc = tid % CP, pk = tid / CP;      // 16 parts x 48 channels = 768 threads
+            float acc = 0.0f;
+            for (int k0 = 0; k0 < nparts; k0 += HEAD_PARTS) {
+                const int k = k0 + pk;
+                if (k < nparts) {
+                    const int sgi = k / npg_used, g = k - sgi * npg_used;
+                    lparts[pk][pc] = pool[(((size_t)b * ns + sgi) * npg + g) * CP + pc];
+                }
+                __syncthreads();
+                if (tid < CP) {
+                    const int n = nparts - k0 < HEAD_PARTS ? nparts - k0 : HEAD_PARTS;
+                    for (int j = 0; j < n; ++j) acc += lparts[j][tid];
+                }
+                __syncthreads();
+            }
             if (tid < CP) {
-                float acc = 0.0f;
-                for (int sgi = 0; sgi < ns; ++sgi)
-                    for (int g = 0; g < npg_used; ++g) acc += pool[(((size_t)b * ns + sgi) * npg + g) * CP + tid];
                 const float v = tid < NMAP ? (acc / (float)P - lst[tid]) * lst[CP + tid] : 0.0f;
                 lp[tid] = v;
                 pooled[(size_t)b * CP + tid] = v;
             }
-        } else
+        } else if (wave < 4)
         // a wave owns channels wave, wave+4, ...: three of them per trip (24 loads in flight) -- one channel per trip is a
         // chain of twelve load latencies
         for (int c0 = wave; c0 < CP; c0 += 12) {
@@ -2243,9 +2267,12 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
             }
         }
         __syncthreads();
-        for (int k = tid; k < C; k += 256) {
+        for (int k = tid; k < C; k += HEAD_THREADS) {
             float acc = bout[k];
-            for (int c = 0; c < NMAP; ++c) acc = fmaf(wout[k * NMAP + c], lp[c], acc);
+            if (w_in_lds)
+                for (int c = 0; c < NMAP; ++c) acc = fmaf(lw[k * NMAP + c], lp[c], acc);
+            else
+                for (int c = 0; c < NMAP; ++c) acc = fmaf(wout[k * NMAP + c], lp[c], acc);
             logits[(size_t)b * C + k] = acc;
             if (labels != nullptr) ll[k] = acc;
         }
@@ -2268,10 +2295,10 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
             dlogits[(size_t)b * C + tid] = d;
         }
         __syncthreads();
-        if (tid < CP) {                        // head_bwd_pool_kernel's sum
+        if (tid < CP) {                        // head_bwd_pool_kernel's sum (labels given: C <= HEAD_XC, the weights are in LDS)
             float acc = 0.0f;
             if (tid < NMAP)
-                for (int k = 0; k < C; ++k) acc = fmaf(dl[k], wout[k * NMAP + tid], acc);
+                for (int k = 0; k < C; ++k) acc = fmaf(dl[k], lw[k * NMAP + tid], acc);
             dpool[(size_t)b * CP + tid] = acc;
         }
     }
@@ -2697,7 +2724,7 @@ int res8_fwd_impl(const HowlRes8Params* prm, const float* feat, long sb, long st
     // wide maps: every utterance is NS strips of 10 pooled columns (HaloSlot); long maps: NR row strips of H rows each (StripGeom);
     // every strip is a block of the (Bv, 45, H, 10) activations
     const Strips sp = strips_for(B, T, M);
-    HOWL_REQUIRE(sp.hv_last >= 1 && sp.nr <= 64, "howl_res8_fwd: T=%d frames unsupported (%d row strips)", T, sp.nr);
+    HOWL_REQUIRE(sp.hv_last >= 1 && sp.nr <= MAX_ROW_STRIPS, "howl_res8_fwd: T=%d frames unsupported (%d row strips)", T, sp.nr);
     const int NS = sp.ns, H = sp.Hs, Bv = sp.Bv, halo = sp.halo;
     const bool grid = halo == 2;
     const int G = even_grid(conv_grid(Bv), NS);
@@ -2774,7 +2801,7 @@ int res8_fwd_impl(const HowlRes8Params* prm, const float* feat, long sb, long st
                                            HowlBnBuffers{prm->bn_running_mean[5], prm->bn_running_var[5], prm->bn_num_batches[5]}}
                                   : BnFold{};
     // the spatial mean runs over all strips of an utterance: nr * ns blocks of 4 SL position groups, Pt positions
-    hipLaunchKernelGGL(head_fwd_kernel, dim3(B < 1024 ? B : 1024), dim3(256), 0, stream, sv->s[6],
+    hipLaunchKernelGGL(head_fwd_kernel, dim3(B < 1024 ? B : 1024), dim3(HEAD_THREADS), 0, stream, sv->s[6],
                        sv->bn_stats + (size_t)5 * 2 * CP, prm->out_w, prm->out_b, sv->pooled, logits, B, Pt, C, labels, nll, dlogits,
                        w.dpool, 1.0f / (float)B, (const float*)w.pool, 4 * SL, 4 * SL < (P + 15) / 16 ? 4 * SL : (P + 15) / 16, hfold,
                        sp.nr * NS);
@@ -2914,7 +2941,7 @@ int res8_bwd_impl(const HowlRes8Params* prm, const float* feat, long sb, long st
     const int Ht = T / 3;
     HOWL_REQUIRE(B >= 1 && Ht >= 1, "howl_res8_bwd: B=%d T=%d unsupported", B, T);
     const Strips sp = strips_for(B, T, M);      // column strips (HaloSlot) x row strips (StripGeom), each a block of the activations
-    HOWL_REQUIRE(sp.hv_last >= 1 && sp.nr <= 64, "howl_res8_bwd: T=%d frames unsupported (%d row strips)", T, sp.nr);
+    HOWL_REQUIRE(sp.hv_last >= 1 && sp.nr <= MAX_ROW_STRIPS, "howl_res8_bwd: T=%d frames unsupported (%d row strips)", T, sp.nr);
     const int NS = sp.ns, H = sp.Hs, Bv = sp.Bv, halo = sp.halo;
     const bool grid = halo == 2;
     const int Pt = Ht * PW * NS;      // positions of one utterance's whole map

@@ -206,9 +206,9 @@ class Res8(RegisteredModel, name="res8"):
 
     # ---- launches ----------------------------------------------------------------------------------------------
     MAX_FRAMES = 83     # one utterance's pooled map (27 rows) fits the kernels' tile; longer inputs run as row strips with exchanged
-                        # halo rows (howl_res8_fwd / _bwd, training and eval; up to 64 strips = 5,184 frames).  The windowed
-                        # eval-mode forward of rounds 2-5 (howl_res8_fwd_long: overlapping 27-row windows, 2.1 x the arithmetic)
-                        # takes eval-mode inputs beyond that (_launch_forward)
+                        # halo rows (howl_res8_fwd / _bwd, training and eval; up to 1024 strips = 82,944 frames).  The windowed
+                        # eval-mode forward of rounds 2-5 (howl_res8_fwd_long: overlapping 27-row windows, 2.1 x the arithmetic,
+                        # up to 64 windows) stays in the library and behind _launch_forward_long
 
     def _launch_forward_long(self, x0, sb, st, sm):
         """Eval-mode inputs beyond 83 frames (``ConvertedStaticModel``'s first window, engine clips > 1 s): ``howl_res8_fwd_long``."""
@@ -222,15 +222,10 @@ class Res8(RegisteredModel, name="res8"):
                         ops._stream())
         return logits
 
-    MAX_ROW_STRIPS = 64   # howl_res8_fwd / _bwd
-
     def _launch_forward(self, feat, grads_struct=None):
         x0, sb, st, sm = self._feat_view(feat)
         B, M, T = x0.shape
-        if not self.training:
-            # cnn.py:127-145 takes any T: beyond 64 row strips (5,184 frames, 65 s) the overlapping-window forward takes over
-            if T > self.MAX_FRAMES and _lib.get().cdll.howl_res8_row_strips(T) > self.MAX_ROW_STRIPS:
-                return self._launch_forward_long(x0, sb, st, sm)
+        if not self.training:     # cnn.py:127-145 takes any T; eval mode on three rotating activation buffers
             buf = self._get_eval_buffers(B, T, x0.device, M)
         else:
             buf = self._get_buffers(B, T, x0.device, M)

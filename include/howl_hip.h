@@ -182,7 +182,7 @@ size_t howl_res8_saved_floats(int B, int T, int M);
 /* Eval mode (training = 0) needs less: the workspace only up to the pooled sums (no backward buffers), and layer i reads
  * s[i-1], s[i-2] while it writes s[i], so THREE activation buffers in rotation (s[i] = buffer i mod 3) may stand in for the
  * seven; mask0 is still written.  howl_res8_row_strips(T): the row strips a T-frame input runs as (howl_res8_fwd / _bwd take
- * up to 64 = 5,184 frames; longer eval inputs: howl_res8_fwd_long). */
+ * up to 1024 = 82,944 frames). */
 size_t howl_res8_eval_workspace_bytes_mels(int B, int T, int M);
 int howl_res8_row_strips(int T);
 

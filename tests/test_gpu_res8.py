@@ -708,16 +708,16 @@ def test_golden_two_second_windows(golden, mels):
 
 
 def test_eval_mode_takes_any_length_and_small_buffers():
-    """cnn.py:127-145 takes any T.  Eval mode: up to 64 row strips (5,184 frames) through howl_res8_fwd on three rotating activation
-    buffers and the forward part of the workspace (a long clip must not allocate a training step's 14 tensors, and
-    must not fail beyond 64 strips); longer clips through the overlapping-window forward.  Both against the oracle."""
+    """cnn.py:127-145 takes any T.  Eval mode runs on three rotating activation buffers and the forward part of the workspace
+    (a long clip must not allocate a training step's 14 tensors) and the row-strip count is no longer capped at 64
+    (5,184 frames = 65 s: ADVICE r5; now 1024 strips): 64, 67 and 149 strips and a short multi-strip batch against the oracle."""
     from howl_amd import lib
     model = make_res8(12, train=False)
     L = lib.get().cdll
     assert L.howl_res8_eval_workspace_bytes_mels(4, 2000, 40) < L.howl_res8_workspace_bytes_mels(4, 2000, 40) // 4
     sd = {k: v.detach() for k, v in om.res8_init(12).items()}
     torch.manual_seed(3)
-    for B, T in ((2, 5184), (1, 5400), (3, 700)):
+    for B, T in ((2, 5184), (1, 5400), (1, 12001), (3, 700)):
         x = (torch.randn(B, T, 40) * 1.2).permute(0, 2, 1).unsqueeze(1)
         with torch.no_grad():
             ev = model(x.to(DEV), None)
