@@ -35,12 +35,12 @@
 
 namespace {
 
-template <int NWAVES, int NGRP>
+template <int NWAVES, int NGRP, bool WIDE = false>
 __global__ __launch_bounds__(NWAVES * 64) void logmel_kernel(const float* __restrict__ pcm, int L, long ld, int T,
                                                              int total_frames, const float* __restrict__ fbp, int M,
                                                              float log_eps, const float* __restrict__ zmuv,
                                                              float* __restrict__ out, int layout, int n_quads, int aligned, int Mo) {
-    logmel_body<NWAVES, NGRP>(pcm, L, ld, T, total_frames, fbp, M, log_eps, zmuv, out, layout, n_quads, aligned, blockIdx.x, gridDim.x, Mo);
+    logmel_body<NWAVES, NGRP, WIDE>(pcm, L, ld, T, total_frames, fbp, M, log_eps, zmuv, out, layout, n_quads, aligned, blockIdx.x, gridDim.x, Mo);
 }
 
 // columns [m0, m0 + Mb) of fb (257, M) row-major -> fbp (260, NCOL) zero padded
@@ -55,16 +55,36 @@ __global__ void fb_pack_kernel(const float* __restrict__ fb, int M, float* __res
 // the 4x4x1 MFMAs of logmel_kernel -- lane 4j + c of fragment (slot s, group g) = fb[bin_of(s, j)][4 g + c] -- once as the
 // banded LDS image ([s][lane][4]: the four groups slot_group(s, .) of a slot side by side) and once for every (s, g) pair,
 // plus the flag that tells the kernel whether the banded image covers every non-zero weight.  One workgroup.
-__global__ __launch_bounds__(1024) void fb_fragments_kernel(float* __restrict__ fbp) {
+// (slot, group) of pair p of a wide table's fragment image (wide_pair's inverse), or slot = -1 past the table's pairs
+__device__ __forceinline__ void wide_pair_at(int bank, int p, int& s_out, int& g_out) {
+    s_out = -1, g_out = 0;
+    int n = 0;
+    for (int s = 0; s < NSLOT; ++s)
+        for (int g = 0; g < 10; ++g)
+            if (wide_has(bank, s, g)) {
+                if (n == p) s_out = s, g_out = g;
+                ++n;
+            }
+}
+// `table`: 0 = the 40-bin slot_group table; 1 / 2 = the lower / upper bank of the 80-bin filterbank (FBQ pair-major, flag [1])
+__global__ __launch_bounds__(1024) void fb_fragments_kernel(float* __restrict__ fbp, int table) {
     __shared__ int uncovered;
     const float* rm = fbp;                 // (K_PAD, HOWL_FB_COLS) row-major
     if (threadIdx.x == 0) uncovered = 0;
     __syncthreads();
     float* fq = fbp + FBQ_OFF;
     for (int idx = threadIdx.x; idx < FBQ_FLOATS; idx += blockDim.x) {
-        const int c = idx & 3, lane = (idx >> 2) & 63, s = idx >> 8;
-        const int g = slot_group(s, c), bin = bin_of(s, lane >> 2);
-        fq[idx] = (g >= 0 && bin >= 0) ? rm[bin * HOWL_FB_COLS + 4 * g + (lane & 3)] : 0.0f;
+        if (table == 0) {
+            const int c = idx & 3, lane = (idx >> 2) & 63, s = idx >> 8;
+            const int g = slot_group(s, c), bin = bin_of(s, lane >> 2);
+            fq[idx] = (g >= 0 && bin >= 0) ? rm[bin * HOWL_FB_COLS + 4 * g + (lane & 3)] : 0.0f;
+        } else {
+            const int lane = idx & 63;
+            int s, g;
+            wide_pair_at(table - 1, idx >> 6, s, g);
+            const int bin = s >= 0 ? bin_of(s, lane >> 2) : -1;
+            fq[idx] = bin >= 0 ? rm[bin * HOWL_FB_COLS + 4 * g + (lane & 3)] : 0.0f;
+        }
     }
     float* fd = fbp + FBD_OFF;
     for (int idx = threadIdx.x; idx < FBD_FLOATS; idx += blockDim.x) {
@@ -74,10 +94,13 @@ __global__ __launch_bounds__(1024) void fb_fragments_kernel(float* __restrict__ 
     }
     for (int idx = threadIdx.x; idx < N_FREQ * HOWL_FB_COLS; idx += blockDim.x) {
         const int k = idx / HOWL_FB_COLS, m = idx - k * HOWL_FB_COLS;
-        if (rm[idx] != 0.0f && !slot_has_group(slot_of_bin(k), m >> 2)) uncovered = 1;   // benign race: every writer stores 1
+        if (rm[idx] != 0.0f && !table_has(table, slot_of_bin(k), m >> 2)) uncovered = 1;   // benign race: every writer stores 1
     }
     __syncthreads();
-    if (threadIdx.x == 0) reinterpret_cast<int*>(fbp + FBF_OFF)[0] = uncovered ? 0 : 1;
+    if (threadIdx.x == 0) {
+        reinterpret_cast<int*>(fbp + FBF_OFF)[0] = (table == 0 && !uncovered) ? 1 : 0;
+        reinterpret_cast<int*>(fbp + FBF_OFF)[1] = (table != 0 && !uncovered) ? 1 : 0;
+    }
 }
 
 // triangles from M+2 corner frequencies (already VTLP-warped on the host: 42 scalars), exactly the
@@ -95,7 +118,8 @@ __device__ __forceinline__ float fb_triangle(const HowlMelPoints& pts, int M, fl
 // The whole packed filterbank of howl_fb_from_points in ONE launch (round 4; it was the row-major matrix, then a one-workgroup
 // kernel gathering the fragment images from it: 5 + 11 us per VTLP step, i.e. on 75 % of the training steps): every element
 // of the three images is computed from the corner points where it is stored, the last block takes the coverage flag.
-__global__ __launch_bounds__(256) void fb_from_points_kernel(HowlMelPoints pts, int M, float nyquist, float* __restrict__ fbp, int m0) {
+__global__ __launch_bounds__(256) void fb_from_points_kernel(HowlMelPoints pts, int M, float nyquist, float* __restrict__ fbp, int m0,
+                                                             int table) {
     constexpr int N_RM = K_PAD * HOWL_FB_COLS;
     if (blockIdx.x == gridDim.x - 1) {      // does the banded image cover every non-zero weight?
         __shared__ int uncovered;
@@ -103,10 +127,13 @@ __global__ __launch_bounds__(256) void fb_from_points_kernel(HowlMelPoints pts, 
         __syncthreads();
         for (int idx = threadIdx.x; idx < N_FREQ * HOWL_FB_COLS; idx += blockDim.x) {
             const int k = idx / HOWL_FB_COLS, m = idx - k * HOWL_FB_COLS;
-            if (fb_triangle(pts, M, nyquist, k, m, m0) != 0.0f && !slot_has_group(slot_of_bin(k), m >> 2)) uncovered = 1;   // benign race
+            if (fb_triangle(pts, M, nyquist, k, m, m0) != 0.0f && !table_has(table, slot_of_bin(k), m >> 2)) uncovered = 1;   // benign race
         }
         __syncthreads();
-        if (threadIdx.x == 0) reinterpret_cast<int*>(fbp + FBF_OFF)[0] = uncovered ? 0 : 1;
+        if (threadIdx.x == 0) {
+            reinterpret_cast<int*>(fbp + FBF_OFF)[0] = (table == 0 && !uncovered) ? 1 : 0;
+            reinterpret_cast<int*>(fbp + FBF_OFF)[1] = (table != 0 && !uncovered) ? 1 : 0;
+        }
         return;
     }
     int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -115,10 +142,18 @@ __global__ __launch_bounds__(256) void fb_from_points_kernel(HowlMelPoints pts, 
         return;
     }
     idx -= N_RM;
-    if (idx < FBQ_FLOATS) {                 // banded LDS image [s][lane][4]
-        const int c = idx & 3, lane = (idx >> 2) & 63, sl = idx >> 8;
-        const int g = slot_group(sl, c), bin = bin_of(sl, lane >> 2);
-        fbp[FBQ_OFF + idx] = (g >= 0 && bin >= 0) ? fb_triangle(pts, M, nyquist, bin, 4 * g + (lane & 3), m0) : 0.0f;
+    if (idx < FBQ_FLOATS) {                 // banded LDS image: [s][lane][4], or [pair][lane] for the 80-bin banks
+        if (table == 0) {
+            const int c = idx & 3, lane = (idx >> 2) & 63, sl = idx >> 8;
+            const int g = slot_group(sl, c), bin = bin_of(sl, lane >> 2);
+            fbp[FBQ_OFF + idx] = (g >= 0 && bin >= 0) ? fb_triangle(pts, M, nyquist, bin, 4 * g + (lane & 3), m0) : 0.0f;
+        } else {
+            const int lane = idx & 63;
+            int sl, g;
+            wide_pair_at(table - 1, idx >> 6, sl, g);
+            const int bin = sl >= 0 ? bin_of(sl, lane >> 2) : -1;
+            fbp[FBQ_OFF + idx] = bin >= 0 ? fb_triangle(pts, M, nyquist, bin, 4 * g + (lane & 3), m0) : 0.0f;
+        }
         return;
     }
     idx -= FBQ_FLOATS;
@@ -413,7 +448,7 @@ int howl_fb_pack(const float* fb, int M, float* fbp, hipStream_t stream) {
         const int m0 = bank == 0 ? 0 : fb_bank_lo(M), Mb = bank == 0 ? fb_bank_lo(M) : M - fb_bank_lo(M);
         float* dst = fbp + (size_t)bank * HOWL_FB_PACKED_FLOATS;
         hipLaunchKernelGGL(fb_pack_kernel, dim3((K_PAD * ncol + 255) / 256), dim3(256), 0, stream, fb, M, dst, ncol, m0, Mb);
-        hipLaunchKernelGGL(fb_fragments_kernel, dim3(1), dim3(1024), 0, stream, dst);
+        hipLaunchKernelGGL(fb_fragments_kernel, dim3(1), dim3(1024), 0, stream, dst, M == WIDE_MELS ? 1 + bank : 0);
     }
     HOWL_CHECK_LAUNCH("howl_fb_pack");
     return HOWL_OK;
@@ -428,7 +463,7 @@ int howl_fb_from_points(const HowlMelPoints* pts, int M, float nyquist, float* f
     for (int bank = 0; bank < fb_banks(M); ++bank) {
         const int m0 = bank == 0 ? 0 : fb_bank_lo(M), Mb = bank == 0 ? fb_bank_lo(M) : M - fb_bank_lo(M);
         hipLaunchKernelGGL(fb_from_points_kernel, dim3((work + 255) / 256 + 1), dim3(256), 0, stream, *pts, Mb, nyquist,
-                           fbp + (size_t)bank * HOWL_FB_PACKED_FLOATS, m0);
+                           fbp + (size_t)bank * HOWL_FB_PACKED_FLOATS, m0, M == WIDE_MELS ? 1 + bank : 0);
     }
     HOWL_CHECK_LAUNCH("howl_fb_from_points");
     return HOWL_OK;
@@ -444,6 +479,14 @@ int howl_logmel_fwd(const float* pcm, int B, int L, long ld, const float* fbp, i
     if (grid > ll.n_quads) grid = ll.n_quads;
     int waves = FE_WAVES;
     if (const char* e = getenv("HOWL_LOGMEL_WAVES")) waves = atoi(e) == 12 ? 12 : 16;   // occupancy experiments
+    if (M == WIDE_MELS && getenv("HOWL_LOGMEL_TWO_LAUNCHES") == nullptr) {
+        // the stock 80 mel bins: ONE pass over the spectrum, both banks' banded contractions on the powers in registers (round 6)
+        HowlProfScope prof("logmel", stream);
+        hipLaunchKernelGGL((logmel_kernel<12, NG_BANDED, true>), dim3((unsigned)grid), dim3(12 * 64), 0, stream, ll.pcm, ll.L, ll.ld, ll.T,
+                           ll.total, fbp, M, ll.log_eps, ll.zmuv, out, ll.layout, ll.n_quads, ll.aligned, M);
+        HOWL_CHECK_LAUNCH("howl_logmel_fwd");
+        return HOWL_OK;
+    }
     for (int bank = 0; bank < fb_banks(M); ++bank) {
         // more than 48 mel bins: one pass over the spectrum per bank, each writing its own columns of `out`
         const int m0 = bank == 0 ? 0 : fb_bank_lo(M);

@@ -23,7 +23,8 @@ constexpr int FBQ_OFF = K_PAD * HOWL_FB_COLS;
 constexpr int FBQ_FLOATS = NSLOT * 64 * 4;
 constexpr int FBD_OFF = FBQ_OFF + FBQ_FLOATS;
 constexpr int FBD_FLOATS = NSLOT * NG_MAX * 64;
-constexpr int FBF_OFF = FBD_OFF + FBD_FLOATS;     // [0]: 1 when every non-zero weight is covered by the banded table
+constexpr int FBF_OFF = FBD_OFF + FBD_FLOATS;     // [0]: 1 when every non-zero weight is covered by the banded table (slot_group layout of
+                                                  // FBQ); [1]: the same for a bank of the 80-bin filterbank (wide_mask, pair-major FBQ)
 static_assert(FBF_OFF + 32 == HOWL_FB_PACKED_FLOATS, "include/howl_hip.h and the kernels disagree on the packed filterbank size");
 constexpr int C_WIN = 0, C_TW = 16 * HOWL_FE_WIN_PITCH, C_PT = 32 * HOWL_FE_WIN_PITCH;
 static_assert(C_PT + 16 * HOWL_FE_PT_PITCH == HOWL_FE_CONST_FLOATS && HOWL_FE_CONST_FLOATS % 4 == 0, "constant table layout");
@@ -46,6 +47,35 @@ __host__ __device__ constexpr int slot_group(int s, int q) {
 __host__ __device__ constexpr bool slot_has_group(int s, int g) {
     return slot_group(s, 0) == g || slot_group(s, 1) == g || slot_group(s, 2) == g || slot_group(s, 3) == g;
 }
+// The stock NUM_MELS = 80 (settings.py:32) as two banks of 40 columns, [0, 40) and [40, 80): which of a bank's ten mel groups a
+// slot's 16 bins can reach -- the same sweep (standard filterbank + VTLP warps over alpha in [0.9, 1.1] in steps of 2.5e-5, the
+// alpha > 1 re-mask quirk included: it is what puts groups 5 / 6 of the upper bank into every slot), as one bit mask per slot.
+// 16 + 62 (slot, group) pairs against 2 x 170 for all pairs.  Up to six groups per slot, so the fragments of these tables are
+// stored one (slot, group) pair after the other ([pair][64 lanes], wide_pair) instead of four groups side by side.
+constexpr int WIDE_MELS = 80, WIDE_BANK = 40;
+__host__ __device__ constexpr unsigned wide_mask(int bank, int s) {
+    constexpr unsigned short t[2][NSLOT] = {
+        {0x01f, 0x0f8, 0x3c0, 0x300, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+        {0x060, 0x060, 0x060, 0x063, 0x067, 0x07e, 0x07c, 0x078, 0x260, 0x360, 0x360, 0x1e0, 0x1e0, 0x0e0, 0x0f0, 0x070, 0x070}};
+    return t[bank][s];
+}
+__host__ __device__ constexpr bool wide_has(int bank, int s, int g) { return (wide_mask(bank, s) >> g) & 1u; }
+__host__ __device__ constexpr int popc16(unsigned v) {
+    int n = 0;
+    for (int i = 0; i < 16; ++i) n += (v >> i) & 1u;
+    return n;
+}
+// index of pair (s, g) in its bank's fragment image (pairs in slot order, groups ascending inside a slot)
+__host__ __device__ constexpr int wide_pair(int bank, int s, int g) {
+    int n = 0;
+    for (int k = 0; k < s; ++k) n += popc16(wide_mask(bank, k));
+    return n + popc16(wide_mask(bank, s) & ((1u << g) - 1u));
+}
+__host__ __device__ constexpr int wide_pairs(int bank) { return wide_pair(bank, NSLOT - 1, 16); }
+static_assert(wide_pairs(0) == 16 && wide_pairs(1) == 62, "the 80-bin banded tables");
+// which table a packed bank's banded image (FBQ) is laid out for: 0 = slot_group (banks of <= 40 columns of any other
+// filterbank), 1 / 2 = the lower / upper bank of an 80-bin filterbank (wide_mask)
+__host__ __device__ constexpr bool table_has(int table, int s, int g) { return table == 0 ? slot_has_group(s, g) : wide_has(table - 1, s, g); }
 
 // ---- packed complex arithmetic: a complex number is a register pair (re, im); every helper is ONE v_pk_* instruction whose
 // operand modifiers (op_sel: which half feeds which result half; neg_lo / neg_hi) do the swaps and sign flips.  The clean
@@ -193,7 +223,10 @@ constexpr int FE_WAVES = 12;     // measured at 512 x 1 s: 23.9 us with twelve w
 
 // NGRP = 10: filterbanks of up to 40 mel bins (banded fragments when the flag allows); 12: up to 48, all pairs.
 // (a device function since round 5: the kernel below in frontend.hip is its wrapper; `bidx` of `nblk` workgroups share the quads)
-template <int NWAVES, int NGRP>
+// WIDE (round 6): NUM_MELS = 80 in ONE pass over the spectrum -- the power values of a quad stay in registers while both banks'
+// banded contractions run (four passes of five mel groups: 78 MFMAs per quad against 2 x 170 in two launches that each repeated
+// the transform); `fbp` is then the two-bank packed buffer and M = 80.
+template <int NWAVES, int NGRP, bool WIDE = false>
 __device__ __forceinline__ void logmel_body(const float* __restrict__ pcm, int L, long ld, int T, int total_frames,
                                             const float* __restrict__ fbp, int M, float log_eps, const float* __restrict__ zmuv,
                                             float* __restrict__ out, int layout, int n_quads, int aligned, unsigned bidx, unsigned nblk,
@@ -201,7 +234,9 @@ __device__ __forceinline__ void logmel_body(const float* __restrict__ pcm, int L
     constexpr int XR = FeGeom<NWAVES>::XR, XF = FeGeom<NWAVES>::XF;
     __shared__ v2f xch[NWAVES * QUAD * XF];             // FFT transpose tiles, private per wave
     __shared__ v4f c_tab[HOWL_FE_CONST_FLOATS / 4];     // window | W_256 | W_512 rows (read-only after the prologue)
-    __shared__ v4f c_frag[NSLOT * 64];                  // banded filterbank fragments
+    constexpr int NPAIR_W = 16 + 62;                     // wide_pairs(0) + wide_pairs(1)
+    __shared__ v4f c_frag[WIDE ? NPAIR_W * 16 : NSLOT * 64];   // banded filterbank fragments ([slot][lane][4] | WIDE: [pair][lane])
+    static_assert(!WIDE || NGRP == NG_BANDED, "the two-bank form runs its banks as passes of five groups");
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -258,10 +293,18 @@ __device__ __forceinline__ void logmel_body(const float* __restrict__ pcm, int L
     {
         const v4f* src = reinterpret_cast<const v4f*>(HOWL_FE_CONST);
         for (int i = tid; i < HOWL_FE_CONST_FLOATS / 4; i += NWAVES * 64) c_tab[i] = src[i];
-        const v4f* fq = reinterpret_cast<const v4f*>(fbp + FBQ_OFF);
-        for (int i = tid; i < NSLOT * 64; i += NWAVES * 64) c_frag[i] = fq[i];
+        if constexpr (WIDE) {      // bank 0's 16 pairs, then bank 1's 62
+            const v4f* f0 = reinterpret_cast<const v4f*>(fbp + FBQ_OFF);
+            const v4f* f1 = reinterpret_cast<const v4f*>(fbp + HOWL_FB_PACKED_FLOATS + FBQ_OFF);
+            for (int i = tid; i < NPAIR_W * 16; i += NWAVES * 64) c_frag[i] = i < 16 * 16 ? f0[i] : f1[i - 16 * 16];
+        } else {
+            const v4f* fq = reinterpret_cast<const v4f*>(fbp + FBQ_OFF);
+            for (int i = tid; i < NSLOT * 64; i += NWAVES * 64) c_frag[i] = fq[i];
+        }
     }
-    const bool banded = NGRP == NG_BANDED && reinterpret_cast<const int*>(fbp + FBF_OFF)[0] != 0;   // wave-uniform
+    const bool banded = WIDE ? (reinterpret_cast<const int*>(fbp + FBF_OFF)[1] != 0 &&
+                                reinterpret_cast<const int*>(fbp + HOWL_FB_PACKED_FLOATS + FBF_OFF)[1] != 0)
+                             : (NGRP == NG_BANDED && reinterpret_cast<const int*>(fbp + FBF_OFF)[0] != 0);   // wave-uniform
     float zm_mean = 0.0f, zm_rstd = 1.0f;
     if (zmuv != nullptr) {
         zm_mean = zmuv[0];
@@ -379,12 +422,23 @@ __device__ __forceinline__ void logmel_body(const float* __restrict__ pcm, int L
             o_base = (long)b * Mo * T + t;
             o_ms = T;
         }
-        auto mel_pass = [&](auto g0c) {
+        auto mel_pass = [&](auto g0c, auto bankc) {
             constexpr int G0 = decltype(g0c)::value;
+            constexpr int BK = decltype(bankc)::value;         // WIDE: which bank of the 80-bin filterbank this pass contracts
+            const int Mb = WIDE ? WIDE_BANK : M;
             f32x4 acc[NH];
 #pragma unroll
             for (int g = 0; g < NH; ++g) acc[g] = {0.0f, 0.0f, 0.0f, 0.0f};
-            if (banded) {
+            if (WIDE && banded) {
+                const float* fw = reinterpret_cast<const float*>(c_frag) + (BK == 0 ? 0 : 16 * 64);
+#pragma unroll
+                for (int s = 0; s < NSLOT; ++s) {
+#pragma unroll
+                    for (int g = G0; g < G0 + NH; ++g)
+                        if (wide_has(BK, s, g))                    // compile-time after unrolling
+                            acc[g - G0] = __builtin_amdgcn_mfma_f32_4x4x1f32(P[s], fw[wide_pair(BK, s, g) * 64 + frow], acc[g - G0], 0, 0, 0);
+                }
+            } else if (banded) {
 #pragma unroll
                 for (int s = 0; s < NSLOT; ++s) {
                     constexpr int lo = G0, hi = G0 + NH;
@@ -403,7 +457,7 @@ __device__ __forceinline__ void logmel_body(const float* __restrict__ pcm, int L
                 // the rare path (a matrix the banded table does not cover, or more than 40 mel bins): every (slot, group) pair,
                 // fragments from global memory at a uniform base + lane
                 const unsigned ulane = (unsigned)frow;
-                const float* fdense = fbp + FBD_OFF;
+                const float* fdense = fbp + (BK == 0 ? 0 : HOWL_FB_PACKED_FLOATS) + FBD_OFF;
                 HOWL_OPAQUE_S(fdense);
 #pragma unroll
                 for (int s = 0; s < NSLOT; ++s) {
@@ -431,16 +485,20 @@ __device__ __forceinline__ void logmel_body(const float* __restrict__ pcm, int L
             for (int h = 0; h < NE; ++h) {
                 const int w = (bit2 ? NE : 0) + h, u = (bit3 ? ND : 0) + w;      // position at the two DPP levels
                 const int m = 4 * (G0 + u) + c_out;
-                if (w < ND && u < NH && m < M && g_frame < total_frames) {
+                if (w < ND && u < NH && m < Mb && g_frame < total_frames) {
                     float y = __builtin_amdgcn_logf(vd[h] + log_eps) * 0.69314718055994530942f;
                     y = (y - zm_mean) * zm_rstd;
-                    out[o_base + (long)m * o_ms] = y;
+                    out[o_base + (long)(m + WIDE_BANK * BK) * o_ms] = y;
                 }
             }
         };
-        mel_pass(std::integral_constant<int, 0>{});
+        mel_pass(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
         HOWL_FE_PROBE(wave, lane, pslot++);   // contracted (first half)
-        mel_pass(std::integral_constant<int, NH>{});
+        mel_pass(std::integral_constant<int, NH>{}, std::integral_constant<int, 0>{});
+        if constexpr (WIDE) {
+            mel_pass(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+            mel_pass(std::integral_constant<int, NH>{}, std::integral_constant<int, 1>{});
+        }
         HOWL_FE_PROBE(wave, lane, pslot++);   // stored
         if (has_next) apply_window(xn);
         b0 = bn;

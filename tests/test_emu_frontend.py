@@ -110,6 +110,56 @@ def test_more_than_48_mel_bins_run_as_two_banks(lib, M):
     assert np.array_equal(out_t, out.transpose(0, 2, 1))
 
 
+def test_80_mel_bins_in_one_pass_over_the_spectrum(lib, monkeypatch):
+    """Round 6: the stock NUM_MELS = 80 no longer runs the transform twice and every (slot, group) pair per bank -- one launch keeps
+    a quad's power values in registers and contracts them with both banks' banded fragment tables (16 + 62 pairs, swept over the
+    VTLP warps like the 40-bin table; csrc/howl_logmel.hip.h wide_mask).  Same products in the same order as the two-launch
+    all-pairs form (the pairs left out are exact zeros): bit-identical log-mels for the standard and for VTLP-warped filterbanks,
+    in both layouts; the packed buffer says which table its banded image is laid out for (flag word [1]); a matrix the tables do
+    not cover takes the all-pairs path inside the same launch."""
+    import math
+    M = 80
+    rng = np.random.default_rng(80)
+    audio = (0.1 * rng.standard_normal((3, 2377))).astype(np.float32)
+    zm = np.array([-2.0, 1.5], np.float32)
+    flags = lambda fbp, bank: fbp[bank * FB_PACKED_FLOATS:(bank + 1) * FB_PACKED_FLOATS][-32:].view(np.int32)[:2].tolist()
+    cases = []
+    fb = fe.mel_fb(M).numpy()
+    cases.append(("standard", pack_fb(lib, fb), fe.mel_fb(M), True))
+    for alpha in (0.9, 1.0999):
+        m_pts = torch.linspace(0.0, 2595.0 * math.log10(1.0 + 8000.0 / 700.0), M + 2)
+        f_pts = 700.0 * (10 ** (m_pts / 2595.0) - 1.0)
+        thr = 4800 * min(alpha, 1) / alpha
+        f_pts[f_pts <= thr] *= alpha
+        f = f_pts[f_pts > thr]
+        f_pts[f_pts > thr] = 8000 - ((8000 - 4800 * min(alpha, 1)) / (8000 - thr)) * (8000 - f)
+        pts = HowlMelPoints()
+        for i, v in enumerate(f_pts.tolist()):
+            pts.f[i] = v
+        out = np.zeros(fb_packed_floats(M), np.float32)
+        lib.call("howl_fb_from_points", pts, M, 8000.0, ptr(out), None)
+        cases.append((f"vtlp {alpha}", out, fe.mel_fb(M, alpha=alpha), True))
+    dense = fb.copy()
+    dense[200, 3] = 0.25                      # a weight far outside the triangles: not covered by the tables
+    cases.append(("uncovered", pack_fb(lib, dense), torch.from_numpy(dense), False))
+    for name, fbp, ref_fb, covered in cases:
+        assert flags(fbp, 0)[0] == 0 and flags(fbp, 1)[0] == 0, name        # FBQ is not in the 40-bin table's layout
+        assert (flags(fbp, 0)[1] == 1 and flags(fbp, 1)[1] == 1) == covered, (name, flags(fbp, 0), flags(fbp, 1))
+        monkeypatch.delenv("HOWL_LOGMEL_TWO_LAUNCHES", raising=False)
+        one = logmel(lib, audio, fbp, M=M, zmuv=zm)
+        one_t = logmel(lib, audio, fbp, M=M, zmuv=zm, layout=1)
+        monkeypatch.setenv("HOWL_LOGMEL_TWO_LAUNCHES", "1")
+        two = logmel(lib, audio, fbp, M=M, zmuv=zm)
+        monkeypatch.delenv("HOWL_LOGMEL_TWO_LAUNCHES", raising=False)
+        assert np.array_equal(one, two), name
+        assert np.array_equal(one_t, one.transpose(0, 2, 1)), name
+        ref = (fe.standard_audio_transform(torch.from_numpy(audio), ref_fb, mels_only=True).numpy() + 2.0) / 1.5
+        np.testing.assert_allclose(one, ref, rtol=0, atol=1e-4, err_msg=name)
+    # a 40-bin filterbank still announces the 40-bin table
+    fbp40 = pack_fb(lib, fe.mel_fb(40).numpy())
+    assert fbp40[-32:].view(np.int32)[:2].tolist() == [1, 0]
+
+
 def test_logmel_zmuv_and_ragged_tail(lib):
     rng = np.random.default_rng(0)
     audio = (0.1 * rng.standard_normal((3, 1000))).astype(np.float32)   # T = 6 -> 18 frames, chunk of 16 + 2

@@ -203,8 +203,8 @@ def test_overlapping_strided_rows(std, stride):
 
 
 def test_frontend_at_80_mel_bins(monkeypatch, golden):
-    """NUM_MELS = 80 (stock Howl, settings.py:32): the mel contraction covers 48 bins per pass, so the filterbank is two banks of
-    40 and the kernel passes over the spectrum once per bank.  Eval and VTLP train mode through the module against the oracle
+    """NUM_MELS = 80 (stock Howl, settings.py:32): the filterbank is packed as two banks of 40 columns; since round 6 ONE launch
+    contracts a quad's power spectrum with both (banded tables per bank).  Eval and VTLP train mode through the module against the oracle
     at full size, plus the golden clips (torchaudio's definition restated in the oracle, pinned at 40 bins by G1 / G2)."""
     from howl_amd.data.transform.operator import ZmuvTransform
     from howl_amd.data.transform.transform import StandardAudioTransform
@@ -236,3 +236,20 @@ def test_frontend_at_80_mel_bins(monkeypatch, golden):
     gate = random.random()
     alpha = random.random() * 0.2 + 0.9 if gate < 0.75 else None
     logmel_close(out, ofe.standard_audio_transform(audio, ofe.mel_fb(80, alpha=alpha), mels_only=True))
+    # round 6: one pass over the spectrum with both banks' banded tables == the two-launch all-pairs form, bit for bit (the pairs
+    # the tables leave out are exact zeros); eval filterbank at full size and 40 VTLP draws on the golden clips
+    std.eval()
+    one = std.log_mel_for_model(pcm.to(DEV), zmuv).clone()
+    monkeypatch.setenv("HOWL_LOGMEL_TWO_LAUNCHES", "1")
+    two = std.log_mel_for_model(pcm.to(DEV), zmuv).clone()
+    monkeypatch.delenv("HOWL_LOGMEL_TWO_LAUNCHES")
+    assert torch.equal(one, two)
+    std.train()
+    for seed in range(40):
+        random.seed(seed)
+        a = std(audio.to(DEV), mels_only=True).clone()
+        monkeypatch.setenv("HOWL_LOGMEL_TWO_LAUNCHES", "1")
+        random.seed(seed)
+        b = std(audio.to(DEV), mels_only=True).clone()
+        monkeypatch.delenv("HOWL_LOGMEL_TWO_LAUNCHES")
+        assert torch.equal(a, b), seed

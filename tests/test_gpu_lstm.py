@@ -245,18 +245,24 @@ def test_seq_lstm_whole_clip_ctc_step_vs_oracle(B, rows, monkeypatch):
     fb = ofe.mel_fb(40)
     z = ofe.Zmuv()
     z.update(ofe.standard_audio_transform(pcm[:4], fb))
-    sd = {k: v.clone().requires_grad_(True) for k, v in om.lstm_init(C).items()}
-    ref, _ = om.seq_lstm_forward(sd, z(ofe.standard_audio_transform(pcm, fb)), flen)
-    ref_loss = torch.nn.CTCLoss(4)(torch.log_softmax(ref, -1), targets, flen, tl)
-    ref_loss.backward()
+    x_ref = z(ofe.standard_audio_transform(pcm, fb))
+    # BPTT over up to 318 steps x B sequences behind a log-space CTC recursion whose alpha + beta reach -700: fp32 rounding alone
+    # moves these gradients at the 1e-4 level (the fp32 oracle sits 7e-6 (W_ih) .. 8e-5 (dnn.0.bias) .. 1e-3 (dnn.2.bias, |g| <= 24)
+    # from its own fp64 run on the B = 64 batch).  So the yardstick is the oracle itself: the fp64 oracle is the truth, the fp32
+    # oracle's distance from it the noise scale, and the kernels must sit within a small multiple of that scale.
+    refs = {}
+    for dt in (torch.float32, torch.float64):
+        sd = {k: v.clone().to(dt).requires_grad_(True) for k, v in om.lstm_init(C).items()}
+        ref, _ = om.seq_lstm_forward(sd, x_ref.to(dt), flen)
+        ref_loss = torch.nn.CTCLoss(4)(torch.log_softmax(ref, -1), targets, flen, tl)
+        ref_loss.backward()
+        refs[dt] = (ref.detach(), ref_loss.detach(), {k: v.grad for k, v in sd.items()})
+    ref, ref_loss, g64 = refs[torch.float64]
     assert tr.last_logits.shape == ref.shape and maxerr(tr.last_logits, ref) < 1e-3
     assert abs(loss.item() - ref_loss.item()) < 1e-4 * max(1.0, ref_loss.item())
-    # BPTT over up to 318 steps x 64 sequences in fp32: the fp32 oracle itself sits 7e-6 (W_ih) .. 2.8e-5 (dnn.0.weight, |g| <=
-    # 0.08) .. 1e-3 (dnn.2.bias, |g| <= 24) from its own fp64 run on this batch; the kernels measured 1.3e-4 on dnn.0.weight with
-    # the 16-sequence recurrence (hardware exp2 / rcp in the gates) and < 1e-4 with the four-sequence one
     for n, gg in zip(om.lstm_param_names(), grads):
-        r = sd[n].grad
-        assert maxerr(gg, r) < 2e-4 * max(1.0, r.abs().max().item()), n
+        noise = maxerr(refs[torch.float32][2][n], g64[n])
+        assert maxerr(gg, g64[n]) < 4.0 * noise + 2e-5 * max(1.0, g64[n].abs().max().item()), (n, maxerr(gg, g64[n]), noise)
     # bit-repeatable, and a second step moves the loss
     model2 = make("seq-lstm", C).train()
     tr2 = FusedTrainer(model2, std, zmuv, lr=1e-3, weight_decay=1e-5)
