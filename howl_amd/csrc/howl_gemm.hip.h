@@ -524,7 +524,32 @@ struct SlabAdamW {
     HowlAdamWCoef c;
     int on;
 };
-__global__ __launch_bounds__(256) void sum_slabs_multi_kernel(SlabJobs jobs, SlabAdamW opt) {
+// Optional rider of the fold launch (round 6): the batch mean of a CTC loss, loss = mean_b nll_b / max(L_b, 1) (CTCLoss reduction
+// "mean", ctc_mean_kernel's summation order over 256 threads) -- one more block row instead of a launch of its own.
+struct SlabMean {
+    const float* nll;
+    const long long* target_lengths;
+    int B;
+    float* loss;
+};
+__device__ __forceinline__ void ctc_mean_256(const float* __restrict__ nll, const long long* __restrict__ target_lengths, int B,
+                                             float* __restrict__ loss) {
+    __shared__ double mred[4];
+    double acc = 0.0;
+    for (int b = threadIdx.x; b < B && threadIdx.x < 256; b += 256) {      // (threads past 256 of a wider block: idle)
+        const long long L = target_lengths[b];
+        acc += (double)(nll[b] / (float)(L > 0 ? L : 1));
+    }
+    acc = wave_sum_d(acc);
+    if ((threadIdx.x & 63) == 0 && threadIdx.x < 256) mred[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) loss[0] = (float)((((mred[0] + mred[1]) + mred[2]) + mred[3]) / (double)B);
+}
+__global__ __launch_bounds__(256) void sum_slabs_multi_kernel(SlabJobs jobs, SlabAdamW opt, SlabMean mean, int njobs) {
+    if ((int)blockIdx.y == njobs) {      // the rider's block row
+        if (blockIdx.x == 0) ctc_mean_256(mean.nll, mean.target_lengths, mean.B, mean.loss);
+        return;
+    }
     __shared__ float red[4][64];
     const SlabJob& jb = jobs.j[blockIdx.y];
     const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
@@ -566,6 +591,7 @@ struct SlabSums {
     int count = 0;
     long max_n = 0;
     bool overflow = false;     // a caller queued more than MAX_SLAB_JOBS folds without a flush: reported by flush()
+    SlabMean mean{nullptr, nullptr, 0, nullptr};      // optional rider of the next flush (ctc_mean_256)
     void add(const float* part, int nparts, long n, float* out, float* out2 = nullptr) { add_strided(part, nparts, n, n, out, out2); }
     // slabs that sit `stride` floats apart (several partial results interleaved per producer block)
     void add_strided(const float* part, int nparts, long stride, long n, float* out, float* out2 = nullptr) {
@@ -599,11 +625,13 @@ struct SlabSums {
             count = 0;
             return false;
         }
-        if (count == 0) return true;
-        hipLaunchKernelGGL(sum_slabs_multi_kernel, dim3((unsigned)((max_n + 63) / 64), count), dim3(256), 0, s, jobs,
-                           opt != nullptr ? *opt : SlabAdamW{nullptr, nullptr, nullptr, nullptr, HowlAdamWCoef{}, 0});
+        if (count == 0 && mean.nll == nullptr) return true;
+        const int rider = mean.nll != nullptr ? 1 : 0;
+        hipLaunchKernelGGL(sum_slabs_multi_kernel, dim3((unsigned)std::max<long>((max_n + 63) / 64, 1), count + rider), dim3(256), 0, s, jobs,
+                           opt != nullptr ? *opt : SlabAdamW{nullptr, nullptr, nullptr, nullptr, HowlAdamWCoef{}, 0}, mean, count);
         count = 0;
         max_n = 0;
+        mean = SlabMean{nullptr, nullptr, 0, nullptr};
         return true;
     }
 };

@@ -21,6 +21,7 @@
 #include "../../include/howl_hip.h"
 #include "howl_gemm.hip.h"
 #include "howl_logmel.hip.h"
+#include "howl_ctc.hip.h"
 
 namespace {
 
@@ -754,16 +755,7 @@ __global__ __launch_bounds__(256) void head_out_kernel(const float* __restrict__
 // loss = mean_b nll_b / max(L_b, 1) (CTCLoss reduction "mean"), in ctc_mean_kernel's summation order (256 threads)
 __device__ __forceinline__ void ctc_mean_block(const float* __restrict__ nll, const long long* __restrict__ target_lengths, int B,
                                                float* __restrict__ loss) {
-    __shared__ double mred[4];
-    double acc = 0.0;
-    for (int b = threadIdx.x; b < B && threadIdx.x < 256; b += 256) {      // (threads past 256 of a wider block: idle)
-        const long long L = target_lengths[b];
-        acc += (double)(nll[b] / (float)(L > 0 ? L : 1));
-    }
-    acc = wave_sum_d(acc);
-    if ((threadIdx.x & 63) == 0 && threadIdx.x < 256) mred[threadIdx.x >> 6] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) loss[0] = (float)((((mred[0] + mred[1]) + mred[2]) + mred[3]) / (double)B);
+    ctc_mean_256(nll, target_lengths, B, loss);      // (howl_gemm.hip.h: shared with the slab fold's rider)
 }
 __global__ __launch_bounds__(256) void ctc_mean_only_kernel(HowlCtcMean m) { ctc_mean_block(m.nll, m.target_lengths, m.B, m.loss); }
 
@@ -1053,11 +1045,302 @@ __global__ __launch_bounds__(HB_THREADS) void head_bwd_rows_kernel(const float* 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Round 6: head forward + log_softmax / CTC + head backward of the sequence model in ONE launch.  Between
+// the two recurrences of a seq-lstm training step sat rowgemm_kernel (y1 = relu(H W1^T + b1), logits) -> ctc_kernel ->
+// head_bwd_rows_kernel (dz1, dW2 / db partials, dH = dz1 W1): three launches touching rows that are independent per utterance,
+// and two trips of the (rows, 256) hidden activations through HBM (20 MB each way at 512 x 38).  Here a workgroup owns a GROUP
+// of U (1 or 2) whole utterances: its U T rows run through the first layer in 16-row tiles on rowgemm_kernel's schedule with
+// the results kept in LDS (y1 never leaves the chip), the thin output layer rides as before, then waves 0 .. U-1 run the
+// utterances' CTC recursions (howl_ctc.hip.h, row pitch 17: <= 8 classes, <= 8 labels) on the logits in LDS while the other
+// waves fetch the second set of W1 fragments, then head_bwd_rows_kernel's tile pipeline runs with its input MADE from LDS.
+// Every product and sum of a row is taken in the order of the three kernels it replaces: logits, nll, dlogits, dz1 and dH are
+// bit-identical to theirs; the per-workgroup slabs of dW2 / db1 / db2 cover different rows (sums in another order).
+// Needs the rows of a group in LDS: 16 ceil(U T / 16) x 260 floats, i.e. windows up to ~0.6 s at U = 2 and ~1.2 s at U = 1
+// (BASELINE config 4: 0.5 s); longer batches (whole clips) keep the three launches.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int SH_THREADS = 512, SH_LDY = HB_HID + 4, SH_LDI = HB_IN + 4, SH_RPC = 17, SH_LG = 8;
+struct SeqHeadArgs {
+    const float* h;            // hidden rows: row (b, t) at h + b * h_souter + t * h_sinner
+    long h_souter, h_sinner;
+    const float *w1, *b1, *w2, *b2;
+    float* y2;                 // (B, T, NO) logits
+    const long long* targets;
+    long tgt_stride;
+    const long long* in_len;
+    const long long* tgt_len;
+    int blank;
+    float* nll;                // (B)
+    float* dz1;                // (B T, 256)
+    float* dx;                 // (B T, 128)
+    float* part;               // [workgroup][(NO + 1) 256 + NO]
+    int B, T, U, ngroups;
+};
+__host__ __device__ inline int seq_head_rt(int U, int T) { return 16 * ((U * T + 15) / 16); }
+__host__ __device__ inline size_t seq_head_lds_floats(int U, int T, int n_out) {
+    const size_t r0a = (size_t)seq_head_rt(U, T) * SH_LDY, r0b = (size_t)(4 * n_out + 4) * SH_THREADS;
+    return (r0a > r0b ? r0a : r0b) + 2 * 16 * SH_LDY + 2 * 8 * 16 * 8 + 2 * (size_t)seq_head_rt(U, T) * SH_LG +
+           (size_t)U * (4 * (size_t)T * SH_RPC + 64);
+}
+
+template <int NO>
+__global__ __launch_bounds__(SH_THREADS) void seq_head_ctc_kernel(SeqHeadArgs a) {
+    HIP_DYNAMIC_SHARED(float, lds)
+    constexpr int NV = NO * 4 + 4, KG = HB_IN / 16, NT = 2;
+    const int T = a.T, U = a.U, RT = seq_head_rt(U, T);
+    const size_t r0a = (size_t)RT * SH_LDY, r0b = (size_t)NV * SH_THREADS;
+    float* y1s = lds;                                        // [RT][260]; at the very end: the partial sums' meeting place
+    float* tiles = lds + (r0a > r0b ? r0a : r0b);            // backward: dz1 tiles [2][16][260]; forward: input tiles [2][16][132]
+    float* red2 = tiles + 2 * 16 * SH_LDY;                   // [2][8][16][8]
+    float* lg = red2 + 2 * 8 * 16 * 8;                       // [RT][8] logits
+    float* dlg = lg + (size_t)RT * SH_LG;                    // [RT][8] d loss / d logits
+    float* ctcb = dlg + (size_t)RT * SH_LG;                  // U x (4 T 17 + 64)
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int mi = lane & 15, kq = lane >> 4;
+    const int nbase = wave * 16 * NT;
+    // backward partial sums: this thread's rows of every tile of every group of the workgroup
+    float4 aw[NO];
+    float ad[NO];
+    float4 ab = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int n = 0; n < NO; ++n) {
+        aw[n] = make_float4(0.f, 0.f, 0.f, 0.f);
+        ad[n] = 0.0f;
+    }
+    for (int i = tid; i < 2 * 16 * SH_LDY; i += SH_THREADS) tiles[i] = 0.0f;
+    const int prow = tid >> 5, pcol = 4 * (tid & 31);        // the 16-byte piece of an input tile this thread moves
+    for (int grp = blockIdx.x; grp < a.ngroups; grp += gridDim.x) {
+        const int R0 = grp * U * T;
+        const int nrows = min(U * T, a.B * T - R0);
+        const int NTL = (nrows + 15) >> 4;
+        const float* w1p = a.w1;
+        HOWL_OPAQUE_S(w1p);       // (the fragments of a phase are loaded in that phase: 2 x 64 registers would not fit next to it)
+        // ---- forward: y1 = relu(H W1^T + b1) -> LDS, logits = y1 W2^T + b2 -> LDS + HBM (rowgemm_kernel<8, 2, true, NO>) --------
+        {
+            float wv[NT][KG][4];
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+#pragma unroll
+                for (int j = 0; j < KG; ++j) {
+                    const float4 t4 = *reinterpret_cast<const float4*>(w1p + (long)(nbase + 16 * i + mi) * HB_IN + 16 * j + 4 * kq);
+                    wv[i][j][0] = t4.x, wv[i][j][1] = t4.y, wv[i][j][2] = t4.z, wv[i][j][3] = t4.w;
+                }
+            float4 bv[NT], w2v[NT];
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                bv[i] = *reinterpret_cast<const float4*>(a.b1 + nbase + 16 * i + 4 * kq);
+                const float4 t4 = *reinterpret_cast<const float4*>(a.w2 + (long)min(mi, NO - 1) * HB_HID + nbase + 16 * i + 4 * kq);
+                w2v[i] = mi < NO ? t4 : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            auto fetch = [&](int k) -> float4 {
+                const int r = R0 + min(16 * k + prow, nrows - 1);
+                const int b = r / T;
+                return *reinterpret_cast<const float4*>(a.h + (long)b * a.h_souter + (long)(r - b * T) * a.h_sinner + pcol);
+            };
+            auto stage = [&](const float4& v, int buf) { *reinterpret_cast<float4*>(&tiles[buf * (16 * SH_LDI + 4) + prow * SH_LDI + pcol]) = v; };
+            float4 p0 = fetch(0);
+            __syncthreads();          // the previous group's backward is past the tiles
+            stage(p0, 0);
+            __syncthreads();
+            for (int k = 0; k < NTL; ++k) {
+                const int cur = k & 1;
+                if (k + 1 < NTL) p0 = fetch(k + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                f32x4 acc[NT][2];
+#pragma unroll
+                for (int i = 0; i < NT; ++i) {
+                    acc[i][0] = {0.0f, 0.0f, 0.0f, 0.0f};
+                    acc[i][1] = {0.0f, 0.0f, 0.0f, 0.0f};
+                }
+                const float* arow = &tiles[cur * (16 * SH_LDI + 4) + mi * SH_LDI + 4 * kq];
+#pragma unroll
+                for (int j = 0; j < KG; ++j) {
+                    const float4 av4 = *reinterpret_cast<const float4*>(arow + 16 * j);
+                    const float av[4] = {av4.x, av4.y, av4.z, av4.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int i = 0; i < NT; ++i)
+                            acc[i][j & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[i][j][e], av[e], acc[i][j & 1], 0, 0, 0);
+                }
+                float4 ov[NT];
+#pragma unroll
+                for (int i = 0; i < NT; ++i) {
+                    float4 v = make_float4(acc[i][0][0] + acc[i][1][0] + bv[i].x, acc[i][0][1] + acc[i][1][1] + bv[i].y,
+                                           acc[i][0][2] + acc[i][1][2] + bv[i].z, acc[i][0][3] + acc[i][1][3] + bv[i].w);
+                    ov[i] = make_float4(fmaxf(v.x, 0.0f), fmaxf(v.y, 0.0f), fmaxf(v.z, 0.0f), fmaxf(v.w, 0.0f));
+                }
+                f32x4 y = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                for (int i = 0; i < NT; ++i) {
+                    y = __builtin_amdgcn_mfma_f32_16x16x4f32(w2v[i].x, ov[i].x, y, 0, 0, 0);
+                    y = __builtin_amdgcn_mfma_f32_16x16x4f32(w2v[i].y, ov[i].y, y, 0, 0, 0);
+                    y = __builtin_amdgcn_mfma_f32_16x16x4f32(w2v[i].z, ov[i].z, y, 0, 0, 0);
+                    y = __builtin_amdgcn_mfma_f32_16x16x4f32(w2v[i].w, ov[i].w, y, 0, 0, 0);
+                }
+                if (kq < 2) *reinterpret_cast<float4*>(&red2[((cur * 8 + wave) * 16 + mi) * 8 + 4 * kq]) = make_float4(y[0], y[1], y[2], y[3]);
+                if (k + 1 < NTL) stage(p0, cur ^ 1);
+#pragma unroll
+                for (int i = 0; i < NT; ++i)
+                    *reinterpret_cast<float4*>(&y1s[(size_t)(16 * k + mi) * SH_LDY + nbase + 16 * i + 4 * kq]) = ov[i];
+                __syncthreads();      // next tile complete, this tile's partial outputs in red2
+                {
+                    const int e = tid % (16 * NO), r = e / NO, n = e - r * NO;
+                    float yy = a.b2[n];
+#pragma unroll
+                    for (int w_ = 0; w_ < 8; ++w_) yy += red2[((cur * 8 + w_) * 16 + r) * 8 + n];
+                    lg[(16 * k + r) * SH_LG + n] = yy;
+                    a.y2[(long)(R0 + min(16 * k + r, nrows - 1)) * NO + n] = yy;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- log_softmax + CTC of the group's utterances on waves 0 .. U-1 (dlogits -> LDS), W1's second set of fragments on all -----
+        if (wave < U && grp * U + wave < a.B) {
+            const int b = grp * U + wave;
+            ctc_wave<SH_RPC>(lg + (size_t)wave * T * SH_LG, SH_LG, T, a.B, NO, a.targets + (size_t)b * a.tgt_stride, (int)a.in_len[b],
+                             (int)a.tgt_len[b], a.blank, a.nll + b, dlg + (size_t)wave * T * SH_LG, SH_LG, T, nullptr,
+                             ctcb + (size_t)wave * (4 * (size_t)T * SH_RPC + 64), lane);
+        }
+        HOWL_OPAQUE_S(w1p);
+        float wvb[HB_HID / 16][4];
+#pragma unroll
+        for (int j = 0; j < HB_HID / 16; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) wvb[j][e] = w1p[(long)(16 * j + 4 * kq + e) * HB_IN + 16 * wave + mi];
+        float4 w2r[NO];
+#pragma unroll
+        for (int n = 0; n < NO; ++n) w2r[n] = *reinterpret_cast<const float4*>(a.w2 + (long)n * HB_HID + 4 * lane);
+        __syncthreads();
+        // ---- backward (head_bwd_rows_kernel): dz1 = (y1 > 0) (dlogits W2) -> HBM + tile, dH = dz1 W1, partial sums --------------------
+        {
+            auto stage = [&](int k, int buf) {
+#pragma unroll
+                for (int l = 0; l < 2; ++l) {
+                    const int r = 16 * k + wave + 8 * l;
+                    const int rc = min(r, nrows - 1);          // rows past the group's end: the last row again (stored there again)
+                    const float4 v = *reinterpret_cast<const float4*>(&y1s[(size_t)rc * SH_LDY + 4 * lane]);
+                    float d[NO];
+#pragma unroll
+                    for (int n = 0; n < NO; ++n) d[n] = dlg[rc * SH_LG + n];
+                    float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                    for (int n = 0; n < NO; ++n) {
+                        z.x = fmaf(d[n], w2r[n].x, z.x);
+                        z.y = fmaf(d[n], w2r[n].y, z.y);
+                        z.z = fmaf(d[n], w2r[n].z, z.z);
+                        z.w = fmaf(d[n], w2r[n].w, z.w);
+                    }
+                    z.x = v.x > 0.0f ? z.x : 0.0f;
+                    z.y = v.y > 0.0f ? z.y : 0.0f;
+                    z.z = v.z > 0.0f ? z.z : 0.0f;
+                    z.w = v.w > 0.0f ? z.w : 0.0f;
+                    *reinterpret_cast<float4*>(&tiles[buf * (16 * SH_LDY) + (wave + 8 * l) * SH_LDY + 4 * lane]) = z;
+                    *reinterpret_cast<float4*>(a.dz1 + (long)(R0 + rc) * HB_HID + 4 * lane) = z;
+                    if (r < nrows) {      // (wave-uniform)
+#pragma unroll
+                        for (int n = 0; n < NO; ++n) {
+                            aw[n].x = fmaf(d[n], v.x, aw[n].x);
+                            aw[n].y = fmaf(d[n], v.y, aw[n].y);
+                            aw[n].z = fmaf(d[n], v.z, aw[n].z);
+                            aw[n].w = fmaf(d[n], v.w, aw[n].w);
+                            ad[n] += d[n];
+                        }
+                        ab.x += z.x;
+                        ab.y += z.y;
+                        ab.z += z.z;
+                        ab.w += z.w;
+                    }
+                }
+            };
+            stage(0, 0);
+            __syncthreads();
+            for (int k = 0; k < NTL; ++k) {
+                const int cur = k & 1;
+                f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
+                const float* arow = &tiles[cur * (16 * SH_LDY) + mi * SH_LDY + 4 * kq];
+#pragma unroll
+                for (int j = 0; j < HB_HID / 16; j += 2) {
+                    const float4 x0 = *reinterpret_cast<const float4*>(arow + 16 * j);
+                    const float4 x1 = *reinterpret_cast<const float4*>(arow + 16 * j + 16);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wvb[j][0], x0.x, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wvb[j + 1][0], x1.x, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wvb[j][1], x0.y, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wvb[j + 1][1], x1.y, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wvb[j][2], x0.z, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wvb[j + 1][2], x1.z, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wvb[j][3], x0.w, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wvb[j + 1][3], x1.w, acc1, 0, 0, 0);
+                }
+                const float4 o = make_float4(acc0[0] + acc1[0], acc0[1] + acc1[1], acc0[2] + acc1[2], acc0[3] + acc1[3]);
+                if (k + 1 < NTL) stage(k + 1, cur ^ 1);
+                *reinterpret_cast<float4*>(a.dx + (long)(R0 + min(16 * k + mi, nrows - 1)) * HB_IN + 16 * wave + 4 * kq) = o;
+                __syncthreads();
+            }
+        }
+    }
+    // the eight waves' partial sums meet in LDS (the y1 region: every wave is past the last barrier), folded in a fixed order
+    float* red = lds;
+#pragma unroll
+    for (int n = 0; n < NO; ++n) {
+        red[(wave * NV + n * 4 + 0) * 64 + lane] = aw[n].x;
+        red[(wave * NV + n * 4 + 1) * 64 + lane] = aw[n].y;
+        red[(wave * NV + n * 4 + 2) * 64 + lane] = aw[n].z;
+        red[(wave * NV + n * 4 + 3) * 64 + lane] = aw[n].w;
+        if (lane == 0) red2[wave * NO + n] = ad[n];
+    }
+    red[(wave * NV + NO * 4 + 0) * 64 + lane] = ab.x;
+    red[(wave * NV + NO * 4 + 1) * 64 + lane] = ab.y;
+    red[(wave * NV + NO * 4 + 2) * 64 + lane] = ab.z;
+    red[(wave * NV + NO * 4 + 3) * 64 + lane] = ab.w;
+    __syncthreads();
+    float* pb = a.part + (size_t)blockIdx.x * ((size_t)(NO + 1) * HB_HID + NO);
+    for (int idx = tid; idx < NV * 64; idx += SH_THREADS) {
+        const int val = idx >> 6, ln = idx & 63;
+        float tsum = 0.0f;
+#pragma unroll
+        for (int w_ = 0; w_ < SH_THREADS / 64; ++w_) tsum += red[(w_ * NV + val) * 64 + ln];
+        pb[(size_t)(val >> 2) * HB_HID + 4 * ln + (val & 3)] = tsum;
+    }
+    if (tid < NO) {
+        float tsum = 0.0f;
+#pragma unroll
+        for (int w_ = 0; w_ < SH_THREADS / 64; ++w_) tsum += red2[w_ * NO + tid];
+        pb[(size_t)(NO + 1) * HB_HID + tid] = tsum;
+    }
+}
+
 // workspace of one Linear layer's backward on the GEMM path, in floats: split-K slabs of the weight gradient (<= 128) + 256 slabs
 // of n_out for the bias column sums
 size_t linear_ws_floats(int n_out, int n_in) { return (size_t)HEAD_W1_SPLITS * n_out * (n_in > 1 ? n_in : 1) + (size_t)256 * n_out + 64; }
 
 bool head_is_thin(int n_hid, int n_out) { return n_out >= 1 && n_out <= 8 && n_hid <= HEAD_MAX_HID && (n_hid & 3) == 0; }
+
+// How (and whether) seq_head_ctc_kernel covers a batch: U utterances per group, groups, workgroups (= slabs of partial sums)
+struct SeqHeadGeom {
+    int U, ngroups, blocks;
+    size_t lds_bytes;
+};
+bool seq_head_geometry(int B, int T, int n_in, int n_hid, int n_out, int max_target, SeqHeadGeom* g) {
+    if (n_in != HB_IN || n_hid != HB_HID || n_out < 1 || n_out > 8 || B < 1 || T < 1 || T > CTC_CHUNK) return false;
+    if (2 * max_target + 1 > SH_RPC) return false;                       // the CTC rows hold <= 17 states
+    if ((long)B * T < rowgemm_min_rows() || (long)B * T >= (1L << 20)) return false;     // few rows: the tile kernels keep more CUs busy
+    const char* e = getenv("HOWL_SEQ_HEAD_FUSED");
+    if (e != nullptr && e[0] == '0') return false;
+    constexpr size_t LDS_MAX = 160 * 1024;
+    int U = 0;
+    for (int u = 2; u >= 1; --u)
+        if (seq_head_lds_floats(u, T, n_out) * sizeof(float) <= LDS_MAX) {
+            U = u;
+            break;
+        }
+    if (U == 0) return false;
+    g->U = U;
+    g->ngroups = (B + U - 1) / U;
+    g->blocks = std::min(std::min(g->ngroups, howl_num_cus()), HEAD_BWD_BLOCKS);
+    g->lds_bytes = seq_head_lds_floats(U, T, n_out) * sizeof(float);
+    return true;
+}
 
 // Which recurrence pair runs: four sequences per workgroup (v_mfma 4x4x1_16b: 93 / 73 us per 38-step launch, one workgroup
 // per CU) while that leaves at most two rounds of workgroups, sixteen per workgroup (16x16x4: 213 / 198 us) beyond --
@@ -1291,7 +1574,7 @@ static int head_bwd_impl(const HowlHeadParams* p, const float* x, int rows_inner
     HOWL_REQUIRE(ctc_mean == nullptr || (ctc_mean->nll && ctc_mean->target_lengths && ctc_mean->loss && ctc_mean->B >= 1),
                  "howl_head_bwd: incomplete HowlCtcMean");
     const HowlCtcMean cm = ctc_mean != nullptr ? *ctc_mean : HowlCtcMean{nullptr, nullptr, 0, nullptr};
-    HOWL_REQUIRE(p && p->w1 && p->w2 && x && y1 && dy2 && dz1 && g && g->w1 && g->b1 && g->w2 && g->b2 && ws,
+    HOWL_REQUIRE(p && p->w1 && p->w2 && x && ((y1 && dy2) || (!y1 && !dy2)) && dz1 && g && g->w1 && g->b1 && g->w2 && g->b2 && ws,
                  "howl_head_bwd: null pointer");
     HOWL_REQUIRE(rows >= 1 && n_in >= 1 && n_hid >= 1 && n_out >= 1 && rows_inner >= 1, "howl_head_bwd: bad shape");
     if (ws_bytes < howl_head_workspace_bytes(n_in, n_hid, n_out)) {
@@ -1302,7 +1585,19 @@ static int head_bwd_impl(const HowlHeadParams* p, const float* x, int rows_inner
     const RowMap xm{rows_inner, s_outer, s_inner};
     auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
     bool dx_done = false;
-    if (head_is_thin(n_hid, n_out) && dx != nullptr && n_hid == HB_HID && n_in == HB_IN && rows >= rowgemm_min_rows() &&
+    if (dy2 == nullptr) {
+        // howl_seq_head_ctc ran the rows already (dz1, dx and one slab of partial sums per workgroup are in place): fold its slabs
+        SeqHeadGeom sg;
+        HOWL_REQUIRE(y1 == nullptr && rows % rows_inner == 0 && seq_head_geometry(rows / rows_inner, rows_inner, n_in, n_hid, n_out, 0, &sg),
+                     "howl_head_bwd: dy2 == NULL means the rows were run by howl_seq_head_ctc, which does not cover this shape");
+        float* thin = first + (size_t)HEAD_W1_SPLITS * n_hid * n_in;
+        if (ctc_mean != nullptr) sums.mean = SlabMean{cm.nll, cm.target_lengths, cm.B, cm.loss};     // rides in the call's fold launch
+        const long slab = (long)(n_out + 1) * n_hid + n_out;
+        sums.add_strided(thin, sg.blocks, slab, (long)n_out * n_hid, g->w2);
+        sums.add_strided(thin + (size_t)n_out * n_hid, sg.blocks, slab, n_hid, g->b1);
+        sums.add_strided(thin + (size_t)(n_out + 1) * n_hid, sg.blocks, slab, n_out, g->b2);
+        dx_done = true;
+    } else if (head_is_thin(n_hid, n_out) && dx != nullptr && n_hid == HB_HID && n_in == HB_IN && rows >= rowgemm_min_rows() &&
         rows < (1 << 20) && al16(y1) && al16(dz1) && al16(dx) && al16(p->w2) && getenv("HOWL_GEMM_NO_ROWGEMM") == nullptr) {
         // many rows: second layer's backward + ReLU mask + dx = dz1 W1 in one launch, one slab of partial sums per workgroup
         float* thin = first + (size_t)HEAD_W1_SPLITS * n_hid * n_in;
@@ -1364,6 +1659,49 @@ int howl_head_bwd(const HowlHeadParams* p, const float* x, int rows_inner, long 
     if (rc != HOWL_OK) return rc;
     if (!sums.flush(stream)) return HOWL_E_ARG;
     HOWL_CHECK_LAUNCH("howl_head_bwd");
+    return HOWL_OK;
+}
+
+int howl_seq_head_ctc_supported(int B, int T, int n_in, int n_hid, int n_out, int max_target_length) {
+    SeqHeadGeom g;
+    return seq_head_geometry(B, T, n_in, n_hid, n_out, max_target_length, &g) ? 1 : 0;
+}
+
+int howl_seq_head_ctc(const HowlHeadParams* p, const float* x, long s_outer, long s_inner, int B, int T, int n_in, int n_hid, int n_out,
+                      const long long* targets, long tgt_stride, int max_target_length, const long long* input_lengths,
+                      const long long* target_lengths, int blank, float* y2, float* nll, float* dz1, float* dhs, void* head_ws,
+                      size_t head_ws_bytes, hipStream_t stream) {
+    HOWL_REQUIRE(p && p->w1 && p->b1 && p->w2 && p->b2 && x && targets && input_lengths && target_lengths && y2 && nll && dz1 && dhs &&
+                     head_ws, "howl_seq_head_ctc: null pointer");
+    HOWL_REQUIRE(blank >= 0 && blank < n_out && max_target_length >= 0, "howl_seq_head_ctc: bad blank / target length");
+    SeqHeadGeom g;
+    HOWL_REQUIRE(seq_head_geometry(B, T, n_in, n_hid, n_out, max_target_length, &g),
+                 "howl_seq_head_ctc: B=%d T=%d (%d -> %d -> %d, targets <= %d) is outside the fused launch's range "
+                 "(howl_seq_head_ctc_supported; use howl_head_fwd + howl_ctc_loss + howl_seq_lstm_bwd)", B, T, n_in, n_hid, n_out,
+                 max_target_length);
+    auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    HOWL_REQUIRE(al16(x) && al16(p->w1) && al16(p->b1) && al16(p->w2) && al16(dz1) && al16(dhs) && (s_outer & 3) == 0 && (s_inner & 3) == 0,
+                 "howl_seq_head_ctc: 16-byte aligned operands");
+    if (head_ws_bytes < howl_head_workspace_bytes(n_in, n_hid, n_out)) {
+        howl_set_error("howl_seq_head_ctc: workspace too small");
+        return HOWL_E_WORKSPACE;
+    }
+    float* thin = static_cast<float*>(head_ws) + (size_t)HEAD_W1_SPLITS * n_hid * n_in;
+    const SeqHeadArgs a{x, s_outer, s_inner, p->w1, p->b1, p->w2, p->b2, y2, targets, tgt_stride, input_lengths, target_lengths, blank,
+                        nll, dz1, dhs, thin, B, T, g.U, g.ngroups};
+    HowlProfScope prof("gemm", stream, 4.0 * (double)B * T * n_in * n_hid);
+#define HOWL_SEQ_HEAD(NO)                                                                                                        \
+    case NO: {                                                                                                                   \
+        static thread_local size_t granted[16] = {};                                                                             \
+        howl_raise_lds(reinterpret_cast<const void*>(seq_head_ctc_kernel<NO>), g.lds_bytes, granted, "howl_seq_head_ctc");        \
+        hipLaunchKernelGGL(seq_head_ctc_kernel<NO>, dim3(g.blocks), dim3(SH_THREADS), g.lds_bytes, stream, a);                   \
+    } break;
+    switch (n_out) {
+        HOWL_SEQ_HEAD(1) HOWL_SEQ_HEAD(2) HOWL_SEQ_HEAD(3) HOWL_SEQ_HEAD(4) HOWL_SEQ_HEAD(5) HOWL_SEQ_HEAD(6) HOWL_SEQ_HEAD(7)
+        HOWL_SEQ_HEAD(8)
+    }
+#undef HOWL_SEQ_HEAD
+    HOWL_CHECK_LAUNCH("howl_seq_head_ctc");
     return HOWL_OK;
 }
 

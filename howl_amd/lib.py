@@ -126,6 +126,9 @@ SIGNATURES = {
     "howl_head_fwd": [POINTER(HowlHeadParams), P, c_int, c_long, c_long, c_int, c_int, c_int, c_int, P, P, STREAM],
     "howl_head_bwd": [POINTER(HowlHeadParams), P, c_int, c_long, c_long, c_int, c_int, c_int, c_int, P, P, P, P,
                       POINTER(HowlHeadGrads), POINTER(HowlCtcMean), P, c_size_t, STREAM],
+    "howl_seq_head_ctc": [POINTER(HowlHeadParams), P, c_long, c_long, c_int, c_int, c_int, c_int, c_int, P, c_long, c_int, P, P, c_int, P, P,
+                          P, P, P, c_size_t, STREAM],
+    "howl_seq_head_ctc_supported": [c_int, c_int, c_int, c_int, c_int, c_int],
     "howl_seq_lstm_bwd": [POINTER(HowlHeadParams), c_int, c_int, P, P, P, P, POINTER(HowlHeadGrads), POINTER(HowlCtcMean), P,
                           c_size_t, POINTER(HowlLstmParams), P, c_int, c_int, c_int, P, P, POINTER(HowlLstmSaved),
                           POINTER(HowlLstmGrads), P, c_size_t, POINTER(HowlAdamW), STREAM],

@@ -134,6 +134,30 @@ def _head_forward_raw(x, w1, b1, w2, b2):
     return y1, y2
 
 
+def _seq_head_ctc_supported(B, T, w1, w2, max_target):
+    n_hid, n_in = w1.shape
+    return bool(_lib.get().cdll.howl_seq_head_ctc_supported(int(B), int(T), n_in, n_hid, w2.shape[0], int(max_target)))
+
+
+def _seq_head_ctc_raw(hs, w1, b1, w2, b2, targets, input_lengths, target_lengths, blank, max_target):
+    """``howl_seq_head_ctc``: head forward + log_softmax / CTC + the head's backward over the rows in one launch.  hs (B, T, 128)
+    view of the hidden states -> (y2 (B, T, n_out), nll (B,), dz1, dhs, head workspace holding the partial sums)."""
+    n_hid, n_in = w1.shape
+    n_out = w2.shape[0]
+    B, T = hs.shape[:2]
+    f32 = dict(dtype=torch.float32, device=hs.device)
+    y2 = torch.empty((B, T, n_out), **f32)
+    nll = torch.empty(B, **f32)
+    dz1 = torch.empty((B, T, n_hid), **f32)
+    dhs = torch.empty((B, T, n_in), **f32)
+    head_ws = torch.empty(_lib.get().cdll.howl_head_workspace_bytes(n_in, n_hid, n_out), dtype=torch.uint8, device=hs.device)
+    prm = _lib.HowlHeadParams(_vp(w1), _vp(b1), _vp(w2), _vp(b2))
+    _lib.get().call("howl_seq_head_ctc", ctypes.byref(prm), _vp(hs), hs.stride(0), hs.stride(1), B, T, n_in, n_hid, n_out,
+                    _vp(targets), targets.stride(0), int(max_target), _vp(input_lengths), _vp(target_lengths), int(blank), _vp(y2),
+                    _vp(nll), _vp(dz1), _vp(dhs), _vp(head_ws), head_ws.numel(), ops._stream())
+    return y2, nll, dz1, dhs, head_ws
+
+
 def _head_backward_raw(x, y1, dy2, w1, b1, w2, b2, need_dx=True, grads=None, ctc_mean=None):
     """``howl_head_bwd``: dy2 (..., n_out) -> (dx or None, [dW1, db1, dW2, db2]), written into ``grads`` when given.
     ``ctc_mean`` = (nll, target_lengths, loss): the batch mean of a CTC loss taken by the same launch (``HowlCtcMean``)."""
@@ -158,21 +182,26 @@ def _head_backward_raw(x, y1, dy2, w1, b1, w2, b2, need_dx=True, grads=None, ctc
     return dx, grads
 
 
-def _seq_backward_raw(saved, y1, dy2, head_params, grads, ctc_mean=None, adamw=None):
+def _seq_backward_raw(saved, y1, dy2, head_params, grads, ctc_mean=None, adamw=None, head_rows_done=None):
     """``howl_seq_lstm_bwd``: head + LSTM backward of the sequence model in one call (t_out == T); ``grads`` = the eight flat-buffer
     views in ``hot_parameters()`` order.  ``adamw`` = (flat params, flat grads, m, v, lr, (beta1, beta2), eps, weight_decay, step,
-    grad_scale): the optimiser step is part of the call (``HowlAdamW``)."""
+    grad_scale): the optimiser step is part of the call (``HowlAdamW``).  ``head_rows_done`` = (dz1, dhs, head_ws) left by
+    ``howl_seq_head_ctc`` (then ``y1`` / ``dy2`` are None: the call folds that launch's partial sums instead of running the rows)."""
     x, lengths, c0, w_ih, w_hh, b_ih, b_hh, gates, cs, hseq, ws = saved
     w1, b1, w2, b2 = head_params
     B, T, M = x.shape
     n_hid, n_in = w1.shape
     n_out = w2.shape[0]
     f32 = dict(dtype=torch.float32, device=x.device)
-    dy2 = dy2.contiguous()
-    dz1 = torch.empty_like(y1)
-    dhs = torch.empty((B, T, HID), **f32)
     dgates = torch.empty((B, T, 4 * HID), **f32)
-    head_ws = torch.empty(_lib.get().cdll.howl_head_workspace_bytes(n_in, n_hid, n_out), dtype=torch.uint8, device=x.device)
+    if head_rows_done is not None:
+        dz1, dhs, head_ws = head_rows_done
+        y1 = dy2 = None
+    else:
+        dy2 = dy2.contiguous()
+        dz1 = torch.empty_like(y1)
+        dhs = torch.empty((B, T, HID), **f32)
+        head_ws = torch.empty(_lib.get().cdll.howl_head_workspace_bytes(n_in, n_hid, n_out), dtype=torch.uint8, device=x.device)
     hp = _lib.HowlHeadParams(_vp(w1), _vp(b1), _vp(w2), _vp(b2))
     hg = _lib.HowlHeadGrads(*[_vp(g) for g in grads[4:8]])
     cm = None
@@ -290,29 +319,45 @@ class SequentialLstm(_LstmBase, name="seq-lstm"):
 
     # --- training.fused.FusedTrainer hooks: the same launches as forward() / autograd, without the autograd graph -----
     TAKES_NEXT_LOGMEL = True      # FusedTrainer.step_sequence(next_audio=...): the next batch's frontend rides in the forward call
+    TAKES_CTC = True              # ... and _launch_forward(ctc=...): head + CTC + head backward rows as one launch where covered
 
-    def _launch_forward(self, feat, lengths, t_out=None, next_logmel=None):
+    def _launch_forward(self, feat, lengths, t_out=None, next_logmel=None, ctc=None):
         """feat (B, C>=1, M, T) -> scores (T_len, B, num_labels) view; keeps what ``_launch_backward`` needs.  ``t_out`` with
-        device-resident ``lengths``: see ``_lstm_inputs``.  ``next_logmel``: see ``_lstm_forward_raw``."""
+        device-resident ``lengths``: see ``_lstm_inputs``.  ``next_logmel``: see ``_lstm_forward_raw``.
+        ``ctc`` = (targets (B, Lmax) int64, target_lengths, blank, max_target), all on the device: where the library's fused launch
+        covers the batch (``howl_seq_head_ctc``: short windows, >= 2048 rows) the head, log_softmax + CTC and the head's backward
+        over the rows run as ONE launch behind the recurrence; ``self.ctc_nll`` is then the (B,) negative log likelihoods and
+        ``_launch_backward`` takes ``dscores=None``.  Otherwise ``self.ctc_nll`` is None and the caller runs the loss itself."""
         xb, lengths, t_out, h0, c0 = self._lstm_inputs(feat, lengths, t_out)
         ps = self.hot_parameters()
         hs, hT, cT, saved = _lstm_forward_raw(xb, lengths, t_out, h0, c0, *ps[:4], next_logmel=next_logmel)
-        y1, y2 = _head_forward_raw(hs, *ps[4:8])
-        self._seq_saved = (saved, t_out, hs, y1)
+        self.ctc_nll = None
         if self.is_streaming:                          # same carry as forward() (rnn.py:64-68)
             self.streaming_state = (hT.detach().clone().unsqueeze(0), cT.detach().clone().unsqueeze(0))
+        if (ctc is not None and lengths is not None and t_out == xb.shape[1]
+                and _seq_head_ctc_supported(xb.shape[0], t_out, ps[4], ps[6], ctc[3])):
+            targets, target_lengths, blank, max_target = ctc
+            y2, nll, dz1, dhs, head_ws = _seq_head_ctc_raw(hs, *ps[4:8], targets, lengths, target_lengths, blank, max_target)
+            self._seq_saved = (saved, t_out, hs, None, (dz1, dhs, head_ws))
+            self.ctc_nll = nll
+            return y2.permute(1, 0, 2)
+        y1, y2 = _head_forward_raw(hs, *ps[4:8])
+        self._seq_saved = (saved, t_out, hs, y1, None)
         return y2.permute(1, 0, 2)
 
     def _launch_backward(self, dscores, out_grads=None, ctc_mean=None, adamw=None):
         """dscores: d loss / d scores as a (T_len, B, num_labels) view of a (B, T_len, num_labels) buffer (ops.ctc_loss_fwd_bwd);
         ``ctc_mean`` = (nll, target_lengths, loss) when the loss launch left its batch mean to the head's backward;
         ``adamw``: see ``_seq_backward_raw`` -- ``self.optimizer_step_done`` says whether the call took it."""
-        saved, t_out, hs, y1 = self._seq_saved
+        saved, t_out, hs, y1, rows_done = self._seq_saved
         ps = self.hot_parameters()
         grads = out_grads if out_grads is not None else [torch.empty_like(p) for p in ps]
         x = saved[0]
         self.optimizer_step_done = False
-        if t_out == x.shape[1]:      # whole buffer ran: one call, the wide weight gradients and the slab folds merged (12 launches)
+        if rows_done is not None:    # howl_seq_head_ctc ran the head's rows behind the forward recurrence: fold, dW1, LSTM backward
+            _seq_backward_raw(saved, None, None, ps[4:8], grads, ctc_mean, adamw, head_rows_done=rows_done)
+            self.optimizer_step_done = adamw is not None
+        elif t_out == x.shape[1]:      # whole buffer ran: one call, the wide weight gradients and the slab folds merged (12 launches)
             _seq_backward_raw(saved, y1, dscores.permute(1, 0, 2), ps[4:8], grads, ctc_mean, adamw)
             self.optimizer_step_done = adamw is not None
         else:

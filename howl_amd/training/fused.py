@@ -161,12 +161,27 @@ class FusedTrainer:
 
     def step_sequence_on_features(self, feat, frame_lengths, targets, target_lengths, blank, max_target=None, max_frames=None,
                                   next_logmel=None):
-        if next_logmel is not None:
-            scores = self.model._launch_forward(feat, frame_lengths, max_frames, next_logmel=next_logmel)
-        else:
-            scores = self.model._launch_forward(feat, frame_lengths, max_frames)   # (T_len, B, C) view of a (B, T_len, C) buffer
         if max_target is None:
             max_target = int(target_lengths.max()) if target_lengths.numel() else 0
+        kw = {}
+        if next_logmel is not None:
+            kw["next_logmel"] = next_logmel
+        if getattr(self.model, "TAKES_CTC", False):
+            # short windows, many rows: head + log_softmax / CTC + the head's backward over the rows ride in ONE launch behind the
+            # forward recurrence (howl_seq_head_ctc); the model says through `ctc_nll` whether that launch covered the batch
+            dev = feat.device
+            tg = targets.to(dev, torch.int64)
+            kw["ctc"] = (tg if tg.stride(-1) == 1 else tg.contiguous(), target_lengths.to(dev, torch.int64).contiguous(), int(blank), max_target)
+            if not ops.on_device(frame_lengths):
+                frame_lengths = frame_lengths.to(torch.int64)
+        scores = self.model._launch_forward(feat, frame_lengths, max_frames, **kw)   # (T_len, B, C) view of a (B, T_len, C) buffer
+        if getattr(self.model, "ctc_nll", None) is not None:
+            loss = torch.empty((), dtype=torch.float32, device=scores.device)
+            adamw = None
+            if self.world == 1:
+                adamw = (self.fp.flat, self.fp.grad, self.m, self.v, self.lr, self.betas, self.eps, self.weight_decay, self.step_count + 1, 1.0)
+            self.model._launch_backward(None, out_grads=self.fp.grad_views, ctc_mean=(self.model.ctc_nll, kw["ctc"][1], loss), adamw=adamw)
+            return self._finish_sequence_step(scores, loss)
         # log-softmax + CTC + their backward as one launch at any clip length (128-frame windows beyond 128 frames); the batch
         # mean of the loss rides in the head's backward launch (HowlCtcMean).  Outside the kernel's range (C > 64, a target
         # of more than 31 labels, T > 8192): HowlHipError from the library -- no vendor kernels on the training path
@@ -179,6 +194,9 @@ class FusedTrainer:
         if self.world == 1:
             adamw = (self.fp.flat, self.fp.grad, self.m, self.v, self.lr, self.betas, self.eps, self.weight_decay, self.step_count + 1, 1.0)
         self.model._launch_backward(dscores, out_grads=self.fp.grad_views, ctc_mean=ctc_mean, adamw=adamw)
+        return self._finish_sequence_step(scores, loss)
+
+    def _finish_sequence_step(self, scores, loss):
         if self.skip_allreduce:
             scale, self.collectives_last_step = 1.0 / self.world, 0
         else:

@@ -381,6 +381,19 @@ int howl_head_bwd(const HowlHeadParams* p, const float* x, int rows_inner, long 
  * (12 launches per seq-lstm training step instead of 15).  Requires saved->t_out == T; head_ws / ws as for the two calls.
  * adamw != NULL: the optimiser step on the flat buffers is part of the call (inside the fold when every gradient pointer lies in
  * adamw->g and together they cover it; as howl_adamw_step's launch behind it otherwise). */
+/* Round 6: head forward + log_softmax / CTC + the head's backward over the rows, of the sequence model's training step, in ONE
+ * launch -- dnn(rnn_seq) (rnn.py:71), log_softmax + CTCLoss(blank) and their backward (train.py:250-256,291-296) for batches whose
+ * utterances fit on chip (howl_seq_head_ctc_supported: 128 -> 256 -> <= 8 labels, T <= ~80 frames, targets <= 8 labels, >= 2048
+ * rows): a workgroup owns whole utterances, the hidden activations never leave LDS.  x: hidden rows, row (b, t) at
+ * x + b * s_outer + t * s_inner; y2 (B, T, n_out) logits; nll (B); dz1 (B T, n_hid) and dhs (B, T, n_in) as howl_head_bwd leaves
+ * them; the per-workgroup partial sums of dW2 / db1 / db2 stay in head_ws (howl_head_workspace_bytes) for howl_seq_lstm_bwd /
+ * howl_head_bwd called with y1 = dy2 = NULL, which folds them, takes the first layer's weight gradient and (HowlCtcMean) the
+ * batch mean of nll.  Same bits as howl_head_fwd + howl_ctc_loss + howl_head_bwd for y2, nll, dz1, dhs. */
+int howl_seq_head_ctc_supported(int B, int T, int n_in, int n_hid, int n_out, int max_target_length);
+int howl_seq_head_ctc(const HowlHeadParams* p, const float* x, long s_outer, long s_inner, int B, int T, int n_in, int n_hid, int n_out,
+                      const long long* targets, long tgt_stride, int max_target_length, const long long* input_lengths,
+                      const long long* target_lengths, int blank, float* y2, float* nll, float* dz1, float* dhs, void* head_ws,
+                      size_t head_ws_bytes, hipStream_t stream);
 int howl_seq_lstm_bwd(const HowlHeadParams* head, int n_hid, int n_out, const float* y1, const float* dy2, float* dz1, float* dhs,
                       const HowlHeadGrads* head_grads, const HowlCtcMean* ctc_mean /* NULL: none */, void* head_ws,
                       size_t head_ws_bytes, const HowlLstmParams* p, const float* x, int B, int T, int M,

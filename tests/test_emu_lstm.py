@@ -411,3 +411,52 @@ def test_golden_whole_clips_on_the_emulator(golden, name):
             else:
                 a, b = model(x[:1, :, :, :160], torch.tensor([160])), model(x[:1, :, :, 160:], torch.tensor([161]))
         assert np.abs(a.numpy() - g["stream_a"]).max() < 2e-5 and np.abs(b.numpy() - g["stream_b"]).max() < 2e-5
+
+
+@pytest.mark.parametrize("B,T,odd", [(6, 11, False), (5, 38, True), (3, 70, False)])
+def test_head_ctc_and_head_backward_rows_in_one_launch(monkeypatch, B, T, odd):
+    """Round 6 (howl_seq_head_ctc): a workgroup owns whole utterances -- first layer in 16-row tiles with y1 kept in LDS, the thin
+    output layer, the utterances' CTC recursions on waves 0 .. U-1, then the backward rows made from LDS.  Against the three launches
+    it replaces (HOWL_SEQ_HEAD_FUSED=0), through FusedTrainer.step_sequence_on_features: same loss, logits, LSTM gradients and first
+    head layer's weight gradient bit for bit (every row's products and sums are taken in the same order); the second layer's and
+    the bias gradients, whose per-workgroup slabs cover other rows, to rounding.  Ragged lengths, 1-3 labels (a repeated one), an
+    odd batch (a group with one utterance), U = 2 (T = 11, 38) and U = 1 (T = 70: two utterances' rows do not fit the LDS)."""
+    from emu_util import emulated_package
+    from howl_amd.model import RegisteredModel
+    from howl_amd.training.fused import FusedTrainer
+    monkeypatch.setenv("HOWL_ROWGEMM_MIN_ROWS", "1")
+    rng = np.random.default_rng(B * 100 + T)
+    feat = torch.from_numpy(rng.standard_normal((B, 1, 40, T)).astype(np.float32))
+    lengths = torch.sort(torch.from_numpy(rng.integers(max(4, T // 2), T + 1, B)), descending=True).values
+    lengths[0] = T
+    targets = torch.tensor([[0, 1, 2], [3, 3, 0], [2, 0, 0], [1, 0, 3], [0, 0, 0], [2, 1, 3]][:B])
+    tl = torch.tensor([3, 2, 1, 3, 0, 2][:B])
+    out = {}
+    with emulated_package():
+        for fused in ("1", "0"):
+            monkeypatch.setenv("HOWL_SEQ_HEAD_FUSED", fused)
+            model = RegisteredModel.find_registered_class("seq-lstm")(5)
+            model.load_state_dict({k: v.clone() for k, v in om.lstm_init(5).items()})
+            model.train()
+            tr = FusedTrainer(model, None, None, lr=1e-3, weight_decay=1e-5)
+            loss = tr.step_sequence_on_features(feat, lengths, targets, tl, 4)
+            assert (model.ctc_nll is not None) == (fused == "1")
+            out[fused] = (loss.clone(), tr.last_logits.clone(), [g.clone() for g in tr.fp.grad_views], tr.fp.flat.clone())
+    a, b = out["1"], out["0"]
+    assert torch.isfinite(a[0]) and torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    names = om.lstm_param_names()
+    for n, ga, gb in zip(names, a[2], b[2]):
+        if n in ("dnn.0.bias", "dnn.2.weight", "dnn.2.bias"):
+            assert (ga - gb).abs().max().item() <= 2e-6 * max(1.0, gb.abs().max().item()), n
+        else:
+            assert torch.equal(ga, gb), n
+    assert (a[3] - b[3]).abs().max().item() < 1e-6
+    # ... and against the oracle
+    sd = {k: v.clone().requires_grad_(True) for k, v in om.lstm_init(5).items()}
+    ref, _ = om.seq_lstm_forward(sd, feat, lengths)
+    ref_loss = torch.nn.CTCLoss(4)(torch.log_softmax(ref, -1), targets, lengths, tl)
+    ref_loss.backward()
+    assert abs(a[0].item() - ref_loss.item()) < 1e-4 and (a[1] - ref).abs().max().item() < 1e-4
+    for n, ga in zip(names, a[2]):
+        r = sd[n].grad
+        assert (ga - r).abs().max().item() < 1e-4 * max(1.0, r.abs().max().item()), n
