@@ -12,6 +12,7 @@ from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
 SRC = ROOT / "howl_amd" / "csrc" / "res8.hip"
+SRC_LSTM = ROOT / "howl_amd" / "csrc" / "lstm.hip"
 OUT = ROOT / "build" / "variants6"
 
 KERNEL_FWD_ENTRY = ("    if (bid >= nblk) return;\n    conv3x3_body<MODE, SLICES, HALO>(cfg, in_stats, wp, res, out, xs, xs_stats, part, pool, B, H, bid, nblk, slice, fold, bfold, wf, sg);",)
@@ -40,17 +41,25 @@ EDITS = {
     "pair_w_empty": [("    else\n        wgrad_body<SW, HALO>(WStage{zc, s_prev, false}, in_stats, bfold, wpart, B, H, j, nblk, r - SD, sg);",
                       "    else if (B < 0)\n        wgrad_body<SW, HALO>(WStage{zc, s_prev, false}, in_stats, bfold, wpart, B, H, j, nblk, r - SD, sg);")],
     "pair_d_empty": [("    if (r < SD)\n        conv3x3_body<1, SD, HALO>(", "    if (r < SD && B < 0)\n        conv3x3_body<1, SD, HALO>(")],
+    # ---- lstm.hip (c4): parts of seq_head_ctc_kernel removed (timing only)
+    "sh_base": [("@lstm",)],
+    "sh_noctc": [("@lstm",), ("        if (wave < U && grp * U + wave < a.B) {\n            const int b = grp * U + wave;", "        if (wave < U && grp * U + wave < a.B && a.B < 0) {\n            const int b = grp * U + wave;")],
+    "sh_nobwd": [("@lstm",), ("            stage(0, 0);\n            __syncthreads();\n            for (int k = 0; k < NTL; ++k) {\n                const int cur = k & 1;\n                f32x4 acc0", "            stage(0, 0);\n            __syncthreads();\n            for (int k = 0; k < NTL && a.B < 0; ++k) {\n                const int cur = k & 1;\n                f32x4 acc0")],
+    "sh_nofwd": [("@lstm",), ("            for (int k = 0; k < NTL; ++k) {\n                const int cur = k & 1;\n                if (k + 1 < NTL) p0 = fetch(k + 1);", "            for (int k = 0; k < NTL && a.B < 0; ++k) {\n                const int cur = k & 1;\n                if (k + 1 < NTL) p0 = fetch(k + 1);")],
 }
 
 
 def build(names):
     OUT.mkdir(parents=True, exist_ok=True)
-    text = SRC.read_text()
-    objs = [str(p) for p in sorted((ROOT / "build" / "obj").glob("*.o")) if p.name != "res8.o"]
     jobs = []
     for name in names:
-        t = text
+        lstm = any(e[0] == "@lstm" for e in EDITS[name])
+        src = SRC_LSTM if lstm else SRC
+        t = src.read_text()
+        objs = [str(p) for p in sorted((ROOT / "build" / "obj").glob("*.o")) if p.name != ("lstm.o" if lstm else "res8.o")]
         for e in EDITS[name]:
+            if e[0] == "@lstm":
+                continue
             old, new = e[0], e[1]
             cnt = e[2] if len(e) > 2 else 1
             assert t.count(old) == cnt, (name, old[:90], t.count(old))
@@ -59,12 +68,12 @@ def build(names):
         tmp = OUT / "_src" / f"{name}.hip"
         tmp.write_text(t)
         obj = OUT / f"res8_{name}.o"
-        jobs.append((name, tmp, obj, subprocess.Popen(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-w",
+        jobs.append((name, tmp, obj, objs, subprocess.Popen(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-w",
                                                        f"-I{SRC.parent}", f"-I{ROOT / 'include'}", "-c", str(tmp), "-o", str(obj)])))
         if len(jobs) % 4 == 0:
             for j in jobs[-4:]:
-                j[3].wait()
-    for name, tmp, obj, proc in jobs:
+                j[4].wait()
+    for name, tmp, obj, objs, proc in jobs:
         rc = proc.wait()
         assert rc == 0, name
         subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(OUT / f"libhowl_{name}.so"), str(obj)] + objs,
