@@ -790,8 +790,8 @@ def main():
             avg_ms = tp / max(npair, 1)
             achieved = 2 * flops_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
             full = B == 512 and L == 16000 and MELS == 40      # the configuration the committed PMC summary was taken on
-            traffic, traffic_src = pmc_traffic("bwd_pair_kernel") if full else (None, None)
-            fwd_traffic, _ = pmc_traffic("conv3x3_mfma_kernel<0") if full else (None, None)
+            traffic, traffic_src = pmc_traffic("bwd_pair_kernel<1, 1, 0>") if full else (None, None)      # (the 40-bin, <= 83-frame instance)
+            fwd_traffic, _ = pmc_traffic("conv3x3_mfma_kernel<0, 1, 0>") if full else (None, None)
             act = 4.0 * 45 * (H * (MELS // 4)) * B      # one (B, 45, H, M/4) fp32 map
             roof = {"bound": "mfma",
                     "kernel": "bwd_pair_kernel (data gradient + weight gradient of one 45->45 3x3 layer in ONE launch, half of "

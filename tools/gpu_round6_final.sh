@@ -25,7 +25,7 @@ done
 cd /tmp && export TMPDIR=/tmp
 for c in c1 c2 c3 c4 c5; do
   echo "== rocprof $c"
-  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/prof_$c -o $c -- python $R/bench.py --config $c --steps 20 --warmup 3 --prewarm 5 --no-cpu-baseline --no-roofline > $R/$OUT/rocprof_$c.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/prof_$c -o $c -- python $R/bench.py --config $c --steps 20 --warmup 3 --prewarm 5 --no-cpu-baseline --no-roofline --no-unfused-leg > $R/$OUT/rocprof_$c.log 2>&1
   f=$(find $R/$OUT/prof_$c -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $R/$OUT/${c}_kernel_stats.csv
   anchor=logmel; [ $c = c4 ] && anchor=lstm_fwd4      # c4: the frontend rides in the forward recurrence's launch, which opens the step
   t=$(find $R/$OUT/prof_$c -name "*kernel_trace.csv" | head -1); [ -n "$t" ] && python $R/tools/step_timeline.py "$t" $anchor > $R/$OUT/${c}_step_timeline.txt && tail -1 $R/$OUT/${c}_step_timeline.txt

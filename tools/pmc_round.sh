@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 rocprofv3 -L > $R/gpurun_out/pmc/counters.txt 2>&1
 CFG=${1:-c3}
-CMD="python $R/bench.py --config $CFG --steps 4 --warmup 2 --prewarm 0 --no-cpu-baseline --no-roofline ${PMC_EXTRA:-}"     # PMC_EXTRA: e.g. "--seconds 2 --batch-per-gpu 256"
+CMD="python $R/bench.py --config $CFG --steps 4 --warmup 2 --prewarm 0 --no-cpu-baseline --no-roofline --no-unfused-leg ${PMC_EXTRA:-}"     # PMC_EXTRA: e.g. "--seconds 2 --batch-per-gpu 256"
 i=0
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE" \
            "SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_INST_LEVEL_VMEM" \
