@@ -41,6 +41,12 @@ EDITS = {
     "pair_w_empty": [("    else\n        wgrad_body<SW, HALO>(WStage{zc, s_prev, false}, in_stats, bfold, wpart, B, H, j, nblk, r - SD, sg);",
                       "    else if (B < 0)\n        wgrad_body<SW, HALO>(WStage{zc, s_prev, false}, in_stats, bfold, wpart, B, H, j, nblk, r - SD, sg);")],
     "pair_d_empty": [("    if (r < SD)\n        conv3x3_body<1, SD, HALO>(", "    if (r < SD && B < 0)\n        conv3x3_body<1, SD, HALO>(")],
+    # 80 mel bins (NUM_MELS=80): the halo column of a strip read from CONTIGUOUS addresses of the neighbour's block instead of one
+    # element per cache line (wrong values, timing only): the upper bound of what a compact side copy of the edge columns could save
+    "halo_compact": [("    hs.g = (tid < nch * H) ? (c0 + c) * P + h * PW : 0;", "    hs.g = (tid < nch * H) ? (c0 + c) * H + h : 0;"),
+                     ("    const unsigned off = hs.pk >= 0 ? 4u * (unsigned)(hs.g + gcol) : 0u;\n    v.s = v.k = make_float2(0.0f, 0.0f);", "    const unsigned off = hs.pk >= 0 ? 4u * (unsigned)(hs.g) : 0u;\n    v.s = v.k = make_float2(0.0f, 0.0f);"),
+                     ("    return WHalo{ok ? c * CSX + (h + row0) * WPW : -1, ok ? c * P + h * PW : 0, ok ? c : 0, ok ? h : 0};", "    return WHalo{ok ? c * CSX + (h + row0) * WPW : -1, ok ? c * nsafe + hh : 0, ok ? c : 0, ok ? h : 0};"),
+                     ("    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(x + nbase) + 4u * (unsigned)(wh.g + gcol));", "    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(x + nbase) + 4u * (unsigned)(wh.g));")],
     # ---- lstm.hip (c4): parts of seq_head_ctc_kernel removed (timing only)
     "sh_base": [("@lstm",)],
     "sh_noctc": [("@lstm",), ("        if (wave < U && grp * U + wave < a.B) {\n            const int b = grp * U + wave;", "        if (wave < U && grp * U + wave < a.B && a.B < 0) {\n            const int b = grp * U + wave;")],
@@ -87,7 +93,7 @@ def run(names, extra):
     cfg = extra if extra else ["--config", "c1"]
     for rep in range(2):
         for name, lib in libs:
-            env = dict(os.environ, HOWL_HIP_LIBRARY=str(lib), NUM_MELS="40")
+            env = dict(os.environ, HOWL_HIP_LIBRARY=str(lib), NUM_MELS=os.environ.get("NUM_MELS", "40"))
             r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--no-cpu-baseline", "--no-roofline", "--no-unfused-leg", "--steps", "200",
                                 "--warmup", "20"] + cfg, env=env, capture_output=True, text=True, timeout=300)
             try:
