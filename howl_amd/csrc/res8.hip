@@ -1651,10 +1651,16 @@ __device__ __forceinline__ void wgrad_body(
             wgrad_loop<2, true, GWS, HALO>(a, zt, xt, ct, zb, xb, cb, b, pslot, wh, gx);
         else
             wgrad_loop<2, false, GWS, HALO>(a, zt, xt, ct, zb, xb, cb, b, pslot, wh, gx);
-    } else {                           // small batches: tiles gw, gw + 24 (< 26) over the 24 waves of two workgroups
-        const WgradArgs a{st, part, tz, tx, lm, B, P, CSZ, CSX, R, R1, tid, lane, wave, bid, nblk, gw, 0, 0};
-        if (gw + 24 < 26)
-            wgrad_loop<2, false, GWS, HALO>(a, zt, xt, ct, zb, xb, cb, b, pslot, wh, gx);
+    } else {
+        // small batches: tile gw for each of the 24 waves of the two workgroups; the six chains of tiles 24 / 25 (three cout tiles
+        // each) go one each to waves 0, 1, 2 of either workgroup -- three different SIMDs (round 6: as whole tiles on waves 0 / 1 of
+        // slice 0 they made that workgroup's SIMD 0 carry 840 MFMAs per utterance against 630 everywhere else, and the launch
+        // waits for its slowest SIMD; the same chains in the same order: bit-identical partials)
+        static_assert(SLICES == 2, "the weight gradient is sliced two ways");
+        const bool ex = wave < 3;
+        const WgradArgs a{st, part, tz, tx, lm, B, P, CSZ, CSX, R, R1, tid, lane, wave, bid, nblk, gw, 24 + slice, ex ? wave : 0};
+        if (ex)
+            wgrad_loop<1, true, GWS, HALO>(a, zt, xt, ct, zb, xb, cb, b, pslot, wh, gx);
         else
             wgrad_loop<1, false, GWS, HALO>(a, zt, xt, ct, zb, xb, cb, b, pslot, wh, gx);
     }

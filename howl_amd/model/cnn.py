@@ -208,7 +208,20 @@ class Res8(RegisteredModel, name="res8"):
     MAX_FRAMES = 83     # one utterance's pooled map (27 rows) fits the kernels' tile; longer inputs run as row strips with exchanged
                         # halo rows (howl_res8_fwd / _bwd, training and eval; up to 1024 strips = 82,944 frames).  The windowed
                         # eval-mode forward of rounds 2-5 (howl_res8_fwd_long: overlapping 27-row windows, 2.1 x the arithmetic,
-                        # up to 64 windows) stays in the library as an entry point (tests/test_emu_res8.py)
+                        # up to 64 windows) stays in the library as an entry point (_launch_forward_long; tests/test_emu_res8.py, test_gpu_res8.py)
+
+    def _launch_forward_long(self, x0, sb, st, sm):
+        """``howl_res8_fwd_long`` (overlapping 27-row windows, up to 64 of them): the module itself takes long inputs as row strips
+        (``_launch_forward``); the device tests reach the entry point through this wrapper."""
+        B, M, T = x0.shape
+        nbytes = _lib.get().cdll.howl_res8_long_workspace_bytes_mels(B, T, M)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=x0.device)
+        logits = torch.empty((B, self.num_labels), dtype=torch.float32, device=x0.device)
+        prm = self._params_struct()
+        _lib.get().call("howl_res8_fwd_long", ctypes.byref(prm), ctypes.c_void_p(x0.data_ptr()), sb, st, sm, B, T, M,
+                        self.num_labels, ctypes.c_void_p(logits.data_ptr()), ctypes.c_void_p(ws.data_ptr()), ws.numel(),
+                        ops._stream())
+        return logits
 
     def _launch_forward(self, feat, grads_struct=None):
         x0, sb, st, sm = self._feat_view(feat)
