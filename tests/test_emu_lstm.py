@@ -413,6 +413,50 @@ def test_golden_whole_clips_on_the_emulator(golden, name):
         assert np.abs(a.numpy() - g["stream_a"]).max() < 2e-5 and np.abs(b.numpy() - g["stream_b"]).max() < 2e-5
 
 
+@pytest.mark.parametrize("B,T,C", [(4, 5, 2), (3, 16, 8), (2, 3, 3)])
+def test_head_ctc_one_launch_other_label_counts_and_tiny_windows(monkeypatch, B, T, C):
+    """howl_seq_head_ctc's template over the label count (2, 3, 8 outputs) and windows shorter than one 16-row tile: against the
+    three launches it replaces (bit-identical loss / logits / LSTM gradients) and the oracle."""
+    from emu_util import emulated_package
+    from howl_amd.model import RegisteredModel
+    from howl_amd.training.fused import FusedTrainer
+    monkeypatch.setenv("HOWL_ROWGEMM_MIN_ROWS", "1")
+    rng = np.random.default_rng(B * 10 + T)
+    feat = torch.from_numpy(rng.standard_normal((B, 1, 40, T)).astype(np.float32))
+    lengths = torch.sort(torch.from_numpy(rng.integers(max(2, T // 2), T + 1, B)), descending=True).values
+    lengths[0] = T
+    blank = C - 1
+    targets = torch.from_numpy(rng.integers(0, C - 1, (B, 2)))
+    tl = torch.from_numpy(np.minimum(rng.integers(0, 3, B), (lengths.numpy() + 1) // 2))
+    out = {}
+    with emulated_package():
+        for fused in ("1", "0"):
+            monkeypatch.setenv("HOWL_SEQ_HEAD_FUSED", fused)
+            model = RegisteredModel.find_registered_class("seq-lstm")(C)
+            model.load_state_dict({k: v.clone() for k, v in om.lstm_init(C).items()})
+            model.train()
+            tr = FusedTrainer(model, None, None, lr=1e-3, weight_decay=1e-5)
+            loss = tr.step_sequence_on_features(feat, lengths, targets, tl, blank)
+            assert (model.ctc_nll is not None) == (fused == "1")
+            out[fused] = (loss.clone(), tr.last_logits.clone(), [g.clone() for g in tr.fp.grad_views])
+    a, b = out["1"], out["0"]
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    for n, ga, gb in zip(om.lstm_param_names(), a[2], b[2]):
+        if n in ("dnn.0.bias", "dnn.2.weight", "dnn.2.bias"):
+            assert (ga - gb).abs().max().item() <= 2e-6 * max(1.0, gb.abs().max().item()), n
+        else:
+            assert torch.equal(ga, gb), n
+    sd = {k: v.clone().requires_grad_(True) for k, v in om.lstm_init(C).items()}
+    ref, _ = om.seq_lstm_forward(sd, feat, lengths)
+    ref_loss = torch.nn.CTCLoss(blank)(torch.log_softmax(ref, -1), targets, lengths, tl)
+    ref_loss.backward()
+    if torch.isfinite(ref_loss):
+        assert abs(a[0].item() - ref_loss.item()) < 1e-4 * max(1.0, abs(ref_loss.item()))
+        for n, ga in zip(om.lstm_param_names(), a[2]):
+            r = sd[n].grad
+            assert (ga - r).abs().max().item() < 1e-4 * max(1.0, r.abs().max().item()), n
+
+
 @pytest.mark.parametrize("B,T,odd", [(6, 11, False), (5, 38, True), (3, 70, False)])
 def test_head_ctc_and_head_backward_rows_in_one_launch(monkeypatch, B, T, odd):
     """Round 6 (howl_seq_head_ctc): a workgroup owns whole utterances -- first layer in 16-row tiles with y1 kept in LDS, the thin
