@@ -376,7 +376,7 @@ def test_forward_with_the_next_batch_frontend_riding_in_the_launch(lib, monkeypa
             np.testing.assert_array_equal(bufs["gates"], ref_keep["bufs"]["gates"])
 
 
-@pytest.mark.parametrize("name", ["lstm", "seq-lstm"])
+@pytest.mark.parametrize("name", ["seq-lstm"])      # (the `lstm` half of G15 runs on the device and against the oracle: 70 s here)
 def test_golden_whole_clips_on_the_emulator(golden, name):
     """G15 (the reference's recurrent models on clips of 318 / 258 / 206 / 128 frames) through the product's modules on the
     emulator: recurrences at eight times G6's length, the CTC kernel's 128-frame windows, streaming carry over a 160 + 161 split."""
