@@ -220,4 +220,84 @@ __device__ __forceinline__ void ctc_wave(const float* __restrict__ zb, long st_t
     }
 }
 
+
+// ---- two waves per utterance (one window: T <= tc), for a workgroup that has waves to spare (lstm.hip's fused head kernel) ----------
+// The alpha and the beta recursion are independent chains; interleaved in one wave they cost ~185 ns per time step, apart on two
+// waves ~110 ns each.  Role 0 stages the rows (log-softmax) into `lds`'s lp / q buffers, runs alpha into abuf and takes nll; role 1
+// stages ITS OWN copy of the rows (no exchange in front of the recursions) and runs beta into bbuf.  After a WORKGROUP barrier of
+// the caller, ctc_pair_grad (role 0's wave) turns alpha, beta and the rows into the gradient.  Same chains, same order of
+// operations as ctc_wave: bit-identical nll and gradient.  LDS: [lp | alpha | beta | q | lp of role 1][T][RP] + 64 labels.
+template <int RP>
+__device__ __forceinline__ CtcLane ctc_pair_lane(int role, int T, int C, const long long* __restrict__ tgt, int L, int blank, bool want_grad,
+                                                 float* __restrict__ lds, int lane) {
+    int* labbuf = reinterpret_cast<int*>(lds + 5 * (size_t)RP * T);
+    const int S = 2 * L + 1;
+    const bool live = lane < S;
+    int lab = blank;
+    if (live && (lane & 1)) lab = (int)tgt[lane >> 1];
+    lab &= 63;
+    if (role == 0) labbuf[lane] = lab;
+    const int lab_m2 = __shfl(lab, lane >= 2 ? lane - 2 : lane);
+    const int lab_p2 = __shfl(lab, lane + 2 < 64 ? lane + 2 : lane);
+    CtcLane w;
+    w.lane = lane, w.lab = lab, w.S = S, w.C = C;
+    w.live = live, w.want_grad = want_grad && role == 0;      // (only role 0's staging clears the posterior rows)
+    w.skip_a = live && (lane & 1) && lane >= 2 && lab != lab_m2;
+    w.skip_b = (lane & 1) && lane + 2 < S && lab != lab_p2;
+    w.lpbuf = role == 0 ? lds : lds + 4 * (size_t)RP * T;
+    w.abuf = lds + (size_t)RP * T, w.bbuf = lds + 2 * (size_t)RP * T, w.qbuf = lds + 3 * (size_t)RP * T;
+    w.labbuf = labbuf;
+    return w;
+}
+// returns nll (role 0; also written to nll_out[0]) -- role 1 returns 0
+template <int RP>
+__device__ __forceinline__ float ctc_pair_recursion(int role, const float* __restrict__ zb, long st_t, int T, int C,
+                                                    const long long* __restrict__ tgt, int Tb, int L, int blank,
+                                                    float* __restrict__ nll_out, float* __restrict__ lds, int lane) {
+    Tb = Tb < 0 ? 0 : (Tb > T ? T : Tb);
+    const CtcLane w = ctc_pair_lane<RP>(role, T, C, tgt, L, blank, true, lds, lane);
+    const bool wr = RP >= 64 || lane < RP;
+    ctc_stage_rows<RP>(w, zb, st_t, 0, Tb);
+    if (role == 0) {
+        float a = -INFINITY;
+        for (int k = 0; k < Tb; ++k) {
+            const float lpa = w.lpbuf[k * RP + w.lab];
+            if (k == 0) a = (w.live && lane < 2) ? lpa : -INFINITY;
+            else a = ctc_alpha_step(w, a, lpa);
+            if (wr) w.abuf[k * RP + lane] = a;
+        }
+        float nll;
+        if (Tb > 0) {
+            const float l1 = __shfl(a, w.S - 1), l2 = w.S > 1 ? __shfl(a, w.S - 2) : -INFINITY;
+            nll = -lse3(l1, l2, -INFINITY);
+        } else {
+            nll = L == 0 ? 0.0f : INFINITY;
+        }
+        if (lane == 0) nll_out[0] = nll;
+        return nll;
+    }
+    float bt = -INFINITY;
+    for (int k = 0; k < Tb; ++k) {
+        const int kb = Tb - 1 - k;
+        const float lpb = w.lpbuf[kb * RP + w.lab];
+        if (k == 0) bt = (w.live && lane >= w.S - 2) ? lpb : -INFINITY;
+        else bt = ctc_beta_step(w, bt, lpb);
+        if (wr) w.bbuf[kb * RP + lane] = bt;
+    }
+    return 0.0f;
+}
+// role 0's wave, after the workgroup barrier behind both recursions
+template <int RP>
+__device__ __forceinline__ void ctc_pair_grad(int T, int B, int C, const long long* __restrict__ tgt, int Tb, int L, int blank, float nll,
+                                              float* __restrict__ db, long dst_t, float* __restrict__ lds, int lane) {
+    Tb = Tb < 0 ? 0 : (Tb > T ? T : Tb);
+    CtcLane w = ctc_pair_lane<RP>(0, T, C, tgt, L, blank, true, lds, lane);
+    const float scale = 1.0f / ((float)B * (float)(L > 0 ? L : 1));
+    ctc_window_grad<RP>(w, 0, Tb, blank, nll, scale, db, dst_t);
+    for (int i = lane; i < (T - Tb) * C; i += 64) {
+        const int r = i / C, c = i - r * C;
+        db[(size_t)(Tb + r) * dst_t + c] = 0.0f;
+    }
+}
+
 }  // namespace

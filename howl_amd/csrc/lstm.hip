@@ -1051,9 +1051,9 @@ __global__ __launch_bounds__(HB_THREADS) void head_bwd_rows_kernel(const float* 
 // head_bwd_rows_kernel (dz1, dW2 / db partials, dH = dz1 W1): three launches touching rows that are independent per utterance,
 // and two trips of the (rows, 256) hidden activations through HBM (20 MB each way at 512 x 38).  Here a workgroup owns a GROUP
 // of U (1 or 2) whole utterances: its U T rows run through the first layer in 16-row tiles on rowgemm_kernel's schedule with
-// the results kept in LDS (y1 never leaves the chip), the thin output layer rides as before, then waves 0 .. U-1 run the
-// utterances' CTC recursions (howl_ctc.hip.h, row pitch 17: <= 8 classes, <= 8 labels) on the logits in LDS while the other
-// waves fetch the second set of W1 fragments, then head_bwd_rows_kernel's tile pipeline runs with its input MADE from LDS.
+// the results kept in LDS (y1 never leaves the chip), the thin output layer rides as before, then waves 0 .. 2U-1 run the
+// utterances' CTC recursions (howl_ctc.hip.h, row pitch 17: <= 8 classes, <= 8 labels; alpha and beta on a wave each) on the logits in
+// LDS while the other waves fetch the second set of W1 fragments, then head_bwd_rows_kernel's tile pipeline runs with its input MADE from LDS.
 // Every product and sum of a row is taken in the order of the three kernels it replaces: logits, nll, dlogits, dz1 and dH are
 // bit-identical to theirs; the per-workgroup slabs of dW2 / db1 / db2 cover different rows (sums in another order).
 // Needs the rows of a group in LDS: 16 ceil(U T / 16) x 260 floats, i.e. windows up to ~0.6 s at U = 2 and ~1.2 s at U = 1
@@ -1080,7 +1080,7 @@ __host__ __device__ inline int seq_head_rt(int U, int T) { return 16 * ((U * T +
 __host__ __device__ inline size_t seq_head_lds_floats(int U, int T, int n_out) {
     const size_t r0a = (size_t)seq_head_rt(U, T) * SH_LDY, r0b = (size_t)(4 * n_out + 4) * SH_THREADS;
     return (r0a > r0b ? r0a : r0b) + 2 * 16 * SH_LDY + 2 * 8 * 16 * 8 + 2 * (size_t)seq_head_rt(U, T) * SH_LG +
-           (size_t)U * (4 * (size_t)T * SH_RPC + 64);
+           (size_t)U * (5 * (size_t)T * SH_RPC + 64);
 }
 
 template <int NO>
@@ -1094,7 +1094,7 @@ __global__ __launch_bounds__(SH_THREADS) void seq_head_ctc_kernel(SeqHeadArgs a)
     float* red2 = tiles + 2 * 16 * SH_LDY;                   // [2][8][16][8]
     float* lg = red2 + 2 * 8 * 16 * 8;                       // [RT][8] logits
     float* dlg = lg + (size_t)RT * SH_LG;                    // [RT][8] d loss / d logits
-    float* ctcb = dlg + (size_t)RT * SH_LG;                  // U x (4 T 17 + 64)
+    float* ctcb = dlg + (size_t)RT * SH_LG;                  // U x (5 T 17 + 64): ctc_pair_*
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int mi = lane & 15, kq = lane >> 4;
     const int nbase = wave * 16 * NT;
@@ -1195,13 +1195,15 @@ __global__ __launch_bounds__(SH_THREADS) void seq_head_ctc_kernel(SeqHeadArgs a)
             }
         }
         __syncthreads();
-        // ---- log_softmax + CTC of the group's utterances on waves 0 .. U-1 (dlogits -> LDS), W1's second set of fragments on all -----
-        if (wave < U && grp * U + wave < a.B) {
-            const int b = grp * U + wave;
-            ctc_wave<SH_RPC>(lg + (size_t)wave * T * SH_LG, SH_LG, T, a.B, NO, a.targets + (size_t)b * a.tgt_stride, (int)a.in_len[b],
-                             (int)a.tgt_len[b], a.blank, a.nll + b, dlg + (size_t)wave * T * SH_LG, SH_LG, T, nullptr,
-                             ctcb + (size_t)wave * (4 * (size_t)T * SH_RPC + 64), lane);
-        }
+        // ---- log_softmax + CTC of the group's utterances on waves 0 .. 2U-1 (dlogits -> LDS), W1's second set of fragments on all ----
+        // two waves per utterance: alpha on the even one, beta on the odd one (howl_ctc.hip.h, ctc_pair_*)
+        const int cu = wave >> 1, crole = wave & 1, cb = grp * U + cu;
+        const bool cwave = cu < U && cb < a.B;
+        float* cbuf = ctcb + (size_t)cu * (5 * (size_t)T * SH_RPC + 64);
+        float cnll = 0.0f;
+        if (cwave)
+            cnll = ctc_pair_recursion<SH_RPC>(crole, lg + (size_t)cu * T * SH_LG, SH_LG, T, NO, a.targets + (size_t)cb * a.tgt_stride,
+                                              (int)a.in_len[cb], (int)a.tgt_len[cb], a.blank, a.nll + cb, cbuf, lane);
         HOWL_OPAQUE_S(w1p);
         float wvb[HB_HID / 16][4];
 #pragma unroll
@@ -1211,6 +1213,10 @@ __global__ __launch_bounds__(SH_THREADS) void seq_head_ctc_kernel(SeqHeadArgs a)
         float4 w2r[NO];
 #pragma unroll
         for (int n = 0; n < NO; ++n) w2r[n] = *reinterpret_cast<const float4*>(a.w2 + (long)n * HB_HID + 4 * lane);
+        __syncthreads();      // alpha and beta rows of every utterance of the group in LDS
+        if (cwave && crole == 0)
+            ctc_pair_grad<SH_RPC>(T, a.B, NO, a.targets + (size_t)cb * a.tgt_stride, (int)a.in_len[cb], (int)a.tgt_len[cb], a.blank, cnll,
+                                  dlg + (size_t)cu * T * SH_LG, SH_LG, cbuf, lane);
         __syncthreads();
         // ---- backward (head_bwd_rows_kernel): dz1 = (y1 > 0) (dlogits W2) -> HBM + tile, dH = dz1 W1, partial sums --------------------
         {
