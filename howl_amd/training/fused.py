@@ -185,6 +185,8 @@ class FusedTrainer:
         # log-softmax + CTC + their backward as one launch at any clip length (128-frame windows beyond 128 frames); the batch
         # mean of the loss rides in the head's backward launch (HowlCtcMean).  Outside the kernel's range (C > 64, a target
         # of more than 31 labels, T > 8192): HowlHipError from the library -- no vendor kernels on the training path
+        if "ctc" in kw:      # (already on the device for the fused launch's benefit: no second upload)
+            targets, target_lengths = kw["ctc"][0], kw["ctc"][1]
         loss, dscores, nll, tl_dev = ops.ctc_loss_fwd_bwd(scores, targets, frame_lengths, target_lengths, blank, max_target,
                                                           defer_mean=True)
         ctc_mean = (nll, tl_dev, loss)
