@@ -36,7 +36,9 @@ def _x_frames(x):
     """Frames per utterance of the buffer behind x (B,T,M): a leading-frames view of a longer (B,T_x,M) feature buffer is used in
     place (``HowlLstmSaved.x_frames``)."""
     M = x.shape[2]
-    if x.stride(2) != 1 or x.stride(1) != M or x.stride(0) % M or x.stride(0) < x.shape[1] * M:
+    # (the stride of a one-frame time axis is never used to address anything -- and torch leaves it arbitrary, e.g. 1 after
+    # permute(0, 2, 1).contiguous() of a (B, M, 1) tensor)
+    if x.stride(2) != 1 or (x.shape[1] > 1 and x.stride(1) != M) or x.stride(0) % M or x.stride(0) < x.shape[1] * M:
         raise ValueError("LSTM input must be a (B,T,M) tensor with contiguous rows and a whole number of frames per utterance")
     return x.stride(0) // M
 
@@ -277,7 +279,7 @@ class _LstmBase(RegisteredModel):
         if t_out < T:                                  # frames no sequence reaches: the kernels and the saved buffers only see
             xb = xb[:, :t_out]                         # t_out steps (a view: the library takes the buffer's frame stride)
         M = xb.shape[2]
-        if (xb.stride(2) != 1 or xb.stride(1) != M or xb.stride(0) % M       # the fused frontend already hands over a (B,T,M) buffer;
+        if (xb.stride(2) != 1 or (xb.shape[1] > 1 and xb.stride(1) != M) or xb.stride(0) % M       # the fused frontend already hands over a (B,T,M) buffer;
                 or xb.stride(0) < xb.shape[1] * M):                            # expanded / overlapping batch views are copied
             xb = xb.contiguous()
         hx = self.streaming_state if self.is_streaming and self.streaming_state is not None else None

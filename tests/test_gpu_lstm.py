@@ -457,21 +457,23 @@ def test_seq_lstm_at_80_mel_bins_vs_oracle(monkeypatch):
     assert torch.isfinite(loss2).all()
 
 
-@pytest.mark.parametrize("B,T", [(512, 38), (257, 38), (64, 70), (1024, 20)])
+@pytest.mark.parametrize("B,T", [(512, 38), (257, 38), (64, 70), (1024, 20), (2049, 8), (300, 16), (129, 41), (40, 64), (2500, 1)])
 def test_head_ctc_and_head_backward_rows_in_one_launch(B, T, monkeypatch):
     """Round 6 (howl_seq_head_ctc): between the two recurrences of the seq-lstm step, head forward + log_softmax / CTC + the head's
     backward over the rows as ONE launch in which a workgroup owns whole utterances (y1 stays in LDS), against the three launches
     it replaces (HOWL_SEQ_HEAD_FUSED=0): loss, logits, LSTM gradients and the first head layer's weight gradient bit for bit, the
-    regrouped partial sums (dnn.0.bias, dnn.2.*) to rounding; BASELINE config 4's size, an odd batch, U = 1 (70 frames) and four
-    groups per workgroup (1024 x 20); ragged lengths, 0-3 labels; three steps each (AdamW in the fold) end in the same weights."""
+    regrouped partial sums (dnn.0.bias, dnn.2.*) to rounding; BASELINE config 4's size, an odd batch, U = 1 (70 / 64 frames), several
+    groups per workgroup (1024 x 20, 2049 x 8: an odd batch on more groups than CUs), groups of exactly one or two tiles (8, 16
+    frames), 41 frames (82 rows: a sixth, two-row tile) and one-frame windows; ragged lengths, 0-3 labels; three steps each
+    (AdamW in the fold) end in the same weights."""
     from howl_amd.training.fused import FusedTrainer
     rng = np.random.default_rng(B + T)
     feat = torch.from_numpy(rng.standard_normal((B, 1, 40, T)).astype(np.float32)).to(DEV)
-    lengths = torch.sort(torch.from_numpy(rng.integers(max(4, T // 2), T + 1, B)), descending=True).values
+    lengths = torch.sort(torch.from_numpy(rng.integers(max(min(4, T), T // 2), T + 1, B)), descending=True).values
     lengths[0] = T
     targets = torch.from_numpy(rng.integers(0, 4, (B, 3)))
     targets[::5, 1] = targets[::5, 0]                       # repeated labels
-    tl = torch.from_numpy(rng.integers(0, 4, B))
+    tl = torch.minimum(torch.from_numpy(rng.integers(0, 4, B)), (lengths + 1) // 2)     # (alignable: repeats need a blank in between)
     out = {}
     for fused in ("1", "0"):
         monkeypatch.setenv("HOWL_SEQ_HEAD_FUSED", fused)
