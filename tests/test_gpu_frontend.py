@@ -244,6 +244,14 @@ def test_frontend_at_80_mel_bins(monkeypatch, golden):
     two = std.log_mel_for_model(pcm.to(DEV), zmuv).clone()
     monkeypatch.delenv("HOWL_LOGMEL_TWO_LAUNCHES")
     assert torch.equal(one, two)
+    for Bq, Lq in ((3, 2377), (7, 8000), (5, 13527), (1, 700), (33, 4001)):     # ragged tails, odd strides, one short clip
+        x = synthetic_pcm(Bq, Lq, seed=Lq).to(DEV)
+        a = std(x, mels_only=True).clone()
+        monkeypatch.setenv("HOWL_LOGMEL_TWO_LAUNCHES", "1")
+        b = std(x, mels_only=True).clone()
+        monkeypatch.delenv("HOWL_LOGMEL_TWO_LAUNCHES")
+        assert torch.equal(a, b), (Bq, Lq)
+        logmel_close(a, ofe.standard_audio_transform(x.cpu(), fb, mels_only=True))
     std.train()
     for seed in range(40):
         random.seed(seed)
